@@ -1,0 +1,98 @@
+"""Deterministic synthetic inputs shared by `make_golden.py` (which feeds them to the
+reference) and by the tests (which feed them to the oracle / the HIP path).
+
+Everything comes from numpy's legacy `RandomState(seed)` stream, which is frozen
+across numpy versions, so the inputs never have to be stored in the fixtures.
+Shapes follow SURVEY.md §8(d): D4RL-shaped transitions with an absorbing bit.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+f32 = np.float32
+
+DIMS = {  # state size incl. absorbing bit, action size (environments.py:27, gym MuJoCo dims)
+    'halfcheetah': (18, 6), 'walker2d': (18, 6), 'hopper': (12, 3), 'ant': (112, 8),
+}
+
+
+def mlp_params(rs, in_dim, hidden, depth, out_dim, out_scale=1.0):
+  """Flat parameter vector in torch order, fan-in scaled weights, small non-zero biases."""
+  dims = [in_dim] + [hidden] * depth + [out_dim]
+  parts = []
+  for i in range(len(dims) - 1):
+    scale = (2.0 if i < len(dims) - 2 else out_scale) / np.sqrt(dims[i])
+    parts.append((rs.standard_normal((dims[i + 1], dims[i])) * scale).astype(f32).ravel())
+    parts.append((rs.standard_normal(dims[i + 1]) * 0.05).astype(f32))
+  return np.concatenate(parts)
+
+
+def transitions(rs, n, S, A, *, state_shift=0.0, absorbing_frac=0.02, terminal_frac=0.01, weighted=False):
+  """n D4RL-shaped rows (fields of memory.py:17) + the `absorbing` flag of memory.py:62."""
+  st = (rs.standard_normal((n, S)) + state_shift).astype(f32)
+  nx = (rs.standard_normal((n, S)) + state_shift).astype(f32)
+  st[:, -1] = 0; nx[:, -1] = 0
+  ac = rs.uniform(-1, 1, (n, A)).astype(f32)
+  n_abs = int(round(n * absorbing_frac))
+  if n_abs:
+    rows = rs.choice(n, n_abs, replace=False)
+    st[rows] = 0; st[rows, -1] = 1; nx[rows] = 0; nx[rows, -1] = 1; ac[rows] = 0
+  out = dict(
+      step=np.arange(1, n + 1, dtype=f32), states=st, actions=ac, rewards=rs.standard_normal(n).astype(f32), next_states=nx,
+      terminals=(rs.uniform(size=n) < terminal_frac).astype(f32), timeouts=np.zeros(n, f32),
+      weights=(rs.uniform(0.5, 1.5, n).astype(f32) if weighted else np.ones(n, f32)))
+  out['absorbing'] = st[:, -1].copy()
+  return out
+
+
+def sac_case(seed, env='halfcheetah', hidden=256, batch=256, steps=3):
+  S, A = DIMS[env]
+  rs = np.random.RandomState(seed)
+  actor = mlp_params(rs, S, hidden, 2, 2 * A, out_scale=0.3)
+  critic = np.concatenate([mlp_params(rs, S + A, hidden, 2, 1) for _ in range(2)])
+  target = (critic + rs.standard_normal(critic.size).astype(f32) * f32(0.01)).astype(f32)
+  log_alpha = np.array([-0.3], f32)
+  batches = [transitions(rs, batch, S, A, weighted=True) for _ in range(steps)]
+  eps_next = [rs.standard_normal((batch, A)).astype(f32) for _ in range(steps)]
+  eps_cur = [rs.standard_normal((batch, A)).astype(f32) for _ in range(steps)]
+  return dict(S=S, A=A, H=hidden, B=batch, actor=actor, critic=critic, target=target, log_alpha=log_alpha, batches=batches,
+              eps_next=eps_next, eps_cur=eps_cur, discount=0.97, entropy_target=-0.5 * A, polyak=0.99, lr=3e-4, weight_decay=0.0)
+
+
+def gail_case(seed, env='halfcheetah', hidden=64, batch=256, steps=3, spectral_norm=True):
+  S, A = DIMS[env]
+  D = S + A
+  rs = np.random.RandomState(seed)
+  W1 = (rs.standard_normal((hidden, D)) * np.sqrt(2.0 / D)).astype(f32)
+  b1 = (rs.standard_normal(hidden) * 0.05).astype(f32)
+  W2 = (rs.standard_normal((1, hidden)) / np.sqrt(hidden)).astype(f32)
+  b2 = (rs.standard_normal(1) * 0.05).astype(f32)
+  unit = lambda x: (x / np.linalg.norm(x)).astype(f32)
+  u1, v1, u2, v2 = unit(rs.standard_normal(hidden)), unit(rs.standard_normal(D)), unit(rs.standard_normal(1)), unit(rs.standard_normal(hidden))
+  pol = [transitions(rs, batch, S, A, weighted=True) for _ in range(steps)]
+  exp = [transitions(rs, batch, S, A, state_shift=0.5, weighted=True) for _ in range(steps)]
+  eps = [rs.uniform(size=batch).astype(f32) for _ in range(steps)]
+  return dict(S=S, A=A, D=D, H=hidden, B=batch, W1=W1, b1=b1, W2=W2, b2=b2, u1=u1, v1=v1, u2=u2, v2=v2, policy=pol, expert=exp, eps=eps,
+              spectral_norm=spectral_norm)
+
+
+def gmmil_case(seed, B1, B2, D, weighted=True):
+  rs = np.random.RandomState(seed)
+  X = rs.standard_normal((B1, D)).astype(f32)
+  E = (rs.standard_normal((B2, D)) * 0.8 + 0.5).astype(f32)
+  w = rs.uniform(0.5, 1.5, B1).astype(f32) if weighted else np.ones(B1, f32)
+  we = rs.uniform(0.5, 1.5, B2).astype(f32) if weighted else np.ones(B2, f32)
+  return X, E, w, we
+
+
+def pwil_case(seed, N, D, steps):
+  rs = np.random.RandomState(seed)
+  atoms = (rs.standard_normal((N, D)) * rs.uniform(0.5, 2.0, D) + rs.standard_normal(D)).astype(f32)
+  atoms[:, -1] = 0  # a constant feature: std == 0 -> scale 1 (models.py:207)
+  agent = (rs.standard_normal((steps, D)) * 1.2).astype(f32)
+  agent[:, -1] = 0
+  return atoms, agent
+
+
+def strided(x, stride=29):
+  return np.ascontiguousarray(np.asarray(x).ravel()[::stride])

@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by running the UNMODIFIED reference on CPU torch.
+
+Run in the build container only (needs /root/reference):  python tests/golden/make_golden.py
+The reference's three hot-path modules import with a 12-line `omegaconf` stub
+(the real package is absent; it is only used for a type annotation and
+attribute/.get access).  Noise is recorded, not re-implemented: the three draw
+sites (`torch.normal` in Normal.sample, `_standard_normal` in rsample,
+`torch.rand_like` for the gradient-penalty epsilon) are wrapped so the values
+the reference consumed are exactly the ones stored in / rebuilt from inputs.py.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import inputs as gi  # noqa: E402
+
+REF = os.environ.get('IL_REFERENCE', '/root/reference')
+stub = tempfile.mkdtemp()
+os.makedirs(os.path.join(stub, 'omegaconf'))
+with open(os.path.join(stub, 'omegaconf', '__init__.py'), 'w') as f:
+  f.write('''
+class DictConfig(dict):
+  def __getattr__(self, k):
+    try: v = self[k]
+    except KeyError: raise AttributeError(k)
+    return DictConfig(v) if isinstance(v, dict) and not isinstance(v, DictConfig) else v
+  def __setattr__(self, k, v): self[k] = v
+class OmegaConf: pass
+''')
+sys.path.insert(0, stub)
+sys.path.insert(0, REF)
+from omegaconf import DictConfig  # noqa: E402
+import memory as ref_memory  # noqa: E402
+import models as ref_models  # noqa: E402
+import training as ref_training  # noqa: E402
+
+torch.set_num_threads(1)
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+N_ = lambda t: t.detach().cpu().numpy().copy()
+
+
+class NoiseFeed:
+  """Feeds pre-drawn noise to the reference's three draw sites, in call order."""
+
+  def __init__(self):
+    self.normal, self.rsample, self.rand = [], [], []
+    self._orig = (torch.normal, torch.distributions.normal._standard_normal, torch.rand_like)
+
+  def __enter__(self):
+    def normal(mean, std, *a, **k):
+      return self.normal.pop(0) * std + mean  # same op order as at::normal (z * std + mean)
+
+    def std_normal(shape, dtype, device):
+      return self.rsample.pop(0)
+
+    def rand_like(x, *a, **k):
+      return self.rand.pop(0)
+    torch.normal, torch.distributions.normal._standard_normal, torch.rand_like = normal, std_normal, rand_like
+    return self
+
+  def __exit__(self, *a):
+    torch.normal, torch.distributions.normal._standard_normal, torch.rand_like = self._orig
+
+
+def flat(module):
+  return N_(torch.nn.utils.parameters_to_vector(module.parameters()))
+
+
+def opt_state(opt, key):
+  return np.concatenate([N_(opt.state[p][key]).ravel() for g in opt.param_groups for p in g['params']])
+
+
+def tbatch(b):
+  return {k: T(v) for k, v in b.items()}
+
+
+# ---------------------------------------------------------------- replay
+def gen_replay():
+  out = {}
+  # index streams: (seed, size, prefill rows) for a not-full ring, a wrapped ring, an expert buffer (full, idx 0)
+  for name, seed, size, fill in (('partial', 0, 1000, 300), ('wrapped', 1, 64, 150), ('expert', 2, 500, None)):
+    S, A = 5, 2
+    rs = np.random.RandomState(100 + seed)
+    if fill is None:
+      tr = gi.transitions(rs, size, S, A)
+      mem = ref_memory.ReplayMemory(size, S, A, True, transitions={**{k: T(v) for k, v in tr.items() if k != 'absorbing'}, 'num_trajectories': 3})
+    else:
+      mem = ref_memory.ReplayMemory(size, S, A, True)
+      tr = gi.transitions(rs, fill, S, A)
+      for i in range(fill):
+        mem.append(i + 1, T(tr['states'][i:i + 1]), T(tr['actions'][i:i + 1]), float(tr['rewards'][i]), T(tr['next_states'][i:i + 1]), bool(tr['terminals'][i]), False)
+        if i % 37 == 36:
+          mem.wrap_for_absorbing_states()
+    np.random.seed(seed)
+    idxs = [mem._sample_idx() for _ in range(256)]
+    out[f'{name}_idx'] = np.array(idxs, np.int64)
+    np.random.seed(seed)
+    batch = mem.sample(32)
+    for k, v in batch.items():
+      out[f'{name}_batch_{k}'] = N_(v)
+    out[f'{name}_state'] = np.array([mem.idx, int(mem.full), mem.num_trajectories, mem.size])
+    for k in ('step', 'states', 'actions', 'rewards', 'next_states', 'terminals', 'timeouts', 'weights'):
+      out[f'{name}_mem_{k}'] = N_(getattr(mem, k))[:min(size, 200)]
+  np.savez_compressed(os.path.join(HERE, 'replay.npz'), **out)
+
+
+# ---------------------------------------------------------------- SAC
+def build_sac(c):
+  cfg = DictConfig(hidden_size=c['H'], depth=2, activation='relu')
+  actor, critic = ref_models.SoftActor(c['S'], c['A'], cfg), ref_models.TwinCritic(c['S'], c['A'], cfg)
+  torch.nn.utils.vector_to_parameters(T(c['actor']), actor.parameters())
+  torch.nn.utils.vector_to_parameters(T(c['critic']), critic.parameters())
+  target = ref_models.create_target_network(critic)
+  torch.nn.utils.vector_to_parameters(T(c['target']), target.parameters())
+  log_alpha = T(c['log_alpha'].copy()).requires_grad_()
+  return actor, critic, target, log_alpha
+
+
+def gen_sac(name, c):
+  actor, critic, target, log_alpha = build_sac(c)
+  ao = torch.optim.AdamW(actor.parameters(), lr=c['lr'], weight_decay=c['weight_decay'])
+  co = torch.optim.AdamW(critic.parameters(), lr=c['lr'], weight_decay=c['weight_decay'])
+  to = torch.optim.Adam([log_alpha], lr=c['lr'])
+  grads = {}
+
+  def snap(opt, key, params):
+    orig = opt.step
+
+    def step(*a, **k):
+      grads.setdefault(key, []).append(np.concatenate([N_(p.grad).ravel() for p in params]))
+      return orig(*a, **k)
+    opt.step = step
+  snap(ao, 'actor', list(actor.parameters())); snap(co, 'critic', list(critic.parameters())); snap(to, 'alpha', [log_alpha])
+  out = {}
+  for i, b in enumerate(c['batches']):
+    with NoiseFeed() as nf:
+      nf.normal.append(T(c['eps_next'][i])); nf.rsample.append(T(c['eps_cur'][i]))
+      logp, q = ref_training.sac_update(actor, critic, log_alpha, target, tbatch(b), ao, co, to, c['discount'], c['entropy_target'], c['polyak'])
+      assert not nf.normal and not nf.rsample
+    k = i + 1
+    out[f'logp_{k}'], out[f'q_{k}'] = N_(logp), N_(q)
+    out[f'log_alpha_{k}'] = N_(log_alpha)
+    for nm, mod, opt in (('actor', actor, ao), ('critic', critic, co)):
+      out[f'{nm}_{k}'] = gi.strided(flat(mod))
+      out[f'{nm}_m_{k}'] = gi.strided(opt_state(opt, 'exp_avg'))
+      out[f'{nm}_v_{k}'] = gi.strided(opt_state(opt, 'exp_avg_sq'))
+      out[f'{nm}_norm_{k}'] = np.array([np.linalg.norm(flat(mod).astype(np.float64))])
+    out[f'target_{k}'] = gi.strided(flat(target))
+    out[f'g_actor_{k}'] = gi.strided(grads['actor'][i]); out[f'g_critic_{k}'] = gi.strided(grads['critic'][i]); out[f'g_alpha_{k}'] = grads['alpha'][i]
+    out[f'g_actor_norm_{k}'] = np.array([np.linalg.norm(grads['actor'][i].astype(np.float64))])
+    out[f'g_critic_norm_{k}'] = np.array([np.linalg.norm(grads['critic'][i].astype(np.float64))])
+  np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
+
+
+def gen_bc(name, env, hidden, batch, steps):
+  S, A = gi.DIMS[env]
+  rs = np.random.RandomState(7)
+  p0 = gi.mlp_params(rs, S, hidden, 2, 2 * A, out_scale=0.3)
+  actor = ref_models.SoftActor(S, A, DictConfig(hidden_size=hidden, depth=2, activation='relu'))
+  torch.nn.utils.vector_to_parameters(T(p0), actor.parameters())
+  opt = torch.optim.AdamW(actor.parameters(), lr=2.5e-4, weight_decay=0.01)
+  out = {}
+  for k in range(1, steps + 1):
+    b = gi.transitions(rs, batch, S, A, weighted=True)
+    b['actions'][:3] = np.array([1.0, -1.0, 0.9999999])[:, None]  # exercise the clamp
+    ref_training.behavioural_cloning_update(actor, tbatch(b), opt)
+    out[f'actor_{k}'] = gi.strided(flat(actor)); out[f'actor_m_{k}'] = gi.strided(opt_state(opt, 'exp_avg')); out[f'actor_v_{k}'] = gi.strided(opt_state(opt, 'exp_avg_sq'))
+    out[f'g_actor_{k}'] = gi.strided(np.concatenate([N_(p.grad).ravel() for p in actor.parameters()]))
+    with torch.no_grad():
+      out[f'logp_{k}'] = N_(actor.log_prob(T(b['states']), T(b['actions'])))
+  np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
+
+
+# ---------------------------------------------------------------- GAIL
+def build_disc(c, reward_function='AIRL'):
+  icfg = DictConfig(state_only=False, spectral_norm=c['spectral_norm'],
+                    discriminator=DictConfig(hidden_size=c['H'], depth=1, activation='relu', reward_shaping=False, subtract_log_policy=False, reward_function=reward_function))
+  d = ref_models.GAILDiscriminator(c['S'], c['A'], icfg, 0.97)
+  with torch.no_grad():
+    if c['spectral_norm']:
+      for li, (W, b, u, v) in ((0, (c['W1'], c['b1'], c['u1'], c['v1'])), (2, (c['W2'], c['b2'], c['u2'], c['v2']))):
+        d.g[li].parametrizations.weight.original.copy_(T(W)); d.g[li].bias.copy_(T(b))
+        d.g[li].parametrizations.weight[0]._u.copy_(T(u)); d.g[li].parametrizations.weight[0]._v.copy_(T(v))
+    else:
+      d.g[0].weight.copy_(T(c['W1'])); d.g[0].bias.copy_(T(c['b1'])); d.g[2].weight.copy_(T(c['W2'])); d.g[2].bias.copy_(T(c['b2']))
+  return d, icfg
+
+
+def gen_gail(name, c, *, lr, weight_decay, grad_penalty, entropy_bonus):
+  d, icfg = build_disc(c)
+  icfg.update(loss_function='BCE', grad_penalty=grad_penalty, mixup_alpha=1, entropy_bonus=entropy_bonus, pos_class_prior=0.7, nonnegative_margin=float('inf'))
+  opt = torch.optim.AdamW(d.parameters(), lr=lr, weight_decay=weight_decay)
+  out = {'param_names': np.array([n for n, _ in d.named_parameters()])}
+  for i in range(len(c['policy'])):
+    d.train()
+    with NoiseFeed() as nf:
+      nf.rand.append(T(c['eps'][i]))
+      ref_training.adversarial_imitation_update(None, d, tbatch(c['policy'][i]), tbatch(c['expert'][i]), opt, icfg)
+    d.eval()
+    k = i + 1
+    out[f'g_{k}'] = np.concatenate([N_(p.grad).ravel() for p in d.parameters()])
+    out[f'p_{k}'] = flat(d); out[f'm_{k}'] = opt_state(opt, 'exp_avg'); out[f'v_{k}'] = opt_state(opt, 'exp_avg_sq')
+    if c['spectral_norm']:
+      for li, nm in ((0, '1'), (2, '2')):
+        out[f'u{nm}_{k}'] = N_(d.g[li].parametrizations.weight[0]._u); out[f'v{nm}_{k}'] = N_(d.g[li].parametrizations.weight[0]._v)
+    b = c['policy'][i]
+    with torch.inference_mode():
+      for rf in ('AIRL', 'GAIL', 'FAIRL'):
+        d.reward_function = rf
+        out[f'reward_{rf}_{k}'] = N_(d.predict_reward(T(b['states']), T(b['actions'])))
+      out[f'logits_{k}'] = N_(d(T(b['states']), T(b['actions'])))
+  np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
+
+
+# ---------------------------------------------------------------- GMMIL / PWIL
+def gen_gmmil():
+  out = {}
+  for name, (B1, B2, D) in (('small', (64, 48, 24)), ('ant', (256, 256, 120))):
+    X, E, w, we = gi.gmmil_case(11, B1, B2, D)
+    S = D - 8 if D > 8 else D - 2
+    d = ref_models.GMMILDiscriminator(S, D - S, DictConfig(state_only=False))
+    args = (T(X[:, :S]), T(X[:, S:]), T(E[:, :S]), T(E[:, S:]), T(w), T(we))
+    out[f'{name}_reward_first'] = N_(d.predict_reward(*args))
+    out[f'{name}_gammas'] = np.array([d.gamma_1, d.gamma_2], np.float64)
+    X2, _, w2, _ = gi.gmmil_case(12, B1, B2, D)
+    out[f'{name}_reward_second'] = N_(d.predict_reward(T(X2[:, :S]), T(X2[:, S:]), T(E[:, :S]), T(E[:, S:]), T(w2), T(we)))
+    out[f'{name}_sqdist_xe'] = N_(ref_models._squared_distance(T(X), T(E)))[:16]
+  np.savez_compressed(os.path.join(HERE, 'gmmil.npz'), **out)
+
+
+def gen_pwil():
+  N, D, steps, Th = 400, 10, 260, 120
+  atoms, agent = gi.pwil_case(21, N, D, steps)
+  S, A = D - 3, 3
+  mem = ref_memory.ReplayMemory(N, S, A, False, transitions=dict(states=T(atoms[:, :S]), actions=T(atoms[:, S:]), rewards=torch.zeros(N), next_states=T(atoms[:, :S]), terminals=torch.zeros(N), timeouts=torch.zeros(N), weights=torch.ones(N), num_trajectories=4))
+  d = ref_models.PWILDiscriminator(S, A, DictConfig(state_only=False, reward_scale=5, reward_bandwidth_scale=5), mem, Th)
+  rewards = []
+  for t in range(steps):
+    rewards.append(d.compute_reward(T(agent[t:t + 1, :S]), T(agent[t:t + 1, S:])))
+    if t % Th == Th - 1:
+      d.reset()
+  np.savez_compressed(os.path.join(HERE, 'pwil.npz'), rewards=np.array(rewards, np.float64), scale=N_(d.data_scale), offset=N_(d.data_offset), remaining=np.array([d.expert_weights.numel()]))
+
+
+if __name__ == '__main__':
+  gen_replay()
+  gen_sac('sac_halfcheetah', gi.sac_case(3, 'halfcheetah', 256, 256, 3))
+  gen_sac('sac_hopper_h64', gi.sac_case(4, 'hopper', 64, 96, 3))
+  gen_sac('sac_ant_b64', gi.sac_case(5, 'ant', 256, 64, 2))
+  gen_bc('bc_hopper', 'hopper', 256, 256, 3)
+  gen_gail('gail_default', gi.gail_case(31), lr=3e-5, weight_decay=10, grad_penalty=1.0, entropy_bonus=0.0)
+  gen_gail('gail_h128_ent', gi.gail_case(32, hidden=128), lr=7.3e-5, weight_decay=6.35, grad_penalty=0.32, entropy_bonus=0.0155)
+  gen_gail('gail_nosn_nogp', gi.gail_case(33, env='hopper', hidden=32, batch=128, spectral_norm=False), lr=3e-4, weight_decay=0.0, grad_penalty=0.0, entropy_bonus=0.0)
+  gen_gmmil()
+  gen_pwil()
+  print('golden vectors written to', HERE)

@@ -1,0 +1,170 @@
+"""Pins the numpy oracle to the reference: every fixture in tests/golden/*.npz was produced by
+the unmodified reference on CPU torch (tests/golden/make_golden.py).  Tolerance: rtol 1e-5 as
+BASELINE.json's north_star states, plus an absolute floor scaled to each tensor's magnitude
+(sums of O(256) float32 products differ in the last ulps between MKL, OpenBLAS and MFMA order)."""
+import os
+
+import numpy as np
+import pytest
+
+import inputs as gi
+from oracle import gail, gmmil, nets, pwil, replay, sac
+from oracle.mt19937 import MT19937
+
+RTOL = 1e-5
+
+
+def close(a, b, name, rtol=RTOL, atol_scale=2e-6):
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  assert a.shape == b.shape, (name, a.shape, b.shape)
+  atol = atol_scale * max(float(np.abs(b).max()), 1e-30)
+  err = np.abs(a - b) - rtol * np.abs(b)
+  assert float(err.max()) <= atol, f'{name}: max excess err {err.max():.3e} (atol {atol:.3e}) at {int(err.argmax())}'
+
+
+def load(golden_dir, name):
+  return np.load(os.path.join(golden_dir, name + '.npz'), allow_pickle=False)
+
+
+# ------------------------------------------------------------------ replay (bit-exact)
+@pytest.mark.parametrize('name,seed,size,fill', [('partial', 0, 1000, 300), ('wrapped', 1, 64, 150), ('expert', 2, 500, None)])
+def test_replay_bit_exact(golden_dir, name, seed, size, fill):
+  g = load(golden_dir, 'replay')
+  S, A = 5, 2
+  rs = np.random.RandomState(100 + seed)
+  if fill is None:
+    tr = gi.transitions(rs, size, S, A)
+    mem = replay.ReplayOracle(size, S, A, True, transitions={**tr, 'num_trajectories': 3})
+  else:
+    mem = replay.ReplayOracle(size, S, A, True)
+    tr = gi.transitions(rs, fill, S, A)
+    for i in range(fill):
+      mem.append(i + 1, tr['states'][i], tr['actions'][i], float(tr['rewards'][i]), tr['next_states'][i], bool(tr['terminals'][i]), False)
+      if i % 37 == 36:
+        mem.wrap_for_absorbing_states()
+  assert [mem.idx, int(mem.full), mem.num_trajectories, mem.size] == g[f'{name}_state'].tolist()
+  for k in replay.FIELDS:
+    np.testing.assert_array_equal(getattr(mem, k)[:min(size, 200)], g[f'{name}_mem_{k}'], err_msg=k)
+  np.testing.assert_array_equal(np.array(mem.sample_idx(MT19937(seed), 256)), g[f'{name}_idx'])
+  batch = mem.sample(MT19937(seed), 32)
+  for k, v in batch.items():
+    np.testing.assert_array_equal(v, g[f'{name}_batch_{k}'], err_msg=k)
+
+
+# ------------------------------------------------------------------ SAC
+def run_sac_oracle(c, steps):
+  st = sac.SacState(c['S'], c['A'], c['H'])
+  st.actor[:], st.critic[:], st.target[:], st.log_alpha[:] = c['actor'], c['critic'], c['target'], c['log_alpha']
+  outs = []
+  for i in range(steps):
+    logp, q, gr = sac.sac_update(st, c['batches'][i], c['eps_next'][i], c['eps_cur'][i], discount=c['discount'], entropy_target=c['entropy_target'],
+                                 polyak_factor=c['polyak'], lr=c['lr'], weight_decay=c['weight_decay'], return_grads=True)
+    outs.append((logp.copy(), q.copy(), gr, {k: getattr(st, k).copy() for k in ('actor', 'critic', 'target', 'log_alpha', 'actor_m', 'actor_v', 'critic_m', 'critic_v')}))
+  return outs
+
+
+@pytest.mark.parametrize('name,args', [('sac_halfcheetah', (3, 'halfcheetah', 256, 256, 3)), ('sac_hopper_h64', (4, 'hopper', 64, 96, 3)), ('sac_ant_b64', (5, 'ant', 256, 64, 2))])
+def test_sac_update_matches_reference(golden_dir, name, args):
+  g, c = load(golden_dir, name), gi.sac_case(*args)
+  outs = run_sac_oracle(c, args[-1])
+  for k, (logp, q, gr, snap) in enumerate(outs, start=1):
+    # gradients are compared at step 1 only as tensors (later steps start from already-rounded state) -- and at every step loosely via the parameters
+    close(logp, g[f'logp_{k}'], f'logp_{k}', atol_scale=2e-6 * k)
+    close(q, g[f'q_{k}'], f'q_{k}', atol_scale=2e-6 * k)
+    if k == 1:
+      close(gi.strided(gr['critic']), g['g_critic_1'], 'g_critic_1')
+      close(gi.strided(gr['actor']), g['g_actor_1'], 'g_actor_1')
+      close(gr['alpha'], g['g_alpha_1'], 'g_alpha_1')
+    # Adam turns ulp-level gradient noise into O(lr * noise/|g|) parameter noise: the per-step bound is lr (3e-4) * 1e-3 relative-gradient noise
+    for nm in ('actor', 'critic'):
+      close(gi.strided(snap[nm]), g[f'{nm}_{k}'], f'{nm}_{k}', atol_scale=1e-5 * k)
+      close(gi.strided(snap[nm + '_m']), g[f'{nm}_m_{k}'], f'{nm}_m_{k}', atol_scale=1e-5 * k)
+      close(gi.strided(snap[nm + '_v']), g[f'{nm}_v_{k}'], f'{nm}_v_{k}', atol_scale=1e-5 * k)
+    close(gi.strided(snap['target']), g[f'target_{k}'], f'target_{k}', atol_scale=1e-5 * k)
+    close(snap['log_alpha'], g[f'log_alpha_{k}'], f'log_alpha_{k}')
+
+
+def test_bc_update_matches_reference(golden_dir):
+  g = load(golden_dir, 'bc_hopper')
+  S, A = gi.DIMS['hopper']
+  rs = np.random.RandomState(7)
+  p = gi.mlp_params(rs, S, 256, 2, 2 * A, out_scale=0.3)
+  m, v = np.zeros_like(p), np.zeros_like(p)
+  shapes = nets.mlp_shapes(S, 256, 2, 2 * A)
+  for k in range(1, 4):
+    b = gi.transitions(rs, 256, S, A, weighted=True)
+    b['actions'][:3] = np.array([1.0, -1.0, 0.9999999])[:, None]
+    _, gr, _ = sac.bc_update(p, m, v, k, shapes, A, b, lr=2.5e-4, weight_decay=0.01, return_grads=True)
+    if k == 1:
+      close(gi.strided(gr), g['g_actor_1'], 'g_actor_1')
+    close(gi.strided(p), g[f'actor_{k}'], f'actor_{k}', atol_scale=1e-5 * k)
+    close(gi.strided(m), g[f'actor_m_{k}'], f'actor_m_{k}', atol_scale=1e-5 * k)
+    # log-prob of the updated actor on the same batch (SoftActor.log_prob, models.py:97-99)
+    out, _ = nets.mlp_forward(nets.unpack(p, shapes), b['states'])
+    mean, _, _, std = nets.actor_head(out, A)
+    x = np.arctanh(np.clip(b['actions'], np.float32(-1 + 1e-6), np.float32(1 - 1e-6)))
+    close(nets.tanh_gaussian_logp(x, mean, std), g[f'logp_{k}'], f'logp_{k}', rtol=1e-4, atol_scale=1e-5)
+
+
+# ------------------------------------------------------------------ GAIL
+def make_disc(c):
+  ds = gail.DiscState(c['D'], c['H'], c['spectral_norm'])
+  for k in ('W1', 'b1', 'W2', 'b2', 'u1', 'v1', 'u2', 'v2'):
+    getattr(ds, k)[...] = c[k]
+  return ds
+
+
+@pytest.mark.parametrize('name,case,hp', [
+    ('gail_default', dict(seed=31), dict(lr=3e-5, weight_decay=10, grad_penalty=1.0, entropy_bonus=0.0)),
+    ('gail_h128_ent', dict(seed=32, hidden=128), dict(lr=7.3e-5, weight_decay=6.35, grad_penalty=0.32, entropy_bonus=0.0155)),
+    ('gail_nosn_nogp', dict(seed=33, env='hopper', hidden=32, batch=128, spectral_norm=False), dict(lr=3e-4, weight_decay=0.0, grad_penalty=0.0, entropy_bonus=0.0)),
+])
+def test_gail_update_matches_reference(golden_dir, name, case, hp):
+  g, c = load(golden_dir, name), gi.gail_case(**case)
+  ds = make_disc(c)
+  want = ['g.0.bias', 'g.0.parametrizations.weight.original', 'g.2.bias', 'g.2.parametrizations.weight.original'] if c['spectral_norm'] else ['g.0.weight', 'g.0.bias', 'g.2.weight', 'g.2.bias']
+  assert g['param_names'].tolist() == want
+  cat = lambda b: np.concatenate([b['states'], b['actions']], axis=1)
+  for k in range(1, len(c['policy']) + 1):
+    pb, eb = c['policy'][k - 1], c['expert'][k - 1]
+    gr = gail.gail_update(ds, cat(pb), pb['weights'], cat(eb), eb['weights'], c['eps'][k - 1], return_grads=True, **hp)
+    close(gr, g[f'g_{k}'], f'g_{k}', atol_scale=2e-6 * k)
+    close(ds.pack(), g[f'p_{k}'], f'p_{k}', atol_scale=2e-6 * k)
+    close(ds.m, g[f'm_{k}'], f'm_{k}', atol_scale=2e-6 * k); close(ds.v, g[f'v_{k}'], f'v_{k}', atol_scale=2e-6 * k)
+    if c['spectral_norm']:
+      for nm in ('u1', 'v1', 'u2', 'v2'):
+        close(getattr(ds, nm), g[f'{nm}_{k}'], f'{nm}_{k}')
+    close(gail.disc_logits(ds, cat(pb)), g[f'logits_{k}'], f'logits_{k}', atol_scale=4e-6)
+    for rf in ('AIRL', 'GAIL', 'FAIRL'):
+      close(gail.predict_reward(ds, cat(pb), rf), g[f'reward_{rf}_{k}'], f'reward_{rf}_{k}', rtol=1e-4, atol_scale=1e-5)
+
+
+# ------------------------------------------------------------------ GMMIL / PWIL
+@pytest.mark.parametrize('name,dims', [('small', (64, 48, 24)), ('ant', (256, 256, 120))])
+def test_gmmil_matches_reference(golden_dir, name, dims):
+  g = load(golden_dir, 'gmmil')
+  X, E, w, we = gi.gmmil_case(11, *dims)
+  g1, g2 = gmmil.median_gammas(X, E, w, we)
+  np.testing.assert_allclose([g1, g2], g[f'{name}_gammas'], rtol=1e-6)
+  close(gmmil.squared_distance(X, E)[:16], g[f'{name}_sqdist_xe'], 'sqdist')
+  r, sim, self_sim = gmmil.gmmil_reward(X, E, w, we, g1, g2, return_parts=True)
+  # reward = difference of two near-equal sums: absolute floor relative to the summands, not to the difference
+  assert np.abs(r - g[f'{name}_reward_first']).max() <= 1e-5 * np.abs(sim).max()
+  X2, _, w2, _ = gi.gmmil_case(12, *dims)
+  r2, sim2, _ = gmmil.gmmil_reward(X2, E, w2, we, g1, g2, return_parts=True)
+  assert np.abs(r2 - g[f'{name}_reward_second']).max() <= 1e-5 * np.abs(sim2).max()
+
+
+def test_pwil_matches_reference(golden_dir):
+  g = load(golden_dir, 'pwil')
+  N, D, steps, Th = 400, 10, 260, 120
+  atoms, agent = gi.pwil_case(21, N, D, steps)
+  o = pwil.PwilOracle(atoms, Th, 5, 5)
+  close(o.scale, g['scale'], 'scale'); close(o.offset, g['offset'], 'offset')
+  rewards = []
+  for t in range(steps):
+    rewards.append(o.compute_reward(agent[t]))
+    if t % Th == Th - 1:
+      o.reset()
+  np.testing.assert_allclose(rewards, g['rewards'], rtol=1e-5)
+  assert o.weights.size == int(g['remaining'][0])
