@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""SAC+GAIL gradient-updates/s at batch 256, HalfCheetah dims (BASELINE.json metric) on N MI355X.
+
+One "step" = one execution of the reference's update block (train.py:173-203, algorithm=GAIL default config):
+2 replay samples (MT19937 index draws + row gathers) + adversarial_imitation_update (BCE, grad-penalty 1, spectral norm)
++ AIRL reward relabel + sac_update, on synthetic D4RL-shaped transitions resident in HBM.
+N > 1 (torch.distributed.run): one rank per GPU, own replay shard, three RCCL gradient all-reduces per update (weak scaling:
+per-GPU batch 256); value = N x synchronous global steps/s.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the launch stream) and, at N=1, `cpu_baseline`
+(the numpy oracle port timed on the host cores; the reference itself cannot travel to the GPU box).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+
+S, A, H, HD, B = 18, 6, 256, 64, 256  # HalfCheetah dims incl. absorbing bit; GAIL.yaml discriminator
+HBM_PEAK_GBS, FP32_PEAK_TFLOPS = 8000.0, 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+class Cfg(dict):
+  __getattr__ = dict.__getitem__
+
+
+def synthetic_transitions(rs, n, state_shift=0.0):
+  import inputs as gi
+  return gi.transitions(rs, n, S, A, state_shift=state_shift, absorbing_frac=0.01, terminal_frac=0.001)
+
+
+def algorithmic_model():
+  Pa = H * S + H + H * H + H + 2 * A * H + 2 * A
+  Pc = H * (S + A) + H + H * H + H + H + 1
+  Pd = HD * (S + A) + HD + HD + 1
+  mac_a, mac_c = S * H + H * H + H * 2 * A, (S + A) * H + H * H + H
+  bytes_k = {
+      'k_dw_adam_critic': 24 * 2 * Pc, 'k_dw_adam_actor': 24 * (Pa + 1) + 8 * 2 * Pc, 'k_gail_reduce': 24 * Pd, 'k_gather': B * (2 * S + A + 5) * 4 + B * 4,
+  }
+  flops_k = {
+      'k_actor_fwd': 2 * 2 * B * mac_a, 'k_critic_fwd': 4 * 2 * B * mac_c, 'k_critic_bwd': 2 * 2 * B * H * H, 'k_dw_adam_critic': 2 * 2 * B * mac_c,
+      'k_policy_critic': 2 * 2 * B * (mac_c + H * H + H * A), 'k_actor_bwd': 2 * B * (2 * A * H + H * H), 'k_dw_adam_actor': 2 * B * mac_a,
+  }
+  update_bytes = 24 * (Pa + 2 * Pc + Pd + 1) + 8 * 2 * Pc + 2 * B * (2 * S + A + 5) * 4
+  return bytes_k, flops_k, update_bytes, sum(flops_k.values())
+
+
+def build(device, rank, seed=0):
+  import imitation_learning_amd as il
+  torch.manual_seed(seed)
+  cfg = Cfg(hidden_size=H, depth=2, activation='relu')
+  actor, critic = il.SoftActor(S, A, cfg, device=device), il.TwinCritic(S, A, cfg, device=device)
+  target, log_alpha = il.create_target_network(critic), torch.zeros(1, device=device)
+  ao, co, to = il.AdamW(actor, lr=3e-4, weight_decay=0), il.AdamW(critic, lr=3e-4, weight_decay=0), il.Adam(log_alpha, lr=3e-4)
+  icfg = Cfg(state_only=False, spectral_norm=True, loss_function='BCE', grad_penalty=1.0, entropy_bonus=0.0, learning_rate=3e-5, weight_decay=10,
+             discriminator=Cfg(hidden_size=HD, depth=1, activation='relu', reward_shaping=False, subtract_log_policy=False, reward_function='AIRL'))
+  disc = il.GAILDiscriminator(S, A, icfg, 0.97, device=device)
+  do = il.AdamW(disc, lr=3e-5, weight_decay=10)
+  rs = np.random.RandomState(1000 + rank)  # per-rank replay shard
+  mem = il.ReplayMemory(1_000_000, S, A, True, device=device)
+  n_fill = 100_000
+  tr = synthetic_transitions(rs, n_fill)
+  for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'timeouts', 'weights'):
+    getattr(mem, k)[:n_fill] = torch.from_numpy(tr[k]).to(device)
+  mem.step[:n_fill] = torch.arange(1, n_fill + 1, dtype=torch.float32, device=device)
+  mem.idx, mem.full = n_fill, False
+  mem._sync_ring_state()
+  et = synthetic_transitions(np.random.RandomState(77), 25_000, state_shift=0.5)  # full copy of the expert buffer on every rank
+  emem = il.ReplayMemory(25_000, S, A, True, transitions={**{k: torch.from_numpy(v) for k, v in et.items() if k != 'absorbing'}, 'num_trajectories': 25}, device=device)
+  il.seed(seed + rank)
+  plan = il.UpdatePlan('GAIL', actor, critic, log_alpha, target, mem, ao, co, to, B, 0.97, -0.5 * A, 0.99, expert_memory=emem, discriminator=disc, discriminator_optimiser=do,
+                       imitation_cfg=icfg)
+  return plan, (actor, critic, target, log_alpha, disc), (tr, et)
+
+
+def cpu_baseline(tr, et, budget_s=12.0):
+  """The oracle port of the same update block on the host cores (index draws through numpy's legacy RNG like the reference)."""
+  from oracle import gail as ogail
+  from oracle import nets as onets
+  from oracle import replay as oreplay
+  from oracle import sac as osac
+  rs = np.random.RandomState(0)
+  import inputs as gi
+  st = osac.SacState(S, A, H)
+  st.actor[:] = gi.mlp_params(rs, S, H, 2, 2 * A, out_scale=0.3)
+  st.critic[:] = np.concatenate([gi.mlp_params(rs, S + A, H, 2, 1) for _ in range(2)]); st.target[:] = st.critic
+  g = gi.gail_case(1)
+  ds = ogail.DiscState(S + A, HD, True)
+  for k in ('W1', 'b1', 'W2', 'b2', 'u1', 'v1', 'u2', 'v2'):
+    getattr(ds, k)[...] = g[k]
+  n = tr['states'].shape[0]
+  mem = oreplay.ReplayOracle(1_000_000, S, A, True)
+  for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'timeouts', 'weights'):
+    getattr(mem, k)[:n] = tr[k]
+  mem.idx = n
+  emem = oreplay.ReplayOracle(et['states'].shape[0], S, A, True, transitions={**et, 'num_trajectories': 25})
+  np.random.seed(0)
+
+  def draw(m, k):
+    out, high, excl = [], (m.size if m.full else m.idx - 1), (m.idx - 1) % m.size
+    while len(out) < k:
+      v = int(np.random.randint(0, high))
+      if v != excl:
+        out.append(v)
+    return out
+  cat = lambda b: np.concatenate([b['states'], b['actions']], axis=1)
+
+  def one():
+    b, e = mem.gather(draw(mem, B)), emem.gather(draw(emem, B))
+    ogail.gail_update(ds, cat(b), b['weights'], cat(e), e['weights'], rs.uniform(size=B).astype(np.float32), lr=3e-5, weight_decay=10, grad_penalty=1.0)
+    b['rewards'] = ogail.predict_reward(ds, cat(b))
+    osac.sac_update(st, b, rs.standard_normal((B, A)).astype(np.float32), rs.standard_normal((B, A)).astype(np.float32), discount=0.97, entropy_target=-0.5 * A, polyak_factor=0.99)
+  for _ in range(3):
+    one()
+  t0, k = time.perf_counter(), 0
+  while time.perf_counter() - t0 < budget_s:
+    one(); k += 1
+  dt = time.perf_counter() - t0
+  try:
+    import threadpoolctl
+    threads = max([p['num_threads'] for p in threadpoolctl.threadpool_info()] + [1])
+  except Exception:
+    threads = os.cpu_count()
+  return dict(value=round(k / dt, 2), unit='updates/s', cores=int(threads), kind='port',
+              sample=f'{k} SAC+GAIL updates (numpy float32 oracle port of train.py:173-203, batch {B}, same synthetic buffers) in {dt:.1f} s on {os.cpu_count()} host cores')
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=2000)
+  ap.add_argument('--warmup', type=int, default=200)
+  ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--trace-steps', type=int, default=100)
+  args = ap.parse_args()
+
+  world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+  assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run --nproc-per-node {args.gpus})'
+  assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU fallback for the HIP path)'
+  torch.cuda.set_device(local)
+  device = torch.device('cuda', local)
+  import torch.distributed as dist
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', device_id=device)
+  from imitation_learning_amd import _lib
+  from imitation_learning_amd.parallel import DataParallelUpdate, broadcast_parameters
+
+  plan, nets, (tr, et) = build(device, rank)
+  runner = plan
+  if world > 1:
+    broadcast_parameters([n.flat if hasattr(n, 'flat') else n for n in nets] + [nets[4].sn])
+    runner = DataParallelUpdate(plan)
+  for _ in range(5):
+    runner.run()   # loads code objects before capture
+  torch.cuda.synchronize()
+  if not args.no_graph:
+    runner.capture(warmup=0)
+    step = runner.replay
+  else:
+    step = runner.run
+
+  def barrier():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+      torch.cuda.synchronize()
+  for _ in range(args.warmup):
+    step()
+  barrier()
+  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  ev0.record()
+  for _ in range(args.steps):
+    step()
+  ev1.record()
+  barrier()
+  elapsed = time.perf_counter() - t0
+  t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+  if world > 1:
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  elapsed = float(t.item())
+  finite = all(bool(torch.isfinite(n.flat if hasattr(n, 'flat') else n).all()) for n in nets)
+
+  if rank == 0:
+    bytes_k, flops_k, update_bytes, update_flops = algorithmic_model()
+    ms_per_step = elapsed / args.steps * 1e3
+    ups = world * args.steps / elapsed
+    # ---- per-kernel durations, HIP events on the launch stream, eager launches of the very same kernels
+    L = _lib.lib()
+    L.il_trace_enable(1)
+    for _ in range(args.trace_steps):
+      plan.run()
+    buf = C.create_string_buffer(1 << 16)
+    _lib.check(L.il_trace_report(buf, len(buf)))
+    L.il_trace_enable(0)
+    kern = {}
+    for line in buf.value.decode().strip().splitlines():
+      name, cnt, tot = line.split()
+      kern[name] = dict(launches_per_update=int(cnt) / args.trace_steps, avg_us=float(tot) / int(cnt) * 1e3)
+    dom = max(kern, key=lambda k: kern[k]['avg_us'] * kern[k]['launches_per_update'])
+    per_kernel = {}
+    for k, v in kern.items():
+      e = dict(avg_us=round(v['avg_us'], 3), launches_per_update=v['launches_per_update'])
+      if k in bytes_k:
+        e['hbm_GBps'] = round(bytes_k[k] / (v['avg_us'] * 1e-6) / 1e9, 2)
+      if k in flops_k:
+        e['fp32_TFLOPs'] = round(flops_k[k] / (v['avg_us'] * 1e-6) / 1e12, 3)
+      per_kernel[k] = e
+    if dom in flops_k:
+      ach = flops_k[dom] / (kern[dom]['avg_us'] * 1e-6) / 1e12
+      roof = dict(bound='mfma', kernel=dom, achieved=round(ach, 3), peak=FP32_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / FP32_PEAK_TFLOPS, 5), traffic=None)
+    else:
+      ach = bytes_k.get(dom, 0) / (kern[dom]['avg_us'] * 1e-6) / 1e9
+      roof = dict(bound='hbm', kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 5), traffic=None)
+    upd_gbs = update_bytes / (ms_per_step * 1e-3) / 1e9
+    roof['update'] = dict(algorithmic_bytes=update_bytes, achieved_GBps=round(upd_gbs, 2), hbm_frac=round(upd_gbs / HBM_PEAK_GBS, 5), algorithmic_flops=update_flops,
+                          fp32_frac=round(update_flops / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5),
+                          sum_kernel_us=round(sum(v['avg_us'] * v['launches_per_update'] for v in kern.values()), 2))
+    roof['kernels'] = per_kernel
+    out = dict(metric='SAC+GAIL grad-updates/sec (batch 256, HalfCheetah dims)', value=round(ups, 1), unit='updates/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=round(ms_per_step, 5), higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+               config=dict(workload='algorithm=GAIL env=halfcheetah: 2 replay samples + discriminator step (BCE+GP+SN) + AIRL relabel + sac_update per step',
+                           batch_per_gpu=B, global_batch=B * world, state_dim=S, action_dim=A, hidden=H, replay_capacity=1_000_000, replay_fill=100_000, expert_rows=25_000,
+                           parallelism=f'dp{world}', launch='eager' if args.no_graph else 'hipGraph replay', noise='on-chip Philox4x32-10', finite=finite),
+               roofline=roof)
+    if world == 1 and not args.no_cpu_baseline:
+      out['cpu_baseline'] = cpu_baseline(tr, et)
+    print(json.dumps(out))
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

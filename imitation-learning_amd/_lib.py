@@ -1,0 +1,123 @@
+"""ctypes binding of libil_hip.so (the C ABI declared in include/il_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, this raises.
+The structures mirror include/il_hip.h field for field.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libil_hip.so')
+
+IL_FLAG_GRADS_ONLY, IL_FLAG_TICK = 1, 2
+c_f32p, c_i32p, c_u32p, c_i64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)
+
+
+class Batch(C.Structure):
+  _fields_ = [(k, C.c_void_p) for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'weights', 'absorbing')] + \
+             [('ld_' + k, C.c_int32) for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'weights', 'absorbing')] + [('n', C.c_int32)]
+
+
+class Adam(C.Structure):
+  _fields_ = [('m', C.c_void_p), ('v', C.c_void_p), ('step', C.c_void_p), ('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
+              ('weight_decay', C.c_float)]
+
+
+class Sac(C.Structure):
+  _fields_ = [('state_dim', C.c_int32), ('action_dim', C.c_int32), ('hidden', C.c_int32), ('batch', C.c_int32),
+              ('actor', C.c_void_p), ('critic', C.c_void_p), ('target', C.c_void_p), ('log_alpha', C.c_void_p),
+              ('actor_grad', C.c_void_p), ('critic_grad', C.c_void_p), ('alpha_grad', C.c_void_p),
+              ('actor_opt', Adam), ('critic_opt', Adam), ('alpha_opt', Adam),
+              ('discount', C.c_float), ('entropy_target', C.c_float), ('polyak', C.c_float),
+              ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p)]
+
+
+class Disc(C.Structure):
+  _fields_ = [('state_dim', C.c_int32), ('action_dim', C.c_int32), ('hidden', C.c_int32), ('batch', C.c_int32),
+              ('spectral_norm', C.c_int32), ('state_only', C.c_int32), ('reward_function', C.c_int32),
+              ('params', C.c_void_p), ('u1', C.c_void_p), ('v1', C.c_void_p), ('u2', C.c_void_p), ('v2', C.c_void_p), ('grad', C.c_void_p),
+              ('opt', Adam), ('grad_penalty', C.c_float), ('entropy_bonus', C.c_float),
+              ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p)]
+
+
+class Pwil(C.Structure):
+  _fields_ = [('n_atoms', C.c_int32), ('dim', C.c_int32), ('state_dim', C.c_int32), ('action_dim', C.c_int32),
+              ('atoms', C.c_void_p), ('weights', C.c_void_p), ('dists', C.c_void_p), ('scale', C.c_void_p), ('offset', C.c_void_p),
+              ('reward_scale', C.c_double), ('reward_bandwidth', C.c_double), ('agent_weight', C.c_double)]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    'il_last_error': (C.c_char_p, []),
+    'il_abi_version': (C.c_int, []),
+    'il_device_info': (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
+    'il_trace_enable': (C.c_int, [C.c_int]),
+    'il_trace_report': (C.c_int, [C.c_char_p, C.c_int]),
+    'il_ring_row_floats': (C.c_int32, [C.c_int32, C.c_int32]),
+    'il_replay_write_rows': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int64, _P, C.c_int32, _P]),
+    'il_replay_wrap_absorbing': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P]),
+    'il_replay_gather': (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int32, _P, _P]),
+    'il_mt19937_seed': (C.c_int, [c_u32p, C.c_uint32]),
+    'il_mt19937_sample_indices': (C.c_int, [c_u32p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, c_i32p]),
+    'il_mt19937_sample_indices_device': (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    'il_adam_step': (C.c_int, [_P, _P, C.POINTER(Adam), C.c_int64, C.c_uint32, _P]),
+    'il_polyak': (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
+    'il_mlp_numel': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    'il_mlp_stride': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    'il_sac_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'il_sac_critic_step': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), _P, C.c_uint32, _P]),
+    'il_sac_actor_step': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), _P, _P, _P, C.c_uint32, _P]),
+    'il_sac_apply_actor_grads': (C.c_int, [C.POINTER(Sac), _P]),
+    'il_sac_apply_critic_grads': (C.c_int, [C.POINTER(Sac), _P]),
+    'il_sac_update': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), _P, _P, _P, _P, C.c_uint32, _P]),
+    'il_bc_step': (C.c_int, [_P, _P, C.POINTER(Adam), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Batch), _P, C.c_int64, _P, C.c_uint32, _P]),
+    'il_actor_act': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_uint64, C.c_uint32, C.c_int32, _P, _P, _P]),
+    'il_disc_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    'il_gail_disc_step': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), C.POINTER(Batch), _P, C.c_uint32, _P]),
+    'il_gail_apply_grads': (C.c_int, [C.POINTER(Disc), _P]),
+    'il_gail_reward': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), _P, _P, _P]),
+    'il_gmmil_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    'il_gmmil_reward': (C.c_int, [C.POINTER(Batch), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, C.c_int64, _P]),
+    'il_gmmil_sqdist': (C.c_int, [C.POINTER(Batch), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
+    'il_pwil_reset': (C.c_int, [C.POINTER(Pwil), _P]),
+    'il_pwil_reward': (C.c_int, [C.POINTER(Pwil), _P, _P, _P, _P]),
+}
+
+
+class HipLibraryMissing(ImportError):
+  pass
+
+
+_lib = None
+
+
+def lib():
+  """Loads libil_hip.so once; raises HipLibraryMissing (no CPU fallback exists) when it has not been built."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise HipLibraryMissing(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                              f'(hipcc --offload-arch=gfx950). There is no CPU fallback for the update path.')
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+      fn = getattr(handle, name)  # AttributeError here = header / library out of sync
+      fn.restype, fn.argtypes = res, args
+    _lib = handle
+  return _lib
+
+
+def check(rc: int):
+  if rc != 0:
+    raise RuntimeError(f'libil_hip error {rc}: {lib().il_last_error().decode()}')
+
+
+def stream_ptr():
+  import torch
+  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+  """Device pointer of a torch tensor (None -> NULL)."""
+  return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,322 @@
+// GAIL discriminator kernels (reference training.py:85-134, models.py:152-180, torch _SpectralNorm).
+//
+// k_gail_grad   tiles of 16 rows. Every workgroup redoes the three spectral-norm power iterations (they depend only on
+//               W, u, v: 2 mat-vecs of a [H x D] matrix) and then, for its rows, the three discriminator passes
+//               (policy, expert, gradient-penalty mix) with closed-form backward:
+//                 BCE:  dz = w (sigmoid(z) - y)/B (+ entropy bonus),  dh = dz w2^ [h>0]
+//                 GP :  q = [h>0] w2^,  g = W1^^T q,  c = 2 lambda w/B:  dW1^ += c q g^T,  dw2^ += c [h>0] (W1^ g)
+//               and the spectral-norm chain rule per pass  dW = G^/sigma - <G^, W>/sigma^2 u v^T, with <G^, W> evaluated
+//               through the forward values (<G1^,W1> = sigma1 sum dh (h - b1), ...) so G^ is never materialised.
+//               Each workgroup writes one partial gradient slab; no atomics => deterministic.
+// k_gail_reduce one workgroup: slab sum -> grad, AdamW, spectral-norm buffers update.
+// k_gail_reward eval-mode forward + AIRL / GAIL / FAIRL reward head.
+#include "il_common.hpp"
+#include "mlp_tile.hpp"
+
+struct DiscLayout { int64_t oW1, ob1, oW2, ob2, P; };
+__host__ __device__ inline DiscLayout disc_layout(int D, int H, int sn) {
+  DiscLayout l;
+  if (sn) { l.ob1 = 0; l.oW1 = H; l.ob2 = H + (int64_t)H * D; l.oW2 = l.ob2 + 1; }
+  else { l.oW1 = 0; l.ob1 = (int64_t)H * D; l.oW2 = l.ob1 + H; l.ob2 = l.oW2 + H; }
+  l.P = (int64_t)H * D + 2 * H + 1;
+  return l;
+}
+struct DiscWs { int64_t slabs, sn_new, total; };
+__host__ __device__ inline DiscWs disc_ws(int D, int H, int B) {
+  DiscWs w; const int64_t P = (int64_t)H * D + 2 * H + 1; const int nt = (B + IL_TILE_R - 1) / IL_TILE_R;
+  w.slabs = 0; w.sn_new = (nt * P + 3) & ~(int64_t)3; w.total = w.sn_new + 2 * H + D + 1 + 3;
+  return w;
+}
+extern "C" int64_t il_disc_workspace_floats(int32_t D, int32_t H, int32_t B) { return disc_ws(D, H, B).total; }
+
+// all-thread helper: vec[i] /= max(||vec||, 1e-12) for an LDS vector of length n (F.normalize)
+__device__ __forceinline__ void normalize_lds(float* vec, int n, float* red) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += vec[i] * vec[i];
+  s = block_sum(s, red);
+  const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) vec[i] *= inv;
+  __syncthreads();
+}
+
+// one spectral-norm power iteration + sigma for W1 [H x D] (global) and W2 [1 x H] (global); u/v live in LDS. Returns sigmas to all threads.
+__device__ __forceinline__ void sn_iterate(const float* __restrict__ W1, const float* __restrict__ W2, int D, int H, float* u1, float* v1, float* u2, float* v2, bool iterate,
+                                           float& s1, float& s2, float* red) {
+  if (iterate) {
+    for (int n = threadIdx.x; n < H; n += blockDim.x) { float s = 0.f; for (int k = 0; k < D; ++k) s += W1[(size_t)n * D + k] * v1[k]; u1[n] = s; }
+    __syncthreads();
+    normalize_lds(u1, H, red);
+    for (int k = threadIdx.x; k < D; k += blockDim.x) { float s = 0.f; for (int n = 0; n < H; ++n) s += W1[(size_t)n * D + k] * u1[n]; v1[k] = s; }
+    __syncthreads();
+    normalize_lds(v1, D, red);
+    // layer 2: W2 is [1 x H]: u2 = normalize(W2 v2) (a scalar), v2 = normalize(W2^T u2)
+    float p = 0.f;
+    for (int n = threadIdx.x; n < H; n += blockDim.x) p += W2[n] * v2[n];
+    p = block_sum(p, red);
+    const float uu = p / fmaxf(fabsf(p), 1e-12f);
+    if (threadIdx.x == 0) u2[0] = uu;
+    for (int n = threadIdx.x; n < H; n += blockDim.x) v2[n] = W2[n] * uu;
+    __syncthreads();
+    normalize_lds(v2, H, red);
+  }
+  float a = 0.f;
+  for (int n = threadIdx.x; n < H; n += blockDim.x) { float s = 0.f; for (int k = 0; k < D; ++k) s += W1[(size_t)n * D + k] * v1[k]; a += u1[n] * s; }
+  s1 = block_sum(a, red);
+  float b = 0.f;
+  for (int n = threadIdx.x; n < H; n += blockDim.x) b += W2[n] * v2[n];
+  s2 = u2[0] * block_sum(b, red);
+}
+
+struct DiscLds {
+  float *X[3], *wt[3], *hs, *dhs, *cg, *ts, *u1, *v1, *u2, *v2, *zs, *dzs, *red;
+};
+__host__ __device__ inline size_t disc_lds_floats(int D, int H) { return (size_t)3 * IL_TILE_R * D + 3 * IL_TILE_R + 3 * (size_t)IL_TILE_R * H + (size_t)IL_TILE_R * D + 2 * H + D + 4 + 2 * IL_TILE_R + 64; }
+__device__ __forceinline__ DiscLds carve(float* s, int D, int H) {
+  DiscLds l; float* p = s;
+  for (int i = 0; i < 3; ++i) { l.X[i] = p; p += IL_TILE_R * D; }
+  for (int i = 0; i < 3; ++i) { l.wt[i] = p; p += IL_TILE_R; }
+  l.hs = p; p += IL_TILE_R * H; l.dhs = p; p += IL_TILE_R * H; l.ts = p; p += IL_TILE_R * H; l.cg = p; p += IL_TILE_R * D;
+  l.u1 = p; p += H; l.v1 = p; p += D; l.v2 = p; p += H; l.u2 = p; p += 4;
+  l.zs = p; p += IL_TILE_R; l.dzs = p; p += IL_TILE_R; l.red = p;
+  return l;
+}
+
+__global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch;
+  const int tile = blockIdx.x, row0 = tile * IL_TILE_R, tid = threadIdx.x;
+  const int nrows = min(IL_TILE_R, B - row0);
+  const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
+  const DiscWs wsl = disc_ws(D, H, B);
+  const float* W1 = d.params + lay.oW1; const float* b1 = d.params + lay.ob1; const float* W2 = d.params + lay.oW2; const float b2 = d.params[lay.ob2];
+  float* slab = d.workspace + wsl.slabs + (size_t)tile * lay.P;
+  DiscLds L = carve(smem, D, H);
+  // ---- stage inputs: policy rows, expert rows, mix rows (training.py:118-120)
+  for (int i = tid; i < IL_TILE_R * D; i += blockDim.x) {
+    const int r = i / D, k = i - r * D; float xp = 0.f, xe = 0.f;
+    if (r < nrows) {
+      xp = k < S ? pol.states[(size_t)(row0 + r) * pol.ld_states + k] : pol.actions[(size_t)(row0 + r) * pol.ld_actions + k - S];
+      xe = k < S ? exp.states[(size_t)(row0 + r) * exp.ld_states + k] : exp.actions[(size_t)(row0 + r) * exp.ld_actions + k - S];
+    }
+    L.X[0][i] = xp; L.X[1][i] = xe;
+  }
+  const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
+  if (tid < IL_TILE_R) {
+    const int r = tid; float wp = 0.f, we = 0.f, e = 0.f;
+    if (r < nrows) {
+      wp = pol.weights[(size_t)(row0 + r) * pol.ld_weights]; we = exp.weights[(size_t)(row0 + r) * exp.ld_weights];
+      e = eps_gp ? eps_gp[row0 + r] : philox_uniform(d.noise_seed, ctr, IL_STREAM_GP, (uint32_t)(row0 + r));
+    }
+    L.wt[0][r] = wp; L.wt[1][r] = we; L.wt[2][r] = e * we + (1.f - e) * wp; L.dzs[r] = e;
+  }
+  for (int i = tid; i < H; i += blockDim.x) { L.u1[i] = d.spectral_norm ? d.u1[i] : 0.f; L.v2[i] = d.spectral_norm ? d.v2[i] : 0.f; }
+  for (int i = tid; i < D; i += blockDim.x) L.v1[i] = d.spectral_norm ? d.v1[i] : 0.f;
+  if (tid == 0) { L.u2[0] = d.spectral_norm ? d.u2[0] : 0.f; if (tile == 0) d.opt.step[0] += 1; }
+  __syncthreads();
+  for (int i = tid; i < IL_TILE_R * D; i += blockDim.x) { const float e = L.dzs[i / D]; L.X[2][i] = e * L.X[1][i] + (1.f - e) * L.X[0][i]; }
+  __syncthreads();
+
+  const int r = tid >> 4, sub = tid & 15;
+  const float fB = (float)B;
+  const int npass = d.grad_penalty > 0.f ? 3 : 2;
+  for (int pass = 0; pass < npass; ++pass) {
+    float s1 = 1.f, s2 = 1.f;
+    if (d.spectral_norm) sn_iterate(W1, W2, D, H, L.u1, L.v1, L.u2, L.v2, true, s1, s2, L.red);
+    const float* X = L.X[pass];
+    const bool valid = r < nrows;
+    // ---- forward for row r (16 threads per row)
+    float zp = 0.f;
+    for (int n = sub; n < H; n += 16) {
+      float s = 0.f;
+      for (int k = 0; k < D; ++k) s += W1[(size_t)n * D + k] * X[r * D + k];
+      const float h = s / s1 + b1[n];
+      L.hs[r * H + n] = h;
+      zp += (W2[n] / s2) * fmaxf(h, 0.f);
+    }
+    zp = group16_sum(zp);
+    const float z = zp + b2;
+    float S_ip = 0.f;  // accumulates the <G^,W>/sigma pieces
+    float ip1, ip2;
+    if (pass < 2) {
+      const float w = L.wt[pass][r], label = pass == 1 ? 1.f : 0.f;
+      const float p = sigmoid_f(z);
+      float dz = valid ? w * (p - label) / fB : 0.f;
+      if (d.entropy_bonus > 0.f && valid) dz += d.entropy_bonus * w * z * p * (1.f - p) / fB;
+      if (sub == 0) { L.dzs[r] = dz; L.zs[r] = z; }
+      float a1 = 0.f;
+      for (int n = sub; n < H; n += 16) {
+        const float h = L.hs[r * H + n];
+        const float dh = h > 0.f ? dz * (W2[n] / s2) : 0.f;
+        L.dhs[r * H + n] = dh;
+        a1 += dh * (h - b1[n]);
+      }
+      ip1 = s1 * block_sum(a1, L.red);
+      ip2 = s2 * block_sum(sub == 0 ? dz * (z - b2) : 0.f, L.red);
+    } else {
+      // q = [h>0] w2^ -> dhs ; g = W1^^T q ; cg = c g
+      for (int n = sub; n < H; n += 16) L.dhs[r * H + n] = L.hs[r * H + n] > 0.f ? (W2[n] / s2) : 0.f;
+      __syncthreads();
+      const float c = valid ? 2.f * d.grad_penalty * L.wt[2][r] / fB : 0.f;
+      for (int k = sub; k < D; k += 16) {
+        float s = 0.f;
+        for (int n = 0; n < H; ++n) s += L.dhs[r * H + n] * W1[(size_t)n * D + k];
+        L.cg[r * D + k] = c * (s / s1);
+      }
+      __syncthreads();
+      for (int n = sub; n < H; n += 16) {
+        float s = 0.f;
+        for (int k = 0; k < D; ++k) s += W1[(size_t)n * D + k] * L.cg[r * D + k];
+        const float tp = s / s1;
+        L.ts[r * H + n] = L.hs[r * H + n] > 0.f ? tp : 0.f;
+        S_ip += L.dhs[r * H + n] * tp;
+      }
+      const float Ssum = block_sum(S_ip, L.red);
+      ip1 = s1 * Ssum; ip2 = s2 * Ssum;
+    }
+    __syncthreads();
+    // ---- accumulate this pass into the slab (each element owned by one thread)
+    const float* left = L.dhs;                         // [16][H]: dh (BCE) or q (GP)
+    const float* right = pass < 2 ? X : L.cg;          // [16][D]: x (BCE) or c*g (GP)
+    const float k1 = d.spectral_norm ? ip1 / (s1 * s1) : 0.f, k2 = d.spectral_norm ? ip2 / (s2 * s2) : 0.f;
+    for (int e = tid; e < H * D; e += blockDim.x) {
+      const int n = e / D, k = e - n * D;
+      float gh = 0.f;
+#pragma unroll 4
+      for (int rr = 0; rr < IL_TILE_R; ++rr) gh += left[rr * H + n] * right[rr * D + k];
+      const float gv = gh / s1 - k1 * L.u1[n] * L.v1[k];
+      slab[lay.oW1 + e] = pass == 0 ? gv : slab[lay.oW1 + e] + gv;
+    }
+    for (int n = tid; n < H; n += blockDim.x) {
+      float g2 = 0.f, gb = 0.f;
+      for (int rr = 0; rr < IL_TILE_R; ++rr) {
+        if (pass < 2) { g2 += L.dzs[rr] * fmaxf(L.hs[rr * H + n], 0.f); gb += L.dhs[rr * H + n]; }
+        else g2 += L.ts[rr * H + n];
+      }
+      const float gv = g2 / s2 - k2 * L.u2[0] * L.v2[n];
+      slab[lay.oW2 + n] = pass == 0 ? gv : slab[lay.oW2 + n] + gv;
+      if (pass < 2) slab[lay.ob1 + n] = pass == 0 ? gb : slab[lay.ob1 + n] + gb;
+    }
+    if (tid == 0 && pass < 2) {
+      float gb2 = 0.f;
+      for (int rr = 0; rr < IL_TILE_R; ++rr) gb2 += L.dzs[rr];
+      slab[lay.ob2] = pass == 0 ? gb2 : slab[lay.ob2] + gb2;
+    }
+    __syncthreads();
+  }
+  if (tile == 0 && d.spectral_norm) {  // final u, v of this update (identical in every workgroup)
+    float* o = d.workspace + wsl.sn_new;
+    for (int i = tid; i < H; i += blockDim.x) { o[i] = L.u1[i]; o[H + D + 1 + i] = L.v2[i]; }
+    for (int i = tid; i < D; i += blockDim.x) o[H + i] = L.v1[i];
+    if (tid == 0) o[H + D] = L.u2[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply) {
+  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch;
+  const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
+  const DiscWs wsl = disc_ws(D, H, B);
+  const int nt = (B + IL_TILE_R - 1) / IL_TILE_R;
+  const adam_consts ac = make_adam_consts(d.opt.lr, d.opt.beta1, d.opt.beta2, d.opt.eps, d.opt.weight_decay, d.opt.step[0]);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < lay.P; e += (int64_t)gridDim.x * blockDim.x) {
+    float g = 0.f;
+    for (int t = 0; t < nt; ++t) g += d.workspace[wsl.slabs + (size_t)t * lay.P + e];
+    d.grad[e] = g;
+    if (apply) {
+      float pp = d.params[e], mm = d.opt.m[e], vv = d.opt.v[e];
+      adam_update(pp, g, mm, vv, ac);
+      d.params[e] = pp; d.opt.m[e] = mm; d.opt.v[e] = vv;
+    }
+  }
+  if (blockIdx.x == 0 && d.spectral_norm) {
+    const float* o = d.workspace + wsl.sn_new;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) { d.u1[i] = o[i]; d.v2[i] = o[H + D + 1 + i]; }
+    for (int i = threadIdx.x; i < D; i += blockDim.x) d.v1[i] = o[H + i];
+    if (threadIdx.x == 0) d.u2[0] = o[H + D];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, float* __restrict__ out_r, float* __restrict__ out_logit) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden;
+  const int row0 = blockIdx.x * IL_TILE_R, tid = threadIdx.x, nrows = min(IL_TILE_R, b.n - row0);
+  const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
+  const float* W1 = d.params + lay.oW1; const float* b1 = d.params + lay.ob1; const float* W2 = d.params + lay.oW2; const float b2 = d.params[lay.ob2];
+  DiscLds L = carve(smem, D, H);
+  for (int i = tid; i < IL_TILE_R * D; i += blockDim.x) {
+    const int r = i / D, k = i - r * D;
+    L.X[0][i] = r < nrows ? (k < S ? b.states[(size_t)(row0 + r) * b.ld_states + k] : b.actions[(size_t)(row0 + r) * b.ld_actions + k - S]) : 0.f;
+  }
+  float s1 = 1.f, s2 = 1.f;
+  if (d.spectral_norm) {
+    for (int i = tid; i < H; i += blockDim.x) { L.u1[i] = d.u1[i]; L.v2[i] = d.v2[i]; }
+    for (int i = tid; i < D; i += blockDim.x) L.v1[i] = d.v1[i];
+    if (tid == 0) L.u2[0] = d.u2[0];
+    __syncthreads();
+    sn_iterate(W1, W2, D, H, L.u1, L.v1, L.u2, L.v2, false, s1, s2, L.red);
+  }
+  __syncthreads();
+  const int r = tid >> 4, sub = tid & 15;
+  float zp = 0.f;
+  for (int n = sub; n < H; n += 16) {
+    float s = 0.f;
+    for (int k = 0; k < D; ++k) s += W1[(size_t)n * D + k] * L.X[0][r * D + k];
+    zp += (W2[n] / s2) * fmaxf(s / s1 + b1[n], 0.f);
+  }
+  zp = group16_sum(zp);
+  if (sub == 0 && r < nrows) {
+    const float z = zp + b2, Dp = sigmoid_f(z);
+    float h = d.reward_function == 1 ? -log1pf(-Dp + 1e-6f) : logf(Dp + 1e-6f) - log1pf(-Dp + 1e-6f);
+    if (d.reward_function == 2) h = expf(h) * -h;
+    out_r[row0 + r] = h;
+    if (out_logit) out_logit[row0 + r] = z;
+  }
+}
+
+static int check_disc(const il_disc* d) {
+  IL_CHECK_ARG(d && d->params && d->grad && d->workspace, "il_disc: null descriptor field");
+  const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
+  IL_CHECK_ARG(d->hidden >= 1 && d->hidden <= 512 && D >= 1 && D <= 512, "il_disc: dims out of range (D=%d, hidden=%d)", D, d->hidden);
+  IL_CHECK_ARG(disc_lds_floats(D, d->hidden) * sizeof(float) <= 64 * 1024, "il_disc: D=%d hidden=%d needs more than 64 KiB of LDS", D, d->hidden);
+  IL_CHECK_ARG(d->reward_function >= 0 && d->reward_function <= 2, "il_disc: reward_function must be 0 (AIRL), 1 (GAIL) or 2 (FAIRL)");
+  if (d->spectral_norm) IL_CHECK_ARG(d->u1 && d->v1 && d->u2 && d->v2, "il_disc: spectral-norm buffers missing");
+  if (d->workspace_floats < disc_ws(D, d->hidden, d->batch).total) return il_set_error(IL_ERR_WORKSPACE, "il_disc: workspace too small");
+  return IL_OK;
+}
+
+extern "C" int il_gail_disc_step(const il_disc* d, const il_batch* pol, const il_batch* exp, const float* eps_gp, uint32_t flags, il_stream_t stream_) {
+  if (int rc = check_disc(d)) return rc;
+  IL_CHECK_ARG(pol && exp && pol->n == d->batch && exp->n == d->batch, "il_gail_disc_step: policy/expert batches must both have %d rows", d->batch);
+  hipStream_t st = (hipStream_t)stream_;
+  const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
+  const int nt = ceil_div(d->batch, IL_TILE_R);
+  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<nt, 256, disc_lds_floats(D, d->hidden) * sizeof(float), st>>>(*d, *pol, *exp, eps_gp); }
+  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<1, 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1); }
+  IL_CHECK_LAUNCH("il_gail_disc_step");
+  return IL_OK;
+}
+
+__global__ __launch_bounds__(256) void k_disc_adam(il_disc d, int64_t P) {
+  const adam_consts ac = make_adam_consts(d.opt.lr, d.opt.beta1, d.opt.beta2, d.opt.eps, d.opt.weight_decay, d.opt.step[0]);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < P; e += (int64_t)gridDim.x * blockDim.x) {
+    float pp = d.params[e], mm = d.opt.m[e], vv = d.opt.v[e];
+    adam_update(pp, d.grad[e], mm, vv, ac);
+    d.params[e] = pp; d.opt.m[e] = mm; d.opt.v[e] = vv;
+  }
+}
+extern "C" int il_gail_apply_grads(const il_disc* d, il_stream_t stream_) {
+  if (int rc = check_disc(d)) return rc;
+  const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
+  const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
+  { IL_TRACE("k_disc_adam", (hipStream_t)stream_); k_disc_adam<<<(int)((P + 255) / 256), 256, 0, (hipStream_t)stream_>>>(*d, P); }
+  IL_CHECK_LAUNCH("il_gail_apply_grads");
+  return IL_OK;
+}
+
+extern "C" int il_gail_reward(const il_disc* d, const il_batch* b, float* out_rewards, float* out_logits, il_stream_t stream_) {
+  if (int rc = check_disc(d)) return rc;
+  IL_CHECK_ARG(b && out_rewards && b->n > 0, "il_gail_reward: bad arguments");
+  const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
+  { IL_TRACE("k_gail_reward", (hipStream_t)stream_); k_gail_reward<<<ceil_div(b->n, IL_TILE_R), 256, disc_lds_floats(D, d->hidden) * sizeof(float), (hipStream_t)stream_>>>(*d, *b, out_rewards, out_logits); }
+  IL_CHECK_LAUNCH("il_gail_reward");
+  return IL_OK;
+}

@@ -1,0 +1,165 @@
+// GMMIL pairwise-RBF reward (reference models.py:25-44, 183-201) for gfx950.
+//
+// reward_i = sum_gamma w~_i sum_j exp(-gamma d(x_i, e_j)) w~e_j  -  w~_i sum_j exp(-gamma d(x_i, x_j)) w~_j,
+// d(x, y) = (1/D) sum_k (x_k - y_k)^2 evaluated in the DIRECT difference form (the ||x||^2+||y||^2-2xy GEMM form loses
+// ~3 digits to cancellation, and the reward is itself a difference of near-equal sums), so this is an fp32-VALU-bound
+// kernel (3 flop per pair-feature), not an MFMA one. The reference materialises [B,B,D] temporaries (0.5 GB at
+// B=1024, D=120); here nothing larger than a 64x64 tile of pair distances ever exists, and it lives in registers:
+//   k_gmmil_pack   feature-major copies XT[D][B1], ET[D][B2] (so LDS tiles load coalesced and read conflict-free) and
+//                  the normalised weights;
+//   k_gmmil_tile   grid (i-tile, j-tile, matrix): 64x64 pairs per workgroup, 4x4 per thread, features streamed through
+//                  LDS in chunks of 32, two ds_read_b128 per 16 pair updates; epilogue exp + weighted row sums;
+//   k_gmmil_final  deterministic sum of the per-j-tile partials.
+#include "il_common.hpp"
+
+#define GT 64   // tile edge (pairs)
+#define GKC 32  // feature chunk
+
+struct GmmilWs { int64_t xt, et, wn, wen, part, total; int b1p, b2p, njt; };
+__host__ __device__ inline GmmilWs gmmil_ws(int n1, int n2, int D) {
+  GmmilWs w; w.b1p = (n1 + GT - 1) / GT * GT; w.b2p = (n2 + GT - 1) / GT * GT;
+  const int nj1 = w.b2p / GT, nj2 = w.b1p / GT; w.njt = nj1 > nj2 ? nj1 : nj2;
+  int64_t o = 0;
+  w.xt = o; o += (int64_t)D * w.b1p; w.et = o; o += (int64_t)D * w.b2p; w.wn = o; o += w.b1p; w.wen = o; o += w.b2p;
+  w.part = o; o += (int64_t)2 * w.njt * w.b1p; w.total = o;
+  return w;
+}
+extern "C" int64_t il_gmmil_workspace_floats(int32_t n1, int32_t n2, int32_t D) { return gmmil_ws(n1, n2, D).total; }
+
+__device__ __forceinline__ float cat_at(const il_batch& b, int S, int r, int k) {
+  return k < S ? b.states[(size_t)r * b.ld_states + k] : b.actions[(size_t)r * b.ld_actions + (k - S)];
+}
+
+// grid.x = tiles of 64 rows over both sets (policy tiles first, then expert tiles)
+__global__ __launch_bounds__(256) void k_gmmil_pack(il_batch pol, il_batch exp, int S, int D, float* __restrict__ ws_) {
+  __shared__ float tile[GT][GKC + 1];
+  __shared__ float red[32];
+  const GmmilWs w = gmmil_ws(pol.n, exp.n, D);
+  const int nt1 = w.b1p / GT;
+  const bool is_exp = (int)blockIdx.x >= nt1;
+  const il_batch& b = is_exp ? exp : pol;
+  const int n = b.n, np = is_exp ? w.b2p : w.b1p, row0 = ((int)blockIdx.x - (is_exp ? nt1 : 0)) * GT;
+  float* T = ws_ + (is_exp ? w.et : w.xt);
+  for (int k0 = 0; k0 < D; k0 += GKC) {
+    for (int i = threadIdx.x; i < GT * GKC; i += blockDim.x) {
+      const int r = i / GKC, k = i - r * GKC;
+      tile[r][k] = (row0 + r < n && k0 + k < D) ? cat_at(b, S, row0 + r, k0 + k) : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < GT * GKC; i += blockDim.x) {
+      const int k = i / GT, r = i - k * GT;
+      if (k0 + k < D) T[(size_t)(k0 + k) * np + row0 + r] = tile[r][k];
+    }
+    __syncthreads();
+  }
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += b.weights[(size_t)i * b.ld_weights];
+  s = block_sum(s, red);
+  float* wn = ws_ + (is_exp ? w.wen : w.wn);
+  for (int r = threadIdx.x; r < GT; r += blockDim.x) wn[row0 + r] = (row0 + r < n) ? b.weights[(size_t)(row0 + r) * b.ld_weights] / s : 0.f;
+}
+
+// MODE 0: reward partials; MODE 1: write the distance matrix (out [n1][n2])
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gmmil_tile(int n1, int n2, int D, float g1, float g2, float* __restrict__ ws_, float* __restrict__ dist_out, int self_second) {
+  __shared__ __attribute__((aligned(16))) float Xs[GKC][GT];
+  __shared__ __attribute__((aligned(16))) float Ys[GKC][GT];
+  const GmmilWs w = gmmil_ws(n1, n2, D);
+  const int it = blockIdx.x, jt = blockIdx.y, mat = blockIdx.z;  // mat 0: policy vs expert, 1: policy vs policy
+  const bool vs_self = (mat == 1) || (MODE == 1 && self_second);
+  const int npy = vs_self ? w.b1p : w.b2p;
+  if (jt * GT >= npy) return;
+  const float* XT = ws_ + w.xt; const float* YT = ws_ + (vs_self ? w.xt : w.et);
+  const float* wy = ws_ + (vs_self ? w.wn : w.wen);
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+  for (int k0 = 0; k0 < D; k0 += GKC) {
+    for (int i = threadIdx.x; i < GKC * GT; i += blockDim.x) {
+      const int k = i / GT, c = i - k * GT;
+      const bool ok = k0 + k < D;
+      Xs[k][c] = ok ? XT[(size_t)(k0 + k) * w.b1p + it * GT + c] : 0.f;
+      Ys[k][c] = ok ? YT[(size_t)(k0 + k) * npy + jt * GT + c] : 0.f;
+    }
+    __syncthreads();
+    const int kc = min(GKC, D - k0);
+    for (int k = 0; k < kc; ++k) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(&Xs[k][ti * 4]);
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(&Ys[k][tj * 4]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { const float df = xv[a] - yv[b]; acc[a][b] = fmaf(df, df, acc[a][b]); }
+    }
+    __syncthreads();
+  }
+  const float fD = (float)D;
+  if (MODE == 1) {
+    const int n2e = vs_self ? n1 : n2;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = it * GT + ti * 4 + a, j = jt * GT + tj * 4 + b;
+        if (i < n1 && j < n2e) dist_out[(size_t)i * n2e + j] = acc[a][b] / fD;
+      }
+    return;
+  }
+  const f32x4 wv = *reinterpret_cast<const f32x4*>(wy + jt * GT + tj * 4);
+  float* part = ws_ + w.part + ((size_t)mat * w.njt + jt) * w.b1p + it * GT;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float s = 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { const float dd = acc[a][b] / fD; s += wv[b] * (expf(-g1 * dd) + expf(-g2 * dd)); }
+    s = group16_sum(s);
+    if (tj == 0) part[ti * 4 + a] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gmmil_final(int n1, int n2, int D, const float* __restrict__ ws_, float* __restrict__ out_r, float* __restrict__ out_sim,
+                                                     float* __restrict__ out_self) {
+  const GmmilWs w = gmmil_ws(n1, n2, D);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n1) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int jt = 0; jt < w.b2p / GT; ++jt) s0 += ws_[w.part + (size_t)jt * w.b1p + i];
+  for (int jt = 0; jt < w.b1p / GT; ++jt) s1 += ws_[w.part + ((size_t)w.njt + jt) * w.b1p + i];
+  const float wi = ws_[w.wn + i];
+  const float sim = wi * s0, self = wi * s1;
+  out_r[i] = sim - self;
+  if (out_sim) out_sim[i] = sim;
+  if (out_self) out_self[i] = self;
+}
+
+extern "C" int il_gmmil_reward(const il_batch* pol, const il_batch* exp, int32_t S, int32_t A, int32_t state_only, float g1, float g2, float* out_rewards,
+                               float* out_sim, float* out_self, float* workspace, int64_t workspace_floats, il_stream_t stream_) {
+  IL_CHECK_ARG(pol && exp && out_rewards && workspace && pol->n > 0 && exp->n > 0, "il_gmmil_reward: bad arguments");
+  const int D = S + (state_only ? 0 : A);
+  const GmmilWs w = gmmil_ws(pol->n, exp->n, D);
+  if (workspace_floats < w.total) return il_set_error(IL_ERR_WORKSPACE, "il_gmmil_reward: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)w.total);
+  hipStream_t st = (hipStream_t)stream_;
+  { IL_TRACE("k_gmmil_pack", st); k_gmmil_pack<<<w.b1p / GT + w.b2p / GT, 256, 0, st>>>(*pol, *exp, S, D, workspace); }
+  { IL_TRACE("k_gmmil_tile", st); k_gmmil_tile<0><<<dim3(w.b1p / GT, w.njt, 2), 256, 0, st>>>(pol->n, exp->n, D, g1, g2, workspace, nullptr, 0); }
+  { IL_TRACE("k_gmmil_final", st); k_gmmil_final<<<ceil_div(pol->n, 256), 256, 0, st>>>(pol->n, exp->n, D, workspace, out_rewards, out_sim, out_self); }
+  IL_CHECK_LAUNCH("il_gmmil_reward");
+  return IL_OK;
+}
+
+// distance matrix between a and b ([na][nb]); needs a workspace of il_gmmil_workspace_floats(na, nb, D) floats appended after `out`?
+// No: to keep the ABI allocation-free the caller passes the same kind of workspace as for il_gmmil_reward.
+extern "C" int il_gmmil_sqdist(const il_batch* a, const il_batch* b, int32_t S, int32_t A, int32_t state_only, float* out, float* workspace,
+                                  int64_t workspace_floats, il_stream_t stream_) {
+  IL_CHECK_ARG(a && b && out && workspace && a->n > 0 && b->n > 0, "il_gmmil_sqdist: bad arguments");
+  const int D = S + (state_only ? 0 : A);
+  const GmmilWs w = gmmil_ws(a->n, b->n, D);
+  if (workspace_floats < w.total) return il_set_error(IL_ERR_WORKSPACE, "il_gmmil_sqdist: workspace too small");
+  hipStream_t st = (hipStream_t)stream_;
+  { IL_TRACE("k_gmmil_pack", st); k_gmmil_pack<<<w.b1p / GT + w.b2p / GT, 256, 0, st>>>(*a, *b, S, D, workspace); }
+  { IL_TRACE("k_gmmil_tile", st); k_gmmil_tile<1><<<dim3(w.b1p / GT, w.b2p / GT, 1), 256, 0, st>>>(a->n, b->n, D, 0.f, 0.f, workspace, out, 0); }
+  IL_CHECK_LAUNCH("il_gmmil_sqdist");
+  return IL_OK;
+}

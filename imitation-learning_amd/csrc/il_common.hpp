@@ -1,0 +1,129 @@
+// Shared device helpers for libil_hip.so (gfx950 only: wave = 64, MFMA f32 16x16x4, LDS 160 KiB/CU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/il_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define IL_WAVE 64
+#define IL_TILE_R 16  // batch rows per workgroup tile (= MFMA M)
+
+int il_set_error(int code, const char* fmt, ...);
+#define IL_CHECK_ARG(cond, ...)                         \
+  do {                                                  \
+    if (!(cond)) return il_set_error(IL_ERR_ARG, __VA_ARGS__); \
+  } while (0)
+#define IL_CHECK_LAUNCH(name)                                                                  \
+  do {                                                                                         \
+    hipError_t e__ = hipGetLastError();                                                        \
+    if (e__ != hipSuccess) return il_set_error(IL_ERR_HIP, "%s: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// MFMA v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] * B[4x16], exact fp32 (bitwise an fmaf chain).
+//   lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
+//   lane l holds   D[row = 4*(l>>4) + reg][col = l&15], reg = 0..3.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over the 16 lanes that share (lane >> 4)
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum, result broadcast to every thread; `red` = LDS scratch of >= 32 floats. All threads must call.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG (Salmon et al. 2011) + Box-Muller; used only when the caller passes eps == NULL.
+// ---------------------------------------------------------------------------------------------
+struct philox_out { uint32_t v[4]; };
+__host__ __device__ inline philox_out philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  philox_out o; o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
+}
+__device__ __forceinline__ float u32_to_unit_open(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+// standard normal #idx of stream `stream_id` at update `ctr`
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint32_t ctr, uint32_t stream_id, uint32_t idx) {
+  const philox_out o = philox4x32_10(idx, ctr, stream_id, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float u1 = u32_to_unit_open(o.v[0]), u2 = u32_to_unit_open(o.v[1]);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t ctr, uint32_t stream_id, uint32_t idx) {
+  const philox_out o = philox4x32_10(idx, ctr, stream_id, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return (float)(o.v[0] >> 8) * (1.0f / 16777216.0f);  // [0,1) like torch.rand
+}
+enum { IL_STREAM_EPS_NEXT = 1, IL_STREAM_EPS_CUR = 2, IL_STREAM_GP = 3, IL_STREAM_ACT = 4 };
+
+// ---------------------------------------------------------------------------------------------
+// AdamW single-tensor step, op order of torch._single_tensor_adam (fp32 tensors, python-double scalars).
+// ---------------------------------------------------------------------------------------------
+struct adam_consts {
+  float decay;      // 1 - lr*wd (1 => no decay)
+  float one_m_b1;   // 1 - beta1
+  float beta2, one_m_b2;
+  float step_size;  // lr / (1 - beta1^t)
+  float bc2_sqrt;   // sqrt(1 - beta2^t)
+  float eps;
+  int has_decay;
+};
+__device__ __forceinline__ adam_consts make_adam_consts(float lr, float b1, float b2, float eps, float wd, int t) {
+  adam_consts c;
+  const double dlr = (double)lr, db1 = (double)b1, db2 = (double)b2;
+  c.has_decay = wd != 0.f;
+  c.decay = (float)(1.0 - dlr * (double)wd);
+  c.one_m_b1 = (float)(1.0 - db1);
+  c.beta2 = b2;
+  c.one_m_b2 = (float)(1.0 - db2);
+  c.step_size = (float)(dlr / (1.0 - pow(db1, (double)t)));
+  c.bc2_sqrt = (float)sqrt(1.0 - pow(db2, (double)t));
+  c.eps = eps;
+  return c;
+}
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, const adam_consts& c) {
+  if (c.has_decay) p = __fmul_rn(p, c.decay);
+  m = __fadd_rn(m, __fmul_rn(c.one_m_b1, __fsub_rn(g, m)));                       // lerp_
+  v = __fadd_rn(__fmul_rn(v, c.beta2), __fmul_rn(__fmul_rn(c.one_m_b2, g), g));   // mul_ + addcmul_ ((value*g)*g)
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), c.bc2_sqrt), c.eps);
+  p = __fsub_rn(p, __fmul_rn(c.step_size, __fdiv_rn(m, denom)));                  // addcdiv_
+}
+
+__device__ __forceinline__ float softplus_f(float z) { return z > 20.f ? z : log1pf(expf(z)); }
+__device__ __forceinline__ float sigmoid_f(float z) { return 1.f / (1.f + expf(-z)); }
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// Optional per-kernel timing with HIP events recorded on the launch stream (il_trace_enable / il_trace_report).
+// Disabled (one branch per launch) unless bench.py / a profiling run switches it on; never enable under graph capture.
+// ---------------------------------------------------------------------------------------------
+struct il_trace_scope {
+  hipStream_t st; int slot;
+  il_trace_scope(const char* name, hipStream_t s);
+  ~il_trace_scope();
+};
+#define IL_TRACE(name, st) il_trace_scope il_trace_scope__(name, (hipStream_t)(st))

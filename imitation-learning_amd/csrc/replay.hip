@@ -1,0 +1,196 @@
+// Replay ring kernels (reference memory.py:12-68) + bit-exact MT19937 index draws (host and device).
+//
+// HBM layout: [capacity][row] fp32, row = roundup4(2S + A + 5) floats so every row is a whole number of 16-B lanes:
+//   states @0 | actions @S | next_states @S+A | rewards @2S+A | terminals | timeouts | weights | step | pad
+// A gather moves row-granular 16-B lanes: consecutive lanes of a wave read consecutive 16-B pieces of ONE ring row
+// (188-192 B contiguous per row at HalfCheetah dims), the only coalescing a random-row gather admits.
+#include "il_common.hpp"
+
+extern "C" int32_t il_ring_row_floats(int32_t S, int32_t A) { return (2 * S + A + 5 + 3) & ~3; }
+
+__global__ __launch_bounds__(256) void k_gather(const float* __restrict__ ring, int64_t capacity, int row4, const int32_t* __restrict__ idx, int n, float* __restrict__ out) {
+  const f32x4* src = reinterpret_cast<const f32x4*>(ring);
+  f32x4* dst = reinterpret_cast<f32x4*>(out);
+  const int64_t total = (int64_t)n * row4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / row4), c = (int)(i - (int64_t)r * row4);
+    int64_t s = idx[r];
+    s = s < 0 ? 0 : (s >= capacity ? capacity - 1 : s);  // never fault on a bad index; the host layer validates ranges
+    dst[i] = src[s * row4 + c];
+  }
+}
+
+extern "C" int il_replay_gather(const float* ring, int64_t capacity, int32_t row_floats, const int32_t* idx, int32_t n, float* out_rows, il_stream_t stream) {
+  IL_CHECK_ARG(ring && idx && out_rows && n > 0 && capacity > 0, "il_replay_gather: bad arguments");
+  IL_CHECK_ARG(row_floats % 4 == 0, "il_replay_gather: row_floats=%d must be a multiple of 4 (use il_ring_row_floats)", row_floats);
+  const int row4 = row_floats / 4;
+  const int64_t total = (int64_t)n * row4;
+  const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  { IL_TRACE("k_gather", (hipStream_t)stream); k_gather<<<blocks, 256, 0, (hipStream_t)stream>>>(ring, capacity, row4, idx, n, out_rows); }
+  IL_CHECK_LAUNCH("il_replay_gather");
+  return IL_OK;
+}
+
+__global__ __launch_bounds__(256) void k_write_rows(float* __restrict__ ring, int64_t capacity, int row, int64_t cursor, const float* __restrict__ src, int n_rows) {
+  const int64_t total = (int64_t)n_rows * row;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / row), c = (int)(i - (int64_t)r * row);
+    ring[((cursor + r) % capacity) * row + c] = src[i];
+  }
+}
+
+extern "C" int il_replay_write_rows(float* ring, int64_t capacity, int32_t row_floats, int64_t cursor, const float* rows_src, int32_t n_rows, il_stream_t stream) {
+  IL_CHECK_ARG(ring && rows_src && n_rows > 0 && capacity > 0 && cursor >= 0 && cursor < capacity, "il_replay_write_rows: bad arguments");
+  const int64_t total = (int64_t)n_rows * row_floats;
+  const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  { IL_TRACE("k_write_rows", (hipStream_t)stream); k_write_rows<<<blocks, 256, 0, (hipStream_t)stream>>>(ring, capacity, row_floats, cursor, rows_src, n_rows); }
+  IL_CHECK_LAUNCH("il_replay_write_rows");
+  return IL_OK;
+}
+
+__global__ void k_wrap_absorbing(float* __restrict__ ring, int row, int S, int A, int64_t last, int64_t cursor) {
+  float* lr = ring + last * row; float* nr = ring + cursor * row;
+  const int o_next = S + A, o_rew = 2 * S + A;
+  for (int c = threadIdx.x; c < row; c += blockDim.x) {
+    // new row: absorbing state -> absorbing state, zero action, reward 0, terminal 0, timeout 0, weight 1, step copied (memory.py:68)
+    float v = 0.f;
+    if (c < S) v = (c == S - 1) ? 1.f : 0.f;
+    else if (c >= o_next && c < o_next + S) v = (c == o_next + S - 1) ? 1.f : 0.f;
+    else if (c == o_rew + 3) v = 1.f;
+    else if (c == o_rew + 4) v = lr[o_rew + 4];
+    nr[c] = v;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < S; c += blockDim.x) lr[o_next + c] = (c == S - 1) ? 1.f : 0.f;  // memory.py:67
+  if (threadIdx.x == 0) lr[o_rew + 1] = 0.f;
+}
+
+extern "C" int il_replay_wrap_absorbing(float* ring, int64_t capacity, int32_t S, int32_t A, int64_t last, int64_t cursor, il_stream_t stream) {
+  IL_CHECK_ARG(ring && last >= 0 && last < capacity && cursor >= 0 && cursor < capacity && last != cursor, "il_replay_wrap_absorbing: bad arguments");
+  { IL_TRACE("k_wrap_absorbing", (hipStream_t)stream); k_wrap_absorbing<<<1, 64, 0, (hipStream_t)stream>>>(ring, il_ring_row_floats(S, A), S, A, last, cursor); }
+  IL_CHECK_LAUNCH("il_replay_wrap_absorbing");
+  return IL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MT19937 (Matsumoto & Nishimura) + numpy legacy masked-rejection randint, as consumed by memory.py:51-56.
+// state[0..623] = mt words, state[624] = position.
+// ---------------------------------------------------------------------------------------------
+#define MT_N 624
+#define MT_M 397
+__host__ __device__ static inline uint32_t mt_temper(uint32_t y) {
+  y ^= y >> 11; y ^= (y << 7) & 0x9D2C5680u; y ^= (y << 15) & 0xEFC60000u; y ^= y >> 18;
+  return y;
+}
+__host__ __device__ static inline uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t y = (a & 0x80000000u) | (b & 0x7FFFFFFFu);
+  return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+}
+static void mt_twist_host(uint32_t* mt) {
+  for (int k = 0; k < MT_N; ++k) mt[k] = mt_mix(mt[k], mt[(k + 1) % MT_N], mt[(k + MT_M) % MT_N]);
+}
+extern "C" int il_mt19937_seed(uint32_t* s, uint32_t seed) {
+  IL_CHECK_ARG(s, "il_mt19937_seed: null state");
+  s[0] = seed;
+  for (uint32_t i = 1; i < MT_N; ++i) s[i] = 1812433253u * (s[i - 1] ^ (s[i - 1] >> 30)) + i;
+  s[MT_N] = MT_N;
+  return IL_OK;
+}
+static inline uint32_t mt_next_host(uint32_t* s) {
+  if (s[MT_N] >= MT_N) { mt_twist_host(s); s[MT_N] = 0; }
+  return mt_temper(s[s[MT_N]++]);
+}
+static inline uint32_t mask_for(uint32_t rng) {
+  uint32_t m = rng; m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8; m |= m >> 16;
+  return m;
+}
+extern "C" int il_mt19937_sample_indices(uint32_t* s, int32_t n, int64_t size, int64_t idx, int32_t full, int32_t* out) {
+  IL_CHECK_ARG(s && out && n >= 0 && size > 0, "il_mt19937_sample_indices: bad arguments");
+  const int64_t high = full ? size : idx - 1;  // np.random.randint(0, high)
+  IL_CHECK_ARG(high >= 1 && high <= 0x7FFFFFFFll, "il_mt19937_sample_indices: empty or oversized range (high=%lld)", (long long)high);
+  const int64_t excl = ((idx - 1) % size + size) % size;
+  IL_CHECK_ARG(!(high == 1 && excl == 0), "il_mt19937_sample_indices: the only candidate slot is the excluded one");
+  const uint32_t rng = (uint32_t)(high - 1), mask = mask_for(rng);
+  for (int32_t i = 0; i < n; ++i) {
+    uint32_t v;
+    do {
+      if (rng == 0) v = 0;
+      else do { v = mt_next_host(s) & mask; } while (v > rng);
+    } while ((int64_t)v == excl);
+    out[i] = (int32_t)v;
+  }
+  return IL_OK;
+}
+
+// Device version: one workgroup. The draw is a stream compaction of the tempered MT output (every candidate consumes
+// exactly one 32-bit word; rejected ones are skipped), so 256 candidates are tested in parallel and compacted in order.
+__global__ __launch_bounds__(256) void k_mt_sample(uint32_t* __restrict__ state, const int64_t* __restrict__ ring_state, int n, int32_t* __restrict__ out) {
+  __shared__ uint32_t mt[MT_N];
+  __shared__ int wave_cnt[4];
+  __shared__ int s_pos, s_count;
+  const int tid = threadIdx.x;
+  const int64_t idx = ring_state[0], full = ring_state[1], size = ring_state[2];
+  const int64_t high = full ? size : idx - 1;
+  const int64_t excl = ((idx - 1) % size + size) % size;
+  const uint32_t rng = high > 0 ? (uint32_t)(high - 1) : 0u;
+  uint32_t mask = rng; mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  for (int i = tid; i < MT_N; i += 256) mt[i] = state[i];
+  if (tid == 0) { s_pos = (int)state[MT_N]; s_count = 0; }
+  __syncthreads();
+  if (rng == 0) {  // degenerate range: numpy returns 0 without consuming the stream
+    for (int i = tid; i < n; i += 256) out[i] = 0;
+    return;
+  }
+  for (int guard = 0; guard < 100000; ++guard) {
+    int pos = s_pos, count = s_count;
+    if (count >= n) break;
+    if (pos >= MT_N) {  // twist: four dependency-free phases
+      uint32_t nv[3]; int q = 0;
+      for (int k = tid; k < 227; k += 256) nv[q++] = mt_mix(mt[k], mt[k + 1], mt[k + MT_M]);
+      __syncthreads(); q = 0;
+      for (int k = tid; k < 227; k += 256) mt[k] = nv[q++];
+      __syncthreads(); q = 0;
+      for (int k = 227 + tid; k < 454; k += 256) nv[q++] = mt_mix(mt[k], mt[k + 1], mt[k - 227]);
+      __syncthreads(); q = 0;
+      for (int k = 227 + tid; k < 454; k += 256) mt[k] = nv[q++];
+      __syncthreads(); q = 0;
+      for (int k = 454 + tid; k < 623; k += 256) nv[q++] = mt_mix(mt[k], mt[k + 1], mt[k - 227]);
+      __syncthreads(); q = 0;
+      for (int k = 454 + tid; k < 623; k += 256) mt[k] = nv[q++];
+      __syncthreads();
+      if (tid == 0) { mt[623] = mt_mix(mt[623], mt[0], mt[396]); s_pos = 0; }
+      __syncthreads();
+      pos = 0;
+    }
+    const int avail = MT_N - pos, take = avail < 256 ? avail : 256;
+    bool ok = false; uint32_t v = 0;
+    if (tid < take) { v = mt_temper(mt[pos + tid]) & mask; ok = (v <= rng) && ((int64_t)v != excl); }
+    const unsigned long long bal = __ballot(ok);
+    const int lane = tid & 63, w = tid >> 6;
+    if (lane == 0) wave_cnt[w] = __popcll(bal);
+    __syncthreads();
+    int before = __popcll(bal & ((1ull << lane) - 1ull));
+    for (int i = 0; i < w; ++i) before += wave_cnt[i];
+    const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    const int need = n - count;
+    // candidates are consumed up to and including the one that completes the batch
+    if (ok && before < need) out[count + before] = (int32_t)v;
+    __shared__ int s_last;
+    if (tot >= need) { if (ok && before == need - 1) s_last = tid; }
+    __syncthreads();
+    if (tid == 0) {
+      if (tot >= need) { s_pos = pos + s_last + 1; s_count = n; }
+      else { s_pos = pos + take; s_count = count + tot; }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < MT_N; i += 256) state[i] = mt[i];
+  if (tid == 0) state[MT_N] = (uint32_t)s_pos;
+}
+
+extern "C" int il_mt19937_sample_indices_device(uint32_t* state_dev, const int64_t* ring_state_dev, int32_t n, int32_t* out_dev, il_stream_t stream) {
+  IL_CHECK_ARG(state_dev && ring_state_dev && out_dev && n > 0, "il_mt19937_sample_indices_device: bad arguments");
+  { IL_TRACE("k_mt_sample", (hipStream_t)stream); k_mt_sample<<<1, 256, 0, (hipStream_t)stream>>>(state_dev, ring_state_dev, n, out_dev); }
+  IL_CHECK_LAUNCH("il_mt19937_sample_indices_device");
+  return IL_OK;
+}

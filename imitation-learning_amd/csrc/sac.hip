@@ -1,0 +1,858 @@
+// SAC update kernels (reference training.py:14-54) for gfx950.
+//
+// One update = 7 dependent launches, cut only where the algorithm has a global dependency:
+//   k_actor_fwd      tiles of 16 rows: actor(s') -> a', logp' (no grad) and actor(s) -> a~, logp (activations kept)
+//   k_critic_fwd     (tile, net) : critic_1/2(s,a) with saved activations, target_1/2(s', a')
+//   k_critic_bwd     (tile, net) : y, dQ, back-propagation to the layer-1 pre-activations
+//   k_dw_adam        output-stationary dW = dZ^T.X over the whole batch on MFMA + fused AdamW (critic)
+//   k_policy_critic  (tile, net) : updated critic on (s, a~), dQ/da~
+//   k_actor_bwd      tiles      : min-Q selection, tanh-Gaussian backward, back-propagation through the actor
+//   k_dw_adam        actor dW + AdamW, Adam(log_alpha), polyak as tail blocks
+// Activations cross kernels through an L2-resident workspace (~3 MB at B=256, H=256); parameters, Adam moments and
+// the target network are each read and written exactly once per update (the algorithmic 24 B/param + 8 B/param).
+#include "il_common.hpp"
+#include "mlp_tile.hpp"
+
+#define LOG_SQRT_2PI 0.91893853320467274178f
+#define LOG_2 0.69314718055994530942f
+
+struct SacWs {  // float offsets into il_sac.workspace
+  int64_t a_h1, a_h2, a_xpre, a_eps, a_lsraw, a_anew, a_logp, n_a2, n_logp2;
+  int64_t c_x0, c_h1, c_h2, c_q, t_q, c_dz3, c_dz2, c_dz1, q_min;
+  int64_t p_q, p_g, a_dz3, a_dz2, a_dz1, alpha_part, total;
+};
+__host__ __device__ inline SacWs sac_ws(int S, int A, int H, int B) {
+  SacWs w; int64_t o = 0;
+  auto take = [&](int64_t n) { int64_t r = o; o += (n + 3) & ~(int64_t)3; return r; };
+  const int64_t BH = (int64_t)B * H, BA = (int64_t)B * A;
+  w.a_h1 = take(BH); w.a_h2 = take(BH); w.a_xpre = take(BA); w.a_eps = take(BA); w.a_lsraw = take(BA); w.a_anew = take(BA); w.a_logp = take(B);
+  w.n_a2 = take(BA); w.n_logp2 = take(B);
+  w.c_x0 = take((int64_t)B * (S + A)); w.c_h1 = take(2 * BH); w.c_h2 = take(2 * BH); w.c_q = take(2 * B); w.t_q = take(2 * B);
+  w.c_dz3 = take(2 * B); w.c_dz2 = take(2 * BH); w.c_dz1 = take(2 * BH); w.q_min = take(B);
+  w.p_q = take(2 * B); w.p_g = take(2 * BA); w.a_dz3 = take((int64_t)B * 16); w.a_dz2 = take(BH); w.a_dz1 = take(BH); w.alpha_part = take(B / IL_TILE_R + 4);
+  w.total = o;
+  return w;
+}
+__host__ __device__ inline int64_t net_stride(int in, int H, int out) { return (mlp_numel(in, H, out) + 3) & ~(int64_t)3; }
+
+// LDS floats needed by the tile kernels
+static inline size_t tile_lds_bytes(int in_pad, int H) { return sizeof(float) * ((size_t)IL_TILE_R * (in_pad + 4) + 2 * (size_t)IL_TILE_R * (H + 4) + 4 * 256 + 256 + 64); }
+
+// ---------------------------------------------------------------------------------------------
+// tanh-Gaussian head for one (row, action component); op order follows torch.distributions (see oracle/nets.py)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void head_sample(float mean, float ls_raw, float eps, float& x, float& a, float& nlp, float& ladj) {
+  const float ls = fminf(fmaxf(ls_raw, -20.f), 2.f);
+  const float sd = expf(ls);
+  x = __fadd_rn(__fmul_rn(eps, sd), mean);
+  a = tanhf(x);
+  const float d = __fsub_rn(x, mean);
+  nlp = -(d * d) / (2.f * (sd * sd)) - logf(sd) - LOG_SQRT_2PI;
+  ladj = 2.f * (LOG_2 - x - softplus_f(-2.f * x));
+}
+
+// mode: 0 = next rows then current rows (grid 2*nt), 1 = next only, 2 = current only
+__global__ __launch_bounds__(256) void k_actor_fwd(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
+  const int nt = B / IL_TILE_R;
+  const bool is_cur = (mode == 2) || (mode == 0 && (int)blockIdx.x >= nt);
+  const int tile = (int)blockIdx.x % nt, row0 = tile * IL_TILE_R;
+  const int Sp = round_up16(S), ldx = Sp + 4, ldh = H + 4;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* part = H2s + IL_TILE_R * ldh; float* Os = part + 4 * 256;
+  float* red = Os + 256;
+  const SacWs ws = sac_ws(S, A, H, B);
+  float* W = d.workspace;
+  const MlpView net = mlp_view(d.actor, S, H, 2 * A);
+  const float* src = is_cur ? b.states : b.next_states;
+  const int ld = is_cur ? b.ld_states : b.ld_next_states;
+  load_rows_cat(Xs, ldx, Sp, src, ld, S, nullptr, 0, 0, row0, IL_TILE_R);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  tile_fwd(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4* acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = c0 + 16 * t + j; const float bb = net.b1[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float h = fmaxf(acc[t][r] + bb, 0.f);
+        H1s[(4 * g + r) * ldh + col] = h;
+        if (is_cur) W[ws.a_h1 + (size_t)(row0 + 4 * g + r) * H + col] = h;
+      }
+    }
+  });
+  __syncthreads();
+  tile_fwd(H1s, ldh, H, net.W2, H, H, H, [&](int c0, f32x4* acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = c0 + 16 * t + j; const float bb = net.b2[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float h = fmaxf(acc[t][r] + bb, 0.f);
+        H2s[(4 * g + r) * ldh + col] = h;
+        if (is_cur) W[ws.a_h2 + (size_t)(row0 + 4 * g + r) * H + col] = h;
+      }
+    }
+  });
+  __syncthreads();
+  tile_fwd_small(H2s, ldh, H, net.W3, H, 2 * A, net.b3, Os, part);
+  // head: one thread per (row, action component); per-row sums through LDS (sequential over A like torch's sum(-1))
+  float* nl = part; float* la = part + 256;
+  const int tid = threadIdx.x;
+  const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
+  if (tid < IL_TILE_R * A) {
+    const int r = tid / A, c = tid - r * A, row = row0 + r;
+    const float* ep = is_cur ? eps_cur : eps_next;
+    const float e = ep ? ep[(size_t)row * A + c] : philox_normal(d.noise_seed, ctr, is_cur ? IL_STREAM_EPS_CUR : IL_STREAM_EPS_NEXT, (uint32_t)(row * A + c));
+    const float mean = Os[r * 16 + c], lsr = Os[r * 16 + A + c];
+    float x, a, nlp, ladj;
+    head_sample(mean, lsr, e, x, a, nlp, ladj);
+    nl[r * 16 + c] = nlp; la[r * 16 + c] = ladj;
+    if (is_cur) {
+      W[ws.a_xpre + (size_t)row * A + c] = x; W[ws.a_eps + (size_t)row * A + c] = e; W[ws.a_lsraw + (size_t)row * A + c] = lsr;
+      W[ws.a_anew + (size_t)row * A + c] = a;
+    } else {
+      W[ws.n_a2 + (size_t)row * A + c] = (1.f - b.absorbing[(size_t)row * b.ld_absorbing]) * a;
+    }
+  }
+  __syncthreads();
+  if (tid < IL_TILE_R) {
+    float sn = 0.f, sl = 0.f;
+    for (int c = 0; c < A; ++c) { sn += nl[tid * 16 + c]; sl += la[tid * 16 + c]; }
+    const float logp = (0.f - sl) + sn;
+    W[(is_cur ? ws.a_logp : ws.n_logp2) + row0 + tid] = logp;
+  }
+  (void)red;
+}
+
+// ---------------------------------------------------------------------------------------------
+// critic forward. net 0,1: critic_k(s, a) keeping h1, h2, x0 ; net 2,3: target_k(s', a').   grid = nt * nnets
+// first_net: 0 => all four (critic step); used with nnets=4.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void critic_head(const float* H2s, int ldh, int H, const float* __restrict__ w3, float b3, float* out16) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int r = wave; r < IL_TILE_R; r += nw) {
+    float s = 0.f;
+    for (int n = lane; n < H; n += 64) s += H2s[r * ldh + n] * w3[n];
+    s = wave_sum(s);
+    if (lane == 0) out16[r] = s + b3;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_critic_fwd(il_sac d, il_batch b) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
+  const int nt = B / IL_TILE_R;
+  const int net = (int)blockIdx.x / nt, tile = (int)blockIdx.x % nt, row0 = tile * IL_TILE_R;
+  const bool is_target = net >= 2; const int k = net & 1;
+  const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* q16 = H2s + IL_TILE_R * ldh;
+  const SacWs ws = sac_ws(S, A, H, B);
+  float* W = d.workspace;
+  const int64_t ns = net_stride(IN, H, 1);
+  const MlpView p = mlp_view((is_target ? d.target : d.critic) + k * ns, IN, H, 1);
+  if (is_target) load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, W + ws.n_a2, A, A, row0, IL_TILE_R);
+  else load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R);
+  __syncthreads();
+  if (net == 0)
+    for (int i = threadIdx.x; i < IL_TILE_R * IN; i += blockDim.x) { const int r = i / IN, c = i - r * IN; W[ws.c_x0 + (size_t)(row0 + r) * IN + c] = Xs[r * ldx + c]; }
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  float* sh1 = W + ws.c_h1 + (size_t)k * B * H; float* sh2 = W + ws.c_h2 + (size_t)k * B * H;
+  tile_fwd(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4* acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = c0 + 16 * t + j; const float bb = p.b1[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float h = fmaxf(acc[t][r] + bb, 0.f);
+        H1s[(4 * g + r) * ldh + col] = h;
+        if (!is_target) sh1[(size_t)(row0 + 4 * g + r) * H + col] = h;
+      }
+    }
+  });
+  __syncthreads();
+  tile_fwd(H1s, ldh, H, p.W2, H, H, H, [&](int c0, f32x4* acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = c0 + 16 * t + j; const float bb = p.b2[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float h = fmaxf(acc[t][r] + bb, 0.f);
+        H2s[(4 * g + r) * ldh + col] = h;
+        if (!is_target) sh2[(size_t)(row0 + 4 * g + r) * H + col] = h;
+      }
+    }
+  });
+  __syncthreads();
+  critic_head(H2s, ldh, H, p.W3, p.b3[0], q16);
+  __syncthreads();
+  if (threadIdx.x < IL_TILE_R) W[(is_target ? ws.t_q : ws.c_q) + (size_t)k * B + row0 + threadIdx.x] = q16[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------
+// critic backward (training.py:24-30): y, dQ_k = w * 2 (Q_k - y) / B, dz2 = dQ w3 [h2>0], dz1 = (dz2 . W2) [h1>0].  grid = nt * 2
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_critic_bwd(il_sac d, il_batch b) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
+  const int nt = B / IL_TILE_R;
+  const int k = (int)blockIdx.x / nt, tile = (int)blockIdx.x % nt, row0 = tile * IL_TILE_R;
+  const int ldh = H + 4;
+  float* DZ2s = smem; float* dz3s = DZ2s + IL_TILE_R * ldh;
+  const SacWs ws = sac_ws(S, A, H, B);
+  float* W = d.workspace;
+  const MlpView p = mlp_view(d.critic + k * net_stride(IN, H, 1), IN, H, 1);
+  if (threadIdx.x < IL_TILE_R) {
+    const int row = row0 + threadIdx.x;
+    const float alpha = expf(d.log_alpha[0]);
+    const float m = 1.f - b.absorbing[(size_t)row * b.ld_absorbing];
+    const float tv = fminf(W[ws.t_q + row], W[ws.t_q + B + row]) - m * alpha * W[ws.n_logp2 + row];
+    const float y = b.rewards[(size_t)row * b.ld_rewards] + (1.f - b.terminals[(size_t)row * b.ld_terminals]) * d.discount * tv;
+    const float q = W[ws.c_q + (size_t)k * B + row];
+    const float dq = (b.weights[(size_t)row * b.ld_weights] * (2.f * (q - y))) / (float)B;
+    dz3s[threadIdx.x] = dq;
+    W[ws.c_dz3 + (size_t)k * B + row] = dq;
+    if (k == 0) W[ws.q_min + row] = fminf(q, W[ws.c_q + B + row]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) d.critic_opt.step[0] += 1;  // consumed by the following k_dw_adam / il_adam_step
+  __syncthreads();
+  const float* h2 = W + ws.c_h2 + (size_t)k * B * H; const float* h1 = W + ws.c_h1 + (size_t)k * B * H;
+  float* gdz2 = W + ws.c_dz2 + (size_t)k * B * H; float* gdz1 = W + ws.c_dz1 + (size_t)k * B * H;
+  for (int i = threadIdx.x; i < IL_TILE_R * H; i += blockDim.x) {
+    const int r = i / H, n = i - r * H;
+    const float v = (h2[(size_t)(row0 + r) * H + n] > 0.f) ? dz3s[r] * p.W3[n] : 0.f;
+    DZ2s[r * ldh + n] = v; gdz2[(size_t)(row0 + r) * H + n] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  tile_bwd_dx(DZ2s, ldh, H, H, p.W2, H, H, [&](int kb, f32x4* acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + 4 * j;
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(h1 + off);
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = hv[i] > 0.f ? acc[i][r] : 0.f;
+      *reinterpret_cast<f32x4*>(gdz1 + off) = o;
+    }
+  });
+}
+
+// ---------------------------------------------------------------------------------------------
+// updated critic on (s, a~) and dQ_k/da~ (training.py:37, backward of :38 through the critic).  grid = nt * 2
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_policy_critic(il_sac d, il_batch b) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
+  const int nt = B / IL_TILE_R;
+  const int k = (int)blockIdx.x / nt, tile = (int)blockIdx.x % nt, row0 = tile * IL_TILE_R;
+  const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* q16 = H2s + IL_TILE_R * ldh;
+  const SacWs ws = sac_ws(S, A, H, B);
+  float* W = d.workspace;
+  const MlpView p = mlp_view(d.critic + k * net_stride(IN, H, 1), IN, H, 1);
+  load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, IL_TILE_R);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  tile_fwd(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4* acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = c0 + 16 * t + j; const float bb = p.b1[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[t][r] + bb, 0.f);
+    }
+  });
+  __syncthreads();
+  tile_fwd(H1s, ldh, H, p.W2, H, H, H, [&](int c0, f32x4* acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = c0 + 16 * t + j; const float bb = p.b2[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = fmaxf(acc[t][r] + bb, 0.f);
+    }
+  });
+  __syncthreads();
+  critic_head(H2s, ldh, H, p.W3, p.b3[0], q16);
+  __syncthreads();
+  if (threadIdx.x < IL_TILE_R) W[ws.p_q + (size_t)k * B + row0 + threadIdx.x] = q16[threadIdx.x];
+  // dQ/dh2 with upstream 1 (scaling and min-selection happen in k_actor_bwd): dz2 = w3 [h2 > 0], in place
+  for (int i = threadIdx.x; i < IL_TILE_R * H; i += blockDim.x) {
+    const int r = i / H, n = i - r * H;
+    H2s[r * ldh + n] = H2s[r * ldh + n] > 0.f ? p.W3[n] : 0.f;
+  }
+  __syncthreads();
+  tile_bwd_dx(H2s, ldh, H, H, p.W2, H, H, [&](int kb, f32x4* acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float* h = H1s + (4 * g + r) * ldh + kb + 4 * j + i;
+        *h = *h > 0.f ? acc[i][r] : 0.f;  // dz1 in place (each element owned by exactly one lane)
+      }
+  });
+  __syncthreads();
+  // g[r][c] = sum_n dz1[r][n] W1[n][S + c] : 16 threads per row, each strides n
+  {
+    const int r = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    for (int c = 0; c < A; ++c) {
+      float s = 0.f;
+      for (int n = sub; n < H; n += 16) s += H1s[r * ldh + n] * p.W1[(size_t)n * IN + S + c];
+      s = group16_sum(s);
+      if (sub == 0) W[ws.p_g + ((size_t)k * B + row0 + r) * A + c] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// actor backward (training.py:38-46): L = mean(w m alpha logp - min Q).  grid = nt
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_actor_bwd(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
+  const int tile = (int)blockIdx.x, row0 = tile * IL_TILE_R;
+  const int ldh = H + 4, ldz = 20;
+  float* DZ2s = smem; float* DZ3s = DZ2s + IL_TILE_R * ldh; float* red = DZ3s + IL_TILE_R * ldz;
+  const SacWs ws = sac_ws(S, A, H, B);
+  float* W = d.workspace;
+  const MlpView net = mlp_view(d.actor, S, H, 2 * A);
+  const float alpha = expf(d.log_alpha[0]);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < IL_TILE_R * ldz; i += blockDim.x) DZ3s[i] = 0.f;
+  __syncthreads();
+  float apart = 0.f;
+  if (tid < IL_TILE_R * A) {
+    const int r = tid / A, c = tid - r * A, row = row0 + r;
+    const float q1 = W[ws.p_q + row], q2 = W[ws.p_q + B + row];
+    const float s1 = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f);
+    const float da = (-(s1) / (float)B) * W[ws.p_g + (size_t)row * A + c] + (-(1.f - s1) / (float)B) * W[ws.p_g + ((size_t)B + row) * A + c];
+    const float wgt = b.weights[(size_t)row * b.ld_weights], m = 1.f - b.absorbing[(size_t)row * b.ld_absorbing];
+    const float cc = (wgt * m * alpha) / (float)B;
+    const float x = W[ws.a_xpre + (size_t)row * A + c], an = W[ws.a_anew + (size_t)row * A + c], e = W[ws.a_eps + (size_t)row * A + c];
+    const float lsr = W[ws.a_lsraw + (size_t)row * A + c];
+    const float sd = expf(fminf(fmaxf(lsr, -20.f), 2.f));
+    const float dxp = cc * (2.f * tanhf(x)) + da * (1.f - an * an);
+    const float dsd = dxp * e - cc / sd;
+    const float dls = (lsr >= -20.f && lsr <= 2.f) ? dsd * sd : 0.f;
+    DZ3s[r * ldz + c] = dxp; DZ3s[r * ldz + A + c] = dls;
+  }
+  if (tid < IL_TILE_R) {
+    const int row = row0 + tid;
+    const float lp = W[ws.a_logp + row];
+    apart = b.weights[(size_t)row * b.ld_weights] * (1.f - b.absorbing[(size_t)row * b.ld_absorbing]) * (lp + d.entropy_target);
+    if (out_logp) out_logp[row] = lp;
+    if (out_q) out_q[row] = W[ws.q_min + row];
+  }
+  apart = block_sum(apart, red);  // contains barriers: DZ3s complete afterwards
+  if (tid == 0) {
+    W[ws.alpha_part + tile] = apart;
+    if (tile == 0) { d.actor_opt.step[0] += 1; d.alpha_opt.step[0] += 1; }
+  }
+  for (int i = tid; i < IL_TILE_R * 16; i += blockDim.x) W[ws.a_dz3 + (size_t)row0 * 16 + i] = DZ3s[(i >> 4) * ldz + (i & 15)];
+  const int lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const float* h2 = W + ws.a_h2; const float* h1 = W + ws.a_h1;
+  // dz2 = (dz3 . W3) [h2 > 0]
+  tile_bwd_dx(DZ3s, ldz, 16, 2 * A, net.W3, H, H, [&](int kb, f32x4* acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + 4 * j;
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(h2 + off);
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = hv[i] > 0.f ? acc[i][r] : 0.f;
+      *reinterpret_cast<f32x4*>(W + ws.a_dz2 + off) = o;
+      *reinterpret_cast<f32x4*>(DZ2s + (4 * g + r) * ldh + kb + 4 * j) = o;
+    }
+  });
+  __syncthreads();
+  tile_bwd_dx(DZ2s, ldh, H, H, net.W2, H, H, [&](int kb, f32x4* acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + 4 * j;
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(h1 + off);
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = hv[i] > 0.f ? acc[i][r] : 0.f;
+      *reinterpret_cast<f32x4*>(W + ws.a_dz1 + off) = o;
+    }
+  });
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_dw_adam: output-stationary weight gradients on MFMA with a fused AdamW epilogue.
+//   dW_l[n][k] = sum_r dZ_l[r][n] X_l[r][k]  (K = batch rows, 4 per MFMA step), db_l[n] = sum_r dZ_l[r][n]
+// One wave = one job: a 16(n) x 64(k) strip of some layer's weight, or 64 bias elements. Gradients never touch HBM
+// unless grads_only (data-parallel: they are all-reduced first).  Tail blocks: Adam(log_alpha) and polyak.
+// ---------------------------------------------------------------------------------------------
+struct DwArgs {
+  float* params; float* grads; il_adam opt; int grads_only;
+  int n_nets; int64_t net_stride;
+  int in_dim, hidden, out_dim, batch;
+  const float* x0; int ld_x0; int64_t x0_net_stride;
+  const float* h1; const float* h2; const float* dz1; const float* dz2; int64_t h_net_stride;
+  const float* dz3; int ld_dz3; int64_t dz3_net_stride;
+  int n_dw_blocks;
+  // tail
+  float* log_alpha; float* alpha_grad; il_adam alpha_opt; const float* alpha_part; int n_alpha_part;
+  float* target; const float* polyak_src; int64_t polyak_n; float tau; uint32_t* noise_counter;
+};
+
+__device__ __forceinline__ void dw_strip(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dz, int ldz, int Nvalid, const float* __restrict__ x,
+                                         int ldx, int Kvalid, int n0, int kb, int64_t poff) {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int B = a.batch;
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  const bool xvec = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const bool nvalid = (n0 + j) < Nvalid;
+  for (int r0 = 0; r0 < B; r0 += 16) {
+    float av[4]; f32x4 bv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int r = r0 + 4 * g + s;
+      av[s] = nvalid ? dz[(size_t)r * ldz + n0 + j] : 0.f;
+      bv[s] = load4_guard(x + (size_t)r * ldx, kb + 4 * j, Kvalid, xvec);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      acc[0] = mfma16(av[s], bv[s][0], acc[0]);
+      acc[1] = mfma16(av[s], bv[s][1], acc[1]);
+      acc[2] = mfma16(av[s], bv[s][2], acc[2]);
+      acc[3] = mfma16(av[s], bv[s][3], acc[3]);
+    }
+  }
+  const bool pvec = ((Kvalid & 3) == 0) && ((poff & 3) == 0) && (kb + 4 * j + 3 < Kvalid);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + 4 * g + r;
+    if (n >= Nvalid) continue;
+    const int64_t o = poff + (int64_t)n * Kvalid + kb + 4 * j;
+    if (pvec) {
+      f32x4 gr; gr[0] = acc[0][r]; gr[1] = acc[1][r]; gr[2] = acc[2][r]; gr[3] = acc[3][r];
+      if (a.grads_only) { *reinterpret_cast<f32x4*>(a.grads + o) = gr; continue; }
+      f32x4 p = *reinterpret_cast<f32x4*>(a.params + o), m = *reinterpret_cast<f32x4*>(a.opt.m + o), v = *reinterpret_cast<f32x4*>(a.opt.v + o);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { float pp = p[i], mm = m[i], vv = v[i]; adam_update(pp, gr[i], mm, vv, ac); p[i] = pp; m[i] = mm; v[i] = vv; }
+      *reinterpret_cast<f32x4*>(a.params + o) = p; *reinterpret_cast<f32x4*>(a.opt.m + o) = m; *reinterpret_cast<f32x4*>(a.opt.v + o) = v;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (kb + 4 * j + i >= Kvalid) continue;
+        const float gr = acc[i][r];
+        if (a.grads_only) { a.grads[o + i] = gr; continue; }
+        float pp = a.params[o + i], mm = a.opt.m[o + i], vv = a.opt.v[o + i];
+        adam_update(pp, gr, mm, vv, ac);
+        a.params[o + i] = pp; a.opt.m[o + i] = mm; a.opt.v[o + i] = vv;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void dw_bias(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dz, int ldz, int Nvalid, int n0, int64_t poff) {
+  const int lane = threadIdx.x & 63, n = n0 + lane;
+  if (n >= Nvalid) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int r = 0; r < a.batch; r += 4) {
+    s0 += dz[(size_t)(r + 0) * ldz + n]; s1 += dz[(size_t)(r + 1) * ldz + n]; s2 += dz[(size_t)(r + 2) * ldz + n]; s3 += dz[(size_t)(r + 3) * ldz + n];
+  }
+  const float gr = (s0 + s1) + (s2 + s3);
+  const int64_t o = poff + n;
+  if (a.grads_only) { a.grads[o] = gr; return; }
+  float pp = a.params[o], mm = a.opt.m[o], vv = a.opt.v[o];
+  adam_update(pp, gr, mm, vv, ac);
+  a.params[o] = pp; a.opt.m[o] = mm; a.opt.v[o] = vv;
+}
+
+__global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
+  const int wave_in_block = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= a.n_dw_blocks) {  // ---- tail blocks
+    const int tb = (int)blockIdx.x - a.n_dw_blocks;
+    if (a.log_alpha && tb == 0 && threadIdx.x == 0) {
+      float s = 0.f;
+      for (int i = 0; i < a.n_alpha_part; ++i) s += a.alpha_part[i];
+      const float alpha = expf(a.log_alpha[0]);
+      const float gr = -(alpha) * (s / (float)a.batch);
+      if (a.grads_only) a.alpha_grad[0] = gr;
+      else {
+        const adam_consts ac = make_adam_consts(a.alpha_opt.lr, a.alpha_opt.beta1, a.alpha_opt.beta2, a.alpha_opt.eps, 0.f, a.alpha_opt.step[0]);
+        float pp = a.log_alpha[0], mm = a.alpha_opt.m[0], vv = a.alpha_opt.v[0];
+        adam_update(pp, gr, mm, vv, ac);
+        a.log_alpha[0] = pp; a.alpha_opt.m[0] = mm; a.alpha_opt.v[0] = vv;
+      }
+      if (a.noise_counter) a.noise_counter[0] += 1;
+    }
+    if (a.target && !a.grads_only) {
+      const float omt = (float)(1.0 - (double)a.tau);
+      const int ntb = (int)gridDim.x - a.n_dw_blocks;
+      for (int64_t i = ((int64_t)tb * blockDim.x + threadIdx.x) * 4; i < a.polyak_n; i += (int64_t)ntb * blockDim.x * 4) {
+        if (i + 3 < a.polyak_n) {
+          f32x4 t = *reinterpret_cast<f32x4*>(a.target + i); const f32x4 p = *reinterpret_cast<const f32x4*>(a.polyak_src + i);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t[q] = __fadd_rn(__fmul_rn(t[q], a.tau), __fmul_rn(omt, p[q]));
+          *reinterpret_cast<f32x4*>(a.target + i) = t;
+        } else {
+          for (int64_t q = i; q < a.polyak_n; ++q) a.target[q] = __fadd_rn(__fmul_rn(a.target[q], a.tau), __fmul_rn(omt, a.polyak_src[q]));
+        }
+      }
+    }
+    return;
+  }
+  // ---- job decode (wave-uniform)
+  const int IN = a.in_dim, H = a.hidden, OUT = a.out_dim;
+  const int nt_h = H / 16, ks_in = (IN + 63) / 64, ks_h = H / 64, nt_out = (OUT + 15) / 16, nb_h = H / 64;
+  const int j1 = nt_h * ks_in, j2 = nt_h * ks_h, j3 = nt_out * ks_h, jb = 2 * nb_h + 1;
+  const int per_net = j1 + j2 + j3 + jb;
+  int job = (int)blockIdx.x * 4 + wave_in_block;
+  if (job >= per_net * a.n_nets) return;
+  const int net = job / per_net; job -= net * per_net;
+  const adam_consts ac = make_adam_consts(a.opt.lr, a.opt.beta1, a.opt.beta2, a.opt.eps, a.opt.weight_decay, a.grads_only ? 1 : a.opt.step[0]);
+  const int64_t pbase = (int64_t)net * a.net_stride;
+  const int64_t oW1 = pbase, ob1 = oW1 + (int64_t)H * IN, oW2 = ob1 + H, ob2 = oW2 + (int64_t)H * H, oW3 = ob2 + H, ob3 = oW3 + (int64_t)OUT * H;
+  const float* x0 = a.x0 + net * a.x0_net_stride;
+  const float* h1 = a.h1 + net * a.h_net_stride; const float* h2 = a.h2 + net * a.h_net_stride;
+  const float* dz1 = a.dz1 + net * a.h_net_stride; const float* dz2 = a.dz2 + net * a.h_net_stride;
+  const float* dz3 = a.dz3 + net * a.dz3_net_stride;
+  if (job < j1) { dw_strip(a, ac, dz1, H, H, x0, a.ld_x0, IN, (job / ks_in) * 16, (job % ks_in) * 64, oW1); return; }
+  job -= j1;
+  if (job < j2) { dw_strip(a, ac, dz2, H, H, h1, H, H, (job / ks_h) * 16, (job % ks_h) * 64, oW2); return; }
+  job -= j2;
+  if (job < j3) { dw_strip(a, ac, dz3, a.ld_dz3, OUT, h2, H, H, (job / ks_h) * 16, (job % ks_h) * 64, oW3); return; }
+  job -= j3;
+  if (job < nb_h) { dw_bias(a, ac, dz1, H, H, job * 64, ob1); return; }
+  job -= nb_h;
+  if (job < nb_h) { dw_bias(a, ac, dz2, H, H, job * 64, ob2); return; }
+  dw_bias(a, ac, dz3, a.ld_dz3, OUT, 0, ob3);
+}
+
+static int dw_blocks(int IN, int H, int OUT, int nets) {
+  const int per_net = (H / 16) * ((IN + 63) / 64) + (H / 16) * (H / 64) + ((OUT + 15) / 16) * (H / 64) + 2 * (H / 64) + 1;
+  return ceil_div(per_net * nets, 4);
+}
+
+// generic elementwise Adam over a flat arena (data-parallel path and stand-alone use)
+__global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, const float* __restrict__ g, il_adam opt, int64_t n) {
+  const adam_consts ac = make_adam_consts(opt.lr, opt.beta1, opt.beta2, opt.eps, opt.weight_decay, opt.step[0]);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float pp = p[i], mm = opt.m[i], vv = opt.v[i];
+    adam_update(pp, g[i], mm, vv, ac);
+    p[i] = pp; opt.m[i] = mm; opt.v[i] = vv;
+  }
+}
+__global__ void k_tick(int32_t* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
+__global__ __launch_bounds__(256) void k_polyak(float* __restrict__ t, const float* __restrict__ p, int64_t n, float tau) {
+  const float omt = (float)(1.0 - (double)tau);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    t[i] = __fadd_rn(__fmul_rn(t[i], tau), __fmul_rn(omt, p[i]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// host entry points
+// ---------------------------------------------------------------------------------------------
+static int check_sac(const il_sac* d, const il_batch* b) {
+  IL_CHECK_ARG(d && b, "il_sac: null descriptor");
+  IL_CHECK_ARG(d->hidden % 64 == 0 && d->hidden >= 64 && d->hidden <= 256, "il_sac: hidden=%d must be a multiple of 64 in [64,256]", d->hidden);
+  IL_CHECK_ARG(d->batch % IL_TILE_R == 0 && d->batch > 0, "il_sac: batch=%d must be a positive multiple of %d", d->batch, IL_TILE_R);
+  IL_CHECK_ARG(b->n == d->batch, "il_sac: batch rows %d != descriptor batch %d", b->n, d->batch);
+  IL_CHECK_ARG(d->action_dim >= 1 && 2 * d->action_dim <= 16, "il_sac: action_dim=%d unsupported (2A <= 16)", d->action_dim);
+  IL_CHECK_ARG(d->state_dim >= 1 && d->state_dim + d->action_dim <= 508, "il_sac: state_dim too large");
+  const SacWs ws = sac_ws(d->state_dim, d->action_dim, d->hidden, d->batch);
+  if (!d->workspace || d->workspace_floats < ws.total) return il_set_error(IL_ERR_WORKSPACE, "il_sac: workspace too small (%lld < %lld floats)", (long long)d->workspace_floats, (long long)ws.total);
+  return IL_OK;
+}
+
+extern "C" int64_t il_mlp_numel(int32_t in_dim, int32_t hidden, int32_t out_dim) { return mlp_numel(in_dim, hidden, out_dim); }
+extern "C" int64_t il_mlp_stride(int32_t in_dim, int32_t hidden, int32_t out_dim) { return net_stride(in_dim, hidden, out_dim); }
+extern "C" int64_t il_sac_workspace_floats(int32_t S, int32_t A, int32_t H, int32_t B) { return sac_ws(S, A, H, B).total; }
+
+static DwArgs critic_dw_args(const il_sac* d, uint32_t flags) {
+  const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, IN = S + A;
+  const SacWs ws = sac_ws(S, A, H, B);
+  DwArgs a = {};
+  a.params = d->critic; a.grads = d->critic_grad; a.opt = d->critic_opt; a.grads_only = (flags & IL_FLAG_GRADS_ONLY) ? 1 : 0;
+  a.n_nets = 2; a.net_stride = net_stride(IN, H, 1); a.in_dim = IN; a.hidden = H; a.out_dim = 1; a.batch = B;
+  a.x0 = d->workspace + ws.c_x0; a.ld_x0 = IN; a.x0_net_stride = 0;
+  a.h1 = d->workspace + ws.c_h1; a.h2 = d->workspace + ws.c_h2; a.dz1 = d->workspace + ws.c_dz1; a.dz2 = d->workspace + ws.c_dz2; a.h_net_stride = (int64_t)B * H;
+  a.dz3 = d->workspace + ws.c_dz3; a.ld_dz3 = 1; a.dz3_net_stride = B;
+  a.n_dw_blocks = dw_blocks(IN, H, 1, 2);
+  return a;
+}
+
+extern "C" int il_sac_critic_step(const il_sac* d, const il_batch* b, const float* eps_next, uint32_t flags, il_stream_t stream_) {
+  if (int rc = check_sac(d, b)) return rc;
+  hipStream_t st = (hipStream_t)stream_;
+  const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
+  const size_t lds = tile_lds_bytes(round_up16(S + A), H);
+  { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, 256, lds, st>>>(*d, *b, eps_next, nullptr, 1); }
+  { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, 256, lds, st>>>(*d, *b); }
+  { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, 256, lds, st>>>(*d, *b); }
+  DwArgs a = critic_dw_args(d, flags);
+  { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<a.n_dw_blocks, 256, 0, st>>>(a); }
+  IL_CHECK_LAUNCH("il_sac_critic_step");
+  return IL_OK;
+}
+
+static DwArgs actor_dw_args(const il_sac* d, const il_batch* b, uint32_t flags) {
+  const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch;
+  const SacWs ws = sac_ws(S, A, H, B);
+  DwArgs a = {};
+  a.params = d->actor; a.grads = d->actor_grad; a.opt = d->actor_opt; a.grads_only = (flags & IL_FLAG_GRADS_ONLY) ? 1 : 0;
+  a.n_nets = 1; a.net_stride = 0; a.in_dim = S; a.hidden = H; a.out_dim = 2 * A; a.batch = B;
+  a.x0 = b->states; a.ld_x0 = b->ld_states; a.x0_net_stride = 0;
+  a.h1 = d->workspace + ws.a_h1; a.h2 = d->workspace + ws.a_h2; a.dz1 = d->workspace + ws.a_dz1; a.dz2 = d->workspace + ws.a_dz2; a.h_net_stride = 0;
+  a.dz3 = d->workspace + ws.a_dz3; a.ld_dz3 = 16; a.dz3_net_stride = 0;
+  a.n_dw_blocks = dw_blocks(S, H, 2 * A, 1);
+  a.log_alpha = d->log_alpha; a.alpha_grad = d->alpha_grad; a.alpha_opt = d->alpha_opt; a.alpha_part = d->workspace + ws.alpha_part; a.n_alpha_part = B / IL_TILE_R;
+  a.target = d->target; a.polyak_src = d->critic; a.polyak_n = 2 * net_stride(S + A, H, 1); a.tau = d->polyak; a.noise_counter = d->noise_counter;
+  return a;
+}
+
+extern "C" int il_sac_actor_step(const il_sac* d, const il_batch* b, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream_) {
+  if (int rc = check_sac(d, b)) return rc;
+  hipStream_t st = (hipStream_t)stream_;
+  const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
+  const size_t lds = tile_lds_bytes(round_up16(S + A), H);
+  { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, 256, lds, st>>>(*d, *b, nullptr, eps_cur, 2); }
+  { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, 256, lds, st>>>(*d, *b); }
+  { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, 256, lds, st>>>(*d, *b, out_logp, out_q); }
+  DwArgs a = actor_dw_args(d, b, flags);
+  const int tail = 1 + ((flags & IL_FLAG_GRADS_ONLY) ? 0 : 32);
+  { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<a.n_dw_blocks + tail, 256, 0, st>>>(a); }
+  IL_CHECK_LAUNCH("il_sac_actor_step");
+  return IL_OK;
+}
+
+extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags,
+                             il_stream_t stream_) {
+  if (int rc = check_sac(d, b)) return rc;
+  hipStream_t st = (hipStream_t)stream_;
+  const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
+  const size_t lds = tile_lds_bytes(round_up16(S + A), H);
+  // the actor is unchanged until the last kernel of the update: both of its forward passes share one launch
+  { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<2 * nt, 256, lds, st>>>(*d, *b, eps_next, eps_cur, 0); }
+  { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, 256, lds, st>>>(*d, *b); }
+  { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, 256, lds, st>>>(*d, *b); }
+  DwArgs ca = critic_dw_args(d, flags);
+  { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
+  if (flags & IL_FLAG_GRADS_ONLY) { IL_CHECK_LAUNCH("il_sac_update"); return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update: IL_FLAG_GRADS_ONLY needs the split critic/actor entry points"); }
+  { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, 256, lds, st>>>(*d, *b); }
+  { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, 256, lds, st>>>(*d, *b, out_logp, out_q); }
+  DwArgs aa = actor_dw_args(d, b, flags);
+  { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 33, 256, 0, st>>>(aa); }
+  IL_CHECK_LAUNCH("il_sac_update");
+  return IL_OK;
+}
+
+extern "C" int il_adam_step(float* p, const float* g, const il_adam* opt, int64_t n, uint32_t flags, il_stream_t stream_) {
+  IL_CHECK_ARG(p && g && opt && opt->m && opt->v && opt->step && n > 0, "il_adam_step: bad arguments");
+  hipStream_t st = (hipStream_t)stream_;
+  if (flags & IL_FLAG_TICK) k_tick<<<1, 64, 0, st>>>(opt->step);
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  { IL_TRACE("k_adam_flat", st); k_adam_flat<<<blocks, 256, 0, st>>>(p, g, *opt, n); }
+  IL_CHECK_LAUNCH("il_adam_step");
+  return IL_OK;
+}
+
+extern "C" int il_polyak(float* target, const float* param, int64_t n, float tau, il_stream_t stream_) {
+  IL_CHECK_ARG(target && param && n > 0, "il_polyak: bad arguments");
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  { IL_TRACE("k_polyak", (hipStream_t)stream_); k_polyak<<<blocks, 256, 0, (hipStream_t)stream_>>>(target, param, n, tau); }
+  IL_CHECK_LAUNCH("il_polyak");
+  return IL_OK;
+}
+
+extern "C" int il_sac_apply_critic_grads(const il_sac* d, il_stream_t stream_) {
+  IL_CHECK_ARG(d && d->critic_grad, "il_sac_apply_critic_grads: critic_grad arena missing");
+  return il_adam_step(d->critic, d->critic_grad, &d->critic_opt, 2 * net_stride(d->state_dim + d->action_dim, d->hidden, 1), 0, stream_);
+}
+
+__global__ void k_alpha_adam(float* log_alpha, const float* g, il_adam opt) {
+  if (threadIdx.x || blockIdx.x) return;
+  const adam_consts ac = make_adam_consts(opt.lr, opt.beta1, opt.beta2, opt.eps, 0.f, opt.step[0]);
+  float pp = log_alpha[0], mm = opt.m[0], vv = opt.v[0];
+  adam_update(pp, g[0], mm, vv, ac);
+  log_alpha[0] = pp; opt.m[0] = mm; opt.v[0] = vv;
+}
+
+extern "C" int il_sac_apply_actor_grads(const il_sac* d, il_stream_t stream_) {
+  IL_CHECK_ARG(d && d->actor_grad && d->alpha_grad, "il_sac_apply_actor_grads: grad arenas missing");
+  if (int rc = il_adam_step(d->actor, d->actor_grad, &d->actor_opt, mlp_numel(d->state_dim, d->hidden, 2 * d->action_dim), 0, stream_)) return rc;
+  { IL_TRACE("k_alpha_adam", (hipStream_t)stream_); k_alpha_adam<<<1, 64, 0, (hipStream_t)stream_>>>(d->log_alpha, d->alpha_grad, d->alpha_opt); }
+  return il_polyak(d->target, d->critic, 2 * net_stride(d->state_dim + d->action_dim, d->hidden, 1), d->polyak, stream_);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Behavioural cloning (training.py:57-64, models.py:97-99): forward, log-prob of the clamped expert action through atanh,
+// backward to the pre-activations -- one tile kernel (activations stay in LDS between forward and backward) -- then the
+// shared k_dw_adam.  grid = nt
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bc_tile(const float* __restrict__ actor, il_adam opt, int S, int A, int H, il_batch b, float* __restrict__ W,
+                                                 float* __restrict__ loss_part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int B = b.n, tile = blockIdx.x, row0 = tile * IL_TILE_R, tid = threadIdx.x;
+  const int Sp = round_up16(S), ldx = Sp + 4, ldh = H + 4, ldz = 20;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* part = H2s + IL_TILE_R * ldh; float* Os = part + 4 * 256;
+  float* red = Os + 256;
+  float* DZ3s = part;  // reused after the head
+  const SacWs ws = sac_ws(S, A, H, B);
+  const MlpView net = mlp_view(actor, S, H, 2 * A);
+  load_rows_cat(Xs, ldx, Sp, b.states, b.ld_states, S, nullptr, 0, 0, row0, IL_TILE_R);
+  __syncthreads();
+  const int lane = tid & 63, j = lane & 15, g = lane >> 4;
+  tile_fwd(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4* acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = c0 + 16 * t + j; const float bb = net.b1[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float h = fmaxf(acc[t][r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = h; W[ws.a_h1 + (size_t)(row0 + 4 * g + r) * H + col] = h; }
+    }
+  });
+  __syncthreads();
+  tile_fwd(H1s, ldh, H, net.W2, H, H, H, [&](int c0, f32x4* acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = c0 + 16 * t + j; const float bb = net.b2[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float h = fmaxf(acc[t][r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = h; W[ws.a_h2 + (size_t)(row0 + 4 * g + r) * H + col] = h; }
+    }
+  });
+  __syncthreads();
+  tile_fwd_small(H2s, ldh, H, net.W3, H, 2 * A, net.b3, Os, part);
+  // head
+  float lp_term = 0.f, dmean = 0.f, dls = 0.f; int hr = 0, hc = 0;
+  const bool head = tid < IL_TILE_R * A;
+  if (head) {
+    hr = tid / A; hc = tid - hr * A; const int row = row0 + hr;
+    const float a = fminf(fmaxf(b.actions[(size_t)row * b.ld_actions + hc], -1.f + 1e-6f), 1.f - 1e-6f);
+    const float x = atanhf(a);
+    const float mean = Os[hr * 16 + hc], lsr = Os[hr * 16 + A + hc];
+    const float sd = expf(fminf(fmaxf(lsr, -20.f), 2.f));
+    const float df = x - mean, var = sd * sd;
+    const float nlp = -(df * df) / (2.f * var) - logf(sd) - LOG_SQRT_2PI;
+    const float ladj = 2.f * (LOG_2 - x - softplus_f(-2.f * x));
+    lp_term = nlp - ladj;
+    const float up = -b.weights[(size_t)row * b.ld_weights] / (float)B;
+    dmean = up * df / var;
+    const float dsd = up * (df * df / (var * sd) - 1.f / sd);
+    dls = (lsr >= -20.f && lsr <= 2.f) ? dsd * sd : 0.f;
+  }
+  __syncthreads();  // Os/part fully consumed before DZ3s (aliasing part) is written
+  for (int i = tid; i < IL_TILE_R * ldz; i += blockDim.x) DZ3s[i] = 0.f;
+  __syncthreads();
+  if (head) { DZ3s[hr * ldz + hc] = dmean; DZ3s[hr * ldz + A + hc] = dls; }
+  const float lsum = block_sum(head ? -b.weights[(size_t)(row0 + hr) * b.ld_weights] * lp_term : 0.f, red);
+  if (tid == 0) { if (loss_part) loss_part[tile] = lsum; if (tile == 0) opt.step[0] += 1; }
+  for (int i = tid; i < IL_TILE_R * 16; i += blockDim.x) W[ws.a_dz3 + (size_t)row0 * 16 + i] = DZ3s[(i >> 4) * ldz + (i & 15)];
+  float* DZ2s = H1s;  // h1 lives in the workspace copy from here on
+  __syncthreads();
+  tile_bwd_dx(DZ3s, ldz, 16, 2 * A, net.W3, H, H, [&](int kb, f32x4* acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + 4 * j;
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(H2s + (4 * g + r) * ldh + kb + 4 * j);
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = hv[i] > 0.f ? acc[i][r] : 0.f;
+      *reinterpret_cast<f32x4*>(W + ws.a_dz2 + off) = o;
+      *reinterpret_cast<f32x4*>(DZ2s + (4 * g + r) * ldh + kb + 4 * j) = o;
+    }
+  });
+  __syncthreads();
+  tile_bwd_dx(DZ2s, ldh, H, H, net.W2, H, H, [&](int kb, f32x4* acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + 4 * j;
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(W + ws.a_h1 + off);
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = hv[i] > 0.f ? acc[i][r] : 0.f;
+      *reinterpret_cast<f32x4*>(W + ws.a_dz1 + off) = o;
+    }
+  });
+}
+
+extern "C" int il_bc_step(float* actor, float* actor_grad, const il_adam* opt, int32_t S, int32_t A, int32_t H, const il_batch* b, float* workspace,
+                          int64_t workspace_floats, float* out_loss_partials, uint32_t flags, il_stream_t stream_) {
+  IL_CHECK_ARG(actor && opt && b && workspace, "il_bc_step: null argument");
+  IL_CHECK_ARG(H % 64 == 0 && H >= 64 && H <= 256, "il_bc_step: hidden=%d must be a multiple of 64 in [64,256]", H);
+  IL_CHECK_ARG(b->n > 0 && b->n % IL_TILE_R == 0, "il_bc_step: batch=%d must be a positive multiple of %d", b->n, IL_TILE_R);
+  IL_CHECK_ARG(A >= 1 && 2 * A <= 16, "il_bc_step: action_dim=%d unsupported (2A <= 16)", A);
+  IL_CHECK_ARG(!(flags & IL_FLAG_GRADS_ONLY) || actor_grad, "il_bc_step: IL_FLAG_GRADS_ONLY needs actor_grad");
+  const SacWs ws = sac_ws(S, A, H, b->n);
+  if (workspace_floats < ws.total) return il_set_error(IL_ERR_WORKSPACE, "il_bc_step: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)ws.total);
+  hipStream_t st = (hipStream_t)stream_;
+  const int nt = b->n / IL_TILE_R;
+  { IL_TRACE("k_bc_tile", st); k_bc_tile<<<nt, 256, tile_lds_bytes(round_up16(S + A), H), st>>>(actor, *opt, S, A, H, *b, workspace, out_loss_partials); }
+  DwArgs a = {};
+  a.params = actor; a.grads = actor_grad; a.opt = *opt; a.grads_only = (flags & IL_FLAG_GRADS_ONLY) ? 1 : 0;
+  a.n_nets = 1; a.in_dim = S; a.hidden = H; a.out_dim = 2 * A; a.batch = b->n;
+  a.x0 = b->states; a.ld_x0 = b->ld_states;
+  a.h1 = workspace + ws.a_h1; a.h2 = workspace + ws.a_h2; a.dz1 = workspace + ws.a_dz1; a.dz2 = workspace + ws.a_dz2;
+  a.dz3 = workspace + ws.a_dz3; a.ld_dz3 = 16;
+  a.n_dw_blocks = dw_blocks(S, H, 2 * A, 1);
+  { IL_TRACE("k_dw_adam_bc", st); k_dw_adam<<<a.n_dw_blocks, 256, 0, st>>>(a); }
+  IL_CHECK_LAUNCH("il_bc_step");
+  return IL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Acting (train.py:152 `actor(state).sample()`, models.py:101-102 greedy): n states, any n >= 1.  grid = ceil(n/16)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_act(const float* __restrict__ actor, int S, int A, int H, const float* __restrict__ states, int ld, int n, const float* __restrict__ eps,
+                                             uint64_t seed, uint32_t offset, int greedy, float* __restrict__ out_a, float* __restrict__ out_logp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int row0 = blockIdx.x * IL_TILE_R, tid = threadIdx.x, nrows = min(IL_TILE_R, n - row0);
+  const int Sp = round_up16(S), ldx = Sp + 4, ldh = H + 4;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* part = H2s + IL_TILE_R * ldh; float* Os = part + 4 * 256;
+  const MlpView net = mlp_view(actor, S, H, 2 * A);
+  load_rows_cat(Xs, ldx, Sp, states, ld, S, nullptr, 0, 0, row0, nrows);
+  __syncthreads();
+  const int lane = tid & 63, j = lane & 15, g = lane >> 4;
+  tile_fwd(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4* acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = c0 + 16 * t + j; const float bb = net.b1[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[t][r] + bb, 0.f);
+    }
+  });
+  __syncthreads();
+  tile_fwd(H1s, ldh, H, net.W2, H, H, H, [&](int c0, f32x4* acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = c0 + 16 * t + j; const float bb = net.b2[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = fmaxf(acc[t][r] + bb, 0.f);
+    }
+  });
+  __syncthreads();
+  tile_fwd_small(H2s, ldh, H, net.W3, H, 2 * A, net.b3, Os, part);
+  float* nl = part; float* la = part + 256;
+  if (tid < IL_TILE_R * A) {
+    const int r = tid / A, c = tid - r * A, row = row0 + r;
+    const float mean = Os[r * 16 + c], lsr = Os[r * 16 + A + c];
+    float x, a = tanhf(mean), nlp = 0.f, ladj = 0.f;
+    if (!greedy) {
+      const float e = eps ? (r < nrows ? eps[(size_t)row * A + c] : 0.f) : philox_normal(seed, offset, IL_STREAM_ACT, (uint32_t)(row * A + c));
+      head_sample(mean, lsr, e, x, a, nlp, ladj);
+    }
+    nl[r * 16 + c] = nlp; la[r * 16 + c] = ladj;
+    if (r < nrows) out_a[(size_t)row * A + c] = a;
+  }
+  __syncthreads();
+  if (out_logp && tid < nrows) {
+    float sn = 0.f, sl = 0.f;
+    for (int c = 0; c < A; ++c) { sn += nl[tid * 16 + c]; sl += la[tid * 16 + c]; }
+    out_logp[row0 + tid] = (0.f - sl) + sn;
+  }
+}
+
+extern "C" int il_actor_act(const float* actor, int32_t S, int32_t A, int32_t H, const float* states, int32_t ld_states, int32_t n, const float* eps,
+                            uint64_t noise_seed, uint32_t noise_offset, int32_t greedy, float* out_action, float* out_logp, il_stream_t stream_) {
+  IL_CHECK_ARG(actor && states && out_action && n > 0, "il_actor_act: null argument");
+  IL_CHECK_ARG(H % 64 == 0 && H >= 64 && H <= 256 && A >= 1 && 2 * A <= 16, "il_actor_act: unsupported dims (hidden=%d, action_dim=%d)", H, A);
+  {
+    IL_TRACE("k_act", stream_);
+    k_act<<<ceil_div(n, IL_TILE_R), 256, tile_lds_bytes(round_up16(S + A), H), (hipStream_t)stream_>>>(actor, S, A, H, states, ld_states, n, eps, noise_seed, noise_offset, greedy,
+                                                                                                       out_action, out_logp);
+  }
+  IL_CHECK_LAUNCH("il_actor_act");
+  return IL_OK;
+}

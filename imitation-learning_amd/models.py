@@ -1,0 +1,313 @@
+"""Host-side mirror of the reference's model classes (reference models.py) over flat HBM arenas.
+
+Same constructors, method names and state_dict keys as the reference (`actor.0.weight`, `critic_1.critic.0.weight`,
+`g.0.parametrizations.weight.original`, `...weight.0._u`), so checkpoints stay interchangeable -- but every network is
+ONE flat fp32 tensor on the GPU (torch `parameters()` order) that the HIP kernels update in place; the `nn.Module`
+parameters are views into it.  Nothing here does arithmetic on the update path: that is libil_hip.so (see training.py).
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+from math import sqrt
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+from torch.nn.utils import parametrizations
+
+from . import _lib
+
+REWARD_FUNCTIONS = {'AIRL': 0, 'GAIL': 1, 'FAIRL': 2}
+
+
+def default_device() -> torch.device:
+  return torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
+
+
+def _cfg_get(cfg, key, default=None):
+  return cfg.get(key, default) if hasattr(cfg, 'get') else getattr(cfg, key, default)
+
+
+def _require_fused_mlp(model_cfg, what):
+  depth, act = _cfg_get(model_cfg, 'depth'), _cfg_get(model_cfg, 'activation')
+  hidden = _cfg_get(model_cfg, 'hidden_size')
+  if depth != 2 or act != 'relu' or hidden % 64 != 0 or not 64 <= hidden <= 256:
+    raise NotImplementedError(f'{what}: the HIP path implements depth=2, activation=relu, hidden_size in {{64,128,192,256}} '
+                              f'(got depth={depth}, activation={act}, hidden_size={hidden}); there is no CPU/torch fallback on this path')
+  if _cfg_get(model_cfg, 'input_dropout', 0) or _cfg_get(model_cfg, 'dropout', 0):
+    raise NotImplementedError(f'{what}: dropout networks (DRIL) are outside the HIP hot path')
+  return hidden
+
+
+def _mlp(in_dim: int, hidden: int, out_dim: int, final_gain: float = 1.0) -> nn.Sequential:
+  """Linear-ReLU-Linear-ReLU-Linear with the reference's init (orthogonal, gain sqrt(2) hidden / final_gain last, zero bias; models.py:55-66)."""
+  dims, layers = [in_dim, hidden, hidden, out_dim], []
+  for i in range(3):
+    lin = nn.Linear(dims[i], dims[i + 1])
+    nn.init.orthogonal_(lin.weight, gain=sqrt(2.0) if i < 2 else final_gain)
+    nn.init.constant_(lin.bias, 0)
+    layers.append(lin)
+    if i < 2:
+      layers.append(nn.ReLU())
+  return nn.Sequential(*layers)
+
+
+def _flatten_into(modules_params, flat: Tensor, offsets):
+  """Copies each parameter into its slot of `flat` and re-points `.data` at the slot (a view)."""
+  for p, o in zip(modules_params, offsets):
+    n = p.numel()
+    view = flat[o:o + n].view(p.shape)
+    view.copy_(p.data)
+    p.data = view
+
+
+class _FlatModule(nn.Module):
+  """nn.Module whose parameters are views into one flat device tensor `self.flat`."""
+
+  flat: Tensor
+
+  def _adopt(self, numel_total: int, offsets, device):
+    params = list(self.parameters())
+    flat = torch.zeros(numel_total, dtype=torch.float32, device=device)
+    with torch.no_grad():
+      _flatten_into(params, flat, offsets)
+    self.flat = flat
+    for p in params:
+      p.requires_grad_(False)  # gradients are produced by the HIP kernels, never by autograd
+
+  @property
+  def device(self):
+    return self.flat.device
+
+
+class SoftActor(_FlatModule):
+  """Tanh-Gaussian policy (reference models.py:84-120). `actor(state).sample()` / `get_greedy_action` run k_act on the GPU."""
+
+  def __init__(self, state_size: int, action_size: int, model_cfg, device=None):
+    super().__init__()
+    self.state_size, self.action_size = state_size, action_size
+    self.hidden = _require_fused_mlp(model_cfg, 'SoftActor')
+    if 2 * action_size > 16:
+      raise NotImplementedError('SoftActor: action_size > 8 is not supported by the fused head (2A <= 16)')
+    self.log_std_dev_min, self.log_std_dev_max = -20, 2
+    self.actor = _mlp(state_size, self.hidden, 2 * action_size)
+    offs, o = [], 0
+    for p in self.parameters():
+      offs.append(o); o += p.numel()
+    self._adopt(o, offs, device or default_device())
+    self._act_calls = 0
+
+  class _Policy:
+    def __init__(self, actor, state):
+      self.actor, self.state = actor, state
+
+    def sample(self, eps: Optional[Tensor] = None) -> Tensor:
+      return self.actor._act(self.state, greedy=False, eps=eps)[0]
+
+    rsample = sample
+
+    def sample_with_log_prob(self, eps: Optional[Tensor] = None):
+      return self.actor._act(self.state, greedy=False, eps=eps, want_logp=True)
+
+  def forward(self, state: Tensor) -> 'SoftActor._Policy':
+    return SoftActor._Policy(self, state)
+
+  def _act(self, state: Tensor, greedy: bool, eps: Optional[Tensor] = None, want_logp: bool = False):
+    state = state.to(self.flat.device, torch.float32)
+    if state.dim() == 1:
+      state = state.unsqueeze(0)
+    assert state.stride(1) == 1
+    n = state.size(0)
+    out = torch.empty(n, self.action_size, device=self.flat.device)
+    logp = torch.empty(n, device=self.flat.device) if want_logp else None
+    if eps is not None:
+      eps = eps.to(self.flat.device, torch.float32).contiguous()
+    self._act_calls += 1
+    _lib.check(_lib.lib().il_actor_act(_lib.ptr(self.flat), self.state_size, self.action_size, self.hidden, _lib.ptr(state), state.stride(0), n, _lib.ptr(eps),
+                                       C.c_uint64(torch.initial_seed() & (2**64 - 1)), self._act_calls & 0xFFFFFFFF, int(greedy), _lib.ptr(out), _lib.ptr(logp), _lib.stream_ptr()))
+    return out, logp
+
+  def get_greedy_action(self, state: Tensor) -> Tensor:
+    return self._act(state, greedy=True)[0]
+
+  def log_prob(self, state: Tensor, action: Tensor) -> Tensor:
+    """models.py:97-99 (not on the update path: BC computes it inside k_bc_tile). Plain torch ops on the device views."""
+    action = action.clamp(-1 + 1e-6, 1 - 1e-6)
+    mean, log_std = self.actor(state).chunk(2, dim=1)
+    log_std = log_std.clamp(self.log_std_dev_min, self.log_std_dev_max)
+    x = torch.atanh(action)
+    normal = -((x - mean) ** 2) / (2 * (2 * log_std).exp()) - log_std - 0.9189385332046727
+    ladj = 2.0 * (0.6931471805599453 - x - torch.nn.functional.softplus(-2.0 * x))
+    return normal.sum(dim=1) - ladj.sum(dim=1)
+
+
+class Critic(nn.Module):
+  def __init__(self, state_size: int, action_size: int, hidden: int):
+    super().__init__()
+    self.critic = _mlp(state_size + action_size, hidden, 1)
+
+  def forward(self, state: Tensor, action: Tensor) -> Tensor:
+    return self.critic(torch.cat([state, action], dim=1)).squeeze(dim=1)
+
+
+class TwinCritic(_FlatModule):
+  """Two independent Q networks (reference models.py:123-141); flat layout critic_1 | critic_2 at stride il_mlp_stride."""
+
+  def __init__(self, state_size: int, action_size: int, model_cfg, device=None):
+    super().__init__()
+    self.state_size, self.action_size = state_size, action_size
+    self.hidden = _require_fused_mlp(model_cfg, 'TwinCritic')
+    self.critic_1, self.critic_2 = Critic(state_size, action_size, self.hidden), Critic(state_size, action_size, self.hidden)
+    numel = sum(p.numel() for p in self.critic_1.parameters())
+    self.net_stride = (numel + 3) // 4 * 4
+    offs = []
+    for k, net in enumerate((self.critic_1, self.critic_2)):
+      o = k * self.net_stride
+      for p in net.parameters():
+        offs.append(o); o += p.numel()
+    self._adopt(2 * self.net_stride, offs, device or default_device())
+
+  def forward(self, state: Tensor, action: Tensor) -> Tuple[Tensor, Tensor]:
+    return self.critic_1(state, action), self.critic_2(state, action)
+
+
+def create_target_network(network: _FlatModule) -> _FlatModule:
+  """Reference models.py:72-76. The copy gets its own flat arena with the same layout."""
+  target = copy.deepcopy(network)
+  target.flat = network.flat.clone()
+  with torch.no_grad():
+    for p, q in zip(target.parameters(), network.parameters()):
+      off = (q.data_ptr() - network.flat.data_ptr()) // 4
+      p.data = target.flat[off:off + q.numel()].view(q.shape)
+      p.requires_grad = False
+  return target
+
+
+def update_target_network(network: _FlatModule, target_network: _FlatModule, polyak_factor: float):
+  """Reference models.py:79-81 as one streaming kernel over the arena (sac_update fuses it; this is the stand-alone form)."""
+  _lib.check(_lib.lib().il_polyak(_lib.ptr(target_network.flat), _lib.ptr(network.flat), network.flat.numel(), float(polyak_factor), _lib.stream_ptr()))
+
+
+def make_gail_input(state, action, next_state, terminal, actor, reward_shaping: bool, subtract_log_policy: bool) -> Dict[str, Tensor]:
+  if reward_shaping or subtract_log_policy:
+    raise NotImplementedError('GAIL reward_shaping / subtract_log_policy variants are outside the HIP hot path (SURVEY.md §8f-4)')
+  return {'state': state, 'action': action}
+
+
+class GAILDiscriminator(_FlatModule):
+  """Depth-1 ReLU discriminator with optional spectral norm (reference models.py:152-180).
+
+  Flat arena = `parameters()` order (spectral norm: g.0.bias, g.0...original, g.2.bias, g.2...original). The torch
+  parametrization modules are kept only for initialisation (same RNG consumption as the reference: normal_ u, v + 15+1
+  power iterations) and for the state_dict keys; their buffers are re-pointed at `self.sn` so the kernels own u, v.
+  """
+
+  def __init__(self, state_size: int, action_size: int, imitation_cfg, discount: float, device=None):
+    super().__init__()
+    model_cfg = imitation_cfg.discriminator
+    self.discount, self.state_only = discount, bool(imitation_cfg.state_only)
+    self.reward_shaping, self.subtract_log_policy, self.reward_function = model_cfg.reward_shaping, model_cfg.subtract_log_policy, model_cfg.reward_function
+    self.spectral_norm = bool(imitation_cfg.spectral_norm)
+    if self.reward_shaping or self.subtract_log_policy or model_cfg.depth != 1 or model_cfg.activation != 'relu':
+      raise NotImplementedError('GAILDiscriminator: the HIP path implements depth=1, activation=relu, no reward shaping / log-policy subtraction '
+                                '(the closed-form gradient-penalty backward assumes it); no torch fallback on this path')
+    self.state_size, self.action_size, self.hidden = state_size, action_size, model_cfg.hidden_size
+    self.in_dim = state_size if self.state_only else state_size + action_size
+    l1, l2 = nn.Linear(self.in_dim, self.hidden), nn.Linear(self.hidden, 1)
+    nn.init.orthogonal_(l1.weight, gain=sqrt(2.0)); nn.init.constant_(l1.bias, 0)
+    if self.spectral_norm: l1 = parametrizations.spectral_norm(l1)
+    nn.init.orthogonal_(l2.weight, gain=1.0); nn.init.constant_(l2.bias, 0)
+    if self.spectral_norm: l2 = parametrizations.spectral_norm(l2)
+    self.g = nn.Sequential(l1, nn.ReLU(), l2)
+    offs, o = [], 0
+    for p in self.parameters():
+      offs.append(o); o += p.numel()
+    dev = device or default_device()
+    self._adopt(o, offs, dev)
+    H, D = self.hidden, self.in_dim
+    self.sn = torch.zeros(2 * H + D + 1, device=dev)  # u1[H] | v1[D] | u2[1] | v2[H]
+    if self.spectral_norm:
+      with torch.no_grad():
+        for mod, (ou, nu, ov, nv) in ((self.g[0].parametrizations.weight[0], (0, H, H, D)), (self.g[2].parametrizations.weight[0], (H + D, 1, H + D + 1, H))):
+          u, v = self.sn[ou:ou + nu], self.sn[ov:ov + nv]
+          u.copy_(mod._u); v.copy_(mod._v)
+          mod._buffers['_u'], mod._buffers['_v'] = u, v
+    self.eval()
+
+  def views(self):
+    H, D = self.hidden, self.in_dim
+    return dict(u1=self.sn[:H], v1=self.sn[H:H + D], u2=self.sn[H + D:H + D + 1], v2=self.sn[H + D + 1:])
+
+  def predict_reward(self, state: Tensor, action: Tensor, next_state=None, terminal=None, log_policy=None) -> Tensor:
+    from .training import gail_predict_reward
+    return gail_predict_reward(self, state, action)
+
+  def forward(self, state: Tensor, action: Tensor, next_state=None, terminal=None, log_policy=None) -> Tensor:
+    from .training import gail_predict_reward
+    return gail_predict_reward(self, state, action, want_logits=True)[1]
+
+
+class GMMILDiscriminator(nn.Module):
+  """Kernel-mean-embedding reward (reference models.py:183-201); O(B^2 D) pair work runs in k_gmmil_tile."""
+
+  def __init__(self, state_size: int, action_size: int, imitation_cfg):
+    super().__init__()
+    self.state_size, self.action_size = state_size, action_size
+    self.state_only = bool(imitation_cfg.state_only)
+    self.gamma_1, self.gamma_2 = None, None
+    self._ws = None
+
+  def predict_reward(self, state, action, expert_state, expert_action, weight, expert_weight) -> Tensor:
+    from .training import gmmil_predict_reward
+    return gmmil_predict_reward(self, state, action, expert_state, expert_action, weight, expert_weight)
+
+
+def _calculate_normalisation_scale_offset(data: Tensor) -> Tuple[Tensor, Tensor]:
+  inv_scale, offset = data.std(dim=0, keepdim=True), -data.mean(dim=0, keepdim=True)
+  inv_scale[inv_scale == 0] = 1
+  return 1 / inv_scale, offset
+
+
+class PWILDiscriminator(nn.Module):
+  """Greedy Wasserstein coupling reward (reference models.py:216-249) on device-resident standardised expert atoms."""
+
+  def __init__(self, state_size: int, action_size: int, imitation_cfg, expert_memory, time_horizon: int):
+    super().__init__()
+    self.state_only = bool(imitation_cfg.state_only)
+    self.state_size, self.action_size = state_size, action_size
+    self.expert_memory, self.time_horizon = expert_memory, time_horizon
+    raw = self._get_expert_atoms().contiguous()
+    self.data_scale, self.data_offset = _calculate_normalisation_scale_offset(raw)
+    dim = state_size if self.state_only else state_size + action_size
+    self.reward_scale, self.reward_bandwidth = imitation_cfg.reward_scale, imitation_cfg.reward_bandwidth_scale * time_horizon / sqrt(dim)
+    self.expert_atoms = (self.data_scale * (raw + self.data_offset)).contiguous()
+    n = self.expert_atoms.size(0)
+    self.expert_weights, self._dists, self._out = torch.empty(n, device=raw.device), torch.empty(n, device=raw.device), torch.empty(1, device=raw.device)
+    self._scale, self._offset = self.data_scale.flatten().contiguous(), self.data_offset.flatten().contiguous()
+    self._desc = _lib.Pwil(n, dim, state_size, action_size, self.expert_atoms.data_ptr(), self.expert_weights.data_ptr(), self._dists.data_ptr(), self._scale.data_ptr(),
+                           self._offset.data_ptr(), float(self.reward_scale), float(self.reward_bandwidth), 1 / time_horizon - 1e-6)
+    self.reset()
+
+  def _get_expert_atoms(self) -> Tensor:
+    return self.expert_memory['states'] if self.state_only else torch.cat([self.expert_memory['states'], self.expert_memory['actions']], dim=1)
+
+  def reset(self):
+    _lib.check(_lib.lib().il_pwil_reset(C.byref(self._desc), _lib.stream_ptr()))
+
+  def compute_reward_async(self, state: Tensor, action: Tensor) -> Tensor:
+    """Enqueues the greedy coupling for one (state, action); returns the 1-element device tensor (no host sync)."""
+    dev = self.expert_atoms.device
+    state, action = state.to(dev, torch.float32).contiguous(), action.to(dev, torch.float32).contiguous()
+    _lib.check(_lib.lib().il_pwil_reward(C.byref(self._desc), _lib.ptr(state), _lib.ptr(action), _lib.ptr(self._out), _lib.stream_ptr()))
+    return self._out
+
+  def compute_reward(self, state: Tensor, action: Tensor) -> float:
+    return float(self.compute_reward_async(state, action).item())
+
+
+def mix_expert_agent_transitions(transitions: Dict[str, Tensor], expert_transitions: Dict[str, Tensor]):
+  """Reference models.py:287-290: first half of EVERY key is overwritten with expert rows (in place)."""
+  batch_size = transitions['rewards'].size(0)
+  for key in transitions.keys():
+    transitions[key][:batch_size // 2] = expert_transitions[key][:batch_size // 2]

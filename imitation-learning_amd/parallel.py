@@ -1,0 +1,93 @@
+"""Data-parallel SAC/GAIL over RCCL (one process per GPU, torch.distributed backend "nccl" == RCCL on ROCm).
+
+The path shards as plain data parallelism: every loss is a mean over samples, so the average of per-rank
+gradients on rank-local batches equals the gradient on the concatenated batch.  Each rank owns an env worker + agent replay
+shard (never exchanged) and a full replica of every network; there are exactly three exchange steps per update, in
+dependency order, each ONE flat pre-allocated fp32 bucket:
+    discriminator grad [P_d]  ->  critic grad [2*Ps]  ->  actor grad + log_alpha grad [Pa + 1 (+pad)]
+Messages are 6.7 KB / 580 KB / 295 KB: latency-bound on xGMI, so one bucket per sync point, no splitting.
+Replicas stay bit-identical because every rank applies the same averaged gradient with the same kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+def all_reduce_mean_(bucket: torch.Tensor, group=None):
+  """In-place mean over ranks. NCCL/RCCL has a native AVG; gloo (CPU tests) sums then scales."""
+  if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    return bucket
+  if dist.get_backend(group) == 'nccl':
+    dist.all_reduce(bucket, op=dist.ReduceOp.AVG, group=group)
+  else:
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+    bucket.div_(dist.get_world_size(group))
+  return bucket
+
+
+def broadcast_parameters(tensors, src: int = 0, group=None):
+  """One-time replica sync of flat arenas (params, SN buffers, log_alpha) from rank `src`."""
+  if dist.is_initialized() and dist.get_world_size(group) > 1:
+    for t in tensors:
+      dist.broadcast(t, src=src, group=group)
+
+
+def rank_seed(base_seed: int) -> int:
+  """Rank-offset seed for index draws / sampling noise (each rank must see different data)."""
+  return base_seed + (dist.get_rank() if dist.is_initialized() else 0)
+
+
+class DataParallelUpdate:
+  """`UpdatePlan` with the three gradient all-reduces between backward and optimiser (IL_FLAG_GRADS_ONLY entry points)."""
+
+  def __init__(self, plan, group=None):
+    self.plan, self.group = plan, group
+    ao, to = plan._keep[4], plan._keep[6]
+    # actor grad and alpha grad travel in one bucket: re-home both into a single flat tensor
+    n = ao.grad.numel()
+    self.actor_bucket = torch.zeros((n + 1 + 3) // 4 * 4, device=ao.grad.device)
+    ao.grad, to.grad = self.actor_bucket[:n], self.actor_bucket[n:n + 1]
+    plan.sac.actor_grad, plan.sac.alpha_grad = ao.grad.data_ptr(), to.grad.data_ptr()
+    self.critic_bucket = plan._keep[5].grad
+    self.disc_bucket = plan._keep[8].grad if plan.algorithm == 'GAIL' else None
+
+  def run(self):
+    p, L, st = self.plan, _lib.lib(), _lib.stream_ptr()
+    G = _lib.IL_FLAG_GRADS_ONLY
+    p._sample(p.memory, p.idx, p.rows)
+    if p.algorithm == 'GAIL':
+      p._sample(p.expert_memory, p.eidx, p.erows)
+      _lib.check(L.il_gail_disc_step(C.byref(p.disc), C.byref(p.pb), C.byref(p.eb), None, G, st))
+      all_reduce_mean_(self.disc_bucket, self.group)
+      _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
+      _lib.check(L.il_gail_reward(C.byref(p.disc), C.byref(p.pb), _lib.ptr(p.rewards), None, _lib.stream_ptr()))
+    _lib.check(L.il_sac_critic_step(C.byref(p.sac), C.byref(p.pb), None, G, _lib.stream_ptr()))
+    all_reduce_mean_(self.critic_bucket, self.group)
+    _lib.check(L.il_sac_apply_critic_grads(C.byref(p.sac), _lib.stream_ptr()))
+    _lib.check(L.il_sac_actor_step(C.byref(p.sac), C.byref(p.pb), None, _lib.ptr(p.logp), _lib.ptr(p.q), G, _lib.stream_ptr()))
+    all_reduce_mean_(self.actor_bucket, self.group)
+    _lib.check(L.il_sac_apply_actor_grads(C.byref(p.sac), _lib.stream_ptr()))
+
+  def capture(self, warmup: int = 3):
+    from .memory import index_stream
+    index_stream().device_state(self.plan.rows.device)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+      for _ in range(warmup):
+        self.run()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    self.graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(self.graph):
+      self.run()
+    return self
+
+  def replay(self):
+    self.graph.replay()

@@ -1,0 +1,246 @@
+"""Update functions with the reference's signatures (reference training.py) forwarding to libil_hip.so.
+
+`sac_update`, `adversarial_imitation_update`, `behavioural_cloning_update` keep the argument lists of the reference (plus
+optional keyword-only noise tensors used by the parity tests); every FLOP happens in the HIP kernels.  `UpdatePlan` is the
+same sequence (train.py:173-203 for algorithm=SAC/GAIL) with persistent buffers so that it can be captured in a hipGraph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from .memory import ReplayMemory, batch_desc, batch_views
+from .models import REWARD_FUNCTIONS, GAILDiscriminator, GMMILDiscriminator, SoftActor, TwinCritic
+from .optim import Adam, AdamW
+
+_WS: Dict[tuple, Tensor] = {}
+_NOISE: Dict[torch.device, Tensor] = {}
+
+
+def _workspace(kind: str, floats: int, device) -> Tensor:
+  key = (kind, str(device))
+  ws = _WS.get(key)
+  if ws is None or ws.numel() < floats:
+    ws = torch.empty(int(floats), dtype=torch.float32, device=device)
+    _WS[key] = ws
+  return ws
+
+
+def _noise_counter(device) -> Tensor:
+  if device not in _NOISE:
+    _NOISE[device] = torch.zeros(1, dtype=torch.int32, device=device)
+  return _NOISE[device]
+
+
+def _noise_seed() -> int:
+  return torch.initial_seed() & (2**64 - 1)
+
+
+def _f32(t: Optional[Tensor], device) -> Optional[Tensor]:
+  return None if t is None else t.to(device, torch.float32).contiguous()
+
+
+def sac_descriptor(actor: SoftActor, critic: TwinCritic, log_alpha: Tensor, target_critic: TwinCritic, batch_size: int, actor_optimiser: AdamW, critic_optimiser: AdamW,
+                   temperature_optimiser: Adam, discount: float, entropy_target: float, polyak_factor: float) -> _lib.Sac:
+  S, A, H, dev = actor.state_size, actor.action_size, actor.hidden, actor.flat.device
+  assert critic.hidden == H and log_alpha.is_cuda and log_alpha.dtype == torch.float32
+  floats = int(_lib.lib().il_sac_workspace_floats(S, A, H, batch_size))
+  ws = _workspace('sac', floats, dev)
+  d = _lib.Sac()
+  d.state_dim, d.action_dim, d.hidden, d.batch = S, A, H, batch_size
+  d.actor, d.critic, d.target, d.log_alpha = actor.flat.data_ptr(), critic.flat.data_ptr(), target_critic.flat.data_ptr(), log_alpha.data_ptr()
+  d.actor_grad, d.critic_grad, d.alpha_grad = actor_optimiser.grad.data_ptr(), critic_optimiser.grad.data_ptr(), temperature_optimiser.grad.data_ptr()
+  d.actor_opt, d.critic_opt, d.alpha_opt = actor_optimiser.desc(), critic_optimiser.desc(), temperature_optimiser.desc()
+  d.discount, d.entropy_target, d.polyak = float(discount), float(entropy_target), float(polyak_factor)
+  d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
+  d.noise_seed, d.noise_counter = _noise_seed(), _noise_counter(dev).data_ptr()
+  return d
+
+
+def sac_update(actor: SoftActor, critic: TwinCritic, log_alpha: Tensor, target_critic: TwinCritic, transitions: Dict[str, Tensor], actor_optimiser: AdamW,
+               critic_optimiser: AdamW, temperature_optimiser: Adam, discount: float, entropy_target: float, polyak_factor: float, *,
+               eps_next: Optional[Tensor] = None, eps_cur: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+  """One SAC update (reference training.py:14-54). Returns (log_probs[B], min(Q1,Q2)[B]) like the reference."""
+  dev = actor.flat.device
+  B = transitions['states'].size(0)
+  d = sac_descriptor(actor, critic, log_alpha, target_critic, B, actor_optimiser, critic_optimiser, temperature_optimiser, discount, entropy_target, polyak_factor)
+  b = batch_desc(transitions)
+  logp, q = torch.empty(B, device=dev), torch.empty(B, device=dev)
+  e1, e2 = _f32(eps_next, dev), _f32(eps_cur, dev)
+  _lib.check(_lib.lib().il_sac_update(C.byref(d), C.byref(b), _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(logp), _lib.ptr(q), 0, _lib.stream_ptr()))
+  return logp, q
+
+
+def behavioural_cloning_update(actor: SoftActor, expert_transition: Dict[str, Tensor], actor_optimiser: AdamW) -> Tensor:
+  """Reference training.py:57-64. Returns the (device) loss for logging; the reference returns None."""
+  dev = actor.flat.device
+  t = {k: v for k, v in expert_transition.items()}
+  for k in ('rewards', 'next_states', 'terminals', 'absorbing'):  # not read by k_bc_tile, but il_batch wants valid pointers
+    t.setdefault(k, t['weights'] if k != 'next_states' else t['states'])
+  b = batch_desc(t)
+  S, A, H, B = actor.state_size, actor.action_size, actor.hidden, b.n
+  floats = int(_lib.lib().il_sac_workspace_floats(S, A, H, B))
+  ws = _workspace('sac', floats, dev)
+  parts = torch.empty(B // 16, device=dev)
+  od = actor_optimiser.desc()
+  _lib.check(_lib.lib().il_bc_step(_lib.ptr(actor.flat), _lib.ptr(actor_optimiser.grad), C.byref(od), S, A, H, C.byref(b), _lib.ptr(ws), ws.numel(), _lib.ptr(parts), 0,
+                                   _lib.stream_ptr()))
+  return parts.sum() / B
+
+
+def target_estimation_update(discriminator, expert_transition, discriminator_optimiser):
+  raise NotImplementedError('RED (target_estimation_update) is outside the HIP hot path (SURVEY.md §8f-4)')
+
+
+# ----------------------------------------------------------------------------------------------- GAIL
+def disc_descriptor(disc: GAILDiscriminator, batch_size: int, opt: AdamW, imitation_cfg=None, grad_penalty: float = 0.0, entropy_bonus: float = 0.0) -> _lib.Disc:
+  dev = disc.flat.device
+  if imitation_cfg is not None:
+    if imitation_cfg.loss_function != 'BCE':
+      raise NotImplementedError(f'adversarial_imitation_update: loss_function={imitation_cfg.loss_function} is not implemented on the HIP path (BCE only)')
+    grad_penalty, entropy_bonus = float(imitation_cfg.grad_penalty), float(imitation_cfg.entropy_bonus)
+  floats = int(_lib.lib().il_disc_workspace_floats(disc.in_dim, disc.hidden, batch_size))
+  ws = _workspace('disc', floats, dev)
+  v = disc.views()
+  d = _lib.Disc()
+  d.state_dim, d.action_dim, d.hidden, d.batch = disc.state_size, disc.action_size, disc.hidden, batch_size
+  d.spectral_norm, d.state_only, d.reward_function = int(disc.spectral_norm), int(disc.state_only), REWARD_FUNCTIONS[disc.reward_function]
+  d.params, d.u1, d.v1, d.u2, d.v2 = disc.flat.data_ptr(), v['u1'].data_ptr(), v['v1'].data_ptr(), v['u2'].data_ptr(), v['v2'].data_ptr()
+  if opt is not None:
+    d.grad, d.opt = opt.grad.data_ptr(), opt.desc()
+  else:
+    d.grad = ws.data_ptr()  # reward only: never written
+  d.grad_penalty, d.entropy_bonus = grad_penalty, entropy_bonus
+  d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
+  d.noise_seed, d.noise_counter = _noise_seed(), _noise_counter(dev).data_ptr()
+  return d
+
+
+def adversarial_imitation_update(actor, discriminator: GAILDiscriminator, transitions: Dict[str, Tensor], expert_transitions: Dict[str, Tensor], discriminator_optimiser: AdamW,
+                                 imitation_cfg, *, eps_gp: Optional[Tensor] = None):
+  """Reference training.py:85-134 for loss_function=BCE (+ gradient penalty, spectral norm, entropy bonus)."""
+  B = transitions['states'].size(0)
+  d = disc_descriptor(discriminator, B, discriminator_optimiser, imitation_cfg)
+  pb, eb = batch_desc(transitions), batch_desc(expert_transitions)
+  e = _f32(eps_gp, discriminator.flat.device)
+  _lib.check(_lib.lib().il_gail_disc_step(C.byref(d), C.byref(pb), C.byref(eb), _lib.ptr(e), 0, _lib.stream_ptr()))
+
+
+def gail_predict_reward(disc: GAILDiscriminator, state: Tensor, action: Tensor, want_logits: bool = False):
+  dev = disc.flat.device
+  n = state.size(0)
+  d = disc_descriptor(disc, n, None)
+  dummy = torch.zeros(n, device=dev)
+  b = batch_desc(dict(states=state, actions=action, rewards=dummy, next_states=state, terminals=dummy, weights=dummy, absorbing=dummy))
+  out, logits = torch.empty(n, device=dev), (torch.empty(n, device=dev) if want_logits else None)
+  _lib.check(_lib.lib().il_gail_reward(C.byref(d), C.byref(b), _lib.ptr(out), _lib.ptr(logits), _lib.stream_ptr()))
+  return (out, logits) if want_logits else out
+
+
+# ----------------------------------------------------------------------------------------------- GMMIL
+def _weighted_median(x: Tensor, weights: Tensor) -> Tensor:
+  """Reference models.py:40-44 (first call only; a device sort of B^2 values)."""
+  x_sorted, indices = torch.sort(x.flatten())
+  w = (weights.flatten() / weights.sum())[indices]
+  return x_sorted[torch.min((torch.cumsum(w, dim=0) >= 0.5).nonzero())]
+
+
+def _sa_batch(state, action, weight):
+  dummy = weight
+  return batch_desc(dict(states=state, actions=action, rewards=dummy, next_states=state, terminals=dummy, weights=weight, absorbing=dummy))
+
+
+def gmmil_sqdist(disc: GMMILDiscriminator, a_state, a_action, b_state, b_action) -> Tensor:
+  dev = a_state.device
+  na, nb = a_state.size(0), b_state.size(0)
+  D = disc.state_size + (0 if disc.state_only else disc.action_size)
+  ws = _workspace('gmmil', int(_lib.lib().il_gmmil_workspace_floats(na, nb, D)), dev)
+  out = torch.empty(na, nb, device=dev)
+  wa, wb = torch.ones(na, device=dev), torch.ones(nb, device=dev)
+  ba, bb = _sa_batch(a_state, a_action, wa), _sa_batch(b_state, b_action, wb)
+  _lib.check(_lib.lib().il_gmmil_sqdist(C.byref(ba), C.byref(bb), disc.state_size, disc.action_size, int(disc.state_only), _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+  return out
+
+
+def gmmil_predict_reward(disc: GMMILDiscriminator, state, action, expert_state, expert_action, weight, expert_weight, return_parts: bool = False):
+  """Reference models.py:189-201."""
+  dev = state.device
+  if disc.gamma_1 is None:  # median heuristic, frozen after the first batch (models.py:193-195)
+    disc.gamma_1 = 1 / (_weighted_median(gmmil_sqdist(disc, state, action, expert_state, expert_action), torch.outer(weight, expert_weight)).item() + 1e-8)
+    disc.gamma_2 = 1 / (_weighted_median(gmmil_sqdist(disc, expert_state, expert_action, expert_state, expert_action), torch.outer(expert_weight, expert_weight)).item() + 1e-8)
+  n1, n2 = state.size(0), expert_state.size(0)
+  D = disc.state_size + (0 if disc.state_only else disc.action_size)
+  ws = _workspace('gmmil', int(_lib.lib().il_gmmil_workspace_floats(n1, n2, D)), dev)
+  out = torch.empty(n1, device=dev)
+  sim, self_sim = (torch.empty(n1, device=dev), torch.empty(n1, device=dev)) if return_parts else (None, None)
+  pb, eb = _sa_batch(state, action, weight), _sa_batch(expert_state, expert_action, expert_weight)
+  _lib.check(_lib.lib().il_gmmil_reward(C.byref(pb), C.byref(eb), disc.state_size, disc.action_size, int(disc.state_only), float(disc.gamma_1), float(disc.gamma_2),
+                                        _lib.ptr(out), _lib.ptr(sim), _lib.ptr(self_sim), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+  return (out, sim, self_sim) if return_parts else out
+
+
+# ----------------------------------------------------------------------------------------------- captured update
+class UpdatePlan:
+  """The per-step update block of the reference loop (train.py:173-203) for algorithm in {SAC, GAIL} with persistent buffers:
+  device-side index draws -> row gathers -> [discriminator step -> reward relabel] -> SAC update.  `run()` enqueues it eagerly;
+  `capture()` records it into a hipGraph (torch.cuda.CUDAGraph) that `replay()` launches with one host call."""
+
+  def __init__(self, algorithm: str, actor, critic, log_alpha, target_critic, memory: ReplayMemory, actor_optimiser, critic_optimiser, temperature_optimiser,
+               batch_size: int, discount: float, entropy_target: float, polyak_factor: float, expert_memory: Optional[ReplayMemory] = None, discriminator=None,
+               discriminator_optimiser=None, imitation_cfg=None, device_index_draw: bool = True):
+    assert algorithm in ('SAC', 'GAIL')
+    self.algorithm, self.B, dev = algorithm, batch_size, actor.flat.device
+    self.memory, self.expert_memory, self.device_index_draw = memory, expert_memory, device_index_draw
+    self.rows = torch.empty(batch_size, memory.row, device=dev); self.idx = torch.empty(batch_size, dtype=torch.int32, device=dev)
+    self.transitions = batch_views(self.rows, memory.state_size, memory.action_size, memory.absorbing)
+    self.logp, self.q = torch.empty(batch_size, device=dev), torch.empty(batch_size, device=dev)
+    self.sac = sac_descriptor(actor, critic, log_alpha, target_critic, batch_size, actor_optimiser, critic_optimiser, temperature_optimiser, discount, entropy_target, polyak_factor)
+    self._keep = (actor, critic, log_alpha, target_critic, actor_optimiser, critic_optimiser, temperature_optimiser, discriminator, discriminator_optimiser)
+    if algorithm == 'GAIL':
+      self.erows = torch.empty(batch_size, expert_memory.row, device=dev); self.eidx = torch.empty(batch_size, dtype=torch.int32, device=dev)
+      self.expert_transitions = batch_views(self.erows, expert_memory.state_size, expert_memory.action_size, expert_memory.absorbing)
+      self.disc = disc_descriptor(discriminator, batch_size, discriminator_optimiser, imitation_cfg)
+      self.eb = batch_desc(self.expert_transitions)
+      self.rewards = torch.empty(batch_size, device=dev)
+      self.transitions['rewards'] = self.rewards  # train.py:194: rewards replaced by the discriminator's prediction
+    self.pb = batch_desc(self.transitions)
+    self.graph = None
+
+  def _sample(self, mem: ReplayMemory, idx: Tensor, rows: Tensor):
+    if self.device_index_draw:
+      mem.sample_device(self.B, idx, rows)
+    else:
+      idx.copy_(mem._sample_idx_tensor(self.B))
+      _lib.check(_lib.lib().il_replay_gather(_lib.ptr(mem.ring), mem.size, mem.row, _lib.ptr(idx), self.B, _lib.ptr(rows), _lib.stream_ptr()))
+
+  def run(self):
+    L, st = _lib.lib(), _lib.stream_ptr()
+    self._sample(self.memory, self.idx, self.rows)
+    if self.algorithm == 'GAIL':
+      self._sample(self.expert_memory, self.eidx, self.erows)
+      _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, 0, st))
+      _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, st))
+    _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), 0, st))
+
+  def capture(self, warmup: int = 3):
+    assert self.device_index_draw, 'graph capture needs device-side index draws (no H2D inside the graph)'
+    from .memory import index_stream
+    index_stream().device_state(self.rows.device)  # materialise the device copy of the MT19937 state before capture starts
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+      for _ in range(warmup):
+        self.run()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    self.graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(self.graph):
+      self.run()
+    return self
+
+  def replay(self):
+    self.graph.replay()

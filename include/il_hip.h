@@ -1,0 +1,211 @@
+/* il_hip.h -- C ABI of libil_hip.so: the MI355X (gfx950) off-policy update hot path of
+ * Kaixhin/imitation-learning, rebuilt as hand-written HIP kernels.
+ *
+ * The reference has no FFI layer; its de-facto operator API is the set of Python callables
+ * train.py imports (reference train.py:13-18).  Each entry point below names the reference
+ * function it replaces (file:line under the reference repo).  The Python package mirrors the
+ * reference signatures on top of this ABI through ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a non-zero IL_ERR_* otherwise; il_last_error() gives text;
+ *   - all pointers are DEVICE pointers unless the parameter name ends in _host;
+ *   - nothing allocates, frees or synchronises: work is enqueued on `stream` (a hipStream_t) and is
+ *     hipGraph-capturable; buffers are owned by the caller (torch tensors in the Python host layer);
+ *   - all floating point is IEEE fp32 (parity target rtol 1e-5 vs the reference CPU path);
+ *   - networks are "depth 2" MLPs Linear(in,H)-ReLU-Linear(H,H)-ReLU-Linear(H,out) stored as ONE flat
+ *     fp32 vector in torch parameters() order: W1[H,in], b1[H], W2[H,H], b2[H], W3[out,H], b3[out]
+ *     (reference models.py:48-69), H a multiple of 64, H <= 256 (one workgroup tile keeps two [16 x H] activation slabs in LDS);
+ *   - Adam step counters live on the device (`il_adam.step[0]`): the gradient-producing entry point
+ *     increments it, so a captured graph replays with the right bias correction.
+ */
+#ifndef IL_HIP_H
+#define IL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IL_ABI_VERSION 1
+
+enum { IL_OK = 0, IL_ERR_ARG = 1, IL_ERR_UNSUPPORTED = 2, IL_ERR_HIP = 3, IL_ERR_WORKSPACE = 4 };
+
+/* flags */
+#define IL_FLAG_GRADS_ONLY 1u /* write gradients to the *_grad arenas and skip the optimiser (data-parallel: all-reduce, then il_adam_step) */
+#define IL_FLAG_TICK 2u       /* il_adam_step: increment the step counter first (stand-alone use) */
+
+typedef void* il_stream_t; /* hipStream_t */
+
+const char* il_last_error(void);
+int il_abi_version(void);
+/* device the library was built for / sees: writes arch name (e.g. "gfx950") */
+int il_device_info(char* name_host, int name_len, int* cu_count_host);
+
+/* Per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the roofline line).
+ * il_trace_enable(1) starts recording every kernel launched through this library (do not enable under graph capture);
+ * il_trace_report synchronises the device and writes "kernel_name launches total_ms" lines into buf_host. */
+int il_trace_enable(int on);
+int il_trace_report(char* buf_host, int len);
+
+/* ------------------------------------------------------------------------------------------
+ * A batch of transitions as strided fp32 fields: row b of field f is f + b*ld_f.
+ * Mirrors the `transitions` dict of reference memory.py:58-63 (keys states, actions, rewards,
+ * next_states, terminals, weights, absorbing); `step`/`timeouts` are not read by any kernel.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct il_batch {
+  const float *states, *actions, *rewards, *next_states, *terminals, *weights, *absorbing;
+  int32_t ld_states, ld_actions, ld_rewards, ld_next_states, ld_terminals, ld_weights, ld_absorbing;
+  int32_t n; /* rows */
+} il_batch;
+
+/* ------------------------------------------------------------------------------------------
+ * Replay ring (reference memory.py:12-68).  HBM layout: row-major [capacity][row] fp32 with
+ *   row = il_ring_row_floats(S, A) = roundup4(2S + A + 5) and fields at
+ *   states @0, actions @S, next_states @S+A, rewards @2S+A, terminals +1, timeouts +2, weights +3, step +4.
+ * A sampled batch is the same packed layout [n][row], so every il_batch field is a strided view.
+ * ------------------------------------------------------------------------------------------ */
+int32_t il_ring_row_floats(int32_t state_dim, int32_t action_dim);
+
+/* memory.py:40-44 `append` (n_rows consecutive slots starting at `cursor`, wrapping at capacity);
+ * rows_src is device-accessible memory (device or pinned host) holding n_rows packed rows. */
+int il_replay_write_rows(float* ring, int64_t capacity, int32_t row_floats, int64_t cursor, const float* rows_src, int32_t n_rows,
+                         il_stream_t stream);
+/* memory.py:65-68 `wrap_for_absorbing_states`: rewrites row `last` (next_state <- absorbing state, terminal <- 0)
+ * and writes the absorbing->absorbing row (step copied from `last`) at `cursor`. */
+int il_replay_wrap_absorbing(float* ring, int64_t capacity, int32_t state_dim, int32_t action_dim, int64_t last, int64_t cursor,
+                             il_stream_t stream);
+/* memory.py:58-63 `sample` gather step: out[i] = ring[idx[i]] for i < n (packed rows, coalesced 16-B lanes). */
+int il_replay_gather(const float* ring, int64_t capacity, int32_t row_floats, const int32_t* idx, int32_t n, float* out_rows,
+                     il_stream_t stream);
+
+/* memory.py:51-59 index draws, bit-exact with numpy's legacy MT19937 `np.random.randint(0, high)` stream plus the
+ * reference's rejection of slot (idx-1) % size.  HOST function; state_host = 625 uint32 (624 words + position). */
+int il_mt19937_seed(uint32_t* state_host, uint32_t seed);
+int il_mt19937_sample_indices(uint32_t* state_host, int32_t n, int64_t size, int64_t idx, int32_t full, int32_t* out_host);
+/* Same stream, generated ON the device (state_dev = 625 uint32 in HBM) so a captured update needs no H2D copy.
+ * ring_state_dev = {int64 idx, int64 full, int64 size}. */
+int il_mt19937_sample_indices_device(uint32_t* state_dev, const int64_t* ring_state_dev, int32_t n, int32_t* out_dev, il_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser state (torch.optim.AdamW / Adam single-tensor step; reference train.py:66,84,95).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct il_adam {
+  float *m, *v;  /* exp_avg, exp_avg_sq */
+  int32_t* step; /* device int32: number of steps taken */
+  float lr, beta1, beta2, eps, weight_decay; /* weight_decay != 0 => decoupled decay p *= 1 - lr*wd */
+} il_adam;
+
+/* p <- AdamW(p, g) elementwise for n parameters using t = *opt.step (after optional IL_FLAG_TICK). */
+int il_adam_step(float* p, const float* g, const il_adam* opt, int64_t n, uint32_t flags, il_stream_t stream);
+/* models.py:79-81 update_target_network: target <- tau*target + (1-tau)*param */
+int il_polyak(float* target, const float* param, int64_t n, float tau, il_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SAC (reference training.py:14-54 `sac_update`; models.py:84-141 SoftActor / TwinCritic).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct il_sac {
+  int32_t state_dim, action_dim, hidden, batch;
+  float *actor;     /* [Pa]   Pa = il_mlp_numel(S, H, 2A)                         */
+  float *critic;    /* [2*Ps] critic_1 | critic_2 at stride Ps = il_mlp_stride(S+A, H, 1) */
+  float *target;    /* [2*Ps] target critics, same layout                           */
+  float *log_alpha; /* [1]                                                        */
+  float *actor_grad, *critic_grad, *alpha_grad; /* [Pa], [2*Ps], [1]: filled when IL_FLAG_GRADS_ONLY */
+  il_adam actor_opt, critic_opt, alpha_opt;
+  float discount, entropy_target, polyak;
+  float* workspace;          /* >= il_sac_workspace_floats() floats */
+  int64_t workspace_floats;
+  uint64_t noise_seed;       /* Philox4x32-10 key when eps pointers are NULL */
+  uint32_t* noise_counter;   /* device uint32, incremented once per il_sac_actor_step */
+} il_sac;
+
+int64_t il_mlp_numel(int32_t in_dim, int32_t hidden, int32_t out_dim);
+/* distance in floats between consecutive networks of one arena (critic_1 -> critic_2): numel rounded up to 4 so that
+ * every network starts on a 16-byte boundary; the pad floats are never read as parameters. */
+int64_t il_mlp_stride(int32_t in_dim, int32_t hidden, int32_t out_dim);
+int64_t il_sac_workspace_floats(int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t batch);
+
+/* training.py:19-31: target values, twin-critic weighted MSE, backward, AdamW(critic).
+ * eps_next [B,A] = the N(0,1) draws of `policy.sample()` on s' (NULL => on-chip Philox). */
+int il_sac_critic_step(const il_sac* d, const il_batch* batch, const float* eps_next, uint32_t flags, il_stream_t stream);
+/* training.py:34-52: policy loss through the UPDATED critic, AdamW(actor), Adam(log_alpha), polyak.
+ * eps_cur [B,A] = rsample noise on s.  out_logp/out_q [B] = the (log_probs, Q_values) the reference returns (:54). */
+int il_sac_actor_step(const il_sac* d, const il_batch* batch, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags,
+                      il_stream_t stream);
+/* DP tail after the all-reduce of actor_grad/alpha_grad: AdamW(actor) + Adam(log_alpha) + polyak (same kernels, no recompute). */
+int il_sac_apply_actor_grads(const il_sac* d, il_stream_t stream);
+int il_sac_apply_critic_grads(const il_sac* d, il_stream_t stream);
+/* whole training.py:14-54 in one call (critic step then actor step) */
+int il_sac_update(const il_sac* d, const il_batch* batch, const float* eps_next, const float* eps_cur, float* out_logp, float* out_q,
+                  uint32_t flags, il_stream_t stream);
+
+/* training.py:57-64 behavioural_cloning_update + models.py:97-99 SoftActor.log_prob (clamp, atanh). */
+int il_bc_step(float* actor, float* actor_grad, const il_adam* opt, int32_t state_dim, int32_t action_dim, int32_t hidden,
+               const il_batch* batch, float* workspace, int64_t workspace_floats, float* out_loss_partials, uint32_t flags,
+               il_stream_t stream); /* workspace >= il_sac_workspace_floats(S,A,H,B); out_loss_partials [B/16] (sum/B = loss) or NULL */
+/* train.py:152 `actor(state).sample()` / models.py:101-102 get_greedy_action for n states: out_action [n,A].
+ * eps [n,A] or NULL (Philox with noise_seed/noise_offset); greedy != 0 => tanh(mean). out_logp may be NULL. */
+int il_actor_act(const float* actor, int32_t state_dim, int32_t action_dim, int32_t hidden, const float* states, int32_t ld_states,
+                 int32_t n, const float* eps, uint64_t noise_seed, uint32_t noise_offset, int32_t greedy, float* out_action,
+                 float* out_logp, il_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GAIL discriminator (reference training.py:85-134 adversarial_imitation_update with loss_function=BCE;
+ * models.py:152-180 GAILDiscriminator depth 1 + ReLU; torch _SpectralNorm: one power iteration per call).
+ * params order = discriminator.parameters(): spectral_norm ? {b1[H], W1[H,D], b2[1], W2[1,H]} : {W1, b1, W2, b2}.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct il_disc {
+  int32_t state_dim, action_dim, hidden, batch;
+  int32_t spectral_norm, state_only, reward_function; /* 0 AIRL, 1 GAIL, 2 FAIRL (models.py:177-180) */
+  float* params;             /* [P], P = H*D + H + H + 1, D = state_only ? S : S+A */
+  float *u1, *v1, *u2, *v2;  /* spectral-norm buffers [H],[D],[1],[H] (ignored when !spectral_norm) */
+  float* grad;               /* [P] summed gradient of the last step (always written) */
+  il_adam opt;
+  float grad_penalty, entropy_bonus;
+  float* workspace;
+  int64_t workspace_floats;
+  uint64_t noise_seed;
+  uint32_t* noise_counter;
+} il_disc;
+
+int64_t il_disc_workspace_floats(int32_t in_dim, int32_t hidden, int32_t batch);
+/* eps_gp [B] = the U(0,1) draw of training.py:118 (NULL => Philox). */
+int il_gail_disc_step(const il_disc* d, const il_batch* policy, const il_batch* expert, const float* eps_gp, uint32_t flags,
+                      il_stream_t stream);
+int il_gail_apply_grads(const il_disc* d, il_stream_t stream);
+/* models.py:177-180 predict_reward (eval mode: no power iteration). out_logits may be NULL. */
+int il_gail_reward(const il_disc* d, const il_batch* batch, float* out_rewards, float* out_logits, il_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GMMIL (reference models.py:25-44, 183-201): d(x,y) = mean_k (x_k-y_k)^2, two RBF bandwidths.
+ * ------------------------------------------------------------------------------------------ */
+int64_t il_gmmil_workspace_floats(int32_t n_policy, int32_t n_expert, int32_t dim);
+/* rewards[i] = sum_gamma w~_i sum_j K(x_i,e_j) w~e_j  -  w~_i sum_j K(x_i,x_j) w~_j ;  x = cat(state, action) (or state). */
+int il_gmmil_reward(const il_batch* policy, const il_batch* expert, int32_t state_dim, int32_t action_dim, int32_t state_only,
+                    float gamma_1, float gamma_2, float* out_rewards, float* out_similarity, float* out_self_similarity,
+                    float* workspace, int64_t workspace_floats, il_stream_t stream);
+/* models.py:25-28 _squared_distance matrix [na, nb] (used once for the median heuristic, models.py:193-195). */
+int il_gmmil_sqdist(const il_batch* a, const il_batch* b, int32_t state_dim, int32_t action_dim, int32_t state_only, float* out,
+                    float* workspace, int64_t workspace_floats, il_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PWIL (reference models.py:205-249): greedy Wasserstein coupling against the expert atoms.
+ * atoms are already standardised (scale*(x+offset)); weights[N] is the consumable mass.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct il_pwil {
+  int32_t n_atoms, dim, state_dim, action_dim;
+  const float* atoms;  /* [N, dim] */
+  float* weights;      /* [N]; <0 marks a consumed (deleted) atom */
+  float* dists;        /* [N] scratch */
+  const float *scale, *offset; /* [dim] */
+  double reward_scale, reward_bandwidth, agent_weight; /* Python-float hyper-parameters; agent_weight = 1/T - 1e-6 (models.py:235) */
+} il_pwil;
+int il_pwil_reset(const il_pwil* d, il_stream_t stream);
+/* compute_reward for one (state, action); writes the reward (double precision accumulate like the reference's Python floats) to out_reward[0]. */
+int il_pwil_reward(const il_pwil* d, const float* state, const float* action, float* out_reward, il_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IL_HIP_H */

@@ -1,0 +1,98 @@
+"""Helpers shared by the `-m gpu` parity tests: move oracle state into the HIP-side objects and compare."""
+import numpy as np
+import torch
+
+import imitation_learning_amd as il
+from imitation_learning_amd import memory as il_memory
+from oracle import gail as ogail
+from oracle import sac as osac
+
+
+class Cfg(dict):
+  __getattr__ = dict.__getitem__
+
+
+DEV = 'cuda'
+
+
+def T(a):
+  return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+  return t.detach().cpu().numpy().copy()
+
+
+def excess(a, b, rtol):
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  return float((np.abs(a - b) - rtol * np.abs(b)).max())
+
+
+def close(a, b, name, rtol=1e-5, atol_scale=2e-6):
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  assert a.shape == b.shape, (name, a.shape, b.shape)
+  assert np.isfinite(a).all(), f'{name}: non-finite values in the HIP result'
+  atol = atol_scale * max(float(np.abs(b).max()), 1e-30)
+  err = np.abs(a - b) - rtol * np.abs(b)
+  i = int(err.argmax())
+  assert float(err.max()) <= atol, f'{name}: max excess err {err.max():.3e} > atol {atol:.3e} at flat index {i} (hip {a.ravel()[i]:.8e} vs oracle {b.ravel()[i]:.8e})'
+
+
+def tbatch(b):
+  return {k: T(v) for k, v in b.items()}
+
+
+def crit_to_flat(critic_mod, packed):
+  """oracle layout [critic_1 | critic_2] (no padding) -> arena with il_mlp_stride padding."""
+  Pc, st = packed.size // 2, critic_mod.net_stride
+  flat = np.zeros(2 * st, np.float32)
+  flat[:Pc], flat[st:st + Pc] = packed[:Pc], packed[Pc:]
+  return T(flat)
+
+
+def crit_from_flat(critic_mod, flat_t):
+  f = N(flat_t)
+  st = critic_mod.net_stride
+  Pc = sum(p.numel() for p in critic_mod.critic_1.parameters())
+  return np.concatenate([f[:Pc], f[st:st + Pc]])
+
+
+def make_sac(c):
+  """HIP-side SAC objects initialised from a golden/inputs.py case dict."""
+  cfg = Cfg(hidden_size=c['H'], depth=2, activation='relu')
+  actor, critic = il.SoftActor(c['S'], c['A'], cfg, device=DEV), il.TwinCritic(c['S'], c['A'], cfg, device=DEV)
+  actor.flat.copy_(T(c['actor'])); critic.flat.copy_(crit_to_flat(critic, c['critic']))
+  target = il.create_target_network(critic)
+  target.flat.copy_(crit_to_flat(critic, c['target']))
+  log_alpha = T(c['log_alpha'].copy())
+  ao = il.AdamW(actor, lr=c['lr'], weight_decay=c['weight_decay']); co = il.AdamW(critic, lr=c['lr'], weight_decay=c['weight_decay']); to = il.Adam(log_alpha, lr=c['lr'])
+  return actor, critic, target, log_alpha, ao, co, to
+
+
+def make_sac_oracle(c):
+  st = osac.SacState(c['S'], c['A'], c['H'])
+  st.actor[:], st.critic[:], st.target[:], st.log_alpha[:] = c['actor'], c['critic'], c['target'], c['log_alpha']
+  return st
+
+
+def make_disc(c, reward_function='AIRL'):
+  icfg = Cfg(state_only=False, spectral_norm=c['spectral_norm'],
+             discriminator=Cfg(hidden_size=c['H'], depth=1, activation='relu', reward_shaping=False, subtract_log_policy=False, reward_function=reward_function))
+  d = il.GAILDiscriminator(c['S'], c['A'], icfg, 0.97, device=DEV)
+  ods = ogail.DiscState(c['D'], c['H'], c['spectral_norm'])
+  for k in ('W1', 'b1', 'W2', 'b2', 'u1', 'v1', 'u2', 'v2'):
+    getattr(ods, k)[...] = c[k]
+  d.flat.copy_(T(ods.pack()))
+  if c['spectral_norm']:
+    v = d.views()
+    for k in ('u1', 'v1', 'u2', 'v2'):
+      v[k].copy_(T(c[k]))
+  return d, ods, icfg
+
+
+def fill_memory(mem, tr, n):
+  for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'timeouts', 'weights'):
+    getattr(mem, k)[:n] = T(tr[k][:n])
+  mem.step[:n] = torch.arange(1, n + 1, dtype=torch.float32, device=DEV)
+  mem.idx, mem.full = n % mem.size, n == mem.size
+  mem._sync_ring_state()

@@ -1,0 +1,358 @@
+"""`-m gpu` parity tests: the HIP path (through the C ABI, via the Python host layer) against the numpy oracle on the same
+seeded inputs, and against the committed reference-generated golden vectors.  Tolerances: rtol 1e-5 (north_star) plus an absolute
+floor relative to each tensor's scale; bit-exact for index draws and replay rows.  /root/reference is never touched here."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import inputs as gi
+from oracle import gail as ogail
+from oracle import gmmil as ogmmil
+from oracle import nets as onets
+from oracle import pwil as opwil
+from oracle import replay as oreplay
+from oracle import sac as osac
+from oracle.mt19937 import MT19937, sample_indices
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+  import imitation_learning_amd as il
+  from imitation_learning_amd import _lib
+  from imitation_learning_amd import memory as il_memory
+  from imitation_learning_amd import training as il_training
+  from gpu_util import DEV, N, T, Cfg, close, crit_from_flat, fill_memory, make_disc, make_sac, make_sac_oracle, tbatch
+
+
+def load(golden_dir, name):
+  return np.load(os.path.join(golden_dir, name + '.npz'), allow_pickle=False)
+
+
+def test_native_library_loaded():
+  name = C.create_string_buffer(64); cu = C.c_int(0)
+  _lib.check(_lib.lib().il_device_info(name, 64, C.byref(cu)))
+  assert name.value.decode().startswith('gfx950'), name.value
+  assert cu.value == 256
+
+
+# ------------------------------------------------------------------------------------------------ replay
+@pytest.mark.parametrize('name,seed,size,fill', [('partial', 0, 1000, 300), ('wrapped', 1, 64, 150), ('expert', 2, 500, None)])
+def test_replay_matches_reference_bit_exact(golden_dir, name, seed, size, fill):
+  g = load(golden_dir, 'replay')
+  S, A = 5, 2
+  rs = np.random.RandomState(100 + seed)
+  if fill is None:
+    tr = gi.transitions(rs, size, S, A)
+    mem = il.ReplayMemory(size, S, A, True, transitions={**{k: torch.from_numpy(v) for k, v in tr.items() if k != 'absorbing'}, 'num_trajectories': 3}, device=DEV)
+  else:
+    mem = il.ReplayMemory(size, S, A, True, device=DEV)
+    tr = gi.transitions(rs, fill, S, A)
+    for i in range(fill):
+      if i % 2:  # exercise both the host-staged and the device-resident append paths
+        mem.append(i + 1, torch.from_numpy(tr['states'][i:i + 1]), torch.from_numpy(tr['actions'][i:i + 1]), float(tr['rewards'][i]), torch.from_numpy(tr['next_states'][i:i + 1]), bool(tr['terminals'][i]), False)
+      else:
+        mem.append(i + 1, T(tr['states'][i:i + 1]), T(tr['actions'][i:i + 1]), float(tr['rewards'][i]), T(tr['next_states'][i:i + 1]), bool(tr['terminals'][i]), False)
+      if i % 37 == 36:
+        mem.wrap_for_absorbing_states()
+  assert [mem.idx, int(mem.full), mem.num_trajectories, mem.size] == g[f'{name}_state'].tolist()
+  for k in oreplay.FIELDS:
+    np.testing.assert_array_equal(N(getattr(mem, k))[:min(size, 200)], g[f'{name}_mem_{k}'], err_msg=k)
+  il.seed(seed)
+  np.testing.assert_array_equal(mem._sample_idx_tensor(256).numpy(), g[f'{name}_idx'])
+  il.seed(seed)
+  batch = mem.sample(32)
+  for k, v in batch.items():
+    np.testing.assert_array_equal(N(v), g[f'{name}_batch_{k}'], err_msg=k)
+  # device-side draw: same stream, same rejection rule, across several calls (twist boundaries included)
+  il.seed(seed)
+  gen = MT19937(seed)
+  idx_out, rows_out = torch.empty(300, dtype=torch.int32, device=DEV), torch.empty(300, mem.row, device=DEV)
+  for call in range(6):
+    mem.sample_device(300, idx_out, rows_out)
+    want = sample_indices(gen, 300, mem.size, mem.idx, mem.full)
+    np.testing.assert_array_equal(N(idx_out), np.array(want), err_msg=f'device draw, call {call}')
+    np.testing.assert_array_equal(N(rows_out), N(mem.ring)[np.array(want)])
+
+
+def test_replay_full_size_gather_property():
+  """BASELINE size (capacity 1e6, HalfCheetah rows): gather == fancy indexing, checked through a checksum of every field."""
+  S, A = gi.DIMS['halfcheetah']
+  mem = il.ReplayMemory(1_000_000, S, A, True, device=DEV)
+  mem.ring.copy_(torch.randn(mem.ring.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(0)))
+  mem.idx, mem.full = 123_457, True
+  mem._sync_ring_state()
+  il.seed(7)
+  idx = mem._sample_idx_tensor(4096)
+  assert int(idx.max()) < 1_000_000 and int(idx.min()) >= 0 and 123_456 not in idx.tolist()
+  rows = mem.gather(idx)
+  assert torch.equal(rows, mem.ring[idx.to(DEV).long()])
+
+
+# ------------------------------------------------------------------------------------------------ SAC
+SAC_CASES = [('sac_halfcheetah', (3, 'halfcheetah', 256, 256, 3)), ('sac_hopper_h64', (4, 'hopper', 64, 96, 3)), ('sac_ant_b64', (5, 'ant', 256, 64, 2))]
+
+
+@pytest.mark.parametrize('name,args', SAC_CASES)
+def test_sac_update_matches_oracle_and_reference(golden_dir, name, args):
+  g, c = load(golden_dir, name), gi.sac_case(*args)
+  actor, critic, target, log_alpha, ao, co, to = make_sac(c)
+  st = make_sac_oracle(c)
+  for k in range(1, args[-1] + 1):
+    b = c['batches'][k - 1]
+    logp, q = il.sac_update(actor, critic, log_alpha, target, tbatch(b), ao, co, to, c['discount'], c['entropy_target'], c['polyak'], eps_next=T(c['eps_next'][k - 1]),
+                            eps_cur=T(c['eps_cur'][k - 1]))
+    ologp, oq = osac.sac_update(st, b, c['eps_next'][k - 1], c['eps_cur'][k - 1], discount=c['discount'], entropy_target=c['entropy_target'], polyak_factor=c['polyak'],
+                                lr=c['lr'], weight_decay=c['weight_decay'])
+    torch.cuda.synchronize()
+    s = 1e-5 * k
+    close(N(logp), ologp, f'logp step {k}', atol_scale=2e-6 * k); close(N(q), oq, f'q step {k}', atol_scale=2e-6 * k)
+    close(N(actor.flat), st.actor, f'actor step {k}', atol_scale=s); close(crit_from_flat(critic, critic.flat), st.critic, f'critic step {k}', atol_scale=s)
+    close(crit_from_flat(critic, target.flat), st.target, f'target step {k}', atol_scale=s); close(N(log_alpha), st.log_alpha, f'log_alpha step {k}')
+    close(N(ao.exp_avg), st.actor_m, f'actor m step {k}', atol_scale=s); close(N(ao.exp_avg_sq), st.actor_v, f'actor v step {k}', atol_scale=s)
+    close(crit_from_flat(critic, co.exp_avg), st.critic_m, f'critic m step {k}', atol_scale=s)
+    # and against the reference-generated vectors directly
+    close(N(logp), g[f'logp_{k}'], f'golden logp {k}', atol_scale=2e-6 * k); close(N(q), g[f'q_{k}'], f'golden q {k}', atol_scale=2e-6 * k)
+    close(gi.strided(N(actor.flat)), g[f'actor_{k}'], f'golden actor {k}', atol_scale=s)
+    close(gi.strided(crit_from_flat(critic, critic.flat)), g[f'critic_{k}'], f'golden critic {k}', atol_scale=s)
+    close(gi.strided(crit_from_flat(critic, target.flat)), g[f'target_{k}'], f'golden target {k}', atol_scale=s)
+    close(N(log_alpha), g[f'log_alpha_{k}'], f'golden log_alpha {k}')
+  assert int(ao.step_count[0]) == args[-1] and int(co.step_count[0]) == args[-1] and int(to.step_count[0]) == args[-1]
+
+
+@pytest.mark.parametrize('name,args', SAC_CASES[:2])
+def test_sac_gradients_match_oracle(golden_dir, name, args):
+  """IL_FLAG_GRADS_ONLY path (what the data-parallel all-reduce sees): gradients as tensors, then the split Adam tail == fused."""
+  g, c = load(golden_dir, name), gi.sac_case(*args)
+  actor, critic, target, log_alpha, ao, co, to = make_sac(c)
+  st = make_sac_oracle(c)
+  b = c['batches'][0]
+  _, _, gr = osac.sac_update(st, b, c['eps_next'][0], c['eps_cur'][0], discount=c['discount'], entropy_target=c['entropy_target'], polyak_factor=c['polyak'], lr=c['lr'],
+                             weight_decay=c['weight_decay'], return_grads=True)
+  d = il_training.sac_descriptor(actor, critic, log_alpha, target, c['B'], ao, co, to, c['discount'], c['entropy_target'], c['polyak'])
+  bd = il_memory.batch_desc(tbatch(b))
+  tb = tbatch(b); bd = il_memory.batch_desc(tb)
+  L, s = _lib.lib(), _lib.stream_ptr()
+  logp, q = torch.empty(c['B'], device=DEV), torch.empty(c['B'], device=DEV)
+  e1, e2 = T(c['eps_next'][0]), T(c['eps_cur'][0])
+  _lib.check(L.il_sac_critic_step(C.byref(d), C.byref(bd), _lib.ptr(e1), _lib.IL_FLAG_GRADS_ONLY, s))
+  close(crit_from_flat(critic, co.grad), gr['critic'], 'critic grad'); close(gi.strided(crit_from_flat(critic, co.grad)), g['g_critic_1'], 'golden critic grad')
+  _lib.check(L.il_sac_apply_critic_grads(C.byref(d), s))
+  _lib.check(L.il_sac_actor_step(C.byref(d), C.byref(bd), _lib.ptr(e2), _lib.ptr(logp), _lib.ptr(q), _lib.IL_FLAG_GRADS_ONLY, s))
+  close(N(ao.grad), gr['actor'], 'actor grad'); close(gi.strided(N(ao.grad)), g['g_actor_1'], 'golden actor grad')
+  close(N(to.grad), gr['alpha'], 'alpha grad'); close(N(to.grad), g['g_alpha_1'], 'golden alpha grad')
+  _lib.check(L.il_sac_apply_actor_grads(C.byref(d), s))
+  torch.cuda.synchronize()
+  close(N(actor.flat), st.actor, 'actor after split step', atol_scale=1e-5); close(crit_from_flat(critic, critic.flat), st.critic, 'critic after split step', atol_scale=1e-5)
+  close(crit_from_flat(critic, target.flat), st.target, 'target after split step', atol_scale=1e-5); close(N(log_alpha), st.log_alpha, 'log_alpha after split step')
+
+
+def test_bc_update_matches_oracle_and_reference(golden_dir):
+  g = load(golden_dir, 'bc_hopper')
+  S, A = gi.DIMS['hopper']
+  rs = np.random.RandomState(7)
+  p = gi.mlp_params(rs, S, 256, 2, 2 * A, out_scale=0.3)
+  actor = il.SoftActor(S, A, Cfg(hidden_size=256, depth=2, activation='relu'), device=DEV)
+  actor.flat.copy_(T(p))
+  opt = il.AdamW(actor, lr=2.5e-4, weight_decay=0.01)
+  m, v = np.zeros_like(p), np.zeros_like(p)
+  shapes = onets.mlp_shapes(S, 256, 2, 2 * A)
+  for k in range(1, 4):
+    b = gi.transitions(rs, 256, S, A, weighted=True)
+    b['actions'][:3] = np.array([1.0, -1.0, 0.9999999])[:, None]
+    loss = il.behavioural_cloning_update(actor, tbatch(b), opt)
+    oloss = osac.bc_update(p, m, v, k, shapes, A, b, lr=2.5e-4, weight_decay=0.01)
+    close(N(loss), oloss, f'bc loss {k}', rtol=1e-5, atol_scale=1e-5)
+    close(N(actor.flat), p, f'bc actor {k}', atol_scale=1e-5 * k); close(N(opt.exp_avg), m, f'bc m {k}', atol_scale=1e-5 * k)
+    close(gi.strided(N(actor.flat)), g[f'actor_{k}'], f'golden bc actor {k}', atol_scale=1e-5 * k)
+    close(N(actor.log_prob(T(b['states']), T(b['actions']))), g[f'logp_{k}'], f'golden bc logp {k}', rtol=1e-4, atol_scale=1e-5)
+
+
+def test_actor_act_matches_oracle():
+  c = gi.sac_case(3, 'halfcheetah', 256, 256, 1)
+  actor = make_sac(c)[0]
+  for n in (1, 5, 16, 37):
+    s, eps = c['batches'][0]['states'][:n], c['eps_cur'][0][:n]
+    out, _ = onets.mlp_forward(onets.unpack(c['actor'], onets.mlp_shapes(c['S'], c['H'], 2, 2 * c['A'])), s)
+    mean, _, _, std = onets.actor_head(out, c['A'])
+    x = mean + eps * std
+    a, lp = actor(T(s)).sample_with_log_prob(T(eps))
+    close(N(a), np.tanh(x), f'act sample n={n}', atol_scale=4e-6); close(N(lp), onets.tanh_gaussian_logp(x, mean, std), f'act logp n={n}', atol_scale=4e-6)
+    close(N(actor.get_greedy_action(T(s))), np.tanh(mean), f'greedy n={n}', atol_scale=4e-6)
+  # Philox path: finite, in (-1, 1), reproducible distribution moments
+  a = actor(T(c['batches'][0]['states'])).sample()
+  assert torch.isfinite(a).all() and float(a.abs().max()) < 1.0
+
+
+def test_adam_and_polyak_kernels():
+  rs = np.random.RandomState(0)
+  n = 100_003
+  p, gr = rs.standard_normal(n).astype(np.float32), (rs.standard_normal(n) * rs.uniform(1e-6, 1, n)).astype(np.float32)
+  m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
+  pt = T(p.copy())
+  opt = il.AdamW(pt, lr=3e-4, weight_decay=0.1)
+  for t in range(1, 4):
+    opt.step(T(gr * t))
+    onets.adam_step(p, gr * t, m, v, t, 3e-4, 0.1)
+    np.testing.assert_allclose(N(pt), p, rtol=2e-7, atol=1e-9); np.testing.assert_allclose(N(opt.exp_avg_sq), v, rtol=2e-7, atol=0)
+  tgt = rs.standard_normal(n).astype(np.float32)
+  tt = T(tgt.copy())
+  _lib.check(_lib.lib().il_polyak(_lib.ptr(tt), _lib.ptr(pt), n, 0.995, _lib.stream_ptr()))
+  onets.polyak(tgt, p, 0.995)
+  np.testing.assert_allclose(N(tt), tgt, rtol=2e-7, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------ GAIL
+GAIL_CASES = [
+    ('gail_default', dict(seed=31), dict(lr=3e-5, weight_decay=10, grad_penalty=1.0, entropy_bonus=0.0)),
+    ('gail_h128_ent', dict(seed=32, hidden=128), dict(lr=7.3e-5, weight_decay=6.35, grad_penalty=0.32, entropy_bonus=0.0155)),
+    ('gail_nosn_nogp', dict(seed=33, env='hopper', hidden=32, batch=128, spectral_norm=False), dict(lr=3e-4, weight_decay=0.0, grad_penalty=0.0, entropy_bonus=0.0)),
+]
+
+
+@pytest.mark.parametrize('name,case,hp', GAIL_CASES)
+def test_gail_update_matches_oracle_and_reference(golden_dir, name, case, hp):
+  g, c = load(golden_dir, name), gi.gail_case(**case)
+  d, ods, icfg = make_disc(c)
+  icfg.update(loss_function='BCE', grad_penalty=hp['grad_penalty'], entropy_bonus=hp['entropy_bonus'], mixup_alpha=1, pos_class_prior=0.7, nonnegative_margin=float('inf'))
+  opt = il.AdamW(d, lr=hp['lr'], weight_decay=hp['weight_decay'])
+  cat = lambda b: np.concatenate([b['states'], b['actions']], axis=1)
+  for k in range(1, len(c['policy']) + 1):
+    pb, eb = c['policy'][k - 1], c['expert'][k - 1]
+    d.train()
+    il.adversarial_imitation_update(None, d, tbatch(pb), tbatch(eb), opt, icfg, eps_gp=T(c['eps'][k - 1]))
+    d.eval()
+    ogr = ogail.gail_update(ods, cat(pb), pb['weights'], cat(eb), eb['weights'], c['eps'][k - 1], return_grads=True, **hp)
+    close(N(opt.grad), ogr, f'disc grad {k}', atol_scale=4e-6 * k); close(N(opt.grad), g[f'g_{k}'], f'golden disc grad {k}', atol_scale=4e-6 * k)
+    close(N(d.flat), ods.pack(), f'disc params {k}', atol_scale=4e-6 * k); close(N(d.flat), g[f'p_{k}'], f'golden disc params {k}', atol_scale=4e-6 * k)
+    close(N(opt.exp_avg), ods.m, f'disc m {k}', atol_scale=4e-6 * k); close(N(opt.exp_avg_sq), ods.v, f'disc v {k}', atol_scale=4e-6 * k)
+    if c['spectral_norm']:
+      for nm, val in d.views().items():
+        close(N(val), getattr(ods, nm), f'{nm} {k}'); close(N(val), g[f'{nm}_{k}'], f'golden {nm} {k}')
+    for rf in ('AIRL', 'GAIL', 'FAIRL'):
+      d.reward_function = rf
+      r = d.predict_reward(T(pb['states']), T(pb['actions']))
+      close(N(r), ogail.predict_reward(ods, cat(pb), rf), f'reward {rf} {k}', rtol=1e-4, atol_scale=1e-5)
+      close(N(r), g[f'reward_{rf}_{k}'], f'golden reward {rf} {k}', rtol=1e-4, atol_scale=1e-5)
+    d.reward_function = 'AIRL'
+    close(N(d(T(pb['states']), T(pb['actions']))), g[f'logits_{k}'], f'golden logits {k}', atol_scale=4e-6)
+
+
+# ------------------------------------------------------------------------------------------------ GMMIL / PWIL
+@pytest.mark.parametrize('name,dims', [('small', (64, 48, 24)), ('ant', (256, 256, 120))])
+def test_gmmil_matches_oracle_and_reference(golden_dir, name, dims):
+  g = load(golden_dir, 'gmmil')
+  X, E, w, we = gi.gmmil_case(11, *dims)
+  D = dims[2]
+  S = D - 8 if D > 8 else D - 2
+  disc = il.GMMILDiscriminator(S, D - S, Cfg(state_only=False))
+  args = (T(X[:, :S]), T(X[:, S:]), T(E[:, :S]), T(E[:, S:]), T(w), T(we))
+  close(N(il_training.gmmil_sqdist(disc, *args[:4]))[:16], g[f'{name}_sqdist_xe'], 'sqdist')
+  r, sim, self_sim = il_training.gmmil_predict_reward(disc, *args, return_parts=True)
+  np.testing.assert_allclose([disc.gamma_1, disc.gamma_2], g[f'{name}_gammas'], rtol=1e-5)
+  _, osim, oself = ogmmil.gmmil_reward(X, E, w, we, disc.gamma_1, disc.gamma_2, return_parts=True)
+  close(N(sim), osim, 'similarity'); close(N(self_sim), oself, 'self similarity')
+  assert np.abs(N(r) - g[f'{name}_reward_first']).max() <= 1e-5 * np.abs(osim).max()
+  X2, _, w2, _ = gi.gmmil_case(12, *dims)
+  r2 = disc.predict_reward(T(X2[:, :S]), T(X2[:, S:]), args[2], args[3], T(w2), args[5])
+  assert np.abs(N(r2) - g[f'{name}_reward_second']).max() <= 1e-5 * np.abs(osim).max()
+
+
+def test_gmmil_full_size_properties():
+  """BASELINE config 4 (B=1024, Ant dims D=120): permutation equivariance and a row-subset check against the oracle."""
+  X, E, w, we = gi.gmmil_case(5, 1024, 1024, 120, weighted=True)
+  disc = il.GMMILDiscriminator(112, 8, Cfg(state_only=False))
+  disc.gamma_1, disc.gamma_2 = 0.37, 0.91
+  f = lambda X_, w_: il_training.gmmil_predict_reward(disc, T(X_[:, :112]), T(X_[:, 112:]), T(E[:, :112]), T(E[:, 112:]), T(w_), T(we), return_parts=True)
+  r, sim, self_sim = f(X, w)
+  perm = np.random.RandomState(0).permutation(1024)
+  rp, simp, selfp = f(X[perm], w[perm])
+  close(N(simp), N(sim)[perm], 'perm similarity', atol_scale=4e-6); close(N(selfp), N(self_sim)[perm], 'perm self similarity', atol_scale=4e-6)
+  # the oracle on 64 query rows against the full sets (self term needs all rows: use the oracle's chunked distance)
+  wn, wen = w / w.sum(dtype=np.float32), we / we.sum(dtype=np.float32)
+  rows = perm[:64]
+  dxe, dxx = ogmmil.squared_distance(X[rows], E), ogmmil.squared_distance(X[rows], X)
+  osim = sum(wn[rows] * (np.exp(np.float32(-gm) * dxe) @ wen) for gm in (0.37, 0.91))
+  oself = sum(wn[rows] * (np.exp(np.float32(-gm) * dxx) @ wn) for gm in (0.37, 0.91))
+  close(N(sim)[rows], osim, 'full-size similarity'); close(N(self_sim)[rows], oself, 'full-size self similarity')
+
+
+def test_pwil_matches_oracle_and_reference(golden_dir):
+  g = load(golden_dir, 'pwil')
+  Nn, D, steps, Th = 400, 10, 260, 120
+  atoms, agent = gi.pwil_case(21, Nn, D, steps)
+  S, A = D - 3, 3
+  mem = il.ReplayMemory(Nn, S, A, False, transitions=dict(states=torch.from_numpy(atoms[:, :S]), actions=torch.from_numpy(atoms[:, S:]), rewards=torch.zeros(Nn),
+                                                          next_states=torch.from_numpy(atoms[:, :S]), terminals=torch.zeros(Nn), timeouts=torch.zeros(Nn), weights=torch.ones(Nn),
+                                                          num_trajectories=4), device=DEV)
+  d = il.PWILDiscriminator(S, A, Cfg(state_only=False, reward_scale=5, reward_bandwidth_scale=5), mem, Th)
+  close(N(d.data_scale), g['scale'], 'scale'); close(N(d.data_offset), g['offset'], 'offset')
+  o = opwil.PwilOracle(atoms, Th, 5, 5)
+  rewards, orewards = [], []
+  for t in range(steps):
+    rewards.append(d.compute_reward(T(agent[t:t + 1, :S]), T(agent[t:t + 1, S:])))
+    orewards.append(o.compute_reward(agent[t]))
+    if t % Th == Th - 1:
+      d.reset(); o.reset()
+  np.testing.assert_allclose(rewards, orewards, rtol=2e-5)
+  np.testing.assert_allclose(rewards, g['rewards'], rtol=2e-5)
+  assert int((d.expert_weights >= 0).sum()) == int(g['remaining'][0])
+
+
+# ------------------------------------------------------------------------------------------------ whole update block
+def _make_plan(algorithm, seed, device_draw=True):
+  S, A = gi.DIMS['halfcheetah']
+  B = 256
+  torch.manual_seed(seed)
+  cfg = Cfg(hidden_size=256, depth=2, activation='relu')
+  actor, critic = il.SoftActor(S, A, cfg, device=DEV), il.TwinCritic(S, A, cfg, device=DEV)
+  target, log_alpha = il.create_target_network(critic), torch.zeros(1, device=DEV)
+  ao, co, to = il.AdamW(actor, lr=3e-4, weight_decay=0), il.AdamW(critic, lr=3e-4, weight_decay=0), il.Adam(log_alpha, lr=3e-4)
+  rs = np.random.RandomState(seed)
+  mem = il.ReplayMemory(20000, S, A, True, device=DEV); fill_memory(mem, gi.transitions(rs, 5000, S, A), 5000)
+  emem = il.ReplayMemory(2000, S, A, True, device=DEV); fill_memory(emem, gi.transitions(rs, 2000, S, A, state_shift=0.5), 2000)
+  icfg = Cfg(state_only=False, spectral_norm=True, loss_function='BCE', grad_penalty=1.0, entropy_bonus=0.0,
+             discriminator=Cfg(hidden_size=64, depth=1, activation='relu', reward_shaping=False, subtract_log_policy=False, reward_function='AIRL'))
+  disc = il.GAILDiscriminator(S, A, icfg, 0.97, device=DEV)
+  do = il.AdamW(disc, lr=3e-5, weight_decay=10)
+  plan = il.UpdatePlan(algorithm, actor, critic, log_alpha, target, mem, ao, co, to, B, 0.97, -0.5 * A, 0.99, expert_memory=emem, discriminator=disc, discriminator_optimiser=do,
+                       imitation_cfg=icfg, device_index_draw=device_draw)
+  return plan, (actor, critic, target, log_alpha, disc)
+
+
+@pytest.mark.parametrize('algorithm', ['SAC', 'GAIL'])
+def test_update_plan_graph_replay_equals_eager(algorithm):
+  """A captured hipGraph of the whole update must evolve the learner exactly like eager launches (same Philox counters, same MT stream)."""
+  results = []
+  for mode in ('eager', 'graph'):
+    il.seed(11)
+    il_training._NOISE.clear()
+    plan, nets = _make_plan(algorithm, 5)
+    if mode == 'graph':
+      plan.capture(warmup=0)   # capture itself does not execute kernels
+      for _ in range(5):
+        plan.replay()
+    else:
+      for _ in range(5):
+        plan.run()
+    torch.cuda.synchronize()
+    results.append([N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [N(plan.idx), N(plan.logp)])
+  for a, b in zip(*results):
+    assert np.isfinite(a).all()
+    np.testing.assert_array_equal(a, b)
+
+
+def test_update_plan_host_and_device_index_draws_agree():
+  outs = []
+  for device_draw in (True, False):
+    il.seed(3)
+    il_training._NOISE.clear()
+    plan, nets = _make_plan('GAIL', 9, device_draw)
+    for _ in range(3):
+      plan.run()
+    torch.cuda.synchronize()
+    outs.append((N(plan.idx), N(plan.eidx), N(nets[0].flat)))
+  for a, b in zip(*outs):
+    np.testing.assert_array_equal(a, b)
