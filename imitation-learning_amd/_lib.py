@@ -21,8 +21,8 @@ class Batch(C.Structure):
 
 
 class Adam(C.Structure):
-  _fields_ = [('m', C.c_void_p), ('v', C.c_void_p), ('step', C.c_void_p), ('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
-              ('weight_decay', C.c_float)]
+  _fields_ = [('m', C.c_void_p), ('v', C.c_void_p), ('step', C.c_void_p), ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double),
+              ('weight_decay', C.c_double)]
 
 
 class Sac(C.Structure):
@@ -30,7 +30,7 @@ class Sac(C.Structure):
               ('actor', C.c_void_p), ('critic', C.c_void_p), ('target', C.c_void_p), ('log_alpha', C.c_void_p),
               ('actor_grad', C.c_void_p), ('critic_grad', C.c_void_p), ('alpha_grad', C.c_void_p),
               ('actor_opt', Adam), ('critic_opt', Adam), ('alpha_opt', Adam),
-              ('discount', C.c_float), ('entropy_target', C.c_float), ('polyak', C.c_float),
+              ('discount', C.c_float), ('entropy_target', C.c_float), ('polyak', C.c_double),
               ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p)]
 
 
@@ -62,8 +62,9 @@ _SIGNATURES = {
     'il_mt19937_seed': (C.c_int, [c_u32p, C.c_uint32]),
     'il_mt19937_sample_indices': (C.c_int, [c_u32p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, c_i32p]),
     'il_mt19937_sample_indices_device': (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    'il_replay_sample_device': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
     'il_adam_step': (C.c_int, [_P, _P, C.POINTER(Adam), C.c_int64, C.c_uint32, _P]),
-    'il_polyak': (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
+    'il_polyak': (C.c_int, [_P, _P, C.c_int64, C.c_double, _P]),
     'il_mlp_numel': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     'il_mlp_stride': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     'il_sac_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -29,76 +29,100 @@ __host__ __device__ inline DiscWs disc_ws(int D, int H, int B) {
 }
 extern "C" int64_t il_disc_workspace_floats(int32_t D, int32_t H, int32_t B) { return disc_ws(D, H, B).total; }
 
-// all-thread helper: vec[i] /= max(||vec||, 1e-12) for an LDS vector of length n (F.normalize)
-__device__ __forceinline__ void normalize_lds(float* vec, int n, float* red) {
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) s += vec[i] * vec[i];
-  s = block_sum(s, red);
-  const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
-  for (int i = threadIdx.x; i < n; i += blockDim.x) vec[i] *= inv;
-  __syncthreads();
-}
+// ---------------------------------------------------------------------------------------------
+// Spectral norm, executed by ONE wave with wave-level reductions only (no block barriers): the power iterations of the three
+// discriminator calls depend on nothing but W, u, v, so wave 0 runs all of them up front while waves 1.. stage the batch rows.
+// W1s: LDS copy of W1 with row stride D+1 (conflict-free for both W v and W^T u).
+// ---------------------------------------------------------------------------------------------
+struct SnCtx { float *u1, *v1, *v2, *sc; };  // per pass: u1[H], v1[D], v2[H], sc = {sigma1, sigma2, u2}
 
-// one spectral-norm power iteration + sigma for W1 [H x D] (global) and W2 [1 x H] (global); u/v live in LDS. Returns sigmas to all threads.
-__device__ __forceinline__ void sn_iterate(const float* __restrict__ W1, const float* __restrict__ W2, int D, int H, float* u1, float* v1, float* u2, float* v2, bool iterate,
-                                           float& s1, float& s2, float* red) {
+// wave-synchronous LDS hand-off between lanes of ONE wave: LDS ops of a wave execute in order, this only pins the compiler
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+__device__ __forceinline__ float wave_norm_scale(float ss) { return 1.f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f); }
+
+// one wave: (u1,v1,u2,v2) <- one power iteration (if iterate), then sigmas. in/out vectors live in LDS.
+__device__ __forceinline__ void sn_wave(const float* W1s, const float* W2s, int D, int H, float* u1, float* v1, float* u2, float* v2, bool iterate, float* sig) {
+  const int lane = threadIdx.x & 63, ldw = D + 1;
   if (iterate) {
-    for (int n = threadIdx.x; n < H; n += blockDim.x) { float s = 0.f; for (int k = 0; k < D; ++k) s += W1[(size_t)n * D + k] * v1[k]; u1[n] = s; }
-    __syncthreads();
-    normalize_lds(u1, H, red);
-    for (int k = threadIdx.x; k < D; k += blockDim.x) { float s = 0.f; for (int n = 0; n < H; ++n) s += W1[(size_t)n * D + k] * u1[n]; v1[k] = s; }
-    __syncthreads();
-    normalize_lds(v1, D, red);
-    // layer 2: W2 is [1 x H]: u2 = normalize(W2 v2) (a scalar), v2 = normalize(W2^T u2)
+    float ss = 0.f;
+    for (int n = lane; n < H; n += 64) { float s = 0.f; for (int k = 0; k < D; ++k) s += W1s[n * ldw + k] * v1[k]; u1[n] = s; ss += s * s; }
+    float inv = wave_norm_scale(ss);
+    for (int n = lane; n < H; n += 64) u1[n] *= inv;
+    WAVE_SYNC();
+    ss = 0.f;
+    for (int k = lane; k < D; k += 64) { float s = 0.f; for (int n = 0; n < H; ++n) s += W1s[n * ldw + k] * u1[n]; v1[k] = s; ss += s * s; }
+    inv = wave_norm_scale(ss);
+    for (int k = lane; k < D; k += 64) v1[k] *= inv;
+    WAVE_SYNC();
     float p = 0.f;
-    for (int n = threadIdx.x; n < H; n += blockDim.x) p += W2[n] * v2[n];
-    p = block_sum(p, red);
+    for (int n = lane; n < H; n += 64) p += W2s[n] * v2[n];
+    p = wave_sum(p);
     const float uu = p / fmaxf(fabsf(p), 1e-12f);
-    if (threadIdx.x == 0) u2[0] = uu;
-    for (int n = threadIdx.x; n < H; n += blockDim.x) v2[n] = W2[n] * uu;
-    __syncthreads();
-    normalize_lds(v2, H, red);
+    ss = 0.f;
+    for (int n = lane; n < H; n += 64) { const float s = W2s[n] * uu; v2[n] = s; ss += s * s; }
+    inv = wave_norm_scale(ss);
+    for (int n = lane; n < H; n += 64) v2[n] *= inv;
+    if (lane == 0) u2[0] = uu;
+    WAVE_SYNC();
   }
-  float a = 0.f;
-  for (int n = threadIdx.x; n < H; n += blockDim.x) { float s = 0.f; for (int k = 0; k < D; ++k) s += W1[(size_t)n * D + k] * v1[k]; a += u1[n] * s; }
-  s1 = block_sum(a, red);
-  float b = 0.f;
-  for (int n = threadIdx.x; n < H; n += blockDim.x) b += W2[n] * v2[n];
-  s2 = u2[0] * block_sum(b, red);
+  float a = 0.f, b = 0.f;
+  for (int n = lane; n < H; n += 64) { float s = 0.f; for (int k = 0; k < D; ++k) s += W1s[n * ldw + k] * v1[k]; a += u1[n] * s; b += W2s[n] * v2[n]; }
+  a = wave_sum(a); b = wave_sum(b);
+  if (lane == 0) { sig[0] = a; sig[1] = u2[0] * b; }
+  WAVE_SYNC();
 }
 
-struct DiscLds {
-  float *X[3], *wt[3], *hs, *dhs, *cg, *ts, *u1, *v1, *u2, *v2, *zs, *dzs, *red;
+struct DiscLds {  // per-pass arrays are contiguous and addressed arithmetically (pointer arrays indexed at run time would go to scratch)
+  float *W1s, *b1s, *W2s, *Xb, *wtb, *hs, *dhs, *ts, *cg, *snb, *zs, *dzs, *red;
+  int D, H;
+  __device__ __forceinline__ float* X(int c) const { return Xb + c * IL_TILE_R * D; }
+  __device__ __forceinline__ float* wt(int c) const { return wtb + c * IL_TILE_R; }
+  __device__ __forceinline__ float* u1(int c) const { return snb + c * (2 * H + D + 4); }
+  __device__ __forceinline__ float* v1(int c) const { return u1(c) + H; }
+  __device__ __forceinline__ float* v2(int c) const { return u1(c) + H + D; }
+  __device__ __forceinline__ float* sc(int c) const { return u1(c) + 2 * H + D; }
 };
-__host__ __device__ inline size_t disc_lds_floats(int D, int H) { return (size_t)3 * IL_TILE_R * D + 3 * IL_TILE_R + 3 * (size_t)IL_TILE_R * H + (size_t)IL_TILE_R * D + 2 * H + D + 4 + 2 * IL_TILE_R + 64; }
+__host__ __device__ inline size_t disc_lds_floats(int D, int H) {
+  return (size_t)H * (D + 1) + 2 * H + 3 * (size_t)IL_TILE_R * D + 3 * IL_TILE_R + 3 * (size_t)IL_TILE_R * H + (size_t)IL_TILE_R * D + 3 * (size_t)(2 * H + D + 4) + 2 * IL_TILE_R + 64;
+}
 __device__ __forceinline__ DiscLds carve(float* s, int D, int H) {
   DiscLds l; float* p = s;
-  for (int i = 0; i < 3; ++i) { l.X[i] = p; p += IL_TILE_R * D; }
-  for (int i = 0; i < 3; ++i) { l.wt[i] = p; p += IL_TILE_R; }
+  l.D = D; l.H = H;
+  l.W1s = p; p += H * (D + 1); l.b1s = p; p += H; l.W2s = p; p += H;
+  l.Xb = p; p += 3 * IL_TILE_R * D; l.wtb = p; p += 3 * IL_TILE_R;
   l.hs = p; p += IL_TILE_R * H; l.dhs = p; p += IL_TILE_R * H; l.ts = p; p += IL_TILE_R * H; l.cg = p; p += IL_TILE_R * D;
-  l.u1 = p; p += H; l.v1 = p; p += D; l.v2 = p; p += H; l.u2 = p; p += 4;
+  l.snb = p; p += 3 * (2 * H + D + 4);
   l.zs = p; p += IL_TILE_R; l.dzs = p; p += IL_TILE_R; l.red = p;
   return l;
 }
 
+// stage W1 (padded rows), b1, W2 into LDS
+__device__ __forceinline__ void stage_weights(const DiscLds& L, const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2, int D, int H) {
+  for (int i = threadIdx.x; i < H * D; i += blockDim.x) { const int n = i / D, k = i - n * D; L.W1s[n * (D + 1) + k] = W1[i]; }
+  for (int i = threadIdx.x; i < H; i += blockDim.x) { L.b1s[i] = b1[i]; L.W2s[i] = W2[i]; }
+}
+
+// GREG: gradient accumulators of W1 live in registers (H*D <= 8*256), else read-modify-write of this workgroup's own slab
+template <bool GREG>
 __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch;
+  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch, ldw = D + 1;
   const int tile = blockIdx.x, row0 = tile * IL_TILE_R, tid = threadIdx.x;
   const int nrows = min(IL_TILE_R, B - row0);
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
   const DiscWs wsl = disc_ws(D, H, B);
-  const float* W1 = d.params + lay.oW1; const float* b1 = d.params + lay.ob1; const float* W2 = d.params + lay.oW2; const float b2 = d.params[lay.ob2];
+  const float b2 = d.params[lay.ob2];
   float* slab = d.workspace + wsl.slabs + (size_t)tile * lay.P;
   DiscLds L = carve(smem, D, H);
-  // ---- stage inputs: policy rows, expert rows, mix rows (training.py:118-120)
+  stage_weights(L, d.params + lay.oW1, d.params + lay.ob1, d.params + lay.oW2, D, H);
+  // ---- stage inputs: policy rows, expert rows (mix rows below, training.py:118-120)
   for (int i = tid; i < IL_TILE_R * D; i += blockDim.x) {
     const int r = i / D, k = i - r * D; float xp = 0.f, xe = 0.f;
     if (r < nrows) {
       xp = k < S ? pol.states[(size_t)(row0 + r) * pol.ld_states + k] : pol.actions[(size_t)(row0 + r) * pol.ld_actions + k - S];
       xe = k < S ? exp.states[(size_t)(row0 + r) * exp.ld_states + k] : exp.actions[(size_t)(row0 + r) * exp.ld_actions + k - S];
     }
-    L.X[0][i] = xp; L.X[1][i] = xe;
+    L.X(0)[i] = xp; L.X(1)[i] = xe;
   }
   const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
   if (tid < IL_TILE_R) {
@@ -107,38 +131,58 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
       wp = pol.weights[(size_t)(row0 + r) * pol.ld_weights]; we = exp.weights[(size_t)(row0 + r) * exp.ld_weights];
       e = eps_gp ? eps_gp[row0 + r] : philox_uniform(d.noise_seed, ctr, IL_STREAM_GP, (uint32_t)(row0 + r));
     }
-    L.wt[0][r] = wp; L.wt[1][r] = we; L.wt[2][r] = e * we + (1.f - e) * wp; L.dzs[r] = e;
+    L.wt(0)[r] = wp; L.wt(1)[r] = we; L.wt(2)[r] = e * we + (1.f - e) * wp; L.dzs[r] = e;
   }
-  for (int i = tid; i < H; i += blockDim.x) { L.u1[i] = d.spectral_norm ? d.u1[i] : 0.f; L.v2[i] = d.spectral_norm ? d.v2[i] : 0.f; }
-  for (int i = tid; i < D; i += blockDim.x) L.v1[i] = d.spectral_norm ? d.v1[i] : 0.f;
-  if (tid == 0) { L.u2[0] = d.spectral_norm ? d.u2[0] : 0.f; if (tile == 0) d.opt.step[0] += 1; }
+  if (d.spectral_norm) {
+    for (int i = tid; i < H; i += blockDim.x) { L.u1(0)[i] = d.u1[i]; L.v2(0)[i] = d.v2[i]; }
+    for (int i = tid; i < D; i += blockDim.x) L.v1(0)[i] = d.v1[i];
+    if (tid == 0) L.sc(0)[2] = d.u2[0];
+  }
+  if (tid == 0 && tile == 0) d.opt.step[0] += 1;
   __syncthreads();
-  for (int i = tid; i < IL_TILE_R * D; i += blockDim.x) { const float e = L.dzs[i / D]; L.X[2][i] = e * L.X[1][i] + (1.f - e) * L.X[0][i]; }
+  const int npass = d.grad_penalty > 0.f ? 3 : 2;
+  if (tid < 64) {  // ---- wave 0: the power iterations of all discriminator calls, chained
+    for (int c = 0; c < npass; ++c) {
+      if (d.spectral_norm) {
+        if (c > 0) {
+          for (int i = tid; i < H; i += 64) { L.u1(c)[i] = L.u1(c - 1)[i]; L.v2(c)[i] = L.v2(c - 1)[i]; }
+          for (int i = tid; i < D; i += 64) L.v1(c)[i] = L.v1(c - 1)[i];
+          if (tid == 0) L.sc(c)[2] = L.sc(c - 1)[2];
+          WAVE_SYNC();
+        }
+        sn_wave(L.W1s, L.W2s, D, H, L.u1(c), L.v1(c), &L.sc(c)[2], L.v2(c), true, L.sc(c));
+      } else if (tid == 0) { L.sc(c)[0] = 1.f; L.sc(c)[1] = 1.f; L.sc(c)[2] = 0.f; }
+    }
+  } else {
+    for (int i = tid - 64; i < IL_TILE_R * D; i += blockDim.x - 64) { const float e = L.dzs[i / D]; L.X(2)[i] = e * L.X(1)[i] + (1.f - e) * L.X(0)[i]; }
+  }
   __syncthreads();
 
   const int r = tid >> 4, sub = tid & 15;
   const float fB = (float)B;
-  const int npass = d.grad_penalty > 0.f ? 3 : 2;
+  const bool valid = r < nrows;
+  constexpr int EPT = 8;
+  float greg[EPT];
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) greg[q] = 0.f;
   for (int pass = 0; pass < npass; ++pass) {
-    float s1 = 1.f, s2 = 1.f;
-    if (d.spectral_norm) sn_iterate(W1, W2, D, H, L.u1, L.v1, L.u2, L.v2, true, s1, s2, L.red);
-    const float* X = L.X[pass];
-    const bool valid = r < nrows;
+    const float s1 = L.sc(pass)[0], s2 = L.sc(pass)[1], u2 = L.sc(pass)[2];
+    const float* u1 = L.u1(pass); const float* v1 = L.v1(pass); const float* v2 = L.v2(pass);
+    const float* X = L.X(pass);
     // ---- forward for row r (16 threads per row)
     float zp = 0.f;
     for (int n = sub; n < H; n += 16) {
       float s = 0.f;
-      for (int k = 0; k < D; ++k) s += W1[(size_t)n * D + k] * X[r * D + k];
-      const float h = s / s1 + b1[n];
+      for (int k = 0; k < D; ++k) s += L.W1s[n * ldw + k] * X[r * D + k];
+      const float h = s / s1 + L.b1s[n];
       L.hs[r * H + n] = h;
-      zp += (W2[n] / s2) * fmaxf(h, 0.f);
+      zp += (L.W2s[n] / s2) * fmaxf(h, 0.f);
     }
     zp = group16_sum(zp);
     const float z = zp + b2;
-    float S_ip = 0.f;  // accumulates the <G^,W>/sigma pieces
     float ip1, ip2;
     if (pass < 2) {
-      const float w = L.wt[pass][r], label = pass == 1 ? 1.f : 0.f;
+      const float w = L.wt(pass)[r], label = pass == 1 ? 1.f : 0.f;
       const float p = sigmoid_f(z);
       float dz = valid ? w * (p - label) / fB : 0.f;
       if (d.entropy_bonus > 0.f && valid) dz += d.entropy_bonus * w * z * p * (1.f - p) / fB;
@@ -146,26 +190,27 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
       float a1 = 0.f;
       for (int n = sub; n < H; n += 16) {
         const float h = L.hs[r * H + n];
-        const float dh = h > 0.f ? dz * (W2[n] / s2) : 0.f;
+        const float dh = h > 0.f ? dz * (L.W2s[n] / s2) : 0.f;
         L.dhs[r * H + n] = dh;
-        a1 += dh * (h - b1[n]);
+        a1 += dh * (h - L.b1s[n]);
       }
       ip1 = s1 * block_sum(a1, L.red);
       ip2 = s2 * block_sum(sub == 0 ? dz * (z - b2) : 0.f, L.red);
     } else {
       // q = [h>0] w2^ -> dhs ; g = W1^^T q ; cg = c g
-      for (int n = sub; n < H; n += 16) L.dhs[r * H + n] = L.hs[r * H + n] > 0.f ? (W2[n] / s2) : 0.f;
+      for (int n = sub; n < H; n += 16) L.dhs[r * H + n] = L.hs[r * H + n] > 0.f ? (L.W2s[n] / s2) : 0.f;
       __syncthreads();
-      const float c = valid ? 2.f * d.grad_penalty * L.wt[2][r] / fB : 0.f;
+      const float c = valid ? 2.f * d.grad_penalty * L.wt(2)[r] / fB : 0.f;
       for (int k = sub; k < D; k += 16) {
         float s = 0.f;
-        for (int n = 0; n < H; ++n) s += L.dhs[r * H + n] * W1[(size_t)n * D + k];
+        for (int n = 0; n < H; ++n) s += L.dhs[r * H + n] * L.W1s[n * ldw + k];
         L.cg[r * D + k] = c * (s / s1);
       }
       __syncthreads();
+      float S_ip = 0.f;
       for (int n = sub; n < H; n += 16) {
         float s = 0.f;
-        for (int k = 0; k < D; ++k) s += W1[(size_t)n * D + k] * L.cg[r * D + k];
+        for (int k = 0; k < D; ++k) s += L.W1s[n * ldw + k] * L.cg[r * D + k];
         const float tp = s / s1;
         L.ts[r * H + n] = L.hs[r * H + n] > 0.f ? tp : 0.f;
         S_ip += L.dhs[r * H + n] * tp;
@@ -174,17 +219,22 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
       ip1 = s1 * Ssum; ip2 = s2 * Ssum;
     }
     __syncthreads();
-    // ---- accumulate this pass into the slab (each element owned by one thread)
+    // ---- accumulate this pass (each gradient element owned by one thread)
     const float* left = L.dhs;                         // [16][H]: dh (BCE) or q (GP)
     const float* right = pass < 2 ? X : L.cg;          // [16][D]: x (BCE) or c*g (GP)
     const float k1 = d.spectral_norm ? ip1 / (s1 * s1) : 0.f, k2 = d.spectral_norm ? ip2 / (s2 * s2) : 0.f;
-    for (int e = tid; e < H * D; e += blockDim.x) {
+    auto grad_w1 = [&](int e) -> float {
       const int n = e / D, k = e - n * D;
       float gh = 0.f;
-#pragma unroll 4
+#pragma unroll
       for (int rr = 0; rr < IL_TILE_R; ++rr) gh += left[rr * H + n] * right[rr * D + k];
-      const float gv = gh / s1 - k1 * L.u1[n] * L.v1[k];
-      slab[lay.oW1 + e] = pass == 0 ? gv : slab[lay.oW1 + e] + gv;
+      return gh / s1 - (d.spectral_norm ? k1 * u1[n] * v1[k] : 0.f);
+    };
+    if (GREG) {
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) { const int e = tid + q * 256; if (e < H * D) greg[q] += grad_w1(e); }  // static register indices
+    } else {
+      for (int e = tid; e < H * D; e += blockDim.x) { const float gv = grad_w1(e); slab[lay.oW1 + e] = pass == 0 ? gv : slab[lay.oW1 + e] + gv; }
     }
     for (int n = tid; n < H; n += blockDim.x) {
       float g2 = 0.f, gb = 0.f;
@@ -192,7 +242,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
         if (pass < 2) { g2 += L.dzs[rr] * fmaxf(L.hs[rr * H + n], 0.f); gb += L.dhs[rr * H + n]; }
         else g2 += L.ts[rr * H + n];
       }
-      const float gv = g2 / s2 - k2 * L.u2[0] * L.v2[n];
+      const float gv = g2 / s2 - (d.spectral_norm ? k2 * u2 * v2[n] : 0.f);
       slab[lay.oW2 + n] = pass == 0 ? gv : slab[lay.oW2 + n] + gv;
       if (pass < 2) slab[lay.ob1 + n] = pass == 0 ? gb : slab[lay.ob1 + n] + gb;
     }
@@ -203,25 +253,41 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     }
     __syncthreads();
   }
+  if (GREG) {
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) { const int e = tid + q * 256; if (e < H * D) slab[lay.oW1 + e] = greg[q]; }
+  }
   if (tile == 0 && d.spectral_norm) {  // final u, v of this update (identical in every workgroup)
     float* o = d.workspace + wsl.sn_new;
-    for (int i = tid; i < H; i += blockDim.x) { o[i] = L.u1[i]; o[H + D + 1 + i] = L.v2[i]; }
-    for (int i = tid; i < D; i += blockDim.x) o[H + i] = L.v1[i];
-    if (tid == 0) o[H + D] = L.u2[0];
+    const int c = npass - 1;
+    for (int i = tid; i < H; i += blockDim.x) { o[i] = L.u1(c)[i]; o[H + D + 1 + i] = L.v2(c)[i]; }
+    for (int i = tid; i < D; i += blockDim.x) o[H + i] = L.v1(c)[i];
+    if (tid == 0) o[H + D] = L.sc(c)[2];
   }
 }
 
+// grid = ceil(P / 256): one gradient element per thread, slabs summed in tile order (deterministic)
 __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply) {
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch;
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
   const DiscWs wsl = disc_ws(D, H, B);
   const int nt = (B + IL_TILE_R - 1) / IL_TILE_R;
-  const adam_consts ac = make_adam_consts(d.opt.lr, d.opt.beta1, d.opt.beta2, d.opt.eps, d.opt.weight_decay, d.opt.step[0]);
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < lay.P; e += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < lay.P) {
+    const float* sl = d.workspace + wsl.slabs + e;
     float g = 0.f;
-    for (int t = 0; t < nt; ++t) g += d.workspace[wsl.slabs + (size_t)t * lay.P + e];
+    int t = 0;
+    for (; t + 8 <= nt; t += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = sl[(size_t)(t + u) * lay.P];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) g += v[u];
+    }
+    for (; t < nt; ++t) g += sl[(size_t)t * lay.P];
     d.grad[e] = g;
     if (apply) {
+      const adam_consts ac = make_adam_consts(d.opt.lr, d.opt.beta1, d.opt.beta2, d.opt.eps, d.opt.weight_decay, d.opt.step[0]);
       float pp = d.params[e], mm = d.opt.m[e], vv = d.opt.v[e];
       adam_update(pp, g, mm, vv, ac);
       d.params[e] = pp; d.opt.m[e] = mm; d.opt.v[e] = vv;
@@ -237,30 +303,31 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply) {
 
 __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, float* __restrict__ out_r, float* __restrict__ out_logit) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden;
+  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, ldw = D + 1;
   const int row0 = blockIdx.x * IL_TILE_R, tid = threadIdx.x, nrows = min(IL_TILE_R, b.n - row0);
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
-  const float* W1 = d.params + lay.oW1; const float* b1 = d.params + lay.ob1; const float* W2 = d.params + lay.oW2; const float b2 = d.params[lay.ob2];
+  const float b2 = d.params[lay.ob2];
   DiscLds L = carve(smem, D, H);
+  stage_weights(L, d.params + lay.oW1, d.params + lay.ob1, d.params + lay.oW2, D, H);
   for (int i = tid; i < IL_TILE_R * D; i += blockDim.x) {
     const int r = i / D, k = i - r * D;
-    L.X[0][i] = r < nrows ? (k < S ? b.states[(size_t)(row0 + r) * b.ld_states + k] : b.actions[(size_t)(row0 + r) * b.ld_actions + k - S]) : 0.f;
+    L.X(0)[i] = r < nrows ? (k < S ? b.states[(size_t)(row0 + r) * b.ld_states + k] : b.actions[(size_t)(row0 + r) * b.ld_actions + k - S]) : 0.f;
   }
-  float s1 = 1.f, s2 = 1.f;
   if (d.spectral_norm) {
-    for (int i = tid; i < H; i += blockDim.x) { L.u1[i] = d.u1[i]; L.v2[i] = d.v2[i]; }
-    for (int i = tid; i < D; i += blockDim.x) L.v1[i] = d.v1[i];
-    if (tid == 0) L.u2[0] = d.u2[0];
-    __syncthreads();
-    sn_iterate(W1, W2, D, H, L.u1, L.v1, L.u2, L.v2, false, s1, s2, L.red);
-  }
+    for (int i = tid; i < H; i += blockDim.x) { L.u1(0)[i] = d.u1[i]; L.v2(0)[i] = d.v2[i]; }
+    for (int i = tid; i < D; i += blockDim.x) L.v1(0)[i] = d.v1[i];
+    if (tid == 0) L.sc(0)[2] = d.u2[0];
+  } else if (tid == 0) { L.sc(0)[0] = 1.f; L.sc(0)[1] = 1.f; }
   __syncthreads();
+  if (d.spectral_norm && tid < 64) sn_wave(L.W1s, L.W2s, D, H, L.u1(0), L.v1(0), &L.sc(0)[2], L.v2(0), false, L.sc(0));  // eval mode: sigma only
+  __syncthreads();
+  const float s1 = L.sc(0)[0], s2 = L.sc(0)[1];
   const int r = tid >> 4, sub = tid & 15;
   float zp = 0.f;
   for (int n = sub; n < H; n += 16) {
     float s = 0.f;
-    for (int k = 0; k < D; ++k) s += W1[(size_t)n * D + k] * L.X[0][r * D + k];
-    zp += (W2[n] / s2) * fmaxf(s / s1 + b1[n], 0.f);
+    for (int k = 0; k < D; ++k) s += L.W1s[n * ldw + k] * L.X(0)[r * D + k];
+    zp += (L.W2s[n] / s2) * fmaxf(s / s1 + L.b1s[n], 0.f);
   }
   zp = group16_sum(zp);
   if (sub == 0 && r < nrows) {
@@ -272,11 +339,19 @@ __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, floa
   }
 }
 
+static int ensure_lds(const void* fn, size_t bytes) {
+  if (bytes <= 64 * 1024) return IL_OK;
+  if (bytes > 160 * 1024) return il_set_error(IL_ERR_UNSUPPORTED, "kernel needs %zu bytes of LDS (> 160 KiB per CU)", bytes);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return il_set_error(IL_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", bytes, hipGetErrorString(e));
+  return IL_OK;
+}
+
 static int check_disc(const il_disc* d) {
   IL_CHECK_ARG(d && d->params && d->grad && d->workspace, "il_disc: null descriptor field");
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
   IL_CHECK_ARG(d->hidden >= 1 && d->hidden <= 512 && D >= 1 && D <= 512, "il_disc: dims out of range (D=%d, hidden=%d)", D, d->hidden);
-  IL_CHECK_ARG(disc_lds_floats(D, d->hidden) * sizeof(float) <= 64 * 1024, "il_disc: D=%d hidden=%d needs more than 64 KiB of LDS", D, d->hidden);
+  IL_CHECK_ARG(disc_lds_floats(D, d->hidden) * sizeof(float) <= 160 * 1024, "il_disc: D=%d hidden=%d needs more than 160 KiB of LDS", D, d->hidden);
   IL_CHECK_ARG(d->reward_function >= 0 && d->reward_function <= 2, "il_disc: reward_function must be 0 (AIRL), 1 (GAIL) or 2 (FAIRL)");
   if (d->spectral_norm) IL_CHECK_ARG(d->u1 && d->v1 && d->u2 && d->v2, "il_disc: spectral-norm buffers missing");
   if (d->workspace_floats < disc_ws(D, d->hidden, d->batch).total) return il_set_error(IL_ERR_WORKSPACE, "il_disc: workspace too small");
@@ -289,8 +364,13 @@ extern "C" int il_gail_disc_step(const il_disc* d, const il_batch* pol, const il
   hipStream_t st = (hipStream_t)stream_;
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
   const int nt = ceil_div(d->batch, IL_TILE_R);
-  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<nt, 256, disc_lds_floats(D, d->hidden) * sizeof(float), st>>>(*d, *pol, *exp, eps_gp); }
-  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<1, 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1); }
+  const size_t lds = disc_lds_floats(D, d->hidden) * sizeof(float);
+  const bool greg = (int64_t)d->hidden * D <= 8 * 256;
+  if (int rc = ensure_lds(greg ? (const void*)k_gail_grad<true> : (const void*)k_gail_grad<false>, lds)) return rc;
+  if (greg) { IL_TRACE("k_gail_grad", st); k_gail_grad<true><<<nt, 256, lds, st>>>(*d, *pol, *exp, eps_gp); }
+  else { IL_TRACE("k_gail_grad", st); k_gail_grad<false><<<nt, 256, lds, st>>>(*d, *pol, *exp, eps_gp); }
+  const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
+  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1); }
   IL_CHECK_LAUNCH("il_gail_disc_step");
   return IL_OK;
 }
@@ -316,7 +396,9 @@ extern "C" int il_gail_reward(const il_disc* d, const il_batch* b, float* out_re
   if (int rc = check_disc(d)) return rc;
   IL_CHECK_ARG(b && out_rewards && b->n > 0, "il_gail_reward: bad arguments");
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
-  { IL_TRACE("k_gail_reward", (hipStream_t)stream_); k_gail_reward<<<ceil_div(b->n, IL_TILE_R), 256, disc_lds_floats(D, d->hidden) * sizeof(float), (hipStream_t)stream_>>>(*d, *b, out_rewards, out_logits); }
+  const size_t lds = disc_lds_floats(D, d->hidden) * sizeof(float);
+  if (int rc = ensure_lds((const void*)k_gail_reward, lds)) return rc;
+  { IL_TRACE("k_gail_reward", stream_); k_gail_reward<<<ceil_div(b->n, IL_TILE_R), 256, lds, (hipStream_t)stream_>>>(*d, *b, out_rewards, out_logits); }
   IL_CHECK_LAUNCH("il_gail_reward");
   return IL_OK;
 }

@@ -91,17 +91,16 @@ struct adam_consts {
   float eps;
   int has_decay;
 };
-__device__ __forceinline__ adam_consts make_adam_consts(float lr, float b1, float b2, float eps, float wd, int t) {
+__device__ __forceinline__ adam_consts make_adam_consts(double lr, double b1, double b2, double eps, double wd, int t) {
   adam_consts c;
-  const double dlr = (double)lr, db1 = (double)b1, db2 = (double)b2;
-  c.has_decay = wd != 0.f;
-  c.decay = (float)(1.0 - dlr * (double)wd);
-  c.one_m_b1 = (float)(1.0 - db1);
-  c.beta2 = b2;
-  c.one_m_b2 = (float)(1.0 - db2);
-  c.step_size = (float)(dlr / (1.0 - pow(db1, (double)t)));
-  c.bc2_sqrt = (float)sqrt(1.0 - pow(db2, (double)t));
-  c.eps = eps;
+  c.has_decay = wd != 0.0;
+  c.decay = (float)(1.0 - lr * wd);
+  c.one_m_b1 = (float)(1.0 - b1);
+  c.beta2 = (float)b2;
+  c.one_m_b2 = (float)(1.0 - b2);
+  c.step_size = (float)(lr / (1.0 - pow(b1, (double)t)));
+  c.bc2_sqrt = (float)sqrt(1.0 - pow(b2, (double)t));
+  c.eps = (float)eps;
   return c;
 }
 __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, const adam_consts& c) {

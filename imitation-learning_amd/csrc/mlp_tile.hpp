@@ -5,7 +5,8 @@
 //  * weights are streamed straight from L2 into MFMA B operands (each weight element is used exactly once per
 //    workgroup, so staging it through LDS would only add traffic); rows of a torch [N][K] weight are read as
 //    16-B lanes (64 contiguous bytes per 4-lane k-group);
-//  * each wave owns 64 output columns (4 accumulator tiles) so one A operand (from LDS, ds_read_b128) feeds 16 MFMAs;
+//  * each wave owns 16 output columns; a workgroup is H/16 waves (16 waves = 4 per SIMD at H = 256) so L2 latency of the
+//    weight lanes is hidden by the other waves on the SIMD;
 //  * the k-index of an MFMA step is permuted (lane group g covers k0+4g..k0+4g+3 over four steps) so that both
 //    operands are single 16-byte loads. Summation order within a dot product changes, results stay exact-fp32 FMAs.
 #pragma once
@@ -13,104 +14,134 @@
 
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 
-// 4 consecutive floats p[k..k+3] with columns >= kvalid reading as 0. `vec` = row base and k are 16-B aligned.
-__device__ __forceinline__ f32x4 load4_guard(const float* __restrict__ p, int k, int kvalid, bool vec) {
-  if (vec && k + 3 < kvalid) return *reinterpret_cast<const f32x4*>(p + k);
+// Operand loads are never wrapped in a branch or a select (hipcc turns `cond ? load : 0` into an exec-masked branch that
+// serialises the loop): out-of-range columns/rows CLAMP their address instead. That is exact because the other MFMA operand
+// is zero there (LDS tiles are zero-padded) or the corresponding outputs are discarded by the epilogue.
+//   MODE 0: row + k is 16-B aligned and k + 3 < kvalid always (hidden layers)
+//   MODE 1: 16-B aligned rows, kvalid % 4 == 0
+//   MODE 2: arbitrary row stride / kvalid (first layer with odd input widths): four clamped dword loads
+template <int MODE>
+__device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int k, int kvalid) {
+  if (MODE == 0) return *reinterpret_cast<const f32x4*>(p + k);
+  if (MODE == 1) return *reinterpret_cast<const f32x4*>(p + min(k, kvalid - 4));
   f32x4 r;
-  r[0] = (k + 0 < kvalid) ? p[k + 0] : 0.f;
-  r[1] = (k + 1 < kvalid) ? p[k + 1] : 0.f;
-  r[2] = (k + 2 < kvalid) ? p[k + 2] : 0.f;
-  r[3] = (k + 3 < kvalid) ? p[k + 3] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = p[min(k + i, kvalid - 1)];
   return r;
 }
 
+// Latency hiding is done with THREAD-level parallelism, not software pipelining (hipcc re-rolls a hand-pipelined loop into
+// load -> s_waitcnt -> MFMA): a workgroup runs one wave per 16 output columns (16 waves = 4 per SIMD at H = 256), so while
+// one wave waits for its weight lanes from L2 the other three keep the SIMD's matrix pipe busy.
+
 // ---------------------------------------------------------------------------------------------
 // Y[16 x N] = Xs[16 x Kpad] . W^T      W: global row-major [N][ldw], columns >= Kw read as zero (Xs is zero-padded too)
-// N % 64 == 0.  epi(c0, acc): acc[t][reg] = Y[row 4g+reg][col c0 + 16t + j],  j = lane&15, g = lane>>4.
+// N % 16 == 0.  epi(c0, acc): acc[reg] = Y[row 4g+reg][col c0 + j],  j = lane&15, g = lane>>4.
 // ---------------------------------------------------------------------------------------------
-template <class Epi>
-__device__ __forceinline__ void tile_fwd(const float* Xs, int ldx, int Kpad, const float* __restrict__ W, int ldw, int Kw, int N, Epi epi) {
+template <int MODE, class Epi>
+__device__ __forceinline__ void tile_fwd_impl(const float* Xs, int ldx, int Kpad, const float* __restrict__ W, int ldw, int Kw, int N, Epi epi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const bool vec = ((ldw & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
-  for (int c0 = wave * 64; c0 < N; c0 += nw * 64) {
-    f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
-    const float* wr0 = W + (size_t)(c0 + j) * ldw;
-    const float* wr1 = wr0 + (size_t)16 * ldw;
-    const float* wr2 = wr1 + (size_t)16 * ldw;
-    const float* wr3 = wr2 + (size_t)16 * ldw;
+  for (int c0 = wave * 16; c0 < N; c0 += nw * 16) {
+    f32x4 acc0 = zero4(), acc1 = zero4();  // two accumulators: the 16x16x4 f32 MFMA has a 40-cycle dependent latency vs 32-cycle issue
+    const float* wr = W + (size_t)(c0 + j) * ldw + 4 * g;
     const float* xr = Xs + j * ldx + 4 * g;
-    f32x4 b0 = load4_guard(wr0, 4 * g, Kw, vec), b1 = load4_guard(wr1, 4 * g, Kw, vec), b2 = load4_guard(wr2, 4 * g, Kw, vec),
-          b3 = load4_guard(wr3, 4 * g, Kw, vec);
-    for (int k0 = 0; k0 < Kpad; k0 += 16) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(xr + k0);
-      const f32x4 c0v = b0, c1v = b1, c2v = b2, c3v = b3;
-      const int kn = k0 + 16 + 4 * g;  // prefetch next k-block while the MFMAs below run
-      if (k0 + 16 < Kpad) {
-        b0 = load4_guard(wr0, kn, Kw, vec); b1 = load4_guard(wr1, kn, Kw, vec); b2 = load4_guard(wr2, kn, Kw, vec); b3 = load4_guard(wr3, kn, Kw, vec);
-      }
+    int k0 = 0;
+    for (; k0 + 64 <= Kpad; k0 += 64) {  // 4 k-blocks per trip: four weight lanes in flight before the first MFMA needs one
+      f32x4 a[4], b[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc[0] = mfma16(a[s], c0v[s], acc[0]);
-        acc[1] = mfma16(a[s], c1v[s], acc[1]);
-        acc[2] = mfma16(a[s], c2v[s], acc[2]);
-        acc[3] = mfma16(a[s], c3v[s], acc[3]);
+      for (int u = 0; u < 4; ++u) { b[u] = load4<MODE>(wr - 4 * g, k0 + 16 * u + 4 * g, Kw); a[u] = *reinterpret_cast<const f32x4*>(xr + k0 + 16 * u); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc0 = mfma16(a[u][0], b[u][0], acc0);
+        acc1 = mfma16(a[u][1], b[u][1], acc1);
+        acc0 = mfma16(a[u][2], b[u][2], acc0);
+        acc1 = mfma16(a[u][3], b[u][3], acc1);
       }
     }
+    for (; k0 < Kpad; k0 += 16) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xr + k0);
+      const f32x4 b = load4<MODE>(wr - 4 * g, k0 + 4 * g, Kw);
+      acc0 = mfma16(a[0], b[0], acc0);
+      acc1 = mfma16(a[1], b[1], acc1);
+      acc0 = mfma16(a[2], b[2], acc0);
+      acc1 = mfma16(a[3], b[3], acc1);
+    }
+    f32x4 acc = acc0 + acc1;
     epi(c0, acc);
   }
 }
+template <class Epi>
+__device__ __forceinline__ void tile_fwd(const float* Xs, int ldx, int Kpad, const float* __restrict__ W, int ldw, int Kw, int N, Epi epi) {
+  const bool aligned = ((ldw & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+  if (aligned && Kw == Kpad) tile_fwd_impl<0>(Xs, ldx, Kpad, W, ldw, Kw, N, epi);
+  else if (aligned && (Kw & 3) == 0 && Kw >= 4) tile_fwd_impl<1>(Xs, ldx, Kpad, W, ldw, Kw, N, epi);
+  else tile_fwd_impl<2>(Xs, ldx, Kpad, W, ldw, Kw, N, epi);
+}
 
 // ---------------------------------------------------------------------------------------------
-// dX[16 x K] = dYs[16 x Npad] . W      W: global row-major [Nvalid][ldw], K % 64 == 0, ldw % 4 == 0, rows >= Nvalid read as zero.
-// epi(kb, acc): acc[i][reg] = dX[row 4g+reg][col kb + 4j + i]   (16 B per lane per row => 256 contiguous bytes per 16 lanes)
+// dX[16 x K] = dYs[16 x Npad] . W      W: global row-major [Nvalid][ldw], K % 16 == 0, rows >= Nvalid read as zero.
+// epi(kb, acc): acc[reg] = dX[row 4g+reg][col kb + j]
 // ---------------------------------------------------------------------------------------------
-template <class Epi>
-__device__ __forceinline__ void tile_bwd_dx(const float* dYs, int ldy, int Npad, int Nvalid, const float* __restrict__ W, int ldw, int K, Epi epi) {
+template <bool FULL, class Epi>
+__device__ __forceinline__ void tile_bwd_dx_impl(const float* dYs, int ldy, int Npad, int Nvalid, const float* __restrict__ W, int ldw, int K, Epi epi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
-  for (int kb = wave * 64; kb < K; kb += nw * 64) {
-    f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
-    const float* wp = W + (size_t)(4 * g) * ldw + kb + 4 * j;
+  for (int kb = wave * 16; kb < K; kb += nw * 16) {
+    f32x4 acc0 = zero4(), acc1 = zero4();
+    const float* wp = W + kb + j;
     const float* yr = dYs + j * ldy + 4 * g;
-    f32x4 b[4];
+    int n0 = 0;
+    for (; n0 + 64 <= Npad; n0 += 64) {  // 16 weight dwords in flight per lane
+      f32x4 a[4]; float b[4][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) b[s] = (4 * g + s < Nvalid) ? *reinterpret_cast<const f32x4*>(wp + (size_t)s * ldw) : zero4();
-    for (int n0 = 0; n0 < Npad; n0 += 16) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(yr + n0);
-      f32x4 c[4] = {b[0], b[1], b[2], b[3]};
-      if (n0 + 16 < Npad) {
+      for (int u = 0; u < 4; ++u) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          b[s] = (n0 + 16 + 4 * g + s < Nvalid) ? *reinterpret_cast<const f32x4*>(wp + (size_t)(n0 + 16 + s) * ldw) : zero4();
+        for (int s = 0; s < 4; ++s) { const int n = n0 + 16 * u + 4 * g + s; b[u][s] = wp[(size_t)(FULL ? n : min(n, Nvalid - 1)) * ldw]; }
+        a[u] = *reinterpret_cast<const f32x4*>(yr + n0 + 16 * u);
       }
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc[0] = mfma16(a[s], c[s][0], acc[0]);
-        acc[1] = mfma16(a[s], c[s][1], acc[1]);
-        acc[2] = mfma16(a[s], c[s][2], acc[2]);
-        acc[3] = mfma16(a[s], c[s][3], acc[3]);
+      for (int u = 0; u < 4; ++u) {
+        acc0 = mfma16(a[u][0], b[u][0], acc0);
+        acc1 = mfma16(a[u][1], b[u][1], acc1);
+        acc0 = mfma16(a[u][2], b[u][2], acc0);
+        acc1 = mfma16(a[u][3], b[u][3], acc1);
       }
     }
+    for (; n0 < Npad; n0 += 16) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(yr + n0);
+      float b[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { const int n = n0 + 4 * g + s; b[s] = wp[(size_t)(FULL ? n : min(n, Nvalid - 1)) * ldw]; }  // rows >= Nvalid: dYs columns are zero there
+      acc0 = mfma16(a[0], b[0], acc0);
+      acc1 = mfma16(a[1], b[1], acc1);
+      acc0 = mfma16(a[2], b[2], acc0);
+      acc1 = mfma16(a[3], b[3], acc1);
+    }
+    f32x4 acc = acc0 + acc1;
     epi(kb, acc);
   }
+}
+template <class Epi>
+__device__ __forceinline__ void tile_bwd_dx(const float* dYs, int ldy, int Npad, int Nvalid, const float* __restrict__ W, int ldw, int K, Epi epi) {
+  if (Nvalid == Npad) tile_bwd_dx_impl<true>(dYs, ldy, Npad, Nvalid, W, ldw, K, epi);
+  else tile_bwd_dx_impl<false>(dYs, ldy, Npad, Nvalid, W, ldw, K, epi);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Small output layer: Os[16][16] = Xs[16 x K] . W^T + b, W [N][ldw] with N <= 16 (actor head 2A, critic head 1).
-// K (multiple of 64) is split across the waves; partial tiles are reduced through LDS (`part` >= nw*256 floats).
+// The K/16 k-blocks are dealt round-robin to the waves; partial tiles are reduced through LDS (`part` >= nw*256 floats).
 // Contains __syncthreads(); every thread of the block must call. Result valid after return.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void tile_fwd_small(const float* Xs, int ldx, int K, const float* __restrict__ W, int ldw, int N, const float* __restrict__ bias,
                                                float* Os, float* part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int kchunk = K / nw;  // K % (16*nw) == 0 for H % 64 == 0, nw = 4
   f32x4 acc = zero4();
-  const float* wr = W + (size_t)j * ldw;
-  for (int k0 = wave * kchunk; k0 < (wave + 1) * kchunk; k0 += 16) {
+  const float* wr = W + (size_t)min(j, N - 1) * ldw;  // clamped row: no divergent branch around the load
+  for (int k0 = wave * 16; k0 < K; k0 += nw * 16) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(Xs + j * ldx + k0 + 4 * g);
-    const f32x4 b = (j < N) ? *reinterpret_cast<const f32x4*>(wr + k0 + 4 * g) : zero4();
+    const f32x4 b = *reinterpret_cast<const f32x4*>(wr + k0 + 4 * g);  // columns j >= N produce garbage that Os below discards
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = mfma16(a[s], b[s], acc);
   }

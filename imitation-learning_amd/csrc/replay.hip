@@ -124,73 +124,108 @@ extern "C" int il_mt19937_sample_indices(uint32_t* s, int32_t n, int64_t size, i
 
 // Device version: one workgroup. The draw is a stream compaction of the tempered MT output (every candidate consumes
 // exactly one 32-bit word; rejected ones are skipped), so 256 candidates are tested in parallel and compacted in order.
-__global__ __launch_bounds__(256) void k_mt_sample(uint32_t* __restrict__ state, const int64_t* __restrict__ ring_state, int n, int32_t* __restrict__ out) {
-  __shared__ uint32_t mt[MT_N];
-  __shared__ int wave_cnt[4];
-  __shared__ int s_pos, s_count;
+struct MtShared { uint32_t mt[MT_N]; int wave_cnt[4]; int pos, count, last; };
+
+__device__ __forceinline__ void mt_draw(MtShared& sh, const int64_t* __restrict__ ring_state, int n, int32_t* __restrict__ out) {
   const int tid = threadIdx.x;
   const int64_t idx = ring_state[0], full = ring_state[1], size = ring_state[2];
   const int64_t high = full ? size : idx - 1;
   const int64_t excl = ((idx - 1) % size + size) % size;
   const uint32_t rng = high > 0 ? (uint32_t)(high - 1) : 0u;
   uint32_t mask = rng; mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-  for (int i = tid; i < MT_N; i += 256) mt[i] = state[i];
-  if (tid == 0) { s_pos = (int)state[MT_N]; s_count = 0; }
+  if (tid == 0) sh.count = 0;
   __syncthreads();
   if (rng == 0) {  // degenerate range: numpy returns 0 without consuming the stream
     for (int i = tid; i < n; i += 256) out[i] = 0;
     return;
   }
   for (int guard = 0; guard < 100000; ++guard) {
-    int pos = s_pos, count = s_count;
+    int pos = sh.pos, count = sh.count;
     if (count >= n) break;
     if (pos >= MT_N) {  // twist: four dependency-free phases
       uint32_t nv[3]; int q = 0;
-      for (int k = tid; k < 227; k += 256) nv[q++] = mt_mix(mt[k], mt[k + 1], mt[k + MT_M]);
+      for (int k = tid; k < 227; k += 256) nv[q++] = mt_mix(sh.mt[k], sh.mt[k + 1], sh.mt[k + MT_M]);
       __syncthreads(); q = 0;
-      for (int k = tid; k < 227; k += 256) mt[k] = nv[q++];
+      for (int k = tid; k < 227; k += 256) sh.mt[k] = nv[q++];
       __syncthreads(); q = 0;
-      for (int k = 227 + tid; k < 454; k += 256) nv[q++] = mt_mix(mt[k], mt[k + 1], mt[k - 227]);
+      for (int k = 227 + tid; k < 454; k += 256) nv[q++] = mt_mix(sh.mt[k], sh.mt[k + 1], sh.mt[k - 227]);
       __syncthreads(); q = 0;
-      for (int k = 227 + tid; k < 454; k += 256) mt[k] = nv[q++];
+      for (int k = 227 + tid; k < 454; k += 256) sh.mt[k] = nv[q++];
       __syncthreads(); q = 0;
-      for (int k = 454 + tid; k < 623; k += 256) nv[q++] = mt_mix(mt[k], mt[k + 1], mt[k - 227]);
+      for (int k = 454 + tid; k < 623; k += 256) nv[q++] = mt_mix(sh.mt[k], sh.mt[k + 1], sh.mt[k - 227]);
       __syncthreads(); q = 0;
-      for (int k = 454 + tid; k < 623; k += 256) mt[k] = nv[q++];
+      for (int k = 454 + tid; k < 623; k += 256) sh.mt[k] = nv[q++];
       __syncthreads();
-      if (tid == 0) { mt[623] = mt_mix(mt[623], mt[0], mt[396]); s_pos = 0; }
+      if (tid == 0) { sh.mt[623] = mt_mix(sh.mt[623], sh.mt[0], sh.mt[396]); sh.pos = 0; }
       __syncthreads();
       pos = 0;
     }
     const int avail = MT_N - pos, take = avail < 256 ? avail : 256;
     bool ok = false; uint32_t v = 0;
-    if (tid < take) { v = mt_temper(mt[pos + tid]) & mask; ok = (v <= rng) && ((int64_t)v != excl); }
+    if (tid < take) { v = mt_temper(sh.mt[pos + tid]) & mask; ok = (v <= rng) && ((int64_t)v != excl); }
     const unsigned long long bal = __ballot(ok);
     const int lane = tid & 63, w = tid >> 6;
-    if (lane == 0) wave_cnt[w] = __popcll(bal);
+    if (lane == 0) sh.wave_cnt[w] = __popcll(bal);
     __syncthreads();
     int before = __popcll(bal & ((1ull << lane) - 1ull));
-    for (int i = 0; i < w; ++i) before += wave_cnt[i];
-    const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    for (int i = 0; i < w; ++i) before += sh.wave_cnt[i];
+    const int tot = sh.wave_cnt[0] + sh.wave_cnt[1] + sh.wave_cnt[2] + sh.wave_cnt[3];
     const int need = n - count;
     // candidates are consumed up to and including the one that completes the batch
     if (ok && before < need) out[count + before] = (int32_t)v;
-    __shared__ int s_last;
-    if (tot >= need) { if (ok && before == need - 1) s_last = tid; }
+    if (tot >= need) { if (ok && before == need - 1) sh.last = tid; }
     __syncthreads();
     if (tid == 0) {
-      if (tot >= need) { s_pos = pos + s_last + 1; s_count = n; }
-      else { s_pos = pos + take; s_count = count + tot; }
+      if (tot >= need) { sh.pos = pos + sh.last + 1; sh.count = n; }
+      else { sh.pos = pos + take; sh.count = count + tot; }
     }
     __syncthreads();
   }
-  for (int i = tid; i < MT_N; i += 256) state[i] = mt[i];
-  if (tid == 0) state[MT_N] = (uint32_t)s_pos;
+}
+
+__device__ __forceinline__ void gather_rows(const float* __restrict__ ring, int64_t capacity, int row4, const int32_t* __restrict__ idx, int n, float* __restrict__ out) {
+  const f32x4* src = reinterpret_cast<const f32x4*>(ring);
+  f32x4* dst = reinterpret_cast<f32x4*>(out);
+  for (int i = threadIdx.x; i < n * row4; i += blockDim.x) {
+    const int r = i / row4, c = i - r * row4;
+    int64_t s = idx[r];
+    s = s < 0 ? 0 : (s >= capacity ? capacity - 1 : s);
+    dst[i] = src[s * row4 + c];
+  }
+}
+
+// memory.sample(B) for the agent ring THEN the expert ring (the order train.py:173 consumes the stream) + both gathers: one launch
+__global__ __launch_bounds__(256) void k_sample2(uint32_t* __restrict__ state, int n, const int64_t* __restrict__ rs_a, const float* __restrict__ ring_a, int64_t cap_a, int row4_a,
+                                                  int32_t* __restrict__ idx_a, float* __restrict__ rows_a, const int64_t* __restrict__ rs_b, const float* __restrict__ ring_b,
+                                                  int64_t cap_b, int row4_b, int32_t* __restrict__ idx_b, float* __restrict__ rows_b) {
+  __shared__ MtShared sh;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < MT_N; i += 256) sh.mt[i] = state[i];
+  if (tid == 0) sh.pos = (int)state[MT_N];
+  __syncthreads();
+  mt_draw(sh, rs_a, n, idx_a);
+  if (ring_b) { __syncthreads(); mt_draw(sh, rs_b, n, idx_b); }
+  __syncthreads();
+  for (int i = tid; i < MT_N; i += 256) state[i] = sh.mt[i];
+  if (tid == 0) state[MT_N] = (uint32_t)sh.pos;
+  if (rows_a) gather_rows(ring_a, cap_a, row4_a, idx_a, n, rows_a);
+  if (ring_b && rows_b) gather_rows(ring_b, cap_b, row4_b, idx_b, n, rows_b);
 }
 
 extern "C" int il_mt19937_sample_indices_device(uint32_t* state_dev, const int64_t* ring_state_dev, int32_t n, int32_t* out_dev, il_stream_t stream) {
   IL_CHECK_ARG(state_dev && ring_state_dev && out_dev && n > 0, "il_mt19937_sample_indices_device: bad arguments");
-  { IL_TRACE("k_mt_sample", (hipStream_t)stream); k_mt_sample<<<1, 256, 0, (hipStream_t)stream>>>(state_dev, ring_state_dev, n, out_dev); }
+  { IL_TRACE("k_sample2", stream); k_sample2<<<1, 256, 0, (hipStream_t)stream>>>(state_dev, n, ring_state_dev, nullptr, 0, 0, out_dev, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr); }
   IL_CHECK_LAUNCH("il_mt19937_sample_indices_device");
+  return IL_OK;
+}
+
+extern "C" int il_replay_sample_device(uint32_t* state_dev, int32_t n, const int64_t* ring_state_a, const float* ring_a, int64_t capacity_a, int32_t row_floats_a, int32_t* idx_a,
+                                       float* rows_a, const int64_t* ring_state_b, const float* ring_b, int64_t capacity_b, int32_t row_floats_b, int32_t* idx_b, float* rows_b,
+                                       il_stream_t stream) {
+  IL_CHECK_ARG(state_dev && ring_state_a && ring_a && idx_a && rows_a && n > 0, "il_replay_sample_device: bad arguments for ring A");
+  IL_CHECK_ARG(row_floats_a % 4 == 0 && (!ring_b || (row_floats_b % 4 == 0 && ring_state_b && idx_b && rows_b)), "il_replay_sample_device: bad arguments for ring B");
+  { IL_TRACE("k_sample2", stream); k_sample2<<<1, 256, 0, (hipStream_t)stream>>>(state_dev, n, ring_state_a, ring_a, capacity_a, row_floats_a / 4, idx_a, rows_a, ring_state_b, ring_b, capacity_b,
+                                                                            row_floats_b / 4, idx_b, rows_b); }
+  IL_CHECK_LAUNCH("il_replay_sample_device");
   return IL_OK;
 }

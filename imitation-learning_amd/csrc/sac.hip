@@ -35,8 +35,12 @@ __host__ __device__ inline SacWs sac_ws(int S, int A, int H, int B) {
 }
 __host__ __device__ inline int64_t net_stride(int in, int H, int out) { return (mlp_numel(in, H, out) + 3) & ~(int64_t)3; }
 
-// LDS floats needed by the tile kernels
-static inline size_t tile_lds_bytes(int in_pad, int H) { return sizeof(float) * ((size_t)IL_TILE_R * (in_pad + 4) + 2 * (size_t)IL_TILE_R * (H + 4) + 4 * 256 + 256 + 64); }
+// one wave per 16 hidden columns (4 waves per SIMD at H = 256), never fewer than 4 waves
+static inline int tile_threads(int H) { return H * 4 < 256 ? 256 : H * 4; }
+// LDS bytes needed by the tile kernels
+static inline size_t tile_lds_bytes(int in_pad, int H) {
+  return sizeof(float) * ((size_t)IL_TILE_R * (in_pad + 4) + 2 * (size_t)IL_TILE_R * (H + 4) + (size_t)(tile_threads(H) / 64) * 256 + 256 + 64);
+}
 
 // ---------------------------------------------------------------------------------------------
 // tanh-Gaussian head for one (row, action component); op order follows torch.distributions (see oracle/nets.py)
@@ -52,14 +56,14 @@ __device__ __forceinline__ void head_sample(float mean, float ls_raw, float eps,
 }
 
 // mode: 0 = next rows then current rows (grid 2*nt), 1 = next only, 2 = current only
-__global__ __launch_bounds__(256) void k_actor_fwd(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, int mode) {
+__global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, int mode) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
   const int nt = B / IL_TILE_R;
   const bool is_cur = (mode == 2) || (mode == 0 && (int)blockIdx.x >= nt);
   const int tile = (int)blockIdx.x % nt, row0 = tile * IL_TILE_R;
   const int Sp = round_up16(S), ldx = Sp + 4, ldh = H + 4;
-  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* part = H2s + IL_TILE_R * ldh; float* Os = part + 4 * 256;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* part = H2s + IL_TILE_R * ldh; float* Os = part + (blockDim.x >> 6) * 256;
   float* red = Os + 256;
   const SacWs ws = sac_ws(S, A, H, B);
   float* W = d.workspace;
@@ -69,30 +73,24 @@ __global__ __launch_bounds__(256) void k_actor_fwd(il_sac d, il_batch b, const f
   load_rows_cat(Xs, ldx, Sp, src, ld, S, nullptr, 0, 0, row0, IL_TILE_R);
   __syncthreads();
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-  tile_fwd(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4* acc) {
+  tile_fwd(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4 acc) {
+    const int col = c0 + j; const float bb = net.b1[col];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int col = c0 + 16 * t + j; const float bb = net.b1[col];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float h = fmaxf(acc[t][r] + bb, 0.f);
+    for (int r = 0; r < 4; ++r) {
+        const float h = fmaxf(acc[r] + bb, 0.f);
         H1s[(4 * g + r) * ldh + col] = h;
         if (is_cur) W[ws.a_h1 + (size_t)(row0 + 4 * g + r) * H + col] = h;
       }
-    }
   });
   __syncthreads();
-  tile_fwd(H1s, ldh, H, net.W2, H, H, H, [&](int c0, f32x4* acc) {
+  tile_fwd(H1s, ldh, H, net.W2, H, H, H, [&](int c0, f32x4 acc) {
+    const int col = c0 + j; const float bb = net.b2[col];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int col = c0 + 16 * t + j; const float bb = net.b2[col];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float h = fmaxf(acc[t][r] + bb, 0.f);
+    for (int r = 0; r < 4; ++r) {
+        const float h = fmaxf(acc[r] + bb, 0.f);
         H2s[(4 * g + r) * ldh + col] = h;
         if (is_cur) W[ws.a_h2 + (size_t)(row0 + 4 * g + r) * H + col] = h;
       }
-    }
   });
   __syncthreads();
   tile_fwd_small(H2s, ldh, H, net.W3, H, 2 * A, net.b3, Os, part);
@@ -139,7 +137,7 @@ __device__ __forceinline__ void critic_head(const float* H2s, int ldh, int H, co
   }
 }
 
-__global__ __launch_bounds__(256) void k_critic_fwd(il_sac d, il_batch b) {
+__global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
@@ -158,30 +156,24 @@ __global__ __launch_bounds__(256) void k_critic_fwd(il_sac d, il_batch b) {
     for (int i = threadIdx.x; i < IL_TILE_R * IN; i += blockDim.x) { const int r = i / IN, c = i - r * IN; W[ws.c_x0 + (size_t)(row0 + r) * IN + c] = Xs[r * ldx + c]; }
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   float* sh1 = W + ws.c_h1 + (size_t)k * B * H; float* sh2 = W + ws.c_h2 + (size_t)k * B * H;
-  tile_fwd(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4* acc) {
+  tile_fwd(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4 acc) {
+    const int col = c0 + j; const float bb = p.b1[col];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int col = c0 + 16 * t + j; const float bb = p.b1[col];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float h = fmaxf(acc[t][r] + bb, 0.f);
+    for (int r = 0; r < 4; ++r) {
+        const float h = fmaxf(acc[r] + bb, 0.f);
         H1s[(4 * g + r) * ldh + col] = h;
         if (!is_target) sh1[(size_t)(row0 + 4 * g + r) * H + col] = h;
       }
-    }
   });
   __syncthreads();
-  tile_fwd(H1s, ldh, H, p.W2, H, H, H, [&](int c0, f32x4* acc) {
+  tile_fwd(H1s, ldh, H, p.W2, H, H, H, [&](int c0, f32x4 acc) {
+    const int col = c0 + j; const float bb = p.b2[col];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int col = c0 + 16 * t + j; const float bb = p.b2[col];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float h = fmaxf(acc[t][r] + bb, 0.f);
+    for (int r = 0; r < 4; ++r) {
+        const float h = fmaxf(acc[r] + bb, 0.f);
         H2s[(4 * g + r) * ldh + col] = h;
         if (!is_target) sh2[(size_t)(row0 + 4 * g + r) * H + col] = h;
       }
-    }
   });
   __syncthreads();
   critic_head(H2s, ldh, H, p.W3, p.b3[0], q16);
@@ -192,7 +184,7 @@ __global__ __launch_bounds__(256) void k_critic_fwd(il_sac d, il_batch b) {
 // ---------------------------------------------------------------------------------------------
 // critic backward (training.py:24-30): y, dQ_k = w * 2 (Q_k - y) / B, dz2 = dQ w3 [h2>0], dz1 = (dz2 . W2) [h1>0].  grid = nt * 2
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_critic_bwd(il_sac d, il_batch b) {
+__global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
@@ -225,15 +217,11 @@ __global__ __launch_bounds__(256) void k_critic_bwd(il_sac d, il_batch b) {
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-  tile_bwd_dx(DZ2s, ldh, H, H, p.W2, H, H, [&](int kb, f32x4* acc) {
+  tile_bwd_dx(DZ2s, ldh, H, H, p.W2, H, H, [&](int kb, f32x4 acc) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + 4 * j;
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(h1 + off);
-      f32x4 o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = hv[i] > 0.f ? acc[i][r] : 0.f;
-      *reinterpret_cast<f32x4*>(gdz1 + off) = o;
+      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + j;
+      gdz1[off] = h1[off] > 0.f ? acc[r] : 0.f;
     }
   });
 }
@@ -241,7 +229,7 @@ __global__ __launch_bounds__(256) void k_critic_bwd(il_sac d, il_batch b) {
 // ---------------------------------------------------------------------------------------------
 // updated critic on (s, a~) and dQ_k/da~ (training.py:37, backward of :38 through the critic).  grid = nt * 2
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_policy_critic(il_sac d, il_batch b) {
+__global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
@@ -254,22 +242,16 @@ __global__ __launch_bounds__(256) void k_policy_critic(il_sac d, il_batch b) {
   load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, IL_TILE_R);
   __syncthreads();
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-  tile_fwd(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4* acc) {
+  tile_fwd(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4 acc) {
+    const int col = c0 + j; const float bb = p.b1[col];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int col = c0 + 16 * t + j; const float bb = p.b1[col];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[t][r] + bb, 0.f);
-    }
+    for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
   });
   __syncthreads();
-  tile_fwd(H1s, ldh, H, p.W2, H, H, H, [&](int c0, f32x4* acc) {
+  tile_fwd(H1s, ldh, H, p.W2, H, H, H, [&](int c0, f32x4 acc) {
+    const int col = c0 + j; const float bb = p.b2[col];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int col = c0 + 16 * t + j; const float bb = p.b2[col];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = fmaxf(acc[t][r] + bb, 0.f);
-    }
+    for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
   });
   __syncthreads();
   critic_head(H2s, ldh, H, p.W3, p.b3[0], q16);
@@ -281,18 +263,16 @@ __global__ __launch_bounds__(256) void k_policy_critic(il_sac d, il_batch b) {
     H2s[r * ldh + n] = H2s[r * ldh + n] > 0.f ? p.W3[n] : 0.f;
   }
   __syncthreads();
-  tile_bwd_dx(H2s, ldh, H, H, p.W2, H, H, [&](int kb, f32x4* acc) {
+  tile_bwd_dx(H2s, ldh, H, H, p.W2, H, H, [&](int kb, f32x4 acc) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float* h = H1s + (4 * g + r) * ldh + kb + 4 * j + i;
-        *h = *h > 0.f ? acc[i][r] : 0.f;  // dz1 in place (each element owned by exactly one lane)
-      }
+    for (int r = 0; r < 4; ++r) {
+      float* h = H1s + (4 * g + r) * ldh + kb + j;
+      *h = *h > 0.f ? acc[r] : 0.f;  // dz1 in place (each element owned by exactly one lane)
+    }
   });
   __syncthreads();
-  // g[r][c] = sum_n dz1[r][n] W1[n][S + c] : 16 threads per row, each strides n
-  {
+  // g[r][c] = sum_n dz1[r][n] W1[n][S + c] : 16 threads per row, each strides n (waves 0-3 only)
+  if (threadIdx.x < 256) {
     const int r = threadIdx.x >> 4, sub = threadIdx.x & 15;
     for (int c = 0; c < A; ++c) {
       float s = 0.f;
@@ -306,7 +286,7 @@ __global__ __launch_bounds__(256) void k_policy_critic(il_sac d, il_batch b) {
 // ---------------------------------------------------------------------------------------------
 // actor backward (training.py:38-46): L = mean(w m alpha logp - min Q).  grid = nt
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_actor_bwd(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q) {
+__global__ __launch_bounds__(1024) void k_actor_bwd(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
   const int tile = (int)blockIdx.x, row0 = tile * IL_TILE_R;
@@ -351,28 +331,21 @@ __global__ __launch_bounds__(256) void k_actor_bwd(il_sac d, il_batch b, float* 
   const int lane = tid & 63, j = lane & 15, g = lane >> 4;
   const float* h2 = W + ws.a_h2; const float* h1 = W + ws.a_h1;
   // dz2 = (dz3 . W3) [h2 > 0]
-  tile_bwd_dx(DZ3s, ldz, 16, 2 * A, net.W3, H, H, [&](int kb, f32x4* acc) {
+  tile_bwd_dx(DZ3s, ldz, 16, 2 * A, net.W3, H, H, [&](int kb, f32x4 acc) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + 4 * j;
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(h2 + off);
-      f32x4 o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = hv[i] > 0.f ? acc[i][r] : 0.f;
-      *reinterpret_cast<f32x4*>(W + ws.a_dz2 + off) = o;
-      *reinterpret_cast<f32x4*>(DZ2s + (4 * g + r) * ldh + kb + 4 * j) = o;
+      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + j;
+      const float o = h2[off] > 0.f ? acc[r] : 0.f;
+      W[ws.a_dz2 + off] = o;
+      DZ2s[(4 * g + r) * ldh + kb + j] = o;
     }
   });
   __syncthreads();
-  tile_bwd_dx(DZ2s, ldh, H, H, net.W2, H, H, [&](int kb, f32x4* acc) {
+  tile_bwd_dx(DZ2s, ldh, H, H, net.W2, H, H, [&](int kb, f32x4 acc) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + 4 * j;
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(h1 + off);
-      f32x4 o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = hv[i] > 0.f ? acc[i][r] : 0.f;
-      *reinterpret_cast<f32x4*>(W + ws.a_dz1 + off) = o;
+      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + j;
+      W[ws.a_dz1 + off] = h1[off] > 0.f ? acc[r] : 0.f;
     }
   });
 }
@@ -393,56 +366,56 @@ struct DwArgs {
   int n_dw_blocks;
   // tail
   float* log_alpha; float* alpha_grad; il_adam alpha_opt; const float* alpha_part; int n_alpha_part;
-  float* target; const float* polyak_src; int64_t polyak_n; float tau; uint32_t* noise_counter;
+  float* target; const float* polyak_src; int64_t polyak_n; double tau; uint32_t* noise_counter;
 };
 
-__device__ __forceinline__ void dw_strip(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dz, int ldz, int Nvalid, const float* __restrict__ x,
-                                         int ldx, int Kvalid, int n0, int kb, int64_t poff) {
+// one wave = one 16(n) x 16(k) tile of dW; the batch (reduction) loop is unrolled by 4 row-blocks so 32 operand loads are in
+// flight per wave, and several workgroups share a CU, so L2 latency overlaps with other waves' MFMAs.
+__device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dz, int ldz, int Nvalid, const float* __restrict__ x, int ldx,
+                                        int Kvalid, int n0, int kb, int64_t poff) {
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int B = a.batch;
-  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
-  const bool xvec = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  const bool nvalid = (n0 + j) < Nvalid;
-  for (int r0 = 0; r0 < B; r0 += 16) {
-    float av[4]; f32x4 bv[4];
+  f32x4 acc0 = zero4(), acc1 = zero4();
+  // out-of-range columns clamp their address: the rows / columns of dW they produce are discarded by the epilogue
+  const float* dzp = dz + min(n0 + j, Nvalid - 1) + (size_t)(4 * g) * ldz;
+  const float* xp = x + min(kb + j, Kvalid - 1) + (size_t)(4 * g) * ldx;
+  int r0 = 0;
+  for (; r0 + 64 <= B; r0 += 64) {
+    float av[4][4], bv[4][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int r = r0 + 4 * g + s;
-      av[s] = nvalid ? dz[(size_t)r * ldz + n0 + j] : 0.f;
-      bv[s] = load4_guard(x + (size_t)r * ldx, kb + 4 * j, Kvalid, xvec);
-    }
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      acc[0] = mfma16(av[s], bv[s][0], acc[0]);
-      acc[1] = mfma16(av[s], bv[s][1], acc[1]);
-      acc[2] = mfma16(av[s], bv[s][2], acc[2]);
-      acc[3] = mfma16(av[s], bv[s][3], acc[3]);
+      for (int s = 0; s < 4; ++s) { av[u][s] = dzp[(size_t)(r0 + 16 * u + s) * ldz]; bv[u][s] = xp[(size_t)(r0 + 16 * u + s) * ldx]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc0 = mfma16(av[u][0], bv[u][0], acc0);
+      acc1 = mfma16(av[u][1], bv[u][1], acc1);
+      acc0 = mfma16(av[u][2], bv[u][2], acc0);
+      acc1 = mfma16(av[u][3], bv[u][3], acc1);
     }
   }
-  const bool pvec = ((Kvalid & 3) == 0) && ((poff & 3) == 0) && (kb + 4 * j + 3 < Kvalid);
+  for (; r0 < B; r0 += 16) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { av[s] = dzp[(size_t)(r0 + s) * ldz]; bv[s] = xp[(size_t)(r0 + s) * ldx]; }
+    acc0 = mfma16(av[0], bv[0], acc0);
+    acc1 = mfma16(av[1], bv[1], acc1);
+    acc0 = mfma16(av[2], bv[2], acc0);
+    acc1 = mfma16(av[3], bv[3], acc1);
+  }
+  const f32x4 acc = acc0 + acc1;
+  const int k = kb + j;
+  if (k >= Kvalid) return;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int n = n0 + 4 * g + r;
     if (n >= Nvalid) continue;
-    const int64_t o = poff + (int64_t)n * Kvalid + kb + 4 * j;
-    if (pvec) {
-      f32x4 gr; gr[0] = acc[0][r]; gr[1] = acc[1][r]; gr[2] = acc[2][r]; gr[3] = acc[3][r];
-      if (a.grads_only) { *reinterpret_cast<f32x4*>(a.grads + o) = gr; continue; }
-      f32x4 p = *reinterpret_cast<f32x4*>(a.params + o), m = *reinterpret_cast<f32x4*>(a.opt.m + o), v = *reinterpret_cast<f32x4*>(a.opt.v + o);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { float pp = p[i], mm = m[i], vv = v[i]; adam_update(pp, gr[i], mm, vv, ac); p[i] = pp; m[i] = mm; v[i] = vv; }
-      *reinterpret_cast<f32x4*>(a.params + o) = p; *reinterpret_cast<f32x4*>(a.opt.m + o) = m; *reinterpret_cast<f32x4*>(a.opt.v + o) = v;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (kb + 4 * j + i >= Kvalid) continue;
-        const float gr = acc[i][r];
-        if (a.grads_only) { a.grads[o + i] = gr; continue; }
-        float pp = a.params[o + i], mm = a.opt.m[o + i], vv = a.opt.v[o + i];
-        adam_update(pp, gr, mm, vv, ac);
-        a.params[o + i] = pp; a.opt.m[o + i] = mm; a.opt.v[o + i] = vv;
-      }
-    }
+    const int64_t o = poff + (int64_t)n * Kvalid + k;
+    const float gr = acc[r];
+    if (a.grads_only) { a.grads[o] = gr; continue; }
+    float pp = a.params[o], mm = a.opt.m[o], vv = a.opt.v[o];
+    adam_update(pp, gr, mm, vv, ac);
+    a.params[o] = pp; a.opt.m[o] = mm; a.opt.v[o] = vv;
   }
 }
 
@@ -472,7 +445,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
       const float gr = -(alpha) * (s / (float)a.batch);
       if (a.grads_only) a.alpha_grad[0] = gr;
       else {
-        const adam_consts ac = make_adam_consts(a.alpha_opt.lr, a.alpha_opt.beta1, a.alpha_opt.beta2, a.alpha_opt.eps, 0.f, a.alpha_opt.step[0]);
+        const adam_consts ac = make_adam_consts(a.alpha_opt.lr, a.alpha_opt.beta1, a.alpha_opt.beta2, a.alpha_opt.eps, 0.0, a.alpha_opt.step[0]);
         float pp = a.log_alpha[0], mm = a.alpha_opt.m[0], vv = a.alpha_opt.v[0];
         adam_update(pp, gr, mm, vv, ac);
         a.log_alpha[0] = pp; a.alpha_opt.m[0] = mm; a.alpha_opt.v[0] = vv;
@@ -480,16 +453,16 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
       if (a.noise_counter) a.noise_counter[0] += 1;
     }
     if (a.target && !a.grads_only) {
-      const float omt = (float)(1.0 - (double)a.tau);
+      const float omt = (float)(1.0 - a.tau), tau = (float)a.tau;
       const int ntb = (int)gridDim.x - a.n_dw_blocks;
       for (int64_t i = ((int64_t)tb * blockDim.x + threadIdx.x) * 4; i < a.polyak_n; i += (int64_t)ntb * blockDim.x * 4) {
         if (i + 3 < a.polyak_n) {
           f32x4 t = *reinterpret_cast<f32x4*>(a.target + i); const f32x4 p = *reinterpret_cast<const f32x4*>(a.polyak_src + i);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) t[q] = __fadd_rn(__fmul_rn(t[q], a.tau), __fmul_rn(omt, p[q]));
+          for (int q = 0; q < 4; ++q) t[q] = __fadd_rn(__fmul_rn(t[q], tau), __fmul_rn(omt, p[q]));
           *reinterpret_cast<f32x4*>(a.target + i) = t;
         } else {
-          for (int64_t q = i; q < a.polyak_n; ++q) a.target[q] = __fadd_rn(__fmul_rn(a.target[q], a.tau), __fmul_rn(omt, a.polyak_src[q]));
+          for (int64_t q = i; q < a.polyak_n; ++q) a.target[q] = __fadd_rn(__fmul_rn(a.target[q], tau), __fmul_rn(omt, a.polyak_src[q]));
         }
       }
     }
@@ -497,8 +470,8 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
   }
   // ---- job decode (wave-uniform)
   const int IN = a.in_dim, H = a.hidden, OUT = a.out_dim;
-  const int nt_h = H / 16, ks_in = (IN + 63) / 64, ks_h = H / 64, nt_out = (OUT + 15) / 16, nb_h = H / 64;
-  const int j1 = nt_h * ks_in, j2 = nt_h * ks_h, j3 = nt_out * ks_h, jb = 2 * nb_h + 1;
+  const int nt_h = H / 16, kt_in = (IN + 15) / 16, nt_out = (OUT + 15) / 16, nb_h = H / 64;
+  const int j1 = nt_h * kt_in, j2 = nt_h * nt_h, j3 = nt_out * nt_h, jb = 2 * nb_h + 1;
   const int per_net = j1 + j2 + j3 + jb;
   int job = (int)blockIdx.x * 4 + wave_in_block;
   if (job >= per_net * a.n_nets) return;
@@ -510,11 +483,12 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
   const float* h1 = a.h1 + net * a.h_net_stride; const float* h2 = a.h2 + net * a.h_net_stride;
   const float* dz1 = a.dz1 + net * a.h_net_stride; const float* dz2 = a.dz2 + net * a.h_net_stride;
   const float* dz3 = a.dz3 + net * a.dz3_net_stride;
-  if (job < j1) { dw_strip(a, ac, dz1, H, H, x0, a.ld_x0, IN, (job / ks_in) * 16, (job % ks_in) * 64, oW1); return; }
-  job -= j1;
-  if (job < j2) { dw_strip(a, ac, dz2, H, H, h1, H, H, (job / ks_h) * 16, (job % ks_h) * 64, oW2); return; }
+  // the big layer first: its tiles are the long pole, the small jobs fill in behind them
+  if (job < j2) { dw_tile(a, ac, dz2, H, H, h1, H, H, (job / nt_h) * 16, (job % nt_h) * 16, oW2); return; }
   job -= j2;
-  if (job < j3) { dw_strip(a, ac, dz3, a.ld_dz3, OUT, h2, H, H, (job / ks_h) * 16, (job % ks_h) * 64, oW3); return; }
+  if (job < j1) { dw_tile(a, ac, dz1, H, H, x0, a.ld_x0, IN, (job / kt_in) * 16, (job % kt_in) * 16, oW1); return; }
+  job -= j1;
+  if (job < j3) { dw_tile(a, ac, dz3, a.ld_dz3, OUT, h2, H, H, (job / nt_h) * 16, (job % nt_h) * 16, oW3); return; }
   job -= j3;
   if (job < nb_h) { dw_bias(a, ac, dz1, H, H, job * 64, ob1); return; }
   job -= nb_h;
@@ -523,10 +497,9 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
 }
 
 static int dw_blocks(int IN, int H, int OUT, int nets) {
-  const int per_net = (H / 16) * ((IN + 63) / 64) + (H / 16) * (H / 64) + ((OUT + 15) / 16) * (H / 64) + 2 * (H / 64) + 1;
+  const int per_net = (H / 16) * ((IN + 15) / 16) + (H / 16) * (H / 16) + ((OUT + 15) / 16) * (H / 16) + 2 * (H / 64) + 1;
   return ceil_div(per_net * nets, 4);
 }
-
 // generic elementwise Adam over a flat arena (data-parallel path and stand-alone use)
 __global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, const float* __restrict__ g, il_adam opt, int64_t n) {
   const adam_consts ac = make_adam_consts(opt.lr, opt.beta1, opt.beta2, opt.eps, opt.weight_decay, opt.step[0]);
@@ -537,8 +510,8 @@ __global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, const 
   }
 }
 __global__ void k_tick(int32_t* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
-__global__ __launch_bounds__(256) void k_polyak(float* __restrict__ t, const float* __restrict__ p, int64_t n, float tau) {
-  const float omt = (float)(1.0 - (double)tau);
+__global__ __launch_bounds__(256) void k_polyak(float* __restrict__ t, const float* __restrict__ p, int64_t n, double tau_) {
+  const float omt = (float)(1.0 - tau_), tau = (float)tau_;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     t[i] = __fadd_rn(__fmul_rn(t[i], tau), __fmul_rn(omt, p[i]));
 }
@@ -580,9 +553,9 @@ extern "C" int il_sac_critic_step(const il_sac* d, const il_batch* b, const floa
   hipStream_t st = (hipStream_t)stream_;
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
-  { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, 256, lds, st>>>(*d, *b, eps_next, nullptr, 1); }
-  { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, 256, lds, st>>>(*d, *b); }
-  { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, 256, lds, st>>>(*d, *b); }
+  { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, nullptr, 1); }
+  { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, tile_threads(H), lds, st>>>(*d, *b); }
+  { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b); }
   DwArgs a = critic_dw_args(d, flags);
   { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<a.n_dw_blocks, 256, 0, st>>>(a); }
   IL_CHECK_LAUNCH("il_sac_critic_step");
@@ -609,9 +582,9 @@ extern "C" int il_sac_actor_step(const il_sac* d, const il_batch* b, const float
   hipStream_t st = (hipStream_t)stream_;
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
-  { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, 256, lds, st>>>(*d, *b, nullptr, eps_cur, 2); }
-  { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, 256, lds, st>>>(*d, *b); }
-  { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, 256, lds, st>>>(*d, *b, out_logp, out_q); }
+  { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, eps_cur, 2); }
+  { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b); }
+  { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q); }
   DwArgs a = actor_dw_args(d, b, flags);
   const int tail = 1 + ((flags & IL_FLAG_GRADS_ONLY) ? 0 : 32);
   { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<a.n_dw_blocks + tail, 256, 0, st>>>(a); }
@@ -626,14 +599,14 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   // the actor is unchanged until the last kernel of the update: both of its forward passes share one launch
-  { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<2 * nt, 256, lds, st>>>(*d, *b, eps_next, eps_cur, 0); }
-  { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, 256, lds, st>>>(*d, *b); }
-  { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, 256, lds, st>>>(*d, *b); }
+  { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, 0); }
+  { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, tile_threads(H), lds, st>>>(*d, *b); }
+  { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b); }
   DwArgs ca = critic_dw_args(d, flags);
   { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
   if (flags & IL_FLAG_GRADS_ONLY) { IL_CHECK_LAUNCH("il_sac_update"); return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update: IL_FLAG_GRADS_ONLY needs the split critic/actor entry points"); }
-  { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, 256, lds, st>>>(*d, *b); }
-  { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, 256, lds, st>>>(*d, *b, out_logp, out_q); }
+  { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b); }
+  { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q); }
   DwArgs aa = actor_dw_args(d, b, flags);
   { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 33, 256, 0, st>>>(aa); }
   IL_CHECK_LAUNCH("il_sac_update");
@@ -650,7 +623,7 @@ extern "C" int il_adam_step(float* p, const float* g, const il_adam* opt, int64_
   return IL_OK;
 }
 
-extern "C" int il_polyak(float* target, const float* param, int64_t n, float tau, il_stream_t stream_) {
+extern "C" int il_polyak(float* target, const float* param, int64_t n, double tau, il_stream_t stream_) {
   IL_CHECK_ARG(target && param && n > 0, "il_polyak: bad arguments");
   const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   { IL_TRACE("k_polyak", (hipStream_t)stream_); k_polyak<<<blocks, 256, 0, (hipStream_t)stream_>>>(target, param, n, tau); }
@@ -665,7 +638,7 @@ extern "C" int il_sac_apply_critic_grads(const il_sac* d, il_stream_t stream_) {
 
 __global__ void k_alpha_adam(float* log_alpha, const float* g, il_adam opt) {
   if (threadIdx.x || blockIdx.x) return;
-  const adam_consts ac = make_adam_consts(opt.lr, opt.beta1, opt.beta2, opt.eps, 0.f, opt.step[0]);
+  const adam_consts ac = make_adam_consts(opt.lr, opt.beta1, opt.beta2, opt.eps, 0.0, opt.step[0]);
   float pp = log_alpha[0], mm = opt.m[0], vv = opt.v[0];
   adam_update(pp, g[0], mm, vv, ac);
   log_alpha[0] = pp; opt.m[0] = mm; opt.v[0] = vv;
@@ -683,12 +656,12 @@ extern "C" int il_sac_apply_actor_grads(const il_sac* d, il_stream_t stream_) {
 // backward to the pre-activations -- one tile kernel (activations stay in LDS between forward and backward) -- then the
 // shared k_dw_adam.  grid = nt
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bc_tile(const float* __restrict__ actor, il_adam opt, int S, int A, int H, il_batch b, float* __restrict__ W,
+__global__ __launch_bounds__(1024) void k_bc_tile(const float* __restrict__ actor, il_adam opt, int S, int A, int H, il_batch b, float* __restrict__ W,
                                                  float* __restrict__ loss_part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int B = b.n, tile = blockIdx.x, row0 = tile * IL_TILE_R, tid = threadIdx.x;
   const int Sp = round_up16(S), ldx = Sp + 4, ldh = H + 4, ldz = 20;
-  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* part = H2s + IL_TILE_R * ldh; float* Os = part + 4 * 256;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* part = H2s + IL_TILE_R * ldh; float* Os = part + (blockDim.x >> 6) * 256;
   float* red = Os + 256;
   float* DZ3s = part;  // reused after the head
   const SacWs ws = sac_ws(S, A, H, B);
@@ -696,22 +669,16 @@ __global__ __launch_bounds__(256) void k_bc_tile(const float* __restrict__ actor
   load_rows_cat(Xs, ldx, Sp, b.states, b.ld_states, S, nullptr, 0, 0, row0, IL_TILE_R);
   __syncthreads();
   const int lane = tid & 63, j = lane & 15, g = lane >> 4;
-  tile_fwd(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4* acc) {
+  tile_fwd(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4 acc) {
+    const int col = c0 + j; const float bb = net.b1[col];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int col = c0 + 16 * t + j; const float bb = net.b1[col];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { const float h = fmaxf(acc[t][r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = h; W[ws.a_h1 + (size_t)(row0 + 4 * g + r) * H + col] = h; }
-    }
+    for (int r = 0; r < 4; ++r) { const float h = fmaxf(acc[r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = h; W[ws.a_h1 + (size_t)(row0 + 4 * g + r) * H + col] = h; }
   });
   __syncthreads();
-  tile_fwd(H1s, ldh, H, net.W2, H, H, H, [&](int c0, f32x4* acc) {
+  tile_fwd(H1s, ldh, H, net.W2, H, H, H, [&](int c0, f32x4 acc) {
+    const int col = c0 + j; const float bb = net.b2[col];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int col = c0 + 16 * t + j; const float bb = net.b2[col];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { const float h = fmaxf(acc[t][r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = h; W[ws.a_h2 + (size_t)(row0 + 4 * g + r) * H + col] = h; }
-    }
+    for (int r = 0; r < 4; ++r) { const float h = fmaxf(acc[r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = h; W[ws.a_h2 + (size_t)(row0 + 4 * g + r) * H + col] = h; }
   });
   __syncthreads();
   tile_fwd_small(H2s, ldh, H, net.W3, H, 2 * A, net.b3, Os, part);
@@ -742,28 +709,21 @@ __global__ __launch_bounds__(256) void k_bc_tile(const float* __restrict__ actor
   for (int i = tid; i < IL_TILE_R * 16; i += blockDim.x) W[ws.a_dz3 + (size_t)row0 * 16 + i] = DZ3s[(i >> 4) * ldz + (i & 15)];
   float* DZ2s = H1s;  // h1 lives in the workspace copy from here on
   __syncthreads();
-  tile_bwd_dx(DZ3s, ldz, 16, 2 * A, net.W3, H, H, [&](int kb, f32x4* acc) {
+  tile_bwd_dx(DZ3s, ldz, 16, 2 * A, net.W3, H, H, [&](int kb, f32x4 acc) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + 4 * j;
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(H2s + (4 * g + r) * ldh + kb + 4 * j);
-      f32x4 o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = hv[i] > 0.f ? acc[i][r] : 0.f;
-      *reinterpret_cast<f32x4*>(W + ws.a_dz2 + off) = o;
-      *reinterpret_cast<f32x4*>(DZ2s + (4 * g + r) * ldh + kb + 4 * j) = o;
+      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + j;
+      const float o = H2s[(4 * g + r) * ldh + kb + j] > 0.f ? acc[r] : 0.f;
+      W[ws.a_dz2 + off] = o;
+      DZ2s[(4 * g + r) * ldh + kb + j] = o;
     }
   });
   __syncthreads();
-  tile_bwd_dx(DZ2s, ldh, H, H, net.W2, H, H, [&](int kb, f32x4* acc) {
+  tile_bwd_dx(DZ2s, ldh, H, H, net.W2, H, H, [&](int kb, f32x4 acc) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + 4 * j;
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(W + ws.a_h1 + off);
-      f32x4 o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = hv[i] > 0.f ? acc[i][r] : 0.f;
-      *reinterpret_cast<f32x4*>(W + ws.a_dz1 + off) = o;
+      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + j;
+      W[ws.a_dz1 + off] = W[ws.a_h1 + off] > 0.f ? acc[r] : 0.f;
     }
   });
 }
@@ -779,7 +739,7 @@ extern "C" int il_bc_step(float* actor, float* actor_grad, const il_adam* opt, i
   if (workspace_floats < ws.total) return il_set_error(IL_ERR_WORKSPACE, "il_bc_step: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)ws.total);
   hipStream_t st = (hipStream_t)stream_;
   const int nt = b->n / IL_TILE_R;
-  { IL_TRACE("k_bc_tile", st); k_bc_tile<<<nt, 256, tile_lds_bytes(round_up16(S + A), H), st>>>(actor, *opt, S, A, H, *b, workspace, out_loss_partials); }
+  { IL_TRACE("k_bc_tile", st); k_bc_tile<<<nt, tile_threads(H), tile_lds_bytes(round_up16(S + A), H), st>>>(actor, *opt, S, A, H, *b, workspace, out_loss_partials); }
   DwArgs a = {};
   a.params = actor; a.grads = actor_grad; a.opt = *opt; a.grads_only = (flags & IL_FLAG_GRADS_ONLY) ? 1 : 0;
   a.n_nets = 1; a.in_dim = S; a.hidden = H; a.out_dim = 2 * A; a.batch = b->n;
@@ -795,32 +755,26 @@ extern "C" int il_bc_step(float* actor, float* actor_grad, const il_adam* opt, i
 // ---------------------------------------------------------------------------------------------
 // Acting (train.py:152 `actor(state).sample()`, models.py:101-102 greedy): n states, any n >= 1.  grid = ceil(n/16)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_act(const float* __restrict__ actor, int S, int A, int H, const float* __restrict__ states, int ld, int n, const float* __restrict__ eps,
+__global__ __launch_bounds__(1024) void k_act(const float* __restrict__ actor, int S, int A, int H, const float* __restrict__ states, int ld, int n, const float* __restrict__ eps,
                                              uint64_t seed, uint32_t offset, int greedy, float* __restrict__ out_a, float* __restrict__ out_logp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int row0 = blockIdx.x * IL_TILE_R, tid = threadIdx.x, nrows = min(IL_TILE_R, n - row0);
   const int Sp = round_up16(S), ldx = Sp + 4, ldh = H + 4;
-  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* part = H2s + IL_TILE_R * ldh; float* Os = part + 4 * 256;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* part = H2s + IL_TILE_R * ldh; float* Os = part + (blockDim.x >> 6) * 256;
   const MlpView net = mlp_view(actor, S, H, 2 * A);
   load_rows_cat(Xs, ldx, Sp, states, ld, S, nullptr, 0, 0, row0, nrows);
   __syncthreads();
   const int lane = tid & 63, j = lane & 15, g = lane >> 4;
-  tile_fwd(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4* acc) {
+  tile_fwd(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4 acc) {
+    const int col = c0 + j; const float bb = net.b1[col];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int col = c0 + 16 * t + j; const float bb = net.b1[col];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[t][r] + bb, 0.f);
-    }
+    for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
   });
   __syncthreads();
-  tile_fwd(H1s, ldh, H, net.W2, H, H, H, [&](int c0, f32x4* acc) {
+  tile_fwd(H1s, ldh, H, net.W2, H, H, H, [&](int c0, f32x4 acc) {
+    const int col = c0 + j; const float bb = net.b2[col];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int col = c0 + 16 * t + j; const float bb = net.b2[col];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = fmaxf(acc[t][r] + bb, 0.f);
-    }
+    for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
   });
   __syncthreads();
   tile_fwd_small(H2s, ldh, H, net.W3, H, 2 * A, net.b3, Os, part);
@@ -850,7 +804,7 @@ extern "C" int il_actor_act(const float* actor, int32_t S, int32_t A, int32_t H,
   IL_CHECK_ARG(H % 64 == 0 && H >= 64 && H <= 256 && A >= 1 && 2 * A <= 16, "il_actor_act: unsupported dims (hidden=%d, action_dim=%d)", H, A);
   {
     IL_TRACE("k_act", stream_);
-    k_act<<<ceil_div(n, IL_TILE_R), 256, tile_lds_bytes(round_up16(S + A), H), (hipStream_t)stream_>>>(actor, S, A, H, states, ld_states, n, eps, noise_seed, noise_offset, greedy,
+    k_act<<<ceil_div(n, IL_TILE_R), tile_threads(H), tile_lds_bytes(round_up16(S + A), H), (hipStream_t)stream_>>>(actor, S, A, H, states, ld_states, n, eps, noise_seed, noise_offset, greedy,
                                                                                                        out_action, out_logp);
   }
   IL_CHECK_LAUNCH("il_actor_act");

@@ -60,9 +60,8 @@ class DataParallelUpdate:
   def run(self):
     p, L, st = self.plan, _lib.lib(), _lib.stream_ptr()
     G = _lib.IL_FLAG_GRADS_ONLY
-    p._sample(p.memory, p.idx, p.rows)
+    p.sample_all()
     if p.algorithm == 'GAIL':
-      p._sample(p.expert_memory, p.eidx, p.erows)
       _lib.check(L.il_gail_disc_step(C.byref(p.disc), C.byref(p.pb), C.byref(p.eb), None, G, st))
       all_reduce_mean_(self.disc_bucket, self.group)
       _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))

@@ -217,11 +217,25 @@ class UpdatePlan:
       idx.copy_(mem._sample_idx_tensor(self.B))
       _lib.check(_lib.lib().il_replay_gather(_lib.ptr(mem.ring), mem.size, mem.row, _lib.ptr(idx), self.B, _lib.ptr(rows), _lib.stream_ptr()))
 
+  def sample_all(self):
+    """Agent batch then expert batch (the order train.py:173 consumes the index stream); one launch when drawn on the device."""
+    if not self.device_index_draw:
+      self._sample(self.memory, self.idx, self.rows)
+      if self.algorithm == 'GAIL':
+        self._sample(self.expert_memory, self.eidx, self.erows)
+      return
+    from .memory import index_stream
+    m, e = self.memory, (self.expert_memory if self.algorithm == 'GAIL' else None)
+    st = index_stream().device_state(m.device)
+    _lib.check(_lib.lib().il_replay_sample_device(
+        _lib.ptr(st), self.B, _lib.ptr(m._ring_state), _lib.ptr(m.ring), m.size, m.row, _lib.ptr(self.idx), _lib.ptr(self.rows),
+        _lib.ptr(e._ring_state) if e else None, _lib.ptr(e.ring) if e else None, e.size if e else 0, e.row if e else 0, _lib.ptr(self.eidx) if e else None,
+        _lib.ptr(self.erows) if e else None, _lib.stream_ptr()))
+
   def run(self):
     L, st = _lib.lib(), _lib.stream_ptr()
-    self._sample(self.memory, self.idx, self.rows)
+    self.sample_all()
     if self.algorithm == 'GAIL':
-      self._sample(self.expert_memory, self.eidx, self.erows)
       _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, 0, st))
       _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, st))
     _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), 0, st))

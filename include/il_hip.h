@@ -87,6 +87,11 @@ int il_mt19937_sample_indices(uint32_t* state_host, int32_t n, int64_t size, int
 /* Same stream, generated ON the device (state_dev = 625 uint32 in HBM) so a captured update needs no H2D copy.
  * ring_state_dev = {int64 idx, int64 full, int64 size}. */
 int il_mt19937_sample_indices_device(uint32_t* state_dev, const int64_t* ring_state_dev, int32_t n, int32_t* out_dev, il_stream_t stream);
+/* train.py:173 `memory.sample(B), expert_memory.sample(B)` in ONE launch: n draws for ring A, then n for ring B (same stream,
+ * same order as the reference), then both row gathers. Ring B may be NULL (algorithm=SAC). */
+int il_replay_sample_device(uint32_t* state_dev, int32_t n, const int64_t* ring_state_a, const float* ring_a, int64_t capacity_a, int32_t row_floats_a,
+                            int32_t* idx_a, float* rows_a, const int64_t* ring_state_b, const float* ring_b, int64_t capacity_b, int32_t row_floats_b,
+                            int32_t* idx_b, float* rows_b, il_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimiser state (torch.optim.AdamW / Adam single-tensor step; reference train.py:66,84,95).
@@ -94,13 +99,14 @@ int il_mt19937_sample_indices_device(uint32_t* state_dev, const int64_t* ring_st
 typedef struct il_adam {
   float *m, *v;  /* exp_avg, exp_avg_sq */
   int32_t* step; /* device int32: number of steps taken */
-  float lr, beta1, beta2, eps, weight_decay; /* weight_decay != 0 => decoupled decay p *= 1 - lr*wd */
+  double lr, beta1, beta2, eps, weight_decay; /* Python-float hyper-parameters (1 - beta etc. are formed in double like torch does);
+                                                  weight_decay != 0 => decoupled decay p *= 1 - lr*wd */
 } il_adam;
 
 /* p <- AdamW(p, g) elementwise for n parameters using t = *opt.step (after optional IL_FLAG_TICK). */
 int il_adam_step(float* p, const float* g, const il_adam* opt, int64_t n, uint32_t flags, il_stream_t stream);
 /* models.py:79-81 update_target_network: target <- tau*target + (1-tau)*param */
-int il_polyak(float* target, const float* param, int64_t n, float tau, il_stream_t stream);
+int il_polyak(float* target, const float* param, int64_t n, double tau, il_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * SAC (reference training.py:14-54 `sac_update`; models.py:84-141 SoftActor / TwinCritic).
@@ -113,7 +119,8 @@ typedef struct il_sac {
   float *log_alpha; /* [1]                                                        */
   float *actor_grad, *critic_grad, *alpha_grad; /* [Pa], [2*Ps], [1]: filled when IL_FLAG_GRADS_ONLY */
   il_adam actor_opt, critic_opt, alpha_opt;
-  float discount, entropy_target, polyak;
+  float discount, entropy_target;
+  double polyak;
   float* workspace;          /* >= il_sac_workspace_floats() floats */
   int64_t workspace_floats;
   uint64_t noise_seed;       /* Philox4x32-10 key when eps pointers are NULL */
