@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 def run_smoke(gi, np, torch):
   import imitation_learning_amd as il
-  from gpu_util import N, T, close, crit_from_flat, make_disc, make_sac, make_sac_oracle, tbatch
+  from gpu_util import N, T, close, close_params, crit_from_flat, make_disc, make_sac, make_sac_oracle, tbatch
   from oracle import gail as ogail
   from oracle import sac as osac
   c = gi.sac_case(1, 'hopper', 64, 32, 1)
@@ -30,5 +30,5 @@ def run_smoke(gi, np, torch):
   ologp, oq = osac.sac_update(st, ob, c['eps_next'][0], c['eps_cur'][0], discount=c['discount'], entropy_target=c['entropy_target'], polyak_factor=c['polyak'], lr=c['lr'])
   close(N(d.flat), ods.pack(), 'smoke disc params', atol_scale=4e-6); close(N(tb['rewards']), ob['rewards'], 'smoke rewards', rtol=1e-4, atol_scale=1e-5)
   close(N(logp), ologp, 'smoke logp', atol_scale=4e-6); close(N(q), oq, 'smoke q', atol_scale=4e-6)
-  close(N(actor.flat), st.actor, 'smoke actor', atol_scale=1e-5); close(crit_from_flat(critic, critic.flat), st.critic, 'smoke critic', atol_scale=1e-5)
+  close_params(N(actor.flat), st.actor, 'smoke actor', c['lr']); close_params(crit_from_flat(critic, critic.flat), st.critic, 'smoke critic', c['lr'])
   print('smoke ok: SAC+GAIL update on', torch.cuda.get_device_name(0), 'matches the oracle')

@@ -38,6 +38,21 @@ def close(a, b, name, rtol=1e-5, atol_scale=2e-6):
   assert float(err.max()) <= atol, f'{name}: max excess err {err.max():.3e} > atol {atol:.3e} at flat index {i} (hip {a.ravel()[i]:.8e} vs oracle {b.ravel()[i]:.8e})'
 
 
+def close_params(a, b, name, lr, steps=1, rtol=1e-5, atol_scale=1e-5, outlier_frac=2e-3):
+  """Parameters after Adam. Adam normalises the gradient, so an element whose true gradient is ~eps_adam (1e-8) turns ulp-level
+  gradient noise into an O(lr) difference (d update / d g = lr * eps / (|g| + eps)^2). Hence: EVERY element within the tight bound
+  plus one full Adam step per update (lr * steps), and all but a `outlier_frac` fraction within the tight bound itself."""
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  assert a.shape == b.shape, (name, a.shape, b.shape)
+  assert np.isfinite(a).all(), f'{name}: non-finite values in the HIP result'
+  tight = rtol * np.abs(b) + atol_scale * max(float(np.abs(b).max()), 1e-30)
+  err = np.abs(a - b)
+  worst = int((err - tight).argmax())
+  assert (err <= tight + 1.01 * lr * steps).all(), f'{name}: element {worst} off by {err[worst]:.3e} (> one Adam step): hip {a.ravel()[worst]:.8e} vs oracle {b.ravel()[worst]:.8e}'
+  frac = float((err > tight).mean())
+  assert frac <= outlier_frac, f'{name}: {frac:.2e} of the elements exceed the tight bound (allowed {outlier_frac:.0e}); worst {err[worst]:.3e} at {worst}'
+
+
 def tbatch(b):
   return {k: T(v) for k, v in b.items()}
 

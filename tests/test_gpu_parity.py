@@ -24,7 +24,7 @@ if torch.cuda.is_available():
   from imitation_learning_amd import _lib
   from imitation_learning_amd import memory as il_memory
   from imitation_learning_amd import training as il_training
-  from gpu_util import DEV, N, T, Cfg, close, crit_from_flat, fill_memory, make_disc, make_sac, make_sac_oracle, tbatch
+  from gpu_util import DEV, N, T, Cfg, close, close_params, crit_from_flat, fill_memory, make_disc, make_sac, make_sac_oracle, tbatch
 
 
 def load(golden_dir, name):
@@ -109,15 +109,15 @@ def test_sac_update_matches_oracle_and_reference(golden_dir, name, args):
     torch.cuda.synchronize()
     s = 1e-5 * k
     close(N(logp), ologp, f'logp step {k}', atol_scale=2e-6 * k); close(N(q), oq, f'q step {k}', atol_scale=2e-6 * k)
-    close(N(actor.flat), st.actor, f'actor step {k}', atol_scale=s); close(crit_from_flat(critic, critic.flat), st.critic, f'critic step {k}', atol_scale=s)
-    close(crit_from_flat(critic, target.flat), st.target, f'target step {k}', atol_scale=s); close(N(log_alpha), st.log_alpha, f'log_alpha step {k}')
+    close_params(N(actor.flat), st.actor, f'actor step {k}', c['lr'], k); close_params(crit_from_flat(critic, critic.flat), st.critic, f'critic step {k}', c['lr'], k)
+    close_params(crit_from_flat(critic, target.flat), st.target, f'target step {k}', c['lr'], k); close(N(log_alpha), st.log_alpha, f'log_alpha step {k}')
     close(N(ao.exp_avg), st.actor_m, f'actor m step {k}', atol_scale=s); close(N(ao.exp_avg_sq), st.actor_v, f'actor v step {k}', atol_scale=s)
     close(crit_from_flat(critic, co.exp_avg), st.critic_m, f'critic m step {k}', atol_scale=s)
     # and against the reference-generated vectors directly
     close(N(logp), g[f'logp_{k}'], f'golden logp {k}', atol_scale=2e-6 * k); close(N(q), g[f'q_{k}'], f'golden q {k}', atol_scale=2e-6 * k)
-    close(gi.strided(N(actor.flat)), g[f'actor_{k}'], f'golden actor {k}', atol_scale=s)
-    close(gi.strided(crit_from_flat(critic, critic.flat)), g[f'critic_{k}'], f'golden critic {k}', atol_scale=s)
-    close(gi.strided(crit_from_flat(critic, target.flat)), g[f'target_{k}'], f'golden target {k}', atol_scale=s)
+    close_params(gi.strided(N(actor.flat)), g[f'actor_{k}'], f'golden actor {k}', c['lr'], k)
+    close_params(gi.strided(crit_from_flat(critic, critic.flat)), g[f'critic_{k}'], f'golden critic {k}', c['lr'], k)
+    close_params(gi.strided(crit_from_flat(critic, target.flat)), g[f'target_{k}'], f'golden target {k}', c['lr'], k)
     close(N(log_alpha), g[f'log_alpha_{k}'], f'golden log_alpha {k}')
   assert int(ao.step_count[0]) == args[-1] and int(co.step_count[0]) == args[-1] and int(to.step_count[0]) == args[-1]
 
@@ -145,8 +145,8 @@ def test_sac_gradients_match_oracle(golden_dir, name, args):
   close(N(to.grad), gr['alpha'], 'alpha grad'); close(N(to.grad), g['g_alpha_1'], 'golden alpha grad')
   _lib.check(L.il_sac_apply_actor_grads(C.byref(d), s))
   torch.cuda.synchronize()
-  close(N(actor.flat), st.actor, 'actor after split step', atol_scale=1e-5); close(crit_from_flat(critic, critic.flat), st.critic, 'critic after split step', atol_scale=1e-5)
-  close(crit_from_flat(critic, target.flat), st.target, 'target after split step', atol_scale=1e-5); close(N(log_alpha), st.log_alpha, 'log_alpha after split step')
+  close_params(N(actor.flat), st.actor, 'actor after split step', c['lr']); close_params(crit_from_flat(critic, critic.flat), st.critic, 'critic after split step', c['lr'])
+  close_params(crit_from_flat(critic, target.flat), st.target, 'target after split step', c['lr']); close(N(log_alpha), st.log_alpha, 'log_alpha after split step')
 
 
 def test_bc_update_matches_oracle_and_reference(golden_dir):
@@ -165,8 +165,8 @@ def test_bc_update_matches_oracle_and_reference(golden_dir):
     loss = il.behavioural_cloning_update(actor, tbatch(b), opt)
     oloss = osac.bc_update(p, m, v, k, shapes, A, b, lr=2.5e-4, weight_decay=0.01)
     close(N(loss), oloss, f'bc loss {k}', rtol=1e-5, atol_scale=1e-5)
-    close(N(actor.flat), p, f'bc actor {k}', atol_scale=1e-5 * k); close(N(opt.exp_avg), m, f'bc m {k}', atol_scale=1e-5 * k)
-    close(gi.strided(N(actor.flat)), g[f'actor_{k}'], f'golden bc actor {k}', atol_scale=1e-5 * k)
+    close_params(N(actor.flat), p, f'bc actor {k}', 2.5e-4, k); close(N(opt.exp_avg), m, f'bc m {k}', atol_scale=1e-5 * k)
+    close_params(gi.strided(N(actor.flat)), g[f'actor_{k}'], f'golden bc actor {k}', 2.5e-4, k)
     close(N(actor.log_prob(T(b['states']), T(b['actions']))), g[f'logp_{k}'], f'golden bc logp {k}', rtol=1e-4, atol_scale=1e-5)
 
 
@@ -183,7 +183,7 @@ def test_actor_act_matches_oracle():
     close(N(actor.get_greedy_action(T(s))), np.tanh(mean), f'greedy n={n}', atol_scale=4e-6)
   # Philox path: finite, in (-1, 1), reproducible distribution moments
   a = actor(T(c['batches'][0]['states'])).sample()
-  assert torch.isfinite(a).all() and float(a.abs().max()) < 1.0
+  assert torch.isfinite(a).all() and float(a.abs().max()) <= 1.0 and 0.05 < float(a.std()) < 1.0
 
 
 def test_adam_and_polyak_kernels():
