@@ -1,0 +1,94 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the data-parallel protocol of imitation-learning_amd/parallel.py
+(bucket mean all-reduce, replica broadcast, rank seeds).  The numerical claim checked is the one the design rests on: every loss
+is a mean over samples, so the mean over ranks of per-rank gradients on rank-local batches == the gradient on the concatenated batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+  return p
+
+
+def _worker(rank, world, port, out_dir):
+  for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
+    sys.path.insert(0, p)
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  import inputs as gi
+  from imitation_learning_amd import parallel
+  from oracle import gail as ogail
+  from oracle import sac as osac
+
+  # --- replicas: rank 0's parameters win
+  p = torch.full((1000,), float(rank + 1))
+  parallel.broadcast_parameters([p])
+  assert torch.all(p == 1.0)
+  assert parallel.rank_seed(10) == 10 + rank
+
+  # --- SAC critic gradient + GAIL gradient on this rank's shard of a global batch of 64
+  c = gi.sac_case(21, 'hopper', 64, 64, 1)
+  g = gi.gail_case(22, env='hopper', hidden=32, batch=64, steps=1)
+  half = slice(rank * 32, (rank + 1) * 32)
+  shard = lambda b: {k: v[half] for k, v in b.items()}
+  st = osac.SacState(c['S'], c['A'], c['H'])
+  st.actor[:], st.critic[:], st.target[:], st.log_alpha[:] = c['actor'], c['critic'], c['target'], c['log_alpha']
+  _, _, gr = osac.sac_update(st, shard(c['batches'][0]), c['eps_next'][0][half], c['eps_cur'][0][half], discount=c['discount'], entropy_target=c['entropy_target'],
+                             polyak_factor=c['polyak'], return_grads=True)
+  bucket = torch.from_numpy(gr['critic'].copy())
+  parallel.all_reduce_mean_(bucket)
+
+  ds = ogail.DiscState(g['D'], g['H'], True)
+  for k in ('W1', 'b1', 'W2', 'b2', 'u1', 'v1', 'u2', 'v2'):
+    getattr(ds, k)[...] = g[k]
+  cat = lambda b: np.concatenate([b['states'], b['actions']], axis=1)
+  pb, eb = shard(g['policy'][0]), shard(g['expert'][0])
+  dg = ogail.gail_update(ds, cat(pb), pb['weights'], cat(eb), eb['weights'], g['eps'][0][half], lr=3e-5, weight_decay=10, grad_penalty=1.0, return_grads=True)
+  dbucket = torch.from_numpy(dg.copy())
+  parallel.all_reduce_mean_(dbucket)
+  np.savez(os.path.join(out_dir, f'rank{rank}.npz'), critic=bucket.numpy(), disc=dbucket.numpy(), u1=ds.u1)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_identity(tmp_path):
+  sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+  import inputs as gi
+  from oracle import gail as ogail
+  from oracle import sac as osac
+  world = 2
+  mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
+  # every rank holds the same averaged buckets (so replicas apply identical updates)
+  np.testing.assert_array_equal(r0['critic'], r1['critic']); np.testing.assert_array_equal(r0['disc'], r1['disc'])
+  np.testing.assert_array_equal(r0['u1'], r1['u1'])  # spectral-norm buffers depend only on the replicated weights
+  # ... and they equal the single-process gradient on the concatenated batch
+  c = gi.sac_case(21, 'hopper', 64, 64, 1)
+  st = osac.SacState(c['S'], c['A'], c['H'])
+  st.actor[:], st.critic[:], st.target[:], st.log_alpha[:] = c['actor'], c['critic'], c['target'], c['log_alpha']
+  _, _, gr = osac.sac_update(st, c['batches'][0], c['eps_next'][0], c['eps_cur'][0], discount=c['discount'], entropy_target=c['entropy_target'], polyak_factor=c['polyak'],
+                             return_grads=True)
+  scale = np.abs(gr['critic']).max()
+  assert np.abs(r0['critic'] - gr['critic']).max() <= 2e-6 * scale
+  g = gi.gail_case(22, env='hopper', hidden=32, batch=64, steps=1)
+  ds = ogail.DiscState(g['D'], g['H'], True)
+  for k in ('W1', 'b1', 'W2', 'b2', 'u1', 'v1', 'u2', 'v2'):
+    getattr(ds, k)[...] = g[k]
+  cat = lambda b: np.concatenate([b['states'], b['actions']], axis=1)
+  pb, eb = g['policy'][0], g['expert'][0]
+  dg = ogail.gail_update(ds, cat(pb), pb['weights'], cat(eb), eb['weights'], g['eps'][0], lr=3e-5, weight_decay=10, grad_penalty=1.0, return_grads=True)
+  assert np.abs(r0['disc'] - dg).max() <= 2e-6 * np.abs(dg).max()
+
+
+def test_all_reduce_mean_is_identity_without_process_group():
+  from imitation_learning_amd import parallel
+  t = torch.arange(8, dtype=torch.float32)
+  assert torch.equal(parallel.all_reduce_mean_(t.clone()), t)
