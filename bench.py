@@ -43,7 +43,7 @@ def algorithmic_model():
   Pd = HD * (S + A) + HD + HD + 1
   mac_a, mac_c = S * H + H * H + H * 2 * A, (S + A) * H + H * H + H
   bytes_k = {
-      'k_dw_adam_critic': 24 * 2 * Pc, 'k_dw_adam_actor': 24 * (Pa + 1) + 8 * 2 * Pc, 'k_gail_reduce': 24 * Pd, 'k_gather': B * (2 * S + A + 5) * 4 + B * 4,
+      'k_dw_adam_critic': 24 * 2 * Pc, 'k_dw_adam_actor': 24 * (Pa + 1) + 8 * 2 * Pc, 'k_gail_reduce': 24 * Pd, 'k_gather2': 2 * B * (2 * S + A + 5) * 4 + 2 * B * 4,
   }
   flops_k = {
       'k_actor_fwd': 2 * 2 * B * mac_a, 'k_critic_fwd': 4 * 2 * B * mac_c, 'k_critic_bwd': 2 * 2 * B * H * H, 'k_dw_adam_critic': 2 * 2 * B * mac_c,

@@ -34,7 +34,27 @@ extern "C" int64_t il_disc_workspace_floats(int32_t D, int32_t H, int32_t B) { r
 // discriminator calls depend on nothing but W, u, v, so wave 0 runs all of them up front while waves 1.. stage the batch rows.
 // W1s: LDS copy of W1 with row stride D+1 (conflict-free for both W v and W^T u).
 // ---------------------------------------------------------------------------------------------
-struct SnCtx { float *u1, *v1, *v2, *sc; };  // per pass: u1[H], v1[D], v2[H], sc = {sigma1, sigma2, u2}
+// LDS dot products with several loads in flight (a plain `for k: s += a[k]*b[k]` waits ~100 cycles per LDS read)
+__device__ __forceinline__ float dot4(const float* a, const float* b, int n4) {  // both 16-B aligned, n4 % 4 == 0
+  f32x4 s0 = zero4(), s1 = zero4();
+  int k = 0;
+  for (; k + 8 <= n4; k += 8) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(a + k), b0 = *reinterpret_cast<const f32x4*>(b + k);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(a + k + 4), b1 = *reinterpret_cast<const f32x4*>(b + k + 4);
+    s0 += a0 * b0; s1 += a1 * b1;
+  }
+  if (k < n4) s0 += *reinterpret_cast<const f32x4*>(a + k) * *reinterpret_cast<const f32x4*>(b + k);
+  s0 += s1;
+  return (s0[0] + s0[1]) + (s0[2] + s0[3]);
+}
+__device__ __forceinline__ float dot_strided(const float* a, const float* b, int bstride, int n) {  // a contiguous (16-B aligned), b[i*bstride], n % 4 == 0
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int i = 0; i < n; i += 4) {
+    const f32x4 av = *reinterpret_cast<const f32x4*>(a + i);
+    s0 += av[0] * b[(i + 0) * bstride]; s1 += av[1] * b[(i + 1) * bstride]; s2 += av[2] * b[(i + 2) * bstride]; s3 += av[3] * b[(i + 3) * bstride];
+  }
+  return (s0 + s1) + (s2 + s3);
+}
 
 // wave-synchronous LDS hand-off between lanes of ONE wave: LDS ops of a wave execute in order, this only pins the compiler
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -42,15 +62,15 @@ __device__ __forceinline__ float wave_norm_scale(float ss) { return 1.f / fmaxf(
 
 // one wave: (u1,v1,u2,v2) <- one power iteration (if iterate), then sigmas. in/out vectors live in LDS.
 __device__ __forceinline__ void sn_wave(const float* W1s, const float* W2s, int D, int H, float* u1, float* v1, float* u2, float* v2, bool iterate, float* sig) {
-  const int lane = threadIdx.x & 63, ldw = D + 1;
+  const int lane = threadIdx.x & 63, Dp = (D + 3) & ~3, ldw = Dp + 4;
   if (iterate) {
     float ss = 0.f;
-    for (int n = lane; n < H; n += 64) { float s = 0.f; for (int k = 0; k < D; ++k) s += W1s[n * ldw + k] * v1[k]; u1[n] = s; ss += s * s; }
+    for (int n = lane; n < H; n += 64) { const float s = dot4(W1s + n * ldw, v1, Dp); u1[n] = s; ss += s * s; }
     float inv = wave_norm_scale(ss);
     for (int n = lane; n < H; n += 64) u1[n] *= inv;
     WAVE_SYNC();
     ss = 0.f;
-    for (int k = lane; k < D; k += 64) { float s = 0.f; for (int n = 0; n < H; ++n) s += W1s[n * ldw + k] * u1[n]; v1[k] = s; ss += s * s; }
+    for (int k = lane; k < D; k += 64) { const float s = dot_strided(u1, W1s + k, ldw, H); v1[k] = s; ss += s * s; }
     inv = wave_norm_scale(ss);
     for (int k = lane; k < D; k += 64) v1[k] *= inv;
     WAVE_SYNC();
@@ -66,7 +86,7 @@ __device__ __forceinline__ void sn_wave(const float* W1s, const float* W2s, int 
     WAVE_SYNC();
   }
   float a = 0.f, b = 0.f;
-  for (int n = lane; n < H; n += 64) { float s = 0.f; for (int k = 0; k < D; ++k) s += W1s[n * ldw + k] * v1[k]; a += u1[n] * s; b += W2s[n] * v2[n]; }
+  for (int n = lane; n < H; n += 64) { a += u1[n] * dot4(W1s + n * ldw, v1, Dp); b += W2s[n] * v2[n]; }
   a = wave_sum(a); b = wave_sum(b);
   if (lane == 0) { sig[0] = a; sig[1] = u2[0] * b; }
   WAVE_SYNC();
@@ -74,31 +94,34 @@ __device__ __forceinline__ void sn_wave(const float* W1s, const float* W2s, int 
 
 struct DiscLds {  // per-pass arrays are contiguous and addressed arithmetically (pointer arrays indexed at run time would go to scratch)
   float *W1s, *b1s, *W2s, *Xb, *wtb, *hs, *dhs, *ts, *cg, *snb, *zs, *dzs, *red;
-  int D, H;
-  __device__ __forceinline__ float* X(int c) const { return Xb + c * IL_TILE_R * D; }
+  int D, H, Dp;  // Dp = D rounded up to 4 (rows of X / cg / v1 are zero-padded so dot products run on 16-byte lanes)
+  __device__ __forceinline__ float* X(int c) const { return Xb + c * IL_TILE_R * Dp; }
   __device__ __forceinline__ float* wt(int c) const { return wtb + c * IL_TILE_R; }
-  __device__ __forceinline__ float* u1(int c) const { return snb + c * (2 * H + D + 4); }
+  __device__ __forceinline__ float* u1(int c) const { return snb + c * (2 * H + Dp + 4); }
   __device__ __forceinline__ float* v1(int c) const { return u1(c) + H; }
-  __device__ __forceinline__ float* v2(int c) const { return u1(c) + H + D; }
-  __device__ __forceinline__ float* sc(int c) const { return u1(c) + 2 * H + D; }
+  __device__ __forceinline__ float* v2(int c) const { return u1(c) + H + Dp; }
+  __device__ __forceinline__ float* sc(int c) const { return u1(c) + 2 * H + Dp; }
 };
 __host__ __device__ inline size_t disc_lds_floats(int D, int H) {
-  return (size_t)H * (D + 1) + 2 * H + 3 * (size_t)IL_TILE_R * D + 3 * IL_TILE_R + 3 * (size_t)IL_TILE_R * H + (size_t)IL_TILE_R * D + 3 * (size_t)(2 * H + D + 4) + 2 * IL_TILE_R + 64;
+  const int Dp = (D + 3) & ~3;
+  return (size_t)H * (Dp + 4) + 2 * H + 3 * (size_t)IL_TILE_R * Dp + 3 * IL_TILE_R + 3 * (size_t)IL_TILE_R * H + (size_t)IL_TILE_R * Dp + 3 * (size_t)(2 * H + Dp + 4) + 2 * IL_TILE_R + 64;
 }
 __device__ __forceinline__ DiscLds carve(float* s, int D, int H) {
   DiscLds l; float* p = s;
-  l.D = D; l.H = H;
-  l.W1s = p; p += H * (D + 1); l.b1s = p; p += H; l.W2s = p; p += H;
-  l.Xb = p; p += 3 * IL_TILE_R * D; l.wtb = p; p += 3 * IL_TILE_R;
-  l.hs = p; p += IL_TILE_R * H; l.dhs = p; p += IL_TILE_R * H; l.ts = p; p += IL_TILE_R * H; l.cg = p; p += IL_TILE_R * D;
-  l.snb = p; p += 3 * (2 * H + D + 4);
+  const int Dp = (D + 3) & ~3;
+  l.D = D; l.H = H; l.Dp = Dp;
+  l.W1s = p; p += H * (Dp + 4); l.b1s = p; p += H; l.W2s = p; p += H;
+  l.Xb = p; p += 3 * IL_TILE_R * Dp; l.wtb = p; p += 3 * IL_TILE_R;
+  l.hs = p; p += IL_TILE_R * H; l.dhs = p; p += IL_TILE_R * H; l.ts = p; p += IL_TILE_R * H; l.cg = p; p += IL_TILE_R * Dp;
+  l.snb = p; p += 3 * (2 * H + Dp + 4);
   l.zs = p; p += IL_TILE_R; l.dzs = p; p += IL_TILE_R; l.red = p;
   return l;
 }
 
 // stage W1 (padded rows), b1, W2 into LDS
 __device__ __forceinline__ void stage_weights(const DiscLds& L, const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2, int D, int H) {
-  for (int i = threadIdx.x; i < H * D; i += blockDim.x) { const int n = i / D, k = i - n * D; L.W1s[n * (D + 1) + k] = W1[i]; }
+  const int Dp = L.Dp, ldw = Dp + 4;
+  for (int i = threadIdx.x; i < H * Dp; i += blockDim.x) { const int n = i / Dp, k = i - n * Dp; L.W1s[n * ldw + k] = k < D ? W1[(size_t)n * D + k] : 0.f; }
   for (int i = threadIdx.x; i < H; i += blockDim.x) { L.b1s[i] = b1[i]; L.W2s[i] = W2[i]; }
 }
 
@@ -106,7 +129,7 @@ __device__ __forceinline__ void stage_weights(const DiscLds& L, const float* __r
 template <bool GREG>
 __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch, ldw = D + 1;
+  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch, Dp = (D + 3) & ~3, ldw = Dp + 4;
   const int tile = blockIdx.x, row0 = tile * IL_TILE_R, tid = threadIdx.x;
   const int nrows = min(IL_TILE_R, B - row0);
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
@@ -116,9 +139,9 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   DiscLds L = carve(smem, D, H);
   stage_weights(L, d.params + lay.oW1, d.params + lay.ob1, d.params + lay.oW2, D, H);
   // ---- stage inputs: policy rows, expert rows (mix rows below, training.py:118-120)
-  for (int i = tid; i < IL_TILE_R * D; i += blockDim.x) {
-    const int r = i / D, k = i - r * D; float xp = 0.f, xe = 0.f;
-    if (r < nrows) {
+  for (int i = tid; i < IL_TILE_R * Dp; i += blockDim.x) {
+    const int r = i / Dp, k = i - r * Dp; float xp = 0.f, xe = 0.f;
+    if (r < nrows && k < D) {
       xp = k < S ? pol.states[(size_t)(row0 + r) * pol.ld_states + k] : pol.actions[(size_t)(row0 + r) * pol.ld_actions + k - S];
       xe = k < S ? exp.states[(size_t)(row0 + r) * exp.ld_states + k] : exp.actions[(size_t)(row0 + r) * exp.ld_actions + k - S];
     }
@@ -135,10 +158,10 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   }
   if (d.spectral_norm) {
     for (int i = tid; i < H; i += blockDim.x) { L.u1(0)[i] = d.u1[i]; L.v2(0)[i] = d.v2[i]; }
-    for (int i = tid; i < D; i += blockDim.x) L.v1(0)[i] = d.v1[i];
+    for (int i = tid; i < Dp; i += blockDim.x) L.v1(0)[i] = i < D ? d.v1[i] : 0.f;
     if (tid == 0) L.sc(0)[2] = d.u2[0];
   }
-  if (tid == 0 && tile == 0) d.opt.step[0] += 1;
+  if (tid == 0 && tile == 0) adam_tick(d.opt);
   __syncthreads();
   const int npass = d.grad_penalty > 0.f ? 3 : 2;
   if (tid < 64) {  // ---- wave 0: the power iterations of all discriminator calls, chained
@@ -146,7 +169,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
       if (d.spectral_norm) {
         if (c > 0) {
           for (int i = tid; i < H; i += 64) { L.u1(c)[i] = L.u1(c - 1)[i]; L.v2(c)[i] = L.v2(c - 1)[i]; }
-          for (int i = tid; i < D; i += 64) L.v1(c)[i] = L.v1(c - 1)[i];
+          for (int i = tid; i < Dp; i += 64) L.v1(c)[i] = L.v1(c - 1)[i];
           if (tid == 0) L.sc(c)[2] = L.sc(c - 1)[2];
           WAVE_SYNC();
         }
@@ -154,7 +177,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
       } else if (tid == 0) { L.sc(c)[0] = 1.f; L.sc(c)[1] = 1.f; L.sc(c)[2] = 0.f; }
     }
   } else {
-    for (int i = tid - 64; i < IL_TILE_R * D; i += blockDim.x - 64) { const float e = L.dzs[i / D]; L.X(2)[i] = e * L.X(1)[i] + (1.f - e) * L.X(0)[i]; }
+    for (int i = tid - 64; i < IL_TILE_R * Dp; i += blockDim.x - 64) { const float e = L.dzs[i / Dp]; L.X(2)[i] = e * L.X(1)[i] + (1.f - e) * L.X(0)[i]; }
   }
   __syncthreads();
 
@@ -172,9 +195,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     // ---- forward for row r (16 threads per row)
     float zp = 0.f;
     for (int n = sub; n < H; n += 16) {
-      float s = 0.f;
-      for (int k = 0; k < D; ++k) s += L.W1s[n * ldw + k] * X[r * D + k];
-      const float h = s / s1 + L.b1s[n];
+      const float h = dot4(L.W1s + n * ldw, X + r * Dp, Dp) / s1 + L.b1s[n];
       L.hs[r * H + n] = h;
       zp += (L.W2s[n] / s2) * fmaxf(h, 0.f);
     }
@@ -201,17 +222,11 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
       for (int n = sub; n < H; n += 16) L.dhs[r * H + n] = L.hs[r * H + n] > 0.f ? (L.W2s[n] / s2) : 0.f;
       __syncthreads();
       const float c = valid ? 2.f * d.grad_penalty * L.wt(2)[r] / fB : 0.f;
-      for (int k = sub; k < D; k += 16) {
-        float s = 0.f;
-        for (int n = 0; n < H; ++n) s += L.dhs[r * H + n] * L.W1s[n * ldw + k];
-        L.cg[r * D + k] = c * (s / s1);
-      }
+      for (int k = sub; k < Dp; k += 16) L.cg[r * Dp + k] = k < D ? c * (dot_strided(L.dhs + r * H, L.W1s + k, ldw, H) / s1) : 0.f;
       __syncthreads();
       float S_ip = 0.f;
       for (int n = sub; n < H; n += 16) {
-        float s = 0.f;
-        for (int k = 0; k < D; ++k) s += L.W1s[n * ldw + k] * L.cg[r * D + k];
-        const float tp = s / s1;
+        const float tp = dot4(L.W1s + n * ldw, L.cg + r * Dp, Dp) / s1;
         L.ts[r * H + n] = L.hs[r * H + n] > 0.f ? tp : 0.f;
         S_ip += L.dhs[r * H + n] * tp;
       }
@@ -227,7 +242,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
       const int n = e / D, k = e - n * D;
       float gh = 0.f;
 #pragma unroll
-      for (int rr = 0; rr < IL_TILE_R; ++rr) gh += left[rr * H + n] * right[rr * D + k];
+      for (int rr = 0; rr < IL_TILE_R; ++rr) gh += left[rr * H + n] * right[rr * Dp + k];
       return gh / s1 - (d.spectral_norm ? k1 * u1[n] * v1[k] : 0.f);
     };
     if (GREG) {
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply) {
     for (; t < nt; ++t) g += sl[(size_t)t * lay.P];
     d.grad[e] = g;
     if (apply) {
-      const adam_consts ac = make_adam_consts(d.opt.lr, d.opt.beta1, d.opt.beta2, d.opt.eps, d.opt.weight_decay, d.opt.step[0]);
+      const adam_consts ac = load_adam_consts(d.opt);
       float pp = d.params[e], mm = d.opt.m[e], vv = d.opt.v[e];
       adam_update(pp, g, mm, vv, ac);
       d.params[e] = pp; d.opt.m[e] = mm; d.opt.v[e] = vv;
@@ -303,19 +318,19 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply) {
 
 __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, float* __restrict__ out_r, float* __restrict__ out_logit) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, ldw = D + 1;
+  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, Dp = (D + 3) & ~3, ldw = Dp + 4;
   const int row0 = blockIdx.x * IL_TILE_R, tid = threadIdx.x, nrows = min(IL_TILE_R, b.n - row0);
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
   const float b2 = d.params[lay.ob2];
   DiscLds L = carve(smem, D, H);
   stage_weights(L, d.params + lay.oW1, d.params + lay.ob1, d.params + lay.oW2, D, H);
-  for (int i = tid; i < IL_TILE_R * D; i += blockDim.x) {
-    const int r = i / D, k = i - r * D;
-    L.X(0)[i] = r < nrows ? (k < S ? b.states[(size_t)(row0 + r) * b.ld_states + k] : b.actions[(size_t)(row0 + r) * b.ld_actions + k - S]) : 0.f;
+  for (int i = tid; i < IL_TILE_R * Dp; i += blockDim.x) {
+    const int r = i / Dp, k = i - r * Dp;
+    L.X(0)[i] = (r < nrows && k < D) ? (k < S ? b.states[(size_t)(row0 + r) * b.ld_states + k] : b.actions[(size_t)(row0 + r) * b.ld_actions + k - S]) : 0.f;
   }
   if (d.spectral_norm) {
     for (int i = tid; i < H; i += blockDim.x) { L.u1(0)[i] = d.u1[i]; L.v2(0)[i] = d.v2[i]; }
-    for (int i = tid; i < D; i += blockDim.x) L.v1(0)[i] = d.v1[i];
+    for (int i = tid; i < Dp; i += blockDim.x) L.v1(0)[i] = i < D ? d.v1[i] : 0.f;
     if (tid == 0) L.sc(0)[2] = d.u2[0];
   } else if (tid == 0) { L.sc(0)[0] = 1.f; L.sc(0)[1] = 1.f; }
   __syncthreads();
@@ -324,11 +339,7 @@ __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, floa
   const float s1 = L.sc(0)[0], s2 = L.sc(0)[1];
   const int r = tid >> 4, sub = tid & 15;
   float zp = 0.f;
-  for (int n = sub; n < H; n += 16) {
-    float s = 0.f;
-    for (int k = 0; k < D; ++k) s += L.W1s[n * ldw + k] * L.X(0)[r * D + k];
-    zp += (L.W2s[n] / s2) * fmaxf(s / s1 + L.b1s[n], 0.f);
-  }
+  for (int n = sub; n < H; n += 16) zp += (L.W2s[n] / s2) * fmaxf(dot4(L.W1s + n * ldw, L.X(0) + r * Dp, Dp) / s1 + L.b1s[n], 0.f);
   zp = group16_sum(zp);
   if (sub == 0 && r < nrows) {
     const float z = zp + b2, Dp = sigmoid_f(z);
@@ -350,7 +361,7 @@ static int ensure_lds(const void* fn, size_t bytes) {
 static int check_disc(const il_disc* d) {
   IL_CHECK_ARG(d && d->params && d->grad && d->workspace, "il_disc: null descriptor field");
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
-  IL_CHECK_ARG(d->hidden >= 1 && d->hidden <= 512 && D >= 1 && D <= 512, "il_disc: dims out of range (D=%d, hidden=%d)", D, d->hidden);
+  IL_CHECK_ARG(d->hidden >= 4 && d->hidden <= 512 && d->hidden % 4 == 0 && D >= 1 && D <= 512, "il_disc: dims out of range (D=%d, hidden=%d: hidden must be a multiple of 4)", D, d->hidden);
   IL_CHECK_ARG(disc_lds_floats(D, d->hidden) * sizeof(float) <= 160 * 1024, "il_disc: D=%d hidden=%d needs more than 160 KiB of LDS", D, d->hidden);
   IL_CHECK_ARG(d->reward_function >= 0 && d->reward_function <= 2, "il_disc: reward_function must be 0 (AIRL), 1 (GAIL) or 2 (FAIRL)");
   if (d->spectral_norm) IL_CHECK_ARG(d->u1 && d->v1 && d->u2 && d->v2, "il_disc: spectral-norm buffers missing");
@@ -376,7 +387,7 @@ extern "C" int il_gail_disc_step(const il_disc* d, const il_batch* pol, const il
 }
 
 __global__ __launch_bounds__(256) void k_disc_adam(il_disc d, int64_t P) {
-  const adam_consts ac = make_adam_consts(d.opt.lr, d.opt.beta1, d.opt.beta2, d.opt.eps, d.opt.weight_decay, d.opt.step[0]);
+  const adam_consts ac = load_adam_consts(d.opt);
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < P; e += (int64_t)gridDim.x * blockDim.x) {
     float pp = d.params[e], mm = d.opt.m[e], vv = d.opt.v[e];
     adam_update(pp, d.grad[e], mm, vv, ac);

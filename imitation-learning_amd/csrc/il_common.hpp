@@ -103,6 +103,22 @@ __device__ __forceinline__ adam_consts make_adam_consts(double lr, double b1, do
   c.eps = (float)eps;
   return c;
 }
+// The kernel that produces a gradient ticks the optimiser: step[0] += 1 and the bias-correction constants of that step are
+// stored next to the counter (floats at int32 offsets 4..11 of the `step` buffer, which holds >= 16 int32), so the hundreds of
+// waves of the following Adam kernel load 8 floats instead of each evaluating two double-precision pow().
+__device__ __forceinline__ void adam_tick(const il_adam& o) {
+  const int t = o.step[0] + 1;
+  o.step[0] = t;
+  const adam_consts c = make_adam_consts(o.lr, o.beta1, o.beta2, o.eps, o.weight_decay, t);
+  float* f = reinterpret_cast<float*>(o.step) + 4;
+  f[0] = c.decay; f[1] = c.one_m_b1; f[2] = c.beta2; f[3] = c.one_m_b2; f[4] = c.step_size; f[5] = c.bc2_sqrt; f[6] = c.eps; f[7] = c.has_decay ? 1.f : 0.f;
+}
+__device__ __forceinline__ adam_consts load_adam_consts(const il_adam& o) {
+  const float* f = reinterpret_cast<const float*>(o.step) + 4;
+  adam_consts c;
+  c.decay = f[0]; c.one_m_b1 = f[1]; c.beta2 = f[2]; c.one_m_b2 = f[3]; c.step_size = f[4]; c.bc2_sqrt = f[5]; c.eps = f[6]; c.has_decay = f[7] != 0.f;
+  return c;
+}
 __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, const adam_consts& c) {
   if (c.has_decay) p = __fmul_rn(p, c.decay);
   m = __fadd_rn(m, __fmul_rn(c.one_m_b1, __fsub_rn(g, m)));                       // lerp_

@@ -47,16 +47,30 @@ __device__ __forceinline__ void tile_fwd_impl(const float* Xs, int ldx, int Kpad
     const float* wr = W + (size_t)(c0 + j) * ldw + 4 * g;
     const float* xr = Xs + j * ldx + 4 * g;
     int k0 = 0;
-    for (; k0 + 64 <= Kpad; k0 += 64) {  // 4 k-blocks per trip: four weight lanes in flight before the first MFMA needs one
-      f32x4 a[4], b[4];
+    for (; k0 + 128 <= Kpad; k0 += 128) {  // 8 k-blocks per trip: eight 16-B weight lanes in flight before the first MFMA needs one
+      f32x4 b[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { b[u] = load4<MODE>(wr - 4 * g, k0 + 16 * u + 4 * g, Kw); a[u] = *reinterpret_cast<const f32x4*>(xr + k0 + 16 * u); }
+      for (int u = 0; u < 8; ++u) b[u] = load4<MODE>(wr - 4 * g, k0 + 16 * u + 4 * g, Kw);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xr + k0 + 16 * u);
+        acc0 = mfma16(a[0], b[u][0], acc0);
+        acc1 = mfma16(a[1], b[u][1], acc1);
+        acc0 = mfma16(a[2], b[u][2], acc0);
+        acc1 = mfma16(a[3], b[u][3], acc1);
+      }
+    }
+    for (; k0 + 64 <= Kpad; k0 += 64) {
+      f32x4 b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = load4<MODE>(wr - 4 * g, k0 + 16 * u + 4 * g, Kw);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        acc0 = mfma16(a[u][0], b[u][0], acc0);
-        acc1 = mfma16(a[u][1], b[u][1], acc1);
-        acc0 = mfma16(a[u][2], b[u][2], acc0);
-        acc1 = mfma16(a[u][3], b[u][3], acc1);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xr + k0 + 16 * u);
+        acc0 = mfma16(a[0], b[u][0], acc0);
+        acc1 = mfma16(a[1], b[u][1], acc1);
+        acc0 = mfma16(a[2], b[u][2], acc0);
+        acc1 = mfma16(a[3], b[u][3], acc1);
       }
     }
     for (; k0 < Kpad; k0 += 16) {
@@ -92,20 +106,34 @@ __device__ __forceinline__ void tile_bwd_dx_impl(const float* dYs, int ldy, int 
     const float* wp = W + kb + j;
     const float* yr = dYs + j * ldy + 4 * g;
     int n0 = 0;
-    for (; n0 + 64 <= Npad; n0 += 64) {  // 16 weight dwords in flight per lane
-      f32x4 a[4]; float b[4][4];
+    for (; n0 + 128 <= Npad; n0 += 128) {  // 32 weight dwords in flight per lane
+      float b[8][4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int s = 0; s < 4; ++s) { const int n = n0 + 16 * u + 4 * g + s; b[u][s] = wp[(size_t)(FULL ? n : min(n, Nvalid - 1)) * ldw]; }
-        a[u] = *reinterpret_cast<const f32x4*>(yr + n0 + 16 * u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(yr + n0 + 16 * u);
+        acc0 = mfma16(a[0], b[u][0], acc0);
+        acc1 = mfma16(a[1], b[u][1], acc1);
+        acc0 = mfma16(a[2], b[u][2], acc0);
+        acc1 = mfma16(a[3], b[u][3], acc1);
       }
+    }
+    for (; n0 + 64 <= Npad; n0 += 64) {
+      float b[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { const int n = n0 + 16 * u + 4 * g + s; b[u][s] = wp[(size_t)(FULL ? n : min(n, Nvalid - 1)) * ldw]; }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        acc0 = mfma16(a[u][0], b[u][0], acc0);
-        acc1 = mfma16(a[u][1], b[u][1], acc1);
-        acc0 = mfma16(a[u][2], b[u][2], acc0);
-        acc1 = mfma16(a[u][3], b[u][3], acc1);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(yr + n0 + 16 * u);
+        acc0 = mfma16(a[0], b[u][0], acc0);
+        acc1 = mfma16(a[1], b[u][1], acc1);
+        acc0 = mfma16(a[2], b[u][2], acc0);
+        acc1 = mfma16(a[3], b[u][3], acc1);
       }
     }
     for (; n0 < Npad; n0 += 16) {

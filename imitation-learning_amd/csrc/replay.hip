@@ -212,6 +212,21 @@ __global__ __launch_bounds__(256) void k_sample2(uint32_t* __restrict__ state, i
   if (ring_b && rows_b) gather_rows(ring_b, cap_b, row4_b, idx_b, n, rows_b);
 }
 
+// both gathers of an update in one launch, one 16-byte lane per thread (the index draw above is a single-workgroup kernel)
+__global__ __launch_bounds__(256) void k_gather2(const float* __restrict__ ring_a, int64_t cap_a, int row4_a, const int32_t* __restrict__ idx_a, float* __restrict__ rows_a,
+                                                 const float* __restrict__ ring_b, int64_t cap_b, int row4_b, const int32_t* __restrict__ idx_b, float* __restrict__ rows_b, int n) {
+  const int na = n * row4_a, nb = ring_b ? n * row4_b : 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += gridDim.x * blockDim.x) {
+    const bool isb = i >= na;
+    const int ii = isb ? i - na : i, row4 = isb ? row4_b : row4_a;
+    const int r = ii / row4, c = ii - r * row4;
+    int64_t s = (isb ? idx_b : idx_a)[r];
+    const int64_t cap = isb ? cap_b : cap_a;
+    s = s < 0 ? 0 : (s >= cap ? cap - 1 : s);
+    reinterpret_cast<f32x4*>(isb ? rows_b : rows_a)[ii] = reinterpret_cast<const f32x4*>(isb ? ring_b : ring_a)[s * row4 + c];
+  }
+}
+
 extern "C" int il_mt19937_sample_indices_device(uint32_t* state_dev, const int64_t* ring_state_dev, int32_t n, int32_t* out_dev, il_stream_t stream) {
   IL_CHECK_ARG(state_dev && ring_state_dev && out_dev && n > 0, "il_mt19937_sample_indices_device: bad arguments");
   { IL_TRACE("k_sample2", stream); k_sample2<<<1, 256, 0, (hipStream_t)stream>>>(state_dev, n, ring_state_dev, nullptr, 0, 0, out_dev, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr); }
@@ -224,8 +239,10 @@ extern "C" int il_replay_sample_device(uint32_t* state_dev, int32_t n, const int
                                        il_stream_t stream) {
   IL_CHECK_ARG(state_dev && ring_state_a && ring_a && idx_a && rows_a && n > 0, "il_replay_sample_device: bad arguments for ring A");
   IL_CHECK_ARG(row_floats_a % 4 == 0 && (!ring_b || (row_floats_b % 4 == 0 && ring_state_b && idx_b && rows_b)), "il_replay_sample_device: bad arguments for ring B");
-  { IL_TRACE("k_sample2", stream); k_sample2<<<1, 256, 0, (hipStream_t)stream>>>(state_dev, n, ring_state_a, ring_a, capacity_a, row_floats_a / 4, idx_a, rows_a, ring_state_b, ring_b, capacity_b,
-                                                                            row_floats_b / 4, idx_b, rows_b); }
+  { IL_TRACE("k_sample2", stream); k_sample2<<<1, 256, 0, (hipStream_t)stream>>>(state_dev, n, ring_state_a, ring_a, capacity_a, row_floats_a / 4, idx_a, nullptr, ring_state_b, ring_b, capacity_b,
+                                                                            row_floats_b / 4, idx_b, nullptr); }
+  const int lanes = n * (row_floats_a / 4) + (ring_b ? n * (row_floats_b / 4) : 0);
+  { IL_TRACE("k_gather2", stream); k_gather2<<<(lanes + 255) / 256, 256, 0, (hipStream_t)stream>>>(ring_a, capacity_a, row_floats_a / 4, idx_a, rows_a, ring_b, capacity_b, row_floats_b / 4, idx_b, rows_b, n); }
   IL_CHECK_LAUNCH("il_replay_sample_device");
   return IL_OK;
 }

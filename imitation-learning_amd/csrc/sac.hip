@@ -8,8 +8,10 @@
 //   k_policy_critic  (tile, net) : updated critic on (s, a~), dQ/da~
 //   k_actor_bwd      tiles      : min-Q selection, tanh-Gaussian backward, back-propagation through the actor
 //   k_dw_adam        actor dW + AdamW, Adam(log_alpha), polyak as tail blocks
-// Activations cross kernels through an L2-resident workspace (~3 MB at B=256, H=256); parameters, Adam moments and
-// the target network are each read and written exactly once per update (the algorithmic 24 B/param + 8 B/param).
+// Activations cross kernels through an L2-resident workspace (~3 MB at B=256, H=256) stored FEATURE-MAJOR ([H][B]): an MFMA
+// accumulator lane holds 4 consecutive batch rows of one feature, so producers store and consumers load whole 16-byte lanes
+// (row masks in the backward epilogues, and both operands of the dW kernel, whose reduction index is the batch row).
+// Parameters, Adam moments and the target network are each read and written exactly once per update (24 B/param + 8 B/param).
 #include "il_common.hpp"
 #include "mlp_tile.hpp"
 
@@ -75,22 +77,18 @@ __global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const 
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   tile_fwd(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = net.b1[col];
+    f32x4 hv;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float h = fmaxf(acc[r] + bb, 0.f);
-        H1s[(4 * g + r) * ldh + col] = h;
-        if (is_cur) W[ws.a_h1 + (size_t)(row0 + 4 * g + r) * H + col] = h;
-      }
+    for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = hv[r]; }
+    if (is_cur) *reinterpret_cast<f32x4*>(W + ws.a_h1 + (size_t)col * B + row0 + 4 * g) = hv;
   });
   __syncthreads();
   tile_fwd(H1s, ldh, H, net.W2, H, H, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = net.b2[col];
+    f32x4 hv;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float h = fmaxf(acc[r] + bb, 0.f);
-        H2s[(4 * g + r) * ldh + col] = h;
-        if (is_cur) W[ws.a_h2 + (size_t)(row0 + 4 * g + r) * H + col] = h;
-      }
+    for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = hv[r]; }
+    if (is_cur) *reinterpret_cast<f32x4*>(W + ws.a_h2 + (size_t)col * B + row0 + 4 * g) = hv;
   });
   __syncthreads();
   tile_fwd_small(H2s, ldh, H, net.W3, H, 2 * A, net.b3, Os, part);
@@ -153,27 +151,23 @@ __global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b) {
   else load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R);
   __syncthreads();
   if (net == 0)
-    for (int i = threadIdx.x; i < IL_TILE_R * IN; i += blockDim.x) { const int r = i / IN, c = i - r * IN; W[ws.c_x0 + (size_t)(row0 + r) * IN + c] = Xs[r * ldx + c]; }
+    for (int i = threadIdx.x; i < IL_TILE_R * IN; i += blockDim.x) { const int c = i >> 4, r = i & 15; W[ws.c_x0 + (size_t)c * B + row0 + r] = Xs[r * ldx + c]; }  // x0^T [IN][B]
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   float* sh1 = W + ws.c_h1 + (size_t)k * B * H; float* sh2 = W + ws.c_h2 + (size_t)k * B * H;
   tile_fwd(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = p.b1[col];
+    f32x4 hv;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float h = fmaxf(acc[r] + bb, 0.f);
-        H1s[(4 * g + r) * ldh + col] = h;
-        if (!is_target) sh1[(size_t)(row0 + 4 * g + r) * H + col] = h;
-      }
+    for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = hv[r]; }
+    if (!is_target) *reinterpret_cast<f32x4*>(sh1 + (size_t)col * B + row0 + 4 * g) = hv;
   });
   __syncthreads();
   tile_fwd(H1s, ldh, H, p.W2, H, H, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = p.b2[col];
+    f32x4 hv;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float h = fmaxf(acc[r] + bb, 0.f);
-        H2s[(4 * g + r) * ldh + col] = h;
-        if (!is_target) sh2[(size_t)(row0 + 4 * g + r) * H + col] = h;
-      }
+    for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = hv[r]; }
+    if (!is_target) *reinterpret_cast<f32x4*>(sh2 + (size_t)col * B + row0 + 4 * g) = hv;
   });
   __syncthreads();
   critic_head(H2s, ldh, H, p.W3, p.b3[0], q16);
@@ -206,23 +200,28 @@ __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b) {
     W[ws.c_dz3 + (size_t)k * B + row] = dq;
     if (k == 0) W[ws.q_min + row] = fminf(q, W[ws.c_q + B + row]);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) d.critic_opt.step[0] += 1;  // consumed by the following k_dw_adam / il_adam_step
+  if (blockIdx.x == 0 && threadIdx.x == 0) adam_tick(d.critic_opt);  // consumed by the following k_dw_adam / il_adam_step
   __syncthreads();
   const float* h2 = W + ws.c_h2 + (size_t)k * B * H; const float* h1 = W + ws.c_h1 + (size_t)k * B * H;
   float* gdz2 = W + ws.c_dz2 + (size_t)k * B * H; float* gdz1 = W + ws.c_dz1 + (size_t)k * B * H;
-  for (int i = threadIdx.x; i < IL_TILE_R * H; i += blockDim.x) {
-    const int r = i / H, n = i - r * H;
-    const float v = (h2[(size_t)(row0 + r) * H + n] > 0.f) ? dz3s[r] * p.W3[n] : 0.f;
-    DZ2s[r * ldh + n] = v; gdz2[(size_t)(row0 + r) * H + n] = v;
+  for (int i = threadIdx.x; i < 4 * H; i += blockDim.x) {  // (feature n, 4 consecutive rows) per thread: 16-byte lanes of the [H][B] layout
+    const int n = i >> 2, r4 = (i & 3) * 4;
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(h2 + (size_t)n * B + row0 + r4);
+    const float w3 = p.W3[n];
+    f32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { o[q] = hv[q] > 0.f ? dz3s[r4 + q] * w3 : 0.f; DZ2s[(r4 + q) * ldh + n] = o[q]; }
+    *reinterpret_cast<f32x4*>(gdz2 + (size_t)n * B + row0 + r4) = o;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   tile_bwd_dx(DZ2s, ldh, H, H, p.W2, H, H, [&](int kb, f32x4 acc) {
+    const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(h1 + off);
+    f32x4 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + j;
-      gdz1[off] = h1[off] > 0.f ? acc[r] : 0.f;
-    }
+    for (int r = 0; r < 4; ++r) o[r] = hv[r] > 0.f ? acc[r] : 0.f;
+    *reinterpret_cast<f32x4*>(gdz1 + off) = o;
   });
 }
 
@@ -325,69 +324,84 @@ __global__ __launch_bounds__(1024) void k_actor_bwd(il_sac d, il_batch b, float*
   apart = block_sum(apart, red);  // contains barriers: DZ3s complete afterwards
   if (tid == 0) {
     W[ws.alpha_part + tile] = apart;
-    if (tile == 0) { d.actor_opt.step[0] += 1; d.alpha_opt.step[0] += 1; }
+    if (tile == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }
   }
-  for (int i = tid; i < IL_TILE_R * 16; i += blockDim.x) W[ws.a_dz3 + (size_t)row0 * 16 + i] = DZ3s[(i >> 4) * ldz + (i & 15)];
+  for (int i = tid; i < IL_TILE_R * 16; i += blockDim.x) W[ws.a_dz3 + (size_t)(i >> 4) * B + row0 + (i & 15)] = DZ3s[(i & 15) * ldz + (i >> 4)];  // dz3^T [16][B]
   const int lane = tid & 63, j = lane & 15, g = lane >> 4;
   const float* h2 = W + ws.a_h2; const float* h1 = W + ws.a_h1;
   // dz2 = (dz3 . W3) [h2 > 0]
   tile_bwd_dx(DZ3s, ldz, 16, 2 * A, net.W3, H, H, [&](int kb, f32x4 acc) {
+    const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(h2 + off);
+    f32x4 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + j;
-      const float o = h2[off] > 0.f ? acc[r] : 0.f;
-      W[ws.a_dz2 + off] = o;
-      DZ2s[(4 * g + r) * ldh + kb + j] = o;
-    }
+    for (int r = 0; r < 4; ++r) { o[r] = hv[r] > 0.f ? acc[r] : 0.f; DZ2s[(4 * g + r) * ldh + kb + j] = o[r]; }
+    *reinterpret_cast<f32x4*>(W + ws.a_dz2 + off) = o;
   });
   __syncthreads();
   tile_bwd_dx(DZ2s, ldh, H, H, net.W2, H, H, [&](int kb, f32x4 acc) {
+    const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(h1 + off);
+    f32x4 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + j;
-      W[ws.a_dz1 + off] = h1[off] > 0.f ? acc[r] : 0.f;
-    }
+    for (int r = 0; r < 4; ++r) o[r] = hv[r] > 0.f ? acc[r] : 0.f;
+    *reinterpret_cast<f32x4*>(W + ws.a_dz1 + off) = o;
   });
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_dw_adam: output-stationary weight gradients on MFMA with a fused AdamW epilogue.
-//   dW_l[n][k] = sum_r dZ_l[r][n] X_l[r][k]  (K = batch rows, 4 per MFMA step), db_l[n] = sum_r dZ_l[r][n]
-// One wave = one job: a 16(n) x 64(k) strip of some layer's weight, or 64 bias elements. Gradients never touch HBM
-// unless grads_only (data-parallel: they are all-reduced first).  Tail blocks: Adam(log_alpha) and polyak.
+//   dW_l[n][k] = sum_r dZ_l[r][n] X_l[r][k]  (reduction index = batch row, 4 per MFMA step), db_l[n] = sum_r dZ_l[r][n]
+// One wave = one job: a 16(n) x 16(k) tile of some layer's weight, or 16 bias elements. Operands come from the feature-major
+// workspace ([feature][B]): lane (j, g) reads 4 consecutive batch rows of feature n0+j / k0+j as ONE 16-byte load, eight such
+// loads per operand are in flight before the first MFMA. Gradients never touch HBM unless grads_only (data-parallel: they are
+// all-reduced first).  Tail blocks: Adam(log_alpha), polyak, Philox counter.
 // ---------------------------------------------------------------------------------------------
 struct DwArgs {
   float* params; float* grads; il_adam opt; int grads_only;
   int n_nets; int64_t net_stride;
   int in_dim, hidden, out_dim, batch;
-  const float* x0; int ld_x0; int64_t x0_net_stride;
-  const float* h1; const float* h2; const float* dz1; const float* dz2; int64_t h_net_stride;
-  const float* dz3; int ld_dz3; int64_t dz3_net_stride;
+  const float* x0; int ld_x0; int x0_transposed; int64_t x0_net_stride;   // layer-1 input: [in][B] (transposed) or row-major [B][ld_x0]
+  const float* h1; const float* h2; const float* dz1; const float* dz2; int64_t h_net_stride;   // [H][B]
+  const float* dz3; int64_t dz3_net_stride;                                // [out][B]
   int n_dw_blocks;
   // tail
   float* log_alpha; float* alpha_grad; il_adam alpha_opt; const float* alpha_part; int n_alpha_part;
   float* target; const float* polyak_src; int64_t polyak_n; double tau; uint32_t* noise_counter;
 };
 
-// one wave = one 16(n) x 16(k) tile of dW; the batch (reduction) loop is unrolled by 4 row-blocks so 32 operand loads are in
-// flight per wave, and several workgroups share a CU, so L2 latency overlaps with other waves' MFMAs.
-__device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dz, int ldz, int Nvalid, const float* __restrict__ x, int ldx,
-                                        int Kvalid, int n0, int kb, int64_t poff) {
+__device__ __forceinline__ void adam_store(const DwArgs& a, const adam_consts& ac, int64_t o, float gr) {
+  if (a.grads_only) { a.grads[o] = gr; return; }
+  float pp = a.params[o], mm = a.opt.m[o], vv = a.opt.v[o];
+  adam_update(pp, gr, mm, vv, ac);
+  a.params[o] = pp; a.opt.m[o] = mm; a.opt.v[o] = vv;
+}
+
+// XT: x is feature-major [Kvalid][B]; otherwise row-major [B][ldx] (the actor's layer-1 input = the states field of the batch)
+template <bool XT>
+__device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dzT, int Nvalid, const float* __restrict__ x, int ldx, int Kvalid,
+                                        int n0, int kb, int64_t poff) {
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int B = a.batch;
   f32x4 acc0 = zero4(), acc1 = zero4();
-  // out-of-range columns clamp their address: the rows / columns of dW they produce are discarded by the epilogue
-  const float* dzp = dz + min(n0 + j, Nvalid - 1) + (size_t)(4 * g) * ldz;
-  const float* xp = x + min(kb + j, Kvalid - 1) + (size_t)(4 * g) * ldx;
+  // out-of-range features clamp their address: the rows / columns of dW they produce are discarded by the epilogue
+  const float* dzp = dzT + (size_t)min(n0 + j, Nvalid - 1) * B + 4 * g;
+  const int kc = min(kb + j, Kvalid - 1);
+  const float* xp = XT ? x + (size_t)kc * B + 4 * g : x + (size_t)(4 * g) * ldx + kc;
+  auto ldx4 = [&](int r0) -> f32x4 {
+    if (XT) return *reinterpret_cast<const f32x4*>(xp + r0);
+    f32x4 v;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[s] = xp[(size_t)(r0 + s) * ldx];
+    return v;
+  };
   int r0 = 0;
-  for (; r0 + 64 <= B; r0 += 64) {
-    float av[4][4], bv[4][4];
+  for (; r0 + 128 <= B; r0 += 128) {
+    f32x4 av[8], bv[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 8; ++u) { av[u] = *reinterpret_cast<const f32x4*>(dzp + r0 + 16 * u); bv[u] = ldx4(r0 + 16 * u); }
 #pragma unroll
-      for (int s = 0; s < 4; ++s) { av[u][s] = dzp[(size_t)(r0 + 16 * u + s) * ldz]; bv[u][s] = xp[(size_t)(r0 + 16 * u + s) * ldx]; }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       acc0 = mfma16(av[u][0], bv[u][0], acc0);
       acc1 = mfma16(av[u][1], bv[u][1], acc1);
       acc0 = mfma16(av[u][2], bv[u][2], acc0);
@@ -395,9 +409,7 @@ __device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, 
     }
   }
   for (; r0 < B; r0 += 16) {
-    float av[4], bv[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { av[s] = dzp[(size_t)(r0 + s) * ldz]; bv[s] = xp[(size_t)(r0 + s) * ldx]; }
+    const f32x4 av = *reinterpret_cast<const f32x4*>(dzp + r0), bv = ldx4(r0);
     acc0 = mfma16(av[0], bv[0], acc0);
     acc1 = mfma16(av[1], bv[1], acc1);
     acc0 = mfma16(av[2], bv[2], acc0);
@@ -409,29 +421,21 @@ __device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int n = n0 + 4 * g + r;
-    if (n >= Nvalid) continue;
-    const int64_t o = poff + (int64_t)n * Kvalid + k;
-    const float gr = acc[r];
-    if (a.grads_only) { a.grads[o] = gr; continue; }
-    float pp = a.params[o], mm = a.opt.m[o], vv = a.opt.v[o];
-    adam_update(pp, gr, mm, vv, ac);
-    a.params[o] = pp; a.opt.m[o] = mm; a.opt.v[o] = vv;
+    if (n < Nvalid) adam_store(a, ac, poff + (int64_t)n * Kvalid + k, acc[r]);
   }
 }
 
-__device__ __forceinline__ void dw_bias(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dz, int ldz, int Nvalid, int n0, int64_t poff) {
-  const int lane = threadIdx.x & 63, n = n0 + lane;
-  if (n >= Nvalid) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int r = 0; r < a.batch; r += 4) {
-    s0 += dz[(size_t)(r + 0) * ldz + n]; s1 += dz[(size_t)(r + 1) * ldz + n]; s2 += dz[(size_t)(r + 2) * ldz + n]; s3 += dz[(size_t)(r + 3) * ldz + n];
-  }
-  const float gr = (s0 + s1) + (s2 + s3);
-  const int64_t o = poff + n;
-  if (a.grads_only) { a.grads[o] = gr; return; }
-  float pp = a.params[o], mm = a.opt.m[o], vv = a.opt.v[o];
-  adam_update(pp, gr, mm, vv, ac);
-  a.params[o] = pp; a.opt.m[o] = mm; a.opt.v[o] = vv;
+// 16 bias elements per wave: lane (j, g) sums rows 16i + 4g .. +3 of feature n0 + j, the four row groups meet through shuffles
+__device__ __forceinline__ void dw_bias(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dzT, int Nvalid, int n0, int64_t poff) {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int B = a.batch;
+  const float* p = dzT + (size_t)min(n0 + j, Nvalid - 1) * B + 4 * g;
+  f32x4 s4 = zero4();
+  for (int r0 = 0; r0 < B; r0 += 16) s4 += *reinterpret_cast<const f32x4*>(p + r0);
+  float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  if (g == 0 && n0 + j < Nvalid) adam_store(a, ac, poff + n0 + j, s);
 }
 
 __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
       const float gr = -(alpha) * (s / (float)a.batch);
       if (a.grads_only) a.alpha_grad[0] = gr;
       else {
-        const adam_consts ac = make_adam_consts(a.alpha_opt.lr, a.alpha_opt.beta1, a.alpha_opt.beta2, a.alpha_opt.eps, 0.0, a.alpha_opt.step[0]);
+        const adam_consts ac = load_adam_consts(a.alpha_opt);
         float pp = a.log_alpha[0], mm = a.alpha_opt.m[0], vv = a.alpha_opt.v[0];
         adam_update(pp, gr, mm, vv, ac);
         a.log_alpha[0] = pp; a.alpha_opt.m[0] = mm; a.alpha_opt.v[0] = vv;
@@ -470,13 +474,14 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
   }
   // ---- job decode (wave-uniform)
   const int IN = a.in_dim, H = a.hidden, OUT = a.out_dim;
-  const int nt_h = H / 16, kt_in = (IN + 15) / 16, nt_out = (OUT + 15) / 16, nb_h = H / 64;
-  const int j1 = nt_h * kt_in, j2 = nt_h * nt_h, j3 = nt_out * nt_h, jb = 2 * nb_h + 1;
+  const int nt_h = H / 16, kt_in = (IN + 15) / 16, nt_out = (OUT + 15) / 16;
+  const int j1 = nt_h * kt_in, j2 = nt_h * nt_h, j3 = nt_out * nt_h, jb = 2 * nt_h + nt_out;
   const int per_net = j1 + j2 + j3 + jb;
   int job = (int)blockIdx.x * 4 + wave_in_block;
   if (job >= per_net * a.n_nets) return;
   const int net = job / per_net; job -= net * per_net;
-  const adam_consts ac = make_adam_consts(a.opt.lr, a.opt.beta1, a.opt.beta2, a.opt.eps, a.opt.weight_decay, a.grads_only ? 1 : a.opt.step[0]);
+  adam_consts ac = {};
+  if (!a.grads_only) ac = load_adam_consts(a.opt);
   const int64_t pbase = (int64_t)net * a.net_stride;
   const int64_t oW1 = pbase, ob1 = oW1 + (int64_t)H * IN, oW2 = ob1 + H, ob2 = oW2 + (int64_t)H * H, oW3 = ob2 + H, ob3 = oW3 + (int64_t)OUT * H;
   const float* x0 = a.x0 + net * a.x0_net_stride;
@@ -484,32 +489,39 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
   const float* dz1 = a.dz1 + net * a.h_net_stride; const float* dz2 = a.dz2 + net * a.h_net_stride;
   const float* dz3 = a.dz3 + net * a.dz3_net_stride;
   // the big layer first: its tiles are the long pole, the small jobs fill in behind them
-  if (job < j2) { dw_tile(a, ac, dz2, H, H, h1, H, H, (job / nt_h) * 16, (job % nt_h) * 16, oW2); return; }
+  if (job < j2) { dw_tile<true>(a, ac, dz2, H, h1, 0, H, (job / nt_h) * 16, (job % nt_h) * 16, oW2); return; }
   job -= j2;
-  if (job < j1) { dw_tile(a, ac, dz1, H, H, x0, a.ld_x0, IN, (job / kt_in) * 16, (job % kt_in) * 16, oW1); return; }
+  if (job < j1) {
+    if (a.x0_transposed) dw_tile<true>(a, ac, dz1, H, x0, 0, IN, (job / kt_in) * 16, (job % kt_in) * 16, oW1);
+    else dw_tile<false>(a, ac, dz1, H, x0, a.ld_x0, IN, (job / kt_in) * 16, (job % kt_in) * 16, oW1);
+    return;
+  }
   job -= j1;
-  if (job < j3) { dw_tile(a, ac, dz3, a.ld_dz3, OUT, h2, H, H, (job / nt_h) * 16, (job % nt_h) * 16, oW3); return; }
+  if (job < j3) { dw_tile<true>(a, ac, dz3, OUT, h2, 0, H, (job / nt_h) * 16, (job % nt_h) * 16, oW3); return; }
   job -= j3;
-  if (job < nb_h) { dw_bias(a, ac, dz1, H, H, job * 64, ob1); return; }
-  job -= nb_h;
-  if (job < nb_h) { dw_bias(a, ac, dz2, H, H, job * 64, ob2); return; }
-  dw_bias(a, ac, dz3, a.ld_dz3, OUT, 0, ob3);
+  if (job < nt_h) { dw_bias(a, ac, dz1, H, job * 16, ob1); return; }
+  job -= nt_h;
+  if (job < nt_h) { dw_bias(a, ac, dz2, H, job * 16, ob2); return; }
+  job -= nt_h;
+  dw_bias(a, ac, dz3, OUT, job * 16, ob3);
 }
 
 static int dw_blocks(int IN, int H, int OUT, int nets) {
-  const int per_net = (H / 16) * ((IN + 15) / 16) + (H / 16) * (H / 16) + ((OUT + 15) / 16) * (H / 16) + 2 * (H / 64) + 1;
+  const int nt_h = H / 16, nt_out = (OUT + 15) / 16;
+  const int per_net = nt_h * ((IN + 15) / 16) + nt_h * nt_h + nt_out * nt_h + 2 * nt_h + nt_out;
   return ceil_div(per_net * nets, 4);
 }
+
 // generic elementwise Adam over a flat arena (data-parallel path and stand-alone use)
 __global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, const float* __restrict__ g, il_adam opt, int64_t n) {
-  const adam_consts ac = make_adam_consts(opt.lr, opt.beta1, opt.beta2, opt.eps, opt.weight_decay, opt.step[0]);
+  const adam_consts ac = load_adam_consts(opt);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float pp = p[i], mm = opt.m[i], vv = opt.v[i];
     adam_update(pp, g[i], mm, vv, ac);
     p[i] = pp; opt.m[i] = mm; opt.v[i] = vv;
   }
 }
-__global__ void k_tick(int32_t* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
+__global__ void k_tick(il_adam opt) { if (threadIdx.x == 0 && blockIdx.x == 0) adam_tick(opt); }
 __global__ __launch_bounds__(256) void k_polyak(float* __restrict__ t, const float* __restrict__ p, int64_t n, double tau_) {
   const float omt = (float)(1.0 - tau_), tau = (float)tau_;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -541,9 +553,9 @@ static DwArgs critic_dw_args(const il_sac* d, uint32_t flags) {
   DwArgs a = {};
   a.params = d->critic; a.grads = d->critic_grad; a.opt = d->critic_opt; a.grads_only = (flags & IL_FLAG_GRADS_ONLY) ? 1 : 0;
   a.n_nets = 2; a.net_stride = net_stride(IN, H, 1); a.in_dim = IN; a.hidden = H; a.out_dim = 1; a.batch = B;
-  a.x0 = d->workspace + ws.c_x0; a.ld_x0 = IN; a.x0_net_stride = 0;
+  a.x0 = d->workspace + ws.c_x0; a.ld_x0 = 0; a.x0_transposed = 1; a.x0_net_stride = 0;
   a.h1 = d->workspace + ws.c_h1; a.h2 = d->workspace + ws.c_h2; a.dz1 = d->workspace + ws.c_dz1; a.dz2 = d->workspace + ws.c_dz2; a.h_net_stride = (int64_t)B * H;
-  a.dz3 = d->workspace + ws.c_dz3; a.ld_dz3 = 1; a.dz3_net_stride = B;
+  a.dz3 = d->workspace + ws.c_dz3; a.dz3_net_stride = B;
   a.n_dw_blocks = dw_blocks(IN, H, 1, 2);
   return a;
 }
@@ -568,9 +580,9 @@ static DwArgs actor_dw_args(const il_sac* d, const il_batch* b, uint32_t flags) 
   DwArgs a = {};
   a.params = d->actor; a.grads = d->actor_grad; a.opt = d->actor_opt; a.grads_only = (flags & IL_FLAG_GRADS_ONLY) ? 1 : 0;
   a.n_nets = 1; a.net_stride = 0; a.in_dim = S; a.hidden = H; a.out_dim = 2 * A; a.batch = B;
-  a.x0 = b->states; a.ld_x0 = b->ld_states; a.x0_net_stride = 0;
+  a.x0 = b->states; a.ld_x0 = b->ld_states; a.x0_transposed = 0; a.x0_net_stride = 0;
   a.h1 = d->workspace + ws.a_h1; a.h2 = d->workspace + ws.a_h2; a.dz1 = d->workspace + ws.a_dz1; a.dz2 = d->workspace + ws.a_dz2; a.h_net_stride = 0;
-  a.dz3 = d->workspace + ws.a_dz3; a.ld_dz3 = 16; a.dz3_net_stride = 0;
+  a.dz3 = d->workspace + ws.a_dz3; a.dz3_net_stride = 0;
   a.n_dw_blocks = dw_blocks(S, H, 2 * A, 1);
   a.log_alpha = d->log_alpha; a.alpha_grad = d->alpha_grad; a.alpha_opt = d->alpha_opt; a.alpha_part = d->workspace + ws.alpha_part; a.n_alpha_part = B / IL_TILE_R;
   a.target = d->target; a.polyak_src = d->critic; a.polyak_n = 2 * net_stride(S + A, H, 1); a.tau = d->polyak; a.noise_counter = d->noise_counter;
@@ -616,7 +628,7 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
 extern "C" int il_adam_step(float* p, const float* g, const il_adam* opt, int64_t n, uint32_t flags, il_stream_t stream_) {
   IL_CHECK_ARG(p && g && opt && opt->m && opt->v && opt->step && n > 0, "il_adam_step: bad arguments");
   hipStream_t st = (hipStream_t)stream_;
-  if (flags & IL_FLAG_TICK) k_tick<<<1, 64, 0, st>>>(opt->step);
+  if (flags & IL_FLAG_TICK) k_tick<<<1, 64, 0, st>>>(*opt);
   const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   { IL_TRACE("k_adam_flat", st); k_adam_flat<<<blocks, 256, 0, st>>>(p, g, *opt, n); }
   IL_CHECK_LAUNCH("il_adam_step");
@@ -638,7 +650,7 @@ extern "C" int il_sac_apply_critic_grads(const il_sac* d, il_stream_t stream_) {
 
 __global__ void k_alpha_adam(float* log_alpha, const float* g, il_adam opt) {
   if (threadIdx.x || blockIdx.x) return;
-  const adam_consts ac = make_adam_consts(opt.lr, opt.beta1, opt.beta2, opt.eps, 0.0, opt.step[0]);
+  const adam_consts ac = load_adam_consts(opt);
   float pp = log_alpha[0], mm = opt.m[0], vv = opt.v[0];
   adam_update(pp, g[0], mm, vv, ac);
   log_alpha[0] = pp; opt.m[0] = mm; opt.v[0] = vv;
@@ -671,14 +683,18 @@ __global__ __launch_bounds__(1024) void k_bc_tile(const float* __restrict__ acto
   const int lane = tid & 63, j = lane & 15, g = lane >> 4;
   tile_fwd(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = net.b1[col];
+    f32x4 hv;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const float h = fmaxf(acc[r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = h; W[ws.a_h1 + (size_t)(row0 + 4 * g + r) * H + col] = h; }
+    for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = hv[r]; }
+    *reinterpret_cast<f32x4*>(W + ws.a_h1 + (size_t)col * B + row0 + 4 * g) = hv;
   });
   __syncthreads();
   tile_fwd(H1s, ldh, H, net.W2, H, H, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = net.b2[col];
+    f32x4 hv;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const float h = fmaxf(acc[r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = h; W[ws.a_h2 + (size_t)(row0 + 4 * g + r) * H + col] = h; }
+    for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = hv[r]; }
+    *reinterpret_cast<f32x4*>(W + ws.a_h2 + (size_t)col * B + row0 + 4 * g) = hv;
   });
   __syncthreads();
   tile_fwd_small(H2s, ldh, H, net.W3, H, 2 * A, net.b3, Os, part);
@@ -705,26 +721,25 @@ __global__ __launch_bounds__(1024) void k_bc_tile(const float* __restrict__ acto
   __syncthreads();
   if (head) { DZ3s[hr * ldz + hc] = dmean; DZ3s[hr * ldz + A + hc] = dls; }
   const float lsum = block_sum(head ? -b.weights[(size_t)(row0 + hr) * b.ld_weights] * lp_term : 0.f, red);
-  if (tid == 0) { if (loss_part) loss_part[tile] = lsum; if (tile == 0) opt.step[0] += 1; }
-  for (int i = tid; i < IL_TILE_R * 16; i += blockDim.x) W[ws.a_dz3 + (size_t)row0 * 16 + i] = DZ3s[(i >> 4) * ldz + (i & 15)];
+  if (tid == 0) { if (loss_part) loss_part[tile] = lsum; if (tile == 0) adam_tick(opt); }
+  for (int i = tid; i < IL_TILE_R * 16; i += blockDim.x) W[ws.a_dz3 + (size_t)(i >> 4) * B + row0 + (i & 15)] = DZ3s[(i & 15) * ldz + (i >> 4)];
   float* DZ2s = H1s;  // h1 lives in the workspace copy from here on
   __syncthreads();
   tile_bwd_dx(DZ3s, ldz, 16, 2 * A, net.W3, H, H, [&](int kb, f32x4 acc) {
+    const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
+    f32x4 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + j;
-      const float o = H2s[(4 * g + r) * ldh + kb + j] > 0.f ? acc[r] : 0.f;
-      W[ws.a_dz2 + off] = o;
-      DZ2s[(4 * g + r) * ldh + kb + j] = o;
-    }
+    for (int r = 0; r < 4; ++r) { o[r] = H2s[(4 * g + r) * ldh + kb + j] > 0.f ? acc[r] : 0.f; DZ2s[(4 * g + r) * ldh + kb + j] = o[r]; }
+    *reinterpret_cast<f32x4*>(W + ws.a_dz2 + off) = o;
   });
   __syncthreads();
   tile_bwd_dx(DZ2s, ldh, H, H, net.W2, H, H, [&](int kb, f32x4 acc) {
+    const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(W + ws.a_h1 + off);
+    f32x4 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const size_t off = (size_t)(row0 + 4 * g + r) * H + kb + j;
-      W[ws.a_dz1 + off] = W[ws.a_h1 + off] > 0.f ? acc[r] : 0.f;
-    }
+    for (int r = 0; r < 4; ++r) o[r] = hv[r] > 0.f ? acc[r] : 0.f;
+    *reinterpret_cast<f32x4*>(W + ws.a_dz1 + off) = o;
   });
 }
 
@@ -743,9 +758,9 @@ extern "C" int il_bc_step(float* actor, float* actor_grad, const il_adam* opt, i
   DwArgs a = {};
   a.params = actor; a.grads = actor_grad; a.opt = *opt; a.grads_only = (flags & IL_FLAG_GRADS_ONLY) ? 1 : 0;
   a.n_nets = 1; a.in_dim = S; a.hidden = H; a.out_dim = 2 * A; a.batch = b->n;
-  a.x0 = b->states; a.ld_x0 = b->ld_states;
+  a.x0 = b->states; a.ld_x0 = b->ld_states; a.x0_transposed = 0;
   a.h1 = workspace + ws.a_h1; a.h2 = workspace + ws.a_h2; a.dz1 = workspace + ws.a_dz1; a.dz2 = workspace + ws.a_dz2;
-  a.dz3 = workspace + ws.a_dz3; a.ld_dz3 = 16;
+  a.dz3 = workspace + ws.a_dz3;
   a.n_dw_blocks = dw_blocks(S, H, 2 * A, 1);
   { IL_TRACE("k_dw_adam_bc", st); k_dw_adam<<<a.n_dw_blocks, 256, 0, st>>>(a); }
   IL_CHECK_LAUNCH("il_bc_step");

@@ -21,7 +21,7 @@ class AdamW:
     self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
     self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
     self.grad = torch.zeros_like(self.flat)          # only used by the data-parallel path (all-reduce between backward and step)
-    self.step_count = torch.zeros(2, dtype=torch.int32, device=self.flat.device)
+    self.step_count = torch.zeros(16, dtype=torch.int32, device=self.flat.device)  # [0] step, [4..11] per-step fp32 constants (library-owned)
 
   def desc(self) -> _lib.Adam:
     return _lib.Adam(self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay)

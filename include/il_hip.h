@@ -98,7 +98,7 @@ int il_replay_sample_device(uint32_t* state_dev, int32_t n, const int64_t* ring_
  * ------------------------------------------------------------------------------------------ */
 typedef struct il_adam {
   float *m, *v;  /* exp_avg, exp_avg_sq */
-  int32_t* step; /* device int32: number of steps taken */
+  int32_t* step; /* device buffer of >= 16 int32: [0] = number of steps taken; [4..11] = fp32 constants of that step (written by the library) */
   double lr, beta1, beta2, eps, weight_decay; /* Python-float hyper-parameters (1 - beta etc. are formed in double like torch does);
                                                   weight_decay != 0 => decoupled decay p *= 1 - lr*wd */
 } il_adam;
