@@ -106,21 +106,7 @@ __device__ __forceinline__ void tile_bwd_dx_impl(const float* dYs, int ldy, int 
     const float* wp = W + kb + j;
     const float* yr = dYs + j * ldy + 4 * g;
     int n0 = 0;
-    for (; n0 + 128 <= Npad; n0 += 128) {  // 32 weight dwords in flight per lane
-      float b[8][4];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) { const int n = n0 + 16 * u + 4 * g + s; b[u][s] = wp[(size_t)(FULL ? n : min(n, Nvalid - 1)) * ldw]; }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(yr + n0 + 16 * u);
-        acc0 = mfma16(a[0], b[u][0], acc0);
-        acc1 = mfma16(a[1], b[u][1], acc1);
-        acc0 = mfma16(a[2], b[u][2], acc0);
-        acc1 = mfma16(a[3], b[u][3], acc1);
-      }
-    }
+    // 16 weight dwords in flight per lane (32 would need 64 address VGPRs: with 1024-thread workgroups the 128-VGPR budget spills)
     for (; n0 + 64 <= Npad; n0 += 64) {
       float b[4][4];
 #pragma unroll
