@@ -24,7 +24,7 @@ __host__ __device__ inline DiscLayout disc_layout(int D, int H, int sn) {
 struct DiscWs { int64_t slabs, sn_new, total; };
 __host__ __device__ inline DiscWs disc_ws(int D, int H, int B) {
   DiscWs w; const int64_t P = (int64_t)H * D + 2 * H + 1; const int nt = (B + IL_TILE_R - 1) / IL_TILE_R;
-  w.slabs = 0; w.sn_new = (nt * P + 3) & ~(int64_t)3; w.total = w.sn_new + 2 * H + D + 1 + 3;
+  w.slabs = 0; w.sn_new = (3 * nt * P + 3) & ~(int64_t)3; w.total = w.sn_new + 2 * H + D + 1 + 3;
   return w;
 }
 extern "C" int64_t il_disc_workspace_floats(int32_t D, int32_t H, int32_t B) { return disc_ws(D, H, B).total; }
@@ -125,159 +125,133 @@ __device__ __forceinline__ void stage_weights(const DiscLds& L, const float* __r
   for (int i = threadIdx.x; i < H; i += blockDim.x) { L.b1s[i] = b1[i]; L.W2s[i] = W2[i]; }
 }
 
-// GREG: gradient accumulators of W1 live in registers (H*D <= 8*256), else read-modify-write of this workgroup's own slab
-template <bool GREG>
+// grid = (tiles, passes): one workgroup = 16 rows of ONE discriminator call (0 policy, 1 expert, 2 gradient-penalty mix), so the
+// three calls run side by side; wave 0 chains the power iterations up to its call (pass + 1 of them) while waves 1.. stage rows.
 __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch, Dp = (D + 3) & ~3, ldw = Dp + 4;
-  const int tile = blockIdx.x, row0 = tile * IL_TILE_R, tid = threadIdx.x;
+  const int tile = blockIdx.x, pass = blockIdx.y, npass = gridDim.y, nt = gridDim.x, row0 = tile * IL_TILE_R, tid = threadIdx.x;
   const int nrows = min(IL_TILE_R, B - row0);
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
   const DiscWs wsl = disc_ws(D, H, B);
   const float b2 = d.params[lay.ob2];
-  float* slab = d.workspace + wsl.slabs + (size_t)tile * lay.P;
+  float* slab = d.workspace + wsl.slabs + ((size_t)pass * nt + tile) * lay.P;
   DiscLds L = carve(smem, D, H);
   stage_weights(L, d.params + lay.oW1, d.params + lay.ob1, d.params + lay.oW2, D, H);
-  // ---- stage inputs: policy rows, expert rows (mix rows below, training.py:118-120)
-  for (int i = tid; i < IL_TILE_R * Dp; i += blockDim.x) {
-    const int r = i / Dp, k = i - r * Dp; float xp = 0.f, xe = 0.f;
-    if (r < nrows && k < D) {
-      xp = k < S ? pol.states[(size_t)(row0 + r) * pol.ld_states + k] : pol.actions[(size_t)(row0 + r) * pol.ld_actions + k - S];
-      xe = k < S ? exp.states[(size_t)(row0 + r) * exp.ld_states + k] : exp.actions[(size_t)(row0 + r) * exp.ld_actions + k - S];
-    }
-    L.X(0)[i] = xp; L.X(1)[i] = xe;
-  }
-  const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
-  if (tid < IL_TILE_R) {
-    const int r = tid; float wp = 0.f, we = 0.f, e = 0.f;
-    if (r < nrows) {
-      wp = pol.weights[(size_t)(row0 + r) * pol.ld_weights]; we = exp.weights[(size_t)(row0 + r) * exp.ld_weights];
-      e = eps_gp ? eps_gp[row0 + r] : philox_uniform(d.noise_seed, ctr, IL_STREAM_GP, (uint32_t)(row0 + r));
-    }
-    L.wt(0)[r] = wp; L.wt(1)[r] = we; L.wt(2)[r] = e * we + (1.f - e) * wp; L.dzs[r] = e;
-  }
   if (d.spectral_norm) {
     for (int i = tid; i < H; i += blockDim.x) { L.u1(0)[i] = d.u1[i]; L.v2(0)[i] = d.v2[i]; }
     for (int i = tid; i < Dp; i += blockDim.x) L.v1(0)[i] = i < D ? d.v1[i] : 0.f;
     if (tid == 0) L.sc(0)[2] = d.u2[0];
-  }
-  if (tid == 0 && tile == 0) adam_tick(d.opt);
+  } else if (tid == 0) { L.sc(0)[0] = 1.f; L.sc(0)[1] = 1.f; L.sc(0)[2] = 0.f; }
+  if (tid == 0 && tile == 0 && pass == 0) adam_tick(d.opt);
   __syncthreads();
-  const int npass = d.grad_penalty > 0.f ? 3 : 2;
-  if (tid < 64) {  // ---- wave 0: the power iterations of all discriminator calls, chained
-    for (int c = 0; c < npass; ++c) {
-      if (d.spectral_norm) {
-        if (c > 0) {
-          for (int i = tid; i < H; i += 64) { L.u1(c)[i] = L.u1(c - 1)[i]; L.v2(c)[i] = L.v2(c - 1)[i]; }
-          for (int i = tid; i < Dp; i += 64) L.v1(c)[i] = L.v1(c - 1)[i];
-          if (tid == 0) L.sc(c)[2] = L.sc(c - 1)[2];
-          WAVE_SYNC();
-        }
-        sn_wave(L.W1s, L.W2s, D, H, L.u1(c), L.v1(c), &L.sc(c)[2], L.v2(c), true, L.sc(c));
-      } else if (tid == 0) { L.sc(c)[0] = 1.f; L.sc(c)[1] = 1.f; L.sc(c)[2] = 0.f; }
+  const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
+  float* X = L.X(0);
+  if (tid < 64) {  // ---- wave 0: power iterations of call 0..pass, chained in place
+    if (d.spectral_norm)
+      for (int c = 0; c <= pass; ++c) sn_wave(L.W1s, L.W2s, D, H, L.u1(0), L.v1(0), &L.sc(0)[2], L.v2(0), true, L.sc(0));
+  } else {         // ---- waves 1..3: rows of this call
+    for (int i = tid - 64; i < IL_TILE_R * Dp; i += blockDim.x - 64) {
+      const int r = i / Dp, k = i - r * Dp; float x = 0.f;
+      if (r < nrows && k < D) {
+        const int row = row0 + r;
+        float xp = 0.f, xe = 0.f;
+        if (pass != 1) xp = k < S ? pol.states[(size_t)row * pol.ld_states + k] : pol.actions[(size_t)row * pol.ld_actions + k - S];
+        if (pass != 0) xe = k < S ? exp.states[(size_t)row * exp.ld_states + k] : exp.actions[(size_t)row * exp.ld_actions + k - S];
+        if (pass == 2) { const float e = eps_gp ? eps_gp[row] : philox_uniform(d.noise_seed, ctr, IL_STREAM_GP, (uint32_t)row); x = e * xe + (1.f - e) * xp; }
+        else x = pass == 0 ? xp : xe;
+      }
+      X[i] = x;
     }
-  } else {
-    for (int i = tid - 64; i < IL_TILE_R * Dp; i += blockDim.x - 64) { const float e = L.dzs[i / Dp]; L.X(2)[i] = e * L.X(1)[i] + (1.f - e) * L.X(0)[i]; }
+    if (tid >= 64 && tid < 64 + IL_TILE_R) {
+      const int r = tid - 64, row = row0 + r; float w = 0.f;
+      if (r < nrows) {
+        const float wp = pass != 1 ? pol.weights[(size_t)row * pol.ld_weights] : 0.f, we = pass != 0 ? exp.weights[(size_t)row * exp.ld_weights] : 0.f;
+        if (pass == 2) { const float e = eps_gp ? eps_gp[row] : philox_uniform(d.noise_seed, ctr, IL_STREAM_GP, (uint32_t)row); w = e * we + (1.f - e) * wp; }
+        else w = pass == 0 ? wp : we;
+      }
+      L.wt(0)[r] = w;
+    }
   }
   __syncthreads();
 
   const int r = tid >> 4, sub = tid & 15;
   const float fB = (float)B;
   const bool valid = r < nrows;
-  constexpr int EPT = 8;
-  float greg[EPT];
-#pragma unroll
-  for (int q = 0; q < EPT; ++q) greg[q] = 0.f;
-  for (int pass = 0; pass < npass; ++pass) {
-    const float s1 = L.sc(pass)[0], s2 = L.sc(pass)[1], u2 = L.sc(pass)[2];
-    const float* u1 = L.u1(pass); const float* v1 = L.v1(pass); const float* v2 = L.v2(pass);
-    const float* X = L.X(pass);
-    // ---- forward for row r (16 threads per row)
-    float zp = 0.f;
+  const float s1 = L.sc(0)[0], s2 = L.sc(0)[1], u2 = L.sc(0)[2];
+  const float* u1 = L.u1(0); const float* v1 = L.v1(0); const float* v2 = L.v2(0);
+  // ---- forward for row r (16 threads per row)
+  float zp = 0.f;
+  for (int n = sub; n < H; n += 16) {
+    const float h = dot4(L.W1s + n * ldw, X + r * Dp, Dp) / s1 + L.b1s[n];
+    L.hs[r * H + n] = h;
+    zp += (L.W2s[n] / s2) * fmaxf(h, 0.f);
+  }
+  zp = group16_sum(zp);
+  const float z = zp + b2;
+  float ip1, ip2;
+  if (pass < 2) {
+    const float w = L.wt(0)[r], label = pass == 1 ? 1.f : 0.f;
+    const float p = sigmoid_f(z);
+    float dz = valid ? w * (p - label) / fB : 0.f;
+    if (d.entropy_bonus > 0.f && valid) dz += d.entropy_bonus * w * z * p * (1.f - p) / fB;
+    if (sub == 0) { L.dzs[r] = dz; L.zs[r] = z; }
+    float a1 = 0.f;
     for (int n = sub; n < H; n += 16) {
-      const float h = dot4(L.W1s + n * ldw, X + r * Dp, Dp) / s1 + L.b1s[n];
-      L.hs[r * H + n] = h;
-      zp += (L.W2s[n] / s2) * fmaxf(h, 0.f);
+      const float h = L.hs[r * H + n];
+      const float dh = h > 0.f ? dz * (L.W2s[n] / s2) : 0.f;
+      L.dhs[r * H + n] = dh;
+      a1 += dh * (h - L.b1s[n]);
     }
-    zp = group16_sum(zp);
-    const float z = zp + b2;
-    float ip1, ip2;
-    if (pass < 2) {
-      const float w = L.wt(pass)[r], label = pass == 1 ? 1.f : 0.f;
-      const float p = sigmoid_f(z);
-      float dz = valid ? w * (p - label) / fB : 0.f;
-      if (d.entropy_bonus > 0.f && valid) dz += d.entropy_bonus * w * z * p * (1.f - p) / fB;
-      if (sub == 0) { L.dzs[r] = dz; L.zs[r] = z; }
-      float a1 = 0.f;
-      for (int n = sub; n < H; n += 16) {
-        const float h = L.hs[r * H + n];
-        const float dh = h > 0.f ? dz * (L.W2s[n] / s2) : 0.f;
-        L.dhs[r * H + n] = dh;
-        a1 += dh * (h - L.b1s[n]);
-      }
-      ip1 = s1 * block_sum(a1, L.red);
-      ip2 = s2 * block_sum(sub == 0 ? dz * (z - b2) : 0.f, L.red);
-    } else {
-      // q = [h>0] w2^ -> dhs ; g = W1^^T q ; cg = c g
-      for (int n = sub; n < H; n += 16) L.dhs[r * H + n] = L.hs[r * H + n] > 0.f ? (L.W2s[n] / s2) : 0.f;
-      __syncthreads();
-      const float c = valid ? 2.f * d.grad_penalty * L.wt(2)[r] / fB : 0.f;
-      for (int k = sub; k < Dp; k += 16) L.cg[r * Dp + k] = k < D ? c * (dot_strided(L.dhs + r * H, L.W1s + k, ldw, H) / s1) : 0.f;
-      __syncthreads();
-      float S_ip = 0.f;
-      for (int n = sub; n < H; n += 16) {
-        const float tp = dot4(L.W1s + n * ldw, L.cg + r * Dp, Dp) / s1;
-        L.ts[r * H + n] = L.hs[r * H + n] > 0.f ? tp : 0.f;
-        S_ip += L.dhs[r * H + n] * tp;
-      }
-      const float Ssum = block_sum(S_ip, L.red);
-      ip1 = s1 * Ssum; ip2 = s2 * Ssum;
-    }
+    ip1 = s1 * block_sum(a1, L.red);
+    ip2 = s2 * block_sum(sub == 0 ? dz * (z - b2) : 0.f, L.red);
+  } else {
+    // q = [h>0] w2^ -> dhs ; g = W1^^T q ; cg = c g
+    for (int n = sub; n < H; n += 16) L.dhs[r * H + n] = L.hs[r * H + n] > 0.f ? (L.W2s[n] / s2) : 0.f;
     __syncthreads();
-    // ---- accumulate this pass (each gradient element owned by one thread)
-    const float* left = L.dhs;                         // [16][H]: dh (BCE) or q (GP)
-    const float* right = pass < 2 ? X : L.cg;          // [16][D]: x (BCE) or c*g (GP)
-    const float k1 = d.spectral_norm ? ip1 / (s1 * s1) : 0.f, k2 = d.spectral_norm ? ip2 / (s2 * s2) : 0.f;
-    auto grad_w1 = [&](int e) -> float {
-      const int n = e / D, k = e - n * D;
-      float gh = 0.f;
-#pragma unroll
-      for (int rr = 0; rr < IL_TILE_R; ++rr) gh += left[rr * H + n] * right[rr * Dp + k];
-      return gh / s1 - (d.spectral_norm ? k1 * u1[n] * v1[k] : 0.f);
-    };
-    if (GREG) {
-#pragma unroll
-      for (int q = 0; q < EPT; ++q) { const int e = tid + q * 256; if (e < H * D) greg[q] += grad_w1(e); }  // static register indices
-    } else {
-      for (int e = tid; e < H * D; e += blockDim.x) { const float gv = grad_w1(e); slab[lay.oW1 + e] = pass == 0 ? gv : slab[lay.oW1 + e] + gv; }
-    }
-    for (int n = tid; n < H; n += blockDim.x) {
-      float g2 = 0.f, gb = 0.f;
-      for (int rr = 0; rr < IL_TILE_R; ++rr) {
-        if (pass < 2) { g2 += L.dzs[rr] * fmaxf(L.hs[rr * H + n], 0.f); gb += L.dhs[rr * H + n]; }
-        else g2 += L.ts[rr * H + n];
-      }
-      const float gv = g2 / s2 - (d.spectral_norm ? k2 * u2 * v2[n] : 0.f);
-      slab[lay.oW2 + n] = pass == 0 ? gv : slab[lay.oW2 + n] + gv;
-      if (pass < 2) slab[lay.ob1 + n] = pass == 0 ? gb : slab[lay.ob1 + n] + gb;
-    }
-    if (tid == 0 && pass < 2) {
-      float gb2 = 0.f;
-      for (int rr = 0; rr < IL_TILE_R; ++rr) gb2 += L.dzs[rr];
-      slab[lay.ob2] = pass == 0 ? gb2 : slab[lay.ob2] + gb2;
-    }
+    const float c = valid ? 2.f * d.grad_penalty * L.wt(0)[r] / fB : 0.f;
+    for (int k = sub; k < Dp; k += 16) L.cg[r * Dp + k] = k < D ? c * (dot_strided(L.dhs + r * H, L.W1s + k, ldw, H) / s1) : 0.f;
     __syncthreads();
+    float S_ip = 0.f;
+    for (int n = sub; n < H; n += 16) {
+      const float tp = dot4(L.W1s + n * ldw, L.cg + r * Dp, Dp) / s1;
+      L.ts[r * H + n] = L.hs[r * H + n] > 0.f ? tp : 0.f;
+      S_ip += L.dhs[r * H + n] * tp;
+    }
+    const float Ssum = block_sum(S_ip, L.red);
+    ip1 = s1 * Ssum; ip2 = s2 * Ssum;
   }
-  if (GREG) {
+  __syncthreads();
+  // ---- this call's gradient slab (each element owned by one thread)
+  const float* left = L.dhs;                         // [16][H]: dh (BCE) or q (GP)
+  const float* right = pass < 2 ? X : L.cg;          // [16][Dp]: x (BCE) or c*g (GP)
+  const float k1 = d.spectral_norm ? ip1 / (s1 * s1) : 0.f, k2 = d.spectral_norm ? ip2 / (s2 * s2) : 0.f;
+  for (int e = tid; e < H * D; e += blockDim.x) {
+    const int n = e / D, k = e - n * D;
+    float gh = 0.f;
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) { const int e = tid + q * 256; if (e < H * D) slab[lay.oW1 + e] = greg[q]; }
+    for (int rr = 0; rr < IL_TILE_R; ++rr) gh += left[rr * H + n] * right[rr * Dp + k];
+    slab[lay.oW1 + e] = gh / s1 - (d.spectral_norm ? k1 * u1[n] * v1[k] : 0.f);
   }
-  if (tile == 0 && d.spectral_norm) {  // final u, v of this update (identical in every workgroup)
+  for (int n = tid; n < H; n += blockDim.x) {
+    float g2 = 0.f, gb = 0.f;
+    for (int rr = 0; rr < IL_TILE_R; ++rr) {
+      if (pass < 2) { g2 += L.dzs[rr] * fmaxf(L.hs[rr * H + n], 0.f); gb += L.dhs[rr * H + n]; }
+      else g2 += L.ts[rr * H + n];
+    }
+    slab[lay.oW2 + n] = g2 / s2 - (d.spectral_norm ? k2 * u2 * v2[n] : 0.f);
+    slab[lay.ob1 + n] = gb;   // zero for the gradient-penalty call (no bias gradient)
+  }
+  if (tid == 0) {
+    float gb2 = 0.f;
+    if (pass < 2) for (int rr = 0; rr < IL_TILE_R; ++rr) gb2 += L.dzs[rr];
+    slab[lay.ob2] = gb2;
+  }
+  if (tile == 0 && pass == npass - 1 && d.spectral_norm) {  // final u, v of this update: the last call's iteration
     float* o = d.workspace + wsl.sn_new;
-    const int c = npass - 1;
-    for (int i = tid; i < H; i += blockDim.x) { o[i] = L.u1(c)[i]; o[H + D + 1 + i] = L.v2(c)[i]; }
-    for (int i = tid; i < D; i += blockDim.x) o[H + i] = L.v1(c)[i];
-    if (tid == 0) o[H + D] = L.sc(c)[2];
+    for (int i = tid; i < H; i += blockDim.x) { o[i] = u1[i]; o[H + D + 1 + i] = v2[i]; }
+    for (int i = tid; i < D; i += blockDim.x) o[H + i] = v1[i];
+    if (tid == 0) o[H + D] = u2;
   }
 }
 
@@ -286,7 +260,7 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply) {
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch;
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
   const DiscWs wsl = disc_ws(D, H, B);
-  const int nt = (B + IL_TILE_R - 1) / IL_TILE_R;
+  const int nt = ((B + IL_TILE_R - 1) / IL_TILE_R) * (d.grad_penalty > 0.f ? 3 : 2);  // one slab per (call, tile)
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < lay.P) {
     const float* sl = d.workspace + wsl.slabs + e;
@@ -376,10 +350,8 @@ extern "C" int il_gail_disc_step(const il_disc* d, const il_batch* pol, const il
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
   const int nt = ceil_div(d->batch, IL_TILE_R);
   const size_t lds = disc_lds_floats(D, d->hidden) * sizeof(float);
-  const bool greg = (int64_t)d->hidden * D <= 8 * 256;
-  if (int rc = ensure_lds(greg ? (const void*)k_gail_grad<true> : (const void*)k_gail_grad<false>, lds)) return rc;
-  if (greg) { IL_TRACE("k_gail_grad", st); k_gail_grad<true><<<nt, 256, lds, st>>>(*d, *pol, *exp, eps_gp); }
-  else { IL_TRACE("k_gail_grad", st); k_gail_grad<false><<<nt, 256, lds, st>>>(*d, *pol, *exp, eps_gp); }
+  if (int rc = ensure_lds((const void*)k_gail_grad, lds)) return rc;
+  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, d->grad_penalty > 0.f ? 3 : 2), 256, lds, st>>>(*d, *pol, *exp, eps_gp); }
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
   { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1); }
   IL_CHECK_LAUNCH("il_gail_disc_step");

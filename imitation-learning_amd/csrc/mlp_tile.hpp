@@ -94,8 +94,8 @@ __device__ __forceinline__ void tile_fwd(const float* Xs, int ldx, int Kpad, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// dX[16 x K] = dYs[16 x Npad] . W      W: global row-major [Nvalid][ldw], K % 16 == 0, rows >= Nvalid read as zero.
-// epi(kb, acc): acc[reg] = dX[row 4g+reg][col kb + j]
+// dX[16 x K] = dYs[16 x Npad] . W      W: global row-major [Nvalid][ldw], rows >= Nvalid read as zero; columns kb + j >= K clamp
+// their address (the epilogue must ignore them when K % 16 != 0).  epi(kb, acc): acc[reg] = dX[row 4g+reg][col kb + j]
 // ---------------------------------------------------------------------------------------------
 template <bool FULL, class Epi>
 __device__ __forceinline__ void tile_bwd_dx_impl(const float* dYs, int ldy, int Npad, int Nvalid, const float* __restrict__ W, int ldw, int K, Epi epi) {
@@ -103,7 +103,7 @@ __device__ __forceinline__ void tile_bwd_dx_impl(const float* dYs, int ldy, int 
   const int j = lane & 15, g = lane >> 4;
   for (int kb = wave * 16; kb < K; kb += nw * 16) {
     f32x4 acc0 = zero4(), acc1 = zero4();
-    const float* wp = W + kb + j;
+    const float* wp = W + min(kb + j, K - 1);
     const float* yr = dYs + j * ldy + 4 * g;
     int n0 = 0;
     // 16 weight dwords in flight per lane (32 would need 64 address VGPRs: with 1024-thread workgroups the 128-VGPR budget spills)

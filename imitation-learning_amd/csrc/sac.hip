@@ -270,16 +270,15 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b) {
     }
   });
   __syncthreads();
-  // g[r][c] = sum_n dz1[r][n] W1[n][S + c] : 16 threads per row, each strides n (waves 0-3 only)
-  if (threadIdx.x < 256) {
-    const int r = threadIdx.x >> 4, sub = threadIdx.x & 15;
-    for (int c = 0; c < A; ++c) {
-      float s = 0.f;
-      for (int n = sub; n < H; n += 16) s += H1s[r * ldh + n] * p.W1[(size_t)n * IN + S + c];
-      s = group16_sum(s);
-      if (sub == 0) W[ws.p_g + ((size_t)k * B + row0 + r) * A + c] = s;
+  // dQ/dx = dz1 . W1 on MFMA (K = S + A columns, not a multiple of 16: out-of-range columns clamp); only the action columns are kept
+  float* gout = W + ws.p_g + ((size_t)k * B + row0) * A;
+  tile_bwd_dx(H1s, ldh, H, H, p.W1, IN, IN, [&](int kb, f32x4 acc) {
+    const int c = kb + j - S;
+    if (c >= 0 && c < A) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gout[(size_t)(4 * g + r) * A + c] = acc[r];
     }
-  }
+  });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -607,20 +606,25 @@ extern "C" int il_sac_actor_step(const il_sac* d, const il_batch* b, const float
 extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags,
                              il_stream_t stream_) {
   if (int rc = check_sac(d, b)) return rc;
+  if (flags & IL_FLAG_GRADS_ONLY) return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update: IL_FLAG_GRADS_ONLY needs the split critic/actor entry points");
   hipStream_t st = (hipStream_t)stream_;
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
-  // the actor is unchanged until the last kernel of the update: both of its forward passes share one launch
-  { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, 0); }
-  { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, tile_threads(H), lds, st>>>(*d, *b); }
-  { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b); }
-  DwArgs ca = critic_dw_args(d, flags);
-  { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
-  if (flags & IL_FLAG_GRADS_ONLY) { IL_CHECK_LAUNCH("il_sac_update"); return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update: IL_FLAG_GRADS_ONLY needs the split critic/actor entry points"); }
-  { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b); }
-  { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q); }
-  DwArgs aa = actor_dw_args(d, b, flags);
-  { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 33, 256, 0, st>>>(aa); }
+  if (!(flags & IL_FLAG_SAC_SKIP_FORWARD)) {
+    // the actor is unchanged until the last kernel of the update: both of its forward passes share one launch; neither this
+    // nor the critic/target forward reads the rewards, so a caller may overlap the reward relabel with them (IL_FLAG_SAC_FORWARD_ONLY)
+    { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, 0); }
+    { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, tile_threads(H), lds, st>>>(*d, *b); }
+  }
+  if (!(flags & IL_FLAG_SAC_FORWARD_ONLY)) {
+    { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b); }
+    DwArgs ca = critic_dw_args(d, flags);
+    { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
+    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b); }
+    { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q); }
+    DwArgs aa = actor_dw_args(d, b, flags);
+    { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 33, 256, 0, st>>>(aa); }
+  }
   IL_CHECK_LAUNCH("il_sac_update");
   return IL_OK;
 }

@@ -191,8 +191,9 @@ class UpdatePlan:
 
   def __init__(self, algorithm: str, actor, critic, log_alpha, target_critic, memory: ReplayMemory, actor_optimiser, critic_optimiser, temperature_optimiser,
                batch_size: int, discount: float, entropy_target: float, polyak_factor: float, expert_memory: Optional[ReplayMemory] = None, discriminator=None,
-               discriminator_optimiser=None, imitation_cfg=None, device_index_draw: bool = True):
+               discriminator_optimiser=None, imitation_cfg=None, device_index_draw: bool = True, overlap: bool = True):
     assert algorithm in ('SAC', 'GAIL')
+    self.overlap, self.side = overlap, (torch.cuda.Stream() if overlap and algorithm == 'GAIL' else None)
     self.algorithm, self.B, dev = algorithm, batch_size, actor.flat.device
     self.memory, self.expert_memory, self.device_index_draw = memory, expert_memory, device_index_draw
     self.rows = torch.empty(batch_size, memory.row, device=dev); self.idx = torch.empty(batch_size, dtype=torch.int32, device=dev)
@@ -233,8 +234,23 @@ class UpdatePlan:
         _lib.ptr(self.erows) if e else None, _lib.stream_ptr()))
 
   def run(self):
-    L, st = _lib.lib(), _lib.stream_ptr()
+    L = _lib.lib()
     self.sample_all()
+    if self.algorithm == 'GAIL' and self.overlap:
+      # fork: the discriminator step + reward relabel run on a side stream next to the reward-independent SAC forward kernels;
+      # join before the critic loss (the first kernel that reads rewards). Captured as two branches of the same hipGraph.
+      main = torch.cuda.current_stream()
+      self.side.wait_stream(main)
+      with torch.cuda.stream(self.side):
+        st = _lib.stream_ptr()
+        _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, 0, st))
+        _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, st))
+      st = _lib.stream_ptr()
+      _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), _lib.IL_FLAG_SAC_FORWARD_ONLY, st))
+      main.wait_stream(self.side)
+      _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), _lib.IL_FLAG_SAC_SKIP_FORWARD, st))
+      return
+    st = _lib.stream_ptr()
     if self.algorithm == 'GAIL':
       _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, 0, st))
       _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, st))

@@ -35,6 +35,8 @@ enum { IL_OK = 0, IL_ERR_ARG = 1, IL_ERR_UNSUPPORTED = 2, IL_ERR_HIP = 3, IL_ERR
 /* flags */
 #define IL_FLAG_GRADS_ONLY 1u /* write gradients to the *_grad arenas and skip the optimiser (data-parallel: all-reduce, then il_adam_step) */
 #define IL_FLAG_TICK 2u       /* il_adam_step: increment the step counter first (stand-alone use) */
+#define IL_FLAG_SAC_FORWARD_ONLY 4u /* il_sac_update: only the reward-independent forward kernels (actor on s and s', critics, targets) */
+#define IL_FLAG_SAC_SKIP_FORWARD 8u /* il_sac_update: everything after them (the caller already ran FORWARD_ONLY on this batch) */
 
 typedef void* il_stream_t; /* hipStream_t */
 
