@@ -45,7 +45,9 @@ def algorithmic_model():
   bytes_k = {
       'k_dw_adam_critic': 24 * 2 * Pc, 'k_dw_adam_actor': 24 * (Pa + 1) + 8 * 2 * Pc, 'k_gail_reduce': 24 * Pd, 'k_gather2': 2 * B * (2 * S + A + 5) * 4 + 2 * B * 4,
   }
+  mac_d = (S + A) * HD + HD
   flops_k = {
+      'k_gail_grad': 2 * B * mac_d * (3 + 2 * 2 + 3), 'k_gail_reward': 2 * B * mac_d,   # 3 forwards, 2 BCE backwards, closed-form GP second-order terms
       'k_actor_fwd': 2 * 2 * B * mac_a, 'k_critic_fwd': 4 * 2 * B * mac_c, 'k_critic_bwd': 2 * 2 * B * H * H, 'k_dw_adam_critic': 2 * 2 * B * mac_c,
       'k_policy_critic': 2 * 2 * B * (mac_c + H * H + H * A), 'k_actor_bwd': 2 * B * (2 * A * H + H * H), 'k_dw_adam_actor': 2 * B * mac_a,
   }
@@ -218,7 +220,7 @@ def main():
       per_kernel[k] = e
     if dom in flops_k:
       ach = flops_k[dom] / (kern[dom]['avg_us'] * 1e-6) / 1e12
-      roof = dict(bound='mfma', kernel=dom, achieved=round(ach, 3), peak=FP32_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / FP32_PEAK_TFLOPS, 5), traffic=None)
+      roof = dict(bound='mfma', kernel=dom, note='fp32: MFMA f32 rate == VALU f32 rate == 157.3 TFLOP/s on gfx950', achieved=round(ach, 3), peak=FP32_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / FP32_PEAK_TFLOPS, 5), traffic=None)
     else:
       ach = bytes_k.get(dom, 0) / (kern[dom]['avg_us'] * 1e-6) / 1e9
       roof = dict(bound='hbm', kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 5), traffic=None)
