@@ -61,6 +61,7 @@ _SIGNATURES = {
     'il_replay_gather': (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int32, _P, _P]),
     'il_mt19937_seed': (C.c_int, [c_u32p, C.c_uint32]),
     'il_mt19937_sample_indices': (C.c_int, [c_u32p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, c_i32p]),
+    'il_mt19937_randint': (C.c_int, [c_u32p, C.c_int64, C.c_int32, c_i32p]),
     'il_mt19937_sample_indices_device': (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     'il_replay_sample_device': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
     'il_adam_step': (C.c_int, [_P, _P, C.POINTER(Adam), C.c_int64, C.c_uint32, _P]),

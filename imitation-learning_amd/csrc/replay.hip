@@ -122,6 +122,18 @@ extern "C" int il_mt19937_sample_indices(uint32_t* s, int32_t n, int64_t size, i
   return IL_OK;
 }
 
+// plain np.random.randint(0, high) draws from the same stream (environments.py:113 `np.random.choice(subsample)` consumes it too)
+extern "C" int il_mt19937_randint(uint32_t* s, int64_t high, int32_t n, int32_t* out) {
+  IL_CHECK_ARG(s && out && n >= 0 && high >= 1 && high <= 0x7FFFFFFFll, "il_mt19937_randint: bad arguments");
+  const uint32_t rng = (uint32_t)(high - 1), mask = mask_for(rng);
+  for (int32_t i = 0; i < n; ++i) {
+    uint32_t v = 0;
+    if (rng != 0) do { v = mt_next_host(s) & mask; } while (v > rng);
+    out[i] = (int32_t)v;
+  }
+  return IL_OK;
+}
+
 // Device version: one workgroup. The draw is a stream compaction of the tempered MT output (every candidate consumes
 // exactly one 32-bit word; rejected ones are skipped), so 256 candidates are tested in parallel and compacted in order.
 struct MtShared { uint32_t mt[MT_N]; int wave_cnt[4]; int pos, count, last; };

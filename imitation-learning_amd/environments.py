@@ -1,0 +1,141 @@
+"""Environment + expert-data side of the loop (reference environments.py).
+
+gym 0.23 + d4rl + MuJoCo are not installable in this environment (no network), and CPU physics is not the path being
+accelerated (out of scope). `SyntheticD4RLEnv` reproduces what the update path depends on: observation /
+action shapes of the four D4RL locomotion tasks, the absorbing-indicator bit, action clipping, `max_episode_steps`, early
+termination for the tasks that have it, and `get_dataset()` with the reference's trajectory split, truncation, absorbing-state
+wrapping, importance weights and sub-sampling semantics (environments.py:63-125) on synthetic expert rollouts.
+If gym and d4rl ARE importable, `D4RLEnv` wraps the real thing with the same interface.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .memory import ReplayMemory, index_stream
+
+ENVS = ['ant', 'halfcheetah', 'hopper', 'walker2d']
+_SPECS = {  # obs dim (without absorbing bit), action dim, can terminate early, (ref_min_score, ref_max_score) of the D4RL tasks
+    'ant': (111, 8, True, (-325.6, 3879.7)), 'halfcheetah': (17, 6, False, (-280.178953, 12135.0)),
+    'hopper': (11, 3, True, (-20.272305, 3234.3)), 'walker2d': (17, 6, True, (1.629008, 4592.3)),
+}
+
+
+class _Space:
+  def __init__(self, dim):
+    self.shape = (dim,)
+    self.low, self.high = -torch.ones(dim), torch.ones(dim)
+
+
+class SyntheticD4RLEnv:
+  """Seeded linear-Gaussian locomotion stand-in with the interface of the reference's `D4RLEnv`."""
+
+  def __init__(self, env_name: str, absorbing: bool, load_data: bool = False, dataset_trajectories: int = 30, max_episode_steps: int = 1000):
+    assert env_name in ENVS
+    self.name, self.absorbing = env_name, absorbing
+    self.obs_dim, self.act_dim, self.can_terminate, (self.ref_min_score, self.ref_max_score) = _SPECS[env_name]
+    self.max_episode_steps = max_episode_steps
+    rs = np.random.RandomState(abs(hash(env_name)) % (2**31))
+    self._A = (np.eye(self.obs_dim) * 0.95 + rs.standard_normal((self.obs_dim, self.obs_dim)) * 0.02).astype(np.float32)
+    self._Bm = (rs.standard_normal((self.obs_dim, self.act_dim)) * 0.3).astype(np.float32)
+    self._K = (rs.standard_normal((self.act_dim, self.obs_dim)) * 0.2).astype(np.float32)  # the synthetic expert's linear policy
+    self._w = (rs.standard_normal(self.obs_dim) * 0.1).astype(np.float32)
+    self.observation_space, self.action_space = _Space(self.obs_dim + (1 if absorbing else 0)), _Space(self.act_dim)
+    self.env = self  # `env.env.ref_max_score` (train.py:58)
+    self._rs, self._t, self._x = np.random.RandomState(0), 0, None
+    self._dataset_trajectories = dataset_trajectories
+    self.dataset = self._make_dataset() if load_data else None
+
+  # --- gym-like API
+  def seed(self, seed: int) -> List[int]:
+    self._rs = np.random.RandomState(seed)
+    return [seed]
+
+  def _obs(self, x) -> Tensor:
+    state = torch.tensor(x, dtype=torch.float32).unsqueeze(0)
+    return torch.cat([state, torch.zeros(1, 1)], dim=1) if self.absorbing else state
+
+  def reset(self) -> Tensor:
+    self._x, self._t = (self._rs.standard_normal(self.obs_dim) * 0.1).astype(np.float32), 0
+    return self._obs(self._x)
+
+  def _dynamics(self, x, a, rs):
+    x2 = self._A @ x + self._Bm @ a + (rs.standard_normal(self.obs_dim) * 0.01).astype(np.float32)
+    reward = float(self._w @ x2 - 0.05 * float(a @ a) + 1.0)
+    done = bool(self.can_terminate and abs(float(x2[0])) > 1.5)
+    return x2.astype(np.float32), reward, done
+
+  def step(self, action: Tensor) -> Tuple[Tensor, float, bool]:
+    a = action.detach().to('cpu', torch.float32).clamp(-1, 1)[0].numpy()
+    self._x, reward, done = self._dynamics(self._x, a, self._rs)
+    self._t += 1
+    return self._obs(self._x), reward, done or self._t >= self.max_episode_steps
+
+  def render(self): pass
+  def close(self): pass
+
+  # --- synthetic "D4RL" dataset in the raw D4RL format (flat arrays + terminals/timeouts flags)
+  def _make_dataset(self):
+    rs = np.random.RandomState(12345)
+    obs, act, nxt, term, tout = [], [], [], [], []
+    for _ in range(self._dataset_trajectories):
+      x = (rs.standard_normal(self.obs_dim) * 0.1).astype(np.float32)
+      for t in range(self.max_episode_steps):
+        a = np.tanh(self._K @ x + rs.standard_normal(self.act_dim).astype(np.float32) * 0.05).astype(np.float32)
+        x2, _, done = self._dynamics(x, a, rs)
+        last = t == self.max_episode_steps - 1
+        obs.append(x); act.append(a); nxt.append(x2); term.append(float(done)); tout.append(float(last and not done))
+        x = x2
+        if done or last:
+          break
+    f = lambda v: torch.tensor(np.asarray(v), dtype=torch.float32)
+    return dict(observations=f(obs), actions=f(act), next_observations=f(nxt), terminals=f(term), timeouts=f(tout))
+
+  def get_dataset(self, trajectories: int = 0, subsample: int = 1, device=None) -> ReplayMemory:
+    """Reference environments.py:63-125 on the synthetic rollouts (vectorised per trajectory)."""
+    d = self.dataset
+    states, actions, next_states, terminals, timeouts = d['observations'], d['actions'], d['next_observations'], d['terminals'], d['timeouts']
+    S, A = states.size(1), actions.size(1)
+    ends = torch.sort(torch.cat([terminals.nonzero().flatten(), timeouts.nonzero().flatten()]))[0].tolist()
+    starts = [0] + [e + 1 for e in ends[:-1]]
+    if trajectories > 0:
+      starts, ends = starts[:trajectories], ends[:trajectories]
+    out = {k: [] for k in ('states', 'actions', 'next_states', 'terminals', 'timeouts', 'weights')}
+    for s0, e0 in zip(starts, ends):
+      sl = slice(s0, e0 + 1)
+      st, ac, nx, te, to = states[sl], actions[sl], next_states[sl], terminals[sl].clone(), timeouts[sl]
+      w = torch.ones_like(te)
+      if self.absorbing:
+        st, nx = torch.cat([st, torch.zeros(st.size(0), 1)], 1), torch.cat([nx, torch.zeros(nx.size(0), 1)], 1)
+        if not to[-1]:  # true termination: rewrite the last next-state to the absorbing state and append absorbing -> absorbing
+          absorbing_state = torch.cat([torch.zeros(1, S), torch.ones(1, 1)], 1)
+          nx[-1], te[-1], w[-1] = absorbing_state[0], 0, 1 / subsample
+          st, ac, nx = torch.cat([st, absorbing_state]), torch.cat([ac, torch.zeros(1, A)]), torch.cat([nx, absorbing_state])
+          te, to, w = torch.cat([te, torch.zeros(1)]), torch.cat([to, torch.zeros(1)]), torch.cat([w, torch.full((1,), 1 / subsample)])
+      if subsample > 1:
+        T = st.size(0)
+        idxs = set(range(index_stream().randint(subsample), T, subsample))  # np.random.choice(subsample) in the reference: same stream
+        if self.absorbing: idxs |= {T - 2, T - 1}
+        idxs = sorted(idxs)
+        st, ac, nx, te, to, w = st[idxs], ac[idxs], nx[idxs], te[idxs], to[idxs], w[idxs]
+      for k, v in zip(out, (st, ac, nx, te, to, w)):
+        out[k].append(v)
+    tr = {k: torch.cat(v) for k, v in out.items()}
+    tr['num_trajectories'], tr['rewards'] = len(starts), torch.zeros_like(tr['terminals'])
+    return ReplayMemory(tr['states'].size(0), S + (1 if self.absorbing else 0), A, self.absorbing, transitions=tr, device=device)
+
+
+def make_env(env_name: str, absorbing: bool, load_data: bool = False, **kw):
+  """Real D4RL when importable, otherwise the synthetic stand-in (this environment)."""
+  try:
+    import d4rl  # noqa: F401
+    import gym  # noqa: F401
+  except Exception:
+    return SyntheticD4RLEnv(env_name, absorbing, load_data, **kw)
+  raise NotImplementedError('gym + d4rl detected: wrap gym.make(f"{env_name}-expert-v2") behind this interface (environments.py:21-61 of the reference)')
+
+
+D4RLEnv = make_env

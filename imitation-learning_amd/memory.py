@@ -35,6 +35,12 @@ class IndexStream:
     _lib.check(_lib.lib().il_mt19937_sample_indices(self.state, n, size, idx, int(full), C.cast(out.data_ptr(), _lib.c_i32p)))
     return out
 
+  def randint(self, high: int) -> int:
+    """`np.random.randint(0, high)` / `np.random.choice(high)` from the same stream."""
+    out = (C.c_int32 * 1)()
+    _lib.check(_lib.lib().il_mt19937_randint(self.state, high, 1, out))
+    return int(out[0])
+
   # device-resident copy of the same stream (moved once; afterwards the device state is the master)
   def device_state(self, device) -> Tensor:
     if self._dev is None:

@@ -86,6 +86,8 @@ int il_replay_gather(const float* ring, int64_t capacity, int32_t row_floats, co
  * reference's rejection of slot (idx-1) % size.  HOST function; state_host = 625 uint32 (624 words + position). */
 int il_mt19937_seed(uint32_t* state_host, uint32_t seed);
 int il_mt19937_sample_indices(uint32_t* state_host, int32_t n, int64_t size, int64_t idx, int32_t full, int32_t* out_host);
+/* n plain `np.random.randint(0, high)` draws from the same stream (reference environments.py:113 consumes it for subsampling offsets). */
+int il_mt19937_randint(uint32_t* state_host, int64_t high, int32_t n, int32_t* out_host);
 /* Same stream, generated ON the device (state_dev = 625 uint32 in HBM) so a captured update needs no H2D copy.
  * ring_state_dev = {int64 idx, int64 full, int64 size}. */
 int il_mt19937_sample_indices_device(uint32_t* state_dev, const int64_t* ring_state_dev, int32_t n, int32_t* out_dev, il_stream_t stream);

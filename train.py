@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Entry point with the reference's command line:  python train.py algorithm=<ALG> env=<ENV> [key.sub=value ...]
+
+Drives the loop of reference train.py:26-243 (act -> store -> [update block] -> evaluate -> save) on the MI355X path:
+the update block (train.py:171-203) is `UpdatePlan` (one captured hipGraph per step for SAC / GAIL) or the per-function HIP entry
+points (GMMIL, PWIL, mixed batches, BC auxiliary loss).  Hydra is replaced by `imitation_learning_amd.config.compose`
+(same keys, same precedence).  Supported on the HIP path: SAC, GAIL (BCE loss), GMMIL, PWIL, BC; AdRIL / DRIL / RED raise.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import imitation_learning_amd as il  # noqa: E402
+from imitation_learning_amd import config as il_config  # noqa: E402
+from imitation_learning_amd.environments import make_env  # noqa: E402
+from imitation_learning_amd.evaluation import evaluate_agent  # noqa: E402
+from imitation_learning_amd.models import default_device  # noqa: E402
+from imitation_learning_amd.utils import cycle, lineplot  # noqa: E402
+
+
+def train(cfg, file_prefix: str = '') -> float:
+  il_config.validate(cfg)
+  if cfg.algorithm in ('AdRIL', 'DRIL', 'RED'):
+    raise NotImplementedError(f'algorithm={cfg.algorithm} is outside the MI355X hot path of this round (SURVEY.md §8f-4); supported: SAC, GAIL, GMMIL, PWIL, BC')
+  dev = default_device()
+  assert dev.type == 'cuda', 'train.py needs a GPU: the update path has no CPU fallback'
+  il.seed(cfg.seed)               # replay index stream (np.random.seed in the reference, train.py:51)
+  np.random.seed(cfg.seed)
+  torch.manual_seed(cfg.seed)
+
+  env_kw = dict(cfg.get('synthetic_env', {}) or {})
+  env, eval_env = make_env(cfg.env, cfg.imitation.absorbing, load_data=True, **env_kw), make_env(cfg.env, cfg.imitation.absorbing, **env_kw)
+  env.seed(cfg.seed); eval_env.seed(cfg.seed)
+  normalization_max, normalization_min = env.env.ref_max_score, env.env.ref_min_score
+  expert_memory = env.get_dataset(trajectories=cfg.imitation.trajectories, subsample=cfg.imitation.subsample, device=dev)
+  state_size, action_size = env.observation_space.shape[0], env.action_space.shape[0]
+
+  actor, critic, log_alpha = il.SoftActor(state_size, action_size, cfg.reinforcement.actor), il.TwinCritic(state_size, action_size, cfg.reinforcement.critic), torch.zeros(1, device=dev)
+  target_critic, entropy_target = il.create_target_network(critic), cfg.reinforcement.target_temperature * action_size
+  actor_optimiser = il.AdamW(actor, lr=cfg.training.learning_rate, weight_decay=cfg.training.weight_decay)
+  critic_optimiser = il.AdamW(critic, lr=cfg.training.learning_rate, weight_decay=cfg.training.weight_decay)
+  temperature_optimiser = il.Adam(log_alpha, lr=cfg.training.learning_rate)
+  memory = il.ReplayMemory(cfg.memory.size, state_size, action_size, cfg.imitation.absorbing)
+
+  discriminator = discriminator_optimiser = None
+  if cfg.algorithm == 'GAIL':
+    discriminator = il.GAILDiscriminator(state_size, action_size, cfg.imitation, cfg.reinforcement.discount)
+    discriminator_optimiser = il.AdamW(discriminator, lr=cfg.imitation.learning_rate, weight_decay=cfg.imitation.weight_decay)
+  elif cfg.algorithm == 'GMMIL':
+    discriminator = il.GMMILDiscriminator(state_size, action_size, cfg.imitation)
+  elif cfg.algorithm == 'PWIL':
+    discriminator = il.PWILDiscriminator(state_size, action_size, cfg.imitation, expert_memory, env.max_episode_steps)
+
+  metrics = dict(train_steps=[], train_returns=[], test_steps=[], test_returns=[], test_returns_normalized=[], update_steps=[], predicted_rewards=[], alphas=[], entropies=[], Q_values=[])
+  score = []
+  if cfg.check_time_usage: start_time = time.time()
+  B = cfg.training.batch_size
+
+  # ---- behavioural cloning pretraining (train.py:93-112)
+  if cfg.bc_pretraining.iterations > 0:
+    pretrain_optimiser = il.AdamW(actor, lr=cfg.bc_pretraining.learning_rate, weight_decay=cfg.bc_pretraining.weight_decay)
+    n = expert_memory.size
+    perm_gen = torch.Generator().manual_seed(cfg.seed)
+    it = 0
+    while it < cfg.bc_pretraining.iterations:  # DataLoader(shuffle=True, drop_last=True) epochs
+      perm = torch.randperm(n, generator=perm_gen)
+      for s in range(0, n - B + 1, B):
+        batch = il.memory.batch_views(expert_memory.gather(perm[s:s + B].to(torch.int32)), state_size, action_size, cfg.imitation.absorbing)
+        il.behavioural_cloning_update(actor, batch, pretrain_optimiser)
+        it += 1
+        if it >= cfg.bc_pretraining.iterations: break
+    if cfg.algorithm == 'BC':
+      if cfg.check_time_usage: metrics['pre_training_time'] = time.time() - start_time
+      test_returns = evaluate_agent(actor, eval_env, cfg.evaluation.episodes)
+      test_returns_normalized = (np.array(test_returns) - normalization_min) / (normalization_max - normalization_min)
+      metrics['test_steps'], metrics['test_returns'], metrics['test_returns_normalized'] = [0], [test_returns], [list(test_returns_normalized)]
+      torch.save(dict(actor=actor.state_dict()), f'{file_prefix}agent.pth')
+      torch.save(metrics, f'{file_prefix}metrics.pth')
+      return float(np.mean(test_returns_normalized))
+
+  if cfg.algorithm == 'PWIL' and cfg.imitation.mix_expert_data != 'none':  # train.py:135-141
+    for i in range(expert_memory.size):
+      tr = expert_memory[i]
+      expert_memory.rewards[i] = discriminator.compute_reward(tr['states'].unsqueeze(0), tr['actions'].unsqueeze(0))
+      if tr['terminals'] or tr['timeouts']: discriminator.reset()
+  if cfg.algorithm in ('PWIL', 'GMMIL') and cfg.imitation.mix_expert_data == 'prefill_memory':
+    memory.transfer_transitions(expert_memory)
+
+  # ---- the update block as a captured graph when nothing host-side sits inside it
+  plan = None
+  fusable = cfg.algorithm in ('SAC', 'GAIL') and cfg.imitation.mix_expert_data == 'none' and not cfg.imitation.bc_aux_loss and B % 16 == 0
+  if fusable:
+    plan = il.UpdatePlan(cfg.algorithm, actor, critic, log_alpha, target_critic, memory, actor_optimiser, critic_optimiser, temperature_optimiser, B, cfg.reinforcement.discount,
+                         entropy_target, cfg.reinforcement.polyak_factor, expert_memory=expert_memory, discriminator=discriminator, discriminator_optimiser=discriminator_optimiser,
+                         imitation_cfg=cfg.imitation if cfg.algorithm == 'GAIL' else None)
+  captured = False
+
+  t, state, terminal, train_return = 0, env.reset(), False, 0
+  for step in range(1, cfg.steps + 1):
+    with torch.inference_mode():
+      action = actor(state).sample()
+      next_state, reward, terminal = env.step(action)
+      t += 1
+      train_return += reward
+      if cfg.algorithm == 'PWIL': reward = discriminator.compute_reward(state, action)
+      memory.append(step, state, action, reward, next_state, terminal and t != env.max_episode_steps, t == env.max_episode_steps)
+      state = next_state
+    if terminal:
+      if cfg.imitation.absorbing and t != env.max_episode_steps: memory.wrap_for_absorbing_states()
+      if cfg.algorithm == 'PWIL': discriminator.reset()
+      metrics['train_steps'].append(step); metrics['train_returns'].append([train_return])
+      t, state, train_return = 0, env.reset(), 0
+
+    if step >= cfg.training.start and step % cfg.training.interval == 0:
+      if plan is not None:
+        if not captured:
+          plan.run(); plan.capture(warmup=0); captured = True   # first update eagerly (loads code objects), then capture
+        else:
+          plan.replay()
+        rewards, log_probs, Q_values = plan.transitions['rewards'], plan.logp, plan.q
+      else:
+        transitions, expert_transitions = memory.sample(B), expert_memory.sample(B)
+        if cfg.algorithm == 'GAIL':
+          discriminator.train()
+          il.adversarial_imitation_update(actor, discriminator, transitions, expert_transitions, discriminator_optimiser, cfg.imitation)
+          discriminator.eval()
+        if cfg.imitation.mix_expert_data == 'mixed_batch': il.mix_expert_agent_transitions(transitions, expert_transitions)
+        if cfg.algorithm == 'GAIL':
+          transitions['rewards'] = discriminator.predict_reward(transitions['states'], transitions['actions'])
+        elif cfg.algorithm == 'GMMIL':
+          transitions['rewards'] = discriminator.predict_reward(transitions['states'], transitions['actions'], expert_transitions['states'], expert_transitions['actions'],
+                                                                transitions['weights'].contiguous(), expert_transitions['weights'].contiguous())
+        if cfg.imitation.bc_aux_loss: il.behavioural_cloning_update(actor, expert_transitions, actor_optimiser)
+        log_probs, Q_values = il.sac_update(actor, critic, log_alpha, target_critic, transitions, actor_optimiser, critic_optimiser, temperature_optimiser, cfg.reinforcement.discount,
+                                            entropy_target, cfg.reinforcement.polyak_factor)
+        rewards = transitions['rewards']
+      if cfg.logging.interval > 0 and step % cfg.logging.interval == 0:  # the only D2H reads of the update path (train.py:205-210)
+        metrics['update_steps'].append(step); metrics['predicted_rewards'].append(rewards.cpu().numpy())
+        metrics['alphas'].append(log_alpha.exp().cpu().numpy()); metrics['entropies'].append((-log_probs).cpu().numpy()); metrics['Q_values'].append(Q_values.cpu().numpy())
+
+    if step % cfg.evaluation.interval == 0 and not cfg.check_time_usage:
+      test_returns = evaluate_agent(actor, eval_env, cfg.evaluation.episodes)
+      test_returns_normalized = (np.array(test_returns) - normalization_min) / (normalization_max - normalization_min)
+      score.append(np.mean(test_returns_normalized))
+      metrics['test_steps'].append(step); metrics['test_returns'].append(test_returns); metrics['test_returns_normalized'].append(list(test_returns_normalized))
+      lineplot(metrics['test_steps'], metrics['test_returns'], filename=f'{file_prefix}test_returns', title=f'{cfg.algorithm}: {cfg.env} Test Returns')
+
+  if cfg.check_time_usage: metrics['training_time'] = time.time() - start_time
+  torch.save(dict(actor=actor.state_dict(), critic=critic.state_dict(), log_alpha=log_alpha), f'{file_prefix}agent.pth')
+  if cfg.algorithm == 'GAIL': torch.save(discriminator.state_dict(), f'{file_prefix}discriminator.pth')
+  torch.save(metrics, f'{file_prefix}metrics.pth')
+  return float(np.mean(score)) if score else float('nan')
+
+
+def main(argv):
+  cfg = il_config.compose(argv)
+  out = os.path.join('outputs', f'{cfg.algorithm}_{cfg.env}', time.strftime('%m-%d_%H-%M-%S'))
+  os.makedirs(out, exist_ok=True)
+  os.chdir(out)  # hydra.job.chdir=true in the reference
+  score = train(cfg)
+  print(f'{cfg.algorithm} {cfg.env}: mean normalised score {score:.4f} (outputs in {out})')
+  return score
+
+
+if __name__ == '__main__':
+  main(sys.argv[1:])
