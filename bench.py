@@ -224,6 +224,15 @@ def main():
     else:
       ach = bytes_k.get(dom, 0) / (kern[dom]['avg_us'] * 1e-6) / 1e9
       roof = dict(bound='hbm', kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 5), traffic=None)
+    try:  # HBM-side bytes per launch from the committed PMC passes (profiles/pmc_latest.json; collected with rocprofv3 --pmc, not in this run)
+      pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')))['kernels']
+      key = 'k_dw_adam' if dom.startswith('k_dw_adam') else dom
+      roof['traffic'] = pmc.get(key, {}).get('traffic_bytes')
+      for k, e in per_kernel.items():
+        kk = 'k_dw_adam' if k.startswith('k_dw_adam') else k
+        if kk in pmc: e['hbm_traffic_bytes'] = pmc[kk]['traffic_bytes']
+    except Exception:
+      pass
     upd_gbs = update_bytes / (ms_per_step * 1e-3) / 1e9
     roof['update'] = dict(algorithmic_bytes=update_bytes, achieved_GBps=round(upd_gbs, 2), hbm_frac=round(upd_gbs / HBM_PEAK_GBS, 5), algorithmic_flops=update_flops,
                           fp32_frac=round(update_flops / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5),
