@@ -159,7 +159,7 @@ def main():
 
   plan, nets, (tr, et) = build(device, rank)
   runner = plan
-  if world > 1:
+  if world > 1 or os.environ.get('IL_FORCE_DP') == '1':  # IL_FORCE_DP=1: the split grads-only / all-reduce / apply path on a single rank
     broadcast_parameters([n.flat if hasattr(n, 'flat') else n for n in nets] + [nets[4].sn])
     runner = DataParallelUpdate(plan)
   for _ in range(5):
@@ -242,7 +242,7 @@ def main():
                ms_per_step=round(ms_per_step, 5), higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                config=dict(workload='algorithm=GAIL env=halfcheetah: 2 replay samples + discriminator step (BCE+GP+SN) + AIRL relabel + sac_update per step',
                            batch_per_gpu=B, global_batch=B * world, state_dim=S, action_dim=A, hidden=H, replay_capacity=1_000_000, replay_fill=100_000, expert_rows=25_000,
-                           parallelism=f'dp{world}', launch='eager' if args.no_graph else 'hipGraph replay', noise='on-chip Philox4x32-10', finite=finite),
+                           parallelism=f'dp{world}' + ('(split path)' if runner is not plan else ''), launch='eager' if args.no_graph else 'hipGraph replay', noise='on-chip Philox4x32-10', finite=finite),
                roofline=roof)
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(tr, et)

@@ -356,3 +356,31 @@ def test_update_plan_host_and_device_index_draws_agree():
     outs.append((N(plan.idx), N(plan.eidx), N(nets[0].flat)))
   for a, b in zip(*outs):
     np.testing.assert_array_equal(a, b)
+
+
+def test_data_parallel_path_equals_fused_path_on_one_rank():
+  """DataParallelUpdate (IL_FLAG_GRADS_ONLY kernels -> [all-reduce] -> apply kernels) must evolve a learner like the fused UpdatePlan:
+  with one rank the all-reduce is the identity, so any difference would be a bug in the split path the multi-GPU run uses."""
+  from imitation_learning_amd.parallel import DataParallelUpdate
+  outs = []
+  for dp in (False, True):
+    il.seed(21)
+    il_training._NOISE.clear()
+    plan, nets = _make_plan('GAIL', 13)
+    runner = DataParallelUpdate(plan) if dp else plan
+    for _ in range(4):
+      runner.run()
+    torch.cuda.synchronize()
+    outs.append([N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [N(plan.logp), N(plan.q), N(plan.rewards)])
+  for i, (a, b) in enumerate(zip(*outs)):
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    np.testing.assert_array_equal(a, b, err_msg=f'tensor {i}')
+  # and the captured DP graph replays like its eager form
+  il.seed(21); il_training._NOISE.clear()
+  plan, nets = _make_plan('GAIL', 13)
+  dp = DataParallelUpdate(plan).capture(warmup=0)
+  for _ in range(4):
+    dp.replay()
+  torch.cuda.synchronize()
+  for a, n in zip(outs[1], nets):
+    np.testing.assert_array_equal(a, N(n.flat if hasattr(n, 'flat') else n))
