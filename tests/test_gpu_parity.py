@@ -384,3 +384,79 @@ def test_data_parallel_path_equals_fused_path_on_one_rank():
   torch.cuda.synchronize()
   for a, n in zip(outs[1], nets):
     np.testing.assert_array_equal(a, N(n.flat if hasattr(n, 'flat') else n))
+
+
+# ------------------------------------------------------------------------------------------------ size-independent properties / edge cases
+def test_sac_gradient_of_concatenated_batch_is_mean_of_shard_gradients():
+  """BASELINE size (B=256 per shard, HalfCheetah dims): the data-parallel identity on the real kernels -- gradients from
+  IL_FLAG_GRADS_ONLY on two 256-row shards average to the gradient on the 512-row concatenation (every loss is a mean)."""
+  c = gi.sac_case(41, 'halfcheetah', 256, 512, 1)
+  big = c['batches'][0]
+  grads = {}
+  for name, sl in (('all', slice(0, 512)), ('lo', slice(0, 256)), ('hi', slice(256, 512))):
+    actor, critic, target, log_alpha, ao, co, to = make_sac(c)
+    tb = tbatch({k: v[sl] for k, v in big.items()})
+    n = tb['states'].size(0)
+    d = il_training.sac_descriptor(actor, critic, log_alpha, target, n, ao, co, to, c['discount'], c['entropy_target'], c['polyak'])
+    bd = il_memory.batch_desc(tb)
+    e1 = T(c['eps_next'][0][sl])
+    _lib.check(_lib.lib().il_sac_critic_step(C.byref(d), C.byref(bd), _lib.ptr(e1), _lib.IL_FLAG_GRADS_ONLY, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    grads[name] = N(co.grad)
+  mean = 0.5 * (grads['lo'] + grads['hi'])
+  close(mean, grads['all'], 'critic grad: mean of shards vs concatenated batch', atol_scale=4e-6)
+
+
+@pytest.mark.parametrize('env,hidden,batch', [('halfcheetah', 128, 1024), ('walker2d', 192, 48), ('hopper', 256, 16)])
+def test_sac_update_other_shapes(env, hidden, batch):
+  """Largest tuned batch (1024), the smallest legal batch (one 16-row tile) and non-power-of-two hidden sizes, one update vs the oracle."""
+  c = gi.sac_case(50 + batch, env, hidden, batch, 1)
+  actor, critic, target, log_alpha, ao, co, to = make_sac(c)
+  st = make_sac_oracle(c)
+  b = c['batches'][0]
+  logp, q = il.sac_update(actor, critic, log_alpha, target, tbatch(b), ao, co, to, c['discount'], c['entropy_target'], c['polyak'], eps_next=T(c['eps_next'][0]), eps_cur=T(c['eps_cur'][0]))
+  ologp, oq = osac.sac_update(st, b, c['eps_next'][0], c['eps_cur'][0], discount=c['discount'], entropy_target=c['entropy_target'], polyak_factor=c['polyak'], lr=c['lr'])
+  close(N(logp), ologp, 'logp', atol_scale=4e-6); close(N(q), oq, 'q', atol_scale=4e-6)
+  close_params(N(actor.flat), st.actor, 'actor', c['lr']); close_params(crit_from_flat(critic, critic.flat), st.critic, 'critic', c['lr'])
+  close_params(crit_from_flat(critic, target.flat), st.target, 'target', c['lr']); close(N(log_alpha), st.log_alpha, 'log_alpha')
+
+
+def test_unsupported_shapes_and_options_fail_loudly():
+  with pytest.raises(NotImplementedError):
+    il.SoftActor(18, 6, Cfg(hidden_size=256, depth=3, activation='relu'))
+  with pytest.raises(NotImplementedError):
+    il.SoftActor(18, 6, Cfg(hidden_size=100, depth=2, activation='relu'))
+  with pytest.raises(NotImplementedError):
+    il.TwinCritic(18, 6, Cfg(hidden_size=256, depth=2, activation='tanh'))
+  c = gi.sac_case(3, 'halfcheetah', 256, 24, 1)   # batch not a multiple of the 16-row tile
+  actor, critic, target, log_alpha, ao, co, to = make_sac(c)
+  with pytest.raises(RuntimeError, match='multiple of 16'):
+    il.sac_update(actor, critic, log_alpha, target, tbatch(c['batches'][0]), ao, co, to, 0.99, -6.0, 0.995)
+  g = gi.gail_case(31)
+  d, _, icfg = make_disc(g)
+  icfg.update(loss_function='Mixup', grad_penalty=1.0, entropy_bonus=0.0)
+  with pytest.raises(NotImplementedError, match='Mixup'):
+    il.adversarial_imitation_update(None, d, tbatch(g['policy'][0]), tbatch(g['expert'][0]), il.AdamW(d, lr=3e-5, weight_decay=10), icfg)
+  with pytest.raises(TypeError):
+    il.sac_update(actor, critic, log_alpha, target, {k: v.cpu() for k, v in tbatch(gi.sac_case(3, 'halfcheetah', 256, 32, 1)['batches'][0]).items()}, ao, co, to, 0.99, -6.0, 0.995)
+
+
+def test_gail_ragged_batch_and_state_only():
+  """Discriminator kernels accept a batch that is not a multiple of the 16-row tile (last tile ragged) and the state_only variant."""
+  g = gi.gail_case(61, env='hopper', hidden=64, batch=40, steps=1)
+  for state_only in (False, True):
+    icfg = Cfg(state_only=state_only, spectral_norm=True, loss_function='BCE', grad_penalty=0.5, entropy_bonus=0.01,
+               discriminator=Cfg(hidden_size=64, depth=1, activation='relu', reward_shaping=False, subtract_log_policy=False, reward_function='AIRL'))
+    d = il.GAILDiscriminator(g['S'], g['A'], icfg, 0.97, device=DEV)
+    D = g['S'] if state_only else g['D']
+    ods = ogail.DiscState(D, 64, True)
+    ods.unpack_into(N(d.flat)); v = d.views()
+    for k in ('u1', 'v1', 'u2', 'v2'):
+      getattr(ods, k)[...] = N(v[k])
+    opt = il.AdamW(d, lr=1e-4, weight_decay=1.0)
+    pb, eb = g['policy'][0], g['expert'][0]
+    cat = (lambda b: b['states']) if state_only else (lambda b: np.concatenate([b['states'], b['actions']], axis=1))
+    il.adversarial_imitation_update(None, d, tbatch(pb), tbatch(eb), opt, icfg, eps_gp=T(g['eps'][0]))
+    ogr = ogail.gail_update(ods, cat(pb), pb['weights'], cat(eb), eb['weights'], g['eps'][0], lr=1e-4, weight_decay=1.0, grad_penalty=0.5, entropy_bonus=0.01, return_grads=True)
+    close(N(opt.grad), ogr, f'disc grad (state_only={state_only})', atol_scale=4e-6); close(N(d.flat), ods.pack(), f'disc params (state_only={state_only})', atol_scale=4e-6)
+    close(N(d.predict_reward(T(pb['states']), T(pb['actions']))), ogail.predict_reward(ods, cat(pb)), 'reward', rtol=1e-4, atol_scale=1e-5)
