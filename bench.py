@@ -55,7 +55,7 @@ def algorithmic_model():
   return bytes_k, flops_k, update_bytes, sum(flops_k.values())
 
 
-def build(device, rank, seed=0):
+def build(device, rank, seed=0, learner_id=None):
   import imitation_learning_amd as il
   torch.manual_seed(seed)
   cfg = Cfg(hidden_size=H, depth=2, activation='relu')
@@ -77,9 +77,12 @@ def build(device, rank, seed=0):
   mem._sync_ring_state()
   et = synthetic_transitions(np.random.RandomState(77), 25_000, state_shift=0.5)  # full copy of the expert buffer on every rank
   emem = il.ReplayMemory(25_000, S, A, True, transitions={**{k: torch.from_numpy(v) for k, v in et.items() if k != 'absorbing'}, 'num_trajectories': 25}, device=device)
-  il.seed(seed + rank)
+  if learner_id is None:
+    il.seed(seed + rank)
+  else:
+    mem.index_rng = il.IndexStream(seed + rank)   # each learner of a population draws from its own MT19937 stream
   plan = il.UpdatePlan('GAIL', actor, critic, log_alpha, target, mem, ao, co, to, B, 0.97, -0.5 * A, 0.99, expert_memory=emem, discriminator=disc, discriminator_optimiser=do,
-                       imitation_cfg=icfg)
+                       imitation_cfg=icfg, learner_id=learner_id)
   return plan, (actor, critic, target, log_alpha, disc), (tr, et)
 
 
@@ -143,6 +146,7 @@ def main():
   ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--trace-steps', type=int, default=100)
+  ap.add_argument('--learners', type=int, default=1, help='population axis: N independent learners per GPU advanced by one graph replay (aggregate updates/s)')
   args = ap.parse_args()
 
   world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
@@ -157,8 +161,13 @@ def main():
   from imitation_learning_amd import _lib
   from imitation_learning_amd.parallel import DataParallelUpdate, broadcast_parameters
 
-  plan, nets, (tr, et) = build(device, rank)
+  plan, nets, (tr, et) = build(device, rank, learner_id=0 if args.learners > 1 else None)
   runner = plan
+  if args.learners > 1:
+    from imitation_learning_amd import PopulationPlan
+    assert world == 1, 'the population axis is a single-GPU mode'
+    plans = [plan] + [build(device, rank, seed=l, learner_id=l)[0] for l in range(1, args.learners)]
+    runner = PopulationPlan(plans)
   if world > 1 or os.environ.get('IL_FORCE_DP') == '1':  # IL_FORCE_DP=1: the split grads-only / all-reduce / apply path on a single rank
     broadcast_parameters([n.flat if hasattr(n, 'flat') else n for n in nets] + [nets[4].sn])
     runner = DataParallelUpdate(plan)
@@ -196,7 +205,7 @@ def main():
   if rank == 0:
     bytes_k, flops_k, update_bytes, update_flops = algorithmic_model()
     ms_per_step = elapsed / args.steps * 1e3
-    ups = world * args.steps / elapsed
+    ups = world * args.learners * args.steps / elapsed
     # ---- per-kernel durations, HIP events on the launch stream, eager launches of the very same kernels
     L = _lib.lib()
     L.il_trace_enable(1)
@@ -242,7 +251,7 @@ def main():
                ms_per_step=round(ms_per_step, 5), higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                config=dict(workload='algorithm=GAIL env=halfcheetah: 2 replay samples + discriminator step (BCE+GP+SN) + AIRL relabel + sac_update per step',
                            batch_per_gpu=B, global_batch=B * world, state_dim=S, action_dim=A, hidden=H, replay_capacity=1_000_000, replay_fill=100_000, expert_rows=25_000,
-                           parallelism=f'dp{world}' + ('(split path)' if runner is not plan else ''), launch='eager' if args.no_graph else 'hipGraph replay', noise='on-chip Philox4x32-10', finite=finite),
+                           learners_per_gpu=args.learners, parallelism=f'dp{world}' + ('(split path)' if runner is not plan else ''), launch='eager' if args.no_graph else 'hipGraph replay', noise='on-chip Philox4x32-10', finite=finite),
                roofline=roof)
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(tr, et)

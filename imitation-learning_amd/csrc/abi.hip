@@ -68,3 +68,4 @@ extern "C" int il_trace_report(char* buf_host, int len) {
   g_trace_n = 0;
   return IL_OK;
 }
+

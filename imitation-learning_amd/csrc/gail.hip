@@ -92,8 +92,58 @@ __device__ __forceinline__ void sn_wave(const float* W1s, const float* W2s, int 
   WAVE_SYNC();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Spectral norm of call `c` (0-based): the reference runs c+1 chained power iterations u <- n(W v), v <- n(W^T u) before that call.
+// v only ever sees M = W^T W:  v_{i+1} = n(M v_i)  (the 1/||W v|| factor cancels in the normalisation), so the chain runs on the
+// small [D x D] Gram matrix (built once per workgroup by all threads) and only the LAST u is formed: u_c = n(W v_c'), v_c' = v after
+// c iterations, sigma_c = u_c . (W v_{c+1}).  Layer 2 (W2 is [1 x H]) is a fixed point after its first iteration: one is enough.
+// Same numbers as the reference's sequence up to fp32 rounding of the re-associated products.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sn_gram(const float* W1s, float* Ms, int D, int Dp, int H, int ldw) {  // all threads; Ms [Dp][Dp]
+  for (int e = threadIdx.x; e < Dp * Dp; e += blockDim.x) {
+    const int a = e / Dp, b = e - a * Dp;
+    float s0 = 0.f, s1 = 0.f;
+    for (int n = 0; n < H; n += 2) { s0 += W1s[n * ldw + a] * W1s[n * ldw + b]; s1 += W1s[(n + 1) * ldw + a] * W1s[(n + 1) * ldw + b]; }
+    Ms[e] = s0 + s1;
+  }
+}
+// one wave; n_iter >= 1 chained iterations starting from (v1, v2); outputs u1, v1, v2, sig = {sigma1, sigma2, u2}
+__device__ __forceinline__ void sn_chain(const float* W1s, const float* W2s, const float* Ms, int D, int H, float* u1, float* v1, float* v2, float* tmp, int n_iter, float* sig) {
+  const int lane = threadIdx.x & 63, Dp = (D + 3) & ~3, ldw = Dp + 4;
+  for (int it = 0; it < n_iter; ++it) {
+    if (it == n_iter - 1) {  // the u of the last iteration: u = n(W v)
+      float ss = 0.f;
+      for (int n = lane; n < H; n += 64) { const float s = dot4(W1s + n * ldw, v1, Dp); u1[n] = s; ss += s * s; }
+      const float inv = wave_norm_scale(ss);
+      for (int n = lane; n < H; n += 64) u1[n] *= inv;
+    }
+    float ss = 0.f;
+    for (int k = lane; k < Dp; k += 64) { const float s = k < D ? dot4(Ms + k * Dp, v1, Dp) : 0.f; tmp[k] = s; ss += s * s; }
+    const float inv = wave_norm_scale(ss);
+    WAVE_SYNC();
+    for (int k = lane; k < Dp; k += 64) v1[k] = tmp[k] * inv;
+    WAVE_SYNC();
+  }
+  // layer 2: p = W2 . v2 ; u2 = p/|p| ; v2 = n(W2^T u2)
+  float p = 0.f;
+  for (int n = lane; n < H; n += 64) p += W2s[n] * v2[n];
+  p = wave_sum(p);
+  const float uu = p / fmaxf(fabsf(p), 1e-12f);
+  float ss = 0.f;
+  for (int n = lane; n < H; n += 64) { const float s = W2s[n] * uu; tmp[n] = s; ss += s * s; }
+  const float inv2 = wave_norm_scale(ss);
+  WAVE_SYNC();
+  for (int n = lane; n < H; n += 64) v2[n] = tmp[n] * inv2;
+  WAVE_SYNC();
+  float a = 0.f, b = 0.f;
+  for (int n = lane; n < H; n += 64) { a += u1[n] * dot4(W1s + n * ldw, v1, Dp); b += W2s[n] * v2[n]; }
+  a = wave_sum(a); b = wave_sum(b);
+  if (lane == 0) { sig[0] = a; sig[1] = uu * b; sig[2] = uu; }
+  WAVE_SYNC();
+}
+
 struct DiscLds {  // per-pass arrays are contiguous and addressed arithmetically (pointer arrays indexed at run time would go to scratch)
-  float *W1s, *b1s, *W2s, *Xb, *wtb, *hs, *dhs, *ts, *cg, *snb, *zs, *dzs, *red;
+  float *W1s, *b1s, *W2s, *Xb, *wtb, *hs, *dhs, *ts, *cg, *snb, *zs, *dzs, *red, *Ms, *tmp;
   int D, H, Dp;  // Dp = D rounded up to 4 (rows of X / cg / v1 are zero-padded so dot products run on 16-byte lanes)
   __device__ __forceinline__ float* X(int c) const { return Xb + c * IL_TILE_R * Dp; }
   __device__ __forceinline__ float* wt(int c) const { return wtb + c * IL_TILE_R; }
@@ -104,7 +154,8 @@ struct DiscLds {  // per-pass arrays are contiguous and addressed arithmetically
 };
 __host__ __device__ inline size_t disc_lds_floats(int D, int H) {
   const int Dp = (D + 3) & ~3;
-  return (size_t)H * (Dp + 4) + 2 * H + 3 * (size_t)IL_TILE_R * Dp + 3 * IL_TILE_R + 3 * (size_t)IL_TILE_R * H + (size_t)IL_TILE_R * Dp + 3 * (size_t)(2 * H + Dp + 4) + 2 * IL_TILE_R + 64;
+  return (size_t)H * (Dp + 4) + 2 * H + 3 * (size_t)IL_TILE_R * Dp + 3 * IL_TILE_R + 3 * (size_t)IL_TILE_R * H + (size_t)IL_TILE_R * Dp + 3 * (size_t)(2 * H + Dp + 4) + 2 * IL_TILE_R + 64 +
+         (size_t)Dp * Dp + H + Dp;
 }
 __device__ __forceinline__ DiscLds carve(float* s, int D, int H) {
   DiscLds l; float* p = s;
@@ -114,7 +165,8 @@ __device__ __forceinline__ DiscLds carve(float* s, int D, int H) {
   l.Xb = p; p += 3 * IL_TILE_R * Dp; l.wtb = p; p += 3 * IL_TILE_R;
   l.hs = p; p += IL_TILE_R * H; l.dhs = p; p += IL_TILE_R * H; l.ts = p; p += IL_TILE_R * H; l.cg = p; p += IL_TILE_R * Dp;
   l.snb = p; p += 3 * (2 * H + Dp + 4);
-  l.zs = p; p += IL_TILE_R; l.dzs = p; p += IL_TILE_R; l.red = p;
+  l.zs = p; p += IL_TILE_R; l.dzs = p; p += IL_TILE_R; l.red = p; p += 64;
+  l.Ms = p; p += Dp * Dp; l.tmp = p;
   return l;
 }
 
@@ -137,7 +189,10 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   const float b2 = d.params[lay.ob2];
   float* slab = d.workspace + wsl.slabs + ((size_t)pass * nt + tile) * lay.P;
   DiscLds L = carve(smem, D, H);
+  const bool stamp = tile == 0 && pass == 2;
+  IL_STAMP(stamp, 0);
   stage_weights(L, d.params + lay.oW1, d.params + lay.ob1, d.params + lay.oW2, D, H);
+  IL_STAMP(stamp, 1);
   if (d.spectral_norm) {
     for (int i = tid; i < H; i += blockDim.x) { L.u1(0)[i] = d.u1[i]; L.v2(0)[i] = d.v2[i]; }
     for (int i = tid; i < Dp; i += blockDim.x) L.v1(0)[i] = i < D ? d.v1[i] : 0.f;
@@ -145,11 +200,14 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   } else if (tid == 0) { L.sc(0)[0] = 1.f; L.sc(0)[1] = 1.f; L.sc(0)[2] = 0.f; }
   if (tid == 0 && tile == 0 && pass == 0) adam_tick(d.opt);
   __syncthreads();
+  IL_STAMP(stamp, 2);
+  if (d.spectral_norm) { sn_gram(L.W1s, L.Ms, D, Dp, H, ldw); __syncthreads(); }
+  IL_STAMP(stamp, 3);
   const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
   float* X = L.X(0);
-  if (tid < 64) {  // ---- wave 0: power iterations of call 0..pass, chained in place
-    if (d.spectral_norm)
-      for (int c = 0; c <= pass; ++c) sn_wave(L.W1s, L.W2s, D, H, L.u1(0), L.v1(0), &L.sc(0)[2], L.v2(0), true, L.sc(0));
+  if (tid < 64) {  // ---- wave 0: the power iterations of calls 0..pass on the Gram matrix
+    if (d.spectral_norm) sn_chain(L.W1s, L.W2s, L.Ms, D, H, L.u1(0), L.v1(0), L.v2(0), L.tmp, pass + 1, L.sc(0));
+    IL_STAMP(stamp, 5);
   } else {         // ---- waves 1..3: rows of this call
     for (int i = tid - 64; i < IL_TILE_R * Dp; i += blockDim.x - 64) {
       const int r = i / Dp, k = i - r * Dp; float x = 0.f;
@@ -174,6 +232,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     }
   }
   __syncthreads();
+  IL_STAMP(stamp, 6);
 
   const int r = tid >> 4, sub = tid & 15;
   const float fB = (float)B;
@@ -222,6 +281,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     ip1 = s1 * Ssum; ip2 = s2 * Ssum;
   }
   __syncthreads();
+  IL_STAMP(stamp, 7);
   // ---- this call's gradient slab (each element owned by one thread)
   const float* left = L.dhs;                         // [16][H]: dh (BCE) or q (GP)
   const float* right = pass < 2 ? X : L.cg;          // [16][Dp]: x (BCE) or c*g (GP)
@@ -247,6 +307,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     if (pass < 2) for (int rr = 0; rr < IL_TILE_R; ++rr) gb2 += L.dzs[rr];
     slab[lay.ob2] = gb2;
   }
+  IL_STAMP(stamp, 8);
   if (tile == 0 && pass == npass - 1 && d.spectral_norm) {  // final u, v of this update: the last call's iteration
     float* o = d.workspace + wsl.sn_new;
     for (int i = tid; i < H; i += blockDim.x) { o[i] = u1[i]; o[H + D + 1 + i] = v2[i]; }
@@ -385,3 +446,5 @@ extern "C" int il_gail_reward(const il_disc* d, const il_batch* b, float* out_re
   IL_CHECK_LAUNCH("il_gail_reward");
   return IL_OK;
 }
+
+IL_STAMP_READER(il_debug_stamps_gail)

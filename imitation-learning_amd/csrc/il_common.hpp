@@ -28,16 +28,28 @@ int il_set_error(int code, const char* fmt, ...);
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane sums on DPP (data-parallel primitives: the operand of a VALU op is fetched from another lane of the same 16-lane
+// row, ~1 issue slot) instead of __shfl_xor, which hipcc lowers to ds_bpermute_b32 -- an LDS round trip of ~100+ cycles per step.
+// row_ror:n rotates within each row of 16 lanes, so four rotate-and-add steps leave the row total in every lane of the row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// sum over the 16 lanes that share (lane >> 4); every lane of the group gets the total
+__device__ __forceinline__ float group16_sum(float v) {
+  v = dpp_add<0x128>(v);  // row_ror:8
+  v = dpp_add<0x124>(v);  // row_ror:4
+  v = dpp_add<0x122>(v);  // row_ror:2
+  v = dpp_add<0x121>(v);  // row_ror:1
   return v;
 }
-// sum over the 16 lanes that share (lane >> 4)
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// sum over the 64 lanes of the wave, broadcast to every lane (all lanes must be active)
+__device__ __forceinline__ float wave_sum(float v) {
+  v = group16_sum(v);
+  const int iv = __float_as_int(v);
+  const float a = __int_as_float(__builtin_amdgcn_readlane(iv, 0)), b = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(iv, 32)), d = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+  return (a + b) + (c + d);
 }
 
 // block-wide sum, result broadcast to every thread; `red` = LDS scratch of >= 32 floats. All threads must call.
@@ -129,6 +141,16 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
 
 __device__ __forceinline__ float softplus_f(float z) { return z > 20.f ? z : log1pf(expf(z)); }
 __device__ __forceinline__ float sigmoid_f(float z) { return 1.f / (1.f + expf(-z)); }
+
+// Developer-only phase timing (build with -DIL_PHASE_STAMPS): thread 0 of one chosen block stores s_memtime at phase boundaries.
+#ifdef IL_PHASE_STAMPS
+static __device__ unsigned long long il_phase_stamps[64];  // one copy per translation unit (no -fgpu-rdc); read through IL_STAMP_READER(name)
+#define IL_STAMP_READER(name) extern "C" int name(unsigned long long* out_host) { return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(il_phase_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 3; }
+#define IL_STAMP(cond, i) do { if ((cond) && threadIdx.x == 0) il_phase_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define IL_STAMP(cond, i) do { (void)(cond); } while (0)
+#define IL_STAMP_READER(name)
+#endif
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

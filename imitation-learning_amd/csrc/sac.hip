@@ -238,8 +238,11 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b) {
   const SacWs ws = sac_ws(S, A, H, B);
   float* W = d.workspace;
   const MlpView p = mlp_view(d.critic + k * net_stride(IN, H, 1), IN, H, 1);
+  const bool stamp = blockIdx.x == 0;
+  IL_STAMP(stamp, 16);
   load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, IL_TILE_R);
   __syncthreads();
+  IL_STAMP(stamp, 17);
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   tile_fwd(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = p.b1[col];
@@ -247,14 +250,17 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b) {
     for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
   });
   __syncthreads();
+  IL_STAMP(stamp, 18);
   tile_fwd(H1s, ldh, H, p.W2, H, H, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = p.b2[col];
 #pragma unroll
     for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
   });
   __syncthreads();
+  IL_STAMP(stamp, 19);
   critic_head(H2s, ldh, H, p.W3, p.b3[0], q16);
   __syncthreads();
+  IL_STAMP(stamp, 20);
   if (threadIdx.x < IL_TILE_R) W[ws.p_q + (size_t)k * B + row0 + threadIdx.x] = q16[threadIdx.x];
   // dQ/dh2 with upstream 1 (scaling and min-selection happen in k_actor_bwd): dz2 = w3 [h2 > 0], in place
   for (int i = threadIdx.x; i < IL_TILE_R * H; i += blockDim.x) {
@@ -262,6 +268,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b) {
     H2s[r * ldh + n] = H2s[r * ldh + n] > 0.f ? p.W3[n] : 0.f;
   }
   __syncthreads();
+  IL_STAMP(stamp, 21);
   tile_bwd_dx(H2s, ldh, H, H, p.W2, H, H, [&](int kb, f32x4 acc) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -270,6 +277,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b) {
     }
   });
   __syncthreads();
+  IL_STAMP(stamp, 22);
   // dQ/dx = dz1 . W1 on MFMA (K = S + A columns, not a multiple of 16: out-of-range columns clamp); only the action columns are kept
   float* gout = W + ws.p_g + ((size_t)k * B + row0) * A;
   tile_bwd_dx(H1s, ldh, H, H, p.W1, IN, IN, [&](int kb, f32x4 acc) {
@@ -279,6 +287,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b) {
       for (int r = 0; r < 4; ++r) gout[(size_t)(4 * g + r) * A + c] = acc[r];
     }
   });
+  IL_STAMP(stamp, 23);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -829,3 +838,5 @@ extern "C" int il_actor_act(const float* actor, int32_t S, int32_t A, int32_t H,
   IL_CHECK_LAUNCH("il_actor_act");
   return IL_OK;
 }
+
+IL_STAMP_READER(il_debug_stamps_sac)

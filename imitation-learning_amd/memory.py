@@ -109,6 +109,7 @@ class ReplayMemory(torch.utils.data.Dataset):
     self.ring = torch.zeros(self.size, self.row, dtype=torch.float32, device=self.device)
     self._stage = torch.zeros(2, self.row, dtype=torch.float32, pin_memory=self.device.type == 'cuda')
     self._ring_state = torch.zeros(3, dtype=torch.int64, device=self.device)
+    self.index_rng: Optional[IndexStream] = None  # None = the process-wide stream (reference behaviour); set to give this memory its own
     if transitions is not None:
       n = min(transitions['states'].size(0), self.size)
       for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'timeouts', 'weights'):
@@ -184,8 +185,11 @@ class ReplayMemory(torch.utils.data.Dataset):
     del first
     self._sync_ring_state()
 
+  def stream(self) -> IndexStream:
+    return self.index_rng if self.index_rng is not None else index_stream()
+
   def _sample_idx_tensor(self, n: int) -> Tensor:
-    return index_stream().draw(n, self.size, self.idx, self.full)
+    return self.stream().draw(n, self.size, self.idx, self.full)
 
   def gather(self, idx: Tensor) -> Tensor:
     idx = idx.to(self.device, torch.int32, non_blocking=True)
@@ -199,7 +203,7 @@ class ReplayMemory(torch.utils.data.Dataset):
 
   def sample_device(self, n: int, idx_out: Tensor, rows_out: Tensor) -> Dict[str, Tensor]:
     """Graph-capturable sample: MT19937 draw + rejection on the device (same stream), then the gather; no host involvement."""
-    st = index_stream().device_state(self.device)
+    st = self.stream().device_state(self.device)
     _lib.check(_lib.lib().il_mt19937_sample_indices_device(_lib.ptr(st), _lib.ptr(self._ring_state), n, _lib.ptr(idx_out), _lib.stream_ptr()))
     _lib.check(_lib.lib().il_replay_gather(_lib.ptr(self.ring), self.size, self.row, _lib.ptr(idx_out), n, _lib.ptr(rows_out), _lib.stream_ptr()))
     return batch_views(rows_out, self.state_size, self.action_size, self.absorbing)

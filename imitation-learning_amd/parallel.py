@@ -74,8 +74,7 @@ class DataParallelUpdate:
     _lib.check(L.il_sac_apply_actor_grads(C.byref(p.sac), _lib.stream_ptr()))
 
   def capture(self, warmup: int = 3):
-    from .memory import index_stream
-    index_stream().device_state(self.plan.rows.device)
+    self.plan.memory.stream().device_state(self.plan.rows.device)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):

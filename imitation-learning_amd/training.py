@@ -21,8 +21,9 @@ _WS: Dict[tuple, Tensor] = {}
 _NOISE: Dict[torch.device, Tensor] = {}
 
 
-def _workspace(kind: str, floats: int, device) -> Tensor:
-  key = (kind, str(device))
+def _workspace(kind: str, floats: int, device, tag=None) -> Tensor:
+  """Scratch arena shared by every call of one kind on a device; `tag` gives a learner its own (learners that run concurrently must not share)."""
+  key = (kind, str(device), tag)
   ws = _WS.get(key)
   if ws is None or ws.numel() < floats:
     ws = torch.empty(int(floats), dtype=torch.float32, device=device)
@@ -30,10 +31,10 @@ def _workspace(kind: str, floats: int, device) -> Tensor:
   return ws
 
 
-def _noise_counter(device) -> Tensor:
-  if device not in _NOISE:
-    _NOISE[device] = torch.zeros(1, dtype=torch.int32, device=device)
-  return _NOISE[device]
+def _noise_counter(device, tag=None) -> Tensor:
+  if (device, tag) not in _NOISE:
+    _NOISE[(device, tag)] = torch.zeros(1, dtype=torch.int32, device=device)
+  return _NOISE[(device, tag)]
 
 
 def _noise_seed() -> int:
@@ -45,11 +46,11 @@ def _f32(t: Optional[Tensor], device) -> Optional[Tensor]:
 
 
 def sac_descriptor(actor: SoftActor, critic: TwinCritic, log_alpha: Tensor, target_critic: TwinCritic, batch_size: int, actor_optimiser: AdamW, critic_optimiser: AdamW,
-                   temperature_optimiser: Adam, discount: float, entropy_target: float, polyak_factor: float) -> _lib.Sac:
+                   temperature_optimiser: Adam, discount: float, entropy_target: float, polyak_factor: float, tag=None, seed_offset: int = 0) -> _lib.Sac:
   S, A, H, dev = actor.state_size, actor.action_size, actor.hidden, actor.flat.device
   assert critic.hidden == H and log_alpha.is_cuda and log_alpha.dtype == torch.float32
   floats = int(_lib.lib().il_sac_workspace_floats(S, A, H, batch_size))
-  ws = _workspace('sac', floats, dev)
+  ws = _workspace('sac', floats, dev, tag)
   d = _lib.Sac()
   d.state_dim, d.action_dim, d.hidden, d.batch = S, A, H, batch_size
   d.actor, d.critic, d.target, d.log_alpha = actor.flat.data_ptr(), critic.flat.data_ptr(), target_critic.flat.data_ptr(), log_alpha.data_ptr()
@@ -57,7 +58,7 @@ def sac_descriptor(actor: SoftActor, critic: TwinCritic, log_alpha: Tensor, targ
   d.actor_opt, d.critic_opt, d.alpha_opt = actor_optimiser.desc(), critic_optimiser.desc(), temperature_optimiser.desc()
   d.discount, d.entropy_target, d.polyak = float(discount), float(entropy_target), float(polyak_factor)
   d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
-  d.noise_seed, d.noise_counter = _noise_seed(), _noise_counter(dev).data_ptr()
+  d.noise_seed, d.noise_counter = (_noise_seed() + seed_offset) & (2**64 - 1), _noise_counter(dev, tag).data_ptr()
   return d
 
 
@@ -97,14 +98,15 @@ def target_estimation_update(discriminator, expert_transition, discriminator_opt
 
 
 # ----------------------------------------------------------------------------------------------- GAIL
-def disc_descriptor(disc: GAILDiscriminator, batch_size: int, opt: AdamW, imitation_cfg=None, grad_penalty: float = 0.0, entropy_bonus: float = 0.0) -> _lib.Disc:
+def disc_descriptor(disc: GAILDiscriminator, batch_size: int, opt: AdamW, imitation_cfg=None, grad_penalty: float = 0.0, entropy_bonus: float = 0.0, tag=None,
+                    seed_offset: int = 0) -> _lib.Disc:
   dev = disc.flat.device
   if imitation_cfg is not None:
     if imitation_cfg.loss_function != 'BCE':
       raise NotImplementedError(f'adversarial_imitation_update: loss_function={imitation_cfg.loss_function} is not implemented on the HIP path (BCE only)')
     grad_penalty, entropy_bonus = float(imitation_cfg.grad_penalty), float(imitation_cfg.entropy_bonus)
   floats = int(_lib.lib().il_disc_workspace_floats(disc.in_dim, disc.hidden, batch_size))
-  ws = _workspace('disc', floats, dev)
+  ws = _workspace('disc', floats, dev, tag)
   v = disc.views()
   d = _lib.Disc()
   d.state_dim, d.action_dim, d.hidden, d.batch = disc.state_size, disc.action_size, disc.hidden, batch_size
@@ -116,7 +118,7 @@ def disc_descriptor(disc: GAILDiscriminator, batch_size: int, opt: AdamW, imitat
     d.grad = ws.data_ptr()  # reward only: never written
   d.grad_penalty, d.entropy_bonus = grad_penalty, entropy_bonus
   d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
-  d.noise_seed, d.noise_counter = _noise_seed(), _noise_counter(dev).data_ptr()
+  d.noise_seed, d.noise_counter = (_noise_seed() + seed_offset) & (2**64 - 1), _noise_counter(dev, tag).data_ptr()
   return d
 
 
@@ -191,7 +193,8 @@ class UpdatePlan:
 
   def __init__(self, algorithm: str, actor, critic, log_alpha, target_critic, memory: ReplayMemory, actor_optimiser, critic_optimiser, temperature_optimiser,
                batch_size: int, discount: float, entropy_target: float, polyak_factor: float, expert_memory: Optional[ReplayMemory] = None, discriminator=None,
-               discriminator_optimiser=None, imitation_cfg=None, device_index_draw: bool = True, overlap: bool = True):
+               discriminator_optimiser=None, imitation_cfg=None, device_index_draw: bool = True, overlap: bool = True, learner_id=None):
+    """`learner_id`: give this plan private scratch / noise / index-stream state so that several plans can run concurrently (`PopulationPlan`)."""
     assert algorithm in ('SAC', 'GAIL')
     self.overlap, self.side = overlap, (torch.cuda.Stream() if overlap and algorithm == 'GAIL' else None)
     self.algorithm, self.B, dev = algorithm, batch_size, actor.flat.device
@@ -199,12 +202,14 @@ class UpdatePlan:
     self.rows = torch.empty(batch_size, memory.row, device=dev); self.idx = torch.empty(batch_size, dtype=torch.int32, device=dev)
     self.transitions = batch_views(self.rows, memory.state_size, memory.action_size, memory.absorbing)
     self.logp, self.q = torch.empty(batch_size, device=dev), torch.empty(batch_size, device=dev)
-    self.sac = sac_descriptor(actor, critic, log_alpha, target_critic, batch_size, actor_optimiser, critic_optimiser, temperature_optimiser, discount, entropy_target, polyak_factor)
+    tag, off = learner_id, (0 if learner_id is None else 7919 * (int(learner_id) + 1))
+    self.sac = sac_descriptor(actor, critic, log_alpha, target_critic, batch_size, actor_optimiser, critic_optimiser, temperature_optimiser, discount, entropy_target, polyak_factor,
+                              tag=tag, seed_offset=off)
     self._keep = (actor, critic, log_alpha, target_critic, actor_optimiser, critic_optimiser, temperature_optimiser, discriminator, discriminator_optimiser)
     if algorithm == 'GAIL':
       self.erows = torch.empty(batch_size, expert_memory.row, device=dev); self.eidx = torch.empty(batch_size, dtype=torch.int32, device=dev)
       self.expert_transitions = batch_views(self.erows, expert_memory.state_size, expert_memory.action_size, expert_memory.absorbing)
-      self.disc = disc_descriptor(discriminator, batch_size, discriminator_optimiser, imitation_cfg)
+      self.disc = disc_descriptor(discriminator, batch_size, discriminator_optimiser, imitation_cfg, tag=tag, seed_offset=off)
       self.eb = batch_desc(self.expert_transitions)
       self.rewards = torch.empty(batch_size, device=dev)
       self.transitions['rewards'] = self.rewards  # train.py:194: rewards replaced by the discriminator's prediction
@@ -225,9 +230,8 @@ class UpdatePlan:
       if self.algorithm == 'GAIL':
         self._sample(self.expert_memory, self.eidx, self.erows)
       return
-    from .memory import index_stream
     m, e = self.memory, (self.expert_memory if self.algorithm == 'GAIL' else None)
-    st = index_stream().device_state(m.device)
+    st = m.stream().device_state(m.device)   # the agent memory's index stream feeds both draws of an update (one stream, agent then expert)
     _lib.check(_lib.lib().il_replay_sample_device(
         _lib.ptr(st), self.B, _lib.ptr(m._ring_state), _lib.ptr(m.ring), m.size, m.row, _lib.ptr(self.idx), _lib.ptr(self.rows),
         _lib.ptr(e._ring_state) if e else None, _lib.ptr(e.ring) if e else None, e.size if e else 0, e.row if e else 0, _lib.ptr(self.eidx) if e else None,
@@ -258,14 +262,47 @@ class UpdatePlan:
 
   def capture(self, warmup: int = 3):
     assert self.device_index_draw, 'graph capture needs device-side index draws (no H2D inside the graph)'
-    from .memory import index_stream
-    index_stream().device_state(self.rows.device)  # materialise the device copy of the MT19937 state before capture starts
+    self.memory.stream().device_state(self.rows.device)  # materialise the device copy of the MT19937 state before capture starts
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
       for _ in range(warmup):
         self.run()
     torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    self.graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(self.graph):
+      self.run()
+    return self
+
+  def replay(self):
+    self.graph.replay()
+
+
+class PopulationPlan:
+  """N independent learners (seeds / hyper-parameter trials: how the reference is actually used, README.md:96-99, train_all.py) advanced
+  by ONE hipGraph replay: every learner's update block is a branch of the graph on its own stream, so their latency-bound kernels
+  (16-64 workgroups each) fill the 256 CUs side by side.  Each learner owns its replay ring, index stream, scratch and noise state."""
+
+  def __init__(self, plans):
+    self.plans = list(plans)
+    self.streams = [torch.cuda.Stream() for _ in self.plans]
+    self.graph = None
+
+  def run(self):
+    main = torch.cuda.current_stream()
+    for p, s in zip(self.plans, self.streams):
+      s.wait_stream(main)
+      with torch.cuda.stream(s):
+        p.run()
+    for s in self.streams:
+      main.wait_stream(s)
+
+  def capture(self, warmup: int = 0):
+    for p in self.plans:
+      p.memory.stream().device_state(p.rows.device)
+    for _ in range(warmup):
+      self.run()
     torch.cuda.synchronize()
     self.graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(self.graph):
