@@ -146,6 +146,7 @@ def main():
   ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--trace-steps', type=int, default=100)
+  ap.add_argument('--no-population', action='store_true')
   ap.add_argument('--learners', type=int, default=1, help='population axis: N independent learners per GPU advanced by one graph replay (aggregate updates/s)')
   args = ap.parse_args()
 
@@ -253,6 +254,28 @@ def main():
                            batch_per_gpu=B, global_batch=B * world, state_dim=S, action_dim=A, hidden=H, replay_capacity=1_000_000, replay_fill=100_000, expert_rows=25_000,
                            learners_per_gpu=args.learners, parallelism=f'dp{world}' + ('(split path)' if runner is not plan else ''), launch='eager' if args.no_graph else 'hipGraph replay', noise='on-chip Philox4x32-10', finite=finite),
                roofline=roof)
+    if world == 1 and args.learners == 1 and not args.no_population:
+      # population axis (the reference's own usage: 10-seed sweeps / Ax trials): 8 independent learners as concurrent
+      # branches of one hipGraph. Reported next to, never instead of, the single-learner `value`.
+      from imitation_learning_amd import PopulationPlan
+      Lp = 8
+      pop = PopulationPlan([build(device, rank, seed=100 + l, learner_id=100 + l)[0] for l in range(Lp)])
+      for _ in range(3):
+        pop.run()
+      torch.cuda.synchronize()
+      pop.capture()
+      for _ in range(50):
+        pop.replay()
+      torch.cuda.synchronize()
+      t1 = time.perf_counter()
+      for _ in range(300):
+        pop.replay()
+      torch.cuda.synchronize()
+      dt = time.perf_counter() - t1
+      agg = Lp * 300 / dt
+      out['population'] = dict(learners=Lp, aggregate_updates_per_s=round(agg, 1), ms_per_replay=round(dt / 300 * 1e3, 5),
+                               hbm_frac=round(agg * update_bytes / 1e9 / HBM_PEAK_GBS, 5), note='8 independent batch-256 learners per hipGraph replay (one branch each)')
+      del pop
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(tr, et)
     print(json.dumps(out))

@@ -286,6 +286,8 @@ class PopulationPlan:
 
   def __init__(self, plans):
     self.plans = list(plans)
+    for p in self.plans:
+      p.overlap = False  # one stream per learner: the learners themselves are the concurrency (nested fork/join breaks hipGraph capture on ROCm 7.2)
     self.streams = [torch.cuda.Stream() for _ in self.plans]
     self.graph = None
 
