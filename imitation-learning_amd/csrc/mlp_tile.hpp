@@ -47,10 +47,26 @@ __device__ __forceinline__ void tile_fwd_impl(const float* Xs, int ldx, int Kpad
     const float* wr = W + (size_t)(c0 + j) * ldw + 4 * g;
     const float* xr = Xs + j * ldx + 4 * g;
     int k0 = 0;
+    if (MODE == 0 && Kpad == 256) {  // the H = 256 hidden layer: the wave's whole weight panel (16 lanes of 16 B) is requested up front, MFMAs
+      f32x4 b[16];                   // start as soon as the first lane lands and the rest stream in underneath them
+#pragma unroll
+      for (int u = 0; u < 16; ++u) b[u] = load4<MODE>(wr - 4 * g, 16 * u + 4 * g, Kw);
+      __builtin_amdgcn_sched_barrier(0);  // keep all 16 requests ahead of the MFMAs (the scheduler otherwise sinks them to 2 in flight)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * u);
+        acc0 = mfma16(a[0], b[u][0], acc0);
+        acc1 = mfma16(a[1], b[u][1], acc1);
+        acc0 = mfma16(a[2], b[u][2], acc0);
+        acc1 = mfma16(a[3], b[u][3], acc1);
+      }
+      k0 = 256;
+    }
     for (; k0 + 128 <= Kpad; k0 += 128) {  // 8 k-blocks per trip: eight 16-B weight lanes in flight before the first MFMA needs one
       f32x4 b[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) b[u] = load4<MODE>(wr - 4 * g, k0 + 16 * u + 4 * g, Kw);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(xr + k0 + 16 * u);
@@ -143,6 +159,67 @@ __device__ __forceinline__ void tile_bwd_dx(const float* dYs, int ldy, int Npad,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Packed hidden-layer weights. Reading a torch [N][K] matrix as MFMA operands touches 16 different rows per wave-load (64 useful
+// bytes of 16 separate 128-B lines): measured 14 B/clk/CU, and the MFMAs starve behind it (19.8k cycles per 16x256x256 layer vs
+// 10.7k without the loads). The same bytes as contiguous 1 KiB wave-loads run at 12.3k. So the H x H layers are read from two
+// lane-ordered copies kept in the workspace (written by k_repack at the start of an update and by the Adam epilogue afterwards):
+//   PF (forward,  B[k][n] = W[n][k]):  PF[((n/16 * H/16 + k/16) * 64 + ((k%16)/4)*16 + n%16) * 4 + k%4]
+//   PB (backward, B[n][k] = W[n][k]):  PB[((k/16 * H/16 + n/16) * 64 + ((n%16)/4)*16 + k%16) * 4 + n%4]
+// i.e. wave-load (tile, block) = 64 lanes x 16 B contiguous, and a wave's whole panel (H/16 blocks) is one contiguous H*16*4-byte run.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t packed_fwd_index(int n, int k, int H) { return ((size_t)((n >> 4) * (H >> 4) + (k >> 4)) * 64 + ((k & 15) >> 2) * 16 + (n & 15)) * 4 + (k & 3); }
+__host__ __device__ inline size_t packed_bwd_index(int n, int k, int H) { return ((size_t)((k >> 4) * (H >> 4) + (n >> 4)) * 64 + ((n & 15) >> 2) * 16 + (k & 15)) * 4 + (n & 3); }
+
+// shared body: acc += A(LDS rows, K = H) . panel, panel = P + tile * (H/16) * 256 floats
+template <class Epi>
+__device__ __forceinline__ void tile_packed(const float* As, int lda, int H, const float* __restrict__ P, Epi epi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4, nb = H >> 4;
+  for (int t = wave; t < nb; t += nw) {
+    f32x4 acc0 = zero4(), acc1 = zero4();
+    const float* pp = P + (size_t)t * nb * 256 + lane * 4;
+    const float* ar = As + j * lda + 4 * g;
+    int kb = 0;
+    for (; kb + 16 <= nb; kb += 16) {
+      f32x4 b[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) b[u] = *reinterpret_cast<const f32x4*>(pp + (size_t)(kb + u) * 256);
+      __builtin_amdgcn_sched_barrier(0);  // all 16 KiB of the panel requested before the first MFMA
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ar + 16 * (kb + u));
+        acc0 = mfma16(a[0], b[u][0], acc0);
+        acc1 = mfma16(a[1], b[u][1], acc1);
+        acc0 = mfma16(a[2], b[u][2], acc0);
+        acc1 = mfma16(a[3], b[u][3], acc1);
+      }
+    }
+    for (; kb + 4 <= nb; kb += 4) {
+      f32x4 b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const f32x4*>(pp + (size_t)(kb + u) * 256);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ar + 16 * (kb + u));
+        acc0 = mfma16(a[0], b[u][0], acc0);
+        acc1 = mfma16(a[1], b[u][1], acc1);
+        acc0 = mfma16(a[2], b[u][2], acc0);
+        acc1 = mfma16(a[3], b[u][3], acc1);
+      }
+    }
+    f32x4 acc = acc0 + acc1;
+    epi(t * 16, acc);
+  }
+}
+// Y[16 x H] = Xs[16 x H] . W^T with W given as its PF copy;  epi(c0, acc): acc[reg] = Y[row 4g+reg][col c0 + j]
+template <class Epi>
+__device__ __forceinline__ void tile_fwd_packed(const float* Xs, int ldx, int H, const float* __restrict__ PF, Epi epi) { tile_packed(Xs, ldx, H, PF, epi); }
+// dX[16 x H] = dYs[16 x H] . W with W given as its PB copy;  epi(kb, acc): acc[reg] = dX[row 4g+reg][col kb + j]
+template <class Epi>
+__device__ __forceinline__ void tile_bwd_packed(const float* dYs, int ldy, int H, const float* __restrict__ PB, Epi epi) { tile_packed(dYs, ldy, H, PB, epi); }
+
+// ---------------------------------------------------------------------------------------------
 // Small output layer: Os[16][16] = Xs[16 x K] . W^T + b, W [N][ldw] with N <= 16 (actor head 2A, critic head 1).
 // The K/16 k-blocks are dealt round-robin to the waves; partial tiles are reduced through LDS (`part` >= nw*256 floats).
 // Contains __syncthreads(); every thread of the block must call. Result valid after return.
@@ -182,6 +259,21 @@ __device__ __forceinline__ void load_rows_cat(float* Xs, int ldx, int Kpad, cons
       else if (k < K1 + K2) v = f2[(size_t)(row0 + r) * ld2 + (k - K1)];
     }
     Xs[r * ldx + k] = v;
+  }
+}
+
+// XCD-aware (tile, net) decode. Workgroup b is observed to run on XCD b % 8 and every XCD has a private L2, so all workgroups that
+// stream the SAME network's weights are placed on the same 8/n_nets XCDs: each XCD then pulls one network through the fabric
+// instead of all of them (the weights were just rewritten by the Adam kernel, so the first touch per XCD is a fabric fetch).
+// Placement is a speed heuristic only; any (tile, net) bijection is correct. Falls back to net-major order when it does not divide.
+__device__ __forceinline__ void xcd_tile_net(int b, int nt, int n_nets, int& tile, int& net) {
+  const int xpn = 8 / n_nets;  // XCDs per network (n_nets in {1, 2, 4, 8})
+  if (n_nets <= 8 && (8 % n_nets) == 0 && (nt % xpn) == 0 && ((nt * n_nets) % 8) == 0) {
+    const int x = b & 7, q = b >> 3;
+    net = x / xpn;
+    tile = (x % xpn) * (nt / xpn) + q;
+  } else {
+    net = b / nt; tile = b - net * nt;
   }
 }
 

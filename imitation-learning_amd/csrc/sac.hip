@@ -21,7 +21,9 @@
 struct SacWs {  // float offsets into il_sac.workspace
   int64_t a_h1, a_h2, a_xpre, a_eps, a_lsraw, a_anew, a_logp, n_a2, n_logp2;
   int64_t c_x0, c_h1, c_h2, c_q, t_q, c_dz3, c_dz2, c_dz1, q_min;
-  int64_t p_q, p_g, a_dz3, a_dz2, a_dz1, alpha_part, total;
+  int64_t p_q, p_g, a_dz3, a_dz2, a_dz1, alpha_part;
+  int64_t pk_af, pk_ab, pk_cf, pk_cb, pk_tf, pk_tb;  // lane-ordered copies of the H x H layers (mlp_tile.hpp "Packed hidden-layer weights")
+  int64_t total;
 };
 __host__ __device__ inline SacWs sac_ws(int S, int A, int H, int B) {
   SacWs w; int64_t o = 0;
@@ -32,6 +34,8 @@ __host__ __device__ inline SacWs sac_ws(int S, int A, int H, int B) {
   w.c_x0 = take((int64_t)B * (S + A)); w.c_h1 = take(2 * BH); w.c_h2 = take(2 * BH); w.c_q = take(2 * B); w.t_q = take(2 * B);
   w.c_dz3 = take(2 * B); w.c_dz2 = take(2 * BH); w.c_dz1 = take(2 * BH); w.q_min = take(B);
   w.p_q = take(2 * B); w.p_g = take(2 * BA); w.a_dz3 = take((int64_t)B * 16); w.a_dz2 = take(BH); w.a_dz1 = take(BH); w.alpha_part = take(B / IL_TILE_R + 4);
+  const int64_t HH = (int64_t)H * H;
+  w.pk_af = take(HH); w.pk_ab = take(HH); w.pk_cf = take(2 * HH); w.pk_cb = take(2 * HH); w.pk_tf = take(2 * HH); w.pk_tb = take(2 * HH);
   w.total = o;
   return w;
 }
@@ -55,6 +59,30 @@ __device__ __forceinline__ void head_sample(float mean, float ls_raw, float eps,
   const float d = __fsub_rn(x, mean);
   nlp = -(d * d) / (2.f * (sd * sd)) - logf(sd) - LOG_SQRT_2PI;
   ladj = 2.f * (LOG_2 - x - softplus_f(-2.f * x));
+}
+
+// k_repack: PF / PB copies of W2 for actor (net 0), critic_1,2 (1,2) and target_1,2 (3,4). `mask` selects nets (bit per net).
+// Every public entry point derives the copies it reads from the parameters inside the same call, so they can never be stale.
+__global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask) {
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, IN = S + A;
+  const int net = blockIdx.y;
+  if (!((mask >> net) & 1u)) return;
+  const SacWs ws = sac_ws(S, A, H, d.batch);
+  const int64_t HH = (int64_t)H * H, ns = net_stride(IN, H, 1);
+  const float* W2; float* pf; float* pb;
+  if (net == 0) { W2 = d.actor + (size_t)H * S + H; pf = d.workspace + ws.pk_af; pb = d.workspace + ws.pk_ab; }
+  else {
+    const int k = (net - 1) & 1; const bool tgt = net >= 3;
+    W2 = (tgt ? d.target : d.critic) + k * ns + (size_t)H * IN + H;
+    pf = d.workspace + (tgt ? ws.pk_tf : ws.pk_cf) + k * HH; pb = d.workspace + (tgt ? ws.pk_tb : ws.pk_cb) + k * HH;
+  }
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < HH; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    const int n = (int)(i / H), k = (int)(i - (int64_t)n * H);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(W2 + i);
+    *reinterpret_cast<f32x4*>(pf + packed_fwd_index(n, k, H)) = w;   // k..k+3 share (n, k/16, (k%16)/4): one 16-byte lane
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pb[packed_bwd_index(n, k + q, H)] = w[q];
+  }
 }
 
 // mode: 0 = next rows then current rows (grid 2*nt), 1 = next only, 2 = current only
@@ -83,7 +111,7 @@ __global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const 
     if (is_cur) *reinterpret_cast<f32x4*>(W + ws.a_h1 + (size_t)col * B + row0 + 4 * g) = hv;
   });
   __syncthreads();
-  tile_fwd(H1s, ldh, H, net.W2, H, H, H, [&](int c0, f32x4 acc) {
+  tile_fwd_packed(H1s, ldh, H, W + ws.pk_af, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = net.b2[col];
     f32x4 hv;
 #pragma unroll
@@ -139,7 +167,9 @@ __global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
-  const int net = (int)blockIdx.x / nt, tile = (int)blockIdx.x % nt, row0 = tile * IL_TILE_R;
+  int net, tile;
+  xcd_tile_net((int)blockIdx.x, nt, 4, tile, net);
+  const int row0 = tile * IL_TILE_R;
   const bool is_target = net >= 2; const int k = net & 1;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
   float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* q16 = H2s + IL_TILE_R * ldh;
@@ -162,7 +192,7 @@ __global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b) {
     if (!is_target) *reinterpret_cast<f32x4*>(sh1 + (size_t)col * B + row0 + 4 * g) = hv;
   });
   __syncthreads();
-  tile_fwd(H1s, ldh, H, p.W2, H, H, H, [&](int c0, f32x4 acc) {
+  tile_fwd_packed(H1s, ldh, H, W + (is_target ? ws.pk_tf : ws.pk_cf) + (size_t)k * H * H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = p.b2[col];
     f32x4 hv;
 #pragma unroll
@@ -182,7 +212,9 @@ __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
-  const int k = (int)blockIdx.x / nt, tile = (int)blockIdx.x % nt, row0 = tile * IL_TILE_R;
+  int k, tile;
+  xcd_tile_net((int)blockIdx.x, nt, 2, tile, k);
+  const int row0 = tile * IL_TILE_R;
   const int ldh = H + 4;
   float* DZ2s = smem; float* dz3s = DZ2s + IL_TILE_R * ldh;
   const SacWs ws = sac_ws(S, A, H, B);
@@ -215,7 +247,7 @@ __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b) {
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-  tile_bwd_dx(DZ2s, ldh, H, H, p.W2, H, H, [&](int kb, f32x4 acc) {
+  tile_bwd_packed(DZ2s, ldh, H, W + ws.pk_cb + (size_t)k * H * H, [&](int kb, f32x4 acc) {
     const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
     const f32x4 hv = *reinterpret_cast<const f32x4*>(h1 + off);
     f32x4 o;
@@ -232,7 +264,9 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
-  const int k = (int)blockIdx.x / nt, tile = (int)blockIdx.x % nt, row0 = tile * IL_TILE_R;
+  int k, tile;
+  xcd_tile_net((int)blockIdx.x, nt, 2, tile, k);
+  const int row0 = tile * IL_TILE_R;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
   float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* q16 = H2s + IL_TILE_R * ldh;
   const SacWs ws = sac_ws(S, A, H, B);
@@ -251,7 +285,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b) {
   });
   __syncthreads();
   IL_STAMP(stamp, 18);
-  tile_fwd(H1s, ldh, H, p.W2, H, H, H, [&](int c0, f32x4 acc) {
+  tile_fwd_packed(H1s, ldh, H, W + ws.pk_cf + (size_t)k * H * H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = p.b2[col];
 #pragma unroll
     for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
@@ -269,7 +303,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b) {
   }
   __syncthreads();
   IL_STAMP(stamp, 21);
-  tile_bwd_dx(H2s, ldh, H, H, p.W2, H, H, [&](int kb, f32x4 acc) {
+  tile_bwd_packed(H2s, ldh, H, W + ws.pk_cb + (size_t)k * H * H, [&](int kb, f32x4 acc) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float* h = H1s + (4 * g + r) * ldh + kb + j;
@@ -347,7 +381,7 @@ __global__ __launch_bounds__(1024) void k_actor_bwd(il_sac d, il_batch b, float*
     *reinterpret_cast<f32x4*>(W + ws.a_dz2 + off) = o;
   });
   __syncthreads();
-  tile_bwd_dx(DZ2s, ldh, H, H, net.W2, H, H, [&](int kb, f32x4 acc) {
+  tile_bwd_packed(DZ2s, ldh, H, W + ws.pk_ab, [&](int kb, f32x4 acc) {
     const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
     const f32x4 hv = *reinterpret_cast<const f32x4*>(h1 + off);
     f32x4 o;
@@ -372,6 +406,7 @@ struct DwArgs {
   const float* x0; int ld_x0; int x0_transposed; int64_t x0_net_stride;   // layer-1 input: [in][B] (transposed) or row-major [B][ld_x0]
   const float* h1; const float* h2; const float* dz1; const float* dz2; int64_t h_net_stride;   // [H][B]
   const float* dz3; int64_t dz3_net_stride;                                // [out][B]
+  float* pk_f; float* pk_b;                                                 // lane-ordered copies of W2 kept in step with the AdamW update (NULL: none)
   int n_dw_blocks;
   // tail
   float* log_alpha; float* alpha_grad; il_adam alpha_opt; const float* alpha_part; int n_alpha_part;
@@ -388,7 +423,7 @@ __device__ __forceinline__ void adam_store(const DwArgs& a, const adam_consts& a
 // XT: x is feature-major [Kvalid][B]; otherwise row-major [B][ldx] (the actor's layer-1 input = the states field of the batch)
 template <bool XT>
 __device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dzT, int Nvalid, const float* __restrict__ x, int ldx, int Kvalid,
-                                        int n0, int kb, int64_t poff) {
+                                        int n0, int kb, int64_t poff, float* __restrict__ pkf = nullptr, float* __restrict__ pkb = nullptr) {
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int B = a.batch;
   f32x4 acc0 = zero4(), acc1 = zero4();
@@ -430,6 +465,12 @@ __device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, 
   for (int r = 0; r < 4; ++r) {
     const int n = n0 + 4 * g + r;
     if (n < Nvalid) adam_store(a, ac, poff + (int64_t)n * Kvalid + k, acc[r]);
+  }
+  if (pkf && !a.grads_only) {  // the updated W2 values, in both lane orders (this tile owns rows n0..n0+15, columns kb..kb+15: always full for an H x H layer)
+    f32x4 w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { w[r] = a.params[poff + (int64_t)(n0 + 4 * g + r) * Kvalid + k]; pkf[packed_fwd_index(n0 + 4 * g + r, k, Kvalid)] = w[r]; }
+    *reinterpret_cast<f32x4*>(pkb + packed_bwd_index(n0 + 4 * g, k, Kvalid)) = w;   // rows n0+4g..+3 of column k: one 16-byte lane of PB
   }
 }
 
@@ -497,7 +538,10 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
   const float* dz1 = a.dz1 + net * a.h_net_stride; const float* dz2 = a.dz2 + net * a.h_net_stride;
   const float* dz3 = a.dz3 + net * a.dz3_net_stride;
   // the big layer first: its tiles are the long pole, the small jobs fill in behind them
-  if (job < j2) { dw_tile<true>(a, ac, dz2, H, h1, 0, H, (job / nt_h) * 16, (job % nt_h) * 16, oW2); return; }
+  if (job < j2) {
+    dw_tile<true>(a, ac, dz2, H, h1, 0, H, (job / nt_h) * 16, (job % nt_h) * 16, oW2, a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr);
+    return;
+  }
   job -= j2;
   if (job < j1) {
     if (a.x0_transposed) dw_tile<true>(a, ac, dz1, H, x0, 0, IN, (job / kt_in) * 16, (job % kt_in) * 16, oW1);
@@ -514,6 +558,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
   dw_bias(a, ac, dz3, OUT, job * 16, ob3);
 }
 
+static int repack_blocks(int H) { return ceil_div(H * H / 4, 256); }
 static int dw_blocks(int IN, int H, int OUT, int nets) {
   const int nt_h = H / 16, nt_out = (OUT + 15) / 16;
   const int per_net = nt_h * ((IN + 15) / 16) + nt_h * nt_h + nt_out * nt_h + 2 * nt_h + nt_out;
@@ -564,6 +609,7 @@ static DwArgs critic_dw_args(const il_sac* d, uint32_t flags) {
   a.x0 = d->workspace + ws.c_x0; a.ld_x0 = 0; a.x0_transposed = 1; a.x0_net_stride = 0;
   a.h1 = d->workspace + ws.c_h1; a.h2 = d->workspace + ws.c_h2; a.dz1 = d->workspace + ws.c_dz1; a.dz2 = d->workspace + ws.c_dz2; a.h_net_stride = (int64_t)B * H;
   a.dz3 = d->workspace + ws.c_dz3; a.dz3_net_stride = B;
+  a.pk_f = d->workspace + ws.pk_cf; a.pk_b = d->workspace + ws.pk_cb;
   a.n_dw_blocks = dw_blocks(IN, H, 1, 2);
   return a;
 }
@@ -573,6 +619,7 @@ extern "C" int il_sac_critic_step(const il_sac* d, const il_batch* b, const floa
   hipStream_t st = (hipStream_t)stream_;
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
+  { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu); }
   { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, nullptr, 1); }
   { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, tile_threads(H), lds, st>>>(*d, *b); }
   { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b); }
@@ -591,6 +638,7 @@ static DwArgs actor_dw_args(const il_sac* d, const il_batch* b, uint32_t flags) 
   a.x0 = b->states; a.ld_x0 = b->ld_states; a.x0_transposed = 0; a.x0_net_stride = 0;
   a.h1 = d->workspace + ws.a_h1; a.h2 = d->workspace + ws.a_h2; a.dz1 = d->workspace + ws.a_dz1; a.dz2 = d->workspace + ws.a_dz2; a.h_net_stride = 0;
   a.dz3 = d->workspace + ws.a_dz3; a.dz3_net_stride = 0;
+  a.pk_f = d->workspace + ws.pk_af; a.pk_b = d->workspace + ws.pk_ab;
   a.n_dw_blocks = dw_blocks(S, H, 2 * A, 1);
   a.log_alpha = d->log_alpha; a.alpha_grad = d->alpha_grad; a.alpha_opt = d->alpha_opt; a.alpha_part = d->workspace + ws.alpha_part; a.n_alpha_part = B / IL_TILE_R;
   a.target = d->target; a.polyak_src = d->critic; a.polyak_n = 2 * net_stride(S + A, H, 1); a.tau = d->polyak; a.noise_counter = d->noise_counter;
@@ -602,6 +650,7 @@ extern "C" int il_sac_actor_step(const il_sac* d, const il_batch* b, const float
   hipStream_t st = (hipStream_t)stream_;
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
+  { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 3), 256, 0, st>>>(*d, 0x07u); }  // actor + critics (the critic may have been stepped by il_adam_step)
   { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, eps_cur, 2); }
   { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b); }
   { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q); }
@@ -620,6 +669,7 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   if (!(flags & IL_FLAG_SAC_SKIP_FORWARD)) {
+    { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu); }
     // the actor is unchanged until the last kernel of the update: both of its forward passes share one launch; neither this
     // nor the critic/target forward reads the rewards, so a caller may overlap the reward relabel with them (IL_FLAG_SAC_FORWARD_ONLY)
     { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, 0); }
@@ -702,7 +752,7 @@ __global__ __launch_bounds__(1024) void k_bc_tile(const float* __restrict__ acto
     *reinterpret_cast<f32x4*>(W + ws.a_h1 + (size_t)col * B + row0 + 4 * g) = hv;
   });
   __syncthreads();
-  tile_fwd(H1s, ldh, H, net.W2, H, H, H, [&](int c0, f32x4 acc) {
+  tile_fwd_packed(H1s, ldh, H, W + ws.pk_af, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = net.b2[col];
     f32x4 hv;
 #pragma unroll
@@ -746,7 +796,7 @@ __global__ __launch_bounds__(1024) void k_bc_tile(const float* __restrict__ acto
     *reinterpret_cast<f32x4*>(W + ws.a_dz2 + off) = o;
   });
   __syncthreads();
-  tile_bwd_dx(DZ2s, ldh, H, H, net.W2, H, H, [&](int kb, f32x4 acc) {
+  tile_bwd_packed(DZ2s, ldh, H, W + ws.pk_ab, [&](int kb, f32x4 acc) {
     const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
     const f32x4 hv = *reinterpret_cast<const f32x4*>(W + ws.a_h1 + off);
     f32x4 o;
@@ -767,6 +817,11 @@ extern "C" int il_bc_step(float* actor, float* actor_grad, const il_adam* opt, i
   if (workspace_floats < ws.total) return il_set_error(IL_ERR_WORKSPACE, "il_bc_step: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)ws.total);
   hipStream_t st = (hipStream_t)stream_;
   const int nt = b->n / IL_TILE_R;
+  {
+    il_sac tmp = {};  // k_repack only needs the dims, the actor arena and the workspace
+    tmp.state_dim = S; tmp.action_dim = A; tmp.hidden = H; tmp.batch = b->n; tmp.actor = actor; tmp.workspace = workspace;
+    IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 1), 256, 0, st>>>(tmp, 0x1u);
+  }
   { IL_TRACE("k_bc_tile", st); k_bc_tile<<<nt, tile_threads(H), tile_lds_bytes(round_up16(S + A), H), st>>>(actor, *opt, S, A, H, *b, workspace, out_loss_partials); }
   DwArgs a = {};
   a.params = actor; a.grads = actor_grad; a.opt = *opt; a.grads_only = (flags & IL_FLAG_GRADS_ONLY) ? 1 : 0;

@@ -1,0 +1,19 @@
+import sys, os, ctypes as C
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/golden')
+from imitation_learning_amd import _lib
+_lib.LIB_PATH = os.path.abspath('scratch/stamps/libil_noload.so')
+import torch
+import imitation_learning_amd as il
+from imitation_learning_amd import training as il_training
+from test_gpu_parity import _make_plan
+plan, nets = _make_plan('GAIL', 13)
+plan.overlap = False
+for _ in range(20): plan.run()
+torch.cuda.synchronize()
+L = _lib.lib()
+for fn, idxs in (('il_debug_stamps_gail', range(0, 9)), ('il_debug_stamps_sac', range(16, 24))):
+  f = getattr(L, fn); f.restype = C.c_int
+  buf = (C.c_ulonglong * 64)()
+  f(buf)
+  vals = [buf[i] for i in idxs]
+  print(fn, 'cycles (100 MHz s_memtime ticks?):', [vals[i + 1] - vals[i] for i in range(len(vals) - 1)], 'total', vals[-1] - vals[0])
