@@ -99,12 +99,34 @@ __device__ __forceinline__ void sn_wave(const float* W1s, const float* W2s, int 
 // c iterations, sigma_c = u_c . (W v_{c+1}).  Layer 2 (W2 is [1 x H]) is a fixed point after its first iteration: one is enough.
 // Same numbers as the reference's sequence up to fp32 rounding of the re-associated products.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sn_gram(const float* W1s, float* Ms, int D, int Dp, int H, int ldw) {  // all threads; Ms [Dp][Dp]
-  for (int e = threadIdx.x; e < Dp * Dp; e += blockDim.x) {
-    const int a = e / Dp, b = e - a * Dp;
-    float s0 = 0.f, s1 = 0.f;
-    for (int n = 0; n < H; n += 2) { s0 += W1s[n * ldw + a] * W1s[n * ldw + b]; s1 += W1s[(n + 1) * ldw + a] * W1s[(n + 1) * ldw + b]; }
-    Ms[e] = s0 + s1;
+// One 16 x 16 tile of C = A . B with BOTH operands in LDS, arbitrary strides: A(i, k) = Ap[i*sai + k*sak], B(k, j) = Bp[k*sbk + j*sbj],
+// K % 4 == 0 (fp32 MFMA 16x16x4: lane (j, g) supplies A(j, k0+g) and B(k0+g, j); holds C(4g+reg, j)). The discriminator's products
+// (16 rows x H x D, a few dozen MFMAs each) were LDS-latency-bound as scalar FMA loops; here four k-steps of operands are in flight.
+__device__ __forceinline__ f32x4 mfma_lds_tile(const float* Ap, int sai, int sak, const float* Bp, int sbk, int sbj, int K) {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const float* ap = Ap + j * sai + g * sak;
+  const float* bp = Bp + g * sbk + j * sbj;
+  f32x4 acc0 = zero4(), acc1 = zero4();
+  int k0 = 0;
+  for (; k0 + 16 <= K; k0 += 16) {
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = ap[(k0 + 4 * u) * sak]; b[u] = bp[(k0 + 4 * u) * sbk]; }
+    acc0 = mfma16(a[0], b[0], acc0); acc1 = mfma16(a[1], b[1], acc1); acc0 = mfma16(a[2], b[2], acc0); acc1 = mfma16(a[3], b[3], acc1);
+  }
+  for (; k0 < K; k0 += 4) acc0 = mfma16(ap[k0 * sak], bp[k0 * sbk], acc0);
+  return acc0 + acc1;
+}
+
+// M = W1^T W1 on MFMA: tiles (a0, b0) of [Dp x Dp], reduction over the H rows; columns beyond Dp read padding / neighbours and are dropped
+__device__ __forceinline__ void sn_gram(const float* W1s, float* Ms, int D, int Dp, int H, int ldw) {
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int nt = (Dp + 15) / 16;
+  for (int t = wave; t < nt * nt; t += nw) {
+    const int a0 = (t / nt) * 16, b0 = (t % nt) * 16;
+    const f32x4 cc = mfma_lds_tile(W1s + a0, 1, ldw, W1s + b0, ldw, 1, H);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int a = a0 + 4 * g + r, b = b0 + j; if (a < Dp && b < Dp) Ms[a * Dp + b] = cc[r]; }
   }
 }
 // one wave; n_iter >= 1 chained iterations starting from (v1, v2); outputs u1, v1, v2, sig = {sigma1, sigma2, u2}
@@ -235,19 +257,29 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   IL_STAMP(stamp, 6);
 
   const int r = tid >> 4, sub = tid & 15;
+  const int wave = tid >> 6, nw = blockDim.x >> 6, lane = tid & 63, jj = lane & 15, gg = lane >> 4;
   const float fB = (float)B;
   const bool valid = r < nrows;
   const float s1 = L.sc(0)[0], s2 = L.sc(0)[1], u2 = L.sc(0)[2];
   const float* u1 = L.u1(0); const float* v1 = L.v1(0); const float* v2 = L.v2(0);
-  // ---- forward for row r (16 threads per row)
-  float zp = 0.f;
-  for (int n = sub; n < H; n += 16) {
-    const float h = dot4(L.W1s + n * ldw, X + r * Dp, Dp) / s1 + L.b1s[n];
-    L.hs[r * H + n] = h;
-    zp += (L.W2s[n] / s2) * fmaxf(h, 0.f);
+  float* zw = L.ts;  // [waves][16] per-wave partial logits (ts is not needed before the gradient-penalty products)
+  // ---- forward on MFMA: hs[r][n] = (X . W1^T)[r][n] / s1 + b1[n]  (one wave per 16 hidden units), per-row partial logits
+  {
+    float zp[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = wave; t < H / 16; t += nw) {
+      const int n = 16 * t + jj;
+      const f32x4 c = mfma_lds_tile(X, Dp, 1, L.W1s + 16 * t * ldw, 1, ldw, Dp);
+      const float bb = L.b1s[n], w2 = L.W2s[n] / s2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const float h = c[q] / s1 + bb; L.hs[(4 * gg + q) * H + n] = h; zp[q] += w2 * fmaxf(h, 0.f); }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const float t = group16_sum(zp[q]); if (jj == 0) zw[wave * 16 + 4 * gg + q] = t; }
   }
-  zp = group16_sum(zp);
-  const float z = zp + b2;
+  __syncthreads();
+  float z = b2;
+  for (int w = 0; w < nw; ++w) z += zw[w * 16 + r];
+  __syncthreads();  // zw (aliasing ts) is free again
   float ip1, ip2;
   if (pass < 2) {
     const float w = L.wt(0)[r], label = pass == 1 ? 1.f : 0.f;
@@ -265,33 +297,49 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     ip1 = s1 * block_sum(a1, L.red);
     ip2 = s2 * block_sum(sub == 0 ? dz * (z - b2) : 0.f, L.red);
   } else {
-    // q = [h>0] w2^ -> dhs ; g = W1^^T q ; cg = c g
+    // q = [h>0] w2^ -> dhs ; g = q . W1^ (MFMA) ; cg = c g ; t' = cg . W1^^T (MFMA)
     for (int n = sub; n < H; n += 16) L.dhs[r * H + n] = L.hs[r * H + n] > 0.f ? (L.W2s[n] / s2) : 0.f;
+    if (sub == 0) L.dzs[r] = valid ? 2.f * d.grad_penalty * L.wt(0)[r] / fB : 0.f;   // c_r
     __syncthreads();
-    const float c = valid ? 2.f * d.grad_penalty * L.wt(0)[r] / fB : 0.f;
-    for (int k = sub; k < Dp; k += 16) L.cg[r * Dp + k] = k < D ? c * (dot_strided(L.dhs + r * H, L.W1s + k, ldw, H) / s1) : 0.f;
+    for (int t = wave; t < (Dp + 15) / 16; t += nw) {
+      const int k = 16 * t + jj;
+      const f32x4 c = mfma_lds_tile(L.dhs, H, 1, L.W1s + 16 * t, ldw, 1, H);
+      if (k < Dp) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) L.cg[(4 * gg + q) * Dp + k] = k < D ? L.dzs[4 * gg + q] * (c[q] / s1) : 0.f;
+      }
+    }
     __syncthreads();
     float S_ip = 0.f;
-    for (int n = sub; n < H; n += 16) {
-      const float tp = dot4(L.W1s + n * ldw, L.cg + r * Dp, Dp) / s1;
-      L.ts[r * H + n] = L.hs[r * H + n] > 0.f ? tp : 0.f;
-      S_ip += L.dhs[r * H + n] * tp;
+    for (int t = wave; t < H / 16; t += nw) {
+      const int n = 16 * t + jj;
+      const f32x4 c = mfma_lds_tile(L.cg, Dp, 1, L.W1s + 16 * t * ldw, 1, ldw, Dp);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = 4 * gg + q; const float tp = c[q] / s1;
+        L.ts[row * H + n] = L.hs[row * H + n] > 0.f ? tp : 0.f;
+        S_ip += L.dhs[row * H + n] * tp;
+      }
     }
     const float Ssum = block_sum(S_ip, L.red);
     ip1 = s1 * Ssum; ip2 = s2 * Ssum;
   }
   __syncthreads();
   IL_STAMP(stamp, 7);
-  // ---- this call's gradient slab (each element owned by one thread)
+  // ---- this call's gradient slab:  G1^[n][k] = sum_r left[r][n] right[r][k]  on MFMA (reduction over the tile's 16 rows)
   const float* left = L.dhs;                         // [16][H]: dh (BCE) or q (GP)
   const float* right = pass < 2 ? X : L.cg;          // [16][Dp]: x (BCE) or c*g (GP)
   const float k1 = d.spectral_norm ? ip1 / (s1 * s1) : 0.f, k2 = d.spectral_norm ? ip2 / (s2 * s2) : 0.f;
-  for (int e = tid; e < H * D; e += blockDim.x) {
-    const int n = e / D, k = e - n * D;
-    float gh = 0.f;
+  {
+    const int nkt = (D + 15) / 16;
+    for (int t = wave; t < (H / 16) * nkt; t += nw) {
+      const int n0 = (t / nkt) * 16, k = (t % nkt) * 16 + jj;
+      const f32x4 c = mfma_lds_tile(left + n0, 1, H, right + (t % nkt) * 16, Dp, 1, IL_TILE_R);
+      if (k < D) {
 #pragma unroll
-    for (int rr = 0; rr < IL_TILE_R; ++rr) gh += left[rr * H + n] * right[rr * Dp + k];
-    slab[lay.oW1 + e] = gh / s1 - (d.spectral_norm ? k1 * u1[n] * v1[k] : 0.f);
+        for (int q = 0; q < 4; ++q) { const int n = n0 + 4 * gg + q; slab[lay.oW1 + (size_t)n * D + k] = c[q] / s1 - (d.spectral_norm ? k1 * u1[n] * v1[k] : 0.f); }
+      }
+    }
   }
   for (int n = tid; n < H; n += blockDim.x) {
     float g2 = 0.f, gb = 0.f;
@@ -396,7 +444,7 @@ static int ensure_lds(const void* fn, size_t bytes) {
 static int check_disc(const il_disc* d) {
   IL_CHECK_ARG(d && d->params && d->grad && d->workspace, "il_disc: null descriptor field");
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
-  IL_CHECK_ARG(d->hidden >= 4 && d->hidden <= 512 && d->hidden % 4 == 0 && D >= 1 && D <= 512, "il_disc: dims out of range (D=%d, hidden=%d: hidden must be a multiple of 4)", D, d->hidden);
+  IL_CHECK_ARG(d->hidden >= 16 && d->hidden <= 512 && d->hidden % 16 == 0 && D >= 1 && D <= 512, "il_disc: dims out of range (D=%d, hidden=%d: hidden must be a multiple of 16)", D, d->hidden);
   IL_CHECK_ARG(disc_lds_floats(D, d->hidden) * sizeof(float) <= 160 * 1024, "il_disc: D=%d hidden=%d needs more than 160 KiB of LDS", D, d->hidden);
   IL_CHECK_ARG(d->reward_function >= 0 && d->reward_function <= 2, "il_disc: reward_function must be 0 (AIRL), 1 (GAIL) or 2 (FAIRL)");
   if (d->spectral_norm) IL_CHECK_ARG(d->u1 && d->v1 && d->u2 && d->v2, "il_disc: spectral-norm buffers missing");

@@ -76,12 +76,20 @@ __global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask) {
     W2 = (tgt ? d.target : d.critic) + k * ns + (size_t)H * IN + H;
     pf = d.workspace + (tgt ? ws.pk_tf : ws.pk_cf) + k * HH; pb = d.workspace + (tgt ? ws.pk_tb : ws.pk_cb) + k * HH;
   }
-  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < HH; i += (int64_t)gridDim.x * blockDim.x * 4) {
-    const int n = (int)(i / H), k = (int)(i - (int64_t)n * H);
-    const f32x4 w = *reinterpret_cast<const f32x4*>(W2 + i);
-    *reinterpret_cast<f32x4*>(pf + packed_fwd_index(n, k, H)) = w;   // k..k+3 share (n, k/16, (k%16)/4): one 16-byte lane
+  // one thread = a 4 x 4 block (rows n..n+3, columns k..k+3): four 16-B row reads, transposed in registers, eight 16-B stores
+  const int kq = H / 4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kq * kq; i += gridDim.x * blockDim.x) {
+    const int n = (i / kq) * 4, k = (i - (i / kq) * kq) * 4;
+    f32x4 w[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pb[packed_bwd_index(n, k + q, H)] = w[q];
+    for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4*>(W2 + (size_t)(n + r) * H + k);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(pf + packed_fwd_index(n + r, k, H)) = w[r];   // k..k+3 of row n+r: one lane of PF
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 c; c[0] = w[0][q]; c[1] = w[1][q]; c[2] = w[2][q]; c[3] = w[3][q];
+      *reinterpret_cast<f32x4*>(pb + packed_bwd_index(n, k + q, H)) = c;                                   // rows n..n+3 of column k+q: one lane of PB
+    }
   }
 }
 
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
   dw_bias(a, ac, dz3, OUT, job * 16, ob3);
 }
 
-static int repack_blocks(int H) { return ceil_div(H * H / 4, 256); }
+static int repack_blocks(int H) { return ceil_div(H * H / 16, 256); }
 static int dw_blocks(int IN, int H, int OUT, int nets) {
   const int nt_h = H / 16, nt_out = (OUT + 15) / 16;
   const int per_net = nt_h * ((IN + 15) / 16) + nt_h * nt_h + nt_out * nt_h + 2 * nt_h + nt_out;
@@ -669,7 +677,7 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   if (!(flags & IL_FLAG_SAC_SKIP_FORWARD)) {
-    { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu); }
+    if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu); }
     // the actor is unchanged until the last kernel of the update: both of its forward passes share one launch; neither this
     // nor the critic/target forward reads the rewards, so a caller may overlap the reward relabel with them (IL_FLAG_SAC_FORWARD_ONLY)
     { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, 0); }
@@ -685,6 +693,15 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 33, 256, 0, st>>>(aa); }
   }
   IL_CHECK_LAUNCH("il_sac_update");
+  return IL_OK;
+}
+
+// The lane-ordered weight copies only depend on the parameters: a caller may build them early (e.g. next to the replay sampling on
+// another stream) and pass IL_FLAG_SAC_PREPARED to il_sac_update.
+extern "C" int il_sac_prepare(const il_sac* d, il_stream_t stream_) {
+  IL_CHECK_ARG(d && d->workspace && d->hidden % 64 == 0 && d->hidden >= 64 && d->hidden <= 256, "il_sac_prepare: bad descriptor");
+  { IL_TRACE("k_repack", stream_); k_repack<<<dim3(repack_blocks(d->hidden), 5), 256, 0, (hipStream_t)stream_>>>(*d, 0x1Fu); }
+  IL_CHECK_LAUNCH("il_sac_prepare");
   return IL_OK;
 }
 

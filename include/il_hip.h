@@ -36,6 +36,7 @@ enum { IL_OK = 0, IL_ERR_ARG = 1, IL_ERR_UNSUPPORTED = 2, IL_ERR_HIP = 3, IL_ERR
 #define IL_FLAG_GRADS_ONLY 1u /* write gradients to the *_grad arenas and skip the optimiser (data-parallel: all-reduce, then il_adam_step) */
 #define IL_FLAG_TICK 2u       /* il_adam_step: increment the step counter first (stand-alone use) */
 #define IL_FLAG_SAC_FORWARD_ONLY 4u /* il_sac_update: only the reward-independent forward kernels (actor on s and s', critics, targets) */
+#define IL_FLAG_SAC_PREPARED 16u    /* il_sac_update: il_sac_prepare() already ran for the current parameters (skips the weight re-ordering kernel) */
 #define IL_FLAG_SAC_SKIP_FORWARD 8u /* il_sac_update: everything after them (the caller already ran FORWARD_ONLY on this batch) */
 
 typedef void* il_stream_t; /* hipStream_t */
@@ -147,6 +148,9 @@ int il_sac_actor_step(const il_sac* d, const il_batch* batch, const float* eps_c
 /* DP tail after the all-reduce of actor_grad/alpha_grad: AdamW(actor) + Adam(log_alpha) + polyak (same kernels, no recompute). */
 int il_sac_apply_actor_grads(const il_sac* d, il_stream_t stream);
 int il_sac_apply_critic_grads(const il_sac* d, il_stream_t stream);
+/* Builds the lane-ordered copies of the hidden-layer weights in the workspace (k_repack). il_sac_update does this itself unless told
+ * IL_FLAG_SAC_PREPARED; exposing it lets a caller overlap it with the replay sampling. */
+int il_sac_prepare(const il_sac* d, il_stream_t stream);
 /* whole training.py:14-54 in one call (critic step then actor step) */
 int il_sac_update(const il_sac* d, const il_batch* batch, const float* eps_next, const float* eps_cur, float* out_logp, float* out_q,
                   uint32_t flags, il_stream_t stream);
