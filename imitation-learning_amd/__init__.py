@@ -9,7 +9,7 @@ from .memory import IndexStream, ReplayMemory, seed  # noqa: F401
 from .models import (GAILDiscriminator, GMMILDiscriminator, PWILDiscriminator, SoftActor, TwinCritic, create_target_network,  # noqa: F401
                      make_gail_input, mix_expert_agent_transitions, update_target_network)
 from .optim import Adam, AdamW  # noqa: F401
-from .training import (PopulationPlan, UpdatePlan, adversarial_imitation_update, behavioural_cloning_update, sac_update,  # noqa: F401
+from .training import (BatchedPopulationPlan, PopulationPlan, UpdatePlan, adversarial_imitation_update, behavioural_cloning_update, sac_update,  # noqa: F401
                        target_estimation_update)
 
 __version__ = '0.1.0'

@@ -48,6 +48,12 @@ class Pwil(C.Structure):
               ('reward_scale', C.c_double), ('reward_bandwidth', C.c_double), ('agent_weight', C.c_double)]
 
 
+class SampleArgs(C.Structure):
+  _fields_ = [('state', C.c_void_p),
+              ('ring_state_a', C.c_void_p), ('ring_a', C.c_void_p), ('capacity_a', C.c_int64), ('row_floats_a', C.c_int32), ('idx_a', C.c_void_p), ('rows_a', C.c_void_p),
+              ('ring_state_b', C.c_void_p), ('ring_b', C.c_void_p), ('capacity_b', C.c_int64), ('row_floats_b', C.c_int32), ('idx_b', C.c_void_p), ('rows_b', C.c_void_p)]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     'il_last_error': (C.c_char_p, []),
@@ -64,6 +70,9 @@ _SIGNATURES = {
     'il_mt19937_randint': (C.c_int, [c_u32p, C.c_int64, C.c_int32, c_i32p]),
     'il_mt19937_sample_indices_device': (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     'il_replay_sample_device': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
+    'il_replay_sample_population': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    'il_sac_update_population': (C.c_int, [_P, _P, C.c_int32, C.POINTER(Sac), C.c_uint32, _P]),
+    'il_gail_step_population': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(Disc), _P]),
     'il_adam_step': (C.c_int, [_P, _P, C.POINTER(Adam), C.c_int64, C.c_uint32, _P]),
     'il_polyak': (C.c_int, [_P, _P, C.c_int64, C.c_double, _P]),
     'il_mlp_numel': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

@@ -201,8 +201,10 @@ __device__ __forceinline__ void stage_weights(const DiscLds& L, const float* __r
 
 // grid = (tiles, passes): one workgroup = 16 rows of ONE discriminator call (0 policy, 1 expert, 2 gradient-penalty mix), so the
 // three calls run side by side; wave 0 chains the power iterations up to its call (pass + 1 of them) while waves 1.. stage rows.
-__global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp) {
+__global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp, const il_disc* __restrict__ dL,
+                                                   const il_batch* __restrict__ polL, const il_batch* __restrict__ expL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (dL) { d = dL[blockIdx.z]; pol = polL[blockIdx.z]; exp = expL[blockIdx.z]; }  // population axis
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch, Dp = (D + 3) & ~3, ldw = Dp + 4;
   const int tile = blockIdx.x, pass = blockIdx.y, npass = gridDim.y, nt = gridDim.x, row0 = tile * IL_TILE_R, tid = threadIdx.x;
   const int nrows = min(IL_TILE_R, B - row0);
@@ -365,7 +367,8 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
 }
 
 // grid = ceil(P / 256): one gradient element per thread, slabs summed in tile order (deterministic)
-__global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply) {
+__global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const il_disc* __restrict__ dL) {
+  if (dL) d = dL[blockIdx.y];
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch;
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
   const DiscWs wsl = disc_ws(D, H, B);
@@ -399,8 +402,10 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, float* __restrict__ out_r, float* __restrict__ out_logit) {
+__global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, float* __restrict__ out_r, float* __restrict__ out_logit, const il_disc* __restrict__ dL,
+                                                     const il_batch* __restrict__ bL, float* const* __restrict__ outL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; out_r = outL[blockIdx.y]; out_logit = nullptr; }
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, Dp = (D + 3) & ~3, ldw = Dp + 4;
   const int row0 = blockIdx.x * IL_TILE_R, tid = threadIdx.x, nrows = min(IL_TILE_R, b.n - row0);
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
@@ -460,10 +465,30 @@ extern "C" int il_gail_disc_step(const il_disc* d, const il_batch* pol, const il
   const int nt = ceil_div(d->batch, IL_TILE_R);
   const size_t lds = disc_lds_floats(D, d->hidden) * sizeof(float);
   if (int rc = ensure_lds((const void*)k_gail_grad, lds)) return rc;
-  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, d->grad_penalty > 0.f ? 3 : 2), 256, lds, st>>>(*d, *pol, *exp, eps_gp); }
+  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, d->grad_penalty > 0.f ? 3 : 2), 256, lds, st>>>(*d, *pol, *exp, eps_gp, nullptr, nullptr, nullptr); }
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
-  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1); }
+  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr); }
   IL_CHECK_LAUNCH("il_gail_disc_step");
+  return IL_OK;
+}
+
+// population axis: discriminator step + reward relabel of n_learners independent discriminators (same shapes) in three launches
+extern "C" int il_gail_step_population(const il_disc* descs_dev, const il_batch* policy_dev, const il_batch* expert_dev, float* const* rewards_out_dev, int32_t n_learners,
+                                       const il_disc* shape_host, il_stream_t stream_) {
+  if (int rc = check_disc(shape_host)) return rc;
+  IL_CHECK_ARG(descs_dev && policy_dev && expert_dev && rewards_out_dev && n_learners >= 1 && n_learners <= 65535, "il_gail_step_population: bad arguments");
+  const il_disc* d = shape_host;
+  hipStream_t st = (hipStream_t)stream_;
+  const int D = d->state_dim + (d->state_only ? 0 : d->action_dim), nt = ceil_div(d->batch, IL_TILE_R), L = n_learners;
+  const size_t lds = disc_lds_floats(D, d->hidden) * sizeof(float);
+  if (int rc = ensure_lds((const void*)k_gail_grad, lds)) return rc;
+  if (int rc = ensure_lds((const void*)k_gail_reward, lds)) return rc;
+  const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
+  il_batch zb = {};
+  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, d->grad_penalty > 0.f ? 3 : 2, L), 256, lds, st>>>(*d, zb, zb, nullptr, descs_dev, policy_dev, expert_dev); }
+  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<dim3((int)((P + 255) / 256), L), 256, 0, st>>>(*d, 1, descs_dev); }
+  { IL_TRACE("k_gail_reward", st); k_gail_reward<<<dim3(nt, L), 256, lds, st>>>(*d, zb, nullptr, nullptr, descs_dev, policy_dev, rewards_out_dev); }
+  IL_CHECK_LAUNCH("il_gail_step_population");
   return IL_OK;
 }
 
@@ -490,7 +515,7 @@ extern "C" int il_gail_reward(const il_disc* d, const il_batch* b, float* out_re
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
   const size_t lds = disc_lds_floats(D, d->hidden) * sizeof(float);
   if (int rc = ensure_lds((const void*)k_gail_reward, lds)) return rc;
-  { IL_TRACE("k_gail_reward", stream_); k_gail_reward<<<ceil_div(b->n, IL_TILE_R), 256, lds, (hipStream_t)stream_>>>(*d, *b, out_rewards, out_logits); }
+  { IL_TRACE("k_gail_reward", stream_); k_gail_reward<<<ceil_div(b->n, IL_TILE_R), 256, lds, (hipStream_t)stream_>>>(*d, *b, out_rewards, out_logits, nullptr, nullptr, nullptr); }
   IL_CHECK_LAUNCH("il_gail_reward");
   return IL_OK;
 }

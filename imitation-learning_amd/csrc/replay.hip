@@ -239,6 +239,43 @@ __global__ __launch_bounds__(256) void k_gather2(const float* __restrict__ ring_
   }
 }
 
+// population axis: one workgroup per learner draws (own MT19937 state), then one launch gathers every learner's rows
+__global__ __launch_bounds__(256) void k_sample2_pop(const il_sample_args* __restrict__ aL, int n) {
+  const il_sample_args a = aL[blockIdx.x];
+  __shared__ MtShared sh;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < MT_N; i += 256) sh.mt[i] = a.state[i];
+  if (tid == 0) sh.pos = (int)a.state[MT_N];
+  __syncthreads();
+  mt_draw(sh, a.ring_state_a, n, a.idx_a);
+  if (a.ring_b) { __syncthreads(); mt_draw(sh, a.ring_state_b, n, a.idx_b); }
+  __syncthreads();
+  for (int i = tid; i < MT_N; i += 256) a.state[i] = sh.mt[i];
+  if (tid == 0) a.state[MT_N] = (uint32_t)sh.pos;
+}
+__global__ __launch_bounds__(256) void k_gather2_pop(const il_sample_args* __restrict__ aL, int n) {
+  const il_sample_args a = aL[blockIdx.y];
+  const int row4_a = a.row_floats_a / 4, row4_b = a.row_floats_b / 4;
+  const int na = n * row4_a, nb = a.ring_b ? n * row4_b : 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += gridDim.x * blockDim.x) {
+    const bool isb = i >= na;
+    const int ii = isb ? i - na : i, row4 = isb ? row4_b : row4_a;
+    const int r = ii / row4, c = ii - r * row4;
+    int64_t s = (isb ? a.idx_b : a.idx_a)[r];
+    const int64_t cap = isb ? a.capacity_b : a.capacity_a;
+    s = s < 0 ? 0 : (s >= cap ? cap - 1 : s);
+    reinterpret_cast<f32x4*>(isb ? a.rows_b : a.rows_a)[ii] = reinterpret_cast<const f32x4*>(isb ? a.ring_b : a.ring_a)[s * row4 + c];
+  }
+}
+extern "C" int il_replay_sample_population(const il_sample_args* args_dev, int32_t n_learners, int32_t n, int32_t max_row_floats, il_stream_t stream) {
+  IL_CHECK_ARG(args_dev && n_learners >= 1 && n > 0 && max_row_floats > 0, "il_replay_sample_population: bad arguments");
+  { IL_TRACE("k_sample2", stream); k_sample2_pop<<<n_learners, 256, 0, (hipStream_t)stream>>>(args_dev, n); }
+  const int lanes = 2 * n * (max_row_floats / 4);
+  { IL_TRACE("k_gather2", stream); k_gather2_pop<<<dim3((lanes + 255) / 256, n_learners), 256, 0, (hipStream_t)stream>>>(args_dev, n); }
+  IL_CHECK_LAUNCH("il_replay_sample_population");
+  return IL_OK;
+}
+
 extern "C" int il_mt19937_sample_indices_device(uint32_t* state_dev, const int64_t* ring_state_dev, int32_t n, int32_t* out_dev, il_stream_t stream) {
   IL_CHECK_ARG(state_dev && ring_state_dev && out_dev && n > 0, "il_mt19937_sample_indices_device: bad arguments");
   { IL_TRACE("k_sample2", stream); k_sample2<<<1, 256, 0, (hipStream_t)stream>>>(state_dev, n, ring_state_dev, nullptr, 0, 0, out_dev, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr); }

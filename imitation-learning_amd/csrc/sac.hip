@@ -63,7 +63,8 @@ __device__ __forceinline__ void head_sample(float mean, float ls_raw, float eps,
 
 // k_repack: PF / PB copies of W2 for actor (net 0), critic_1,2 (1,2) and target_1,2 (3,4). `mask` selects nets (bit per net).
 // Every public entry point derives the copies it reads from the parameters inside the same call, so they can never be stale.
-__global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask) {
+__global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask, const il_sac* __restrict__ dL) {
+  if (dL) d = dL[blockIdx.z];  // population axis: one descriptor per learner (wave-uniform scalar loads)
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, IN = S + A;
   const int net = blockIdx.y;
   if (!((mask >> net) & 1u)) return;
@@ -94,8 +95,10 @@ __global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask) {
 }
 
 // mode: 0 = next rows then current rows (grid 2*nt), 1 = next only, 2 = current only
-__global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, int mode) {
+__global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, int mode,
+                                                    const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
   const int nt = B / IL_TILE_R;
   const bool is_cur = (mode == 2) || (mode == 0 && (int)blockIdx.x >= nt);
@@ -171,8 +174,9 @@ __device__ __forceinline__ void critic_head(const float* H2s, int ldh, int H, co
   }
 }
 
-__global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b) {
+__global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
   int net, tile;
@@ -216,8 +220,9 @@ __global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b) {
 // ---------------------------------------------------------------------------------------------
 // critic backward (training.py:24-30): y, dQ_k = w * 2 (Q_k - y) / B, dz2 = dQ w3 [h2>0], dz1 = (dz2 . W2) [h1>0].  grid = nt * 2
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b) {
+__global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
   int k, tile;
@@ -268,8 +273,9 @@ __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b) {
 // ---------------------------------------------------------------------------------------------
 // updated critic on (s, a~) and dQ_k/da~ (training.py:37, backward of :38 through the critic).  grid = nt * 2
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b) {
+__global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
   int k, tile;
@@ -335,8 +341,10 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b) {
 // ---------------------------------------------------------------------------------------------
 // actor backward (training.py:38-46): L = mean(w m alpha logp - min Q).  grid = nt
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_actor_bwd(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q) {
+__global__ __launch_bounds__(1024) void k_actor_bwd(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, const il_sac* __restrict__ dL,
+                                                    const il_batch* __restrict__ bL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
   const int tile = (int)blockIdx.x, row0 = tile * IL_TILE_R;
   const int ldh = H + 4, ldz = 20;
@@ -495,7 +503,7 @@ __device__ __forceinline__ void dw_bias(const DwArgs& a, const adam_consts& ac, 
   if (g == 0 && n0 + j < Nvalid) adam_store(a, ac, poff + n0 + j, s);
 }
 
-__global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
+__device__ __forceinline__ void dw_adam_body(const DwArgs& a) {
   const int wave_in_block = threadIdx.x >> 6;
   if ((int)blockIdx.x >= a.n_dw_blocks) {  // ---- tail blocks
     const int tb = (int)blockIdx.x - a.n_dw_blocks;
@@ -566,11 +574,13 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
   dw_bias(a, ac, dz3, OUT, job * 16, ob3);
 }
 
+__global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) { dw_adam_body(a); }
+
 static int repack_blocks(int H) { return ceil_div(H * H / 16, 256); }
-static int dw_blocks(int IN, int H, int OUT, int nets) {
+__host__ __device__ static inline int dw_blocks(int IN, int H, int OUT, int nets) {
   const int nt_h = H / 16, nt_out = (OUT + 15) / 16;
   const int per_net = nt_h * ((IN + 15) / 16) + nt_h * nt_h + nt_out * nt_h + 2 * nt_h + nt_out;
-  return ceil_div(per_net * nets, 4);
+  return (per_net * nets + 3) / 4;
 }
 
 // generic elementwise Adam over a flat arena (data-parallel path and stand-alone use)
@@ -608,7 +618,8 @@ extern "C" int64_t il_mlp_numel(int32_t in_dim, int32_t hidden, int32_t out_dim)
 extern "C" int64_t il_mlp_stride(int32_t in_dim, int32_t hidden, int32_t out_dim) { return net_stride(in_dim, hidden, out_dim); }
 extern "C" int64_t il_sac_workspace_floats(int32_t S, int32_t A, int32_t H, int32_t B) { return sac_ws(S, A, H, B).total; }
 
-static DwArgs critic_dw_args(const il_sac* d, uint32_t flags) {
+__host__ __device__ static inline int dw_blocks(int IN, int H, int OUT, int nets);
+__host__ __device__ static DwArgs critic_dw_args(const il_sac* d, uint32_t flags) {
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, IN = S + A;
   const SacWs ws = sac_ws(S, A, H, B);
   DwArgs a = {};
@@ -627,17 +638,17 @@ extern "C" int il_sac_critic_step(const il_sac* d, const il_batch* b, const floa
   hipStream_t st = (hipStream_t)stream_;
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
-  { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu); }
-  { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, nullptr, 1); }
-  { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, tile_threads(H), lds, st>>>(*d, *b); }
-  { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b); }
+  { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
+  { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, nullptr, 1, nullptr, nullptr); }
+  { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
+  { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
   DwArgs a = critic_dw_args(d, flags);
   { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<a.n_dw_blocks, 256, 0, st>>>(a); }
   IL_CHECK_LAUNCH("il_sac_critic_step");
   return IL_OK;
 }
 
-static DwArgs actor_dw_args(const il_sac* d, const il_batch* b, uint32_t flags) {
+__host__ __device__ static DwArgs actor_dw_args(const il_sac* d, const il_batch* b, uint32_t flags) {
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch;
   const SacWs ws = sac_ws(S, A, H, B);
   DwArgs a = {};
@@ -658,10 +669,10 @@ extern "C" int il_sac_actor_step(const il_sac* d, const il_batch* b, const float
   hipStream_t st = (hipStream_t)stream_;
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
-  { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 3), 256, 0, st>>>(*d, 0x07u); }  // actor + critics (the critic may have been stepped by il_adam_step)
-  { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, eps_cur, 2); }
-  { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b); }
-  { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q); }
+  { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 3), 256, 0, st>>>(*d, 0x07u, nullptr); }  // actor + critics (the critic may have been stepped by il_adam_step)
+  { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, eps_cur, 2, nullptr, nullptr); }
+  { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
+  { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr); }
   DwArgs a = actor_dw_args(d, b, flags);
   const int tail = 1 + ((flags & IL_FLAG_GRADS_ONLY) ? 0 : 32);
   { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<a.n_dw_blocks + tail, 256, 0, st>>>(a); }
@@ -677,18 +688,18 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   if (!(flags & IL_FLAG_SAC_SKIP_FORWARD)) {
-    if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu); }
+    if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
     // the actor is unchanged until the last kernel of the update: both of its forward passes share one launch; neither this
     // nor the critic/target forward reads the rewards, so a caller may overlap the reward relabel with them (IL_FLAG_SAC_FORWARD_ONLY)
-    { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, 0); }
-    { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, tile_threads(H), lds, st>>>(*d, *b); }
+    { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, 0, nullptr, nullptr); }
+    { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
   }
   if (!(flags & IL_FLAG_SAC_FORWARD_ONLY)) {
-    { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b); }
+    { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
     DwArgs ca = critic_dw_args(d, flags);
     { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
-    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b); }
-    { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q); }
+    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
+    { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr); }
     DwArgs aa = actor_dw_args(d, b, flags);
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 33, 256, 0, st>>>(aa); }
   }
@@ -696,11 +707,47 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
   return IL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Population axis: N independent learners with identical shapes advanced by the SAME launches. descs_dev / batches_dev
+// are device arrays of n_learners descriptors (each learner has its own arenas, optimiser state, workspace, noise counter and batch);
+// gridDim.y (z for k_repack) selects the learner. Kernels are latency-bound at B = 256 (16-64 workgroups): a population fills the chip.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ dL, const il_batch* __restrict__ bL, int kind, uint32_t flags) {
+  const il_sac d = dL[blockIdx.y]; const il_batch b = bL[blockIdx.y];
+  const DwArgs a = kind ? actor_dw_args(&d, &b, flags) : critic_dw_args(&d, flags);
+  dw_adam_body(a);
+}
+
+extern "C" int il_sac_update_population(const il_sac* descs_dev, const il_batch* batches_dev, int32_t n_learners, const il_sac* shape_host, uint32_t flags, il_stream_t stream_) {
+  IL_CHECK_ARG(descs_dev && batches_dev && shape_host && n_learners >= 1 && n_learners <= 65535, "il_sac_update_population: bad arguments");
+  IL_CHECK_ARG(!(flags & IL_FLAG_GRADS_ONLY), "il_sac_update_population: IL_FLAG_GRADS_ONLY is not supported on the population path");
+  const il_sac* d = shape_host;
+  IL_CHECK_ARG(d->hidden % 64 == 0 && d->hidden >= 64 && d->hidden <= 256 && d->batch % IL_TILE_R == 0 && d->batch > 0 && 2 * d->action_dim <= 16, "il_sac_update_population: unsupported shape");
+  hipStream_t st = (hipStream_t)stream_;
+  const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R, L = n_learners;
+  const size_t lds = tile_lds_bytes(round_up16(S + A), H);
+  il_sac z = *d; il_batch zb = {};
+  if (!(flags & IL_FLAG_SAC_SKIP_FORWARD)) {
+    if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5, L), 256, 0, st>>>(z, 0x1Fu, descs_dev); }
+    { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<dim3(2 * nt, L), tile_threads(H), lds, st>>>(z, zb, nullptr, nullptr, 0, descs_dev, batches_dev); }
+    { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<dim3(4 * nt, L), tile_threads(H), lds, st>>>(z, zb, descs_dev, batches_dev); }
+  }
+  if (!(flags & IL_FLAG_SAC_FORWARD_ONLY)) {
+    { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<dim3(2 * nt, L), tile_threads(H), lds, st>>>(z, zb, descs_dev, batches_dev); }
+    { IL_TRACE("k_dw_adam_critic", st); k_dw_adam_pop<<<dim3(dw_blocks(S + A, H, 1, 2), L), 256, 0, st>>>(descs_dev, batches_dev, 0, flags); }
+    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<dim3(2 * nt, L), tile_threads(H), lds, st>>>(z, zb, descs_dev, batches_dev); }
+    { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<dim3(nt, L), tile_threads(H), lds, st>>>(z, zb, nullptr, nullptr, descs_dev, batches_dev); }
+    { IL_TRACE("k_dw_adam_actor", st); k_dw_adam_pop<<<dim3(dw_blocks(S, H, 2 * A, 1) + 33, L), 256, 0, st>>>(descs_dev, batches_dev, 1, flags); }
+  }
+  IL_CHECK_LAUNCH("il_sac_update_population");
+  return IL_OK;
+}
+
 // The lane-ordered weight copies only depend on the parameters: a caller may build them early (e.g. next to the replay sampling on
 // another stream) and pass IL_FLAG_SAC_PREPARED to il_sac_update.
 extern "C" int il_sac_prepare(const il_sac* d, il_stream_t stream_) {
   IL_CHECK_ARG(d && d->workspace && d->hidden % 64 == 0 && d->hidden >= 64 && d->hidden <= 256, "il_sac_prepare: bad descriptor");
-  { IL_TRACE("k_repack", stream_); k_repack<<<dim3(repack_blocks(d->hidden), 5), 256, 0, (hipStream_t)stream_>>>(*d, 0x1Fu); }
+  { IL_TRACE("k_repack", stream_); k_repack<<<dim3(repack_blocks(d->hidden), 5), 256, 0, (hipStream_t)stream_>>>(*d, 0x1Fu, nullptr); }
   IL_CHECK_LAUNCH("il_sac_prepare");
   return IL_OK;
 }
@@ -837,7 +884,7 @@ extern "C" int il_bc_step(float* actor, float* actor_grad, const il_adam* opt, i
   {
     il_sac tmp = {};  // k_repack only needs the dims, the actor arena and the workspace
     tmp.state_dim = S; tmp.action_dim = A; tmp.hidden = H; tmp.batch = b->n; tmp.actor = actor; tmp.workspace = workspace;
-    IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 1), 256, 0, st>>>(tmp, 0x1u);
+    IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 1), 256, 0, st>>>(tmp, 0x1u, nullptr);
   }
   { IL_TRACE("k_bc_tile", st); k_bc_tile<<<nt, tile_threads(H), tile_lds_bytes(round_up16(S + A), H), st>>>(actor, *opt, S, A, H, *b, workspace, out_loss_partials); }
   DwArgs a = {};

@@ -325,3 +325,57 @@ class PopulationPlan:
 
   def replay(self):
     self.graph.replay()
+
+
+def _device_array(structs, device) -> Tensor:
+  """ctypes descriptors -> one device byte tensor (the kernels index it with the learner id)."""
+  raw = b''.join(bytes(x) for x in structs)
+  return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+class BatchedPopulationPlan:
+  """N independent learners with identical shapes advanced by the SAME kernel launches (`il_*_population`): the learner id is a grid
+  dimension, so one update of the whole population costs 11 launches instead of 11 N.  This is the route from the latency-bound
+  single-learner regime towards the HBM roofline.  Every learner keeps its own replay ring, MT19937 index stream,
+  networks, optimiser state, scratch and Philox counter (build the `UpdatePlan`s with distinct `learner_id`s)."""
+
+  def __init__(self, plans):
+    self.plans = list(plans)
+    p0 = self.plans[0]
+    assert all(p.algorithm == p0.algorithm and p.B == p0.B for p in self.plans)
+    self.algorithm, self.B, self.L, dev = p0.algorithm, p0.B, len(self.plans), p0.rows.device
+    self.sac_descs = _device_array([p.sac for p in self.plans], dev)
+    self.batches = _device_array([p.pb for p in self.plans], dev)
+    args = []
+    for p in self.plans:
+      m, e = p.memory, (p.expert_memory if p.algorithm == 'GAIL' else None)
+      st = m.stream().device_state(dev)
+      args.append(_lib.SampleArgs(st.data_ptr(), m._ring_state.data_ptr(), m.ring.data_ptr(), m.size, m.row, p.idx.data_ptr(), p.rows.data_ptr(),
+                                  e._ring_state.data_ptr() if e else None, e.ring.data_ptr() if e else None, e.size if e else 0, e.row if e else 0,
+                                  p.eidx.data_ptr() if e else None, p.erows.data_ptr() if e else None))
+    self.sample_args = _device_array(args, dev)
+    self.max_row = max([p.memory.row for p in self.plans] + [p.expert_memory.row for p in self.plans if p.algorithm == 'GAIL'])
+    if self.algorithm == 'GAIL':
+      self.disc_descs = _device_array([p.disc for p in self.plans], dev)
+      self.expert_batches = _device_array([p.eb for p in self.plans], dev)
+      self.reward_ptrs = torch.tensor([p.rewards.data_ptr() for p in self.plans], dtype=torch.int64, device=dev)
+    self.graph = None
+
+  def run(self):
+    L, st, p0 = _lib.lib(), _lib.stream_ptr(), self.plans[0]
+    _lib.check(L.il_replay_sample_population(_lib.ptr(self.sample_args), self.L, self.B, self.max_row, st))
+    if self.algorithm == 'GAIL':
+      _lib.check(L.il_gail_step_population(_lib.ptr(self.disc_descs), _lib.ptr(self.batches), _lib.ptr(self.expert_batches), _lib.ptr(self.reward_ptrs), self.L, C.byref(p0.disc), st))
+    _lib.check(L.il_sac_update_population(_lib.ptr(self.sac_descs), _lib.ptr(self.batches), self.L, C.byref(p0.sac), 0, st))
+
+  def capture(self, warmup: int = 0):
+    for _ in range(warmup):
+      self.run()
+    torch.cuda.synchronize()
+    self.graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(self.graph):
+      self.run()
+    return self
+
+  def replay(self):
+    self.graph.replay()

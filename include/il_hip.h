@@ -98,6 +98,14 @@ int il_replay_sample_device(uint32_t* state_dev, int32_t n, const int64_t* ring_
                             int32_t* idx_a, float* rows_a, const int64_t* ring_state_b, const float* ring_b, int64_t capacity_b, int32_t row_floats_b,
                             int32_t* idx_b, float* rows_b, il_stream_t stream);
 
+/* Population axis: per-learner arguments of il_replay_sample_device, as a device array. */
+typedef struct il_sample_args {
+  uint32_t* state;                 /* this learner's MT19937 state (625 uint32, device) */
+  const int64_t* ring_state_a; const float* ring_a; int64_t capacity_a; int32_t row_floats_a; int32_t* idx_a; float* rows_a;
+  const int64_t* ring_state_b; const float* ring_b; int64_t capacity_b; int32_t row_floats_b; int32_t* idx_b; float* rows_b;   /* ring_b may be NULL */
+} il_sample_args;
+int il_replay_sample_population(const il_sample_args* args_dev, int32_t n_learners, int32_t n, int32_t max_row_floats, il_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimiser state (torch.optim.AdamW / Adam single-tensor step; reference train.py:66,84,95).
  * ------------------------------------------------------------------------------------------ */
@@ -148,6 +156,11 @@ int il_sac_actor_step(const il_sac* d, const il_batch* batch, const float* eps_c
 /* DP tail after the all-reduce of actor_grad/alpha_grad: AdamW(actor) + Adam(log_alpha) + polyak (same kernels, no recompute). */
 int il_sac_apply_actor_grads(const il_sac* d, il_stream_t stream);
 int il_sac_apply_critic_grads(const il_sac* d, il_stream_t stream);
+/* Population axis (the reference's own usage: 10-seed sweeps, Ax trials -- README.md:96-99, train_all.py:26): n_learners independent
+ * learners with identical shapes advanced by the same launches. descs_dev / batches_dev are DEVICE arrays of descriptors (each learner
+ * owns its arenas, optimiser state, workspace, noise counter, batch); shape_host supplies the common dimensions. Philox noise only. */
+int il_sac_update_population(const il_sac* descs_dev, const il_batch* batches_dev, int32_t n_learners, const il_sac* shape_host, uint32_t flags,
+                             il_stream_t stream);
 /* Builds the lane-ordered copies of the hidden-layer weights in the workspace (k_repack). il_sac_update does this itself unless told
  * IL_FLAG_SAC_PREPARED; exposing it lets a caller overlap it with the replay sampling. */
 int il_sac_prepare(const il_sac* d, il_stream_t stream);
@@ -189,6 +202,9 @@ int64_t il_disc_workspace_floats(int32_t in_dim, int32_t hidden, int32_t batch);
 int il_gail_disc_step(const il_disc* d, const il_batch* policy, const il_batch* expert, const float* eps_gp, uint32_t flags,
                       il_stream_t stream);
 int il_gail_apply_grads(const il_disc* d, il_stream_t stream);
+/* Population axis: discriminator step + AIRL/GAIL/FAIRL reward relabel for n_learners discriminators; rewards_out_dev[l] -> float[batch]. */
+int il_gail_step_population(const il_disc* descs_dev, const il_batch* policy_dev, const il_batch* expert_dev, float* const* rewards_out_dev,
+                            int32_t n_learners, const il_disc* shape_host, il_stream_t stream);
 /* models.py:177-180 predict_reward (eval mode: no power iteration). out_logits may be NULL. */
 int il_gail_reward(const il_disc* d, const il_batch* batch, float* out_rewards, float* out_logits, il_stream_t stream);
 
