@@ -138,6 +138,58 @@ def cpu_baseline(tr, et, budget_s=12.0):
               sample=f'{k} SAC+GAIL updates (numpy float32 oracle port of train.py:173-203, batch {B}, same synthetic buffers) in {dt:.1f} s on {os.cpu_count()} host cores')
 
 
+def roofline(run_fn, trace_steps, units_per_launch, ms_per_step, side_stream_disc):
+  """Per-kernel average durations from HIP events recorded on the launch stream(s) (il_trace_*), eager launches of the same kernels;
+  `units_per_launch` = updates one launch advances (1, or the number of learners on the population path)."""
+  from imitation_learning_amd import _lib
+  bytes_k, flops_k, update_bytes, update_flops = algorithmic_model()
+  L = _lib.lib()
+  L.il_trace_enable(1)
+  for _ in range(trace_steps):
+    run_fn()
+  buf = C.create_string_buffer(1 << 16)
+  _lib.check(L.il_trace_report(buf, len(buf)))
+  L.il_trace_enable(0)
+  kern = {}
+  for line in buf.value.decode().strip().splitlines():
+    name, cnt, tot = line.split()
+    kern[name] = dict(launches_per_update=int(cnt) / trace_steps, avg_us=float(tot) / int(cnt) * 1e3)
+  # dominant = largest share of the critical path: the discriminator kernels run on the side stream next to the SAC forward kernels
+  side = ('k_gail_grad', 'k_gail_reduce', 'k_gail_reward') if side_stream_disc else ()
+  dom = max((k for k in kern if k not in side), key=lambda k: kern[k]['avg_us'] * kern[k]['launches_per_update'])
+  per_kernel = {}
+  for k, v in kern.items():
+    e = dict(avg_us=round(v['avg_us'], 3), launches_per_update=v['launches_per_update'])
+    if k in bytes_k:
+      e['hbm_GBps'] = round(units_per_launch * bytes_k[k] / (v['avg_us'] * 1e-6) / 1e9, 2)
+    if k in flops_k:
+      e['fp32_TFLOPs'] = round(units_per_launch * flops_k[k] / (v['avg_us'] * 1e-6) / 1e12, 3)
+    per_kernel[k] = e
+  if dom in flops_k:
+    ach = units_per_launch * flops_k[dom] / (kern[dom]['avg_us'] * 1e-6) / 1e12
+    roof = dict(bound='mfma', kernel=dom, note='fp32: MFMA f32 rate == VALU f32 rate == 157.3 TFLOP/s on gfx950', achieved=round(ach, 3), peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
+                frac=round(ach / FP32_PEAK_TFLOPS, 5), traffic=None)
+  else:
+    ach = units_per_launch * bytes_k.get(dom, 0) / (kern[dom]['avg_us'] * 1e-6) / 1e9
+    roof = dict(bound='hbm', kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 5), traffic=None)
+  try:  # HBM-side bytes per launch from the committed PMC passes (profiles/pmc_latest.json; collected with rocprofv3 --pmc, not in this run)
+    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')))['kernels']
+    if units_per_launch == 1:
+      key = 'k_dw_adam' if dom.startswith('k_dw_adam') else dom
+      roof['traffic'] = pmc.get(key, {}).get('traffic_bytes')
+      for k, e in per_kernel.items():
+        kk = 'k_dw_adam' if k.startswith('k_dw_adam') else k
+        if kk in pmc: e['hbm_traffic_bytes'] = pmc[kk]['traffic_bytes']
+  except Exception:
+    pass
+  upd_gbs = units_per_launch * update_bytes / (ms_per_step * 1e-3) / 1e9
+  roof['update'] = dict(algorithmic_bytes=update_bytes, achieved_GBps=round(upd_gbs, 2), hbm_frac=round(upd_gbs / HBM_PEAK_GBS, 5), algorithmic_flops=update_flops,
+                        fp32_frac=round(units_per_launch * update_flops / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5),
+                        sum_kernel_us=round(sum(v['avg_us'] * v['launches_per_update'] for v in kern.values()), 2))
+  roof['kernels'] = per_kernel
+  return roof
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -147,6 +199,7 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--trace-steps', type=int, default=100)
   ap.add_argument('--no-population', action='store_true')
+  ap.add_argument('--population-learners', type=int, default=16)
   ap.add_argument('--learners', type=int, default=1, help='population axis: N independent learners per GPU advanced by one graph replay (aggregate updates/s)')
   args = ap.parse_args()
 
@@ -204,52 +257,10 @@ def main():
   finite = all(bool(torch.isfinite(n.flat if hasattr(n, 'flat') else n).all()) for n in nets)
 
   if rank == 0:
-    bytes_k, flops_k, update_bytes, update_flops = algorithmic_model()
     ms_per_step = elapsed / args.steps * 1e3
     ups = world * args.learners * args.steps / elapsed
     # ---- per-kernel durations, HIP events on the launch stream, eager launches of the very same kernels
-    L = _lib.lib()
-    L.il_trace_enable(1)
-    for _ in range(args.trace_steps):
-      plan.run()
-    buf = C.create_string_buffer(1 << 16)
-    _lib.check(L.il_trace_report(buf, len(buf)))
-    L.il_trace_enable(0)
-    kern = {}
-    for line in buf.value.decode().strip().splitlines():
-      name, cnt, tot = line.split()
-      kern[name] = dict(launches_per_update=int(cnt) / args.trace_steps, avg_us=float(tot) / int(cnt) * 1e3)
-    # dominant = largest share of the critical path: the discriminator kernels run on the side stream next to the SAC forward kernels
-    side = ('k_gail_grad', 'k_gail_reduce', 'k_gail_reward') if getattr(plan, 'overlap', False) else ()
-    dom = max((k for k in kern if k not in side), key=lambda k: kern[k]['avg_us'] * kern[k]['launches_per_update'])
-    per_kernel = {}
-    for k, v in kern.items():
-      e = dict(avg_us=round(v['avg_us'], 3), launches_per_update=v['launches_per_update'])
-      if k in bytes_k:
-        e['hbm_GBps'] = round(bytes_k[k] / (v['avg_us'] * 1e-6) / 1e9, 2)
-      if k in flops_k:
-        e['fp32_TFLOPs'] = round(flops_k[k] / (v['avg_us'] * 1e-6) / 1e12, 3)
-      per_kernel[k] = e
-    if dom in flops_k:
-      ach = flops_k[dom] / (kern[dom]['avg_us'] * 1e-6) / 1e12
-      roof = dict(bound='mfma', kernel=dom, note='fp32: MFMA f32 rate == VALU f32 rate == 157.3 TFLOP/s on gfx950', achieved=round(ach, 3), peak=FP32_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / FP32_PEAK_TFLOPS, 5), traffic=None)
-    else:
-      ach = bytes_k.get(dom, 0) / (kern[dom]['avg_us'] * 1e-6) / 1e9
-      roof = dict(bound='hbm', kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 5), traffic=None)
-    try:  # HBM-side bytes per launch from the committed PMC passes (profiles/pmc_latest.json; collected with rocprofv3 --pmc, not in this run)
-      pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')))['kernels']
-      key = 'k_dw_adam' if dom.startswith('k_dw_adam') else dom
-      roof['traffic'] = pmc.get(key, {}).get('traffic_bytes')
-      for k, e in per_kernel.items():
-        kk = 'k_dw_adam' if k.startswith('k_dw_adam') else k
-        if kk in pmc: e['hbm_traffic_bytes'] = pmc[kk]['traffic_bytes']
-    except Exception:
-      pass
-    upd_gbs = update_bytes / (ms_per_step * 1e-3) / 1e9
-    roof['update'] = dict(algorithmic_bytes=update_bytes, achieved_GBps=round(upd_gbs, 2), hbm_frac=round(upd_gbs / HBM_PEAK_GBS, 5), algorithmic_flops=update_flops,
-                          fp32_frac=round(update_flops / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5),
-                          sum_kernel_us=round(sum(v['avg_us'] * v['launches_per_update'] for v in kern.values()), 2))
-    roof['kernels'] = per_kernel
+    roof = roofline(plan.run, args.trace_steps, 1, ms_per_step, getattr(plan, 'overlap', False))
     out = dict(metric='SAC+GAIL grad-updates/sec (batch 256, HalfCheetah dims)', value=round(ups, 1), unit='updates/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=round(ms_per_step, 5), higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                config=dict(workload='algorithm=GAIL env=halfcheetah: 2 replay samples + discriminator step (BCE+GP+SN) + AIRL relabel + sac_update per step',
@@ -257,26 +268,27 @@ def main():
                            learners_per_gpu=args.learners, parallelism=f'dp{world}' + ('(split path)' if runner is not plan else ''), launch='eager' if args.no_graph else 'hipGraph replay', noise='on-chip Philox4x32-10', finite=finite),
                roofline=roof)
     if world == 1 and args.learners == 1 and not args.no_population:
-      # population axis (the reference's own usage: 10-seed sweeps / Ax trials): 8 independent learners as concurrent
-      # branches of one hipGraph. Reported next to, never instead of, the single-learner `value`.
-      from imitation_learning_amd import PopulationPlan
-      Lp = 8
-      pop = PopulationPlan([build(device, rank, seed=100 + l, learner_id=100 + l)[0] for l in range(Lp)])
+      # population axis (the reference's own usage: 10-seed sweeps / Ax trials): independent batch-256 learners advanced by the
+      # SAME launches (learner id = grid dimension). Reported next to, never instead of, the single-learner `value`.
+      from imitation_learning_amd import BatchedPopulationPlan
+      Lp = args.population_learners
+      pop = BatchedPopulationPlan([build(device, rank, seed=100 + l, learner_id=100 + l)[0] for l in range(Lp)])
       for _ in range(3):
         pop.run()
       torch.cuda.synchronize()
       pop.capture()
-      for _ in range(50):
+      for _ in range(30):
         pop.replay()
       torch.cuda.synchronize()
       t1 = time.perf_counter()
-      for _ in range(300):
+      for _ in range(200):
         pop.replay()
       torch.cuda.synchronize()
-      dt = time.perf_counter() - t1
-      agg = Lp * 300 / dt
-      out['population'] = dict(learners=Lp, aggregate_updates_per_s=round(agg, 1), ms_per_replay=round(dt / 300 * 1e3, 5),
-                               hbm_frac=round(agg * update_bytes / 1e9 / HBM_PEAK_GBS, 5), note='8 independent batch-256 learners per hipGraph replay (one branch each)')
+      dt = (time.perf_counter() - t1) / 200
+      proof = roofline(pop.run, 10, Lp, dt * 1e3, False)
+      proof.pop('kernels', None)
+      out['population'] = dict(learners=Lp, aggregate_updates_per_s=round(Lp / dt, 1), ms_per_replay=round(dt * 1e3, 5), roofline=proof,
+                               note=f'{Lp} independent batch-256 SAC+GAIL learners per launch (il_*_population: learner id = grid dimension), own replay ring / index stream / Philox counter each')
       del pop
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(tr, et)

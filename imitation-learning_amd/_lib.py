@@ -31,7 +31,8 @@ class Sac(C.Structure):
               ('actor_grad', C.c_void_p), ('critic_grad', C.c_void_p), ('alpha_grad', C.c_void_p),
               ('actor_opt', Adam), ('critic_opt', Adam), ('alpha_opt', Adam),
               ('discount', C.c_float), ('entropy_target', C.c_float), ('polyak', C.c_double),
-              ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p)]
+              ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p),
+              ('out_logp', C.c_void_p), ('out_q', C.c_void_p)]
 
 
 class Disc(C.Structure):

@@ -345,6 +345,8 @@ __global__ __launch_bounds__(1024) void k_actor_bwd(il_sac d, il_batch b, float*
                                                     const il_batch* __restrict__ bL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
+  if (!out_logp) out_logp = d.out_logp;
+  if (!out_q) out_q = d.out_q;
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
   const int tile = (int)blockIdx.x, row0 = tile * IL_TILE_R;
   const int ldh = H + 4, ldz = 20;

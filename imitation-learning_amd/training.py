@@ -206,6 +206,7 @@ class UpdatePlan:
     tag, off = learner_id, (0 if learner_id is None else 7919 * (int(learner_id) + 1))
     self.sac = sac_descriptor(actor, critic, log_alpha, target_critic, batch_size, actor_optimiser, critic_optimiser, temperature_optimiser, discount, entropy_target, polyak_factor,
                               tag=tag, seed_offset=off)
+    self.sac.out_logp, self.sac.out_q = self.logp.data_ptr(), self.q.data_ptr()
     self._keep = (actor, critic, log_alpha, target_critic, actor_optimiser, critic_optimiser, temperature_optimiser, discriminator, discriminator_optimiser)
     if algorithm == 'GAIL':
       self.erows = torch.empty(batch_size, expert_memory.row, device=dev); self.eidx = torch.empty(batch_size, dtype=torch.int32, device=dev)

@@ -138,6 +138,7 @@ typedef struct il_sac {
   int64_t workspace_floats;
   uint64_t noise_seed;       /* Philox4x32-10 key when eps pointers are NULL */
   uint32_t* noise_counter;   /* device uint32, incremented once per il_sac_actor_step */
+  float *out_logp, *out_q;   /* optional [B] outputs (training.py:54) used when the call passes NULL output pointers (population path) */
 } il_sac;
 
 int64_t il_mlp_numel(int32_t in_dim, int32_t hidden, int32_t out_dim);
