@@ -1,11 +1,11 @@
 """Developer tool: per-phase cycle counts (s_memtime) inside k_gail_grad and k_policy_critic.
 Build the stamped library first (never shipped):
-  cd imitation-learning_amd/csrc \&\& hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DIL_PHASE_STAMPS -shared *.hip -o ../../gpurun_out/libil_hip_stamps.so
+  cd imitation-learning_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DIL_PHASE_STAMPS -shared *.hip -o build/libil_hip_stamps.so
 then run this script on the GPU box."""
 import sys, os, ctypes as C
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/golden')
 from imitation_learning_amd import _lib
-_lib.LIB_PATH = os.path.abspath(os.environ.get('IL_STAMP_LIB', 'gpurun_out/libil_hip_stamps.so'))  # built with -DIL_PHASE_STAMPS, see the header of this file
+_lib.LIB_PATH = os.path.abspath(os.environ.get('IL_STAMP_LIB', 'imitation-learning_amd/csrc/build/libil_hip_stamps.so'))  # built with -DIL_PHASE_STAMPS, see the header of this file
 import torch
 import imitation_learning_amd as il
 from imitation_learning_amd import training as il_training
