@@ -772,6 +772,86 @@ extern "C" int il_polyak(float* target, const float* param, int64_t n, double ta
   return IL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Data-parallel schedule of one update: the fused path's kernels with the AdamW steps split off so that the caller can all-reduce the
+// gradient arenas in between.  phase 0: re-order weights, actor forward (s' and s), critic/target forward (reward-independent)
+//                              phase 1: critic loss + backward, critic gradients -> critic_grad          [all-reduce critic_grad]
+//                              phase 2: AdamW(critic) (+ lane-ordered copies), policy loss through the updated critic, actor/alpha
+//                                       gradients -> actor_grad / alpha_grad                              [all-reduce actor_grad|alpha_grad]
+//                              phase 3: AdamW(actor), Adam(log_alpha), polyak -- one launch
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_apply_critic(il_sac d) {
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, IN = S + A;
+  const SacWs ws = sac_ws(S, A, H, d.batch);
+  const int64_t ns = net_stride(IN, H, 1), HH = (int64_t)H * H, oW2 = (int64_t)H * IN + H;
+  const adam_consts ac = load_adam_consts(d.critic_opt);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < 2 * ns; e += (int64_t)gridDim.x * blockDim.x) {
+    float pp = d.critic[e], mm = d.critic_opt.m[e], vv = d.critic_opt.v[e];
+    adam_update(pp, d.critic_grad[e], mm, vv, ac);
+    d.critic[e] = pp; d.critic_opt.m[e] = mm; d.critic_opt.v[e] = vv;
+    const int k = e >= ns; const int64_t o = e - k * ns - oW2;
+    if (o >= 0 && o < HH) {  // an element of a hidden-layer matrix: keep its two lane-ordered copies in step
+      const int n = (int)(o / H), kk = (int)(o - (int64_t)n * H);
+      d.workspace[ws.pk_cf + k * HH + packed_fwd_index(n, kk, H)] = pp;
+      d.workspace[ws.pk_cb + k * HH + packed_bwd_index(n, kk, H)] = pp;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_apply_actor_tail(il_sac d, int n_actor_blocks) {
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, IN = S + A;
+  if ((int)blockIdx.x < n_actor_blocks) {
+    const int64_t Pa = mlp_numel(S, H, 2 * A);
+    const adam_consts ac = load_adam_consts(d.actor_opt);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < Pa; e += (int64_t)n_actor_blocks * blockDim.x) {
+      float pp = d.actor[e], mm = d.actor_opt.m[e], vv = d.actor_opt.v[e];
+      adam_update(pp, d.actor_grad[e], mm, vv, ac);
+      d.actor[e] = pp; d.actor_opt.m[e] = mm; d.actor_opt.v[e] = vv;
+    }
+    return;
+  }
+  const int tb = (int)blockIdx.x - n_actor_blocks, ntb = (int)gridDim.x - n_actor_blocks;
+  if (tb == 0 && threadIdx.x == 0) {
+    const adam_consts ac = load_adam_consts(d.alpha_opt);
+    float pp = d.log_alpha[0], mm = d.alpha_opt.m[0], vv = d.alpha_opt.v[0];
+    adam_update(pp, d.alpha_grad[0], mm, vv, ac);
+    d.log_alpha[0] = pp; d.alpha_opt.m[0] = mm; d.alpha_opt.v[0] = vv;
+  }
+  const int64_t n = 2 * net_stride(IN, H, 1);
+  const float omt = (float)(1.0 - d.polyak), tau = (float)d.polyak;
+  for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < n; i += (int64_t)ntb * blockDim.x) d.target[i] = __fadd_rn(__fmul_rn(d.target[i], tau), __fmul_rn(omt, d.critic[i]));
+}
+
+extern "C" int il_sac_dp_phase(const il_sac* d, const il_batch* b, int32_t phase, float* out_logp, float* out_q, il_stream_t stream_) {
+  if (int rc = check_sac(d, b)) return rc;
+  IL_CHECK_ARG(phase >= 0 && phase <= 3, "il_sac_dp_phase: phase must be 0..3");
+  IL_CHECK_ARG(d->actor_grad && d->critic_grad && d->alpha_grad, "il_sac_dp_phase: gradient arenas missing");
+  hipStream_t st = (hipStream_t)stream_;
+  const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
+  const size_t lds = tile_lds_bytes(round_up16(S + A), H);
+  if (phase == 0) {
+    { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
+    { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr, 0, nullptr, nullptr); }
+    { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
+  } else if (phase == 1) {
+    { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
+    DwArgs ca = critic_dw_args(d, IL_FLAG_GRADS_ONLY);
+    { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
+  } else if (phase == 2) {
+    const int64_t n = 2 * net_stride(S + A, H, 1);
+    { IL_TRACE("k_apply_critic", st); k_apply_critic<<<(int)((n + 255) / 256), 256, 0, st>>>(*d); }
+    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
+    { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr); }
+    DwArgs aa = actor_dw_args(d, b, IL_FLAG_GRADS_ONLY);
+    { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 1, 256, 0, st>>>(aa); }
+  } else {
+    const int na = (int)((mlp_numel(S, H, 2 * A) + 255) / 256);
+    { IL_TRACE("k_apply_actor_tail", st); k_apply_actor_tail<<<na + 64, 256, 0, st>>>(*d, na); }
+  }
+  IL_CHECK_LAUNCH("il_sac_dp_phase");
+  return IL_OK;
+}
+
 extern "C" int il_sac_apply_critic_grads(const il_sac* d, il_stream_t stream_) {
   IL_CHECK_ARG(d && d->critic_grad, "il_sac_apply_critic_grads: critic_grad arena missing");
   return il_adam_step(d->critic, d->critic_grad, &d->critic_opt, 2 * net_stride(d->state_dim + d->action_dim, d->hidden, 1), 0, stream_);

@@ -54,24 +54,33 @@ class DataParallelUpdate:
     self.actor_bucket = torch.zeros((n + 1 + 3) // 4 * 4, device=ao.grad.device)
     ao.grad, to.grad = self.actor_bucket[:n], self.actor_bucket[n:n + 1]
     plan.sac.actor_grad, plan.sac.alpha_grad = ao.grad.data_ptr(), to.grad.data_ptr()
+    self.side = torch.cuda.Stream() if plan.algorithm == 'GAIL' else None
     self.critic_bucket = plan._keep[5].grad
     self.disc_bucket = plan._keep[8].grad if plan.algorithm == 'GAIL' else None
 
   def run(self):
-    p, L, st = self.plan, _lib.lib(), _lib.stream_ptr()
+    """sample -> [side stream: discriminator grads -> all-reduce -> AdamW -> reward | main: SAC forward] -> critic grads -> all-reduce ->
+    AdamW(critic) + actor grads -> all-reduce -> AdamW(actor) + Adam(alpha) + polyak.  The discriminator's all-reduce hides under the
+    SAC forward kernels; the critic and actor all-reduces are on the critical path (the algorithm orders them)."""
+    p, L = self.plan, _lib.lib()
     G = _lib.IL_FLAG_GRADS_ONLY
     p.sample_all()
+    main = torch.cuda.current_stream()
     if p.algorithm == 'GAIL':
-      _lib.check(L.il_gail_disc_step(C.byref(p.disc), C.byref(p.pb), C.byref(p.eb), None, G, st))
-      all_reduce_mean_(self.disc_bucket, self.group)
-      _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
-      _lib.check(L.il_gail_reward(C.byref(p.disc), C.byref(p.pb), _lib.ptr(p.rewards), None, _lib.stream_ptr()))
-    _lib.check(L.il_sac_critic_step(C.byref(p.sac), C.byref(p.pb), None, G, _lib.stream_ptr()))
+      self.side.wait_stream(main)
+      with torch.cuda.stream(self.side):
+        _lib.check(L.il_gail_disc_step(C.byref(p.disc), C.byref(p.pb), C.byref(p.eb), None, G, _lib.stream_ptr()))
+        all_reduce_mean_(self.disc_bucket, self.group)
+        _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
+        _lib.check(L.il_gail_reward(C.byref(p.disc), C.byref(p.pb), _lib.ptr(p.rewards), None, _lib.stream_ptr()))
+    _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 0, None, None, _lib.stream_ptr()))
+    if p.algorithm == 'GAIL':
+      main.wait_stream(self.side)
+    _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 1, None, None, _lib.stream_ptr()))
     all_reduce_mean_(self.critic_bucket, self.group)
-    _lib.check(L.il_sac_apply_critic_grads(C.byref(p.sac), _lib.stream_ptr()))
-    _lib.check(L.il_sac_actor_step(C.byref(p.sac), C.byref(p.pb), None, _lib.ptr(p.logp), _lib.ptr(p.q), G, _lib.stream_ptr()))
+    _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 2, _lib.ptr(p.logp), _lib.ptr(p.q), _lib.stream_ptr()))
     all_reduce_mean_(self.actor_bucket, self.group)
-    _lib.check(L.il_sac_apply_actor_grads(C.byref(p.sac), _lib.stream_ptr()))
+    _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 3, None, None, _lib.stream_ptr()))
 
   def capture(self, warmup: int = 3):
     self.plan.memory.stream().device_state(self.plan.rows.device)

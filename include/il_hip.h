@@ -154,6 +154,10 @@ int il_sac_critic_step(const il_sac* d, const il_batch* batch, const float* eps_
  * eps_cur [B,A] = rsample noise on s.  out_logp/out_q [B] = the (log_probs, Q_values) the reference returns (:54). */
 int il_sac_actor_step(const il_sac* d, const il_batch* batch, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags,
                       il_stream_t stream);
+/* Data-parallel schedule of one update in four phases (0 forward, 1 critic gradients, 2 AdamW(critic) + actor/alpha gradients,
+ * 3 AdamW(actor) + Adam(log_alpha) + polyak); the caller all-reduces critic_grad after phase 1 and actor_grad|alpha_grad after phase 2.
+ * Same kernels as il_sac_update, Philox noise. */
+int il_sac_dp_phase(const il_sac* d, const il_batch* batch, int32_t phase, float* out_logp, float* out_q, il_stream_t stream);
 /* DP tail after the all-reduce of actor_grad/alpha_grad: AdamW(actor) + Adam(log_alpha) + polyak (same kernels, no recompute). */
 int il_sac_apply_actor_grads(const il_sac* d, il_stream_t stream);
 int il_sac_apply_critic_grads(const il_sac* d, il_stream_t stream);
