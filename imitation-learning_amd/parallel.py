@@ -11,6 +11,7 @@ Replicas stay bit-identical because every rank applies the same averaged gradien
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -21,8 +22,8 @@ from . import _lib
 
 def all_reduce_mean_(bucket: torch.Tensor, group=None):
   """In-place mean over ranks. NCCL/RCCL has a native AVG; gloo (CPU tests) sums then scales."""
-  if not dist.is_initialized() or dist.get_world_size(group) == 1:
-    return bucket
+  if not dist.is_initialized() or (dist.get_world_size(group) == 1 and os.environ.get('IL_FORCE_ALLREDUCE') != '1'):
+    return bucket  # IL_FORCE_ALLREDUCE=1 issues the collective even on one rank (exercises the RCCL + graph-capture path on a 1-GPU box)
   if dist.get_backend(group) == 'nccl':
     dist.all_reduce(bucket, op=dist.ReduceOp.AVG, group=group)
   else:
