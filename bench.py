@@ -209,9 +209,10 @@ def main():
   torch.cuda.set_device(local)
   device = torch.device('cuda', local)
   import torch.distributed as dist
-  if world > 1:
+  if world > 1 or os.environ.get('IL_FORCE_ALLREDUCE') == '1':
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', device_id=device)
+    os.environ.setdefault('MASTER_PORT', '29517')
+    dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
   from imitation_learning_amd import _lib
   from imitation_learning_amd.parallel import DataParallelUpdate, broadcast_parameters
 
@@ -293,7 +294,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(tr, et)
     print(json.dumps(out))
-  if world > 1:
+  if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()
 
