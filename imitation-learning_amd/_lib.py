@@ -84,7 +84,7 @@ _SIGNATURES = {
     'il_sac_apply_actor_grads': (C.c_int, [C.POINTER(Sac), _P]),
     'il_sac_apply_critic_grads': (C.c_int, [C.POINTER(Sac), _P]),
     'il_sac_prepare': (C.c_int, [C.POINTER(Sac), _P]),
-    'il_sac_dp_phase': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.c_int32, _P, _P, _P]),
+    'il_sac_dp_phase': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.c_int32, _P, _P, C.c_uint32, _P]),
     'il_sac_update': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), _P, _P, _P, _P, C.c_uint32, _P]),
     'il_bc_step': (C.c_int, [_P, _P, C.POINTER(Adam), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Batch), _P, C.c_int64, _P, C.c_uint32, _P]),
     'il_actor_act': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_uint64, C.c_uint32, C.c_int32, _P, _P, _P]),

@@ -429,6 +429,7 @@ struct DwArgs {
   // tail
   float* log_alpha; float* alpha_grad; il_adam alpha_opt; const float* alpha_part; int n_alpha_part;
   float* target; const float* polyak_src; int64_t polyak_n; double tau; uint32_t* noise_counter;
+  float* pk_target; const float* pk_critic; int64_t pk_n;   // lane-ordered copies of the target / critic hidden layers (polyak is elementwise, so it commutes with the re-ordering)
 };
 
 __device__ __forceinline__ void adam_store(const DwArgs& a, const adam_consts& ac, int64_t o, float gr) {
@@ -536,6 +537,13 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a) {
           for (int64_t q = i; q < a.polyak_n; ++q) a.target[q] = __fadd_rn(__fmul_rn(a.target[q], tau), __fmul_rn(omt, a.polyak_src[q]));
         }
       }
+      if (a.pk_target)
+        for (int64_t i = ((int64_t)tb * blockDim.x + threadIdx.x) * 4; i < a.pk_n; i += (int64_t)ntb * blockDim.x * 4) {
+          f32x4 t = *reinterpret_cast<f32x4*>(a.pk_target + i); const f32x4 p = *reinterpret_cast<const f32x4*>(a.pk_critic + i);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t[q] = __fadd_rn(__fmul_rn(t[q], tau), __fmul_rn(omt, p[q]));
+          *reinterpret_cast<f32x4*>(a.pk_target + i) = t;
+        }
     }
     return;
   }
@@ -663,6 +671,7 @@ __host__ __device__ static DwArgs actor_dw_args(const il_sac* d, const il_batch*
   a.n_dw_blocks = dw_blocks(S, H, 2 * A, 1);
   a.log_alpha = d->log_alpha; a.alpha_grad = d->alpha_grad; a.alpha_opt = d->alpha_opt; a.alpha_part = d->workspace + ws.alpha_part; a.n_alpha_part = B / IL_TILE_R;
   a.target = d->target; a.polyak_src = d->critic; a.polyak_n = 2 * net_stride(S + A, H, 1); a.tau = d->polyak; a.noise_counter = d->noise_counter;
+  a.pk_target = d->workspace + ws.pk_tf; a.pk_critic = d->workspace + ws.pk_cf; a.pk_n = 4 * (int64_t)H * H;   // pk_tf|pk_tb and pk_cf|pk_cb are adjacent pairs
   return a;
 }
 
@@ -803,10 +812,18 @@ __global__ __launch_bounds__(256) void k_apply_actor_tail(il_sac d, int n_actor_
   if ((int)blockIdx.x < n_actor_blocks) {
     const int64_t Pa = mlp_numel(S, H, 2 * A);
     const adam_consts ac = load_adam_consts(d.actor_opt);
+    const SacWs wsa = sac_ws(S, A, H, d.batch);
+    const int64_t oW2 = (int64_t)H * S + H, HH = (int64_t)H * H;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < Pa; e += (int64_t)n_actor_blocks * blockDim.x) {
       float pp = d.actor[e], mm = d.actor_opt.m[e], vv = d.actor_opt.v[e];
       adam_update(pp, d.actor_grad[e], mm, vv, ac);
       d.actor[e] = pp; d.actor_opt.m[e] = mm; d.actor_opt.v[e] = vv;
+      const int64_t o = e - oW2;
+      if (o >= 0 && o < HH) {
+        const int n = (int)(o / H), kk = (int)(o - (int64_t)n * H);
+        d.workspace[wsa.pk_af + packed_fwd_index(n, kk, H)] = pp;
+        d.workspace[wsa.pk_ab + packed_bwd_index(n, kk, H)] = pp;
+      }
     }
     return;
   }
@@ -820,9 +837,12 @@ __global__ __launch_bounds__(256) void k_apply_actor_tail(il_sac d, int n_actor_
   const int64_t n = 2 * net_stride(IN, H, 1);
   const float omt = (float)(1.0 - d.polyak), tau = (float)d.polyak;
   for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < n; i += (int64_t)ntb * blockDim.x) d.target[i] = __fadd_rn(__fmul_rn(d.target[i], tau), __fmul_rn(omt, d.critic[i]));
+  const SacWs ws = sac_ws(S, A, H, d.batch);
+  float* pt = d.workspace + ws.pk_tf; const float* pc = d.workspace + ws.pk_cf;
+  for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < 4 * (int64_t)H * H; i += (int64_t)ntb * blockDim.x) pt[i] = __fadd_rn(__fmul_rn(pt[i], tau), __fmul_rn(omt, pc[i]));
 }
 
-extern "C" int il_sac_dp_phase(const il_sac* d, const il_batch* b, int32_t phase, float* out_logp, float* out_q, il_stream_t stream_) {
+extern "C" int il_sac_dp_phase(const il_sac* d, const il_batch* b, int32_t phase, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream_) {
   if (int rc = check_sac(d, b)) return rc;
   IL_CHECK_ARG(phase >= 0 && phase <= 3, "il_sac_dp_phase: phase must be 0..3");
   IL_CHECK_ARG(d->actor_grad && d->critic_grad && d->alpha_grad, "il_sac_dp_phase: gradient arenas missing");
@@ -830,7 +850,7 @@ extern "C" int il_sac_dp_phase(const il_sac* d, const il_batch* b, int32_t phase
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   if (phase == 0) {
-    { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
+    if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
     { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr, 0, nullptr, nullptr); }
     { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
   } else if (phase == 1) {

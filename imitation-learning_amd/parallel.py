@@ -74,14 +74,15 @@ class DataParallelUpdate:
         all_reduce_mean_(self.disc_bucket, self.group)
         _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
         _lib.check(L.il_gail_reward(C.byref(p.disc), C.byref(p.pb), _lib.ptr(p.rewards), None, _lib.stream_ptr()))
-    _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 0, None, None, _lib.stream_ptr()))
+    _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 0, None, None, p.prepared_flag(), _lib.stream_ptr()))
     if p.algorithm == 'GAIL':
       main.wait_stream(self.side)
-    _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 1, None, None, _lib.stream_ptr()))
+    _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 1, None, None, 0, _lib.stream_ptr()))
     all_reduce_mean_(self.critic_bucket, self.group)
-    _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 2, _lib.ptr(p.logp), _lib.ptr(p.q), _lib.stream_ptr()))
+    _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 2, _lib.ptr(p.logp), _lib.ptr(p.q), 0, _lib.stream_ptr()))
     all_reduce_mean_(self.actor_bucket, self.group)
-    _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 3, None, None, _lib.stream_ptr()))
+    _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 3, None, None, 0, _lib.stream_ptr()))
+    p._prepared = True
 
   def capture(self, warmup: int = 3):
     self.plan.memory.stream().device_state(self.plan.rows.device)

@@ -217,6 +217,17 @@ class UpdatePlan:
       self.transitions['rewards'] = self.rewards  # train.py:194: rewards replaced by the discriminator's prediction
     self.pb = batch_desc(self.transitions)
     self.graph = None
+    self._prepared = False   # True once an update of THIS plan has left the lane-ordered weight copies in step with the parameters
+
+  def invalidate(self):
+    """Call after changing actor / critic / target parameters from outside the plan (load_state_dict, manual edits): the next update
+    re-derives the lane-ordered weight copies (k_repack) instead of trusting the ones its own Adam / polyak epilogues maintain."""
+    self._prepared = False
+    if self.graph is not None:
+      raise RuntimeError('UpdatePlan.invalidate(): re-capture the plan after changing parameters externally')
+
+  def prepared_flag(self) -> int:
+    return _lib.IL_FLAG_SAC_PREPARED if self._prepared else 0
 
   def _sample(self, mem: ReplayMemory, idx: Tensor, rows: Tensor):
     if self.device_index_draw:
@@ -261,17 +272,19 @@ class UpdatePlan:
       if early_prepare:
         main.wait_event(prepared)                                   # main needs the re-ordered weights, not the discriminator
       st = _lib.stream_ptr()
-      fwd = _lib.IL_FLAG_SAC_FORWARD_ONLY | (_lib.IL_FLAG_SAC_PREPARED if early_prepare else 0)
+      fwd = _lib.IL_FLAG_SAC_FORWARD_ONLY | (_lib.IL_FLAG_SAC_PREPARED if early_prepare else self.prepared_flag())
       _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), fwd, st))
       main.wait_stream(self.side)                                   # join: the critic loss reads the rewards
       _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), _lib.IL_FLAG_SAC_SKIP_FORWARD, st))
+      self._prepared = True
       return
     self.sample_all()
     st = _lib.stream_ptr()
     if self.algorithm == 'GAIL':
       _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, 0, st))
       _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, st))
-    _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), 0, st))
+    _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), self.prepared_flag(), st))
+    self._prepared = True
 
   def capture(self, warmup: int = 3):
     assert self.device_index_draw, 'graph capture needs device-side index draws (no H2D inside the graph)'
@@ -361,13 +374,15 @@ class BatchedPopulationPlan:
       self.expert_batches = _device_array([p.eb for p in self.plans], dev)
       self.reward_ptrs = torch.tensor([p.rewards.data_ptr() for p in self.plans], dtype=torch.int64, device=dev)
     self.graph = None
+    self._prepared = False
 
   def run(self):
     L, st, p0 = _lib.lib(), _lib.stream_ptr(), self.plans[0]
     _lib.check(L.il_replay_sample_population(_lib.ptr(self.sample_args), self.L, self.B, self.max_row, st))
     if self.algorithm == 'GAIL':
       _lib.check(L.il_gail_step_population(_lib.ptr(self.disc_descs), _lib.ptr(self.batches), _lib.ptr(self.expert_batches), _lib.ptr(self.reward_ptrs), self.L, C.byref(p0.disc), st))
-    _lib.check(L.il_sac_update_population(_lib.ptr(self.sac_descs), _lib.ptr(self.batches), self.L, C.byref(p0.sac), 0, st))
+    _lib.check(L.il_sac_update_population(_lib.ptr(self.sac_descs), _lib.ptr(self.batches), self.L, C.byref(p0.sac), _lib.IL_FLAG_SAC_PREPARED if self._prepared else 0, st))
+    self._prepared = True
 
   def capture(self, warmup: int = 0):
     for _ in range(warmup):

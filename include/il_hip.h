@@ -36,7 +36,9 @@ enum { IL_OK = 0, IL_ERR_ARG = 1, IL_ERR_UNSUPPORTED = 2, IL_ERR_HIP = 3, IL_ERR
 #define IL_FLAG_GRADS_ONLY 1u /* write gradients to the *_grad arenas and skip the optimiser (data-parallel: all-reduce, then il_adam_step) */
 #define IL_FLAG_TICK 2u       /* il_adam_step: increment the step counter first (stand-alone use) */
 #define IL_FLAG_SAC_FORWARD_ONLY 4u /* il_sac_update: only the reward-independent forward kernels (actor on s and s', critics, targets) */
-#define IL_FLAG_SAC_PREPARED 16u    /* il_sac_update: il_sac_prepare() already ran for the current parameters (skips the weight re-ordering kernel) */
+#define IL_FLAG_SAC_PREPARED 16u    /* the lane-ordered weight copies in the workspace match the parameters: il_sac_prepare() ran, or the previous
+                                       il_sac_update / il_sac_dp_phase / il_sac_update_population call on this descriptor left them in step (its Adam and
+                                       polyak epilogues update them) and nothing else touched the parameters since. Skips the re-ordering kernel. */
 #define IL_FLAG_SAC_SKIP_FORWARD 8u /* il_sac_update: everything after them (the caller already ran FORWARD_ONLY on this batch) */
 
 typedef void* il_stream_t; /* hipStream_t */
@@ -157,7 +159,7 @@ int il_sac_actor_step(const il_sac* d, const il_batch* batch, const float* eps_c
 /* Data-parallel schedule of one update in four phases (0 forward, 1 critic gradients, 2 AdamW(critic) + actor/alpha gradients,
  * 3 AdamW(actor) + Adam(log_alpha) + polyak); the caller all-reduces critic_grad after phase 1 and actor_grad|alpha_grad after phase 2.
  * Same kernels as il_sac_update, Philox noise. */
-int il_sac_dp_phase(const il_sac* d, const il_batch* batch, int32_t phase, float* out_logp, float* out_q, il_stream_t stream);
+int il_sac_dp_phase(const il_sac* d, const il_batch* batch, int32_t phase, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream);
 /* DP tail after the all-reduce of actor_grad/alpha_grad: AdamW(actor) + Adam(log_alpha) + polyak (same kernels, no recompute). */
 int il_sac_apply_actor_grads(const il_sac* d, il_stream_t stream);
 int il_sac_apply_critic_grads(const il_sac* d, il_stream_t stream);
