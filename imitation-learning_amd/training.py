@@ -227,7 +227,7 @@ class UpdatePlan:
       raise RuntimeError('UpdatePlan.invalidate(): re-capture the plan after changing parameters externally')
 
   def prepared_flag(self) -> int:
-    return _lib.IL_FLAG_SAC_PREPARED if self._prepared else 0
+    return _lib.IL_FLAG_SAC_PREPARED if (self._prepared and os.environ.get('IL_ALWAYS_REPACK') != '1') else 0
 
   def _sample(self, mem: ReplayMemory, idx: Tensor, rows: Tensor):
     if self.device_index_draw:
