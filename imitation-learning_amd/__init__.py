@@ -5,6 +5,7 @@ HIP kernels behind the C ABI in include/il_hip.h).  Import as `imitation_learnin
 the importable alias at the repo root points its package path here).
 """
 from . import _lib  # noqa: F401
+from .acting import ActingWorker  # noqa: F401
 from .memory import IndexStream, ReplayMemory, seed  # noqa: F401
 from .models import (GAILDiscriminator, GMMILDiscriminator, PWILDiscriminator, SoftActor, TwinCritic, create_target_network,  # noqa: F401
                      make_gail_input, mix_expert_agent_transitions, update_target_network)

@@ -88,6 +88,8 @@ _SIGNATURES = {
     'il_sac_update': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), _P, _P, _P, _P, C.c_uint32, _P]),
     'il_bc_step': (C.c_int, [_P, _P, C.POINTER(Adam), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Batch), _P, C.c_int64, _P, C.c_uint32, _P]),
     'il_actor_act': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_uint64, C.c_uint32, C.c_int32, _P, _P, _P]),
+    'il_act_mailbox_floats': (C.c_int32, [C.c_int32, C.c_int32]),
+    'il_act_step': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_uint64, C.c_uint32, _P]),
     'il_disc_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     'il_gail_disc_step': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), C.POINTER(Batch), _P, C.c_uint32, _P]),
     'il_gail_apply_grads': (C.c_int, [C.POINTER(Disc), _P]),

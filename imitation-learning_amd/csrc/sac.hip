@@ -1004,10 +1004,11 @@ extern "C" int il_bc_step(float* actor, float* actor_grad, const il_adam* opt, i
 // ---------------------------------------------------------------------------------------------
 // Acting (train.py:152 `actor(state).sample()`, models.py:101-102 greedy): n states, any n >= 1.  grid = ceil(n/16)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_act(const float* __restrict__ actor, int S, int A, int H, const float* __restrict__ states, int ld, int n, const float* __restrict__ eps,
-                                             uint64_t seed, uint32_t offset, int greedy, float* __restrict__ out_a, float* __restrict__ out_logp) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int row0 = blockIdx.x * IL_TILE_R, tid = threadIdx.x, nrows = min(IL_TILE_R, n - row0);
+struct ActTile { float* Os; float* part; };
+
+// actor MLP on one 16-row tile of states -> Os[r*16 + c] = (mean | raw log-std) of row r; shared by k_act and k_act_step
+__device__ __forceinline__ ActTile actor_tile(float* smem, const float* __restrict__ actor, int S, int A, int H, const float* __restrict__ states, int ld, int row0, int nrows) {
+  const int tid = threadIdx.x;
   const int Sp = round_up16(S), ldx = Sp + 4, ldh = H + 4;
   float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* part = H2s + IL_TILE_R * ldh; float* Os = part + (blockDim.x >> 6) * 256;
   const MlpView net = mlp_view(actor, S, H, 2 * A);
@@ -1027,10 +1028,18 @@ __global__ __launch_bounds__(1024) void k_act(const float* __restrict__ actor, i
   });
   __syncthreads();
   tile_fwd_small(H2s, ldh, H, net.W3, H, 2 * A, net.b3, Os, part);
-  float* nl = part; float* la = part + 256;
+  return ActTile{Os, part};
+}
+
+__global__ __launch_bounds__(1024) void k_act(const float* __restrict__ actor, int S, int A, int H, const float* __restrict__ states, int ld, int n, const float* __restrict__ eps,
+                                             uint64_t seed, uint32_t offset, int greedy, float* __restrict__ out_a, float* __restrict__ out_logp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int row0 = blockIdx.x * IL_TILE_R, tid = threadIdx.x, nrows = min(IL_TILE_R, n - row0);
+  const ActTile t = actor_tile(smem, actor, S, A, H, states, ld, row0, nrows);
+  float* nl = t.part; float* la = t.part + 256;
   if (tid < IL_TILE_R * A) {
     const int r = tid / A, c = tid - r * A, row = row0 + r;
-    const float mean = Os[r * 16 + c], lsr = Os[r * 16 + A + c];
+    const float mean = t.Os[r * 16 + c], lsr = t.Os[r * 16 + A + c];
     float x, a = tanhf(mean), nlp = 0.f, ladj = 0.f;
     if (!greedy) {
       const float e = eps ? (r < nrows ? eps[(size_t)row * A + c] : 0.f) : philox_normal(seed, offset, IL_STREAM_ACT, (uint32_t)(row * A + c));
@@ -1047,6 +1056,63 @@ __global__ __launch_bounds__(1024) void k_act(const float* __restrict__ actor, i
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One environment step of the acting worker (train.py:151-168) as ONE launch: append the pending transition to the ring
+// (memory.py:40-44), optionally wrap it for absorbing states (memory.py:65-68), sample the action for the next observation
+// (models.py:90-94) and hand it to the host through a pinned, device-mapped mailbox. The ring cursor lives on the device.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_act_step(const float* __restrict__ actor, int S, int A, int H, float* mail, float* __restrict__ carry, float* __restrict__ ring,
+                                                  long long* __restrict__ ring_state, int row, uint64_t seed, uint32_t offset) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int Sp4 = (S + 3) & ~3, Ap4 = (A + 3) & ~3;
+  const float* m_next = mail + IL_MAIL_HEADER; const float* m_obs = m_next + Sp4; float* m_act = mail + IL_MAIL_HEADER + 2 * Sp4; float* m_echo = m_act + Ap4;
+  const float seq = mail[0];
+  const unsigned flags = (unsigned)mail[1];
+  const long long cursor = ring_state[0], cap = ring_state[2];
+  const bool pending = flags & IL_ACT_PENDING, wrap = pending && (flags & IL_ACT_WRAP_ABSORBING);
+  const int o_next = S + A, o_rew = 2 * S + A;
+  if (pending && tid < row) {
+    const int c = tid;
+    float v = 0.f;
+    if (c < o_next) v = carry[c];                                                        // state | action of the previous act
+    else if (c < o_rew) v = wrap ? (c == o_rew - 1 ? 1.f : 0.f) : m_next[c - o_next];    // next_state, or the absorbing state (memory.py:67)
+    else if (c == o_rew) v = mail[2];                                                    // reward
+    else if (c == o_rew + 1) v = wrap ? 0.f : mail[3];                                   // terminal (cleared by the wrap)
+    else if (c == o_rew + 2) v = mail[4];                                                // timeout
+    else if (c == o_rew + 3) v = 1.f;                                                    // weight
+    else if (c == o_rew + 4) v = mail[5];                                                // step
+    ring[cursor * row + c] = v;
+    if (wrap) {  // absorbing -> absorbing row (memory.py:68)
+      float w = 0.f;
+      if (c < S) w = (c == S - 1) ? 1.f : 0.f;
+      else if (c >= o_next && c < o_rew) w = (c == o_rew - 1) ? 1.f : 0.f;
+      else if (c == o_rew + 3) w = 1.f;
+      else if (c == o_rew + 4) w = mail[5];
+      ring[((cursor + 1) % cap) * row + c] = w;
+    }
+  }
+  if (!(flags & IL_ACT_NO_ACTION)) {  // block-uniform
+    const int greedy = flags & IL_ACT_GREEDY;
+    const ActTile t = actor_tile(smem, actor, S, A, H, m_obs, Sp4, 0, 1);   // barriers inside: every carry[] read above precedes the writes below
+    if (tid < A) {
+      const float mean = t.Os[tid], lsr = t.Os[A + tid];
+      float x, a = tanhf(mean), nlp, ladj;
+      if (!greedy) head_sample(mean, lsr, philox_normal(seed, offset, IL_STREAM_ACT, (uint32_t)tid), x, a, nlp, ladj);
+      m_act[tid] = a; carry[S + tid] = a;
+    }
+    if (tid >= 64 && tid < 64 + S) carry[tid - 64] = m_obs[tid - 64];
+  }
+  if (tid == 0 && pending) {
+    const long long adv = wrap ? 2 : 1, nc = cursor + adv;
+    ring_state[0] = nc % cap;
+    if (nc >= cap) ring_state[1] = 1;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(m_echo, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 extern "C" int il_actor_act(const float* actor, int32_t S, int32_t A, int32_t H, const float* states, int32_t ld_states, int32_t n, const float* eps,
                             uint64_t noise_seed, uint32_t noise_offset, int32_t greedy, float* out_action, float* out_logp, il_stream_t stream_) {
   IL_CHECK_ARG(actor && states && out_action && n > 0, "il_actor_act: null argument");
@@ -1057,6 +1123,22 @@ extern "C" int il_actor_act(const float* actor, int32_t S, int32_t A, int32_t H,
                                                                                                        out_action, out_logp);
   }
   IL_CHECK_LAUNCH("il_actor_act");
+  return IL_OK;
+}
+
+extern "C" int32_t il_act_mailbox_floats(int32_t S, int32_t A) { return (IL_MAIL_HEADER + 2 * ((S + 3) & ~3) + ((A + 3) & ~3) + 1 + 15) & ~15; }
+
+extern "C" int il_act_step(const float* actor, int32_t S, int32_t A, int32_t H, float* mailbox, float* carry, float* ring, int64_t* ring_state, uint64_t noise_seed,
+                           uint32_t noise_offset, il_stream_t stream_) {
+  IL_CHECK_ARG(actor && mailbox && carry && ring && ring_state, "il_act_step: null argument");
+  IL_CHECK_ARG(H % 64 == 0 && H >= 64 && H <= 256 && A >= 1 && 2 * A <= 16, "il_act_step: unsupported dims (hidden=%d, action_dim=%d)", H, A);
+  const int row = il_ring_row_floats(S, A);
+  IL_CHECK_ARG(row <= tile_threads(H) && 64 + S <= tile_threads(H), "il_act_step: ring row of %d floats / state_dim %d exceed the %d-thread workgroup", row, S, tile_threads(H));
+  {
+    IL_TRACE("k_act_step", stream_);
+    k_act_step<<<1, tile_threads(H), tile_lds_bytes(round_up16(S + A), H), (hipStream_t)stream_>>>(actor, S, A, H, mailbox, carry, ring, (long long*)ring_state, row, noise_seed, noise_offset);
+  }
+  IL_CHECK_LAUNCH("il_act_step");
   return IL_OK;
 }
 

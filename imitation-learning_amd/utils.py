@@ -1,21 +1,24 @@
-"""Small helpers of the reference's utils.py (plotting is optional: seaborn / matplotlib are not part of this environment)."""
+"""Host-side conveniences of the training loop (reference utils.py). Plotting is optional: matplotlib is not part of this image."""
+import itertools
 
 
 def cycle(iterable):
-  """Cycles over an iterable without caching the order (reference utils.py:10-13)."""
-  while True:
-    for x in iterable:
-      yield x
+  """Endless pass over `iterable`, re-iterating it each epoch so a shuffling loader reshuffles (reference utils.py:10-13)."""
+  return itertools.chain.from_iterable(iter(lambda: iterable, None))
 
 
 def lineplot(x, y, y2=None, filename='', xaxis='Steps', yaxis='Return', title=''):
+  """Mean +- std band of per-evaluation returns over steps, written to `<filename>.png`; silently skipped without matplotlib."""
   try:
     import numpy as np
     from matplotlib import pyplot as plt
-  except Exception:
-    return  # plotting is a convenience of the reference loop, never a dependency of the update path
-  y = np.array(y)
-  mean, std = y.mean(axis=1), y.std(axis=1)
-  plt.plot(x, mean, color='coral'); plt.fill_between(x, mean - std, mean + std, color='coral', alpha=0.3)
-  plt.xlim(left=0, right=x[-1]); plt.xlabel(xaxis); plt.ylabel(yaxis); plt.title(title)
-  plt.savefig(f'{filename}.png'); plt.close()
+  except ImportError:
+    return
+  series = np.asarray(y, dtype=np.float64)
+  centre, spread = series.mean(axis=1), series.std(axis=1)
+  fig, ax = plt.subplots()
+  ax.plot(x, centre, color='coral')
+  ax.fill_between(x, centre - spread, centre + spread, color='coral', alpha=0.3)
+  ax.set(xlim=(0, x[-1]), xlabel=xaxis, ylabel=yaxis, title=title)
+  fig.savefig(f'{filename}.png')
+  plt.close(fig)

@@ -185,6 +185,26 @@ int il_actor_act(const float* actor, int32_t state_dim, int32_t action_dim, int3
                  int32_t n, const float* eps, uint64_t noise_seed, uint32_t noise_offset, int32_t greedy, float* out_action,
                  float* out_logp, il_stream_t stream);
 
+/* One environment step of the acting worker (train.py:151-168) as ONE launch:
+ *   [memory.append of the pending transition, memory.py:40-44] + [wrap_for_absorbing_states, memory.py:65-68] +
+ *   [actor(state).sample(), models.py:90-94], with the action returned through host-pinned, device-mapped memory.
+ * mailbox: il_act_mailbox_floats(S,A) floats of pinned host memory, Sp = roundup4(S), Ap = roundup4(A):
+ *   host -> device  [0] sequence number  [1] IL_ACT_* flags  [2] reward  [3] terminal  [4] timeout  [5] step
+ *                   [8, 8+S)       next_state of the pending transition
+ *                   [8+Sp, 8+Sp+S) observation to act on (== next_state unless the episode ended and the env was reset)
+ *   device -> host  [8+2Sp, +A)    action;   [8+2Sp+Ap] echo of the sequence number, stored last with system-scope release
+ *                   (the host spins on it instead of synchronising the stream).
+ * carry (device, S+A floats): state | action of the pending transition, written by the previous call.
+ * ring_state (device int64[3] = cursor, full, capacity) is advanced on the device (by 2 when the wrap is requested). */
+#define IL_MAIL_HEADER 8
+#define IL_ACT_PENDING 1u        /* a transition (carry, mailbox) is waiting to be appended */
+#define IL_ACT_WRAP_ABSORBING 2u /* episode ended by true termination with absorbing=true: rewrite + extra row */
+#define IL_ACT_GREEDY 4u         /* tanh(mean) instead of a sample */
+#define IL_ACT_NO_ACTION 8u      /* append only: no policy evaluation, carry left untouched */
+int32_t il_act_mailbox_floats(int32_t state_dim, int32_t action_dim);
+int il_act_step(const float* actor, int32_t state_dim, int32_t action_dim, int32_t hidden, float* mailbox, float* carry, float* ring,
+                int64_t* ring_state, uint64_t noise_seed, uint32_t noise_offset, il_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * GAIL discriminator (reference training.py:85-134 adversarial_imitation_update with loss_function=BCE;
  * models.py:152-180 GAILDiscriminator depth 1 + ReLU; torch _SpectralNorm: one power iteration per call).

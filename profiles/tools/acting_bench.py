@@ -1,0 +1,65 @@
+"""Env-steps/s of the acting path on the synthetic HalfCheetah stand-in: per-function calls vs il_act_step
+(exact / overlap schedules), without updates and with one captured GAIL update per env step.  Usage: python profiles/tools/acting_bench.py"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+import bench  # noqa: E402
+import imitation_learning_amd as il  # noqa: E402
+from imitation_learning_amd.environments import make_env  # noqa: E402
+
+
+def loop(schedule, plan, actor, memory, env, steps, update):
+  worker = il.ActingWorker(actor, memory) if schedule != 'per_function' else None
+  state, t = env.reset(), 0
+  action = worker.act(state) if schedule == 'overlap' else None
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for step in range(1, steps + 1):
+    if worker is None:
+      action = actor(state).sample()
+      nxt, r, term = env.step(action); t += 1
+      memory.append(step, state, action, r, nxt, term and t != env.max_episode_steps, t == env.max_episode_steps)
+      if term and t != env.max_episode_steps: memory.wrap_for_absorbing_states()
+      state = env.reset() if term else nxt
+    elif schedule == 'exact':
+      action = worker.act(state)
+      nxt, r, term = env.step(action); t += 1
+      worker.append(step, nxt, r, term and t != env.max_episode_steps, t == env.max_episode_steps)
+      state = env.reset() if term else nxt
+    else:
+      nxt, r, term = env.step(action); t += 1
+      action = worker.step(step, nxt, r, term and t != env.max_episode_steps, t == env.max_episode_steps, obs=env.reset() if term else None)
+    if term: t = 0
+    if update: plan.replay()
+  torch.cuda.synchronize()
+  return steps / (time.perf_counter() - t0)
+
+
+def main():
+  dev = torch.device('cuda', 0)
+  plan, nets, _ = bench.build(dev, 0)
+  actor, memory = nets[0], plan.memory
+  env = make_env('halfcheetah', True)
+  env.seed(0)
+  for _ in range(3): plan.run()
+  plan.capture(warmup=0)
+  # host-only cost of the environment itself, for reference
+  s, t0 = env.reset(), time.perf_counter()
+  a = torch.zeros(1, 6)
+  for _ in range(2000): env.step(a)
+  env_only = 2000 / (time.perf_counter() - t0)
+  out = dict(env_only_steps_per_s=round(env_only, 1))
+  for update in (False, True):
+    for schedule in ('per_function', 'exact', 'overlap'):
+      loop(schedule, plan, actor, memory, env, 200, update)
+      out[f'{schedule}{"+update" if update else ""}'] = round(loop(schedule, plan, actor, memory, env, 3000, update), 1)
+  print(json.dumps(out))
+
+
+if __name__ == '__main__':
+  main()

@@ -505,3 +505,86 @@ def test_batched_population_equals_independent_learners():
       assert np.isfinite(a).all()
       np.testing.assert_array_equal(a, b, err_msg=f'learner {l}, tensor {i}')
   assert not np.array_equal(results[0][0][0], results[0][1][0])  # the learners really are different
+
+
+# ---------------------------------------------------------------------------------------------
+# acting worker: il_act_step == actor(state).sample() + memory.append + wrap_for_absorbing_states
+# ---------------------------------------------------------------------------------------------
+def _acting_pair(absorbing, capacity=37, S=18, A=6, H=256):
+  cfg = Cfg(hidden_size=H, depth=2, activation='relu')
+  torch.manual_seed(3)
+  actor_a, actor_b = il.SoftActor(S, A, cfg, device=DEV), il.SoftActor(S, A, cfg, device=DEV)
+  actor_a.flat.copy_(torch.randn_like(actor_a.flat) * 0.08); actor_b.flat.copy_(actor_a.flat)
+  return actor_a, actor_b, il.ReplayMemory(capacity, S, A, absorbing, device=DEV), il.ReplayMemory(capacity, S, A, absorbing, device=DEV)
+
+
+def _episode_script(rs, n, S, absorbing):
+  """(next_obs, reward, true_terminal, timeout) per step with a few episode ends of both kinds."""
+  out = []
+  for t in range(1, n + 1):
+    obs = rs.standard_normal(S).astype(np.float32)
+    if absorbing: obs[-1] = 0.0
+    out.append((obs, float(rs.standard_normal()), t in (7, 31, 52), t in (19, 44)))
+  return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('absorbing', [True, False])
+@pytest.mark.parametrize('schedule', ['exact', 'overlap'])
+def test_acting_worker_matches_separate_calls(absorbing, schedule):
+  """One launch per env step (mailbox in pinned memory, cursor on the device) against the per-function path: same actions (same
+  Philox offsets), bit-identical ring including absorbing wraps and ring wrap-around, same host-side cursor / trajectory count."""
+  actor_a, actor_b, mem_a, mem_b = _acting_pair(absorbing)
+  S = mem_a.state_size
+  rs = np.random.RandomState(5)
+  script = _episode_script(rs, 60, S, absorbing)
+  first = rs.standard_normal(S).astype(np.float32); first[-1] = 0.0 if absorbing else first[-1]
+  resets = [rs.standard_normal(S).astype(np.float32) * 0.1 for _ in range(8)]
+  if absorbing:
+    for r in resets: r[-1] = 0.0
+
+  # reference order with the per-function entry points
+  acts_a, obs, k = [], torch.from_numpy(first).unsqueeze(0), 0
+  for t, (nxt, rew, term, tout) in enumerate(script, 1):
+    a = actor_a(obs).sample()
+    acts_a.append(N(a))
+    nxt_t = torch.from_numpy(nxt).unsqueeze(0)
+    mem_a.append(t, obs, a.cpu(), rew, nxt_t, term, tout)
+    if term or tout:
+      if absorbing and term and not tout: mem_a.wrap_for_absorbing_states()
+      obs = torch.from_numpy(resets[k]).unsqueeze(0); k += 1
+    else:
+      obs = nxt_t
+
+  w = il.ActingWorker(actor_b, mem_b)
+  acts_b, k = [], 0
+  if schedule == 'exact':
+    obs = first
+    for t, (nxt, rew, term, tout) in enumerate(script, 1):
+      acts_b.append(N(w.act(obs)))
+      w.append(t, nxt, rew, term, tout)
+      if term or tout: obs = resets[k]; k += 1
+      else: obs = nxt
+  else:
+    a = w.act(first)
+    for t, (nxt, rew, term, tout) in enumerate(script, 1):
+      acts_b.append(N(a))
+      ended = term or tout
+      a = w.step(t, nxt, rew, term, tout, obs=resets[k] if ended else None)
+      k += int(ended)
+  torch.cuda.synchronize()
+  np.testing.assert_array_equal(np.concatenate(acts_a), np.concatenate(acts_b))
+  np.testing.assert_array_equal(N(mem_a.ring), N(mem_b.ring))
+  assert (mem_a.idx, mem_a.full, mem_a.num_trajectories) == (mem_b.idx, mem_b.full, mem_b.num_trajectories)
+  assert N(mem_b._ring_state).tolist() == [mem_b.idx, int(mem_b.full), mem_b.size]
+  assert mem_a.full, 'the script is meant to wrap the ring'
+
+
+@pytest.mark.gpu
+def test_acting_worker_greedy_and_loud_failure():
+  actor_a, actor_b, mem_a, mem_b = _acting_pair(True)
+  obs = np.random.RandomState(1).standard_normal(mem_a.state_size).astype(np.float32)
+  w = il.ActingWorker(actor_b, mem_b)
+  np.testing.assert_array_equal(N(w.act(obs, greedy=True)), N(actor_a.get_greedy_action(torch.from_numpy(obs))))
+  L = _lib.lib()
+  assert L.il_act_step(None, 18, 6, 256, None, None, None, None, 0, 0, None) != 0 and b'il_act_step' in L.il_last_error()
