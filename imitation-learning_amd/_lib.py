@@ -49,6 +49,12 @@ class Pwil(C.Structure):
               ('reward_scale', C.c_double), ('reward_bandwidth', C.c_double), ('agent_weight', C.c_double)]
 
 
+class Red(C.Structure):
+  _fields_ = [('state_dim', C.c_int32), ('action_dim', C.c_int32), ('hidden', C.c_int32), ('batch', C.c_int32), ('state_only', C.c_int32), ('reserved', C.c_int32),
+              ('predictor', C.c_void_p), ('target', C.c_void_p), ('grad', C.c_void_p), ('opt', Adam), ('workspace', C.c_void_p),
+              ('sigma_1', C.c_float), ('reserved2', C.c_float), ('out_pred', C.c_void_p), ('out_target', C.c_void_p)]
+
+
 class SampleArgs(C.Structure):
   _fields_ = [('state', C.c_void_p),
               ('ring_state_a', C.c_void_p), ('ring_a', C.c_void_p), ('capacity_a', C.c_int64), ('row_floats_a', C.c_int32), ('idx_a', C.c_void_p), ('rows_a', C.c_void_p),
@@ -88,6 +94,7 @@ _SIGNATURES = {
     'il_sac_update': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), _P, _P, _P, _P, C.c_uint32, _P]),
     'il_bc_step': (C.c_int, [_P, _P, C.POINTER(Adam), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Batch), _P, C.c_int64, _P, C.c_uint32, _P]),
     'il_actor_act': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_uint64, C.c_uint32, C.c_int32, _P, _P, _P]),
+    'il_batch_mix_relabel': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_int64, _P]),
     'il_act_mailbox_floats': (C.c_int32, [C.c_int32, C.c_int32]),
     'il_act_step': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_uint64, C.c_uint32, _P]),
     'il_disc_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
@@ -99,6 +106,10 @@ _SIGNATURES = {
     'il_gmmil_sqdist': (C.c_int, [C.POINTER(Batch), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
     'il_pwil_reset': (C.c_int, [C.POINTER(Pwil), _P]),
     'il_pwil_reward': (C.c_int, [C.POINTER(Pwil), _P, _P, _P, _P]),
+    'il_red_numel': (C.c_int64, [C.c_int32, C.c_int32]),
+    'il_red_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    'il_red_step': (C.c_int, [C.POINTER(Red), C.POINTER(Batch), _P, C.c_uint32, _P]),
+    'il_red_forward': (C.c_int, [C.POINTER(Red), C.POINTER(Batch), _P, _P, _P, _P]),
 }
 
 

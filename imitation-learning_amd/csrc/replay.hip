@@ -65,6 +65,42 @@ __global__ void k_wrap_absorbing(float* __restrict__ ring, int row, int S, int A
   if (threadIdx.x == 0) lr[o_rew + 1] = 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batch mixing + constant-reward relabelling on packed rows (models.py:287-318: mix_expert_agent_transitions, RewardRelabeller).
+// rows [n][row] <- expert rows for r < n_expert (every field: the reference overwrites every key); label: 0 none, 1 SQIL, 2 AdRIL.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mix_relabel(float* __restrict__ rows, const float* __restrict__ expert, int n, int row, int o_rew, int n_expert, int label,
+                                                    float update_freq, float round_num, float reward_expert, float policy_trajectories) {
+  const int total = n * row;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i / row, c = i - r * row;
+    const bool from_expert = r < n_expert;
+    float v = from_expert ? expert[i] : rows[i];
+    if (label && c == o_rew) {
+      if (from_expert) v = (label == 1) ? 1.f : reward_expert;
+      else if (label == 1) v = 0.f;
+      else {
+        const float stamped = ceilf(__fdiv_rn(rows[(size_t)r * row + o_rew + 4], update_freq));  // round in which the row was collected
+        v = __fdiv_rn(-1.f * ((round_num > stamped) ? 1.f : 0.f), policy_trajectories);          // -0.0 for the current round, like torch
+      }
+    }
+    if (from_expert || (label && c == o_rew)) rows[i] = v;
+  }
+}
+
+extern "C" int il_batch_mix_relabel(float* rows, const float* expert_rows, int32_t n, int32_t S, int32_t A, int32_t n_expert, int32_t label, int32_t update_freq,
+                                    int64_t round_num, float reward_expert, int64_t policy_trajectories, il_stream_t stream) {
+  IL_CHECK_ARG(rows && n > 0 && n_expert >= 0 && n_expert <= n && (n_expert == 0 || expert_rows), "il_batch_mix_relabel: bad arguments");
+  IL_CHECK_ARG(label >= 0 && label <= 2 && (label != 2 || update_freq > 0), "il_batch_mix_relabel: label=%d update_freq=%d", label, update_freq);
+  const int row = il_ring_row_floats(S, A);
+  const int blocks = (n * row + 255) / 256 < 512 ? (n * row + 255) / 256 : 512;
+  { IL_TRACE("k_mix_relabel", (hipStream_t)stream);
+    k_mix_relabel<<<blocks, 256, 0, (hipStream_t)stream>>>(rows, expert_rows, n, row, 2 * S + A, n_expert, label, (float)update_freq, (float)round_num, reward_expert,
+                                                           (float)(policy_trajectories > 1 ? policy_trajectories : 1)); }
+  IL_CHECK_LAUNCH("il_batch_mix_relabel");
+  return IL_OK;
+}
+
 extern "C" int il_replay_wrap_absorbing(float* ring, int64_t capacity, int32_t S, int32_t A, int64_t last, int64_t cursor, il_stream_t stream) {
   IL_CHECK_ARG(ring && last >= 0 && last < capacity && cursor >= 0 && cursor < capacity && last != cursor, "il_replay_wrap_absorbing: bad arguments");
   { IL_TRACE("k_wrap_absorbing", (hipStream_t)stream); k_wrap_absorbing<<<1, 64, 0, (hipStream_t)stream>>>(ring, il_ring_row_floats(S, A), S, A, last, cursor); }

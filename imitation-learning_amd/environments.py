@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import List, Tuple
 
+import zlib
+
 import numpy as np
 import torch
 from torch import Tensor
@@ -38,7 +40,7 @@ class SyntheticD4RLEnv:
     self.name, self.absorbing = env_name, absorbing
     self.obs_dim, self.act_dim, self.can_terminate, (self.ref_min_score, self.ref_max_score) = _SPECS[env_name]
     self.max_episode_steps = max_episode_steps
-    rs = np.random.RandomState(abs(hash(env_name)) % (2**31))
+    rs = np.random.RandomState(zlib.crc32(env_name.encode()))  # stable across processes (str hashes are salted)
     self._A = (np.eye(self.obs_dim) * 0.95 + rs.standard_normal((self.obs_dim, self.obs_dim)) * 0.02).astype(np.float32)
     self._Bm = (rs.standard_normal((self.obs_dim, self.act_dim)) * 0.3).astype(np.float32)
     self._K = (rs.standard_normal((self.act_dim, self.obs_dim)) * 0.2).astype(np.float32)  # the synthetic expert's linear policy

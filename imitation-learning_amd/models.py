@@ -306,8 +306,134 @@ class PWILDiscriminator(nn.Module):
     return float(self.compute_reward_async(state, action).item())
 
 
+class REDDiscriminator(_FlatModule):
+  """Random Expert Distillation (reference models.py:252-284): a predictor regressed onto a frozen random target network, both
+  Linear(D,H)-ReLU-Linear(H,D); reward = exp(-sigma_1 * mean (pred - target)^2).  `self.flat` is the predictor arena (what the
+  optimiser owns), `self.target_flat` the frozen one; state_dict keys are the reference's (predictor.embedding.N.*, target.embedding.N.*)."""
+
+  def __init__(self, state_size: int, action_size: int, imitation_cfg, device=None):
+    super().__init__()
+    model_cfg = imitation_cfg.discriminator
+    if model_cfg.depth != 1 or model_cfg.activation != 'relu' or _cfg_get(model_cfg, 'input_dropout', 0) or _cfg_get(model_cfg, 'dropout', 0):
+      raise NotImplementedError('REDDiscriminator: the HIP path implements depth=1, activation=relu without dropout (the conf/algorithm/RED.yaml defaults); no torch fallback')
+    self.state_size, self.action_size, self.hidden, self.state_only = state_size, action_size, int(model_cfg.hidden_size), bool(imitation_cfg.state_only)
+    self.in_dim = state_size if self.state_only else state_size + action_size
+    if self.in_dim > 128 or self.hidden > 256 or self.hidden % 2:
+      raise NotImplementedError(f'REDDiscriminator: input {self.in_dim} (<= 128) / hidden {self.hidden} (even, <= 256) outside the kernel limits')
+
+    def embedding():
+      l1, l2 = nn.Linear(self.in_dim, self.hidden), nn.Linear(self.hidden, self.in_dim)
+      nn.init.orthogonal_(l1.weight, gain=sqrt(2.0)); nn.init.constant_(l1.bias, 0)
+      nn.init.orthogonal_(l2.weight, gain=1.0); nn.init.constant_(l2.bias, 0)
+      holder = nn.Module()
+      holder.embedding = nn.Sequential(l1, nn.ReLU(), l2)
+      return holder
+    self.predictor, self.target = embedding(), embedding()   # same construction order as the reference: identical RNG consumption
+    dev = device or default_device()
+    P = int(_lib.lib().il_red_numel(self.in_dim, self.hidden))
+    flats = []
+    for net in (self.predictor, self.target):
+      offs, o = [], 0
+      for p in net.parameters():
+        offs.append(o); o += p.numel()
+      assert o == P
+      flat = torch.zeros(P, dtype=torch.float32, device=dev)
+      with torch.no_grad():
+        _flatten_into(list(net.parameters()), flat, offs)
+      flats.append(flat)
+    self.flat, self.target_flat = flats
+    for p in self.parameters():
+      p.requires_grad_(False)
+    self.sigma_1 = imitation_cfg.reward_bandwidth_scale
+
+  def _desc(self, batch_size: int, opt=None) -> '_lib.Red':
+    d = _lib.Red()
+    d.state_dim, d.action_dim, d.hidden, d.batch, d.state_only = self.state_size, self.action_size, self.hidden, batch_size, int(self.state_only)
+    d.predictor, d.target = self.flat.data_ptr(), self.target_flat.data_ptr()
+    d.sigma_1 = float(self.sigma_1) if self.sigma_1 else 0.0
+    if opt is not None:
+      from .training import _workspace
+      ws = _workspace('red', int(_lib.lib().il_red_workspace_floats(self.in_dim, self.hidden, batch_size)), self.flat.device)
+      d.grad, d.opt, d.workspace = opt.grad.data_ptr(), opt.desc(), ws.data_ptr()
+    return d
+
+  def _batch(self, state: Tensor, action: Tensor):
+    from .training import _sa_batch
+    dev = self.flat.device
+    state = state.to(dev, torch.float32)
+    action = action.to(dev, torch.float32)
+    if state.stride(-1) != 1: state = state.contiguous()
+    if action.stride(-1) != 1: action = action.contiguous()
+    return _sa_batch(state, action, torch.ones(state.size(0), device=dev)), state.size(0), (state, action)
+
+  def forward(self, state: Tensor, action: Tensor) -> Tuple[Tensor, Tensor]:
+    b, n, keep = self._batch(state, action)
+    pred, targ = torch.empty(n, self.in_dim, device=self.flat.device), torch.empty(n, self.in_dim, device=self.flat.device)
+    d = self._desc(n)
+    _lib.check(_lib.lib().il_red_forward(C.byref(d), C.byref(b), None, _lib.ptr(pred), _lib.ptr(targ), _lib.stream_ptr()))
+    return pred, targ
+
+  def set_sigma(self, expert_state: Tensor, expert_action: Tensor):
+    """models.py:274-277: kernel median heuristic on one expert minibatch unless reward_bandwidth_scale was configured."""
+    if not self.sigma_1:
+      from .training import embedding_sqdist
+      pred, targ = self.forward(expert_state, expert_action)
+      self.sigma_1 = 1 / embedding_sqdist(pred, targ).flatten().median().item()
+
+  def predict_reward(self, state: Tensor, action: Tensor) -> Tensor:
+    assert self.sigma_1, 'REDDiscriminator.predict_reward before set_sigma (train.py:128)'
+    b, n, keep = self._batch(state, action)
+    out = torch.empty(n, device=self.flat.device)
+    d = self._desc(n)
+    _lib.check(_lib.lib().il_red_forward(C.byref(d), C.byref(b), _lib.ptr(out), None, None, _lib.stream_ptr()))
+    return out
+
+
+def _packed_rows(t: Dict[str, Tensor]) -> Tuple[Tensor, int, int]:
+  """The packed [n, row] tensor a `ReplayMemory.sample` dict views into (plus state / action size), or TypeError."""
+  st, ac, rw = t['states'], t['actions'], t['rewards']
+  base = st._base if st._base is not None else None
+  S, A = st.size(1), ac.size(1)
+  row = int(_lib.lib().il_ring_row_floats(S, A))
+  ok = (base is not None and base.is_cuda and base.dim() == 2 and base.size(1) == row and base.is_contiguous() and st.data_ptr() == base.data_ptr()
+        and ac.data_ptr() == base.data_ptr() + 4 * S and rw.data_ptr() == base.data_ptr() + 4 * (2 * S + A) and st.size(0) == base.size(0))
+  if not ok:
+    raise TypeError('expected a transitions dict produced by ReplayMemory.sample / batch_views (fields are views into packed device rows)')
+  return base, S, A
+
+
+def _mix_relabel(transitions, expert_transitions, n_expert: int, label: int = 0, update_freq: int = 0, round_num: int = 0, reward_expert: float = 0.0, policy_trajectories: int = 1):
+  rows, S, A = _packed_rows(transitions)
+  erows = _packed_rows(expert_transitions)[0] if n_expert else None
+  assert erows is None or erows.size(0) >= n_expert
+  _lib.check(_lib.lib().il_batch_mix_relabel(_lib.ptr(rows), _lib.ptr(erows), rows.size(0), S, A, n_expert, label, update_freq, round_num, reward_expert, policy_trajectories, _lib.stream_ptr()))
+
+
 def mix_expert_agent_transitions(transitions: Dict[str, Tensor], expert_transitions: Dict[str, Tensor]):
-  """Reference models.py:287-290: first half of EVERY key is overwritten with expert rows (in place)."""
-  batch_size = transitions['rewards'].size(0)
-  for key in transitions.keys():
-    transitions[key][:batch_size // 2] = expert_transitions[key][:batch_size // 2]
+  """Reference models.py:287-290: first half of EVERY key is overwritten with expert rows (in place); one k_mix_relabel launch."""
+  _mix_relabel(transitions, expert_transitions, transitions['rewards'].size(0) // 2)
+
+
+class RewardRelabeller:
+  """AdRIL / SQIL constant-reward relabelling (reference models.py:293-318) as one k_mix_relabel launch per update.
+
+  balanced: alternate all-expert and all-policy batches (stateful, expert first); otherwise the first half of the batch is expert data.
+  update_freq > 0 (AdRIL): expert +1/|expert trajectories|, policy 0 for the current round / -1/|policy trajectories| for older rounds;
+  update_freq == 0 (SQIL): expert 1, policy 0.  The batch is rewritten in place (the reference rebinds the dict entries in the
+  all-expert case; here the expert rows are copied over the policy rows, which yields the same values)."""
+
+  def __init__(self, update_freq: int, balanced: bool):
+    self.update_freq, self.balanced, self.sample_expert = int(update_freq), bool(balanced), True
+
+  def resample_and_relabel(self, transitions: Dict[str, Tensor], expert_transitions: Dict[str, Tensor], step: int, num_trajectories: int, num_expert_trajectories: int):
+    B = transitions['rewards'].size(0)
+    if self.balanced:
+      n_expert = B if self.sample_expert else 0
+      self.sample_expert = not self.sample_expert
+    else:
+      n_expert = B // 2
+    if self.update_freq > 0:
+      import numpy as np
+      _mix_relabel(transitions, expert_transitions, n_expert, 2, self.update_freq, -(-int(step) // self.update_freq), float(np.float32(1 / num_expert_trajectories)), int(num_trajectories))
+    else:
+      _mix_relabel(transitions, expert_transitions, n_expert, 1)

@@ -94,8 +94,16 @@ def behavioural_cloning_update(actor: SoftActor, expert_transition: Dict[str, Te
   return parts.sum() / B
 
 
-def target_estimation_update(discriminator, expert_transition, discriminator_optimiser):
-  raise NotImplementedError('RED (target_estimation_update) is outside the HIP hot path (SURVEY.md §8f-4)')
+def target_estimation_update(discriminator, expert_transition: Dict[str, Tensor], discriminator_optimiser: AdamW, *, want_loss: bool = False):
+  """Reference training.py:68-75: regress the RED predictor onto the frozen target on one weighted expert batch (k_red_grad + k_red_apply)."""
+  t = dict(expert_transition)
+  for k in ('rewards', 'terminals', 'absorbing', 'next_states'):
+    t.setdefault(k, t['weights'] if k != 'next_states' else t['states'])
+  b = batch_desc(t)
+  d = discriminator._desc(b.n, discriminator_optimiser)
+  loss = torch.empty(1, device=discriminator.flat.device) if want_loss else None
+  _lib.check(_lib.lib().il_red_step(C.byref(d), C.byref(b), _lib.ptr(loss), 0, _lib.stream_ptr()))
+  return loss
 
 
 # ----------------------------------------------------------------------------------------------- GAIL
@@ -155,6 +163,17 @@ def _weighted_median(x: Tensor, weights: Tensor) -> Tensor:
 def _sa_batch(state, action, weight):
   dummy = weight
   return batch_desc(dict(states=state, actions=action, rewards=dummy, next_states=state, terminals=dummy, weights=weight, absorbing=dummy))
+
+
+def embedding_sqdist(x: Tensor, y: Tensor) -> Tensor:
+  """models.py:25-29 `_squared_distance` between two sets of feature rows [n1, D], [n2, D] -> [n1, n2] (k_gmmil_tile, direct form)."""
+  n1, n2, D = x.size(0), y.size(0), x.size(1)
+  dev = x.device
+  ws = _workspace('gmmil', int(_lib.lib().il_gmmil_workspace_floats(n1, n2, D)), dev)
+  out = torch.empty(n1, n2, device=dev)
+  ba, bb = _sa_batch(x, x, torch.ones(n1, device=dev)), _sa_batch(y, y, torch.ones(n2, device=dev))
+  _lib.check(_lib.lib().il_gmmil_sqdist(C.byref(ba), C.byref(bb), D, 0, 1, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+  return out
 
 
 def gmmil_sqdist(disc: GMMILDiscriminator, a_state, a_action, b_state, b_action) -> Tensor:

@@ -81,6 +81,12 @@ int il_replay_write_rows(float* ring, int64_t capacity, int32_t row_floats, int6
  * and writes the absorbing->absorbing row (step copied from `last`) at `cursor`. */
 int il_replay_wrap_absorbing(float* ring, int64_t capacity, int32_t state_dim, int32_t action_dim, int64_t last, int64_t cursor,
                              il_stream_t stream);
+/* models.py:287-290 mix_expert_agent_transitions and models.py:293-318 RewardRelabeller.resample_and_relabel on packed batch rows
+ * (il_ring_row_floats floats per row): rows[0:n_expert) <- expert_rows[0:n_expert) (every field), then rewards relabelled:
+ *   label 0: untouched (plain mixing);  1 (SQIL): expert 1, policy 0;
+ *   2 (AdRIL): expert `reward_expert` (= 1/|expert trajectories|), policy -[round_num > ceil(row.step / update_freq)] / max(policy_trajectories, 1). */
+int il_batch_mix_relabel(float* rows, const float* expert_rows, int32_t n, int32_t state_dim, int32_t action_dim, int32_t n_expert, int32_t label,
+                         int32_t update_freq, int64_t round_num, float reward_expert, int64_t policy_trajectories, il_stream_t stream);
 /* memory.py:58-63 `sample` gather step: out[i] = ring[idx[i]] for i < n (packed rows, coalesced 16-B lanes). */
 int il_replay_gather(const float* ring, int64_t capacity, int32_t row_floats, const int32_t* idx, int32_t n, float* out_rows,
                      il_stream_t stream);
@@ -262,6 +268,31 @@ typedef struct il_pwil {
 int il_pwil_reset(const il_pwil* d, il_stream_t stream);
 /* compute_reward for one (state, action); writes the reward (double precision accumulate like the reference's Python floats) to out_reward[0]. */
 int il_pwil_reward(const il_pwil* d, const float* state, const float* action, float* out_reward, il_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * RED (reference models.py:252-284 REDDiscriminator, training.py:68-75 target_estimation_update).
+ * predictor / target: Linear(D,H) -> ReLU -> Linear(H,D), D = state_dim (+ action_dim unless state_only), flat arenas in
+ * torch parameters() order [W1 (H,D) | b1 (H) | W2 (D,H) | b2 (D)], il_red_numel(D,H) floats each.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct il_red {
+  int32_t state_dim, action_dim, hidden, batch, state_only, reserved;
+  float* predictor;     /* trained */
+  const float* target;  /* frozen random network */
+  float* grad;          /* [P] */
+  il_adam opt;          /* AdamW state of the predictor (train.py:84) */
+  float* workspace;     /* >= il_red_workspace_floats(D, H, batch) */
+  float sigma_1;        /* reward bandwidth (models.py:274-277 set_sigma or imitation.reward_bandwidth_scale) */
+  float reserved2;
+  float *out_pred, *out_target; /* filled by il_red_forward; leave NULL */
+} il_red;
+int64_t il_red_numel(int32_t input_dim, int32_t hidden);
+int64_t il_red_workspace_floats(int32_t input_dim, int32_t hidden, int32_t batch);
+/* target_estimation_update: loss = mean_i w_i mean_c (pred_ic - target_ic)^2, AdamW on the predictor (IL_FLAG_GRADS_ONLY: d->grad only).
+ * out_loss [1] or NULL. */
+int il_red_step(const il_red* d, const il_batch* expert, float* out_loss, uint32_t flags, il_stream_t stream);
+/* predict_reward (models.py:279-280): out_reward[i] = exp(-sigma_1 * mean_c (pred - target)^2), and / or the embeddings
+ * out_pred, out_target [n, D] (what set_sigma feeds to the pairwise distance + median). */
+int il_red_forward(const il_red* d, const il_batch* batch, float* out_reward, float* out_pred, float* out_target, il_stream_t stream);
 
 #ifdef __cplusplus
 }

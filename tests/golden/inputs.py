@@ -96,3 +96,25 @@ def pwil_case(seed, N, D, steps):
 
 def strided(x, stride=29):
   return np.ascontiguousarray(np.asarray(x).ravel()[::stride])
+
+
+ADRIL_STEP, ADRIL_TRAJ = 2600, 4
+
+
+def adril_batches(seed, B, S, A):
+  """(policy batch, expert batch) for the AdRIL / SQIL relabeller: policy rows carry env-step stamps spread over three rounds of 1250."""
+  rs = np.random.RandomState(seed)
+  pol, exp = transitions(rs, B, S, A), transitions(rs, B, S, A, state_shift=0.5, weighted=True)
+  pol['step'] = rs.randint(1, 3800, B).astype(f32)
+  return pol, exp
+
+
+def red_case(seed, env, hidden, batch, steps):
+  """RED predictor / frozen target (Linear(D,H)-ReLU-Linear(H,D)), weighted expert batches, a sigma batch and a query batch."""
+  S, A = DIMS[env]
+  D = S + A
+  rs = np.random.RandomState(seed)
+  predictor, target = mlp_params(rs, D, hidden, 1, D), mlp_params(rs, D, hidden, 1, D)
+  batches = [transitions(rs, batch, S, A, state_shift=0.5, weighted=True) for _ in range(steps)]
+  return dict(S=S, A=A, D=D, H=hidden, B=batch, predictor=predictor, target=target, batches=batches,
+              sigma_batch=transitions(rs, batch, S, A, state_shift=0.5), query=transitions(rs, batch + 16, S, A))

@@ -248,15 +248,63 @@ def gen_pwil():
   np.savez_compressed(os.path.join(HERE, 'pwil.npz'), rewards=np.array(rewards, np.float64), scale=N_(d.data_scale), offset=N_(d.data_offset), remaining=np.array([d.expert_weights.numel()]))
 
 
+def gen_adril():
+  """RewardRelabeller (models.py:293-318) and mix_expert_agent_transitions (models.py:287-290) on seeded batches."""
+  S, A, B = gi.DIMS['hopper'][0], gi.DIMS['hopper'][1], 64
+  out = {}
+  for name, update_freq, balanced in (('adril_balanced', 1250, True), ('adril_halves', 1250, False), ('sqil_balanced', 0, True), ('sqil_halves', 0, False)):
+    rel = ref_models.RewardRelabeller(update_freq, balanced)
+    for call in range(3):
+      pol, exp = gi.adril_batches(40 + call, B, S, A)
+      tp, te = tbatch(pol), tbatch(exp)
+      rel.resample_and_relabel(tp, te, step=gi.ADRIL_STEP + call * 700, num_trajectories=gi.ADRIL_TRAJ + call, num_expert_trajectories=7)
+      for k, v in tp.items():
+        out[f'{name}.{call}.{k}'] = N_(v)
+  pol, exp = gi.adril_batches(50, B, S, A)
+  tp, te = tbatch(pol), tbatch(exp)
+  ref_models.mix_expert_agent_transitions(tp, te)
+  for k, v in tp.items():
+    out[f'mix.{k}'] = N_(v)
+  np.savez_compressed(os.path.join(HERE, 'adril.npz'), **out)
+
+
+def gen_red():
+  """REDDiscriminator (models.py:252-284) + target_estimation_update (training.py:68-75): 4 updates, set_sigma, predict_reward."""
+  out = {}
+  for name, c, lr, wd in (('hopper_h32', gi.red_case(61, 'hopper', 32, 64, 4), 3e-5, 0.0), ('halfcheetah_h64', gi.red_case(62, 'halfcheetah', 64, 256, 3), 1e-3, 0.01)):
+    cfg = DictConfig(state_only=False, reward_bandwidth_scale=None, discriminator=DictConfig(hidden_size=c['H'], depth=1, activation='relu', input_dropout=0, dropout=0))
+    d = ref_models.REDDiscriminator(c['S'], c['A'], cfg)
+    torch.nn.utils.vector_to_parameters(T(c['predictor']), d.predictor.parameters())
+    torch.nn.utils.vector_to_parameters(T(c['target']), d.target.parameters())
+    opt = torch.optim.AdamW(d.predictor.parameters(), lr=lr, weight_decay=wd)
+    for k, b in enumerate(c['batches'], 1):
+      ref_training.target_estimation_update(d, tbatch(b), opt)
+      out[f'{name}.predictor.{k}'] = flat(d.predictor)
+    out[f'{name}.exp_avg'], out[f'{name}.exp_avg_sq'] = opt_state(opt, 'exp_avg'), opt_state(opt, 'exp_avg_sq')
+    with torch.inference_mode():
+      e = tbatch(c['sigma_batch'])
+      d.set_sigma(e['states'], e['actions'])
+      out[f'{name}.sigma_1'] = np.array([d.sigma_1], np.float64)
+      q = tbatch(c['query'])
+      out[f'{name}.reward'] = N_(d.predict_reward(q['states'], q['actions']))
+    out[f'{name}.hyper'] = np.array([lr, wd], np.float64)
+  np.savez_compressed(os.path.join(HERE, 'red.npz'), **out)
+
+
 if __name__ == '__main__':
-  gen_replay()
-  gen_sac('sac_halfcheetah', gi.sac_case(3, 'halfcheetah', 256, 256, 3))
-  gen_sac('sac_hopper_h64', gi.sac_case(4, 'hopper', 64, 96, 3))
-  gen_sac('sac_ant_b64', gi.sac_case(5, 'ant', 256, 64, 2))
-  gen_bc('bc_hopper', 'hopper', 256, 256, 3)
-  gen_gail('gail_default', gi.gail_case(31), lr=3e-5, weight_decay=10, grad_penalty=1.0, entropy_bonus=0.0)
-  gen_gail('gail_h128_ent', gi.gail_case(32, hidden=128), lr=7.3e-5, weight_decay=6.35, grad_penalty=0.32, entropy_bonus=0.0155)
-  gen_gail('gail_nosn_nogp', gi.gail_case(33, env='hopper', hidden=32, batch=128, spectral_norm=False), lr=3e-4, weight_decay=0.0, grad_penalty=0.0, entropy_bonus=0.0)
-  gen_gmmil()
-  gen_pwil()
-  print('golden vectors written to', HERE)
+  only = set(sys.argv[1:])  # e.g. `make_golden.py adril` regenerates just that fixture
+  want = lambda tag: not only or tag in only
+  if want('replay'): gen_replay()
+  if want('sac'):
+    gen_sac('sac_halfcheetah', gi.sac_case(3, 'halfcheetah', 256, 256, 3))
+    gen_sac('sac_hopper_h64', gi.sac_case(4, 'hopper', 64, 96, 3))
+    gen_sac('sac_ant_b64', gi.sac_case(5, 'ant', 256, 64, 2))
+  if want('bc'): gen_bc('bc_hopper', 'hopper', 256, 256, 3)
+  if want('gail'):
+    gen_gail('gail_default', gi.gail_case(31), lr=3e-5, weight_decay=10, grad_penalty=1.0, entropy_bonus=0.0)
+    gen_gail('gail_h128_ent', gi.gail_case(32, hidden=128), lr=7.3e-5, weight_decay=6.35, grad_penalty=0.32, entropy_bonus=0.0155)
+    gen_gail('gail_nosn_nogp', gi.gail_case(33, env='hopper', hidden=32, batch=128, spectral_norm=False), lr=3e-4, weight_decay=0.0, grad_penalty=0.0, entropy_bonus=0.0)
+  if want('gmmil'): gen_gmmil()
+  if want('pwil'): gen_pwil()
+  if want('adril'): gen_adril()
+  if want('red'): gen_red()

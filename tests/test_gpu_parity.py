@@ -588,3 +588,94 @@ def test_acting_worker_greedy_and_loud_failure():
   np.testing.assert_array_equal(N(w.act(obs, greedy=True)), N(actor_a.get_greedy_action(torch.from_numpy(obs))))
   L = _lib.lib()
   assert L.il_act_step(None, 18, 6, 256, None, None, None, None, 0, 0, None) != 0 and b'il_act_step' in L.il_last_error()
+
+
+# ---------------------------------------------------------------------------------------------
+# AdRIL / SQIL relabeller and batch mixing (models.py:287-318): bit-exact against the reference-generated fixture and the oracle
+# ---------------------------------------------------------------------------------------------
+def _packed(batch, S, A):
+  """A ReplayMemory.sample-style dict (views into packed device rows) holding `batch`."""
+  n = batch['rewards'].shape[0]
+  rows = torch.zeros(n, int(_lib.lib().il_ring_row_floats(S, A)), device=DEV)
+  views = il_memory.batch_views(rows, S, A, True)
+  for k in il_memory.FIELDS:
+    views[k].copy_(T(batch[k]))
+  return views
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,update_freq,balanced', [('adril_balanced', 1250, True), ('adril_halves', 1250, False), ('sqil_balanced', 0, True), ('sqil_halves', 0, False)])
+def test_reward_relabeller_bit_exact(golden_dir, name, update_freq, balanced):
+  from oracle import adril as oadril
+  g = load(golden_dir, 'adril')
+  S, A = gi.DIMS['hopper']
+  rel, orel = il.RewardRelabeller(update_freq, balanced), oadril.RelabellerOracle(update_freq, balanced)
+  for call in range(3):
+    pol, exp = gi.adril_batches(40 + call, 64, S, A)
+    tp, te = _packed(pol, S, A), _packed(exp, S, A)
+    rel.resample_and_relabel(tp, te, gi.ADRIL_STEP + call * 700, gi.ADRIL_TRAJ + call, 7)
+    orel.resample_and_relabel(pol, exp, gi.ADRIL_STEP + call * 700, gi.ADRIL_TRAJ + call, 7)
+    for k in il_memory.FIELDS + ('absorbing',):
+      got = N(tp[k])
+      assert got.tobytes() == g[f'{name}.{call}.{k}'].tobytes(), (name, call, k)   # includes the sign of -0.0 rewards
+      assert got.tobytes() == np.asarray(pol[k], np.float32).tobytes()
+
+
+@pytest.mark.gpu
+def test_mix_expert_agent_transitions_bit_exact(golden_dir):
+  g = load(golden_dir, 'adril')
+  S, A = gi.DIMS['hopper']
+  pol, exp = gi.adril_batches(50, 64, S, A)
+  tp, te = _packed(pol, S, A), _packed(exp, S, A)
+  il.mix_expert_agent_transitions(tp, te)
+  for k in il_memory.FIELDS + ('absorbing',):
+    assert N(tp[k]).tobytes() == g[f'mix.{k}'].tobytes(), k
+  with pytest.raises(TypeError):
+    il.mix_expert_agent_transitions(tbatch(pol), tbatch(exp))   # loose tensors, not views into packed rows
+
+
+# ---------------------------------------------------------------------------------------------
+# RED (models.py:252-284, training.py:68-75) against the reference-generated fixture and the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,case', [('hopper_h32', (61, 'hopper', 32, 64, 4)), ('halfcheetah_h64', (62, 'halfcheetah', 64, 256, 3))])
+def test_red_matches_reference(golden_dir, name, case):
+  from oracle import red as ored
+  g = load(golden_dir, 'red')
+  c = gi.red_case(*case)
+  lr, wd = (float(x) for x in g[f'{name}.hyper'])
+  icfg = Cfg(state_only=False, reward_bandwidth_scale=None, discriminator=Cfg(hidden_size=c['H'], depth=1, activation='relu', input_dropout=0, dropout=0))
+  d = il.REDDiscriminator(c['S'], c['A'], icfg, device=DEV)
+  assert set(d.state_dict()) == {f'{net}.embedding.{i}.{p}' for net in ('predictor', 'target') for i in (0, 2) for p in ('weight', 'bias')}
+  d.flat.copy_(T(c['predictor'])); d.target_flat.copy_(T(c['target']))
+  opt = il.AdamW(d, lr=lr, weight_decay=wd)
+  st = ored.RedState(c['D'], c['H']); st.predictor[:] = c['predictor']; st.target[:] = c['target']
+  for k, b in enumerate(c['batches'], 1):
+    loss = il.target_estimation_update(d, tbatch(b), opt, want_loss=True)
+    oloss = ored.target_estimation_update(st, np.concatenate([b['states'], b['actions']], 1), b['weights'], lr=lr, weight_decay=wd)
+    close(N(loss)[0], oloss, f'{name} loss {k}')
+    close_params(N(d.flat), g[f'{name}.predictor.{k}'], f'{name} predictor after update {k} (reference)', lr, steps=k)
+    close_params(N(d.flat), st.predictor, f'{name} predictor after update {k} (oracle)', lr, steps=k)
+  close(N(opt.exp_avg), g[f'{name}.exp_avg'], f'{name} exp_avg', rtol=1e-4)
+  assert int(opt.step_count[0]) == len(c['batches'])
+  assert np.array_equal(N(d.target_flat), c['target']), 'the target network is frozen'
+  # bandwidth + reward on the reference's post-training predictor (isolates the two calls from Adam-amplified differences)
+  d.flat.copy_(T(g[f'{name}.predictor.{len(c["batches"])}']))
+  e, q = tbatch(c['sigma_batch']), tbatch(c['query'])
+  d.set_sigma(e['states'], e['actions'])
+  assert abs(d.sigma_1 - float(g[f'{name}.sigma_1'][0])) <= 1e-5 * d.sigma_1
+  close(N(d.predict_reward(q['states'], q['actions'])), g[f'{name}.reward'], f'{name} reward')   # ragged: B + 16 rows
+  pred, targ = d(q['states'][:5], q['actions'][:5])
+  x = np.concatenate([c['query']['states'][:5], c['query']['actions'][:5]], 1)
+  st.predictor[:] = g[f'{name}.predictor.{len(c["batches"])}']
+  op, ot, _ = ored.forward(st, x)
+  close(N(pred), op, f'{name} predictor embedding'); close(N(targ), ot, f'{name} target embedding')
+
+
+@pytest.mark.gpu
+def test_red_loud_failures():
+  icfg = Cfg(state_only=False, reward_bandwidth_scale=None, discriminator=Cfg(hidden_size=32, depth=2, activation='relu', input_dropout=0, dropout=0))
+  with pytest.raises(NotImplementedError):
+    il.REDDiscriminator(11, 3, icfg, device=DEV)
+  L = _lib.lib()
+  assert L.il_red_step(None, None, None, 0, None) != 0 and b'il_red' in L.il_last_error()

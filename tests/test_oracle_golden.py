@@ -168,3 +168,40 @@ def test_pwil_matches_reference(golden_dir):
       o.reset()
   np.testing.assert_allclose(rewards, g['rewards'], rtol=1e-5)
   assert o.weights.size == int(g['remaining'][0])
+
+
+def test_adril_relabeller_oracle_matches_reference_fixture(golden_dir):
+  """oracle/adril.py against RewardRelabeller / mix_expert_agent_transitions outputs of the reference (bitwise, incl. -0.0)."""
+  from oracle import adril as oadril
+  g = np.load(os.path.join(golden_dir, 'adril.npz'))
+  S, A = gi.DIMS['hopper']
+  for name, update_freq, balanced in (('adril_balanced', 1250, True), ('adril_halves', 1250, False), ('sqil_balanced', 0, True), ('sqil_halves', 0, False)):
+    rel = oadril.RelabellerOracle(update_freq, balanced)
+    for call in range(3):
+      pol, exp = gi.adril_batches(40 + call, 64, S, A)
+      rel.resample_and_relabel(pol, exp, gi.ADRIL_STEP + call * 700, gi.ADRIL_TRAJ + call, 7)
+      for k, v in pol.items():
+        assert np.asarray(v, np.float32).tobytes() == g[f'{name}.{call}.{k}'].tobytes(), (name, call, k)
+  pol, exp = gi.adril_batches(50, 64, S, A)
+  oadril.mix(pol, exp)
+  for k, v in pol.items():
+    assert np.asarray(v, np.float32).tobytes() == g[f'mix.{k}'].tobytes(), k
+
+
+@pytest.mark.parametrize('name,case', [('hopper_h32', (61, 'hopper', 32, 64, 4)), ('halfcheetah_h64', (62, 'halfcheetah', 64, 256, 3))])
+def test_red_oracle_matches_reference_fixture(golden_dir, name, case):
+  """oracle/red.py against REDDiscriminator + target_estimation_update outputs of the reference (predictor after each AdamW step,
+  kernel-median bandwidth, rewards)."""
+  from oracle import red
+  g = np.load(os.path.join(golden_dir, 'red.npz'))
+  c = gi.red_case(*case)
+  lr, wd = (float(x) for x in g[f'{name}.hyper'])
+  st = red.RedState(c['D'], c['H']); st.predictor[:] = c['predictor']; st.target[:] = c['target']
+  for k, b in enumerate(c['batches'], 1):
+    red.target_estimation_update(st, np.concatenate([b['states'], b['actions']], 1), b['weights'], lr=lr, weight_decay=wd)
+    ref = g[f'{name}.predictor.{k}']
+    assert np.max(np.abs(st.predictor - ref) - 1e-5 * np.abs(ref)) <= 1e-5 * np.abs(ref).max()
+  e, q = c['sigma_batch'], c['query']
+  sigma = red.set_sigma(st, np.concatenate([e['states'], e['actions']], 1))
+  assert abs(sigma - float(g[f'{name}.sigma_1'][0])) <= 1e-5 * sigma
+  np.testing.assert_allclose(red.predict_reward(st, np.concatenate([q['states'], q['actions']], 1)), g[f'{name}.reward'], rtol=1e-5)

@@ -19,6 +19,11 @@ COMMON = ['steps=260', 'training.start=120', 'evaluation.interval=130', 'evaluat
     ['algorithm=GAIL', 'env=hopper', 'imitation.mix_expert_data=mixed_batch', 'imitation.bc_aux_loss=true'],   # un-fused path (host-visible batch edits)
     ['algorithm=GMMIL', 'env=ant'],
     ['algorithm=PWIL', 'env=walker2d'],
+    ['algorithm=AdRIL', 'env=hopper', 'imitation.update_freq=100'],
+    ['algorithm=AdRIL', 'env=walker2d', 'imitation.update_freq=0', 'imitation.balanced=false'],   # SQIL
+    ['algorithm=RED', 'env=hopper', 'imitation.pretraining.iterations=50'],
+    ['algorithm=SAC', 'env=hopper', '+acting.schedule=overlap'],
+    ['algorithm=GAIL', 'env=walker2d', '+acting.schedule=per_function'],
     ['algorithm=BC', 'env=hopper', 'bc_pretraining.iterations=60'],
 ])
 def test_train_runs(tmp_path, args):
@@ -46,4 +51,4 @@ def test_unsupported_algorithms_fail_loudly():
   import train
   from imitation_learning_amd import config
   with pytest.raises(NotImplementedError):
-    train.train(config.compose(['algorithm=RED', 'env=hopper', 'steps=10']))
+    train.train(config.compose(['algorithm=DRIL', 'env=hopper', 'steps=10']))

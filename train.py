@@ -4,7 +4,7 @@
 Drives the loop of reference train.py:26-243 (act -> store -> [update block] -> evaluate -> save) on the MI355X path:
 the update block (train.py:171-203) is `UpdatePlan` (one captured hipGraph per step for SAC / GAIL) or the per-function HIP entry
 points (GMMIL, PWIL, mixed batches, BC auxiliary loss).  Hydra is replaced by `imitation_learning_amd.config.compose`
-(same keys, same precedence).  Supported on the HIP path: SAC, GAIL (BCE loss), GMMIL, PWIL, BC; AdRIL / DRIL / RED raise.
+(same keys, same precedence).  Supported on the HIP path: SAC, GAIL (BCE loss), GMMIL, PWIL, AdRIL (and SQIL via update_freq=0), RED, BC; DRIL raises.
 """
 import os
 import sys
@@ -22,24 +22,29 @@ from imitation_learning_amd.models import default_device  # noqa: E402
 from imitation_learning_amd.utils import cycle, lineplot  # noqa: E402
 
 
-def pretrain_bc(cfg, actor, expert_memory, state_size, action_size):
-  """cfg.bc_pretraining.iterations steps of il_bc_step over shuffled, drop-last expert epochs (DataLoader semantics of train.py:93-100)."""
-  B, n, todo = cfg.training.batch_size, expert_memory.size, cfg.bc_pretraining.iterations
-  optimiser = il.AdamW(actor, lr=cfg.bc_pretraining.learning_rate, weight_decay=cfg.bc_pretraining.weight_decay)
-  assert n >= B, f'BC pretraining needs at least one full batch of expert data ({n} < {B})'
+def expert_batches(cfg, expert_memory, state_size, action_size, count):
+  """`count` shuffled, drop-last minibatches of the expert memory, reshuffled every epoch (the cycle(DataLoader(...)) of train.py:94,116)."""
+  B, n = cfg.training.batch_size, expert_memory.size
+  assert n >= B, f'pretraining needs at least one full batch of expert data ({n} < {B})'
   shuffle = torch.Generator().manual_seed(cfg.seed)
-  while todo > 0:
+  while count > 0:
     order = torch.randperm(n, generator=shuffle).to(torch.int32)
-    for lo in range(0, min(n - B + 1, todo * B), B):
-      rows = expert_memory.gather(order[lo:lo + B])
-      il.behavioural_cloning_update(actor, il.memory.batch_views(rows, state_size, action_size, cfg.imitation.absorbing), optimiser)
-      todo -= 1
+    for lo in range(0, min(n - B + 1, count * B), B):
+      yield il.memory.batch_views(expert_memory.gather(order[lo:lo + B]), state_size, action_size, cfg.imitation.absorbing)
+      count -= 1
+
+
+def pretrain_bc(cfg, actor, expert_memory, state_size, action_size):
+  """cfg.bc_pretraining.iterations steps of il_bc_step (train.py:93-100)."""
+  optimiser = il.AdamW(actor, lr=cfg.bc_pretraining.learning_rate, weight_decay=cfg.bc_pretraining.weight_decay)
+  for batch in expert_batches(cfg, expert_memory, state_size, action_size, cfg.bc_pretraining.iterations):
+    il.behavioural_cloning_update(actor, batch, optimiser)
 
 
 def train(cfg, file_prefix: str = '') -> float:
   il_config.validate(cfg)
-  if cfg.algorithm in ('AdRIL', 'DRIL', 'RED'):
-    raise NotImplementedError(f'algorithm={cfg.algorithm} is outside the MI355X hot path of this round (SURVEY.md §8f-4); supported: SAC, GAIL, GMMIL, PWIL, BC')
+  if cfg.algorithm == 'DRIL':
+    raise NotImplementedError('algorithm=DRIL (dropout policy ensemble) is outside the MI355X hot path of this round (SURVEY.md §8f-4); supported: SAC, GAIL, GMMIL, PWIL, AdRIL, RED, BC')
   dev = default_device()
   assert dev.type == 'cuda', 'train.py needs a GPU: the update path has no CPU fallback'
   il.seed(cfg.seed)               # replay index stream (np.random.seed in the reference, train.py:51)
@@ -62,13 +67,18 @@ def train(cfg, file_prefix: str = '') -> float:
   memory = il.ReplayMemory(cfg.memory.size, state_size, action_size, cfg.imitation.absorbing)
 
   discriminator = discriminator_optimiser = None
-  if cfg.algorithm == 'GAIL':
+  if cfg.algorithm == 'AdRIL':
+    discriminator = il.RewardRelabeller(cfg.imitation.update_freq, cfg.imitation.balanced)
+  elif cfg.algorithm == 'GAIL':
     discriminator = il.GAILDiscriminator(state_size, action_size, cfg.imitation, cfg.reinforcement.discount)
     discriminator_optimiser = il.AdamW(discriminator, lr=cfg.imitation.learning_rate, weight_decay=cfg.imitation.weight_decay)
   elif cfg.algorithm == 'GMMIL':
     discriminator = il.GMMILDiscriminator(state_size, action_size, cfg.imitation)
   elif cfg.algorithm == 'PWIL':
     discriminator = il.PWILDiscriminator(state_size, action_size, cfg.imitation, expert_memory, env.max_episode_steps)
+  elif cfg.algorithm == 'RED':
+    discriminator = il.REDDiscriminator(state_size, action_size, cfg.imitation)
+    discriminator_optimiser = il.AdamW(discriminator, lr=cfg.imitation.learning_rate, weight_decay=cfg.imitation.weight_decay)
 
   metrics = dict(train_steps=[], train_returns=[], test_steps=[], test_returns=[], test_returns_normalized=[], update_steps=[], predicted_rewards=[], alphas=[], entropies=[], Q_values=[])
   score = []
@@ -86,6 +96,13 @@ def train(cfg, file_prefix: str = '') -> float:
       torch.save(dict(actor=actor.state_dict()), f'{file_prefix}agent.pth')
       torch.save(metrics, f'{file_prefix}metrics.pth')
       return float(np.mean(normalised))
+
+  if cfg.algorithm == 'RED':  # train.py:114-128: distil the random target on expert data, then fix the reward bandwidth on one minibatch
+    for batch in expert_batches(cfg, expert_memory, state_size, action_size, cfg.imitation.pretraining.iterations):
+      il.target_estimation_update(discriminator, batch, discriminator_optimiser)
+    discriminator.set_sigma(expert_memory['states'][:B], expert_memory['actions'][:B])
+    if cfg.check_time_usage: metrics['pre_training_time'], start_time = time.time() - start_time, time.time()
+    if cfg.imitation.mix_expert_data == 'prefill_memory': memory.transfer_transitions(expert_memory)
 
   if cfg.algorithm == 'PWIL' and cfg.imitation.mix_expert_data != 'none':  # train.py:135-141
     for i in range(expert_memory.size):
@@ -147,9 +164,13 @@ def train(cfg, file_prefix: str = '') -> float:
           discriminator.train()
           il.adversarial_imitation_update(actor, discriminator, transitions, expert_transitions, discriminator_optimiser, cfg.imitation)
           discriminator.eval()
-        if cfg.imitation.mix_expert_data == 'mixed_batch': il.mix_expert_agent_transitions(transitions, expert_transitions)
+        if cfg.imitation.mix_expert_data == 'mixed_batch' and cfg.algorithm != 'AdRIL': il.mix_expert_agent_transitions(transitions, expert_transitions)
+        if cfg.algorithm == 'AdRIL':
+          discriminator.resample_and_relabel(transitions, expert_transitions, step, memory.num_trajectories, expert_memory.num_trajectories)
         if cfg.algorithm == 'GAIL':
           transitions['rewards'] = discriminator.predict_reward(transitions['states'], transitions['actions'])
+        elif cfg.algorithm == 'RED':
+          transitions['rewards'].copy_(discriminator.predict_reward(transitions['states'], transitions['actions']))
         elif cfg.algorithm == 'GMMIL':
           transitions['rewards'] = discriminator.predict_reward(transitions['states'], transitions['actions'], expert_transitions['states'], expert_transitions['actions'],
                                                                 transitions['weights'].contiguous(), expert_transitions['weights'].contiguous())
