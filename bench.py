@@ -229,11 +229,18 @@ def main():
   for _ in range(5):
     runner.run()   # loads code objects before capture
   torch.cuda.synchronize()
+  launch = 'eager'
+  step = runner.run
   if not args.no_graph:
-    runner.capture(warmup=0)
-    step = runner.replay
-  else:
-    step = runner.run
+    try:
+      runner.capture(warmup=0)
+      step, launch = runner.replay, 'hipGraph replay'
+    except Exception as e:  # e.g. a collective that refuses stream capture: keep measuring, eagerly, and say so
+      if world == 1 and os.environ.get('IL_FORCE_ALLREDUCE') != '1':
+        raise
+      torch.cuda.synchronize()
+      launch = f'eager (graph capture failed: {type(e).__name__})'
+      print(f'[bench] rank {rank}: graph capture failed, falling back to eager launches: {e}', file=sys.stderr)
 
   def barrier():
     torch.cuda.synchronize()
@@ -266,7 +273,7 @@ def main():
                ms_per_step=round(ms_per_step, 5), higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                config=dict(workload='algorithm=GAIL env=halfcheetah: 2 replay samples + discriminator step (BCE+GP+SN) + AIRL relabel + sac_update per step',
                            batch_per_gpu=B, global_batch=B * world, state_dim=S, action_dim=A, hidden=H, replay_capacity=1_000_000, replay_fill=100_000, expert_rows=25_000,
-                           learners_per_gpu=args.learners, parallelism=f'dp{world}' + ('(split path)' if runner is not plan else ''), launch='eager' if args.no_graph else 'hipGraph replay', noise='on-chip Philox4x32-10', finite=finite),
+                           learners_per_gpu=args.learners, parallelism=f'dp{world}' + ('(split path)' if runner is not plan else ''), launch=launch, noise='on-chip Philox4x32-10', finite=finite),
                roofline=roof)
     if world == 1 and args.learners == 1 and not args.no_population:
       # population axis (the reference's own usage: 10-seed sweeps / Ax trials): independent batch-256 learners advanced by the

@@ -96,7 +96,8 @@ _SIGNATURES = {
     'il_actor_act': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_uint64, C.c_uint32, C.c_int32, _P, _P, _P]),
     'il_batch_mix_relabel': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_int64, _P]),
     'il_act_mailbox_floats': (C.c_int32, [C.c_int32, C.c_int32]),
-    'il_act_step': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_uint64, C.c_uint32, _P]),
+    'il_act_step': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_uint64, C.c_uint32, _P, C.c_int64, _P]),
+    'il_act_publish': (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P]),
     'il_disc_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     'il_gail_disc_step': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), C.POINTER(Batch), _P, C.c_uint32, _P]),
     'il_gail_apply_grads': (C.c_int, [C.POINTER(Disc), _P]),

@@ -1062,20 +1062,25 @@ __global__ __launch_bounds__(1024) void k_act(const float* __restrict__ actor, i
 // (models.py:90-94) and hand it to the host through a pinned, device-mapped mailbox. The ring cursor lives on the device.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_act_step(const float* __restrict__ actor, int S, int A, int H, float* mail, float* __restrict__ carry, float* __restrict__ ring,
-                                                  long long* __restrict__ ring_state, int row, uint64_t seed, uint32_t offset) {
+                                                  long long* __restrict__ ring_state, int row, uint64_t seed, uint32_t offset, const int* __restrict__ version, long long mirror_stride) {
+  if (version) actor += (size_t)version[0] * mirror_stride;   // published parameter snapshot (il_act_publish): never the arena an update is rewriting
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int Sp4 = (S + 3) & ~3, Ap4 = (A + 3) & ~3;
   const float* m_next = mail + IL_MAIL_HEADER; const float* m_obs = m_next + Sp4; float* m_act = mail + IL_MAIL_HEADER + 2 * Sp4; float* m_echo = m_act + Ap4;
-  const float seq = mail[0];
-  const unsigned flags = (unsigned)mail[1];
+  // mail[0] is the commit word (sequence << 6 | IL_ACT_* flags), the LAST thing the host writes: one 4-byte store publishes the post.
+  // carry[S+A] remembers the commit word of the last appended transition, so a launch that runs again without a new post (a replayed
+  // graph, or a launch still queued when the host posts the next step) appends each transition exactly once.
+  const float commit = mail[0];
+  const unsigned word = (unsigned)commit, flags = word & 63u;
+  float* consumed = carry + S + A;
   const long long cursor = ring_state[0], cap = ring_state[2];
-  const bool pending = flags & IL_ACT_PENDING, wrap = pending && (flags & IL_ACT_WRAP_ABSORBING);
+  const bool pending = (flags & IL_ACT_PENDING) && __float_as_uint(consumed[0]) != word, wrap = pending && (flags & IL_ACT_WRAP_ABSORBING);
   const int o_next = S + A, o_rew = 2 * S + A;
   if (pending && tid < row) {
     const int c = tid;
     float v = 0.f;
-    if (c < o_next) v = carry[c];                                                        // state | action of the previous act
+    if (c < o_next) v = (flags & IL_ACT_CARRY_FROM_MAILBOX) ? (c < S ? m_obs[c] : m_act[c - S]) : carry[c];   // state | action of the transition
     else if (c < o_rew) v = wrap ? (c == o_rew - 1 ? 1.f : 0.f) : m_next[c - o_next];    // next_state, or the absorbing state (memory.py:67)
     else if (c == o_rew) v = mail[2];                                                    // reward
     else if (c == o_rew + 1) v = wrap ? 0.f : mail[3];                                   // terminal (cleared by the wrap)
@@ -1109,8 +1114,11 @@ __global__ __launch_bounds__(1024) void k_act_step(const float* __restrict__ act
     if (nc >= cap) ring_state[1] = 1;
   }
   __threadfence_system();
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(m_echo, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();   // every thread has read consumed[0] and the mailbox by now
+  if (tid == 0) {
+    if (pending) consumed[0] = __uint_as_float(word);
+    __hip_atomic_store(m_echo, commit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 extern "C" int il_actor_act(const float* actor, int32_t S, int32_t A, int32_t H, const float* states, int32_t ld_states, int32_t n, const float* eps,
@@ -1126,17 +1134,42 @@ extern "C" int il_actor_act(const float* actor, int32_t S, int32_t A, int32_t H,
   return IL_OK;
 }
 
+// Parameter snapshot for an acting worker that runs next to the updates (its own stream): copy the actor arena into slot (version+1)%3
+// of `mirror` and then advance `version` (last workgroup to finish), so a concurrent k_act_step always reads a complete snapshot.
+__global__ __launch_bounds__(256) void k_act_publish(const float* __restrict__ actor, long long n, float* __restrict__ mirror, long long stride, int* __restrict__ version,
+                                                    unsigned* __restrict__ done) {
+  const int next = (version[0] + 1) % 3;
+  float* dst = mirror + (size_t)next * stride;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = actor[i];
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(done, 1u) == gridDim.x - 1) {
+    *done = 0u;
+    __threadfence();
+    __hip_atomic_store(version, next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+extern "C" int il_act_publish(const float* actor, int64_t n, float* mirror, int64_t mirror_stride, int32_t* version_and_counter, il_stream_t stream_) {
+  IL_CHECK_ARG(actor && mirror && version_and_counter && n > 0 && mirror_stride >= n, "il_act_publish: bad arguments");
+  const int blocks = (int)((n + 1023) / 1024 < 64 ? (n + 1023) / 1024 : 64);
+  { IL_TRACE("k_act_publish", stream_); k_act_publish<<<blocks, 256, 0, (hipStream_t)stream_>>>(actor, n, mirror, mirror_stride, version_and_counter, (unsigned*)(version_and_counter + 1)); }
+  IL_CHECK_LAUNCH("il_act_publish");
+  return IL_OK;
+}
+
 extern "C" int32_t il_act_mailbox_floats(int32_t S, int32_t A) { return (IL_MAIL_HEADER + 2 * ((S + 3) & ~3) + ((A + 3) & ~3) + 1 + 15) & ~15; }
 
 extern "C" int il_act_step(const float* actor, int32_t S, int32_t A, int32_t H, float* mailbox, float* carry, float* ring, int64_t* ring_state, uint64_t noise_seed,
-                           uint32_t noise_offset, il_stream_t stream_) {
+                           uint32_t noise_offset, const int32_t* mirror_version, int64_t mirror_stride, il_stream_t stream_) {
   IL_CHECK_ARG(actor && mailbox && carry && ring && ring_state, "il_act_step: null argument");
   IL_CHECK_ARG(H % 64 == 0 && H >= 64 && H <= 256 && A >= 1 && 2 * A <= 16, "il_act_step: unsupported dims (hidden=%d, action_dim=%d)", H, A);
   const int row = il_ring_row_floats(S, A);
   IL_CHECK_ARG(row <= tile_threads(H) && 64 + S <= tile_threads(H), "il_act_step: ring row of %d floats / state_dim %d exceed the %d-thread workgroup", row, S, tile_threads(H));
   {
     IL_TRACE("k_act_step", stream_);
-    k_act_step<<<1, tile_threads(H), tile_lds_bytes(round_up16(S + A), H), (hipStream_t)stream_>>>(actor, S, A, H, mailbox, carry, ring, (long long*)ring_state, row, noise_seed, noise_offset);
+    k_act_step<<<1, tile_threads(H), tile_lds_bytes(round_up16(S + A), H), (hipStream_t)stream_>>>(actor, S, A, H, mailbox, carry, ring, (long long*)ring_state, row, noise_seed, noise_offset,
+                                                                                                    mirror_version, mirror_stride);
   }
   IL_CHECK_LAUNCH("il_act_step");
   return IL_OK;

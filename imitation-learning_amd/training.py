@@ -236,6 +236,7 @@ class UpdatePlan:
       self.transitions['rewards'] = self.rewards  # train.py:194: rewards replaced by the discriminator's prediction
     self.pb = batch_desc(self.transitions)
     self.graph = None
+    self.pre_hooks, self.post_hooks = [], []   # callables enqueuing extra work on the update's stream before / after it (captured with it), e.g. ActingWorker
     self._prepared = False   # True once an update of THIS plan has left the lane-ordered weight copies in step with the parameters
 
   def invalidate(self):
@@ -270,6 +271,13 @@ class UpdatePlan:
         _lib.ptr(self.erows) if e else None, _lib.stream_ptr()))
 
   def run(self):
+    for hook in self.pre_hooks:
+      hook()
+    self._run_update()
+    for hook in self.post_hooks:
+      hook()
+
+  def _run_update(self):
     L = _lib.lib()
     if self.algorithm == 'GAIL' and self.overlap:
       # Two streams, one hipGraph: the weight re-ordering (parameters only) runs next to the replay sampling; then the discriminator

@@ -195,21 +195,31 @@ int il_actor_act(const float* actor, int32_t state_dim, int32_t action_dim, int3
  *   [memory.append of the pending transition, memory.py:40-44] + [wrap_for_absorbing_states, memory.py:65-68] +
  *   [actor(state).sample(), models.py:90-94], with the action returned through host-pinned, device-mapped memory.
  * mailbox: il_act_mailbox_floats(S,A) floats of pinned host memory, Sp = roundup4(S), Ap = roundup4(A):
- *   host -> device  [0] sequence number  [1] IL_ACT_* flags  [2] reward  [3] terminal  [4] timeout  [5] step
+ *   host -> device  [0] commit word = sequence * 64 + IL_ACT_* flags (as a float, < 2^23), written LAST: it publishes the post
+ *                   [2] reward  [3] terminal  [4] timeout  [5] step
  *                   [8, 8+S)       next_state of the pending transition
  *                   [8+Sp, 8+Sp+S) observation to act on (== next_state unless the episode ended and the env was reset)
- *   device -> host  [8+2Sp, +A)    action;   [8+2Sp+Ap] echo of the sequence number, stored last with system-scope release
+ *   device -> host  [8+2Sp, +A)    action;   [8+2Sp+Ap] echo of the commit word, stored last with system-scope release
  *                   (the host spins on it instead of synchronising the stream).
- * carry (device, S+A floats): state | action of the pending transition, written by the previous call.
+ * carry (device, S+A+4 floats, zero-initialised): state | action of the pending transition written by the previous call, then the
+ *   commit word of the last appended transition: a launch that runs again without a new post appends nothing (exactly-once).
  * ring_state (device int64[3] = cursor, full, capacity) is advanced on the device (by 2 when the wrap is requested). */
 #define IL_MAIL_HEADER 8
 #define IL_ACT_PENDING 1u        /* a transition (carry, mailbox) is waiting to be appended */
 #define IL_ACT_WRAP_ABSORBING 2u /* episode ended by true termination with absorbing=true: rewrite + extra row */
 #define IL_ACT_GREEDY 4u         /* tanh(mean) instead of a sample */
 #define IL_ACT_NO_ACTION 8u      /* append only: no policy evaluation, carry left untouched */
+#define IL_ACT_CARRY_FROM_MAILBOX 16u /* the pending transition's state | action come from the mailbox's observation / action slots
+                                       * (written back by the host) instead of `carry`: for a worker whose act launches run ahead of its appends */
 int32_t il_act_mailbox_floats(int32_t state_dim, int32_t action_dim);
+/* mirror_version != NULL: `actor` is the base of 3 parameter snapshots `mirror_stride` floats apart and *mirror_version selects one
+ * (see il_act_publish); NULL: `actor` is the live arena (launch on the stream the updates run on). */
 int il_act_step(const float* actor, int32_t state_dim, int32_t action_dim, int32_t hidden, float* mailbox, float* carry, float* ring,
-                int64_t* ring_state, uint64_t noise_seed, uint32_t noise_offset, il_stream_t stream);
+                int64_t* ring_state, uint64_t noise_seed, uint32_t noise_offset, const int32_t* mirror_version, int64_t mirror_stride,
+                il_stream_t stream);
+/* Publish the actor arena (n floats) into snapshot slot (version+1)%3 of `mirror` and advance the version. version_and_counter: device
+ * int32[2] = {version, internal completion counter}, zero-initialised. Enqueue after every update (capturable into the update's graph). */
+int il_act_publish(const float* actor, int64_t n, float* mirror, int64_t mirror_stride, int32_t* version_and_counter, il_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * GAIL discriminator (reference training.py:85-134 adversarial_imitation_update with loss_function=BCE;

@@ -14,9 +14,12 @@ from imitation_learning_amd.environments import make_env  # noqa: E402
 
 
 def loop(schedule, plan, actor, memory, env, steps, update):
-  worker = il.ActingWorker(actor, memory) if schedule != 'per_function' else None
+  worker = il.ActingWorker(actor, memory, mirror=schedule == 'overlap') if schedule != 'per_function' else None
+  if schedule == 'overlap' and update:   # re-capture the update with this worker's append + snapshot inside the graph
+    plan.graph = None; plan.pre_hooks.clear(); plan.post_hooks.clear()
+    worker.attach(plan); plan.capture(warmup=0)
   state, t = env.reset(), 0
-  action = worker.act(state) if schedule == 'overlap' else None
+  action = worker.act(state) if schedule in ('fused', 'overlap') else None
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   for step in range(1, steps + 1):
@@ -31,11 +34,17 @@ def loop(schedule, plan, actor, memory, env, steps, update):
       nxt, r, term = env.step(action); t += 1
       worker.append(step, nxt, r, term and t != env.max_episode_steps, t == env.max_episode_steps)
       state = env.reset() if term else nxt
-    else:
+    elif schedule == 'fused':
       nxt, r, term = env.step(action); t += 1
       action = worker.step(step, nxt, r, term and t != env.max_episode_steps, t == env.max_episode_steps, obs=env.reset() if term else None)
+    else:
+      nxt, r, term = env.step(action); t += 1
+      worker.post(step, state, action, nxt, r, term and t != env.max_episode_steps, t == env.max_episode_steps)
+      state = env.reset() if term else nxt
+      if not update: worker.enqueue_append()
     if term: t = 0
     if update: plan.replay()
+    if schedule == 'overlap': action = worker.act(state)
   torch.cuda.synchronize()
   return steps / (time.perf_counter() - t0)
 
@@ -55,7 +64,7 @@ def main():
   env_only = 2000 / (time.perf_counter() - t0)
   out = dict(env_only_steps_per_s=round(env_only, 1))
   for update in (False, True):
-    for schedule in ('per_function', 'exact', 'overlap'):
+    for schedule in ('per_function', 'exact', 'fused', 'overlap'):
       loop(schedule, plan, actor, memory, env, 200, update)
       out[f'{schedule}{"+update" if update else ""}'] = round(loop(schedule, plan, actor, memory, env, 3000, update), 1)
   print(json.dumps(out))

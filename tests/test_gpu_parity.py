@@ -530,7 +530,7 @@ def _episode_script(rs, n, S, absorbing):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('absorbing', [True, False])
-@pytest.mark.parametrize('schedule', ['exact', 'overlap'])
+@pytest.mark.parametrize('schedule', ['exact', 'fused', 'overlap'])
 def test_acting_worker_matches_separate_calls(absorbing, schedule):
   """One launch per env step (mailbox in pinned memory, cursor on the device) against the per-function path: same actions (same
   Philox offsets), bit-identical ring including absorbing wraps and ring wrap-around, same host-side cursor / trajectory count."""
@@ -556,7 +556,7 @@ def test_acting_worker_matches_separate_calls(absorbing, schedule):
     else:
       obs = nxt_t
 
-  w = il.ActingWorker(actor_b, mem_b)
+  w = il.ActingWorker(actor_b, mem_b, mirror=schedule == 'overlap')
   acts_b, k = [], 0
   if schedule == 'exact':
     obs = first
@@ -565,13 +565,24 @@ def test_acting_worker_matches_separate_calls(absorbing, schedule):
       w.append(t, nxt, rew, term, tout)
       if term or tout: obs = resets[k]; k += 1
       else: obs = nxt
-  else:
+  elif schedule == 'fused':
     a = w.act(first)
     for t, (nxt, rew, term, tout) in enumerate(script, 1):
       acts_b.append(N(a))
       ended = term or tout
       a = w.step(t, nxt, rew, term, tout, obs=resets[k] if ended else None)
       k += int(ended)
+  else:  # act on its own stream from the published snapshot (== the live parameters here: nothing updates them), appends on the main stream
+    obs, a = first, w.act(first)
+    for t, (nxt, rew, term, tout) in enumerate(script, 1):
+      acts_b.append(N(a))
+      w.post(t, obs, a, nxt, rew, term, tout)
+      w.enqueue_append()
+      if t % 3 == 0: w.enqueue_append()   # a replayed launch without a new post must append nothing
+      ended = term or tout
+      obs = resets[k] if ended else nxt
+      k += int(ended)
+      a = w.act(obs)
   torch.cuda.synchronize()
   np.testing.assert_array_equal(np.concatenate(acts_a), np.concatenate(acts_b))
   np.testing.assert_array_equal(N(mem_a.ring), N(mem_b.ring))
@@ -587,7 +598,7 @@ def test_acting_worker_greedy_and_loud_failure():
   w = il.ActingWorker(actor_b, mem_b)
   np.testing.assert_array_equal(N(w.act(obs, greedy=True)), N(actor_a.get_greedy_action(torch.from_numpy(obs))))
   L = _lib.lib()
-  assert L.il_act_step(None, 18, 6, 256, None, None, None, None, 0, 0, None) != 0 and b'il_act_step' in L.il_last_error()
+  assert L.il_act_step(None, 18, 6, 256, None, None, None, None, 0, 0, None, 0, None) != 0 and b'il_act_step' in L.il_last_error()
 
 
 # ---------------------------------------------------------------------------------------------

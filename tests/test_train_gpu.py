@@ -23,6 +23,9 @@ COMMON = ['steps=260', 'training.start=120', 'evaluation.interval=130', 'evaluat
     ['algorithm=AdRIL', 'env=walker2d', 'imitation.update_freq=0', 'imitation.balanced=false'],   # SQIL
     ['algorithm=RED', 'env=hopper', 'imitation.pretraining.iterations=50'],
     ['algorithm=SAC', 'env=hopper', '+acting.schedule=overlap'],
+    ['algorithm=GAIL', 'env=halfcheetah', '+acting.schedule=overlap'],
+    ['algorithm=AdRIL', 'env=hopper', '+acting.schedule=overlap'],
+    ['algorithm=SAC', 'env=walker2d', '+acting.schedule=fused'],
     ['algorithm=GAIL', 'env=walker2d', '+acting.schedule=per_function'],
     ['algorithm=BC', 'env=hopper', 'bc_pretraining.iterations=60'],
 ])

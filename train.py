@@ -122,19 +122,21 @@ def train(cfg, file_prefix: str = '') -> float:
   captured = False
 
   # acting (train.py:151-168): il_act_step through a pinned mailbox; PWIL computes its reward per step on the device and keeps the per-function path
-  schedule = (cfg.get('acting', {}) or {}).get('schedule', 'exact')  # `+acting.schedule=overlap`: env.step on the host overlaps the GPU update (policy lags one update)
-  assert schedule in ('exact', 'overlap', 'per_function')
-  worker = il.ActingWorker(actor, memory) if cfg.algorithm != 'PWIL' and schedule != 'per_function' else None
+  schedule = (cfg.get('acting', {}) or {}).get('schedule', 'exact')  # `+acting.schedule=fused|overlap`: see imitation_learning_amd/acting.py (behaviour policy lags 1-2 updates)
+  assert schedule in ('exact', 'fused', 'overlap', 'per_function')
+  worker = il.ActingWorker(actor, memory, mirror=schedule == 'overlap') if cfg.algorithm != 'PWIL' and schedule != 'per_function' else None
+  if worker is None: schedule = 'per_function'
+  if schedule == 'overlap' and plan is not None: worker.attach(plan)   # append + parameter snapshot ride in the update's hipGraph
   t, state, terminal, train_return = 0, env.reset(), False, 0
-  action = worker.act(state) if worker is not None and schedule == 'overlap' else None
+  action = worker.act(state) if schedule in ('fused', 'overlap') else None
   for step in range(1, cfg.steps + 1):
-    if worker is None:
+    update_due = step >= cfg.training.start and step % cfg.training.interval == 0
+    if schedule == 'per_function':
       with torch.inference_mode():
         action = actor(state).sample()
         next_state, reward, terminal = env.step(action)
         t += 1
-        if cfg.algorithm == 'PWIL': reward_stored = discriminator.compute_reward(state, action)
-        else: reward_stored = reward
+        reward_stored = discriminator.compute_reward(state, action) if cfg.algorithm == 'PWIL' else reward
         memory.append(step, state, action, reward_stored, next_state, terminal and t != env.max_episode_steps, t == env.max_episode_steps)
         if terminal and cfg.imitation.absorbing and t != env.max_episode_steps: memory.wrap_for_absorbing_states()
     else:
@@ -142,16 +144,24 @@ def train(cfg, file_prefix: str = '') -> float:
       next_state, reward, terminal = env.step(action)
       t += 1
       timed_out = t == env.max_episode_steps
-      if schedule == 'exact': worker.append(step, next_state, reward, terminal and not timed_out, timed_out)
-      else: action = worker.step(step, next_state, reward, terminal and not timed_out, timed_out, obs=(reset_state := env.reset()) if terminal else None)
+      following = env.reset() if terminal else next_state   # the observation the next action is for
+      if schedule == 'exact':
+        worker.append(step, next_state, reward, terminal and not timed_out, timed_out)
+      elif schedule == 'fused':
+        action = worker.step(step, next_state, reward, terminal and not timed_out, timed_out, obs=following)
+      else:
+        worker.post(step, state, action, next_state, reward, terminal and not timed_out, timed_out)
+        if not (update_due and plan is not None): worker.enqueue_append()   # otherwise the update graph carries it
     train_return += reward
-    state = next_state
     if terminal:
       if cfg.algorithm == 'PWIL': discriminator.reset()
       metrics['train_steps'].append(step); metrics['train_returns'].append([train_return])
-      t, state, train_return = 0, (reset_state if worker is not None and schedule == 'overlap' else env.reset()), 0
+      t, train_return = 0, 0
+      state = env.reset() if schedule == 'per_function' else following
+    else:
+      state = next_state
 
-    if step >= cfg.training.start and step % cfg.training.interval == 0:
+    if update_due:
       if plan is not None:
         if not captured:
           plan.run(); plan.capture(warmup=0); captured = True   # first update eagerly (loads code objects), then capture
@@ -178,9 +188,12 @@ def train(cfg, file_prefix: str = '') -> float:
         log_probs, Q_values = il.sac_update(actor, critic, log_alpha, target_critic, transitions, actor_optimiser, critic_optimiser, temperature_optimiser, cfg.reinforcement.discount,
                                             entropy_target, cfg.reinforcement.polyak_factor)
         rewards = transitions['rewards']
+      if schedule == 'overlap' and plan is None: worker.enqueue_publish()
       if cfg.logging.interval > 0 and step % cfg.logging.interval == 0:  # the only D2H reads of the update path (train.py:205-210)
         metrics['update_steps'].append(step); metrics['predicted_rewards'].append(rewards.cpu().numpy())
         metrics['alphas'].append(log_alpha.exp().cpu().numpy()); metrics['entropies'].append((-log_probs).cpu().numpy()); metrics['Q_values'].append(Q_values.cpu().numpy())
+
+    if schedule == 'overlap': action = worker.act(state)   # own stream, published snapshot: returns while the update is still running
 
     if step % cfg.evaluation.interval == 0 and not cfg.check_time_usage:
       episode_returns = evaluate_agent(actor, eval_env, cfg.evaluation.episodes)
