@@ -55,6 +55,11 @@ class Red(C.Structure):
               ('sigma_1', C.c_float), ('reserved2', C.c_float), ('out_pred', C.c_void_p), ('out_target', C.c_void_p)]
 
 
+class Dril(C.Structure):
+  _fields_ = [('state_dim', C.c_int32), ('action_dim', C.c_int32), ('hidden', C.c_int32), ('batch', C.c_int32), ('p_in', C.c_float), ('p', C.c_float),
+              ('params', C.c_void_p), ('grad', C.c_void_p), ('opt', Adam), ('workspace', C.c_void_p), ('noise_seed', C.c_uint64), ('q', C.c_float), ('reserved', C.c_float)]
+
+
 class SampleArgs(C.Structure):
   _fields_ = [('state', C.c_void_p),
               ('ring_state_a', C.c_void_p), ('ring_a', C.c_void_p), ('capacity_a', C.c_int64), ('row_floats_a', C.c_int32), ('idx_a', C.c_void_p), ('rows_a', C.c_void_p),
@@ -107,6 +112,10 @@ _SIGNATURES = {
     'il_gmmil_sqdist': (C.c_int, [C.POINTER(Batch), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
     'il_pwil_reset': (C.c_int, [C.POINTER(Pwil), _P]),
     'il_pwil_reward': (C.c_int, [C.POINTER(Pwil), _P, _P, _P, _P]),
+    'il_dril_numel': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    'il_dril_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'il_dril_bc_step': (C.c_int, [C.POINTER(Dril), C.POINTER(Batch), _P, _P, C.c_uint32, _P, C.c_uint32, _P]),
+    'il_dril_uncertainty': (C.c_int, [C.POINTER(Dril), C.POINTER(Batch), _P, _P, C.c_uint32, _P, _P, _P]),
     'il_red_numel': (C.c_int64, [C.c_int32, C.c_int32]),
     'il_red_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     'il_red_step': (C.c_int, [C.POINTER(Red), C.POINTER(Batch), _P, C.c_uint32, _P]),

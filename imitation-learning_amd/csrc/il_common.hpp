@@ -139,6 +139,8 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
   p = __fsub_rn(p, __fmul_rn(c.step_size, __fdiv_rn(m, denom)));                  // addcdiv_
 }
 
+#define LOG_SQRT_2PI 0.91893853320467274178f
+#define LOG_2 0.69314718055994530942f
 __device__ __forceinline__ float softplus_f(float z) { return z > 20.f ? z : log1pf(expf(z)); }
 __device__ __forceinline__ float sigmoid_f(float z) { return 1.f / (1.f + expf(-z)); }
 

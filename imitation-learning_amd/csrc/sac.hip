@@ -15,8 +15,6 @@
 #include "il_common.hpp"
 #include "mlp_tile.hpp"
 
-#define LOG_SQRT_2PI 0.91893853320467274178f
-#define LOG_2 0.69314718055994530942f
 
 struct SacWs {  // float offsets into il_sac.workspace
   int64_t a_h1, a_h2, a_xpre, a_eps, a_lsraw, a_anew, a_logp, n_a2, n_logp2;

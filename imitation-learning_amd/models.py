@@ -84,6 +84,12 @@ class _FlatModule(nn.Module):
 class SoftActor(_FlatModule):
   """Tanh-Gaussian policy (reference models.py:84-120). `actor(state).sample()` / `get_greedy_action` run k_act on the GPU."""
 
+  def __new__(cls, state_size=None, action_size=None, model_cfg=None, device=None):
+    # train.py:73 builds the DRIL "discriminator" with this same class from conf/algorithm/DRIL.yaml's depth-1 tanh dropout config
+    if cls is SoftActor and model_cfg is not None and _cfg_get(model_cfg, 'depth') == 1 and _cfg_get(model_cfg, 'activation') == 'tanh':
+      return super().__new__(DropoutSoftActor)
+    return super().__new__(cls)
+
   def __init__(self, state_size: int, action_size: int, model_cfg, device=None):
     super().__init__()
     self.state_size, self.action_size = state_size, action_size
@@ -140,6 +146,100 @@ class SoftActor(_FlatModule):
     normal = -((x - mean) ** 2) / (2 * (2 * log_std).exp()) - log_std - 0.9189385332046727
     ladj = 2.0 * (0.6931471805599453 - x - torch.nn.functional.softplus(-2.0 * x))
     return normal.sum(dim=1) - ladj.sum(dim=1)
+
+
+class DropoutSoftActor(SoftActor):
+  """The DRIL policy ensemble (reference models.py:84-120 with conf/algorithm/DRIL.yaml: Dropout(p_in)-Linear(S,H)-Dropout(p)-Tanh-Linear(H,2A)).
+
+  Created through `SoftActor(state_size, action_size, cfg.imitation.discriminator)` like in the reference (train.py:73). It stays in train
+  mode (dropout active) for its whole life, as the reference's does: `behavioural_cloning_update` on it runs k_dril_grad / k_dril_apply,
+  the Monte-Carlo-dropout uncertainty runs k_dril_unc.  Pass `masks=(mask_in, mask_hidden)` to reproduce given dropout draws; otherwise the
+  masks come from the on-chip Philox stream.  state_dict keys: actor.1.*, actor.4.* (the Dropout / Tanh modules occupy 0, 2, 3)."""
+  ENSEMBLE = 5
+
+  def __init__(self, state_size: int, action_size: int, model_cfg, device=None):
+    nn.Module.__init__(self)
+    self.state_size, self.action_size, self.hidden = state_size, action_size, int(_cfg_get(model_cfg, 'hidden_size'))
+    self.p_in, self.p = float(_cfg_get(model_cfg, 'input_dropout', 0) or 0), float(_cfg_get(model_cfg, 'dropout', 0) or 0)
+    if state_size > 128 or 2 * action_size > 16 or self.hidden > 256 or self.hidden % 2:
+      raise NotImplementedError(f'DRIL policy: state {state_size} (<= 128), action {action_size} (<= 8), hidden {self.hidden} (even, <= 256) outside the kernel limits')
+    self.log_std_dev_min, self.log_std_dev_max = -20, 2
+    l1, l2 = nn.Linear(state_size, self.hidden), nn.Linear(self.hidden, 2 * action_size)
+    nn.init.orthogonal_(l1.weight, gain=nn.init.calculate_gain('tanh')); nn.init.constant_(l1.bias, 0)
+    nn.init.orthogonal_(l2.weight, gain=1.0); nn.init.constant_(l2.bias, 0)
+    layers = ([nn.Dropout(self.p_in)] if self.p_in > 0 else []) + [l1] + ([nn.Dropout(self.p)] if self.p > 0 else []) + [nn.Tanh(), l2]
+    self.actor = nn.Sequential(*layers)   # module indices (hence state_dict keys) as in the reference's _create_fcnn
+    offs, o = [], 0
+    for p in self.parameters():
+      offs.append(o); o += p.numel()
+    assert o == int(_lib.lib().il_dril_numel(state_size, action_size, self.hidden))
+    self._adopt(o, offs, device or default_device())
+    self._act_calls, self.q = 0, None
+
+  def _desc(self, batch_size: int, opt=None) -> '_lib.Dril':
+    d = _lib.Dril()
+    d.state_dim, d.action_dim, d.hidden, d.batch, d.p_in, d.p = self.state_size, self.action_size, self.hidden, batch_size, self.p_in, self.p
+    d.params, d.noise_seed, d.q = self.flat.data_ptr(), torch.initial_seed() & (2**64 - 1), float(self.q) if self.q is not None else 0.0
+    if opt is not None:
+      from .training import _workspace
+      ws = _workspace('dril', int(_lib.lib().il_dril_workspace_floats(self.state_size, self.action_size, self.hidden, batch_size)), self.flat.device)
+      d.grad, d.opt, d.workspace = opt.grad.data_ptr(), opt.desc(), ws.data_ptr()
+    return d
+
+  def _masks(self, masks, rows):
+    if masks is None:
+      return None, None
+    dev = self.flat.device
+    m0, m1 = (x.to(dev, torch.float32).contiguous() for x in masks)
+    assert m0.shape == (rows, self.state_size) and m1.shape == (rows, self.hidden), 'dropout keep-masks must be [rows, S] and [rows, H]'
+    return m0, m1
+
+  def _next_offset(self) -> int:
+    self._act_calls += 1
+    return self._act_calls & 0xFFFFFFFF
+
+  def bc_update(self, expert_transition, optimiser, masks=None, want_loss: bool = False):
+    from .memory import batch_desc
+    t = dict(expert_transition)
+    for k in ('rewards', 'terminals', 'absorbing', 'next_states'):
+      t.setdefault(k, t['weights'] if k != 'next_states' else t['states'])
+    b = batch_desc(t)
+    m0, m1 = self._masks(masks, b.n)
+    loss = torch.empty(1, device=self.flat.device) if want_loss else None
+    d = self._desc(b.n, optimiser)
+    _lib.check(_lib.lib().il_dril_bc_step(C.byref(d), C.byref(b), _lib.ptr(m0), _lib.ptr(m1), self._next_offset(), _lib.ptr(loss), 0, _lib.stream_ptr()))
+    return loss
+
+  def _uncertainty(self, state: Tensor, action: Tensor, masks=None, want_reward: bool = False) -> Tensor:
+    from .training import _sa_batch
+    dev = self.flat.device
+    state, action = state.to(dev, torch.float32), action.to(dev, torch.float32)
+    if state.stride(-1) != 1: state = state.contiguous()
+    if action.stride(-1) != 1: action = action.contiguous()
+    n = state.size(0)
+    b = _sa_batch(state, action, torch.ones(n, device=dev))
+    m0, m1 = self._masks(masks, n * self.ENSEMBLE)
+    out = torch.empty(n, device=dev)
+    d = self._desc(n)
+    _lib.check(_lib.lib().il_dril_uncertainty(C.byref(d), C.byref(b), _lib.ptr(m0), _lib.ptr(m1), self._next_offset(), None if want_reward else _lib.ptr(out),
+                                              _lib.ptr(out) if want_reward else None, _lib.stream_ptr()))
+    return out
+
+  def _get_action_uncertainty(self, state: Tensor, action: Tensor, masks=None) -> Tensor:
+    """models.py:104-107: variance over 5 dropout masks of exp(log_prob(state, action))."""
+    return self._uncertainty(state, action, masks)
+
+  def set_uncertainty_threshold(self, expert_state: Tensor, expert_action: Tensor, quantile_cutoff: float, masks=None):
+    self.q = torch.quantile(self._uncertainty(expert_state, expert_action, masks), quantile_cutoff).item()   # models.py:110-111
+
+  def predict_reward(self, state: Tensor, action: Tensor, masks=None) -> Tensor:
+    assert self.q is not None, 'predict_reward before set_uncertainty_threshold (train.py:126)'
+    return self._uncertainty(state, action, masks, want_reward=True)
+
+  def forward(self, state):
+    raise NotImplementedError('the DRIL policy ensemble is only evaluated through log-probabilities of given actions (uncertainty / BC) on the HIP path')
+
+  get_greedy_action = log_prob = forward
 
 
 class Critic(nn.Module):

@@ -77,8 +77,11 @@ def sac_update(actor: SoftActor, critic: TwinCritic, log_alpha: Tensor, target_c
   return logp, q
 
 
-def behavioural_cloning_update(actor: SoftActor, expert_transition: Dict[str, Tensor], actor_optimiser: AdamW) -> Tensor:
-  """Reference training.py:57-64. Returns the (device) loss for logging; the reference returns None."""
+def behavioural_cloning_update(actor: SoftActor, expert_transition: Dict[str, Tensor], actor_optimiser: AdamW, *, masks=None) -> Tensor:
+  """Reference training.py:57-64. Returns the (device) loss for logging; the reference returns None.
+  The DRIL policy ensemble (depth-1 tanh dropout network, train.py:119) takes the k_dril_* path; `masks` = its dropout keep-masks, if given."""
+  if hasattr(actor, 'bc_update'):
+    return actor.bc_update(expert_transition, actor_optimiser, masks=masks, want_loss=True)
   dev = actor.flat.device
   t = {k: v for k, v in expert_transition.items()}
   for k in ('rewards', 'next_states', 'terminals', 'absorbing'):  # not read by k_bc_tile, but il_batch wants valid pointers

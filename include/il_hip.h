@@ -304,6 +304,33 @@ int il_red_step(const il_red* d, const il_batch* expert, float* out_loss, uint32
  * out_pred, out_target [n, D] (what set_sigma feeds to the pairwise distance + median). */
 int il_red_forward(const il_red* d, const il_batch* batch, float* out_reward, float* out_pred, float* out_target, il_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * DRIL (reference models.py:84-120: SoftActor built from conf/algorithm/DRIL.yaml's discriminator config = Dropout(p_in) -> Linear(S,H)
+ * -> Dropout(p) -> Tanh -> Linear(H,2A), kept in train mode; training.py:57-64 behavioural_cloning_update trains it).
+ * Flat arena in parameters() order [W1 (H,S) | b1 (H) | W2 (2A,H) | b2 (2A)], il_dril_numel floats.
+ * Dropout keep-masks (1 = kept) may be supplied (what the parity tests do) or NULL = drawn on chip (Philox, noise_seed / noise_offset).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct il_dril {
+  int32_t state_dim, action_dim, hidden, batch;
+  float p_in, p;        /* input_dropout, dropout */
+  float* params;
+  float* grad;          /* [P] */
+  il_adam opt;
+  float* workspace;     /* >= il_dril_workspace_floats(S, A, H, batch) */
+  uint64_t noise_seed;
+  float q;              /* uncertainty threshold (models.py:110-111 set_uncertainty_threshold) */
+  float reserved;
+} il_dril;
+int64_t il_dril_numel(int32_t state_dim, int32_t action_dim, int32_t hidden);
+int64_t il_dril_workspace_floats(int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t batch);
+/* behavioural_cloning_update on the dropout policy: loss = mean_i w_i * -log pi(a_i | s_i; masks), AdamW. mask_in [B,S], mask_hidden [B,H] or NULL. */
+int il_dril_bc_step(const il_dril* d, const il_batch* expert, const float* mask_in, const float* mask_hidden, uint32_t noise_offset, float* out_loss,
+                    uint32_t flags, il_stream_t stream);
+/* models.py:104-120: Monte-Carlo dropout uncertainty = unbiased variance over 5 masks of exp(log_prob(s, a)); masks [5n,S], [5n,H] in
+ * repeat_interleave order or NULL. out_uncertainty [n] and / or out_reward [n] = (uncertainty <= d->q ? +1 : -1). */
+int il_dril_uncertainty(const il_dril* d, const il_batch* batch, const float* mask_in, const float* mask_hidden, uint32_t noise_offset,
+                        float* out_uncertainty, float* out_reward, il_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,3 +118,19 @@ def red_case(seed, env, hidden, batch, steps):
   batches = [transitions(rs, batch, S, A, state_shift=0.5, weighted=True) for _ in range(steps)]
   return dict(S=S, A=A, D=D, H=hidden, B=batch, predictor=predictor, target=target, batches=batches,
               sigma_batch=transitions(rs, batch, S, A, state_shift=0.5), query=transitions(rs, batch + 16, S, A))
+
+
+def dril_case(seed, env, hidden, batch, steps, p_in=0.1, p=0.1):
+  """DRIL policy ensemble (Dropout-Linear(S,H)-Dropout-Tanh-Linear(H,2A)), expert batches with their dropout keep-masks, and the masks of
+  the 5-member Monte-Carlo ensemble for an expert set and a query set (rows in repeat_interleave order)."""
+  S, A = DIMS[env]
+  rs = np.random.RandomState(seed)
+  params = mlp_params(rs, S, hidden, 1, 2 * A, out_scale=0.3)
+  keep = lambda shape, pr: (rs.uniform(size=shape) >= pr).astype(f32)
+  batches = [transitions(rs, batch, S, A, state_shift=0.5, weighted=True) for _ in range(steps)]
+  for b in batches:
+    b['actions'] = np.clip(b['actions'], -0.97, 0.97).astype(f32); b['actions'][:2] = np.array([1.0, -1.0], f32)[:, None]  # exercise the clamp
+  expert, query = transitions(rs, 80, S, A, state_shift=0.5), transitions(rs, 37, S, A)
+  return dict(S=S, A=A, H=hidden, B=batch, p_in=p_in, p=p, params=params, batches=batches, m0=[keep((batch, S), p_in) for _ in range(steps)],
+              m1=[keep((batch, hidden), p) for _ in range(steps)], expert=expert, query=query, e_m0=keep((80 * 5, S), p_in), e_m1=keep((80 * 5, hidden), p),
+              q_m0=keep((37 * 5, S), p_in), q_m1=keep((37 * 5, hidden), p))

@@ -291,6 +291,53 @@ def gen_red():
   np.savez_compressed(os.path.join(HERE, 'red.npz'), **out)
 
 
+class DropoutFeed:
+  """Feeds pre-drawn keep-masks to F.dropout (nn.Dropout.forward), in call order, with ATen's arithmetic (mask / (1 - p), then multiply)."""
+
+  def __init__(self, masks):
+    self.masks, self._orig = list(masks), torch.nn.functional.dropout
+
+  def __enter__(self):
+    def dropout(input, p=0.5, training=True, inplace=False):
+      if not training or p == 0: return input
+      return input * (self.masks.pop(0) / (1 - p))
+    torch.nn.functional.dropout = dropout
+    return self
+
+  def __exit__(self, *a):
+    torch.nn.functional.dropout = self._orig
+    assert not self.masks, 'unused dropout masks'
+
+
+def gen_dril():
+  """SoftActor with the DRIL discriminator config (models.py:84-120) in train mode: 3 BC updates, uncertainty, threshold, reward."""
+  out = {}
+  for name, c, lr, wd in (('hopper_h64', gi.dril_case(71, 'hopper', 64, 64, 3), 3e-5, 0.0), ('halfcheetah_h32', gi.dril_case(72, 'halfcheetah', 32, 128, 2, p_in=0.2, p=0.3), 1e-3, 0.01)):
+    cfg = DictConfig(hidden_size=c['H'], depth=1, activation='tanh', input_dropout=c['p_in'], dropout=c['p'])
+    d = ref_models.SoftActor(c['S'], c['A'], cfg)
+    assert [k for k in d.state_dict()] == ['actor.1.weight', 'actor.1.bias', 'actor.4.weight', 'actor.4.bias']
+    torch.nn.utils.vector_to_parameters(T(c['params']), d.parameters())
+    opt = torch.optim.AdamW(d.parameters(), lr=lr, weight_decay=wd)
+    for k, (b, m0, m1) in enumerate(zip(c['batches'], c['m0'], c['m1']), 1):
+      with DropoutFeed([T(m0), T(m1)]):
+        ref_training.behavioural_cloning_update(d, tbatch(b), opt)
+      out[f'{name}.params.{k}'] = flat(d)
+    out[f'{name}.exp_avg'] = opt_state(opt, 'exp_avg')
+    with torch.inference_mode():
+      e, q = tbatch(c['expert']), tbatch(c['query'])
+      with DropoutFeed([T(c['e_m0']), T(c['e_m1'])]):
+        out[f'{name}.expert_uncertainty'] = N_(d._get_action_uncertainty(e['states'], e['actions']))
+      with DropoutFeed([T(c['e_m0']), T(c['e_m1'])]):
+        d.set_uncertainty_threshold(e['states'], e['actions'], 0.9)
+      out[f'{name}.q'] = np.array([d.q], np.float64)
+      with DropoutFeed([T(c['q_m0']), T(c['q_m1'])]):
+        out[f'{name}.reward'] = N_(d.predict_reward(q['states'], q['actions']))
+      with DropoutFeed([T(c['q_m0']), T(c['q_m1'])]):
+        out[f'{name}.query_uncertainty'] = N_(d._get_action_uncertainty(q['states'], q['actions']))
+    out[f'{name}.hyper'] = np.array([lr, wd], np.float64)
+  np.savez_compressed(os.path.join(HERE, 'dril.npz'), **out)
+
+
 if __name__ == '__main__':
   only = set(sys.argv[1:])  # e.g. `make_golden.py adril` regenerates just that fixture
   want = lambda tag: not only or tag in only
@@ -308,3 +355,4 @@ if __name__ == '__main__':
   if want('pwil'): gen_pwil()
   if want('adril'): gen_adril()
   if want('red'): gen_red()
+  if want('dril'): gen_dril()

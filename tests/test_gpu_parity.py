@@ -690,3 +690,57 @@ def test_red_loud_failures():
     il.REDDiscriminator(11, 3, icfg, device=DEV)
   L = _lib.lib()
   assert L.il_red_step(None, None, None, 0, None) != 0 and b'il_red' in L.il_last_error()
+
+
+# ---------------------------------------------------------------------------------------------
+# DRIL dropout policy ensemble (models.py:84-120 + training.py:57-64) against the reference-generated fixture and the oracle
+# ---------------------------------------------------------------------------------------------
+DRIL_CASES = [('hopper_h64', (71, 'hopper', 64, 64, 3), {}), ('halfcheetah_h32', (72, 'halfcheetah', 32, 128, 2), dict(p_in=0.2, p=0.3))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,case,kw', DRIL_CASES)
+def test_dril_matches_reference(golden_dir, name, case, kw):
+  from oracle import dril as odril
+  g = load(golden_dir, 'dril')
+  c = gi.dril_case(*case, **kw)
+  lr, wd = (float(x) for x in g[f'{name}.hyper'])
+  d = il.SoftActor(c['S'], c['A'], Cfg(hidden_size=c['H'], depth=1, activation='tanh', input_dropout=c['p_in'], dropout=c['p']), device=DEV)
+  assert type(d).__name__ == 'DropoutSoftActor' and list(d.state_dict()) == ['actor.1.weight', 'actor.1.bias', 'actor.4.weight', 'actor.4.bias']
+  d.flat.copy_(T(c['params']))
+  opt = il.AdamW(d, lr=lr, weight_decay=wd)
+  ds = odril.DrilState(c['S'], c['A'], c['H'], c['p_in'], c['p']); ds.params[:] = c['params']
+  for k, (b, m0, m1) in enumerate(zip(c['batches'], c['m0'], c['m1']), 1):
+    loss = il.behavioural_cloning_update(d, tbatch(b), opt, masks=(T(m0), T(m1)))
+    oloss = odril.bc_update(ds, b, m0, m1, lr=lr, weight_decay=wd)
+    close(N(loss)[0], oloss, f'{name} BC loss {k}')
+    close_params(N(d.flat), g[f'{name}.params.{k}'], f'{name} params after update {k} (reference)', lr, steps=k)
+    close_params(N(d.flat), ds.params, f'{name} params after update {k} (oracle)', lr, steps=k)
+  close(N(opt.exp_avg), g[f'{name}.exp_avg'], f'{name} exp_avg', rtol=1e-4)
+  # uncertainty / threshold / reward on the reference's trained parameters. The variance of 5 nearly equal probabilities cancels
+  # leading digits, so it is compared at 1e-4 of the largest value in the batch rather than 1e-5 per element.
+  d.flat.copy_(T(g[f'{name}.params.{len(c["batches"])}']))
+  e, q = tbatch(c['expert']), tbatch(c['query'])
+  ue = N(d._get_action_uncertainty(e['states'], e['actions'], masks=(T(c['e_m0']), T(c['e_m1']))))
+  ref_ue = g[f'{name}.expert_uncertainty']
+  assert np.abs(ue - ref_ue).max() <= 1e-4 * np.abs(ref_ue).max() + 1e-5 * 0
+  d.set_uncertainty_threshold(e['states'], e['actions'], 0.9, masks=(T(c['e_m0']), T(c['e_m1'])))
+  assert abs(d.q - float(g[f'{name}.q'][0])) <= 1e-4 * abs(d.q)
+  d.q = float(g[f'{name}.q'][0])
+  r = N(d.predict_reward(q['states'], q['actions'], masks=(T(c['q_m0']), T(c['q_m1']))))   # 37 rows: ragged tiles
+  ref_r, ref_u = g[f'{name}.reward'], g[f'{name}.query_uncertainty']
+  decided = np.abs(ref_u - d.q) > 1e-4 * np.abs(ref_u).max()   # rows whose uncertainty is not within rounding of the threshold
+  assert decided.sum() >= len(ref_r) - 2 and np.array_equal(r[decided], ref_r[decided]) and set(np.unique(r)) <= {-1.0, 1.0}
+
+
+@pytest.mark.gpu
+def test_dril_onchip_masks_are_bernoulli_and_change_per_call():
+  c = gi.dril_case(71, 'hopper', 64, 64, 1)
+  d = il.SoftActor(c['S'], c['A'], Cfg(hidden_size=64, depth=1, activation='tanh', input_dropout=0.1, dropout=0.1), device=DEV)
+  d.flat.copy_(T(c['params']))
+  e = tbatch(c['expert'])
+  u1, u2 = N(d._get_action_uncertainty(e['states'], e['actions'])), N(d._get_action_uncertainty(e['states'], e['actions']))
+  assert np.isfinite(u1).all() and (u1 >= 0).all() and (u1 > 0).mean() > 0.9 and not np.array_equal(u1, u2)
+  nodrop = il.SoftActor(c['S'], c['A'], Cfg(hidden_size=64, depth=1, activation='tanh', input_dropout=0, dropout=0), device=DEV)
+  nodrop.flat.copy_(T(c['params']))
+  assert float(nodrop._get_action_uncertainty(e['states'], e['actions']).abs().max()) < 1e-12   # no dropout: the 5 members agree (up to the rounding of their mean)

@@ -205,3 +205,23 @@ def test_red_oracle_matches_reference_fixture(golden_dir, name, case):
   sigma = red.set_sigma(st, np.concatenate([e['states'], e['actions']], 1))
   assert abs(sigma - float(g[f'{name}.sigma_1'][0])) <= 1e-5 * sigma
   np.testing.assert_allclose(red.predict_reward(st, np.concatenate([q['states'], q['actions']], 1)), g[f'{name}.reward'], rtol=1e-5)
+
+
+@pytest.mark.parametrize('name,case,kw', [('hopper_h64', (71, 'hopper', 64, 64, 3), {}), ('halfcheetah_h32', (72, 'halfcheetah', 32, 128, 2), dict(p_in=0.2, p=0.3))])
+def test_dril_oracle_matches_reference_fixture(golden_dir, name, case, kw):
+  """oracle/dril.py against the reference SoftActor (DRIL config, train mode) fed the same dropout masks: BC updates, MC-dropout
+  uncertainty, +-1 reward."""
+  from oracle import dril
+  g = np.load(os.path.join(golden_dir, 'dril.npz'))
+  c = gi.dril_case(*case, **kw)
+  lr, wd = (float(x) for x in g[f'{name}.hyper'])
+  ds = dril.DrilState(c['S'], c['A'], c['H'], c['p_in'], c['p']); ds.params[:] = c['params']
+  for k, (b, m0, m1) in enumerate(zip(c['batches'], c['m0'], c['m1']), 1):
+    dril.bc_update(ds, b, m0, m1, lr=lr, weight_decay=wd)
+    ref = g[f'{name}.params.{k}']
+    assert np.max(np.abs(ds.params - ref) - 1e-5 * np.abs(ref)) <= 1e-5 * np.abs(ref).max()
+  e, q = c['expert'], c['query']
+  ue, ref_ue = dril.uncertainty(ds, e['states'], e['actions'], c['e_m0'], c['e_m1']), g[f'{name}.expert_uncertainty']
+  assert np.abs(ue - ref_ue).max() <= 1e-4 * np.abs(ref_ue).max()
+  ds.q = float(g[f'{name}.q'][0])
+  assert np.array_equal(dril.predict_reward(ds, q['states'], q['actions'], c['q_m0'], c['q_m1']), g[f'{name}.reward'])

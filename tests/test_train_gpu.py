@@ -22,6 +22,7 @@ COMMON = ['steps=260', 'training.start=120', 'evaluation.interval=130', 'evaluat
     ['algorithm=AdRIL', 'env=hopper', 'imitation.update_freq=100'],
     ['algorithm=AdRIL', 'env=walker2d', 'imitation.update_freq=0', 'imitation.balanced=false'],   # SQIL
     ['algorithm=RED', 'env=hopper', 'imitation.pretraining.iterations=50'],
+    ['algorithm=DRIL', 'env=hopper', 'imitation.pretraining.iterations=50'],
     ['algorithm=SAC', 'env=hopper', '+acting.schedule=overlap'],
     ['algorithm=GAIL', 'env=halfcheetah', '+acting.schedule=overlap'],
     ['algorithm=AdRIL', 'env=hopper', '+acting.schedule=overlap'],
@@ -49,9 +50,12 @@ def test_train_runs(tmp_path, args):
     assert 'g.0.parametrizations.weight.original' in disc and 'g.2.parametrizations.weight.0._v' in disc
 
 
-def test_unsupported_algorithms_fail_loudly():
+def test_unsupported_configurations_fail_loudly():
+  """Every algorithm= of the reference runs; option combinations without a kernel raise instead of silently running something else."""
   sys.path.insert(0, ROOT)
   import train
   from imitation_learning_amd import config
-  with pytest.raises(NotImplementedError):
-    train.train(config.compose(['algorithm=DRIL', 'env=hopper', 'steps=10']))
+  for extra in (['algorithm=GAIL', 'imitation.discriminator.reward_shaping=true'], ['algorithm=SAC', 'reinforcement.actor.depth=3'],
+                ['algorithm=RED', 'imitation.discriminator.depth=2']):
+    with pytest.raises(NotImplementedError):
+      train.train(config.compose(extra + ['env=hopper', 'steps=10'] + COMMON[5:7]))

@@ -4,7 +4,7 @@
 Drives the loop of reference train.py:26-243 (act -> store -> [update block] -> evaluate -> save) on the MI355X path:
 the update block (train.py:171-203) is `UpdatePlan` (one captured hipGraph per step for SAC / GAIL) or the per-function HIP entry
 points (GMMIL, PWIL, mixed batches, BC auxiliary loss).  Hydra is replaced by `imitation_learning_amd.config.compose`
-(same keys, same precedence).  Supported on the HIP path: SAC, GAIL (BCE loss), GMMIL, PWIL, AdRIL (and SQIL via update_freq=0), RED, BC; DRIL raises.
+(same keys, same precedence).  Supported on the HIP path: SAC, GAIL (BCE loss), GMMIL, PWIL, AdRIL (and SQIL via update_freq=0), RED, DRIL, BC - every algorithm= of the reference.
 """
 import os
 import sys
@@ -43,8 +43,6 @@ def pretrain_bc(cfg, actor, expert_memory, state_size, action_size):
 
 def train(cfg, file_prefix: str = '') -> float:
   il_config.validate(cfg)
-  if cfg.algorithm == 'DRIL':
-    raise NotImplementedError('algorithm=DRIL (dropout policy ensemble) is outside the MI355X hot path of this round (SURVEY.md §8f-4); supported: SAC, GAIL, GMMIL, PWIL, AdRIL, RED, BC')
   dev = default_device()
   assert dev.type == 'cuda', 'train.py needs a GPU: the update path has no CPU fallback'
   il.seed(cfg.seed)               # replay index stream (np.random.seed in the reference, train.py:51)
@@ -76,6 +74,9 @@ def train(cfg, file_prefix: str = '') -> float:
     discriminator = il.GMMILDiscriminator(state_size, action_size, cfg.imitation)
   elif cfg.algorithm == 'PWIL':
     discriminator = il.PWILDiscriminator(state_size, action_size, cfg.imitation, expert_memory, env.max_episode_steps)
+  elif cfg.algorithm == 'DRIL':
+    discriminator = il.SoftActor(state_size, action_size, cfg.imitation.discriminator)   # dropout policy ensemble (train.py:73)
+    discriminator_optimiser = il.AdamW(discriminator, lr=cfg.imitation.learning_rate, weight_decay=cfg.imitation.weight_decay)
   elif cfg.algorithm == 'RED':
     discriminator = il.REDDiscriminator(state_size, action_size, cfg.imitation)
     discriminator_optimiser = il.AdamW(discriminator, lr=cfg.imitation.learning_rate, weight_decay=cfg.imitation.weight_decay)
@@ -97,10 +98,12 @@ def train(cfg, file_prefix: str = '') -> float:
       torch.save(metrics, f'{file_prefix}metrics.pth')
       return float(np.mean(normalised))
 
-  if cfg.algorithm == 'RED':  # train.py:114-128: distil the random target on expert data, then fix the reward bandwidth on one minibatch
+  if cfg.algorithm in ('DRIL', 'RED'):  # train.py:114-134: pretrain the "discriminator" on expert data, then fix its reward threshold / bandwidth
     for batch in expert_batches(cfg, expert_memory, state_size, action_size, cfg.imitation.pretraining.iterations):
-      il.target_estimation_update(discriminator, batch, discriminator_optimiser)
-    discriminator.set_sigma(expert_memory['states'][:B], expert_memory['actions'][:B])
+      if cfg.algorithm == 'DRIL': il.behavioural_cloning_update(discriminator, batch, discriminator_optimiser)
+      else: il.target_estimation_update(discriminator, batch, discriminator_optimiser)
+    if cfg.algorithm == 'DRIL': discriminator.set_uncertainty_threshold(expert_memory['states'][:expert_memory.size], expert_memory['actions'][:expert_memory.size], cfg.imitation.quantile_cutoff)
+    else: discriminator.set_sigma(expert_memory['states'][:B], expert_memory['actions'][:B])
     if cfg.check_time_usage: metrics['pre_training_time'], start_time = time.time() - start_time, time.time()
     if cfg.imitation.mix_expert_data == 'prefill_memory': memory.transfer_transitions(expert_memory)
 
@@ -179,7 +182,7 @@ def train(cfg, file_prefix: str = '') -> float:
           discriminator.resample_and_relabel(transitions, expert_transitions, step, memory.num_trajectories, expert_memory.num_trajectories)
         if cfg.algorithm == 'GAIL':
           transitions['rewards'] = discriminator.predict_reward(transitions['states'], transitions['actions'])
-        elif cfg.algorithm == 'RED':
+        elif cfg.algorithm in ('DRIL', 'RED'):
           transitions['rewards'].copy_(discriminator.predict_reward(transitions['states'], transitions['actions']))
         elif cfg.algorithm == 'GMMIL':
           transitions['rewards'] = discriminator.predict_reward(transitions['states'], transitions['actions'], expert_transitions['states'], expert_transitions['actions'],
