@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libil_hip.so')
+LIB_PATH = os.environ.get('IL_HIP_LIBRARY') or os.path.join(_HERE, 'libil_hip.so')   # IL_HIP_LIBRARY: developer A/B builds of the same ABI
 
 IL_FLAG_GRADS_ONLY, IL_FLAG_TICK, IL_FLAG_SAC_FORWARD_ONLY, IL_FLAG_SAC_SKIP_FORWARD, IL_FLAG_SAC_PREPARED = 1, 2, 4, 8, 16
 c_f32p, c_i32p, c_u32p, c_i64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)

@@ -376,6 +376,8 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < lay.P) {
     const float* sl = d.workspace + wsl.slabs + e;
+    float pp = 0.f, mm = 0.f, vv = 0.f;
+    if (apply) { pp = d.params[e]; mm = d.opt.m[e]; vv = d.opt.v[e]; }   // independent of the slab sum: in flight while it runs
     float g = 0.f;
     int t = 0;
     for (; t + 8 <= nt; t += 8) {
@@ -389,7 +391,6 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const
     d.grad[e] = g;
     if (apply) {
       const adam_consts ac = load_adam_consts(d.opt);
-      float pp = d.params[e], mm = d.opt.m[e], vv = d.opt.v[e];
       adam_update(pp, g, mm, vv, ac);
       d.params[e] = pp; d.opt.m[e] = mm; d.opt.v[e] = vv;
     }

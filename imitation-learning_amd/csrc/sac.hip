@@ -437,6 +437,9 @@ __device__ __forceinline__ void adam_store(const DwArgs& a, const adam_consts& a
   a.params[o] = pp; a.opt.m[o] = mm; a.opt.v[o] = vv;
 }
 
+#ifndef IL_DW_PREFETCH
+#define IL_DW_PREFETCH 1
+#endif
 // XT: x is feature-major [Kvalid][B]; otherwise row-major [B][ldx] (the actor's layer-1 input = the states field of the batch)
 template <bool XT>
 __device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dzT, int Nvalid, const float* __restrict__ x, int ldx, int Kvalid,
@@ -455,6 +458,17 @@ __device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, 
     for (int s = 0; s < 4; ++s) v[s] = xp[(size_t)(r0 + s) * ldx];
     return v;
   };
+  // The Adam operands of this lane's four dW elements do not depend on the products: fetch them before the MFMA loop so that their
+  // HBM latency (they were last touched one update ago) hides under it instead of following it.
+  const int k = kb + j, kk = min(k, Kvalid - 1);
+  float pp[4], mm[4], vv[4];
+  if (IL_DW_PREFETCH && !a.grads_only) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t o = poff + (int64_t)min(n0 + 4 * g + r, Nvalid - 1) * Kvalid + kk;
+      pp[r] = a.params[o]; mm[r] = a.opt.m[o]; vv[r] = a.opt.v[o];
+    }
+  }
   int r0 = 0;
   for (; r0 + 128 <= B; r0 += 128) {
     f32x4 av[8], bv[8];
@@ -476,17 +490,29 @@ __device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, 
     acc1 = mfma16(av[3], bv[3], acc1);
   }
   const f32x4 acc = acc0 + acc1;
-  const int k = kb + j;
   if (k >= Kvalid) return;
+  if (a.grads_only) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 4 * g + r;
+      if (n < Nvalid) a.grads[poff + (int64_t)n * Kvalid + k] = acc[r];
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int n = n0 + 4 * g + r;
-    if (n < Nvalid) adam_store(a, ac, poff + (int64_t)n * Kvalid + k, acc[r]);
+    if (n < Nvalid) {
+      const int64_t o = poff + (int64_t)n * Kvalid + k;
+      if (!IL_DW_PREFETCH) { pp[r] = a.params[o]; mm[r] = a.opt.m[o]; vv[r] = a.opt.v[o]; }
+      adam_update(pp[r], acc[r], mm[r], vv[r], ac);
+      a.params[o] = pp[r]; a.opt.m[o] = mm[r]; a.opt.v[o] = vv[r];
+    }
   }
-  if (pkf && !a.grads_only) {  // the updated W2 values, in both lane orders (this tile owns rows n0..n0+15, columns kb..kb+15: always full for an H x H layer)
+  if (pkf) {  // the updated W2 values, in both lane orders (this tile owns rows n0..n0+15, columns kb..kb+15: always full for an H x H layer)
     f32x4 w;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { w[r] = a.params[poff + (int64_t)(n0 + 4 * g + r) * Kvalid + k]; pkf[packed_fwd_index(n0 + 4 * g + r, k, Kvalid)] = w[r]; }
+    for (int r = 0; r < 4; ++r) { w[r] = pp[r]; pkf[packed_fwd_index(n0 + 4 * g + r, k, Kvalid)] = w[r]; }
     *reinterpret_cast<f32x4*>(pkb + packed_bwd_index(n0 + 4 * g, k, Kvalid)) = w;   // rows n0+4g..+3 of column k: one 16-byte lane of PB
   }
 }
