@@ -19,7 +19,7 @@
 struct SacWs {  // float offsets into il_sac.workspace
   int64_t a_h1, a_h2, a_xpre, a_eps, a_lsraw, a_anew, a_logp, n_a2, n_logp2;
   int64_t c_x0, c_h1, c_h2, c_q, t_q, c_dz3, c_dz2, c_dz1, q_min;
-  int64_t p_q, p_g, a_dz3, a_dz2, a_dz1, alpha_part;
+  int64_t p_q, p_g, a_dz3, a_dz2, a_dz1, alpha_part, pair_ctr;
   int64_t pk_af, pk_ab, pk_cf, pk_cb, pk_tf, pk_tb;  // lane-ordered copies of the H x H layers (mlp_tile.hpp "Packed hidden-layer weights")
   int64_t total;
 };
@@ -31,7 +31,7 @@ __host__ __device__ inline SacWs sac_ws(int S, int A, int H, int B) {
   w.n_a2 = take(BA); w.n_logp2 = take(B);
   w.c_x0 = take((int64_t)B * (S + A)); w.c_h1 = take(2 * BH); w.c_h2 = take(2 * BH); w.c_q = take(2 * B); w.t_q = take(2 * B);
   w.c_dz3 = take(2 * B); w.c_dz2 = take(2 * BH); w.c_dz1 = take(2 * BH); w.q_min = take(B);
-  w.p_q = take(2 * B); w.p_g = take(2 * BA); w.a_dz3 = take((int64_t)B * 16); w.a_dz2 = take(BH); w.a_dz1 = take(BH); w.alpha_part = take(B / IL_TILE_R + 4);
+  w.p_q = take(2 * B); w.p_g = take(2 * BA); w.a_dz3 = take((int64_t)B * 16); w.a_dz2 = take(BH); w.a_dz1 = take(BH); w.alpha_part = take(B / IL_TILE_R + 4); w.pair_ctr = take(B / IL_TILE_R + 4);
   const int64_t HH = (int64_t)H * H;
   w.pk_af = take(HH); w.pk_ab = take(HH); w.pk_cf = take(2 * HH); w.pk_cb = take(2 * HH); w.pk_tf = take(2 * HH); w.pk_tb = take(2 * HH);
   w.total = o;
@@ -65,8 +65,10 @@ __global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask, const i
   if (dL) d = dL[blockIdx.z];  // population axis: one descriptor per learner (wave-uniform scalar loads)
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, IN = S + A;
   const int net = blockIdx.y;
-  if (!((mask >> net) & 1u)) return;
   const SacWs ws = sac_ws(S, A, H, d.batch);
+  if (blockIdx.x == 0 && blockIdx.y == 0)   // arrival counters of k_policy_critic's tile pairs (they reset themselves; this covers a reused arena)
+    for (int i = threadIdx.x; i < d.batch / IL_TILE_R; i += blockDim.x) reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr)[i] = 0u;
+  if (!((mask >> net) & 1u)) return;
   const int64_t HH = (int64_t)H * H, ns = net_stride(IN, H, 1);
   const float* W2; float* pf; float* pb;
   if (net == 0) { W2 = d.actor + (size_t)H * S + H; pf = d.workspace + ws.pk_af; pb = d.workspace + ws.pk_ab; }
@@ -231,6 +233,16 @@ __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b, const
   const SacWs ws = sac_ws(S, A, H, B);
   float* W = d.workspace;
   const MlpView p = mlp_view(d.critic + k * net_stride(IN, H, 1), IN, H, 1);
+  const float* h2 = W + ws.c_h2 + (size_t)k * B * H; const float* h1 = W + ws.c_h1 + (size_t)k * B * H;
+  float* gdz2 = W + ws.c_dz2 + (size_t)k * B * H; float* gdz1 = W + ws.c_dz1 + (size_t)k * B * H;
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+  // Operands that do not depend on this kernel's own results are requested up front, so their latency overlaps the dQ phase and the
+  // MFMA loop instead of following a barrier: this thread's (feature, 4 rows) lane of h2 with its w3, and its epilogue lane of h1.
+  const int pn = threadIdx.x >> 2, pr4 = (threadIdx.x & 3) * 4;
+  const bool pre = blockDim.x == 4 * H;   // one (feature, row group) item per thread: true for every supported hidden size
+  f32x4 hv2 = zero4(); float w3p = 0.f;
+  if (pre) { hv2 = *reinterpret_cast<const f32x4*>(h2 + (size_t)pn * B + row0 + pr4); w3p = p.W3[pn]; }
+  const f32x4 hv1 = *reinterpret_cast<const f32x4*>(h1 + (size_t)min(wave * 16 + j, H - 1) * B + row0 + 4 * g);
   if (threadIdx.x < IL_TILE_R) {
     const int row = row0 + threadIdx.x;
     const float alpha = expf(d.log_alpha[0]);
@@ -243,24 +255,21 @@ __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b, const
     W[ws.c_dz3 + (size_t)k * B + row] = dq;
     if (k == 0) W[ws.q_min + row] = fminf(q, W[ws.c_q + B + row]);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) adam_tick(d.critic_opt);  // consumed by the following k_dw_adam / il_adam_step
+  if (blockIdx.x == 0 && threadIdx.x == 64) adam_tick(d.critic_opt);  // consumed by the following k_dw_adam / il_adam_step (a lane that is idle in this phase)
   __syncthreads();
-  const float* h2 = W + ws.c_h2 + (size_t)k * B * H; const float* h1 = W + ws.c_h1 + (size_t)k * B * H;
-  float* gdz2 = W + ws.c_dz2 + (size_t)k * B * H; float* gdz1 = W + ws.c_dz1 + (size_t)k * B * H;
   for (int i = threadIdx.x; i < 4 * H; i += blockDim.x) {  // (feature n, 4 consecutive rows) per thread: 16-byte lanes of the [H][B] layout
     const int n = i >> 2, r4 = (i & 3) * 4;
-    const f32x4 hv = *reinterpret_cast<const f32x4*>(h2 + (size_t)n * B + row0 + r4);
-    const float w3 = p.W3[n];
+    const f32x4 hv = pre ? hv2 : *reinterpret_cast<const f32x4*>(h2 + (size_t)n * B + row0 + r4);
+    const float w3 = pre ? w3p : p.W3[n];
     f32x4 o;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { o[q] = hv[q] > 0.f ? dz3s[r4 + q] * w3 : 0.f; DZ2s[(r4 + q) * ldh + n] = o[q]; }
     *reinterpret_cast<f32x4*>(gdz2 + (size_t)n * B + row0 + r4) = o;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   tile_bwd_packed(DZ2s, ldh, H, W + ws.pk_cb + (size_t)k * H * H, [&](int kb, f32x4 acc) {
     const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
-    const f32x4 hv = *reinterpret_cast<const f32x4*>(h1 + off);
+    const f32x4 hv = (kb == wave * 16) ? hv1 : *reinterpret_cast<const f32x4*>(h1 + off);
     f32x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = hv[r] > 0.f ? acc[r] : 0.f;
@@ -268,85 +277,13 @@ __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b, const
   });
 }
 
-// ---------------------------------------------------------------------------------------------
-// updated critic on (s, a~) and dQ_k/da~ (training.py:37, backward of :38 through the critic).  grid = nt * 2
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
-  const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
-  const int nt = B / IL_TILE_R;
-  int k, tile;
-  xcd_tile_net((int)blockIdx.x, nt, 2, tile, k);
-  const int row0 = tile * IL_TILE_R;
-  const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
-  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* q16 = H2s + IL_TILE_R * ldh;
-  const SacWs ws = sac_ws(S, A, H, B);
-  float* W = d.workspace;
-  const MlpView p = mlp_view(d.critic + k * net_stride(IN, H, 1), IN, H, 1);
-  const bool stamp = blockIdx.x == 0;
-  IL_STAMP(stamp, 16);
-  load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, IL_TILE_R);
-  __syncthreads();
-  IL_STAMP(stamp, 17);
-  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-  tile_fwd(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4 acc) {
-    const int col = c0 + j; const float bb = p.b1[col];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
-  });
-  __syncthreads();
-  IL_STAMP(stamp, 18);
-  tile_fwd_packed(H1s, ldh, H, W + ws.pk_cf + (size_t)k * H * H, [&](int c0, f32x4 acc) {
-    const int col = c0 + j; const float bb = p.b2[col];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
-  });
-  __syncthreads();
-  IL_STAMP(stamp, 19);
-  critic_head(H2s, ldh, H, p.W3, p.b3[0], q16);
-  __syncthreads();
-  IL_STAMP(stamp, 20);
-  if (threadIdx.x < IL_TILE_R) W[ws.p_q + (size_t)k * B + row0 + threadIdx.x] = q16[threadIdx.x];
-  // dQ/dh2 with upstream 1 (scaling and min-selection happen in k_actor_bwd): dz2 = w3 [h2 > 0], in place
-  for (int i = threadIdx.x; i < IL_TILE_R * H; i += blockDim.x) {
-    const int r = i / H, n = i - r * H;
-    H2s[r * ldh + n] = H2s[r * ldh + n] > 0.f ? p.W3[n] : 0.f;
-  }
-  __syncthreads();
-  IL_STAMP(stamp, 21);
-  tile_bwd_packed(H2s, ldh, H, W + ws.pk_cb + (size_t)k * H * H, [&](int kb, f32x4 acc) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float* h = H1s + (4 * g + r) * ldh + kb + j;
-      *h = *h > 0.f ? acc[r] : 0.f;  // dz1 in place (each element owned by exactly one lane)
-    }
-  });
-  __syncthreads();
-  IL_STAMP(stamp, 22);
-  // dQ/dx = dz1 . W1 on MFMA (K = S + A columns, not a multiple of 16: out-of-range columns clamp); only the action columns are kept
-  float* gout = W + ws.p_g + ((size_t)k * B + row0) * A;
-  tile_bwd_dx(H1s, ldh, H, H, p.W1, IN, IN, [&](int kb, f32x4 acc) {
-    const int c = kb + j - S;
-    if (c >= 0 && c < A) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) gout[(size_t)(4 * g + r) * A + c] = acc[r];
-    }
-  });
-  IL_STAMP(stamp, 23);
-}
-
-// ---------------------------------------------------------------------------------------------
-// actor backward (training.py:38-46): L = mean(w m alpha logp - min Q).  grid = nt
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_actor_bwd(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, const il_sac* __restrict__ dL,
-                                                    const il_batch* __restrict__ bL) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
+// policy-loss backward of one 16-row tile: min-Q selection, tanh-Gaussian backward, actor back-prop (dz3, dz2, dz1 for the dW kernel), alpha partial.
+// Runs as the tail of k_policy_critic in the workgroup that finishes the tile's second critic.
+__device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& b, int tile, float* __restrict__ out_logp, float* __restrict__ out_q, float* smem) {
   if (!out_logp) out_logp = d.out_logp;
   if (!out_q) out_q = d.out_q;
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
-  const int tile = (int)blockIdx.x, row0 = tile * IL_TILE_R;
+  const int row0 = tile * IL_TILE_R;
   const int ldh = H + 4, ldz = 20;
   float* DZ2s = smem; float* DZ3s = DZ2s + IL_TILE_R * ldh; float* red = DZ3s + IL_TILE_R * ldz;
   const SacWs ws = sac_ws(S, A, H, B);
@@ -354,6 +291,13 @@ __global__ __launch_bounds__(1024) void k_actor_bwd(il_sac d, il_batch b, float*
   const MlpView net = mlp_view(d.actor, S, H, 2 * A);
   const float alpha = expf(d.log_alpha[0]);
   const int tid = threadIdx.x;
+  const int lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
+  const float* h2 = W + ws.a_h2; const float* h1 = W + ws.a_h1;
+  // epilogue operands of the two back-propagation GEMMs (this lane's 4 rows of one feature of h2 / h1): requested now, used after the MFMA loops
+  const size_t poff = (size_t)min(wave * 16 + j, H - 1) * B + row0 + 4 * g;
+  const f32x4 hv2p = *reinterpret_cast<const f32x4*>(h2 + poff), hv1p = *reinterpret_cast<const f32x4*>(h1 + poff);
+  const bool stamp = tile == 0;
+  IL_STAMP(stamp, 24);
   for (int i = tid; i < IL_TILE_R * ldz; i += blockDim.x) DZ3s[i] = 0.f;
   __syncthreads();
   float apart = 0.f;
@@ -379,33 +323,130 @@ __global__ __launch_bounds__(1024) void k_actor_bwd(il_sac d, il_batch b, float*
     if (out_logp) out_logp[row] = lp;
     if (out_q) out_q[row] = W[ws.q_min + row];
   }
+  IL_STAMP(stamp, 25);
   apart = block_sum(apart, red);  // contains barriers: DZ3s complete afterwards
+  IL_STAMP(stamp, 26);
   if (tid == 0) {
     W[ws.alpha_part + tile] = apart;
-    if (tile == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }
   }
   for (int i = tid; i < IL_TILE_R * 16; i += blockDim.x) W[ws.a_dz3 + (size_t)(i >> 4) * B + row0 + (i & 15)] = DZ3s[(i & 15) * ldz + (i >> 4)];  // dz3^T [16][B]
-  const int lane = tid & 63, j = lane & 15, g = lane >> 4;
-  const float* h2 = W + ws.a_h2; const float* h1 = W + ws.a_h1;
+  IL_STAMP(stamp, 27);
   // dz2 = (dz3 . W3) [h2 > 0]
   tile_bwd_dx(DZ3s, ldz, 16, 2 * A, net.W3, H, H, [&](int kb, f32x4 acc) {
     const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
-    const f32x4 hv = *reinterpret_cast<const f32x4*>(h2 + off);
+    const f32x4 hv = (kb == wave * 16) ? hv2p : *reinterpret_cast<const f32x4*>(h2 + off);
     f32x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { o[r] = hv[r] > 0.f ? acc[r] : 0.f; DZ2s[(4 * g + r) * ldh + kb + j] = o[r]; }
     *reinterpret_cast<f32x4*>(W + ws.a_dz2 + off) = o;
   });
   __syncthreads();
+  IL_STAMP(stamp, 28);
   tile_bwd_packed(DZ2s, ldh, H, W + ws.pk_ab, [&](int kb, f32x4 acc) {
     const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
-    const f32x4 hv = *reinterpret_cast<const f32x4*>(h1 + off);
+    const f32x4 hv = (kb == wave * 16) ? hv1p : *reinterpret_cast<const f32x4*>(h1 + off);
     f32x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = hv[r] > 0.f ? acc[r] : 0.f;
     *reinterpret_cast<f32x4*>(W + ws.a_dz1 + off) = o;
   });
+  IL_STAMP(stamp, 29);
 }
+
+__global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, const il_sac* __restrict__ dL,
+                                                        const il_batch* __restrict__ bL) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
+  const int nt = B / IL_TILE_R;
+  int k, tile;
+  xcd_tile_net((int)blockIdx.x, nt, 2, tile, k);
+  const int row0 = tile * IL_TILE_R;
+  const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* q16 = H2s + IL_TILE_R * ldh;
+  const SacWs ws = sac_ws(S, A, H, B);
+  float* W = d.workspace;
+  const MlpView p = mlp_view(d.critic + k * net_stride(IN, H, 1), IN, H, 1);
+  const bool stamp = blockIdx.x == 0;
+  IL_STAMP(stamp, 16);
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  // biases of this wave's 16 columns and this lane's slice of w3: requested before the first barrier, used after the MFMA loops
+  const int pc = min(wave * 16 + j, H - 1);
+  const float pb1 = p.b1[pc], pb2 = p.b2[pc], pb3 = p.b3[0];
+  float w3v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) w3v[u] = p.W3[min(lane + 64 * u, H - 1)];
+  load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, IL_TILE_R);
+  __syncthreads();
+  IL_STAMP(stamp, 17);
+  tile_fwd(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4 acc) {
+    const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1 : p.b1[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
+  });
+  __syncthreads();
+  IL_STAMP(stamp, 18);
+  tile_fwd_packed(H1s, ldh, H, W + ws.pk_cf + (size_t)k * H * H, [&](int c0, f32x4 acc) {
+    const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb2 : p.b2[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
+  });
+  __syncthreads();
+  IL_STAMP(stamp, 19);
+  // Q = h2 . w3 + b3 and, in the same pass, dQ/dh2 with upstream 1 (scaling and min-selection happen in the tail): dz2 = w3 [h2 > 0], in place.
+  // One wave per row; w3 comes from the registers loaded at the top.
+  for (int r = wave; r < IL_TILE_R; r += nw) {
+    float sq = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = lane + 64 * u;
+      if (n < H) { const float h = H2s[r * ldh + n]; sq += h * w3v[u]; H2s[r * ldh + n] = h > 0.f ? w3v[u] : 0.f; }
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) W[ws.p_q + (size_t)k * B + row0 + r] = sq + pb3;
+  }
+  __syncthreads();
+  IL_STAMP(stamp, 21);
+  tile_bwd_packed(H2s, ldh, H, W + ws.pk_cb + (size_t)k * H * H, [&](int kb, f32x4 acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* h = H1s + (4 * g + r) * ldh + kb + j;
+      *h = *h > 0.f ? acc[r] : 0.f;  // dz1 in place (each element owned by exactly one lane)
+    }
+  });
+  __syncthreads();
+  IL_STAMP(stamp, 22);
+  // dQ/dx = dz1 . W1 on MFMA (K = S + A columns, not a multiple of 16: out-of-range columns clamp); only the action columns are kept
+  float* gout = W + ws.p_g + ((size_t)k * B + row0) * A;
+  tile_bwd_dx(H1s, ldh, H, H, p.W1, IN, IN, [&](int kb, f32x4 acc) {
+    const int c = kb + j - S;
+    if (c >= 0 && c < A) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gout[(size_t)(4 * g + r) * A + c] = acc[r];
+    }
+  });
+  IL_STAMP(stamp, 23);
+  // The policy backward of this tile needs Q and dQ/da of BOTH critics, i.e. of two workgroups. Instead of a kernel boundary, the workgroup
+  // that arrives second continues with it. The barrier orders every wave's stores before thread 0's agent-scope acq_rel ticket, which
+  // is the only L2 write-back / invalidate of the hand-off (a __threadfence() per wave costs 16 of them per workgroup: measured -8 %).
+  __syncthreads();
+  unsigned* ctr = reinterpret_cast<unsigned*>(W + ws.pair_ctr) + tile;
+  if (threadIdx.x == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // second arriver: ready for the next launch
+    q16[0] = __uint_as_float(ticket);
+  }
+  __syncthreads();
+  if (__float_as_uint(q16[0]) == 0u) {   // first arriver: done, after ticking the two optimisers the next kernel steps (off everyone's critical path)
+    if (tile == 0 && threadIdx.x == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }
+    return;
+  }
+  actor_bwd_tile(d, b, tile, out_logp, out_q, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// actor backward (training.py:38-46): L = mean(w m alpha logp - min Q).  grid = nt
+// ---------------------------------------------------------------------------------------------
 
 // ---------------------------------------------------------------------------------------------
 // k_dw_adam: output-stationary weight gradients on MFMA with a fused AdamW epilogue.
@@ -706,8 +747,7 @@ extern "C" int il_sac_actor_step(const il_sac* d, const il_batch* b, const float
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 3), 256, 0, st>>>(*d, 0x07u, nullptr); }  // actor + critics (the critic may have been stepped by il_adam_step)
   { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, eps_cur, 2, nullptr, nullptr); }
-  { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
-  { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr); }
+  { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr); }
   DwArgs a = actor_dw_args(d, b, flags);
   const int tail = 1 + ((flags & IL_FLAG_GRADS_ONLY) ? 0 : 32);
   { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<a.n_dw_blocks + tail, 256, 0, st>>>(a); }
@@ -733,8 +773,7 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
     { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
     DwArgs ca = critic_dw_args(d, flags);
     { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
-    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
-    { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr); }
+    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr); }
     DwArgs aa = actor_dw_args(d, b, flags);
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 33, 256, 0, st>>>(aa); }
   }
@@ -770,8 +809,7 @@ extern "C" int il_sac_update_population(const il_sac* descs_dev, const il_batch*
   if (!(flags & IL_FLAG_SAC_FORWARD_ONLY)) {
     { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<dim3(2 * nt, L), tile_threads(H), lds, st>>>(z, zb, descs_dev, batches_dev); }
     { IL_TRACE("k_dw_adam_critic", st); k_dw_adam_pop<<<dim3(dw_blocks(S + A, H, 1, 2), L), 256, 0, st>>>(descs_dev, batches_dev, 0, flags); }
-    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<dim3(2 * nt, L), tile_threads(H), lds, st>>>(z, zb, descs_dev, batches_dev); }
-    { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<dim3(nt, L), tile_threads(H), lds, st>>>(z, zb, nullptr, nullptr, descs_dev, batches_dev); }
+    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<dim3(2 * nt, L), tile_threads(H), lds, st>>>(z, zb, nullptr, nullptr, descs_dev, batches_dev); }
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam_pop<<<dim3(dw_blocks(S, H, 2 * A, 1) + 33, L), 256, 0, st>>>(descs_dev, batches_dev, 1, flags); }
   }
   IL_CHECK_LAUNCH("il_sac_update_population");
@@ -884,8 +922,7 @@ extern "C" int il_sac_dp_phase(const il_sac* d, const il_batch* b, int32_t phase
   } else if (phase == 2) {
     const int64_t n = 2 * net_stride(S + A, H, 1);
     { IL_TRACE("k_apply_critic", st); k_apply_critic<<<(int)((n + 255) / 256), 256, 0, st>>>(*d); }
-    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
-    { IL_TRACE("k_actor_bwd", st); k_actor_bwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr); }
+    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr); }
     DwArgs aa = actor_dw_args(d, b, IL_FLAG_GRADS_ONLY);
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 1, 256, 0, st>>>(aa); }
   } else {

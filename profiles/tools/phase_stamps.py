@@ -15,7 +15,7 @@ plan.overlap = False
 for _ in range(20): plan.run()
 torch.cuda.synchronize()
 L = _lib.lib()
-for fn, idxs in (('il_debug_stamps_gail', range(0, 9)), ('il_debug_stamps_sac', range(16, 24))):
+for fn, idxs in (('il_debug_stamps_gail', range(0, 9)), ('il_debug_stamps_sac', range(16, 30))):
   f = getattr(L, fn); f.restype = C.c_int
   buf = (C.c_ulonglong * 64)()
   f(buf)
