@@ -49,7 +49,8 @@ def algorithmic_model():
   flops_k = {
       'k_gail_grad': 2 * B * mac_d * (3 + 2 * 2 + 3), 'k_gail_reward': 2 * B * mac_d,   # 3 forwards, 2 BCE backwards, closed-form GP second-order terms
       'k_actor_fwd': 2 * 2 * B * mac_a, 'k_critic_fwd': 4 * 2 * B * mac_c, 'k_critic_bwd': 2 * 2 * B * H * H, 'k_dw_adam_critic': 2 * 2 * B * mac_c,
-      'k_policy_critic': 2 * 2 * B * (mac_c + H * H + H * A), 'k_actor_bwd': 2 * B * (2 * A * H + H * H), 'k_dw_adam_actor': 2 * B * mac_a,
+      'k_policy_critic': 2 * 2 * B * (mac_c + H * H + H * A) + 2 * B * (2 * A * H + H * H),   # both critics on (s, a~) fwd + dQ/da, then the policy backward as the pair's tail
+      'k_dw_adam_actor': 2 * B * mac_a,
   }
   update_bytes = 24 * (Pa + 2 * Pc + Pd + 1) + 8 * 2 * Pc + 2 * B * (2 * S + A + 5) * 4
   return bytes_k, flops_k, update_bytes, sum(flops_k.values())
