@@ -264,6 +264,8 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
   elapsed = float(t.item())
   finite = all(bool(torch.isfinite(n.flat if hasattr(n, 'flat') else n).all()) for n in nets)
+  if getattr(plan, 'device_sync', False) and plan.sync_timeouts():
+    raise RuntimeError(f'{plan.sync_timeouts()} device-side waits timed out: the two branches of the update did not run concurrently (set IL_DEVICE_SYNC=0)')
 
   if rank == 0:
     ms_per_step = elapsed / args.steps * 1e3
@@ -274,7 +276,8 @@ def main():
                ms_per_step=round(ms_per_step, 5), higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                config=dict(workload='algorithm=GAIL env=halfcheetah: 2 replay samples + discriminator step (BCE+GP+SN) + AIRL relabel + sac_update per step',
                            batch_per_gpu=B, global_batch=B * world, state_dim=S, action_dim=A, hidden=H, replay_capacity=1_000_000, replay_fill=100_000, expert_rows=25_000,
-                           learners_per_gpu=args.learners, parallelism=f'dp{world}' + ('(split path)' if runner is not plan else ''), launch=launch, noise='on-chip Philox4x32-10', finite=finite),
+                           learners_per_gpu=args.learners, parallelism=f'dp{world}' + ('(split path)' if runner is not plan else ''), launch=launch, noise='on-chip Philox4x32-10', finite=finite,
+                           branch_sync=('device counters (two graphs, no cross-stream edge)' if getattr(plan, 'device_sync', False) and runner is plan else 'stream dependencies')),
                roofline=roof)
     if world == 1 and args.learners == 1 and not args.no_population:
       # population axis (the reference's own usage: 10-seed sweeps / Ax trials): independent batch-256 learners advanced by the

@@ -32,7 +32,7 @@ class Sac(C.Structure):
               ('actor_opt', Adam), ('critic_opt', Adam), ('alpha_opt', Adam),
               ('discount', C.c_float), ('entropy_target', C.c_float), ('polyak', C.c_double),
               ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p),
-              ('out_logp', C.c_void_p), ('out_q', C.c_void_p)]
+              ('out_logp', C.c_void_p), ('out_q', C.c_void_p), ('sync', C.c_void_p)]
 
 
 class Disc(C.Structure):
@@ -40,7 +40,7 @@ class Disc(C.Structure):
               ('spectral_norm', C.c_int32), ('state_only', C.c_int32), ('reward_function', C.c_int32),
               ('params', C.c_void_p), ('u1', C.c_void_p), ('v1', C.c_void_p), ('u2', C.c_void_p), ('v2', C.c_void_p), ('grad', C.c_void_p),
               ('opt', Adam), ('grad_penalty', C.c_float), ('entropy_bonus', C.c_float),
-              ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p)]
+              ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p), ('sync', C.c_void_p)]
 
 
 class Pwil(C.Structure):
@@ -81,7 +81,10 @@ _SIGNATURES = {
     'il_mt19937_sample_indices': (C.c_int, [c_u32p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, c_i32p]),
     'il_mt19937_randint': (C.c_int, [c_u32p, C.c_int64, C.c_int32, c_i32p]),
     'il_mt19937_sample_indices_device': (C.c_int, [_P, _P, C.c_int32, _P, _P]),
-    'il_replay_sample_device': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
+    'il_struct_size': (C.c_int32, [C.c_int32]),
+    'il_sync_probe': (C.c_int, [_P, C.c_int32, _P]),
+    'il_replay_gather_workgroups': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    'il_replay_sample_device': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
     'il_replay_sample_population': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
     'il_sac_update_population': (C.c_int, [_P, _P, C.c_int32, C.POINTER(Sac), C.c_uint32, _P]),
     'il_gail_step_population': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(Disc), _P]),

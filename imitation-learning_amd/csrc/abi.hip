@@ -69,3 +69,32 @@ extern "C" int il_trace_report(char* buf_host, int len) {
   return IL_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Probe for the device-side hand-off (il_sync): one waiter and one setter kernel with the same bounded wait the update kernels use.
+// A caller enqueues the waiter on its side stream FIRST and the setter on its main stream (inside the same kind of two-stream graph
+// it will run updates with); if the runtime executes the two streams one after the other, the waiter times out and
+// sync[IL_SYNC_TIMEOUTS] counts it - the caller then keeps plain stream dependencies.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_sync_probe(long long* sync, int setter) {
+  if (setter) { sync_signal(sync + 6); return; }
+  const long long e = sync[7];
+  sync_wait(sync, 6, e + 1);
+  if (threadIdx.x == 0) sync[7] = e + 1;
+}
+extern "C" int il_sync_probe(int64_t* sync, int32_t setter, il_stream_t stream) {
+  IL_CHECK_ARG(sync, "il_sync_probe: null counters");
+  k_sync_probe<<<1, 64, 0, (hipStream_t)stream>>>((long long*)sync, setter);
+  IL_CHECK_LAUNCH("il_sync_probe");
+  return IL_OK;
+}
+
+// sizeof() of the descriptor structs as this library was compiled: a binding checks its own struct definitions against these
+// (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red, 7 il_dril).
+extern "C" int32_t il_struct_size(int32_t which) {
+  switch (which) {
+    case 0: return (int32_t)sizeof(il_batch); case 1: return (int32_t)sizeof(il_adam); case 2: return (int32_t)sizeof(il_sac); case 3: return (int32_t)sizeof(il_disc);
+    case 4: return (int32_t)sizeof(il_pwil); case 5: return (int32_t)sizeof(il_sample_args); case 6: return (int32_t)sizeof(il_red); case 7: return (int32_t)sizeof(il_dril);
+    default: return -1;
+  }
+}

@@ -227,8 +227,12 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   IL_STAMP(stamp, 2);
   if (d.spectral_norm) { sn_gram(L.W1s, L.Ms, D, Dp, H, ldw); __syncthreads(); }
   IL_STAMP(stamp, 3);
-  const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
   float* X = L.X(0);
+  if (d.sync) {   // this launch did not wait for the gather on its stream: its rows are ready once every gather workgroup of THIS update has signalled
+    long long* sy = reinterpret_cast<long long*>(d.sync);
+    sync_wait(sy, IL_SYNC_ROWS, (sy[IL_SYNC_SIDE_EPOCH] + 1) * sy[IL_SYNC_GATHER_WGS]);
+  }
+  const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;   // after the wait: the previous update's actor step (which bumps it) precedes this update's gather
   if (tid < 64) {  // ---- wave 0: the power iterations of calls 0..pass on the Gram matrix
     if (d.spectral_norm) sn_chain(L.W1s, L.W2s, L.Ms, D, H, L.u1(0), L.v1(0), L.v2(0), L.tmp, pass + 1, L.sc(0));
     IL_STAMP(stamp, 5);
@@ -380,6 +384,13 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const
     if (apply) { pp = d.params[e]; mm = d.opt.m[e]; vv = d.opt.v[e]; }   // independent of the slab sum: in flight while it runs
     float g = 0.f;
     int t = 0;
+    for (; t + 24 <= nt; t += 24) {   // the slabs were written by other XCDs: every load is a full-latency miss, so keep 24 in flight (2 rounds at B = 256)
+      float v[24];
+#pragma unroll
+      for (int u = 0; u < 24; ++u) v[u] = sl[(size_t)(t + u) * lay.P];
+#pragma unroll
+      for (int u = 0; u < 24; ++u) g += v[u];
+    }
     for (; t + 8 <= nt; t += 8) {
       float v[8];
 #pragma unroll
@@ -436,6 +447,14 @@ __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, floa
     if (d.reward_function == 2) h = expf(h) * -h;
     out_r[row0 + r] = h;
     if (out_logit) out_logit[row0 + r] = z;
+  }
+  if (d.sync) {   // rewards of this tile are in place; the workgroup that completes the relabel closes the side branch's epoch
+    long long* sy = reinterpret_cast<long long*>(d.sync);
+    __syncthreads();
+    if (tid == 0) {
+      const long long done = __hip_atomic_fetch_add(sy + IL_SYNC_REWARDS, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1;
+      if (done % (long long)gridDim.x == 0) __hip_atomic_fetch_add(sy + IL_SYNC_SIDE_EPOCH, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 

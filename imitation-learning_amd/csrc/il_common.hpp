@@ -147,6 +147,36 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
   p = __fsub_rn(p, __fmul_rn(c.step_size, __fdiv_rn(m, denom)));                  // addcdiv_
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-side hand-off between kernels of ONE update that run on different streams (il_sync, include/il_hip.h). A cross-stream edge
+// in a hipGraph costs 7-16 us of queue-to-queue signalling (rocprofv3 timeline); here the consumer kernel is already
+// resident and its thread 0 polls a monotonic counter the producer's workgroups bump with one agent-scope release each.
+// Bounded: after IL_SYNC_SPIN_LIMIT polls the waiter gives up, counts a timeout (the host checks it) and proceeds, so a runtime that
+// serialises the two queues (a counter-collecting profiler) can never hang the GPU.
+// ---------------------------------------------------------------------------------------------
+#define IL_SYNC_SPIN_LIMIT 20000
+__device__ __forceinline__ void sync_signal(long long* ctr) {   // all threads of the workgroup, after their stores
+  __syncthreads();
+#ifdef IL_SYNC_UNSAFE
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void sync_wait(long long* sync, int which, long long target) {   // all threads of the workgroup, before their loads
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(sync + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > IL_SYNC_SPIN_LIMIT) { __hip_atomic_fetch_add(sync + IL_SYNC_TIMEOUTS, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+#ifndef IL_SYNC_UNSAFE
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);   // agent scope: the producer's stores are visible to this CU from here on
+#endif
+  }
+  __syncthreads();
+}
+
 #define LOG_SQRT_2PI 0.91893853320467274178f
 #define LOG_2 0.69314718055994530942f
 __device__ __forceinline__ float softplus_f(float z) { return z > 20.f ? z : log1pf(expf(z)); }

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_sample2(uint32_t* __restrict__ state, i
 
 // both gathers of an update in one launch, one 16-byte lane per thread (the index draw above is a single-workgroup kernel)
 __global__ __launch_bounds__(256) void k_gather2(const float* __restrict__ ring_a, int64_t cap_a, int row4_a, const int32_t* __restrict__ idx_a, float* __restrict__ rows_a,
-                                                 const float* __restrict__ ring_b, int64_t cap_b, int row4_b, const int32_t* __restrict__ idx_b, float* __restrict__ rows_b, int n) {
+                                                 const float* __restrict__ ring_b, int64_t cap_b, int row4_b, const int32_t* __restrict__ idx_b, float* __restrict__ rows_b, int n, long long* __restrict__ sync) {
   const int na = n * row4_a, nb = ring_b ? n * row4_b : 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += gridDim.x * blockDim.x) {
     const bool isb = i >= na;
@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void k_gather2(const float* __restrict__ ring_
     s = s < 0 ? 0 : (s >= cap ? cap - 1 : s);
     reinterpret_cast<f32x4*>(isb ? rows_b : rows_a)[ii] = reinterpret_cast<const f32x4*>(isb ? ring_b : ring_a)[s * row4 + c];
   }
+  if (sync) sync_signal(sync + IL_SYNC_ROWS);   // rows of this workgroup are in place
 }
 
 // population axis: one workgroup per learner draws (own MT19937 state), then one launch gathers every learner's rows
@@ -319,15 +320,17 @@ extern "C" int il_mt19937_sample_indices_device(uint32_t* state_dev, const int64
   return IL_OK;
 }
 
+extern "C" int32_t il_replay_gather_workgroups(int32_t n, int32_t row_floats_a, int32_t row_floats_b) { return (n * (row_floats_a / 4) + n * (row_floats_b / 4) + 255) / 256; }
+
 extern "C" int il_replay_sample_device(uint32_t* state_dev, int32_t n, const int64_t* ring_state_a, const float* ring_a, int64_t capacity_a, int32_t row_floats_a, int32_t* idx_a,
                                        float* rows_a, const int64_t* ring_state_b, const float* ring_b, int64_t capacity_b, int32_t row_floats_b, int32_t* idx_b, float* rows_b,
-                                       il_stream_t stream) {
+                                       int64_t* sync, il_stream_t stream) {
   IL_CHECK_ARG(state_dev && ring_state_a && ring_a && idx_a && rows_a && n > 0, "il_replay_sample_device: bad arguments for ring A");
   IL_CHECK_ARG(row_floats_a % 4 == 0 && (!ring_b || (row_floats_b % 4 == 0 && ring_state_b && idx_b && rows_b)), "il_replay_sample_device: bad arguments for ring B");
   { IL_TRACE("k_sample2", stream); k_sample2<<<1, 256, 0, (hipStream_t)stream>>>(state_dev, n, ring_state_a, ring_a, capacity_a, row_floats_a / 4, idx_a, nullptr, ring_state_b, ring_b, capacity_b,
                                                                             row_floats_b / 4, idx_b, nullptr); }
-  const int lanes = n * (row_floats_a / 4) + (ring_b ? n * (row_floats_b / 4) : 0);
-  { IL_TRACE("k_gather2", stream); k_gather2<<<(lanes + 255) / 256, 256, 0, (hipStream_t)stream>>>(ring_a, capacity_a, row_floats_a / 4, idx_a, rows_a, ring_b, capacity_b, row_floats_b / 4, idx_b, rows_b, n); }
+  const int lanes = n * (row_floats_a / 4) + (ring_b ? n * (row_floats_b / 4) : 0);   // il_replay_gather_workgroups() = ceil(lanes / 256)
+  { IL_TRACE("k_gather2", stream); k_gather2<<<(lanes + 255) / 256, 256, 0, (hipStream_t)stream>>>(ring_a, capacity_a, row_floats_a / 4, idx_a, rows_a, ring_b, capacity_b, row_floats_b / 4, idx_b, rows_b, n, (long long*)sync); }
   IL_CHECK_LAUNCH("il_replay_sample_device");
   return IL_OK;
 }

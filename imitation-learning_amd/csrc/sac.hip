@@ -243,6 +243,10 @@ __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b, const
   f32x4 hv2 = zero4(); float w3p = 0.f;
   if (pre) { hv2 = *reinterpret_cast<const f32x4*>(h2 + (size_t)pn * B + row0 + pr4); w3p = p.W3[pn]; }
   const f32x4 hv1 = *reinterpret_cast<const f32x4*>(h1 + (size_t)min(wave * 16 + j, H - 1) * B + row0 + 4 * g);
+  if (d.sync) {   // the rewards come from the discriminator branch on another stream: ready once every reward workgroup of THIS update has signalled
+    long long* sy = reinterpret_cast<long long*>(d.sync);
+    sync_wait(sy, IL_SYNC_REWARDS, (sy[IL_SYNC_MAIN_EPOCH] + 1) * (long long)nt);
+  }
   if (threadIdx.x < IL_TILE_R) {
     const int row = row0 + threadIdx.x;
     const float alpha = expf(d.log_alpha[0]);
@@ -467,7 +471,7 @@ struct DwArgs {
   int n_dw_blocks;
   // tail
   float* log_alpha; float* alpha_grad; il_adam alpha_opt; const float* alpha_part; int n_alpha_part;
-  float* target; const float* polyak_src; int64_t polyak_n; double tau; uint32_t* noise_counter;
+  float* target; const float* polyak_src; int64_t polyak_n; double tau; uint32_t* noise_counter; int64_t* sync;
   float* pk_target; const float* pk_critic; int64_t pk_n;   // lane-ordered copies of the target / critic hidden layers (polyak is elementwise, so it commutes with the re-ordering)
 };
 
@@ -588,6 +592,7 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a) {
         a.log_alpha[0] = pp; a.alpha_opt.m[0] = mm; a.alpha_opt.v[0] = vv;
       }
       if (a.noise_counter) a.noise_counter[0] += 1;
+      if (a.sync) __hip_atomic_fetch_add(reinterpret_cast<long long*>(a.sync) + IL_SYNC_MAIN_EPOCH, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // this update's SAC half is done
     }
     if (a.target && !a.grads_only) {
       const float omt = (float)(1.0 - a.tau), tau = (float)a.tau;
@@ -735,7 +740,7 @@ __host__ __device__ static DwArgs actor_dw_args(const il_sac* d, const il_batch*
   a.pk_f = d->workspace + ws.pk_af; a.pk_b = d->workspace + ws.pk_ab;
   a.n_dw_blocks = dw_blocks(S, H, 2 * A, 1);
   a.log_alpha = d->log_alpha; a.alpha_grad = d->alpha_grad; a.alpha_opt = d->alpha_opt; a.alpha_part = d->workspace + ws.alpha_part; a.n_alpha_part = B / IL_TILE_R;
-  a.target = d->target; a.polyak_src = d->critic; a.polyak_n = 2 * net_stride(S + A, H, 1); a.tau = d->polyak; a.noise_counter = d->noise_counter;
+  a.target = d->target; a.polyak_src = d->critic; a.polyak_n = 2 * net_stride(S + A, H, 1); a.tau = d->polyak; a.noise_counter = d->noise_counter; a.sync = d->sync;
   a.pk_target = d->workspace + ws.pk_tf; a.pk_critic = d->workspace + ws.pk_cf; a.pk_n = 4 * (int64_t)H * H;   // pk_tf|pk_tb and pk_cf|pk_cb are adjacent pairs
   return a;
 }

@@ -49,6 +49,7 @@ class DataParallelUpdate:
 
   def __init__(self, plan, group=None):
     self.plan, self.group = plan, group
+    plan._set_device_sync(False)   # this path orders its two streams with events around the all-reduces
     ao, to = plan._keep[4], plan._keep[6]
     # actor grad and alpha grad travel in one bucket: re-home both into a single flat tensor
     n = ao.grad.numel()

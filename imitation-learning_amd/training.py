@@ -238,7 +238,15 @@ class UpdatePlan:
       self.rewards = torch.empty(batch_size, device=dev)
       self.transitions['rewards'] = self.rewards  # train.py:194: rewards replaced by the discriminator's prediction
     self.pb = batch_desc(self.transitions)
-    self.graph = None
+    # Device-side hand-off between the two branches (include/il_hip.h `il_sync`): the discriminator branch and the SAC forward then share no stream
+    # dependency between the gather and the critic loss. Validated by `capture()`; IL_DEVICE_SYNC=0 keeps plain stream dependencies.
+    self.sync = torch.zeros(8, dtype=torch.int64, device=dev)
+    self.device_sync = False
+    if algorithm == 'GAIL' and overlap and device_index_draw and os.environ.get('IL_DEVICE_SYNC', '1') != '0':
+      self.sync[5] = int(_lib.lib().il_replay_gather_workgroups(batch_size, memory.row, expert_memory.row))
+      self._set_device_sync(self._probe_device_sync(graph=False))
+    self.graph = self.graph_side = None
+    self._capturing = None   # 'main' / 'side' while one branch of the device-synchronised update is being captured
     self.pre_hooks, self.post_hooks = [], []   # callables enqueuing extra work on the update's stream before / after it (captured with it), e.g. ActingWorker
     self._prepared = False   # True once an update of THIS plan has left the lane-ordered weight copies in step with the parameters
 
@@ -248,6 +256,47 @@ class UpdatePlan:
     self._prepared = False
     if self.graph is not None:
       raise RuntimeError('UpdatePlan.invalidate(): re-capture the plan after changing parameters externally')
+
+  def _set_device_sync(self, on: bool):
+    self.device_sync = bool(on)
+    ptr = self.sync.data_ptr() if on else None
+    self.sac.sync = ptr
+    if self.algorithm == 'GAIL':
+      self.disc.sync = ptr
+
+  def _probe_device_sync(self, graph: bool) -> bool:
+    """True if a kernel on the side stream and a kernel on the main stream really run concurrently (eagerly, or as two branches of a
+    captured graph): a waiter enqueued first on the side stream must see the setter enqueued after it on the main stream."""
+    L, main = _lib.lib(), torch.cuda.current_stream()
+
+    def enqueue():
+      self.side.wait_stream(main)
+      with torch.cuda.stream(self.side):
+        _lib.check(L.il_sync_probe(_lib.ptr(self.sync), 0, _lib.stream_ptr()))
+      _lib.check(L.il_sync_probe(_lib.ptr(self.sync), 1, _lib.stream_ptr()))
+      main.wait_stream(self.side)
+    before = self.sync_timeouts()
+    if not graph:
+      for _ in range(3): enqueue()
+    else:   # the shape capture() uses: one graph per stream, the waiter's launched first
+      gw, gs = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+      with torch.cuda.graph(gw, stream=self.side):
+        _lib.check(L.il_sync_probe(_lib.ptr(self.sync), 0, _lib.stream_ptr()))
+      with torch.cuda.graph(gs):
+        _lib.check(L.il_sync_probe(_lib.ptr(self.sync), 1, _lib.stream_ptr()))
+      for _ in range(3):
+        with torch.cuda.stream(self.side):
+          gw.replay()
+        gs.replay()
+    torch.cuda.synchronize()
+    ok = self.sync_timeouts() == before
+    self.sync[4] = 0
+    return ok
+
+  def sync_timeouts(self) -> int:
+    """Bounded waits that gave up (device counter). Non-zero means the two branches did not run concurrently (e.g. a counter-collecting
+    profiler serialises kernels): results of those updates are invalid; `capture()` checks this once and falls back to stream dependencies."""
+    return int(self.sync[4].item())
 
   def prepared_flag(self) -> int:
     return _lib.IL_FLAG_SAC_PREPARED if (self._prepared and os.environ.get('IL_ALWAYS_REPACK') != '1') else 0
@@ -271,7 +320,7 @@ class UpdatePlan:
     _lib.check(_lib.lib().il_replay_sample_device(
         _lib.ptr(st), self.B, _lib.ptr(m._ring_state), _lib.ptr(m.ring), m.size, m.row, _lib.ptr(self.idx), _lib.ptr(self.rows),
         _lib.ptr(e._ring_state) if e else None, _lib.ptr(e.ring) if e else None, e.size if e else 0, e.row if e else 0, _lib.ptr(self.eidx) if e else None,
-        _lib.ptr(self.erows) if e else None, _lib.stream_ptr()))
+        _lib.ptr(self.erows) if e else None, _lib.ptr(self.sync) if self.device_sync else None, _lib.stream_ptr()))
 
   def run(self):
     for hook in self.pre_hooks:
@@ -279,6 +328,15 @@ class UpdatePlan:
     self._run_update()
     for hook in self.post_hooks:
       hook()
+
+  def _enqueue_discriminator_branch(self):
+    L, st = _lib.lib(), _lib.stream_ptr()
+    _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, 0, st))
+    _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, st))
+
+  def _enqueue_sac_branch(self):
+    self.sample_all()
+    _lib.check(_lib.lib().il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), self.prepared_flag(), _lib.stream_ptr()))
 
   def _run_update(self):
     L = _lib.lib()
@@ -293,6 +351,20 @@ class UpdatePlan:
           _lib.check(L.il_sac_prepare(C.byref(self.sac), _lib.stream_ptr()))
           prepared = torch.cuda.Event()
           prepared.record(self.side)
+      fwd = _lib.IL_FLAG_SAC_FORWARD_ONLY | (_lib.IL_FLAG_SAC_PREPARED if early_prepare else self.prepared_flag())
+      if self.device_sync:
+        # No stream dependency between the branches at all: they hand over on the device (k_gather2 -> k_gail_grad, k_gail_reward ->
+        # k_critic_bwd). Captured, they are TWO graphs replayed on two streams (a fork inside one hipGraph delays one branch by 16-20 us).
+        if self._capturing != 'main':
+          with torch.cuda.stream(self.side):
+            self._enqueue_discriminator_branch()
+        if self._capturing != 'side':
+          self._enqueue_sac_branch()
+        if self._capturing is None:
+          main.wait_stream(self.side)   # eager: leave the caller's stream ordered after both branches
+        if self._capturing != 'side':
+          self._prepared = True         # the SAC branch has (or, once replayed, will have) left the lane-ordered weight copies in step
+        return
       self.sample_all()                                             # main: index draws + gathers, next to the re-ordering kernel
       self.side.wait_stream(main)                                   # the discriminator needs the sampled batches
       with torch.cuda.stream(self.side):
@@ -302,7 +374,6 @@ class UpdatePlan:
       if early_prepare:
         main.wait_event(prepared)                                   # main needs the re-ordered weights, not the discriminator
       st = _lib.stream_ptr()
-      fwd = _lib.IL_FLAG_SAC_FORWARD_ONLY | (_lib.IL_FLAG_SAC_PREPARED if early_prepare else self.prepared_flag())
       _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), fwd, st))
       main.wait_stream(self.side)                                   # join: the critic loss reads the rewards
       _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), _lib.IL_FLAG_SAC_SKIP_FORWARD, st))
@@ -318,6 +389,8 @@ class UpdatePlan:
 
   def capture(self, warmup: int = 3):
     assert self.device_index_draw, 'graph capture needs device-side index draws (no H2D inside the graph)'
+    if self.device_sync and not self._probe_device_sync(graph=True):
+      self._set_device_sync(False)   # the runtime serialises graph branches here (e.g. a counter-collecting profiler): keep stream dependencies
     self.memory.stream().device_state(self.rows.device)  # materialise the device copy of the MT19937 state before capture starts
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
@@ -326,12 +399,24 @@ class UpdatePlan:
         self.run()
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
+    if self.device_sync:   # two graphs, one per branch, replayed on two streams; no edge between them (see _run_update)
+      self.graph_side, self._capturing = torch.cuda.CUDAGraph(), 'side'
+      with torch.cuda.graph(self.graph_side, stream=self.side):
+        self._run_update()
+      self.graph, self._capturing = torch.cuda.CUDAGraph(), 'main'
+      with torch.cuda.graph(self.graph):
+        self.run()
+      self._capturing = None
+      return self
     self.graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(self.graph):
       self.run()
     return self
 
   def replay(self):
+    if self.graph_side is not None:
+      with torch.cuda.stream(self.side):
+        self.graph_side.replay()
     self.graph.replay()
 
 
@@ -344,6 +429,7 @@ class PopulationPlan:
     self.plans = list(plans)
     for p in self.plans:
       p.overlap = False  # one stream per learner: the learners themselves are the concurrency (nested fork/join breaks hipGraph capture on ROCm 7.2)
+      p._set_device_sync(False)
     self.streams = [torch.cuda.Stream() for _ in self.plans]
     self.graph = None
 
@@ -385,6 +471,8 @@ class BatchedPopulationPlan:
 
   def __init__(self, plans):
     self.plans = list(plans)
+    for p in self.plans:
+      p._set_device_sync(False)   # one stream, one set of launches for all learners: plain stream order
     p0 = self.plans[0]
     assert all(p.algorithm == p0.algorithm and p.B == p0.B for p in self.plans)
     self.algorithm, self.B, self.L, dev = p0.algorithm, p0.B, len(self.plans), p0.rows.device

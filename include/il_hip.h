@@ -102,9 +102,10 @@ int il_mt19937_randint(uint32_t* state_host, int64_t high, int32_t n, int32_t* o
 int il_mt19937_sample_indices_device(uint32_t* state_dev, const int64_t* ring_state_dev, int32_t n, int32_t* out_dev, il_stream_t stream);
 /* train.py:173 `memory.sample(B), expert_memory.sample(B)` in ONE launch: n draws for ring A, then n for ring B (same stream,
  * same order as the reference), then both row gathers. Ring B may be NULL (algorithm=SAC). */
+int32_t il_replay_gather_workgroups(int32_t n, int32_t row_floats_a, int32_t row_floats_b); /* row_floats_b = 0 without ring B */
 int il_replay_sample_device(uint32_t* state_dev, int32_t n, const int64_t* ring_state_a, const float* ring_a, int64_t capacity_a, int32_t row_floats_a,
                             int32_t* idx_a, float* rows_a, const int64_t* ring_state_b, const float* ring_b, int64_t capacity_b, int32_t row_floats_b,
-                            int32_t* idx_b, float* rows_b, il_stream_t stream);
+                            int32_t* idx_b, float* rows_b, int64_t* sync, il_stream_t stream);
 
 /* Population axis: per-learner arguments of il_replay_sample_device, as a device array. */
 typedef struct il_sample_args {
@@ -129,6 +130,19 @@ int il_adam_step(float* p, const float* g, const il_adam* opt, int64_t n, uint32
 /* models.py:79-81 update_target_network: target <- tau*target + (1-tau)*param */
 int il_polyak(float* target, const float* param, int64_t n, double tau, il_stream_t stream);
 
+/* Device-side hand-off for an update whose discriminator branch and SAC forward run on two streams (one hipGraph). `sync` = device
+ * int64[8], zero-initialised once, shared by the il_sac / il_disc descriptors and il_replay_sample_device of ONE learner:
+ *   [IL_SYNC_ROWS]       += 1 per finished gather workgroup        -> k_gail_grad waits for (side_epoch + 1) * [IL_SYNC_GATHER_WGS]
+ *   [IL_SYNC_REWARDS]    += 1 per finished reward workgroup        -> k_critic_bwd waits for (main_epoch + 1) * ceil(batch / 16)
+ *   [IL_SYNC_SIDE_EPOCH] += 1 when a reward relabel has finished;  [IL_SYNC_MAIN_EPOCH] += 1 at the end of the actor step
+ *   [IL_SYNC_TIMEOUTS]   += 1 whenever a bounded wait gave up (must stay 0: check it on the host after the first update)
+ *   [IL_SYNC_GATHER_WGS] = il_replay_gather_workgroups(n, row_floats_a, row_floats_b), written by the caller when it creates the buffer.
+ * With it the two branches need no stream dependency between the gather and the critic loss (fork at the start of the update, join at
+ * its end). NULL everywhere = plain stream ordering (the caller serialises or uses events). */
+/* il_sync_probe: slots 6, 7 of the same buffer; enqueue setter = 0 on the side stream first, then setter = 1 on the main stream. */
+int il_sync_probe(int64_t* sync, int32_t setter, il_stream_t stream);
+enum { IL_SYNC_ROWS = 0, IL_SYNC_REWARDS = 1, IL_SYNC_SIDE_EPOCH = 2, IL_SYNC_MAIN_EPOCH = 3, IL_SYNC_TIMEOUTS = 4, IL_SYNC_GATHER_WGS = 5 };
+
 /* ------------------------------------------------------------------------------------------
  * SAC (reference training.py:14-54 `sac_update`; models.py:84-141 SoftActor / TwinCritic).
  * ------------------------------------------------------------------------------------------ */
@@ -147,6 +161,7 @@ typedef struct il_sac {
   uint64_t noise_seed;       /* Philox4x32-10 key when eps pointers are NULL */
   uint32_t* noise_counter;   /* device uint32, incremented once per il_sac_actor_step */
   float *out_logp, *out_q;   /* optional [B] outputs (training.py:54) used when the call passes NULL output pointers (population path) */
+  int64_t* sync;             /* il_sync counters or NULL (see below) */
 } il_sac;
 
 int64_t il_mlp_numel(int32_t in_dim, int32_t hidden, int32_t out_dim);
@@ -238,6 +253,7 @@ typedef struct il_disc {
   int64_t workspace_floats;
   uint64_t noise_seed;
   uint32_t* noise_counter;
+  int64_t* sync;             /* il_sync counters or NULL (see below) */
 } il_disc;
 
 int64_t il_disc_workspace_floats(int32_t in_dim, int32_t hidden, int32_t batch);
@@ -330,6 +346,10 @@ int il_dril_bc_step(const il_dril* d, const il_batch* expert, const float* mask_
  * repeat_interleave order or NULL. out_uncertainty [n] and / or out_reward [n] = (uncertainty <= d->q ? +1 : -1). */
 int il_dril_uncertainty(const il_dril* d, const il_batch* batch, const float* mask_in, const float* mask_hidden, uint32_t noise_offset,
                         float* out_uncertainty, float* out_reward, il_stream_t stream);
+
+/* sizeof() of the descriptor structs in this build (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red,
+ * 7 il_dril; -1 otherwise): lets a binding verify its own struct definitions. */
+int32_t il_struct_size(int32_t which);
 
 #ifdef __cplusplus
 }

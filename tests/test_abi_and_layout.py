@@ -34,7 +34,7 @@ def test_struct_sizes_match_header():
   assert C.sizeof(_lib.Batch) == 7 * 8 + 8 * 4
   assert C.sizeof(_lib.Adam) == 3 * 8 + 5 * 8
   assert C.sizeof(_lib.Pwil) == 4 * 4 + 5 * 8 + 3 * 8
-  assert C.sizeof(_lib.Sac) == 4 * 4 + 7 * 8 + 3 * C.sizeof(_lib.Adam) + 2 * 4 + 8 + 8 + 8 + 8 + 8 + 2 * 8
+  assert C.sizeof(_lib.Sac) == 4 * 4 + 7 * 8 + 3 * C.sizeof(_lib.Adam) + 2 * 4 + 8 + 8 + 8 + 8 + 8 + 2 * 8 + 8
   assert _lib.lib().il_ring_row_floats(18, 6) == 48 and _lib.lib().il_ring_row_floats(112, 8) == 240
   assert _lib.lib().il_mlp_numel(18, 256, 12) == 73740 and _lib.lib().il_mlp_stride(24, 256, 1) == 72452
 
@@ -79,3 +79,12 @@ def test_host_index_draw_rejects_empty_ranges():
   out = (C.c_int32 * 4)()
   assert _lib.lib().il_mt19937_sample_indices(st, 4, 100, 1, 0, out) != 0   # not full, idx - 1 == 0 candidates
   assert b'range' in _lib.lib().il_last_error()
+
+
+def test_ctypes_structs_match_the_compiled_library():
+  """sizeof() of every descriptor struct as compiled into libil_hip.so equals the ctypes mirror's (a stale binding would pass garbage)."""
+  from imitation_learning_amd import _lib
+  L = _lib.lib()
+  for which, cls in enumerate((_lib.Batch, _lib.Adam, _lib.Sac, _lib.Disc, _lib.Pwil, _lib.SampleArgs, _lib.Red, _lib.Dril)):
+    assert L.il_struct_size(which) == C.sizeof(cls), cls.__name__
+  assert L.il_struct_size(99) == -1

@@ -338,6 +338,7 @@ def test_update_plan_graph_replay_equals_eager(algorithm):
       for _ in range(5):
         plan.run()
     torch.cuda.synchronize()
+    assert plan.sync_timeouts() == 0 and (algorithm != 'GAIL' or plan.device_sync), 'the device-side hand-off between the two branches must be live and never time out'
     results.append([N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [N(plan.idx), N(plan.logp)])
   for a, b in zip(*results):
     assert np.isfinite(a).all()
