@@ -1,12 +1,12 @@
 // SAC update kernels (reference training.py:14-54) for gfx950.
 //
-// One update = 7 dependent launches, cut only where the algorithm has a global dependency:
+// One update = 6 dependent launches, cut only where the algorithm has a global dependency:
 //   k_actor_fwd      tiles of 16 rows: actor(s') -> a', logp' (no grad) and actor(s) -> a~, logp (activations kept)
 //   k_critic_fwd     (tile, net) : critic_1/2(s,a) with saved activations, target_1/2(s', a')
 //   k_critic_bwd     (tile, net) : y, dQ, back-propagation to the layer-1 pre-activations
 //   k_dw_adam        output-stationary dW = dZ^T.X over the whole batch on MFMA + fused AdamW (critic)
-//   k_policy_critic  (tile, net) : updated critic on (s, a~), dQ/da~
-//   k_actor_bwd      tiles      : min-Q selection, tanh-Gaussian backward, back-propagation through the actor
+//   k_policy_critic  (tile, net) : updated critic on (s, a~), dQ/da~; the pair's second workgroup to finish continues with the policy
+//                                  backward of the tile (min-Q selection, tanh-Gaussian backward, back-propagation through the actor)
 //   k_dw_adam        actor dW + AdamW, Adam(log_alpha), polyak as tail blocks
 // Activations cross kernels through an L2-resident workspace (~3 MB at B=256, H=256) stored FEATURE-MAJOR ([H][B]): an MFMA
 // accumulator lane holds 4 consecutive batch rows of one feature, so producers store and consumers load whole 16-byte lanes
