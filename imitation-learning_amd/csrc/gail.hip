@@ -228,16 +228,10 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   if (d.spectral_norm) { sn_gram(L.W1s, L.Ms, D, Dp, H, ldw); __syncthreads(); }
   IL_STAMP(stamp, 3);
   float* X = L.X(0);
-  if (d.sync) {   // this launch did not wait for the gather on its stream: its rows are ready once every gather workgroup of THIS update has signalled
-    long long* sy = reinterpret_cast<long long*>(d.sync);
-    sync_wait(sy, IL_SYNC_ROWS, (sy[IL_SYNC_SIDE_EPOCH] + 1) * sy[IL_SYNC_GATHER_WGS]);
-  }
-  const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;   // after the wait: the previous update's actor step (which bumps it) precedes this update's gather
-  if (tid < 64) {  // ---- wave 0: the power iterations of calls 0..pass on the Gram matrix
-    if (d.spectral_norm) sn_chain(L.W1s, L.W2s, L.Ms, D, H, L.u1(0), L.v1(0), L.v2(0), L.tmp, pass + 1, L.sc(0));
-    IL_STAMP(stamp, 5);
-  } else {         // ---- waves 1..3: rows of this call
-    for (int i = tid - 64; i < IL_TILE_R * Dp; i += blockDim.x - 64) {
+  // rows (and mixing weights) of this call, staged by threads [t0, blockDim.x)
+  auto stage_rows = [&](int t0, uint32_t ctr) {
+    const int nthr = blockDim.x - t0;
+    for (int i = tid - t0; i >= 0 && i < IL_TILE_R * Dp; i += nthr) {
       const int r = i / Dp, k = i - r * Dp; float x = 0.f;
       if (r < nrows && k < D) {
         const int row = row0 + r;
@@ -249,14 +243,31 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
       }
       X[i] = x;
     }
-    if (tid >= 64 && tid < 64 + IL_TILE_R) {
-      const int r = tid - 64, row = row0 + r; float w = 0.f;
+    if (tid >= t0 && tid < t0 + IL_TILE_R) {
+      const int r = tid - t0, row = row0 + r; float w = 0.f;
       if (r < nrows) {
         const float wp = pass != 1 ? pol.weights[(size_t)row * pol.ld_weights] : 0.f, we = pass != 0 ? exp.weights[(size_t)row * exp.ld_weights] : 0.f;
         if (pass == 2) { const float e = eps_gp ? eps_gp[row] : philox_uniform(d.noise_seed, ctr, IL_STREAM_GP, (uint32_t)row); w = e * we + (1.f - e) * wp; }
         else w = pass == 0 ? wp : we;
       }
       L.wt(0)[r] = w;
+    }
+  };
+  if (d.sync) {
+    // Launched without a stream dependency on the gather: everything that only needs the parameters (weights in LDS, Gram matrix, the power
+    // iterations) has run or runs now; then wait for THIS update's rows (every gather workgroup has signalled) and stage them with all threads.
+    if (tid < 64 && d.spectral_norm) sn_chain(L.W1s, L.W2s, L.Ms, D, H, L.u1(0), L.v1(0), L.v2(0), L.tmp, pass + 1, L.sc(0));
+    long long* sy = reinterpret_cast<long long*>(d.sync);
+    sync_wait(sy, IL_SYNC_ROWS, (sy[IL_SYNC_SIDE_EPOCH] + 1) * sy[IL_SYNC_GATHER_WGS]);
+    const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;   // after the wait: the previous update's actor step (which bumps it) precedes this update's gather
+    stage_rows(0, ctr);
+  } else {
+    const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
+    if (tid < 64) {  // ---- wave 0: the power iterations of calls 0..pass on the Gram matrix
+      if (d.spectral_norm) sn_chain(L.W1s, L.W2s, L.Ms, D, H, L.u1(0), L.v1(0), L.v2(0), L.tmp, pass + 1, L.sc(0));
+      IL_STAMP(stamp, 5);
+    } else {         // ---- waves 1..3: rows of this call
+      stage_rows(64, ctr);
     }
   }
   __syncthreads();

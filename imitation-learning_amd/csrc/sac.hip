@@ -109,13 +109,25 @@ __global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const 
   const SacWs ws = sac_ws(S, A, H, B);
   float* W = d.workspace;
   const MlpView net = mlp_view(d.actor, S, H, 2 * A);
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, tid = threadIdx.x;
+  // Requested / computed before the first barrier, consumed after the MFMA loops: the biases of this wave's 16 columns, and for the head
+  // threads their noise sample (Philox + Box-Muller is ~1 us of dependent ALU work that needs nothing from the MLP) and absorbing flag.
+  const int pc = min(wave * 16 + j, H - 1);
+  const float pb1 = net.b1[pc], pb2 = net.b2[pc];
+  const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
+  float e_pre = 0.f, absorb_pre = 0.f;
+  if (tid < IL_TILE_R * A) {
+    const int r = tid / A, c = tid - r * A, row = row0 + r;
+    const float* ep = is_cur ? eps_cur : eps_next;
+    e_pre = ep ? ep[(size_t)row * A + c] : philox_normal(d.noise_seed, ctr, is_cur ? IL_STREAM_EPS_CUR : IL_STREAM_EPS_NEXT, (uint32_t)(row * A + c));
+    if (!is_cur) absorb_pre = b.absorbing[(size_t)row * b.ld_absorbing];
+  }
   const float* src = is_cur ? b.states : b.next_states;
   const int ld = is_cur ? b.ld_states : b.ld_next_states;
   load_rows_cat(Xs, ldx, Sp, src, ld, S, nullptr, 0, 0, row0, IL_TILE_R);
   __syncthreads();
-  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   tile_fwd(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4 acc) {
-    const int col = c0 + j; const float bb = net.b1[col];
+    const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1 : net.b1[col];
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = hv[r]; }
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const 
   });
   __syncthreads();
   tile_fwd_packed(H1s, ldh, H, W + ws.pk_af, [&](int c0, f32x4 acc) {
-    const int col = c0 + j; const float bb = net.b2[col];
+    const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb2 : net.b2[col];
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = hv[r]; }
@@ -133,12 +145,9 @@ __global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const 
   tile_fwd_small(H2s, ldh, H, net.W3, H, 2 * A, net.b3, Os, part);
   // head: one thread per (row, action component); per-row sums through LDS (sequential over A like torch's sum(-1))
   float* nl = part; float* la = part + 256;
-  const int tid = threadIdx.x;
-  const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
   if (tid < IL_TILE_R * A) {
     const int r = tid / A, c = tid - r * A, row = row0 + r;
-    const float* ep = is_cur ? eps_cur : eps_next;
-    const float e = ep ? ep[(size_t)row * A + c] : philox_normal(d.noise_seed, ctr, is_cur ? IL_STREAM_EPS_CUR : IL_STREAM_EPS_NEXT, (uint32_t)(row * A + c));
+    const float e = e_pre;
     const float mean = Os[r * 16 + c], lsr = Os[r * 16 + A + c];
     float x, a, nlp, ladj;
     head_sample(mean, lsr, e, x, a, nlp, ladj);
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const 
       W[ws.a_xpre + (size_t)row * A + c] = x; W[ws.a_eps + (size_t)row * A + c] = e; W[ws.a_lsraw + (size_t)row * A + c] = lsr;
       W[ws.a_anew + (size_t)row * A + c] = a;
     } else {
-      W[ws.n_a2 + (size_t)row * A + c] = (1.f - b.absorbing[(size_t)row * b.ld_absorbing]) * a;
+      W[ws.n_a2 + (size_t)row * A + c] = (1.f - absorb_pre) * a;
     }
   }
   __syncthreads();
@@ -189,15 +198,21 @@ __global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b, const
   float* W = d.workspace;
   const int64_t ns = net_stride(IN, H, 1);
   const MlpView p = mlp_view((is_target ? d.target : d.critic) + k * ns, IN, H, 1);
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  // biases of this wave's 16 columns and this lane's slice of w3: requested before the first barrier, consumed after the MFMA loops
+  const int pc = min(wave * 16 + j, H - 1);
+  const float pb1 = p.b1[pc], pb2 = p.b2[pc], pb3 = p.b3[0];
+  float w3v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) w3v[u] = p.W3[min(lane + 64 * u, H - 1)];
   if (is_target) load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, W + ws.n_a2, A, A, row0, IL_TILE_R);
   else load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R);
   __syncthreads();
   if (net == 0)
     for (int i = threadIdx.x; i < IL_TILE_R * IN; i += blockDim.x) { const int c = i >> 4, r = i & 15; W[ws.c_x0 + (size_t)c * B + row0 + r] = Xs[r * ldx + c]; }  // x0^T [IN][B]
-  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   float* sh1 = W + ws.c_h1 + (size_t)k * B * H; float* sh2 = W + ws.c_h2 + (size_t)k * B * H;
   tile_fwd(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4 acc) {
-    const int col = c0 + j; const float bb = p.b1[col];
+    const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1 : p.b1[col];
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = hv[r]; }
@@ -205,16 +220,21 @@ __global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b, const
   });
   __syncthreads();
   tile_fwd_packed(H1s, ldh, H, W + (is_target ? ws.pk_tf : ws.pk_cf) + (size_t)k * H * H, [&](int c0, f32x4 acc) {
-    const int col = c0 + j; const float bb = p.b2[col];
+    const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb2 : p.b2[col];
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = hv[r]; }
     if (!is_target) *reinterpret_cast<f32x4*>(sh2 + (size_t)col * B + row0 + 4 * g) = hv;
   });
   __syncthreads();
-  critic_head(H2s, ldh, H, p.W3, p.b3[0], q16);
-  __syncthreads();
-  if (threadIdx.x < IL_TILE_R) W[(is_target ? ws.t_q : ws.c_q) + (size_t)k * B + row0 + threadIdx.x] = q16[threadIdx.x];
+  for (int r = wave; r < IL_TILE_R; r += nw) {   // Q = h2 . w3 + b3: one wave per row, w3 from the registers loaded at the top
+    float sq = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int n = lane + 64 * u; if (n < H) sq += H2s[r * ldh + n] * w3v[u]; }
+    sq = wave_sum(sq);
+    if (lane == 0) W[(is_target ? ws.t_q : ws.c_q) + (size_t)k * B + row0 + r] = sq + pb3;
+  }
+  (void)q16;
 }
 
 // ---------------------------------------------------------------------------------------------
