@@ -304,10 +304,12 @@ def main():
       del pop
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(tr, et)
-    print(json.dumps(out))
   if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()
+  if rank == 0:
+    C.CDLL(None).fflush(None)   # RCCL writes its banner through C stdio (possibly at teardown): drain it so that the JSON line is the LAST line of stdout
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -201,13 +201,17 @@ __device__ __forceinline__ void stage_weights(const DiscLds& L, const float* __r
 
 // grid = (tiles, passes): one workgroup = 16 rows of ONE discriminator call (0 policy, 1 expert, 2 gradient-penalty mix), so the
 // three calls run side by side; wave 0 chains the power iterations up to its call (pass + 1 of them) while waves 1.. stage rows.
-__global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp, const il_disc* __restrict__ dL,
+// Loss variants (training.py:97-113): BCE and PUGAIL (nonnegative_margin = inf) are calls {policy, expert}; Mixup is ONE call on convex combinations
+// with per-row soft labels. All three are  d loss / d logit = w (c_sig * sigmoid(z) - c_lab) / B  with different constants. `x` carries the optional
+// inputs: the Mixup draws and the log pi(a|s) offsets of subtract_log_policy (logit z = f - log pi; computed without a graph, so a pure shift).
+__global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp, il_gail_extra x, const il_disc* __restrict__ dL,
                                                    const il_batch* __restrict__ polL, const il_batch* __restrict__ expL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (dL) { d = dL[blockIdx.z]; pol = polL[blockIdx.z]; exp = expL[blockIdx.z]; }  // population axis
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch, Dp = (D + 3) & ~3, ldw = Dp + 4;
   const int tile = blockIdx.x, pass = blockIdx.y, npass = gridDim.y, nt = gridDim.x, row0 = tile * IL_TILE_R, tid = threadIdx.x;
   const int nrows = min(IL_TILE_R, B - row0);
+  const int kind = d.loss_function == IL_LOSS_MIXUP ? (pass == 0 ? 3 : 2) : pass;   // 0 policy, 1 expert, 2 gradient-penalty mix, 3 mixup mix
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
   const DiscWs wsl = disc_ws(D, H, B);
   const float b2 = d.params[lay.ob2];
@@ -229,26 +233,31 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   IL_STAMP(stamp, 3);
   float* X = L.X(0);
   // rows (and mixing weights) of this call, staged by threads [t0, blockDim.x)
-  auto stage_rows = [&](int t0, uint32_t ctr) {
+  uint32_t ctr = 0u;   // Philox counter of this update (read below, once it is known to be this update's)
+  auto mix_eps = [&](int row) -> float {   // U(0,1) of the gradient penalty (training.py:118) or the Beta(alpha, alpha) draw of Mixup (:106; on chip only alpha = 1)
+    const float* given = kind == 2 ? eps_gp : x.eps_mix;
+    return given ? given[row] : philox_uniform(d.noise_seed, ctr, kind == 2 ? IL_STREAM_GP : IL_STREAM_MIX, (uint32_t)row);
+  };
+  auto stage_rows = [&](int t0) {
     const int nthr = blockDim.x - t0;
     for (int i = tid - t0; i >= 0 && i < IL_TILE_R * Dp; i += nthr) {
-      const int r = i / Dp, k = i - r * Dp; float x = 0.f;
+      const int r = i / Dp, k = i - r * Dp; float xv = 0.f;
       if (r < nrows && k < D) {
         const int row = row0 + r;
         float xp = 0.f, xe = 0.f;
-        if (pass != 1) xp = k < S ? pol.states[(size_t)row * pol.ld_states + k] : pol.actions[(size_t)row * pol.ld_actions + k - S];
-        if (pass != 0) xe = k < S ? exp.states[(size_t)row * exp.ld_states + k] : exp.actions[(size_t)row * exp.ld_actions + k - S];
-        if (pass == 2) { const float e = eps_gp ? eps_gp[row] : philox_uniform(d.noise_seed, ctr, IL_STREAM_GP, (uint32_t)row); x = e * xe + (1.f - e) * xp; }
-        else x = pass == 0 ? xp : xe;
+        if (kind != 1) xp = k < S ? pol.states[(size_t)row * pol.ld_states + k] : pol.actions[(size_t)row * pol.ld_actions + k - S];
+        if (kind != 0) xe = k < S ? exp.states[(size_t)row * exp.ld_states + k] : exp.actions[(size_t)row * exp.ld_actions + k - S];
+        if (kind >= 2) { const float e = mix_eps(row); xv = e * xe + (1.f - e) * xp; }
+        else xv = kind == 0 ? xp : xe;
       }
-      X[i] = x;
+      X[i] = xv;
     }
     if (tid >= t0 && tid < t0 + IL_TILE_R) {
       const int r = tid - t0, row = row0 + r; float w = 0.f;
       if (r < nrows) {
-        const float wp = pass != 1 ? pol.weights[(size_t)row * pol.ld_weights] : 0.f, we = pass != 0 ? exp.weights[(size_t)row * exp.ld_weights] : 0.f;
-        if (pass == 2) { const float e = eps_gp ? eps_gp[row] : philox_uniform(d.noise_seed, ctr, IL_STREAM_GP, (uint32_t)row); w = e * we + (1.f - e) * wp; }
-        else w = pass == 0 ? wp : we;
+        const float wp = kind != 1 ? pol.weights[(size_t)row * pol.ld_weights] : 0.f, we = kind != 0 ? exp.weights[(size_t)row * exp.ld_weights] : 0.f;
+        if (kind >= 2) { const float e = mix_eps(row); w = e * we + (1.f - e) * wp; }
+        else w = kind == 0 ? wp : we;
       }
       L.wt(0)[r] = w;
     }
@@ -259,15 +268,15 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     if (tid < 64 && d.spectral_norm) sn_chain(L.W1s, L.W2s, L.Ms, D, H, L.u1(0), L.v1(0), L.v2(0), L.tmp, pass + 1, L.sc(0));
     long long* sy = reinterpret_cast<long long*>(d.sync);
     sync_wait(sy, IL_SYNC_ROWS, (sy[IL_SYNC_SIDE_EPOCH] + 1) * sy[IL_SYNC_GATHER_WGS]);
-    const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;   // after the wait: the previous update's actor step (which bumps it) precedes this update's gather
-    stage_rows(0, ctr);
+    ctr = d.noise_counter ? *d.noise_counter : 0u;   // after the wait: the previous update's actor step (which bumps it) precedes this update's gather
+    stage_rows(0);
   } else {
-    const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
+    ctr = d.noise_counter ? *d.noise_counter : 0u;
     if (tid < 64) {  // ---- wave 0: the power iterations of calls 0..pass on the Gram matrix
       if (d.spectral_norm) sn_chain(L.W1s, L.W2s, L.Ms, D, H, L.u1(0), L.v1(0), L.v2(0), L.tmp, pass + 1, L.sc(0));
       IL_STAMP(stamp, 5);
     } else {         // ---- waves 1..3: rows of this call
-      stage_rows(64, ctr);
+      stage_rows(64);
     }
   }
   __syncthreads();
@@ -294,14 +303,21 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     for (int q = 0; q < 4; ++q) { const float t = group16_sum(zp[q]); if (jj == 0) zw[wave * 16 + 4 * gg + q] = t; }
   }
   __syncthreads();
-  float z = b2;
-  for (int w = 0; w < nw; ++w) z += zw[w * 16 + r];
+  float f = b2;   // the network's logit
+  for (int w = 0; w < nw; ++w) f += zw[w * 16 + r];
   __syncthreads();  // zw (aliasing ts) is free again
   float ip1, ip2;
-  if (pass < 2) {
-    const float w = L.wt(0)[r], label = pass == 1 ? 1.f : 0.f;
+  if (kind != 2) {
+    const float w = L.wt(0)[r];
+    const int row = row0 + min(r, nrows - 1);
+    const float* off = kind == 0 ? x.logit_offset_policy : (kind == 1 ? x.logit_offset_expert : nullptr);
+    const float z = off ? f - off[row] : f;   // subtract_log_policy (models.py:175)
+    const bool pu = d.loss_function == IL_LOSS_PUGAIL;
+    // d loss / d z = w (c_sig sigmoid(z) - c_lab) / B: BCE {1, label}; PUGAIL policy {-1, 0}, expert {2 prior, prior}; Mixup {1, eps}
+    const float c_sig = pu ? (kind == 1 ? 2.f * d.pos_class_prior : -1.f) : 1.f;
+    const float c_lab = kind == 3 ? mix_eps(row) : (kind == 1 ? (pu ? d.pos_class_prior : 1.f) : 0.f);
     const float p = sigmoid_f(z);
-    float dz = valid ? w * (p - label) / fB : 0.f;
+    float dz = valid ? w * (c_sig * p - c_lab) / fB : 0.f;
     if (d.entropy_bonus > 0.f && valid) dz += d.entropy_bonus * w * z * p * (1.f - p) / fB;
     if (sub == 0) { L.dzs[r] = dz; L.zs[r] = z; }
     float a1 = 0.f;
@@ -312,7 +328,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
       a1 += dh * (h - L.b1s[n]);
     }
     ip1 = s1 * block_sum(a1, L.red);
-    ip2 = s2 * block_sum(sub == 0 ? dz * (z - b2) : 0.f, L.red);
+    ip2 = s2 * block_sum(sub == 0 ? dz * (f - b2) : 0.f, L.red);
   } else {
     // q = [h>0] w2^ -> dhs ; g = q . W1^ (MFMA) ; cg = c g ; t' = cg . W1^^T (MFMA)
     for (int n = sub; n < H; n += 16) L.dhs[r * H + n] = L.hs[r * H + n] > 0.f ? (L.W2s[n] / s2) : 0.f;
@@ -345,7 +361,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   IL_STAMP(stamp, 7);
   // ---- this call's gradient slab:  G1^[n][k] = sum_r left[r][n] right[r][k]  on MFMA (reduction over the tile's 16 rows)
   const float* left = L.dhs;                         // [16][H]: dh (BCE) or q (GP)
-  const float* right = pass < 2 ? X : L.cg;          // [16][Dp]: x (BCE) or c*g (GP)
+  const float* right = kind != 2 ? X : L.cg;         // [16][Dp]: x (BCE) or c*g (GP)
   const float k1 = d.spectral_norm ? ip1 / (s1 * s1) : 0.f, k2 = d.spectral_norm ? ip2 / (s2 * s2) : 0.f;
   {
     const int nkt = (D + 15) / 16;
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   for (int n = tid; n < H; n += blockDim.x) {
     float g2 = 0.f, gb = 0.f;
     for (int rr = 0; rr < IL_TILE_R; ++rr) {
-      if (pass < 2) { g2 += L.dzs[rr] * fmaxf(L.hs[rr * H + n], 0.f); gb += L.dhs[rr * H + n]; }
+      if (kind != 2) { g2 += L.dzs[rr] * fmaxf(L.hs[rr * H + n], 0.f); gb += L.dhs[rr * H + n]; }
       else g2 += L.ts[rr * H + n];
     }
     slab[lay.oW2 + n] = g2 / s2 - (d.spectral_norm ? k2 * u2 * v2[n] : 0.f);
@@ -369,7 +385,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   }
   if (tid == 0) {
     float gb2 = 0.f;
-    if (pass < 2) for (int rr = 0; rr < IL_TILE_R; ++rr) gb2 += L.dzs[rr];
+    if (kind != 2) for (int rr = 0; rr < IL_TILE_R; ++rr) gb2 += L.dzs[rr];
     slab[lay.ob2] = gb2;
   }
   IL_STAMP(stamp, 8);
@@ -381,13 +397,15 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   }
 }
 
+__host__ __device__ inline int gail_calls(const il_disc& d) { return (d.loss_function == IL_LOSS_MIXUP ? 1 : 2) + (d.grad_penalty > 0.f ? 1 : 0); }
+
 // grid = ceil(P / 256): one gradient element per thread, slabs summed in tile order (deterministic)
 __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const il_disc* __restrict__ dL) {
   if (dL) d = dL[blockIdx.y];
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch;
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
   const DiscWs wsl = disc_ws(D, H, B);
-  const int nt = ((B + IL_TILE_R - 1) / IL_TILE_R) * (d.grad_penalty > 0.f ? 3 : 2);  // one slab per (call, tile)
+  const int nt = ((B + IL_TILE_R - 1) / IL_TILE_R) * gail_calls(d);  // one slab per (call, tile)
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < lay.P) {
     const float* sl = d.workspace + wsl.slabs + e;
@@ -425,7 +443,7 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const
   }
 }
 
-__global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, float* __restrict__ out_r, float* __restrict__ out_logit, const il_disc* __restrict__ dL,
+__global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, float* __restrict__ out_r, float* __restrict__ out_logit, const float* __restrict__ logit_offset, const il_disc* __restrict__ dL,
                                                      const il_batch* __restrict__ bL, float* const* __restrict__ outL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; out_r = outL[blockIdx.y]; out_logit = nullptr; }
@@ -453,7 +471,7 @@ __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, floa
   for (int n = sub; n < H; n += 16) zp += (L.W2s[n] / s2) * fmaxf(dot4(L.W1s + n * ldw, L.X(0) + r * Dp, Dp) / s1 + L.b1s[n], 0.f);
   zp = group16_sum(zp);
   if (sub == 0 && r < nrows) {
-    const float z = zp + b2, Dp = sigmoid_f(z);
+    const float f = zp + b2, z = logit_offset ? f - logit_offset[row0 + r] : f, Dp = sigmoid_f(z);
     float h = d.reward_function == 1 ? -log1pf(-Dp + 1e-6f) : logf(Dp + 1e-6f) - log1pf(-Dp + 1e-6f);
     if (d.reward_function == 2) h = expf(h) * -h;
     out_r[row0 + r] = h;
@@ -483,20 +501,24 @@ static int check_disc(const il_disc* d) {
   IL_CHECK_ARG(d->hidden >= 16 && d->hidden <= 512 && d->hidden % 16 == 0 && D >= 1 && D <= 512, "il_disc: dims out of range (D=%d, hidden=%d: hidden must be a multiple of 16)", D, d->hidden);
   IL_CHECK_ARG(disc_lds_floats(D, d->hidden) * sizeof(float) <= 160 * 1024, "il_disc: D=%d hidden=%d needs more than 160 KiB of LDS", D, d->hidden);
   IL_CHECK_ARG(d->reward_function >= 0 && d->reward_function <= 2, "il_disc: reward_function must be 0 (AIRL), 1 (GAIL) or 2 (FAIRL)");
+  IL_CHECK_ARG(d->loss_function >= 0 && d->loss_function <= 2, "il_disc: loss_function must be 0 (BCE), 1 (PUGAIL) or 2 (Mixup)");
   if (d->spectral_norm) IL_CHECK_ARG(d->u1 && d->v1 && d->u2 && d->v2, "il_disc: spectral-norm buffers missing");
   if (d->workspace_floats < disc_ws(D, d->hidden, d->batch).total) return il_set_error(IL_ERR_WORKSPACE, "il_disc: workspace too small");
   return IL_OK;
 }
 
-extern "C" int il_gail_disc_step(const il_disc* d, const il_batch* pol, const il_batch* exp, const float* eps_gp, uint32_t flags, il_stream_t stream_) {
+extern "C" int il_gail_disc_step(const il_disc* d, const il_batch* pol, const il_batch* exp, const float* eps_gp, const il_gail_extra* extra, uint32_t flags, il_stream_t stream_) {
   if (int rc = check_disc(d)) return rc;
   IL_CHECK_ARG(pol && exp && pol->n == d->batch && exp->n == d->batch, "il_gail_disc_step: policy/expert batches must both have %d rows", d->batch);
+  il_gail_extra x = {};
+  if (extra) x = *extra;
+  IL_CHECK_ARG(d->loss_function != IL_LOSS_MIXUP || (!x.logit_offset_policy && !x.logit_offset_expert), "il_gail_disc_step: Mixup with subtract_log_policy is not supported");
   hipStream_t st = (hipStream_t)stream_;
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
   const int nt = ceil_div(d->batch, IL_TILE_R);
   const size_t lds = disc_lds_floats(D, d->hidden) * sizeof(float);
   if (int rc = ensure_lds((const void*)k_gail_grad, lds)) return rc;
-  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, d->grad_penalty > 0.f ? 3 : 2), 256, lds, st>>>(*d, *pol, *exp, eps_gp, nullptr, nullptr, nullptr); }
+  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, nullptr, nullptr, nullptr); }
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
   { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr); }
   IL_CHECK_LAUNCH("il_gail_disc_step");
@@ -508,6 +530,7 @@ extern "C" int il_gail_step_population(const il_disc* descs_dev, const il_batch*
                                        const il_disc* shape_host, il_stream_t stream_) {
   if (int rc = check_disc(shape_host)) return rc;
   IL_CHECK_ARG(descs_dev && policy_dev && expert_dev && rewards_out_dev && n_learners >= 1 && n_learners <= 65535, "il_gail_step_population: bad arguments");
+  IL_CHECK_ARG(shape_host->loss_function != IL_LOSS_MIXUP, "il_gail_step_population: loss_function Mixup is not available on the population path");
   const il_disc* d = shape_host;
   hipStream_t st = (hipStream_t)stream_;
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim), nt = ceil_div(d->batch, IL_TILE_R), L = n_learners;
@@ -516,9 +539,9 @@ extern "C" int il_gail_step_population(const il_disc* descs_dev, const il_batch*
   if (int rc = ensure_lds((const void*)k_gail_reward, lds)) return rc;
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
   il_batch zb = {};
-  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, d->grad_penalty > 0.f ? 3 : 2, L), 256, lds, st>>>(*d, zb, zb, nullptr, descs_dev, policy_dev, expert_dev); }
+  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d), L), 256, lds, st>>>(*d, zb, zb, nullptr, il_gail_extra{}, descs_dev, policy_dev, expert_dev); }
   { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<dim3((int)((P + 255) / 256), L), 256, 0, st>>>(*d, 1, descs_dev); }
-  { IL_TRACE("k_gail_reward", st); k_gail_reward<<<dim3(nt, L), 256, lds, st>>>(*d, zb, nullptr, nullptr, descs_dev, policy_dev, rewards_out_dev); }
+  { IL_TRACE("k_gail_reward", st); k_gail_reward<<<dim3(nt, L), 256, lds, st>>>(*d, zb, nullptr, nullptr, nullptr, descs_dev, policy_dev, rewards_out_dev); }
   IL_CHECK_LAUNCH("il_gail_step_population");
   return IL_OK;
 }
@@ -540,13 +563,13 @@ extern "C" int il_gail_apply_grads(const il_disc* d, il_stream_t stream_) {
   return IL_OK;
 }
 
-extern "C" int il_gail_reward(const il_disc* d, const il_batch* b, float* out_rewards, float* out_logits, il_stream_t stream_) {
+extern "C" int il_gail_reward(const il_disc* d, const il_batch* b, float* out_rewards, float* out_logits, const float* logit_offset, il_stream_t stream_) {
   if (int rc = check_disc(d)) return rc;
   IL_CHECK_ARG(b && out_rewards && b->n > 0, "il_gail_reward: bad arguments");
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
   const size_t lds = disc_lds_floats(D, d->hidden) * sizeof(float);
   if (int rc = ensure_lds((const void*)k_gail_reward, lds)) return rc;
-  { IL_TRACE("k_gail_reward", stream_); k_gail_reward<<<ceil_div(b->n, IL_TILE_R), 256, lds, (hipStream_t)stream_>>>(*d, *b, out_rewards, out_logits, nullptr, nullptr, nullptr); }
+  { IL_TRACE("k_gail_reward", stream_); k_gail_reward<<<ceil_div(b->n, IL_TILE_R), 256, lds, (hipStream_t)stream_>>>(*d, *b, out_rewards, out_logits, logit_offset, nullptr, nullptr, nullptr); }
   IL_CHECK_LAUNCH("il_gail_reward");
   return IL_OK;
 }

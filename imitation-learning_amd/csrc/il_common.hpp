@@ -89,7 +89,7 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t ctr, uin
   const philox_out o = philox4x32_10(idx, ctr, stream_id, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
   return (float)(o.v[0] >> 8) * (1.0f / 16777216.0f);  // [0,1) like torch.rand
 }
-enum { IL_STREAM_EPS_NEXT = 1, IL_STREAM_EPS_CUR = 2, IL_STREAM_GP = 3, IL_STREAM_ACT = 4 };
+enum { IL_STREAM_EPS_NEXT = 1, IL_STREAM_EPS_CUR = 2, IL_STREAM_GP = 3, IL_STREAM_ACT = 4, IL_STREAM_MIX = 7 };   // 5, 6: dropout masks (dril.hip)
 
 // ---------------------------------------------------------------------------------------------
 // AdamW single-tensor step, op order of torch._single_tensor_adam (fp32 tensors, python-double scalars).

@@ -1142,6 +1142,40 @@ __global__ __launch_bounds__(1024) void k_act(const float* __restrict__ actor, i
   }
 }
 
+// SoftActor.log_prob(state, action) (models.py:97-99: action clamped to +-(1 - 1e-6), tanh-Gaussian density) for n rows: the log pi(a|s) that
+// subtract_log_policy feeds to the discriminator (models.py:144). grid = ceil(n/16)
+__global__ __launch_bounds__(1024) void k_actor_logp(const float* __restrict__ actor, int S, int A, int H, const float* __restrict__ states, int ld_s, const float* __restrict__ actions,
+                                                    int ld_a, int n, float* __restrict__ out_logp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int row0 = blockIdx.x * IL_TILE_R, tid = threadIdx.x, nrows = min(IL_TILE_R, n - row0);
+  const ActTile t = actor_tile(smem, actor, S, A, H, states, ld_s, row0, nrows);
+  float* nl = t.part; float* la = t.part + 256;
+  if (tid < IL_TILE_R * A) {
+    const int r = tid / A, c = tid - r * A, row = row0 + min(r, nrows - 1);
+    const float mean = t.Os[r * 16 + c], sd = expf(fminf(fmaxf(t.Os[r * 16 + A + c], -20.f), 2.f));
+    const float a = fminf(fmaxf(actions[(size_t)row * ld_a + c], -1.f + 1e-6f), 1.f - 1e-6f);
+    const float x = atanhf(a), dx = x - mean;
+    nl[r * 16 + c] = -(dx * dx) / (2.f * (sd * sd)) - logf(sd) - LOG_SQRT_2PI;
+    la[r * 16 + c] = 2.f * (LOG_2 - x - softplus_f(-2.f * x));
+  }
+  __syncthreads();
+  if (tid < nrows) {
+    float sn = 0.f, sl = 0.f;
+    for (int c = 0; c < A; ++c) { sn += nl[tid * 16 + c]; sl += la[tid * 16 + c]; }
+    out_logp[row0 + tid] = (0.f - sl) + sn;
+  }
+}
+
+extern "C" int il_actor_log_prob(const float* actor, int32_t S, int32_t A, int32_t H, const float* states, int32_t ld_states, const float* actions, int32_t ld_actions, int32_t n,
+                                 float* out_logp, il_stream_t stream_) {
+  IL_CHECK_ARG(actor && states && actions && out_logp && n > 0, "il_actor_log_prob: null argument");
+  IL_CHECK_ARG(H % 64 == 0 && H >= 64 && H <= 256 && A >= 1 && 2 * A <= 16, "il_actor_log_prob: unsupported dims (hidden=%d, action_dim=%d)", H, A);
+  { IL_TRACE("k_actor_logp", stream_);
+    k_actor_logp<<<ceil_div(n, IL_TILE_R), tile_threads(H), tile_lds_bytes(round_up16(S + A), H), (hipStream_t)stream_>>>(actor, S, A, H, states, ld_states, actions, ld_actions, n, out_logp); }
+  IL_CHECK_LAUNCH("il_actor_log_prob");
+  return IL_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // One environment step of the acting worker (train.py:151-168) as ONE launch: append the pending transition to the ring
 // (memory.py:40-44), optionally wrap it for absorbing states (memory.py:65-68), sample the action for the next observation

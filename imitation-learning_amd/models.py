@@ -19,6 +19,7 @@ from torch.nn.utils import parametrizations
 from . import _lib
 
 REWARD_FUNCTIONS = {'AIRL': 0, 'GAIL': 1, 'FAIRL': 2}
+LOSS_FUNCTIONS = {'BCE': 0, 'PUGAIL': 1, 'Mixup': 2}   # IL_LOSS_* (include/il_hip.h)
 
 
 def default_device() -> torch.device:
@@ -138,14 +139,17 @@ class SoftActor(_FlatModule):
     return self._act(state, greedy=True)[0]
 
   def log_prob(self, state: Tensor, action: Tensor) -> Tensor:
-    """models.py:97-99 (not on the update path: BC computes it inside k_bc_tile). Plain torch ops on the device views."""
-    action = action.clamp(-1 + 1e-6, 1 - 1e-6)
-    mean, log_std = self.actor(state).chunk(2, dim=1)
-    log_std = log_std.clamp(self.log_std_dev_min, self.log_std_dev_max)
-    x = torch.atanh(action)
-    normal = -((x - mean) ** 2) / (2 * (2 * log_std).exp()) - log_std - 0.9189385332046727
-    ladj = 2.0 * (0.6931471805599453 - x - torch.nn.functional.softplus(-2.0 * x))
-    return normal.sum(dim=1) - ladj.sum(dim=1)
+    """models.py:97-99: log pi(a|s) with the action clamped to +-(1 - 1e-6) (k_actor_logp)."""
+    dev = self.flat.device
+    state, action = state.to(dev, torch.float32), action.to(dev, torch.float32)
+    if state.dim() == 1: state, action = state.unsqueeze(0), action.unsqueeze(0)
+    if state.stride(1) != 1: state = state.contiguous()
+    if action.stride(1) != 1: action = action.contiguous()
+    n = state.size(0)
+    out = torch.empty(n, device=dev)
+    _lib.check(_lib.lib().il_actor_log_prob(_lib.ptr(self.flat), self.state_size, self.action_size, self.hidden, _lib.ptr(state), state.stride(0) if n > 1 else state.size(1),
+                                            _lib.ptr(action), action.stride(0) if n > 1 else action.size(1), n, _lib.ptr(out), _lib.stream_ptr()))
+    return out
 
 
 class DropoutSoftActor(SoftActor):
@@ -290,9 +294,13 @@ def update_target_network(network: _FlatModule, target_network: _FlatModule, pol
 
 
 def make_gail_input(state, action, next_state, terminal, actor, reward_shaping: bool, subtract_log_policy: bool) -> Dict[str, Tensor]:
-  if reward_shaping or subtract_log_policy:
-    raise NotImplementedError('GAIL reward_shaping / subtract_log_policy variants are outside the HIP hot path (SURVEY.md §8f-4)')
-  return {'state': state, 'action': action}
+  """models.py:139-144."""
+  if reward_shaping:
+    raise NotImplementedError('GAIL reward_shaping (a separate shaping network h(s), models.py:157-160) has no kernel on the HIP path')
+  out = {'state': state, 'action': action}
+  if subtract_log_policy:
+    out['log_policy'] = actor.log_prob(state, action)
+  return out
 
 
 class GAILDiscriminator(_FlatModule):
@@ -309,8 +317,8 @@ class GAILDiscriminator(_FlatModule):
     self.discount, self.state_only = discount, bool(imitation_cfg.state_only)
     self.reward_shaping, self.subtract_log_policy, self.reward_function = model_cfg.reward_shaping, model_cfg.subtract_log_policy, model_cfg.reward_function
     self.spectral_norm = bool(imitation_cfg.spectral_norm)
-    if self.reward_shaping or self.subtract_log_policy or model_cfg.depth != 1 or model_cfg.activation != 'relu':
-      raise NotImplementedError('GAILDiscriminator: the HIP path implements depth=1, activation=relu, no reward shaping / log-policy subtraction '
+    if self.reward_shaping or model_cfg.depth != 1 or model_cfg.activation != 'relu':
+      raise NotImplementedError('GAILDiscriminator: the HIP path implements depth=1, activation=relu without reward shaping '
                                 '(the closed-form gradient-penalty backward assumes it); no torch fallback on this path')
     self.state_size, self.action_size, self.hidden = state_size, action_size, model_cfg.hidden_size
     self.in_dim = state_size if self.state_only else state_size + action_size
@@ -341,11 +349,12 @@ class GAILDiscriminator(_FlatModule):
 
   def predict_reward(self, state: Tensor, action: Tensor, next_state=None, terminal=None, log_policy=None) -> Tensor:
     from .training import gail_predict_reward
-    return gail_predict_reward(self, state, action)
+    assert (log_policy is not None) == bool(self.subtract_log_policy), 'pass log_policy exactly when subtract_log_policy is set (make_gail_input does)'
+    return gail_predict_reward(self, state, action, log_policy=log_policy)
 
   def forward(self, state: Tensor, action: Tensor, next_state=None, terminal=None, log_policy=None) -> Tensor:
     from .training import gail_predict_reward
-    return gail_predict_reward(self, state, action, want_logits=True)[1]
+    return gail_predict_reward(self, state, action, want_logits=True, log_policy=log_policy)[1]
 
 
 class GMMILDiscriminator(nn.Module):

@@ -71,10 +71,10 @@ class DataParallelUpdate:
     if p.algorithm == 'GAIL':
       self.side.wait_stream(main)
       with torch.cuda.stream(self.side):
-        _lib.check(L.il_gail_disc_step(C.byref(p.disc), C.byref(p.pb), C.byref(p.eb), None, G, _lib.stream_ptr()))
+        _lib.check(L.il_gail_disc_step(C.byref(p.disc), C.byref(p.pb), C.byref(p.eb), None, None, G, _lib.stream_ptr()))
         all_reduce_mean_(self.disc_bucket, self.group)
         _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
-        _lib.check(L.il_gail_reward(C.byref(p.disc), C.byref(p.pb), _lib.ptr(p.rewards), None, _lib.stream_ptr()))
+        _lib.check(L.il_gail_reward(C.byref(p.disc), C.byref(p.pb), _lib.ptr(p.rewards), None, None, _lib.stream_ptr()))
     _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 0, None, None, p.prepared_flag(), _lib.stream_ptr()))
     if p.algorithm == 'GAIL':
       main.wait_stream(self.side)

@@ -15,7 +15,7 @@ from torch import Tensor
 
 from . import _lib
 from .memory import ReplayMemory, batch_desc, batch_views
-from .models import REWARD_FUNCTIONS, GAILDiscriminator, GMMILDiscriminator, SoftActor, TwinCritic
+from .models import LOSS_FUNCTIONS, REWARD_FUNCTIONS, GAILDiscriminator, GMMILDiscriminator, SoftActor, TwinCritic
 from .optim import Adam, AdamW
 
 _WS: Dict[tuple, Tensor] = {}
@@ -40,6 +40,10 @@ def _noise_counter(device, tag=None) -> Tensor:
 
 def _noise_seed() -> int:
   return torch.initial_seed() & (2**64 - 1)
+
+
+def _cfg_value(cfg, key, default=None):
+  return cfg.get(key, default) if hasattr(cfg, 'get') else getattr(cfg, key, default)
 
 
 def _f32(t: Optional[Tensor], device) -> Optional[Tensor]:
@@ -113,9 +117,13 @@ def target_estimation_update(discriminator, expert_transition: Dict[str, Tensor]
 def disc_descriptor(disc: GAILDiscriminator, batch_size: int, opt: AdamW, imitation_cfg=None, grad_penalty: float = 0.0, entropy_bonus: float = 0.0, tag=None,
                     seed_offset: int = 0) -> _lib.Disc:
   dev = disc.flat.device
+  loss_function, prior = 'BCE', 0.0
   if imitation_cfg is not None:
-    if imitation_cfg.loss_function != 'BCE':
-      raise NotImplementedError(f'adversarial_imitation_update: loss_function={imitation_cfg.loss_function} is not implemented on the HIP path (BCE only)')
+    loss_function, prior = imitation_cfg.loss_function, float(_cfg_value(imitation_cfg, 'pos_class_prior', 0.0) or 0.0)
+    if loss_function not in LOSS_FUNCTIONS:
+      raise ValueError(f'adversarial_imitation_update: unknown loss_function={loss_function}')
+    if loss_function == 'PUGAIL' and float(_cfg_value(imitation_cfg, 'nonnegative_margin', float('inf'))) != float('inf'):
+      raise NotImplementedError('adversarial_imitation_update: PUGAIL with a finite nonnegative_margin (the clamp needs a batch-wide reduction before the backward) has no kernel; the default inf does')
     grad_penalty, entropy_bonus = float(imitation_cfg.grad_penalty), float(imitation_cfg.entropy_bonus)
   floats = int(_lib.lib().il_disc_workspace_floats(disc.in_dim, disc.hidden, batch_size))
   ws = _workspace('disc', floats, dev, tag)
@@ -131,27 +139,43 @@ def disc_descriptor(disc: GAILDiscriminator, batch_size: int, opt: AdamW, imitat
   d.grad_penalty, d.entropy_bonus = grad_penalty, entropy_bonus
   d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
   d.noise_seed, d.noise_counter = (_noise_seed() + seed_offset) & (2**64 - 1), _noise_counter(dev, tag).data_ptr()
+  d.loss_function, d.pos_class_prior = LOSS_FUNCTIONS[loss_function], prior
   return d
 
 
 def adversarial_imitation_update(actor, discriminator: GAILDiscriminator, transitions: Dict[str, Tensor], expert_transitions: Dict[str, Tensor], discriminator_optimiser: AdamW,
-                                 imitation_cfg, *, eps_gp: Optional[Tensor] = None):
-  """Reference training.py:85-134 for loss_function=BCE (+ gradient penalty, spectral norm, entropy bonus)."""
+                                 imitation_cfg, *, eps_gp: Optional[Tensor] = None, eps_mix: Optional[Tensor] = None):
+  """Reference training.py:85-134: loss_function BCE / PUGAIL (nonnegative_margin = inf) / Mixup, + gradient penalty, spectral norm, entropy bonus,
+  subtract_log_policy.  `eps_gp` / `eps_mix`: the U(0,1) and Beta(alpha, alpha) draws (None: drawn here)."""
+  dev = discriminator.flat.device
   B = transitions['states'].size(0)
   d = disc_descriptor(discriminator, B, discriminator_optimiser, imitation_cfg)
   pb, eb = batch_desc(transitions), batch_desc(expert_transitions)
-  e = _f32(eps_gp, discriminator.flat.device)
-  _lib.check(_lib.lib().il_gail_disc_step(C.byref(d), C.byref(pb), C.byref(eb), _lib.ptr(e), 0, _lib.stream_ptr()))
+  e = _f32(eps_gp, dev)
+  x, keep = _lib.GailExtra(), []
+  if imitation_cfg.loss_function == 'Mixup':
+    if discriminator.subtract_log_policy:
+      raise NotImplementedError('adversarial_imitation_update: Mixup with subtract_log_policy (log pi of the mixed inputs) has no kernel')
+    alpha = float(_cfg_value(imitation_cfg, 'mixup_alpha', 1.0))
+    if eps_mix is None and alpha != 1.0:   # Beta(1, 1) = U(0, 1) comes from the on-chip Philox stream; other alphas are drawn on the host like the reference
+      eps_mix = torch.distributions.Beta(torch.full((B,), alpha), torch.full((B,), alpha)).sample()
+    if eps_mix is not None:
+      keep.append(_f32(eps_mix, dev)); x.eps_mix = keep[-1].data_ptr()
+  if discriminator.subtract_log_policy:   # models.py:144: log pi(a|s) of both batches, no graph
+    keep += [actor.log_prob(transitions['states'], transitions['actions']), actor.log_prob(expert_transitions['states'], expert_transitions['actions'])]
+    x.logit_offset_policy, x.logit_offset_expert = keep[-2].data_ptr(), keep[-1].data_ptr()
+  _lib.check(_lib.lib().il_gail_disc_step(C.byref(d), C.byref(pb), C.byref(eb), _lib.ptr(e), C.byref(x), 0, _lib.stream_ptr()))
 
 
-def gail_predict_reward(disc: GAILDiscriminator, state: Tensor, action: Tensor, want_logits: bool = False):
+def gail_predict_reward(disc: GAILDiscriminator, state: Tensor, action: Tensor, want_logits: bool = False, log_policy: Optional[Tensor] = None):
   dev = disc.flat.device
   n = state.size(0)
   d = disc_descriptor(disc, n, None)
   dummy = torch.zeros(n, device=dev)
   b = batch_desc(dict(states=state, actions=action, rewards=dummy, next_states=state, terminals=dummy, weights=dummy, absorbing=dummy))
   out, logits = torch.empty(n, device=dev), (torch.empty(n, device=dev) if want_logits else None)
-  _lib.check(_lib.lib().il_gail_reward(C.byref(d), C.byref(b), _lib.ptr(out), _lib.ptr(logits), _lib.stream_ptr()))
+  off = _f32(log_policy, dev)
+  _lib.check(_lib.lib().il_gail_reward(C.byref(d), C.byref(b), _lib.ptr(out), _lib.ptr(logits), _lib.ptr(off), _lib.stream_ptr()))
   return (out, logits) if want_logits else out
 
 
@@ -233,6 +257,8 @@ class UpdatePlan:
     if algorithm == 'GAIL':
       self.erows = torch.empty(batch_size, expert_memory.row, device=dev); self.eidx = torch.empty(batch_size, dtype=torch.int32, device=dev)
       self.expert_transitions = batch_views(self.erows, expert_memory.state_size, expert_memory.action_size, expert_memory.absorbing)
+      if imitation_cfg is not None and (imitation_cfg.loss_function == 'Mixup' or discriminator.subtract_log_policy):
+        raise NotImplementedError('UpdatePlan: GAIL with Mixup / subtract_log_policy needs per-update inputs; use adversarial_imitation_update + sac_update')
       self.disc = disc_descriptor(discriminator, batch_size, discriminator_optimiser, imitation_cfg, tag=tag, seed_offset=off)
       self.eb = batch_desc(self.expert_transitions)
       self.rewards = torch.empty(batch_size, device=dev)
@@ -331,8 +357,8 @@ class UpdatePlan:
 
   def _enqueue_discriminator_branch(self):
     L, st = _lib.lib(), _lib.stream_ptr()
-    _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, 0, st))
-    _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, st))
+    _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))
+    _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
 
   def _enqueue_sac_branch(self):
     self.sample_all()
@@ -369,8 +395,8 @@ class UpdatePlan:
       self.side.wait_stream(main)                                   # the discriminator needs the sampled batches
       with torch.cuda.stream(self.side):
         st = _lib.stream_ptr()
-        _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, 0, st))
-        _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, st))
+        _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))
+        _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
       if early_prepare:
         main.wait_event(prepared)                                   # main needs the re-ordered weights, not the discriminator
       st = _lib.stream_ptr()
@@ -382,8 +408,8 @@ class UpdatePlan:
     self.sample_all()
     st = _lib.stream_ptr()
     if self.algorithm == 'GAIL':
-      _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, 0, st))
-      _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, st))
+      _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))
+      _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
     _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), self.prepared_flag(), st))
     self._prepared = True
 

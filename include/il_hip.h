@@ -205,6 +205,9 @@ int il_bc_step(float* actor, float* actor_grad, const il_adam* opt, int32_t stat
 int il_actor_act(const float* actor, int32_t state_dim, int32_t action_dim, int32_t hidden, const float* states, int32_t ld_states,
                  int32_t n, const float* eps, uint64_t noise_seed, uint32_t noise_offset, int32_t greedy, float* out_action,
                  float* out_logp, il_stream_t stream);
+/* models.py:97-99 SoftActor.log_prob(state, action) for n rows (action clamped like the reference): the log pi(a|s) of subtract_log_policy. */
+int il_actor_log_prob(const float* actor, int32_t state_dim, int32_t action_dim, int32_t hidden, const float* states, int32_t ld_states,
+                      const float* actions, int32_t ld_actions, int32_t n, float* out_logp, il_stream_t stream);
 
 /* One environment step of the acting worker (train.py:151-168) as ONE launch:
  *   [memory.append of the pending transition, memory.py:40-44] + [wrap_for_absorbing_states, memory.py:65-68] +
@@ -254,18 +257,28 @@ typedef struct il_disc {
   uint64_t noise_seed;
   uint32_t* noise_counter;
   int64_t* sync;             /* il_sync counters or NULL (see below) */
+  int32_t loss_function;     /* IL_LOSS_BCE / IL_LOSS_PUGAIL (nonnegative_margin = inf) / IL_LOSS_MIXUP (training.py:97-113) */
+  float pos_class_prior;     /* PUGAIL (training.py:101-102) */
 } il_disc;
+enum { IL_LOSS_BCE = 0, IL_LOSS_PUGAIL = 1, IL_LOSS_MIXUP = 2 };
+/* optional inputs of the loss variants; every pointer may be NULL */
+typedef struct il_gail_extra {
+  const float* eps_mix;              /* [B] the Beta(alpha, alpha) draws of Mixup (training.py:106); NULL => U(0,1) from Philox, i.e. alpha = 1 */
+  const float* logit_offset_policy;  /* [B] log pi(a|s) of the policy batch when subtract_log_policy (models.py:144,175) */
+  const float* logit_offset_expert;  /* [B] same for the expert batch */
+} il_gail_extra;
 
 int64_t il_disc_workspace_floats(int32_t in_dim, int32_t hidden, int32_t batch);
 /* eps_gp [B] = the U(0,1) draw of training.py:118 (NULL => Philox). */
-int il_gail_disc_step(const il_disc* d, const il_batch* policy, const il_batch* expert, const float* eps_gp, uint32_t flags,
-                      il_stream_t stream);
+int il_gail_disc_step(const il_disc* d, const il_batch* policy, const il_batch* expert, const float* eps_gp, const il_gail_extra* extra,
+                      uint32_t flags, il_stream_t stream);
 int il_gail_apply_grads(const il_disc* d, il_stream_t stream);
 /* Population axis: discriminator step + AIRL/GAIL/FAIRL reward relabel for n_learners discriminators; rewards_out_dev[l] -> float[batch]. */
 int il_gail_step_population(const il_disc* descs_dev, const il_batch* policy_dev, const il_batch* expert_dev, float* const* rewards_out_dev,
                             int32_t n_learners, const il_disc* shape_host, il_stream_t stream);
 /* models.py:177-180 predict_reward (eval mode: no power iteration). out_logits may be NULL. */
-int il_gail_reward(const il_disc* d, const il_batch* batch, float* out_rewards, float* out_logits, il_stream_t stream);
+int il_gail_reward(const il_disc* d, const il_batch* batch, float* out_rewards, float* out_logits, const float* logit_offset,
+                   il_stream_t stream); /* logit_offset [n] = log pi(a|s) when subtract_log_policy, else NULL */
 
 /* ------------------------------------------------------------------------------------------
  * GMMIL (reference models.py:25-44, 183-201): d(x,y) = mean_k (x_k-y_k)^2, two RBF bandwidths.

@@ -97,18 +97,36 @@ def disc_logits(ds: DiscState, x, train=False):
   return _forward(W1h, ds.b1, W2h, ds.b2, x.astype(f32))[2]
 
 
-def gail_update(ds: DiscState, xp, wp, xe, we, eps_gp, *, lr, weight_decay, grad_penalty=1.0, entropy_bonus=0.0, return_grads=False):
-  """One `adversarial_imitation_update` (loss_function=BCE). xp/xe = cat(state, action) of policy / expert batch."""
+def gail_update(ds: DiscState, xp, wp, xe, we, eps_gp, *, lr, weight_decay, grad_penalty=1.0, entropy_bonus=0.0, return_grads=False, loss_function='BCE',
+                pos_class_prior=0.7, eps_mix=None, logp_policy=None, logp_expert=None):
+  """One `adversarial_imitation_update` (training.py:85-134). xp/xe = cat(state, action) of policy / expert batch.
+  loss_function: 'BCE' (:97-99), 'PUGAIL' with nonnegative_margin = inf (:100-102: the clamp never binds) or 'Mixup' (:104-113, eps_mix = the
+  Beta(alpha, alpha) draws). logp_policy / logp_expert: log pi(a|s) of the two batches when subtract_log_policy (models.py:173-175: D = f - log pi;
+  computed under no_grad, so it only shifts the logits)."""
   xp, xe, wp, we = xp.astype(f32), xe.astype(f32), wp.astype(f32), we.astype(f32)
   B = xp.shape[0]
   g = dict(W1=np.zeros_like(ds.W1), b1=np.zeros_like(ds.b1), W2=np.zeros_like(ds.W2), b2=np.zeros_like(ds.b2))
+  zero = np.zeros(B, f32)
+  if loss_function == 'BCE':      # d loss / d logit = w (c_sig * sigmoid - c_lab) / B
+    calls = [(xp, wp, f32(1), zero, logp_policy), (xe, we, f32(1), zero + f32(1), logp_expert)]
+  elif loss_function == 'PUGAIL':  # prior*BCE(D_e,1) + [prior*BCE(D_e,0) - BCE(D_p,0)]
+    pr = f32(pos_class_prior)
+    calls = [(xp, wp, f32(-1), zero, logp_policy), (xe, we, f32(2) * pr, zero + pr, logp_expert)]
+  elif loss_function == 'Mixup':   # eps*BCE(D_mix,1) + (1-eps)*BCE(D_mix,0) on convex combinations
+    em = eps_mix.astype(f32)
+    calls = [(em[:, None] * xe + (f32(1) - em[:, None]) * xp, em * we + (f32(1) - em) * wp, f32(1), em, None)]
+    assert logp_policy is None and logp_expert is None
+  else:
+    raise ValueError(loss_function)
 
-  # D_policy then D_expert (training.py:95): each call runs its own power iteration
-  for x, w, label in ((xp, wp, f32(0)), (xe, we, f32(1))):
+  # D_policy then D_expert (training.py:95) / D_mix: each call runs its own power iteration
+  for x, w, c_sig, c_lab, off in calls:
     W1h, W2h, ctx = _sn_weights(ds, True)
     h, a, z = _forward(W1h, ds.b1, W2h, ds.b2, x)
+    if off is not None:
+      z = z - off.astype(f32)
     p = _sigmoid(z)
-    dz = w * (p - label) / f32(B)                      # BCE-with-logits, mean reduction, per-sample weight
+    dz = w * (c_sig * p - c_lab) / f32(B)              # BCE-with-logits, mean reduction, per-sample weight
     if entropy_bonus > 0:                             # training.py:130-132: -beta * mean(w * H(Bernoulli(logits=z)))
       dz = dz + f32(entropy_bonus) * w * z * p * (f32(1) - p) / f32(B)   # dH/dz = -z p (1-p)
     G2h = (dz @ a)[None, :]
@@ -140,9 +158,10 @@ def gail_update(ds: DiscState, xp, wp, xe, we, eps_gp, *, lr, weight_decay, grad
   return flat_g if return_grads else None
 
 
-def predict_reward(ds: DiscState, x, reward_function='AIRL'):
-  """models.py:177-180, eval mode (no power iteration)."""
-  D = _sigmoid(disc_logits(ds, x, train=False))
+def predict_reward(ds: DiscState, x, reward_function='AIRL', log_policy=None):
+  """models.py:177-180, eval mode (no power iteration); log_policy: the subtract_log_policy offset (models.py:175)."""
+  z = disc_logits(ds, x, train=False)
+  D = _sigmoid(z if log_policy is None else z - log_policy.astype(f32))
   if reward_function == 'GAIL':
     h = -np.log1p(-D + f32(1e-6))
   else:

@@ -134,3 +134,10 @@ def dril_case(seed, env, hidden, batch, steps, p_in=0.1, p=0.1):
   return dict(S=S, A=A, H=hidden, B=batch, p_in=p_in, p=p, params=params, batches=batches, m0=[keep((batch, S), p_in) for _ in range(steps)],
               m1=[keep((batch, hidden), p) for _ in range(steps)], expert=expert, query=query, e_m0=keep((80 * 5, S), p_in), e_m1=keep((80 * 5, hidden), p),
               q_m0=keep((37 * 5, S), p_in), q_m1=keep((37 * 5, hidden), p))
+
+
+def gail_extras(seed, c):
+  """Extra inputs of the GAIL loss variants: Beta(alpha, alpha)-like mixup draws per step and an actor (for subtract_log_policy)."""
+  rs = np.random.RandomState(seed + 1000)
+  steps, B = len(c['policy']), c['B']
+  return dict(eps_mix=[rs.beta(0.7, 0.7, B).astype(f32) for _ in range(steps)], actor=mlp_params(rs, c['S'], 64, 2, 2 * c['A'], out_scale=0.3))

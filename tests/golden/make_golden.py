@@ -218,6 +218,46 @@ def gen_gail(name, c, *, lr, weight_decay, grad_penalty, entropy_bonus):
   np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
 
 
+def gen_gail_variants():
+  """adversarial_imitation_update with loss_function=PUGAIL / Mixup and with subtract_log_policy (training.py:100-113, models.py:139-144,173-175):
+  gradients, parameters after AdamW, rewards. Mixup's Beta(alpha, alpha) draws are fed (Beta.sample patched), like the other noise."""
+  out = {}
+  for name, loss, sub in (('pugail', 'PUGAIL', False), ('mixup', 'Mixup', False), ('sublogp', 'BCE', True)):
+    c = gi.gail_case(35, env='hopper', hidden=32, batch=96, steps=2)
+    x = gi.gail_extras(35, c)
+    d, icfg = build_disc(c)
+    icfg.discriminator.update(subtract_log_policy=sub); icfg['discriminator'] = icfg.discriminator
+    d.subtract_log_policy = sub
+    icfg.update(loss_function=loss, grad_penalty=0.5, mixup_alpha=0.7, entropy_bonus=0.02, pos_class_prior=0.7, nonnegative_margin=float('inf'))
+    actor = ref_models.SoftActor(c['S'], c['A'], DictConfig(hidden_size=64, depth=2, activation='relu'))
+    torch.nn.utils.vector_to_parameters(T(x['actor']), actor.parameters())
+    opt = torch.optim.AdamW(d.parameters(), lr=1e-3, weight_decay=0.1)
+    for i in range(len(c['policy'])):
+      d.train()
+      feed = [T(x['eps_mix'][i])]
+      orig = torch.distributions.Beta.sample
+      torch.distributions.Beta.sample = lambda self, *a, **k: feed.pop(0)
+      try:
+        with NoiseFeed() as nf:
+          nf.rand.append(T(c['eps'][i]))
+          ref_training.adversarial_imitation_update(actor, d, tbatch(c['policy'][i]), tbatch(c['expert'][i]), opt, icfg)
+      finally:
+        torch.distributions.Beta.sample = orig
+      d.eval()
+      k = i + 1
+      out[f'{name}.g_{k}'] = np.concatenate([N_(p.grad).ravel() for p in d.parameters()])
+      out[f'{name}.p_{k}'] = flat(d)
+      b = c['policy'][i]
+      with torch.inference_mode():
+        inp = ref_models.make_gail_input(T(b['states']), T(b['actions']), T(b['next_states']), T(b['terminals']), actor, False, sub)
+        out[f'{name}.reward_{k}'] = N_(d.predict_reward(**inp))
+        if sub:
+          out[f'{name}.logp_policy_{k}'] = N_(actor.log_prob(T(b['states']), T(b['actions'])))
+          e = c['expert'][i]
+          out[f'{name}.logp_expert_{k}'] = N_(actor.log_prob(T(e['states']), T(e['actions'])))
+  np.savez_compressed(os.path.join(HERE, 'gail_variants.npz'), **out)
+
+
 # ---------------------------------------------------------------- GMMIL / PWIL
 def gen_gmmil():
   out = {}
@@ -351,6 +391,7 @@ if __name__ == '__main__':
     gen_gail('gail_default', gi.gail_case(31), lr=3e-5, weight_decay=10, grad_penalty=1.0, entropy_bonus=0.0)
     gen_gail('gail_h128_ent', gi.gail_case(32, hidden=128), lr=7.3e-5, weight_decay=6.35, grad_penalty=0.32, entropy_bonus=0.0155)
     gen_gail('gail_nosn_nogp', gi.gail_case(33, env='hopper', hidden=32, batch=128, spectral_norm=False), lr=3e-4, weight_decay=0.0, grad_penalty=0.0, entropy_bonus=0.0)
+  if want('gail_variants'): gen_gail_variants()
   if want('gmmil'): gen_gmmil()
   if want('pwil'): gen_pwil()
   if want('adril'): gen_adril()

@@ -435,8 +435,8 @@ def test_unsupported_shapes_and_options_fail_loudly():
     il.sac_update(actor, critic, log_alpha, target, tbatch(c['batches'][0]), ao, co, to, 0.99, -6.0, 0.995)
   g = gi.gail_case(31)
   d, _, icfg = make_disc(g)
-  icfg.update(loss_function='Mixup', grad_penalty=1.0, entropy_bonus=0.0)
-  with pytest.raises(NotImplementedError, match='Mixup'):
+  icfg.update(loss_function='Hinge', grad_penalty=1.0, entropy_bonus=0.0)
+  with pytest.raises(ValueError, match='Hinge'):
     il.adversarial_imitation_update(None, d, tbatch(g['policy'][0]), tbatch(g['expert'][0]), il.AdamW(d, lr=3e-5, weight_decay=10), icfg)
   with pytest.raises(TypeError):
     il.sac_update(actor, critic, log_alpha, target, {k: v.cpu() for k, v in tbatch(gi.sac_case(3, 'halfcheetah', 256, 32, 1)['batches'][0]).items()}, ao, co, to, 0.99, -6.0, 0.995)
@@ -745,3 +745,50 @@ def test_dril_onchip_masks_are_bernoulli_and_change_per_call():
   nodrop = il.SoftActor(c['S'], c['A'], Cfg(hidden_size=64, depth=1, activation='tanh', input_dropout=0, dropout=0), device=DEV)
   nodrop.flat.copy_(T(c['params']))
   assert float(nodrop._get_action_uncertainty(e['states'], e['actions']).abs().max()) < 1e-12   # no dropout: the 5 members agree (up to the rounding of their mean)
+
+
+# ---------------------------------------------------------------------------------------------
+# GAIL loss variants (training.py:100-113) and subtract_log_policy (models.py:144,175) against the reference fixture and the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,loss,sub', [('pugail', 'PUGAIL', False), ('mixup', 'Mixup', False), ('sublogp', 'BCE', True)])
+def test_gail_loss_variants_match_reference(golden_dir, name, loss, sub):
+  g = load(golden_dir, 'gail_variants')
+  c = gi.gail_case(35, env='hopper', hidden=32, batch=96, steps=2)
+  x = gi.gail_extras(35, c)
+  icfg = Cfg(state_only=False, spectral_norm=True, loss_function=loss, grad_penalty=0.5, mixup_alpha=0.7, entropy_bonus=0.02, pos_class_prior=0.7, nonnegative_margin=float('inf'),
+             discriminator=Cfg(hidden_size=c['H'], depth=1, activation='relu', reward_shaping=False, subtract_log_policy=sub, reward_function='AIRL'))
+  d = il.GAILDiscriminator(c['S'], c['A'], icfg, 0.97, device=DEV)
+  ods = ogail.DiscState(c['D'], c['H'], True)
+  for k in ('W1', 'b1', 'W2', 'b2', 'u1', 'v1', 'u2', 'v2'):
+    getattr(ods, k)[...] = c[k]
+  d.flat.copy_(T(ods.pack()))
+  for k, v in d.views().items():
+    v.copy_(T(c[k]))
+  actor = il.SoftActor(c['S'], c['A'], Cfg(hidden_size=64, depth=2, activation='relu'), device=DEV)
+  actor.flat.copy_(T(x['actor']))
+  opt = il.AdamW(d, lr=1e-3, weight_decay=0.1)
+  for i in range(2):
+    p, e = tbatch(c['policy'][i]), tbatch(c['expert'][i])
+    if sub:
+      close(N(actor.log_prob(p['states'], p['actions'])), g[f'{name}.logp_policy_{i + 1}'], 'log pi (policy batch)')
+      close(N(actor.log_prob(e['states'], e['actions'])), g[f'{name}.logp_expert_{i + 1}'], 'log pi (expert batch)')
+    il.adversarial_imitation_update(actor, d, p, e, opt, icfg, eps_gp=T(c['eps'][i]), eps_mix=T(x['eps_mix'][i]) if loss == 'Mixup' else None)
+    close(N(opt.grad), g[f'{name}.g_{i + 1}'], f'{name} gradient {i + 1}', rtol=1e-5, atol_scale=1e-5)
+    close_params(N(d.flat), g[f'{name}.p_{i + 1}'], f'{name} parameters {i + 1}', 1e-3, steps=i + 1)
+    d.flat.copy_(T(g[f'{name}.p_{i + 1}']))   # continue from the reference's parameters: later steps then test one step each
+    r = d.predict_reward(**il.make_gail_input(p['states'], p['actions'], p['next_states'], p['terminals'], actor, False, sub))
+    close(N(r), g[f'{name}.reward_{i + 1}'], f'{name} reward {i + 1}', rtol=2e-5, atol_scale=1e-5)
+
+
+@pytest.mark.gpu
+def test_gail_variants_loud_failures():
+  c = gi.gail_case(35, env='hopper', hidden=32, batch=96, steps=1)
+  mk = lambda **kw: Cfg(state_only=False, spectral_norm=True, loss_function='PUGAIL', grad_penalty=0.5, mixup_alpha=1, entropy_bonus=0.0, pos_class_prior=0.7, nonnegative_margin=kw.get('margin', float('inf')),
+                        discriminator=Cfg(hidden_size=32, depth=1, activation='relu', reward_shaping=kw.get('shaping', False), subtract_log_policy=False, reward_function='AIRL'))
+  with pytest.raises(NotImplementedError):
+    il.GAILDiscriminator(c['S'], c['A'], mk(shaping=True), 0.97, device=DEV)
+  d = il.GAILDiscriminator(c['S'], c['A'], mk(), 0.97, device=DEV)
+  opt = il.AdamW(d, lr=1e-3, weight_decay=0.1)
+  with pytest.raises(NotImplementedError):
+    il.adversarial_imitation_update(None, d, tbatch(c['policy'][0]), tbatch(c['expert'][0]), opt, mk(margin=0.1))

@@ -225,3 +225,24 @@ def test_dril_oracle_matches_reference_fixture(golden_dir, name, case, kw):
   assert np.abs(ue - ref_ue).max() <= 1e-4 * np.abs(ref_ue).max()
   ds.q = float(g[f'{name}.q'][0])
   assert np.array_equal(dril.predict_reward(ds, q['states'], q['actions'], c['q_m0'], c['q_m1']), g[f'{name}.reward'])
+
+
+@pytest.mark.parametrize('name,loss,sub', [('pugail', 'PUGAIL', False), ('mixup', 'Mixup', False), ('sublogp', 'BCE', True)])
+def test_gail_variant_oracle_matches_reference_fixture(golden_dir, name, loss, sub):
+  """oracle/gail.py with loss_function PUGAIL / Mixup and with the subtract_log_policy offsets against adversarial_imitation_update of the reference."""
+  g = np.load(os.path.join(golden_dir, 'gail_variants.npz'))
+  c = gi.gail_case(35, env='hopper', hidden=32, batch=96, steps=2)
+  x = gi.gail_extras(35, c)
+  ds = gail.DiscState(c['D'], c['H'], True)
+  for k in ('W1', 'b1', 'W2', 'b2', 'u1', 'v1', 'u2', 'v2'):
+    getattr(ds, k)[...] = c[k]
+  for i in range(2):
+    p, e = c['policy'][i], c['expert'][i]
+    xp, xe = np.concatenate([p['states'], p['actions']], 1), np.concatenate([e['states'], e['actions']], 1)
+    lp = g[f'{name}.logp_policy_{i + 1}'] if sub else None
+    le = g[f'{name}.logp_expert_{i + 1}'] if sub else None
+    gr = gail.gail_update(ds, xp, p['weights'], xe, e['weights'], c['eps'][i], lr=1e-3, weight_decay=0.1, grad_penalty=0.5, entropy_bonus=0.02, return_grads=True,
+                          loss_function=loss, pos_class_prior=0.7, eps_mix=x['eps_mix'][i], logp_policy=lp, logp_expert=le)
+    ref = g[f'{name}.g_{i + 1}']
+    assert np.abs(gr - ref).max() <= 1e-5 * np.abs(ref).max()
+    np.testing.assert_allclose(gail.predict_reward(ds, xp, 'AIRL', log_policy=lp), g[f'{name}.reward_{i + 1}'], rtol=3e-5, atol=1e-6)

@@ -21,6 +21,9 @@ COMMON = ['steps=260', 'training.start=120', 'evaluation.interval=130', 'evaluat
     ['algorithm=PWIL', 'env=walker2d'],
     ['algorithm=AdRIL', 'env=hopper', 'imitation.update_freq=100'],
     ['algorithm=AdRIL', 'env=walker2d', 'imitation.update_freq=0', 'imitation.balanced=false'],   # SQIL
+    ['algorithm=GAIL', 'env=hopper', 'imitation.loss_function=PUGAIL'],
+    ['algorithm=GAIL', 'env=walker2d', 'imitation.loss_function=Mixup', 'imitation.discriminator.reward_function=FAIRL'],
+    ['algorithm=GAIL', 'env=halfcheetah', 'imitation.discriminator.subtract_log_policy=true'],
     ['algorithm=RED', 'env=hopper', 'imitation.pretraining.iterations=50'],
     ['algorithm=DRIL', 'env=hopper', 'imitation.pretraining.iterations=50'],
     ['algorithm=SAC', 'env=hopper', '+acting.schedule=overlap'],

@@ -118,6 +118,8 @@ def train(cfg, file_prefix: str = '') -> float:
   # ---- the update block as a captured graph when nothing host-side sits inside it
   plan = None
   fusable = cfg.algorithm in ('SAC', 'GAIL') and cfg.imitation.mix_expert_data == 'none' and not cfg.imitation.bc_aux_loss and B % 16 == 0
+  if cfg.algorithm == 'GAIL' and (cfg.imitation.loss_function == 'Mixup' or cfg.imitation.discriminator.subtract_log_policy):
+    fusable = False   # per-update host inputs (Beta draws) / an extra actor pass: the per-function entry points
   if fusable:
     plan = il.UpdatePlan(cfg.algorithm, actor, critic, log_alpha, target_critic, memory, actor_optimiser, critic_optimiser, temperature_optimiser, B, cfg.reinforcement.discount,
                          entropy_target, cfg.reinforcement.polyak_factor, expert_memory=expert_memory, discriminator=discriminator, discriminator_optimiser=discriminator_optimiser,
@@ -181,7 +183,8 @@ def train(cfg, file_prefix: str = '') -> float:
         if cfg.algorithm == 'AdRIL':
           discriminator.resample_and_relabel(transitions, expert_transitions, step, memory.num_trajectories, expert_memory.num_trajectories)
         if cfg.algorithm == 'GAIL':
-          transitions['rewards'] = discriminator.predict_reward(transitions['states'], transitions['actions'])
+          transitions['rewards'] = discriminator.predict_reward(**il.make_gail_input(transitions['states'], transitions['actions'], transitions['next_states'], transitions['terminals'], actor,
+                                                                                     cfg.imitation.discriminator.reward_shaping, cfg.imitation.discriminator.subtract_log_policy))
         elif cfg.algorithm in ('DRIL', 'RED'):
           transitions['rewards'].copy_(discriminator.predict_reward(transitions['states'], transitions['actions']))
         elif cfg.algorithm == 'GMMIL':
