@@ -35,7 +35,7 @@ class _Space:
 class SyntheticD4RLEnv:
   """Seeded linear-Gaussian locomotion stand-in with the interface of the reference's `D4RLEnv`."""
 
-  def __init__(self, env_name: str, absorbing: bool, load_data: bool = False, dataset_trajectories: int = 30, max_episode_steps: int = 1000):
+  def __init__(self, env_name: str, absorbing: bool, load_data: bool = False, dataset_trajectories: int = 30, max_episode_steps: int = 1000, dataset_path: str = None):
     assert env_name in ENVS
     self.name, self.absorbing = env_name, absorbing
     self.obs_dim, self.act_dim, self.can_terminate, (self.ref_min_score, self.ref_max_score) = _SPECS[env_name]
@@ -49,7 +49,7 @@ class SyntheticD4RLEnv:
     self.env = self  # `env.env.ref_max_score` (train.py:58)
     self._rs, self._t, self._x = np.random.RandomState(0), 0, None
     self._dataset_trajectories = dataset_trajectories
-    self.dataset = self._make_dataset() if load_data else None
+    self.dataset = (load_dataset_file(dataset_path) if dataset_path else self._make_dataset()) if load_data else None   # `+synthetic_env.dataset_path=<file>`: real D4RL arrays
 
   # --- gym-like API
   def seed(self, seed: int) -> List[int]:
@@ -97,37 +97,69 @@ class SyntheticD4RLEnv:
     return dict(observations=f(obs), actions=f(act), next_observations=f(nxt), terminals=f(term), timeouts=f(tout))
 
   def get_dataset(self, trajectories: int = 0, subsample: int = 1, device=None) -> ReplayMemory:
-    """Reference environments.py:63-125 on the synthetic rollouts (vectorised per trajectory)."""
-    d = self.dataset
-    states, actions, next_states, terminals, timeouts = d['observations'], d['actions'], d['next_observations'], d['terminals'], d['timeouts']
-    S, A = states.size(1), actions.size(1)
-    ends = torch.sort(torch.cat([terminals.nonzero().flatten(), timeouts.nonzero().flatten()]))[0].tolist()
-    starts = [0] + [e + 1 for e in ends[:-1]]
-    if trajectories > 0:
-      starts, ends = starts[:trajectories], ends[:trajectories]
-    out = {k: [] for k in ('states', 'actions', 'next_states', 'terminals', 'timeouts', 'weights')}
-    for s0, e0 in zip(starts, ends):
-      sl = slice(s0, e0 + 1)
-      st, ac, nx, te, to = states[sl], actions[sl], next_states[sl], terminals[sl].clone(), timeouts[sl]
-      w = torch.ones_like(te)
-      if self.absorbing:
-        st, nx = torch.cat([st, torch.zeros(st.size(0), 1)], 1), torch.cat([nx, torch.zeros(nx.size(0), 1)], 1)
-        if not to[-1]:  # true termination: rewrite the last next-state to the absorbing state and append absorbing -> absorbing
-          absorbing_state = torch.cat([torch.zeros(1, S), torch.ones(1, 1)], 1)
-          nx[-1], te[-1], w[-1] = absorbing_state[0], 0, 1 / subsample
-          st, ac, nx = torch.cat([st, absorbing_state]), torch.cat([ac, torch.zeros(1, A)]), torch.cat([nx, absorbing_state])
-          te, to, w = torch.cat([te, torch.zeros(1)]), torch.cat([to, torch.zeros(1)]), torch.cat([w, torch.full((1,), 1 / subsample)])
-      if subsample > 1:
-        T = st.size(0)
-        idxs = set(range(index_stream().randint(subsample), T, subsample))  # np.random.choice(subsample) in the reference: same stream
-        if self.absorbing: idxs |= {T - 2, T - 1}
-        idxs = sorted(idxs)
-        st, ac, nx, te, to, w = st[idxs], ac[idxs], nx[idxs], te[idxs], to[idxs], w[idxs]
-      for k, v in zip(out, (st, ac, nx, te, to, w)):
-        out[k].append(v)
-    tr = {k: torch.cat(v) for k, v in out.items()}
-    tr['num_trajectories'], tr['rewards'] = len(starts), torch.zeros_like(tr['terminals'])
-    return ReplayMemory(tr['states'].size(0), S + (1 if self.absorbing else 0), A, self.absorbing, transitions=tr, device=device)
+    """Reference environments.py:63-125 on this environment's raw dataset."""
+    return dataset_to_memory(self.dataset, self.absorbing, trajectories, subsample, device)
+
+
+def load_dataset_file(path: str) -> dict:
+  """Raw D4RL-format dataset (observations, actions, next_observations, terminals, timeouts) from disk: `.npz`, or the `.hdf5` files D4RL ships
+  when h5py is importable (it is not in this image). `next_observations` is rebuilt from the observations when the file lacks it, as d4rl.qlearning_dataset does."""
+  keys = ('observations', 'actions', 'next_observations', 'terminals', 'timeouts')
+  if path.endswith('.npz'):
+    with np.load(path) as f:
+      raw = {k: np.asarray(f[k]) for k in keys if k in f}
+  else:
+    try:
+      import h5py
+    except ImportError as e:
+      raise ImportError(f'{path}: reading HDF5 needs h5py (not installed here); convert the file to .npz with the five D4RL arrays') from e
+    with h5py.File(path, 'r') as f:
+      raw = {k: np.asarray(f[k]) for k in keys if k in f}
+  if 'next_observations' not in raw:
+    nxt = np.roll(raw['observations'], -1, axis=0)
+    nxt[-1] = raw['observations'][-1]
+    raw['next_observations'] = nxt
+  missing = [k for k in keys if k not in raw]
+  if missing:
+    raise KeyError(f'{path}: missing dataset arrays {missing}')
+  return {k: torch.as_tensor(np.ascontiguousarray(v), dtype=torch.float32) for k, v in raw.items()}
+
+
+def dataset_to_memory(dataset: dict, absorbing: bool, trajectories: int = 0, subsample: int = 1, device=None) -> ReplayMemory:
+  """Expert-data ingest (reference environments.py:63-125): split the flat arrays into trajectories at the terminal / timeout flags (a dangling
+  tail is dropped), keep the first `trajectories`, append the absorbing indicator and - for true terminations - rewrite the last next-state and add
+  the absorbing -> absorbing transition with importance weight 1/subsample, sub-sample every `subsample`-th step from a random phase (same index
+  stream as the reference's np.random.choice) while keeping the two absorbing rows, and upload the result as one packed ReplayMemory."""
+  f = lambda v: torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v, dtype=torch.float32)
+  states, actions, next_states, terminals, timeouts = (f(dataset[k]) for k in ('observations', 'actions', 'next_observations', 'terminals', 'timeouts'))
+  S, A = states.size(1), actions.size(1)
+  ends = torch.sort(torch.cat([terminals.nonzero().flatten(), timeouts.nonzero().flatten()]))[0].tolist()
+  starts = [0] + [e + 1 for e in ends[:-1]]
+  if trajectories > 0:
+    starts, ends = starts[:trajectories], ends[:trajectories]
+  out = {k: [] for k in ('states', 'actions', 'next_states', 'terminals', 'timeouts', 'weights')}
+  for s0, e0 in zip(starts, ends):
+    sl = slice(s0, e0 + 1)
+    st, ac, nx, te, to = states[sl], actions[sl], next_states[sl], terminals[sl].clone(), timeouts[sl]
+    w = torch.ones_like(te)
+    if absorbing:
+      st, nx = torch.cat([st, torch.zeros(st.size(0), 1)], 1), torch.cat([nx, torch.zeros(nx.size(0), 1)], 1)
+      if not to[-1]:  # true termination: rewrite the last next-state to the absorbing state and append absorbing -> absorbing
+        absorbing_state = torch.cat([torch.zeros(1, S), torch.ones(1, 1)], 1)
+        nx[-1], te[-1], w[-1] = absorbing_state[0], 0, 1 / subsample
+        st, ac, nx = torch.cat([st, absorbing_state]), torch.cat([ac, torch.zeros(1, A)]), torch.cat([nx, absorbing_state])
+        te, to, w = torch.cat([te, torch.zeros(1)]), torch.cat([to, torch.zeros(1)]), torch.cat([w, torch.full((1,), 1 / subsample)])
+    if subsample > 1:
+      T = st.size(0)
+      idxs = set(range(index_stream().randint(subsample), T, subsample))  # np.random.choice(subsample) in the reference: same stream
+      if absorbing: idxs |= {T - 2, T - 1}
+      idxs = sorted(idxs)
+      st, ac, nx, te, to, w = st[idxs], ac[idxs], nx[idxs], te[idxs], to[idxs], w[idxs]
+    for k, v in zip(out, (st, ac, nx, te, to, w)):
+      out[k].append(v)
+  tr = {k: torch.cat(v) for k, v in out.items()}
+  tr['num_trajectories'], tr['rewards'] = len(starts), torch.zeros_like(tr['terminals'])
+  return ReplayMemory(tr['states'].size(0), S + (1 if absorbing else 0), A, absorbing, transitions=tr, device=device)
 
 
 def make_env(env_name: str, absorbing: bool, load_data: bool = False, **kw):

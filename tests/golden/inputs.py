@@ -141,3 +141,18 @@ def gail_extras(seed, c):
   rs = np.random.RandomState(seed + 1000)
   steps, B = len(c['policy']), c['B']
   return dict(eps_mix=[rs.beta(0.7, 0.7, B).astype(f32) for _ in range(steps)], actor=mlp_params(rs, c['S'], 64, 2, 2 * c['A'], out_scale=0.3))
+
+
+def raw_d4rl_dataset(seed, obs_dim=5, act_dim=2):
+  """A raw D4RL-format dataset (flat arrays + terminals / timeouts flags): 5 trajectories of different lengths, ended by true termination,
+  timeout, termination, timeout, termination, plus a dangling tail without an end flag (dropped by the trajectory split)."""
+  rs = np.random.RandomState(seed)
+  lengths, ends = [7, 9, 4, 12, 6], ['terminal', 'timeout', 'terminal', 'timeout', 'terminal']
+  n = sum(lengths) + 3
+  d = dict(observations=rs.standard_normal((n, obs_dim)).astype(f32), actions=rs.uniform(-1, 1, (n, act_dim)).astype(f32),
+           next_observations=rs.standard_normal((n, obs_dim)).astype(f32), terminals=np.zeros(n, f32), timeouts=np.zeros(n, f32))
+  pos = 0
+  for L, e in zip(lengths, ends):
+    pos += L
+    d['terminals' if e == 'terminal' else 'timeouts'][pos - 1] = 1
+  return d

@@ -378,6 +378,29 @@ def gen_dril():
   np.savez_compressed(os.path.join(HERE, 'dril.npz'), **out)
 
 
+def gen_dataset():
+  """D4RLEnv.get_dataset (environments.py:63-125) on a raw D4RL-format dataset. environments.py itself cannot be imported (gym, d4rl), so the
+  method's source is extracted with `ast` and executed unmodified on a stand-in object that has the two attributes it reads."""
+  import ast, types
+  src = open(os.path.join(REF, 'environments.py')).read()
+  fn = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == 'get_dataset')
+  ns = dict(torch=torch, np=np, ReplayMemory=ref_memory.ReplayMemory)
+  exec(compile(ast.Module(body=[fn], type_ignores=[]), 'environments.py', 'exec'), ns)
+  raw = gi.raw_d4rl_dataset(81)
+  out = {}
+  for absorbing in (True, False):
+    for subsample in (1, 3):
+      for trajectories in (0, 2):
+        env = types.SimpleNamespace(dataset={k: v.copy() for k, v in raw.items()}, absorbing=absorbing)
+        np.random.seed(17)
+        mem = ns['get_dataset'](env, trajectories=trajectories, subsample=subsample)
+        tag = f'abs{int(absorbing)}_sub{subsample}_traj{trajectories}'
+        for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'timeouts', 'weights', 'step'):
+          out[f'{tag}.{k}'] = N_(getattr(mem, k))
+        out[f'{tag}.meta'] = np.array([mem.num_trajectories, mem.idx, int(mem.full), len(mem)], np.int64)
+  np.savez_compressed(os.path.join(HERE, 'dataset.npz'), **out)
+
+
 if __name__ == '__main__':
   only = set(sys.argv[1:])  # e.g. `make_golden.py adril` regenerates just that fixture
   want = lambda tag: not only or tag in only
@@ -397,3 +420,4 @@ if __name__ == '__main__':
   if want('adril'): gen_adril()
   if want('red'): gen_red()
   if want('dril'): gen_dril()
+  if want('dataset'): gen_dataset()

@@ -35,3 +35,37 @@ def test_tuned_overlays_need_the_reference_tree(tmp_path):
   (d / 'GAIL_5_trajectories.yaml').write_text('# @package _global_\ntraining:\n  batch_size: 1024\nimitation:\n  trajectories: 5\n  grad_penalty: 0.28\n')
   c = config.compose(['algorithm=GAIL', 'optimised_hyperparameters=GAIL_5_trajectories', 'training.batch_size=128'], config_dir=str(tmp_path))
   assert c.imitation.trajectories == 5 and c.imitation.grad_penalty == 0.28 and c.training.batch_size == 128 and c.imitation.weight_decay == 10
+
+
+def test_expert_data_ingest_matches_reference(tmp_path):
+  """dataset_to_memory (trajectory split, truncation, absorbing wrap, importance weights, sub-sampling, ReplayMemory layout) against
+  D4RLEnv.get_dataset of the reference on the same raw arrays, bit for bit; also through an .npz file on disk."""
+  import os
+  import numpy as np
+  import torch
+  import imitation_learning_amd as il
+  from imitation_learning_amd import environments
+  sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+  import sys
+  sys.path.insert(0, sys_path)
+  import inputs as gi
+  g = np.load(os.path.join(sys_path, 'dataset.npz'))
+  raw = gi.raw_d4rl_dataset(81)
+  path = str(tmp_path / 'expert.npz')
+  np.savez(path, **raw)
+  from_file = environments.load_dataset_file(path)
+  for absorbing in (True, False):
+    for subsample in (1, 3):
+      for trajectories in (0, 2):
+        for source in (raw, from_file):
+          il.seed(17)
+          mem = environments.dataset_to_memory(source, absorbing, trajectories, subsample, device='cpu')
+          tag = f'abs{int(absorbing)}_sub{subsample}_traj{trajectories}'
+          for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'timeouts', 'weights', 'step'):
+            assert getattr(mem, k).numpy().tobytes() == g[f'{tag}.{k}'].tobytes(), (tag, k)
+          assert [mem.num_trajectories, mem.idx, int(mem.full), len(mem)] == g[f'{tag}.meta'].tolist(), tag
+  no_next = {k: v for k, v in raw.items() if k != 'next_observations'}
+  np.savez(path, **no_next)
+  assert environments.load_dataset_file(path)['next_observations'].shape == raw['observations'].shape
+  with pytest.raises(ImportError):
+    environments.load_dataset_file(str(tmp_path / 'expert.hdf5'))
