@@ -506,7 +506,9 @@ __device__ __forceinline__ void adam_store(const DwArgs& a, const adam_consts& a
 #define IL_DW_PREFETCH 1
 #endif
 // XT: x is feature-major [Kvalid][B]; otherwise row-major [B][ldx] (the actor's layer-1 input = the states field of the batch)
-template <bool XT>
+// U = 16-row operand lanes in flight per operand: 8 for the single learner (one block per CU: latency hiding has to come from the wave itself),
+// 4 for the population launch (half the registers -> four waves per SIMD instead of two hide the latency across blocks).
+template <bool XT, int U>
 __device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dzT, int Nvalid, const float* __restrict__ x, int ldx, int Kvalid,
                                         int n0, int kb, int64_t poff, float* __restrict__ pkf = nullptr, float* __restrict__ pkb = nullptr) {
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
@@ -535,12 +537,12 @@ __device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, 
     }
   }
   int r0 = 0;
-  for (; r0 + 128 <= B; r0 += 128) {
-    f32x4 av[8], bv[8];
+  for (; r0 + 16 * U <= B; r0 += 16 * U) {
+    f32x4 av[U], bv[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { av[u] = *reinterpret_cast<const f32x4*>(dzp + r0 + 16 * u); bv[u] = ldx4(r0 + 16 * u); }
+    for (int u = 0; u < U; ++u) { av[u] = *reinterpret_cast<const f32x4*>(dzp + r0 + 16 * u); bv[u] = ldx4(r0 + 16 * u); }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < U; ++u) {
       acc0 = mfma16(av[u][0], bv[u][0], acc0);
       acc1 = mfma16(av[u][1], bv[u][1], acc1);
       acc0 = mfma16(av[u][2], bv[u][2], acc0);
@@ -595,10 +597,11 @@ __device__ __forceinline__ void dw_bias(const DwArgs& a, const adam_consts& ac, 
   if (g == 0 && n0 + j < Nvalid) adam_store(a, ac, poff + n0 + j, s);
 }
 
-__device__ __forceinline__ void dw_adam_body(const DwArgs& a) {
+template <int U>
+__device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, const int nblocks) {   // bid / nblocks: this learner's block index / count
   const int wave_in_block = threadIdx.x >> 6;
-  if ((int)blockIdx.x >= a.n_dw_blocks) {  // ---- tail blocks
-    const int tb = (int)blockIdx.x - a.n_dw_blocks;
+  if (bid >= a.n_dw_blocks) {  // ---- tail blocks
+    const int tb = bid - a.n_dw_blocks;
     if (a.log_alpha && tb == 0 && threadIdx.x == 0) {
       float s = 0.f;
       for (int i = 0; i < a.n_alpha_part; ++i) s += a.alpha_part[i];
@@ -616,7 +619,7 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a) {
     }
     if (a.target && !a.grads_only) {
       const float omt = (float)(1.0 - a.tau), tau = (float)a.tau;
-      const int ntb = (int)gridDim.x - a.n_dw_blocks;
+      const int ntb = nblocks - a.n_dw_blocks;
       for (int64_t i = ((int64_t)tb * blockDim.x + threadIdx.x) * 4; i < a.polyak_n; i += (int64_t)ntb * blockDim.x * 4) {
         if (i + 3 < a.polyak_n) {
           f32x4 t = *reinterpret_cast<f32x4*>(a.target + i); const f32x4 p = *reinterpret_cast<const f32x4*>(a.polyak_src + i);
@@ -642,7 +645,7 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a) {
   const int nt_h = H / 16, kt_in = (IN + 15) / 16, nt_out = (OUT + 15) / 16;
   const int j1 = nt_h * kt_in, j2 = nt_h * nt_h, j3 = nt_out * nt_h, jb = 2 * nt_h + nt_out;
   const int per_net = j1 + j2 + j3 + jb;
-  int job = (int)blockIdx.x * 4 + wave_in_block;
+  int job = bid * 4 + wave_in_block;
   if (job >= per_net * a.n_nets) return;
   const int net = job / per_net; job -= net * per_net;
   adam_consts ac = {};
@@ -655,17 +658,17 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a) {
   const float* dz3 = a.dz3 + net * a.dz3_net_stride;
   // the big layer first: its tiles are the long pole, the small jobs fill in behind them
   if (job < j2) {
-    dw_tile<true>(a, ac, dz2, H, h1, 0, H, (job / nt_h) * 16, (job % nt_h) * 16, oW2, a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr);
+    dw_tile<true, U>(a, ac, dz2, H, h1, 0, H, (job / nt_h) * 16, (job % nt_h) * 16, oW2, a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr);
     return;
   }
   job -= j2;
   if (job < j1) {
-    if (a.x0_transposed) dw_tile<true>(a, ac, dz1, H, x0, 0, IN, (job / kt_in) * 16, (job % kt_in) * 16, oW1);
-    else dw_tile<false>(a, ac, dz1, H, x0, a.ld_x0, IN, (job / kt_in) * 16, (job % kt_in) * 16, oW1);
+    if (a.x0_transposed) dw_tile<true, U>(a, ac, dz1, H, x0, 0, IN, (job / kt_in) * 16, (job % kt_in) * 16, oW1);
+    else dw_tile<false, U>(a, ac, dz1, H, x0, a.ld_x0, IN, (job / kt_in) * 16, (job % kt_in) * 16, oW1);
     return;
   }
   job -= j1;
-  if (job < j3) { dw_tile<true>(a, ac, dz3, OUT, h2, 0, H, (job / nt_h) * 16, (job % nt_h) * 16, oW3); return; }
+  if (job < j3) { dw_tile<true, U>(a, ac, dz3, OUT, h2, 0, H, (job / nt_h) * 16, (job % nt_h) * 16, oW3); return; }
   job -= j3;
   if (job < nt_h) { dw_bias(a, ac, dz1, H, job * 16, ob1); return; }
   job -= nt_h;
@@ -674,7 +677,7 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a) {
   dw_bias(a, ac, dz3, OUT, job * 16, ob3);
 }
 
-__global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) { dw_adam_body(a); }
+__global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) { dw_adam_body<8>(a, (int)blockIdx.x, (int)gridDim.x); }
 
 static int repack_blocks(int H) { return ceil_div(H * H / 16, 256); }
 __host__ __device__ static inline int dw_blocks(int IN, int H, int OUT, int nets) {
@@ -814,7 +817,7 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
 __global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ dL, const il_batch* __restrict__ bL, int kind, uint32_t flags) {
   const il_sac d = dL[blockIdx.y]; const il_batch b = bL[blockIdx.y];
   const DwArgs a = kind ? actor_dw_args(&d, &b, flags) : critic_dw_args(&d, flags);
-  dw_adam_body(a);
+  dw_adam_body<4>(a, (int)blockIdx.x, (int)gridDim.x);   // (confining a learner to one XCD so that its dW operands cross the fabric once was measured: no gain)
 }
 
 extern "C" int il_sac_update_population(const il_sac* descs_dev, const il_batch* batches_dev, int32_t n_learners, const il_sac* shape_host, uint32_t flags, il_stream_t stream_) {
