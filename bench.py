@@ -87,6 +87,79 @@ def build(device, rank, seed=0, learner_id=None):
   return plan, (actor, critic, target, log_alpha, disc), (tr, et)
 
 
+def secondary(device, plan, nets):
+  """The other single-GPU configurations of BASELINE.json, reported next to the headline line: SAC only (configs[1]), the GAIL
+  discriminator step + relabel alone (configs[2]), the GMMIL pairwise-RBF reward at B = 1024 with Ant dims (configs[3]) and the PWIL per-step reward
+  against 25,000 expert atoms.  Each: captured where capturable, 300 timed repetitions, inputs resident."""
+  import imitation_learning_amd as il
+  from imitation_learning_amd import training as T
+  out = {}
+
+  def timed(step, reps=300, warm=30):
+    for _ in range(warm): step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): step()
+    torch.cuda.synchronize()
+    return reps / (time.perf_counter() - t0)
+
+  actor, critic, target, log_alpha, disc = nets
+  keep = plan._keep
+  sac_plan = il.UpdatePlan('SAC', actor, critic, log_alpha, target, plan.memory, keep[4], keep[5], keep[6], B, 0.97, -0.5 * A, 0.99, learner_id=9001)
+  sac_plan.run(); sac_plan.capture(warmup=0)
+  out['sac_only_updates_per_s'] = round(timed(sac_plan.replay, 1000, 100), 1)
+
+  g = torch.cuda.CUDAGraph()
+  L = _lib_mod().lib()
+  side = torch.cuda.Stream()
+  dd, pb, eb, rew = plan.disc, plan.pb, plan.eb, plan.rewards
+  was = plan.device_sync
+  plan._set_device_sync(False)
+  def disc_step():
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.il_gail_disc_step(C.byref(plan.disc), C.byref(pb), C.byref(eb), None, None, 0, st) == 0
+    assert L.il_gail_reward(C.byref(plan.disc), C.byref(pb), C.c_void_p(rew.data_ptr()), None, None, st) == 0
+  side.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(side):
+    disc_step(); torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=side):
+      disc_step()
+    out['gail_disc_step_and_relabel_per_s'] = round(timed(g.replay, 1000, 100), 1)
+  torch.cuda.current_stream().wait_stream(side)
+  plan._set_device_sync(was)
+  del dd
+
+  # GMMIL, Ant dims (S = 112 incl. absorbing bit, A = 8 -> D = 120), B = 1024 policy rows against 1024 expert rows
+  rs = np.random.RandomState(5)
+  Sg, Ag, Bg = 112, 8, 1024
+  mk = lambda shift: (torch.from_numpy((rs.standard_normal((Bg, Sg)) + shift).astype(np.float32)).to(device), torch.from_numpy(rs.uniform(-1, 1, (Bg, Ag)).astype(np.float32)).to(device))
+  (xs, xa), (es, ea) = mk(0.0), mk(0.5)
+  w = torch.ones(Bg, device=device)
+  gm = il.GMMILDiscriminator(Sg, Ag, Cfg(state_only=False))
+  gm.predict_reward(xs, xa, es, ea, w, w)   # first call fixes the bandwidths (median heuristic)
+  rate = timed(lambda: gm.predict_reward(xs, xa, es, ea, w, w))
+  pair_flops = 2 * (2 * Bg * Bg) * (3 * (Sg + Ag))   # two gammas share the distances: 2 matrices x B^2 pairs x 3 flop per pair-feature (direct form)
+  out['gmmil_reward_B1024_ant'] = dict(calls_per_s=round(rate, 1), pair_feature_TFLOPs=round(pair_flops * rate / 1e12 / 2, 2),
+                                        note='k_gmmil_pack/tile/final; the reference materialises [B,B,D] temporaries (0.33 s per call on its CPU path, SURVEY.md a20)')
+
+  # PWIL: one (state, action) against N = 25,000 standardised expert atoms, D = 24, consumed greedily (models.py:232-249)
+  emem = plan.expert_memory
+  pw = il.PWILDiscriminator(S, A, Cfg(state_only=False, reward_scale=5, reward_bandwidth_scale=5), emem, 1000)
+  s1, a1 = torch.zeros(1, S, device=device), torch.zeros(1, A, device=device)
+  k = [0]
+  def pwil_step():
+    pw.compute_reward_async(s1, a1)
+    k[0] += 1
+    if k[0] % 1000 == 0: pw.reset()
+  out['pwil_reward_25k_atoms_steps_per_s'] = round(timed(pwil_step, 2000, 100), 1)
+  return out
+
+
+def _lib_mod():
+  from imitation_learning_amd import _lib
+  return _lib
+
+
 def cpu_baseline(tr, et, budget_s=12.0):
   """The oracle port of the same update block on the host cores (index draws through numpy's legacy RNG like the reference)."""
   from oracle import gail as ogail
@@ -200,6 +273,7 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--trace-steps', type=int, default=100)
   ap.add_argument('--no-population', action='store_true')
+  ap.add_argument('--no-secondary', action='store_true', help='skip the SAC-only / discriminator-only / GMMIL / PWIL rates')
   ap.add_argument('--population-learners', type=int, default=16)
   ap.add_argument('--learners', type=int, default=1, help='population axis: N independent learners per GPU advanced by one graph replay (aggregate updates/s)')
   args = ap.parse_args()
@@ -302,6 +376,8 @@ def main():
       out['population'] = dict(learners=Lp, aggregate_updates_per_s=round(Lp / dt, 1), ms_per_replay=round(dt * 1e3, 5), roofline=proof,
                                note=f'{Lp} independent batch-256 SAC+GAIL learners per launch (il_*_population: learner id = grid dimension), own replay ring / index stream / Philox counter each')
       del pop
+    if world == 1 and args.learners == 1 and not args.no_secondary:
+      out['secondary'] = secondary(device, plan, nets)
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(tr, et)
   if dist.is_initialized():

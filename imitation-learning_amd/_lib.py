@@ -119,6 +119,7 @@ _SIGNATURES = {
     'il_gmmil_reward': (C.c_int, [C.POINTER(Batch), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, C.c_int64, _P]),
     'il_gmmil_sqdist': (C.c_int, [C.POINTER(Batch), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
     'il_pwil_reset': (C.c_int, [C.POINTER(Pwil), _P]),
+    'il_pwil_scratch_floats': (C.c_int64, [C.c_int32, C.c_double]),
     'il_pwil_reward': (C.c_int, [C.POINTER(Pwil), _P, _P, _P, _P]),
     'il_dril_numel': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     'il_dril_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

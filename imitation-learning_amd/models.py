@@ -392,7 +392,8 @@ class PWILDiscriminator(nn.Module):
     self.reward_scale, self.reward_bandwidth = imitation_cfg.reward_scale, imitation_cfg.reward_bandwidth_scale * time_horizon / sqrt(dim)
     self.expert_atoms = (self.data_scale * (raw + self.data_offset)).contiguous()
     n = self.expert_atoms.size(0)
-    self.expert_weights, self._dists, self._out = torch.empty(n, device=raw.device), torch.empty(n, device=raw.device), torch.empty(1, device=raw.device)
+    scratch = int(_lib.lib().il_pwil_scratch_floats(n, 1 / time_horizon - 1e-6))
+    self.expert_weights, self._dists, self._out = torch.empty(n, device=raw.device), torch.empty(scratch, device=raw.device), torch.empty(1, device=raw.device)
     self._scale, self._offset = self.data_scale.flatten().contiguous(), self.data_offset.flatten().contiguous()
     self._desc = _lib.Pwil(n, dim, state_size, action_size, self.expert_atoms.data_ptr(), self.expert_weights.data_ptr(), self._dists.data_ptr(), self._scale.data_ptr(),
                            self._offset.data_ptr(), float(self.reward_scale), float(self.reward_bandwidth), 1 / time_horizon - 1e-6)

@@ -300,10 +300,11 @@ typedef struct il_pwil {
   int32_t n_atoms, dim, state_dim, action_dim;
   const float* atoms;  /* [N, dim] */
   float* weights;      /* [N]; <0 marks a consumed (deleted) atom */
-  float* dists;        /* [N] scratch */
+  float* dists;        /* scratch, >= il_pwil_scratch_floats(N, agent_weight) floats */
   const float *scale, *offset; /* [dim] */
   double reward_scale, reward_bandwidth, agent_weight; /* Python-float hyper-parameters; agent_weight = 1/T - 1e-6 (models.py:235) */
 } il_pwil;
+int64_t il_pwil_scratch_floats(int32_t n_atoms, double agent_weight);
 int il_pwil_reset(const il_pwil* d, il_stream_t stream);
 /* compute_reward for one (state, action); writes the reward (double precision accumulate like the reference's Python floats) to out_reward[0]. */
 int il_pwil_reward(const il_pwil* d, const float* state, const float* action, float* out_reward, il_stream_t stream);
