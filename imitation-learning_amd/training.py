@@ -367,17 +367,9 @@ class UpdatePlan:
   def _run_update(self):
     L = _lib.lib()
     if self.algorithm == 'GAIL' and self.overlap:
-      # Two streams, one hipGraph: the weight re-ordering (parameters only) runs next to the replay sampling; then the discriminator
-      # step + reward relabel run next to the reward-independent SAC forward kernels; join before the critic loss reads the rewards.
+      # Two streams: the discriminator step + reward relabel run next to the reward-independent SAC forward kernels and the critic loss needs both.
       main = torch.cuda.current_stream()
-      early_prepare = os.environ.get('IL_EARLY_PREPARE', '0') == '1'  # measured slower (7.2k vs 8.0k updates/s): the extra graph edge costs more than the 3 us kernel
-      if early_prepare:
-        self.side.wait_stream(main)                                   # fork
-        with torch.cuda.stream(self.side):
-          _lib.check(L.il_sac_prepare(C.byref(self.sac), _lib.stream_ptr()))
-          prepared = torch.cuda.Event()
-          prepared.record(self.side)
-      fwd = _lib.IL_FLAG_SAC_FORWARD_ONLY | (_lib.IL_FLAG_SAC_PREPARED if early_prepare else self.prepared_flag())
+      fwd = _lib.IL_FLAG_SAC_FORWARD_ONLY | self.prepared_flag()   # (building the lane-ordered copies on the side stream first was measured: 7.2k vs 8.0k updates/s, the extra edge costs more than the 3 us kernel)
       if self.device_sync:
         # No stream dependency between the branches at all: they hand over on the device (k_gather2 -> k_gail_grad, k_gail_reward ->
         # k_critic_bwd). Captured, they are TWO graphs replayed on two streams (a fork inside one hipGraph delays one branch by 16-20 us).
@@ -391,14 +383,13 @@ class UpdatePlan:
         if self._capturing != 'side':
           self._prepared = True         # the SAC branch has (or, once replayed, will have) left the lane-ordered weight copies in step
         return
-      self.sample_all()                                             # main: index draws + gathers, next to the re-ordering kernel
+      # fallback (the runtime does not run the two streams concurrently, or IL_DEVICE_SYNC=0): one graph, fork after the gather, join before the critic loss
+      self.sample_all()
       self.side.wait_stream(main)                                   # the discriminator needs the sampled batches
       with torch.cuda.stream(self.side):
         st = _lib.stream_ptr()
         _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))
         _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
-      if early_prepare:
-        main.wait_event(prepared)                                   # main needs the re-ordered weights, not the discriminator
       st = _lib.stream_ptr()
       _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), fwd, st))
       main.wait_stream(self.side)                                   # join: the critic loss reads the rewards
