@@ -9,19 +9,21 @@
 //                  the normalised weights;
 //   k_gmmil_tile   grid (i-tile, j-tile, matrix): 64x64 pairs per workgroup, 4x4 per thread, features streamed through
 //                  LDS in chunks of 32, two ds_read_b128 per 16 pair updates; epilogue exp + weighted row sums;
-//   k_gmmil_final  deterministic sum of the per-j-tile partials.
+//                  the row tile's last-arriving workgroup then sums the per-column-tile partials in tile order (deterministic).
 #include "il_common.hpp"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define GT 64   // tile edge (pairs)
 #define GKC 32  // feature chunk
 
-struct GmmilWs { int64_t xt, et, wn, wen, part, total; int b1p, b2p, njt; };
+struct GmmilWs { int64_t xt, et, wn, wen, part, ctr, total; int b1p, b2p, njt; };
 __host__ __device__ inline GmmilWs gmmil_ws(int n1, int n2, int D) {
   GmmilWs w; w.b1p = (n1 + GT - 1) / GT * GT; w.b2p = (n2 + GT - 1) / GT * GT;
   const int nj1 = w.b2p / GT, nj2 = w.b1p / GT; w.njt = nj1 > nj2 ? nj1 : nj2;
   int64_t o = 0;
   w.xt = o; o += (int64_t)D * w.b1p; w.et = o; o += (int64_t)D * w.b2p; w.wn = o; o += w.b1p; w.wen = o; o += w.b2p;
-  w.part = o; o += (int64_t)2 * w.njt * w.b1p; w.total = o;
+  w.part = o; o += (int64_t)2 * w.njt * w.b1p; w.ctr = o; o += (w.b1p / GT + 3) & ~3;   // arrival counter per row tile (zeroed by k_gmmil_pack)
+  w.total = o;
   return w;
 }
 extern "C" int64_t il_gmmil_workspace_floats(int32_t n1, int32_t n2, int32_t D) { return gmmil_ws(n1, n2, D).total; }
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(256) void k_gmmil_pack(il_batch pol, il_batch exp, 
   __shared__ float red[32];
   const GmmilWs w = gmmil_ws(pol.n, exp.n, D);
   const int nt1 = w.b1p / GT;
+  if (blockIdx.x == 0) for (int i = threadIdx.x; i < nt1; i += blockDim.x) reinterpret_cast<unsigned*>(ws_ + w.ctr)[i] = 0u;
   const bool is_exp = (int)blockIdx.x >= nt1;
   const il_batch& b = is_exp ? exp : pol;
   const int n = b.n, np = is_exp ? w.b2p : w.b1p, row0 = ((int)blockIdx.x - (is_exp ? nt1 : 0)) * GT;
@@ -61,7 +64,8 @@ __global__ __launch_bounds__(256) void k_gmmil_pack(il_batch pol, il_batch exp, 
 
 // MODE 0: reward partials; MODE 1: write the distance matrix (out [n1][n2])
 template <int MODE>
-__global__ __launch_bounds__(256) void k_gmmil_tile(int n1, int n2, int D, float g1, float g2, float* __restrict__ ws_, float* __restrict__ dist_out, int self_second) {
+__global__ __launch_bounds__(256) void k_gmmil_tile(int n1, int n2, int D, float g1, float g2, float* __restrict__ ws_, float* __restrict__ dist_out, int self_second,
+                                                    float* __restrict__ out_r, float* __restrict__ out_sim, float* __restrict__ out_self) {
   __shared__ __attribute__((aligned(16))) float Xs[GKC][GT];
   __shared__ __attribute__((aligned(16))) float Ys[GKC][GT];
   const GmmilWs w = gmmil_ws(n1, n2, D);
@@ -72,30 +76,51 @@ __global__ __launch_bounds__(256) void k_gmmil_tile(int n1, int n2, int D, float
   const float* XT = ws_ + w.xt; const float* YT = ws_ + (vs_self ? w.xt : w.et);
   const float* wy = ws_ + (vs_self ? w.wn : w.wen);
   const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
-  float acc[4][4];
+  f32x2 acc2[4][2];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 4; ++a) { acc2[a][0] = f32x2{0.f, 0.f}; acc2[a][1] = f32x2{0.f, 0.f}; }
+  // feature chunks of GKC: the next chunk's 2 x 8 values per thread are requested before the current chunk is consumed (their global latency used to
+  // sit between two barriers with nothing to overlap it: two workgroups per CU at B = 1024)
+  constexpr int PER = GKC * GT / 256;
+  float xr[PER], yr[PER];
+  auto fetch = [&](int k0) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-  for (int k0 = 0; k0 < D; k0 += GKC) {
-    for (int i = threadIdx.x; i < GKC * GT; i += blockDim.x) {
-      const int k = i / GT, c = i - k * GT;
+    for (int u = 0; u < PER; ++u) {
+      const int i = threadIdx.x + u * 256, k = i / GT, c = i - k * GT;
       const bool ok = k0 + k < D;
-      Xs[k][c] = ok ? XT[(size_t)(k0 + k) * w.b1p + it * GT + c] : 0.f;
-      Ys[k][c] = ok ? YT[(size_t)(k0 + k) * npy + jt * GT + c] : 0.f;
+      xr[u] = ok ? XT[(size_t)(k0 + k) * w.b1p + it * GT + c] : 0.f;
+      yr[u] = ok ? YT[(size_t)(k0 + k) * npy + jt * GT + c] : 0.f;
     }
+  };
+  const bool stamp = blockIdx.x == 3 && blockIdx.y == 5 && blockIdx.z == 0;
+  IL_STAMP(stamp, 0);
+  fetch(0);
+  for (int k0 = 0; k0 < D; k0 += GKC) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { const int i = threadIdx.x + u * 256, k = i / GT, c = i - k * GT; Xs[k][c] = xr[u]; Ys[k][c] = yr[u]; }
     __syncthreads();
-    const int kc = min(GKC, D - k0);
-    for (int k = 0; k < kc; ++k) {
+    if (k0 + GKC < D) fetch(k0 + GKC);
+    // all GKC features of the chunk (features >= D are staged as zeros on both sides: they add (0 - 0)^2), so the loop has a fixed trip count and
+    // unrolls: eight LDS reads in flight ahead of 64 packed ops instead of read - wait - 16 ops with one wave per SIMD
+#pragma unroll 4
+    for (int k = 0; k < GKC; ++k) {
       const f32x4 xv = *reinterpret_cast<const f32x4*>(&Xs[k][ti * 4]);
       const f32x4 yv = *reinterpret_cast<const f32x4*>(&Ys[k][tj * 4]);
+      const f32x2 y01 = {yv[0], yv[1]}, y23 = {yv[2], yv[3]};
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { const float df = xv[a] - yv[b]; acc[a][b] = fmaf(df, df, acc[a][b]); }
+      for (int a = 0; a < 4; ++a) {   // two pairs per instruction: v_pk_add_f32 + v_pk_fma_f32 (same roundings as the scalar sub + fma)
+        const f32x2 xa = {xv[a], xv[a]};
+        const f32x2 d0 = xa - y01, d1 = xa - y23;
+        acc2[a][0] = __builtin_elementwise_fma(d0, d0, acc2[a][0]);
+        acc2[a][1] = __builtin_elementwise_fma(d1, d1, acc2[a][1]);
+      }
     }
     __syncthreads();
   }
+  IL_STAMP(stamp, 1);
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { acc[a][0] = acc2[a][0][0]; acc[a][1] = acc2[a][0][1]; acc[a][2] = acc2[a][1][0]; acc[a][3] = acc2[a][1][1]; }
   const float fD = (float)D;
   if (MODE == 1) {
     const int n2e = vs_self ? n1 : n2;
@@ -118,16 +143,24 @@ __global__ __launch_bounds__(256) void k_gmmil_tile(int n1, int n2, int D, float
     s = group16_sum(s);
     if (tj == 0) part[ti * 4 + a] = s;
   }
-}
-
-__global__ __launch_bounds__(256) void k_gmmil_final(int n1, int n2, int D, const float* __restrict__ ws_, float* __restrict__ out_r, float* __restrict__ out_sim,
-                                                     float* __restrict__ out_self) {
-  const GmmilWs w = gmmil_ws(n1, n2, D);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  IL_STAMP(stamp, 2);
+  if (!out_r) return;
+  // The row tile's reward needs the partial sums of every column tile of BOTH matrices: the workgroup that arrives last (one agent-scope acq_rel
+  // ticket per workgroup, after a barrier) adds them up in tile order - the separate, launch-bound "final" kernel this replaces cost 11 us.
+  __shared__ unsigned last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned expect = (unsigned)(w.b2p / GT + w.b1p / GT);
+    last = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(ws_ + w.ctr) + it, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == expect;
+  }
+  __syncthreads();
+  IL_STAMP(stamp, 3);
+  if (!last || threadIdx.x >= GT) return;
+  const int i = it * GT + threadIdx.x;
   if (i >= n1) return;
   float s0 = 0.f, s1 = 0.f;
-  for (int jt = 0; jt < w.b2p / GT; ++jt) s0 += ws_[w.part + (size_t)jt * w.b1p + i];
-  for (int jt = 0; jt < w.b1p / GT; ++jt) s1 += ws_[w.part + ((size_t)w.njt + jt) * w.b1p + i];
+  for (int q = 0; q < w.b2p / GT; ++q) s0 += ws_[w.part + (size_t)q * w.b1p + i];
+  for (int q = 0; q < w.b1p / GT; ++q) s1 += ws_[w.part + ((size_t)w.njt + q) * w.b1p + i];
   const float wi = ws_[w.wn + i];
   const float sim = wi * s0, self = wi * s1;
   out_r[i] = sim - self;
@@ -143,8 +176,7 @@ extern "C" int il_gmmil_reward(const il_batch* pol, const il_batch* exp, int32_t
   if (workspace_floats < w.total) return il_set_error(IL_ERR_WORKSPACE, "il_gmmil_reward: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)w.total);
   hipStream_t st = (hipStream_t)stream_;
   { IL_TRACE("k_gmmil_pack", st); k_gmmil_pack<<<w.b1p / GT + w.b2p / GT, 256, 0, st>>>(*pol, *exp, S, D, workspace); }
-  { IL_TRACE("k_gmmil_tile", st); k_gmmil_tile<0><<<dim3(w.b1p / GT, w.njt, 2), 256, 0, st>>>(pol->n, exp->n, D, g1, g2, workspace, nullptr, 0); }
-  { IL_TRACE("k_gmmil_final", st); k_gmmil_final<<<ceil_div(pol->n, 256), 256, 0, st>>>(pol->n, exp->n, D, workspace, out_rewards, out_sim, out_self); }
+  { IL_TRACE("k_gmmil_tile", st); k_gmmil_tile<0><<<dim3(w.b1p / GT, w.njt, 2), 256, 0, st>>>(pol->n, exp->n, D, g1, g2, workspace, nullptr, 0, out_rewards, out_sim, out_self); }
   IL_CHECK_LAUNCH("il_gmmil_reward");
   return IL_OK;
 }
@@ -159,7 +191,9 @@ extern "C" int il_gmmil_sqdist(const il_batch* a, const il_batch* b, int32_t S, 
   if (workspace_floats < w.total) return il_set_error(IL_ERR_WORKSPACE, "il_gmmil_sqdist: workspace too small");
   hipStream_t st = (hipStream_t)stream_;
   { IL_TRACE("k_gmmil_pack", st); k_gmmil_pack<<<w.b1p / GT + w.b2p / GT, 256, 0, st>>>(*a, *b, S, D, workspace); }
-  { IL_TRACE("k_gmmil_tile", st); k_gmmil_tile<1><<<dim3(w.b1p / GT, w.b2p / GT, 1), 256, 0, st>>>(a->n, b->n, D, 0.f, 0.f, workspace, out, 0); }
+  { IL_TRACE("k_gmmil_tile", st); k_gmmil_tile<1><<<dim3(w.b1p / GT, w.b2p / GT, 1), 256, 0, st>>>(a->n, b->n, D, 0.f, 0.f, workspace, out, 0, nullptr, nullptr, nullptr); }
   IL_CHECK_LAUNCH("il_gmmil_sqdist");
   return IL_OK;
 }
+
+IL_STAMP_READER(il_debug_stamps_gmmil)
