@@ -792,3 +792,25 @@ def test_gail_variants_loud_failures():
   opt = il.AdamW(d, lr=1e-3, weight_decay=0.1)
   with pytest.raises(NotImplementedError):
     il.adversarial_imitation_update(None, d, tbatch(c['policy'][0]), tbatch(c['expert'][0]), opt, mk(margin=0.1))
+
+
+@pytest.mark.gpu
+def test_device_handoff_equals_stream_dependencies(monkeypatch):
+  """The two-graph update whose branches hand over through device counters must evolve the learner bit for bit like the one-graph update with a
+  fork / join (same kernels, same order of dependent work); 400 replays, and no bounded wait may have timed out."""
+  results = []
+  for device_sync in ('1', '0'):
+    monkeypatch.setenv('IL_DEVICE_SYNC', device_sync)
+    il.seed(23)
+    il_training._NOISE.clear()
+    plan, nets = _make_plan('GAIL', 8)
+    assert plan.device_sync == (device_sync == '1')
+    plan.capture(warmup=0)
+    for _ in range(400):
+      plan.replay()
+    torch.cuda.synchronize()
+    assert plan.sync_timeouts() == 0
+    results.append([N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [N(plan.idx), N(plan.logp), N(plan.rewards)])
+  for a, b in zip(*results):
+    assert np.isfinite(a).all()
+    np.testing.assert_array_equal(a, b)
