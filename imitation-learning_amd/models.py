@@ -295,9 +295,9 @@ def update_target_network(network: _FlatModule, target_network: _FlatModule, pol
 
 def make_gail_input(state, action, next_state, terminal, actor, reward_shaping: bool, subtract_log_policy: bool) -> Dict[str, Tensor]:
   """models.py:139-144."""
-  if reward_shaping:
-    raise NotImplementedError('GAIL reward_shaping (a separate shaping network h(s), models.py:157-160) has no kernel on the HIP path')
   out = {'state': state, 'action': action}
+  if reward_shaping:
+    out.update(next_state=next_state, terminal=terminal)
   if subtract_log_policy:
     out['log_policy'] = actor.log_prob(state, action)
   return out
@@ -310,6 +310,11 @@ class GAILDiscriminator(_FlatModule):
   parametrization modules are kept only for initialisation (same RNG consumption as the reference: normal_ u, v + 15+1
   power iterations) and for the state_dict keys; their buffers are re-pointed at `self.sn` so the kernels own u, v.
   """
+
+  def __new__(cls, state_size=None, action_size=None, imitation_cfg=None, discount=None, device=None):
+    if cls is GAILDiscriminator and imitation_cfg is not None and imitation_cfg.discriminator.reward_shaping:
+      return super().__new__(ShapedGAILDiscriminator)   # f = g(s, a) + (1 - t)(discount h(s') - h(s)): its own kernels (gail_shaped.hip)
+    return super().__new__(cls)
 
   def __init__(self, state_size: int, action_size: int, imitation_cfg, discount: float, device=None):
     super().__init__()
@@ -355,6 +360,58 @@ class GAILDiscriminator(_FlatModule):
   def forward(self, state: Tensor, action: Tensor, next_state=None, terminal=None, log_policy=None) -> Tensor:
     from .training import gail_predict_reward
     return gail_predict_reward(self, state, action, want_logits=True, log_policy=log_policy)[1]
+
+
+class ShapedGAILDiscriminator(GAILDiscriminator):
+  """GAIL discriminator with reward shaping (reference models.py:152-180, reward_shaping=True): g = Linear(Dg, 1) is the reward, h = Linear(S, H)-ReLU-
+  Linear(H, 1) the potential, f = g(s, a) + (1 - terminal)(discount h(s') - h(s)); every weight optionally under spectral norm.  Created through
+  `GAILDiscriminator(...)` when `imitation.discriminator.reward_shaping` is set.  Flat arena = parameters() order, buffers `self.sn` =
+  ug[1] | vg[Dg] | u1[H] | v1[S] | u2[1] | v2[H]; same RNG consumption at construction as the reference (default-initialised g, orthogonal h)."""
+
+  def __init__(self, state_size: int, action_size: int, imitation_cfg, discount: float, device=None):
+    nn.Module.__init__(self)
+    model_cfg = imitation_cfg.discriminator
+    self.discount, self.state_only = discount, bool(imitation_cfg.state_only)
+    self.reward_shaping, self.subtract_log_policy, self.reward_function = True, model_cfg.subtract_log_policy, model_cfg.reward_function
+    self.spectral_norm = bool(imitation_cfg.spectral_norm)
+    if model_cfg.depth != 1 or model_cfg.activation != 'relu' or model_cfg.hidden_size > 256:
+      raise NotImplementedError('GAILDiscriminator (reward shaping): the HIP path implements depth=1, activation=relu, hidden_size <= 256 for the shaping network')
+    self.state_size, self.action_size, self.hidden = state_size, action_size, model_cfg.hidden_size
+    self.in_dim = state_size if self.state_only else state_size + action_size
+    sn = parametrizations.spectral_norm if self.spectral_norm else (lambda layer: layer)
+    self.g = sn(nn.Linear(self.in_dim, 1))   # default nn.Linear init, like the reference (models.py:158)
+    l1 = nn.Linear(state_size, self.hidden); nn.init.orthogonal_(l1.weight, gain=sqrt(2.0)); nn.init.constant_(l1.bias, 0); l1 = sn(l1)
+    l2 = nn.Linear(self.hidden, 1); nn.init.orthogonal_(l2.weight, gain=1.0); nn.init.constant_(l2.bias, 0); l2 = sn(l2)
+    self.h = nn.Sequential(l1, nn.ReLU(), l2)
+    offs, o = [], 0
+    for p in self.parameters():
+      offs.append(o); o += p.numel()
+    assert o == int(_lib.lib().il_disc_shaped_numel(state_size, action_size, self.hidden, int(self.state_only)))
+    dev = device or default_device()
+    self._adopt(o, offs, dev)
+    H, D, S = self.hidden, self.in_dim, state_size
+    self.sn = torch.zeros(2 + D + 2 * H + S, device=dev)
+    self._sn_slices = dict(ug=(0, 1), vg=(1, D), u1=(1 + D, H), v1=(1 + D + H, S), u2=(1 + D + H + S, 1), v2=(2 + D + H + S, H))
+    if self.spectral_norm:
+      with torch.no_grad():
+        for mod, (ku, kv) in ((self.g.parametrizations.weight[0], ('ug', 'vg')), (self.h[0].parametrizations.weight[0], ('u1', 'v1')), (self.h[2].parametrizations.weight[0], ('u2', 'v2'))):
+          u, v = self.views()[ku], self.views()[kv]
+          u.copy_(mod._u); v.copy_(mod._v)
+          mod._buffers['_u'], mod._buffers['_v'] = u, v
+    self.eval()
+
+  def views(self):
+    return {k: self.sn[o:o + n] for k, (o, n) in self._sn_slices.items()}
+
+  def predict_reward(self, state: Tensor, action: Tensor, next_state=None, terminal=None, log_policy=None) -> Tensor:
+    from .training import shaped_predict_reward
+    assert next_state is not None and terminal is not None, 'reward shaping: pass next_state and terminal (make_gail_input does)'
+    assert (log_policy is not None) == bool(self.subtract_log_policy)
+    return shaped_predict_reward(self, state, action, next_state, terminal, log_policy=log_policy)
+
+  def forward(self, state: Tensor, action: Tensor, next_state=None, terminal=None, log_policy=None) -> Tensor:
+    from .training import shaped_predict_reward
+    return shaped_predict_reward(self, state, action, next_state, terminal, log_policy=log_policy, want_logits=True)[1]
 
 
 class GMMILDiscriminator(nn.Module):

@@ -143,16 +143,64 @@ def disc_descriptor(disc: GAILDiscriminator, batch_size: int, opt: AdamW, imitat
   return d
 
 
+def shaped_descriptor(disc, batch_size: int, opt, imitation_cfg=None) -> _lib.DiscShaped:
+  dev = disc.flat.device
+  loss_function, prior, grad_penalty, entropy_bonus = 'BCE', 0.0, 0.0, 0.0
+  if imitation_cfg is not None:
+    loss_function, prior = imitation_cfg.loss_function, float(_cfg_value(imitation_cfg, 'pos_class_prior', 0.0) or 0.0)
+    if loss_function not in ('BCE', 'PUGAIL'):
+      raise NotImplementedError(f'adversarial_imitation_update: reward shaping with loss_function={loss_function} has no kernel (BCE and PUGAIL do)')
+    if loss_function == 'PUGAIL' and float(_cfg_value(imitation_cfg, 'nonnegative_margin', float('inf'))) != float('inf'):
+      raise NotImplementedError('adversarial_imitation_update: PUGAIL with a finite nonnegative_margin has no kernel; the default inf does')
+    grad_penalty, entropy_bonus = float(imitation_cfg.grad_penalty), float(imitation_cfg.entropy_bonus)
+  ws = _workspace('disc_shaped', int(_lib.lib().il_disc_shaped_workspace_floats(disc.state_size, disc.action_size, disc.hidden, batch_size, int(disc.state_only))), dev)
+  v = disc.views()
+  d = _lib.DiscShaped()
+  d.state_dim, d.action_dim, d.hidden, d.batch = disc.state_size, disc.action_size, disc.hidden, batch_size
+  d.spectral_norm, d.state_only, d.reward_function, d.loss_function = int(disc.spectral_norm), int(disc.state_only), REWARD_FUNCTIONS[disc.reward_function], LOSS_FUNCTIONS[loss_function]
+  d.params = disc.flat.data_ptr()
+  d.ug, d.vg, d.u1, d.v1, d.u2, d.v2 = (v[k].data_ptr() for k in ('ug', 'vg', 'u1', 'v1', 'u2', 'v2'))
+  if opt is not None:
+    d.grad, d.opt = opt.grad.data_ptr(), opt.desc()
+  d.grad_penalty, d.entropy_bonus, d.pos_class_prior, d.discount = grad_penalty, entropy_bonus, prior, float(disc.discount)
+  d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
+  d.noise_seed, d.noise_counter = _noise_seed() & (2**64 - 1), _noise_counter(dev, 'disc_shaped').data_ptr()
+  return d
+
+
+def _shaped_batch(state, action, next_state, terminal, weight=None):
+  w = weight if weight is not None else terminal
+  return batch_desc(dict(states=state, actions=action, rewards=w, next_states=next_state, terminals=terminal, weights=w, absorbing=w))
+
+
+def shaped_predict_reward(disc, state: Tensor, action: Tensor, next_state: Tensor, terminal: Tensor, log_policy: Optional[Tensor] = None, want_logits: bool = False):
+  """models.py:173-180 for the reward-shaping discriminator (eval mode)."""
+  dev = disc.flat.device
+  n = state.size(0)
+  d = shaped_descriptor(disc, n, None)
+  b = _shaped_batch(state, action, next_state, terminal.to(dev, torch.float32).contiguous())
+  out, logits, off = torch.empty(n, device=dev), (torch.empty(n, device=dev) if want_logits else None), _f32(log_policy, dev)
+  _lib.check(_lib.lib().il_gail_shaped_reward(C.byref(d), C.byref(b), _lib.ptr(out), _lib.ptr(logits), _lib.ptr(off), _lib.stream_ptr()))
+  return (out, logits) if want_logits else out
+
+
 def adversarial_imitation_update(actor, discriminator: GAILDiscriminator, transitions: Dict[str, Tensor], expert_transitions: Dict[str, Tensor], discriminator_optimiser: AdamW,
                                  imitation_cfg, *, eps_gp: Optional[Tensor] = None, eps_mix: Optional[Tensor] = None):
   """Reference training.py:85-134: loss_function BCE / PUGAIL (nonnegative_margin = inf) / Mixup, + gradient penalty, spectral norm, entropy bonus,
   subtract_log_policy.  `eps_gp` / `eps_mix`: the U(0,1) and Beta(alpha, alpha) draws (None: drawn here)."""
   dev = discriminator.flat.device
   B = transitions['states'].size(0)
-  d = disc_descriptor(discriminator, B, discriminator_optimiser, imitation_cfg)
   pb, eb = batch_desc(transitions), batch_desc(expert_transitions)
   e = _f32(eps_gp, dev)
   x, keep = _lib.GailExtra(), []
+  if getattr(discriminator, 'reward_shaping', False):   # models.py:157-160: its own kernels (k_gs_grad / k_gs_reduce)
+    d = shaped_descriptor(discriminator, B, discriminator_optimiser, imitation_cfg)
+    if discriminator.subtract_log_policy:
+      keep += [actor.log_prob(transitions['states'], transitions['actions']), actor.log_prob(expert_transitions['states'], expert_transitions['actions'])]
+      x.logit_offset_policy, x.logit_offset_expert = keep[-2].data_ptr(), keep[-1].data_ptr()
+    _lib.check(_lib.lib().il_gail_shaped_step(C.byref(d), C.byref(pb), C.byref(eb), _lib.ptr(e), C.byref(x), 0, _lib.stream_ptr()))
+    return
+  d = disc_descriptor(discriminator, B, discriminator_optimiser, imitation_cfg)
   if imitation_cfg.loss_function == 'Mixup':
     if discriminator.subtract_log_policy:
       raise NotImplementedError('adversarial_imitation_update: Mixup with subtract_log_policy (log pi of the mixed inputs) has no kernel')
@@ -257,8 +305,8 @@ class UpdatePlan:
     if algorithm == 'GAIL':
       self.erows = torch.empty(batch_size, expert_memory.row, device=dev); self.eidx = torch.empty(batch_size, dtype=torch.int32, device=dev)
       self.expert_transitions = batch_views(self.erows, expert_memory.state_size, expert_memory.action_size, expert_memory.absorbing)
-      if imitation_cfg is not None and (imitation_cfg.loss_function == 'Mixup' or discriminator.subtract_log_policy):
-        raise NotImplementedError('UpdatePlan: GAIL with Mixup / subtract_log_policy needs per-update inputs; use adversarial_imitation_update + sac_update')
+      if imitation_cfg is not None and (imitation_cfg.loss_function == 'Mixup' or discriminator.subtract_log_policy or getattr(discriminator, 'reward_shaping', False)):
+        raise NotImplementedError('UpdatePlan: GAIL with Mixup / subtract_log_policy / reward shaping runs through adversarial_imitation_update + sac_update')
       self.disc = disc_descriptor(discriminator, batch_size, discriminator_optimiser, imitation_cfg, tag=tag, seed_offset=off)
       self.eb = batch_desc(self.expert_transitions)
       self.rewards = torch.empty(batch_size, device=dev)

@@ -281,6 +281,33 @@ int il_gail_reward(const il_disc* d, const il_batch* batch, float* out_rewards, 
                    il_stream_t stream); /* logit_offset [n] = log pi(a|s) when subtract_log_policy, else NULL */
 
 /* ------------------------------------------------------------------------------------------
+ * GAIL discriminator with reward shaping (reference models.py:152-180, reward_shaping = true):
+ *   f = g(x) + (1 - terminal)(discount * h(s') - h(s)),  g = Linear(Dg, 1),  h = Linear(S, H) -> ReLU -> Linear(H, 1),  Dg = S (+ A unless state_only).
+ * params in parameters() order: spectral norm  {g.bias, g.original[1,Dg], h.0.bias[H], h.0.original[H,S], h.2.bias, h.2.original[1,H]},
+ * otherwise {g.weight, g.bias, h.0.weight, h.0.bias, h.2.weight, h.2.bias}; il_disc_shaped_numel floats. Buffers ug[1] vg[Dg] u1[H] v1[S] u2[1] v2[H].
+ * Losses BCE / PUGAIL (margin = inf); il_gail_extra carries the subtract_log_policy offsets (eps_mix unused). Batches must carry next_states, terminals.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct il_disc_shaped {
+  int32_t state_dim, action_dim, hidden, batch;
+  int32_t spectral_norm, state_only, reward_function, loss_function;
+  float* params;
+  float *ug, *vg, *u1, *v1, *u2, *v2;
+  float* grad;
+  il_adam opt;
+  float grad_penalty, entropy_bonus, pos_class_prior, discount;
+  float* workspace;          /* >= il_disc_shaped_workspace_floats() */
+  int64_t workspace_floats;
+  uint64_t noise_seed;
+  uint32_t* noise_counter;
+} il_disc_shaped;
+int64_t il_disc_shaped_numel(int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t state_only);
+int64_t il_disc_shaped_workspace_floats(int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t batch, int32_t state_only);
+int il_gail_shaped_step(const il_disc_shaped* d, const il_batch* policy, const il_batch* expert, const float* eps_gp, const il_gail_extra* extra,
+                        uint32_t flags, il_stream_t stream);
+int il_gail_shaped_reward(const il_disc_shaped* d, const il_batch* batch, float* out_rewards, float* out_logits, const float* logit_offset,
+                          il_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * GMMIL (reference models.py:25-44, 183-201): d(x,y) = mean_k (x_k-y_k)^2, two RBF bandwidths.
  * ------------------------------------------------------------------------------------------ */
 int64_t il_gmmil_workspace_floats(int32_t n_policy, int32_t n_expert, int32_t dim);
@@ -362,7 +389,7 @@ int il_dril_uncertainty(const il_dril* d, const il_batch* batch, const float* ma
                         float* out_uncertainty, float* out_reward, il_stream_t stream);
 
 /* sizeof() of the descriptor structs in this build (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red,
- * 7 il_dril; -1 otherwise): lets a binding verify its own struct definitions. */
+ * 7 il_dril, 8 il_disc_shaped; -1 otherwise): lets a binding verify its own struct definitions. */
 int32_t il_struct_size(int32_t which);
 
 #ifdef __cplusplus

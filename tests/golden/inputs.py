@@ -156,3 +156,22 @@ def raw_d4rl_dataset(seed, obs_dim=5, act_dim=2):
     pos += L
     d['terminals' if e == 'terminal' else 'timeouts'][pos - 1] = 1
   return d
+
+
+def gail_shaped_case(seed, env, hidden, batch, steps, spectral_norm):
+  """Reward-shaping discriminator: g = Linear(S+A, 1), h = Linear(S, H)-ReLU-Linear(H, 1), spectral-norm buffers, batches with ~30 % terminals so that
+  the (1 - terminal) factor is exercised, gradient-penalty draws."""
+  S, A = DIMS[env]
+  rs = np.random.RandomState(seed)
+  D = S + A
+  unit = lambda x: (x / np.linalg.norm(x)).astype(f32)
+  c = dict(S=S, A=A, H=hidden, B=batch, spectral_norm=spectral_norm,
+           Wg=(rs.standard_normal((1, D)) / np.sqrt(D)).astype(f32), bg=(rs.standard_normal(1) * 0.05).astype(f32),
+           W1=(rs.standard_normal((hidden, S)) * np.sqrt(2.0 / S)).astype(f32), b1=(rs.standard_normal(hidden) * 0.05).astype(f32),
+           W2=(rs.standard_normal((1, hidden)) / np.sqrt(hidden)).astype(f32), b2=(rs.standard_normal(1) * 0.05).astype(f32),
+           ug=unit(rs.standard_normal(1)), vg=unit(rs.standard_normal(D)), u1=unit(rs.standard_normal(hidden)), v1=unit(rs.standard_normal(S)),
+           u2=unit(rs.standard_normal(1)), v2=unit(rs.standard_normal(hidden)))
+  c['policy'] = [transitions(rs, batch, S, A, weighted=True, terminal_frac=0.3) for _ in range(steps)]
+  c['expert'] = [transitions(rs, batch, S, A, state_shift=0.5, weighted=True, terminal_frac=0.3) for _ in range(steps)]
+  c['eps'] = [rs.uniform(size=batch).astype(f32) for _ in range(steps)]
+  return c

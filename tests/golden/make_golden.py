@@ -258,6 +258,46 @@ def gen_gail_variants():
   np.savez_compressed(os.path.join(HERE, 'gail_variants.npz'), **out)
 
 
+def gen_gail_shaped():
+  """GAILDiscriminator with reward_shaping (models.py:152-180) under adversarial_imitation_update: gradients, parameters, u / v buffers, rewards."""
+  out = {}
+  for name, sn, loss in (('sn_bce', True, 'BCE'), ('plain_pugail', False, 'PUGAIL')):
+    c = gi.gail_shaped_case(91, 'hopper', 32, 96, 2, sn)
+    icfg = DictConfig(state_only=False, spectral_norm=sn, loss_function=loss, grad_penalty=0.7, mixup_alpha=1, entropy_bonus=0.01, pos_class_prior=0.7, nonnegative_margin=float('inf'),
+                      discriminator=DictConfig(hidden_size=c['H'], depth=1, activation='relu', reward_shaping=True, subtract_log_policy=False, reward_function='AIRL'))
+    d = ref_models.GAILDiscriminator(c['S'], c['A'], icfg, 0.97)
+    names = [n for n, _ in d.named_parameters()]
+    out[f'{name}.param_names'] = np.array(names)
+    with torch.no_grad():
+      if sn:
+        d.g.parametrizations.weight.original.copy_(T(c['Wg'])); d.g.bias.copy_(T(c['bg']))
+        d.g.parametrizations.weight[0]._u.copy_(T(c['ug'])); d.g.parametrizations.weight[0]._v.copy_(T(c['vg']))
+        for li, (W, b, u, v) in ((0, (c['W1'], c['b1'], c['u1'], c['v1'])), (2, (c['W2'], c['b2'], c['u2'], c['v2']))):
+          d.h[li].parametrizations.weight.original.copy_(T(W)); d.h[li].bias.copy_(T(b))
+          d.h[li].parametrizations.weight[0]._u.copy_(T(u)); d.h[li].parametrizations.weight[0]._v.copy_(T(v))
+      else:
+        d.g.weight.copy_(T(c['Wg'])); d.g.bias.copy_(T(c['bg']))
+        d.h[0].weight.copy_(T(c['W1'])); d.h[0].bias.copy_(T(c['b1'])); d.h[2].weight.copy_(T(c['W2'])); d.h[2].bias.copy_(T(c['b2']))
+    opt = torch.optim.AdamW(d.parameters(), lr=1e-3, weight_decay=0.1)
+    for i in range(len(c['policy'])):
+      d.train()
+      with NoiseFeed() as nf:
+        nf.rand.append(T(c['eps'][i]))
+        ref_training.adversarial_imitation_update(None, d, tbatch(c['policy'][i]), tbatch(c['expert'][i]), opt, icfg)
+      d.eval()
+      k = i + 1
+      out[f'{name}.g_{k}'] = np.concatenate([N_(p.grad).ravel() for p in d.parameters()])
+      out[f'{name}.p_{k}'] = flat(d)
+      if sn:
+        out[f'{name}.ug_{k}'] = N_(d.g.parametrizations.weight[0]._u); out[f'{name}.vg_{k}'] = N_(d.g.parametrizations.weight[0]._v)
+        for li, nm in ((0, '1'), (2, '2')):
+          out[f'{name}.u{nm}_{k}'] = N_(d.h[li].parametrizations.weight[0]._u); out[f'{name}.v{nm}_{k}'] = N_(d.h[li].parametrizations.weight[0]._v)
+      b = c['policy'][i]
+      with torch.inference_mode():
+        out[f'{name}.reward_{k}'] = N_(d.predict_reward(T(b['states']), T(b['actions']), T(b['next_states']), T(b['terminals'])))
+  np.savez_compressed(os.path.join(HERE, 'gail_shaped.npz'), **out)
+
+
 # ---------------------------------------------------------------- GMMIL / PWIL
 def gen_gmmil():
   out = {}
@@ -415,6 +455,7 @@ if __name__ == '__main__':
     gen_gail('gail_h128_ent', gi.gail_case(32, hidden=128), lr=7.3e-5, weight_decay=6.35, grad_penalty=0.32, entropy_bonus=0.0155)
     gen_gail('gail_nosn_nogp', gi.gail_case(33, env='hopper', hidden=32, batch=128, spectral_norm=False), lr=3e-4, weight_decay=0.0, grad_penalty=0.0, entropy_bonus=0.0)
   if want('gail_variants'): gen_gail_variants()
+  if want('gail_shaped'): gen_gail_shaped()
   if want('gmmil'): gen_gmmil()
   if want('pwil'): gen_pwil()
   if want('adril'): gen_adril()

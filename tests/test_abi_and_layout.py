@@ -85,6 +85,6 @@ def test_ctypes_structs_match_the_compiled_library():
   """sizeof() of every descriptor struct as compiled into libil_hip.so equals the ctypes mirror's (a stale binding would pass garbage)."""
   from imitation_learning_amd import _lib
   L = _lib.lib()
-  for which, cls in enumerate((_lib.Batch, _lib.Adam, _lib.Sac, _lib.Disc, _lib.Pwil, _lib.SampleArgs, _lib.Red, _lib.Dril)):
+  for which, cls in enumerate((_lib.Batch, _lib.Adam, _lib.Sac, _lib.Disc, _lib.Pwil, _lib.SampleArgs, _lib.Red, _lib.Dril, _lib.DiscShaped)):
     assert L.il_struct_size(which) == C.sizeof(cls), cls.__name__
   assert L.il_struct_size(99) == -1

@@ -786,8 +786,7 @@ def test_gail_variants_loud_failures():
   c = gi.gail_case(35, env='hopper', hidden=32, batch=96, steps=1)
   mk = lambda **kw: Cfg(state_only=False, spectral_norm=True, loss_function='PUGAIL', grad_penalty=0.5, mixup_alpha=1, entropy_bonus=0.0, pos_class_prior=0.7, nonnegative_margin=kw.get('margin', float('inf')),
                         discriminator=Cfg(hidden_size=32, depth=1, activation='relu', reward_shaping=kw.get('shaping', False), subtract_log_policy=False, reward_function='AIRL'))
-  with pytest.raises(NotImplementedError):
-    il.GAILDiscriminator(c['S'], c['A'], mk(shaping=True), 0.97, device=DEV)
+  assert type(il.GAILDiscriminator(c['S'], c['A'], mk(shaping=True), 0.97, device=DEV)).__name__ == 'ShapedGAILDiscriminator'
   d = il.GAILDiscriminator(c['S'], c['A'], mk(), 0.97, device=DEV)
   opt = il.AdamW(d, lr=1e-3, weight_decay=0.1)
   with pytest.raises(NotImplementedError):
@@ -814,3 +813,40 @@ def test_device_handoff_equals_stream_dependencies(monkeypatch):
   for a, b in zip(*results):
     assert np.isfinite(a).all()
     np.testing.assert_array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# GAIL with reward shaping (models.py:152-180, reward_shaping=True) against the reference fixture and the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,sn,loss', [('sn_bce', True, 'BCE'), ('plain_pugail', False, 'PUGAIL')])
+def test_gail_reward_shaping_matches_reference(golden_dir, name, sn, loss):
+  from oracle import gail_shaped as ogs
+  g = load(golden_dir, 'gail_shaped')
+  c = gi.gail_shaped_case(91, 'hopper', 32, 96, 2, sn)
+  icfg = Cfg(state_only=False, spectral_norm=sn, loss_function=loss, grad_penalty=0.7, mixup_alpha=1, entropy_bonus=0.01, pos_class_prior=0.7, nonnegative_margin=float('inf'),
+             discriminator=Cfg(hidden_size=c['H'], depth=1, activation='relu', reward_shaping=True, subtract_log_policy=False, reward_function='AIRL'))
+  d = il.GAILDiscriminator(c['S'], c['A'], icfg, 0.97, device=DEV)
+  assert type(d).__name__ == 'ShapedGAILDiscriminator'
+  assert [n for n, _ in d.named_parameters()] == list(g[f'{name}.param_names'])
+  ods = ogs.ShapedState(c['S'], c['A'], c['H'], 0.97, sn)
+  for k in ('Wg', 'bg', 'W1', 'b1', 'W2', 'b2', 'ug', 'vg', 'u1', 'v1', 'u2', 'v2'):
+    getattr(ods, k)[...] = c[k]
+  d.flat.copy_(T(ods.pack()))
+  if sn:
+    for k, v in d.views().items():
+      v.copy_(T(c[k]))
+  opt = il.AdamW(d, lr=1e-3, weight_decay=0.1)
+  for i in range(2):
+    p, e = tbatch(c['policy'][i]), tbatch(c['expert'][i])
+    il.adversarial_imitation_update(None, d, p, e, opt, icfg, eps_gp=T(c['eps'][i]))
+    ogr = ogs.gail_update(ods, c['policy'][i], c['expert'][i], c['eps'][i], lr=1e-3, weight_decay=0.1, grad_penalty=0.7, entropy_bonus=0.01, loss_function=loss, return_grads=True)
+    close(N(opt.grad), g[f'{name}.g_{i + 1}'], f'{name} gradient {i + 1} (reference)', rtol=1e-5, atol_scale=1e-5)
+    close(N(opt.grad), ogr, f'{name} gradient {i + 1} (oracle)', rtol=1e-5, atol_scale=1e-5)
+    close_params(N(d.flat), g[f'{name}.p_{i + 1}'], f'{name} parameters {i + 1}', 1e-3, steps=i + 1)
+    if sn:
+      for k in ('ug', 'vg', 'u1', 'v1', 'u2', 'v2'):
+        close(N(d.views()[k]), g[f'{name}.{k}_{i + 1}'], f'{name} {k} after update {i + 1}', rtol=1e-5, atol_scale=1e-5)
+    d.flat.copy_(T(g[f'{name}.p_{i + 1}'])); ods.unpack_into(g[f'{name}.p_{i + 1}'].copy())
+    r = d.predict_reward(**il.make_gail_input(p['states'], p['actions'], p['next_states'], p['terminals'], None, True, False))
+    close(N(r), g[f'{name}.reward_{i + 1}'], f'{name} reward {i + 1}', rtol=2e-5, atol_scale=1e-5)

@@ -246,3 +246,24 @@ def test_gail_variant_oracle_matches_reference_fixture(golden_dir, name, loss, s
     ref = g[f'{name}.g_{i + 1}']
     assert np.abs(gr - ref).max() <= 1e-5 * np.abs(ref).max()
     np.testing.assert_allclose(gail.predict_reward(ds, xp, 'AIRL', log_policy=lp), g[f'{name}.reward_{i + 1}'], rtol=3e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('name,sn,loss', [('sn_bce', True, 'BCE'), ('plain_pugail', False, 'PUGAIL')])
+def test_gail_shaped_oracle_matches_reference_fixture(golden_dir, name, sn, loss):
+  """oracle/gail_shaped.py (reward shaping: g + (1 - t)(discount h(s') - h(s)), two power iterations of h per call, closed-form gradient penalty)
+  against the reference's autograd: gradients, parameters after AdamW, spectral-norm buffers, rewards."""
+  from oracle import gail_shaped as ogs
+  g = np.load(os.path.join(golden_dir, 'gail_shaped.npz'))
+  c = gi.gail_shaped_case(91, 'hopper', 32, 96, 2, sn)
+  ds = ogs.ShapedState(c['S'], c['A'], c['H'], 0.97, sn)
+  for k in ('Wg', 'bg', 'W1', 'b1', 'W2', 'b2', 'ug', 'vg', 'u1', 'v1', 'u2', 'v2'):
+    getattr(ds, k)[...] = c[k]
+  for i in range(2):
+    gr = ogs.gail_update(ds, c['policy'][i], c['expert'][i], c['eps'][i], lr=1e-3, weight_decay=0.1, grad_penalty=0.7, entropy_bonus=0.01, loss_function=loss, return_grads=True)
+    ref = g[f'{name}.g_{i + 1}']
+    assert np.abs(gr - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert np.abs(ds.pack() - g[f'{name}.p_{i + 1}']).max() <= 2e-6
+    if sn:
+      for k in ('ug', 'vg', 'u1', 'v1', 'u2', 'v2'):
+        np.testing.assert_allclose(getattr(ds, k), g[f'{name}.{k}_{i + 1}'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ogs.predict_reward(ds, c['policy'][i]), g[f'{name}.reward_{i + 1}'], rtol=5e-5, atol=2e-6)

@@ -24,6 +24,7 @@ COMMON = ['steps=260', 'training.start=120', 'evaluation.interval=130', 'evaluat
     ['algorithm=GAIL', 'env=hopper', 'imitation.loss_function=PUGAIL'],
     ['algorithm=GAIL', 'env=walker2d', 'imitation.loss_function=Mixup', 'imitation.discriminator.reward_function=FAIRL'],
     ['algorithm=GAIL', 'env=halfcheetah', 'imitation.discriminator.subtract_log_policy=true'],
+    ['algorithm=GAIL', 'env=hopper', 'imitation.discriminator.reward_shaping=true', 'imitation.discriminator.subtract_log_policy=true'],
     ['algorithm=RED', 'env=hopper', 'imitation.pretraining.iterations=50'],
     ['algorithm=DRIL', 'env=hopper', 'imitation.pretraining.iterations=50'],
     ['algorithm=SAC', 'env=hopper', '+acting.schedule=overlap'],
@@ -50,7 +51,10 @@ def test_train_runs(tmp_path, args):
     assert all(np.isfinite(q).all() for q in metrics['Q_values'])
   if cfg.algorithm == 'GAIL':
     disc = torch.load(tmp_path / 'discriminator.pth', weights_only=False)
-    assert 'g.0.parametrizations.weight.original' in disc and 'g.2.parametrizations.weight.0._v' in disc
+    if cfg.imitation.discriminator.reward_shaping:
+      assert 'g.parametrizations.weight.original' in disc and 'h.0.parametrizations.weight.original' in disc and 'h.2.parametrizations.weight.0._v' in disc
+    else:
+      assert 'g.0.parametrizations.weight.original' in disc and 'g.2.parametrizations.weight.0._v' in disc
 
 
 def test_unsupported_configurations_fail_loudly():
@@ -58,7 +62,7 @@ def test_unsupported_configurations_fail_loudly():
   sys.path.insert(0, ROOT)
   import train
   from imitation_learning_amd import config
-  for extra in (['algorithm=GAIL', 'imitation.discriminator.reward_shaping=true'], ['algorithm=SAC', 'reinforcement.actor.depth=3'],
+  for extra in (['algorithm=GAIL', 'imitation.discriminator.depth=2'], ['algorithm=SAC', 'reinforcement.actor.depth=3'],
                 ['algorithm=RED', 'imitation.discriminator.depth=2']):
     with pytest.raises(NotImplementedError):
       train.train(config.compose(extra + ['env=hopper', 'steps=10'] + COMMON[5:7]))
