@@ -11,6 +11,14 @@ for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
 
 def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+  # libil_hip.so is a build artefact (git-ignored): bring it up to date with the sources before anything imports it. `make` is a no-op when it is
+  # current; without hipcc the tests that need the library fail loudly (there is no fallback to test instead).
+  import shutil
+  import subprocess
+  csrc = os.path.join(ROOT, 'imitation-learning_amd', 'csrc')
+  if shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc'):
+    env = dict(os.environ, PATH=os.environ.get('PATH', '') + ':/opt/rocm/bin')
+    subprocess.run(['make', '-C', csrc, '-j8', '-s'], env=env, check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope='session')
