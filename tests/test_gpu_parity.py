@@ -850,3 +850,55 @@ def test_gail_reward_shaping_matches_reference(golden_dir, name, sn, loss):
     d.flat.copy_(T(g[f'{name}.p_{i + 1}'])); ods.unpack_into(g[f'{name}.p_{i + 1}'].copy())
     r = d.predict_reward(**il.make_gail_input(p['states'], p['actions'], p['next_states'], p['terminals'], None, True, False))
     close(N(r), g[f'{name}.reward_{i + 1}'], f'{name} reward {i + 1}', rtol=2e-5, atol_scale=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# the small-network kernels at the largest environment (Ant: S = 112, A = 8) and ragged batches, against the oracle (no reference fixture at these sizes)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_red_dril_shaped_at_ant_dims_match_oracle():
+  from oracle import dril as odril, gail_shaped as ogs, red as ored
+  # RED, hidden 64, ragged batch of 100
+  c = gi.red_case(63, 'ant', 64, 100, 2)
+  icfg = Cfg(state_only=False, reward_bandwidth_scale=None, discriminator=Cfg(hidden_size=64, depth=1, activation='relu', input_dropout=0, dropout=0))
+  d = il.REDDiscriminator(c['S'], c['A'], icfg, device=DEV)
+  d.flat.copy_(T(c['predictor'])); d.target_flat.copy_(T(c['target']))
+  opt = il.AdamW(d, lr=1e-3, weight_decay=0.0)
+  st = ored.RedState(c['D'], c['H']); st.predictor[:] = c['predictor']; st.target[:] = c['target']
+  for k, b in enumerate(c['batches'], 1):
+    il.target_estimation_update(d, tbatch(b), opt)
+    ored.target_estimation_update(st, np.concatenate([b['states'], b['actions']], 1), b['weights'], lr=1e-3, weight_decay=0.0)
+    close_params(N(d.flat), st.predictor, f'RED ant predictor {k}', 1e-3, steps=k)
+  # DRIL, hidden 64, ragged batch of 80
+  c = gi.dril_case(73, 'ant', 64, 80, 2)
+  a = il.SoftActor(c['S'], c['A'], Cfg(hidden_size=64, depth=1, activation='tanh', input_dropout=0.1, dropout=0.1), device=DEV)
+  a.flat.copy_(T(c['params']))
+  opt = il.AdamW(a, lr=1e-3, weight_decay=0.0)
+  ds = odril.DrilState(c['S'], c['A'], 64, 0.1, 0.1); ds.params[:] = c['params']
+  for k, (b, m0, m1) in enumerate(zip(c['batches'], c['m0'], c['m1']), 1):
+    il.behavioural_cloning_update(a, tbatch(b), opt, masks=(T(m0), T(m1)))
+    odril.bc_update(ds, b, m0, m1, lr=1e-3, weight_decay=0.0)
+    close_params(N(a.flat), ds.params, f'DRIL ant params {k}', 1e-3, steps=k)
+  q = tbatch(c['query'])
+  u = N(a._get_action_uncertainty(q['states'], q['actions'], masks=(T(c['q_m0']), T(c['q_m1']))))
+  ou = odril.uncertainty(ds, c['query']['states'], c['query']['actions'], c['q_m0'], c['q_m1'])
+  a.flat.copy_(T(ds.params)); u = N(a._get_action_uncertainty(q['states'], q['actions'], masks=(T(c['q_m0']), T(c['q_m1']))))
+  assert np.abs(u - ou).max() <= 1e-4 * max(np.abs(ou).max(), 1e-30)
+  # reward-shaping GAIL, hidden 64, ragged batch of 72, state_only
+  c = gi.gail_shaped_case(92, 'ant', 64, 72, 1, True)
+  icfg = Cfg(state_only=False, spectral_norm=True, loss_function='BCE', grad_penalty=1.0, mixup_alpha=1, entropy_bonus=0.0, pos_class_prior=0.7, nonnegative_margin=float('inf'),
+             discriminator=Cfg(hidden_size=64, depth=1, activation='relu', reward_shaping=True, subtract_log_policy=False, reward_function='GAIL'))
+  dd = il.GAILDiscriminator(c['S'], c['A'], icfg, 0.99, device=DEV)
+  ods = ogs.ShapedState(c['S'], c['A'], 64, 0.99, True)
+  for k in ('Wg', 'bg', 'W1', 'b1', 'W2', 'b2', 'ug', 'vg', 'u1', 'v1', 'u2', 'v2'):
+    getattr(ods, k)[...] = c[k]
+  dd.flat.copy_(T(ods.pack()))
+  for k, v in dd.views().items():
+    v.copy_(T(c[k]))
+  opt = il.AdamW(dd, lr=1e-3, weight_decay=0.0)
+  il.adversarial_imitation_update(None, dd, tbatch(c['policy'][0]), tbatch(c['expert'][0]), opt, icfg, eps_gp=T(c['eps'][0]))
+  og = ogs.gail_update(ods, c['policy'][0], c['expert'][0], c['eps'][0], lr=1e-3, weight_decay=0.0, grad_penalty=1.0, return_grads=True)
+  close(N(opt.grad), og, 'shaped GAIL ant gradient', rtol=1e-5, atol_scale=1e-5)
+  p = tbatch(c['policy'][0])
+  dd.flat.copy_(T(ods.pack()))
+  close(N(dd.predict_reward(p['states'], p['actions'], p['next_states'], p['terminals'])), ogs.predict_reward(ods, c['policy'][0], 'GAIL'), 'shaped GAIL ant reward', rtol=2e-5, atol_scale=1e-5)
