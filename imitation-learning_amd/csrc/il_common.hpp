@@ -26,6 +26,33 @@ int il_set_error(int code, const char* fmt, ...);
 //   lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
 //   lane l holds   D[row = 4*(l>>4) + reg][col = l&15], reg = 0..3.
 // ---------------------------------------------------------------------------------------------
+// Loads through a pointer the compiler cannot prove to be global memory (every pointer that is a FIELD of a by-value descriptor struct is generic)
+// become FLAT instructions. FLAT loads count against both vmcnt and lgkmcnt and may return out of order with LDS traffic, so hipcc puts
+// `s_waitcnt vmcnt(0) lgkmcnt(0)` before the first use of ANY of them: a wave that requested its 16-load weight panel waited for all of it before the
+// first MFMA, and LDS reads could not overlap it. An explicit global address space makes them global_load: precise vmcnt(N) waits, MFMAs start as the
+// operands arrive.
+template <class T>
+__device__ __forceinline__ T gload(const T* p) { return *(const __attribute__((address_space(1))) T*)p; }
+__device__ __forceinline__ f32x4 gload4(const float* p) { return *(const __attribute__((address_space(1))) f32x4*)p; }
+
+// Whole-descriptor version of the same: a descriptor fetched from memory (population axis: d = dL[blockIdx.y]) carries generic pointers, and
+// ONE pending flat access (a flat_store of an activation slab is enough) makes the compiler turn every later wait into vmcnt(0) lgkmcnt(0).
+// Round-tripping the fields through address space 1 lets address-space inference type every derived access as global.
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) { auto g = (__attribute__((address_space(1))) T*)p; asm volatile("" : "+s"(g)); return (T*)g; }
+__device__ __forceinline__ void globalize(il_adam& o) { o.m = as_global(o.m); o.v = as_global(o.v); o.step = as_global(o.step); }
+__device__ __forceinline__ void globalize(il_batch& b) {
+  b.states = as_global(b.states); b.actions = as_global(b.actions); b.rewards = as_global(b.rewards); b.next_states = as_global(b.next_states);
+  b.terminals = as_global(b.terminals); b.weights = as_global(b.weights); b.absorbing = as_global(b.absorbing);
+}
+__device__ __forceinline__ void globalize(il_sac& d) {
+  d.actor = as_global(d.actor); d.critic = as_global(d.critic); d.target = as_global(d.target); d.log_alpha = as_global(d.log_alpha);
+  d.actor_grad = as_global(d.actor_grad); d.critic_grad = as_global(d.critic_grad); d.alpha_grad = as_global(d.alpha_grad);
+  globalize(d.actor_opt); globalize(d.critic_opt); globalize(d.alpha_opt);
+  d.workspace = as_global(d.workspace); d.noise_counter = as_global(d.noise_counter); d.out_logp = as_global(d.out_logp); d.out_q = as_global(d.out_q);
+  d.sync = as_global(d.sync);
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // Cross-lane sums on DPP (data-parallel primitives: the operand of a VALU op is fetched from another lane of the same 16-lane

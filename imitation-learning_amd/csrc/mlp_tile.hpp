@@ -22,11 +22,11 @@ __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; retur
 //   MODE 2: arbitrary row stride / kvalid (first layer with odd input widths): four clamped dword loads
 template <int MODE>
 __device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int k, int kvalid) {
-  if (MODE == 0) return *reinterpret_cast<const f32x4*>(p + k);
-  if (MODE == 1) return *reinterpret_cast<const f32x4*>(p + min(k, kvalid - 4));
+  if (MODE == 0) return gload4(p + k);
+  if (MODE == 1) return gload4(p + min(k, kvalid - 4));
   f32x4 r;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = p[min(k + i, kvalid - 1)];
+  for (int i = 0; i < 4; ++i) r[i] = gload(p + min(k + i, kvalid - 1));
   return r;
 }
 
@@ -128,7 +128,7 @@ __device__ __forceinline__ void tile_bwd_dx_impl(const float* dYs, int ldy, int 
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { const int n = n0 + 16 * u + 4 * g + s; b[u][s] = wp[(size_t)(FULL ? n : min(n, Nvalid - 1)) * ldw]; }
+        for (int s = 0; s < 4; ++s) { const int n = n0 + 16 * u + 4 * g + s; b[u][s] = gload(wp + (size_t)(FULL ? n : min(n, Nvalid - 1)) * ldw); }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(yr + n0 + 16 * u);
@@ -142,7 +142,7 @@ __device__ __forceinline__ void tile_bwd_dx_impl(const float* dYs, int ldy, int 
       const f32x4 a = *reinterpret_cast<const f32x4*>(yr + n0);
       float b[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) { const int n = n0 + 4 * g + s; b[s] = wp[(size_t)(FULL ? n : min(n, Nvalid - 1)) * ldw]; }  // rows >= Nvalid: dYs columns are zero there
+      for (int s = 0; s < 4; ++s) { const int n = n0 + 4 * g + s; b[s] = gload(wp + (size_t)(FULL ? n : min(n, Nvalid - 1)) * ldw); }  // rows >= Nvalid: dYs columns are zero there
       acc0 = mfma16(a[0], b[0], acc0);
       acc1 = mfma16(a[1], b[1], acc1);
       acc0 = mfma16(a[2], b[2], acc0);
@@ -183,7 +183,7 @@ __device__ __forceinline__ void tile_packed(const float* As, int lda, int H, con
     for (; kb + 16 <= nb; kb += 16) {
       f32x4 b[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) b[u] = *reinterpret_cast<const f32x4*>(pp + (size_t)(kb + u) * 256);
+      for (int u = 0; u < 16; ++u) b[u] = gload4(pp + (size_t)(kb + u) * 256);
       __builtin_amdgcn_sched_barrier(0);  // all 16 KiB of the panel requested before the first MFMA
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
@@ -197,7 +197,7 @@ __device__ __forceinline__ void tile_packed(const float* As, int lda, int H, con
     for (; kb + 4 <= nb; kb += 4) {
       f32x4 b[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const f32x4*>(pp + (size_t)(kb + u) * 256);
+      for (int u = 0; u < 4; ++u) b[u] = gload4(pp + (size_t)(kb + u) * 256);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -232,7 +232,7 @@ __device__ __forceinline__ void tile_fwd_small(const float* Xs, int ldx, int K, 
   const float* wr = W + (size_t)min(j, N - 1) * ldw;  // clamped row: no divergent branch around the load
   for (int k0 = wave * 16; k0 < K; k0 += nw * 16) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(Xs + j * ldx + k0 + 4 * g);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(wr + k0 + 4 * g);  // columns j >= N produce garbage that Os below discards
+    const f32x4 b = gload4(wr + k0 + 4 * g);  // columns j >= N produce garbage that Os below discards
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = mfma16(a[s], b[s], acc);
   }

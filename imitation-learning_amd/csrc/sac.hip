@@ -63,6 +63,7 @@ __device__ __forceinline__ void head_sample(float mean, float ls_raw, float eps,
 // Every public entry point derives the copies it reads from the parameters inside the same call, so they can never be stale.
 __global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask, const il_sac* __restrict__ dL) {
   if (dL) d = dL[blockIdx.z];  // population axis: one descriptor per learner (wave-uniform scalar loads)
+  globalize(d);
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, IN = S + A;
   const int net = blockIdx.y;
   const SacWs ws = sac_ws(S, A, H, d.batch);
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const 
                                                     const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
+  globalize(d); globalize(b);
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
   const int nt = B / IL_TILE_R;
   const bool is_cur = (mode == 2) || (mode == 0 && (int)blockIdx.x >= nt);
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const 
   // Requested / computed before the first barrier, consumed after the MFMA loops: the biases of this wave's 16 columns, and for the head
   // threads their noise sample (Philox + Box-Muller is ~1 us of dependent ALU work that needs nothing from the MLP) and absorbing flag.
   const int pc = min(wave * 16 + j, H - 1);
-  const float pb1 = net.b1[pc], pb2 = net.b2[pc];
+  const float pb1 = gload(net.b1 + pc), pb2 = gload(net.b2 + pc);
   const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
   float e_pre = 0.f, absorb_pre = 0.f;
   if (tid < IL_TILE_R * A) {
@@ -186,6 +188,7 @@ __device__ __forceinline__ void critic_head(const float* H2s, int ldh, int H, co
 __global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
+  globalize(d); globalize(b);
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
   int net, tile;
@@ -201,10 +204,10 @@ __global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b, const
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   // biases of this wave's 16 columns and this lane's slice of w3: requested before the first barrier, consumed after the MFMA loops
   const int pc = min(wave * 16 + j, H - 1);
-  const float pb1 = p.b1[pc], pb2 = p.b2[pc], pb3 = p.b3[0];
+  const float pb1 = gload(p.b1 + pc), pb2 = gload(p.b2 + pc), pb3 = gload(p.b3);
   float w3v[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) w3v[u] = p.W3[min(lane + 64 * u, H - 1)];
+  for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
   if (is_target) load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, W + ws.n_a2, A, A, row0, IL_TILE_R);
   else load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R);
   __syncthreads();
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b, const
 __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
+  globalize(d); globalize(b);
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
   int k, tile;
@@ -261,8 +265,8 @@ __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b, const
   const int pn = threadIdx.x >> 2, pr4 = (threadIdx.x & 3) * 4;
   const bool pre = blockDim.x == 4 * H;   // one (feature, row group) item per thread: true for every supported hidden size
   f32x4 hv2 = zero4(); float w3p = 0.f;
-  if (pre) { hv2 = *reinterpret_cast<const f32x4*>(h2 + (size_t)pn * B + row0 + pr4); w3p = p.W3[pn]; }
-  const f32x4 hv1 = *reinterpret_cast<const f32x4*>(h1 + (size_t)min(wave * 16 + j, H - 1) * B + row0 + 4 * g);
+  if (pre) { hv2 = gload4(h2 + (size_t)pn * B + row0 + pr4); w3p = gload(p.W3 + pn); }
+  const f32x4 hv1 = gload4(h1 + (size_t)min(wave * 16 + j, H - 1) * B + row0 + 4 * g);
   if (d.sync) {   // the rewards come from the discriminator branch on another stream: ready once every reward workgroup of THIS update has signalled
     long long* sy = reinterpret_cast<long long*>(d.sync);
     sync_wait(sy, IL_SYNC_REWARDS, (sy[IL_SYNC_MAIN_EPOCH] + 1) * (long long)nt);
@@ -319,7 +323,7 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
   const float* h2 = W + ws.a_h2; const float* h1 = W + ws.a_h1;
   // epilogue operands of the two back-propagation GEMMs (this lane's 4 rows of one feature of h2 / h1): requested now, used after the MFMA loops
   const size_t poff = (size_t)min(wave * 16 + j, H - 1) * B + row0 + 4 * g;
-  const f32x4 hv2p = *reinterpret_cast<const f32x4*>(h2 + poff), hv1p = *reinterpret_cast<const f32x4*>(h1 + poff);
+  const f32x4 hv2p = gload4(h2 + poff), hv1p = gload4(h1 + poff);
   const bool stamp = tile == 0;
   IL_STAMP(stamp, 24);
   for (int i = tid; i < IL_TILE_R * ldz; i += blockDim.x) DZ3s[i] = 0.f;
@@ -381,6 +385,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
                                                         const il_batch* __restrict__ bL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
+  globalize(d); globalize(b);
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
   int k, tile;
@@ -396,10 +401,10 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   // biases of this wave's 16 columns and this lane's slice of w3: requested before the first barrier, used after the MFMA loops
   const int pc = min(wave * 16 + j, H - 1);
-  const float pb1 = p.b1[pc], pb2 = p.b2[pc], pb3 = p.b3[0];
+  const float pb1 = gload(p.b1 + pc), pb2 = gload(p.b2 + pc), pb3 = gload(p.b3);
   float w3v[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) w3v[u] = p.W3[min(lane + 64 * u, H - 1)];
+  for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
   load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, IL_TILE_R);
   __syncthreads();
   IL_STAMP(stamp, 17);
@@ -519,10 +524,10 @@ __device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, 
   const int kc = min(kb + j, Kvalid - 1);
   const float* xp = XT ? x + (size_t)kc * B + 4 * g : x + (size_t)(4 * g) * ldx + kc;
   auto ldx4 = [&](int r0) -> f32x4 {
-    if (XT) return *reinterpret_cast<const f32x4*>(xp + r0);
+    if (XT) return gload4(xp + r0);
     f32x4 v;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) v[s] = xp[(size_t)(r0 + s) * ldx];
+    for (int s = 0; s < 4; ++s) v[s] = gload(xp + (size_t)(r0 + s) * ldx);
     return v;
   };
   // The Adam operands of this lane's four dW elements do not depend on the products: fetch them before the MFMA loop so that their
@@ -533,14 +538,14 @@ __device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t o = poff + (int64_t)min(n0 + 4 * g + r, Nvalid - 1) * Kvalid + kk;
-      pp[r] = a.params[o]; mm[r] = a.opt.m[o]; vv[r] = a.opt.v[o];
+      pp[r] = gload(a.params + o); mm[r] = gload(a.opt.m + o); vv[r] = gload(a.opt.v + o);
     }
   }
   int r0 = 0;
   for (; r0 + 16 * U <= B; r0 += 16 * U) {
     f32x4 av[U], bv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { av[u] = *reinterpret_cast<const f32x4*>(dzp + r0 + 16 * u); bv[u] = ldx4(r0 + 16 * u); }
+    for (int u = 0; u < U; ++u) { av[u] = gload4(dzp + r0 + 16 * u); bv[u] = ldx4(r0 + 16 * u); }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       acc0 = mfma16(av[u][0], bv[u][0], acc0);
@@ -550,7 +555,7 @@ __device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, 
     }
   }
   for (; r0 < B; r0 += 16) {
-    const f32x4 av = *reinterpret_cast<const f32x4*>(dzp + r0), bv = ldx4(r0);
+    const f32x4 av = gload4(dzp + r0), bv = ldx4(r0);
     acc0 = mfma16(av[0], bv[0], acc0);
     acc1 = mfma16(av[1], bv[1], acc1);
     acc0 = mfma16(av[2], bv[2], acc0);
