@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
                                                    const il_batch* __restrict__ polL, const il_batch* __restrict__ expL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (dL) { d = dL[blockIdx.z]; pol = polL[blockIdx.z]; exp = expL[blockIdx.z]; }  // population axis
+  globalize(d); globalize(pol); globalize(exp); globalize(x);
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch, Dp = (D + 3) & ~3, ldw = Dp + 4;
   const int tile = blockIdx.x, pass = blockIdx.y, npass = gridDim.y, nt = gridDim.x, row0 = tile * IL_TILE_R, tid = threadIdx.x;
   const int nrows = min(IL_TILE_R, B - row0);
@@ -402,6 +403,7 @@ __host__ __device__ inline int gail_calls(const il_disc& d) { return (d.loss_fun
 // grid = ceil(P / 256): one gradient element per thread, slabs summed in tile order (deterministic)
 __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const il_disc* __restrict__ dL) {
   if (dL) d = dL[blockIdx.y];
+  globalize(d);
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch;
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
   const DiscWs wsl = disc_ws(D, H, B);
@@ -447,6 +449,7 @@ __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, floa
                                                      const il_batch* __restrict__ bL, float* const* __restrict__ outL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; out_r = outL[blockIdx.y]; out_logit = nullptr; }
+  globalize(d); globalize(b); out_r = as_global(out_r);
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, Dp = (D + 3) & ~3, ldw = Dp + 4;
   const int row0 = blockIdx.x * IL_TILE_R, tid = threadIdx.x, nrows = min(IL_TILE_R, b.n - row0);
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);

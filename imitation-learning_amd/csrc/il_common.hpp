@@ -53,6 +53,20 @@ __device__ __forceinline__ void globalize(il_sac& d) {
   d.sync = as_global(d.sync);
 }
 
+__device__ __forceinline__ void globalize(il_disc& d) {
+  d.params = as_global(d.params); d.u1 = as_global(d.u1); d.v1 = as_global(d.v1); d.u2 = as_global(d.u2); d.v2 = as_global(d.v2); d.grad = as_global(d.grad);
+  globalize(d.opt); d.workspace = as_global(d.workspace); d.noise_counter = as_global(d.noise_counter); d.sync = as_global(d.sync);
+}
+__device__ __forceinline__ void globalize(il_gail_extra& x) {
+  x.eps_mix = as_global(x.eps_mix); x.logit_offset_policy = as_global(x.logit_offset_policy); x.logit_offset_expert = as_global(x.logit_offset_expert);
+}
+
+__device__ __forceinline__ void globalize(il_sample_args& a) {
+  a.state = as_global(a.state);
+  a.ring_state_a = as_global(a.ring_state_a); a.ring_a = as_global(a.ring_a); a.idx_a = as_global(a.idx_a); a.rows_a = as_global(a.rows_a);
+  a.ring_state_b = as_global(a.ring_state_b); a.ring_b = as_global(a.ring_b); a.idx_b = as_global(a.idx_b); a.rows_b = as_global(a.rows_b);
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // Cross-lane sums on DPP (data-parallel primitives: the operand of a VALU op is fetched from another lane of the same 16-lane

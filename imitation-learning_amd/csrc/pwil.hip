@@ -136,15 +136,10 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // 256 threads stage the candidate lists in LDS, then ONE wave merges: a round is a local min over the lane's own list heads, a DPP min over
 // the wave and a readlane of the winner's weight - no barrier and no LDS round trip between lanes (the 4-value __shfl_xor arg-min of a
 // 256-thread version cost 1.6 us per round, i.e. 44 us for the 26 atoms of a step at N = 25k, T = 1000).
-__global__ __launch_bounds__(256) void k_pwil_merge(il_pwil d, int G, int K, const PwCand* __restrict__ cand, float* __restrict__ out) {
-  __shared__ PwCand sc[PW_LDS_CAND];
-  const int tid = threadIdx.x;
-  const bool staged = G * K <= PW_LDS_CAND;
-  if (staged) for (int i = tid; i < G * K; i += 256) sc[i] = cand[i];
-  __syncthreads();
-  if (tid >= 64) return;
-  const PwCand* cl = staged ? sc : cand;
-  const int lane = tid;
+// The serial merge of one wave over the per-chunk candidate lists `cl` (instantiated once for the LDS copy and once for the lists in
+// HBM: a pointer that may be either is generic, and every head fetch of this latency-bound loop would be a flat_load).
+__device__ __forceinline__ void pwil_merge_wave(const il_pwil& d, int G, int K, const PwCand* __restrict__ cl, float* __restrict__ out) {
+  const int lane = threadIdx.x;
   int ptr[PW_MAXQ];
 #pragma unroll
   for (int q = 0; q < PW_MAXQ; ++q) ptr[q] = 0;
@@ -179,6 +174,17 @@ __global__ __launch_bounds__(256) void k_pwil_merge(il_pwil d, int G, int K, con
     }
   }
   if (lane == 0) out[0] = (float)(d.reward_scale * exp(-d.reward_bandwidth * cost));
+}
+
+__global__ __launch_bounds__(256) void k_pwil_merge(il_pwil d, int G, int K, const PwCand* __restrict__ cand, float* __restrict__ out) {
+  __shared__ PwCand sc[PW_LDS_CAND];
+  const int tid = threadIdx.x;
+  const bool staged = G * K <= PW_LDS_CAND;
+  if (staged) for (int i = tid; i < G * K; i += 256) sc[i] = cand[i];
+  __syncthreads();
+  if (tid >= 64) return;
+  if (staged) pwil_merge_wave(d, G, K, sc, out);
+  else pwil_merge_wave(d, G, K, cand, out);
 }
 
 static int pwil_take(const il_pwil* d) { return (int)ceil(d->agent_weight * (double)d->n_atoms) + 2; }   // most atoms one step can consume

@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256) void k_gather2(const float* __restrict__ ring_
 
 // population axis: one workgroup per learner draws (own MT19937 state), then one launch gathers every learner's rows
 __global__ __launch_bounds__(256) void k_sample2_pop(const il_sample_args* __restrict__ aL, int n) {
-  const il_sample_args a = aL[blockIdx.x];
+  il_sample_args a = aL[blockIdx.x];
+  globalize(a);
   __shared__ MtShared sh;
   const int tid = threadIdx.x;
   for (int i = tid; i < MT_N; i += 256) sh.mt[i] = a.state[i];
@@ -291,7 +292,8 @@ __global__ __launch_bounds__(256) void k_sample2_pop(const il_sample_args* __res
   if (tid == 0) a.state[MT_N] = (uint32_t)sh.pos;
 }
 __global__ __launch_bounds__(256) void k_gather2_pop(const il_sample_args* __restrict__ aL, int n) {
-  const il_sample_args a = aL[blockIdx.y];
+  il_sample_args a = aL[blockIdx.y];
+  globalize(a);
   const int row4_a = a.row_floats_a / 4, row4_b = a.row_floats_b / 4;
   const int na = n * row4_a, nb = a.ring_b ? n * row4_b : 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += gridDim.x * blockDim.x) {

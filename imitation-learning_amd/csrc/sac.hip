@@ -820,7 +820,8 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
 // gridDim.y (z for k_repack) selects the learner. Kernels are latency-bound at B = 256 (16-64 workgroups): a population fills the chip.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ dL, const il_batch* __restrict__ bL, int kind, uint32_t flags) {
-  const il_sac d = dL[blockIdx.y]; const il_batch b = bL[blockIdx.y];
+  il_sac d = dL[blockIdx.y]; il_batch b = bL[blockIdx.y];
+  globalize(d); globalize(b);
   const DwArgs a = kind ? actor_dw_args(&d, &b, flags) : critic_dw_args(&d, flags);
   dw_adam_body<4>(a, (int)blockIdx.x, (int)gridDim.x);   // (confining a learner to one XCD so that its dW operands cross the fabric once was measured: no gain)
 }
