@@ -53,7 +53,7 @@ __device__ __forceinline__ void dril_forward(const il_dril& d, const il_batch& b
     int k = 0;
     for (; k + 2 <= S; k += 2) { s0 = fmaf(x[k], w[k], s0); s1 = fmaf(x[k + 1], w[k + 1], s1); }
     if (k < S) s0 = fmaf(x[k], w[k], s0);
-    const float ms = keep_scale(mask_hid, ((size_t)row0 * rep + v) * H + j, d.p, d.noise_seed, ctr, IL_STREAM_DROP_HID);
+    const float ms = (row0 + v / rep < b.n) ? keep_scale(mask_hid, ((size_t)row0 * rep + v) * H + j, d.p, d.noise_seed, ctr, IL_STREAM_DROP_HID) : 0.f;   // rows past the batch: no mask entry exists
     Ms[v * ldh + j] = ms;
     Hh[v * ldh + j] = tanhf(((s0 + s1) + d.params[lay.ob1 + j]) * ms);
   }

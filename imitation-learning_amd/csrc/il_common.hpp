@@ -195,7 +195,7 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
 // Bounded: after IL_SYNC_SPIN_LIMIT polls the waiter gives up, counts a timeout (the host checks it) and proceeds, so a runtime that
 // serialises the two queues (a counter-collecting profiler) can never hang the GPU.
 // ---------------------------------------------------------------------------------------------
-#define IL_SYNC_SPIN_LIMIT 20000
+#define IL_SYNC_SPIN_LIMIT (1 << 20)   // ~1 s of polling: the first replay of a freshly instantiated graph can reach the device >10 ms after the other branch's
 __device__ __forceinline__ void sync_signal(long long* ctr) {   // all threads of the workgroup, after their stores
   __syncthreads();
 #ifdef IL_SYNC_UNSAFE

@@ -19,7 +19,7 @@
 struct SacWs {  // float offsets into il_sac.workspace
   int64_t a_h1, a_h2, a_xpre, a_eps, a_lsraw, a_anew, a_logp, n_a2, n_logp2;
   int64_t c_x0, c_h1, c_h2, c_q, t_q, c_dz3, c_dz2, c_dz1, q_min;
-  int64_t p_q, p_g, a_dz3, a_dz2, a_dz1, alpha_part, pair_ctr;
+  int64_t p_q, p_g, a_dz3, a_dz2, a_dz1, alpha_part, pair_ctr, chain_ctr;
   int64_t pk_af, pk_ab, pk_cf, pk_cb, pk_tf, pk_tb;  // lane-ordered copies of the H x H layers (mlp_tile.hpp "Packed hidden-layer weights")
   int64_t total;
 };
@@ -31,7 +31,7 @@ __host__ __device__ inline SacWs sac_ws(int S, int A, int H, int B) {
   w.n_a2 = take(BA); w.n_logp2 = take(B);
   w.c_x0 = take((int64_t)B * (S + A)); w.c_h1 = take(2 * BH); w.c_h2 = take(2 * BH); w.c_q = take(2 * B); w.t_q = take(2 * B);
   w.c_dz3 = take(2 * B); w.c_dz2 = take(2 * BH); w.c_dz1 = take(2 * BH); w.q_min = take(B);
-  w.p_q = take(2 * B); w.p_g = take(2 * BA); w.a_dz3 = take((int64_t)B * 16); w.a_dz2 = take(BH); w.a_dz1 = take(BH); w.alpha_part = take(B / IL_TILE_R + 4); w.pair_ctr = take(B / IL_TILE_R + 4);
+  w.p_q = take(2 * B); w.p_g = take(2 * BA); w.a_dz3 = take((int64_t)B * 16); w.a_dz2 = take(BH); w.a_dz1 = take(BH); w.alpha_part = take(B / IL_TILE_R + 4); w.pair_ctr = take(B / IL_TILE_R + 4); w.chain_ctr = take(B / IL_TILE_R + 4);
   const int64_t HH = (int64_t)H * H;
   w.pk_af = take(HH); w.pk_ab = take(HH); w.pk_cf = take(2 * HH); w.pk_cb = take(2 * HH); w.pk_tf = take(2 * HH); w.pk_tb = take(2 * HH);
   w.total = o;
@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask, const i
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, IN = S + A;
   const int net = blockIdx.y;
   const SacWs ws = sac_ws(S, A, H, d.batch);
-  if (blockIdx.x == 0 && blockIdx.y == 0)   // arrival counters of k_policy_critic's tile pairs (they reset themselves; this covers a reused arena)
-    for (int i = threadIdx.x; i < d.batch / IL_TILE_R; i += blockDim.x) reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr)[i] = 0u;
+  if (blockIdx.x == 0 && blockIdx.y == 0)   // arrival counters of k_policy_critic's tile pairs and of k_sac_chain's tiles (they reset themselves; this covers a reused arena)
+    for (int i = threadIdx.x; i < d.batch / IL_TILE_R; i += blockDim.x) { reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr)[i] = 0u; reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr)[i] = 0u; }
   if (!((mask >> net) & 1u)) return;
   const int64_t HH = (int64_t)H * H, ns = net_stride(IN, H, 1);
   const float* W2; float* pf; float* pb;
@@ -96,15 +96,10 @@ __global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask, const i
 }
 
 // mode: 0 = next rows then current rows (grid 2*nt), 1 = next only, 2 = current only
-__global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, int mode,
-                                                    const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
-  globalize(d); globalize(b);
+__device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, bool is_cur, int tile,
+                                               float* smem) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
-  const int nt = B / IL_TILE_R;
-  const bool is_cur = (mode == 2) || (mode == 0 && (int)blockIdx.x >= nt);
-  const int tile = (int)blockIdx.x % nt, row0 = tile * IL_TILE_R;
+  const int row0 = tile * IL_TILE_R;
   const int Sp = round_up16(S), ldx = Sp + 4, ldh = H + 4;
   float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* part = H2s + IL_TILE_R * ldh; float* Os = part + (blockDim.x >> 6) * 256;
   float* red = Os + 256;
@@ -171,6 +166,16 @@ __global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const 
   (void)red;
 }
 
+__global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, int mode,
+                                                    const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
+  globalize(d); globalize(b);
+  const int nt = d.batch / IL_TILE_R;
+  const bool is_cur = (mode == 2) || (mode == 0 && (int)blockIdx.x >= nt);
+  actor_fwd_tile(d, b, eps_next, eps_cur, is_cur, (int)blockIdx.x % nt, smem);
+}
+
 // ---------------------------------------------------------------------------------------------
 // critic forward. net 0,1: critic_k(s, a) keeping h1, h2, x0 ; net 2,3: target_k(s', a').   grid = nt * nnets
 // first_net: 0 => all four (critic step); used with nnets=4.
@@ -185,14 +190,30 @@ __device__ __forceinline__ void critic_head(const float* H2s, int ldh, int H, co
   }
 }
 
-__global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
-  globalize(d); globalize(b);
+// Per-tile arrival counter of the fused forward + critic-loss launch (k_sac_chain): 0 -> 1 (actor on s' done) -> 3 (both target critics done)
+// -> 5 (both critics have read the targets; the one that sees 4 resets it to 0 for the next launch). Producer side: every thread's stores,
+// barrier, ONE agent-scope release; consumer side: ONE polling lane, an agent-scope acquire, barrier (cf. sync_signal / sync_wait).
+__device__ __forceinline__ void tile_arrive(unsigned* ctr) {
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tile_await(unsigned* ctr, unsigned target, unsigned* timeouts) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > IL_SYNC_SPIN_LIMIT) { __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+  __syncthreads();
+}
+
+// Forward of one critic-shaped network on one 16-row tile. net 0,1: critic_k(s, a) keeping h1, h2 (and x0 for net 0) for the weight gradients;
+// net 2,3: target_k(s', a'). Leaves H1s / H2s (post-ReLU activations) and q16[r] = Q in LDS. `await` != NULL (target networks inside k_sac_chain):
+// a' of this tile is still being produced by another workgroup of the same launch; everything that does not need it is done first.
+__device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch& b, int net, int tile, float* smem, unsigned* await, unsigned* timeouts) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
-  const int nt = B / IL_TILE_R;
-  int net, tile;
-  xcd_tile_net((int)blockIdx.x, nt, 4, tile, net);
   const int row0 = tile * IL_TILE_R;
   const bool is_target = net >= 2; const int k = net & 1;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
@@ -208,7 +229,11 @@ __global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b, const
   float w3v[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
-  if (is_target) load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, W + ws.n_a2, A, A, row0, IL_TILE_R);
+  if (is_target && await) {
+    load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, IL_TILE_R);   // s' columns, zero elsewhere
+    tile_await(await, 1u, timeouts);
+    for (int i = threadIdx.x; i < IL_TILE_R * A; i += blockDim.x) { const int r = i / A, c = i - r * A; Xs[r * ldx + S + c] = W[ws.n_a2 + (size_t)(row0 + r) * A + c]; }
+  } else if (is_target) load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, W + ws.n_a2, A, A, row0, IL_TILE_R);
   else load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R);
   __syncthreads();
   if (net == 0)
@@ -235,9 +260,17 @@ __global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b, const
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int n = lane + 64 * u; if (n < H) sq += H2s[r * ldh + n] * w3v[u]; }
     sq = wave_sum(sq);
-    if (lane == 0) W[(is_target ? ws.t_q : ws.c_q) + (size_t)k * B + row0 + r] = sq + pb3;
+    if (lane == 0) { W[(is_target ? ws.t_q : ws.c_q) + (size_t)k * B + row0 + r] = sq + pb3; q16[r] = sq + pb3; }
   }
-  (void)q16;
+}
+
+__global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
+  globalize(d); globalize(b);
+  int net, tile;
+  xcd_tile_net((int)blockIdx.x, d.batch / IL_TILE_R, 4, tile, net);
+  critic_fwd_tile(d, b, net, tile, smem, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -281,7 +314,6 @@ __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b, const
     const float dq = (b.weights[(size_t)row * b.ld_weights] * (2.f * (q - y))) / (float)B;
     dz3s[threadIdx.x] = dq;
     W[ws.c_dz3 + (size_t)k * B + row] = dq;
-    if (k == 0) W[ws.q_min + row] = fminf(q, W[ws.c_q + B + row]);
   }
   if (blockIdx.x == 0 && threadIdx.x == 64) adam_tick(d.critic_opt);  // consumed by the following k_dw_adam / il_adam_step (a lane that is idle in this phase)
   __syncthreads();
@@ -291,18 +323,119 @@ __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b, const
     const float w3 = pre ? w3p : p.W3[n];
     f32x4 o;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { o[q] = hv[q] > 0.f ? dz3s[r4 + q] * w3 : 0.f; DZ2s[(r4 + q) * ldh + n] = o[q]; }
+    for (int q = 0; q < 4; ++q) { const float m = hv[q] > 0.f ? w3 : 0.f; DZ2s[(r4 + q) * ldh + n] = m; o[q] = dz3s[r4 + q] * m; }
     *reinterpret_cast<f32x4*>(gdz2 + (size_t)n * B + row0 + r4) = o;
   }
   __syncthreads();
+  // dz1 = dQ * ([h1 > 0] (m . W2)) with m = [h2 > 0] w3: the row factor dQ is applied AFTER the GEMM, so that k_sac_chain can run the GEMM
+  // before the rewards (hence dQ) exist; every path uses this order, which keeps them bit-identical to each other.
   tile_bwd_packed(DZ2s, ldh, H, W + ws.pk_cb + (size_t)k * H * H, [&](int kb, f32x4 acc) {
     const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
     const f32x4 hv = (kb == wave * 16) ? hv1 : *reinterpret_cast<const f32x4*>(h1 + off);
     f32x4 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = hv[r] > 0.f ? acc[r] : 0.f;
+    for (int r = 0; r < 4; ++r) o[r] = dz3s[4 * g + r] * (hv[r] > 0.f ? acc[r] : 0.f);
     *reinterpret_cast<f32x4*>(gdz1 + off) = o;
   });
+}
+
+// Critic-loss backward of (critic k, tile) continuing from critic_fwd_tile in the SAME workgroup: h1, h2 and Q are still in LDS, so nothing is
+// re-read from HBM. Same arithmetic, in the same order, as k_critic_bwd, in two parts: `_gemm` needs neither the targets nor the rewards
+// (G = [h1 > 0] ((w3 [h2 > 0]) . W2), left in LDS over h1; m = w3 [h2 > 0] over h2) and runs before the waits; `_scale` forms dQ and scales.
+__device__ __forceinline__ void critic_bwd_resident_gemm(const il_sac& d, int k, float* smem) {
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
+  const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh;
+  const SacWs ws = sac_ws(S, A, H, B);
+  const MlpView p = mlp_view(d.critic + k * net_stride(IN, H, 1), IN, H, 1);
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const bool pre = blockDim.x == 4 * H;
+  const float w3p = pre ? gload(p.W3 + (threadIdx.x >> 2)) : 0.f;
+  __syncthreads();   // the Q pass of critic_fwd_tile has read h2
+  for (int i = threadIdx.x; i < 4 * H; i += blockDim.x) {
+    const int n = i >> 2, r4 = (i & 3) * 4;
+    const float w3 = pre ? w3p : p.W3[n];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { float* h = H2s + (r4 + q) * ldh + n; *h = *h > 0.f ? w3 : 0.f; }
+  }
+  __syncthreads();
+  tile_bwd_packed(H2s, ldh, H, d.workspace + ws.pk_cb + (size_t)k * H * H, [&](int kb, f32x4 acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { float* h = H1s + (4 * g + r) * ldh + kb + j; *h = *h > 0.f ? acc[r] : 0.f; }   // each element owned by one lane
+  });
+}
+__device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const il_batch& b, int k, int tile, float* smem) {
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
+  const int nt = B / IL_TILE_R, row0 = tile * IL_TILE_R;
+  const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* q16 = H2s + IL_TILE_R * ldh; float* dz3s = q16 + IL_TILE_R;
+  const SacWs ws = sac_ws(S, A, H, B);
+  float* W = d.workspace;
+  float* gdz2 = W + ws.c_dz2 + (size_t)k * B * H; float* gdz1 = W + ws.c_dz1 + (size_t)k * B * H;
+  if (d.sync) {   // rewards come from the discriminator branch on another stream (see k_critic_bwd)
+    long long* sy = reinterpret_cast<long long*>(d.sync);
+    sync_wait(sy, IL_SYNC_REWARDS, (sy[IL_SYNC_MAIN_EPOCH] + 1) * (long long)nt);
+  }
+  if (threadIdx.x < IL_TILE_R) {
+    const int row = row0 + threadIdx.x;
+    const float alpha = expf(d.log_alpha[0]);
+    const float m = 1.f - b.absorbing[(size_t)row * b.ld_absorbing];
+    const float tv = fminf(W[ws.t_q + row], W[ws.t_q + B + row]) - m * alpha * W[ws.n_logp2 + row];
+    const float y = b.rewards[(size_t)row * b.ld_rewards] + (1.f - b.terminals[(size_t)row * b.ld_terminals]) * d.discount * tv;
+    const float q = q16[threadIdx.x];
+    const float dq = (b.weights[(size_t)row * b.ld_weights] * (2.f * (q - y))) / (float)B;
+    dz3s[threadIdx.x] = dq;
+    W[ws.c_dz3 + (size_t)k * B + row] = dq;
+  }
+  if (k == 0 && tile == 0 && threadIdx.x == 64) adam_tick(d.critic_opt);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * H; i += blockDim.x) {  // (feature n, 4 consecutive rows) per thread: 16-byte lanes of the [H][B] layout
+    const int n = i >> 2, r4 = (i & 3) * 4;
+    f32x4 o2, o1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { o2[q] = dz3s[r4 + q] * H2s[(r4 + q) * ldh + n]; o1[q] = dz3s[r4 + q] * H1s[(r4 + q) * ldh + n]; }
+    *reinterpret_cast<f32x4*>(gdz2 + (size_t)n * B + row0 + r4) = o2;
+    *reinterpret_cast<f32x4*>(gdz1 + (size_t)n * B + row0 + r4) = o1;
+  }
+}
+
+// k_sac_chain: both actor forwards, the four critic / target forwards and the critic-loss backward of ONE learner in one launch of 6 * nt
+// workgroups, chained per 16-row TILE instead of per kernel:   actor(s') [tile] -> target_1,2(s', a') [tile] -> critic_1,2 backward [tile],
+// while actor(s) and the critic forwards, which depend on nothing, run beside them. Versus the three launches (k_actor_fwd, k_critic_fwd,
+// k_critic_bwd) the critical path loses two kernel boundaries, the waiting workgroups have their weights' first lanes and biases in
+// flight already, and the critic backward never re-reads h1 / h2. Roles are laid out in block order actor(s'), targets, critics, actor(s):
+// a workgroup only waits for lower-numbered ones, so in-order dispatch keeps the waits deadlock-free (the grid is co-resident anyway:
+// 6 * nt <= number of CUs is checked by the caller).
+__device__ __forceinline__ void chain_decode(int bid, int nt, int& role, int& net, int& tile) {
+  if ((nt & 7) == 0) {   // XCD-aware (workgroup b runs on XCD b % 8): each critic-shaped network's workgroups share 4 XCDs
+    const int x = bid & 7, q = bid >> 3, ra = nt >> 3, rc = nt >> 2;
+    if (q < ra) { role = 0; net = 0; tile = q * 8 + x; }
+    else if (q < ra + 2 * rc) { role = q < ra + rc ? 1 : 2; net = x >> 2; tile = (x & 3) * rc + (q - ra) % rc; }
+    else { role = 3; net = 0; tile = (q - ra - 2 * rc) * 8 + x; }
+  } else {
+    role = bid < nt ? 0 : (bid < 3 * nt ? 1 : (bid < 5 * nt ? 2 : 3));
+    const int l = bid - (role == 0 ? 0 : (role == 1 ? nt : (role == 2 ? 3 * nt : 5 * nt)));
+    net = l / nt; tile = l - net * nt;
+  }
+}
+__global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  globalize(d); globalize(b);
+  const int nt = d.batch / IL_TILE_R;
+  int role, net, tile;
+  chain_decode((int)blockIdx.x, nt, role, net, tile);
+  const SacWs ws = sac_ws(d.state_dim, d.action_dim, d.hidden, d.batch);
+  unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + tile;
+  unsigned* timeouts = reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + nt + 1;
+  if (role == 0) { actor_fwd_tile(d, b, eps_next, eps_cur, false, tile, smem); tile_arrive(ctr); }
+  else if (role == 1) { critic_fwd_tile(d, b, 2 + net, tile, smem, ctr, timeouts); tile_arrive(ctr); }
+  else if (role == 2) {
+    critic_fwd_tile(d, b, net, tile, smem, nullptr, nullptr);
+    critic_bwd_resident_gemm(d, net, smem);
+    tile_await(ctr, 3u, timeouts);
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 4u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    critic_bwd_resident_scale(d, b, net, tile, smem);
+  } else actor_fwd_tile(d, b, eps_next, eps_cur, true, tile, smem);
 }
 
 // policy-loss backward of one 16-row tile: min-Q selection, tanh-Gaussian backward, actor back-prop (dz3, dz2, dz1 for the dW kernel), alpha partial.
@@ -349,7 +482,7 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
     const float lp = W[ws.a_logp + row];
     apart = b.weights[(size_t)row * b.ld_weights] * (1.f - b.absorbing[(size_t)row * b.ld_absorbing]) * (lp + d.entropy_target);
     if (out_logp) out_logp[row] = lp;
-    if (out_q) out_q[row] = W[ws.q_min + row];
+    if (out_q) out_q[row] = fminf(W[ws.c_q + row], W[ws.c_q + B + row]);   // training.py:54 Q_values = min of the critics on the sampled (s, a), before their step
   }
   IL_STAMP(stamp, 25);
   apart = block_sum(apart, red);  // contains barriers: DZ3s complete afterwards
@@ -788,6 +921,12 @@ extern "C" int il_sac_actor_step(const il_sac* d, const il_batch* b, const float
   return IL_OK;
 }
 
+// k_sac_chain needs its 6 * nt workgroups resident together; IL_SAC_CHAIN=0 keeps the three separate launches (developer A/B switch).
+static bool chain_enabled() { static const int on = [] { const char* e = getenv("IL_SAC_CHAIN"); return e && e[0] == '0' ? 0 : 1; }(); return on != 0; }
+static int chain_cu_count() {
+  static const int n = [] { int dev = 0, cu = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0; return cu; }();
+  return n;
+}
 extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags,
                              il_stream_t stream_) {
   if (int rc = check_sac(d, b)) return rc;
@@ -795,6 +934,12 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
   hipStream_t st = (hipStream_t)stream_;
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
+  const bool whole = !(flags & (IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY));
+  if (whole && chain_enabled() && 6 * nt <= chain_cu_count()) {   // forward + critic loss chained per tile in one co-resident launch (k_sac_chain)
+    if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
+    { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur); }
+    flags |= IL_FLAG_SAC_SKIP_FORWARD | 0x80000000u;
+  }
   if (!(flags & IL_FLAG_SAC_SKIP_FORWARD)) {
     if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
     // the actor is unchanged until the last kernel of the update: both of its forward passes share one launch; neither this
@@ -803,7 +948,7 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
     { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
   }
   if (!(flags & IL_FLAG_SAC_FORWARD_ONLY)) {
-    { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
+    if (!(flags & 0x80000000u)) { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
     DwArgs ca = critic_dw_args(d, flags);
     { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
     { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr); }
