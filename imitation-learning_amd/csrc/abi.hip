@@ -79,7 +79,7 @@ extern "C" int il_trace_report(char* buf_host, int len) {
 __global__ void k_sync_probe(long long* sync, int setter) {
   if (setter) { sync_signal(sync + 6); return; }
   const long long e = sync[7];
-  sync_wait(sync, 6, e + 1);
+  sync_wait(sync, 6, e + 1, 20000);   // ~10 ms: the probe is enqueued back to back, and a serialising runtime should be detected quickly
   if (threadIdx.x == 0) sync[7] = e + 1;
 }
 extern "C" int il_sync_probe(int64_t* sync, int32_t setter, il_stream_t stream) {

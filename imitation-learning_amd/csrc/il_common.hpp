@@ -204,12 +204,12 @@ __device__ __forceinline__ void sync_signal(long long* ctr) {   // all threads o
   if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
-__device__ __forceinline__ void sync_wait(long long* sync, int which, long long target) {   // all threads of the workgroup, before their loads
+__device__ __forceinline__ void sync_wait(long long* sync, int which, long long target, int limit = IL_SYNC_SPIN_LIMIT) {   // all threads of the workgroup, before their loads
   if (threadIdx.x == 0) {
     int spins = 0;
     while (__hip_atomic_load(sync + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > IL_SYNC_SPIN_LIMIT) { __hip_atomic_fetch_add(sync + IL_SYNC_TIMEOUTS, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (++spins > limit) { __hip_atomic_fetch_add(sync + IL_SYNC_TIMEOUTS, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
 #ifndef IL_SYNC_UNSAFE
     __atomic_thread_fence(__ATOMIC_ACQUIRE);   // agent scope: the producer's stores are visible to this CU from here on

@@ -172,10 +172,11 @@ __host__ __device__ inline size_t packed_bwd_index(int n, int k, int H) { return
 
 // shared body: acc += A(LDS rows, K = H) . panel, panel = P + tile * (H/16) * 256 floats
 template <class Epi>
-__device__ __forceinline__ void tile_packed(const float* As, int lda, int H, const float* __restrict__ P, Epi epi) {
+__device__ __forceinline__ void tile_packed(const float* As, int lda, int H, const float* __restrict__ P, Epi epi, int t0 = 0, int t1 = -1) {   // output tiles [t0, t1): default all
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4, nb = H >> 4;
-  for (int t = wave; t < nb; t += nw) {
+  if (t1 < 0) t1 = nb;
+  for (int t = t0 + wave; t < t1; t += nw) {
     f32x4 acc0 = zero4(), acc1 = zero4();
     const float* pp = P + (size_t)t * nb * 256 + lane * 4;
     const float* ar = As + j * lda + 4 * g;
@@ -217,7 +218,7 @@ template <class Epi>
 __device__ __forceinline__ void tile_fwd_packed(const float* Xs, int ldx, int H, const float* __restrict__ PF, Epi epi) { tile_packed(Xs, ldx, H, PF, epi); }
 // dX[16 x H] = dYs[16 x H] . W with W given as its PB copy;  epi(kb, acc): acc[reg] = dX[row 4g+reg][col kb + j]
 template <class Epi>
-__device__ __forceinline__ void tile_bwd_packed(const float* dYs, int ldy, int H, const float* __restrict__ PB, Epi epi) { tile_packed(dYs, ldy, H, PB, epi); }
+__device__ __forceinline__ void tile_bwd_packed(const float* dYs, int ldy, int H, const float* __restrict__ PB, Epi epi, int t0 = 0, int t1 = -1) { tile_packed(dYs, ldy, H, PB, epi, t0, t1); }
 
 // ---------------------------------------------------------------------------------------------
 // Small output layer: Os[16][16] = Xs[16 x K] . W^T + b, W [N][ldw] with N <= 16 (actor head 2A, critic head 1).

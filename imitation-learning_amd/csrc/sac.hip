@@ -440,7 +440,12 @@ __global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const 
 
 // policy-loss backward of one 16-row tile: min-Q selection, tanh-Gaussian backward, actor back-prop (dz3, dz2, dz1 for the dW kernel), alpha partial.
 // Runs as the tail of k_policy_critic in the workgroup that finishes the tile's second critic.
-__device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& b, int tile, float* __restrict__ out_logp, float* __restrict__ out_q, float* smem) {
+// (part, nparts): the last GEMM, whose result only goes to HBM for the weight-gradient kernel, is split by output columns over `nparts` workgroups
+// that each run everything before it redundantly (k_policy_critic helpers); part 0 writes the shared outputs. nparts = 1: the whole tail.
+// `wait` is called once everything that does not depend on the critics of this launch has been requested / computed.
+template <class Wait>
+__device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& b, int tile, float* __restrict__ out_logp, float* __restrict__ out_q, float* smem, int part,
+                                               int nparts, Wait wait) {
   if (!out_logp) out_logp = d.out_logp;
   if (!out_q) out_q = d.out_q;
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
@@ -455,42 +460,59 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
   const int lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
   const float* h2 = W + ws.a_h2; const float* h1 = W + ws.a_h1;
   // epilogue operands of the two back-propagation GEMMs (this lane's 4 rows of one feature of h2 / h1): requested now, used after the MFMA loops
+  const int nb = H >> 4, pt0 = part * nb / nparts, pt1 = (part + 1) * nb / nparts;   // this part's output tiles of the last GEMM
   const size_t poff = (size_t)min(wave * 16 + j, H - 1) * B + row0 + 4 * g;
-  const f32x4 hv2p = gload4(h2 + poff), hv1p = gload4(h1 + poff);
-  const bool stamp = tile == 0;
+  const f32x4 hv2p = gload4(h2 + poff), hv1p = gload4(h1 + (size_t)min((pt0 + wave) * 16 + j, H - 1) * B + row0 + 4 * g);
+  const bool stamp = tile == 0 && part == 0;
   IL_STAMP(stamp, 24);
   for (int i = tid; i < IL_TILE_R * ldz; i += blockDim.x) DZ3s[i] = 0.f;
-  __syncthreads();
   float apart = 0.f;
+  // operands of the head backward that do not depend on the critics (training.py:38-46)
+  float cc = 0.f, th2 = 0.f, omaa = 0.f, e = 0.f, lsr = 0.f, sd = 1.f;
+  const int hr = tid / A, hc = tid - hr * A, hrow = row0 + hr;
   if (tid < IL_TILE_R * A) {
-    const int r = tid / A, c = tid - r * A, row = row0 + r;
-    const float q1 = W[ws.p_q + row], q2 = W[ws.p_q + B + row];
-    const float s1 = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f);
-    const float da = (-(s1) / (float)B) * W[ws.p_g + (size_t)row * A + c] + (-(1.f - s1) / (float)B) * W[ws.p_g + ((size_t)B + row) * A + c];
-    const float wgt = b.weights[(size_t)row * b.ld_weights], m = 1.f - b.absorbing[(size_t)row * b.ld_absorbing];
-    const float cc = (wgt * m * alpha) / (float)B;
-    const float x = W[ws.a_xpre + (size_t)row * A + c], an = W[ws.a_anew + (size_t)row * A + c], e = W[ws.a_eps + (size_t)row * A + c];
-    const float lsr = W[ws.a_lsraw + (size_t)row * A + c];
-    const float sd = expf(fminf(fmaxf(lsr, -20.f), 2.f));
-    const float dxp = cc * (2.f * tanhf(x)) + da * (1.f - an * an);
-    const float dsd = dxp * e - cc / sd;
-    const float dls = (lsr >= -20.f && lsr <= 2.f) ? dsd * sd : 0.f;
-    DZ3s[r * ldz + c] = dxp; DZ3s[r * ldz + A + c] = dls;
+    const float wgt = b.weights[(size_t)hrow * b.ld_weights], m = 1.f - b.absorbing[(size_t)hrow * b.ld_absorbing];
+    cc = (wgt * m * alpha) / (float)B;
+    const float x = W[ws.a_xpre + (size_t)hrow * A + hc], an = W[ws.a_anew + (size_t)hrow * A + hc];
+    e = W[ws.a_eps + (size_t)hrow * A + hc]; lsr = W[ws.a_lsraw + (size_t)hrow * A + hc];
+    sd = expf(fminf(fmaxf(lsr, -20.f), 2.f));
+    th2 = 2.f * tanhf(x); omaa = 1.f - an * an;
   }
   if (tid < IL_TILE_R) {
     const int row = row0 + tid;
     const float lp = W[ws.a_logp + row];
     apart = b.weights[(size_t)row * b.ld_weights] * (1.f - b.absorbing[(size_t)row * b.ld_absorbing]) * (lp + d.entropy_target);
+    if (part != 0) { out_logp = nullptr; out_q = nullptr; }
     if (out_logp) out_logp[row] = lp;
     if (out_q) out_q[row] = fminf(W[ws.c_q + row], W[ws.c_q + B + row]);   // training.py:54 Q_values = min of the critics on the sampled (s, a), before their step
   }
   IL_STAMP(stamp, 25);
-  apart = block_sum(apart, red);  // contains barriers: DZ3s complete afterwards
+  apart = block_sum(apart, red);  // contains barriers: the zeroing of DZ3s is complete afterwards
   IL_STAMP(stamp, 26);
-  if (tid == 0) {
+  if (tid == 0 && part == 0) {
     W[ws.alpha_part + tile] = apart;
   }
-  for (int i = tid; i < IL_TILE_R * 16; i += blockDim.x) W[ws.a_dz3 + (size_t)(i >> 4) * B + row0 + (i & 15)] = DZ3s[(i & 15) * ldz + (i >> 4)];  // dz3^T [16][B]
+  if (nparts > 1) {   // a waiting helper pulls the operands of its two GEMMs into this XCD's L2 (they were rewritten by the previous update's Adam kernel on other XCDs)
+    if (pt0 + wave < pt1) {
+      const float* pp = W + ws.pk_ab + (size_t)(pt0 + wave) * nb * 256 + lane * 4;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { if (u < nb) { f32x4 v = gload4(pp + (size_t)u * 256); asm volatile("" ::"v"(v)); } }
+    }
+    for (int i = tid * 4; i < 2 * A * H; i += blockDim.x * 4) { f32x4 v = gload4(net.W3 + i); asm volatile("" ::"v"(v)); }
+  }
+  wait();
+  if (tid < IL_TILE_R * A) {
+    const float q1 = W[ws.p_q + hrow], q2 = W[ws.p_q + B + hrow];
+    const float s1 = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f);
+    const float da = (-(s1) / (float)B) * W[ws.p_g + (size_t)hrow * A + hc] + (-(1.f - s1) / (float)B) * W[ws.p_g + ((size_t)B + hrow) * A + hc];
+    const float dxp = cc * th2 + da * omaa;
+    const float dsd = dxp * e - cc / sd;
+    const float dls = (lsr >= -20.f && lsr <= 2.f) ? dsd * sd : 0.f;
+    DZ3s[hr * ldz + hc] = dxp; DZ3s[hr * ldz + A + hc] = dls;
+  }
+  __syncthreads();
+  if (part == 0)
+    for (int i = tid; i < IL_TILE_R * 16; i += blockDim.x) W[ws.a_dz3 + (size_t)(i >> 4) * B + row0 + (i & 15)] = DZ3s[(i & 15) * ldz + (i >> 4)];  // dz3^T [16][B]
   IL_STAMP(stamp, 27);
   // dz2 = (dz3 . W3) [h2 > 0]
   tile_bwd_dx(DZ3s, ldz, 16, 2 * A, net.W3, H, H, [&](int kb, f32x4 acc) {
@@ -499,28 +521,44 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
     f32x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { o[r] = hv[r] > 0.f ? acc[r] : 0.f; DZ2s[(4 * g + r) * ldh + kb + j] = o[r]; }
-    *reinterpret_cast<f32x4*>(W + ws.a_dz2 + off) = o;
+    if (part == 0) *reinterpret_cast<f32x4*>(W + ws.a_dz2 + off) = o;
   });
   __syncthreads();
   IL_STAMP(stamp, 28);
   tile_bwd_packed(DZ2s, ldh, H, W + ws.pk_ab, [&](int kb, f32x4 acc) {
     const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
-    const f32x4 hv = (kb == wave * 16) ? hv1p : *reinterpret_cast<const f32x4*>(h1 + off);
+    const f32x4 hv = (kb == (pt0 + wave) * 16) ? hv1p : *reinterpret_cast<const f32x4*>(h1 + off);
     f32x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = hv[r] > 0.f ? acc[r] : 0.f;
     *reinterpret_cast<f32x4*>(W + ws.a_dz1 + off) = o;
-  });
+  }, pt0, pt1);
   IL_STAMP(stamp, 29);
 }
 
+// helpers > 0 (single learner, 2 * nt + helpers * nt co-resident workgroups): the policy backward of a tile is not run by the pair's second
+// arriver but by `helpers` extra workgroups per tile that wait for both critics (tile counter) with their own operands already requested,
+// and split the last GEMM between them by output columns. Same arithmetic per element, so the result is bit-identical to helpers = 0.
+#define IL_PC_HELPERS 4
 __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, const il_sac* __restrict__ dL,
-                                                        const il_batch* __restrict__ bL) {
+                                                        const il_batch* __restrict__ bL, int helpers) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
   globalize(d); globalize(b);
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
+  if ((int)blockIdx.x >= 2 * nt) {   // helper: block order keeps it behind both critics of its tile (it only waits for lower-numbered workgroups)
+    const int h = (int)blockIdx.x - 2 * nt, tile = h % nt, part = h / nt;
+    const SacWs ws = sac_ws(S, A, H, B);
+    unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr) + tile;
+    if (h == 0 && threadIdx.x == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }   // consumed by the next kernel
+    actor_bwd_tile(d, b, tile, out_logp, out_q, smem, part, helpers, [&] {
+      tile_await(ctr, 2u, reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + nt + 1);
+      if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u + (unsigned)helpers)
+        __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // last helper through: ready for the next launch
+    });
+    return;
+  }
   int k, tile;
   xcd_tile_net((int)blockIdx.x, nt, 2, tile, k);
   const int row0 = tile * IL_TILE_R;
@@ -591,8 +629,9 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   // The policy backward of this tile needs Q and dQ/da of BOTH critics, i.e. of two workgroups. Instead of a kernel boundary, the workgroup
   // that arrives second continues with it. The barrier orders every wave's stores before thread 0's agent-scope acq_rel ticket, which
   // is the only L2 write-back / invalidate of the hand-off (a __threadfence() per wave costs 16 of them per workgroup: measured -8 %).
-  __syncthreads();
   unsigned* ctr = reinterpret_cast<unsigned*>(W + ws.pair_ctr) + tile;
+  if (helpers > 0) { tile_arrive(ctr); return; }
+  __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (ticket) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // second arriver: ready for the next launch
@@ -603,7 +642,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
     if (tile == 0 && threadIdx.x == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }
     return;
   }
-  actor_bwd_tile(d, b, tile, out_logp, out_q, smem);
+  actor_bwd_tile(d, b, tile, out_logp, out_q, smem, 0, 1, [] {});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -874,6 +913,15 @@ __host__ __device__ static DwArgs critic_dw_args(const il_sac* d, uint32_t flags
   return a;
 }
 
+// k_policy_critic helpers need all (2 + helpers) * nt workgroups resident together; IL_PC_SPLIT=0 keeps the pair's second arriver doing the tail.
+static int device_cu_count() {
+  static const int n = [] { int dev = 0, cu = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0; return cu; }();
+  return n;
+}
+static int pc_helpers(int nt) {
+  static const int on = [] { const char* e = getenv("IL_PC_SPLIT"); return e && e[0] == '0' ? 0 : 1; }();
+  return (on && (2 + IL_PC_HELPERS) * nt <= device_cu_count()) ? IL_PC_HELPERS : 0;
+}
 extern "C" int il_sac_critic_step(const il_sac* d, const il_batch* b, const float* eps_next, uint32_t flags, il_stream_t stream_) {
   if (int rc = check_sac(d, b)) return rc;
   hipStream_t st = (hipStream_t)stream_;
@@ -913,7 +961,7 @@ extern "C" int il_sac_actor_step(const il_sac* d, const il_batch* b, const float
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 3), 256, 0, st>>>(*d, 0x07u, nullptr); }  // actor + critics (the critic may have been stepped by il_adam_step)
   { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, eps_cur, 2, nullptr, nullptr); }
-  { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr); }
+  { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); k_policy_critic<<<(2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, hp); }
   DwArgs a = actor_dw_args(d, b, flags);
   const int tail = 1 + ((flags & IL_FLAG_GRADS_ONLY) ? 0 : 32);
   { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<a.n_dw_blocks + tail, 256, 0, st>>>(a); }
@@ -923,10 +971,7 @@ extern "C" int il_sac_actor_step(const il_sac* d, const il_batch* b, const float
 
 // k_sac_chain needs its 6 * nt workgroups resident together; IL_SAC_CHAIN=0 keeps the three separate launches (developer A/B switch).
 static bool chain_enabled() { static const int on = [] { const char* e = getenv("IL_SAC_CHAIN"); return e && e[0] == '0' ? 0 : 1; }(); return on != 0; }
-static int chain_cu_count() {
-  static const int n = [] { int dev = 0, cu = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0; return cu; }();
-  return n;
-}
+static int chain_cu_count() { return device_cu_count(); }
 extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags,
                              il_stream_t stream_) {
   if (int rc = check_sac(d, b)) return rc;
@@ -951,7 +996,7 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
     if (!(flags & 0x80000000u)) { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
     DwArgs ca = critic_dw_args(d, flags);
     { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
-    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr); }
+    { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); k_policy_critic<<<(2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, hp); }
     DwArgs aa = actor_dw_args(d, b, flags);
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 33, 256, 0, st>>>(aa); }
   }
@@ -988,7 +1033,7 @@ extern "C" int il_sac_update_population(const il_sac* descs_dev, const il_batch*
   if (!(flags & IL_FLAG_SAC_FORWARD_ONLY)) {
     { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<dim3(2 * nt, L), tile_threads(H), lds, st>>>(z, zb, descs_dev, batches_dev); }
     { IL_TRACE("k_dw_adam_critic", st); k_dw_adam_pop<<<dim3(dw_blocks(S + A, H, 1, 2), L), 256, 0, st>>>(descs_dev, batches_dev, 0, flags); }
-    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<dim3(2 * nt, L), tile_threads(H), lds, st>>>(z, zb, nullptr, nullptr, descs_dev, batches_dev); }
+    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<dim3(2 * nt, L), tile_threads(H), lds, st>>>(z, zb, nullptr, nullptr, descs_dev, batches_dev, 0); }
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam_pop<<<dim3(dw_blocks(S, H, 2 * A, 1) + 33, L), 256, 0, st>>>(descs_dev, batches_dev, 1, flags); }
   }
   IL_CHECK_LAUNCH("il_sac_update_population");
@@ -1101,7 +1146,7 @@ extern "C" int il_sac_dp_phase(const il_sac* d, const il_batch* b, int32_t phase
   } else if (phase == 2) {
     const int64_t n = 2 * net_stride(S + A, H, 1);
     { IL_TRACE("k_apply_critic", st); k_apply_critic<<<(int)((n + 255) / 256), 256, 0, st>>>(*d); }
-    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr); }
+    { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); k_policy_critic<<<(2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, hp); }
     DwArgs aa = actor_dw_args(d, b, IL_FLAG_GRADS_ONLY);
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 1, 256, 0, st>>>(aa); }
   } else {

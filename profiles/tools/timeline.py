@@ -4,7 +4,7 @@ import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 rows = [(n.split('(')[0], s, e) for n, s, e in db.execute("select name, start, end from kernels order by start")]
-starts = [i for i, r in enumerate(rows) if r[0].startswith('k_sample2')]
+starts = [i for i, r in enumerate(rows) if r[0].startswith('k_sample')]
 i0, i1 = starts[-back], starts[-back + 1]
 t0 = rows[i0][1]
 print(f'update = kernels {i0}..{i1 - 1}; period {(rows[i1][1] - t0) / 1e3:.2f} us')
