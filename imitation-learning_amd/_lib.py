@@ -52,7 +52,8 @@ class DiscShaped(C.Structure):
 
 
 class GailExtra(C.Structure):
-  _fields_ = [('eps_mix', C.c_void_p), ('logit_offset_policy', C.c_void_p), ('logit_offset_expert', C.c_void_p)]
+  _fields_ = [('eps_mix', C.c_void_p), ('logit_offset_policy', C.c_void_p), ('logit_offset_expert', C.c_void_p),
+              ('gather_policy', C.c_void_p), ('gather_expert', C.c_void_p), ('capacity_policy', C.c_int64), ('capacity_expert', C.c_int64)]
 
 
 class Pwil(C.Structure):

@@ -59,6 +59,7 @@ __device__ __forceinline__ void globalize(il_disc& d) {
 }
 __device__ __forceinline__ void globalize(il_gail_extra& x) {
   x.eps_mix = as_global(x.eps_mix); x.logit_offset_policy = as_global(x.logit_offset_policy); x.logit_offset_expert = as_global(x.logit_offset_expert);
+  x.gather_policy = as_global(x.gather_policy); x.gather_expert = as_global(x.gather_expert);
 }
 
 __device__ __forceinline__ void globalize(il_sample_args& a) {

@@ -314,12 +314,13 @@ class UpdatePlan:
     self.pb = batch_desc(self.transitions)
     # Device-side hand-off between the two branches (include/il_hip.h `il_sync`): the discriminator branch and the SAC forward then share no stream
     # dependency between the gather and the critic loss. Validated by `capture()`; IL_DEVICE_SYNC=0 keeps plain stream dependencies.
-    self.sync = torch.zeros(8, dtype=torch.int64, device=dev)
+    self.sync = torch.zeros(16, dtype=torch.int64, device=dev)   # IL_SYNC_SLOTS
     self.device_sync = False
     if algorithm == 'GAIL' and overlap and device_index_draw and os.environ.get('IL_DEVICE_SYNC', '1') != '0':
       self.sync[5] = int(_lib.lib().il_replay_gather_workgroups(batch_size, memory.row, expert_memory.row))
       self._set_device_sync(self._probe_device_sync(graph=False))
     self.graph = self.graph_side = None
+    self._ring_desc = None
     self._capturing = None   # 'main' / 'side' while one branch of the device-synchronised update is being captured
     self.pre_hooks, self.post_hooks = [], []   # callables enqueuing extra work on the update's stream before / after it (captured with it), e.g. ActingWorker
     self._prepared = False   # True once an update of THIS plan has left the lane-ordered weight copies in step with the parameters
@@ -403,9 +404,28 @@ class UpdatePlan:
     for hook in self.post_hooks:
       hook()
 
+  def _ring_batches(self):
+    """The discriminator step reads its 2 x B rows straight from the two rings through the drawn indices (il_gail_extra.gather_*): on the device-side
+    hand-off it then waits for the index draw only, not for the gather kernel behind it."""
+    if self._ring_desc is None:
+      def ring_desc(mem):
+        t = batch_views(mem.ring, mem.state_size, mem.action_size, False)
+        t['absorbing'] = t['terminals']   # not read by the discriminator step (avoids a capacity-sized zeros tensor)
+        b = batch_desc(t); b.n = self.B
+        return b
+      x = _lib.GailExtra()
+      x.gather_policy, x.gather_expert = self.idx.data_ptr(), self.eidx.data_ptr()
+      x.capacity_policy, x.capacity_expert = self.memory.size, self.expert_memory.size
+      self._ring_desc = (ring_desc(self.memory), ring_desc(self.expert_memory), x)
+    return self._ring_desc
+
   def _enqueue_discriminator_branch(self):
     L, st = _lib.lib(), _lib.stream_ptr()
-    _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))
+    if os.environ.get('IL_GAIL_GATHER', '1') != '0':
+      rp, re_, x = self._ring_batches()
+      _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(rp), C.byref(re_), None, C.byref(x), 0, st))
+    else:
+      _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))
     _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
 
   def _enqueue_sac_branch(self):

@@ -131,17 +131,18 @@ int il_adam_step(float* p, const float* g, const il_adam* opt, int64_t n, uint32
 int il_polyak(float* target, const float* param, int64_t n, double tau, il_stream_t stream);
 
 /* Device-side hand-off for an update whose discriminator branch and SAC forward run on two streams (one hipGraph). `sync` = device
- * int64[8], zero-initialised once, shared by the il_sac / il_disc descriptors and il_replay_sample_device of ONE learner:
+ * int64[IL_SYNC_SLOTS], zero-initialised once, shared by the il_sac / il_disc descriptors and il_replay_sample_device of ONE learner:
  *   [IL_SYNC_ROWS]       += 1 per finished gather workgroup        -> k_gail_grad waits for (side_epoch + 1) * [IL_SYNC_GATHER_WGS]
  *   [IL_SYNC_REWARDS]    += 1 per finished reward workgroup        -> k_critic_bwd waits for (main_epoch + 1) * ceil(batch / 16)
  *   [IL_SYNC_SIDE_EPOCH] += 1 when a reward relabel has finished;  [IL_SYNC_MAIN_EPOCH] += 1 at the end of the actor step
  *   [IL_SYNC_TIMEOUTS]   += 1 whenever a bounded wait gave up (must stay 0: check it on the host after the first update)
  *   [IL_SYNC_GATHER_WGS] = il_replay_gather_workgroups(n, row_floats_a, row_floats_b), written by the caller when it creates the buffer.
+ *   [IL_SYNC_INDICES]    += 1 per finished index draw              -> k_gail_grad with il_gail_extra.gather_* waits for side_epoch + 1
  * With it the two branches need no stream dependency between the gather and the critic loss (fork at the start of the update, join at
  * its end). NULL everywhere = plain stream ordering (the caller serialises or uses events). */
 /* il_sync_probe: slots 6, 7 of the same buffer; enqueue setter = 0 on the side stream first, then setter = 1 on the main stream. */
 int il_sync_probe(int64_t* sync, int32_t setter, il_stream_t stream);
-enum { IL_SYNC_ROWS = 0, IL_SYNC_REWARDS = 1, IL_SYNC_SIDE_EPOCH = 2, IL_SYNC_MAIN_EPOCH = 3, IL_SYNC_TIMEOUTS = 4, IL_SYNC_GATHER_WGS = 5 };
+enum { IL_SYNC_ROWS = 0, IL_SYNC_REWARDS = 1, IL_SYNC_SIDE_EPOCH = 2, IL_SYNC_MAIN_EPOCH = 3, IL_SYNC_TIMEOUTS = 4, IL_SYNC_GATHER_WGS = 5, IL_SYNC_INDICES = 8, IL_SYNC_SLOTS = 16 };
 
 /* ------------------------------------------------------------------------------------------
  * SAC (reference training.py:14-54 `sac_update`; models.py:84-141 SoftActor / TwinCritic).
@@ -266,6 +267,12 @@ typedef struct il_gail_extra {
   const float* eps_mix;              /* [B] the Beta(alpha, alpha) draws of Mixup (training.py:106); NULL => U(0,1) from Philox, i.e. alpha = 1 */
   const float* logit_offset_policy;  /* [B] log pi(a|s) of the policy batch when subtract_log_policy (models.py:144,175) */
   const float* logit_offset_expert;  /* [B] same for the expert batch */
+  /* Optional row indirection for il_gail_disc_step: with gather_policy != NULL the `policy` argument describes the replay RING (field pointers of
+   * ring row 0, ld = ring row floats, n = batch) and batch row r is ring row gather_policy[r], clamped to [0, capacity_policy) like
+   * il_replay_gather does; likewise for the expert ring. The step then needs the index DRAW of an update but not its gather: with il_sync counters
+   * it waits for [IL_SYNC_INDICES] instead of [IL_SYNC_ROWS] and starts one kernel earlier. Results are identical to passing the gathered rows. */
+  const int32_t* gather_policy; const int32_t* gather_expert;
+  int64_t capacity_policy, capacity_expert;
 } il_gail_extra;
 
 int64_t il_disc_workspace_floats(int32_t in_dim, int32_t hidden, int32_t batch);
