@@ -17,7 +17,8 @@ c_f32p, c_i32p, c_u32p, c_i64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.P
 
 class Batch(C.Structure):
   _fields_ = [(k, C.c_void_p) for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'weights', 'absorbing')] + \
-             [('ld_' + k, C.c_int32) for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'weights', 'absorbing')] + [('n', C.c_int32)]
+             [('ld_' + k, C.c_int32) for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'weights', 'absorbing')] + [('n', C.c_int32)] + \
+             [('gather', C.c_void_p), ('gather_capacity', C.c_int64)]   # optional row indirection (include/il_hip.h il_batch)
 
 
 class Adam(C.Structure):
@@ -52,8 +53,7 @@ class DiscShaped(C.Structure):
 
 
 class GailExtra(C.Structure):
-  _fields_ = [('eps_mix', C.c_void_p), ('logit_offset_policy', C.c_void_p), ('logit_offset_expert', C.c_void_p),
-              ('gather_policy', C.c_void_p), ('gather_expert', C.c_void_p), ('capacity_policy', C.c_int64), ('capacity_expert', C.c_int64)]
+  _fields_ = [('eps_mix', C.c_void_p), ('logit_offset_policy', C.c_void_p), ('logit_offset_expert', C.c_void_p)]
 
 
 class Pwil(C.Structure):
@@ -113,6 +113,8 @@ _SIGNATURES = {
     'il_sac_prepare': (C.c_int, [C.POINTER(Sac), _P]),
     'il_sac_dp_phase': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.c_int32, _P, _P, C.c_uint32, _P]),
     'il_sac_update': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), _P, _P, _P, _P, C.c_uint32, _P]),
+    'il_sac_update_gather': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.POINTER(Batch), _P, _P, _P, _P, _P, C.c_uint32, _P]),
+    'il_sac_chain_gather_workgroups': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     'il_bc_step': (C.c_int, [_P, _P, C.POINTER(Adam), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Batch), _P, C.c_int64, _P, C.c_uint32, _P]),
     'il_actor_act': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_uint64, C.c_uint32, C.c_int32, _P, _P, _P]),
     'il_batch_mix_relabel': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_int64, _P]),

@@ -218,6 +218,7 @@ static int dril_ensure_lds(const void* fn, size_t bytes) {
 
 extern "C" int il_dril_bc_step(const il_dril* d, const il_batch* expert, const float* mask_in, const float* mask_hidden, uint32_t noise_offset, float* out_loss, uint32_t flags,
                                il_stream_t stream_) {
+  IL_NO_GATHER(expert, "il_dril_bc_step");
   if (int rc = check_dril(d, expert)) return rc;
   IL_CHECK_ARG(d->grad && d->workspace && d->opt.m && d->opt.v && d->opt.step && expert->weights, "il_dril_bc_step: null optimiser / workspace / weights");
   IL_CHECK_ARG(d->batch == expert->n, "il_dril_bc_step: descriptor batch %d != batch rows %d", d->batch, expert->n);
@@ -234,6 +235,7 @@ extern "C" int il_dril_bc_step(const il_dril* d, const il_batch* expert, const f
 
 extern "C" int il_dril_uncertainty(const il_dril* d, const il_batch* batch, const float* mask_in, const float* mask_hidden, uint32_t noise_offset, float* out_uncertainty,
                                    float* out_reward, il_stream_t stream_) {
+  IL_NO_GATHER(batch, "il_dril_uncertainty");
   if (int rc = check_dril(d, batch)) return rc;
   IL_CHECK_ARG(out_uncertainty || out_reward, "il_dril_uncertainty: nothing to write");
   const size_t lds = dril_lds_floats(DU * DRIL_ENSEMBLE, d->state_dim, d->hidden) * sizeof(float);

@@ -199,13 +199,6 @@ __device__ __forceinline__ void stage_weights(const DiscLds& L, const float* __r
   for (int i = threadIdx.x; i < H; i += blockDim.x) { L.b1s[i] = b1[i]; L.W2s[i] = W2[i]; }
 }
 
-// batch row -> source row: identity, or through the caller's index array (il_gail_extra.gather_*, clamped like il_replay_gather)
-__device__ __forceinline__ size_t src_row(const int32_t* __restrict__ gather, int64_t capacity, int row) {
-  if (!gather) return (size_t)row;
-  int64_t s = gather[row];
-  return (size_t)(s < 0 ? 0 : (s >= capacity ? capacity - 1 : s));
-}
-
 // grid = (tiles, passes): one workgroup = 16 rows of ONE discriminator call (0 policy, 1 expert, 2 gradient-penalty mix), so the
 // three calls run side by side; wave 0 chains the power iterations up to its call (pass + 1 of them) while waves 1.. stage rows.
 // Loss variants (training.py:97-113): BCE and PUGAIL (nonnegative_margin = inf) are calls {policy, expert}; Mixup is ONE call on convex combinations
@@ -253,8 +246,8 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
       if (r < nrows && k < D) {
         const int row = row0 + r;
         float xp = 0.f, xe = 0.f;
-        if (kind != 1) { const size_t pr = src_row(x.gather_policy, x.capacity_policy, row); xp = k < S ? pol.states[pr * pol.ld_states + k] : pol.actions[pr * pol.ld_actions + k - S]; }
-        if (kind != 0) { const size_t er = src_row(x.gather_expert, x.capacity_expert, row); xe = k < S ? exp.states[er * exp.ld_states + k] : exp.actions[er * exp.ld_actions + k - S]; }
+        if (kind != 1) { const size_t pr = brow(pol, row); xp = k < S ? pol.states[pr * pol.ld_states + k] : pol.actions[pr * pol.ld_actions + k - S]; }
+        if (kind != 0) { const size_t er = brow(exp, row); xe = k < S ? exp.states[er * exp.ld_states + k] : exp.actions[er * exp.ld_actions + k - S]; }
         if (kind >= 2) { const float e = mix_eps(row); xv = e * xe + (1.f - e) * xp; }
         else xv = kind == 0 ? xp : xe;
       }
@@ -263,8 +256,8 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     if (tid >= t0 && tid < t0 + IL_TILE_R) {
       const int r = tid - t0, row = row0 + r; float w = 0.f;
       if (r < nrows) {
-        const float wp = kind != 1 ? pol.weights[src_row(x.gather_policy, x.capacity_policy, row) * pol.ld_weights] : 0.f;
-        const float we = kind != 0 ? exp.weights[src_row(x.gather_expert, x.capacity_expert, row) * exp.ld_weights] : 0.f;
+        const float wp = kind != 1 ? pol.weights[brow(pol, row) * pol.ld_weights] : 0.f;
+        const float we = kind != 0 ? exp.weights[brow(exp, row) * exp.ld_weights] : 0.f;
         if (kind >= 2) { const float e = mix_eps(row); w = e * we + (1.f - e) * wp; }
         else w = kind == 0 ? wp : we;
       }
@@ -276,7 +269,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     // iterations) has run or runs now; then wait for THIS update's rows (every gather workgroup has signalled) and stage them with all threads.
     if (tid < 64 && d.spectral_norm) sn_chain(L.W1s, L.W2s, L.Ms, D, H, L.u1(0), L.v1(0), L.v2(0), L.tmp, pass + 1, L.sc(0));
     long long* sy = reinterpret_cast<long long*>(d.sync);
-    if (x.gather_policy && x.gather_expert) sync_wait(sy, IL_SYNC_INDICES, sy[IL_SYNC_SIDE_EPOCH] + 1);   // rows come straight from the rings: only the draw has to be done
+    if (pol.gather && exp.gather) sync_wait(sy, IL_SYNC_INDICES, sy[IL_SYNC_SIDE_EPOCH] + 1);   // rows come straight from the rings: only the draw has to be done
     else sync_wait(sy, IL_SYNC_ROWS, (sy[IL_SYNC_SIDE_EPOCH] + 1) * sy[IL_SYNC_GATHER_WGS]);
     ctr = d.noise_counter ? *d.noise_counter : 0u;   // after the wait: the previous update's actor step (which bumps it) precedes this update's gather
     stage_rows(0);
@@ -580,6 +573,7 @@ extern "C" int il_gail_apply_grads(const il_disc* d, il_stream_t stream_) {
 }
 
 extern "C" int il_gail_reward(const il_disc* d, const il_batch* b, float* out_rewards, float* out_logits, const float* logit_offset, il_stream_t stream_) {
+  IL_NO_GATHER(b, "il_gail_reward");
   if (int rc = check_disc(d)) return rc;
   IL_CHECK_ARG(b && out_rewards && b->n > 0, "il_gail_reward: bad arguments");
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);

@@ -380,6 +380,7 @@ static int gs_ensure_lds(const void* fn, size_t bytes) {
 }
 
 extern "C" int il_gail_shaped_step(const il_disc_shaped* d, const il_batch* pol, const il_batch* exp, const float* eps_gp, const il_gail_extra* extra, uint32_t flags, il_stream_t stream_) {
+  IL_NO_GATHER(pol, "il_gail_shaped_step"); IL_NO_GATHER(exp, "il_gail_shaped_step");
   if (int rc = check_gs(d)) return rc;
   IL_CHECK_ARG(pol && exp && pol->n == d->batch && exp->n == d->batch && d->grad && d->opt.m && d->opt.v && d->opt.step, "il_gail_shaped_step: bad batches / optimiser state");
   IL_CHECK_ARG(pol->next_states && pol->terminals && exp->next_states && exp->terminals && pol->weights && exp->weights, "il_gail_shaped_step: the shaping term needs next_states, terminals and weights");
@@ -397,6 +398,7 @@ extern "C" int il_gail_shaped_step(const il_disc_shaped* d, const il_batch* pol,
 }
 
 extern "C" int il_gail_shaped_reward(const il_disc_shaped* d, const il_batch* b, float* out_rewards, float* out_logits, const float* logit_offset, il_stream_t stream_) {
+  IL_NO_GATHER(b, "il_gail_shaped_reward");
   if (int rc = check_gs(d)) return rc;
   IL_CHECK_ARG(b && out_rewards && b->n > 0 && b->next_states && b->terminals, "il_gail_shaped_reward: bad arguments (next_states and terminals are inputs of the shaping term)");
   const int S = d->state_dim, Dg = d->state_only ? S : S + d->action_dim;

@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256) void k_gmmil_tile(int n1, int n2, int D, float
 
 extern "C" int il_gmmil_reward(const il_batch* pol, const il_batch* exp, int32_t S, int32_t A, int32_t state_only, float g1, float g2, float* out_rewards,
                                float* out_sim, float* out_self, float* workspace, int64_t workspace_floats, il_stream_t stream_) {
+  IL_NO_GATHER(pol, "il_gmmil_reward"); IL_NO_GATHER(exp, "il_gmmil_reward");
   IL_CHECK_ARG(pol && exp && out_rewards && workspace && pol->n > 0 && exp->n > 0, "il_gmmil_reward: bad arguments");
   const int D = S + (state_only ? 0 : A);
   const GmmilWs w = gmmil_ws(pol->n, exp->n, D);
@@ -185,6 +186,7 @@ extern "C" int il_gmmil_reward(const il_batch* pol, const il_batch* exp, int32_t
 // No: to keep the ABI allocation-free the caller passes the same kind of workspace as for il_gmmil_reward.
 extern "C" int il_gmmil_sqdist(const il_batch* a, const il_batch* b, int32_t S, int32_t A, int32_t state_only, float* out, float* workspace,
                                   int64_t workspace_floats, il_stream_t stream_) {
+  IL_NO_GATHER(a, "il_gmmil_sqdist"); IL_NO_GATHER(b, "il_gmmil_sqdist");
   IL_CHECK_ARG(a && b && out && workspace && a->n > 0 && b->n > 0, "il_gmmil_sqdist: bad arguments");
   const int D = S + (state_only ? 0 : A);
   const GmmilWs w = gmmil_ws(a->n, b->n, D);

@@ -38,12 +38,21 @@ __device__ __forceinline__ f32x4 gload4(const float* p) { return *(const __attri
 // Whole-descriptor version of the same: a descriptor fetched from memory (population axis: d = dL[blockIdx.y]) carries generic pointers, and
 // ONE pending flat access (a flat_store of an activation slab is enough) makes the compiler turn every later wait into vmcnt(0) lgkmcnt(0).
 // Round-tripping the fields through address space 1 lets address-space inference type every derived access as global.
+// entry points whose kernels index batch rows directly
+#define IL_NO_GATHER(b, who) IL_CHECK_ARG(!(b) || !(b)->gather, who ": il_batch.gather is only honoured by il_gail_disc_step and il_sac_update_gather")
+// batch row -> source row of an il_batch: identity, or through the batch's index array (il_batch.gather, clamped like il_replay_gather)
+__device__ __forceinline__ size_t brow(const il_batch& b, int row) {
+  if (!b.gather) return (size_t)row;
+  const int64_t s = b.gather[row];
+  return (size_t)(s < 0 ? 0 : (s >= b.gather_capacity ? b.gather_capacity - 1 : s));
+}
 template <class T>
 __device__ __forceinline__ T* as_global(T* p) { auto g = (__attribute__((address_space(1))) T*)p; asm volatile("" : "+s"(g)); return (T*)g; }
 __device__ __forceinline__ void globalize(il_adam& o) { o.m = as_global(o.m); o.v = as_global(o.v); o.step = as_global(o.step); }
 __device__ __forceinline__ void globalize(il_batch& b) {
   b.states = as_global(b.states); b.actions = as_global(b.actions); b.rewards = as_global(b.rewards); b.next_states = as_global(b.next_states);
   b.terminals = as_global(b.terminals); b.weights = as_global(b.weights); b.absorbing = as_global(b.absorbing);
+  b.gather = as_global(b.gather);
 }
 __device__ __forceinline__ void globalize(il_sac& d) {
   d.actor = as_global(d.actor); d.critic = as_global(d.critic); d.target = as_global(d.target); d.log_alpha = as_global(d.log_alpha);
@@ -59,7 +68,6 @@ __device__ __forceinline__ void globalize(il_disc& d) {
 }
 __device__ __forceinline__ void globalize(il_gail_extra& x) {
   x.eps_mix = as_global(x.eps_mix); x.logit_offset_policy = as_global(x.logit_offset_policy); x.logit_offset_expert = as_global(x.logit_offset_expert);
-  x.gather_policy = as_global(x.gather_policy); x.gather_expert = as_global(x.gather_expert);
 }
 
 __device__ __forceinline__ void globalize(il_sample_args& a) {

@@ -250,14 +250,18 @@ __device__ __forceinline__ void tile_fwd_small(const float* Xs, int ldx, int K, 
 }
 
 // Load a [16 x (K1+K2)] tile of concatenated fields (e.g. cat(state, action)) into LDS, zero-padded to Kpad columns.
+// gather != NULL: batch row r of f1 (and of f2 unless f2_dense) is source row gather[r], clamped to [0, capacity) (il_batch.gather)
 __device__ __forceinline__ void load_rows_cat(float* Xs, int ldx, int Kpad, const float* __restrict__ f1, int ld1, int K1, const float* __restrict__ f2,
-                                              int ld2, int K2, int row0, int nrows_valid) {
+                                              int ld2, int K2, int row0, int nrows_valid, const int32_t* __restrict__ gather = nullptr, int64_t capacity = 0,
+                                              bool f2_dense = false) {
   for (int i = threadIdx.x; i < IL_TILE_R * Kpad; i += blockDim.x) {
     const int r = i / Kpad, k = i - r * Kpad;
     float v = 0.f;
     if (r < nrows_valid) {
-      if (k < K1) v = f1[(size_t)(row0 + r) * ld1 + k];
-      else if (k < K1 + K2) v = f2[(size_t)(row0 + r) * ld2 + (k - K1)];
+      size_t sr = (size_t)(row0 + r);
+      if (gather) { const int64_t g = gather[row0 + r]; sr = (size_t)(g < 0 ? 0 : (g >= capacity ? capacity - 1 : g)); }
+      if (k < K1) v = f1[sr * ld1 + k];
+      else if (k < K1 + K2) v = f2[(f2_dense ? (size_t)(row0 + r) : sr) * ld2 + (k - K1)];
     }
     Xs[r * ldx + k] = v;
   }

@@ -189,6 +189,7 @@ static int red_ensure_lds(const void* fn, size_t bytes) {
 }
 
 extern "C" int il_red_step(const il_red* d, const il_batch* expert, float* out_loss, uint32_t flags, il_stream_t stream_) {
+  IL_NO_GATHER(expert, "il_red_step");
   if (int rc = check_red(d, expert)) return rc;
   IL_CHECK_ARG(d->grad && d->workspace && d->opt.m && d->opt.v && d->opt.step && expert->weights, "il_red_step: null optimiser / workspace / weights");
   IL_CHECK_ARG(d->batch == expert->n, "il_red_step: descriptor batch %d != batch rows %d", d->batch, expert->n);
@@ -204,6 +205,7 @@ extern "C" int il_red_step(const il_red* d, const il_batch* expert, float* out_l
 }
 
 extern "C" int il_red_forward(const il_red* d, const il_batch* batch, float* out_reward, float* out_pred, float* out_target, il_stream_t stream_) {
+  IL_NO_GATHER(batch, "il_red_forward");
   if (int rc = check_red(d, batch)) return rc;
   IL_CHECK_ARG(out_reward || (out_pred && out_target), "il_red_forward: nothing to write");
   IL_CHECK_ARG((out_pred == nullptr) == (out_target == nullptr), "il_red_forward: out_pred and out_target go together");

@@ -328,10 +328,11 @@ extern "C" int32_t il_replay_gather_workgroups(int32_t n, int32_t row_floats_a, 
 extern "C" int il_replay_sample_device(uint32_t* state_dev, int32_t n, const int64_t* ring_state_a, const float* ring_a, int64_t capacity_a, int32_t row_floats_a, int32_t* idx_a,
                                        float* rows_a, const int64_t* ring_state_b, const float* ring_b, int64_t capacity_b, int32_t row_floats_b, int32_t* idx_b, float* rows_b,
                                        int64_t* sync, il_stream_t stream) {
-  IL_CHECK_ARG(state_dev && ring_state_a && ring_a && idx_a && rows_a && n > 0, "il_replay_sample_device: bad arguments for ring A");
-  IL_CHECK_ARG(row_floats_a % 4 == 0 && (!ring_b || (row_floats_b % 4 == 0 && ring_state_b && idx_b && rows_b)), "il_replay_sample_device: bad arguments for ring B");
+  IL_CHECK_ARG(state_dev && ring_state_a && ring_a && idx_a && n > 0, "il_replay_sample_device: bad arguments for ring A");
+  IL_CHECK_ARG(row_floats_a % 4 == 0 && (!ring_b || (row_floats_b % 4 == 0 && ring_state_b && idx_b && (!rows_a == !rows_b))), "il_replay_sample_device: bad arguments for ring B");
   { IL_TRACE("k_sample2", stream); k_sample2<<<1, 256, 0, (hipStream_t)stream>>>(state_dev, n, ring_state_a, ring_a, capacity_a, row_floats_a / 4, idx_a, nullptr, ring_state_b, ring_b, capacity_b,
                                                                             row_floats_b / 4, idx_b, nullptr, (long long*)sync); }
+  if (!rows_a) { IL_CHECK_LAUNCH("il_replay_sample_device"); return IL_OK; }   // draw only
   const int lanes = n * (row_floats_a / 4) + (ring_b ? n * (row_floats_b / 4) : 0);   // il_replay_gather_workgroups() = ceil(lanes / 256)
   { IL_TRACE("k_gather2", stream); k_gather2<<<(lanes + 255) / 256, 256, 0, (hipStream_t)stream>>>(ring_a, capacity_a, row_floats_a / 4, idx_a, rows_a, ring_b, capacity_b, row_floats_b / 4, idx_b, rows_b, n, (long long*)sync); }
   IL_CHECK_LAUNCH("il_replay_sample_device");

@@ -117,11 +117,11 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
     const int r = tid / A, c = tid - r * A, row = row0 + r;
     const float* ep = is_cur ? eps_cur : eps_next;
     e_pre = ep ? ep[(size_t)row * A + c] : philox_normal(d.noise_seed, ctr, is_cur ? IL_STREAM_EPS_CUR : IL_STREAM_EPS_NEXT, (uint32_t)(row * A + c));
-    if (!is_cur) absorb_pre = b.absorbing[(size_t)row * b.ld_absorbing];
+    if (!is_cur) absorb_pre = b.absorbing[brow(b, row) * b.ld_absorbing];
   }
   const float* src = is_cur ? b.states : b.next_states;
   const int ld = is_cur ? b.ld_states : b.ld_next_states;
-  load_rows_cat(Xs, ldx, Sp, src, ld, S, nullptr, 0, 0, row0, IL_TILE_R);
+  load_rows_cat(Xs, ldx, Sp, src, ld, S, nullptr, 0, 0, row0, IL_TILE_R, b.gather, b.gather_capacity);
   __syncthreads();
   tile_fwd(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1 : net.b1[col];
@@ -230,11 +230,11 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
 #pragma unroll
   for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
   if (is_target && await) {
-    load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, IL_TILE_R);   // s' columns, zero elsewhere
+    load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, IL_TILE_R, b.gather, b.gather_capacity);   // s' columns, zero elsewhere
     tile_await(await, 1u, timeouts);
     for (int i = threadIdx.x; i < IL_TILE_R * A; i += blockDim.x) { const int r = i / A, c = i - r * A; Xs[r * ldx + S + c] = W[ws.n_a2 + (size_t)(row0 + r) * A + c]; }
-  } else if (is_target) load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, W + ws.n_a2, A, A, row0, IL_TILE_R);
-  else load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R);
+  } else if (is_target) load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, W + ws.n_a2, A, A, row0, IL_TILE_R, b.gather, b.gather_capacity, true);
+  else load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R, b.gather, b.gather_capacity);
   __syncthreads();
   if (net == 0)
     for (int i = threadIdx.x; i < IL_TILE_R * IN; i += blockDim.x) { const int c = i >> 4, r = i & 15; W[ws.c_x0 + (size_t)c * B + row0 + r] = Xs[r * ldx + c]; }  // x0^T [IN][B]
@@ -364,7 +364,7 @@ __device__ __forceinline__ void critic_bwd_resident_gemm(const il_sac& d, int k,
     for (int r = 0; r < 4; ++r) { float* h = H1s + (4 * g + r) * ldh + kb + j; *h = *h > 0.f ? acc[r] : 0.f; }   // each element owned by one lane
   });
 }
-__device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const il_batch& b, int k, int tile, float* smem) {
+__device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const il_batch& b, const float* __restrict__ rewards, int k, int tile, float* smem) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R, row0 = tile * IL_TILE_R;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
@@ -379,11 +379,13 @@ __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const
   if (threadIdx.x < IL_TILE_R) {
     const int row = row0 + threadIdx.x;
     const float alpha = expf(d.log_alpha[0]);
-    const float m = 1.f - b.absorbing[(size_t)row * b.ld_absorbing];
+    const size_t sr = brow(b, row);
+    const float m = 1.f - b.absorbing[sr * b.ld_absorbing];
     const float tv = fminf(W[ws.t_q + row], W[ws.t_q + B + row]) - m * alpha * W[ws.n_logp2 + row];
-    const float y = b.rewards[(size_t)row * b.ld_rewards] + (1.f - b.terminals[(size_t)row * b.ld_terminals]) * d.discount * tv;
+    const float rew = rewards ? rewards[row] : b.rewards[sr * b.ld_rewards];
+    const float y = rew + (1.f - b.terminals[sr * b.ld_terminals]) * d.discount * tv;
     const float q = q16[threadIdx.x];
-    const float dq = (b.weights[(size_t)row * b.ld_weights] * (2.f * (q - y))) / (float)B;
+    const float dq = (b.weights[sr * b.ld_weights] * (2.f * (q - y))) / (float)B;
     dz3s[threadIdx.x] = dq;
     W[ws.c_dz3 + (size_t)k * B + row] = dq;
   }
@@ -418,10 +420,25 @@ __device__ __forceinline__ void chain_decode(int bid, int nt, int& role, int& ne
     net = l / nt; tile = l - net * nt;
   }
 }
-__global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur) {
+// b.gather != NULL (il_sac_update_gather): the batch has been drawn but not gathered. Every role reads its rows straight from the ring through the
+// indices, and the workgroups behind the 6 * nt chain roles copy the rows to `rows_out` for the later kernels of the update (one 16-byte
+// lane per thread, [IL_SYNC_ROWS] += 1 per workgroup) - they wait for nothing and nobody in this launch waits for them.
+__global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, const float* __restrict__ rewards,
+                                                    float* __restrict__ rows_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   globalize(d); globalize(b);
   const int nt = d.batch / IL_TILE_R;
+  if ((int)blockIdx.x >= 6 * nt) {
+    const int row4 = b.ld_states / 4, lanes = d.batch * row4, G = (int)gridDim.x - 6 * nt;
+    const f32x4* src = reinterpret_cast<const f32x4*>(b.states);
+    f32x4* dst = reinterpret_cast<f32x4*>(as_global(rows_out));
+    for (int i = ((int)blockIdx.x - 6 * nt) * blockDim.x + threadIdx.x; i < lanes; i += G * blockDim.x) {
+      const int r = i / row4, c = i - r * row4;
+      dst[i] = src[brow(b, r) * row4 + c];
+    }
+    if (d.sync) sync_signal(reinterpret_cast<long long*>(d.sync) + IL_SYNC_ROWS);
+    return;
+  }
   int role, net, tile;
   chain_decode((int)blockIdx.x, nt, role, net, tile);
   const SacWs ws = sac_ws(d.state_dim, d.action_dim, d.hidden, d.batch);
@@ -434,7 +451,7 @@ __global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const 
     critic_bwd_resident_gemm(d, net, smem);
     tile_await(ctr, 3u, timeouts);
     if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 4u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    critic_bwd_resident_scale(d, b, net, tile, smem);
+    critic_bwd_resident_scale(d, b, rewards, net, tile, smem);
   } else actor_fwd_tile(d, b, eps_next, eps_cur, true, tile, smem);
 }
 
@@ -887,6 +904,7 @@ static int check_sac(const il_sac* d, const il_batch* b) {
   IL_CHECK_ARG(d->hidden % 64 == 0 && d->hidden >= 64 && d->hidden <= 256, "il_sac: hidden=%d must be a multiple of 64 in [64,256]", d->hidden);
   IL_CHECK_ARG(d->batch % IL_TILE_R == 0 && d->batch > 0, "il_sac: batch=%d must be a positive multiple of %d", d->batch, IL_TILE_R);
   IL_CHECK_ARG(b->n == d->batch, "il_sac: batch rows %d != descriptor batch %d", b->n, d->batch);
+  IL_NO_GATHER(b, "il_sac");
   IL_CHECK_ARG(d->action_dim >= 1 && 2 * d->action_dim <= 16, "il_sac: action_dim=%d unsupported (2A <= 16)", d->action_dim);
   IL_CHECK_ARG(d->state_dim >= 1 && d->state_dim + d->action_dim <= 508, "il_sac: state_dim too large");
   const SacWs ws = sac_ws(d->state_dim, d->action_dim, d->hidden, d->batch);
@@ -982,7 +1000,7 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
   const bool whole = !(flags & (IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY));
   if (whole && chain_enabled() && 6 * nt <= chain_cu_count()) {   // forward + critic loss chained per tile in one co-resident launch (k_sac_chain)
     if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
-    { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur); }
+    { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr); }
     flags |= IL_FLAG_SAC_SKIP_FORWARD | 0x80000000u;
   }
   if (!(flags & IL_FLAG_SAC_SKIP_FORWARD)) {
@@ -1001,6 +1019,33 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 33, 256, 0, st>>>(aa); }
   }
   IL_CHECK_LAUNCH("il_sac_update");
+  return IL_OK;
+}
+
+// gather workgroups appended to k_sac_chain by il_sac_update_gather: one 16-byte lane per thread (this is also what the caller writes to [IL_SYNC_GATHER_WGS])
+extern "C" int32_t il_sac_chain_gather_workgroups(int32_t batch, int32_t row_floats, int32_t hidden) {
+  return (int32_t)(((int64_t)batch * (row_floats / 4) + tile_threads(hidden) - 1) / tile_threads(hidden));
+}
+
+extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const float* eps_next, const float* eps_cur, float* out_logp,
+                                    float* out_q, uint32_t flags, il_stream_t stream_) {
+  if (int rc = check_sac(d, rows)) return rc;
+  IL_CHECK_ARG(ring && ring->gather && ring->gather_capacity > 0 && ring->n == d->batch, "il_sac_update_gather: `ring` must carry the %d drawn indices (il_batch.gather)", d->batch);
+  IL_CHECK_ARG(rows->states && ring->states && rows->ld_states == ring->ld_states && ring->ld_states % 4 == 0, "il_sac_update_gather: rows / ring must be packed rows of the same width");
+  IL_CHECK_ARG(!(flags & (IL_FLAG_GRADS_ONLY | IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY)), "il_sac_update_gather: whole updates only");
+  hipStream_t st = (hipStream_t)stream_;
+  const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
+  const int G = il_sac_chain_gather_workgroups(B, ring->ld_states, H);
+  if (6 * nt + G > chain_cu_count()) return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update_gather: %d workgroups cannot be co-resident on %d CUs (gather first, then il_sac_update)", 6 * nt + G, chain_cu_count());
+  const size_t lds = tile_lds_bytes(round_up16(S + A), H);
+  if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
+  { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt + G, tile_threads(H), lds, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states)); }
+  DwArgs ca = critic_dw_args(d, flags);
+  { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
+  { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); k_policy_critic<<<(2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *rows, out_logp, out_q, nullptr, nullptr, hp); }
+  DwArgs aa = actor_dw_args(d, rows, flags);
+  { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 33, 256, 0, st>>>(aa); }
+  IL_CHECK_LAUNCH("il_sac_update_gather");
   return IL_OK;
 }
 
@@ -1259,6 +1304,7 @@ __global__ __launch_bounds__(1024) void k_bc_tile(const float* __restrict__ acto
 
 extern "C" int il_bc_step(float* actor, float* actor_grad, const il_adam* opt, int32_t S, int32_t A, int32_t H, const il_batch* b, float* workspace,
                           int64_t workspace_floats, float* out_loss_partials, uint32_t flags, il_stream_t stream_) {
+  IL_NO_GATHER(b, "il_bc_step");
   IL_CHECK_ARG(actor && opt && b && workspace, "il_bc_step: null argument");
   IL_CHECK_ARG(H % 64 == 0 && H >= 64 && H <= 256, "il_bc_step: hidden=%d must be a multiple of 64 in [64,256]", H);
   IL_CHECK_ARG(b->n > 0 && b->n % IL_TILE_R == 0, "il_bc_step: batch=%d must be a positive multiple of %d", b->n, IL_TILE_R);

@@ -317,7 +317,6 @@ class UpdatePlan:
     self.sync = torch.zeros(16, dtype=torch.int64, device=dev)   # IL_SYNC_SLOTS
     self.device_sync = False
     if algorithm == 'GAIL' and overlap and device_index_draw and os.environ.get('IL_DEVICE_SYNC', '1') != '0':
-      self.sync[5] = int(_lib.lib().il_replay_gather_workgroups(batch_size, memory.row, expert_memory.row))
       self._set_device_sync(self._probe_device_sync(graph=False))
     self.graph = self.graph_side = None
     self._ring_desc = None
@@ -334,6 +333,10 @@ class UpdatePlan:
 
   def _set_device_sync(self, on: bool):
     self.device_sync = bool(on)
+    if self.algorithm == 'GAIL' and self.expert_memory is not None:   # [IL_SYNC_GATHER_WGS]: who signals IL_SYNC_ROWS, and how many times per update
+      L = _lib.lib()
+      self.sync[5] = int(L.il_sac_chain_gather_workgroups(self.B, self.memory.row, self.sac.hidden) if self.ring_mode
+                         else L.il_replay_gather_workgroups(self.B, self.memory.row, self.expert_memory.row))
     ptr = self.sync.data_ptr() if on else None
     self.sac.sync = ptr
     if self.algorithm == 'GAIL':
@@ -393,9 +396,9 @@ class UpdatePlan:
     m, e = self.memory, (self.expert_memory if self.algorithm == 'GAIL' else None)
     st = m.stream().device_state(m.device)   # the agent memory's index stream feeds both draws of an update (one stream, agent then expert)
     _lib.check(_lib.lib().il_replay_sample_device(
-        _lib.ptr(st), self.B, _lib.ptr(m._ring_state), _lib.ptr(m.ring), m.size, m.row, _lib.ptr(self.idx), _lib.ptr(self.rows),
+        _lib.ptr(st), self.B, _lib.ptr(m._ring_state), _lib.ptr(m.ring), m.size, m.row, _lib.ptr(self.idx), None if self.ring_mode else _lib.ptr(self.rows),
         _lib.ptr(e._ring_state) if e else None, _lib.ptr(e.ring) if e else None, e.size if e else 0, e.row if e else 0, _lib.ptr(self.eidx) if e else None,
-        _lib.ptr(self.erows) if e else None, _lib.ptr(self.sync) if self.device_sync else None, _lib.stream_ptr()))
+        _lib.ptr(self.erows) if e and not self.ring_mode else None, _lib.ptr(self.sync) if self.device_sync else None, _lib.stream_ptr()))   # ring mode: the draw only
 
   def run(self):
     for hook in self.pre_hooks:
@@ -404,32 +407,46 @@ class UpdatePlan:
     for hook in self.post_hooks:
       hook()
 
+  @property
+  def ring_mode(self) -> bool:
+    """Device-side hand-off only: an update is DRAWN but never gathered by a kernel of its own. The discriminator step and the forward / critic-loss
+    launch read their rows straight from the rings through the indices (il_batch.gather), so both branches start right after the index draw;
+    extra workgroups of k_sac_chain write the gathered agent rows for the later kernels (il_sac_update_gather). IL_RING_GATHER=0: gather first."""
+    return self.device_sync and os.environ.get('IL_RING_GATHER', '1') != '0'
+
   def _ring_batches(self):
-    """The discriminator step reads its 2 x B rows straight from the two rings through the drawn indices (il_gail_extra.gather_*): on the device-side
-    hand-off it then waits for the index draw only, not for the gather kernel behind it."""
     if self._ring_desc is None:
-      def ring_desc(mem):
-        t = batch_views(mem.ring, mem.state_size, mem.action_size, False)
-        t['absorbing'] = t['terminals']   # not read by the discriminator step (avoids a capacity-sized zeros tensor)
+      def ring_desc(mem, idx):
+        t = batch_views(mem.ring, mem.state_size, mem.action_size, True)
+        if not mem.absorbing: t['absorbing'] = self._zero_column(mem)
         b = batch_desc(t); b.n = self.B
+        b.gather, b.gather_capacity = idx.data_ptr(), mem.size
         return b
-      x = _lib.GailExtra()
-      x.gather_policy, x.gather_expert = self.idx.data_ptr(), self.eidx.data_ptr()
-      x.capacity_policy, x.capacity_expert = self.memory.size, self.expert_memory.size
-      self._ring_desc = (ring_desc(self.memory), ring_desc(self.expert_memory), x)
+      self._ring_desc = (ring_desc(self.memory, self.idx), ring_desc(self.expert_memory, self.eidx))
     return self._ring_desc
+
+  def _zero_column(self, mem):
+    """A ring-strided view of zeros for the `absorbing` field of a ring without absorbing states (one float per ring row would be wasteful: every
+    row reads the same zero through stride 0)."""
+    z = torch.zeros(1, dtype=torch.float32, device=mem.ring.device)
+    self._keep_zero = z
+    return z.expand(mem.size)
 
   def _enqueue_discriminator_branch(self):
     L, st = _lib.lib(), _lib.stream_ptr()
-    if os.environ.get('IL_GAIL_GATHER', '1') != '0':
-      rp, re_, x = self._ring_batches()
-      _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(rp), C.byref(re_), None, C.byref(x), 0, st))
+    if self.ring_mode:
+      rp, re_ = self._ring_batches()
+      _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(rp), C.byref(re_), None, None, 0, st))
     else:
       _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))
     _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
 
   def _enqueue_sac_branch(self):
     self.sample_all()
+    if self.ring_mode:
+      _lib.check(_lib.lib().il_sac_update_gather(C.byref(self.sac), C.byref(self.pb), C.byref(self._ring_batches()[0]), _lib.ptr(self.rewards), None, None,
+                                                 _lib.ptr(self.logp), _lib.ptr(self.q), self.prepared_flag(), _lib.stream_ptr()))
+      return
     _lib.check(_lib.lib().il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), self.prepared_flag(), _lib.stream_ptr()))
 
   def _run_update(self):

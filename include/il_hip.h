@@ -63,6 +63,11 @@ typedef struct il_batch {
   const float *states, *actions, *rewards, *next_states, *terminals, *weights, *absorbing;
   int32_t ld_states, ld_actions, ld_rewards, ld_next_states, ld_terminals, ld_weights, ld_absorbing;
   int32_t n; /* rows */
+  /* Optional row indirection: with gather != NULL the field pointers describe a replay RING (ring row 0, ld = ring row floats) and batch row r
+   * of every field is ring row gather[r], clamped to [0, gather_capacity) like il_replay_gather. Honoured by il_gail_disc_step and
+   * il_sac_update_gather only (they then need an update's index DRAW but not its gather); every other entry point rejects it. */
+  const int32_t* gather;
+  int64_t gather_capacity;
 } il_batch;
 
 /* ------------------------------------------------------------------------------------------
@@ -101,7 +106,8 @@ int il_mt19937_randint(uint32_t* state_host, int64_t high, int32_t n, int32_t* o
  * ring_state_dev = {int64 idx, int64 full, int64 size}. */
 int il_mt19937_sample_indices_device(uint32_t* state_dev, const int64_t* ring_state_dev, int32_t n, int32_t* out_dev, il_stream_t stream);
 /* train.py:173 `memory.sample(B), expert_memory.sample(B)` in ONE launch: n draws for ring A, then n for ring B (same stream,
- * same order as the reference), then both row gathers. Ring B may be NULL (algorithm=SAC). */
+ * same order as the reference), then both row gathers. Ring B may be NULL (algorithm=SAC). rows_a = rows_b = NULL: the draw only
+ * (the consumers then read the rings through il_batch.gather). */
 int32_t il_replay_gather_workgroups(int32_t n, int32_t row_floats_a, int32_t row_floats_b); /* row_floats_b = 0 without ring B */
 int il_replay_sample_device(uint32_t* state_dev, int32_t n, const int64_t* ring_state_a, const float* ring_a, int64_t capacity_a, int32_t row_floats_a,
                             int32_t* idx_a, float* rows_a, const int64_t* ring_state_b, const float* ring_b, int64_t capacity_b, int32_t row_floats_b,
@@ -137,7 +143,7 @@ int il_polyak(float* target, const float* param, int64_t n, double tau, il_strea
  *   [IL_SYNC_SIDE_EPOCH] += 1 when a reward relabel has finished;  [IL_SYNC_MAIN_EPOCH] += 1 at the end of the actor step
  *   [IL_SYNC_TIMEOUTS]   += 1 whenever a bounded wait gave up (must stay 0: check it on the host after the first update)
  *   [IL_SYNC_GATHER_WGS] = il_replay_gather_workgroups(n, row_floats_a, row_floats_b), written by the caller when it creates the buffer.
- *   [IL_SYNC_INDICES]    += 1 per finished index draw              -> k_gail_grad with il_gail_extra.gather_* waits for side_epoch + 1
+ *   [IL_SYNC_INDICES]    += 1 per finished index draw              -> k_gail_grad on il_batch.gather batches waits for side_epoch + 1 (not for the rows)
  * With it the two branches need no stream dependency between the gather and the critic loss (fork at the start of the update, join at
  * its end). NULL everywhere = plain stream ordering (the caller serialises or uses events). */
 /* il_sync_probe: slots 6, 7 of the same buffer; enqueue setter = 0 on the side stream first, then setter = 1 on the main stream. */
@@ -196,6 +202,15 @@ int il_sac_prepare(const il_sac* d, il_stream_t stream);
 /* whole training.py:14-54 in one call (critic step then actor step) */
 int il_sac_update(const il_sac* d, const il_batch* batch, const float* eps_next, const float* eps_cur, float* out_logp, float* out_q,
                   uint32_t flags, il_stream_t stream);
+/* il_sac_update for a batch that has been DRAWN but not gathered: `ring` is an il_batch with `gather` set (the replay ring and this update's indices),
+ * `rows` describes the destination of the gather (packed rows: states at offset 0, ld_states = row floats) and is what the later kernels of the
+ * update read. The forward / critic-loss launch (k_sac_chain) reads its rows straight from the ring while extra workgroups of the same launch
+ * write `rows` (and signal [IL_SYNC_ROWS], il_sac_chain_gather_workgroups() times), so no gather kernel precedes the update.
+ * rewards: optional dense [B] rewards that replace the ring's (train.py:194 relabelled rewards); NULL = the ring's reward field. Whole updates of a
+ * single learner only; IL_ERR_UNSUPPORTED when the launch cannot be co-resident (then gather first and call il_sac_update). */
+int il_sac_update_gather(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const float* eps_next, const float* eps_cur, float* out_logp,
+                         float* out_q, uint32_t flags, il_stream_t stream);
+int32_t il_sac_chain_gather_workgroups(int32_t batch, int32_t row_floats, int32_t hidden);
 
 /* training.py:57-64 behavioural_cloning_update + models.py:97-99 SoftActor.log_prob (clamp, atanh). */
 int il_bc_step(float* actor, float* actor_grad, const il_adam* opt, int32_t state_dim, int32_t action_dim, int32_t hidden,
@@ -267,12 +282,6 @@ typedef struct il_gail_extra {
   const float* eps_mix;              /* [B] the Beta(alpha, alpha) draws of Mixup (training.py:106); NULL => U(0,1) from Philox, i.e. alpha = 1 */
   const float* logit_offset_policy;  /* [B] log pi(a|s) of the policy batch when subtract_log_policy (models.py:144,175) */
   const float* logit_offset_expert;  /* [B] same for the expert batch */
-  /* Optional row indirection for il_gail_disc_step: with gather_policy != NULL the `policy` argument describes the replay RING (field pointers of
-   * ring row 0, ld = ring row floats, n = batch) and batch row r is ring row gather_policy[r], clamped to [0, capacity_policy) like
-   * il_replay_gather does; likewise for the expert ring. The step then needs the index DRAW of an update but not its gather: with il_sync counters
-   * it waits for [IL_SYNC_INDICES] instead of [IL_SYNC_ROWS] and starts one kernel earlier. Results are identical to passing the gathered rows. */
-  const int32_t* gather_policy; const int32_t* gather_expert;
-  int64_t capacity_policy, capacity_expert;
 } il_gail_extra;
 
 int64_t il_disc_workspace_floats(int32_t in_dim, int32_t hidden, int32_t batch);

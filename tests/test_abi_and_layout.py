@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header():
   """ctypes mirrors vs the C structs (sizes computed from the header's field lists on an LP64 target)."""
   from imitation_learning_amd import _lib
-  assert C.sizeof(_lib.Batch) == 7 * 8 + 8 * 4
+  assert C.sizeof(_lib.Batch) == 7 * 8 + 8 * 4 + 8 + 8   # + gather, gather_capacity
   assert C.sizeof(_lib.Adam) == 3 * 8 + 5 * 8
   assert C.sizeof(_lib.Pwil) == 4 * 4 + 5 * 8 + 3 * 8
   assert C.sizeof(_lib.Sac) == 4 * 4 + 7 * 8 + 3 * C.sizeof(_lib.Adam) + 2 * 4 + 8 + 8 + 8 + 8 + 8 + 2 * 8 + 8
