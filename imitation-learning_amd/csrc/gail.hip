@@ -458,13 +458,14 @@ __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, floa
   const float b2 = d.params[lay.ob2];
   DiscLds L = carve(smem, D, H);
   stage_weights(L, d.params + lay.oW1, d.params + lay.ob1, d.params + lay.oW2, D, H);
-  if (d.sync) {   // the discriminator step before this kernel may have run off the index draw alone (il_gail_extra.gather_*): the gathered rows are read here
+  if (d.sync && !b.gather) {   // gathered rows: the discriminator step before this kernel may have run off the index draw alone, so their arrival is checked here
     long long* sy = reinterpret_cast<long long*>(d.sync);
     sync_wait(sy, IL_SYNC_ROWS, (sy[IL_SYNC_SIDE_EPOCH] + 1) * sy[IL_SYNC_GATHER_WGS]);
   }
   for (int i = tid; i < IL_TILE_R * Dp; i += blockDim.x) {
-    const int r = i / Dp, k = i - r * Dp;
-    L.X(0)[i] = (r < nrows && k < D) ? (k < S ? b.states[(size_t)(row0 + r) * b.ld_states + k] : b.actions[(size_t)(row0 + r) * b.ld_actions + k - S]) : 0.f;
+    const int r = i / Dp, k = i - r * Dp; float xv = 0.f;
+    if (r < nrows && k < D) { const size_t sr = brow(b, row0 + r); xv = k < S ? b.states[sr * b.ld_states + k] : b.actions[sr * b.ld_actions + k - S]; }
+    L.X(0)[i] = xv;
   }
   if (d.spectral_norm) {
     for (int i = tid; i < H; i += blockDim.x) { L.u1(0)[i] = d.u1[i]; L.v2(0)[i] = d.v2[i]; }
@@ -573,7 +574,6 @@ extern "C" int il_gail_apply_grads(const il_disc* d, il_stream_t stream_) {
 }
 
 extern "C" int il_gail_reward(const il_disc* d, const il_batch* b, float* out_rewards, float* out_logits, const float* logit_offset, il_stream_t stream_) {
-  IL_NO_GATHER(b, "il_gail_reward");
   if (int rc = check_disc(d)) return rc;
   IL_CHECK_ARG(b && out_rewards && b->n > 0, "il_gail_reward: bad arguments");
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);

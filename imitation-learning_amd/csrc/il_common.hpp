@@ -39,7 +39,7 @@ __device__ __forceinline__ f32x4 gload4(const float* p) { return *(const __attri
 // ONE pending flat access (a flat_store of an activation slab is enough) makes the compiler turn every later wait into vmcnt(0) lgkmcnt(0).
 // Round-tripping the fields through address space 1 lets address-space inference type every derived access as global.
 // entry points whose kernels index batch rows directly
-#define IL_NO_GATHER(b, who) IL_CHECK_ARG(!(b) || !(b)->gather, who ": il_batch.gather is only honoured by il_gail_disc_step and il_sac_update_gather")
+#define IL_NO_GATHER(b, who) IL_CHECK_ARG(!(b) || !(b)->gather, who ": il_batch.gather is only honoured by il_gail_disc_step, il_gail_reward and il_sac_update_gather")
 // batch row -> source row of an il_batch: identity, or through the batch's index array (il_batch.gather, clamped like il_replay_gather)
 __device__ __forceinline__ size_t brow(const il_batch& b, int row) {
   if (!b.gather) return (size_t)row;

@@ -437,8 +437,9 @@ class UpdatePlan:
     if self.ring_mode:
       rp, re_ = self._ring_batches()
       _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(rp), C.byref(re_), None, None, 0, st))
-    else:
-      _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))
+      _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(rp), _lib.ptr(self.rewards), None, None, st))
+      return
+    _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))
     _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
 
   def _enqueue_sac_branch(self):

@@ -64,7 +64,7 @@ typedef struct il_batch {
   int32_t ld_states, ld_actions, ld_rewards, ld_next_states, ld_terminals, ld_weights, ld_absorbing;
   int32_t n; /* rows */
   /* Optional row indirection: with gather != NULL the field pointers describe a replay RING (ring row 0, ld = ring row floats) and batch row r
-   * of every field is ring row gather[r], clamped to [0, gather_capacity) like il_replay_gather. Honoured by il_gail_disc_step and
+   * of every field is ring row gather[r], clamped to [0, gather_capacity) like il_replay_gather. Honoured by il_gail_disc_step, il_gail_reward and
    * il_sac_update_gather only (they then need an update's index DRAW but not its gather); every other entry point rejects it. */
   const int32_t* gather;
   int64_t gather_capacity;
