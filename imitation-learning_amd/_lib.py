@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('IL_HIP_LIBRARY') or os.path.join(_HERE, 'libil_hip.so')   # IL_HIP_LIBRARY: developer A/B builds of the same ABI
 
 IL_FLAG_GRADS_ONLY, IL_FLAG_TICK, IL_FLAG_SAC_FORWARD_ONLY, IL_FLAG_SAC_SKIP_FORWARD, IL_FLAG_SAC_PREPARED = 1, 2, 4, 8, 16
+IL_FLAG_GAIL_CLOSE_EPOCH = 32
 c_f32p, c_i32p, c_u32p, c_i64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)
 
 
@@ -113,7 +114,8 @@ _SIGNATURES = {
     'il_sac_prepare': (C.c_int, [C.POINTER(Sac), _P]),
     'il_sac_dp_phase': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.c_int32, _P, _P, C.c_uint32, _P]),
     'il_sac_update': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), _P, _P, _P, _P, C.c_uint32, _P]),
-    'il_sac_update_gather': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.POINTER(Batch), _P, _P, _P, _P, _P, C.c_uint32, _P]),
+    'il_sac_update_gather': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.POINTER(Batch), _P, C.POINTER(Disc), _P, _P, _P, _P, _P, C.c_uint32, _P]),
+    'il_gail_step_workgroups': (C.c_int32, [C.POINTER(Disc)]),
     'il_sac_chain_gather_workgroups': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     'il_bc_step': (C.c_int, [_P, _P, C.POINTER(Adam), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Batch), _P, C.c_int64, _P, C.c_uint32, _P]),
     'il_actor_act': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_uint64, C.c_uint32, C.c_int32, _P, _P, _P]),

@@ -12,15 +12,8 @@
 // k_gail_reward eval-mode forward + AIRL / GAIL / FAIRL reward head.
 #include "il_common.hpp"
 #include "mlp_tile.hpp"
+#include "disc_reward.hpp"
 
-struct DiscLayout { int64_t oW1, ob1, oW2, ob2, P; };
-__host__ __device__ inline DiscLayout disc_layout(int D, int H, int sn) {
-  DiscLayout l;
-  if (sn) { l.ob1 = 0; l.oW1 = H; l.ob2 = H + (int64_t)H * D; l.oW2 = l.ob2 + 1; }
-  else { l.oW1 = 0; l.ob1 = (int64_t)H * D; l.oW2 = l.ob1 + H; l.ob2 = l.oW2 + H; }
-  l.P = (int64_t)H * D + 2 * H + 1;
-  return l;
-}
 struct DiscWs { int64_t slabs, sn_new, total; };
 __host__ __device__ inline DiscWs disc_ws(int D, int H, int B) {
   DiscWs w; const int64_t P = (int64_t)H * D + 2 * H + 1; const int nt = (B + IL_TILE_R - 1) / IL_TILE_R;
@@ -34,64 +27,6 @@ extern "C" int64_t il_disc_workspace_floats(int32_t D, int32_t H, int32_t B) { r
 // discriminator calls depend on nothing but W, u, v, so wave 0 runs all of them up front while waves 1.. stage the batch rows.
 // W1s: LDS copy of W1 with row stride D+1 (conflict-free for both W v and W^T u).
 // ---------------------------------------------------------------------------------------------
-// LDS dot products with several loads in flight (a plain `for k: s += a[k]*b[k]` waits ~100 cycles per LDS read)
-__device__ __forceinline__ float dot4(const float* a, const float* b, int n4) {  // both 16-B aligned, n4 % 4 == 0
-  f32x4 s0 = zero4(), s1 = zero4();
-  int k = 0;
-  for (; k + 8 <= n4; k += 8) {
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(a + k), b0 = *reinterpret_cast<const f32x4*>(b + k);
-    const f32x4 a1 = *reinterpret_cast<const f32x4*>(a + k + 4), b1 = *reinterpret_cast<const f32x4*>(b + k + 4);
-    s0 += a0 * b0; s1 += a1 * b1;
-  }
-  if (k < n4) s0 += *reinterpret_cast<const f32x4*>(a + k) * *reinterpret_cast<const f32x4*>(b + k);
-  s0 += s1;
-  return (s0[0] + s0[1]) + (s0[2] + s0[3]);
-}
-__device__ __forceinline__ float dot_strided(const float* a, const float* b, int bstride, int n) {  // a contiguous (16-B aligned), b[i*bstride], n % 4 == 0
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int i = 0; i < n; i += 4) {
-    const f32x4 av = *reinterpret_cast<const f32x4*>(a + i);
-    s0 += av[0] * b[(i + 0) * bstride]; s1 += av[1] * b[(i + 1) * bstride]; s2 += av[2] * b[(i + 2) * bstride]; s3 += av[3] * b[(i + 3) * bstride];
-  }
-  return (s0 + s1) + (s2 + s3);
-}
-
-// wave-synchronous LDS hand-off between lanes of ONE wave: LDS ops of a wave execute in order, this only pins the compiler
-#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-__device__ __forceinline__ float wave_norm_scale(float ss) { return 1.f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f); }
-
-// one wave: (u1,v1,u2,v2) <- one power iteration (if iterate), then sigmas. in/out vectors live in LDS.
-__device__ __forceinline__ void sn_wave(const float* W1s, const float* W2s, int D, int H, float* u1, float* v1, float* u2, float* v2, bool iterate, float* sig) {
-  const int lane = threadIdx.x & 63, Dp = (D + 3) & ~3, ldw = Dp + 4;
-  if (iterate) {
-    float ss = 0.f;
-    for (int n = lane; n < H; n += 64) { const float s = dot4(W1s + n * ldw, v1, Dp); u1[n] = s; ss += s * s; }
-    float inv = wave_norm_scale(ss);
-    for (int n = lane; n < H; n += 64) u1[n] *= inv;
-    WAVE_SYNC();
-    ss = 0.f;
-    for (int k = lane; k < D; k += 64) { const float s = dot_strided(u1, W1s + k, ldw, H); v1[k] = s; ss += s * s; }
-    inv = wave_norm_scale(ss);
-    for (int k = lane; k < D; k += 64) v1[k] *= inv;
-    WAVE_SYNC();
-    float p = 0.f;
-    for (int n = lane; n < H; n += 64) p += W2s[n] * v2[n];
-    p = wave_sum(p);
-    const float uu = p / fmaxf(fabsf(p), 1e-12f);
-    ss = 0.f;
-    for (int n = lane; n < H; n += 64) { const float s = W2s[n] * uu; v2[n] = s; ss += s * s; }
-    inv = wave_norm_scale(ss);
-    for (int n = lane; n < H; n += 64) v2[n] *= inv;
-    if (lane == 0) u2[0] = uu;
-    WAVE_SYNC();
-  }
-  float a = 0.f, b = 0.f;
-  for (int n = lane; n < H; n += 64) { a += u1[n] * dot4(W1s + n * ldw, v1, Dp); b += W2s[n] * v2[n]; }
-  a = wave_sum(a); b = wave_sum(b);
-  if (lane == 0) { sig[0] = a; sig[1] = u2[0] * b; }
-  WAVE_SYNC();
-}
-
 // ---------------------------------------------------------------------------------------------
 // Spectral norm of call `c` (0-based): the reference runs c+1 chained power iterations u <- n(W v), v <- n(W^T u) before that call.
 // v only ever sees M = W^T W:  v_{i+1} = n(M v_i)  (the 1/||W v|| factor cancels in the normalisation), so the chain runs on the
@@ -403,7 +338,9 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
 __host__ __device__ inline int gail_calls(const il_disc& d) { return (d.loss_function == IL_LOSS_MIXUP ? 1 : 2) + (d.grad_penalty > 0.f ? 1 : 0); }
 
 // grid = ceil(P / 256): one gradient element per thread, slabs summed in tile order (deterministic)
-__global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const il_disc* __restrict__ dL) {
+// close_epoch (il_gail_disc_step with IL_FLAG_GAIL_CLOSE_EPOCH): no relabel kernel follows on this stream - the stepped parameters are consumed by the
+// critic-loss workgroups of k_sac_chain - so each workgroup reports [IL_SYNC_PARAMS] and the last one closes the side branch's epoch.
+__global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const il_disc* __restrict__ dL, int close_epoch) {
   if (dL) d = dL[blockIdx.y];
   globalize(d);
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch;
@@ -445,6 +382,14 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const
     for (int i = threadIdx.x; i < D; i += blockDim.x) d.v1[i] = o[H + i];
     if (threadIdx.x == 0) d.u2[0] = o[H + D];
   }
+  if (close_epoch && d.sync) {
+    long long* sy = reinterpret_cast<long long*>(d.sync);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const long long done = __hip_atomic_fetch_add(sy + IL_SYNC_PARAMS, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1;
+      if (done % (long long)gridDim.x == 0) __hip_atomic_fetch_add(sy + IL_SYNC_SIDE_EPOCH, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, float* __restrict__ out_r, float* __restrict__ out_logit, const float* __restrict__ logit_offset, const il_disc* __restrict__ dL,
@@ -452,12 +397,9 @@ __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, floa
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; out_r = outL[blockIdx.y]; out_logit = nullptr; }
   globalize(d); globalize(b); out_r = as_global(out_r);
-  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, Dp = (D + 3) & ~3, ldw = Dp + 4;
+  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, Dp = (D + 3) & ~3;
   const int row0 = blockIdx.x * IL_TILE_R, tid = threadIdx.x, nrows = min(IL_TILE_R, b.n - row0);
-  const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
-  const float b2 = d.params[lay.ob2];
   DiscLds L = carve(smem, D, H);
-  stage_weights(L, d.params + lay.oW1, d.params + lay.ob1, d.params + lay.oW2, D, H);
   if (d.sync && !b.gather) {   // gathered rows: the discriminator step before this kernel may have run off the index draw alone, so their arrival is checked here
     long long* sy = reinterpret_cast<long long*>(d.sync);
     sync_wait(sy, IL_SYNC_ROWS, (sy[IL_SYNC_SIDE_EPOCH] + 1) * sy[IL_SYNC_GATHER_WGS]);
@@ -467,26 +409,11 @@ __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, floa
     if (r < nrows && k < D) { const size_t sr = brow(b, row0 + r); xv = k < S ? b.states[sr * b.ld_states + k] : b.actions[sr * b.ld_actions + k - S]; }
     L.X(0)[i] = xv;
   }
-  if (d.spectral_norm) {
-    for (int i = tid; i < H; i += blockDim.x) { L.u1(0)[i] = d.u1[i]; L.v2(0)[i] = d.v2[i]; }
-    for (int i = tid; i < Dp; i += blockDim.x) L.v1(0)[i] = i < D ? d.v1[i] : 0.f;
-    if (tid == 0) L.sc(0)[2] = d.u2[0];
-  } else if (tid == 0) { L.sc(0)[0] = 1.f; L.sc(0)[1] = 1.f; }
-  __syncthreads();
-  if (d.spectral_norm && tid < 64) sn_wave(L.W1s, L.W2s, D, H, L.u1(0), L.v1(0), &L.sc(0)[2], L.v2(0), false, L.sc(0));  // eval mode: sigma only
-  __syncthreads();
-  const float s1 = L.sc(0)[0], s2 = L.sc(0)[1];
-  const int r = tid >> 4, sub = tid & 15;
-  float zp = 0.f;
-  for (int n = sub; n < H; n += 16) zp += (L.W2s[n] / s2) * fmaxf(dot4(L.W1s + n * ldw, L.X(0) + r * Dp, Dp) / s1 + L.b1s[n], 0.f);
-  zp = group16_sum(zp);
-  if (sub == 0 && r < nrows) {
-    const float f = zp + b2, z = logit_offset ? f - logit_offset[row0 + r] : f, Dp = sigmoid_f(z);
-    float h = d.reward_function == 1 ? -log1pf(-Dp + 1e-6f) : logf(Dp + 1e-6f) - log1pf(-Dp + 1e-6f);
-    if (d.reward_function == 2) h = expf(h) * -h;
-    out_r[row0 + r] = h;
-    if (out_logit) out_logit[row0 + r] = z;
-  }
+  const RewardLds R = {L.W1s, L.b1s, L.W2s, L.u1(0), L.v1(0), L.v2(0), L.sc(0)};
+  disc_reward_tile(d, R, L.X(0), Dp, nrows, logit_offset, row0, [&](int r, float reward, float logit) {
+    out_r[row0 + r] = reward;
+    if (out_logit) out_logit[row0 + r] = logit;
+  });
   if (d.sync) {   // rewards of this tile are in place; the workgroup that completes the relabel closes the side branch's epoch
     long long* sy = reinterpret_cast<long long*>(d.sync);
     __syncthreads();
@@ -530,7 +457,7 @@ extern "C" int il_gail_disc_step(const il_disc* d, const il_batch* pol, const il
   if (int rc = ensure_lds((const void*)k_gail_grad, lds)) return rc;
   { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, nullptr, nullptr, nullptr); }
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
-  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr); }
+  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr, (flags & IL_FLAG_GAIL_CLOSE_EPOCH) ? 1 : 0); }
   IL_CHECK_LAUNCH("il_gail_disc_step");
   return IL_OK;
 }
@@ -550,7 +477,7 @@ extern "C" int il_gail_step_population(const il_disc* descs_dev, const il_batch*
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
   il_batch zb = {};
   { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d), L), 256, lds, st>>>(*d, zb, zb, nullptr, il_gail_extra{}, descs_dev, policy_dev, expert_dev); }
-  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<dim3((int)((P + 255) / 256), L), 256, 0, st>>>(*d, 1, descs_dev); }
+  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<dim3((int)((P + 255) / 256), L), 256, 0, st>>>(*d, 1, descs_dev, 0); }
   { IL_TRACE("k_gail_reward", st); k_gail_reward<<<dim3(nt, L), 256, lds, st>>>(*d, zb, nullptr, nullptr, nullptr, descs_dev, policy_dev, rewards_out_dev); }
   IL_CHECK_LAUNCH("il_gail_step_population");
   return IL_OK;

@@ -14,6 +14,7 @@
 // Parameters, Adam moments and the target network are each read and written exactly once per update (24 B/param + 8 B/param).
 #include "il_common.hpp"
 #include "mlp_tile.hpp"
+#include "disc_reward.hpp"
 
 
 struct SacWs {  // float offsets into il_sac.workspace
@@ -364,7 +365,24 @@ __device__ __forceinline__ void critic_bwd_resident_gemm(const il_sac& d, int k,
     for (int r = 0; r < 4; ++r) { float* h = H1s + (4 * g + r) * ldh + kb + j; *h = *h > 0.f ? acc[r] : 0.f; }   // each element owned by one lane
   });
 }
-__device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const il_batch& b, const float* __restrict__ rewards, int k, int tile, float* smem) {
+// relabel: the rewards of this tile are the discriminator `dd`'s prediction on (s, a) - the rows still sit in Xs - computed here once its AdamW step of
+// this update is complete ([IL_SYNC_PARAMS], n_reduce workgroups per step); otherwise dense `rewards` or the batch's own reward field.
+struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; };
+// Runs between the critic's own work and its wait for the targets: the discriminator's step usually lands while the targets are still being computed,
+// so the relabel stays off the critical path. Leaves the tile's rewards in LDS (rew16) for critic_bwd_resident_scale.
+__device__ __forceinline__ void critic_relabel_tile(const il_sac& d, const ChainRelabel& rl, int k, int tile, float* smem) {
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, IN = S + A;
+  const int row0 = tile * IL_TILE_R, INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
+  float* Xs = smem; float* q16 = Xs + IL_TILE_R * ldx + 2 * IL_TILE_R * ldh; float* rew16 = q16 + 2 * IL_TILE_R;
+  long long* sy = reinterpret_cast<long long*>(d.sync);
+  sync_wait(sy, IL_SYNC_PARAMS, (sy[IL_SYNC_MAIN_EPOCH] + 1) * (long long)rl.n_reduce);
+  const RewardLds R = reward_carve(q16 + 64, rl.dd.state_dim + rl.dd.action_dim, rl.dd.hidden);
+  disc_reward_tile(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
+    rew16[r] = reward;
+    if (k == 0 && rl.out) rl.out[row0 + r] = reward;
+  });
+}
+__device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const il_batch& b, const float* __restrict__ rewards, const ChainRelabel& rl, int k, int tile, float* smem) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R, row0 = tile * IL_TILE_R;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
@@ -372,7 +390,8 @@ __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const
   const SacWs ws = sac_ws(S, A, H, B);
   float* W = d.workspace;
   float* gdz2 = W + ws.c_dz2 + (size_t)k * B * H; float* gdz1 = W + ws.c_dz1 + (size_t)k * B * H;
-  if (d.sync) {   // rewards come from the discriminator branch on another stream (see k_critic_bwd)
+  float* rew16 = dz3s + IL_TILE_R;   // filled by critic_relabel_tile when rl.on
+  if (!rl.on && d.sync) {   // rewards come from the discriminator branch on another stream (see k_critic_bwd)
     long long* sy = reinterpret_cast<long long*>(d.sync);
     sync_wait(sy, IL_SYNC_REWARDS, (sy[IL_SYNC_MAIN_EPOCH] + 1) * (long long)nt);
   }
@@ -382,7 +401,7 @@ __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const
     const size_t sr = brow(b, row);
     const float m = 1.f - b.absorbing[sr * b.ld_absorbing];
     const float tv = fminf(W[ws.t_q + row], W[ws.t_q + B + row]) - m * alpha * W[ws.n_logp2 + row];
-    const float rew = rewards ? rewards[row] : b.rewards[sr * b.ld_rewards];
+    const float rew = rl.on ? rew16[threadIdx.x] : (rewards ? rewards[row] : b.rewards[sr * b.ld_rewards]);
     const float y = rew + (1.f - b.terminals[sr * b.ld_terminals]) * d.discount * tv;
     const float q = q16[threadIdx.x];
     const float dq = (b.weights[sr * b.ld_weights] * (2.f * (q - y))) / (float)B;
@@ -424,9 +443,10 @@ __device__ __forceinline__ void chain_decode(int bid, int nt, int& role, int& ne
 // indices, and the workgroups behind the 6 * nt chain roles copy the rows to `rows_out` for the later kernels of the update (one 16-byte
 // lane per thread, [IL_SYNC_ROWS] += 1 per workgroup) - they wait for nothing and nobody in this launch waits for them.
 __global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, const float* __restrict__ rewards,
-                                                    float* __restrict__ rows_out) {
+                                                    float* __restrict__ rows_out, ChainRelabel rl) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   globalize(d); globalize(b);
+  if (rl.on) { globalize(rl.dd); rl.out = as_global(rl.out); }
   const int nt = d.batch / IL_TILE_R;
   if ((int)blockIdx.x >= 6 * nt) {
     const int row4 = b.ld_states / 4, lanes = d.batch * row4, G = (int)gridDim.x - 6 * nt;
@@ -449,9 +469,10 @@ __global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const 
   else if (role == 2) {
     critic_fwd_tile(d, b, net, tile, smem, nullptr, nullptr);
     critic_bwd_resident_gemm(d, net, smem);
+    if (rl.on) critic_relabel_tile(d, rl, net, tile, smem);
     tile_await(ctr, 3u, timeouts);
     if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 4u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    critic_bwd_resident_scale(d, b, rewards, net, tile, smem);
+    critic_bwd_resident_scale(d, b, rewards, rl, net, tile, smem);
   } else actor_fwd_tile(d, b, eps_next, eps_cur, true, tile, smem);
 }
 
@@ -1000,7 +1021,7 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
   const bool whole = !(flags & (IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY));
   if (whole && chain_enabled() && 6 * nt <= chain_cu_count()) {   // forward + critic loss chained per tile in one co-resident launch (k_sac_chain)
     if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
-    { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr); }
+    { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr, ChainRelabel{}); }
     flags |= IL_FLAG_SAC_SKIP_FORWARD | 0x80000000u;
   }
   if (!(flags & IL_FLAG_SAC_SKIP_FORWARD)) {
@@ -1027,9 +1048,25 @@ extern "C" int32_t il_sac_chain_gather_workgroups(int32_t batch, int32_t row_flo
   return (int32_t)(((int64_t)batch * (row_floats / 4) + tile_threads(hidden) - 1) / tile_threads(hidden));
 }
 
-extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const float* eps_next, const float* eps_cur, float* out_logp,
-                                    float* out_q, uint32_t flags, il_stream_t stream_) {
+extern "C" int32_t il_gail_step_workgroups(const il_disc* d) {
+  if (!d) return 0;
+  return (int32_t)((disc_layout(d->state_dim + (d->state_only ? 0 : d->action_dim), d->hidden, d->spectral_norm).P + 255) / 256);
+}
+
+extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const il_disc* relabel, float* rewards_out,
+                                    const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream_) {
   if (int rc = check_sac(d, rows)) return rc;
+  ChainRelabel rl = {};
+  if (relabel) {
+    IL_CHECK_ARG(d->sync && relabel->sync == d->sync, "il_sac_update_gather: the inline relabel needs the il_sync counters shared with the discriminator");
+    IL_CHECK_ARG(!rewards, "il_sac_update_gather: pass either `rewards` or `relabel`");
+    if (relabel->state_only || relabel->state_dim != d->state_dim || relabel->action_dim != d->action_dim)
+      return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update_gather: inline relabel needs a discriminator on the critic's (s, a) input");
+    const size_t spare = (size_t)(tile_threads(d->hidden) / 64) * 256 + 256 - 32;   // the workgroup's LDS behind q16 / dz3 / rewards16 (tile_lds_bytes)
+    if (reward_lds_floats(d->state_dim + d->action_dim, relabel->hidden) > spare)
+      return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update_gather: discriminator too large for the inline relabel (%zu > %zu LDS floats)", reward_lds_floats(d->state_dim + d->action_dim, relabel->hidden), spare);
+    rl.dd = *relabel; rl.on = 1; rl.n_reduce = il_gail_step_workgroups(relabel); rl.out = rewards_out;
+  }
   IL_CHECK_ARG(ring && ring->gather && ring->gather_capacity > 0 && ring->n == d->batch, "il_sac_update_gather: `ring` must carry the %d drawn indices (il_batch.gather)", d->batch);
   IL_CHECK_ARG(rows->states && ring->states && rows->ld_states == ring->ld_states && ring->ld_states % 4 == 0, "il_sac_update_gather: rows / ring must be packed rows of the same width");
   IL_CHECK_ARG(!(flags & (IL_FLAG_GRADS_ONLY | IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY)), "il_sac_update_gather: whole updates only");
@@ -1039,7 +1076,7 @@ extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const
   if (6 * nt + G > chain_cu_count()) return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update_gather: %d workgroups cannot be co-resident on %d CUs (gather first, then il_sac_update)", 6 * nt + G, chain_cu_count());
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
-  { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt + G, tile_threads(H), lds, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states)); }
+  { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt + G, tile_threads(H), lds, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl); }
   DwArgs ca = critic_dw_args(d, flags);
   { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
   { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); k_policy_critic<<<(2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *rows, out_logp, out_q, nullptr, nullptr, hp); }

@@ -432,10 +432,23 @@ class UpdatePlan:
     self._keep_zero = z
     return z.expand(mem.size)
 
+  @property
+  def inline_relabel(self) -> bool:
+    """Ring mode with a discriminator on (s, a) small enough for the critic-loss workgroups' spare LDS: the reward relabel runs INSIDE k_sac_chain as soon as
+    the discriminator's AdamW step has signalled (il_sac_update_gather `relabel`), so the side branch ends with that step. IL_INLINE_RELABEL=0: separate kernel."""
+    if not self.ring_mode or os.environ.get('IL_INLINE_RELABEL', '1') == '0' or self.disc.state_only:
+      return False
+    D, Hd = self.disc.state_dim + self.disc.action_dim, self.disc.hidden
+    Dp = (D + 3) // 4 * 4
+    return Hd * (Dp + 4) + 4 * Hd + Dp + 8 <= max(4, self.sac.hidden // 16) * 256 + 256 - 32
+
   def _enqueue_discriminator_branch(self):
     L, st = _lib.lib(), _lib.stream_ptr()
     if self.ring_mode:
       rp, re_ = self._ring_batches()
+      if self.inline_relabel:
+        _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(rp), C.byref(re_), None, None, _lib.IL_FLAG_GAIL_CLOSE_EPOCH, st))
+        return
       _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(rp), C.byref(re_), None, None, 0, st))
       _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(rp), _lib.ptr(self.rewards), None, None, st))
       return
@@ -445,7 +458,9 @@ class UpdatePlan:
   def _enqueue_sac_branch(self):
     self.sample_all()
     if self.ring_mode:
-      _lib.check(_lib.lib().il_sac_update_gather(C.byref(self.sac), C.byref(self.pb), C.byref(self._ring_batches()[0]), _lib.ptr(self.rewards), None, None,
+      inline = self.inline_relabel
+      _lib.check(_lib.lib().il_sac_update_gather(C.byref(self.sac), C.byref(self.pb), C.byref(self._ring_batches()[0]), None if inline else _lib.ptr(self.rewards),
+                                                 C.byref(self.disc) if inline else None, _lib.ptr(self.rewards) if inline else None, None, None,
                                                  _lib.ptr(self.logp), _lib.ptr(self.q), self.prepared_flag(), _lib.stream_ptr()))
       return
     _lib.check(_lib.lib().il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), self.prepared_flag(), _lib.stream_ptr()))

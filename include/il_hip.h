@@ -39,6 +39,8 @@ enum { IL_OK = 0, IL_ERR_ARG = 1, IL_ERR_UNSUPPORTED = 2, IL_ERR_HIP = 3, IL_ERR
 #define IL_FLAG_SAC_PREPARED 16u    /* the lane-ordered weight copies in the workspace match the parameters: il_sac_prepare() ran, or the previous
                                        il_sac_update / il_sac_dp_phase / il_sac_update_population call on this descriptor left them in step (its Adam and
                                        polyak epilogues update them) and nothing else touched the parameters since. Skips the re-ordering kernel. */
+#define IL_FLAG_GAIL_CLOSE_EPOCH 32u /* il_gail_disc_step with il_sync counters: no il_gail_reward follows (il_sac_update_gather relabels inline): the AdamW
+                                      workgroups report [IL_SYNC_PARAMS] and the last one closes the discriminator branch's epoch */
 #define IL_FLAG_SAC_SKIP_FORWARD 8u /* il_sac_update: everything after them (the caller already ran FORWARD_ONLY on this batch) */
 
 typedef void* il_stream_t; /* hipStream_t */
@@ -144,11 +146,13 @@ int il_polyak(float* target, const float* param, int64_t n, double tau, il_strea
  *   [IL_SYNC_TIMEOUTS]   += 1 whenever a bounded wait gave up (must stay 0: check it on the host after the first update)
  *   [IL_SYNC_GATHER_WGS] = il_replay_gather_workgroups(n, row_floats_a, row_floats_b), written by the caller when it creates the buffer.
  *   [IL_SYNC_INDICES]    += 1 per finished index draw              -> k_gail_grad on il_batch.gather batches waits for side_epoch + 1 (not for the rows)
+ *   [IL_SYNC_PARAMS]     += 1 per finished AdamW(discriminator) workgroup (IL_FLAG_GAIL_CLOSE_EPOCH) -> the inline relabel of il_sac_update_gather waits
+ *                          for (main_epoch + 1) * il_gail_step_workgroups()
  * With it the two branches need no stream dependency between the gather and the critic loss (fork at the start of the update, join at
  * its end). NULL everywhere = plain stream ordering (the caller serialises or uses events). */
 /* il_sync_probe: slots 6, 7 of the same buffer; enqueue setter = 0 on the side stream first, then setter = 1 on the main stream. */
 int il_sync_probe(int64_t* sync, int32_t setter, il_stream_t stream);
-enum { IL_SYNC_ROWS = 0, IL_SYNC_REWARDS = 1, IL_SYNC_SIDE_EPOCH = 2, IL_SYNC_MAIN_EPOCH = 3, IL_SYNC_TIMEOUTS = 4, IL_SYNC_GATHER_WGS = 5, IL_SYNC_INDICES = 8, IL_SYNC_SLOTS = 16 };
+enum { IL_SYNC_ROWS = 0, IL_SYNC_REWARDS = 1, IL_SYNC_SIDE_EPOCH = 2, IL_SYNC_MAIN_EPOCH = 3, IL_SYNC_TIMEOUTS = 4, IL_SYNC_GATHER_WGS = 5, IL_SYNC_INDICES = 8, IL_SYNC_PARAMS = 9, IL_SYNC_SLOTS = 16 };
 
 /* ------------------------------------------------------------------------------------------
  * SAC (reference training.py:14-54 `sac_update`; models.py:84-141 SoftActor / TwinCritic).
@@ -208,8 +212,14 @@ int il_sac_update(const il_sac* d, const il_batch* batch, const float* eps_next,
  * write `rows` (and signal [IL_SYNC_ROWS], il_sac_chain_gather_workgroups() times), so no gather kernel precedes the update.
  * rewards: optional dense [B] rewards that replace the ring's (train.py:194 relabelled rewards); NULL = the ring's reward field. Whole updates of a
  * single learner only; IL_ERR_UNSUPPORTED when the launch cannot be co-resident (then gather first and call il_sac_update). */
-int il_sac_update_gather(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const float* eps_next, const float* eps_cur, float* out_logp,
-                         float* out_q, uint32_t flags, il_stream_t stream);
+int il_sac_update_gather(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const struct il_disc* relabel, float* rewards_out,
+                         const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream);
+/* relabel != NULL (needs d->sync; the discriminator must be stepped by il_gail_disc_step(..., IL_FLAG_GAIL_CLOSE_EPOCH) on another stream): the rewards
+ * are predict_reward(s, a) of that discriminator (models.py:177-180, train.py:192-194), computed per 16-row tile INSIDE the critic-loss workgroups as
+ * soon as [IL_SYNC_PARAMS] says its AdamW step is done - no relabel kernel, no reward hand-off; written to rewards_out [B] if given. Same code and
+ * thread mapping as il_gail_reward, so the values are bit-identical. IL_ERR_UNSUPPORTED for state_only discriminators or ones too large for the
+ * workgroup's spare LDS (then relabel with il_gail_reward and pass `rewards`). */
+int32_t il_gail_step_workgroups(const struct il_disc* d); /* AdamW workgroups of il_gail_disc_step = what [IL_SYNC_PARAMS] advances by per step */
 int32_t il_sac_chain_gather_workgroups(int32_t batch, int32_t row_floats, int32_t hidden);
 
 /* training.py:57-64 behavioural_cloning_update + models.py:97-99 SoftActor.log_prob (clamp, atanh). */
