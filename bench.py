@@ -273,6 +273,7 @@ def main():
   ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--trace-steps', type=int, default=100)
+  ap.add_argument('--no-overlap', action='store_true', help='one stream, no device-side hand-off: the same kernels back to back (what a counter-collecting profiler needs; il_sac_update still takes its chained launch)')
   ap.add_argument('--no-population', action='store_true')
   ap.add_argument('--no-secondary', action='store_true', help='skip the SAC-only / discriminator-only / GMMIL / PWIL rates')
   ap.add_argument('--population-learners', type=int, default=16)
@@ -293,6 +294,9 @@ def main():
   from imitation_learning_amd.parallel import DataParallelUpdate, broadcast_parameters
 
   plan, nets, (tr, et) = build(device, rank, learner_id=0 if args.learners > 1 else None)
+  if args.no_overlap:
+    plan.overlap = False
+    plan._set_device_sync(False)
   runner = plan
   if args.learners > 1:
     from imitation_learning_amd import PopulationPlan
@@ -352,7 +356,9 @@ def main():
                config=dict(workload='algorithm=GAIL env=halfcheetah: 2 replay samples + discriminator step (BCE+GP+SN) + AIRL relabel + sac_update per step',
                            batch_per_gpu=B, global_batch=B * world, state_dim=S, action_dim=A, hidden=H, replay_capacity=1_000_000, replay_fill=100_000, expert_rows=25_000,
                            learners_per_gpu=args.learners, parallelism=f'dp{world}' + ('(split path)' if runner is not plan else ''), launch=launch, noise='on-chip Philox4x32-10', finite=finite,
-                           branch_sync=('device counters (two graphs, no cross-stream edge)' if getattr(plan, 'device_sync', False) and runner is plan else 'stream dependencies')),
+                           branch_sync=('device counters (two graphs, no cross-stream edge)' if getattr(plan, 'device_sync', False) and runner is plan else 'stream dependencies'),
+                           rows=('read from the rings through the drawn indices (il_batch.gather), relabel inline in k_sac_chain' if getattr(plan, 'inline_relabel', False) and runner is plan
+                                 else ('read from the rings through the drawn indices (il_batch.gather)' if getattr(plan, 'ring_mode', False) and runner is plan else 'gathered by k_gather2'))),
                roofline=roof)
     if world == 1 and args.learners == 1 and not args.no_population:
       # population axis (the reference's own usage: 10-seed sweeps / Ax trials): independent batch-256 learners advanced by the

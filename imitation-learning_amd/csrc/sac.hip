@@ -382,7 +382,23 @@ __device__ __forceinline__ void critic_relabel_tile(const il_sac& d, const Chain
     if (k == 0 && rl.out) rl.out[row0 + r] = reward;
   });
 }
-__device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const il_batch& b, const float* __restrict__ rewards, const ChainRelabel& rl, int k, int tile, float* smem) {
+// per-row scalars of the critic loss that depend on neither the targets nor the rewards: requested before the wait for the targets (through il_batch.gather they
+// are two dependent global loads, index then ring row)
+struct RowScalars { float m, not_done, weight, reward; };
+__device__ __forceinline__ RowScalars critic_row_scalars(const il_batch& b, bool reward_ready, int tile) {
+  RowScalars rs = {0.f, 0.f, 0.f, 0.f};
+  if (threadIdx.x < IL_TILE_R) {
+    const int row = tile * IL_TILE_R + threadIdx.x;
+    const size_t sr = brow(b, row);
+    rs.m = 1.f - b.absorbing[sr * b.ld_absorbing];
+    rs.not_done = 1.f - b.terminals[sr * b.ld_terminals];
+    rs.weight = b.weights[sr * b.ld_weights];
+    if (reward_ready) rs.reward = b.rewards[sr * b.ld_rewards];   // (rewards that another stream is still relabelling are read after their wait)
+  }
+  return rs;
+}
+__device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const il_batch& b, const float* __restrict__ rewards, const ChainRelabel& rl, const RowScalars& rs, int k, int tile,
+                                                          float* smem) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R, row0 = tile * IL_TILE_R;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
@@ -398,13 +414,12 @@ __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const
   if (threadIdx.x < IL_TILE_R) {
     const int row = row0 + threadIdx.x;
     const float alpha = expf(d.log_alpha[0]);
-    const size_t sr = brow(b, row);
-    const float m = 1.f - b.absorbing[sr * b.ld_absorbing];
+    const float m = rs.m;
     const float tv = fminf(W[ws.t_q + row], W[ws.t_q + B + row]) - m * alpha * W[ws.n_logp2 + row];
-    const float rew = rl.on ? rew16[threadIdx.x] : (rewards ? rewards[row] : b.rewards[sr * b.ld_rewards]);
-    const float y = rew + (1.f - b.terminals[sr * b.ld_terminals]) * d.discount * tv;
+    const float rew = rl.on ? rew16[threadIdx.x] : (rewards ? rewards[row] : (d.sync ? b.rewards[brow(b, row) * b.ld_rewards] : rs.reward));
+    const float y = rew + rs.not_done * d.discount * tv;
     const float q = q16[threadIdx.x];
-    const float dq = (b.weights[sr * b.ld_weights] * (2.f * (q - y))) / (float)B;
+    const float dq = (rs.weight * (2.f * (q - y))) / (float)B;
     dz3s[threadIdx.x] = dq;
     W[ws.c_dz3 + (size_t)k * B + row] = dq;
   }
@@ -470,9 +485,10 @@ __global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const 
     critic_fwd_tile(d, b, net, tile, smem, nullptr, nullptr);
     critic_bwd_resident_gemm(d, net, smem);
     if (rl.on) critic_relabel_tile(d, rl, net, tile, smem);
+    const RowScalars rs = critic_row_scalars(b, !rl.on && !rewards && !d.sync, tile);
     tile_await(ctr, 3u, timeouts);
     if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 4u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    critic_bwd_resident_scale(d, b, rewards, rl, net, tile, smem);
+    critic_bwd_resident_scale(d, b, rewards, rl, rs, net, tile, smem);
   } else actor_fwd_tile(d, b, eps_next, eps_cur, true, tile, smem);
 }
 
