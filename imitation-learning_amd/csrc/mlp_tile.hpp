@@ -159,6 +159,42 @@ __device__ __forceinline__ void tile_bwd_dx(const float* dYs, int ldy, int Npad,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Columns [c_lo, c_hi) of dX[16 x K] = dYs[16 x N] . W with the N-REDUCTION split over the waves (wave w owns n in [16w, 16w + 16), ...): for a
+// narrow dX (dQ/da: A <= 8 columns of a K = S + A wide product) tile_bwd_dx keeps one or two waves busy with N/4 dependent MFMAs each; here
+// every wave issues 4 and the partial tiles meet in LDS (`part` >= nw * 256 floats), summed in wave order (deterministic).
+// Contains __syncthreads(); every thread of the block must call. epi(col, row, value) once per element of the 16-column tiles that overlap the range.
+// ---------------------------------------------------------------------------------------------
+template <class Epi>
+__device__ __forceinline__ void tile_bwd_dx_cols(const float* dYs, int ldy, int N, const float* __restrict__ W, int ldw, int K, int c_lo, int c_hi, float* part, Epi epi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  for (int kb = (c_lo >> 4) << 4; kb < c_hi; kb += 16) {
+    f32x4 acc0 = zero4(), acc1 = zero4();
+    const float* wp = W + min(kb + j, K - 1);
+    for (int n0 = wave * 16; n0 < N; n0 += nw * 16) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(dYs + j * ldy + n0 + 4 * g);
+      float b[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b[s] = gload(wp + (size_t)(n0 + 4 * g + s) * ldw);
+      acc0 = mfma16(a[0], b[0], acc0);
+      acc1 = mfma16(a[1], b[1], acc1);
+      acc0 = mfma16(a[2], b[2], acc0);
+      acc1 = mfma16(a[3], b[3], acc1);
+    }
+    const f32x4 acc = acc0 + acc1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave * 256 + (4 * g + r) * 16 + j] = acc[r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+      float s = 0.f;
+      for (int w = 0; w < nw; ++w) s += part[w * 256 + i];
+      epi(kb + (i & 15), i >> 4, s);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Packed hidden-layer weights. Reading a torch [N][K] matrix as MFMA operands touches 16 different rows per wave-load (64 useful
 // bytes of 16 separate 128-B lines): measured 14 B/clk/CU, and the MFMAs starve behind it (19.8k cycles per 16x256x256 layer vs
 // 10.7k without the loads). The same bytes as contiguous 1 KiB wave-loads run at 12.3k. So the H x H layers are read from two

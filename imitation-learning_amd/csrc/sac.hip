@@ -670,14 +670,11 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   });
   __syncthreads();
   IL_STAMP(stamp, 22);
-  // dQ/dx = dz1 . W1 on MFMA (K = S + A columns, not a multiple of 16: out-of-range columns clamp); only the action columns are kept
+  // dQ/da = the action columns of dz1 . W1 on MFMA, the H-reduction split over the 16 waves (tile_bwd_dx_cols)
   float* gout = W + ws.p_g + ((size_t)k * B + row0) * A;
-  tile_bwd_dx(H1s, ldh, H, H, p.W1, IN, IN, [&](int kb, f32x4 acc) {
-    const int c = kb + j - S;
-    if (c >= 0 && c < A) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) gout[(size_t)(4 * g + r) * A + c] = acc[r];
-    }
+  tile_bwd_dx_cols(H1s, ldh, H, p.W1, IN, IN, S, S + A, q16 + 64, [&](int col, int row, float v) {
+    const int c = col - S;
+    if (c >= 0 && c < A) gout[(size_t)row * A + c] = v;
   });
   IL_STAMP(stamp, 23);
   // The policy backward of this tile needs Q and dQ/da of BOTH critics, i.e. of two workgroups. Instead of a kernel boundary, the workgroup
