@@ -815,6 +815,53 @@ def test_device_handoff_equals_stream_dependencies(monkeypatch):
     np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('switch', ['IL_RING_GATHER', 'IL_INLINE_RELABEL', 'IL_SAC_CHAIN', 'IL_PC_SPLIT'])
+def test_schedule_switches_are_bit_identical(monkeypatch, switch):
+  """Every schedule of the update (rows through il_batch.gather vs a gather kernel, inline relabel vs k_gail_reward, chained vs separate forward / critic-loss
+  launches, helper-split vs second-arriver policy tail) runs the same arithmetic per element: switching one off must not change a bit.
+  The C-side switches are read once per process, so they are compared through a subprocess."""
+  import subprocess, sys, json
+  code = (
+      "import sys, json, hashlib, numpy as np, torch; sys.path[:0] = ['.', 'tests', 'tests/golden']\n"
+      "import imitation_learning_amd as il\n"
+      "from imitation_learning_amd import training as T\n"
+      "from test_gpu_parity import _make_plan, N\n"
+      "il.seed(31); T._NOISE.clear()\n"
+      "plan, nets = _make_plan('GAIL', 17)\n"
+      "for _ in range(6): plan.run()\n"
+      "torch.cuda.synchronize()\n"
+      "assert plan.sync_timeouts() == 0\n"
+      "h = hashlib.sha256()\n"
+      "for n in list(nets) + [plan.logp, plan.q, plan.rewards, plan.idx]: h.update(np.ascontiguousarray(N(n.flat if hasattr(n, 'flat') else n)).tobytes())\n"
+      "print(json.dumps(dict(digest=h.hexdigest(), ring=plan.ring_mode, inline=plan.inline_relabel)))\n")
+  outs = []
+  for value in ('1', '0'):
+    env = dict(os.environ, **{switch: value})
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+  assert outs[0]['ring'] and outs[0]['inline'], 'the default schedule reads rows through il_batch.gather and relabels inline'
+  if switch == 'IL_RING_GATHER': assert not outs[1]['ring']
+  if switch == 'IL_INLINE_RELABEL': assert outs[1]['ring'] and not outs[1]['inline']
+  assert outs[0]['digest'] == outs[1]['digest']
+
+
+@pytest.mark.gpu
+def test_batch_gather_is_rejected_where_it_is_not_honoured():
+  """il_batch.gather silently ignored would read the wrong rows: every entry point that indexes batch rows directly must refuse it."""
+  from imitation_learning_amd import _lib
+  plan, nets = _make_plan('GAIL', 19)
+  plan.run(); torch.cuda.synchronize()
+  ring_batch = plan._ring_batches()[0]
+  rc = _lib.lib().il_sac_update(C.byref(plan.sac), C.byref(ring_batch), None, None, _lib.ptr(plan.logp), _lib.ptr(plan.q), 0, _lib.stream_ptr())
+  assert rc != 0 and b'gather' in _lib.lib().il_last_error()
+  with pytest.raises(RuntimeError, match='gather'):
+    _lib.check(_lib.lib().il_sac_actor_step(C.byref(plan.sac), C.byref(ring_batch), None, _lib.ptr(plan.logp), _lib.ptr(plan.q), 0, _lib.stream_ptr()))
+  with pytest.raises(RuntimeError, match='gather'):   # and il_sac_update_gather insists on it for `ring`
+    _lib.check(_lib.lib().il_sac_update_gather(C.byref(plan.sac), C.byref(plan.pb), C.byref(plan.pb), None, None, None, None, None, _lib.ptr(plan.logp), _lib.ptr(plan.q), 0, _lib.stream_ptr()))
+
+
 # ---------------------------------------------------------------------------------------------
 # GAIL with reward shaping (models.py:152-180, reward_shaping=True) against the reference fixture and the oracle
 # ---------------------------------------------------------------------------------------------
