@@ -19,7 +19,7 @@
 
 struct SacWs {  // float offsets into il_sac.workspace
   int64_t a_h1, a_h2, a_xpre, a_eps, a_lsraw, a_anew, a_logp, n_a2, n_logp2;
-  int64_t c_x0, c_h1, c_h2, c_q, t_q, c_dz3, c_dz2, c_dz1, q_min;
+  int64_t c_x0, c_h1, c_h2, c_q, t_q, c_dz3, c_dz2, c_dz1;
   int64_t p_q, p_g, a_dz3, a_dz2, a_dz1, alpha_part, pair_ctr, chain_ctr;
   int64_t pk_af, pk_ab, pk_cf, pk_cb, pk_tf, pk_tb;  // lane-ordered copies of the H x H layers (mlp_tile.hpp "Packed hidden-layer weights")
   int64_t total;
@@ -31,7 +31,7 @@ __host__ __device__ inline SacWs sac_ws(int S, int A, int H, int B) {
   w.a_h1 = take(BH); w.a_h2 = take(BH); w.a_xpre = take(BA); w.a_eps = take(BA); w.a_lsraw = take(BA); w.a_anew = take(BA); w.a_logp = take(B);
   w.n_a2 = take(BA); w.n_logp2 = take(B);
   w.c_x0 = take((int64_t)B * (S + A)); w.c_h1 = take(2 * BH); w.c_h2 = take(2 * BH); w.c_q = take(2 * B); w.t_q = take(2 * B);
-  w.c_dz3 = take(2 * B); w.c_dz2 = take(2 * BH); w.c_dz1 = take(2 * BH); w.q_min = take(B);
+  w.c_dz3 = take(2 * B); w.c_dz2 = take(2 * BH); w.c_dz1 = take(2 * BH);
   w.p_q = take(2 * B); w.p_g = take(2 * BA); w.a_dz3 = take((int64_t)B * 16); w.a_dz2 = take(BH); w.a_dz1 = take(BH); w.alpha_part = take(B / IL_TILE_R + 4); w.pair_ctr = take(B / IL_TILE_R + 4); w.chain_ctr = take(B / IL_TILE_R + 4);
   const int64_t HH = (int64_t)H * H;
   w.pk_af = take(HH); w.pk_ab = take(HH); w.pk_cf = take(2 * HH); w.pk_cb = take(2 * HH); w.pk_tf = take(2 * HH); w.pk_tb = take(2 * HH);
@@ -178,19 +178,8 @@ __global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// critic forward. net 0,1: critic_k(s, a) keeping h1, h2, x0 ; net 2,3: target_k(s', a').   grid = nt * nnets
-// first_net: 0 => all four (critic step); used with nnets=4.
+// Critic / target forward (critic_fwd_tile; k_critic_fwd: grid = 4 * nt) and the per-tile chaining primitives of k_sac_chain.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void critic_head(const float* H2s, int ldh, int H, const float* __restrict__ w3, float b3, float* out16) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int r = wave; r < IL_TILE_R; r += nw) {
-    float s = 0.f;
-    for (int n = lane; n < H; n += 64) s += H2s[r * ldh + n] * w3[n];
-    s = wave_sum(s);
-    if (lane == 0) out16[r] = s + b3;
-  }
-}
-
 // Per-tile arrival counter of the fused forward + critic-loss launch (k_sac_chain): 0 -> 1 (actor on s' done) -> 3 (both target critics done)
 // -> 5 (both critics have read the targets; the one that sees 4 resets it to 0 for the next launch). Producer side: every thread's stores,
 // barrier, ONE agent-scope release; consumer side: ONE polling lane, an agent-scope acquire, barrier (cf. sync_signal / sync_wait).
@@ -1023,7 +1012,6 @@ extern "C" int il_sac_actor_step(const il_sac* d, const il_batch* b, const float
 
 // k_sac_chain needs its 6 * nt workgroups resident together; IL_SAC_CHAIN=0 keeps the three separate launches (developer A/B switch).
 static bool chain_enabled() { static const int on = [] { const char* e = getenv("IL_SAC_CHAIN"); return e && e[0] == '0' ? 0 : 1; }(); return on != 0; }
-static int chain_cu_count() { return device_cu_count(); }
 extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags,
                              il_stream_t stream_) {
   if (int rc = check_sac(d, b)) return rc;
@@ -1032,7 +1020,7 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   const bool whole = !(flags & (IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY));
-  if (whole && chain_enabled() && 6 * nt <= chain_cu_count()) {   // forward + critic loss chained per tile in one co-resident launch (k_sac_chain)
+  if (whole && chain_enabled() && 6 * nt <= device_cu_count()) {   // forward + critic loss chained per tile in one co-resident launch (k_sac_chain)
     if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
     { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr, ChainRelabel{}); }
     flags |= IL_FLAG_SAC_SKIP_FORWARD | 0x80000000u;
@@ -1086,7 +1074,7 @@ extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const
   hipStream_t st = (hipStream_t)stream_;
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const int G = il_sac_chain_gather_workgroups(B, ring->ld_states, H);
-  if (6 * nt + G > chain_cu_count()) return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update_gather: %d workgroups cannot be co-resident on %d CUs (gather first, then il_sac_update)", 6 * nt + G, chain_cu_count());
+  if (6 * nt + G > device_cu_count()) return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update_gather: %d workgroups cannot be co-resident on %d CUs (gather first, then il_sac_update)", 6 * nt + G, device_cu_count());
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
   { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt + G, tile_threads(H), lds, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl); }
