@@ -64,9 +64,10 @@ class Pwil(C.Structure):
 
 
 class Red(C.Structure):
-  _fields_ = [('state_dim', C.c_int32), ('action_dim', C.c_int32), ('hidden', C.c_int32), ('batch', C.c_int32), ('state_only', C.c_int32), ('reserved', C.c_int32),
+  _fields_ = [('state_dim', C.c_int32), ('action_dim', C.c_int32), ('hidden', C.c_int32), ('batch', C.c_int32), ('state_only', C.c_int32), ('depth', C.c_int32),
               ('predictor', C.c_void_p), ('target', C.c_void_p), ('grad', C.c_void_p), ('opt', Adam), ('workspace', C.c_void_p),
-              ('sigma_1', C.c_float), ('reserved2', C.c_float), ('out_pred', C.c_void_p), ('out_target', C.c_void_p)]
+              ('sigma_1', C.c_float), ('activation', C.c_int32), ('out_pred', C.c_void_p), ('out_target', C.c_void_p),
+              ('p_in', C.c_float), ('p', C.c_float), ('noise_seed', C.c_uint64)]
 
 
 class Dril(C.Structure):
@@ -142,10 +143,10 @@ _SIGNATURES = {
     'il_dril_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'il_dril_bc_step': (C.c_int, [C.POINTER(Dril), C.POINTER(Batch), _P, _P, C.c_uint32, _P, C.c_uint32, _P]),
     'il_dril_uncertainty': (C.c_int, [C.POINTER(Dril), C.POINTER(Batch), _P, _P, C.c_uint32, _P, _P, _P]),
-    'il_red_numel': (C.c_int64, [C.c_int32, C.c_int32]),
-    'il_red_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
-    'il_red_step': (C.c_int, [C.POINTER(Red), C.POINTER(Batch), _P, C.c_uint32, _P]),
-    'il_red_forward': (C.c_int, [C.POINTER(Red), C.POINTER(Batch), _P, _P, _P, _P]),
+    'il_red_numel': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    'il_red_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'il_red_step': (C.c_int, [C.POINTER(Red), C.POINTER(Batch), _P, _P, _P, C.c_uint32, _P, C.c_uint32, _P]),
+    'il_red_forward': (C.c_int, [C.POINTER(Red), C.POINTER(Batch), C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P, _P]),
 }
 
 

@@ -474,30 +474,43 @@ class PWILDiscriminator(nn.Module):
 
 
 class REDDiscriminator(_FlatModule):
-  """Random Expert Distillation (reference models.py:252-284): a predictor regressed onto a frozen random target network, both
-  Linear(D,H)-ReLU-Linear(H,D); reward = exp(-sigma_1 * mean (pred - target)^2).  `self.flat` is the predictor arena (what the
-  optimiser owns), `self.target_flat` the frozen one; state_dict keys are the reference's (predictor.embedding.N.*, target.embedding.N.*)."""
+  """Random Expert Distillation (reference models.py:252-284): a predictor regressed onto a frozen random target network, both `_create_fcnn`
+  MLPs D -> H (-> H) -> D with ReLU / Tanh; the predictor additionally carries the config's input_dropout / dropout layers (active in train mode:
+  target_estimation_update and set_sigma, train.py:115-128; predict_reward runs after `discriminator.eval()`, train.py:147).
+  reward = exp(-sigma_1 * mean (pred - target)^2).  `self.flat` is the predictor arena (what the optimiser owns), `self.target_flat` the frozen one;
+  state_dict keys are the reference's (predictor.embedding.N.*, target.embedding.N.*: Dropout / activation modules occupy Sequential slots too).
+  Pass `masks=(mask_in, mask_h1[, mask_h2])` (keep-masks, 0/1) to reproduce given dropout draws; otherwise they come from the on-chip Philox stream."""
 
   def __init__(self, state_size: int, action_size: int, imitation_cfg, device=None):
     super().__init__()
     model_cfg = imitation_cfg.discriminator
-    if model_cfg.depth != 1 or model_cfg.activation != 'relu' or _cfg_get(model_cfg, 'input_dropout', 0) or _cfg_get(model_cfg, 'dropout', 0):
-      raise NotImplementedError('REDDiscriminator: the HIP path implements depth=1, activation=relu without dropout (the conf/algorithm/RED.yaml defaults); no torch fallback')
+    self.depth, self.activation = int(model_cfg.depth), str(model_cfg.activation)
+    self.p_in, self.p = float(_cfg_get(model_cfg, 'input_dropout', 0) or 0), float(_cfg_get(model_cfg, 'dropout', 0) or 0)
+    if self.depth not in (1, 2) or self.activation not in ('relu', 'tanh'):
+      raise NotImplementedError(f'REDDiscriminator: the HIP path implements depth 1-2 with relu / tanh (got depth={self.depth}, activation={self.activation}); no torch fallback')
     self.state_size, self.action_size, self.hidden, self.state_only = state_size, action_size, int(model_cfg.hidden_size), bool(imitation_cfg.state_only)
     self.in_dim = state_size if self.state_only else state_size + action_size
     if self.in_dim > 128 or self.hidden > 256 or self.hidden % 2:
       raise NotImplementedError(f'REDDiscriminator: input {self.in_dim} (<= 128) / hidden {self.hidden} (even, <= 256) outside the kernel limits')
+    act, gain = (nn.ReLU, sqrt(2.0)) if self.activation == 'relu' else (nn.Tanh, 5.0 / 3.0)
 
-    def embedding():
-      l1, l2 = nn.Linear(self.in_dim, self.hidden), nn.Linear(self.hidden, self.in_dim)
-      nn.init.orthogonal_(l1.weight, gain=sqrt(2.0)); nn.init.constant_(l1.bias, 0)
-      nn.init.orthogonal_(l2.weight, gain=1.0); nn.init.constant_(l2.bias, 0)
+    def embedding(p_in, p):   # models.py:49-70 `_create_fcnn`, same module order (hence the same state_dict keys) and RNG consumption
+      dims, layers = [self.in_dim] + [self.hidden] * self.depth, []
+      if p_in > 0: layers.append(nn.Dropout(p_in))
+      for a, b in zip(dims[:-1], dims[1:]):
+        lin = nn.Linear(a, b)
+        nn.init.orthogonal_(lin.weight, gain=gain); nn.init.constant_(lin.bias, 0)
+        layers.append(lin)
+        if p > 0: layers.append(nn.Dropout(p))
+        layers.append(act())
+      last = nn.Linear(dims[-1], self.in_dim)
+      nn.init.orthogonal_(last.weight, gain=1.0); nn.init.constant_(last.bias, 0)
       holder = nn.Module()
-      holder.embedding = nn.Sequential(l1, nn.ReLU(), l2)
+      holder.embedding = nn.Sequential(*layers, last)
       return holder
-    self.predictor, self.target = embedding(), embedding()   # same construction order as the reference: identical RNG consumption
+    self.predictor, self.target = embedding(self.p_in, self.p), embedding(0, 0)   # same construction order as the reference: identical RNG consumption
     dev = device or default_device()
-    P = int(_lib.lib().il_red_numel(self.in_dim, self.hidden))
+    P = int(_lib.lib().il_red_numel(self.in_dim, self.hidden, self.depth))
     flats = []
     for net in (self.predictor, self.target):
       offs, o = [], 0
@@ -512,17 +525,35 @@ class REDDiscriminator(_FlatModule):
     for p in self.parameters():
       p.requires_grad_(False)
     self.sigma_1 = imitation_cfg.reward_bandwidth_scale
+    self._noise_calls = 0
 
   def _desc(self, batch_size: int, opt=None) -> '_lib.Red':
     d = _lib.Red()
     d.state_dim, d.action_dim, d.hidden, d.batch, d.state_only = self.state_size, self.action_size, self.hidden, batch_size, int(self.state_only)
+    d.depth, d.activation, d.p_in, d.p = self.depth, int(self.activation == 'tanh'), self.p_in, self.p
+    d.noise_seed = torch.initial_seed() & (2**64 - 1)
     d.predictor, d.target = self.flat.data_ptr(), self.target_flat.data_ptr()
     d.sigma_1 = float(self.sigma_1) if self.sigma_1 else 0.0
     if opt is not None:
       from .training import _workspace
-      ws = _workspace('red', int(_lib.lib().il_red_workspace_floats(self.in_dim, self.hidden, batch_size)), self.flat.device)
+      ws = _workspace('red', int(_lib.lib().il_red_workspace_floats(self.in_dim, self.hidden, batch_size, self.depth)), self.flat.device)
       d.grad, d.opt, d.workspace = opt.grad.data_ptr(), opt.desc(), ws.data_ptr()
     return d
+
+  def _masks(self, masks, rows: int):
+    """(mask_in, mask_h1, mask_h2) pointers for the C ABI (None = on-chip Philox) + the tensors to keep alive, and this call's Philox counter."""
+    self._noise_calls += 1
+    if masks is None:
+      return (None, None, None), (), self._noise_calls & 0xFFFFFFFF
+    dev, keep = self.flat.device, []
+    want = [(rows, self.in_dim)] + [(rows, self.hidden)] * self.depth
+    assert len(masks) == len(want), f'REDDiscriminator: expected {len(want)} masks (input + one per hidden layer)'
+    for m, shape in zip(masks, want):
+      m = m.to(dev, torch.float32).contiguous()
+      assert tuple(m.shape) == shape, f'mask shape {tuple(m.shape)} != {shape}'
+      keep.append(m)
+    ptrs = [_lib.ptr(m) for m in keep] + [None] * (3 - len(keep))
+    return tuple(ptrs), tuple(keep), self._noise_calls & 0xFFFFFFFF
 
   def _batch(self, state: Tensor, action: Tensor):
     from .training import _sa_batch
@@ -533,26 +564,28 @@ class REDDiscriminator(_FlatModule):
     if action.stride(-1) != 1: action = action.contiguous()
     return _sa_batch(state, action, torch.ones(state.size(0), device=dev)), state.size(0), (state, action)
 
-  def forward(self, state: Tensor, action: Tensor) -> Tuple[Tensor, Tensor]:
+  def forward(self, state: Tensor, action: Tensor, masks=None) -> Tuple[Tensor, Tensor]:
     b, n, keep = self._batch(state, action)
     pred, targ = torch.empty(n, self.in_dim, device=self.flat.device), torch.empty(n, self.in_dim, device=self.flat.device)
     d = self._desc(n)
-    _lib.check(_lib.lib().il_red_forward(C.byref(d), C.byref(b), None, _lib.ptr(pred), _lib.ptr(targ), _lib.stream_ptr()))
+    (m0, m1, m2), alive, ctr = self._masks(masks, n) if self.training else ((None, None, None), (), 0)
+    _lib.check(_lib.lib().il_red_forward(C.byref(d), C.byref(b), int(self.training), m0, m1, m2, ctr, None, _lib.ptr(pred), _lib.ptr(targ), _lib.stream_ptr()))
     return pred, targ
 
-  def set_sigma(self, expert_state: Tensor, expert_action: Tensor):
-    """models.py:274-277: kernel median heuristic on one expert minibatch unless reward_bandwidth_scale was configured."""
+  def set_sigma(self, expert_state: Tensor, expert_action: Tensor, masks=None):
+    """models.py:274-277: kernel median heuristic on one expert minibatch unless reward_bandwidth_scale was configured (train mode: dropout is active)."""
     if not self.sigma_1:
       from .training import embedding_sqdist
-      pred, targ = self.forward(expert_state, expert_action)
+      pred, targ = self.forward(expert_state, expert_action, masks=masks)
       self.sigma_1 = 1 / embedding_sqdist(pred, targ).flatten().median().item()
 
-  def predict_reward(self, state: Tensor, action: Tensor) -> Tensor:
+  def predict_reward(self, state: Tensor, action: Tensor, masks=None) -> Tensor:
     assert self.sigma_1, 'REDDiscriminator.predict_reward before set_sigma (train.py:128)'
     b, n, keep = self._batch(state, action)
     out = torch.empty(n, device=self.flat.device)
     d = self._desc(n)
-    _lib.check(_lib.lib().il_red_forward(C.byref(d), C.byref(b), _lib.ptr(out), None, None, _lib.stream_ptr()))
+    (m0, m1, m2), alive, ctr = self._masks(masks, n) if self.training else ((None, None, None), (), 0)
+    _lib.check(_lib.lib().il_red_forward(C.byref(d), C.byref(b), int(self.training), m0, m1, m2, ctr, _lib.ptr(out), None, None, _lib.stream_ptr()))
     return out
 
 

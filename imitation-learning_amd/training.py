@@ -101,15 +101,17 @@ def behavioural_cloning_update(actor: SoftActor, expert_transition: Dict[str, Te
   return parts.sum() / B
 
 
-def target_estimation_update(discriminator, expert_transition: Dict[str, Tensor], discriminator_optimiser: AdamW, *, want_loss: bool = False):
-  """Reference training.py:68-75: regress the RED predictor onto the frozen target on one weighted expert batch (k_red_grad + k_red_apply)."""
+def target_estimation_update(discriminator, expert_transition: Dict[str, Tensor], discriminator_optimiser: AdamW, *, want_loss: bool = False, masks=None):
+  """Reference training.py:68-75: regress the RED predictor onto the frozen target on one weighted expert batch (k_red_grad + k_red_apply), train mode:
+  `masks` = the predictor's dropout keep-masks (input, hidden 1[, hidden 2]) when they must be reproduced, else drawn on chip."""
   t = dict(expert_transition)
   for k in ('rewards', 'terminals', 'absorbing', 'next_states'):
     t.setdefault(k, t['weights'] if k != 'next_states' else t['states'])
   b = batch_desc(t)
   d = discriminator._desc(b.n, discriminator_optimiser)
   loss = torch.empty(1, device=discriminator.flat.device) if want_loss else None
-  _lib.check(_lib.lib().il_red_step(C.byref(d), C.byref(b), _lib.ptr(loss), 0, _lib.stream_ptr()))
+  (m0, m1, m2), alive, ctr = discriminator._masks(masks, b.n)
+  _lib.check(_lib.lib().il_red_step(C.byref(d), C.byref(b), m0, m1, m2, ctr, _lib.ptr(loss), 0, _lib.stream_ptr()))
   return loss
 
 

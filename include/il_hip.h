@@ -368,24 +368,31 @@ int il_pwil_reward(const il_pwil* d, const float* state, const float* action, fl
  * torch parameters() order [W1 (H,D) | b1 (H) | W2 (D,H) | b2 (D)], il_red_numel(D,H) floats each.
  * ------------------------------------------------------------------------------------------ */
 typedef struct il_red {
-  int32_t state_dim, action_dim, hidden, batch, state_only, reserved;
+  int32_t state_dim, action_dim, hidden, batch, state_only;
+  int32_t depth;        /* hidden layers of both networks: 1 or 2 (0 = 1) */
   float* predictor;     /* trained */
   const float* target;  /* frozen random network */
   float* grad;          /* [P] */
   il_adam opt;          /* AdamW state of the predictor (train.py:84) */
-  float* workspace;     /* >= il_red_workspace_floats(D, H, batch) */
+  float* workspace;     /* >= il_red_workspace_floats(D, H, batch, depth) */
   float sigma_1;        /* reward bandwidth (models.py:274-277 set_sigma or imitation.reward_bandwidth_scale) */
-  float reserved2;
+  int32_t activation;   /* 0 relu, 1 tanh (imitation.discriminator.activation) */
   float *out_pred, *out_target; /* filled by il_red_forward; leave NULL */
+  float p_in, p;        /* input_dropout / dropout of the PREDICTOR (models.py:256; the target has none); applied in train mode only */
+  uint64_t noise_seed;  /* Philox key of the keep-masks when the mask pointers are NULL */
 } il_red;
-int64_t il_red_numel(int32_t input_dim, int32_t hidden);
-int64_t il_red_workspace_floats(int32_t input_dim, int32_t hidden, int32_t batch);
-/* target_estimation_update: loss = mean_i w_i mean_c (pred_ic - target_ic)^2, AdamW on the predictor (IL_FLAG_GRADS_ONLY: d->grad only).
- * out_loss [1] or NULL. */
-int il_red_step(const il_red* d, const il_batch* expert, float* out_loss, uint32_t flags, il_stream_t stream);
-/* predict_reward (models.py:279-280): out_reward[i] = exp(-sigma_1 * mean_c (pred - target)^2), and / or the embeddings
- * out_pred, out_target [n, D] (what set_sigma feeds to the pairwise distance + median). */
-int il_red_forward(const il_red* d, const il_batch* batch, float* out_reward, float* out_pred, float* out_target, il_stream_t stream);
+/* parameters in torch order: W1[H,D] b1 (W2[H,H] b2 when depth = 2) Wo[D,H] bo */
+int64_t il_red_numel(int32_t input_dim, int32_t hidden, int32_t depth);
+int64_t il_red_workspace_floats(int32_t input_dim, int32_t hidden, int32_t batch, int32_t depth);
+/* target_estimation_update: loss = mean_i w_i mean_c (pred_ic - target_ic)^2, AdamW on the predictor (IL_FLAG_GRADS_ONLY: d->grad only), train mode
+ * (train.py:115-123 run before :147 `discriminator.eval()`): keep-masks mask_in [B,D], mask_h1 / mask_h2 [B,H] (0/1) or NULL = drawn on chip
+ * (Philox counter noise_offset). out_loss [1] or NULL. */
+int il_red_step(const il_red* d, const il_batch* expert, const float* mask_in, const float* mask_h1, const float* mask_h2, uint32_t noise_offset, float* out_loss,
+                uint32_t flags, il_stream_t stream);
+/* predict_reward (models.py:279-280, eval mode: training = 0): out_reward[i] = exp(-sigma_1 * mean_c (pred - target)^2), and / or the embeddings
+ * out_pred, out_target [n, D] (what set_sigma feeds to the pairwise distance + median; set_sigma runs in TRAIN mode, train.py:128: training = 1 + masks). */
+int il_red_forward(const il_red* d, const il_batch* batch, int32_t training, const float* mask_in, const float* mask_h1, const float* mask_h2, uint32_t noise_offset,
+                   float* out_reward, float* out_pred, float* out_target, il_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * DRIL (reference models.py:84-120: SoftActor built from conf/algorithm/DRIL.yaml's discriminator config = Dropout(p_in) -> Linear(S,H)

@@ -109,15 +109,30 @@ def adril_batches(seed, B, S, A):
   return pol, exp
 
 
-def red_case(seed, env, hidden, batch, steps):
-  """RED predictor / frozen target (Linear(D,H)-ReLU-Linear(H,D)), weighted expert batches, a sigma batch and a query batch."""
+def red_case(seed, env, hidden, batch, steps, depth=1, activation='relu', p_in=0.0, p=0.0):
+  """RED predictor / frozen target (`_create_fcnn`: D -> H (-> H) -> D, ReLU / Tanh), weighted expert batches, a sigma batch and a query batch; with
+  dropout also the predictor's keep-masks per update (input, hidden 1[, hidden 2]) and for the train-mode set_sigma forward."""
   S, A = DIMS[env]
   D = S + A
   rs = np.random.RandomState(seed)
-  predictor, target = mlp_params(rs, D, hidden, 1, D), mlp_params(rs, D, hidden, 1, D)
+  predictor, target = mlp_params(rs, D, hidden, depth, D), mlp_params(rs, D, hidden, depth, D)
   batches = [transitions(rs, batch, S, A, state_shift=0.5, weighted=True) for _ in range(steps)]
-  return dict(S=S, A=A, D=D, H=hidden, B=batch, predictor=predictor, target=target, batches=batches,
-              sigma_batch=transitions(rs, batch, S, A, state_shift=0.5), query=transitions(rs, batch + 16, S, A))
+  c = dict(S=S, A=A, D=D, H=hidden, B=batch, depth=depth, activation=activation, p_in=p_in, p=p, predictor=predictor, target=target, batches=batches,
+           sigma_batch=transitions(rs, batch, S, A, state_shift=0.5), query=transitions(rs, batch + 16, S, A))
+  keep = lambda shape, pr: (rs.uniform(size=shape) >= pr).astype(f32)   # drawn after everything else: the dropout-free cases stay what they were
+  masks = lambda n: ([keep((n, D), p_in)] if p_in > 0 else []) + ([keep((n, hidden), p) for _ in range(depth)] if p > 0 else [])
+  c['masks'] = [masks(batch) for _ in range(steps)]
+  c['sigma_masks'] = masks(batch)
+  return c
+
+
+RED_CASES = (   # name, red_case arguments, lr, weight decay; the last three mirror conf/optimised_hyperparameters/RED_{5,10,25}_trajectories.yaml
+    ('hopper_h32', dict(seed=61, env='hopper', hidden=32, batch=64, steps=4), 3e-5, 0.0),
+    ('halfcheetah_h64', dict(seed=62, env='halfcheetah', hidden=64, batch=256, steps=3), 1e-3, 0.01),
+    ('hopper_d2_relu_drop', dict(seed=63, env='hopper', hidden=32, batch=96, steps=3, depth=2, activation='relu', p_in=0.1, p=0.3), 1e-3, 0.5),
+    ('halfcheetah_d1_tanh_drop', dict(seed=64, env='halfcheetah', hidden=32, batch=64, steps=3, depth=1, activation='tanh', p_in=0.2, p=0.1), 5e-4, 0.0),
+    ('hopper_d2_tanh_drop', dict(seed=65, env='hopper', hidden=64, batch=128, steps=3, depth=2, activation='tanh', p_in=0.05, p=0.4), 2.4e-4, 2.5),
+)
 
 
 def dril_case(seed, env, hidden, batch, steps, p_in=0.1, p=0.1):

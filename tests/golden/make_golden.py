@@ -349,22 +349,28 @@ def gen_adril():
 
 
 def gen_red():
-  """REDDiscriminator (models.py:252-284) + target_estimation_update (training.py:68-75): 4 updates, set_sigma, predict_reward."""
+  """REDDiscriminator (models.py:252-284) + target_estimation_update (training.py:68-75): updates (train mode: the predictor's dropout masks are fed in
+  module order), set_sigma (still train mode, train.py:128), then `eval()` and predict_reward (train.py:147)."""
   out = {}
-  for name, c, lr, wd in (('hopper_h32', gi.red_case(61, 'hopper', 32, 64, 4), 3e-5, 0.0), ('halfcheetah_h64', gi.red_case(62, 'halfcheetah', 64, 256, 3), 1e-3, 0.01)):
-    cfg = DictConfig(state_only=False, reward_bandwidth_scale=None, discriminator=DictConfig(hidden_size=c['H'], depth=1, activation='relu', input_dropout=0, dropout=0))
+  for name, kw, lr, wd in gi.RED_CASES:
+    c = gi.red_case(**kw)
+    cfg = DictConfig(state_only=False, reward_bandwidth_scale=None,
+                     discriminator=DictConfig(hidden_size=c['H'], depth=c['depth'], activation=c['activation'], input_dropout=c['p_in'], dropout=c['p']))
     d = ref_models.REDDiscriminator(c['S'], c['A'], cfg)
     torch.nn.utils.vector_to_parameters(T(c['predictor']), d.predictor.parameters())
     torch.nn.utils.vector_to_parameters(T(c['target']), d.target.parameters())
     opt = torch.optim.AdamW(d.predictor.parameters(), lr=lr, weight_decay=wd)
-    for k, b in enumerate(c['batches'], 1):
-      ref_training.target_estimation_update(d, tbatch(b), opt)
+    for k, (b, masks) in enumerate(zip(c['batches'], c['masks']), 1):
+      with DropoutFeed([T(m) for m in masks]):
+        ref_training.target_estimation_update(d, tbatch(b), opt)
       out[f'{name}.predictor.{k}'] = flat(d.predictor)
     out[f'{name}.exp_avg'], out[f'{name}.exp_avg_sq'] = opt_state(opt, 'exp_avg'), opt_state(opt, 'exp_avg_sq')
     with torch.inference_mode():
       e = tbatch(c['sigma_batch'])
-      d.set_sigma(e['states'], e['actions'])
+      with DropoutFeed([T(m) for m in c['sigma_masks']]):
+        d.set_sigma(e['states'], e['actions'])
       out[f'{name}.sigma_1'] = np.array([d.sigma_1], np.float64)
+      d.eval()
       q = tbatch(c['query'])
       out[f'{name}.reward'] = N_(d.predict_reward(q['states'], q['actions']))
     out[f'{name}.hyper'] = np.array([lr, wd], np.float64)

@@ -650,21 +650,29 @@ def test_mix_expert_agent_transitions_bit_exact(golden_dir):
 # RED (models.py:252-284, training.py:68-75) against the reference-generated fixture and the oracle
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize('name,case', [('hopper_h32', (61, 'hopper', 32, 64, 4)), ('halfcheetah_h64', (62, 'halfcheetah', 64, 256, 3))])
-def test_red_matches_reference(golden_dir, name, case):
+@pytest.mark.parametrize('name,kw', [(n, kw) for n, kw, _, _ in gi.RED_CASES], ids=[n for n, *_ in gi.RED_CASES])
+def test_red_matches_reference(golden_dir, name, kw):
+  """REDDiscriminator on the HIP path against the reference fixture and the oracle: conf/algorithm/RED.yaml (depth 1, relu) and the shapes of
+  conf/optimised_hyperparameters/RED_*.yaml (depth 2 / tanh / predictor dropout, the reference's keep-masks fed back in)."""
   from oracle import red as ored
   g = load(golden_dir, 'red')
-  c = gi.red_case(*case)
+  c = gi.red_case(**kw)
   lr, wd = (float(x) for x in g[f'{name}.hyper'])
-  icfg = Cfg(state_only=False, reward_bandwidth_scale=None, discriminator=Cfg(hidden_size=c['H'], depth=1, activation='relu', input_dropout=0, dropout=0))
+  icfg = Cfg(state_only=False, reward_bandwidth_scale=None,
+             discriminator=Cfg(hidden_size=c['H'], depth=c['depth'], activation=c['activation'], input_dropout=c['p_in'], dropout=c['p']))
   d = il.REDDiscriminator(c['S'], c['A'], icfg, device=DEV)
-  assert set(d.state_dict()) == {f'{net}.embedding.{i}.{p}' for net in ('predictor', 'target') for i in (0, 2) for p in ('weight', 'bias')}
+  # Sequential slots of the Linear layers: Dropout modules and activations occupy slots too (models.py:49-70)
+  step = 2 + (c['p'] > 0)
+  lin = [int(c['p_in'] > 0) + step * l for l in range(c['depth'] + 1)]
+  assert set(d.state_dict()) == ({f'predictor.embedding.{i}.{p}' for i in lin for p in ('weight', 'bias')}
+                                 | {f'target.embedding.{2 * l}.{p}' for l in range(c['depth'] + 1) for p in ('weight', 'bias')})
   d.flat.copy_(T(c['predictor'])); d.target_flat.copy_(T(c['target']))
   opt = il.AdamW(d, lr=lr, weight_decay=wd)
-  st = ored.RedState(c['D'], c['H']); st.predictor[:] = c['predictor']; st.target[:] = c['target']
-  for k, b in enumerate(c['batches'], 1):
-    loss = il.target_estimation_update(d, tbatch(b), opt, want_loss=True)
-    oloss = ored.target_estimation_update(st, np.concatenate([b['states'], b['actions']], 1), b['weights'], lr=lr, weight_decay=wd)
+  st = ored.RedState(c['D'], c['H'], c['depth'], c['activation'], c['p_in'], c['p']); st.predictor[:] = c['predictor']; st.target[:] = c['target']
+  tm = lambda masks: tuple(T(m) for m in masks) if masks else None
+  for k, (b, masks) in enumerate(zip(c['batches'], c['masks']), 1):
+    loss = il.target_estimation_update(d, tbatch(b), opt, want_loss=True, masks=tm(masks))
+    oloss = ored.target_estimation_update(st, np.concatenate([b['states'], b['actions']], 1), b['weights'], lr=lr, weight_decay=wd, masks=masks)
     close(N(loss)[0], oloss, f'{name} loss {k}')
     close_params(N(d.flat), g[f'{name}.predictor.{k}'], f'{name} predictor after update {k} (reference)', lr, steps=k)
     close_params(N(d.flat), st.predictor, f'{name} predictor after update {k} (oracle)', lr, steps=k)
@@ -674,23 +682,29 @@ def test_red_matches_reference(golden_dir, name, case):
   # bandwidth + reward on the reference's post-training predictor (isolates the two calls from Adam-amplified differences)
   d.flat.copy_(T(g[f'{name}.predictor.{len(c["batches"])}']))
   e, q = tbatch(c['sigma_batch']), tbatch(c['query'])
-  d.set_sigma(e['states'], e['actions'])
+  d.set_sigma(e['states'], e['actions'], masks=tm(c['sigma_masks']))   # still in train mode (train.py:128)
   assert abs(d.sigma_1 - float(g[f'{name}.sigma_1'][0])) <= 1e-5 * d.sigma_1
-  close(N(d.predict_reward(q['states'], q['actions'])), g[f'{name}.reward'], f'{name} reward')   # ragged: B + 16 rows
+  d.eval()                                                              # train.py:147
+  close(N(d.predict_reward(q['states'], q['actions'])), g[f'{name}.reward'], f'{name} reward', rtol=2e-5)   # ragged: B + 16 rows
   pred, targ = d(q['states'][:5], q['actions'][:5])
   x = np.concatenate([c['query']['states'][:5], c['query']['actions'][:5]], 1)
   st.predictor[:] = g[f'{name}.predictor.{len(c["batches"])}']
   op, ot, _ = ored.forward(st, x)
   close(N(pred), op, f'{name} predictor embedding'); close(N(targ), ot, f'{name} target embedding')
+  if c['p'] > 0:   # on-chip masks: train-mode forwards differ from call to call and from the eval-mode forward, at the keep rate the config asks for
+    d.train()
+    p1, _ = d(q['states'], q['actions']); p2, _ = d(q['states'], q['actions'])
+    assert not np.array_equal(N(p1), N(p2)) and np.isfinite(N(p1)).all()
 
 
 @pytest.mark.gpu
 def test_red_loud_failures():
-  icfg = Cfg(state_only=False, reward_bandwidth_scale=None, discriminator=Cfg(hidden_size=32, depth=2, activation='relu', input_dropout=0, dropout=0))
-  with pytest.raises(NotImplementedError):
-    il.REDDiscriminator(11, 3, icfg, device=DEV)
+  for bad in (dict(depth=3, activation='relu'), dict(depth=1, activation='sigmoid')):
+    icfg = Cfg(state_only=False, reward_bandwidth_scale=None, discriminator=Cfg(hidden_size=32, input_dropout=0, dropout=0, **bad))
+    with pytest.raises(NotImplementedError):
+      il.REDDiscriminator(11, 3, icfg, device=DEV)
   L = _lib.lib()
-  assert L.il_red_step(None, None, None, 0, None) != 0 and b'il_red' in L.il_last_error()
+  assert L.il_red_step(None, None, None, None, None, 0, None, 0, None) != 0 and b'il_red' in L.il_last_error()
 
 
 # ---------------------------------------------------------------------------------------------

@@ -188,23 +188,25 @@ def test_adril_relabeller_oracle_matches_reference_fixture(golden_dir):
     assert np.asarray(v, np.float32).tobytes() == g[f'mix.{k}'].tobytes(), k
 
 
-@pytest.mark.parametrize('name,case', [('hopper_h32', (61, 'hopper', 32, 64, 4)), ('halfcheetah_h64', (62, 'halfcheetah', 64, 256, 3))])
-def test_red_oracle_matches_reference_fixture(golden_dir, name, case):
+@pytest.mark.parametrize('name,kw', [(n, kw) for n, kw, _, _ in gi.RED_CASES], ids=[n for n, *_ in gi.RED_CASES])
+def test_red_oracle_matches_reference_fixture(golden_dir, name, kw):
   """oracle/red.py against REDDiscriminator + target_estimation_update outputs of the reference (predictor after each AdamW step,
-  kernel-median bandwidth, rewards)."""
+  kernel-median bandwidth, rewards) for depth 1-2, relu / tanh, with and without the predictor's dropout (the reference's masks are inputs)."""
   from oracle import red
   g = np.load(os.path.join(golden_dir, 'red.npz'))
-  c = gi.red_case(*case)
+  c = gi.red_case(**kw)
   lr, wd = (float(x) for x in g[f'{name}.hyper'])
-  st = red.RedState(c['D'], c['H']); st.predictor[:] = c['predictor']; st.target[:] = c['target']
-  for k, b in enumerate(c['batches'], 1):
-    red.target_estimation_update(st, np.concatenate([b['states'], b['actions']], 1), b['weights'], lr=lr, weight_decay=wd)
+  st = red.RedState(c['D'], c['H'], c['depth'], c['activation'], c['p_in'], c['p']); st.predictor[:] = c['predictor']; st.target[:] = c['target']
+  for k, (b, masks) in enumerate(zip(c['batches'], c['masks']), 1):
+    red.target_estimation_update(st, np.concatenate([b['states'], b['actions']], 1), b['weights'], lr=lr, weight_decay=wd, masks=masks)
     ref = g[f'{name}.predictor.{k}']
-    assert np.max(np.abs(st.predictor - ref) - 1e-5 * np.abs(ref)) <= 1e-5 * np.abs(ref).max()
+    assert np.max(np.abs(st.predictor - ref) - 1e-5 * np.abs(ref)) <= (1e-5 + 2 * lr * (c['p'] > 0)) * np.abs(ref).max()   # Adam turns ulp-level noise on ~0 gradients (dropped units) into O(lr)
+    assert np.mean(np.abs(st.predictor - ref) > 1e-5 * np.abs(ref) + 1e-6) < 5e-3
   e, q = c['sigma_batch'], c['query']
-  sigma = red.set_sigma(st, np.concatenate([e['states'], e['actions']], 1))
+  st.predictor[:] = g[f'{name}.predictor.{len(c["batches"])}']
+  sigma = red.set_sigma(st, np.concatenate([e['states'], e['actions']], 1), masks=c['sigma_masks'])
   assert abs(sigma - float(g[f'{name}.sigma_1'][0])) <= 1e-5 * sigma
-  np.testing.assert_allclose(red.predict_reward(st, np.concatenate([q['states'], q['actions']], 1)), g[f'{name}.reward'], rtol=1e-5)
+  np.testing.assert_allclose(red.predict_reward(st, np.concatenate([q['states'], q['actions']], 1)), g[f'{name}.reward'], rtol=2e-5)
 
 
 @pytest.mark.parametrize('name,case,kw', [('hopper_h64', (71, 'hopper', 64, 64, 3), {}), ('halfcheetah_h32', (72, 'halfcheetah', 32, 128, 2), dict(p_in=0.2, p=0.3))])

@@ -26,6 +26,8 @@ COMMON = ['steps=260', 'training.start=120', 'evaluation.interval=130', 'evaluat
     ['algorithm=GAIL', 'env=halfcheetah', 'imitation.discriminator.subtract_log_policy=true'],
     ['algorithm=GAIL', 'env=hopper', 'imitation.discriminator.reward_shaping=true', 'imitation.discriminator.subtract_log_policy=true'],
     ['algorithm=RED', 'env=hopper', 'imitation.pretraining.iterations=50'],
+    ['algorithm=RED', 'env=walker2d', 'imitation.pretraining.iterations=50', 'imitation.discriminator.depth=2', 'imitation.discriminator.activation=tanh',
+     'imitation.discriminator.hidden_size=64', 'imitation.discriminator.input_dropout=0.05', 'imitation.discriminator.dropout=0.4'],   # conf/optimised_hyperparameters/RED_25_trajectories.yaml's shape
     ['algorithm=DRIL', 'env=hopper', 'imitation.pretraining.iterations=50'],
     ['algorithm=SAC', 'env=hopper', '+acting.schedule=overlap'],
     ['algorithm=GAIL', 'env=halfcheetah', '+acting.schedule=overlap'],
@@ -63,6 +65,6 @@ def test_unsupported_configurations_fail_loudly():
   import train
   from imitation_learning_amd import config
   for extra in (['algorithm=GAIL', 'imitation.discriminator.depth=2'], ['algorithm=SAC', 'reinforcement.actor.depth=3'],
-                ['algorithm=RED', 'imitation.discriminator.depth=2']):
+                ['algorithm=RED', 'imitation.discriminator.depth=3'], ['algorithm=RED', 'imitation.discriminator.activation=sigmoid']):
     with pytest.raises(NotImplementedError):
       train.train(config.compose(extra + ['env=hopper', 'steps=10'] + COMMON[5:7]))
