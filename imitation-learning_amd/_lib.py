@@ -72,7 +72,8 @@ class Red(C.Structure):
 
 class Dril(C.Structure):
   _fields_ = [('state_dim', C.c_int32), ('action_dim', C.c_int32), ('hidden', C.c_int32), ('batch', C.c_int32), ('p_in', C.c_float), ('p', C.c_float),
-              ('params', C.c_void_p), ('grad', C.c_void_p), ('opt', Adam), ('workspace', C.c_void_p), ('noise_seed', C.c_uint64), ('q', C.c_float), ('reserved', C.c_float)]
+              ('params', C.c_void_p), ('grad', C.c_void_p), ('opt', Adam), ('workspace', C.c_void_p), ('noise_seed', C.c_uint64), ('q', C.c_float), ('activation', C.c_int32),
+              ('depth', C.c_int32), ('reserved', C.c_int32)]
 
 
 class SampleArgs(C.Structure):
@@ -139,10 +140,10 @@ _SIGNATURES = {
     'il_pwil_reset': (C.c_int, [C.POINTER(Pwil), _P]),
     'il_pwil_scratch_floats': (C.c_int64, [C.c_int32, C.c_double]),
     'il_pwil_reward': (C.c_int, [C.POINTER(Pwil), _P, _P, _P, _P]),
-    'il_dril_numel': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
-    'il_dril_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
-    'il_dril_bc_step': (C.c_int, [C.POINTER(Dril), C.POINTER(Batch), _P, _P, C.c_uint32, _P, C.c_uint32, _P]),
-    'il_dril_uncertainty': (C.c_int, [C.POINTER(Dril), C.POINTER(Batch), _P, _P, C.c_uint32, _P, _P, _P]),
+    'il_dril_numel': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'il_dril_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'il_dril_bc_step': (C.c_int, [C.POINTER(Dril), C.POINTER(Batch), _P, _P, _P, C.c_uint32, _P, C.c_uint32, _P]),
+    'il_dril_uncertainty': (C.c_int, [C.POINTER(Dril), C.POINTER(Batch), _P, _P, _P, C.c_uint32, _P, _P, _P]),
     'il_red_numel': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     'il_red_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'il_red_step': (C.c_int, [C.POINTER(Red), C.POINTER(Batch), _P, _P, _P, C.c_uint32, _P, C.c_uint32, _P]),

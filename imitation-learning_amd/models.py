@@ -86,8 +86,10 @@ class SoftActor(_FlatModule):
   """Tanh-Gaussian policy (reference models.py:84-120). `actor(state).sample()` / `get_greedy_action` run k_act on the GPU."""
 
   def __new__(cls, state_size=None, action_size=None, model_cfg=None, device=None):
-    # train.py:73 builds the DRIL "discriminator" with this same class from conf/algorithm/DRIL.yaml's depth-1 tanh dropout config
-    if cls is SoftActor and model_cfg is not None and _cfg_get(model_cfg, 'depth') == 1 and _cfg_get(model_cfg, 'activation') == 'tanh':
+    # train.py:73 builds the DRIL "discriminator" with this same class from the imitation.discriminator config (conf/algorithm/DRIL.yaml: depth 1, tanh,
+    # dropout; conf/optimised_hyperparameters/DRIL_*.yaml: also depth 2 / relu): a config with dropout, or the depth-1 tanh shape, is the policy ensemble
+    if cls is SoftActor and model_cfg is not None and ((_cfg_get(model_cfg, 'depth') == 1 and _cfg_get(model_cfg, 'activation') == 'tanh')
+                                                      or float(_cfg_get(model_cfg, 'dropout', 0) or 0) > 0 or float(_cfg_get(model_cfg, 'input_dropout', 0) or 0) > 0):
       return super().__new__(DropoutSoftActor)
     return super().__new__(cls)
 
@@ -153,50 +155,65 @@ class SoftActor(_FlatModule):
 
 
 class DropoutSoftActor(SoftActor):
-  """The DRIL policy ensemble (reference models.py:84-120 with conf/algorithm/DRIL.yaml: Dropout(p_in)-Linear(S,H)-Dropout(p)-Tanh-Linear(H,2A)).
+  """The DRIL policy ensemble (reference models.py:84-120 built by `_create_fcnn` from the imitation.discriminator config): Dropout(p_in)-Linear(S,H)-
+  Dropout(p)-act(-Linear(H,H)-Dropout(p)-act)-Linear(H,2A), depth 1-2, act in {tanh, relu} (conf/algorithm/DRIL.yaml: depth 1 tanh;
+  conf/optimised_hyperparameters/DRIL_{10,25}_trajectories.yaml: depth 2 relu).
 
   Created through `SoftActor(state_size, action_size, cfg.imitation.discriminator)` like in the reference (train.py:73). It stays in train
   mode (dropout active) for its whole life, as the reference's does: `behavioural_cloning_update` on it runs k_dril_grad / k_dril_apply,
-  the Monte-Carlo-dropout uncertainty runs k_dril_unc.  Pass `masks=(mask_in, mask_hidden)` to reproduce given dropout draws; otherwise the
-  masks come from the on-chip Philox stream.  state_dict keys: actor.1.*, actor.4.* (the Dropout / Tanh modules occupy 0, 2, 3)."""
+  the Monte-Carlo-dropout uncertainty runs k_dril_unc.  Pass `masks=(mask_in, mask_hidden[, mask_hidden2])` to reproduce given dropout draws; otherwise
+  the masks come from the on-chip Philox stream.  state_dict keys: actor.N.* with the Dropout / activation modules occupying Sequential slots too."""
   ENSEMBLE = 5
 
   def __init__(self, state_size: int, action_size: int, model_cfg, device=None):
     nn.Module.__init__(self)
     self.state_size, self.action_size, self.hidden = state_size, action_size, int(_cfg_get(model_cfg, 'hidden_size'))
+    self.depth, self.activation = int(_cfg_get(model_cfg, 'depth')), str(_cfg_get(model_cfg, 'activation'))
     self.p_in, self.p = float(_cfg_get(model_cfg, 'input_dropout', 0) or 0), float(_cfg_get(model_cfg, 'dropout', 0) or 0)
+    if self.depth not in (1, 2) or self.activation not in ('tanh', 'relu'):
+      raise NotImplementedError(f'DRIL policy: the HIP path implements depth 1-2 with tanh / relu (got depth={self.depth}, activation={self.activation}); no torch fallback')
     if state_size > 128 or 2 * action_size > 16 or self.hidden > 256 or self.hidden % 2:
       raise NotImplementedError(f'DRIL policy: state {state_size} (<= 128), action {action_size} (<= 8), hidden {self.hidden} (even, <= 256) outside the kernel limits')
     self.log_std_dev_min, self.log_std_dev_max = -20, 2
-    l1, l2 = nn.Linear(state_size, self.hidden), nn.Linear(self.hidden, 2 * action_size)
-    nn.init.orthogonal_(l1.weight, gain=nn.init.calculate_gain('tanh')); nn.init.constant_(l1.bias, 0)
-    nn.init.orthogonal_(l2.weight, gain=1.0); nn.init.constant_(l2.bias, 0)
-    layers = ([nn.Dropout(self.p_in)] if self.p_in > 0 else []) + [l1] + ([nn.Dropout(self.p)] if self.p > 0 else []) + [nn.Tanh(), l2]
-    self.actor = nn.Sequential(*layers)   # module indices (hence state_dict keys) as in the reference's _create_fcnn
+    act = nn.Tanh if self.activation == 'tanh' else nn.ReLU
+    dims, layers = [state_size] + [self.hidden] * self.depth, []
+    if self.p_in > 0: layers.append(nn.Dropout(self.p_in))
+    for a, b in zip(dims[:-1], dims[1:]):   # module order (hence state_dict keys) and RNG consumption as in the reference's _create_fcnn
+      lin = nn.Linear(a, b)
+      nn.init.orthogonal_(lin.weight, gain=nn.init.calculate_gain(self.activation)); nn.init.constant_(lin.bias, 0)
+      layers.append(lin)
+      if self.p > 0: layers.append(nn.Dropout(self.p))
+      layers.append(act())
+    last = nn.Linear(self.hidden, 2 * action_size)
+    nn.init.orthogonal_(last.weight, gain=1.0); nn.init.constant_(last.bias, 0)
+    self.actor = nn.Sequential(*layers, last)
     offs, o = [], 0
     for p in self.parameters():
       offs.append(o); o += p.numel()
-    assert o == int(_lib.lib().il_dril_numel(state_size, action_size, self.hidden))
+    assert o == int(_lib.lib().il_dril_numel(state_size, action_size, self.hidden, self.depth))
     self._adopt(o, offs, device or default_device())
     self._act_calls, self.q = 0, None
 
   def _desc(self, batch_size: int, opt=None) -> '_lib.Dril':
     d = _lib.Dril()
     d.state_dim, d.action_dim, d.hidden, d.batch, d.p_in, d.p = self.state_size, self.action_size, self.hidden, batch_size, self.p_in, self.p
+    d.depth, d.activation = self.depth, int(self.activation == 'relu')
     d.params, d.noise_seed, d.q = self.flat.data_ptr(), torch.initial_seed() & (2**64 - 1), float(self.q) if self.q is not None else 0.0
     if opt is not None:
       from .training import _workspace
-      ws = _workspace('dril', int(_lib.lib().il_dril_workspace_floats(self.state_size, self.action_size, self.hidden, batch_size)), self.flat.device)
+      ws = _workspace('dril', int(_lib.lib().il_dril_workspace_floats(self.state_size, self.action_size, self.hidden, batch_size, self.depth)), self.flat.device)
       d.grad, d.opt, d.workspace = opt.grad.data_ptr(), opt.desc(), ws.data_ptr()
     return d
 
   def _masks(self, masks, rows):
+    """(mask_in, mask_hidden, mask_hidden2) tensors (None = drawn on chip); with masks given, one per dropout layer in module order."""
     if masks is None:
-      return None, None
+      return None, None, None
     dev = self.flat.device
-    m0, m1 = (x.to(dev, torch.float32).contiguous() for x in masks)
-    assert m0.shape == (rows, self.state_size) and m1.shape == (rows, self.hidden), 'dropout keep-masks must be [rows, S] and [rows, H]'
-    return m0, m1
+    masks = [x.to(dev, torch.float32).contiguous() for x in masks]
+    assert len(masks) == 1 + self.depth, f'dropout keep-masks: expected {1 + self.depth} (input + one per hidden layer)'
+    assert masks[0].shape == (rows, self.state_size) and all(m.shape == (rows, self.hidden) for m in masks[1:]), 'dropout keep-masks must be [rows, S] and [rows, H]'
+    return tuple(masks) + (None,) * (3 - len(masks))
 
   def _next_offset(self) -> int:
     self._act_calls += 1
@@ -208,10 +225,10 @@ class DropoutSoftActor(SoftActor):
     for k in ('rewards', 'terminals', 'absorbing', 'next_states'):
       t.setdefault(k, t['weights'] if k != 'next_states' else t['states'])
     b = batch_desc(t)
-    m0, m1 = self._masks(masks, b.n)
+    m0, m1, m2 = self._masks(masks, b.n)
     loss = torch.empty(1, device=self.flat.device) if want_loss else None
     d = self._desc(b.n, optimiser)
-    _lib.check(_lib.lib().il_dril_bc_step(C.byref(d), C.byref(b), _lib.ptr(m0), _lib.ptr(m1), self._next_offset(), _lib.ptr(loss), 0, _lib.stream_ptr()))
+    _lib.check(_lib.lib().il_dril_bc_step(C.byref(d), C.byref(b), _lib.ptr(m0), _lib.ptr(m1), _lib.ptr(m2), self._next_offset(), _lib.ptr(loss), 0, _lib.stream_ptr()))
     return loss
 
   def _uncertainty(self, state: Tensor, action: Tensor, masks=None, want_reward: bool = False) -> Tensor:
@@ -222,10 +239,10 @@ class DropoutSoftActor(SoftActor):
     if action.stride(-1) != 1: action = action.contiguous()
     n = state.size(0)
     b = _sa_batch(state, action, torch.ones(n, device=dev))
-    m0, m1 = self._masks(masks, n * self.ENSEMBLE)
+    m0, m1, m2 = self._masks(masks, n * self.ENSEMBLE)
     out = torch.empty(n, device=dev)
     d = self._desc(n)
-    _lib.check(_lib.lib().il_dril_uncertainty(C.byref(d), C.byref(b), _lib.ptr(m0), _lib.ptr(m1), self._next_offset(), None if want_reward else _lib.ptr(out),
+    _lib.check(_lib.lib().il_dril_uncertainty(C.byref(d), C.byref(b), _lib.ptr(m0), _lib.ptr(m1), _lib.ptr(m2), self._next_offset(), None if want_reward else _lib.ptr(out),
                                               _lib.ptr(out) if want_reward else None, _lib.stream_ptr()))
     return out
 

@@ -406,19 +406,22 @@ typedef struct il_dril {
   float* params;
   float* grad;          /* [P] */
   il_adam opt;
-  float* workspace;     /* >= il_dril_workspace_floats(S, A, H, batch) */
+  float* workspace;     /* >= il_dril_workspace_floats(S, A, H, batch, depth) */
   uint64_t noise_seed;
   float q;              /* uncertainty threshold (models.py:110-111 set_uncertainty_threshold) */
-  float reserved;
+  int32_t activation;   /* 0 tanh (conf/algorithm/DRIL.yaml), 1 relu */
+  int32_t depth;        /* hidden layers: 1 or 2 (0 = 1) */
+  int32_t reserved;
 } il_dril;
-int64_t il_dril_numel(int32_t state_dim, int32_t action_dim, int32_t hidden);
-int64_t il_dril_workspace_floats(int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t batch);
-/* behavioural_cloning_update on the dropout policy: loss = mean_i w_i * -log pi(a_i | s_i; masks), AdamW. mask_in [B,S], mask_hidden [B,H] or NULL. */
-int il_dril_bc_step(const il_dril* d, const il_batch* expert, const float* mask_in, const float* mask_hidden, uint32_t noise_offset, float* out_loss,
-                    uint32_t flags, il_stream_t stream);
-/* models.py:104-120: Monte-Carlo dropout uncertainty = unbiased variance over 5 masks of exp(log_prob(s, a)); masks [5n,S], [5n,H] in
+/* parameters in torch order: W1[H,S] b1 (Wh[H,H] bh when depth = 2) W2[2A,H] b2 */
+int64_t il_dril_numel(int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t depth);
+int64_t il_dril_workspace_floats(int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t batch, int32_t depth);
+/* behavioural_cloning_update on the dropout policy: loss = mean_i w_i * -log pi(a_i | s_i; masks), AdamW. mask_in [B,S], mask_hidden / mask_hidden2 [B,H] or NULL. */
+int il_dril_bc_step(const il_dril* d, const il_batch* expert, const float* mask_in, const float* mask_hidden, const float* mask_hidden2, uint32_t noise_offset,
+                    float* out_loss, uint32_t flags, il_stream_t stream);
+/* models.py:104-120: Monte-Carlo dropout uncertainty = unbiased variance over 5 masks of exp(log_prob(s, a)); masks [5n,S], [5n,H] (one per hidden layer) in
  * repeat_interleave order or NULL. out_uncertainty [n] and / or out_reward [n] = (uncertainty <= d->q ? +1 : -1). */
-int il_dril_uncertainty(const il_dril* d, const il_batch* batch, const float* mask_in, const float* mask_hidden, uint32_t noise_offset,
+int il_dril_uncertainty(const il_dril* d, const il_batch* batch, const float* mask_in, const float* mask_hidden, const float* mask_hidden2, uint32_t noise_offset,
                         float* out_uncertainty, float* out_reward, il_stream_t stream);
 
 /* sizeof() of the descriptor structs in this build (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red,

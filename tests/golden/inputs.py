@@ -135,20 +135,38 @@ RED_CASES = (   # name, red_case arguments, lr, weight decay; the last three mir
 )
 
 
-def dril_case(seed, env, hidden, batch, steps, p_in=0.1, p=0.1):
-  """DRIL policy ensemble (Dropout-Linear(S,H)-Dropout-Tanh-Linear(H,2A)), expert batches with their dropout keep-masks, and the masks of
-  the 5-member Monte-Carlo ensemble for an expert set and a query set (rows in repeat_interleave order)."""
+def dril_case(seed, env, hidden, batch, steps, p_in=0.1, p=0.1, depth=1, activation='tanh'):
+  """DRIL policy ensemble (`_create_fcnn`: Dropout-Linear(S,H)-Dropout-act(-Linear(H,H)-Dropout-act)-Linear(H,2A)), expert batches with their dropout
+  keep-masks, and the masks of the 5-member Monte-Carlo ensemble for an expert set and a query set (rows in repeat_interleave order)."""
   S, A = DIMS[env]
   rs = np.random.RandomState(seed)
-  params = mlp_params(rs, S, hidden, 1, 2 * A, out_scale=0.3)
+  params = mlp_params(rs, S, hidden, depth, 2 * A, out_scale=0.3)
   keep = lambda shape, pr: (rs.uniform(size=shape) >= pr).astype(f32)
   batches = [transitions(rs, batch, S, A, state_shift=0.5, weighted=True) for _ in range(steps)]
   for b in batches:
     b['actions'] = np.clip(b['actions'], -0.97, 0.97).astype(f32); b['actions'][:2] = np.array([1.0, -1.0], f32)[:, None]  # exercise the clamp
   expert, query = transitions(rs, 80, S, A, state_shift=0.5), transitions(rs, 37, S, A)
-  return dict(S=S, A=A, H=hidden, B=batch, p_in=p_in, p=p, params=params, batches=batches, m0=[keep((batch, S), p_in) for _ in range(steps)],
-              m1=[keep((batch, hidden), p) for _ in range(steps)], expert=expert, query=query, e_m0=keep((80 * 5, S), p_in), e_m1=keep((80 * 5, hidden), p),
-              q_m0=keep((37 * 5, S), p_in), q_m1=keep((37 * 5, hidden), p))
+  c = dict(S=S, A=A, H=hidden, B=batch, p_in=p_in, p=p, depth=depth, activation=activation, params=params, batches=batches, m0=[keep((batch, S), p_in) for _ in range(steps)],
+           m1=[keep((batch, hidden), p) for _ in range(steps)], expert=expert, query=query, e_m0=keep((80 * 5, S), p_in), e_m1=keep((80 * 5, hidden), p),
+           q_m0=keep((37 * 5, S), p_in), q_m1=keep((37 * 5, hidden), p))
+  if depth == 2:   # drawn last: the depth-1 cases stay what they were
+    c.update(m2=[keep((batch, hidden), p) for _ in range(steps)], e_m2=keep((80 * 5, hidden), p), q_m2=keep((37 * 5, hidden), p))
+  return c
+
+
+def dril_masks(c, which, k=None):
+  """The keep-masks of one call in module order: which = 'm' (update k), 'e_m' (expert set) or 'q_m' (query set)."""
+  names = [f'{which}{i}' for i in range(1 + c['depth'])]
+  return [c[n][k] if k is not None else c[n] for n in names]
+
+
+DRIL_CASES = (   # name, dril_case arguments, lr, weight decay; the last two mirror conf/optimised_hyperparameters/DRIL_{10,25}_trajectories.yaml (depth 2, relu)
+    ('hopper_h64', dict(seed=71, env='hopper', hidden=64, batch=64, steps=3), 3e-5, 0.0),
+    ('halfcheetah_h32', dict(seed=72, env='halfcheetah', hidden=32, batch=128, steps=2, p_in=0.2, p=0.3), 1e-3, 0.01),
+    ('hopper_d2_relu', dict(seed=74, env='hopper', hidden=32, batch=96, steps=3, p_in=0.4, p=0.55, depth=2, activation='relu'), 2.7e-4, 5.4),
+    ('walker2d_d2_tanh', dict(seed=75, env='walker2d', hidden=64, batch=64, steps=2, p_in=0.1, p=0.2, depth=2, activation='tanh'), 1e-3, 0.0),
+    ('halfcheetah_d1_relu', dict(seed=76, env='halfcheetah', hidden=128, batch=64, steps=2, p_in=0.05, p=0.3, depth=1, activation='relu'), 5e-4, 0.1),
+)
 
 
 def gail_extras(seed, c):

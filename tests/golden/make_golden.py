@@ -396,29 +396,32 @@ class DropoutFeed:
 
 
 def gen_dril():
-  """SoftActor with the DRIL discriminator config (models.py:84-120) in train mode: 3 BC updates, uncertainty, threshold, reward."""
+  """SoftActor with the DRIL discriminator config (models.py:84-120) in train mode: BC updates, uncertainty, threshold, reward; depth 1-2, tanh / relu."""
   out = {}
-  for name, c, lr, wd in (('hopper_h64', gi.dril_case(71, 'hopper', 64, 64, 3), 3e-5, 0.0), ('halfcheetah_h32', gi.dril_case(72, 'halfcheetah', 32, 128, 2, p_in=0.2, p=0.3), 1e-3, 0.01)):
-    cfg = DictConfig(hidden_size=c['H'], depth=1, activation='tanh', input_dropout=c['p_in'], dropout=c['p'])
+  for name, kw, lr, wd in gi.DRIL_CASES:
+    c = gi.dril_case(**kw)
+    cfg = DictConfig(hidden_size=c['H'], depth=c['depth'], activation=c['activation'], input_dropout=c['p_in'], dropout=c['p'])
     d = ref_models.SoftActor(c['S'], c['A'], cfg)
-    assert [k for k in d.state_dict()] == ['actor.1.weight', 'actor.1.bias', 'actor.4.weight', 'actor.4.bias']
+    lin = [1 + 3 * l for l in range(c['depth'] + 1)]   # Dropout, [Linear, Dropout, act] x depth, Linear
+    assert [k for k in d.state_dict()] == [f'actor.{i}.{p}' for i in lin for p in ('weight', 'bias')]
     torch.nn.utils.vector_to_parameters(T(c['params']), d.parameters())
     opt = torch.optim.AdamW(d.parameters(), lr=lr, weight_decay=wd)
-    for k, (b, m0, m1) in enumerate(zip(c['batches'], c['m0'], c['m1']), 1):
-      with DropoutFeed([T(m0), T(m1)]):
+    for k, b in enumerate(c['batches'], 1):
+      with DropoutFeed([T(m) for m in gi.dril_masks(c, 'm', k - 1)]):
         ref_training.behavioural_cloning_update(d, tbatch(b), opt)
       out[f'{name}.params.{k}'] = flat(d)
     out[f'{name}.exp_avg'] = opt_state(opt, 'exp_avg')
     with torch.inference_mode():
       e, q = tbatch(c['expert']), tbatch(c['query'])
-      with DropoutFeed([T(c['e_m0']), T(c['e_m1'])]):
+      em, qm = [T(m) for m in gi.dril_masks(c, 'e_m')], [T(m) for m in gi.dril_masks(c, 'q_m')]
+      with DropoutFeed(list(em)):
         out[f'{name}.expert_uncertainty'] = N_(d._get_action_uncertainty(e['states'], e['actions']))
-      with DropoutFeed([T(c['e_m0']), T(c['e_m1'])]):
+      with DropoutFeed(list(em)):
         d.set_uncertainty_threshold(e['states'], e['actions'], 0.9)
       out[f'{name}.q'] = np.array([d.q], np.float64)
-      with DropoutFeed([T(c['q_m0']), T(c['q_m1'])]):
+      with DropoutFeed(list(qm)):
         out[f'{name}.reward'] = N_(d.predict_reward(q['states'], q['actions']))
-      with DropoutFeed([T(c['q_m0']), T(c['q_m1'])]):
+      with DropoutFeed(list(qm)):
         out[f'{name}.query_uncertainty'] = N_(d._get_action_uncertainty(q['states'], q['actions']))
     out[f'{name}.hyper'] = np.array([lr, wd], np.float64)
   np.savez_compressed(os.path.join(HERE, 'dril.npz'), **out)

@@ -710,24 +710,26 @@ def test_red_loud_failures():
 # ---------------------------------------------------------------------------------------------
 # DRIL dropout policy ensemble (models.py:84-120 + training.py:57-64) against the reference-generated fixture and the oracle
 # ---------------------------------------------------------------------------------------------
-DRIL_CASES = [('hopper_h64', (71, 'hopper', 64, 64, 3), {}), ('halfcheetah_h32', (72, 'halfcheetah', 32, 128, 2), dict(p_in=0.2, p=0.3))]
-
-
 @pytest.mark.gpu
-@pytest.mark.parametrize('name,case,kw', DRIL_CASES)
-def test_dril_matches_reference(golden_dir, name, case, kw):
+@pytest.mark.parametrize('name,kw', [(n, kw) for n, kw, _, _ in gi.DRIL_CASES], ids=[n for n, *_ in gi.DRIL_CASES])
+def test_dril_matches_reference(golden_dir, name, kw):
+  """The DRIL policy ensemble on the HIP path against the reference fixture and the oracle: conf/algorithm/DRIL.yaml (depth 1, tanh) and the shapes of
+  conf/optimised_hyperparameters/DRIL_*.yaml (depth 2 / relu), the reference's keep-masks fed back in."""
   from oracle import dril as odril
   g = load(golden_dir, 'dril')
-  c = gi.dril_case(*case, **kw)
+  c = gi.dril_case(**kw)
   lr, wd = (float(x) for x in g[f'{name}.hyper'])
-  d = il.SoftActor(c['S'], c['A'], Cfg(hidden_size=c['H'], depth=1, activation='tanh', input_dropout=c['p_in'], dropout=c['p']), device=DEV)
-  assert type(d).__name__ == 'DropoutSoftActor' and list(d.state_dict()) == ['actor.1.weight', 'actor.1.bias', 'actor.4.weight', 'actor.4.bias']
+  d = il.SoftActor(c['S'], c['A'], Cfg(hidden_size=c['H'], depth=c['depth'], activation=c['activation'], input_dropout=c['p_in'], dropout=c['p']), device=DEV)
+  lin = [1 + 3 * l for l in range(c['depth'] + 1)]
+  assert type(d).__name__ == 'DropoutSoftActor' and list(d.state_dict()) == [f'actor.{i}.{p}' for i in lin for p in ('weight', 'bias')]
   d.flat.copy_(T(c['params']))
   opt = il.AdamW(d, lr=lr, weight_decay=wd)
-  ds = odril.DrilState(c['S'], c['A'], c['H'], c['p_in'], c['p']); ds.params[:] = c['params']
-  for k, (b, m0, m1) in enumerate(zip(c['batches'], c['m0'], c['m1']), 1):
-    loss = il.behavioural_cloning_update(d, tbatch(b), opt, masks=(T(m0), T(m1)))
-    oloss = odril.bc_update(ds, b, m0, m1, lr=lr, weight_decay=wd)
+  ds = odril.DrilState(c['S'], c['A'], c['H'], c['p_in'], c['p'], c['depth'], c['activation']); ds.params[:] = c['params']
+  tm = lambda masks: tuple(T(m) for m in masks)
+  for k, b in enumerate(c['batches'], 1):
+    masks = gi.dril_masks(c, 'm', k - 1)
+    loss = il.behavioural_cloning_update(d, tbatch(b), opt, masks=tm(masks))
+    oloss = odril.bc_update(ds, b, *masks, lr=lr, weight_decay=wd)
     close(N(loss)[0], oloss, f'{name} BC loss {k}')
     close_params(N(d.flat), g[f'{name}.params.{k}'], f'{name} params after update {k} (reference)', lr, steps=k)
     close_params(N(d.flat), ds.params, f'{name} params after update {k} (oracle)', lr, steps=k)
@@ -736,13 +738,14 @@ def test_dril_matches_reference(golden_dir, name, case, kw):
   # leading digits, so it is compared at 1e-4 of the largest value in the batch rather than 1e-5 per element.
   d.flat.copy_(T(g[f'{name}.params.{len(c["batches"])}']))
   e, q = tbatch(c['expert']), tbatch(c['query'])
-  ue = N(d._get_action_uncertainty(e['states'], e['actions'], masks=(T(c['e_m0']), T(c['e_m1']))))
+  em, qm = tm(gi.dril_masks(c, 'e_m')), tm(gi.dril_masks(c, 'q_m'))
+  ue = N(d._get_action_uncertainty(e['states'], e['actions'], masks=em))
   ref_ue = g[f'{name}.expert_uncertainty']
-  assert np.abs(ue - ref_ue).max() <= 1e-4 * np.abs(ref_ue).max() + 1e-5 * 0
-  d.set_uncertainty_threshold(e['states'], e['actions'], 0.9, masks=(T(c['e_m0']), T(c['e_m1'])))
-  assert abs(d.q - float(g[f'{name}.q'][0])) <= 1e-4 * abs(d.q)
+  assert np.abs(ue - ref_ue).max() <= 1e-4 * np.abs(ref_ue).max()
+  d.set_uncertainty_threshold(e['states'], e['actions'], 0.9, masks=em)
+  assert abs(d.q - float(g[f'{name}.q'][0])) <= 1e-4 * max(abs(d.q), np.abs(ref_ue).max())
   d.q = float(g[f'{name}.q'][0])
-  r = N(d.predict_reward(q['states'], q['actions'], masks=(T(c['q_m0']), T(c['q_m1']))))   # 37 rows: ragged tiles
+  r = N(d.predict_reward(q['states'], q['actions'], masks=qm))   # 37 rows: ragged tiles
   ref_r, ref_u = g[f'{name}.reward'], g[f'{name}.query_uncertainty']
   decided = np.abs(ref_u - d.q) > 1e-4 * np.abs(ref_u).max()   # rows whose uncertainty is not within rounding of the threshold
   assert decided.sum() >= len(ref_r) - 2 and np.array_equal(r[decided], ref_r[decided]) and set(np.unique(r)) <= {-1.0, 1.0}

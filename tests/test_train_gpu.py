@@ -29,6 +29,8 @@ COMMON = ['steps=260', 'training.start=120', 'evaluation.interval=130', 'evaluat
     ['algorithm=RED', 'env=walker2d', 'imitation.pretraining.iterations=50', 'imitation.discriminator.depth=2', 'imitation.discriminator.activation=tanh',
      'imitation.discriminator.hidden_size=64', 'imitation.discriminator.input_dropout=0.05', 'imitation.discriminator.dropout=0.4'],   # conf/optimised_hyperparameters/RED_25_trajectories.yaml's shape
     ['algorithm=DRIL', 'env=hopper', 'imitation.pretraining.iterations=50'],
+    ['algorithm=DRIL', 'env=walker2d', 'imitation.pretraining.iterations=50', 'imitation.discriminator.depth=2', 'imitation.discriminator.activation=relu',
+     'imitation.discriminator.hidden_size=32', 'imitation.discriminator.input_dropout=0.4', 'imitation.discriminator.dropout=0.55'],   # conf/optimised_hyperparameters/DRIL_25_trajectories.yaml's shape
     ['algorithm=SAC', 'env=hopper', '+acting.schedule=overlap'],
     ['algorithm=GAIL', 'env=halfcheetah', '+acting.schedule=overlap'],
     ['algorithm=AdRIL', 'env=hopper', '+acting.schedule=overlap'],
