@@ -751,6 +751,42 @@ def test_dril_matches_reference(golden_dir, name, kw):
   assert decided.sum() >= len(ref_r) - 2 and np.array_equal(r[decided], ref_r[decided]) and set(np.unique(r)) <= {-1.0, 1.0}
 
 
+# imitation.discriminator of every conf/optimised_hyperparameters/{RED,DRIL}_*_trajectories.yaml of the reference (hidden, depth, activation, input_dropout, dropout)
+SHIPPED_SHAPES = {'RED_5': (128, 2, 'relu', 0.0776, 0.3771), 'RED_10': (32, 1, 'tanh', 0.3861, 0.6857), 'RED_25': (64, 2, 'tanh', 0.0534, 0.4138),
+                  'DRIL_5': (64, 1, 'tanh', 0.2122, 0.2069), 'DRIL_10': (32, 2, 'relu', 0.0906, 0.4719), 'DRIL_25': (32, 2, 'relu', 0.4033, 0.5565)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', sorted(SHIPPED_SHAPES))
+def test_every_shipped_red_dril_shape_runs_at_ant_dims(name):
+  """The tuned configurations the reference ships must all run on the HIP path, at the largest environment (Ant: the LDS-heaviest tiles), with on-chip masks
+  and a ragged batch: two updates and the reward, everything finite and the parameters moving."""
+  H, depth, act, p_in, p = SHIPPED_SHAPES[name]
+  S, A = gi.DIMS['ant']
+  rs = np.random.RandomState(5)
+  b = gi.transitions(rs, 200, S, A, state_shift=0.5, weighted=True)
+  b['actions'] = np.clip(b['actions'], -0.97, 0.97).astype(np.float32)
+  mcfg = Cfg(hidden_size=H, depth=depth, activation=act, input_dropout=p_in, dropout=p)
+  if name.startswith('RED'):
+    d = il.REDDiscriminator(S, A, Cfg(state_only=False, reward_bandwidth_scale=None, discriminator=mcfg), device=DEV)
+    opt = il.AdamW(d, lr=1e-3, weight_decay=0.1)
+    before = N(d.flat).copy()
+    for _ in range(2): il.target_estimation_update(d, tbatch(b), opt)
+    d.set_sigma(T(b['states'][:64]), T(b['actions'][:64])); d.eval()
+    r = N(d.predict_reward(T(b['states']), T(b['actions'])))
+    assert ((r > 0) & (r <= 1)).all()
+  else:
+    d = il.SoftActor(S, A, mcfg, device=DEV)
+    opt = il.AdamW(d, lr=1e-3, weight_decay=0.1)
+    before = N(d.flat).copy()
+    for _ in range(2): il.behavioural_cloning_update(d, tbatch(b), opt)
+    d.set_uncertainty_threshold(T(b['states']), T(b['actions']), 0.9)
+    r = N(d.predict_reward(T(b['states']), T(b['actions'])))
+    assert set(np.unique(r)) <= {-1.0, 1.0}
+  after = N(d.flat)
+  assert np.isfinite(after).all() and np.isfinite(r).all() and not np.array_equal(before, after)
+
+
 @pytest.mark.gpu
 def test_dril_onchip_masks_are_bernoulli_and_change_per_call():
   c = gi.dril_case(71, 'hopper', 64, 64, 1)
