@@ -307,8 +307,11 @@ class UpdatePlan:
     if algorithm == 'GAIL':
       self.erows = torch.empty(batch_size, expert_memory.row, device=dev); self.eidx = torch.empty(batch_size, dtype=torch.int32, device=dev)
       self.expert_transitions = batch_views(self.erows, expert_memory.state_size, expert_memory.action_size, expert_memory.absorbing)
-      if imitation_cfg is not None and (imitation_cfg.loss_function == 'Mixup' or discriminator.subtract_log_policy or getattr(discriminator, 'reward_shaping', False)):
-        raise NotImplementedError('UpdatePlan: GAIL with Mixup / subtract_log_policy / reward shaping runs through adversarial_imitation_update + sac_update')
+      host_mixup = imitation_cfg is not None and imitation_cfg.loss_function == 'Mixup' and float(_cfg_value(imitation_cfg, 'mixup_alpha', 1.0)) != 1.0
+      if imitation_cfg is not None and (host_mixup or discriminator.subtract_log_policy or getattr(discriminator, 'reward_shaping', False)):
+        # Mixup with alpha = 1 draws its Beta(1, 1) = U(0, 1) coefficients from the on-chip Philox stream like the gradient penalty does: capturable
+        raise NotImplementedError('UpdatePlan: GAIL with Mixup (alpha != 1: Beta draws on the host) / subtract_log_policy / reward shaping runs through '
+                                  'adversarial_imitation_update + sac_update')
       self.disc = disc_descriptor(discriminator, batch_size, discriminator_optimiser, imitation_cfg, tag=tag, seed_offset=off)
       self.eb = batch_desc(self.expert_transitions)
       self.rewards = torch.empty(batch_size, device=dev)

@@ -302,7 +302,7 @@ def test_pwil_matches_oracle_and_reference(golden_dir):
 
 
 # ------------------------------------------------------------------------------------------------ whole update block
-def _make_plan(algorithm, seed, device_draw=True):
+def _make_plan(algorithm, seed, device_draw=True, loss='BCE', entropy_bonus=0.0):
   S, A = gi.DIMS['halfcheetah']
   B = 256
   torch.manual_seed(seed)
@@ -313,7 +313,7 @@ def _make_plan(algorithm, seed, device_draw=True):
   rs = np.random.RandomState(seed)
   mem = il.ReplayMemory(20000, S, A, True, device=DEV); fill_memory(mem, gi.transitions(rs, 5000, S, A), 5000)
   emem = il.ReplayMemory(2000, S, A, True, device=DEV); fill_memory(emem, gi.transitions(rs, 2000, S, A, state_shift=0.5), 2000)
-  icfg = Cfg(state_only=False, spectral_norm=True, loss_function='BCE', grad_penalty=1.0, entropy_bonus=0.0,
+  icfg = Cfg(state_only=False, spectral_norm=True, loss_function=loss, grad_penalty=1.0, entropy_bonus=entropy_bonus, mixup_alpha=1, pos_class_prior=0.7, nonnegative_margin=float('inf'),
              discriminator=Cfg(hidden_size=64, depth=1, activation='relu', reward_shaping=False, subtract_log_policy=False, reward_function='AIRL'))
   disc = il.GAILDiscriminator(S, A, icfg, 0.97, device=DEV)
   do = il.AdamW(disc, lr=3e-5, weight_decay=10)
@@ -847,18 +847,20 @@ def test_gail_variants_loud_failures():
 
 
 @pytest.mark.gpu
-def test_device_handoff_equals_stream_dependencies(monkeypatch):
-  """The two-graph update whose branches hand over through device counters must evolve the learner bit for bit like the one-graph update with a
-  fork / join (same kernels, same order of dependent work); 400 replays, and no bounded wait may have timed out."""
+@pytest.mark.parametrize('loss,replays', [('BCE', 400), ('Mixup', 60), ('PUGAIL', 60)])
+def test_device_handoff_equals_stream_dependencies(monkeypatch, loss, replays):
+  """The two-graph update whose branches hand over through device counters (rows read from the rings, relabel inline) must evolve the learner bit for bit like
+  the one-graph update with a fork / join on gathered rows and the stand-alone relabel kernel; no bounded wait may have timed out. Mixup (alpha = 1: on-chip
+  U(0,1) coefficients, the loss of conf/optimised_hyperparameters/GAIL_{5,10}_trajectories.yaml) and PUGAIL run the same fused plan."""
   results = []
   for device_sync in ('1', '0'):
     monkeypatch.setenv('IL_DEVICE_SYNC', device_sync)
     il.seed(23)
     il_training._NOISE.clear()
-    plan, nets = _make_plan('GAIL', 8)
+    plan, nets = _make_plan('GAIL', 8, loss=loss, entropy_bonus=0.0 if loss == 'BCE' else 0.05)
     assert plan.device_sync == (device_sync == '1')
     plan.capture(warmup=0)
-    for _ in range(400):
+    for _ in range(replays):
       plan.replay()
     torch.cuda.synchronize()
     assert plan.sync_timeouts() == 0
