@@ -321,6 +321,7 @@ class UpdatePlan:
     # dependency between the gather and the critic loss. Validated by `capture()`; IL_DEVICE_SYNC=0 keeps plain stream dependencies.
     self.sync = torch.zeros(16, dtype=torch.int64, device=dev)   # IL_SYNC_SLOTS
     self.device_sync = False
+    self._chain_fits = None
     if algorithm == 'GAIL' and overlap and device_index_draw and os.environ.get('IL_DEVICE_SYNC', '1') != '0':
       self._set_device_sync(self._probe_device_sync(graph=False))
     self.graph = self.graph_side = None
@@ -417,7 +418,14 @@ class UpdatePlan:
     """Device-side hand-off only: an update is DRAWN but never gathered by a kernel of its own. The discriminator step and the forward / critic-loss
     launch read their rows straight from the rings through the indices (il_batch.gather), so both branches start right after the index draw;
     extra workgroups of k_sac_chain write the gathered agent rows for the later kernels (il_sac_update_gather). IL_RING_GATHER=0: gather first."""
-    return self.device_sync and os.environ.get('IL_RING_GATHER', '1') != '0'
+    if not self.device_sync or os.environ.get('IL_RING_GATHER', '1') == '0':
+      return False
+    # il_sac_update_gather's launch (6 workgroups per 16-row tile + the gather workgroups) must be co-resident: batch sizes beyond that gather first
+    # (il_sac_update then also keeps its forward / critic-loss kernels separate)
+    if self._chain_fits is None:
+      cus = torch.cuda.get_device_properties(self.rows.device).multi_processor_count
+      self._chain_fits = 6 * (self.B // 16) + int(_lib.lib().il_sac_chain_gather_workgroups(self.B, self.memory.row, self.sac.hidden)) <= cus
+    return self._chain_fits
 
   def _ring_batches(self):
     if self._ring_desc is None:

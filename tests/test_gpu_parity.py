@@ -302,9 +302,8 @@ def test_pwil_matches_oracle_and_reference(golden_dir):
 
 
 # ------------------------------------------------------------------------------------------------ whole update block
-def _make_plan(algorithm, seed, device_draw=True, loss='BCE', entropy_bonus=0.0):
+def _make_plan(algorithm, seed, device_draw=True, loss='BCE', entropy_bonus=0.0, B=256):
   S, A = gi.DIMS['halfcheetah']
-  B = 256
   torch.manual_seed(seed)
   cfg = Cfg(hidden_size=256, depth=2, activation='relu')
   actor, critic = il.SoftActor(S, A, cfg, device=DEV), il.TwinCritic(S, A, cfg, device=DEV)
@@ -865,6 +864,27 @@ def test_device_handoff_equals_stream_dependencies(monkeypatch, loss, replays):
     torch.cuda.synchronize()
     assert plan.sync_timeouts() == 0
     results.append([N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [N(plan.idx), N(plan.logp), N(plan.rewards)])
+  for a, b in zip(*results):
+    assert np.isfinite(a).all()
+    np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,ring', [(128, True), (512, True), (1024, False)])
+def test_update_plan_batch_sizes_of_the_tuned_configs(monkeypatch, B, ring):
+  """training.batch_size of conf/optimised_hyperparameters/*.yaml is 128 ... 1024: up to 512 the chained launch is co-resident and the plan reads its rows through
+  il_batch.gather; at 1024 (64 tiles x 6 workgroups > 256 CUs) it gathers first and keeps the separate kernels. Either way the device hand-off must equal the
+  stream-dependency schedule bit for bit."""
+  results = []
+  for device_sync in ('1', '0'):
+    monkeypatch.setenv('IL_DEVICE_SYNC', device_sync)
+    il.seed(29); il_training._NOISE.clear()
+    plan, nets = _make_plan('GAIL', 10, B=B)
+    if device_sync == '1': assert plan.device_sync and plan.ring_mode == ring and plan.inline_relabel == ring
+    for _ in range(6): plan.run()
+    torch.cuda.synchronize()
+    assert plan.sync_timeouts() == 0
+    results.append([N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [N(plan.logp), N(plan.rewards)])
   for a, b in zip(*results):
     assert np.isfinite(a).all()
     np.testing.assert_array_equal(a, b)
