@@ -119,6 +119,7 @@ _SIGNATURES = {
     'il_sac_update_gather': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.POINTER(Batch), _P, C.POINTER(Disc), _P, _P, _P, _P, _P, C.c_uint32, _P]),
     'il_gail_step_workgroups': (C.c_int32, [C.POINTER(Disc)]),
     'il_sac_chain_gather_workgroups': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    'il_sac_handoff_timeouts': (C.c_int, [C.POINTER(Sac), C.POINTER(C.c_uint32)]),
     'il_bc_step': (C.c_int, [_P, _P, C.POINTER(Adam), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Batch), _P, C.c_int64, _P, C.c_uint32, _P]),
     'il_actor_act': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_uint64, C.c_uint32, C.c_int32, _P, _P, _P]),
     'il_batch_mix_relabel': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_int64, _P]),

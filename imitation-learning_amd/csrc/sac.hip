@@ -69,7 +69,10 @@ __global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask, const i
   const int net = blockIdx.y;
   const SacWs ws = sac_ws(S, A, H, d.batch);
   if (blockIdx.x == 0 && blockIdx.y == 0)   // arrival counters of k_policy_critic's tile pairs and of k_sac_chain's tiles (they reset themselves; this covers a reused arena)
+  {
     for (int i = threadIdx.x; i < d.batch / IL_TILE_R; i += blockDim.x) { reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr)[i] = 0u; reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr)[i] = 0u; }
+    if (threadIdx.x == 0) reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr)[d.batch / IL_TILE_R + 1] = 0u;   // il_sac_handoff_timeouts counts from here
+  }
   if (!((mask >> net) & 1u)) return;
   const int64_t HH = (int64_t)H * H, ns = net_stride(IN, H, 1);
   const float* W2; float* pf; float* pb;
@@ -187,12 +190,23 @@ __device__ __forceinline__ void tile_arrive(unsigned* ctr) {
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void tile_await(unsigned* ctr, unsigned target, unsigned* timeouts) {
+// A wait that gives up is counted twice: in the workspace slot il_sac_handoff_timeouts() reads, and in [IL_SYNC_TIMEOUTS] when the learner has il_sync counters
+// (what UpdatePlan.sync_timeouts() checks). Neither can happen while the launch is co-resident or dispatched in block order; both must read 0.
+struct TileTimeouts { unsigned* slot; long long* sync; };
+__device__ __forceinline__ TileTimeouts tile_timeouts(const il_sac& d) {
+  const SacWs ws = sac_ws(d.state_dim, d.action_dim, d.hidden, d.batch);
+  return {reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + d.batch / IL_TILE_R + 1, reinterpret_cast<long long*>(d.sync)};
+}
+__device__ __forceinline__ void tile_await(unsigned* ctr, unsigned target, const TileTimeouts& timeouts) {
   if (threadIdx.x == 0) {
     int spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(4);
-      if (++spins > IL_SYNC_SPIN_LIMIT) { __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (++spins > IL_SYNC_SPIN_LIMIT) {
+        __hip_atomic_fetch_add(timeouts.slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (timeouts.sync) __hip_atomic_fetch_add(timeouts.sync + IL_SYNC_TIMEOUTS, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
   }
@@ -202,7 +216,7 @@ __device__ __forceinline__ void tile_await(unsigned* ctr, unsigned target, unsig
 // Forward of one critic-shaped network on one 16-row tile. net 0,1: critic_k(s, a) keeping h1, h2 (and x0 for net 0) for the weight gradients;
 // net 2,3: target_k(s', a'). Leaves H1s / H2s (post-ReLU activations) and q16[r] = Q in LDS. `await` != NULL (target networks inside k_sac_chain):
 // a' of this tile is still being produced by another workgroup of the same launch; everything that does not need it is done first.
-__device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch& b, int net, int tile, float* smem, unsigned* await, unsigned* timeouts) {
+__device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch& b, int net, int tile, float* smem, unsigned* await) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int row0 = tile * IL_TILE_R;
   const bool is_target = net >= 2; const int k = net & 1;
@@ -221,7 +235,7 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
   for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
   if (is_target && await) {
     load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, IL_TILE_R, b.gather, b.gather_capacity);   // s' columns, zero elsewhere
-    tile_await(await, 1u, timeouts);
+    tile_await(await, 1u, tile_timeouts(d));
     for (int i = threadIdx.x; i < IL_TILE_R * A; i += blockDim.x) { const int r = i / A, c = i - r * A; Xs[r * ldx + S + c] = W[ws.n_a2 + (size_t)(row0 + r) * A + c]; }
   } else if (is_target) load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, W + ws.n_a2, A, A, row0, IL_TILE_R, b.gather, b.gather_capacity, true);
   else load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R, b.gather, b.gather_capacity);
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b, const
   globalize(d); globalize(b);
   int net, tile;
   xcd_tile_net((int)blockIdx.x, d.batch / IL_TILE_R, 4, tile, net);
-  critic_fwd_tile(d, b, net, tile, smem, nullptr, nullptr);
+  critic_fwd_tile(d, b, net, tile, smem, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -467,15 +481,14 @@ __global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const 
   chain_decode((int)blockIdx.x, nt, role, net, tile);
   const SacWs ws = sac_ws(d.state_dim, d.action_dim, d.hidden, d.batch);
   unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + tile;
-  unsigned* timeouts = reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + nt + 1;
   if (role == 0) { actor_fwd_tile(d, b, eps_next, eps_cur, false, tile, smem); tile_arrive(ctr); }
-  else if (role == 1) { critic_fwd_tile(d, b, 2 + net, tile, smem, ctr, timeouts); tile_arrive(ctr); }
+  else if (role == 1) { critic_fwd_tile(d, b, 2 + net, tile, smem, ctr); tile_arrive(ctr); }
   else if (role == 2) {
-    critic_fwd_tile(d, b, net, tile, smem, nullptr, nullptr);
+    critic_fwd_tile(d, b, net, tile, smem, nullptr);
     critic_bwd_resident_gemm(d, net, smem);
     if (rl.on) critic_relabel_tile(d, rl, net, tile, smem);
     const RowScalars rs = critic_row_scalars(b, !rl.on && !rewards && !d.sync, tile);
-    tile_await(ctr, 3u, timeouts);
+    tile_await(ctr, 3u, tile_timeouts(d));
     if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 4u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     critic_bwd_resident_scale(d, b, rewards, rl, rs, net, tile, smem);
   } else actor_fwd_tile(d, b, eps_next, eps_cur, true, tile, smem);
@@ -596,7 +609,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
     unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr) + tile;
     if (h == 0 && threadIdx.x == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }   // consumed by the next kernel
     actor_bwd_tile(d, b, tile, out_logp, out_q, smem, part, helpers, [&] {
-      tile_await(ctr, 2u, reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + nt + 1);
+      tile_await(ctr, 2u, tile_timeouts(d));
       if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u + (unsigned)helpers)
         __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // last helper through: ready for the next launch
     });
@@ -1045,6 +1058,14 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
 }
 
 // gather workgroups appended to k_sac_chain by il_sac_update_gather: one 16-byte lane per thread (this is also what the caller writes to [IL_SYNC_GATHER_WGS])
+// in-launch waits of k_sac_chain / k_policy_critic that gave up since the workspace was created (must be 0); synchronous, for tests and post-mortems
+extern "C" int il_sac_handoff_timeouts(const il_sac* d, uint32_t* out_host) {
+  IL_CHECK_ARG(d && d->workspace && out_host, "il_sac_handoff_timeouts: bad arguments");
+  const SacWs ws = sac_ws(d->state_dim, d->action_dim, d->hidden, d->batch);
+  const hipError_t e = hipMemcpy(out_host, reinterpret_cast<const unsigned*>(d->workspace + ws.chain_ctr) + d->batch / IL_TILE_R + 1, sizeof(uint32_t), hipMemcpyDeviceToHost);
+  return e == hipSuccess ? IL_OK : il_set_error(IL_ERR_HIP, "il_sac_handoff_timeouts: %s", hipGetErrorString(e));
+}
+
 extern "C" int32_t il_sac_chain_gather_workgroups(int32_t batch, int32_t row_floats, int32_t hidden) {
   return (int32_t)(((int64_t)batch * (row_floats / 4) + tile_threads(hidden) - 1) / tile_threads(hidden));
 }

@@ -380,7 +380,10 @@ class UpdatePlan:
   def sync_timeouts(self) -> int:
     """Bounded waits that gave up (device counter). Non-zero means the two branches did not run concurrently (e.g. a counter-collecting
     profiler serialises kernels): results of those updates are invalid; `capture()` checks this once and falls back to stream dependencies."""
-    return int(self.sync[4].item())
+    handoff = C.c_uint32(0)
+    if getattr(self, '_prepared', False):   # the in-launch waits of the chained kernels (counted since the first update's k_repack); with il_sync counters they are in sync[4] too
+      _lib.check(_lib.lib().il_sac_handoff_timeouts(C.byref(self.sac), C.byref(handoff)))
+    return max(int(self.sync[4].item()), int(handoff.value))
 
   def prepared_flag(self) -> int:
     return _lib.IL_FLAG_SAC_PREPARED if (self._prepared and os.environ.get('IL_ALWAYS_REPACK') != '1') else 0

@@ -221,6 +221,9 @@ int il_sac_update_gather(const il_sac* d, const il_batch* rows, const il_batch* 
  * workgroup's spare LDS (then relabel with il_gail_reward and pass `rewards`). */
 int32_t il_gail_step_workgroups(const struct il_disc* d); /* AdamW workgroups of il_gail_disc_step = what [IL_SYNC_PARAMS] advances by per step */
 int32_t il_sac_chain_gather_workgroups(int32_t batch, int32_t row_floats, int32_t hidden);
+/* Bounded in-launch waits (tile counters of the chained forward / critic-loss launch and of the policy helpers) that gave up since the last k_repack of this workspace (= the
+ * first update after creation, or any update without IL_FLAG_SAC_PREPARED): must be 0 (they cannot expire while the launch is co-resident or dispatched in block order). Synchronous copy; out_host[0]. */
+int il_sac_handoff_timeouts(const il_sac* d, uint32_t* out_host);
 
 /* training.py:57-64 behavioural_cloning_update + models.py:97-99 SoftActor.log_prob (clamp, atanh). */
 int il_bc_step(float* actor, float* actor_grad, const il_adam* opt, int32_t state_dim, int32_t action_dim, int32_t hidden,
