@@ -891,8 +891,9 @@ def test_update_plan_batch_sizes_of_the_tuned_configs(monkeypatch, B, ring):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('switch', ['IL_RING_GATHER', 'IL_INLINE_RELABEL', 'IL_SAC_CHAIN', 'IL_PC_SPLIT'])
-def test_schedule_switches_are_bit_identical(monkeypatch, switch):
+@pytest.mark.parametrize('switch,B', [('IL_RING_GATHER', 256), ('IL_INLINE_RELABEL', 256), ('IL_SAC_CHAIN', 256), ('IL_PC_SPLIT', 256),
+                                      ('IL_SAC_CHAIN', 80), ('IL_RING_GATHER', 80), ('IL_PC_SPLIT', 48)])   # 80 / 48 rows: 5 / 3 tiles, the non-XCD-aware role decode
+def test_schedule_switches_are_bit_identical(monkeypatch, switch, B):
   """Every schedule of the update (rows through il_batch.gather vs a gather kernel, inline relabel vs k_gail_reward, chained vs separate forward / critic-loss
   launches, helper-split vs second-arriver policy tail) runs the same arithmetic per element: switching one off must not change a bit.
   The C-side switches are read once per process, so they are compared through a subprocess."""
@@ -903,7 +904,7 @@ def test_schedule_switches_are_bit_identical(monkeypatch, switch):
       "from imitation_learning_amd import training as T\n"
       "from test_gpu_parity import _make_plan, N\n"
       "il.seed(31); T._NOISE.clear()\n"
-      "plan, nets = _make_plan('GAIL', 17)\n"
+      f"plan, nets = _make_plan('GAIL', 17, B={B})\n"
       "for _ in range(6): plan.run()\n"
       "torch.cuda.synchronize()\n"
       "assert plan.sync_timeouts() == 0\n"
