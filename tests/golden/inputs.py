@@ -76,6 +76,33 @@ def gail_case(seed, env='halfcheetah', hidden=64, batch=256, steps=3, spectral_n
               spectral_norm=spectral_norm)
 
 
+def gail_deep_case(seed, env, hidden, batch, steps, depth=2, activation='tanh', spectral_norm=True):
+  """GAIL discriminator of any `_create_fcnn` shape: weights / biases / u / v per layer (hidden layers then the H -> 1 output), policy + expert batches,
+  the U(0,1) draws of the gradient penalty and of Mixup, and log pi offsets for subtract_log_policy."""
+  S, A = DIMS[env]
+  D = S + A
+  rs = np.random.RandomState(seed)
+  dims = [D] + [hidden] * depth + [1]
+  unit = lambda x: (x / np.linalg.norm(x)).astype(f32)
+  W = [(rs.standard_normal((dims[i + 1], dims[i])) * np.sqrt((2.0 if i < depth else 1.0) / dims[i])).astype(f32) for i in range(depth + 1)]
+  b = [(rs.standard_normal(dims[i + 1]) * 0.05).astype(f32) for i in range(depth + 1)]
+  u = [unit(rs.standard_normal(dims[i + 1])) for i in range(depth + 1)]
+  v = [unit(rs.standard_normal(dims[i])) for i in range(depth + 1)]
+  pol = [transitions(rs, batch, S, A, weighted=True) for _ in range(steps)]
+  exp = [transitions(rs, batch, S, A, state_shift=0.5, weighted=True) for _ in range(steps)]
+  eps = [rs.uniform(size=batch).astype(f32) for _ in range(steps)]
+  eps_mix = [rs.uniform(size=batch).astype(f32) for _ in range(steps)]
+  return dict(S=S, A=A, D=D, H=hidden, B=batch, depth=depth, activation=activation, spectral_norm=spectral_norm, W=W, b=b, u=u, v=v, policy=pol, expert=exp, eps=eps, eps_mix=eps_mix)
+
+
+GAIL_DEEP_CASES = (   # name, gail_deep_case arguments, loss_function, (lr, weight decay, grad_penalty, entropy_bonus), reward_function
+    ('hopper_d2_tanh_sn', dict(seed=101, env='hopper', hidden=32, batch=96, steps=2, depth=2, activation='tanh', spectral_norm=True), 'BCE', (1e-3, 0.1, 0.6, 0.02), 'AIRL'),
+    ('halfcheetah_d2_relu', dict(seed=102, env='halfcheetah', hidden=64, batch=64, steps=2, depth=2, activation='relu', spectral_norm=False), 'PUGAIL', (5e-4, 1.0, 1.0, 0.0), 'GAIL'),
+    ('walker2d_d1_tanh_sn', dict(seed=103, env='walker2d', hidden=64, batch=80, steps=2, depth=1, activation='tanh', spectral_norm=True), 'Mixup', (1e-3, 0.0, 0.3, 0.05), 'FAIRL'),
+    ('hopper_d2_relu_sn', dict(seed=104, env='hopper', hidden=32, batch=64, steps=2, depth=2, activation='relu', spectral_norm=True), 'BCE', (1e-3, 0.1, 1.0, 0.0), 'AIRL'),
+)
+
+
 def gmmil_case(seed, B1, B2, D, weighted=True):
   rs = np.random.RandomState(seed)
   X = rs.standard_normal((B1, D)).astype(f32)

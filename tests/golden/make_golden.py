@@ -258,6 +258,50 @@ def gen_gail_variants():
   np.savez_compressed(os.path.join(HERE, 'gail_variants.npz'), **out)
 
 
+def gen_gail_deep():
+  """GAILDiscriminator with depth 1-2 / relu / tanh (models.py:152-162, no reward shaping) under adversarial_imitation_update: gradients, parameters after
+  AdamW, u / v buffers, rewards. The gradient-penalty and Mixup draws are fed like the other noise."""
+  out = {}
+  for name, kw, loss, (lr, wd, gp, ent), rf in gi.GAIL_DEEP_CASES:
+    c = gi.gail_deep_case(**kw)
+    icfg = DictConfig(state_only=False, spectral_norm=c['spectral_norm'], loss_function=loss, grad_penalty=gp, mixup_alpha=0.7, entropy_bonus=ent, pos_class_prior=0.7,
+                      nonnegative_margin=float('inf'),
+                      discriminator=DictConfig(hidden_size=c['H'], depth=c['depth'], activation=c['activation'], reward_shaping=False, subtract_log_policy=False, reward_function=rf))
+    d = ref_models.GAILDiscriminator(c['S'], c['A'], icfg, 0.97)
+    lin = [2 * l for l in range(c['depth'] + 1)]
+    with torch.no_grad():
+      for l, li in enumerate(lin):
+        if c['spectral_norm']:
+          d.g[li].parametrizations.weight.original.copy_(T(c['W'][l])); d.g[li].bias.copy_(T(c['b'][l]))
+          d.g[li].parametrizations.weight[0]._u.copy_(T(c['u'][l])); d.g[li].parametrizations.weight[0]._v.copy_(T(c['v'][l]))
+        else:
+          d.g[li].weight.copy_(T(c['W'][l])); d.g[li].bias.copy_(T(c['b'][l]))
+    out[f'{name}.param_names'] = np.array([n for n, _ in d.named_parameters()])
+    opt = torch.optim.AdamW(d.parameters(), lr=lr, weight_decay=wd)
+    for i in range(len(c['policy'])):
+      d.train()
+      feed = [T(c['eps_mix'][i])]
+      orig = torch.distributions.Beta.sample
+      torch.distributions.Beta.sample = lambda self, *a, **k: feed.pop(0)
+      try:
+        with NoiseFeed() as nf:
+          nf.rand.append(T(c['eps'][i]))
+          ref_training.adversarial_imitation_update(None, d, tbatch(c['policy'][i]), tbatch(c['expert'][i]), opt, icfg)
+      finally:
+        torch.distributions.Beta.sample = orig
+      d.eval()
+      k = i + 1
+      out[f'{name}.g_{k}'] = np.concatenate([N_(p.grad).ravel() for p in d.parameters()])
+      out[f'{name}.p_{k}'] = flat(d)
+      if c['spectral_norm']:
+        out[f'{name}.sn_{k}'] = np.concatenate([np.concatenate([N_(d.g[li].parametrizations.weight[0]._u), N_(d.g[li].parametrizations.weight[0]._v)]) for li in lin])
+      b = c['policy'][i]
+      with torch.inference_mode():
+        out[f'{name}.reward_{k}'] = N_(d.predict_reward(T(b['states']), T(b['actions'])))
+    out[f'{name}.exp_avg'] = opt_state(opt, 'exp_avg')
+  np.savez_compressed(os.path.join(HERE, 'gail_deep.npz'), **out)
+
+
 def gen_gail_shaped():
   """GAILDiscriminator with reward_shaping (models.py:152-180) under adversarial_imitation_update: gradients, parameters, u / v buffers, rewards."""
   out = {}
@@ -465,6 +509,7 @@ if __name__ == '__main__':
     gen_gail('gail_nosn_nogp', gi.gail_case(33, env='hopper', hidden=32, batch=128, spectral_norm=False), lr=3e-4, weight_decay=0.0, grad_penalty=0.0, entropy_bonus=0.0)
   if want('gail_variants'): gen_gail_variants()
   if want('gail_shaped'): gen_gail_shaped()
+  if want('gail_deep'): gen_gail_deep()
   if want('gmmil'): gen_gmmil()
   if want('pwil'): gen_pwil()
   if want('adril'): gen_adril()

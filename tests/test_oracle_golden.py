@@ -273,3 +273,34 @@ def test_gail_shaped_oracle_matches_reference_fixture(golden_dir, name, sn, loss
       for k in ('ug', 'vg', 'u1', 'v1', 'u2', 'v2'):
         np.testing.assert_allclose(getattr(ds, k), g[f'{name}.{k}_{i + 1}'], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(ogs.predict_reward(ds, c['policy'][i]), g[f'{name}.reward_{i + 1}'], rtol=5e-5, atol=2e-6)
+
+def _deep_state(c):
+  from oracle import gail_deep as ogd
+  ds = ogd.DeepDiscState(c['D'], c['H'], c['depth'], c['activation'], c['spectral_norm'])
+  for l in range(c['depth'] + 1):
+    ds.W[l][...] = c['W'][l]; ds.b[l][...] = c['b'][l]; ds.u[l][...] = c['u'][l]; ds.v[l][...] = c['v'][l]
+  return ds
+
+
+@pytest.mark.parametrize('name', [n for n, *_ in gi.GAIL_DEEP_CASES])
+def test_gail_deep_oracle_matches_reference_fixture(golden_dir, name):
+  """oracle/gail_deep.py (depth 1-2, relu / tanh discriminators: closed-form backward incl. the double backward of the gradient penalty) against
+  adversarial_imitation_update + predict_reward of the reference."""
+  from oracle import gail_deep as ogd
+  g = np.load(os.path.join(golden_dir, 'gail_deep.npz'))
+  _, kw, loss, (lr, wd, gp, ent), rf = next(c for c in gi.GAIL_DEEP_CASES if c[0] == name)
+  c = gi.gail_deep_case(**kw)
+  ds = _deep_state(c)
+  cat = lambda b: np.concatenate([b['states'], b['actions']], 1)
+  for i in range(len(c['policy'])):
+    pb, eb = c['policy'][i], c['expert'][i]
+    ds.unpack_into(g[f'{name}.p_{i}']) if i else None            # start every step from the reference's parameters (isolates the step)
+    if i and c['spectral_norm']: ds.unpack_sn(g[f'{name}.sn_{i}'])
+    grad = ogd.gail_update(ds, cat(pb), pb['weights'], cat(eb), eb['weights'], c['eps'][i], lr=lr, weight_decay=wd, grad_penalty=gp, entropy_bonus=ent, return_grads=True,
+                           loss_function=loss, eps_mix=c['eps_mix'][i])
+    ref = g[f'{name}.g_{i + 1}']
+    np.testing.assert_allclose(grad, ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max())
+    if c['spectral_norm']:
+      np.testing.assert_allclose(ds.pack_sn(), g[f'{name}.sn_{i + 1}'], rtol=1e-4, atol=1e-6)
+    ds.unpack_into(g[f'{name}.p_{i + 1}'])
+    np.testing.assert_allclose(ogd.predict_reward(ds, cat(pb), rf), g[f'{name}.reward_{i + 1}'], rtol=1e-4, atol=1e-5)
