@@ -331,6 +331,8 @@ class GAILDiscriminator(_FlatModule):
   def __new__(cls, state_size=None, action_size=None, imitation_cfg=None, discount=None, device=None):
     if cls is GAILDiscriminator and imitation_cfg is not None and imitation_cfg.discriminator.reward_shaping:
       return super().__new__(ShapedGAILDiscriminator)   # f = g(s, a) + (1 - t)(discount h(s') - h(s)): its own kernels (gail_shaped.hip)
+    if cls is GAILDiscriminator and imitation_cfg is not None and (imitation_cfg.discriminator.depth, imitation_cfg.discriminator.activation) != (1, 'relu'):
+      return super().__new__(DeepGAILDiscriminator)     # depth 2 and / or tanh: the general kernels (gail_deep.hip)
     return super().__new__(cls)
 
   def __init__(self, state_size: int, action_size: int, imitation_cfg, discount: float, device=None):
@@ -429,6 +431,63 @@ class ShapedGAILDiscriminator(GAILDiscriminator):
   def forward(self, state: Tensor, action: Tensor, next_state=None, terminal=None, log_policy=None) -> Tensor:
     from .training import shaped_predict_reward
     return shaped_predict_reward(self, state, action, next_state, terminal, log_policy=log_policy, want_logits=True)[1]
+
+
+class DeepGAILDiscriminator(GAILDiscriminator):
+  """GAIL discriminator of any `_create_fcnn` shape without reward shaping (reference models.py:152-162): depth 1-2, relu / tanh, every Linear optionally
+  under spectral norm.  Created through `GAILDiscriminator(...)` for configurations other than depth 1 / relu (which keep the fast path).  Flat arena =
+  parameters() order, `self.sn` = per layer [u | v]; same module order, state_dict keys and RNG consumption at construction as the reference."""
+
+  def __init__(self, state_size: int, action_size: int, imitation_cfg, discount: float, device=None):
+    nn.Module.__init__(self)
+    model_cfg = imitation_cfg.discriminator
+    self.discount, self.state_only = discount, bool(imitation_cfg.state_only)
+    self.reward_shaping, self.subtract_log_policy, self.reward_function = False, model_cfg.subtract_log_policy, model_cfg.reward_function
+    self.spectral_norm = bool(imitation_cfg.spectral_norm)
+    self.depth, self.activation = int(model_cfg.depth), str(model_cfg.activation)
+    self.state_size, self.action_size, self.hidden = state_size, action_size, int(model_cfg.hidden_size)
+    self.in_dim = state_size if self.state_only else state_size + action_size
+    if self.depth not in (1, 2) or self.activation not in ('relu', 'tanh') or self.hidden > 128 or self.in_dim > 128:
+      raise NotImplementedError(f'GAILDiscriminator: the HIP path implements depth 1-2 with relu / tanh, hidden_size <= 128, input <= 128 '
+                                f'(got depth={self.depth}, activation={self.activation}, hidden_size={self.hidden}); no torch fallback')
+    sn = parametrizations.spectral_norm if self.spectral_norm else (lambda layer: layer)
+    act = nn.ReLU if self.activation == 'relu' else nn.Tanh
+    dims, layers = [self.in_dim] + [self.hidden] * self.depth, []
+    for a, b in zip(dims[:-1], dims[1:]):   # models.py:49-70 `_create_fcnn`
+      lin = nn.Linear(a, b)
+      nn.init.orthogonal_(lin.weight, gain=nn.init.calculate_gain(self.activation)); nn.init.constant_(lin.bias, 0)
+      layers += [sn(lin), act()]
+    last = nn.Linear(self.hidden, 1)
+    nn.init.orthogonal_(last.weight, gain=1.0); nn.init.constant_(last.bias, 0)
+    self.g = nn.Sequential(*layers, sn(last))
+    offs, o = [], 0
+    for p in self.parameters():
+      offs.append(o); o += p.numel()
+    assert o == int(_lib.lib().il_disc_deep_numel(self.in_dim, self.hidden, self.depth))
+    dev = device or default_device()
+    self._adopt(o, offs, dev)
+    self.sn = torch.zeros(int(_lib.lib().il_disc_deep_sn_numel(self.in_dim, self.hidden, self.depth)), device=dev)
+    self._sn_slices, o = [], 0
+    for l in range(self.depth + 1):
+      n_out, n_in = (1 if l == self.depth else self.hidden), (self.in_dim if l == 0 else self.hidden)
+      self._sn_slices.append(((o, n_out), (o + n_out, n_in))); o += n_out + n_in
+    if self.spectral_norm:
+      with torch.no_grad():
+        for l, ((ou, nu), (ov, nv)) in enumerate(self._sn_slices):
+          mod = self.g[2 * l].parametrizations.weight[0]
+          u, v = self.sn[ou:ou + nu], self.sn[ov:ov + nv]
+          u.copy_(mod._u); v.copy_(mod._v)
+          mod._buffers['_u'], mod._buffers['_v'] = u, v
+    self.eval()
+
+  def predict_reward(self, state: Tensor, action: Tensor, next_state=None, terminal=None, log_policy=None) -> Tensor:
+    from .training import deep_predict_reward
+    assert (log_policy is not None) == bool(self.subtract_log_policy)
+    return deep_predict_reward(self, state, action, log_policy=log_policy)
+
+  def forward(self, state: Tensor, action: Tensor, next_state=None, terminal=None, log_policy=None) -> Tensor:
+    from .training import deep_predict_reward
+    return deep_predict_reward(self, state, action, log_policy=log_policy, want_logits=True)[1]
 
 
 class GMMILDiscriminator(nn.Module):

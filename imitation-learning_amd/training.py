@@ -170,6 +170,45 @@ def shaped_descriptor(disc, batch_size: int, opt, imitation_cfg=None) -> _lib.Di
   return d
 
 
+def deep_descriptor(disc, batch_size: int, opt, imitation_cfg=None) -> _lib.DiscDeep:
+  """il_disc_deep for a DeepGAILDiscriminator (depth 1-2, relu / tanh; gail_deep.hip)."""
+  dev = disc.flat.device
+  loss_function, prior, grad_penalty, entropy_bonus = 'BCE', 0.0, 0.0, 0.0
+  if imitation_cfg is not None:
+    loss_function, prior = imitation_cfg.loss_function, float(_cfg_value(imitation_cfg, 'pos_class_prior', 0.0) or 0.0)
+    if loss_function not in LOSS_FUNCTIONS:
+      raise ValueError(f'adversarial_imitation_update: unknown loss_function={loss_function}')
+    if loss_function == 'PUGAIL' and float(_cfg_value(imitation_cfg, 'nonnegative_margin', float('inf'))) != float('inf'):
+      raise NotImplementedError('adversarial_imitation_update: PUGAIL with a finite nonnegative_margin has no kernel; the default inf does')
+    grad_penalty, entropy_bonus = float(imitation_cfg.grad_penalty), float(imitation_cfg.entropy_bonus)
+  L = _lib.lib()
+  ws = _workspace('disc_deep', int(L.il_disc_deep_workspace_floats(disc.in_dim, disc.hidden, disc.depth, batch_size)), dev)
+  d = _lib.DiscDeep()
+  d.state_dim, d.action_dim, d.hidden, d.batch = disc.state_size, disc.action_size, disc.hidden, batch_size
+  d.spectral_norm, d.state_only, d.reward_function, d.loss_function = int(disc.spectral_norm), int(disc.state_only), REWARD_FUNCTIONS[disc.reward_function], LOSS_FUNCTIONS[loss_function]
+  d.depth, d.activation = disc.depth, int(disc.activation == 'tanh')
+  d.params, d.sn = disc.flat.data_ptr(), disc.sn.data_ptr()
+  if opt is not None:
+    d.grad, d.opt = opt.grad.data_ptr(), opt.desc()
+  d.grad_penalty, d.entropy_bonus, d.pos_class_prior = grad_penalty, entropy_bonus, prior
+  d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
+  d.noise_seed, d.noise_counter = _noise_seed() & (2**64 - 1), _noise_counter(dev, 'disc_deep').data_ptr()
+  return d
+
+
+def deep_predict_reward(disc, state: Tensor, action: Tensor, log_policy: Optional[Tensor] = None, want_logits: bool = False):
+  dev = disc.flat.device
+  state, action = _f32(state, dev), _f32(action, dev)
+  n = state.size(0)
+  d = deep_descriptor(disc, n, None)
+  dummy = torch.zeros(n, device=dev)
+  b = batch_desc(dict(states=state, actions=action, rewards=dummy, next_states=state, terminals=dummy, weights=dummy, absorbing=dummy))
+  out, logits = torch.empty(n, device=dev), (torch.empty(n, device=dev) if want_logits else None)
+  off = _f32(log_policy, dev)
+  _lib.check(_lib.lib().il_gail_deep_reward(C.byref(d), C.byref(b), _lib.ptr(out), _lib.ptr(logits), _lib.ptr(off), _lib.stream_ptr()))
+  return (out, logits) if want_logits else out
+
+
 def _shaped_batch(state, action, next_state, terminal, weight=None):
   w = weight if weight is not None else terminal
   return batch_desc(dict(states=state, actions=action, rewards=w, next_states=next_state, terminals=terminal, weights=w, absorbing=w))
@@ -202,7 +241,8 @@ def adversarial_imitation_update(actor, discriminator: GAILDiscriminator, transi
       x.logit_offset_policy, x.logit_offset_expert = keep[-2].data_ptr(), keep[-1].data_ptr()
     _lib.check(_lib.lib().il_gail_shaped_step(C.byref(d), C.byref(pb), C.byref(eb), _lib.ptr(e), C.byref(x), 0, _lib.stream_ptr()))
     return
-  d = disc_descriptor(discriminator, B, discriminator_optimiser, imitation_cfg)
+  deep = type(discriminator).__name__ == 'DeepGAILDiscriminator'   # depth 2 and / or tanh: the general kernels, same arguments
+  d = (deep_descriptor if deep else disc_descriptor)(discriminator, B, discriminator_optimiser, imitation_cfg)
   if imitation_cfg.loss_function == 'Mixup':
     if discriminator.subtract_log_policy:
       raise NotImplementedError('adversarial_imitation_update: Mixup with subtract_log_policy (log pi of the mixed inputs) has no kernel')
@@ -214,7 +254,8 @@ def adversarial_imitation_update(actor, discriminator: GAILDiscriminator, transi
   if discriminator.subtract_log_policy:   # models.py:144: log pi(a|s) of both batches, no graph
     keep += [actor.log_prob(transitions['states'], transitions['actions']), actor.log_prob(expert_transitions['states'], expert_transitions['actions'])]
     x.logit_offset_policy, x.logit_offset_expert = keep[-2].data_ptr(), keep[-1].data_ptr()
-  _lib.check(_lib.lib().il_gail_disc_step(C.byref(d), C.byref(pb), C.byref(eb), _lib.ptr(e), C.byref(x), 0, _lib.stream_ptr()))
+  step = _lib.lib().il_gail_deep_step if deep else _lib.lib().il_gail_disc_step
+  _lib.check(step(C.byref(d), C.byref(pb), C.byref(eb), _lib.ptr(e), C.byref(x), 0, _lib.stream_ptr()))
 
 
 def gail_predict_reward(disc: GAILDiscriminator, state: Tensor, action: Tensor, want_logits: bool = False, log_policy: Optional[Tensor] = None):
@@ -308,9 +349,10 @@ class UpdatePlan:
       self.erows = torch.empty(batch_size, expert_memory.row, device=dev); self.eidx = torch.empty(batch_size, dtype=torch.int32, device=dev)
       self.expert_transitions = batch_views(self.erows, expert_memory.state_size, expert_memory.action_size, expert_memory.absorbing)
       host_mixup = imitation_cfg is not None and imitation_cfg.loss_function == 'Mixup' and float(_cfg_value(imitation_cfg, 'mixup_alpha', 1.0)) != 1.0
-      if imitation_cfg is not None and (host_mixup or discriminator.subtract_log_policy or getattr(discriminator, 'reward_shaping', False)):
+      deep = type(discriminator).__name__ == 'DeepGAILDiscriminator'   # depth 2 / tanh: the general kernels, per-function path
+      if imitation_cfg is not None and (host_mixup or deep or discriminator.subtract_log_policy or getattr(discriminator, 'reward_shaping', False)):
         # Mixup with alpha = 1 draws its Beta(1, 1) = U(0, 1) coefficients from the on-chip Philox stream like the gradient penalty does: capturable
-        raise NotImplementedError('UpdatePlan: GAIL with Mixup (alpha != 1: Beta draws on the host) / subtract_log_policy / reward shaping runs through '
+        raise NotImplementedError('UpdatePlan: GAIL with Mixup (alpha != 1: Beta draws on the host) / subtract_log_policy / reward shaping / a depth-2 or tanh discriminator runs through '
                                   'adversarial_imitation_update + sac_update')
       self.disc = disc_descriptor(discriminator, batch_size, discriminator_optimiser, imitation_cfg, tag=tag, seed_offset=off)
       self.eb = batch_desc(self.expert_transitions)

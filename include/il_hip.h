@@ -337,6 +337,35 @@ int il_gail_shaped_reward(const il_disc_shaped* d, const il_batch* batch, float*
                           il_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * GAIL discriminator of any `_create_fcnn` shape without reward shaping (models.py:152-162): depth 1-2, relu / tanh
+ * (conf/hyperparameter_search_space/GAIL.yaml). il_disc / gail.hip is the fast path of the depth-1 ReLU shape every shipped configuration uses.
+ * params in `discriminator.parameters()` order: per Linear (bias, weight) with spectral norm, (weight, bias) without; layers: hidden x depth, then H -> 1.
+ * sn: the spectral-norm buffers, per layer [u (out) | v (in)] in layer order (il_disc_deep_sn_numel floats).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct il_disc_deep {
+  int32_t state_dim, action_dim, hidden, batch;
+  int32_t spectral_norm, state_only, reward_function, loss_function;   /* as in il_disc */
+  int32_t depth;        /* hidden layers: 1 or 2 (0 = 1) */
+  int32_t activation;   /* 0 relu, 1 tanh */
+  float* params;
+  float* sn;
+  float* grad;          /* [P] summed gradient of the last step (always written) */
+  il_adam opt;
+  float grad_penalty, entropy_bonus, pos_class_prior, reserved;
+  float* workspace;     /* >= il_disc_deep_workspace_floats() */
+  int64_t workspace_floats;
+  uint64_t noise_seed;
+  uint32_t* noise_counter;
+} il_disc_deep;
+int64_t il_disc_deep_numel(int32_t in_dim, int32_t hidden, int32_t depth);
+int64_t il_disc_deep_sn_numel(int32_t in_dim, int32_t hidden, int32_t depth);
+int64_t il_disc_deep_workspace_floats(int32_t in_dim, int32_t hidden, int32_t depth, int32_t batch);
+/* adversarial_imitation_update (training.py:85-134) / predict_reward (models.py:177-180); arguments as il_gail_disc_step / il_gail_reward */
+int il_gail_deep_step(const il_disc_deep* d, const il_batch* policy, const il_batch* expert, const float* eps_gp, const il_gail_extra* extra, uint32_t flags,
+                      il_stream_t stream);
+int il_gail_deep_reward(const il_disc_deep* d, const il_batch* batch, float* out_rewards, float* out_logits, const float* logit_offset, il_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * GMMIL (reference models.py:25-44, 183-201): d(x,y) = mean_k (x_k-y_k)^2, two RBF bandwidths.
  * ------------------------------------------------------------------------------------------ */
 int64_t il_gmmil_workspace_floats(int32_t n_policy, int32_t n_expert, int32_t dim);
@@ -428,7 +457,7 @@ int il_dril_uncertainty(const il_dril* d, const il_batch* batch, const float* ma
                         float* out_uncertainty, float* out_reward, il_stream_t stream);
 
 /* sizeof() of the descriptor structs in this build (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red,
- * 7 il_dril, 8 il_disc_shaped; -1 otherwise): lets a binding verify its own struct definitions. */
+ * 7 il_dril, 8 il_disc_shaped, 9 il_disc_deep; -1 otherwise): lets a binding verify its own struct definitions. */
 int32_t il_struct_size(int32_t which);
 
 #ifdef __cplusplus

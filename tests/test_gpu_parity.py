@@ -939,6 +939,45 @@ def test_batch_gather_is_rejected_where_it_is_not_honoured():
 
 
 # ---------------------------------------------------------------------------------------------
+# GAIL discriminators of depth 1-2 with relu / tanh (gail_deep.hip) against the reference fixture and the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', [n for n, *_ in gi.GAIL_DEEP_CASES])
+def test_gail_deep_discriminator_matches_reference(golden_dir, name):
+  from oracle import gail_deep as ogd
+  g = load(golden_dir, 'gail_deep')
+  _, kw, loss, (lr, wd, gp, ent), rf = next(c for c in gi.GAIL_DEEP_CASES if c[0] == name)
+  c = gi.gail_deep_case(**kw)
+  icfg = Cfg(state_only=False, spectral_norm=c['spectral_norm'], loss_function=loss, grad_penalty=gp, mixup_alpha=0.7, entropy_bonus=ent, pos_class_prior=0.7, nonnegative_margin=float('inf'),
+             discriminator=Cfg(hidden_size=c['H'], depth=c['depth'], activation=c['activation'], reward_shaping=False, subtract_log_policy=False, reward_function=rf))
+  d = il.GAILDiscriminator(c['S'], c['A'], icfg, 0.97, device=DEV)
+  assert type(d).__name__ == 'DeepGAILDiscriminator' and list(d.state_dict())[:2] == [str(x) for x in g[f'{name}.param_names'][:2]]
+  ds = ogd.DeepDiscState(c['D'], c['H'], c['depth'], c['activation'], c['spectral_norm'])
+  for l in range(c['depth'] + 1):
+    ds.W[l][...] = c['W'][l]; ds.b[l][...] = c['b'][l]; ds.u[l][...] = c['u'][l]; ds.v[l][...] = c['v'][l]
+  d.flat.copy_(T(ds.pack()))
+  if c['spectral_norm']: d.sn.copy_(T(ds.pack_sn()))
+  opt = il.AdamW(d, lr=lr, weight_decay=wd)
+  cat = lambda b: np.concatenate([b['states'], b['actions']], 1)
+  for i in range(len(c['policy'])):
+    pb, eb = c['policy'][i], c['expert'][i]
+    if i:   # every step starts from the reference's state (isolates the step from Adam-amplified differences)
+      d.flat.copy_(T(g[f'{name}.p_{i}'])); ds.unpack_into(g[f'{name}.p_{i}'])
+      if c['spectral_norm']: d.sn.copy_(T(g[f'{name}.sn_{i}'])); ds.unpack_sn(g[f'{name}.sn_{i}'])
+    il.adversarial_imitation_update(None, d, tbatch(pb), tbatch(eb), opt, icfg, eps_gp=T(c['eps'][i]), eps_mix=T(c['eps_mix'][i]))
+    ogr = ogd.gail_update(ds, cat(pb), pb['weights'], cat(eb), eb['weights'], c['eps'][i], lr=lr, weight_decay=wd, grad_penalty=gp, entropy_bonus=ent, return_grads=True,
+                          loss_function=loss, eps_mix=c['eps_mix'][i])
+    close(N(opt.grad), g[f'{name}.g_{i + 1}'], f'{name} gradient {i + 1} (reference)', rtol=2e-5, atol_scale=1e-5)
+    close(N(opt.grad), ogr, f'{name} gradient {i + 1} (oracle)', rtol=2e-5, atol_scale=1e-5)
+    if c['spectral_norm']:
+      close(N(d.sn), g[f'{name}.sn_{i + 1}'], f'{name} u / v after update {i + 1}', rtol=2e-5, atol_scale=1e-5)
+    d.flat.copy_(T(g[f'{name}.p_{i + 1}']))
+    r = d.predict_reward(T(pb['states']), T(pb['actions']))
+    close(N(r), g[f'{name}.reward_{i + 1}'], f'{name} reward {i + 1}', rtol=5e-5, atol_scale=1e-5)
+  assert int(opt.step_count[0]) == len(c['policy'])
+
+
+# ---------------------------------------------------------------------------------------------
 # GAIL with reward shaping (models.py:152-180, reward_shaping=True) against the reference fixture and the oracle
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu

@@ -22,6 +22,8 @@ COMMON = ['steps=260', 'training.start=120', 'evaluation.interval=130', 'evaluat
     ['algorithm=AdRIL', 'env=hopper', 'imitation.update_freq=100'],
     ['algorithm=AdRIL', 'env=walker2d', 'imitation.update_freq=0', 'imitation.balanced=false'],   # SQIL
     ['algorithm=GAIL', 'env=hopper', 'imitation.loss_function=PUGAIL'],
+    ['algorithm=GAIL', 'env=hopper', 'imitation.discriminator.depth=2', 'imitation.discriminator.activation=tanh'],   # general discriminator kernels (gail_deep.hip)
+    ['algorithm=GAIL', 'env=walker2d', 'imitation.discriminator.depth=2', 'imitation.loss_function=Mixup', 'imitation.spectral_norm=false'],
     ['algorithm=GAIL', 'env=walker2d', 'imitation.loss_function=Mixup', 'imitation.discriminator.reward_function=FAIRL'],
     ['algorithm=GAIL', 'env=hopper', 'imitation.loss_function=Mixup', 'imitation.entropy_bonus=0.24', 'imitation.grad_penalty=0.28', 'imitation.weight_decay=8.5'],   # GAIL_5_trajectories.yaml's shape: fused plan
     ['algorithm=GAIL', 'env=hopper', 'imitation.loss_function=Mixup', 'imitation.mixup_alpha=0.5'],   # Beta(0.5, 0.5) drawn on the host: per-function path
@@ -57,7 +59,9 @@ def test_train_runs(tmp_path, args):
     assert all(np.isfinite(q).all() for q in metrics['Q_values'])
   if cfg.algorithm == 'GAIL':
     disc = torch.load(tmp_path / 'discriminator.pth', weights_only=False)
-    if cfg.imitation.discriminator.reward_shaping:
+    if (cfg.imitation.discriminator.depth, cfg.imitation.discriminator.activation) != (1, 'relu'):
+      assert ('g.4.parametrizations.weight.original' if cfg.imitation.spectral_norm else 'g.4.weight') in disc
+    elif cfg.imitation.discriminator.reward_shaping:
       assert 'g.parametrizations.weight.original' in disc and 'h.0.parametrizations.weight.original' in disc and 'h.2.parametrizations.weight.0._v' in disc
     else:
       assert 'g.0.parametrizations.weight.original' in disc and 'g.2.parametrizations.weight.0._v' in disc
@@ -68,7 +72,8 @@ def test_unsupported_configurations_fail_loudly():
   sys.path.insert(0, ROOT)
   import train
   from imitation_learning_amd import config
-  for extra in (['algorithm=GAIL', 'imitation.discriminator.depth=2'], ['algorithm=SAC', 'reinforcement.actor.depth=3'],
+  for extra in (['algorithm=GAIL', 'imitation.discriminator.depth=3'], ['algorithm=GAIL', 'imitation.discriminator.hidden_size=256', 'imitation.discriminator.activation=tanh'],
+                ['algorithm=SAC', 'reinforcement.actor.depth=3'],
                 ['algorithm=RED', 'imitation.discriminator.depth=3'], ['algorithm=RED', 'imitation.discriminator.activation=sigmoid']):
     with pytest.raises(NotImplementedError):
       train.train(config.compose(extra + ['env=hopper', 'steps=10'] + COMMON[5:7]))

@@ -119,7 +119,7 @@ def train(cfg, file_prefix: str = '') -> float:
   plan = None
   fusable = cfg.algorithm in ('SAC', 'GAIL') and cfg.imitation.mix_expert_data == 'none' and not cfg.imitation.bc_aux_loss and B % 16 == 0
   if cfg.algorithm == 'GAIL' and ((cfg.imitation.loss_function == 'Mixup' and float(cfg.imitation.mixup_alpha) != 1.0) or cfg.imitation.discriminator.subtract_log_policy
-                                  or cfg.imitation.discriminator.reward_shaping):
+                                  or cfg.imitation.discriminator.reward_shaping or (cfg.imitation.discriminator.depth, cfg.imitation.discriminator.activation) != (1, 'relu')):
     fusable = False   # per-update host inputs (Beta(alpha != 1) draws) / an extra actor pass: the per-function entry points
   if fusable:
     plan = il.UpdatePlan(cfg.algorithm, actor, critic, log_alpha, target_critic, memory, actor_optimiser, critic_optimiser, temperature_optimiser, B, cfg.reinforcement.discount,
