@@ -138,6 +138,7 @@ _SIGNATURES = {
     'il_gail_disc_step': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), C.POINTER(Batch), _P, C.POINTER(GailExtra), C.c_uint32, _P]),
     'il_disc_deep_numel': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     'il_disc_deep_sn_numel': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    'il_disc_deep_lds_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     'il_disc_deep_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'il_gail_deep_step': (C.c_int, [C.POINTER(DiscDeep), C.POINTER(Batch), C.POINTER(Batch), _P, C.POINTER(GailExtra), C.c_uint32, _P]),
     'il_gail_deep_reward': (C.c_int, [C.POINTER(DiscDeep), C.POINTER(Batch), _P, _P, _P, _P]),

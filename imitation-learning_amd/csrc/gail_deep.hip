@@ -49,10 +49,11 @@ __host__ __device__ inline size_t gd_lds_floats(int D, int H, int depth) {
   size_t n = 0;
   for (int i = 0; i <= depth; ++i) { const int out = i == depth ? 1 : H, in = i == 0 ? D : H; n += (size_t)out * (in + 1) + out + out + in; }
   n += (size_t)(D > H ? D : H) + 8;                                                        // tmp, sc
-  n += (size_t)GD_R * (D + 1) + (size_t)(2 * depth + 2 * depth + 1) * GD_R * (H + 1);       // X, A, Z / U (ping-pong pairs), S1
+  n += (size_t)GD_R * (D + 1) + (size_t)(3 * depth + 1) * GD_R * (H + 1);                   // X; A, Z, U per hidden layer; S1
   n += (size_t)GD_R * ((D > H ? D : H) + 1) + 8 * GD_R + 64;                                // SB, row, red
   return n;
 }
+extern "C" int64_t il_disc_deep_lds_bytes(int32_t D, int32_t H, int32_t depth) { return (int64_t)(gd_lds_floats(D, H, depth == 2 ? 2 : 1) * sizeof(float)); }
 __device__ __forceinline__ GdLds gd_carve(float* p, int D, int H, int depth) {
   GdLds l; l.ldx = D + 1; l.ldh = H + 1;
   for (int i = 0; i < 3; ++i) {

@@ -450,6 +450,9 @@ class DeepGAILDiscriminator(GAILDiscriminator):
     if self.depth not in (1, 2) or self.activation not in ('relu', 'tanh') or self.hidden > 128 or self.in_dim > 128:
       raise NotImplementedError(f'GAILDiscriminator: the HIP path implements depth 1-2 with relu / tanh, hidden_size <= 128, input <= 128 '
                                 f'(got depth={self.depth}, activation={self.activation}, hidden_size={self.hidden}); no torch fallback')
+    lds = int(_lib.lib().il_disc_deep_lds_bytes(self.in_dim, self.hidden, self.depth))
+    if lds > 160 * 1024:
+      raise NotImplementedError(f'GAILDiscriminator: input {self.in_dim} x hidden {self.hidden} x depth {self.depth} needs {lds} bytes of LDS per workgroup (> 160 KiB)')
     sn = parametrizations.spectral_norm if self.spectral_norm else (lambda layer: layer)
     act = nn.ReLU if self.activation == 'relu' else nn.Tanh
     dims, layers = [self.in_dim] + [self.hidden] * self.depth, []

@@ -360,6 +360,7 @@ typedef struct il_disc_deep {
 int64_t il_disc_deep_numel(int32_t in_dim, int32_t hidden, int32_t depth);
 int64_t il_disc_deep_sn_numel(int32_t in_dim, int32_t hidden, int32_t depth);
 int64_t il_disc_deep_workspace_floats(int32_t in_dim, int32_t hidden, int32_t depth, int32_t batch);
+int64_t il_disc_deep_lds_bytes(int32_t in_dim, int32_t hidden, int32_t depth); /* LDS one workgroup needs; shapes beyond 160 KiB (e.g. input 120, hidden 128, depth 2) are refused */
 /* adversarial_imitation_update (training.py:85-134) / predict_reward (models.py:177-180); arguments as il_gail_disc_step / il_gail_reward */
 int il_gail_deep_step(const il_disc_deep* d, const il_batch* policy, const il_batch* expert, const float* eps_gp, const il_gail_extra* extra, uint32_t flags,
                       il_stream_t stream);
