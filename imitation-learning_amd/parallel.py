@@ -66,15 +66,28 @@ class DataParallelUpdate:
     SAC forward kernels; the critic and actor all-reduces are on the critical path (the algorithm orders them)."""
     p, L = self.plan, _lib.lib()
     G = _lib.IL_FLAG_GRADS_ONLY
-    p.sample_all()
     main = torch.cuda.current_stream()
-    if p.algorithm == 'GAIL':
+    if p.algorithm == 'GAIL' and p.device_index_draw:
+      # The discriminator branch (gradients, all-reduce, AdamW, relabel: the longer one) reads its rows straight from the rings through the drawn indices
+      # (il_batch.gather), so it forks right after the index draw; the gathers the SAC kernels need run on the main stream beside it.
+      p.draw_all()
       self.side.wait_stream(main)
+      rp, re_ = p._ring_batches()
       with torch.cuda.stream(self.side):
-        _lib.check(L.il_gail_disc_step(C.byref(p.disc), C.byref(p.pb), C.byref(p.eb), None, None, G, _lib.stream_ptr()))
+        _lib.check(L.il_gail_disc_step(C.byref(p.disc), C.byref(rp), C.byref(re_), None, None, G, _lib.stream_ptr()))
         all_reduce_mean_(self.disc_bucket, self.group)
         _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
-        _lib.check(L.il_gail_reward(C.byref(p.disc), C.byref(p.pb), _lib.ptr(p.rewards), None, None, _lib.stream_ptr()))
+        _lib.check(L.il_gail_reward(C.byref(p.disc), C.byref(rp), _lib.ptr(p.rewards), None, None, _lib.stream_ptr()))
+      p.gather_all()
+    else:
+      p.sample_all()
+      if p.algorithm == 'GAIL':
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+          _lib.check(L.il_gail_disc_step(C.byref(p.disc), C.byref(p.pb), C.byref(p.eb), None, None, G, _lib.stream_ptr()))
+          all_reduce_mean_(self.disc_bucket, self.group)
+          _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
+          _lib.check(L.il_gail_reward(C.byref(p.disc), C.byref(p.pb), _lib.ptr(p.rewards), None, None, _lib.stream_ptr()))
     _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 0, None, None, p.prepared_flag(), _lib.stream_ptr()))
     if p.algorithm == 'GAIL':
       main.wait_stream(self.side)

@@ -437,6 +437,25 @@ class UpdatePlan:
       idx.copy_(mem._sample_idx_tensor(self.B))
       _lib.check(_lib.lib().il_replay_gather(_lib.ptr(mem.ring), mem.size, mem.row, _lib.ptr(idx), self.B, _lib.ptr(rows), _lib.stream_ptr()))
 
+  def draw_all(self):
+    """The index draws of `sample_all` alone (device draw): consumers that read the rings through il_batch.gather (`_ring_batches`) can start from here,
+    before `gather_all` has produced the packed rows."""
+    assert self.device_index_draw
+    m, e = self.memory, (self.expert_memory if self.algorithm == 'GAIL' else None)
+    st = m.stream().device_state(m.device)
+    _lib.check(_lib.lib().il_replay_sample_device(
+        _lib.ptr(st), self.B, _lib.ptr(m._ring_state), _lib.ptr(m.ring), m.size, m.row, _lib.ptr(self.idx), None,
+        _lib.ptr(e._ring_state) if e else None, _lib.ptr(e.ring) if e else None, e.size if e else 0, e.row if e else 0, _lib.ptr(self.eidx) if e else None, None, None, _lib.stream_ptr()))
+
+  def gather_all(self):
+    """The row gathers of `sample_all` for indices drawn by `draw_all` (same values as `sample_all`)."""
+    L, st = _lib.lib(), _lib.stream_ptr()
+    m = self.memory
+    _lib.check(L.il_replay_gather(_lib.ptr(m.ring), m.size, m.row, _lib.ptr(self.idx), self.B, _lib.ptr(self.rows), st))
+    if self.algorithm == 'GAIL':
+      e = self.expert_memory
+      _lib.check(L.il_replay_gather(_lib.ptr(e.ring), e.size, e.row, _lib.ptr(self.eidx), self.B, _lib.ptr(self.erows), st))
+
   def sample_all(self):
     """Agent batch then expert batch (the order train.py:173 consumes the index stream); one launch when drawn on the device."""
     if not self.device_index_draw:
