@@ -78,7 +78,7 @@ class DataParallelUpdate:
         all_reduce_mean_(self.disc_bucket, self.group)
         _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
         _lib.check(L.il_gail_reward(C.byref(p.disc), C.byref(rp), _lib.ptr(p.rewards), None, None, _lib.stream_ptr()))
-      p.gather_all()
+      p.gather_all(expert=False)   # the SAC kernels read the packed agent rows; the expert rows were only needed by the discriminator step
     else:
       p.sample_all()
       if p.algorithm == 'GAIL':

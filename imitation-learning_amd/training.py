@@ -447,12 +447,13 @@ class UpdatePlan:
         _lib.ptr(st), self.B, _lib.ptr(m._ring_state), _lib.ptr(m.ring), m.size, m.row, _lib.ptr(self.idx), None,
         _lib.ptr(e._ring_state) if e else None, _lib.ptr(e.ring) if e else None, e.size if e else 0, e.row if e else 0, _lib.ptr(self.eidx) if e else None, None, None, _lib.stream_ptr()))
 
-  def gather_all(self):
-    """The row gathers of `sample_all` for indices drawn by `draw_all` (same values as `sample_all`)."""
+  def gather_all(self, expert: bool = True):
+    """The row gathers of `sample_all` for indices drawn by `draw_all` (same values as `sample_all`); expert=False when the expert rows are only read
+    through the ring (nothing else consumes the packed expert batch)."""
     L, st = _lib.lib(), _lib.stream_ptr()
     m = self.memory
     _lib.check(L.il_replay_gather(_lib.ptr(m.ring), m.size, m.row, _lib.ptr(self.idx), self.B, _lib.ptr(self.rows), st))
-    if self.algorithm == 'GAIL':
+    if self.algorithm == 'GAIL' and expert:
       e = self.expert_memory
       _lib.check(L.il_replay_gather(_lib.ptr(e.ring), e.size, e.row, _lib.ptr(self.eidx), self.B, _lib.ptr(self.erows), st))
 
