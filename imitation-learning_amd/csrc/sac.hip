@@ -370,7 +370,7 @@ __device__ __forceinline__ void critic_bwd_resident_gemm(const il_sac& d, int k,
 }
 // relabel: the rewards of this tile are the discriminator `dd`'s prediction on (s, a) - the rows still sit in Xs - computed here once its AdamW step of
 // this update is complete ([IL_SYNC_PARAMS], n_reduce workgroups per step); otherwise dense `rewards` or the batch's own reward field.
-struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; };
+struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; int fwd_only; };   // fwd_only: the forward kernels only (IL_FLAG_SAC_FORWARD_ONLY / data-parallel phase 0): no critic backward
 // Runs between the critic's own work and its wait for the targets: the discriminator's step usually lands while the targets are still being computed,
 // so the relabel stays off the critical path. Leaves the tile's rewards in LDS (rew16) for critic_bwd_resident_scale.
 __device__ __forceinline__ void critic_relabel_tile(const il_sac& d, const ChainRelabel& rl, int k, int tile, float* smem) {
@@ -482,9 +482,17 @@ __global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const 
   const SacWs ws = sac_ws(d.state_dim, d.action_dim, d.hidden, d.batch);
   unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + tile;
   if (role == 0) { actor_fwd_tile(d, b, eps_next, eps_cur, false, tile, smem); tile_arrive(ctr); }
-  else if (role == 1) { critic_fwd_tile(d, b, 2 + net, tile, smem, ctr); tile_arrive(ctr); }
+  else if (role == 1) {
+    critic_fwd_tile(d, b, 2 + net, tile, smem, ctr);
+    if (!rl.fwd_only) tile_arrive(ctr);
+    else {   // nobody waits for the targets in this launch: the second target workgroup of the tile leaves the counter at 0 for the next one
+      __syncthreads();
+      if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == 2u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   else if (role == 2) {
     critic_fwd_tile(d, b, net, tile, smem, nullptr);
+    if (rl.fwd_only) return;
     critic_bwd_resident_gemm(d, net, smem);
     if (rl.on) critic_relabel_tile(d, rl, net, tile, smem);
     const RowScalars rs = critic_row_scalars(b, !rl.on && !rewards && !d.sync, tile);
@@ -1038,6 +1046,14 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
     { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr, ChainRelabel{}); }
     flags |= IL_FLAG_SAC_SKIP_FORWARD | 0x80000000u;
   }
+  if ((flags & IL_FLAG_SAC_FORWARD_ONLY) && !(flags & IL_FLAG_SAC_SKIP_FORWARD) && chain_enabled() && 6 * nt <= device_cu_count()) {
+    // the four forward passes as one launch chained per tile (the target critics wait for their tile's actor(s') inside it), no critic backward
+    if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
+    ChainRelabel fo = {}; fo.fwd_only = 1;
+    { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr, fo); }
+    IL_CHECK_LAUNCH("il_sac_update");
+    return IL_OK;
+  }
   if (!(flags & IL_FLAG_SAC_SKIP_FORWARD)) {
     if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
     // the actor is unchanged until the last kernel of the update: both of its forward passes share one launch; neither this
@@ -1239,7 +1255,11 @@ extern "C" int il_sac_dp_phase(const il_sac* d, const il_batch* b, int32_t phase
   hipStream_t st = (hipStream_t)stream_;
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
-  if (phase == 0) {
+  if (phase == 0 && chain_enabled() && 6 * nt <= device_cu_count()) {
+    if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
+    ChainRelabel fo = {}; fo.fwd_only = 1;
+    { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr, nullptr, nullptr, fo); }
+  } else if (phase == 0) {
     if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
     { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr, 0, nullptr, nullptr); }
     { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
