@@ -62,7 +62,7 @@ class DiscDeep(C.Structure):
 
 
 class GailExtra(C.Structure):
-  _fields_ = [('eps_mix', C.c_void_p), ('logit_offset_policy', C.c_void_p), ('logit_offset_expert', C.c_void_p)]
+  _fields_ = [('eps_mix', C.c_void_p), ('logit_offset_policy', C.c_void_p), ('logit_offset_expert', C.c_void_p), ('logit_offset_mix', C.c_void_p)]
 
 
 class Pwil(C.Structure):

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   if (kind != 2) {
     const float w = L.wt(0)[r];
     const int row = row0 + min(r, nrows - 1);
-    const float* off = kind == 0 ? x.logit_offset_policy : (kind == 1 ? x.logit_offset_expert : nullptr);
+    const float* off = kind == 0 ? x.logit_offset_policy : (kind == 1 ? x.logit_offset_expert : (kind == 3 ? x.logit_offset_mix : nullptr));
     const float z = off ? f - off[row] : f;   // subtract_log_policy (models.py:175)
     const bool pu = d.loss_function == IL_LOSS_PUGAIL;
     // d loss / d z = w (c_sig sigmoid(z) - c_lab) / B: BCE {1, label}; PUGAIL policy {-1, 0}, expert {2 prior, prior}; Mixup {1, eps}
@@ -449,7 +449,7 @@ extern "C" int il_gail_disc_step(const il_disc* d, const il_batch* pol, const il
   IL_CHECK_ARG(pol && exp && pol->n == d->batch && exp->n == d->batch, "il_gail_disc_step: policy/expert batches must both have %d rows", d->batch);
   il_gail_extra x = {};
   if (extra) x = *extra;
-  IL_CHECK_ARG(d->loss_function != IL_LOSS_MIXUP || (!x.logit_offset_policy && !x.logit_offset_expert), "il_gail_disc_step: Mixup with subtract_log_policy is not supported");
+  IL_CHECK_ARG(d->loss_function != IL_LOSS_MIXUP || (!x.logit_offset_policy && !x.logit_offset_expert), "il_gail_disc_step: with Mixup the log-policy offset belongs to the mixed batch (logit_offset_mix)");
   hipStream_t st = (hipStream_t)stream_;
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
   const int nt = ceil_div(d->batch, IL_TILE_R);

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void k_gd_grad(il_disc_deep d, il_batch pol, i
     // ---- first-order call: dL/dz = w (c_sig sigmoid(z) - c_lab) / B (+ entropy bonus), then plain back-propagation
     if (tid < GD_R) {
       const int row = row0 + min(tid, nrows - 1);
-      const float* off = kind == 0 ? x.logit_offset_policy : (kind == 1 ? x.logit_offset_expert : nullptr);
+      const float* off = kind == 0 ? x.logit_offset_policy : (kind == 1 ? x.logit_offset_expert : (kind == 3 ? x.logit_offset_mix : nullptr));
       const float f = l.row[tid], z = off ? f - off[row] : f;
       const bool pu = d.loss_function == IL_LOSS_PUGAIL;
       const float c_sig = pu ? (kind == 1 ? 2.f * d.pos_class_prior : -1.f) : 1.f;
@@ -466,7 +466,7 @@ extern "C" int il_gail_deep_step(const il_disc_deep* d, const il_batch* pol, con
   IL_CHECK_ARG(d->grad && d->workspace && d->opt.m && d->opt.v && d->opt.step && pol->weights && exp->weights, "il_gail_deep_step: null optimiser / workspace / weights");
   il_gail_extra x = {};
   if (extra) x = *extra;
-  IL_CHECK_ARG(d->loss_function != IL_LOSS_MIXUP || (!x.logit_offset_policy && !x.logit_offset_expert), "il_gail_deep_step: Mixup with subtract_log_policy is not supported");
+  IL_CHECK_ARG(d->loss_function != IL_LOSS_MIXUP || (!x.logit_offset_policy && !x.logit_offset_expert), "il_gail_deep_step: with Mixup the log-policy offset belongs to the mixed batch (logit_offset_mix)");
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim), depth = gd_depth(*d), nt = ceil_div(d->batch, GD_R);
   const size_t lds = gd_lds_floats(D, d->hidden, depth) * sizeof(float);
   if (int rc = gd_ensure_lds((const void*)k_gd_grad, lds)) return rc;

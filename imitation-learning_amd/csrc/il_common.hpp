@@ -67,7 +67,7 @@ __device__ __forceinline__ void globalize(il_disc& d) {
   globalize(d.opt); d.workspace = as_global(d.workspace); d.noise_counter = as_global(d.noise_counter); d.sync = as_global(d.sync);
 }
 __device__ __forceinline__ void globalize(il_gail_extra& x) {
-  x.eps_mix = as_global(x.eps_mix); x.logit_offset_policy = as_global(x.logit_offset_policy); x.logit_offset_expert = as_global(x.logit_offset_expert);
+  x.eps_mix = as_global(x.eps_mix); x.logit_offset_policy = as_global(x.logit_offset_policy); x.logit_offset_expert = as_global(x.logit_offset_expert); x.logit_offset_mix = as_global(x.logit_offset_mix);
 }
 
 __device__ __forceinline__ void globalize(il_sample_args& a) {

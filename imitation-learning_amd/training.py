@@ -244,14 +244,17 @@ def adversarial_imitation_update(actor, discriminator: GAILDiscriminator, transi
   deep = type(discriminator).__name__ == 'DeepGAILDiscriminator'   # depth 2 and / or tanh: the general kernels, same arguments
   d = (deep_descriptor if deep else disc_descriptor)(discriminator, B, discriminator_optimiser, imitation_cfg)
   if imitation_cfg.loss_function == 'Mixup':
-    if discriminator.subtract_log_policy:
-      raise NotImplementedError('adversarial_imitation_update: Mixup with subtract_log_policy (log pi of the mixed inputs) has no kernel')
     alpha = float(_cfg_value(imitation_cfg, 'mixup_alpha', 1.0))
-    if eps_mix is None and alpha != 1.0:   # Beta(1, 1) = U(0, 1) comes from the on-chip Philox stream; other alphas are drawn on the host like the reference
-      eps_mix = torch.distributions.Beta(torch.full((B,), alpha), torch.full((B,), alpha)).sample()
+    if eps_mix is None and (alpha != 1.0 or discriminator.subtract_log_policy):   # Beta(1, 1) = U(0, 1) normally comes from the on-chip Philox stream; other alphas,
+      eps_mix = torch.distributions.Beta(torch.full((B,), alpha), torch.full((B,), alpha)).sample()   # and draws this function needs itself, are made here like the reference's
     if eps_mix is not None:
       keep.append(_f32(eps_mix, dev)); x.eps_mix = keep[-1].data_ptr()
-  if discriminator.subtract_log_policy:   # models.py:144: log pi(a|s) of both batches, no graph
+    if discriminator.subtract_log_policy:   # training.py:108 + models.py:144: log pi of the MIXED inputs (no graph), a per-row shift of the mixed logits
+      e2 = keep[-1].unsqueeze(1)
+      mix = lambda k: e2 * _f32(expert_transitions[k], dev) + (1 - e2) * _f32(transitions[k], dev)
+      keep.append(actor.log_prob(mix('states'), mix('actions')))
+      x.logit_offset_mix = keep[-1].data_ptr()
+  elif discriminator.subtract_log_policy:   # models.py:144: log pi(a|s) of both batches, no graph
     keep += [actor.log_prob(transitions['states'], transitions['actions']), actor.log_prob(expert_transitions['states'], expert_transitions['actions'])]
     x.logit_offset_policy, x.logit_offset_expert = keep[-2].data_ptr(), keep[-1].data_ptr()
   step = _lib.lib().il_gail_deep_step if deep else _lib.lib().il_gail_disc_step

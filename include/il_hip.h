@@ -295,6 +295,7 @@ typedef struct il_gail_extra {
   const float* eps_mix;              /* [B] the Beta(alpha, alpha) draws of Mixup (training.py:106); NULL => U(0,1) from Philox, i.e. alpha = 1 */
   const float* logit_offset_policy;  /* [B] log pi(a|s) of the policy batch when subtract_log_policy (models.py:144,175) */
   const float* logit_offset_expert;  /* [B] same for the expert batch */
+  const float* logit_offset_mix;     /* [B] Mixup with subtract_log_policy: log pi of the MIXED (state, action) rows (training.py:108: the caller mixes with the eps_mix it passes) */
 } il_gail_extra;
 
 int64_t il_disc_workspace_floats(int32_t in_dim, int32_t hidden, int32_t batch);

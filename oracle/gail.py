@@ -98,7 +98,7 @@ def disc_logits(ds: DiscState, x, train=False):
 
 
 def gail_update(ds: DiscState, xp, wp, xe, we, eps_gp, *, lr, weight_decay, grad_penalty=1.0, entropy_bonus=0.0, return_grads=False, loss_function='BCE',
-                pos_class_prior=0.7, eps_mix=None, logp_policy=None, logp_expert=None):
+                pos_class_prior=0.7, eps_mix=None, logp_policy=None, logp_expert=None, logp_mix=None):
   """One `adversarial_imitation_update` (training.py:85-134). xp/xe = cat(state, action) of policy / expert batch.
   loss_function: 'BCE' (:97-99), 'PUGAIL' with nonnegative_margin = inf (:100-102: the clamp never binds) or 'Mixup' (:104-113, eps_mix = the
   Beta(alpha, alpha) draws). logp_policy / logp_expert: log pi(a|s) of the two batches when subtract_log_policy (models.py:173-175: D = f - log pi;
@@ -114,7 +114,7 @@ def gail_update(ds: DiscState, xp, wp, xe, we, eps_gp, *, lr, weight_decay, grad
     calls = [(xp, wp, f32(-1), zero, logp_policy), (xe, we, f32(2) * pr, zero + pr, logp_expert)]
   elif loss_function == 'Mixup':   # eps*BCE(D_mix,1) + (1-eps)*BCE(D_mix,0) on convex combinations
     em = eps_mix.astype(f32)
-    calls = [(em[:, None] * xe + (f32(1) - em[:, None]) * xp, em * we + (f32(1) - em) * wp, f32(1), em, None)]
+    calls = [(em[:, None] * xe + (f32(1) - em[:, None]) * xp, em * we + (f32(1) - em) * wp, f32(1), em, logp_mix)]   # logp_mix: log pi of the mixed rows (training.py:108)
     assert logp_policy is None and logp_expert is None
   else:
     raise ValueError(loss_function)

@@ -222,7 +222,7 @@ def gen_gail_variants():
   """adversarial_imitation_update with loss_function=PUGAIL / Mixup and with subtract_log_policy (training.py:100-113, models.py:139-144,173-175):
   gradients, parameters after AdamW, rewards. Mixup's Beta(alpha, alpha) draws are fed (Beta.sample patched), like the other noise."""
   out = {}
-  for name, loss, sub in (('pugail', 'PUGAIL', False), ('mixup', 'Mixup', False), ('sublogp', 'BCE', True)):
+  for name, loss, sub in (('pugail', 'PUGAIL', False), ('mixup', 'Mixup', False), ('sublogp', 'BCE', True), ('mixup_sublogp', 'Mixup', True)):
     c = gi.gail_case(35, env='hopper', hidden=32, batch=96, steps=2)
     x = gi.gail_extras(35, c)
     d, icfg = build_disc(c)
@@ -255,6 +255,9 @@ def gen_gail_variants():
           out[f'{name}.logp_policy_{k}'] = N_(actor.log_prob(T(b['states']), T(b['actions'])))
           e = c['expert'][i]
           out[f'{name}.logp_expert_{k}'] = N_(actor.log_prob(T(e['states']), T(e['actions'])))
+          if loss == 'Mixup':
+            em = T(x['eps_mix'][i]).unsqueeze(1)
+            out[f'{name}.logp_mix_{k}'] = N_(actor.log_prob(em * T(e['states']) + (1 - em) * T(b['states']), em * T(e['actions']) + (1 - em) * T(b['actions'])))
   np.savez_compressed(os.path.join(HERE, 'gail_variants.npz'), **out)
 
 

@@ -803,7 +803,7 @@ def test_dril_onchip_masks_are_bernoulli_and_change_per_call():
 # GAIL loss variants (training.py:100-113) and subtract_log_policy (models.py:144,175) against the reference fixture and the oracle
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize('name,loss,sub', [('pugail', 'PUGAIL', False), ('mixup', 'Mixup', False), ('sublogp', 'BCE', True)])
+@pytest.mark.parametrize('name,loss,sub', [('pugail', 'PUGAIL', False), ('mixup', 'Mixup', False), ('sublogp', 'BCE', True), ('mixup_sublogp', 'Mixup', True)])
 def test_gail_loss_variants_match_reference(golden_dir, name, loss, sub):
   g = load(golden_dir, 'gail_variants')
   c = gi.gail_case(35, env='hopper', hidden=32, batch=96, steps=2)

@@ -233,7 +233,7 @@ def test_dril_oracle_matches_reference_fixture(golden_dir, name, kw):
   assert decided.sum() >= len(ref_r) - 2 and np.array_equal(r[decided], ref_r[decided])
 
 
-@pytest.mark.parametrize('name,loss,sub', [('pugail', 'PUGAIL', False), ('mixup', 'Mixup', False), ('sublogp', 'BCE', True)])
+@pytest.mark.parametrize('name,loss,sub', [('pugail', 'PUGAIL', False), ('mixup', 'Mixup', False), ('sublogp', 'BCE', True), ('mixup_sublogp', 'Mixup', True)])
 def test_gail_variant_oracle_matches_reference_fixture(golden_dir, name, loss, sub):
   """oracle/gail.py with loss_function PUGAIL / Mixup and with the subtract_log_policy offsets against adversarial_imitation_update of the reference."""
   g = np.load(os.path.join(golden_dir, 'gail_variants.npz'))
@@ -247,8 +247,9 @@ def test_gail_variant_oracle_matches_reference_fixture(golden_dir, name, loss, s
     xp, xe = np.concatenate([p['states'], p['actions']], 1), np.concatenate([e['states'], e['actions']], 1)
     lp = g[f'{name}.logp_policy_{i + 1}'] if sub else None
     le = g[f'{name}.logp_expert_{i + 1}'] if sub else None
+    lm = g[f'{name}.logp_mix_{i + 1}'] if sub and loss == 'Mixup' else None
     gr = gail.gail_update(ds, xp, p['weights'], xe, e['weights'], c['eps'][i], lr=1e-3, weight_decay=0.1, grad_penalty=0.5, entropy_bonus=0.02, return_grads=True,
-                          loss_function=loss, pos_class_prior=0.7, eps_mix=x['eps_mix'][i], logp_policy=lp, logp_expert=le)
+                          loss_function=loss, pos_class_prior=0.7, eps_mix=x['eps_mix'][i], logp_policy=None if loss == 'Mixup' else lp, logp_expert=None if loss == 'Mixup' else le, logp_mix=lm)
     ref = g[f'{name}.g_{i + 1}']
     assert np.abs(gr - ref).max() <= 1e-5 * np.abs(ref).max()
     np.testing.assert_allclose(gail.predict_reward(ds, xp, 'AIRL', log_policy=lp), g[f'{name}.reward_{i + 1}'], rtol=3e-5, atol=1e-6)
