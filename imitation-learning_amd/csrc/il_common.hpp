@@ -221,7 +221,7 @@ __device__ __forceinline__ void sync_wait(long long* sync, int which, long long 
       if (++spins > limit) { __hip_atomic_fetch_add(sync + IL_SYNC_TIMEOUTS, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
 #ifndef IL_SYNC_UNSAFE
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);   // agent scope: the producer's stores are visible to this CU from here on
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the producer's stores are visible to this CU from here on (every producer is a kernel on this GPU)
 #endif
   }
   __syncthreads();

@@ -208,7 +208,7 @@ __device__ __forceinline__ void tile_await(unsigned* ctr, unsigned target, const
         break;
       }
     }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
 }
