@@ -89,6 +89,25 @@ extern "C" int il_sync_probe(int64_t* sync, int32_t setter, il_stream_t stream) 
   return IL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// il_noise_fill: the update kernels' on-chip noise as a function of (key, update counter, stream id, index) -- the same device functions
+// (philox_normal / philox_uniform, il_common.hpp) they evaluate when their eps pointer is NULL. A caller that knows the counter range a
+// captured run covered can therefore record exactly what those updates consumed (the parity tests replay it through the CPU oracle).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_noise_fill(uint64_t seed, uint32_t ctr, uint32_t stream_id, long long n, int normal, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = normal ? philox_normal(seed, ctr, stream_id, (uint32_t)i) : philox_uniform(seed, ctr, stream_id, (uint32_t)i);
+}
+extern "C" int il_noise_fill(uint64_t noise_seed, uint32_t ctr, uint32_t stream_id, int64_t n, float* out, il_stream_t stream) {
+  IL_CHECK_ARG(out && n >= 0 && n < (1LL << 32), "il_noise_fill: bad arguments");
+  const bool normal = stream_id == IL_STREAM_EPS_NEXT || stream_id == IL_STREAM_EPS_CUR || stream_id == IL_STREAM_ACT;
+  IL_CHECK_ARG(normal || stream_id == IL_STREAM_GP || stream_id == IL_STREAM_MIX, "il_noise_fill: unknown stream id %u", stream_id);
+  if (n == 0) return IL_OK;
+  k_noise_fill<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(noise_seed, ctr, stream_id, (long long)n, normal ? 1 : 0, out);
+  IL_CHECK_LAUNCH("il_noise_fill");
+  return IL_OK;
+}
+
 // sizeof() of the descriptor structs as this library was compiled: a binding checks its own struct definitions against these
 // (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red, 7 il_dril, 8 il_disc_shaped, 9 il_disc_deep).
 extern "C" int32_t il_struct_size(int32_t which) {

@@ -56,6 +56,17 @@ int il_device_info(char* name_host, int name_len, int* cu_count_host);
 int il_trace_enable(int on);
 int il_trace_report(char* buf_host, int len);
 
+/* The on-chip noise of the update kernels as a function: out[i] = draw #i of noise stream `stream_id` at update counter `ctr` under key `noise_seed`,
+ * evaluated by the same device functions the kernels call when their eps pointer is NULL (Philox4x32-10 keyed by noise_seed, counter words
+ * {i, ctr, stream_id, 0}; normals by Box-Muller from words 0, 1; uniforms = (word 0 >> 8) / 2^24 like torch.rand). The counter of an il_sac / il_disc
+ * descriptor (`noise_counter`) starts at 0 and is advanced by 1 at the end of every il_sac_actor_step, so update #k of a learner consumed ctr = k:
+ *   IL_NOISE_EPS_NEXT [B*A] = the N(0,1) draws of policy.sample() on s' (training.py:21), IL_NOISE_EPS_CUR [B*A] = rsample on s (training.py:35),
+ *   IL_NOISE_GP [B] = the U(0,1) of the gradient penalty (training.py:118), IL_NOISE_MIX [B] = Mixup coefficients at alpha = 1 (training.py:106),
+ *   IL_NOISE_ACT [n*A] = actor(state).sample() of il_actor_act / il_act_step (train.py:152; there `ctr` is the call's noise_offset).
+ * This is how a captured run is recorded for replay through a CPU oracle (tests/test_timed_path_oracle.py). */
+enum { IL_NOISE_EPS_NEXT = 1, IL_NOISE_EPS_CUR = 2, IL_NOISE_GP = 3, IL_NOISE_ACT = 4, IL_NOISE_MIX = 7 };
+int il_noise_fill(uint64_t noise_seed, uint32_t ctr, uint32_t stream_id, int64_t n, float* out, il_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * A batch of transitions as strided fp32 fields: row b of field f is f + b*ld_f.
  * Mirrors the `transitions` dict of reference memory.py:58-63 (keys states, actions, rewards,

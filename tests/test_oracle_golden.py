@@ -305,3 +305,18 @@ def test_gail_deep_oracle_matches_reference_fixture(golden_dir, name):
       np.testing.assert_allclose(ds.pack_sn(), g[f'{name}.sn_{i + 1}'], rtol=1e-4, atol=1e-6)
     ds.unpack_into(g[f'{name}.p_{i + 1}'])
     np.testing.assert_allclose(ogd.predict_reward(ds, cat(pb), rf), g[f'{name}.reward_{i + 1}'], rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ Philox (the on-chip noise source's restatement)
+def test_philox_restatement_matches_random123_known_answers():
+  """Known-answer vectors of Random123's philox4x32_10 (kat_vectors: all-zero, all-ones and the pi-digits counter / key)."""
+  from oracle import philox
+  kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+         ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+         ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+  for ctr, key, want in kat:
+    assert tuple(int(x) for x in philox.philox4x32_10(*ctr, *key)) == want
+  z = philox.normal(7, 3, philox.STREAM_EPS_CUR, 1 << 18).astype(np.float64)
+  assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+  u = philox.uniform(7, 3, philox.STREAM_GP, 1 << 18)
+  assert 0 <= u.min() and u.max() < 1 and abs(float(u.mean()) - 0.5) < 0.01

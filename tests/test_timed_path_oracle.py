@@ -1,0 +1,241 @@
+"""`-m gpu`: the TIMED path against the CPU oracle, by record and replay.
+
+What `bench.py` measures is `UpdatePlan` at the BASELINE configuration (algorithm=GAIL, HalfCheetah dims, B = 256, ring 1e6 / fill 1e5, 25k expert
+rows): device-side MT19937 index draws, rows read from the rings through the indices, on-chip Philox noise, inline reward relabel, two hipGraphs
+handing over through device counters (reference train.py:171-203).  The per-function parity tests feed injected noise through a different branch of
+the kernels; here the captured plan itself is run, what it consumed is RECORDED -- the index stream is bit-exact with the oracle's own MT19937, the
+noise of update k is a pure function of (key, k, stream) exported by `il_noise_fill` -- and the oracle (`oracle.replay` -> `oracle.gail.gail_update`
+-> `predict_reward` -> `oracle.sac.sac_update`) REPLAYS the same updates from the same initial state.  Every tensor is compared at the bounds of
+tests/gpu_util.py.  Same for a 3-learner `BatchedPopulationPlan` and for the acting launch `il_act_step` (f2).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import inputs as gi
+from oracle import gail as ogail
+from oracle import nets as onets
+from oracle import philox
+from oracle import replay as oreplay
+from oracle import sac as osac
+from oracle.mt19937 import MT19937
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+  import bench
+  import imitation_learning_amd as il
+  from imitation_learning_amd import _lib
+  from imitation_learning_amd import training as il_training
+  from gpu_util import DEV, N, Cfg, close, close_params, crit_from_flat
+
+S, A, H, HD, B = 18, 6, 256, 64, 256
+LR, LR_D, WD_D, DISCOUNT, POLYAK, ENT = 3e-4, 3e-5, 10.0, 0.97, 0.99, -0.5 * 6
+
+
+def record_noise(seed, ctr, stream_id, n):
+  """What update `ctr` drew from noise stream `stream_id` (include/il_hip.h il_noise_fill: the kernels' own device functions)."""
+  out = torch.empty(n, device=DEV)
+  _lib.check(_lib.lib().il_noise_fill(C.c_uint64(seed), ctr, stream_id, n, _lib.ptr(out), _lib.stream_ptr()))
+  return N(out)
+
+
+# ------------------------------------------------------------------------------------------------ the recorder itself
+def test_noise_recorder_matches_the_independent_philox_restatement():
+  """il_noise_fill against oracle/philox.py (Random123 known answers are checked on the CPU side): uniforms bit-exact (pure integer path), normals to a
+  few float32 ulp of numpy's log / cos / sqrt, so the recorder cannot share a mistake with the kernels unnoticed."""
+  for seed, ctr in ((0, 0), (3, 11), (0x1234_5678_9ABC_DEF0, 70000)):
+    np.testing.assert_array_equal(record_noise(seed, ctr, philox.STREAM_GP, 4096), philox.uniform(seed, ctr, philox.STREAM_GP, 4096))
+    np.testing.assert_array_equal(record_noise(seed, ctr, philox.STREAM_MIX, 300), philox.uniform(seed, ctr, philox.STREAM_MIX, 300))
+    for stream in (philox.STREAM_EPS_NEXT, philox.STREAM_EPS_CUR, philox.STREAM_ACT):
+      got, want = record_noise(seed, ctr, stream, 1 << 15), philox.normal(seed, ctr, stream, 1 << 15)
+      assert np.abs(got - want).max() <= 4e-6, (seed, ctr, stream, np.abs(got - want).max())   # |x| <= 6: a few ulp of the factors, absolute because cos() crosses 0
+
+
+def test_philox_streams_are_standard_normal_and_uniform():
+  """Moments and a Kolmogorov-Smirnov test on 2^20 draws of each kind (the old check was 0.05 < std < 1)."""
+  from scipy import stats
+  n = 1 << 20
+  z = record_noise(12345, 7, philox.STREAM_EPS_CUR, n).astype(np.float64)
+  assert abs(z.mean()) < 4 / np.sqrt(n) and abs(z.var() - 1) < 4 * np.sqrt(2 / n)
+  assert abs(stats.skew(z)) < 4 * np.sqrt(6 / n) and abs(stats.kurtosis(z)) < 4 * np.sqrt(24 / n)
+  assert stats.kstest(z, 'norm').pvalue > 1e-3
+  u = record_noise(12345, 7, philox.STREAM_GP, n).astype(np.float64)
+  assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 4 / np.sqrt(12 * n) and stats.kstest(u, 'uniform').pvalue > 1e-3
+  # different counters / streams / keys are different, uncorrelated sequences
+  for other in (record_noise(12345, 8, philox.STREAM_EPS_CUR, n), record_noise(12345, 7, philox.STREAM_EPS_NEXT, n), record_noise(12346, 7, philox.STREAM_EPS_CUR, n)):
+    assert abs(np.corrcoef(z, other)[0, 1]) < 5 / np.sqrt(n)
+
+
+# ------------------------------------------------------------------------------------------------ oracle twin of a learner
+class OracleLearner:
+  """The oracle's copy of one bench learner: same initial parameters / buffers, its own MT19937 stream."""
+
+  def __init__(self, nets, plan, tr, et, index_seed):
+    actor, critic, target, log_alpha, disc = nets
+    self.st = osac.SacState(S, A, H)
+    self.st.actor[:], self.st.critic[:], self.st.target[:] = N(actor.flat), crit_from_flat(critic, critic.flat), crit_from_flat(critic, target.flat)
+    self.st.log_alpha[:] = N(log_alpha)
+    self.ds = ogail.DiscState(S + A, HD, True)
+    self.ds.unpack_into(N(disc.flat))
+    v = disc.views()
+    for k in ('u1', 'v1', 'u2', 'v2'):
+      getattr(self.ds, k)[...] = N(v[k])
+    n = tr['states'].shape[0]
+    self.mem = oreplay.ReplayOracle(plan.memory.size, S, A, True)
+    for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'timeouts', 'weights'):
+      getattr(self.mem, k)[:n] = tr[k]
+    self.mem.step[:n] = np.arange(1, n + 1, dtype=np.float32)
+    self.mem.idx = n
+    self.emem = oreplay.ReplayOracle(et['states'].shape[0], S, A, True, transitions={**et, 'num_trajectories': 25})
+    assert (self.mem.idx, self.mem.full) == (plan.memory.idx, plan.memory.full) and (self.emem.idx, self.emem.full) == (plan.expert_memory.idx, plan.expert_memory.full)
+    self.gen = MT19937(index_seed)
+    self.key = int(plan.sac.noise_seed)
+    assert int(plan.disc.noise_seed) == self.key and plan.sac.noise_counter == plan.disc.noise_counter, 'one Philox key / counter per learner'
+
+  def update(self, k):
+    """Update #k (0-based) of train.py:173-203, consuming the recorded draws of counter k. Returns (idx, eidx, rewards, logp, q)."""
+    cat = lambda b: np.concatenate([b['states'], b['actions']], axis=1)
+    idx, eidx = self.mem.sample_idx(self.gen, B), self.emem.sample_idx(self.gen, B)   # train.py:173: agent batch first, then the expert batch, one stream
+    b, e = self.mem.gather(idx), self.emem.gather(eidx)
+    eps_gp = record_noise(self.key, k, philox.STREAM_GP, B)
+    eps_next, eps_cur = record_noise(self.key, k, philox.STREAM_EPS_NEXT, B * A).reshape(B, A), record_noise(self.key, k, philox.STREAM_EPS_CUR, B * A).reshape(B, A)
+    ogail.gail_update(self.ds, cat(b), b['weights'], cat(e), e['weights'], eps_gp, lr=LR_D, weight_decay=WD_D, grad_penalty=1.0)        # train.py:178-180
+    b['rewards'] = ogail.predict_reward(self.ds, cat(b), 'AIRL')                                                                      # train.py:192-194
+    logp, q = osac.sac_update(self.st, b, eps_next, eps_cur, discount=DISCOUNT, entropy_target=ENT, polyak_factor=POLYAK, lr=LR)       # train.py:203
+    return np.array(idx), np.array(eidx), b['rewards'], logp, q
+
+
+def compare_learner(o, nets, plan, k, tag=''):
+  """Every persistent tensor of the learner after k updates, at the tests/gpu_util.py bounds."""
+  actor, critic, target, log_alpha, disc = nets
+  ao, co, to, do = plan._keep[4], plan._keep[5], plan._keep[6], plan._keep[8]
+  s = 1e-5 * k
+  close_params(N(actor.flat), o.st.actor, f'{tag}actor after {k}', LR, k); close_params(crit_from_flat(critic, critic.flat), o.st.critic, f'{tag}critic after {k}', LR, k)
+  close_params(crit_from_flat(critic, target.flat), o.st.target, f'{tag}target after {k}', LR, k)
+  close(N(log_alpha), o.st.log_alpha, f'{tag}log_alpha after {k}', atol_scale=s)
+  close(N(ao.exp_avg), o.st.actor_m, f'{tag}actor exp_avg', atol_scale=s); close(N(ao.exp_avg_sq), o.st.actor_v, f'{tag}actor exp_avg_sq', atol_scale=s)
+  close(crit_from_flat(critic, co.exp_avg), o.st.critic_m, f'{tag}critic exp_avg', atol_scale=s); close(crit_from_flat(critic, co.exp_avg_sq), o.st.critic_v, f'{tag}critic exp_avg_sq', atol_scale=s)
+  close(N(to.exp_avg), o.st.alpha_m, f'{tag}alpha exp_avg', atol_scale=s)
+  close(N(disc.flat), o.ds.pack(), f'{tag}discriminator after {k}', atol_scale=4e-6 * k)
+  close(N(do.exp_avg), o.ds.m, f'{tag}discriminator exp_avg', atol_scale=4e-6 * k); close(N(do.exp_avg_sq), o.ds.v, f'{tag}discriminator exp_avg_sq', atol_scale=4e-6 * k)
+  for nm, val in disc.views().items():
+    close(N(val), getattr(o.ds, nm), f'{tag}{nm} after {k}', atol_scale=4e-6 * k)
+
+
+def per_update_outputs(plan):
+  return N(plan.idx), N(plan.eidx), N(plan.rewards), N(plan.logp), N(plan.q)
+
+
+def compare_outputs(got, want, k, tag=''):
+  idx, eidx, rew, logp, q = got
+  oidx, oeidx, orew, ologp, oq = want
+  np.testing.assert_array_equal(idx, oidx, err_msg=f'{tag}agent index draw of update {k}'); np.testing.assert_array_equal(eidx, oeidx, err_msg=f'{tag}expert index draw of update {k}')
+  s = 2e-6 * (k + 1)
+  close(rew, orew, f'{tag}relabelled rewards of update {k}', rtol=1e-4, atol_scale=1e-5)   # log(D) - log1p(-D) near D = 1/2: the conditioning test_gpu_parity documents (and brackets with fp64)
+  close(logp, ologp, f'{tag}log pi of update {k}', atol_scale=s); close(q, oq, f'{tag}min Q of update {k}', atol_scale=s)
+
+
+# ------------------------------------------------------------------------------------------------ a23: the single-learner plan bench.py times
+def test_captured_update_plan_replays_through_the_oracle():
+  WARM, K, SEED = 2, 10, 3
+  il_training._NOISE.clear(); il_training._WS.clear()
+  plan, nets, (tr, et) = bench.build(torch.device(DEV), 0, seed=SEED)
+  o = OracleLearner(nets, plan, tr, et, index_seed=SEED)
+  plan.capture(warmup=WARM)          # WARM eager updates (they count), then the two graphs
+  assert plan.device_sync and plan.ring_mode and plan.inline_relabel and plan.graph_side is not None, 'this must be the schedule bench.py times: device hand-off, ring reads, inline relabel, two graphs'
+  for k in range(WARM):
+    o.update(k)
+  compare_learner(o, nets, plan, WARM, 'eager warm-up: ')
+  for k in range(WARM, WARM + K):
+    plan.replay()
+    torch.cuda.synchronize()
+    compare_outputs(per_update_outputs(plan), o.update(k), k)
+  assert plan.sync_timeouts() == 0
+  assert int(N(il_training._noise_counter(nets[0].flat.device))[0]) == WARM + K, 'one Philox counter tick per update'
+  compare_learner(o, nets, plan, WARM + K)
+  final = [N(n.flat if hasattr(n, 'flat') else n) for n in nets]
+
+  # the same replays back to back with no host synchronisation in between (the timed regime) end in the same bits
+  il_training._NOISE.clear(); il_training._WS.clear()
+  plan2, nets2, _ = bench.build(torch.device(DEV), 0, seed=SEED)
+  plan2.capture(warmup=WARM)
+  for _ in range(K):
+    plan2.replay()
+  torch.cuda.synchronize()
+  assert plan2.sync_timeouts() == 0
+  for a, n in zip(final, nets2):
+    np.testing.assert_array_equal(a, N(n.flat if hasattr(n, 'flat') else n))
+
+
+# ------------------------------------------------------------------------------------------------ f1: the population launches
+def test_batched_population_replays_through_the_oracle():
+  Lp, K = 3, 6
+  il_training._NOISE.clear(); il_training._WS.clear()
+  built = [bench.build(torch.device(DEV), 0, seed=100 + l, learner_id=100 + l) for l in range(Lp)]
+  oracles = [OracleLearner(nets, plan, tr, et, index_seed=100 + l) for l, (plan, nets, (tr, et)) in enumerate(built)]
+  assert len({o.key for o in oracles}) == Lp
+  pop = il.BatchedPopulationPlan([b[0] for b in built])
+  pop.run()                      # one eager update (builds the lane-ordered weight copies), then the captured launches
+  pop.capture()
+  for o in oracles:
+    o.update(0)
+  for k in range(1, K):
+    pop.replay()
+    torch.cuda.synchronize()
+    for l, (o, (plan, nets, _)) in enumerate(zip(oracles, built)):
+      compare_outputs(per_update_outputs(plan), o.update(k), k, f'learner {l}: ')
+  for l, (o, (plan, nets, _)) in enumerate(zip(oracles, built)):
+    compare_learner(o, nets, plan, K, f'learner {l}: ')
+
+
+# ------------------------------------------------------------------------------------------------ f2: the acting launch
+@pytest.mark.parametrize('schedule', ['exact', 'fused'])
+def test_acting_launch_replays_through_the_oracle(schedule):
+  """il_act_step (append + absorbing wrap + actor(state).sample() in one launch, train.py:151-168) against ReplayOracle + oracle.nets, with the Philox
+  draws of every act recorded: ring contents bit-exact (the stored action = the returned action), actions at rtol 1e-5 of the oracle's."""
+  cap, steps = 41, 70
+  cfg = Cfg(hidden_size=H, depth=2, activation='relu')
+  torch.manual_seed(17)
+  actor = il.SoftActor(S, A, cfg, device=DEV)
+  rs = np.random.RandomState(8)
+  actor.flat.copy_(torch.from_numpy(gi.mlp_params(rs, S, H, 2, 2 * A, out_scale=0.3)).to(DEV))
+  mem = il.ReplayMemory(cap, S, A, True, device=DEV)
+  omem = oreplay.ReplayOracle(cap, S, A, True)
+  layers = onets.unpack(N(actor.flat), onets.mlp_shapes(S, H, 2, 2 * A))
+  w = il.ActingWorker(actor, mem)
+  key = int(w._seed.value)
+
+  def oracle_action(obs):
+    """models.py:90-94 with the draw this act consumed (counter = the actor's act-call count after the launch)."""
+    eps = record_noise(key, actor._act_calls & 0xFFFFFFFF, philox.STREAM_ACT, A)
+    out, _ = onets.mlp_forward(layers, obs[None, :])
+    mean, _, _, std = onets.actor_head(out, A)
+    return np.tanh(mean + std * eps[None, :])[0]
+
+  def obs_row():
+    o = rs.standard_normal(S).astype(np.float32); o[-1] = 0
+    return o
+  obs = obs_row()
+  act = N(w.act(obs))[0]
+  close(act, oracle_action(obs), 'first action')
+  for t in range(1, steps + 1):
+    nxt, rew, term, tout = obs_row(), float(rs.standard_normal()), t in (9, 33, 58), t in (21, 47)
+    omem.append(t, obs, act, rew, nxt, term, tout)
+    if term and not tout:
+      omem.wrap_for_absorbing_states()                       # train.py:161
+    nobs = obs_row() if (term or tout) else nxt              # env.reset()
+    if schedule == 'exact':
+      w.append(t, nxt, rew, term, tout)
+      a2 = N(w.act(nobs))[0]
+    else:
+      a2 = N(w.step(t, nxt, rew, term, tout, obs=nobs))[0]
+    close(a2, oracle_action(nobs), f'action at step {t}')
+    obs, act = nobs, a2
+  torch.cuda.synchronize()
+  assert (mem.idx, mem.full, mem.num_trajectories) == (omem.idx, omem.full, omem.num_trajectories) and omem.full, 'the script wraps the ring'
+  assert N(mem._ring_state).tolist() == [omem.idx, int(omem.full), cap]
+  for f in oreplay.FIELDS:
+    np.testing.assert_array_equal(N(getattr(mem, f)), getattr(omem, f), err_msg=f)
