@@ -509,7 +509,10 @@ class GMMILDiscriminator(nn.Module):
 
 
 def _calculate_normalisation_scale_offset(data: Tensor) -> Tuple[Tensor, Tensor]:
-  inv_scale, offset = data.std(dim=0, keepdim=True), -data.mean(dim=0, keepdim=True)
+  """Reference models.py:204-207. torch's CPU reductions accumulate float32 inputs in double (acc_type) and round once; a float32 tree reduction over
+  25,000 rows is off by ~4e-6, which PWIL's exp(-beta T / sqrt(D) * cost) turns into 1e-3 of reward. One-off statistics: accumulate in float64 too."""
+  d64 = data.double()
+  inv_scale, offset = d64.std(dim=0, keepdim=True).float(), (-d64.mean(dim=0, keepdim=True)).float()
   inv_scale[inv_scale == 0] = 1
   return 1 / inv_scale, offset
 

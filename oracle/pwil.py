@@ -15,8 +15,9 @@ from .nets import f32
 class PwilOracle:
   def __init__(self, expert_atoms_raw, time_horizon, reward_scale, reward_bandwidth_scale):
     raw = np.asarray(expert_atoms_raw, f32)
-    inv_scale = raw.std(axis=0, ddof=1, keepdims=True).astype(f32)      # torch .std() is unbiased
-    self.offset = (-raw.mean(axis=0, keepdims=True)).astype(f32)
+    r64 = raw.astype(np.float64)   # torch's CPU reductions accumulate float32 in double (at::acc_type) and round the result once (models.py:204-205)
+    inv_scale = r64.std(axis=0, ddof=1, keepdims=True).astype(f32)      # torch .std() is unbiased
+    self.offset = (-r64.mean(axis=0, keepdims=True)).astype(f32)
     inv_scale[inv_scale == 0] = 1
     self.scale = (f32(1) / inv_scale).astype(f32)
     self.raw, self.T = raw, time_horizon

@@ -1,0 +1,26 @@
+import sys, os
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo/tests/golden')
+import numpy as np, torch
+import test_timed_path_oracle as t
+from gpu_util import N, crit_from_flat
+import bench, imitation_learning_amd as il
+from imitation_learning_amd import training as il_training
+Lp, K = 3, 6
+built = [bench.build(torch.device('cuda'), 0, seed=100 + l, learner_id=100 + l) for l in range(Lp)]
+oracles = [t.OracleLearner(nets, plan, tr, et, index_seed=100 + l) for l, (plan, nets, (tr, et)) in enumerate(built)]
+pop = il.BatchedPopulationPlan([b[0] for b in built])
+pop.run(); pop.capture()
+for o in oracles: o.update(0)
+for k in range(1, K):
+  pop.replay(); torch.cuda.synchronize()
+  for o in oracles: o.update(k)
+  for l, (o, (plan, nets, _)) in enumerate(zip(oracles, built)):
+    co = plan._keep[5]
+    a, b = crit_from_flat(nets[1], co.exp_avg).astype(np.float64), o.st.critic_m.astype(np.float64)
+    err = np.abs(a - b) - 1e-5 * np.abs(b)
+    bad = np.nonzero(err > 1e-5 * (k + 1) * np.abs(b).max())[0]
+    print('update', k, 'learner', l, 'max|m|', np.abs(b).max(), 'n_bad', bad.size, 'worst', err.max(), 'idx', bad[:12].tolist(), flush=True)
+    if bad.size:
+      net = bad // 72452; off = bad % 72452
+      rows = np.where((off >= 6400) & (off < 71936), (off - 6400) // 256, -1)
+      print('   nets', np.unique(net), 'W2 rows', np.unique(rows)[:10], 'first-layer/bias elems', int((rows < 0).sum()))

@@ -80,6 +80,16 @@ def tbatch(b):
   return {k: T(v) for k, v in b.items()}
 
 
+def tbatch64(b):
+  return {k: T(v).double() for k, v in b.items()}
+
+
+def twin64(module):
+  """A float64 copy of a reference module (same parameters / buffers, widened): the reference's own code evaluated in double precision."""
+  import copy
+  return copy.deepcopy(module).double()
+
+
 # ---------------------------------------------------------------- replay
 def gen_replay():
   out = {}
@@ -158,7 +168,7 @@ def gen_sac(name, c):
   np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
 
 
-def gen_bc(name, env, hidden, batch, steps):
+def gen_bc(name, env, hidden, batch, steps, f64=None):
   S, A = gi.DIMS[env]
   rs = np.random.RandomState(7)
   p0 = gi.mlp_params(rs, S, hidden, 2, 2 * A, out_scale=0.3)
@@ -169,11 +179,16 @@ def gen_bc(name, env, hidden, batch, steps):
   for k in range(1, steps + 1):
     b = gi.transitions(rs, batch, S, A, weighted=True)
     b['actions'][:3] = np.array([1.0, -1.0, 0.9999999])[:, None]  # exercise the clamp
+    if f64 is not None and k == 1:   # log pi on the INITIAL parameters (known to the tests from the seed): float32 and float64
+      with torch.no_grad():
+        f64[f'{name}.logp_init_f32'] = N_(actor.log_prob(T(b['states']), T(b['actions'])))
+        f64[f'{name}.logp_init'] = N_(twin64(actor).log_prob(T(b['states']).double(), T(b['actions']).double()))
     ref_training.behavioural_cloning_update(actor, tbatch(b), opt)
     out[f'actor_{k}'] = gi.strided(flat(actor)); out[f'actor_m_{k}'] = gi.strided(opt_state(opt, 'exp_avg')); out[f'actor_v_{k}'] = gi.strided(opt_state(opt, 'exp_avg_sq'))
     out[f'g_actor_{k}'] = gi.strided(np.concatenate([N_(p.grad).ravel() for p in actor.parameters()]))
     with torch.no_grad():
       out[f'logp_{k}'] = N_(actor.log_prob(T(b['states']), T(b['actions'])))
+  if f64 is not None: return
   np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
 
 
@@ -192,7 +207,7 @@ def build_disc(c, reward_function='AIRL'):
   return d, icfg
 
 
-def gen_gail(name, c, *, lr, weight_decay, grad_penalty, entropy_bonus):
+def gen_gail(name, c, *, lr, weight_decay, grad_penalty, entropy_bonus, f64=None):
   d, icfg = build_disc(c)
   icfg.update(loss_function='BCE', grad_penalty=grad_penalty, mixup_alpha=1, entropy_bonus=entropy_bonus, pos_class_prior=0.7, nonnegative_margin=float('inf'))
   opt = torch.optim.AdamW(d.parameters(), lr=lr, weight_decay=weight_decay)
@@ -214,7 +229,11 @@ def gen_gail(name, c, *, lr, weight_decay, grad_penalty, entropy_bonus):
       for rf in ('AIRL', 'GAIL', 'FAIRL'):
         d.reward_function = rf
         out[f'reward_{rf}_{k}'] = N_(d.predict_reward(T(b['states']), T(b['actions'])))
+        if f64 is not None:
+          d64 = twin64(d); d64.reward_function = rf
+          f64[f'{name}.reward_{rf}_{k}'] = N_(d64.predict_reward(T(b['states']).double(), T(b['actions']).double()))
       out[f'logits_{k}'] = N_(d(T(b['states']), T(b['actions'])))
+  if f64 is not None: return
   np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
 
 
@@ -261,7 +280,7 @@ def gen_gail_variants():
   np.savez_compressed(os.path.join(HERE, 'gail_variants.npz'), **out)
 
 
-def gen_gail_deep():
+def gen_gail_deep(f64=None):
   """GAILDiscriminator with depth 1-2 / relu / tanh (models.py:152-162, no reward shaping) under adversarial_imitation_update: gradients, parameters after
   AdamW, u / v buffers, rewards. The gradient-penalty and Mixup draws are fed like the other noise."""
   out = {}
@@ -283,8 +302,19 @@ def gen_gail_deep():
     opt = torch.optim.AdamW(d.parameters(), lr=lr, weight_decay=wd)
     for i in range(len(c['policy'])):
       d.train()
-      feed = [T(c['eps_mix'][i])]
       orig = torch.distributions.Beta.sample
+      if f64 is not None:   # the same update from the same float32 state, evaluated in float64 (gradients only: the twin is discarded)
+        d64 = twin64(d)
+        feed = [T(c['eps_mix'][i]).double()]
+        torch.distributions.Beta.sample = lambda self, *a, **k: feed.pop(0)
+        try:
+          with NoiseFeed() as nf:
+            nf.rand.append(T(c['eps'][i]).double())
+            ref_training.adversarial_imitation_update(None, d64, tbatch64(c['policy'][i]), tbatch64(c['expert'][i]), torch.optim.AdamW(d64.parameters(), lr=lr, weight_decay=wd), icfg)
+        finally:
+          torch.distributions.Beta.sample = orig
+        f64[f'{name}.g_{i + 1}'] = np.concatenate([N_(p.grad).ravel() for p in d64.parameters()])
+      feed = [T(c['eps_mix'][i])]
       torch.distributions.Beta.sample = lambda self, *a, **k: feed.pop(0)
       try:
         with NoiseFeed() as nf:
@@ -301,7 +331,10 @@ def gen_gail_deep():
       b = c['policy'][i]
       with torch.inference_mode():
         out[f'{name}.reward_{k}'] = N_(d.predict_reward(T(b['states']), T(b['actions'])))
+        if f64 is not None:
+          f64[f'{name}.reward_{k}'] = N_(twin64(d).predict_reward(T(b['states']).double(), T(b['actions']).double()))
     out[f'{name}.exp_avg'] = opt_state(opt, 'exp_avg')
+  if f64 is not None: return
   np.savez_compressed(os.path.join(HERE, 'gail_deep.npz'), **out)
 
 
@@ -361,17 +394,25 @@ def gen_gmmil():
   np.savez_compressed(os.path.join(HERE, 'gmmil.npz'), **out)
 
 
-def gen_pwil():
-  N, D, steps, Th = 400, 10, 260, 120
-  atoms, agent = gi.pwil_case(21, N, D, steps)
-  S, A = D - 3, 3
+def run_pwil(seed, N, D, steps, Th, A, double=False):
+  """PWILDiscriminator.compute_reward over `steps` agent atoms with a reset() every Th (models.py:216-249). double=True: the same code on float64 atoms."""
+  atoms, agent = gi.pwil_case(seed, N, D, steps)
+  S = D - A
   mem = ref_memory.ReplayMemory(N, S, A, False, transitions=dict(states=T(atoms[:, :S]), actions=T(atoms[:, S:]), rewards=torch.zeros(N), next_states=T(atoms[:, :S]), terminals=torch.zeros(N), timeouts=torch.zeros(N), weights=torch.ones(N), num_trajectories=4))
+  cast = (lambda t: t.double()) if double else (lambda t: t)
+  if double:
+    mem.states, mem.actions = mem.states.double(), mem.actions.double()
   d = ref_models.PWILDiscriminator(S, A, DictConfig(state_only=False, reward_scale=5, reward_bandwidth_scale=5), mem, Th)
   rewards = []
   for t in range(steps):
-    rewards.append(d.compute_reward(T(agent[t:t + 1, :S]), T(agent[t:t + 1, S:])))
+    rewards.append(d.compute_reward(cast(T(agent[t:t + 1, :S])), cast(T(agent[t:t + 1, S:]))))
     if t % Th == Th - 1:
       d.reset()
+  return d, np.array(rewards, np.float64)
+
+
+def gen_pwil():
+  d, rewards = run_pwil(21, 400, 10, 260, 120, 3)
   np.savez_compressed(os.path.join(HERE, 'pwil.npz'), rewards=np.array(rewards, np.float64), scale=N_(d.data_scale), offset=N_(d.data_offset), remaining=np.array([d.expert_weights.numel()]))
 
 
@@ -442,7 +483,7 @@ class DropoutFeed:
     assert not self.masks, 'unused dropout masks'
 
 
-def gen_dril():
+def gen_dril(f64=None):
   """SoftActor with the DRIL discriminator config (models.py:84-120) in train mode: BC updates, uncertainty, threshold, reward; depth 1-2, tanh / relu."""
   out = {}
   for name, kw, lr, wd in gi.DRIL_CASES:
@@ -470,7 +511,13 @@ def gen_dril():
         out[f'{name}.reward'] = N_(d.predict_reward(q['states'], q['actions']))
       with DropoutFeed(list(qm)):
         out[f'{name}.query_uncertainty'] = N_(d._get_action_uncertainty(q['states'], q['actions']))
+      if f64 is not None:
+        d64 = twin64(d)
+        for tag, bb, mm in (('expert', e, em), ('query', q, qm)):
+          with DropoutFeed([m.double() for m in mm]):
+            f64[f'{name}.{tag}_uncertainty'] = N_(d64._get_action_uncertainty(bb['states'].double(), bb['actions'].double()))
     out[f'{name}.hyper'] = np.array([lr, wd], np.float64)
+  if f64 is not None: return
   np.savez_compressed(os.path.join(HERE, 'dril.npz'), **out)
 
 
@@ -497,6 +544,81 @@ def gen_dataset():
   np.savez_compressed(os.path.join(HERE, 'dataset.npz'), **out)
 
 
+# ---------------------------------------------------------------- the sizes bench.py times
+TIMED_GAIL = dict(lr=0.0002778119723405689, weight_decay=8.46588535234332, grad_penalty=0.2799364347010851, entropy_bonus=0.24145587952807546)  # conf/optimised_hyperparameters/GAIL_5_trajectories.yaml
+
+
+def timed_gail_eps_mix():
+  return np.random.RandomState(4036).uniform(size=1024).astype(np.float32)   # mixup_alpha = 1 (conf/algorithm/GAIL.yaml): Beta(1, 1) = U(0, 1)
+
+
+def gen_timed_sizes():
+  """Reference outputs at the sizes the benchmarks run: PWIL against N = 25,000 atoms, D = 24, T = 1000 over 1,100 steps including a
+  reset(); GMMIL.predict_reward at B = 1024, D = 120 (BASELINE.json configs[3]), the full reward vector; one adversarial_imitation_update at B = 1024 with
+  the tuned GAIL_5 hyper-parameters (Mixup, spectral norm, gradient penalty, entropy bonus)."""
+  out = {}
+  d, rewards = run_pwil(22, 25000, 24, 1100, 1000, 6)
+  out['pwil25k.rewards'], out['pwil25k.remaining'] = rewards, np.array([d.expert_weights.numel()])
+  _, out['pwil25k.rewards_f64'] = run_pwil(22, 25000, 24, 1100, 1000, 6, double=True)
+
+  X, E, w, we = gi.gmmil_case(13, 1024, 1024, 120)
+  S = 112
+  g = ref_models.GMMILDiscriminator(S, 8, DictConfig(state_only=False))
+  args = (T(X[:, :S]), T(X[:, S:]), T(E[:, :S]), T(E[:, S:]), T(w), T(we))
+  out['gmmil1024.reward_first'] = N_(g.predict_reward(*args))
+  out['gmmil1024.gammas'] = np.array([g.gamma_1, g.gamma_2], np.float64)
+  X2, _, w2, _ = gi.gmmil_case(14, 1024, 1024, 120)
+  out['gmmil1024.reward_second'] = N_(g.predict_reward(T(X2[:, :S]), T(X2[:, S:]), args[2], args[3], T(w2), args[5]))
+  g64 = ref_models.GMMILDiscriminator(S, 8, DictConfig(state_only=False))
+  g64.gamma_1, g64.gamma_2 = g.gamma_1, g.gamma_2   # same frozen bandwidths; the kernel sums in float64
+  r64 = []
+  for i in range(0, 1024, 128):   # row blocks: [128, 1024, 120] float64 temporaries instead of [1024, 1024, 120]; the self term needs all rows -> weights of the full set
+    wn, wen = (T(w2) / T(w2).sum()).double(), (T(we) / T(we).sum()).double()
+    xb, xall, eall = T(X2[i:i + 128]).double(), T(X2).double(), T(E).double()
+    sim = sum((wn[i:i + 128, None] * torch.exp(-gam * ref_models._squared_distance(xb, eall)) * wen[None, :]).sum(1) for gam in (g.gamma_1, g.gamma_2))
+    slf = sum((wn[i:i + 128, None] * torch.exp(-gam * ref_models._squared_distance(xb, xall)) * wn[None, :]).sum(1) for gam in (g.gamma_1, g.gamma_2))
+    r64.append(N_(sim - slf))
+  out['gmmil1024.reward_second_f64'] = np.concatenate(r64)
+
+  c = gi.gail_case(36, env='halfcheetah', hidden=64, batch=1024, steps=1)
+  dd, icfg = build_disc(c)
+  icfg.update(loss_function='Mixup', grad_penalty=TIMED_GAIL['grad_penalty'], mixup_alpha=1, entropy_bonus=TIMED_GAIL['entropy_bonus'], pos_class_prior=0.7, nonnegative_margin=float('inf'))
+  opt = torch.optim.AdamW(dd.parameters(), lr=TIMED_GAIL['lr'], weight_decay=TIMED_GAIL['weight_decay'])
+  dd.train()
+  feed, orig = [T(timed_gail_eps_mix())], torch.distributions.Beta.sample
+  torch.distributions.Beta.sample = lambda self, *a, **k: feed.pop(0)
+  try:
+    with NoiseFeed() as nf:
+      nf.rand.append(T(c['eps'][0]))
+      ref_training.adversarial_imitation_update(None, dd, tbatch(c['policy'][0]), tbatch(c['expert'][0]), opt, icfg)
+  finally:
+    torch.distributions.Beta.sample = orig
+  dd.eval()
+  out['gail1024.g_1'] = np.concatenate([N_(p.grad).ravel() for p in dd.parameters()]); out['gail1024.p_1'] = flat(dd)
+  for li, nm in ((0, '1'), (2, '2')):
+    out[f'gail1024.u{nm}_1'] = N_(dd.g[li].parametrizations.weight[0]._u); out[f'gail1024.v{nm}_1'] = N_(dd.g[li].parametrizations.weight[0]._v)
+  b = c['policy'][0]
+  with torch.inference_mode():
+    out['gail1024.reward_1'] = N_(dd.predict_reward(T(b['states']), T(b['actions'])))
+    out['gail1024.reward_1_f64'] = N_(twin64(dd).predict_reward(T(b['states']).double(), T(b['actions']).double()))
+  np.savez_compressed(os.path.join(HERE, 'timed_sizes.npz'), **out)
+
+
+def gen_f64():
+  """Float64 evaluations of the reference at the comparison sites whose float32 tolerance the GPU tests widen beyond rtol 1e-5 (rewards = a difference of
+  logs near D = 1/2, log pi of actions at the clamp, second-order gradients of deep discriminators, exp(-1000 cost), a variance of 5 exponentials): the tests
+  then bound |hip - f64| by the reference's own |f32 - f64| instead of a hand-picked number."""
+  f64 = {}
+  gen_gail('gail_default', gi.gail_case(31), lr=3e-5, weight_decay=10, grad_penalty=1.0, entropy_bonus=0.0, f64=f64)
+  gen_gail('gail_h128_ent', gi.gail_case(32, hidden=128), lr=7.3e-5, weight_decay=6.35, grad_penalty=0.32, entropy_bonus=0.0155, f64=f64)
+  gen_gail('gail_nosn_nogp', gi.gail_case(33, env='hopper', hidden=32, batch=128, spectral_norm=False), lr=3e-4, weight_decay=0.0, grad_penalty=0.0, entropy_bonus=0.0, f64=f64)
+  gen_bc('bc_hopper', 'hopper', 256, 256, 3, f64=f64)
+  gen_gail_deep(f64=f64)
+  gen_dril(f64=f64)
+  _, f64['pwil.rewards'] = run_pwil(21, 400, 10, 260, 120, 3, double=True)
+  np.savez_compressed(os.path.join(HERE, 'f64_brackets.npz'), **f64)
+
+
 if __name__ == '__main__':
   only = set(sys.argv[1:])  # e.g. `make_golden.py adril` regenerates just that fixture
   want = lambda tag: not only or tag in only
@@ -519,3 +641,5 @@ if __name__ == '__main__':
   if want('red'): gen_red()
   if want('dril'): gen_dril()
   if want('dataset'): gen_dataset()
+  if want('timed_sizes'): gen_timed_sizes()
+  if want('f64'): gen_f64()

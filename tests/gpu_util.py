@@ -53,6 +53,38 @@ def close_params(a, b, name, lr, steps=1, rtol=1e-5, atol_scale=1e-5, outlier_fr
   assert frac <= outlier_frac, f'{name}: {frac:.2e} of the elements exceed the tight bound (allowed {outlier_frac:.0e}); worst {err[worst]:.3e} at {worst}'
 
 
+def bracket(hip, ref32, ref64, name, factor=2.0, floor=2e-7):
+  """Conditioning bracket for a comparison site whose float32 tolerance is wider than rtol 1e-5: `ref64` is the REFERENCE's own code evaluated in float64 on
+  the same inputs (tests/golden/f64_brackets.npz, make_golden.py gen_f64), `ref32` its float32 result. The HIP result may be at most `factor` times as far
+  from the float64 value as the reference's float32 result is (max norm and RMS; `floor` = 2 ulp of the tensor's scale, for sites where the reference
+  happens to round exactly). Returns (hip error, reference error) in units of the scale."""
+  hip, ref32, ref64 = (np.asarray(x, np.float64) for x in (hip, ref32, ref64))
+  assert hip.shape == ref32.shape == ref64.shape, (name, hip.shape, ref32.shape, ref64.shape)
+  scale = max(float(np.abs(ref64).max()), 1e-30)
+  eh, er = np.abs(hip - ref64), np.abs(ref32 - ref64)
+  assert eh.max() <= factor * er.max() + floor * scale, f'{name}: max |hip - f64| = {eh.max():.3e} vs reference f32 {er.max():.3e} (scale {scale:.3e}): more than {factor}x the reference\'s own float32 error'
+  rh, rr = float(np.sqrt((eh ** 2).mean())), float(np.sqrt((er ** 2).mean()))
+  assert rh <= factor * rr + floor * scale, f'{name}: rms |hip - f64| = {rh:.3e} vs reference f32 {rr:.3e} (scale {scale:.3e})'
+  return eh.max() / scale, er.max() / scale
+
+
+def close_sparse(a, b, name, rtol=1e-5, atol_scale=2e-6, outlier_frac=2e-3, outlier_atol_scale=1e-3):
+  """`close` for gradient-like tensors of a CHAIN of updates (Adam moments): a ReLU pre-activation that lands within rounding of 0 takes a different sign
+  in two correct fp32 evaluations, which changes one sample's contribution to one weight row (and what it back-propagates) by a finite amount. Measured
+  signature (population replay, 6 updates): 3e-9 everywhere except 64 elements = one row of one critic's W2 plus that sample's first-layer terms, off by
+  2e-4 of the tensor's scale and decaying by beta1 per update. Hence: all but `outlier_frac` of the elements within the tight bound, every element within
+  `outlier_atol_scale` of the tensor's scale."""
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  assert a.shape == b.shape, (name, a.shape, b.shape)
+  assert np.isfinite(a).all(), f'{name}: non-finite values in the HIP result'
+  scale = max(float(np.abs(b).max()), 1e-30)
+  err = np.abs(a - b) - rtol * np.abs(b)
+  i = int(err.argmax())
+  assert float(err.max()) <= outlier_atol_scale * scale, f'{name}: element {i} off by {err.max():.3e} (> {outlier_atol_scale:.0e} of the scale {scale:.3e}): hip {a.ravel()[i]:.8e} vs oracle {b.ravel()[i]:.8e}'
+  frac = float((err > atol_scale * scale).mean())
+  assert frac <= outlier_frac, f'{name}: {frac:.2e} of the elements exceed the tight bound (allowed {outlier_frac:.0e}); worst {err.max():.3e} at {i}'
+
+
 def tbatch(b):
   return {k: T(v) for k, v in b.items()}
 

@@ -24,7 +24,7 @@ if torch.cuda.is_available():
   from imitation_learning_amd import _lib
   from imitation_learning_amd import memory as il_memory
   from imitation_learning_amd import training as il_training
-  from gpu_util import DEV, N, T, Cfg, close, close_params, crit_from_flat, fill_memory, make_disc, make_sac, make_sac_oracle, tbatch
+  from gpu_util import DEV, N, T, Cfg, bracket, close, close_params, crit_from_flat, fill_memory, make_disc, make_sac, make_sac_oracle, tbatch
 
 
 def load(golden_dir, name):
@@ -159,9 +159,12 @@ def test_bc_update_matches_oracle_and_reference(golden_dir):
   opt = il.AdamW(actor, lr=2.5e-4, weight_decay=0.01)
   m, v = np.zeros_like(p), np.zeros_like(p)
   shapes = onets.mlp_shapes(S, 256, 2, 2 * A)
+  f64 = load(golden_dir, 'f64_brackets')
   for k in range(1, 4):
     b = gi.transitions(rs, 256, S, A, weighted=True)
     b['actions'][:3] = np.array([1.0, -1.0, 0.9999999])[:, None]
+    if k == 1:   # why log pi is compared at 1e-4 below: atanh at the clamp (|a| = 1 - 1e-6) amplifies ulps. Bracket on the initial parameters (identical on both sides):
+      bracket(N(actor.log_prob(T(b['states']), T(b['actions']))), f64['bc_hopper.logp_init_f32'], f64['bc_hopper.logp_init'], 'bc log pi (initial parameters)')
     loss = il.behavioural_cloning_update(actor, tbatch(b), opt)
     oloss = osac.bc_update(p, m, v, k, shapes, A, b, lr=2.5e-4, weight_decay=0.01)
     close(N(loss), oloss, f'bc loss {k}', rtol=1e-5, atol_scale=1e-5)
@@ -214,7 +217,7 @@ GAIL_CASES = [
 
 @pytest.mark.parametrize('name,case,hp', GAIL_CASES)
 def test_gail_update_matches_oracle_and_reference(golden_dir, name, case, hp):
-  g, c = load(golden_dir, name), gi.gail_case(**case)
+  g, c, f64 = load(golden_dir, name), gi.gail_case(**case), load(golden_dir, 'f64_brackets')
   d, ods, icfg = make_disc(c)
   icfg.update(loss_function='BCE', grad_penalty=hp['grad_penalty'], entropy_bonus=hp['entropy_bonus'], mixup_alpha=1, pos_class_prior=0.7, nonnegative_margin=float('inf'))
   opt = il.AdamW(d, lr=hp['lr'], weight_decay=hp['weight_decay'])
@@ -238,6 +241,19 @@ def test_gail_update_matches_oracle_and_reference(golden_dir, name, case, hp):
       close(N(r), g[f'reward_{rf}_{k}'], f'golden reward {rf} {k}', rtol=1e-4, atol_scale=1e-5)
     d.reward_function = 'AIRL'
     close(N(d(T(pb['states']), T(pb['actions']))), g[f'logits_{k}'], f'golden logits {k}', atol_scale=4e-6)
+    # why rewards are compared at 1e-4: log(D) - log1p(-D) crosses 0 near D = 1/2 (the reference's own float32 result is off by up to 1.5e-3 elementwise against its
+    # float64 evaluation). Bracket on the REFERENCE's parameters / u / v of this step, so that both float32 results evaluate the same function:
+    keep = d.flat.clone(), {nm: val.clone() for nm, val in d.views().items()} if c['spectral_norm'] else {}
+    d.flat.copy_(T(g[f'p_{k}']))
+    for nm, val in (d.views().items() if c['spectral_norm'] else ()):
+      val.copy_(T(g[f'{nm}_{k}']))
+    for rf in ('AIRL', 'GAIL', 'FAIRL'):
+      d.reward_function = rf
+      bracket(N(d.predict_reward(T(pb['states']), T(pb['actions']))), g[f'reward_{rf}_{k}'], f64[f'{name}.reward_{rf}_{k}'], f'{name} reward {rf} {k}')
+    d.reward_function = 'AIRL'
+    d.flat.copy_(keep[0])
+    for nm, val in (d.views().items() if c['spectral_norm'] else ()):
+      val.copy_(keep[1][nm])
 
 
 # ------------------------------------------------------------------------------------------------ GMMIL / PWIL
@@ -298,6 +314,7 @@ def test_pwil_matches_oracle_and_reference(golden_dir):
       d.reset(); o.reset()
   np.testing.assert_allclose(rewards, orewards, rtol=2e-5)
   np.testing.assert_allclose(rewards, g['rewards'], rtol=2e-5)
+  bracket(rewards, g['rewards'], load(golden_dir, 'f64_brackets')['pwil.rewards'], 'PWIL rewards')   # exp(-beta T / sqrt(D) * cost) turns 1e-8 of cost into 1e-5 of reward
   assert int((d.expert_weights >= 0).sum()) == int(g['remaining'][0])
 
 
@@ -741,6 +758,9 @@ def test_dril_matches_reference(golden_dir, name, kw):
   ue = N(d._get_action_uncertainty(e['states'], e['actions'], masks=em))
   ref_ue = g[f'{name}.expert_uncertainty']
   assert np.abs(ue - ref_ue).max() <= 1e-4 * np.abs(ref_ue).max()
+  f64 = load(golden_dir, 'f64_brackets')
+  bracket(ue, ref_ue, f64[f'{name}.expert_uncertainty'], f'{name} expert uncertainty')
+  bracket(N(d._get_action_uncertainty(q['states'], q['actions'], masks=qm)), g[f'{name}.query_uncertainty'], f64[f'{name}.query_uncertainty'], f'{name} query uncertainty')
   d.set_uncertainty_threshold(e['states'], e['actions'], 0.9, masks=em)
   assert abs(d.q - float(g[f'{name}.q'][0])) <= 1e-4 * max(abs(d.q), np.abs(ref_ue).max())
   d.q = float(g[f'{name}.q'][0])
@@ -945,7 +965,7 @@ def test_batch_gather_is_rejected_where_it_is_not_honoured():
 @pytest.mark.parametrize('name', [n for n, *_ in gi.GAIL_DEEP_CASES])
 def test_gail_deep_discriminator_matches_reference(golden_dir, name):
   from oracle import gail_deep as ogd
-  g = load(golden_dir, 'gail_deep')
+  g, f64 = load(golden_dir, 'gail_deep'), load(golden_dir, 'f64_brackets')
   _, kw, loss, (lr, wd, gp, ent), rf = next(c for c in gi.GAIL_DEEP_CASES if c[0] == name)
   c = gi.gail_deep_case(**kw)
   icfg = Cfg(state_only=False, spectral_norm=c['spectral_norm'], loss_function=loss, grad_penalty=gp, mixup_alpha=0.7, entropy_bonus=ent, pos_class_prior=0.7, nonnegative_margin=float('inf'),
@@ -969,11 +989,13 @@ def test_gail_deep_discriminator_matches_reference(golden_dir, name):
                           loss_function=loss, eps_mix=c['eps_mix'][i])
     close(N(opt.grad), g[f'{name}.g_{i + 1}'], f'{name} gradient {i + 1} (reference)', rtol=2e-5, atol_scale=1e-5)
     close(N(opt.grad), ogr, f'{name} gradient {i + 1} (oracle)', rtol=2e-5, atol_scale=1e-5)
+    bracket(N(opt.grad), g[f'{name}.g_{i + 1}'], f64[f'{name}.g_{i + 1}'], f'{name} gradient {i + 1}')   # the same update from the same float32 state, evaluated by the reference in float64
     if c['spectral_norm']:
       close(N(d.sn), g[f'{name}.sn_{i + 1}'], f'{name} u / v after update {i + 1}', rtol=2e-5, atol_scale=1e-5)
     d.flat.copy_(T(g[f'{name}.p_{i + 1}']))
     r = d.predict_reward(T(pb['states']), T(pb['actions']))
     close(N(r), g[f'{name}.reward_{i + 1}'], f'{name} reward {i + 1}', rtol=5e-5, atol_scale=1e-5)
+    bracket(N(r), g[f'{name}.reward_{i + 1}'], f64[f'{name}.reward_{i + 1}'], f'{name} reward {i + 1}')
   assert int(opt.step_count[0]) == len(c['policy'])
 
 

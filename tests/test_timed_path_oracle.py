@@ -29,7 +29,7 @@ if torch.cuda.is_available():
   import imitation_learning_amd as il
   from imitation_learning_amd import _lib
   from imitation_learning_amd import training as il_training
-  from gpu_util import DEV, N, Cfg, close, close_params, crit_from_flat
+  from gpu_util import DEV, N, Cfg, close, close_params, close_sparse, crit_from_flat
 
 S, A, H, HD, B = 18, 6, 256, 64, 256
 LR, LR_D, WD_D, DISCOUNT, POLYAK, ENT = 3e-4, 3e-5, 10.0, 0.97, 0.99, -0.5 * 6
@@ -116,8 +116,8 @@ def compare_learner(o, nets, plan, k, tag=''):
   close_params(N(actor.flat), o.st.actor, f'{tag}actor after {k}', LR, k); close_params(crit_from_flat(critic, critic.flat), o.st.critic, f'{tag}critic after {k}', LR, k)
   close_params(crit_from_flat(critic, target.flat), o.st.target, f'{tag}target after {k}', LR, k)
   close(N(log_alpha), o.st.log_alpha, f'{tag}log_alpha after {k}', atol_scale=s)
-  close(N(ao.exp_avg), o.st.actor_m, f'{tag}actor exp_avg', atol_scale=s); close(N(ao.exp_avg_sq), o.st.actor_v, f'{tag}actor exp_avg_sq', atol_scale=s)
-  close(crit_from_flat(critic, co.exp_avg), o.st.critic_m, f'{tag}critic exp_avg', atol_scale=s); close(crit_from_flat(critic, co.exp_avg_sq), o.st.critic_v, f'{tag}critic exp_avg_sq', atol_scale=s)
+  close_sparse(N(ao.exp_avg), o.st.actor_m, f'{tag}actor exp_avg', atol_scale=s); close_sparse(N(ao.exp_avg_sq), o.st.actor_v, f'{tag}actor exp_avg_sq', atol_scale=s)
+  close_sparse(crit_from_flat(critic, co.exp_avg), o.st.critic_m, f'{tag}critic exp_avg', atol_scale=s); close_sparse(crit_from_flat(critic, co.exp_avg_sq), o.st.critic_v, f'{tag}critic exp_avg_sq', atol_scale=s)
   close(N(to.exp_avg), o.st.alpha_m, f'{tag}alpha exp_avg', atol_scale=s)
   close(N(disc.flat), o.ds.pack(), f'{tag}discriminator after {k}', atol_scale=4e-6 * k)
   close(N(do.exp_avg), o.ds.m, f'{tag}discriminator exp_avg', atol_scale=4e-6 * k); close(N(do.exp_avg_sq), o.ds.v, f'{tag}discriminator exp_avg_sq', atol_scale=4e-6 * k)
