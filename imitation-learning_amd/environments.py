@@ -5,7 +5,8 @@ accelerated (out of scope). `SyntheticD4RLEnv` reproduces what th
 action shapes of the four D4RL locomotion tasks, the absorbing-indicator bit, action clipping, `max_episode_steps`, early
 termination for the tasks that have it, and `get_dataset()` with the reference's trajectory split, truncation, absorbing-state
 wrapping, importance weights and sub-sampling semantics (environments.py:63-125) on synthetic expert rollouts.
-If gym and d4rl ARE importable, `D4RLEnv` wraps the real thing with the same interface.
+If gym and d4rl ARE importable, `make_env` returns `GymD4RLEnv`, the real task behind the same interface (exercised in tests/test_config_cpu.py
+against a stub gym; the real packages cannot be installed here).
 """
 from __future__ import annotations
 
@@ -162,14 +163,77 @@ def dataset_to_memory(dataset: dict, absorbing: bool, trajectories: int = 0, sub
   return ReplayMemory(tr['states'].size(0), S + (1 if absorbing else 0), A, absorbing, transitions=tr, device=device)
 
 
+class GymD4RLEnv:
+  """The real D4RL locomotion task behind the interface the training loop uses (reference environments.py:20-61): `{env}-expert-v2` from gym + d4rl,
+  observations / actions as [1, dim] float32 CPU tensors, the absorbing indicator bit appended to every observation when `absorbing`, actions clipped to
+  the action space, `max_episode_steps` from the TimeLimit wrapper, D4RL's reference scores on `env.env`, and `get_dataset()` = the same ingest as the
+  synthetic environment (`dataset_to_memory`) on the arrays d4rl ships."""
+
+  def __init__(self, env_name: str, absorbing: bool, load_data: bool = False):
+    import d4rl  # noqa: F401  (registers the `-expert-v2` ids)
+    import gym
+    assert env_name in ENVS
+    self.env, self.absorbing = gym.make(f'{env_name}-expert-v2'), absorbing
+    self.dataset = None
+    if load_data:
+      raw = self.env.get_dataset()
+      if 'next_observations' not in raw:   # older d4rl files: what d4rl.qlearning_dataset does
+        raw = dict(raw); raw['next_observations'] = np.concatenate([raw['observations'][1:], raw['observations'][-1:]])
+      self.dataset = {k: torch.as_tensor(np.ascontiguousarray(raw[k]), dtype=torch.float32) for k in ('observations', 'actions', 'next_observations', 'terminals', 'timeouts')}
+    space = self.env.action_space
+    self._low, self._high = torch.as_tensor(space.low, dtype=torch.float32), torch.as_tensor(space.high, dtype=torch.float32)
+    obs_dim = int(self.env.observation_space.shape[0])
+    self.observation_space, self.action_space = _Space(obs_dim + (1 if absorbing else 0)), _Space(int(space.shape[0]))
+    self.action_space.low, self.action_space.high = self._low, self._high
+
+  def _obs(self, x) -> Tensor:
+    state = torch.as_tensor(np.asarray(x), dtype=torch.float32).reshape(1, -1)
+    return torch.cat([state, torch.zeros(1, 1)], dim=1) if self.absorbing else state   # the absorbing rewrite itself happens in the replay memory
+
+  def reset(self) -> Tensor:
+    out = self.env.reset()
+    return self._obs(out[0] if isinstance(out, tuple) else out)   # gym >= 0.26 returns (obs, info)
+
+  def step(self, action: Tensor) -> Tuple[Tensor, float, bool]:
+    a = torch.max(torch.min(action.detach().to('cpu', torch.float32), self._high), self._low)[0].numpy()
+    out = self.env.step(a)
+    obs, reward, done = out[0], out[1], (bool(out[2]) if len(out) == 4 else bool(out[2]) or bool(out[3]))   # gym >= 0.26: (obs, r, terminated, truncated, info)
+    return self._obs(obs), float(reward), done
+
+  def seed(self, seed: int):
+    return self.env.seed(seed) if hasattr(self.env, 'seed') else [seed]
+
+  def render(self):
+    return self.env.render()
+
+  def close(self):
+    self.env.close()
+
+  @property
+  def max_episode_steps(self) -> int:
+    return int(self.env._max_episode_steps)
+
+  def get_dataset(self, trajectories: int = 0, subsample: int = 1, device=None) -> ReplayMemory:
+    return dataset_to_memory(self.dataset, self.absorbing, trajectories, subsample, device)
+
+
 def make_env(env_name: str, absorbing: bool, load_data: bool = False, **kw):
-  """Real D4RL when importable, otherwise the synthetic stand-in (this environment)."""
-  try:
-    import d4rl  # noqa: F401
-    import gym  # noqa: F401
-  except Exception:
-    return SyntheticD4RLEnv(env_name, absorbing, load_data, **kw)
-  raise NotImplementedError('gym + d4rl detected: wrap gym.make(f"{env_name}-expert-v2") behind this interface (environments.py:21-61 of the reference)')
+  """The real D4RL task when gym + d4rl are importable (`GymD4RLEnv`), otherwise the synthetic stand-in - loudly, once: results on it say nothing about D4RL scores.
+  `+synthetic_env.*` keys force the stand-in (they have no meaning for the real task)."""
+  if not kw:
+    try:
+      import d4rl  # noqa: F401
+      import gym  # noqa: F401
+      return GymD4RLEnv(env_name, absorbing, load_data)
+    except ImportError:
+      pass
+  global _WARNED
+  if not _WARNED and not kw:
+    import warnings
+    warnings.warn('gym / d4rl are not importable: using SyntheticD4RLEnv (D4RL-shaped linear-Gaussian stand-in). Normalised scores are not D4RL scores.', RuntimeWarning, stacklevel=2)
+    _WARNED = True
+  return SyntheticD4RLEnv(env_name, absorbing, load_data, **kw)
 
 
+_WARNED = False
 D4RLEnv = make_env

@@ -172,17 +172,18 @@ class ReplayMemory(torch.utils.data.Dataset):
     self._sync_ring_state()
 
   def transfer_transitions(self, memory: 'ReplayMemory'):
-    """memory.py:46-48: re-append every slot of `memory` (weights reset to 1). Done as one bulk device copy, cursor walked on the host."""
+    """memory.py:46-48: re-append every slot of `memory` (weights reset to 1). Done as one bulk device copy, cursor walked on the host. The reference appends one
+    row at a time, so when the source holds more rows than this ring the LAST write to a slot wins: only the final `self.size` rows are copied (a parallel
+    launch over all n rows would race on the slots that are written twice), to the slots the sequential appends would have left them in."""
     n = len(memory)
-    src = memory.ring[:n].clone()
-    src[:, self.layout['weights'][0]] = 1.0
     flags = (memory.terminals[:n] + memory.timeouts[:n]).ne(0).cpu()
-    first = min(n, self.size - self.idx)
-    _lib.check(_lib.lib().il_replay_write_rows(_lib.ptr(self.ring), self.size, self.row, self.idx, _lib.ptr(src), n, _lib.stream_ptr()))
-    self.num_trajectories += int(flags.sum())
+    skip = max(0, n - self.size)                      # rows that a later append overwrites anyway
+    src = memory.ring[skip:n].clone()
+    src[:, self.layout['weights'][0]] = 1.0
+    _lib.check(_lib.lib().il_replay_write_rows(_lib.ptr(self.ring), self.size, self.row, (self.idx + skip) % self.size, _lib.ptr(src), n - skip, _lib.stream_ptr()))
+    self.num_trajectories += int(flags.sum())         # every append counts its episode end, overwritten or not (memory.py:44)
     self.full = self.full or (self.idx + n >= self.size)
     self.idx = (self.idx + n) % self.size
-    del first
     self._sync_ring_state()
 
   def stream(self) -> IndexStream:

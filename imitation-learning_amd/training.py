@@ -591,13 +591,15 @@ class UpdatePlan:
     if self.device_sync and not self._probe_device_sync(graph=True):
       self._set_device_sync(False)   # the runtime serialises graph branches here (e.g. a counter-collecting profiler): keep stream dependencies
     self.memory.stream().device_state(self.rows.device)  # materialise the device copy of the MT19937 state before capture starts
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-      for _ in range(warmup):
-        self.run()
-    torch.cuda.current_stream().wait_stream(s)
+    # Warm-up updates run on the CALLER's stream, i.e. on the (main, side) pair the probe above validated. A fresh warm-up stream may be mapped onto the
+    # hardware queue the side stream uses (HIP multiplexes streams onto a few HSA queues, round-robin at creation): the two branches then serialise, the
+    # device-side waits of those updates expire and they consume stale rewards (seen once in the full test suite: 48 expired waits per warm-up update).
+    for _ in range(warmup):
+      self.run()
     torch.cuda.synchronize()
+    if warmup and self.sync_timeouts():
+      raise RuntimeError(f'UpdatePlan.capture: {self.sync_timeouts()} device-side waits expired during the warm-up updates (the two branches did not run concurrently); '
+                         'their results are invalid. Set IL_DEVICE_SYNC=0 to keep plain stream dependencies.')
     if self.device_sync:   # two graphs, one per branch, replayed on two streams; no edge between them (see _run_update)
       self.graph_side, self._capturing = torch.cuda.CUDAGraph(), 'side'
       with torch.cuda.graph(self.graph_side, stream=self.side):

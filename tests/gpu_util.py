@@ -53,11 +53,11 @@ def close_params(a, b, name, lr, steps=1, rtol=1e-5, atol_scale=1e-5, outlier_fr
   assert frac <= outlier_frac, f'{name}: {frac:.2e} of the elements exceed the tight bound (allowed {outlier_frac:.0e}); worst {err[worst]:.3e} at {worst}'
 
 
-def bracket(hip, ref32, ref64, name, factor=2.0, floor=2e-7):
+def bracket(hip, ref32, ref64, name, factor=2.0, floor=1e-6):
   """Conditioning bracket for a comparison site whose float32 tolerance is wider than rtol 1e-5: `ref64` is the REFERENCE's own code evaluated in float64 on
   the same inputs (tests/golden/f64_brackets.npz, make_golden.py gen_f64), `ref32` its float32 result. The HIP result may be at most `factor` times as far
-  from the float64 value as the reference's float32 result is (max norm and RMS; `floor` = 2 ulp of the tensor's scale, for sites where the reference
-  happens to round exactly). Returns (hip error, reference error) in units of the scale."""
+  from the float64 value as the reference's float32 result is (max norm and RMS), plus `floor` = 1e-6 of the tensor's scale = a tenth of the contract's
+  rtol 1e-5 (where the reference itself is within a couple of ulp of float64, a factor between two libm implementations means nothing). Returns (hip error, reference error) in units of the scale."""
   hip, ref32, ref64 = (np.asarray(x, np.float64) for x in (hip, ref32, ref64))
   assert hip.shape == ref32.shape == ref64.shape, (name, hip.shape, ref32.shape, ref64.shape)
   scale = max(float(np.abs(ref64).max()), 1e-30)

@@ -69,3 +69,51 @@ def test_expert_data_ingest_matches_reference(tmp_path):
   assert environments.load_dataset_file(path)['next_observations'].shape == raw['observations'].shape
   with pytest.raises(ImportError):
     environments.load_dataset_file(str(tmp_path / 'expert.hdf5'))
+
+
+def test_make_env_wraps_the_real_task_when_gym_and_d4rl_import(monkeypatch):
+  """`make_env` with importable gym + d4rl returns GymD4RLEnv (reference environments.py:20-61). The packages cannot be installed here, so a stub gym
+  stands in: what is checked is the wrapper's own behaviour - absorbing bit, action clipping, batch dimension, horizon, dataset ingest."""
+  import sys
+  import types
+  import numpy as np
+  import torch
+  import imitation_learning_amd as il
+  from imitation_learning_amd import environments
+  sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), 'golden'))
+  import inputs as gi
+  raw = gi.raw_d4rl_dataset(81)
+
+  class Box:
+    def __init__(self, low, high): self.low, self.high, self.shape = np.asarray(low, np.float32), np.asarray(high, np.float32), (len(low),)
+
+  class FakeTask:
+    _max_episode_steps, ref_min_score, ref_max_score = 1000, -1.0, 99.0
+    observation_space, action_space = Box([-np.inf] * 5, [np.inf] * 5), Box([-1, -1], [1, 1])
+    def __init__(self): self.seen, self.t = None, 0
+    def get_dataset(self): return {k: v for k, v in raw.items()}
+    def reset(self): self.t = 0; return np.arange(5, dtype=np.float64)
+    def step(self, a): self.seen = a; self.t += 1; return np.full(5, self.t, np.float64), 0.5, self.t == 3, {}
+    def seed(self, s): return [s]
+    def close(self): pass
+  made = []
+  gym = types.ModuleType('gym'); gym.make = lambda name: made.append(name) or FakeTask()
+  monkeypatch.setitem(sys.modules, 'gym', gym); monkeypatch.setitem(sys.modules, 'd4rl', types.ModuleType('d4rl'))
+  env = environments.make_env('hopper', True, load_data=True)
+  assert type(env).__name__ == 'GymD4RLEnv' and made == ['hopper-expert-v2']
+  assert env.observation_space.shape == (6,) and env.action_space.shape == (2,) and env.max_episode_steps == 1000 and env.env.ref_max_score == 99.0
+  obs = env.reset()
+  assert obs.shape == (1, 6) and obs.dtype == torch.float32 and obs[0, -1] == 0 and obs[0, :5].tolist() == [0, 1, 2, 3, 4]
+  nxt, r, done = env.step(torch.tensor([[3.0, -0.25]]))
+  assert env.env.seen.tolist() == [1.0, -0.25] and nxt.shape == (1, 6) and r == 0.5 and done is False
+  env.step(torch.zeros(1, 2)); assert env.step(torch.zeros(1, 2))[2] is True
+  il.seed(17); got = env.get_dataset(trajectories=2, subsample=3, device='cpu')
+  il.seed(17); want = environments.dataset_to_memory(raw, True, 2, 3, device='cpu')
+  assert torch.equal(got.ring, want.ring) and got.num_trajectories == want.num_trajectories
+  plain = environments.make_env('hopper', False)
+  assert plain.reset().shape == (1, 5) and plain.dataset is None
+  # without the packages: the synthetic stand-in, with a warning
+  monkeypatch.setitem(sys.modules, 'gym', None)
+  environments._WARNED = False
+  with pytest.warns(RuntimeWarning, match='SyntheticD4RLEnv'):
+    assert type(environments.make_env('hopper', True)).__name__ == 'SyntheticD4RLEnv'

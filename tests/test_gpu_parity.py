@@ -77,6 +77,28 @@ def test_replay_matches_reference_bit_exact(golden_dir, name, seed, size, fill):
     np.testing.assert_array_equal(N(rows_out), N(mem.ring)[np.array(want)])
 
 
+@pytest.mark.parametrize('n_src,cap,pre', [(50, 64, 10), (50, 64, 40), (150, 64, 7), (128, 64, 0)])
+def test_transfer_transitions_matches_sequential_appends(n_src, cap, pre):
+  """memory.py:46-48 re-appends row by row; the bulk device copy must leave the ring, cursor, `full` and trajectory count exactly as that loop does - including a
+  source LARGER than the destination (train.py:30 clamps memory.size to `steps`), where the last write to a slot wins."""
+  S, A = 5, 2
+  rs = np.random.RandomState(n_src + cap)
+  tr = gi.transitions(rs, n_src, S, A, terminal_frac=0.1, weighted=True)
+  src = il.ReplayMemory(n_src, S, A, True, transitions={**{k: torch.from_numpy(v) for k, v in tr.items() if k != 'absorbing'}, 'num_trajectories': 3}, device=DEV)
+  osrc = oreplay.ReplayOracle(n_src, S, A, True, transitions={**tr, 'num_trajectories': 3})
+  dst, odst = il.ReplayMemory(cap, S, A, True, device=DEV), oreplay.ReplayOracle(cap, S, A, True)
+  filler = gi.transitions(rs, pre, S, A) if pre else None
+  for i in range(pre):
+    args = (i + 1, filler['states'][i:i + 1], filler['actions'][i:i + 1], float(filler['rewards'][i]), filler['next_states'][i:i + 1], False, False)
+    dst.append(args[0], *(torch.from_numpy(a) if isinstance(a, np.ndarray) else a for a in args[1:])); odst.append(*args)
+  dst.transfer_transitions(src); odst.transfer_transitions(osrc)
+  assert (dst.idx, dst.full, dst.num_trajectories) == (odst.idx, odst.full, odst.num_trajectories)
+  written = cap if odst.full else odst.idx
+  for k in oreplay.FIELDS:
+    np.testing.assert_array_equal(N(getattr(dst, k))[:written], getattr(odst, k)[:written], err_msg=k)
+  assert N(dst._ring_state).tolist() == [odst.idx, int(odst.full), cap]
+
+
 def test_replay_full_size_gather_property():
   """BASELINE size (capacity 1e6, HalfCheetah rows): gather == fancy indexing, checked through a checksum of every field."""
   S, A = gi.DIMS['halfcheetah']
@@ -359,6 +381,25 @@ def test_update_plan_graph_replay_equals_eager(algorithm):
   for a, b in zip(*results):
     assert np.isfinite(a).all()
     np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize('extra_streams', [0, 1, 2, 3, 5])
+def test_capture_warmup_runs_on_the_probed_stream_pair(extra_streams):
+  """HIP multiplexes streams onto a few hardware queues (round-robin at creation). capture() used to warm up on a fresh stream; when that stream shared a
+  queue with the plan's side stream the two branches serialised, the device-side waits expired (48 per update, seen in the full suite) and the warm-up updates
+  consumed stale rewards. The warm-up now runs on the caller's stream - the pair the probe validated - whatever else the process created before."""
+  keep = [torch.cuda.Stream() for _ in range(extra_streams)]
+  for s in keep:
+    with torch.cuda.stream(s):
+      torch.zeros(1, device=DEV)
+  il.seed(1); il_training._NOISE.clear()
+  plan, nets = _make_plan('GAIL', 5)
+  plan.capture(warmup=2)
+  for _ in range(3):
+    plan.replay()
+  torch.cuda.synchronize()
+  assert plan.device_sync and plan.sync_timeouts() == 0
+  del keep
 
 
 def test_update_plan_host_and_device_index_draws_agree():

@@ -41,6 +41,18 @@ def pretrain_bc(cfg, actor, expert_memory, state_size, action_size):
     il.behavioural_cloning_update(actor, batch, optimiser)
 
 
+def check_handoff(plan, step):
+  """The two branches of a captured GAIL update hand over through device counters with BOUNDED waits (include/il_hip.h il_sync): a wait that expires lets the
+  update proceed on stale rewards / discriminator weights and bumps a counter. That can only happen if something stops the two streams from running
+  concurrently after `capture()` validated them (a profiler attached mid-run, a CU mask, a co-tenant process). Training on such updates silently is worse
+  than stopping: raise, naming the switch that trades the hand-off for plain stream dependencies."""
+  if plan is None or not getattr(plan, 'device_sync', False): return
+  n = plan.sync_timeouts()
+  if n:
+    raise RuntimeError(f'step {step}: {n} device-side hand-off waits expired since the last check - the discriminator and SAC branches of the update did not run concurrently, '
+                       'so updates in this interval used stale rewards. Re-run with IL_DEVICE_SYNC=0 (stream dependencies instead of device counters).')
+
+
 def train(cfg, file_prefix: str = '') -> float:
   il_config.validate(cfg)
   dev = default_device()
@@ -181,7 +193,8 @@ def train(cfg, file_prefix: str = '') -> float:
           discriminator.train()
           il.adversarial_imitation_update(actor, discriminator, transitions, expert_transitions, discriminator_optimiser, cfg.imitation)
           discriminator.eval()
-        if cfg.imitation.mix_expert_data == 'mixed_batch' and cfg.algorithm != 'AdRIL': il.mix_expert_agent_transitions(transitions, expert_transitions)
+        if cfg.imitation.mix_expert_data == 'mixed_batch' and cfg.algorithm in ('DRIL', 'GAIL', 'GMMIL', 'RED'):   # train.py:175,183: only inside the imitation block, never for SAC / PWIL / AdRIL
+          il.mix_expert_agent_transitions(transitions, expert_transitions)
         if cfg.algorithm == 'AdRIL':
           discriminator.resample_and_relabel(transitions, expert_transitions, step, memory.num_trajectories, expert_memory.num_trajectories)
         if cfg.algorithm == 'GAIL':
@@ -198,6 +211,7 @@ def train(cfg, file_prefix: str = '') -> float:
         rewards = transitions['rewards']
       if schedule == 'overlap' and plan is None: worker.enqueue_publish()
       if cfg.logging.interval > 0 and step % cfg.logging.interval == 0:  # the only D2H reads of the update path (train.py:205-210)
+        check_handoff(plan, step)
         metrics['update_steps'].append(step); metrics['predicted_rewards'].append(rewards.cpu().numpy())
         metrics['alphas'].append(log_alpha.exp().cpu().numpy()); metrics['entropies'].append((-log_probs).cpu().numpy()); metrics['Q_values'].append(Q_values.cpu().numpy())
 
@@ -209,10 +223,21 @@ def train(cfg, file_prefix: str = '') -> float:
       score.append(float(normalised.mean()))
       for key, value in (('test_steps', step), ('test_returns', episode_returns), ('test_returns_normalized', list(normalised))): metrics[key].append(value)
       lineplot(metrics['test_steps'], metrics['test_returns'], filename=f'{file_prefix}test_returns', title=f'{cfg.algorithm}: {cfg.env} Test Returns')
+      if len(metrics['train_returns']) > 0:
+        lineplot(metrics['train_steps'], metrics['train_returns'], filename=f'{file_prefix}train_returns', title=f'Training {cfg.algorithm}: {cfg.env} Train Returns')
+      if cfg.logging.interval > 0 and len(metrics['update_steps']) > 0:   # train.py:224-228
+        if cfg.algorithm != 'SAC': lineplot(metrics['update_steps'], metrics['predicted_rewards'], filename=f'{file_prefix}predicted_rewards', yaxis='Predicted Reward', title=f'{cfg.algorithm}: {cfg.env} Predicted Rewards')
+        lineplot(metrics['update_steps'], metrics['alphas'], filename=f'{file_prefix}sac_alpha', yaxis='Alpha', title=f'{cfg.algorithm}: {cfg.env} Alpha')
+        lineplot(metrics['update_steps'], metrics['entropies'], filename=f'{file_prefix}sac_entropy', yaxis='Entropy', title=f'{cfg.algorithm}: {cfg.env} Entropy')
+        lineplot(metrics['update_steps'], metrics['Q_values'], filename=f'{file_prefix}Q_values', yaxis='Q-value', title=f'{cfg.algorithm}: {cfg.env} Q-values')
 
+  check_handoff(plan, cfg.steps)   # never save a learner whose last updates ran on expired device-side waits
   if cfg.check_time_usage: metrics['training_time'] = time.time() - start_time
+  if cfg.save_trajectories:   # train.py:231-234
+    _, trajectories = evaluate_agent(actor, eval_env, cfg.evaluation.episodes, return_trajectories=True, render=cfg.render)
+    torch.save(trajectories, f'{file_prefix}trajectories.pth')
   torch.save(dict(actor=actor.state_dict(), critic=critic.state_dict(), log_alpha=log_alpha), f'{file_prefix}agent.pth')
-  if cfg.algorithm == 'GAIL': torch.save(discriminator.state_dict(), f'{file_prefix}discriminator.pth')
+  if cfg.algorithm in ('DRIL', 'GAIL', 'RED'): torch.save(discriminator.state_dict(), f'{file_prefix}discriminator.pth')   # train.py:238
   torch.save(metrics, f'{file_prefix}metrics.pth')
   return float(np.mean(score)) if score else float('nan')
 
