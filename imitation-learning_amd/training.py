@@ -368,7 +368,14 @@ class UpdatePlan:
     self.device_sync = False
     self._chain_fits = None
     if algorithm == 'GAIL' and overlap and device_index_draw and os.environ.get('IL_DEVICE_SYNC', '1') != '0':
-      self._set_device_sync(self._probe_device_sync(graph=False))
+      # HIP multiplexes streams onto a few hardware queues (round-robin at creation): a side stream that landed on the caller's queue runs serialised with it and
+      # fails the probe. Another stream usually lands elsewhere: try a few (the rejected ones stay alive meanwhile, so that the next one gets a different queue).
+      ok, rejected = self._probe_device_sync(graph=False), []
+      while not ok and len(rejected) < 8:
+        rejected.append(self.side)
+        self.side = torch.cuda.Stream()
+        ok = self._probe_device_sync(graph=False)
+      self._set_device_sync(ok)
     self.graph = self.graph_side = None
     self._ring_desc = None
     self._capturing = None   # 'main' / 'side' while one branch of the device-synchronised update is being captured

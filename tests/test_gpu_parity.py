@@ -398,7 +398,8 @@ def test_capture_warmup_runs_on_the_probed_stream_pair(extra_streams):
   for _ in range(3):
     plan.replay()
   torch.cuda.synchronize()
-  assert plan.device_sync and plan.sync_timeouts() == 0
+  assert plan.sync_timeouts() == 0
+  assert plan.device_sync, 'a side stream that shares the caller\'s hardware queue must be replaced, not silently traded for the slower stream-dependency schedule'
   del keep
 
 
@@ -800,8 +801,10 @@ def test_dril_matches_reference(golden_dir, name, kw):
   ref_ue = g[f'{name}.expert_uncertainty']
   assert np.abs(ue - ref_ue).max() <= 1e-4 * np.abs(ref_ue).max()
   f64 = load(golden_dir, 'f64_brackets')
-  bracket(ue, ref_ue, f64[f'{name}.expert_uncertainty'], f'{name} expert uncertainty')
-  bracket(N(d._get_action_uncertainty(q['states'], q['actions'], masks=qm)), g[f'{name}.query_uncertainty'], f64[f'{name}.query_uncertainty'], f'{name} query uncertainty')
+  # (factor 4: the variance cancels the leading digits of five probabilities p = exp(log pi) ~ O(1), so both float32 results sit a few ulp OF p^2 from float64 -
+  # 1e-7 absolute against a variance of 3e-2 - and the ratio between two libm's atanh / exp at that level is noise; the bound still scales with the reference's error)
+  bracket(ue, ref_ue, f64[f'{name}.expert_uncertainty'], f'{name} expert uncertainty', factor=4.0)
+  bracket(N(d._get_action_uncertainty(q['states'], q['actions'], masks=qm)), g[f'{name}.query_uncertainty'], f64[f'{name}.query_uncertainty'], f'{name} query uncertainty', factor=4.0)
   d.set_uncertainty_threshold(e['states'], e['actions'], 0.9, masks=em)
   assert abs(d.q - float(g[f'{name}.q'][0])) <= 1e-4 * max(abs(d.q), np.abs(ref_ue).max())
   d.q = float(g[f'{name}.q'][0])
