@@ -209,8 +209,22 @@ def cpu_baseline(tr, et, budget_s=12.0):
     threads = max([p['num_threads'] for p in threadpoolctl.threadpool_info()] + [1])
   except Exception:
     threads = os.cpu_count()
-  return dict(value=round(k / dt, 2), unit='updates/s', cores=int(threads), kind='port',
-              sample=f'{k} SAC+GAIL updates (numpy float32 oracle port of train.py:173-203, batch {B}, same synthetic buffers) in {dt:.1f} s on {os.cpu_count()} host cores')
+  return dict(value=round(k / dt, 2), unit='updates/s', cores=int(threads), kind='port', where='GPU box host',
+              sample=f'{k} SAC+GAIL updates (numpy float32 oracle port of train.py:173-203, batch {B}, same synthetic buffers) in {dt:.1f} s; numpy BLAS pool of {int(threads)} threads '
+                     f'(the `cores` field) on a host with {os.cpu_count()} logical cores; everything outside the GEMMs is single-threaded')
+
+
+def cpu_reference():
+  """The reference's OWN code timed on its CPU path (profiles/tools/cpu_reference.py -> profiles/cpu_reference.json). /root/reference cannot travel to the GPU
+  box, so the number comes from the build container and says so; the live-timed oracle port is reported next to it as `cpu_port`."""
+  try:
+    ref = json.load(open(os.path.join(ROOT, 'profiles', 'cpu_reference.json')))
+  except Exception:
+    return None
+  r, n = ref['results'], ref['nproc']
+  return dict(value=r[f'threads_{n}_with_memory_sample'], unit='updates/s', cores=n, kind='reference', where=ref['where'], cpu_model=ref['cpu_model'],
+              one_thread=r['threads_1_with_memory_sample'], without_memory_sample=dict(one_thread=r['threads_1_without_memory_sample'], all_cores=r[f'threads_{n}_without_memory_sample']),
+              sample=f"{ref['updates_timed']} updates after {ref['warmup']} warm-up: {ref['what']}; source profiles/cpu_reference.json (committed; not re-timed in this run)")
 
 
 def roofline(run_fn, trace_steps, units_per_launch, ms_per_step, side_stream_disc):
@@ -252,12 +266,19 @@ def roofline(run_fn, trace_steps, units_per_launch, ms_per_step, side_stream_dis
     if units_per_launch == 1:
       key = 'k_dw_adam' if dom.startswith('k_dw_adam') else dom
       roof['traffic'] = pmc.get(key, {}).get('traffic_bytes')
+      roof['traffic_source'] = ('profiles/pmc_latest.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --no-overlap` (a counter-collecting profiler serialises '
+                                'kernels, so the device hand-off schedule cannot run under it: same kernels, stream-dependency schedule, gathered rows); not collected in this run')
       for k, e in per_kernel.items():
         kk = 'k_dw_adam' if k.startswith('k_dw_adam') else k
         if kk in pmc: e['hbm_traffic_bytes'] = pmc[kk]['traffic_bytes']
   except Exception:
     pass
   upd_gbs = units_per_launch * update_bytes / (ms_per_step * 1e-3) / 1e9
+  # Whole-update fractions at the top level. The contract figure is the HBM fraction; the BINDING roof of this path is fp32 compute:
+  # 0.587 GFLOP at 157.3 TFLOP/s is 3.7 us per update = 268k updates/s = 22 % of the HBM roof, so hbm_frac cannot exceed 0.22 before fp32_frac reaches 1.
+  roof['hbm_frac'] = round(upd_gbs / HBM_PEAK_GBS, 5)
+  roof['fp32_frac'] = round(units_per_launch * update_flops / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5)
+  roof['binding_roof'] = 'fp32 (exact-fp32 MFMA = VALU rate): the update needs 3.7 us of fp32 issue but only 0.8 us of HBM time; `frac` above is the dominant kernel against that roof'
   roof['update'] = dict(algorithmic_bytes=update_bytes, achieved_GBps=round(upd_gbs, 2), hbm_frac=round(upd_gbs / HBM_PEAK_GBS, 5), algorithmic_flops=update_flops,
                         fp32_frac=round(units_per_launch * update_flops / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5),
                         sum_kernel_us=round(sum(v['avg_us'] * v['launches_per_update'] for v in kern.values()), 2))
@@ -386,7 +407,9 @@ def main():
     if world == 1 and args.learners == 1 and not args.no_secondary:
       out['secondary'] = secondary(device, plan, nets)
     if world == 1 and not args.no_cpu_baseline:
-      out['cpu_baseline'] = cpu_baseline(tr, et)
+      port, ref = cpu_baseline(tr, et), cpu_reference()
+      out['cpu_baseline'], out['cpu_port'] = (ref, port) if ref is not None else (port, None)
+      if out['cpu_port'] is None: out.pop('cpu_port')
   if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()
