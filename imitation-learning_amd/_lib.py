@@ -81,7 +81,7 @@ class Red(C.Structure):
 class Dril(C.Structure):
   _fields_ = [('state_dim', C.c_int32), ('action_dim', C.c_int32), ('hidden', C.c_int32), ('batch', C.c_int32), ('p_in', C.c_float), ('p', C.c_float),
               ('params', C.c_void_p), ('grad', C.c_void_p), ('opt', Adam), ('workspace', C.c_void_p), ('noise_seed', C.c_uint64), ('q', C.c_float), ('activation', C.c_int32),
-              ('depth', C.c_int32), ('reserved', C.c_int32)]
+              ('depth', C.c_int32), ('reserved', C.c_int32), ('noise_counter', C.c_void_p)]
 
 
 class SampleArgs(C.Structure):
@@ -132,6 +132,7 @@ _SIGNATURES = {
     'il_bc_step': (C.c_int, [_P, _P, C.POINTER(Adam), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Batch), _P, C.c_int64, _P, C.c_uint32, _P]),
     'il_actor_act': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_uint64, C.c_uint32, C.c_int32, _P, _P, _P]),
     'il_batch_mix_relabel': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_int64, _P]),
+    'il_batch_mix_relabel_dyn': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P]),
     'il_act_mailbox_floats': (C.c_int32, [C.c_int32, C.c_int32]),
     'il_act_step': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_uint64, C.c_uint32, _P, C.c_int64, _P]),
     'il_act_publish': (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P]),

@@ -101,7 +101,7 @@ __global__ void k_noise_fill(uint64_t seed, uint32_t ctr, uint32_t stream_id, lo
 extern "C" int il_noise_fill(uint64_t noise_seed, uint32_t ctr, uint32_t stream_id, int64_t n, float* out, il_stream_t stream) {
   IL_CHECK_ARG(out && n >= 0 && n < (1LL << 32), "il_noise_fill: bad arguments");
   const bool normal = stream_id == IL_STREAM_EPS_NEXT || stream_id == IL_STREAM_EPS_CUR || stream_id == IL_STREAM_ACT;
-  IL_CHECK_ARG(normal || stream_id == IL_STREAM_GP || stream_id == IL_STREAM_MIX, "il_noise_fill: unknown stream id %u", stream_id);
+  IL_CHECK_ARG(normal || stream_id == IL_STREAM_GP || stream_id == IL_STREAM_MIX || stream_id == 5u || stream_id == 6u || stream_id == 11u, "il_noise_fill: unknown stream id %u", stream_id);   // 5, 6, 11: dropout uniforms (dril.hip)
   if (n == 0) return IL_OK;
   k_noise_fill<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(noise_seed, ctr, stream_id, (long long)n, normal ? 1 : 0, out);
   IL_CHECK_LAUNCH("il_noise_fill");

@@ -115,6 +115,7 @@ __device__ __forceinline__ float dril_logp_row(const il_dril& d, const il_batch&
 }
 
 __global__ __launch_bounds__(256) void k_dril_grad(il_dril d, il_batch b, DrilMasks mk) {
+  if (d.noise_counter) mk.ctr += *d.noise_counter;   // captured plans: the per-update part of the Philox counter lives on the device
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = b.n, ldx = S + 1, ldh = H + 1, depth = dril_depth(d), relu = d.activation == 1;
   const DrilLayout lay = dril_layout(S, A, H, depth);
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(256) void k_dril_apply(il_dril d, int nt, int apply
 }
 
 __global__ __launch_bounds__(256) void k_dril_unc(il_dril d, il_batch b, DrilMasks mk, float* __restrict__ out_unc, float* __restrict__ out_reward) {
+  if (d.noise_counter) mk.ctr += *d.noise_counter;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int V = DU * DRIL_ENSEMBLE;
   const DrilLds L = dril_carve(smem, V, d.state_dim, d.hidden, dril_depth(d), 0);   // forward only: the keep-scales are not kept

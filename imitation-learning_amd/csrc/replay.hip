@@ -70,7 +70,10 @@ __global__ void k_wrap_absorbing(float* __restrict__ ring, int row, int S, int A
 // rows [n][row] <- expert rows for r < n_expert (every field: the reference overwrites every key); label: 0 none, 1 SQIL, 2 AdRIL.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mix_relabel(float* __restrict__ rows, const float* __restrict__ expert, int n, int row, int o_rew, int n_expert, int label,
-                                                    float update_freq, float round_num, float reward_expert, float policy_trajectories) {
+                                                    float update_freq, float round_num, float reward_expert, float policy_trajectories, const long long* __restrict__ dyn) {
+  if (dyn) {   // il_batch_mix_relabel_dyn: per-update quantities from device memory (same conversions as the host entry point)
+    n_expert = (int)(dyn[0] < 0 ? 0 : (dyn[0] > n ? n : dyn[0])); round_num = (float)dyn[1]; policy_trajectories = (float)(dyn[2] > 1 ? dyn[2] : 1);
+  }
   const int total = n * row;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int r = i / row, c = i - r * row;
@@ -96,8 +99,20 @@ extern "C" int il_batch_mix_relabel(float* rows, const float* expert_rows, int32
   const int blocks = (n * row + 255) / 256 < 512 ? (n * row + 255) / 256 : 512;
   { IL_TRACE("k_mix_relabel", (hipStream_t)stream);
     k_mix_relabel<<<blocks, 256, 0, (hipStream_t)stream>>>(rows, expert_rows, n, row, 2 * S + A, n_expert, label, (float)update_freq, (float)round_num, reward_expert,
-                                                           (float)(policy_trajectories > 1 ? policy_trajectories : 1)); }
+                                                           (float)(policy_trajectories > 1 ? policy_trajectories : 1), nullptr); }
   IL_CHECK_LAUNCH("il_batch_mix_relabel");
+  return IL_OK;
+}
+
+extern "C" int il_batch_mix_relabel_dyn(float* rows, const float* expert_rows, int32_t n, int32_t S, int32_t A, int32_t label, int32_t update_freq, float reward_expert, const int64_t* dyn,
+                                        il_stream_t stream) {
+  IL_CHECK_ARG(rows && expert_rows && dyn && n > 0, "il_batch_mix_relabel_dyn: bad arguments");
+  IL_CHECK_ARG(label >= 0 && label <= 2 && (label != 2 || update_freq > 0), "il_batch_mix_relabel_dyn: label=%d update_freq=%d", label, update_freq);
+  const int row = il_ring_row_floats(S, A);
+  const int blocks = (n * row + 255) / 256 < 512 ? (n * row + 255) / 256 : 512;
+  { IL_TRACE("k_mix_relabel", (hipStream_t)stream);
+    k_mix_relabel<<<blocks, 256, 0, (hipStream_t)stream>>>(rows, expert_rows, n, row, 2 * S + A, 0, label, (float)update_freq, 0.f, reward_expert, 1.f, (const long long*)dyn); }
+  IL_CHECK_LAUNCH("il_batch_mix_relabel_dyn");
   return IL_OK;
 }
 

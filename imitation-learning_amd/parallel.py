@@ -49,6 +49,7 @@ class DataParallelUpdate:
 
   def __init__(self, plan, group=None):
     self.plan, self.group = plan, group
+    assert not plan.bc_aux, 'DataParallelUpdate: the behavioural-cloning auxiliary step has no data-parallel form (use the per-function path)'
     plan._set_device_sync(False)   # this path orders its two streams with events around the all-reduces
     ao, to = plan._keep[4], plan._keep[6]
     # actor grad and alpha grad travel in one bucket: re-home both into a single flat tensor
@@ -81,6 +82,8 @@ class DataParallelUpdate:
       p.gather_all(expert=False)   # the SAC kernels read the packed agent rows; the expert rows were only needed by the discriminator step
     else:
       p.sample_all()
+      if p.algorithm not in ('SAC', 'PWIL', 'GAIL'):
+        p._enqueue_reward_model(_lib.stream_ptr())   # GMMIL / RED / DRIL / AdRIL: no parameters are trained inside the update block, so nothing to all-reduce here
       if p.algorithm == 'GAIL':
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):

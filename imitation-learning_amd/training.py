@@ -328,18 +328,32 @@ def gmmil_predict_reward(disc: GMMILDiscriminator, state, action, expert_state, 
 
 # ----------------------------------------------------------------------------------------------- captured update
 class UpdatePlan:
-  """The per-step update block of the reference loop (train.py:173-203) for algorithm in {SAC, GAIL} with persistent buffers:
-  device-side index draws -> row gathers -> [discriminator step -> reward relabel] -> SAC update.  `run()` enqueues it eagerly;
-  `capture()` records it into a hipGraph (torch.cuda.CUDAGraph) that `replay()` launches with one host call."""
+  """The per-step update block of the reference loop (train.py:173-203) with persistent buffers, for every algorithm= of the reference:
+  device-side index draws (agent batch, then expert batch: the order and the stream of train.py:173) -> row gathers -> the algorithm's reward step ->
+  [behavioural-cloning auxiliary step] -> SAC update.  The reward step is
+    SAC / PWIL  none (PWIL stores its rewards online, train.py:156),
+    GAIL        discriminator step + reward relabel (two streams, device-side hand-off; see `_run_update`),
+    GMMIL       k_gmmil_tile on the two batches (bandwidths frozen by the first, eager, update: models.py:193-195),
+    RED         predictor / target forward (eval mode),   DRIL  5-member Monte-Carlo-dropout uncertainty (Philox counter on the device),
+    AdRIL/SQIL  k_mix_relabel with the per-update scalars (round, trajectory count, balanced alternation) read from a device buffer (`relabel_args`),
+  preceded by `mix_expert_agent_transitions` when imitation.mix_expert_data = mixed_batch (train.py:183; GAIL with mixing keeps the per-function path).
+  `run()` enqueues it eagerly; `capture()` records it into a hipGraph (torch.cuda.CUDAGraph) that `replay()` launches with one host call."""
+  ALGORITHMS = ('SAC', 'GAIL', 'GMMIL', 'PWIL', 'RED', 'DRIL', 'AdRIL')
 
   def __init__(self, algorithm: str, actor, critic, log_alpha, target_critic, memory: ReplayMemory, actor_optimiser, critic_optimiser, temperature_optimiser,
                batch_size: int, discount: float, entropy_target: float, polyak_factor: float, expert_memory: Optional[ReplayMemory] = None, discriminator=None,
-               discriminator_optimiser=None, imitation_cfg=None, device_index_draw: bool = True, overlap: bool = True, learner_id=None):
-    """`learner_id`: give this plan private scratch / noise / index-stream state so that several plans can run concurrently (`PopulationPlan`)."""
-    assert algorithm in ('SAC', 'GAIL')
+               discriminator_optimiser=None, imitation_cfg=None, device_index_draw: bool = True, overlap: bool = True, learner_id=None, mix_expert: bool = False,
+               bc_aux: bool = False):
+    """`learner_id`: give this plan private scratch / noise / index-stream state so that several plans can run concurrently (`PopulationPlan`).
+    `mix_expert`: imitation.mix_expert_data == 'mixed_batch' (DRIL / GMMIL / RED); `bc_aux`: imitation.bc_aux_loss (train.py:201)."""
+    assert algorithm in self.ALGORITHMS, f'UpdatePlan: unknown algorithm {algorithm}'
+    assert expert_memory is not None or (algorithm in ('SAC', 'PWIL') and not mix_expert and not bc_aux), f'UpdatePlan({algorithm}): needs the expert memory'
+    assert not (mix_expert and algorithm in ('GAIL', 'SAC', 'PWIL', 'AdRIL')), 'mixed batches: DRIL / GMMIL / RED plans (train.py:175,183); GAIL with mixing runs the per-function path'
     self.overlap, self.side = overlap, (torch.cuda.Stream() if overlap and algorithm == 'GAIL' else None)
     self.algorithm, self.B, dev = algorithm, batch_size, actor.flat.device
     self.memory, self.expert_memory, self.device_index_draw = memory, expert_memory, device_index_draw
+    self.has_expert, self.mix_expert, self.bc_aux = expert_memory is not None, bool(mix_expert), bool(bc_aux)
+    self.discriminator = discriminator
     self.rows = torch.empty(batch_size, memory.row, device=dev); self.idx = torch.empty(batch_size, dtype=torch.int32, device=dev)
     self.transitions = batch_views(self.rows, memory.state_size, memory.action_size, memory.absorbing)
     self.logp, self.q = torch.empty(batch_size, device=dev), torch.empty(batch_size, device=dev)
@@ -348,9 +362,24 @@ class UpdatePlan:
                               tag=tag, seed_offset=off)
     self.sac.out_logp, self.sac.out_q = self.logp.data_ptr(), self.q.data_ptr()
     self._keep = (actor, critic, log_alpha, target_critic, actor_optimiser, critic_optimiser, temperature_optimiser, discriminator, discriminator_optimiser)
-    if algorithm == 'GAIL':
+    if self.has_expert:   # the expert batch is drawn for every algorithm (train.py:173), which keeps the index stream in step with the reference's
       self.erows = torch.empty(batch_size, expert_memory.row, device=dev); self.eidx = torch.empty(batch_size, dtype=torch.int32, device=dev)
       self.expert_transitions = batch_views(self.erows, expert_memory.state_size, expert_memory.action_size, expert_memory.absorbing)
+      self.eb = batch_desc(self.expert_transitions)
+    if algorithm in ('GMMIL', 'RED', 'DRIL'):
+      self.rewards = torch.empty(batch_size, device=dev)
+      self.transitions['rewards'] = self.rewards   # train.py:190-198: rewards replaced by the reward model's prediction
+      if algorithm == 'RED':
+        assert discriminator.sigma_1, 'UpdatePlan(RED): set_sigma first (train.py:128)'
+        self.red = discriminator._desc(batch_size)
+      elif algorithm == 'DRIL':
+        assert discriminator.q is not None, 'UpdatePlan(DRIL): set_uncertainty_threshold first (train.py:126)'
+        self.dril = discriminator._desc(batch_size)
+        self.dril.noise_counter = self.sac.noise_counter   # the per-update part of the dropout masks' Philox counter: advanced on the device by the actor step
+    if algorithm == 'AdRIL':
+      self.dyn = torch.zeros(3, dtype=torch.int64, device=dev)   # {n_expert, round, policy trajectories} of the next update (il_batch_mix_relabel_dyn)
+      self._dyn_set = False
+    if algorithm == 'GAIL':
       host_mixup = imitation_cfg is not None and imitation_cfg.loss_function == 'Mixup' and float(_cfg_value(imitation_cfg, 'mixup_alpha', 1.0)) != 1.0
       deep = type(discriminator).__name__ == 'DeepGAILDiscriminator'   # depth 2 / tanh: the general kernels, per-function path
       if imitation_cfg is not None and (host_mixup or deep or discriminator.subtract_log_policy or getattr(discriminator, 'reward_shaping', False)):
@@ -358,7 +387,6 @@ class UpdatePlan:
         raise NotImplementedError('UpdatePlan: GAIL with Mixup (alpha != 1: Beta draws on the host) / subtract_log_policy / reward shaping / a depth-2 or tanh discriminator runs through '
                                   'adversarial_imitation_update + sac_update')
       self.disc = disc_descriptor(discriminator, batch_size, discriminator_optimiser, imitation_cfg, tag=tag, seed_offset=off)
-      self.eb = batch_desc(self.expert_transitions)
       self.rewards = torch.empty(batch_size, device=dev)
       self.transitions['rewards'] = self.rewards  # train.py:194: rewards replaced by the discriminator's prediction
     self.pb = batch_desc(self.transitions)
@@ -451,7 +479,7 @@ class UpdatePlan:
     """The index draws of `sample_all` alone (device draw): consumers that read the rings through il_batch.gather (`_ring_batches`) can start from here,
     before `gather_all` has produced the packed rows."""
     assert self.device_index_draw
-    m, e = self.memory, (self.expert_memory if self.algorithm == 'GAIL' else None)
+    m, e = self.memory, (self.expert_memory if self.has_expert else None)
     st = m.stream().device_state(m.device)
     _lib.check(_lib.lib().il_replay_sample_device(
         _lib.ptr(st), self.B, _lib.ptr(m._ring_state), _lib.ptr(m.ring), m.size, m.row, _lib.ptr(self.idx), None,
@@ -463,7 +491,7 @@ class UpdatePlan:
     L, st = _lib.lib(), _lib.stream_ptr()
     m = self.memory
     _lib.check(L.il_replay_gather(_lib.ptr(m.ring), m.size, m.row, _lib.ptr(self.idx), self.B, _lib.ptr(self.rows), st))
-    if self.algorithm == 'GAIL' and expert:
+    if self.has_expert and expert:
       e = self.expert_memory
       _lib.check(L.il_replay_gather(_lib.ptr(e.ring), e.size, e.row, _lib.ptr(self.eidx), self.B, _lib.ptr(self.erows), st))
 
@@ -471,10 +499,10 @@ class UpdatePlan:
     """Agent batch then expert batch (the order train.py:173 consumes the index stream); one launch when drawn on the device."""
     if not self.device_index_draw:
       self._sample(self.memory, self.idx, self.rows)
-      if self.algorithm == 'GAIL':
+      if self.has_expert:
         self._sample(self.expert_memory, self.eidx, self.erows)
       return
-    m, e = self.memory, (self.expert_memory if self.algorithm == 'GAIL' else None)
+    m, e = self.memory, (self.expert_memory if self.has_expert else None)
     st = m.stream().device_state(m.device)   # the agent memory's index stream feeds both draws of an update (one stream, agent then expert)
     _lib.check(_lib.lib().il_replay_sample_device(
         _lib.ptr(st), self.B, _lib.ptr(m._ring_state), _lib.ptr(m.ring), m.size, m.row, _lib.ptr(self.idx), None if self.ring_mode else _lib.ptr(self.rows),
@@ -590,8 +618,60 @@ class UpdatePlan:
     if self.algorithm == 'GAIL':
       _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))
       _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
-    _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), self.prepared_flag(), st))
+    else:
+      self._enqueue_reward_model(st)
+    flag = self.prepared_flag()
+    if self.bc_aux:   # train.py:201: a behavioural-cloning step on the expert batch with the ACTOR's optimiser; it moves the actor, so the lane-ordered copies are re-derived
+      a, ao = self._keep[0], self._keep[4]
+      od = ao.desc()
+      _lib.check(L.il_bc_step(_lib.ptr(a.flat), _lib.ptr(ao.grad), C.byref(od), a.state_size, a.action_size, a.hidden, C.byref(self.eb), C.c_void_p(self.sac.workspace), self.sac.workspace_floats,
+                              None, 0, st))
+      flag = 0
+    _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), flag, st))
     self._prepared = True
+
+  def relabel_args(self, step: int, num_trajectories: int):
+    """AdRIL / SQIL: the per-update scalars of RewardRelabeller.resample_and_relabel (models.py:300-318) for the NEXT update: a stream-ordered copy into the device
+    buffer the captured k_mix_relabel reads. Call once before every run() / replay()."""
+    r = self.discriminator
+    if r.balanced:
+      n_expert = self.B if r.sample_expert else 0
+      r.sample_expert = not r.sample_expert
+    else:
+      n_expert = self.B // 2
+    rnd = -(-int(step) // r.update_freq) if r.update_freq > 0 else 0
+    self.dyn.copy_(torch.tensor([n_expert, rnd, int(num_trajectories)], dtype=torch.int64))   # pageable source: staged synchronously, ordered on the current stream
+    self._dyn_set = True
+
+  def _enqueue_reward_model(self, st):
+    """train.py:183-198 for the non-adversarial algorithms, on the sampled batches (`self.rows` / `self.erows`)."""
+    L, alg, m = _lib.lib(), self.algorithm, self.memory
+    if self.mix_expert:   # models.py:287-290: the first half of every field <- expert rows
+      _lib.check(L.il_batch_mix_relabel(_lib.ptr(self.rows), _lib.ptr(self.erows), self.B, m.state_size, m.action_size, self.B // 2, 0, 0, 0, 0.0, 0, st))
+    if alg == 'AdRIL':
+      capturing = torch.cuda.is_current_stream_capturing()   # a captured launch reads whatever relabel_args() stored before the replay
+      assert capturing or self._dyn_set, 'UpdatePlan(AdRIL): call relabel_args(step, memory.num_trajectories) before every update'
+      r = self.discriminator
+      import numpy as np
+      reward_expert = float(np.float32(1 / self.expert_memory.num_trajectories)) if r.update_freq > 0 else 0.0
+      _lib.check(L.il_batch_mix_relabel_dyn(_lib.ptr(self.rows), _lib.ptr(self.erows), self.B, m.state_size, m.action_size, 2 if r.update_freq > 0 else 1, r.update_freq, reward_expert,
+                                            _lib.ptr(self.dyn), st))
+      if not capturing: self._dyn_set = False
+    elif alg == 'GMMIL':
+      d, t, e = self.discriminator, self.transitions, self.expert_transitions
+      if d.gamma_1 is None:   # the median heuristic of the FIRST batch (models.py:193-195): host-side, once - the first update must be an eager run()
+        assert not torch.cuda.is_current_stream_capturing(), 'UpdatePlan(GMMIL): run() once before capture() (the first batch fixes the kernel bandwidths)'
+        self.rewards.copy_(gmmil_predict_reward(d, t['states'], t['actions'], e['states'], e['actions'], t['weights'].contiguous(), e['weights'].contiguous()))
+        return
+      D = d.state_size + (0 if d.state_only else d.action_size)
+      ws = _workspace('gmmil', int(L.il_gmmil_workspace_floats(self.B, self.B, D)), self.rows.device)
+      _lib.check(L.il_gmmil_reward(C.byref(self.pb), C.byref(self.eb), d.state_size, d.action_size, int(d.state_only), float(d.gamma_1), float(d.gamma_2), _lib.ptr(self.rewards), None, None,
+                                   _lib.ptr(ws), ws.numel(), st))
+    elif alg == 'RED':
+      assert not self.discriminator.training, 'UpdatePlan(RED): discriminator.eval() first (train.py:147)'
+      _lib.check(L.il_red_forward(C.byref(self.red), C.byref(self.pb), 0, None, None, None, 0, _lib.ptr(self.rewards), None, None, st))
+    elif alg == 'DRIL':
+      _lib.check(L.il_dril_uncertainty(C.byref(self.dril), C.byref(self.pb), None, None, None, 0x40000000, None, _lib.ptr(self.rewards), st))   # offset range apart from the eager calls' small counters
 
   def capture(self, warmup: int = 3):
     assert self.device_index_draw, 'graph capture needs device-side index draws (no H2D inside the graph)'
@@ -682,19 +762,19 @@ class BatchedPopulationPlan:
     for p in self.plans:
       p._set_device_sync(False)   # one stream, one set of launches for all learners: plain stream order
     p0 = self.plans[0]
-    assert all(p.algorithm == p0.algorithm and p.B == p0.B for p in self.plans)
+    assert all(p.algorithm == p0.algorithm and p.B == p0.B for p in self.plans) and p0.algorithm in ('SAC', 'GAIL'), 'the population launches exist for SAC and GAIL learners'
     self.algorithm, self.B, self.L, dev = p0.algorithm, p0.B, len(self.plans), p0.rows.device
     self.sac_descs = _device_array([p.sac for p in self.plans], dev)
     self.batches = _device_array([p.pb for p in self.plans], dev)
     args = []
     for p in self.plans:
-      m, e = p.memory, (p.expert_memory if p.algorithm == 'GAIL' else None)
+      m, e = p.memory, (p.expert_memory if p.has_expert else None)
       st = m.stream().device_state(dev)
       args.append(_lib.SampleArgs(st.data_ptr(), m._ring_state.data_ptr(), m.ring.data_ptr(), m.size, m.row, p.idx.data_ptr(), p.rows.data_ptr(),
                                   e._ring_state.data_ptr() if e else None, e.ring.data_ptr() if e else None, e.size if e else 0, e.row if e else 0,
                                   p.eidx.data_ptr() if e else None, p.erows.data_ptr() if e else None))
     self.sample_args = _device_array(args, dev)
-    self.max_row = max([p.memory.row for p in self.plans] + [p.expert_memory.row for p in self.plans if p.algorithm == 'GAIL'])
+    self.max_row = max([p.memory.row for p in self.plans] + [p.expert_memory.row for p in self.plans if p.has_expert])
     if self.algorithm == 'GAIL':
       self.disc_descs = _device_array([p.disc for p in self.plans], dev)
       self.expert_batches = _device_array([p.eb for p in self.plans], dev)

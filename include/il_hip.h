@@ -63,8 +63,10 @@ int il_trace_report(char* buf_host, int len);
  *   IL_NOISE_EPS_NEXT [B*A] = the N(0,1) draws of policy.sample() on s' (training.py:21), IL_NOISE_EPS_CUR [B*A] = rsample on s (training.py:35),
  *   IL_NOISE_GP [B] = the U(0,1) of the gradient penalty (training.py:118), IL_NOISE_MIX [B] = Mixup coefficients at alpha = 1 (training.py:106),
  *   IL_NOISE_ACT [n*A] = actor(state).sample() of il_actor_act / il_act_step (train.py:152; there `ctr` is the call's noise_offset).
- * This is how a captured run is recorded for replay through a CPU oracle (tests/test_timed_path_oracle.py). */
-enum { IL_NOISE_EPS_NEXT = 1, IL_NOISE_EPS_CUR = 2, IL_NOISE_GP = 3, IL_NOISE_ACT = 4, IL_NOISE_MIX = 7 };
+ * This is how a captured run is recorded for replay through a CPU oracle (tests/test_timed_path_oracle.py).
+ *   IL_NOISE_DROP_IN / _HID / _HID2 = the U(0,1) behind the DRIL dropout keep-masks (keep = u >= p) of the input [rows*S] and the hidden layers [rows*H], rows in
+ *   repeat_interleave order for the 5-member ensemble; ctr = the call's noise_offset (+ *il_dril.noise_counter). */
+enum { IL_NOISE_EPS_NEXT = 1, IL_NOISE_EPS_CUR = 2, IL_NOISE_GP = 3, IL_NOISE_ACT = 4, IL_NOISE_DROP_IN = 5, IL_NOISE_DROP_HID = 6, IL_NOISE_MIX = 7, IL_NOISE_DROP_HID2 = 11 };
 int il_noise_fill(uint64_t noise_seed, uint32_t ctr, uint32_t stream_id, int64_t n, float* out, il_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -105,6 +107,10 @@ int il_replay_wrap_absorbing(float* ring, int64_t capacity, int32_t state_dim, i
  *   2 (AdRIL): expert `reward_expert` (= 1/|expert trajectories|), policy -[round_num > ceil(row.step / update_freq)] / max(policy_trajectories, 1). */
 int il_batch_mix_relabel(float* rows, const float* expert_rows, int32_t n, int32_t state_dim, int32_t action_dim, int32_t n_expert, int32_t label,
                          int32_t update_freq, int64_t round_num, float reward_expert, int64_t policy_trajectories, il_stream_t stream);
+/* The same with the per-update quantities read from DEVICE memory, so that the launch can sit in a captured graph: dyn = int64[3] {n_expert (balanced AdRIL alternates
+ * all-expert / all-policy batches), round_num = ceil(step / update_freq), policy_trajectories}; the caller refreshes it with a stream-ordered copy before each replay. */
+int il_batch_mix_relabel_dyn(float* rows, const float* expert_rows, int32_t n, int32_t state_dim, int32_t action_dim, int32_t label, int32_t update_freq, float reward_expert,
+                             const int64_t* dyn, il_stream_t stream);
 /* memory.py:58-63 `sample` gather step: out[i] = ring[idx[i]] for i < n (packed rows, coalesced 16-B lanes). */
 int il_replay_gather(const float* ring, int64_t capacity, int32_t row_floats, const int32_t* idx, int32_t n, float* out_rows,
                      il_stream_t stream);
@@ -457,6 +463,8 @@ typedef struct il_dril {
   int32_t activation;   /* 0 tanh (conf/algorithm/DRIL.yaml), 1 relu */
   int32_t depth;        /* hidden layers: 1 or 2 (0 = 1) */
   int32_t reserved;
+  const uint32_t* noise_counter; /* optional device uint32 added to every call's noise_offset when the masks are drawn on chip: a captured update (hipGraph replay) passes
+                                    a constant noise_offset and lets the counter an il_sac descriptor advances once per update (il_sac.noise_counter) move the stream on */
 } il_dril;
 /* parameters in torch order: W1[H,S] b1 (Wh[H,H] bh when depth = 2) W2[2A,H] b2 */
 int64_t il_dril_numel(int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t depth);

@@ -2,8 +2,8 @@
 """Entry point with the reference's command line:  python train.py algorithm=<ALG> env=<ENV> [key.sub=value ...]
 
 Drives the loop of reference train.py:26-243 (act -> store -> [update block] -> evaluate -> save) on the MI355X path:
-the update block (train.py:171-203) is `UpdatePlan` (one captured hipGraph per step for SAC / GAIL) or the per-function HIP entry
-points (GMMIL, PWIL, mixed batches, BC auxiliary loss).  Hydra is replaced by `imitation_learning_amd.config.compose`
+the update block (train.py:171-203) is `UpdatePlan` (one captured hipGraph replay per step, every algorithm) or the per-function HIP entry
+points (GAIL variants with per-update host inputs, batch sizes that are not a multiple of 16).  Hydra is replaced by `imitation_learning_amd.config.compose`
 (same keys, same precedence).  Supported on the HIP path: SAC, GAIL (BCE loss), GMMIL, PWIL, AdRIL (and SQIL via update_freq=0), RED, DRIL, BC - every algorithm= of the reference.
 """
 import os
@@ -127,16 +127,19 @@ def train(cfg, file_prefix: str = '') -> float:
   if cfg.algorithm in ('PWIL', 'GMMIL') and cfg.imitation.mix_expert_data == 'prefill_memory':
     memory.transfer_transitions(expert_memory)
 
-  # ---- the update block as a captured graph when nothing host-side sits inside it
+  # ---- the update block as ONE captured graph per step (UpdatePlan) whenever its inputs are device-resident; otherwise the per-function entry points
   plan = None
-  fusable = cfg.algorithm in ('SAC', 'GAIL') and cfg.imitation.mix_expert_data == 'none' and not cfg.imitation.bc_aux_loss and B % 16 == 0
-  if cfg.algorithm == 'GAIL' and ((cfg.imitation.loss_function == 'Mixup' and float(cfg.imitation.mixup_alpha) != 1.0) or cfg.imitation.discriminator.subtract_log_policy
-                                  or cfg.imitation.discriminator.reward_shaping or (cfg.imitation.discriminator.depth, cfg.imitation.discriminator.activation) != (1, 'relu')):
-    fusable = False   # per-update host inputs (Beta(alpha != 1) draws) / an extra actor pass: the per-function entry points
+  mixed = cfg.imitation.mix_expert_data == 'mixed_batch'
+  fusable = B % 16 == 0
+  if cfg.algorithm == 'GAIL' and (mixed or cfg.imitation.bc_aux_loss or (cfg.imitation.loss_function == 'Mixup' and float(cfg.imitation.mixup_alpha) != 1.0)
+                                  or cfg.imitation.discriminator.subtract_log_policy or cfg.imitation.discriminator.reward_shaping
+                                  or (cfg.imitation.discriminator.depth, cfg.imitation.discriminator.activation) != (1, 'relu')):
+    fusable = False   # per-update host inputs (Beta(alpha != 1) draws) / an extra actor pass / a mix between the discriminator step and the relabel: per-function path
   if fusable:
     plan = il.UpdatePlan(cfg.algorithm, actor, critic, log_alpha, target_critic, memory, actor_optimiser, critic_optimiser, temperature_optimiser, B, cfg.reinforcement.discount,
                          entropy_target, cfg.reinforcement.polyak_factor, expert_memory=expert_memory, discriminator=discriminator, discriminator_optimiser=discriminator_optimiser,
-                         imitation_cfg=cfg.imitation if cfg.algorithm == 'GAIL' else None)
+                         imitation_cfg=cfg.imitation if cfg.algorithm == 'GAIL' else None, mix_expert=mixed and cfg.algorithm in ('DRIL', 'GMMIL', 'RED'),
+                         bc_aux=bool(cfg.imitation.bc_aux_loss))
   captured = False
 
   # acting (train.py:151-168): il_act_step through a pinned mailbox; PWIL computes its reward per step on the device and keeps the per-function path
@@ -182,8 +185,9 @@ def train(cfg, file_prefix: str = '') -> float:
 
     if update_due:
       if plan is not None:
+        if cfg.algorithm == 'AdRIL': plan.relabel_args(step, memory.num_trajectories)   # the relabeller's per-update scalars -> device buffer (models.py:300-318)
         if not captured:
-          plan.run(); plan.capture(warmup=0); captured = True   # first update eagerly (loads code objects), then capture
+          plan.run(); plan.capture(warmup=0); captured = True   # first update eagerly (loads code objects; GMMIL: fixes the kernel bandwidths), then capture
         else:
           plan.replay()
         rewards, log_probs, Q_values = plan.transitions['rewards'], plan.logp, plan.q
