@@ -143,6 +143,27 @@ def secondary(device, plan, nets):
   out['gmmil_reward_B1024_ant'] = dict(calls_per_s=round(rate, 1), pair_feature_TFLOPs=round(pair_flops * rate / 1e12 / 2, 2),
                                         note='k_gmmil_pack/tile/final; the reference materialises [B,B,D] temporaries (0.33 s per call on its CPU path, SURVEY.md a20)')
 
+  # BASELINE.json configs[3] as WHOLE updates: algorithm=GMMIL env=ant, batch 1024 - 2 replay samples + the pairwise-RBF reward + sac_update as one captured graph per step
+  rs2 = np.random.RandomState(6)
+  import inputs as gi
+  cfgn = Cfg(hidden_size=H, depth=2, activation='relu')
+  a2, c2 = il.SoftActor(Sg, Ag, cfgn, device=device), il.TwinCritic(Sg, Ag, cfgn, device=device)
+  t2, la2 = il.create_target_network(c2), torch.zeros(1, device=device)
+  o2 = (il.AdamW(a2, lr=3e-4, weight_decay=0), il.AdamW(c2, lr=3e-4, weight_decay=0), il.Adam(la2, lr=3e-4))
+  def ring(n, cap, shift):
+    tr = gi.transitions(rs2, n, Sg, Ag, state_shift=shift, absorbing_frac=0.01, terminal_frac=0.001)
+    m = il.ReplayMemory(cap, Sg, Ag, True, device=device)
+    for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'timeouts', 'weights'):
+      getattr(m, k)[:n] = torch.from_numpy(tr[k]).to(device)
+    m.step[:n] = torch.arange(1, n + 1, dtype=torch.float32, device=device)
+    m.idx, m.full = n % cap, n == cap
+    m._sync_ring_state()
+    return m
+  gplan = il.UpdatePlan('GMMIL', a2, c2, la2, t2, ring(100_000, 1_000_000, 0.0), *o2, Bg, 0.99, -1.0 * Ag, 0.995, expert_memory=ring(25_000, 25_000, 0.5),
+                        discriminator=il.GMMILDiscriminator(Sg, Ag, Cfg(state_only=False)), learner_id=9002)
+  gplan.run(); gplan.capture(warmup=0)
+  out['gmmil_ant_b1024_updates_per_s'] = round(timed(gplan.replay, 300, 30), 1)
+
   # PWIL: one (state, action) against N = 25,000 standardised expert atoms, D = 24, consumed greedily (models.py:232-249)
   emem = plan.expert_memory
   pw = il.PWILDiscriminator(S, A, Cfg(state_only=False, reward_scale=5, reward_bandwidth_scale=5), emem, 1000)
