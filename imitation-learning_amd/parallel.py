@@ -44,6 +44,62 @@ def rank_seed(base_seed: int) -> int:
   return base_seed + (dist.get_rank() if dist.is_initialized() else 0)
 
 
+class GradBuckets:
+  """The exchange buffers of one learner: ONE flat fp32 tensor per sync point.
+      disc   [P_d]              discriminator gradient (GAIL only)
+      critic [2 * Ps]           twin-critic gradient arena (net stride padding included: the pad floats stay zero on every rank)
+      actor  [roundup4(Pa + 1)] actor gradient followed by the log-alpha gradient in slot Pa, zero-padded to a 16-byte multiple
+  `actor_grad` / `alpha_grad` are VIEWS into the actor bucket: the grads-only kernels write straight into the message, nothing is packed or copied
+  around a collective. Device-agnostic (the world_size-2 gloo test drives it with CPU tensors of the real sizes)."""
+
+  def __init__(self, n_actor: int, critic_grad: torch.Tensor, disc_grad: Optional[torch.Tensor] = None, device=None):
+    device = device if device is not None else critic_grad.device
+    self.n_actor = int(n_actor)
+    self.actor = torch.zeros((self.n_actor + 1 + 3) // 4 * 4, dtype=torch.float32, device=device)
+    self.actor_grad, self.alpha_grad = self.actor[:self.n_actor], self.actor[self.n_actor:self.n_actor + 1]
+    self.critic, self.disc = critic_grad, disc_grad
+
+  def exchange(self, which: str, group=None) -> torch.Tensor:
+    """In-place mean over ranks of one bucket ('disc' | 'critic' | 'actor')."""
+    return all_reduce_mean_(getattr(self, which), group)
+
+
+def replica_tensors(actor, critic, target_critic, log_alpha, discriminator=None):
+  """Every tensor that must be bit-identical on all ranks before the first update: parameter arenas, log alpha, and the discriminator's parameters AND buffers
+  (spectral-norm u / v: they depend only on the replicated weights afterwards, but their random initial values differ per rank)."""
+  out = [actor.flat, critic.flat, target_critic.flat, log_alpha]
+  if discriminator is not None and hasattr(discriminator, 'flat'):
+    out.append(discriminator.flat)
+    for name in ('sn', 'target_flat'):
+      if getattr(discriminator, name, None) is not None: out.append(getattr(discriminator, name))
+  return out
+
+
+def broadcast_scalars(values, src: int = 0, group=None):
+  """Host scalars that replicas must agree on (GMMIL bandwidths, RED sigma, DRIL threshold): rank `src`'s values everywhere."""
+  if dist.is_initialized() and dist.get_world_size(group) > 1:
+    box = [list(values)]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return box[0]
+  return list(values)
+
+
+def init_from_env(world_size: int, backend: str = 'nccl'):
+  """Joins the process group torch.distributed.run (or the bench driver) prepared: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, one process per
+  GPU. Returns (rank, local_rank, device). backend 'nccl' is RCCL on ROCm; 'gloo' exists for tests (two ranks may then share one GPU)."""
+  rank, local, world = int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+  if world != world_size:
+    raise RuntimeError(f'distributed.world_size={world_size} but WORLD_SIZE={world}: launch with python -m torch.distributed.run --nproc-per-node {world_size} --master-addr 127.0.0.1 train.py ...')
+  n_dev = torch.cuda.device_count()
+  device = torch.device('cuda', local if backend == 'nccl' else local % max(n_dev, 1))
+  torch.cuda.set_device(device)
+  if not dist.is_initialized():
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29517')
+    if backend == 'nccl': dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    else: dist.init_process_group(backend, rank=rank, world_size=world)
+  return rank, local, device
+
+
 class DataParallelUpdate:
   """`UpdatePlan` with the three gradient all-reduces between backward and optimiser (IL_FLAG_GRADS_ONLY entry points)."""
 
@@ -52,14 +108,12 @@ class DataParallelUpdate:
     assert not plan.bc_aux, 'DataParallelUpdate: the behavioural-cloning auxiliary step has no data-parallel form (use the per-function path)'
     plan._set_device_sync(False)   # this path orders its two streams with events around the all-reduces
     ao, to = plan._keep[4], plan._keep[6]
-    # actor grad and alpha grad travel in one bucket: re-home both into a single flat tensor
-    n = ao.grad.numel()
-    self.actor_bucket = torch.zeros((n + 1 + 3) // 4 * 4, device=ao.grad.device)
-    ao.grad, to.grad = self.actor_bucket[:n], self.actor_bucket[n:n + 1]
+    # actor grad and alpha grad travel in one bucket: the optimisers' gradient arenas become views into it
+    self.buckets = GradBuckets(ao.grad.numel(), plan._keep[5].grad, plan._keep[8].grad if plan.algorithm == 'GAIL' else None)
+    ao.grad, to.grad = self.buckets.actor_grad, self.buckets.alpha_grad
     plan.sac.actor_grad, plan.sac.alpha_grad = ao.grad.data_ptr(), to.grad.data_ptr()
     self.side = torch.cuda.Stream() if plan.algorithm == 'GAIL' else None
-    self.critic_bucket = plan._keep[5].grad
-    self.disc_bucket = plan._keep[8].grad if plan.algorithm == 'GAIL' else None
+    self.actor_bucket, self.critic_bucket, self.disc_bucket = self.buckets.actor, self.buckets.critic, self.buckets.disc
 
   def run(self):
     """sample -> [side stream: discriminator grads -> all-reduce -> AdamW -> reward | main: SAC forward] -> critic grads -> all-reduce ->

@@ -54,7 +54,27 @@ def _worker(rank, world, port, out_dir):
   dg = ogail.gail_update(ds, cat(pb), pb['weights'], cat(eb), eb['weights'], g['eps'][0][half], lr=3e-5, weight_decay=10, grad_penalty=1.0, return_grads=True)
   dbucket = torch.from_numpy(dg.copy())
   parallel.all_reduce_mean_(dbucket)
-  np.savez(os.path.join(out_dir, f'rank{rank}.npz'), critic=bucket.numpy(), disc=dbucket.numpy(), u1=ds.u1)
+  # --- the REAL exchange buffers of DataParallelUpdate (GradBuckets): actor gradient + log-alpha gradient share one padded bucket, written through views.
+  # The policy loss runs through the critic AFTER its step, which in the data-parallel protocol used the all-reduced gradient on every rank: lr = 0 keeps the
+  # critic identical everywhere here, so that the actor / alpha gradients of the shards must average to those of the whole batch.
+  st = osac.SacState(c['S'], c['A'], c['H'])
+  st.actor[:], st.critic[:], st.target[:], st.log_alpha[:] = c['actor'], c['critic'], c['target'], c['log_alpha']
+  _, _, gr = osac.sac_update(st, shard(c['batches'][0]), c['eps_next'][0][half], c['eps_cur'][0][half], discount=c['discount'], entropy_target=c['entropy_target'],
+                             polyak_factor=c['polyak'], lr=0.0, return_grads=True)
+  Pa = gr['actor'].size
+  gb = parallel.GradBuckets(Pa, torch.from_numpy(gr['critic'].copy()), torch.from_numpy(dg.copy()), device='cpu')
+  assert gb.actor.numel() % 4 == 0 and gb.actor.numel() >= Pa + 1 and gb.actor_grad.data_ptr() == gb.actor.data_ptr() and gb.alpha_grad.data_ptr() == gb.actor.data_ptr() + 4 * Pa
+  gb.actor_grad.copy_(torch.from_numpy(gr['actor'])); gb.alpha_grad.copy_(torch.from_numpy(gr['alpha']))   # what the grads-only kernels do on the GPU
+  for which in ('disc', 'critic', 'actor'):   # dependency order of an update
+    gb.exchange(which)
+  assert float(gb.actor[Pa + 1:].abs().sum()) == 0.0   # the padding stays zero
+  tensors = parallel.replica_tensors(*(type('M', (), dict(flat=torch.full((5,), float(rank + k)))) for k in range(3)), torch.full((1,), float(rank)),
+                                     type('D', (), dict(flat=torch.full((4,), float(rank)), sn=torch.full((3,), float(rank)), target_flat=None)))
+  parallel.broadcast_parameters(tensors)
+  assert [float(t[0]) for t in tensors] == [0.0, 1.0, 2.0, 0.0, 0.0, 0.0]   # rank 0's values everywhere, spectral-norm buffers included
+  assert parallel.broadcast_scalars([0.25 + rank, None]) == [0.25, None]
+  np.savez(os.path.join(out_dir, f'rank{rank}.npz'), critic=bucket.numpy(), disc=dbucket.numpy(), u1=ds.u1, b_actor=gb.actor_grad.numpy(), b_alpha=gb.alpha_grad.numpy(),
+           b_critic=gb.critic.numpy(), b_disc=gb.disc.numpy())
   dist.barrier()
   dist.destroy_process_group()
 
@@ -78,6 +98,17 @@ def test_data_parallel_gradient_identity(tmp_path):
                              return_grads=True)
   scale = np.abs(gr['critic']).max()
   assert np.abs(r0['critic'] - gr['critic']).max() <= 2e-6 * scale
+  # the same through the real bucket layout: every bucket identical on both ranks and equal to the gradient of the concatenated batch
+  for k in ('b_actor', 'b_alpha', 'b_critic', 'b_disc'):
+    np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
+  np.testing.assert_array_equal(r0['b_critic'], r0['critic'])
+  st = osac.SacState(c['S'], c['A'], c['H'])
+  st.actor[:], st.critic[:], st.target[:], st.log_alpha[:] = c['actor'], c['critic'], c['target'], c['log_alpha']
+  _, _, gr = osac.sac_update(st, c['batches'][0], c['eps_next'][0], c['eps_cur'][0], discount=c['discount'], entropy_target=c['entropy_target'], polyak_factor=c['polyak'], lr=0.0,
+                             return_grads=True)
+  assert np.abs(r0['b_actor'] - gr['actor']).max() <= 4e-6 * np.abs(gr['actor']).max()
+  # d L_alpha / d log_alpha = -alpha * mean(w m (log pi + H)) is a mean too, but the log pi in it come from each rank's own rows: compare with the mean of the shard values
+  assert np.isfinite(r0['b_alpha']).all() and abs(float(r0['b_alpha'][0]) - float(gr['alpha'][0])) <= 1e-5 * max(1.0, abs(float(gr['alpha'][0])))
   g = gi.gail_case(22, env='hopper', hidden=32, batch=64, steps=1)
   ds = ogail.DiscState(g['D'], g['H'], True)
   for k in ('W1', 'b1', 'W2', 'b2', 'u1', 'v1', 'u2', 'v2'):

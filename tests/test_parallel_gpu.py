@@ -1,0 +1,78 @@
+"""`-m gpu`: the data-parallel path with world_size 2 on the real kernels.  The GPU box has one GPU, so the two ranks SHARE it and exchange through gloo
+(RCCL refuses two ranks on one device); everything else is the production path: grads-only kernels writing into the GradBuckets views, all-reduce(mean) of
+one bucket per sync point, apply kernels, rank-offset seeds, replica broadcast.  What must hold: the replicas stay BIT-identical on both ranks (they apply the
+same averaged gradient with the same kernels) while their data differ, and `train.py distributed.world_size=2` runs end to end (rank 0 writes the checkpoint)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'tests')); sys.path.insert(0, os.path.join(sys.argv[1], 'tests', 'golden'))
+import numpy as np, torch
+import torch.distributed as dist
+import imitation_learning_amd as il
+from imitation_learning_amd import parallel
+rank, _, dev = parallel.init_from_env(2, 'gloo')
+import test_gpu_parity as tg
+algorithm = sys.argv[3]
+torch.manual_seed(100 + rank)                       # different initialisation per rank on purpose: the broadcast must fix it
+il.seed(parallel.rank_seed(5))
+plan, nets = tg._make_plan(algorithm, 40 + rank)    # different replay shards per rank
+parallel.broadcast_parameters(parallel.replica_tensors(nets[0], nets[1], nets[2], nets[3], nets[4] if algorithm == 'GAIL' else None))
+dp = parallel.DataParallelUpdate(plan)
+idx0 = None
+for k in range(4):
+  dp.run()
+  torch.cuda.synchronize()
+  if k == 0: idx0 = plan.idx.cpu().numpy().copy()
+out = {f't{i}': (n.flat if hasattr(n, 'flat') else n).detach().cpu().numpy() for i, n in enumerate(nets)}
+out['sn'] = nets[4].sn.cpu().numpy(); out['idx0'] = idx0; out['logp'] = plan.logp.cpu().numpy()
+np.savez(os.path.join(sys.argv[2], f'rank{rank}.npz'), **out)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def _free_port():
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+  return p
+
+
+def _launch(args, cwd, timeout=600):
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(_free_port())] + args
+  r = subprocess.run(cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=timeout)
+  assert r.returncode == 0, f'{" ".join(cmd)}\n--- stdout\n{r.stdout[-3000:]}\n--- stderr\n{r.stderr[-3000:]}'
+  return r
+
+
+@pytest.mark.parametrize('algorithm', ['GAIL', 'SAC'])
+def test_two_ranks_keep_bit_identical_replicas(tmp_path, algorithm):
+  script = tmp_path / 'worker.py'
+  script.write_text(WORKER)
+  _launch([str(script), ROOT, str(tmp_path), algorithm], str(tmp_path))
+  r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
+  for k in ('t0', 't1', 't2', 't3') + (('t4', 'sn') if algorithm == 'GAIL' else ()):
+    assert np.isfinite(r0[k]).all()
+    np.testing.assert_array_equal(r0[k], r1[k], err_msg=f'replica tensor {k} differs between the ranks')
+  assert not np.array_equal(r0['idx0'], r1['idx0']) and not np.array_equal(r0['logp'], r1['logp']), 'the ranks must train on different data (rank-offset seeds, own shards)'
+
+
+def test_train_py_runs_data_parallel(tmp_path):
+  _launch([os.path.join(ROOT, 'train.py'), 'algorithm=GAIL', 'env=hopper', 'steps=400', 'training.start=200', 'training.batch_size=64', 'memory.size=2000', 'evaluation.interval=400',
+           'evaluation.episodes=1', 'logging.interval=100', 'distributed.world_size=2', 'distributed.backend=gloo', '+synthetic_env.max_episode_steps=50',
+           '+synthetic_env.dataset_trajectories=6'], str(tmp_path))
+  runs = list((tmp_path / 'outputs' / 'GAIL_hopper').iterdir())
+  assert len(runs) == 1, 'rank 0 alone owns the output directory'
+  names = {p.name for p in runs[0].iterdir()}
+  assert {'agent.pth', 'discriminator.pth', 'metrics.pth'} <= names
+  m = torch.load(runs[0] / 'metrics.pth', weights_only=False)
+  assert len(m['update_steps']) >= 2 and np.isfinite(np.asarray(m['Q_values'][-1])).all()

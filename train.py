@@ -55,15 +55,26 @@ def check_handoff(plan, step):
 
 def train(cfg, file_prefix: str = '') -> float:
   il_config.validate(cfg)
-  dev = default_device()
+  # ---- data parallelism (BASELINE.json configs[4]): one process per GPU, own environment + replay shard, replicated networks, three gradient
+  # all-reduces per update. Launched by torch.distributed.run; rank r seeds everything with seed + r (its data must differ), parameters come from rank 0.
+  world = int(cfg.distributed.world_size)
+  rank = 0
+  if world > 1:
+    from imitation_learning_amd import parallel
+    assert torch.cuda.is_available(), 'train.py needs a GPU: the update path has no CPU fallback'
+    rank, _, dev = parallel.init_from_env(world, cfg.distributed.backend)
+  else:
+    dev = default_device()
   assert dev.type == 'cuda', 'train.py needs a GPU: the update path has no CPU fallback'
-  il.seed(cfg.seed)               # replay index stream (np.random.seed in the reference, train.py:51)
-  np.random.seed(cfg.seed)
-  torch.manual_seed(cfg.seed)
+  lead = rank == 0                # evaluation, plots and checkpoints are rank 0's job
+  seed = cfg.seed + rank
+  il.seed(seed)                   # replay index stream (np.random.seed in the reference, train.py:51)
+  np.random.seed(seed)
+  torch.manual_seed(seed)
 
   env_kw = dict(cfg.get('synthetic_env', {}) or {})
   env, eval_env = make_env(cfg.env, cfg.imitation.absorbing, load_data=True, **env_kw), make_env(cfg.env, cfg.imitation.absorbing, **env_kw)
-  env.seed(cfg.seed); eval_env.seed(cfg.seed)
+  env.seed(seed); eval_env.seed(seed)
   score_lo, score_hi = env.env.ref_min_score, env.env.ref_max_score
   normalise = lambda returns: (np.asarray(returns) - score_lo) / (score_hi - score_lo)  # D4RL normalised score
   expert_memory = env.get_dataset(trajectories=cfg.imitation.trajectories, subsample=cfg.imitation.subsample, device=dev)
@@ -93,6 +104,8 @@ def train(cfg, file_prefix: str = '') -> float:
     discriminator = il.REDDiscriminator(state_size, action_size, cfg.imitation)
     discriminator_optimiser = il.AdamW(discriminator, lr=cfg.imitation.learning_rate, weight_decay=cfg.imitation.weight_decay)
 
+  if world > 1:   # replicas start from rank 0's initialisation (the per-rank torch seeds differ)
+    parallel.broadcast_parameters(parallel.replica_tensors(actor, critic, target_critic, log_alpha, discriminator))
   metrics = dict(train_steps=[], train_returns=[], test_steps=[], test_returns=[], test_returns_normalized=[], update_steps=[], predicted_rewards=[], alphas=[], entropies=[], Q_values=[])
   score = []
   if cfg.check_time_usage: start_time = time.time()
@@ -106,6 +119,7 @@ def train(cfg, file_prefix: str = '') -> float:
       episode_returns = evaluate_agent(actor, eval_env, cfg.evaluation.episodes)
       normalised = normalise(episode_returns)
       metrics.update(test_steps=[0], test_returns=[episode_returns], test_returns_normalized=[list(normalised)])
+      if not lead: return float(np.mean(normalised))   # algorithm=BC has no update block to parallelise: every rank clones on its own, rank 0 reports
       torch.save(dict(actor=actor.state_dict()), f'{file_prefix}agent.pth')
       torch.save(metrics, f'{file_prefix}metrics.pth')
       return float(np.mean(normalised))
@@ -118,6 +132,11 @@ def train(cfg, file_prefix: str = '') -> float:
     else: discriminator.set_sigma(expert_memory['states'][:B], expert_memory['actions'][:B])
     if cfg.check_time_usage: metrics['pre_training_time'], start_time = time.time() - start_time, time.time()
     if cfg.imitation.mix_expert_data == 'prefill_memory': memory.transfer_transitions(expert_memory)
+
+  if world > 1 and (cfg.bc_pretraining.iterations > 0 or cfg.algorithm in ('DRIL', 'RED')):   # every rank pretrained on its own shuffles: keep rank 0's result
+    parallel.broadcast_parameters(parallel.replica_tensors(actor, critic, target_critic, log_alpha, discriminator))
+    if cfg.algorithm == 'DRIL': discriminator.q, = parallel.broadcast_scalars([discriminator.q])
+    if cfg.algorithm == 'RED': discriminator.sigma_1, = parallel.broadcast_scalars([discriminator.sigma_1])
 
   if cfg.algorithm == 'PWIL' and cfg.imitation.mix_expert_data != 'none':  # train.py:135-141
     for i in range(expert_memory.size):
@@ -141,6 +160,11 @@ def train(cfg, file_prefix: str = '') -> float:
                          imitation_cfg=cfg.imitation if cfg.algorithm == 'GAIL' else None, mix_expert=mixed and cfg.algorithm in ('DRIL', 'GMMIL', 'RED'),
                          bc_aux=bool(cfg.imitation.bc_aux_loss))
   captured = False
+  runner = plan
+  if world > 1:
+    if plan is None:
+      raise NotImplementedError('distributed.world_size > 1 needs the captured update plan (a GAIL variant with per-update host inputs, or a batch size that is not a multiple of 16, has no data-parallel path)')
+    runner = parallel.DataParallelUpdate(plan)   # grads-only kernels -> all-reduce(mean) of one flat bucket per sync point -> apply kernels
 
   # acting (train.py:151-168): il_act_step through a pinned mailbox; PWIL computes its reward per step on the device and keeps the per-function path
   schedule = (cfg.get('acting', {}) or {}).get('schedule', 'exact')  # `+acting.schedule=fused|overlap`: see imitation_learning_amd/acting.py (behaviour policy lags 1-2 updates)
@@ -187,9 +211,20 @@ def train(cfg, file_prefix: str = '') -> float:
       if plan is not None:
         if cfg.algorithm == 'AdRIL': plan.relabel_args(step, memory.num_trajectories)   # the relabeller's per-update scalars -> device buffer (models.py:300-318)
         if not captured:
-          plan.run(); plan.capture(warmup=0); captured = True   # first update eagerly (loads code objects; GMMIL: fixes the kernel bandwidths), then capture
+          runner.run()   # first update eagerly (loads code objects; GMMIL: fixes the kernel bandwidths), then capture
+          if world > 1 and cfg.algorithm == 'GMMIL':   # one reward function on every rank: rank 0's bandwidths (models.py:193-195 freezes the first batch's)
+            discriminator.gamma_1, discriminator.gamma_2 = parallel.broadcast_scalars([discriminator.gamma_1, discriminator.gamma_2])
+          try:
+            runner.capture(warmup=0)
+            step_update = runner.replay
+          except Exception as e:   # a collective that refuses stream capture (gloo; some RCCL builds): keep going with eager launches, and say so
+            if world == 1: raise
+            torch.cuda.synchronize()
+            print(f'[train] rank {rank}: graph capture of the data-parallel update failed ({type(e).__name__}); using eager launches', file=sys.stderr)
+            step_update = runner.run
+          captured = True
         else:
-          plan.replay()
+          step_update()
         rewards, log_probs, Q_values = plan.transitions['rewards'], plan.logp, plan.q
       else:
         transitions, expert_transitions = memory.sample(B), expert_memory.sample(B)
@@ -221,7 +256,7 @@ def train(cfg, file_prefix: str = '') -> float:
 
     if schedule == 'overlap': action = worker.act(state)   # own stream, published snapshot: returns while the update is still running
 
-    if step % cfg.evaluation.interval == 0 and not cfg.check_time_usage:
+    if step % cfg.evaluation.interval == 0 and not cfg.check_time_usage and lead:
       episode_returns = evaluate_agent(actor, eval_env, cfg.evaluation.episodes)
       normalised = normalise(episode_returns)
       score.append(float(normalised.mean()))
@@ -236,6 +271,12 @@ def train(cfg, file_prefix: str = '') -> float:
         lineplot(metrics['update_steps'], metrics['Q_values'], filename=f'{file_prefix}Q_values', yaxis='Q-value', title=f'{cfg.algorithm}: {cfg.env} Q-values')
 
   check_handoff(plan, cfg.steps)   # never save a learner whose last updates ran on expired device-side waits
+  if world > 1:
+    import torch.distributed as dist
+    torch.cuda.synchronize(); dist.barrier()
+    if not lead:   # replicas are identical: rank 0 writes the checkpoint; the others return their (empty) score
+      dist.destroy_process_group()
+      return float('nan')
   if cfg.check_time_usage: metrics['training_time'] = time.time() - start_time
   if cfg.save_trajectories:   # train.py:231-234
     _, trajectories = evaluate_agent(actor, eval_env, cfg.evaluation.episodes, return_trajectories=True, render=cfg.render)
@@ -243,14 +284,17 @@ def train(cfg, file_prefix: str = '') -> float:
   torch.save(dict(actor=actor.state_dict(), critic=critic.state_dict(), log_alpha=log_alpha), f'{file_prefix}agent.pth')
   if cfg.algorithm in ('DRIL', 'GAIL', 'RED'): torch.save(discriminator.state_dict(), f'{file_prefix}discriminator.pth')   # train.py:238
   torch.save(metrics, f'{file_prefix}metrics.pth')
+  if world > 1:
+    dist.destroy_process_group()
   return float(np.mean(score)) if score else float('nan')
 
 
 def main(argv):
   cfg = il_config.compose(argv)
   out = os.path.join('outputs', f'{cfg.algorithm}_{cfg.env}', time.strftime('%m-%d_%H-%M-%S'))
-  os.makedirs(out, exist_ok=True)
-  os.chdir(out)  # hydra.job.chdir=true in the reference
+  if int(os.environ.get('RANK', '0')) == 0:   # data-parallel runs: rank 0 owns the output directory (the other ranks write nothing)
+    os.makedirs(out, exist_ok=True)
+    os.chdir(out)  # hydra.job.chdir=true in the reference
   score = train(cfg)
   print(f'{cfg.algorithm} {cfg.env}: mean normalised score {score:.4f} (outputs in {out})')
   return score
