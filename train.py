@@ -214,14 +214,11 @@ def train(cfg, file_prefix: str = '') -> float:
           runner.run()   # first update eagerly (loads code objects; GMMIL: fixes the kernel bandwidths), then capture
           if world > 1 and cfg.algorithm == 'GMMIL':   # one reward function on every rank: rank 0's bandwidths (models.py:193-195 freezes the first batch's)
             discriminator.gamma_1, discriminator.gamma_2 = parallel.broadcast_scalars([discriminator.gamma_1, discriminator.gamma_2])
-          try:
-            runner.capture(warmup=0)
+          if world > 1 and cfg.distributed.backend != 'nccl':
+            step_update = runner.run   # gloo collectives synchronise the host: not capturable (and a failed capture poisons the stream) - eager launches
+          else:
+            runner.capture(warmup=0)   # RCCL collectives are captured with the kernels: one graph replay per data-parallel update
             step_update = runner.replay
-          except Exception as e:   # a collective that refuses stream capture (gloo; some RCCL builds): keep going with eager launches, and say so
-            if world == 1: raise
-            torch.cuda.synchronize()
-            print(f'[train] rank {rank}: graph capture of the data-parallel update failed ({type(e).__name__}); using eager launches', file=sys.stderr)
-            step_update = runner.run
           captured = True
         else:
           step_update()
