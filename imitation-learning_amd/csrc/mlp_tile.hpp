@@ -161,17 +161,19 @@ __device__ __forceinline__ void tile_bwd_dx(const float* dYs, int ldy, int Npad,
 // ---------------------------------------------------------------------------------------------
 // Columns [c_lo, c_hi) of dX[16 x K] = dYs[16 x N] . W with the N-REDUCTION split over the waves (wave w owns n in [16w, 16w + 16), ...): for a
 // narrow dX (dQ/da: A <= 8 columns of a K = S + A wide product) tile_bwd_dx keeps one or two waves busy with N/4 dependent MFMAs each; here
-// every wave issues 4 and the partial tiles meet in LDS (`part` >= nw * 256 floats), summed in wave order (deterministic).
+// every wave issues 4 and the partial tiles meet in LDS (`part` >= (N/16) * 256 floats), summed in n-block order (deterministic).
 // Contains __syncthreads(); every thread of the block must call. epi(col, row, value) once per element of the 16-column tiles that overlap the range.
 // ---------------------------------------------------------------------------------------------
 template <class Epi>
 __device__ __forceinline__ void tile_bwd_dx_cols(const float* dYs, int ldy, int N, const float* __restrict__ W, int ldw, int K, int c_lo, int c_hi, float* part, Epi epi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
+  // One partial tile per 16-wide n-block (N / 16 <= 16 of them), summed in n-block order: the result does not depend on how many waves the workgroup
+  // has (a 512-thread launch of the population path gives bit-identical values to the 1024-thread launch of a single learner).
   for (int kb = (c_lo >> 4) << 4; kb < c_hi; kb += 16) {
-    f32x4 acc0 = zero4(), acc1 = zero4();
     const float* wp = W + min(kb + j, K - 1);
     for (int n0 = wave * 16; n0 < N; n0 += nw * 16) {
+      f32x4 acc0 = zero4(), acc1 = zero4();
       const f32x4 a = *reinterpret_cast<const f32x4*>(dYs + j * ldy + n0 + 4 * g);
       float b[4];
 #pragma unroll
@@ -180,14 +182,14 @@ __device__ __forceinline__ void tile_bwd_dx_cols(const float* dYs, int ldy, int 
       acc1 = mfma16(a[1], b[1], acc1);
       acc0 = mfma16(a[2], b[2], acc0);
       acc1 = mfma16(a[3], b[3], acc1);
-    }
-    const f32x4 acc = acc0 + acc1;
+      const f32x4 acc = acc0 + acc1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) part[wave * 256 + (4 * g + r) * 16 + j] = acc[r];
+      for (int r = 0; r < 4; ++r) part[(n0 >> 4) * 256 + (4 * g + r) * 16 + j] = acc[r];
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
       float s = 0.f;
-      for (int w = 0; w < nw; ++w) s += part[w * 256 + i];
+      for (int w = 0; w < (N >> 4); ++w) s += part[w * 256 + i];
       epi(kb + (i & 15), i >> 4, s);
     }
     __syncthreads();
@@ -258,27 +260,27 @@ __device__ __forceinline__ void tile_bwd_packed(const float* dYs, int ldy, int H
 
 // ---------------------------------------------------------------------------------------------
 // Small output layer: Os[16][16] = Xs[16 x K] . W^T + b, W [N][ldw] with N <= 16 (actor head 2A, critic head 1).
-// The K/16 k-blocks are dealt round-robin to the waves; partial tiles are reduced through LDS (`part` >= nw*256 floats).
+// The K/16 k-blocks are dealt round-robin to the waves; partial tiles are reduced through LDS (`part` >= (K/16)*256 floats; K % 16 == 0).
 // Contains __syncthreads(); every thread of the block must call. Result valid after return.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void tile_fwd_small(const float* Xs, int ldx, int K, const float* __restrict__ W, int ldw, int N, const float* __restrict__ bias,
                                                float* Os, float* part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
-  f32x4 acc = zero4();
   const float* wr = W + (size_t)min(j, N - 1) * ldw;  // clamped row: no divergent branch around the load
-  for (int k0 = wave * 16; k0 < K; k0 += nw * 16) {
+  for (int k0 = wave * 16; k0 < K; k0 += nw * 16) {   // one partial tile per k-block (K / 16 <= 16), summed in k-block order below: independent of the wave count
+    f32x4 acc = zero4();
     const f32x4 a = *reinterpret_cast<const f32x4*>(Xs + j * ldx + k0 + 4 * g);
     const f32x4 b = gload4(wr + k0 + 4 * g);  // columns j >= N produce garbage that Os below discards
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = mfma16(a[s], b[s], acc);
-  }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) part[wave * 256 + (4 * g + r) * 16 + j] = acc[r];
+    for (int r = 0; r < 4; ++r) part[(k0 >> 4) * 256 + (4 * g + r) * 16 + j] = acc[r];
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < 256; i += blockDim.x) {
     float s = 0.f;
-    for (int w = 0; w < nw; ++w) s += part[w * 256 + i];
+    for (int w = 0; w < (K >> 4); ++w) s += part[w * 256 + i];
     const int col = i & 15;
     Os[i] = (col < N) ? s + bias[col] : 0.f;
   }
