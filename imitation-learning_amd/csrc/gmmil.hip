@@ -32,31 +32,32 @@ __device__ __forceinline__ float cat_at(const il_batch& b, int S, int r, int k) 
   return k < S ? b.states[(size_t)r * b.ld_states + k] : b.actions[(size_t)r * b.ld_actions + (k - S)];
 }
 
-// grid.x = tiles of 64 rows over both sets (policy tiles first, then expert tiles)
+// grid = (tiles of 64 rows over both sets: policy tiles first, then expert tiles; feature chunks of GKC): one workgroup transposes ONE 64 x 32 chunk, so the 1 MB of
+// inputs is spread over ~128 workgroups instead of 32 that each looped over four chunks behind barriers (12.7 us -> see profiles/r02_*); the chunk-0 workgroup of a
+// tile also normalises its 64 weights (every such workgroup sums the whole weight column: B strided loads, a few per thread).
 __global__ __launch_bounds__(256) void k_gmmil_pack(il_batch pol, il_batch exp, int S, int D, float* __restrict__ ws_) {
   __shared__ float tile[GT][GKC + 1];
   __shared__ float red[32];
   const GmmilWs w = gmmil_ws(pol.n, exp.n, D);
   const int nt1 = w.b1p / GT;
-  if (blockIdx.x == 0) for (int i = threadIdx.x; i < nt1; i += blockDim.x) reinterpret_cast<unsigned*>(ws_ + w.ctr)[i] = 0u;
+  if (blockIdx.x == 0 && blockIdx.y == 0) for (int i = threadIdx.x; i < nt1; i += blockDim.x) reinterpret_cast<unsigned*>(ws_ + w.ctr)[i] = 0u;
   const bool is_exp = (int)blockIdx.x >= nt1;
   const il_batch& b = is_exp ? exp : pol;
   const int n = b.n, np = is_exp ? w.b2p : w.b1p, row0 = ((int)blockIdx.x - (is_exp ? nt1 : 0)) * GT;
   float* T = ws_ + (is_exp ? w.et : w.xt);
-  for (int k0 = 0; k0 < D; k0 += GKC) {
-    for (int i = threadIdx.x; i < GT * GKC; i += blockDim.x) {
-      const int r = i / GKC, k = i - r * GKC;
-      tile[r][k] = (row0 + r < n && k0 + k < D) ? cat_at(b, S, row0 + r, k0 + k) : 0.f;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < GT * GKC; i += blockDim.x) {
-      const int k = i / GT, r = i - k * GT;
-      if (k0 + k < D) T[(size_t)(k0 + k) * np + row0 + r] = tile[r][k];
-    }
-    __syncthreads();
-  }
+  const int k0 = (int)blockIdx.y * GKC;
   float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) s += b.weights[(size_t)i * b.ld_weights];
+  if (blockIdx.y == 0) for (int i = threadIdx.x; i < n; i += blockDim.x) s += b.weights[(size_t)i * b.ld_weights];   // requested before the transpose: in flight under it
+  for (int i = threadIdx.x; i < GT * GKC; i += blockDim.x) {
+    const int r = i / GKC, k = i - r * GKC;
+    tile[r][k] = (row0 + r < n && k0 + k < D) ? cat_at(b, S, row0 + r, k0 + k) : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < GT * GKC; i += blockDim.x) {
+    const int k = i / GT, r = i - k * GT;
+    if (k0 + k < D) T[(size_t)(k0 + k) * np + row0 + r] = tile[r][k];
+  }
+  if (blockIdx.y != 0) return;
   s = block_sum(s, red);
   float* wn = ws_ + (is_exp ? w.wen : w.wn);
   for (int r = threadIdx.x; r < GT; r += blockDim.x) wn[row0 + r] = (row0 + r < n) ? b.weights[(size_t)(row0 + r) * b.ld_weights] / s : 0.f;
@@ -176,7 +177,7 @@ extern "C" int il_gmmil_reward(const il_batch* pol, const il_batch* exp, int32_t
   const GmmilWs w = gmmil_ws(pol->n, exp->n, D);
   if (workspace_floats < w.total) return il_set_error(IL_ERR_WORKSPACE, "il_gmmil_reward: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)w.total);
   hipStream_t st = (hipStream_t)stream_;
-  { IL_TRACE("k_gmmil_pack", st); k_gmmil_pack<<<w.b1p / GT + w.b2p / GT, 256, 0, st>>>(*pol, *exp, S, D, workspace); }
+  { IL_TRACE("k_gmmil_pack", st); k_gmmil_pack<<<dim3(w.b1p / GT + w.b2p / GT, (D + GKC - 1) / GKC), 256, 0, st>>>(*pol, *exp, S, D, workspace); }
   { IL_TRACE("k_gmmil_tile", st); k_gmmil_tile<0><<<dim3(w.b1p / GT, w.njt, 2), 256, 0, st>>>(pol->n, exp->n, D, g1, g2, workspace, nullptr, 0, out_rewards, out_sim, out_self); }
   IL_CHECK_LAUNCH("il_gmmil_reward");
   return IL_OK;
@@ -192,7 +193,7 @@ extern "C" int il_gmmil_sqdist(const il_batch* a, const il_batch* b, int32_t S, 
   const GmmilWs w = gmmil_ws(a->n, b->n, D);
   if (workspace_floats < w.total) return il_set_error(IL_ERR_WORKSPACE, "il_gmmil_sqdist: workspace too small");
   hipStream_t st = (hipStream_t)stream_;
-  { IL_TRACE("k_gmmil_pack", st); k_gmmil_pack<<<w.b1p / GT + w.b2p / GT, 256, 0, st>>>(*a, *b, S, D, workspace); }
+  { IL_TRACE("k_gmmil_pack", st); k_gmmil_pack<<<dim3(w.b1p / GT + w.b2p / GT, (D + GKC - 1) / GKC), 256, 0, st>>>(*a, *b, S, D, workspace); }
   { IL_TRACE("k_gmmil_tile", st); k_gmmil_tile<1><<<dim3(w.b1p / GT, w.b2p / GT, 1), 256, 0, st>>>(a->n, b->n, D, 0.f, 0.f, workspace, out, 0, nullptr, nullptr, nullptr); }
   IL_CHECK_LAUNCH("il_gmmil_sqdist");
   return IL_OK;

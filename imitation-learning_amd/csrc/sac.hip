@@ -1133,7 +1133,12 @@ __global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ 
   il_sac d = dL[blockIdx.y]; il_batch b = bL[blockIdx.y];
   globalize(d); globalize(b);
   const DwArgs a = kind ? actor_dw_args(&d, &b, flags) : critic_dw_args(&d, flags);
-  dw_adam_body<4>(a, (int)blockIdx.x, (int)gridDim.x);   // (confining a learner to one XCD so that its dW operands cross the fabric once was measured: no gain)
+  // Measured at 32 learners (round 2, one box, k_dw_adam critic launch 103 us = 23 TFLOP/s, MfmaUtil 12.7 %, 1.8 waves per SIMD resident on average): the products alone
+  // (no Adam epilogue) take 79 us, the epilogue alone 46 us. What did NOT move it: 32 x 32 blocks of dW per wave (half the operand bytes per MFMA): 100 us; every learner
+  // confined to XCD l % 8 (operand panels cross the fabric once; `s_getreg XCC_ID` confirms workgroup g runs on XCD g % 8): 103 us; 16 instead of 8 operand loads in
+  // flight per lane: 113 us. It is neither L2 -> CU nor fabric bandwidth: each wave is a serial chain of (8 loads -> wait -> 16 MFMAs) with three waves per SIMD to hide
+  // a loaded-memory latency of microseconds. The fix is structural (a workgroup staging 64-feature operand panels through LDS for a 64 x 64 block of dW); not built yet.
+  dw_adam_body<4>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 extern "C" int il_sac_update_population(const il_sac* descs_dev, const il_batch* batches_dev, int32_t n_learners, const il_sac* shape_host, uint32_t flags, il_stream_t stream_) {
