@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get('IL_HIP_LIBRARY') or os.path.join(_HERE, 'libil_hip.so
 
 IL_FLAG_GRADS_ONLY, IL_FLAG_TICK, IL_FLAG_SAC_FORWARD_ONLY, IL_FLAG_SAC_SKIP_FORWARD, IL_FLAG_SAC_PREPARED = 1, 2, 4, 8, 16
 IL_FLAG_GAIL_CLOSE_EPOCH = 32
+IL_FLAG_SAC_WAIT_INDICES = 64
 c_f32p, c_i32p, c_u32p, c_i64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)
 
 
@@ -110,6 +111,7 @@ _SIGNATURES = {
     'il_sync_probe': (C.c_int, [_P, C.c_int32, _P]),
     'il_replay_gather_workgroups': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     'il_replay_sample_device': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
+    'il_replay_draw_resident': (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     'il_replay_sample_population': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
     'il_sac_update_population': (C.c_int, [_P, _P, C.c_int32, C.POINTER(Sac), C.c_uint32, _P]),
     'il_gail_step_population': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(Disc), _P]),

@@ -260,20 +260,33 @@ __device__ __forceinline__ void gather_rows(const float* __restrict__ ring, int6
 // memory.sample(B) for the agent ring THEN the expert ring (the order train.py:173 consumes the stream) + both gathers: one launch
 __global__ __launch_bounds__(256) void k_sample2(uint32_t* __restrict__ state, int n, const int64_t* __restrict__ rs_a, const float* __restrict__ ring_a, int64_t cap_a, int row4_a,
                                                   int32_t* __restrict__ idx_a, float* __restrict__ rows_a, const int64_t* __restrict__ rs_b, const float* __restrict__ ring_b,
-                                                  int64_t cap_b, int row4_b, int32_t* __restrict__ idx_b, float* __restrict__ rows_b, long long* __restrict__ sync) {
+                                                  int64_t cap_b, int row4_b, int32_t* __restrict__ idx_b, float* __restrict__ rows_b, long long* __restrict__ sync, int resident) {
   __shared__ MtShared sh;
   const int tid = threadIdx.x;
   for (int i = tid; i < MT_N; i += 256) sh.mt[i] = state[i];
   if (tid == 0) sh.pos = (int)state[MT_N];
+  // resident (il_replay_draw_resident): launched on the discriminator branch's stream with NO dependency on the update's main stream, i.e. while the previous
+  // update is still running. The generator state is in LDS already; the draw itself must wait until that update is over (its kernels read the index arrays this
+  // one overwrites, and the ring cursor may still move): [IL_SYNC_MAIN_EPOCH] has to reach the number of draws made so far (= [IL_SYNC_INDICES]).
+  if (resident) sync_wait(sync, IL_SYNC_MAIN_EPOCH, sync[IL_SYNC_INDICES]);
   __syncthreads();
   mt_draw(sh, rs_a, n, idx_a);
-  if (ring_b) { __syncthreads(); mt_draw(sh, rs_b, n, idx_b); }
+  if (rs_b) { __syncthreads(); mt_draw(sh, rs_b, n, idx_b); }
   if (sync) sync_signal(sync + IL_SYNC_INDICES);   // both index arrays are in place (a consumer that gathers its own rows need not wait for k_gather2)
   __syncthreads();
   for (int i = tid; i < MT_N; i += 256) state[i] = sh.mt[i];
   if (tid == 0) state[MT_N] = (uint32_t)sh.pos;
   if (rows_a) gather_rows(ring_a, cap_a, row4_a, idx_a, n, rows_a);
   if (ring_b && rows_b) gather_rows(ring_b, cap_b, row4_b, idx_b, n, rows_b);
+}
+
+extern "C" int il_replay_draw_resident(uint32_t* state_dev, int32_t n, const int64_t* ring_state_a, int32_t* idx_a, const int64_t* ring_state_b, int32_t* idx_b, int64_t* sync,
+                                       il_stream_t stream) {
+  IL_CHECK_ARG(state_dev && ring_state_a && idx_a && n > 0 && sync && (!ring_state_b == !idx_b), "il_replay_draw_resident: bad arguments (the il_sync counters are required)");
+  { IL_TRACE("k_sample2", stream); k_sample2<<<1, 256, 0, (hipStream_t)stream>>>(state_dev, n, ring_state_a, nullptr, 0, 0, idx_a, nullptr, ring_state_b, nullptr, 0, 0,
+                                                                            idx_b, nullptr, (long long*)sync, 1); }
+  IL_CHECK_LAUNCH("il_replay_draw_resident");
+  return IL_OK;
 }
 
 // both gathers of an update in one launch, one 16-byte lane per thread (the index draw above is a single-workgroup kernel)
@@ -333,7 +346,7 @@ extern "C" int il_replay_sample_population(const il_sample_args* args_dev, int32
 
 extern "C" int il_mt19937_sample_indices_device(uint32_t* state_dev, const int64_t* ring_state_dev, int32_t n, int32_t* out_dev, il_stream_t stream) {
   IL_CHECK_ARG(state_dev && ring_state_dev && out_dev && n > 0, "il_mt19937_sample_indices_device: bad arguments");
-  { IL_TRACE("k_sample2", stream); k_sample2<<<1, 256, 0, (hipStream_t)stream>>>(state_dev, n, ring_state_dev, nullptr, 0, 0, out_dev, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr); }
+  { IL_TRACE("k_sample2", stream); k_sample2<<<1, 256, 0, (hipStream_t)stream>>>(state_dev, n, ring_state_dev, nullptr, 0, 0, out_dev, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0); }
   IL_CHECK_LAUNCH("il_mt19937_sample_indices_device");
   return IL_OK;
 }
@@ -346,7 +359,7 @@ extern "C" int il_replay_sample_device(uint32_t* state_dev, int32_t n, const int
   IL_CHECK_ARG(state_dev && ring_state_a && ring_a && idx_a && n > 0, "il_replay_sample_device: bad arguments for ring A");
   IL_CHECK_ARG(row_floats_a % 4 == 0 && (!ring_b || (row_floats_b % 4 == 0 && ring_state_b && idx_b && (!rows_a == !rows_b))), "il_replay_sample_device: bad arguments for ring B");
   { IL_TRACE("k_sample2", stream); k_sample2<<<1, 256, 0, (hipStream_t)stream>>>(state_dev, n, ring_state_a, ring_a, capacity_a, row_floats_a / 4, idx_a, nullptr, ring_state_b, ring_b, capacity_b,
-                                                                            row_floats_b / 4, idx_b, nullptr, (long long*)sync); }
+                                                                            row_floats_b / 4, idx_b, nullptr, (long long*)sync, 0); }
   if (!rows_a) { IL_CHECK_LAUNCH("il_replay_sample_device"); return IL_OK; }   // draw only
   const int lanes = n * (row_floats_a / 4) + (ring_b ? n * (row_floats_b / 4) : 0);   // il_replay_gather_workgroups() = ceil(lanes / 256)
   { IL_TRACE("k_gather2", stream); k_gather2<<<(lanes + 255) / 256, 256, 0, (hipStream_t)stream>>>(ring_a, capacity_a, row_floats_a / 4, idx_a, rows_a, ring_b, capacity_b, row_floats_b / 4, idx_b, rows_b, n, (long long*)sync); }

@@ -370,7 +370,7 @@ __device__ __forceinline__ void critic_bwd_resident_gemm(const il_sac& d, int k,
 }
 // relabel: the rewards of this tile are the discriminator `dd`'s prediction on (s, a) - the rows still sit in Xs - computed here once its AdamW step of
 // this update is complete ([IL_SYNC_PARAMS], n_reduce workgroups per step); otherwise dense `rewards` or the batch's own reward field.
-struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; int fwd_only; };   // fwd_only: the forward kernels only (IL_FLAG_SAC_FORWARD_ONLY / data-parallel phase 0): no critic backward
+struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; int fwd_only; int wait_indices; };   // wait_indices: IL_FLAG_SAC_WAIT_INDICES   // fwd_only: the forward kernels only (IL_FLAG_SAC_FORWARD_ONLY / data-parallel phase 0): no critic backward
 // Runs between the critic's own work and its wait for the targets: the discriminator's step usually lands while the targets are still being computed,
 // so the relabel stays off the critical path. Leaves the tile's rewards in LDS (rew16) for critic_bwd_resident_scale.
 __device__ __forceinline__ void critic_relabel_tile(const il_sac& d, const ChainRelabel& rl, int k, int tile, float* smem) {
@@ -466,6 +466,9 @@ __global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const 
   globalize(d); globalize(b);
   if (rl.on) { globalize(rl.dd); rl.out = as_global(rl.out); }
   const int nt = d.batch / IL_TILE_R;
+  // resident sampler (il_replay_draw_resident on the other stream): this update's indices are signalled, not stream-ordered. This launch follows the previous
+  // update's last kernel in its stream, so [IL_SYNC_MAIN_EPOCH] already counts that update; the draw usually finished while this launch was being dispatched.
+  if (rl.wait_indices) { long long* sy = reinterpret_cast<long long*>(d.sync); sync_wait(sy, IL_SYNC_INDICES, sy[IL_SYNC_MAIN_EPOCH] + 1); }
   if ((int)blockIdx.x >= 6 * nt) {
     const int row4 = b.ld_states / 4, lanes = d.batch * row4, G = (int)gridDim.x - 6 * nt;
     const f32x4* src = reinterpret_cast<const f32x4*>(b.states);
@@ -853,7 +856,8 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
         a.log_alpha[0] = pp; a.alpha_opt.m[0] = mm; a.alpha_opt.v[0] = vv;
       }
       if (a.noise_counter) a.noise_counter[0] += 1;
-      if (a.sync) __hip_atomic_fetch_add(reinterpret_cast<long long*>(a.sync) + IL_SYNC_MAIN_EPOCH, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // this update's SAC half is done
+      // this update's SAC half is done. Release: the resident sampler and, behind it, the discriminator kernels of the NEXT update start from this signal and read the noise counter bumped above
+      if (a.sync) __hip_atomic_fetch_add(reinterpret_cast<long long*>(a.sync) + IL_SYNC_MAIN_EPOCH, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (a.target && !a.grads_only) {
       const float omt = (float)(1.0 - a.tau), tau = (float)a.tau;
@@ -1105,6 +1109,7 @@ extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const
       return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update_gather: discriminator too large for the inline relabel (%zu > %zu LDS floats)", reward_lds_floats(d->state_dim + d->action_dim, relabel->hidden), spare);
     rl.dd = *relabel; rl.on = 1; rl.n_reduce = il_gail_step_workgroups(relabel); rl.out = rewards_out;
   }
+  if (flags & IL_FLAG_SAC_WAIT_INDICES) { IL_CHECK_ARG(d->sync, "il_sac_update_gather: IL_FLAG_SAC_WAIT_INDICES needs the il_sync counters"); rl.wait_indices = 1; }
   IL_CHECK_ARG(ring && ring->gather && ring->gather_capacity > 0 && ring->n == d->batch, "il_sac_update_gather: `ring` must carry the %d drawn indices (il_batch.gather)", d->batch);
   IL_CHECK_ARG(rows->states && ring->states && rows->ld_states == ring->ld_states && ring->ld_states % 4 == 0, "il_sac_update_gather: rows / ring must be packed rows of the same width");
   IL_CHECK_ARG(!(flags & (IL_FLAG_GRADS_ONLY | IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY)), "il_sac_update_gather: whole updates only");

@@ -405,6 +405,8 @@ class UpdatePlan:
         ok = self._probe_device_sync(graph=False)
       self._set_device_sync(ok)
     self.graph = self.graph_side = None
+    self.main_feeds_ring = False   # set True when work enqueued on the caller's stream BETWEEN updates moves the agent ring's cursor (train.py: ActingWorker / memory.append)
+    self._captured_resident = False
     self._ring_desc = None
     self._capturing = None   # 'main' / 'side' while one branch of the device-synchronised update is being captured
     self.pre_hooks, self.post_hooks = [], []   # callables enqueuing extra work on the update's stream before / after it (captured with it), e.g. ActingWorker
@@ -549,6 +551,20 @@ class UpdatePlan:
     return z.expand(mem.size)
 
   @property
+  def resident_sampler(self) -> bool:
+    """Ring mode only: the index draw is a RESIDENT launch at the head of the discriminator branch (il_replay_draw_resident) instead of the first kernel of the SAC
+    branch. It starts while the previous update is still running, waits on the device for that update's end ([IL_SYNC_MAIN_EPOCH]), draws and signals
+    [IL_SYNC_INDICES]; the forward / critic-loss launch waits for that signal. The sampling launch (~7 us + a kernel boundary) leaves the update's critical path.
+    Not with `pre_hooks` (an append captured at the head of the main branch must precede the draw in stream order). IL_RESIDENT_SAMPLER=0: draw on the main stream."""
+    return self.ring_mode and not self.pre_hooks and os.environ.get('IL_RESIDENT_SAMPLER', '1') != '0'
+
+  def _draw_resident(self):
+    m, e = self.memory, self.expert_memory
+    st = m.stream().device_state(m.device)
+    _lib.check(_lib.lib().il_replay_draw_resident(_lib.ptr(st), self.B, _lib.ptr(m._ring_state), _lib.ptr(self.idx), _lib.ptr(e._ring_state), _lib.ptr(self.eidx), _lib.ptr(self.sync),
+                                                  _lib.stream_ptr()))
+
+  @property
   def inline_relabel(self) -> bool:
     """Ring mode with a discriminator on (s, a) small enough for the critic-loss workgroups' spare LDS: the reward relabel runs INSIDE k_sac_chain as soon as
     the discriminator's AdamW step has signalled (il_sac_update_gather `relabel`), so the side branch ends with that step. IL_INLINE_RELABEL=0: separate kernel."""
@@ -560,6 +576,8 @@ class UpdatePlan:
 
   def _enqueue_discriminator_branch(self):
     L, st = _lib.lib(), _lib.stream_ptr()
+    if self.resident_sampler:
+      self._draw_resident()
     if self.ring_mode:
       rp, re_ = self._ring_batches()
       if self.inline_relabel:
@@ -572,12 +590,15 @@ class UpdatePlan:
     _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
 
   def _enqueue_sac_branch(self):
-    self.sample_all()
+    resident = self.resident_sampler
+    if not resident:
+      self.sample_all()
     if self.ring_mode:
       inline = self.inline_relabel
+      flags = self.prepared_flag() | (_lib.IL_FLAG_SAC_WAIT_INDICES if resident else 0)
       _lib.check(_lib.lib().il_sac_update_gather(C.byref(self.sac), C.byref(self.pb), C.byref(self._ring_batches()[0]), None if inline else _lib.ptr(self.rewards),
                                                  C.byref(self.disc) if inline else None, _lib.ptr(self.rewards) if inline else None, None, None,
-                                                 _lib.ptr(self.logp), _lib.ptr(self.q), self.prepared_flag(), _lib.stream_ptr()))
+                                                 _lib.ptr(self.logp), _lib.ptr(self.q), flags, _lib.stream_ptr()))
       return
     _lib.check(_lib.lib().il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), self.prepared_flag(), _lib.stream_ptr()))
 
@@ -591,6 +612,8 @@ class UpdatePlan:
         # No stream dependency between the branches at all: they hand over on the device (k_gather2 -> k_gail_grad, k_gail_reward ->
         # k_critic_bwd). Captured, they are TWO graphs replayed on two streams (a fork inside one hipGraph delays one branch by 16-20 us).
         if self._capturing != 'main':
+          if self._capturing is None and self.resident_sampler:
+            self.side.wait_stream(main)   # eager: whatever the caller enqueued before this update (appends moving the ring cursor) precedes the resident draw
           with torch.cuda.stream(self.side):
             self._enqueue_discriminator_branch()
         if self._capturing != 'side':
@@ -688,6 +711,7 @@ class UpdatePlan:
       raise RuntimeError(f'UpdatePlan.capture: {self.sync_timeouts()} device-side waits expired during the warm-up updates (the two branches did not run concurrently); '
                          'their results are invalid. Set IL_DEVICE_SYNC=0 to keep plain stream dependencies.')
     if self.device_sync:   # two graphs, one per branch, replayed on two streams; no edge between them (see _run_update)
+      self._captured_resident = self.resident_sampler
       self.graph_side, self._capturing = torch.cuda.CUDAGraph(), 'side'
       with torch.cuda.graph(self.graph_side, stream=self.side):
         self._run_update()
@@ -703,6 +727,8 @@ class UpdatePlan:
 
   def replay(self):
     if self.graph_side is not None:
+      if self.main_feeds_ring and self._captured_resident:
+        self.side.wait_stream(torch.cuda.current_stream())   # appends enqueued on the caller's stream since the last update must precede the resident index draw
       with torch.cuda.stream(self.side):
         self.graph_side.replay()
     self.graph.replay()

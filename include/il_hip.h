@@ -42,6 +42,7 @@ enum { IL_OK = 0, IL_ERR_ARG = 1, IL_ERR_UNSUPPORTED = 2, IL_ERR_HIP = 3, IL_ERR
 #define IL_FLAG_GAIL_CLOSE_EPOCH 32u /* il_gail_disc_step with il_sync counters: no il_gail_reward follows (il_sac_update_gather relabels inline): the AdamW
                                       workgroups report [IL_SYNC_PARAMS] and the last one closes the discriminator branch's epoch */
 #define IL_FLAG_SAC_SKIP_FORWARD 8u /* il_sac_update: everything after them (the caller already ran FORWARD_ONLY on this batch) */
+#define IL_FLAG_SAC_WAIT_INDICES 64u /* il_sac_update_gather: no sampling kernel precedes this call in its stream - wait on the device for [IL_SYNC_INDICES] (il_replay_draw_resident) */
 
 typedef void* il_stream_t; /* hipStream_t */
 
@@ -131,6 +132,15 @@ int32_t il_replay_gather_workgroups(int32_t n, int32_t row_floats_a, int32_t row
 int il_replay_sample_device(uint32_t* state_dev, int32_t n, const int64_t* ring_state_a, const float* ring_a, int64_t capacity_a, int32_t row_floats_a,
                             int32_t* idx_a, float* rows_a, const int64_t* ring_state_b, const float* ring_b, int64_t capacity_b, int32_t row_floats_b,
                             int32_t* idx_b, float* rows_b, int64_t* sync, il_stream_t stream);
+
+/* The index draws of an update as a RESIDENT launch (train.py:173 draws only; consumers read the rings through il_batch.gather): enqueue it on the discriminator
+ * branch's stream, which has no dependency on the main stream, so the kernel is running - its generator state already in LDS - before the previous update has
+ * finished. It waits on the device until [IL_SYNC_MAIN_EPOCH] equals the number of draws made so far ([IL_SYNC_INDICES]): the previous update no longer reads the
+ * index arrays and every append that precedes this update in stream order has moved the ring cursor; then it draws and signals [IL_SYNC_INDICES].
+ * il_sac_update_gather(IL_FLAG_SAC_WAIT_INDICES) on the main stream waits for that signal instead of for a sampling kernel ahead of it in its own stream: the draw
+ * (one workgroup, ~7 us as a launch of its own) leaves the critical path of the update except for its ~2 us of arithmetic. Ring B may be NULL. */
+int il_replay_draw_resident(uint32_t* state_dev, int32_t n, const int64_t* ring_state_a, int32_t* idx_a, const int64_t* ring_state_b, int32_t* idx_b, int64_t* sync,
+                            il_stream_t stream);
 
 /* Population axis: per-learner arguments of il_replay_sample_device, as a device array. */
 typedef struct il_sample_args {

@@ -172,6 +172,7 @@ def train(cfg, file_prefix: str = '') -> float:
   worker = il.ActingWorker(actor, memory, mirror=schedule == 'overlap') if cfg.algorithm != 'PWIL' and schedule != 'per_function' else None
   if worker is None: schedule = 'per_function'
   if schedule == 'overlap' and plan is not None: worker.attach(plan)   # append + parameter snapshot ride in the update's hipGraph
+  elif plan is not None: plan.main_feeds_ring = True   # appends are enqueued on this stream between updates: a resident index draw on the other stream must come after them
   if cfg.algorithm in ('GAIL', 'RED'): discriminator.eval()   # train.py:147: from here on the RED predictor's dropout is off (DRIL keeps its dropout on purpose)
   t, state, terminal, train_return = 0, env.reset(), False, 0
   action = worker.act(state) if schedule in ('fused', 'overlap') else None
