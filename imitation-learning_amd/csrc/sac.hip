@@ -838,7 +838,7 @@ __device__ __forceinline__ void dw_bias(const DwArgs& a, const adam_consts& ac, 
   if (g == 0 && n0 + j < Nvalid) adam_store(a, ac, poff + n0 + j, s);
 }
 
-template <int U>
+template <int U, bool SKIPBIG = false>   // SKIPBIG: the H x H layers are done by dw_block64 workgroups of the same launch (population path)
 __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, const int nblocks) {   // bid / nblocks: this learner's block index / count
   const int wave_in_block = threadIdx.x >> 6;
   if (bid >= a.n_dw_blocks) {  // ---- tail blocks
@@ -885,7 +885,7 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
   // ---- job decode (wave-uniform)
   const int IN = a.in_dim, H = a.hidden, OUT = a.out_dim;
   const int nt_h = H / 16, kt_in = (IN + 15) / 16, nt_out = (OUT + 15) / 16;
-  const int j1 = nt_h * kt_in, j2 = nt_h * nt_h, j3 = nt_out * nt_h, jb = 2 * nt_h + nt_out;
+  const int j1 = nt_h * kt_in, j2 = SKIPBIG ? 0 : nt_h * nt_h, j3 = nt_out * nt_h, jb = 2 * nt_h + nt_out;
   const int per_net = j1 + j2 + j3 + jb;
   int job = bid * 4 + wave_in_block;
   if (job >= per_net * a.n_nets) return;
@@ -919,12 +919,109 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
   dw_bias(a, ac, dz3, OUT, job * 16, ob3);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Population launch: one WORKGROUP = a 64(n) x 64(k) block of an H x H layer's dW (+ AdamW), operands staged through LDS.
+// dw_tile gives every wave its own 16 x 16 tile with operands straight from global memory: a serial chain of (8 loads -> wait -> 16 MFMAs) per wave, which at
+// population scale runs at MfmaUtil 13 % whatever the operand traffic is (see k_dw_adam_pop). Here the 256 threads fetch 64-row chunks of the two [feature][B]
+// panels with all their loads in flight, park them in LDS ([64][64 + 4] floats each: the +4 makes the 16 lanes of a row group hit 16 different 16-byte bank
+// groups), and each wave runs a 2 x 2 arrangement of 16 x 16 tiles out of it; the next chunk's loads are issued before the current chunk's 64 MFMAs per wave.
+// Every tile keeps dw_tile's two accumulators and its MFMA order (row groups ascending; k-steps 0, 2 -> acc0 and 1, 3 -> acc1), so the gradients, and with them
+// the learners, stay bit-identical to the single-learner kernel.
+// ---------------------------------------------------------------------------------------------
+#define DWB 64            // block edge (features) and batch rows per chunk
+#define DWB_LD (DWB + 4)
+__device__ __forceinline__ void dw_block64(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dzT, const float* __restrict__ xT, int H, int n0, int k0, int64_t poff,
+                                           float* __restrict__ pkf, float* __restrict__ pkb, float* smem) {
+  float* Zs = smem; float* Xs = smem + DWB * DWB_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int ti = wave >> 1, tq = wave & 1;   // this wave's 32 x 32 quadrant: tiles (2 ti + i, 2 tq + q)
+  const int B = a.batch;
+  f32x4 acc[2][2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { acc[i][q][0] = zero4(); acc[i][q][1] = zero4(); }
+  // staging: thread t moves 16-byte lane (feature f = t / 16 + 16 u, rows 4 (t % 16) .. +3) of both panels, u = 0..3
+  const int sf = tid >> 4, sr = (tid & 15) * 4;
+  f32x4 zr[4], xr[4];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { zr[u] = gload4(dzT + (size_t)(n0 + sf + 16 * u) * B + r0 + sr); xr[u] = gload4(xT + (size_t)(k0 + sf + 16 * u) * B + r0 + sr); }
+  };
+  fetch(0);
+  for (int r0 = 0; r0 < B; r0 += DWB) {
+    __syncthreads();   // the previous chunk's readers are done
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { *reinterpret_cast<f32x4*>(Zs + (sf + 16 * u) * DWB_LD + sr) = zr[u]; *reinterpret_cast<f32x4*>(Xs + (sf + 16 * u) * DWB_LD + sr) = xr[u]; }
+    __syncthreads();
+    if (r0 + DWB < B) fetch(r0 + DWB);
+#pragma unroll
+    for (int u = 0; u < DWB / 16; ++u) {   // 16-row groups in ascending order, like dw_tile
+      f32x4 av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { av[i] = *reinterpret_cast<const f32x4*>(Zs + (32 * ti + 16 * i + j) * DWB_LD + 16 * u + 4 * g); bv[i] = *reinterpret_cast<const f32x4*>(Xs + (32 * tq + 16 * i + j) * DWB_LD + 16 * u + 4 * g); }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          acc[i][q][0] = mfma16(av[i][0], bv[q][0], acc[i][q][0]);
+          acc[i][q][1] = mfma16(av[i][1], bv[q][1], acc[i][q][1]);
+          acc[i][q][0] = mfma16(av[i][2], bv[q][2], acc[i][q][0]);
+          acc[i][q][1] = mfma16(av[i][3], bv[q][3], acc[i][q][1]);
+        }
+    }
+  }
+  // Epilogue through LDS: the accumulator layout (a lane owns 4 rows of ONE column) would stream p / m / v as 64-byte pieces of 16 different rows per instruction;
+  // parked in LDS the block is re-read row-wise, so that every wave instruction moves whole 256-byte row segments (the AdamW traffic is the floor of this kernel:
+  // 24 B per parameter). The updated parameters go back to LDS once more for the column-wise lane order of the PB copy.
+  float* Gs = Zs;   // [64][DWB_LD] gradient block, then the updated parameters
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const f32x4 t = acc[i][q][0] + acc[i][q][1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Gs[(32 * ti + 16 * i + 4 * g + r) * DWB_LD + 32 * tq + 16 * q + j] = t[r];
+    }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int rr = sf + 16 * u, n = n0 + rr, k = k0 + sr;
+    const int64_t o = poff + (int64_t)n * H + k;
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + rr * DWB_LD + sr);
+    if (a.grads_only) { *reinterpret_cast<f32x4*>(a.grads + o) = gv; continue; }
+    f32x4 pv = gload4(a.params + o), mv = gload4(a.opt.m + o), vv = gload4(a.opt.v + o);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { float pp = pv[c], mm = mv[c], v2 = vv[c]; adam_update(pp, gv[c], mm, v2, ac); pv[c] = pp; mv[c] = mm; vv[c] = v2; }
+    *reinterpret_cast<f32x4*>(a.params + o) = pv; *reinterpret_cast<f32x4*>(a.opt.m + o) = mv; *reinterpret_cast<f32x4*>(a.opt.v + o) = vv;
+    if (pkf) {
+      *reinterpret_cast<f32x4*>(pkf + packed_fwd_index(n, k, H)) = pv;   // k .. k+3 of row n: one 16-byte lane of PF
+      *reinterpret_cast<f32x4*>(Gs + rr * DWB_LD + sr) = pv;
+    }
+  }
+  if (!pkf || a.grads_only) return;
+  __syncthreads();
+  {  // PB: rows n .. n+3 of column k are one 16-byte lane; thread t takes column t % 64 and row quads (t / 64) + 4 u
+    const int kc = tid & 63;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rq = (tid >> 6) + 4 * u;   // row quad 0..15
+      f32x4 w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = Gs[(4 * rq + r) * DWB_LD + kc];
+      *reinterpret_cast<f32x4*>(pkb + packed_bwd_index(n0 + 4 * rq, k0 + kc, H)) = w;
+    }
+  }
+}
+static inline int dw_block64_count(int H, int nets) { return (H / DWB) * (H / DWB) * nets; }
+
 __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) { dw_adam_body<8>(a, (int)blockIdx.x, (int)gridDim.x); }
 
 static int repack_blocks(int H) { return ceil_div(H * H / 16, 256); }
-__host__ __device__ static inline int dw_blocks(int IN, int H, int OUT, int nets) {
+__host__ __device__ static inline int dw_blocks(int IN, int H, int OUT, int nets, int skip_big = 0) {
   const int nt_h = H / 16, nt_out = (OUT + 15) / 16;
-  const int per_net = nt_h * ((IN + 15) / 16) + nt_h * nt_h + nt_out * nt_h + 2 * nt_h + nt_out;
+  const int per_net = nt_h * ((IN + 15) / 16) + (skip_big ? 0 : nt_h * nt_h) + nt_out * nt_h + 2 * nt_h + nt_out;
   return (per_net * nets + 3) / 4;
 }
 
@@ -964,7 +1061,7 @@ extern "C" int64_t il_mlp_numel(int32_t in_dim, int32_t hidden, int32_t out_dim)
 extern "C" int64_t il_mlp_stride(int32_t in_dim, int32_t hidden, int32_t out_dim) { return net_stride(in_dim, hidden, out_dim); }
 extern "C" int64_t il_sac_workspace_floats(int32_t S, int32_t A, int32_t H, int32_t B) { return sac_ws(S, A, H, B).total; }
 
-__host__ __device__ static inline int dw_blocks(int IN, int H, int OUT, int nets);
+__host__ __device__ static inline int dw_blocks(int IN, int H, int OUT, int nets, int skip_big);
 __host__ __device__ static DwArgs critic_dw_args(const il_sac* d, uint32_t flags) {
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, IN = S + A;
   const SacWs ws = sac_ws(S, A, H, B);
@@ -1016,7 +1113,7 @@ __host__ __device__ static DwArgs actor_dw_args(const il_sac* d, const il_batch*
   a.n_dw_blocks = dw_blocks(S, H, 2 * A, 1);
   a.log_alpha = d->log_alpha; a.alpha_grad = d->alpha_grad; a.alpha_opt = d->alpha_opt; a.alpha_part = d->workspace + ws.alpha_part; a.n_alpha_part = B / IL_TILE_R;
   a.target = d->target; a.polyak_src = d->critic; a.polyak_n = 2 * net_stride(S + A, H, 1); a.tau = d->polyak; a.noise_counter = d->noise_counter; a.sync = d->sync;
-  a.pk_target = d->workspace + ws.pk_tf; a.pk_critic = d->workspace + ws.pk_cf; a.pk_n = 4 * (int64_t)H * H;   // pk_tf|pk_tb and pk_cf|pk_cb are adjacent pairs
+  a.pk_target = d->workspace + ws.pk_tf; a.pk_critic = d->workspace + ws.pk_cf; a.pk_n = 2 * (int64_t)H * H;   // the FORWARD-order copies of both target critics only: targets are never back-propagated, so their PB copies (pk_tb) have no reader (round 2: 1.5 MB of polyak traffic per update removed)
   return a;
 }
 
@@ -1134,15 +1231,30 @@ extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const
 // are device arrays of n_learners descriptors (each learner has its own arenas, optimiser state, workspace, noise counter and batch);
 // gridDim.y (z for k_repack) selects the learner. Kernels are latency-bound at B = 256 (16-64 workgroups): a population fills the chip.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ dL, const il_batch* __restrict__ bL, int kind, uint32_t flags) {
+__global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ dL, const il_batch* __restrict__ bL, int kind, uint32_t flags, int nb64) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * DWB * DWB_LD];
   il_sac d = dL[blockIdx.y]; il_batch b = bL[blockIdx.y];
   globalize(d); globalize(b);
-  const DwArgs a = kind ? actor_dw_args(&d, &b, flags) : critic_dw_args(&d, flags);
-  // Measured at 32 learners (round 2, one box, k_dw_adam critic launch 103 us = 23 TFLOP/s, MfmaUtil 12.7 %, 1.8 waves per SIMD resident on average): the products alone
-  // (no Adam epilogue) take 79 us, the epilogue alone 46 us. What did NOT move it: 32 x 32 blocks of dW per wave (half the operand bytes per MFMA): 100 us; every learner
-  // confined to XCD l % 8 (operand panels cross the fabric once; `s_getreg XCC_ID` confirms workgroup g runs on XCD g % 8): 103 us; 16 instead of 8 operand loads in
-  // flight per lane: 113 us. It is neither L2 -> CU nor fabric bandwidth: each wave is a serial chain of (8 loads -> wait -> 16 MFMAs) with three waves per SIMD to hide
-  // a loaded-memory latency of microseconds. The fix is structural (a workgroup staging 64-feature operand panels through LDS for a 64 x 64 block of dW); not built yet.
+  DwArgs a = kind ? actor_dw_args(&d, &b, flags) : critic_dw_args(&d, flags);
+  // Measured at 32 learners (round 2, one box; critic launch with dw_tile for every layer: 103 us = 23 TFLOP/s, MfmaUtil 12.7 %, 1.8 waves per SIMD resident on average):
+  // the products alone took 79 us, the Adam epilogue alone 46 us. What did NOT move it: 32 x 32 blocks of dW per wave straight from global memory (half the operand
+  // bytes per MFMA): 100 us; every learner confined to XCD l % 8 (`s_getreg XCC_ID` confirms workgroup g runs on XCD g % 8): 103 us; 16 instead of 8 operand loads in
+  // flight per lane: 113 us. Neither L2 -> CU nor fabric bandwidth: a serial (8 loads -> wait -> 16 MFMAs) chain per wave. Hence dw_block64 for the H x H layers.
+  if (nb64 > 0) {
+    const int H = a.hidden, nbh = H / DWB, per_net = nbh * nbh;
+    if ((int)blockIdx.x < nb64) {
+      const int net = (int)blockIdx.x / per_net, blk = (int)blockIdx.x - net * per_net;
+      adam_consts ac = {};
+      if (!a.grads_only) ac = load_adam_consts(a.opt);
+      const int64_t oW2 = (int64_t)net * a.net_stride + (int64_t)H * a.in_dim + H;
+      dw_block64(a, ac, a.dz2 + net * a.h_net_stride, a.h1 + net * a.h_net_stride, H, (blk / nbh) * DWB, (blk % nbh) * DWB, oW2,
+                 a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem);
+      return;
+    }
+    a.n_dw_blocks = dw_blocks(a.in_dim, a.hidden, a.out_dim, a.n_nets, 1);
+    dw_adam_body<4, true>(a, (int)blockIdx.x - nb64, (int)gridDim.x - nb64);
+    return;
+  }
   dw_adam_body<4>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
@@ -1168,9 +1280,12 @@ extern "C" int il_sac_update_population(const il_sac* descs_dev, const il_batch*
   }
   if (!(flags & IL_FLAG_SAC_FORWARD_ONLY)) {
     { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, descs_dev, batches_dev); }
-    { IL_TRACE("k_dw_adam_critic", st); k_dw_adam_pop<<<dim3(dw_blocks(S + A, H, 1, 2), L), 256, 0, st>>>(descs_dev, batches_dev, 0, flags); }
+    static const int lds_dw = [] { const char* e = getenv("IL_POP_DW_LDS"); return e && e[0] == '0' ? 0 : 1; }();
+    const bool b64 = lds_dw && H % DWB == 0 && B % DWB == 0;   // H x H layers as 64 x 64 blocks staged through LDS (dw_block64); IL_POP_DW_LDS=0: dw_tile for every layer
+    const int nbc = b64 ? dw_block64_count(H, 2) : 0, nba = b64 ? dw_block64_count(H, 1) : 0;
+    { IL_TRACE("k_dw_adam_critic", st); k_dw_adam_pop<<<dim3(nbc + dw_blocks(S + A, H, 1, 2, b64), L), 256, 0, st>>>(descs_dev, batches_dev, 0, flags, nbc); }
     { IL_TRACE("k_policy_critic", st); k_policy_critic<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, nullptr, nullptr, descs_dev, batches_dev, 0); }
-    { IL_TRACE("k_dw_adam_actor", st); k_dw_adam_pop<<<dim3(dw_blocks(S, H, 2 * A, 1) + 33, L), 256, 0, st>>>(descs_dev, batches_dev, 1, flags); }
+    { IL_TRACE("k_dw_adam_actor", st); k_dw_adam_pop<<<dim3(nba + dw_blocks(S, H, 2 * A, 1, b64) + 33, L), 256, 0, st>>>(descs_dev, batches_dev, 1, flags, nba); }
   }
   IL_CHECK_LAUNCH("il_sac_update_population");
   return IL_OK;
@@ -1261,7 +1376,7 @@ __global__ __launch_bounds__(256) void k_apply_actor_tail(il_sac d, int n_actor_
   for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < n; i += (int64_t)ntb * blockDim.x) d.target[i] = __fadd_rn(__fmul_rn(d.target[i], tau), __fmul_rn(omt, d.critic[i]));
   const SacWs ws = sac_ws(S, A, H, d.batch);
   float* pt = d.workspace + ws.pk_tf; const float* pc = d.workspace + ws.pk_cf;
-  for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < 4 * (int64_t)H * H; i += (int64_t)ntb * blockDim.x) pt[i] = __fadd_rn(__fmul_rn(pt[i], tau), __fmul_rn(omt, pc[i]));
+  for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < 2 * (int64_t)H * H; i += (int64_t)ntb * blockDim.x) pt[i] = __fadd_rn(__fmul_rn(pt[i], tau), __fmul_rn(omt, pc[i]));   // PF copies only (see actor_dw_args)
 }
 
 extern "C" int il_sac_dp_phase(const il_sac* d, const il_batch* b, int32_t phase, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream_) {
