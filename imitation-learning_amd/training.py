@@ -807,13 +807,27 @@ class BatchedPopulationPlan:
       self.reward_ptrs = torch.tensor([p.rewards.data_ptr() for p in self.plans], dtype=torch.int64, device=dev)
     self.graph = None
     self._prepared = False
+    self.side = torch.cuda.Stream() if self.algorithm == 'GAIL' and os.environ.get('IL_POP_OVERLAP', '1') != '0' else None
 
   def run(self):
     L, st, p0 = _lib.lib(), _lib.stream_ptr(), self.plans[0]
+    prepared = _lib.IL_FLAG_SAC_PREPARED if self._prepared else 0
     _lib.check(L.il_replay_sample_population(_lib.ptr(self.sample_args), self.L, self.B, self.max_row, st))
-    if self.algorithm == 'GAIL':
-      _lib.check(L.il_gail_step_population(_lib.ptr(self.disc_descs), _lib.ptr(self.batches), _lib.ptr(self.expert_batches), _lib.ptr(self.reward_ptrs), self.L, C.byref(p0.disc), st))
-    _lib.check(L.il_sac_update_population(_lib.ptr(self.sac_descs), _lib.ptr(self.batches), self.L, C.byref(p0.sac), _lib.IL_FLAG_SAC_PREPARED if self._prepared else 0, st))
+    if self.algorithm == 'GAIL' and self.side is not None:
+      # The discriminator kernels (48 small workgroups per learner, latency-bound: ~60 us of a ~450 us replay at 32 learners) run on a second stream beside the
+      # reward-independent forward kernels of every learner and join before the critic loss. One fork / join per replay (its ~10 us of queue signalling is paid once
+      # for the whole population, unlike in the single-learner update where it is why the branches hand over on the device instead).
+      main = torch.cuda.current_stream()
+      self.side.wait_stream(main)
+      with torch.cuda.stream(self.side):
+        _lib.check(L.il_gail_step_population(_lib.ptr(self.disc_descs), _lib.ptr(self.batches), _lib.ptr(self.expert_batches), _lib.ptr(self.reward_ptrs), self.L, C.byref(p0.disc), _lib.stream_ptr()))
+      _lib.check(L.il_sac_update_population(_lib.ptr(self.sac_descs), _lib.ptr(self.batches), self.L, C.byref(p0.sac), prepared | _lib.IL_FLAG_SAC_FORWARD_ONLY, st))
+      main.wait_stream(self.side)
+      _lib.check(L.il_sac_update_population(_lib.ptr(self.sac_descs), _lib.ptr(self.batches), self.L, C.byref(p0.sac), _lib.IL_FLAG_SAC_SKIP_FORWARD, st))
+    else:
+      if self.algorithm == 'GAIL':
+        _lib.check(L.il_gail_step_population(_lib.ptr(self.disc_descs), _lib.ptr(self.batches), _lib.ptr(self.expert_batches), _lib.ptr(self.reward_ptrs), self.L, C.byref(p0.disc), st))
+      _lib.check(L.il_sac_update_population(_lib.ptr(self.sac_descs), _lib.ptr(self.batches), self.L, C.byref(p0.sac), prepared, st))
     self._prepared = True
 
   def capture(self, warmup: int = 0):
