@@ -490,6 +490,14 @@ __global__ __launch_bounds__(256) void k_disc_adam(il_disc d, int64_t P) {
     adam_update(pp, d.grad[e], mm, vv, ac);
     d.params[e] = pp; d.opt.m[e] = mm; d.opt.v[e] = vv;
   }
+  if (d.sync) {   // data-parallel schedule with the device-side hand-off: this is the discriminator branch's last kernel (cf. k_gail_reduce with close_epoch): the inline relabel of
+    long long* sy = reinterpret_cast<long long*>(d.sync);   // il_sac_update_gather waits for [IL_SYNC_PARAMS]; the last workgroup closes the branch's epoch
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const long long done = __hip_atomic_fetch_add(sy + IL_SYNC_PARAMS, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1;
+      if (done % (long long)gridDim.x == 0) __hip_atomic_fetch_add(sy + IL_SYNC_SIDE_EPOCH, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 extern "C" int il_gail_apply_grads(const il_disc* d, il_stream_t stream_) {
   if (int rc = check_disc(d)) return rc;

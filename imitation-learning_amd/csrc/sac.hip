@@ -1209,7 +1209,8 @@ extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const
   if (flags & IL_FLAG_SAC_WAIT_INDICES) { IL_CHECK_ARG(d->sync, "il_sac_update_gather: IL_FLAG_SAC_WAIT_INDICES needs the il_sync counters"); rl.wait_indices = 1; }
   IL_CHECK_ARG(ring && ring->gather && ring->gather_capacity > 0 && ring->n == d->batch, "il_sac_update_gather: `ring` must carry the %d drawn indices (il_batch.gather)", d->batch);
   IL_CHECK_ARG(rows->states && ring->states && rows->ld_states == ring->ld_states && ring->ld_states % 4 == 0, "il_sac_update_gather: rows / ring must be packed rows of the same width");
-  IL_CHECK_ARG(!(flags & (IL_FLAG_GRADS_ONLY | IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY)), "il_sac_update_gather: whole updates only");
+  IL_CHECK_ARG(!(flags & (IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY)), "il_sac_update_gather: whole updates (or, with IL_FLAG_GRADS_ONLY, everything up to the critic gradients)");
+  IL_CHECK_ARG(!(flags & IL_FLAG_GRADS_ONLY) || d->critic_grad, "il_sac_update_gather: IL_FLAG_GRADS_ONLY needs the critic_grad arena");
   hipStream_t st = (hipStream_t)stream_;
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const int G = il_sac_chain_gather_workgroups(B, ring->ld_states, H);
@@ -1219,6 +1220,10 @@ extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const
   { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt + G, tile_threads(H), lds, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl); }
   DwArgs ca = critic_dw_args(d, flags);
   { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
+  if (flags & IL_FLAG_GRADS_ONLY) {   // data-parallel: stop at the critic gradients (critic_grad); the caller all-reduces them and continues with il_sac_dp_phase(rows, 2) and (rows, 3)
+    IL_CHECK_LAUNCH("il_sac_update_gather");
+    return IL_OK;
+  }
   { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); k_policy_critic<<<(2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *rows, out_logp, out_q, nullptr, nullptr, hp); }
   DwArgs aa = actor_dw_args(d, rows, flags);
   { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 33, 256, 0, st>>>(aa); }

@@ -106,7 +106,17 @@ class DataParallelUpdate:
   def __init__(self, plan, group=None):
     self.plan, self.group = plan, group
     assert not plan.bc_aux, 'DataParallelUpdate: the behavioural-cloning auxiliary step has no data-parallel form (use the per-function path)'
-    plan._set_device_sync(False)   # this path orders its two streams with events around the all-reduces
+    # Device-side hand-off between the discriminator branch and the SAC branch, as on one GPU (UpdatePlan): no stream dependency between the two streams, the index
+    # draw resident at the head of the discriminator branch, the reward relabel inline in the forward / critic-loss launch. The discriminator's all-reduce then sits
+    # on a stream of its own and must not share a communicator with the critic / actor all-reduces of the main stream (two unordered streams could issue the
+    # collectives of ONE communicator in different orders on different ranks): it gets its own process group. IL_DP_HANDOFF=0: stream dependencies, one communicator.
+    self.handoff = bool(plan.algorithm == 'GAIL' and plan.device_sync and plan.ring_mode and plan.inline_relabel and os.environ.get('IL_DP_HANDOFF', '1') != '0')
+    if not self.handoff:
+      plan._set_device_sync(False)   # this schedule orders its two streams with events around the all-reduces
+    self.side_group = group
+    if self.handoff and dist.is_initialized():
+      self.side_group = dist.new_group(ranks=None if group is None else dist.get_process_group_ranks(group), backend=dist.get_backend(group))
+    self.graph = self.graph_side = None
     ao, to = plan._keep[4], plan._keep[6]
     # actor grad and alpha grad travel in one bucket: the optimisers' gradient arenas become views into it
     self.buckets = GradBuckets(ao.grad.numel(), plan._keep[5].grad, plan._keep[8].grad if plan.algorithm == 'GAIL' else None)
@@ -122,6 +132,9 @@ class DataParallelUpdate:
     p, L = self.plan, _lib.lib()
     G = _lib.IL_FLAG_GRADS_ONLY
     main = torch.cuda.current_stream()
+    if self.handoff:
+      self._run_handoff(main)
+      return
     if p.algorithm == 'GAIL' and p.device_index_draw:
       # The discriminator branch (gradients, all-reduce, AdamW, relabel: the longer one) reads its rows straight from the rings through the drawn indices
       # (il_batch.gather), so it forks right after the index draw; the gathers the SAC kernels need run on the main stream beside it.
@@ -155,7 +168,58 @@ class DataParallelUpdate:
     _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 3, None, None, 0, _lib.stream_ptr()))
     p._prepared = True
 
+  def _enqueue_side(self):
+    """Discriminator branch: [resident index draw] -> gradients from the rings through the indices -> all-reduce (own communicator) -> AdamW, which signals [IL_SYNC_PARAMS]."""
+    p, L = self.plan, _lib.lib()
+    if p.resident_sampler:
+      p._draw_resident()
+    rp, re_ = p._ring_batches()
+    _lib.check(L.il_gail_disc_step(C.byref(p.disc), C.byref(rp), C.byref(re_), None, None, _lib.IL_FLAG_GRADS_ONLY, _lib.stream_ptr()))
+    all_reduce_mean_(self.disc_bucket, self.side_group)
+    _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
+
+  def _enqueue_main(self):
+    """SAC branch: [index draw] -> forward + critic loss chained per tile with the rewards relabelled inline (waits on the device for the discriminator's all-reduced step)
+    -> critic gradients -> all-reduce -> AdamW(critic) + policy loss + actor gradients -> all-reduce -> AdamW(actor), Adam(alpha), polyak."""
+    p, L = self.plan, _lib.lib()
+    resident = p.resident_sampler
+    if not resident:
+      p.sample_all()
+    flags = p.prepared_flag() | _lib.IL_FLAG_GRADS_ONLY | (_lib.IL_FLAG_SAC_WAIT_INDICES if resident else 0)
+    _lib.check(L.il_sac_update_gather(C.byref(p.sac), C.byref(p.pb), C.byref(p._ring_batches()[0]), None, C.byref(p.disc), _lib.ptr(p.rewards), None, None, _lib.ptr(p.logp), _lib.ptr(p.q),
+                                      flags, _lib.stream_ptr()))
+    all_reduce_mean_(self.critic_bucket, self.group)
+    _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 2, _lib.ptr(p.logp), _lib.ptr(p.q), 0, _lib.stream_ptr()))
+    all_reduce_mean_(self.actor_bucket, self.group)
+    _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 3, None, None, 0, _lib.stream_ptr()))
+    p._prepared = True
+
+  def _run_handoff(self, main):
+    if self.plan.resident_sampler:
+      self.side.wait_stream(main)   # eager: appends the caller enqueued before this update precede the resident draw
+    with torch.cuda.stream(self.side):
+      self._enqueue_side()
+    self._enqueue_main()
+    main.wait_stream(self.side)     # eager: leave the caller's stream ordered after both branches
+
   def capture(self, warmup: int = 3):
+    if self.handoff:   # two graphs, one per branch and per communicator, replayed on two streams with no edge between them (cf. UpdatePlan.capture)
+      p = self.plan
+      if not p._probe_device_sync(graph=True):   # e.g. a counter-collecting profiler serialises the two graphs: stream dependencies, one graph (below)
+        self.handoff = False
+        p._set_device_sync(False)
+        return self.capture(warmup)
+      p.memory.stream().device_state(p.rows.device)
+      for _ in range(warmup):
+        self.run()
+      torch.cuda.synchronize()
+      self.graph_side = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(self.graph_side, stream=self.side):
+        self._enqueue_side()
+      self.graph = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(self.graph):
+        self._enqueue_main()
+      return self
     self.plan.memory.stream().device_state(self.plan.rows.device)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
@@ -170,4 +234,9 @@ class DataParallelUpdate:
     return self
 
   def replay(self):
+    if self.graph_side is not None:
+      if self.plan.main_feeds_ring and self.plan.resident_sampler:
+        self.side.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(self.side):
+        self.graph_side.replay()
     self.graph.replay()

@@ -238,7 +238,9 @@ int il_sac_update(const il_sac* d, const il_batch* batch, const float* eps_next,
  * update read. The forward / critic-loss launch (k_sac_chain) reads its rows straight from the ring while extra workgroups of the same launch
  * write `rows` (and signal [IL_SYNC_ROWS], il_sac_chain_gather_workgroups() times), so no gather kernel precedes the update.
  * rewards: optional dense [B] rewards that replace the ring's (train.py:194 relabelled rewards); NULL = the ring's reward field. Whole updates of a
- * single learner only; IL_ERR_UNSUPPORTED when the launch cannot be co-resident (then gather first and call il_sac_update). */
+ * single learner only; IL_ERR_UNSUPPORTED when the launch cannot be co-resident (then gather first and call il_sac_update).
+ * IL_FLAG_GRADS_ONLY (data-parallel schedule): stops after the critic gradients (critic_grad arena): the caller all-reduces them and continues with
+ * il_sac_dp_phase(rows, 2) / (rows, 3). */
 int il_sac_update_gather(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const struct il_disc* relabel, float* rewards_out,
                          const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream);
 /* relabel != NULL (needs d->sync; the discriminator must be stepped by il_gail_disc_step(..., IL_FLAG_GAIL_CLOSE_EPOCH) on another stream): the rewards
@@ -329,6 +331,9 @@ int64_t il_disc_workspace_floats(int32_t in_dim, int32_t hidden, int32_t batch);
 /* eps_gp [B] = the U(0,1) draw of training.py:118 (NULL => Philox). */
 int il_gail_disc_step(const il_disc* d, const il_batch* policy, const il_batch* expert, const float* eps_gp, const il_gail_extra* extra,
                       uint32_t flags, il_stream_t stream);
+/* AdamW(discriminator) from d->grad after the all-reduce of the data-parallel schedule. With il_sync counters in the descriptor this is the discriminator branch's last
+ * kernel: its workgroups report [IL_SYNC_PARAMS] and the last one closes the branch's epoch, exactly like il_gail_disc_step(IL_FLAG_GAIL_CLOSE_EPOCH) does on one GPU, so
+ * that il_sac_update_gather(relabel, IL_FLAG_GRADS_ONLY) on the other stream relabels inline as soon as the all-reduced step has landed. */
 int il_gail_apply_grads(const il_disc* d, il_stream_t stream);
 /* Population axis: discriminator step + AIRL/GAIL/FAIRL reward relabel for n_learners discriminators; rewards_out_dev[l] -> float[batch]. */
 int il_gail_step_population(const il_disc* descs_dev, const il_batch* policy_dev, const il_batch* expert_dev, float* const* rewards_out_dev,
