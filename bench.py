@@ -7,8 +7,10 @@ One "step" = one execution of the reference's update block (train.py:173-203, al
 N > 1 (torch.distributed.run): one rank per GPU, own replay shard, three RCCL gradient all-reduces per update (weak scaling:
 per-GPU batch 256); value = N x synchronous global steps/s.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the launch stream) and, at N=1, `cpu_baseline`
-(the numpy oracle port timed on the host cores; the reference itself cannot travel to the GPU box).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the launch stream; whole-update `hbm_frac` / `fp32_frac` at its top level) and,
+at N=1, `cpu_baseline` = the reference's own CPU path (profiles/cpu_reference.json: timed in the build container by profiles/tools/cpu_reference.py, because
+/root/reference cannot travel to the GPU box) next to `cpu_port` = the numpy oracle port timed live on this box's host cores; `population` = the aggregate rate
+of 32 independent learners advanced by the same launches; `secondary` = the other single-GPU configurations of BASELINE.json.
 """
 import argparse
 import ctypes as C
@@ -318,7 +320,7 @@ def main():
   ap.add_argument('--no-overlap', action='store_true', help='one stream, no device-side hand-off: the same kernels back to back (what a counter-collecting profiler needs; il_sac_update still takes its chained launch)')
   ap.add_argument('--no-population', action='store_true')
   ap.add_argument('--no-secondary', action='store_true', help='skip the SAC-only / discriminator-only / GMMIL / PWIL rates')
-  ap.add_argument('--population-learners', type=int, default=16)
+  ap.add_argument('--population-learners', type=int, default=32)
   ap.add_argument('--learners', type=int, default=1, help='population axis: N independent learners per GPU advanced by one graph replay (aggregate updates/s)')
   args = ap.parse_args()
 
@@ -392,7 +394,13 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     ups = world * args.learners * args.steps / elapsed
     # ---- per-kernel durations, HIP events on the launch stream, eager launches of the very same kernels
+    # (traced with the index draw stream-ordered ahead of the forward / critic-loss launch: with the resident draw that launch is dispatched while the draw is still
+    #  waiting for the previous update, so its HIP-event window would include that wait instead of its own work; both schedules are bit-identical)
+    plan.stream_ordered_draw = True
     roof = roofline(plan.run, args.trace_steps, 1, ms_per_step, getattr(plan, 'overlap', False))
+    plan.stream_ordered_draw = False
+    roof['timing_note'] = 'kernel durations: HIP events around eager launches with the index draw stream-ordered (il_replay_sample_device); the timed `value` above runs the resident-draw schedule as two hipGraphs'
+
     out = dict(metric='SAC+GAIL grad-updates/sec (batch 256, HalfCheetah dims)', value=round(ups, 1), unit='updates/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=round(ms_per_step, 5), higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                config=dict(workload='algorithm=GAIL env=halfcheetah: 2 replay samples + discriminator step (BCE+GP+SN) + AIRL relabel + sac_update per step',

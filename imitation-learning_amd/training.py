@@ -407,6 +407,7 @@ class UpdatePlan:
     self.graph = self.graph_side = None
     self.main_feeds_ring = False   # set True when work enqueued on the caller's stream BETWEEN updates moves the agent ring's cursor (train.py: ActingWorker / memory.append)
     self._captured_resident = False
+    self.stream_ordered_draw = False   # True: the index draw stays the first kernel of the SAC branch (bit-identical; what per-kernel timing wants: see bench.py roofline())
     self._ring_desc = None
     self._capturing = None   # 'main' / 'side' while one branch of the device-synchronised update is being captured
     self.pre_hooks, self.post_hooks = [], []   # callables enqueuing extra work on the update's stream before / after it (captured with it), e.g. ActingWorker
@@ -556,7 +557,7 @@ class UpdatePlan:
     branch. It starts while the previous update is still running, waits on the device for that update's end ([IL_SYNC_MAIN_EPOCH]), draws and signals
     [IL_SYNC_INDICES]; the forward / critic-loss launch waits for that signal. The sampling launch (~7 us + a kernel boundary) leaves the update's critical path.
     Not with `pre_hooks` (an append captured at the head of the main branch must precede the draw in stream order). IL_RESIDENT_SAMPLER=0: draw on the main stream."""
-    return self.ring_mode and not self.pre_hooks and os.environ.get('IL_RESIDENT_SAMPLER', '1') != '0'
+    return self.ring_mode and not self.pre_hooks and not self.stream_ordered_draw and os.environ.get('IL_RESIDENT_SAMPLER', '1') != '0'
 
   def _draw_resident(self):
     m, e = self.memory, self.expert_memory
