@@ -187,7 +187,21 @@ extern "C" int il_mt19937_randint(uint32_t* s, int64_t high, int32_t n, int32_t*
 
 // Device version: one workgroup. The draw is a stream compaction of the tempered MT output (every candidate consumes
 // exactly one 32-bit word; rejected ones are skipped), so 256 candidates are tested in parallel and compacted in order.
-struct MtShared { uint32_t mt[MT_N]; int wave_cnt[4]; int pos, count, last; };
+struct MtShared { uint32_t mt[MT_N]; uint32_t nx[MT_N]; int wave_cnt[4]; int pos, count, last, have_next; };
+
+// The NEXT block of 624 words (the twist of sh.mt) into sh.nx. A pure function of the current block, so the resident sampler computes it while it waits for the previous
+// update: when the draw crosses the block boundary (about once per update: two batches of 256 consume ~670 words) the new block is already there.
+__device__ __forceinline__ void mt_next_block(MtShared& sh) {
+  const int tid = threadIdx.x;
+  for (int k = tid; k < 227; k += 256) sh.nx[k] = mt_mix(sh.mt[k], sh.mt[k + 1], sh.mt[k + MT_M]);
+  __syncthreads();
+  for (int k = 227 + tid; k < 454; k += 256) sh.nx[k] = mt_mix(sh.mt[k], sh.mt[k + 1], sh.nx[k - 227]);
+  __syncthreads();
+  for (int k = 454 + tid; k < 623; k += 256) sh.nx[k] = mt_mix(sh.mt[k], sh.mt[k + 1], sh.nx[k - 227]);
+  __syncthreads();
+  if (tid == 0) { sh.nx[623] = mt_mix(sh.mt[623], sh.nx[0], sh.nx[396]); sh.have_next = 1; }
+  __syncthreads();
+}
 
 __device__ __forceinline__ void mt_draw(MtShared& sh, const int64_t* __restrict__ ring_state, int n, int32_t* __restrict__ out) {
   const int tid = threadIdx.x;
@@ -205,7 +219,13 @@ __device__ __forceinline__ void mt_draw(MtShared& sh, const int64_t* __restrict_
   for (int guard = 0; guard < 100000; ++guard) {
     int pos = sh.pos, count = sh.count;
     if (count >= n) break;
-    if (pos >= MT_N) {  // twist: four dependency-free phases
+    if (pos >= MT_N && sh.have_next) {   // the block prepared by mt_next_block
+      for (int k = tid; k < MT_N; k += 256) sh.mt[k] = sh.nx[k];
+      __syncthreads();
+      if (tid == 0) { sh.pos = 0; sh.have_next = 0; }
+      __syncthreads();
+      pos = 0;
+    } else if (pos >= MT_N) {  // twist in place: four dependency-free phases
       uint32_t nv[3]; int q = 0;
       for (int k = tid; k < 227; k += 256) nv[q++] = mt_mix(sh.mt[k], sh.mt[k + 1], sh.mt[k + MT_M]);
       __syncthreads(); q = 0;
@@ -264,7 +284,9 @@ __global__ __launch_bounds__(256) void k_sample2(uint32_t* __restrict__ state, i
   __shared__ MtShared sh;
   const int tid = threadIdx.x;
   for (int i = tid; i < MT_N; i += 256) sh.mt[i] = state[i];
-  if (tid == 0) sh.pos = (int)state[MT_N];
+  if (tid == 0) { sh.pos = (int)state[MT_N]; sh.have_next = 0; }
+  __syncthreads();
+  mt_next_block(sh);   // before the ring state is needed (and, resident, before the wait): off the path from "previous update done" to "indices drawn"
   // resident (il_replay_draw_resident): launched on the discriminator branch's stream with NO dependency on the update's main stream, i.e. while the previous
   // update is still running. The generator state is in LDS already; the draw itself must wait until that update is over (its kernels read the index arrays this
   // one overwrites, and the ring cursor may still move): [IL_SYNC_MAIN_EPOCH] has to reach the number of draws made so far (= [IL_SYNC_INDICES]).
@@ -312,7 +334,7 @@ __global__ __launch_bounds__(256) void k_sample2_pop(const il_sample_args* __res
   __shared__ MtShared sh;
   const int tid = threadIdx.x;
   for (int i = tid; i < MT_N; i += 256) sh.mt[i] = a.state[i];
-  if (tid == 0) sh.pos = (int)a.state[MT_N];
+  if (tid == 0) { sh.pos = (int)a.state[MT_N]; sh.have_next = 0; }
   __syncthreads();
   mt_draw(sh, a.ring_state_a, n, a.idx_a);
   if (a.ring_b) { __syncthreads(); mt_draw(sh, a.ring_state_b, n, a.idx_b); }
