@@ -151,6 +151,7 @@ _SIGNATURES = {
     'il_gail_shaped_step': (C.c_int, [C.POINTER(DiscShaped), C.POINTER(Batch), C.POINTER(Batch), _P, C.POINTER(GailExtra), C.c_uint32, _P]),
     'il_gail_shaped_reward': (C.c_int, [C.POINTER(DiscShaped), C.POINTER(Batch), _P, _P, _P, _P]),
     'il_actor_log_prob': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
+    'il_gail_disc_step_draw': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), C.POINTER(Batch), _P, _P, _P, _P, _P, C.c_uint32, _P]),
     'il_gail_apply_grads': (C.c_int, [C.POINTER(Disc), _P]),
     'il_gail_reward': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), _P, _P, _P, _P]),
     'il_gmmil_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

@@ -11,6 +11,7 @@
 // k_gail_reduce one workgroup: slab sum -> grad, AdamW, spectral-norm buffers update.
 // k_gail_reward eval-mode forward + AIRL / GAIL / FAIRL reward head.
 #include "il_common.hpp"
+#include "mt_device.hpp"
 #include "mlp_tile.hpp"
 #include "disc_reward.hpp"
 
@@ -139,13 +140,24 @@ __device__ __forceinline__ void stage_weights(const DiscLds& L, const float* __r
 // Loss variants (training.py:97-113): BCE and PUGAIL (nonnegative_margin = inf) are calls {policy, expert}; Mixup is ONE call on convex combinations
 // with per-row soft labels. All three are  d loss / d logit = w (c_sig * sigmoid(z) - c_lab) / B  with different constants. `x` carries the optional
 // inputs: the Mixup draws and the log pi(a|s) offsets of subtract_log_policy (logit z = f - log pi; computed without a graph, so a pure shift).
+// The index draw of the update riding in this launch (il_gail_disc_step_draw): gridDim.x carries ONE extra column of workgroups, of which (nt, 0) is the sampler.
+// The discriminator workgroups are resident early - weights staged, Gram matrix and power iterations done - and wait for [IL_SYNC_INDICES]; a sampler launched BEHIND
+// this kernel in the same stream could never satisfy that wait, and one launched AHEAD of it would put this kernel's preparation back on the update's critical path.
+struct GailSampler { uint32_t* state; const int64_t* rs_a; int32_t* idx_a; const int64_t* rs_b; int32_t* idx_b; int n; };
+
 __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp, il_gail_extra x, const il_disc* __restrict__ dL,
-                                                   const il_batch* __restrict__ polL, const il_batch* __restrict__ expL) {
+                                                   const il_batch* __restrict__ polL, const il_batch* __restrict__ expL, GailSampler sa) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int has_sampler = sa.state != nullptr;
+  if (has_sampler && (int)blockIdx.x == (int)gridDim.x - 1) {
+    if (blockIdx.y == 0) mt_sample_update(*reinterpret_cast<MtShared*>(smem), as_global(sa.state), sa.n, as_global(sa.rs_a), as_global(sa.idx_a), as_global(sa.rs_b), as_global(sa.idx_b),
+                                          reinterpret_cast<long long*>(as_global(d.sync)), 1);
+    return;
+  }
   if (dL) { d = dL[blockIdx.z]; pol = polL[blockIdx.z]; exp = expL[blockIdx.z]; }  // population axis
   globalize(d); globalize(pol); globalize(exp); globalize(x);
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch, Dp = (D + 3) & ~3, ldw = Dp + 4;
-  const int tile = blockIdx.x, pass = blockIdx.y, npass = gridDim.y, nt = gridDim.x, row0 = tile * IL_TILE_R, tid = threadIdx.x;
+  const int tile = blockIdx.x, pass = blockIdx.y, npass = gridDim.y, nt = (int)gridDim.x - has_sampler, row0 = tile * IL_TILE_R, tid = threadIdx.x;
   const int nrows = min(IL_TILE_R, B - row0);
   const int kind = d.loss_function == IL_LOSS_MIXUP ? (pass == 0 ? 3 : 2) : pass;   // 0 policy, 1 expert, 2 gradient-penalty mix, 3 mixup mix
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
@@ -455,10 +467,30 @@ extern "C" int il_gail_disc_step(const il_disc* d, const il_batch* pol, const il
   const int nt = ceil_div(d->batch, IL_TILE_R);
   const size_t lds = disc_lds_floats(D, d->hidden) * sizeof(float);
   if (int rc = ensure_lds((const void*)k_gail_grad, lds)) return rc;
-  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, nullptr, nullptr, nullptr); }
+  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, nullptr, nullptr, nullptr, GailSampler{}); }
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
   { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr, (flags & IL_FLAG_GAIL_CLOSE_EPOCH) ? 1 : 0); }
   IL_CHECK_LAUNCH("il_gail_disc_step");
+  return IL_OK;
+}
+
+extern "C" int il_gail_disc_step_draw(const il_disc* d, const il_batch* pol, const il_batch* exp, uint32_t* mt_state_dev, const int64_t* ring_state_a, int32_t* idx_a,
+                                      const int64_t* ring_state_b, int32_t* idx_b, uint32_t flags, il_stream_t stream_) {
+  if (int rc = check_disc(d)) return rc;
+  IL_CHECK_ARG(pol && exp && pol->n == d->batch && exp->n == d->batch && pol->gather && exp->gather, "il_gail_disc_step_draw: both batches must be rings read through il_batch.gather");
+  IL_CHECK_ARG(d->sync && mt_state_dev && ring_state_a && idx_a && ring_state_b && idx_b, "il_gail_disc_step_draw: the il_sync counters, the generator state and both rings' states / index arrays are required");
+  IL_CHECK_ARG(pol->gather == idx_a && exp->gather == idx_b, "il_gail_disc_step_draw: the batches must gather through the index arrays this call draws");
+  hipStream_t st = (hipStream_t)stream_;
+  const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
+  const int nt = ceil_div(d->batch, IL_TILE_R);
+  const size_t lds = disc_lds_floats(D, d->hidden) * sizeof(float);
+  IL_CHECK_ARG(lds >= sizeof(MtShared), "il_gail_disc_step_draw: discriminator too small to host the sampler's state in its workgroup LDS");
+  if (int rc = ensure_lds((const void*)k_gail_grad, lds)) return rc;
+  const GailSampler sa = {mt_state_dev, ring_state_a, idx_a, ring_state_b, idx_b, d->batch};
+  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt + 1, gail_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, nullptr, il_gail_extra{}, nullptr, nullptr, nullptr, sa); }
+  const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
+  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr, (flags & IL_FLAG_GAIL_CLOSE_EPOCH) ? 1 : 0); }
+  IL_CHECK_LAUNCH("il_gail_disc_step_draw");
   return IL_OK;
 }
 
@@ -476,7 +508,7 @@ extern "C" int il_gail_step_population(const il_disc* descs_dev, const il_batch*
   if (int rc = ensure_lds((const void*)k_gail_reward, lds)) return rc;
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
   il_batch zb = {};
-  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d), L), 256, lds, st>>>(*d, zb, zb, nullptr, il_gail_extra{}, descs_dev, policy_dev, expert_dev); }
+  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d), L), 256, lds, st>>>(*d, zb, zb, nullptr, il_gail_extra{}, descs_dev, policy_dev, expert_dev, GailSampler{}); }
   { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<dim3((int)((P + 255) / 256), L), 256, 0, st>>>(*d, 1, descs_dev, 0); }
   { IL_TRACE("k_gail_reward", st); k_gail_reward<<<dim3(nt, L), 256, lds, st>>>(*d, zb, nullptr, nullptr, nullptr, descs_dev, policy_dev, rewards_out_dev); }
   IL_CHECK_LAUNCH("il_gail_step_population");

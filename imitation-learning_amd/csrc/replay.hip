@@ -5,6 +5,7 @@
 // A gather moves row-granular 16-B lanes: consecutive lanes of a wave read consecutive 16-B pieces of ONE ring row
 // (188-192 B contiguous per row at HalfCheetah dims), the only coalescing a random-row gather admits.
 #include "il_common.hpp"
+#include "mt_device.hpp"
 
 extern "C" int32_t il_ring_row_floats(int32_t S, int32_t A) { return (2 * S + A + 5 + 3) & ~3; }
 
@@ -127,16 +128,6 @@ extern "C" int il_replay_wrap_absorbing(float* ring, int64_t capacity, int32_t S
 // MT19937 (Matsumoto & Nishimura) + numpy legacy masked-rejection randint, as consumed by memory.py:51-56.
 // state[0..623] = mt words, state[624] = position.
 // ---------------------------------------------------------------------------------------------
-#define MT_N 624
-#define MT_M 397
-__host__ __device__ static inline uint32_t mt_temper(uint32_t y) {
-  y ^= y >> 11; y ^= (y << 7) & 0x9D2C5680u; y ^= (y << 15) & 0xEFC60000u; y ^= y >> 18;
-  return y;
-}
-__host__ __device__ static inline uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t c) {
-  const uint32_t y = (a & 0x80000000u) | (b & 0x7FFFFFFFu);
-  return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
-}
 static void mt_twist_host(uint32_t* mt) {
   for (int k = 0; k < MT_N; ++k) mt[k] = mt_mix(mt[k], mt[(k + 1) % MT_N], mt[(k + MT_M) % MT_N]);
 }
@@ -185,87 +176,6 @@ extern "C" int il_mt19937_randint(uint32_t* s, int64_t high, int32_t n, int32_t*
   return IL_OK;
 }
 
-// Device version: one workgroup. The draw is a stream compaction of the tempered MT output (every candidate consumes
-// exactly one 32-bit word; rejected ones are skipped), so 256 candidates are tested in parallel and compacted in order.
-struct MtShared { uint32_t mt[MT_N]; uint32_t nx[MT_N]; int wave_cnt[4]; int pos, count, last, have_next; };
-
-// The NEXT block of 624 words (the twist of sh.mt) into sh.nx. A pure function of the current block, so the resident sampler computes it while it waits for the previous
-// update: when the draw crosses the block boundary (about once per update: two batches of 256 consume ~670 words) the new block is already there.
-__device__ __forceinline__ void mt_next_block(MtShared& sh) {
-  const int tid = threadIdx.x;
-  for (int k = tid; k < 227; k += 256) sh.nx[k] = mt_mix(sh.mt[k], sh.mt[k + 1], sh.mt[k + MT_M]);
-  __syncthreads();
-  for (int k = 227 + tid; k < 454; k += 256) sh.nx[k] = mt_mix(sh.mt[k], sh.mt[k + 1], sh.nx[k - 227]);
-  __syncthreads();
-  for (int k = 454 + tid; k < 623; k += 256) sh.nx[k] = mt_mix(sh.mt[k], sh.mt[k + 1], sh.nx[k - 227]);
-  __syncthreads();
-  if (tid == 0) { sh.nx[623] = mt_mix(sh.mt[623], sh.nx[0], sh.nx[396]); sh.have_next = 1; }
-  __syncthreads();
-}
-
-__device__ __forceinline__ void mt_draw(MtShared& sh, const int64_t* __restrict__ ring_state, int n, int32_t* __restrict__ out) {
-  const int tid = threadIdx.x;
-  const int64_t idx = ring_state[0], full = ring_state[1], size = ring_state[2];
-  const int64_t high = full ? size : idx - 1;
-  const int64_t excl = ((idx - 1) % size + size) % size;
-  const uint32_t rng = high > 0 ? (uint32_t)(high - 1) : 0u;
-  uint32_t mask = rng; mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-  if (tid == 0) sh.count = 0;
-  __syncthreads();
-  if (rng == 0) {  // degenerate range: numpy returns 0 without consuming the stream
-    for (int i = tid; i < n; i += 256) out[i] = 0;
-    return;
-  }
-  for (int guard = 0; guard < 100000; ++guard) {
-    int pos = sh.pos, count = sh.count;
-    if (count >= n) break;
-    if (pos >= MT_N && sh.have_next) {   // the block prepared by mt_next_block
-      for (int k = tid; k < MT_N; k += 256) sh.mt[k] = sh.nx[k];
-      __syncthreads();
-      if (tid == 0) { sh.pos = 0; sh.have_next = 0; }
-      __syncthreads();
-      pos = 0;
-    } else if (pos >= MT_N) {  // twist in place: four dependency-free phases
-      uint32_t nv[3]; int q = 0;
-      for (int k = tid; k < 227; k += 256) nv[q++] = mt_mix(sh.mt[k], sh.mt[k + 1], sh.mt[k + MT_M]);
-      __syncthreads(); q = 0;
-      for (int k = tid; k < 227; k += 256) sh.mt[k] = nv[q++];
-      __syncthreads(); q = 0;
-      for (int k = 227 + tid; k < 454; k += 256) nv[q++] = mt_mix(sh.mt[k], sh.mt[k + 1], sh.mt[k - 227]);
-      __syncthreads(); q = 0;
-      for (int k = 227 + tid; k < 454; k += 256) sh.mt[k] = nv[q++];
-      __syncthreads(); q = 0;
-      for (int k = 454 + tid; k < 623; k += 256) nv[q++] = mt_mix(sh.mt[k], sh.mt[k + 1], sh.mt[k - 227]);
-      __syncthreads(); q = 0;
-      for (int k = 454 + tid; k < 623; k += 256) sh.mt[k] = nv[q++];
-      __syncthreads();
-      if (tid == 0) { sh.mt[623] = mt_mix(sh.mt[623], sh.mt[0], sh.mt[396]); sh.pos = 0; }
-      __syncthreads();
-      pos = 0;
-    }
-    const int avail = MT_N - pos, take = avail < 256 ? avail : 256;
-    bool ok = false; uint32_t v = 0;
-    if (tid < take) { v = mt_temper(sh.mt[pos + tid]) & mask; ok = (v <= rng) && ((int64_t)v != excl); }
-    const unsigned long long bal = __ballot(ok);
-    const int lane = tid & 63, w = tid >> 6;
-    if (lane == 0) sh.wave_cnt[w] = __popcll(bal);
-    __syncthreads();
-    int before = __popcll(bal & ((1ull << lane) - 1ull));
-    for (int i = 0; i < w; ++i) before += sh.wave_cnt[i];
-    const int tot = sh.wave_cnt[0] + sh.wave_cnt[1] + sh.wave_cnt[2] + sh.wave_cnt[3];
-    const int need = n - count;
-    // candidates are consumed up to and including the one that completes the batch
-    if (ok && before < need) out[count + before] = (int32_t)v;
-    if (tot >= need) { if (ok && before == need - 1) sh.last = tid; }
-    __syncthreads();
-    if (tid == 0) {
-      if (tot >= need) { sh.pos = pos + sh.last + 1; sh.count = n; }
-      else { sh.pos = pos + take; sh.count = count + tot; }
-    }
-    __syncthreads();
-  }
-}
-
 __device__ __forceinline__ void gather_rows(const float* __restrict__ ring, int64_t capacity, int row4, const int32_t* __restrict__ idx, int n, float* __restrict__ out) {
   const f32x4* src = reinterpret_cast<const f32x4*>(ring);
   f32x4* dst = reinterpret_cast<f32x4*>(out);
@@ -282,22 +192,7 @@ __global__ __launch_bounds__(256) void k_sample2(uint32_t* __restrict__ state, i
                                                   int32_t* __restrict__ idx_a, float* __restrict__ rows_a, const int64_t* __restrict__ rs_b, const float* __restrict__ ring_b,
                                                   int64_t cap_b, int row4_b, int32_t* __restrict__ idx_b, float* __restrict__ rows_b, long long* __restrict__ sync, int resident) {
   __shared__ MtShared sh;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < MT_N; i += 256) sh.mt[i] = state[i];
-  if (tid == 0) { sh.pos = (int)state[MT_N]; sh.have_next = 0; }
-  __syncthreads();
-  mt_next_block(sh);   // before the ring state is needed (and, resident, before the wait): off the path from "previous update done" to "indices drawn"
-  // resident (il_replay_draw_resident): launched on the discriminator branch's stream with NO dependency on the update's main stream, i.e. while the previous
-  // update is still running. The generator state is in LDS already; the draw itself must wait until that update is over (its kernels read the index arrays this
-  // one overwrites, and the ring cursor may still move): [IL_SYNC_MAIN_EPOCH] has to reach the number of draws made so far (= [IL_SYNC_INDICES]).
-  if (resident) sync_wait(sync, IL_SYNC_MAIN_EPOCH, sync[IL_SYNC_INDICES]);
-  __syncthreads();
-  mt_draw(sh, rs_a, n, idx_a);
-  if (rs_b) { __syncthreads(); mt_draw(sh, rs_b, n, idx_b); }
-  if (sync) sync_signal(sync + IL_SYNC_INDICES);   // both index arrays are in place (a consumer that gathers its own rows need not wait for k_gather2)
-  __syncthreads();
-  for (int i = tid; i < MT_N; i += 256) state[i] = sh.mt[i];
-  if (tid == 0) state[MT_N] = (uint32_t)sh.pos;
+  mt_sample_update(sh, state, n, rs_a, idx_a, rs_b, idx_b, sync, resident);
   if (rows_a) gather_rows(ring_a, cap_a, row4_a, idx_a, n, rows_a);
   if (ring_b && rows_b) gather_rows(ring_b, cap_b, row4_b, idx_b, n, rows_b);
 }

@@ -171,10 +171,7 @@ class DataParallelUpdate:
   def _enqueue_side(self):
     """Discriminator branch: [resident index draw] -> gradients from the rings through the indices -> all-reduce (own communicator) -> AdamW, which signals [IL_SYNC_PARAMS]."""
     p, L = self.plan, _lib.lib()
-    if p.resident_sampler:
-      p._draw_resident()
-    rp, re_ = p._ring_batches()
-    _lib.check(L.il_gail_disc_step(C.byref(p.disc), C.byref(rp), C.byref(re_), None, None, _lib.IL_FLAG_GRADS_ONLY, _lib.stream_ptr()))
+    p._disc_step(_lib.IL_FLAG_GRADS_ONLY)   # the index draw rides in this launch when the sampler is resident
     all_reduce_mean_(self.disc_bucket, self.side_group)
     _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
 

@@ -553,17 +553,12 @@ class UpdatePlan:
 
   @property
   def resident_sampler(self) -> bool:
-    """Ring mode only: the index draw is a RESIDENT launch at the head of the discriminator branch (il_replay_draw_resident) instead of the first kernel of the SAC
-    branch. It starts while the previous update is still running, waits on the device for that update's end ([IL_SYNC_MAIN_EPOCH]), draws and signals
-    [IL_SYNC_INDICES]; the forward / critic-loss launch waits for that signal. The sampling launch (~7 us + a kernel boundary) leaves the update's critical path.
+    """Ring mode only: the index draw is RESIDENT - one extra workgroup of the discriminator branch's first launch (il_gail_disc_step_draw) - instead of the first
+    kernel of the SAC branch. It starts while the previous update is still running, waits on the device for that update's end ([IL_SYNC_MAIN_EPOCH]), draws and
+    signals [IL_SYNC_INDICES]; the discriminator workgroups beside it and the forward / critic-loss launch on the other stream wait for that signal. The sampling
+    launch (~7 us + a kernel boundary) leaves the update's critical path, and the discriminator kernel keeps preparing (weights, power iterations) ahead of the rows.
     Not with `pre_hooks` (an append captured at the head of the main branch must precede the draw in stream order). IL_RESIDENT_SAMPLER=0: draw on the main stream."""
     return self.ring_mode and not self.pre_hooks and not self.stream_ordered_draw and os.environ.get('IL_RESIDENT_SAMPLER', '1') != '0'
-
-  def _draw_resident(self):
-    m, e = self.memory, self.expert_memory
-    st = m.stream().device_state(m.device)
-    _lib.check(_lib.lib().il_replay_draw_resident(_lib.ptr(st), self.B, _lib.ptr(m._ring_state), _lib.ptr(self.idx), _lib.ptr(e._ring_state), _lib.ptr(self.eidx), _lib.ptr(self.sync),
-                                                  _lib.stream_ptr()))
 
   @property
   def inline_relabel(self) -> bool:
@@ -575,16 +570,26 @@ class UpdatePlan:
     Dp = (D + 3) // 4 * 4
     return Hd * (Dp + 4) + 4 * Hd + Dp + 8 <= max(4, self.sac.hidden // 16) * 256 + 256 - 32
 
+  def _disc_step(self, flags: int):
+    """The discriminator step of the ring schedule; with the resident sampler the index draw rides in the same launch (il_gail_disc_step_draw)."""
+    L, st = _lib.lib(), _lib.stream_ptr()
+    rp, re_ = self._ring_batches()
+    if self.resident_sampler:
+      m, e = self.memory, self.expert_memory
+      mt = m.stream().device_state(m.device)
+      _lib.check(L.il_gail_disc_step_draw(C.byref(self.disc), C.byref(rp), C.byref(re_), _lib.ptr(mt), _lib.ptr(m._ring_state), _lib.ptr(self.idx), _lib.ptr(e._ring_state), _lib.ptr(self.eidx),
+                                          flags, st))
+    else:
+      _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(rp), C.byref(re_), None, None, flags, st))
+
   def _enqueue_discriminator_branch(self):
     L, st = _lib.lib(), _lib.stream_ptr()
-    if self.resident_sampler:
-      self._draw_resident()
     if self.ring_mode:
       rp, re_ = self._ring_batches()
       if self.inline_relabel:
-        _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(rp), C.byref(re_), None, None, _lib.IL_FLAG_GAIL_CLOSE_EPOCH, st))
+        self._disc_step(_lib.IL_FLAG_GAIL_CLOSE_EPOCH)
         return
-      _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(rp), C.byref(re_), None, None, 0, st))
+      self._disc_step(0)
       _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(rp), _lib.ptr(self.rewards), None, None, st))
       return
     _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))

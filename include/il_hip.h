@@ -335,6 +335,13 @@ int il_gail_disc_step(const il_disc* d, const il_batch* policy, const il_batch* 
  * kernel: its workgroups report [IL_SYNC_PARAMS] and the last one closes the branch's epoch, exactly like il_gail_disc_step(IL_FLAG_GAIL_CLOSE_EPOCH) does on one GPU, so
  * that il_sac_update_gather(relabel, IL_FLAG_GRADS_ONLY) on the other stream relabels inline as soon as the all-reduced step has landed. */
 int il_gail_apply_grads(const il_disc* d, il_stream_t stream);
+/* il_gail_disc_step with the update's index draw (il_replay_draw_resident) riding in the same launch as ONE extra workgroup: the discriminator workgroups are resident
+ * early (weights staged, power iterations done) and wait for [IL_SYNC_INDICES]; the sampler workgroup waits for the previous update's end ([IL_SYNC_MAIN_EPOCH]),
+ * draws the agent batch then the expert batch (train.py:173) and signals. A sampler launched behind this kernel in the same stream could never satisfy its wait;
+ * one launched ahead of it would put the kernel's preparation back on the critical path. policy / expert must be rings read through il_batch.gather = idx_a / idx_b;
+ * on-chip Philox noise; flags as il_gail_disc_step. The SAC branch on the other stream uses il_sac_update_gather(IL_FLAG_SAC_WAIT_INDICES). */
+int il_gail_disc_step_draw(const il_disc* d, const il_batch* policy, const il_batch* expert, uint32_t* mt_state_dev, const int64_t* ring_state_a, int32_t* idx_a,
+                           const int64_t* ring_state_b, int32_t* idx_b, uint32_t flags, il_stream_t stream);
 /* Population axis: discriminator step + AIRL/GAIL/FAIRL reward relabel for n_learners discriminators; rewards_out_dev[l] -> float[batch]. */
 int il_gail_step_population(const il_disc* descs_dev, const il_batch* policy_dev, const il_batch* expert_dev, float* const* rewards_out_dev,
                             int32_t n_learners, const il_disc* shape_host, il_stream_t stream);
