@@ -112,6 +112,14 @@ def secondary(device, plan, nets):
   sac_plan.run(); sac_plan.capture(warmup=0)
   out['sac_only_updates_per_s'] = round(timed(sac_plan.replay, 1000, 100), 1)
 
+  # the headline update with FOUR consecutive updates captured per replay (UpdatePlan.capture(updates=4): offline training / several updates per environment step):
+  # the ~3.5 us of queue work between two graph launches is then paid once per four updates. The headline `value` replays one update per launch, like train.py does.
+  was_side, was_main = plan.graph_side, plan.graph
+  if was_main is not None:
+    plan.capture(warmup=0, updates=4)
+    out['sac_gail_updates_per_s_4_per_replay'] = round(4 * timed(plan.replay, 500, 50), 1)
+    plan.graph_side, plan.graph = was_side, was_main
+
   g = torch.cuda.CUDAGraph()
   L = _lib_mod().lib()
   side = torch.cuda.Stream()

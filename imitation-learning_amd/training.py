@@ -702,7 +702,8 @@ class UpdatePlan:
     elif alg == 'DRIL':
       _lib.check(L.il_dril_uncertainty(C.byref(self.dril), C.byref(self.pb), None, None, None, 0x40000000, None, _lib.ptr(self.rewards), st))   # offset range apart from the eager calls' small counters
 
-  def capture(self, warmup: int = 3):
+  def capture(self, warmup: int = 3, updates: int = 1):
+    """`updates` > 1: that many CONSECUTIVE updates per replay (offline training, several updates per environment step)."""
     assert self.device_index_draw, 'graph capture needs device-side index draws (no H2D inside the graph)'
     if self.device_sync and not self._probe_device_sync(graph=True):
       self._set_device_sync(False)   # the runtime serialises graph branches here (e.g. a counter-collecting profiler): keep stream dependencies
@@ -720,15 +721,15 @@ class UpdatePlan:
       self._captured_resident = self.resident_sampler
       self.graph_side, self._capturing = torch.cuda.CUDAGraph(), 'side'
       with torch.cuda.graph(self.graph_side, stream=self.side):
-        self._run_update()
+        for _ in range(updates): self._run_update()
       self.graph, self._capturing = torch.cuda.CUDAGraph(), 'main'
       with torch.cuda.graph(self.graph):
-        self.run()
+        for _ in range(updates): self.run()
       self._capturing = None
       return self
     self.graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(self.graph):
-      self.run()
+      for _ in range(updates): self.run()
     return self
 
   def replay(self):
