@@ -1,10 +1,12 @@
 """Timeline of ONE steady-state update from a rocprofv3 kernel trace (rocpd sqlite): start offset, duration and idle gap per kernel, so the
-critical path through the two-stream graph can be read off.  Usage: python profiles/tools/timeline.py <results.db> [update index from the end]"""
+critical path through the two-stream graph can be read off.  Usage: python profiles/tools/timeline.py <results.db> [update index from the end] [anchor kernel prefix]
+The anchor (default k_sample, the first kernel of an update in the round-1 schedules; k_sac_chain for the resident-sampler schedule) marks where an update starts."""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 rows = [(n.split('(')[0], s, e) for n, s, e in db.execute("select name, start, end from kernels order by start")]
-starts = [i for i, r in enumerate(rows) if r[0].startswith('k_sample')]
+anchor = sys.argv[3] if len(sys.argv) > 3 else 'k_sample'
+starts = [i for i, r in enumerate(rows) if r[0].startswith(anchor)]
 i0, i1 = starts[-back], starts[-back + 1]
 t0 = rows[i0][1]
 print(f'update = kernels {i0}..{i1 - 1}; period {(rows[i1][1] - t0) / 1e3:.2f} us')
