@@ -370,7 +370,7 @@ __device__ __forceinline__ void critic_bwd_resident_gemm(const il_sac& d, int k,
 }
 // relabel: the rewards of this tile are the discriminator `dd`'s prediction on (s, a) - the rows still sit in Xs - computed here once its AdamW step of
 // this update is complete ([IL_SYNC_PARAMS], n_reduce workgroups per step); otherwise dense `rewards` or the batch's own reward field.
-struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; int fwd_only; int wait_indices; };   // wait_indices: IL_FLAG_SAC_WAIT_INDICES   // fwd_only: the forward kernels only (IL_FLAG_SAC_FORWARD_ONLY / data-parallel phase 0): no critic backward
+struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; int fwd_only; int wait_indices; int local_rewards; };   // wait_indices: IL_FLAG_SAC_WAIT_INDICES; local_rewards: il_sac_update_gather without `rewards` / `relabel` (the ring's reward field: nothing to wait for)   // fwd_only: the forward kernels only (IL_FLAG_SAC_FORWARD_ONLY / data-parallel phase 0): no critic backward
 // Runs between the critic's own work and its wait for the targets: the discriminator's step usually lands while the targets are still being computed,
 // so the relabel stays off the critical path. Leaves the tile's rewards in LDS (rew16) for critic_bwd_resident_scale.
 __device__ __forceinline__ void critic_relabel_tile(const il_sac& d, const ChainRelabel& rl, int k, int tile, float* smem) {
@@ -410,7 +410,7 @@ __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const
   float* W = d.workspace;
   float* gdz2 = W + ws.c_dz2 + (size_t)k * B * H; float* gdz1 = W + ws.c_dz1 + (size_t)k * B * H;
   float* rew16 = dz3s + IL_TILE_R;   // filled by critic_relabel_tile when rl.on
-  if (!rl.on && d.sync) {   // rewards come from the discriminator branch on another stream (see k_critic_bwd)
+  if (!rl.on && d.sync && !rl.local_rewards) {   // rewards come from the discriminator branch on another stream (see k_critic_bwd); the ring's own rewards (SAC / PWIL plans) need no hand-off
     long long* sy = reinterpret_cast<long long*>(d.sync);
     sync_wait(sy, IL_SYNC_REWARDS, (sy[IL_SYNC_MAIN_EPOCH] + 1) * (long long)nt);
   }
@@ -1207,6 +1207,7 @@ extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const
     rl.dd = *relabel; rl.on = 1; rl.n_reduce = il_gail_step_workgroups(relabel); rl.out = rewards_out;
   }
   if (flags & IL_FLAG_SAC_WAIT_INDICES) { IL_CHECK_ARG(d->sync, "il_sac_update_gather: IL_FLAG_SAC_WAIT_INDICES needs the il_sync counters"); rl.wait_indices = 1; }
+  rl.local_rewards = (!rewards && !relabel) ? 1 : 0;
   IL_CHECK_ARG(ring && ring->gather && ring->gather_capacity > 0 && ring->n == d->batch, "il_sac_update_gather: `ring` must carry the %d drawn indices (il_batch.gather)", d->batch);
   IL_CHECK_ARG(rows->states && ring->states && rows->ld_states == ring->ld_states && ring->ld_states % 4 == 0, "il_sac_update_gather: rows / ring must be packed rows of the same width");
   IL_CHECK_ARG(!(flags & (IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY)), "il_sac_update_gather: whole updates (or, with IL_FLAG_GRADS_ONLY, everything up to the critic gradients)");

@@ -349,7 +349,9 @@ class UpdatePlan:
     assert algorithm in self.ALGORITHMS, f'UpdatePlan: unknown algorithm {algorithm}'
     assert expert_memory is not None or (algorithm in ('SAC', 'PWIL') and not mix_expert and not bc_aux), f'UpdatePlan({algorithm}): needs the expert memory'
     assert not (mix_expert and algorithm in ('GAIL', 'SAC', 'PWIL', 'AdRIL')), 'mixed batches: DRIL / GMMIL / RED plans (train.py:175,183); GAIL with mixing runs the per-function path'
-    self.overlap, self.side = overlap, (torch.cuda.Stream() if overlap and algorithm == 'GAIL' else None)
+    # GAIL: discriminator branch || SAC branch. SAC / PWIL (no reward step, nothing host-side inside): the second stream only hosts the resident index draw.
+    self._two_stream = bool(overlap and (algorithm == 'GAIL' or (algorithm in ('SAC', 'PWIL') and not mix_expert and not bc_aux)))
+    self.overlap, self.side = overlap, (torch.cuda.Stream() if self._two_stream else None)
     self.algorithm, self.B, dev = algorithm, batch_size, actor.flat.device
     self.memory, self.expert_memory, self.device_index_draw = memory, expert_memory, device_index_draw
     self.has_expert, self.mix_expert, self.bc_aux = expert_memory is not None, bool(mix_expert), bool(bc_aux)
@@ -395,7 +397,9 @@ class UpdatePlan:
     self.sync = torch.zeros(16, dtype=torch.int64, device=dev)   # IL_SYNC_SLOTS
     self.device_sync = False
     self._chain_fits = None
-    if algorithm == 'GAIL' and overlap and device_index_draw and os.environ.get('IL_DEVICE_SYNC', '1') != '0':
+    self.pre_hooks, self.post_hooks = [], []   # callables enqueuing extra work on the update's stream before / after it (captured with it), e.g. ActingWorker
+    self.stream_ordered_draw = False   # True: the index draw stays the first kernel of the SAC branch (bit-identical; what per-kernel timing wants: see bench.py roofline())
+    if self._two_stream and device_index_draw and os.environ.get('IL_DEVICE_SYNC', '1') != '0':
       # HIP multiplexes streams onto a few hardware queues (round-robin at creation): a side stream that landed on the caller's queue runs serialised with it and
       # fails the probe. Another stream usually lands elsewhere: try a few (the rejected ones stay alive meanwhile, so that the next one gets a different queue).
       ok, rejected = self._probe_device_sync(graph=False), []
@@ -407,10 +411,8 @@ class UpdatePlan:
     self.graph = self.graph_side = None
     self.main_feeds_ring = False   # set True when work enqueued on the caller's stream BETWEEN updates moves the agent ring's cursor (train.py: ActingWorker / memory.append)
     self._captured_resident = False
-    self.stream_ordered_draw = False   # True: the index draw stays the first kernel of the SAC branch (bit-identical; what per-kernel timing wants: see bench.py roofline())
     self._ring_desc = None
     self._capturing = None   # 'main' / 'side' while one branch of the device-synchronised update is being captured
-    self.pre_hooks, self.post_hooks = [], []   # callables enqueuing extra work on the update's stream before / after it (captured with it), e.g. ActingWorker
     self._prepared = False   # True once an update of THIS plan has left the lane-ordered weight copies in step with the parameters
 
   def invalidate(self):
@@ -422,10 +424,10 @@ class UpdatePlan:
 
   def _set_device_sync(self, on: bool):
     self.device_sync = bool(on)
-    if self.algorithm == 'GAIL' and self.expert_memory is not None:   # [IL_SYNC_GATHER_WGS]: who signals IL_SYNC_ROWS, and how many times per update
+    if self._two_stream:   # [IL_SYNC_GATHER_WGS]: who signals IL_SYNC_ROWS, and how many times per update
       L = _lib.lib()
       self.sync[5] = int(L.il_sac_chain_gather_workgroups(self.B, self.memory.row, self.sac.hidden) if self.ring_mode
-                         else L.il_replay_gather_workgroups(self.B, self.memory.row, self.expert_memory.row))
+                         else L.il_replay_gather_workgroups(self.B, self.memory.row, self.expert_memory.row if self.has_expert else 0))
     ptr = self.sync.data_ptr() if on else None
     self.sac.sync = ptr
     if self.algorithm == 'GAIL':
@@ -510,7 +512,7 @@ class UpdatePlan:
     _lib.check(_lib.lib().il_replay_sample_device(
         _lib.ptr(st), self.B, _lib.ptr(m._ring_state), _lib.ptr(m.ring), m.size, m.row, _lib.ptr(self.idx), None if self.ring_mode else _lib.ptr(self.rows),
         _lib.ptr(e._ring_state) if e else None, _lib.ptr(e.ring) if e else None, e.size if e else 0, e.row if e else 0, _lib.ptr(self.eidx) if e else None,
-        _lib.ptr(self.erows) if e and not self.ring_mode else None, _lib.ptr(self.sync) if self.device_sync else None, _lib.stream_ptr()))   # ring mode: the draw only
+        _lib.ptr(self.erows) if e and not self.ring_mode else None, _lib.ptr(self.sync) if self.device_sync and self.algorithm == 'GAIL' else None, _lib.stream_ptr()))   # ring mode: the draw only (SAC / PWIL reach this call on their one-stream schedule only: no counters move)
 
   def run(self):
     for hook in self.pre_hooks:
@@ -520,11 +522,18 @@ class UpdatePlan:
       hook()
 
   @property
+  def _sampler_ok(self) -> bool:
+    return not self.pre_hooks and not self.stream_ordered_draw and os.environ.get('IL_RESIDENT_SAMPLER', '1') != '0'
+
+  @property
   def ring_mode(self) -> bool:
     """Device-side hand-off only: an update is DRAWN but never gathered by a kernel of its own. The discriminator step and the forward / critic-loss
     launch read their rows straight from the rings through the indices (il_batch.gather), so both branches start right after the index draw;
-    extra workgroups of k_sac_chain write the gathered agent rows for the later kernels (il_sac_update_gather). IL_RING_GATHER=0: gather first."""
+    extra workgroups of k_sac_chain write the gathered agent rows for the later kernels (il_sac_update_gather). IL_RING_GATHER=0: gather first.
+    SAC / PWIL plans: only together with the resident sampler (their second stream has nothing else to do)."""
     if not self.device_sync or os.environ.get('IL_RING_GATHER', '1') == '0':
+      return False
+    if self.algorithm != 'GAIL' and not self._sampler_ok:
       return False
     # il_sac_update_gather's launch (6 workgroups per 16-row tile + the gather workgroups) must be co-resident: batch sizes beyond that gather first
     # (il_sac_update then also keeps its forward / critic-loss kernels separate)
@@ -541,7 +550,7 @@ class UpdatePlan:
         b = batch_desc(t); b.n = self.B
         b.gather, b.gather_capacity = idx.data_ptr(), mem.size
         return b
-      self._ring_desc = (ring_desc(self.memory, self.idx), ring_desc(self.expert_memory, self.eidx))
+      self._ring_desc = (ring_desc(self.memory, self.idx), ring_desc(self.expert_memory, self.eidx) if self.has_expert else None)
     return self._ring_desc
 
   def _zero_column(self, mem):
@@ -558,7 +567,7 @@ class UpdatePlan:
     signals [IL_SYNC_INDICES]; the discriminator workgroups beside it and the forward / critic-loss launch on the other stream wait for that signal. The sampling
     launch (~7 us + a kernel boundary) leaves the update's critical path, and the discriminator kernel keeps preparing (weights, power iterations) ahead of the rows.
     Not with `pre_hooks` (an append captured at the head of the main branch must precede the draw in stream order). IL_RESIDENT_SAMPLER=0: draw on the main stream."""
-    return self.ring_mode and not self.pre_hooks and not self.stream_ordered_draw and os.environ.get('IL_RESIDENT_SAMPLER', '1') != '0'
+    return self.ring_mode and self._sampler_ok
 
   @property
   def inline_relabel(self) -> bool:
@@ -642,8 +651,30 @@ class UpdatePlan:
       _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), _lib.IL_FLAG_SAC_SKIP_FORWARD, st))
       self._prepared = True
       return
+    if self.algorithm != 'GAIL' and self.resident_sampler:
+      # SAC / PWIL: the index draw is a resident launch on the second stream (il_replay_draw_resident: it waits on the device for the previous update's end), the update
+      # itself one chain of four launches that reads its rows from the ring through the indices. Captured as two graphs with no edge between them, like GAIL's.
+      main = torch.cuda.current_stream()
+      if self._capturing != 'main':
+        if self._capturing is None:
+          self.side.wait_stream(main)   # eager: appends the caller enqueued before this update precede the draw
+        with torch.cuda.stream(self.side):
+          m, e = self.memory, (self.expert_memory if self.has_expert else None)
+          mt = m.stream().device_state(m.device)
+          _lib.check(L.il_replay_draw_resident(_lib.ptr(mt), self.B, _lib.ptr(m._ring_state), _lib.ptr(self.idx), _lib.ptr(e._ring_state) if e else None, _lib.ptr(self.eidx) if e else None,
+                                               _lib.ptr(self.sync), _lib.stream_ptr()))
+      if self._capturing != 'side':
+        _lib.check(L.il_sac_update_gather(C.byref(self.sac), C.byref(self.pb), C.byref(self._ring_batches()[0]), None, None, None, None, None, _lib.ptr(self.logp), _lib.ptr(self.q),
+                                          self.prepared_flag() | _lib.IL_FLAG_SAC_WAIT_INDICES, _lib.stream_ptr()))
+        self._prepared = True
+      if self._capturing is None:
+        main.wait_stream(self.side)
+      return
     self.sample_all()
     st = _lib.stream_ptr()
+    sync_kept = self.sac.sync
+    if self.algorithm != 'GAIL':
+      self.sac.sync = None   # one stream from here on: no kernel of this schedule hands anything over on the device (the critic loss would wait for [IL_SYNC_REWARDS])
     if self.algorithm == 'GAIL':
       _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))
       _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
@@ -657,6 +688,7 @@ class UpdatePlan:
                               None, 0, st))
       flag = 0
     _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), flag, st))
+    self.sac.sync = sync_kept
     self._prepared = True
 
   def relabel_args(self, step: int, num_trajectories: int):
@@ -717,7 +749,7 @@ class UpdatePlan:
     if warmup and self.sync_timeouts():
       raise RuntimeError(f'UpdatePlan.capture: {self.sync_timeouts()} device-side waits expired during the warm-up updates (the two branches did not run concurrently); '
                          'their results are invalid. Set IL_DEVICE_SYNC=0 to keep plain stream dependencies.')
-    if self.device_sync:   # two graphs, one per branch, replayed on two streams; no edge between them (see _run_update)
+    if self.device_sync and (self.algorithm == 'GAIL' or self.resident_sampler):   # two graphs, one per branch, replayed on two streams; no edge between them (see _run_update)
       self._captured_resident = self.resident_sampler
       self.graph_side, self._capturing = torch.cuda.CUDAGraph(), 'side'
       with torch.cuda.graph(self.graph_side, stream=self.side):
