@@ -764,6 +764,12 @@ class UpdatePlan:
       for _ in range(updates): self.run()
     return self
 
+  def join(self):
+    """Order the caller's stream after the plan's second stream: `replay()` leaves the two branches unjoined (no edge between the graphs), so anything the caller reads
+    on its own stream that the other branch wrote - the discriminator's parameters / buffers for a checkpoint, the rewards on the fallback schedules - needs this first."""
+    if self.side is not None:
+      torch.cuda.current_stream().wait_stream(self.side)
+
   def replay(self):
     if self.graph_side is not None:
       if self.main_feeds_ring and self._captured_resident:

@@ -248,6 +248,7 @@ def train(cfg, file_prefix: str = '') -> float:
         rewards = transitions['rewards']
       if schedule == 'overlap' and plan is None: worker.enqueue_publish()
       if cfg.logging.interval > 0 and step % cfg.logging.interval == 0:  # the only D2H reads of the update path (train.py:205-210)
+        if plan is not None: plan.join()   # the logged tensors may have been written by the plan's second stream
         check_handoff(plan, step)
         metrics['update_steps'].append(step); metrics['predicted_rewards'].append(rewards.cpu().numpy())
         metrics['alphas'].append(log_alpha.exp().cpu().numpy()); metrics['entropies'].append((-log_probs).cpu().numpy()); metrics['Q_values'].append(Q_values.cpu().numpy())
@@ -268,6 +269,7 @@ def train(cfg, file_prefix: str = '') -> float:
         lineplot(metrics['update_steps'], metrics['entropies'], filename=f'{file_prefix}sac_entropy', yaxis='Entropy', title=f'{cfg.algorithm}: {cfg.env} Entropy')
         lineplot(metrics['update_steps'], metrics['Q_values'], filename=f'{file_prefix}Q_values', yaxis='Q-value', title=f'{cfg.algorithm}: {cfg.env} Q-values')
 
+  if plan is not None: plan.join()   # the discriminator is stepped on the plan's second stream: order the checkpoint reads after it
   check_handoff(plan, cfg.steps)   # never save a learner whose last updates ran on expired device-side waits
   if world > 1:
     import torch.distributed as dist
