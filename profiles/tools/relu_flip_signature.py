@@ -1,5 +1,8 @@
+"""Developer tool: where do HIP and the oracle differ after a chain of population updates?  Prints, per update and learner, the elements of the critic's Adam first moment
+beyond the tight bound and the weight rows they belong to. Measured signature (round 2): 3e-9 everywhere except ONE row of one critic's W2 plus that sample's first-layer
+terms, decaying by beta1 per update = a ReLU pre-activation within rounding of 0 that took different signs in the two evaluations (tests/gpu_util.py close_sparse)."""
 import sys, os
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo/tests/golden')
+sys.path.insert(0, "."); sys.path.insert(0, "tests"); sys.path.insert(0, "tests/golden")
 import numpy as np, torch
 import test_timed_path_oracle as t
 from gpu_util import N, crit_from_flat

@@ -1,3 +1,5 @@
+// Developer tool: which XCD does workgroup g of a 2-D / 3-D grid run on?  Reads HW_REG_XCC_ID per workgroup.  hipcc --offload-arch=gfx950 -O2 xcc_probe.hip -o xcc_probe && ./xcc_probe
+// Measured on MI355X (round 2): XCD = linear workgroup id % 8 (x fastest) for every grid shape tried - what xcd_tile_net / chain_decode (csrc) rely on.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 __global__ void k(int* out) {
