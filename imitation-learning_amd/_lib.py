@@ -43,7 +43,7 @@ class Disc(C.Structure):
               ('spectral_norm', C.c_int32), ('state_only', C.c_int32), ('reward_function', C.c_int32),
               ('params', C.c_void_p), ('u1', C.c_void_p), ('v1', C.c_void_p), ('u2', C.c_void_p), ('v2', C.c_void_p), ('grad', C.c_void_p),
               ('opt', Adam), ('grad_penalty', C.c_float), ('entropy_bonus', C.c_float),
-              ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p), ('sync', C.c_void_p), ('loss_function', C.c_int32), ('pos_class_prior', C.c_float)]
+              ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p), ('sync', C.c_void_p), ('loss_function', C.c_int32), ('pos_class_prior', C.c_float), ('pu_clamped', C.c_int32), ('nonnegative_margin', C.c_float)]
 
 
 class DiscShaped(C.Structure):

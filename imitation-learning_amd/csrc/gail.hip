@@ -15,10 +15,10 @@
 #include "mlp_tile.hpp"
 #include "disc_reward.hpp"
 
-struct DiscWs { int64_t slabs, sn_new, total; };
+struct DiscWs { int64_t slabs, sn_new, pu, total; };   // pu: [2][nt] per-tile sums of w softplus(z) of the policy / expert call (PUGAIL with a finite nonnegative_margin)
 __host__ __device__ inline DiscWs disc_ws(int D, int H, int B) {
   DiscWs w; const int64_t P = (int64_t)H * D + 2 * H + 1; const int nt = (B + IL_TILE_R - 1) / IL_TILE_R;
-  w.slabs = 0; w.sn_new = (3 * nt * P + 3) & ~(int64_t)3; w.total = w.sn_new + 2 * H + D + 1 + 3;
+  w.slabs = 0; w.sn_new = (3 * nt * P + 3) & ~(int64_t)3; w.pu = (w.sn_new + 2 * H + D + 1 + 3) & ~(int64_t)3; w.total = w.pu + 2 * nt + 4;
   return w;
 }
 extern "C" int64_t il_disc_workspace_floats(int32_t D, int32_t H, int32_t B) { return disc_ws(D, H, B).total; }
@@ -146,7 +146,7 @@ __device__ __forceinline__ void stage_weights(const DiscLds& L, const float* __r
 struct GailSampler { uint32_t* state; const int64_t* rs_a; int32_t* idx_a; const int64_t* rs_b; int32_t* idx_b; int n; };
 
 __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp, il_gail_extra x, const il_disc* __restrict__ dL,
-                                                   const il_batch* __restrict__ polL, const il_batch* __restrict__ expL, GailSampler sa) {
+                                                   const il_batch* __restrict__ polL, const il_batch* __restrict__ expL, GailSampler sa, int pu_value_pass) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int has_sampler = sa.state != nullptr;
   if (has_sampler && (int)blockIdx.x == (int)gridDim.x - 1) {
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   const int kind = d.loss_function == IL_LOSS_MIXUP ? (pass == 0 ? 3 : 2) : pass;   // 0 policy, 1 expert, 2 gradient-penalty mix, 3 mixup mix
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
   const DiscWs wsl = disc_ws(D, H, B);
+  if (pu_value_pass && kind != 0 && kind != 1) return;   // the value pass only needs the logits of the policy and the expert call
   const float b2 = d.params[lay.ob2];
   float* slab = d.workspace + wsl.slabs + ((size_t)pass * nt + tile) * lay.P;
   DiscLds L = carve(smem, D, H);
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     for (int i = tid; i < Dp; i += blockDim.x) L.v1(0)[i] = i < D ? d.v1[i] : 0.f;
     if (tid == 0) L.sc(0)[2] = d.u2[0];
   } else if (tid == 0) { L.sc(0)[0] = 1.f; L.sc(0)[1] = 1.f; L.sc(0)[2] = 0.f; }
-  if (tid == 0 && tile == 0 && pass == 0) adam_tick(d.opt);
+  if (tid == 0 && tile == 0 && pass == 0 && !pu_value_pass) adam_tick(d.opt);
   __syncthreads();
   IL_STAMP(stamp, 2);
   if (d.spectral_norm) { sn_gram(L.W1s, L.Ms, D, Dp, H, ldw); __syncthreads(); }
@@ -263,8 +264,21 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     const float* off = kind == 0 ? x.logit_offset_policy : (kind == 1 ? x.logit_offset_expert : (kind == 3 ? x.logit_offset_mix : nullptr));
     const float z = off ? f - off[row] : f;   // subtract_log_policy (models.py:175)
     const bool pu = d.loss_function == IL_LOSS_PUGAIL;
-    // d loss / d z = w (c_sig sigmoid(z) - c_lab) / B: BCE {1, label}; PUGAIL policy {-1, 0}, expert {2 prior, prior}; Mixup {1, eps}
-    const float c_sig = pu ? (kind == 1 ? 2.f * d.pos_class_prior : -1.f) : 1.f;
+    if (pu_value_pass) {   // training.py:100-102 with a finite margin: V = prior mean(w_e bce(z_e, 0)) - mean(w_p bce(z_p, 0)) decides whether the clamped term has a gradient.
+      // This launch only leaves the per-tile sums of w softplus(z) (= w bce(z, 0)); the real launch that follows reads them all and decides (every workgroup the same way).
+      const float part = block_sum(sub == 0 && valid ? w * softplus_f(z) : 0.f, L.red);
+      if (tid == 0) d.workspace[wsl.pu + (size_t)kind * nt + tile] = part;
+      return;
+    }
+    float pu_on = 1.f;   // 1: the clamp passes the gradient (always, with nonnegative_margin = inf)
+    if (pu && d.pu_clamped) {
+      float se = 0.f, sp = 0.f;
+      for (int t = 0; t < nt; ++t) { sp += d.workspace[wsl.pu + t]; se += d.workspace[wsl.pu + nt + t]; }
+      const float V = d.pos_class_prior * (se / fB) - sp / fB;
+      pu_on = V >= -d.nonnegative_margin ? 1.f : 0.f;   // torch.clamp(min = -margin): gradient where the input is not below the bound
+    }
+    // d loss / d z = w (c_sig sigmoid(z) - c_lab) / B: BCE {1, label}; PUGAIL policy {-1, 0}, expert {2 prior, prior} (clamped away: policy {0, 0}, expert {prior, prior}); Mixup {1, eps}
+    const float c_sig = pu ? (kind == 1 ? (1.f + pu_on) * d.pos_class_prior : -pu_on) : 1.f;
     const float c_lab = kind == 3 ? mix_eps(row) : (kind == 1 ? (pu ? d.pos_class_prior : 1.f) : 0.f);
     const float p = sigmoid_f(z);
     float dz = valid ? w * (c_sig * p - c_lab) / fB : 0.f;
@@ -467,7 +481,12 @@ extern "C" int il_gail_disc_step(const il_disc* d, const il_batch* pol, const il
   const int nt = ceil_div(d->batch, IL_TILE_R);
   const size_t lds = disc_lds_floats(D, d->hidden) * sizeof(float);
   if (int rc = ensure_lds((const void*)k_gail_grad, lds)) return rc;
-  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, nullptr, nullptr, nullptr, GailSampler{}); }
+  if (d->loss_function == IL_LOSS_PUGAIL && d->pu_clamped) {   // finite nonnegative_margin: a value pass (logits only) ahead of the gradient pass, which reads the clamp decision
+    IL_CHECK_ARG(!d->sync, "il_gail_disc_step: PUGAIL with a finite nonnegative_margin runs on one stream (no il_sync hand-off)");
+    IL_CHECK_ARG(d->nonnegative_margin >= 0.f, "il_gail_disc_step: nonnegative_margin must be >= 0");
+    { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, 2), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, nullptr, nullptr, nullptr, GailSampler{}, 1); }
+  }
+  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, nullptr, nullptr, nullptr, GailSampler{}, 0); }
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
   { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr, (flags & IL_FLAG_GAIL_CLOSE_EPOCH) ? 1 : 0); }
   IL_CHECK_LAUNCH("il_gail_disc_step");
@@ -487,7 +506,7 @@ extern "C" int il_gail_disc_step_draw(const il_disc* d, const il_batch* pol, con
   IL_CHECK_ARG(lds >= sizeof(MtShared), "il_gail_disc_step_draw: discriminator too small to host the sampler's state in its workgroup LDS");
   if (int rc = ensure_lds((const void*)k_gail_grad, lds)) return rc;
   const GailSampler sa = {mt_state_dev, ring_state_a, idx_a, ring_state_b, idx_b, d->batch};
-  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt + 1, gail_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, nullptr, il_gail_extra{}, nullptr, nullptr, nullptr, sa); }
+  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt + 1, gail_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, nullptr, il_gail_extra{}, nullptr, nullptr, nullptr, sa, 0); }
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
   { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr, (flags & IL_FLAG_GAIL_CLOSE_EPOCH) ? 1 : 0); }
   IL_CHECK_LAUNCH("il_gail_disc_step_draw");
@@ -508,7 +527,7 @@ extern "C" int il_gail_step_population(const il_disc* descs_dev, const il_batch*
   if (int rc = ensure_lds((const void*)k_gail_reward, lds)) return rc;
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
   il_batch zb = {};
-  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d), L), 256, lds, st>>>(*d, zb, zb, nullptr, il_gail_extra{}, descs_dev, policy_dev, expert_dev, GailSampler{}); }
+  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d), L), 256, lds, st>>>(*d, zb, zb, nullptr, il_gail_extra{}, descs_dev, policy_dev, expert_dev, GailSampler{}, 0); }
   { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<dim3((int)((P + 255) / 256), L), 256, 0, st>>>(*d, 1, descs_dev, 0); }
   { IL_TRACE("k_gail_reward", st); k_gail_reward<<<dim3(nt, L), 256, lds, st>>>(*d, zb, nullptr, nullptr, nullptr, descs_dev, policy_dev, rewards_out_dev); }
   IL_CHECK_LAUNCH("il_gail_step_population");

@@ -119,13 +119,12 @@ def target_estimation_update(discriminator, expert_transition: Dict[str, Tensor]
 def disc_descriptor(disc: GAILDiscriminator, batch_size: int, opt: AdamW, imitation_cfg=None, grad_penalty: float = 0.0, entropy_bonus: float = 0.0, tag=None,
                     seed_offset: int = 0) -> _lib.Disc:
   dev = disc.flat.device
-  loss_function, prior = 'BCE', 0.0
+  loss_function, prior, margin = 'BCE', 0.0, float('inf')
   if imitation_cfg is not None:
     loss_function, prior = imitation_cfg.loss_function, float(_cfg_value(imitation_cfg, 'pos_class_prior', 0.0) or 0.0)
     if loss_function not in LOSS_FUNCTIONS:
       raise ValueError(f'adversarial_imitation_update: unknown loss_function={loss_function}')
-    if loss_function == 'PUGAIL' and float(_cfg_value(imitation_cfg, 'nonnegative_margin', float('inf'))) != float('inf'):
-      raise NotImplementedError('adversarial_imitation_update: PUGAIL with a finite nonnegative_margin (the clamp needs a batch-wide reduction before the backward) has no kernel; the default inf does')
+    margin = float(_cfg_value(imitation_cfg, 'nonnegative_margin', float('inf')))
     grad_penalty, entropy_bonus = float(imitation_cfg.grad_penalty), float(imitation_cfg.entropy_bonus)
   floats = int(_lib.lib().il_disc_workspace_floats(disc.in_dim, disc.hidden, batch_size))
   ws = _workspace('disc', floats, dev, tag)
@@ -142,6 +141,8 @@ def disc_descriptor(disc: GAILDiscriminator, batch_size: int, opt: AdamW, imitat
   d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
   d.noise_seed, d.noise_counter = (_noise_seed() + seed_offset) & (2**64 - 1), _noise_counter(dev, tag).data_ptr()
   d.loss_function, d.pos_class_prior = LOSS_FUNCTIONS[loss_function], prior
+  if loss_function == 'PUGAIL' and margin != float('inf'):   # training.py:102: torch.clamp(..., min=-nonnegative_margin) on the batch-wide value (a value pass precedes the gradients)
+    d.pu_clamped, d.nonnegative_margin = 1, margin
   return d
 
 
@@ -384,9 +385,10 @@ class UpdatePlan:
     if algorithm == 'GAIL':
       host_mixup = imitation_cfg is not None and imitation_cfg.loss_function == 'Mixup' and float(_cfg_value(imitation_cfg, 'mixup_alpha', 1.0)) != 1.0
       deep = type(discriminator).__name__ == 'DeepGAILDiscriminator'   # depth 2 / tanh: the general kernels, per-function path
-      if imitation_cfg is not None and (host_mixup or deep or discriminator.subtract_log_policy or getattr(discriminator, 'reward_shaping', False)):
+      pu_margin = imitation_cfg is not None and imitation_cfg.loss_function == 'PUGAIL' and float(_cfg_value(imitation_cfg, 'nonnegative_margin', float('inf'))) != float('inf')
+      if imitation_cfg is not None and (host_mixup or deep or pu_margin or discriminator.subtract_log_policy or getattr(discriminator, 'reward_shaping', False)):
         # Mixup with alpha = 1 draws its Beta(1, 1) = U(0, 1) coefficients from the on-chip Philox stream like the gradient penalty does: capturable
-        raise NotImplementedError('UpdatePlan: GAIL with Mixup (alpha != 1: Beta draws on the host) / subtract_log_policy / reward shaping / a depth-2 or tanh discriminator runs through '
+        raise NotImplementedError('UpdatePlan: GAIL with Mixup (alpha != 1: Beta draws on the host) / PUGAIL with a finite margin / subtract_log_policy / reward shaping / a depth-2 or tanh discriminator runs through '
                                   'adversarial_imitation_update + sac_update')
       self.disc = disc_descriptor(discriminator, batch_size, discriminator_optimiser, imitation_cfg, tag=tag, seed_offset=off)
       self.rewards = torch.empty(batch_size, device=dev)

@@ -315,8 +315,11 @@ typedef struct il_disc {
   uint64_t noise_seed;
   uint32_t* noise_counter;
   int64_t* sync;             /* il_sync counters or NULL (see below) */
-  int32_t loss_function;     /* IL_LOSS_BCE / IL_LOSS_PUGAIL (nonnegative_margin = inf) / IL_LOSS_MIXUP (training.py:97-113) */
+  int32_t loss_function;     /* IL_LOSS_BCE / IL_LOSS_PUGAIL / IL_LOSS_MIXUP (training.py:97-113) */
   float pos_class_prior;     /* PUGAIL (training.py:101-102) */
+  int32_t pu_clamped;        /* PUGAIL: 0 = nonnegative_margin is inf (conf/algorithm/GAIL.yaml: the clamp never binds); 1 = finite margin below: il_gail_disc_step then runs a
+                                value pass (the logits of both calls) ahead of the gradient pass, whose workgroups all evaluate the clamp of training.py:102 on the batch-wide value */
+  float nonnegative_margin;
 } il_disc;
 enum { IL_LOSS_BCE = 0, IL_LOSS_PUGAIL = 1, IL_LOSS_MIXUP = 2 };
 /* optional inputs of the loss variants; every pointer may be NULL */

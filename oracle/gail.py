@@ -98,7 +98,7 @@ def disc_logits(ds: DiscState, x, train=False):
 
 
 def gail_update(ds: DiscState, xp, wp, xe, we, eps_gp, *, lr, weight_decay, grad_penalty=1.0, entropy_bonus=0.0, return_grads=False, loss_function='BCE',
-                pos_class_prior=0.7, eps_mix=None, logp_policy=None, logp_expert=None, logp_mix=None):
+                pos_class_prior=0.7, eps_mix=None, logp_policy=None, logp_expert=None, logp_mix=None, nonnegative_margin=float('inf')):
   """One `adversarial_imitation_update` (training.py:85-134). xp/xe = cat(state, action) of policy / expert batch.
   loss_function: 'BCE' (:97-99), 'PUGAIL' with nonnegative_margin = inf (:100-102: the clamp never binds) or 'Mixup' (:104-113, eps_mix = the
   Beta(alpha, alpha) draws). logp_policy / logp_expert: log pi(a|s) of the two batches when subtract_log_policy (models.py:173-175: D = f - log pi;
@@ -109,9 +109,20 @@ def gail_update(ds: DiscState, xp, wp, xe, we, eps_gp, *, lr, weight_decay, grad
   zero = np.zeros(B, f32)
   if loss_function == 'BCE':      # d loss / d logit = w (c_sig * sigmoid - c_lab) / B
     calls = [(xp, wp, f32(1), zero, logp_policy), (xe, we, f32(1), zero + f32(1), logp_expert)]
-  elif loss_function == 'PUGAIL':  # prior*BCE(D_e,1) + [prior*BCE(D_e,0) - BCE(D_p,0)]
+  elif loss_function == 'PUGAIL':  # prior*BCE(D_e,1) + clamp(prior*BCE(D_e,0) - BCE(D_p,0), min=-margin)   (training.py:100-102)
     pr = f32(pos_class_prior)
-    calls = [(xp, wp, f32(-1), zero, logp_policy), (xe, we, f32(2) * pr, zero + pr, logp_expert)]
+    on = f32(1)
+    if nonnegative_margin != float('inf'):   # the clamp passes the gradient only where its argument is not below the bound: a batch-wide decision on the logits of both calls
+      import copy
+      probe = copy.deepcopy(ds)              # the same two power iterations the calls below will run
+      zs = []
+      for x, off in ((xp, logp_policy), (xe, logp_expert)):
+        W1h, W2h, _ = _sn_weights(probe, True)
+        z = _forward(W1h, probe.b1, W2h, probe.b2, x)[2]
+        zs.append(z if off is None else z - off.astype(f32))
+      V = pr * np.mean(we * nets.softplus(zs[1]), dtype=f32) - np.mean(wp * nets.softplus(zs[0]), dtype=f32)
+      on = f32(1) if V >= -nonnegative_margin else f32(0)
+    calls = [(xp, wp, -on, zero, logp_policy), (xe, we, (f32(1) + on) * pr, zero + pr, logp_expert)]
   elif loss_function == 'Mixup':   # eps*BCE(D_mix,1) + (1-eps)*BCE(D_mix,0) on convex combinations
     em = eps_mix.astype(f32)
     calls = [(em[:, None] * xe + (f32(1) - em[:, None]) * xp, em * we + (f32(1) - em) * wp, f32(1), em, logp_mix)]   # logp_mix: log pi of the mixed rows (training.py:108)

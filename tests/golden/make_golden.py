@@ -280,6 +280,37 @@ def gen_gail_variants():
   np.savez_compressed(os.path.join(HERE, 'gail_variants.npz'), **out)
 
 
+def gen_gail_pu_margin():
+  """adversarial_imitation_update with loss_function=PUGAIL and a FINITE nonnegative_margin (training.py:100-102): one margin that clamps the unlabelled term away
+  (its gradient vanishes) and one that does not; gradients, parameters, and the clamped value itself."""
+  out = {}
+  for name, margin in (('clamped', 0.02), ('open', 1.5)):
+    c = gi.gail_case(37, env='halfcheetah', hidden=64, batch=128, steps=2)
+    d, icfg = build_disc(c)
+    icfg.update(loss_function='PUGAIL', grad_penalty=0.5, mixup_alpha=1, entropy_bonus=0.01, pos_class_prior=0.7, nonnegative_margin=margin)
+    opt = torch.optim.AdamW(d.parameters(), lr=1e-3, weight_decay=0.1)
+    for i in range(2):
+      d.train()
+      seen = []
+      orig = torch.clamp
+      def spy(x, *a, **k):
+        if x.dim() == 0: seen.append(float(x))
+        return orig(x, *a, **k)
+      torch.clamp = spy
+      try:
+        with NoiseFeed() as nf:
+          nf.rand.append(T(c['eps'][i]))
+          ref_training.adversarial_imitation_update(None, d, tbatch(c['policy'][i]), tbatch(c['expert'][i]), opt, icfg)
+      finally:
+        torch.clamp = orig
+      d.eval()
+      k = i + 1
+      out[f'{name}.g_{k}'] = np.concatenate([N_(p.grad).ravel() for p in d.parameters()]); out[f'{name}.p_{k}'] = flat(d)
+      out[f'{name}.value_{k}'] = np.array(seen[:1], np.float64)
+    out[f'{name}.margin'] = np.array([margin])
+  np.savez_compressed(os.path.join(HERE, 'gail_pu_margin.npz'), **out)
+
+
 def gen_gail_deep(f64=None):
   """GAILDiscriminator with depth 1-2 / relu / tanh (models.py:152-162, no reward shaping) under adversarial_imitation_update: gradients, parameters after
   AdamW, u / v buffers, rewards. The gradient-penalty and Mixup draws are fed like the other noise."""
@@ -633,6 +664,7 @@ if __name__ == '__main__':
     gen_gail('gail_h128_ent', gi.gail_case(32, hidden=128), lr=7.3e-5, weight_decay=6.35, grad_penalty=0.32, entropy_bonus=0.0155)
     gen_gail('gail_nosn_nogp', gi.gail_case(33, env='hopper', hidden=32, batch=128, spectral_norm=False), lr=3e-4, weight_decay=0.0, grad_penalty=0.0, entropy_bonus=0.0)
   if want('gail_variants'): gen_gail_variants()
+  if want('gail_pu_margin'): gen_gail_pu_margin()
   if want('gail_shaped'): gen_gail_shaped()
   if want('gail_deep'): gen_gail_deep()
   if want('gmmil'): gen_gmmil()

@@ -341,7 +341,7 @@ def test_pwil_matches_oracle_and_reference(golden_dir):
 
 
 # ------------------------------------------------------------------------------------------------ whole update block
-def _make_plan(algorithm, seed, device_draw=True, loss='BCE', entropy_bonus=0.0, B=256):
+def _make_plan(algorithm, seed, device_draw=True, loss='BCE', entropy_bonus=0.0, B=256, margin=float('inf')):
   S, A = gi.DIMS['halfcheetah']
   torch.manual_seed(seed)
   cfg = Cfg(hidden_size=256, depth=2, activation='relu')
@@ -351,7 +351,7 @@ def _make_plan(algorithm, seed, device_draw=True, loss='BCE', entropy_bonus=0.0,
   rs = np.random.RandomState(seed)
   mem = il.ReplayMemory(20000, S, A, True, device=DEV); fill_memory(mem, gi.transitions(rs, 5000, S, A), 5000)
   emem = il.ReplayMemory(2000, S, A, True, device=DEV); fill_memory(emem, gi.transitions(rs, 2000, S, A, state_shift=0.5), 2000)
-  icfg = Cfg(state_only=False, spectral_norm=True, loss_function=loss, grad_penalty=1.0, entropy_bonus=entropy_bonus, mixup_alpha=1, pos_class_prior=0.7, nonnegative_margin=float('inf'),
+  icfg = Cfg(state_only=False, spectral_norm=True, loss_function=loss, grad_penalty=1.0, entropy_bonus=entropy_bonus, mixup_alpha=1, pos_class_prior=0.7, nonnegative_margin=margin,
              discriminator=Cfg(hidden_size=64, depth=1, activation='relu', reward_shaping=False, subtract_log_policy=False, reward_function='AIRL'))
   disc = il.GAILDiscriminator(S, A, icfg, 0.97, device=DEV)
   do = il.AdamW(disc, lr=3e-5, weight_decay=10)
@@ -898,15 +898,41 @@ def test_gail_loss_variants_match_reference(golden_dir, name, loss, sub):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', ['clamped', 'open'])
+def test_gail_pugail_finite_margin_matches_reference(golden_dir, name):
+  """PUGAIL with a finite nonnegative_margin (training.py:100-102): the value pass + clamp decision of il_gail_disc_step against the reference fixture and the oracle,
+  once with the unlabelled term clamped away and once with the gradient passing."""
+  g = load(golden_dir, 'gail_pu_margin')
+  c = gi.gail_case(37, env='halfcheetah', hidden=64, batch=128, steps=2)
+  margin = float(g[f'{name}.margin'][0])
+  d, ods, icfg = make_disc(c)
+  icfg.update(loss_function='PUGAIL', grad_penalty=0.5, entropy_bonus=0.01, mixup_alpha=1, pos_class_prior=0.7, nonnegative_margin=margin)
+  opt = il.AdamW(d, lr=1e-3, weight_decay=0.1)
+  cat = lambda b: np.concatenate([b['states'], b['actions']], axis=1)
+  for i in range(2):
+    pb, eb = c['policy'][i], c['expert'][i]
+    d.train()
+    il.adversarial_imitation_update(None, d, tbatch(pb), tbatch(eb), opt, icfg, eps_gp=T(c['eps'][i]))
+    d.eval()
+    ogr = ogail.gail_update(ods, cat(pb), pb['weights'], cat(eb), eb['weights'], c['eps'][i], lr=1e-3, weight_decay=0.1, grad_penalty=0.5, entropy_bonus=0.01, return_grads=True,
+                            loss_function='PUGAIL', pos_class_prior=0.7, nonnegative_margin=margin)
+    close(N(opt.grad), g[f'{name}.g_{i + 1}'], f'{name} gradient {i + 1} (reference)', atol_scale=4e-6 * (i + 1)); close(N(opt.grad), ogr, f'{name} gradient {i + 1} (oracle)', atol_scale=4e-6 * (i + 1))
+    close(N(d.flat), g[f'{name}.p_{i + 1}'], f'{name} parameters {i + 1}', atol_scale=4e-6 * (i + 1))
+  assert int(opt.step_count[0]) == 2, 'the value pass must not tick the optimiser'
+  with pytest.raises(NotImplementedError, match='PUGAIL with a finite margin'):   # the captured plan keeps the per-function path for it (train.py does)
+    _make_plan('GAIL', 3, loss='PUGAIL', margin=0.1)
+
+
+@pytest.mark.gpu
 def test_gail_variants_loud_failures():
   c = gi.gail_case(35, env='hopper', hidden=32, batch=96, steps=1)
   mk = lambda **kw: Cfg(state_only=False, spectral_norm=True, loss_function='PUGAIL', grad_penalty=0.5, mixup_alpha=1, entropy_bonus=0.0, pos_class_prior=0.7, nonnegative_margin=kw.get('margin', float('inf')),
                         discriminator=Cfg(hidden_size=32, depth=1, activation='relu', reward_shaping=kw.get('shaping', False), subtract_log_policy=False, reward_function='AIRL'))
   assert type(il.GAILDiscriminator(c['S'], c['A'], mk(shaping=True), 0.97, device=DEV)).__name__ == 'ShapedGAILDiscriminator'
-  d = il.GAILDiscriminator(c['S'], c['A'], mk(), 0.97, device=DEV)
+  d = il.GAILDiscriminator(c['S'], c['A'], mk(shaping=True), 0.97, device=DEV)   # the depth-1 / relu discriminator handles a finite margin (test above); the shaped and the deep ones refuse it
   opt = il.AdamW(d, lr=1e-3, weight_decay=0.1)
   with pytest.raises(NotImplementedError):
-    il.adversarial_imitation_update(None, d, tbatch(c['policy'][0]), tbatch(c['expert'][0]), opt, mk(margin=0.1))
+    il.adversarial_imitation_update(None, d, tbatch(c['policy'][0]), tbatch(c['expert'][0]), opt, mk(shaping=True, margin=0.1))
 
 
 @pytest.mark.gpu

@@ -320,3 +320,22 @@ def test_philox_restatement_matches_random123_known_answers():
   assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
   u = philox.uniform(7, 3, philox.STREAM_GP, 1 << 18)
   assert 0 <= u.min() and u.max() < 1 and abs(float(u.mean()) - 0.5) < 0.01
+
+
+@pytest.mark.parametrize('name', ['clamped', 'open'])
+def test_oracle_pugail_finite_margin_matches_reference(name):
+  """training.py:100-102 with a finite nonnegative_margin: the clamp decides batch-wide whether the unlabelled term has a gradient (fixture: one margin each way)."""
+  g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'gail_pu_margin.npz'))
+  c = gi.gail_case(37, env='halfcheetah', hidden=64, batch=128, steps=2)
+  ds = gail.DiscState(c['D'], c['H'], True)
+  for k in ('W1', 'b1', 'W2', 'b2', 'u1', 'v1', 'u2', 'v2'):
+    getattr(ds, k)[...] = c[k]
+  cat = lambda b: np.concatenate([b['states'], b['actions']], axis=1)
+  margin = float(g[f'{name}.margin'][0])
+  assert (float(g[f'{name}.value_1'][0]) < -margin) == (name == 'clamped')
+  for i in range(2):
+    pb, eb = c['policy'][i], c['expert'][i]
+    gr = gail.gail_update(ds, cat(pb), pb['weights'], cat(eb), eb['weights'], c['eps'][i], lr=1e-3, weight_decay=0.1, grad_penalty=0.5, entropy_bonus=0.01, return_grads=True,
+                          loss_function='PUGAIL', pos_class_prior=0.7, nonnegative_margin=margin)
+    np.testing.assert_allclose(gr, g[f'{name}.g_{i + 1}'], rtol=1e-5, atol=4e-6 * np.abs(g[f'{name}.g_{i + 1}']).max())
+    np.testing.assert_allclose(ds.pack(), g[f'{name}.p_{i + 1}'], rtol=1e-5, atol=4e-6 * (i + 1) * np.abs(g[f'{name}.p_{i + 1}']).max())
