@@ -448,6 +448,11 @@ class UpdatePlan:
       main.wait_stream(self.side)
     before = self.sync_timeouts()
     if not graph:
+      _lib.check(L.il_sync_probe(_lib.ptr(self.sync), 1, _lib.stream_ptr()))   # code object loaded, counters one ahead: the first timed waiter cannot be late because of a cold launch
+      with torch.cuda.stream(self.side):
+        self.side.wait_stream(main)
+        _lib.check(L.il_sync_probe(_lib.ptr(self.sync), 0, _lib.stream_ptr()))
+      torch.cuda.synchronize()
       for _ in range(3): enqueue()
     else:   # the shape capture() uses: one graph per stream, the waiter's launched first
       gw, gs = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -455,6 +460,13 @@ class UpdatePlan:
         _lib.check(L.il_sync_probe(_lib.ptr(self.sync), 0, _lib.stream_ptr()))
       with torch.cuda.graph(gs):
         _lib.check(L.il_sync_probe(_lib.ptr(self.sync), 1, _lib.stream_ptr()))
+      # first launches of freshly instantiated graphs can take > 10 ms (the probe's bound) to reach the device: launch each once in the order that cannot wait
+      # (setter, then waiter), and only then run the real test with the waiter first
+      gs.replay()
+      torch.cuda.synchronize()
+      with torch.cuda.stream(self.side):
+        gw.replay()
+      torch.cuda.synchronize()
       for _ in range(3):
         with torch.cuda.stream(self.side):
           gw.replay()
