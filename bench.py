@@ -361,6 +361,8 @@ def main():
   for _ in range(5):
     runner.run()   # loads code objects before capture
   torch.cuda.synchronize()
+  if runner is not plan and getattr(runner, 'handoff', False) and not runner.agree_on_handoff():   # collective: an expired device-side wait on ANY rank sends every rank to the stream-dependency schedule
+    print(f'[bench] rank {rank}: device-side hand-off left (a bounded wait expired on some rank during the eager warm-up); using stream dependencies', file=sys.stderr)
   launch = 'eager'
   step = runner.run
   if not args.no_graph:

@@ -117,6 +117,7 @@ class DataParallelUpdate:
     if self.handoff and dist.is_initialized():
       self.side_group = dist.new_group(ranks=None if group is None else dist.get_process_group_ranks(group), backend=dist.get_backend(group))
     self.graph = self.graph_side = None
+    self._warm_collectives_pending = True
     ao, to = plan._keep[4], plan._keep[6]
     # actor grad and alpha grad travel in one bucket: the optimisers' gradient arenas become views into it
     self.buckets = GradBuckets(ao.grad.numel(), plan._keep[5].grad, plan._keep[8].grad if plan.algorithm == 'GAIL' else None)
@@ -125,6 +126,36 @@ class DataParallelUpdate:
     self.side = torch.cuda.Stream() if plan.algorithm == 'GAIL' else None
     self.actor_bucket, self.critic_bucket, self.disc_bucket = self.buckets.actor, self.buckets.critic, self.buckets.disc
 
+  def _warm_collectives(self):
+    """First use of a communicator sets up its connections (host-blocking, up to seconds) and ranks reach their first update seconds apart: neither may happen inside an
+    update of the hand-off schedule, whose device-side waits are bounded. One all-reduce per (bucket, communicator) - the gradient arenas still hold zeros - then a
+    barrier: afterwards the ranks are aligned and every later collective is a steady-state one."""
+    self._warm_collectives_pending = False
+    if not dist.is_initialized():
+      return
+    for bucket, group in ((self.disc_bucket, self.side_group), (self.critic_bucket, self.group), (self.actor_bucket, self.group)):
+      if bucket is not None:
+        all_reduce_mean_(bucket, group)
+    torch.cuda.synchronize()
+    if dist.get_world_size(self.group) > 1:
+      dist.barrier(self.group)
+
+  def agree_on_handoff(self) -> bool:
+    """Call after a few eager updates: if ANY rank saw a bounded device-side wait expire (its two streams did not run concurrently, or a peer stalled for longer than the
+    bound), EVERY rank leaves the hand-off schedule - the decision must be collective, the two schedules issue the discriminator's all-reduce on different communicators.
+    Returns whether the hand-off schedule stays on. The updates that timed out used stale rewards: a training run should stop (train.py does); a benchmark carries on."""
+    if not self.handoff:
+      return False
+    bad = torch.tensor([float(self.plan.sync_timeouts())], device=self.plan.rows.device)
+    if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+      dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+    if float(bad.item()) > 0:
+      torch.cuda.synchronize()
+      self.handoff = False
+      self.plan.sync.zero_()
+      self.plan._set_device_sync(False)
+    return self.handoff
+
   def run(self):
     """sample -> [side stream: discriminator grads -> all-reduce -> AdamW -> reward | main: SAC forward] -> critic grads -> all-reduce ->
     AdamW(critic) + actor grads -> all-reduce -> AdamW(actor) + Adam(alpha) + polyak.  The discriminator's all-reduce hides under the
@@ -132,6 +163,8 @@ class DataParallelUpdate:
     p, L = self.plan, _lib.lib()
     G = _lib.IL_FLAG_GRADS_ONLY
     main = torch.cuda.current_stream()
+    if self._warm_collectives_pending:
+      self._warm_collectives()
     if self.handoff:
       self._run_handoff(main)
       return
