@@ -460,11 +460,8 @@ __device__ __forceinline__ void chain_decode(int bid, int nt, int& role, int& ne
 // b.gather != NULL (il_sac_update_gather): the batch has been drawn but not gathered. Every role reads its rows straight from the ring through the
 // indices, and the workgroups behind the 6 * nt chain roles copy the rows to `rows_out` for the later kernels of the update (one 16-byte
 // lane per thread, [IL_SYNC_ROWS] += 1 per workgroup) - they wait for nothing and nobody in this launch waits for them.
-__global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, const float* __restrict__ rewards,
-                                                    float* __restrict__ rows_out, ChainRelabel rl) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  globalize(d); globalize(b);
-  if (rl.on) { globalize(rl.dd); rl.out = as_global(rl.out); }
+__device__ __forceinline__ void sac_chain_body(il_sac& d, il_batch& b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, const float* __restrict__ rewards,
+                                               float* __restrict__ rows_out, ChainRelabel& rl, float* smem) {
   const int nt = d.batch / IL_TILE_R;
   // resident sampler (il_replay_draw_resident on the other stream): this update's indices are signalled, not stream-ordered. This launch follows the previous
   // update's last kernel in its stream, so [IL_SYNC_MAIN_EPOCH] already counts that update; the draw usually finished while this launch was being dispatched.
@@ -503,6 +500,25 @@ __global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const 
     if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 4u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     critic_bwd_resident_scale(d, b, rewards, rl, rs, net, tile, smem);
   } else actor_fwd_tile(d, b, eps_next, eps_cur, true, tile, smem);
+}
+
+__global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, const float* __restrict__ rewards,
+                                                    float* __restrict__ rows_out, ChainRelabel rl) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  globalize(d); globalize(b);
+  if (rl.on) { globalize(rl.dd); rl.out = as_global(rl.out); }
+  sac_chain_body(d, b, eps_next, eps_cur, rewards, rows_out, rl, smem);
+}
+
+// Population launch of the chain: grid (6 * nt, learners). Workgroups are dispatched in linear order (x fastest), a role only waits for lower-numbered workgroups of ITS
+// learner (block order actor(s') < targets < critics < actor(s)), so the waits are deadlock-free without the whole grid being co-resident: a producer is always dispatched
+// before its consumers. Replaces k_actor_fwd + k_critic_fwd + k_critic_bwd of the population path (two launches and the h1 / h2 round trip of the critics less).
+__global__ __launch_bounds__(1024) void k_sac_chain_pop(const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  il_sac d = dL[blockIdx.y]; il_batch b = bL[blockIdx.y];
+  globalize(d); globalize(b);
+  ChainRelabel rl = {};
+  sac_chain_body(d, b, nullptr, nullptr, nullptr, nullptr, rl, smem);
 }
 
 // policy-loss backward of one 16-row tile: min-Q selection, tanh-Gaussian backward, actor back-prop (dz3, dz2, dz1 for the dW kernel), alpha partial.
@@ -1279,13 +1295,22 @@ extern "C" int il_sac_update_population(const il_sac* descs_dev, const il_batch*
   static const int pop_threads_env = [] { const char* e = getenv("IL_POP_TILE_THREADS"); return e ? atoi(e) : 0; }();
   const int tt_default = tile_threads(H) >= 512 ? tile_threads(H) / 2 : tile_threads(H);
   const int tt = (pop_threads_env >= 256 && pop_threads_env <= tile_threads(H) && pop_threads_env % 64 == 0) ? pop_threads_env : tt_default;
+  // Measured at 32 learners (round 2): chained 61.6k aggregate updates/s vs 70.7k with the three separate launches (k_sac_chain_pop 215 us against 46 + 71 + 35 us): the
+  // workgroups that wait for their tile's producers hold CU slots the oversubscribed launch needs. Hence OFF by default; IL_POP_CHAIN=1 switches it on.
+  static const int pop_chain = [] { const char* e = getenv("IL_POP_CHAIN"); return e && e[0] == '1' ? 1 : 0; }();
+  const bool whole = !(flags & (IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY));
+  if (whole && pop_chain) {   // forward + critic loss chained per tile inside one launch (k_sac_chain_pop); IL_POP_CHAIN=0: the three separate launches
+    if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5, L), 256, 0, st>>>(z, 0x1Fu, descs_dev); }
+    { IL_TRACE("k_sac_chain", st); k_sac_chain_pop<<<dim3(6 * nt, L), tt, lds, st>>>(descs_dev, batches_dev); }
+    flags |= IL_FLAG_SAC_SKIP_FORWARD | 0x80000000u;
+  }
   if (!(flags & IL_FLAG_SAC_SKIP_FORWARD)) {
     if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5, L), 256, 0, st>>>(z, 0x1Fu, descs_dev); }
     { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, nullptr, nullptr, 0, descs_dev, batches_dev); }
     { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<dim3(4 * nt, L), tt, lds, st>>>(z, zb, descs_dev, batches_dev); }
   }
   if (!(flags & IL_FLAG_SAC_FORWARD_ONLY)) {
-    { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, descs_dev, batches_dev); }
+    if (!(flags & 0x80000000u)) { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, descs_dev, batches_dev); }
     static const int lds_dw = [] { const char* e = getenv("IL_POP_DW_LDS"); return e && e[0] == '0' ? 0 : 1; }();
     const bool b64 = lds_dw && H % DWB == 0 && B % DWB == 0;   // H x H layers as 64 x 64 blocks staged through LDS (dw_block64); IL_POP_DW_LDS=0: dw_tile for every layer
     const int nbc = b64 ? dw_block64_count(H, 2) : 0, nba = b64 ? dw_block64_count(H, 1) : 0;
