@@ -566,6 +566,32 @@ def test_batched_population_equals_independent_learners():
   assert not np.array_equal(results[0][0][0], results[0][1][0])  # the learners really are different
 
 
+@pytest.mark.gpu
+def test_population_launch_switches_are_bit_identical():
+  """The population path's optional schedules - forward / critic loss chained per tile inside the population launch (IL_POP_CHAIN=1), full-width tile kernels
+  (IL_POP_TILE_THREADS=1024), dW without the LDS-staged blocks (IL_POP_DW_LDS=0), no second stream (IL_POP_OVERLAP=0) - run the same arithmetic per element."""
+  import subprocess, sys, json
+  code = (
+      "import sys, json, hashlib, numpy as np, torch; sys.path[:0] = ['.', 'tests', 'tests/golden']\n"
+      "import imitation_learning_amd as il, bench\n"
+      "from test_gpu_parity import N\n"
+      "built = [bench.build(torch.device('cuda'), 0, seed=50 + l, learner_id=50 + l) for l in range(3)]\n"
+      "pop = il.BatchedPopulationPlan([b[0] for b in built])\n"
+      "for _ in range(4): pop.run()\n"
+      "torch.cuda.synchronize()\n"
+      "h = hashlib.sha256()\n"
+      "for plan, nets, _ in built:\n"
+      "  for n in list(nets) + [plan.logp, plan.q, plan.rewards]: h.update(np.ascontiguousarray(N(n.flat if hasattr(n, 'flat') else n)).tobytes())\n"
+      "print(json.dumps(dict(digest=h.hexdigest())))\n")
+  digests = {}
+  for name, env in (('default', {}), ('chain', dict(IL_POP_CHAIN='1', IL_POP_OVERLAP='0')), ('full width', dict(IL_POP_TILE_THREADS='1024')), ('dw tiles', dict(IL_POP_DW_LDS='0')),
+                    ('one stream', dict(IL_POP_OVERLAP='0'))):
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (name, r.stderr[-2000:])
+    digests[name] = json.loads(r.stdout.strip().splitlines()[-1])['digest']
+  assert len(set(digests.values())) == 1, digests
+
+
 # ---------------------------------------------------------------------------------------------
 # acting worker (SURVEY.md §8f-2): il_act_step == actor(state).sample() + memory.append + wrap_for_absorbing_states
 # ---------------------------------------------------------------------------------------------
