@@ -8,21 +8,37 @@
 //   k_gmmil_pack   feature-major copies XT[D][B1], ET[D][B2] (so LDS tiles load coalesced and read conflict-free) and
 //                  the normalised weights;
 //   k_gmmil_tile   grid (i-tile, j-tile, matrix): 64x64 pairs per workgroup, 4x4 per thread, features streamed through
-//                  LDS in chunks of 32, two ds_read_b128 per 16 pair updates; epilogue exp + weighted row sums;
-//                  the row tile's last-arriving workgroup then sums the per-column-tile partials in tile order (deterministic).
+//                  LDS in chunks of 32 (a ring of register slots keeps every chunk of D <= 128 in flight from the start;
+//                  LDS operands double-buffered in registers), two ds_read_b128 per 16 pair updates; epilogue exp +
+//                  weighted row sums; the row tile's last-arriving workgroup then sums the per-column-tile partials in
+//                  tile order (deterministic).
+// Measured anatomy at B = 1024, D = 120 (profiles/r02_gmmil_timeline.md; s_memtime per workgroup): the packed-op loop runs at the VALU issue rate
+// (4.3-4.9 ticks per v_pk instruction per SIMD); what the kernel time holds beyond it is the first fabric round trip, the exp epilogue, the
+// release ticket and the last arriver's sums.
 #include "il_common.hpp"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-#define GT 64   // tile edge (pairs)
+#define GT 64   // tile edge (pairs): columns of a pair tile, rows of a pack tile
 #define GKC 32  // feature chunk
+#ifndef GMMIL_RB
+#define GMMIL_RB 4   // rows of a thread's register block (x 4 columns); a pair tile is GTR rows x GT columns
+#endif
+#ifndef GMMIL_GG
+#define GMMIL_GG 2   // features per double-buffered group of LDS operand reads
+#endif
+#ifndef GMMIL_PF
+#define GMMIL_PF 4   // feature chunks in flight (register slots of the global -> LDS ring)
+#endif
+#define GTR (16 * GMMIL_RB)
+#define GCTR 32   // floats between two arrival counters: same-line atomics from 8 XCDs serialise at the memory side
 
 struct GmmilWs { int64_t xt, et, wn, wen, part, ctr, total; int b1p, b2p, njt; };
 __host__ __device__ inline GmmilWs gmmil_ws(int n1, int n2, int D) {
-  GmmilWs w; w.b1p = (n1 + GT - 1) / GT * GT; w.b2p = (n2 + GT - 1) / GT * GT;
+  GmmilWs w; w.b1p = (n1 + GTR - 1) / GTR * GTR; w.b2p = (n2 + GT - 1) / GT * GT;   // policy rows: whole row tiles (GTR is a multiple of GT); padded rows / columns carry weight 0
   const int nj1 = w.b2p / GT, nj2 = w.b1p / GT; w.njt = nj1 > nj2 ? nj1 : nj2;
   int64_t o = 0;
   w.xt = o; o += (int64_t)D * w.b1p; w.et = o; o += (int64_t)D * w.b2p; w.wn = o; o += w.b1p; w.wen = o; o += w.b2p;
-  w.part = o; o += (int64_t)2 * w.njt * w.b1p; w.ctr = o; o += (w.b1p / GT + 3) & ~3;   // arrival counter per row tile (zeroed by k_gmmil_pack)
+  w.part = o; o += (int64_t)2 * w.njt * w.b1p; w.ctr = o; o += (int64_t)(w.b1p / GTR) * GCTR;   // arrival counter per row tile, one 128-byte line each (zeroed by k_gmmil_pack)
   w.total = o;
   return w;
 }
@@ -40,7 +56,7 @@ __global__ __launch_bounds__(256) void k_gmmil_pack(il_batch pol, il_batch exp, 
   __shared__ float red[32];
   const GmmilWs w = gmmil_ws(pol.n, exp.n, D);
   const int nt1 = w.b1p / GT;
-  if (blockIdx.x == 0 && blockIdx.y == 0) for (int i = threadIdx.x; i < nt1; i += blockDim.x) reinterpret_cast<unsigned*>(ws_ + w.ctr)[i] = 0u;
+  if (blockIdx.x == 0 && blockIdx.y == 0) for (int i = threadIdx.x; i < w.b1p / GTR; i += blockDim.x) reinterpret_cast<unsigned*>(ws_ + w.ctr)[i * GCTR] = 0u;
   const bool is_exp = (int)blockIdx.x >= nt1;
   const il_batch& b = is_exp ? exp : pol;
   const int n = b.n, np = is_exp ? w.b2p : w.b1p, row0 = ((int)blockIdx.x - (is_exp ? nt1 : 0)) * GT;
@@ -67,7 +83,8 @@ __global__ __launch_bounds__(256) void k_gmmil_pack(il_batch pol, il_batch exp, 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_gmmil_tile(int n1, int n2, int D, float g1, float g2, float* __restrict__ ws_, float* __restrict__ dist_out, int self_second,
                                                     float* __restrict__ out_r, float* __restrict__ out_sim, float* __restrict__ out_self) {
-  __shared__ __attribute__((aligned(16))) float Xs[GKC][GT];
+  constexpr int RB = GMMIL_RB, RQ = RB / 4;   // a thread's block: RB rows (RQ 16-byte LDS reads) x 4 columns (one read)
+  __shared__ __attribute__((aligned(16))) float Xs[GKC][GTR];
   __shared__ __attribute__((aligned(16))) float Ys[GKC][GT];
   const GmmilWs w = gmmil_ws(n1, n2, D);
   const int it = blockIdx.x, jt = blockIdx.y, mat = blockIdx.z;  // mat 0: policy vs expert, 1: policy vs policy
@@ -77,91 +94,143 @@ __global__ __launch_bounds__(256) void k_gmmil_tile(int n1, int n2, int D, float
   const float* XT = ws_ + w.xt; const float* YT = ws_ + (vs_self ? w.xt : w.et);
   const float* wy = ws_ + (vs_self ? w.wn : w.wen);
   const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
-  f32x2 acc2[4][2];
+  f32x2 acc2[RB][2];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) { acc2[a][0] = f32x2{0.f, 0.f}; acc2[a][1] = f32x2{0.f, 0.f}; }
-  // feature chunks of GKC: the next chunk's 2 x 8 values per thread are requested before the current chunk is consumed (their global latency used to
-  // sit between two barriers with nothing to overlap it: two workgroups per CU at B = 1024)
-  constexpr int PER = GKC * GT / 256;
-  float xr[PER], yr[PER];
-  auto fetch = [&](int k0) {
+  for (int a = 0; a < RB; ++a) { acc2[a][0] = f32x2{0.f, 0.f}; acc2[a][1] = f32x2{0.f, 0.f}; }
+  // Feature chunks of GKC through a ring of NPF register slots: the loads of chunks c+1 .. c+NPF-1 are in flight while chunk c is consumed, and a slot is
+  // refilled (chunk c+NPF) as soon as its values are in LDS. XT / ET were written by k_gmmil_pack a moment ago, mostly on other XCDs, so a load is a trip to
+  // the fabric: measured 1.7 us per chunk against 1 us of packed ops - with one chunk of look-ahead the loop waited 60 % of its time. D <= NPF * GKC (every
+  // shipped environment): all of a tile's operands are requested before the first barrier.
+  constexpr int PERX = GKC * GTR / 256, PERY = GKC * GT / 256, NPF = GMMIL_PF;
+  float xr[NPF][PERX], yr[NPF][PERY];
+  auto fetch = [&](float* xs_, float* ys_, int k0) {
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
+    for (int u = 0; u < PERX; ++u) {
+      const int i = threadIdx.x + u * 256, k = i / GTR, c = i - k * GTR;
+      xs_[u] = XT[(size_t)min(k0 + k, D - 1) * w.b1p + it * GTR + c];   // clamped address, zeroed when it is stored to LDS: a predicated load is an exec-masked branch each,
+                                                                        // a select right here would wait for the load
+    }
+#pragma unroll
+    for (int u = 0; u < PERY; ++u) {
       const int i = threadIdx.x + u * 256, k = i / GT, c = i - k * GT;
-      const bool ok = k0 + k < D;
-      xr[u] = ok ? XT[(size_t)(k0 + k) * w.b1p + it * GT + c] : 0.f;
-      yr[u] = ok ? YT[(size_t)(k0 + k) * npy + jt * GT + c] : 0.f;
+      ys_[u] = YT[(size_t)min(k0 + k, D - 1) * npy + jt * GT + c];
     }
   };
   const bool stamp = blockIdx.x == 3 && blockIdx.y == 5 && blockIdx.z == 0;
   IL_STAMP(stamp, 0);
-  fetch(0);
-  for (int k0 = 0; k0 < D; k0 += GKC) {
 #pragma unroll
-    for (int u = 0; u < PER; ++u) { const int i = threadIdx.x + u * 256, k = i / GT, c = i - k * GT; Xs[k][c] = xr[u]; Ys[k][c] = yr[u]; }
+  for (int sl = 0; sl < NPF; ++sl) if (sl * GKC < D) fetch(xr[sl], yr[sl], sl * GKC);
+  for (int kk = 0; kk < D; kk += NPF * GKC) {
+#pragma unroll
+   for (int sl = 0; sl < NPF; ++sl) {
+    const int k0 = kk + sl * GKC;
+    if (k0 >= D) break;
+#pragma unroll
+    for (int u = 0; u < PERX; ++u) { const int i = threadIdx.x + u * 256, k = i / GTR, c = i - k * GTR; Xs[k][c] = (k0 + k < D) ? xr[sl][u] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < PERY; ++u) { const int i = threadIdx.x + u * 256, k = i / GT, c = i - k * GT; Ys[k][c] = (k0 + k < D) ? yr[sl][u] : 0.f; }
     __syncthreads();
-    if (k0 + GKC < D) fetch(k0 + GKC);
-    // all GKC features of the chunk (features >= D are staged as zeros on both sides: they add (0 - 0)^2), so the loop has a fixed trip count and
-    // unrolls: eight LDS reads in flight ahead of 64 packed ops instead of read - wait - 16 ops with one wave per SIMD
-#pragma unroll 4
-    for (int k = 0; k < GKC; ++k) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(&Xs[k][ti * 4]);
-      const f32x4 yv = *reinterpret_cast<const f32x4*>(&Ys[k][tj * 4]);
-      const f32x2 y01 = {yv[0], yv[1]}, y23 = {yv[2], yv[3]};
+    if (k0 + NPF * GKC < D) fetch(xr[sl], yr[sl], k0 + NPF * GKC);
+    // all GKC features of the chunk (features >= D are staged as zeros on both sides: they add (0 - 0)^2), so the loop has a fixed trip count.
+    // The LDS operands are double-buffered in registers in groups of GG features: the ds_read_b128 of the NEXT group are issued (and pinned there by a
+    // scheduling barrier) before the packed ops of the current one. Left to itself hipcc sinks every read to its first use: read - s_waitcnt lgkmcnt(0) -
+    // 16 ops per feature, i.e. a full LDS round trip exposed per feature step with one or two waves per SIMD (measured 200 cycles per step against 68 of VALU issue).
+    constexpr int GG = GMMIL_GG;
+    f32x4 xa_[GG][RQ], ya_[GG], xb_[GG][RQ], yb_[GG];
+    auto lds_group = [&](f32x4 (*xg)[RQ], f32x4* yg, int kb) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {   // two pairs per instruction: v_pk_add_f32 + v_pk_fma_f32 (same roundings as the scalar sub + fma)
-        const f32x2 xa = {xv[a], xv[a]};
-        const f32x2 d0 = xa - y01, d1 = xa - y23;
-        acc2[a][0] = __builtin_elementwise_fma(d0, d0, acc2[a][0]);
-        acc2[a][1] = __builtin_elementwise_fma(d1, d1, acc2[a][1]);
+      for (int u = 0; u < GG; ++u) {
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) xg[u][q] = *reinterpret_cast<const f32x4*>(&Xs[kb + u][ti * RB + 4 * q]);
+        yg[u] = *reinterpret_cast<const f32x4*>(&Ys[kb + u][tj * 4]);
       }
+    };
+    auto fma_group = [&](const f32x4 (*xg)[RQ], const f32x4* yg) {
+#pragma unroll
+      for (int u = 0; u < GG; ++u) {
+        const f32x2 y01 = {yg[u][0], yg[u][1]}, y23 = {yg[u][2], yg[u][3]};
+#pragma unroll
+        for (int a = 0; a < RB; ++a) {   // two pairs per instruction: v_pk_add_f32 + v_pk_fma_f32 (same roundings as the scalar sub + fma)
+          const float xs = xg[u][a >> 2][a & 3];
+          const f32x2 xa = {xs, xs};
+          const f32x2 d0 = xa - y01, d1 = xa - y23;
+          acc2[a][0] = __builtin_elementwise_fma(d0, d0, acc2[a][0]);
+          acc2[a][1] = __builtin_elementwise_fma(d1, d1, acc2[a][1]);
+        }
+      }
+    };
+    lds_group(xa_, ya_, 0);
+#pragma unroll 1
+    for (int kb = 0; kb < GKC; kb += 2 * GG) {   // a rolled loop: unrolled, the copies do not share registers (296 VGPRs with four chunks in flight)
+      lds_group(xb_, yb_, kb + GG);
+      __builtin_amdgcn_sched_barrier(0);
+      fma_group(xa_, ya_);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_group(xa_, ya_, (kb + 2 * GG) & (GKC - 1));   // the last trip re-reads group 0 (discarded) instead of branching
+      __builtin_amdgcn_sched_barrier(0);
+      fma_group(xb_, yb_);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
+   }
   }
   IL_STAMP(stamp, 1);
-  float acc[4][4];
+  float acc[RB][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) { acc[a][0] = acc2[a][0][0]; acc[a][1] = acc2[a][0][1]; acc[a][2] = acc2[a][1][0]; acc[a][3] = acc2[a][1][1]; }
+  for (int a = 0; a < RB; ++a) { acc[a][0] = acc2[a][0][0]; acc[a][1] = acc2[a][0][1]; acc[a][2] = acc2[a][1][0]; acc[a][3] = acc2[a][1][1]; }
   const float fD = (float)D;
   if (MODE == 1) {
     const int n2e = vs_self ? n1 : n2;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < RB; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const int i = it * GT + ti * 4 + a, j = jt * GT + tj * 4 + b;
+        const int i = it * GTR + ti * RB + a, j = jt * GT + tj * 4 + b;
         if (i < n1 && j < n2e) dist_out[(size_t)i * n2e + j] = acc[a][b] / fD;
       }
     return;
   }
   const f32x4 wv = *reinterpret_cast<const f32x4*>(wy + jt * GT + tj * 4);
-  float* part = ws_ + w.part + ((size_t)mat * w.njt + jt) * w.b1p + it * GT;
+  float* part = ws_ + w.part + ((size_t)mat * w.njt + jt) * w.b1p + it * GTR;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
+  for (int a = 0; a < RB; ++a) {
     float s = 0.f;
 #pragma unroll
     for (int b = 0; b < 4; ++b) { const float dd = acc[a][b] / fD; s += wv[b] * (expf(-g1 * dd) + expf(-g2 * dd)); }
     s = group16_sum(s);
-    if (tj == 0) part[ti * 4 + a] = s;
+    if (tj == 0) part[ti * RB + a] = s;
   }
   IL_STAMP(stamp, 2);
   if (!out_r) return;
-  // The row tile's reward needs the partial sums of every column tile of BOTH matrices: the workgroup that arrives last (one agent-scope acq_rel
-  // ticket per workgroup, after a barrier) adds them up in tile order - the separate, launch-bound "final" kernel this replaces cost 11 us.
+  // The row tile's reward needs the partial sums of every column tile of BOTH matrices: the workgroup that arrives last (one agent-scope release
+  // ticket per workgroup, after a barrier; only the last arriver pays for the acquire) adds them up in tile order - the separate, launch-bound
+  // "final" kernel this replaces cost 11 us.
   __shared__ unsigned last;
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned expect = (unsigned)(w.b2p / GT + w.b1p / GT);
-    last = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(ws_ + w.ctr) + it, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == expect;
+    last = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(ws_ + w.ctr) + it * GCTR, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1u == expect;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
   IL_STAMP(stamp, 3);
-  if (!last || threadIdx.x >= GT) return;
-  const int i = it * GT + threadIdx.x;
+  if (!last || threadIdx.x >= GTR) return;
+  const int i = it * GTR + threadIdx.x;
   if (i >= n1) return;
-  float s0 = 0.f, s1 = 0.f;
-  for (int q = 0; q < w.b2p / GT; ++q) s0 += ws_[w.part + (size_t)q * w.b1p + i];
-  for (int q = 0; q < w.b1p / GT; ++q) s1 += ws_[w.part + ((size_t)w.njt + q) * w.b1p + i];
+  // all partials of a matrix requested before the first add (a dependent load-add chain is one fabric round trip per column tile); added in tile order
+  auto ordered_sum = [&](const float* p, int nq) {
+    float s = 0.f;
+    for (int q0 = 0; q0 < nq; q0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = p[(size_t)min(q0 + u, nq - 1) * w.b1p];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) if (q0 + u < nq) s += v[u];
+    }
+    return s;
+  };
+  const float s0 = ordered_sum(ws_ + w.part + i, w.b2p / GT);
+  const float s1 = ordered_sum(ws_ + w.part + (size_t)w.njt * w.b1p + i, w.b1p / GT);
   const float wi = ws_[w.wn + i];
   const float sim = wi * s0, self = wi * s1;
   out_r[i] = sim - self;
@@ -178,7 +247,7 @@ extern "C" int il_gmmil_reward(const il_batch* pol, const il_batch* exp, int32_t
   if (workspace_floats < w.total) return il_set_error(IL_ERR_WORKSPACE, "il_gmmil_reward: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)w.total);
   hipStream_t st = (hipStream_t)stream_;
   { IL_TRACE("k_gmmil_pack", st); k_gmmil_pack<<<dim3(w.b1p / GT + w.b2p / GT, (D + GKC - 1) / GKC), 256, 0, st>>>(*pol, *exp, S, D, workspace); }
-  { IL_TRACE("k_gmmil_tile", st); k_gmmil_tile<0><<<dim3(w.b1p / GT, w.njt, 2), 256, 0, st>>>(pol->n, exp->n, D, g1, g2, workspace, nullptr, 0, out_rewards, out_sim, out_self); }
+  { IL_TRACE("k_gmmil_tile", st); k_gmmil_tile<0><<<dim3(w.b1p / GTR, w.njt, 2), 256, 0, st>>>(pol->n, exp->n, D, g1, g2, workspace, nullptr, 0, out_rewards, out_sim, out_self); }
   IL_CHECK_LAUNCH("il_gmmil_reward");
   return IL_OK;
 }
@@ -194,7 +263,7 @@ extern "C" int il_gmmil_sqdist(const il_batch* a, const il_batch* b, int32_t S, 
   if (workspace_floats < w.total) return il_set_error(IL_ERR_WORKSPACE, "il_gmmil_sqdist: workspace too small");
   hipStream_t st = (hipStream_t)stream_;
   { IL_TRACE("k_gmmil_pack", st); k_gmmil_pack<<<dim3(w.b1p / GT + w.b2p / GT, (D + GKC - 1) / GKC), 256, 0, st>>>(*a, *b, S, D, workspace); }
-  { IL_TRACE("k_gmmil_tile", st); k_gmmil_tile<1><<<dim3(w.b1p / GT, w.b2p / GT, 1), 256, 0, st>>>(a->n, b->n, D, 0.f, 0.f, workspace, out, 0, nullptr, nullptr, nullptr); }
+  { IL_TRACE("k_gmmil_tile", st); k_gmmil_tile<1><<<dim3(w.b1p / GTR, w.b2p / GT, 1), 256, 0, st>>>(a->n, b->n, D, 0.f, 0.f, workspace, out, 0, nullptr, nullptr, nullptr); }
   IL_CHECK_LAUNCH("il_gmmil_sqdist");
   return IL_OK;
 }
