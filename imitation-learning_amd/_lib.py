@@ -96,6 +96,7 @@ _SIGNATURES = {
     'il_last_error': (C.c_char_p, []),
     'il_abi_version': (C.c_int, []),
     'il_device_info': (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
+    'il_sync_layout': (None, [C.POINTER(C.c_int32)]),
     'il_trace_enable': (C.c_int, [C.c_int]),
     'il_trace_report': (C.c_int, [C.c_char_p, C.c_int]),
     'il_ring_row_floats': (C.c_int32, [C.c_int32, C.c_int32]),
@@ -191,6 +192,19 @@ def lib():
       fn.restype, fn.argtypes = res, args
     _lib = handle
   return _lib
+
+
+_SYNC_LAYOUT = None
+
+
+def sync_layout():
+  """(slots, timeouts index, gather-workgroups index, stride) of the il_sync counter buffer, as the loaded library lays it out (include/il_hip.h IL_SYNC_*)."""
+  global _SYNC_LAYOUT
+  if _SYNC_LAYOUT is None:
+    out = (C.c_int32 * 4)()
+    lib().il_sync_layout(out)
+    _SYNC_LAYOUT = tuple(int(v) for v in out)
+  return _SYNC_LAYOUT
 
 
 def check(rc: int):

@@ -9,6 +9,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define IL_WAVE 64
 #define IL_TILE_R 16  // batch rows per workgroup tile (= MFMA M)
+#ifndef IL_CTR_STRIDE
+#define IL_CTR_STRIDE 32  // 32-bit words between two per-tile arrival counters (one 128-byte line each: agent-scope atomics and polls on one line serialise at the memory side)
+#endif
 
 int il_set_error(int code, const char* fmt, ...);
 #define IL_CHECK_ARG(cond, ...)                         \

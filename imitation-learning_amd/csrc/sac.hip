@@ -32,7 +32,7 @@ __host__ __device__ inline SacWs sac_ws(int S, int A, int H, int B) {
   w.n_a2 = take(BA); w.n_logp2 = take(B);
   w.c_x0 = take((int64_t)B * (S + A)); w.c_h1 = take(2 * BH); w.c_h2 = take(2 * BH); w.c_q = take(2 * B); w.t_q = take(2 * B);
   w.c_dz3 = take(2 * B); w.c_dz2 = take(2 * BH); w.c_dz1 = take(2 * BH);
-  w.p_q = take(2 * B); w.p_g = take(2 * BA); w.a_dz3 = take((int64_t)B * 16); w.a_dz2 = take(BH); w.a_dz1 = take(BH); w.alpha_part = take(B / IL_TILE_R + 4); w.pair_ctr = take(B / IL_TILE_R + 4); w.chain_ctr = take(B / IL_TILE_R + 4);
+  w.p_q = take(2 * B); w.p_g = take(2 * BA); w.a_dz3 = take((int64_t)B * 16); w.a_dz2 = take(BH); w.a_dz1 = take(BH); w.alpha_part = take(B / IL_TILE_R + 4); w.pair_ctr = take((int64_t)(B / IL_TILE_R) * IL_CTR_STRIDE + 4); w.chain_ctr = take((int64_t)(B / IL_TILE_R) * IL_CTR_STRIDE + 4);
   const int64_t HH = (int64_t)H * H;
   w.pk_af = take(HH); w.pk_ab = take(HH); w.pk_cf = take(2 * HH); w.pk_cb = take(2 * HH); w.pk_tf = take(2 * HH); w.pk_tb = take(2 * HH);
   w.total = o;
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask, const i
   const SacWs ws = sac_ws(S, A, H, d.batch);
   if (blockIdx.x == 0 && blockIdx.y == 0)   // arrival counters of k_policy_critic's tile pairs and of k_sac_chain's tiles (they reset themselves; this covers a reused arena)
   {
-    for (int i = threadIdx.x; i < d.batch / IL_TILE_R; i += blockDim.x) { reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr)[i] = 0u; reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr)[i] = 0u; }
-    if (threadIdx.x == 0) reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr)[d.batch / IL_TILE_R + 1] = 0u;   // il_sac_handoff_timeouts counts from here
+    for (int i = threadIdx.x; i < d.batch / IL_TILE_R; i += blockDim.x) { reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr)[i * IL_CTR_STRIDE] = 0u; reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr)[i * IL_CTR_STRIDE] = 0u; }
+    if (threadIdx.x == 0) reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr)[(d.batch / IL_TILE_R) * IL_CTR_STRIDE + 1] = 0u;   // il_sac_handoff_timeouts counts from here
   }
   if (!((mask >> net) & 1u)) return;
   const int64_t HH = (int64_t)H * H, ns = net_stride(IN, H, 1);
@@ -195,7 +195,7 @@ __device__ __forceinline__ void tile_arrive(unsigned* ctr) {
 struct TileTimeouts { unsigned* slot; long long* sync; };
 __device__ __forceinline__ TileTimeouts tile_timeouts(const il_sac& d) {
   const SacWs ws = sac_ws(d.state_dim, d.action_dim, d.hidden, d.batch);
-  return {reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + d.batch / IL_TILE_R + 1, reinterpret_cast<long long*>(d.sync)};
+  return {reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + (d.batch / IL_TILE_R) * IL_CTR_STRIDE + 1, reinterpret_cast<long long*>(d.sync)};
 }
 __device__ __forceinline__ void tile_await(unsigned* ctr, unsigned target, const TileTimeouts& timeouts) {
   if (threadIdx.x == 0) {
@@ -480,7 +480,7 @@ __device__ __forceinline__ void sac_chain_body(il_sac& d, il_batch& b, const flo
   int role, net, tile;
   chain_decode((int)blockIdx.x, nt, role, net, tile);
   const SacWs ws = sac_ws(d.state_dim, d.action_dim, d.hidden, d.batch);
-  unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + tile;
+  unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + tile * IL_CTR_STRIDE;
   if (role == 0) { actor_fwd_tile(d, b, eps_next, eps_cur, false, tile, smem); tile_arrive(ctr); }
   else if (role == 1) {
     critic_fwd_tile(d, b, 2 + net, tile, smem, ctr);
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   if ((int)blockIdx.x >= 2 * nt) {   // helper: block order keeps it behind both critics of its tile (it only waits for lower-numbered workgroups)
     const int h = (int)blockIdx.x - 2 * nt, tile = h % nt, part = h / nt;
     const SacWs ws = sac_ws(S, A, H, B);
-    unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr) + tile;
+    unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr) + tile * IL_CTR_STRIDE;
     if (h == 0 && threadIdx.x == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }   // consumed by the next kernel
     actor_bwd_tile(d, b, tile, out_logp, out_q, smem, part, helpers, [&] {
       tile_await(ctr, 2u, tile_timeouts(d));
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   // The policy backward of this tile needs Q and dQ/da of BOTH critics, i.e. of two workgroups. Instead of a kernel boundary, the workgroup
   // that arrives second continues with it. The barrier orders every wave's stores before thread 0's agent-scope acq_rel ticket, which
   // is the only L2 write-back / invalidate of the hand-off (a __threadfence() per wave costs 16 of them per workgroup: measured -8 %).
-  unsigned* ctr = reinterpret_cast<unsigned*>(W + ws.pair_ctr) + tile;
+  unsigned* ctr = reinterpret_cast<unsigned*>(W + ws.pair_ctr) + tile * IL_CTR_STRIDE;
   if (helpers > 0) { tile_arrive(ctr); return; }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1195,7 +1195,7 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
 extern "C" int il_sac_handoff_timeouts(const il_sac* d, uint32_t* out_host) {
   IL_CHECK_ARG(d && d->workspace && out_host, "il_sac_handoff_timeouts: bad arguments");
   const SacWs ws = sac_ws(d->state_dim, d->action_dim, d->hidden, d->batch);
-  const hipError_t e = hipMemcpy(out_host, reinterpret_cast<const unsigned*>(d->workspace + ws.chain_ctr) + d->batch / IL_TILE_R + 1, sizeof(uint32_t), hipMemcpyDeviceToHost);
+  const hipError_t e = hipMemcpy(out_host, reinterpret_cast<const unsigned*>(d->workspace + ws.chain_ctr) + (d->batch / IL_TILE_R) * IL_CTR_STRIDE + 1, sizeof(uint32_t), hipMemcpyDeviceToHost);
   return e == hipSuccess ? IL_OK : il_set_error(IL_ERR_HIP, "il_sac_handoff_timeouts: %s", hipGetErrorString(e));
 }
 

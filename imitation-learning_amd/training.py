@@ -396,7 +396,8 @@ class UpdatePlan:
     self.pb = batch_desc(self.transitions)
     # Device-side hand-off between the two branches (include/il_hip.h `il_sync`): the discriminator branch and the SAC forward then share no stream
     # dependency between the gather and the critic loss. Validated by `capture()`; IL_DEVICE_SYNC=0 keeps plain stream dependencies.
-    self.sync = torch.zeros(16, dtype=torch.int64, device=dev)   # IL_SYNC_SLOTS
+    self._sync_slots, self._sync_timeouts, self._sync_gather_wgs, _ = _lib.sync_layout()
+    self.sync = torch.zeros(self._sync_slots, dtype=torch.int64, device=dev)   # IL_SYNC_SLOTS: every counter on its own 128-byte line
     self.device_sync = False
     self._chain_fits = None
     self.pre_hooks, self.post_hooks = [], []   # callables enqueuing extra work on the update's stream before / after it (captured with it), e.g. ActingWorker
@@ -428,7 +429,7 @@ class UpdatePlan:
     self.device_sync = bool(on)
     if self._two_stream:   # [IL_SYNC_GATHER_WGS]: who signals IL_SYNC_ROWS, and how many times per update
       L = _lib.lib()
-      self.sync[5] = int(L.il_sac_chain_gather_workgroups(self.B, self.memory.row, self.sac.hidden) if self.ring_mode
+      self.sync[self._sync_gather_wgs] = int(L.il_sac_chain_gather_workgroups(self.B, self.memory.row, self.sac.hidden) if self.ring_mode
                          else L.il_replay_gather_workgroups(self.B, self.memory.row, self.expert_memory.row if self.has_expert else 0))
     ptr = self.sync.data_ptr() if on else None
     self.sac.sync = ptr
@@ -473,16 +474,16 @@ class UpdatePlan:
         gs.replay()
     torch.cuda.synchronize()
     ok = self.sync_timeouts() == before
-    self.sync[4] = 0
+    self.sync[self._sync_timeouts] = 0
     return ok
 
   def sync_timeouts(self) -> int:
     """Bounded waits that gave up (device counter). Non-zero means the two branches did not run concurrently (e.g. a counter-collecting
     profiler serialises kernels): results of those updates are invalid; `capture()` checks this once and falls back to stream dependencies."""
     handoff = C.c_uint32(0)
-    if getattr(self, '_prepared', False):   # the in-launch waits of the chained kernels (counted since the first update's k_repack); with il_sync counters they are in sync[4] too
+    if getattr(self, '_prepared', False):   # the in-launch waits of the chained kernels (counted since the first update's k_repack); with il_sync counters they are in sync[IL_SYNC_TIMEOUTS] too
       _lib.check(_lib.lib().il_sac_handoff_timeouts(C.byref(self.sac), C.byref(handoff)))
-    return max(int(self.sync[4].item()), int(handoff.value))
+    return max(int(self.sync[self._sync_timeouts].item()), int(handoff.value))
 
   def prepared_flag(self) -> int:
     return _lib.IL_FLAG_SAC_PREPARED if (self._prepared and os.environ.get('IL_ALWAYS_REPACK') != '1') else 0

@@ -177,9 +177,19 @@ int il_polyak(float* target, const float* param, int64_t n, double tau, il_strea
  *                          for (main_epoch + 1) * il_gail_step_workgroups()
  * With it the two branches need no stream dependency between the gather and the critic loss (fork at the start of the update, join at
  * its end). NULL everywhere = plain stream ordering (the caller serialises or uses events). */
-/* il_sync_probe: slots 6, 7 of the same buffer; enqueue setter = 0 on the side stream first, then setter = 1 on the main stream. */
+/* il_sync_probe: [IL_SYNC_PROBE_FLAG], [IL_SYNC_PROBE_EPOCH] of the same buffer; enqueue setter = 0 on the side stream first, then setter = 1 on the main stream. */
 int il_sync_probe(int64_t* sync, int32_t setter, il_stream_t stream);
-enum { IL_SYNC_ROWS = 0, IL_SYNC_REWARDS = 1, IL_SYNC_SIDE_EPOCH = 2, IL_SYNC_MAIN_EPOCH = 3, IL_SYNC_TIMEOUTS = 4, IL_SYNC_GATHER_WGS = 5, IL_SYNC_INDICES = 8, IL_SYNC_PARAMS = 9, IL_SYNC_SLOTS = 16 };
+/* Every counter sits on its own 128-byte line (IL_SYNC_STRIDE int64 apart): agent-scope atomics and polls execute at the memory side, where accesses to one line
+ * serialise - ~150 polling workgroups on [IL_SYNC_INDICES] must not queue in front of the signals on [IL_SYNC_PARAMS]. il_sync_layout() reports the indices to a
+ * host that does not compile this header. */
+#ifndef IL_SYNC_STRIDE
+#define IL_SYNC_STRIDE 16
+#endif
+enum { IL_SYNC_ROWS = 0, IL_SYNC_REWARDS = 1 * IL_SYNC_STRIDE, IL_SYNC_SIDE_EPOCH = 2 * IL_SYNC_STRIDE, IL_SYNC_MAIN_EPOCH = 3 * IL_SYNC_STRIDE, IL_SYNC_TIMEOUTS = 4 * IL_SYNC_STRIDE,
+       IL_SYNC_GATHER_WGS = 5 * IL_SYNC_STRIDE, IL_SYNC_PROBE_FLAG = 6 * IL_SYNC_STRIDE, IL_SYNC_PROBE_EPOCH = 7 * IL_SYNC_STRIDE, IL_SYNC_INDICES = 8 * IL_SYNC_STRIDE,
+       IL_SYNC_PARAMS = 9 * IL_SYNC_STRIDE, IL_SYNC_SLOTS = 16 * IL_SYNC_STRIDE };
+/* out[0] = IL_SYNC_SLOTS (int64 elements to allocate and zero), out[1] = IL_SYNC_TIMEOUTS, out[2] = IL_SYNC_GATHER_WGS, out[3] = IL_SYNC_STRIDE */
+void il_sync_layout(int32_t* out);
 
 /* ------------------------------------------------------------------------------------------
  * SAC (reference training.py:14-54 `sac_update`; models.py:84-141 SoftActor / TwinCritic).
