@@ -148,6 +148,7 @@ struct GailSampler { uint32_t* state; const int64_t* rs_a; int32_t* idx_a; const
 __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp, il_gail_extra x, const il_disc* __restrict__ dL,
                                                    const il_batch* __restrict__ polL, const il_batch* __restrict__ expL, GailSampler sa, int pu_value_pass) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  IL_TL(0, 0);
   const int has_sampler = sa.state != nullptr;
   if (has_sampler && (int)blockIdx.x == (int)gridDim.x - 1) {
     if (blockIdx.y == 0) mt_sample_update(*reinterpret_cast<MtShared*>(smem), as_global(sa.state), sa.n, as_global(sa.rs_a), as_global(sa.idx_a), as_global(sa.rs_b), as_global(sa.idx_b),
@@ -217,8 +218,10 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     // iterations) has run or runs now; then wait for THIS update's rows (every gather workgroup has signalled) and stage them with all threads.
     if (tid < 64 && d.spectral_norm) sn_chain(L.W1s, L.W2s, L.Ms, D, H, L.u1(0), L.v1(0), L.v2(0), L.tmp, pass + 1, L.sc(0));
     long long* sy = reinterpret_cast<long long*>(d.sync);
+    IL_TL(0, 1);
     if (pol.gather && exp.gather) sync_wait(sy, IL_SYNC_INDICES, sy[IL_SYNC_SIDE_EPOCH] + 1);   // rows come straight from the rings: only the draw has to be done
     else sync_wait(sy, IL_SYNC_ROWS, (sy[IL_SYNC_SIDE_EPOCH] + 1) * sy[IL_SYNC_GATHER_WGS]);
+    IL_TL(0, 2);
     ctr = d.noise_counter ? *d.noise_counter : 0u;   // after the wait: the previous update's actor step (which bumps it) precedes this update's gather
     stage_rows(0);
   } else {
@@ -359,6 +362,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     for (int i = tid; i < D; i += blockDim.x) o[H + i] = v1[i];
     if (tid == 0) o[H + D] = u2;
   }
+  IL_TL_END(0);
 }
 
 __host__ __device__ inline int gail_calls(const il_disc& d) { return (d.loss_function == IL_LOSS_MIXUP ? 1 : 2) + (d.grad_penalty > 0.f ? 1 : 0); }
@@ -367,6 +371,7 @@ __host__ __device__ inline int gail_calls(const il_disc& d) { return (d.loss_fun
 // close_epoch (il_gail_disc_step with IL_FLAG_GAIL_CLOSE_EPOCH): no relabel kernel follows on this stream - the stepped parameters are consumed by the
 // critic-loss workgroups of k_sac_chain - so each workgroup reports [IL_SYNC_PARAMS] and the last one closes the side branch's epoch.
 __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const il_disc* __restrict__ dL, int close_epoch) {
+  IL_TL(1, 0);
   if (dL) d = dL[blockIdx.y];
   globalize(d);
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch;
@@ -416,6 +421,7 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const
       if (done % (long long)gridDim.x == 0) __hip_atomic_fetch_add(sy + IL_SYNC_SIDE_EPOCH, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  IL_TL(1, 7);
 }
 
 __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, float* __restrict__ out_r, float* __restrict__ out_logit, const float* __restrict__ logit_offset, const il_disc* __restrict__ dL,
@@ -571,3 +577,4 @@ extern "C" int il_gail_reward(const il_disc* d, const il_batch* b, float* out_re
 }
 
 IL_STAMP_READER(il_debug_stamps_gail)
+IL_TL_READER(il_debug_timeline_gail)

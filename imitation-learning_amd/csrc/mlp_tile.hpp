@@ -251,6 +251,9 @@ __device__ __forceinline__ void tile_packed(const float* As, int lda, int H, con
     epi(t * 16, acc);
   }
 }
+// (Measured and dropped in round 2: an early "touch" of a workgroup's packed panels - one dword per 128-byte line requested at the top of the kernel so that the
+// lines rewritten by the previous Adam kernel are already in this XCD's L2 when the layer starts. Same-box A/B 14.24k -> 13.39k updates/s: loads return in order,
+// so the rows and first-layer operands issued behind the cold touches wait for them; profiles/r02_update_timeline.md.)
 // Y[16 x H] = Xs[16 x H] . W^T with W given as its PF copy;  epi(c0, acc): acc[reg] = Y[row 4g+reg][col c0 + j]
 template <class Epi>
 __device__ __forceinline__ void tile_fwd_packed(const float* Xs, int ldx, int H, const float* __restrict__ PF, Epi epi) { tile_packed(Xs, ldx, H, PF, epi); }

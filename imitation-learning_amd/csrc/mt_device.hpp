@@ -108,12 +108,16 @@ __device__ __forceinline__ void mt_sample_update(MtShared& sh, uint32_t* __restr
   // resident: launched with NO dependency on the update's main stream, i.e. while the previous update is still running. The draw itself must wait until that update
   // is over (its kernels read the index arrays this one overwrites, and the ring cursor may still move): [IL_SYNC_MAIN_EPOCH] has to reach the number of draws made
   // so far (= [IL_SYNC_INDICES]).
+  IL_TL(0, 1);
   if (resident) sync_wait(sync, IL_SYNC_MAIN_EPOCH, sync[IL_SYNC_INDICES]);
+  IL_TL(0, 2);
   __syncthreads();
   mt_draw(sh, rs_a, n, idx_a);
   if (rs_b) { __syncthreads(); mt_draw(sh, rs_b, n, idx_b); }
+  IL_TL(0, 3);
   if (sync) sync_signal(sync + IL_SYNC_INDICES);   // both index arrays are in place (a consumer that gathers its own rows need not wait for k_gather2)
   __syncthreads();
   for (int i = tid; i < MT_N; i += 256) state[i] = sh.mt[i];
   if (tid == 0) state[MT_N] = (uint32_t)sh.pos;
+  IL_TL(0, 7);
 }

@@ -236,6 +236,7 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
   if (is_target && await) {
     load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, IL_TILE_R, b.gather, b.gather_capacity);   // s' columns, zero elsewhere
     tile_await(await, 1u, tile_timeouts(d));
+    IL_TL(0, 2);
     for (int i = threadIdx.x; i < IL_TILE_R * A; i += blockDim.x) { const int r = i / A, c = i - r * A; Xs[r * ldx + S + c] = W[ws.n_a2 + (size_t)(row0 + r) * A + c]; }
   } else if (is_target) load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, W + ws.n_a2, A, A, row0, IL_TILE_R, b.gather, b.gather_capacity, true);
   else load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R, b.gather, b.gather_capacity);
@@ -379,6 +380,7 @@ __device__ __forceinline__ void critic_relabel_tile(const il_sac& d, const Chain
   float* Xs = smem; float* q16 = Xs + IL_TILE_R * ldx + 2 * IL_TILE_R * ldh; float* rew16 = q16 + 2 * IL_TILE_R;
   long long* sy = reinterpret_cast<long long*>(d.sync);
   sync_wait(sy, IL_SYNC_PARAMS, (sy[IL_SYNC_MAIN_EPOCH] + 1) * (long long)rl.n_reduce);
+  IL_TL(4, 0);   // [4]: the moment the discriminator's step became visible to this critic workgroup
   const RewardLds R = reward_carve(q16 + 64, rl.dd.state_dim + rl.dd.action_dim, rl.dd.hidden);
   disc_reward_tile(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
     rew16[r] = reward;
@@ -465,7 +467,9 @@ __device__ __forceinline__ void sac_chain_body(il_sac& d, il_batch& b, const flo
   const int nt = d.batch / IL_TILE_R;
   // resident sampler (il_replay_draw_resident on the other stream): this update's indices are signalled, not stream-ordered. This launch follows the previous
   // update's last kernel in its stream, so [IL_SYNC_MAIN_EPOCH] already counts that update; the draw usually finished while this launch was being dispatched.
+  IL_TL(0, 0);
   if (rl.wait_indices) { long long* sy = reinterpret_cast<long long*>(d.sync); sync_wait(sy, IL_SYNC_INDICES, sy[IL_SYNC_MAIN_EPOCH] + 1); }
+  IL_TL(0, 1);
   if ((int)blockIdx.x >= 6 * nt) {
     const int row4 = b.ld_states / 4, lanes = d.batch * row4, G = (int)gridDim.x - 6 * nt;
     const f32x4* src = reinterpret_cast<const f32x4*>(b.states);
@@ -475,16 +479,18 @@ __device__ __forceinline__ void sac_chain_body(il_sac& d, il_batch& b, const flo
       dst[i] = src[brow(b, r) * row4 + c];
     }
     if (d.sync) sync_signal(reinterpret_cast<long long*>(d.sync) + IL_SYNC_ROWS);
+    IL_TL(0, 7);
     return;
   }
   int role, net, tile;
   chain_decode((int)blockIdx.x, nt, role, net, tile);
   const SacWs ws = sac_ws(d.state_dim, d.action_dim, d.hidden, d.batch);
   unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + tile * IL_CTR_STRIDE;
-  if (role == 0) { actor_fwd_tile(d, b, eps_next, eps_cur, false, tile, smem); tile_arrive(ctr); }
+  if (role == 0) { actor_fwd_tile(d, b, eps_next, eps_cur, false, tile, smem); IL_TL(0, 6); tile_arrive(ctr); IL_TL(0, 7); }
   else if (role == 1) {
     critic_fwd_tile(d, b, 2 + net, tile, smem, ctr);
-    if (!rl.fwd_only) tile_arrive(ctr);
+    IL_TL(0, 6);
+    if (!rl.fwd_only) { tile_arrive(ctr); IL_TL(0, 7); }
     else {   // nobody waits for the targets in this launch: the second target workgroup of the tile leaves the counter at 0 for the next one
       __syncthreads();
       if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == 2u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -492,14 +498,19 @@ __device__ __forceinline__ void sac_chain_body(il_sac& d, il_batch& b, const flo
   }
   else if (role == 2) {
     critic_fwd_tile(d, b, net, tile, smem, nullptr);
+    IL_TL(0, 2);
     if (rl.fwd_only) return;
     critic_bwd_resident_gemm(d, net, smem);
+    IL_TL(0, 3);
     if (rl.on) critic_relabel_tile(d, rl, net, tile, smem);
+    IL_TL(0, 4);
     const RowScalars rs = critic_row_scalars(b, !rl.on && !rewards && !d.sync, tile);
     tile_await(ctr, 3u, tile_timeouts(d));
+    IL_TL(0, 5);
     if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 4u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     critic_bwd_resident_scale(d, b, rewards, rl, rs, net, tile, smem);
-  } else actor_fwd_tile(d, b, eps_next, eps_cur, true, tile, smem);
+    IL_TL(0, 7);
+  } else { actor_fwd_tile(d, b, eps_next, eps_cur, true, tile, smem); IL_TL(0, 7); }
 }
 
 __global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, const float* __restrict__ rewards,
@@ -635,11 +646,15 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
     const SacWs ws = sac_ws(S, A, H, B);
     unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr) + tile * IL_CTR_STRIDE;
     if (h == 0 && threadIdx.x == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }   // consumed by the next kernel
+    IL_TL(3, 0);
     actor_bwd_tile(d, b, tile, out_logp, out_q, smem, part, helpers, [&] {
+      IL_TL(3, 1);
       tile_await(ctr, 2u, tile_timeouts(d));
+      IL_TL(3, 2);
       if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u + (unsigned)helpers)
         __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // last helper through: ready for the next launch
     });
+    IL_TL_END(3);
     return;
   }
   int k, tile;
@@ -652,6 +667,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   const MlpView p = mlp_view(d.critic + k * net_stride(IN, H, 1), IN, H, 1);
   const bool stamp = blockIdx.x == 0;
   IL_STAMP(stamp, 16);
+  IL_TL(3, 0);
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   // biases of this wave's 16 columns and this lane's slice of w3: requested before the first barrier, used after the MFMA loops
   const int pc = min(wave * 16 + j, H - 1);
@@ -710,7 +726,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   // that arrives second continues with it. The barrier orders every wave's stores before thread 0's agent-scope acq_rel ticket, which
   // is the only L2 write-back / invalidate of the hand-off (a __threadfence() per wave costs 16 of them per workgroup: measured -8 %).
   unsigned* ctr = reinterpret_cast<unsigned*>(W + ws.pair_ctr) + tile * IL_CTR_STRIDE;
-  if (helpers > 0) { tile_arrive(ctr); return; }
+  if (helpers > 0) { IL_TL(3, 6); tile_arrive(ctr); IL_TL(3, 7); return; }
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -1032,7 +1048,11 @@ __device__ __forceinline__ void dw_block64(const DwArgs& a, const adam_consts& a
 }
 static inline int dw_block64_count(int H, int nets) { return (H / DWB) * (H / DWB) * nets; }
 
-__global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) { dw_adam_body<8>(a, (int)blockIdx.x, (int)gridDim.x); }
+__global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
+  IL_TL(a.log_alpha ? 2 : 1, 0);   // [1] critic launch, [2] actor launch (the one with the alpha / polyak tail)
+  dw_adam_body<8>(a, (int)blockIdx.x, (int)gridDim.x);
+  IL_TL_END(a.log_alpha ? 2 : 1);
+}
 
 static int repack_blocks(int H) { return ceil_div(H * H / 16, 256); }
 __host__ __device__ static inline int dw_blocks(int IN, int H, int OUT, int nets, int skip_big = 0) {
@@ -1782,3 +1802,4 @@ extern "C" int il_act_step(const float* actor, int32_t S, int32_t A, int32_t H, 
 }
 
 IL_STAMP_READER(il_debug_stamps_sac)
+IL_TL_READER(il_debug_timeline_sac)
