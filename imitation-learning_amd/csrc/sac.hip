@@ -125,8 +125,10 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
   }
   const float* src = is_cur ? b.states : b.next_states;
   const int ld = is_cur ? b.ld_states : b.ld_next_states;
+  IL_TL(is_cur ? 6 : 5, 0);
   load_rows_cat(Xs, ldx, Sp, src, ld, S, nullptr, 0, 0, row0, IL_TILE_R, b.gather, b.gather_capacity);
   __syncthreads();
+  IL_TL(is_cur ? 6 : 5, 1);
   tile_fwd(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1 : net.b1[col];
     f32x4 hv;
@@ -135,6 +137,7 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
     if (is_cur) *reinterpret_cast<f32x4*>(W + ws.a_h1 + (size_t)col * B + row0 + 4 * g) = hv;
   });
   __syncthreads();
+  IL_TL(is_cur ? 6 : 5, 2);
   tile_fwd_packed(H1s, ldh, H, W + ws.pk_af, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb2 : net.b2[col];
     f32x4 hv;
@@ -143,7 +146,9 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
     if (is_cur) *reinterpret_cast<f32x4*>(W + ws.a_h2 + (size_t)col * B + row0 + 4 * g) = hv;
   });
   __syncthreads();
+  IL_TL(is_cur ? 6 : 5, 3);
   tile_fwd_small(H2s, ldh, H, net.W3, H, 2 * A, net.b3, Os, part);
+  IL_TL(is_cur ? 6 : 5, 4);
   // head: one thread per (row, action component); per-row sums through LDS (sequential over A like torch's sum(-1))
   float* nl = part; float* la = part + 256;
   if (tid < IL_TILE_R * A) {
@@ -167,6 +172,7 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
     const float logp = (0.f - sl) + sn;
     W[(is_cur ? ws.a_logp : ws.n_logp2) + row0 + tid] = logp;
   }
+  IL_TL(is_cur ? 6 : 5, 5);
   (void)red;
 }
 
@@ -440,6 +446,10 @@ __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const
   }
 }
 
+// Measured in round 2 and NOT kept (profiles/r02_update_timeline.md): a hidden layer of a tile takes 5.2 us against 3.4 us of MFMA issue at the nominal clock, and that gap is
+// not a cold first touch of the weights the previous Adam kernel rewrote: (a) warmer workgroups on idle CUs that pull every panel of an XCD's roles into its L2 at launch
+// (2 - 4 per XCD): layer times and updates/s unchanged; (b) the same lines requested early by the role workgroups themselves: slower (their first loads queue behind them);
+// (c) the panel (or half of it) in registers across the first layer: over the 128-VGPR budget of a 16-wave workgroup, spills.
 // k_sac_chain: both actor forwards, the four critic / target forwards and the critic-loss backward of ONE learner in one launch of 6 * nt
 // workgroups, chained per 16-row TILE instead of per kernel:   actor(s') [tile] -> target_1,2(s', a') [tile] -> critic_1,2 backward [tile],
 // while actor(s) and the critic forwards, which depend on nothing, run beside them. Versus the three launches (k_actor_fwd, k_critic_fwd,
@@ -668,6 +678,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   const bool stamp = blockIdx.x == 0;
   IL_STAMP(stamp, 16);
   IL_TL(3, 0);
+  IL_TL(7, 0);
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   // biases of this wave's 16 columns and this lane's slice of w3: requested before the first barrier, used after the MFMA loops
   const int pc = min(wave * 16 + j, H - 1);
@@ -678,6 +689,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, IL_TILE_R);
   __syncthreads();
   IL_STAMP(stamp, 17);
+  IL_TL(7, 1);
   tile_fwd(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1 : p.b1[col];
 #pragma unroll
@@ -685,6 +697,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   });
   __syncthreads();
   IL_STAMP(stamp, 18);
+  IL_TL(7, 2);
   tile_fwd_packed(H1s, ldh, H, W + ws.pk_cf + (size_t)k * H * H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb2 : p.b2[col];
 #pragma unroll
@@ -692,6 +705,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   });
   __syncthreads();
   IL_STAMP(stamp, 19);
+  IL_TL(7, 3);
   // Q = h2 . w3 + b3 and, in the same pass, dQ/dh2 with upstream 1 (scaling and min-selection happen in the tail): dz2 = w3 [h2 > 0], in place.
   // One wave per row; w3 comes from the registers loaded at the top.
   for (int r = wave; r < IL_TILE_R; r += nw) {
@@ -706,6 +720,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   }
   __syncthreads();
   IL_STAMP(stamp, 21);
+  IL_TL(7, 5);
   tile_bwd_packed(H2s, ldh, H, W + ws.pk_cb + (size_t)k * H * H, [&](int kb, f32x4 acc) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -715,6 +730,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   });
   __syncthreads();
   IL_STAMP(stamp, 22);
+  IL_TL(7, 6);
   // dQ/da = the action columns of dz1 . W1 on MFMA, the H-reduction split over the 16 waves (tile_bwd_dx_cols)
   float* gout = W + ws.p_g + ((size_t)k * B + row0) * A;
   tile_bwd_dx_cols(H1s, ldh, H, p.W1, IN, IN, S, S + A, q16 + 64, [&](int col, int row, float v) {
@@ -722,6 +738,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
     if (c >= 0 && c < A) gout[(size_t)row * A + c] = v;
   });
   IL_STAMP(stamp, 23);
+  IL_TL(7, 7);
   // The policy backward of this tile needs Q and dQ/da of BOTH critics, i.e. of two workgroups. Instead of a kernel boundary, the workgroup
   // that arrives second continues with it. The barrier orders every wave's stores before thread 0's agent-scope acq_rel ticket, which
   // is the only L2 write-back / invalidate of the hand-off (a __threadfence() per wave costs 16 of them per workgroup: measured -8 %).

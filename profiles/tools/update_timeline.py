@@ -101,3 +101,11 @@ row('  helpers: done', us(h[:, 7]))
 m = sac[2, :, 7] >= t0
 row('k_dw_adam (actor) + tail: launched', us(sac[2, m, 0]))
 row('k_dw_adam (actor) + tail: done', us(sac[2, m, 7]))
+print('phases inside the forward tiles of k_sac_chain and the critic workgroups of k_policy_critic (us since the workgroup entered the phase list; median over workgroups)')
+for kid, name, idx in ((5, "actor(s') tile", np.where(role == 0)[0]), (6, 'actor(s) tile', np.where(role == 3)[0])):
+  a = sac[kid][idx]
+  d = (a[:, 1:6] - a[:, 0:5]) / 100.0
+  print(f'  {name:16s} rows gathered {np.median(d[:, 0]):.2f} | layer 1 {np.median(d[:, 1]):.2f} | layer 2 {np.median(d[:, 2]):.2f} | head GEMM {np.median(d[:, 3]):.2f} | sample, log-prob, stores {np.median(d[:, 4]):.2f}')
+a = sac[7][:2 * nt]
+d = (a[:, [1, 2, 3, 5, 6, 7]] - a[:, [0, 1, 2, 3, 5, 6]]) / 100.0
+print(f'  policy critic    rows {np.median(d[:, 0]):.2f} | layer 1 {np.median(d[:, 1]):.2f} | layer 2 {np.median(d[:, 2]):.2f} | Q + mask {np.median(d[:, 3]):.2f} | layer 2 backward {np.median(d[:, 4]):.2f} | dQ/da columns {np.median(d[:, 5]):.2f}')
