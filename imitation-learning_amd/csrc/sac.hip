@@ -450,6 +450,9 @@ __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const
 // not a cold first touch of the weights the previous Adam kernel rewrote: (a) warmer workgroups on idle CUs that pull every panel of an XCD's roles into its L2 at launch
 // (2 - 4 per XCD): layer times and updates/s unchanged; (b) the same lines requested early by the role workgroups themselves: slower (their first loads queue behind them);
 // (c) the panel (or half of it) in registers across the first layer: over the 128-VGPR budget of a 16-wave workgroup, spills.
+// Also measured and not kept: consecutive updates on two ALTERNATING main streams, the first kernel of update n waiting on the device for every workgroup of update n-1's
+// last kernel (a counter) instead of following it in stream order, to take the ~5 us hipGraph boundary between two launches on one stream off the critical path:
+// 12.9-13.0k against 14.03k updates/s on the same box (the resident, spinning launch of the next update costs the running one more than the boundary it hides).
 // k_sac_chain: both actor forwards, the four critic / target forwards and the critic-loss backward of ONE learner in one launch of 6 * nt
 // workgroups, chained per 16-row TILE instead of per kernel:   actor(s') [tile] -> target_1,2(s', a') [tile] -> critic_1,2 backward [tile],
 // while actor(s) and the critic forwards, which depend on nothing, run beside them. Versus the three launches (k_actor_fwd, k_critic_fwd,
