@@ -248,7 +248,7 @@ static __device__ unsigned long long il_phase_stamps[64];  // one copy per trans
 // Developer-only workgroup timeline (build with -DIL_TIMELINE, profiles/tools/update_timeline.py): thread 0 of every workgroup of the instrumented kernels stores
 // s_memrealtime (the 100 MHz device-wide counter: comparable across XCDs, unlike s_memtime) at its phase boundaries. [kernel][workgroup][slot], one copy per translation unit.
 #ifdef IL_TIMELINE
-#define IL_TL_K 8
+#define IL_TL_K 12
 #define IL_TL_WGS 512
 #define IL_TL_SLOTS 8
 static __device__ unsigned long long il_tl[IL_TL_K][IL_TL_WGS][IL_TL_SLOTS];

@@ -184,6 +184,7 @@ __global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const 
   const int nt = d.batch / IL_TILE_R;
   const bool is_cur = (mode == 2) || (mode == 0 && (int)blockIdx.x >= nt);
   actor_fwd_tile(d, b, eps_next, eps_cur, is_cur, (int)blockIdx.x % nt, smem);
+  IL_TL_END(is_cur ? 6 : 5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -239,6 +240,7 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
   float w3v[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
+  IL_TL(8, 0);
   if (is_target && await) {
     load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, IL_TILE_R, b.gather, b.gather_capacity);   // s' columns, zero elsewhere
     tile_await(await, 1u, tile_timeouts(d));
@@ -247,6 +249,7 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
   } else if (is_target) load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, W + ws.n_a2, A, A, row0, IL_TILE_R, b.gather, b.gather_capacity, true);
   else load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R, b.gather, b.gather_capacity);
   __syncthreads();
+  IL_TL(8, 1);
   if (net == 0)
     for (int i = threadIdx.x; i < IL_TILE_R * IN; i += blockDim.x) { const int c = i >> 4, r = i & 15; W[ws.c_x0 + (size_t)c * B + row0 + r] = Xs[r * ldx + c]; }  // x0^T [IN][B]
   float* sh1 = W + ws.c_h1 + (size_t)k * B * H; float* sh2 = W + ws.c_h2 + (size_t)k * B * H;
@@ -258,6 +261,7 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
     if (!is_target) *reinterpret_cast<f32x4*>(sh1 + (size_t)col * B + row0 + 4 * g) = hv;
   });
   __syncthreads();
+  IL_TL(8, 2);
   tile_fwd_packed(H1s, ldh, H, W + (is_target ? ws.pk_tf : ws.pk_cf) + (size_t)k * H * H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb2 : p.b2[col];
     f32x4 hv;
@@ -266,6 +270,7 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
     if (!is_target) *reinterpret_cast<f32x4*>(sh2 + (size_t)col * B + row0 + 4 * g) = hv;
   });
   __syncthreads();
+  IL_TL(8, 3);
   for (int r = wave; r < IL_TILE_R; r += nw) {   // Q = h2 . w3 + b3: one wave per row, w3 from the registers loaded at the top
     float sq = 0.f;
 #pragma unroll
@@ -273,6 +278,7 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
     sq = wave_sum(sq);
     if (lane == 0) { W[(is_target ? ws.t_q : ws.c_q) + (size_t)k * B + row0 + r] = sq + pb3; q16[r] = sq + pb3; }
   }
+  IL_TL_END(8);
 }
 
 __global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
@@ -295,6 +301,7 @@ __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b, const
   const int nt = B / IL_TILE_R;
   int k, tile;
   xcd_tile_net((int)blockIdx.x, nt, 2, tile, k);
+  IL_TL(9, 0);
   const int row0 = tile * IL_TILE_R;
   const int ldh = H + 4;
   float* DZ2s = smem; float* dz3s = DZ2s + IL_TILE_R * ldh;
@@ -348,6 +355,7 @@ __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b, const
     for (int r = 0; r < 4; ++r) o[r] = dz3s[4 * g + r] * (hv[r] > 0.f ? acc[r] : 0.f);
     *reinterpret_cast<f32x4*>(gdz1 + off) = o;
   });
+  IL_TL_END(9);
 }
 
 // Critic-loss backward of (critic k, tile) continuing from critic_fwd_tile in the SAME workgroup: h1, h2 and Q are still in LDS, so nothing is
@@ -1028,6 +1036,7 @@ __device__ __forceinline__ void dw_block64(const DwArgs& a, const adam_consts& a
   // 24 B per parameter). The updated parameters go back to LDS once more for the column-wise lane order of the PB copy.
   float* Gs = Zs;   // [64][DWB_LD] gradient block, then the updated parameters
   __syncthreads();
+  IL_TL(a.log_alpha ? 11 : 10, 1);   // products done
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1298,6 +1307,7 @@ __global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ 
   il_sac d = dL[blockIdx.y]; il_batch b = bL[blockIdx.y];
   globalize(d); globalize(b);
   DwArgs a = kind ? actor_dw_args(&d, &b, flags) : critic_dw_args(&d, flags);
+  IL_TL(kind ? 11 : 10, 0);
   // Measured at 32 learners (round 2, one box; critic launch with dw_tile for every layer: 103 us = 23 TFLOP/s, MfmaUtil 12.7 %, 1.8 waves per SIMD resident on average):
   // the products alone took 79 us, the Adam epilogue alone 46 us. What did NOT move it: 32 x 32 blocks of dW per wave straight from global memory (half the operand
   // bytes per MFMA): 100 us; every learner confined to XCD l % 8 (`s_getreg XCC_ID` confirms workgroup g runs on XCD g % 8): 103 us; 16 instead of 8 operand loads in
@@ -1311,10 +1321,12 @@ __global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ 
       const int64_t oW2 = (int64_t)net * a.net_stride + (int64_t)H * a.in_dim + H;
       dw_block64(a, ac, a.dz2 + net * a.h_net_stride, a.h1 + net * a.h_net_stride, H, (blk / nbh) * DWB, (blk % nbh) * DWB, oW2,
                  a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem);
+      IL_TL_END(kind ? 11 : 10);
       return;
     }
     a.n_dw_blocks = dw_blocks(a.in_dim, a.hidden, a.out_dim, a.n_nets, 1);
     dw_adam_body<4, true>(a, (int)blockIdx.x - nb64, (int)gridDim.x - nb64);
+    IL_TL_END(kind ? 11 : 10);
     return;
   }
   dw_adam_body<4>(a, (int)blockIdx.x, (int)gridDim.x);

@@ -13,7 +13,7 @@ sys.path.insert(0, '.')
 import numpy as np, torch, bench
 from imitation_learning_amd import _lib
 
-K, W, S = 8, 512, 8
+K, W, S = 12, 512, 8   # IL_TL_K, IL_TL_WGS, IL_TL_SLOTS (csrc/il_common.hpp)
 dev = torch.device('cuda', 0)
 plan, nets, _ = bench.build(dev, 0)
 plan.capture(warmup=3)
