@@ -397,6 +397,8 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
   elapsed = float(t.item())
   finite = all(bool(torch.isfinite(n.flat if hasattr(n, 'flat') else n).all()) for n in nets)
+  if getattr(runner, 'exchange_timeouts', None) is not None and runner.exchange_timeouts():
+    raise RuntimeError(f'{runner.exchange_timeouts()} device-side waits of the peer-window gradient exchange expired (set IL_PEER_EXCHANGE=0 for RCCL all-reduces)')
   if getattr(plan, 'device_sync', False) and plan.sync_timeouts():
     raise RuntimeError(f'{plan.sync_timeouts()} device-side waits timed out: the two branches of the update did not run concurrently (set IL_DEVICE_SYNC=0)')
 
@@ -416,6 +418,8 @@ def main():
                config=dict(workload='algorithm=GAIL env=halfcheetah: 2 replay samples + discriminator step (BCE+GP+SN) + AIRL relabel + sac_update per step',
                            batch_per_gpu=B, global_batch=B * world, state_dim=S, action_dim=A, hidden=H, replay_capacity=1_000_000, replay_fill=100_000, expert_rows=25_000,
                            learners_per_gpu=args.learners, parallelism=f'dp{world}' + ('(split path' + (', device hand-off between the discriminator and SAC branches, own communicator per branch)' if getattr(runner, 'handoff', False) else ', stream dependencies)') if runner is not plan else ''), launch=launch, noise='on-chip Philox4x32-10', finite=finite,
+                           gradient_exchange=(None if runner is plan else ('one kernel per sync point over peer-mapped windows (il_peer_allreduce_mean: push to every rank, rank-ordered sum)'
+                                                                             if getattr(runner, 'peer', None) is not None else 'RCCL all-reduce (AVG) per sync point')),
                            branch_sync=('device counters (two graphs, no cross-stream edge)' if getattr(plan, 'device_sync', False) and runner is plan else 'stream dependencies'),
                            rows=('read from the rings through the drawn indices (il_batch.gather), relabel inline in k_sac_chain' if getattr(plan, 'inline_relabel', False) and runner is plan
                                  else ('read from the rings through the drawn indices (il_batch.gather)' if getattr(plan, 'ring_mode', False) and runner is plan else 'gathered by k_gather2'))),

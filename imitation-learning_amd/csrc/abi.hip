@@ -110,11 +110,11 @@ extern "C" int il_noise_fill(uint64_t noise_seed, uint32_t ctr, uint32_t stream_
 }
 
 // sizeof() of the descriptor structs as this library was compiled: a binding checks its own struct definitions against these
-// (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red, 7 il_dril, 8 il_disc_shaped, 9 il_disc_deep).
+// (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red, 7 il_dril, 8 il_disc_shaped, 9 il_disc_deep, 10 il_peer_bucket).
 extern "C" int32_t il_struct_size(int32_t which) {
   switch (which) {
     case 0: return (int32_t)sizeof(il_batch); case 1: return (int32_t)sizeof(il_adam); case 2: return (int32_t)sizeof(il_sac); case 3: return (int32_t)sizeof(il_disc);
-    case 4: return (int32_t)sizeof(il_pwil); case 5: return (int32_t)sizeof(il_sample_args); case 6: return (int32_t)sizeof(il_red); case 7: return (int32_t)sizeof(il_dril); case 8: return (int32_t)sizeof(il_disc_shaped); case 9: return (int32_t)sizeof(il_disc_deep);
+    case 4: return (int32_t)sizeof(il_pwil); case 5: return (int32_t)sizeof(il_sample_args); case 6: return (int32_t)sizeof(il_red); case 7: return (int32_t)sizeof(il_dril); case 8: return (int32_t)sizeof(il_disc_shaped); case 9: return (int32_t)sizeof(il_disc_deep); case 10: return (int32_t)sizeof(il_peer_bucket);
     default: return -1;
   }
 }

@@ -100,6 +100,117 @@ def init_from_env(world_size: int, backend: str = 'nccl'):
   return rank, local, device
 
 
+def _agree(ok: bool, group=None) -> bool:
+  """Collective AND of a per-rank flag (every rank must take the same branch afterwards)."""
+  if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    return bool(ok)
+  t = torch.tensor([1.0 if ok else 0.0], device='cuda' if dist.get_backend(group) == 'nccl' else 'cpu')
+  dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+  return bool(t.item() > 0.5)
+
+
+class PeerExchange:
+  """The three gradient exchanges as ONE kernel each over peer-mapped windows (include/il_hip.h il_peer_*, csrc/peer.hip) instead of RCCL all-reduces.
+
+  xGMI is a point-to-point mesh and the messages are 6.7 / 580 / 295 KB, i.e. latency-bound: every rank stores its bucket straight into slot [rank] of every rank's
+  receive window (one fabric crossing, each peer over its own link), waits on the device for the others' arrival words and sums the slabs in rank order - the result is
+  the same bits on every rank, so replicas stay identical exactly as with an all-reduce. Set-up is collective: one uncached / fine-grained window per rank holding a region
+  per bucket, hipIpc handles all-gathered through the host-side process group, every rank maps the others' windows. `create()` returns None - on EVERY rank - when any rank
+  cannot set it up or the self-test (known patterns through the real kernel, several epochs) fails anywhere; the caller then keeps the collectives."""
+
+  def __init__(self, sizes: dict, device, group=None, spin_limit: int = 0):
+    L = _lib.lib()
+    self.group, self.device = group, device
+    self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+    self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if self.world > _lib.IL_PEER_MAX_RANKS:
+      raise RuntimeError(f'PeerExchange: {self.world} ranks > IL_PEER_MAX_RANKS = {_lib.IL_PEER_MAX_RANKS}')
+    self.sizes = {k: int(n) for k, n in sizes.items() if n}
+    self.window, self.opened, self.desc, self._keep = None, [], {}, []
+    offsets, total = {}, 0
+    for k, n in self.sizes.items():
+      offsets[k] = total
+      total += int(L.il_peer_region_bytes(self.world, n))
+    w, handle = C.c_void_p(), C.create_string_buffer(_lib.IL_PEER_HANDLE_BYTES)
+    with torch.cuda.device(device):
+      _lib.check(L.il_peer_window_alloc(total, C.byref(w), handle))
+      self.window = w.value
+      handles = [handle.raw]
+      if self.world > 1:
+        handles = [None] * self.world
+        dist.all_gather_object(handles, handle.raw, group=group)
+      windows = []
+      for r, h in enumerate(handles):
+        if r == self.rank:
+          windows.append(self.window)
+          continue
+        o = C.c_void_p()
+        _lib.check(L.il_peer_window_open(h, C.byref(o)))
+        self.opened.append(o.value)
+        windows.append(o.value)
+    self.status = torch.zeros(2, dtype=torch.int64, device=device)
+    for k, n in self.sizes.items():
+      epoch = torch.zeros((n + _lib.IL_PEER_CHUNK_FLOATS - 1) // _lib.IL_PEER_CHUNK_FLOATS, dtype=torch.int32, device=device)
+      d = _lib.PeerBucket(rank=self.rank, world=self.world, n=n, window_offset=offsets[k], epoch=epoch.data_ptr(), status=self.status.data_ptr(), spin_limit=int(spin_limit))
+      for r, wp in enumerate(windows): d.windows[r] = wp
+      self.desc[k] = d
+      self._keep.append(epoch)
+    torch.cuda.synchronize(device)
+
+  @classmethod
+  def create(cls, sizes: dict, device, group=None, verify_rounds: int = 3):
+    """Collective. A PeerExchange that passed its self-test on every rank, or None on every rank."""
+    x, err = None, None
+    try:
+      x = cls(sizes, device, group)
+    except Exception as e:   # no IPC between these processes, no fine-grained memory, ...: fall back together
+      err = e
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+      dist.barrier(group)   # every window is mapped everywhere before the first store into a peer
+    ok = _agree(x is not None, group)
+    if ok:
+      ok = _agree(x.verify(verify_rounds), group)
+    if not ok:
+      if x is not None: x.close()
+      if err is not None and os.environ.get('IL_PEER_EXCHANGE') == 'require': raise err
+      return None
+    return x
+
+  def allreduce_mean(self, name: str, bucket: torch.Tensor):
+    """bucket <- mean over ranks, in place, enqueued on the current stream (capturable). Every rank issues the same sequence of calls per name."""
+    d = self.desc[name]
+    assert bucket.numel() == d.n and bucket.dtype == torch.float32 and bucket.is_contiguous()
+    _lib.check(_lib.lib().il_peer_allreduce_mean(C.byref(d), _lib.ptr(bucket), _lib.stream_ptr()))
+    return bucket
+
+  def timeouts(self) -> int:
+    """Device-side waits for a peer that gave up (must stay 0; the affected update averaged stale slabs)."""
+    return int(self.status[0].item())
+
+  def verify(self, rounds: int = 3) -> bool:
+    """Known rank- and round-dependent patterns through the real kernel; the mean is exact in fp32, so the comparison is bitwise. A stale line, a lost store or a
+    window mapped to the wrong rank shows up as a mismatch; several rounds exercise both slot parities and the epoch logic."""
+    ok = True
+    for k, n in self.sizes.items():
+      i = torch.arange(n, device=self.device, dtype=torch.float32)
+      for r in range(rounds):
+        scratch = (i % 97) * 0.25 + float((self.rank + 1) * (r + 1))
+        self.allreduce_mean(k, scratch)
+        expect = (i % 97) * 0.25 + float((self.world + 1) * (r + 1)) / 2.0
+        ok = ok and bool(torch.equal(scratch, expect))
+    torch.cuda.synchronize(self.device)
+    return ok and self.timeouts() == 0
+
+  def close(self):
+    L = _lib.lib()
+    torch.cuda.synchronize(self.device)
+    if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+      dist.barrier(self.group)   # nobody unmaps a window a peer's kernel may still store into
+    for o in self.opened: L.il_peer_window_close(C.c_void_p(o))
+    if self.window: L.il_peer_window_free(C.c_void_p(self.window))
+    self.opened, self.window, self.desc = [], None, {}
+
+
 class DataParallelUpdate:
   """`UpdatePlan` with the three gradient all-reduces between backward and optimiser (IL_FLAG_GRADS_ONLY entry points)."""
 
@@ -118,6 +229,7 @@ class DataParallelUpdate:
       self.side_group = dist.new_group(ranks=None if group is None else dist.get_process_group_ranks(group), backend=dist.get_backend(group))
     self.graph = self.graph_side = None
     self._warm_collectives_pending = True
+    self.peer = None   # PeerExchange once the first run() has set it up (collective); None = torch.distributed all-reduces
     ao, to = plan._keep[4], plan._keep[6]
     # actor grad and alpha grad travel in one bucket: the optimisers' gradient arenas become views into it
     self.buckets = GradBuckets(ao.grad.numel(), plan._keep[5].grad, plan._keep[8].grad if plan.algorithm == 'GAIL' else None)
@@ -131,6 +243,7 @@ class DataParallelUpdate:
     update of the hand-off schedule, whose device-side waits are bounded. One all-reduce per (bucket, communicator) - the gradient arenas still hold zeros - then a
     barrier: afterwards the ranks are aligned and every later collective is a steady-state one."""
     self._warm_collectives_pending = False
+    self._setup_peer_exchange()
     if not dist.is_initialized():
       return
     for bucket, group in ((self.disc_bucket, self.side_group), (self.critic_bucket, self.group), (self.actor_bucket, self.group)):
@@ -139,6 +252,30 @@ class DataParallelUpdate:
     torch.cuda.synchronize()
     if dist.get_world_size(self.group) > 1:
       dist.barrier(self.group)
+
+  def _setup_peer_exchange(self):
+    """IL_PEER_EXCHANGE: unset / '1' = the one-kernel exchange over peer-mapped windows whenever more than one rank takes part (falls back, on every rank, if set-up or
+    the self-test fails anywhere); '0' = torch.distributed all-reduces; 'force' = also with a single rank (exercises the kernel on a 1-GPU box); 'require' = raise instead
+    of falling back."""
+    mode = os.environ.get('IL_PEER_EXCHANGE', '1')
+    world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+    if mode == '0' or (world == 1 and mode not in ('force', 'require')):
+      return
+    sizes = dict(disc=self.disc_bucket.numel() if self.disc_bucket is not None else 0, critic=self.critic_bucket.numel(), actor=self.actor_bucket.numel())
+    self.peer = PeerExchange.create(sizes, self.plan.rows.device, self.group)
+    if self.peer is None and mode == 'require':
+      raise RuntimeError('IL_PEER_EXCHANGE=require: the peer-window exchange could not be set up or failed its self-test on some rank')
+
+  def _exchange(self, name: str, group=None):
+    """One sync point: mean over ranks of bucket `name`, in place, on the current stream."""
+    bucket = getattr(self, name + '_bucket')
+    if self.peer is not None:
+      return self.peer.allreduce_mean(name, bucket)
+    return all_reduce_mean_(bucket, group)
+
+  def exchange_timeouts(self) -> int:
+    """Peer-window waits that gave up since set-up (0 with the collectives); a non-zero count means some update averaged stale gradients."""
+    return self.peer.timeouts() if self.peer is not None else 0
 
   def agree_on_handoff(self) -> bool:
     """Call after a few eager updates: if ANY rank saw a bounded device-side wait expire (its two streams did not run concurrently, or a peer stalled for longer than the
@@ -176,7 +313,7 @@ class DataParallelUpdate:
       rp, re_ = p._ring_batches()
       with torch.cuda.stream(self.side):
         _lib.check(L.il_gail_disc_step(C.byref(p.disc), C.byref(rp), C.byref(re_), None, None, G, _lib.stream_ptr()))
-        all_reduce_mean_(self.disc_bucket, self.group)
+        self._exchange('disc', self.group)
         _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
         _lib.check(L.il_gail_reward(C.byref(p.disc), C.byref(rp), _lib.ptr(p.rewards), None, None, _lib.stream_ptr()))
       p.gather_all(expert=False)   # the SAC kernels read the packed agent rows; the expert rows were only needed by the discriminator step
@@ -188,16 +325,16 @@ class DataParallelUpdate:
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
           _lib.check(L.il_gail_disc_step(C.byref(p.disc), C.byref(p.pb), C.byref(p.eb), None, None, G, _lib.stream_ptr()))
-          all_reduce_mean_(self.disc_bucket, self.group)
+          self._exchange('disc', self.group)
           _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
           _lib.check(L.il_gail_reward(C.byref(p.disc), C.byref(p.pb), _lib.ptr(p.rewards), None, None, _lib.stream_ptr()))
     _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 0, None, None, p.prepared_flag(), _lib.stream_ptr()))
     if p.algorithm == 'GAIL':
       main.wait_stream(self.side)
     _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 1, None, None, 0, _lib.stream_ptr()))
-    all_reduce_mean_(self.critic_bucket, self.group)
+    self._exchange('critic', self.group)
     _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 2, _lib.ptr(p.logp), _lib.ptr(p.q), 0, _lib.stream_ptr()))
-    all_reduce_mean_(self.actor_bucket, self.group)
+    self._exchange('actor', self.group)
     _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 3, None, None, 0, _lib.stream_ptr()))
     p._prepared = True
 
@@ -205,7 +342,7 @@ class DataParallelUpdate:
     """Discriminator branch: [resident index draw] -> gradients from the rings through the indices -> all-reduce (own communicator) -> AdamW, which signals [IL_SYNC_PARAMS]."""
     p, L = self.plan, _lib.lib()
     p._disc_step(_lib.IL_FLAG_GRADS_ONLY)   # the index draw rides in this launch when the sampler is resident
-    all_reduce_mean_(self.disc_bucket, self.side_group)
+    self._exchange('disc', self.side_group)
     _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
 
   def _enqueue_main(self):
@@ -218,9 +355,9 @@ class DataParallelUpdate:
     flags = p.prepared_flag() | _lib.IL_FLAG_GRADS_ONLY | (_lib.IL_FLAG_SAC_WAIT_INDICES if resident else 0)
     _lib.check(L.il_sac_update_gather(C.byref(p.sac), C.byref(p.pb), C.byref(p._ring_batches()[0]), None, C.byref(p.disc), _lib.ptr(p.rewards), None, None, _lib.ptr(p.logp), _lib.ptr(p.q),
                                       flags, _lib.stream_ptr()))
-    all_reduce_mean_(self.critic_bucket, self.group)
+    self._exchange('critic', self.group)
     _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 2, _lib.ptr(p.logp), _lib.ptr(p.q), 0, _lib.stream_ptr()))
-    all_reduce_mean_(self.actor_bucket, self.group)
+    self._exchange('actor', self.group)
     _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 3, None, None, 0, _lib.stream_ptr()))
     p._prepared = True
 

@@ -512,8 +512,44 @@ int il_dril_bc_step(const il_dril* d, const il_batch* expert, const float* mask_
 int il_dril_uncertainty(const il_dril* d, const il_batch* batch, const float* mask_in, const float* mask_hidden, const float* mask_hidden2, uint32_t noise_offset,
                         float* out_uncertainty, float* out_reward, il_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange as ONE kernel per sync point over peer-mapped windows (the reference has no multi-GPU path: this is the
+ * exchange step BASELINE.json's north_star adds between training.py:31 / :50 `backward()` and `optimiser.step()`, and between training.py:132 and :133).
+ * il_peer_allreduce_mean(x, bucket) == torch.distributed.all_reduce(bucket, AVG) for the ranks of `x`: every rank stores its bucket into slot [rank] of every
+ * rank's receive window (one fabric crossing, each peer over its own xGMI link), waits on the device for the other ranks' arrival words and sums the slabs in
+ * rank order (bit-identical results on every rank). Unlike the rest of this ABI the window functions DO allocate (fine-grained device memory) and synchronise:
+ * they run once, at set-up. Set-up (imitation_learning_amd/parallel.py PeerExchange): every rank allocates one window of sum(il_peer_region_bytes) bytes,
+ * the 64-byte handles are all-gathered with the host-side process group, every rank opens the other ranks' handles; buckets are told apart by
+ * `window_offset`. A call may sit in a captured graph (epochs are device counters). RCCL stays the fallback (IL_PEER_EXCHANGE=0, or set-up / self-test failure).
+ * ------------------------------------------------------------------------------------------ */
+#define IL_PEER_MAX_RANKS 16
+#define IL_PEER_HANDLE_BYTES 64      /* sizeof(hipIpcMemHandle_t) */
+#define IL_PEER_CHUNK_FLOATS 2048    /* one workgroup's share of a bucket */
+#define IL_PEER_FLAG_STRIDE 32       /* uint32 words per chunk in the arrival array: one 128-byte line per chunk, word r = the last epoch rank r pushed */
+#define IL_PEER_SPIN_LIMIT (1 << 23) /* default bound of a device-side wait for the peers (polls of >= 8 sleep quanta: several seconds) */
+typedef struct il_peer_bucket {
+  int32_t rank, world;                 /* this process's rank among the `world` <= IL_PEER_MAX_RANKS ranks that exchange */
+  int64_t n;                           /* floats in the bucket */
+  int64_t window_offset;               /* byte offset of this bucket's region (il_peer_region_bytes) in EVERY rank's window; multiple of 256 */
+  void* windows[IL_PEER_MAX_RANKS];    /* windows[r] = rank r's window as mapped in this process ([rank] = the own allocation) */
+  uint32_t* epoch;                     /* local device uint32[ceil(n / IL_PEER_CHUNK_FLOATS)], zero-initialised: exchanges done per chunk */
+  int64_t* status;                     /* local device int64[2], zero-initialised: [0] += 1 per wait that gave up (must stay 0) */
+  int32_t spin_limit, reserved;        /* polls before a wait gives up; 0 = IL_PEER_SPIN_LIMIT */
+} il_peer_bucket;
+/* bytes of a bucket's region: slots float[2 parities][world][n rounded up to chunks] + arrival words; -1 on bad arguments */
+int64_t il_peer_region_bytes(int32_t world, int64_t n);
+/* zero-filled fine-grained device allocation on the current device + its IPC handle (IL_PEER_HANDLE_BYTES bytes, host) */
+int il_peer_window_alloc(int64_t bytes, void** window_host, unsigned char* handle_host);
+/* maps another rank's window (a handle produced by il_peer_window_alloc in ANOTHER process) into this process */
+int il_peer_window_open(const unsigned char* handle_host, void** window_host);
+int il_peer_window_close(void* window);  /* a window obtained from il_peer_window_open */
+int il_peer_window_free(void* window);   /* a window obtained from il_peer_window_alloc */
+/* bucket[i] <- mean over ranks of bucket[i], i < x->n, in place; one launch of ceil(n / IL_PEER_CHUNK_FLOATS) workgroups. Every rank must issue the same
+ * sequence of calls per bucket (like a collective). */
+int il_peer_allreduce_mean(const il_peer_bucket* x, float* bucket, il_stream_t stream);
+
 /* sizeof() of the descriptor structs in this build (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red,
- * 7 il_dril, 8 il_disc_shaped, 9 il_disc_deep; -1 otherwise): lets a binding verify its own struct definitions. */
+ * 7 il_dril, 8 il_disc_shaped, 9 il_disc_deep, 10 il_peer_bucket; -1 otherwise): lets a binding verify its own struct definitions. */
 int32_t il_struct_size(int32_t which);
 
 #ifdef __cplusplus

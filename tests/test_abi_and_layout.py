@@ -85,6 +85,22 @@ def test_ctypes_structs_match_the_compiled_library():
   """sizeof() of every descriptor struct as compiled into libil_hip.so equals the ctypes mirror's (a stale binding would pass garbage)."""
   from imitation_learning_amd import _lib
   L = _lib.lib()
-  for which, cls in enumerate((_lib.Batch, _lib.Adam, _lib.Sac, _lib.Disc, _lib.Pwil, _lib.SampleArgs, _lib.Red, _lib.Dril, _lib.DiscShaped)):
+  for which, cls in enumerate((_lib.Batch, _lib.Adam, _lib.Sac, _lib.Disc, _lib.Pwil, _lib.SampleArgs, _lib.Red, _lib.Dril, _lib.DiscShaped, _lib.DiscDeep, _lib.PeerBucket)):
     assert L.il_struct_size(which) == C.sizeof(cls), cls.__name__
   assert L.il_struct_size(99) == -1
+
+
+def test_peer_window_layout():
+  """Host-side arithmetic of the peer-window exchange (include/il_hip.h il_peer_*): a bucket's region holds two parities x world slots of whole chunks plus one
+  128-byte arrival line per chunk, rounded to 256 bytes, so that regions packed back to back keep every slot 16-byte aligned."""
+  from imitation_learning_amd import _lib
+  L = _lib.lib()
+  CH = _lib.IL_PEER_CHUNK_FLOATS
+  for world in (1, 2, 8, 16):
+    for n in (1, 5, 1665, CH, CH + 1, 144904, 73744):
+      nch = -(-n // CH)
+      want = 2 * world * nch * CH * 4 + nch * 128
+      got = L.il_peer_region_bytes(world, n)
+      assert got % 256 == 0 and want <= got < want + 256, (world, n, got, want)
+  assert L.il_peer_region_bytes(0, 10) == -1 and L.il_peer_region_bytes(17, 10) == -1 and L.il_peer_region_bytes(2, 0) == -1
+  assert C.sizeof(_lib.PeerBucket) == 4 + 4 + 8 + 8 + 16 * 8 + 8 + 8 + 4 + 4

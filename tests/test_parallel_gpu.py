@@ -37,6 +37,7 @@ for k in range(4):
 out = {f't{i}': (n.flat if hasattr(n, 'flat') else n).detach().cpu().numpy() for i, n in enumerate(nets)}
 out['sn'] = nets[4].sn.cpu().numpy(); out['idx0'] = idx0; out['logp'] = plan.logp.cpu().numpy()
 out['handoff'] = np.array([int(dp.handoff), plan.sync_timeouts()])
+out['peer'] = np.array([int(dp.peer is not None), dp.exchange_timeouts()])
 np.savez(os.path.join(sys.argv[2], f'rank{rank}.npz'), **out)
 dist.barrier(); dist.destroy_process_group()
 '''
@@ -55,13 +56,17 @@ def _launch(args, cwd, timeout=600, **extra_env):
   return r
 
 
-@pytest.mark.parametrize('algorithm,handoff', [('GAIL', '1'), ('GAIL', '0'), ('SAC', '0')])
-def test_two_ranks_keep_bit_identical_replicas(tmp_path, algorithm, handoff):
-  """handoff = '1': the device-side hand-off schedule of DataParallelUpdate (resident index draw, inline relabel, one communicator per branch); '0': stream dependencies."""
+@pytest.mark.parametrize('algorithm,handoff,peer', [('GAIL', '1', '1'), ('GAIL', '0', '1'), ('SAC', '0', '1')])
+def test_two_ranks_keep_bit_identical_replicas(tmp_path, algorithm, handoff, peer):
+  """handoff = '1': the device-side hand-off schedule of DataParallelUpdate (resident index draw, inline relabel, one communicator per branch); '0': stream dependencies.
+  peer = '1': the gradient exchange is the one-kernel push / rank-ordered sum over peer-mapped windows (csrc/peer.hip; the two processes map each other's window through
+  hipIpc exactly as two GPUs would); '0' (gloo all-reduces) is covered by test_peer_exchange_equals_the_collective."""
   script = tmp_path / 'worker.py'
   script.write_text(WORKER)
-  _launch([str(script), ROOT, str(tmp_path), algorithm], str(tmp_path), IL_DP_HANDOFF=handoff)
+  _launch([str(script), ROOT, str(tmp_path), algorithm], str(tmp_path), IL_DP_HANDOFF=handoff, IL_PEER_EXCHANGE='require' if peer == '1' else '0')
   r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
+  assert [int(r0['peer'][0]), int(r1['peer'][0])] == [int(peer)] * 2
+  assert int(r0['peer'][1]) == 0 and int(r1['peer'][1]) == 0, 'a device-side wait of the peer-window exchange expired'
   if algorithm == 'GAIL':
     assert [int(r0['handoff'][0]), int(r1['handoff'][0])] == [int(handoff)] * 2
     if handoff == '1' and (r0['handoff'][1] or r1['handoff'][1]):
@@ -70,6 +75,91 @@ def test_two_ranks_keep_bit_identical_replicas(tmp_path, algorithm, handoff):
     assert np.isfinite(r0[k]).all()
     np.testing.assert_array_equal(r0[k], r1[k], err_msg=f'replica tensor {k} differs between the ranks')
   assert not np.array_equal(r0['idx0'], r1['idx0']) and not np.array_equal(r0['logp'], r1['logp']), 'the ranks must train on different data (rank-offset seeds, own shards)'
+
+
+def test_peer_exchange_equals_the_collective(tmp_path):
+  """Same seeds, same shards, four updates: the peer-window exchange and gloo's all-reduce leave the SAME bits in every replica tensor (two ranks: (a + b) / 2 either way)."""
+  script = tmp_path / 'worker.py'
+  script.write_text(WORKER)
+  res = {}
+  for peer in ('require', '0'):
+    d = tmp_path / f'peer_{peer}'
+    d.mkdir()
+    _launch([str(script), ROOT, str(d), 'GAIL'], str(tmp_path), IL_DP_HANDOFF='0', IL_PEER_EXCHANGE=peer)
+    res[peer] = np.load(d / 'rank0.npz')
+  assert int(res['require']['peer'][0]) == 1 and int(res['0']['peer'][0]) == 0
+  for k in ('t0', 't1', 't2', 't3', 't4', 'sn', 'logp'):
+    np.testing.assert_array_equal(res['require'][k], res['0'][k], err_msg=k)
+
+
+PEER_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+import torch.distributed as dist
+from imitation_learning_amd import parallel
+rank, _, dev = parallel.init_from_env(2, 'gloo')
+sizes = dict(a=1, b=5, c=1665, d=2048, e=2049, f=144904)
+x = parallel.PeerExchange.create(sizes, dev)
+assert x is not None, 'peer-window set-up or self-test failed'
+g = torch.Generator(device='cpu'); g.manual_seed(7 + rank)
+bad = 0
+graph_bad = 0
+for rnd in range(5):                                   # odd and even epochs: both slot parities
+  for k, n in sizes.items():
+    mine = torch.randn(n, generator=g)
+    both = [torch.empty(n), torch.empty(n)]
+    dist.all_gather(both, mine)
+    t = mine.to(dev)
+    x.allreduce_mean(k, t)
+    want = ((both[0] + both[1]) / 2).to(dev)         # rank order, then the mean: what the kernel evaluates
+    bad += int(not torch.equal(t, want))
+# the same launch inside a captured graph: epochs are device counters, so replays keep working
+buf = torch.zeros(sizes['f'], device=dev)
+torch.cuda.synchronize()
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+  gr = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(gr, stream=s):
+    x.allreduce_mean('f', buf)
+  for rep in range(3):
+    buf.fill_(float(rank + 1 + rep))
+    gr.replay()
+    s.synchronize()
+    graph_bad += int(not torch.equal(buf, torch.full_like(buf, 1.5 + rep)))
+torch.cuda.synchronize()
+np.save(os.path.join(sys.argv[2], f'peer{rank}.npy'), np.array([bad, graph_bad, x.timeouts()]))
+x.close()
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_peer_exchange_kernel_two_ranks(tmp_path):
+  """il_peer_allreduce_mean between two processes that map each other's window (hipIpc): bucket sizes that are not multiples of 4 floats nor of a chunk, several epochs,
+  bitwise against (a + b) / 2 of the gathered inputs; then the launch captured in a hipGraph and replayed."""
+  script = tmp_path / 'peer_worker.py'
+  script.write_text(PEER_WORKER)
+  _launch([str(script), ROOT, str(tmp_path)], str(tmp_path))
+  for r in (0, 1):
+    bad, graph_bad, timeouts = np.load(tmp_path / f'peer{r}.npy')
+    assert (bad, graph_bad, timeouts) == (0, 0, 0), f'rank {r}: {bad} mismatching exchanges, {graph_bad} mismatching graph replays, {timeouts} expired waits'
+
+
+def test_peer_exchange_single_rank_is_identity():
+  """World size 1 (IL_PEER_EXCHANGE=force, no process group): push to the own window, sum of one slab, mean = the input bits; the data-parallel split path through it equals
+  the split path without an exchange."""
+  from imitation_learning_amd import parallel
+  dev = torch.device('cuda', 0)
+  x = parallel.PeerExchange.create(dict(g=144904, h=7), dev)
+  assert x is not None
+  for n, k in ((144904, 'g'), (7, 'h')):
+    for _ in range(3):
+      t = torch.randn(n, device=dev)
+      ref = t.clone()
+      x.allreduce_mean(k, t)
+      assert torch.equal(t, ref)
+  assert x.timeouts() == 0
+  x.close()
 
 
 def test_train_py_runs_data_parallel(tmp_path):

@@ -41,11 +41,15 @@ def pretrain_bc(cfg, actor, expert_memory, state_size, action_size):
     il.behavioural_cloning_update(actor, batch, optimiser)
 
 
-def check_handoff(plan, step):
+def check_handoff(plan, step, runner=None):
   """The two branches of a captured GAIL update hand over through device counters with BOUNDED waits (include/il_hip.h il_sync): a wait that expires lets the
   update proceed on stale rewards / discriminator weights and bumps a counter. That can only happen if something stops the two streams from running
   concurrently after `capture()` validated them (a profiler attached mid-run, a CU mask, a co-tenant process). Training on such updates silently is worse
   than stopping: raise, naming the switch that trades the hand-off for plain stream dependencies."""
+  n = runner.exchange_timeouts() if hasattr(runner, 'exchange_timeouts') else 0
+  if n:
+    raise RuntimeError(f'step {step}: {n} device-side waits of the peer-window gradient exchange expired since set-up - a rank did not deliver its gradients within the bound, '
+                       'so some update averaged stale slabs and the replicas may have diverged. Re-run with IL_PEER_EXCHANGE=0 (RCCL all-reduces).')
   if plan is None or not getattr(plan, 'device_sync', False): return
   n = plan.sync_timeouts()
   if n:
@@ -219,10 +223,10 @@ def train(cfg, file_prefix: str = '') -> float:
                   '(that one update used stale rewards on the affected rank; replicas remain identical)', file=sys.stderr)
           if world > 1 and cfg.algorithm == 'GMMIL':   # one reward function on every rank: rank 0's bandwidths (models.py:193-195 freezes the first batch's)
             discriminator.gamma_1, discriminator.gamma_2 = parallel.broadcast_scalars([discriminator.gamma_1, discriminator.gamma_2])
-          if world > 1 and cfg.distributed.backend != 'nccl':
+          if world > 1 and cfg.distributed.backend != 'nccl' and getattr(runner, 'peer', None) is None:
             step_update = runner.run   # gloo collectives synchronise the host: not capturable (and a failed capture poisons the stream) - eager launches
           else:
-            runner.capture(warmup=0)   # RCCL collectives are captured with the kernels: one graph replay per data-parallel update
+            runner.capture(warmup=0)   # the gradient exchange (peer-window kernels, or RCCL collectives) is captured with the kernels: one graph replay per data-parallel update
             step_update = runner.replay
           captured = True
         else:
@@ -253,7 +257,7 @@ def train(cfg, file_prefix: str = '') -> float:
       if schedule == 'overlap' and plan is None: worker.enqueue_publish()
       if cfg.logging.interval > 0 and step % cfg.logging.interval == 0:  # the only D2H reads of the update path (train.py:205-210)
         if plan is not None: plan.join()   # the logged tensors may have been written by the plan's second stream
-        check_handoff(plan, step)
+        check_handoff(plan, step, runner)
         metrics['update_steps'].append(step); metrics['predicted_rewards'].append(rewards.cpu().numpy())
         metrics['alphas'].append(log_alpha.exp().cpu().numpy()); metrics['entropies'].append((-log_probs).cpu().numpy()); metrics['Q_values'].append(Q_values.cpu().numpy())
 
@@ -272,9 +276,13 @@ def train(cfg, file_prefix: str = '') -> float:
         lineplot(metrics['update_steps'], metrics['alphas'], filename=f'{file_prefix}sac_alpha', yaxis='Alpha', title=f'{cfg.algorithm}: {cfg.env} Alpha')
         lineplot(metrics['update_steps'], metrics['entropies'], filename=f'{file_prefix}sac_entropy', yaxis='Entropy', title=f'{cfg.algorithm}: {cfg.env} Entropy')
         lineplot(metrics['update_steps'], metrics['Q_values'], filename=f'{file_prefix}Q_values', yaxis='Q-value', title=f'{cfg.algorithm}: {cfg.env} Q-values')
+    if world > 1 and step % cfg.evaluation.interval == 0 and not cfg.check_time_usage:
+      # rank 0 has just spent seconds evaluating: align the hosts here, so that no BOUNDED device-side wait of the next update (the peer-window exchange, the hand-off on
+      # the all-reduced discriminator step) has to span that gap
+      torch.cuda.synchronize(); torch.distributed.barrier()
 
   if plan is not None: plan.join()   # the discriminator is stepped on the plan's second stream: order the checkpoint reads after it
-  check_handoff(plan, cfg.steps)   # never save a learner whose last updates ran on expired device-side waits
+  check_handoff(plan, cfg.steps, runner)   # never save a learner whose last updates ran on expired device-side waits
   if world > 1:
     import torch.distributed as dist
     torch.cuda.synchronize(); dist.barrier()
