@@ -323,6 +323,22 @@ __device__ __forceinline__ void xcd_tile_net(int b, int nt, int n_nets, int& til
   }
 }
 
+// Population launches: grid = (workgroups per learner, learners). The dispatcher hands out workgroups in linear order (x fastest) round-robin over the 8 XCDs (workgroup g
+// runs on XCD g % 8, confirmed with s_getreg XCC_ID), so with the natural decode (learner = blockIdx.y) every learner's workgroups are spread over all eight private L2s:
+// each of them pulls that learner's weight panels through the fabric, and an L2 sees the weights of every learner in flight (16 at a time: 5x its capacity). Re-decoding
+// the linear id puts learner l on XCD l % 8 - groups of 8 learners are interleaved - so an L2 holds the panels of the two learners it is working on and the 16 tiles of a
+// network re-use them. A learner's workgroups keep their relative order (a role that waits for lower-numbered workgroups of its learner still does). Learners beyond the
+// last full group of 8 keep the natural decode. Pure re-labelling: results are bit-identical.
+#ifndef IL_POP_XCD
+#define IL_POP_XCD 1
+#endif
+__device__ __forceinline__ void pop_ids(int& bx, int& by) {
+#if IL_POP_XCD
+  const int nx = gridDim.x, g = by * nx + bx, full = ((int)gridDim.y >> 3) * 8 * nx;
+  if (g < full) { const int grp = g / (8 * nx), r = g - grp * 8 * nx; by = grp * 8 + (r & 7); bx = r >> 3; }
+#endif
+}
+
 struct MlpView {  // flat torch-order parameter vector of a depth-2 MLP
   const float *W1, *b1, *W2, *b2, *W3, *b3;
 };

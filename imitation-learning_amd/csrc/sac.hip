@@ -179,11 +179,12 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
 __global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, int mode,
                                                     const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (dL) { pop_ids(bx, by); d = dL[by]; b = bL[by]; }
   globalize(d); globalize(b);
   const int nt = d.batch / IL_TILE_R;
-  const bool is_cur = (mode == 2) || (mode == 0 && (int)blockIdx.x >= nt);
-  actor_fwd_tile(d, b, eps_next, eps_cur, is_cur, (int)blockIdx.x % nt, smem);
+  const bool is_cur = (mode == 2) || (mode == 0 && bx >= nt);
+  actor_fwd_tile(d, b, eps_next, eps_cur, is_cur, bx % nt, smem);
   IL_TL_END(is_cur ? 6 : 5);
 }
 
@@ -283,10 +284,11 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
 
 __global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (dL) { pop_ids(bx, by); d = dL[by]; b = bL[by]; }
   globalize(d); globalize(b);
   int net, tile;
-  xcd_tile_net((int)blockIdx.x, d.batch / IL_TILE_R, 4, tile, net);
+  xcd_tile_net(bx, d.batch / IL_TILE_R, 4, tile, net);
   critic_fwd_tile(d, b, net, tile, smem, nullptr);
 }
 
@@ -295,12 +297,13 @@ __global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b, const
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (dL) { pop_ids(bx, by); d = dL[by]; b = bL[by]; }
   globalize(d); globalize(b);
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
   int k, tile;
-  xcd_tile_net((int)blockIdx.x, nt, 2, tile, k);
+  xcd_tile_net(bx, nt, 2, tile, k);
   IL_TL(9, 0);
   const int row0 = tile * IL_TILE_R;
   const int ldh = H + 4;
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b, const
     dz3s[threadIdx.x] = dq;
     W[ws.c_dz3 + (size_t)k * B + row] = dq;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 64) adam_tick(d.critic_opt);  // consumed by the following k_dw_adam / il_adam_step (a lane that is idle in this phase)
+  if (bx == 0 && threadIdx.x == 64) adam_tick(d.critic_opt);  // consumed by the following k_dw_adam / il_adam_step (a lane that is idle in this phase)
   __syncthreads();
   for (int i = threadIdx.x; i < 4 * H; i += blockDim.x) {  // (feature n, 4 consecutive rows) per thread: 16-byte lanes of the [H][B] layout
     const int n = i >> 2, r4 = (i & 3) * 4;
@@ -658,12 +661,13 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
 __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, const il_sac* __restrict__ dL,
                                                         const il_batch* __restrict__ bL, int helpers) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (dL) { d = dL[blockIdx.y]; b = bL[blockIdx.y]; }
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (dL) { pop_ids(bx, by); d = dL[by]; b = bL[by]; }
   globalize(d); globalize(b);
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
-  if ((int)blockIdx.x >= 2 * nt) {   // helper: block order keeps it behind both critics of its tile (it only waits for lower-numbered workgroups)
-    const int h = (int)blockIdx.x - 2 * nt, tile = h % nt, part = h / nt;
+  if (bx >= 2 * nt) {   // helper: block order keeps it behind both critics of its tile (it only waits for lower-numbered workgroups)
+    const int h = bx - 2 * nt, tile = h % nt, part = h / nt;
     const SacWs ws = sac_ws(S, A, H, B);
     unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr) + tile * IL_CTR_STRIDE;
     if (h == 0 && threadIdx.x == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }   // consumed by the next kernel
@@ -679,14 +683,14 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
     return;
   }
   int k, tile;
-  xcd_tile_net((int)blockIdx.x, nt, 2, tile, k);
+  xcd_tile_net(bx, nt, 2, tile, k);
   const int row0 = tile * IL_TILE_R;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
   float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* q16 = H2s + IL_TILE_R * ldh;
   const SacWs ws = sac_ws(S, A, H, B);
   float* W = d.workspace;
   const MlpView p = mlp_view(d.critic + k * net_stride(IN, H, 1), IN, H, 1);
-  const bool stamp = blockIdx.x == 0;
+  const bool stamp = bx == 0;
   IL_STAMP(stamp, 16);
   IL_TL(3, 0);
   IL_TL(7, 0);
@@ -988,6 +992,9 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
 // Every tile keeps dw_tile's two accumulators and its MFMA order (row groups ascending; k-steps 0, 2 -> acc0 and 1, 3 -> acc1), so the gradients, and with them
 // the learners, stay bit-identical to the single-learner kernel.
 // ---------------------------------------------------------------------------------------------
+#ifndef IL_POP_XCD_DW
+#define IL_POP_XCD_DW 1
+#endif
 #define DWB 64            // block edge (features) and batch rows per chunk
 #define DWB_LD (DWB + 4)
 __device__ __forceinline__ void dw_block64(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dzT, const float* __restrict__ xT, int H, int n0, int k0, int64_t poff,
@@ -1304,7 +1311,11 @@ extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ dL, const il_batch* __restrict__ bL, int kind, uint32_t flags, int nb64) {
   __shared__ __attribute__((aligned(16))) float smem[2 * DWB * DWB_LD];
-  il_sac d = dL[blockIdx.y]; il_batch b = bL[blockIdx.y];
+  int bx = blockIdx.x, by = blockIdx.y;
+#if IL_POP_XCD_DW
+  pop_ids(bx, by);   // a learner's blocks on one XCD: the four blocks that share a [64 features][B] operand panel find it in that L2
+#endif
+  il_sac d = dL[by]; il_batch b = bL[by];
   globalize(d); globalize(b);
   DwArgs a = kind ? actor_dw_args(&d, &b, flags) : critic_dw_args(&d, flags);
   IL_TL(kind ? 11 : 10, 0);
@@ -1314,8 +1325,8 @@ __global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ 
   // flight per lane: 113 us. Neither L2 -> CU nor fabric bandwidth: a serial (8 loads -> wait -> 16 MFMAs) chain per wave. Hence dw_block64 for the H x H layers.
   if (nb64 > 0) {
     const int H = a.hidden, nbh = H / DWB, per_net = nbh * nbh;
-    if ((int)blockIdx.x < nb64) {
-      const int net = (int)blockIdx.x / per_net, blk = (int)blockIdx.x - net * per_net;
+    if (bx < nb64) {
+      const int net = bx / per_net, blk = bx - net * per_net;
       adam_consts ac = {};
       if (!a.grads_only) ac = load_adam_consts(a.opt);
       const int64_t oW2 = (int64_t)net * a.net_stride + (int64_t)H * a.in_dim + H;
@@ -1325,11 +1336,11 @@ __global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ 
       return;
     }
     a.n_dw_blocks = dw_blocks(a.in_dim, a.hidden, a.out_dim, a.n_nets, 1);
-    dw_adam_body<4, true>(a, (int)blockIdx.x - nb64, (int)gridDim.x - nb64);
+    dw_adam_body<4, true>(a, bx - nb64, (int)gridDim.x - nb64);
     IL_TL_END(kind ? 11 : 10);
     return;
   }
-  dw_adam_body<4>(a, (int)blockIdx.x, (int)gridDim.x);
+  dw_adam_body<4>(a, bx, (int)gridDim.x);
 }
 
 extern "C" int il_sac_update_population(const il_sac* descs_dev, const il_batch* batches_dev, int32_t n_learners, const il_sac* shape_host, uint32_t flags, il_stream_t stream_) {

@@ -843,8 +843,20 @@ class BatchedPopulationPlan:
   single-learner regime towards the HBM roofline.  Every learner keeps its own replay ring, MT19937 index stream,
   networks, optimiser state, scratch and Philox counter (build the `UpdatePlan`s with distinct `learner_id`s)."""
 
-  def __init__(self, plans):
+  def __init__(self, plans, groups: Optional[int] = None):
     self.plans = list(plans)
+    # groups > 1: the population is cut into `groups` contiguous sub-populations, each advanced by its own launches on its own stream (parallel branches of the
+    # captured graph). A population launch ends with a tail in which the last workgroups of every learner drain while most CUs idle, and the next kernel cannot
+    # start before it: with two or more independent branches the other sub-population's workgroups fill those CUs. IL_POP_GROUPS overrides the default of 1.
+    groups = int(os.environ.get('IL_POP_GROUPS', '1')) if groups is None else int(groups)
+    self.subs = None
+    if groups > 1 and len(self.plans) >= 2 * groups:
+      per = (len(self.plans) + groups - 1) // groups
+      self.subs = [BatchedPopulationPlan(self.plans[i:i + per], groups=1) for i in range(0, len(self.plans), per)]
+      self.streams = [torch.cuda.Stream() for _ in self.subs]
+      for sub in self.subs: sub.side = None   # nested fork / join breaks hipGraph capture on ROCm 7.2: inside a branch the discriminator kernels stay in stream order (the other branches run beside them)
+      self.algorithm, self.B, self.L, self.graph = self.subs[0].algorithm, self.subs[0].B, len(self.plans), None
+      return
     for p in self.plans:
       p._set_device_sync(False)   # one stream, one set of launches for all learners: plain stream order
     p0 = self.plans[0]
@@ -870,6 +882,15 @@ class BatchedPopulationPlan:
     self.side = torch.cuda.Stream() if self.algorithm == 'GAIL' and os.environ.get('IL_POP_OVERLAP', '1') != '0' else None
 
   def run(self):
+    if self.subs is not None:
+      main = torch.cuda.current_stream()
+      for sub, s in zip(self.subs, self.streams):
+        s.wait_stream(main)
+        with torch.cuda.stream(s):
+          sub.run()
+      for s in self.streams:
+        main.wait_stream(s)
+      return
     L, st, p0 = _lib.lib(), _lib.stream_ptr(), self.plans[0]
     prepared = _lib.IL_FLAG_SAC_PREPARED if self._prepared else 0
     _lib.check(L.il_replay_sample_population(_lib.ptr(self.sample_args), self.L, self.B, self.max_row, st))
