@@ -388,7 +388,7 @@ __device__ __forceinline__ void critic_bwd_resident_gemm(const il_sac& d, int k,
 }
 // relabel: the rewards of this tile are the discriminator `dd`'s prediction on (s, a) - the rows still sit in Xs - computed here once its AdamW step of
 // this update is complete ([IL_SYNC_PARAMS], n_reduce workgroups per step); otherwise dense `rewards` or the batch's own reward field.
-struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; int fwd_only; int wait_indices; int local_rewards; };   // wait_indices: IL_FLAG_SAC_WAIT_INDICES; local_rewards: il_sac_update_gather without `rewards` / `relabel` (the ring's reward field: nothing to wait for)   // fwd_only: the forward kernels only (IL_FLAG_SAC_FORWARD_ONLY / data-parallel phase 0): no critic backward
+struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; int fwd_only; int wait_indices; int local_rewards; int xcd_nets, gather_wgs; };   // xcd_nets: grid = 8 * nt, one network per XCD (chain_decode_xcd); gather_wgs: row-copy workgroups among the blocks of XCDs 6, 7   // wait_indices: IL_FLAG_SAC_WAIT_INDICES; local_rewards: il_sac_update_gather without `rewards` / `relabel` (the ring's reward field: nothing to wait for)   // fwd_only: the forward kernels only (IL_FLAG_SAC_FORWARD_ONLY / data-parallel phase 0): no critic backward
 // Runs between the critic's own work and its wait for the targets: the discriminator's step usually lands while the targets are still being computed,
 // so the relabel stays off the critical path. Leaves the tile's rewards in LDS (rew16) for critic_bwd_resident_scale.
 __device__ __forceinline__ void critic_relabel_tile(const il_sac& d, const ChainRelabel& rl, int k, int tile, float* smem) {
@@ -483,6 +483,18 @@ __device__ __forceinline__ void chain_decode(int bid, int nt, int& role, int& ne
     net = l / nt; tile = l - net * nt;
   }
 }
+// One network per XCD (grid = 8 * nt; workgroup b runs on XCD b % 8): the nt tile workgroups of a role-network all sit on the same XCD, so its weights cross the fabric
+// once instead of once per XCD that hosts one of its tiles (chain_decode: 8x for the actor roles, 4x for the critic-shaped ones - 11 MB of reads per launch against
+// 1.7 MB of weights). XCD 0: actor(s'), 1-2: targets, 3-4: critics, 5: actor(s), 6-7: the row-copy workgroups (the rest of their blocks exit at once). A role still only
+// waits for lower-numbered workgroups (tile q: 8q < 8q + 1, 8q + 2 < 8q + 3, 8q + 4).
+__device__ __forceinline__ void chain_decode_xcd(int bid, int& role, int& net, int& tile) {
+  const int x = bid & 7;
+  tile = bid >> 3;
+  if (x == 0) { role = 0; net = 0; }
+  else if (x <= 2) { role = 1; net = x - 1; }
+  else if (x <= 4) { role = 2; net = x - 3; }
+  else { role = 3; net = 0; }
+}
 // b.gather != NULL (il_sac_update_gather): the batch has been drawn but not gathered. Every role reads its rows straight from the ring through the
 // indices, and the workgroups behind the 6 * nt chain roles copy the rows to `rows_out` for the later kernels of the update (one 16-byte
 // lane per thread, [IL_SYNC_ROWS] += 1 per workgroup) - they wait for nothing and nobody in this launch waits for them.
@@ -491,14 +503,18 @@ __device__ __forceinline__ void sac_chain_body(il_sac& d, il_batch& b, const flo
   const int nt = d.batch / IL_TILE_R;
   // resident sampler (il_replay_draw_resident on the other stream): this update's indices are signalled, not stream-ordered. This launch follows the previous
   // update's last kernel in its stream, so [IL_SYNC_MAIN_EPOCH] already counts that update; the draw usually finished while this launch was being dispatched.
+  const int bid = blockIdx.x;
+  int gw = -1, G = 0;   // row-copy workgroup index / count
+  if (rl.xcd_nets) { if ((bid & 7) >= 6) { gw = 2 * (bid >> 3) + (bid & 7) - 6; G = rl.gather_wgs; if (gw >= G) return; } }
+  else if (bid >= 6 * nt) { gw = bid - 6 * nt; G = (int)gridDim.x - 6 * nt; }
   IL_TL(0, 0);
   if (rl.wait_indices) { long long* sy = reinterpret_cast<long long*>(d.sync); sync_wait(sy, IL_SYNC_INDICES, sy[IL_SYNC_MAIN_EPOCH] + 1); }
   IL_TL(0, 1);
-  if ((int)blockIdx.x >= 6 * nt) {
-    const int row4 = b.ld_states / 4, lanes = d.batch * row4, G = (int)gridDim.x - 6 * nt;
+  if (gw >= 0) {
+    const int row4 = b.ld_states / 4, lanes = d.batch * row4;
     const f32x4* src = reinterpret_cast<const f32x4*>(b.states);
     f32x4* dst = reinterpret_cast<f32x4*>(as_global(rows_out));
-    for (int i = ((int)blockIdx.x - 6 * nt) * blockDim.x + threadIdx.x; i < lanes; i += G * blockDim.x) {
+    for (int i = gw * blockDim.x + threadIdx.x; i < lanes; i += G * blockDim.x) {
       const int r = i / row4, c = i - r * row4;
       dst[i] = src[brow(b, r) * row4 + c];
     }
@@ -507,7 +523,7 @@ __device__ __forceinline__ void sac_chain_body(il_sac& d, il_batch& b, const flo
     return;
   }
   int role, net, tile;
-  chain_decode((int)blockIdx.x, nt, role, net, tile);
+  if (rl.xcd_nets) chain_decode_xcd(bid, role, net, tile); else chain_decode(bid, nt, role, net, tile);
   const SacWs ws = sac_ws(d.state_dim, d.action_dim, d.hidden, d.batch);
   unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + tile * IL_CTR_STRIDE;
   if (role == 0) { actor_fwd_tile(d, b, eps_next, eps_cur, false, tile, smem); IL_TL(0, 6); tile_arrive(ctr); IL_TL(0, 7); }
@@ -658,6 +674,7 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
 // arriver but by `helpers` extra workgroups per tile that wait for both critics (tile counter) with their own operands already requested,
 // and split the last GEMM between them by output columns. Same arithmetic per element, so the result is bit-identical to helpers = 0.
 #define IL_PC_HELPERS 4
+#define IL_PC_XCD_NETS 0x100   // flag bit in k_policy_critic's `helpers` argument
 __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, const il_sac* __restrict__ dL,
                                                         const il_batch* __restrict__ bL, int helpers) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -666,8 +683,14 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   globalize(d); globalize(b);
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R;
-  if (bx >= 2 * nt) {   // helper: block order keeps it behind both critics of its tile (it only waits for lower-numbered workgroups)
-    const int h = bx - 2 * nt, tile = h % nt, part = h / nt;
+  // helpers & IL_PC_XCD_NETS (single learner, grid = 8 * nt): one critic per XCD (workgroup b runs on XCD b % 8) - XCD 0 / 1: the nt tiles of critic 0 / 1, XCD 2 ..
+  // 2 + helpers - 1: helper part p of every tile (its column slice of the actor's backward panel is read by that XCD alone), the other blocks exit. Tile q: blocks
+  // 8q, 8q + 1 (critics) < 8q + 2 + p (helpers): a helper still only waits for lower-numbered workgroups.
+  const bool xcd_nets = (helpers & IL_PC_XCD_NETS) != 0;
+  helpers &= ~IL_PC_XCD_NETS;
+  if (xcd_nets && (bx & 7) >= 2 + helpers) return;
+  if (xcd_nets ? (bx & 7) >= 2 : bx >= 2 * nt) {   // helper: block order keeps it behind both critics of its tile (it only waits for lower-numbered workgroups)
+    const int h = xcd_nets ? ((bx & 7) - 2) * nt + (bx >> 3) : bx - 2 * nt, tile = h % nt, part = h / nt;
     const SacWs ws = sac_ws(S, A, H, B);
     unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr) + tile * IL_CTR_STRIDE;
     if (h == 0 && threadIdx.x == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }   // consumed by the next kernel
@@ -683,7 +706,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
     return;
   }
   int k, tile;
-  xcd_tile_net(bx, nt, 2, tile, k);
+  if (xcd_nets) { k = bx & 7; tile = bx >> 3; } else xcd_tile_net(bx, nt, 2, tile, k);
   const int row0 = tile * IL_TILE_R;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
   float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* q16 = H2s + IL_TILE_R * ldh;
@@ -1153,6 +1176,8 @@ static int device_cu_count() {
   static const int n = [] { int dev = 0, cu = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0; return cu; }();
   return n;
 }
+// IL_CHAIN_XCD_NETS=1: single-learner k_sac_chain / k_policy_critic launches place each network's tile workgroups on ONE XCD (chain_decode_xcd; grid = 8 * nt)
+static bool chain_xcd_nets(int nt) { static const int on = [] { const char* e = getenv("IL_CHAIN_XCD_NETS"); return e && e[0] == '1' ? 1 : 0; }(); return on != 0 && 8 * nt <= device_cu_count(); }
 static int pc_helpers(int nt) {
   static const int on = [] { const char* e = getenv("IL_PC_SPLIT"); return e && e[0] == '0' ? 0 : 1; }();
   return (on && (2 + IL_PC_HELPERS) * nt <= device_cu_count()) ? IL_PC_HELPERS : 0;
@@ -1196,7 +1221,7 @@ extern "C" int il_sac_actor_step(const il_sac* d, const il_batch* b, const float
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 3), 256, 0, st>>>(*d, 0x07u, nullptr); }  // actor + critics (the critic may have been stepped by il_adam_step)
   { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, eps_cur, 2, nullptr, nullptr); }
-  { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); k_policy_critic<<<(2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, hp); }
+  { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
   DwArgs a = actor_dw_args(d, b, flags);
   const int tail = 1 + ((flags & IL_FLAG_GRADS_ONLY) ? 0 : 32);
   { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<a.n_dw_blocks + tail, 256, 0, st>>>(a); }
@@ -1216,14 +1241,16 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
   const bool whole = !(flags & (IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY));
   if (whole && chain_enabled() && 6 * nt <= device_cu_count()) {   // forward + critic loss chained per tile in one co-resident launch (k_sac_chain)
     if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
-    { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr, ChainRelabel{}); }
+    ChainRelabel cr = {}; cr.xcd_nets = chain_xcd_nets(nt) ? 1 : 0;
+    { IL_TRACE("k_sac_chain", st); k_sac_chain<<<(cr.xcd_nets ? 8 : 6) * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr, cr); }
     flags |= IL_FLAG_SAC_SKIP_FORWARD | 0x80000000u;
   }
   if ((flags & IL_FLAG_SAC_FORWARD_ONLY) && !(flags & IL_FLAG_SAC_SKIP_FORWARD) && chain_enabled() && 6 * nt <= device_cu_count()) {
     // the four forward passes as one launch chained per tile (the target critics wait for their tile's actor(s') inside it), no critic backward
     if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
     ChainRelabel fo = {}; fo.fwd_only = 1;
-    { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr, fo); }
+    fo.xcd_nets = chain_xcd_nets(nt) ? 1 : 0;
+    { IL_TRACE("k_sac_chain", st); k_sac_chain<<<(fo.xcd_nets ? 8 : 6) * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr, fo); }
     IL_CHECK_LAUNCH("il_sac_update");
     return IL_OK;
   }
@@ -1238,7 +1265,7 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
     if (!(flags & 0x80000000u)) { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
     DwArgs ca = critic_dw_args(d, flags);
     { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
-    { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); k_policy_critic<<<(2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, hp); }
+    { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
     DwArgs aa = actor_dw_args(d, b, flags);
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 33, 256, 0, st>>>(aa); }
   }
@@ -1290,14 +1317,15 @@ extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const
   if (6 * nt + G > device_cu_count()) return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update_gather: %d workgroups cannot be co-resident on %d CUs (gather first, then il_sac_update)", 6 * nt + G, device_cu_count());
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
-  { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt + G, tile_threads(H), lds, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl); }
+  if (chain_xcd_nets(nt) && G <= 2 * nt) { rl.xcd_nets = 1; rl.gather_wgs = G; }
+  { IL_TRACE("k_sac_chain", st); k_sac_chain<<<rl.xcd_nets ? 8 * nt : 6 * nt + G, tile_threads(H), lds, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl); }
   DwArgs ca = critic_dw_args(d, flags);
   { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
   if (flags & IL_FLAG_GRADS_ONLY) {   // data-parallel: stop at the critic gradients (critic_grad); the caller all-reduces them and continues with il_sac_dp_phase(rows, 2) and (rows, 3)
     IL_CHECK_LAUNCH("il_sac_update_gather");
     return IL_OK;
   }
-  { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); k_policy_critic<<<(2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *rows, out_logp, out_q, nullptr, nullptr, hp); }
+  { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *rows, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
   DwArgs aa = actor_dw_args(d, rows, flags);
   { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 33, 256, 0, st>>>(aa); }
   IL_CHECK_LAUNCH("il_sac_update_gather");
@@ -1483,7 +1511,8 @@ extern "C" int il_sac_dp_phase(const il_sac* d, const il_batch* b, int32_t phase
   if (phase == 0 && chain_enabled() && 6 * nt <= device_cu_count()) {
     if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
     ChainRelabel fo = {}; fo.fwd_only = 1;
-    { IL_TRACE("k_sac_chain", st); k_sac_chain<<<6 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr, nullptr, nullptr, fo); }
+    fo.xcd_nets = chain_xcd_nets(nt) ? 1 : 0;
+    { IL_TRACE("k_sac_chain", st); k_sac_chain<<<(fo.xcd_nets ? 8 : 6) * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr, nullptr, nullptr, fo); }
   } else if (phase == 0) {
     if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
     { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr, 0, nullptr, nullptr); }
@@ -1495,7 +1524,7 @@ extern "C" int il_sac_dp_phase(const il_sac* d, const il_batch* b, int32_t phase
   } else if (phase == 2) {
     const int64_t n = 2 * net_stride(S + A, H, 1);
     { IL_TRACE("k_apply_critic", st); k_apply_critic<<<(int)((n + 255) / 256), 256, 0, st>>>(*d); }
-    { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); k_policy_critic<<<(2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, hp); }
+    { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
     DwArgs aa = actor_dw_args(d, b, IL_FLAG_GRADS_ONLY);
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 1, 256, 0, st>>>(aa); }
   } else {
