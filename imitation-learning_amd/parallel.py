@@ -370,6 +370,8 @@ class DataParallelUpdate:
     main.wait_stream(self.side)     # eager: leave the caller's stream ordered after both branches
 
   def capture(self, warmup: int = 3):
+    if self._warm_collectives_pending:
+      self._warm_collectives()   # set-up (communicators, peer windows: allocations, host synchronisation) never happens inside a capture
     if self.handoff:   # two graphs, one per branch and per communicator, replayed on two streams with no edge between them (cf. UpdatePlan.capture)
       p = self.plan
       if not p._probe_device_sync(graph=True):   # e.g. a counter-collecting profiler serialises the two graphs: stream dependencies, one graph (below)

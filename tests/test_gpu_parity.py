@@ -417,10 +417,15 @@ def test_update_plan_host_and_device_index_draws_agree():
     np.testing.assert_array_equal(a, b)
 
 
-def test_data_parallel_path_equals_fused_path_on_one_rank():
+@pytest.mark.parametrize('exchange', ['none', 'peer_windows'])
+def test_data_parallel_path_equals_fused_path_on_one_rank(monkeypatch, exchange):
   """DataParallelUpdate (IL_FLAG_GRADS_ONLY kernels -> [all-reduce] -> apply kernels) must evolve a learner like the fused UpdatePlan:
-  with one rank the all-reduce is the identity, so any difference would be a bug in the split path the multi-GPU run uses."""
+  with one rank the all-reduce is the identity, so any difference would be a bug in the split path the multi-GPU run uses.
+  exchange = 'peer_windows': one il_peer_allreduce_mean launch per sync point with a world of one rank (the gradients travel through the window's slot and back);
+  'none': no exchange is enqueued."""
   from imitation_learning_amd.parallel import DataParallelUpdate
+  if exchange != 'none':
+    monkeypatch.setenv('IL_PEER_EXCHANGE', 'require')
   outs = []
   for dp in (False, True):
     il.seed(21)
@@ -443,6 +448,7 @@ def test_data_parallel_path_equals_fused_path_on_one_rank():
   torch.cuda.synchronize()
   for a, n in zip(outs[1], nets):
     np.testing.assert_array_equal(a, N(n.flat if hasattr(n, 'flat') else n))
+  assert (dp.peer is not None) == (exchange != 'none') and dp.exchange_timeouts() == 0
 
 
 # ------------------------------------------------------------------------------------------------ size-independent properties / edge cases
