@@ -328,7 +328,8 @@ def main():
   ap.add_argument('--no-overlap', action='store_true', help='one stream, no device-side hand-off: the same kernels back to back (what a counter-collecting profiler needs; il_sac_update still takes its chained launch)')
   ap.add_argument('--no-population', action='store_true')
   ap.add_argument('--no-secondary', action='store_true', help='skip the SAC-only / discriminator-only / GMMIL / PWIL rates')
-  ap.add_argument('--population-learners', type=int, default=32)
+  ap.add_argument('--population-learners', type=int, default=64)
+  ap.add_argument('--population-groups', type=int, default=2, help='sub-populations replayed as parallel graph branches (BatchedPopulationPlan(groups=))')
   ap.add_argument('--learners', type=int, default=1, help='population axis: N independent learners per GPU advanced by one graph replay (aggregate updates/s)')
   args = ap.parse_args()
 
@@ -429,7 +430,7 @@ def main():
       # SAME launches (learner id = grid dimension). Reported next to, never instead of, the single-learner `value`.
       from imitation_learning_amd import BatchedPopulationPlan
       Lp = args.population_learners
-      pop = BatchedPopulationPlan([build(device, rank, seed=100 + l, learner_id=100 + l)[0] for l in range(Lp)])
+      pop = BatchedPopulationPlan([build(device, rank, seed=100 + l, learner_id=100 + l)[0] for l in range(Lp)], groups=args.population_groups)
       for _ in range(3):
         pop.run()
       torch.cuda.synchronize()
@@ -444,8 +445,8 @@ def main():
       dt = (time.perf_counter() - t1) / 200
       proof = roofline(pop.run, 10, Lp, dt * 1e3, False)
       proof.pop('kernels', None)
-      out['population'] = dict(learners=Lp, aggregate_updates_per_s=round(Lp / dt, 1), ms_per_replay=round(dt * 1e3, 5), roofline=proof,
-                               note=f'{Lp} independent batch-256 SAC+GAIL learners per launch (il_*_population: learner id = grid dimension), own replay ring / index stream / Philox counter each')
+      out['population'] = dict(learners=Lp, groups=args.population_groups, aggregate_updates_per_s=round(Lp / dt, 1), ms_per_replay=round(dt * 1e3, 5), roofline=proof,
+                               note=f'{Lp} independent batch-256 SAC+GAIL learners (il_*_population launches: learner id = grid dimension, learner l on XCD l % 8; {args.population_groups} sub-populations as parallel graph branches), own replay ring / index stream / Philox counter each')
       del pop
     if world == 1 and args.learners == 1 and not args.no_secondary:
       out['secondary'] = secondary(device, plan, nets)

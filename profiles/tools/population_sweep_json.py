@@ -10,9 +10,9 @@ _, _, ub, uf = bench.algorithmic_model()
 out = dict(what='BatchedPopulationPlan (il_*_population launches, hipGraph replay), SAC+GAIL, batch 256 per learner, HalfCheetah dims, own 1e6-row ring / index stream / Philox counter per learner',
            algorithmic_bytes_per_update=ub, algorithmic_flops_per_update=uf, sweep=[])
 plans = []
-for L in (8, 16, 32, 64):
+for L, G in ((8, 1), (16, 1), (32, 1), (64, 1), (64, 2)):   # G: sub-populations as parallel graph branches (BatchedPopulationPlan(groups=))
   plans += [bench.build(dev, 0, seed=len(plans) + l, learner_id=len(plans) + l)[0] for l in range(L - len(plans))]
-  pop = il.BatchedPopulationPlan(plans)
+  pop = il.BatchedPopulationPlan(plans, groups=G)
   for _ in range(3): pop.run()
   torch.cuda.synchronize()
   pop.capture()
@@ -22,7 +22,7 @@ for L in (8, 16, 32, 64):
   for _ in range(200): pop.replay()
   torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
   rate = L / dt
-  out['sweep'].append(dict(learners=L, aggregate_updates_per_s=round(rate, 1), us_per_replay=round(dt * 1e6, 1), fp32_frac=round(rate * uf / 1e12 / bench.FP32_PEAK_TFLOPS, 4),
+  out['sweep'].append(dict(learners=L, groups=G, aggregate_updates_per_s=round(rate, 1), us_per_replay=round(dt * 1e6, 1), fp32_frac=round(rate * uf / 1e12 / bench.FP32_PEAK_TFLOPS, 4),
                            hbm_frac=round(rate * ub / 1e9 / bench.HBM_PEAK_GBS, 4)))
   print(out['sweep'][-1], file=sys.stderr, flush=True)
   del pop
