@@ -258,11 +258,14 @@ def cpu_reference():
               sample=f"{ref['updates_timed']} updates after {ref['warmup']} warm-up: {ref['what']}; source profiles/cpu_reference.json (committed; not re-timed in this run)")
 
 
-def roofline(run_fn, trace_steps, units_per_launch, ms_per_step, side_stream_disc):
+def roofline(run_fn, trace_steps, units_per_launch, ms_per_step, side_stream_disc, kernel_units=None):
   """Per-kernel average durations from HIP events recorded on the launch stream(s) (il_trace_*), eager launches of the same kernels;
-  `units_per_launch` = updates one launch advances (1, or the number of learners on the population path)."""
+  `units_per_launch` = updates one step / replay advances (1, or the number of learners on the population path); `kernel_units` = updates ONE kernel launch advances when that
+  differs (a population replayed as g parallel sub-populations: learners / g per launch; the per-kernel rates are then lower bounds - a launch shares the chip with the other
+  branches' launches for part of its HIP-event window)."""
   from imitation_learning_amd import _lib
   bytes_k, flops_k, update_bytes, update_flops = algorithmic_model()
+  ku = units_per_launch if kernel_units is None else kernel_units
   L = _lib.lib()
   L.il_trace_enable(1)
   for _ in range(trace_steps):
@@ -281,16 +284,16 @@ def roofline(run_fn, trace_steps, units_per_launch, ms_per_step, side_stream_dis
   for k, v in kern.items():
     e = dict(avg_us=round(v['avg_us'], 3), launches_per_update=v['launches_per_update'])
     if k in bytes_k:
-      e['hbm_GBps'] = round(units_per_launch * bytes_k[k] / (v['avg_us'] * 1e-6) / 1e9, 2)
+      e['hbm_GBps'] = round(ku * bytes_k[k] / (v['avg_us'] * 1e-6) / 1e9, 2)
     if k in flops_k:
-      e['fp32_TFLOPs'] = round(units_per_launch * flops_k[k] / (v['avg_us'] * 1e-6) / 1e12, 3)
+      e['fp32_TFLOPs'] = round(ku * flops_k[k] / (v['avg_us'] * 1e-6) / 1e12, 3)
     per_kernel[k] = e
   if dom in flops_k:
-    ach = units_per_launch * flops_k[dom] / (kern[dom]['avg_us'] * 1e-6) / 1e12
+    ach = ku * flops_k[dom] / (kern[dom]['avg_us'] * 1e-6) / 1e12
     roof = dict(bound='mfma', kernel=dom, note='fp32: MFMA f32 rate == VALU f32 rate == 157.3 TFLOP/s on gfx950', achieved=round(ach, 3), peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
                 frac=round(ach / FP32_PEAK_TFLOPS, 5), traffic=None)
   else:
-    ach = units_per_launch * bytes_k.get(dom, 0) / (kern[dom]['avg_us'] * 1e-6) / 1e9
+    ach = ku * bytes_k.get(dom, 0) / (kern[dom]['avg_us'] * 1e-6) / 1e9
     roof = dict(bound='hbm', kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 5), traffic=None)
   try:  # HBM-side bytes per launch from the committed PMC passes (profiles/pmc_latest.json; collected with rocprofv3 --pmc, not in this run)
     pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')))['kernels']
@@ -443,7 +446,8 @@ def main():
         pop.replay()
       torch.cuda.synchronize()
       dt = (time.perf_counter() - t1) / 200
-      proof = roofline(pop.run, 10, Lp, dt * 1e3, False)
+      proof = roofline(pop.run, 10, Lp, dt * 1e3, False, kernel_units=Lp // max(1, args.population_groups))
+      if args.population_groups > 1: proof['note'] += f'; {args.population_groups} sub-populations run as parallel branches: `frac` is a lower bound (a launch covers {Lp // args.population_groups} learners and shares the chip with the other branch for part of its HIP-event window), the whole-replay fp32_frac is exact'
       proof.pop('kernels', None)
       out['population'] = dict(learners=Lp, groups=args.population_groups, aggregate_updates_per_s=round(Lp / dt, 1), ms_per_replay=round(dt * 1e3, 5), roofline=proof,
                                note=f'{Lp} independent batch-256 SAC+GAIL learners (il_*_population launches: learner id = grid dimension, learner l on XCD l % 8; {args.population_groups} sub-populations as parallel graph branches), own replay ring / index stream / Philox counter each')
