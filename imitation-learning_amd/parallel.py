@@ -133,21 +133,31 @@ class PeerExchange:
       total += int(L.il_peer_region_bytes(self.world, n))
     w, handle = C.c_void_p(), C.create_string_buffer(_lib.IL_PEER_HANDLE_BYTES)
     with torch.cuda.device(device):
-      _lib.check(L.il_peer_window_alloc(total, C.byref(w), handle))
-      self.window = w.value
-      handles = [handle.raw]
+      # Every rank takes part in the handle exchange whether or not its own allocation worked (a rank that raised before the collective would leave the others waiting
+      # in it): a failed allocation travels as None and fails the set-up on every rank.
+      rc = L.il_peer_window_alloc(total, C.byref(w), handle)
+      mine = handle.raw if rc == 0 else None
+      why = None if rc == 0 else L.il_last_error().decode()
+      self.window = w.value if rc == 0 else None
+      handles = [mine]
       if self.world > 1:
         handles = [None] * self.world
-        dist.all_gather_object(handles, handle.raw, group=group)
-      windows = []
-      for r, h in enumerate(handles):
-        if r == self.rank:
-          windows.append(self.window)
-          continue
-        o = C.c_void_p()
-        _lib.check(L.il_peer_window_open(h, C.byref(o)))
-        self.opened.append(o.value)
-        windows.append(o.value)
+        dist.all_gather_object(handles, mine, group=group)
+      try:
+        if any(h is None for h in handles):
+          raise RuntimeError('PeerExchange: no peer window on rank(s) ' + ', '.join(str(r) for r, h in enumerate(handles) if h is None) + (f' ({why})' if why else ''))
+        windows = []
+        for r, h in enumerate(handles):
+          if r == self.rank:
+            windows.append(self.window)
+            continue
+          o = C.c_void_p()
+          _lib.check(L.il_peer_window_open(h, C.byref(o)))
+          self.opened.append(o.value)
+          windows.append(o.value)
+      except Exception:
+        self.close(collective=False)   # leave nothing mapped or allocated behind; create() turns this into a collective fall-back
+        raise
     self.status = torch.zeros(2, dtype=torch.int64, device=device)
     for k, n in self.sizes.items():
       epoch = torch.zeros((n + _lib.IL_PEER_CHUNK_FLOATS - 1) // _lib.IL_PEER_CHUNK_FLOATS, dtype=torch.int32, device=device)
@@ -169,9 +179,15 @@ class PeerExchange:
       dist.barrier(group)   # every window is mapped everywhere before the first store into a peer
     ok = _agree(x is not None, group)
     if ok:
-      ok = _agree(x.verify(verify_rounds), group)
+      try:
+        good = x.verify(verify_rounds)
+      except Exception as e:   # a HIP error in the self-test on this rank: still take part in the agreement
+        good, err = False, e
+      ok = _agree(good, group)
     if not ok:
-      if x is not None: x.close()
+      if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group)   # EVERY rank, with or without an exchange of its own: no kernel of the self-test is still storing into a window that is about to go away
+      if x is not None: x.close(collective=False)
       if err is not None and os.environ.get('IL_PEER_EXCHANGE') == 'require': raise err
       return None
     return x
@@ -201,11 +217,12 @@ class PeerExchange:
     torch.cuda.synchronize(self.device)
     return ok and self.timeouts() == 0
 
-  def close(self):
+  def close(self, collective: bool = True):
+    """collective=True: every rank of the group calls close() together (a barrier makes sure nobody unmaps a window a peer's kernel may still store into)."""
     L = _lib.lib()
     torch.cuda.synchronize(self.device)
-    if dist.is_initialized() and dist.get_world_size(self.group) > 1:
-      dist.barrier(self.group)   # nobody unmaps a window a peer's kernel may still store into
+    if collective and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+      dist.barrier(self.group)
     for o in self.opened: L.il_peer_window_close(C.c_void_p(o))
     if self.window: L.il_peer_window_free(C.c_void_p(self.window))
     self.opened, self.window, self.desc = [], None, {}

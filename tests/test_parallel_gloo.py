@@ -123,3 +123,44 @@ def test_all_reduce_mean_is_identity_without_process_group():
   from imitation_learning_amd import parallel
   t = torch.arange(8, dtype=torch.float32)
   assert torch.equal(parallel.all_reduce_mean_(t.clone()), t)
+
+
+def _peer_fallback_worker(rank, world, port, out_dir, scenario):
+  """PeerExchange.create() with a set-up failure on ONE rank only (faked library calls: there is no GPU here): every rank must come back with None - no rank may be left
+  waiting in a collective the failing rank never entered - so that DataParallelUpdate falls back to the collectives everywhere."""
+  sys.path.insert(0, ROOT)
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  import contextlib
+  import torch as _torch
+  from imitation_learning_amd import _lib, parallel
+  real = _lib.lib()
+
+  class Fake:
+    def __getattr__(self, name): return getattr(real, name)
+    def il_peer_window_alloc(self, total, wref, handle):
+      if scenario == 'alloc' and rank == 1: return 3
+      wref._obj.value = 0x1000 * (rank + 1)
+      return 0
+    def il_peer_window_open(self, h, oref):
+      if scenario == 'open' and rank == 0: return 3
+      oref._obj.value = 0x9000
+      return 0
+    def il_peer_window_close(self, p): return 0
+    def il_peer_window_free(self, p): return 0
+    def il_last_error(self): return b'faked failure'
+    def il_peer_allreduce_mean(self, d, b, st): return 3 if scenario == 'kernel' and rank == 1 else 0   # the self-test then raises (rank 1) or sees wrong values (rank 0)
+  _lib._lib = Fake()
+  _torch.cuda.device = lambda d: contextlib.nullcontext()
+  _torch.cuda.synchronize = lambda d=None: None
+  _lib.stream_ptr = lambda: None
+  x = parallel.PeerExchange.create(dict(critic=5000, actor=37), _torch.device('cpu'))
+  open(os.path.join(out_dir, f'{scenario}{rank}.txt'), 'w').write('none' if x is None else 'exchange')
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_peer_exchange_setup_failure_on_one_rank_falls_back_everywhere(tmp_path):
+  for scenario in ('alloc', 'open', 'kernel'):
+    mp.spawn(_peer_fallback_worker, args=(2, _free_port(), str(tmp_path), scenario), nprocs=2, join=True)
+    assert [open(tmp_path / f'{scenario}{r}.txt').read() for r in (0, 1)] == ['none', 'none'], scenario
