@@ -107,6 +107,7 @@ _SIGNATURES = {
     'il_peer_window_close': (C.c_int, [_P]),
     'il_peer_window_free': (C.c_int, [_P]),
     'il_peer_allreduce_mean': (C.c_int, [C.POINTER(PeerBucket), _P, _P]),
+    'il_sac_dp_phase_peer': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.c_int32, _P, _P, C.c_uint32, C.POINTER(PeerBucket), _P]),
     'il_last_error': (C.c_char_p, []),
     'il_abi_version': (C.c_int, []),
     'il_device_info': (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),

@@ -20,11 +20,10 @@
 // rank that never arrives makes the waiters count an expiry in status[0] and carry on, the host checks it (never a hang).
 #include <string.h>
 
-#include "il_common.hpp"
+#include "peer_device.hpp"
 
 static_assert(sizeof(hipIpcMemHandle_t) == IL_PEER_HANDLE_BYTES, "IL_PEER_HANDLE_BYTES must match hipIpcMemHandle_t");
 
-static inline int64_t peer_chunks(int64_t n) { return (n + IL_PEER_CHUNK_FLOATS - 1) / IL_PEER_CHUNK_FLOATS; }
 
 extern "C" int64_t il_peer_region_bytes(int32_t world, int64_t n) {
   if (world < 1 || world > IL_PEER_MAX_RANKS || n < 1) return -1;
@@ -73,77 +72,18 @@ extern "C" int il_peer_window_free(void* window) {
   return e == hipSuccess ? IL_OK : il_set_error(IL_ERR_HIP, "il_peer_window_free: %s", hipGetErrorString(e));
 }
 
-// region of one bucket inside a window: float slots[2][W][nch * CHUNK], then uint32 arrival[nch][IL_PEER_FLAG_STRIDE] (word r of a chunk's line = rank r's epoch).
-// Pointers are typed as global (address space 1) from the start: window bases come out of the kernel-argument array (generic), and generic accesses become FLAT ones.
-typedef __attribute__((address_space(1))) float gfloat;
-typedef __attribute__((address_space(1))) f32x4 gfloat4;
-typedef __attribute__((address_space(1))) uint32_t gu32;
-__device__ __forceinline__ gfloat* peer_slots(const il_peer_bucket& x, int r) { return (gfloat*)(static_cast<char*>(x.windows[r]) + x.window_offset); }
-__device__ __forceinline__ gu32* peer_arrival(const il_peer_bucket& x, int r, int64_t npad) { return (gu32*)(peer_slots(x, r) + 2 * (int64_t)x.world * npad); }
-
-#define IL_PEER_Q (IL_PEER_CHUNK_FLOATS / 4 / 256)   // 16-byte lanes per thread and chunk
 __global__ __launch_bounds__(256) void k_peer_allreduce(il_peer_bucket x, float* __restrict__ bucket_) {
-  const int c = blockIdx.x, tid = threadIdx.x, W = x.world, me = x.rank;
-  const int64_t npad = (int64_t)gridDim.x * IL_PEER_CHUNK_FLOATS, o = (int64_t)c * IL_PEER_CHUNK_FLOATS;
-  const int64_t left = x.n - o;
-  const int cnt = left < IL_PEER_CHUNK_FLOATS ? (int)left : IL_PEER_CHUNK_FLOATS;
-  const uint32_t e = ((gu32*)x.epoch)[c] + 1u;
-  const int64_t par = (int64_t)(e & 1u);
-  gfloat* bucket = (gfloat*)bucket_ + o;
-
-  // ---- push: this rank's chunk into slot [par][me] of every window (the slot is padded to whole chunks: whole 16-byte lanes, zero-filled past n)
-  f32x4 v[IL_PEER_Q];
-#pragma unroll
-  for (int j = 0; j < IL_PEER_Q; ++j) {
-    const int b = 4 * (tid + 256 * j);
-    if (b + 3 < cnt) v[j] = *(gfloat4*)(bucket + b);
-    else { float t[4]; for (int k = 0; k < 4; ++k) t[k] = b + k < cnt ? bucket[b + k] : 0.f; v[j] = f32x4{t[0], t[1], t[2], t[3]}; }
-  }
-  for (int i = 1; i <= W; ++i) {   // remote windows first (each over its own link), the local one last
-    const int r = (me + i) % W;
-    gfloat4* dst = (gfloat4*)(peer_slots(x, r) + (par * W + me) * npad + o);
-#pragma unroll
-    for (int j = 0; j < IL_PEER_Q; ++j) dst[tid + 256 * j] = v[j];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope, every thread: its stores have reached their windows before the barrier below
-  __syncthreads();
-  if (tid < W) __hip_atomic_store((uint32_t*)(peer_arrival(x, tid, npad) + (int64_t)c * IL_PEER_FLAG_STRIDE + me), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-
-  // ---- wait: all W arrival words of this chunk in the own window at epoch e (or later: a peer may already have pushed e + 1 into the other parity)
-  if (tid < IL_WAVE) {
-    uint32_t* mine = (uint32_t*)(peer_arrival(x, me, npad) + (int64_t)c * IL_PEER_FLAG_STRIDE);
-    const int limit = x.spin_limit > 0 ? x.spin_limit : IL_PEER_SPIN_LIMIT;
-    int spins = 0;
-    bool all = false;
-    for (;;) {
-      uint32_t f = e;
-      if (tid < W) f = __hip_atomic_load(mine + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      all = __builtin_amdgcn_ballot_w64((int32_t)(f - e) < 0) == 0ull;
-      if (all || ++spins > limit) break;
-      __builtin_amdgcn_s_sleep(8);
-    }
-    if (!all && tid == 0) __hip_atomic_fetch_add(reinterpret_cast<long long*>(x.status), 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: the peers' stores into this window are visible to this CU from here on
-
-  // ---- reduce: the W slabs of the chunk in rank order, then the mean
-  const gfloat* slab0 = peer_slots(x, me) + par * W * npad + o;
-  const float fw = (float)W;
+  f32x4 mean[IL_PEER_Q];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int cnt = peer_chunk_allreduce(x, bucket_, c, mean);
+  gfloat* bucket = (gfloat*)bucket_ + (int64_t)c * IL_PEER_CHUNK_FLOATS;
 #pragma unroll
   for (int j = 0; j < IL_PEER_Q; ++j) {
     const int b = 4 * (tid + 256 * j);
     if (b >= cnt) continue;
-    f32x4 acc = *(const gfloat4*)(slab0 + b);
-    for (int r = 1; r < W; ++r) {
-      const f32x4 t = *(const gfloat4*)(slab0 + r * npad + b);
-      acc[0] = __fadd_rn(acc[0], t[0]); acc[1] = __fadd_rn(acc[1], t[1]); acc[2] = __fadd_rn(acc[2], t[2]); acc[3] = __fadd_rn(acc[3], t[3]);
-    }
-    acc[0] = __fdiv_rn(acc[0], fw); acc[1] = __fdiv_rn(acc[1], fw); acc[2] = __fdiv_rn(acc[2], fw); acc[3] = __fdiv_rn(acc[3], fw);
-    if (b + 3 < cnt) *(gfloat4*)(bucket + b) = acc;
-    else { const float t[4] = {acc[0], acc[1], acc[2], acc[3]}; for (int k = 0; k < 4; ++k) if (b + k < cnt) bucket[b + k] = t[k]; }
+    if (b + 3 < cnt) *(gfloat4*)(bucket + b) = mean[j];
+    else { const float t[4] = {mean[j][0], mean[j][1], mean[j][2], mean[j][3]}; for (int k = 0; k < 4; ++k) if (b + k < cnt) bucket[b + k] = t[k]; }
   }
-  if (tid == 0) ((gu32*)x.epoch)[c] = e;   // every thread read epoch[c] before the first barrier
 }
 
 extern "C" int il_peer_allreduce_mean(const il_peer_bucket* x, float* bucket, il_stream_t stream_) {

@@ -1,0 +1,80 @@
+// Device side of the peer-window gradient exchange (include/il_hip.h il_peer_*; protocol notes at the top of peer.hip).
+#pragma once
+#include "il_common.hpp"
+
+// region of one bucket inside a window: float slots[2][W][nch * CHUNK], then uint32 arrival[nch][IL_PEER_FLAG_STRIDE] (word r of a chunk's line = rank r's epoch).
+// Pointers are typed as global (address space 1) from the start: window bases come out of the kernel-argument array (generic), and generic accesses become FLAT ones.
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) f32x4 gfloat4;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+__host__ __device__ inline int64_t peer_chunks(int64_t n) { return (n + IL_PEER_CHUNK_FLOATS - 1) / IL_PEER_CHUNK_FLOATS; }
+__device__ __forceinline__ gfloat* peer_slots(const il_peer_bucket& x, int r) { return (gfloat*)(static_cast<char*>(x.windows[r]) + x.window_offset); }
+__device__ __forceinline__ gu32* peer_arrival(const il_peer_bucket& x, int r, int64_t npad) { return (gu32*)(peer_slots(x, r) + 2 * (int64_t)x.world * npad); }
+
+#define IL_PEER_Q (IL_PEER_CHUNK_FLOATS / 4 / 256)   // 16-byte lanes per thread and chunk
+// One workgroup (256 threads, all of them, convergent: contains barriers) exchanges chunk `c` of `bucket_`: push into slot [parity][rank] of every window, release the
+// epoch, wait for all ranks' arrival words, rank-ordered sum / W. Returns the number of valid floats in the chunk; mean[j] = the mean of the 16-byte lane
+// b = 4 * (tid + 256 j) of the chunk (undefined for b >= the return value). The caller stores them (k_peer_allreduce) or consumes them in place (the fused apply kernels).
+__device__ __forceinline__ int peer_chunk_allreduce(const il_peer_bucket& x, const float* __restrict__ bucket_, int c, f32x4 (&mean)[IL_PEER_Q]) {
+  const int tid = threadIdx.x, W = x.world, me = x.rank;
+  const int64_t npad = peer_chunks(x.n) * IL_PEER_CHUNK_FLOATS, o = (int64_t)c * IL_PEER_CHUNK_FLOATS;
+  const int64_t left = x.n - o;
+  const int cnt = left < IL_PEER_CHUNK_FLOATS ? (int)left : IL_PEER_CHUNK_FLOATS;
+  const uint32_t e = ((gu32*)x.epoch)[c] + 1u;
+  const int64_t par = (int64_t)(e & 1u);
+  const gfloat* bucket = (const gfloat*)bucket_ + o;
+
+  // ---- push: this rank's chunk into slot [par][me] of every window (the slot is padded to whole chunks: whole 16-byte lanes, zero-filled past n)
+  f32x4 v[IL_PEER_Q];
+#pragma unroll
+  for (int j = 0; j < IL_PEER_Q; ++j) {
+    const int b = 4 * (tid + 256 * j);
+    if (b + 3 < cnt) v[j] = *(const gfloat4*)(bucket + b);
+    else { float t[4]; for (int k = 0; k < 4; ++k) t[k] = b + k < cnt ? bucket[b + k] : 0.f; v[j] = f32x4{t[0], t[1], t[2], t[3]}; }
+  }
+  for (int i = 1; i <= W; ++i) {   // remote windows first (each over its own link), the local one last
+    const int r = (me + i) % W;
+    gfloat4* dst = (gfloat4*)(peer_slots(x, r) + (par * W + me) * npad + o);
+#pragma unroll
+    for (int j = 0; j < IL_PEER_Q; ++j) dst[tid + 256 * j] = v[j];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope, every thread: its stores have reached their windows before the barrier below
+  __syncthreads();
+  if (tid < W) __hip_atomic_store((uint32_t*)(peer_arrival(x, tid, npad) + (int64_t)c * IL_PEER_FLAG_STRIDE + me), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+
+  // ---- wait: all W arrival words of this chunk in the own window at epoch e (or later: a peer may already have pushed e + 1 into the other parity)
+  if (tid < IL_WAVE) {
+    uint32_t* mine = (uint32_t*)(peer_arrival(x, me, npad) + (int64_t)c * IL_PEER_FLAG_STRIDE);
+    const int limit = x.spin_limit > 0 ? x.spin_limit : IL_PEER_SPIN_LIMIT;
+    int spins = 0;
+    bool all = false;
+    for (;;) {
+      uint32_t f = e;
+      if (tid < W) f = __hip_atomic_load(mine + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      all = __builtin_amdgcn_ballot_w64((int32_t)(f - e) < 0) == 0ull;
+      if (all || ++spins > limit) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (!all && tid == 0) __hip_atomic_fetch_add(reinterpret_cast<long long*>(x.status), 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: the peers' stores into this window are visible to this CU from here on
+
+  // ---- reduce: the W slabs of the chunk in rank order, then the mean
+  const gfloat* slab0 = peer_slots(x, me) + par * W * npad + o;
+  const float fw = (float)W;
+#pragma unroll
+  for (int j = 0; j < IL_PEER_Q; ++j) {
+    const int b = 4 * (tid + 256 * j);
+    if (b >= cnt) { mean[j] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+    f32x4 acc = *(const gfloat4*)(slab0 + b);
+    for (int r = 1; r < W; ++r) {
+      const f32x4 t = *(const gfloat4*)(slab0 + r * npad + b);
+      acc[0] = __fadd_rn(acc[0], t[0]); acc[1] = __fadd_rn(acc[1], t[1]); acc[2] = __fadd_rn(acc[2], t[2]); acc[3] = __fadd_rn(acc[3], t[3]);
+    }
+    acc[0] = __fdiv_rn(acc[0], fw); acc[1] = __fdiv_rn(acc[1], fw); acc[2] = __fdiv_rn(acc[2], fw); acc[3] = __fdiv_rn(acc[3], fw);
+    mean[j] = acc;
+  }
+  if (tid == 0) ((gu32*)x.epoch)[c] = e;   // every thread read epoch[c] before the first barrier
+  return cnt;
+}

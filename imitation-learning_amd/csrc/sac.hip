@@ -14,6 +14,7 @@
 // Parameters, Adam moments and the target network are each read and written exactly once per update (24 B/param + 8 B/param).
 #include "il_common.hpp"
 #include "mlp_tile.hpp"
+#include "peer_device.hpp"
 #include "disc_reward.hpp"
 
 
@@ -1501,6 +1502,91 @@ __global__ __launch_bounds__(256) void k_apply_actor_tail(il_sac d, int n_actor_
   for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < 2 * (int64_t)H * H; i += (int64_t)ntb * blockDim.x) pt[i] = __fadd_rn(__fmul_rn(pt[i], tau), __fmul_rn(omt, pc[i]));   // PF copies only (see actor_dw_args)
 }
 
+// ---------------------------------------------------------------------------------------------
+// The apply launches of phases 2 and 3 with the gradient exchange built in (il_sac_dp_phase_peer): workgroup c exchanges chunk c of the bucket with the other ranks
+// (peer_chunk_allreduce: the body of k_peer_allreduce) and steps the parameters of that chunk with the means it holds in registers - one launch and one pass over the
+// gradient arena less per sync point than il_peer_allreduce_mean + il_sac_dp_phase. Same means (rank-ordered sum / W), same AdamW operations: bit-identical to that sequence.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_peer_apply_critic(il_sac d, il_peer_bucket x) {
+  f32x4 mean[IL_PEER_Q];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int cnt = peer_chunk_allreduce(x, d.critic_grad, c, mean);
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, IN = S + A;
+  const SacWs ws = sac_ws(S, A, H, d.batch);
+  const int64_t ns = net_stride(IN, H, 1), HH = (int64_t)H * H, oW2 = (int64_t)H * IN + H;
+  const adam_consts ac = load_adam_consts(d.critic_opt);
+#pragma unroll
+  for (int j = 0; j < IL_PEER_Q; ++j) {
+    const int b0 = 4 * (tid + 256 * j);
+    if (b0 >= cnt) continue;
+    const int64_t e0 = (int64_t)c * IL_PEER_CHUNK_FLOATS + b0;
+    const bool whole = b0 + 3 < cnt;   // the arenas are 16-byte aligned and a chunk starts at a multiple of 2,048 floats: whole 16-byte lanes except at the very end
+    f32x4 p4 = zero4(), m4 = zero4(), v4 = zero4();
+    if (whole) { p4 = gload4(d.critic + e0); m4 = gload4(d.critic_opt.m + e0); v4 = gload4(d.critic_opt.v + e0); }
+    else for (int q = 0; q < 4; ++q) if (b0 + q < cnt) { p4[q] = d.critic[e0 + q]; m4[q] = d.critic_opt.m[e0 + q]; v4[q] = d.critic_opt.v[e0 + q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { float pp = p4[q], mm = m4[q], vv = v4[q]; adam_update(pp, mean[j][q], mm, vv, ac); p4[q] = pp; m4[q] = mm; v4[q] = vv; }
+    if (whole) { *reinterpret_cast<f32x4*>(d.critic + e0) = p4; *reinterpret_cast<f32x4*>(d.critic_opt.m + e0) = m4; *reinterpret_cast<f32x4*>(d.critic_opt.v + e0) = v4; }
+    else for (int q = 0; q < 4; ++q) if (b0 + q < cnt) { d.critic[e0 + q] = p4[q]; d.critic_opt.m[e0 + q] = m4[q]; d.critic_opt.v[e0 + q] = v4[q]; }
+    for (int q = 0; q < 4; ++q) {
+      if (b0 + q >= cnt) break;
+      const int64_t e = e0 + q;
+      const int k = e >= ns; const int64_t o = e - k * ns - oW2;
+      if (o >= 0 && o < HH) {  // an element of a hidden-layer matrix: keep its two lane-ordered copies in step
+        const int n = (int)(o / H), kk = (int)(o - (int64_t)n * H);
+        d.workspace[ws.pk_cf + k * HH + packed_fwd_index(n, kk, H)] = p4[q];
+        d.workspace[ws.pk_cb + k * HH + packed_bwd_index(n, kk, H)] = p4[q];
+      }
+    }
+  }
+}
+
+// blocks [0, n_chunks): the chunks of the actor bucket (actor gradient | log-alpha gradient | padding); the blocks behind them: polyak, as in k_apply_actor_tail
+__global__ __launch_bounds__(256) void k_peer_apply_actor_tail(il_sac d, int n_chunks, il_peer_bucket x) {
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, IN = S + A;
+  if ((int)blockIdx.x < n_chunks) {
+    f32x4 mean[IL_PEER_Q];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int cnt = peer_chunk_allreduce(x, d.actor_grad, c, mean);   // the bucket starts at the actor gradient; the log-alpha gradient sits at offset alpha_grad - actor_grad
+    const int64_t Pa = mlp_numel(S, H, 2 * A), alpha_at = d.alpha_grad - d.actor_grad;
+    const adam_consts ac = load_adam_consts(d.actor_opt);
+    const SacWs wsa = sac_ws(S, A, H, d.batch);
+    const int64_t oW2 = (int64_t)H * S + H, HH = (int64_t)H * H;
+#pragma unroll
+    for (int j = 0; j < IL_PEER_Q; ++j) {
+      const int b0 = 4 * (tid + 256 * j);
+      for (int q = 0; q < 4; ++q) {
+        if (b0 + q >= cnt) break;
+        const int64_t e = (int64_t)c * IL_PEER_CHUNK_FLOATS + b0 + q;
+        if (e < Pa) {
+          float pp = d.actor[e], mm = d.actor_opt.m[e], vv = d.actor_opt.v[e];
+          adam_update(pp, mean[j][q], mm, vv, ac);
+          d.actor[e] = pp; d.actor_opt.m[e] = mm; d.actor_opt.v[e] = vv;
+          const int64_t o = e - oW2;
+          if (o >= 0 && o < HH) {
+            const int n = (int)(o / H), kk = (int)(o - (int64_t)n * H);
+            d.workspace[wsa.pk_af + packed_fwd_index(n, kk, H)] = pp;
+            d.workspace[wsa.pk_ab + packed_bwd_index(n, kk, H)] = pp;
+          }
+        } else if (e == alpha_at) {
+          const adam_consts aa = load_adam_consts(d.alpha_opt);
+          float pp = d.log_alpha[0], mm = d.alpha_opt.m[0], vv = d.alpha_opt.v[0];
+          adam_update(pp, mean[j][q], mm, vv, aa);
+          d.log_alpha[0] = pp; d.alpha_opt.m[0] = mm; d.alpha_opt.v[0] = vv;
+        }
+      }
+    }
+    return;
+  }
+  const int tb = (int)blockIdx.x - n_chunks, ntb = (int)gridDim.x - n_chunks;
+  const int64_t n = 2 * net_stride(IN, H, 1);
+  const float omt = (float)(1.0 - d.polyak), tau = (float)d.polyak;
+  for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < n; i += (int64_t)ntb * blockDim.x) d.target[i] = __fadd_rn(__fmul_rn(d.target[i], tau), __fmul_rn(omt, d.critic[i]));
+  const SacWs ws = sac_ws(S, A, H, d.batch);
+  float* pt = d.workspace + ws.pk_tf; const float* pc = d.workspace + ws.pk_cf;
+  for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < 2 * (int64_t)H * H; i += (int64_t)ntb * blockDim.x) pt[i] = __fadd_rn(__fmul_rn(pt[i], tau), __fmul_rn(omt, pc[i]));   // PF copies only (see actor_dw_args)
+}
+
 extern "C" int il_sac_dp_phase(const il_sac* d, const il_batch* b, int32_t phase, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream_) {
   if (int rc = check_sac(d, b)) return rc;
   IL_CHECK_ARG(phase >= 0 && phase <= 3, "il_sac_dp_phase: phase must be 0..3");
@@ -1532,6 +1618,32 @@ extern "C" int il_sac_dp_phase(const il_sac* d, const il_batch* b, int32_t phase
     { IL_TRACE("k_apply_actor_tail", st); k_apply_actor_tail<<<na + 64, 256, 0, st>>>(*d, na); }
   }
   IL_CHECK_LAUNCH("il_sac_dp_phase");
+  return IL_OK;
+}
+
+extern "C" int il_sac_dp_phase_peer(const il_sac* d, const il_batch* b, int32_t phase, float* out_logp, float* out_q, uint32_t flags, const il_peer_bucket* x, il_stream_t stream_) {
+  if (int rc = check_sac(d, b)) return rc;
+  IL_CHECK_ARG(phase == 2 || phase == 3, "il_sac_dp_phase_peer: phases 2 and 3 begin with an apply step (got %d)", phase);
+  IL_CHECK_ARG(d->actor_grad && d->critic_grad && d->alpha_grad, "il_sac_dp_phase_peer: gradient arenas missing");
+  IL_CHECK_ARG(x && x->world >= 1 && x->world <= IL_PEER_MAX_RANKS && x->rank >= 0 && x->rank < x->world && x->epoch && x->status, "il_sac_dp_phase_peer: bad peer descriptor");
+  for (int r = 0; r < x->world; ++r) IL_CHECK_ARG(x->windows[r], "il_sac_dp_phase_peer: window of rank %d is not mapped", r);
+  hipStream_t st = (hipStream_t)stream_;
+  const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
+  const size_t lds = tile_lds_bytes(round_up16(S + A), H);
+  if (phase == 2) {
+    IL_CHECK_ARG(x->n == 2 * net_stride(S + A, H, 1), "il_sac_dp_phase_peer: phase 2 takes the critic bucket (%lld floats, got %lld)", (long long)(2 * net_stride(S + A, H, 1)), (long long)x->n);
+    { IL_TRACE("k_peer_apply_critic", st); k_peer_apply_critic<<<(unsigned)peer_chunks(x->n), 256, 0, st>>>(*d, *x); }
+    { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
+    DwArgs aa = actor_dw_args(d, b, IL_FLAG_GRADS_ONLY);
+    { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 1, 256, 0, st>>>(aa); }
+  } else {
+    const int64_t Pa = mlp_numel(S, H, 2 * A), alpha_at = d->alpha_grad - d->actor_grad;
+    IL_CHECK_ARG(alpha_at >= Pa && alpha_at < x->n, "il_sac_dp_phase_peer: phase 3 takes the actor bucket: actor_grad | alpha_grad must be one allocation of %lld floats (GradBuckets)", (long long)x->n);
+    const int nc = (int)peer_chunks(x->n);
+    { IL_TRACE("k_peer_apply_actor_tail", st); k_peer_apply_actor_tail<<<nc + 64, 256, 0, st>>>(*d, nc, *x); }
+  }
+  (void)flags;
+  IL_CHECK_LAUNCH("il_sac_dp_phase_peer");
   return IL_OK;
 }
 

@@ -548,6 +548,12 @@ int il_peer_window_free(void* window);   /* a window obtained from il_peer_windo
  * sequence of calls per bucket (like a collective). */
 int il_peer_allreduce_mean(const il_peer_bucket* x, float* bucket, il_stream_t stream);
 
+/* il_sac_dp_phase(2) / (3) with the gradient exchange of the phase's bucket carried by its apply launch: workgroup c exchanges chunk c (the body of
+ * il_peer_allreduce_mean) and steps that chunk's parameters with the means it holds in registers - one launch and one pass over the gradient arena less per sync
+ * point. x = the descriptor of the critic bucket (phase 2: il_sac.critic_grad, 2 * il_mlp_stride floats) or of the actor bucket (phase 3: il_sac.actor_grad with
+ * il_sac.alpha_grad inside the same allocation, parallel.GradBuckets). Bit-identical to il_peer_allreduce_mean(x, bucket) followed by il_sac_dp_phase. */
+int il_sac_dp_phase_peer(const il_sac* d, const il_batch* batch, int32_t phase, float* out_logp, float* out_q, uint32_t flags, const il_peer_bucket* x, il_stream_t stream);
+
 /* sizeof() of the descriptor structs in this build (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red,
  * 7 il_dril, 8 il_disc_shaped, 9 il_disc_deep, 10 il_peer_bucket; -1 otherwise): lets a binding verify its own struct definitions. */
 int32_t il_struct_size(int32_t which);

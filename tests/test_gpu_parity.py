@@ -417,15 +417,16 @@ def test_update_plan_host_and_device_index_draws_agree():
     np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize('exchange', ['none', 'peer_windows'])
+@pytest.mark.parametrize('exchange', ['none', 'peer_windows', 'peer_windows_in_apply'])
 def test_data_parallel_path_equals_fused_path_on_one_rank(monkeypatch, exchange):
   """DataParallelUpdate (IL_FLAG_GRADS_ONLY kernels -> [all-reduce] -> apply kernels) must evolve a learner like the fused UpdatePlan:
   with one rank the all-reduce is the identity, so any difference would be a bug in the split path the multi-GPU run uses.
-  exchange = 'peer_windows': one il_peer_allreduce_mean launch per sync point with a world of one rank (the gradients travel through the window's slot and back);
-  'none': no exchange is enqueued."""
+  exchange = 'peer_windows': the peer-window exchange with a world of one rank (the gradients travel through the window's slot and back), one il_peer_allreduce_mean launch per
+  sync point; 'peer_windows_in_apply': the critic / actor exchanges inside the apply launches (il_sac_dp_phase_peer, IL_PEER_APPLY=1); 'none': no exchange is enqueued."""
   from imitation_learning_amd.parallel import DataParallelUpdate
   if exchange != 'none':
     monkeypatch.setenv('IL_PEER_EXCHANGE', 'require')
+    monkeypatch.setenv('IL_PEER_APPLY', '1' if exchange == 'peer_windows_in_apply' else '0')
   outs = []
   for dp in (False, True):
     il.seed(21)

@@ -56,16 +56,17 @@ def _launch(args, cwd, timeout=600, **extra_env):
   return r
 
 
-@pytest.mark.parametrize('algorithm,handoff,peer', [('GAIL', '1', '1'), ('GAIL', '0', '1'), ('SAC', '0', '1')])
+@pytest.mark.parametrize('algorithm,handoff,peer', [('GAIL', '1', '1'), ('GAIL', '0', '1'), ('SAC', '0', '1'), ('GAIL', '0', 'in_apply')])
 def test_two_ranks_keep_bit_identical_replicas(tmp_path, algorithm, handoff, peer):
   """handoff = '1': the device-side hand-off schedule of DataParallelUpdate (resident index draw, inline relabel, one communicator per branch); '0': stream dependencies.
-  peer = '1': the gradient exchange is the one-kernel push / rank-ordered sum over peer-mapped windows (csrc/peer.hip; the two processes map each other's window through
-  hipIpc exactly as two GPUs would); '0' (gloo all-reduces) is covered by test_peer_exchange_equals_the_collective."""
+  The gradient exchange runs over peer-mapped windows (csrc/peer.hip; the two processes map each other's window through hipIpc exactly as two GPUs would): peer = '1' with one
+  il_peer_allreduce_mean launch per sync point, 'in_apply' with the critic / actor exchanges inside the apply launches (il_sac_dp_phase_peer, IL_PEER_APPLY=1); gloo all-reduces
+  are covered by test_peer_exchange_equals_the_collective."""
   script = tmp_path / 'worker.py'
   script.write_text(WORKER)
-  _launch([str(script), ROOT, str(tmp_path), algorithm], str(tmp_path), IL_DP_HANDOFF=handoff, IL_PEER_EXCHANGE='require' if peer == '1' else '0')
+  _launch([str(script), ROOT, str(tmp_path), algorithm], str(tmp_path), IL_DP_HANDOFF=handoff, IL_PEER_EXCHANGE='require', IL_PEER_APPLY='1' if peer == 'in_apply' else '0')
   r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
-  assert [int(r0['peer'][0]), int(r1['peer'][0])] == [int(peer)] * 2
+  assert [int(r0['peer'][0]), int(r1['peer'][0])] == [1, 1]
   assert int(r0['peer'][1]) == 0 and int(r1['peer'][1]) == 0, 'a device-side wait of the peer-window exchange expired'
   if algorithm == 'GAIL':
     assert [int(r0['handoff'][0]), int(r1['handoff'][0])] == [int(handoff)] * 2
