@@ -15,7 +15,7 @@
 // A cannot push e+2 before B has pushed e+1, which B does after its epoch-e kernel has finished. Epochs are per-chunk device counters advanced by the kernel
 // itself, so a captured graph replays correctly.
 //
-// Windows are fine-grained device allocations shared through hipIpc handles (what RCCL does for its own buffers); stores / flags / polls use system-scope
+// Windows are uncached (failing that, fine-grained) device allocations shared through hipIpc handles (what RCCL does for its own buffers); stores / flags / polls use system-scope
 // release / acquire so that hipcc emits the cache maintenance gfx950 needs for memory another agent writes. Waits are bounded (il_peer_bucket.spin_limit): a
 // rank that never arrives makes the waiters count an expiry in status[0] and carry on, the host checks it (never a hang).
 #include <string.h>

@@ -538,7 +538,7 @@ typedef struct il_peer_bucket {
 } il_peer_bucket;
 /* bytes of a bucket's region: slots float[2 parities][world][n rounded up to chunks] + arrival words; -1 on bad arguments */
 int64_t il_peer_region_bytes(int32_t world, int64_t n);
-/* zero-filled fine-grained device allocation on the current device + its IPC handle (IL_PEER_HANDLE_BYTES bytes, host) */
+/* zero-filled uncached (failing that, fine-grained) device allocation on the current device + its IPC handle (IL_PEER_HANDLE_BYTES bytes, host) */
 int il_peer_window_alloc(int64_t bytes, void** window_host, unsigned char* handle_host);
 /* maps another rank's window (a handle produced by il_peer_window_alloc in ANOTHER process) into this process */
 int il_peer_window_open(const unsigned char* handle_host, void** window_host);
