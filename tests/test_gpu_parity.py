@@ -528,34 +528,42 @@ def test_gail_ragged_batch_and_state_only():
     close(N(d.predict_reward(T(pb['states']), T(pb['actions']))), ogail.predict_reward(ods, cat(pb)), 'reward', rtol=1e-4, atol_scale=1e-5)
 
 
+def _population_learners(n):
+  """n independent GAIL learners (own networks, rings, index streams, Philox counters) as UpdatePlans, reproducibly."""
+  il_training._NOISE.clear(); il_training._WS.clear()
+  plans, nets_all = [], []
+  for l in range(n):
+    S, A = gi.DIMS['halfcheetah']
+    torch.manual_seed(30 + l)
+    cfg = Cfg(hidden_size=256, depth=2, activation='relu')
+    actor, critic = il.SoftActor(S, A, cfg, device=DEV), il.TwinCritic(S, A, cfg, device=DEV)
+    target, log_alpha = il.create_target_network(critic), torch.zeros(1, device=DEV)
+    ao, co, to = il.AdamW(actor, lr=3e-4, weight_decay=0), il.AdamW(critic, lr=3e-4, weight_decay=0), il.Adam(log_alpha, lr=3e-4)
+    rs = np.random.RandomState(30 + l)
+    mem = il.ReplayMemory(20000, S, A, True, device=DEV); fill_memory(mem, gi.transitions(rs, 5000, S, A), 5000)
+    emem = il.ReplayMemory(2000, S, A, True, device=DEV); fill_memory(emem, gi.transitions(rs, 2000, S, A, state_shift=0.5), 2000)
+    mem.index_rng = il.IndexStream(100 + l)
+    icfg = Cfg(state_only=False, spectral_norm=True, loss_function='BCE', grad_penalty=1.0, entropy_bonus=0.0,
+               discriminator=Cfg(hidden_size=64, depth=1, activation='relu', reward_shaping=False, subtract_log_policy=False, reward_function='AIRL'))
+    disc = il.GAILDiscriminator(S, A, icfg, 0.97, device=DEV)
+    do = il.AdamW(disc, lr=3e-5, weight_decay=10)
+    plans.append(il.UpdatePlan('GAIL', actor, critic, log_alpha, target, mem, ao, co, to, 256, 0.97, -0.5 * A, 0.99, expert_memory=emem, discriminator=disc,
+                               discriminator_optimiser=do, imitation_cfg=icfg, overlap=False, learner_id=l))
+    nets_all.append((actor, critic, target, log_alpha, disc))
+  return plans, nets_all
+
+
+def _population_state(plans, nets_all):
+  torch.cuda.synchronize()
+  return [[N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [N(p.idx), N(p.logp), N(p.rewards)] for nets, p in zip(nets_all, plans)]
+
+
 def test_batched_population_equals_independent_learners():
   """The population axis must not couple learners: L learners advanced by the il_*_population launches evolve exactly like the same
   L learners advanced one by one (same seeds, own index streams, own Philox counters)."""
-  def make(l):
-    plan, nets = _make_plan('GAIL', 30 + l)
-    return plan, nets
   results = []
   for batched in (False, True):
-    il_training._NOISE.clear(); il_training._WS.clear()
-    plans, nets_all = [], []
-    for l in range(3):
-      S, A = gi.DIMS['halfcheetah']
-      torch.manual_seed(30 + l)
-      cfg = Cfg(hidden_size=256, depth=2, activation='relu')
-      actor, critic = il.SoftActor(S, A, cfg, device=DEV), il.TwinCritic(S, A, cfg, device=DEV)
-      target, log_alpha = il.create_target_network(critic), torch.zeros(1, device=DEV)
-      ao, co, to = il.AdamW(actor, lr=3e-4, weight_decay=0), il.AdamW(critic, lr=3e-4, weight_decay=0), il.Adam(log_alpha, lr=3e-4)
-      rs = np.random.RandomState(30 + l)
-      mem = il.ReplayMemory(20000, S, A, True, device=DEV); fill_memory(mem, gi.transitions(rs, 5000, S, A), 5000)
-      emem = il.ReplayMemory(2000, S, A, True, device=DEV); fill_memory(emem, gi.transitions(rs, 2000, S, A, state_shift=0.5), 2000)
-      mem.index_rng = il.IndexStream(100 + l)
-      icfg = Cfg(state_only=False, spectral_norm=True, loss_function='BCE', grad_penalty=1.0, entropy_bonus=0.0,
-                 discriminator=Cfg(hidden_size=64, depth=1, activation='relu', reward_shaping=False, subtract_log_policy=False, reward_function='AIRL'))
-      disc = il.GAILDiscriminator(S, A, icfg, 0.97, device=DEV)
-      do = il.AdamW(disc, lr=3e-5, weight_decay=10)
-      plans.append(il.UpdatePlan('GAIL', actor, critic, log_alpha, target, mem, ao, co, to, 256, 0.97, -0.5 * A, 0.99, expert_memory=emem, discriminator=disc,
-                                 discriminator_optimiser=do, imitation_cfg=icfg, overlap=False, learner_id=l))
-      nets_all.append((actor, critic, target, log_alpha, disc))
+    plans, nets_all = _population_learners(3)
     if batched:
       pop = il.BatchedPopulationPlan(plans)
       for _ in range(3):
@@ -564,13 +572,43 @@ def test_batched_population_equals_independent_learners():
       for _ in range(3):
         for p in plans:
           p.run()
-    torch.cuda.synchronize()
-    results.append([[N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [N(p.idx), N(p.logp), N(p.rewards)] for nets, p in zip(nets_all, plans)])
+    results.append(_population_state(plans, nets_all))
   for l, (a_l, b_l) in enumerate(zip(*results)):
     for i, (a, b) in enumerate(zip(a_l, b_l)):
       assert np.isfinite(a).all()
       np.testing.assert_array_equal(a, b, err_msg=f'learner {l}, tensor {i}')
   assert not np.array_equal(results[0][0][0], results[0][1][0])  # the learners really are different
+
+
+def test_population_xcd_decode_and_groups_are_bit_identical():
+  """With 8 or more learners the population launches re-decode the linear workgroup id so that learner l sits on XCD l % 8 (pop_ids: full groups of 8 learners interleaved, the
+  rest in natural order), and `groups` cuts the population into sub-populations replayed as parallel graph branches. Both are pure re-labelling / re-scheduling: 18 learners
+  (two full groups + a tail of two) advanced by one population, by two sub-populations of nine (one full group + a tail each) through a captured graph, and one by one must
+  end in the same bits."""
+  results = {}
+  for how in ('one by one', 'population', 'two groups, captured'):
+    plans, nets_all = _population_learners(18)
+    if how == 'one by one':
+      for _ in range(3):
+        for p in plans:
+          p.run()
+    elif how == 'population':
+      pop = il.BatchedPopulationPlan(plans, groups=1)
+      for _ in range(3):
+        pop.run()
+    else:
+      pop = il.BatchedPopulationPlan(plans, groups=2)
+      pop.run()
+      torch.cuda.synchronize()
+      pop.capture()
+      for _ in range(2):
+        pop.replay()
+    results[how] = _population_state(plans, nets_all)
+  ref = results['one by one']
+  for how in ('population', 'two groups, captured'):
+    for l, (a_l, b_l) in enumerate(zip(ref, results[how])):
+      for i, (a, b) in enumerate(zip(a_l, b_l)):
+        np.testing.assert_array_equal(a, b, err_msg=f'{how}: learner {l}, tensor {i}')
 
 
 @pytest.mark.gpu
