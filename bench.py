@@ -422,7 +422,7 @@ def main():
                config=dict(workload='algorithm=GAIL env=halfcheetah: 2 replay samples + discriminator step (BCE+GP+SN) + AIRL relabel + sac_update per step',
                            batch_per_gpu=B, global_batch=B * world, state_dim=S, action_dim=A, hidden=H, replay_capacity=1_000_000, replay_fill=100_000, expert_rows=25_000,
                            learners_per_gpu=args.learners, parallelism=f'dp{world}' + ('(split path' + (', device hand-off between the discriminator and SAC branches, own communicator per branch)' if getattr(runner, 'handoff', False) else ', stream dependencies)') if runner is not plan else ''), launch=launch, noise='on-chip Philox4x32-10', finite=finite,
-                           gradient_exchange=(None if runner is plan else ('one kernel per sync point over peer-mapped windows (il_peer_allreduce_mean: push to every rank, rank-ordered sum)'
+                           gradient_exchange=(None if runner is plan else ('one kernel per sync point over peer-mapped windows (il_peer_allreduce_mean: push to every rank, rank-ordered sum; ' + ('write-through payload, no fences' if getattr(runner.peer, 'form', 0) else 'system-scope fences') + ')'
                                                                              if getattr(runner, 'peer', None) is not None else 'RCCL all-reduce (AVG) per sync point')),
                            branch_sync=('device counters (two graphs, no cross-stream edge)' if getattr(plan, 'device_sync', False) and runner is plan else 'stream dependencies'),
                            rows=('read from the rings through the drawn indices (il_batch.gather), relabel inline in k_sac_chain' if getattr(plan, 'inline_relabel', False) and runner is plan

@@ -91,18 +91,18 @@ class SampleArgs(C.Structure):
               ('ring_state_b', C.c_void_p), ('ring_b', C.c_void_p), ('capacity_b', C.c_int64), ('row_floats_b', C.c_int32), ('idx_b', C.c_void_p), ('rows_b', C.c_void_p)]
 
 
-IL_PEER_MAX_RANKS, IL_PEER_HANDLE_BYTES, IL_PEER_CHUNK_FLOATS = 16, 64, 2048
+IL_PEER_MAX_RANKS, IL_PEER_HANDLE_BYTES, IL_PEER_CHUNK_FLOATS, IL_PEER_WRITE_THROUGH = 16, 64, 2048, 1
 
 
 class PeerBucket(C.Structure):
   _fields_ = [('rank', C.c_int32), ('world', C.c_int32), ('n', C.c_int64), ('window_offset', C.c_int64), ('windows', C.c_void_p * IL_PEER_MAX_RANKS),
-              ('epoch', C.c_void_p), ('status', C.c_void_p), ('spin_limit', C.c_int32), ('reserved', C.c_int32)]
+              ('epoch', C.c_void_p), ('status', C.c_void_p), ('spin_limit', C.c_int32), ('flags', C.c_int32)]
 
 
 _P = C.c_void_p
 _SIGNATURES = {
     'il_peer_region_bytes': (C.c_int64, [C.c_int32, C.c_int64]),
-    'il_peer_window_alloc': (C.c_int, [C.c_int64, C.POINTER(C.c_void_p), C.c_char_p]),
+    'il_peer_window_alloc': (C.c_int, [C.c_int64, C.POINTER(C.c_void_p), C.c_char_p, C.POINTER(C.c_int32)]),
     'il_peer_window_open': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     'il_peer_window_close': (C.c_int, [_P]),
     'il_peer_window_free': (C.c_int, [_P]),

@@ -15,8 +15,9 @@
 // A cannot push e+2 before B has pushed e+1, which B does after its epoch-e kernel has finished. Epochs are per-chunk device counters advanced by the kernel
 // itself, so a captured graph replays correctly.
 //
-// Windows are uncached (failing that, fine-grained) device allocations shared through hipIpc handles (what RCCL does for its own buffers); stores / flags / polls use system-scope
-// release / acquire so that hipcc emits the cache maintenance gfx950 needs for memory another agent writes. Waits are bounded (il_peer_bucket.spin_limit): a
+// Windows are uncached (failing that, fine-grained) device allocations shared through hipIpc handles (what RCCL does for its own buffers). Two forms (peer_device.hpp): stores /
+// flags / polls with the compiler's system-scope release / acquire fences, or - uncached windows only - the payload through sc0 sc1 (write-through / cache-bypassing)
+// accesses with drained stores and no fence; PeerExchange adopts a form only after a bitwise self-test with it on every rank. Waits are bounded (il_peer_bucket.spin_limit): a
 // rank that never arrives makes the waiters count an expiry in status[0] and carry on, the host checks it (never a hang).
 #include <string.h>
 
@@ -32,12 +33,13 @@ extern "C" int64_t il_peer_region_bytes(int32_t world, int64_t n) {
   return (bytes + 255) / 256 * 256;
 }
 
-extern "C" int il_peer_window_alloc(int64_t bytes, void** window_host, unsigned char* handle_host) {
-  IL_CHECK_ARG(bytes > 0 && window_host && handle_host, "il_peer_window_alloc: bad arguments");
+extern "C" int il_peer_window_alloc(int64_t bytes, void** window_host, unsigned char* handle_host, int32_t* kind_host) {
+  IL_CHECK_ARG(bytes > 0 && window_host && handle_host && kind_host, "il_peer_window_alloc: bad arguments");
+  *kind_host = 0;
   void* p = nullptr;
   // uncached (MTYPE UC: neither this GPU's L2 nor a peer's keeps a line of it, what RCCL uses for its own flag / LL buffers on gfx94x+), else fine-grained
   hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
-  if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained); }
+  if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained); *kind_host = 1; }
   if (e != hipSuccess) return il_set_error(IL_ERR_HIP, "il_peer_window_alloc: hipExtMallocWithFlags(uncached / fine-grained, %lld bytes): %s", (long long)bytes, hipGetErrorString(e));
   e = hipMemset(p, 0, (size_t)bytes);
   if (e == hipSuccess) e = hipDeviceSynchronize();

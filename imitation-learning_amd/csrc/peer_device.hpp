@@ -12,6 +12,15 @@ __device__ __forceinline__ gfloat* peer_slots(const il_peer_bucket& x, int r) { 
 __device__ __forceinline__ gu32* peer_arrival(const il_peer_bucket& x, int r, int64_t npad) { return (gu32*)(peer_slots(x, r) + 2 * (int64_t)x.world * npad); }
 
 #define IL_PEER_Q (IL_PEER_CHUNK_FLOATS / 4 / 256)   // 16-byte lanes per thread and chunk
+// Write-through form (il_peer_bucket.flags & IL_PEER_WRITE_THROUGH; only on UNCACHED windows): the system-scope fences of the default form cost a write-back of the XCD's
+// L2 (release) and an invalidate (acquire) per workgroup although no line of an uncached window is ever held in a cache. Here the payload is stored and loaded with sc0 sc1
+// buffer accesses (system scope, compiler-tracked waits), every storing wave drains its stores (s_waitcnt vmcnt(0): they have been acknowledged by the owning memory) before
+// the barrier that precedes the arrival words, and the consumer reads the slabs with sc0 sc1 loads after its poll matched - no fence on either side.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define IL_PEER_SYS 17   // cache-policy bits of the raw buffer intrinsics: sc0 (1) | sc1 (16)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t peer_rsrc(const void* base, int64_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);   // raw buffer (stride 0), 32-bit data format: byte offsets, range-checked
+}
 // One workgroup (256 threads, all of them, convergent: contains barriers) exchanges chunk `c` of `bucket_`: push into slot [parity][rank] of every window, release the
 // epoch, wait for all ranks' arrival words, rank-ordered sum / W. Returns the number of valid floats in the chunk; mean[j] = the mean of the 16-byte lane
 // b = 4 * (tid + 256 j) of the chunk (undefined for b >= the return value). The caller stores them (k_peer_allreduce) or consumes them in place (the fused apply kernels).
@@ -32,15 +41,29 @@ __device__ __forceinline__ int peer_chunk_allreduce(const il_peer_bucket& x, con
     if (b + 3 < cnt) v[j] = *(const gfloat4*)(bucket + b);
     else { float t[4]; for (int k = 0; k < 4; ++k) t[k] = b + k < cnt ? bucket[b + k] : 0.f; v[j] = f32x4{t[0], t[1], t[2], t[3]}; }
   }
+  const bool wt = (x.flags & IL_PEER_WRITE_THROUGH) != 0;
+  const int64_t slot_bytes = 2 * (int64_t)W * npad * 4;
   for (int i = 1; i <= W; ++i) {   // remote windows first (each over its own link), the local one last
     const int r = (me + i) % W;
-    gfloat4* dst = (gfloat4*)(peer_slots(x, r) + (par * W + me) * npad + o);
+    if (wt) {
+      const __amdgpu_buffer_rsrc_t rs = peer_rsrc((const void*)peer_slots(x, r), slot_bytes);
+      const int off = (int)(((par * W + me) * npad + o) * 4);
 #pragma unroll
-    for (int j = 0; j < IL_PEER_Q; ++j) dst[tid + 256 * j] = v[j];
+      for (int j = 0; j < IL_PEER_Q; ++j) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), rs, off + 16 * (tid + 256 * j), 0, IL_PEER_SYS);
+    } else {
+      gfloat4* dst = (gfloat4*)(peer_slots(x, r) + (par * W + me) * npad + o);
+#pragma unroll
+      for (int j = 0; j < IL_PEER_Q; ++j) dst[tid + 256 * j] = v[j];
+    }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope, every thread: its stores have reached their windows before the barrier below
+  if (!wt) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope, every thread: its stores have reached their windows before the barrier below
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains (write-through form: THE ordering; fence form: restates the wait the compiler may drop behind buffer_wbl2)
   __syncthreads();
-  if (tid < W) __hip_atomic_store((uint32_t*)(peer_arrival(x, tid, npad) + (int64_t)c * IL_PEER_FLAG_STRIDE + me), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tid < W) {
+    uint32_t* flag = (uint32_t*)(peer_arrival(x, tid, npad) + (int64_t)c * IL_PEER_FLAG_STRIDE + me);
+    if (wt) __hip_atomic_store(flag, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // an sc0 sc1 store behind the drained payload
+    else __hip_atomic_store(flag, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 
   // ---- wait: all W arrival words of this chunk in the own window at epoch e (or later: a peer may already have pushed e + 1 into the other parity)
   if (tid < IL_WAVE) {
@@ -58,7 +81,7 @@ __device__ __forceinline__ int peer_chunk_allreduce(const il_peer_bucket& x, con
     if (!all && tid == 0) __hip_atomic_fetch_add(reinterpret_cast<long long*>(x.status), 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: the peers' stores into this window are visible to this CU from here on
+  if (!wt) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: the peers' stores into this window are visible to this CU from here on
 
   // ---- reduce: the W slabs of the chunk in rank order, then the mean
   const gfloat* slab0 = peer_slots(x, me) + par * W * npad + o;
@@ -67,10 +90,21 @@ __device__ __forceinline__ int peer_chunk_allreduce(const il_peer_bucket& x, con
   for (int j = 0; j < IL_PEER_Q; ++j) {
     const int b = 4 * (tid + 256 * j);
     if (b >= cnt) { mean[j] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
-    f32x4 acc = *(const gfloat4*)(slab0 + b);
-    for (int r = 1; r < W; ++r) {
-      const f32x4 t = *(const gfloat4*)(slab0 + r * npad + b);
-      acc[0] = __fadd_rn(acc[0], t[0]); acc[1] = __fadd_rn(acc[1], t[1]); acc[2] = __fadd_rn(acc[2], t[2]); acc[3] = __fadd_rn(acc[3], t[3]);
+    f32x4 acc;
+    if (wt) {
+      const __amdgpu_buffer_rsrc_t rs = peer_rsrc((const void*)peer_slots(x, me), slot_bytes);
+      const int off = (int)((par * W * npad + o + b) * 4);
+      acc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, IL_PEER_SYS));
+      for (int r = 1; r < W; ++r) {
+        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + (int)(r * npad * 4), 0, IL_PEER_SYS));
+        acc[0] = __fadd_rn(acc[0], t[0]); acc[1] = __fadd_rn(acc[1], t[1]); acc[2] = __fadd_rn(acc[2], t[2]); acc[3] = __fadd_rn(acc[3], t[3]);
+      }
+    } else {
+      acc = *(const gfloat4*)(slab0 + b);
+      for (int r = 1; r < W; ++r) {
+        const f32x4 t = *(const gfloat4*)(slab0 + r * npad + b);
+        acc[0] = __fadd_rn(acc[0], t[0]); acc[1] = __fadd_rn(acc[1], t[1]); acc[2] = __fadd_rn(acc[2], t[2]); acc[3] = __fadd_rn(acc[3], t[3]);
+      }
     }
     acc[0] = __fdiv_rn(acc[0], fw); acc[1] = __fdiv_rn(acc[1], fw); acc[2] = __fdiv_rn(acc[2], fw); acc[3] = __fdiv_rn(acc[3], fw);
     mean[j] = acc;

@@ -126,7 +126,7 @@ class PeerExchange:
     if self.world > _lib.IL_PEER_MAX_RANKS:
       raise RuntimeError(f'PeerExchange: {self.world} ranks > IL_PEER_MAX_RANKS = {_lib.IL_PEER_MAX_RANKS}')
     self.sizes = {k: int(n) for k, n in sizes.items() if n}
-    self.window, self.opened, self.desc, self._keep = None, [], {}, []
+    self.window, self.opened, self.desc, self._keep, self.uncached, self.form = None, [], {}, [], False, 0
     offsets, total = {}, 0
     for k, n in self.sizes.items():
       offsets[k] = total
@@ -135,8 +135,9 @@ class PeerExchange:
     with torch.cuda.device(device):
       # Every rank takes part in the handle exchange whether or not its own allocation worked (a rank that raised before the collective would leave the others waiting
       # in it): a failed allocation travels as None and fails the set-up on every rank.
-      rc = L.il_peer_window_alloc(total, C.byref(w), handle)
-      mine = handle.raw if rc == 0 else None
+      kind = C.c_int32(0)
+      rc = L.il_peer_window_alloc(total, C.byref(w), handle, C.byref(kind))
+      mine = (handle.raw, int(kind.value)) if rc == 0 else None   # kind: 0 uncached, 1 fine-grained
       why = None if rc == 0 else L.il_last_error().decode()
       self.window = w.value if rc == 0 else None
       handles = [mine]
@@ -146,8 +147,9 @@ class PeerExchange:
       try:
         if any(h is None for h in handles):
           raise RuntimeError('PeerExchange: no peer window on rank(s) ' + ', '.join(str(r) for r, h in enumerate(handles) if h is None) + (f' ({why})' if why else ''))
+        self.uncached = all(h[1] == 0 for h in handles)   # the write-through form needs every window uncached
         windows = []
-        for r, h in enumerate(handles):
+        for r, (h, _) in enumerate(handles):
           if r == self.rank:
             windows.append(self.window)
             continue
@@ -179,11 +181,18 @@ class PeerExchange:
       dist.barrier(group)   # every window is mapped everywhere before the first store into a peer
     ok = _agree(x is not None, group)
     if ok:
-      try:
-        good = x.verify(verify_rounds)
-      except Exception as e:   # a HIP error in the self-test on this rank: still take part in the agreement
-        good, err = False, e
-      ok = _agree(good, group)
+      # Two forms of the same kernel, tried in this order, each adopted only if the self-test passes on EVERY rank: write-through (payload through sc0 sc1 accesses +
+      # drained stores, no fences: uncached windows only; IL_PEER_WRITE_THROUGH=0 skips it), then the compiler's system-scope release / acquire fences.
+      forms = ([_lib.IL_PEER_WRITE_THROUGH] if _agree(x.uncached and os.environ.get('IL_PEER_WRITE_THROUGH', '1') != '0', group) else []) + [0]
+      for form in forms:
+        x.set_form(form)
+        try:
+          good = x.verify(verify_rounds)
+        except Exception as e:   # a HIP error in the self-test on this rank: still take part in the agreement
+          good, err = False, e
+        ok = _agree(good, group)
+        if ok: break
+        x.status.zero_()
     if not ok:
       if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.barrier(group)   # EVERY rank, with or without an exchange of its own: no kernel of the self-test is still storing into a window that is about to go away
@@ -191,6 +200,12 @@ class PeerExchange:
       if err is not None and os.environ.get('IL_PEER_EXCHANGE') == 'require': raise err
       return None
     return x
+
+  def set_form(self, flags: int):
+    """IL_PEER_WRITE_THROUGH or 0 (fences) for every bucket; every rank must use the same form."""
+    self.form = int(flags)
+    for d in self.desc.values():
+      d.flags = self.form
 
   def allreduce_mean(self, name: str, bucket: torch.Tensor):
     """bucket <- mean over ranks, in place, enqueued on the current stream (capturable). Every rank issues the same sequence of calls per name."""

@@ -526,6 +526,8 @@ int il_dril_uncertainty(const il_dril* d, const il_batch* batch, const float* ma
 #define IL_PEER_HANDLE_BYTES 64      /* sizeof(hipIpcMemHandle_t) */
 #define IL_PEER_CHUNK_FLOATS 2048    /* one workgroup's share of a bucket */
 #define IL_PEER_FLAG_STRIDE 32       /* uint32 words per chunk in the arrival array: one 128-byte line per chunk, word r = the last epoch rank r pushed */
+#define IL_PEER_WRITE_THROUGH 1      /* il_peer_bucket.flags: payload through sc0 sc1 (write-through / cache-bypassing) accesses + drained stores instead of system-scope fences;
+                                        only for windows that il_peer_window_alloc reported as UNCACHED (kind 0) */
 #define IL_PEER_SPIN_LIMIT (1 << 23) /* default bound of a device-side wait for the peers (polls of >= 8 sleep quanta: several seconds) */
 typedef struct il_peer_bucket {
   int32_t rank, world;                 /* this process's rank among the `world` <= IL_PEER_MAX_RANKS ranks that exchange */
@@ -534,12 +536,12 @@ typedef struct il_peer_bucket {
   void* windows[IL_PEER_MAX_RANKS];    /* windows[r] = rank r's window as mapped in this process ([rank] = the own allocation) */
   uint32_t* epoch;                     /* local device uint32[ceil(n / IL_PEER_CHUNK_FLOATS)], zero-initialised: exchanges done per chunk */
   int64_t* status;                     /* local device int64[2], zero-initialised: [0] += 1 per wait that gave up (must stay 0) */
-  int32_t spin_limit, reserved;        /* polls before a wait gives up; 0 = IL_PEER_SPIN_LIMIT */
+  int32_t spin_limit, flags;           /* polls before a wait gives up (0 = IL_PEER_SPIN_LIMIT); IL_PEER_WRITE_THROUGH or 0 */
 } il_peer_bucket;
 /* bytes of a bucket's region: slots float[2 parities][world][n rounded up to chunks] + arrival words; -1 on bad arguments */
 int64_t il_peer_region_bytes(int32_t world, int64_t n);
 /* zero-filled uncached (failing that, fine-grained) device allocation on the current device + its IPC handle (IL_PEER_HANDLE_BYTES bytes, host) */
-int il_peer_window_alloc(int64_t bytes, void** window_host, unsigned char* handle_host);
+int il_peer_window_alloc(int64_t bytes, void** window_host, unsigned char* handle_host, int32_t* kind_host);   /* *kind_host: 0 uncached, 1 fine-grained */
 /* maps another rank's window (a handle produced by il_peer_window_alloc in ANOTHER process) into this process */
 int il_peer_window_open(const unsigned char* handle_host, void** window_host);
 int il_peer_window_close(void* window);  /* a window obtained from il_peer_window_open */

@@ -138,9 +138,10 @@ def _peer_fallback_worker(rank, world, port, out_dir, scenario):
 
   class Fake:
     def __getattr__(self, name): return getattr(real, name)
-    def il_peer_window_alloc(self, total, wref, handle):
+    def il_peer_window_alloc(self, total, wref, handle, kind):
       if scenario == 'alloc' and rank == 1: return 3
       wref._obj.value = 0x1000 * (rank + 1)
+      kind._obj.value = 0
       return 0
     def il_peer_window_open(self, h, oref):
       if scenario == 'open' and rank == 0: return 3

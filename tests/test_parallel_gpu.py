@@ -106,7 +106,9 @@ assert x is not None, 'peer-window set-up or self-test failed'
 g = torch.Generator(device='cpu'); g.manual_seed(7 + rank)
 bad = 0
 graph_bad = 0
-for rnd in range(5):                                   # odd and even epochs: both slot parities
+form0 = x.form                                         # what the set-up ladder adopted: write-through (uncached windows), else fences
+for rnd in range(8):                                   # odd and even epochs: both slot parities; rounds 5..7 with the OTHER form of the kernel (fences)
+  if rnd == 5: x.set_form(0)
   for k, n in sizes.items():
     mine = torch.randn(n, generator=g)
     both = [torch.empty(n), torch.empty(n)]
@@ -129,7 +131,7 @@ with torch.cuda.stream(s):
     s.synchronize()
     graph_bad += int(not torch.equal(buf, torch.full_like(buf, 1.5 + rep)))
 torch.cuda.synchronize()
-np.save(os.path.join(sys.argv[2], f'peer{rank}.npy'), np.array([bad, graph_bad, x.timeouts()]))
+np.save(os.path.join(sys.argv[2], f'peer{rank}.npy'), np.array([bad, graph_bad, x.timeouts(), form0]))
 x.close()
 dist.barrier(); dist.destroy_process_group()
 '''
@@ -142,8 +144,9 @@ def test_peer_exchange_kernel_two_ranks(tmp_path):
   script.write_text(PEER_WORKER)
   _launch([str(script), ROOT, str(tmp_path)], str(tmp_path))
   for r in (0, 1):
-    bad, graph_bad, timeouts = np.load(tmp_path / f'peer{r}.npy')
+    bad, graph_bad, timeouts, form0 = np.load(tmp_path / f'peer{r}.npy')
     assert (bad, graph_bad, timeouts) == (0, 0, 0), f'rank {r}: {bad} mismatching exchanges, {graph_bad} mismatching graph replays, {timeouts} expired waits'
+    assert form0 == 1, 'the windows of an MI355X are uncached allocations: the set-up ladder should have adopted the write-through form'
 
 
 def test_peer_exchange_single_rank_is_identity():
