@@ -222,6 +222,21 @@ class PeerExchange:
     """Known rank- and round-dependent patterns through the real kernel; the mean is exact in fp32, so the comparison is bitwise. A stale line, a lost store or a
     window mapped to the wrong rank shows up as a mismatch; several rounds exercise both slot parities and the epoch logic."""
     ok = True
+    # The ranks have just met at a barrier: a wait of the self-test that is going to be satisfied is satisfied within milliseconds. A shorter bound (a few seconds instead of
+    # tens) keeps a set-up that does NOT work - stores that never become visible - from stalling the start of a run for minutes before it falls back.
+    keep = {k: d.spin_limit for k, d in self.desc.items()}
+    for d in self.desc.values():
+      d.spin_limit = 1 << 21
+    try:
+      ok = self._verify_rounds(rounds)
+    finally:
+      for k, d in self.desc.items():
+        d.spin_limit = keep[k]
+    torch.cuda.synchronize(self.device)
+    return ok and self.timeouts() == 0
+
+  def _verify_rounds(self, rounds: int) -> bool:
+    ok = True
     for k, n in self.sizes.items():
       i = torch.arange(n, device=self.device, dtype=torch.float32)
       for r in range(rounds):
@@ -229,8 +244,7 @@ class PeerExchange:
         self.allreduce_mean(k, scratch)
         expect = (i % 97) * 0.25 + float((self.world + 1) * (r + 1)) / 2.0
         ok = ok and bool(torch.equal(scratch, expect))
-    torch.cuda.synchronize(self.device)
-    return ok and self.timeouts() == 0
+    return ok
 
   def close(self, collective: bool = True):
     """collective=True: every rank of the group calls close() together (a barrier makes sure nobody unmaps a window a peer's kernel may still store into)."""
