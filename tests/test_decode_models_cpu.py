@@ -1,0 +1,72 @@
+"""Python models of two workgroup re-labellings of the HIP kernels (no GPU): what must hold for ANY launch shape is a bijection plus an ordering property the
+device-side waits rely on. The formulas are restated from the kernels (imitation-learning_amd/csrc/mlp_tile.hpp pop_ids, csrc/sac.hip chain_decode_xcd and the
+IL_PC_XCD_NETS decode of k_policy_critic); the -m gpu tests check the kernels themselves bit for bit."""
+import pytest
+
+
+def pop_ids(bx, by, nx, L):
+  """Population launches, grid (nx workgroups per learner, L learners), dispatched in linear order g = by * nx + bx round-robin over 8 XCDs: learner l -> XCD l % 8."""
+  g, full = by * nx + bx, (L >> 3) * 8 * nx
+  if g < full:
+    grp, r = divmod(g, 8 * nx)
+    return r >> 3, grp * 8 + (r & 7)
+  return bx, by
+
+
+@pytest.mark.parametrize('nx,L', [(32, 8), (32, 18), (96, 64), (41, 16), (7, 9), (33, 3), (64, 1)])
+def test_pop_ids_is_a_bijection_that_pins_a_learner_to_one_xcd_and_keeps_its_block_order(nx, L):
+  seen, last_bx = set(), {}
+  for g in range(nx * L):          # dispatch order
+    by, bx = divmod(g, nx)
+    nbx, nby = pop_ids(bx, by, nx, L)
+    assert 0 <= nbx < nx and 0 <= nby < L and (nbx, nby) not in seen
+    seen.add((nbx, nby))
+    if nby < (L >> 3) * 8:
+      assert g % 8 == nby % 8, 'a learner of a full group of 8 lives on XCD learner % 8'
+    assert last_bx.get(nby, -1) < nbx, "a learner's workgroups are dispatched in increasing block order (a role only waits for lower-numbered workgroups of its learner)"
+    last_bx[nby] = nbx
+  assert len(seen) == nx * L
+
+
+def chain_decode_xcd(bid):
+  x, tile = bid & 7, bid >> 3
+  if x == 0: return 0, 0, tile      # actor(s')
+  if x <= 2: return 1, x - 1, tile  # targets
+  if x <= 4: return 2, x - 3, tile  # critics
+  if x == 5: return 3, 0, tile      # actor(s)
+  return None                        # XCDs 6, 7: row-copy workgroups / idle
+
+
+@pytest.mark.parametrize('nt', [1, 5, 16, 32])
+def test_chain_decode_xcd_one_network_per_xcd_and_waits_only_on_lower_blocks(nt):
+  where = {}
+  for bid in range(8 * nt):
+    d = chain_decode_xcd(bid)
+    if d is None: continue
+    role, net, tile = d
+    assert (role, net, tile) not in where and tile < nt
+    where[(role, net, tile)] = bid
+    assert bid % 8 == {(0, 0): 0, (1, 0): 1, (1, 1): 2, (2, 0): 3, (2, 1): 4, (3, 0): 5}[(role, net)], 'every tile of a role-network sits on the same XCD'
+  assert len(where) == 6 * nt
+  for tile in range(nt):
+    for net in (0, 1):
+      assert where[(0, 0, tile)] < where[(1, net, tile)], 'a target waits for actor(s′) of its tile'
+      for tnet in (0, 1):
+        assert where[(1, tnet, tile)] < where[(2, net, tile)], 'a critic waits for both targets of its tile'
+
+
+@pytest.mark.parametrize('nt,helpers', [(16, 4), (5, 4), (16, 6)])
+def test_policy_critic_xcd_decode(nt, helpers):
+  crit, help_ = {}, {}
+  for bx in range(8 * nt):
+    x, q = bx & 7, bx >> 3
+    if x >= 2 + helpers: continue
+    if x < 2: crit[(x, q)] = bx
+    else:
+      h = (x - 2) * nt + q
+      tile, part = h % nt, h // nt
+      assert tile == q and part == x - 2 and (tile, part) not in help_
+      help_[(tile, part)] = bx
+  assert len(crit) == 2 * nt and len(help_) == helpers * nt
+  for (tile, part), bx in help_.items():
+    assert crit[(0, tile)] < bx and crit[(1, tile)] < bx, 'a helper only waits for lower-numbered workgroups (both critics of its tile)'
