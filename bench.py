@@ -245,15 +245,35 @@ def cpu_baseline(tr, et, budget_s=12.0):
                      f'(the `cores` field) on a host with {os.cpu_count()} logical cores; everything outside the GEMMs is single-threaded')
 
 
-def cpu_reference():
-  """The reference's OWN code timed on its CPU path (profiles/tools/cpu_reference.py -> profiles/cpu_reference.json). /root/reference cannot travel to the GPU
-  box, so the number comes from the build container and says so; the live-timed oracle port is reported next to it as `cpu_port`."""
+def cpu_reference(budget_s=20.0):
+  """The reference's OWN code on its CPU path, timed LIVE on this host beside the GPU number: oracle/ref_cpu_baseline.py in a subprocess runs the
+  reference's training.py / models.py / memory.py - byte-compiled from /root/reference into the git-ignored oracle/_ref/ by __graft_entry__.build() (oracle/build_ref.py),
+  shipped to the GPU box like the in-tree .so - through train.py:173-203 at 1 thread and at all cores, with and without memory.sample. Only when oracle/_ref is absent does
+  the committed build-container measurement (profiles/cpu_reference.json) stand in, and `where` says so."""
+  import subprocess
+  runner = os.path.join(ROOT, 'oracle', 'ref_cpu_baseline.py')
+  try:
+    r = subprocess.run([sys.executable, runner, '--budget', str(budget_s)], capture_output=True, text=True, timeout=60 + 6 * budget_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=''))
+    if r.returncode == 0:
+      j = json.loads(r.stdout.strip().splitlines()[-1])
+      res, n = j['results'], j['threads_all_cores']
+      return dict(value=max(res['all_cores_with_memory_sample'], res['one_thread_with_memory_sample']), unit='updates/s',
+                  cores=n if res['all_cores_with_memory_sample'] >= res['one_thread_with_memory_sample'] else 1, kind='reference',
+                  where='this host, live (oracle/_ref: the reference\'s own modules byte-compiled from /root/reference)', cpu_model=j['cpu_model'], nproc=j['nproc'],
+                  one_thread=res['one_thread_with_memory_sample'], all_cores=res['all_cores_with_memory_sample'], threads_all_cores=n,
+                  without_memory_sample=dict(one_thread=res['one_thread_without_memory_sample'], all_cores=res['all_cores_without_memory_sample']), torch=j['torch'],
+                  sample=f"{sum(j['updates_timed'].values())} updates of train.py:173-203 (algorithm=GAIL, batch {B}, same synthetic buffers) in {j['seconds']} s of CPU work: "
+                         f"{j['updates_timed']}; `value` = the better of 1 thread and {n} threads WITH the two memory.sample calls (`cores` says which)",
+                  reference_sources_sha256={m: v['source_sha256'][:16] for m, v in j['manifest']['modules'].items()})
+    print(f'[bench] oracle/ref_cpu_baseline.py: rc {r.returncode}: {(r.stdout + r.stderr).strip()[-300:]}', file=sys.stderr)
+  except Exception as e:
+    print(f'[bench] live reference timing failed ({type(e).__name__}: {e}); using the committed measurement', file=sys.stderr)
   try:
     ref = json.load(open(os.path.join(ROOT, 'profiles', 'cpu_reference.json')))
   except Exception:
     return None
   r, n = ref['results'], ref['nproc']
-  return dict(value=r[f'threads_{n}_with_memory_sample'], unit='updates/s', cores=n, kind='reference', where=ref['where'], cpu_model=ref['cpu_model'],
+  return dict(value=r[f'threads_{n}_with_memory_sample'], unit='updates/s', cores=n, kind='reference', where=ref['where'] + ' - NOT measured in this run: oracle/_ref is absent here', cpu_model=ref['cpu_model'],
               one_thread=r['threads_1_with_memory_sample'], without_memory_sample=dict(one_thread=r['threads_1_without_memory_sample'], all_cores=r[f'threads_{n}_without_memory_sample']),
               sample=f"{ref['updates_timed']} updates after {ref['warmup']} warm-up: {ref['what']}; source profiles/cpu_reference.json (committed; not re-timed in this run)")
 
@@ -320,6 +340,47 @@ def roofline(run_fn, trace_steps, units_per_launch, ms_per_step, side_stream_dis
   return roof
 
 
+def self_launch(args) -> int:
+  """`python bench.py --gpus N` with no rank environment: start the N ranks here (python -m torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1), pass rank 0's
+  JSON line through as the last line of stdout and return the launcher's exit code. Fewer than N visible GPUs is an error, not an N = 1 result. If the run with the
+  peer-window gradient exchange fails outright (a rank raised or was ended by its watchdog), ONE retry with IL_PEER_EXCHANGE=0 (RCCL all-reduces); the retry is named in
+  `config.exchange_fallback`."""
+  import socket
+  import subprocess
+  n, have = args.gpus, torch.cuda.device_count()
+  if have < n and os.environ.get('IL_BENCH_SHARE_GPU') != '1':
+    print(f'bench.py: --gpus {n} needs {n} visible GPUs, this host shows {have}: refusing to report an N = {n} number from fewer devices '
+          '(IL_BENCH_SHARE_GPU=1 lets test ranks share a device over gloo)', file=sys.stderr)
+    return 2
+  attempts = [({}, None)]
+  if os.environ.get('IL_PEER_EXCHANGE', '1') != '0':
+    attempts.append((dict(IL_PEER_EXCHANGE='0'), 'the run with the peer-window gradient exchange failed (launcher exit code {rc}); this is the retry with IL_PEER_EXCHANGE=0 (RCCL all-reduces)'))
+  rc, note = 1, None
+  for extra, why in attempts:
+    sock = socket.socket(); sock.bind(('127.0.0.1', 0)); port = sock.getsockname()[1]; sock.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), **extra)
+    if why is not None:
+      note = why.format(rc=rc)
+      print(f'[bench] {note}', file=sys.stderr)
+    try:
+      r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=float(os.environ.get('IL_BENCH_LAUNCH_TIMEOUT_S', 1500)))
+      rc, out = r.returncode, r.stdout
+    except subprocess.TimeoutExpired as e:
+      rc, out = 124, (e.stdout or '') if isinstance(e.stdout, str) else ''
+    lines = [l for l in out.strip().splitlines() if l.strip()]
+    last = next((l for l in reversed(lines) if l.startswith('{') and '"metric"' in l), None)
+    for l in lines:
+      if l is not last: print(l, file=sys.stderr)
+    if rc == 0 and last is not None:
+      j = json.loads(last)
+      j.setdefault('config', {})['launched_by'] = f'bench.py itself (torch.distributed.run, {n} ranks)'
+      if note: j['config']['exchange_fallback'] = note
+      print(json.dumps(j), flush=True)
+      return 0
+  return rc or 1
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -336,16 +397,31 @@ def main():
   ap.add_argument('--learners', type=int, default=1, help='population axis: N independent learners per GPU advanced by one graph replay (aggregate updates/s)')
   args = ap.parse_args()
 
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(self_launch(args))   # `python bench.py --gpus N` on its own: start the N ranks (torch.distributed.run), pass their JSON line through
   world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
-  assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run --nproc-per-node {args.gpus})'
+  if world != args.gpus:
+    sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...` '
+             f'(or plain `python bench.py --gpus {args.gpus}`, which starts the ranks itself)')
   assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU fallback for the HIP path)'
+  share = os.environ.get('IL_BENCH_SHARE_GPU') == '1'   # tests only: the ranks time-slice the visible GPU(s) and meet over gloo (RCCL refuses two ranks on one device)
+  n_dev = torch.cuda.device_count()
+  if world > 1 and n_dev < world and not share:
+    sys.exit(f'bench.py: --gpus {world} needs {world} visible GPUs, this host shows {n_dev}: refusing to report an N = {world} number from fewer devices')
+  local = local % n_dev if share else local
   torch.cuda.set_device(local)
   device = torch.device('cuda', local)
   import torch.distributed as dist
+  from imitation_learning_amd import parallel
+  dog = parallel.Watchdog(float(os.environ.get('IL_WATCHDOG_S', 240)), what=f'bench.py --gpus {world}') if world > 1 else None   # a rank that dies inside a collective must not hang the others
+  beat = (lambda phase: dog.beat(phase)) if dog is not None else (lambda phase: None)
+  backend = os.environ.get('IL_BENCH_BACKEND', 'gloo' if share else 'nccl')
   if world > 1 or os.environ.get('IL_FORCE_ALLREDUCE') == '1':
+    import datetime
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29517')
-    dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
+    kw = dict(device_id=device) if backend == 'nccl' else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(60.0, dog.timeout_s if dog else 600.0)), **kw)
   from imitation_learning_amd import _lib
   from imitation_learning_amd.parallel import DataParallelUpdate, broadcast_parameters
 
@@ -362,49 +438,78 @@ def main():
   if world > 1 or os.environ.get('IL_FORCE_DP') == '1':  # IL_FORCE_DP=1: the split grads-only / all-reduce / apply path on a single rank
     broadcast_parameters([n.flat if hasattr(n, 'flat') else n for n in nets] + [nets[4].sn])
     runner = DataParallelUpdate(plan)
-  for _ in range(5):
-    runner.run()   # loads code objects before capture
-  torch.cuda.synchronize()
-  if runner is not plan and getattr(runner, 'handoff', False) and not runner.agree_on_handoff():   # collective: an expired device-side wait on ANY rank sends every rank to the stream-dependency schedule
-    print(f'[bench] rank {rank}: device-side hand-off left (a bounded wait expired on some rank during the eager warm-up); using stream dependencies', file=sys.stderr)
-  launch = 'eager'
-  step = runner.run
-  if not args.no_graph:
-    try:
-      runner.capture(warmup=0)
-      step, launch = runner.replay, 'hipGraph replay'
-    except Exception as e:  # e.g. a collective that refuses stream capture: keep measuring, eagerly, and say so
-      if world == 1 and os.environ.get('IL_FORCE_ALLREDUCE') != '1':
-        raise
-      torch.cuda.synchronize()
-      launch = f'eager (graph capture failed: {type(e).__name__})'
-      print(f'[bench] rank {rank}: graph capture failed, falling back to eager launches: {e}', file=sys.stderr)
+  gloo_eager = world > 1 and backend != 'nccl'   # gloo collectives synchronise the host: not capturable - eager launches unless the peer-window kernels carry the exchange
 
   def barrier():
     torch.cuda.synchronize()
     if world > 1:
       dist.barrier()
       torch.cuda.synchronize()
-  for _ in range(args.warmup):
-    step()
-  barrier()
-  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  t0 = time.perf_counter()
-  ev0.record()
-  for _ in range(args.steps):
-    step()
-  ev1.record()
-  barrier()
-  elapsed = time.perf_counter() - t0
-  t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-  if world > 1:
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-  elapsed = float(t.item())
+
+  def measure():
+    """warm-up (eager, then captured), the timed region, max over ranks. Returns (elapsed seconds, launch mode)."""
+    beat('eager warm-up')
+    for _ in range(5):
+      runner.run()   # loads code objects before capture; the first one sets up communicators / peer windows (self-test + soak)
+    torch.cuda.synchronize()
+    if runner is not plan and getattr(runner, 'handoff', False) and not runner.agree_on_handoff():   # collective: an expired device-side wait on ANY rank sends every rank to the stream-dependency schedule
+      print(f'[bench] rank {rank}: device-side hand-off left (a bounded wait expired on some rank during the eager warm-up); using stream dependencies', file=sys.stderr)
+    launch, step = 'eager', runner.run
+    if not args.no_graph and not (gloo_eager and getattr(runner, 'peer', None) is None):
+      beat('graph capture')
+      try:
+        runner.capture(warmup=0)
+        step, launch = runner.replay, 'hipGraph replay'
+      except Exception as e:  # e.g. a collective that refuses stream capture: keep measuring, eagerly, and say so
+        if world == 1 and os.environ.get('IL_FORCE_ALLREDUCE') != '1':
+          raise
+        torch.cuda.synchronize()
+        launch = f'eager (graph capture failed: {type(e).__name__})'
+        print(f'[bench] rank {rank}: graph capture failed, falling back to eager launches: {e}', file=sys.stderr)
+    barrier()   # no rank enters the replays while another is still capturing (bounded device-side waits downstream of the exchange)
+    beat('warm-up')
+    for _ in range(args.warmup):
+      step()
+    barrier()
+    beat('timed region')
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
+    if world > 1:
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()), launch
+
+  def health():
+    """Collective verdict on the run just timed: (ok on every rank, replicas bit-identical, digests, note)."""
+    ex = runner.exchange_timeouts() if getattr(runner, 'exchange_timeouts', None) is not None else 0
+    hs = plan.sync_timeouts() if getattr(plan, 'device_sync', False) else 0
+    ok = parallel._agree(ex == 0 and hs == 0) if world > 1 else (ex == 0 and hs == 0)
+    same, digests = (parallel.replicas_bit_identical(runner.replica_state()) if runner is not plan and hasattr(runner, 'replica_state') else (True, []))
+    note = f'rank {rank}: {ex} expired exchange waits, {hs} expired hand-off waits' if (ex or hs) else None
+    return ok, same, digests, note
+
+  elapsed, launch = measure()
+  exchange_fallback = None
+  ok, same, digests, note = health()
+  if world > 1 and getattr(runner, 'peer', None) is not None and not (ok and same):
+    # One retry, in process, on the collectives: the peer-window exchange delivered late (expired waits) or wrong (replicas apart). Rank 0's state everywhere, then RCCL.
+    exchange_fallback = f'peer-window exchange failed the post-run check ({"replicas differ" if not same else "expired waits"}{"; " + note if note else ""}): re-timed with torch.distributed all-reduces'
+    print(f'[bench] rank {rank}: {exchange_fallback}', file=sys.stderr)
+    beat('fall-back to the collectives')
+    runner.use_collectives(exchange_fallback)
+    plan.sync[plan._sync_timeouts] = 0
+    runner.resync_replicas()
+    elapsed, launch = measure()
+    ok, same, digests, note = health()
   finite = all(bool(torch.isfinite(n.flat if hasattr(n, 'flat') else n).all()) for n in nets)
-  if getattr(runner, 'exchange_timeouts', None) is not None and runner.exchange_timeouts():
-    raise RuntimeError(f'{runner.exchange_timeouts()} device-side waits of the peer-window gradient exchange expired (set IL_PEER_EXCHANGE=0 for RCCL all-reduces)')
-  if getattr(plan, 'device_sync', False) and plan.sync_timeouts():
-    raise RuntimeError(f'{plan.sync_timeouts()} device-side waits timed out: the two branches of the update did not run concurrently (set IL_DEVICE_SYNC=0)')
+  if not ok:
+    raise RuntimeError(f'device-side waits expired during the timed run ({note}): the result is invalid (IL_PEER_EXCHANGE=0 selects RCCL all-reduces, IL_DEVICE_SYNC=0 stream dependencies)')
+  if not same:
+    raise RuntimeError(f'data-parallel replicas are NOT bit-identical after the timed run (digests {digests}): the gradient exchange delivered different values to different ranks')
+  beat('reporting')
 
   if rank == 0:
     ms_per_step = elapsed / args.steps * 1e3
@@ -423,7 +528,10 @@ def main():
                            batch_per_gpu=B, global_batch=B * world, state_dim=S, action_dim=A, hidden=H, replay_capacity=1_000_000, replay_fill=100_000, expert_rows=25_000,
                            learners_per_gpu=args.learners, parallelism=f'dp{world}' + ('(split path' + (', device hand-off between the discriminator and SAC branches, own communicator per branch)' if getattr(runner, 'handoff', False) else ', stream dependencies)') if runner is not plan else ''), launch=launch, noise='on-chip Philox4x32-10', finite=finite,
                            gradient_exchange=(None if runner is plan else ('one kernel per sync point over peer-mapped windows (il_peer_allreduce_mean: push to every rank, rank-ordered sum; ' + ('write-through payload, no fences' if getattr(runner.peer, 'form', 0) else 'system-scope fences') + ')'
-                                                                             if getattr(runner, 'peer', None) is not None else 'RCCL all-reduce (AVG) per sync point')),
+                                                                             if getattr(runner, 'peer', None) is not None else f'{backend.replace("nccl", "RCCL")} all-reduce (mean) per sync point')),
+                           exchange=(None if runner is plan else runner.exchange_name()), exchange_note=(None if runner is plan else runner.peer_note), exchange_fallback=exchange_fallback,
+                           exchange_soak=(getattr(runner.peer, 'soak_report', None) if getattr(runner, 'peer', None) is not None else None),
+                           replicas_bit_identical=(same if runner is not plan else None), replica_digests=([d[:16] for d in digests] if runner is not plan else None),
                            branch_sync=('device counters (two graphs, no cross-stream edge)' if getattr(plan, 'device_sync', False) and runner is plan else 'stream dependencies'),
                            rows=('read from the rings through the drawn indices (il_batch.gather), relabel inline in k_sac_chain' if getattr(plan, 'inline_relabel', False) and runner is plan
                                  else ('read from the rings through the drawn indices (il_batch.gather)' if getattr(plan, 'ring_mode', False) and runner is plan else 'gathered by k_gather2'))),
@@ -459,8 +567,10 @@ def main():
       out['cpu_baseline'], out['cpu_port'] = (ref, port) if ref is not None else (port, None)
       if out['cpu_port'] is None: out.pop('cpu_port')
   if dist.is_initialized():
+    beat('teardown')
     dist.barrier()
     dist.destroy_process_group()
+  if dog is not None: dog.stop()
   if rank == 0:
     C.CDLL(None).fflush(None)   # RCCL writes its banner through C stdio (possibly at teardown): drain it so that the JSON line is the LAST line of stdout
     print(json.dumps(out), flush=True)

@@ -92,6 +92,7 @@ class SampleArgs(C.Structure):
 
 
 IL_PEER_MAX_RANKS, IL_PEER_HANDLE_BYTES, IL_PEER_CHUNK_FLOATS, IL_PEER_WRITE_THROUGH = 16, 64, 2048, 1
+IL_PEER_SPIN_LIMIT = 1 << 23   # include/il_hip.h: default bound (polls) of a device-side wait for the peers
 
 
 class PeerBucket(C.Structure):
@@ -213,10 +214,10 @@ _SYNC_LAYOUT = None
 
 
 def sync_layout():
-  """(slots, timeouts index, gather-workgroups index, stride) of the il_sync counter buffer, as the loaded library lays it out (include/il_hip.h IL_SYNC_*)."""
+  """(slots, timeouts index, gather-workgroups index, stride, spin-limit index, host-flag index) of the il_sync counter buffer, as the loaded library lays it out (include/il_hip.h IL_SYNC_*)."""
   global _SYNC_LAYOUT
   if _SYNC_LAYOUT is None:
-    out = (C.c_int32 * 4)()
+    out = (C.c_int32 * 6)()
     lib().il_sync_layout(out)
     _SYNC_LAYOUT = tuple(int(v) for v in out)
   return _SYNC_LAYOUT

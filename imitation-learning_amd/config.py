@@ -50,7 +50,7 @@ BASE: Dict[str, Any] = dict(
     memory=dict(size=1000000),
     imitation=dict(trajectories=0, subsample=1, state_only=False, absorbing=True, mix_expert_data='none', bc_aux_loss=False),
     check_time_usage=False, save_trajectories=False, render=False,
-    distributed=dict(world_size=1, backend='nccl'),   # data-parallel SAC over RCCL: launch with torch.distributed.run --nproc-per-node <world_size>; not a key of the reference
+    distributed=dict(world_size=1, backend='nccl', timeout_s=600),   # data-parallel SAC over RCCL: launch with torch.distributed.run --nproc-per-node <world_size>; not a key of the reference
 )
 
 _DISC = dict(reward_shaping=False, subtract_log_policy=False, reward_function='AIRL')
@@ -144,4 +144,6 @@ def validate(cfg: Config):
     if cfg.imitation.loss_function == 'PUGAIL': assert 0 <= cfg.imitation.pos_class_prior <= 1 and cfg.imitation.nonnegative_margin >= 0
   assert cfg.logging.interval >= 0
   assert int(cfg.distributed.world_size) >= 1 and cfg.distributed.backend in ('nccl', 'gloo')
+  if int(cfg.distributed.world_size) > 1 and cfg.imitation.bc_aux_loss:
+    raise NotImplementedError('distributed.world_size > 1 with imitation.bc_aux_loss=true: the behavioural-cloning auxiliary step (train.py:201) has no data-parallel form; run it on one GPU')
   return cfg

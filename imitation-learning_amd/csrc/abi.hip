@@ -82,7 +82,7 @@ __global__ void k_sync_probe(long long* sync, int setter) {
   sync_wait(sync, IL_SYNC_PROBE_FLAG, e + 1, 20000);   // ~10 ms: the probe is enqueued back to back, and a serialising runtime should be detected quickly
   if (threadIdx.x == 0) sync[IL_SYNC_PROBE_EPOCH] = e + 1;
 }
-extern "C" void il_sync_layout(int32_t* out) { out[0] = IL_SYNC_SLOTS; out[1] = IL_SYNC_TIMEOUTS; out[2] = IL_SYNC_GATHER_WGS; out[3] = IL_SYNC_STRIDE; }
+extern "C" void il_sync_layout(int32_t* out) { out[0] = IL_SYNC_SLOTS; out[1] = IL_SYNC_TIMEOUTS; out[2] = IL_SYNC_GATHER_WGS; out[3] = IL_SYNC_STRIDE; out[4] = IL_SYNC_SPIN; out[5] = IL_SYNC_HOST_FLAG; }
 extern "C" int il_sync_probe(int64_t* sync, int32_t setter, il_stream_t stream) {
   IL_CHECK_ARG(sync, "il_sync_probe: null counters");
   k_sync_probe<<<1, 64, 0, (hipStream_t)stream>>>((long long*)sync, setter);

@@ -216,12 +216,18 @@ __device__ __forceinline__ void sync_signal(long long* ctr) {   // all threads o
   if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
-__device__ __forceinline__ void sync_wait(long long* sync, int which, long long target, int limit = IL_SYNC_SPIN_LIMIT) {   // all threads of the workgroup, before their loads
-  if (threadIdx.x == 0) {
+__device__ __forceinline__ void sync_timed_out(long long* sync) {   // one thread: count the expired wait, and raise the host's flag if it gave us one ([IL_SYNC_HOST_FLAG])
+  const long long n = __hip_atomic_fetch_add(sync + IL_SYNC_TIMEOUTS, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  const long long host = sync[IL_SYNC_HOST_FLAG];
+  if (host) __hip_atomic_store(reinterpret_cast<long long*>(host), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void sync_wait(long long* sync, int which, long long target, int limit = 0) {   // all threads of the workgroup, before their loads
+  if (threadIdx.x == 0) {   // limit 0: the learner's own bound [IL_SYNC_SPIN] (0 there = IL_SYNC_SPIN_LIMIT), read only once a poll has failed: nothing on the fast path
     int spins = 0;
     while (__hip_atomic_load(sync + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > limit) { __hip_atomic_fetch_add(sync + IL_SYNC_TIMEOUTS, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (limit == 0) { const long long own = sync[IL_SYNC_SPIN]; limit = own > 0 ? (int)(own > 0x7fffffffLL ? 0x7fffffffLL : own) : IL_SYNC_SPIN_LIMIT; }
+      if (++spins > limit) { sync_timed_out(sync); break; }
     }
 #ifndef IL_SYNC_UNSAFE
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the producer's stores are visible to this CU from here on (every producer is a kernel on this GPU)

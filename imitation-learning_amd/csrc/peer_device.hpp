@@ -78,7 +78,11 @@ __device__ __forceinline__ int peer_chunk_allreduce(const il_peer_bucket& x, con
       if (all || ++spins > limit) break;
       __builtin_amdgcn_s_sleep(8);
     }
-    if (!all && tid == 0) __hip_atomic_fetch_add(reinterpret_cast<long long*>(x.status), 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!all && tid == 0) {
+      const long long n = __hip_atomic_fetch_add(reinterpret_cast<long long*>(x.status), 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+      const long long host = reinterpret_cast<const long long*>(x.status)[1];   // a host-mapped flag the training loop reads every step without synchronising (0 = none)
+      if (host) __hip_atomic_store(reinterpret_cast<long long*>(host), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   __syncthreads();
   if (!wt) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: the peers' stores into this window are visible to this CU from here on

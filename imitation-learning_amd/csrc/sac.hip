@@ -213,7 +213,7 @@ __device__ __forceinline__ void tile_await(unsigned* ctr, unsigned target, const
       __builtin_amdgcn_s_sleep(4);
       if (++spins > IL_SYNC_SPIN_LIMIT) {
         __hip_atomic_fetch_add(timeouts.slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (timeouts.sync) __hip_atomic_fetch_add(timeouts.sync + IL_SYNC_TIMEOUTS, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (timeouts.sync) sync_timed_out(timeouts.sync);
         break;
       }
     }

@@ -109,6 +109,76 @@ def _agree(ok: bool, group=None) -> bool:
   return bool(t.item() > 0.5)
 
 
+def agree_min(value: float, group=None) -> float:
+  """Collective MIN of a per-rank number (host value; every rank gets the same result)."""
+  if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    return float(value)
+  t = torch.tensor([float(value)], dtype=torch.float64, device='cuda' if dist.get_backend(group) == 'nccl' else 'cpu')
+  dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+  return float(t.item())
+
+
+def replica_digest(tensors) -> str:
+  """sha256 over the bytes of every replica tensor (parameter / Adam arenas, log alpha, spectral-norm buffers) in the given order. A few MB copied to the host: an
+  end-of-run / evaluation-time check, never inside the timed region."""
+  import hashlib
+  h = hashlib.sha256()
+  for t in tensors:
+    if t is None: continue
+    h.update(t.detach().contiguous().cpu().numpy().tobytes())
+  return h.hexdigest()
+
+
+def replicas_bit_identical(tensors, group=None):
+  """Collective. (True | False, [digest of every rank]): do all ranks hold the same bits? Data-parallel replicas apply the same averaged gradient with the same kernels,
+  so anything but identical digests means an exchange delivered different (stale, torn) gradients to different ranks."""
+  mine = replica_digest(tensors)
+  if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    return True, [mine]
+  words = torch.tensor([int(mine[i:i + 15], 16) for i in range(0, 60, 15)], dtype=torch.int64)   # 240 of the 256 bits, as four int64: travels through any backend as a plain tensor
+  dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+  words = words.to(dev)
+  every = [torch.empty_like(words) for _ in range(dist.get_world_size(group))]
+  dist.all_gather(every, words, group=group)
+  digests = [''.join(f'{int(v):015x}' for v in w.cpu().tolist()) for w in every]
+  return all(d == digests[0] for d in digests), digests
+
+
+class Watchdog:
+  """A rank that dies (or stalls) inside a collective must not hang the others past `timeout_s`: RCCL's kernels spin on the device for a peer that never arrives and the
+  host then sits in a synchronise for ever. A daemon thread watches a heartbeat the main loop refreshes (`beat()`, a host-side timestamp store); when it goes stale the
+  thread says which phase was running and ends THIS process with `os._exit` (exit code 124) - the launcher (torch.distributed.run, or bench.py's own) then tears the
+  remaining ranks down. IL_WATCHDOG_S overrides the bound; 0 disables."""
+  EXIT_CODE = 124
+
+  def __init__(self, timeout_s: float = 300.0, what: str = 'run'):
+    import threading
+    import time
+    self.timeout_s = float(os.environ.get('IL_WATCHDOG_S', timeout_s))
+    self.what, self.phase, self._time, self._last, self._stop = what, 'start', time, time.monotonic(), threading.Event()
+    self._thread = None
+    if self.timeout_s > 0:
+      self._thread = threading.Thread(target=self._watch, name='il-watchdog', daemon=True)
+      self._thread.start()
+
+  def beat(self, phase: Optional[str] = None):
+    self._last = self._time.monotonic()
+    if phase is not None: self.phase = phase
+
+  def stop(self):
+    self._stop.set()
+
+  def _watch(self):
+    import sys
+    while not self._stop.wait(min(1.0, self.timeout_s / 4)):
+      idle = self._time.monotonic() - self._last
+      if idle > self.timeout_s:
+        rank = os.environ.get('RANK', '0')
+        print(f'[watchdog] rank {rank}: no progress for {idle:.0f} s in phase "{self.phase}" of {self.what} (bound {self.timeout_s:.0f} s): a peer rank died or stalled inside a '
+              f'collective / device-side wait. Ending this rank (exit {self.EXIT_CODE}) so that the job fails instead of hanging.', file=sys.stderr, flush=True)
+        os._exit(self.EXIT_CODE)
+
+
 class PeerExchange:
   """The three gradient exchanges as ONE kernel each over peer-mapped windows (include/il_hip.h il_peer_*, csrc/peer.hip) instead of RCCL all-reduces.
 
@@ -126,6 +196,10 @@ class PeerExchange:
     if self.world > _lib.IL_PEER_MAX_RANKS:
       raise RuntimeError(f'PeerExchange: {self.world} ranks > IL_PEER_MAX_RANKS = {_lib.IL_PEER_MAX_RANKS}')
     self.sizes = {k: int(n) for k, n in sizes.items() if n}
+    # '_load': a bucket nobody trains on - the soak test (below) exchanges it on a third stream so that the real buckets are verified while the links carry traffic
+    load = int(os.environ.get('IL_PEER_SOAK_LOAD_FLOATS', 1 << 20)) if self.world > 1 or os.environ.get('IL_PEER_SOAK_LOAD_FLOATS') else 0
+    if load > 0: self.sizes['_load'] = load
+    self.soak_report = None
     self.window, self.opened, self.desc, self._keep, self.uncached, self.form = None, [], {}, [], False, 0
     offsets, total = {}, 0
     for k, n in self.sizes.items():
@@ -170,8 +244,8 @@ class PeerExchange:
     torch.cuda.synchronize(device)
 
   @classmethod
-  def create(cls, sizes: dict, device, group=None, verify_rounds: int = 3):
-    """Collective. A PeerExchange that passed its self-test on every rank, or None on every rank."""
+  def create(cls, sizes: dict, device, group=None, verify_rounds: int = 3, soak_rounds: Optional[int] = None):
+    """Collective. A PeerExchange that passed its self-test AND its soak test (`soak`) on every rank, or None on every rank."""
     x, err = None, None
     try:
       x = cls(sizes, device, group)
@@ -187,7 +261,7 @@ class PeerExchange:
       for form in forms:
         x.set_form(form)
         try:
-          good = x.verify(verify_rounds)
+          good = x.verify(verify_rounds) and x.soak(soak_rounds)
         except Exception as e:   # a HIP error in the self-test on this rank: still take part in the agreement
           good, err = False, e
         ok = _agree(good, group)
@@ -246,6 +320,52 @@ class PeerExchange:
         ok = ok and bool(torch.equal(scratch, expect))
     return ok
 
+  def soak(self, rounds: Optional[int] = None) -> bool:
+    """The set-up check a fabric deserves before gradients travel over it: `rounds` (IL_PEER_SOAK_ROUNDS, default 2,000) exchanges of EVERY bucket, interleaved the way the
+    update issues them - the discriminator's on one stream, the critic's and the actor's on another, nothing ordering the two - while a third stream keeps exchanging the
+    4 MB '_load' bucket so that the links are busy; the payload is rewritten on the device before every exchange with a pattern that depends on rank, round and position
+    (rotating by one element per round, so a slab that is stale by two rounds - the same slot parity - or misplaced by a lane differs everywhere), and every result is
+    compared BITWISE on the device (the pattern's sum over ranks is exact in fp32 and a multiple of W, so sum / W is exact for any W). No host synchronisation inside the loop.
+    One mismatching element or one expired wait on any rank fails the soak (the caller, `create`, makes that decision collective): a flag overtaking its payload under load,
+    a lost or torn store, a window mapped to the wrong rank all show up here rather than as silently averaged stale gradients. rounds <= 0 skips it."""
+    rounds = int(os.environ.get('IL_PEER_SOAK_ROUNDS', 2000)) if rounds is None else int(rounds)
+    if rounds <= 0 or not self.desc:
+      return True
+    import time
+    dev, W, me = self.device, self.world, self.rank
+    names = list(self.sizes)
+    streams = {'side': torch.cuda.Stream(dev), 'main': torch.cuda.Stream(dev), 'load': torch.cuda.Stream(dev)}
+    lane = {k: ('load' if k == '_load' else ('side' if k == 'disc' or (i % 2 == 0 and 'disc' not in self.sizes) else 'main')) for i, k in enumerate(names)}
+    pos = {k: torch.arange(n, device=dev, dtype=torch.int32) for k, n in self.sizes.items()}
+    bad = {k: torch.zeros((), dtype=torch.int64, device=dev) for k in names}
+    keep = {k: d.spin_limit for k, d in self.desc.items()}
+    for d in self.desc.values():
+      d.spin_limit = 1 << 22   # the ranks met at a barrier moments ago; a wait that is going to be satisfied is satisfied within milliseconds
+    before = self.timeouts()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    try:
+      here = torch.cuda.current_stream(dev)
+      for s in streams.values(): s.wait_stream(here)
+      for r in range(rounds):
+        k_r = float(r % 251 + 1)
+        for k in names:
+          with torch.cuda.stream(streams[lane[k]]):
+            base = ((pos[k] + r) % 97).to(torch.float32) * 0.25
+            buf = base + float(me + 1) * k_r                      # this rank's "gradient" of round r
+            self.allreduce_mean(k, buf)
+            bad[k] += (buf != base + k_r * (W + 1) / 2.0).sum()   # mean over ranks q of base + (q + 1) k_r, exact
+      for s in streams.values(): here.wait_stream(s)
+      torch.cuda.synchronize(dev)
+    finally:
+      for k, d in self.desc.items():
+        d.spin_limit = keep[k]
+    mismatches = {k: int(v.item()) for k, v in bad.items()}
+    expired = self.timeouts() - before
+    self.soak_report = dict(rounds=rounds, buckets={k: self.sizes[k] for k in names}, mismatching_elements=mismatches, expired_waits=expired,
+                            seconds=round(time.perf_counter() - t0, 3), form='write-through' if self.form else 'fences')
+    return expired == 0 and not any(mismatches.values())
+
   def close(self, collective: bool = True):
     """collective=True: every rank of the group calls close() together (a barrier makes sure nobody unmaps a window a peer's kernel may still store into)."""
     L = _lib.lib()
@@ -262,27 +382,39 @@ class DataParallelUpdate:
 
   def __init__(self, plan, group=None):
     self.plan, self.group = plan, group
-    assert not plan.bc_aux, 'DataParallelUpdate: the behavioural-cloning auxiliary step has no data-parallel form (use the per-function path)'
+    if plan.bc_aux:
+      raise NotImplementedError('DataParallelUpdate: imitation.bc_aux_loss (the behavioural-cloning auxiliary step, train.py:201) has no data-parallel form; run it with distributed.world_size=1')
     # Device-side hand-off between the discriminator branch and the SAC branch, as on one GPU (UpdatePlan): no stream dependency between the two streams, the index
     # draw resident at the head of the discriminator branch, the reward relabel inline in the forward / critic-loss launch. The discriminator's all-reduce then sits
     # on a stream of its own and must not share a communicator with the critic / actor all-reduces of the main stream (two unordered streams could issue the
     # collectives of ONE communicator in different orders on different ranks): it gets its own process group. IL_DP_HANDOFF=0: stream dependencies, one communicator.
-    self.handoff = bool(plan.algorithm == 'GAIL' and plan.device_sync and plan.ring_mode and plan.inline_relabel and os.environ.get('IL_DP_HANDOFF', '1') != '0')
+    # EVERY per-rank input of this decision (the stream / hardware-queue probe of UpdatePlan.__init__ is one) goes through a collective AND first: a rank that chose the
+    # other schedule would create no side group and issue the discriminator's all-reduce on another communicator than its peers - a hang, not an error.
+    mine = bool(plan.algorithm == 'GAIL' and plan.device_sync and plan.ring_mode and plan.inline_relabel and os.environ.get('IL_DP_HANDOFF', '1') != '0')
+    self.handoff = _agree(mine, group)
     if not self.handoff:
       plan._set_device_sync(False)   # this schedule orders its two streams with events around the all-reduces
     self.side_group = group
-    if self.handoff and dist.is_initialized():
+    if plan.algorithm == 'GAIL' and dist.is_initialized():
+      # unconditionally, on every rank (new_group is collective over the whole default group), whichever schedule was agreed on: it is only USED by the hand-off schedule
       self.side_group = dist.new_group(ranks=None if group is None else dist.get_process_group_ranks(group), backend=dist.get_backend(group))
     self.graph = self.graph_side = None
     self._warm_collectives_pending = True
     self.peer = None   # PeerExchange once the first run() has set it up (collective); None = torch.distributed all-reduces
+    self.peer_note = None   # why the peer-window exchange is not in use, when it was asked for
     ao, to = plan._keep[4], plan._keep[6]
     # actor grad and alpha grad travel in one bucket: the optimisers' gradient arenas become views into it
     self.buckets = GradBuckets(ao.grad.numel(), plan._keep[5].grad, plan._keep[8].grad if plan.algorithm == 'GAIL' else None)
     ao.grad, to.grad = self.buckets.actor_grad, self.buckets.alpha_grad
     plan.sac.actor_grad, plan.sac.alpha_grad = ao.grad.data_ptr(), to.grad.data_ptr()
-    self.side = torch.cuda.Stream() if plan.algorithm == 'GAIL' else None
+    # The discriminator branch runs on the plan's own second stream: the one UpdatePlan's probes validated against the caller's stream (a fresh stream may be multiplexed
+    # onto the caller's hardware queue, and the two branches would then serialise)
+    self.side = (plan.side if plan.side is not None else torch.cuda.Stream()) if plan.algorithm == 'GAIL' else None
     self.actor_bucket, self.critic_bucket, self.disc_bucket = self.buckets.actor, self.buckets.critic, self.buckets.disc
+    if dist.is_initialized() and dist.get_world_size(group) > 1 and plan.device_sync:
+      # a rank waits for the all-reduced discriminator step INSIDE its SAC branch: that bound must not be shorter than the exchange's own (IL_PEER_SPIN_LIMIT), or ordinary
+      # inter-rank skew (an environment reset, a GC pause) expires the inner wait first and the update trains on stale rewards
+      plan.widen_handoff_bound()
 
   def _warm_collectives(self):
     """First use of a communicator sets up its connections (host-blocking, up to seconds) and ranks reach their first update seconds apart: neither may happen inside an
@@ -309,6 +441,8 @@ class DataParallelUpdate:
       return
     sizes = dict(disc=self.disc_bucket.numel() if self.disc_bucket is not None else 0, critic=self.critic_bucket.numel(), actor=self.actor_bucket.numel())
     self.peer = PeerExchange.create(sizes, self.plan.rows.device, self.group)
+    if self.peer is None:
+      self.peer_note = 'set-up, self-test or soak test of the peer-window exchange failed on some rank: torch.distributed all-reduces'
     if self.peer is None and mode == 'require':
       raise RuntimeError('IL_PEER_EXCHANGE=require: the peer-window exchange could not be set up or failed its self-test on some rank')
 
@@ -332,6 +466,39 @@ class DataParallelUpdate:
       return
     self._exchange(name, group)
     _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), phase, logp, q, 0, _lib.stream_ptr()))
+
+  def replica_state(self):
+    """Every tensor the ranks must agree on bit for bit after any number of data-parallel updates: parameter arenas, log alpha, spectral-norm buffers, and each optimiser's
+    moments and step counter (`replicas_bit_identical` hashes them)."""
+    actor, critic, log_alpha, target, ao, co, to, disc, do = self.plan._keep
+    out = replica_tensors(actor, critic, target, log_alpha, disc if self.plan.algorithm == 'GAIL' else None)
+    for o in (ao, co, to) + ((do,) if self.plan.algorithm == 'GAIL' and do is not None else ()):
+      out += [o.exp_avg, o.exp_avg_sq, o.step_count[:1]]
+    return out
+
+  def resync_replicas(self, src: int = 0):
+    """Collective: rank `src`'s replica state everywhere (after a failed exchange left the replicas apart)."""
+    torch.cuda.synchronize()
+    broadcast_parameters(self.replica_state(), src=src, group=self.group)
+    self.plan._prepared = False   # the lane-ordered weight copies are re-derived from the broadcast parameters by the next update
+    torch.cuda.synchronize()
+
+  def exchange_name(self) -> str:
+    """What moves the gradients: 'peer write-through' | 'peer fences' (il_peer_allreduce_mean over peer-mapped windows) | 'rccl' | 'gloo' | 'none' (one rank, no exchange)."""
+    if self.peer is not None:
+      return 'peer write-through' if self.peer.form else 'peer fences'
+    if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and os.environ.get('IL_FORCE_ALLREDUCE') != '1'):
+      return 'none'
+    return 'rccl' if dist.get_backend(self.group) == 'nccl' else dist.get_backend(self.group)
+
+  def use_collectives(self, why: str):
+    """Collective: leave the peer-window exchange for torch.distributed all-reduces (RCCL) - after an expired exchange wait or diverged replicas. Captured graphs are dropped
+    (they hold the peer launches): capture again. The caller re-broadcasts the replicas."""
+    torch.cuda.synchronize()
+    if self.peer is not None:
+      self.peer.close(collective=True)
+    self.peer, self.peer_note = None, why
+    self.graph = self.graph_side = None
 
   def exchange_timeouts(self) -> int:
     """Peer-window waits that gave up since set-up (0 with the collectives); a non-zero count means some update averaged stale gradients."""
@@ -430,7 +597,7 @@ class DataParallelUpdate:
       self._warm_collectives()   # set-up (communicators, peer windows: allocations, host synchronisation) never happens inside a capture
     if self.handoff:   # two graphs, one per branch and per communicator, replayed on two streams with no edge between them (cf. UpdatePlan.capture)
       p = self.plan
-      if not p._probe_device_sync(graph=True):   # e.g. a counter-collecting profiler serialises the two graphs: stream dependencies, one graph (below)
+      if not _agree(p._probe_device_sync(graph=True), self.group):   # e.g. a counter-collecting profiler serialises the two graphs on SOME rank: every rank takes stream dependencies, one graph (below)
         self.handoff = False
         p._set_device_sync(False)
         return self.capture(warmup)

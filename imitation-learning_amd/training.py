@@ -396,7 +396,7 @@ class UpdatePlan:
     self.pb = batch_desc(self.transitions)
     # Device-side hand-off between the two branches (include/il_hip.h `il_sync`): the discriminator branch and the SAC forward then share no stream
     # dependency between the gather and the critic loss. Validated by `capture()`; IL_DEVICE_SYNC=0 keeps plain stream dependencies.
-    self._sync_slots, self._sync_timeouts, self._sync_gather_wgs, _ = _lib.sync_layout()
+    self._sync_slots, self._sync_timeouts, self._sync_gather_wgs, _, self._sync_spin, self._sync_host_flag = _lib.sync_layout()
     self.sync = torch.zeros(self._sync_slots, dtype=torch.int64, device=dev)   # IL_SYNC_SLOTS: every counter on its own 128-byte line
     self.device_sync = False
     self._chain_fits = None
@@ -476,6 +476,29 @@ class UpdatePlan:
     ok = self.sync_timeouts() == before
     self.sync[self._sync_timeouts] = 0
     return ok
+
+  def widen_handoff_bound(self, polls: Optional[int] = None):
+    """[IL_SYNC_SPIN]: the bound of this learner's device-side waits, in polls. A data-parallel rank waits for the all-reduced discriminator step inside its SAC branch and
+    for the previous update's end (which contains two gradient exchanges) in its resident index draw: those waits must outlast the exchange's own bound (IL_PEER_SPIN_LIMIT),
+    or ordinary inter-rank skew expires the inner wait first. Default: twice the exchange's."""
+    self.sync[self._sync_spin] = int(polls) if polls else 2 * _lib.IL_PEER_SPIN_LIMIT
+
+  def watch_timeouts(self, peer_status: Optional[Tensor] = None):
+    """Gives the device a pinned host word per time-out counter ([IL_SYNC_HOST_FLAG]; word [1] of the peer exchange's status): a device-side wait that gives up stores its
+    count there as well, so the training loop reads plain host memory every step (`timeouts_seen()`) - no synchronisation, nothing added to the captured update - and an
+    expired wait is noticed within the pipeline depth (one or two updates) instead of at the next logging interval. Works for captured graphs (the address is read on the
+    device when a wait expires, not baked into a launch)."""
+    if getattr(self, '_watch_host', None) is None:
+      self._watch_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+    self.sync[self._sync_host_flag] = self._watch_host.data_ptr()
+    if peer_status is not None:
+      peer_status[1] = self._watch_host[1:].data_ptr()
+    return self
+
+  def timeouts_seen(self):
+    """(hand-off waits, exchange waits) that have expired so far, as far as the device has reported them. Host read of pinned memory: no synchronisation."""
+    w = getattr(self, '_watch_host', None)
+    return (0, 0) if w is None else (int(w[0]), int(w[1]))
 
   def sync_timeouts(self) -> int:
     """Bounded waits that gave up (device counter). Non-zero means the two branches did not run concurrently (e.g. a counter-collecting

@@ -172,6 +172,10 @@ int il_polyak(float* target, const float* param, int64_t n, double tau, il_strea
  *   [IL_SYNC_SIDE_EPOCH] += 1 when a reward relabel has finished;  [IL_SYNC_MAIN_EPOCH] += 1 at the end of the actor step
  *   [IL_SYNC_TIMEOUTS]   += 1 whenever a bounded wait gave up (must stay 0: check it on the host after the first update)
  *   [IL_SYNC_GATHER_WGS] = il_replay_gather_workgroups(n, row_floats_a, row_floats_b), written by the caller when it creates the buffer.
+ *   [IL_SYNC_SPIN]       = polls before a bounded wait of this learner gives up; 0 = the built-in ~1 s (IL_SYNC_SPIN_LIMIT). Written by the caller; shares the read-only
+ *                          line of [IL_SYNC_GATHER_WGS]. A data-parallel rank whose waits sit downstream of a gradient exchange raises it above the exchange's own bound.
+ *   [IL_SYNC_HOST_FLAG]  = address of a host-mapped (pinned) int64, or 0: a wait that gives up ALSO stores the new [IL_SYNC_TIMEOUTS] value there (system scope), so the host
+ *                          loop can notice an expired wait by reading its own memory every step - no synchronisation, no copy node in the captured update. Same read-only line.
  *   [IL_SYNC_INDICES]    += 1 per finished index draw              -> k_gail_grad on il_batch.gather batches waits for side_epoch + 1 (not for the rows)
  *   [IL_SYNC_PARAMS]     += 1 per finished AdamW(discriminator) workgroup (IL_FLAG_GAIL_CLOSE_EPOCH) -> the inline relabel of il_sac_update_gather waits
  *                          for (main_epoch + 1) * il_gail_step_workgroups()
@@ -187,8 +191,8 @@ int il_sync_probe(int64_t* sync, int32_t setter, il_stream_t stream);
 #endif
 enum { IL_SYNC_ROWS = 0, IL_SYNC_REWARDS = 1 * IL_SYNC_STRIDE, IL_SYNC_SIDE_EPOCH = 2 * IL_SYNC_STRIDE, IL_SYNC_MAIN_EPOCH = 3 * IL_SYNC_STRIDE, IL_SYNC_TIMEOUTS = 4 * IL_SYNC_STRIDE,
        IL_SYNC_GATHER_WGS = 5 * IL_SYNC_STRIDE, IL_SYNC_PROBE_FLAG = 6 * IL_SYNC_STRIDE, IL_SYNC_PROBE_EPOCH = 7 * IL_SYNC_STRIDE, IL_SYNC_INDICES = 8 * IL_SYNC_STRIDE,
-       IL_SYNC_PARAMS = 9 * IL_SYNC_STRIDE, IL_SYNC_SLOTS = 16 * IL_SYNC_STRIDE };
-/* out[0] = IL_SYNC_SLOTS (int64 elements to allocate and zero), out[1] = IL_SYNC_TIMEOUTS, out[2] = IL_SYNC_GATHER_WGS, out[3] = IL_SYNC_STRIDE */
+       IL_SYNC_PARAMS = 9 * IL_SYNC_STRIDE, IL_SYNC_SPIN = 5 * IL_SYNC_STRIDE + 1, IL_SYNC_HOST_FLAG = 5 * IL_SYNC_STRIDE + 2, IL_SYNC_SLOTS = 16 * IL_SYNC_STRIDE };
+/* out[0] = IL_SYNC_SLOTS (int64 elements to allocate and zero), out[1] = IL_SYNC_TIMEOUTS, out[2] = IL_SYNC_GATHER_WGS, out[3] = IL_SYNC_STRIDE, out[4] = IL_SYNC_SPIN, out[5] = IL_SYNC_HOST_FLAG */
 void il_sync_layout(int32_t* out);
 
 /* ------------------------------------------------------------------------------------------
@@ -535,7 +539,8 @@ typedef struct il_peer_bucket {
   int64_t window_offset;               /* byte offset of this bucket's region (il_peer_region_bytes) in EVERY rank's window; multiple of 256 */
   void* windows[IL_PEER_MAX_RANKS];    /* windows[r] = rank r's window as mapped in this process ([rank] = the own allocation) */
   uint32_t* epoch;                     /* local device uint32[ceil(n / IL_PEER_CHUNK_FLOATS)], zero-initialised: exchanges done per chunk */
-  int64_t* status;                     /* local device int64[2], zero-initialised: [0] += 1 per wait that gave up (must stay 0) */
+  int64_t* status;                     /* local device int64[2], zero-initialised: [0] += 1 per wait that gave up (must stay 0); [1] = address of a host-mapped int64 that
+                                          receives the new count whenever [0] moves (0 = none): the host notices without synchronising */
   int32_t spin_limit, flags;           /* polls before a wait gives up (0 = IL_PEER_SPIN_LIMIT); IL_PEER_WRITE_THROUGH or 0 */
 } il_peer_bucket;
 /* bytes of a bucket's region: slots float[2 parities][world][n rounded up to chunks] + arrival words; -1 on bad arguments */

@@ -40,7 +40,7 @@ def test_struct_sizes_match_header():
 
 
 def test_product_package_never_imports_the_oracle():
-  pat = re.compile(r'^\s*(from|import)\s+oracle\b|[\'"]oracle[/\'"]', re.M)
+  pat = re.compile(r'^\s*(from|import)\s+oracle\b|[\'"]oracle[/\'"]|_ref\b|ref_cpu_baseline|build_ref|/root/reference', re.M)   # neither the numpy oracle nor oracle/_ref (the reference's own modules, byte-compiled) nor the reference itself
   for dirpath, _, files in os.walk(PKG):
     for f in files:
       if f.endswith(('.py', '.hip', '.hpp', '.cpp', '.h')):
@@ -50,6 +50,30 @@ def test_product_package_never_imports_the_oracle():
     p = os.path.join(ROOT, f)
     if os.path.exists(p):
       assert not pat.search(open(p).read())
+
+
+def test_reference_build_product_is_the_reference():
+  """oracle/_ref (what bench.py's cpu_baseline leg times live): byte-compiled from the reference's own three hot-path modules - the MANIFEST's source hashes equal the files
+  under /root/reference when that is present (this container), the modules import sourcelessly and expose the reference's entry points, and nothing of it is tracked by git."""
+  import hashlib, json, subprocess, sys
+  ref_dir = os.path.join(ROOT, 'oracle', '_ref')
+  have_reference = os.path.isfile('/root/reference/training.py')
+  if have_reference:
+    subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'build_ref.py')], check=True, capture_output=True)
+  if not os.path.isdir(ref_dir):
+    pytest.skip('oracle/_ref is absent and there is no /root/reference to build it from')
+  man = json.load(open(os.path.join(ref_dir, 'MANIFEST.json')))
+  assert set(man['modules']) == {'memory', 'models', 'training'}
+  if have_reference:
+    for m, v in man['modules'].items():
+      assert v['source_sha256'] == hashlib.sha256(open(f'/root/reference/{m}.py', 'rb').read()).hexdigest()
+  assert not any(f.endswith('.py') for f in os.listdir(ref_dir)), 'no reference source text in the repo: byte code only (plus our omegaconf stand-in in its own directory)'
+  code = ('import sys; sys.path.insert(0, %r); import memory, models, training; '
+          'assert training.sac_update and training.adversarial_imitation_update and models.GAILDiscriminator and memory.ReplayMemory; print(memory.__file__)' % ref_dir)
+  r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+  assert r.returncode == 0 and r.stdout.strip().endswith('memory.pyc'), r.stderr[-500:]
+  tracked = subprocess.run(['git', '-C', ROOT, 'ls-files', 'oracle/_ref'], capture_output=True, text=True).stdout.strip()
+  assert tracked == '', 'oracle/_ref must stay out of git history'
 
 
 @pytest.mark.parametrize('seed,size,idx,full', [(0, 1000, 300, False), (1, 64, 22, True), (2, 500, 0, True), (3, 1_000_000, 100_000, False), (4, 25_000, 0, True), (5, 3, 0, True)])

@@ -131,7 +131,9 @@ with torch.cuda.stream(s):
     s.synchronize()
     graph_bad += int(not torch.equal(buf, torch.full_like(buf, 1.5 + rep)))
 torch.cuda.synchronize()
+rep = x.soak_report
 np.save(os.path.join(sys.argv[2], f'peer{rank}.npy'), np.array([bad, graph_bad, x.timeouts(), form0]))
+np.save(os.path.join(sys.argv[2], f'soak{rank}.npy'), np.array([rep['rounds'], sum(rep['mismatching_elements'].values()), rep['expired_waits'], len(rep['buckets']), int('_load' in rep['buckets'])]))
 x.close()
 dist.barrier(); dist.destroy_process_group()
 '''
@@ -142,11 +144,13 @@ def test_peer_exchange_kernel_two_ranks(tmp_path):
   bitwise against (a + b) / 2 of the gathered inputs; then the launch captured in a hipGraph and replayed."""
   script = tmp_path / 'peer_worker.py'
   script.write_text(PEER_WORKER)
-  _launch([str(script), ROOT, str(tmp_path)], str(tmp_path))
+  _launch([str(script), ROOT, str(tmp_path)], str(tmp_path), IL_PEER_SOAK_ROUNDS='300')   # 2,000 by default; the two ranks of this test share one GPU
   for r in (0, 1):
     bad, graph_bad, timeouts, form0 = np.load(tmp_path / f'peer{r}.npy')
     assert (bad, graph_bad, timeouts) == (0, 0, 0), f'rank {r}: {bad} mismatching exchanges, {graph_bad} mismatching graph replays, {timeouts} expired waits'
     assert form0 == 1, 'the windows of an MI355X are uncached allocations: the set-up ladder should have adopted the write-through form'
+    rounds, mism, expired, nb, has_load = np.load(tmp_path / f'soak{r}.npy')
+    assert (rounds, mism, expired, nb, has_load) == (300, 0, 0, 7, 1), 'create() adopts a form only after the soak: every bucket + the 4 MB load bucket, interleaved on three streams, bitwise every round'
 
 
 def test_peer_exchange_single_rank_is_identity():
@@ -176,3 +180,71 @@ def test_train_py_runs_data_parallel(tmp_path):
   assert {'agent.pth', 'discriminator.pth', 'metrics.pth'} <= names
   m = torch.load(runs[0] / 'metrics.pth', weights_only=False)
   assert len(m['update_steps']) >= 2 and np.isfinite(np.asarray(m['Q_values'][-1])).all()
+
+
+def test_soak_catches_a_corrupted_exchange():
+  """The soak's comparison is live: one rank, one bucket, and a 'peer' that flips a single element of the result once, mid-run, must fail it."""
+  from imitation_learning_amd import parallel
+  dev = torch.device('cuda', 0)
+  x = parallel.PeerExchange.create(dict(g=5000), dev, soak_rounds=50)
+  assert x is not None and x.soak_report['rounds'] == 50 and not any(x.soak_report['mismatching_elements'].values())
+  real, calls = x.allreduce_mean, [0]
+
+  def tampering(name, bucket):
+    out = real(name, bucket)
+    calls[0] += 1
+    if calls[0] == 17: bucket[1234] += 0.25
+    return out
+  x.allreduce_mean = tampering
+  assert x.soak(40) is False and sum(x.soak_report['mismatching_elements'].values()) == 1
+  x.allreduce_mean = real
+  assert x.soak(40) is True
+  x.close()
+
+
+def test_expired_wait_raises_the_host_flag():
+  """[IL_SYNC_HOST_FLAG]: a bounded device-side wait that gives up stores its count into a pinned host word as well (UpdatePlan.watch_timeouts / train.py's per-step check).
+  The probe's waiter with no setter behind it is such a wait (~10 ms)."""
+  import ctypes as C
+  from imitation_learning_amd import _lib
+  slots, timeouts, _, _, spin, host_flag = _lib.sync_layout()
+  sync = torch.zeros(slots, dtype=torch.int64, device='cuda')
+  word = torch.zeros(2, dtype=torch.int64).pin_memory()
+  sync[host_flag] = word.data_ptr()
+  _lib.check(_lib.lib().il_sync_probe(_lib.ptr(sync), 0, _lib.stream_ptr()))   # waiter only: expires
+  torch.cuda.synchronize()
+  assert int(sync[timeouts].item()) == 1 and int(word[0]) == 1
+  _lib.check(_lib.lib().il_sync_probe(_lib.ptr(sync), 0, _lib.stream_ptr()))
+  torch.cuda.synchronize()
+  assert int(word[0]) == 2 and int(word[1]) == 0
+
+
+def _bench(args, **env):
+  e = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+  e.update(HSA_ENABLE_IPC_MODE_LEGACY='0', **env)
+  return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=e, capture_output=True, text=True, timeout=900)
+
+
+def test_bench_gpus_2_refuses_on_a_one_gpu_box():
+  if torch.cuda.device_count() >= 2:
+    pytest.skip('this box has two GPUs')
+  r = _bench(['--gpus', '2', '--steps', '5', '--warmup', '2'])
+  assert r.returncode == 2 and 'needs 2 visible GPUs' in r.stderr and '"metric"' not in r.stdout
+
+
+@pytest.mark.parametrize('peer', ['1', '0'])
+def test_bench_starts_its_own_ranks_and_reports_the_replica_digest(peer):
+  """`python bench.py --gpus 2` with no rank environment: bench.py launches the two ranks itself (here they share the box's GPU and meet over gloo: IL_BENCH_SHARE_GPU=1),
+  prints n_gpus 2, the exchange actually used, the soak report and replicas_bit_identical."""
+  import json
+  r = _bench(['--gpus', '2', '--steps', '30', '--warmup', '5', '--trace-steps', '2'], IL_BENCH_SHARE_GPU='1', IL_PEER_EXCHANGE=peer, IL_PEER_SOAK_ROUNDS='200', IL_DEVICE_SYNC='0')
+  assert r.returncode == 0, r.stderr[-3000:]
+  j = json.loads(r.stdout.strip().splitlines()[-1])
+  c = j['config']
+  assert j['n_gpus'] == 2 and c['global_batch'] == 512 and 'bench.py itself' in c['launched_by']
+  assert c['replicas_bit_identical'] is True and len(c['replica_digests']) == 2 and len(set(c['replica_digests'])) == 1
+  if peer == '1':
+    assert c['exchange'].startswith('peer') and c['exchange_soak']['rounds'] == 200 and c['exchange_soak']['expired_waits'] == 0 and not any(c['exchange_soak']['mismatching_elements'].values())
+  else:
+    assert c['exchange'] == 'gloo' and c['exchange_soak'] is None
+  assert c['exchange_fallback'] is None and j['value'] > 0

@@ -41,6 +41,16 @@ def pretrain_bc(cfg, actor, expert_memory, state_size, action_size):
     il.behavioural_cloning_update(actor, batch, optimiser)
 
 
+def check_timeouts_seen(plan, step, last_good):
+  """Every update step, no synchronisation: the pinned host words a device-side wait stores into when it gives up (UpdatePlan.watch_timeouts). Raises within the pipeline
+  depth of the expiry (one or two updates), naming the last step at which the words still read zero - checkpoints are only ever written after a clean check."""
+  handoff, exchange = plan.timeouts_seen()
+  if handoff or exchange:
+    what = (f'{exchange} wait(s) of the peer-window gradient exchange (a rank did not deliver its gradients within the bound: IL_PEER_EXCHANGE=0 selects RCCL all-reduces)' if exchange else
+            f'{handoff} device-side hand-off wait(s) (the discriminator and SAC branches did not run concurrently: IL_DEVICE_SYNC=0 selects stream dependencies)')
+    raise RuntimeError(f'step {step}: {what} expired; updates since step {last_good} (the last one checked clean) may have trained on stale rewards / gradients. Nothing was saved after that step.')
+
+
 def check_handoff(plan, step, runner=None):
   """The two branches of a captured GAIL update hand over through device counters with BOUNDED waits (include/il_hip.h il_sync): a wait that expires lets the
   update proceed on stale rewards / discriminator weights and bumps a counter. That can only happen if something stops the two streams from running
@@ -67,8 +77,9 @@ def train(cfg, file_prefix: str = '') -> float:
     from imitation_learning_amd import parallel
     assert torch.cuda.is_available(), 'train.py needs a GPU: the update path has no CPU fallback'
     rank, _, dev = parallel.init_from_env(world, cfg.distributed.backend)
+    dog = parallel.Watchdog(float(cfg.distributed.timeout_s), what=f'train.py (rank {rank} of {world})')   # a rank that dies inside a collective must not hang the others
   else:
-    dev = default_device()
+    dev, dog = default_device(), None
   assert dev.type == 'cuda', 'train.py needs a GPU: the update path has no CPU fallback'
   lead = rank == 0                # evaluation, plots and checkpoints are rank 0's job
   seed = cfg.seed + rank
@@ -123,7 +134,9 @@ def train(cfg, file_prefix: str = '') -> float:
       episode_returns = evaluate_agent(actor, eval_env, cfg.evaluation.episodes)
       normalised = normalise(episode_returns)
       metrics.update(test_steps=[0], test_returns=[episode_returns], test_returns_normalized=[list(normalised)])
-      if not lead: return float(np.mean(normalised))   # algorithm=BC has no update block to parallelise: every rank clones on its own, rank 0 reports
+      if world > 1:   # algorithm=BC has no update block to parallelise: every rank clones on its own, rank 0 reports
+        torch.distributed.barrier(); torch.distributed.destroy_process_group(); dog.stop()
+      if not lead: return float(np.mean(normalised))
       torch.save(dict(actor=actor.state_dict()), f'{file_prefix}agent.pth')
       torch.save(metrics, f'{file_prefix}metrics.pth')
       return float(np.mean(normalised))
@@ -181,7 +194,9 @@ def train(cfg, file_prefix: str = '') -> float:
   if cfg.algorithm in ('GAIL', 'RED'): discriminator.eval()   # train.py:147: from here on the RED predictor's dropout is off (DRIL keeps its dropout on purpose)
   t, state, terminal, train_return = 0, env.reset(), False, 0
   action = worker.act(state) if schedule in ('fused', 'overlap') else None
+  last_good = 0   # the last update step whose time-out words read zero (check_timeouts_seen)
   for step in range(1, cfg.steps + 1):
+    if dog is not None: dog.beat(f'step {step}')
     update_due = step >= cfg.training.start and step % cfg.training.interval == 0
     if schedule == 'per_function':
       with torch.inference_mode():
@@ -229,8 +244,13 @@ def train(cfg, file_prefix: str = '') -> float:
             runner.capture(warmup=0)   # the gradient exchange (peer-window kernels, or RCCL collectives) is captured with the kernels: one graph replay per data-parallel update
             step_update = runner.replay
           captured = True
+          plan.watch_timeouts(runner.peer.status if getattr(runner, 'peer', None) is not None else None)   # expired device-side waits raise a host-visible flag from now on
+          if world > 1:   # graph capture takes different times on different ranks: meet again before the first replay, whose device-side waits are bounded
+            torch.cuda.synchronize(); torch.distributed.barrier()
         else:
           step_update()
+        check_timeouts_seen(plan, step, last_good)   # host read of pinned words: every step, independent of logging.interval
+        last_good = step
         rewards, log_probs, Q_values = plan.transitions['rewards'], plan.logp, plan.q
       else:
         transitions, expert_transitions = memory.sample(B), expert_memory.sample(B)
@@ -280,12 +300,24 @@ def train(cfg, file_prefix: str = '') -> float:
       # rank 0 has just spent seconds evaluating: align the hosts here, so that no BOUNDED device-side wait of the next update (the peer-window exchange, the hand-off on
       # the all-reduced discriminator step) has to span that gap
       torch.cuda.synchronize(); torch.distributed.barrier()
+      if plan is not None:   # replicas apply the same averaged gradients with the same kernels: anything but identical bits means an exchange went wrong - stop before training on
+        check_handoff(plan, step, runner)
+        same, digests = parallel.replicas_bit_identical(runner.replica_state())
+        if not same:
+          raise RuntimeError(f'step {step}: the data-parallel replicas are no longer bit-identical (sha256 per rank: {[d[:12] for d in digests]}; exchange: {runner.exchange_name()}). '
+                             'Re-run with IL_PEER_EXCHANGE=0 (RCCL all-reduces).')
+        metrics.setdefault('replica_checks', []).append((step, digests[0][:16], runner.exchange_name()))
 
   if plan is not None: plan.join()   # the discriminator is stepped on the plan's second stream: order the checkpoint reads after it
   check_handoff(plan, cfg.steps, runner)   # never save a learner whose last updates ran on expired device-side waits
   if world > 1:
     import torch.distributed as dist
     torch.cuda.synchronize(); dist.barrier()
+    if plan is not None:
+      same, digests = parallel.replicas_bit_identical(runner.replica_state())
+      if not same:
+        raise RuntimeError(f'end of training: the data-parallel replicas are not bit-identical (sha256 per rank: {[d[:12] for d in digests]}); nothing saved')
+    dog.stop()
     if not lead:   # replicas are identical: rank 0 writes the checkpoint; the others return their (empty) score
       dist.destroy_process_group()
       return float('nan')
