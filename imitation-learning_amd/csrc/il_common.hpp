@@ -219,7 +219,7 @@ __device__ __forceinline__ void sync_signal(long long* ctr) {   // all threads o
 __device__ __forceinline__ void sync_timed_out(long long* sync) {   // one thread: count the expired wait, and raise the host's flag if it gave us one ([IL_SYNC_HOST_FLAG])
   const long long n = __hip_atomic_fetch_add(sync + IL_SYNC_TIMEOUTS, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
   const long long host = sync[IL_SYNC_HOST_FLAG];
-  if (host) __hip_atomic_store(reinterpret_cast<long long*>(host), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (host) __hip_atomic_store((__attribute__((address_space(1))) long long*)host, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // typed global: a FLAT store would make every later wait of the kernel conservative
 }
 __device__ __forceinline__ void sync_wait(long long* sync, int which, long long target, int limit = 0) {   // all threads of the workgroup, before their loads
   if (threadIdx.x == 0) {   // limit 0: the learner's own bound [IL_SYNC_SPIN] (0 there = IL_SYNC_SPIN_LIMIT), read only once a poll has failed: nothing on the fast path

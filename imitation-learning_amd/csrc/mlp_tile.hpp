@@ -12,6 +12,9 @@
 #pragma once
 #include "il_common.hpp"
 
+#ifndef IL_L1_PAIR
+#define IL_L1_PAIR 1   // tile_fwd: k-blocks of a narrow first layer fetched pairwise (0 = the round-2 one-at-a-time loop, for A/B builds); same MFMA order, same bits
+#endif
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 
 // Operand loads are never wrapped in a branch or a select (hipcc turns `cond ? load : 0` into an exec-masked branch that
@@ -89,6 +92,22 @@ __device__ __forceinline__ void tile_fwd_impl(const float* Xs, int ldx, int Kpad
         acc1 = mfma16(a[3], b[u][3], acc1);
       }
     }
+#if IL_L1_PAIR
+    for (; k0 + 32 <= Kpad; k0 += 32) {   // the first layers (K = 17 .. 32 -> Kpad = 32): both k-blocks' weight lanes requested before the first MFMA instead of two dependent L2 round trips
+      f32x4 b[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) b[u] = load4<MODE>(wr - 4 * g, k0 + 16 * u + 4 * g, Kw);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xr + k0 + 16 * u);
+        acc0 = mfma16(a[0], b[u][0], acc0);
+        acc1 = mfma16(a[1], b[u][1], acc1);
+        acc0 = mfma16(a[2], b[u][2], acc0);
+        acc1 = mfma16(a[3], b[u][3], acc1);
+      }
+    }
+#endif
     for (; k0 < Kpad; k0 += 16) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(xr + k0);
       const f32x4 b = load4<MODE>(wr - 4 * g, k0 + 4 * g, Kw);
@@ -164,8 +183,29 @@ __device__ __forceinline__ void tile_bwd_dx(const float* dYs, int ldy, int Npad,
 // every wave issues 4 and the partial tiles meet in LDS (`part` >= (N/16) * 256 floats), summed in n-block order (deterministic).
 // Contains __syncthreads(); every thread of the block must call. epi(col, row, value) once per element of the 16-column tiles that overlap the range.
 // ---------------------------------------------------------------------------------------------
+// The weight operands of tile_bwd_dx_cols / tile_fwd_small depend on nothing the kernel computes: `*_prefetch` requests this wave's lanes (first column tile; up to two
+// n- / k-blocks per wave, i.e. every block of a 16- or 8-wave workgroup at H = 256) at the top of the kernel, so that the small GEMM at the END of a dependent chain of
+// layers starts from registers instead of from an L2 / fabric round trip behind a barrier. Same values, same MFMA order: same bits.
+#ifndef IL_SMALL_PREFETCH
+#define IL_SMALL_PREFETCH 1
+#endif
+struct ColsPre { float b[2][4]; };
+__device__ __forceinline__ ColsPre tile_bwd_dx_cols_prefetch(const float* __restrict__ W, int ldw, int K, int N, int c_lo) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const float* wp = W + min(((c_lo >> 4) << 4) + j, K - 1);
+  ColsPre p;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int n0 = min((wave + q * nw) * 16, N - 16);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) p.b[q][s] = gload(wp + (size_t)(n0 + 4 * g + s) * ldw);
+  }
+  return p;
+}
 template <class Epi>
-__device__ __forceinline__ void tile_bwd_dx_cols(const float* dYs, int ldy, int N, const float* __restrict__ W, int ldw, int K, int c_lo, int c_hi, float* part, Epi epi) {
+__device__ __forceinline__ void tile_bwd_dx_cols(const float* dYs, int ldy, int N, const float* __restrict__ W, int ldw, int K, int c_lo, int c_hi, float* part, Epi epi,
+                                                 const ColsPre* pre = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   // One partial tile per 16-wide n-block (N / 16 <= 16 of them), summed in n-block order: the result does not depend on how many waves the workgroup
@@ -176,8 +216,14 @@ __device__ __forceinline__ void tile_bwd_dx_cols(const float* dYs, int ldy, int 
       f32x4 acc0 = zero4(), acc1 = zero4();
       const f32x4 a = *reinterpret_cast<const f32x4*>(dYs + j * ldy + n0 + 4 * g);
       float b[4];
+      const int q = (n0 >> 4) - wave;   // 0, nw, 2 nw, ...
+      if (pre && kb == ((c_lo >> 4) << 4) && q <= nw) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) b[s] = gload(wp + (size_t)(n0 + 4 * g + s) * ldw);
+        for (int s = 0; s < 4; ++s) b[s] = q == 0 ? pre->b[0][s] : pre->b[1][s];
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[s] = gload(wp + (size_t)(n0 + 4 * g + s) * ldw);
+      }
       acc0 = mfma16(a[0], b[0], acc0);
       acc1 = mfma16(a[1], b[1], acc1);
       acc0 = mfma16(a[2], b[2], acc0);
@@ -266,15 +312,26 @@ __device__ __forceinline__ void tile_bwd_packed(const float* dYs, int ldy, int H
 // The K/16 k-blocks are dealt round-robin to the waves; partial tiles are reduced through LDS (`part` >= (K/16)*256 floats; K % 16 == 0).
 // Contains __syncthreads(); every thread of the block must call. Result valid after return.
 // ---------------------------------------------------------------------------------------------
+struct SmallPre { f32x4 b[2]; };
+__device__ __forceinline__ SmallPre tile_fwd_small_prefetch(const float* __restrict__ W, int ldw, int N, int K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const float* wr = W + (size_t)min(j, N - 1) * ldw;
+  SmallPre p;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) p.b[q] = gload4(wr + min((wave + q * nw) * 16, K - 16) + 4 * g);
+  return p;
+}
 __device__ __forceinline__ void tile_fwd_small(const float* Xs, int ldx, int K, const float* __restrict__ W, int ldw, int N, const float* __restrict__ bias,
-                                               float* Os, float* part) {
+                                               float* Os, float* part, const SmallPre* pre = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const float* wr = W + (size_t)min(j, N - 1) * ldw;  // clamped row: no divergent branch around the load
   for (int k0 = wave * 16; k0 < K; k0 += nw * 16) {   // one partial tile per k-block (K / 16 <= 16), summed in k-block order below: independent of the wave count
     f32x4 acc = zero4();
     const f32x4 a = *reinterpret_cast<const f32x4*>(Xs + j * ldx + k0 + 4 * g);
-    const f32x4 b = gload4(wr + k0 + 4 * g);  // columns j >= N produce garbage that Os below discards
+    const int q = (k0 >> 4) - wave;
+    const f32x4 b = (pre && q <= nw) ? (q == 0 ? pre->b[0] : pre->b[1]) : gload4(wr + k0 + 4 * g);  // columns j >= N produce garbage that Os below discards
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = mfma16(a[s], b[s], acc);
 #pragma unroll

@@ -81,7 +81,7 @@ __device__ __forceinline__ int peer_chunk_allreduce(const il_peer_bucket& x, con
     if (!all && tid == 0) {
       const long long n = __hip_atomic_fetch_add(reinterpret_cast<long long*>(x.status), 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
       const long long host = reinterpret_cast<const long long*>(x.status)[1];   // a host-mapped flag the training loop reads every step without synchronising (0 = none)
-      if (host) __hip_atomic_store(reinterpret_cast<long long*>(host), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (host) __hip_atomic_store((__attribute__((address_space(1))) long long*)host, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   __syncthreads();

@@ -98,7 +98,25 @@ __global__ __launch_bounds__(PW_CHUNK) void k_pwil_select(il_pwil d, const float
   if (i < N && d.weights[i] >= 0.f) {
     const float* a = d.atoms + (size_t)i * D;
     float s = 0.f;
-    for (int k = 0; k < D; ++k) { const float df = a[k] - z[k]; s += df * df; }
+    int k = 0;
+    if ((D & 3) == 0 && (reinterpret_cast<uintptr_t>(d.atoms) & 15) == 0) {
+      // (round 3) the scalar loop below compiled to load -> wait -> fma once per feature: D dependent round trips to HBM per atom (24 at HalfCheetah dims) were the
+      // whole cost of this kernel. Eight 16-byte lanes of the row are requested first (addresses past the row clamp to its last lane and are not used); the adds
+      // keep their order k = 0, 1, 2, ..., so the distance keeps its bits (and with it the order of the coupling).
+      for (; k < D; k += 32) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = gload4(a + min(k + 4 * u, D - 4));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k + 4 * u < D) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float df = v[u][c] - z[k + 4 * u + c]; s += df * df; }
+          }
+      }
+    }
+    for (; k < D; ++k) { const float df = a[k] - z[k]; s += df * df; }
     dist = sqrtf(s);
   }
   sd[tid] = dist;
@@ -176,7 +194,98 @@ __device__ __forceinline__ void pwil_merge_wave(const il_pwil& d, int G, int K, 
   if (lane == 0) out[0] = (float)(d.reward_scale * exp(-d.reward_bandwidth * cost));
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_pwil_merge (round 3): the step's coupling WITHOUT a serial merge. The step consumes at most m <= K atoms, in ascending (distance, index) order - so all it needs is
+// the m smallest candidates, sorted. (i) A threshold that provably covers them: T = min(the smallest list TAIL - that list alone holds K candidates <= it -, the K-th
+// smallest list HEAD - K different lists hold a candidate <= it). With distances spread over ~100 chunks the second bound leaves ~1.2 K survivors of the G K
+// candidates. (ii) Survivors are compacted into LDS (order irrelevant), (iii) ranked by counting (keys are unique: the atom index is part of the key), (iv) the first m
+// of them, in rank order, go through the same greedy loop as before - cost and remaining weight accumulated in double, consumed in ascending key order: the same
+// operations on the same values in the same order as the serial merge and the one-workgroup kernel, so the reward and the weights keep their bits - (v) the consumed
+// atoms are marked in parallel. The single wave's G-way merge this replaces took ~1 us per consumed atom (25.5 of the 35 us of a step at N = 25k, T = 1000).
+// Needs G K <= PW_LDS_CAND (every candidate may survive when few atoms are left); larger sets keep k_pwil_merge_serial.
+// ---------------------------------------------------------------------------------------------
+#define PW_PER_THREAD (PW_LDS_CAND / 256)
 __global__ __launch_bounds__(256) void k_pwil_merge(il_pwil d, int G, int K, const PwCand* __restrict__ cand, float* __restrict__ out) {
+  __shared__ unsigned long long skey[PW_LDS_CAND];   // survivors, then (first G entries, earlier) the list heads
+  __shared__ float sw[PW_LDS_CAND];
+  __shared__ unsigned long long okey[PW_CHUNK];
+  __shared__ float ow[PW_CHUNK];
+  __shared__ unsigned long long red[8];
+  __shared__ int nsurv;
+  const int tid = threadIdx.x, total = G * K;
+  const unsigned long long EMPTY = ~0ull;
+  // every candidate this thread owns, and the head / tail of the lists it owns, requested together: ONE round trip to the lists k_pwil_select just wrote
+  PwCand c[PW_PER_THREAD];
+#pragma unroll
+  for (int u = 0; u < PW_PER_THREAD; ++u) c[u] = cand[min(tid + 256 * u, total - 1)];
+  PwCand hd[4], tl[4];   // lists tid, tid + 256, ... (G <= 1024)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int l = min(tid + 256 * q, G - 1); hd[q] = cand[(size_t)l * K]; tl[q] = cand[(size_t)l * K + K - 1]; }
+  __builtin_amdgcn_sched_barrier(0);
+  if (tid == 0) nsurv = 0;
+  unsigned long long tmin = EMPTY;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int l = tid + 256 * q;
+    if (l < G) {
+      skey[l] = hd[q].idx == INT_MAX ? EMPTY : pw_key(hd[q].dist, hd[q].idx);
+      const unsigned long long t = tl[q].idx == INT_MAX ? EMPTY : pw_key(tl[q].dist, tl[q].idx);
+      tmin = t < tmin ? t : tmin;
+    }
+  }
+  tmin = wave_min_u64(tmin);
+  if ((tid & 63) == 0) red[tid >> 6] = tmin;
+  __syncthreads();
+  // the K-th smallest head by counting: head h has rank #{heads < h} (unique keys; EMPTY heads never qualify)
+  unsigned long long thead = EMPTY;
+  for (int l = tid; l < G; l += 256) {
+    const unsigned long long h = skey[l];
+    if (h == EMPTY) continue;
+    int rank = 0;
+    for (int j = 0; j < G; ++j) rank += skey[j] < h ? 1 : 0;
+    if (rank == K - 1) thead = h;
+  }
+  thead = wave_min_u64(thead);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = thead;
+  __syncthreads();
+  unsigned long long T = red[0];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) T = red[w] < T ? red[w] : T;
+  __syncthreads();   // the heads in skey have been read by everyone: the survivors may overwrite them
+#pragma unroll
+  for (int u = 0; u < PW_PER_THREAD; ++u) {
+    if (tid + 256 * u < total && c[u].idx != INT_MAX) {
+      const unsigned long long k2 = pw_key(c[u].dist, c[u].idx);
+      if (k2 <= T) { const int pos = atomicAdd(&nsurv, 1); skey[pos] = k2; sw[pos] = c[u].w; }
+    }
+  }
+  __syncthreads();
+  const int n = nsurv;
+  for (int s = tid; s < n; s += 256) {
+    const unsigned long long k2 = skey[s];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += skey[j] < k2 ? 1 : 0;
+    if (rank < PW_CHUNK) { okey[rank] = k2; ow[rank] = sw[s]; }
+  }
+  __syncthreads();
+  // the greedy coupling over the sorted survivors, by every thread redundantly (LDS broadcast reads): afterwards each thread knows what was consumed
+  const int nn = n < K ? n : K;   // a step consumes at most K = pwil_take() atoms
+  double weight = d.agent_weight, cost = 0.0;
+  int consumed = 0, part_idx = -1; float part_w = 0.f;
+  for (int it = 0; it < nn && weight > 0.0; ++it) {
+    const unsigned long long best = okey[it];
+    const double ew = (double)ow[it], dist = (double)__uint_as_float((unsigned)(best >> 32));
+    if (weight >= ew) { cost += ew * dist; weight -= ew; ++consumed; }
+    else { cost += weight * dist; part_idx = (int)(unsigned)best; part_w = (float)ew - (float)weight; weight = 0.0; }
+  }
+  if (tid < consumed) d.weights[(int)(unsigned)okey[tid]] = -1.f;
+  if (tid == 0) {
+    if (part_idx >= 0) d.weights[part_idx] = part_w;
+    out[0] = (float)(d.reward_scale * exp(-d.reward_bandwidth * cost));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pwil_merge_serial(il_pwil d, int G, int K, const PwCand* __restrict__ cand, float* __restrict__ out) {
   __shared__ PwCand sc[PW_LDS_CAND];
   const int tid = threadIdx.x;
   const bool staged = G * K <= PW_LDS_CAND;
@@ -210,7 +319,9 @@ extern "C" int il_pwil_reward(const il_pwil* d, const float* state, const float*
   if (m <= PW_CHUNK && G <= 64 * PW_MAXQ && !one_wg) {
     PwCand* cand = reinterpret_cast<PwCand*>(d->dists);   // >= il_pwil_scratch_floats(n_atoms, agent_weight) floats
     { IL_TRACE("k_pwil_select", (hipStream_t)stream_); k_pwil_select<<<G, PW_CHUNK, 0, (hipStream_t)stream_>>>(*d, state, action, m, cand); }
-    { IL_TRACE("k_pwil_merge", (hipStream_t)stream_); k_pwil_merge<<<1, 256, 0, (hipStream_t)stream_>>>(*d, G, m, cand, out_reward); }
+    static const bool serial = getenv("IL_PWIL_SERIAL_MERGE") != nullptr;   // developer A/B switch: the round-2 one-wave merge
+    if (G * m <= PW_LDS_CAND && !serial) { IL_TRACE("k_pwil_merge", (hipStream_t)stream_); k_pwil_merge<<<1, 256, 0, (hipStream_t)stream_>>>(*d, G, m, cand, out_reward); }
+    else { IL_TRACE("k_pwil_merge_serial", (hipStream_t)stream_); k_pwil_merge_serial<<<1, 256, 0, (hipStream_t)stream_>>>(*d, G, m, cand, out_reward); }
   } else {
     IL_TRACE("k_pwil_reward", (hipStream_t)stream_); k_pwil_reward<<<1, 1024, 0, (hipStream_t)stream_>>>(*d, state, action, out_reward);
   }

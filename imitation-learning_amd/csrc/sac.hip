@@ -116,6 +116,9 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
   // threads their noise sample (Philox + Box-Muller is ~1 us of dependent ALU work that needs nothing from the MLP) and absorbing flag.
   const int pc = min(wave * 16 + j, H - 1);
   const float pb1 = gload(net.b1 + pc), pb2 = gload(net.b2 + pc);
+#if IL_SMALL_PREFETCH
+  const SmallPre w3pre = tile_fwd_small_prefetch(net.W3, H, 2 * A, H);   // the head's weight lanes: consumed after both hidden layers
+#endif
   const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
   float e_pre = 0.f, absorb_pre = 0.f;
   if (tid < IL_TILE_R * A) {
@@ -148,7 +151,11 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
   });
   __syncthreads();
   IL_TL(is_cur ? 6 : 5, 3);
+#if IL_SMALL_PREFETCH
+  tile_fwd_small(H2s, ldh, H, net.W3, H, 2 * A, net.b3, Os, part, &w3pre);
+#else
   tile_fwd_small(H2s, ldh, H, net.W3, H, 2 * A, net.b3, Os, part);
+#endif
   IL_TL(is_cur ? 6 : 5, 4);
   // head: one thread per (row, action component); per-row sums through LDS (sequential over A like torch's sum(-1))
   float* nl = part; float* la = part + 256;
@@ -725,6 +732,9 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   float w3v[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
+#if IL_SMALL_PREFETCH
+  const ColsPre w1pre = tile_bwd_dx_cols_prefetch(p.W1, IN, IN, H, S);   // the action columns of W1 for dQ/da, the last GEMM of this workgroup
+#endif
   load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, IL_TILE_R);
   __syncthreads();
   IL_STAMP(stamp, 17);
@@ -775,7 +785,11 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   tile_bwd_dx_cols(H1s, ldh, H, p.W1, IN, IN, S, S + A, q16 + 64, [&](int col, int row, float v) {
     const int c = col - S;
     if (c >= 0 && c < A) gout[(size_t)row * A + c] = v;
+#if IL_SMALL_PREFETCH
+  }, &w1pre);
+#else
   });
+#endif
   IL_STAMP(stamp, 23);
   IL_TL(7, 7);
   // The policy backward of this tile needs Q and dQ/da of BOTH critics, i.e. of two workgroups. Instead of a kernel boundary, the workgroup
@@ -834,6 +848,15 @@ __device__ __forceinline__ void adam_store(const DwArgs& a, const adam_consts& a
 #ifndef IL_DW_PREFETCH
 #define IL_DW_PREFETCH 1
 #endif
+#ifndef IL_DW_SCHED_BARRIER
+#define IL_DW_SCHED_BARRIER 1   // dw_tile: all operand loads of a chunk ahead of its MFMAs (0 = the round-2 schedule, for A/B builds)
+#endif
+#ifndef IL_TAIL_BLOCKS
+#define IL_TAIL_BLOCKS 69       // single learner: tail blocks of the actor launch (block 0: Adam(log alpha) + counters; all: polyak over the target arena and its lane-ordered copies, one trip each at H = 256)
+#endif
+#ifndef IL_DW_U
+#define IL_DW_U 16              // single-learner k_dw_adam: 16-row operand lanes in flight per operand and chunk (16 = the whole batch of 256 rows in one round)
+#endif
 // XT: x is feature-major [Kvalid][B]; otherwise row-major [B][ldx] (the actor's layer-1 input = the states field of the batch)
 // U = 16-row operand lanes in flight per operand: 8 for the single learner (one block per CU: latency hiding has to come from the wave itself),
 // 4 for the population launch (half the registers -> four waves per SIMD instead of two hide the latency across blocks).
@@ -866,25 +889,26 @@ __device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, 
     }
   }
   int r0 = 0;
-  for (; r0 + 16 * U <= B; r0 += 16 * U) {
-    f32x4 av[U], bv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) { av[u] = gload4(dzp + r0 + 16 * u); bv[u] = ldx4(r0 + 16 * u); }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      acc0 = mfma16(av[u][0], bv[u][0], acc0);
-      acc1 = mfma16(av[u][1], bv[u][1], acc1);
-      acc0 = mfma16(av[u][2], bv[u][2], acc0);
-      acc1 = mfma16(av[u][3], bv[u][3], acc1);
-    }
+  // Every operand lane of a chunk is REQUESTED before its first MFMA: without the scheduling barrier hipcc sinks the loads back between the MFMAs (round 3, ISA of the
+  // round-2 build: four loads in flight, `s_waitcnt vmcnt(2)` in front of every group of four MFMAs - sixteen dependent L2 round trips per tile, which is what made this
+  // launch 6-8 us for 0.85 us of MFMA issue). Chunks of 16 U, then 64, then 16 rows; the MFMA order (row groups ascending, k-steps 0, 2 -> acc0 and 1, 3 -> acc1) does not
+  // depend on the chunking, so every chunk size gives the same bits.
+#define IL_DW_CHUNK(UU)                                                                                            \
+  for (; r0 + 16 * (UU) <= B; r0 += 16 * (UU)) {                                                                   \
+    f32x4 av[UU], bv[UU];                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < (UU); ++u) { av[u] = gload4(dzp + r0 + 16 * u); bv[u] = ldx4(r0 + 16 * u); } \
+    if (IL_DW_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);                                                    \
+    _Pragma("unroll") for (int u = 0; u < (UU); ++u) {                                                             \
+      acc0 = mfma16(av[u][0], bv[u][0], acc0);                                                                     \
+      acc1 = mfma16(av[u][1], bv[u][1], acc1);                                                                     \
+      acc0 = mfma16(av[u][2], bv[u][2], acc0);                                                                     \
+      acc1 = mfma16(av[u][3], bv[u][3], acc1);                                                                     \
+    }                                                                                                              \
   }
-  for (; r0 < B; r0 += 16) {
-    const f32x4 av = gload4(dzp + r0), bv = ldx4(r0);
-    acc0 = mfma16(av[0], bv[0], acc0);
-    acc1 = mfma16(av[1], bv[1], acc1);
-    acc0 = mfma16(av[2], bv[2], acc0);
-    acc1 = mfma16(av[3], bv[3], acc1);
-  }
+  IL_DW_CHUNK(U)
+  if (U > 4) { IL_DW_CHUNK(4) }
+  IL_DW_CHUNK(1)
+#undef IL_DW_CHUNK
   const f32x4 acc = acc0 + acc1;
   if (k >= Kvalid) return;
   if (a.grads_only) {
@@ -919,7 +943,28 @@ __device__ __forceinline__ void dw_bias(const DwArgs& a, const adam_consts& ac, 
   const int B = a.batch;
   const float* p = dzT + (size_t)min(n0 + j, Nvalid - 1) * B + 4 * g;
   f32x4 s4 = zero4();
-  for (int r0 = 0; r0 < B; r0 += 16) s4 += *reinterpret_cast<const f32x4*>(p + r0);
+  int r0 = 0;
+#if IL_DW_SCHED_BARRIER
+  // (round 3) as a plain loop this was load -> s_waitcnt vmcnt(0) -> add, once per 16 rows: sixteen DEPENDENT L2 round trips at B = 256 - the bias jobs, not the MFMA
+  // tiles, were the long pole of the launch. All lanes of a chunk are requested first; the adds keep their order (ascending rows), so the sums keep their bits.
+  for (; r0 + 256 <= B; r0 += 256) {
+    f32x4 t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = gload4(p + r0 + 16 * u);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s4 += t[u];
+  }
+  for (; r0 + 64 <= B; r0 += 64) {
+    f32x4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = gload4(p + r0 + 16 * u);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4 += t[u];
+  }
+#endif
+  for (; r0 < B; r0 += 16) s4 += *reinterpret_cast<const f32x4*>(p + r0);
   float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
   s += __shfl_xor(s, 16, 64);
   s += __shfl_xor(s, 32, 64);
@@ -933,7 +978,18 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
     const int tb = bid - a.n_dw_blocks;
     if (a.log_alpha && tb == 0 && threadIdx.x == 0) {
       float s = 0.f;
-      for (int i = 0; i < a.n_alpha_part; ++i) s += a.alpha_part[i];
+      int i0 = 0;
+#if IL_DW_SCHED_BARRIER
+      for (; i0 + 16 <= a.n_alpha_part; i0 += 16) {   // one thread, B / 16 partials: requested together, added in index order (as a plain loop: one dependent round trip per partial)
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = gload(a.alpha_part + i0 + u);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += t[u];
+      }
+#endif
+      for (int i = i0; i < a.n_alpha_part; ++i) s += a.alpha_part[i];
       const float alpha = expf(a.log_alpha[0]);
       const float gr = -(alpha) * (s / (float)a.batch);
       if (a.grads_only) a.alpha_grad[0] = gr;
@@ -950,6 +1006,32 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
     if (a.target && !a.grads_only) {
       const float omt = (float)(1.0 - a.tau), tau = (float)a.tau;
       const int ntb = nblocks - a.n_dw_blocks;
+#if IL_DW_SCHED_BARRIER
+      // (round 3) target <- tau target + (1 - tau) critic over the parameter arena AND its lane-ordered copies as ONE index space of 16-byte lanes, four lanes per thread
+      // and trip with all eight loads requested first: the grid-stride loops below were a dependent HBM round trip per trip (the target was last touched an update ago),
+      // 8 trips per thread with 33 tail blocks. Elementwise: the bits do not depend on who computes which lane.
+      if ((a.polyak_n & 3) == 0 && (!a.pk_target || (a.pk_n & 3) == 0)) {
+        const int64_t n1 = a.polyak_n >> 2, n2 = a.pk_target ? (a.pk_n >> 2) : 0, stride = (int64_t)ntb * blockDim.x;
+        for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < n1 + n2; i += 4 * stride) {
+          f32x4 t[4], p[4]; f32x4* dst[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int64_t q = i + u * stride, qc = q < n1 + n2 ? q : i;   // out of range: re-read lane i, never stored
+            const bool second = qc >= n1;
+            dst[u] = reinterpret_cast<f32x4*>(second ? a.pk_target : a.target) + (second ? qc - n1 : qc);
+            t[u] = *dst[u]; p[u] = *(reinterpret_cast<const f32x4*>(second ? a.pk_critic : a.polyak_src) + (second ? qc - n1 : qc));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[u][q] = __fadd_rn(__fmul_rn(t[u][q], tau), __fmul_rn(omt, p[u][q]));
+            if (i + u * stride < n1 + n2) *dst[u] = t[u];
+          }
+        }
+        return;
+      }
+#endif
       for (int64_t i = ((int64_t)tb * blockDim.x + threadIdx.x) * 4; i < a.polyak_n; i += (int64_t)ntb * blockDim.x * 4) {
         if (i + 3 < a.polyak_n) {
           f32x4 t = *reinterpret_cast<f32x4*>(a.target + i); const f32x4 p = *reinterpret_cast<const f32x4*>(a.polyak_src + i);
@@ -1110,7 +1192,7 @@ static inline int dw_block64_count(int H, int nets) { return (H / DWB) * (H / DW
 
 __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
   IL_TL(a.log_alpha ? 2 : 1, 0);   // [1] critic launch, [2] actor launch (the one with the alpha / polyak tail)
-  dw_adam_body<8>(a, (int)blockIdx.x, (int)gridDim.x);
+  dw_adam_body<IL_DW_U>(a, (int)blockIdx.x, (int)gridDim.x);
   IL_TL_END(a.log_alpha ? 2 : 1);
 }
 
@@ -1224,7 +1306,7 @@ extern "C" int il_sac_actor_step(const il_sac* d, const il_batch* b, const float
   { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, eps_cur, 2, nullptr, nullptr); }
   { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
   DwArgs a = actor_dw_args(d, b, flags);
-  const int tail = 1 + ((flags & IL_FLAG_GRADS_ONLY) ? 0 : 32);
+  const int tail = (flags & IL_FLAG_GRADS_ONLY) ? 1 : IL_TAIL_BLOCKS;
   { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<a.n_dw_blocks + tail, 256, 0, st>>>(a); }
   IL_CHECK_LAUNCH("il_sac_actor_step");
   return IL_OK;
@@ -1268,7 +1350,7 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
     { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
     { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
     DwArgs aa = actor_dw_args(d, b, flags);
-    { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 33, 256, 0, st>>>(aa); }
+    { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + IL_TAIL_BLOCKS, 256, 0, st>>>(aa); }
   }
   IL_CHECK_LAUNCH("il_sac_update");
   return IL_OK;
@@ -1328,7 +1410,7 @@ extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const
   }
   { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *rows, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
   DwArgs aa = actor_dw_args(d, rows, flags);
-  { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 33, 256, 0, st>>>(aa); }
+  { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + IL_TAIL_BLOCKS, 256, 0, st>>>(aa); }
   IL_CHECK_LAUNCH("il_sac_update_gather");
   return IL_OK;
 }

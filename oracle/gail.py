@@ -169,6 +169,20 @@ def gail_update(ds: DiscState, xp, wp, xe, we, eps_gp, *, lr, weight_decay, grad
   return flat_g if return_grads else None
 
 
+def predict_reward_f64(ds: DiscState, x, reward_function='AIRL'):
+  """`predict_reward` of the SAME float32 state evaluated in float64 (eval mode): the conditioning reference of a reward comparison. AIRL's log D - log1p(-D) loses
+  digits near D = 1/2, so a float32 evaluation is itself off by up to ~1e-3 relative; a test that allows another float32 implementation `2 x |f32 - f64|` instead of a
+  hand-picked rtol cannot be loosened by accident (tests/gpu_util.py bracket)."""
+  d = np.float64
+  W1, W2, b1, b2 = ds.W1.astype(d), ds.W2.astype(d), ds.b1.astype(d), ds.b2.astype(d)
+  if ds.sn:
+    W1 = W1 / np.dot(ds.u1.astype(d), W1 @ ds.v1.astype(d)); W2 = W2 / np.dot(ds.u2.astype(d), W2 @ ds.v2.astype(d))
+  z = np.maximum(x.astype(d) @ W1.T + b1, 0.0) @ W2[0] + b2[0]
+  D = 1.0 / (1.0 + np.exp(-z))
+  h = -np.log1p(-D + 1e-6) if reward_function == 'GAIL' else np.log(D + 1e-6) - np.log1p(-D + 1e-6)
+  return np.exp(h) * -h if reward_function == 'FAIRL' else h
+
+
 def predict_reward(ds: DiscState, x, reward_function='AIRL', log_policy=None):
   """models.py:177-180, eval mode (no power iteration); log_policy: the subtract_log_policy offset (models.py:175)."""
   z = disc_logits(ds, x, train=False)

@@ -24,3 +24,13 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
   return os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_terminal_summary(terminalreporter):
+  """The largest measured outlier fractions of the Adam-state comparisons (tests/gpu_util.py close_params / close_sparse) against their allowance."""
+  import sys
+  gu = sys.modules.get('gpu_util')
+  if gu is None or not getattr(gu, 'FRACTIONS', None):
+    return
+  worst = sorted(gu.FRACTIONS, key=lambda t: -t[1])[:5]
+  terminalreporter.write_line('largest outlier fractions (measured / allowed): ' + '; '.join(f'{n}: {f:.1e} / {a:.0e}' for n, f, a in worst))

@@ -38,7 +38,18 @@ def close(a, b, name, rtol=1e-5, atol_scale=2e-6):
   assert float(err.max()) <= atol, f'{name}: max excess err {err.max():.3e} > atol {atol:.3e} at flat index {i} (hip {a.ravel()[i]:.8e} vs oracle {b.ravel()[i]:.8e})'
 
 
-def close_params(a, b, name, lr, steps=1, rtol=1e-5, atol_scale=1e-5, outlier_frac=2e-3):
+FRACTIONS = []   # (name, measured outlier fraction, allowed) of every close_params / close_sparse call: conftest prints the largest at the end of a run, so a drift
+                 # towards the allowance is visible long before it fails
+
+
+def _note_fraction(name, frac, allowed):
+  FRACTIONS.append((name, frac, allowed))
+  if frac > 0.5 * allowed:
+    import warnings
+    warnings.warn(f'{name}: {frac:.2e} of the elements are outside the tight bound - more than half of the allowance ({allowed:.0e})')
+
+
+def close_params(a, b, name, lr, steps=1, rtol=1e-5, atol_scale=1e-5, outlier_frac=5e-4):
   """Parameters after Adam. Adam normalises the gradient, so an element whose true gradient is ~eps_adam (1e-8) turns ulp-level
   gradient noise into an O(lr) difference (d update / d g = lr * eps / (|g| + eps)^2). Hence: EVERY element within the tight bound
   plus one full Adam step per update (lr * steps), and all but a `outlier_frac` fraction within the tight bound itself."""
@@ -50,6 +61,7 @@ def close_params(a, b, name, lr, steps=1, rtol=1e-5, atol_scale=1e-5, outlier_fr
   worst = int((err - tight).argmax())
   assert (err <= tight + 1.01 * lr * steps).all(), f'{name}: element {worst} off by {err[worst]:.3e} (> one Adam step): hip {a.ravel()[worst]:.8e} vs oracle {b.ravel()[worst]:.8e}'
   frac = float((err > tight).mean())
+  _note_fraction(name, frac, outlier_frac)
   assert frac <= outlier_frac, f'{name}: {frac:.2e} of the elements exceed the tight bound (allowed {outlier_frac:.0e}); worst {err[worst]:.3e} at {worst}'
 
 
@@ -68,7 +80,7 @@ def bracket(hip, ref32, ref64, name, factor=2.0, floor=1e-6):
   return eh.max() / scale, er.max() / scale
 
 
-def close_sparse(a, b, name, rtol=1e-5, atol_scale=2e-6, outlier_frac=2e-3, outlier_atol_scale=1e-3):
+def close_sparse(a, b, name, rtol=1e-5, atol_scale=2e-6, outlier_frac=5e-4, outlier_atol_scale=1e-3):
   """`close` for gradient-like tensors of a CHAIN of updates (Adam moments): a ReLU pre-activation that lands within rounding of 0 takes a different sign
   in two correct fp32 evaluations, which changes one sample's contribution to one weight row (and what it back-propagates) by a finite amount. Measured
   signature (population replay, 6 updates): 3e-9 everywhere except 64 elements = one row of one critic's W2 plus that sample's first-layer terms, off by
@@ -82,6 +94,7 @@ def close_sparse(a, b, name, rtol=1e-5, atol_scale=2e-6, outlier_frac=2e-3, outl
   i = int(err.argmax())
   assert float(err.max()) <= outlier_atol_scale * scale, f'{name}: element {i} off by {err.max():.3e} (> {outlier_atol_scale:.0e} of the scale {scale:.3e}): hip {a.ravel()[i]:.8e} vs oracle {b.ravel()[i]:.8e}'
   frac = float((err > atol_scale * scale).mean())
+  _note_fraction(name, frac, outlier_frac)
   assert frac <= outlier_frac, f'{name}: {frac:.2e} of the elements exceed the tight bound (allowed {outlier_frac:.0e}); worst {err.max():.3e} at {i}'
 
 
