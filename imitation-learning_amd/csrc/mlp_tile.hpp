@@ -41,7 +41,7 @@ __device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int k, int k
 // Y[16 x N] = Xs[16 x Kpad] . W^T      W: global row-major [N][ldw], columns >= Kw read as zero (Xs is zero-padded too)
 // N % 16 == 0.  epi(c0, acc): acc[reg] = Y[row 4g+reg][col c0 + j],  j = lane&15, g = lane>>4.
 // ---------------------------------------------------------------------------------------------
-template <int MODE, class Epi>
+template <int MODE, int PANEL, class Epi>
 __device__ __forceinline__ void tile_fwd_impl(const float* Xs, int ldx, int Kpad, const float* __restrict__ W, int ldw, int Kw, int N, Epi epi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -50,7 +50,7 @@ __device__ __forceinline__ void tile_fwd_impl(const float* Xs, int ldx, int Kpad
     const float* wr = W + (size_t)(c0 + j) * ldw + 4 * g;
     const float* xr = Xs + j * ldx + 4 * g;
     int k0 = 0;
-    if (MODE == 0 && Kpad == 256) {  // the H = 256 hidden layer: the wave's whole weight panel (16 lanes of 16 B) is requested up front, MFMAs
+    if (MODE == 0 && Kpad == 256 && PANEL >= 16) {  // the H = 256 hidden layer: the wave's whole weight panel (16 lanes of 16 B) is requested up front, MFMAs
       f32x4 b[16];                   // start as soon as the first lane lands and the rest stream in underneath them
 #pragma unroll
       for (int u = 0; u < 16; ++u) b[u] = load4<MODE>(wr - 4 * g, 16 * u + 4 * g, Kw);
@@ -120,12 +120,12 @@ __device__ __forceinline__ void tile_fwd_impl(const float* Xs, int ldx, int Kpad
     epi(c0, acc);
   }
 }
-template <class Epi>
+template <int PANEL = 16, class Epi>
 __device__ __forceinline__ void tile_fwd(const float* Xs, int ldx, int Kpad, const float* __restrict__ W, int ldw, int Kw, int N, Epi epi) {
   const bool aligned = ((ldw & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
-  if (aligned && Kw == Kpad) tile_fwd_impl<0>(Xs, ldx, Kpad, W, ldw, Kw, N, epi);
-  else if (aligned && (Kw & 3) == 0 && Kw >= 4) tile_fwd_impl<1>(Xs, ldx, Kpad, W, ldw, Kw, N, epi);
-  else tile_fwd_impl<2>(Xs, ldx, Kpad, W, ldw, Kw, N, epi);
+  if (aligned && Kw == Kpad) tile_fwd_impl<0, PANEL>(Xs, ldx, Kpad, W, ldw, Kw, N, epi);
+  else if (aligned && (Kw & 3) == 0 && Kw >= 4) tile_fwd_impl<1, PANEL>(Xs, ldx, Kpad, W, ldw, Kw, N, epi);
+  else tile_fwd_impl<2, PANEL>(Xs, ldx, Kpad, W, ldw, Kw, N, epi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -255,7 +255,9 @@ __host__ __device__ inline size_t packed_fwd_index(int n, int k, int H) { return
 __host__ __device__ inline size_t packed_bwd_index(int n, int k, int H) { return ((size_t)((k >> 4) * (H >> 4) + (n >> 4)) * 64 + ((n & 15) >> 2) * 16 + (k & 15)) * 4 + (n & 3); }
 
 // shared body: acc += A(LDS rows, K = H) . panel, panel = P + tile * (H/16) * 256 floats
-template <class Epi>
+// PANEL = weight blocks (16-byte lanes per thread) requested ahead of a tile's MFMAs: 16 = the whole H = 256 panel (64 VGPRs; the single learner's 16-wave workgroups, one per
+// CU), 8 = half of it per round (the population launches: ~80 VGPRs let THREE 8-wave workgroups share a CU instead of two). Same MFMA order either way: same bits.
+template <int PANEL = 16, class Epi>
 __device__ __forceinline__ void tile_packed(const float* As, int lda, int H, const float* __restrict__ P, Epi epi, int t0 = 0, int t1 = -1) {   // output tiles [t0, t1): default all
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4, nb = H >> 4;
@@ -265,13 +267,13 @@ __device__ __forceinline__ void tile_packed(const float* As, int lda, int H, con
     const float* pp = P + (size_t)t * nb * 256 + lane * 4;
     const float* ar = As + j * lda + 4 * g;
     int kb = 0;
-    for (; kb + 16 <= nb; kb += 16) {
-      f32x4 b[16];
+    for (; kb + PANEL <= nb; kb += PANEL) {
+      f32x4 b[PANEL];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) b[u] = gload4(pp + (size_t)(kb + u) * 256);
-      __builtin_amdgcn_sched_barrier(0);  // all 16 KiB of the panel requested before the first MFMA
+      for (int u = 0; u < PANEL; ++u) b[u] = gload4(pp + (size_t)(kb + u) * 256);
+      __builtin_amdgcn_sched_barrier(0);  // all 16 KiB of the panel (PANEL = 16) requested before the first MFMA
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
+      for (int u = 0; u < PANEL; ++u) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(ar + 16 * (kb + u));
         acc0 = mfma16(a[0], b[u][0], acc0);
         acc1 = mfma16(a[1], b[u][1], acc1);
@@ -301,11 +303,11 @@ __device__ __forceinline__ void tile_packed(const float* As, int lda, int H, con
 // lines rewritten by the previous Adam kernel are already in this XCD's L2 when the layer starts. Same-box A/B 14.24k -> 13.39k updates/s: loads return in order,
 // so the rows and first-layer operands issued behind the cold touches wait for them; profiles/r02_update_timeline.md.)
 // Y[16 x H] = Xs[16 x H] . W^T with W given as its PF copy;  epi(c0, acc): acc[reg] = Y[row 4g+reg][col c0 + j]
-template <class Epi>
-__device__ __forceinline__ void tile_fwd_packed(const float* Xs, int ldx, int H, const float* __restrict__ PF, Epi epi) { tile_packed(Xs, ldx, H, PF, epi); }
+template <int PANEL = 16, class Epi>
+__device__ __forceinline__ void tile_fwd_packed(const float* Xs, int ldx, int H, const float* __restrict__ PF, Epi epi) { tile_packed<PANEL>(Xs, ldx, H, PF, epi); }
 // dX[16 x H] = dYs[16 x H] . W with W given as its PB copy;  epi(kb, acc): acc[reg] = dX[row 4g+reg][col kb + j]
-template <class Epi>
-__device__ __forceinline__ void tile_bwd_packed(const float* dYs, int ldy, int H, const float* __restrict__ PB, Epi epi, int t0 = 0, int t1 = -1) { tile_packed(dYs, ldy, H, PB, epi, t0, t1); }
+template <int PANEL = 16, class Epi>
+__device__ __forceinline__ void tile_bwd_packed(const float* dYs, int ldy, int H, const float* __restrict__ PB, Epi epi, int t0 = 0, int t1 = -1) { tile_packed<PANEL>(dYs, ldy, H, PB, epi, t0, t1); }
 
 // ---------------------------------------------------------------------------------------------
 // Small output layer: Os[16][16] = Xs[16 x K] . W^T + b, W [N][ldw] with N <= 16 (actor head 2A, critic head 1).

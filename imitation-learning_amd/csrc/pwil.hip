@@ -11,8 +11,9 @@
 
 #include "il_common.hpp"
 
-__global__ __launch_bounds__(1024) void k_pwil_reset(il_pwil d) {
+__global__ __launch_bounds__(1024) void k_pwil_reset(il_pwil d, unsigned* ticket) {
   const float w = (float)(1.0 / (double)d.n_atoms);
+  if (ticket && blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;   // k_pwil_step's arrival counter (it also resets itself at the end of every step)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.n_atoms; i += gridDim.x * blockDim.x) d.weights[i] = w;
 }
 
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(1024) void k_pwil_reward(il_pwil d, const float* __
 #define PW_CHUNK 256
 struct __attribute__((aligned(16))) PwCand { float dist; int idx; float w; float pad; };   // w = the atom's remaining weight at selection time
 
-__global__ __launch_bounds__(PW_CHUNK) void k_pwil_select(il_pwil d, const float* __restrict__ state, const float* __restrict__ action, int K, PwCand* __restrict__ cand) {
+__device__ __forceinline__ void pwil_select_block(const il_pwil& d, const float* __restrict__ state, const float* __restrict__ action, int K, PwCand* __restrict__ cand) {
   __shared__ float z[512];
   __shared__ float sd[PW_CHUNK];
   const int tid = threadIdx.x, N = d.n_atoms, D = d.dim, S = d.state_dim;
@@ -125,6 +126,9 @@ __global__ __launch_bounds__(PW_CHUNK) void k_pwil_select(il_pwil d, const float
 #pragma unroll 8
   for (int j = 0; j < PW_CHUNK; ++j) { const float o = sd[j]; rank += (o < dist || (o == dist && j < tid)) ? 1 : 0; }
   if (rank < K) { PwCand c; c.dist = dist; c.idx = dist < FLT_MAX ? i : INT_MAX; c.w = dist < FLT_MAX ? d.weights[i] : 0.f; c.pad = 0.f; cand[(size_t)blockIdx.x * K + rank] = c; }
+}
+__global__ __launch_bounds__(PW_CHUNK) void k_pwil_select(il_pwil d, const float* __restrict__ state, const float* __restrict__ action, int K, PwCand* __restrict__ cand) {
+  pwil_select_block(d, state, action, K, cand);
 }
 
 #define PW_LDS_CAND 4096   // candidates staged in LDS (64 KB): the merge loop then touches no global memory
@@ -205,7 +209,7 @@ __device__ __forceinline__ void pwil_merge_wave(const il_pwil& d, int G, int K, 
 // Needs G K <= PW_LDS_CAND (every candidate may survive when few atoms are left); larger sets keep k_pwil_merge_serial.
 // ---------------------------------------------------------------------------------------------
 #define PW_PER_THREAD (PW_LDS_CAND / 256)
-__global__ __launch_bounds__(256) void k_pwil_merge(il_pwil d, int G, int K, const PwCand* __restrict__ cand, float* __restrict__ out) {
+__device__ __forceinline__ void pwil_merge_block(const il_pwil& d, int G, int K, const PwCand* __restrict__ cand, float* __restrict__ out) {
   __shared__ unsigned long long skey[PW_LDS_CAND];   // survivors, then (first G entries, earlier) the list heads
   __shared__ float sw[PW_LDS_CAND];
   __shared__ unsigned long long okey[PW_CHUNK];
@@ -285,6 +289,27 @@ __global__ __launch_bounds__(256) void k_pwil_merge(il_pwil d, int G, int K, con
   }
 }
 
+__global__ __launch_bounds__(256) void k_pwil_merge(il_pwil d, int G, int K, const PwCand* __restrict__ cand, float* __restrict__ out) {
+  pwil_merge_block(d, G, K, cand, out);
+}
+
+// One launch per environment step: every workgroup selects its chunk's candidates, takes a ticket, and the LAST one to arrive runs the merge (nobody waits: no
+// co-residency requirement). A step was two launches of ~5 us of work each; at 19 us per step the launches themselves were what was left.
+__global__ __launch_bounds__(PW_CHUNK) void k_pwil_step(il_pwil d, const float* __restrict__ state, const float* __restrict__ action, int K, PwCand* __restrict__ cand,
+                                                        unsigned* __restrict__ ticket, float* __restrict__ out) {
+  __shared__ unsigned last;
+  pwil_select_block(d, state, action, K, cand);
+  __syncthreads();   // every thread's candidate stores precede thread 0's release
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = t == gridDim.x - 1 ? 1u : 0u;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next step's launch (stream-ordered behind this one)
+  }
+  __syncthreads();
+  if (!last) return;
+  pwil_merge_block(d, (int)gridDim.x, K, cand, out);
+}
+
 __global__ __launch_bounds__(256) void k_pwil_merge_serial(il_pwil d, int G, int K, const PwCand* __restrict__ cand, float* __restrict__ out) {
   __shared__ PwCand sc[PW_LDS_CAND];
   const int tid = threadIdx.x;
@@ -300,12 +325,16 @@ static int pwil_take(const il_pwil* d) { return (int)ceil(d->agent_weight * (dou
 extern "C" int64_t il_pwil_scratch_floats(int32_t n_atoms, double agent_weight) {
   const int m = (int)ceil(agent_weight * (double)n_atoms) + 2, K = m < PW_CHUNK ? m : PW_CHUNK;
   const int64_t lists = ((int64_t)n_atoms + PW_CHUNK - 1) / PW_CHUNK * K * 4;
-  return lists > n_atoms ? lists : n_atoms;
+  return (lists > n_atoms ? lists : n_atoms) + 4;   // + one 16-byte slot behind everything: k_pwil_step's arrival counter
+}
+static unsigned* pwil_ticket(const il_pwil* d) {
+  const int64_t n = il_pwil_scratch_floats(d->n_atoms, d->agent_weight);
+  return reinterpret_cast<unsigned*>(d->dists + n - 4);
 }
 
 extern "C" int il_pwil_reset(const il_pwil* d, il_stream_t stream_) {
   IL_CHECK_ARG(d && d->weights && d->n_atoms > 0, "il_pwil_reset: bad arguments");
-  { IL_TRACE("k_pwil_reset", (hipStream_t)stream_); k_pwil_reset<<<ceil_div(d->n_atoms, 1024) < 256 ? ceil_div(d->n_atoms, 1024) : 256, 1024, 0, (hipStream_t)stream_>>>(*d); }
+  { IL_TRACE("k_pwil_reset", (hipStream_t)stream_); k_pwil_reset<<<ceil_div(d->n_atoms, 1024) < 256 ? ceil_div(d->n_atoms, 1024) : 256, 1024, 0, (hipStream_t)stream_>>>(*d, d->dists ? pwil_ticket(d) : nullptr); }
   IL_CHECK_LAUNCH("il_pwil_reset");
   return IL_OK;
 }
@@ -318,8 +347,14 @@ extern "C" int il_pwil_reward(const il_pwil* d, const float* state, const float*
   static const bool one_wg = getenv("IL_PWIL_ONE_WORKGROUP") != nullptr;   // developer A/B switch
   if (m <= PW_CHUNK && G <= 64 * PW_MAXQ && !one_wg) {
     PwCand* cand = reinterpret_cast<PwCand*>(d->dists);   // >= il_pwil_scratch_floats(n_atoms, agent_weight) floats
+    static const bool serial = getenv("IL_PWIL_SERIAL_MERGE") != nullptr;   // developer A/B switches: the round-2 one-wave merge; select and merge as two launches
+    static const bool two = getenv("IL_PWIL_TWO_LAUNCHES") != nullptr;
+    if (G * m <= PW_LDS_CAND && !serial && !two) {
+      IL_TRACE("k_pwil_step", (hipStream_t)stream_); k_pwil_step<<<G, PW_CHUNK, 0, (hipStream_t)stream_>>>(*d, state, action, m, cand, pwil_ticket(d), out_reward);
+      IL_CHECK_LAUNCH("il_pwil_reward");
+      return IL_OK;
+    }
     { IL_TRACE("k_pwil_select", (hipStream_t)stream_); k_pwil_select<<<G, PW_CHUNK, 0, (hipStream_t)stream_>>>(*d, state, action, m, cand); }
-    static const bool serial = getenv("IL_PWIL_SERIAL_MERGE") != nullptr;   // developer A/B switch: the round-2 one-wave merge
     if (G * m <= PW_LDS_CAND && !serial) { IL_TRACE("k_pwil_merge", (hipStream_t)stream_); k_pwil_merge<<<1, 256, 0, (hipStream_t)stream_>>>(*d, G, m, cand, out_reward); }
     else { IL_TRACE("k_pwil_merge_serial", (hipStream_t)stream_); k_pwil_merge_serial<<<1, 256, 0, (hipStream_t)stream_>>>(*d, G, m, cand, out_reward); }
   } else {

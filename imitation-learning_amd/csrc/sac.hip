@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask, const i
 }
 
 // mode: 0 = next rows then current rows (grid 2*nt), 1 = next only, 2 = current only
+template <int PANEL = 16>
 __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, bool is_cur, int tile,
                                                float* smem) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
@@ -133,7 +134,7 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
   load_rows_cat(Xs, ldx, Sp, src, ld, S, nullptr, 0, 0, row0, IL_TILE_R, b.gather, b.gather_capacity);
   __syncthreads();
   IL_TL(is_cur ? 6 : 5, 1);
-  tile_fwd(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4 acc) {
+  tile_fwd<PANEL>(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1 : net.b1[col];
     f32x4 hv;
 #pragma unroll
@@ -142,7 +143,7 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
   });
   __syncthreads();
   IL_TL(is_cur ? 6 : 5, 2);
-  tile_fwd_packed(H1s, ldh, H, W + ws.pk_af, [&](int c0, f32x4 acc) {
+  tile_fwd_packed<PANEL>(H1s, ldh, H, W + ws.pk_af, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb2 : net.b2[col];
     f32x4 hv;
 #pragma unroll
@@ -184,15 +185,15 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
   (void)red;
 }
 
-__global__ __launch_bounds__(1024) void k_actor_fwd(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, int mode,
-                                                    const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int PANEL>
+__device__ __forceinline__ void k_actor_fwd_body(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, int mode,
+                                                    const il_sac* __restrict__ dL, const il_batch* __restrict__ bL, float* smem) {
   int bx = blockIdx.x, by = blockIdx.y;
   if (dL) { pop_ids(bx, by); d = dL[by]; b = bL[by]; }
   globalize(d); globalize(b);
   const int nt = d.batch / IL_TILE_R;
   const bool is_cur = (mode == 2) || (mode == 0 && bx >= nt);
-  actor_fwd_tile(d, b, eps_next, eps_cur, is_cur, bx % nt, smem);
+  actor_fwd_tile<PANEL>(d, b, eps_next, eps_cur, is_cur, bx % nt, smem);
   IL_TL_END(is_cur ? 6 : 5);
 }
 
@@ -232,6 +233,7 @@ __device__ __forceinline__ void tile_await(unsigned* ctr, unsigned target, const
 // Forward of one critic-shaped network on one 16-row tile. net 0,1: critic_k(s, a) keeping h1, h2 (and x0 for net 0) for the weight gradients;
 // net 2,3: target_k(s', a'). Leaves H1s / H2s (post-ReLU activations) and q16[r] = Q in LDS. `await` != NULL (target networks inside k_sac_chain):
 // a' of this tile is still being produced by another workgroup of the same launch; everything that does not need it is done first.
+template <int PANEL = 16>
 __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch& b, int net, int tile, float* smem, unsigned* await) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int row0 = tile * IL_TILE_R;
@@ -262,7 +264,7 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
   if (net == 0)
     for (int i = threadIdx.x; i < IL_TILE_R * IN; i += blockDim.x) { const int c = i >> 4, r = i & 15; W[ws.c_x0 + (size_t)c * B + row0 + r] = Xs[r * ldx + c]; }  // x0^T [IN][B]
   float* sh1 = W + ws.c_h1 + (size_t)k * B * H; float* sh2 = W + ws.c_h2 + (size_t)k * B * H;
-  tile_fwd(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4 acc) {
+  tile_fwd<PANEL>(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1 : p.b1[col];
     f32x4 hv;
 #pragma unroll
@@ -271,7 +273,7 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
   });
   __syncthreads();
   IL_TL(8, 2);
-  tile_fwd_packed(H1s, ldh, H, W + (is_target ? ws.pk_tf : ws.pk_cf) + (size_t)k * H * H, [&](int c0, f32x4 acc) {
+  tile_fwd_packed<PANEL>(H1s, ldh, H, W + (is_target ? ws.pk_tf : ws.pk_cf) + (size_t)k * H * H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb2 : p.b2[col];
     f32x4 hv;
 #pragma unroll
@@ -290,21 +292,21 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
   IL_TL_END(8);
 }
 
-__global__ __launch_bounds__(1024) void k_critic_fwd(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int PANEL>
+__device__ __forceinline__ void k_critic_fwd_body(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL, float* smem) {
   int bx = blockIdx.x, by = blockIdx.y;
   if (dL) { pop_ids(bx, by); d = dL[by]; b = bL[by]; }
   globalize(d); globalize(b);
   int net, tile;
   xcd_tile_net(bx, d.batch / IL_TILE_R, 4, tile, net);
-  critic_fwd_tile(d, b, net, tile, smem, nullptr);
+  critic_fwd_tile<PANEL>(d, b, net, tile, smem, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
 // critic backward (training.py:24-30): y, dQ_k = w * 2 (Q_k - y) / B, dz2 = dQ w3 [h2>0], dz1 = (dz2 . W2) [h1>0].  grid = nt * 2
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int PANEL>
+__device__ __forceinline__ void k_critic_bwd_body(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL, float* smem) {
   int bx = blockIdx.x, by = blockIdx.y;
   if (dL) { pop_ids(bx, by); d = dL[by]; b = bL[by]; }
   globalize(d); globalize(b);
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(1024) void k_critic_bwd(il_sac d, il_batch b, const
   __syncthreads();
   // dz1 = dQ * ([h1 > 0] (m . W2)) with m = [h2 > 0] w3: the row factor dQ is applied AFTER the GEMM, so that k_sac_chain can run the GEMM
   // before the rewards (hence dQ) exist; every path uses this order, which keeps them bit-identical to each other.
-  tile_bwd_packed(DZ2s, ldh, H, W + ws.pk_cb + (size_t)k * H * H, [&](int kb, f32x4 acc) {
+  tile_bwd_packed<PANEL>(DZ2s, ldh, H, W + ws.pk_cb + (size_t)k * H * H, [&](int kb, f32x4 acc) {
     const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
     const f32x4 hv = (kb == wave * 16) ? hv1 : *reinterpret_cast<const f32x4*>(h1 + off);
     f32x4 o;
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(1024) void k_sac_chain_pop(const il_sac* __restrict
 // (part, nparts): the last GEMM, whose result only goes to HBM for the weight-gradient kernel, is split by output columns over `nparts` workgroups
 // that each run everything before it redundantly (k_policy_critic helpers); part 0 writes the shared outputs. nparts = 1: the whole tail.
 // `wait` is called once everything that does not depend on the critics of this launch has been requested / computed.
-template <class Wait>
+template <int PANEL = 16, class Wait>
 __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& b, int tile, float* __restrict__ out_logp, float* __restrict__ out_q, float* smem, int part,
                                                int nparts, Wait wait) {
   if (!out_logp) out_logp = d.out_logp;
@@ -667,7 +669,7 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
   });
   __syncthreads();
   IL_STAMP(stamp, 28);
-  tile_bwd_packed(DZ2s, ldh, H, W + ws.pk_ab, [&](int kb, f32x4 acc) {
+  tile_bwd_packed<PANEL>(DZ2s, ldh, H, W + ws.pk_ab, [&](int kb, f32x4 acc) {
     const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
     const f32x4 hv = (kb == (pt0 + wave) * 16) ? hv1p : *reinterpret_cast<const f32x4*>(h1 + off);
     f32x4 o;
@@ -683,9 +685,9 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
 // and split the last GEMM between them by output columns. Same arithmetic per element, so the result is bit-identical to helpers = 0.
 #define IL_PC_HELPERS 4
 #define IL_PC_XCD_NETS 0x100   // flag bit in k_policy_critic's `helpers` argument
-__global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, const il_sac* __restrict__ dL,
-                                                        const il_batch* __restrict__ bL, int helpers) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int PANEL>
+__device__ __forceinline__ void k_policy_critic_body(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, const il_sac* __restrict__ dL,
+                                                        const il_batch* __restrict__ bL, int helpers, float* smem) {
   int bx = blockIdx.x, by = blockIdx.y;
   if (dL) { pop_ids(bx, by); d = dL[by]; b = bL[by]; }
   globalize(d); globalize(b);
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
     unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr) + tile * IL_CTR_STRIDE;
     if (h == 0 && threadIdx.x == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }   // consumed by the next kernel
     IL_TL(3, 0);
-    actor_bwd_tile(d, b, tile, out_logp, out_q, smem, part, helpers, [&] {
+    actor_bwd_tile<PANEL>(d, b, tile, out_logp, out_q, smem, part, helpers, [&] {
       IL_TL(3, 1);
       tile_await(ctr, 2u, tile_timeouts(d));
       IL_TL(3, 2);
@@ -732,14 +734,14 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   float w3v[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
-#if IL_SMALL_PREFETCH
-  const ColsPre w1pre = tile_bwd_dx_cols_prefetch(p.W1, IN, IN, H, S);   // the action columns of W1 for dQ/da, the last GEMM of this workgroup
-#endif
+  constexpr bool cols_pre = IL_SMALL_PREFETCH && PANEL >= 16;   // (the 80-VGPR population build has no registers to park them in)
+  ColsPre w1pre = {};
+  if (cols_pre) w1pre = tile_bwd_dx_cols_prefetch(p.W1, IN, IN, H, S);   // the action columns of W1 for dQ/da, the last GEMM of this workgroup
   load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, IL_TILE_R);
   __syncthreads();
   IL_STAMP(stamp, 17);
   IL_TL(7, 1);
-  tile_fwd(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4 acc) {
+  tile_fwd<PANEL>(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1 : p.b1[col];
 #pragma unroll
     for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   __syncthreads();
   IL_STAMP(stamp, 18);
   IL_TL(7, 2);
-  tile_fwd_packed(H1s, ldh, H, W + ws.pk_cf + (size_t)k * H * H, [&](int c0, f32x4 acc) {
+  tile_fwd_packed<PANEL>(H1s, ldh, H, W + ws.pk_cf + (size_t)k * H * H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb2 : p.b2[col];
 #pragma unroll
     for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
@@ -770,7 +772,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   __syncthreads();
   IL_STAMP(stamp, 21);
   IL_TL(7, 5);
-  tile_bwd_packed(H2s, ldh, H, W + ws.pk_cb + (size_t)k * H * H, [&](int kb, f32x4 acc) {
+  tile_bwd_packed<PANEL>(H2s, ldh, H, W + ws.pk_cb + (size_t)k * H * H, [&](int kb, f32x4 acc) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float* h = H1s + (4 * g + r) * ldh + kb + j;
@@ -785,11 +787,7 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
   tile_bwd_dx_cols(H1s, ldh, H, p.W1, IN, IN, S, S + A, q16 + 64, [&](int col, int row, float v) {
     const int c = col - S;
     if (c >= 0 && c < A) gout[(size_t)row * A + c] = v;
-#if IL_SMALL_PREFETCH
-  }, &w1pre);
-#else
-  });
-#endif
+  }, cols_pre ? &w1pre : nullptr);
   IL_STAMP(stamp, 23);
   IL_TL(7, 7);
   // The policy backward of this tile needs Q and dQ/da of BOTH critics, i.e. of two workgroups. Instead of a kernel boundary, the workgroup
@@ -808,8 +806,39 @@ __global__ __launch_bounds__(1024) void k_policy_critic(il_sac d, il_batch b, fl
     if (tile == 0 && threadIdx.x == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }
     return;
   }
-  actor_bwd_tile(d, b, tile, out_logp, out_q, smem, 0, 1, [] {});
+  actor_bwd_tile<PANEL>(d, b, tile, out_logp, out_q, smem, 0, 1, [] {});
 }
+
+// The tile kernels, twice: 1024-thread workgroups with the whole weight panel of a tile in flight (single learner, data-parallel and per-function paths: one workgroup
+// per CU, latency hidden inside the workgroup), and `_pop` = 512-thread workgroups with half panels compiled for six waves per SIMD (<= 80 VGPRs), so that THREE workgroups
+// of the population launches share a CU instead of two and the latency-bound small phases of one hide under the MFMA phases of the others. Same arithmetic, same order.
+#define IL_TILE_KERNELS(SUFFIX, PANEL, BOUNDS)                                                                                                                            \
+  __global__ BOUNDS void k_actor_fwd##SUFFIX(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, int mode,                      \
+                                             const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {                                                           \
+    extern __shared__ __attribute__((aligned(16))) float smem[];                                                                                                         \
+    k_actor_fwd_body<PANEL>(d, b, eps_next, eps_cur, mode, dL, bL, smem);                                                                                                \
+  }                                                                                                                                                                      \
+  __global__ BOUNDS void k_critic_fwd##SUFFIX(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {                                    \
+    extern __shared__ __attribute__((aligned(16))) float smem[];                                                                                                         \
+    k_critic_fwd_body<PANEL>(d, b, dL, bL, smem);                                                                                                                        \
+  }                                                                                                                                                                      \
+  __global__ BOUNDS void k_critic_bwd##SUFFIX(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {                                    \
+    extern __shared__ __attribute__((aligned(16))) float smem[];                                                                                                         \
+    k_critic_bwd_body<PANEL>(d, b, dL, bL, smem);                                                                                                                        \
+  }                                                                                                                                                                      \
+  __global__ BOUNDS void k_policy_critic##SUFFIX(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, const il_sac* __restrict__ dL,           \
+                                                 const il_batch* __restrict__ bL, int helpers) {                                                                         \
+    extern __shared__ __attribute__((aligned(16))) float smem[];                                                                                                         \
+    k_policy_critic_body<PANEL>(d, b, out_logp, out_q, dL, bL, helpers, smem);                                                                                           \
+  }
+IL_TILE_KERNELS(, 16, __launch_bounds__(1024))
+#ifndef IL_POP_PANEL
+#define IL_POP_PANEL 8
+#endif
+#ifndef IL_POP_WAVES_PER_EU
+#define IL_POP_WAVES_PER_EU 6
+#endif
+IL_TILE_KERNELS(_pop, IL_POP_PANEL, __launch_bounds__(512, IL_POP_WAVES_PER_EU))
 
 // ---------------------------------------------------------------------------------------------
 // actor backward (training.py:38-46): L = mean(w m alpha logp - min Q).  grid = nt
@@ -1471,6 +1500,10 @@ extern "C" int il_sac_update_population(const il_sac* descs_dev, const il_batch*
   const int tt = (pop_threads_env >= 256 && pop_threads_env <= tile_threads(H) && pop_threads_env % 64 == 0) ? pop_threads_env : tt_default;
   // Measured at 32 learners (round 2): chained 61.6k aggregate updates/s vs 70.7k with the three separate launches (k_sac_chain_pop 215 us against 46 + 71 + 35 us): the
   // workgroups that wait for their tile's producers hold CU slots the oversubscribed launch needs. Hence OFF by default; IL_POP_CHAIN=1 switches it on.
+  // (round 3) the `_pop` builds of the tile kernels (half weight panels, <= 80 VGPRs: three workgroups per CU instead of two) whenever the launch is at most 512 threads wide;
+  // IL_POP_THREE=0 keeps the 128-VGPR builds (bit-identical either way)
+  static const int pop_three = [] { const char* e = getenv("IL_POP_THREE"); return e && e[0] == '0' ? 0 : 1; }();
+  const bool pop3 = pop_three && tt <= 512;
   static const int pop_chain = [] { const char* e = getenv("IL_POP_CHAIN"); return e && e[0] == '1' ? 1 : 0; }();
   const bool whole = !(flags & (IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY));
   if (whole && pop_chain) {   // forward + critic loss chained per tile inside one launch (k_sac_chain_pop); IL_POP_CHAIN=0: the three separate launches
@@ -1480,16 +1513,29 @@ extern "C" int il_sac_update_population(const il_sac* descs_dev, const il_batch*
   }
   if (!(flags & IL_FLAG_SAC_SKIP_FORWARD)) {
     if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5, L), 256, 0, st>>>(z, 0x1Fu, descs_dev); }
-    { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, nullptr, nullptr, 0, descs_dev, batches_dev); }
-    { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<dim3(4 * nt, L), tt, lds, st>>>(z, zb, descs_dev, batches_dev); }
+    if (pop3) {
+      { IL_TRACE("k_actor_fwd", st); k_actor_fwd_pop<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, nullptr, nullptr, 0, descs_dev, batches_dev); }
+      { IL_TRACE("k_critic_fwd", st); k_critic_fwd_pop<<<dim3(4 * nt, L), tt, lds, st>>>(z, zb, descs_dev, batches_dev); }
+    } else {
+      { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, nullptr, nullptr, 0, descs_dev, batches_dev); }
+      { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<dim3(4 * nt, L), tt, lds, st>>>(z, zb, descs_dev, batches_dev); }
+    }
   }
   if (!(flags & IL_FLAG_SAC_FORWARD_ONLY)) {
-    if (!(flags & 0x80000000u)) { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, descs_dev, batches_dev); }
+    if (!(flags & 0x80000000u)) {
+      IL_TRACE("k_critic_bwd", st);
+      if (pop3) k_critic_bwd_pop<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, descs_dev, batches_dev);
+      else k_critic_bwd<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, descs_dev, batches_dev);
+    }
     static const int lds_dw = [] { const char* e = getenv("IL_POP_DW_LDS"); return e && e[0] == '0' ? 0 : 1; }();
     const bool b64 = lds_dw && H % DWB == 0 && B % DWB == 0;   // H x H layers as 64 x 64 blocks staged through LDS (dw_block64); IL_POP_DW_LDS=0: dw_tile for every layer
     const int nbc = b64 ? dw_block64_count(H, 2) : 0, nba = b64 ? dw_block64_count(H, 1) : 0;
     { IL_TRACE("k_dw_adam_critic", st); k_dw_adam_pop<<<dim3(nbc + dw_blocks(S + A, H, 1, 2, b64), L), 256, 0, st>>>(descs_dev, batches_dev, 0, flags, nbc); }
-    { IL_TRACE("k_policy_critic", st); k_policy_critic<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, nullptr, nullptr, descs_dev, batches_dev, 0); }
+    {
+      IL_TRACE("k_policy_critic", st);
+      if (pop3) k_policy_critic_pop<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, nullptr, nullptr, descs_dev, batches_dev, 0);
+      else k_policy_critic<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, nullptr, nullptr, descs_dev, batches_dev, 0);
+    }
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam_pop<<<dim3(nba + dw_blocks(S, H, 2 * A, 1, b64) + 33, L), 256, 0, st>>>(descs_dev, batches_dev, 1, flags, nba); }
   }
   IL_CHECK_LAUNCH("il_sac_update_population");

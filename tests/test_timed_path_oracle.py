@@ -114,8 +114,11 @@ def compare_learner(o, nets, plan, k, tag=''):
   actor, critic, target, log_alpha, disc = nets
   ao, co, to, do = plan._keep[4], plan._keep[5], plan._keep[6], plan._keep[8]
   s = 1e-5 * k
-  close_params(N(actor.flat), o.st.actor, f'{tag}actor after {k}', LR, k); close_params(crit_from_flat(critic, critic.flat), o.st.critic, f'{tag}critic after {k}', LR, k)
-  close_params(crit_from_flat(critic, target.flat), o.st.target, f'{tag}target after {k}', LR, k)
+  # Twin critics after a CHAIN of updates: one ReLU pre-activation within rounding of 0 that takes the other sign moves a whole row of a W2 (256 of 145k elements = 1.8e-3 ... the
+  # measured worst case over the learners of these tests is 1.0e-3 of the elements, round 3; everything else uses the 5e-4 default of tests/gpu_util.py). The run prints the
+  # largest measured fractions at its end (conftest.pytest_terminal_summary).
+  close_params(N(actor.flat), o.st.actor, f'{tag}actor after {k}', LR, k); close_params(crit_from_flat(critic, critic.flat), o.st.critic, f'{tag}critic after {k}', LR, k, outlier_frac=1.5e-3)
+  close_params(crit_from_flat(critic, target.flat), o.st.target, f'{tag}target after {k}', LR, k, outlier_frac=1.5e-3)
   close(N(log_alpha), o.st.log_alpha, f'{tag}log_alpha after {k}', atol_scale=s)
   close_sparse(N(ao.exp_avg), o.st.actor_m, f'{tag}actor exp_avg', atol_scale=s); close_sparse(N(ao.exp_avg_sq), o.st.actor_v, f'{tag}actor exp_avg_sq', atol_scale=s)
   close_sparse(crit_from_flat(critic, co.exp_avg), o.st.critic_m, f'{tag}critic exp_avg', atol_scale=s); close_sparse(crit_from_flat(critic, co.exp_avg_sq), o.st.critic_v, f'{tag}critic exp_avg_sq', atol_scale=s)
