@@ -199,90 +199,97 @@ __device__ __forceinline__ void pwil_merge_wave(const il_pwil& d, int G, int K, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_pwil_merge (round 3): the step's coupling WITHOUT a serial merge. The step consumes at most m <= K atoms, in ascending (distance, index) order - so all it needs is
-// the m smallest candidates, sorted. (i) A threshold that provably covers them: T = min(the smallest list TAIL - that list alone holds K candidates <= it -, the K-th
-// smallest list HEAD - K different lists hold a candidate <= it). With distances spread over ~100 chunks the second bound leaves ~1.2 K survivors of the G K
-// candidates. (ii) Survivors are compacted into LDS (order irrelevant), (iii) ranked by counting (keys are unique: the atom index is part of the key), (iv) the first m
-// of them, in rank order, go through the same greedy loop as before - cost and remaining weight accumulated in double, consumed in ascending key order: the same
-// operations on the same values in the same order as the serial merge and the one-workgroup kernel, so the reward and the weights keep their bits - (v) the consumed
-// atoms are marked in parallel. The single wave's G-way merge this replaces took ~1 us per consumed atom (25.5 of the 35 us of a step at N = 25k, T = 1000).
-// Needs G K <= PW_LDS_CAND (every candidate may survive when few atoms are left); larger sets keep k_pwil_merge_serial.
+// k_pwil_merge (round 3): the step's coupling WITHOUT a serial G-way merge. The greedy coupling consumes candidates in ascending (distance, index) order until the
+// agent's weight 1/T is spent - so all it needs is a sorted PREFIX of the candidates whose weights add up to at least that. (i) A threshold that provably covers the
+// prefix: sort the G list heads (the chunk minima) by rank counting and walk them until their cumulative weight reaches the agent's weight (plus one head of slack):
+// every candidate of the prefix is <= that head's key. With distances spread over ~100 chunks this leaves ~1.2 x the consumed atoms of the G K candidates. (ii) The
+// survivors are compacted into LDS (order irrelevant), (iii) ranked by counting (keys are unique: the atom index is part of the key), (iv) walked in rank order by the
+// same greedy loop as before - cost and remaining weight in double, consumed in ascending key order: the same operations on the same values in the same order as the
+// serial merge and the one-workgroup kernel, so the reward and the weights keep their bits - (v) the consumed atoms are marked in parallel. If the survivors run out
+// before the weight does (partially consumed atoms of earlier steps are lighter than 1/N, rounding at the threshold) and candidates above the threshold exist, the step
+// is redone with every candidate (pass 2: exact by construction, rare). The single wave's G-way merge this replaces took ~1 us per consumed atom (25.5 of the 35 us of
+// a step at N = 25k, T = 1000). Needs G K <= PW_LDS_CAND; larger sets keep k_pwil_merge_serial.
 // ---------------------------------------------------------------------------------------------
 #define PW_PER_THREAD (PW_LDS_CAND / 256)
 __device__ __forceinline__ void pwil_merge_block(const il_pwil& d, int G, int K, const PwCand* __restrict__ cand, float* __restrict__ out) {
-  __shared__ unsigned long long skey[PW_LDS_CAND];   // survivors, then (first G entries, earlier) the list heads
-  __shared__ float sw[PW_LDS_CAND];
-  __shared__ unsigned long long okey[PW_CHUNK];
-  __shared__ float ow[PW_CHUNK];
-  __shared__ unsigned long long red[8];
-  __shared__ int nsurv;
+  __shared__ unsigned long long skey[PW_LDS_CAND];   // survivors (unsorted); before that: [0, G) the list heads, [2048, 2048 + G) the heads in ascending order
+  __shared__ float sw[PW_LDS_CAND];                  // their weights, same indexing
+  __shared__ unsigned short order[PW_LDS_CAND];      // order[rank] = survivor slot
+  __shared__ int nsurv, nvalid;
   const int tid = threadIdx.x, total = G * K;
   const unsigned long long EMPTY = ~0ull;
-  // every candidate this thread owns, and the head / tail of the lists it owns, requested together: ONE round trip to the lists k_pwil_select just wrote
+  // every candidate this thread owns, and the heads of the lists it owns, requested together: ONE round trip to the lists k_pwil_select just wrote
   PwCand c[PW_PER_THREAD];
 #pragma unroll
   for (int u = 0; u < PW_PER_THREAD; ++u) c[u] = cand[min(tid + 256 * u, total - 1)];
-  PwCand hd[4], tl[4];   // lists tid, tid + 256, ... (G <= 1024)
+  PwCand hd[4];   // lists tid, tid + 256, ... (G <= 1024)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) { const int l = min(tid + 256 * q, G - 1); hd[q] = cand[(size_t)l * K]; tl[q] = cand[(size_t)l * K + K - 1]; }
+  for (int q = 0; q < 4; ++q) hd[q] = cand[(size_t)min(tid + 256 * q, G - 1) * K];
   __builtin_amdgcn_sched_barrier(0);
-  if (tid == 0) nsurv = 0;
-  unsigned long long tmin = EMPTY;
+  if (tid == 0) { nsurv = 0; nvalid = 0; }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int l = tid + 256 * q;
-    if (l < G) {
-      skey[l] = hd[q].idx == INT_MAX ? EMPTY : pw_key(hd[q].dist, hd[q].idx);
-      const unsigned long long t = tl[q].idx == INT_MAX ? EMPTY : pw_key(tl[q].dist, tl[q].idx);
-      tmin = t < tmin ? t : tmin;
-    }
+    if (l < G) { skey[l] = hd[q].idx == INT_MAX ? EMPTY : pw_key(hd[q].dist, hd[q].idx); sw[l] = hd[q].w; }
   }
-  tmin = wave_min_u64(tmin);
-  if ((tid & 63) == 0) red[tid >> 6] = tmin;
   __syncthreads();
-  // the K-th smallest head by counting: head h has rank #{heads < h} (unique keys; EMPTY heads never qualify)
-  unsigned long long thead = EMPTY;
-  for (int l = tid; l < G; l += 256) {
+  for (int l = tid; l < G; l += 256) {   // heads in ascending order (EMPTY heads tie: give them distinct ranks by list index, they sort last)
     const unsigned long long h = skey[l];
-    if (h == EMPTY) continue;
     int rank = 0;
-    for (int j = 0; j < G; ++j) rank += skey[j] < h ? 1 : 0;
-    if (rank == K - 1) thead = h;
+    for (int j = 0; j < G; ++j) { const unsigned long long o = skey[j]; rank += (o < h || (o == h && j < l)) ? 1 : 0; }
+    skey[2048 + rank] = h; sw[2048 + rank] = sw[l];
   }
-  thead = wave_min_u64(thead);
-  if ((tid & 63) == 0) red[4 + (tid >> 6)] = thead;
   __syncthreads();
-  unsigned long long T = red[0];
-#pragma unroll
-  for (int w = 1; w < 8; ++w) T = red[w] < T ? red[w] : T;
-  __syncthreads();   // the heads in skey have been read by everyone: the survivors may overwrite them
-#pragma unroll
-  for (int u = 0; u < PW_PER_THREAD; ++u) {
-    if (tid + 256 * u < total && c[u].idx != INT_MAX) {
-      const unsigned long long k2 = pw_key(c[u].dist, c[u].idx);
-      if (k2 <= T) { const int pos = atomicAdd(&nsurv, 1); skey[pos] = k2; sw[pos] = c[u].w; }
+  // walk the sorted heads until their weights cover the agent's weight, then one more (slack for the rounding of the running difference in the greedy loop)
+  unsigned long long T = EMPTY;
+  {
+    double cum = 0.0; int j = 0;
+    for (; j < G; ++j) {
+      if (skey[2048 + j] == EMPTY) break;
+      cum += (double)sw[2048 + j];
+      if (cum >= d.agent_weight) break;
     }
+    if (j < G && skey[2048 + j] != EMPTY && j + 1 < G && skey[2048 + j + 1] != EMPTY) T = skey[2048 + j + 1];   // otherwise every candidate survives
   }
-  __syncthreads();
-  const int n = nsurv;
-  for (int s = tid; s < n; s += 256) {
-    const unsigned long long k2 = skey[s];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) rank += skey[j] < k2 ? 1 : 0;
-    if (rank < PW_CHUNK) { okey[rank] = k2; ow[rank] = sw[s]; }
-  }
-  __syncthreads();
-  // the greedy coupling over the sorted survivors, by every thread redundantly (LDS broadcast reads): afterwards each thread knows what was consumed
-  const int nn = n < K ? n : K;   // a step consumes at most K = pwil_take() atoms
+  __syncthreads();   // the heads have been read by everyone: the survivors may overwrite them
   double weight = d.agent_weight, cost = 0.0;
   int consumed = 0, part_idx = -1; float part_w = 0.f;
-  for (int it = 0; it < nn && weight > 0.0; ++it) {
-    const unsigned long long best = okey[it];
-    const double ew = (double)ow[it], dist = (double)__uint_as_float((unsigned)(best >> 32));
-    if (weight >= ew) { cost += ew * dist; weight -= ew; ++consumed; }
-    else { cost += weight * dist; part_idx = (int)(unsigned)best; part_w = (float)ew - (float)weight; weight = 0.0; }
+  for (int pass = 0; pass < 2; ++pass) {
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < PW_PER_THREAD; ++u) {
+      if (tid + 256 * u < total && c[u].idx != INT_MAX) {
+        const unsigned long long k2 = pw_key(c[u].dist, c[u].idx);
+        ++mine;
+        if (k2 <= T) { const int pos = atomicAdd(&nsurv, 1); skey[pos] = k2; sw[pos] = c[u].w; }
+      }
+    }
+    if (pass == 0 && mine) atomicAdd(&nvalid, mine);
+    __syncthreads();
+    const int n = nsurv;
+    for (int s = tid; s < n; s += 256) {
+      const unsigned long long k2 = skey[s];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += skey[j] < k2 ? 1 : 0;
+      order[rank] = (unsigned short)s;
+    }
+    __syncthreads();
+    // the greedy coupling over the sorted survivors, by every thread redundantly (LDS broadcast reads): afterwards each thread knows what was consumed
+    weight = d.agent_weight; cost = 0.0; consumed = 0; part_idx = -1; part_w = 0.f;
+    for (int it = 0; it < n && weight > 0.0; ++it) {
+      const int s = order[it];
+      const unsigned long long best = skey[s];
+      const double ew = (double)sw[s], dist = (double)__uint_as_float((unsigned)(best >> 32));
+      if (weight >= ew) { cost += ew * dist; weight -= ew; ++consumed; }
+      else { cost += weight * dist; part_idx = (int)(unsigned)best; part_w = (float)ew - (float)weight; weight = 0.0; }
+    }
+    if (!(weight > 0.0) || n == nvalid || T == EMPTY) break;   // done, or there is nothing above the threshold to add
+    __syncthreads();   // everyone has finished reading this pass's survivors
+    if (tid == 0) nsurv = 0;
+    T = EMPTY;
+    __syncthreads();
   }
-  if (tid < consumed) d.weights[(int)(unsigned)okey[tid]] = -1.f;
+  for (int t = tid; t < consumed; t += 256) d.weights[(int)(unsigned)skey[order[t]]] = -1.f;
   if (tid == 0) {
     if (part_idx >= 0) d.weights[part_idx] = part_w;
     out[0] = (float)(d.reward_scale * exp(-d.reward_bandwidth * cost));
