@@ -299,13 +299,6 @@ def roofline(run_fn, trace_steps, units_per_launch, ms_per_step, side_stream_dis
   for line in buf.value.decode().strip().splitlines():
     name, cnt, tot = line.split()
     kern[name] = dict(launches_per_update=int(cnt) / trace_steps, avg_us=float(tot) / int(cnt) * 1e3)
-  # Round 3: on the fused single-learner path the weight-gradient / AdamW jobs run INSIDE the launches that produce their dZ (dw_jobs_inline): no k_dw_adam launch shows up,
-  # and the chained launches carry its flops and its AdamW bytes.
-  flops_k, bytes_k = dict(flops_k), dict(bytes_k)
-  if 'k_dw_adam_critic' not in kern and 'k_sac_chain' in kern:
-    flops_k['k_sac_chain'] += flops_k['k_dw_adam_critic']; bytes_k['k_sac_chain'] = bytes_k['k_dw_adam_critic']
-  if 'k_dw_adam_actor' not in kern and 'k_policy_critic' in kern:
-    flops_k['k_policy_critic'] += flops_k['k_dw_adam_actor']; bytes_k['k_policy_critic'] = bytes_k['k_dw_adam_actor']
   # dominant = largest share of the critical path: the discriminator kernels run on the side stream next to the SAC forward kernels
   side = ('k_gail_grad', 'k_gail_reduce', 'k_gail_reward') if side_stream_disc else ()
   dom = max((k for k in kern if k not in side), key=lambda k: kern[k]['avg_us'] * kern[k]['launches_per_update'])

@@ -72,11 +72,7 @@ __global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask, const i
   if (blockIdx.x == 0 && blockIdx.y == 0)   // arrival counters of k_policy_critic's tile pairs and of k_sac_chain's tiles (they reset themselves; this covers a reused arena)
   {
     for (int i = threadIdx.x; i < d.batch / IL_TILE_R; i += blockDim.x) { reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr)[i * IL_CTR_STRIDE] = 0u; reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr)[i * IL_CTR_STRIDE] = 0u; }
-    if (threadIdx.x == 0) {
-      unsigned* c = reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + (d.batch / IL_TILE_R) * IL_CTR_STRIDE;
-      c[1] = 0u;   // il_sac_handoff_timeouts counts from here
-      c[2] = 0u; reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr)[(d.batch / IL_TILE_R) * IL_CTR_STRIDE + 2] = 0u;   // arrival counters of the in-launch dW jobs (dw_counter)
-    }
+    if (threadIdx.x == 0) reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr)[(d.batch / IL_TILE_R) * IL_CTR_STRIDE + 1] = 0u;   // il_sac_handoff_timeouts counts from here
   }
   if (!((mask >> net) & 1u)) return;
   const int64_t HH = (int64_t)H * H, ns = net_stride(IN, H, 1);
@@ -232,442 +228,6 @@ __device__ __forceinline__ void tile_await(unsigned* ctr, unsigned target, const
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_dw_adam: output-stationary weight gradients on MFMA with a fused AdamW epilogue.
-//   dW_l[n][k] = sum_r dZ_l[r][n] X_l[r][k]  (reduction index = batch row, 4 per MFMA step), db_l[n] = sum_r dZ_l[r][n]
-// One wave = one job: a 16(n) x 16(k) tile of some layer's weight, or 16 bias elements. Operands come from the feature-major
-// workspace ([feature][B]): lane (j, g) reads 4 consecutive batch rows of feature n0+j / k0+j as ONE 16-byte load, eight such
-// loads per operand are in flight before the first MFMA. Gradients never touch HBM unless grads_only (data-parallel: they are
-// all-reduced first).  Tail blocks: Adam(log_alpha), polyak, Philox counter.
-// ---------------------------------------------------------------------------------------------
-struct DwArgs {
-  float* params; float* grads; il_adam opt; int grads_only;
-  int n_nets; int64_t net_stride;
-  int in_dim, hidden, out_dim, batch;
-  const float* x0; int ld_x0; int x0_transposed; int64_t x0_net_stride;   // layer-1 input: [in][B] (transposed) or row-major [B][ld_x0]
-  const float* h1; const float* h2; const float* dz1; const float* dz2; int64_t h_net_stride;   // [H][B]
-  const float* dz3; int64_t dz3_net_stride;                                // [out][B]
-  float* pk_f; float* pk_b;                                                 // lane-ordered copies of W2 kept in step with the AdamW update (NULL: none)
-  int n_dw_blocks;
-  // tail
-  float* log_alpha; float* alpha_grad; il_adam alpha_opt; const float* alpha_part; int n_alpha_part;
-  float* target; const float* polyak_src; int64_t polyak_n; double tau; uint32_t* noise_counter; int64_t* sync;
-  float* pk_target; const float* pk_critic; int64_t pk_n;   // lane-ordered copies of the target / critic hidden layers (polyak is elementwise, so it commutes with the re-ordering)
-};
-
-__device__ __forceinline__ void adam_store(const DwArgs& a, const adam_consts& ac, int64_t o, float gr) {
-  if (a.grads_only) { a.grads[o] = gr; return; }
-  float pp = a.params[o], mm = a.opt.m[o], vv = a.opt.v[o];
-  adam_update(pp, gr, mm, vv, ac);
-  a.params[o] = pp; a.opt.m[o] = mm; a.opt.v[o] = vv;
-}
-
-#ifndef IL_DW_PREFETCH
-#define IL_DW_PREFETCH 1
-#endif
-#ifndef IL_DW_SCHED_BARRIER
-#define IL_DW_SCHED_BARRIER 1   // dw_tile: all operand loads of a chunk ahead of its MFMAs (0 = the round-2 schedule, for A/B builds)
-#endif
-#ifndef IL_TAIL_BLOCKS
-#define IL_TAIL_BLOCKS 69       // single learner: tail blocks of the actor launch (block 0: Adam(log alpha) + counters; all: polyak over the target arena and its lane-ordered copies, one trip each at H = 256)
-#endif
-#ifndef IL_DW_U
-#define IL_DW_U 16              // single-learner k_dw_adam: 16-row operand lanes in flight per operand and chunk (16 = the whole batch of 256 rows in one round)
-#endif
-// XT: x is feature-major [Kvalid][B]; otherwise row-major [B][ldx] (the actor's layer-1 input = the states field of the batch)
-// U = 16-row operand lanes in flight per operand: 8 for the single learner (one block per CU: latency hiding has to come from the wave itself),
-// 4 for the population launch (half the registers -> four waves per SIMD instead of two hide the latency across blocks).
-struct DwPre { float pp[4], mm[4], vv[4]; };
-__device__ __forceinline__ DwPre dw_prefetch(const DwArgs& a, int Nvalid, int Kvalid, int n0, int kb, int64_t poff) {
-  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-  const int kk = min(kb + j, Kvalid - 1);
-  DwPre p = {};
-  if (IL_DW_PREFETCH && !a.grads_only) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t o = poff + (int64_t)min(n0 + 4 * g + r, Nvalid - 1) * Kvalid + kk;
-      p.pp[r] = gload(a.params + o); p.mm[r] = gload(a.opt.m + o); p.vv[r] = gload(a.opt.v + o);
-    }
-  }
-  return p;
-}
-template <bool XT, int U>
-__device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dzT, int Nvalid, const float* __restrict__ x, int ldx, int Kvalid,
-                                        int n0, int kb, int64_t poff, const DwPre& pre, float* __restrict__ pkf = nullptr, float* __restrict__ pkb = nullptr) {
-  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-  const int B = a.batch;
-  f32x4 acc0 = zero4(), acc1 = zero4();
-  // out-of-range features clamp their address: the rows / columns of dW they produce are discarded by the epilogue
-  const float* dzp = dzT + (size_t)min(n0 + j, Nvalid - 1) * B + 4 * g;
-  const int kc = min(kb + j, Kvalid - 1);
-  const float* xp = XT ? x + (size_t)kc * B + 4 * g : x + (size_t)(4 * g) * ldx + kc;
-  auto ldx4 = [&](int r0) -> f32x4 {
-    if (XT) return gload4(xp + r0);
-    f32x4 v;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) v[s] = gload(xp + (size_t)(r0 + s) * ldx);
-    return v;
-  };
-  // The Adam operands of this lane's four dW elements do not depend on the products: they are fetched (dw_prefetch) before the MFMA loop - and, when the tile is a
-  // job of a launch that is still waiting for its operands (dw_jobs_inline), before that wait - so that their HBM latency (they were last touched one update ago)
-  // hides instead of following the products.
-  const int k = kb + j;
-  float pp[4], mm[4], vv[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { pp[r] = pre.pp[r]; mm[r] = pre.mm[r]; vv[r] = pre.vv[r]; }
-  int r0 = 0;
-  // Every operand lane of a chunk is REQUESTED before its first MFMA: without the scheduling barrier hipcc sinks the loads back between the MFMAs (round 3, ISA of the
-  // round-2 build: four loads in flight, `s_waitcnt vmcnt(2)` in front of every group of four MFMAs - sixteen dependent L2 round trips per tile, which is what made this
-  // launch 6-8 us for 0.85 us of MFMA issue). Chunks of 16 U, then 64, then 16 rows; the MFMA order (row groups ascending, k-steps 0, 2 -> acc0 and 1, 3 -> acc1) does not
-  // depend on the chunking, so every chunk size gives the same bits.
-#define IL_DW_CHUNK(UU)                                                                                            \
-  for (; r0 + 16 * (UU) <= B; r0 += 16 * (UU)) {                                                                   \
-    f32x4 av[UU], bv[UU];                                                                                          \
-    _Pragma("unroll") for (int u = 0; u < (UU); ++u) { av[u] = gload4(dzp + r0 + 16 * u); bv[u] = ldx4(r0 + 16 * u); } \
-    if (IL_DW_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);                                                    \
-    _Pragma("unroll") for (int u = 0; u < (UU); ++u) {                                                             \
-      acc0 = mfma16(av[u][0], bv[u][0], acc0);                                                                     \
-      acc1 = mfma16(av[u][1], bv[u][1], acc1);                                                                     \
-      acc0 = mfma16(av[u][2], bv[u][2], acc0);                                                                     \
-      acc1 = mfma16(av[u][3], bv[u][3], acc1);                                                                     \
-    }                                                                                                              \
-  }
-  IL_DW_CHUNK(U)
-  if (U > 4) { IL_DW_CHUNK(4) }
-  IL_DW_CHUNK(1)
-#undef IL_DW_CHUNK
-  const f32x4 acc = acc0 + acc1;
-  if (k >= Kvalid) return;
-  if (a.grads_only) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + 4 * g + r;
-      if (n < Nvalid) a.grads[poff + (int64_t)n * Kvalid + k] = acc[r];
-    }
-    return;
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int n = n0 + 4 * g + r;
-    if (n < Nvalid) {
-      const int64_t o = poff + (int64_t)n * Kvalid + k;
-      if (!IL_DW_PREFETCH) { pp[r] = a.params[o]; mm[r] = a.opt.m[o]; vv[r] = a.opt.v[o]; }
-      adam_update(pp[r], acc[r], mm[r], vv[r], ac);
-      a.params[o] = pp[r]; a.opt.m[o] = mm[r]; a.opt.v[o] = vv[r];
-    }
-  }
-  if (pkf) {  // the updated W2 values, in both lane orders (this tile owns rows n0..n0+15, columns kb..kb+15: always full for an H x H layer)
-    f32x4 w;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { w[r] = pp[r]; pkf[packed_fwd_index(n0 + 4 * g + r, k, Kvalid)] = w[r]; }
-    *reinterpret_cast<f32x4*>(pkb + packed_bwd_index(n0 + 4 * g, k, Kvalid)) = w;   // rows n0+4g..+3 of column k: one 16-byte lane of PB
-  }
-}
-
-// 16 bias elements per wave: lane (j, g) sums rows 16i + 4g .. +3 of feature n0 + j, the four row groups meet through shuffles
-__device__ __forceinline__ void dw_bias(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dzT, int Nvalid, int n0, int64_t poff) {
-  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-  const int B = a.batch;
-  const float* p = dzT + (size_t)min(n0 + j, Nvalid - 1) * B + 4 * g;
-  f32x4 s4 = zero4();
-  int r0 = 0;
-#if IL_DW_SCHED_BARRIER
-  // (round 3) as a plain loop this was load -> s_waitcnt vmcnt(0) -> add, once per 16 rows: sixteen DEPENDENT L2 round trips at B = 256 - the bias jobs, not the MFMA
-  // tiles, were the long pole of the launch. All lanes of a chunk are requested first; the adds keep their order (ascending rows), so the sums keep their bits.
-  for (; r0 + 256 <= B; r0 += 256) {
-    f32x4 t[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) t[u] = gload4(p + r0 + 16 * u);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < 16; ++u) s4 += t[u];
-  }
-  for (; r0 + 64 <= B; r0 += 64) {
-    f32x4 t[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) t[u] = gload4(p + r0 + 16 * u);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) s4 += t[u];
-  }
-#endif
-  for (; r0 < B; r0 += 16) s4 += *reinterpret_cast<const f32x4*>(p + r0);
-  float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
-  if (g == 0 && n0 + j < Nvalid) adam_store(a, ac, poff + n0 + j, s);
-}
-
-// One wave = one job of the launch's job list (wave-uniform decode): a 16 x 16 tile of a layer's weight gradient, or 16 bias elements. `wait` is called exactly once by
-// every wave - after the Adam operands of its tile have been requested, before the first operand of the products is: the stand-alone kernel passes a no-op; a launch
-// that runs these jobs in workgroups which finished their own work early (dw_jobs_inline) passes the wait for the producers of dZ.
-template <int U, bool SKIPBIG, class Wait>
-__device__ __forceinline__ void dw_jobs(const DwArgs& a, int job, Wait wait) {
-  const int IN = a.in_dim, H = a.hidden, OUT = a.out_dim;
-  const int nt_h = H / 16, kt_in = (IN + 15) / 16, nt_out = (OUT + 15) / 16;
-  const int j1 = nt_h * kt_in, j2 = SKIPBIG ? 0 : nt_h * nt_h, j3 = nt_out * nt_h, jb = 2 * nt_h + nt_out;
-  const int per_net = j1 + j2 + j3 + jb;
-  if (job >= per_net * a.n_nets) { wait(); return; }
-  const int net = job / per_net; job -= net * per_net;
-  adam_consts ac = {};
-  const int64_t pbase = (int64_t)net * a.net_stride;
-  const int64_t oW1 = pbase, ob1 = oW1 + (int64_t)H * IN, oW2 = ob1 + H, ob2 = oW2 + (int64_t)H * H, oW3 = ob2 + H, ob3 = oW3 + (int64_t)OUT * H;
-  const float* x0 = a.x0 + net * a.x0_net_stride;
-  const float* h1 = a.h1 + net * a.h_net_stride; const float* h2 = a.h2 + net * a.h_net_stride;
-  const float* dz1 = a.dz1 + net * a.h_net_stride; const float* dz2 = a.dz2 + net * a.h_net_stride;
-  const float* dz3 = a.dz3 + net * a.dz3_net_stride;
-  // the big layer first: its tiles are the long pole, the small jobs fill in behind them
-  if (job < j2) {
-    const int n0 = (job / nt_h) * 16, kb = (job % nt_h) * 16;
-    const DwPre pre = dw_prefetch(a, H, H, n0, kb, oW2);
-    wait();
-    if (!a.grads_only) ac = load_adam_consts(a.opt);   // (the step constants are ticked by the producers of dZ: read them after the wait)
-    dw_tile<true, U>(a, ac, dz2, H, h1, 0, H, n0, kb, oW2, pre, a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr);
-    return;
-  }
-  job -= j2;
-  if (job < j1) {
-    const int n0 = (job / kt_in) * 16, kb = (job % kt_in) * 16;
-    const DwPre pre = dw_prefetch(a, H, IN, n0, kb, oW1);
-    wait();
-    if (!a.grads_only) ac = load_adam_consts(a.opt);
-    if (a.x0_transposed) dw_tile<true, U>(a, ac, dz1, H, x0, 0, IN, n0, kb, oW1, pre);
-    else dw_tile<false, (U > 4 ? 4 : U)>(a, ac, dz1, H, x0, a.ld_x0, IN, n0, kb, oW1, pre);   // row-major x (the actor's layer 1, 2 % of the jobs): four dword loads per operand lane - keep its register footprint at the U = 4 level
-    return;
-  }
-  job -= j1;
-  if (job < j3) {
-    const int n0 = (job / nt_h) * 16, kb = (job % nt_h) * 16;
-    const DwPre pre = dw_prefetch(a, OUT, H, n0, kb, oW3);
-    wait();
-    if (!a.grads_only) ac = load_adam_consts(a.opt);
-    dw_tile<true, U>(a, ac, dz3, OUT, h2, 0, H, n0, kb, oW3, pre);
-    return;
-  }
-  job -= j3;
-  wait();
-  if (!a.grads_only) ac = load_adam_consts(a.opt);
-  if (job < nt_h) { dw_bias(a, ac, dz1, H, job * 16, ob1); return; }
-  job -= nt_h;
-  if (job < nt_h) { dw_bias(a, ac, dz2, H, job * 16, ob2); return; }
-  job -= nt_h;
-  dw_bias(a, ac, dz3, OUT, job * 16, ob3);
-}
-
-template <int U, bool SKIPBIG = false>   // SKIPBIG: the H x H layers are done by dw_block64 workgroups of the same launch (population path)
-__device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, const int nblocks) {   // bid / nblocks: this learner's block index / count
-  const int wave_in_block = threadIdx.x >> 6;
-  if (bid >= a.n_dw_blocks) {  // ---- tail blocks
-    const int tb = bid - a.n_dw_blocks;
-    if (a.log_alpha && tb == 0 && threadIdx.x == 0) {
-      float s = 0.f;
-      int i0 = 0;
-#if IL_DW_SCHED_BARRIER
-      for (; i0 + 16 <= a.n_alpha_part; i0 += 16) {   // one thread, B / 16 partials: requested together, added in index order (as a plain loop: one dependent round trip per partial)
-        float t[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) t[u] = gload(a.alpha_part + i0 + u);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 16; ++u) s += t[u];
-      }
-#endif
-      for (int i = i0; i < a.n_alpha_part; ++i) s += a.alpha_part[i];
-      const float alpha = expf(a.log_alpha[0]);
-      const float gr = -(alpha) * (s / (float)a.batch);
-      if (a.grads_only) a.alpha_grad[0] = gr;
-      else {
-        const adam_consts ac = load_adam_consts(a.alpha_opt);
-        float pp = a.log_alpha[0], mm = a.alpha_opt.m[0], vv = a.alpha_opt.v[0];
-        adam_update(pp, gr, mm, vv, ac);
-        a.log_alpha[0] = pp; a.alpha_opt.m[0] = mm; a.alpha_opt.v[0] = vv;
-      }
-      if (a.noise_counter) a.noise_counter[0] += 1;
-      // this update's SAC half is done. Release: the resident sampler and, behind it, the discriminator kernels of the NEXT update start from this signal and read the noise counter bumped above
-      if (a.sync) __hip_atomic_fetch_add(reinterpret_cast<long long*>(a.sync) + IL_SYNC_MAIN_EPOCH, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (a.target && !a.grads_only) {
-      const float omt = (float)(1.0 - a.tau), tau = (float)a.tau;
-      const int ntb = nblocks - a.n_dw_blocks;
-#if IL_DW_SCHED_BARRIER
-      // (round 3) target <- tau target + (1 - tau) critic over the parameter arena AND its lane-ordered copies as ONE index space of 16-byte lanes, four lanes per thread
-      // and trip with all eight loads requested first: the grid-stride loops below were a dependent HBM round trip per trip (the target was last touched an update ago),
-      // 8 trips per thread with 33 tail blocks. Elementwise: the bits do not depend on who computes which lane.
-      if ((a.polyak_n & 3) == 0 && (!a.pk_target || (a.pk_n & 3) == 0)) {
-        const int64_t n1 = a.polyak_n >> 2, n2 = a.pk_target ? (a.pk_n >> 2) : 0, stride = (int64_t)ntb * blockDim.x;
-        for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < n1 + n2; i += 4 * stride) {
-          f32x4 t[4], p[4]; f32x4* dst[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int64_t q = i + u * stride, qc = q < n1 + n2 ? q : i;   // out of range: re-read lane i, never stored
-            const bool second = qc >= n1;
-            dst[u] = reinterpret_cast<f32x4*>(second ? a.pk_target : a.target) + (second ? qc - n1 : qc);
-            t[u] = *dst[u]; p[u] = *(reinterpret_cast<const f32x4*>(second ? a.pk_critic : a.polyak_src) + (second ? qc - n1 : qc));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) t[u][q] = __fadd_rn(__fmul_rn(t[u][q], tau), __fmul_rn(omt, p[u][q]));
-            if (i + u * stride < n1 + n2) *dst[u] = t[u];
-          }
-        }
-        return;
-      }
-#endif
-      for (int64_t i = ((int64_t)tb * blockDim.x + threadIdx.x) * 4; i < a.polyak_n; i += (int64_t)ntb * blockDim.x * 4) {
-        if (i + 3 < a.polyak_n) {
-          f32x4 t = *reinterpret_cast<f32x4*>(a.target + i); const f32x4 p = *reinterpret_cast<const f32x4*>(a.polyak_src + i);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) t[q] = __fadd_rn(__fmul_rn(t[q], tau), __fmul_rn(omt, p[q]));
-          *reinterpret_cast<f32x4*>(a.target + i) = t;
-        } else {
-          for (int64_t q = i; q < a.polyak_n; ++q) a.target[q] = __fadd_rn(__fmul_rn(a.target[q], tau), __fmul_rn(omt, a.polyak_src[q]));
-        }
-      }
-      if (a.pk_target)
-        for (int64_t i = ((int64_t)tb * blockDim.x + threadIdx.x) * 4; i < a.pk_n; i += (int64_t)ntb * blockDim.x * 4) {
-          f32x4 t = *reinterpret_cast<f32x4*>(a.pk_target + i); const f32x4 p = *reinterpret_cast<const f32x4*>(a.pk_critic + i);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) t[q] = __fadd_rn(__fmul_rn(t[q], tau), __fmul_rn(omt, p[q]));
-          *reinterpret_cast<f32x4*>(a.pk_target + i) = t;
-        }
-    }
-    return;
-  }
-  dw_jobs<U, SKIPBIG>(a, bid * 4 + wave_in_block, [] {});
-}
-
-__host__ __device__ static inline int dw_blocks(int IN, int H, int OUT, int nets, int skip_big = 0) {
-  const int nt_h = H / 16, nt_out = (OUT + 15) / 16;
-  const int per_net = nt_h * ((IN + 15) / 16) + (skip_big ? 0 : nt_h * nt_h) + nt_out * nt_h + 2 * nt_h + nt_out;
-  return (per_net * nets + 3) / 4;
-}
-
-
-__host__ __device__ static DwArgs critic_dw_args(const il_sac* d, uint32_t flags) {
-  const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, IN = S + A;
-  const SacWs ws = sac_ws(S, A, H, B);
-  DwArgs a = {};
-  a.params = d->critic; a.grads = d->critic_grad; a.opt = d->critic_opt; a.grads_only = (flags & IL_FLAG_GRADS_ONLY) ? 1 : 0;
-  a.n_nets = 2; a.net_stride = net_stride(IN, H, 1); a.in_dim = IN; a.hidden = H; a.out_dim = 1; a.batch = B;
-  a.x0 = d->workspace + ws.c_x0; a.ld_x0 = 0; a.x0_transposed = 1; a.x0_net_stride = 0;
-  a.h1 = d->workspace + ws.c_h1; a.h2 = d->workspace + ws.c_h2; a.dz1 = d->workspace + ws.c_dz1; a.dz2 = d->workspace + ws.c_dz2; a.h_net_stride = (int64_t)B * H;
-  a.dz3 = d->workspace + ws.c_dz3; a.dz3_net_stride = B;
-  a.pk_f = d->workspace + ws.pk_cf; a.pk_b = d->workspace + ws.pk_cb;
-  a.n_dw_blocks = dw_blocks(IN, H, 1, 2);
-  return a;
-}
-
-__host__ __device__ static DwArgs actor_dw_args(const il_sac* d, const il_batch* b, uint32_t flags) {
-  const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch;
-  const SacWs ws = sac_ws(S, A, H, B);
-  DwArgs a = {};
-  a.params = d->actor; a.grads = d->actor_grad; a.opt = d->actor_opt; a.grads_only = (flags & IL_FLAG_GRADS_ONLY) ? 1 : 0;
-  a.n_nets = 1; a.net_stride = 0; a.in_dim = S; a.hidden = H; a.out_dim = 2 * A; a.batch = B;
-  a.x0 = b->states; a.ld_x0 = b->ld_states; a.x0_transposed = 0; a.x0_net_stride = 0;
-  a.h1 = d->workspace + ws.a_h1; a.h2 = d->workspace + ws.a_h2; a.dz1 = d->workspace + ws.a_dz1; a.dz2 = d->workspace + ws.a_dz2; a.h_net_stride = 0;
-  a.dz3 = d->workspace + ws.a_dz3; a.dz3_net_stride = 0;
-  a.pk_f = d->workspace + ws.pk_af; a.pk_b = d->workspace + ws.pk_ab;
-  a.n_dw_blocks = dw_blocks(S, H, 2 * A, 1);
-  a.log_alpha = d->log_alpha; a.alpha_grad = d->alpha_grad; a.alpha_opt = d->alpha_opt; a.alpha_part = d->workspace + ws.alpha_part; a.n_alpha_part = B / IL_TILE_R;
-  a.target = d->target; a.polyak_src = d->critic; a.polyak_n = 2 * net_stride(S + A, H, 1); a.tau = d->polyak; a.noise_counter = d->noise_counter; a.sync = d->sync;
-  a.pk_target = d->workspace + ws.pk_tf; a.pk_critic = d->workspace + ws.pk_cf; a.pk_n = 2 * (int64_t)H * H;   // the FORWARD-order copies of both target critics only: targets are never back-propagated, so their PB copies (pk_tb) have no reader (round 2: 1.5 MB of polyak traffic per update removed)
-  return a;
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Weight-gradient jobs INSIDE the launch that produces dZ (round 3). The dW + AdamW launch sat between two kernel boundaries (1.6 + 2.6 us around the critic's, 1.4 us
-// before the actor's) and spent most of its own 6-7 us waiting: for the Adam operands (HBM, last touched an update ago), then for the dZ / activation panels (written a
-// moment ago on other XCDs). In the single learner's co-resident launches most workgroups finish long before the last producer of dZ does (actor(s), actor(s') and the
-// target critics in k_sac_chain; the critic workgroups in k_policy_critic): instead of exiting they take the dW jobs - one wave, one job, as in k_dw_adam -, request the
-// Adam operands of their tile at once, wait ON THE DEVICE for the producers' arrival counter and then run the products and the AdamW epilogue. One launch and one
-// boundary less per optimiser step, and the HBM latency of p / m / v is gone from the critical path. Same dw_tile / dw_bias code, same job list: same bits.
-// The wait is per wave and barrier-free (the job paths diverge between waves): lane 0 of wave 0 polls the producers' counter (bounded, like every device-side wait here),
-// acquires, and raises a flag in LDS the other waves of the workgroup poll.
-// ---------------------------------------------------------------------------------------------
-#ifndef IL_DW_INLINE_U
-#define IL_DW_INLINE_U 6
-#endif
-__device__ __forceinline__ void dw_jobs_inline(const DwArgs& a, int pidx, unsigned* producers, unsigned n_producers, const TileTimeouts& timeouts, unsigned* lds_flag) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-  __syncthreads();   // (uniform: every thread of the workgroup enters here) the workgroup's own work is over, its LDS is free
-  if (threadIdx.x == 0) __hip_atomic_store(lds_flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  __syncthreads();
-  dw_jobs<IL_DW_INLINE_U, false>(a, pidx * nw + wave, [&] {
-    if (wave == 0) {
-      if (lane == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(producers, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_producers) {
-          __builtin_amdgcn_s_sleep(4);
-          if (++spins > IL_SYNC_SPIN_LIMIT) {
-            __hip_atomic_fetch_add(timeouts.slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (timeouts.sync) sync_timed_out(timeouts.sync);
-            break;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the producers' stores are visible to this CU from here on
-        __hip_atomic_store(lds_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    } else {
-      while (__hip_atomic_load(lds_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) __builtin_amdgcn_s_sleep(1);
-    }
-  });
-}
-// polyak over the target arena and its lane-ordered copies by `np` workgroups (the tail blocks' loop of dw_adam_body, as a function of a dense participant index)
-__device__ __forceinline__ void polyak_part(const DwArgs& a, int pidx, int np) {
-  if (!a.target || a.grads_only) return;
-  const float omt = (float)(1.0 - a.tau), tau = (float)a.tau;
-  const int64_t n1 = a.polyak_n >> 2, n2 = a.pk_target ? (a.pk_n >> 2) : 0, stride = (int64_t)np * blockDim.x;
-  for (int64_t i = (int64_t)pidx * blockDim.x + threadIdx.x; i < n1 + n2; i += 4 * stride) {
-    f32x4 t[4], p[4]; f32x4* dst[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t q = i + u * stride, qc = q < n1 + n2 ? q : i;
-      const bool second = qc >= n1;
-      dst[u] = reinterpret_cast<f32x4*>(second ? a.pk_target : a.target) + (second ? qc - n1 : qc);
-      t[u] = *dst[u]; p[u] = *(reinterpret_cast<const f32x4*>(second ? a.pk_critic : a.polyak_src) + (second ? qc - n1 : qc));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) t[u][q] = __fadd_rn(__fmul_rn(t[u][q], tau), __fmul_rn(omt, p[u][q]));
-      if (i + u * stride < n1 + n2) *dst[u] = t[u];
-    }
-  }
-}
-// Adam(log alpha), the Philox counter and the end-of-update signal: ONE thread (tail block 0, thread 0 of dw_adam_body)
-__device__ __forceinline__ void alpha_tail(const DwArgs& a) {
-  float s = 0.f;
-  int i0 = 0;
-  for (; i0 + 16 <= a.n_alpha_part; i0 += 16) {
-    float t[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) t[u] = gload(a.alpha_part + i0 + u);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < 16; ++u) s += t[u];
-  }
-  for (int i = i0; i < a.n_alpha_part; ++i) s += a.alpha_part[i];
-  const float alpha = expf(a.log_alpha[0]);
-  const float gr = -(alpha) * (s / (float)a.batch);
-  if (a.grads_only) a.alpha_grad[0] = gr;
-  else {
-    const adam_consts ac = load_adam_consts(a.alpha_opt);
-    float pp = a.log_alpha[0], mm = a.alpha_opt.m[0], vv = a.alpha_opt.v[0];
-    adam_update(pp, gr, mm, vv, ac);
-    a.log_alpha[0] = pp; a.alpha_opt.m[0] = mm; a.alpha_opt.v[0] = vv;
-  }
-  if (a.noise_counter) a.noise_counter[0] += 1;
-  if (a.sync) __hip_atomic_fetch_add(reinterpret_cast<long long*>(a.sync) + IL_SYNC_MAIN_EPOCH, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned* dw_counter(const il_sac& d, bool policy) {   // the arrival counters of the dZ producers: word 2 of the line behind the per-tile counters
-  const SacWs ws = sac_ws(d.state_dim, d.action_dim, d.hidden, d.batch);
-  return reinterpret_cast<unsigned*>(d.workspace + (policy ? ws.pair_ctr : ws.chain_ctr)) + (d.batch / IL_TILE_R) * IL_CTR_STRIDE + 2;
 }
 
 // Forward of one critic-shaped network on one 16-row tile. net 0,1: critic_k(s, a) keeping h1, h2 (and x0 for net 0) for the weight gradients;
@@ -838,7 +398,7 @@ __device__ __forceinline__ void critic_bwd_resident_gemm(const il_sac& d, int k,
 }
 // relabel: the rewards of this tile are the discriminator `dd`'s prediction on (s, a) - the rows still sit in Xs - computed here once its AdamW step of
 // this update is complete ([IL_SYNC_PARAMS], n_reduce workgroups per step); otherwise dense `rewards` or the batch's own reward field.
-struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; int fwd_only; int wait_indices; int local_rewards; int xcd_nets, gather_wgs; int dw_inline; };   // dw_inline: the critic dW + AdamW jobs run in this launch (dw_jobs_inline)   // xcd_nets: grid = 8 * nt, one network per XCD (chain_decode_xcd); gather_wgs: row-copy workgroups among the blocks of XCDs 6, 7   // wait_indices: IL_FLAG_SAC_WAIT_INDICES; local_rewards: il_sac_update_gather without `rewards` / `relabel` (the ring's reward field: nothing to wait for)   // fwd_only: the forward kernels only (IL_FLAG_SAC_FORWARD_ONLY / data-parallel phase 0): no critic backward
+struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; int fwd_only; int wait_indices; int local_rewards; int xcd_nets, gather_wgs; };   // xcd_nets: grid = 8 * nt, one network per XCD (chain_decode_xcd); gather_wgs: row-copy workgroups among the blocks of XCDs 6, 7   // wait_indices: IL_FLAG_SAC_WAIT_INDICES; local_rewards: il_sac_update_gather without `rewards` / `relabel` (the ring's reward field: nothing to wait for)   // fwd_only: the forward kernels only (IL_FLAG_SAC_FORWARD_ONLY / data-parallel phase 0): no critic backward
 // Runs between the critic's own work and its wait for the targets: the discriminator's step usually lands while the targets are still being computed,
 // so the relabel stays off the critical path. Leaves the tile's rewards in LDS (rew16) for critic_bwd_resident_scale.
 __device__ __forceinline__ void critic_relabel_tile(const il_sac& d, const ChainRelabel& rl, int k, int tile, float* smem) {
@@ -976,9 +536,6 @@ __device__ __forceinline__ void sac_chain_body(il_sac& d, il_batch& b, const flo
   if (rl.xcd_nets) chain_decode_xcd(bid, role, net, tile); else chain_decode(bid, nt, role, net, tile);
   const SacWs ws = sac_ws(d.state_dim, d.action_dim, d.hidden, d.batch);
   unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + tile * IL_CTR_STRIDE;
-  if (rl.dw_inline && bid == 0 && threadIdx.x == 0) *dw_counter(d, true) = 0u;   // k_policy_critic's dW counter: its last launch is complete (stream order), its next one follows this launch
-  // participant index of the in-launch dW jobs, earliest finishers first: actor(s), actor(s'), targets, critics
-  const int pidx = role == 3 ? tile : (role == 0 ? nt + tile : (role == 1 ? 2 * nt + net * nt + tile : 4 * nt + net * nt + tile));
   if (role == 0) { actor_fwd_tile(d, b, eps_next, eps_cur, false, tile, smem); IL_TL(0, 6); tile_arrive(ctr); IL_TL(0, 7); }
   else if (role == 1) {
     critic_fwd_tile(d, b, 2 + net, tile, smem, ctr);
@@ -1003,12 +560,7 @@ __device__ __forceinline__ void sac_chain_body(il_sac& d, il_batch& b, const flo
     if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 4u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     critic_bwd_resident_scale(d, b, rewards, rl, rs, net, tile, smem);
     IL_TL(0, 7);
-    if (rl.dw_inline) tile_arrive(dw_counter(d, false));   // dz1 / dz2 / dz3 of this (tile, critic) are written (and, for tile 0 of critic 0, the optimiser's step constants ticked)
   } else { actor_fwd_tile(d, b, eps_next, eps_cur, true, tile, smem); IL_TL(0, 7); }
-  if (rl.dw_inline) {
-    const DwArgs a = critic_dw_args(&d, 0);
-    dw_jobs_inline(a, pidx, dw_counter(d, false), 2u * (unsigned)nt, tile_timeouts(d), reinterpret_cast<unsigned*>(smem));
-  }
 }
 
 __global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, const float* __restrict__ rewards,
@@ -1133,7 +685,6 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
 // and split the last GEMM between them by output columns. Same arithmetic per element, so the result is bit-identical to helpers = 0.
 #define IL_PC_HELPERS 4
 #define IL_PC_XCD_NETS 0x100   // flag bit in k_policy_critic's `helpers` argument
-#define IL_PC_DW_INLINE 0x200  // flag bit: the actor dW + AdamW jobs, polyak and the alpha / end-of-update tail run in this launch (critic workgroups, dw_jobs_inline)
 template <int PANEL>
 __device__ __forceinline__ void k_policy_critic_body(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, const il_sac* __restrict__ dL,
                                                         const il_batch* __restrict__ bL, int helpers, float* smem) {
@@ -1145,8 +696,8 @@ __device__ __forceinline__ void k_policy_critic_body(il_sac d, il_batch b, float
   // helpers & IL_PC_XCD_NETS (single learner, grid = 8 * nt): one critic per XCD (workgroup b runs on XCD b % 8) - XCD 0 / 1: the nt tiles of critic 0 / 1, XCD 2 ..
   // 2 + helpers - 1: helper part p of every tile (its column slice of the actor's backward panel is read by that XCD alone), the other blocks exit. Tile q: blocks
   // 8q, 8q + 1 (critics) < 8q + 2 + p (helpers): a helper still only waits for lower-numbered workgroups.
-  const bool xcd_nets = (helpers & IL_PC_XCD_NETS) != 0, dw_inline = (helpers & IL_PC_DW_INLINE) != 0;
-  helpers &= ~(IL_PC_XCD_NETS | IL_PC_DW_INLINE);
+  const bool xcd_nets = (helpers & IL_PC_XCD_NETS) != 0;
+  helpers &= ~IL_PC_XCD_NETS;
   if (xcd_nets && (bx & 7) >= 2 + helpers) return;
   if (xcd_nets ? (bx & 7) >= 2 : bx >= 2 * nt) {   // helper: block order keeps it behind both critics of its tile (it only waits for lower-numbered workgroups)
     const int h = xcd_nets ? ((bx & 7) - 2) * nt + (bx >> 3) : bx - 2 * nt, tile = h % nt, part = h / nt;
@@ -1161,7 +712,6 @@ __device__ __forceinline__ void k_policy_critic_body(il_sac d, il_batch b, float
       if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u + (unsigned)helpers)
         __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // last helper through: ready for the next launch
     });
-    if (dw_inline) tile_arrive(dw_counter(d, true));   // this helper's share of dz1 (and, for part 0, dz2 / dz3 / the alpha partial) is written
     IL_TL_END(3);
     return;
   }
@@ -1244,18 +794,7 @@ __device__ __forceinline__ void k_policy_critic_body(il_sac d, il_batch b, float
   // that arrives second continues with it. The barrier orders every wave's stores before thread 0's agent-scope acq_rel ticket, which
   // is the only L2 write-back / invalidate of the hand-off (a __threadfence() per wave costs 16 of them per workgroup: measured -8 %).
   unsigned* ctr = reinterpret_cast<unsigned*>(W + ws.pair_ctr) + tile * IL_CTR_STRIDE;
-  if (helpers > 0) {
-    IL_TL(3, 6); tile_arrive(ctr); IL_TL(3, 7);
-    if (dw_inline) {   // the critic workgroups finish ~4 us before the helpers: they run polyak now, and the actor's dW + AdamW jobs as soon as every helper has arrived
-      const int pidx = k * nt + tile, np = 2 * nt;
-      if (bx == 0 && threadIdx.x == 0) *dw_counter(d, false) = 0u;   // k_sac_chain's dW counter: that launch is complete (stream order), its next one follows this launch
-      const DwArgs a = actor_dw_args(&d, &b, 0);
-      polyak_part(a, pidx, np);
-      dw_jobs_inline(a, pidx, dw_counter(d, true), (unsigned)(helpers * nt), tile_timeouts(d), reinterpret_cast<unsigned*>(smem));
-      if (pidx == np - 1 && threadIdx.x == 0) alpha_tail(a);   // (a workgroup without jobs of its own: its wave 0 has just seen every helper arrive)
-    }
-    return;
-  }
+  if (helpers > 0) { IL_TL(3, 6); tile_arrive(ctr); IL_TL(3, 7); return; }
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -1304,6 +843,280 @@ IL_TILE_KERNELS(_pop, IL_POP_PANEL, __launch_bounds__(512, IL_POP_WAVES_PER_EU))
 // ---------------------------------------------------------------------------------------------
 // actor backward (training.py:38-46): L = mean(w m alpha logp - min Q).  grid = nt
 // ---------------------------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------------------------
+// k_dw_adam: output-stationary weight gradients on MFMA with a fused AdamW epilogue.
+//   dW_l[n][k] = sum_r dZ_l[r][n] X_l[r][k]  (reduction index = batch row, 4 per MFMA step), db_l[n] = sum_r dZ_l[r][n]
+// One wave = one job: a 16(n) x 16(k) tile of some layer's weight, or 16 bias elements. Operands come from the feature-major
+// workspace ([feature][B]): lane (j, g) reads 4 consecutive batch rows of feature n0+j / k0+j as ONE 16-byte load, eight such
+// loads per operand are in flight before the first MFMA. Gradients never touch HBM unless grads_only (data-parallel: they are
+// all-reduced first).  Tail blocks: Adam(log_alpha), polyak, Philox counter.
+// ---------------------------------------------------------------------------------------------
+struct DwArgs {
+  float* params; float* grads; il_adam opt; int grads_only;
+  int n_nets; int64_t net_stride;
+  int in_dim, hidden, out_dim, batch;
+  const float* x0; int ld_x0; int x0_transposed; int64_t x0_net_stride;   // layer-1 input: [in][B] (transposed) or row-major [B][ld_x0]
+  const float* h1; const float* h2; const float* dz1; const float* dz2; int64_t h_net_stride;   // [H][B]
+  const float* dz3; int64_t dz3_net_stride;                                // [out][B]
+  float* pk_f; float* pk_b;                                                 // lane-ordered copies of W2 kept in step with the AdamW update (NULL: none)
+  int n_dw_blocks;
+  // tail
+  float* log_alpha; float* alpha_grad; il_adam alpha_opt; const float* alpha_part; int n_alpha_part;
+  float* target; const float* polyak_src; int64_t polyak_n; double tau; uint32_t* noise_counter; int64_t* sync;
+  float* pk_target; const float* pk_critic; int64_t pk_n;   // lane-ordered copies of the target / critic hidden layers (polyak is elementwise, so it commutes with the re-ordering)
+};
+
+__device__ __forceinline__ void adam_store(const DwArgs& a, const adam_consts& ac, int64_t o, float gr) {
+  if (a.grads_only) { a.grads[o] = gr; return; }
+  float pp = a.params[o], mm = a.opt.m[o], vv = a.opt.v[o];
+  adam_update(pp, gr, mm, vv, ac);
+  a.params[o] = pp; a.opt.m[o] = mm; a.opt.v[o] = vv;
+}
+
+#ifndef IL_DW_PREFETCH
+#define IL_DW_PREFETCH 1
+#endif
+#ifndef IL_DW_SCHED_BARRIER
+#define IL_DW_SCHED_BARRIER 1   // dw_tile: all operand loads of a chunk ahead of its MFMAs (0 = the round-2 schedule, for A/B builds)
+#endif
+#ifndef IL_TAIL_BLOCKS
+#define IL_TAIL_BLOCKS 69       // single learner: tail blocks of the actor launch (block 0: Adam(log alpha) + counters; all: polyak over the target arena and its lane-ordered copies, one trip each at H = 256)
+#endif
+#ifndef IL_DW_U
+#define IL_DW_U 16              // single-learner k_dw_adam: 16-row operand lanes in flight per operand and chunk (16 = the whole batch of 256 rows in one round)
+#endif
+// XT: x is feature-major [Kvalid][B]; otherwise row-major [B][ldx] (the actor's layer-1 input = the states field of the batch)
+// U = 16-row operand lanes in flight per operand: 8 for the single learner (one block per CU: latency hiding has to come from the wave itself),
+// 4 for the population launch (half the registers -> four waves per SIMD instead of two hide the latency across blocks).
+template <bool XT, int U>
+__device__ __forceinline__ void dw_tile(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dzT, int Nvalid, const float* __restrict__ x, int ldx, int Kvalid,
+                                        int n0, int kb, int64_t poff, float* __restrict__ pkf = nullptr, float* __restrict__ pkb = nullptr) {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int B = a.batch;
+  f32x4 acc0 = zero4(), acc1 = zero4();
+  // out-of-range features clamp their address: the rows / columns of dW they produce are discarded by the epilogue
+  const float* dzp = dzT + (size_t)min(n0 + j, Nvalid - 1) * B + 4 * g;
+  const int kc = min(kb + j, Kvalid - 1);
+  const float* xp = XT ? x + (size_t)kc * B + 4 * g : x + (size_t)(4 * g) * ldx + kc;
+  auto ldx4 = [&](int r0) -> f32x4 {
+    if (XT) return gload4(xp + r0);
+    f32x4 v;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[s] = gload(xp + (size_t)(r0 + s) * ldx);
+    return v;
+  };
+  // The Adam operands of this lane's four dW elements do not depend on the products: fetch them before the MFMA loop so that their
+  // HBM latency (they were last touched one update ago) hides under it instead of following it.
+  const int k = kb + j, kk = min(k, Kvalid - 1);
+  float pp[4], mm[4], vv[4];
+  if (IL_DW_PREFETCH && !a.grads_only) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t o = poff + (int64_t)min(n0 + 4 * g + r, Nvalid - 1) * Kvalid + kk;
+      pp[r] = gload(a.params + o); mm[r] = gload(a.opt.m + o); vv[r] = gload(a.opt.v + o);
+    }
+  }
+  int r0 = 0;
+  // Every operand lane of a chunk is REQUESTED before its first MFMA: without the scheduling barrier hipcc sinks the loads back between the MFMAs (round 3, ISA of the
+  // round-2 build: four loads in flight, `s_waitcnt vmcnt(2)` in front of every group of four MFMAs - sixteen dependent L2 round trips per tile, which is what made this
+  // launch 6-8 us for 0.85 us of MFMA issue). Chunks of 16 U, then 64, then 16 rows; the MFMA order (row groups ascending, k-steps 0, 2 -> acc0 and 1, 3 -> acc1) does not
+  // depend on the chunking, so every chunk size gives the same bits.
+#define IL_DW_CHUNK(UU)                                                                                            \
+  for (; r0 + 16 * (UU) <= B; r0 += 16 * (UU)) {                                                                   \
+    f32x4 av[UU], bv[UU];                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < (UU); ++u) { av[u] = gload4(dzp + r0 + 16 * u); bv[u] = ldx4(r0 + 16 * u); } \
+    if (IL_DW_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);                                                    \
+    _Pragma("unroll") for (int u = 0; u < (UU); ++u) {                                                             \
+      acc0 = mfma16(av[u][0], bv[u][0], acc0);                                                                     \
+      acc1 = mfma16(av[u][1], bv[u][1], acc1);                                                                     \
+      acc0 = mfma16(av[u][2], bv[u][2], acc0);                                                                     \
+      acc1 = mfma16(av[u][3], bv[u][3], acc1);                                                                     \
+    }                                                                                                              \
+  }
+  IL_DW_CHUNK(U)
+  if (U > 4) { IL_DW_CHUNK(4) }
+  IL_DW_CHUNK(1)
+#undef IL_DW_CHUNK
+  const f32x4 acc = acc0 + acc1;
+  if (k >= Kvalid) return;
+  if (a.grads_only) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 4 * g + r;
+      if (n < Nvalid) a.grads[poff + (int64_t)n * Kvalid + k] = acc[r];
+    }
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + 4 * g + r;
+    if (n < Nvalid) {
+      const int64_t o = poff + (int64_t)n * Kvalid + k;
+      if (!IL_DW_PREFETCH) { pp[r] = a.params[o]; mm[r] = a.opt.m[o]; vv[r] = a.opt.v[o]; }
+      adam_update(pp[r], acc[r], mm[r], vv[r], ac);
+      a.params[o] = pp[r]; a.opt.m[o] = mm[r]; a.opt.v[o] = vv[r];
+    }
+  }
+  if (pkf) {  // the updated W2 values, in both lane orders (this tile owns rows n0..n0+15, columns kb..kb+15: always full for an H x H layer)
+    f32x4 w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { w[r] = pp[r]; pkf[packed_fwd_index(n0 + 4 * g + r, k, Kvalid)] = w[r]; }
+    *reinterpret_cast<f32x4*>(pkb + packed_bwd_index(n0 + 4 * g, k, Kvalid)) = w;   // rows n0+4g..+3 of column k: one 16-byte lane of PB
+  }
+}
+
+// 16 bias elements per wave: lane (j, g) sums rows 16i + 4g .. +3 of feature n0 + j, the four row groups meet through shuffles
+__device__ __forceinline__ void dw_bias(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dzT, int Nvalid, int n0, int64_t poff) {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int B = a.batch;
+  const float* p = dzT + (size_t)min(n0 + j, Nvalid - 1) * B + 4 * g;
+  f32x4 s4 = zero4();
+  int r0 = 0;
+#if IL_DW_SCHED_BARRIER
+  // (round 3) as a plain loop this was load -> s_waitcnt vmcnt(0) -> add, once per 16 rows: sixteen DEPENDENT L2 round trips at B = 256 - the bias jobs, not the MFMA
+  // tiles, were the long pole of the launch. All lanes of a chunk are requested first; the adds keep their order (ascending rows), so the sums keep their bits.
+  for (; r0 + 256 <= B; r0 += 256) {
+    f32x4 t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = gload4(p + r0 + 16 * u);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s4 += t[u];
+  }
+  for (; r0 + 64 <= B; r0 += 64) {
+    f32x4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = gload4(p + r0 + 16 * u);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4 += t[u];
+  }
+#endif
+  for (; r0 < B; r0 += 16) s4 += *reinterpret_cast<const f32x4*>(p + r0);
+  float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  if (g == 0 && n0 + j < Nvalid) adam_store(a, ac, poff + n0 + j, s);
+}
+
+template <int U, bool SKIPBIG = false>   // SKIPBIG: the H x H layers are done by dw_block64 workgroups of the same launch (population path)
+__device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, const int nblocks) {   // bid / nblocks: this learner's block index / count
+  const int wave_in_block = threadIdx.x >> 6;
+  if (bid >= a.n_dw_blocks) {  // ---- tail blocks
+    const int tb = bid - a.n_dw_blocks;
+    if (a.log_alpha && tb == 0 && threadIdx.x == 0) {
+      float s = 0.f;
+      int i0 = 0;
+#if IL_DW_SCHED_BARRIER
+      for (; i0 + 16 <= a.n_alpha_part; i0 += 16) {   // one thread, B / 16 partials: requested together, added in index order (as a plain loop: one dependent round trip per partial)
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = gload(a.alpha_part + i0 + u);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += t[u];
+      }
+#endif
+      for (int i = i0; i < a.n_alpha_part; ++i) s += a.alpha_part[i];
+      const float alpha = expf(a.log_alpha[0]);
+      const float gr = -(alpha) * (s / (float)a.batch);
+      if (a.grads_only) a.alpha_grad[0] = gr;
+      else {
+        const adam_consts ac = load_adam_consts(a.alpha_opt);
+        float pp = a.log_alpha[0], mm = a.alpha_opt.m[0], vv = a.alpha_opt.v[0];
+        adam_update(pp, gr, mm, vv, ac);
+        a.log_alpha[0] = pp; a.alpha_opt.m[0] = mm; a.alpha_opt.v[0] = vv;
+      }
+      if (a.noise_counter) a.noise_counter[0] += 1;
+      // this update's SAC half is done. Release: the resident sampler and, behind it, the discriminator kernels of the NEXT update start from this signal and read the noise counter bumped above
+      if (a.sync) __hip_atomic_fetch_add(reinterpret_cast<long long*>(a.sync) + IL_SYNC_MAIN_EPOCH, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (a.target && !a.grads_only) {
+      const float omt = (float)(1.0 - a.tau), tau = (float)a.tau;
+      const int ntb = nblocks - a.n_dw_blocks;
+#if IL_DW_SCHED_BARRIER
+      // (round 3) target <- tau target + (1 - tau) critic over the parameter arena AND its lane-ordered copies as ONE index space of 16-byte lanes, four lanes per thread
+      // and trip with all eight loads requested first: the grid-stride loops below were a dependent HBM round trip per trip (the target was last touched an update ago),
+      // 8 trips per thread with 33 tail blocks. Elementwise: the bits do not depend on who computes which lane.
+      if ((a.polyak_n & 3) == 0 && (!a.pk_target || (a.pk_n & 3) == 0)) {
+        const int64_t n1 = a.polyak_n >> 2, n2 = a.pk_target ? (a.pk_n >> 2) : 0, stride = (int64_t)ntb * blockDim.x;
+        for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < n1 + n2; i += 4 * stride) {
+          f32x4 t[4], p[4]; f32x4* dst[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int64_t q = i + u * stride, qc = q < n1 + n2 ? q : i;   // out of range: re-read lane i, never stored
+            const bool second = qc >= n1;
+            dst[u] = reinterpret_cast<f32x4*>(second ? a.pk_target : a.target) + (second ? qc - n1 : qc);
+            t[u] = *dst[u]; p[u] = *(reinterpret_cast<const f32x4*>(second ? a.pk_critic : a.polyak_src) + (second ? qc - n1 : qc));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[u][q] = __fadd_rn(__fmul_rn(t[u][q], tau), __fmul_rn(omt, p[u][q]));
+            if (i + u * stride < n1 + n2) *dst[u] = t[u];
+          }
+        }
+        return;
+      }
+#endif
+      for (int64_t i = ((int64_t)tb * blockDim.x + threadIdx.x) * 4; i < a.polyak_n; i += (int64_t)ntb * blockDim.x * 4) {
+        if (i + 3 < a.polyak_n) {
+          f32x4 t = *reinterpret_cast<f32x4*>(a.target + i); const f32x4 p = *reinterpret_cast<const f32x4*>(a.polyak_src + i);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t[q] = __fadd_rn(__fmul_rn(t[q], tau), __fmul_rn(omt, p[q]));
+          *reinterpret_cast<f32x4*>(a.target + i) = t;
+        } else {
+          for (int64_t q = i; q < a.polyak_n; ++q) a.target[q] = __fadd_rn(__fmul_rn(a.target[q], tau), __fmul_rn(omt, a.polyak_src[q]));
+        }
+      }
+      if (a.pk_target)
+        for (int64_t i = ((int64_t)tb * blockDim.x + threadIdx.x) * 4; i < a.pk_n; i += (int64_t)ntb * blockDim.x * 4) {
+          f32x4 t = *reinterpret_cast<f32x4*>(a.pk_target + i); const f32x4 p = *reinterpret_cast<const f32x4*>(a.pk_critic + i);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t[q] = __fadd_rn(__fmul_rn(t[q], tau), __fmul_rn(omt, p[q]));
+          *reinterpret_cast<f32x4*>(a.pk_target + i) = t;
+        }
+    }
+    return;
+  }
+  // ---- job decode (wave-uniform)
+  const int IN = a.in_dim, H = a.hidden, OUT = a.out_dim;
+  const int nt_h = H / 16, kt_in = (IN + 15) / 16, nt_out = (OUT + 15) / 16;
+  const int j1 = nt_h * kt_in, j2 = SKIPBIG ? 0 : nt_h * nt_h, j3 = nt_out * nt_h, jb = 2 * nt_h + nt_out;
+  const int per_net = j1 + j2 + j3 + jb;
+  int job = bid * 4 + wave_in_block;
+  if (job >= per_net * a.n_nets) return;
+  const int net = job / per_net; job -= net * per_net;
+  adam_consts ac = {};
+  if (!a.grads_only) ac = load_adam_consts(a.opt);
+  const int64_t pbase = (int64_t)net * a.net_stride;
+  const int64_t oW1 = pbase, ob1 = oW1 + (int64_t)H * IN, oW2 = ob1 + H, ob2 = oW2 + (int64_t)H * H, oW3 = ob2 + H, ob3 = oW3 + (int64_t)OUT * H;
+  const float* x0 = a.x0 + net * a.x0_net_stride;
+  const float* h1 = a.h1 + net * a.h_net_stride; const float* h2 = a.h2 + net * a.h_net_stride;
+  const float* dz1 = a.dz1 + net * a.h_net_stride; const float* dz2 = a.dz2 + net * a.h_net_stride;
+  const float* dz3 = a.dz3 + net * a.dz3_net_stride;
+  // the big layer first: its tiles are the long pole, the small jobs fill in behind them
+  if (job < j2) {
+    dw_tile<true, U>(a, ac, dz2, H, h1, 0, H, (job / nt_h) * 16, (job % nt_h) * 16, oW2, a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr);
+    return;
+  }
+  job -= j2;
+  if (job < j1) {
+    if (a.x0_transposed) dw_tile<true, U>(a, ac, dz1, H, x0, 0, IN, (job / kt_in) * 16, (job % kt_in) * 16, oW1);
+    else dw_tile<false, U>(a, ac, dz1, H, x0, a.ld_x0, IN, (job / kt_in) * 16, (job % kt_in) * 16, oW1);
+    return;
+  }
+  job -= j1;
+  if (job < j3) { dw_tile<true, U>(a, ac, dz3, OUT, h2, 0, H, (job / nt_h) * 16, (job % nt_h) * 16, oW3); return; }
+  job -= j3;
+  if (job < nt_h) { dw_bias(a, ac, dz1, H, job * 16, ob1); return; }
+  job -= nt_h;
+  if (job < nt_h) { dw_bias(a, ac, dz2, H, job * 16, ob2); return; }
+  job -= nt_h;
+  dw_bias(a, ac, dz3, OUT, job * 16, ob3);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Population launch: one WORKGROUP = a 64(n) x 64(k) block of an H x H layer's dW (+ AdamW), operands staged through LDS.
@@ -1413,6 +1226,12 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
 }
 
 static int repack_blocks(int H) { return ceil_div(H * H / 16, 256); }
+__host__ __device__ static inline int dw_blocks(int IN, int H, int OUT, int nets, int skip_big = 0) {
+  const int nt_h = H / 16, nt_out = (OUT + 15) / 16;
+  const int per_net = nt_h * ((IN + 15) / 16) + (skip_big ? 0 : nt_h * nt_h) + nt_out * nt_h + 2 * nt_h + nt_out;
+  return (per_net * nets + 3) / 4;
+}
+
 // generic elementwise Adam over a flat arena (data-parallel path and stand-alone use)
 __global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, const float* __restrict__ g, il_adam opt, int64_t n) {
   const adam_consts ac = load_adam_consts(opt);
@@ -1449,6 +1268,21 @@ extern "C" int64_t il_mlp_numel(int32_t in_dim, int32_t hidden, int32_t out_dim)
 extern "C" int64_t il_mlp_stride(int32_t in_dim, int32_t hidden, int32_t out_dim) { return net_stride(in_dim, hidden, out_dim); }
 extern "C" int64_t il_sac_workspace_floats(int32_t S, int32_t A, int32_t H, int32_t B) { return sac_ws(S, A, H, B).total; }
 
+__host__ __device__ static inline int dw_blocks(int IN, int H, int OUT, int nets, int skip_big);
+__host__ __device__ static DwArgs critic_dw_args(const il_sac* d, uint32_t flags) {
+  const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, IN = S + A;
+  const SacWs ws = sac_ws(S, A, H, B);
+  DwArgs a = {};
+  a.params = d->critic; a.grads = d->critic_grad; a.opt = d->critic_opt; a.grads_only = (flags & IL_FLAG_GRADS_ONLY) ? 1 : 0;
+  a.n_nets = 2; a.net_stride = net_stride(IN, H, 1); a.in_dim = IN; a.hidden = H; a.out_dim = 1; a.batch = B;
+  a.x0 = d->workspace + ws.c_x0; a.ld_x0 = 0; a.x0_transposed = 1; a.x0_net_stride = 0;
+  a.h1 = d->workspace + ws.c_h1; a.h2 = d->workspace + ws.c_h2; a.dz1 = d->workspace + ws.c_dz1; a.dz2 = d->workspace + ws.c_dz2; a.h_net_stride = (int64_t)B * H;
+  a.dz3 = d->workspace + ws.c_dz3; a.dz3_net_stride = B;
+  a.pk_f = d->workspace + ws.pk_cf; a.pk_b = d->workspace + ws.pk_cb;
+  a.n_dw_blocks = dw_blocks(IN, H, 1, 2);
+  return a;
+}
+
 // k_policy_critic helpers need all (2 + helpers) * nt workgroups resident together; IL_PC_SPLIT=0 keeps the pair's second arriver doing the tail.
 static int device_cu_count() {
   static const int n = [] { int dev = 0, cu = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0; return cu; }();
@@ -1456,8 +1290,6 @@ static int device_cu_count() {
 }
 // IL_CHAIN_XCD_NETS=1: single-learner k_sac_chain / k_policy_critic launches place each network's tile workgroups on ONE XCD (chain_decode_xcd; grid = 8 * nt)
 static bool chain_xcd_nets(int nt) { static const int on = [] { const char* e = getenv("IL_CHAIN_XCD_NETS"); return e && e[0] == '1' ? 1 : 0; }(); return on != 0 && 8 * nt <= device_cu_count(); }
-// IL_DW_INLINE=0: the weight-gradient / AdamW jobs as launches of their own (k_dw_adam) instead of inside k_sac_chain / k_policy_critic (developer A/B switch; bit-identical)
-static bool dw_inline_enabled() { static const int on = [] { const char* e = getenv("IL_DW_INLINE"); return e && e[0] == '0' ? 0 : 1; }(); return on != 0; }
 static int pc_helpers(int nt) {
   static const int on = [] { const char* e = getenv("IL_PC_SPLIT"); return e && e[0] == '0' ? 0 : 1; }();
   return (on && (2 + IL_PC_HELPERS) * nt <= device_cu_count()) ? IL_PC_HELPERS : 0;
@@ -1475,6 +1307,23 @@ extern "C" int il_sac_critic_step(const il_sac* d, const il_batch* b, const floa
   { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<a.n_dw_blocks, 256, 0, st>>>(a); }
   IL_CHECK_LAUNCH("il_sac_critic_step");
   return IL_OK;
+}
+
+__host__ __device__ static DwArgs actor_dw_args(const il_sac* d, const il_batch* b, uint32_t flags) {
+  const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch;
+  const SacWs ws = sac_ws(S, A, H, B);
+  DwArgs a = {};
+  a.params = d->actor; a.grads = d->actor_grad; a.opt = d->actor_opt; a.grads_only = (flags & IL_FLAG_GRADS_ONLY) ? 1 : 0;
+  a.n_nets = 1; a.net_stride = 0; a.in_dim = S; a.hidden = H; a.out_dim = 2 * A; a.batch = B;
+  a.x0 = b->states; a.ld_x0 = b->ld_states; a.x0_transposed = 0; a.x0_net_stride = 0;
+  a.h1 = d->workspace + ws.a_h1; a.h2 = d->workspace + ws.a_h2; a.dz1 = d->workspace + ws.a_dz1; a.dz2 = d->workspace + ws.a_dz2; a.h_net_stride = 0;
+  a.dz3 = d->workspace + ws.a_dz3; a.dz3_net_stride = 0;
+  a.pk_f = d->workspace + ws.pk_af; a.pk_b = d->workspace + ws.pk_ab;
+  a.n_dw_blocks = dw_blocks(S, H, 2 * A, 1);
+  a.log_alpha = d->log_alpha; a.alpha_grad = d->alpha_grad; a.alpha_opt = d->alpha_opt; a.alpha_part = d->workspace + ws.alpha_part; a.n_alpha_part = B / IL_TILE_R;
+  a.target = d->target; a.polyak_src = d->critic; a.polyak_n = 2 * net_stride(S + A, H, 1); a.tau = d->polyak; a.noise_counter = d->noise_counter; a.sync = d->sync;
+  a.pk_target = d->workspace + ws.pk_tf; a.pk_critic = d->workspace + ws.pk_cf; a.pk_n = 2 * (int64_t)H * H;   // the FORWARD-order copies of both target critics only: targets are never back-propagated, so their PB copies (pk_tb) have no reader (round 2: 1.5 MB of polyak traffic per update removed)
+  return a;
 }
 
 extern "C" int il_sac_actor_step(const il_sac* d, const il_batch* b, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream_) {
@@ -1502,11 +1351,9 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   const bool whole = !(flags & (IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY));
-  bool inl = false;
   if (whole && chain_enabled() && 6 * nt <= device_cu_count()) {   // forward + critic loss chained per tile in one co-resident launch (k_sac_chain)
     if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
     ChainRelabel cr = {}; cr.xcd_nets = chain_xcd_nets(nt) ? 1 : 0;
-    cr.dw_inline = inl = dw_inline_enabled() && !cr.xcd_nets && pc_helpers(nt) > 0;   // both optimiser steps inside the launches that produce their dZ (dw_jobs_inline)
     { IL_TRACE("k_sac_chain", st); k_sac_chain<<<(cr.xcd_nets ? 8 : 6) * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr, cr); }
     flags |= IL_FLAG_SAC_SKIP_FORWARD | 0x80000000u;
   }
@@ -1529,10 +1376,10 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
   if (!(flags & IL_FLAG_SAC_FORWARD_ONLY)) {
     if (!(flags & 0x80000000u)) { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
     DwArgs ca = critic_dw_args(d, flags);
-    if (!inl) { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
-    { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : (inl ? (hp | IL_PC_DW_INLINE) : hp)); }
+    { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
+    { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
     DwArgs aa = actor_dw_args(d, b, flags);
-    if (!inl) { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + IL_TAIL_BLOCKS, 256, 0, st>>>(aa); }
+    { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + IL_TAIL_BLOCKS, 256, 0, st>>>(aa); }
   }
   IL_CHECK_LAUNCH("il_sac_update");
   return IL_OK;
@@ -1583,18 +1430,16 @@ extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
   if (chain_xcd_nets(nt) && G <= 2 * nt) { rl.xcd_nets = 1; rl.gather_wgs = G; }
-  const bool inl = dw_inline_enabled() && !(flags & IL_FLAG_GRADS_ONLY) && !rl.xcd_nets && pc_helpers(nt) > 0;   // both optimiser steps inside the launches that produce their dZ
-  rl.dw_inline = inl ? 1 : 0;
   { IL_TRACE("k_sac_chain", st); k_sac_chain<<<rl.xcd_nets ? 8 * nt : 6 * nt + G, tile_threads(H), lds, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl); }
   DwArgs ca = critic_dw_args(d, flags);
-  if (!inl) { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
+  { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
   if (flags & IL_FLAG_GRADS_ONLY) {   // data-parallel: stop at the critic gradients (critic_grad); the caller all-reduces them and continues with il_sac_dp_phase(rows, 2) and (rows, 3)
     IL_CHECK_LAUNCH("il_sac_update_gather");
     return IL_OK;
   }
-  { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *rows, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : (inl ? (hp | IL_PC_DW_INLINE) : hp)); }
+  { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *rows, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
   DwArgs aa = actor_dw_args(d, rows, flags);
-  if (!inl) { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + IL_TAIL_BLOCKS, 256, 0, st>>>(aa); }
+  { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + IL_TAIL_BLOCKS, 256, 0, st>>>(aa); }
   IL_CHECK_LAUNCH("il_sac_update_gather");
   return IL_OK;
 }
