@@ -861,6 +861,7 @@ struct DwArgs {
   const float* dz3; int64_t dz3_net_stride;                                // [out][B]
   float* pk_f; float* pk_b;                                                 // lane-ordered copies of W2 kept in step with the AdamW update (NULL: none)
   int n_dw_blocks;
+  int n_big_blocks;   // single learner: leading workgroups that each own a 32 x 32 block of an H x H layer's dW (dw_block32); 0 = wave-per-tile jobs for every layer
   // tail
   float* log_alpha; float* alpha_grad; il_adam alpha_opt; const float* alpha_part; int n_alpha_part;
   float* target; const float* polyak_src; int64_t polyak_n; double tau; uint32_t* noise_counter; int64_t* sync;
@@ -882,6 +883,9 @@ __device__ __forceinline__ void adam_store(const DwArgs& a, const adam_consts& a
 #endif
 #ifndef IL_TAIL_BLOCKS
 #define IL_TAIL_BLOCKS 69       // single learner: tail blocks of the actor launch (block 0: Adam(log alpha) + counters; all: polyak over the target arena and its lane-ordered copies, one trip each at H = 256)
+#endif
+#ifndef IL_DW_BLOCK32
+#define IL_DW_BLOCK32 1         // single learner: the H x H layers' dW as 32 x 32 blocks staged through LDS (dw_block32); 0 = a wave per 16 x 16 tile straight from global memory
 #endif
 #ifndef IL_DW_U
 #define IL_DW_U 16              // single-learner k_dw_adam: 16-row operand lanes in flight per operand and chunk (16 = the whole batch of 256 rows in one round)
@@ -1219,8 +1223,110 @@ __device__ __forceinline__ void dw_block64(const DwArgs& a, const adam_consts& a
 }
 static inline int dw_block64_count(int H, int nets) { return (H / DWB) * (H / DWB) * nets; }
 
+// ---------------------------------------------------------------------------------------------
+// Single learner (round 3): one WORKGROUP = a 32(n) x 32(k) block of an H x H layer's dW (+ AdamW), operands staged through LDS.
+// What bounded the wave-per-tile form was not latency but the texture-address rate: lane (j, g) of a tile's operand load reads 16 bytes of feature j, so ONE wave
+// instruction touches 16 half-used 128-byte lines (14 B/clk/CU measured for this pattern, mlp_tile.hpp) and a CU with four tiles pulls 4 x 32 KB through it: 9.4k
+// clocks = 3.9 us - the duration of the launch, whatever the schedule of the loads (round 3 A/B: all operand lanes ahead of the MFMAs, 16 lanes per operand in flight:
+// no change; the same jobs at 16 per CU inside k_sac_chain: 4x longer). Here the 256 threads of a workgroup fetch the two [32 features][B] panels with every wave
+// instruction covering whole lines (64 lanes = 2 features x 512 contiguous bytes), 16 KB per tile instead of 32 KB, park them in LDS in two 128-row chunks (all
+// loads of both chunks are requested up front, with the block's p / m / v lanes), and each wave runs ONE 16 x 16 tile out of LDS with dw_tile's accumulators and MFMA
+// order (row groups ascending; k-steps 0, 2 -> acc0 and 1, 3 -> acc1): same bits. The epilogue goes through LDS like dw_block64's: AdamW row-wise on 16-byte lanes
+// (128-byte row segments per 8 threads instead of 4-byte pieces of 16 rows), the updated block once more for the column-wise lane order of the PB copy.
+// ---------------------------------------------------------------------------------------------
+#define DWS 32
+#define DWS_ROWS 128
+#define DWS_LD (DWS_ROWS + 4)
+#define DWS_GLD (DWS + 4)
+__device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restrict__ dzT, const float* __restrict__ xT, int H, int n0, int k0, int64_t poff,
+                                           float* __restrict__ pkf, float* __restrict__ pkb, float* smem) {
+  float* Zs = smem; float* Xs = smem + DWS * DWS_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int ti = wave >> 1, tq = wave & 1;   // this wave's tile of the block
+  const int B = a.batch;
+  // staging map: thread t moves the 16-byte lane (feature t / 32 + 8 u, rows 4 (t % 32) .. +3) of a 128-row chunk of both panels, u = 0..3
+  const int sf = tid >> 5, sr = (tid & 31) * 4;
+  // epilogue map: thread t owns the 16-byte lane (row t / 8, columns 4 (t % 8) .. +3) of the block
+  const int er = tid >> 3, ec = (tid & 7) * 4;
+  const int64_t eo = poff + (int64_t)(n0 + er) * H + k0 + ec;
+  f32x4 pv = zero4(), mv = zero4(), vv = zero4();
+  if (!a.grads_only) { pv = gload4(a.params + eo); mv = gload4(a.opt.m + eo); vv = gload4(a.opt.v + eo); }   // HBM (last touched an update ago): under everything that follows
+  f32x4 acc0 = zero4(), acc1 = zero4();
+  for (int r0 = 0; r0 < B; r0 += 2 * DWS_ROWS) {   // two chunks per trip, all their loads in flight together (B = 256: one trip)
+    f32x4 zr[2][4], xr[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = min(r0 + c * DWS_ROWS, B - DWS_ROWS) + sr;   // (B % 256 == 128: the second chunk of the last trip re-reads the first and is not used)
+        zr[c][u] = gload4(dzT + (size_t)(n0 + sf + 8 * u) * B + rr); xr[c][u] = gload4(xT + (size_t)(k0 + sf + 8 * u) * B + rr);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (r0 + c * DWS_ROWS >= B) break;
+      __syncthreads();   // the previous chunk's readers are done
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { *reinterpret_cast<f32x4*>(Zs + (sf + 8 * u) * DWS_LD + sr) = zr[c][u]; *reinterpret_cast<f32x4*>(Xs + (sf + 8 * u) * DWS_LD + sr) = xr[c][u]; }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < DWS_ROWS / 16; ++u) {   // 16-row groups in ascending order, like dw_tile
+        const f32x4 av = *reinterpret_cast<const f32x4*>(Zs + (16 * ti + j) * DWS_LD + 16 * u + 4 * g), bv = *reinterpret_cast<const f32x4*>(Xs + (16 * tq + j) * DWS_LD + 16 * u + 4 * g);
+        acc0 = mfma16(av[0], bv[0], acc0);
+        acc1 = mfma16(av[1], bv[1], acc1);
+        acc0 = mfma16(av[2], bv[2], acc0);
+        acc1 = mfma16(av[3], bv[3], acc1);
+      }
+    }
+  }
+  float* Gs = Zs;   // [32][DWS_GLD] gradient block, then the updated parameters
+  __syncthreads();
+  {
+    const f32x4 t = acc0 + acc1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Gs[(16 * ti + 4 * g + r) * DWS_GLD + 16 * tq + j] = t[r];
+  }
+  __syncthreads();
+  const f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + er * DWS_GLD + ec);
+  if (a.grads_only) { *reinterpret_cast<f32x4*>(a.grads + eo) = gv; return; }
+  const adam_consts ac = load_adam_consts(a.opt);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { float pp = pv[c], mm = mv[c], v2 = vv[c]; adam_update(pp, gv[c], mm, v2, ac); pv[c] = pp; mv[c] = mm; vv[c] = v2; }
+  *reinterpret_cast<f32x4*>(a.params + eo) = pv; *reinterpret_cast<f32x4*>(a.opt.m + eo) = mv; *reinterpret_cast<f32x4*>(a.opt.v + eo) = vv;
+  if (!pkf) return;
+  *reinterpret_cast<f32x4*>(pkf + packed_fwd_index(n0 + er, k0 + ec, H)) = pv;   // k .. k+3 of row n: one 16-byte lane of PF
+  *reinterpret_cast<f32x4*>(Gs + er * DWS_GLD + ec) = pv;
+  __syncthreads();
+  {  // PB: rows n .. n+3 of column k are one 16-byte lane; thread t takes column t % 32 and row quad t / 32
+    const int kc = tid & 31, rq = tid >> 5;
+    f32x4 w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = Gs[(4 * rq + r) * DWS_GLD + kc];
+    *reinterpret_cast<f32x4*>(pkb + packed_bwd_index(n0 + 4 * rq, k0 + kc, H)) = w;
+  }
+}
+static inline int dw_block32_count(int H, int nets) { return (H / DWS) * (H / DWS) * nets; }
+static inline bool dw_block32_fits(int H, int B) { return H % DWS == 0 && B % DWS_ROWS == 0; }
+
 __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * DWS * DWS_LD];
   IL_TL(a.log_alpha ? 2 : 1, 0);   // [1] critic launch, [2] actor launch (the one with the alpha / polyak tail)
+  if (a.n_big_blocks > 0) {   // [0, n_big_blocks): 32 x 32 blocks of the H x H layers through LDS; then the wave-per-tile jobs of the other layers and the biases; then the tail
+    const int bx = (int)blockIdx.x, H = a.hidden, nbh = H / DWS, per_net = nbh * nbh;
+    if (bx < a.n_big_blocks) {
+      const int net = bx / per_net, blk = bx - net * per_net;
+      const int64_t oW2 = (int64_t)net * a.net_stride + (int64_t)H * a.in_dim + H;
+      dw_block32(a, a.dz2 + net * a.h_net_stride, a.h1 + net * a.h_net_stride, H, (blk / nbh) * DWS, (blk % nbh) * DWS, oW2,
+                 a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem);
+      IL_TL_END(a.log_alpha ? 2 : 1);
+      return;
+    }
+    DwArgs r = a;
+    r.n_dw_blocks = a.n_dw_blocks - a.n_big_blocks;
+    dw_adam_body<IL_DW_U, true>(r, bx - a.n_big_blocks, (int)gridDim.x - a.n_big_blocks);
+    IL_TL_END(a.log_alpha ? 2 : 1);
+    return;
+  }
   dw_adam_body<IL_DW_U>(a, (int)blockIdx.x, (int)gridDim.x);
   IL_TL_END(a.log_alpha ? 2 : 1);
 }
@@ -1269,6 +1375,14 @@ extern "C" int64_t il_mlp_stride(int32_t in_dim, int32_t hidden, int32_t out_dim
 extern "C" int64_t il_sac_workspace_floats(int32_t S, int32_t A, int32_t H, int32_t B) { return sac_ws(S, A, H, B).total; }
 
 __host__ __device__ static inline int dw_blocks(int IN, int H, int OUT, int nets, int skip_big);
+__host__ __device__ static inline bool dw_block32_on() {   // host: IL_DW_BLOCK32=0|1 overrides the build's default (developer A/B switch; same bits either way)
+#ifdef __HIP_DEVICE_COMPILE__
+  return IL_DW_BLOCK32 != 0;   // (device-side callers - the population launch - lay out their own grid and ignore n_big_blocks)
+#else
+  static const int on = [] { const char* e = getenv("IL_DW_BLOCK32"); return e ? (e[0] != '0' ? 1 : 0) : (IL_DW_BLOCK32 != 0 ? 1 : 0); }();
+  return on != 0;
+#endif
+}
 __host__ __device__ static DwArgs critic_dw_args(const il_sac* d, uint32_t flags) {
   const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, IN = S + A;
   const SacWs ws = sac_ws(S, A, H, B);
@@ -1279,7 +1393,8 @@ __host__ __device__ static DwArgs critic_dw_args(const il_sac* d, uint32_t flags
   a.h1 = d->workspace + ws.c_h1; a.h2 = d->workspace + ws.c_h2; a.dz1 = d->workspace + ws.c_dz1; a.dz2 = d->workspace + ws.c_dz2; a.h_net_stride = (int64_t)B * H;
   a.dz3 = d->workspace + ws.c_dz3; a.dz3_net_stride = B;
   a.pk_f = d->workspace + ws.pk_cf; a.pk_b = d->workspace + ws.pk_cb;
-  a.n_dw_blocks = dw_blocks(IN, H, 1, 2);
+  a.n_big_blocks = (dw_block32_on() && H % 32 == 0 && B % 128 == 0) ? (H / 32) * (H / 32) * 2 : 0;   // dw_block32 (defined below: DWS = 32, DWS_ROWS = 128)
+  a.n_dw_blocks = a.n_big_blocks + dw_blocks(IN, H, 1, 2, a.n_big_blocks > 0);
   return a;
 }
 
@@ -1319,7 +1434,8 @@ __host__ __device__ static DwArgs actor_dw_args(const il_sac* d, const il_batch*
   a.h1 = d->workspace + ws.a_h1; a.h2 = d->workspace + ws.a_h2; a.dz1 = d->workspace + ws.a_dz1; a.dz2 = d->workspace + ws.a_dz2; a.h_net_stride = 0;
   a.dz3 = d->workspace + ws.a_dz3; a.dz3_net_stride = 0;
   a.pk_f = d->workspace + ws.pk_af; a.pk_b = d->workspace + ws.pk_ab;
-  a.n_dw_blocks = dw_blocks(S, H, 2 * A, 1);
+  a.n_big_blocks = (dw_block32_on() && H % 32 == 0 && B % 128 == 0) ? (H / 32) * (H / 32) : 0;
+  a.n_dw_blocks = a.n_big_blocks + dw_blocks(S, H, 2 * A, 1, a.n_big_blocks > 0);
   a.log_alpha = d->log_alpha; a.alpha_grad = d->alpha_grad; a.alpha_opt = d->alpha_opt; a.alpha_part = d->workspace + ws.alpha_part; a.n_alpha_part = B / IL_TILE_R;
   a.target = d->target; a.polyak_src = d->critic; a.polyak_n = 2 * net_stride(S + A, H, 1); a.tau = d->polyak; a.noise_counter = d->noise_counter; a.sync = d->sync;
   a.pk_target = d->workspace + ws.pk_tf; a.pk_critic = d->workspace + ws.pk_cf; a.pk_n = 2 * (int64_t)H * H;   // the FORWARD-order copies of both target critics only: targets are never back-propagated, so their PB copies (pk_tb) have no reader (round 2: 1.5 MB of polyak traffic per update removed)
@@ -1475,11 +1591,12 @@ __global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ 
       IL_TL_END(kind ? 11 : 10);
       return;
     }
-    a.n_dw_blocks = dw_blocks(a.in_dim, a.hidden, a.out_dim, a.n_nets, 1);
+    a.n_dw_blocks = dw_blocks(a.in_dim, a.hidden, a.out_dim, a.n_nets, 1); a.n_big_blocks = 0;
     dw_adam_body<4, true>(a, bx - nb64, (int)gridDim.x - nb64);
     IL_TL_END(kind ? 11 : 10);
     return;
   }
+  a.n_dw_blocks = dw_blocks(a.in_dim, a.hidden, a.out_dim, a.n_nets, 0); a.n_big_blocks = 0;
   dw_adam_body<4>(a, bx, (int)gridDim.x);
 }
 

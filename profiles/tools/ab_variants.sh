@@ -6,8 +6,8 @@ ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 cd "$ROOT"
 for i in $(seq $N); do
   for v in "$@"; do
-    unset IL_DW_INLINE
-    if [ "$v" = default ]; then unset IL_HIP_LIBRARY; elif [ "$v" = noinline ]; then unset IL_HIP_LIBRARY; export IL_DW_INLINE=0; else export IL_HIP_LIBRARY="$ROOT/variants/$v/libil_hip.so"; fi
+    unset IL_DW_BLOCK32
+    if [ "$v" = default ]; then unset IL_HIP_LIBRARY; elif [ "$v" = noblock32 ]; then unset IL_HIP_LIBRARY; export IL_DW_BLOCK32=0; else export IL_HIP_LIBRARY="$ROOT/variants/$v/libil_hip.so"; fi
     python bench.py --steps 3000 --warmup 300 --no-cpu-baseline --no-population --no-secondary --trace-steps 50 2>/dev/null | python -c "
 import sys, json
 j = json.loads(sys.stdin.read().strip().splitlines()[-1])
