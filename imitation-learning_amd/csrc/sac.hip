@@ -861,6 +861,7 @@ struct DwArgs {
   const float* dz3; int64_t dz3_net_stride;                                // [out][B]
   float* pk_f; float* pk_b;                                                 // lane-ordered copies of W2 kept in step with the AdamW update (NULL: none)
   int n_dw_blocks;
+  int jobs_per_block;   // wave-per-tile jobs per 256-thread workgroup (0 = 4): with 32 KB of half-line operand gathers per job, four jobs on one CU take 3.8 us of texture-address time - the single learner has CUs to spare and runs two
   int n_big_blocks;   // single learner: leading workgroups that each own a 32 x 32 block of an H x H layer's dW (dw_block32); 0 = wave-per-tile jobs for every layer
   // tail
   float* log_alpha; float* alpha_grad; il_adam alpha_opt; const float* alpha_part; int n_alpha_part;
@@ -883,6 +884,9 @@ __device__ __forceinline__ void adam_store(const DwArgs& a, const adam_consts& a
 #endif
 #ifndef IL_TAIL_BLOCKS
 #define IL_TAIL_BLOCKS 69       // single learner: tail blocks of the actor launch (block 0: Adam(log alpha) + counters; all: polyak over the target arena and its lane-ordered copies, one trip each at H = 256)
+#endif
+#ifndef IL_DW_SMALL_JOBS_PER_BLOCK
+#define IL_DW_SMALL_JOBS_PER_BLOCK 2   // single learner with dw_block32: wave-per-tile jobs (first / last layer, biases) per workgroup
 #endif
 #ifndef IL_DW_BLOCK32
 #define IL_DW_BLOCK32 1         // single learner: the H x H layers' dW as 32 x 32 blocks staged through LDS (dw_block32); 0 = a wave per 16 x 16 tile straight from global memory
@@ -1086,11 +1090,13 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
     return;
   }
   // ---- job decode (wave-uniform)
+  const int jpb = a.jobs_per_block > 0 ? a.jobs_per_block : 4;
+  if (wave_in_block >= jpb) return;
   const int IN = a.in_dim, H = a.hidden, OUT = a.out_dim;
   const int nt_h = H / 16, kt_in = (IN + 15) / 16, nt_out = (OUT + 15) / 16;
   const int j1 = nt_h * kt_in, j2 = SKIPBIG ? 0 : nt_h * nt_h, j3 = nt_out * nt_h, jb = 2 * nt_h + nt_out;
   const int per_net = j1 + j2 + j3 + jb;
-  int job = bid * 4 + wave_in_block;
+  int job = bid * jpb + wave_in_block;
   if (job >= per_net * a.n_nets) return;
   const int net = job / per_net; job -= net * per_net;
   adam_consts ac = {};
@@ -1281,6 +1287,7 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
   }
   float* Gs = Zs;   // [32][DWS_GLD] gradient block, then the updated parameters
   __syncthreads();
+  IL_TL(a.log_alpha ? 2 : 1, 1);   // products done
   {
     const f32x4 t = acc0 + acc1;
 #pragma unroll
@@ -1293,6 +1300,7 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
 #pragma unroll
   for (int c = 0; c < 4; ++c) { float pp = pv[c], mm = mv[c], v2 = vv[c]; adam_update(pp, gv[c], mm, v2, ac); pv[c] = pp; mv[c] = mm; vv[c] = v2; }
   *reinterpret_cast<f32x4*>(a.params + eo) = pv; *reinterpret_cast<f32x4*>(a.opt.m + eo) = mv; *reinterpret_cast<f32x4*>(a.opt.v + eo) = vv;
+  IL_TL(a.log_alpha ? 2 : 1, 2);   // AdamW stores issued
   if (!pkf) return;
   *reinterpret_cast<f32x4*>(pkf + packed_fwd_index(n0 + er, k0 + ec, H)) = pv;   // k .. k+3 of row n: one 16-byte lane of PF
   *reinterpret_cast<f32x4*>(Gs + er * DWS_GLD + ec) = pv;
@@ -1332,10 +1340,10 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
 }
 
 static int repack_blocks(int H) { return ceil_div(H * H / 16, 256); }
-__host__ __device__ static inline int dw_blocks(int IN, int H, int OUT, int nets, int skip_big = 0) {
+__host__ __device__ static inline int dw_blocks(int IN, int H, int OUT, int nets, int skip_big = 0, int jobs_per_block = 4) {
   const int nt_h = H / 16, nt_out = (OUT + 15) / 16;
   const int per_net = nt_h * ((IN + 15) / 16) + (skip_big ? 0 : nt_h * nt_h) + nt_out * nt_h + 2 * nt_h + nt_out;
-  return (per_net * nets + 3) / 4;
+  return (per_net * nets + jobs_per_block - 1) / jobs_per_block;
 }
 
 // generic elementwise Adam over a flat arena (data-parallel path and stand-alone use)
@@ -1374,7 +1382,6 @@ extern "C" int64_t il_mlp_numel(int32_t in_dim, int32_t hidden, int32_t out_dim)
 extern "C" int64_t il_mlp_stride(int32_t in_dim, int32_t hidden, int32_t out_dim) { return net_stride(in_dim, hidden, out_dim); }
 extern "C" int64_t il_sac_workspace_floats(int32_t S, int32_t A, int32_t H, int32_t B) { return sac_ws(S, A, H, B).total; }
 
-__host__ __device__ static inline int dw_blocks(int IN, int H, int OUT, int nets, int skip_big);
 __host__ __device__ static inline bool dw_block32_on() {   // host: IL_DW_BLOCK32=0|1 overrides the build's default (developer A/B switch; same bits either way)
 #ifdef __HIP_DEVICE_COMPILE__
   return IL_DW_BLOCK32 != 0;   // (device-side callers - the population launch - lay out their own grid and ignore n_big_blocks)
@@ -1394,7 +1401,8 @@ __host__ __device__ static DwArgs critic_dw_args(const il_sac* d, uint32_t flags
   a.dz3 = d->workspace + ws.c_dz3; a.dz3_net_stride = B;
   a.pk_f = d->workspace + ws.pk_cf; a.pk_b = d->workspace + ws.pk_cb;
   a.n_big_blocks = (dw_block32_on() && H % 32 == 0 && B % 128 == 0) ? (H / 32) * (H / 32) * 2 : 0;   // dw_block32 (defined below: DWS = 32, DWS_ROWS = 128)
-  a.n_dw_blocks = a.n_big_blocks + dw_blocks(IN, H, 1, 2, a.n_big_blocks > 0);
+  a.jobs_per_block = a.n_big_blocks > 0 ? IL_DW_SMALL_JOBS_PER_BLOCK : 4;
+  a.n_dw_blocks = a.n_big_blocks + dw_blocks(IN, H, 1, 2, a.n_big_blocks > 0, a.jobs_per_block);
   return a;
 }
 
@@ -1435,7 +1443,8 @@ __host__ __device__ static DwArgs actor_dw_args(const il_sac* d, const il_batch*
   a.dz3 = d->workspace + ws.a_dz3; a.dz3_net_stride = 0;
   a.pk_f = d->workspace + ws.pk_af; a.pk_b = d->workspace + ws.pk_ab;
   a.n_big_blocks = (dw_block32_on() && H % 32 == 0 && B % 128 == 0) ? (H / 32) * (H / 32) : 0;
-  a.n_dw_blocks = a.n_big_blocks + dw_blocks(S, H, 2 * A, 1, a.n_big_blocks > 0);
+  a.jobs_per_block = a.n_big_blocks > 0 ? IL_DW_SMALL_JOBS_PER_BLOCK : 4;
+  a.n_dw_blocks = a.n_big_blocks + dw_blocks(S, H, 2 * A, 1, a.n_big_blocks > 0, a.jobs_per_block);
   a.log_alpha = d->log_alpha; a.alpha_grad = d->alpha_grad; a.alpha_opt = d->alpha_opt; a.alpha_part = d->workspace + ws.alpha_part; a.n_alpha_part = B / IL_TILE_R;
   a.target = d->target; a.polyak_src = d->critic; a.polyak_n = 2 * net_stride(S + A, H, 1); a.tau = d->polyak; a.noise_counter = d->noise_counter; a.sync = d->sync;
   a.pk_target = d->workspace + ws.pk_tf; a.pk_critic = d->workspace + ws.pk_cf; a.pk_n = 2 * (int64_t)H * H;   // the FORWARD-order copies of both target critics only: targets are never back-propagated, so their PB copies (pk_tb) have no reader (round 2: 1.5 MB of polyak traffic per update removed)
@@ -1591,12 +1600,12 @@ __global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ 
       IL_TL_END(kind ? 11 : 10);
       return;
     }
-    a.n_dw_blocks = dw_blocks(a.in_dim, a.hidden, a.out_dim, a.n_nets, 1); a.n_big_blocks = 0;
+    a.n_dw_blocks = dw_blocks(a.in_dim, a.hidden, a.out_dim, a.n_nets, 1); a.n_big_blocks = 0; a.jobs_per_block = 4;
     dw_adam_body<4, true>(a, bx - nb64, (int)gridDim.x - nb64);
     IL_TL_END(kind ? 11 : 10);
     return;
   }
-  a.n_dw_blocks = dw_blocks(a.in_dim, a.hidden, a.out_dim, a.n_nets, 0); a.n_big_blocks = 0;
+  a.n_dw_blocks = dw_blocks(a.in_dim, a.hidden, a.out_dim, a.n_nets, 0); a.n_big_blocks = 0; a.jobs_per_block = 4;
   dw_adam_body<4>(a, bx, (int)gridDim.x);
 }
 
