@@ -19,7 +19,7 @@
 
 
 struct SacWs {  // float offsets into il_sac.workspace
-  int64_t a_h1, a_h2, a_xpre, a_eps, a_lsraw, a_anew, a_logp, n_a2, n_logp2;
+  int64_t a_h1, a_h2, a_xpre, a_eps, a_lsraw, a_anew, a_logp, n_a2, n_logp2, a_x0;
   int64_t c_x0, c_h1, c_h2, c_q, t_q, c_dz3, c_dz2, c_dz1;
   int64_t p_q, p_g, a_dz3, a_dz2, a_dz1, alpha_part, pair_ctr, chain_ctr;
   int64_t pk_af, pk_ab, pk_cf, pk_cb, pk_tf, pk_tb;  // lane-ordered copies of the H x H layers (mlp_tile.hpp "Packed hidden-layer weights")
@@ -30,7 +30,7 @@ __host__ __device__ inline SacWs sac_ws(int S, int A, int H, int B) {
   auto take = [&](int64_t n) { int64_t r = o; o += (n + 3) & ~(int64_t)3; return r; };
   const int64_t BH = (int64_t)B * H, BA = (int64_t)B * A;
   w.a_h1 = take(BH); w.a_h2 = take(BH); w.a_xpre = take(BA); w.a_eps = take(BA); w.a_lsraw = take(BA); w.a_anew = take(BA); w.a_logp = take(B);
-  w.n_a2 = take(BA); w.n_logp2 = take(B);
+  w.n_a2 = take(BA); w.n_logp2 = take(B); w.a_x0 = take((int64_t)B * S);   // a_x0: s^T [S][B] of the sampled rows (written by the actor(s) tiles; the actor's layer-1 dW reads it like every other [feature][B] operand)
   w.c_x0 = take((int64_t)B * (S + A)); w.c_h1 = take(2 * BH); w.c_h2 = take(2 * BH); w.c_q = take(2 * B); w.t_q = take(2 * B);
   w.c_dz3 = take(2 * B); w.c_dz2 = take(2 * BH); w.c_dz1 = take(2 * BH);
   w.p_q = take(2 * B); w.p_g = take(2 * BA); w.a_dz3 = take((int64_t)B * 16); w.a_dz2 = take(BH); w.a_dz1 = take(BH); w.alpha_part = take(B / IL_TILE_R + 4); w.pair_ctr = take((int64_t)(B / IL_TILE_R) * IL_CTR_STRIDE + 4); w.chain_ctr = take((int64_t)(B / IL_TILE_R) * IL_CTR_STRIDE + 4);
@@ -134,6 +134,8 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
   load_rows_cat(Xs, ldx, Sp, src, ld, S, nullptr, 0, 0, row0, IL_TILE_R, b.gather, b.gather_capacity);
   __syncthreads();
   IL_TL(is_cur ? 6 : 5, 1);
+  if (is_cur)
+    for (int i = tid; i < IL_TILE_R * S; i += blockDim.x) { const int c = i >> 4, r = i & 15; W[ws.a_x0 + (size_t)c * B + row0 + r] = Xs[r * ldx + c]; }   // x0^T [S][B]
   tile_fwd<PANEL>(Xs, ldx, Sp, net.W1, S, S, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1 : net.b1[col];
     f32x4 hv;
@@ -1244,8 +1246,14 @@ static inline int dw_block64_count(int H, int nets) { return (H / DWB) * (H / DW
 #define DWS_ROWS 128
 #define DWS_LD (DWS_ROWS + 4)
 #define DWS_GLD (DWS + 4)
-__device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restrict__ dzT, const float* __restrict__ xT, int H, int n0, int k0, int64_t poff,
-                                           float* __restrict__ pkf, float* __restrict__ pkb, float* smem) {
+// General form (round 3, second step): ANY layer's dW - dZ [Nvalid][B] x X [Kvalid][B], both feature-major - as 32 x 32 blocks, partial blocks included (features past
+// the matrix clamp their address; their rows / columns are masked in the epilogue), and the layer's BIAS gradient folded into the blocks of the first k-column: the dZ
+// panel is in LDS anyway, 128 threads sum it with dw_bias's exact order (lane (f, g): rows 16 i + 4 g .. + 3 for ascending i as one 4-vector, (s0 + s1) + (s2 + s3),
+// then the four g as (g0 + g1) + (g2 + g3)), so the bias keeps its bits too. With it a network's whole optimiser step is nbh^2 + 2 nbh uniform workgroups (H = 256: 80)
+// and no wave-per-tile job is left: those were 72 % of the launch's line requests (32 KB of half-line gathers each).
+// `boff` >= 0: parameter offset of the bias of this dZ (only looked at by blocks with k0 == 0).
+__device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restrict__ dzT, int Nvalid, const float* __restrict__ xT, int Kvalid, int n0, int k0, int64_t poff,
+                                           int64_t boff, float* __restrict__ pkf, float* __restrict__ pkb, float* smem) {
   float* Zs = smem; float* Xs = smem + DWS * DWS_LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int ti = wave >> 1, tq = wave & 1;   // this wave's tile of the block
@@ -1254,9 +1262,20 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
   const int sf = tid >> 5, sr = (tid & 31) * 4;
   // epilogue map: thread t owns the 16-byte lane (row t / 8, columns 4 (t % 8) .. +3) of the block
   const int er = tid >> 3, ec = (tid & 7) * 4;
-  const int64_t eo = poff + (int64_t)(n0 + er) * H + k0 + ec;
+  const int en = n0 + er, ek = k0 + ec;
+  const bool full = n0 + DWS <= Nvalid && k0 + DWS <= Kvalid && (Kvalid & 3) == 0 && (poff & 3) == 0;   // whole block inside the matrix, rows 16-byte aligned: 16-byte lanes
+  const int64_t eo = poff + (int64_t)min(en, Nvalid - 1) * Kvalid + min(ek, Kvalid - 1);
   f32x4 pv = zero4(), mv = zero4(), vv = zero4();
-  if (!a.grads_only) { pv = gload4(a.params + eo); mv = gload4(a.opt.m + eo); vv = gload4(a.opt.v + eo); }   // HBM (last touched an update ago): under everything that follows
+  if (!a.grads_only) {   // HBM (last touched an update ago): requested before anything else
+    if (full) { pv = gload4(a.params + eo); mv = gload4(a.opt.m + eo); vv = gload4(a.opt.v + eo); }
+    else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { const int64_t o = poff + (int64_t)min(en, Nvalid - 1) * Kvalid + min(ek + c, Kvalid - 1); pv[c] = gload(a.params + o); mv[c] = gload(a.opt.m + o); vv[c] = gload(a.opt.v + o); }
+    }
+  }
+  const bool do_bias = boff >= 0 && k0 == 0;
+  const int bf = tid >> 2, bg = tid & 3;   // bias: threads 0..127 = (feature, row group of 4)
+  f32x4 bs4 = zero4();
   f32x4 acc0 = zero4(), acc1 = zero4();
   for (int r0 = 0; r0 < B; r0 += 2 * DWS_ROWS) {   // two chunks per trip, all their loads in flight together (B = 256: one trip)
     f32x4 zr[2][4], xr[2][4];
@@ -1265,7 +1284,7 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int rr = min(r0 + c * DWS_ROWS, B - DWS_ROWS) + sr;   // (B % 256 == 128: the second chunk of the last trip re-reads the first and is not used)
-        zr[c][u] = gload4(dzT + (size_t)(n0 + sf + 8 * u) * B + rr); xr[c][u] = gload4(xT + (size_t)(k0 + sf + 8 * u) * B + rr);
+        zr[c][u] = gload4(dzT + (size_t)min(n0 + sf + 8 * u, Nvalid - 1) * B + rr); xr[c][u] = gload4(xT + (size_t)min(k0 + sf + 8 * u, Kvalid - 1) * B + rr);
       }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1283,6 +1302,10 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
         acc0 = mfma16(av[2], bv[2], acc0);
         acc1 = mfma16(av[3], bv[3], acc1);
       }
+      if (do_bias && tid < 128) {
+#pragma unroll
+        for (int u = 0; u < DWS_ROWS / 16; ++u) bs4 += *reinterpret_cast<const f32x4*>(Zs + bf * DWS_LD + 16 * u + 4 * bg);
+      }
     }
   }
   float* Gs = Zs;   // [32][DWS_GLD] gradient block, then the updated parameters
@@ -1293,16 +1316,37 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
 #pragma unroll
     for (int r = 0; r < 4; ++r) Gs[(16 * ti + 4 * g + r) * DWS_GLD + 16 * tq + j] = t[r];
   }
+  adam_consts ac = {};
+  if (!a.grads_only) ac = load_adam_consts(a.opt);
+  if (do_bias && tid < 128) {   // (all 64 lanes of waves 0, 1 take part in the shuffles)
+    float bsum = (bs4[0] + bs4[1]) + (bs4[2] + bs4[3]);
+    bsum += __shfl_xor(bsum, 1, 64);
+    bsum += __shfl_xor(bsum, 2, 64);
+    if (bg == 0 && n0 + bf < Nvalid) adam_store(a, ac, boff + n0 + bf, bsum);
+  }
   __syncthreads();
   const f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + er * DWS_GLD + ec);
+  if (!full) {   // partial block (first / last layer): element-wise with guards
+    if (en < Nvalid) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (ek + c >= Kvalid) continue;
+        const int64_t o = poff + (int64_t)en * Kvalid + ek + c;
+        if (a.grads_only) { a.grads[o] = gv[c]; continue; }
+        float pp = pv[c], mm = mv[c], v2 = vv[c];
+        adam_update(pp, gv[c], mm, v2, ac);
+        a.params[o] = pp; a.opt.m[o] = mm; a.opt.v[o] = v2;
+      }
+    }
+    return;
+  }
   if (a.grads_only) { *reinterpret_cast<f32x4*>(a.grads + eo) = gv; return; }
-  const adam_consts ac = load_adam_consts(a.opt);
 #pragma unroll
   for (int c = 0; c < 4; ++c) { float pp = pv[c], mm = mv[c], v2 = vv[c]; adam_update(pp, gv[c], mm, v2, ac); pv[c] = pp; mv[c] = mm; vv[c] = v2; }
   *reinterpret_cast<f32x4*>(a.params + eo) = pv; *reinterpret_cast<f32x4*>(a.opt.m + eo) = mv; *reinterpret_cast<f32x4*>(a.opt.v + eo) = vv;
   IL_TL(a.log_alpha ? 2 : 1, 2);   // AdamW stores issued
   if (!pkf) return;
-  *reinterpret_cast<f32x4*>(pkf + packed_fwd_index(n0 + er, k0 + ec, H)) = pv;   // k .. k+3 of row n: one 16-byte lane of PF
+  *reinterpret_cast<f32x4*>(pkf + packed_fwd_index(en, ek, Kvalid)) = pv;   // k .. k+3 of row n: one 16-byte lane of PF
   *reinterpret_cast<f32x4*>(Gs + er * DWS_GLD + ec) = pv;
   __syncthreads();
   {  // PB: rows n .. n+3 of column k are one 16-byte lane; thread t takes column t % 32 and row quad t / 32
@@ -1310,8 +1354,26 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
     f32x4 w;
 #pragma unroll
     for (int r = 0; r < 4; ++r) w[r] = Gs[(4 * rq + r) * DWS_GLD + kc];
-    *reinterpret_cast<f32x4*>(pkb + packed_bwd_index(n0 + 4 * rq, k0 + kc, H)) = w;
+    *reinterpret_cast<f32x4*>(pkb + packed_bwd_index(n0 + 4 * rq, k0 + kc, Kvalid)) = w;
   }
+}
+// One network's optimiser step as uniform block jobs: [0, nbh^2) the H x H layer (bias 2 with the k0 = 0 blocks), then nbh x kin blocks of layer 1 (bias 1), then
+// nout x nbh blocks of layer 3 (bias 3). Returns false when `job` is past the network's list.
+__host__ __device__ static inline int dw_block_jobs(int IN, int H, int OUT) { const int nbh = H / DWS; return nbh * nbh + nbh * ((IN + DWS - 1) / DWS) + ((OUT + DWS - 1) / DWS) * nbh; }
+__device__ __forceinline__ void dw_block_job(const DwArgs& a, int net, int job, float* smem) {
+  const int IN = a.in_dim, H = a.hidden, OUT = a.out_dim, nbh = H / DWS, kin = (IN + DWS - 1) / DWS;
+  const int64_t pbase = (int64_t)net * a.net_stride;
+  const int64_t oW1 = pbase, ob1 = oW1 + (int64_t)H * IN, oW2 = ob1 + H, ob2 = oW2 + (int64_t)H * H, oW3 = ob2 + H, ob3 = oW3 + (int64_t)OUT * H;
+  const float* h1 = a.h1 + net * a.h_net_stride; const float* h2 = a.h2 + net * a.h_net_stride;
+  const float* dz1 = a.dz1 + net * a.h_net_stride; const float* dz2 = a.dz2 + net * a.h_net_stride;
+  if (job < nbh * nbh) {
+    dw_block32(a, dz2, H, h1, H, (job / nbh) * DWS, (job % nbh) * DWS, oW2, ob2, a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem);
+    return;
+  }
+  job -= nbh * nbh;
+  if (job < nbh * kin) { dw_block32(a, dz1, H, a.x0 + net * a.x0_net_stride, IN, (job / kin) * DWS, (job % kin) * DWS, oW1, ob1, nullptr, nullptr, smem); return; }
+  job -= nbh * kin;
+  dw_block32(a, a.dz3 + net * a.dz3_net_stride, OUT, h2, H, (job / nbh) * DWS, (job % nbh) * DWS, oW3, ob3, nullptr, nullptr, smem);
 }
 static inline int dw_block32_count(int H, int nets) { return (H / DWS) * (H / DWS) * nets; }
 static inline bool dw_block32_fits(int H, int B) { return H % DWS == 0 && B % DWS_ROWS == 0; }
@@ -1319,18 +1381,16 @@ static inline bool dw_block32_fits(int H, int B) { return H % DWS == 0 && B % DW
 __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[2 * DWS * DWS_LD];
   IL_TL(a.log_alpha ? 2 : 1, 0);   // [1] critic launch, [2] actor launch (the one with the alpha / polyak tail)
-  if (a.n_big_blocks > 0) {   // [0, n_big_blocks): 32 x 32 blocks of the H x H layers through LDS; then the wave-per-tile jobs of the other layers and the biases; then the tail
-    const int bx = (int)blockIdx.x, H = a.hidden, nbh = H / DWS, per_net = nbh * nbh;
+  if (a.n_big_blocks > 0) {   // [0, n_big_blocks): every layer's dW + bias as 32 x 32 block jobs through LDS (x0 must be feature-major); then the tail blocks
+    const int bx = (int)blockIdx.x;
     if (bx < a.n_big_blocks) {
-      const int net = bx / per_net, blk = bx - net * per_net;
-      const int64_t oW2 = (int64_t)net * a.net_stride + (int64_t)H * a.in_dim + H;
-      dw_block32(a, a.dz2 + net * a.h_net_stride, a.h1 + net * a.h_net_stride, H, (blk / nbh) * DWS, (blk % nbh) * DWS, oW2,
-                 a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem);
+      const int per_net = dw_block_jobs(a.in_dim, a.hidden, a.out_dim);
+      dw_block_job(a, bx / per_net, bx % per_net, smem);
       IL_TL_END(a.log_alpha ? 2 : 1);
       return;
     }
     DwArgs r = a;
-    r.n_dw_blocks = a.n_dw_blocks - a.n_big_blocks;
+    r.n_dw_blocks = 0;   // nothing but the tail is left
     dw_adam_body<IL_DW_U, true>(r, bx - a.n_big_blocks, (int)gridDim.x - a.n_big_blocks);
     IL_TL_END(a.log_alpha ? 2 : 1);
     return;
@@ -1382,6 +1442,7 @@ extern "C" int64_t il_mlp_numel(int32_t in_dim, int32_t hidden, int32_t out_dim)
 extern "C" int64_t il_mlp_stride(int32_t in_dim, int32_t hidden, int32_t out_dim) { return net_stride(in_dim, hidden, out_dim); }
 extern "C" int64_t il_sac_workspace_floats(int32_t S, int32_t A, int32_t H, int32_t B) { return sac_ws(S, A, H, B).total; }
 
+__host__ __device__ static inline int dw_block_jobs_n(int IN, int H, int OUT) { const int nbh = H / 32; return nbh * nbh + nbh * ((IN + 31) / 32) + ((OUT + 31) / 32) * nbh; }   // = dw_block_jobs (DWS = 32)
 __host__ __device__ static inline bool dw_block32_on() {   // host: IL_DW_BLOCK32=0|1 overrides the build's default (developer A/B switch; same bits either way)
 #ifdef __HIP_DEVICE_COMPILE__
   return IL_DW_BLOCK32 != 0;   // (device-side callers - the population launch - lay out their own grid and ignore n_big_blocks)
@@ -1400,9 +1461,9 @@ __host__ __device__ static DwArgs critic_dw_args(const il_sac* d, uint32_t flags
   a.h1 = d->workspace + ws.c_h1; a.h2 = d->workspace + ws.c_h2; a.dz1 = d->workspace + ws.c_dz1; a.dz2 = d->workspace + ws.c_dz2; a.h_net_stride = (int64_t)B * H;
   a.dz3 = d->workspace + ws.c_dz3; a.dz3_net_stride = B;
   a.pk_f = d->workspace + ws.pk_cf; a.pk_b = d->workspace + ws.pk_cb;
-  a.n_big_blocks = (dw_block32_on() && H % 32 == 0 && B % 128 == 0) ? (H / 32) * (H / 32) * 2 : 0;   // dw_block32 (defined below: DWS = 32, DWS_ROWS = 128)
-  a.jobs_per_block = a.n_big_blocks > 0 ? IL_DW_SMALL_JOBS_PER_BLOCK : 4;
-  a.n_dw_blocks = a.n_big_blocks + dw_blocks(IN, H, 1, 2, a.n_big_blocks > 0, a.jobs_per_block);
+  a.n_big_blocks = (dw_block32_on() && H % 32 == 0 && B % 128 == 0) ? 2 * dw_block_jobs_n(IN, H, 1) : 0;   // every layer + the biases as 32 x 32 block jobs (dw_block32)
+  a.jobs_per_block = 4;
+  a.n_dw_blocks = a.n_big_blocks > 0 ? a.n_big_blocks : dw_blocks(IN, H, 1, 2);
   return a;
 }
 
@@ -1438,13 +1499,13 @@ __host__ __device__ static DwArgs actor_dw_args(const il_sac* d, const il_batch*
   DwArgs a = {};
   a.params = d->actor; a.grads = d->actor_grad; a.opt = d->actor_opt; a.grads_only = (flags & IL_FLAG_GRADS_ONLY) ? 1 : 0;
   a.n_nets = 1; a.net_stride = 0; a.in_dim = S; a.hidden = H; a.out_dim = 2 * A; a.batch = B;
-  a.x0 = b->states; a.ld_x0 = b->ld_states; a.x0_transposed = 0; a.x0_net_stride = 0;
+  a.x0 = d->workspace + ws.a_x0; a.ld_x0 = 0; a.x0_transposed = 1; a.x0_net_stride = 0;   // (round 3) s^T from the workspace; `b` keeps the row-major states for callers that build their own arguments
   a.h1 = d->workspace + ws.a_h1; a.h2 = d->workspace + ws.a_h2; a.dz1 = d->workspace + ws.a_dz1; a.dz2 = d->workspace + ws.a_dz2; a.h_net_stride = 0;
   a.dz3 = d->workspace + ws.a_dz3; a.dz3_net_stride = 0;
   a.pk_f = d->workspace + ws.pk_af; a.pk_b = d->workspace + ws.pk_ab;
-  a.n_big_blocks = (dw_block32_on() && H % 32 == 0 && B % 128 == 0) ? (H / 32) * (H / 32) : 0;
-  a.jobs_per_block = a.n_big_blocks > 0 ? IL_DW_SMALL_JOBS_PER_BLOCK : 4;
-  a.n_dw_blocks = a.n_big_blocks + dw_blocks(S, H, 2 * A, 1, a.n_big_blocks > 0, a.jobs_per_block);
+  a.n_big_blocks = (dw_block32_on() && H % 32 == 0 && B % 128 == 0) ? dw_block_jobs_n(S, H, 2 * A) : 0;
+  a.jobs_per_block = 4;
+  a.n_dw_blocks = a.n_big_blocks > 0 ? a.n_big_blocks : dw_blocks(S, H, 2 * A, 1);
   a.log_alpha = d->log_alpha; a.alpha_grad = d->alpha_grad; a.alpha_opt = d->alpha_opt; a.alpha_part = d->workspace + ws.alpha_part; a.n_alpha_part = B / IL_TILE_R;
   a.target = d->target; a.polyak_src = d->critic; a.polyak_n = 2 * net_stride(S + A, H, 1); a.tau = d->polyak; a.noise_counter = d->noise_counter; a.sync = d->sync;
   a.pk_target = d->workspace + ws.pk_tf; a.pk_critic = d->workspace + ws.pk_cf; a.pk_n = 2 * (int64_t)H * H;   // the FORWARD-order copies of both target critics only: targets are never back-propagated, so their PB copies (pk_tb) have no reader (round 2: 1.5 MB of polyak traffic per update removed)
