@@ -1276,6 +1276,9 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
   const bool do_bias = boff >= 0 && k0 == 0;
   const int bf = tid >> 2, bg = tid & 3;   // bias: threads 0..127 = (feature, row group of 4)
   f32x4 bs4 = zero4();
+  const bool bias_owner = do_bias && tid < 128 && bg == 0 && n0 + bf < Nvalid;
+  float bpp = 0.f, bmm = 0.f, bvv = 0.f;
+  if (bias_owner && !a.grads_only) { const int64_t o = boff + n0 + bf; bpp = gload(a.params + o); bmm = gload(a.opt.m + o); bvv = gload(a.opt.v + o); }   // the bias's Adam operands: with the block's, up front
   f32x4 acc0 = zero4(), acc1 = zero4();
   for (int r0 = 0; r0 < B; r0 += 2 * DWS_ROWS) {   // two chunks per trip, all their loads in flight together (B = 256: one trip)
     f32x4 zr[2][4], xr[2][4];
@@ -1322,7 +1325,11 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
     float bsum = (bs4[0] + bs4[1]) + (bs4[2] + bs4[3]);
     bsum += __shfl_xor(bsum, 1, 64);
     bsum += __shfl_xor(bsum, 2, 64);
-    if (bg == 0 && n0 + bf < Nvalid) adam_store(a, ac, boff + n0 + bf, bsum);
+    if (bias_owner) {
+      const int64_t o = boff + n0 + bf;
+      if (a.grads_only) a.grads[o] = bsum;
+      else { adam_update(bpp, bsum, bmm, bvv, ac); a.params[o] = bpp; a.opt.m[o] = bmm; a.opt.v[o] = bvv; }
+    }
   }
   __syncthreads();
   const f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + er * DWS_GLD + ec);
