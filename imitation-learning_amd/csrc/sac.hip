@@ -1642,6 +1642,15 @@ extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const
 // are device arrays of n_learners descriptors (each learner has its own arenas, optimiser state, workspace, noise counter and batch);
 // gridDim.y (z for k_repack) selects the learner. Kernels are latency-bound at B = 256 (16-64 workgroups): a population fills the chip.
 // ---------------------------------------------------------------------------------------------
+#ifndef IL_POP_SMALL_BLOCKS
+#define IL_POP_SMALL_BLOCKS 1
+#endif
+__host__ __device__ static inline bool pop_small_blocks(int H, int B) { return IL_POP_SMALL_BLOCKS && H % DWS == 0 && B % DWS_ROWS == 0; }
+// workgroups per learner of a population dW launch behind its nb64 dw_block64 workgroups (without the tail)
+static inline int pop_dw_small_grid(int IN, int H, int OUT, int nets, int B, bool b64) {
+  if (b64 && pop_small_blocks(H, B)) return (dw_block_jobs(IN, H, OUT) - (H / DWS) * (H / DWS)) * nets + (H / 16 * nets + 3) / 4;
+  return dw_blocks(IN, H, OUT, nets, b64);
+}
 __global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ dL, const il_batch* __restrict__ bL, int kind, uint32_t flags, int nb64) {
   __shared__ __attribute__((aligned(16))) float smem[2 * DWB * DWB_LD];
   int bx = blockIdx.x, by = blockIdx.y;
@@ -1665,6 +1674,28 @@ __global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ 
       const int64_t oW2 = (int64_t)net * a.net_stride + (int64_t)H * a.in_dim + H;
       dw_block64(a, ac, a.dz2 + net * a.h_net_stride, a.h1 + net * a.h_net_stride, H, (blk / nbh) * DWB, (blk % nbh) * DWB, oW2,
                  a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem);
+      IL_TL_END(kind ? 11 : 10);
+      return;
+    }
+    if (pop_small_blocks(a.hidden, a.batch)) {
+      // (round 3) layers 1 and 3 with their biases as 32 x 32 LDS block jobs (dw_block32: whole-line staging instead of the wave-per-tile jobs' half-line gathers, which were
+      // 72 % of this launch's line requests), bias 2 as wave jobs (dw_block64 does not fold it), then the tail. Grid: pop_dw_grid().
+      const int nb32 = H / DWS, small = dw_block_jobs(a.in_dim, H, a.out_dim) - nb32 * nb32, sb = bx - nb64;
+      if (sb < small * a.n_nets) { dw_block_job(a, sb / small, nb32 * nb32 + sb % small, smem); IL_TL_END(kind ? 11 : 10); return; }
+      const int bias_blocks = (H / 16 * a.n_nets + 3) / 4, bb = sb - small * a.n_nets;
+      if (bb < bias_blocks) {
+        const int job = bb * 4 + (int)(threadIdx.x >> 6);
+        if (job < H / 16 * a.n_nets) {
+          const int net = job / (H / 16), jn = job % (H / 16);
+          adam_consts ac = {};
+          if (!a.grads_only) ac = load_adam_consts(a.opt);
+          dw_bias(a, ac, a.dz2 + net * a.h_net_stride, H, jn * 16, (int64_t)net * a.net_stride + (int64_t)H * a.in_dim + H + (int64_t)H * H);
+        }
+        IL_TL_END(kind ? 11 : 10);
+        return;
+      }
+      a.n_dw_blocks = 0; a.n_big_blocks = 0; a.jobs_per_block = 4;   // the tail blocks (actor launch)
+      dw_adam_body<4, true>(a, bb - bias_blocks, (int)gridDim.x - nb64 - small * a.n_nets - bias_blocks);
       IL_TL_END(kind ? 11 : 10);
       return;
     }
@@ -1724,13 +1755,13 @@ extern "C" int il_sac_update_population(const il_sac* descs_dev, const il_batch*
     static const int lds_dw = [] { const char* e = getenv("IL_POP_DW_LDS"); return e && e[0] == '0' ? 0 : 1; }();
     const bool b64 = lds_dw && H % DWB == 0 && B % DWB == 0;   // H x H layers as 64 x 64 blocks staged through LDS (dw_block64); IL_POP_DW_LDS=0: dw_tile for every layer
     const int nbc = b64 ? dw_block64_count(H, 2) : 0, nba = b64 ? dw_block64_count(H, 1) : 0;
-    { IL_TRACE("k_dw_adam_critic", st); k_dw_adam_pop<<<dim3(nbc + dw_blocks(S + A, H, 1, 2, b64), L), 256, 0, st>>>(descs_dev, batches_dev, 0, flags, nbc); }
+    { IL_TRACE("k_dw_adam_critic", st); k_dw_adam_pop<<<dim3(nbc + pop_dw_small_grid(S + A, H, 1, 2, B, b64), L), 256, 0, st>>>(descs_dev, batches_dev, 0, flags, nbc); }
     {
       IL_TRACE("k_policy_critic", st);
       if (pop3) k_policy_critic_pop<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, nullptr, nullptr, descs_dev, batches_dev, 0);
       else k_policy_critic<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, nullptr, nullptr, descs_dev, batches_dev, 0);
     }
-    { IL_TRACE("k_dw_adam_actor", st); k_dw_adam_pop<<<dim3(nba + dw_blocks(S, H, 2 * A, 1, b64) + 33, L), 256, 0, st>>>(descs_dev, batches_dev, 1, flags, nba); }
+    { IL_TRACE("k_dw_adam_actor", st); k_dw_adam_pop<<<dim3(nba + pop_dw_small_grid(S, H, 2 * A, 1, B, b64) + 33, L), 256, 0, st>>>(descs_dev, batches_dev, 1, flags, nba); }
   }
   IL_CHECK_LAUNCH("il_sac_update_population");
   return IL_OK;
