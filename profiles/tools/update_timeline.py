@@ -86,23 +86,20 @@ row('  critics: relabel done', us(cr[:, 4]))
 row('  critics: targets of the tile seen', us(cr[:, 5]))
 row('  critics: done', us(cr[:, 7]))
 row('  row-copy workgroups: done', us(c[6 * nt:6 * nt + 3, 7]))
-def dw_rows(kid, name, n_big, n_small):
+def dw_rows(kid, name, n_blocks):
   m = sac[kid, :, 7] >= t0
   row(f'{name}: launched', us(sac[kid, m, 0]))
   row(f'{name}: done', us(sac[kid, m, 7]))
   idx = np.where(m)[0]
-  for lo, hi, what in ((0, n_big, '32 x 32 LDS blocks of the H x H layers'), (n_big, n_big + n_small, 'wave-per-tile jobs (first / last layer, biases)'), (n_big + n_small, 10 ** 6, 'tail blocks (polyak, alpha)')):
+  for lo, hi, what in ((0, n_blocks, '32 x 32 LDS block jobs (every layer + biases)'), (n_blocks, 10 ** 6, 'tail blocks (polyak, alpha)')):
     sel = idx[(idx >= lo) & (idx < hi)]
     if sel.size:
-      row(f'    {what}: launched', us(sac[kid, sel, 0]))
       if lo == 0 and (sac[kid, sel, 1] >= t0).all():
         row(f'    {what}: products done', us(sac[kid, sel, 1]))
-        row(f'    {what}: AdamW stores issued', us(sac[kid, sel, 2]))
       row(f'    {what}: done', us(sac[kid, sel, 7]))
 H = 256
-big = lambda nets: (H // 32) ** 2 * nets
-small = lambda IN, OUT, nets: ((H // 16) * ((IN + 15) // 16) + ((OUT + 15) // 16) * (H // 16) + 2 * (H // 16) + (OUT + 15) // 16) * nets
-dw_rows(1, 'k_dw_adam (critic)', big(2), (small(bench.S + bench.A, 1, 2) + 3) // 4)
+jobs = lambda IN, OUT: (H // 32) ** 2 + (H // 32) * ((IN + 31) // 32) + ((OUT + 31) // 32) * (H // 32)
+dw_rows(1, 'k_dw_adam (critic)', 2 * jobs(bench.S + bench.A, 1))
 p = sac[3]
 row('k_policy_critic: launched', us(p[:2 * nt + 4 * nt][p[:6 * nt, 0] >= t0, 0]))
 row('  critic workgroups: arrival signalled', us(p[:2 * nt, 7]))
@@ -111,7 +108,7 @@ h = h[h[:, 7] >= t0]
 row('  helpers: own work done, waiting for the critics', us(h[:, 1]))
 row('  helpers: both critics of the tile seen', us(h[:, 2]))
 row('  helpers: done', us(h[:, 7]))
-dw_rows(2, 'k_dw_adam (actor) + tail', big(1), (small(bench.S, 2 * bench.A, 1) + 3) // 4)
+dw_rows(2, 'k_dw_adam (actor) + tail', jobs(bench.S, 2 * bench.A))
 print('phases inside the forward tiles of k_sac_chain and the critic workgroups of k_policy_critic (us since the workgroup entered the phase list; median over workgroups)')
 for kid, name, idx in ((5, "actor(s') tile", np.where(role == 0)[0]), (6, 'actor(s) tile', np.where(role == 3)[0])):
   a = sac[kid][idx]
