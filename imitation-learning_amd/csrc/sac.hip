@@ -890,6 +890,9 @@ __device__ __forceinline__ void adam_store(const DwArgs& a, const adam_consts& a
 #ifndef IL_DW_SMALL_JOBS_PER_BLOCK
 #define IL_DW_SMALL_JOBS_PER_BLOCK 2   // single learner with dw_block32: wave-per-tile jobs (first / last layer, biases) per workgroup
 #endif
+#ifndef IL_DW_XCD_BLOCKS
+#define IL_DW_XCD_BLOCKS 1      // dw_block_job: the H x H layer's 64 blocks dealt to the XCDs as 2 x 4 rectangles (fabric traffic; 0 = row-major job order)
+#endif
 #ifndef IL_DW_BLOCK32
 #define IL_DW_BLOCK32 1         // single learner: the H x H layers' dW as 32 x 32 blocks staged through LDS (dw_block32); 0 = a wave per 16 x 16 tile straight from global memory
 #endif
@@ -1374,7 +1377,15 @@ __device__ __forceinline__ void dw_block_job(const DwArgs& a, int net, int job, 
   const float* h1 = a.h1 + net * a.h_net_stride; const float* h2 = a.h2 + net * a.h_net_stride;
   const float* dz1 = a.dz1 + net * a.h_net_stride; const float* dz2 = a.dz2 + net * a.h_net_stride;
   if (job < nbh * nbh) {
-    dw_block32(a, dz2, H, h1, H, (job / nbh) * DWS, (job % nbh) * DWS, oW2, ob2, a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem);
+    int nb = job / nbh, kb = job % nbh;
+    if (IL_DW_XCD_BLOCKS && nbh == 8) {
+      // Workgroup b runs on XCD b % 8 (and a network's job list starts at a multiple of 8), and every XCD has a private L2: with (n, k) = (job / 8, job % 8) the eight
+      // blocks that share a dZ panel sit on eight different XCDs and every XCD pulls EVERY dZ panel through the fabric. Here XCD x owns the 2 x 4 rectangle of blocks
+      // n in {2 (x / 2), + 1}, k in {4 (x % 2) .. + 3}: 2 + 4 panels per XCD instead of 8 + 1. A re-labelling of the jobs: same tiles, same bits.
+      const int x = job & 7, slot = job >> 3;
+      nb = 2 * (x >> 1) + (slot >> 2); kb = 4 * (x & 1) + (slot & 3);
+    }
+    dw_block32(a, dz2, H, h1, H, nb * DWS, kb * DWS, oW2, ob2, a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem);
     return;
   }
   job -= nbh * nbh;

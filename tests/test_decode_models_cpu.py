@@ -70,3 +70,19 @@ def test_policy_critic_xcd_decode(nt, helpers):
   assert len(crit) == 2 * nt and len(help_) == helpers * nt
   for (tile, part), bx in help_.items():
     assert crit[(0, tile)] < bx and crit[(1, tile)] < bx, 'a helper only waits for lower-numbered workgroups (both critics of its tile)'
+
+
+def test_dw_block_xcd_rectangles():
+  """csrc/sac.hip dw_block_job (IL_DW_XCD_BLOCKS): the 64 blocks of an H = 256 layer's dW re-labelled so that XCD x (= workgroup index % 8; a network's job list starts at a
+  multiple of 8) owns the 2 x 4 rectangle n in {2 (x / 2), + 1}, k in {4 (x % 2) .. + 3}: a bijection, 2 + 4 operand panels per XCD instead of 8 + 1."""
+  seen, panels = set(), {x: (set(), set()) for x in range(8)}
+  for job in range(64):
+    x, slot = job & 7, job >> 3
+    nb, kb = 2 * (x >> 1) + (slot >> 2), 4 * (x & 1) + (slot & 3)
+    seen.add((nb, kb))
+    panels[x][0].add(nb); panels[x][1].add(kb)
+  assert len(seen) == 64 and seen == {(n, k) for n in range(8) for k in range(8)}
+  assert all(len(dz) == 2 and len(xp) == 4 for dz, xp in panels.values())
+  # the job counts the host and the kernel agree on (dw_block_jobs): per network nbh^2 + nbh * ceil(IN / 32) + ceil(OUT / 32) * nbh, a multiple of 8 at H = 256
+  jobs = lambda IN, H, OUT: (H // 32) ** 2 + (H // 32) * ((IN + 31) // 32) + ((OUT + 31) // 32) * (H // 32)
+  assert jobs(24, 256, 1) == 80 and jobs(18, 256, 12) == 80 and jobs(120, 256, 1) % 8 == 0
