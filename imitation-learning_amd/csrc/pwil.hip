@@ -87,7 +87,7 @@ struct __attribute__((aligned(16))) PwCand { float dist; int idx; float w; float
 
 __device__ __forceinline__ void pwil_select_block(const il_pwil& d, const float* __restrict__ state, const float* __restrict__ action, int K, PwCand* __restrict__ cand) {
   __shared__ float z[512];
-  __shared__ float sd[PW_CHUNK];
+  __shared__ __attribute__((aligned(16))) float sd[PW_CHUNK];
   const int tid = threadIdx.x, N = d.n_atoms, D = d.dim, S = d.state_dim;
   for (int k = tid; k < D; k += PW_CHUNK) {
     const float x = k < S ? state[k] : action[k - S];
@@ -96,14 +96,17 @@ __device__ __forceinline__ void pwil_select_block(const il_pwil& d, const float*
   __syncthreads();
   const int i = (int)blockIdx.x * PW_CHUNK + tid;
   float dist = FLT_MAX;
-  if (i < N && d.weights[i] >= 0.f) {
-    const float* a = d.atoms + (size_t)i * D;
+  // (round 3) the atom's weight and its row are requested TOGETHER (the row of a consumed atom is simply not used): as `if (weights[i] >= 0) { load the row }` the kernel
+  // paid two dependent memory round trips per atom
+  const int ic = i < N ? i : N - 1;
+  const float wi = gload(d.weights + ic);
+  {
+    const float* a = d.atoms + (size_t)ic * D;
     float s = 0.f;
     int k = 0;
     if ((D & 3) == 0 && (reinterpret_cast<uintptr_t>(d.atoms) & 15) == 0) {
-      // (round 3) the scalar loop below compiled to load -> wait -> fma once per feature: D dependent round trips to HBM per atom (24 at HalfCheetah dims) were the
-      // whole cost of this kernel. Eight 16-byte lanes of the row are requested first (addresses past the row clamp to its last lane and are not used); the adds
-      // keep their order k = 0, 1, 2, ..., so the distance keeps its bits (and with it the order of the coupling).
+      // the scalar loop below compiled to load -> wait -> fma once per feature: D dependent round trips per atom. Eight 16-byte lanes of the row are requested first
+      // (addresses past the row clamp to its last lane and are not used); the adds keep their order k = 0, 1, 2, ..., so the distance keeps its bits.
       for (; k < D; k += 32) {
         f32x4 v[8];
 #pragma unroll
@@ -118,14 +121,18 @@ __device__ __forceinline__ void pwil_select_block(const il_pwil& d, const float*
       }
     }
     for (; k < D; ++k) { const float df = a[k] - z[k]; s += df * df; }
-    dist = sqrtf(s);
+    if (i < N && wi >= 0.f) dist = sqrtf(s);
   }
   sd[tid] = dist;
   __syncthreads();
   int rank = 0;
-#pragma unroll 8
-  for (int j = 0; j < PW_CHUNK; ++j) { const float o = sd[j]; rank += (o < dist || (o == dist && j < tid)) ? 1 : 0; }
-  if (rank < K) { PwCand c; c.dist = dist; c.idx = dist < FLT_MAX ? i : INT_MAX; c.w = dist < FLT_MAX ? d.weights[i] : 0.f; c.pad = 0.f; cand[(size_t)blockIdx.x * K + rank] = c; }
+#pragma unroll 4
+  for (int j = 0; j < PW_CHUNK; j += 4) {   // 16-byte LDS broadcasts: a quarter of the LDS instructions of the float-by-float loop
+    const f32x4 o = *reinterpret_cast<const f32x4*>(sd + j);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rank += (o[c] < dist || (o[c] == dist && j + c < tid)) ? 1 : 0;
+  }
+  if (rank < K) { PwCand c; c.dist = dist; c.idx = dist < FLT_MAX ? i : INT_MAX; c.w = dist < FLT_MAX ? wi : 0.f; c.pad = 0.f; cand[(size_t)blockIdx.x * K + rank] = c; }
 }
 __global__ __launch_bounds__(PW_CHUNK) void k_pwil_select(il_pwil d, const float* __restrict__ state, const float* __restrict__ action, int K, PwCand* __restrict__ cand) {
   pwil_select_block(d, state, action, K, cand);
