@@ -96,12 +96,10 @@ __device__ __forceinline__ void pwil_select_block(const il_pwil& d, const float*
   __syncthreads();
   const int i = (int)blockIdx.x * PW_CHUNK + tid;
   float dist = FLT_MAX;
-  // (round 3) the atom's weight and its row are requested TOGETHER (the row of a consumed atom is simply not used): as `if (weights[i] >= 0) { load the row }` the kernel
-  // paid two dependent memory round trips per atom
   const int ic = i < N ? i : N - 1;
   const float wi = gload(d.weights + ic);
-  {
-    const float* a = d.atoms + (size_t)ic * D;
+  if (i < N && wi >= 0.f) {   // (the row of a consumed atom is not read: over an episode half of the rows are)
+    const float* a = d.atoms + (size_t)i * D;
     float s = 0.f;
     int k = 0;
     if ((D & 3) == 0 && (reinterpret_cast<uintptr_t>(d.atoms) & 15) == 0) {
@@ -121,17 +119,13 @@ __device__ __forceinline__ void pwil_select_block(const il_pwil& d, const float*
       }
     }
     for (; k < D; ++k) { const float df = a[k] - z[k]; s += df * df; }
-    if (i < N && wi >= 0.f) dist = sqrtf(s);
+    dist = sqrtf(s);
   }
   sd[tid] = dist;
   __syncthreads();
-  int rank = 0;
-#pragma unroll 4
-  for (int j = 0; j < PW_CHUNK; j += 4) {   // 16-byte LDS broadcasts: a quarter of the LDS instructions of the float-by-float loop
-    const f32x4 o = *reinterpret_cast<const f32x4*>(sd + j);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) rank += (o[c] < dist || (o[c] == dist && j + c < tid)) ? 1 : 0;
-  }
+  int rank = 0;   // (measured, round 3: the same count with 16-byte LDS broadcasts - a quarter of the LDS instructions - made the whole step 6.6 us SLOWER: 21.2 -> 27.8 us)
+#pragma unroll 8
+  for (int j = 0; j < PW_CHUNK; ++j) { const float o = sd[j]; rank += (o < dist || (o == dist && j < tid)) ? 1 : 0; }
   if (rank < K) { PwCand c; c.dist = dist; c.idx = dist < FLT_MAX ? i : INT_MAX; c.w = dist < FLT_MAX ? wi : 0.f; c.pad = 0.f; cand[(size_t)blockIdx.x * K + rank] = c; }
 }
 __global__ __launch_bounds__(PW_CHUNK) void k_pwil_select(il_pwil d, const float* __restrict__ state, const float* __restrict__ action, int K, PwCand* __restrict__ cand) {
