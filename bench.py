@@ -7,10 +7,15 @@ One "step" = one execution of the reference's update block (train.py:173-203, al
 N > 1 (torch.distributed.run): one rank per GPU, own replay shard, three RCCL gradient all-reduces per update (weak scaling:
 per-GPU batch 256); value = N x synchronous global steps/s.
 
+N > 1: `python bench.py --gpus N` with no rank environment starts the N ranks itself (torch.distributed.run on 127.0.0.1; fewer than N visible GPUs is an error, never an
+N = 1 line); under torch.distributed.run it joins the ranks it is given. After the timed loop every rank hashes its replica state: `config.replicas_bit_identical`,
+`config.exchange` (peer write-through | peer fences | rccl), `config.exchange_soak`; a peer-window run that expired a wait or left the replicas apart is re-timed on RCCL.
+
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the launch stream; whole-update `hbm_frac` / `fp32_frac` at its top level) and,
-at N=1, `cpu_baseline` = the reference's own CPU path (profiles/cpu_reference.json: timed in the build container by profiles/tools/cpu_reference.py, because
-/root/reference cannot travel to the GPU box) next to `cpu_port` = the numpy oracle port timed live on this box's host cores; `population` = the aggregate rate
-of 32 independent learners advanced by the same launches; `secondary` = the other single-GPU configurations of BASELINE.json.
+at N=1, `cpu_baseline` = the reference's OWN code timed live on this host's cores (oracle/_ref: its three hot-path modules byte-compiled from /root/reference by
+__graft_entry__.build(), run by oracle/ref_cpu_baseline.py in a subprocess at 1 / 8 / all threads, with and without memory.sample; only when oracle/_ref is absent the
+committed build-container measurement profiles/cpu_reference.json stands in, and `where` says so) next to `cpu_port` = the numpy oracle port timed live;
+`population` = the aggregate rate of 64 independent learners advanced by the same launches; `secondary` = the other single-GPU configurations of BASELINE.json.
 """
 import argparse
 import ctypes as C

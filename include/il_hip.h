@@ -447,6 +447,9 @@ typedef struct il_pwil {
   const float *scale, *offset; /* [dim] */
   double reward_scale, reward_bandwidth, agent_weight; /* Python-float hyper-parameters; agent_weight = 1/T - 1e-6 (models.py:235) */
 } il_pwil;
+/* floats of il_pwil.dists: the per-chunk candidate lists of a step (or the N distances of the one-workgroup kernel) + one 16-byte slot at the very end, the arrival
+ * counter of the one-launch step kernel (round 3: every workgroup selects its chunk's candidates, the last to arrive merges). il_pwil_reset zeroes that counter, and the
+ * step kernel leaves it at zero: a caller that allocates the scratch itself must call il_pwil_reset before the first il_pwil_reward (models.py:216-230 does). */
 int64_t il_pwil_scratch_floats(int32_t n_atoms, double agent_weight);
 int il_pwil_reset(const il_pwil* d, il_stream_t stream);
 /* compute_reward for one (state, action); writes the reward (double precision accumulate like the reference's Python floats) to out_reward[0]. */
