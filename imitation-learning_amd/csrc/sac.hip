@@ -854,6 +854,23 @@ IL_TILE_KERNELS(_pop, IL_POP_PANEL, __launch_bounds__(512, IL_POP_WAVES_PER_EU))
 // loads per operand are in flight before the first MFMA. Gradients never touch HBM unless grads_only (data-parallel: they are
 // all-reduced first).  Tail blocks: Adam(log_alpha), polyak, Philox counter.
 // ---------------------------------------------------------------------------------------------
+// How the optimiser epilogues store p / m / v and the lane-ordered copies (IL_DW_STORE_MODE): 0 = plain stores (the lines sit dirty in this XCD's L2 until the
+// end-of-kernel write-back, which is on the critical path of the following launch boundary), 1 = `nt` (streaming) stores, 2 = `sc0 sc1` write-through stores (the data
+// leaves for memory while the kernel still runs; nothing of it is left to flush). m and v are not read again before the next update, p only by other XCDs.
+#ifndef IL_DW_STORE_MODE
+#define IL_DW_STORE_MODE 0
+#endif
+typedef unsigned dw_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dw_store4(float* base, int64_t off, const f32x4& v) {
+#if IL_DW_STORE_MODE == 1
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(base + off));
+#elif IL_DW_STORE_MODE == 2
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7ffffff0, 0x00020000);   // raw buffer over the arena (byte offsets < 2 GiB)
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dw_u32x4, v), rs, (int)(off * 4), 0, 17);       // sc0 | sc1
+#else
+  *reinterpret_cast<f32x4*>(base + off) = v;
+#endif
+}
 struct DwArgs {
   float* params; float* grads; il_adam opt; int grads_only;
   int n_nets; int64_t net_stride;
@@ -1068,7 +1085,13 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
           for (int u = 0; u < 4; ++u) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) t[u][q] = __fadd_rn(__fmul_rn(t[u][q], tau), __fmul_rn(omt, p[u][q]));
-            if (i + u * stride < n1 + n2) *dst[u] = t[u];
+            if (i + u * stride < n1 + n2) {
+#if IL_DW_STORE_MODE >= 1
+              __builtin_nontemporal_store(t[u], dst[u]);   // the target network is not read again before the next update's forward
+#else
+              *dst[u] = t[u];
+#endif
+            }
           }
         }
         return;
@@ -1353,10 +1376,10 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
   if (a.grads_only) { *reinterpret_cast<f32x4*>(a.grads + eo) = gv; return; }
 #pragma unroll
   for (int c = 0; c < 4; ++c) { float pp = pv[c], mm = mv[c], v2 = vv[c]; adam_update(pp, gv[c], mm, v2, ac); pv[c] = pp; mv[c] = mm; vv[c] = v2; }
-  *reinterpret_cast<f32x4*>(a.params + eo) = pv; *reinterpret_cast<f32x4*>(a.opt.m + eo) = mv; *reinterpret_cast<f32x4*>(a.opt.v + eo) = vv;
+  dw_store4(a.params, eo, pv); dw_store4(a.opt.m, eo, mv); dw_store4(a.opt.v, eo, vv);
   IL_TL(a.log_alpha ? 2 : 1, 2);   // AdamW stores issued
   if (!pkf) return;
-  *reinterpret_cast<f32x4*>(pkf + packed_fwd_index(en, ek, Kvalid)) = pv;   // k .. k+3 of row n: one 16-byte lane of PF
+  dw_store4(pkf, (int64_t)packed_fwd_index(en, ek, Kvalid), pv);   // k .. k+3 of row n: one 16-byte lane of PF
   *reinterpret_cast<f32x4*>(Gs + er * DWS_GLD + ec) = pv;
   __syncthreads();
   {  // PB: rows n .. n+3 of column k are one 16-byte lane; thread t takes column t % 32 and row quad t / 32
@@ -1364,7 +1387,7 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
     f32x4 w;
 #pragma unroll
     for (int r = 0; r < 4; ++r) w[r] = Gs[(4 * rq + r) * DWS_GLD + kc];
-    *reinterpret_cast<f32x4*>(pkb + packed_bwd_index(n0 + 4 * rq, k0 + kc, Kvalid)) = w;
+    dw_store4(pkb, (int64_t)packed_bwd_index(n0 + 4 * rq, k0 + kc, Kvalid), w);
   }
 }
 // One network's optimiser step as uniform block jobs: [0, nbh^2) the H x H layer (bias 2 with the k0 = 0 blocks), then nbh x kin blocks of layer 1 (bias 1), then
