@@ -37,6 +37,24 @@ int il_set_error(int code, const char* fmt, ...);
 template <class T>
 __device__ __forceinline__ T gload(const T* p) { return *(const __attribute__((address_space(1))) T*)p; }
 __device__ __forceinline__ f32x4 gload4(const float* p) { return *(const __attribute__((address_space(1))) f32x4*)p; }
+// Write-through stores for data that the NEXT launch reads on other XCDs (activations / dZ in the workspace, the optimiser's p / m / v and lane-ordered copies). A plain
+// store leaves a dirty line in this XCD's L2; the end-of-kernel release writes all of them back, and that write-back sits between this launch and the next one on the
+// update's critical path (round 3: `sc0 sc1` stores in the dW epilogue alone: 14.76k -> 14.97k updates/s; `nt` stores: no change). `base` must be wave-uniform (it
+// becomes the buffer resource), `off` is in floats (< 2^29). IL_WT_STORES=0: plain stores (A/B builds).
+#ifndef IL_WT_STORES
+#define IL_WT_STORES 1
+#endif
+typedef unsigned il_u32x4 __attribute__((ext_vector_type(4)));
+template <bool WT = true>
+__device__ __forceinline__ void wstore4(float* base, int64_t off, const f32x4& v) {
+#if IL_WT_STORES
+  if (!WT) { *reinterpret_cast<f32x4*>(base + off) = v; return; }   // (the 80-VGPR population builds keep plain stores: their chip is oversubscribed, the flush is not exposed)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7ffffff0, 0x00020000);   // raw buffer, byte offsets
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(il_u32x4, v), rs, (int)(off * 4), 0, 17);       // sc0 | sc1
+#else
+  *reinterpret_cast<f32x4*>(base + off) = v;
+#endif
+}
 
 // Whole-descriptor version of the same: a descriptor fetched from memory (population axis: d = dL[blockIdx.y]) carries generic pointers, and
 // ONE pending flat access (a flat_store of an activation slab is enough) makes the compiler turn every later wait into vmcnt(0) lgkmcnt(0).

@@ -141,7 +141,7 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = hv[r]; }
-    if (is_cur) *reinterpret_cast<f32x4*>(W + ws.a_h1 + (size_t)col * B + row0 + 4 * g) = hv;
+    if (is_cur) wstore4<(PANEL >= 16)>(W, ws.a_h1 + (int64_t)col * B + row0 + 4 * g, hv);
   });
   __syncthreads();
   IL_TL(is_cur ? 6 : 5, 2);
@@ -150,7 +150,7 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = hv[r]; }
-    if (is_cur) *reinterpret_cast<f32x4*>(W + ws.a_h2 + (size_t)col * B + row0 + 4 * g) = hv;
+    if (is_cur) wstore4<(PANEL >= 16)>(W, ws.a_h2 + (int64_t)col * B + row0 + 4 * g, hv);
   });
   __syncthreads();
   IL_TL(is_cur ? 6 : 5, 3);
@@ -265,13 +265,12 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
   IL_TL(8, 1);
   if (net == 0)
     for (int i = threadIdx.x; i < IL_TILE_R * IN; i += blockDim.x) { const int c = i >> 4, r = i & 15; W[ws.c_x0 + (size_t)c * B + row0 + r] = Xs[r * ldx + c]; }  // x0^T [IN][B]
-  float* sh1 = W + ws.c_h1 + (size_t)k * B * H; float* sh2 = W + ws.c_h2 + (size_t)k * B * H;
   tile_fwd<PANEL>(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1 : p.b1[col];
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = hv[r]; }
-    if (!is_target) *reinterpret_cast<f32x4*>(sh1 + (size_t)col * B + row0 + 4 * g) = hv;
+    if (!is_target) wstore4<(PANEL >= 16)>(W, ws.c_h1 + (int64_t)k * B * H + (int64_t)col * B + row0 + 4 * g, hv);
   });
   __syncthreads();
   IL_TL(8, 2);
@@ -280,7 +279,7 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = hv[r]; }
-    if (!is_target) *reinterpret_cast<f32x4*>(sh2 + (size_t)col * B + row0 + 4 * g) = hv;
+    if (!is_target) wstore4<(PANEL >= 16)>(W, ws.c_h2 + (int64_t)k * B * H + (int64_t)col * B + row0 + 4 * g, hv);
   });
   __syncthreads();
   IL_TL(8, 3);
@@ -324,7 +323,6 @@ __device__ __forceinline__ void k_critic_bwd_body(il_sac d, il_batch b, const il
   float* W = d.workspace;
   const MlpView p = mlp_view(d.critic + k * net_stride(IN, H, 1), IN, H, 1);
   const float* h2 = W + ws.c_h2 + (size_t)k * B * H; const float* h1 = W + ws.c_h1 + (size_t)k * B * H;
-  float* gdz2 = W + ws.c_dz2 + (size_t)k * B * H; float* gdz1 = W + ws.c_dz1 + (size_t)k * B * H;
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
   // Operands that do not depend on this kernel's own results are requested up front, so their latency overlaps the dQ phase and the
   // MFMA loop instead of following a barrier: this thread's (feature, 4 rows) lane of h2 with its w3, and its epilogue lane of h1.
@@ -357,7 +355,7 @@ __device__ __forceinline__ void k_critic_bwd_body(il_sac d, il_batch b, const il
     f32x4 o;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const float m = hv[q] > 0.f ? w3 : 0.f; DZ2s[(r4 + q) * ldh + n] = m; o[q] = dz3s[r4 + q] * m; }
-    *reinterpret_cast<f32x4*>(gdz2 + (size_t)n * B + row0 + r4) = o;
+    wstore4<(PANEL >= 16)>(W, ws.c_dz2 + (int64_t)k * B * H + (int64_t)n * B + row0 + r4, o);
   }
   __syncthreads();
   // dz1 = dQ * ([h1 > 0] (m . W2)) with m = [h2 > 0] w3: the row factor dQ is applied AFTER the GEMM, so that k_sac_chain can run the GEMM
@@ -368,7 +366,7 @@ __device__ __forceinline__ void k_critic_bwd_body(il_sac d, il_batch b, const il
     f32x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = dz3s[4 * g + r] * (hv[r] > 0.f ? acc[r] : 0.f);
-    *reinterpret_cast<f32x4*>(gdz1 + off) = o;
+    wstore4<(PANEL >= 16)>(W, ws.c_dz1 + (int64_t)k * B * H + (int64_t)off, o);
   });
   IL_TL_END(9);
 }
@@ -439,7 +437,6 @@ __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const
   float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* q16 = H2s + IL_TILE_R * ldh; float* dz3s = q16 + IL_TILE_R;
   const SacWs ws = sac_ws(S, A, H, B);
   float* W = d.workspace;
-  float* gdz2 = W + ws.c_dz2 + (size_t)k * B * H; float* gdz1 = W + ws.c_dz1 + (size_t)k * B * H;
   float* rew16 = dz3s + IL_TILE_R;   // filled by critic_relabel_tile when rl.on
   if (!rl.on && d.sync && !rl.local_rewards) {   // rewards come from the discriminator branch on another stream (see k_critic_bwd); the ring's own rewards (SAC / PWIL plans) need no hand-off
     long long* sy = reinterpret_cast<long long*>(d.sync);
@@ -464,8 +461,8 @@ __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const
     f32x4 o2, o1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { o2[q] = dz3s[r4 + q] * H2s[(r4 + q) * ldh + n]; o1[q] = dz3s[r4 + q] * H1s[(r4 + q) * ldh + n]; }
-    *reinterpret_cast<f32x4*>(gdz2 + (size_t)n * B + row0 + r4) = o2;
-    *reinterpret_cast<f32x4*>(gdz1 + (size_t)n * B + row0 + r4) = o1;
+    wstore4(W, ws.c_dz2 + (int64_t)k * B * H + (int64_t)n * B + row0 + r4, o2);
+    wstore4(W, ws.c_dz1 + (int64_t)k * B * H + (int64_t)n * B + row0 + r4, o1);
   }
 }
 
@@ -667,7 +664,7 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
     f32x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { o[r] = hv[r] > 0.f ? acc[r] : 0.f; DZ2s[(4 * g + r) * ldh + kb + j] = o[r]; }
-    if (part == 0) *reinterpret_cast<f32x4*>(W + ws.a_dz2 + off) = o;
+    if (part == 0) wstore4<(PANEL >= 16)>(W, ws.a_dz2 + (int64_t)off, o);
   });
   __syncthreads();
   IL_STAMP(stamp, 28);
@@ -677,7 +674,7 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
     f32x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = hv[r] > 0.f ? acc[r] : 0.f;
-    *reinterpret_cast<f32x4*>(W + ws.a_dz1 + off) = o;
+    wstore4<(PANEL >= 16)>(W, ws.a_dz1 + (int64_t)off, o);
   }, pt0, pt1);
   IL_STAMP(stamp, 29);
 }
@@ -858,15 +855,14 @@ IL_TILE_KERNELS(_pop, IL_POP_PANEL, __launch_bounds__(512, IL_POP_WAVES_PER_EU))
 // end-of-kernel write-back, which is on the critical path of the following launch boundary), 1 = `nt` (streaming) stores, 2 = `sc0 sc1` write-through stores (the data
 // leaves for memory while the kernel still runs; nothing of it is left to flush). m and v are not read again before the next update, p only by other XCDs.
 #ifndef IL_DW_STORE_MODE
-#define IL_DW_STORE_MODE 0
+#define IL_DW_STORE_MODE 2
 #endif
 typedef unsigned dw_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void dw_store4(float* base, int64_t off, const f32x4& v) {
 #if IL_DW_STORE_MODE == 1
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(base + off));
 #elif IL_DW_STORE_MODE == 2
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7ffffff0, 0x00020000);   // raw buffer over the arena (byte offsets < 2 GiB)
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dw_u32x4, v), rs, (int)(off * 4), 0, 17);       // sc0 | sc1
+  wstore4(base, off, v);
 #else
   *reinterpret_cast<f32x4*>(base + off) = v;
 #endif
