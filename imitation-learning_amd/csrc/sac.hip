@@ -17,6 +17,12 @@
 #include "peer_device.hpp"
 #include "disc_reward.hpp"
 
+// Measured (round 3, same box, three interleaved rounds): write-through stores in the dW / AdamW epilogue ONLY: 14.71k -> 14.90k updates/s; ALSO for the activations and dZ
+// the tile kernels leave in the workspace: 14.59k - the next launch reads those, and a written-through line is not left behind in the L2 for the readers of its own XCD.
+#ifndef IL_WT_TILE_STORES
+#define IL_WT_TILE_STORES 0
+#endif
+
 
 struct SacWs {  // float offsets into il_sac.workspace
   int64_t a_h1, a_h2, a_xpre, a_eps, a_lsraw, a_anew, a_logp, n_a2, n_logp2, a_x0;
@@ -141,7 +147,7 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = hv[r]; }
-    if (is_cur) wstore4<(PANEL >= 16)>(W, ws.a_h1 + (int64_t)col * B + row0 + 4 * g, hv);
+    if (is_cur) wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.a_h1 + (int64_t)col * B + row0 + 4 * g, hv);
   });
   __syncthreads();
   IL_TL(is_cur ? 6 : 5, 2);
@@ -150,7 +156,7 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = hv[r]; }
-    if (is_cur) wstore4<(PANEL >= 16)>(W, ws.a_h2 + (int64_t)col * B + row0 + 4 * g, hv);
+    if (is_cur) wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.a_h2 + (int64_t)col * B + row0 + 4 * g, hv);
   });
   __syncthreads();
   IL_TL(is_cur ? 6 : 5, 3);
@@ -270,7 +276,7 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = hv[r]; }
-    if (!is_target) wstore4<(PANEL >= 16)>(W, ws.c_h1 + (int64_t)k * B * H + (int64_t)col * B + row0 + 4 * g, hv);
+    if (!is_target) wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.c_h1 + (int64_t)k * B * H + (int64_t)col * B + row0 + 4 * g, hv);
   });
   __syncthreads();
   IL_TL(8, 2);
@@ -279,7 +285,7 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = hv[r]; }
-    if (!is_target) wstore4<(PANEL >= 16)>(W, ws.c_h2 + (int64_t)k * B * H + (int64_t)col * B + row0 + 4 * g, hv);
+    if (!is_target) wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.c_h2 + (int64_t)k * B * H + (int64_t)col * B + row0 + 4 * g, hv);
   });
   __syncthreads();
   IL_TL(8, 3);
@@ -355,7 +361,7 @@ __device__ __forceinline__ void k_critic_bwd_body(il_sac d, il_batch b, const il
     f32x4 o;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const float m = hv[q] > 0.f ? w3 : 0.f; DZ2s[(r4 + q) * ldh + n] = m; o[q] = dz3s[r4 + q] * m; }
-    wstore4<(PANEL >= 16)>(W, ws.c_dz2 + (int64_t)k * B * H + (int64_t)n * B + row0 + r4, o);
+    wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.c_dz2 + (int64_t)k * B * H + (int64_t)n * B + row0 + r4, o);
   }
   __syncthreads();
   // dz1 = dQ * ([h1 > 0] (m . W2)) with m = [h2 > 0] w3: the row factor dQ is applied AFTER the GEMM, so that k_sac_chain can run the GEMM
@@ -366,7 +372,7 @@ __device__ __forceinline__ void k_critic_bwd_body(il_sac d, il_batch b, const il
     f32x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = dz3s[4 * g + r] * (hv[r] > 0.f ? acc[r] : 0.f);
-    wstore4<(PANEL >= 16)>(W, ws.c_dz1 + (int64_t)k * B * H + (int64_t)off, o);
+    wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.c_dz1 + (int64_t)k * B * H + (int64_t)off, o);
   });
   IL_TL_END(9);
 }
@@ -461,8 +467,8 @@ __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const
     f32x4 o2, o1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { o2[q] = dz3s[r4 + q] * H2s[(r4 + q) * ldh + n]; o1[q] = dz3s[r4 + q] * H1s[(r4 + q) * ldh + n]; }
-    wstore4(W, ws.c_dz2 + (int64_t)k * B * H + (int64_t)n * B + row0 + r4, o2);
-    wstore4(W, ws.c_dz1 + (int64_t)k * B * H + (int64_t)n * B + row0 + r4, o1);
+    wstore4<(IL_WT_TILE_STORES != 0)>(W, ws.c_dz2 + (int64_t)k * B * H + (int64_t)n * B + row0 + r4, o2);
+    wstore4<(IL_WT_TILE_STORES != 0)>(W, ws.c_dz1 + (int64_t)k * B * H + (int64_t)n * B + row0 + r4, o1);
   }
 }
 
@@ -664,7 +670,7 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
     f32x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { o[r] = hv[r] > 0.f ? acc[r] : 0.f; DZ2s[(4 * g + r) * ldh + kb + j] = o[r]; }
-    if (part == 0) wstore4<(PANEL >= 16)>(W, ws.a_dz2 + (int64_t)off, o);
+    if (part == 0) wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.a_dz2 + (int64_t)off, o);
   });
   __syncthreads();
   IL_STAMP(stamp, 28);
@@ -674,7 +680,7 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
     f32x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = hv[r] > 0.f ? acc[r] : 0.f;
-    wstore4<(PANEL >= 16)>(W, ws.a_dz1 + (int64_t)off, o);
+    wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.a_dz1 + (int64_t)off, o);
   }, pt0, pt1);
   IL_STAMP(stamp, 29);
 }
