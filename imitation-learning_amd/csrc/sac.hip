@@ -860,6 +860,9 @@ IL_TILE_KERNELS(_pop, IL_POP_PANEL, __launch_bounds__(512, IL_POP_WAVES_PER_EU))
 // How the optimiser epilogues store p / m / v and the lane-ordered copies (IL_DW_STORE_MODE): 0 = plain stores (the lines sit dirty in this XCD's L2 until the
 // end-of-kernel write-back, which is on the critical path of the following launch boundary), 1 = `nt` (streaming) stores, 2 = `sc0 sc1` write-through stores (the data
 // leaves for memory while the kernel still runs; nothing of it is left to flush). m and v are not read again before the next update, p only by other XCDs.
+#ifndef IL_POLYAK_WT
+#define IL_POLYAK_WT 1
+#endif
 #ifndef IL_DW_STORE_MODE
 #define IL_DW_STORE_MODE 2
 #endif
@@ -1088,8 +1091,9 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
 #pragma unroll
             for (int q = 0; q < 4; ++q) t[u][q] = __fadd_rn(__fmul_rn(t[u][q], tau), __fmul_rn(omt, p[u][q]));
             if (i + u * stride < n1 + n2) {
-#if IL_DW_STORE_MODE >= 1
-              __builtin_nontemporal_store(t[u], dst[u]);   // the target network is not read again before the next update's forward
+#if IL_DW_STORE_MODE == 2 && IL_POLYAK_WT
+              const int64_t q2 = i + u * stride;   // written through like p / m / v: the target network is not read again before the next update's forward
+              if (q2 >= n1) wstore4(a.pk_target, (q2 - n1) * 4, t[u]); else wstore4(a.target, q2 * 4, t[u]);
 #else
               *dst[u] = t[u];
 #endif
