@@ -20,6 +20,14 @@ for what in "$@"; do
       python profiles/tools/make_pmc_json.py $f $w > $OUT/pmc_latest.json 2> $OUT/pmc_json.err
       python profiles/pmc_summary.py $f $w > $OUT/pmc.md 2>> $OUT/pmc_json.err
       continue ;;
+    pop32pmc)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        rm -rf /tmp/ppmc_$c
+        (cd $ROOT && rocprofv3 --pmc $c -d /tmp/ppmc_$c -o p -- python profiles/tools/secondary_workloads.py population 32 > $OUT/pop32pmc_$c.log 2>&1)
+      done
+      f=$(find /tmp/ppmc_FETCH_SIZE -name "*.db" | head -1); w=$(find /tmp/ppmc_WRITE_SIZE -name "*.db" | head -1)
+      python profiles/tools/make_pmc_json.py $f $w > $OUT/pop32_pmc.json 2> $OUT/pop32_pmc.err
+      continue ;;
     dp) cmd="env IL_FORCE_DP=1 IL_PEER_EXCHANGE=force python bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-population --no-secondary --trace-steps 2" ;;
   esac
   rm -rf /tmp/prof_$what

@@ -128,3 +128,22 @@ def test_peer_window_layout():
       assert got % 256 == 0 and want <= got < want + 256, (world, n, got, want)
   assert L.il_peer_region_bytes(0, 10) == -1 and L.il_peer_region_bytes(17, 10) == -1 and L.il_peer_region_bytes(2, 0) == -1
   assert C.sizeof(_lib.PeerBucket) == 4 + 4 + 8 + 8 + 16 * 8 + 8 + 8 + 4 + 4
+
+
+def test_reference_cpu_baseline_runner_reports_every_configuration():
+  """oracle/ref_cpu_baseline.py (bench.py's cpu_baseline leg) on this host with a small budget: one JSON line with the reference's update rate at 1 thread and at all
+  usable cores, with and without memory.sample, strictly time-boxed; needs oracle/_ref (built from /root/reference when that is present)."""
+  import json, subprocess, sys, time
+  if not os.path.isfile(os.path.join(ROOT, 'oracle', '_ref', 'training.pyc')):
+    if not os.path.isfile('/root/reference/training.py'):
+      pytest.skip('no oracle/_ref and no /root/reference to build it from')
+    subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'build_ref.py')], check=True, capture_output=True)
+  t0 = time.time()
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'ref_cpu_baseline.py'), '--budget', '3'], capture_output=True, text=True, timeout=240, env=dict(os.environ, HIP_VISIBLE_DEVICES=''))
+  assert r.returncode == 0, r.stderr[-800:]
+  j = json.loads(r.stdout.strip().splitlines()[-1])
+  res = j['results']
+  assert {'one_thread_with_memory_sample', 'one_thread_without_memory_sample', 'all_cores_with_memory_sample'} <= set(res)
+  assert res['one_thread_with_memory_sample'] > 1 and res['one_thread_without_memory_sample'] >= res['one_thread_with_memory_sample'] * 0.8
+  assert j['nproc'] >= 1 and j['cpu_model'] and set(j['manifest']['modules']) == {'memory', 'models', 'training'}
+  assert time.time() - t0 < 120, 'the runner must stay inside its time box'
