@@ -909,9 +909,6 @@ __device__ __forceinline__ void adam_store(const DwArgs& a, const adam_consts& a
 #ifndef IL_TAIL_BLOCKS
 #define IL_TAIL_BLOCKS 69       // single learner: tail blocks of the actor launch (block 0: Adam(log alpha) + counters; all: polyak over the target arena and its lane-ordered copies, one trip each at H = 256)
 #endif
-#ifndef IL_DW_SMALL_JOBS_PER_BLOCK
-#define IL_DW_SMALL_JOBS_PER_BLOCK 2   // single learner with dw_block32: wave-per-tile jobs (first / last layer, biases) per workgroup
-#endif
 #ifndef IL_DW_XCD_BLOCKS
 #define IL_DW_XCD_BLOCKS 1      // dw_block_job: the H x H layer's 64 blocks dealt to the XCDs as 2 x 4 rectangles (fabric traffic; 0 = row-major job order)
 #endif
