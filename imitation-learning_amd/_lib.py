@@ -51,7 +51,7 @@ class DiscShaped(C.Structure):
               ('spectral_norm', C.c_int32), ('state_only', C.c_int32), ('reward_function', C.c_int32), ('loss_function', C.c_int32),
               ('params', C.c_void_p), ('ug', C.c_void_p), ('vg', C.c_void_p), ('u1', C.c_void_p), ('v1', C.c_void_p), ('u2', C.c_void_p), ('v2', C.c_void_p), ('grad', C.c_void_p),
               ('opt', Adam), ('grad_penalty', C.c_float), ('entropy_bonus', C.c_float), ('pos_class_prior', C.c_float), ('discount', C.c_float),
-              ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p)]
+              ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p), ('pu_clamped', C.c_int32), ('nonnegative_margin', C.c_float)]
 
 
 class DiscDeep(C.Structure):
@@ -59,7 +59,7 @@ class DiscDeep(C.Structure):
               ('spectral_norm', C.c_int32), ('state_only', C.c_int32), ('reward_function', C.c_int32), ('loss_function', C.c_int32),
               ('depth', C.c_int32), ('activation', C.c_int32), ('params', C.c_void_p), ('sn', C.c_void_p), ('grad', C.c_void_p), ('opt', Adam),
               ('grad_penalty', C.c_float), ('entropy_bonus', C.c_float), ('pos_class_prior', C.c_float), ('reserved', C.c_float),
-              ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p)]
+              ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p), ('pu_clamped', C.c_int32), ('nonnegative_margin', C.c_float)]
 
 
 class GailExtra(C.Structure):

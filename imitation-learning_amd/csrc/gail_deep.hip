@@ -28,12 +28,14 @@ __host__ __device__ inline GdLayout gd_layout(int D, int H, int depth, int sn) {
 __host__ __device__ inline int64_t gd_sn_numel(int D, int H, int depth) { int64_t n = 0; for (int i = 0; i <= depth; ++i) n += (i == depth ? 1 : H) + (i == 0 ? D : H); return n; }
 __host__ __device__ inline int gd_depth(const il_disc_deep& d) { return d.depth == 2 ? 2 : 1; }
 __host__ __device__ inline int gd_calls(const il_disc_deep& d) { return (d.loss_function == IL_LOSS_MIXUP ? 1 : 2) + (d.grad_penalty > 0.f ? 1 : 0); }
-// workspace: slabs [calls][tiles][P + 4] | call context [3][4 sigmas + sn_numel]
-struct GdWs { int64_t slabs, ctx, ctx_stride, slab_stride, total; };
+// workspace: slabs [calls][tiles][P + 4] | call context [3][4 sigmas + sn_numel] | pu [2][tiles]: per-tile sums of w softplus(z) of the policy / expert call
+// (PUGAIL with a finite nonnegative_margin)
+struct GdWs { int64_t slabs, ctx, ctx_stride, slab_stride, pu, total; };
 __host__ __device__ inline GdWs gd_ws(int D, int H, int depth, int B) {
   GdWs w; const int64_t P = gd_layout(D, H, depth, 1).P, nt = (B + GD_R - 1) / GD_R;
   w.slab_stride = (P + 4 + 3) & ~(int64_t)3; w.slabs = 0; w.ctx = 3 * nt * w.slab_stride; w.ctx_stride = (4 + gd_sn_numel(D, H, depth) + 3) & ~(int64_t)3;
-  w.total = w.ctx + 3 * w.ctx_stride;
+  w.pu = w.ctx + 3 * w.ctx_stride;
+  w.total = w.pu + ((2 * nt + 3) & ~(int64_t)3);
   return w;
 }
 extern "C" int64_t il_disc_deep_numel(int32_t D, int32_t H, int32_t depth) { return gd_layout(D, H, depth == 2 ? 2 : 1, 1).P; }
@@ -178,7 +180,7 @@ __device__ __forceinline__ void gd_outer(float* slab, const GdLayout& lay, int i
     }
 }
 
-__global__ __launch_bounds__(256) void k_gd_grad(il_disc_deep d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp, il_gail_extra x) {
+__global__ __launch_bounds__(256) void k_gd_grad(il_disc_deep d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp, il_gail_extra x, int pu_value_pass) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch, depth = gd_depth(d), tanh_ = d.activation == 1;
   const int tile = blockIdx.x, call = blockIdx.y, nt = gridDim.x, row0 = tile * GD_R, tid = threadIdx.x, nthr = blockDim.x;
@@ -189,10 +191,10 @@ __global__ __launch_bounds__(256) void k_gd_grad(il_disc_deep d, il_batch pol, i
   const GdWs ws = gd_ws(D, H, depth, B);
   const GdLds l = gd_carve(smem, D, H, depth);
   float* slab = d.workspace + ws.slabs + ((size_t)call * nt + tile) * ws.slab_stride;
-  if (tile == 0 && call == 0 && tid == 0) adam_tick(d.opt);
+  if (tile == 0 && call == 0 && tid == 0 && !pu_value_pass) adam_tick(d.opt);
   gd_stage(l, d, lay);
   if (d.spectral_norm) gd_spectral(l, lay, call + 1);
-  if (tile == 0) {   // this call's (sigma, u, v) for the reduce kernel
+  if (tile == 0 && !pu_value_pass) {   // this call's (sigma, u, v) for the reduce kernel
     float* c = d.workspace + ws.ctx + (size_t)call * ws.ctx_stride;
     if (tid < 4) c[tid] = tid <= depth ? l.sc[tid] : 1.f;
     int64_t o = 4;
@@ -240,13 +242,27 @@ __global__ __launch_bounds__(256) void k_gd_grad(il_disc_deep d, il_batch pol, i
       const float* off = kind == 0 ? x.logit_offset_policy : (kind == 1 ? x.logit_offset_expert : (kind == 3 ? x.logit_offset_mix : nullptr));
       const float f = l.row[tid], z = off ? f - off[row] : f;
       const bool pu = d.loss_function == IL_LOSS_PUGAIL;
-      const float c_sig = pu ? (kind == 1 ? 2.f * d.pos_class_prior : -1.f) : 1.f;
+      if (pu_value_pass) {   // training.py:100-102 with a finite margin: this launch (policy and expert call, the same power iterations as the real one) only leaves the
+        // per-tile sums of w softplus(z) = w bce(z, 0); the gradient launch reads them all and decides, every workgroup the same way (gail.hip does the same)
+        const float ws_ = tid < nrows ? wt[tid] * softplus_f(z) : 0.f;
+        float part = 0.f;
+        for (int o = 0; o < GD_R; ++o) part += __shfl(ws_, o, GD_R);
+        if (tid == 0) d.workspace[ws.pu + (size_t)kind * nt + tile] = part;
+      }
+      float pu_on = 1.f;   // 1: the clamp passes the gradient (always, with nonnegative_margin = inf)
+      if (pu && d.pu_clamped && !pu_value_pass) {
+        float se = 0.f, sp = 0.f;
+        for (int t = 0; t < nt; ++t) { sp += d.workspace[ws.pu + t]; se += d.workspace[ws.pu + nt + t]; }
+        pu_on = d.pos_class_prior * (se / fB) - sp / fB >= -d.nonnegative_margin ? 1.f : 0.f;   // torch.clamp(min = -margin): gradient where the input is not below the bound
+      }
+      const float c_sig = pu ? (kind == 1 ? (1.f + pu_on) * d.pos_class_prior : -pu_on) : 1.f;
       const float c_lab = kind == 3 ? mix_eps(row) : (kind == 1 ? (pu ? d.pos_class_prior : 1.f) : 0.f);
       const float p = sigmoid_f(z), w = wt[tid];
       float dz = tid < nrows ? w * (c_sig * p - c_lab) / fB : 0.f;
       if (d.entropy_bonus > 0.f && tid < nrows) dz += d.entropy_bonus * w * z * p * (1.f - p) / fB;
       dzr[tid] = dz;
     }
+    if (pu_value_pass) return;   // uniform: every thread of the workgroup leaves here
     __syncthreads();
     const float* AL = l.A[depth - 1];
     for (int j = tid; j < H; j += nthr) {   // output layer
@@ -471,7 +487,11 @@ extern "C" int il_gail_deep_step(const il_disc_deep* d, const il_batch* pol, con
   const size_t lds = gd_lds_floats(D, d->hidden, depth) * sizeof(float);
   if (int rc = gd_ensure_lds((const void*)k_gd_grad, lds)) return rc;
   hipStream_t st = (hipStream_t)stream_;
-  { IL_TRACE("k_gd_grad", st); k_gd_grad<<<dim3(nt, gd_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x); }
+  if (d->loss_function == IL_LOSS_PUGAIL && d->pu_clamped) {   // finite nonnegative_margin: a value pass (logits only) ahead of the gradient pass, which reads the clamp decision
+    IL_CHECK_ARG(d->nonnegative_margin >= 0.f, "il_gail_deep_step: nonnegative_margin must be >= 0");
+    { IL_TRACE("k_gd_grad", st); k_gd_grad<<<dim3(nt, 2), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, 1); }
+  }
+  { IL_TRACE("k_gd_grad", st); k_gd_grad<<<dim3(nt, gd_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, 0); }
   const int64_t P = gd_layout(D, d->hidden, depth, d->spectral_norm).P;
   { IL_TRACE("k_gd_reduce", st); k_gd_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1); }
   IL_CHECK_LAUNCH("il_gail_deep_step");

@@ -22,10 +22,10 @@ __host__ __device__ inline GsLayout gs_layout(int S, int Dg, int H, int sn) {
   return l;
 }
 __host__ __device__ inline int gs_calls(const il_disc_shaped& d) { return 2 + (d.grad_penalty > 0.f ? 1 : 0); }
-struct GsWs { int64_t slabs, sn_new, total; };
+struct GsWs { int64_t slabs, sn_new, pu, total; };   // pu: [2][nt] per-tile sums of w softplus(z) of the policy / expert call (PUGAIL with a finite nonnegative_margin)
 __host__ __device__ inline GsWs gs_ws(int S, int Dg, int H, int B) {
   GsWs w; const int64_t P = gs_layout(S, Dg, H, 1).P, nt = (B + GS_R - 1) / GS_R;
-  w.slabs = 0; w.sn_new = (3 * nt * P + 3) & ~(int64_t)3; w.total = w.sn_new + ((2 + Dg + 2 * H + S + 3) & ~3);
+  w.slabs = 0; w.sn_new = (3 * nt * P + 3) & ~(int64_t)3; w.pu = w.sn_new + ((2 + Dg + 2 * H + S + 3) & ~3); w.total = w.pu + ((2 * nt + 3) & ~(int64_t)3);
   return w;
 }
 extern "C" int64_t il_disc_shaped_numel(int32_t S, int32_t A, int32_t H, int32_t state_only) { return gs_layout(S, state_only ? S : S + A, H, 1).P; }
@@ -180,7 +180,7 @@ __device__ __forceinline__ void gs_forward(const GsLds& l, int S, int Dg, int H,
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_gs_grad(il_disc_shaped d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp, il_gail_extra x) {
+__global__ __launch_bounds__(256) void k_gs_grad(il_disc_shaped d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp, il_gail_extra x, int pu_value_pass) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = d.state_dim, Dg = d.state_only ? S : S + d.action_dim, H = d.hidden, B = d.batch, tid = threadIdx.x;
   const int tile = blockIdx.x, call = blockIdx.y, ncalls = gridDim.y, nt = gridDim.x, row0 = tile * GS_R;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_gs_grad(il_disc_shaped d, il_batch pol,
   const GsWs wsl = gs_ws(S, Dg, H, B);
   const GsLds l = gs_carve(smem, S, Dg, H);
   float* slab = d.workspace + wsl.slabs + ((size_t)call * nt + tile) * lay.P;
-  if (tid == 0 && tile == 0 && call == 0) adam_tick(d.opt);
+  if (tid == 0 && tile == 0 && call == 0 && !pu_value_pass) adam_tick(d.opt);
   gs_stage_params(l, d, lay, S, Dg, H);
   if (d.spectral_norm) gs_spectral(l, S, Dg, H, call + 1, 2 * call + 1);
   const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
@@ -201,17 +201,37 @@ __global__ __launch_bounds__(256) void k_gs_grad(il_disc_shaped d, il_batch pol,
     if (tid < GS_R) {
       const int r = tid, row = row0 + r;
       float dz = 0.f;
+      const bool pu_gate = d.loss_function == IL_LOSS_PUGAIL && d.pu_clamped;
+      if (pu_value_pass) {   // training.py:100-102 with a finite margin: this launch (the same power iterations as the real one) only leaves the per-tile sums of
+        // w softplus(z) = w bce(z, 0) of the policy / expert call; the gradient launch reads them all and decides, every workgroup the same way (gail.hip does the same)
+        float ws_ = 0.f;
+        if (row < B) {
+          const float* off = call == 0 ? x.logit_offset_policy : x.logit_offset_expert;
+          const float f = l.row[2 * GS_R + r];
+          ws_ = l.row[GS_R + r] * softplus_f(off ? f - off[row] : f);
+        }
+        float part = 0.f;
+        for (int o = 0; o < GS_R; ++o) part += __shfl(ws_, o, GS_R);
+        if (tid == 0) d.workspace[wsl.pu + (size_t)call * nt + tile] = part;
+      }
+      float pu_on = 1.f;   // 1: the clamp passes the gradient (always, with nonnegative_margin = inf)
+      if (pu_gate && !pu_value_pass) {
+        float se = 0.f, sp = 0.f;
+        for (int t = 0; t < nt; ++t) { sp += d.workspace[wsl.pu + t]; se += d.workspace[wsl.pu + nt + t]; }
+        pu_on = d.pos_class_prior * (se / fB) - sp / fB >= -d.nonnegative_margin ? 1.f : 0.f;   // torch.clamp(min = -margin): gradient where the input is not below the bound
+      }
       if (row < B) {
         const float* off = call == 0 ? x.logit_offset_policy : x.logit_offset_expert;
         const float f = l.row[2 * GS_R + r], z = off ? f - off[row] : f, w = l.row[GS_R + r];
         const bool pu = d.loss_function == IL_LOSS_PUGAIL;
-        const float c_sig = pu ? (call == 1 ? 2.f * d.pos_class_prior : -1.f) : 1.f, c_lab = call == 1 ? (pu ? d.pos_class_prior : 1.f) : 0.f;
+        const float c_sig = pu ? (call == 1 ? (1.f + pu_on) * d.pos_class_prior : -pu_on) : 1.f, c_lab = call == 1 ? (pu ? d.pos_class_prior : 1.f) : 0.f;
         const float p = sigmoid_f(z);
         dz = w * (c_sig * p - c_lab) / fB;
         if (d.entropy_bonus > 0.f) dz += d.entropy_bonus * w * z * p * (1.f - p) / fB;
       }
       dzr[r] = dz; coef_n[r] = dz * (1.f - l.row[r]) * d.discount; coef_s[r] = -dz * (1.f - l.row[r]);
     }
+    if (pu_value_pass) return;   // uniform: every thread of the workgroup leaves here
     __syncthreads();
     // ---- g: G^g[k] = sum_r dz x ; bias
     {
@@ -390,7 +410,11 @@ extern "C" int il_gail_shaped_step(const il_disc_shaped* d, const il_batch* pol,
   const size_t lds = gs_lds_floats(S, Dg, d->hidden) * sizeof(float);
   if (int rc = gs_ensure_lds((const void*)k_gs_grad, lds)) return rc;
   hipStream_t st = (hipStream_t)stream_;
-  { IL_TRACE("k_gs_grad", st); k_gs_grad<<<dim3(ceil_div(d->batch, GS_R), gs_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x); }
+  if (d->loss_function == IL_LOSS_PUGAIL && d->pu_clamped) {   // finite nonnegative_margin: a value pass (logits only) ahead of the gradient pass, which reads the clamp decision
+    IL_CHECK_ARG(d->nonnegative_margin >= 0.f, "il_gail_shaped_step: nonnegative_margin must be >= 0");
+    { IL_TRACE("k_gs_grad", st); k_gs_grad<<<dim3(ceil_div(d->batch, GS_R), 2), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, 1); }
+  }
+  { IL_TRACE("k_gs_grad", st); k_gs_grad<<<dim3(ceil_div(d->batch, GS_R), gs_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, 0); }
   const int64_t P = gs_layout(S, Dg, d->hidden, d->spectral_norm).P;
   { IL_TRACE("k_gs_reduce", st); k_gs_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1); }
   IL_CHECK_LAUNCH("il_gail_shaped_step");

@@ -148,13 +148,12 @@ def disc_descriptor(disc: GAILDiscriminator, batch_size: int, opt: AdamW, imitat
 
 def shaped_descriptor(disc, batch_size: int, opt, imitation_cfg=None) -> _lib.DiscShaped:
   dev = disc.flat.device
-  loss_function, prior, grad_penalty, entropy_bonus = 'BCE', 0.0, 0.0, 0.0
+  loss_function, prior, grad_penalty, entropy_bonus, margin = 'BCE', 0.0, 0.0, 0.0, float('inf')
   if imitation_cfg is not None:
     loss_function, prior = imitation_cfg.loss_function, float(_cfg_value(imitation_cfg, 'pos_class_prior', 0.0) or 0.0)
     if loss_function not in ('BCE', 'PUGAIL'):
       raise NotImplementedError(f'adversarial_imitation_update: reward shaping with loss_function={loss_function} has no kernel (BCE and PUGAIL do)')
-    if loss_function == 'PUGAIL' and float(_cfg_value(imitation_cfg, 'nonnegative_margin', float('inf'))) != float('inf'):
-      raise NotImplementedError('adversarial_imitation_update: PUGAIL with a finite nonnegative_margin has no kernel; the default inf does')
+    margin = float(_cfg_value(imitation_cfg, 'nonnegative_margin', float('inf')))
     grad_penalty, entropy_bonus = float(imitation_cfg.grad_penalty), float(imitation_cfg.entropy_bonus)
   ws = _workspace('disc_shaped', int(_lib.lib().il_disc_shaped_workspace_floats(disc.state_size, disc.action_size, disc.hidden, batch_size, int(disc.state_only))), dev)
   v = disc.views()
@@ -168,19 +167,20 @@ def shaped_descriptor(disc, batch_size: int, opt, imitation_cfg=None) -> _lib.Di
   d.grad_penalty, d.entropy_bonus, d.pos_class_prior, d.discount = grad_penalty, entropy_bonus, prior, float(disc.discount)
   d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
   d.noise_seed, d.noise_counter = _noise_seed() & (2**64 - 1), _noise_counter(dev, 'disc_shaped').data_ptr()
+  if loss_function == 'PUGAIL' and margin != float('inf'):   # training.py:102, as in disc_descriptor
+    d.pu_clamped, d.nonnegative_margin = 1, margin
   return d
 
 
 def deep_descriptor(disc, batch_size: int, opt, imitation_cfg=None) -> _lib.DiscDeep:
   """il_disc_deep for a DeepGAILDiscriminator (depth 1-2, relu / tanh; gail_deep.hip)."""
   dev = disc.flat.device
-  loss_function, prior, grad_penalty, entropy_bonus = 'BCE', 0.0, 0.0, 0.0
+  loss_function, prior, grad_penalty, entropy_bonus, margin = 'BCE', 0.0, 0.0, 0.0, float('inf')
   if imitation_cfg is not None:
     loss_function, prior = imitation_cfg.loss_function, float(_cfg_value(imitation_cfg, 'pos_class_prior', 0.0) or 0.0)
     if loss_function not in LOSS_FUNCTIONS:
       raise ValueError(f'adversarial_imitation_update: unknown loss_function={loss_function}')
-    if loss_function == 'PUGAIL' and float(_cfg_value(imitation_cfg, 'nonnegative_margin', float('inf'))) != float('inf'):
-      raise NotImplementedError('adversarial_imitation_update: PUGAIL with a finite nonnegative_margin has no kernel; the default inf does')
+    margin = float(_cfg_value(imitation_cfg, 'nonnegative_margin', float('inf')))
     grad_penalty, entropy_bonus = float(imitation_cfg.grad_penalty), float(imitation_cfg.entropy_bonus)
   L = _lib.lib()
   ws = _workspace('disc_deep', int(L.il_disc_deep_workspace_floats(disc.in_dim, disc.hidden, disc.depth, batch_size)), dev)
@@ -194,6 +194,8 @@ def deep_descriptor(disc, batch_size: int, opt, imitation_cfg=None) -> _lib.Disc
   d.grad_penalty, d.entropy_bonus, d.pos_class_prior = grad_penalty, entropy_bonus, prior
   d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
   d.noise_seed, d.noise_counter = _noise_seed() & (2**64 - 1), _noise_counter(dev, 'disc_deep').data_ptr()
+  if loss_function == 'PUGAIL' and margin != float('inf'):   # training.py:102, as in disc_descriptor
+    d.pu_clamped, d.nonnegative_margin = 1, margin
   return d
 
 

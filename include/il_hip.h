@@ -371,7 +371,7 @@ int il_gail_reward(const il_disc* d, const il_batch* batch, float* out_rewards, 
  *   f = g(x) + (1 - terminal)(discount * h(s') - h(s)),  g = Linear(Dg, 1),  h = Linear(S, H) -> ReLU -> Linear(H, 1),  Dg = S (+ A unless state_only).
  * params in parameters() order: spectral norm  {g.bias, g.original[1,Dg], h.0.bias[H], h.0.original[H,S], h.2.bias, h.2.original[1,H]},
  * otherwise {g.weight, g.bias, h.0.weight, h.0.bias, h.2.weight, h.2.bias}; il_disc_shaped_numel floats. Buffers ug[1] vg[Dg] u1[H] v1[S] u2[1] v2[H].
- * Losses BCE / PUGAIL (margin = inf); il_gail_extra carries the subtract_log_policy offsets (eps_mix unused). Batches must carry next_states, terminals.
+ * Losses BCE / PUGAIL (any margin); il_gail_extra carries the subtract_log_policy offsets (eps_mix unused). Batches must carry next_states, terminals.
  * ------------------------------------------------------------------------------------------ */
 typedef struct il_disc_shaped {
   int32_t state_dim, action_dim, hidden, batch;
@@ -385,6 +385,8 @@ typedef struct il_disc_shaped {
   int64_t workspace_floats;
   uint64_t noise_seed;
   uint32_t* noise_counter;
+  int32_t pu_clamped;        /* PUGAIL with a finite nonnegative_margin, as in il_disc: a value pass ahead of the gradients decides whether the clamped term has one */
+  float nonnegative_margin;
 } il_disc_shaped;
 int64_t il_disc_shaped_numel(int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t state_only);
 int64_t il_disc_shaped_workspace_floats(int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t batch, int32_t state_only);
@@ -413,6 +415,8 @@ typedef struct il_disc_deep {
   int64_t workspace_floats;
   uint64_t noise_seed;
   uint32_t* noise_counter;
+  int32_t pu_clamped;        /* as in il_disc (training.py:100-102 with a finite nonnegative_margin) */
+  float nonnegative_margin;
 } il_disc_deep;
 int64_t il_disc_deep_numel(int32_t in_dim, int32_t hidden, int32_t depth);
 int64_t il_disc_deep_sn_numel(int32_t in_dim, int32_t hidden, int32_t depth);

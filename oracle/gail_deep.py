@@ -2,7 +2,7 @@
 
 Generalises oracle/gail.py (depth 1, ReLU) to `imitation.discriminator.depth` in {1, 2} and `activation` in {relu, tanh}
 (conf/hyperparameter_search_space/GAIL.yaml), without reward shaping:  g = [SN(Linear) - act] x depth - SN(Linear(H, 1))  on x = cat(s, a)
-(models.py:49-70, 152-162). Restates `adversarial_imitation_update` (training.py:85-134: BCE / PUGAIL with nonnegative_margin = inf / Mixup, entropy
+(models.py:49-70, 152-162). Restates `adversarial_imitation_update` (training.py:85-134: BCE / PUGAIL / Mixup, entropy
 bonus, gradient penalty), torch `_SpectralNorm` (one power iteration per weight access in train mode, sigma = u^T W v, u and v constants in autograd)
 and `predict_reward` (models.py:177-180). Pinned by tests/golden/gail_deep.npz (reference outputs).
 
@@ -150,7 +150,7 @@ def _grad_penalty_grads(Wh, acts, c, act):
 
 
 def gail_update(ds: DeepDiscState, xp, wp, xe, we, eps_gp, *, lr, weight_decay, grad_penalty=1.0, entropy_bonus=0.0, return_grads=False, loss_function='BCE',
-                pos_class_prior=0.7, eps_mix=None, logp_policy=None, logp_expert=None):
+                pos_class_prior=0.7, eps_mix=None, logp_policy=None, logp_expert=None, nonnegative_margin=float('inf')):
   """One `adversarial_imitation_update` (training.py:85-134); arguments as in oracle/gail.py:gail_update."""
   xp, xe, wp, we = xp.astype(f32), xe.astype(f32), wp.astype(f32), we.astype(f32)
   B, act = xp.shape[0], ds.activation
@@ -160,7 +160,18 @@ def gail_update(ds: DeepDiscState, xp, wp, xe, we, eps_gp, *, lr, weight_decay, 
     calls = [(xp, wp, f32(1), zero, logp_policy), (xe, we, f32(1), zero + f32(1), logp_expert)]
   elif loss_function == 'PUGAIL':
     pr = f32(pos_class_prior)
-    calls = [(xp, wp, f32(-1), zero, logp_policy), (xe, we, f32(2) * pr, zero + pr, logp_expert)]
+    on = f32(1)
+    if nonnegative_margin != float('inf'):   # training.py:102: the clamp passes the gradient only where its argument is not below the bound (a batch-wide decision)
+      import copy
+      probe = copy.deepcopy(ds)              # the same two power iterations the calls below will run
+      zs = []
+      for x, off in ((xp, logp_policy), (xe, logp_expert)):
+        Wh, _ = _sn_weights(probe, True)
+        z = _forward(Wh, probe.b, x, act)[1]
+        zs.append(z if off is None else z - off.astype(f32))
+      V = pr * np.mean(we * nets.softplus(zs[1]), dtype=f32) - np.mean(wp * nets.softplus(zs[0]), dtype=f32)
+      on = f32(1) if V >= -nonnegative_margin else f32(0)
+    calls = [(xp, wp, -on, zero, logp_policy), (xe, we, (f32(1) + on) * pr, zero + pr, logp_expert)]
   elif loss_function == 'Mixup':
     em = eps_mix.astype(f32)
     calls = [(em[:, None] * xe + (f32(1) - em[:, None]) * xp, em * we + (f32(1) - em) * wp, f32(1), em, None)]

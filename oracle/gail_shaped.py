@@ -102,14 +102,25 @@ def _split(ds, b):
 
 
 def gail_update(ds: ShapedState, pol, exp, eps_gp, *, lr, weight_decay, grad_penalty=1.0, entropy_bonus=0.0, loss_function='BCE', pos_class_prior=0.7,
-                logp_policy=None, logp_expert=None, return_grads=False):
-  """One `adversarial_imitation_update` with reward shaping; pol / exp are transition dicts."""
+                logp_policy=None, logp_expert=None, return_grads=False, nonnegative_margin=float('inf')):
+  """One `adversarial_imitation_update` with reward shaping; pol / exp are transition dicts. nonnegative_margin: training.py:100-102 (PUGAIL), as in oracle/gail.py."""
   B = pol['states'].shape[0]
   g = {k: np.zeros_like(getattr(ds, k)) for k in ('Wg', 'bg', 'W1', 'b1', 'W2', 'b2')}
   pu = loss_function == 'PUGAIL'
   pr = f32(pos_class_prior)
   zero = np.zeros(B, f32)
-  calls = [(pol, f32(-1) if pu else f32(1), zero, logp_policy), (exp, f32(2) * pr if pu else f32(1), zero + (pr if pu else f32(1)), logp_expert)]
+  on = f32(1)
+  if pu and nonnegative_margin != float('inf'):   # the clamp passes the gradient only where its argument is not below the bound: a batch-wide decision on the logits of both calls
+    import copy
+    probe = copy.deepcopy(ds)                      # the same power iterations the calls below will run
+    zs = []
+    for b, off in ((pol, logp_policy), (exp, logp_expert)):
+      x, s, ns, t, _ = _split(probe, b)
+      f = forward(probe, x, s, ns, t, train=True)[0]
+      zs.append(f if off is None else f - off.astype(f32))
+    V = pr * np.mean(exp['weights'].astype(f32) * nets.softplus(zs[1]), dtype=f32) - np.mean(pol['weights'].astype(f32) * nets.softplus(zs[0]), dtype=f32)
+    on = f32(1) if V >= -nonnegative_margin else f32(0)
+  calls = [(pol, -on if pu else f32(1), zero, logp_policy), (exp, (f32(1) + on) * pr if pu else f32(1), zero + (pr if pu else f32(1)), logp_expert)]
   for b, c_sig, c_lab, off in calls:
     x, s, ns, t, w = _split(ds, b)
     f, (Wgh, cg, cn, cs) = forward(ds, x, s, ns, t, train=True)

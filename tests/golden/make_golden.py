@@ -311,6 +311,96 @@ def gen_gail_pu_margin():
   np.savez_compressed(os.path.join(HERE, 'gail_pu_margin.npz'), **out)
 
 
+def deep_disc(c, icfg):
+  """The reference's GAILDiscriminator for a gail_deep_case, weights / biases / u / v set from the case; and the indices of its Linear layers in d.g."""
+  d = ref_models.GAILDiscriminator(c['S'], c['A'], icfg, 0.97)
+  lin = [2 * l for l in range(c['depth'] + 1)]
+  with torch.no_grad():
+    for l, li in enumerate(lin):
+      if c['spectral_norm']:
+        d.g[li].parametrizations.weight.original.copy_(T(c['W'][l])); d.g[li].bias.copy_(T(c['b'][l]))
+        d.g[li].parametrizations.weight[0]._u.copy_(T(c['u'][l])); d.g[li].parametrizations.weight[0]._v.copy_(T(c['v'][l]))
+      else:
+        d.g[li].weight.copy_(T(c['W'][l])); d.g[li].bias.copy_(T(c['b'][l]))
+  return d, lin
+
+
+def shaped_disc(c, icfg, sn):
+  """The reference's reward-shaping GAILDiscriminator for a gail_shaped_case."""
+  d = ref_models.GAILDiscriminator(c['S'], c['A'], icfg, 0.97)
+  with torch.no_grad():
+    if sn:
+      d.g.parametrizations.weight.original.copy_(T(c['Wg'])); d.g.bias.copy_(T(c['bg']))
+      d.g.parametrizations.weight[0]._u.copy_(T(c['ug'])); d.g.parametrizations.weight[0]._v.copy_(T(c['vg']))
+      for li, (W, b, u, v) in ((0, (c['W1'], c['b1'], c['u1'], c['v1'])), (2, (c['W2'], c['b2'], c['u2'], c['v2']))):
+        d.h[li].parametrizations.weight.original.copy_(T(W)); d.h[li].bias.copy_(T(b))
+        d.h[li].parametrizations.weight[0]._u.copy_(T(u)); d.h[li].parametrizations.weight[0]._v.copy_(T(v))
+    else:
+      d.g.weight.copy_(T(c['Wg'])); d.g.bias.copy_(T(c['bg']))
+      d.h[0].weight.copy_(T(c['W1'])); d.h[0].bias.copy_(T(c['b1'])); d.h[2].weight.copy_(T(c['W2'])); d.h[2].bias.copy_(T(c['b2']))
+  return d
+
+
+class ClampSpy:
+  """Records the scalar arguments of torch.clamp (training.py:102: the value the PUGAIL margin is compared with)."""
+  def __enter__(self):
+    self.seen, self.orig = [], torch.clamp
+    def spy(x, *a, **k):
+      if x.dim() == 0: self.seen.append(float(x))
+      return self.orig(x, *a, **k)
+    torch.clamp = spy
+    return self
+  def __exit__(self, *exc):
+    torch.clamp = self.orig
+
+
+PU_MARGINS = (('clamped', 0.02), ('open', 1.5))
+
+
+def gen_gail_pu_margin_general():
+  """PUGAIL with a FINITE nonnegative_margin (training.py:100-102) on the two other discriminator shapes: depth 2 / tanh / spectral norm (models.py:152-162) and
+  reward shaping with spectral norm (models.py:163-176). One margin that clamps the unlabelled term away and one that does not; gradients, parameters, u / v
+  buffers and the clamped value."""
+  out = {}
+  for name, margin in PU_MARGINS:
+    c = gi.gail_deep_case(seed=111, env='hopper', hidden=32, batch=96, steps=2, depth=2, activation='tanh', spectral_norm=True)
+    icfg = DictConfig(state_only=False, spectral_norm=True, loss_function='PUGAIL', grad_penalty=0.6, mixup_alpha=1, entropy_bonus=0.02, pos_class_prior=0.7, nonnegative_margin=margin,
+                      discriminator=DictConfig(hidden_size=c['H'], depth=2, activation='tanh', reward_shaping=False, subtract_log_policy=False, reward_function='AIRL'))
+    d, lin = deep_disc(c, icfg)
+    opt = torch.optim.AdamW(d.parameters(), lr=1e-3, weight_decay=0.1)
+    for i in range(2):
+      d.train()
+      with ClampSpy() as spy, NoiseFeed() as nf:
+        nf.rand.append(T(c['eps'][i]))
+        ref_training.adversarial_imitation_update(None, d, tbatch(c['policy'][i]), tbatch(c['expert'][i]), opt, icfg)
+      d.eval()
+      k = i + 1
+      out[f'deep.{name}.g_{k}'] = np.concatenate([N_(p.grad).ravel() for p in d.parameters()]); out[f'deep.{name}.p_{k}'] = flat(d)
+      out[f'deep.{name}.sn_{k}'] = np.concatenate([np.concatenate([N_(d.g[li].parametrizations.weight[0]._u), N_(d.g[li].parametrizations.weight[0]._v)]) for li in lin])
+      out[f'deep.{name}.value_{k}'] = np.array(spy.seen[:1], np.float64)
+    out[f'deep.{name}.margin'] = np.array([margin])
+
+    c = gi.gail_shaped_case(93, 'hopper', 32, 96, 2, True)
+    icfg = DictConfig(state_only=False, spectral_norm=True, loss_function='PUGAIL', grad_penalty=0.7, mixup_alpha=1, entropy_bonus=0.01, pos_class_prior=0.7, nonnegative_margin=margin,
+                      discriminator=DictConfig(hidden_size=c['H'], depth=1, activation='relu', reward_shaping=True, subtract_log_policy=False, reward_function='AIRL'))
+    d = shaped_disc(c, icfg, True)
+    opt = torch.optim.AdamW(d.parameters(), lr=1e-3, weight_decay=0.1)
+    for i in range(2):
+      d.train()
+      with ClampSpy() as spy, NoiseFeed() as nf:
+        nf.rand.append(T(c['eps'][i]))
+        ref_training.adversarial_imitation_update(None, d, tbatch(c['policy'][i]), tbatch(c['expert'][i]), opt, icfg)
+      d.eval()
+      k = i + 1
+      out[f'shaped.{name}.g_{k}'] = np.concatenate([N_(p.grad).ravel() for p in d.parameters()]); out[f'shaped.{name}.p_{k}'] = flat(d)
+      out[f'shaped.{name}.ug_{k}'] = N_(d.g.parametrizations.weight[0]._u); out[f'shaped.{name}.vg_{k}'] = N_(d.g.parametrizations.weight[0]._v)
+      for li, nm in ((0, '1'), (2, '2')):
+        out[f'shaped.{name}.u{nm}_{k}'] = N_(d.h[li].parametrizations.weight[0]._u); out[f'shaped.{name}.v{nm}_{k}'] = N_(d.h[li].parametrizations.weight[0]._v)
+      out[f'shaped.{name}.value_{k}'] = np.array(spy.seen[:1], np.float64)
+    out[f'shaped.{name}.margin'] = np.array([margin])
+  np.savez_compressed(os.path.join(HERE, 'gail_pu_margin_general.npz'), **out)
+
+
 def gen_gail_deep(f64=None):
   """GAILDiscriminator with depth 1-2 / relu / tanh (models.py:152-162, no reward shaping) under adversarial_imitation_update: gradients, parameters after
   AdamW, u / v buffers, rewards. The gradient-penalty and Mixup draws are fed like the other noise."""
@@ -320,15 +410,7 @@ def gen_gail_deep(f64=None):
     icfg = DictConfig(state_only=False, spectral_norm=c['spectral_norm'], loss_function=loss, grad_penalty=gp, mixup_alpha=0.7, entropy_bonus=ent, pos_class_prior=0.7,
                       nonnegative_margin=float('inf'),
                       discriminator=DictConfig(hidden_size=c['H'], depth=c['depth'], activation=c['activation'], reward_shaping=False, subtract_log_policy=False, reward_function=rf))
-    d = ref_models.GAILDiscriminator(c['S'], c['A'], icfg, 0.97)
-    lin = [2 * l for l in range(c['depth'] + 1)]
-    with torch.no_grad():
-      for l, li in enumerate(lin):
-        if c['spectral_norm']:
-          d.g[li].parametrizations.weight.original.copy_(T(c['W'][l])); d.g[li].bias.copy_(T(c['b'][l]))
-          d.g[li].parametrizations.weight[0]._u.copy_(T(c['u'][l])); d.g[li].parametrizations.weight[0]._v.copy_(T(c['v'][l]))
-        else:
-          d.g[li].weight.copy_(T(c['W'][l])); d.g[li].bias.copy_(T(c['b'][l]))
+    d, lin = deep_disc(c, icfg)
     out[f'{name}.param_names'] = np.array([n for n, _ in d.named_parameters()])
     opt = torch.optim.AdamW(d.parameters(), lr=lr, weight_decay=wd)
     for i in range(len(c['policy'])):
@@ -376,19 +458,9 @@ def gen_gail_shaped():
     c = gi.gail_shaped_case(91, 'hopper', 32, 96, 2, sn)
     icfg = DictConfig(state_only=False, spectral_norm=sn, loss_function=loss, grad_penalty=0.7, mixup_alpha=1, entropy_bonus=0.01, pos_class_prior=0.7, nonnegative_margin=float('inf'),
                       discriminator=DictConfig(hidden_size=c['H'], depth=1, activation='relu', reward_shaping=True, subtract_log_policy=False, reward_function='AIRL'))
-    d = ref_models.GAILDiscriminator(c['S'], c['A'], icfg, 0.97)
+    d = shaped_disc(c, icfg, sn)
     names = [n for n, _ in d.named_parameters()]
     out[f'{name}.param_names'] = np.array(names)
-    with torch.no_grad():
-      if sn:
-        d.g.parametrizations.weight.original.copy_(T(c['Wg'])); d.g.bias.copy_(T(c['bg']))
-        d.g.parametrizations.weight[0]._u.copy_(T(c['ug'])); d.g.parametrizations.weight[0]._v.copy_(T(c['vg']))
-        for li, (W, b, u, v) in ((0, (c['W1'], c['b1'], c['u1'], c['v1'])), (2, (c['W2'], c['b2'], c['u2'], c['v2']))):
-          d.h[li].parametrizations.weight.original.copy_(T(W)); d.h[li].bias.copy_(T(b))
-          d.h[li].parametrizations.weight[0]._u.copy_(T(u)); d.h[li].parametrizations.weight[0]._v.copy_(T(v))
-      else:
-        d.g.weight.copy_(T(c['Wg'])); d.g.bias.copy_(T(c['bg']))
-        d.h[0].weight.copy_(T(c['W1'])); d.h[0].bias.copy_(T(c['b1'])); d.h[2].weight.copy_(T(c['W2'])); d.h[2].bias.copy_(T(c['b2']))
     opt = torch.optim.AdamW(d.parameters(), lr=1e-3, weight_decay=0.1)
     for i in range(len(c['policy'])):
       d.train()
@@ -665,6 +737,7 @@ if __name__ == '__main__':
     gen_gail('gail_nosn_nogp', gi.gail_case(33, env='hopper', hidden=32, batch=128, spectral_norm=False), lr=3e-4, weight_decay=0.0, grad_penalty=0.0, entropy_bonus=0.0)
   if want('gail_variants'): gen_gail_variants()
   if want('gail_pu_margin'): gen_gail_pu_margin()
+  if want('gail_pu_margin_general'): gen_gail_pu_margin_general()
   if want('gail_shaped'): gen_gail_shaped()
   if want('gail_deep'): gen_gail_deep()
   if want('gmmil'): gen_gmmil()

@@ -1178,6 +1178,74 @@ def test_gail_reward_shaping_matches_reference(golden_dir, name, sn, loss):
 
 
 # ---------------------------------------------------------------------------------------------
+# PUGAIL with a finite nonnegative_margin (training.py:100-102) on the depth-2 / tanh and the reward-shaping discriminator
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['clamped', 'open'])
+def test_gail_deep_pugail_finite_margin_matches_reference(golden_dir, name):
+  from oracle import gail_deep as ogd
+  g = load(golden_dir, 'gail_pu_margin_general')
+  margin = float(g[f'deep.{name}.margin'][0])
+  c = gi.gail_deep_case(seed=111, env='hopper', hidden=32, batch=96, steps=2, depth=2, activation='tanh', spectral_norm=True)
+  icfg = Cfg(state_only=False, spectral_norm=True, loss_function='PUGAIL', grad_penalty=0.6, mixup_alpha=1, entropy_bonus=0.02, pos_class_prior=0.7, nonnegative_margin=margin,
+             discriminator=Cfg(hidden_size=c['H'], depth=2, activation='tanh', reward_shaping=False, subtract_log_policy=False, reward_function='AIRL'))
+  d = il.GAILDiscriminator(c['S'], c['A'], icfg, 0.97, device=DEV)
+  assert type(d).__name__ == 'DeepGAILDiscriminator'
+  ds = ogd.DeepDiscState(c['D'], c['H'], 2, 'tanh', True)
+  for l in range(3):
+    ds.W[l][...] = c['W'][l]; ds.b[l][...] = c['b'][l]; ds.u[l][...] = c['u'][l]; ds.v[l][...] = c['v'][l]
+  d.flat.copy_(T(ds.pack())); d.sn.copy_(T(ds.pack_sn()))
+  opt = il.AdamW(d, lr=1e-3, weight_decay=0.1)
+  cat = lambda b: np.concatenate([b['states'], b['actions']], 1)
+  for i in range(2):
+    pb, eb = c['policy'][i], c['expert'][i]
+    if i:
+      d.flat.copy_(T(g[f'deep.{name}.p_{i}'])); ds.unpack_into(g[f'deep.{name}.p_{i}'])
+      d.sn.copy_(T(g[f'deep.{name}.sn_{i}'])); ds.unpack_sn(g[f'deep.{name}.sn_{i}'])
+    il.adversarial_imitation_update(None, d, tbatch(pb), tbatch(eb), opt, icfg, eps_gp=T(c['eps'][i]))
+    ogr = ogd.gail_update(ds, cat(pb), pb['weights'], cat(eb), eb['weights'], c['eps'][i], lr=1e-3, weight_decay=0.1, grad_penalty=0.6, entropy_bonus=0.02, return_grads=True,
+                          loss_function='PUGAIL', pos_class_prior=0.7, nonnegative_margin=margin)
+    close(N(opt.grad), g[f'deep.{name}.g_{i + 1}'], f'deep {name} gradient {i + 1} (reference)', rtol=2e-5, atol_scale=1e-5)
+    close(N(opt.grad), ogr, f'deep {name} gradient {i + 1} (oracle)', rtol=2e-5, atol_scale=1e-5)
+    close(N(d.sn), g[f'deep.{name}.sn_{i + 1}'], f'deep {name} u / v after update {i + 1}', rtol=2e-5, atol_scale=1e-5)
+  assert int(opt.step_count[0]) == 2   # the value pass does not tick the optimiser
+  # the two margins give different gradients at the first update (one side of the clamp each), so a kernel that ignored the margin fails one of the two cases
+  assert np.abs(g['deep.clamped.g_1'] - g['deep.open.g_1']).max() > 1e-3 * np.abs(g['deep.open.g_1']).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['clamped', 'open'])
+def test_gail_shaped_pugail_finite_margin_matches_reference(golden_dir, name):
+  from oracle import gail_shaped as ogs
+  g = load(golden_dir, 'gail_pu_margin_general')
+  margin = float(g[f'shaped.{name}.margin'][0])
+  c = gi.gail_shaped_case(93, 'hopper', 32, 96, 2, True)
+  icfg = Cfg(state_only=False, spectral_norm=True, loss_function='PUGAIL', grad_penalty=0.7, mixup_alpha=1, entropy_bonus=0.01, pos_class_prior=0.7, nonnegative_margin=margin,
+             discriminator=Cfg(hidden_size=c['H'], depth=1, activation='relu', reward_shaping=True, subtract_log_policy=False, reward_function='AIRL'))
+  d = il.GAILDiscriminator(c['S'], c['A'], icfg, 0.97, device=DEV)
+  assert type(d).__name__ == 'ShapedGAILDiscriminator'
+  ods = ogs.ShapedState(c['S'], c['A'], c['H'], 0.97, True)
+  for k in ('Wg', 'bg', 'W1', 'b1', 'W2', 'b2', 'ug', 'vg', 'u1', 'v1', 'u2', 'v2'):
+    getattr(ods, k)[...] = c[k]
+  d.flat.copy_(T(ods.pack()))
+  for k, v in d.views().items():
+    v.copy_(T(c[k]))
+  opt = il.AdamW(d, lr=1e-3, weight_decay=0.1)
+  for i in range(2):   # the second update of 'clamped' is on the open side of the clamp (value_2 > -margin): the decision is taken per update, on the device
+    il.adversarial_imitation_update(None, d, tbatch(c['policy'][i]), tbatch(c['expert'][i]), opt, icfg, eps_gp=T(c['eps'][i]))
+    ogr = ogs.gail_update(ods, c['policy'][i], c['expert'][i], c['eps'][i], lr=1e-3, weight_decay=0.1, grad_penalty=0.7, entropy_bonus=0.01, loss_function='PUGAIL', return_grads=True,
+                          pos_class_prior=0.7, nonnegative_margin=margin)
+    close(N(opt.grad), g[f'shaped.{name}.g_{i + 1}'], f'shaped {name} gradient {i + 1} (reference)', rtol=1e-5, atol_scale=1e-5)
+    close(N(opt.grad), ogr, f'shaped {name} gradient {i + 1} (oracle)', rtol=1e-5, atol_scale=1e-5)
+    close_params(N(d.flat), g[f'shaped.{name}.p_{i + 1}'], f'shaped {name} parameters {i + 1}', 1e-3, steps=i + 1)
+    for k in ('ug', 'vg', 'u1', 'v1', 'u2', 'v2'):
+      close(N(d.views()[k]), g[f'shaped.{name}.{k}_{i + 1}'], f'shaped {name} {k} after update {i + 1}', rtol=1e-5, atol_scale=1e-5)
+    d.flat.copy_(T(g[f'shaped.{name}.p_{i + 1}'])); ods.unpack_into(g[f'shaped.{name}.p_{i + 1}'].copy())
+  assert int(opt.step_count[0]) == 2
+  assert np.abs(g['shaped.clamped.g_1'] - g['shaped.open.g_1']).max() > 1e-3 * np.abs(g['shaped.open.g_1']).max()
+
+
+# ---------------------------------------------------------------------------------------------
 # the small-network kernels at the largest environment (Ant: S = 112, A = 8) and ragged batches, against the oracle (no reference fixture at these sizes)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu

@@ -307,6 +307,39 @@ def test_gail_deep_oracle_matches_reference_fixture(golden_dir, name):
     np.testing.assert_allclose(ogd.predict_reward(ds, cat(pb), rf), g[f'{name}.reward_{i + 1}'], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('name', ['clamped', 'open'])
+def test_gail_deep_and_shaped_oracles_pugail_finite_margin(golden_dir, name):
+  """training.py:100-102 with a finite nonnegative_margin on the depth-2 / tanh and on the reward-shaping discriminator (fixture: gail_pu_margin_general.npz, one margin
+  that clamps the unlabelled term away at the first update and one that never does): gradients, parameters, u / v buffers."""
+  from oracle import gail_deep as ogd, gail_shaped as ogs
+  g = np.load(os.path.join(golden_dir, 'gail_pu_margin_general.npz'))
+  margin = float(g[f'deep.{name}.margin'][0])
+  assert (float(g[f'deep.{name}.value_1'][0]) < -margin) == (name == 'clamped') and (float(g[f'shaped.{name}.value_1'][0]) < -margin) == (name == 'clamped')
+  c = gi.gail_deep_case(seed=111, env='hopper', hidden=32, batch=96, steps=2, depth=2, activation='tanh', spectral_norm=True)
+  ds = _deep_state(c)
+  cat = lambda b: np.concatenate([b['states'], b['actions']], 1)
+  for i in range(2):
+    pb, eb = c['policy'][i], c['expert'][i]
+    if i: ds.unpack_into(g[f'deep.{name}.p_{i}']); ds.unpack_sn(g[f'deep.{name}.sn_{i}'])
+    grad = ogd.gail_update(ds, cat(pb), pb['weights'], cat(eb), eb['weights'], c['eps'][i], lr=1e-3, weight_decay=0.1, grad_penalty=0.6, entropy_bonus=0.02, return_grads=True,
+                           loss_function='PUGAIL', pos_class_prior=0.7, nonnegative_margin=margin)
+    ref = g[f'deep.{name}.g_{i + 1}']
+    np.testing.assert_allclose(grad, ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max())
+    np.testing.assert_allclose(ds.pack_sn(), g[f'deep.{name}.sn_{i + 1}'], rtol=1e-4, atol=1e-6)
+  c = gi.gail_shaped_case(93, 'hopper', 32, 96, 2, True)
+  ss = ogs.ShapedState(c['S'], c['A'], c['H'], 0.97, True)
+  for k in ('Wg', 'bg', 'W1', 'b1', 'W2', 'b2', 'ug', 'vg', 'u1', 'v1', 'u2', 'v2'):
+    getattr(ss, k)[...] = c[k]
+  for i in range(2):
+    gr = ogs.gail_update(ss, c['policy'][i], c['expert'][i], c['eps'][i], lr=1e-3, weight_decay=0.1, grad_penalty=0.7, entropy_bonus=0.01, loss_function='PUGAIL', return_grads=True,
+                         pos_class_prior=0.7, nonnegative_margin=margin)
+    ref = g[f'shaped.{name}.g_{i + 1}']
+    assert np.abs(gr - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert np.abs(ss.pack() - g[f'shaped.{name}.p_{i + 1}']).max() <= 2e-6
+    for k in ('ug', 'vg', 'u1', 'v1', 'u2', 'v2'):
+      np.testing.assert_allclose(getattr(ss, k), g[f'shaped.{name}.{k}_{i + 1}'], rtol=1e-5, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ Philox (the on-chip noise source's restatement)
 def test_philox_restatement_matches_random123_known_answers():
   """Known-answer vectors of Random123's philox4x32_10 (kat_vectors: all-zero, all-ones and the pi-digits counter / key)."""
