@@ -1000,10 +1000,11 @@ def test_gail_variants_loud_failures():
   mk = lambda **kw: Cfg(state_only=False, spectral_norm=True, loss_function='PUGAIL', grad_penalty=0.5, mixup_alpha=1, entropy_bonus=0.0, pos_class_prior=0.7, nonnegative_margin=kw.get('margin', float('inf')),
                         discriminator=Cfg(hidden_size=32, depth=1, activation='relu', reward_shaping=kw.get('shaping', False), subtract_log_policy=False, reward_function='AIRL'))
   assert type(il.GAILDiscriminator(c['S'], c['A'], mk(shaping=True), 0.97, device=DEV)).__name__ == 'ShapedGAILDiscriminator'
-  d = il.GAILDiscriminator(c['S'], c['A'], mk(shaping=True), 0.97, device=DEV)   # the depth-1 / relu discriminator handles a finite margin (test above); the shaped and the deep ones refuse it
+  d = il.GAILDiscriminator(c['S'], c['A'], mk(shaping=True), 0.97, device=DEV)   # reward shaping has BCE and PUGAIL kernels (any margin: tests below); Mixup has none
   opt = il.AdamW(d, lr=1e-3, weight_decay=0.1)
+  mix = mk(shaping=True); mix['loss_function'] = 'Mixup'
   with pytest.raises(NotImplementedError):
-    il.adversarial_imitation_update(None, d, tbatch(c['policy'][0]), tbatch(c['expert'][0]), opt, mk(shaping=True, margin=0.1))
+    il.adversarial_imitation_update(None, d, tbatch(c['policy'][0]), tbatch(c['expert'][0]), opt, mix)
 
 
 @pytest.mark.gpu
