@@ -97,12 +97,15 @@ IL_PEER_SPIN_LIMIT = 1 << 23   # include/il_hip.h: default bound (polls) of a de
 
 class PeerBucket(C.Structure):
   _fields_ = [('rank', C.c_int32), ('world', C.c_int32), ('n', C.c_int64), ('window_offset', C.c_int64), ('windows', C.c_void_p * IL_PEER_MAX_RANKS),
-              ('epoch', C.c_void_p), ('status', C.c_void_p), ('spin_limit', C.c_int32), ('flags', C.c_int32)]
+              ('epoch', C.c_void_p), ('status', C.c_void_p), ('spin_limit', C.c_int32), ('flags', C.c_int32), ('n_jobs', C.c_int32), ('reserved', C.c_int32)]
 
 
 _P = C.c_void_p
 _SIGNATURES = {
     'il_peer_region_bytes': (C.c_int64, [C.c_int32, C.c_int64]),
+    'il_peer_job_region_bytes': (C.c_int64, [C.c_int32, C.c_int64, C.c_int32]),
+    'il_sac_peer_bucket_floats': (C.c_int64, [C.POINTER(Sac), C.c_int32]),
+    'il_sac_peer_jobs': (C.c_int32, [C.POINTER(Sac), C.c_int32]),
     'il_peer_window_alloc': (C.c_int, [C.c_int64, C.POINTER(C.c_void_p), C.c_char_p, C.POINTER(C.c_int32)]),
     'il_peer_window_open': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     'il_peer_window_close': (C.c_int, [_P]),
@@ -145,6 +148,7 @@ _SIGNATURES = {
     'il_sac_dp_phase': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.c_int32, _P, _P, C.c_uint32, _P]),
     'il_sac_update': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), _P, _P, _P, _P, C.c_uint32, _P]),
     'il_sac_update_gather': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.POINTER(Batch), _P, C.POINTER(Disc), _P, _P, _P, _P, _P, C.c_uint32, _P]),
+    'il_sac_update_gather_peer': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.POINTER(Batch), _P, C.POINTER(Disc), _P, _P, _P, _P, _P, C.c_uint32, C.POINTER(PeerBucket), C.POINTER(PeerBucket), _P]),
     'il_gail_step_workgroups': (C.c_int32, [C.POINTER(Disc)]),
     'il_sac_chain_gather_workgroups': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     'il_sac_handoff_timeouts': (C.c_int, [C.POINTER(Sac), C.POINTER(C.c_uint32)]),
@@ -169,6 +173,7 @@ _SIGNATURES = {
     'il_gail_shaped_reward': (C.c_int, [C.POINTER(DiscShaped), C.POINTER(Batch), _P, _P, _P, _P]),
     'il_actor_log_prob': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
     'il_gail_disc_step_draw': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), C.POINTER(Batch), _P, _P, _P, _P, _P, C.c_uint32, _P]),
+    'il_gail_disc_step_draw_peer': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), C.POINTER(Batch), _P, _P, _P, _P, _P, C.c_uint32, C.POINTER(PeerBucket), _P]),
     'il_gail_apply_grads': (C.c_int, [C.POINTER(Disc), _P]),
     'il_gail_reward': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), _P, _P, _P, _P]),
     'il_gmmil_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

@@ -14,6 +14,7 @@
 #include "mt_device.hpp"
 #include "mlp_tile.hpp"
 #include "disc_reward.hpp"
+#include "peer_device.hpp"
 
 struct DiscWs { int64_t slabs, sn_new, pu, total; };   // pu: [2][nt] per-tile sums of w softplus(z) of the policy / expert call (PUGAIL with a finite nonnegative_margin)
 __host__ __device__ inline DiscWs disc_ws(int D, int H, int B) {
@@ -370,7 +371,7 @@ __host__ __device__ inline int gail_calls(const il_disc& d) { return (d.loss_fun
 // grid = ceil(P / 256): one gradient element per thread, slabs summed in tile order (deterministic)
 // close_epoch (il_gail_disc_step with IL_FLAG_GAIL_CLOSE_EPOCH): no relabel kernel follows on this stream - the stepped parameters are consumed by the
 // critic-loss workgroups of k_sac_chain - so each workgroup reports [IL_SYNC_PARAMS] and the last one closes the side branch's epoch.
-__global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const il_disc* __restrict__ dL, int close_epoch) {
+__global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const il_disc* __restrict__ dL, int close_epoch, il_peer_bucket peer) {
   IL_TL(1, 0);
   if (dL) d = dL[blockIdx.y];
   globalize(d);
@@ -379,11 +380,10 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const
   const DiscWs wsl = disc_ws(D, H, B);
   const int nt = ((B + IL_TILE_R - 1) / IL_TILE_R) * gail_calls(d);  // one slab per (call, tile)
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float pp = 0.f, mm = 0.f, vv = 0.f, g = 0.f;
   if (e < lay.P) {
     const float* sl = d.workspace + wsl.slabs + e;
-    float pp = 0.f, mm = 0.f, vv = 0.f;
     if (apply) { pp = d.params[e]; mm = d.opt.m[e]; vv = d.opt.v[e]; }   // independent of the slab sum: in flight while it runs
-    float g = 0.f;
     int t = 0;
     for (; t + 24 <= nt; t += 24) {   // the slabs were written by other XCDs: every load is a full-latency miss, so keep 24 in flight (2 rounds at B = 256)
       float v[24];
@@ -400,6 +400,15 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const
       for (int u = 0; u < 8; ++u) g += v[u];
     }
     for (; t < nt; ++t) g += sl[(size_t)t * lay.P];
+  }
+  if (peer.world > 0) {   // data-parallel: the gradient becomes its mean over the ranks inside this launch (peer_device.hpp; one arrival line per workgroup)
+    const PeerJob pj = peer_job_begin(peer, (int)blockIdx.x);
+    if (e < lay.P) peer_job_push1(peer, pj, e, g);
+    peer_job_exchange(peer, pj, (int)blockIdx.x);
+    if (e < lay.P) g = peer_job_mean1(peer, pj, e);
+    peer_job_end(peer, pj, (int)blockIdx.x);
+  }
+  if (e < lay.P) {
     d.grad[e] = g;
     if (apply) {
       const adam_consts ac = load_adam_consts(d.opt);
@@ -494,13 +503,13 @@ extern "C" int il_gail_disc_step(const il_disc* d, const il_batch* pol, const il
   }
   { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, nullptr, nullptr, nullptr, GailSampler{}, 0); }
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
-  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr, (flags & IL_FLAG_GAIL_CLOSE_EPOCH) ? 1 : 0); }
+  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr, (flags & IL_FLAG_GAIL_CLOSE_EPOCH) ? 1 : 0, il_peer_bucket{}); }
   IL_CHECK_LAUNCH("il_gail_disc_step");
   return IL_OK;
 }
 
-extern "C" int il_gail_disc_step_draw(const il_disc* d, const il_batch* pol, const il_batch* exp, uint32_t* mt_state_dev, const int64_t* ring_state_a, int32_t* idx_a,
-                                      const int64_t* ring_state_b, int32_t* idx_b, uint32_t flags, il_stream_t stream_) {
+static int gail_disc_step_draw_impl(const il_disc* d, const il_batch* pol, const il_batch* exp, uint32_t* mt_state_dev, const int64_t* ring_state_a, int32_t* idx_a,
+                                    const int64_t* ring_state_b, int32_t* idx_b, uint32_t flags, const il_peer_bucket* peer, il_stream_t stream_) {
   if (int rc = check_disc(d)) return rc;
   IL_CHECK_ARG(pol && exp && pol->n == d->batch && exp->n == d->batch && pol->gather && exp->gather, "il_gail_disc_step_draw: both batches must be rings read through il_batch.gather");
   IL_CHECK_ARG(d->sync && mt_state_dev && ring_state_a && idx_a && ring_state_b && idx_b, "il_gail_disc_step_draw: the il_sync counters, the generator state and both rings' states / index arrays are required");
@@ -514,9 +523,26 @@ extern "C" int il_gail_disc_step_draw(const il_disc* d, const il_batch* pol, con
   const GailSampler sa = {mt_state_dev, ring_state_a, idx_a, ring_state_b, idx_b, d->batch};
   { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt + 1, gail_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, nullptr, il_gail_extra{}, nullptr, nullptr, nullptr, sa, 0); }
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
-  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr, (flags & IL_FLAG_GAIL_CLOSE_EPOCH) ? 1 : 0); }
+  il_peer_bucket px = {};
+  if (peer) {
+    IL_CHECK_ARG(!(flags & IL_FLAG_GRADS_ONLY), "il_gail_disc_step_draw_peer: the AdamW step runs inside (no IL_FLAG_GRADS_ONLY)");
+    IL_CHECK_ARG(peer->world >= 1 && peer->world <= IL_PEER_MAX_RANKS && peer->rank >= 0 && peer->rank < peer->world && peer->epoch && peer->status && (peer->window_offset & 255) == 0, "il_gail_disc_step_draw_peer: bad peer descriptor");
+    IL_CHECK_ARG(peer->n == P && peer->n_jobs >= (int)((P + 255) / 256), "il_gail_disc_step_draw_peer: the bucket must hold %lld floats and %d arrival lines (got %lld, %d)", (long long)P, (int)((P + 255) / 256), (long long)peer->n, peer->n_jobs);
+    for (int r = 0; r < peer->world; ++r) IL_CHECK_ARG(peer->windows[r], "il_gail_disc_step_draw_peer: window of rank %d is not mapped", r);
+    px = *peer;
+  }
+  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr, (flags & IL_FLAG_GAIL_CLOSE_EPOCH) ? 1 : 0, px); }
   IL_CHECK_LAUNCH("il_gail_disc_step_draw");
   return IL_OK;
+}
+extern "C" int il_gail_disc_step_draw(const il_disc* d, const il_batch* pol, const il_batch* exp, uint32_t* mt_state_dev, const int64_t* ring_state_a, int32_t* idx_a,
+                                      const int64_t* ring_state_b, int32_t* idx_b, uint32_t flags, il_stream_t stream_) {
+  return gail_disc_step_draw_impl(d, pol, exp, mt_state_dev, ring_state_a, idx_a, ring_state_b, idx_b, flags, nullptr, stream_);
+}
+extern "C" int il_gail_disc_step_draw_peer(const il_disc* d, const il_batch* pol, const il_batch* exp, uint32_t* mt_state_dev, const int64_t* ring_state_a, int32_t* idx_a,
+                                           const int64_t* ring_state_b, int32_t* idx_b, uint32_t flags, const il_peer_bucket* peer, il_stream_t stream_) {
+  IL_CHECK_ARG(peer, "il_gail_disc_step_draw_peer: null peer descriptor");
+  return gail_disc_step_draw_impl(d, pol, exp, mt_state_dev, ring_state_a, idx_a, ring_state_b, idx_b, flags, peer, stream_);
 }
 
 // population axis: discriminator step + reward relabel of n_learners independent discriminators (same shapes) in three launches
@@ -534,7 +560,7 @@ extern "C" int il_gail_step_population(const il_disc* descs_dev, const il_batch*
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
   il_batch zb = {};
   { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d), L), 256, lds, st>>>(*d, zb, zb, nullptr, il_gail_extra{}, descs_dev, policy_dev, expert_dev, GailSampler{}, 0); }
-  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<dim3((int)((P + 255) / 256), L), 256, 0, st>>>(*d, 1, descs_dev, 0); }
+  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<dim3((int)((P + 255) / 256), L), 256, 0, st>>>(*d, 1, descs_dev, 0, il_peer_bucket{}); }
   { IL_TRACE("k_gail_reward", st); k_gail_reward<<<dim3(nt, L), 256, lds, st>>>(*d, zb, nullptr, nullptr, nullptr, descs_dev, policy_dev, rewards_out_dev); }
   IL_CHECK_LAUNCH("il_gail_step_population");
   return IL_OK;

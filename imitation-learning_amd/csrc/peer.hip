@@ -33,6 +33,12 @@ extern "C" int64_t il_peer_region_bytes(int32_t world, int64_t n) {
   return (bytes + 255) / 256 * 256;
 }
 
+extern "C" int64_t il_peer_job_region_bytes(int32_t world, int64_t n, int32_t n_jobs) {
+  if (world < 1 || world > IL_PEER_MAX_RANKS || n < 1 || n_jobs < 1) return -1;
+  const int64_t bytes = 2 * (int64_t)world * peer_chunks(n) * IL_PEER_CHUNK_FLOATS * 4 + (int64_t)n_jobs * IL_PEER_FLAG_STRIDE * 4;
+  return (bytes + 255) / 256 * 256;
+}
+
 extern "C" int il_peer_window_alloc(int64_t bytes, void** window_host, unsigned char* handle_host, int32_t* kind_host) {
   IL_CHECK_ARG(bytes > 0 && window_host && handle_host && kind_host, "il_peer_window_alloc: bad arguments");
   *kind_host = 0;
@@ -88,6 +94,22 @@ __global__ __launch_bounds__(256) void k_peer_allreduce(il_peer_bucket x, float*
   }
 }
 
+// The stand-alone exchange of a JOB-mode bucket (n_jobs arrival lines): workgroup j pushes, releases, waits and averages its share of the bucket through the very
+// primitives the producing kernels use (peer_job_*), so PeerExchange's self-test and soak exercise that code path over the real windows before an update relies on it.
+__global__ __launch_bounds__(256) void k_peer_job_allreduce(il_peer_bucket x, float* __restrict__ bucket_) {
+  const int job = blockIdx.x, tid = threadIdx.x;
+  gfloat* bucket = (gfloat*)bucket_;
+  const int64_t n4 = x.n >> 2, per = (n4 + x.n_jobs - 1) / x.n_jobs, lo = (int64_t)job * per, hi = lo + per < n4 ? lo + per : n4;
+  const PeerJob pj = peer_job_begin(x, job);
+  for (int64_t i = lo + tid; i < hi; i += 256) { const f32x4 v = *(const gfloat4*)(bucket + 4 * i); peer_job_push4(x, pj, 4 * i, v); }
+  const bool tail = job == x.n_jobs - 1 && tid < (int)(x.n & 3);   // the last floats of a bucket that is not a whole number of 16-byte lanes
+  if (tail) peer_job_push1(x, pj, 4 * n4 + tid, bucket[4 * n4 + tid]);
+  peer_job_exchange(x, pj, job);
+  for (int64_t i = lo + tid; i < hi; i += 256) *(gfloat4*)(bucket + 4 * i) = peer_job_mean4(x, pj, 4 * i);
+  if (tail) bucket[4 * n4 + tid] = peer_job_mean1(x, pj, 4 * n4 + tid);
+  peer_job_end(x, pj, job);
+}
+
 extern "C" int il_peer_allreduce_mean(const il_peer_bucket* x, float* bucket, il_stream_t stream_) {
   IL_CHECK_ARG(x && bucket, "il_peer_allreduce_mean: null argument");
   IL_CHECK_ARG(x->world >= 1 && x->world <= IL_PEER_MAX_RANKS && x->rank >= 0 && x->rank < x->world, "il_peer_allreduce_mean: rank %d of %d", x->rank, x->world);
@@ -95,7 +117,8 @@ extern "C" int il_peer_allreduce_mean(const il_peer_bucket* x, float* bucket, il
   IL_CHECK_ARG((reinterpret_cast<uintptr_t>(bucket) & 15) == 0, "il_peer_allreduce_mean: the bucket must be 16-byte aligned");
   for (int r = 0; r < x->world; ++r) IL_CHECK_ARG(x->windows[r], "il_peer_allreduce_mean: window of rank %d is not mapped", r);
   hipStream_t st = (hipStream_t)stream_;
-  { IL_TRACE("k_peer_allreduce", st); k_peer_allreduce<<<(unsigned)peer_chunks(x->n), 256, 0, st>>>(*x, bucket); }
+  if (x->n_jobs > 0) { IL_TRACE("k_peer_job_allreduce", st); k_peer_job_allreduce<<<(unsigned)x->n_jobs, 256, 0, st>>>(*x, bucket); }
+  else { IL_TRACE("k_peer_allreduce", st); k_peer_allreduce<<<(unsigned)peer_chunks(x->n), 256, 0, st>>>(*x, bucket); }
   IL_CHECK_LAUNCH("il_peer_allreduce_mean");
   return IL_OK;
 }

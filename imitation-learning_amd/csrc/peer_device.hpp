@@ -116,3 +116,141 @@ __device__ __forceinline__ int peer_chunk_allreduce(const il_peer_bucket& x, con
   if (tid == 0) ((gu32*)x.epoch)[c] = e;   // every thread read epoch[c] before the first barrier
   return cnt;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The exchange INSIDE the kernel that produces the gradients (round 3; il_peer_bucket.n_jobs > 0). The data-parallel schedule of one update used to be the single-GPU
+// one cut open at its three optimiser steps: gradients to an arena, an exchange launch, an apply launch - eight launches on the critical stream instead of four. Here the
+// workgroup ("job") that holds a piece of the gradient in registers - a 32 x 32 block of a layer's dW in k_dw_adam, 256 elements of the slab sum in k_gail_reduce - pushes
+// what it holds into slot [parity][rank] of every rank's window at the parameter's own offset, releases ITS arrival line, waits for the same job of the other ranks and
+// averages the W slabs in rank order, then runs its AdamW epilogue as on one GPU. Same protocol, same parity argument and the same bounded wait as peer_chunk_allreduce
+// (a job pushes before it waits and only waits for the same job of the other ranks: no co-residency requirement, no deadlock); the region carries n_jobs arrival
+// lines instead of one per chunk. Same means as the exchange launch (rank-ordered sum / W of the same gradient values): the replicas stay bit-identical to each other
+// AND to the three-launch schedule.
+// ---------------------------------------------------------------------------------------------
+struct PeerJob { uint32_t e; int par; int64_t npad, slot_bytes; bool wt; };
+__device__ __forceinline__ PeerJob peer_job_begin(const il_peer_bucket& x, int job) {   // every thread that takes part; reads the job's epoch (advanced by peer_job_end)
+  PeerJob pj;
+  pj.e = ((gu32*)x.epoch)[job] + 1u; pj.par = (int)(pj.e & 1u);
+  pj.npad = peer_chunks(x.n) * IL_PEER_CHUNK_FLOATS; pj.slot_bytes = 2 * (int64_t)x.world * pj.npad * 4;
+  pj.wt = (x.flags & IL_PEER_WRITE_THROUGH) != 0;
+  return pj;
+}
+// one 16-byte lane / one float of this rank's gradient at float offset o of the bucket, into every window (remote ones first, each over its own link)
+__device__ __forceinline__ void peer_job_push4(const il_peer_bucket& x, const PeerJob& pj, int64_t o, const f32x4& v) {
+  const int W = x.world, me = x.rank;
+  const int64_t at = ((int64_t)pj.par * W + me) * pj.npad + o;
+  for (int i = 1; i <= W; ++i) {
+    const int r = (me + i) % W;
+    if (pj.wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), peer_rsrc((const void*)peer_slots(x, r), pj.slot_bytes), (int)(at * 4), 0, IL_PEER_SYS);
+    else *(gfloat4*)(peer_slots(x, r) + at) = v;
+  }
+}
+__device__ __forceinline__ void peer_job_push1(const il_peer_bucket& x, const PeerJob& pj, int64_t o, float v) {
+  const int W = x.world, me = x.rank;
+  const int64_t at = ((int64_t)pj.par * W + me) * pj.npad + o;
+  for (int i = 1; i <= W; ++i) {
+    const int r = (me + i) % W;
+    if (pj.wt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), peer_rsrc((const void*)peer_slots(x, r), pj.slot_bytes), (int)(at * 4), 0, IL_PEER_SYS);
+    else peer_slots(x, r)[at] = v;
+  }
+}
+__device__ __forceinline__ void peer_wait_expired(const il_peer_bucket& x) {
+  const long long n = __hip_atomic_fetch_add(reinterpret_cast<long long*>(x.status), 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  const long long host = reinterpret_cast<const long long*>(x.status)[1];
+  if (host) __hip_atomic_store((__attribute__((address_space(1))) long long*)host, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ALL threads of the workgroup (barriers inside): the pushes above are complete -> arrival words of `job` in every window -> all W arrival words in the own window
+__device__ __forceinline__ void peer_job_exchange(const il_peer_bucket& x, const PeerJob& pj, int job) {
+  const int tid = threadIdx.x, W = x.world, me = x.rank;
+  if (!pj.wt) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains (cf. peer_chunk_allreduce)
+  __syncthreads();
+  if (tid < W) {
+    uint32_t* flag = (uint32_t*)(peer_arrival(x, tid, pj.npad) + (int64_t)job * IL_PEER_FLAG_STRIDE + me);
+    if (pj.wt) __hip_atomic_store(flag, pj.e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else __hip_atomic_store(flag, pj.e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (tid < IL_WAVE) {
+    uint32_t* mine = (uint32_t*)(peer_arrival(x, me, pj.npad) + (int64_t)job * IL_PEER_FLAG_STRIDE);
+    const int limit = x.spin_limit > 0 ? x.spin_limit : IL_PEER_SPIN_LIMIT;
+    int spins = 0;
+    bool all = false;
+    for (;;) {
+      uint32_t f = pj.e;
+      if (tid < W) f = __hip_atomic_load(mine + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      all = __builtin_amdgcn_ballot_w64((int32_t)(f - pj.e) < 0) == 0ull;
+      if (all || ++spins > limit) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (!all && tid == 0) peer_wait_expired(x);
+  }
+  __syncthreads();
+  if (!pj.wt) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+// the mean over the ranks (rank-ordered sum / W, the expression of peer_chunk_allreduce) of the lane / float at offset o
+__device__ __forceinline__ f32x4 peer_job_mean4(const il_peer_bucket& x, const PeerJob& pj, int64_t o) {
+  const int W = x.world;
+  const int64_t at = (int64_t)pj.par * W * pj.npad + o;
+  f32x4 acc;
+  if (pj.wt) {
+    const __amdgpu_buffer_rsrc_t rs = peer_rsrc((const void*)peer_slots(x, x.rank), pj.slot_bytes);
+    acc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(at * 4), 0, IL_PEER_SYS));
+    for (int r = 1; r < W; ++r) {
+      const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((at + r * pj.npad) * 4), 0, IL_PEER_SYS));
+      acc[0] = __fadd_rn(acc[0], t[0]); acc[1] = __fadd_rn(acc[1], t[1]); acc[2] = __fadd_rn(acc[2], t[2]); acc[3] = __fadd_rn(acc[3], t[3]);
+    }
+  } else {
+    const gfloat* s0 = peer_slots(x, x.rank) + at;
+    acc = *(const gfloat4*)s0;
+    for (int r = 1; r < W; ++r) {
+      const f32x4 t = *(const gfloat4*)(s0 + r * pj.npad);
+      acc[0] = __fadd_rn(acc[0], t[0]); acc[1] = __fadd_rn(acc[1], t[1]); acc[2] = __fadd_rn(acc[2], t[2]); acc[3] = __fadd_rn(acc[3], t[3]);
+    }
+  }
+  const float fw = (float)W;
+  acc[0] = __fdiv_rn(acc[0], fw); acc[1] = __fdiv_rn(acc[1], fw); acc[2] = __fdiv_rn(acc[2], fw); acc[3] = __fdiv_rn(acc[3], fw);
+  return acc;
+}
+__device__ __forceinline__ float peer_job_mean1(const il_peer_bucket& x, const PeerJob& pj, int64_t o) {
+  const int W = x.world;
+  const int64_t at = (int64_t)pj.par * W * pj.npad + o;
+  float acc;
+  if (pj.wt) {
+    const __amdgpu_buffer_rsrc_t rs = peer_rsrc((const void*)peer_slots(x, x.rank), pj.slot_bytes);
+    acc = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(at * 4), 0, IL_PEER_SYS));
+    for (int r = 1; r < W; ++r) acc = __fadd_rn(acc, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)((at + r * pj.npad) * 4), 0, IL_PEER_SYS)));
+  } else {
+    const gfloat* s0 = peer_slots(x, x.rank) + at;
+    acc = s0[0];
+    for (int r = 1; r < W; ++r) acc = __fadd_rn(acc, s0[r * pj.npad]);
+  }
+  return __fdiv_rn(acc, (float)W);
+}
+__device__ __forceinline__ void peer_job_end(const il_peer_bucket& x, const PeerJob& pj, int job) { if (threadIdx.x == 0) ((gu32*)x.epoch)[job] = pj.e; }   // (every thread read it before the barriers of peer_job_exchange)
+// The same for ONE float held by ONE thread (Adam(log alpha) in the tail of k_dw_adam): no barrier, the thread orders its own accesses.
+__device__ __forceinline__ float peer_thread_allreduce1(const il_peer_bucket& x, int job, int64_t o, float v) {
+  const PeerJob pj = peer_job_begin(x, job);
+  const int W = x.world, me = x.rank;
+  peer_job_push1(x, pj, o, v);
+  if (!pj.wt) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int r = 0; r < W; ++r) {
+    uint32_t* flag = (uint32_t*)(peer_arrival(x, r, pj.npad) + (int64_t)job * IL_PEER_FLAG_STRIDE + me);
+    if (pj.wt) __hip_atomic_store(flag, pj.e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else __hip_atomic_store(flag, pj.e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  uint32_t* mine = (uint32_t*)(peer_arrival(x, me, pj.npad) + (int64_t)job * IL_PEER_FLAG_STRIDE);
+  const int limit = x.spin_limit > 0 ? x.spin_limit : IL_PEER_SPIN_LIMIT;
+  bool all = false;
+  for (int spins = 0; spins <= limit; ++spins) {
+    all = true;
+    for (int r = 0; r < W; ++r) all = all && (int32_t)(__hip_atomic_load(mine + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - pj.e) >= 0;
+    if (all) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (!all) peer_wait_expired(x);
+  if (!pj.wt) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  const float m = peer_job_mean1(x, pj, o);
+  ((gu32*)x.epoch)[job] = pj.e;
+  return m;
+}

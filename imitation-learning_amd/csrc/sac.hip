@@ -891,6 +891,9 @@ struct DwArgs {
   float* log_alpha; float* alpha_grad; il_adam alpha_opt; const float* alpha_part; int n_alpha_part;
   float* target; const float* polyak_src; int64_t polyak_n; double tau; uint32_t* noise_counter; int64_t* sync;
   float* pk_target; const float* pk_critic; int64_t pk_n;   // lane-ordered copies of the target / critic hidden layers (polyak is elementwise, so it commutes with the re-ordering)
+  // data-parallel: the gradient exchange of this optimiser step rides in its block jobs (peer_device.hpp "the exchange INSIDE the kernel that produces the gradients"):
+  // job = the block job's index (the log-alpha step: n_big_blocks); peer.world == 0: none
+  il_peer_bucket peer; int64_t peer_alpha_at;
 };
 
 __device__ __forceinline__ void adam_store(const DwArgs& a, const adam_consts& ac, int64_t o, float gr) {
@@ -1052,7 +1055,8 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
 #endif
       for (int i = i0; i < a.n_alpha_part; ++i) s += a.alpha_part[i];
       const float alpha = expf(a.log_alpha[0]);
-      const float gr = -(alpha) * (s / (float)a.batch);
+      float gr = -(alpha) * (s / (float)a.batch);
+      if (a.peer.world > 0) gr = peer_thread_allreduce1(a.peer, a.n_big_blocks, a.peer_alpha_at, gr);   // data-parallel: the mean over the ranks (its own arrival line behind the block jobs')
       if (a.grads_only) a.alpha_grad[0] = gr;
       else {
         const adam_consts ac = load_adam_consts(a.alpha_opt);
@@ -1282,7 +1286,7 @@ static inline int dw_block64_count(int H, int nets) { return (H / DWB) * (H / DW
 // and no wave-per-tile job is left: those were 72 % of the launch's line requests (32 KB of half-line gathers each).
 // `boff` >= 0: parameter offset of the bias of this dZ (only looked at by blocks with k0 == 0).
 __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restrict__ dzT, int Nvalid, const float* __restrict__ xT, int Kvalid, int n0, int k0, int64_t poff,
-                                           int64_t boff, float* __restrict__ pkf, float* __restrict__ pkb, float* smem) {
+                                           int64_t boff, float* __restrict__ pkf, float* __restrict__ pkb, float* smem, int pjob = -1) {
   float* Zs = smem; float* Xs = smem + DWS * DWS_LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int ti = wave >> 1, tq = wave & 1;   // this wave's tile of the block
@@ -1350,18 +1354,36 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
   }
   adam_consts ac = {};
   if (!a.grads_only) ac = load_adam_consts(a.opt);
+  float bsum = 0.f;
   if (do_bias && tid < 128) {   // (all 64 lanes of waves 0, 1 take part in the shuffles)
-    float bsum = (bs4[0] + bs4[1]) + (bs4[2] + bs4[3]);
+    bsum = (bs4[0] + bs4[1]) + (bs4[2] + bs4[3]);
     bsum += __shfl_xor(bsum, 1, 64);
     bsum += __shfl_xor(bsum, 2, 64);
-    if (bias_owner) {
-      const int64_t o = boff + n0 + bf;
-      if (a.grads_only) a.grads[o] = bsum;
-      else { adam_update(bpp, bsum, bmm, bvv, ac); a.params[o] = bpp; a.opt.m[o] = bmm; a.opt.v[o] = bvv; }
-    }
   }
   __syncthreads();
-  const f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + er * DWS_GLD + ec);
+  f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + er * DWS_GLD + ec);
+  if (a.peer.world > 0 && pjob >= 0) {   // data-parallel: this block's gradients (and bias gradients) become their mean over the ranks before the optimiser sees them
+    const PeerJob pj = peer_job_begin(a.peer, pjob);
+    if (full) peer_job_push4(a.peer, pj, eo, gv);
+    else if (en < Nvalid) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (ek + c < Kvalid) peer_job_push1(a.peer, pj, poff + (int64_t)en * Kvalid + ek + c, gv[c]);
+    }
+    if (bias_owner) peer_job_push1(a.peer, pj, boff + n0 + bf, bsum);
+    peer_job_exchange(a.peer, pj, pjob);
+    if (full) gv = peer_job_mean4(a.peer, pj, eo);
+    else if (en < Nvalid) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (ek + c < Kvalid) gv[c] = peer_job_mean1(a.peer, pj, poff + (int64_t)en * Kvalid + ek + c);
+    }
+    if (bias_owner) bsum = peer_job_mean1(a.peer, pj, boff + n0 + bf);
+    peer_job_end(a.peer, pj, pjob);
+  }
+  if (bias_owner) {
+    const int64_t o = boff + n0 + bf;
+    if (a.grads_only) a.grads[o] = bsum;
+    else { adam_update(bpp, bsum, bmm, bvv, ac); a.params[o] = bpp; a.opt.m[o] = bmm; a.opt.v[o] = bvv; }
+  }
   if (!full) {   // partial block (first / last layer): element-wise with guards
     if (en < Nvalid) {
 #pragma unroll
@@ -1396,7 +1418,7 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
 // One network's optimiser step as uniform block jobs: [0, nbh^2) the H x H layer (bias 2 with the k0 = 0 blocks), then nbh x kin blocks of layer 1 (bias 1), then
 // nout x nbh blocks of layer 3 (bias 3). Returns false when `job` is past the network's list.
 __host__ __device__ static inline int dw_block_jobs(int IN, int H, int OUT) { const int nbh = H / DWS; return nbh * nbh + nbh * ((IN + DWS - 1) / DWS) + ((OUT + DWS - 1) / DWS) * nbh; }
-__device__ __forceinline__ void dw_block_job(const DwArgs& a, int net, int job, float* smem) {
+__device__ __forceinline__ void dw_block_job(const DwArgs& a, int net, int job, float* smem, int pjob = -1) {
   const int IN = a.in_dim, H = a.hidden, OUT = a.out_dim, nbh = H / DWS, kin = (IN + DWS - 1) / DWS;
   const int64_t pbase = (int64_t)net * a.net_stride;
   const int64_t oW1 = pbase, ob1 = oW1 + (int64_t)H * IN, oW2 = ob1 + H, ob2 = oW2 + (int64_t)H * H, oW3 = ob2 + H, ob3 = oW3 + (int64_t)OUT * H;
@@ -1411,13 +1433,13 @@ __device__ __forceinline__ void dw_block_job(const DwArgs& a, int net, int job, 
       const int x = job & 7, slot = job >> 3;
       nb = 2 * (x >> 1) + (slot >> 2); kb = 4 * (x & 1) + (slot & 3);
     }
-    dw_block32(a, dz2, H, h1, H, nb * DWS, kb * DWS, oW2, ob2, a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem);
+    dw_block32(a, dz2, H, h1, H, nb * DWS, kb * DWS, oW2, ob2, a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem, pjob);
     return;
   }
   job -= nbh * nbh;
-  if (job < nbh * kin) { dw_block32(a, dz1, H, a.x0 + net * a.x0_net_stride, IN, (job / kin) * DWS, (job % kin) * DWS, oW1, ob1, nullptr, nullptr, smem); return; }
+  if (job < nbh * kin) { dw_block32(a, dz1, H, a.x0 + net * a.x0_net_stride, IN, (job / kin) * DWS, (job % kin) * DWS, oW1, ob1, nullptr, nullptr, smem, pjob); return; }
   job -= nbh * kin;
-  dw_block32(a, a.dz3 + net * a.dz3_net_stride, OUT, h2, H, (job / nbh) * DWS, (job % nbh) * DWS, oW3, ob3, nullptr, nullptr, smem);
+  dw_block32(a, a.dz3 + net * a.dz3_net_stride, OUT, h2, H, (job / nbh) * DWS, (job % nbh) * DWS, oW3, ob3, nullptr, nullptr, smem, pjob);
 }
 static inline int dw_block32_count(int H, int nets) { return (H / DWS) * (H / DWS) * nets; }
 static inline bool dw_block32_fits(int H, int B) { return H % DWS == 0 && B % DWS_ROWS == 0; }
@@ -1429,7 +1451,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
     const int bx = (int)blockIdx.x;
     if (bx < a.n_big_blocks) {
       const int per_net = dw_block_jobs(a.in_dim, a.hidden, a.out_dim);
-      dw_block_job(a, bx / per_net, bx % per_net, smem);
+      dw_block_job(a, bx / per_net, bx % per_net, smem, bx);
       IL_TL_END(a.log_alpha ? 2 : 1);
       return;
     }
@@ -1633,9 +1655,32 @@ extern "C" int32_t il_gail_step_workgroups(const il_disc* d) {
   return (int32_t)((disc_layout(d->state_dim + (d->state_only ? 0 : d->action_dim), d->hidden, d->spectral_norm).P + 255) / 256);
 }
 
-extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const il_disc* relabel, float* rewards_out,
-                                    const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream_) {
+// data-parallel with the exchange inside the optimiser launches (il_sac_update_gather_peer): bucket sizes and job counts a caller lays its peer regions out for
+static int64_t round_up4(int64_t n) { return (n + 3) & ~(int64_t)3; }
+extern "C" int64_t il_sac_peer_bucket_floats(const il_sac* d, int32_t which) {   // 0: the twin critic's arena; 1: the actor's arena + one 16-byte slot whose first float is log alpha's gradient
+  if (!d) return 0;
+  return which == 0 ? 2 * net_stride(d->state_dim + d->action_dim, d->hidden, 1) : round_up4(mlp_numel(d->state_dim, d->hidden, 2 * d->action_dim)) + 4;
+}
+extern "C" int32_t il_sac_peer_jobs(const il_sac* d, int32_t which) {   // arrival lines of the bucket (0: this shape's optimiser launches have no block form: use the exchange launches)
+  if (!d || !(dw_block32_on() && d->hidden % 32 == 0 && d->batch % 128 == 0)) return 0;
+  return which == 0 ? 2 * dw_block_jobs_n(d->state_dim + d->action_dim, d->hidden, 1) : dw_block_jobs_n(d->state_dim, d->hidden, 2 * d->action_dim) + 1;
+}
+static int check_peer_jobs(const il_peer_bucket* x, int64_t n, int32_t jobs, const char* what) {
+  IL_CHECK_ARG(x->world >= 1 && x->world <= IL_PEER_MAX_RANKS && x->rank >= 0 && x->rank < x->world && x->epoch && x->status && (x->window_offset & 255) == 0, "il_sac_update_gather_peer: bad %s descriptor", what);
+  IL_CHECK_ARG(jobs > 0, "il_sac_update_gather_peer: this shape's optimiser launches have no block form (il_sac_peer_jobs == 0): use the exchange launches");
+  IL_CHECK_ARG(x->n == n && x->n_jobs >= jobs, "il_sac_update_gather_peer: the %s bucket must hold %lld floats and %d arrival lines (got %lld, %d)", what, (long long)n, jobs, (long long)x->n, x->n_jobs);
+  for (int r = 0; r < x->world; ++r) IL_CHECK_ARG(x->windows[r], "il_sac_update_gather_peer: window of rank %d is not mapped", r);
+  return IL_OK;
+}
+static int sac_update_gather_impl(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const il_disc* relabel, float* rewards_out,
+                                  const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, const il_peer_bucket* peer_critic,
+                                  const il_peer_bucket* peer_actor, il_stream_t stream_) {
   if (int rc = check_sac(d, rows)) return rc;
+  if (peer_critic || peer_actor) {
+    IL_CHECK_ARG(peer_critic && peer_actor && !(flags & IL_FLAG_GRADS_ONLY), "il_sac_update_gather_peer: both buckets, and no IL_FLAG_GRADS_ONLY (the optimiser steps run inside)");
+    if (int rc = check_peer_jobs(peer_critic, il_sac_peer_bucket_floats(d, 0), il_sac_peer_jobs(d, 0), "critic")) return rc;
+    if (int rc = check_peer_jobs(peer_actor, il_sac_peer_bucket_floats(d, 1), il_sac_peer_jobs(d, 1), "actor")) return rc;
+  }
   ChainRelabel rl = {};
   if (relabel) {
     IL_CHECK_ARG(d->sync && relabel->sync == d->sync, "il_sac_update_gather: the inline relabel needs the il_sync counters shared with the discriminator");
@@ -1662,6 +1707,7 @@ extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const
   if (chain_xcd_nets(nt) && G <= 2 * nt) { rl.xcd_nets = 1; rl.gather_wgs = G; }
   { IL_TRACE("k_sac_chain", st); k_sac_chain<<<rl.xcd_nets ? 8 * nt : 6 * nt + G, tile_threads(H), lds, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl); }
   DwArgs ca = critic_dw_args(d, flags);
+  if (peer_critic) ca.peer = *peer_critic;
   { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
   if (flags & IL_FLAG_GRADS_ONLY) {   // data-parallel: stop at the critic gradients (critic_grad); the caller all-reduces them and continues with il_sac_dp_phase(rows, 2) and (rows, 3)
     IL_CHECK_LAUNCH("il_sac_update_gather");
@@ -1669,9 +1715,20 @@ extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const
   }
   { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *rows, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
   DwArgs aa = actor_dw_args(d, rows, flags);
+  if (peer_actor) { aa.peer = *peer_actor; aa.peer_alpha_at = il_sac_peer_bucket_floats(d, 1) - 4; }
   { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + IL_TAIL_BLOCKS, 256, 0, st>>>(aa); }
   IL_CHECK_LAUNCH("il_sac_update_gather");
   return IL_OK;
+}
+extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const il_disc* relabel, float* rewards_out,
+                                    const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream_) {
+  return sac_update_gather_impl(d, rows, ring, rewards, relabel, rewards_out, eps_next, eps_cur, out_logp, out_q, flags, nullptr, nullptr, stream_);
+}
+extern "C" int il_sac_update_gather_peer(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const il_disc* relabel, float* rewards_out,
+                                         const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, const il_peer_bucket* peer_critic,
+                                         const il_peer_bucket* peer_actor, il_stream_t stream_) {
+  IL_CHECK_ARG(peer_critic && peer_actor, "il_sac_update_gather_peer: null peer descriptor");
+  return sac_update_gather_impl(d, rows, ring, rewards, relabel, rewards_out, eps_next, eps_cur, out_logp, out_q, flags, peer_critic, peer_actor, stream_);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -188,9 +188,10 @@ class PeerExchange:
   per bucket, hipIpc handles all-gathered through the host-side process group, every rank maps the others' windows. `create()` returns None - on EVERY rank - when any rank
   cannot set it up or the self-test (known patterns through the real kernel, several epochs) fails anywhere; the caller then keeps the collectives."""
 
-  def __init__(self, sizes: dict, device, group=None, spin_limit: int = 0):
+  def __init__(self, sizes: dict, device, group=None, spin_limit: int = 0, jobs: Optional[dict] = None):
     L = _lib.lib()
     self.group, self.device = group, device
+    self.jobs = {k: int(v) for k, v in (jobs or {}).items() if v}   # buckets whose exchange rides in the kernel producing the gradients: arrival lines per producing workgroup
     self.world = dist.get_world_size(group) if dist.is_initialized() else 1
     self.rank = dist.get_rank(group) if dist.is_initialized() else 0
     if self.world > _lib.IL_PEER_MAX_RANKS:
@@ -204,7 +205,7 @@ class PeerExchange:
     offsets, total = {}, 0
     for k, n in self.sizes.items():
       offsets[k] = total
-      total += int(L.il_peer_region_bytes(self.world, n))
+      total += int(L.il_peer_job_region_bytes(self.world, n, self.jobs[k]) if k in self.jobs else L.il_peer_region_bytes(self.world, n))
     w, handle = C.c_void_p(), C.create_string_buffer(_lib.IL_PEER_HANDLE_BYTES)
     with torch.cuda.device(device):
       # Every rank takes part in the handle exchange whether or not its own allocation worked (a rank that raised before the collective would leave the others waiting
@@ -236,19 +237,21 @@ class PeerExchange:
         raise
     self.status = torch.zeros(2, dtype=torch.int64, device=device)
     for k, n in self.sizes.items():
-      epoch = torch.zeros((n + _lib.IL_PEER_CHUNK_FLOATS - 1) // _lib.IL_PEER_CHUNK_FLOATS, dtype=torch.int32, device=device)
-      d = _lib.PeerBucket(rank=self.rank, world=self.world, n=n, window_offset=offsets[k], epoch=epoch.data_ptr(), status=self.status.data_ptr(), spin_limit=int(spin_limit))
+      epoch = torch.zeros(self.jobs.get(k) or (n + _lib.IL_PEER_CHUNK_FLOATS - 1) // _lib.IL_PEER_CHUNK_FLOATS, dtype=torch.int32, device=device)
+      d = _lib.PeerBucket(rank=self.rank, world=self.world, n=n, window_offset=offsets[k], epoch=epoch.data_ptr(), status=self.status.data_ptr(), spin_limit=int(spin_limit),
+                          n_jobs=self.jobs.get(k, 0))
       for r, wp in enumerate(windows): d.windows[r] = wp
       self.desc[k] = d
       self._keep.append(epoch)
     torch.cuda.synchronize(device)
 
   @classmethod
-  def create(cls, sizes: dict, device, group=None, verify_rounds: int = 3, soak_rounds: Optional[int] = None):
-    """Collective. A PeerExchange that passed its self-test AND its soak test (`soak`) on every rank, or None on every rank."""
+  def create(cls, sizes: dict, device, group=None, verify_rounds: int = 3, soak_rounds: Optional[int] = None, jobs: Optional[dict] = None):
+    """Collective. A PeerExchange that passed its self-test AND its soak test (`soak`) on every rank, or None on every rank. `jobs`: buckets laid out for the exchange inside
+    the producing kernels (name -> arrival lines); the self-test and the soak drive them through the same device functions (k_peer_job_allreduce)."""
     x, err = None, None
     try:
-      x = cls(sizes, device, group)
+      x = cls(sizes, device, group, jobs=jobs)
     except Exception as e:   # no IPC between these processes, no fine-grained memory, ...: fall back together
       err = e
     if dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -400,6 +403,14 @@ class DataParallelUpdate:
       self.side_group = dist.new_group(ranks=None if group is None else dist.get_process_group_ranks(group), backend=dist.get_backend(group))
     self.graph = self.graph_side = None
     self._warm_collectives_pending = True
+    # The exchanges INSIDE the optimiser launches (il_sac_update_gather_peer, il_gail_disc_step_draw_peer): the update is then the launch sequence of ONE GPU - two
+    # launches on the discriminator's stream, four on the main one - instead of three + eight. Needs the hand-off schedule with the resident sampler, the block form of
+    # the optimiser launches for this shape, and the peer windows (decided collectively in _setup_peer_exchange). IL_DP_FUSED=0: the exchange launches.
+    L = _lib.lib()
+    self._fused_jobs = dict(disc=int(L.il_gail_step_workgroups(C.byref(plan.disc))), critic=int(L.il_sac_peer_jobs(C.byref(plan.sac), 0)), actor=int(L.il_sac_peer_jobs(C.byref(plan.sac), 1))) \
+        if plan.algorithm == 'GAIL' else {}
+    mine = bool(self.handoff and plan.resident_sampler and self._fused_jobs and all(self._fused_jobs.values()) and os.environ.get('IL_DP_FUSED', '1') != '0')
+    self.fused = _agree(mine, group) if self.handoff else False
     self.peer = None   # PeerExchange once the first run() has set it up (collective); None = torch.distributed all-reduces
     self.peer_note = None   # why the peer-window exchange is not in use, when it was asked for
     ao, to = plan._keep[4], plan._keep[6]
@@ -438,11 +449,19 @@ class DataParallelUpdate:
     mode = os.environ.get('IL_PEER_EXCHANGE', '1')
     world = dist.get_world_size(self.group) if dist.is_initialized() else 1
     if mode == '0' or (world == 1 and mode not in ('force', 'require')):
+      self.fused = False   # (the fused form lives on the peer windows)
       return
     sizes = dict(disc=self.disc_bucket.numel() if self.disc_bucket is not None else 0, critic=self.critic_bucket.numel(), actor=self.actor_bucket.numel())
-    self.peer = PeerExchange.create(sizes, self.plan.rows.device, self.group)
+    jobs = None
+    if self.fused:   # the same three buckets laid out by PARAMETER offset with one arrival line per producing workgroup (the actor's carries log alpha's gradient in its last lane)
+      L = _lib.lib()
+      sizes = dict(disc=sizes['disc'], critic=int(L.il_sac_peer_bucket_floats(C.byref(self.plan.sac), 0)), actor=int(L.il_sac_peer_bucket_floats(C.byref(self.plan.sac), 1)))
+      jobs = dict(self._fused_jobs)
+    self.peer = PeerExchange.create(sizes, self.plan.rows.device, self.group, jobs=jobs)
     if self.peer is None:
       self.peer_note = 'set-up, self-test or soak test of the peer-window exchange failed on some rank: torch.distributed all-reduces'
+    self.fused = bool(self.fused and self.peer is not None)
+    self.plan.peer_desc = self.peer.desc if self.fused else None
     if self.peer is None and mode == 'require':
       raise RuntimeError('IL_PEER_EXCHANGE=require: the peer-window exchange could not be set up or failed its self-test on some rank')
 
@@ -486,7 +505,7 @@ class DataParallelUpdate:
   def exchange_name(self) -> str:
     """What moves the gradients: 'peer write-through' | 'peer fences' (il_peer_allreduce_mean over peer-mapped windows) | 'rccl' | 'gloo' | 'none' (one rank, no exchange)."""
     if self.peer is not None:
-      return 'peer write-through' if self.peer.form else 'peer fences'
+      return ('peer write-through' if self.peer.form else 'peer fences') + (', inside the optimiser launches' if self.fused else '')
     if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and os.environ.get('IL_FORCE_ALLREDUCE') != '1'):
       return 'none'
     return 'rccl' if dist.get_backend(self.group) == 'nccl' else dist.get_backend(self.group)
@@ -498,6 +517,7 @@ class DataParallelUpdate:
     if self.peer is not None:
       self.peer.close(collective=True)
     self.peer, self.peer_note = None, why
+    self.fused, self.plan.peer_desc = False, None
     self.graph = self.graph_side = None
 
   def exchange_timeouts(self) -> int:
@@ -566,6 +586,9 @@ class DataParallelUpdate:
   def _enqueue_side(self):
     """Discriminator branch: [resident index draw] -> gradients from the rings through the indices -> all-reduce (own communicator) -> AdamW, which signals [IL_SYNC_PARAMS]."""
     p, L = self.plan, _lib.lib()
+    if self.fused:   # the exchange rides in the reduce + AdamW launch, which signals [IL_SYNC_PARAMS] as on one GPU
+      p._disc_step(_lib.IL_FLAG_GAIL_CLOSE_EPOCH)
+      return
     p._disc_step(_lib.IL_FLAG_GRADS_ONLY)   # the index draw rides in this launch when the sampler is resident
     self._exchange('disc', self.side_group)
     _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
@@ -574,6 +597,10 @@ class DataParallelUpdate:
     """SAC branch: [index draw] -> forward + critic loss chained per tile with the rewards relabelled inline (waits on the device for the discriminator's all-reduced step)
     -> critic gradients -> all-reduce -> AdamW(critic) + policy loss + actor gradients -> all-reduce -> AdamW(actor), Adam(alpha), polyak."""
     p, L = self.plan, _lib.lib()
+    if self.fused:   # the single-GPU branch; its two optimiser launches carry the critic's and the actor's exchange (plan.peer_desc)
+      p._enqueue_sac_branch()
+      p._prepared = True
+      return
     resident = p.resident_sampler
     if not resident:
       p.sample_all()

@@ -357,6 +357,7 @@ class UpdatePlan:
     self.overlap, self.side = overlap, (torch.cuda.Stream() if self._two_stream else None)
     self.algorithm, self.B, dev = algorithm, batch_size, actor.flat.device
     self.memory, self.expert_memory, self.device_index_draw = memory, expert_memory, device_index_draw
+    self.peer_desc = None   # parallel.DataParallelUpdate (fused form): il_peer_bucket descriptors of the exchanges that ride in this plan's optimiser launches
     self.has_expert, self.mix_expert, self.bc_aux = expert_memory is not None, bool(mix_expert), bool(bc_aux)
     self.discriminator = discriminator
     self.rows = torch.empty(batch_size, memory.row, device=dev); self.idx = torch.empty(batch_size, dtype=torch.int32, device=dev)
@@ -626,6 +627,10 @@ class UpdatePlan:
     if self.resident_sampler:
       m, e = self.memory, self.expert_memory
       mt = m.stream().device_state(m.device)
+      if self.peer_desc is not None:   # data-parallel: the gradient exchange rides in the reduce + AdamW launch (parallel.DataParallelUpdate, fused form)
+        _lib.check(L.il_gail_disc_step_draw_peer(C.byref(self.disc), C.byref(rp), C.byref(re_), _lib.ptr(mt), _lib.ptr(m._ring_state), _lib.ptr(self.idx), _lib.ptr(e._ring_state),
+                                                 _lib.ptr(self.eidx), flags, C.byref(self.peer_desc['disc']), st))
+        return
       _lib.check(L.il_gail_disc_step_draw(C.byref(self.disc), C.byref(rp), C.byref(re_), _lib.ptr(mt), _lib.ptr(m._ring_state), _lib.ptr(self.idx), _lib.ptr(e._ring_state), _lib.ptr(self.eidx),
                                           flags, st))
     else:
@@ -651,6 +656,11 @@ class UpdatePlan:
     if self.ring_mode:
       inline = self.inline_relabel
       flags = self.prepared_flag() | (_lib.IL_FLAG_SAC_WAIT_INDICES if resident else 0)
+      if self.peer_desc is not None:   # data-parallel: the critic's and the actor's exchange ride in the two optimiser launches
+        _lib.check(_lib.lib().il_sac_update_gather_peer(C.byref(self.sac), C.byref(self.pb), C.byref(self._ring_batches()[0]), None if inline else _lib.ptr(self.rewards),
+                                                        C.byref(self.disc) if inline else None, _lib.ptr(self.rewards) if inline else None, None, None,
+                                                        _lib.ptr(self.logp), _lib.ptr(self.q), flags, C.byref(self.peer_desc['critic']), C.byref(self.peer_desc['actor']), _lib.stream_ptr()))
+        return
       _lib.check(_lib.lib().il_sac_update_gather(C.byref(self.sac), C.byref(self.pb), C.byref(self._ring_batches()[0]), None if inline else _lib.ptr(self.rewards),
                                                  C.byref(self.disc) if inline else None, _lib.ptr(self.rewards) if inline else None, None, None,
                                                  _lib.ptr(self.logp), _lib.ptr(self.q), flags, _lib.stream_ptr()))

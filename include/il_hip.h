@@ -549,9 +549,14 @@ typedef struct il_peer_bucket {
   int64_t* status;                     /* local device int64[2], zero-initialised: [0] += 1 per wait that gave up (must stay 0); [1] = address of a host-mapped int64 that
                                           receives the new count whenever [0] moves (0 = none): the host notices without synchronising */
   int32_t spin_limit, flags;           /* polls before a wait gives up (0 = IL_PEER_SPIN_LIMIT); IL_PEER_WRITE_THROUGH or 0 */
+  int32_t n_jobs, reserved;            /* 0: a region of il_peer_region_bytes (one arrival line per chunk: il_peer_allreduce_mean). > 0: a region of il_peer_job_region_bytes with
+                                          n_jobs arrival lines, for an exchange that rides in the kernel PRODUCING the gradients (il_sac_update_gather_peer, il_gail_disc_step_draw_peer);
+                                          `epoch` then has n_jobs entries */
 } il_peer_bucket;
 /* bytes of a bucket's region: slots float[2 parities][world][n rounded up to chunks] + arrival words; -1 on bad arguments */
 int64_t il_peer_region_bytes(int32_t world, int64_t n);
+/* the same with n_jobs arrival lines (one per producing workgroup) instead of one per chunk */
+int64_t il_peer_job_region_bytes(int32_t world, int64_t n, int32_t n_jobs);
 /* zero-filled uncached (failing that, fine-grained) device allocation on the current device + its IPC handle (IL_PEER_HANDLE_BYTES bytes, host) */
 int il_peer_window_alloc(int64_t bytes, void** window_host, unsigned char* handle_host, int32_t* kind_host);   /* *kind_host: 0 uncached, 1 fine-grained */
 /* maps another rank's window (a handle produced by il_peer_window_alloc in ANOTHER process) into this process */
@@ -567,6 +572,21 @@ int il_peer_allreduce_mean(const il_peer_bucket* x, float* bucket, il_stream_t s
  * point. x = the descriptor of the critic bucket (phase 2: il_sac.critic_grad, 2 * il_mlp_stride floats) or of the actor bucket (phase 3: il_sac.actor_grad with
  * il_sac.alpha_grad inside the same allocation, parallel.GradBuckets). Bit-identical to il_peer_allreduce_mean(x, bucket) followed by il_sac_dp_phase. */
 int il_sac_dp_phase_peer(const il_sac* d, const il_batch* batch, int32_t phase, float* out_logp, float* out_q, uint32_t flags, const il_peer_bucket* x, il_stream_t stream);
+
+/* Data-parallel update with NO extra launch: il_sac_update_gather whose two optimiser launches carry the gradient exchange. The workgroup that holds a 32 x 32 block of
+ * a layer's dW (or a bias slice, or log alpha's gradient) pushes it into every rank's window at the parameter's own offset, waits for the same workgroup of the other
+ * ranks, averages the slabs in rank order and runs its AdamW epilogue on the mean: the launch sequence of ONE GPU (train.py:171-203 per rank), replicas bit-identical to
+ * each other and to il_sac_update_gather(IL_FLAG_GRADS_ONLY) + il_peer_allreduce_mean + il_sac_dp_phase. Buckets: il_sac_peer_bucket_floats(d, 0 | 1) floats,
+ * il_sac_peer_jobs(d, 0 | 1) arrival lines (0: this shape has no block form - use the exchange launches), regions of il_peer_job_region_bytes. Every rank must issue the
+ * same sequence of calls. */
+int64_t il_sac_peer_bucket_floats(const il_sac* d, int32_t which);   /* 0 critic, 1 actor (+ log alpha) */
+int32_t il_sac_peer_jobs(const il_sac* d, int32_t which);
+int il_sac_update_gather_peer(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const il_disc* relabel, float* rewards_out,
+                              const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, const il_peer_bucket* peer_critic,
+                              const il_peer_bucket* peer_actor, il_stream_t stream);
+/* il_gail_disc_step_draw whose reduce + AdamW launch carries the exchange of the discriminator's gradient (bucket: the parameter count, il_gail_step_workgroups(d) arrival lines) */
+int il_gail_disc_step_draw_peer(const il_disc* d, const il_batch* policy, const il_batch* expert, uint32_t* mt_state_dev, const int64_t* ring_state_a, int32_t* idx_a,
+                                const int64_t* ring_state_b, int32_t* idx_b, uint32_t flags, const il_peer_bucket* peer, il_stream_t stream);
 
 /* sizeof() of the descriptor structs in this build (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red,
  * 7 il_dril, 8 il_disc_shaped, 9 il_disc_deep, 10 il_peer_bucket; -1 otherwise): lets a binding verify its own struct definitions. */

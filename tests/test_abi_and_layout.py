@@ -127,7 +127,12 @@ def test_peer_window_layout():
       got = L.il_peer_region_bytes(world, n)
       assert got % 256 == 0 and want <= got < want + 256, (world, n, got, want)
   assert L.il_peer_region_bytes(0, 10) == -1 and L.il_peer_region_bytes(17, 10) == -1 and L.il_peer_region_bytes(2, 0) == -1
-  assert C.sizeof(_lib.PeerBucket) == 4 + 4 + 8 + 8 + 16 * 8 + 8 + 8 + 4 + 4
+  for world, n, jobs in ((2, 1665, 7), (8, 144904, 160), (16, 73748, 81)):   # the layout for exchanges inside the producing kernels: one arrival line per producing workgroup
+    want = 2 * world * -(-n // CH) * CH * 4 + jobs * 128
+    got = L.il_peer_job_region_bytes(world, n, jobs)
+    assert got % 256 == 0 and want <= got < want + 256, (world, n, jobs, got, want)
+  assert L.il_peer_job_region_bytes(2, 10, 0) == -1 and L.il_peer_job_region_bytes(0, 10, 1) == -1
+  assert C.sizeof(_lib.PeerBucket) == 4 + 4 + 8 + 8 + 16 * 8 + 8 + 8 + 4 + 4 + 4 + 4
 
 
 def test_reference_cpu_baseline_runner_reports_every_configuration():

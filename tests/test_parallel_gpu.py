@@ -37,7 +37,7 @@ for k in range(4):
 out = {f't{i}': (n.flat if hasattr(n, 'flat') else n).detach().cpu().numpy() for i, n in enumerate(nets)}
 out['sn'] = nets[4].sn.cpu().numpy(); out['idx0'] = idx0; out['logp'] = plan.logp.cpu().numpy()
 out['handoff'] = np.array([int(dp.handoff), plan.sync_timeouts()])
-out['peer'] = np.array([int(dp.peer is not None), dp.exchange_timeouts()])
+out['peer'] = np.array([int(dp.peer is not None), dp.exchange_timeouts(), int(dp.fused)])
 np.savez(os.path.join(sys.argv[2], f'rank{rank}.npz'), **out)
 dist.barrier(); dist.destroy_process_group()
 '''
@@ -56,17 +56,20 @@ def _launch(args, cwd, timeout=600, **extra_env):
   return r
 
 
-@pytest.mark.parametrize('algorithm,handoff,peer', [('GAIL', '1', '1'), ('GAIL', '0', '1'), ('SAC', '0', '1'), ('GAIL', '0', 'in_apply')])
+@pytest.mark.parametrize('algorithm,handoff,peer', [('GAIL', '1', 'fused'), ('GAIL', '1', '1'), ('GAIL', '0', '1'), ('SAC', '0', '1'), ('GAIL', '0', 'in_apply')])
 def test_two_ranks_keep_bit_identical_replicas(tmp_path, algorithm, handoff, peer):
   """handoff = '1': the device-side hand-off schedule of DataParallelUpdate (resident index draw, inline relabel, one communicator per branch); '0': stream dependencies.
-  The gradient exchange runs over peer-mapped windows (csrc/peer.hip; the two processes map each other's window through hipIpc exactly as two GPUs would): peer = '1' with one
-  il_peer_allreduce_mean launch per sync point, 'in_apply' with the critic / actor exchanges inside the apply launches (il_sac_dp_phase_peer, IL_PEER_APPLY=1); gloo all-reduces
-  are covered by test_peer_exchange_equals_the_collective."""
+  The gradient exchange runs over peer-mapped windows (csrc/peer.hip; the two processes map each other's window through hipIpc exactly as two GPUs would): peer = 'fused' inside
+  the optimiser launches (il_sac_update_gather_peer / il_gail_disc_step_draw_peer: the launch sequence of one GPU - the default with the hand-off), '1' with one
+  il_peer_allreduce_mean launch per sync point (IL_DP_FUSED=0), 'in_apply' with the critic / actor exchanges inside the apply launches (il_sac_dp_phase_peer, IL_PEER_APPLY=1);
+  gloo all-reduces are covered by test_peer_exchange_equals_the_collective."""
   script = tmp_path / 'worker.py'
   script.write_text(WORKER)
-  _launch([str(script), ROOT, str(tmp_path), algorithm], str(tmp_path), IL_DP_HANDOFF=handoff, IL_PEER_EXCHANGE='require', IL_PEER_APPLY='1' if peer == 'in_apply' else '0')
+  _launch([str(script), ROOT, str(tmp_path), algorithm], str(tmp_path), IL_DP_HANDOFF=handoff, IL_PEER_EXCHANGE='require', IL_PEER_APPLY='1' if peer == 'in_apply' else '0',
+          IL_DP_FUSED='1' if peer == 'fused' else '0')
   r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
   assert [int(r0['peer'][0]), int(r1['peer'][0])] == [1, 1]
+  assert [int(r0['peer'][2]), int(r1['peer'][2])] == [int(peer == 'fused')] * 2
   assert int(r0['peer'][1]) == 0 and int(r1['peer'][1]) == 0, 'a device-side wait of the peer-window exchange expired'
   if algorithm == 'GAIL':
     assert [int(r0['handoff'][0]), int(r1['handoff'][0])] == [int(handoff)] * 2
@@ -76,6 +79,27 @@ def test_two_ranks_keep_bit_identical_replicas(tmp_path, algorithm, handoff, pee
     assert np.isfinite(r0[k]).all()
     np.testing.assert_array_equal(r0[k], r1[k], err_msg=f'replica tensor {k} differs between the ranks')
   assert not np.array_equal(r0['idx0'], r1['idx0']) and not np.array_equal(r0['logp'], r1['logp']), 'the ranks must train on different data (rank-offset seeds, own shards)'
+
+
+def test_exchange_inside_the_optimiser_launches_equals_the_exchange_launches(tmp_path):
+  """Same seeds, same shards, four updates of the hand-off schedule: with the gradient exchange inside the producing kernels (block jobs of k_dw_adam, workgroups of
+  k_gail_reduce) every replica tensor keeps the bits it has with one exchange launch per sync point - the same rank-ordered means of the same gradients."""
+  script = tmp_path / 'worker.py'
+  script.write_text(WORKER)
+  res = {}
+  for fused in ('1', '0'):
+    d = tmp_path / f'fused_{fused}'
+    d.mkdir()
+    _launch([str(script), ROOT, str(d), 'GAIL'], str(tmp_path), IL_DP_HANDOFF='1', IL_PEER_EXCHANGE='require', IL_DP_FUSED=fused)
+    res[fused] = [np.load(d / 'rank0.npz'), np.load(d / 'rank1.npz')]
+    for r in res[fused]:
+      assert int(r['peer'][1]) == 0, 'a device-side wait of the peer-window exchange expired'
+      if r['handoff'][1]:
+        pytest.skip('bounded device-side waits expired: the two ranks of this test SHARE one GPU and were time-sliced against each other')
+  assert int(res['1'][0]['peer'][2]) == 1 and int(res['0'][0]['peer'][2]) == 0
+  for rank in (0, 1):
+    for k in ('t0', 't1', 't2', 't3', 't4', 'sn', 'logp'):
+      np.testing.assert_array_equal(res['1'][rank][k], res['0'][rank][k], err_msg=f'rank {rank}, {k}')
 
 
 def test_peer_exchange_equals_the_collective(tmp_path):
@@ -100,8 +124,8 @@ import numpy as np, torch
 import torch.distributed as dist
 from imitation_learning_amd import parallel
 rank, _, dev = parallel.init_from_env(2, 'gloo')
-sizes = dict(a=1, b=5, c=1665, d=2048, e=2049, f=144904)
-x = parallel.PeerExchange.create(sizes, dev)
+sizes = dict(a=1, b=5, c=1665, d=2048, e=2049, f=144904, ja=1, jb=7, jc=1665, jf=144904)
+x = parallel.PeerExchange.create(sizes, dev, jobs=dict(ja=1, jb=3, jc=7, jf=160))   # j*: arrival lines per producing workgroup (the form the optimiser launches use), through k_peer_job_allreduce
 assert x is not None, 'peer-window set-up or self-test failed'
 g = torch.Generator(device='cpu'); g.manual_seed(7 + rank)
 bad = 0
@@ -150,7 +174,7 @@ def test_peer_exchange_kernel_two_ranks(tmp_path):
     assert (bad, graph_bad, timeouts) == (0, 0, 0), f'rank {r}: {bad} mismatching exchanges, {graph_bad} mismatching graph replays, {timeouts} expired waits'
     assert form0 == 1, 'the windows of an MI355X are uncached allocations: the set-up ladder should have adopted the write-through form'
     rounds, mism, expired, nb, has_load = np.load(tmp_path / f'soak{r}.npy')
-    assert (rounds, mism, expired, nb, has_load) == (300, 0, 0, 7, 1), 'create() adopts a form only after the soak: every bucket + the 4 MB load bucket, interleaved on three streams, bitwise every round'
+    assert (rounds, mism, expired, nb, has_load) == (300, 0, 0, 11, 1), 'create() adopts a form only after the soak: every bucket + the 4 MB load bucket, interleaved on three streams, bitwise every round'
 
 
 def test_peer_exchange_single_rank_is_identity():
