@@ -21,7 +21,9 @@ __host__ __device__ inline GsLayout gs_layout(int S, int Dg, int H, int sn) {
   l.P = o;
   return l;
 }
-__host__ __device__ inline int gs_calls(const il_disc_shaped& d) { return 2 + (d.grad_penalty > 0.f ? 1 : 0); }
+__host__ __device__ inline int gs_calls(const il_disc_shaped& d) { return (d.loss_function == IL_LOSS_MIXUP ? 1 : 2) + (d.grad_penalty > 0.f ? 1 : 0); }   // Mixup: ONE call on the convex combinations (training.py:104-113)
+// what a call runs on: 0 policy, 1 expert, 2 gradient-penalty mix (training.py:116-126), 3 Mixup mix
+__host__ __device__ inline int gs_kind(const il_disc_shaped& d, int call) { return d.loss_function == IL_LOSS_MIXUP ? (call == 0 ? 3 : 2) : call; }
 struct GsWs { int64_t slabs, sn_new, pu, total; };   // pu: [2][nt] per-tile sums of w softplus(z) of the policy / expert call (PUGAIL with a finite nonnegative_margin)
 __host__ __device__ inline GsWs gs_ws(int S, int Dg, int H, int B) {
   GsWs w; const int64_t P = gs_layout(S, Dg, H, 1).P, nt = (B + GS_R - 1) / GS_R;
@@ -121,12 +123,13 @@ __device__ __forceinline__ void gs_spectral(const GsLds& l, int S, int Dg, int H
 }
 
 // rows of one call into LDS: x = cat(s, a) (or s), s' ; mixing for the gradient-penalty call. Also t, w per row -> row[0..R), row[R..2R)
-__device__ __forceinline__ void gs_stage_rows(const GsLds& l, const il_disc_shaped& d, const il_batch& pol, const il_batch& exp, int call, const float* eps_gp, uint32_t ctr, int row0,
+__device__ __forceinline__ void gs_stage_rows(const GsLds& l, const il_disc_shaped& d, const il_batch& pol, const il_batch& exp, int kind, const float* eps_given, uint32_t ctr, int row0,
                                               int S, int Dg) {
+  const int call = kind == 3 ? 2 : kind;   // both mixes stage their rows the same way
   const int B = pol.n;
-  float* epsr = l.row + 6 * GS_R;   // the U(0,1) draw of each row of the mix call (training.py:118), once
+  float* epsr = l.row + 6 * GS_R;   // the draw of each row of a mix call (training.py:118 U(0,1); :106 Beta(alpha, alpha), on the chip only for alpha = 1), once
   if (call == 2) {
-    if (threadIdx.x < GS_R) { const int row = row0 + threadIdx.x; epsr[threadIdx.x] = row < B ? (eps_gp ? eps_gp[row] : philox_uniform(d.noise_seed, ctr, IL_STREAM_GP, (uint32_t)row)) : 0.f; }
+    if (threadIdx.x < GS_R) { const int row = row0 + threadIdx.x; epsr[threadIdx.x] = row < B ? (eps_given ? eps_given[row] : philox_uniform(d.noise_seed, ctr, kind == 3 ? IL_STREAM_MIX : IL_STREAM_GP, (uint32_t)row)) : 0.f; }
     __syncthreads();
   }
   auto pick = [&](const il_batch& b, int row, int k, bool next) {
@@ -192,11 +195,12 @@ __global__ __launch_bounds__(256) void k_gs_grad(il_disc_shaped d, il_batch pol,
   gs_stage_params(l, d, lay, S, Dg, H);
   if (d.spectral_norm) gs_spectral(l, S, Dg, H, call + 1, 2 * call + 1);
   const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
-  gs_stage_rows(l, d, pol, exp, call, eps_gp, ctr, row0, S, Dg);
+  const int kind = gs_kind(d, call);
+  gs_stage_rows(l, d, pol, exp, kind, kind == 3 ? x.eps_mix : eps_gp, ctr, row0, S, Dg);
   gs_forward(l, S, Dg, H, d.discount);
   const float s1n = l.sc[5], s2n = l.sc[6], s1s = l.sc[7], s2s = l.sc[8], sg = l.sc[4], fB = (float)B;
   float* coef_n = l.row + 3 * GS_R; float* coef_s = l.row + 4 * GS_R; float* dzr = l.row + 5 * GS_R;
-  const bool is_gp = call == 2;
+  const bool is_gp = kind == 2;
   if (!is_gp) {
     if (tid < GS_R) {
       const int r = tid, row = row0 + r;
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256) void k_gs_grad(il_disc_shaped d, il_batch pol,
         // w softplus(z) = w bce(z, 0) of the policy / expert call; the gradient launch reads them all and decides, every workgroup the same way (gail.hip does the same)
         float ws_ = 0.f;
         if (row < B) {
-          const float* off = call == 0 ? x.logit_offset_policy : x.logit_offset_expert;
+          const float* off = kind == 0 ? x.logit_offset_policy : x.logit_offset_expert;
           const float f = l.row[2 * GS_R + r];
           ws_ = l.row[GS_R + r] * softplus_f(off ? f - off[row] : f);
         }
@@ -221,10 +225,12 @@ __global__ __launch_bounds__(256) void k_gs_grad(il_disc_shaped d, il_batch pol,
         pu_on = d.pos_class_prior * (se / fB) - sp / fB >= -d.nonnegative_margin ? 1.f : 0.f;   // torch.clamp(min = -margin): gradient where the input is not below the bound
       }
       if (row < B) {
-        const float* off = call == 0 ? x.logit_offset_policy : x.logit_offset_expert;
+        const float* off = kind == 0 ? x.logit_offset_policy : (kind == 1 ? x.logit_offset_expert : x.logit_offset_mix);
         const float f = l.row[2 * GS_R + r], z = off ? f - off[row] : f, w = l.row[GS_R + r];
         const bool pu = d.loss_function == IL_LOSS_PUGAIL;
-        const float c_sig = pu ? (call == 1 ? (1.f + pu_on) * d.pos_class_prior : -pu_on) : 1.f, c_lab = call == 1 ? (pu ? d.pos_class_prior : 1.f) : 0.f;
+        // d loss / d z = w (c_sig sigmoid(z) - c_lab) / B: BCE {1, label}; PUGAIL policy {-1, 0}, expert {2 prior, prior} (clamped away: {0, 0}, {prior, prior}); Mixup {1, eps}
+        const float c_sig = pu ? (kind == 1 ? (1.f + pu_on) * d.pos_class_prior : -pu_on) : 1.f;
+        const float c_lab = kind == 3 ? l.row[6 * GS_R + r] : (kind == 1 ? (pu ? d.pos_class_prior : 1.f) : 0.f);
         const float p = sigmoid_f(z);
         dz = w * (c_sig * p - c_lab) / fB;
         if (d.entropy_bonus > 0.f) dz += d.entropy_bonus * w * z * p * (1.f - p) / fB;
@@ -386,8 +392,8 @@ static int check_gs(const il_disc_shaped* d) {
   const int S = d->state_dim, Dg = d->state_only ? S : S + d->action_dim;
   IL_CHECK_ARG(S >= 1 && Dg <= 512 && d->hidden >= 1 && d->hidden <= 256, "il_disc_shaped: dims out of range (state=%d, input=%d, hidden=%d; hidden <= 256)", S, Dg, d->hidden);
   IL_CHECK_ARG(gs_lds_floats(S, Dg, d->hidden) * sizeof(float) <= 160 * 1024, "il_disc_shaped: state=%d hidden=%d needs more than 160 KiB of LDS", S, d->hidden);
-  IL_CHECK_ARG(d->reward_function >= 0 && d->reward_function <= 2 && (d->loss_function == IL_LOSS_BCE || d->loss_function == IL_LOSS_PUGAIL),
-               "il_disc_shaped: reward_function in {0,1,2}, loss_function BCE or PUGAIL");
+  IL_CHECK_ARG(d->reward_function >= 0 && d->reward_function <= 2 && d->loss_function >= IL_LOSS_BCE && d->loss_function <= IL_LOSS_MIXUP,
+               "il_disc_shaped: reward_function in {0,1,2}, loss_function BCE, PUGAIL or Mixup");
   if (d->spectral_norm) IL_CHECK_ARG(d->ug && d->vg && d->u1 && d->v1 && d->u2 && d->v2, "il_disc_shaped: spectral-norm buffers missing");
   if (d->workspace_floats < gs_ws(S, Dg, d->hidden, d->batch).total) return il_set_error(IL_ERR_WORKSPACE, "il_disc_shaped: workspace too small");
   return IL_OK;
@@ -406,6 +412,7 @@ extern "C" int il_gail_shaped_step(const il_disc_shaped* d, const il_batch* pol,
   IL_CHECK_ARG(pol->next_states && pol->terminals && exp->next_states && exp->terminals && pol->weights && exp->weights, "il_gail_shaped_step: the shaping term needs next_states, terminals and weights");
   il_gail_extra x = {};
   if (extra) x = *extra;
+  IL_CHECK_ARG(d->loss_function != IL_LOSS_MIXUP || (!x.logit_offset_policy && !x.logit_offset_expert), "il_gail_shaped_step: with Mixup the log-policy offset belongs to the mixed batch (logit_offset_mix)");
   const int S = d->state_dim, Dg = d->state_only ? S : S + d->action_dim;
   const size_t lds = gs_lds_floats(S, Dg, d->hidden) * sizeof(float);
   if (int rc = gs_ensure_lds((const void*)k_gs_grad, lds)) return rc;

@@ -151,8 +151,8 @@ def shaped_descriptor(disc, batch_size: int, opt, imitation_cfg=None) -> _lib.Di
   loss_function, prior, grad_penalty, entropy_bonus, margin = 'BCE', 0.0, 0.0, 0.0, float('inf')
   if imitation_cfg is not None:
     loss_function, prior = imitation_cfg.loss_function, float(_cfg_value(imitation_cfg, 'pos_class_prior', 0.0) or 0.0)
-    if loss_function not in ('BCE', 'PUGAIL'):
-      raise NotImplementedError(f'adversarial_imitation_update: reward shaping with loss_function={loss_function} has no kernel (BCE and PUGAIL do)')
+    if loss_function not in LOSS_FUNCTIONS:
+      raise ValueError(f'adversarial_imitation_update: unknown loss_function={loss_function}')
     margin = float(_cfg_value(imitation_cfg, 'nonnegative_margin', float('inf')))
     grad_penalty, entropy_bonus = float(imitation_cfg.grad_penalty), float(imitation_cfg.entropy_bonus)
   ws = _workspace('disc_shaped', int(_lib.lib().il_disc_shaped_workspace_floats(disc.state_size, disc.action_size, disc.hidden, batch_size, int(disc.state_only))), dev)
@@ -230,7 +230,7 @@ def shaped_predict_reward(disc, state: Tensor, action: Tensor, next_state: Tenso
 
 def adversarial_imitation_update(actor, discriminator: GAILDiscriminator, transitions: Dict[str, Tensor], expert_transitions: Dict[str, Tensor], discriminator_optimiser: AdamW,
                                  imitation_cfg, *, eps_gp: Optional[Tensor] = None, eps_mix: Optional[Tensor] = None):
-  """Reference training.py:85-134: loss_function BCE / PUGAIL (nonnegative_margin = inf) / Mixup, + gradient penalty, spectral norm, entropy bonus,
+  """Reference training.py:85-134: loss_function BCE / PUGAIL (any nonnegative_margin) / Mixup, + gradient penalty, spectral norm, entropy bonus,
   subtract_log_policy.  `eps_gp` / `eps_mix`: the U(0,1) and Beta(alpha, alpha) draws (None: drawn here)."""
   dev = discriminator.flat.device
   B = transitions['states'].size(0)
@@ -239,7 +239,18 @@ def adversarial_imitation_update(actor, discriminator: GAILDiscriminator, transi
   x, keep = _lib.GailExtra(), []
   if getattr(discriminator, 'reward_shaping', False):   # models.py:157-160: its own kernels (k_gs_grad / k_gs_reduce)
     d = shaped_descriptor(discriminator, B, discriminator_optimiser, imitation_cfg)
-    if discriminator.subtract_log_policy:
+    if imitation_cfg.loss_function == 'Mixup':   # training.py:104-113 on every field of the transition (the kernel mixes next_states and terminals too)
+      alpha = float(_cfg_value(imitation_cfg, 'mixup_alpha', 1.0))
+      if eps_mix is None and (alpha != 1.0 or discriminator.subtract_log_policy):
+        eps_mix = torch.distributions.Beta(torch.full((B,), alpha), torch.full((B,), alpha)).sample()
+      if eps_mix is not None:
+        keep.append(_f32(eps_mix, dev)); x.eps_mix = keep[-1].data_ptr()
+      if discriminator.subtract_log_policy:
+        e2 = keep[-1].unsqueeze(1)
+        mix = lambda k: e2 * _f32(expert_transitions[k], dev) + (1 - e2) * _f32(transitions[k], dev)
+        keep.append(actor.log_prob(mix('states'), mix('actions')))
+        x.logit_offset_mix = keep[-1].data_ptr()
+    elif discriminator.subtract_log_policy:
       keep += [actor.log_prob(transitions['states'], transitions['actions']), actor.log_prob(expert_transitions['states'], expert_transitions['actions'])]
       x.logit_offset_policy, x.logit_offset_expert = keep[-2].data_ptr(), keep[-1].data_ptr()
     _lib.check(_lib.lib().il_gail_shaped_step(C.byref(d), C.byref(pb), C.byref(eb), _lib.ptr(e), C.byref(x), 0, _lib.stream_ptr()))

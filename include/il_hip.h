@@ -371,7 +371,7 @@ int il_gail_reward(const il_disc* d, const il_batch* batch, float* out_rewards, 
  *   f = g(x) + (1 - terminal)(discount * h(s') - h(s)),  g = Linear(Dg, 1),  h = Linear(S, H) -> ReLU -> Linear(H, 1),  Dg = S (+ A unless state_only).
  * params in parameters() order: spectral norm  {g.bias, g.original[1,Dg], h.0.bias[H], h.0.original[H,S], h.2.bias, h.2.original[1,H]},
  * otherwise {g.weight, g.bias, h.0.weight, h.0.bias, h.2.weight, h.2.bias}; il_disc_shaped_numel floats. Buffers ug[1] vg[Dg] u1[H] v1[S] u2[1] v2[H].
- * Losses BCE / PUGAIL (any margin); il_gail_extra carries the subtract_log_policy offsets (eps_mix unused). Batches must carry next_states, terminals.
+ * Losses BCE / PUGAIL (any margin) / Mixup (il_gail_extra.eps_mix, or the on-chip U(0,1) stream for alpha = 1); il_gail_extra carries the subtract_log_policy offsets. Batches must carry next_states, terminals.
  * ------------------------------------------------------------------------------------------ */
 typedef struct il_disc_shaped {
   int32_t state_dim, action_dim, hidden, batch;

@@ -102,7 +102,7 @@ def _split(ds, b):
 
 
 def gail_update(ds: ShapedState, pol, exp, eps_gp, *, lr, weight_decay, grad_penalty=1.0, entropy_bonus=0.0, loss_function='BCE', pos_class_prior=0.7,
-                logp_policy=None, logp_expert=None, return_grads=False, nonnegative_margin=float('inf')):
+                logp_policy=None, logp_expert=None, return_grads=False, nonnegative_margin=float('inf'), eps_mix=None, logp_mix=None):
   """One `adversarial_imitation_update` with reward shaping; pol / exp are transition dicts. nonnegative_margin: training.py:100-102 (PUGAIL), as in oracle/gail.py."""
   B = pol['states'].shape[0]
   g = {k: np.zeros_like(getattr(ds, k)) for k in ('Wg', 'bg', 'W1', 'b1', 'W2', 'b2')}
@@ -121,6 +121,11 @@ def gail_update(ds: ShapedState, pol, exp, eps_gp, *, lr, weight_decay, grad_pen
     V = pr * np.mean(exp['weights'].astype(f32) * nets.softplus(zs[1]), dtype=f32) - np.mean(pol['weights'].astype(f32) * nets.softplus(zs[0]), dtype=f32)
     on = f32(1) if V >= -nonnegative_margin else f32(0)
   calls = [(pol, -on if pu else f32(1), zero, logp_policy), (exp, (f32(1) + on) * pr if pu else f32(1), zero + (pr if pu else f32(1)), logp_expert)]
+  if loss_function == 'Mixup':   # training.py:104-113: ONE call on the convex combination of every field (the mixed terminal is fractional), label = the coefficient
+    em = eps_mix.astype(f32)
+    mixf = lambda a, b_: (em[:, None] * a.astype(f32) + (f32(1) - em[:, None]) * b_.astype(f32)) if a.ndim == 2 else (em * a.astype(f32) + (f32(1) - em) * b_.astype(f32))
+    calls = [({k: mixf(exp[k], pol[k]) for k in ('states', 'actions', 'next_states', 'terminals', 'weights')}, f32(1), em, logp_mix)]
+    assert logp_policy is None and logp_expert is None
   for b, c_sig, c_lab, off in calls:
     x, s, ns, t, w = _split(ds, b)
     f, (Wgh, cg, cn, cs) = forward(ds, x, s, ns, t, train=True)

@@ -103,6 +103,12 @@ GAIL_DEEP_CASES = (   # name, gail_deep_case arguments, loss_function, (lr, weig
 )
 
 
+def mixup_draws(seed, batch, steps):
+  """The Beta(alpha, alpha) coefficients of `steps` Mixup updates (training.py:106), fed to the reference and to the HIP path alike."""
+  rs = np.random.RandomState(seed)
+  return [rs.beta(0.7, 0.7, size=batch).astype(f32) for _ in range(steps)]
+
+
 def gmmil_case(seed, B1, B2, D, weighted=True):
   rs = np.random.RandomState(seed)
   X = rs.standard_normal((B1, D)).astype(f32)

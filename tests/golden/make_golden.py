@@ -481,6 +481,39 @@ def gen_gail_shaped():
   np.savez_compressed(os.path.join(HERE, 'gail_shaped.npz'), **out)
 
 
+def gen_gail_shaped_mixup():
+  """Reward shaping under loss_function=Mixup (training.py:104-113: ONE discriminator call on the convex combination of every field of the transitions - the mixed
+  terminal is fractional), spectral norm, gradient penalty, entropy bonus: gradients, parameters, u / v buffers, rewards. The Beta draws are fed like the other noise."""
+  out = {}
+  c = gi.gail_shaped_case(95, 'hopper', 32, 96, 2, True)
+  em = gi.mixup_draws(1095, 96, 2)
+  icfg = DictConfig(state_only=False, spectral_norm=True, loss_function='Mixup', grad_penalty=0.7, mixup_alpha=0.7, entropy_bonus=0.01, pos_class_prior=0.7, nonnegative_margin=float('inf'),
+                    discriminator=DictConfig(hidden_size=c['H'], depth=1, activation='relu', reward_shaping=True, subtract_log_policy=False, reward_function='AIRL'))
+  d = shaped_disc(c, icfg, True)
+  opt = torch.optim.AdamW(d.parameters(), lr=1e-3, weight_decay=0.1)
+  for i in range(2):
+    d.train()
+    orig = torch.distributions.Beta.sample
+    feed = [T(em[i])]
+    torch.distributions.Beta.sample = lambda self, *a, **k: feed.pop(0)
+    try:
+      with NoiseFeed() as nf:
+        nf.rand.append(T(c['eps'][i]))
+        ref_training.adversarial_imitation_update(None, d, tbatch(c['policy'][i]), tbatch(c['expert'][i]), opt, icfg)
+    finally:
+      torch.distributions.Beta.sample = orig
+    d.eval()
+    k = i + 1
+    out[f'g_{k}'] = np.concatenate([N_(p.grad).ravel() for p in d.parameters()]); out[f'p_{k}'] = flat(d)
+    out[f'ug_{k}'] = N_(d.g.parametrizations.weight[0]._u); out[f'vg_{k}'] = N_(d.g.parametrizations.weight[0]._v)
+    for li, nm in ((0, '1'), (2, '2')):
+      out[f'u{nm}_{k}'] = N_(d.h[li].parametrizations.weight[0]._u); out[f'v{nm}_{k}'] = N_(d.h[li].parametrizations.weight[0]._v)
+    b = c['policy'][i]
+    with torch.inference_mode():
+      out[f'reward_{k}'] = N_(d.predict_reward(T(b['states']), T(b['actions']), T(b['next_states']), T(b['terminals'])))
+  np.savez_compressed(os.path.join(HERE, 'gail_shaped_mixup.npz'), **out)
+
+
 # ---------------------------------------------------------------- GMMIL / PWIL
 def gen_gmmil():
   out = {}
@@ -739,6 +772,7 @@ if __name__ == '__main__':
   if want('gail_pu_margin'): gen_gail_pu_margin()
   if want('gail_pu_margin_general'): gen_gail_pu_margin_general()
   if want('gail_shaped'): gen_gail_shaped()
+  if want('gail_shaped_mixup'): gen_gail_shaped_mixup()
   if want('gail_deep'): gen_gail_deep()
   if want('gmmil'): gen_gmmil()
   if want('pwil'): gen_pwil()

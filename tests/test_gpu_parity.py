@@ -1000,11 +1000,9 @@ def test_gail_variants_loud_failures():
   mk = lambda **kw: Cfg(state_only=False, spectral_norm=True, loss_function='PUGAIL', grad_penalty=0.5, mixup_alpha=1, entropy_bonus=0.0, pos_class_prior=0.7, nonnegative_margin=kw.get('margin', float('inf')),
                         discriminator=Cfg(hidden_size=32, depth=1, activation='relu', reward_shaping=kw.get('shaping', False), subtract_log_policy=False, reward_function='AIRL'))
   assert type(il.GAILDiscriminator(c['S'], c['A'], mk(shaping=True), 0.97, device=DEV)).__name__ == 'ShapedGAILDiscriminator'
-  d = il.GAILDiscriminator(c['S'], c['A'], mk(shaping=True), 0.97, device=DEV)   # reward shaping has BCE and PUGAIL kernels (any margin: tests below); Mixup has none
-  opt = il.AdamW(d, lr=1e-3, weight_decay=0.1)
-  mix = mk(shaping=True); mix['loss_function'] = 'Mixup'
+  deep_shaping = mk(shaping=True); deep_shaping['discriminator'] = Cfg(deep_shaping['discriminator'], depth=2)   # every loss has a reward-shaping kernel; a depth-2 / tanh potential has none
   with pytest.raises(NotImplementedError):
-    il.adversarial_imitation_update(None, d, tbatch(c['policy'][0]), tbatch(c['expert'][0]), opt, mix)
+    il.GAILDiscriminator(c['S'], c['A'], deep_shaping, 0.97, device=DEV)
 
 
 @pytest.mark.gpu
@@ -1176,6 +1174,44 @@ def test_gail_reward_shaping_matches_reference(golden_dir, name, sn, loss):
     d.flat.copy_(T(g[f'{name}.p_{i + 1}'])); ods.unpack_into(g[f'{name}.p_{i + 1}'].copy())
     r = d.predict_reward(**il.make_gail_input(p['states'], p['actions'], p['next_states'], p['terminals'], None, True, False))
     close(N(r), g[f'{name}.reward_{i + 1}'], f'{name} reward {i + 1}', rtol=2e-5, atol_scale=1e-5)
+
+
+@pytest.mark.gpu
+def test_gail_reward_shaping_mixup_matches_reference(golden_dir):
+  """Reward shaping under loss_function = Mixup (one call on the convex combination of every field, fractional terminals), spectral norm, penalty, entropy bonus."""
+  from oracle import gail_shaped as ogs
+  g = load(golden_dir, 'gail_shaped_mixup')
+  c = gi.gail_shaped_case(95, 'hopper', 32, 96, 2, True)
+  em = gi.mixup_draws(1095, 96, 2)
+  icfg = Cfg(state_only=False, spectral_norm=True, loss_function='Mixup', grad_penalty=0.7, mixup_alpha=0.7, entropy_bonus=0.01, pos_class_prior=0.7, nonnegative_margin=float('inf'),
+             discriminator=Cfg(hidden_size=c['H'], depth=1, activation='relu', reward_shaping=True, subtract_log_policy=False, reward_function='AIRL'))
+  d = il.GAILDiscriminator(c['S'], c['A'], icfg, 0.97, device=DEV)
+  assert type(d).__name__ == 'ShapedGAILDiscriminator'
+  ods = ogs.ShapedState(c['S'], c['A'], c['H'], 0.97, True)
+  for k in ('Wg', 'bg', 'W1', 'b1', 'W2', 'b2', 'ug', 'vg', 'u1', 'v1', 'u2', 'v2'):
+    getattr(ods, k)[...] = c[k]
+  d.flat.copy_(T(ods.pack()))
+  for k, v in d.views().items():
+    v.copy_(T(c[k]))
+  opt = il.AdamW(d, lr=1e-3, weight_decay=0.1)
+  for i in range(2):
+    p, e = tbatch(c['policy'][i]), tbatch(c['expert'][i])
+    il.adversarial_imitation_update(None, d, p, e, opt, icfg, eps_gp=T(c['eps'][i]), eps_mix=T(em[i]))
+    ogr = ogs.gail_update(ods, c['policy'][i], c['expert'][i], c['eps'][i], lr=1e-3, weight_decay=0.1, grad_penalty=0.7, entropy_bonus=0.01, loss_function='Mixup', return_grads=True,
+                          eps_mix=em[i])
+    close(N(opt.grad), g[f'g_{i + 1}'], f'shaped mixup gradient {i + 1} (reference)', rtol=1e-5, atol_scale=1e-5)
+    close(N(opt.grad), ogr, f'shaped mixup gradient {i + 1} (oracle)', rtol=1e-5, atol_scale=1e-5)
+    close_params(N(d.flat), g[f'p_{i + 1}'], f'shaped mixup parameters {i + 1}', 1e-3, steps=i + 1)
+    for k in ('ug', 'vg', 'u1', 'v1', 'u2', 'v2'):
+      close(N(d.views()[k]), g[f'{k}_{i + 1}'], f'shaped mixup {k} after update {i + 1}', rtol=1e-5, atol_scale=1e-5)
+    d.flat.copy_(T(g[f'p_{i + 1}'])); ods.unpack_into(g[f'p_{i + 1}'].copy())
+    r = d.predict_reward(**il.make_gail_input(p['states'], p['actions'], p['next_states'], p['terminals'], None, True, False))
+    close(N(r), g[f'reward_{i + 1}'], f'shaped mixup reward {i + 1}', rtol=2e-5, atol_scale=1e-5)
+  # alpha = 1 without given draws: the coefficients come from the on-chip Philox stream (IL_STREAM_MIX), the update must run and change the parameters
+  icfg1 = Cfg(icfg); icfg1['mixup_alpha'] = 1
+  before = N(d.flat)
+  il.adversarial_imitation_update(None, d, tbatch(c['policy'][0]), tbatch(c['expert'][0]), opt, icfg1)
+  assert np.isfinite(N(d.flat)).all() and not np.array_equal(before, N(d.flat))
 
 
 # ---------------------------------------------------------------------------------------------

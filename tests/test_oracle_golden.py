@@ -275,6 +275,26 @@ def test_gail_shaped_oracle_matches_reference_fixture(golden_dir, name, sn, loss
         np.testing.assert_allclose(getattr(ds, k), g[f'{name}.{k}_{i + 1}'], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(ogs.predict_reward(ds, c['policy'][i]), g[f'{name}.reward_{i + 1}'], rtol=5e-5, atol=2e-6)
 
+def test_gail_shaped_oracle_mixup_matches_reference_fixture(golden_dir):
+  """Reward shaping under Mixup (training.py:104-113 on every field of the transitions, fractional terminals): oracle/gail_shaped.py against the reference's autograd."""
+  from oracle import gail_shaped as ogs
+  g = np.load(os.path.join(golden_dir, 'gail_shaped_mixup.npz'))
+  c = gi.gail_shaped_case(95, 'hopper', 32, 96, 2, True)
+  em = gi.mixup_draws(1095, 96, 2)
+  ds = ogs.ShapedState(c['S'], c['A'], c['H'], 0.97, True)
+  for k in ('Wg', 'bg', 'W1', 'b1', 'W2', 'b2', 'ug', 'vg', 'u1', 'v1', 'u2', 'v2'):
+    getattr(ds, k)[...] = c[k]
+  for i in range(2):
+    gr = ogs.gail_update(ds, c['policy'][i], c['expert'][i], c['eps'][i], lr=1e-3, weight_decay=0.1, grad_penalty=0.7, entropy_bonus=0.01, loss_function='Mixup', return_grads=True,
+                         eps_mix=em[i])
+    ref = g[f'g_{i + 1}']
+    assert np.abs(gr - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert np.abs(ds.pack() - g[f'p_{i + 1}']).max() <= 2e-6
+    for k in ('ug', 'vg', 'u1', 'v1', 'u2', 'v2'):
+      np.testing.assert_allclose(getattr(ds, k), g[f'{k}_{i + 1}'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ogs.predict_reward(ds, c['policy'][i]), g[f'reward_{i + 1}'], rtol=5e-5, atol=2e-6)
+
+
 def _deep_state(c):
   from oracle import gail_deep as ogd
   ds = ogd.DeepDiscState(c['D'], c['H'], c['depth'], c['activation'], c['spectral_norm'])
