@@ -1657,9 +1657,9 @@ extern "C" int32_t il_gail_step_workgroups(const il_disc* d) {
 
 // data-parallel with the exchange inside the optimiser launches (il_sac_update_gather_peer): bucket sizes and job counts a caller lays its peer regions out for
 static int64_t round_up4(int64_t n) { return (n + 3) & ~(int64_t)3; }
-extern "C" int64_t il_sac_peer_bucket_floats(const il_sac* d, int32_t which) {   // 0: the twin critic's arena; 1: the actor's arena + one 16-byte slot whose first float is log alpha's gradient
-  if (!d) return 0;
-  return which == 0 ? 2 * net_stride(d->state_dim + d->action_dim, d->hidden, 1) : round_up4(mlp_numel(d->state_dim, d->hidden, 2 * d->action_dim)) + 4;
+extern "C" int64_t il_sac_peer_bucket_floats(const il_sac* d, int32_t which) {   // 0: the twin critic's arena; 1: the actor's arena with log alpha's gradient in the slot behind it, padded
+  if (!d) return 0;                                                              // to 16 bytes - the layout of parallel.GradBuckets, so that an exchange LAUNCH can serve the same region
+  return which == 0 ? 2 * net_stride(d->state_dim + d->action_dim, d->hidden, 1) : round_up4(mlp_numel(d->state_dim, d->hidden, 2 * d->action_dim) + 1);
 }
 extern "C" int32_t il_sac_peer_jobs(const il_sac* d, int32_t which) {   // arrival lines of the bucket (0: this shape's optimiser launches have no block form: use the exchange launches)
   if (!d || !(dw_block32_on() && d->hidden % 32 == 0 && d->batch % 128 == 0)) return 0;
@@ -1715,7 +1715,7 @@ static int sac_update_gather_impl(const il_sac* d, const il_batch* rows, const i
   }
   { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *rows, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
   DwArgs aa = actor_dw_args(d, rows, flags);
-  if (peer_actor) { aa.peer = *peer_actor; aa.peer_alpha_at = il_sac_peer_bucket_floats(d, 1) - 4; }
+  if (peer_actor) { aa.peer = *peer_actor; aa.peer_alpha_at = mlp_numel(d->state_dim, d->hidden, 2 * d->action_dim); }
   { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + IL_TAIL_BLOCKS, 256, 0, st>>>(aa); }
   IL_CHECK_LAUNCH("il_sac_update_gather");
   return IL_OK;

@@ -536,6 +536,7 @@ class DataParallelUpdate:
     if float(bad.item()) > 0:
       torch.cuda.synchronize()
       self.handoff = False
+      self.fused, self.plan.peer_desc = False, None   # the stream-dependency schedule keeps one exchange launch per sync point (the same peer regions serve it)
       self.plan.sync.zero_()
       self.plan._set_device_sync(False)
     return self.handoff
@@ -626,6 +627,7 @@ class DataParallelUpdate:
       p = self.plan
       if not _agree(p._probe_device_sync(graph=True), self.group):   # e.g. a counter-collecting profiler serialises the two graphs on SOME rank: every rank takes stream dependencies, one graph (below)
         self.handoff = False
+        self.fused, p.peer_desc = False, None
         p._set_device_sync(False)
         return self.capture(warmup)
       p.memory.stream().device_state(p.rows.device)

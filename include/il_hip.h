@@ -579,7 +579,7 @@ int il_sac_dp_phase_peer(const il_sac* d, const il_batch* batch, int32_t phase, 
  * each other and to il_sac_update_gather(IL_FLAG_GRADS_ONLY) + il_peer_allreduce_mean + il_sac_dp_phase. Buckets: il_sac_peer_bucket_floats(d, 0 | 1) floats,
  * il_sac_peer_jobs(d, 0 | 1) arrival lines (0: this shape has no block form - use the exchange launches), regions of il_peer_job_region_bytes. Every rank must issue the
  * same sequence of calls. */
-int64_t il_sac_peer_bucket_floats(const il_sac* d, int32_t which);   /* 0 critic, 1 actor (+ log alpha) */
+int64_t il_sac_peer_bucket_floats(const il_sac* d, int32_t which);   /* 0 critic [2 * il_mlp_stride], 1 actor [round-up-4(Pa + 1)]: log alpha's gradient in slot Pa (parallel.GradBuckets' layout) */
 int32_t il_sac_peer_jobs(const il_sac* d, int32_t which);
 int il_sac_update_gather_peer(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const il_disc* relabel, float* rewards_out,
                               const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, const il_peer_bucket* peer_critic,
