@@ -85,15 +85,48 @@ __global__ __launch_bounds__(1024) void k_pwil_reward(il_pwil d, const float* __
 #define PW_CHUNK 256
 struct __attribute__((aligned(16))) PwCand { float dist; int idx; float w; float pad; };   // w = the atom's remaining weight at selection time
 
+// (distance, index) as one ordered 64-bit key: distances are >= 0, so their IEEE bits order like the values; ties go to the lower index (argmin).
+__device__ __forceinline__ unsigned long long pw_key(float dist, int idx) { return ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)idx; }
+typedef unsigned pw_u32x4 __attribute__((ext_vector_type(4)));
+// Rank of this thread's key among the (up to) 256 DISTINCT keys of a 256-thread workgroup (every thread calls; one barrier inside). Each wave ranks its own 64 keys with
+// v_readlane broadcasts (no LDS), leaves them in `sk` in ascending order - padded to 128 slots with the largest key, so that the binary searches need no bounds -, and a
+// key's rank is its rank in its wave plus, per other wave, the number of smaller keys found by a binary search in that wave's sorted run: 64 register broadcasts + 21 LDS
+// reads per thread where counting the 256 keys out of LDS took 256 broadcast reads + compares (4.9 of a 20 us step).
+__device__ __forceinline__ int pw_rank256(unsigned long long key, unsigned long long (*sk)[128]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int klo = (int)(unsigned)key, khi = (int)(unsigned)(key >> 32);
+  int rw = 0;
+#pragma unroll 16
+  for (int l = 0; l < 64; ++l) {
+    const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(khi, l) << 32) | (unsigned)__builtin_amdgcn_readlane(klo, l);
+    rw += o < key ? 1 : 0;
+  }
+  sk[wave][rw] = key; sk[wave][64 + lane] = ~0ull;
+  __syncthreads();
+  int rank = rw;
+#pragma unroll
+  for (int q = 1; q < 4; ++q) {
+    const unsigned long long* a = sk[(wave + q) & 3];
+    int pos = 0;
+#pragma unroll
+    for (int step = 64; step > 0; step >>= 1) pos += a[pos + step - 1] < key ? step : 0;
+    rank += pos;
+  }
+  return rank;
+}
+// WT: the candidates leave with sc0 sc1 (write-through) stores - k_pwil_step's arrival ticket then needs no release (an L2 write-back per workgroup), only drained stores
+template <bool WT>
 __device__ __forceinline__ void pwil_select_block(const il_pwil& d, const float* __restrict__ state, const float* __restrict__ action, int K, PwCand* __restrict__ cand) {
   __shared__ float z[512];
-  __shared__ __attribute__((aligned(16))) float sd[PW_CHUNK];
+  __shared__ unsigned long long sk[4][128];   // each wave's 64 keys in ascending order, padded with the largest key (binary searches over 128 slots need no bounds)
   const int tid = threadIdx.x, N = d.n_atoms, D = d.dim, S = d.state_dim;
+  IL_TL(0, 0);
   for (int k = tid; k < D; k += PW_CHUNK) {
     const float x = k < S ? state[k] : action[k - S];
     z[k] = d.scale[k] * (x + d.offset[k]);
   }
   __syncthreads();
+  IL_TL(0, 1);
   const int i = (int)blockIdx.x * PW_CHUNK + tid;
   float dist = FLT_MAX;
   const int ic = i < N ? i : N - 1;
@@ -121,22 +154,25 @@ __device__ __forceinline__ void pwil_select_block(const il_pwil& d, const float*
     for (; k < D; ++k) { const float df = a[k] - z[k]; s += df * df; }
     dist = sqrtf(s);
   }
-  sd[tid] = dist;
-  __syncthreads();
-  int rank = 0;   // (measured, round 3: the same count with 16-byte LDS broadcasts - a quarter of the LDS instructions - made the whole step 6.6 us SLOWER: 21.2 -> 27.8 us)
-#pragma unroll 8
-  for (int j = 0; j < PW_CHUNK; ++j) { const float o = sd[j]; rank += (o < dist || (o == dist && j < tid)) ? 1 : 0; }
-  if (rank < K) { PwCand c; c.dist = dist; c.idx = dist < FLT_MAX ? i : INT_MAX; c.w = dist < FLT_MAX ? wi : 0.f; c.pad = 0.f; cand[(size_t)blockIdx.x * K + rank] = c; }
+  // rank of every atom inside its chunk by (distance, index) - ties to the lower index, like argmin (the in-chunk index is the key's low word)
+  const int rank = pw_rank256(pw_key(dist, tid), sk);
+  IL_TL(0, 2);
+  if (rank < K) {
+    PwCand c; c.dist = dist; c.idx = dist < FLT_MAX ? i : INT_MAX; c.w = dist < FLT_MAX ? wi : 0.f; c.pad = 0.f;
+    if (WT) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(cand, 0, 0x7ffffff0, 0x00020000);   // raw buffer, byte offsets
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pw_u32x4, c), rs, (int)(((size_t)blockIdx.x * K + rank) * sizeof(PwCand)), 0, 17);   // sc0 | sc1
+    } else cand[(size_t)blockIdx.x * K + rank] = c;
+  }
+  IL_TL(0, 3);
 }
 __global__ __launch_bounds__(PW_CHUNK) void k_pwil_select(il_pwil d, const float* __restrict__ state, const float* __restrict__ action, int K, PwCand* __restrict__ cand) {
-  pwil_select_block(d, state, action, K, cand);
+  pwil_select_block<false>(d, state, action, K, cand);
 }
 
 #define PW_LDS_CAND 4096   // candidates staged in LDS (64 KB): the merge loop then touches no global memory
 #define PW_MAXQ 16         // lists per lane of the merging wave: G <= 64 * PW_MAXQ chunks (262k atoms); larger sets use the one-workgroup kernel
 
-// (distance, index) as one ordered 64-bit key: distances are >= 0, so their IEEE bits order like the values; ties go to the lower index (argmin).
-__device__ __forceinline__ unsigned long long pw_key(float dist, int idx) { return ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)idx; }
 template <int CTRL>
 __device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long v) {
   const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xf, 0xf, false);
@@ -227,20 +263,33 @@ __device__ __forceinline__ void pwil_merge_block(const il_pwil& d, int G, int K,
 #pragma unroll
   for (int q = 0; q < 4; ++q) hd[q] = cand[(size_t)min(tid + 256 * q, G - 1) * K];
   __builtin_amdgcn_sched_barrier(0);
+  IL_TL(1, 0);
   if (tid == 0) { nsurv = 0; nvalid = 0; }
+  if (G <= 256) {   // the usual case: the heads in ascending order through the wave-level ranking of the selecting workgroups (an exhausted list sorts last, by list index)
+    const bool mine = tid < G;
+    // (hd[0] = the head of list tid; threads past the last list carry distinct keys above every list's, so that each wave still fills its 64 sorted slots)
+    const unsigned long long h = !mine ? (0xFFFFFFFFull << 32) | (0x80000000u | (unsigned)tid) : (hd[0].idx == INT_MAX ? (0xFFFFFFFFull << 32) | (unsigned)tid : pw_key(hd[0].dist, hd[0].idx));
+    IL_TL(1, 1);   // the heads have arrived (the first use of the candidate loads)
+    const int rank = pw_rank256(h, reinterpret_cast<unsigned long long(*)[128]>(skey + 1024));   // scratch between the two halves this function uses
+    if (mine) { skey[2048 + rank] = hd[0].idx == INT_MAX ? EMPTY : h; sw[2048 + rank] = hd[0].w; }
+  } else {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int l = tid + 256 * q;
-    if (l < G) { skey[l] = hd[q].idx == INT_MAX ? EMPTY : pw_key(hd[q].dist, hd[q].idx); sw[l] = hd[q].w; }
+    for (int q = 0; q < 4; ++q) {
+      const int l = tid + 256 * q;
+      if (l < G) { skey[l] = hd[q].idx == INT_MAX ? EMPTY : pw_key(hd[q].dist, hd[q].idx); sw[l] = hd[q].w; }
+    }
+    __syncthreads();
+    IL_TL(1, 1);
+    for (int l = tid; l < G; l += 256) {   // heads in ascending order (EMPTY heads tie: give them distinct ranks by list index, they sort last)
+      const unsigned long long h = skey[l];
+      int rank = 0;
+#pragma unroll 8
+      for (int j = 0; j < G; ++j) { const unsigned long long o = skey[j]; rank += (o < h || (o == h && j < l)) ? 1 : 0; }
+      skey[2048 + rank] = h; sw[2048 + rank] = sw[l];
+    }
   }
   __syncthreads();
-  for (int l = tid; l < G; l += 256) {   // heads in ascending order (EMPTY heads tie: give them distinct ranks by list index, they sort last)
-    const unsigned long long h = skey[l];
-    int rank = 0;
-    for (int j = 0; j < G; ++j) { const unsigned long long o = skey[j]; rank += (o < h || (o == h && j < l)) ? 1 : 0; }
-    skey[2048 + rank] = h; sw[2048 + rank] = sw[l];
-  }
-  __syncthreads();
+  IL_TL(1, 2);   // heads sorted
   // The threshold: walk the sorted heads until their weights cover the agent's weight, then one more head of slack. The bound only has to be safe (pass 2 below makes the
   // step exact whatever it is), so it is a wave-parallel float prefix sum over the first 64 sorted heads - every wave computes the same value - instead of a loop of
   // dependent LDS reads (round 3, second step: that loop and the greedy loop below were ~6 us of a 25 us step).
@@ -258,6 +307,7 @@ __device__ __forceinline__ void pwil_merge_block(const il_pwil& d, int G, int K,
     }
   }
   __syncthreads();   // the heads have been read by everyone: the survivors may overwrite them
+  IL_TL(1, 3);   // threshold known
   __shared__ int again;
   for (int pass = 0; pass < 2; ++pass) {
     int mine = 0;
@@ -269,16 +319,24 @@ __device__ __forceinline__ void pwil_merge_block(const il_pwil& d, int G, int K,
         if (k2 <= T) { const int pos = atomicAdd(&nsurv, 1); skey[pos] = k2; sw[pos] = c[u].w; }
       }
     }
-    if (pass == 0 && mine) atomicAdd(&nvalid, mine);
+    if (pass == 0) {   // one LDS atomic per wave (256 threads adding to one word serialise: ~2 us of the first version of this merge)
+      int m = mine;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
+      if ((tid & 63) == 0 && m) atomicAdd(&nvalid, m);
+    }
     __syncthreads();
+    if (pass == 0) IL_TL(1, 4);   // survivors compacted
     const int n = nsurv;
     for (int s = tid; s < n; s += 256) {
       const unsigned long long k2 = skey[s];
       int rank = 0;
+#pragma unroll 8
       for (int j = 0; j < n; ++j) rank += skey[j] < k2 ? 1 : 0;
       order[rank] = (unsigned short)s;
     }
     __syncthreads();
+    if (pass == 0) IL_TL(1, 5);   // survivors ranked
     if (tid < 64) {   // wave 0: the greedy coupling over the sorted survivors - cost and remaining weight in double, ascending key order, exactly the serial merge's operations
       const int lane = tid;
       double weight = d.agent_weight, cost = 0.0;
@@ -287,12 +345,18 @@ __device__ __forceinline__ void pwil_merge_block(const il_pwil& d, int G, int K,
         const int s = lane < n ? order[lane] : 0;
         const unsigned long long key = lane < n ? skey[s] : 0ull;
         const int kdist = (int)(unsigned)(key >> 32), kidx = (int)(unsigned)key, kw = __float_as_int(lane < n ? sw[s] : 0.f);
+        if (pass == 0) IL_TL(2, 0);
+        // (Measured, round 3: the conversions and the product ew dist hoisted out of the loop as per-lane doubles broadcast with two v_readlane each: 2.8 us for the ~26
+        // atoms of a step against 2.2 us for this form; a branch-free form with selects: 2.2 us. A trip costs ~200 clocks of dependent double-precision latency and
+        // VALU -> scalar-branch hand-offs on a single wave, not instruction issue.)
         for (int it = 0; it < n && weight > 0.0; ++it) {
           const double ew = (double)__int_as_float(__builtin_amdgcn_readlane(kw, it)), dist = (double)__int_as_float(__builtin_amdgcn_readlane(kdist, it));
           if (weight >= ew) { cost += ew * dist; weight -= ew; ++consumed; }
           else { cost += weight * dist; part_idx = __builtin_amdgcn_readlane(kidx, it); part_w = (float)ew - (float)weight; weight = 0.0; }
         }
+        if (pass == 0) IL_TL(2, 1);
         if (!(weight > 0.0) || n == nvalid || T == EMPTY) { if (lane < consumed) d.weights[kidx] = -1.f; }
+        if (pass == 0) IL_TL(2, 2);
       } else {
         for (int it = 0; it < n && weight > 0.0; ++it) {
           const int s = order[it];
@@ -312,8 +376,10 @@ __device__ __forceinline__ void pwil_merge_block(const il_pwil& d, int G, int K,
           out[0] = (float)(d.reward_scale * exp(-d.reward_bandwidth * cost));
         }
       }
+      if (pass == 0) IL_TL(2, 3);
     }
     __syncthreads();
+    if (pass == 0) IL_TL(1, 6);   // greedy coupling done
     if (!again) break;
     if (tid == 0) nsurv = 0;   // pass 2: every candidate (exact by construction; rare)
     T = EMPTY;
@@ -330,16 +396,24 @@ __global__ __launch_bounds__(256) void k_pwil_merge(il_pwil d, int G, int K, con
 __global__ __launch_bounds__(PW_CHUNK) void k_pwil_step(il_pwil d, const float* __restrict__ state, const float* __restrict__ action, int K, PwCand* __restrict__ cand,
                                                         unsigned* __restrict__ ticket, float* __restrict__ out) {
   __shared__ unsigned last;
-  pwil_select_block(d, state, action, K, cand);
-  __syncthreads();   // every thread's candidate stores precede thread 0's release
+  pwil_select_block<true>(d, state, action, K, cand);
+  // The candidates left with write-through stores: once every wave has drained its own (acknowledged by the memory side) and the workgroup has met, a RELAXED ticket is
+  // enough - no release, i.e. no write-back of the XCD's L2 per workgroup; only the last arriver pays an acquire (an invalidate) before it reads the lists.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last = t == gridDim.x - 1 ? 1u : 0u;
-    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next step's launch (stream-ordered behind this one)
+    if (last) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next step's launch (stream-ordered behind this one)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
   }
+  IL_TL(0, 4);   // ticket taken
   __syncthreads();
   if (!last) return;
   pwil_merge_block(d, (int)gridDim.x, K, cand, out);
+  IL_TL(1, 7);
 }
 
 __global__ __launch_bounds__(256) void k_pwil_merge_serial(il_pwil d, int G, int K, const PwCand* __restrict__ cand, float* __restrict__ out) {
@@ -395,3 +469,5 @@ extern "C" int il_pwil_reward(const il_pwil* d, const float* state, const float*
   IL_CHECK_LAUNCH("il_pwil_reward");
   return IL_OK;
 }
+
+IL_TL_READER(il_debug_timeline_pwil)
