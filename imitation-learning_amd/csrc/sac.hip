@@ -891,10 +891,12 @@ struct DwArgs {
   float* log_alpha; float* alpha_grad; il_adam alpha_opt; const float* alpha_part; int n_alpha_part;
   float* target; const float* polyak_src; int64_t polyak_n; double tau; uint32_t* noise_counter; int64_t* sync;
   float* pk_target; const float* pk_critic; int64_t pk_n;   // lane-ordered copies of the target / critic hidden layers (polyak is elementwise, so it commutes with the re-ordering)
-  // data-parallel: the gradient exchange of this optimiser step rides in its block jobs (peer_device.hpp "the exchange INSIDE the kernel that produces the gradients"):
-  // job = the block job's index (the log-alpha step: n_big_blocks); peer.world == 0: none
-  il_peer_bucket peer; int64_t peer_alpha_at;
 };
+// data-parallel: the gradient exchange of an optimiser step rides in its block jobs (peer_device.hpp "the exchange INSIDE the kernel that produces the gradients"): job = the
+// block job's index (the log-alpha step: n_big_blocks). A kernel argument of its own, and a kernel of its own (k_dw_adam_peer: the functions below are templated on PEER):
+// the descriptor's window array is indexed at run time, which sends whatever struct holds it to scratch memory - inside DwArgs that cost the single-GPU k_dw_adam
+// 592 bytes of scratch per lane and 4 us per launch (measured, round 3).
+struct DwPeer { il_peer_bucket x; int64_t alpha_at; };
 
 __device__ __forceinline__ void adam_store(const DwArgs& a, const adam_consts& ac, int64_t o, float gr) {
   if (a.grads_only) { a.grads[o] = gr; return; }
@@ -1035,8 +1037,8 @@ __device__ __forceinline__ void dw_bias(const DwArgs& a, const adam_consts& ac, 
   if (g == 0 && n0 + j < Nvalid) adam_store(a, ac, poff + n0 + j, s);
 }
 
-template <int U, bool SKIPBIG = false>   // SKIPBIG: the H x H layers are done by dw_block64 workgroups of the same launch (population path)
-__device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, const int nblocks) {   // bid / nblocks: this learner's block index / count
+template <int U, bool SKIPBIG = false, bool PEER = false>   // SKIPBIG: the H x H layers are done by dw_block64 workgroups of the same launch (population path)
+__device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, const int nblocks, const DwPeer* pp = nullptr) {   // bid / nblocks: this learner's block index / count
   const int wave_in_block = threadIdx.x >> 6;
   if (bid >= a.n_dw_blocks) {  // ---- tail blocks
     const int tb = bid - a.n_dw_blocks;
@@ -1056,7 +1058,7 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
       for (int i = i0; i < a.n_alpha_part; ++i) s += a.alpha_part[i];
       const float alpha = expf(a.log_alpha[0]);
       float gr = -(alpha) * (s / (float)a.batch);
-      if (a.peer.world > 0) gr = peer_thread_allreduce1(a.peer, a.n_big_blocks, a.peer_alpha_at, gr);   // data-parallel: the mean over the ranks (its own arrival line behind the block jobs')
+      if (PEER) gr = peer_thread_allreduce1(pp->x, a.n_big_blocks, pp->alpha_at, gr);   // data-parallel: the mean over the ranks (its own arrival line behind the block jobs')
       if (a.grads_only) a.alpha_grad[0] = gr;
       else {
         const adam_consts ac = load_adam_consts(a.alpha_opt);
@@ -1285,8 +1287,9 @@ static inline int dw_block64_count(int H, int nets) { return (H / DWB) * (H / DW
 // then the four g as (g0 + g1) + (g2 + g3)), so the bias keeps its bits too. With it a network's whole optimiser step is nbh^2 + 2 nbh uniform workgroups (H = 256: 80)
 // and no wave-per-tile job is left: those were 72 % of the launch's line requests (32 KB of half-line gathers each).
 // `boff` >= 0: parameter offset of the bias of this dZ (only looked at by blocks with k0 == 0).
+template <bool PEER = false>
 __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restrict__ dzT, int Nvalid, const float* __restrict__ xT, int Kvalid, int n0, int k0, int64_t poff,
-                                           int64_t boff, float* __restrict__ pkf, float* __restrict__ pkb, float* smem, int pjob = -1) {
+                                           int64_t boff, float* __restrict__ pkf, float* __restrict__ pkb, float* smem, const DwPeer* pp = nullptr, int pjob = -1) {
   float* Zs = smem; float* Xs = smem + DWS * DWS_LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int ti = wave >> 1, tq = wave & 1;   // this wave's tile of the block
@@ -1362,22 +1365,23 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
   }
   __syncthreads();
   f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + er * DWS_GLD + ec);
-  if (a.peer.world > 0 && pjob >= 0) {   // data-parallel: this block's gradients (and bias gradients) become their mean over the ranks before the optimiser sees them
-    const PeerJob pj = peer_job_begin(a.peer, pjob);
-    if (full) peer_job_push4(a.peer, pj, eo, gv);
+  if (PEER) {   // data-parallel: this block's gradients (and bias gradients) become their mean over the ranks before the optimiser sees them
+    const il_peer_bucket& x = pp->x;
+    const PeerJob pj = peer_job_begin(x, pjob);
+    if (full) peer_job_push4(x, pj, eo, gv);
     else if (en < Nvalid) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) if (ek + c < Kvalid) peer_job_push1(a.peer, pj, poff + (int64_t)en * Kvalid + ek + c, gv[c]);
+      for (int c = 0; c < 4; ++c) if (ek + c < Kvalid) peer_job_push1(x, pj, poff + (int64_t)en * Kvalid + ek + c, gv[c]);
     }
-    if (bias_owner) peer_job_push1(a.peer, pj, boff + n0 + bf, bsum);
-    peer_job_exchange(a.peer, pj, pjob);
-    if (full) gv = peer_job_mean4(a.peer, pj, eo);
+    if (bias_owner) peer_job_push1(x, pj, boff + n0 + bf, bsum);
+    peer_job_exchange(x, pj, pjob);
+    if (full) gv = peer_job_mean4(x, pj, eo);
     else if (en < Nvalid) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) if (ek + c < Kvalid) gv[c] = peer_job_mean1(a.peer, pj, poff + (int64_t)en * Kvalid + ek + c);
+      for (int c = 0; c < 4; ++c) if (ek + c < Kvalid) gv[c] = peer_job_mean1(x, pj, poff + (int64_t)en * Kvalid + ek + c);
     }
-    if (bias_owner) bsum = peer_job_mean1(a.peer, pj, boff + n0 + bf);
-    peer_job_end(a.peer, pj, pjob);
+    if (bias_owner) bsum = peer_job_mean1(x, pj, boff + n0 + bf);
+    peer_job_end(x, pj, pjob);
   }
   if (bias_owner) {
     const int64_t o = boff + n0 + bf;
@@ -1418,7 +1422,8 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
 // One network's optimiser step as uniform block jobs: [0, nbh^2) the H x H layer (bias 2 with the k0 = 0 blocks), then nbh x kin blocks of layer 1 (bias 1), then
 // nout x nbh blocks of layer 3 (bias 3). Returns false when `job` is past the network's list.
 __host__ __device__ static inline int dw_block_jobs(int IN, int H, int OUT) { const int nbh = H / DWS; return nbh * nbh + nbh * ((IN + DWS - 1) / DWS) + ((OUT + DWS - 1) / DWS) * nbh; }
-__device__ __forceinline__ void dw_block_job(const DwArgs& a, int net, int job, float* smem, int pjob = -1) {
+template <bool PEER = false>
+__device__ __forceinline__ void dw_block_job(const DwArgs& a, int net, int job, float* smem, const DwPeer* pp = nullptr, int pjob = -1) {
   const int IN = a.in_dim, H = a.hidden, OUT = a.out_dim, nbh = H / DWS, kin = (IN + DWS - 1) / DWS;
   const int64_t pbase = (int64_t)net * a.net_stride;
   const int64_t oW1 = pbase, ob1 = oW1 + (int64_t)H * IN, oW2 = ob1 + H, ob2 = oW2 + (int64_t)H * H, oW3 = ob2 + H, ob3 = oW3 + (int64_t)OUT * H;
@@ -1433,36 +1438,45 @@ __device__ __forceinline__ void dw_block_job(const DwArgs& a, int net, int job, 
       const int x = job & 7, slot = job >> 3;
       nb = 2 * (x >> 1) + (slot >> 2); kb = 4 * (x & 1) + (slot & 3);
     }
-    dw_block32(a, dz2, H, h1, H, nb * DWS, kb * DWS, oW2, ob2, a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem, pjob);
+    dw_block32<PEER>(a, dz2, H, h1, H, nb * DWS, kb * DWS, oW2, ob2, a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem, pp, pjob);
     return;
   }
   job -= nbh * nbh;
-  if (job < nbh * kin) { dw_block32(a, dz1, H, a.x0 + net * a.x0_net_stride, IN, (job / kin) * DWS, (job % kin) * DWS, oW1, ob1, nullptr, nullptr, smem, pjob); return; }
+  if (job < nbh * kin) { dw_block32<PEER>(a, dz1, H, a.x0 + net * a.x0_net_stride, IN, (job / kin) * DWS, (job % kin) * DWS, oW1, ob1, nullptr, nullptr, smem, pp, pjob); return; }
   job -= nbh * kin;
-  dw_block32(a, a.dz3 + net * a.dz3_net_stride, OUT, h2, H, (job / nbh) * DWS, (job % nbh) * DWS, oW3, ob3, nullptr, nullptr, smem, pjob);
+  dw_block32<PEER>(a, a.dz3 + net * a.dz3_net_stride, OUT, h2, H, (job / nbh) * DWS, (job % nbh) * DWS, oW3, ob3, nullptr, nullptr, smem, pp, pjob);
 }
 static inline int dw_block32_count(int H, int nets) { return (H / DWS) * (H / DWS) * nets; }
 static inline bool dw_block32_fits(int H, int B) { return H % DWS == 0 && B % DWS_ROWS == 0; }
 
-__global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * DWS * DWS_LD];
+template <bool PEER>
+__device__ __forceinline__ void dw_adam_kernel(const DwArgs& a, const DwPeer* pp, float* smem) {
   IL_TL(a.log_alpha ? 2 : 1, 0);   // [1] critic launch, [2] actor launch (the one with the alpha / polyak tail)
   if (a.n_big_blocks > 0) {   // [0, n_big_blocks): every layer's dW + bias as 32 x 32 block jobs through LDS (x0 must be feature-major); then the tail blocks
     const int bx = (int)blockIdx.x;
     if (bx < a.n_big_blocks) {
       const int per_net = dw_block_jobs(a.in_dim, a.hidden, a.out_dim);
-      dw_block_job(a, bx / per_net, bx % per_net, smem, bx);
+      dw_block_job<PEER>(a, bx / per_net, bx % per_net, smem, pp, bx);
       IL_TL_END(a.log_alpha ? 2 : 1);
       return;
     }
     DwArgs r = a;
     r.n_dw_blocks = 0;   // nothing but the tail is left
-    dw_adam_body<IL_DW_U, true>(r, bx - a.n_big_blocks, (int)gridDim.x - a.n_big_blocks);
+    dw_adam_body<IL_DW_U, true, PEER>(r, bx - a.n_big_blocks, (int)gridDim.x - a.n_big_blocks, pp);
     IL_TL_END(a.log_alpha ? 2 : 1);
     return;
   }
   dw_adam_body<IL_DW_U>(a, (int)blockIdx.x, (int)gridDim.x);
   IL_TL_END(a.log_alpha ? 2 : 1);
+}
+__global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * DWS * DWS_LD];
+  dw_adam_kernel<false>(a, nullptr, smem);
+}
+// the same launch with the gradient exchange of a data-parallel run inside its block jobs (il_sac_update_gather_peer; n_big_blocks > 0 is checked by the caller)
+__global__ __launch_bounds__(256) void k_dw_adam_peer(DwArgs a, DwPeer p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * DWS * DWS_LD];
+  dw_adam_kernel<true>(a, &p, smem);
 }
 
 static int repack_blocks(int H) { return ceil_div(H * H / 16, 256); }
@@ -1707,16 +1721,18 @@ static int sac_update_gather_impl(const il_sac* d, const il_batch* rows, const i
   if (chain_xcd_nets(nt) && G <= 2 * nt) { rl.xcd_nets = 1; rl.gather_wgs = G; }
   { IL_TRACE("k_sac_chain", st); k_sac_chain<<<rl.xcd_nets ? 8 * nt : 6 * nt + G, tile_threads(H), lds, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl); }
   DwArgs ca = critic_dw_args(d, flags);
-  if (peer_critic) ca.peer = *peer_critic;
-  { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
+  if (peer_critic) { DwPeer cp = {*peer_critic, 0}; IL_TRACE("k_dw_adam_critic", st); k_dw_adam_peer<<<ca.n_dw_blocks, 256, 0, st>>>(ca, cp); }
+  else { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
   if (flags & IL_FLAG_GRADS_ONLY) {   // data-parallel: stop at the critic gradients (critic_grad); the caller all-reduces them and continues with il_sac_dp_phase(rows, 2) and (rows, 3)
     IL_CHECK_LAUNCH("il_sac_update_gather");
     return IL_OK;
   }
   { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *rows, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
   DwArgs aa = actor_dw_args(d, rows, flags);
-  if (peer_actor) { aa.peer = *peer_actor; aa.peer_alpha_at = mlp_numel(d->state_dim, d->hidden, 2 * d->action_dim); }
-  { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + IL_TAIL_BLOCKS, 256, 0, st>>>(aa); }
+  if (peer_actor) {
+    DwPeer ap = {*peer_actor, mlp_numel(d->state_dim, d->hidden, 2 * d->action_dim)};
+    IL_TRACE("k_dw_adam_actor", st); k_dw_adam_peer<<<aa.n_dw_blocks + IL_TAIL_BLOCKS, 256, 0, st>>>(aa, ap);
+  } else { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + IL_TAIL_BLOCKS, 256, 0, st>>>(aa); }
   IL_CHECK_LAUNCH("il_sac_update_gather");
   return IL_OK;
 }
