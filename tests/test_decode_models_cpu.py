@@ -86,3 +86,31 @@ def test_dw_block_xcd_rectangles():
   # the job counts the host and the kernel agree on (dw_block_jobs): per network nbh^2 + nbh * ceil(IN / 32) + ceil(OUT / 32) * nbh, a multiple of 8 at H = 256
   jobs = lambda IN, H, OUT: (H // 32) ** 2 + (H // 32) * ((IN + 31) // 32) + ((OUT + 31) // 32) * (H // 32)
   assert jobs(24, 256, 1) == 80 and jobs(18, 256, 12) == 80 and jobs(120, 256, 1) % 8 == 0
+
+
+def test_pwil_wave_ranking_equals_full_rank_counting():
+  import numpy as np
+  """csrc/pwil.hip pw_rank256: a key's rank among the 256 (distance, index) keys of a chunk = its rank inside its wave of 64 + per other wave the number of smaller keys
+  found by a branch-free binary search (steps 64 .. 1) over that wave's sorted run padded to 128 slots with the largest key. Must equal counting every key - ties on the
+  distance (consumed atoms all carry FLT_MAX), exhausted lists and pad keys included."""
+  rng = np.random.RandomState(5)
+  for case in range(6):
+    dist = rng.uniform(0, 4, 256).astype(np.float32)
+    if case >= 1: dist[rng.choice(256, 90, replace=False)] = np.finfo(np.float32).max   # consumed atoms / rows past the end of the set
+    if case >= 2: dist[rng.choice(256, 40, replace=False)] = dist[3]                      # exact ties: the index decides
+    if case == 5: dist[:] = 1.5
+    key = (dist.view(np.uint32).astype(np.uint64) << np.uint64(32)) | np.arange(256, dtype=np.uint64)
+    want = np.array([(key < k).sum() for k in key])
+    runs = [np.concatenate([np.sort(key[64 * w:64 * w + 64]), np.full(64, np.uint64(2 ** 64 - 1))]) for w in range(4)]
+    got = np.empty(256, np.int64)
+    for t in range(256):
+      w = t // 64
+      r = int((key[64 * w:64 * w + 64] < key[t]).sum())   # the v_readlane loop of the wave
+      for q in (1, 2, 3):
+        a, pos = runs[(w + q) & 3], 0
+        for step in (64, 32, 16, 8, 4, 2, 1):
+          if a[pos + step - 1] < key[t]: pos += step
+        r += pos
+      got[t] = r
+    np.testing.assert_array_equal(got, want)
+    assert sorted(got) == list(range(256))
