@@ -55,8 +55,11 @@ struct DrilMasks { const float* in; const float* h[2]; uint32_t ctr; };
 
 // Masked forward of `rows` virtual rows (virtual row v reads batch row row0 + v / rep). Leaves x~ in X, the hidden activations in Hh[l], m_l/(1-p) in Ms[l]
 // (when carved), the head in O.
+// (DEPTH as a template parameter of the kernels: with a run-time depth the per-layer tables of DrilLds / DrilLayout / DrilMasks are indexed dynamically and live in scratch memory)
+template <int DEPTH>
 __device__ __forceinline__ void dril_forward(const il_dril& d, const il_batch& b, const DrilMasks& mk, int row0, int rows, int rep, const DrilLds& L) {
-  const int S = d.state_dim, A = d.action_dim, H = d.hidden, ldx = S + 1, ldh = H + 1, depth = dril_depth(d), relu = d.activation == 1;
+  constexpr int depth = DEPTH;
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, ldx = S + 1, ldh = H + 1, relu = d.activation == 1;
   const DrilLayout lay = dril_layout(S, A, H, depth);
   const int tid = threadIdx.x, nthr = blockDim.x;
   for (int i = tid; i < rows * S; i += nthr) {
@@ -114,16 +117,18 @@ __device__ __forceinline__ float dril_logp_row(const il_dril& d, const il_batch&
   return (0.f - sl) + sn;
 }
 
+template <int DEPTH>
 __global__ __launch_bounds__(256) void k_dril_grad(il_dril d, il_batch b, DrilMasks mk) {
   if (d.noise_counter) mk.ctr += *d.noise_counter;   // captured plans: the per-update part of the Philox counter lives on the device
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = b.n, ldx = S + 1, ldh = H + 1, depth = dril_depth(d), relu = d.activation == 1;
+  constexpr int depth = DEPTH;
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = b.n, ldx = S + 1, ldh = H + 1, relu = d.activation == 1;
   const DrilLayout lay = dril_layout(S, A, H, depth);
   const DrilLds L = dril_carve(smem, DT, S, H, depth, 1);
   float* X = L.X; float* O = L.O; float* lossr = L.tail;
   const int tile = blockIdx.x, row0 = tile * DT, tid = threadIdx.x, nthr = blockDim.x;
   if (tile == 0 && tid == 0) adam_tick(d.opt);
-  dril_forward(d, b, mk, row0, DT, 1, L);
+  dril_forward<DEPTH>(d, b, mk, row0, DT, 1, L);
   if (tid < DT) {
     const int r = row0 + tid;
     float l = 0.f;
@@ -229,14 +234,15 @@ __global__ __launch_bounds__(256) void k_dril_apply(il_dril d, int nt, int apply
   }
 }
 
+template <int DEPTH>
 __global__ __launch_bounds__(256) void k_dril_unc(il_dril d, il_batch b, DrilMasks mk, float* __restrict__ out_unc, float* __restrict__ out_reward) {
   if (d.noise_counter) mk.ctr += *d.noise_counter;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int V = DU * DRIL_ENSEMBLE;
-  const DrilLds L = dril_carve(smem, V, d.state_dim, d.hidden, dril_depth(d), 0);   // forward only: the keep-scales are not kept
+  const DrilLds L = dril_carve(smem, V, d.state_dim, d.hidden, DEPTH, 0);   // forward only: the keep-scales are not kept
   float* O = L.O; float* prob = L.tail;
   const int row0 = blockIdx.x * DU, tid = threadIdx.x;
-  dril_forward(d, b, mk, row0, V, DRIL_ENSEMBLE, L);
+  dril_forward<DEPTH>(d, b, mk, row0, V, DRIL_ENSEMBLE, L);
   if (tid < V) {
     const int r = row0 + tid / DRIL_ENSEMBLE;
     prob[tid] = (r < b.n) ? expf(dril_logp_row(d, b, r, O + tid * 17, false, 0.f)) : 0.f;   // models.py:106
@@ -281,11 +287,12 @@ extern "C" int il_dril_bc_step(const il_dril* d, const il_batch* expert, const f
   IL_CHECK_ARG(d->batch == expert->n, "il_dril_bc_step: descriptor batch %d != batch rows %d", d->batch, expert->n);
   const int nt = ceil_div(expert->n, DT), depth = dril_depth(*d);
   const size_t lds = dril_lds_floats(DT, d->state_dim, d->hidden, depth, 1) * sizeof(float);
-  if (int rc = dril_ensure_lds((const void*)k_dril_grad, lds)) return rc;
+  const auto grad = depth == 2 ? k_dril_grad<2> : k_dril_grad<1>;
+  if (int rc = dril_ensure_lds((const void*)grad, lds)) return rc;
   hipStream_t st = (hipStream_t)stream_;
   const int64_t P = dril_layout(d->state_dim, d->action_dim, d->hidden, depth).P;
   const DrilMasks mk = {mask_in, {mask_hidden, mask_hidden2}, noise_offset};
-  { IL_TRACE("k_dril_grad", st); k_dril_grad<<<nt, 256, lds, st>>>(*d, *expert, mk); }
+  { IL_TRACE("k_dril_grad", st); grad<<<nt, 256, lds, st>>>(*d, *expert, mk); }
   { IL_TRACE("k_dril_apply", st); k_dril_apply<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, nt, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, out_loss); }
   IL_CHECK_LAUNCH("il_dril_bc_step");
   return IL_OK;
@@ -297,10 +304,11 @@ extern "C" int il_dril_uncertainty(const il_dril* d, const il_batch* batch, cons
   if (int rc = check_dril(d, batch)) return rc;
   IL_CHECK_ARG(out_uncertainty || out_reward, "il_dril_uncertainty: nothing to write");
   const size_t lds = dril_lds_floats(DU * DRIL_ENSEMBLE, d->state_dim, d->hidden, dril_depth(*d), 0) * sizeof(float);
-  if (int rc = dril_ensure_lds((const void*)k_dril_unc, lds)) return rc;
+  const auto unc = dril_depth(*d) == 2 ? k_dril_unc<2> : k_dril_unc<1>;
+  if (int rc = dril_ensure_lds((const void*)unc, lds)) return rc;
   const DrilMasks mk = {mask_in, {mask_hidden, mask_hidden2}, noise_offset};
   { IL_TRACE("k_dril_unc", (hipStream_t)stream_);
-    k_dril_unc<<<ceil_div(batch->n, DU), 256, lds, (hipStream_t)stream_>>>(*d, *batch, mk, out_uncertainty, out_reward); }
+    unc<<<ceil_div(batch->n, DU), 256, lds, (hipStream_t)stream_>>>(*d, *batch, mk, out_uncertainty, out_reward); }
   IL_CHECK_LAUNCH("il_dril_uncertainty");
   return IL_OK;
 }

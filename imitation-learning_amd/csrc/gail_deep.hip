@@ -180,9 +180,12 @@ __device__ __forceinline__ void gd_outer(float* slab, const GdLayout& lay, int i
     }
 }
 
+// (DEPTH as a template parameter: with a run-time depth the per-layer tables of GdLds / GdLayout are indexed dynamically and live in scratch memory, 320 bytes per lane)
+template <int DEPTH>
 __global__ __launch_bounds__(256) void k_gd_grad(il_disc_deep d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp, il_gail_extra x, int pu_value_pass) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch, depth = gd_depth(d), tanh_ = d.activation == 1;
+  constexpr int depth = DEPTH;
+  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch, tanh_ = d.activation == 1;
   const int tile = blockIdx.x, call = blockIdx.y, nt = gridDim.x, row0 = tile * GD_R, tid = threadIdx.x, nthr = blockDim.x;
   const int nrows = min(GD_R, B - row0);
   const bool mixup = d.loss_function == IL_LOSS_MIXUP;
@@ -394,16 +397,22 @@ __global__ __launch_bounds__(256) void k_gd_grad(il_disc_deep d, il_batch pol, i
 }
 
 // grid = ceil(P / 256): one parameter per thread; slabs summed in (call, tile) order (deterministic)
+template <int DEPTH>
 __global__ __launch_bounds__(256) void k_gd_reduce(il_disc_deep d, int apply) {
-  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch, depth = gd_depth(d);
+  constexpr int depth = DEPTH;
+  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch;
   const GdLayout lay = gd_layout(D, H, depth, d.spectral_norm);
   const GdWs ws = gd_ws(D, H, depth, B);
   const int nt = (B + GD_R - 1) / GD_R, calls = gd_calls(d);
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < lay.P) {
-    int layer = -1, n = 0, k = 0;
-    for (int i = 0; i <= depth; ++i)
-      if (e >= lay.oW[i] && e < lay.oW[i] + (int64_t)lay.out[i] * lay.in[i]) { layer = i; n = (int)((e - lay.oW[i]) / lay.in[i]); k = (int)((e - lay.oW[i]) % lay.in[i]); }
+    int layer = -1, n = 0, k = 0, out_l = 0;
+    int64_t o_l = 4, o_run = 4;   // where the layer's u | v sit in a call's context (found with compile-time indices: a table looked up by `layer` would live in scratch memory)
+#pragma unroll
+    for (int i = 0; i <= depth; ++i) {
+      if (e >= lay.oW[i] && e < lay.oW[i] + (int64_t)lay.out[i] * lay.in[i]) { layer = i; n = (int)((e - lay.oW[i]) / lay.in[i]); k = (int)((e - lay.oW[i]) % lay.in[i]); o_l = o_run; out_l = lay.out[i]; }
+      o_run += lay.out[i] + lay.in[i];
+    }
     float g = 0.f;
     for (int c = 0; c < calls; ++c) {
       const float* sl = d.workspace + ws.slabs + (size_t)c * nt * ws.slab_stride;
@@ -413,9 +422,7 @@ __global__ __launch_bounds__(256) void k_gd_reduce(il_disc_deep d, int apply) {
         const float* ctx = d.workspace + ws.ctx + (size_t)c * ws.ctx_stride;
         float ip = 0.f;
         for (int t = 0; t < nt; ++t) ip += sl[(size_t)t * ws.slab_stride + lay.P + layer];
-        int64_t o = 4;
-        for (int i = 0; i < layer; ++i) o += lay.out[i] + lay.in[i];
-        const float sg = ctx[layer], u = ctx[o + n], v = ctx[o + lay.out[layer] + k];
+        const float sg = ctx[layer], u = ctx[o_l + n], v = ctx[o_l + out_l + k];
         gc = gc / sg - (ip / (sg * sg)) * (u * v);
       }
       g += gc;
@@ -434,9 +441,11 @@ __global__ __launch_bounds__(256) void k_gd_reduce(il_disc_deep d, int apply) {
   }
 }
 
+template <int DEPTH>
 __global__ __launch_bounds__(256) void k_gd_reward(il_disc_deep d, il_batch b, float* __restrict__ out_r, float* __restrict__ out_logit, const float* __restrict__ logit_offset) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, depth = gd_depth(d), tanh_ = d.activation == 1;
+  constexpr int depth = DEPTH;
+  const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, tanh_ = d.activation == 1;
   const int row0 = blockIdx.x * GD_R, tid = threadIdx.x, nrows = min(GD_R, b.n - row0);
   const GdLayout lay = gd_layout(D, H, depth, d.spectral_norm);
   const GdLds l = gd_carve(smem, D, H, depth);
@@ -485,15 +494,17 @@ extern "C" int il_gail_deep_step(const il_disc_deep* d, const il_batch* pol, con
   IL_CHECK_ARG(d->loss_function != IL_LOSS_MIXUP || (!x.logit_offset_policy && !x.logit_offset_expert), "il_gail_deep_step: with Mixup the log-policy offset belongs to the mixed batch (logit_offset_mix)");
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim), depth = gd_depth(*d), nt = ceil_div(d->batch, GD_R);
   const size_t lds = gd_lds_floats(D, d->hidden, depth) * sizeof(float);
-  if (int rc = gd_ensure_lds((const void*)k_gd_grad, lds)) return rc;
+  const auto grad = depth == 2 ? k_gd_grad<2> : k_gd_grad<1>;
+  const auto reduce = depth == 2 ? k_gd_reduce<2> : k_gd_reduce<1>;
+  if (int rc = gd_ensure_lds((const void*)grad, lds)) return rc;
   hipStream_t st = (hipStream_t)stream_;
   if (d->loss_function == IL_LOSS_PUGAIL && d->pu_clamped) {   // finite nonnegative_margin: a value pass (logits only) ahead of the gradient pass, which reads the clamp decision
     IL_CHECK_ARG(d->nonnegative_margin >= 0.f, "il_gail_deep_step: nonnegative_margin must be >= 0");
-    { IL_TRACE("k_gd_grad", st); k_gd_grad<<<dim3(nt, 2), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, 1); }
+    { IL_TRACE("k_gd_grad", st); grad<<<dim3(nt, 2), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, 1); }
   }
-  { IL_TRACE("k_gd_grad", st); k_gd_grad<<<dim3(nt, gd_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, 0); }
+  { IL_TRACE("k_gd_grad", st); grad<<<dim3(nt, gd_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, 0); }
   const int64_t P = gd_layout(D, d->hidden, depth, d->spectral_norm).P;
-  { IL_TRACE("k_gd_reduce", st); k_gd_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1); }
+  { IL_TRACE("k_gd_reduce", st); reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1); }
   IL_CHECK_LAUNCH("il_gail_deep_step");
   return IL_OK;
 }
@@ -504,8 +515,9 @@ extern "C" int il_gail_deep_reward(const il_disc_deep* d, const il_batch* b, flo
   IL_CHECK_ARG(b && out_rewards && b->n > 0, "il_gail_deep_reward: bad arguments");
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
   const size_t lds = gd_lds_floats(D, d->hidden, gd_depth(*d)) * sizeof(float);
-  if (int rc = gd_ensure_lds((const void*)k_gd_reward, lds)) return rc;
-  { IL_TRACE("k_gd_reward", stream_); k_gd_reward<<<ceil_div(b->n, GD_R), 256, lds, (hipStream_t)stream_>>>(*d, *b, out_rewards, out_logits, logit_offset); }
+  const auto reward = gd_depth(*d) == 2 ? k_gd_reward<2> : k_gd_reward<1>;
+  if (int rc = gd_ensure_lds((const void*)reward, lds)) return rc;
+  { IL_TRACE("k_gd_reward", stream_); reward<<<ceil_div(b->n, GD_R), 256, lds, (hipStream_t)stream_>>>(*d, *b, out_rewards, out_logits, logit_offset); }
   IL_CHECK_LAUNCH("il_gail_deep_reward");
   return IL_OK;
 }

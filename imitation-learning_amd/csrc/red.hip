@@ -68,8 +68,11 @@ __device__ __forceinline__ float red_dot(const float* x, const float* __restrict
 struct RedMasks { const float* in; const float* h[2]; uint32_t ctr; int training; };
 
 // Both networks' forward on one tile. Leaves X, Xm, Hp / Ht / M per layer and E = pred - target in LDS. Rows >= n are zero inputs with zero keep-scales.
+// (DEPTH as a template parameter of the kernels: with a run-time depth the per-layer tables of RedLds / RedLayout / RedMasks are indexed dynamically and live in scratch memory)
+template <int DEPTH>
 __device__ __forceinline__ void red_forward_tile(const RedLds& l, const il_red& d, const il_batch& b, const RedMasks& mk, int row0, int D, int H) {
-  const int depth = red_depth(d), tanh_ = d.activation == 1;
+  constexpr int depth = DEPTH;
+  const int tanh_ = d.activation == 1;
   const RedLayout lay = red_layout(D, H, depth);
   const int S = d.state_dim, tid = threadIdx.x, nthr = blockDim.x;
   const bool drop_in = mk.training && d.p_in > 0.f, drop_h = mk.training && d.p > 0.f;
@@ -117,17 +120,19 @@ __device__ __forceinline__ void red_forward_tile(const RedLds& l, const il_red& 
   __syncthreads();
 }
 
+template <int DEPTH>
 __global__ __launch_bounds__(256) void k_red_grad(il_red d, il_batch b, RedMasks mk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int D = d.state_dim + (d.state_only ? 0 : d.action_dim), H = d.hidden, B = b.n;
-  const int depth = red_depth(d), tanh_ = d.activation == 1;
+  constexpr int depth = DEPTH;
+  const int tanh_ = d.activation == 1;
   const RedLayout lay = red_layout(D, H, depth);
   const RedLds l = red_carve(smem, D, H, depth);
   float* rowsum = l.scratch;  // [RT] + [RT]
   const int tile = blockIdx.x, row0 = tile * RT, tid = threadIdx.x, nthr = blockDim.x;
   if (tile == 0 && tid == 0) adam_tick(d.opt);
   d.out_pred = nullptr;
-  red_forward_tile(l, d, b, mk, row0, D, H);
+  red_forward_tile<DEPTH>(l, d, b, mk, row0, D, H);
   // loss partial and G = dLoss/dpred = 2 w_r E / (B D)   (training.py:72: (w * err^2.mean(1)).mean())
   if (tid < RT) {
     const int r = tid;
@@ -232,12 +237,13 @@ __global__ __launch_bounds__(256) void k_red_apply(il_red d, int nt, int apply, 
   }
 }
 
+template <int DEPTH>
 __global__ __launch_bounds__(256) void k_red_eval(il_red d, il_batch b, RedMasks mk, float* __restrict__ out_reward) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int D = d.state_dim + (d.state_only ? 0 : d.action_dim), H = d.hidden;
-  const RedLds l = red_carve(smem, D, H, red_depth(d));
+  const RedLds l = red_carve(smem, D, H, DEPTH);
   const int row0 = blockIdx.x * RT;
-  red_forward_tile(l, d, b, mk, row0, D, H);
+  red_forward_tile<DEPTH>(l, d, b, mk, row0, D, H);
   if (out_reward && threadIdx.x < RT && row0 + threadIdx.x < b.n) {
     const int r = threadIdx.x;
     float s = 0.f;
@@ -273,11 +279,12 @@ extern "C" int il_red_step(const il_red* d, const il_batch* expert, const float*
   IL_CHECK_ARG(d->batch == expert->n, "il_red_step: descriptor batch %d != batch rows %d", d->batch, expert->n);
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim), nt = ceil_div(expert->n, RT), depth = red_depth(*d);
   const size_t lds = red_lds_floats(D, d->hidden, depth) * sizeof(float);
-  if (int rc = red_ensure_lds((const void*)k_red_grad, lds)) return rc;
+  const auto grad = depth == 2 ? k_red_grad<2> : k_red_grad<1>;
+  if (int rc = red_ensure_lds((const void*)grad, lds)) return rc;
   hipStream_t st = (hipStream_t)stream_;
   const int64_t P = red_layout(D, d->hidden, depth).P;
   const RedMasks mk = {mask_in, {mask_h1, mask_h2}, noise_offset, 1};   // target_estimation_update runs in train mode (train.py:115-123 precede :147)
-  { IL_TRACE("k_red_grad", st); k_red_grad<<<nt, 256, lds, st>>>(*d, *expert, mk); }
+  { IL_TRACE("k_red_grad", st); grad<<<nt, 256, lds, st>>>(*d, *expert, mk); }
   { IL_TRACE("k_red_apply", st); k_red_apply<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, nt, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, out_loss); }
   IL_CHECK_LAUNCH("il_red_step");
   return IL_OK;
@@ -291,10 +298,11 @@ extern "C" int il_red_forward(const il_red* d, const il_batch* batch, int32_t tr
   IL_CHECK_ARG((out_pred == nullptr) == (out_target == nullptr), "il_red_forward: out_pred and out_target go together");
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
   const size_t lds = red_lds_floats(D, d->hidden, red_depth(*d)) * sizeof(float);
-  if (int rc = red_ensure_lds((const void*)k_red_eval, lds)) return rc;
+  const auto eval = red_depth(*d) == 2 ? k_red_eval<2> : k_red_eval<1>;
+  if (int rc = red_ensure_lds((const void*)eval, lds)) return rc;
   il_red dd = *d; dd.out_pred = out_pred; dd.out_target = out_target;
   const RedMasks mk = {mask_in, {mask_h1, mask_h2}, noise_offset, training ? 1 : 0};
-  { IL_TRACE("k_red_eval", (hipStream_t)stream_); k_red_eval<<<ceil_div(batch->n, RT), 256, lds, (hipStream_t)stream_>>>(dd, *batch, mk, out_reward); }
+  { IL_TRACE("k_red_eval", (hipStream_t)stream_); eval<<<ceil_div(batch->n, RT), 256, lds, (hipStream_t)stream_>>>(dd, *batch, mk, out_reward); }
   IL_CHECK_LAUNCH("il_red_forward");
   return IL_OK;
 }
