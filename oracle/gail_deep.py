@@ -116,20 +116,23 @@ def _backward_first_order(Wh, acts, dz_out, act):
   return GW, Gb
 
 
-def _grad_penalty_grads(Wh, acts, c, act):
-  """Gradients of sum_r c_r ||dD/dx_r||^2 w.r.t. the effective weights / biases. acts = [x, a_1 .. a_L]; layer index l = 0 .. L-1 hidden, L = output."""
+def _input_gradient(Wh, acts, act):
+  """The input-gradient pass g = dD/dx of one call: u[l] = dD/dz_{l+1} (hidden layer l, 0-based), s[l] = u[l] W^_l = dD/da_l; g = s[0]."""
   L = len(Wh) - 1
-  # the input-gradient pass: u[l] = dD/dz_{l+1} (hidden layer l, 0-based), s[l] = u[l] W^_l = dD/da_l
   u, s = [None] * L, [None] * L
   u[L - 1] = _dphi(acts[L], act) * Wh[L][0][None, :]
   for l in range(L - 1, -1, -1):
     s[l] = (u[l] @ Wh[l]).astype(f32)
     if l > 0:
       u[l - 1] = _dphi(acts[l], act) * s[l]
-  g = s[0]
+  return u, s
+
+
+def _input_gradient_backward(Wh, acts, u, s, sbar, act):
+  """Gradients w.r.t. the effective weights / biases of a loss that reaches the parameters only through g = dD/dx, given sbar = dL/dg [B, D]."""
+  L = len(Wh) - 1
   GW = [np.zeros_like(w) for w in Wh]; Gb = [np.zeros(w.shape[0], f32) for w in Wh]
-  # derivative of that pass
-  sbar = (f32(2) * c[:, None] * g).astype(f32)              # dL/dg
+  sbar = sbar.astype(f32)
   zbar2 = [None] * L                                         # second-order terms entering the forward graph at z_{l+1}
   for l in range(L):
     GW[l] += (u[l].T @ sbar).astype(f32)                     # s_l = u_l W^_l
@@ -147,6 +150,12 @@ def _grad_penalty_grads(Wh, acts, c, act):
       if l > 0:
         zbar = (zbar @ Wh[l]) * _dphi(acts[l], act) + zbar2[l - 1]
   return GW, Gb
+
+
+def _grad_penalty_grads(Wh, acts, c, act):
+  """Gradients of sum_r c_r ||dD/dx_r||^2 w.r.t. the effective weights / biases. acts = [x, a_1 .. a_L]; layer index l = 0 .. L-1 hidden, L = output."""
+  u, s = _input_gradient(Wh, acts, act)
+  return _input_gradient_backward(Wh, acts, u, s, (f32(2) * c[:, None] * s[0]).astype(f32), act)   # dL/dg = 2 c g
 
 
 def gail_update(ds: DeepDiscState, xp, wp, xe, we, eps_gp, *, lr, weight_decay, grad_penalty=1.0, entropy_bonus=0.0, return_grads=False, loss_function='BCE',

@@ -103,6 +103,39 @@ GAIL_DEEP_CASES = (   # name, gail_deep_case arguments, loss_function, (lr, weig
 )
 
 
+def gail_shaped_deep_case(seed, env, hidden, batch, steps, depth=2, activation='tanh', spectral_norm=True, state_only=False):
+  """Reward-shaping discriminator with a shaping potential of any `_create_fcnn` shape: g = Linear(Dg, 1), h = [Linear - act] x depth - Linear(H, 1) on the state,
+  spectral-norm buffers per Linear, batches with ~30 % terminals, the U(0,1) draws of the gradient penalty, Beta draws for Mixup and log pi offsets."""
+  S, A = DIMS[env]
+  Dg = S if state_only else S + A
+  rs = np.random.RandomState(seed)
+  dims = [S] + [hidden] * depth + [1]
+  unit = lambda x: (x / np.linalg.norm(x)).astype(f32)
+  c = dict(S=S, A=A, Dg=Dg, H=hidden, B=batch, depth=depth, activation=activation, spectral_norm=spectral_norm, state_only=state_only,
+           Wg=(rs.standard_normal((1, Dg)) / np.sqrt(Dg)).astype(f32), bg=(rs.standard_normal(1) * 0.05).astype(f32),
+           ug=unit(rs.standard_normal(1)), vg=unit(rs.standard_normal(Dg)),
+           W=[(rs.standard_normal((dims[i + 1], dims[i])) * np.sqrt((2.0 if i < depth else 1.0) / dims[i])).astype(f32) for i in range(depth + 1)],
+           b=[(rs.standard_normal(dims[i + 1]) * 0.05).astype(f32) for i in range(depth + 1)],
+           u=[unit(rs.standard_normal(dims[i + 1])) for i in range(depth + 1)], v=[unit(rs.standard_normal(dims[i])) for i in range(depth + 1)])
+  c['policy'] = [transitions(rs, batch, S, A, weighted=True, terminal_frac=0.3) for _ in range(steps)]
+  c['expert'] = [transitions(rs, batch, S, A, state_shift=0.5, weighted=True, terminal_frac=0.3) for _ in range(steps)]
+  c['eps'] = [rs.uniform(size=batch).astype(f32) for _ in range(steps)]
+  c['eps_mix'] = [rs.beta(0.7, 0.7, size=batch).astype(f32) for _ in range(steps)]
+  c['logp_policy'] = [(rs.standard_normal(batch) * 0.5 - 1.0).astype(f32) for _ in range(steps)]
+  c['logp_expert'] = [(rs.standard_normal(batch) * 0.5 - 1.0).astype(f32) for _ in range(steps)]
+  return c
+
+
+GAIL_SHAPED_DEEP_CASES = (   # name, gail_shaped_deep_case arguments, loss_function, (lr, weight decay, grad_penalty, entropy_bonus), reward_function, nonnegative_margin
+    ('hopper_d2_tanh_sn', dict(seed=121, env='hopper', hidden=32, batch=96, steps=2, depth=2, activation='tanh', spectral_norm=True), 'BCE', (1e-3, 0.1, 0.7, 0.01), 'AIRL', float('inf')),
+    ('halfcheetah_d2_relu', dict(seed=122, env='halfcheetah', hidden=64, batch=64, steps=2, depth=2, activation='relu', spectral_norm=False), 'PUGAIL', (5e-4, 1.0, 1.0, 0.0), 'GAIL', float('inf')),
+    ('walker2d_d1_tanh_sn', dict(seed=123, env='walker2d', hidden=64, batch=80, steps=2, depth=1, activation='tanh', spectral_norm=True), 'Mixup', (1e-3, 0.0, 0.3, 0.05), 'FAIRL', float('inf')),
+    ('hopper_d2_relu_sn_margin', dict(seed=124, env='hopper', hidden=32, batch=72, steps=2, depth=2, activation='relu', spectral_norm=True), 'PUGAIL', (1e-3, 0.1, 0.5, 0.02), 'AIRL', 0.02),
+    ('hopper_d2_tanh_sn_state_only', dict(seed=125, env='hopper', hidden=32, batch=64, steps=2, depth=2, activation='tanh', spectral_norm=True, state_only=True), 'BCE', (1e-3, 0.1, 0.0, 0.01), 'AIRL',
+     float('inf')),   # state_only: the reference's gradient penalty differentiates w.r.t. an action the discriminator never saw and raises, so grad_penalty = 0 here
+)
+
+
 def mixup_draws(seed, batch, steps):
   """The Beta(alpha, alpha) coefficients of `steps` Mixup updates (training.py:106), fed to the reference and to the HIP path alike."""
   rs = np.random.RandomState(seed)

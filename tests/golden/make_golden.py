@@ -514,6 +514,66 @@ def gen_gail_shaped_mixup():
   np.savez_compressed(os.path.join(HERE, 'gail_shaped_mixup.npz'), **out)
 
 
+def shaped_deep_disc(c, icfg):
+  """The reference's reward-shaping GAILDiscriminator for a gail_shaped_deep_case; and the indices of the Linear layers of its potential d.h."""
+  d = ref_models.GAILDiscriminator(c['S'], c['A'], icfg, 0.97)
+  lin = [2 * l for l in range(c['depth'] + 1)]
+  with torch.no_grad():
+    if c['spectral_norm']:
+      d.g.parametrizations.weight.original.copy_(T(c['Wg'])); d.g.bias.copy_(T(c['bg']))
+      d.g.parametrizations.weight[0]._u.copy_(T(c['ug'])); d.g.parametrizations.weight[0]._v.copy_(T(c['vg']))
+      for l, li in enumerate(lin):
+        d.h[li].parametrizations.weight.original.copy_(T(c['W'][l])); d.h[li].bias.copy_(T(c['b'][l]))
+        d.h[li].parametrizations.weight[0]._u.copy_(T(c['u'][l])); d.h[li].parametrizations.weight[0]._v.copy_(T(c['v'][l]))
+    else:
+      d.g.weight.copy_(T(c['Wg'])); d.g.bias.copy_(T(c['bg']))
+      for l, li in enumerate(lin):
+        d.h[li].weight.copy_(T(c['W'][l])); d.h[li].bias.copy_(T(c['b'][l]))
+  return d, lin
+
+
+def gen_gail_shaped_deep():
+  """Reward shaping with a depth 1-2 / relu / tanh potential (models.py:157-160 with discriminator.depth / activation from conf/hyperparameter_search_space/GAIL.yaml)
+  under adversarial_imitation_update: BCE, PUGAIL (infinite and finite margin), Mixup; gradients, parameters after AdamW, u / v buffers, rewards. The first case also
+  runs a third update with subtract_log_policy-style logit offsets fed through `log_policy` (models.py:175)."""
+  out = {}
+  for name, kw, loss, (lr, wd, gp, ent), rf, margin in gi.GAIL_SHAPED_DEEP_CASES:
+    c = gi.gail_shaped_deep_case(**kw)
+    sn = c['spectral_norm']
+    icfg = DictConfig(state_only=c['state_only'], spectral_norm=sn, loss_function=loss, grad_penalty=gp, mixup_alpha=0.7, entropy_bonus=ent, pos_class_prior=0.7, nonnegative_margin=margin,
+                      discriminator=DictConfig(hidden_size=c['H'], depth=c['depth'], activation=c['activation'], reward_shaping=True, subtract_log_policy=False, reward_function=rf))
+    d, lin = shaped_deep_disc(c, icfg)
+    out[f'{name}.param_names'] = np.array([n for n, _ in d.named_parameters()])
+    opt = torch.optim.AdamW(d.parameters(), lr=lr, weight_decay=wd)
+    for i in range(len(c['policy'])):
+      d.train()
+      orig = torch.distributions.Beta.sample
+      feed = [T(c['eps_mix'][i])]
+      torch.distributions.Beta.sample = lambda self, *a, **k: feed.pop(0)
+      try:
+        with ClampSpy() as spy, NoiseFeed() as nf:
+          nf.rand.append(T(c['eps'][i]))
+          ref_training.adversarial_imitation_update(None, d, tbatch(c['policy'][i]), tbatch(c['expert'][i]), opt, icfg)
+      finally:
+        torch.distributions.Beta.sample = orig
+      d.eval()
+      k = i + 1
+      out[f'{name}.g_{k}'] = np.concatenate([N_(p.grad).ravel() for p in d.parameters()]); out[f'{name}.p_{k}'] = flat(d)
+      if sn:
+        out[f'{name}.sn_{k}'] = np.concatenate([N_(d.g.parametrizations.weight[0]._u), N_(d.g.parametrizations.weight[0]._v)] +
+                                               [np.concatenate([N_(d.h[li].parametrizations.weight[0]._u), N_(d.h[li].parametrizations.weight[0]._v)]) for li in lin])
+      if loss == 'PUGAIL' and margin != float('inf'):
+        out[f'{name}.value_{k}'] = np.array(spy.seen[:1], np.float64)
+      b = c['policy'][i]
+      with torch.inference_mode():
+        out[f'{name}.reward_{k}'] = N_(d.predict_reward(T(b['states']), T(b['actions']), T(b['next_states']), T(b['terminals'])))
+        d.subtract_log_policy = True    # models.py:175 (the flag only selects `f - log_policy`): the reward head with an offset, on the same weights
+        out[f'{name}.reward_logp_{k}'] = N_(d.predict_reward(T(b['states']), T(b['actions']), T(b['next_states']), T(b['terminals']), log_policy=T(c['logp_policy'][i])))
+        d.subtract_log_policy = False
+    out[f'{name}.exp_avg'] = opt_state(opt, 'exp_avg')
+  np.savez_compressed(os.path.join(HERE, 'gail_shaped_deep.npz'), **out)
+
+
 # ---------------------------------------------------------------- GMMIL / PWIL
 def gen_gmmil():
   out = {}
@@ -773,6 +833,7 @@ if __name__ == '__main__':
   if want('gail_pu_margin_general'): gen_gail_pu_margin_general()
   if want('gail_shaped'): gen_gail_shaped()
   if want('gail_shaped_mixup'): gen_gail_shaped_mixup()
+  if want('gail_shaped_deep'): gen_gail_shaped_deep()
   if want('gail_deep'): gen_gail_deep()
   if want('gmmil'): gen_gmmil()
   if want('pwil'): gen_pwil()

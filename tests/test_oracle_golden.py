@@ -360,6 +360,66 @@ def test_gail_deep_and_shaped_oracles_pugail_finite_margin(golden_dir, name):
       np.testing.assert_allclose(getattr(ss, k), g[f'shaped.{name}.{k}_{i + 1}'], rtol=1e-5, atol=1e-6)
 
 
+def _shaped_deep_state(c):
+  from oracle import gail_shaped_deep as osd
+  ds = osd.ShapedDeepState(c['S'], c['A'], c['H'], 0.97, c['depth'], c['activation'], c['spectral_norm'], c['state_only'])
+  ds.Wg[...] = c['Wg']; ds.bg[...] = c['bg']; ds.ug[...] = c['ug']; ds.vg[...] = c['vg']
+  for l in range(c['depth'] + 1):
+    ds.h.W[l][...] = c['W'][l]; ds.h.b[l][...] = c['b'][l]; ds.h.u[l][...] = c['u'][l]; ds.h.v[l][...] = c['v'][l]
+  return ds
+
+
+@pytest.mark.parametrize('name', [n for n, *_ in gi.GAIL_SHAPED_DEEP_CASES])
+def test_gail_shaped_deep_oracle_matches_reference_fixture(golden_dir, name):
+  """oracle/gail_shaped_deep.py (reward shaping with a depth 1-2 / relu / tanh potential: two power iterations of every layer of h per call, chain rule per use,
+  the gradient penalty's double backward through the second use) against adversarial_imitation_update + predict_reward of the reference."""
+  from oracle import gail_shaped_deep as osd
+  g = np.load(os.path.join(golden_dir, 'gail_shaped_deep.npz'))
+  _, kw, loss, (lr, wd, gp, ent), rf, margin = next(c for c in gi.GAIL_SHAPED_DEEP_CASES if c[0] == name)
+  c = gi.gail_shaped_deep_case(**kw)
+  ds = _shaped_deep_state(c)
+  if margin != float('inf'):
+    assert float(g[f'{name}.value_1'][0]) < -margin, 'the fixture is meant to have the clamp binding at the first update'
+  for i in range(len(c['policy'])):
+    if i:   # start every step from the reference's parameters (isolates the step)
+      ds.unpack_into(g[f'{name}.p_{i}'])
+      if c['spectral_norm']: ds.unpack_sn(g[f'{name}.sn_{i}'])
+    grad = osd.gail_update(ds, c['policy'][i], c['expert'][i], c['eps'][i], lr=lr, weight_decay=wd, grad_penalty=gp, entropy_bonus=ent, return_grads=True, loss_function=loss,
+                           pos_class_prior=0.7, nonnegative_margin=margin, eps_mix=c['eps_mix'][i])
+    ref = g[f'{name}.g_{i + 1}']
+    np.testing.assert_allclose(grad, ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max())
+    assert np.abs(ds.pack() - g[f'{name}.p_{i + 1}']).max() <= 6e-6   # lr <= 1e-3; Adam's early steps are lr * m / sqrt(v): the ratio amplifies the gradient's last bits where |g| is small
+    if c['spectral_norm']:
+      np.testing.assert_allclose(ds.pack_sn(), g[f'{name}.sn_{i + 1}'], rtol=1e-4, atol=1e-6)
+    ds.unpack_into(g[f'{name}.p_{i + 1}'])
+    np.testing.assert_allclose(osd.predict_reward(ds, c['policy'][i], rf), g[f'{name}.reward_{i + 1}'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(osd.predict_reward(ds, c['policy'][i], rf, log_policy=c['logp_policy'][i]), g[f'{name}.reward_logp_{i + 1}'], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('sn,loss', [(True, 'BCE'), (False, 'PUGAIL'), (True, 'Mixup')])
+def test_gail_shaped_deep_oracle_equals_the_depth1_relu_oracle(sn, loss):
+  """The general restatement reduces to oracle/gail_shaped.py (itself pinned to the reference) for a depth-1 ReLU potential: same gradients, parameters, buffers, rewards."""
+  from oracle import gail_shaped as ogs, gail_shaped_deep as osd
+  c = gi.gail_shaped_case(97, 'hopper', 32, 96, 2, sn)
+  em = gi.mixup_draws(1097, 96, 2)
+  a = ogs.ShapedState(c['S'], c['A'], c['H'], 0.97, sn)
+  for k in ('Wg', 'bg', 'W1', 'b1', 'W2', 'b2', 'ug', 'vg', 'u1', 'v1', 'u2', 'v2'):
+    getattr(a, k)[...] = c[k]
+  b = osd.ShapedDeepState(c['S'], c['A'], c['H'], 0.97, 1, 'relu', sn)
+  b.Wg[...] = c['Wg']; b.bg[...] = c['bg']; b.ug[...] = c['ug']; b.vg[...] = c['vg']
+  for l, n in enumerate(('1', '2')):
+    b.h.W[l][...] = c['W' + n]; b.h.b[l][...] = c['b' + n]; b.h.u[l][...] = c['u' + n]; b.h.v[l][...] = c['v' + n]
+  kw = dict(lr=1e-3, weight_decay=0.1, grad_penalty=0.7, entropy_bonus=0.01, loss_function=loss, return_grads=True)
+  for i in range(2):
+    ga = ogs.gail_update(a, c['policy'][i], c['expert'][i], c['eps'][i], eps_mix=em[i], **kw)
+    gb = osd.gail_update(b, c['policy'][i], c['expert'][i], c['eps'][i], eps_mix=em[i], **kw)
+    np.testing.assert_allclose(gb, ga, rtol=1e-5, atol=1e-6 * np.abs(ga).max())
+    np.testing.assert_allclose(b.pack(), a.pack(), rtol=1e-5, atol=2e-6)
+    if sn:
+      np.testing.assert_allclose(b.pack_sn(), np.concatenate([a.ug, a.vg, a.u1, a.v1, a.u2, a.v2]), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(osd.predict_reward(b, c['policy'][i]), ogs.predict_reward(a, c['policy'][i]), rtol=1e-5, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ Philox (the on-chip noise source's restatement)
 def test_philox_restatement_matches_random123_known_answers():
   """Known-answer vectors of Random123's philox4x32_10 (kat_vectors: all-zero, all-ones and the pi-digits counter / key)."""
