@@ -62,6 +62,14 @@ class DiscDeep(C.Structure):
               ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p), ('pu_clamped', C.c_int32), ('nonnegative_margin', C.c_float)]
 
 
+class DiscShapedDeep(C.Structure):
+  _fields_ = [('state_dim', C.c_int32), ('action_dim', C.c_int32), ('hidden', C.c_int32), ('batch', C.c_int32),
+              ('spectral_norm', C.c_int32), ('state_only', C.c_int32), ('reward_function', C.c_int32), ('loss_function', C.c_int32),
+              ('depth', C.c_int32), ('activation', C.c_int32), ('params', C.c_void_p), ('sn', C.c_void_p), ('grad', C.c_void_p), ('opt', Adam),
+              ('grad_penalty', C.c_float), ('entropy_bonus', C.c_float), ('pos_class_prior', C.c_float), ('discount', C.c_float),
+              ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p), ('pu_clamped', C.c_int32), ('nonnegative_margin', C.c_float)]
+
+
 class GailExtra(C.Structure):
   _fields_ = [('eps_mix', C.c_void_p), ('logit_offset_policy', C.c_void_p), ('logit_offset_expert', C.c_void_p), ('logit_offset_mix', C.c_void_p)]
 
@@ -171,6 +179,12 @@ _SIGNATURES = {
     'il_disc_shaped_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'il_gail_shaped_step': (C.c_int, [C.POINTER(DiscShaped), C.POINTER(Batch), C.POINTER(Batch), _P, C.POINTER(GailExtra), C.c_uint32, _P]),
     'il_gail_shaped_reward': (C.c_int, [C.POINTER(DiscShaped), C.POINTER(Batch), _P, _P, _P, _P]),
+    'il_disc_shaped_deep_numel': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'il_disc_shaped_deep_sn_numel': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'il_disc_shaped_deep_workspace_floats': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'il_disc_shaped_deep_lds_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'il_gail_shaped_deep_step': (C.c_int, [C.POINTER(DiscShapedDeep), C.POINTER(Batch), C.POINTER(Batch), _P, C.POINTER(GailExtra), C.c_uint32, _P]),
+    'il_gail_shaped_deep_reward': (C.c_int, [C.POINTER(DiscShapedDeep), C.POINTER(Batch), _P, _P, _P, _P]),
     'il_actor_log_prob': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
     'il_gail_disc_step_draw': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), C.POINTER(Batch), _P, _P, _P, _P, _P, C.c_uint32, _P]),
     'il_gail_disc_step_draw_peer': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), C.POINTER(Batch), _P, _P, _P, _P, _P, C.c_uint32, C.POINTER(PeerBucket), _P]),

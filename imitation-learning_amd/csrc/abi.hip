@@ -114,7 +114,7 @@ extern "C" int il_noise_fill(uint64_t noise_seed, uint32_t ctr, uint32_t stream_
 extern "C" int32_t il_struct_size(int32_t which) {
   switch (which) {
     case 0: return (int32_t)sizeof(il_batch); case 1: return (int32_t)sizeof(il_adam); case 2: return (int32_t)sizeof(il_sac); case 3: return (int32_t)sizeof(il_disc);
-    case 4: return (int32_t)sizeof(il_pwil); case 5: return (int32_t)sizeof(il_sample_args); case 6: return (int32_t)sizeof(il_red); case 7: return (int32_t)sizeof(il_dril); case 8: return (int32_t)sizeof(il_disc_shaped); case 9: return (int32_t)sizeof(il_disc_deep); case 10: return (int32_t)sizeof(il_peer_bucket);
+    case 4: return (int32_t)sizeof(il_pwil); case 5: return (int32_t)sizeof(il_sample_args); case 6: return (int32_t)sizeof(il_red); case 7: return (int32_t)sizeof(il_dril); case 8: return (int32_t)sizeof(il_disc_shaped); case 9: return (int32_t)sizeof(il_disc_deep); case 10: return (int32_t)sizeof(il_peer_bucket); case 11: return (int32_t)sizeof(il_disc_shaped_deep);
     default: return -1;
   }
 }

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import copy
 import ctypes as C
+import os
 from math import sqrt
 from typing import Dict, Optional, Tuple
 
@@ -330,7 +331,10 @@ class GAILDiscriminator(_FlatModule):
 
   def __new__(cls, state_size=None, action_size=None, imitation_cfg=None, discount=None, device=None):
     if cls is GAILDiscriminator and imitation_cfg is not None and imitation_cfg.discriminator.reward_shaping:
-      return super().__new__(ShapedGAILDiscriminator)   # f = g(s, a) + (1 - t)(discount h(s') - h(s)): its own kernels (gail_shaped.hip)
+      # f = g(s, a) + (1 - t)(discount h(s') - h(s)): its own kernels - gail_shaped.hip for the depth-1 ReLU potential of the default configuration, gail_shaped_deep.hip for
+      # depth 2 and / or tanh (IL_SHAPED_GENERAL=1 sends the default shape through the general kernels too: a cross-check of the two implementations)
+      general = (imitation_cfg.discriminator.depth, imitation_cfg.discriminator.activation) != (1, 'relu') or os.environ.get('IL_SHAPED_GENERAL', '0') == '1'
+      return super().__new__(ShapedDeepGAILDiscriminator if general else ShapedGAILDiscriminator)
     if cls is GAILDiscriminator and imitation_cfg is not None and (imitation_cfg.discriminator.depth, imitation_cfg.discriminator.activation) != (1, 'relu'):
       return super().__new__(DeepGAILDiscriminator)     # depth 2 and / or tanh: the general kernels (gail_deep.hip)
     return super().__new__(cls)
@@ -393,8 +397,8 @@ class ShapedGAILDiscriminator(GAILDiscriminator):
     self.discount, self.state_only = discount, bool(imitation_cfg.state_only)
     self.reward_shaping, self.subtract_log_policy, self.reward_function = True, model_cfg.subtract_log_policy, model_cfg.reward_function
     self.spectral_norm = bool(imitation_cfg.spectral_norm)
-    if model_cfg.depth != 1 or model_cfg.activation != 'relu' or model_cfg.hidden_size > 256:
-      raise NotImplementedError('GAILDiscriminator (reward shaping): the HIP path implements depth=1, activation=relu, hidden_size <= 256 for the shaping network')
+    if model_cfg.depth != 1 or model_cfg.activation != 'relu' or model_cfg.hidden_size > 256:   # (other depths / activations are ShapedDeepGAILDiscriminator's)
+      raise NotImplementedError('GAILDiscriminator (reward shaping, depth-1 ReLU potential): hidden_size <= 256; no torch fallback')
     self.state_size, self.action_size, self.hidden = state_size, action_size, model_cfg.hidden_size
     self.in_dim = state_size if self.state_only else state_size + action_size
     sn = parametrizations.spectral_norm if self.spectral_norm else (lambda layer: layer)
@@ -421,6 +425,69 @@ class ShapedGAILDiscriminator(GAILDiscriminator):
 
   def views(self):
     return {k: self.sn[o:o + n] for k, (o, n) in self._sn_slices.items()}
+
+  def predict_reward(self, state: Tensor, action: Tensor, next_state=None, terminal=None, log_policy=None) -> Tensor:
+    from .training import shaped_predict_reward
+    assert next_state is not None and terminal is not None, 'reward shaping: pass next_state and terminal (make_gail_input does)'
+    assert (log_policy is not None) == bool(self.subtract_log_policy)
+    return shaped_predict_reward(self, state, action, next_state, terminal, log_policy=log_policy)
+
+  def forward(self, state: Tensor, action: Tensor, next_state=None, terminal=None, log_policy=None) -> Tensor:
+    from .training import shaped_predict_reward
+    return shaped_predict_reward(self, state, action, next_state, terminal, log_policy=log_policy, want_logits=True)[1]
+
+
+class ShapedDeepGAILDiscriminator(GAILDiscriminator):
+  """GAIL discriminator with reward shaping whose potential is any `_create_fcnn` shape (reference models.py:152-180 with reward_shaping=True and
+  discriminator.depth in {1, 2}, activation in {relu, tanh}): g = Linear(Dg, 1), h = [Linear - act] x depth - Linear(H, 1) on the state, every Linear optionally under
+  spectral norm. Created through `GAILDiscriminator(...)` when the potential is not the depth-1 ReLU shape ShapedGAILDiscriminator serves. Flat arena = parameters()
+  order; `self.sn` = ug[1] | vg[Dg] | per layer of h [u | v]; same module order, state_dict keys and RNG consumption at construction as the reference."""
+
+  def __init__(self, state_size: int, action_size: int, imitation_cfg, discount: float, device=None):
+    nn.Module.__init__(self)
+    model_cfg = imitation_cfg.discriminator
+    self.discount, self.state_only = discount, bool(imitation_cfg.state_only)
+    self.reward_shaping, self.subtract_log_policy, self.reward_function = True, model_cfg.subtract_log_policy, model_cfg.reward_function
+    self.spectral_norm = bool(imitation_cfg.spectral_norm)
+    self.depth, self.activation = int(model_cfg.depth), str(model_cfg.activation)
+    self.state_size, self.action_size, self.hidden = state_size, action_size, int(model_cfg.hidden_size)
+    self.in_dim = state_size if self.state_only else state_size + action_size
+    if self.depth not in (1, 2) or self.activation not in ('relu', 'tanh') or self.hidden > 128 or self.hidden < 2 or state_size > 128 or self.in_dim > 256:
+      raise NotImplementedError(f'GAILDiscriminator (reward shaping): the HIP path implements a potential of depth 1-2 with relu / tanh, hidden_size <= 128, state <= 128 '
+                                f'(got depth={self.depth}, activation={self.activation}, hidden_size={self.hidden}, state={state_size}); no torch fallback')
+    L = _lib.lib()
+    lds = int(L.il_disc_shaped_deep_lds_bytes(state_size, action_size, self.hidden, self.depth, int(self.state_only)))
+    if lds > 160 * 1024:
+      raise NotImplementedError(f'GAILDiscriminator (reward shaping): state {state_size} x hidden {self.hidden} x depth {self.depth} needs {lds} bytes of LDS per workgroup (> 160 KiB)')
+    sn = parametrizations.spectral_norm if self.spectral_norm else (lambda layer: layer)
+    self.g = sn(nn.Linear(self.in_dim, 1))   # default nn.Linear init, like the reference (models.py:158)
+    act = nn.ReLU if self.activation == 'relu' else nn.Tanh
+    dims, layers = [state_size] + [self.hidden] * self.depth, []
+    for a, b in zip(dims[:-1], dims[1:]):   # models.py:49-70 `_create_fcnn`
+      lin = nn.Linear(a, b)
+      nn.init.orthogonal_(lin.weight, gain=nn.init.calculate_gain(self.activation)); nn.init.constant_(lin.bias, 0)
+      layers += [sn(lin), act()]
+    last = nn.Linear(self.hidden, 1)
+    nn.init.orthogonal_(last.weight, gain=1.0); nn.init.constant_(last.bias, 0)
+    self.h = nn.Sequential(*layers, sn(last))
+    offs, o = [], 0
+    for p in self.parameters():
+      offs.append(o); o += p.numel()
+    assert o == int(L.il_disc_shaped_deep_numel(state_size, action_size, self.hidden, self.depth, int(self.state_only)))
+    dev = device or default_device()
+    self._adopt(o, offs, dev)
+    self.sn = torch.zeros(int(L.il_disc_shaped_deep_sn_numel(state_size, action_size, self.hidden, self.depth, int(self.state_only))), device=dev)
+    if self.spectral_norm:
+      mods, o = [self.g.parametrizations.weight[0]] + [self.h[2 * l].parametrizations.weight[0] for l in range(self.depth + 1)], 0
+      with torch.no_grad():
+        for mod in mods:
+          nu, nv = mod._u.numel(), mod._v.numel()
+          u, v = self.sn[o:o + nu], self.sn[o + nu:o + nu + nv]
+          u.copy_(mod._u); v.copy_(mod._v)
+          mod._buffers['_u'], mod._buffers['_v'] = u, v
+          o += nu + nv
+      assert o == self.sn.numel()
+    self.eval()
 
   def predict_reward(self, state: Tensor, action: Tensor, next_state=None, terminal=None, log_policy=None) -> Tensor:
     from .training import shaped_predict_reward

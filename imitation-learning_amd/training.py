@@ -146,7 +146,12 @@ def disc_descriptor(disc: GAILDiscriminator, batch_size: int, opt: AdamW, imitat
   return d
 
 
-def shaped_descriptor(disc, batch_size: int, opt, imitation_cfg=None) -> _lib.DiscShaped:
+def _shaped_general(disc) -> bool:
+  return type(disc).__name__ == 'ShapedDeepGAILDiscriminator'   # a depth-2 and / or tanh potential: gail_shaped_deep.hip, same arguments
+
+
+def shaped_descriptor(disc, batch_size: int, opt, imitation_cfg=None):
+  """il_disc_shaped (depth-1 ReLU potential, gail_shaped.hip) or il_disc_shaped_deep (any potential, gail_shaped_deep.hip) for a reward-shaping discriminator."""
   dev = disc.flat.device
   loss_function, prior, grad_penalty, entropy_bonus, margin = 'BCE', 0.0, 0.0, 0.0, float('inf')
   if imitation_cfg is not None:
@@ -155,13 +160,18 @@ def shaped_descriptor(disc, batch_size: int, opt, imitation_cfg=None) -> _lib.Di
       raise ValueError(f'adversarial_imitation_update: unknown loss_function={loss_function}')
     margin = float(_cfg_value(imitation_cfg, 'nonnegative_margin', float('inf')))
     grad_penalty, entropy_bonus = float(imitation_cfg.grad_penalty), float(imitation_cfg.entropy_bonus)
-  ws = _workspace('disc_shaped', int(_lib.lib().il_disc_shaped_workspace_floats(disc.state_size, disc.action_size, disc.hidden, batch_size, int(disc.state_only))), dev)
-  v = disc.views()
-  d = _lib.DiscShaped()
+  if _shaped_general(disc):
+    ws = _workspace('disc_shaped', int(_lib.lib().il_disc_shaped_deep_workspace_floats(disc.state_size, disc.action_size, disc.hidden, disc.depth, batch_size, int(disc.state_only))), dev)
+    d = _lib.DiscShapedDeep()
+    d.depth, d.activation, d.sn = disc.depth, int(disc.activation == 'tanh'), disc.sn.data_ptr()
+  else:
+    ws = _workspace('disc_shaped', int(_lib.lib().il_disc_shaped_workspace_floats(disc.state_size, disc.action_size, disc.hidden, batch_size, int(disc.state_only))), dev)
+    v = disc.views()
+    d = _lib.DiscShaped()
+    d.ug, d.vg, d.u1, d.v1, d.u2, d.v2 = (v[k].data_ptr() for k in ('ug', 'vg', 'u1', 'v1', 'u2', 'v2'))
   d.state_dim, d.action_dim, d.hidden, d.batch = disc.state_size, disc.action_size, disc.hidden, batch_size
   d.spectral_norm, d.state_only, d.reward_function, d.loss_function = int(disc.spectral_norm), int(disc.state_only), REWARD_FUNCTIONS[disc.reward_function], LOSS_FUNCTIONS[loss_function]
   d.params = disc.flat.data_ptr()
-  d.ug, d.vg, d.u1, d.v1, d.u2, d.v2 = (v[k].data_ptr() for k in ('ug', 'vg', 'u1', 'v1', 'u2', 'v2'))
   if opt is not None:
     d.grad, d.opt = opt.grad.data_ptr(), opt.desc()
   d.grad_penalty, d.entropy_bonus, d.pos_class_prior, d.discount = grad_penalty, entropy_bonus, prior, float(disc.discount)
@@ -224,7 +234,8 @@ def shaped_predict_reward(disc, state: Tensor, action: Tensor, next_state: Tenso
   d = shaped_descriptor(disc, n, None)
   b = _shaped_batch(state, action, next_state, terminal.to(dev, torch.float32).contiguous())
   out, logits, off = torch.empty(n, device=dev), (torch.empty(n, device=dev) if want_logits else None), _f32(log_policy, dev)
-  _lib.check(_lib.lib().il_gail_shaped_reward(C.byref(d), C.byref(b), _lib.ptr(out), _lib.ptr(logits), _lib.ptr(off), _lib.stream_ptr()))
+  reward = _lib.lib().il_gail_shaped_deep_reward if _shaped_general(disc) else _lib.lib().il_gail_shaped_reward
+  _lib.check(reward(C.byref(d), C.byref(b), _lib.ptr(out), _lib.ptr(logits), _lib.ptr(off), _lib.stream_ptr()))
   return (out, logits) if want_logits else out
 
 
@@ -237,7 +248,7 @@ def adversarial_imitation_update(actor, discriminator: GAILDiscriminator, transi
   pb, eb = batch_desc(transitions), batch_desc(expert_transitions)
   e = _f32(eps_gp, dev)
   x, keep = _lib.GailExtra(), []
-  if getattr(discriminator, 'reward_shaping', False):   # models.py:157-160: its own kernels (k_gs_grad / k_gs_reduce)
+  if getattr(discriminator, 'reward_shaping', False):   # models.py:157-160: its own kernels (k_gs_* for the depth-1 ReLU potential, k_gsd_* for the others)
     d = shaped_descriptor(discriminator, B, discriminator_optimiser, imitation_cfg)
     if imitation_cfg.loss_function == 'Mixup':   # training.py:104-113 on every field of the transition (the kernel mixes next_states and terminals too)
       alpha = float(_cfg_value(imitation_cfg, 'mixup_alpha', 1.0))
@@ -253,7 +264,8 @@ def adversarial_imitation_update(actor, discriminator: GAILDiscriminator, transi
     elif discriminator.subtract_log_policy:
       keep += [actor.log_prob(transitions['states'], transitions['actions']), actor.log_prob(expert_transitions['states'], expert_transitions['actions'])]
       x.logit_offset_policy, x.logit_offset_expert = keep[-2].data_ptr(), keep[-1].data_ptr()
-    _lib.check(_lib.lib().il_gail_shaped_step(C.byref(d), C.byref(pb), C.byref(eb), _lib.ptr(e), C.byref(x), 0, _lib.stream_ptr()))
+    step = _lib.lib().il_gail_shaped_deep_step if _shaped_general(discriminator) else _lib.lib().il_gail_shaped_step
+    _lib.check(step(C.byref(d), C.byref(pb), C.byref(eb), _lib.ptr(e), C.byref(x), 0, _lib.stream_ptr()))
     return
   deep = type(discriminator).__name__ == 'DeepGAILDiscriminator'   # depth 2 and / or tanh: the general kernels, same arguments
   d = (deep_descriptor if deep else disc_descriptor)(discriminator, B, discriminator_optimiser, imitation_cfg)

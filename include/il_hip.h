@@ -428,6 +428,40 @@ int il_gail_deep_step(const il_disc_deep* d, const il_batch* policy, const il_ba
 int il_gail_deep_reward(const il_disc_deep* d, const il_batch* batch, float* out_rewards, float* out_logits, const float* logit_offset, il_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * GAIL discriminator with reward shaping whose potential h is any `_create_fcnn` shape (models.py:157-160 with discriminator.depth in {1, 2} and activation in
+ * {relu, tanh}: conf/hyperparameter_search_space/GAIL.yaml); il_disc_shaped above is the depth-1 ReLU potential of the default configuration.
+ *   f = g(x) + (1 - terminal)(discount * h(s') - h(s)),  g = Linear(Dg, 1),  h = [Linear - act] x depth - Linear(H, 1) on the state,  Dg = S (+ A unless state_only).
+ * params in parameters() order: g (bias, weight) then h's Linears (bias, weight) each with spectral norm; (weight, bias) without. il_disc_shaped_deep_numel floats.
+ * sn: ug[1] | vg[Dg] | per layer of h [u (out) | v (in)] (il_disc_shaped_deep_sn_numel floats). state <= 128, hidden <= 128, LDS per il_disc_shaped_deep_lds_bytes.
+ * Losses, il_gail_extra, eps_gp and the batches as for il_disc_shaped.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct il_disc_shaped_deep {
+  int32_t state_dim, action_dim, hidden, batch;
+  int32_t spectral_norm, state_only, reward_function, loss_function;
+  int32_t depth;        /* hidden layers of h: 1 or 2 (0 = 1) */
+  int32_t activation;   /* 0 relu, 1 tanh */
+  float* params;
+  float* sn;
+  float* grad;          /* [P] summed gradient of the last step (always written) */
+  il_adam opt;
+  float grad_penalty, entropy_bonus, pos_class_prior, discount;
+  float* workspace;     /* >= il_disc_shaped_deep_workspace_floats() */
+  int64_t workspace_floats;
+  uint64_t noise_seed;
+  uint32_t* noise_counter;
+  int32_t pu_clamped;        /* as in il_disc (training.py:100-102 with a finite nonnegative_margin) */
+  float nonnegative_margin;
+} il_disc_shaped_deep;
+int64_t il_disc_shaped_deep_numel(int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t depth, int32_t state_only);
+int64_t il_disc_shaped_deep_sn_numel(int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t depth, int32_t state_only);
+int64_t il_disc_shaped_deep_workspace_floats(int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t depth, int32_t batch, int32_t state_only);
+int64_t il_disc_shaped_deep_lds_bytes(int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t depth, int32_t state_only);
+/* adversarial_imitation_update (training.py:85-134) / predict_reward (models.py:177-180); arguments as il_gail_shaped_step / il_gail_shaped_reward */
+int il_gail_shaped_deep_step(const il_disc_shaped_deep* d, const il_batch* policy, const il_batch* expert, const float* eps_gp, const il_gail_extra* extra, uint32_t flags,
+                             il_stream_t stream);
+int il_gail_shaped_deep_reward(const il_disc_shaped_deep* d, const il_batch* batch, float* out_rewards, float* out_logits, const float* logit_offset, il_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * GMMIL (reference models.py:25-44, 183-201): d(x,y) = mean_k (x_k-y_k)^2, two RBF bandwidths.
  * ------------------------------------------------------------------------------------------ */
 int64_t il_gmmil_workspace_floats(int32_t n_policy, int32_t n_expert, int32_t dim);
@@ -589,7 +623,7 @@ int il_gail_disc_step_draw_peer(const il_disc* d, const il_batch* policy, const 
                                 const int64_t* ring_state_b, int32_t* idx_b, uint32_t flags, const il_peer_bucket* peer, il_stream_t stream);
 
 /* sizeof() of the descriptor structs in this build (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red,
- * 7 il_dril, 8 il_disc_shaped, 9 il_disc_deep, 10 il_peer_bucket; -1 otherwise): lets a binding verify its own struct definitions. */
+ * 7 il_dril, 8 il_disc_shaped, 9 il_disc_deep, 10 il_peer_bucket, 11 il_disc_shaped_deep; -1 otherwise): lets a binding verify its own struct definitions. */
 int32_t il_struct_size(int32_t which);
 
 #ifdef __cplusplus

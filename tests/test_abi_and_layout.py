@@ -109,7 +109,7 @@ def test_ctypes_structs_match_the_compiled_library():
   """sizeof() of every descriptor struct as compiled into libil_hip.so equals the ctypes mirror's (a stale binding would pass garbage)."""
   from imitation_learning_amd import _lib
   L = _lib.lib()
-  for which, cls in enumerate((_lib.Batch, _lib.Adam, _lib.Sac, _lib.Disc, _lib.Pwil, _lib.SampleArgs, _lib.Red, _lib.Dril, _lib.DiscShaped, _lib.DiscDeep, _lib.PeerBucket)):
+  for which, cls in enumerate((_lib.Batch, _lib.Adam, _lib.Sac, _lib.Disc, _lib.Pwil, _lib.SampleArgs, _lib.Red, _lib.Dril, _lib.DiscShaped, _lib.DiscDeep, _lib.PeerBucket, _lib.DiscShapedDeep)):
     assert L.il_struct_size(which) == C.sizeof(cls), cls.__name__
   assert L.il_struct_size(99) == -1
 

@@ -1000,9 +1000,12 @@ def test_gail_variants_loud_failures():
   mk = lambda **kw: Cfg(state_only=False, spectral_norm=True, loss_function='PUGAIL', grad_penalty=0.5, mixup_alpha=1, entropy_bonus=0.0, pos_class_prior=0.7, nonnegative_margin=kw.get('margin', float('inf')),
                         discriminator=Cfg(hidden_size=32, depth=1, activation='relu', reward_shaping=kw.get('shaping', False), subtract_log_policy=False, reward_function='AIRL'))
   assert type(il.GAILDiscriminator(c['S'], c['A'], mk(shaping=True), 0.97, device=DEV)).__name__ == 'ShapedGAILDiscriminator'
-  deep_shaping = mk(shaping=True); deep_shaping['discriminator'] = Cfg(deep_shaping['discriminator'], depth=2)   # every loss has a reward-shaping kernel; a depth-2 / tanh potential has none
-  with pytest.raises(NotImplementedError):
-    il.GAILDiscriminator(c['S'], c['A'], deep_shaping, 0.97, device=DEV)
+  deep_shaping = mk(shaping=True); deep_shaping['discriminator'] = Cfg(deep_shaping['discriminator'], depth=2)   # a depth-2 / tanh potential: the general kernels
+  assert type(il.GAILDiscriminator(c['S'], c['A'], deep_shaping, 0.97, device=DEV)).__name__ == 'ShapedDeepGAILDiscriminator'
+  for bad in (dict(depth=3), dict(depth=2, hidden_size=192), dict(depth=1, activation='sigmoid')):   # what has no kernel raises at construction; there is no torch fallback to fall into
+    cfg = mk(shaping=True); cfg['discriminator'] = Cfg(cfg['discriminator'], **bad)
+    with pytest.raises(NotImplementedError):
+      il.GAILDiscriminator(c['S'], c['A'], cfg, 0.97, device=DEV)
 
 
 @pytest.mark.gpu
@@ -1212,6 +1215,80 @@ def test_gail_reward_shaping_mixup_matches_reference(golden_dir):
   before = N(d.flat)
   il.adversarial_imitation_update(None, d, tbatch(c['policy'][0]), tbatch(c['expert'][0]), opt, icfg1)
   assert np.isfinite(N(d.flat)).all() and not np.array_equal(before, N(d.flat))
+
+
+# ---------------------------------------------------------------------------------------------
+# GAIL with reward shaping and a depth 1-2 / relu / tanh potential (gail_shaped_deep.hip) against the reference fixture and the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', [n for n, *_ in gi.GAIL_SHAPED_DEEP_CASES])
+def test_gail_reward_shaping_general_potential_matches_reference(golden_dir, name):
+  """BCE / PUGAIL (infinite margin, and a finite one that binds) / Mixup with fractional terminals, spectral norm on and off, state_only, the three reward heads, a
+  log-policy offset: gradients, parameters, u / v buffers and rewards of `adversarial_imitation_update` + `predict_reward` on the reference's own outputs."""
+  from oracle import gail_shaped_deep as osd
+  from test_oracle_golden import _shaped_deep_state
+  g = load(golden_dir, 'gail_shaped_deep')
+  _, kw, loss, (lr, wd, gp, ent), rf, margin = next(c for c in gi.GAIL_SHAPED_DEEP_CASES if c[0] == name)
+  c = gi.gail_shaped_deep_case(**kw)
+  icfg = Cfg(state_only=c['state_only'], spectral_norm=c['spectral_norm'], loss_function=loss, grad_penalty=gp, mixup_alpha=0.7, entropy_bonus=ent, pos_class_prior=0.7, nonnegative_margin=margin,
+             discriminator=Cfg(hidden_size=c['H'], depth=c['depth'], activation=c['activation'], reward_shaping=True, subtract_log_policy=False, reward_function=rf))
+  d = il.GAILDiscriminator(c['S'], c['A'], icfg, 0.97, device=DEV)
+  assert type(d).__name__ == 'ShapedDeepGAILDiscriminator' and [n for n, _ in d.named_parameters()] == list(g[f'{name}.param_names'])
+  ods = _shaped_deep_state(c)
+  d.flat.copy_(T(ods.pack()))
+  if c['spectral_norm']: d.sn.copy_(T(ods.pack_sn()))
+  opt = il.AdamW(d, lr=lr, weight_decay=wd)
+  for i in range(len(c['policy'])):
+    pb, eb = c['policy'][i], c['expert'][i]
+    if i:   # every step starts from the reference's state (isolates the step from Adam-amplified differences)
+      d.flat.copy_(T(g[f'{name}.p_{i}'])); ods.unpack_into(g[f'{name}.p_{i}'].copy())
+      if c['spectral_norm']: d.sn.copy_(T(g[f'{name}.sn_{i}'])); ods.unpack_sn(g[f'{name}.sn_{i}'].copy())
+    il.adversarial_imitation_update(None, d, tbatch(pb), tbatch(eb), opt, icfg, eps_gp=T(c['eps'][i]), eps_mix=T(c['eps_mix'][i]))
+    ogr = osd.gail_update(ods, pb, eb, c['eps'][i], lr=lr, weight_decay=wd, grad_penalty=gp, entropy_bonus=ent, return_grads=True, loss_function=loss, pos_class_prior=0.7,
+                          nonnegative_margin=margin, eps_mix=c['eps_mix'][i])
+    close(N(opt.grad), g[f'{name}.g_{i + 1}'], f'{name} gradient {i + 1} (reference)', rtol=2e-5, atol_scale=1e-5)
+    close(N(opt.grad), ogr, f'{name} gradient {i + 1} (oracle)', rtol=2e-5, atol_scale=1e-5)
+    close_params(N(d.flat), g[f'{name}.p_{i + 1}'], f'{name} parameters {i + 1}', lr, steps=1, outlier_frac=2e-3)   # <= 3 of ~1,500 elements (one would already be 6.6e-4)
+    if c['spectral_norm']:
+      close(N(d.sn), g[f'{name}.sn_{i + 1}'], f'{name} u / v after update {i + 1}', rtol=2e-5, atol_scale=1e-5)
+    d.flat.copy_(T(g[f'{name}.p_{i + 1}']))
+    p = tbatch(pb)
+    r = d.predict_reward(**il.make_gail_input(p['states'], p['actions'], p['next_states'], p['terminals'], None, True, False))
+    close(N(r), g[f'{name}.reward_{i + 1}'], f'{name} reward {i + 1}', rtol=5e-5, atol_scale=1e-5)
+    d.subtract_log_policy = True
+    r = d.predict_reward(p['states'], p['actions'], p['next_states'], p['terminals'], log_policy=T(c['logp_policy'][i]))
+    d.subtract_log_policy = False
+    close(N(r), g[f'{name}.reward_logp_{i + 1}'], f'{name} reward with a log-policy offset {i + 1}', rtol=5e-5, atol_scale=1e-5)
+  assert int(opt.step_count[0]) == len(c['policy'])   # the PUGAIL value pass does not tick the optimiser
+
+
+@pytest.mark.gpu
+def test_gail_reward_shaping_general_kernels_equal_the_depth1_relu_kernels(golden_dir, monkeypatch):
+  """IL_SHAPED_GENERAL=1 sends the default potential through gail_shaped_deep.hip: the two implementations of the same update agree with the reference fixture and with
+  each other (gradients to 2e-5 of the scale: different tile heights and summation orders), and on the on-chip draws (the same Philox streams)."""
+  g = load(golden_dir, 'gail_shaped')
+  c = gi.gail_shaped_case(91, 'hopper', 32, 96, 2, True)
+  icfg = Cfg(state_only=False, spectral_norm=True, loss_function='BCE', grad_penalty=0.7, mixup_alpha=1, entropy_bonus=0.01, pos_class_prior=0.7, nonnegative_margin=float('inf'),
+             discriminator=Cfg(hidden_size=c['H'], depth=1, activation='relu', reward_shaping=True, subtract_log_policy=False, reward_function='AIRL'))
+  from oracle import gail_shaped as ogs
+  ods = ogs.ShapedState(c['S'], c['A'], c['H'], 0.97, True)
+  for k in ('Wg', 'bg', 'W1', 'b1', 'W2', 'b2'):
+    getattr(ods, k)[...] = c[k]
+  sn0 = np.concatenate([c[k] for k in ('ug', 'vg', 'u1', 'v1', 'u2', 'v2')])
+  grads = {}
+  for general in ('0', '1'):
+    monkeypatch.setenv('IL_SHAPED_GENERAL', general)
+    il.seed(41); il_training._NOISE.clear()
+    d = il.GAILDiscriminator(c['S'], c['A'], icfg, 0.97, device=DEV)
+    assert type(d).__name__ == ('ShapedDeepGAILDiscriminator' if general == '1' else 'ShapedGAILDiscriminator')
+    d.flat.copy_(T(ods.pack())); d.sn.copy_(T(sn0))
+    opt = il.AdamW(d, lr=1e-3, weight_decay=0.1)
+    il.adversarial_imitation_update(None, d, tbatch(c['policy'][0]), tbatch(c['expert'][0]), opt, icfg, eps_gp=T(c['eps'][0]))
+    close(N(opt.grad), g['sn_bce.g_1'], f'general={general} gradient (reference)', rtol=2e-5, atol_scale=1e-5)
+    close(N(d.sn), np.concatenate([g[f'sn_bce.{k}_1'] for k in ('ug', 'vg', 'u1', 'v1', 'u2', 'v2')]), f'general={general} u / v', rtol=2e-5, atol_scale=1e-5)
+    il.adversarial_imitation_update(None, d, tbatch(c['policy'][1]), tbatch(c['expert'][1]), opt, icfg)   # on-chip gradient-penalty draws
+    grads[general] = N(opt.grad)
+  close(grads['1'], grads['0'], 'general vs depth-1 kernels, on-chip draws', rtol=5e-5, atol_scale=2e-5)
 
 
 # ---------------------------------------------------------------------------------------------
