@@ -29,6 +29,8 @@ COMMON = ['steps=260', 'training.start=120', 'evaluation.interval=130', 'evaluat
     ['algorithm=GAIL', 'env=hopper', 'imitation.loss_function=Mixup', 'imitation.mixup_alpha=0.5'],   # Beta(0.5, 0.5) drawn on the host: per-function path
     ['algorithm=GAIL', 'env=halfcheetah', 'imitation.discriminator.subtract_log_policy=true'],
     ['algorithm=GAIL', 'env=hopper', 'imitation.discriminator.reward_shaping=true', 'imitation.discriminator.subtract_log_policy=true'],
+    ['algorithm=GAIL', 'env=hopper', 'imitation.discriminator.reward_shaping=true', 'imitation.discriminator.depth=2', 'imitation.discriminator.activation=tanh',
+     'imitation.discriminator.hidden_size=64', 'imitation.loss_function=PUGAIL', 'imitation.nonnegative_margin=0.05'],   # a depth-2 tanh shaping potential (gail_shaped_deep.hip), finite PUGAIL margin
     ['algorithm=RED', 'env=hopper', 'imitation.pretraining.iterations=50'],
     ['algorithm=RED', 'env=walker2d', 'imitation.pretraining.iterations=50', 'imitation.discriminator.depth=2', 'imitation.discriminator.activation=tanh',
      'imitation.discriminator.hidden_size=64', 'imitation.discriminator.input_dropout=0.05', 'imitation.discriminator.dropout=0.4'],   # conf/optimised_hyperparameters/RED_25_trajectories.yaml's shape
@@ -59,10 +61,11 @@ def test_train_runs(tmp_path, args):
     assert all(np.isfinite(q).all() for q in metrics['Q_values'])
   if cfg.algorithm == 'GAIL':
     disc = torch.load(tmp_path / 'discriminator.pth', weights_only=False)
-    if (cfg.imitation.discriminator.depth, cfg.imitation.discriminator.activation) != (1, 'relu'):
+    if cfg.imitation.discriminator.reward_shaping:
+      last = 2 * cfg.imitation.discriminator.depth
+      assert 'g.parametrizations.weight.original' in disc and 'h.0.parametrizations.weight.original' in disc and f'h.{last}.parametrizations.weight.0._v' in disc
+    elif (cfg.imitation.discriminator.depth, cfg.imitation.discriminator.activation) != (1, 'relu'):
       assert ('g.4.parametrizations.weight.original' if cfg.imitation.spectral_norm else 'g.4.weight') in disc
-    elif cfg.imitation.discriminator.reward_shaping:
-      assert 'g.parametrizations.weight.original' in disc and 'h.0.parametrizations.weight.original' in disc and 'h.2.parametrizations.weight.0._v' in disc
     else:
       assert 'g.0.parametrizations.weight.original' in disc and 'g.2.parametrizations.weight.0._v' in disc
 
