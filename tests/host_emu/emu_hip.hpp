@@ -48,6 +48,16 @@ inline float __fsub_rn(float a, float b) { return a - b; }
 inline float __fdiv_rn(float a, float b) { return a / b; }
 inline float __fsqrt_rn(float a) { return sqrtf(a); }
 
+// device-only builtins the emulated sources mention: scheduling hints and memory-order fences mean nothing to one OS thread running one workgroup at a time
+#define __builtin_amdgcn_sched_barrier(x) do { } while (0)
+#define __builtin_amdgcn_fence(...) do { } while (0)
+#define __HIP_MEMORY_SCOPE_AGENT 0
+template <class T> inline T __hip_atomic_fetch_add(T* p, T v, int, int) { const T old = *p; *p = old + v; return old; }
+template <class T> inline T __hip_atomic_load(const T* p, int, int) { return *p; }
+template <class T> inline void __hip_atomic_store(T* p, T v, int, int) { *p = v; }
+template <class V> inline V emu_elementwise_fma(V a, V b, V c) { V r = c; for (unsigned i = 0; i < sizeof(V) / sizeof(float); ++i) r[i] = fmaf(a[i], b[i], c[i]); return r; }
+#define __builtin_elementwise_fma emu_elementwise_fma
+
 namespace emu {
 enum { RUNNABLE = 0, AT_BARRIER = 1, DONE = 2 };
 enum { MAX_THREADS = 1024, STACK_BYTES = 256 * 1024, SHFL_RING = 64 };

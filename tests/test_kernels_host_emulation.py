@@ -239,32 +239,37 @@ def test_emulated_gail_shaped_deep_kernels_on_the_depth1_relu_fixtures(golden_di
       close(r, g[f'{prefix}reward_{i + 1}'], f'{prefix} reward {i + 1}', rtol=1e-4, atol_scale=1e-5)
 
 
-# ------------------------------------------------------------------------------------------------ the Python entry points over the emulated library
-@pytest.mark.parametrize('name', ['hopper_d2_tanh_sn', 'walker2d_d1_tanh_sn', 'hopper_d2_relu_sn_margin'])
-def test_python_entry_points_over_the_emulated_library(golden_dir, monkeypatch, name):
-  """`GAILDiscriminator(...)` -> ShapedDeepGAILDiscriminator -> `adversarial_imitation_update` / `predict_reward` (models.py / training.py of the product package) with the
-  library handle swapped for the host emulation of gail_shaped_deep.hip and CPU tensors: the descriptor the glue fills, the parameter order, the buffers' layout and
-  the dispatch are what the GPU run uses. (The product refuses CPU tensors - memory.batch_desc - so the test substitutes a lenient batch descriptor.)"""
-  import torch
-  import imitation_learning_amd as il
-  from imitation_learning_amd import training as il_training
-  from gpu_util import Cfg
-  from test_oracle_golden import _shaped_deep_state
-  h, real = emu('gail_shaped_deep'), _lib.lib()
+# ------------------------------------------------------------------------------------------------ the `-m gpu` test bodies over the emulated libraries
+EMULATED = ('gail_deep', 'gail_shaped', 'gail_shaped_deep', 'red', 'dril', 'gmmil')   # the kernel files without MFMA / DPP / buffer intrinsics
 
-  class Facade:   # the emulated entry points where they exist, the real (host-side, size-query) ones otherwise
+
+def _emulated_product(monkeypatch):
+  """Swaps the product's library handle for the host emulations (entry points they export; the real library's host-side size queries otherwise), lets CPU tensors through
+  (the product refuses them: memory.batch_desc) and hands back tests/test_gpu_parity.py with its GPU-only names bound to the CPU, so that the BODIES of the `-m gpu`
+  parity tests - same inputs, same fixtures, same tolerances, the product's own models.py / training.py in between - run here on the kernel sources."""
+  import torch
+  import gpu_util
+  import imitation_learning_amd as il
+  import test_gpu_parity as tgp
+  from imitation_learning_amd import memory as il_memory, training as il_training
+  libs, real = [emu(n) if n.startswith('gail') else _HANDLES.setdefault(n, emu_build.load(n, headers=())) for n in EMULATED], _lib.lib()
+
+  class Facade:
     def __getattr__(self, fn_name):
-      try:
-        fn = getattr(h, fn_name)
-      except AttributeError:
-        return getattr(real, fn_name)
-      fn.restype, fn.argtypes = _lib._SIGNATURES[fn_name]
-      return fn
+      for h in libs:
+        try:
+          fn = getattr(h, fn_name)
+        except AttributeError:
+          continue
+        fn.restype, fn.argtypes = _lib._SIGNATURES[fn_name]
+        return fn
+      return getattr(real, fn_name)
 
   def lenient_batch_desc(t):
     b, n = _lib.Batch(), None
     for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'weights', 'absorbing'):
       v = t[k]
+      assert v.dtype == torch.float32 and (v.dim() == 1 or v.stride(1) == 1)
       setattr(b, k, v.data_ptr()); setattr(b, 'ld_' + k, v.stride(0) if v.size(0) > 1 else (v.size(1) if v.dim() == 2 else 1)); n = v.size(0)
     b.n = n
     return b
@@ -272,27 +277,55 @@ def test_python_entry_points_over_the_emulated_library(golden_dir, monkeypatch, 
   monkeypatch.setattr(_lib, '_lib', Facade())
   monkeypatch.setattr(_lib, 'stream_ptr', lambda: None)
   monkeypatch.setattr(il_training, 'batch_desc', lenient_batch_desc)
-  il_training._WS.clear(); il_training._NOISE.clear()
-  g = np.load(os.path.join(golden_dir, 'gail_shaped_deep.npz'))
-  _, kw, loss, (lr, wd, gp, ent), rf, margin = next(c for c in gi.GAIL_SHAPED_DEEP_CASES if c[0] == name)
-  c = gi.gail_shaped_deep_case(**kw)
-  icfg = Cfg(state_only=c['state_only'], spectral_norm=c['spectral_norm'], loss_function=loss, grad_penalty=gp, mixup_alpha=0.7, entropy_bonus=ent, pos_class_prior=0.7, nonnegative_margin=margin,
-             discriminator=Cfg(hidden_size=c['H'], depth=c['depth'], activation=c['activation'], reward_shaping=True, subtract_log_policy=False, reward_function=rf))
-  d = il.GAILDiscriminator(c['S'], c['A'], icfg, 0.97, device='cpu')
-  assert type(d).__name__ == 'ShapedDeepGAILDiscriminator' and [n for n, _ in d.named_parameters()] == list(g[f'{name}.param_names'])
-  ods = _shaped_deep_state(c)
-  TT = lambda a: torch.from_numpy(np.ascontiguousarray(a, f32))
-  tb = lambda b: dict({k: TT(v) for k, v in b.items()}, absorbing=torch.zeros(len(b['weights'])))
-  d.flat.copy_(TT(ods.pack())); d.sn.copy_(TT(ods.pack_sn()))
-  opt = il.AdamW(d, lr=lr, weight_decay=wd)
-  try:
-    il.adversarial_imitation_update(None, d, tb(c['policy'][0]), tb(c['expert'][0]), opt, icfg, eps_gp=TT(c['eps'][0]), eps_mix=TT(c['eps_mix'][0]))
-    close(opt.grad.numpy(), g[f'{name}.g_1'], f'{name} gradient', rtol=2e-4, atol_scale=2e-6)
-    assert np.abs(d.flat.detach().numpy() - g[f'{name}.p_1']).max() <= 6e-6
-    close(d.sn.numpy(), g[f'{name}.sn_1'], f'{name} u / v', rtol=1e-4, atol_scale=1e-6)
-    p = tb(c['policy'][0])
-    d.flat.copy_(TT(g[f'{name}.p_1']))
-    r = d.predict_reward(**il.make_gail_input(p['states'], p['actions'], p['next_states'], p['terminals'], None, True, False))
-    close(r.numpy(), g[f'{name}.reward_1'], f'{name} reward', rtol=1e-4, atol_scale=1e-5)
-  finally:
-    il_training._WS.clear(); il_training._NOISE.clear()   # CPU arenas must not outlive the test (a GPU test in the same process would find them)
+  monkeypatch.setattr(il_memory, 'batch_desc', lenient_batch_desc)
+  monkeypatch.setattr(gpu_util, 'DEV', 'cpu')
+  for k in ('DEV', 'N', 'T', 'Cfg', 'bracket', 'close', 'close_params', 'crit_from_flat', 'fill_memory', 'make_disc', 'make_sac', 'make_sac_oracle', 'tbatch'):
+    monkeypatch.setattr(tgp, k, getattr(gpu_util, k), raising=False)
+  for k, v in (('il', il), ('_lib', _lib), ('il_memory', il_memory), ('il_training', il_training)):
+    monkeypatch.setattr(tgp, k, v, raising=False)
+  monkeypatch.setattr(il_training, '_WS', {})      # CPU arenas of this test only
+  monkeypatch.setattr(il_training, '_NOISE', {})
+  return tgp
+
+
+def _gpu_bodies():
+  out = [('test_red_matches_reference', (n, kw)) for n, kw, _, _ in gi.RED_CASES] + [('test_dril_matches_reference', (n, kw)) for n, kw, _, _ in gi.DRIL_CASES]
+  out += [('test_gail_deep_discriminator_matches_reference', (n,)) for n, *_ in gi.GAIL_DEEP_CASES]
+  out += [('test_gail_reward_shaping_matches_reference', a) for a in (('sn_bce', True, 'BCE'), ('plain_pugail', False, 'PUGAIL'))] + [('test_gail_reward_shaping_mixup_matches_reference', ())]
+  out += [(t, (n,)) for n in ('clamped', 'open') for t in ('test_gail_deep_pugail_finite_margin_matches_reference', 'test_gail_shaped_pugail_finite_margin_matches_reference')]
+  out += [('test_gail_reward_shaping_general_potential_matches_reference', (n,)) for n, *_ in gi.GAIL_SHAPED_DEEP_CASES]
+  out += [('test_gmmil_matches_oracle_and_reference', a) for a in (('small', (64, 48, 24)), ('ant', (256, 256, 120)))] + [('test_gmmil_full_size_properties', ())]
+  out += [('test_every_shipped_red_dril_shape_runs_at_ant_dims', (n,)) for n in ('RED_5', 'RED_10', 'RED_25', 'DRIL_5', 'DRIL_10', 'DRIL_25')]   # on-chip Philox dropout masks
+  out += [('test_dril_onchip_masks_are_bernoulli_and_change_per_call', ())]
+  return out
+
+
+@pytest.mark.parametrize('body,args', _gpu_bodies(), ids=[f'{b[5:]}-{a[0] if a else ""}' for b, a in _gpu_bodies()])
+def test_gpu_parity_bodies_on_the_emulated_kernels(golden_dir, monkeypatch, body, args):
+  """RED, DRIL, the general GAIL discriminators (deep, reward shaping, both), GMMIL: the parity tests the GPU runs, at the GPU's tolerances (rtol 1e-5 .. 2e-5, float64
+  brackets), on the kernel sources executed by the host emulator."""
+  tgp = _emulated_product(monkeypatch)
+  fn = getattr(tgp, body)
+  fn(golden_dir, *args) if 'golden_dir' in fn.__code__.co_varnames[:fn.__code__.co_argcount] else fn(*args)
+
+
+def test_gmmil_at_the_timed_size_on_the_emulated_kernels(monkeypatch):
+  """BASELINE config 4's reward pass (B = 1024 against 1024 expert rows, Ant dims): the full reward vector of k_gmmil_pack / k_gmmil_tile against the reference fixture."""
+  tgp = _emulated_product(monkeypatch)
+  import test_timed_sizes as tts
+  for k in ('il', 'il_training', 'T', 'N', 'Cfg', 'bracket'):
+    monkeypatch.setattr(tts, k, getattr(tgp, k), raising=False)
+  tts.test_gmmil_b1024_full_reward_vector_matches_reference()
+
+
+def test_small_network_kernels_at_ant_dims_on_the_emulated_kernels(monkeypatch):
+  _emulated_product(monkeypatch).test_red_dril_shaped_at_ant_dims_match_oracle()
+
+
+def test_emulated_product_refuses_nothing_silently(monkeypatch):
+  """The swap above is test scaffolding: outside it the product still refuses CPU tensors."""
+  import torch
+  from imitation_learning_amd import memory as il_memory
+  z = torch.zeros(4)
+  with pytest.raises(TypeError, match='CUDA'):
+    il_memory.batch_desc(dict(states=torch.zeros(4, 3), actions=torch.zeros(4, 2), rewards=z, next_states=torch.zeros(4, 3), terminals=z, weights=z, absorbing=z))
