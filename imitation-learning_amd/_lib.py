@@ -252,6 +252,12 @@ def stream_ptr():
   return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def on_device(t) -> bool:
+  """The one definition of "a tensor the kernels may be handed": HIP device memory. Every guard of the host layer asks here (there is no CPU path to fall into);
+  tests/host_emu, which runs the kernel sources on the host, substitutes it - nothing else may."""
+  return bool(t.is_cuda)
+
+
 def ptr(t):
   """Device pointer of a torch tensor (None -> NULL)."""
   return None if t is None else C.c_void_p(t.data_ptr())

@@ -86,7 +86,7 @@ def batch_desc(t: Dict[str, Tensor]) -> _lib.Batch:
   n = None
   for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'weights', 'absorbing'):
     v = t[k]
-    if v.dtype != torch.float32 or not v.is_cuda:
+    if v.dtype != torch.float32 or not _lib.on_device(v):
       raise TypeError(f'transitions[{k!r}] must be a float32 CUDA tensor (got {v.dtype} on {v.device})')
     if v.dim() == 2 and v.stride(1) != 1:
       raise ValueError(f'transitions[{k!r}] must have unit inner stride')

@@ -744,7 +744,7 @@ def _packed_rows(t: Dict[str, Tensor]) -> Tuple[Tensor, int, int]:
   base = st._base if st._base is not None else None
   S, A = st.size(1), ac.size(1)
   row = int(_lib.lib().il_ring_row_floats(S, A))
-  ok = (base is not None and base.is_cuda and base.dim() == 2 and base.size(1) == row and base.is_contiguous() and st.data_ptr() == base.data_ptr()
+  ok = (base is not None and _lib.on_device(base) and base.dim() == 2 and base.size(1) == row and base.is_contiguous() and st.data_ptr() == base.data_ptr()
         and ac.data_ptr() == base.data_ptr() + 4 * S and rw.data_ptr() == base.data_ptr() + 4 * (2 * S + A) and st.size(0) == base.size(0))
   if not ok:
     raise TypeError('expected a transitions dict produced by ReplayMemory.sample / batch_views (fields are views into packed device rows)')

@@ -53,7 +53,7 @@ def _f32(t: Optional[Tensor], device) -> Optional[Tensor]:
 def sac_descriptor(actor: SoftActor, critic: TwinCritic, log_alpha: Tensor, target_critic: TwinCritic, batch_size: int, actor_optimiser: AdamW, critic_optimiser: AdamW,
                    temperature_optimiser: Adam, discount: float, entropy_target: float, polyak_factor: float, tag=None, seed_offset: int = 0) -> _lib.Sac:
   S, A, H, dev = actor.state_size, actor.action_size, actor.hidden, actor.flat.device
-  assert critic.hidden == H and log_alpha.is_cuda and log_alpha.dtype == torch.float32
+  assert critic.hidden == H and _lib.on_device(log_alpha) and log_alpha.dtype == torch.float32
   floats = int(_lib.lib().il_sac_workspace_floats(S, A, H, batch_size))
   ws = _workspace('sac', floats, dev, tag)
   d = _lib.Sac()

@@ -1,8 +1,10 @@
-"""The plain-VALU HIP kernels of the general GAIL discriminators, executed on the HOST from their own source text (tests/host_emu: workgroups as fibers, the `<<<>>>`
-launches rewritten, nothing else) against the reference fixtures. This is what `pytest -m "not gpu"` can say about kernel code where there is no GPU: indexing, the
-order of power iterations, slab / context layouts, the reduce kernel's chain rule. It says nothing about performance or about anything wave-level; the `-m gpu`
-tests run the same comparisons on the real library. gail_deep.hip and gail_shaped.hip are also the emulator's own check: both are green on the GPU against these
-very fixtures, so a disagreement here would be the emulator's."""
+"""The HIP kernels executed on the HOST from their own source text (tests/host_emu: workgroups as fibers, MFMA / DPP / readlane / ballot on a wave-level exchange,
+the `<<<>>>` launches rewritten - nothing else) against the reference fixtures. This is what `pytest -m "not gpu"` can say about kernel code where there is no GPU:
+indexing, iteration orders, tile / slab / counter layouts, the reduce kernels' chain rules, the arithmetic. It says nothing about performance, memory ordering or
+anything that needs two workgroups in flight; the `-m gpu` tests run the same comparisons on the real library.
+
+Two layers: (1) the general GAIL discriminators through the raw C ABI with numpy pointers; (2) the BODIES of the `-m gpu` parity tests (tests/test_gpu_parity.py,
+tests/test_timed_sizes.py) - the product's own models.py / training.py / memory.py in between, the GPU's tolerances - with the library handle swapped for the emulation."""
 import ctypes as C
 import os
 import sys
@@ -27,13 +29,8 @@ def golden_dir():
   return os.path.join(HERE, 'golden')
 
 
-_HANDLES = {}
-
-
-def emu(name):
-  if name not in _HANDLES:
-    _HANDLES[name] = emu_build.load(name)
-  return _HANDLES[name]
+def emu(name=None):
+  return emu_build.load()   # one library with every kernel file (built once per change of the sources, ~25 s)
 
 
 class Keep(list):
@@ -62,8 +59,8 @@ def np_adam(keep, n, lr, wd):
 
 def check(h, rc):
   if rc != 0:
-    h.emu_il_last_error.restype = C.c_char_p
-    raise RuntimeError(f'emulated library error {rc}: {h.emu_il_last_error().decode()}')
+    h.il_last_error.restype = C.c_char_p
+    raise RuntimeError(f'emulated library error {rc}: {h.il_last_error().decode()}')
 
 
 def close(a, b, what, rtol, atol_scale):
@@ -240,44 +237,30 @@ def test_emulated_gail_shaped_deep_kernels_on_the_depth1_relu_fixtures(golden_di
 
 
 # ------------------------------------------------------------------------------------------------ the `-m gpu` test bodies over the emulated libraries
-EMULATED = ('gail_deep', 'gail_shaped', 'gail_shaped_deep', 'red', 'dril', 'gmmil')   # the kernel files without MFMA / DPP / buffer intrinsics
-
-
 def _emulated_product(monkeypatch):
-  """Swaps the product's library handle for the host emulations (entry points they export; the real library's host-side size queries otherwise), lets CPU tensors through
-  (the product refuses them: memory.batch_desc) and hands back tests/test_gpu_parity.py with its GPU-only names bound to the CPU, so that the BODIES of the `-m gpu`
-  parity tests - same inputs, same fixtures, same tolerances, the product's own models.py / training.py in between - run here on the kernel sources."""
+  """Swaps the product's library handle for the host emulation (the entry points it exports; the real library's host-side functions - abi.hip - otherwise), lets CPU
+  tensors through the product's one device guard (_lib.on_device) and hands back tests/test_gpu_parity.py with its GPU-only names bound to the CPU, so that the BODIES
+  of the `-m gpu` parity tests - same inputs, same fixtures, same tolerances, the product's own host layer in between - run here on the kernel sources."""
   import torch
   import gpu_util
   import imitation_learning_amd as il
   import test_gpu_parity as tgp
   from imitation_learning_amd import memory as il_memory, training as il_training
-  libs, real = [emu(n) if n.startswith('gail') else _HANDLES.setdefault(n, emu_build.load(n, headers=())) for n in EMULATED], _lib.lib()
+  h, real = emu(), _lib.lib()
 
   class Facade:
     def __getattr__(self, fn_name):
-      for h in libs:
-        try:
-          fn = getattr(h, fn_name)
-        except AttributeError:
-          continue
-        fn.restype, fn.argtypes = _lib._SIGNATURES[fn_name]
-        return fn
-      return getattr(real, fn_name)
-
-  def lenient_batch_desc(t):
-    b, n = _lib.Batch(), None
-    for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'weights', 'absorbing'):
-      v = t[k]
-      assert v.dtype == torch.float32 and (v.dim() == 1 or v.stride(1) == 1)
-      setattr(b, k, v.data_ptr()); setattr(b, 'ld_' + k, v.stride(0) if v.size(0) > 1 else (v.size(1) if v.dim() == 2 else 1)); n = v.size(0)
-    b.n = n
-    return b
+      try:
+        fn = getattr(h, fn_name)
+      except AttributeError:
+        return getattr(real, fn_name)
+      fn.restype, fn.argtypes = _lib._SIGNATURES[fn_name]
+      return fn
 
   monkeypatch.setattr(_lib, '_lib', Facade())
   monkeypatch.setattr(_lib, 'stream_ptr', lambda: None)
-  monkeypatch.setattr(il_training, 'batch_desc', lenient_batch_desc)
-  monkeypatch.setattr(il_memory, 'batch_desc', lenient_batch_desc)
+  monkeypatch.setattr(_lib, 'on_device', lambda t: True)
+  monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
   monkeypatch.setattr(gpu_util, 'DEV', 'cpu')
   for k in ('DEV', 'N', 'T', 'Cfg', 'bracket', 'close', 'close_params', 'crit_from_flat', 'fill_memory', 'make_disc', 'make_sac', 'make_sac_oracle', 'tbatch'):
     monkeypatch.setattr(tgp, k, getattr(gpu_util, k), raising=False)
@@ -288,38 +271,67 @@ def _emulated_product(monkeypatch):
   return tgp
 
 
+# the `-m gpu` parity tests whose bodies run here: everything that goes through the per-function entry points (the captured two-graph plans, the acting worker's
+# mailbox and the multi-process paths need streams, graphs or a second process, i.e. a GPU)
+GPU_BODIES = (
+    'test_replay_matches_reference_bit_exact', 'test_transfer_transitions_matches_sequential_appends', 'test_replay_full_size_gather_property',
+    'test_sac_update_matches_oracle_and_reference', 'test_sac_gradients_match_oracle', 'test_sac_update_other_shapes', 'test_sac_gradient_of_concatenated_batch_is_mean_of_shard_gradients',
+    'test_bc_update_matches_oracle_and_reference', 'test_actor_act_matches_oracle', 'test_adam_and_polyak_kernels',
+    'test_gail_update_matches_oracle_and_reference', 'test_gail_loss_variants_match_reference', 'test_gail_ragged_batch_and_state_only',
+    'test_gmmil_matches_oracle_and_reference', 'test_gmmil_full_size_properties', 'test_pwil_matches_oracle_and_reference',
+    'test_reward_relabeller_bit_exact', 'test_mix_expert_agent_transitions_bit_exact',
+    'test_red_matches_reference', 'test_dril_matches_reference', 'test_every_shipped_red_dril_shape_runs_at_ant_dims', 'test_dril_onchip_masks_are_bernoulli_and_change_per_call',
+    'test_gail_deep_discriminator_matches_reference', 'test_gail_deep_pugail_finite_margin_matches_reference',
+    'test_gail_reward_shaping_matches_reference', 'test_gail_reward_shaping_mixup_matches_reference', 'test_gail_shaped_pugail_finite_margin_matches_reference',
+    'test_gail_reward_shaping_general_potential_matches_reference', 'test_red_dril_shaped_at_ant_dims_match_oracle',
+)
+
+
 def _gpu_bodies():
-  out = [('test_red_matches_reference', (n, kw)) for n, kw, _, _ in gi.RED_CASES] + [('test_dril_matches_reference', (n, kw)) for n, kw, _, _ in gi.DRIL_CASES]
-  out += [('test_gail_deep_discriminator_matches_reference', (n,)) for n, *_ in gi.GAIL_DEEP_CASES]
-  out += [('test_gail_reward_shaping_matches_reference', a) for a in (('sn_bce', True, 'BCE'), ('plain_pugail', False, 'PUGAIL'))] + [('test_gail_reward_shaping_mixup_matches_reference', ())]
-  out += [(t, (n,)) for n in ('clamped', 'open') for t in ('test_gail_deep_pugail_finite_margin_matches_reference', 'test_gail_shaped_pugail_finite_margin_matches_reference')]
-  out += [('test_gail_reward_shaping_general_potential_matches_reference', (n,)) for n, *_ in gi.GAIL_SHAPED_DEEP_CASES]
-  out += [('test_gmmil_matches_oracle_and_reference', a) for a in (('small', (64, 48, 24)), ('ant', (256, 256, 120)))] + [('test_gmmil_full_size_properties', ())]
-  out += [('test_every_shipped_red_dril_shape_runs_at_ant_dims', (n,)) for n in ('RED_5', 'RED_10', 'RED_25', 'DRIL_5', 'DRIL_10', 'DRIL_25')]   # on-chip Philox dropout masks
-  out += [('test_dril_onchip_masks_are_bernoulli_and_change_per_call', ())]
+  """(function name, keyword arguments) for every parametrisation the GPU test itself declares (its own pytest.mark.parametrize marks are read, not restated)."""
+  import itertools
+  import test_gpu_parity as tgp
+  out = []
+  for name in GPU_BODIES:
+    fn = getattr(tgp, name)
+    axes = []
+    for m in getattr(fn, 'pytestmark', []):
+      if m.name == 'parametrize':
+        names = [n.strip() for n in m.args[0].split(',')]
+        axes.append([dict(zip(names, v if len(names) > 1 else (v,))) for v in m.args[1]])
+    for combo in itertools.product(*axes) if axes else [()]:
+      kw = {}
+      for part in combo: kw.update(part)
+      out.append((name, kw))
   return out
 
 
-@pytest.mark.parametrize('body,args', _gpu_bodies(), ids=[f'{b[5:]}-{a[0] if a else ""}' for b, a in _gpu_bodies()])
-def test_gpu_parity_bodies_on_the_emulated_kernels(golden_dir, monkeypatch, body, args):
-  """RED, DRIL, the general GAIL discriminators (deep, reward shaping, both), GMMIL: the parity tests the GPU runs, at the GPU's tolerances (rtol 1e-5 .. 2e-5, float64
-  brackets), on the kernel sources executed by the host emulator."""
+def _body_id(name, kw):
+  first = next(iter(kw.values()), '')
+  return f'{name[5:]}-{first}' if kw else name[5:]
+
+
+@pytest.mark.parametrize('body,kw', _gpu_bodies(), ids=[_body_id(n, kw) for n, kw in _gpu_bodies()])
+def test_gpu_parity_bodies_on_the_emulated_kernels(golden_dir, monkeypatch, body, kw):
+  """The replay ring and the device index draw, `sac_update` (incl. the headline shape: HalfCheetah, hidden 256, batch 256) and its gradients, behavioural cloning, the
+  acting forward, AdamW / polyak, the GAIL discriminator with every loss variant, GMMIL, PWIL, the relabellers, RED, DRIL and the general discriminators: the parity
+  tests the GPU runs, at the GPU's tolerances (rtol 1e-5 .. 2e-5, float64 brackets, bit equality for rows and indices), on the kernel sources executed by the emulator."""
   tgp = _emulated_product(monkeypatch)
   fn = getattr(tgp, body)
-  fn(golden_dir, *args) if 'golden_dir' in fn.__code__.co_varnames[:fn.__code__.co_argcount] else fn(*args)
+  if 'golden_dir' in fn.__code__.co_varnames[:fn.__code__.co_argcount]: kw = dict(kw, golden_dir=golden_dir)
+  fn(**kw)
 
 
-def test_gmmil_at_the_timed_size_on_the_emulated_kernels(monkeypatch):
-  """BASELINE config 4's reward pass (B = 1024 against 1024 expert rows, Ant dims): the full reward vector of k_gmmil_pack / k_gmmil_tile against the reference fixture."""
+@pytest.mark.parametrize('body', ['test_gmmil_b1024_full_reward_vector_matches_reference', 'test_gail_b1024_mixup_update_matches_reference',
+                                  pytest.param('test_pwil_25k_atoms_matches_reference', marks=pytest.mark.skipif(os.environ.get('IL_EMU_SLOW', '0') != '1', reason='1,100 emulated steps against 25,000 atoms take ~5 min (passes; IL_EMU_SLOW=1 runs it)'))])
+def test_timed_sizes_on_the_emulated_kernels(monkeypatch, body):
+  """The sizes the benchmarks run (tests/test_timed_sizes.py): BASELINE config 4's GMMIL reward pass as a full reward vector (B = 1024 against 1024 expert rows, Ant
+  dims), one adversarial_imitation_update at B = 1024 with the tuned GAIL_5 hyper-parameters, PWIL against 25,000 atoms over 1,100 steps incl. a reset()."""
   tgp = _emulated_product(monkeypatch)
   import test_timed_sizes as tts
-  for k in ('il', 'il_training', 'T', 'N', 'Cfg', 'bracket'):
+  for k in ('il', 'il_training', 'il_memory', '_lib', 'T', 'N', 'Cfg', 'DEV', 'bracket', 'close', 'close_params', 'make_disc', 'tbatch'):
     monkeypatch.setattr(tts, k, getattr(tgp, k), raising=False)
-  tts.test_gmmil_b1024_full_reward_vector_matches_reference()
-
-
-def test_small_network_kernels_at_ant_dims_on_the_emulated_kernels(monkeypatch):
-  _emulated_product(monkeypatch).test_red_dril_shaped_at_ant_dims_match_oracle()
+  getattr(tts, body)()
 
 
 def test_emulated_product_refuses_nothing_silently(monkeypatch):
