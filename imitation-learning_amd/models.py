@@ -239,7 +239,8 @@ class DropoutSoftActor(SoftActor):
     if state.stride(-1) != 1: state = state.contiguous()
     if action.stride(-1) != 1: action = action.contiguous()
     n = state.size(0)
-    b = _sa_batch(state, action, torch.ones(n, device=dev))
+    ones = torch.ones(n, device=dev)   # named: an il_batch holds raw pointers
+    b = _sa_batch(state, action, ones)
     m0, m1, m2 = self._masks(masks, n * self.ENSEMBLE)
     out = torch.empty(n, device=dev)
     d = self._desc(n)
@@ -711,7 +712,8 @@ class REDDiscriminator(_FlatModule):
     action = action.to(dev, torch.float32)
     if state.stride(-1) != 1: state = state.contiguous()
     if action.stride(-1) != 1: action = action.contiguous()
-    return _sa_batch(state, action, torch.ones(state.size(0), device=dev)), state.size(0), (state, action)
+    ones = torch.ones(state.size(0), device=dev)
+    return _sa_batch(state, action, ones), state.size(0), (state, action, ones)   # the il_batch holds raw pointers: the caller keeps the tensors alive
 
   def forward(self, state: Tensor, action: Tensor, masks=None) -> Tuple[Tensor, Tensor]:
     b, n, keep = self._batch(state, action)

@@ -232,7 +232,8 @@ def shaped_predict_reward(disc, state: Tensor, action: Tensor, next_state: Tenso
   dev = disc.flat.device
   n = state.size(0)
   d = shaped_descriptor(disc, n, None)
-  b = _shaped_batch(state, action, next_state, terminal.to(dev, torch.float32).contiguous())
+  terminal = terminal.to(dev, torch.float32).contiguous()   # named: the il_batch below holds raw pointers
+  b = _shaped_batch(state, action, next_state, terminal)
   out, logits, off = torch.empty(n, device=dev), (torch.empty(n, device=dev) if want_logits else None), _f32(log_policy, dev)
   reward = _lib.lib().il_gail_shaped_deep_reward if _shaped_general(disc) else _lib.lib().il_gail_shaped_reward
   _lib.check(reward(C.byref(d), C.byref(b), _lib.ptr(out), _lib.ptr(logits), _lib.ptr(off), _lib.stream_ptr()))
@@ -318,7 +319,8 @@ def embedding_sqdist(x: Tensor, y: Tensor) -> Tensor:
   dev = x.device
   ws = _workspace('gmmil', int(_lib.lib().il_gmmil_workspace_floats(n1, n2, D)), dev)
   out = torch.empty(n1, n2, device=dev)
-  ba, bb = _sa_batch(x, x, torch.ones(n1, device=dev)), _sa_batch(y, y, torch.ones(n2, device=dev))
+  w1, w2 = torch.ones(n1, device=dev), torch.ones(n2, device=dev)   # named: an il_batch holds raw pointers, the tensors must outlive the launch
+  ba, bb = _sa_batch(x, x, w1), _sa_batch(y, y, w2)
   _lib.check(_lib.lib().il_gmmil_sqdist(C.byref(ba), C.byref(bb), D, 0, 1, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
   return out
 

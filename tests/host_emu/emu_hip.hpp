@@ -201,8 +201,7 @@ inline bool lane_live(int t) { return fibers[t].state != DONE; }
 
 template <class K, class... Args>
 inline void launch(K kernel, dim3 grid, dim3 block, size_t lds_bytes, Args... args) {
-  std::vector<char> smem(lds_bytes + 64);
-  void* aligned = (void*)(((uintptr_t)smem.data() + 63) & ~(uintptr_t)63);
+  void* aligned = malloc(lds_bytes ? lds_bytes : 16);   // exactly the launch's LDS (16-byte aligned like every malloc): an AddressSanitizer build sees the first byte past it
   gridDim = grid; blockDim = block;
   for (unsigned z = 0; z < grid.z; ++z)
     for (unsigned y = 0; y < grid.y; ++y)
@@ -212,6 +211,7 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t lds_bytes, Args... ar
         memset(aligned, 0xcd, lds_bytes);   // LDS is not zero on the GPU either: poison it so that a read of an unwritten word shows
         run_block(block, [&]() { kernel(args...); });
       }
+  free(aligned);
 }
 }  // namespace emu
 
