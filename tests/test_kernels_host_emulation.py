@@ -350,10 +350,11 @@ ASAN_SUBSET = ('sac_update_matches_oracle_and_reference-sac_hopper_h64 or sac_gr
 
 
 def test_emulated_kernels_are_address_sanitizer_clean():
-  """The same emulation compiled with -fsanitize=address (IL_EMU_ASAN=1), a subset of the bodies above in a child process: every load and store of those kernels - the
-  global buffers (numpy / torch allocations go through the intercepted malloc), the workgroup's LDS (allocated to the byte) - is bounds- and lifetime-checked. A GPU run
-  cannot say this: an access a few words past a tensor lands in the caching allocator's pool and is silent. The whole file is clean under it (IL_EMU_ASAN_ALL=1 runs all
-  of it, ~2.5 min); round 3 found one use-after-free this way - a temporary `torch.ones` whose pointer sat in an il_batch after the tensor had died (training.py)."""
+  """The same emulation compiled with -fsanitize=address,undefined (IL_EMU_ASAN=1), a subset of the bodies above in a child process: every load and store of those
+  kernels - the global buffers (numpy / torch allocations go through the intercepted malloc), the workgroup's LDS (allocated to the byte) - is bounds- and lifetime-
+  checked, every 16-byte vector access alignment-checked, signed overflow and shifts checked. A GPU run cannot say this: an access a few words past a tensor lands in
+  the caching allocator's pool and is silent. The whole file is clean under it (IL_EMU_ASAN_ALL=1 runs all of it, ~4 min); round 3 found one use-after-free this way -
+  a temporary `torch.ones` whose pointer sat in an il_batch after the tensor had died (training.py)."""
   import subprocess
   asan = subprocess.run(['gcc', '-print-file-name=libasan.so'], capture_output=True, text=True).stdout.strip()
   if not os.path.isabs(asan) or not os.path.exists(asan):
