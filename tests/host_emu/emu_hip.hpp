@@ -114,6 +114,15 @@ inline unsigned char coll_val[COLL_RING][MAX_THREADS][COLL_BYTES];
 inline unsigned coll_tag[COLL_RING][MAX_THREADS];
 inline unsigned coll_seq[MAX_THREADS];
 inline int block_threads = 0;
+inline int schedule_mode = -1;          // 0 forward, 1 reverse, 2 random (IL_EMU_SCHEDULE, read at the first launch)
+inline unsigned long long rng_state = 1;
+inline unsigned next_random() { rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(rng_state >> 33); }
+inline void read_schedule() {
+  if (schedule_mode >= 0) return;
+  const char* e = getenv("IL_EMU_SCHEDULE");
+  schedule_mode = !e || !strcmp(e, "forward") ? 0 : (!strcmp(e, "reverse") ? 1 : 2);
+  if (schedule_mode == 2) { const char* c = strchr(e, ':'); rng_state = c ? strtoull(c + 1, nullptr, 10) * 2 + 1 : 1; }
+}
 
 #if EMU_FAST_SWITCH
 inline void to_scheduler() { emu_switch(&fibers[cur].sp, sched_sp); }
@@ -159,14 +168,25 @@ inline void run_block(const dim3& bdim, const std::function<void()>& fn) {
   }
   memset(shfl_tag, 0xff, sizeof(shfl_tag));
   memset(coll_tag, 0xff, sizeof(coll_tag));
+  const int nwaves = (n + 63) / 64;
+  int wave_order[MAX_THREADS / 64], lane_order[64];
   for (;;) {
-    // one wave at a time: its lanes take turns until each of them sits at a barrier or has returned (lanes that yield inside a wave-level exchange stay runnable)
-    for (int w0 = 0; w0 < n; w0 += 64) {
-      const int w1 = std::min(w0 + 64, n);
+    // one wave at a time: its lanes take turns until each of them sits at a barrier or has returned (lanes that yield inside a wave-level exchange stay runnable).
+    // IL_EMU_SCHEDULE = reverse | random:<seed> changes the order of the waves between two barriers and of the lanes within a wave: a kernel whose result depends on
+    // that order is missing a barrier (an LDS race the forward order happens to hide)
+    for (int w = 0; w < nwaves; ++w) wave_order[w] = schedule_mode == 1 ? nwaves - 1 - w : w;
+    for (int l = 0; l < 64; ++l) lane_order[l] = schedule_mode == 1 ? 63 - l : l;
+    if (schedule_mode == 2) {
+      for (int w = nwaves - 1; w > 0; --w) std::swap(wave_order[w], wave_order[next_random() % (unsigned)(w + 1)]);
+      for (int l = 63; l > 0; --l) std::swap(lane_order[l], lane_order[next_random() % (unsigned)(l + 1)]);
+    }
+    for (int wi = 0; wi < nwaves; ++wi) {
+      const int w0 = 64 * wave_order[wi];
       for (bool any = true; any;) {
         any = false;
-        for (int i = w0; i < w1; ++i) {
-          if (fibers[i].state != RUNNABLE) continue;
+        for (int li = 0; li < 64; ++li) {
+          const int i = w0 + lane_order[li];
+          if (i >= n || fibers[i].state != RUNNABLE) continue;
           any = true;
           cur = i;
           threadIdx = dim3(i % bdim.x, (i / bdim.x) % bdim.y, i / (bdim.x * bdim.y));
@@ -202,6 +222,7 @@ inline bool lane_live(int t) { return fibers[t].state != DONE; }
 template <class K, class... Args>
 inline void launch(K kernel, dim3 grid, dim3 block, size_t lds_bytes, Args... args) {
   void* aligned = malloc(lds_bytes ? lds_bytes : 16);   // exactly the launch's LDS (16-byte aligned like every malloc): an AddressSanitizer build sees the first byte past it
+  read_schedule();
   gridDim = grid; blockDim = block;
   for (unsigned z = 0; z < grid.z; ++z)
     for (unsigned y = 0; y < grid.y; ++y)

@@ -70,6 +70,67 @@ def close(a, b, what, rtol, atol_scale):
   assert np.isfinite(a).all() and err.max() <= 0, f'{what}: worst excess {err.max():.3e} at {int(err.argmax())} ({a.ravel()[err.argmax()]} vs {b.ravel()[err.argmax()]})'
 
 
+# ------------------------------------------------------------------------------------------------ the emulator's own checks
+def test_emulator_mfma_is_the_16x16x4_instruction_the_kernels_assume():
+  """v_mfma_f32_16x16x4_f32 in the lane layout of mlp_tile.hpp / DESIGN §3: against a float64 matmul, and bitwise against an fmaf chain over k in float32."""
+  h = emu_build.load_selftest()
+  rs = np.random.RandomState(0)
+  K4 = 5
+  A, B = rs.standard_normal((16, 4 * K4)).astype(f32), rs.standard_normal((4 * K4, 16)).astype(f32)
+  D = np.zeros((16, 16), f32)
+  h.selftest_mfma(P(A), P(B), P(D), K4)
+  np.testing.assert_allclose(D, A.astype(np.float64) @ B.astype(np.float64), rtol=1e-5, atol=1e-5)
+  chain = np.zeros((16, 16), f32)
+  for k in range(4 * K4):   # fmaf(a, b, acc): one rounding per step; float64 holds the exact product and sum of two float32 terms up to the final rounding
+    chain = (A[:, k:k + 1].astype(np.float64) * B[k:k + 1, :].astype(np.float64) + chain.astype(np.float64)).astype(f32)
+  np.testing.assert_array_equal(D, chain)
+
+
+def test_emulator_lane_instructions():
+  h = emu_build.load_selftest()
+  out = np.zeros((6, 64), np.int32)
+  h.selftest_lanes(P(out))
+  l = np.arange(64)
+  np.testing.assert_array_equal(out[0], (l & ~15) | ((l - 1) & 15))                       # row_ror:1: lane i of a row reads lane i - 1 (mod 16)
+  np.testing.assert_array_equal(out[1], np.where(l & 15, l - 1, -1))                      # row_shr:1: lane 0 of a row has no source and keeps `old`
+  np.testing.assert_array_equal(out[2], np.full(64, 170))                                  # readlane(17)
+  np.testing.assert_array_equal(out[3], np.full(64, 22))                                   # 22 multiples of 3 below 64
+  np.testing.assert_array_equal(out[4], l ^ 5)
+  np.testing.assert_array_equal(out[5], l ^ 1)                                             # quad_perm [1, 0, 3, 2]
+
+
+def test_emulator_schedule_perturbation_exposes_a_missing_barrier():
+  """IL_EMU_SCHEDULE=reverse|random:<seed> re-orders the waves between two barriers (and the lanes within a wave). A kernel that is missing a barrier gives a different
+  answer under one of the orders; the whole file above passes under forward, reverse and random orders. Here: a deliberately racy kernel, in child processes
+  (the schedule is read once per process)."""
+  import subprocess
+  code = ("import sys, numpy as np, ctypes as C; sys.path[:0] = ['tests']\n"
+          "from host_emu import build\n"
+          "h = build.load_selftest(); out = np.full(64, -1, np.float32)\n"
+          "h.selftest_race(C.c_void_p(out.ctypes.data), int(sys.argv[1])); print(int(np.array_equal(out, np.arange(63, -1, -1, dtype=np.float32))))\n")
+  run = lambda schedule, barrier: subprocess.run([sys.executable, '-c', code, str(barrier)], env=dict(os.environ, IL_EMU_SCHEDULE=schedule), cwd=os.path.dirname(HERE),
+                                                 capture_output=True, text=True, timeout=300).stdout.strip()
+  assert run('forward', 1) == '1' and run('reverse', 1) == '1' and run('random:3', 1) == '1'   # with the barrier: every order agrees
+  assert run('forward', 0) == '1'                                                                # the race, hidden by the order a simple emulator would use
+  assert run('reverse', 0) == '0'                                                                # ... and exposed
+
+
+def test_emulator_sanitised_build_sees_one_element_past_a_buffer():
+  import subprocess
+  asan = subprocess.run(['gcc', '-print-file-name=libasan.so'], capture_output=True, text=True).stdout.strip()
+  if not os.path.isabs(asan) or not os.path.exists(asan):
+    pytest.skip('libasan.so not found next to gcc')
+  code = ("import sys, numpy as np, ctypes as C; sys.path[:0] = ['tests']\n"
+          "from host_emu import build\n"
+          "h = build.load_selftest(); a = np.ones(40, np.float32); o = np.zeros(64, np.float32)\n"
+          "h.selftest_overrun(C.c_void_p(a.ctypes.data), C.c_void_p(o.ctypes.data), int(sys.argv[1])); print('returned')\n")
+  env = dict(os.environ, IL_EMU_ASAN='1', LD_PRELOAD=asan, ASAN_OPTIONS='detect_leaks=0:detect_stack_use_after_return=0')
+  ok = subprocess.run([sys.executable, '-c', code, '39'], env=env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=600)    # reads in[0..39]: in bounds
+  assert ok.returncode == 0 and 'returned' in ok.stdout, ok.stderr[-2000:]
+  bad = subprocess.run([sys.executable, '-c', code, '40'], env=env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=600)   # reads in[40]
+  assert bad.returncode != 0 and 'heap-buffer-overflow' in bad.stderr, bad.stderr[-2000:]
+
+
 # ------------------------------------------------------------------------------------------------ gail_deep.hip
 @pytest.mark.parametrize('name', [n for n, *_ in gi.GAIL_DEEP_CASES])
 def test_emulated_gail_deep_kernels_match_reference(golden_dir, name):
@@ -366,3 +427,14 @@ def test_emulated_kernels_are_address_sanitizer_clean():
   out = r.stdout + r.stderr
   assert 'AddressSanitizer' not in out, out[out.index('AddressSanitizer') - 200:][:6000]
   assert r.returncode == 0 and ' passed' in out, out[-3000:]
+
+
+@pytest.mark.parametrize('schedule', ['reverse', 'random:5'])
+def test_emulated_kernels_do_not_depend_on_the_wave_schedule(schedule):
+  """The same subset with the waves of every workgroup (and the lanes of every wave) scheduled in reverse / in a random order between two barriers: the parity bounds
+  still hold, i.e. no result depends on which wave reaches a barrier-free stretch first (a missing __syncthreads() would - see the emulator's self-test above).
+  IL_EMU_SCHEDULE=... with the whole file: 90 passed under reverse, random:1, random:7."""
+  import subprocess
+  r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-p', 'no:cacheprovider', '-k', ASAN_SUBSET], env=dict(os.environ, IL_EMU_SCHEDULE=schedule),
+                     cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=1500)
+  assert r.returncode == 0 and ' passed' in r.stdout, (r.stdout + r.stderr)[-3000:]
