@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE: builds ONE host-emulation library from the HIP kernel sources of imitation-learning_amd/csrc (see emu_hip.hpp for the execution model).
 
-`load()` translates every kernel file (all of csrc/*.hip but abi.hip and peer.hip: host-side tracing and cross-process memory windows) and every device header into
+`load()` translates every source file (all of csrc/*.hip but peer.hip: cross-process memory windows) and every device header into
 tests/host_emu/_build/, compiles them with g++ (-ffp-contract=off like the device build) against emu_hip.hpp standing in for <hip/hip_runtime.h>, and returns a ctypes
 handle exporting the same `extern "C"` entry points as libil_hip.so - to be called with HOST pointers. Only the source TEXT is transformed, never its logic:
   * `kernel<<<grid, block, lds, stream>>>(args);`          -> `EMU_LAUNCH(kernel, grid, block, lds, args);`
@@ -25,18 +25,7 @@ BUILD = os.path.join(HERE, '_build')
 # IL_EMU_ASAN=1: AddressSanitizer build (run python with LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0):
 # every load / store of every emulated kernel - global buffers (numpy / torch allocations go through the intercepted malloc) and the workgroup's LDS - bounds-checked
 SANITIZE = ['-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-fno-omit-frame-pointer'] if os.environ.get('IL_EMU_ASAN', '0') == '1' else []
-NOT_EMULATED = ('abi.hip', 'peer.hip')   # il_set_error / tracing (stubbed below) and hipIpc* memory windows
-
-_EMU_ABI = '''// GENERATED by tests/host_emu/build.py: what abi.hip provides to the other translation units
-#include "il_common.hpp"
-#include <stdarg.h>
-static char emu_last_error[512];
-int il_set_error(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(emu_last_error, sizeof(emu_last_error), fmt, ap); va_end(ap); return code; }
-extern "C" const char* il_last_error() { return emu_last_error; }
-il_trace_scope::il_trace_scope(const char*, hipStream_t s) : st(s), slot(-1) {}
-il_trace_scope::~il_trace_scope() {}
-'''
-
+NOT_EMULATED = ('peer.hip',)   # hipIpc* memory windows between processes
 
 def _split_top_level(s: str):
   parts, depth, cur = [], 0, ''
@@ -51,6 +40,25 @@ def _split_top_level(s: str):
   return parts
 
 
+# `__shared__ [aligned] T a[..][..];` / `__shared__ T a, b;`: a workgroup's static LDS. Several workgroups can be resident at once (emu_hip.hpp), so a C++ `static` would be
+# shared between them: each declaration becomes a reference to per-workgroup storage, allocated to the byte (the sanitised build then bounds-checks it too).
+_SHARED = re.compile(r'__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?((?:unsigned\s+)?(?:long\s+long|short|int|float|\w+))\s+(\w+(?:\s*,\s*\w+)*)((?:\[[^\]]*\])*)\s*;')
+_shared_count = [0]
+
+
+def _shared_decl(m):
+  typ, names, dims = m.group(1), [n.strip() for n in m.group(2).split(',')], m.group(3)
+  out = []
+  for n in names:
+    _shared_count[0] += 1
+    key = f'(const void*)"static-lds-{_shared_count[0]}-{n}"'
+    if dims:
+      out.append(f'{typ} (&{n}){dims} = *({typ} (*){dims})emu::block_static({key}, sizeof({typ}{dims}));')
+    else:
+      out.append(f'{typ}& {n} = *({typ}*)emu::block_static({key}, sizeof({typ}));')
+  return ' '.join(out)
+
+
 _LAUNCH = re.compile(r'([A-Za-z_][\w:]*(?:<[\w, ]+>)?)\s*<<<(.*?)>>>\s*\(')
 
 
@@ -61,16 +69,28 @@ def translate(src: str) -> str:
   src = re.sub(r'asm volatile\(""[^;]*\);', '', src)
   src = re.sub(r'asm volatile\("s_waitcnt [^"]*"[^;]*\);', '', src)
   assert 'asm volatile' not in src, 'an inline-assembly statement the emulator does not know'
+  src = _SHARED.sub(_shared_decl, src)
+  assert '__shared__' not in re.sub(r'//[^\n]*', '', src), 'a static __shared__ declaration the translation did not recognise'
   out, pos = '', 0
   for m in _LAUNCH.finditer(src):
     cfg = _split_top_level(m.group(2))
     assert 2 <= len(cfg) <= 4, m.group(0)
-    grid, block, lds = cfg[0], cfg[1], (cfg[2] if len(cfg) > 2 else '0')
-    out += src[pos:m.start()] + f'EMU_LAUNCH({m.group(1)}, {grid}, {block}, {lds}, '
+    grid, block, lds, stream = cfg[0], cfg[1], (cfg[2] if len(cfg) > 2 else '0'), (cfg[3] if len(cfg) > 3 else '0')
+    out += src[pos:m.start()] + f'EMU_LAUNCH({m.group(1)}, {grid}, {block}, {lds}, {stream}, '
     pos = m.end()
   out += src[pos:]
+  if os.environ.get('IL_EMU_DEBUG_WAITS', '0') == '1':   # name the device-side wait that expired
+    out = out.replace('if (++spins > limit) { sync_timed_out(sync); break; }',
+                      'if (++spins > limit) { fprintf(stderr, "emu: wait expired in block (%u,%u) of (%u,%u): counter %d is %lld, target %lld\\n", blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, which, (long long)sync[which], (long long)target); sync_timed_out(sync); break; }')
   assert '<<<' not in re.sub(r'//[^\n]*', '', out), 'a kernel launch the translation did not recognise'
   return out
+
+
+_EXPORTS = '''// GENERATED by tests/host_emu/build.py: what a test drives the emulated streams with
+#include <hip/hip_runtime.h>
+extern "C" void emu_drain() { emu::drain(); }                                                          // hipDeviceSynchronize
+extern "C" void emu_stream_wait(uintptr_t waiter, uintptr_t on) { emu::stream_wait(waiter, on); }      // waiter.wait_stream(on)
+'''
 
 
 def sources():
@@ -88,8 +108,8 @@ def load() -> C.CDLL:
   texts = {h: translate(open(os.path.join(CSRC, h)).read()) for h in sorted(os.listdir(CSRC)) if h.endswith('.hpp')}
   for f in sources():
     texts[f[:-4] + '.cpp'] = translate(open(os.path.join(CSRC, f)).read())
-  texts['emu_abi.cpp'] = _EMU_ABI
-  hashed = dict(texts, **{'flags': ' '.join(SANITIZE), 'emu_hip.hpp': open(os.path.join(HERE, 'emu_hip.hpp')).read(), 'il_hip.h': open(os.path.join(ROOT, 'include', 'il_hip.h')).read()})
+  texts['emu_exports.cpp'] = _EXPORTS
+  hashed = dict(texts, **{'flags': ' '.join(SANITIZE) + os.environ.get('IL_EMU_DEBUG_WAITS', ''), 'emu_hip.hpp': open(os.path.join(HERE, 'emu_hip.hpp')).read(), 'il_hip.h': open(os.path.join(ROOT, 'include', 'il_hip.h')).read()})
   tag = hashlib.sha256('\0'.join(k + '\0' + v for k, v in sorted(hashed.items())).encode()).hexdigest()[:16]
   so = os.path.join(BUILD, f'libil_emu_{tag}.so')
   if not os.path.exists(so):

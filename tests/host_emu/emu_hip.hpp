@@ -17,11 +17,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <ucontext.h>
 
 #include <algorithm>
 #include <cmath>
+#include <deque>
 #include <functional>
+#include <map>
 #include <vector>
 
 #define __host__
@@ -29,7 +32,6 @@
 #define __global__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__ static
 using std::max;
 using std::min;
 
@@ -100,20 +102,27 @@ struct Fiber { ucontext_t ctx; int state; };
 inline ucontext_t sched_ctx;
 #define EMU_FAST_SWITCH 0
 #endif
-inline std::vector<Fiber> fibers;
-inline std::vector<char> stacks;
+// ---- workgroups, launches, streams
+// A launch is a job in its stream's queue; jobs of one stream run in order, jobs of different streams side by side. A workgroup (Block) owns its fibers, stacks, LDS and
+// exchange buffers, so that several can be resident at once: a lane that polls a device-side counter (every polling loop of the kernels sleeps: s_sleep) suspends its
+// WORKGROUP and lets the others - of the same launch, or of the launch at the head of another stream - run; that is what co-residency gives the device hand-offs on
+// the GPU. Launches on the null stream run to completion at once (everything else drained first), which is all the per-function tests need.
+struct Block {
+  dim3 idx, gdim, bdim;
+  int n = 0, cap = 0;
+  Fiber* fibers = nullptr; char* stacks = nullptr;
+  void* lds = nullptr;
+  uint64_t* shfl_val = nullptr; unsigned* shfl_tag = nullptr; unsigned* shfl_seq = nullptr;
+  unsigned char* coll_val = nullptr; unsigned* coll_tag = nullptr; unsigned* coll_seq = nullptr;
+  std::vector<std::pair<const void*, void*>> statics;   // static __shared__ variables of the kernel: per workgroup (build.py turns the declarations into lookups)
+  const std::function<void()>* body = nullptr;
+  bool yield_requested = false;
+};
+inline Block* blk = nullptr;   // the workgroup whose fiber is running
 inline int cur = 0;
-inline std::function<void()> body;
 inline void* dyn_smem = nullptr;
-inline uint64_t shfl_val[SHFL_RING][MAX_THREADS];
-inline unsigned shfl_tag[SHFL_RING][MAX_THREADS];
-inline unsigned shfl_seq[MAX_THREADS];
-inline float bs_buf[MAX_THREADS];
-enum { COLL_RING = 8, COLL_BYTES = 16 };
-inline unsigned char coll_val[COLL_RING][MAX_THREADS][COLL_BYTES];
-inline unsigned coll_tag[COLL_RING][MAX_THREADS];
-inline unsigned coll_seq[MAX_THREADS];
 inline int block_threads = 0;
+enum { COLL_RING = 8, COLL_BYTES = 16 };
 inline int schedule_mode = -1;          // 0 forward, 1 reverse, 2 random (IL_EMU_SCHEDULE, read at the first launch)
 inline unsigned long long rng_state = 1;
 inline unsigned next_random() { rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(rng_state >> 33); }
@@ -125,55 +134,83 @@ inline void read_schedule() {
 }
 
 #if EMU_FAST_SWITCH
-inline void to_scheduler() { emu_switch(&fibers[cur].sp, sched_sp); }
-inline void to_fiber(int i) { emu_switch(&sched_sp, fibers[i].sp); }
+inline void to_scheduler() { emu_switch(&blk->fibers[cur].sp, sched_sp); }
+inline void to_fiber(int i) { emu_switch(&sched_sp, blk->fibers[i].sp); }
 #else
-inline void to_scheduler() { swapcontext(&fibers[cur].ctx, &sched_ctx); }
-inline void to_fiber(int i) { swapcontext(&sched_ctx, &fibers[i].ctx); }
+inline void to_scheduler() { swapcontext(&blk->fibers[cur].ctx, &sched_ctx); }
+inline void to_fiber(int i) { swapcontext(&sched_ctx, &blk->fibers[i].ctx); }
 #endif
 inline void fiber_entry() {
-  body();
-  fibers[cur].state = DONE;
+  (*blk->body)();
+  blk->fibers[cur].state = DONE;
   to_scheduler();
   abort();   // a finished fiber is never resumed
 }
-inline void make_fiber(int i) {
-  char* base = stacks.data() + (size_t)i * STACK_BYTES;
+inline void make_fiber(Block* b, int i) {
+  char* base = b->stacks + (size_t)i * STACK_BYTES;
 #if EMU_FAST_SWITCH
   void** sp = (void**)(((uintptr_t)base + STACK_BYTES) & ~(uintptr_t)15);
   *--sp = nullptr;                       // where a return address would sit: fiber_entry starts with rsp = 8 mod 16 like any called function
   *--sp = (void*)&fiber_entry;           // popped by emu_switch's `ret`
   for (int r = 0; r < 6; ++r) *--sp = nullptr;   // rbp rbx r12 r13 r14 r15
-  fibers[i].sp = sp;
+  b->fibers[i].sp = sp;
 #else
-  getcontext(&fibers[i].ctx);
-  fibers[i].ctx.uc_stack.ss_sp = base;
-  fibers[i].ctx.uc_stack.ss_size = STACK_BYTES;
-  fibers[i].ctx.uc_link = nullptr;
-  makecontext(&fibers[i].ctx, fiber_entry, 0);
+  getcontext(&b->fibers[i].ctx);
+  b->fibers[i].ctx.uc_stack.ss_sp = base;
+  b->fibers[i].ctx.uc_stack.ss_size = STACK_BYTES;
+  b->fibers[i].ctx.uc_link = nullptr;
+  makecontext(&b->fibers[i].ctx, fiber_entry, 0);
 #endif
 }
 inline int linear_tid() { return (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)); }
 
-inline void run_block(const dim3& bdim, const std::function<void()>& fn) {
-  const int n = (int)(bdim.x * bdim.y * bdim.z);
-  if (n > MAX_THREADS) { fprintf(stderr, "emu: %d threads per block\n", n); abort(); }
-  if ((int)fibers.size() < n) { fibers.resize(n); stacks.resize((size_t)n * STACK_BYTES); }
-  body = fn;
-  block_threads = n;
-  for (int i = 0; i < n; ++i) {
-    make_fiber(i);
-    fibers[i].state = RUNNABLE;
-    shfl_seq[i] = 0; coll_seq[i] = 0;
+inline std::vector<Block*> free_blocks;   // finished workgroups keep their stacks (page faults on fresh stacks would dominate small kernels)
+inline Block* acquire_block(int n) {
+  Block* b = nullptr;
+  for (size_t i = 0; i < free_blocks.size(); ++i) if (free_blocks[i]->cap >= n) { b = free_blocks[i]; free_blocks.erase(free_blocks.begin() + i); break; }
+  if (!b) {
+    b = new Block();
+    b->cap = n;
+    b->stacks = (char*)mmap(nullptr, (size_t)n * STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);   // committed page by page as touched
+    if (b->stacks == (char*)MAP_FAILED) { perror("emu: mmap of fiber stacks"); abort(); }
+    b->fibers = new Fiber[n];
+    b->shfl_val = new uint64_t[(size_t)SHFL_RING * n]; b->shfl_tag = new unsigned[(size_t)SHFL_RING * n]; b->shfl_seq = new unsigned[n];
+    b->coll_val = new unsigned char[(size_t)COLL_RING * n * COLL_BYTES]; b->coll_tag = new unsigned[(size_t)COLL_RING * n]; b->coll_seq = new unsigned[n];
   }
-  memset(shfl_tag, 0xff, sizeof(shfl_tag));
-  memset(coll_tag, 0xff, sizeof(coll_tag));
-  const int nwaves = (n + 63) / 64;
+  return b;
+}
+inline void start_block(Block* b, dim3 idx, dim3 gdim, dim3 bdim, size_t lds_bytes, const std::function<void()>* body) {
+  b->idx = idx; b->gdim = gdim; b->bdim = bdim; b->n = (int)(bdim.x * bdim.y * bdim.z); b->body = body; b->yield_requested = false;
+  b->lds = malloc(lds_bytes ? lds_bytes : 16);   // exactly the launch's LDS (16-byte aligned like every malloc): an AddressSanitizer build sees the first byte past it
+  memset(b->lds, 0xcd, lds_bytes);               // LDS is not zero on the GPU either: poison it so that a read of an unwritten word shows
+  for (int i = 0; i < b->n; ++i) { make_fiber(b, i); b->fibers[i].state = RUNNABLE; b->shfl_seq[i] = 0; b->coll_seq[i] = 0; }
+  memset(b->shfl_tag, 0xff, sizeof(unsigned) * SHFL_RING * b->cap);
+  memset(b->coll_tag, 0xff, sizeof(unsigned) * COLL_RING * b->cap);
+}
+inline void finish_block(Block* b) {
+  free(b->lds); b->lds = nullptr;
+  for (auto& kv : b->statics) free(kv.second);
+  b->statics.clear();
+  free_blocks.push_back(b);
+}
+// a static __shared__ variable of the running workgroup (key: the address of a string literal naming the declaration)
+inline void* block_static(const void* key, size_t bytes) {
+  for (auto& kv : blk->statics) if (kv.first == key) return kv.second;
+  void* p = malloc(bytes ? bytes : 1);
+  memset(p, 0xcd, bytes);
+  blk->statics.emplace_back(key, p);
+  return p;
+}
+
+// Runs the workgroup until every fiber has returned (true) or one of them asked to let other workgroups run (false): one wave at a time, its lanes taking turns until
+// each sits at a barrier or has returned (lanes that yield inside a wave-level exchange stay runnable); a barrier releases when every live fiber has arrived.
+// IL_EMU_SCHEDULE = reverse | random:<seed> changes the order of the waves between two barriers and of the lanes within a wave: a kernel whose result depends on that
+// order is missing a barrier (an LDS race the forward order happens to hide).
+inline bool run_slice(Block* b) {
+  blk = b; blockIdx = b->idx; gridDim = b->gdim; blockDim = b->bdim; dyn_smem = b->lds; block_threads = b->n;
+  const int n = b->n, nwaves = (n + 63) / 64;
   int wave_order[MAX_THREADS / 64], lane_order[64];
   for (;;) {
-    // one wave at a time: its lanes take turns until each of them sits at a barrier or has returned (lanes that yield inside a wave-level exchange stay runnable).
-    // IL_EMU_SCHEDULE = reverse | random:<seed> changes the order of the waves between two barriers and of the lanes within a wave: a kernel whose result depends on
-    // that order is missing a barrier (an LDS race the forward order happens to hide)
     for (int w = 0; w < nwaves; ++w) wave_order[w] = schedule_mode == 1 ? nwaves - 1 - w : w;
     for (int l = 0; l < 64; ++l) lane_order[l] = schedule_mode == 1 ? 63 - l : l;
     if (schedule_mode == 2) {
@@ -186,73 +223,135 @@ inline void run_block(const dim3& bdim, const std::function<void()>& fn) {
         any = false;
         for (int li = 0; li < 64; ++li) {
           const int i = w0 + lane_order[li];
-          if (i >= n || fibers[i].state != RUNNABLE) continue;
+          if (i >= n || b->fibers[i].state != RUNNABLE) continue;
           any = true;
           cur = i;
-          threadIdx = dim3(i % bdim.x, (i / bdim.x) % bdim.y, i / (bdim.x * bdim.y));
+          threadIdx = dim3(i % b->bdim.x, (i / b->bdim.x) % b->bdim.y, i / (b->bdim.x * b->bdim.y));
           to_fiber(i);
+          if (b->yield_requested) { b->yield_requested = false; return false; }
         }
       }
     }
     int waiting = 0;
-    for (int i = 0; i < n; ++i) waiting += fibers[i].state == AT_BARRIER;
-    if (!waiting) break;                                                  // every fiber has returned
-    for (int i = 0; i < n; ++i) if (fibers[i].state == AT_BARRIER) fibers[i].state = RUNNABLE;   // barrier: all live fibers arrived
+    for (int i = 0; i < n; ++i) waiting += b->fibers[i].state == AT_BARRIER;
+    if (!waiting) return true;                                            // every fiber has returned
+    for (int i = 0; i < n; ++i) if (b->fibers[i].state == AT_BARRIER) b->fibers[i].state = RUNNABLE;   // barrier: all live fibers arrived
   }
 }
+// called by a lane inside a polling loop (s_sleep): the workgroup steps aside
+inline void poll_yield() { blk->yield_requested = true; to_scheduler(); }
 
 // Wave-level exchange: every LIVE lane of the calling lane's wave publishes `bytes` of payload; returns once all of them have, with `all` pointing at the 64 payload
 // slots (a lane that has already returned from the kernel counts as arrived; its slot is stale). The building block of the emulated MFMA / DPP / readlane / ballot.
 inline const unsigned char* wave_exchange(const void* mine, size_t bytes) {
-  const int t = linear_tid(), w0 = t & ~63, w1 = std::min(w0 + 64, block_threads);
-  const unsigned k = coll_seq[t]++;
+  Block* b = blk;
+  const int t = linear_tid(), w0 = t & ~63, w1 = std::min(w0 + 64, b->n), cap = b->cap;
+  const unsigned k = b->coll_seq[t]++;
   const unsigned slot = k % COLL_RING;
-  memcpy(coll_val[slot][t], mine, bytes);
-  coll_tag[slot][t] = k;
+  memcpy(b->coll_val + ((size_t)slot * cap + t) * COLL_BYTES, mine, bytes);
+  b->coll_tag[(size_t)slot * cap + t] = k;
   for (;;) {
     bool all = true;
-    for (int i = w0; i < w1 && all; ++i) all = fibers[i].state == DONE || coll_tag[slot][i] == k || (int)(coll_tag[slot][i] - k) > 0;
+    for (int i = w0; i < w1 && all; ++i) { const unsigned tag = b->coll_tag[(size_t)slot * cap + i]; all = b->fibers[i].state == DONE || tag == k || (int)(tag - k) > 0; }
     if (all) break;
     to_scheduler();
   }
-  return &coll_val[slot][w0][0];
+  return b->coll_val + ((size_t)slot * cap + w0) * COLL_BYTES;
 }
-inline bool lane_live(int t) { return fibers[t].state != DONE; }
+inline bool lane_live(int t) { return blk->fibers[t].state != DONE; }
+
+struct Job {
+  dim3 grid, block; size_t lds = 0; std::function<void()> body;
+  unsigned next = 0, total = 0, done = 0;
+  std::vector<Block*> resident;
+  uintptr_t stream = 0; uint64_t seq = 0;
+  bool is_wait = false; uintptr_t wait_stream = 0; uint64_t wait_seq = 0;   // a marker: the stream goes on once `wait_stream` has finished its job number `wait_seq`
+};
+struct StreamQ { std::deque<Job*> q; uint64_t enqueued = 0, finished = 0; };
+inline std::map<uintptr_t, StreamQ> streams;
+inline bool draining = false;
+
+inline dim3 nth_block(const Job* j, unsigned i) { return dim3(i % j->grid.x, (i / j->grid.x) % j->grid.y, i / (j->grid.x * j->grid.y)); }
+// one turn of a launch: every resident (suspended) workgroup gets a slice, then one more workgroup is dispatched; true if anything finished or started
+inline bool step(Job* j) {
+  bool progress = false;
+  for (size_t r = 0; r < j->resident.size();) {
+    if (run_slice(j->resident[r])) { finish_block(j->resident[r]); j->resident.erase(j->resident.begin() + r); ++j->done; progress = true; } else ++r;
+  }
+  if (j->next < j->total) {
+    Block* b = acquire_block((int)(j->block.x * j->block.y * j->block.z));
+    start_block(b, nth_block(j, j->next++), j->grid, j->block, j->lds, &j->body);
+    progress = true;
+    if (run_slice(b)) { finish_block(b); ++j->done; } else j->resident.push_back(b);
+  }
+  return progress;
+}
+// runs every queued launch of every stream to completion
+inline void drain() {
+  if (draining) return;
+  draining = true;
+  read_schedule();
+  for (;;) {
+    bool any = false;
+    std::vector<uintptr_t> order;
+    for (auto& kv : streams) if (!kv.second.q.empty()) order.push_back(kv.first);
+    if (order.empty()) break;
+    if (schedule_mode == 1) std::reverse(order.begin(), order.end());
+    if (schedule_mode == 2) for (size_t i = order.size(); i > 1; --i) std::swap(order[i - 1], order[next_random() % (unsigned)i]);
+    for (uintptr_t sid : order) {
+      StreamQ& s = streams[sid];
+      Job* j = s.q.front();
+      if (j->is_wait) {
+        if (streams[j->wait_stream].finished >= j->wait_seq) { s.q.pop_front(); s.finished = j->seq; delete j; any = true; }
+        continue;
+      }
+      any |= step(j);
+      if (j->done == j->total) { s.q.pop_front(); s.finished = j->seq; delete j; any = true; }
+    }
+    (void)any;   // no progress in a round = every workgroup is polling: their own bounds end that (a wait that nothing will satisfy expires, as on the device)
+  }
+  draining = false;
+}
+inline void stream_wait(uintptr_t waiter, uintptr_t on) {   // hipStreamWaitEvent(waiter, event recorded on `on` now)
+  if (waiter == on || streams[on].enqueued == streams[on].finished) return;
+  Job* j = new Job(); j->is_wait = true; j->wait_stream = on; j->wait_seq = streams[on].enqueued; j->stream = waiter; j->seq = ++streams[waiter].enqueued;
+  streams[waiter].q.push_back(j);
+}
 
 template <class K, class... Args>
-inline void launch(K kernel, dim3 grid, dim3 block, size_t lds_bytes, Args... args) {
-  void* aligned = malloc(lds_bytes ? lds_bytes : 16);   // exactly the launch's LDS (16-byte aligned like every malloc): an AddressSanitizer build sees the first byte past it
-  read_schedule();
-  gridDim = grid; blockDim = block;
-  for (unsigned z = 0; z < grid.z; ++z)
-    for (unsigned y = 0; y < grid.y; ++y)
-      for (unsigned x = 0; x < grid.x; ++x) {
-        blockIdx = dim3(x, y, z);
-        dyn_smem = aligned;
-        memset(aligned, 0xcd, lds_bytes);   // LDS is not zero on the GPU either: poison it so that a read of an unwritten word shows
-        run_block(block, [&]() { kernel(args...); });
-      }
-  free(aligned);
+inline void launch(K kernel, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t stream, Args... args) {
+  const int n = (int)(block.x * block.y * block.z);
+  if (n > MAX_THREADS) { fprintf(stderr, "emu: %d threads per block\n", n); abort(); }
+  Job* j = new Job();
+  j->grid = grid; j->block = block; j->lds = lds_bytes; j->total = grid.x * grid.y * grid.z; j->stream = (uintptr_t)stream;
+  j->body = [=]() { kernel(args...); };
+  StreamQ& s = streams[j->stream];
+  j->seq = ++s.enqueued;
+  s.q.push_back(j);
+  if (!stream) drain();   // the null stream: synchronous with everything
 }
 }  // namespace emu
 
-#define EMU_LAUNCH(kernel, grid, block, lds, ...) emu::launch(kernel, dim3(grid), dim3(block), (size_t)(lds), __VA_ARGS__)
+
+#define EMU_LAUNCH(kernel, grid, block, lds, stream, ...) emu::launch(kernel, dim3(grid), dim3(block), (size_t)(lds), (hipStream_t)(stream), __VA_ARGS__)
 
 inline void __syncthreads() {
-  emu::fibers[emu::cur].state = emu::AT_BARRIER;
+  emu::blk->fibers[emu::cur].state = emu::AT_BARRIER;
   emu::to_scheduler();
 }
 template <class T>
 inline T __shfl(T v, int src, int width = 64) {
   static_assert(sizeof(T) <= 8, "emulated __shfl: at most 8 bytes");
-  const int t = emu::linear_tid();
-  const unsigned k = emu::shfl_seq[t]++;
+  emu::Block* b = emu::blk;
+  const int t = emu::linear_tid(), cap = b->cap;
+  const unsigned k = b->shfl_seq[t]++;
+  const size_t row = (size_t)(k % emu::SHFL_RING) * cap;
   uint64_t raw = 0; memcpy(&raw, &v, sizeof(T));
-  emu::shfl_val[k % emu::SHFL_RING][t] = raw; emu::shfl_tag[k % emu::SHFL_RING][t] = k;
+  b->shfl_val[row + t] = raw; b->shfl_tag[row + t] = k;
   const int wave0 = t & ~63, s = wave0 + ((t - wave0) / width) * width + (src % width);
-  while (emu::shfl_tag[k % emu::SHFL_RING][s] != k) emu::to_scheduler();   // the source lane has not reached this shuffle yet
-  emu::to_scheduler();                                                     // let every lane publish before any lane runs ahead and recycles the ring
-  T out; memcpy(&out, &emu::shfl_val[k % emu::SHFL_RING][s], sizeof(T));
+  while (b->shfl_tag[row + s] != k) emu::to_scheduler();   // the source lane has not reached this shuffle yet
+  emu::to_scheduler();                                     // let every lane publish before any lane runs ahead and recycles the ring
+  T out; memcpy(&out, &b->shfl_val[row + s], sizeof(T));
   return out;
 }
 
@@ -320,7 +419,7 @@ inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned 
 inline void __threadfence() {}
 inline void __threadfence_system() {}
 inline void __threadfence_block() {}
-#define __builtin_amdgcn_s_sleep(x) do { } while (0)
+#define __builtin_amdgcn_s_sleep(x) emu::poll_yield()   // every polling loop of the kernels sleeps between two polls: the place where the workgroup steps aside
 inline void emu_wave_barrier() { const int z = 0; (void)emu::wave_exchange(&z, 4); }   // lanes of a wave run one after the other here: a wave barrier has to be a real rendezvous
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 #define __builtin_amdgcn_s_memtime() 0ull
@@ -348,9 +447,9 @@ enum { hipMemcpyDeviceToHost = 2, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToDe
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { strcpy(p->gcnArchName, "host-emulation"); p->multiProcessorCount = 256; return hipSuccess; }
 inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 256; return hipSuccess; }
-inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { emu::drain(); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { emu::drain(); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { emu::drain(); memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t*) { return hipSuccess; }

@@ -298,7 +298,7 @@ def test_emulated_gail_shaped_deep_kernels_on_the_depth1_relu_fixtures(golden_di
 
 
 # ------------------------------------------------------------------------------------------------ the `-m gpu` test bodies over the emulated libraries
-def _emulated_product(monkeypatch):
+def _emulated_product(monkeypatch, streams=False):
   """Swaps the product's library handle for the host emulation (the entry points it exports; the real library's host-side functions - abi.hip - otherwise), lets CPU
   tensors through the product's one device guard (_lib.on_device) and hands back tests/test_gpu_parity.py with its GPU-only names bound to the CPU, so that the BODIES
   of the `-m gpu` parity tests - same inputs, same fixtures, same tolerances, the product's own host layer in between - run here on the kernel sources."""
@@ -329,6 +329,39 @@ def _emulated_product(monkeypatch):
     monkeypatch.setattr(tgp, k, v, raising=False)
   monkeypatch.setattr(il_training, '_WS', {})      # CPU arenas of this test only
   monkeypatch.setattr(il_training, '_NOISE', {})
+  if streams:
+    # Two-stream schedules (UpdatePlan): torch's streams become emulated stream handles - launches on them are queued, run side by side with co-resident workgroups
+    # (emu_hip.hpp) and finish at a synchronisation point. The per-function bodies above stay on the null stream: synchronous, as their host-side reads expect.
+    import contextlib
+    h.emu_stream_wait.argtypes = [C.c_size_t, C.c_size_t]
+
+    class Stream:
+      count = [0]
+      def __init__(self, *a, **k):
+        Stream.count[0] += 1; self.cuda_stream = 0x1000 * Stream.count[0]
+      def wait_stream(self, other): h.emu_stream_wait(self.cuda_stream, other.cuda_stream)
+      def synchronize(self): h.emu_drain()
+
+    current = [Stream()]
+
+    @contextlib.contextmanager
+    def use(s):
+      current.append(s)
+      try: yield
+      finally: current.pop()
+
+    class Props: multi_processor_count = 256
+    monkeypatch.setattr(_lib, 'stream_ptr', lambda: C.c_void_p(current[-1].cuda_stream))
+    monkeypatch.setattr(torch.cuda, 'Stream', Stream)
+    monkeypatch.setattr(torch.cuda, 'current_stream', lambda *a, **k: current[-1])
+    monkeypatch.setattr(torch.cuda, 'stream', use)
+    monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: h.emu_drain())
+    monkeypatch.setattr(torch.cuda, 'is_current_stream_capturing', lambda: False)
+    monkeypatch.setattr(torch.cuda, 'get_device_properties', lambda *a, **k: Props())
+    monkeypatch.setattr(il_training.UpdatePlan, '_probe_device_sync', lambda self, graph: True)   # "the two streams run concurrently": true of the emulated ones
+    host_copy = gpu_util.N
+    monkeypatch.setattr(gpu_util, 'N', lambda t: (h.emu_drain(), host_copy(t))[1])
+    monkeypatch.setattr(tgp, 'N', gpu_util.N, raising=False)
   return tgp
 
 
@@ -383,6 +416,36 @@ def test_gpu_parity_bodies_on_the_emulated_kernels(golden_dir, monkeypatch, body
   fn(**kw)
 
 
+def test_timed_path_replays_through_the_oracle_on_the_emulated_kernels(monkeypatch):
+  """What bench.py times (tests/test_timed_path_oracle.py on the GPU): the UpdatePlan at the BASELINE configuration - HalfCheetah dims, batch 256, ring 1e6 / fill 1e5,
+  25k expert rows, device MT19937 draws by the sampler workgroup riding in the discriminator launch, rows read from the rings through the indices, on-chip Philox
+  noise, inline relabel, the two branches on two streams handing over through device counters - run eagerly on emulated streams (the branches' workgroups co-resident,
+  a polling workgroup stepping aside), recorded, and replayed through oracle.replay -> gail_update -> predict_reward -> sac_update: index draws bit-exact, rewards
+  bracketed in float64, log pi / Q / every parameter and Adam moment at the GPU's bounds, and no device-side wait expired."""
+  tgp = _emulated_product(monkeypatch, streams=True)
+  import bench
+  import gpu_util
+  import torch
+  import test_timed_path_oracle as tt
+  from imitation_learning_amd import training as il_training
+  for k in ('DEV', 'N', 'Cfg', 'bracket', 'close', 'close_params', 'close_sparse', 'crit_from_flat'):
+    monkeypatch.setattr(tt, k, getattr(gpu_util, k), raising=False)
+  for k, v in (('il', tgp.il), ('_lib', _lib), ('il_training', il_training), ('bench', bench)):
+    monkeypatch.setattr(tt, k, v, raising=False)
+  K, SEED = 3, 3
+  plan, nets, (tr, et) = bench.build(torch.device('cpu'), 0, seed=SEED)
+  assert plan.device_sync and plan.ring_mode and plan.inline_relabel and plan.resident_sampler, 'this must be the schedule bench.py times'
+  o = tt.OracleLearner(nets, plan, tr, et, index_seed=SEED)
+  for k in range(K):
+    plan.run()
+    torch.cuda.synchronize()
+    got = tt.per_update_outputs(plan)
+    tt.compare_outputs(got, o.update(k), k)
+    tt.reward_bracket(o, nets[4], got[2], k)
+  assert plan.sync_timeouts() == 0
+  tt.compare_learner(o, nets, plan, K)
+
+
 @pytest.mark.parametrize('body', ['test_gmmil_b1024_full_reward_vector_matches_reference', 'test_gail_b1024_mixup_update_matches_reference',
                                   pytest.param('test_pwil_25k_atoms_matches_reference', marks=pytest.mark.skipif(os.environ.get('IL_EMU_SLOW', '0') != '1', reason='1,100 emulated steps against 25,000 atoms take ~5 min (passes; IL_EMU_SLOW=1 runs it)'))])
 def test_timed_sizes_on_the_emulated_kernels(monkeypatch, body):
@@ -404,17 +467,20 @@ def test_emulated_product_refuses_nothing_silently(monkeypatch):
     il_memory.batch_desc(dict(states=torch.zeros(4, 3), actions=torch.zeros(4, 2), rewards=z, next_states=torch.zeros(4, 3), terminals=z, weights=z, absorbing=z))
 
 
+SCHEDULE_SUBSET_EXTRA = ' or timed_path_replays'   # the device hand-off between two streams: the schedule perturbation also shuffles which stream's workgroup runs next
 ASAN_SUBSET = ('sac_update_matches_oracle_and_reference-sac_hopper_h64 or sac_gradients_match_oracle-sac_hopper_h64 or gail_update_matches_oracle_and_reference-gail_default or '
                'gail_loss_variants_match_reference-mixup_sublogp or gmmil_matches_oracle_and_reference-small or pwil_matches_oracle or replay_matches_reference_bit_exact-wrapped or '
                'red_matches_reference-hopper_d2_tanh_drop or dril_matches_reference-hopper_d2_relu or gail_deep_discriminator_matches_reference-hopper_d2_tanh_sn or '
                'general_potential_matches_reference-hopper_d2_relu_sn_margin or gail_reward_shaping_mixup or bc_update or actor_act or reward_relabeller')
 
 
+@pytest.mark.skipif(os.environ.get('IL_EMU_ASAN_RUN', '0') != '1' and os.environ.get('IL_EMU_ASAN_ALL', '0') != '1',
+                    reason='the sanitised build of the whole library takes ~45 s to compile: IL_EMU_ASAN_RUN=1 (18 bodies, ~1.5 min) or IL_EMU_ASAN_ALL=1 (everything, ~5 min)')
 def test_emulated_kernels_are_address_sanitizer_clean():
   """The same emulation compiled with -fsanitize=address,undefined (IL_EMU_ASAN=1), a subset of the bodies above in a child process: every load and store of those
   kernels - the global buffers (numpy / torch allocations go through the intercepted malloc), the workgroup's LDS (allocated to the byte) - is bounds- and lifetime-
   checked, every 16-byte vector access alignment-checked, signed overflow and shifts checked. A GPU run cannot say this: an access a few words past a tensor lands in
-  the caching allocator's pool and is silent. The whole file is clean under it (IL_EMU_ASAN_ALL=1 runs all of it, ~4 min); round 3 found one use-after-free this way -
+  the caching allocator's pool and is silent. The whole file is clean under it (IL_EMU_ASAN_ALL=1 runs all of it, ~5 min; last run: end of round 3, 97 passed); round 3 found one use-after-free this way -
   a temporary `torch.ones` whose pointer sat in an il_batch after the tensor had died (training.py)."""
   import subprocess
   asan = subprocess.run(['gcc', '-print-file-name=libasan.so'], capture_output=True, text=True).stdout.strip()
@@ -435,6 +501,6 @@ def test_emulated_kernels_do_not_depend_on_the_wave_schedule(schedule):
   still hold, i.e. no result depends on which wave reaches a barrier-free stretch first (a missing __syncthreads() would - see the emulator's self-test above).
   IL_EMU_SCHEDULE=... with the whole file: 90 passed under reverse, random:1, random:7."""
   import subprocess
-  r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-p', 'no:cacheprovider', '-k', ASAN_SUBSET], env=dict(os.environ, IL_EMU_SCHEDULE=schedule),
+  r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-p', 'no:cacheprovider', '-k', ASAN_SUBSET + SCHEDULE_SUBSET_EXTRA], env=dict(os.environ, IL_EMU_SCHEDULE=schedule),
                      cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=1500)
   assert r.returncode == 0 and ' passed' in r.stdout, (r.stdout + r.stderr)[-3000:]
