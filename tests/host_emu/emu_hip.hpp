@@ -3,15 +3,20 @@
 // `extern __shared__` declaration into a pointer, drops address-space qualifiers and empty asm pins, and compiles the result with g++ against this header in the
 // place of <hip/hip_runtime.h>.
 //
-// Execution model: one workgroup at a time, in blockIdx order (x fastest); its threads are fibers on ONE OS thread. A wave's 64 lanes take turns until each sits at a
-// __syncthreads() or has returned, then the next wave runs; a barrier releases when every live fiber has arrived. Wave-level instructions - __shfl*, DPP, readlane,
-// ballot, the wave barrier, v_mfma_f32_16x16x4_f32 - are built on one exchange: every live lane of the wave publishes its operand under a per-lane sequence number and
-// yields until all of them have. Atomics are plain read-modify-writes, fences and s_waitcnt nothing: program order on one thread is stronger than any of them.
-// What this can show: indexing, tile / slab / counter layouts, iteration orders, the arithmetic (MFMA = an fmaf chain over k, as on the device) - everything a parity
-// test compares. What it cannot: performance, memory-ordering bugs between workgroups or waves, anything that needs two workgroups in flight at once (a workgroup that
-// waits for a HIGHER-numbered one would spin out its bound here; the kernels' hand-offs all point at lower-numbered workgroups or earlier launches, which is also what
-// keeps them deadlock-free on the device), and code that leans on wave lockstep without a wave barrier. Sums follow the device's association order (the DPP steps and
-// readlanes are emulated lane for lane); libm is glibc's, so comparisons use the parity tests' tolerances, not bit equality.
+// Execution model: everything on ONE OS thread. A workgroup's threads are fibers; a wave's 64 lanes take turns until each sits at a __syncthreads() or has returned,
+// then the next wave runs; a barrier releases when every live fiber has arrived. Wave-level instructions - __shfl*, DPP, readlane, ballot, the wave barrier,
+// v_mfma_f32_16x16x4_f32 - are built on one exchange: every live lane of the wave publishes its operand under a per-lane sequence number and yields until all of them
+// have. A launch is a job in its stream's queue: jobs of one stream run in order, the jobs at the heads of different streams side by side, workgroups dispatched in
+// blockIdx order (x fastest). Several workgroups can be RESIDENT at once: a lane that polls a device-side counter (every polling loop of the kernels sleeps between two
+// polls: s_sleep) suspends its workgroup, and the others - later workgroups of the same launch, workgroups of the launch on the other stream - run until the counter
+// moves; that is what co-residency gives the device-side hand-offs on the GPU. Launches on the null stream run to completion at once. Atomics are plain
+// read-modify-writes, fences and s_waitcnt nothing: program order on one thread is stronger than any of them.
+// IL_EMU_SCHEDULE=reverse|random:<seed> perturbs every choice the model leaves open (lane order, wave order between two barriers, which stream's launch takes the next
+// turn): a result that changes with it is a missing barrier or a hand-off that only works in one order.
+// What this can show: indexing, tile / slab / counter layouts, iteration orders, the hand-off protocols' logic, the arithmetic (MFMA = an fmaf chain over k, as on the
+// device) - everything a parity test compares. What it cannot: performance, the memory model (a missing fence or a non-atomic flag is invisible here), code that leans
+// on wave lockstep without a wave barrier. Sums follow the device's association order (the DPP steps and readlanes are emulated lane for lane); libm is glibc's, so
+// comparisons use the parity tests' tolerances, not bit equality.
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
