@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE: builds ONE host-emulation library from the HIP kernel sources of imitation-learning_amd/csrc (see emu_hip.hpp for the execution model).
 
-`load()` translates every source file (all of csrc/*.hip but peer.hip: cross-process memory windows) and every device header into
+`load()` translates every source file of csrc/ and every device header into
 tests/host_emu/_build/, compiles them with g++ (-ffp-contract=off like the device build) against emu_hip.hpp standing in for <hip/hip_runtime.h>, and returns a ctypes
 handle exporting the same `extern "C"` entry points as libil_hip.so - to be called with HOST pointers. Only the source TEXT is transformed, never its logic:
   * `kernel<<<grid, block, lds, stream>>>(args);`          -> `EMU_LAUNCH(kernel, grid, block, lds, args);`
@@ -25,7 +25,7 @@ BUILD = os.path.join(HERE, '_build')
 # IL_EMU_ASAN=1: AddressSanitizer build (run python with LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0):
 # every load / store of every emulated kernel - global buffers (numpy / torch allocations go through the intercepted malloc) and the workgroup's LDS - bounds-checked
 SANITIZE = ['-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-fno-omit-frame-pointer'] if os.environ.get('IL_EMU_ASAN', '0') == '1' else []
-NOT_EMULATED = ('peer.hip',)   # hipIpc* memory windows between processes
+NOT_EMULATED = ()
 
 def _split_top_level(s: str):
   parts, depth, cur = [], 0, ''

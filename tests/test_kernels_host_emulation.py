@@ -446,6 +446,59 @@ def test_timed_path_replays_through_the_oracle_on_the_emulated_kernels(monkeypat
   tt.compare_learner(o, nets, plan, K)
 
 
+# ------------------------------------------------------------------------------------------------ the peer-window gradient exchange between emulated ranks
+def _peer_exchange_rounds(world, n, n_jobs, write_through, rounds=6, depth=1, seed=0):
+  """`world` ranks in one process: rank r's window is a host buffer every rank's descriptor points at (on the GPUs: a peer-mapped uncached allocation), its launch goes
+  to its own emulated stream, the ranks' workgroups are co-resident and a rank that polls a peer's arrival word steps aside. The DEVICE code of the exchange
+  (csrc/peer_device.hpp: push to every rank's slot, drain, arrival words, bounded wait, rank-ordered sum, parity double buffering) runs as it is."""
+  h = emu()
+  for name in ('il_peer_region_bytes', 'il_peer_job_region_bytes', 'il_peer_allreduce_mean'):
+    getattr(h, name).restype, getattr(h, name).argtypes = _lib._SIGNATURES[name]
+  rs = np.random.RandomState(seed)
+  region = int(h.il_peer_job_region_bytes(world, n, n_jobs) if n_jobs else h.il_peer_region_bytes(world, n))
+  assert region > 0
+  windows = [np.zeros(region // 4 + 64, f32) for _ in range(world)]
+  base = [w.ctypes.data + (-w.ctypes.data) % 256 for w in windows]
+  lines = n_jobs if n_jobs else (n + 2047) // 2048
+  epochs, status = [np.zeros(lines, np.uint32) for _ in range(world)], [np.zeros(2, np.int64) for _ in range(world)]
+  buckets = []
+  for r in range(world):
+    b = _lib.PeerBucket()
+    b.rank, b.world, b.n, b.window_offset = r, world, n, 0
+    for q in range(world): b.windows[q] = base[q]
+    b.epoch, b.status, b.spin_limit, b.flags, b.n_jobs = epochs[r].ctypes.data, status[r].ctypes.data, 1 << 16, int(write_through), n_jobs
+    buckets.append(b)
+  for it in range(0, rounds, depth):
+    # `depth` exchanges are queued on every rank's stream before anything runs: a rank that the scheduler favours is then a whole exchange ahead of the others and
+    # must be held back by the protocol (a slot of parity p is only rewritten once every rank has read the exchange before last)
+    batch = []
+    for _ in range(depth):
+      xs = [rs.standard_normal(n).astype(f32) for _ in range(world)]
+      want = xs[0].copy()
+      for q in range(1, world): want = want + xs[q]          # the sum in rank order, then one division: what every rank must hold, bit for bit
+      batch.append((xs, want / f32(world)))
+    order = list(range(world)); rs.shuffle(order)            # the ranks reach the exchange in any order
+    for r in order:
+      for xs, _ in batch:
+        assert h.il_peer_allreduce_mean(C.byref(buckets[r]), P(xs[r]), C.c_void_p(0x100 * (r + 1))) == 0
+    h.emu_drain()
+    for k, (xs, want) in enumerate(batch):
+      for r in range(world):
+        assert status[r][0] == 0, f'rank {r}: {status[r][0]} waits expired by round {it + k}'
+        np.testing.assert_array_equal(xs[r], want, err_msg=f'rank {r}, round {it + k}')
+
+
+@pytest.mark.parametrize('world,n,n_jobs', [(2, 5000, 0), (4, 1665, 0), (8, 18113, 0), (2, 1665, 7), (4, 36226, 20), (8, 9062, 5)])
+@pytest.mark.parametrize('write_through', [0, 1])
+def test_peer_exchange_between_emulated_ranks(world, n, n_jobs, write_through):
+  """The gradient exchange that has never crossed a fabric link: here at least its LOGIC runs between 2 / 4 / 8 ranks - chunk mode (il_peer_allreduce_mean) and
+  job mode (the form that rides in k_dw_adam_peer / k_gail_reduce), fence and write-through variants, six rounds (both parities, epochs wrapping the double buffer), ranks
+  arriving in random order: every rank ends with the rank-ordered mean, bit-identical, and no wait expired. What this cannot show is the memory model - whether a
+  remote uncached store is visible before the flag that follows it; that needs two GPUs."""
+  _peer_exchange_rounds(world, n, n_jobs, write_through)
+  _peer_exchange_rounds(world, n, n_jobs, write_through, rounds=9, depth=3, seed=1)   # three exchanges in flight per rank: the ranks drift apart as far as the protocol lets them
+
+
 @pytest.mark.parametrize('body', ['test_gmmil_b1024_full_reward_vector_matches_reference', 'test_gail_b1024_mixup_update_matches_reference',
                                   pytest.param('test_pwil_25k_atoms_matches_reference', marks=pytest.mark.skipif(os.environ.get('IL_EMU_SLOW', '0') != '1', reason='1,100 emulated steps against 25,000 atoms take ~5 min (passes; IL_EMU_SLOW=1 runs it)'))])
 def test_timed_sizes_on_the_emulated_kernels(monkeypatch, body):
@@ -467,7 +520,7 @@ def test_emulated_product_refuses_nothing_silently(monkeypatch):
     il_memory.batch_desc(dict(states=torch.zeros(4, 3), actions=torch.zeros(4, 2), rewards=z, next_states=torch.zeros(4, 3), terminals=z, weights=z, absorbing=z))
 
 
-SCHEDULE_SUBSET_EXTRA = ' or timed_path_replays'   # the device hand-off between two streams: the schedule perturbation also shuffles which stream's workgroup runs next
+SCHEDULE_SUBSET_EXTRA = ' or timed_path_replays or peer_exchange_between'   # the device hand-off between two streams: the schedule perturbation also shuffles which stream's workgroup runs next
 ASAN_SUBSET = ('sac_update_matches_oracle_and_reference-sac_hopper_h64 or sac_gradients_match_oracle-sac_hopper_h64 or gail_update_matches_oracle_and_reference-gail_default or '
                'gail_loss_variants_match_reference-mixup_sublogp or gmmil_matches_oracle_and_reference-small or pwil_matches_oracle or replay_matches_reference_bit_exact-wrapped or '
                'red_matches_reference-hopper_d2_tanh_drop or dril_matches_reference-hopper_d2_relu or gail_deep_discriminator_matches_reference-hopper_d2_tanh_sn or '
