@@ -357,6 +357,7 @@ def _emulated_product(monkeypatch, streams=False):
     monkeypatch.setattr(torch.cuda, 'stream', use)
     monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: h.emu_drain())
     monkeypatch.setattr(torch.cuda, 'is_current_stream_capturing', lambda: False)
+    monkeypatch.setattr(torch.cuda, 'device', lambda d: contextlib.nullcontext())
     monkeypatch.setattr(torch.cuda, 'get_device_properties', lambda *a, **k: Props())
     monkeypatch.setattr(il_training.UpdatePlan, '_probe_device_sync', lambda self, graph: True)   # "the two streams run concurrently": true of the emulated ones
     host_copy = gpu_util.N
@@ -444,6 +445,43 @@ def test_timed_path_replays_through_the_oracle_on_the_emulated_kernels(monkeypat
     tt.reward_bracket(o, nets[4], got[2], k)
   assert plan.sync_timeouts() == 0
   tt.compare_learner(o, nets, plan, K)
+
+
+_PLAIN_PLAN_RESULT = []
+
+
+@pytest.mark.parametrize('name,env', [('no exchange', dict(IL_PEER_EXCHANGE='0')),
+                                      ('exchange launches', dict(IL_PEER_EXCHANGE='require', IL_PEER_APPLY='0', IL_DP_FUSED='0')),
+                                      ('exchange in the apply launches', dict(IL_PEER_EXCHANGE='require', IL_PEER_APPLY='1', IL_DP_FUSED='0')),
+                                      ('exchange in the optimiser launches', dict(IL_PEER_EXCHANGE='require', IL_DP_FUSED='1'))])
+def test_data_parallel_schedules_equal_the_plain_plan_on_the_emulated_kernels(monkeypatch, name, env):
+  """parallel.DataParallelUpdate with a world of one rank (the eager half of tests/test_gpu_parity.py::test_data_parallel_path_equals_fused_path_on_one_rank and of
+  tests/test_parallel_gpu.py's fused variant): the IL_FLAG_GRADS_ONLY kernels, the peer window set up and soak-tested through the emulated library, the gradients
+  travelling through the window's slot and back - as exchange launches, inside the apply launches, or inside the launches that produce them (k_dw_adam_peer's block jobs,
+  k_gail_reduce: the schedule a multi-GPU run uses by default) - must evolve the learner bit for bit like the plain UpdatePlan."""
+  tgp = _emulated_product(monkeypatch, streams=True)
+  import torch
+  from imitation_learning_amd import training as il_training
+  from imitation_learning_amd.parallel import DataParallelUpdate
+  monkeypatch.setenv('IL_PEER_SOAK_ROUNDS', '40')
+  outs = [_PLAIN_PLAN_RESULT[0]] if _PLAIN_PLAN_RESULT else []
+  for dp in ((True,) if outs else (False, True)):
+    for k, v in env.items():
+      monkeypatch.setenv(k, v)
+    tgp.il.seed(21); il_training._NOISE.clear()
+    plan, nets = tgp._make_plan('GAIL', 13)
+    runner = DataParallelUpdate(plan) if dp else plan
+    for _ in range(2):
+      runner.run()
+    torch.cuda.synchronize()
+    assert (runner.exchange_timeouts() if dp else plan.sync_timeouts()) == 0
+    if dp:
+      assert (runner.peer is not None) == (env['IL_PEER_EXCHANGE'] != '0') and bool(runner.fused) == (env.get('IL_DP_FUSED') == '1'), (runner.exchange_name(), runner.fused)
+    outs.append([tgp.N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [tgp.N(plan.logp), tgp.N(plan.q), tgp.N(plan.rewards)])
+    if not dp: _PLAIN_PLAN_RESULT.append(outs[0])   # the plain plan does not depend on the exchange settings: run once per session
+  for i, (a, b) in enumerate(zip(*outs)):
+    assert np.isfinite(a).all()
+    np.testing.assert_array_equal(a, b, err_msg=f'{name}: tensor {i}')
 
 
 # ------------------------------------------------------------------------------------------------ the peer-window gradient exchange between emulated ranks
