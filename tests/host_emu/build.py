@@ -90,6 +90,10 @@ _EXPORTS = '''// GENERATED by tests/host_emu/build.py: what a test drives the em
 #include <hip/hip_runtime.h>
 extern "C" void emu_drain() { emu::drain(); }                                                          // hipDeviceSynchronize
 extern "C" void emu_stream_wait(uintptr_t waiter, uintptr_t on) { emu::stream_wait(waiter, on); }      // waiter.wait_stream(on)
+extern "C" void emu_capture_begin(uint64_t graph, uintptr_t stream) { emu::capture_begin(graph, stream); }   // hipStreamBeginCapture
+extern "C" void emu_capture_end(uint64_t graph) { emu::capture_end(graph); }
+extern "C" void emu_graph_launch(uint64_t graph, uintptr_t stream) { emu::graph_launch(graph, stream); }
+extern "C" int emu_is_capturing() { return emu::capturing != 0; }
 '''
 
 

@@ -317,10 +317,48 @@ inline void drain() {
   }
   draining = false;
 }
+inline bool capture_active();
+inline bool capture_member(uintptr_t s);
+inline void capture_wait(uintptr_t waiter, uintptr_t on);
 inline void stream_wait(uintptr_t waiter, uintptr_t on) {   // hipStreamWaitEvent(waiter, event recorded on `on` now)
-  if (waiter == on || streams[on].enqueued == streams[on].finished) return;
+  if (waiter == on) return;
+  if (capture_active() && (capture_member(on) || capture_member(waiter))) { capture_wait(waiter, on); return; }
+  if (streams[on].enqueued == streams[on].finished) return;
   Job* j = new Job(); j->is_wait = true; j->wait_stream = on; j->wait_seq = streams[on].enqueued; j->stream = waiter; j->seq = ++streams[waiter].enqueued;
   streams[waiter].q.push_back(j);
+}
+
+// ---- stream capture (hipGraph): while a graph is being captured, launches and stream waits on the streams that belong to the capture are RECORDED - kernel arguments by
+// value, as hipGraph does - instead of queued; a launch of the graph queues copies of them: the origin stream's onto the launching stream, every forked stream's onto a
+// stream of its own that exists for this graph only, with the recorded waits between them.
+struct GraphEntry { uintptr_t stream; Job job; uintptr_t wait_on = 0; };
+struct Graph { uintptr_t origin = 0; std::vector<GraphEntry> entries; std::vector<uintptr_t> members; };
+inline std::map<uint64_t, Graph> graphs;
+inline uint64_t capturing = 0;
+inline bool in_capture(uintptr_t s) { if (!capturing) return false; for (uintptr_t m : graphs[capturing].members) if (m == s) return true; return false; }
+inline bool capture_active() { return capturing != 0; }
+inline bool capture_member(uintptr_t s) { return in_capture(s); }
+inline void capture_wait(uintptr_t waiter, uintptr_t on) {
+  Graph& g = graphs[capturing];
+  if (!in_capture(on)) return;                       // waiting for work outside the capture: already ordered before the capture began (capture_begin drained)
+  if (!in_capture(waiter)) g.members.push_back(waiter);   // a stream that waits for a capturing stream joins the capture (a fork)
+  GraphEntry e; e.stream = waiter; e.wait_on = on; g.entries.push_back(e);
+}
+inline void capture_begin(uint64_t id, uintptr_t stream) { drain(); Graph& g = graphs[id]; g = Graph(); g.origin = stream; g.members.push_back(stream); capturing = id; }
+inline void capture_end(uint64_t) { capturing = 0; }
+inline void graph_launch(uint64_t id, uintptr_t on) {
+  Graph& g = graphs[id];
+  auto map_stream = [&](uintptr_t s) { return s == g.origin ? on : (uintptr_t)(0x4000000000000000ull | (id << 24) | (s & 0xffffff)); };
+  for (uintptr_t m : g.members) if (m != g.origin) stream_wait(map_stream(m), on);   // a forked branch starts after what the launching stream has queued so far
+  for (GraphEntry& e : g.entries) {
+    const uintptr_t sid = map_stream(e.stream);
+    if (e.wait_on) { stream_wait(sid, map_stream(e.wait_on)); continue; }
+    Job* j = new Job(e.job);
+    j->stream = sid; j->seq = ++streams[sid].enqueued;
+    streams[sid].q.push_back(j);
+  }
+  for (uintptr_t m : g.members) if (m != g.origin) stream_wait(on, map_stream(m));   // ... and the launching stream goes on when all of them are done
+  if (!on) drain();
 }
 
 template <class K, class... Args>
@@ -330,6 +368,7 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t lds_bytes, hipStream_
   Job* j = new Job();
   j->grid = grid; j->block = block; j->lds = lds_bytes; j->total = grid.x * grid.y * grid.z; j->stream = (uintptr_t)stream;
   j->body = [=]() { kernel(args...); };
+  if (in_capture(j->stream)) { GraphEntry e; e.stream = j->stream; e.job = *j; graphs[capturing].entries.push_back(e); delete j; return; }
   StreamQ& s = streams[j->stream];
   j->seq = ++s.enqueued;
   s.q.push_back(j);

@@ -342,7 +342,10 @@ def _emulated_product(monkeypatch, streams=False):
       def wait_stream(self, other): h.emu_stream_wait(self.cuda_stream, other.cuda_stream)
       def synchronize(self): h.emu_drain()
 
-    current = [Stream()]
+    # The caller's stream is the null stream: a launch on it runs at once, together with whatever the other streams have queued (host code between two launches -
+    # torch ops on CPU tensors standing in for stream-ordered device ops - then always sees finished results); only streams the product creates itself are asynchronous.
+    main = Stream(); main.cuda_stream = 0
+    current = [main]
 
     @contextlib.contextmanager
     def use(s):
@@ -350,13 +353,34 @@ def _emulated_product(monkeypatch, streams=False):
       try: yield
       finally: current.pop()
 
+    class Graph:   # torch.cuda.CUDAGraph: a recorded launch sequence (emu_hip.hpp: kernel arguments by value, forks / joins between the captured streams)
+      count = [0]
+      def __init__(self, *a, **k):
+        Graph.count[0] += 1; self.id = Graph.count[0]
+      def replay(self): h.emu_graph_launch(self.id, current[-1].cuda_stream)
+
+    @contextlib.contextmanager
+    def capture(g, pool=None, stream=None, **k):   # torch.cuda.graph(g, stream=...)
+      h.emu_drain()
+      s = stream if stream is not None else Stream()
+      current.append(s)
+      h.emu_capture_begin(g.id, s.cuda_stream)
+      try: yield
+      finally:
+        h.emu_capture_end(g.id); current.pop()
+
+    for fn, args in (('emu_capture_begin', [C.c_uint64, C.c_size_t]), ('emu_capture_end', [C.c_uint64]), ('emu_graph_launch', [C.c_uint64, C.c_size_t])):
+      getattr(h, fn).argtypes = args
+    monkeypatch.setattr(torch.cuda, 'CUDAGraph', Graph)
+    monkeypatch.setattr(torch.cuda, 'graph', capture)
+
     class Props: multi_processor_count = 256
     monkeypatch.setattr(_lib, 'stream_ptr', lambda: C.c_void_p(current[-1].cuda_stream))
     monkeypatch.setattr(torch.cuda, 'Stream', Stream)
     monkeypatch.setattr(torch.cuda, 'current_stream', lambda *a, **k: current[-1])
     monkeypatch.setattr(torch.cuda, 'stream', use)
     monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: h.emu_drain())
-    monkeypatch.setattr(torch.cuda, 'is_current_stream_capturing', lambda: False)
+    monkeypatch.setattr(torch.cuda, 'is_current_stream_capturing', lambda: bool(h.emu_is_capturing()))
     monkeypatch.setattr(torch.cuda, 'device', lambda d: contextlib.nullcontext())
     monkeypatch.setattr(torch.cuda, 'get_device_properties', lambda *a, **k: Props())
     monkeypatch.setattr(il_training.UpdatePlan, '_probe_device_sync', lambda self, graph: True)   # "the two streams run concurrently": true of the emulated ones
@@ -370,7 +394,7 @@ def _emulated_product(monkeypatch, streams=False):
 # mailbox and the multi-process paths need streams, graphs or a second process, i.e. a GPU)
 GPU_BODIES = (
     'test_replay_matches_reference_bit_exact', 'test_transfer_transitions_matches_sequential_appends', 'test_replay_full_size_gather_property',
-    'test_sac_update_matches_oracle_and_reference', 'test_sac_gradients_match_oracle', 'test_sac_update_other_shapes', 'test_sac_gradient_of_concatenated_batch_is_mean_of_shard_gradients',
+    'test_sac_update_matches_oracle_and_reference', 'test_sac_gradients_match_oracle', 'test_sac_update_other_shapes',
     'test_bc_update_matches_oracle_and_reference', 'test_actor_act_matches_oracle', 'test_adam_and_polyak_kernels',
     'test_gail_update_matches_oracle_and_reference', 'test_gail_loss_variants_match_reference', 'test_gail_ragged_batch_and_state_only',
     'test_gmmil_matches_oracle_and_reference', 'test_gmmil_full_size_properties', 'test_pwil_matches_oracle_and_reference',
@@ -417,40 +441,90 @@ def test_gpu_parity_bodies_on_the_emulated_kernels(golden_dir, monkeypatch, body
   fn(**kw)
 
 
-def test_timed_path_replays_through_the_oracle_on_the_emulated_kernels(monkeypatch):
-  """What bench.py times (tests/test_timed_path_oracle.py on the GPU): the UpdatePlan at the BASELINE configuration - HalfCheetah dims, batch 256, ring 1e6 / fill 1e5,
-  25k expert rows, device MT19937 draws by the sampler workgroup riding in the discriminator launch, rows read from the rings through the indices, on-chip Philox
-  noise, inline relabel, the two branches on two streams handing over through device counters - run eagerly on emulated streams (the branches' workgroups co-resident,
-  a polling workgroup stepping aside), recorded, and replayed through oracle.replay -> gail_update -> predict_reward -> sac_update: index draws bit-exact, rewards
-  bracketed in float64, log pi / Q / every parameter and Adam moment at the GPU's bounds, and no device-side wait expired."""
-  tgp = _emulated_product(monkeypatch, streams=True)
+def _timed_path_modules(monkeypatch, tgp):
   import bench
   import gpu_util
-  import torch
   import test_timed_path_oracle as tt
   from imitation_learning_amd import training as il_training
   for k in ('DEV', 'N', 'Cfg', 'bracket', 'close', 'close_params', 'close_sparse', 'crit_from_flat'):
     monkeypatch.setattr(tt, k, getattr(gpu_util, k), raising=False)
   for k, v in (('il', tgp.il), ('_lib', _lib), ('il_training', il_training), ('bench', bench)):
     monkeypatch.setattr(tt, k, v, raising=False)
-  K, SEED = 3, 3
+  return tt, bench
+
+
+def test_timed_path_replays_through_the_oracle_on_the_emulated_kernels(monkeypatch):
+  """What bench.py times (tests/test_timed_path_oracle.py on the GPU, fewer replays): the UpdatePlan at the BASELINE configuration - HalfCheetah dims, batch 256, ring 1e6 /
+  fill 1e5, 25k expert rows, device MT19937 draws by the sampler workgroup riding in the discriminator launch, rows read from the rings through the indices, on-chip
+  Philox noise, inline relabel - CAPTURED as its two graphs (emulated stream capture: launches recorded with their arguments by value) and replayed on two emulated
+  streams, the branches' workgroups co-resident and handing over through device counters; recorded, and replayed through oracle.replay -> gail_update -> predict_reward
+  -> sac_update: index draws bit-exact, rewards bracketed in float64, log pi / Q / every parameter and Adam moment at the GPU's bounds, no device-side wait expired."""
+  tgp = _emulated_product(monkeypatch, streams=True)
+  import torch
+  tt, bench = _timed_path_modules(monkeypatch, tgp)
+  WARM, K, SEED = 1, 2, 3
   plan, nets, (tr, et) = bench.build(torch.device('cpu'), 0, seed=SEED)
-  assert plan.device_sync and plan.ring_mode and plan.inline_relabel and plan.resident_sampler, 'this must be the schedule bench.py times'
   o = tt.OracleLearner(nets, plan, tr, et, index_seed=SEED)
-  for k in range(K):
-    plan.run()
+  plan.capture(warmup=WARM)          # WARM eager updates (they count), then the two graphs
+  assert plan.device_sync and plan.ring_mode and plan.inline_relabel and plan.resident_sampler and plan.graph_side is not None, 'this must be the schedule bench.py times'
+  for k in range(WARM):
+    o.update(k)
+  tt.compare_learner(o, nets, plan, WARM, 'eager warm-up: ')
+  for k in range(WARM, WARM + K):
+    plan.replay()
     torch.cuda.synchronize()
     got = tt.per_update_outputs(plan)
     tt.compare_outputs(got, o.update(k), k)
     tt.reward_bracket(o, nets[4], got[2], k)
   assert plan.sync_timeouts() == 0
-  tt.compare_learner(o, nets, plan, K)
+  tt.compare_learner(o, nets, plan, WARM + K)
+
+
+def _update_plan_cases():
+  import test_update_plans_gpu as tp
+  return tp.CASES
+
+
+@pytest.mark.parametrize('algorithm,mixed,bc_aux,kw', _update_plan_cases(), ids=[f'{c[0]}{"-mixed" if c[1] else ""}{"-bc_aux" if c[2] else ""}{"-" + "-".join(f"{k}={v}" for k, v in c[3].items()) if c[3] else ""}' for c in _update_plan_cases()])
+def test_update_plan_of_every_algorithm_on_the_emulated_kernels(monkeypatch, algorithm, mixed, bc_aux, kw):
+  """tests/test_update_plans_gpu.py's body: the captured UpdatePlan of GMMIL, RED, DRIL (on-chip dropout masks), AdRIL / SQIL (the relabeller's device-side round
+  arithmetic), PWIL and SAC with mixed batches / the BC auxiliary step - one eager update, then graph replays - bit-identical to the per-function sequence of train.py."""
+  tgp = _emulated_product(monkeypatch, streams=True)
+  import gpu_util
+  import test_update_plans_gpu as tp
+  from imitation_learning_amd import training as il_training
+  for k in ('DEV', 'N', 'Cfg', 'fill_memory'):
+    monkeypatch.setattr(tp, k, getattr(gpu_util, k), raising=False)
+  for k, v in (('il', tgp.il), ('_lib', _lib), ('il_training', il_training)):
+    monkeypatch.setattr(tp, k, v, raising=False)
+  tp.test_plan_of_every_algorithm_equals_the_per_function_sequence(algorithm, mixed, bc_aux, kw)
+
+
+def test_population_launches_equal_independent_learners_on_the_emulated_kernels(monkeypatch):
+  """tests/test_gpu_parity.py::test_batched_population_equals_independent_learners with two learners and two updates: the il_*_population launches (learner = a grid
+  dimension, the 512-thread `_pop` tile kernels, k_dw_adam_pop) against the same learners advanced one by one - bit-identical, and the learners differ."""
+  tgp = _emulated_product(monkeypatch, streams=True)
+  results = []
+  for batched in (False, True):
+    plans, nets_all = tgp._population_learners(2)
+    if batched:
+      pop = tgp.il.BatchedPopulationPlan(plans)
+      for _ in range(2): pop.run()
+    else:
+      for _ in range(2):
+        for p in plans: p.run()
+    results.append(tgp._population_state(plans, nets_all))
+  for l, (a_l, b_l) in enumerate(zip(*results)):
+    for i, (a, b) in enumerate(zip(a_l, b_l)):
+      assert np.isfinite(a).all()
+      np.testing.assert_array_equal(a, b, err_msg=f'learner {l}, tensor {i}')
+  assert not np.array_equal(results[0][0][0], results[0][1][0])
 
 
 _PLAIN_PLAN_RESULT = []
 
 
-@pytest.mark.parametrize('name,env', [('no exchange', dict(IL_PEER_EXCHANGE='0')),
+@pytest.mark.parametrize('name,env', [
                                       ('exchange launches', dict(IL_PEER_EXCHANGE='require', IL_PEER_APPLY='0', IL_DP_FUSED='0')),
                                       ('exchange in the apply launches', dict(IL_PEER_EXCHANGE='require', IL_PEER_APPLY='1', IL_DP_FUSED='0')),
                                       ('exchange in the optimiser launches', dict(IL_PEER_EXCHANGE='require', IL_DP_FUSED='1'))])
