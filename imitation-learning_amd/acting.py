@@ -81,7 +81,7 @@ class ActingWorker:
   """One environment worker feeding one `ReplayMemory` from one `SoftActor` (train.py:151-168)."""
 
   def __init__(self, actor, memory, mirror: bool = False):
-    assert actor.flat.is_cuda and memory.ring.is_cuda, 'ActingWorker needs the actor and the ring on the GPU (there is no CPU path)'
+    assert _lib.on_device(actor.flat) and _lib.on_device(memory.ring), 'ActingWorker needs the actor and the ring on the GPU (there is no CPU path)'
     assert actor.state_size == memory.state_size and actor.action_size == memory.action_size
     self.actor, self.memory = actor, memory
     self.S, self.A = memory.state_size, memory.action_size

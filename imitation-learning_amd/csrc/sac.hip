@@ -2381,15 +2381,17 @@ __global__ __launch_bounds__(1024) void k_act_step(const float* __restrict__ act
     }
     if (tid >= 64 && tid < 64 + S) carry[tid - 64] = m_obs[tid - 64];
   }
-  if (tid == 0 && pending) {
-    const long long adv = wrap ? 2 : 1, nc = cursor + adv;
-    ring_state[0] = nc % cap;
-    if (nc >= cap) ring_state[1] = 1;
-  }
   __threadfence_system();
-  __syncthreads();   // every thread has read consumed[0] and the mailbox by now
+  __syncthreads();   // every thread has read consumed[0], the cursor and the mailbox by now
   if (tid == 0) {
-    if (pending) consumed[0] = __uint_as_float(word);
+    if (pending) {
+      // the cursor moves only here, behind the barrier: an append-only launch (IL_ACT_NO_ACTION) has no other barrier between the waves' loads of ring_state[0] above and
+      // this store, and with rows wider than one wave (Ant: 240 floats) a wave that loaded late would have written its columns into the next row
+      const long long adv = wrap ? 2 : 1, nc = cursor + adv;
+      ring_state[0] = nc % cap;
+      if (nc >= cap) ring_state[1] = 1;
+      consumed[0] = __uint_as_float(word);
+    }
     __hip_atomic_store(m_echo, commit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }

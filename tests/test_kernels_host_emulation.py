@@ -337,8 +337,10 @@ def _emulated_product(monkeypatch, streams=False):
 
     class Stream:
       count = [0]
-      def __init__(self, *a, **k):
-        Stream.count[0] += 1; self.cuda_stream = 0x1000 * Stream.count[0]
+      def __init__(self, *a, priority=0, **k):
+        Stream.count[0] += 1
+        # (a priority stream - the acting worker's - is synchronous here: its host side polls a mailbox the launch writes, and nothing else would run the launch)
+        self.cuda_stream = 0 if priority else 0x1000 * Stream.count[0]
       def wait_stream(self, other): h.emu_stream_wait(self.cuda_stream, other.cuda_stream)
       def synchronize(self): h.emu_drain()
 
@@ -373,6 +375,9 @@ def _emulated_product(monkeypatch, streams=False):
       getattr(h, fn).argtypes = args
     monkeypatch.setattr(torch.cuda, 'CUDAGraph', Graph)
     monkeypatch.setattr(torch.cuda, 'graph', capture)
+
+    zeros = torch.zeros
+    monkeypatch.setattr(torch, 'zeros', lambda *a, pin_memory=False, **k: zeros(*a, **k))   # the acting mailbox is pinned host memory: plain host memory here
 
     class Props: multi_processor_count = 256
     monkeypatch.setattr(_lib, 'stream_ptr', lambda: C.c_void_p(current[-1].cuda_stream))
@@ -498,6 +503,21 @@ def test_update_plan_of_every_algorithm_on_the_emulated_kernels(monkeypatch, alg
   for k, v in (('il', tgp.il), ('_lib', _lib), ('il_training', il_training)):
     monkeypatch.setattr(tp, k, v, raising=False)
   tp.test_plan_of_every_algorithm_equals_the_per_function_sequence(algorithm, mixed, bc_aux, kw)
+
+
+@pytest.mark.parametrize('absorbing', [True, False])
+@pytest.mark.parametrize('schedule', ['exact', 'fused', 'overlap'])
+def test_acting_worker_on_the_emulated_kernels(monkeypatch, absorbing, schedule):
+  """tests/test_gpu_parity.py::test_acting_worker_matches_separate_calls: the one-launch-per-env-step worker (mailbox, device-side cursor, absorbing wraps, ring
+  wrap-around) against the per-function path - same actions, bit-identical ring. Round 3: the emulator, whose lanes do not run in lockstep, failed the append-only
+  schedules here: k_act_step moved the ring cursor before every wave had read it (no barrier on that path; harmless within one wave on the device, a latent race for rows
+  wider than a wave - Ant's 240 floats). The store now sits behind the kernel's barrier."""
+  tgp = _emulated_product(monkeypatch, streams=True)
+  tgp.test_acting_worker_matches_separate_calls(absorbing, schedule)
+
+
+def test_acting_worker_greedy_and_loud_failure_on_the_emulated_kernels(monkeypatch):
+  _emulated_product(monkeypatch, streams=True).test_acting_worker_greedy_and_loud_failure()
 
 
 def test_population_launches_equal_independent_learners_on_the_emulated_kernels(monkeypatch):
