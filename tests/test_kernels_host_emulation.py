@@ -446,6 +446,17 @@ def test_gpu_parity_bodies_on_the_emulated_kernels(golden_dir, monkeypatch, body
   fn(**kw)
 
 
+@pytest.mark.parametrize('body,kw', [('test_batch_gather_is_rejected_where_it_is_not_honoured', {}),
+                                     ('test_gail_pugail_finite_margin_matches_reference', dict(name='clamped')), ('test_gail_pugail_finite_margin_matches_reference', dict(name='open'))],
+                         ids=['gather_rejected', 'pugail_margin-clamped', 'pugail_margin-open'])
+def test_gpu_parity_bodies_that_build_a_plan_on_the_emulated_kernels(golden_dir, monkeypatch, body, kw):
+  """More bodies of tests/test_gpu_parity.py: the ones that construct an UpdatePlan (its second stream, the device-sync probe) around what they check."""
+  tgp = _emulated_product(monkeypatch, streams=True)
+  fn = getattr(tgp, body)
+  if 'golden_dir' in fn.__code__.co_varnames[:fn.__code__.co_argcount]: kw = dict(kw, golden_dir=golden_dir)
+  fn(**kw)
+
+
 def _timed_path_modules(monkeypatch, tgp):
   import bench
   import gpu_util
@@ -514,6 +525,14 @@ def test_acting_worker_on_the_emulated_kernels(monkeypatch, absorbing, schedule)
   wider than a wave - Ant's 240 floats). The store now sits behind the kernel's barrier."""
   tgp = _emulated_product(monkeypatch, streams=True)
   tgp.test_acting_worker_matches_separate_calls(absorbing, schedule)
+
+
+@pytest.mark.parametrize('schedule', ['exact', 'fused'])
+def test_acting_launch_replays_through_the_oracle_on_the_emulated_kernels(monkeypatch, schedule):
+  """tests/test_timed_path_oracle.py::test_acting_launch_replays_through_the_oracle: il_act_step against ReplayOracle + oracle.nets with the recorded Philox draws."""
+  tgp = _emulated_product(monkeypatch, streams=True)
+  tt, _ = _timed_path_modules(monkeypatch, tgp)
+  tt.test_acting_launch_replays_through_the_oracle(schedule)
 
 
 def test_acting_worker_greedy_and_loud_failure_on_the_emulated_kernels(monkeypatch):
