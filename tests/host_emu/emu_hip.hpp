@@ -11,8 +11,9 @@
 // polls: s_sleep) suspends its workgroup, and the others - later workgroups of the same launch, workgroups of the launch on the other stream - run until the counter
 // moves; that is what co-residency gives the device-side hand-offs on the GPU. Launches on the null stream run to completion at once. Atomics are plain
 // read-modify-writes, fences and s_waitcnt nothing: program order on one thread is stronger than any of them.
-// IL_EMU_SCHEDULE=reverse|random:<seed> perturbs every choice the model leaves open (lane order, wave order between two barriers, which stream's launch takes the next
-// turn): a result that changes with it is a missing barrier or a hand-off that only works in one order.
+// IL_EMU_SCHEDULE=reverse|random:<seed> perturbs every choice the model leaves open (lane order, wave order between two barriers, the dispatch order of a launch's
+// workgroups, which stream's launch takes the next turn): a result that changes with it is a missing barrier, a race between workgroups or a hand-off that only works in
+// one order.
 // What this can show: indexing, tile / slab / counter layouts, iteration orders, the hand-off protocols' logic, the arithmetic (MFMA = an fmaf chain over k, as on the
 // device) - everything a parity test compares. What it cannot: performance, the memory model (a missing fence or a non-atomic flag is invisible here), code that leans
 // on wave lockstep without a wave barrier. Sums follow the device's association order (the DPP steps and readlanes are emulated lane for lane); libm is glibc's, so
@@ -269,6 +270,7 @@ struct Job {
   dim3 grid, block; size_t lds = 0; std::function<void()> body;
   unsigned next = 0, total = 0, done = 0;
   std::vector<Block*> resident;
+  std::vector<unsigned> order;   // dispatch order of the workgroups when the schedule is perturbed (empty: blockIdx order)
   uintptr_t stream = 0; uint64_t seq = 0;
   bool is_wait = false; uintptr_t wait_stream = 0; uint64_t wait_seq = 0;   // a marker: the stream goes on once `wait_stream` has finished its job number `wait_seq`
 };
@@ -284,8 +286,18 @@ inline bool step(Job* j) {
     if (run_slice(j->resident[r])) { finish_block(j->resident[r]); j->resident.erase(j->resident.begin() + r); ++j->done; progress = true; } else ++r;
   }
   if (j->next < j->total) {
+    // IL_EMU_SCHEDULE also perturbs the DISPATCH order of a launch's workgroups (reverse / a random permutation). The device dispatches in blockIdx order, and the
+    // kernels' hand-offs rely on that only for progress (a waiter is never dispatched before ALL CUs are taken by workgroups that wait for it); with unbounded
+    // residency any order makes progress here, and a result that depends on it is a race between workgroups of one launch (they run concurrently on the device).
+    if (schedule_mode != 0 && j->order.empty()) {
+      j->order.resize(j->total);
+      for (unsigned i = 0; i < j->total; ++i) j->order[i] = schedule_mode == 1 ? j->total - 1 - i : i;
+      if (schedule_mode == 2) for (unsigned i = j->total; i > 1; --i) std::swap(j->order[i - 1], j->order[next_random() % i]);
+    }
+    const unsigned which = j->order.empty() ? j->next : j->order[j->next];
+    ++j->next;
     Block* b = acquire_block((int)(j->block.x * j->block.y * j->block.z));
-    start_block(b, nth_block(j, j->next++), j->grid, j->block, j->lds, &j->body);
+    start_block(b, nth_block(j, which), j->grid, j->block, j->lds, &j->body);
     progress = true;
     if (run_slice(b)) { finish_block(b); ++j->done; } else j->resident.push_back(b);
   }
