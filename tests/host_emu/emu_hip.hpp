@@ -516,9 +516,10 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms =
 enum { hipDeviceMallocUncached = 3, hipDeviceMallocFinegrained = 1, hipIpcMemLazyEnablePeerAccess = 1 };
 struct hipIpcMemHandle_t { char reserved[64]; };
 inline hipError_t hipExtMallocWithFlags(void** p, size_t bytes, unsigned) { *p = aligned_alloc(256, (bytes + 255) / 256 * 256); return *p ? hipSuccess : 2; }
-inline hipError_t hipMalloc(void** p, size_t bytes) { return hipExtMallocWithFlags(p, bytes, 0); }
+template <class T> inline hipError_t hipMalloc(T** p, size_t bytes) { return hipExtMallocWithFlags((void**)p, bytes, 0); }
 inline hipError_t hipMemset(void* p, int v, size_t bytes) { emu::drain(); memset(p, v, bytes); return hipSuccess; }
 inline hipError_t hipFree(void* p) { emu::drain(); free(p); return hipSuccess; }
 inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) { memset(h, 0, sizeof(*h)); memcpy(h->reserved, &p, sizeof(p)); return hipSuccess; }
 inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) { memcpy(p, h.reserved, sizeof(*p)); return hipSuccess; }
 inline hipError_t hipIpcCloseMemHandle(void*) { return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t* s) { static uintptr_t next = 0x7000; next += 0x10; *s = (hipStream_t)next; return hipSuccess; }
