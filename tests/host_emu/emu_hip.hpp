@@ -120,6 +120,7 @@ struct Block {
   void* lds = nullptr;
   uint64_t* shfl_val = nullptr; unsigned* shfl_tag = nullptr; unsigned* shfl_seq = nullptr;
   unsigned char* coll_val = nullptr; unsigned* coll_tag = nullptr; unsigned* coll_seq = nullptr;
+  unsigned* wave_done = nullptr;   // per wave: lanes that have returned from the kernel
   std::vector<std::pair<const void*, void*>> statics;   // static __shared__ variables of the kernel: per workgroup (build.py turns the declarations into lookups)
   const std::function<void()>* body = nullptr;
   bool yield_requested = false;
@@ -149,6 +150,7 @@ inline void to_fiber(int i) { swapcontext(&sched_ctx, &blk->fibers[i].ctx); }
 inline void fiber_entry() {
   (*blk->body)();
   blk->fibers[cur].state = DONE;
+  ++blk->wave_done[cur >> 6];
   to_scheduler();
   abort();   // a finished fiber is never resumed
 }
@@ -181,7 +183,7 @@ inline Block* acquire_block(int n) {
     if (b->stacks == (char*)MAP_FAILED) { perror("emu: mmap of fiber stacks"); abort(); }
     b->fibers = new Fiber[n];
     b->shfl_val = new uint64_t[(size_t)SHFL_RING * n]; b->shfl_tag = new unsigned[(size_t)SHFL_RING * n]; b->shfl_seq = new unsigned[n];
-    b->coll_val = new unsigned char[(size_t)COLL_RING * n * COLL_BYTES]; b->coll_tag = new unsigned[(size_t)COLL_RING * n]; b->coll_seq = new unsigned[n];
+    b->coll_val = new unsigned char[(size_t)COLL_RING * n * COLL_BYTES]; b->coll_tag = new unsigned[(size_t)COLL_RING * n]; b->coll_seq = new unsigned[n]; b->wave_done = new unsigned[(n + 63) / 64];
   }
   return b;
 }
@@ -192,6 +194,7 @@ inline void start_block(Block* b, dim3 idx, dim3 gdim, dim3 bdim, size_t lds_byt
   for (int i = 0; i < b->n; ++i) { make_fiber(b, i); b->fibers[i].state = RUNNABLE; b->shfl_seq[i] = 0; b->coll_seq[i] = 0; }
   memset(b->shfl_tag, 0xff, sizeof(unsigned) * SHFL_RING * b->cap);
   memset(b->coll_tag, 0xff, sizeof(unsigned) * COLL_RING * b->cap);
+  memset(b->wave_done, 0, sizeof(unsigned) * ((b->cap + 63) / 64));
 }
 inline void finish_block(Block* b) {
   free(b->lds); b->lds = nullptr;
@@ -255,13 +258,13 @@ inline const unsigned char* wave_exchange(const void* mine, size_t bytes) {
   const unsigned k = b->coll_seq[t]++;
   const unsigned slot = k % COLL_RING;
   memcpy(b->coll_val + ((size_t)slot * cap + t) * COLL_BYTES, mine, bytes);
-  b->coll_tag[(size_t)slot * cap + t] = k;
-  for (;;) {
-    bool all = true;
-    for (int i = w0; i < w1 && all; ++i) { const unsigned tag = b->coll_tag[(size_t)slot * cap + i]; all = b->fibers[i].state == DONE || tag == k || (int)(tag - k) > 0; }
-    if (all) break;
-    to_scheduler();
-  }
+  // arrivals are counted per (ring slot, wave): the lanes of a wave go through the same exchanges in the same order, so the first lane to reach exchange k re-arms the
+  // slot's counter; a lane that has returned from the kernel counts as arrived for good (wave_done)
+  const int w = t >> 6, nw = (cap + 63) >> 6;
+  unsigned* cnt = b->coll_tag + ((size_t)slot * nw + w) * 2;
+  if (cnt[1] != k) { cnt[1] = k; cnt[0] = 0; }
+  ++cnt[0];
+  while ((int)(cnt[0] + b->wave_done[w]) < w1 - w0 && cnt[1] == k) to_scheduler();
   return b->coll_val + ((size_t)slot * cap + w0) * COLL_BYTES;
 }
 inline bool lane_live(int t) { return blk->fibers[t].state != DONE; }
