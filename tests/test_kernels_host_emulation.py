@@ -672,7 +672,7 @@ def test_emulated_product_refuses_nothing_silently(monkeypatch):
     il_memory.batch_desc(dict(states=torch.zeros(4, 3), actions=torch.zeros(4, 2), rewards=z, next_states=torch.zeros(4, 3), terminals=z, weights=z, absorbing=z))
 
 
-SCHEDULE_SUBSET_EXTRA = ' or peer_exchange_between'   # (the timed two-stream plan passes under reverse / random:2 / random:9 too - 12 s each, run by hand: IL_EMU_SCHEDULE=... pytest -k timed_path)   # the device hand-off between two streams: the schedule perturbation also shuffles which stream's workgroup runs next
+SCHEDULE_SUBSET_EXTRA = ' or peer_exchange_between or timed_path_replays'   # the hand-offs between ranks and between the two streams of the timed plan: the perturbation also shuffles workgroup dispatch and which stream runs next   # the device hand-off between two streams: the schedule perturbation also shuffles which stream's workgroup runs next
 ASAN_SUBSET = ('sac_update_matches_oracle_and_reference-sac_hopper_h64 or sac_gradients_match_oracle-sac_hopper_h64 or gail_update_matches_oracle_and_reference-gail_default or '
                'gail_loss_variants_match_reference-mixup_sublogp or gmmil_matches_oracle_and_reference-small or pwil_matches_oracle or replay_matches_reference_bit_exact-wrapped or '
                'red_matches_reference-hopper_d2_tanh_drop or dril_matches_reference-hopper_d2_relu or gail_deep_discriminator_matches_reference-hopper_d2_tanh_sn or '
