@@ -316,6 +316,8 @@ def _emulated_product(monkeypatch, streams=False):
       except AttributeError:
         return getattr(real, fn_name)
       fn.restype, fn.argtypes = _lib._SIGNATURES[fn_name]
+      if os.environ.get('IL_EMU_LOG_CALLS'):   # which entry points does the emulated suite reach? (one name per line)
+        with open(os.environ['IL_EMU_LOG_CALLS'], 'a') as f: f.write(fn_name + '\n')
       return fn
 
   monkeypatch.setattr(_lib, '_lib', Facade())
