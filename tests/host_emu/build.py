@@ -25,6 +25,9 @@ BUILD = os.path.join(HERE, '_build')
 # IL_EMU_ASAN=1: AddressSanitizer build (run python with LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0):
 # every load / store of every emulated kernel - global buffers (numpy / torch allocations go through the intercepted malloc) and the workgroup's LDS - bounds-checked
 SANITIZE = ['-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-fno-omit-frame-pointer'] if os.environ.get('IL_EMU_ASAN', '0') == '1' else []
+# IL_EMU_COVERAGE=1: gcov instrumentation (the translation keeps the sources' line numbers: profiles/tools/emu_coverage.sh reports executed lines per kernel file)
+if os.environ.get('IL_EMU_COVERAGE', '0') == '1':
+  SANITIZE = SANITIZE + ['--coverage']
 NOT_EMULATED = ()
 
 def _split_top_level(s: str):
