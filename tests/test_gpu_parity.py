@@ -341,7 +341,7 @@ def test_pwil_matches_oracle_and_reference(golden_dir):
 
 
 # ------------------------------------------------------------------------------------------------ whole update block
-def _make_plan(algorithm, seed, device_draw=True, loss='BCE', entropy_bonus=0.0, B=256, margin=float('inf')):
+def _make_plan(algorithm, seed, device_draw=True, loss='BCE', entropy_bonus=0.0, B=256, margin=float('inf'), reward_function='AIRL'):
   S, A = gi.DIMS['halfcheetah']
   torch.manual_seed(seed)
   cfg = Cfg(hidden_size=256, depth=2, activation='relu')
@@ -352,12 +352,29 @@ def _make_plan(algorithm, seed, device_draw=True, loss='BCE', entropy_bonus=0.0,
   mem = il.ReplayMemory(20000, S, A, True, device=DEV); fill_memory(mem, gi.transitions(rs, 5000, S, A), 5000)
   emem = il.ReplayMemory(2000, S, A, True, device=DEV); fill_memory(emem, gi.transitions(rs, 2000, S, A, state_shift=0.5), 2000)
   icfg = Cfg(state_only=False, spectral_norm=True, loss_function=loss, grad_penalty=1.0, entropy_bonus=entropy_bonus, mixup_alpha=1, pos_class_prior=0.7, nonnegative_margin=margin,
-             discriminator=Cfg(hidden_size=64, depth=1, activation='relu', reward_shaping=False, subtract_log_policy=False, reward_function='AIRL'))
+             discriminator=Cfg(hidden_size=64, depth=1, activation='relu', reward_shaping=False, subtract_log_policy=False, reward_function=reward_function))
   disc = il.GAILDiscriminator(S, A, icfg, 0.97, device=DEV)
   do = il.AdamW(disc, lr=3e-5, weight_decay=10)
   plan = il.UpdatePlan(algorithm, actor, critic, log_alpha, target, mem, ao, co, to, B, 0.97, -0.5 * A, 0.99, expert_memory=emem, discriminator=disc, discriminator_optimiser=do,
                        imitation_cfg=icfg, device_index_draw=device_draw)
   return plan, (actor, critic, target, log_alpha, disc)
+
+
+@pytest.mark.parametrize('reward_function', ['AIRL', 'GAIL', 'FAIRL'])
+def test_inline_relabel_heads_equal_the_reward_kernel(reward_function):
+  """models.py:177-180 inside the chained SAC launch (disc_reward.hpp: the rows a critic tile already holds are relabelled by the discriminator the other branch has just
+  stepped) against `predict_reward` (k_gail_reward) on the same rows and the same, updated discriminator: the three reward heads, bit for bit."""
+  il.seed(37); il_training._NOISE.clear()
+  plan, nets = _make_plan('GAIL', 19, reward_function=reward_function, B=64)
+  for _ in range(2):
+    plan.run()
+  torch.cuda.synchronize()
+  assert plan.inline_relabel and plan.sync_timeouts() == 0
+  t = plan.transitions
+  want = nets[4].predict_reward(t['states'].contiguous(), t['actions'].contiguous())
+  torch.cuda.synchronize()
+  assert np.isfinite(N(plan.rewards)).all() and (N(plan.rewards) > 0).any() == (reward_function != 'FAIRL' or (N(want) > 0).any())
+  np.testing.assert_array_equal(N(plan.rewards), N(want))
 
 
 @pytest.mark.parametrize('algorithm', ['SAC', 'GAIL'])

@@ -448,9 +448,10 @@ def test_gpu_parity_bodies_on_the_emulated_kernels(golden_dir, monkeypatch, body
   fn(**kw)
 
 
-@pytest.mark.parametrize('body,kw', [('test_batch_gather_is_rejected_where_it_is_not_honoured', {}),
+@pytest.mark.parametrize('body,kw', [('test_inline_relabel_heads_equal_the_reward_kernel', dict(reward_function='GAIL')), ('test_inline_relabel_heads_equal_the_reward_kernel', dict(reward_function='FAIRL')),
+                                     ('test_batch_gather_is_rejected_where_it_is_not_honoured', {}),
                                      ('test_gail_pugail_finite_margin_matches_reference', dict(name='clamped')), ('test_gail_pugail_finite_margin_matches_reference', dict(name='open'))],
-                         ids=['gather_rejected', 'pugail_margin-clamped', 'pugail_margin-open'])
+                         ids=['inline_relabel-GAIL', 'inline_relabel-FAIRL', 'gather_rejected', 'pugail_margin-clamped', 'pugail_margin-open'])
 def test_gpu_parity_bodies_that_build_a_plan_on_the_emulated_kernels(golden_dir, monkeypatch, body, kw):
   """More bodies of tests/test_gpu_parity.py: the ones that construct an UpdatePlan (its second stream, the device-sync probe) around what they check."""
   tgp = _emulated_product(monkeypatch, streams=True)
