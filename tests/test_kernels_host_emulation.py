@@ -666,6 +666,31 @@ def test_timed_sizes_on_the_emulated_kernels(monkeypatch, body):
   getattr(tts, body)()
 
 
+def test_pwil_many_candidate_lists_on_the_emulated_kernels(monkeypatch):
+  """PWIL against 20,000 atoms for 40 steps incl. a reset(): enough atom chunks (79 > 64) that the merging workgroup owns more than one candidate list per lane and stages
+  candidates in LDS - the paths the 400-atom fixture never reaches and the 25,000-atom fixture (IL_EMU_SLOW=1, 5 min) does - against the oracle, which is pinned to the
+  reference at both sizes. Rewards at the bound of those tests (rtol 2e-5), the remaining atoms exactly."""
+  tgp = _emulated_product(monkeypatch)
+  import torch
+  from oracle import pwil as opwil
+  Nn, D, steps, Th, A = 20000, 24, 40, 28, 6
+  S = D - A
+  atoms, agent = gi.pwil_case(23, Nn, D, steps)
+  mem = tgp.il.ReplayMemory(Nn, S, A, False, transitions=dict(states=torch.from_numpy(atoms[:, :S]), actions=torch.from_numpy(atoms[:, S:]), rewards=torch.zeros(Nn),
+                                                             next_states=torch.from_numpy(atoms[:, :S]), terminals=torch.zeros(Nn), timeouts=torch.zeros(Nn), weights=torch.ones(Nn),
+                                                             num_trajectories=20), device='cpu')
+  d = tgp.il.PWILDiscriminator(S, A, tgp.Cfg(state_only=False, reward_scale=5, reward_bandwidth_scale=5), mem, Th)
+  o = opwil.PwilOracle(atoms, Th, 5, 5)
+  got, want = [], []
+  for k in range(steps):
+    got.append(float(d.compute_reward(tgp.T(agent[k:k + 1, :S]), tgp.T(agent[k:k + 1, S:]))))
+    want.append(o.compute_reward(agent[k]))
+    if k % Th == Th - 1:
+      d.reset(); o.reset()
+  np.testing.assert_allclose(got, want, rtol=2e-5)
+  assert int((d.expert_weights >= 0).sum()) == len(o.weights)
+
+
 def test_emulated_product_refuses_nothing_silently(monkeypatch):
   """The swap above is test scaffolding: outside it the product still refuses CPU tensors."""
   import torch
