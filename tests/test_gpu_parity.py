@@ -341,6 +341,31 @@ def test_pwil_matches_oracle_and_reference(golden_dir):
 
 
 # ------------------------------------------------------------------------------------------------ whole update block
+@pytest.mark.parametrize('name,Nn,Th', [('one_workgroup', 3000, 10), ('two_launches_serial_merge', 6000, 30), ('step', 6000, 600)])
+def test_pwil_every_launch_path_matches_oracle(name, Nn, Th):
+  """il_pwil_reward picks its kernels from the atoms one step can consume (m = ceil(N / T) + 2) and the number of 256-atom chunks G: the one-launch k_pwil_step when
+  G m <= 4096 candidates fit in LDS (every shipped configuration: T = 1000), k_pwil_select + the serial merge beyond that, the one-workgroup k_pwil_reward when m > 256
+  (short horizons). All three against the oracle over a few episodes with resets: rewards at the bound of the other PWIL tests, the remaining atoms exactly."""
+  D, A, steps = 10, 3, 2 * Th + 7 if Th <= 30 else 40
+  S = D - A
+  atoms, agent = gi.pwil_case(31, Nn, D, steps)
+  mem = il.ReplayMemory(Nn, S, A, False, transitions=dict(states=torch.from_numpy(atoms[:, :S]), actions=torch.from_numpy(atoms[:, S:]), rewards=torch.zeros(Nn),
+                                                          next_states=torch.from_numpy(atoms[:, :S]), terminals=torch.zeros(Nn), timeouts=torch.zeros(Nn), weights=torch.ones(Nn),
+                                                          num_trajectories=4), device=DEV)
+  d = il.PWILDiscriminator(S, A, Cfg(state_only=False, reward_scale=5, reward_bandwidth_scale=5), mem, Th)
+  m, G = int(np.ceil(Nn / Th)) + 2, -(-Nn // 256)
+  assert {'one_workgroup': m > 256, 'two_launches_serial_merge': m <= 256 and G * m > 4096, 'step': G * m <= 4096}[name], (m, G)
+  o = opwil.PwilOracle(atoms, Th, 5, 5)
+  got, want = [], []
+  for k in range(steps):
+    got.append(float(d.compute_reward(T(agent[k:k + 1, :S]), T(agent[k:k + 1, S:]))))
+    want.append(o.compute_reward(agent[k]))
+    if k % Th == Th - 1 or (Th > 30 and k == 17):
+      d.reset(); o.reset()
+  np.testing.assert_allclose(got, want, rtol=2e-5)
+  assert int((d.expert_weights >= 0).sum()) == len(o.weights)
+
+
 def _make_plan(algorithm, seed, device_draw=True, loss='BCE', entropy_bonus=0.0, B=256, margin=float('inf'), reward_function='AIRL'):
   S, A = gi.DIMS['halfcheetah']
   torch.manual_seed(seed)
