@@ -378,6 +378,7 @@ def _emulated_product(monkeypatch, streams=False):
     monkeypatch.setattr(torch.cuda, 'CUDAGraph', Graph)
     monkeypatch.setattr(torch.cuda, 'graph', capture)
 
+    monkeypatch.setattr(torch.Tensor, 'pin_memory', lambda self, *a, **k: self)   # pinned host words (time-out flags the host polls): plain host memory here
     zeros = torch.zeros
     monkeypatch.setattr(torch, 'zeros', lambda *a, pin_memory=False, **k: zeros(*a, **k))   # the acting mailbox is pinned host memory: plain host memory here
 
@@ -677,6 +678,29 @@ def test_sac_update_at_random_shapes_on_the_emulated_kernels(monkeypatch):
     S, A, H, B = int(rs.randint(2, 41)), int(rs.randint(1, 9)), int(rs.choice([64, 128, 192, 256])), int(rs.choice([16, 32, 48, 80, 112]))
     monkeypatch.setitem(gi.DIMS, 'fuzz', (S, A))
     tgp.test_sac_update_other_shapes('fuzz', H, B)
+
+
+@pytest.mark.parametrize('args', [['algorithm=GAIL', 'env=hopper'], ['algorithm=SAC', 'env=hopper', '+acting.schedule=overlap']], ids=['GAIL', 'SAC-acting-overlap'])
+def test_train_py_end_to_end_on_the_emulated_kernels(monkeypatch, tmp_path, args):
+  """The entry point itself (tests/test_train_gpu.py on the GPU, shortened: 140 environment steps, 20 updates, one evaluation): configuration, expert-data ingest, the
+  acting worker feeding the ring, the captured UpdatePlan, the time-out watch, evaluation, checkpoints - every line of train.py a GPU run executes, on CPU tensors and the
+  emulated library. Also run by hand: AdRIL, PWIL, reward shaping with a depth-2 tanh potential (15 s each)."""
+  _emulated_product(monkeypatch, streams=True)
+  import torch
+  sys.path.insert(0, os.path.dirname(HERE))
+  import train
+  from imitation_learning_amd import config
+  monkeypatch.chdir(tmp_path)
+  cfg = config.compose(args + ['steps=140', 'training.start=120', 'evaluation.interval=70', 'evaluation.episodes=1', 'logging.interval=10', '+synthetic_env.max_episode_steps=60',
+                               '+synthetic_env.dataset_trajectories=6', 'training.batch_size=64'])
+  score = train.train(cfg)
+  assert np.isfinite(score)
+  agent = torch.load(tmp_path / 'agent.pth', weights_only=False)
+  assert all(torch.isfinite(v).all() for v in agent['actor'].values()) and 'critic_1.critic.0.weight' in agent['critic']
+  metrics = torch.load(tmp_path / 'metrics.pth', weights_only=False)
+  assert len(metrics['update_steps']) >= 1 and all(np.isfinite(q).all() for q in metrics['Q_values'])
+  if cfg.algorithm == 'GAIL':
+    assert 'g.0.parametrizations.weight.original' in torch.load(tmp_path / 'discriminator.pth', weights_only=False)
 
 
 def test_pwil_many_candidate_lists_on_the_emulated_kernels(monkeypatch):

@@ -15,6 +15,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import imitation_learning_amd as il  # noqa: E402
+from imitation_learning_amd import _lib  # noqa: E402
 from imitation_learning_amd import config as il_config  # noqa: E402
 from imitation_learning_amd.environments import make_env  # noqa: E402
 from imitation_learning_amd.evaluation import evaluate_agent  # noqa: E402
@@ -80,7 +81,7 @@ def train(cfg, file_prefix: str = '') -> float:
     dog = parallel.Watchdog(float(cfg.distributed.timeout_s), what=f'train.py (rank {rank} of {world})')   # a rank that dies inside a collective must not hang the others
   else:
     dev, dog = default_device(), None
-  assert dev.type == 'cuda', 'train.py needs a GPU: the update path has no CPU fallback'
+  assert _lib.on_device(torch.empty(0, device=dev)), 'train.py needs a GPU: the update path has no CPU fallback'
   lead = rank == 0                # evaluation, plots and checkpoints are rank 0's job
   seed = cfg.seed + rank
   il.seed(seed)                   # replay index stream (np.random.seed in the reference, train.py:51)
