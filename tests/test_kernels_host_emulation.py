@@ -680,6 +680,7 @@ def test_sac_update_at_random_shapes_on_the_emulated_kernels(monkeypatch):
     tgp.test_sac_update_other_shapes('fuzz', H, B)
 
 
+@pytest.mark.skipif(os.environ.get('IL_EMU_ASAN', '0') == '1', reason='a preloaded AddressSanitizer cannot intercept the C++ exceptions torch / matplotlib throw and catch internally on this path (CHECK real___cxa_throw)')
 @pytest.mark.parametrize('args', [['algorithm=GAIL', 'env=hopper'], ['algorithm=SAC', 'env=hopper', '+acting.schedule=overlap']], ids=['GAIL', 'SAC-acting-overlap'])
 def test_train_py_end_to_end_on_the_emulated_kernels(monkeypatch, tmp_path, args):
   """The entry point itself (tests/test_train_gpu.py on the GPU, shortened: 140 environment steps, 20 updates, one evaluation): configuration, expert-data ingest, the
@@ -750,7 +751,7 @@ def test_emulated_kernels_are_address_sanitizer_clean():
   """The same emulation compiled with -fsanitize=address,undefined (IL_EMU_ASAN=1), a subset of the bodies above in a child process: every load and store of those
   kernels - the global buffers (numpy / torch allocations go through the intercepted malloc), the workgroup's LDS (allocated to the byte) - is bounds- and lifetime-
   checked, every 16-byte vector access alignment-checked, signed overflow and shifts checked. A GPU run cannot say this: an access a few words past a tensor lands in
-  the caching allocator's pool and is silent. The whole file is clean under it (IL_EMU_ASAN_ALL=1 runs all of it, ~5 min; last run: end of round 3, 97 passed); round 3 found one use-after-free this way -
+  the caching allocator's pool and is silent. The whole file is clean under it (IL_EMU_ASAN_ALL=1 runs all of it, ~5 min; last run: end of round 3, 143 passed, the two train.py cases excluded); round 3 found one use-after-free this way -
   a temporary `torch.ones` whose pointer sat in an il_batch after the tensor had died (training.py)."""
   import subprocess
   asan = subprocess.run(['gcc', '-print-file-name=libasan.so'], capture_output=True, text=True).stdout.strip()
