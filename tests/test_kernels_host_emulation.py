@@ -461,6 +461,24 @@ def test_gpu_parity_bodies_that_build_a_plan_on_the_emulated_kernels(golden_dir,
   fn(**kw)
 
 
+SLOW = pytest.mark.skipif(os.environ.get('IL_EMU_SLOW', '0') != '1', reason='IL_EMU_SLOW=1: the heavier plan-level bodies (12 - 40 s each; all passed at the end of round 3)')
+
+
+@SLOW
+@pytest.mark.parametrize('body,args', [('test_update_plan_graph_replay_equals_eager', ('SAC',)), ('test_update_plan_graph_replay_equals_eager', ('GAIL',)),
+                                       ('test_capture_warmup_runs_on_the_probed_stream_pair', (0,)), ('test_update_plan_host_and_device_index_draws_agree', ()),
+                                       ('test_batched_population_equals_independent_learners', ()), ('test_data_parallel_path_equals_fused_path_on_one_rank', ('none',)),
+                                       ('test_data_parallel_path_equals_fused_path_on_one_rank', ('peer_windows',)), ('test_data_parallel_path_equals_fused_path_on_one_rank', ('peer_windows_in_apply',))])
+def test_plan_level_gpu_bodies_on_the_emulated_kernels_slow(monkeypatch, body, args):
+  """Verbatim bodies of tests/test_gpu_parity.py that capture and replay graphs: graph replay == eager for SAC and GAIL, the capture warm-up, host vs device index draws,
+  three learners batched vs independent, and DataParallelUpdate with one rank - eager AND as captured graphs - for the three exchange forms."""
+  import inspect
+  tgp = _emulated_product(monkeypatch, streams=True)
+  monkeypatch.setenv('IL_PEER_SOAK_ROUNDS', '0')
+  fn = getattr(tgp, body)
+  fn(monkeypatch, *args) if 'monkeypatch' in inspect.signature(fn).parameters else fn(*args)
+
+
 def _timed_path_modules(monkeypatch, tgp):
   import bench
   import gpu_util
