@@ -620,6 +620,63 @@ def test_data_parallel_schedules_equal_the_plain_plan_on_the_emulated_kernels(mo
     np.testing.assert_array_equal(a, b, err_msg=f'{name}: tensor {i}')
 
 
+def _two_data_parallel_ranks(monkeypatch, fused, updates=2):
+  """Two data-parallel ranks in ONE process: two learners built like bench.py's (the same networks, their own replay shard, index stream, noise stream and scratch), a
+  DataParallelUpdate each, every bucket of their peer exchanges re-homed into windows both ranks point at (what PeerExchange does with hipIpc handles between processes), and
+  each rank's update enqueued on emulated streams of its own: the four branches' workgroups are co-resident and hand over through the windows' arrival words."""
+  tgp = _emulated_product(monkeypatch, streams=True)
+  import bench
+  import torch
+  from imitation_learning_amd.parallel import DataParallelUpdate
+  monkeypatch.setenv('IL_PEER_SOAK_ROUNDS', '0'); monkeypatch.setenv('IL_PEER_EXCHANGE', 'require'); monkeypatch.setenv('IL_DP_FUSED', '1' if fused else '0')
+  L, W, keep = _lib.lib(), 2, []
+  ranks = []
+  for r in range(W):
+    plan, nets, _ = bench.build(torch.device('cpu'), r, seed=7, learner_id=r)
+    runner = DataParallelUpdate(plan)
+    runner._warm_collectives()          # sets the exchange up (a world of one) without running an update
+    ranks.append((plan, nets, runner))
+  assert all(bool(runner.fused) == fused for _, _, runner in ranks)
+  names = [k for k in ranks[0][2].peer.desc if not k.startswith('_')]
+  d0, offs, total = ranks[0][2].peer.desc, {}, 0
+  for k in names:
+    offs[k] = total
+    total += int(L.il_peer_job_region_bytes(W, d0[k].n, d0[k].n_jobs) if d0[k].n_jobs else L.il_peer_region_bytes(W, d0[k].n))
+  windows = [np.zeros(total // 4 + 64, f32) for _ in range(W)]
+  base = [w.ctypes.data + (-w.ctypes.data) % 256 for w in windows]
+  status = []
+  for r, (plan, nets, runner) in enumerate(ranks):
+    for k in names:
+      d = runner.peer.desc[k]
+      ep, st = np.zeros(d.n_jobs if d.n_jobs else (d.n + 2047) // 2048, np.uint32), np.zeros(2, np.int64)
+      keep += [ep, st]; status.append(st)
+      d.rank, d.world, d.window_offset, d.epoch, d.status = r, W, offs[k], ep.ctypes.data, st.ctypes.data
+      for q in range(W): d.windows[q] = base[q]
+  mains = [torch.cuda.Stream() for _ in range(W)]
+  for _ in range(updates):
+    for r, (plan, nets, runner) in enumerate(ranks):
+      with torch.cuda.stream(mains[r]):
+        runner.run()
+    torch.cuda.synchronize()
+  assert all(int(st[0]) == 0 for st in status) and all(plan.sync_timeouts() == 0 for plan, _, _ in ranks), 'a device-side wait expired'
+  return [[tgp.N(n.flat if hasattr(n, 'flat') else n) for n in nets] for _, nets, _ in ranks], (windows, keep)
+
+
+def test_two_data_parallel_ranks_on_the_emulated_kernels(monkeypatch):
+  """The multi-GPU default - the three gradient exchanges INSIDE the launches that produce the gradients (k_dw_adam_peer's block jobs, k_gail_reduce) - between two ranks
+  with different data, at the BASELINE configuration: the replicas stay bit-identical, and they equal, bit for bit, the same two ranks run with one exchange launch per
+  sync point (tests/test_parallel_gpu.py checks this between two processes sharing one GPU; no run on two GPUs exists)."""
+  fused, _k1 = _two_data_parallel_ranks(monkeypatch, True)
+  for a, b in zip(*fused):
+    assert np.isfinite(a).all()
+    np.testing.assert_array_equal(a, b, err_msg='replicas differ (exchange inside the optimiser launches)')
+  launches, _k2 = _two_data_parallel_ranks(monkeypatch, False)
+  for a, b in zip(*launches):
+    np.testing.assert_array_equal(a, b, err_msg='replicas differ (exchange launches)')
+  for a, b in zip(fused[0], launches[0]):
+    np.testing.assert_array_equal(a, b, err_msg='the two schedules differ')
+
+
 # ------------------------------------------------------------------------------------------------ the peer-window gradient exchange between emulated ranks
 def _peer_exchange_rounds(world, n, n_jobs, write_through, rounds=6, depth=1, seed=0):
   """`world` ranks in one process: rank r's window is a host buffer every rank's descriptor points at (on the GPUs: a peer-mapped uncached allocation), its launch goes
