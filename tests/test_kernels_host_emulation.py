@@ -620,7 +620,7 @@ def test_data_parallel_schedules_equal_the_plain_plan_on_the_emulated_kernels(mo
     np.testing.assert_array_equal(a, b, err_msg=f'{name}: tensor {i}')
 
 
-def _two_data_parallel_ranks(monkeypatch, fused, updates=2):
+def _two_data_parallel_ranks(monkeypatch, fused, updates=2, world=2):
   """Two data-parallel ranks in ONE process: two learners built like bench.py's (the same networks, their own replay shard, index stream, noise stream and scratch), a
   DataParallelUpdate each, every bucket of their peer exchanges re-homed into windows both ranks point at (what PeerExchange does with hipIpc handles between processes), and
   each rank's update enqueued on emulated streams of its own: the four branches' workgroups are co-resident and hand over through the windows' arrival words."""
@@ -629,7 +629,7 @@ def _two_data_parallel_ranks(monkeypatch, fused, updates=2):
   import torch
   from imitation_learning_amd.parallel import DataParallelUpdate
   monkeypatch.setenv('IL_PEER_SOAK_ROUNDS', '0'); monkeypatch.setenv('IL_PEER_EXCHANGE', 'require'); monkeypatch.setenv('IL_DP_FUSED', '1' if fused else '0')
-  L, W, keep = _lib.lib(), 2, []
+  L, W, keep = _lib.lib(), world, []
   ranks = []
   for r in range(W):
     plan, nets, _ = bench.build(torch.device('cpu'), r, seed=7, learner_id=r)
@@ -675,6 +675,15 @@ def test_two_data_parallel_ranks_on_the_emulated_kernels(monkeypatch):
     np.testing.assert_array_equal(a, b, err_msg='replicas differ (exchange launches)')
   for a, b in zip(fused[0], launches[0]):
     np.testing.assert_array_equal(a, b, err_msg='the two schedules differ')
+
+
+@SLOW
+def test_eight_data_parallel_ranks_on_the_emulated_kernels_slow(monkeypatch):
+  """BASELINE config 5's shape of parallelism (8 ranks) with the fused exchange: eight learners in one process, replicas bit-identical after two updates (~70 s)."""
+  state, _keep = _two_data_parallel_ranks(monkeypatch, True, world=8)
+  for r in range(1, 8):
+    for a, b in zip(state[0], state[r]):
+      np.testing.assert_array_equal(a, b, err_msg=f'rank {r} differs from rank 0')
 
 
 # ------------------------------------------------------------------------------------------------ the peer-window gradient exchange between emulated ranks
