@@ -119,7 +119,7 @@ struct Block {
   Fiber* fibers = nullptr; char* stacks = nullptr;
   void* lds = nullptr;
   uint64_t* shfl_val = nullptr; unsigned* shfl_tag = nullptr; unsigned* shfl_seq = nullptr;
-  unsigned char* coll_val = nullptr; unsigned* coll_tag = nullptr; unsigned* coll_seq = nullptr;
+  unsigned char* coll_val = nullptr; unsigned* coll_tag = nullptr; unsigned* coll_seq = nullptr;   // wave-level exchange: payload slots [ring][lane], per (ring slot, wave) {arrivals, exchange number}, per-lane exchange counter
   unsigned* wave_done = nullptr;   // per wave: lanes that have returned from the kernel
   std::vector<std::pair<const void*, void*>> statics;   // static __shared__ variables of the kernel: per workgroup (build.py turns the declarations into lookups)
   const std::function<void()>* body = nullptr;
