@@ -310,6 +310,118 @@ template <int PANEL = 16, class Epi>
 __device__ __forceinline__ void tile_bwd_packed(const float* dYs, int ldy, int H, const float* __restrict__ PB, Epi epi, int t0 = 0, int t1 = -1) { tile_packed<PANEL>(dYs, ldy, H, PB, epi, t0, t1); }
 
 // ---------------------------------------------------------------------------------------------
+// Pair mode (round 4): a 16-row tile of a 16 x 256 x 256 layer is 8,192 MFMA clocks on ONE CU however many CUs idle, and its 256 KB weight panel reaches that CU at
+// ~75 GB/s - both 3.4 us. A PAIR of 8-wave workgroups (512 threads, <= 256 VGPRs per wave) splits the layer by OUTPUT COLUMNS: wave w of half p owns output tile 8 p + w,
+// i.e. the same 64 MFMAs in the same k order on the same operands as wave 8 p + w of the 16-wave workgroup - every element keeps its summation order, the results are
+// bit-identical - while each CU issues half the MFMAs and pulls half the panel. What the two halves need of each other (the next layer's K dimension) crosses through an
+// 8 KB slab in the workspace: write-through (sc0 sc1) 16-byte stores, a drained flag, sc0 sc1 loads on the consumer - no L2 write-back, no L1 invalidate (MI355X guide,
+// "Valid forms": `sc1` payload -> vmcnt(0) -> flag; `sc1` loads replace the acquire when the producer stored `sc1`). The narrow first layer (K <= 64) is computed by both
+// halves in full - cheaper than a hop. With 256 VGPRs a wave parks its whole 16 KB panel of the NEXT big layer in registers while the current phase runs.
+// ---------------------------------------------------------------------------------------------
+struct Panel16 { f32x4 b[16]; };
+// the 16 lane-ordered weight blocks of output tile t (H = 256: nb = 16), requested at once
+__device__ __forceinline__ void panel_prefetch(Panel16& p, const float* __restrict__ P, int t) {
+  const float* pp = P + (size_t)t * 16 * 256 + (threadIdx.x & 63) * 4;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) p.b[u] = gload4(pp + (size_t)u * 256);
+  __builtin_amdgcn_sched_barrier(0);
+}
+// output tile t of As[16 x 256] . panel from registers; the MFMA order of tile_packed.  epi(t * 16, acc)
+template <class Epi>
+__device__ __forceinline__ void tile_packed_regs(const float* As, int lda, const Panel16& p, int t, Epi epi) {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const float* ar = As + j * lda + 4 * g;
+  f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ar + 16 * u);
+    acc0 = mfma16(a[0], p.b[u][0], acc0);
+    acc1 = mfma16(a[1], p.b[u][1], acc1);
+    acc0 = mfma16(a[2], p.b[u][2], acc0);
+    acc1 = mfma16(a[3], p.b[u][3], acc1);
+  }
+  const f32x4 acc = acc0 + acc1;
+  epi(t * 16, acc);
+}
+// The narrow first layer (Kpad <= 64, N = 32 waves' worth of columns over 8 waves: two column tiles per wave, c0 = 16 wave and 16 (wave + nw)) with its weight lanes
+// requested BEFORE the rows are in LDS; k-blocks beyond Kpad repeat the last one's address (never used). Same loads (load4<MODE>, same arguments) and the same MFMA
+// order per 16-wide k-block as tile_fwd_impl: same bits.
+struct L1Pre { f32x4 b[2][4]; };
+template <int MODE>
+__device__ __forceinline__ void l1_prefetch_impl(L1Pre& w, const float* __restrict__ W, int ldw, int Kw, int Kpad, int N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c0 = min((wave + q * nw) * 16, N - 16);
+    const float* wr = W + (size_t)(c0 + j) * ldw;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w.b[q][u] = load4<MODE>(wr, min(16 * u, Kpad - 16) + 4 * g, Kw);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void l1_prefetch(L1Pre& w, const float* __restrict__ W, int ldw, int Kw, int Kpad, int N) {
+  const bool aligned = ((ldw & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+  if (aligned && Kw == Kpad) l1_prefetch_impl<0>(w, W, ldw, Kw, Kpad, N);
+  else if (aligned && (Kw & 3) == 0 && Kw >= 4) l1_prefetch_impl<1>(w, W, ldw, Kw, Kpad, N);
+  else l1_prefetch_impl<2>(w, W, ldw, Kw, Kpad, N);
+}
+template <class Epi>
+__device__ __forceinline__ void l1_compute(const L1Pre& w, const float* Xs, int ldx, int Kpad, int N, Epi epi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, j = lane & 15, g = lane >> 4;
+  const float* xr = Xs + j * ldx + 4 * g;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c0 = (wave + q * nw) * 16;
+    if (c0 >= N) break;
+    f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (16 * u < Kpad) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * u);
+        acc0 = mfma16(a[0], w.b[q][u][0], acc0);
+        acc1 = mfma16(a[1], w.b[q][u][1], acc1);
+        acc0 = mfma16(a[2], w.b[q][u][2], acc0);
+        acc1 = mfma16(a[3], w.b[q][u][3], acc1);
+      }
+    }
+    const f32x4 acc = acc0 + acc1;
+    epi(c0, acc);
+  }
+}
+// The hop between the halves of a pair. Slab: [128 columns][16 rows] floats, one 16-byte lane = 4 rows of one column (what an MFMA accumulator lane holds).
+// Producer: wstore4<true> (sc0 sc1) lanes, then pair_publish (every wave drains its stores; barrier; ONE relaxed agent-scope flag store). Consumer: pair_await (one
+// polling lane, bounded like every device-side wait; barrier), pair_load4 (sc0 sc1: served below this CU's L1), then thread 0 clears the flag for the next launch.
+__device__ __forceinline__ f32x4 pair_load4(const float* base, int64_t off) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7ffffff0, 0x00020000);
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off * 4), 0, 17));   // sc0 | sc1
+}
+__device__ __forceinline__ void pair_publish(unsigned* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// copies the partner's 16 x 128 half out of `slab` into columns [c_base, c_base + 128) of the [16][ld] LDS tile; every thread calls (barriers inside)
+template <class Timeout>
+__device__ __forceinline__ void pair_receive(unsigned* flag, const float* slab, float* Ts, int ld, int c_base, Timeout timed_out) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > IL_SYNC_SPIN_LIMIT) { timed_out(); break; }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 128 * 4; i += blockDim.x) {
+    const int c = i >> 2, r4 = (i & 3) * 4;
+    const f32x4 v = pair_load4(slab, (int64_t)c * 16 + r4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Ts[(r4 + q) * ld + c_base + c] = v[q];
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: ready for the next launch (which follows this one in stream order)
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Small output layer: Os[16][16] = Xs[16 x K] . W^T + b, W [N][ldw] with N <= 16 (actor head 2A, critic head 1).
 // The K/16 k-blocks are dealt round-robin to the waves; partial tiles are reduced through LDS (`part` >= (K/16)*256 floats; K % 16 == 0).
 // Contains __syncthreads(); every thread of the block must call. Result valid after return.

@@ -29,6 +29,7 @@ struct SacWs {  // float offsets into il_sac.workspace
   int64_t c_x0, c_h1, c_h2, c_q, t_q, c_dz3, c_dz2, c_dz1;
   int64_t p_q, p_g, a_dz3, a_dz2, a_dz1, alpha_part, pair_ctr, chain_ctr;
   int64_t pk_af, pk_ab, pk_cf, pk_cb, pk_tf, pk_tb;  // lane-ordered copies of the H x H layers (mlp_tile.hpp "Packed hidden-layer weights")
+  int64_t x_slab, x_flag, c_rew;   // pair mode (mlp_tile.hpp): 6 * nt hop slabs of 16 x H/2 floats, their flags (one 128-byte line each), the relabel role's rewards [B]
   int64_t total;
 };
 __host__ __device__ inline SacWs sac_ws(int S, int A, int H, int B) {
@@ -42,6 +43,7 @@ __host__ __device__ inline SacWs sac_ws(int S, int A, int H, int B) {
   w.p_q = take(2 * B); w.p_g = take(2 * BA); w.a_dz3 = take((int64_t)B * 16); w.a_dz2 = take(BH); w.a_dz1 = take(BH); w.alpha_part = take(B / IL_TILE_R + 4); w.pair_ctr = take((int64_t)(B / IL_TILE_R) * IL_CTR_STRIDE + 4); w.chain_ctr = take((int64_t)(B / IL_TILE_R) * IL_CTR_STRIDE + 4);
   const int64_t HH = (int64_t)H * H;
   w.pk_af = take(HH); w.pk_ab = take(HH); w.pk_cf = take(2 * HH); w.pk_cb = take(2 * HH); w.pk_tf = take(2 * HH); w.pk_tb = take(2 * HH);
+  w.x_slab = take((int64_t)6 * (B / IL_TILE_R) * IL_TILE_R * (H / 2)); w.x_flag = take((int64_t)6 * (B / IL_TILE_R) * IL_CTR_STRIDE + 4); w.c_rew = take(B);
   w.total = o;
   return w;
 }
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask, const i
   {
     for (int i = threadIdx.x; i < d.batch / IL_TILE_R; i += blockDim.x) { reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr)[i * IL_CTR_STRIDE] = 0u; reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr)[i * IL_CTR_STRIDE] = 0u; }
     if (threadIdx.x == 0) reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr)[(d.batch / IL_TILE_R) * IL_CTR_STRIDE + 1] = 0u;   // il_sac_handoff_timeouts counts from here
+    for (int i = threadIdx.x; i < 6 * (d.batch / IL_TILE_R); i += blockDim.x) reinterpret_cast<unsigned*>(d.workspace + ws.x_flag)[i * IL_CTR_STRIDE] = 0u;   // pair-mode hop flags (their consumers clear them; this covers a reused arena)
   }
   if (!((mask >> net) & 1u)) return;
   const int64_t HH = (int64_t)H * H, ns = net_stride(IN, H, 1);
@@ -226,6 +229,26 @@ __device__ __forceinline__ void tile_await(unsigned* ctr, unsigned target, const
   if (threadIdx.x == 0) {
     int spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > IL_SYNC_SPIN_LIMIT) {
+        __hip_atomic_fetch_add(timeouts.slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (timeouts.sync) sync_timed_out(timeouts.sync);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+// Pair-mode chain: arrivals in the low four bits of the tile counter, flag bits above them (the relabel role arrives with += 16, so that it cannot be mistaken for
+// the tile's actor(s') or a target); waits until (value & 15) >= low and every bit of `bits` is set. Same bounded poll + one agent acquire as tile_await.
+__device__ __forceinline__ void tile_await_bits(unsigned* ctr, unsigned low, unsigned bits, const TileTimeouts& timeouts) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    for (;;) {
+      const unsigned v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((v & 15u) >= low && (v & bits) == bits) break;
       __builtin_amdgcn_s_sleep(4);
       if (++spins > IL_SYNC_SPIN_LIMIT) {
         __hip_atomic_fetch_add(timeouts.slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -436,7 +459,7 @@ __device__ __forceinline__ RowScalars critic_row_scalars(const il_batch& b, bool
   return rs;
 }
 __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const il_batch& b, const float* __restrict__ rewards, const ChainRelabel& rl, const RowScalars& rs, int k, int tile,
-                                                          float* smem) {
+                                                          float* smem, const float* __restrict__ rew_ws = nullptr) {   // rew_ws: the tile's rewards were predicted by the relabel role of this launch (pair mode), visible behind the tile counter's acquire
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R, row0 = tile * IL_TILE_R;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
@@ -453,7 +476,7 @@ __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const
     const float alpha = expf(d.log_alpha[0]);
     const float m = rs.m;
     const float tv = fminf(W[ws.t_q + row], W[ws.t_q + B + row]) - m * alpha * W[ws.n_logp2 + row];
-    const float rew = rl.on ? rew16[threadIdx.x] : (rewards ? rewards[row] : (d.sync ? b.rewards[brow(b, row) * b.ld_rewards] : rs.reward));
+    const float rew = rew_ws ? rew_ws[row] : (rl.on ? rew16[threadIdx.x] : (rewards ? rewards[row] : (d.sync ? b.rewards[brow(b, row) * b.ld_rewards] : rs.reward)));
     const float y = rew + rs.not_done * d.discount * tv;
     const float q = q16[threadIdx.x];
     const float dq = (rs.weight * (2.f * (q - y))) / (float)B;
@@ -585,6 +608,241 @@ __global__ __launch_bounds__(1024) void k_sac_chain_pop(const il_sac* __restrict
   globalize(d); globalize(b);
   ChainRelabel rl = {};
   sac_chain_body(d, b, nullptr, nullptr, nullptr, nullptr, rl, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pair mode of the chained launch (round 4; mlp_tile.hpp "Pair mode"). k_sac_chain's critical path is actor(s') -> targets -> critic-loss scale, two 16 x 256 x 256
+// layers of 5 us each on one CU apiece, with the inline relabel (5 us behind the discriminator's step) on the critic workgroups' own path. Here, with 512-thread
+// workgroups (H = 256, round_up16(S + A) <= 64):
+//   * actor(s') and each target critic of a tile are a PAIR of workgroups that split the hidden layer by output columns (half p = 1 sends its 16 x 128 half of h2 and
+//     exits; half 0 continues with the head / Q). Narrow first layers are computed by both halves; their weight lanes are requested before the rows are in LDS, the hidden
+//     layer's panel before the first layer runs;
+//   * the reward relabel of a tile is a role of its own (it waits for [IL_SYNC_PARAMS] beside the critics instead of inside them) and arrives on the tile counter with
+//     += 16; the critic-loss workgroups wait ONCE, for both targets and the rewards;
+//   * critics and actor(s) run the same tile functions as k_sac_chain with 8 waves (two column tiles per wave; off the critical path).
+// Block order: actor(s') p = 1, p = 0 | targets p = 1, p = 0 | relabel | critics | actor(s) | row copies: a workgroup still only waits for lower-numbered ones, and a
+// pair's halves share block id mod 8 (same XCD: the hop stays short; placement is speed only). Every element keeps its summation order: bit-identical to k_sac_chain.
+// ---------------------------------------------------------------------------------------------
+struct PairIds { int role, net, tile, half; };   // role 0 actor(s'), 1 target, 2 critic, 3 actor(s), 4 relabel, 5 row copy
+__device__ __forceinline__ void seg_decode(int l, int nt, int n_nets, int& net, int& tile) {   // l in [0, n_nets * nt): XCD-aware when nt % 8 == 0 (a network's tiles share 8 / n_nets XCDs)
+  if ((nt & 7) == 0 && n_nets == 2) { const int x = l & 7, q = l >> 3, rc = nt >> 2; net = x >> 2; tile = (x & 3) * rc + q; }
+  else if ((nt & 7) == 0) { net = 0; tile = l; }
+  else { net = l / nt; tile = l - net * nt; }
+}
+__device__ __forceinline__ PairIds chain_pair_decode(int bid, int nt, int relabel) {
+  PairIds r = {5, 0, 0, 0};
+  int l = bid;
+  if (l < 2 * nt) { r.role = 0; r.half = l < nt ? 1 : 0; seg_decode(l % nt, nt, 1, r.net, r.tile); return r; }
+  l -= 2 * nt;
+  if (l < 4 * nt) { r.role = 1; r.half = l < 2 * nt ? 1 : 0; seg_decode(l % (2 * nt), nt, 2, r.net, r.tile); return r; }
+  l -= 4 * nt;
+  if (relabel) { if (l < nt) { r.role = 4; r.tile = l; return r; } l -= nt; }
+  if (l < 2 * nt) { r.role = 2; seg_decode(l, nt, 2, r.net, r.tile); return r; }
+  l -= 2 * nt;
+  if (l < nt) { r.role = 3; r.tile = l; return r; }
+  r.tile = l - nt;   // row-copy workgroup index
+  return r;
+}
+__host__ __device__ static inline int chain_pair_workgroups(int nt, int relabel, int G) { return (relabel ? 10 : 9) * nt + G; }
+
+// actor(s') of one tile as a pair (reference models.py:90-94 on next_states; training.py:21): the arithmetic of actor_fwd_tile(is_cur = false)
+__device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch& b, const float* __restrict__ eps_next, int tile, int half, float* smem, float* slab, unsigned* flag) {
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
+  const int row0 = tile * IL_TILE_R;
+  const int Sp = round_up16(S), ldx = Sp + 4, ldh = H + 4;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* part = H2s + IL_TILE_R * ldh; float* Os = part + (H >> 4) * 256;
+  const SacWs ws = sac_ws(S, A, H, B);
+  float* W = d.workspace;
+  const MlpView net = mlp_view(d.actor, S, H, 2 * A);
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, tid = threadIdx.x;
+  const int t2 = 8 * half + wave;   // this wave's output tile of the hidden layer
+  const float pb1a = gload(net.b1 + wave * 16 + j), pb1b = gload(net.b1 + min((wave + nw) * 16 + j, H - 1)), pb2 = gload(net.b2 + t2 * 16 + j);
+  L1Pre w1; l1_prefetch(w1, net.W1, S, S, Sp, H);
+  SmallPre w3pre = {};
+  if (half == 0) w3pre = tile_fwd_small_prefetch(net.W3, H, 2 * A, H);
+  float e_pre = 0.f, absorb_pre = 0.f;
+  if (half == 0 && tid < IL_TILE_R * A) {
+    const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
+    const int r = tid / A, c = tid - r * A, row = row0 + r;
+    e_pre = eps_next ? eps_next[(size_t)row * A + c] : philox_normal(d.noise_seed, ctr, IL_STREAM_EPS_NEXT, (uint32_t)(row * A + c));
+    absorb_pre = b.absorbing[brow(b, row) * b.ld_absorbing];
+  }
+  IL_TL(10, 1);
+  load_rows_cat(Xs, ldx, Sp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, IL_TILE_R, b.gather, b.gather_capacity);
+  Panel16 pn; panel_prefetch(pn, W + ws.pk_af, t2);
+  __syncthreads();
+  IL_TL(10, 2);
+  l1_compute(w1, Xs, ldx, Sp, H, [&](int c0, f32x4 acc) {
+    const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1a : pb1b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
+  });
+  __syncthreads();
+  IL_TL(10, 3);
+  tile_packed_regs(H1s, ldh, pn, t2, [&](int c0, f32x4 acc) {
+    const int col = c0 + j;
+    f32x4 hv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hv[r] = fmaxf(acc[r] + pb2, 0.f);
+    if (half == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = hv[r];
+    } else wstore4<true>(slab, (int64_t)(col - 128) * 16 + 4 * g, hv);
+  });
+  IL_TL(10, 4);
+  if (half == 1) { pair_publish(flag); IL_TL(10, 7); return; }
+  const TileTimeouts tmo = tile_timeouts(d);
+  pair_receive(flag, slab, H2s, ldh, 128, [&] { __hip_atomic_fetch_add(tmo.slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (tmo.sync) sync_timed_out(tmo.sync); });
+  IL_TL(10, 5);
+  tile_fwd_small(H2s, ldh, H, net.W3, H, 2 * A, net.b3, Os, part, &w3pre);
+  float* nl = part; float* la = part + 256;
+  if (tid < IL_TILE_R * A) {
+    const int r = tid / A, c = tid - r * A, row = row0 + r;
+    const float mean = Os[r * 16 + c], lsr = Os[r * 16 + A + c];
+    float x, a, nlp, ladj;
+    head_sample(mean, lsr, e_pre, x, a, nlp, ladj);
+    nl[r * 16 + c] = nlp; la[r * 16 + c] = ladj;
+    W[ws.n_a2 + (size_t)row * A + c] = (1.f - absorb_pre) * a;
+  }
+  __syncthreads();
+  if (tid < IL_TILE_R) {
+    float sn = 0.f, sl = 0.f;
+    for (int c = 0; c < A; ++c) { sn += nl[tid * 16 + c]; sl += la[tid * 16 + c]; }
+    W[ws.n_logp2 + row0 + tid] = (0.f - sl) + sn;
+  }
+  IL_TL(10, 6);
+}
+
+// target_k(s', a') of one tile as a pair (training.py:22): the arithmetic of critic_fwd_tile(net = 2 + k, await)
+__device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, int k, int tile, int half, float* smem, float* slab, unsigned* flag, unsigned* ctr) {
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
+  const int row0 = tile * IL_TILE_R;
+  const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh;
+  const SacWs ws = sac_ws(S, A, H, B);
+  float* W = d.workspace;
+  const MlpView p = mlp_view(d.target + k * net_stride(IN, H, 1), IN, H, 1);
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int t2 = 8 * half + wave;
+  const float pb1a = gload(p.b1 + wave * 16 + j), pb1b = gload(p.b1 + min((wave + nw) * 16 + j, H - 1)), pb2 = gload(p.b2 + t2 * 16 + j), pb3 = gload(p.b3);
+  float w3v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
+  L1Pre w1; l1_prefetch(w1, p.W1, IN, IN, INp, H);
+  load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, IL_TILE_R, b.gather, b.gather_capacity);   // s' columns, zero elsewhere
+  Panel16 pn; panel_prefetch(pn, W + ws.pk_tf + (size_t)k * H * H, t2);
+  IL_TL(10, 1);
+  tile_await_bits(ctr, 1u, 0u, tile_timeouts(d));   // a' and log pi(a'|s') of this tile
+  IL_TL(10, 2);
+  for (int i = threadIdx.x; i < IL_TILE_R * A; i += blockDim.x) { const int r = i / A, c = i - r * A; Xs[r * ldx + S + c] = W[ws.n_a2 + (size_t)(row0 + r) * A + c]; }
+  __syncthreads();
+  l1_compute(w1, Xs, ldx, INp, H, [&](int c0, f32x4 acc) {
+    const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1a : pb1b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
+  });
+  __syncthreads();
+  IL_TL(10, 3);
+  tile_packed_regs(H1s, ldh, pn, t2, [&](int c0, f32x4 acc) {
+    const int col = c0 + j;
+    f32x4 hv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hv[r] = fmaxf(acc[r] + pb2, 0.f);
+    if (half == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = hv[r];
+    } else wstore4<true>(slab, (int64_t)(col - 128) * 16 + 4 * g, hv);
+  });
+  IL_TL(10, 4);
+  if (half == 1) { pair_publish(flag); IL_TL(10, 7); return; }
+  const TileTimeouts tmo = tile_timeouts(d);
+  pair_receive(flag, slab, H2s, ldh, 128, [&] { __hip_atomic_fetch_add(tmo.slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (tmo.sync) sync_timed_out(tmo.sync); });
+  IL_TL(10, 5);
+  for (int r = wave; r < IL_TILE_R; r += nw) {   // Q = h2 . w3 + b3: one wave per row, the lane / DPP order of critic_fwd_tile
+    float sq = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int n = lane + 64 * u; if (n < H) sq += H2s[r * ldh + n] * w3v[u]; }
+    sq = wave_sum(sq);
+    if (lane == 0) W[ws.t_q + (size_t)k * B + row0 + r] = sq + pb3;
+  }
+  IL_TL(10, 6);
+}
+
+// the reward relabel of one tile as a role of its own (models.py:177-180 through disc_reward_tile: the code, thread mapping and bits of k_gail_reward)
+__device__ __forceinline__ void relabel_role(const il_sac& d, const il_batch& b, const ChainRelabel& rl, int tile, float* smem) {
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, IN = S + A;
+  const int row0 = tile * IL_TILE_R, INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
+  float* Xs = smem; float* q16 = Xs + IL_TILE_R * ldx + 2 * IL_TILE_R * ldh;
+  const SacWs ws = sac_ws(S, A, H, d.batch);
+  float* W = d.workspace;
+  load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R, b.gather, b.gather_capacity);
+  long long* sy = reinterpret_cast<long long*>(d.sync);
+  IL_TL(10, 1);
+  sync_wait(sy, IL_SYNC_PARAMS, (sy[IL_SYNC_MAIN_EPOCH] + 1) * (long long)rl.n_reduce);   // (its barrier also covers the rows above)
+  IL_TL(10, 2);
+  const RewardLds R = reward_carve(q16 + 64, rl.dd.state_dim + rl.dd.action_dim, rl.dd.hidden);
+  disc_reward_tile(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
+    W[ws.c_rew + row0 + r] = reward;
+    if (rl.out) rl.out[row0 + r] = reward;
+  });
+  IL_TL(10, 6);
+}
+
+__device__ __forceinline__ void sac_chain_pair_body(il_sac& d, il_batch& b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, const float* __restrict__ rewards,
+                                                    float* __restrict__ rows_out, ChainRelabel& rl, float* smem) {
+  const int nt = d.batch / IL_TILE_R, H = d.hidden;
+  const PairIds id = chain_pair_decode(blockIdx.x, nt, rl.on);
+  IL_TL(10, 0);
+  if (rl.wait_indices) { long long* sy = reinterpret_cast<long long*>(d.sync); sync_wait(sy, IL_SYNC_INDICES, sy[IL_SYNC_MAIN_EPOCH] + 1); }
+  if (id.role == 5) {
+    const int G = (int)gridDim.x - chain_pair_workgroups(nt, rl.on, 0), gw = id.tile;
+    const int row4 = b.ld_states / 4, lanes = d.batch * row4;
+    const f32x4* src = reinterpret_cast<const f32x4*>(b.states);
+    f32x4* dst = reinterpret_cast<f32x4*>(as_global(rows_out));
+    for (int i = gw * blockDim.x + threadIdx.x; i < lanes; i += G * blockDim.x) {
+      const int r = i / row4, c = i - r * row4;
+      dst[i] = src[brow(b, r) * row4 + c];
+    }
+    if (d.sync) sync_signal(reinterpret_cast<long long*>(d.sync) + IL_SYNC_ROWS);
+    IL_TL(10, 7);
+    return;
+  }
+  const SacWs ws = sac_ws(d.state_dim, d.action_dim, H, d.batch);
+  unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + id.tile * IL_CTR_STRIDE;
+  const int slot = id.role == 0 ? id.tile : nt + id.net * nt + id.tile;   // hop slabs / flags: [0, nt) actor(s'), [nt, 3 nt) the targets
+  float* slab = d.workspace + ws.x_slab + (size_t)slot * IL_TILE_R * (H / 2);
+  unsigned* flag = reinterpret_cast<unsigned*>(d.workspace + ws.x_flag) + slot * IL_CTR_STRIDE;
+  if (id.role == 0) {
+    actor_next_pair(d, b, eps_next, id.tile, id.half, smem, slab, flag);
+    if (id.half == 0) { tile_arrive(ctr); IL_TL(10, 7); }
+  } else if (id.role == 1) {
+    target_pair(d, b, id.net, id.tile, id.half, smem, slab, flag, ctr);
+    if (id.half == 0) { tile_arrive(ctr); IL_TL(10, 7); }
+  } else if (id.role == 4) {
+    relabel_role(d, b, rl, id.tile, smem);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 16u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    IL_TL(10, 7);
+  } else if (id.role == 2) {
+    critic_fwd_tile(d, b, id.net, id.tile, smem, nullptr);
+    IL_TL(10, 2);
+    critic_bwd_resident_gemm(d, id.net, smem);
+    IL_TL(10, 3);
+    const RowScalars rs = critic_row_scalars(b, !rl.on && !rewards && !d.sync, id.tile);
+    tile_await_bits(ctr, 3u, rl.on ? 16u : 0u, tile_timeouts(d));
+    IL_TL(10, 5);
+    if (threadIdx.x == 0 && (__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 15u) == 4u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    critic_bwd_resident_scale(d, b, rewards, rl, rs, id.net, id.tile, smem, rl.on ? d.workspace + ws.c_rew : nullptr);
+    IL_TL(10, 7);
+  } else { actor_fwd_tile(d, b, eps_next, eps_cur, true, id.tile, smem); IL_TL(10, 7); }
+}
+
+__global__ __launch_bounds__(512) void k_sac_chain_pair(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, const float* __restrict__ rewards,
+                                                        float* __restrict__ rows_out, ChainRelabel rl) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  globalize(d); globalize(b);
+  if (rl.on) { globalize(rl.dd); rl.out = as_global(rl.out); }
+  sac_chain_pair_body(d, b, eps_next, eps_cur, rewards, rows_out, rl, smem);
 }
 
 // policy-loss backward of one 16-row tile: min-Q selection, tanh-Gaussian backward, actor back-prop (dz3, dz2, dz1 for the dW kernel), alpha partial.
@@ -844,6 +1102,119 @@ IL_TILE_KERNELS(, 16, __launch_bounds__(1024))
 #define IL_POP_WAVES_PER_EU 6
 #endif
 IL_TILE_KERNELS(_pop, IL_POP_PANEL, __launch_bounds__(512, IL_POP_WAVES_PER_EU))
+
+// ---------------------------------------------------------------------------------------------
+// Pair mode of k_policy_critic (round 4): (critic k, tile) is a pair of 512-thread workgroups. Both compute the narrow first layer in full; the hidden layer's forward
+// and its backward are split by output columns (wave w of half p: output tile 8 p + w, both panels parked in registers - the backward one is requested while the forward
+// MFMAs run); after the forward the halves SWAP their 16 x 128 halves of h2 (Q and the mask w3 [h2 > 0] need whole rows; both compute them), after the backward half 1
+// sends its half of dz1 and exits, half 0 runs the dQ/da columns and arrives on the tile's counter. Helpers as in k_policy_critic. Block order: critics p = 1, p = 0,
+// helpers. A pair waits for each other: both halves must be resident - (4 + helpers) * nt <= CUs is checked by the caller. Bit-identical to k_policy_critic.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_batch& b, int k, int tile, int half, float* smem) {
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
+  const int nt = B / IL_TILE_R, row0 = tile * IL_TILE_R;
+  const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* q16 = H2s + IL_TILE_R * ldh;
+  const SacWs ws = sac_ws(S, A, H, B);
+  float* W = d.workspace;
+  const MlpView p = mlp_view(d.critic + k * net_stride(IN, H, 1), IN, H, 1);
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int t2 = 8 * half + wave;
+  // hop slots: stage A (h2 halves, both directions) [0, 4 nt): ((k nt + tile) 2 + half); stage B (dz1 half 1 -> half 0) [4 nt, 6 nt)
+  const size_t slab_floats = (size_t)IL_TILE_R * (H / 2);
+  const int sa = (k * nt + tile) * 2, sb = 4 * nt + k * nt + tile;
+  float* slabs = W + ws.x_slab; unsigned* flags = reinterpret_cast<unsigned*>(W + ws.x_flag);
+  const TileTimeouts tmo = tile_timeouts(d);
+  auto timed_out = [&] { __hip_atomic_fetch_add(tmo.slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (tmo.sync) sync_timed_out(tmo.sync); };
+  IL_TL(11, 0);
+  const float pb1a = gload(p.b1 + wave * 16 + j), pb1b = gload(p.b1 + min((wave + nw) * 16 + j, H - 1)), pb2 = gload(p.b2 + t2 * 16 + j), pb3 = gload(p.b3);
+  float w3v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
+  ColsPre w1pre = {};
+  if (half == 0) w1pre = tile_bwd_dx_cols_prefetch(p.W1, IN, IN, H, S);
+  L1Pre w1; l1_prefetch(w1, p.W1, IN, IN, INp, H);
+  load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, IL_TILE_R);
+  Panel16 pf; panel_prefetch(pf, W + ws.pk_cf + (size_t)k * H * H, t2);
+  __syncthreads();
+  IL_TL(11, 1);
+  l1_compute(w1, Xs, ldx, INp, H, [&](int c0, f32x4 acc) {
+    const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1a : pb1b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
+  });
+  __syncthreads();
+  IL_TL(11, 2);
+  Panel16 pk; panel_prefetch(pk, W + ws.pk_cb + (size_t)k * H * H, t2);   // the backward panel streams in under the forward MFMAs
+  tile_packed_regs(H1s, ldh, pf, t2, [&](int c0, f32x4 acc) {
+    const int col = c0 + j;
+    f32x4 hv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + pb2, 0.f); H2s[(4 * g + r) * ldh + col] = hv[r]; }
+    wstore4<true>(slabs + (size_t)(sa + half) * slab_floats, (int64_t)(col - 128 * half) * 16 + 4 * g, hv);
+  });
+  pair_publish(flags + (size_t)(sa + half) * IL_CTR_STRIDE);
+  IL_TL(11, 3);
+  pair_receive(flags + (size_t)(sa + 1 - half) * IL_CTR_STRIDE, slabs + (size_t)(sa + 1 - half) * slab_floats, H2s, ldh, 128 * (1 - half), timed_out);
+  IL_TL(11, 4);
+  // Q = h2 . w3 + b3 and dz2 = w3 [h2 > 0] in place: whole rows, computed by both halves (half 0 stores Q)
+  for (int r = wave; r < IL_TILE_R; r += nw) {
+    float sq = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = lane + 64 * u;
+      if (n < H) { const float h = H2s[r * ldh + n]; sq += h * w3v[u]; H2s[r * ldh + n] = h > 0.f ? w3v[u] : 0.f; }
+    }
+    sq = wave_sum(sq);
+    if (lane == 0 && half == 0) W[ws.p_q + (size_t)k * B + row0 + r] = sq + pb3;
+  }
+  __syncthreads();
+  IL_TL(11, 5);
+  tile_packed_regs(H2s, ldh, pk, t2, [&](int kb, f32x4 acc) {
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { float* h = H1s + (4 * g + r) * ldh + kb + j; o[r] = *h > 0.f ? acc[r] : 0.f; if (half == 0) *h = o[r]; }   // dz1 in place (each element owned by one lane)
+    if (half == 1) wstore4<true>(slabs + (size_t)sb * slab_floats, (int64_t)(kb + j - 128) * 16 + 4 * g, o);
+  });
+  IL_TL(11, 6);
+  if (half == 1) { pair_publish(flags + (size_t)sb * IL_CTR_STRIDE); IL_TL(11, 7); return; }
+  pair_receive(flags + (size_t)sb * IL_CTR_STRIDE, slabs + (size_t)sb * slab_floats, H1s, ldh, 128, timed_out);
+  // dQ/da = the action columns of dz1 . W1 (tile_bwd_dx_cols: the H-reduction in n-block order, independent of the wave count)
+  float* gout = W + ws.p_g + ((size_t)k * B + row0) * A;
+  tile_bwd_dx_cols(H1s, ldh, H, p.W1, IN, IN, S, S + A, q16 + 64, [&](int col, int row, float v) {
+    const int c = col - S;
+    if (c >= 0 && c < A) gout[(size_t)row * A + c] = v;
+  }, IL_SMALL_PREFETCH ? &w1pre : nullptr);
+  unsigned* ctr = reinterpret_cast<unsigned*>(W + ws.pair_ctr) + tile * IL_CTR_STRIDE;
+  tile_arrive(ctr);
+  IL_TL(11, 7);
+}
+
+__global__ __launch_bounds__(512) void k_policy_critic_pair(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, int helpers) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  globalize(d); globalize(b);
+  const int nt = d.batch / IL_TILE_R, bx = blockIdx.x;
+  if (bx >= 4 * nt) {   // helper: behind both critics' pairs of its tile in block order
+    const int h = bx - 4 * nt, tile = h % nt, part = h / nt;
+    const SacWs ws = sac_ws(d.state_dim, d.action_dim, d.hidden, d.batch);
+    unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr) + tile * IL_CTR_STRIDE;
+    if (h == 0 && threadIdx.x == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }
+    IL_TL(3, 0);
+    actor_bwd_tile<16>(d, b, tile, out_logp, out_q, smem, part, helpers, [&] {
+      IL_TL(3, 1);
+      tile_await(ctr, 2u, tile_timeouts(d));
+      IL_TL(3, 2);
+      if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u + (unsigned)helpers)
+        __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    });
+    IL_TL_END(3);
+    return;
+  }
+  const int half = bx < 2 * nt ? 1 : 0;
+  int k, tile;
+  seg_decode(bx % (2 * nt), nt, 2, k, tile);
+  policy_critic_pair(d, b, k, tile, half, smem);
+}
 
 // ---------------------------------------------------------------------------------------------
 // actor backward (training.py:38-46): L = mean(w m alpha logp - min Q).  grid = nt
@@ -1558,6 +1929,19 @@ static int pc_helpers(int nt) {
   static const int on = [] { const char* e = getenv("IL_PC_SPLIT"); return e && e[0] == '0' ? 0 : 1; }();
   return (on && (2 + IL_PC_HELPERS) * nt <= device_cu_count()) ? IL_PC_HELPERS : 0;
 }
+// Pair mode (k_sac_chain_pair / k_policy_critic_pair): H = 256, first layers of at most four 16-wide k-blocks, every workgroup of the launch resident. IL_PAIR=0 keeps
+// the 16-wave workgroups (developer A/B switch; same bits either way).
+static bool pair_env() { static const int on = [] { const char* e = getenv("IL_PAIR"); return e && e[0] == '0' ? 0 : 1; }(); return on != 0; }
+static bool pair_shape_ok(const il_sac* d) { return d->hidden == 256 && round_up16(d->state_dim + d->action_dim) <= 64; }
+static bool chain_pair_ok(const il_sac* d, int relabel, int G) { return pair_env() && pair_shape_ok(d) && chain_pair_workgroups(d->batch / IL_TILE_R, relabel, G) <= device_cu_count(); }
+static void launch_policy_critic(const il_sac* d, const il_batch* b, float* out_logp, float* out_q, size_t lds, hipStream_t st) {
+  const int H = d->hidden, nt = d->batch / IL_TILE_R;
+  IL_TRACE("k_policy_critic", st);
+  const int hp = pc_helpers(nt);
+  if (pair_env() && pair_shape_ok(d) && hp > 0 && (4 + hp) * nt <= device_cu_count()) { k_policy_critic_pair<<<(4 + hp) * nt, 512, lds, st>>>(*d, *b, out_logp, out_q, hp); return; }
+  const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt);
+  k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp);
+}
 extern "C" int il_sac_critic_step(const il_sac* d, const il_batch* b, const float* eps_next, uint32_t flags, il_stream_t stream_) {
   if (int rc = check_sac(d, b)) return rc;
   hipStream_t st = (hipStream_t)stream_;
@@ -1599,7 +1983,7 @@ extern "C" int il_sac_actor_step(const il_sac* d, const il_batch* b, const float
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 3), 256, 0, st>>>(*d, 0x07u, nullptr); }  // actor + critics (the critic may have been stepped by il_adam_step)
   { IL_TRACE("k_actor_fwd", st); k_actor_fwd<<<nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, eps_cur, 2, nullptr, nullptr); }
-  { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
+  launch_policy_critic(d, b, out_logp, out_q, lds, st);
   DwArgs a = actor_dw_args(d, b, flags);
   const int tail = (flags & IL_FLAG_GRADS_ONLY) ? 1 : IL_TAIL_BLOCKS;
   { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<a.n_dw_blocks + tail, 256, 0, st>>>(a); }
@@ -1620,7 +2004,8 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
   if (whole && chain_enabled() && 6 * nt <= device_cu_count()) {   // forward + critic loss chained per tile in one co-resident launch (k_sac_chain)
     if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
     ChainRelabel cr = {}; cr.xcd_nets = chain_xcd_nets(nt) ? 1 : 0;
-    { IL_TRACE("k_sac_chain", st); k_sac_chain<<<(cr.xcd_nets ? 8 : 6) * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr, cr); }
+    if (chain_pair_ok(d, 0, 0)) { IL_TRACE("k_sac_chain", st); k_sac_chain_pair<<<chain_pair_workgroups(nt, 0, 0), 512, lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr, cr); }
+    else { IL_TRACE("k_sac_chain", st); k_sac_chain<<<(cr.xcd_nets ? 8 : 6) * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr, cr); }
     flags |= IL_FLAG_SAC_SKIP_FORWARD | 0x80000000u;
   }
   if ((flags & IL_FLAG_SAC_FORWARD_ONLY) && !(flags & IL_FLAG_SAC_SKIP_FORWARD) && chain_enabled() && 6 * nt <= device_cu_count()) {
@@ -1643,7 +2028,7 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
     if (!(flags & 0x80000000u)) { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
     DwArgs ca = critic_dw_args(d, flags);
     { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
-    { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
+    launch_policy_critic(d, b, out_logp, out_q, lds, st);
     DwArgs aa = actor_dw_args(d, b, flags);
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + IL_TAIL_BLOCKS, 256, 0, st>>>(aa); }
   }
@@ -1718,8 +2103,11 @@ static int sac_update_gather_impl(const il_sac* d, const il_batch* rows, const i
   if (6 * nt + G > device_cu_count()) return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update_gather: %d workgroups cannot be co-resident on %d CUs (gather first, then il_sac_update)", 6 * nt + G, device_cu_count());
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
-  if (chain_xcd_nets(nt) && G <= 2 * nt) { rl.xcd_nets = 1; rl.gather_wgs = G; }
-  { IL_TRACE("k_sac_chain", st); k_sac_chain<<<rl.xcd_nets ? 8 * nt : 6 * nt + G, tile_threads(H), lds, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl); }
+  if (chain_pair_ok(d, rl.on, G)) { IL_TRACE("k_sac_chain", st); k_sac_chain_pair<<<chain_pair_workgroups(nt, rl.on, G), 512, lds, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl); }
+  else {
+    if (chain_xcd_nets(nt) && G <= 2 * nt) { rl.xcd_nets = 1; rl.gather_wgs = G; }
+    IL_TRACE("k_sac_chain", st); k_sac_chain<<<rl.xcd_nets ? 8 * nt : 6 * nt + G, tile_threads(H), lds, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl);
+  }
   DwArgs ca = critic_dw_args(d, flags);
   if (peer_critic) { DwPeer cp = {*peer_critic, 0}; IL_TRACE("k_dw_adam_critic", st); k_dw_adam_peer<<<ca.n_dw_blocks, 256, 0, st>>>(ca, cp); }
   else { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
@@ -1727,7 +2115,7 @@ static int sac_update_gather_impl(const il_sac* d, const il_batch* rows, const i
     IL_CHECK_LAUNCH("il_sac_update_gather");
     return IL_OK;
   }
-  { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *rows, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
+  launch_policy_critic(d, rows, out_logp, out_q, lds, st);
   DwArgs aa = actor_dw_args(d, rows, flags);
   if (peer_actor) {
     DwPeer ap = {*peer_actor, mlp_numel(d->state_dim, d->hidden, 2 * d->action_dim)};
@@ -2073,7 +2461,7 @@ extern "C" int il_sac_dp_phase(const il_sac* d, const il_batch* b, int32_t phase
   } else if (phase == 2) {
     const int64_t n = 2 * net_stride(S + A, H, 1);
     { IL_TRACE("k_apply_critic", st); k_apply_critic<<<(int)((n + 255) / 256), 256, 0, st>>>(*d); }
-    { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
+    launch_policy_critic(d, b, out_logp, out_q, lds, st);
     DwArgs aa = actor_dw_args(d, b, IL_FLAG_GRADS_ONLY);
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 1, 256, 0, st>>>(aa); }
   } else {
@@ -2091,12 +2479,12 @@ extern "C" int il_sac_dp_phase_peer(const il_sac* d, const il_batch* b, int32_t 
   IL_CHECK_ARG(x && x->world >= 1 && x->world <= IL_PEER_MAX_RANKS && x->rank >= 0 && x->rank < x->world && x->epoch && x->status, "il_sac_dp_phase_peer: bad peer descriptor");
   for (int r = 0; r < x->world; ++r) IL_CHECK_ARG(x->windows[r], "il_sac_dp_phase_peer: window of rank %d is not mapped", r);
   hipStream_t st = (hipStream_t)stream_;
-  const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, nt = B / IL_TILE_R;
+  const int S = d->state_dim, A = d->action_dim, H = d->hidden;
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   if (phase == 2) {
     IL_CHECK_ARG(x->n == 2 * net_stride(S + A, H, 1), "il_sac_dp_phase_peer: phase 2 takes the critic bucket (%lld floats, got %lld)", (long long)(2 * net_stride(S + A, H, 1)), (long long)x->n);
     { IL_TRACE("k_peer_apply_critic", st); k_peer_apply_critic<<<(unsigned)peer_chunks(x->n), 256, 0, st>>>(*d, *x); }
-    { IL_TRACE("k_policy_critic", st); const int hp = pc_helpers(nt); const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt); k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp); }
+    launch_policy_critic(d, b, out_logp, out_q, lds, st);
     DwArgs aa = actor_dw_args(d, b, IL_FLAG_GRADS_ONLY);
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 1, 256, 0, st>>>(aa); }
   } else {

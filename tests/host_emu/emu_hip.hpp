@@ -392,7 +392,9 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t lds_bytes, hipStream_
 }  // namespace emu
 
 
-#define EMU_LAUNCH(kernel, grid, block, lds, stream, ...) emu::launch(kernel, dim3(grid), dim3(block), (size_t)(lds), (hipStream_t)(stream), __VA_ARGS__)
+// IL_EMU_LOG_LAUNCHES=<file>: one kernel name per launch (which kernels did a test reach?)
+inline void emu_log_launch(const char* name) { static const char* f = getenv("IL_EMU_LOG_LAUNCHES"); if (f) { FILE* o = fopen(f, "a"); if (o) { fprintf(o, "%s\n", name); fclose(o); } } }
+#define EMU_LAUNCH(kernel, grid, block, lds, stream, ...) (emu_log_launch(#kernel), emu::launch(kernel, dim3(grid), dim3(block), (size_t)(lds), (hipStream_t)(stream), __VA_ARGS__))
 
 inline void __syncthreads() {
   emu::blk->fibers[emu::cur].state = emu::AT_BARRIER;
