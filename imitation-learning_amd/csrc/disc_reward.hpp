@@ -85,17 +85,33 @@ template <class Emit>
 __device__ __forceinline__ void disc_reward_tile(const il_disc& d, const RewardLds& L, const float* X, int ldX, int nrows, const float* __restrict__ logit_offset, int row0, Emit emit) {
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, Dp = (D + 3) & ~3, ldw = Dp + 4, tid = threadIdx.x;
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
-  const float b2 = d.params[lay.ob2];
+  const float b2 = gload(d.params + lay.ob2);
   {
+    // (round 4) EVERY parameter this thread stages is requested before its first LDS store: the parameters were rewritten by the AdamW launch an instant ago (each line a
+    // fabric / HBM round trip), and the load -> store loops this replaces made one such trip after the other - three for W1 in a 512-thread workgroup, then b1 / W2, then
+    // u / v: 4.5 us of the relabel's 6 (profiles/r04_update_timeline.md).
     const float* W1 = d.params + lay.oW1; const float* b1 = d.params + lay.ob1; const float* W2 = d.params + lay.oW2;
-    for (int i = tid; i < H * Dp; i += blockDim.x) { const int n = i / Dp, k = i - n * Dp; L.W1s[n * ldw + k] = k < D ? W1[(size_t)n * D + k] : 0.f; }
-    for (int i = tid; i < H; i += blockDim.x) { L.b1s[i] = b1[i]; L.W2s[i] = W2[i]; }
+    const int bd = blockDim.x, sn = d.spectral_norm, th = min(tid, H - 1), tk = min(tid, D - 1);
+    const unsigned md = fastdiv_magic(Dp);   // (H * Dp < 2^16 for every shape whose tile fits the LDS)
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int i = min(q * bd + tid, H * Dp - 1), n = fastdiv(i, md), k = min(i - n * Dp, D - 1); v[q] = gload(W1 + (size_t)n * D + k); }
+    const float vb1 = gload(b1 + th), vw2 = gload(W2 + th);
+    float vu1 = 0.f, vv2 = 0.f, vv1 = 0.f, vu2 = 0.f;
+    if (sn) { vu1 = gload(d.u1 + th); vv2 = gload(d.v2 + th); vv1 = gload(d.v1 + tk); vu2 = gload(d.u2); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int i = q * bd + tid; if (i < H * Dp) { const int n = fastdiv(i, md), k = i - n * Dp; L.W1s[n * ldw + k] = k < D ? v[q] : 0.f; } }
+    for (int i = 4 * bd + tid; i < H * Dp; i += bd) { const int n = i / Dp, k = i - n * Dp; L.W1s[n * ldw + k] = k < D ? W1[(size_t)n * D + k] : 0.f; }   // (shapes beyond four elements per thread)
+    if (tid < H) { L.b1s[tid] = vb1; L.W2s[tid] = vw2; }
+    for (int i = bd + tid; i < H; i += bd) { L.b1s[i] = b1[i]; L.W2s[i] = W2[i]; }
+    if (sn) {
+      if (tid < H) { L.u1[tid] = vu1; L.v2[tid] = vv2; }
+      for (int i = bd + tid; i < H; i += bd) { L.u1[i] = d.u1[i]; L.v2[i] = d.v2[i]; }
+      if (tid < Dp) L.v1[tid] = tid < D ? vv1 : 0.f;
+      for (int i = bd + tid; i < Dp; i += bd) L.v1[i] = i < D ? d.v1[i] : 0.f;
+      if (tid == 0) L.sc[2] = vu2;
+    } else if (tid == 0) { L.sc[0] = 1.f; L.sc[1] = 1.f; }
   }
-  if (d.spectral_norm) {
-    for (int i = tid; i < H; i += blockDim.x) { L.u1[i] = d.u1[i]; L.v2[i] = d.v2[i]; }
-    for (int i = tid; i < Dp; i += blockDim.x) L.v1[i] = i < D ? d.v1[i] : 0.f;
-    if (tid == 0) L.sc[2] = d.u2[0];
-  } else if (tid == 0) { L.sc[0] = 1.f; L.sc[1] = 1.f; }
   __syncthreads();
   if (d.spectral_norm && tid < 64) sn_wave(L.W1s, L.W2s, D, H, L.u1, L.v1, &L.sc[2], L.v2, false, L.sc);  // eval mode: sigma only
   __syncthreads();

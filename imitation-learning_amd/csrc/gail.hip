@@ -503,7 +503,9 @@ extern "C" int il_gail_disc_step(const il_disc* d, const il_batch* pol, const il
   }
   { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, eps_gp, x, nullptr, nullptr, nullptr, GailSampler{}, 0); }
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
-  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr, (flags & IL_FLAG_GAIL_CLOSE_EPOCH) ? 1 : 0, il_peer_bucket{}); }
+  // (1 KB of LDS it never touches: a workgroup with no LDS can be placed on a CU whose LDS a pair-mode workgroup of the SAC branch holds entirely - sac.hip
+  // IL_PAIR_LDS_BYTES - and its loads then queue behind that workgroup's weight stream: measured 4.95 -> 9.4 us for this launch, the relabel 4 us later)
+  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 1024, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr, (flags & IL_FLAG_GAIL_CLOSE_EPOCH) ? 1 : 0, il_peer_bucket{}); }
   IL_CHECK_LAUNCH("il_gail_disc_step");
   return IL_OK;
 }
@@ -531,7 +533,7 @@ static int gail_disc_step_draw_impl(const il_disc* d, const il_batch* pol, const
     for (int r = 0; r < peer->world; ++r) IL_CHECK_ARG(peer->windows[r], "il_gail_disc_step_draw_peer: window of rank %d is not mapped", r);
     px = *peer;
   }
-  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 0, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr, (flags & IL_FLAG_GAIL_CLOSE_EPOCH) ? 1 : 0, px); }
+  { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<(int)((P + 255) / 256), 256, 1024, st>>>(*d, (flags & IL_FLAG_GRADS_ONLY) ? 0 : 1, nullptr, (flags & IL_FLAG_GAIL_CLOSE_EPOCH) ? 1 : 0, px); }
   IL_CHECK_LAUNCH("il_gail_disc_step_draw");
   return IL_OK;
 }

@@ -97,6 +97,10 @@ __device__ __forceinline__ void globalize(il_sample_args& a) {
   a.ring_state_b = as_global(a.ring_state_b); a.ring_b = as_global(a.ring_b); a.idx_b = as_global(a.idx_b); a.rows_b = as_global(a.rows_b);
 }
 
+// x / d for 0 <= x < 2^16, 1 <= d <= 2^10 as one v_mul_hi (a runtime integer division is ~40 VALU instructions; the staging loops of the pair-mode tiles and of the
+// discriminator's reward tile did twenty of them per thread: measured as 2 us of prologue). m = fastdiv_magic(d) is wave-uniform.
+__device__ __forceinline__ unsigned fastdiv_magic(int d) { return 0xFFFFFFFFu / (unsigned)d + 1u; }
+__device__ __forceinline__ int fastdiv(int x, unsigned m) { return m ? (int)(((unsigned long long)(unsigned)x * m) >> 32) : x; }   // (m = 0: d = 1, whose magic does not fit 32 bits)
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // Cross-lane sums on DPP (data-parallel primitives: the operand of a VALU op is fetched from another lane of the same 16-lane

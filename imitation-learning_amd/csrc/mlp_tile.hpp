@@ -319,6 +319,10 @@ __device__ __forceinline__ void tile_bwd_packed(const float* dYs, int ldy, int H
 // halves in full - cheaper than a hop. With 256 VGPRs a wave parks its whole 16 KB panel of the NEXT big layer in registers while the current phase runs.
 // ---------------------------------------------------------------------------------------------
 struct Panel16 { f32x4 b[16]; };
+// Between the small requests of a tile's prologue (row indices, W1, biases, rows) and its panel requests: a bare s_barrier (no fence, no wait). A CU returns its loads
+// in request order ACROSS its waves, so a wave that runs a little behind the others (the one that announced, the head threads) would otherwise find its few small loads
+// queued behind seven other waves' 16 KB panels (224 KB at ~75 GB/s = 3 us: measured as a 4.3 us prologue of k_policy_critic_pair).
+__device__ __forceinline__ void issue_fence() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
 // the 16 lane-ordered weight blocks of output tile t (H = 256: nb = 16), requested at once
 __device__ __forceinline__ void panel_prefetch(Panel16& p, const float* __restrict__ P, int t) {
   const float* pp = P + (size_t)t * 16 * 256 + (threadIdx.x & 63) * 4;
@@ -343,70 +347,121 @@ __device__ __forceinline__ void tile_packed_regs(const float* As, int lda, const
   const f32x4 acc = acc0 + acc1;
   epi(t * 16, acc);
 }
-// The narrow first layer (Kpad <= 64, N = 32 waves' worth of columns over 8 waves: two column tiles per wave, c0 = 16 wave and 16 (wave + nw)) with its weight lanes
-// requested BEFORE the rows are in LDS; k-blocks beyond Kpad repeat the last one's address (never used). Same loads (load4<MODE>, same arguments) and the same MFMA
-// order per 16-wide k-block as tile_fwd_impl: same bits.
-struct L1Pre { f32x4 b[2][4]; };
-template <int MODE>
-__device__ __forceinline__ void l1_prefetch_impl(L1Pre& w, const float* __restrict__ W, int ldw, int Kw, int Kpad, int N) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, j = lane & 15, g = lane >> 4;
+// The narrow first layer (Kpad <= 64) of a pair-mode tile. Read as MFMA operands straight from the torch [N][Kw] matrix it is 16 scattered dword loads per lane and column
+// tile when the rows are not 16-byte aligned (Kw = 18: 1.7 us of texture-address time per CU, measured as the first version's prologue): here the matrix is pulled in as
+// whole 16-byte lanes (N * Kw / 4 of them, contiguous; <= 8 per thread), left in LDS as W1s[N][Kpad + 4] with zero columns behind Kw, and the operands come from there.
+// Zero weights against the zero-padded rows give the same exact +0 products as the clamped addresses of load4<MODE>: same bits. Everything is REQUESTED first (w1_issue,
+// rows_idx / rows_issue, then the hidden layer's panel) and committed to LDS afterwards, so the small loads are at the head of the CU's in-order return queue.
+struct W1Pre { f32x4 v[8]; };
+__device__ __forceinline__ void w1_issue(W1Pre& w, const float* __restrict__ W, int nlanes) {   // W 16-byte aligned, nlanes = N * Kw / 4
+  const int bd = blockDim.x, tid = threadIdx.x;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int c0 = min((wave + q * nw) * 16, N - 16);
-    const float* wr = W + (size_t)(c0 + j) * ldw;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) w.b[q][u] = load4<MODE>(wr, min(16 * u, Kpad - 16) + 4 * g, Kw);
-  }
-  __builtin_amdgcn_sched_barrier(0);
+  for (int q = 0; q < 8; ++q) if (q * bd < nlanes) w.v[q] = gload4(W + 4 * (size_t)min(q * bd + tid, nlanes - 1));
 }
-__device__ __forceinline__ void l1_prefetch(L1Pre& w, const float* __restrict__ W, int ldw, int Kw, int Kpad, int N) {
-  const bool aligned = ((ldw & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
-  if (aligned && Kw == Kpad) l1_prefetch_impl<0>(w, W, ldw, Kw, Kpad, N);
-  else if (aligned && (Kw & 3) == 0 && Kw >= 4) l1_prefetch_impl<1>(w, W, ldw, Kw, Kpad, N);
-  else l1_prefetch_impl<2>(w, W, ldw, Kw, Kpad, N);
+__device__ __forceinline__ void w1_commit(const W1Pre& w, float* W1s, int ldw1, int Kw, int Kpad, int N, int nlanes) {
+  const int bd = blockDim.x, tid = threadIdx.x;
+  const unsigned mk = fastdiv_magic(Kw);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) if (q * bd < nlanes) {
+    const int i = q * bd + tid;
+    if (i < nlanes) {
+      int n = fastdiv(4 * i, mk), k = 4 * i - n * Kw;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { W1s[n * ldw1 + k] = w.v[q][c]; if (++k == Kw) { k = 0; ++n; } }
+    }
+  }
+  const int pad = Kpad - Kw;
+  if (pad > 0) { const unsigned mp = fastdiv_magic(pad); for (int i = tid; i < N * pad; i += bd) { const int n = fastdiv(i, mp), k = i - n * pad; W1s[n * ldw1 + Kw + k] = 0.f; } }
 }
 template <class Epi>
-__device__ __forceinline__ void l1_compute(const L1Pre& w, const float* Xs, int ldx, int Kpad, int N, Epi epi) {
+__device__ __forceinline__ void l1_compute_lds(const float* W1s, int ldw1, const float* Xs, int ldx, int Kpad, int N, Epi epi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, j = lane & 15, g = lane >> 4;
   const float* xr = Xs + j * ldx + 4 * g;
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int c0 = (wave + q * nw) * 16;
-    if (c0 >= N) break;
+  for (int c0 = wave * 16; c0 < N; c0 += nw * 16) {
+    const float* wr = W1s + (c0 + j) * ldw1 + 4 * g;
     f32x4 acc0 = zero4(), acc1 = zero4();
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (16 * u < Kpad) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * u);
-        acc0 = mfma16(a[0], w.b[q][u][0], acc0);
-        acc1 = mfma16(a[1], w.b[q][u][1], acc1);
-        acc0 = mfma16(a[2], w.b[q][u][2], acc0);
-        acc1 = mfma16(a[3], w.b[q][u][3], acc1);
-      }
+    for (int k0 = 0; k0 < Kpad; k0 += 16) {   // the per-k-block MFMA order of tile_fwd_impl
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xr + k0), bq = *reinterpret_cast<const f32x4*>(wr + k0);
+      acc0 = mfma16(a[0], bq[0], acc0);
+      acc1 = mfma16(a[1], bq[1], acc1);
+      acc0 = mfma16(a[2], bq[2], acc0);
+      acc1 = mfma16(a[3], bq[3], acc1);
     }
     const f32x4 acc = acc0 + acc1;
     epi(c0, acc);
   }
 }
+// The tile's [16][Kpad] input rows (load_rows_cat's values: cat(f1, f2), zero-padded; through il_batch.gather when `gather`), two elements per thread at most
+// (16 * Kpad <= 2 * blockDim.x): index, then element, requested into registers; rows_commit writes them to LDS.
+struct RowsPre { int64_t sr[2]; float v[2]; };
+__device__ __forceinline__ void rows_idx(RowsPre& p, int Kpad, int row0, const int32_t* __restrict__ gather) {
+  const int bd = blockDim.x, tid = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) { const int r = fastdiv(min(q * bd + tid, IL_TILE_R * Kpad - 1), fastdiv_magic(Kpad)); p.sr[q] = gather ? (int64_t)gload(gather + row0 + r) : (int64_t)(row0 + r); }
+}
+__device__ __forceinline__ void rows_issue(RowsPre& p, int Kpad, const float* __restrict__ f1, int ld1, int K1, const float* __restrict__ f2, int ld2, int K2, int row0,
+                                           bool gathered, int64_t capacity, bool f2_dense) {
+  const int bd = blockDim.x, tid = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = min(q * bd + tid, IL_TILE_R * Kpad - 1), r = fastdiv(i, fastdiv_magic(Kpad)), k = i - r * Kpad;
+    int64_t sr = p.sr[q];
+    if (gathered) sr = sr < 0 ? 0 : (sr >= capacity ? capacity - 1 : sr);
+    const float* a = f1 + (size_t)sr * ld1 + min(k, K1 - 1);
+    if (f2 && k >= K1) a = f2 + (size_t)(f2_dense ? (int64_t)(row0 + r) : sr) * ld2 + min(k - K1, K2 - 1);
+    p.v[q] = gload(a);
+  }
+}
+__device__ __forceinline__ void rows_commit(const RowsPre& p, float* Xs, int ldx, int Kpad, int Kvalid) {
+  const int bd = blockDim.x, tid = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = q * bd + tid;
+    if (i < IL_TILE_R * Kpad) { const int r = fastdiv(i, fastdiv_magic(Kpad)), k = i - r * Kpad; Xs[r * ldx + k] = k < Kvalid ? p.v[q] : 0.f; }
+  }
+}
 // The hop between the halves of a pair. Slab: [128 columns][16 rows] floats, one 16-byte lane = 4 rows of one column (what an MFMA accumulator lane holds).
-// Producer: wstore4<true> (sc0 sc1) lanes, then pair_publish (every wave drains its stores; barrier; ONE relaxed agent-scope flag store). Consumer: pair_await (one
-// polling lane, bounded like every device-side wait; barrier), pair_load4 (sc0 sc1: served below this CU's L1), then thread 0 clears the flag for the next launch.
+// Flag line (128 bytes per slab): word 0 = the flag (producer: 1; consumer: back to 0), word 1 = the CONSUMER's XCD + 1 (announced at its start, cleared with the flag).
+// Producer: pair_store lanes, then pair_publish (every wave drains its stores; barrier; ONE relaxed agent-scope flag store). Consumer: pair_announce at its start;
+// pair_receive (one polling lane, bounded like every device-side wait; barrier; sc0 sc1 loads: never served by this CU's L1; thread 0 clears the line).
+// Two store flavours, chosen per wave (IL_PAIR_L2_HOP): if the consumer has announced the producer's own XCD (HW_REG_XCC_ID - checked, not assumed from the block id), the
+// halves share an L2: plain stores are complete for every CU of the XCD once vmcnt says so (the vector L1 writes through), and the consumer's L1-bypassing loads hit that
+// L2 - no trip to HBM on either side (measured: publish 1.3 -> x us, receive 1.0 -> x us). Otherwise (other XCD, or not announced yet): write-through (sc0 sc1) stores,
+// the form that is valid under any placement (MI355X guide, "Valid forms").
+#ifndef IL_PAIR_L2_HOP
+#define IL_PAIR_L2_HOP 1
+#endif
+__device__ __forceinline__ unsigned il_xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 0xfu; }
 __device__ __forceinline__ f32x4 pair_load4(const float* base, int64_t off) {
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7ffffff0, 0x00020000);
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off * 4), 0, 17));   // sc0 | sc1
 }
-__device__ __forceinline__ void pair_publish(unsigned* flag) {
+__device__ __forceinline__ void pair_announce(unsigned* line) {   // consumer, first thing
+  if (threadIdx.x == 0) __hip_atomic_store(line + 1, il_xcc_id() + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool pair_same_xcd(unsigned* line) {   // producer, a little before its stores (the load's latency hides under the MFMAs); wave-uniform
+#if IL_PAIR_L2_HOP
+  return __hip_atomic_load(line + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == il_xcc_id() + 1u;
+#else
+  return false;
+#endif
+}
+__device__ __forceinline__ void pair_store(float* slab, int64_t off, const f32x4& v, bool same_xcd) {
+  if (same_xcd) *reinterpret_cast<f32x4*>(slab + off) = v;
+  else wstore4<true>(slab, off, v);
+}
+__device__ __forceinline__ void pair_publish(unsigned* line) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) __hip_atomic_store(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // copies the partner's 16 x 128 half out of `slab` into columns [c_base, c_base + 128) of the [16][ld] LDS tile; every thread calls (barriers inside)
 template <class Timeout>
-__device__ __forceinline__ void pair_receive(unsigned* flag, const float* slab, float* Ts, int ld, int c_base, Timeout timed_out) {
+__device__ __forceinline__ void pair_receive(unsigned* line, const float* slab, float* Ts, int ld, int c_base, Timeout timed_out) {
   if (threadIdx.x == 0) {
     int spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-      __builtin_amdgcn_s_sleep(2);
+    while (__hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      __builtin_amdgcn_s_sleep(1);
       if (++spins > IL_SYNC_SPIN_LIMIT) { timed_out(); break; }
     }
   }
@@ -417,7 +472,10 @@ __device__ __forceinline__ void pair_receive(unsigned* flag, const float* slab, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) Ts[(r4 + q) * ld + c_base + c] = v[q];
   }
-  if (threadIdx.x == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: ready for the next launch (which follows this one in stream order)
+  if (threadIdx.x == 0) {   // consumed: ready for the next launch (which follows this one in stream order)
+    __hip_atomic_store(line, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(line + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __syncthreads();
 }
 

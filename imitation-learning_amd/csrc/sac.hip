@@ -43,7 +43,8 @@ __host__ __device__ inline SacWs sac_ws(int S, int A, int H, int B) {
   w.p_q = take(2 * B); w.p_g = take(2 * BA); w.a_dz3 = take((int64_t)B * 16); w.a_dz2 = take(BH); w.a_dz1 = take(BH); w.alpha_part = take(B / IL_TILE_R + 4); w.pair_ctr = take((int64_t)(B / IL_TILE_R) * IL_CTR_STRIDE + 4); w.chain_ctr = take((int64_t)(B / IL_TILE_R) * IL_CTR_STRIDE + 4);
   const int64_t HH = (int64_t)H * H;
   w.pk_af = take(HH); w.pk_ab = take(HH); w.pk_cf = take(2 * HH); w.pk_cb = take(2 * HH); w.pk_tf = take(2 * HH); w.pk_tb = take(2 * HH);
-  w.x_slab = take((int64_t)6 * (B / IL_TILE_R) * IL_TILE_R * (H / 2)); w.x_flag = take((int64_t)6 * (B / IL_TILE_R) * IL_CTR_STRIDE + 4); w.c_rew = take(B);
+  o = (o + 31) & ~(int64_t)31;   // slabs and flag lines start on 128-byte lines of their own
+  w.x_slab = take((int64_t)6 * (B / IL_TILE_R) * IL_TILE_R * (H / 2)); o = (o + 31) & ~(int64_t)31; w.x_flag = take((int64_t)6 * (B / IL_TILE_R) * IL_CTR_STRIDE + 32); w.c_rew = take(B);
   w.total = o;
   return w;
 }
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask, const i
   {
     for (int i = threadIdx.x; i < d.batch / IL_TILE_R; i += blockDim.x) { reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr)[i * IL_CTR_STRIDE] = 0u; reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr)[i * IL_CTR_STRIDE] = 0u; }
     if (threadIdx.x == 0) reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr)[(d.batch / IL_TILE_R) * IL_CTR_STRIDE + 1] = 0u;   // il_sac_handoff_timeouts counts from here
-    for (int i = threadIdx.x; i < 6 * (d.batch / IL_TILE_R); i += blockDim.x) reinterpret_cast<unsigned*>(d.workspace + ws.x_flag)[i * IL_CTR_STRIDE] = 0u;   // pair-mode hop flags (their consumers clear them; this covers a reused arena)
+    for (int i = threadIdx.x; i < 6 * (d.batch / IL_TILE_R); i += blockDim.x) { reinterpret_cast<unsigned*>(d.workspace + ws.x_flag)[i * IL_CTR_STRIDE] = 0u; reinterpret_cast<unsigned*>(d.workspace + ws.x_flag)[i * IL_CTR_STRIDE + 1] = 0u; }   // pair-mode hop flags (their consumers clear them; this covers a reused arena)
   }
   if (!((mask >> net) & 1u)) return;
   const int64_t HH = (int64_t)H * H, ns = net_stride(IN, H, 1);
@@ -645,40 +646,54 @@ __device__ __forceinline__ PairIds chain_pair_decode(int bid, int nt, int relabe
 }
 __host__ __device__ static inline int chain_pair_workgroups(int nt, int relabel, int G) { return (relabel ? 10 : 9) * nt + G; }
 
+// LDS of a pair-mode tile: the tile kernels' carve (tile_lds_bytes) followed by W1s[H][Kpad + 4]
+__device__ __forceinline__ float* pair_w1s(float* smem, int in_pad, int H) { return smem + IL_TILE_R * (in_pad + 4) + 2 * IL_TILE_R * (H + 4) + (H >> 4) * 256 + 256 + 64; }
 // actor(s') of one tile as a pair (reference models.py:90-94 on next_states; training.py:21): the arithmetic of actor_fwd_tile(is_cur = false)
 __device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch& b, const float* __restrict__ eps_next, int tile, int half, float* smem, float* slab, unsigned* flag) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
   const int row0 = tile * IL_TILE_R;
-  const int Sp = round_up16(S), ldx = Sp + 4, ldh = H + 4;
+  const int Sp = round_up16(S), ldx = Sp + 4, ldh = H + 4, ldw1 = Sp + 4;
   float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* part = H2s + IL_TILE_R * ldh; float* Os = part + (H >> 4) * 256;
+  float* W1s = pair_w1s(smem, Sp, H);
   const SacWs ws = sac_ws(S, A, H, B);
   float* W = d.workspace;
   const MlpView net = mlp_view(d.actor, S, H, 2 * A);
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, tid = threadIdx.x;
   const int t2 = 8 * half + wave;   // this wave's output tile of the hidden layer
+  if (half == 0) pair_announce(flag);
+  // requests, smallest first: row indices, W1, biases, the rows, then the hidden layer's panel
+  RowsPre rp; rows_idx(rp, Sp, row0, b.gather);
+  const bool head_thread = half == 0 && tid < IL_TILE_R * A;
+  const int hr = tid / A, hc = tid - hr * A;
+  int64_t hidx = row0 + min(hr, IL_TILE_R - 1);
+  if (head_thread && b.gather) hidx = gload(b.gather + row0 + hr);
+  const int w1_lanes = H * S / 4;
+  W1Pre w1; w1_issue(w1, net.W1, w1_lanes);
   const float pb1a = gload(net.b1 + wave * 16 + j), pb1b = gload(net.b1 + min((wave + nw) * 16 + j, H - 1)), pb2 = gload(net.b2 + t2 * 16 + j);
-  L1Pre w1; l1_prefetch(w1, net.W1, S, S, Sp, H);
+  const uint32_t nctr = (half == 0 && d.noise_counter) ? gload(d.noise_counter) : 0u;
+  __builtin_amdgcn_sched_barrier(0);
+  rows_issue(rp, Sp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, b.gather != nullptr, b.gather_capacity, false);
+  float absorb_pre = 0.f;
+  if (head_thread) { if (b.gather) hidx = hidx < 0 ? 0 : (hidx >= b.gather_capacity ? b.gather_capacity - 1 : hidx); absorb_pre = gload(b.absorbing + (size_t)hidx * b.ld_absorbing); }
   SmallPre w3pre = {};
   if (half == 0) w3pre = tile_fwd_small_prefetch(net.W3, H, 2 * A, H);
-  float e_pre = 0.f, absorb_pre = 0.f;
-  if (half == 0 && tid < IL_TILE_R * A) {
-    const uint32_t ctr = d.noise_counter ? *d.noise_counter : 0u;
-    const int r = tid / A, c = tid - r * A, row = row0 + r;
-    e_pre = eps_next ? eps_next[(size_t)row * A + c] : philox_normal(d.noise_seed, ctr, IL_STREAM_EPS_NEXT, (uint32_t)(row * A + c));
-    absorb_pre = b.absorbing[brow(b, row) * b.ld_absorbing];
-  }
+  // (The panel of the hidden layer is NOT requested here: a wave that issues 16 KB of loads is held at the issue stage until the CU's memory pipeline has taken them -
+  // with eight waves doing so, ~0.85 us per panel during which it cannot commit its rows; measured as a 4.8 us prologue of the first pair-mode k_policy_critic with two
+  // panels parked. Requested right before its MFMAs, the panel streams in under them - the schedule of tile_packed.)
   IL_TL(10, 1);
-  load_rows_cat(Xs, ldx, Sp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, IL_TILE_R, b.gather, b.gather_capacity);
-  Panel16 pn; panel_prefetch(pn, W + ws.pk_af, t2);
+  w1_commit(w1, W1s, ldw1, S, Sp, H, w1_lanes);
+  rows_commit(rp, Xs, ldx, Sp, S);
   __syncthreads();
   IL_TL(10, 2);
-  l1_compute(w1, Xs, ldx, Sp, H, [&](int c0, f32x4 acc) {
+  l1_compute_lds(W1s, ldw1, Xs, ldx, Sp, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1a : pb1b;
 #pragma unroll
     for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
   });
+  const bool near = half == 1 && pair_same_xcd(flag);
   __syncthreads();
   IL_TL(10, 3);
+  Panel16 pn; panel_prefetch(pn, W + ws.pk_af, t2);
   tile_packed_regs(H1s, ldh, pn, t2, [&](int c0, f32x4 acc) {
     const int col = c0 + j;
     f32x4 hv;
@@ -687,22 +702,25 @@ __device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch&
     if (half == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = hv[r];
-    } else wstore4<true>(slab, (int64_t)(col - 128) * 16 + 4 * g, hv);
+    } else pair_store(slab, (int64_t)(col - 128) * 16 + 4 * g, hv, near);
   });
   IL_TL(10, 4);
   if (half == 1) { pair_publish(flag); IL_TL(10, 7); return; }
+  // the noise of the head (Philox + Box-Muller: ~1 us of dependent ALU work) is drawn while the partner's half is on its way
+  float e_pre = 0.f;
+  if (head_thread) e_pre = eps_next ? eps_next[(size_t)(row0 + hr) * A + hc] : philox_normal(d.noise_seed, nctr, IL_STREAM_EPS_NEXT, (uint32_t)((row0 + hr) * A + hc));
   const TileTimeouts tmo = tile_timeouts(d);
   pair_receive(flag, slab, H2s, ldh, 128, [&] { __hip_atomic_fetch_add(tmo.slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (tmo.sync) sync_timed_out(tmo.sync); });
   IL_TL(10, 5);
   tile_fwd_small(H2s, ldh, H, net.W3, H, 2 * A, net.b3, Os, part, &w3pre);
   float* nl = part; float* la = part + 256;
-  if (tid < IL_TILE_R * A) {
-    const int r = tid / A, c = tid - r * A, row = row0 + r;
-    const float mean = Os[r * 16 + c], lsr = Os[r * 16 + A + c];
+  if (head_thread) {
+    const int row = row0 + hr;
+    const float mean = Os[hr * 16 + hc], lsr = Os[hr * 16 + A + hc];
     float x, a, nlp, ladj;
     head_sample(mean, lsr, e_pre, x, a, nlp, ladj);
-    nl[r * 16 + c] = nlp; la[r * 16 + c] = ladj;
-    W[ws.n_a2 + (size_t)row * A + c] = (1.f - absorb_pre) * a;
+    nl[hr * 16 + hc] = nlp; la[hr * 16 + hc] = ladj;
+    W[ws.n_a2 + (size_t)row * A + hc] = (1.f - absorb_pre) * a;
   }
   __syncthreads();
   if (tid < IL_TILE_R) {
@@ -718,31 +736,39 @@ __device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, 
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int row0 = tile * IL_TILE_R;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
-  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* W1s = pair_w1s(smem, INp, H);
+  const int ldw1 = INp + 4, w1_lanes = H * IN / 4;
   const SacWs ws = sac_ws(S, A, H, B);
   float* W = d.workspace;
   const MlpView p = mlp_view(d.target + k * net_stride(IN, H, 1), IN, H, 1);
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int t2 = 8 * half + wave;
+  if (half == 0) pair_announce(flag);
+  RowsPre rp; rows_idx(rp, INp, row0, b.gather);
+  W1Pre w1; w1_issue(w1, p.W1, w1_lanes);
   const float pb1a = gload(p.b1 + wave * 16 + j), pb1b = gload(p.b1 + min((wave + nw) * 16 + j, H - 1)), pb2 = gload(p.b2 + t2 * 16 + j), pb3 = gload(p.b3);
   float w3v[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
-  L1Pre w1; l1_prefetch(w1, p.W1, IN, IN, INp, H);
-  load_rows_cat(Xs, ldx, INp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, IL_TILE_R, b.gather, b.gather_capacity);   // s' columns, zero elsewhere
+  __builtin_amdgcn_sched_barrier(0);
+  rows_issue(rp, INp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, b.gather != nullptr, b.gather_capacity, false);   // s' columns, zero elsewhere
+  issue_fence();
   Panel16 pn; panel_prefetch(pn, W + ws.pk_tf + (size_t)k * H * H, t2);
+  w1_commit(w1, W1s, ldw1, IN, INp, H, w1_lanes);
+  rows_commit(rp, Xs, ldx, INp, S);
   IL_TL(10, 1);
-  tile_await_bits(ctr, 1u, 0u, tile_timeouts(d));   // a' and log pi(a'|s') of this tile
+  tile_await_bits(ctr, 1u, 0u, tile_timeouts(d));   // a' and log pi(a'|s') of this tile (its barrier also covers the LDS writes above)
   IL_TL(10, 2);
   for (int i = threadIdx.x; i < IL_TILE_R * A; i += blockDim.x) { const int r = i / A, c = i - r * A; Xs[r * ldx + S + c] = W[ws.n_a2 + (size_t)(row0 + r) * A + c]; }
   __syncthreads();
-  l1_compute(w1, Xs, ldx, INp, H, [&](int c0, f32x4 acc) {
+  l1_compute_lds(W1s, ldw1, Xs, ldx, INp, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1a : pb1b;
 #pragma unroll
     for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
   });
   __syncthreads();
   IL_TL(10, 3);
+  const bool near = half == 1 && pair_same_xcd(flag);
   tile_packed_regs(H1s, ldh, pn, t2, [&](int c0, f32x4 acc) {
     const int col = c0 + j;
     f32x4 hv;
@@ -751,7 +777,7 @@ __device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, 
     if (half == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = hv[r];
-    } else wstore4<true>(slab, (int64_t)(col - 128) * 16 + 4 * g, hv);
+    } else pair_store(slab, (int64_t)(col - 128) * 16 + 4 * g, hv, near);
   });
   IL_TL(10, 4);
   if (half == 1) { pair_publish(flag); IL_TL(10, 7); return; }
@@ -1114,7 +1140,8 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R, row0 = tile * IL_TILE_R;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
-  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* q16 = H2s + IL_TILE_R * ldh;
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* q16 = H2s + IL_TILE_R * ldh; float* W1s = pair_w1s(smem, INp, H);
+  const int ldw1 = INp + 4, w1_lanes = H * IN / 4;
   const SacWs ws = sac_ws(S, A, H, B);
   float* W = d.workspace;
   const MlpView p = mlp_view(d.critic + k * net_stride(IN, H, 1), IN, H, 1);
@@ -1127,31 +1154,36 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
   const TileTimeouts tmo = tile_timeouts(d);
   auto timed_out = [&] { __hip_atomic_fetch_add(tmo.slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (tmo.sync) sync_timed_out(tmo.sync); };
   IL_TL(11, 0);
+  pair_announce(flags + (size_t)(sa + 1 - half) * IL_CTR_STRIDE);   // consumer of the partner's h2 half ...
+  if (half == 0) pair_announce(flags + (size_t)sb * IL_CTR_STRIDE);   // ... and of its dz1 half
+  RowsPre rp; rows_idx(rp, INp, row0, nullptr);
+  W1Pre w1; w1_issue(w1, p.W1, w1_lanes);
+  rows_issue(rp, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, false, 0, true);
   const float pb1a = gload(p.b1 + wave * 16 + j), pb1b = gload(p.b1 + min((wave + nw) * 16 + j, H - 1)), pb2 = gload(p.b2 + t2 * 16 + j), pb3 = gload(p.b3);
   float w3v[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
   ColsPre w1pre = {};
   if (half == 0) w1pre = tile_bwd_dx_cols_prefetch(p.W1, IN, IN, H, S);
-  L1Pre w1; l1_prefetch(w1, p.W1, IN, IN, INp, H);
-  load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, IL_TILE_R);
-  Panel16 pf; panel_prefetch(pf, W + ws.pk_cf + (size_t)k * H * H, t2);
+  w1_commit(w1, W1s, ldw1, IN, INp, H, w1_lanes);
+  rows_commit(rp, Xs, ldx, INp, IN);
   __syncthreads();
   IL_TL(11, 1);
-  l1_compute(w1, Xs, ldx, INp, H, [&](int c0, f32x4 acc) {
+  l1_compute_lds(W1s, ldw1, Xs, ldx, INp, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1a : pb1b;
 #pragma unroll
     for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
   });
   __syncthreads();
   IL_TL(11, 2);
-  Panel16 pk; panel_prefetch(pk, W + ws.pk_cb + (size_t)k * H * H, t2);   // the backward panel streams in under the forward MFMAs
+  const bool near_a = pair_same_xcd(flags + (size_t)(sa + half) * IL_CTR_STRIDE);
+  Panel16 pf; panel_prefetch(pf, W + ws.pk_cf + (size_t)k * H * H, t2);   // (requested right before their MFMAs, like tile_packed: see actor_next_pair)
   tile_packed_regs(H1s, ldh, pf, t2, [&](int c0, f32x4 acc) {
     const int col = c0 + j;
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + pb2, 0.f); H2s[(4 * g + r) * ldh + col] = hv[r]; }
-    wstore4<true>(slabs + (size_t)(sa + half) * slab_floats, (int64_t)(col - 128 * half) * 16 + 4 * g, hv);
+    pair_store(slabs + (size_t)(sa + half) * slab_floats, (int64_t)(col - 128 * half) * 16 + 4 * g, hv, near_a);
   });
   pair_publish(flags + (size_t)(sa + half) * IL_CTR_STRIDE);
   IL_TL(11, 3);
@@ -1170,11 +1202,13 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
   }
   __syncthreads();
   IL_TL(11, 5);
+  const bool near_b = half == 1 && pair_same_xcd(flags + (size_t)sb * IL_CTR_STRIDE);
+  Panel16 pk; panel_prefetch(pk, W + ws.pk_cb + (size_t)k * H * H, t2);
   tile_packed_regs(H2s, ldh, pk, t2, [&](int kb, f32x4 acc) {
     f32x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { float* h = H1s + (4 * g + r) * ldh + kb + j; o[r] = *h > 0.f ? acc[r] : 0.f; if (half == 0) *h = o[r]; }   // dz1 in place (each element owned by one lane)
-    if (half == 1) wstore4<true>(slabs + (size_t)sb * slab_floats, (int64_t)(kb + j - 128) * 16 + 4 * g, o);
+    if (half == 1) pair_store(slabs + (size_t)sb * slab_floats, (int64_t)(kb + j - 128) * 16 + 4 * g, o, near_b);
   });
   IL_TL(11, 6);
   if (half == 1) { pair_publish(flags + (size_t)sb * IL_CTR_STRIDE); IL_TL(11, 7); return; }
@@ -1932,13 +1966,30 @@ static int pc_helpers(int nt) {
 // Pair mode (k_sac_chain_pair / k_policy_critic_pair): H = 256, first layers of at most four 16-wide k-blocks, every workgroup of the launch resident. IL_PAIR=0 keeps
 // the 16-wave workgroups (developer A/B switch; same bits either way).
 static bool pair_env() { static const int on = [] { const char* e = getenv("IL_PAIR"); return e && e[0] == '0' ? 0 : 1; }(); return on != 0; }
-static bool pair_shape_ok(const il_sac* d) { return d->hidden == 256 && round_up16(d->state_dim + d->action_dim) <= 64; }
-static bool chain_pair_ok(const il_sac* d, int relabel, int G) { return pair_env() && pair_shape_ok(d) && chain_pair_workgroups(d->batch / IL_TILE_R, relabel, G) <= device_cu_count(); }
+static bool pair_shape_ok(const il_sac* d) {
+  const auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return d->hidden == 256 && round_up16(d->state_dim + d->action_dim) <= 64 && al(d->actor) && al(d->critic) && al(d->target);
+}
+// Pair-mode workgroups ask for (nearly) a whole CU's LDS: their tile carve + W1s needs up to 121 KB, and a 512-thread workgroup with ~170 VGPRs would otherwise leave room
+// on its CU for a discriminator workgroup of the other stream - measured (round 4, first build): k_gail_grad's slowest workgroup 14.3 -> 17.7 us, its AdamW step and with it
+// the relabel 4 us later. One workgroup per CU, as the 16-wave workgroups had by their register footprint.
+static size_t pair_lds_bytes() { static const size_t n = [] { const char* e = getenv("IL_PAIR_LDS_KB"); const int kb = e ? atoi(e) : 160; return (size_t)(kb < 124 ? 124 : (kb > 160 ? 160 : kb)) * 1024; }(); return n; }   // (developer A/B: 124 KB still lets a small workgroup of another launch share the CU)
+#define IL_PAIR_LDS_BYTES pair_lds_bytes()
+static int pair_lds_ready() {
+  static const int rc = [] {
+    if (hipFuncSetAttribute((const void*)k_sac_chain_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_PAIR_LDS_BYTES) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_policy_critic_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_PAIR_LDS_BYTES) != hipSuccess) return 1;
+    return 0;
+  }();
+  if (rc) (void)hipGetLastError();
+  return rc == 0;
+}
+static bool chain_pair_ok(const il_sac* d, int relabel, int G) { return pair_env() && pair_shape_ok(d) && chain_pair_workgroups(d->batch / IL_TILE_R, relabel, G) <= device_cu_count() && pair_lds_ready(); }
 static void launch_policy_critic(const il_sac* d, const il_batch* b, float* out_logp, float* out_q, size_t lds, hipStream_t st) {
   const int H = d->hidden, nt = d->batch / IL_TILE_R;
   IL_TRACE("k_policy_critic", st);
   const int hp = pc_helpers(nt);
-  if (pair_env() && pair_shape_ok(d) && hp > 0 && (4 + hp) * nt <= device_cu_count()) { k_policy_critic_pair<<<(4 + hp) * nt, 512, lds, st>>>(*d, *b, out_logp, out_q, hp); return; }
+  if (pair_env() && pair_shape_ok(d) && hp > 0 && (4 + hp) * nt <= device_cu_count() && pair_lds_ready()) { k_policy_critic_pair<<<(4 + hp) * nt, 512, IL_PAIR_LDS_BYTES, st>>>(*d, *b, out_logp, out_q, hp); return; }
   const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt);
   k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp);
 }
@@ -2004,7 +2055,7 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
   if (whole && chain_enabled() && 6 * nt <= device_cu_count()) {   // forward + critic loss chained per tile in one co-resident launch (k_sac_chain)
     if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
     ChainRelabel cr = {}; cr.xcd_nets = chain_xcd_nets(nt) ? 1 : 0;
-    if (chain_pair_ok(d, 0, 0)) { IL_TRACE("k_sac_chain", st); k_sac_chain_pair<<<chain_pair_workgroups(nt, 0, 0), 512, lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr, cr); }
+    if (chain_pair_ok(d, 0, 0)) { IL_TRACE("k_sac_chain", st); k_sac_chain_pair<<<chain_pair_workgroups(nt, 0, 0), 512, IL_PAIR_LDS_BYTES, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr, cr); }
     else { IL_TRACE("k_sac_chain", st); k_sac_chain<<<(cr.xcd_nets ? 8 : 6) * nt, tile_threads(H), lds, st>>>(*d, *b, eps_next, eps_cur, nullptr, nullptr, cr); }
     flags |= IL_FLAG_SAC_SKIP_FORWARD | 0x80000000u;
   }
@@ -2103,7 +2154,7 @@ static int sac_update_gather_impl(const il_sac* d, const il_batch* rows, const i
   if (6 * nt + G > device_cu_count()) return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update_gather: %d workgroups cannot be co-resident on %d CUs (gather first, then il_sac_update)", 6 * nt + G, device_cu_count());
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
   if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
-  if (chain_pair_ok(d, rl.on, G)) { IL_TRACE("k_sac_chain", st); k_sac_chain_pair<<<chain_pair_workgroups(nt, rl.on, G), 512, lds, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl); }
+  if (chain_pair_ok(d, rl.on, G)) { IL_TRACE("k_sac_chain", st); k_sac_chain_pair<<<chain_pair_workgroups(nt, rl.on, G), 512, IL_PAIR_LDS_BYTES, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl); }
   else {
     if (chain_xcd_nets(nt) && G <= 2 * nt) { rl.xcd_nets = 1; rl.gather_wgs = G; }
     IL_TRACE("k_sac_chain", st); k_sac_chain<<<rl.xcd_nets ? 8 * nt : 6 * nt + G, tile_threads(H), lds, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl);

@@ -71,6 +71,7 @@ def translate(src: str) -> str:
   src = re.sub(r'__attribute__\(\(address_space\(\d+\)\)\)', '', src)
   src = re.sub(r'asm volatile\(""[^;]*\);', '', src)
   src = re.sub(r'asm volatile\("s_waitcnt [^"]*"[^;]*\);', '', src)
+  src = re.sub(r'asm volatile\("s_getreg_b32 %0, hwreg\(HW_REG_XCC_ID\)" : "=s"\((\w+)\)\);', r'\1 = emu::xcc_id();', src)   # which XCD: the block's linear id mod 8, as observed on the device
   assert 'asm volatile' not in src, 'an inline-assembly statement the emulator does not know'
   src = _SHARED.sub(_shared_decl, src)
   assert '__shared__' not in re.sub(r'//[^\n]*', '', src), 'a static __shared__ declaration the translation did not recognise'

@@ -485,6 +485,8 @@ inline void emu_wave_barrier() { const int z = 0; (void)emu::wave_exchange(&z, 4
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 #define __builtin_amdgcn_s_memtime() 0ull
 #define __builtin_amdgcn_s_memrealtime() 0ull
+#define __builtin_amdgcn_s_barrier() __syncthreads()
+namespace emu { inline unsigned xcc_id() { static const char* e = getenv("IL_EMU_XCC"); const unsigned l = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); return e ? (l * 2654435761u >> 7) & 7u : l & 7u; } }   // IL_EMU_XCC=scatter: a placement under which partners do not share an XCD
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 #define __HIP_MEMORY_SCOPE_SYSTEM 1
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2

@@ -1097,7 +1097,8 @@ def test_update_plan_batch_sizes_of_the_tuned_configs(monkeypatch, B, ring):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('switch,B', [('IL_RING_GATHER', 256), ('IL_INLINE_RELABEL', 256), ('IL_SAC_CHAIN', 256), ('IL_PC_SPLIT', 256), ('IL_RESIDENT_SAMPLER', 256), ('IL_RESIDENT_SAMPLER', 80),
-                                      ('IL_SAC_CHAIN', 80), ('IL_RING_GATHER', 80), ('IL_PC_SPLIT', 48), ('IL_CHAIN_XCD_NETS', 256), ('IL_CHAIN_XCD_NETS', 80)])   # 80 / 48 rows: 5 / 3 tiles, the non-XCD-aware role decode; IL_CHAIN_XCD_NETS: one network per XCD (off by default)
+                                      ('IL_SAC_CHAIN', 80), ('IL_RING_GATHER', 80), ('IL_PC_SPLIT', 48), ('IL_CHAIN_XCD_NETS', 256), ('IL_CHAIN_XCD_NETS', 80),
+                                      ('IL_PAIR', 256), ('IL_PAIR', 128), ('IL_PAIR', 80)])   # IL_PAIR: the column-split pairs of k_sac_chain_pair / k_policy_critic_pair against the 16-wave workgroups   # 80 / 48 rows: 5 / 3 tiles, the non-XCD-aware role decode; IL_CHAIN_XCD_NETS: one network per XCD (off by default)
 def test_schedule_switches_are_bit_identical(monkeypatch, switch, B):
   """Every schedule of the update (rows through il_batch.gather vs a gather kernel, inline relabel vs k_gail_reward, chained vs separate forward / critic-loss
   launches, helper-split vs second-arriver policy tail) runs the same arithmetic per element: switching one off must not change a bit.
@@ -1126,6 +1127,34 @@ def test_schedule_switches_are_bit_identical(monkeypatch, switch, B):
   if switch == 'IL_RING_GATHER': assert not outs[1]['ring']
   if switch == 'IL_INLINE_RELABEL': assert outs[1]['ring'] and not outs[1]['inline']
   assert outs[0]['digest'] == outs[1]['digest']
+
+
+@pytest.mark.gpu
+def test_pair_mode_hops_stay_bit_identical_over_many_replays():
+  """k_sac_chain_pair / k_policy_critic_pair hand 16 x 128 halves between workgroups through L2 (same XCD: plain stores behind a drained flag) or write-through stores
+  (any placement), read with L1-bypassing loads - no fence. A stale or torn hop would change a hidden activation and, within an update, every parameter: 1,500 captured
+  replays back to back (the timed regime: launches overlap, consumers L1-warm from the previous replay) must end in the bits of the 16-wave workgroups (IL_PAIR=0)."""
+  import subprocess, sys, json
+  code = (
+      "import sys, json, hashlib, numpy as np, torch; sys.path[:0] = ['.', 'tests', 'tests/golden']\n"
+      "import imitation_learning_amd as il\n"
+      "from imitation_learning_amd import training as T\n"
+      "from test_gpu_parity import _make_plan, N\n"
+      "il.seed(41); T._NOISE.clear()\n"
+      "plan, nets = _make_plan('GAIL', 23)\n"
+      "plan.capture(warmup=2)\n"
+      "for _ in range(1500): plan.replay()\n"
+      "torch.cuda.synchronize()\n"
+      "assert plan.sync_timeouts() == 0\n"
+      "h = hashlib.sha256()\n"
+      "for n in list(nets) + [plan.logp, plan.q, plan.rewards, plan.idx]: h.update(np.ascontiguousarray(N(n.flat if hasattr(n, 'flat') else n)).tobytes())\n"
+      "print(json.dumps(dict(digest=h.hexdigest(), finite=bool(np.isfinite(N(nets[0].flat)).all()))))\n")
+  outs = []
+  for value in ('1', '0'):
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, IL_PAIR=value), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+  assert outs[0]['finite'] and outs[0]['digest'] == outs[1]['digest']
 
 
 @pytest.mark.gpu
