@@ -391,6 +391,46 @@ __device__ __forceinline__ void l1_compute_lds(const float* W1s, int ldw1, const
     epi(c0, acc);
   }
 }
+// The same first layer when the rows of W1 ARE 16-byte aligned (Kw % 4 == 0: the critics at HalfCheetah dims, IN = 24): two column tiles x Kpad / 16 k-blocks of plain
+// 16-byte operand lanes per wave, requested with the rest of the prologue and held in registers - no LDS staging to pay for (w1_commit is ~150 VALU instructions per
+// thread at two waves per SIMD: 0.6 us). load4<MODE> with tile_fwd_impl's arguments, tile_fwd_impl's MFMA order: same bits.
+struct L1Pre { f32x4 b[2][4]; };
+template <int MODE>
+__device__ __forceinline__ void l1_prefetch_impl(L1Pre& w, const float* __restrict__ W, int ldw, int Kw, int Kpad, int N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float* wr = W + (size_t)(min((wave + q * nw) * 16, N - 16) + j) * ldw;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (16 * u < Kpad) w.b[q][u] = load4<MODE>(wr, 16 * u + 4 * g, Kw);
+  }
+}
+__device__ __forceinline__ bool l1_rows_aligned(const float* W, int Kw) { return (Kw & 3) == 0 && Kw >= 4 && (reinterpret_cast<uintptr_t>(W) & 15) == 0; }
+__device__ __forceinline__ void l1_prefetch(L1Pre& w, const float* __restrict__ W, int Kw, int Kpad, int N) {   // l1_rows_aligned(W, Kw)
+  if (Kw == Kpad) l1_prefetch_impl<0>(w, W, Kw, Kw, Kpad, N); else l1_prefetch_impl<1>(w, W, Kw, Kw, Kpad, N);
+}
+template <class Epi>
+__device__ __forceinline__ void l1_compute_regs(const L1Pre& w, const float* Xs, int ldx, int Kpad, int N, Epi epi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, j = lane & 15, g = lane >> 4;
+  const float* xr = Xs + j * ldx + 4 * g;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c0 = (wave + q * nw) * 16;
+    if (c0 < N) {
+      f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (16 * u < Kpad) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * u);
+        acc0 = mfma16(a[0], w.b[q][u][0], acc0);
+        acc1 = mfma16(a[1], w.b[q][u][1], acc1);
+        acc0 = mfma16(a[2], w.b[q][u][2], acc0);
+        acc1 = mfma16(a[3], w.b[q][u][3], acc1);
+      }
+      const f32x4 acc = acc0 + acc1;
+      epi(c0, acc);
+    }
+  }
+}
 // The tile's [16][Kpad] input rows (load_rows_cat's values: cat(f1, f2), zero-padded; through il_batch.gather when `gather`), two elements per thread at most
 // (16 * Kpad <= 2 * blockDim.x): index, then element, requested into registers; rows_commit writes them to LDS.
 struct RowsPre { int64_t sr[2]; float v[2]; };

@@ -668,7 +668,9 @@ __device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch&
   int64_t hidx = row0 + min(hr, IL_TILE_R - 1);
   if (head_thread && b.gather) hidx = gload(b.gather + row0 + hr);
   const int w1_lanes = H * S / 4;
-  W1Pre w1; w1_issue(w1, net.W1, w1_lanes);
+  const bool w1_regs = l1_rows_aligned(net.W1, S);
+  W1Pre w1; L1Pre w1r;
+  if (w1_regs) l1_prefetch(w1r, net.W1, S, Sp, H); else w1_issue(w1, net.W1, w1_lanes);
   const float pb1a = gload(net.b1 + wave * 16 + j), pb1b = gload(net.b1 + min((wave + nw) * 16 + j, H - 1)), pb2 = gload(net.b2 + t2 * 16 + j);
   const uint32_t nctr = (half == 0 && d.noise_counter) ? gload(d.noise_counter) : 0u;
   __builtin_amdgcn_sched_barrier(0);
@@ -681,15 +683,18 @@ __device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch&
   // with eight waves doing so, ~0.85 us per panel during which it cannot commit its rows; measured as a 4.8 us prologue of the first pair-mode k_policy_critic with two
   // panels parked. Requested right before its MFMAs, the panel streams in under them - the schedule of tile_packed.)
   IL_TL(10, 1);
-  w1_commit(w1, W1s, ldw1, S, Sp, H, w1_lanes);
+  if (!w1_regs) w1_commit(w1, W1s, ldw1, S, Sp, H, w1_lanes);
   rows_commit(rp, Xs, ldx, Sp, S);
   __syncthreads();
   IL_TL(10, 2);
-  l1_compute_lds(W1s, ldw1, Xs, ldx, Sp, H, [&](int c0, f32x4 acc) {
-    const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1a : pb1b;
+  {
+    auto epi1 = [&](int c0, f32x4 acc) {
+      const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1a : pb1b;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
-  });
+      for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
+    };
+    if (w1_regs) l1_compute_regs(w1r, Xs, ldx, Sp, H, epi1); else l1_compute_lds(W1s, ldw1, Xs, ldx, Sp, H, epi1);
+  }
   const bool near = half == 1 && pair_same_xcd(flag);
   __syncthreads();
   IL_TL(10, 3);
@@ -745,7 +750,9 @@ __device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, 
   const int t2 = 8 * half + wave;
   if (half == 0) pair_announce(flag);
   RowsPre rp; rows_idx(rp, INp, row0, b.gather);
-  W1Pre w1; w1_issue(w1, p.W1, w1_lanes);
+  const bool w1_regs = l1_rows_aligned(p.W1, IN);   // (wave-uniform) aligned rows: operand lanes straight into registers; otherwise through LDS
+  W1Pre w1; L1Pre w1r;
+  if (w1_regs) l1_prefetch(w1r, p.W1, IN, INp, H); else w1_issue(w1, p.W1, w1_lanes);
   const float pb1a = gload(p.b1 + wave * 16 + j), pb1b = gload(p.b1 + min((wave + nw) * 16 + j, H - 1)), pb2 = gload(p.b2 + t2 * 16 + j), pb3 = gload(p.b3);
   float w3v[4];
 #pragma unroll
@@ -753,19 +760,22 @@ __device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, 
   __builtin_amdgcn_sched_barrier(0);
   rows_issue(rp, INp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, b.gather != nullptr, b.gather_capacity, false);   // s' columns, zero elsewhere
   issue_fence();
-  Panel16 pn; panel_prefetch(pn, W + ws.pk_tf + (size_t)k * H * H, t2);
-  w1_commit(w1, W1s, ldw1, IN, INp, H, w1_lanes);
+  Panel16 pn; panel_prefetch(pn, W + ws.pk_tf + (size_t)k * H * H, t2);   // (this workgroup is about to wait for its tile's actor(s'): being held at the issue stage costs nothing here)
+  if (!w1_regs) w1_commit(w1, W1s, ldw1, IN, INp, H, w1_lanes);
   rows_commit(rp, Xs, ldx, INp, S);
   IL_TL(10, 1);
   tile_await_bits(ctr, 1u, 0u, tile_timeouts(d));   // a' and log pi(a'|s') of this tile (its barrier also covers the LDS writes above)
   IL_TL(10, 2);
   for (int i = threadIdx.x; i < IL_TILE_R * A; i += blockDim.x) { const int r = i / A, c = i - r * A; Xs[r * ldx + S + c] = W[ws.n_a2 + (size_t)(row0 + r) * A + c]; }
   __syncthreads();
-  l1_compute_lds(W1s, ldw1, Xs, ldx, INp, H, [&](int c0, f32x4 acc) {
-    const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1a : pb1b;
+  {
+    auto epi1 = [&](int c0, f32x4 acc) {
+      const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1a : pb1b;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
-  });
+      for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
+    };
+    if (w1_regs) l1_compute_regs(w1r, Xs, ldx, INp, H, epi1); else l1_compute_lds(W1s, ldw1, Xs, ldx, INp, H, epi1);
+  }
   __syncthreads();
   IL_TL(10, 3);
   const bool near = half == 1 && pair_same_xcd(flag);
@@ -876,7 +886,10 @@ __global__ __launch_bounds__(512) void k_sac_chain_pair(il_sac d, il_batch b, co
 // (part, nparts): the last GEMM, whose result only goes to HBM for the weight-gradient kernel, is split by output columns over `nparts` workgroups
 // that each run everything before it redundantly (k_policy_critic helpers); part 0 writes the shared outputs. nparts = 1: the whole tail.
 // `wait` is called once everything that does not depend on the critics of this launch has been requested / computed.
-template <int PANEL = 16, class Wait>
+// PARK (pair-mode helpers: 512 threads, <= 256 VGPRs, H = 256, at most one output tile of the last GEMM per wave): that tile's 16 KB panel is requested before the wait
+// for the critics and parked in registers - the helper idles ~8 us there, so being held at the issue stage is free, and the GEMM at the very end of the update's
+// longest dependent chain starts from registers.
+template <int PANEL = 16, bool PARK = false, class Wait>
 __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& b, int tile, float* __restrict__ out_logp, float* __restrict__ out_q, float* smem, int part,
                                                int nparts, Wait wait) {
   if (!out_logp) out_logp = d.out_logp;
@@ -925,8 +938,11 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
   if (tid == 0 && part == 0) {
     W[ws.alpha_part + tile] = apart;
   }
+  Panel16 parked;
+  const bool own_tile = pt0 + wave < pt1;
+  if (PARK && own_tile) panel_prefetch(parked, W + ws.pk_ab, pt0 + wave);
   if (nparts > 1) {   // a waiting helper pulls the operands of its two GEMMs into this XCD's L2 (they were rewritten by the previous update's Adam kernel on other XCDs)
-    if (pt0 + wave < pt1) {
+    if (!PARK && pt0 + wave < pt1) {
       const float* pp = W + ws.pk_ab + (size_t)(pt0 + wave) * nb * 256 + lane * 4;
 #pragma unroll
       for (int u = 0; u < 16; ++u) { if (u < nb) { f32x4 v = gload4(pp + (size_t)u * 256); asm volatile("" ::"v"(v)); } }
@@ -958,14 +974,16 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
   });
   __syncthreads();
   IL_STAMP(stamp, 28);
-  tile_bwd_packed<PANEL>(DZ2s, ldh, H, W + ws.pk_ab, [&](int kb, f32x4 acc) {
+  auto epi_dz1 = [&](int kb, f32x4 acc) {
     const size_t off = (size_t)(kb + j) * B + row0 + 4 * g;
     const f32x4 hv = (kb == (pt0 + wave) * 16) ? hv1p : *reinterpret_cast<const f32x4*>(h1 + off);
     f32x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = hv[r] > 0.f ? acc[r] : 0.f;
     wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.a_dz1 + (int64_t)off, o);
-  }, pt0, pt1);
+  };
+  if (PARK) { if (own_tile) tile_packed_regs(DZ2s, ldh, parked, pt0 + wave, epi_dz1); }
+  else tile_bwd_packed<PANEL>(DZ2s, ldh, H, W + ws.pk_ab, epi_dz1, pt0, pt1);
   IL_STAMP(stamp, 29);
 }
 
@@ -1157,7 +1175,9 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
   pair_announce(flags + (size_t)(sa + 1 - half) * IL_CTR_STRIDE);   // consumer of the partner's h2 half ...
   if (half == 0) pair_announce(flags + (size_t)sb * IL_CTR_STRIDE);   // ... and of its dz1 half
   RowsPre rp; rows_idx(rp, INp, row0, nullptr);
-  W1Pre w1; w1_issue(w1, p.W1, w1_lanes);
+  const bool w1_regs = l1_rows_aligned(p.W1, IN);
+  W1Pre w1; L1Pre w1r;
+  if (w1_regs) l1_prefetch(w1r, p.W1, IN, INp, H); else w1_issue(w1, p.W1, w1_lanes);
   rows_issue(rp, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, false, 0, true);
   const float pb1a = gload(p.b1 + wave * 16 + j), pb1b = gload(p.b1 + min((wave + nw) * 16 + j, H - 1)), pb2 = gload(p.b2 + t2 * 16 + j), pb3 = gload(p.b3);
   float w3v[4];
@@ -1165,15 +1185,18 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
   for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
   ColsPre w1pre = {};
   if (half == 0) w1pre = tile_bwd_dx_cols_prefetch(p.W1, IN, IN, H, S);
-  w1_commit(w1, W1s, ldw1, IN, INp, H, w1_lanes);
+  if (!w1_regs) w1_commit(w1, W1s, ldw1, IN, INp, H, w1_lanes);
   rows_commit(rp, Xs, ldx, INp, IN);
   __syncthreads();
   IL_TL(11, 1);
-  l1_compute_lds(W1s, ldw1, Xs, ldx, INp, H, [&](int c0, f32x4 acc) {
-    const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1a : pb1b;
+  {
+    auto epi1 = [&](int c0, f32x4 acc) {
+      const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1a : pb1b;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
-  });
+      for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
+    };
+    if (w1_regs) l1_compute_regs(w1r, Xs, ldx, INp, H, epi1); else l1_compute_lds(W1s, ldw1, Xs, ldx, INp, H, epi1);
+  }
   __syncthreads();
   IL_TL(11, 2);
   const bool near_a = pair_same_xcd(flags + (size_t)(sa + half) * IL_CTR_STRIDE);
@@ -1234,13 +1257,15 @@ __global__ __launch_bounds__(512) void k_policy_critic_pair(il_sac d, il_batch b
     unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr) + tile * IL_CTR_STRIDE;
     if (h == 0 && threadIdx.x == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }
     IL_TL(3, 0);
-    actor_bwd_tile<16>(d, b, tile, out_logp, out_q, smem, part, helpers, [&] {
+    const auto wait = [&] {
       IL_TL(3, 1);
       tile_await(ctr, 2u, tile_timeouts(d));
       IL_TL(3, 2);
       if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u + (unsigned)helpers)
         __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    });
+    };
+    if ((d.hidden >> 4) <= helpers * (int)(blockDim.x >> 6)) actor_bwd_tile<16, true>(d, b, tile, out_logp, out_q, smem, part, helpers, wait);   // one output tile of the last GEMM per wave at most
+    else actor_bwd_tile<16, false>(d, b, tile, out_logp, out_q, smem, part, helpers, wait);
     IL_TL_END(3);
     return;
   }
