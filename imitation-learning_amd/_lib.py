@@ -35,7 +35,7 @@ class Sac(C.Structure):
               ('actor_opt', Adam), ('critic_opt', Adam), ('alpha_opt', Adam),
               ('discount', C.c_float), ('entropy_target', C.c_float), ('polyak', C.c_double),
               ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('noise_seed', C.c_uint64), ('noise_counter', C.c_void_p),
-              ('out_logp', C.c_void_p), ('out_q', C.c_void_p), ('sync', C.c_void_p)]
+              ('out_logp', C.c_void_p), ('out_q', C.c_void_p), ('sync', C.c_void_p), ('debug_masks', C.c_void_p)]
 
 
 class Disc(C.Structure):

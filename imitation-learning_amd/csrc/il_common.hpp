@@ -80,7 +80,7 @@ __device__ __forceinline__ void globalize(il_sac& d) {
   d.actor_grad = as_global(d.actor_grad); d.critic_grad = as_global(d.critic_grad); d.alpha_grad = as_global(d.alpha_grad);
   globalize(d.actor_opt); globalize(d.critic_opt); globalize(d.alpha_opt);
   d.workspace = as_global(d.workspace); d.noise_counter = as_global(d.noise_counter); d.out_logp = as_global(d.out_logp); d.out_q = as_global(d.out_q);
-  d.sync = as_global(d.sync);
+  d.sync = as_global(d.sync); d.debug_masks = as_global(d.debug_masks);
 }
 
 __device__ __forceinline__ void globalize(il_disc& d) {

@@ -70,6 +70,14 @@ __device__ __forceinline__ void head_sample(float mean, float ls_raw, float eps,
   ladj = 2.f * (LOG_2 - x - softplus_f(-2.f * x));
 }
 
+// il_sac.debug_masks (tests only; include/il_hip.h): hv = 4 consecutive rows (row .. row + 3) of hidden column `col` after the ReLU
+__device__ __forceinline__ void debug_mask4(const il_sac& d, int slot, int row, int col, const f32x4& hv) {
+  if (d.debug_masks) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d.debug_masks[((size_t)slot * d.batch + row + r) * d.hidden + col] = hv[r] > 0.f ? 1.f : 0.f;
+  }
+}
+
 // k_repack: PF / PB copies of W2 for actor (net 0), critic_1,2 (1,2) and target_1,2 (3,4). `mask` selects nets (bit per net).
 // Every public entry point derives the copies it reads from the parameters inside the same call, so they can never be stale.
 __global__ __launch_bounds__(256) void k_repack(il_sac d, unsigned mask, const il_sac* __restrict__ dL) {
@@ -151,7 +159,7 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = hv[r]; }
-    if (is_cur) wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.a_h1 + (int64_t)col * B + row0 + 4 * g, hv);
+    if (is_cur) { wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.a_h1 + (int64_t)col * B + row0 + 4 * g, hv); debug_mask4(d, 0, row0 + 4 * g, col, hv); }
   });
   __syncthreads();
   IL_TL(is_cur ? 6 : 5, 2);
@@ -160,7 +168,7 @@ __device__ __forceinline__ void actor_fwd_tile(const il_sac& d, const il_batch& 
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = hv[r]; }
-    if (is_cur) wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.a_h2 + (int64_t)col * B + row0 + 4 * g, hv);
+    if (is_cur) { wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.a_h2 + (int64_t)col * B + row0 + 4 * g, hv); debug_mask4(d, 1, row0 + 4 * g, col, hv); }
   });
   __syncthreads();
   IL_TL(is_cur ? 6 : 5, 3);
@@ -300,7 +308,7 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = hv[r]; }
-    if (!is_target) wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.c_h1 + (int64_t)k * B * H + (int64_t)col * B + row0 + 4 * g, hv);
+    if (!is_target) { wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.c_h1 + (int64_t)k * B * H + (int64_t)col * B + row0 + 4 * g, hv); debug_mask4(d, 2 + 2 * k, row0 + 4 * g, col, hv); }
   });
   __syncthreads();
   IL_TL(8, 2);
@@ -309,7 +317,7 @@ __device__ __forceinline__ void critic_fwd_tile(const il_sac& d, const il_batch&
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = hv[r]; }
-    if (!is_target) wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.c_h2 + (int64_t)k * B * H + (int64_t)col * B + row0 + 4 * g, hv);
+    if (!is_target) { wstore4<(IL_WT_TILE_STORES && PANEL >= 16)>(W, ws.c_h2 + (int64_t)k * B * H + (int64_t)col * B + row0 + 4 * g, hv); debug_mask4(d, 3 + 2 * k, row0 + 4 * g, col, hv); }
   });
   __syncthreads();
   IL_TL(8, 3);
@@ -1050,16 +1058,20 @@ __device__ __forceinline__ void k_policy_critic_body(il_sac d, il_batch b, float
   IL_TL(7, 1);
   tile_fwd<PANEL>(Xs, ldx, INp, p.W1, IN, IN, H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1 : p.b1[col];
+    f32x4 hv;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
+    for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = hv[r]; }
+    debug_mask4(d, 6 + 2 * k, row0 + 4 * g, col, hv);
   });
   __syncthreads();
   IL_STAMP(stamp, 18);
   IL_TL(7, 2);
   tile_fwd_packed<PANEL>(H1s, ldh, H, W + ws.pk_cf + (size_t)k * H * H, [&](int c0, f32x4 acc) {
     const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb2 : p.b2[col];
+    f32x4 hv;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
+    for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H2s[(4 * g + r) * ldh + col] = hv[r]; }
+    debug_mask4(d, 7 + 2 * k, row0 + 4 * g, col, hv);
   });
   __syncthreads();
   IL_STAMP(stamp, 19);
@@ -1192,8 +1204,10 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
   {
     auto epi1 = [&](int c0, f32x4 acc) {
       const int col = c0 + j; const float bb = (c0 == wave * 16) ? pb1a : pb1b;
+      f32x4 hv;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) H1s[(4 * g + r) * ldh + col] = fmaxf(acc[r] + bb, 0.f);
+      for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + bb, 0.f); H1s[(4 * g + r) * ldh + col] = hv[r]; }
+      if (half == 0) debug_mask4(d, 6 + 2 * k, row0 + 4 * g, col, hv);
     };
     if (w1_regs) l1_compute_regs(w1r, Xs, ldx, INp, H, epi1); else l1_compute_lds(W1s, ldw1, Xs, ldx, INp, H, epi1);
   }
@@ -1206,6 +1220,7 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
     f32x4 hv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hv[r] = fmaxf(acc[r] + pb2, 0.f); H2s[(4 * g + r) * ldh + col] = hv[r]; }
+    debug_mask4(d, 7 + 2 * k, row0 + 4 * g, col, hv);
     pair_store(slabs + (size_t)(sa + half) * slab_floats, (int64_t)(col - 128 * half) * 16 + 4 * g, hv, near_a);
   });
   pair_publish(flags + (size_t)(sa + half) * IL_CTR_STRIDE);

@@ -446,6 +446,15 @@ class UpdatePlan:
     self._capturing = None   # 'main' / 'side' while one branch of the device-synchronised update is being captured
     self._prepared = False   # True once an update of THIS plan has left the lane-ordered weight copies in step with the parameters
 
+  def record_relu_masks(self) -> Tensor:
+    """Tests only (il_sac.debug_masks, include/il_hip.h): from now on every update ALSO writes, for its three back-propagated passes, which hidden pre-activations
+    it found > 0 - [10, B, H] floats: actor(s) layers 1, 2; critic_k(s, a) at 2 + 2k, 3 + 2k; the updated critic_k(s, a~) at 6 + 2k, 7 + 2k. Call before capture()
+    (a captured launch carries the descriptor by value). The oracle replays an update with these decisions (oracle.nets.mlp_forward(masks=...))."""
+    assert self.graph is None, 'record_relu_masks(): before capture()'
+    self.relu_masks = torch.zeros(10, self.B, self.sac.hidden, device=self.rows.device)
+    self.sac.debug_masks = self.relu_masks.data_ptr()
+    return self.relu_masks
+
   def invalidate(self):
     """Call after changing actor / critic / target parameters from outside the plan (load_state_dict, manual edits): the next update
     re-derives the lane-ordered weight copies (k_repack) instead of trusting the ones its own Adam / polyak epilogues maintain."""

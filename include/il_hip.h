@@ -214,6 +214,10 @@ typedef struct il_sac {
   uint32_t* noise_counter;   /* device uint32, incremented once per il_sac_actor_step */
   float *out_logp, *out_q;   /* optional [B] outputs (training.py:54) used when the call passes NULL output pointers (population path) */
   int64_t* sync;             /* il_sync counters or NULL (see below) */
+  float* debug_masks;        /* NULL, or [10][batch][hidden] floats (tests only): 1 where a hidden PRE-activation was > 0 as this path computed it, for the passes that are
+                              * back-propagated - [0,1] actor(s) layers 1,2; [2 + 2k, 3 + 2k] critic_k(s, a); [6 + 2k, 7 + 2k] the updated critic_k(s, a~). Two correct
+                              * fp32 evaluations disagree on the sign of a pre-activation within rounding of 0; the oracle replays an update WITH these masks
+                              * (oracle/nets.py), which isolates that effect from everything else (tests/test_timed_path_oracle.py) */
 } il_sac;
 
 int64_t il_mlp_numel(int32_t in_dim, int32_t hidden, int32_t out_dim);

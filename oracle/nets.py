@@ -43,18 +43,25 @@ def unpack(flat, shapes):
   return out
 
 
-def mlp_forward(layers, x):
-  """Returns (out, acts) with acts[i] = input of layer i (post-ReLU hidden)."""
+def mlp_forward(layers, x, masks=None):
+  """Returns (out, acts) with acts[i] = input of layer i (post-ReLU hidden).
+
+  masks (tests only): one boolean [B, H] array per hidden layer = "this pre-activation was > 0" as ANOTHER correct fp32 evaluation of the same network decided it (the
+  HIP path's il_sac.debug_masks). A pre-activation within rounding of 0 takes either sign depending on the summation order; with `masks` the ReLU passes z where the mask
+  says so (z itself is then ~1e-8: the forward value barely moves) and `mlp_backward(..., masks=...)` back-propagates through the same units - which isolates every other
+  source of difference from that one."""
   acts, h = [], x.astype(f32)
   for i, (W, b) in enumerate(layers):
     acts.append(h)
     z = h @ W.T + b
-    h = np.maximum(z, f32(0)) if i < len(layers) - 1 else z
+    if i == len(layers) - 1: h = z
+    elif masks is None: h = np.maximum(z, f32(0))
+    else: h = np.where(masks[i], z, f32(0)).astype(f32)
   return h, acts
 
 
-def mlp_backward(layers, acts, dout, need_dx=True):
-  """Gradient of sum(out * dout). Returns (flat grad in parameter order, dx)."""
+def mlp_backward(layers, acts, dout, need_dx=True, masks=None):
+  """Gradient of sum(out * dout). Returns (flat grad in parameter order, dx). masks: see mlp_forward (masks[i - 1] gates the input of layer i)."""
   grads, dz = [None] * len(layers), dout.astype(f32)
   for i in range(len(layers) - 1, -1, -1):
     W, _ = layers[i]
@@ -62,7 +69,7 @@ def mlp_backward(layers, acts, dout, need_dx=True):
     if i > 0 or need_dx:
       dh = dz @ W
       if i > 0:
-        dz = dh * (acts[i] > 0)  # ReLU mask: post-ReLU input of layer i is > 0 iff pre-activation > 0
+        dz = dh * ((acts[i] > 0) if masks is None else masks[i - 1])  # ReLU mask: post-ReLU input of layer i is > 0 iff pre-activation > 0
   flat = np.concatenate([np.concatenate([g[0].ravel(), g[1].ravel()]) for g in grads]).astype(f32)
   return flat, (dh if need_dx else None)
 

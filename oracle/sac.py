@@ -35,16 +35,18 @@ class SacState:
     return nets.unpack(flat[k * self.Pc:(k + 1) * self.Pc], self.critic_shapes)
 
 
-def critic_forward(st, flat, s, a):
+def critic_forward(st, flat, s, a, masks=None):
   x = np.concatenate([s, a], axis=1).astype(f32)
   outs = []
   for k in range(2):
-    q, acts = nets.mlp_forward(st.critic_layers(flat, k), x)
+    q, acts = nets.mlp_forward(st.critic_layers(flat, k), x, None if masks is None else masks[k])
     outs.append((q[:, 0], acts))
   return outs
 
 
-def sac_update(st: SacState, batch, eps_next, eps_cur, *, discount, entropy_target, polyak_factor, lr=3e-4, weight_decay=0.0, lr_alpha=None, return_grads=False):
+def sac_update(st: SacState, batch, eps_next, eps_cur, *, discount, entropy_target, polyak_factor, lr=3e-4, weight_decay=0.0, lr_alpha=None, return_grads=False, masks=None):
+  """masks (tests only): {'actor': [m1, m2], 'critic': [[m1, m2], [m1, m2]], 'pcritic': [[m1, m2], [m1, m2]]} - the ReLU decisions of the three back-propagated
+  passes as another evaluation made them (nets.mlp_forward); the no-grad passes (actor and targets on s') have no backward to disagree in."""
   s, a, r, s2 = batch['states'], batch['actions'], batch['rewards'], batch['next_states']
   term, w, absb = batch['terminals'], batch['weights'], batch['absorbing']
   B, A = s.shape[0], st.A
@@ -64,11 +66,12 @@ def sac_update(st: SacState, batch, eps_next, eps_cur, *, discount, entropy_targ
   y = (r + (f32(1) - term) * f32(discount) * tv).astype(f32)
 
   # --- critic loss + step (training.py:26-31)
-  (q1, acts1), (q2, acts2) = critic_forward(st, st.critic, s, a)
+  mk = masks or {}
+  (q1, acts1), (q2, acts2) = critic_forward(st, st.critic, s, a, mk.get('critic'))
   g_c = []
   for k, (q, acts) in enumerate(((q1, acts1), (q2, acts2))):
     dq = (w * (f32(2) * (q - y))) / f32(B)
-    g, _ = nets.mlp_backward(st.critic_layers(st.critic, k), acts, dq[:, None], need_dx=False)
+    g, _ = nets.mlp_backward(st.critic_layers(st.critic, k), acts, dq[:, None], need_dx=False, masks=mk['critic'][k] if masks else None)
     g_c.append(g)
   g_c = np.concatenate(g_c)
   st.t_critic += 1
@@ -76,23 +79,23 @@ def sac_update(st: SacState, batch, eps_next, eps_cur, *, discount, entropy_targ
 
   # --- policy loss + step (training.py:34-42), critic already updated
   a_layers = st.actor_layers()
-  out, acts_a = nets.mlp_forward(a_layers, s)
+  out, acts_a = nets.mlp_forward(a_layers, s, mk.get('actor'))
   mean, ls_raw, _, std = nets.actor_head(out, A)
   x = mean + eps_cur * std                          # rsample: loc + eps*scale
   an = np.tanh(x)
   logp = nets.tanh_gaussian_logp(x, mean, std)
-  (qn1, actsn1), (qn2, actsn2) = critic_forward(st, st.critic, s, an)
+  (qn1, actsn1), (qn2, actsn2) = critic_forward(st, st.critic, s, an, mk.get('pcritic'))
   sel1 = np.where(qn1 < qn2, f32(1), np.where(qn1 == qn2, f32(0.5), f32(0)))
   da = np.zeros((B, A), f32)
   for k, (acts, sel) in enumerate(((actsn1, sel1), (actsn2, f32(1) - sel1))):
-    _, dx = nets.mlp_backward(st.critic_layers(st.critic, k), acts, (-(sel) / f32(B))[:, None], need_dx=True)
+    _, dx = nets.mlp_backward(st.critic_layers(st.critic, k), acts, (-(sel) / f32(B))[:, None], need_dx=True, masks=mk['pcritic'][k] if masks else None)
     da += dx[:, st.S:]
   c = (w * m * alpha) / f32(B)                       # dL/dlogp
   dx_pre = c[:, None] * (f32(2) * np.tanh(x)) + da * (f32(1) - an * an)
   dmean = dx_pre
   dstd = dx_pre * eps_cur - c[:, None] / std
   dls = dstd * std * ((ls_raw >= nets.LOG_STD_MIN) & (ls_raw <= nets.LOG_STD_MAX))
-  g_a, _ = nets.mlp_backward(a_layers, acts_a, np.concatenate([dmean, dls], axis=1), need_dx=False)
+  g_a, _ = nets.mlp_backward(a_layers, acts_a, np.concatenate([dmean, dls], axis=1), need_dx=False, masks=mk.get('actor'))
   st.t_actor += 1
   nets.adam_step(st.actor, g_a, st.actor_m, st.actor_v, st.t_actor, lr, weight_decay)
 

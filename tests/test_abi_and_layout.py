@@ -34,7 +34,7 @@ def test_struct_sizes_match_header():
   assert C.sizeof(_lib.Batch) == 7 * 8 + 8 * 4 + 8 + 8   # + gather, gather_capacity
   assert C.sizeof(_lib.Adam) == 3 * 8 + 5 * 8
   assert C.sizeof(_lib.Pwil) == 4 * 4 + 5 * 8 + 3 * 8
-  assert C.sizeof(_lib.Sac) == 4 * 4 + 7 * 8 + 3 * C.sizeof(_lib.Adam) + 2 * 4 + 8 + 8 + 8 + 8 + 8 + 2 * 8 + 8
+  assert C.sizeof(_lib.Sac) == 4 * 4 + 7 * 8 + 3 * C.sizeof(_lib.Adam) + 2 * 4 + 8 + 8 + 8 + 8 + 8 + 2 * 8 + 8 + 8   # + debug_masks
   assert _lib.lib().il_ring_row_floats(18, 6) == 48 and _lib.lib().il_ring_row_floats(112, 8) == 240
   assert _lib.lib().il_mlp_numel(18, 256, 12) == 73740 and _lib.lib().il_mlp_stride(24, 256, 1) == 72452
 

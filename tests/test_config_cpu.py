@@ -71,6 +71,42 @@ def test_expert_data_ingest_matches_reference(tmp_path):
     environments.load_dataset_file(str(tmp_path / 'expert.hdf5'))
 
 
+def test_hdf5_branch_of_the_dataset_reader_behind_a_stub_h5py(tmp_path, monkeypatch):
+  """The `.hdf5` branch of load_dataset_file (what D4RL ships: reference environments.py:63-70 reads it through d4rl.qlearning_dataset) cannot run against real h5py in
+  this image; a stub module with h5py's File / mapping surface executes it once: same five arrays, same ingest result as the .npz route, bit for bit."""
+  import os
+  import sys
+  import types
+  import numpy as np
+  import imitation_learning_amd as il
+  from imitation_learning_amd import environments
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+  import inputs as gi
+  raw = gi.raw_d4rl_dataset(81)
+  opened = []
+
+  class File:   # h5py.File(path, 'r') as f: `k in f`, f[k] -> array-like
+    def __init__(self, path, mode):
+      assert mode == 'r'; opened.append(path)
+      self.d = {k: v for k, v in raw.items() if k != 'next_observations'}   # the raw D4RL files carry no next_observations: qlearning_dataset derives them
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+    def __contains__(self, k): return k in self.d
+    def __getitem__(self, k): return self.d[k]
+  h5 = types.ModuleType('h5py'); h5.File = File
+  monkeypatch.setitem(sys.modules, 'h5py', h5)
+  path = str(tmp_path / 'hopper_expert-v2.hdf5')
+  got = environments.load_dataset_file(path)
+  assert opened == [path] and set(got) == {'observations', 'actions', 'next_observations', 'terminals', 'timeouts'}
+  for k in ('observations', 'actions', 'terminals', 'timeouts'):
+    assert got[k].numpy().tobytes() == np.ascontiguousarray(raw[k], np.float32).tobytes(), k
+  assert got['next_observations'][:-1].numpy().tobytes() == np.ascontiguousarray(raw['observations'][1:], np.float32).tobytes()
+  np.savez(str(tmp_path / 'e.npz'), **{k: v for k, v in raw.items() if k != 'next_observations'})
+  il.seed(17); a = environments.dataset_to_memory(got, True, 2, 3, device='cpu')
+  il.seed(17); b = environments.dataset_to_memory(environments.load_dataset_file(str(tmp_path / 'e.npz')), True, 2, 3, device='cpu')
+  assert a.ring.numpy().tobytes() == b.ring.numpy().tobytes() and (a.idx, a.num_trajectories) == (b.idx, b.num_trajectories)
+
+
 def test_make_env_wraps_the_real_task_when_gym_and_d4rl_import(monkeypatch):
   """`make_env` with importable gym + d4rl returns GymD4RLEnv (reference environments.py:20-61). The packages cannot be installed here, so a stub gym
   stands in: what is checked is the wrapper's own behaviour - absorbing bit, action clipping, batch dimension, horizon, dataset ingest."""

@@ -1130,6 +1130,48 @@ def test_schedule_switches_are_bit_identical(monkeypatch, switch, B):
 
 
 @pytest.mark.gpu
+def test_expert_data_ingest_on_device(tmp_path):
+  """SURVEY.md 8 f3 on the GPU (reference environments.py:63-125 ends in a ReplayMemory): `dataset_to_memory(..., device='cuda')` for the 8 (absorbing, subsample,
+  trajectories) cases of tests/golden/dataset.npz - every field of the DEVICE-resident ring bit-equal to what D4RLEnv.get_dataset built from the same raw arrays, the
+  bookkeeping (num_trajectories, idx, full, len) equal, and 4,096 rows drawn from it (`sample`: host draw + il_replay_gather; `sample_device`: device draw + gather)
+  equal to the fixture's rows at the drawn indices."""
+  from imitation_learning_amd import environments
+  g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'dataset.npz'))
+  raw = gi.raw_d4rl_dataset(81)
+  path = str(tmp_path / 'expert.npz')
+  np.savez(path, **raw)
+  fields = ('states', 'actions', 'rewards', 'next_states', 'terminals', 'timeouts', 'weights', 'step')
+  for absorbing in (True, False):
+    for subsample in (1, 3):
+      for trajectories in (0, 2):
+        for source in (raw, environments.load_dataset_file(path)):
+          il.seed(17)
+          mem = environments.dataset_to_memory(source, absorbing, trajectories, subsample, device=DEV)
+          assert mem.ring.device.type == torch.device(DEV).type
+          tag = f'abs{int(absorbing)}_sub{subsample}_traj{trajectories}'
+          for k in fields:
+            assert N(getattr(mem, k)).tobytes() == g[f'{tag}.{k}'].tobytes(), (tag, k)
+          assert [mem.num_trajectories, mem.idx, int(mem.full), len(mem)] == g[f'{tag}.meta'].tolist(), tag
+        n = 4096
+        idx = mem._sample_idx_tensor(n)
+        hi = mem.size if mem.full else mem.idx - 1
+        assert int(idx.min()) >= 0 and int(idx.max()) < hi
+        got, ix = mem.gather(idx), N(idx).astype(np.int64)
+        views = il_memory.batch_views(got, mem.state_size, mem.action_size, mem.absorbing)
+        for k in ('states', 'actions', 'rewards', 'next_states', 'terminals', 'weights'):
+          want = g[f'{tag}.{k}'][ix]
+          assert N(views[k]).reshape(want.shape).tobytes() == want.tobytes(), (tag, k, 'sample')
+        didx, drows = torch.empty(n, dtype=torch.int32, device=DEV), torch.empty(n, mem.row, device=DEV)
+        dv = mem.sample_device(n, didx, drows)
+        torch.cuda.synchronize()
+        dix = N(didx).astype(np.int64)
+        assert dix.min() >= 0 and dix.max() < hi
+        for k in ('states', 'actions', 'next_states', 'weights'):
+          want = g[f'{tag}.{k}'][dix]
+          assert N(dv[k]).reshape(want.shape).tobytes() == want.tobytes(), (tag, k, 'sample_device')
+
+
+@pytest.mark.gpu
 def test_pair_mode_hops_stay_bit_identical_over_many_replays():
   """k_sac_chain_pair / k_policy_critic_pair hand 16 x 128 halves between workgroups through L2 (same XCD: plain stores behind a drained flag) or write-through stores
   (any placement), read with L1-bypassing loads - no fence. A stale or torn hop would change a hidden activation and, within an update, every parameter: 1,500 captured

@@ -503,18 +503,23 @@ def test_timed_path_replays_through_the_oracle_on_the_emulated_kernels(monkeypat
   WARM, K, SEED = 1, 2, 3
   plan, nets, (tr, et) = bench.build(torch.device('cpu'), 0, seed=SEED)
   o = tt.OracleLearner(nets, plan, tr, et, index_seed=SEED)
-  plan.capture(warmup=WARM)          # WARM eager updates (they count), then the two graphs
+  om = tt.OracleLearner(nets, plan, tr, et, index_seed=SEED)   # replays with the kernels' own ReLU decisions (il_sac.debug_masks)
+  plan.record_relu_masks()
+  for k in range(WARM):              # WARM eager updates (they count), then the two graphs
+    plan.run(); torch.cuda.synchronize()
+    o.update(k); om.update(k, masks=tt.relu_masks(plan))
+  plan.capture(warmup=0)
   assert plan.device_sync and plan.ring_mode and plan.inline_relabel and plan.resident_sampler and plan.graph_side is not None, 'this must be the schedule bench.py times'
-  for k in range(WARM):
-    o.update(k)
   tt.compare_learner(o, nets, plan, WARM, 'eager warm-up: ')
   for k in range(WARM, WARM + K):
     plan.replay()
     torch.cuda.synchronize()
     got = tt.per_update_outputs(plan)
     tt.compare_outputs(got, o.update(k), k)
+    om.update(k, masks=tt.relu_masks(plan))
     tt.reward_bracket(o, nets[4], got[2], k)
   assert plan.sync_timeouts() == 0
+  tt.compare_learner_masked(om, nets, plan, WARM + K)
   tt.compare_learner(o, nets, plan, WARM + K)
 
 

@@ -95,8 +95,9 @@ class OracleLearner:
     self.key = int(plan.sac.noise_seed)
     assert int(plan.disc.noise_seed) == self.key and plan.sac.noise_counter == plan.disc.noise_counter, 'one Philox key / counter per learner'
 
-  def update(self, k):
-    """Update #k (0-based) of train.py:173-203, consuming the recorded draws of counter k. Returns (idx, eidx, rewards, logp, q)."""
+  def update(self, k, masks=None):
+    """Update #k (0-based) of train.py:173-203, consuming the recorded draws of counter k. Returns (idx, eidx, rewards, logp, q).
+    masks: the HIP path's ReLU decisions of this update (relu_masks()): the SAC step then back-propagates through the units the device back-propagated through."""
     cat = lambda b: np.concatenate([b['states'], b['actions']], axis=1)
     idx, eidx = self.mem.sample_idx(self.gen, B), self.emem.sample_idx(self.gen, B)   # train.py:173: agent batch first, then the expert batch, one stream
     b, e = self.mem.gather(idx), self.emem.gather(eidx)
@@ -105,8 +106,28 @@ class OracleLearner:
     ogail.gail_update(self.ds, cat(b), b['weights'], cat(e), e['weights'], eps_gp, lr=LR_D, weight_decay=WD_D, grad_penalty=1.0)        # train.py:178-180
     b['rewards'] = ogail.predict_reward(self.ds, cat(b), 'AIRL')                                                                      # train.py:192-194
     self.last_x = cat(b)   # the rows the rewards were predicted on (the bracket below re-evaluates them on the HIP path's own discriminator state)
-    logp, q = osac.sac_update(self.st, b, eps_next, eps_cur, discount=DISCOUNT, entropy_target=ENT, polyak_factor=POLYAK, lr=LR)       # train.py:203
+    logp, q = osac.sac_update(self.st, b, eps_next, eps_cur, discount=DISCOUNT, entropy_target=ENT, polyak_factor=POLYAK, lr=LR, masks=masks)       # train.py:203
     return np.array(idx), np.array(eidx), b['rewards'], logp, q
+
+
+def relu_masks(plan):
+  """il_sac.debug_masks of the update that has just run, in oracle.sac.sac_update's layout."""
+  m = N(plan.relu_masks) > 0.5
+  return dict(actor=[m[0], m[1]], critic=[[m[2], m[3]], [m[4], m[5]]], pcritic=[[m[6], m[7]], [m[8], m[9]]])
+
+
+def compare_learner_masked(o, nets, plan, k, tag='masked oracle: '):
+  """The SAC tensors of a learner against the oracle that replayed every update WITH the HIP path's ReLU decisions: what remains is fp32 re-association, so
+  the tight bound (rtol 1e-5 + 1e-5 of the scale) must hold for all but 1e-5 of the elements of EVERY tensor - no allowance for moved rows, twin critics included.
+  This is the gate; the unmasked comparison below keeps its documented allowance (two correct evaluations do differ there)."""
+  actor, critic, target, log_alpha, disc = nets
+  ao, co, to = plan._keep[4], plan._keep[5], plan._keep[6]
+  s, f = 1e-5 * k, 1e-5
+  close_params(N(actor.flat), o.st.actor, f'{tag}actor after {k}', LR, k, outlier_frac=f); close_params(crit_from_flat(critic, critic.flat), o.st.critic, f'{tag}critic after {k}', LR, k, outlier_frac=f)
+  close_params(crit_from_flat(critic, target.flat), o.st.target, f'{tag}target after {k}', LR, k, outlier_frac=f)
+  close(N(log_alpha), o.st.log_alpha, f'{tag}log_alpha after {k}', atol_scale=s)
+  close_sparse(N(ao.exp_avg), o.st.actor_m, f'{tag}actor exp_avg', atol_scale=s, outlier_frac=f); close_sparse(N(ao.exp_avg_sq), o.st.actor_v, f'{tag}actor exp_avg_sq', atol_scale=s, outlier_frac=f)
+  close_sparse(crit_from_flat(critic, co.exp_avg), o.st.critic_m, f'{tag}critic exp_avg', atol_scale=s, outlier_frac=f); close_sparse(crit_from_flat(critic, co.exp_avg_sq), o.st.critic_v, f'{tag}critic exp_avg_sq', atol_scale=s, outlier_frac=f)
 
 
 def compare_learner(o, nets, plan, k, tag=''):
@@ -159,21 +180,34 @@ def test_captured_update_plan_replays_through_the_oracle():
   il_training._NOISE.clear(); il_training._WS.clear()
   plan, nets, (tr, et) = bench.build(torch.device(DEV), 0, seed=SEED)
   o = OracleLearner(nets, plan, tr, et, index_seed=SEED)
-  plan.capture(warmup=WARM)          # WARM eager updates (they count), then the two graphs
+  om = OracleLearner(nets, plan, tr, et, index_seed=SEED)   # its twin, replaying every update with the HIP path's ReLU decisions (the gate: compare_learner_masked)
+  plan.record_relu_masks()
+  for k in range(WARM):              # WARM eager updates (they count) ...
+    plan.run(); torch.cuda.synchronize()
+    o.update(k); om.update(k, masks=relu_masks(plan))
+  plan.capture(warmup=0)             # ... then the two graphs
   assert plan.device_sync and plan.ring_mode and plan.inline_relabel and plan.graph_side is not None, 'this must be the schedule bench.py times: device hand-off, ring reads, inline relabel, two graphs'
-  for k in range(WARM):
-    o.update(k)
   compare_learner(o, nets, plan, WARM, 'eager warm-up: ')
   for k in range(WARM, WARM + K):
     plan.replay()
     torch.cuda.synchronize()
     got = per_update_outputs(plan)
     compare_outputs(got, o.update(k), k)
+    om.update(k, masks=relu_masks(plan))
     reward_bracket(o, nets[4], got[2], k)
   assert plan.sync_timeouts() == 0
   assert int(N(il_training._noise_counter(nets[0].flat.device))[0]) == WARM + K, 'one Philox counter tick per update'
+  compare_learner_masked(om, nets, plan, WARM + K)
   compare_learner(o, nets, plan, WARM + K)
   final = [N(n.flat if hasattr(n, 'flat') else n) for n in nets]
+  # test of the test: ONE row of one critic's W2 moved by one Adam step - the error a real defect in one sample's back-propagation would leave, and what the unmasked
+  # comparison's allowance (1.5e-3 of the elements, each up to an Adam step) cannot tell from a ReLU flip - must fail the masked comparison
+  keep = om.st.critic.copy()
+  row = S + A + 1   # (any row of W2: offset H * IN + H + row * H in critic_1)
+  om.st.critic[H * (S + A) + H + row * H: H * (S + A) + H + (row + 1) * H] += np.float32(LR)
+  with pytest.raises(AssertionError, match='critic'):
+    compare_learner_masked(om, nets, plan, WARM + K)
+  om.st.critic[:] = keep
 
   # the same replays back to back with no host synchronisation in between (the timed regime) end in the same bits
   il_training._NOISE.clear(); il_training._WS.clear()
@@ -193,20 +227,25 @@ def test_batched_population_replays_through_the_oracle():
   il_training._NOISE.clear(); il_training._WS.clear()
   built = [bench.build(torch.device(DEV), 0, seed=100 + l, learner_id=100 + l) for l in range(Lp)]
   oracles = [OracleLearner(nets, plan, tr, et, index_seed=100 + l) for l, (plan, nets, (tr, et)) in enumerate(built)]
+  masked = [OracleLearner(nets, plan, tr, et, index_seed=100 + l) for l, (plan, nets, (tr, et)) in enumerate(built)]   # twins replaying with the launches' ReLU decisions
   assert len({o.key for o in oracles}) == Lp
+  for plan, _, _ in built: plan.record_relu_masks()   # (before the population copies the descriptors to the device)
   pop = il.BatchedPopulationPlan([b[0] for b in built])
   pop.run()                      # one eager update (builds the lane-ordered weight copies), then the captured launches
+  torch.cuda.synchronize()
+  for o, om, (plan, _, _) in zip(oracles, masked, built):
+    o.update(0); om.update(0, masks=relu_masks(plan))
   pop.capture()
-  for o in oracles:
-    o.update(0)
   for k in range(1, K):
     pop.replay()
     torch.cuda.synchronize()
-    for l, (o, (plan, nets, _)) in enumerate(zip(oracles, built)):
+    for l, (o, om, (plan, nets, _)) in enumerate(zip(oracles, masked, built)):
       got = per_update_outputs(plan)
       compare_outputs(got, o.update(k), k, f'learner {l}: ')
+      om.update(k, masks=relu_masks(plan))
       reward_bracket(o, nets[4], got[2], k, f'learner {l}: ')
-  for l, (o, (plan, nets, _)) in enumerate(zip(oracles, built)):
+  for l, (o, om, (plan, nets, _)) in enumerate(zip(oracles, masked, built)):
+    compare_learner_masked(om, nets, plan, K, f'learner {l}, masked oracle: ')
     compare_learner(o, nets, plan, K, f'learner {l}: ')
 
 
