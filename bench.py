@@ -501,6 +501,27 @@ def main():
   elapsed, launch = measure()
   exchange_fallback = None
   ok, same, digests, note = health()
+  # N > 1: BOTH gradient exchanges timed in this one invocation (an 8-GPU node may be available for a single run per round): first the default - the peer-window exchange,
+  # inside the optimiser launches where the schedule allows - then, from rank 0's replica state, torch.distributed all-reduces (RCCL). `value` is the better of the runs
+  # that passed the post-run check (no expired wait, replicas bit-identical); config.exchange names it, config.exchange_ab carries both.
+  exchange_ab = None
+  if world > 1 and getattr(runner, 'peer', None) is not None and ok and same and os.environ.get('IL_BENCH_EXCHANGE_AB', '1') != '0':
+    first = dict(exchange=runner.exchange_name(), updates_per_s=round(world * args.steps / elapsed, 1), ms_per_step=round(elapsed / args.steps * 1e3, 5), launch=launch,
+                 replicas_bit_identical=same, replica_digests=[d[:16] for d in digests], exchange_soak=getattr(runner.peer, 'soak_report', None), valid=True)
+    peer_form = getattr(runner.peer, 'form', 0)
+    beat('A/B: the collectives')
+    runner.use_collectives('A/B run of bench.py: the same job re-timed with torch.distributed all-reduces')
+    plan.sync[plan._sync_timeouts] = 0
+    runner.resync_replicas()
+    elapsed2, launch2 = measure()
+    ok2, same2, digests2, note2 = health()
+    second = dict(exchange=runner.exchange_name(), updates_per_s=round(world * args.steps / elapsed2, 1), ms_per_step=round(elapsed2 / args.steps * 1e3, 5), launch=launch2,
+                  replicas_bit_identical=same2, replica_digests=[d[:16] for d in digests2], valid=bool(ok2 and same2), note=note2)
+    exchange_ab = dict(peer=first, collectives=second, chosen='peer' if (not second['valid'] or elapsed <= elapsed2) else 'collectives')
+    if exchange_ab['chosen'] == 'collectives':
+      elapsed, launch, ok, same, digests, note = elapsed2, launch2, ok2, same2, digests2, note2
+    else:
+      exchange_ab['reported_exchange'] = first['exchange']   # (the runner itself now sits on the collectives; the line below reports the run that was chosen)
   if world > 1 and getattr(runner, 'peer', None) is not None and not (ok and same):
     # One retry, in process, on the collectives: the peer-window exchange delivered late (expired waits) or wrong (replicas apart). Rank 0's state everywhere, then RCCL.
     exchange_fallback = f'peer-window exchange failed the post-run check ({"replicas differ" if not same else "expired waits"}{"; " + note if note else ""}): re-timed with torch.distributed all-reduces'
@@ -518,6 +539,25 @@ def main():
     raise RuntimeError(f'data-parallel replicas are NOT bit-identical after the timed run (digests {digests}): the gradient exchange delivered different values to different ranks')
   beat('reporting')
 
+  single = None
+  if world > 1 and os.environ.get('IL_BENCH_SINGLE', '1') != '0':
+    # The N = 1 schedule (one GPU's own update plan: no split path, no exchange) timed on every rank at the same time, each on its own GPU and its own fresh learner, in this
+    # same job: data-parallel efficiency = (value / n_gpus) / config.single_gpu_same_job.updates_per_s is computable from this one line.
+    beat('N = 1 schedule, same job')
+    from imitation_learning_amd import training as il_training
+    plan1, nets1, _ = build(device, rank, seed=1000 + rank, learner_id=1000 + rank)
+    plan1.capture(warmup=3)
+    for _ in range(min(args.warmup, 300)): plan1.replay()
+    barrier()
+    n1 = min(args.steps, 2000)
+    t1 = time.perf_counter()
+    for _ in range(n1): plan1.replay()
+    torch.cuda.synchronize()
+    e1 = time.perf_counter() - t1
+    assert plan1.sync_timeouts() == 0
+    single = dict(updates_per_s=round(n1 / e1, 1), ms_per_step=round(e1 / n1 * 1e3, 5), steps=n1, note=f'rank 0 of {world}, all ranks running their own single-GPU plan concurrently (one per GPU)')
+    barrier()
+    del plan1, nets1
   if rank == 0:
     ms_per_step = elapsed / args.steps * 1e3
     ups = world * args.learners * args.steps / elapsed
@@ -534,10 +574,13 @@ def main():
                config=dict(workload='algorithm=GAIL env=halfcheetah: 2 replay samples + discriminator step (BCE+GP+SN) + AIRL relabel + sac_update per step',
                            batch_per_gpu=B, global_batch=B * world, state_dim=S, action_dim=A, hidden=H, replay_capacity=1_000_000, replay_fill=100_000, expert_rows=25_000,
                            learners_per_gpu=args.learners, parallelism=f'dp{world}' + ('(split path' + (', device hand-off between the discriminator and SAC branches, own communicator per branch)' if getattr(runner, 'handoff', False) else ', stream dependencies)') if runner is not plan else ''), launch=launch, noise='on-chip Philox4x32-10', finite=finite,
-                           gradient_exchange=(None if runner is plan else ('one kernel per sync point over peer-mapped windows (il_peer_allreduce_mean: push to every rank, rank-ordered sum; ' + ('write-through payload, no fences' if getattr(runner.peer, 'form', 0) else 'system-scope fences') + ')'
+                           gradient_exchange=(None if runner is plan else ('the peer-window exchange (see exchange_ab.peer)' if exchange_ab and exchange_ab['chosen'] == 'peer' else None) or ('one kernel per sync point over peer-mapped windows (il_peer_allreduce_mean: push to every rank, rank-ordered sum; ' + ('write-through payload, no fences' if getattr(runner.peer, 'form', 0) else 'system-scope fences') + ')'
                                                                              if getattr(runner, 'peer', None) is not None else f'{backend.replace("nccl", "RCCL")} all-reduce (mean) per sync point')),
-                           exchange=(None if runner is plan else runner.exchange_name()), exchange_note=(None if runner is plan else runner.peer_note), exchange_fallback=exchange_fallback,
-                           exchange_soak=(getattr(runner.peer, 'soak_report', None) if getattr(runner, 'peer', None) is not None else None),
+                           exchange=(None if runner is plan else (exchange_ab['reported_exchange'] if exchange_ab and 'reported_exchange' in exchange_ab else runner.exchange_name())),
+                           exchange_ab=exchange_ab, single_gpu_same_job=single,
+                           dp_efficiency=(round(ups / world / single['updates_per_s'], 4) if single else None),
+                           exchange_note=(None if runner is plan else runner.peer_note), exchange_fallback=exchange_fallback,
+                           exchange_soak=(exchange_ab['peer']['exchange_soak'] if exchange_ab else (getattr(runner.peer, 'soak_report', None) if getattr(runner, 'peer', None) is not None else None)),
                            replicas_bit_identical=(same if runner is not plan else None), replica_digests=([d[:16] for d in digests] if runner is not plan else None),
                            branch_sync=('device counters (two graphs, no cross-stream edge)' if getattr(plan, 'device_sync', False) and runner is plan else 'stream dependencies'),
                            rows=('read from the rings through the drawn indices (il_batch.gather), relabel inline in k_sac_chain' if getattr(plan, 'inline_relabel', False) and runner is plan

@@ -2568,6 +2568,7 @@ extern "C" int il_sac_dp_phase_peer(const il_sac* d, const il_batch* b, int32_t 
   IL_CHECK_ARG(phase == 2 || phase == 3, "il_sac_dp_phase_peer: phases 2 and 3 begin with an apply step (got %d)", phase);
   IL_CHECK_ARG(d->actor_grad && d->critic_grad && d->alpha_grad, "il_sac_dp_phase_peer: gradient arenas missing");
   IL_CHECK_ARG(x && x->world >= 1 && x->world <= IL_PEER_MAX_RANKS && x->rank >= 0 && x->rank < x->world && x->epoch && x->status, "il_sac_dp_phase_peer: bad peer descriptor");
+  IL_CHECK_ARG(x->n_jobs == 0, "il_sac_dp_phase_peer: the bucket is laid out for the exchange INSIDE the optimiser launches (%d arrival lines per job): its apply kernels index epochs and arrival lines by chunk", x->n_jobs);
   for (int r = 0; r < x->world; ++r) IL_CHECK_ARG(x->windows[r], "il_sac_dp_phase_peer: window of rank %d is not mapped", r);
   hipStream_t st = (hipStream_t)stream_;
   const int S = d->state_dim, A = d->action_dim, H = d->hidden;

@@ -151,10 +151,13 @@ class Watchdog:
   remaining ranks down. IL_WATCHDOG_S overrides the bound; 0 disables."""
   EXIT_CODE = 124
 
-  def __init__(self, timeout_s: float = 300.0, what: str = 'run'):
+  def __init__(self, timeout_s: float = 300.0, what: str = 'run', armed: bool = True):
+    """armed=False: the heartbeat is only watched from `arm()` on - a training run arms it at its first captured update, so that the single-rank phases before it whose
+    length the bound knows nothing about (expert-data load, 100k pretraining iterations, PWIL relabelling, peer-window set-up and soak, graph capture) cannot trip it."""
     import threading
     import time
     self.timeout_s = float(os.environ.get('IL_WATCHDOG_S', timeout_s))
+    self.armed = bool(armed)
     self.what, self.phase, self._time, self._last, self._stop = what, 'start', time, time.monotonic(), threading.Event()
     self._thread = None
     if self.timeout_s > 0:
@@ -162,7 +165,16 @@ class Watchdog:
       self._thread.start()
 
   def beat(self, phase: Optional[str] = None):
-    self._last = self._time.monotonic()
+    self._last = max(self._last, self._time.monotonic())   # (never shortens a grace period)
+    if phase is not None: self.phase = phase
+
+  def arm(self, phase: Optional[str] = None):
+    self._last, self.armed = self._time.monotonic(), True
+    if phase is not None: self.phase = phase
+
+  def grace(self, seconds: float, phase: Optional[str] = None):
+    """A phase every rank knows to be long (rank 0's evaluation episodes, during which its peers wait inside the next collective): no alarm for `seconds` + the bound."""
+    self._last = max(self._last, self._time.monotonic() + float(seconds))
     if phase is not None: self.phase = phase
 
   def stop(self):
@@ -172,7 +184,7 @@ class Watchdog:
     import sys
     while not self._stop.wait(min(1.0, self.timeout_s / 4)):
       idle = self._time.monotonic() - self._last
-      if idle > self.timeout_s:
+      if self.armed and idle > self.timeout_s:
         rank = os.environ.get('RANK', '0')
         print(f'[watchdog] rank {rank}: no progress for {idle:.0f} s in phase "{self.phase}" of {self.what} (bound {self.timeout_s:.0f} s): a peer rank died or stalled inside a '
               f'collective / device-side wait. Ending this rank (exit {self.EXIT_CODE}) so that the job fails instead of hanging.', file=sys.stderr, flush=True)
@@ -537,7 +549,9 @@ class DataParallelUpdate:
       torch.cuda.synchronize()
       self.handoff = False
       self.fused, self.plan.peer_desc = False, None   # the stream-dependency schedule keeps one exchange launch per sync point (the same peer regions serve it)
+      keep = (self.plan.sync[self.plan._sync_spin].clone(), self.plan.sync[self.plan._sync_host_flag].clone())   # the widened bound and the host's time-out word survive the reset
       self.plan.sync.zero_()
+      self.plan.sync[self.plan._sync_spin], self.plan.sync[self.plan._sync_host_flag] = keep
       self.plan._set_device_sync(False)
     return self.handoff
 

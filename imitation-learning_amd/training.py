@@ -512,6 +512,8 @@ class UpdatePlan:
     torch.cuda.synchronize()
     ok = self.sync_timeouts() == before
     self.sync[self._sync_timeouts] = 0
+    w = getattr(self, '_watch_host', None)
+    if w is not None: w[0] = 0   # an expired PROBE wait also reached the pinned host word (watch_timeouts): it is not an expired wait of an update
     return ok
 
   def widen_handoff_bound(self, polls: Optional[int] = None):
@@ -658,6 +660,7 @@ class UpdatePlan:
     """The discriminator step of the ring schedule; with the resident sampler the index draw rides in the same launch (il_gail_disc_step_draw)."""
     L, st = _lib.lib(), _lib.stream_ptr()
     rp, re_ = self._ring_batches()
+    self._fused_exchange_needs_the_resident_sampler()
     if self.resident_sampler:
       m, e = self.memory, self.expert_memory
       mt = m.stream().device_state(m.device)
@@ -683,7 +686,18 @@ class UpdatePlan:
     _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))
     _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
 
+  def _fused_exchange_needs_the_resident_sampler(self):
+    """parallel.DataParallelUpdate decides ONCE (collectively) that the gradient exchanges ride in the optimiser launches (`peer_desc`); `resident_sampler` is re-evaluated
+    on every call and depends on `pre_hooks` / `stream_ordered_draw` / IL_RESIDENT_SAMPLER. A hook attached AFTER that decision (ActingWorker.attach for
+    +acting.schedule=overlap) would send the discriminator step down the non-resident branch, which has no exchange at all: the replicas would diverge silently until the
+    next replica check. Fail at the first such update instead."""
+    if self.peer_desc is not None and not self.resident_sampler:
+      raise RuntimeError('UpdatePlan: the data-parallel gradient exchange rides in the optimiser launches of the resident-sampler schedule, but that schedule is no longer '
+                         'active (a pre-hook was attached, stream_ordered_draw was set or IL_RESIDENT_SAMPLER changed after DataParallelUpdate was built). Build the '
+                         'DataParallelUpdate after attaching hooks, or call DataParallelUpdate.use_collectives() on every rank.')
+
   def _enqueue_sac_branch(self):
+    self._fused_exchange_needs_the_resident_sampler()
     resident = self.resident_sampler
     if not resident:
       self.sample_all()

@@ -42,14 +42,14 @@ FRACTIONS = []   # (name, measured outlier fraction, allowed) of every close_par
                  # towards the allowance is visible long before it fails
 
 
-def _note_fraction(name, frac, allowed):
+def _note_fraction(name, frac, allowed, gate=True):
   FRACTIONS.append((name, frac, allowed))
-  if frac > 0.5 * allowed:
+  if gate and frac > 0.5 * allowed:   # gate=False: a comparison that documents a known effect next to the test's real gate (the masked-oracle comparison): recorded, no warning
     import warnings
     warnings.warn(f'{name}: {frac:.2e} of the elements are outside the tight bound - more than half of the allowance ({allowed:.0e})')
 
 
-def close_params(a, b, name, lr, steps=1, rtol=1e-5, atol_scale=1e-5, outlier_frac=5e-4):
+def close_params(a, b, name, lr, steps=1, rtol=1e-5, atol_scale=1e-5, outlier_frac=5e-4, gate=True):
   """Parameters after Adam. Adam normalises the gradient, so an element whose true gradient is ~eps_adam (1e-8) turns ulp-level
   gradient noise into an O(lr) difference (d update / d g = lr * eps / (|g| + eps)^2). Hence: EVERY element within the tight bound
   plus one full Adam step per update (lr * steps), and all but a `outlier_frac` fraction within the tight bound itself."""
@@ -61,7 +61,7 @@ def close_params(a, b, name, lr, steps=1, rtol=1e-5, atol_scale=1e-5, outlier_fr
   worst = int((err - tight).argmax())
   assert (err <= tight + 1.01 * lr * steps).all(), f'{name}: element {worst} off by {err[worst]:.3e} (> one Adam step): hip {a.ravel()[worst]:.8e} vs oracle {b.ravel()[worst]:.8e}'
   frac = float((err > tight).mean())
-  _note_fraction(name, frac, outlier_frac)
+  _note_fraction(name, frac, outlier_frac, gate)
   assert frac <= outlier_frac, f'{name}: {frac:.2e} of the elements exceed the tight bound (allowed {outlier_frac:.0e}); worst {err[worst]:.3e} at {worst}'
 
 

@@ -268,7 +268,16 @@ def test_bench_starts_its_own_ranks_and_reports_the_replica_digest(peer):
   assert j['n_gpus'] == 2 and c['global_batch'] == 512 and 'bench.py itself' in c['launched_by']
   assert c['replicas_bit_identical'] is True and len(c['replica_digests']) == 2 and len(set(c['replica_digests'])) == 1
   if peer == '1':
-    assert c['exchange'].startswith('peer') and c['exchange_soak']['rounds'] == 200 and c['exchange_soak']['expired_waits'] == 0 and not any(c['exchange_soak']['mismatching_elements'].values())
+    assert c['exchange_soak']['rounds'] == 200 and c['exchange_soak']['expired_waits'] == 0 and not any(c['exchange_soak']['mismatching_elements'].values())
+    # one invocation times BOTH exchanges (an 8-GPU node may be there for one run only): the peer windows, then - from rank 0's replicas - the collectives
+    ab = c['exchange_ab']
+    assert ab['peer']['exchange'].startswith('peer') and ab['collectives']['exchange'] == 'gloo' and ab['peer']['valid'] and ab['collectives']['valid']
+    for run in (ab['peer'], ab['collectives']):
+      assert run['replicas_bit_identical'] is True and len(set(run['replica_digests'])) == 1 and run['updates_per_s'] > 0
+    assert ab['chosen'] in ('peer', 'collectives') and j['value'] == ab[ab['chosen']]['updates_per_s']
+    assert c['exchange'] == ab[ab['chosen']]['exchange']
   else:
-    assert c['exchange'] == 'gloo' and c['exchange_soak'] is None
+    assert c['exchange'] == 'gloo' and c['exchange_soak'] is None and c['exchange_ab'] is None
+  # the N = 1 schedule timed in the same job: data-parallel efficiency from this one line
+  assert c['single_gpu_same_job']['updates_per_s'] > 0 and abs(c['dp_efficiency'] - j['value'] / 2 / c['single_gpu_same_job']['updates_per_s']) < 1e-3
   assert c['exchange_fallback'] is None and j['value'] > 0

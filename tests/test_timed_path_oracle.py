@@ -138,8 +138,9 @@ def compare_learner(o, nets, plan, k, tag=''):
   # Twin critics after a CHAIN of updates: one ReLU pre-activation within rounding of 0 that takes the other sign moves a whole row of a W2 (256 of 145k elements = 1.8e-3 ... the
   # measured worst case over the learners of these tests is 1.0e-3 of the elements, round 3; everything else uses the 5e-4 default of tests/gpu_util.py). The run prints the
   # largest measured fractions at its end (conftest.pytest_terminal_summary).
-  close_params(N(actor.flat), o.st.actor, f'{tag}actor after {k}', LR, k); close_params(crit_from_flat(critic, critic.flat), o.st.critic, f'{tag}critic after {k}', LR, k, outlier_frac=1.5e-3)
-  close_params(crit_from_flat(critic, target.flat), o.st.target, f'{tag}target after {k}', LR, k, outlier_frac=1.5e-3)
+  # (gate=False: the fraction is recorded, not warned about - compare_learner_masked is the gate of these tests; this comparison documents how far two correct evaluations drift)
+  close_params(N(actor.flat), o.st.actor, f'{tag}actor after {k}', LR, k); close_params(crit_from_flat(critic, critic.flat), o.st.critic, f'{tag}critic after {k}', LR, k, outlier_frac=1.5e-3, gate=False)
+  close_params(crit_from_flat(critic, target.flat), o.st.target, f'{tag}target after {k}', LR, k, outlier_frac=1.5e-3, gate=False)
   close(N(log_alpha), o.st.log_alpha, f'{tag}log_alpha after {k}', atol_scale=s)
   close_sparse(N(ao.exp_avg), o.st.actor_m, f'{tag}actor exp_avg', atol_scale=s); close_sparse(N(ao.exp_avg_sq), o.st.actor_v, f'{tag}actor exp_avg_sq', atol_scale=s)
   close_sparse(crit_from_flat(critic, co.exp_avg), o.st.critic_m, f'{tag}critic exp_avg', atol_scale=s); close_sparse(crit_from_flat(critic, co.exp_avg_sq), o.st.critic_v, f'{tag}critic exp_avg_sq', atol_scale=s)
@@ -205,8 +206,14 @@ def test_captured_update_plan_replays_through_the_oracle():
   keep = om.st.critic.copy()
   row = S + A + 1   # (any row of W2: offset H * IN + H + row * H in critic_1)
   om.st.critic[H * (S + A) + H + row * H: H * (S + A) + H + (row + 1) * H] += np.float32(LR)
-  with pytest.raises(AssertionError, match='critic'):
-    compare_learner_masked(om, nets, plan, WARM + K)
+  import warnings
+  import gpu_util
+  n_before = len(gpu_util.FRACTIONS)
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    with pytest.raises(AssertionError, match='critic'):
+      compare_learner_masked(om, nets, plan, WARM + K)
+  del gpu_util.FRACTIONS[n_before:]   # (the deliberate failure is not a measurement)
   om.st.critic[:] = keep
 
   # the same replays back to back with no host synchronisation in between (the timed regime) end in the same bits

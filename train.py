@@ -78,7 +78,7 @@ def train(cfg, file_prefix: str = '') -> float:
     from imitation_learning_amd import parallel
     assert torch.cuda.is_available(), 'train.py needs a GPU: the update path has no CPU fallback'
     rank, _, dev = parallel.init_from_env(world, cfg.distributed.backend)
-    dog = parallel.Watchdog(float(cfg.distributed.timeout_s), what=f'train.py (rank {rank} of {world})')   # a rank that dies inside a collective must not hang the others
+    dog = parallel.Watchdog(float(cfg.distributed.timeout_s), what=f'train.py (rank {rank} of {world})', armed=False)   # a rank that dies inside a collective must not hang the others; armed at the first captured update (the set-up phases before it have no bound of their own)
   else:
     dev, dog = default_device(), None
   assert _lib.on_device(torch.empty(0, device=dev)), 'train.py needs a GPU: the update path has no CPU fallback'
@@ -190,6 +190,9 @@ def train(cfg, file_prefix: str = '') -> float:
   assert schedule in ('exact', 'fused', 'overlap', 'per_function')
   worker = il.ActingWorker(actor, memory, mirror=schedule == 'overlap') if cfg.algorithm != 'PWIL' and schedule != 'per_function' else None
   if worker is None: schedule = 'per_function'
+  if schedule == 'overlap' and world > 1:
+    raise NotImplementedError('+acting.schedule=overlap with distributed.world_size > 1: the overlap schedule captures the append in the update plan\'s hooks, which the '
+                              'data-parallel runner does not run (use exact or fused)')
   if schedule == 'overlap' and plan is not None: worker.attach(plan)   # append + parameter snapshot ride in the update's hipGraph
   elif plan is not None: plan.main_feeds_ring = True   # appends are enqueued on this stream between updates: a resident index draw on the other stream must come after them
   if cfg.algorithm in ('GAIL', 'RED'): discriminator.eval()   # train.py:147: from here on the RED predictor's dropout is off (DRIL keeps its dropout on purpose)
@@ -248,6 +251,7 @@ def train(cfg, file_prefix: str = '') -> float:
           plan.watch_timeouts(runner.peer.status if getattr(runner, 'peer', None) is not None else None)   # expired device-side waits raise a host-visible flag from now on
           if world > 1:   # graph capture takes different times on different ranks: meet again before the first replay, whose device-side waits are bounded
             torch.cuda.synchronize(); torch.distributed.barrier()
+          if dog is not None: dog.arm(f'step {step}')
         else:
           step_update()
         check_timeouts_seen(plan, step, last_good)   # host read of pinned words: every step, independent of logging.interval
@@ -284,6 +288,8 @@ def train(cfg, file_prefix: str = '') -> float:
 
     if schedule == 'overlap': action = worker.act(state)   # own stream, published snapshot: returns while the update is still running
 
+    if dog is not None and step % cfg.evaluation.interval == 0 and not cfg.check_time_usage:   # every rank: rank 0 evaluates, its peers wait for it inside their next collective
+      dog.grace(0.005 * cfg.evaluation.episodes * env.max_episode_steps, 'evaluation')
     if step % cfg.evaluation.interval == 0 and not cfg.check_time_usage and lead:
       episode_returns = evaluate_agent(actor, eval_env, cfg.evaluation.episodes)
       normalised = normalise(episode_returns)
