@@ -238,6 +238,194 @@ __global__ __launch_bounds__(256) void k_gmmil_tile(int n1, int n2, int D, float
   if (out_self) out_self[i] = self;
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_gmmil_direct (round 4): k_gmmil_tile reading its operands straight from the two batches. k_gmmil_pack only existed to give the tile kernel feature-major operands; it
+// cost a 6 us launch plus a kernel boundary per reward call, and its output - written an instant earlier, mostly on other XCDs - made every operand load of the tile
+// kernel a fabric round trip. Here a thread loads 16-byte lanes ALONG a row (8 lanes cover the 32 features of a chunk: whole 128-byte lines of the row-major batch),
+// and transposes on its way into LDS: Xs[k][r ^ 4 ((k / 4) % 8)] - the XOR swizzle keeps every group of four consecutive rows aligned and contiguous (the inner loop's
+// ds_read_b128) and spreads the eight lanes that write one row's 32 features over eight banks (an unswizzled transposed store is an 8-way conflict). Each workgroup sums
+// the weight columns itself (k_gmmil_pack's chunk-0 workgroups did the same sums in the same order: same bits). Same pair arithmetic, same partial sums, same
+// last-arriver reduction: bit-identical rewards. The arrival counters are left at zero by the last arriver of each row tile: zero-initialise the workspace ONCE per shape
+// (include/il_hip.h). Rows that are not whole 16-byte lanes (S, A, strides or pointers not multiples of 4 floats) take the element-wise loads of cat_at.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 cat_lane(const il_batch& b, int S, int D, int r, int k, bool lanes) {   // features k .. k + 3 of row r (k % 4 == 0); beyond D: don't care (zeroed at the LDS store)
+  if (lanes) {
+    const int kc = min(k, D - 4);
+    return kc < S ? gload4(b.states + (size_t)r * b.ld_states + kc) : gload4(b.actions + (size_t)r * b.ld_actions + (kc - S));
+  }
+  f32x4 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = cat_at(b, S, r, min(k + q, D - 1));
+  return v;
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gmmil_direct(il_batch pol, il_batch exp, int S, int D, float g1, float g2, float* __restrict__ ws_, float* __restrict__ dist_out, int self_second,
+                                                      float* __restrict__ out_r, float* __restrict__ out_sim, float* __restrict__ out_self, int lanes) {
+  constexpr int RB = GMMIL_RB, RQ = RB / 4;
+  __shared__ __attribute__((aligned(16))) float Xs[GKC][GTR];
+  __shared__ __attribute__((aligned(16))) float Ys[GKC][GT];
+  __shared__ float red[32];
+  globalize(pol); globalize(exp);
+  const int n1 = pol.n, n2 = exp.n;
+  const GmmilWs w = gmmil_ws(n1, n2, D);
+  const int it = blockIdx.x, jt = blockIdx.y, mat = blockIdx.z;  // mat 0: policy vs expert, 1: policy vs policy
+  const bool vs_self = (mat == 1) || (MODE == 1 && self_second);
+  const int npy = vs_self ? w.b1p : w.b2p;
+  if (jt * GT >= npy) return;
+  const il_batch& yb = vs_self ? pol : exp;
+  const int ny = yb.n;
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  // weight-column sums (MODE 0): requested first, reduced after the feature loop
+  float sx = 0.f, sy = 0.f;
+  if (MODE == 0) {
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) sx += pol.weights[(size_t)i * pol.ld_weights];
+    if (!vs_self) for (int i = threadIdx.x; i < ny; i += blockDim.x) sy += yb.weights[(size_t)i * yb.ld_weights];
+  }
+  f32x2 acc2[RB][2];
+#pragma unroll
+  for (int a = 0; a < RB; ++a) { acc2[a][0] = f32x2{0.f, 0.f}; acc2[a][1] = f32x2{0.f, 0.f}; }
+  constexpr int PX4 = GKC * GTR / 4 / 256, PY4 = GKC * GT / 4 / 256, NPF = GMMIL_PF;   // 16-byte lanes per thread and chunk
+  f32x4 xr[NPF][PX4], yr[NPF][PY4];
+  auto fetch = [&](f32x4* xs_, f32x4* ys_, int k0) {
+#pragma unroll
+    for (int u = 0; u < PX4; ++u) { const int i = threadIdx.x + u * 256, r = i >> 3, kq = i & 7; xs_[u] = cat_lane(pol, S, D, min(it * GTR + r, n1 - 1), k0 + 4 * kq, lanes != 0); }
+#pragma unroll
+    for (int u = 0; u < PY4; ++u) { const int i = threadIdx.x + u * 256, r = i >> 3, kq = i & 7; ys_[u] = cat_lane(yb, S, D, min(jt * GT + r, ny - 1), k0 + 4 * kq, lanes != 0); }
+  };
+#pragma unroll
+  for (int sl = 0; sl < NPF; ++sl) if (sl * GKC < D) fetch(xr[sl], yr[sl], sl * GKC);
+  for (int kk = 0; kk < D; kk += NPF * GKC) {
+#pragma unroll
+   for (int sl = 0; sl < NPF; ++sl) {
+    const int k0 = kk + sl * GKC;
+    if (k0 >= D) break;
+#pragma unroll
+    for (int u = 0; u < PX4; ++u) {
+      const int i = threadIdx.x + u * 256, r = i >> 3, kq = i & 7, col = r ^ (4 * kq);
+      const bool rv = it * GTR + r < n1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Xs[4 * kq + q][col] = (rv && k0 + 4 * kq + q < D) ? xr[sl][u][q] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < PY4; ++u) {
+      const int i = threadIdx.x + u * 256, r = i >> 3, kq = i & 7, col = r ^ (4 * kq);
+      const bool rv = jt * GT + r < ny;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Ys[4 * kq + q][col] = (rv && k0 + 4 * kq + q < D) ? yr[sl][u][q] : 0.f;
+    }
+    __syncthreads();
+    if (k0 + NPF * GKC < D) fetch(xr[sl], yr[sl], k0 + NPF * GKC);
+    constexpr int GG = GMMIL_GG;   // (2: both features of a group share the swizzle of their group of four)
+    f32x4 xa_[GG][RQ], ya_[GG], xb_[GG][RQ], yb_[GG];
+    auto lds_group = [&](f32x4 (*xg)[RQ], f32x4* yg, int kb) {
+      const int sw = ((kb >> 2) & 7) << 2;
+#pragma unroll
+      for (int u = 0; u < GG; ++u) {
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) xg[u][q] = *reinterpret_cast<const f32x4*>(&Xs[kb + u][(ti * RB + 4 * q) ^ sw]);
+        yg[u] = *reinterpret_cast<const f32x4*>(&Ys[kb + u][(tj * 4) ^ sw]);
+      }
+    };
+    auto fma_group = [&](const f32x4 (*xg)[RQ], const f32x4* yg) {
+#pragma unroll
+      for (int u = 0; u < GG; ++u) {
+        const f32x2 y01 = {yg[u][0], yg[u][1]}, y23 = {yg[u][2], yg[u][3]};
+#pragma unroll
+        for (int a = 0; a < RB; ++a) {
+          const float xs = xg[u][a >> 2][a & 3];
+          const f32x2 xa = {xs, xs};
+          const f32x2 d0 = xa - y01, d1 = xa - y23;
+          acc2[a][0] = __builtin_elementwise_fma(d0, d0, acc2[a][0]);
+          acc2[a][1] = __builtin_elementwise_fma(d1, d1, acc2[a][1]);
+        }
+      }
+    };
+    lds_group(xa_, ya_, 0);
+#pragma unroll 1
+    for (int kb = 0; kb < GKC; kb += 2 * GG) {
+      lds_group(xb_, yb_, kb + GG);
+      __builtin_amdgcn_sched_barrier(0);
+      fma_group(xa_, ya_);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_group(xa_, ya_, (kb + 2 * GG) & (GKC - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      fma_group(xb_, yb_);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+   }
+  }
+  float acc[RB][4];
+#pragma unroll
+  for (int a = 0; a < RB; ++a) { acc[a][0] = acc2[a][0][0]; acc[a][1] = acc2[a][0][1]; acc[a][2] = acc2[a][1][0]; acc[a][3] = acc2[a][1][1]; }
+  const float fD = (float)D;
+  if (MODE == 1) {
+    const int n2e = vs_self ? n1 : n2;
+#pragma unroll
+    for (int a = 0; a < RB; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = it * GTR + ti * RB + a, j = jt * GT + tj * 4 + b;
+        if (i < n1 && j < n2e) dist_out[(size_t)i * n2e + j] = acc[a][b] / fD;
+      }
+    return;
+  }
+  sx = block_sum(sx, red);
+  sy = vs_self ? sx : block_sum(sy, red);
+  f32x4 wv;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { const int j = jt * GT + tj * 4 + b; wv[b] = j < ny ? yb.weights[(size_t)j * yb.ld_weights] / sy : 0.f; }
+  float* part = ws_ + w.part + ((size_t)mat * w.njt + jt) * w.b1p + it * GTR;
+#pragma unroll
+  for (int a = 0; a < RB; ++a) {
+    float s = 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { const float dd = acc[a][b] / fD; s += wv[b] * (expf(-g1 * dd) + expf(-g2 * dd)); }
+    s = group16_sum(s);
+    if (tj == 0) part[ti * RB + a] = s;
+  }
+  if (!out_r) return;
+  __shared__ unsigned last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned expect = (unsigned)(w.b2p / GT + w.b1p / GT);
+    unsigned* ctr = reinterpret_cast<unsigned*>(ws_ + w.ctr) + it * GCTR;
+    last = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1u == expect;
+    if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // zero again for the next call
+  }
+  __syncthreads();
+  if (!last || threadIdx.x >= GTR) return;
+  const int i = it * GTR + threadIdx.x;
+  if (i >= n1) return;
+  auto ordered_sum = [&](const float* p, int nq) {
+    float s = 0.f;
+    for (int q0 = 0; q0 < nq; q0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = p[(size_t)min(q0 + u, nq - 1) * w.b1p];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) if (q0 + u < nq) s += v[u];
+    }
+    return s;
+  };
+  const float s0 = ordered_sum(ws_ + w.part + i, w.b2p / GT);
+  const float s1 = ordered_sum(ws_ + w.part + (size_t)w.njt * w.b1p + i, w.b1p / GT);
+  const float wi = pol.weights[(size_t)i * pol.ld_weights] / sx;
+  const float sim = wi * s0, self = wi * s1;
+  out_r[i] = sim - self;
+  if (out_sim) out_sim[i] = sim;
+  if (out_self) out_self[i] = self;
+}
+static bool gmmil_direct() { static const int on = [] { const char* e = getenv("IL_GMMIL_DIRECT"); return e && e[0] == '0' ? 0 : 1; }(); return on != 0; }   // IL_GMMIL_DIRECT=0: k_gmmil_pack + k_gmmil_tile (developer A/B; same bits)
+static int gmmil_lanes(const il_batch* a, const il_batch* b, int S, int A, int state_only) {   // whole 16-byte lanes along the rows of both batches?
+  auto ok = [&](const il_batch* x) {
+    const bool st = (reinterpret_cast<uintptr_t>(x->states) & 15) == 0 && x->ld_states % 4 == 0 && S % 4 == 0;
+    const bool ac = state_only || ((reinterpret_cast<uintptr_t>(x->actions) & 15) == 0 && x->ld_actions % 4 == 0 && A % 4 == 0);
+    return st && ac;
+  };
+  return ok(a) && ok(b) ? 1 : 0;
+}
+
 extern "C" int il_gmmil_reward(const il_batch* pol, const il_batch* exp, int32_t S, int32_t A, int32_t state_only, float g1, float g2, float* out_rewards,
                                float* out_sim, float* out_self, float* workspace, int64_t workspace_floats, il_stream_t stream_) {
   IL_NO_GATHER(pol, "il_gmmil_reward"); IL_NO_GATHER(exp, "il_gmmil_reward");
@@ -246,6 +434,12 @@ extern "C" int il_gmmil_reward(const il_batch* pol, const il_batch* exp, int32_t
   const GmmilWs w = gmmil_ws(pol->n, exp->n, D);
   if (workspace_floats < w.total) return il_set_error(IL_ERR_WORKSPACE, "il_gmmil_reward: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)w.total);
   hipStream_t st = (hipStream_t)stream_;
+  if (gmmil_direct() && D >= 4) {
+    IL_TRACE("k_gmmil_tile", st);
+    k_gmmil_direct<0><<<dim3(w.b1p / GTR, w.njt, 2), 256, 0, st>>>(*pol, *exp, S, D, g1, g2, workspace, nullptr, 0, out_rewards, out_sim, out_self, gmmil_lanes(pol, exp, S, A, state_only));
+    IL_CHECK_LAUNCH("il_gmmil_reward");
+    return IL_OK;
+  }
   { IL_TRACE("k_gmmil_pack", st); k_gmmil_pack<<<dim3(w.b1p / GT + w.b2p / GT, (D + GKC - 1) / GKC), 256, 0, st>>>(*pol, *exp, S, D, workspace); }
   { IL_TRACE("k_gmmil_tile", st); k_gmmil_tile<0><<<dim3(w.b1p / GTR, w.njt, 2), 256, 0, st>>>(pol->n, exp->n, D, g1, g2, workspace, nullptr, 0, out_rewards, out_sim, out_self); }
   IL_CHECK_LAUNCH("il_gmmil_reward");
@@ -262,6 +456,12 @@ extern "C" int il_gmmil_sqdist(const il_batch* a, const il_batch* b, int32_t S, 
   const GmmilWs w = gmmil_ws(a->n, b->n, D);
   if (workspace_floats < w.total) return il_set_error(IL_ERR_WORKSPACE, "il_gmmil_sqdist: workspace too small");
   hipStream_t st = (hipStream_t)stream_;
+  if (gmmil_direct() && D >= 4) {
+    IL_TRACE("k_gmmil_tile", st);
+    k_gmmil_direct<1><<<dim3(w.b1p / GTR, w.b2p / GT, 1), 256, 0, st>>>(*a, *b, S, D, 0.f, 0.f, workspace, out, 0, nullptr, nullptr, nullptr, gmmil_lanes(a, b, S, A, state_only));
+    IL_CHECK_LAUNCH("il_gmmil_sqdist");
+    return IL_OK;
+  }
   { IL_TRACE("k_gmmil_pack", st); k_gmmil_pack<<<dim3(w.b1p / GT + w.b2p / GT, (D + GKC - 1) / GKC), 256, 0, st>>>(*a, *b, S, D, workspace); }
   { IL_TRACE("k_gmmil_tile", st); k_gmmil_tile<1><<<dim3(w.b1p / GTR, w.b2p / GT, 1), 256, 0, st>>>(a->n, b->n, D, 0.f, 0.f, workspace, out, 0, nullptr, nullptr, nullptr); }
   IL_CHECK_LAUNCH("il_gmmil_sqdist");

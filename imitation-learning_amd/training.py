@@ -22,12 +22,13 @@ _WS: Dict[tuple, Tensor] = {}
 _NOISE: Dict[torch.device, Tensor] = {}
 
 
-def _workspace(kind: str, floats: int, device, tag=None) -> Tensor:
-  """Scratch arena shared by every call of one kind on a device; `tag` gives a learner its own (learners that run concurrently must not share)."""
+def _workspace(kind: str, floats: int, device, tag=None, zero: bool = False) -> Tensor:
+  """Scratch arena shared by every call of one kind on a device; `tag` gives a learner its own (learners that run concurrently must not share).
+  zero=True: zero-filled at creation and never shared between sizes (kernels that keep self-resetting arrival counters in it: il_gmmil_reward)."""
   key = (kind, str(device), tag)
   ws = _WS.get(key)
-  if ws is None or ws.numel() < floats:
-    ws = torch.empty(int(floats), dtype=torch.float32, device=device)
+  if ws is None or ws.numel() < floats or (zero and ws.numel() != floats):
+    ws = (torch.zeros if zero else torch.empty)(int(floats), dtype=torch.float32, device=device)
     _WS[key] = ws
   return ws
 
@@ -317,7 +318,7 @@ def embedding_sqdist(x: Tensor, y: Tensor) -> Tensor:
   """models.py:25-29 `_squared_distance` between two sets of feature rows [n1, D], [n2, D] -> [n1, n2] (k_gmmil_tile, direct form)."""
   n1, n2, D = x.size(0), y.size(0), x.size(1)
   dev = x.device
-  ws = _workspace('gmmil', int(_lib.lib().il_gmmil_workspace_floats(n1, n2, D)), dev)
+  ws = _workspace(f'gmmil:{n1}:{n2}:{D}', int(_lib.lib().il_gmmil_workspace_floats(n1, n2, D)), dev, zero=True)   # (arrival counters: zero once per shape, left at zero by every call)
   out = torch.empty(n1, n2, device=dev)
   w1, w2 = torch.ones(n1, device=dev), torch.ones(n2, device=dev)   # named: an il_batch holds raw pointers, the tensors must outlive the launch
   ba, bb = _sa_batch(x, x, w1), _sa_batch(y, y, w2)
@@ -329,7 +330,7 @@ def gmmil_sqdist(disc: GMMILDiscriminator, a_state, a_action, b_state, b_action)
   dev = a_state.device
   na, nb = a_state.size(0), b_state.size(0)
   D = disc.state_size + (0 if disc.state_only else disc.action_size)
-  ws = _workspace('gmmil', int(_lib.lib().il_gmmil_workspace_floats(na, nb, D)), dev)
+  ws = _workspace(f'gmmil:{na}:{nb}:{D}', int(_lib.lib().il_gmmil_workspace_floats(na, nb, D)), dev, zero=True)
   out = torch.empty(na, nb, device=dev)
   wa, wb = torch.ones(na, device=dev), torch.ones(nb, device=dev)
   ba, bb = _sa_batch(a_state, a_action, wa), _sa_batch(b_state, b_action, wb)
@@ -345,7 +346,7 @@ def gmmil_predict_reward(disc: GMMILDiscriminator, state, action, expert_state, 
     disc.gamma_2 = 1 / (_weighted_median(gmmil_sqdist(disc, expert_state, expert_action, expert_state, expert_action), torch.outer(expert_weight, expert_weight)).item() + 1e-8)
   n1, n2 = state.size(0), expert_state.size(0)
   D = disc.state_size + (0 if disc.state_only else disc.action_size)
-  ws = _workspace('gmmil', int(_lib.lib().il_gmmil_workspace_floats(n1, n2, D)), dev)
+  ws = _workspace(f'gmmil:{n1}:{n2}:{D}', int(_lib.lib().il_gmmil_workspace_floats(n1, n2, D)), dev, zero=True)   # (arrival counters: zero once per shape, left at zero by every call)
   out = torch.empty(n1, device=dev)
   sim, self_sim = (torch.empty(n1, device=dev), torch.empty(n1, device=dev)) if return_parts else (None, None)
   pb, eb = _sa_batch(state, action, weight), _sa_batch(expert_state, expert_action, expert_weight)
@@ -823,7 +824,7 @@ class UpdatePlan:
         self.rewards.copy_(gmmil_predict_reward(d, t['states'], t['actions'], e['states'], e['actions'], t['weights'].contiguous(), e['weights'].contiguous()))
         return
       D = d.state_size + (0 if d.state_only else d.action_size)
-      ws = _workspace('gmmil', int(L.il_gmmil_workspace_floats(self.B, self.B, D)), self.rows.device)
+      ws = _workspace(f'gmmil:{self.B}:{self.B}:{D}', int(L.il_gmmil_workspace_floats(self.B, self.B, D)), self.rows.device, zero=True)
       _lib.check(L.il_gmmil_reward(C.byref(self.pb), C.byref(self.eb), d.state_size, d.action_size, int(d.state_only), float(d.gamma_1), float(d.gamma_2), _lib.ptr(self.rewards), None, None,
                                    _lib.ptr(ws), ws.numel(), st))
     elif alg == 'RED':

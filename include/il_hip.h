@@ -468,6 +468,9 @@ int il_gail_shaped_deep_reward(const il_disc_shaped_deep* d, const il_batch* bat
 /* ------------------------------------------------------------------------------------------
  * GMMIL (reference models.py:25-44, 183-201): d(x,y) = mean_k (x_k-y_k)^2, two RBF bandwidths.
  * ------------------------------------------------------------------------------------------ */
+/* The workspace holds per-row-tile arrival counters that every call leaves at ZERO: zero-fill it once when it is created, and do not share one workspace between
+ * calls of different (n_policy, n_expert, dim) - the counters sit at shape-dependent offsets (round 4: the reward is ONE launch that reads the batches directly; the
+ * packing launch that used to zero them is gone). */
 int64_t il_gmmil_workspace_floats(int32_t n_policy, int32_t n_expert, int32_t dim);
 /* rewards[i] = sum_gamma w~_i sum_j K(x_i,e_j) w~e_j  -  w~_i sum_j K(x_i,x_j) w~_j ;  x = cat(state, action) (or state). */
 int il_gmmil_reward(const il_batch* policy, const il_batch* expert, int32_t state_dim, int32_t action_dim, int32_t state_only,
