@@ -56,6 +56,16 @@ __device__ __forceinline__ void wstore4(float* base, int64_t off, const f32x4& v
 #endif
 }
 
+// One float written through / read below this CU's L1 (the fence-free hand-offs of the pair-mode kernels: a few scalars per lane next to a relaxed arrival counter)
+__device__ __forceinline__ void wstore1(float* base, int64_t off, float v) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7ffffff0, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)(off * 4), 0, 17);   // sc0 | sc1
+}
+__device__ __forceinline__ float sload1(const float* base, int64_t off) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7ffffff0, 0x00020000);
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(off * 4), 0, 17));
+}
+
 // Whole-descriptor version of the same: a descriptor fetched from memory (population axis: d = dL[blockIdx.y]) carries generic pointers, and
 // ONE pending flat access (a flat_store of an activation slab is enough) makes the compiler turn every later wait into vmcnt(0) lgkmcnt(0).
 // Round-tripping the fields through address space 1 lets address-space inference type every derived access as global.

@@ -29,7 +29,7 @@ struct SacWs {  // float offsets into il_sac.workspace
   int64_t c_x0, c_h1, c_h2, c_q, t_q, c_dz3, c_dz2, c_dz1;
   int64_t p_q, p_g, a_dz3, a_dz2, a_dz1, alpha_part, pair_ctr, chain_ctr;
   int64_t pk_af, pk_ab, pk_cf, pk_cb, pk_tf, pk_tb;  // lane-ordered copies of the H x H layers (mlp_tile.hpp "Packed hidden-layer weights")
-  int64_t x_slab, x_flag, c_rew;   // pair mode (mlp_tile.hpp): 6 * nt hop slabs of 16 x H/2 floats, their flags (one 128-byte line each), the relabel role's rewards [B]
+  int64_t x_slab, x_flag, c_rew, p_part;   // p_part: pair-mode k_policy_critic: dQ/da partial tiles [2][nt][16 n-blocks][16 rows][A]   // pair mode (mlp_tile.hpp): 6 * nt hop slabs of 16 x H/2 floats, their flags (one 128-byte line each), the relabel role's rewards [B]
   int64_t total;
 };
 __host__ __device__ inline SacWs sac_ws(int S, int A, int H, int B) {
@@ -44,7 +44,7 @@ __host__ __device__ inline SacWs sac_ws(int S, int A, int H, int B) {
   const int64_t HH = (int64_t)H * H;
   w.pk_af = take(HH); w.pk_ab = take(HH); w.pk_cf = take(2 * HH); w.pk_cb = take(2 * HH); w.pk_tf = take(2 * HH); w.pk_tb = take(2 * HH);
   o = (o + 31) & ~(int64_t)31;   // slabs and flag lines start on 128-byte lines of their own
-  w.x_slab = take((int64_t)6 * (B / IL_TILE_R) * IL_TILE_R * (H / 2)); o = (o + 31) & ~(int64_t)31; w.x_flag = take((int64_t)6 * (B / IL_TILE_R) * IL_CTR_STRIDE + 32); w.c_rew = take(B);
+  w.x_slab = take((int64_t)6 * (B / IL_TILE_R) * IL_TILE_R * (H / 2)); o = (o + 31) & ~(int64_t)31; w.x_flag = take((int64_t)6 * (B / IL_TILE_R) * IL_CTR_STRIDE + 32); w.c_rew = take(B); w.p_part = take((int64_t)2 * (B / IL_TILE_R) * 16 * IL_TILE_R * A);
   w.total = o;
   return w;
 }
@@ -252,6 +252,7 @@ __device__ __forceinline__ void tile_await(unsigned* ctr, unsigned target, const
 
 // Pair-mode chain: arrivals in the low four bits of the tile counter, flag bits above them (the relabel role arrives with += 16, so that it cannot be mistaken for
 // the tile's actor(s') or a target); waits until (value & 15) >= low and every bit of `bits` is set. Same bounded poll + one agent acquire as tile_await.
+template <bool ACQUIRE = true>   // ACQUIRE = false: everything the waiter reads afterwards was written through by its producer and is read below the L1 (sload1)
 __device__ __forceinline__ void tile_await_bits(unsigned* ctr, unsigned low, unsigned bits, const TileTimeouts& timeouts) {
   if (threadIdx.x == 0) {
     int spins = 0;
@@ -265,9 +266,15 @@ __device__ __forceinline__ void tile_await_bits(unsigned* ctr, unsigned low, uns
         break;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
+}
+// the producer side of the same: every wave drains its write-through stores, barrier, ONE relaxed arrival
+__device__ __forceinline__ void tile_arrive_through(unsigned* ctr, unsigned inc) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Forward of one critic-shaped network on one 16-row tile. net 0,1: critic_k(s, a) keeping h1, h2 (and x0 for net 0) for the weight gradients;
@@ -468,7 +475,7 @@ __device__ __forceinline__ RowScalars critic_row_scalars(const il_batch& b, bool
   return rs;
 }
 __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const il_batch& b, const float* __restrict__ rewards, const ChainRelabel& rl, const RowScalars& rs, int k, int tile,
-                                                          float* smem, const float* __restrict__ rew_ws = nullptr) {   // rew_ws: the tile's rewards were predicted by the relabel role of this launch (pair mode), visible behind the tile counter's acquire
+                                                          float* smem, const float* __restrict__ rew_ws = nullptr, bool through = false) {   // through: the targets' Q, log pi(a'|s') and the rewards were written THROUGH by their producers in this launch (pair mode): read below the L1, no acquire needed   // rew_ws: the tile's rewards were predicted by the relabel role of this launch (pair mode), visible behind the tile counter's acquire
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R, row0 = tile * IL_TILE_R;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
@@ -484,8 +491,10 @@ __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const
     const int row = row0 + threadIdx.x;
     const float alpha = expf(d.log_alpha[0]);
     const float m = rs.m;
-    const float tv = fminf(W[ws.t_q + row], W[ws.t_q + B + row]) - m * alpha * W[ws.n_logp2 + row];
-    const float rew = rew_ws ? rew_ws[row] : (rl.on ? rew16[threadIdx.x] : (rewards ? rewards[row] : (d.sync ? b.rewards[brow(b, row) * b.ld_rewards] : rs.reward)));
+    const float tq1 = through ? sload1(W, ws.t_q + row) : W[ws.t_q + row], tq2 = through ? sload1(W, ws.t_q + B + row) : W[ws.t_q + B + row];
+    const float lp2 = through ? sload1(W, ws.n_logp2 + row) : W[ws.n_logp2 + row];
+    const float tv = fminf(tq1, tq2) - m * alpha * lp2;
+    const float rew = rew_ws ? (through ? sload1(rew_ws, row) : rew_ws[row]) : (rl.on ? rew16[threadIdx.x] : (rewards ? rewards[row] : (d.sync ? b.rewards[brow(b, row) * b.ld_rewards] : rs.reward)));
     const float y = rew + rs.not_done * d.discount * tv;
     const float q = q16[threadIdx.x];
     const float dq = (rs.weight * (2.f * (q - y))) / (float)B;
@@ -733,13 +742,13 @@ __device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch&
     float x, a, nlp, ladj;
     head_sample(mean, lsr, e_pre, x, a, nlp, ladj);
     nl[hr * 16 + hc] = nlp; la[hr * 16 + hc] = ladj;
-    W[ws.n_a2 + (size_t)row * A + hc] = (1.f - absorb_pre) * a;
+    wstore1(W, ws.n_a2 + (int64_t)row * A + hc, (1.f - absorb_pre) * a);   // (written through: the targets and the critic-loss workgroups read these without an acquire)
   }
   __syncthreads();
   if (tid < IL_TILE_R) {
     float sn = 0.f, sl = 0.f;
     for (int c = 0; c < A; ++c) { sn += nl[tid * 16 + c]; sl += la[tid * 16 + c]; }
-    W[ws.n_logp2 + row0 + tid] = (0.f - sl) + sn;
+    wstore1(W, ws.n_logp2 + row0 + tid, (0.f - sl) + sn);
   }
   IL_TL(10, 6);
 }
@@ -772,9 +781,9 @@ __device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, 
   if (!w1_regs) w1_commit(w1, W1s, ldw1, IN, INp, H, w1_lanes);
   rows_commit(rp, Xs, ldx, INp, S);
   IL_TL(10, 1);
-  tile_await_bits(ctr, 1u, 0u, tile_timeouts(d));   // a' and log pi(a'|s') of this tile (its barrier also covers the LDS writes above)
+  tile_await_bits<false>(ctr, 1u, 0u, tile_timeouts(d));   // a' of this tile, written through by its actor(s') workgroup (the barrier also covers the LDS writes above)
   IL_TL(10, 2);
-  for (int i = threadIdx.x; i < IL_TILE_R * A; i += blockDim.x) { const int r = i / A, c = i - r * A; Xs[r * ldx + S + c] = W[ws.n_a2 + (size_t)(row0 + r) * A + c]; }
+  for (int i = threadIdx.x; i < IL_TILE_R * A; i += blockDim.x) { const int r = i / A, c = i - r * A; Xs[r * ldx + S + c] = sload1(W, ws.n_a2 + (int64_t)(row0 + r) * A + c); }
   __syncthreads();
   {
     auto epi1 = [&](int c0, f32x4 acc) {
@@ -807,7 +816,7 @@ __device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, 
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int n = lane + 64 * u; if (n < H) sq += H2s[r * ldh + n] * w3v[u]; }
     sq = wave_sum(sq);
-    if (lane == 0) W[ws.t_q + (size_t)k * B + row0 + r] = sq + pb3;
+    if (lane == 0) wstore1(W, ws.t_q + (int64_t)k * B + row0 + r, sq + pb3);
   }
   IL_TL(10, 6);
 }
@@ -826,7 +835,7 @@ __device__ __forceinline__ void relabel_role(const il_sac& d, const il_batch& b,
   IL_TL(10, 2);
   const RewardLds R = reward_carve(q16 + 64, rl.dd.state_dim + rl.dd.action_dim, rl.dd.hidden);
   disc_reward_tile(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
-    W[ws.c_rew + row0 + r] = reward;
+    wstore1(W, ws.c_rew + row0 + r, reward);
     if (rl.out) rl.out[row0 + r] = reward;
   });
   IL_TL(10, 6);
@@ -858,14 +867,13 @@ __device__ __forceinline__ void sac_chain_pair_body(il_sac& d, il_batch& b, cons
   unsigned* flag = reinterpret_cast<unsigned*>(d.workspace + ws.x_flag) + slot * IL_CTR_STRIDE;
   if (id.role == 0) {
     actor_next_pair(d, b, eps_next, id.tile, id.half, smem, slab, flag);
-    if (id.half == 0) { tile_arrive(ctr); IL_TL(10, 7); }
+    if (id.half == 0) { tile_arrive_through(ctr, 1u); IL_TL(10, 7); }
   } else if (id.role == 1) {
     target_pair(d, b, id.net, id.tile, id.half, smem, slab, flag, ctr);
-    if (id.half == 0) { tile_arrive(ctr); IL_TL(10, 7); }
+    if (id.half == 0) { tile_arrive_through(ctr, 1u); IL_TL(10, 7); }
   } else if (id.role == 4) {
     relabel_role(d, b, rl, id.tile, smem);
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 16u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    tile_arrive_through(ctr, 16u);
     IL_TL(10, 7);
   } else if (id.role == 2) {
     critic_fwd_tile(d, b, id.net, id.tile, smem, nullptr);
@@ -873,10 +881,10 @@ __device__ __forceinline__ void sac_chain_pair_body(il_sac& d, il_batch& b, cons
     critic_bwd_resident_gemm(d, id.net, smem);
     IL_TL(10, 3);
     const RowScalars rs = critic_row_scalars(b, !rl.on && !rewards && !d.sync, id.tile);
-    tile_await_bits(ctr, 3u, rl.on ? 16u : 0u, tile_timeouts(d));
+    tile_await_bits<false>(ctr, 3u, rl.on ? 16u : 0u, tile_timeouts(d));   // (no acquire: what this workgroup reads of the tile's producers was written through, critic_bwd_resident_scale reads it below the L1)
     IL_TL(10, 5);
     if (threadIdx.x == 0 && (__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 15u) == 4u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    critic_bwd_resident_scale(d, b, rewards, rl, rs, id.net, id.tile, smem, rl.on ? d.workspace + ws.c_rew : nullptr);
+    critic_bwd_resident_scale(d, b, rewards, rl, rs, id.net, id.tile, smem, rl.on ? d.workspace + ws.c_rew : nullptr, true);
     IL_TL(10, 7);
   } else { actor_fwd_tile(d, b, eps_next, eps_cur, true, id.tile, smem); IL_TL(10, 7); }
 }
@@ -897,7 +905,9 @@ __global__ __launch_bounds__(512) void k_sac_chain_pair(il_sac d, il_batch b, co
 // PARK (pair-mode helpers: 512 threads, <= 256 VGPRs, H = 256, at most one output tile of the last GEMM per wave): that tile's 16 KB panel is requested before the wait
 // for the critics and parked in registers - the helper idles ~8 us there, so being held at the issue stage is free, and the GEMM at the very end of the update's
 // longest dependent chain starts from registers.
-template <int PANEL = 16, bool PARK = false, class Wait>
+// PARTS (pair-mode k_policy_critic): dQ/da arrives as its 16 per-n-block partial tiles per critic (written through by the critic halves, read below the L1, summed here in
+// n-block order - the order tile_bwd_dx_cols sums them in), and Q through the same kind of store: the wait in front needs no acquire.
+template <int PANEL = 16, bool PARK = false, bool PARTS = false, class Wait>
 __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& b, int tile, float* __restrict__ out_logp, float* __restrict__ out_q, float* smem, int part,
                                                int nparts, Wait wait) {
   if (!out_logp) out_logp = d.out_logp;
@@ -959,9 +969,26 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
   }
   wait();
   if (tid < IL_TILE_R * A) {
-    const float q1 = W[ws.p_q + hrow], q2 = W[ws.p_q + B + hrow];
+    float q1, q2, g1, g2;
+    if (PARTS) {
+      q1 = sload1(W, ws.p_q + hrow); q2 = sload1(W, ws.p_q + B + hrow);
+      const int nt_ = B / IL_TILE_R;
+      float v1[16], v2[16];
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {   // all 32 requested before the first add
+        v1[w] = sload1(W, ws.p_part + (((int64_t)(0 * nt_ + tile) * 16 + w) * IL_TILE_R + hr) * A + hc);
+        v2[w] = sload1(W, ws.p_part + (((int64_t)(1 * nt_ + tile) * 16 + w) * IL_TILE_R + hr) * A + hc);
+      }
+      g1 = 0.f; g2 = 0.f;
+      const int nbk = H >> 4;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) if (w < nbk) { g1 += v1[w]; g2 += v2[w]; }
+    } else {
+      q1 = W[ws.p_q + hrow]; q2 = W[ws.p_q + B + hrow];
+      g1 = W[ws.p_g + (size_t)hrow * A + hc]; g2 = W[ws.p_g + ((size_t)B + hrow) * A + hc];
+    }
     const float s1 = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f);
-    const float da = (-(s1) / (float)B) * W[ws.p_g + (size_t)hrow * A + hc] + (-(1.f - s1) / (float)B) * W[ws.p_g + ((size_t)B + hrow) * A + hc];
+    const float da = (-(s1) / (float)B) * g1 + (-(1.f - s1) / (float)B) * g2;
     const float dxp = cc * th2 + da * omaa;
     const float dsd = dxp * e - cc / sd;
     const float dls = (lsr >= -20.f && lsr <= 2.f) ? dsd * sd : 0.f;
@@ -1170,22 +1197,21 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R, row0 = tile * IL_TILE_R;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
-  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* q16 = H2s + IL_TILE_R * ldh; float* W1s = pair_w1s(smem, INp, H);
+  float* Xs = smem; float* H1s = Xs + IL_TILE_R * ldx; float* H2s = H1s + IL_TILE_R * ldh; float* W1s = pair_w1s(smem, INp, H);
   const int ldw1 = INp + 4, w1_lanes = H * IN / 4;
   const SacWs ws = sac_ws(S, A, H, B);
   float* W = d.workspace;
   const MlpView p = mlp_view(d.critic + k * net_stride(IN, H, 1), IN, H, 1);
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int t2 = 8 * half + wave;
-  // hop slots: stage A (h2 halves, both directions) [0, 4 nt): ((k nt + tile) 2 + half); stage B (dz1 half 1 -> half 0) [4 nt, 6 nt)
+  // hop slots (h2 halves, both directions): ((k nt + tile) 2 + half) in [0, 4 nt)
   const size_t slab_floats = (size_t)IL_TILE_R * (H / 2);
-  const int sa = (k * nt + tile) * 2, sb = 4 * nt + k * nt + tile;
+  const int sa = (k * nt + tile) * 2;
   float* slabs = W + ws.x_slab; unsigned* flags = reinterpret_cast<unsigned*>(W + ws.x_flag);
   const TileTimeouts tmo = tile_timeouts(d);
   auto timed_out = [&] { __hip_atomic_fetch_add(tmo.slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (tmo.sync) sync_timed_out(tmo.sync); };
   IL_TL(11, 0);
   pair_announce(flags + (size_t)(sa + 1 - half) * IL_CTR_STRIDE);   // consumer of the partner's h2 half ...
-  if (half == 0) pair_announce(flags + (size_t)sb * IL_CTR_STRIDE);   // ... and of its dz1 half
   RowsPre rp; rows_idx(rp, INp, row0, nullptr);
   const bool w1_regs = l1_rows_aligned(p.W1, IN);
   W1Pre w1; L1Pre w1r;
@@ -1195,8 +1221,7 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
   float w3v[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
-  ColsPre w1pre = {};
-  if (half == 0) w1pre = tile_bwd_dx_cols_prefetch(p.W1, IN, IN, H, S);
+  const ColsPre w1pre = tile_bwd_dx_cols_prefetch(p.W1, IN, IN, H, S);   // (slot `half` holds this wave's n-block 8 half + wave of the dQ/da columns)
   if (!w1_regs) w1_commit(w1, W1s, ldw1, IN, INp, H, w1_lanes);
   rows_commit(rp, Xs, ldx, INp, IN);
   __syncthreads();
@@ -1236,29 +1261,52 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
       if (n < H) { const float h = H2s[r * ldh + n]; sq += h * w3v[u]; H2s[r * ldh + n] = h > 0.f ? w3v[u] : 0.f; }
     }
     sq = wave_sum(sq);
-    if (lane == 0 && half == 0) W[ws.p_q + (size_t)k * B + row0 + r] = sq + pb3;
+    if (lane == 0 && half == 0) wstore1(W, ws.p_q + (int64_t)k * B + row0 + r, sq + pb3);   // (written through: the helpers read it without an acquire)
   }
   __syncthreads();
   IL_TL(11, 5);
-  const bool near_b = half == 1 && pair_same_xcd(flags + (size_t)sb * IL_CTR_STRIDE);
   Panel16 pk; panel_prefetch(pk, W + ws.pk_cb + (size_t)k * H * H, t2);
   tile_packed_regs(H2s, ldh, pk, t2, [&](int kb, f32x4 acc) {
-    f32x4 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { float* h = H1s + (4 * g + r) * ldh + kb + j; o[r] = *h > 0.f ? acc[r] : 0.f; if (half == 0) *h = o[r]; }   // dz1 in place (each element owned by one lane)
-    if (half == 1) pair_store(slabs + (size_t)sb * slab_floats, (int64_t)(kb + j - 128) * 16 + 4 * g, o, near_b);
+    for (int r = 0; r < 4; ++r) { float* h = H1s + (4 * g + r) * ldh + kb + j; *h = *h > 0.f ? acc[r] : 0.f; }   // dz1 in place, this half's columns (each element owned by one lane)
   });
+  __syncthreads();
   IL_TL(11, 6);
-  if (half == 1) { pair_publish(flags + (size_t)sb * IL_CTR_STRIDE); IL_TL(11, 7); return; }
-  pair_receive(flags + (size_t)sb * IL_CTR_STRIDE, slabs + (size_t)sb * slab_floats, H1s, ldh, 128, timed_out);
-  // dQ/da = the action columns of dz1 . W1 (tile_bwd_dx_cols: the H-reduction in n-block order, independent of the wave count)
-  float* gout = W + ws.p_g + ((size_t)k * B + row0) * A;
-  tile_bwd_dx_cols(H1s, ldh, H, p.W1, IN, IN, S, S + A, q16 + 64, [&](int col, int row, float v) {
-    const int c = col - S;
-    if (c >= 0 && c < A) gout[(size_t)row * A + c] = v;
-  }, IL_SMALL_PREFETCH ? &w1pre : nullptr);
+  // dQ/da = the action columns of dz1 . W1: a sum over the 16 n-blocks of hidden units, in n-block order. Each half holds the dz1 columns of EIGHT of them: wave w forms
+  // the partial tile of block 8 half + w (the four MFMAs of tile_bwd_dx_cols) and writes it through; the tile's helpers add the sixteen partials in n-block order, as
+  // tile_bwd_dx_cols' own reduction does - no second hop between the halves, no release here, no acquire there (round 4: -1.5 us on the critical path of this launch).
+  {
+    const int nb = 8 * half + wave, n0 = nb * 16;
+    float* pp = W + ws.p_part + ((int64_t)(k * nt + tile) * 16 + nb) * IL_TILE_R * A;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(H1s + j * ldh + n0 + 4 * g);
+    const int kb0 = (S >> 4) << 4;
+    for (int kb = kb0; kb < S + A; kb += 16) {
+      float bq[4];
+      if (IL_SMALL_PREFETCH && kb == kb0) {
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) bq[s_] = half == 0 ? w1pre.b[0][s_] : w1pre.b[1][s_];
+      } else {
+        const float* wp = p.W1 + min(kb + j, IN - 1);
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) bq[s_] = gload(wp + (size_t)(n0 + 4 * g + s_) * IN);
+      }
+      f32x4 acc0 = zero4(), acc1 = zero4();
+      acc0 = mfma16(a[0], bq[0], acc0);
+      acc1 = mfma16(a[1], bq[1], acc1);
+      acc0 = mfma16(a[2], bq[2], acc0);
+      acc1 = mfma16(a[3], bq[3], acc1);
+      const f32x4 acc = acc0 + acc1;
+      const int c = kb + j - S;
+      if (c >= 0 && c < A) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wstore1(pp, (int64_t)(4 * g + r) * A + c, acc[r]);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   unsigned* ctr = reinterpret_cast<unsigned*>(W + ws.pair_ctr) + tile * IL_CTR_STRIDE;
-  tile_arrive(ctr);
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   IL_TL(11, 7);
 }
 
@@ -1272,15 +1320,23 @@ __global__ __launch_bounds__(512) void k_policy_critic_pair(il_sac d, il_batch b
     unsigned* ctr = reinterpret_cast<unsigned*>(d.workspace + ws.pair_ctr) + tile * IL_CTR_STRIDE;
     if (h == 0 && threadIdx.x == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }
     IL_TL(3, 0);
-    const auto wait = [&] {
+    const auto wait = [&] {   // both halves of both critics have written Q and their dQ/da partial tiles THROUGH (sc0 sc1) before arriving: one relaxed poll, no acquire
       IL_TL(3, 1);
-      tile_await(ctr, 2u, tile_timeouts(d));
+      if (threadIdx.x == 0) {
+        const TileTimeouts tmo = tile_timeouts(d);
+        int spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4u) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > IL_SYNC_SPIN_LIMIT) { __hip_atomic_fetch_add(tmo.slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (tmo.sync) sync_timed_out(tmo.sync); break; }
+        }
+      }
+      __syncthreads();
       IL_TL(3, 2);
-      if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u + (unsigned)helpers)
+      if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3u + (unsigned)helpers)
         __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    if ((d.hidden >> 4) <= helpers * (int)(blockDim.x >> 6)) actor_bwd_tile<16, true>(d, b, tile, out_logp, out_q, smem, part, helpers, wait);   // one output tile of the last GEMM per wave at most
-    else actor_bwd_tile<16, false>(d, b, tile, out_logp, out_q, smem, part, helpers, wait);
+    if ((d.hidden >> 4) <= helpers * (int)(blockDim.x >> 6)) actor_bwd_tile<16, true, true>(d, b, tile, out_logp, out_q, smem, part, helpers, wait);   // one output tile of the last GEMM per wave at most
+    else actor_bwd_tile<16, false, true>(d, b, tile, out_logp, out_q, smem, part, helpers, wait);
     IL_TL_END(3);
     return;
   }
