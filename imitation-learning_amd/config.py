@@ -4,8 +4,9 @@
   base defaults  <-  algorithm overlay (`# @package _global_` files)  <-  optimised_hyperparameters overlay  <-  dotted CLI overrides
 and returns an attribute/`.get` dict like omegaconf's DictConfig.  The base and per-algorithm defaults are stated here (same
 keys and values as the reference's YAML, reference conf/train_config.yaml:7-52 and conf/algorithm/*.yaml); the 21 tuned
-`optimised_hyperparameters=<ALG>_<N>_trajectories` overlays are read from a reference-style YAML tree given with
-`config_dir=<path>/conf` (they are data files of the reference and are not duplicated in this repository).
+`optimised_hyperparameters=<ALG>_<N>_trajectories` overlays come from `tuned.py` (their values as flat tables, generated from the reference's data
+files by tests/golden/make_tuned_table.py) or, with `config_dir=<path>/conf`, from a reference-style YAML tree (which then also supplies the algorithm
+overlays). `write_conf_tree(path)` writes such a tree - train_config.yaml, algorithm/*.yaml, optimised_hyperparameters/*.yaml - from this module's tables.
 """
 from __future__ import annotations
 
@@ -113,10 +114,17 @@ def compose(overrides: List[str], config_dir: str = None) -> Config:
   cfg['algorithm'] = algorithm
   oh = groups.get('optimised_hyperparameters')
   if oh and oh != 'null':
-    path = os.path.join(config_dir or 'conf', 'optimised_hyperparameters', f'{oh}.yaml')
-    if not os.path.exists(path):
-      raise FileNotFoundError(f'optimised_hyperparameters={oh}: {path} not found; pass config_dir=<reference>/conf (the tuned overlays are the reference\'s data files)')
-    _merge(cfg, yaml.safe_load(open(path)) or {})
+    if config_dir:   # an explicit tree wins (and must then hold the overlay)
+      path = os.path.join(config_dir, 'optimised_hyperparameters', f'{oh}.yaml')
+      if not os.path.exists(path):
+        raise FileNotFoundError(f'optimised_hyperparameters={oh}: {path} not found')
+      _merge(cfg, yaml.safe_load(open(path)) or {})
+    else:
+      from .tuned import TUNED
+      if oh not in TUNED:
+        raise FileNotFoundError(f'optimised_hyperparameters={oh}: not one of the reference\'s tuned overlays ({", ".join(sorted(TUNED))}); pass config_dir=<path>/conf for your own')
+      for k, v in TUNED[oh].items():
+        _set_dotted(cfg, k, copy.deepcopy(v))
   for k, v in dotted:
     _set_dotted(cfg, k, _parse_value(v))
   return Config(cfg)
@@ -147,3 +155,27 @@ def validate(cfg: Config):
   if int(cfg.distributed.world_size) > 1 and cfg.imitation.bc_aux_loss:
     raise NotImplementedError('distributed.world_size > 1 with imitation.bc_aux_loss=true: the behavioural-cloning auxiliary step (train.py:201) has no data-parallel form; run it on one GPU')
   return cfg
+
+
+def write_conf_tree(path: str):
+  """A reference-style `conf/` tree (train_config.yaml, algorithm/<ALG>.yaml with the `# @package _global_` header, optimised_hyperparameters/<name>.yaml) written from this
+  module's tables: what `config_dir=` reads back, and a starting point for one's own overlays. `distributed` is this repository's key and is left out."""
+  import yaml
+  from .tuned import TUNED
+
+  def nest(flat):
+    out = {}
+    for k, v in flat.items(): _set_dotted(out, k, v)
+    return out
+
+  def dump(d):
+    return yaml.safe_dump(d, sort_keys=False, default_flow_style=False).replace('.inf', '.inf')
+  os.makedirs(os.path.join(path, 'algorithm'), exist_ok=True)
+  os.makedirs(os.path.join(path, 'optimised_hyperparameters'), exist_ok=True)
+  base = {k: copy.deepcopy(v) for k, v in BASE.items() if k not in ('algorithm', 'distributed')}
+  open(os.path.join(path, 'train_config.yaml'), 'w').write('defaults:\n  - _self_\n  - algorithm: SAC\n\n' + dump(base))
+  for alg, overlay in ALGORITHM_OVERLAYS.items():
+    open(os.path.join(path, 'algorithm', f'{alg}.yaml'), 'w').write('# @package _global_\n\n' + dump(dict(algorithm=alg, **copy.deepcopy(overlay))))
+  for name, flat in TUNED.items():
+    open(os.path.join(path, 'optimised_hyperparameters', f'{name}.yaml'), 'w').write('# @package _global_\n\n' + dump(nest(flat)))
+  return path

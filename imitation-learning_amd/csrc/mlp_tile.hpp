@@ -330,6 +330,21 @@ __device__ __forceinline__ void panel_prefetch(Panel16& p, const float* __restri
   for (int u = 0; u < 16; ++u) p.b[u] = gload4(pp + (size_t)u * 256);
   __builtin_amdgcn_sched_barrier(0);
 }
+// The same request in two halves (blocks [0, 8) and [8, 16) - the order the MFMAs consume them in): the first half goes out EARLY, behind a prologue's small loads - 8 KB per
+// wave holds a wave at the issue stage for ~0.4 us, inside the latency of those small loads - and streams in under the first layer; the second half is requested right
+// before the MFMAs and streams in under the first half's. (Measured round 4: a hidden layer with its whole panel requested at its start 3.0 us, 1.7 us of it MFMA issue.)
+__device__ __forceinline__ void panel_prefetch_lo(Panel16& p, const float* __restrict__ P, int t) {
+  const float* pp = P + (size_t)t * 16 * 256 + (threadIdx.x & 63) * 4;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) p.b[u] = gload4(pp + (size_t)u * 256);
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void panel_prefetch_hi(Panel16& p, const float* __restrict__ P, int t) {
+  const float* pp = P + (size_t)t * 16 * 256 + (threadIdx.x & 63) * 4;
+#pragma unroll
+  for (int u = 8; u < 16; ++u) p.b[u] = gload4(pp + (size_t)u * 256);
+  __builtin_amdgcn_sched_barrier(0);
+}
 // output tile t of As[16 x 256] . panel from registers; the MFMA order of tile_packed.  epi(t * 16, acc)
 template <class Epi>
 __device__ __forceinline__ void tile_packed_regs(const float* As, int lda, const Panel16& p, int t, Epi epi) {

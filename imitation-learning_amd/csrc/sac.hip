@@ -699,6 +699,8 @@ __device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch&
   // (The panel of the hidden layer is NOT requested here: a wave that issues 16 KB of loads is held at the issue stage until the CU's memory pipeline has taken them -
   // with eight waves doing so, ~0.85 us per panel during which it cannot commit its rows; measured as a 4.8 us prologue of the first pair-mode k_policy_critic with two
   // panels parked. Requested right before its MFMAs, the panel streams in under them - the schedule of tile_packed.)
+  issue_fence();
+  Panel16 pn; panel_prefetch_lo(pn, W + ws.pk_af, t2);
   IL_TL(10, 1);
   if (!w1_regs) w1_commit(w1, W1s, ldw1, S, Sp, H, w1_lanes);
   rows_commit(rp, Xs, ldx, Sp, S);
@@ -715,7 +717,7 @@ __device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch&
   const bool near = half == 1 && pair_same_xcd(flag);
   __syncthreads();
   IL_TL(10, 3);
-  Panel16 pn; panel_prefetch(pn, W + ws.pk_af, t2);
+  panel_prefetch_hi(pn, W + ws.pk_af, t2);
   tile_packed_regs(H1s, ldh, pn, t2, [&](int c0, f32x4 acc) {
     const int col = c0 + j;
     f32x4 hv;
@@ -1222,6 +1224,8 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
 #pragma unroll
   for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
   const ColsPre w1pre = tile_bwd_dx_cols_prefetch(p.W1, IN, IN, H, S);   // (slot `half` holds this wave's n-block 8 half + wave of the dQ/da columns)
+  issue_fence();
+  Panel16 pf; panel_prefetch_lo(pf, W + ws.pk_cf + (size_t)k * H * H, t2);
   if (!w1_regs) w1_commit(w1, W1s, ldw1, IN, INp, H, w1_lanes);
   rows_commit(rp, Xs, ldx, INp, IN);
   __syncthreads();
@@ -1239,7 +1243,7 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
   __syncthreads();
   IL_TL(11, 2);
   const bool near_a = pair_same_xcd(flags + (size_t)(sa + half) * IL_CTR_STRIDE);
-  Panel16 pf; panel_prefetch(pf, W + ws.pk_cf + (size_t)k * H * H, t2);   // (requested right before their MFMAs, like tile_packed: see actor_next_pair)
+  panel_prefetch_hi(pf, W + ws.pk_cf + (size_t)k * H * H, t2);
   tile_packed_regs(H1s, ldh, pf, t2, [&](int c0, f32x4 acc) {
     const int col = c0 + j;
     f32x4 hv;
@@ -1252,6 +1256,7 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
   IL_TL(11, 3);
   pair_receive(flags + (size_t)(sa + 1 - half) * IL_CTR_STRIDE, slabs + (size_t)(sa + 1 - half) * slab_floats, H2s, ldh, 128 * (1 - half), timed_out);
   IL_TL(11, 4);
+  Panel16 pk; panel_prefetch_lo(pk, W + ws.pk_cb + (size_t)k * H * H, t2);   // streams in under the Q pass
   // Q = h2 . w3 + b3 and dz2 = w3 [h2 > 0] in place: whole rows, computed by both halves (half 0 stores Q)
   for (int r = wave; r < IL_TILE_R; r += nw) {
     float sq = 0.f;
@@ -1265,7 +1270,7 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
   }
   __syncthreads();
   IL_TL(11, 5);
-  Panel16 pk; panel_prefetch(pk, W + ws.pk_cb + (size_t)k * H * H, t2);
+  panel_prefetch_hi(pk, W + ws.pk_cb + (size_t)k * H * H, t2);
   tile_packed_regs(H2s, ldh, pk, t2, [&](int kb, f32x4 acc) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { float* h = H1s + (4 * g + r) * ldh + kb + j; *h = *h > 0.f ? acc[r] : 0.f; }   // dz1 in place, this half's columns (each element owned by one lane)
