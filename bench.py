@@ -156,7 +156,7 @@ def secondary(device, plan, nets):
   rate = timed(lambda: gm.predict_reward(xs, xa, es, ea, w, w))
   pair_flops = 2 * (2 * Bg * Bg) * (3 * (Sg + Ag))   # two gammas share the distances: 2 matrices x B^2 pairs x 3 flop per pair-feature (direct form)
   out['gmmil_reward_B1024_ant'] = dict(calls_per_s=round(rate, 1), pair_feature_TFLOPs=round(pair_flops * rate / 1e12 / 2, 2),
-                                        note='k_gmmil_pack/tile/final; the reference materialises [B,B,D] temporaries (0.33 s per call on its CPU path, SURVEY.md a20)')
+                                        note='k_gmmil_direct (one launch reading the batches; IL_GMMIL_DIRECT=0: k_gmmil_pack + k_gmmil_tile); the reference materialises [B,B,D] temporaries (0.33 s per call on its CPU path, SURVEY.md a20)')
 
   # BASELINE.json configs[3] as WHOLE updates: algorithm=GMMIL env=ant, batch 1024 - 2 replay samples + the pairwise-RBF reward + sac_update as one captured graph per step
   rs2 = np.random.RandomState(6)
@@ -567,6 +567,8 @@ def main():
     plan.stream_ordered_draw = True
     roof = roofline(plan.run, args.trace_steps, 1, ms_per_step, getattr(plan, 'overlap', False))
     plan.stream_ordered_draw = False
+    roof['frac_note'] = ('`frac` / `achieved` are an eager-window LOWER bound: the HIP-event window around an eager launch includes the device-side waits the timed schedule overlaps '
+                         '(k_sac_chain 30 us here against 24.0 us in the rocprofv3 trace of the graph replays, profiles/r04_headline_kernel_stats.md: 289 MFLOP / 24.0 us = 12.0 TFLOP/s = 0.077 of fp32)')
     roof['timing_note'] = 'kernel durations: HIP events around eager launches with the index draw stream-ordered (il_replay_sample_device); the timed `value` above runs the resident-draw schedule as two hipGraphs'
 
     out = dict(metric='SAC+GAIL grad-updates/sec (batch 256, HalfCheetah dims)', value=round(ups, 1), unit='updates/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -583,7 +585,7 @@ def main():
                            exchange_soak=(exchange_ab['peer']['exchange_soak'] if exchange_ab else (getattr(runner.peer, 'soak_report', None) if getattr(runner, 'peer', None) is not None else None)),
                            replicas_bit_identical=(same if runner is not plan else None), replica_digests=([d[:16] for d in digests] if runner is not plan else None),
                            branch_sync=('device counters (two graphs, no cross-stream edge)' if getattr(plan, 'device_sync', False) and runner is plan else 'stream dependencies'),
-                           rows=('read from the rings through the drawn indices (il_batch.gather), relabel inline in k_sac_chain' if getattr(plan, 'inline_relabel', False) and runner is plan
+                           rows=('read from the rings through the drawn indices (il_batch.gather); reward relabel as a role of k_sac_chain_pair (16-wave schedule: inline in the critic-loss workgroups)' if getattr(plan, 'inline_relabel', False) and runner is plan
                                  else ('read from the rings through the drawn indices (il_batch.gather)' if getattr(plan, 'ring_mode', False) and runner is plan else 'gathered by k_gather2'))),
                roofline=roof)
     if world == 1 and args.learners == 1 and not args.no_population:
