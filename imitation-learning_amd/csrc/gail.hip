@@ -224,7 +224,58 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     else sync_wait(sy, IL_SYNC_ROWS, (sy[IL_SYNC_SIDE_EPOCH] + 1) * sy[IL_SYNC_GATHER_WGS]);
     IL_TL(0, 2);
     ctr = d.noise_counter ? *d.noise_counter : 0u;   // after the wait: the previous update's actor step (which bumps it) precedes this update's gather
-    stage_rows(0);
+    // (round 4) The rows of this call with every load of a round in flight: stage_rows' element loop makes, per element, an index load and then a dependent row load -
+    // four serialised fabric / HBM round trips for the two elements a thread owns at HalfCheetah dims - and draws the mixing coefficient of a row once per ELEMENT
+    // (a Philox call each). Here: the coefficients once per row (16 threads, into zs, which nothing reads before the loss), the indices of up to four elements per thread
+    // requested together, then their rows. Same values, same X: same bits.
+    float* eps_s = L.zs;
+    if (kind >= 2 && tid < IL_TILE_R) eps_s[tid] = tid < nrows ? mix_eps(row0 + tid) : 0.f;
+    const unsigned mdp = fastdiv_magic(Dp);
+    for (int base = 0; base < IL_TILE_R * Dp; base += 4 * (int)blockDim.x) {
+      int64_t pr[4], er[4]; int rr[4], kk[4]; bool ok[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = base + q * (int)blockDim.x + tid, ic = min(i, IL_TILE_R * Dp - 1);
+        rr[q] = fastdiv(ic, mdp); kk[q] = ic - rr[q] * Dp; ok[q] = i < IL_TILE_R * Dp && rr[q] < nrows && kk[q] < D;
+        const int row = row0 + min(rr[q], nrows - 1);
+        pr[q] = (kind != 1 && pol.gather) ? (int64_t)gload(pol.gather + row) : (int64_t)row;
+        er[q] = (kind != 0 && exp.gather) ? (int64_t)gload(exp.gather + row) : (int64_t)row;
+      }
+      int64_t wpr = row0 + min(tid, nrows - 1), wer = wpr;
+      if (base == 0 && tid < IL_TILE_R) { if (kind != 1 && pol.gather) wpr = gload(pol.gather + wpr); if (kind != 0 && exp.gather) wer = gload(exp.gather + wer); }
+      float xp[4], xe[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = min(kk[q], D - 1);
+        int64_t a = pr[q], b = er[q];
+        if (pol.gather) a = a < 0 ? 0 : (a >= pol.gather_capacity ? pol.gather_capacity - 1 : a);
+        if (exp.gather) b = b < 0 ? 0 : (b >= exp.gather_capacity ? exp.gather_capacity - 1 : b);
+        xp[q] = kind != 1 ? gload(k < S ? pol.states + (size_t)a * pol.ld_states + k : pol.actions + (size_t)a * pol.ld_actions + (k - S)) : 0.f;
+        xe[q] = kind != 0 ? gload(k < S ? exp.states + (size_t)b * exp.ld_states + k : exp.actions + (size_t)b * exp.ld_actions + (k - S)) : 0.f;
+      }
+      float wp = 0.f, we = 0.f;
+      if (base == 0 && tid < IL_TILE_R) {
+        if (pol.gather) wpr = wpr < 0 ? 0 : (wpr >= pol.gather_capacity ? pol.gather_capacity - 1 : wpr);
+        if (exp.gather) wer = wer < 0 ? 0 : (wer >= exp.gather_capacity ? exp.gather_capacity - 1 : wer);
+        if (kind != 1) wp = gload(pol.weights + (size_t)wpr * pol.ld_weights);
+        if (kind != 0) we = gload(exp.weights + (size_t)wer * exp.ld_weights);
+      }
+      if (base == 0) __syncthreads();   // the rows' mixing coefficients are in LDS
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = base + q * (int)blockDim.x + tid;
+        if (i < IL_TILE_R * Dp) {
+          float xv = 0.f;
+          if (ok[q]) { if (kind >= 2) { const float e = eps_s[rr[q]]; xv = e * xe[q] + (1.f - e) * xp[q]; } else xv = kind == 0 ? xp[q] : xe[q]; }
+          X[i] = xv;
+        }
+      }
+      if (base == 0 && tid < IL_TILE_R) {
+        float w = 0.f;
+        if (tid < nrows) { if (kind >= 2) { const float e = eps_s[tid]; w = e * we + (1.f - e) * wp; } else w = kind == 0 ? wp : we; }
+        L.wt(0)[tid] = w;
+      }
+    }
   } else {
     ctr = d.noise_counter ? *d.noise_counter : 0u;
     if (tid < 64) {  // ---- wave 0: the power iterations of calls 0..pass on the Gram matrix
