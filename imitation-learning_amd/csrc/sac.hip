@@ -696,9 +696,10 @@ __device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch&
   if (head_thread) { if (b.gather) hidx = hidx < 0 ? 0 : (hidx >= b.gather_capacity ? b.gather_capacity - 1 : hidx); absorb_pre = gload(b.absorbing + (size_t)hidx * b.ld_absorbing); }
   SmallPre w3pre = {};
   if (half == 0) w3pre = tile_fwd_small_prefetch(net.W3, H, 2 * A, H);
-  // (The panel of the hidden layer is NOT requested here: a wave that issues 16 KB of loads is held at the issue stage until the CU's memory pipeline has taken them -
-  // with eight waves doing so, ~0.85 us per panel during which it cannot commit its rows; measured as a 4.8 us prologue of the first pair-mode k_policy_critic with two
-  // panels parked. Requested right before its MFMAs, the panel streams in under them - the schedule of tile_packed.)
+  // Only the FIRST HALF of the hidden layer's panel is requested here (panel_prefetch_lo), behind every wave's small loads (issue_fence): a wave that issues 16 KB of
+  // loads is held at the issue stage until the CU's memory pipeline has taken them - with eight waves doing so ~0.85 us per panel, during which it cannot commit its rows
+  // (two whole panels parked in the prologue of the first pair-mode k_policy_critic: a 4.8 us prologue). The second half goes out right before the MFMAs and streams in
+  // under the first half's.
   issue_fence();
   Panel16 pn; panel_prefetch_lo(pn, W + ws.pk_af, t2);
   IL_TL(10, 1);
