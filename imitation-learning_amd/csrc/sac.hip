@@ -1807,10 +1807,19 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
   const int er = tid >> 3, ec = (tid & 7) * 4;
   const int en = n0 + er, ek = k0 + ec;
   const bool full = n0 + DWS <= Nvalid && k0 + DWS <= Kvalid && (Kvalid & 3) == 0 && (poff & 3) == 0;   // whole block inside the matrix, rows 16-byte aligned: 16-byte lanes
-  const int64_t eo = poff + (int64_t)min(en, Nvalid - 1) * Kvalid + min(ek, Kvalid - 1);
+  // (round 4) A first-layer block (all Kvalid <= 32 columns of 32 whole rows) is not `full` - its rows are narrower than the block, and 18 floats wide they are not even
+  // 16-byte aligned - and took the element-wise path below: twelve dword loads and twelve plain dword stores per thread, 0.9 us behind the H x H blocks at the end of BOTH
+  // optimiser launches (profiles/tools/dw_stragglers.py). But its parameters are ONE contiguous run of 32 Kvalid floats: `flat` treats it as 8 Kvalid 16-byte lanes (one per
+  // thread), gathers each lane's four gradients out of the LDS block, and stores write-through like a full block. Same gradients, same AdamW: same bits.
+  // Last-layer blocks (OUT < 32 rows of H columns) are whole 16-byte lanes too, only fewer rows: `rowg` keeps the lane form with a row guard.
+  const bool rowg = !full && k0 + DWS <= Kvalid && (Kvalid & 3) == 0 && (poff & 3) == 0 && n0 < Nvalid;
+  const bool flat = !full && !rowg && k0 == 0 && Kvalid <= DWS && n0 + DWS <= Nvalid && ((poff + (int64_t)n0 * Kvalid) & 3) == 0 && ((DWS * Kvalid) & 3) == 0;
+  const bool flat_on = flat && tid < DWS * Kvalid / 4;
+  const int64_t fo = poff + (int64_t)n0 * Kvalid + 4 * (int64_t)min(tid, DWS * Kvalid / 4 - 1);
+  const int64_t eo = flat ? fo : poff + (int64_t)min(en, Nvalid - 1) * Kvalid + min(ek, Kvalid - 1);
   f32x4 pv = zero4(), mv = zero4(), vv = zero4();
   if (!a.grads_only) {   // HBM (last touched an update ago): requested before anything else
-    if (full) { pv = gload4(a.params + eo); mv = gload4(a.opt.m + eo); vv = gload4(a.opt.v + eo); }
+    if (full || flat || rowg) { pv = gload4(a.params + eo); mv = gload4(a.opt.m + eo); vv = gload4(a.opt.v + eo); }   // (rowg: rows past the matrix clamp to its last row and are not stored)
     else {
 #pragma unroll
       for (int c = 0; c < 4; ++c) { const int64_t o = poff + (int64_t)min(en, Nvalid - 1) * Kvalid + min(ek + c, Kvalid - 1); pv[c] = gload(a.params + o); mv[c] = gload(a.opt.m + o); vv[c] = gload(a.opt.v + o); }
@@ -1872,17 +1881,26 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
   }
   __syncthreads();
   f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + er * DWS_GLD + ec);
+  if (flat) {   // this thread's lane of the contiguous run: elements 4 tid .. + 3 = (row e / Kvalid, column e % Kvalid) of the block
+    const unsigned mk = fastdiv_magic(Kvalid);
+    const int e0 = 4 * min(tid, DWS * Kvalid / 4 - 1);
+    int row = fastdiv(e0, mk), col = e0 - row * Kvalid;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { gv[c] = Gs[row * DWS_GLD + col]; if (++col == Kvalid) { col = 0; ++row; } }
+  }
   if (PEER) {   // data-parallel: this block's gradients (and bias gradients) become their mean over the ranks before the optimiser sees them
     const il_peer_bucket& x = pp->x;
     const PeerJob pj = peer_job_begin(x, pjob);
-    if (full) peer_job_push4(x, pj, eo, gv);
+    if (full || flat_on || (rowg && en < Nvalid)) peer_job_push4(x, pj, eo, gv);
+    else if (flat || rowg) { }
     else if (en < Nvalid) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) if (ek + c < Kvalid) peer_job_push1(x, pj, poff + (int64_t)en * Kvalid + ek + c, gv[c]);
     }
     if (bias_owner) peer_job_push1(x, pj, boff + n0 + bf, bsum);
     peer_job_exchange(x, pj, pjob);
-    if (full) gv = peer_job_mean4(x, pj, eo);
+    if (full || flat_on || (rowg && en < Nvalid)) gv = peer_job_mean4(x, pj, eo);
+    else if (flat || rowg) { }
     else if (en < Nvalid) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) if (ek + c < Kvalid) gv[c] = peer_job_mean1(x, pj, poff + (int64_t)en * Kvalid + ek + c);
@@ -1895,7 +1913,15 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
     if (a.grads_only) a.grads[o] = bsum;
     else { adam_update(bpp, bsum, bmm, bvv, ac); a.params[o] = bpp; a.opt.m[o] = bmm; a.opt.v[o] = bvv; }
   }
-  if (!full) {   // partial block (first / last layer): element-wise with guards
+  if (flat || rowg) {
+    if (flat ? !flat_on : en >= Nvalid) return;
+    if (a.grads_only) { *reinterpret_cast<f32x4*>(a.grads + eo) = gv; return; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { float pp_ = pv[c], mm = mv[c], v2 = vv[c]; adam_update(pp_, gv[c], mm, v2, ac); pv[c] = pp_; mv[c] = mm; vv[c] = v2; }
+    dw_store4(a.params, eo, pv); dw_store4(a.opt.m, eo, mv); dw_store4(a.opt.v, eo, vv);
+    return;
+  }
+  if (!full) {   // partial block (last layer; first layers wider than a block): element-wise with guards
     if (en < Nvalid) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
