@@ -564,9 +564,11 @@ def main():
     # ---- per-kernel durations, HIP events on the launch stream, eager launches of the very same kernels
     # (traced with the index draw stream-ordered ahead of the forward / critic-loss launch: with the resident draw that launch is dispatched while the draw is still
     #  waiting for the previous update, so its HIP-event window would include that wait instead of its own work; both schedules are bit-identical)
+    fused_desc, plan.peer_desc = getattr(plan, 'peer_desc', None), None   # (data-parallel runs: the per-kernel windows are taken on this rank's plain single-GPU launches - the fused exchange lives on the resident-sampler schedule only, and rank 0 alone runs this section)
     plan.stream_ordered_draw = True
     roof = roofline(plan.run, args.trace_steps, 1, ms_per_step, getattr(plan, 'overlap', False))
     plan.stream_ordered_draw = False
+    plan.peer_desc = fused_desc
     roof['frac_note'] = ('`frac` / `achieved` are an eager-window LOWER bound: the HIP-event window around an eager launch includes the device-side waits the timed schedule overlaps '
                          '(k_sac_chain 30 us here against 24.0 us in the rocprofv3 trace of the graph replays, profiles/r04_headline_kernel_stats.md: 289 MFLOP / 24.0 us = 12.0 TFLOP/s = 0.077 of fp32)')
     roof['timing_note'] = 'kernel durations: HIP events around eager launches with the index draw stream-ordered (il_replay_sample_device); the timed `value` above runs the resident-draw schedule as two hipGraphs'

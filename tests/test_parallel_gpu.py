@@ -256,6 +256,23 @@ def test_bench_gpus_2_refuses_on_a_one_gpu_box():
   assert r.returncode == 2 and 'needs 2 visible GPUs' in r.stderr and '"metric"' not in r.stdout
 
 
+@pytest.mark.parametrize('fused', ['1', '0'])
+def test_bench_runs_the_multi_gpu_default_schedule_with_one_rank(fused):
+  """What every rank of `bench.py --gpus N` runs by default - the hand-off schedule with the resident sampler and the three exchanges INSIDE the optimiser launches over the
+  peer windows - forced on with a world of one rank (IL_FORCE_DP=1, IL_PEER_EXCHANGE=force): the whole of bench.py must get through it, including the per-kernel section
+  rank 0 runs after the timed region (round 4: it switched the plan to the stream-ordered draw while the fused exchange was still attached - the first real multi-GPU run
+  would have died there after its measurement). IL_DP_FUSED=0: one exchange launch per sync point."""
+  import json
+  r = _bench(['--steps', '40', '--warmup', '10', '--trace-steps', '3', '--no-cpu-baseline', '--no-population', '--no-secondary'], IL_FORCE_DP='1', IL_PEER_EXCHANGE='force', IL_DP_FUSED=fused,
+             IL_PEER_SOAK_ROUNDS='100')
+  assert r.returncode == 0, r.stderr[-3000:]
+  j = json.loads(r.stdout.strip().splitlines()[-1])
+  c = j['config']
+  assert j['n_gpus'] == 1 and j['value'] > 0 and c['replicas_bit_identical'] is True and c['exchange'].startswith('peer')
+  assert ('inside the optimiser launches' in c['exchange']) == (fused == '1')
+  assert 'k_sac_chain' in j['roofline']['kernels'] and c['finite'] is True
+
+
 @pytest.mark.parametrize('peer', ['1', '0'])
 def test_bench_starts_its_own_ranks_and_reports_the_replica_digest(peer):
   """`python bench.py --gpus 2` with no rank environment: bench.py launches the two ranks itself (here they share the box's GPU and meet over gloo: IL_BENCH_SHARE_GPU=1),
