@@ -1030,6 +1030,7 @@ __device__ __forceinline__ void actor_bwd_tile(const il_sac& d, const il_batch& 
 // and split the last GEMM between them by output columns. Same arithmetic per element, so the result is bit-identical to helpers = 0.
 #define IL_PC_HELPERS 4
 #define IL_PC_XCD_NETS 0x100   // flag bit in k_policy_critic's `helpers` argument
+#define IL_PC_NO_TAIL 0x200    // flag bit: critic workgroups only, the policy backward is a launch of its own (k_actor_bwd: population path, IL_POP_SPLIT_TAIL)
 template <int PANEL>
 __device__ __forceinline__ void k_policy_critic_body(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, const il_sac* __restrict__ dL,
                                                         const il_batch* __restrict__ bL, int helpers, float* smem) {
@@ -1042,7 +1043,8 @@ __device__ __forceinline__ void k_policy_critic_body(il_sac d, il_batch b, float
   // 2 + helpers - 1: helper part p of every tile (its column slice of the actor's backward panel is read by that XCD alone), the other blocks exit. Tile q: blocks
   // 8q, 8q + 1 (critics) < 8q + 2 + p (helpers): a helper still only waits for lower-numbered workgroups.
   const bool xcd_nets = (helpers & IL_PC_XCD_NETS) != 0;
-  helpers &= ~IL_PC_XCD_NETS;
+  const bool no_tail = (helpers & IL_PC_NO_TAIL) != 0;
+  helpers &= ~(IL_PC_XCD_NETS | IL_PC_NO_TAIL);
   if (xcd_nets && (bx & 7) >= 2 + helpers) return;
   if (xcd_nets ? (bx & 7) >= 2 : bx >= 2 * nt) {   // helper: block order keeps it behind both critics of its tile (it only waits for lower-numbered workgroups)
     const int h = xcd_nets ? ((bx & 7) - 2) * nt + (bx >> 3) : bx - 2 * nt, tile = h % nt, part = h / nt;
@@ -1144,6 +1146,7 @@ __device__ __forceinline__ void k_policy_critic_body(il_sac d, il_batch b, float
   // is the only L2 write-back / invalidate of the hand-off (a __threadfence() per wave costs 16 of them per workgroup: measured -8 %).
   unsigned* ctr = reinterpret_cast<unsigned*>(W + ws.pair_ctr) + tile * IL_CTR_STRIDE;
   if (helpers > 0) { IL_TL(3, 6); tile_arrive(ctr); IL_TL(3, 7); return; }
+  if (no_tail) return;
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -1156,6 +1159,17 @@ __device__ __forceinline__ void k_policy_critic_body(il_sac d, il_batch b, float
     return;
   }
   actor_bwd_tile<PANEL>(d, b, tile, out_logp, out_q, smem, 0, 1, [] {});
+}
+
+// The policy backward of one tile as a workgroup of a launch of its own (population path): in k_policy_critic_pop the second of a tile's two critic workgroups to arrive
+// runs it as its tail, so half the workgroups of that launch are 1.7 x as long as the other half and the launch ends on the long ones. grid = (nt, learners).
+template <int PANEL>
+__device__ __forceinline__ void k_actor_bwd_body(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL, float* smem) {
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (dL) { pop_ids(bx, by); d = dL[by]; b = bL[by]; }
+  globalize(d); globalize(b);
+  if (bx == 0 && threadIdx.x == 0) { adam_tick(d.actor_opt); adam_tick(d.alpha_opt); }   // consumed by the next kernel
+  actor_bwd_tile<PANEL>(d, b, bx, nullptr, nullptr, smem, 0, 1, [] {});
 }
 
 // The tile kernels, twice: 1024-thread workgroups with the whole weight panel of a tile in flight (single learner, data-parallel and per-function paths: one workgroup
@@ -1179,6 +1193,10 @@ __device__ __forceinline__ void k_policy_critic_body(il_sac d, il_batch b, float
                                                  const il_batch* __restrict__ bL, int helpers) {                                                                         \
     extern __shared__ __attribute__((aligned(16))) float smem[];                                                                                                         \
     k_policy_critic_body<PANEL>(d, b, out_logp, out_q, dL, bL, helpers, smem);                                                                                           \
+  }                                                                                                                                                                      \
+  __global__ BOUNDS void k_actor_bwd##SUFFIX(il_sac d, il_batch b, const il_sac* __restrict__ dL, const il_batch* __restrict__ bL) {                                     \
+    extern __shared__ __attribute__((aligned(16))) float smem[];                                                                                                         \
+    k_actor_bwd_body<PANEL>(d, b, dL, bL, smem);                                                                                                                         \
   }
 IL_TILE_KERNELS(, 16, __launch_bounds__(1024))
 #ifndef IL_POP_PANEL
@@ -2435,8 +2453,15 @@ extern "C" int il_sac_update_population(const il_sac* descs_dev, const il_batch*
     { IL_TRACE("k_dw_adam_critic", st); k_dw_adam_pop<<<dim3(nbc + pop_dw_small_grid(S + A, H, 1, 2, B, b64), L), 256, 0, st>>>(descs_dev, batches_dev, 0, flags, nbc); }
     {
       IL_TRACE("k_policy_critic", st);
-      if (pop3) k_policy_critic_pop<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, nullptr, nullptr, descs_dev, batches_dev, 0);
-      else k_policy_critic<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, nullptr, nullptr, descs_dev, batches_dev, 0);
+      // Round 4: the policy backward is a launch of its own behind the critics (uniform workgroups in both) instead of the tail of each tile's second arriver, which made
+      // half the workgroups of the launch 1.7 x as long as the rest: +11 % aggregate on one box (profiles/r04_pop_split_ab.txt). IL_POP_SPLIT_TAIL=0: the one-launch form.
+      static const int split_tail = [] { const char* e = getenv("IL_POP_SPLIT_TAIL"); return e && e[0] == '0' ? 0 : 1; }();
+      if (pop3) k_policy_critic_pop<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, nullptr, nullptr, descs_dev, batches_dev, split_tail ? IL_PC_NO_TAIL : 0);
+      else k_policy_critic<<<dim3(2 * nt, L), tt, lds, st>>>(z, zb, nullptr, nullptr, descs_dev, batches_dev, split_tail ? IL_PC_NO_TAIL : 0);
+      if (split_tail) {
+        if (pop3) k_actor_bwd_pop<<<dim3(nt, L), tt, lds, st>>>(z, zb, descs_dev, batches_dev);
+        else k_actor_bwd<<<dim3(nt, L), tt, lds, st>>>(z, zb, descs_dev, batches_dev);
+      }
     }
     { IL_TRACE("k_dw_adam_actor", st); k_dw_adam_pop<<<dim3(nba + pop_dw_small_grid(S, H, 2 * A, 1, B, b64) + 33, L), 256, 0, st>>>(descs_dev, batches_dev, 1, flags, nba); }
   }
