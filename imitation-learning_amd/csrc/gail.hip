@@ -101,29 +101,36 @@ __device__ __forceinline__ void sn_chain(const float* W1s, const float* W2s, con
   WAVE_SYNC();
 }
 
-struct DiscLds {  // per-pass arrays are contiguous and addressed arithmetically (pointer arrays indexed at run time would go to scratch)
-  float *W1s, *b1s, *W2s, *Xb, *wtb, *hs, *dhs, *ts, *cg, *snb, *zs, *dzs, *red, *Ms, *tmp;
+// LDS of one discriminator workgroup. The arrays k_gail_reward needs come first (disc_reward_lds_floats: its launches ask for that prefix only - 34 KB at HalfCheetah dims, four
+// workgroups per CU); the whole set is 73 KB, two workgroups of k_gail_grad per CU (round 3: three slots of X / wt / u,v of which only the first was used and a third
+// [16][H] array made it 96 KB - ONE four-wave workgroup per CU on the population launches, every dependent phase exposed). `ts` IS `hs`: the gradient-penalty call
+// replaces h by [h > 0] t' element by element (same lane reads and writes), and nothing reads h after that.
+struct DiscLds {
+  float *W1s, *b1s, *W2s, *Xb, *wtb, *snb, *hs, *dhs, *ts, *cg, *zs, *dzs, *red, *Ms, *tmp;
   int D, H, Dp;  // Dp = D rounded up to 4 (rows of X / cg / v1 are zero-padded so dot products run on 16-byte lanes)
-  __device__ __forceinline__ float* X(int c) const { return Xb + c * IL_TILE_R * Dp; }
-  __device__ __forceinline__ float* wt(int c) const { return wtb + c * IL_TILE_R; }
-  __device__ __forceinline__ float* u1(int c) const { return snb + c * (2 * H + Dp + 4); }
-  __device__ __forceinline__ float* v1(int c) const { return u1(c) + H; }
-  __device__ __forceinline__ float* v2(int c) const { return u1(c) + H + Dp; }
-  __device__ __forceinline__ float* sc(int c) const { return u1(c) + 2 * H + Dp; }
+  __device__ __forceinline__ float* X(int) const { return Xb; }
+  __device__ __forceinline__ float* wt(int) const { return wtb; }
+  __device__ __forceinline__ float* u1(int) const { return snb; }
+  __device__ __forceinline__ float* v1(int) const { return snb + H; }
+  __device__ __forceinline__ float* v2(int) const { return snb + H + Dp; }
+  __device__ __forceinline__ float* sc(int) const { return snb + 2 * H + Dp; }
 };
+__host__ __device__ inline size_t disc_reward_lds_floats(int D, int H) {
+  const int Dp = (D + 3) & ~3;
+  return (size_t)H * (Dp + 4) + 2 * H + (size_t)IL_TILE_R * Dp + IL_TILE_R + (size_t)(2 * H + Dp + 4);
+}
 __host__ __device__ inline size_t disc_lds_floats(int D, int H) {
   const int Dp = (D + 3) & ~3;
-  return (size_t)H * (Dp + 4) + 2 * H + 3 * (size_t)IL_TILE_R * Dp + 3 * IL_TILE_R + 3 * (size_t)IL_TILE_R * H + (size_t)IL_TILE_R * Dp + 3 * (size_t)(2 * H + Dp + 4) + 2 * IL_TILE_R + 64 +
-         (size_t)Dp * Dp + H + Dp;
+  return disc_reward_lds_floats(D, H) + 2 * (size_t)IL_TILE_R * H + (size_t)IL_TILE_R * Dp + 2 * IL_TILE_R + 64 + (size_t)Dp * Dp + H + Dp;
 }
 __device__ __forceinline__ DiscLds carve(float* s, int D, int H) {
   DiscLds l; float* p = s;
   const int Dp = (D + 3) & ~3;
   l.D = D; l.H = H; l.Dp = Dp;
   l.W1s = p; p += H * (Dp + 4); l.b1s = p; p += H; l.W2s = p; p += H;
-  l.Xb = p; p += 3 * IL_TILE_R * Dp; l.wtb = p; p += 3 * IL_TILE_R;
-  l.hs = p; p += IL_TILE_R * H; l.dhs = p; p += IL_TILE_R * H; l.ts = p; p += IL_TILE_R * H; l.cg = p; p += IL_TILE_R * Dp;
-  l.snb = p; p += 3 * (2 * H + Dp + 4);
+  l.Xb = p; p += IL_TILE_R * Dp; l.wtb = p; p += IL_TILE_R;
+  l.snb = p; p += 2 * H + Dp + 4;
+  l.hs = p; p += IL_TILE_R * H; l.dhs = p; p += IL_TILE_R * H; l.ts = l.hs; l.cg = p; p += IL_TILE_R * Dp;
   l.zs = p; p += IL_TILE_R; l.dzs = p; p += IL_TILE_R; l.red = p; p += 64;
   l.Ms = p; p += Dp * Dp; l.tmp = p;
   return l;
@@ -131,9 +138,22 @@ __device__ __forceinline__ DiscLds carve(float* s, int D, int H) {
 
 // stage W1 (padded rows), b1, W2 into LDS
 __device__ __forceinline__ void stage_weights(const DiscLds& L, const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2, int D, int H) {
-  const int Dp = L.Dp, ldw = Dp + 4;
-  for (int i = threadIdx.x; i < H * Dp; i += blockDim.x) { const int n = i / Dp, k = i - n * Dp; L.W1s[n * ldw + k] = k < D ? W1[(size_t)n * D + k] : 0.f; }
-  for (int i = threadIdx.x; i < H; i += blockDim.x) { L.b1s[i] = b1[i]; L.W2s[i] = W2[i]; }
+  const int Dp = L.Dp, ldw = Dp + 4, tid = threadIdx.x, bd = blockDim.x;
+  if (w1_flat_ok(W1, D, H)) {   // (round 4) 16-byte lanes of the flat array, six per thread in flight (disc_reward.hpp)
+    const int nvec = (H * D) >> 2;
+    const unsigned mdd = fastdiv_magic(D);
+    W1Stage<6> ws;
+    w1_issue(ws, W1, nvec, 0);
+    const float vb1 = gload(b1 + min(tid, H - 1)), vw2 = gload(W2 + min(tid, H - 1));
+    w1_commit(ws, L.W1s, D, ldw, nvec, 0, mdd);
+    for (int base = 6 * bd; base < nvec; base += 6 * bd) { w1_issue(ws, W1, nvec, base); w1_commit(ws, L.W1s, D, ldw, nvec, base, mdd); }
+    w1_zero_padding(L.W1s, D, Dp, H, ldw);
+    if (tid < H) { L.b1s[tid] = vb1; L.W2s[tid] = vw2; }
+    for (int i = bd + tid; i < H; i += bd) { L.b1s[i] = b1[i]; L.W2s[i] = W2[i]; }
+    return;
+  }
+  for (int i = tid; i < H * Dp; i += bd) { const int n = i / Dp, k = i - n * Dp; L.W1s[n * ldw + k] = k < D ? W1[(size_t)n * D + k] : 0.f; }
+  for (int i = tid; i < H; i += bd) { L.b1s[i] = b1[i]; L.W2s[i] = W2[i]; }
 }
 
 // grid = (tiles, passes): one workgroup = 16 rows of ONE discriminator call (0 policy, 1 expert, 2 gradient-penalty mix), so the
@@ -180,8 +200,10 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   if (tid == 0 && tile == 0 && pass == 0 && !pu_value_pass) adam_tick(d.opt);
   __syncthreads();
   IL_STAMP(stamp, 2);
+  if (!d.sync) IL_TL(0, 1);   // (slots 1 / 2 on the hand-off path: before / after the wait for the index draw)
   if (d.spectral_norm) { sn_gram(L.W1s, L.Ms, D, Dp, H, ldw); __syncthreads(); }
   IL_STAMP(stamp, 3);
+  IL_TL(0, 3);
   float* X = L.X(0);
   // rows (and mixing weights) of this call, staged by threads [t0, blockDim.x)
   uint32_t ctr = 0u;   // Philox counter of this update (read below, once it is known to be this update's)
@@ -287,6 +309,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   }
   __syncthreads();
   IL_STAMP(stamp, 6);
+  IL_TL(0, 4);
 
   const int r = tid >> 4, sub = tid & 15;
   const int wave = tid >> 6, nw = blockDim.x >> 6, lane = tid & 63, jj = lane & 15, gg = lane >> 4;
@@ -294,7 +317,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   const bool valid = r < nrows;
   const float s1 = L.sc(0)[0], s2 = L.sc(0)[1], u2 = L.sc(0)[2];
   const float* u1 = L.u1(0); const float* v1 = L.v1(0); const float* v2 = L.v2(0);
-  float* zw = L.ts;  // [waves][16] per-wave partial logits (ts is not needed before the gradient-penalty products)
+  float* zw = L.dhs;  // [waves][16] per-wave partial logits (dhs is written after the barriers below)
   // ---- forward on MFMA: hs[r][n] = (X . W1^T)[r][n] / s1 + b1[n]  (one wave per 16 hidden units), per-row partial logits
   {
     float zp[4] = {0.f, 0.f, 0.f, 0.f};
@@ -311,7 +334,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   __syncthreads();
   float f = b2;   // the network's logit
   for (int w = 0; w < nw; ++w) f += zw[w * 16 + r];
-  __syncthreads();  // zw (aliasing ts) is free again
+  __syncthreads();  // zw (aliasing dhs) is free again
   float ip1, ip2;
   if (kind != 2) {
     const float w = L.wt(0)[r];
@@ -378,6 +401,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   }
   __syncthreads();
   IL_STAMP(stamp, 7);
+  IL_TL(0, 5);
   // ---- this call's gradient slab:  G1^[n][k] = sum_r left[r][n] right[r][k]  on MFMA (reduction over the tile's 16 rows)
   const float* left = L.dhs;                         // [16][H]: dh (BCE) or q (GP)
   const float* right = kind != 2 ? X : L.cg;         // [16][Dp]: x (BCE) or c*g (GP)
@@ -408,6 +432,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     slab[lay.ob2] = gb2;
   }
   IL_STAMP(stamp, 8);
+  IL_TL(0, 6);
   if (tile == 0 && pass == npass - 1 && d.spectral_norm) {  // final u, v of this update: the last call's iteration
     float* o = d.workspace + wsl.sn_new;
     for (int i = tid; i < H; i += blockDim.x) { o[i] = u1[i]; o[H + D + 1 + i] = v2[i]; }
@@ -492,20 +517,34 @@ __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, floa
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, Dp = (D + 3) & ~3;
   const int row0 = blockIdx.x * IL_TILE_R, tid = threadIdx.x, nrows = min(IL_TILE_R, b.n - row0);
   DiscLds L = carve(smem, D, H);
+  IL_TL(2, 0);
   if (d.sync && !b.gather) {   // gathered rows: the discriminator step before this kernel may have run off the index draw alone, so their arrival is checked here
     long long* sy = reinterpret_cast<long long*>(d.sync);
     sync_wait(sy, IL_SYNC_ROWS, (sy[IL_SYNC_SIDE_EPOCH] + 1) * sy[IL_SYNC_GATHER_WGS]);
   }
-  for (int i = tid; i < IL_TILE_R * Dp; i += blockDim.x) {
-    const int r = i / Dp, k = i - r * Dp; float xv = 0.f;
-    if (r < nrows && k < D) { const size_t sr = brow(b, row0 + r); xv = k < S ? b.states[sr * b.ld_states + k] : b.actions[sr * b.ld_actions + k - S]; }
-    L.X(0)[i] = xv;
+  {   // the tile's rows, four elements per thread and round: their indices requested together, then their rows (an index -> row chain per element made 2 x 2 serial round trips)
+    const unsigned mdp = fastdiv_magic(Dp);
+    for (int base = 0; base < IL_TILE_R * Dp; base += 4 * (int)blockDim.x) {
+      size_t sr[4]; int kk[4]; bool ok[4]; float xv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = base + q * (int)blockDim.x + tid, ic = min(i, IL_TILE_R * Dp - 1), r = fastdiv(ic, mdp);
+        kk[q] = ic - r * Dp; ok[q] = i < IL_TILE_R * Dp && r < nrows && kk[q] < D;
+        sr[q] = brow(b, row0 + min(r, nrows - 1));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int k = min(kk[q], D - 1); xv[q] = gload(k < S ? b.states + sr[q] * b.ld_states + k : b.actions + sr[q] * b.ld_actions + (k - S)); }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int i = base + q * (int)blockDim.x + tid; if (i < IL_TILE_R * Dp) L.X(0)[i] = ok[q] ? xv[q] : 0.f; }
+    }
   }
+  IL_TL(2, 1);
   const RewardLds R = {L.W1s, L.b1s, L.W2s, L.u1(0), L.v1(0), L.v2(0), L.sc(0)};
-  disc_reward_tile(d, R, L.X(0), Dp, nrows, logit_offset, row0, [&](int r, float reward, float logit) {
+  disc_reward_tile<6>(d, R, L.X(0), Dp, nrows, logit_offset, row0, [&](int r, float reward, float logit) {
     out_r[row0 + r] = reward;
     if (out_logit) out_logit[row0 + r] = logit;
   });
+  IL_TL_END(2);
   if (d.sync) {   // rewards of this tile are in place; the workgroup that completes the relabel closes the side branch's epoch
     long long* sy = reinterpret_cast<long long*>(d.sync);
     __syncthreads();
@@ -523,6 +562,11 @@ static int ensure_lds(const void* fn, size_t bytes) {
   if (e != hipSuccess) return il_set_error(IL_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", bytes, hipGetErrorString(e));
   return IL_OK;
 }
+
+// Dynamic LDS of the single-learner k_gail_grad launches: at least 81 KB, so that its workgroups keep a CU each as they did with the round-3 layout (they are resident
+// early and wait for the index draw; two of them per CU would share the issue slots of the preparation every one of them runs). The population launch asks for what
+// the layout needs (two workgroups per CU).
+static size_t disc_lds_single(int D, int H) { const size_t b = disc_lds_floats(D, H) * sizeof(float); return b < 81 * 1024 ? 81 * 1024 : b; }
 
 static int check_disc(const il_disc* d) {
   IL_CHECK_ARG(d && d->params && d->grad && d->workspace, "il_disc: null descriptor field");
@@ -545,7 +589,7 @@ extern "C" int il_gail_disc_step(const il_disc* d, const il_batch* pol, const il
   hipStream_t st = (hipStream_t)stream_;
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
   const int nt = ceil_div(d->batch, IL_TILE_R);
-  const size_t lds = disc_lds_floats(D, d->hidden) * sizeof(float);
+  const size_t lds = disc_lds_single(D, d->hidden);
   if (int rc = ensure_lds((const void*)k_gail_grad, lds)) return rc;
   if (d->loss_function == IL_LOSS_PUGAIL && d->pu_clamped) {   // finite nonnegative_margin: a value pass (logits only) ahead of the gradient pass, which reads the clamp decision
     IL_CHECK_ARG(!d->sync, "il_gail_disc_step: PUGAIL with a finite nonnegative_margin runs on one stream (no il_sync hand-off)");
@@ -570,7 +614,7 @@ static int gail_disc_step_draw_impl(const il_disc* d, const il_batch* pol, const
   hipStream_t st = (hipStream_t)stream_;
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
   const int nt = ceil_div(d->batch, IL_TILE_R);
-  const size_t lds = disc_lds_floats(D, d->hidden) * sizeof(float);
+  const size_t lds = disc_lds_single(D, d->hidden);
   IL_CHECK_ARG(lds >= sizeof(MtShared), "il_gail_disc_step_draw: discriminator too small to host the sampler's state in its workgroup LDS");
   if (int rc = ensure_lds((const void*)k_gail_grad, lds)) return rc;
   const GailSampler sa = {mt_state_dev, ring_state_a, idx_a, ring_state_b, idx_b, d->batch};
@@ -607,14 +651,15 @@ extern "C" int il_gail_step_population(const il_disc* descs_dev, const il_batch*
   const il_disc* d = shape_host;
   hipStream_t st = (hipStream_t)stream_;
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim), nt = ceil_div(d->batch, IL_TILE_R), L = n_learners;
-  const size_t lds = disc_lds_floats(D, d->hidden) * sizeof(float);
+  static const int compact = [] { const char* e = getenv("IL_POP_DISC_LDS"); return e && e[0] == '0' ? 0 : 1; }();   // IL_POP_DISC_LDS=0: one workgroup per CU, as in round 3 (A/B)
+  const size_t lds = compact ? disc_lds_floats(D, d->hidden) * sizeof(float) : (size_t)96 * 1024, lds_r = compact ? disc_reward_lds_floats(D, d->hidden) * sizeof(float) : lds;
   if (int rc = ensure_lds((const void*)k_gail_grad, lds)) return rc;
-  if (int rc = ensure_lds((const void*)k_gail_reward, lds)) return rc;
+  if (int rc = ensure_lds((const void*)k_gail_reward, lds_r)) return rc;
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
   il_batch zb = {};
   { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d), L), 256, lds, st>>>(*d, zb, zb, nullptr, il_gail_extra{}, descs_dev, policy_dev, expert_dev, GailSampler{}, 0); }
   { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<dim3((int)((P + 255) / 256), L), 256, 0, st>>>(*d, 1, descs_dev, 0, il_peer_bucket{}); }
-  { IL_TRACE("k_gail_reward", st); k_gail_reward<<<dim3(nt, L), 256, lds, st>>>(*d, zb, nullptr, nullptr, nullptr, descs_dev, policy_dev, rewards_out_dev); }
+  { IL_TRACE("k_gail_reward", st); k_gail_reward<<<dim3(nt, L), 256, lds_r, st>>>(*d, zb, nullptr, nullptr, nullptr, descs_dev, policy_dev, rewards_out_dev); }
   IL_CHECK_LAUNCH("il_gail_step_population");
   return IL_OK;
 }
@@ -648,7 +693,7 @@ extern "C" int il_gail_reward(const il_disc* d, const il_batch* b, float* out_re
   if (int rc = check_disc(d)) return rc;
   IL_CHECK_ARG(b && out_rewards && b->n > 0, "il_gail_reward: bad arguments");
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim);
-  const size_t lds = disc_lds_floats(D, d->hidden) * sizeof(float);
+  const size_t lds = disc_reward_lds_floats(D, d->hidden) * sizeof(float);
   if (int rc = ensure_lds((const void*)k_gail_reward, lds)) return rc;
   { IL_TRACE("k_gail_reward", stream_); k_gail_reward<<<ceil_div(b->n, IL_TILE_R), 256, lds, (hipStream_t)stream_>>>(*d, *b, out_rewards, out_logits, logit_offset, nullptr, nullptr, nullptr); }
   IL_CHECK_LAUNCH("il_gail_reward");

@@ -454,7 +454,7 @@ __device__ __forceinline__ void critic_relabel_tile(const il_sac& d, const Chain
   sync_wait(sy, IL_SYNC_PARAMS, (sy[IL_SYNC_MAIN_EPOCH] + 1) * (long long)rl.n_reduce);
   IL_TL(4, 0);   // [4]: the moment the discriminator's step became visible to this critic workgroup
   const RewardLds R = reward_carve(q16 + 64, rl.dd.state_dim + rl.dd.action_dim, rl.dd.hidden);
-  disc_reward_tile(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
+  disc_reward_tile<3>(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
     rew16[r] = reward;
     if (k == 0 && rl.out) rl.out[row0 + r] = reward;
   });
@@ -837,7 +837,7 @@ __device__ __forceinline__ void relabel_role(const il_sac& d, const il_batch& b,
   sync_wait(sy, IL_SYNC_PARAMS, (sy[IL_SYNC_MAIN_EPOCH] + 1) * (long long)rl.n_reduce);   // (its barrier also covers the rows above)
   IL_TL(10, 2);
   const RewardLds R = reward_carve(q16 + 64, rl.dd.state_dim + rl.dd.action_dim, rl.dd.hidden);
-  disc_reward_tile(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
+  disc_reward_tile<3>(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
     wstore1(W, ws.c_rew + row0 + r, reward);
     if (rl.out) rl.out[row0 + r] = reward;
   });
@@ -1760,22 +1760,36 @@ __device__ __forceinline__ void dw_block64(const DwArgs& a, const adam_consts& a
       for (int r = 0; r < 4; ++r) Gs[(32 * ti + 16 * i + 4 * g + r) * DWB_LD + 32 * tq + 16 * q + j] = t[r];
     }
   __syncthreads();
+  // (round 4) The four lanes' p / m / v are requested together, ahead of the first store: params / m / v are not `restrict` against each other, so in the one-loop form
+  // each trip's loads waited for the previous trip's stores - four HBM round trips in a row, 9.2 of a block workgroup's 19.3 us (profiles/r04_population_timeline.txt).
+  if (a.grads_only) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = sf + 16 * u;
+      *reinterpret_cast<f32x4*>(a.grads + poff + (int64_t)(n0 + rr) * H + k0 + sr) = *reinterpret_cast<const f32x4*>(Gs + rr * DWB_LD + sr);
+    }
+    return;
+  }
+  f32x4 pv[4], mv[4], vv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t o = poff + (int64_t)(n0 + sf + 16 * u) * H + k0 + sr;
+    pv[u] = gload4(a.params + o); mv[u] = gload4(a.opt.m + o); vv[u] = gload4(a.opt.v + o);
+  }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int rr = sf + 16 * u, n = n0 + rr, k = k0 + sr;
     const int64_t o = poff + (int64_t)n * H + k;
     const f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + rr * DWB_LD + sr);
-    if (a.grads_only) { *reinterpret_cast<f32x4*>(a.grads + o) = gv; continue; }
-    f32x4 pv = gload4(a.params + o), mv = gload4(a.opt.m + o), vv = gload4(a.opt.v + o);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { float pp = pv[c], mm = mv[c], v2 = vv[c]; adam_update(pp, gv[c], mm, v2, ac); pv[c] = pp; mv[c] = mm; vv[c] = v2; }
-    *reinterpret_cast<f32x4*>(a.params + o) = pv; *reinterpret_cast<f32x4*>(a.opt.m + o) = mv; *reinterpret_cast<f32x4*>(a.opt.v + o) = vv;
+    for (int c = 0; c < 4; ++c) { float pp = pv[u][c], mm = mv[u][c], v2 = vv[u][c]; adam_update(pp, gv[c], mm, v2, ac); pv[u][c] = pp; mv[u][c] = mm; vv[u][c] = v2; }
+    *reinterpret_cast<f32x4*>(a.params + o) = pv[u]; *reinterpret_cast<f32x4*>(a.opt.m + o) = mv[u]; *reinterpret_cast<f32x4*>(a.opt.v + o) = vv[u];
     if (pkf) {
-      *reinterpret_cast<f32x4*>(pkf + packed_fwd_index(n, k, H)) = pv;   // k .. k+3 of row n: one 16-byte lane of PF
-      *reinterpret_cast<f32x4*>(Gs + rr * DWB_LD + sr) = pv;
+      *reinterpret_cast<f32x4*>(pkf + packed_fwd_index(n, k, H)) = pv[u];   // k .. k+3 of row n: one 16-byte lane of PF
+      *reinterpret_cast<f32x4*>(Gs + rr * DWB_LD + sr) = pv[u];
     }
   }
-  if (!pkf || a.grads_only) return;
+  if (!pkf) return;
   __syncthreads();
   {  // PB: rows n .. n+3 of column k are one 16-byte lane; thread t takes column t % 64 and row quads (t / 64) + 4 u
     const int kc = tid & 63;
