@@ -400,6 +400,7 @@ def main():
   ap.add_argument('--no-population', action='store_true')
   ap.add_argument('--no-secondary', action='store_true', help='skip the SAC-only / discriminator-only / GMMIL / PWIL rates')
   ap.add_argument('--population-learners', type=int, default=64)
+  ap.add_argument('--population-wide', type=int, default=128, help='a second, wider population point (learners; sub-populations of 32); 0 = skip')
   ap.add_argument('--population-groups', type=int, default=2, help='sub-populations replayed as parallel graph branches (BatchedPopulationPlan(groups=))')
   ap.add_argument('--learners', type=int, default=1, help='population axis: N independent learners per GPU advanced by one graph replay (aggregate updates/s)')
   args = ap.parse_args()
@@ -614,6 +615,29 @@ def main():
       out['population'] = dict(learners=Lp, groups=args.population_groups, aggregate_updates_per_s=round(Lp / dt, 1), ms_per_replay=round(dt * 1e3, 5), roofline=proof,
                                note=f'{Lp} independent batch-256 SAC+GAIL learners (il_*_population launches: learner id = grid dimension, learner l on XCD l % 8; {args.population_groups} sub-populations as parallel graph branches), own replay ring / index stream / Philox counter each')
       del pop
+      torch.cuda.empty_cache()
+      if args.population_wide > Lp:
+        # the same axis one step wider (round 4): `population_wide` learners as population_wide / 32 sub-populations of 32 - the launches of more branches fill each other's
+        # dependent phases. Rate only (the per-kernel roofline above is the 64-learner one).
+        Lw, gw = args.population_wide, max(1, args.population_wide // 32)
+        popw = BatchedPopulationPlan([build(device, rank, seed=100 + l, learner_id=100 + l)[0] for l in range(Lw)], groups=gw)
+        for _ in range(3):
+          popw.run()
+        torch.cuda.synchronize()
+        popw.capture()
+        for _ in range(20):
+          popw.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(100):
+          popw.replay()
+        torch.cuda.synchronize()
+        dtw = (time.perf_counter() - t1) / 100
+        _, _, _, update_flops = algorithmic_model()
+        out['population']['wide'] = dict(learners=Lw, groups=gw, aggregate_updates_per_s=round(Lw / dtw, 1), ms_per_replay=round(dtw * 1e3, 5),
+                                         fp32_frac=round(Lw * update_flops / dtw / 1e12 / FP32_PEAK_TFLOPS, 5))
+        del popw
+        torch.cuda.empty_cache()
     if world == 1 and args.learners == 1 and not args.no_secondary:
       out['secondary'] = secondary(device, plan, nets)
     if world == 1 and not args.no_cpu_baseline:

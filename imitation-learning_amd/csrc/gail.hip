@@ -166,9 +166,12 @@ __device__ __forceinline__ void stage_weights(const DiscLds& L, const float* __r
 // this kernel in the same stream could never satisfy that wait, and one launched AHEAD of it would put this kernel's preparation back on the update's critical path.
 struct GailSampler { uint32_t* state; const int64_t* rs_a; int32_t* idx_a; const int64_t* rs_b; int32_t* idx_b; int n; };
 
-__global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp, il_gail_extra x, const il_disc* __restrict__ dL,
-                                                   const il_batch* __restrict__ polL, const il_batch* __restrict__ expL, GailSampler sa, int pu_value_pass) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// MULTI: several tiles per workgroup (k_gail_grad_pop); the one-tile instantiation is the single learner's kernel, whose registers and schedule the loop must not touch
+// (as a run-time trip count it cost the headline 2 %: profiles/r04_pop_ab.txt).
+template <bool MULTI>
+__device__ __forceinline__ void gail_grad_body(il_disc d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp, il_gail_extra x, const il_disc* __restrict__ dL,
+                                               const il_batch* __restrict__ polL, const il_batch* __restrict__ expL, GailSampler sa, int pu_value_pass, int tpw_, float* smem) {
+  const int tpw = MULTI ? tpw_ : 1;
   IL_TL(0, 0);
   const int has_sampler = sa.state != nullptr;
   if (has_sampler && (int)blockIdx.x == (int)gridDim.x - 1) {
@@ -179,16 +182,17 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   if (dL) { d = dL[blockIdx.z]; pol = polL[blockIdx.z]; exp = expL[blockIdx.z]; }  // population axis
   globalize(d); globalize(pol); globalize(exp); globalize(x);
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch, Dp = (D + 3) & ~3, ldw = Dp + 4;
-  const int tile = blockIdx.x, pass = blockIdx.y, npass = gridDim.y, nt = (int)gridDim.x - has_sampler, row0 = tile * IL_TILE_R, tid = threadIdx.x;
-  const int nrows = min(IL_TILE_R, B - row0);
+  // tpw (population launch): this workgroup runs `tpw` consecutive tiles of its call one after the other - the weights in LDS, the Gram matrix and the power iterations
+  // (12 of a one-tile workgroup's 21 us there) are paid once per workgroup instead of once per tile. Every tile still leaves its own slab: same bits.
+  const int pass = blockIdx.y, npass = gridDim.y, nt = (B + IL_TILE_R - 1) / IL_TILE_R, tid = threadIdx.x, tile0 = (int)blockIdx.x * tpw;
+  int tile = tile0, row0 = tile * IL_TILE_R, nrows = min(IL_TILE_R, B - row0);
   const int kind = d.loss_function == IL_LOSS_MIXUP ? (pass == 0 ? 3 : 2) : pass;   // 0 policy, 1 expert, 2 gradient-penalty mix, 3 mixup mix
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
   const DiscWs wsl = disc_ws(D, H, B);
   if (pu_value_pass && kind != 0 && kind != 1) return;   // the value pass only needs the logits of the policy and the expert call
   const float b2 = d.params[lay.ob2];
-  float* slab = d.workspace + wsl.slabs + ((size_t)pass * nt + tile) * lay.P;
   DiscLds L = carve(smem, D, H);
-  const bool stamp = tile == 0 && pass == 2;
+  bool stamp = tile == 0 && pass == 2;
   IL_STAMP(stamp, 0);
   stage_weights(L, d.params + lay.oW1, d.params + lay.ob1, d.params + lay.oW2, D, H);
   IL_STAMP(stamp, 1);
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     for (int i = tid; i < Dp; i += blockDim.x) L.v1(0)[i] = i < D ? d.v1[i] : 0.f;
     if (tid == 0) L.sc(0)[2] = d.u2[0];
   } else if (tid == 0) { L.sc(0)[0] = 1.f; L.sc(0)[1] = 1.f; L.sc(0)[2] = 0.f; }
-  if (tid == 0 && tile == 0 && pass == 0 && !pu_value_pass) adam_tick(d.opt);
+  if (tid == 0 && tile0 == 0 && pass == 0 && !pu_value_pass) adam_tick(d.opt);
   __syncthreads();
   IL_STAMP(stamp, 2);
   if (!d.sync) IL_TL(0, 1);   // (slots 1 / 2 on the hand-off path: before / after the wait for the index draw)
@@ -308,6 +312,9 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
     }
   }
   __syncthreads();
+  for (int ti = 0;; ++ti) {   // the tiles of this workgroup (one, except on the population launch)
+  float* slab = d.workspace + wsl.slabs + ((size_t)pass * nt + tile) * lay.P;
+  stamp = tile == 0 && pass == 2;
   IL_STAMP(stamp, 6);
   IL_TL(0, 4);
 
@@ -433,13 +440,29 @@ __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_b
   }
   IL_STAMP(stamp, 8);
   IL_TL(0, 6);
-  if (tile == 0 && pass == npass - 1 && d.spectral_norm) {  // final u, v of this update: the last call's iteration
+  if (!MULTI || ti + 1 >= tpw || tile + 1 >= nt) break;
+  ++tile; row0 += IL_TILE_R; nrows = min(IL_TILE_R, B - row0);
+  __syncthreads();   // every reader of the previous tile's rows, activations and loss terms is done
+  stage_rows(0);
+  __syncthreads();
+  }
+  if (tile0 == 0 && pass == npass - 1 && d.spectral_norm) {  // final u, v of this update: the last call's iteration
     float* o = d.workspace + wsl.sn_new;
-    for (int i = tid; i < H; i += blockDim.x) { o[i] = u1[i]; o[H + D + 1 + i] = v2[i]; }
-    for (int i = tid; i < D; i += blockDim.x) o[H + i] = v1[i];
-    if (tid == 0) o[H + D] = u2;
+    for (int i = tid; i < H; i += blockDim.x) { o[i] = L.u1(0)[i]; o[H + D + 1 + i] = L.v2(0)[i]; }
+    for (int i = tid; i < D; i += blockDim.x) o[H + i] = L.v1(0)[i];
+    if (tid == 0) o[H + D] = L.sc(0)[2];
   }
   IL_TL_END(0);
+}
+
+__global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp, il_gail_extra x, const il_disc* __restrict__ dL,
+                                                   const il_batch* __restrict__ polL, const il_batch* __restrict__ expL, GailSampler sa, int pu_value_pass) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  gail_grad_body<false>(d, pol, exp, eps_gp, x, dL, polL, expL, sa, pu_value_pass, 1, smem);
+}
+__global__ __launch_bounds__(256) void k_gail_grad_pop(il_disc d, const il_disc* __restrict__ dL, const il_batch* __restrict__ polL, const il_batch* __restrict__ expL, int tpw) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  gail_grad_body<true>(d, il_batch{}, il_batch{}, nullptr, il_gail_extra{}, dL, polL, expL, GailSampler{}, 0, tpw, smem);
 }
 
 __host__ __device__ inline int gail_calls(const il_disc& d) { return (d.loss_function == IL_LOSS_MIXUP ? 1 : 2) + (d.grad_penalty > 0.f ? 1 : 0); }
@@ -653,11 +676,14 @@ extern "C" int il_gail_step_population(const il_disc* descs_dev, const il_batch*
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim), nt = ceil_div(d->batch, IL_TILE_R), L = n_learners;
   static const int compact = [] { const char* e = getenv("IL_POP_DISC_LDS"); return e && e[0] == '0' ? 0 : 1; }();   // IL_POP_DISC_LDS=0: one workgroup per CU, as in round 3 (A/B)
   const size_t lds = compact ? disc_lds_floats(D, d->hidden) * sizeof(float) : (size_t)96 * 1024, lds_r = compact ? disc_reward_lds_floats(D, d->hidden) * sizeof(float) : lds;
-  if (int rc = ensure_lds((const void*)k_gail_grad, lds)) return rc;
+  if (int rc = ensure_lds((const void*)k_gail_grad_pop, lds)) return rc;
   if (int rc = ensure_lds((const void*)k_gail_reward, lds_r)) return rc;
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
   il_batch zb = {};
-  { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt, gail_calls(*d), L), 256, lds, st>>>(*d, zb, zb, nullptr, il_gail_extra{}, descs_dev, policy_dev, expert_dev, GailSampler{}, 0); }
+  // tiles per workgroup of the gradient launch (k_gail_grad `tpw`): IL_POP_DISC_TPW, default 4
+  static const int tpw_env = [] { const char* e = getenv("IL_POP_DISC_TPW"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
+  const int tpw = tpw_env < nt ? tpw_env : nt;
+  { IL_TRACE("k_gail_grad", st); k_gail_grad_pop<<<dim3(ceil_div(nt, tpw), gail_calls(*d), L), 256, lds, st>>>(*d, descs_dev, policy_dev, expert_dev, tpw); }
   { IL_TRACE("k_gail_reduce", st); k_gail_reduce<<<dim3((int)((P + 255) / 256), L), 256, 0, st>>>(*d, 1, descs_dev, 0, il_peer_bucket{}); }
   { IL_TRACE("k_gail_reward", st); k_gail_reward<<<dim3(nt, L), 256, lds_r, st>>>(*d, zb, nullptr, nullptr, nullptr, descs_dev, policy_dev, rewards_out_dev); }
   IL_CHECK_LAUNCH("il_gail_step_population");

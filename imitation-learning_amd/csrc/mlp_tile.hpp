@@ -45,6 +45,32 @@ template <int MODE, int PANEL, class Epi>
 __device__ __forceinline__ void tile_fwd_impl(const float* Xs, int ldx, int Kpad, const float* __restrict__ W, int ldw, int Kw, int N, Epi epi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
+#if IL_L1_PAIR
+  if (Kpad == 32 && N == 32 * nw) {   // (round 4) a narrow first layer with TWO column tiles per wave (the 8-wave population kernels): the weight lanes of both tiles are
+    f32x4 b[2][2];                    // requested before the first MFMA - the tile loop below made the second tile's round trip wait for the first tile's epilogue
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) b[t][u] = load4<MODE>(W + (size_t)((wave + t * nw) * 16 + j) * ldw, 16 * u + 4 * g, Kw);
+    __builtin_amdgcn_sched_barrier(0);
+    const float* xr = Xs + j * ldx + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * u);
+        acc0 = mfma16(a[0], b[t][u][0], acc0);
+        acc1 = mfma16(a[1], b[t][u][1], acc1);
+        acc0 = mfma16(a[2], b[t][u][2], acc0);
+        acc1 = mfma16(a[3], b[t][u][3], acc1);
+      }
+      f32x4 acc = acc0 + acc1;
+      epi((wave + t * nw) * 16, acc);
+    }
+    return;
+  }
+#endif
   for (int c0 = wave * 16; c0 < N; c0 += nw * 16) {
     f32x4 acc0 = zero4(), acc1 = zero4();  // two accumulators: the 16x16x4 f32 MFMA has a 40-cycle dependent latency vs 32-cycle issue
     const float* wr = W + (size_t)(c0 + j) * ldw + 4 * g;
