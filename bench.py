@@ -15,7 +15,7 @@ Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed 
 at N=1, `cpu_baseline` = the reference's OWN code timed live on this host's cores (oracle/_ref: its three hot-path modules byte-compiled from /root/reference by
 __graft_entry__.build(), run by oracle/ref_cpu_baseline.py in a subprocess at 1 / 8 / all threads, with and without memory.sample; only when oracle/_ref is absent the
 committed build-container measurement profiles/cpu_reference.json stands in, and `where` says so) next to `cpu_port` = the numpy oracle port timed live;
-`population` = the aggregate rate of 64 independent learners advanced by the same launches; `secondary` = the other single-GPU configurations of BASELINE.json.
+`population` = the aggregate rate of 128 independent learners (two sub-populations of 64) advanced by the same launches; `secondary` = the other single-GPU configurations of BASELINE.json.
 """
 import argparse
 import ctypes as C
@@ -399,8 +399,8 @@ def main():
   ap.add_argument('--no-overlap', action='store_true', help='one stream, no device-side hand-off: the same kernels back to back (what a counter-collecting profiler needs; il_sac_update still takes its chained launch)')
   ap.add_argument('--no-population', action='store_true')
   ap.add_argument('--no-secondary', action='store_true', help='skip the SAC-only / discriminator-only / GMMIL / PWIL rates')
-  ap.add_argument('--population-learners', type=int, default=64)
-  ap.add_argument('--population-wide', type=int, default=128, help='a second, wider population point (learners; sub-populations of 32); 0 = skip')
+  ap.add_argument('--population-learners', type=int, default=128, help='learners of the population line (round 4: 128 as two sub-populations of 64; 64 learners: --population-learners 64)')
+  ap.add_argument('--population-wide', type=int, default=0, help='a second, wider population point (learners; sub-populations of 32); 0 = skip')
   ap.add_argument('--population-groups', type=int, default=2, help='sub-populations replayed as parallel graph branches (BatchedPopulationPlan(groups=))')
   ap.add_argument('--learners', type=int, default=1, help='population axis: N independent learners per GPU advanced by one graph replay (aggregate updates/s)')
   args = ap.parse_args()
