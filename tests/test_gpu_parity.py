@@ -1130,6 +1130,35 @@ def test_schedule_switches_are_bit_identical(monkeypatch, switch, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('switch,values', [('IL_POP_SPLIT_TAIL', ('1', '0')), ('IL_POP_DISC_TPW', ('4', '1')), ('IL_POP_DISC_TPW', ('3', '16'))])
+def test_population_switches_are_bit_identical(switch, values):
+  """The round-4 forms of the population launches - the policy backward as a launch of its own (k_actor_bwd_pop) instead of the tail of each tile's second critic
+  workgroup, several tiles per workgroup of k_gail_grad_pop (3: a ragged last workgroup; 16: a whole call in one workgroup) - only move work between workgroups:
+  three learners after two population updates must not differ in a bit from the other setting (and, by test_batched_population_equals_independent_learners, from
+  independent learners). The switches are read once per process: compared through subprocesses."""
+  import subprocess, sys, json
+  code = (
+      "import sys, json, hashlib, numpy as np, torch; sys.path[:0] = ['.', 'tests', 'tests/golden']\n"
+      "import imitation_learning_amd as il\n"
+      "from test_gpu_parity import _population_learners, _population_state\n"
+      "plans, nets_all = _population_learners(3)\n"
+      "pop = il.BatchedPopulationPlan(plans)\n"
+      "for _ in range(2): pop.run()\n"
+      "torch.cuda.synchronize()\n"
+      "h = hashlib.sha256()\n"
+      "for learner in _population_state(plans, nets_all):\n"
+      "  for a in learner: h.update(np.ascontiguousarray(a).tobytes())\n"
+      "print(json.dumps(dict(digest=h.hexdigest())))\n")
+  outs = []
+  for value in values:
+    env = dict(os.environ, **{switch: value})
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+  assert outs[0]['digest'] == outs[1]['digest']
+
+
+@pytest.mark.gpu
 def test_expert_data_ingest_on_device(tmp_path):
   """SURVEY.md 8 f3 on the GPU (reference environments.py:63-125 ends in a ReplayMemory): `dataset_to_memory(..., device='cuda')` for the 8 (absorbing, subsample,
   trajectories) cases of tests/golden/dataset.npz - every field of the DEVICE-resident ring bit-equal to what D4RLEnv.get_dataset built from the same raw arrays, the
