@@ -43,7 +43,23 @@ def unpack(flat, shapes):
   return out
 
 
-def mlp_forward(layers, x, masks=None):
+def _act(z, activation):
+  """models.py:16 ACTIVATION_FUNCTIONS: relu / tanh / sigmoid (torch op by op in float32)."""
+  if activation == 'relu': return np.maximum(z, f32(0))
+  if activation == 'tanh': return np.tanh(z).astype(f32)
+  if activation == 'sigmoid': return (f32(1) / (f32(1) + np.exp(-z))).astype(f32)
+  raise ValueError(activation)
+
+
+def _act_grad(h, activation):
+  """d act / d z from the POST-activation value h."""
+  if activation == 'relu': return (h > 0)
+  if activation == 'tanh': return (f32(1) - h * h).astype(f32)
+  if activation == 'sigmoid': return (h * (f32(1) - h)).astype(f32)
+  raise ValueError(activation)
+
+
+def mlp_forward(layers, x, masks=None, activation='relu'):
   """Returns (out, acts) with acts[i] = input of layer i (post-ReLU hidden).
 
   masks (tests only): one boolean [B, H] array per hidden layer = "this pre-activation was > 0" as ANOTHER correct fp32 evaluation of the same network decided it (the
@@ -55,12 +71,12 @@ def mlp_forward(layers, x, masks=None):
     acts.append(h)
     z = h @ W.T + b
     if i == len(layers) - 1: h = z
-    elif masks is None: h = np.maximum(z, f32(0))
-    else: h = np.where(masks[i], z, f32(0)).astype(f32)
+    elif masks is None: h = _act(z, activation)
+    else: h = np.where(masks[i], z, f32(0)).astype(f32)   # (masks: ReLU networks only)
   return h, acts
 
 
-def mlp_backward(layers, acts, dout, need_dx=True, masks=None):
+def mlp_backward(layers, acts, dout, need_dx=True, masks=None, activation='relu'):
   """Gradient of sum(out * dout). Returns (flat grad in parameter order, dx). masks: see mlp_forward (masks[i - 1] gates the input of layer i)."""
   grads, dz = [None] * len(layers), dout.astype(f32)
   for i in range(len(layers) - 1, -1, -1):
@@ -69,7 +85,7 @@ def mlp_backward(layers, acts, dout, need_dx=True, masks=None):
     if i > 0 or need_dx:
       dh = dz @ W
       if i > 0:
-        dz = dh * ((acts[i] > 0) if masks is None else masks[i - 1])  # ReLU mask: post-ReLU input of layer i is > 0 iff pre-activation > 0
+        dz = (dh * (_act_grad(acts[i], activation) if masks is None else masks[i - 1])).astype(f32)  # ReLU: the post-ReLU input of layer i is > 0 iff its pre-activation was
   flat = np.concatenate([np.concatenate([g[0].ravel(), g[1].ravel()]) for g in grads]).astype(f32)
   return flat, (dh if need_dx else None)
 

@@ -15,8 +15,8 @@ from .nets import f32
 class SacState:
   """Flat parameter / optimiser arenas for one learner (reference objects at train.py:64-67)."""
 
-  def __init__(self, state_size, action_size, hidden=256, depth=2):
-    self.S, self.A, self.H, self.depth = state_size, action_size, hidden, depth
+  def __init__(self, state_size, action_size, hidden=256, depth=2, activation='relu'):
+    self.S, self.A, self.H, self.depth, self.activation = state_size, action_size, hidden, depth, activation
     self.actor_shapes = nets.mlp_shapes(state_size, hidden, depth, 2 * action_size)
     self.critic_shapes = nets.mlp_shapes(state_size + action_size, hidden, depth, 1)
     self.Pa = nets.mlp_numel(state_size, hidden, depth, 2 * action_size)
@@ -39,7 +39,7 @@ def critic_forward(st, flat, s, a, masks=None):
   x = np.concatenate([s, a], axis=1).astype(f32)
   outs = []
   for k in range(2):
-    q, acts = nets.mlp_forward(st.critic_layers(flat, k), x, None if masks is None else masks[k])
+    q, acts = nets.mlp_forward(st.critic_layers(flat, k), x, None if masks is None else masks[k], activation=st.activation)
     outs.append((q[:, 0], acts))
   return outs
 
@@ -55,7 +55,7 @@ def sac_update(st: SacState, batch, eps_next, eps_cur, *, discount, entropy_targ
   m = (f32(1) - absb).astype(f32)
 
   # --- target values (training.py:19-25, no grad)
-  out, _ = nets.mlp_forward(st.actor_layers(), s2)
+  out, _ = nets.mlp_forward(st.actor_layers(), s2, activation=st.activation)
   mean2, _, _, std2 = nets.actor_head(out, A)
   x2 = eps_next * std2 + mean2                      # torch.normal: z*std + mean
   a2 = np.tanh(x2)
@@ -71,7 +71,7 @@ def sac_update(st: SacState, batch, eps_next, eps_cur, *, discount, entropy_targ
   g_c = []
   for k, (q, acts) in enumerate(((q1, acts1), (q2, acts2))):
     dq = (w * (f32(2) * (q - y))) / f32(B)
-    g, _ = nets.mlp_backward(st.critic_layers(st.critic, k), acts, dq[:, None], need_dx=False, masks=mk['critic'][k] if masks else None)
+    g, _ = nets.mlp_backward(st.critic_layers(st.critic, k), acts, dq[:, None], need_dx=False, masks=mk['critic'][k] if masks else None, activation=st.activation)
     g_c.append(g)
   g_c = np.concatenate(g_c)
   st.t_critic += 1
@@ -79,7 +79,7 @@ def sac_update(st: SacState, batch, eps_next, eps_cur, *, discount, entropy_targ
 
   # --- policy loss + step (training.py:34-42), critic already updated
   a_layers = st.actor_layers()
-  out, acts_a = nets.mlp_forward(a_layers, s, mk.get('actor'))
+  out, acts_a = nets.mlp_forward(a_layers, s, mk.get('actor'), activation=st.activation)
   mean, ls_raw, _, std = nets.actor_head(out, A)
   x = mean + eps_cur * std                          # rsample: loc + eps*scale
   an = np.tanh(x)
@@ -88,14 +88,14 @@ def sac_update(st: SacState, batch, eps_next, eps_cur, *, discount, entropy_targ
   sel1 = np.where(qn1 < qn2, f32(1), np.where(qn1 == qn2, f32(0.5), f32(0)))
   da = np.zeros((B, A), f32)
   for k, (acts, sel) in enumerate(((actsn1, sel1), (actsn2, f32(1) - sel1))):
-    _, dx = nets.mlp_backward(st.critic_layers(st.critic, k), acts, (-(sel) / f32(B))[:, None], need_dx=True, masks=mk['pcritic'][k] if masks else None)
+    _, dx = nets.mlp_backward(st.critic_layers(st.critic, k), acts, (-(sel) / f32(B))[:, None], need_dx=True, masks=mk['pcritic'][k] if masks else None, activation=st.activation)
     da += dx[:, st.S:]
   c = (w * m * alpha) / f32(B)                       # dL/dlogp
   dx_pre = c[:, None] * (f32(2) * np.tanh(x)) + da * (f32(1) - an * an)
   dmean = dx_pre
   dstd = dx_pre * eps_cur - c[:, None] / std
   dls = dstd * std * ((ls_raw >= nets.LOG_STD_MIN) & (ls_raw <= nets.LOG_STD_MAX))
-  g_a, _ = nets.mlp_backward(a_layers, acts_a, np.concatenate([dmean, dls], axis=1), need_dx=False, masks=mk.get('actor'))
+  g_a, _ = nets.mlp_backward(a_layers, acts_a, np.concatenate([dmean, dls], axis=1), need_dx=False, masks=mk.get('actor'), activation=st.activation)
   st.t_actor += 1
   nets.adam_step(st.actor, g_a, st.actor_m, st.actor_v, st.t_actor, lr, weight_decay)
 
@@ -113,13 +113,13 @@ def sac_update(st: SacState, batch, eps_next, eps_cur, *, discount, entropy_targ
   return logp, out_q
 
 
-def bc_update(actor_flat, m_, v_, t, shapes, action_size, batch, *, lr, weight_decay=0.0, return_grads=False):
+def bc_update(actor_flat, m_, v_, t, shapes, action_size, batch, *, lr, weight_decay=0.0, return_grads=False, activation='relu'):
   """behavioural_cloning_update (training.py:57-64) + SoftActor.log_prob (models.py:97-99)."""
   s, a, w = batch['states'], batch['actions'], batch['weights']
   B, A = s.shape[0], action_size
   a = np.clip(a, f32(-1 + 1e-6), f32(1 - 1e-6))
   layers = nets.unpack(actor_flat, shapes)
-  out, acts = nets.mlp_forward(layers, s)
+  out, acts = nets.mlp_forward(layers, s, activation=activation)
   mean, ls_raw, _, std = nets.actor_head(out, A)
   x = np.arctanh(a).astype(f32)
   logp = nets.tanh_gaussian_logp(x, mean, std)
@@ -128,7 +128,7 @@ def bc_update(actor_flat, m_, v_, t, shapes, action_size, batch, *, lr, weight_d
   dmean = up * d / (std * std)
   dstd = up * (d * d / (std * std * std) - f32(1) / std)
   dls = dstd * std * ((ls_raw >= nets.LOG_STD_MIN) & (ls_raw <= nets.LOG_STD_MAX))
-  g, _ = nets.mlp_backward(layers, acts, np.concatenate([dmean, dls], axis=1), need_dx=False)
+  g, _ = nets.mlp_backward(layers, acts, np.concatenate([dmean, dls], axis=1), need_dx=False, activation=activation)
   nets.adam_step(actor_flat, g, m_, v_, t, lr, weight_decay)
   loss = np.mean(w * -logp, dtype=f32)
   return (loss, g, logp) if return_grads else loss

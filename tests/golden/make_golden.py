@@ -122,7 +122,7 @@ def gen_replay():
 
 # ---------------------------------------------------------------- SAC
 def build_sac(c):
-  cfg = DictConfig(hidden_size=c['H'], depth=2, activation='relu')
+  cfg = DictConfig(hidden_size=c['H'], depth=c.get('depth', 2), activation=c.get('activation', 'relu'))
   actor, critic = ref_models.SoftActor(c['S'], c['A'], cfg), ref_models.TwinCritic(c['S'], c['A'], cfg)
   torch.nn.utils.vector_to_parameters(T(c['actor']), actor.parameters())
   torch.nn.utils.vector_to_parameters(T(c['critic']), critic.parameters())
@@ -165,6 +165,32 @@ def gen_sac(name, c):
     out[f'g_actor_{k}'] = gi.strided(grads['actor'][i]); out[f'g_critic_{k}'] = gi.strided(grads['critic'][i]); out[f'g_alpha_{k}'] = grads['alpha'][i]
     out[f'g_actor_norm_{k}'] = np.array([np.linalg.norm(grads['actor'][i].astype(np.float64))])
     out[f'g_critic_norm_{k}'] = np.array([np.linalg.norm(grads['critic'][i].astype(np.float64))])
+  np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
+
+
+def gen_sac_general(name, kw):
+  """General actor / critic shapes (models.py:48-69: any depth, relu / tanh / sigmoid): the same quantities as gen_sac plus, on the INITIAL actor, what acting and
+  behavioural cloning need - greedy action, a sample and its log-probability with fed noise, log pi of given actions - and two behavioural_cloning_update steps on a copy."""
+  gen_sac(name, gi.sac_case(**kw))
+  out = dict(np.load(os.path.join(HERE, f'{name}.npz')))
+  c = gi.sac_case(**kw)   # (a fresh case: the reference's optimisers stepped the first one's parameter arrays in place)
+  actor, _, _, _ = build_sac(c)
+  b = c['batches'][0]
+  st, ac = T(b['states']), T(b['actions'])
+  with torch.no_grad():
+    out['act_greedy'] = N_(actor.get_greedy_action(st))
+    with NoiseFeed() as nf:
+      nf.normal.append(T(c['eps_cur'][0]))
+      pol = actor(st)
+      a = pol.sample()
+      out['act_sample'], out['act_sample_logp'] = N_(a), N_(pol.log_prob(a))
+    out['act_logp_given'] = N_(actor.log_prob(st, ac))
+  opt = torch.optim.AdamW(actor.parameters(), lr=2.5e-4, weight_decay=0.01)
+  for k in (1, 2):
+    bb = c['batches'][k % len(c['batches'])]
+    ref_training.behavioural_cloning_update(actor, tbatch(bb), opt)
+    out[f'bc_actor_{k}'] = gi.strided(flat(actor)); out[f'bc_g_actor_{k}'] = gi.strided(np.concatenate([N_(p.grad).ravel() for p in actor.parameters()]))
+    out[f'bc_actor_norm_{k}'] = np.array([np.linalg.norm(flat(actor).astype(np.float64))])
   np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
 
 
@@ -823,6 +849,8 @@ if __name__ == '__main__':
     gen_sac('sac_halfcheetah', gi.sac_case(3, 'halfcheetah', 256, 256, 3))
     gen_sac('sac_hopper_h64', gi.sac_case(4, 'hopper', 64, 96, 3))
     gen_sac('sac_ant_b64', gi.sac_case(5, 'ant', 256, 64, 2))
+  if want('sac_general'):
+    for name, kw in gi.GENERAL_SAC_CASES.items(): gen_sac_general(name, kw)
   if want('bc'): gen_bc('bc_hopper', 'hopper', 256, 256, 3)
   if want('gail'):
     gen_gail('gail_default', gi.gail_case(31), lr=3e-5, weight_decay=10, grad_penalty=1.0, entropy_bonus=0.0)

@@ -53,7 +53,7 @@ def test_replay_bit_exact(golden_dir, name, seed, size, fill):
 
 # ------------------------------------------------------------------ SAC
 def run_sac_oracle(c, steps):
-  st = sac.SacState(c['S'], c['A'], c['H'])
+  st = sac.SacState(c['S'], c['A'], c['H'], c.get('depth', 2), c.get('activation', 'relu'))
   st.actor[:], st.critic[:], st.target[:], st.log_alpha[:] = c['actor'], c['critic'], c['target'], c['log_alpha']
   outs = []
   for i in range(steps):
@@ -82,6 +82,58 @@ def test_sac_update_matches_reference(golden_dir, name, args):
       close(gi.strided(snap[nm + '_v']), g[f'{nm}_v_{k}'], f'{nm}_v_{k}', atol_scale=1e-5 * k)
     close(gi.strided(snap['target']), g[f'target_{k}'], f'target_{k}', atol_scale=1e-5 * k)
     close(snap['log_alpha'], g[f'log_alpha_{k}'], f'log_alpha_{k}')
+
+
+def check_sac_against_golden(g, outs):
+  for k, (logp, q, gr, snap) in enumerate(outs, start=1):
+    close(logp, g[f'logp_{k}'], f'logp_{k}', atol_scale=2e-6 * k)
+    close(q, g[f'q_{k}'], f'q_{k}', atol_scale=2e-6 * k)
+    if k == 1:
+      close(gi.strided(gr['critic']), g['g_critic_1'], 'g_critic_1')
+      close(gi.strided(gr['actor']), g['g_actor_1'], 'g_actor_1')
+      close(gr['alpha'], g['g_alpha_1'], 'g_alpha_1')
+    for nm in ('actor', 'critic'):
+      close(gi.strided(snap[nm]), g[f'{nm}_{k}'], f'{nm}_{k}', atol_scale=1e-5 * k)
+      close(gi.strided(snap[nm + '_m']), g[f'{nm}_m_{k}'], f'{nm}_m_{k}', atol_scale=1e-5 * k)
+      close(gi.strided(snap[nm + '_v']), g[f'{nm}_v_{k}'], f'{nm}_v_{k}', atol_scale=1e-5 * k)
+    close(gi.strided(snap['target']), g[f'target_{k}'], f'target_{k}', atol_scale=1e-5 * k)
+    close(snap['log_alpha'], g[f'log_alpha_{k}'], f'log_alpha_{k}')
+
+
+def general_actor_oracle(c):
+  """Acting and behavioural cloning of a general-shape actor through the oracle: what make_golden.gen_sac_general recorded from the reference (models.py:90-105, training.py:57-64)."""
+  A, act = c['A'], c['activation']
+  shapes = nets.mlp_shapes(c['S'], c['H'], c['depth'], 2 * A)
+  p = c['actor'].copy()
+  b = c['batches'][0]
+  out, _ = nets.mlp_forward(nets.unpack(p, shapes), b['states'], activation=act)
+  mean, _, _, std = nets.actor_head(out, A)
+  x = c['eps_cur'][0] * std + mean                        # torch.normal: z * std + mean (Normal.sample)
+  res = dict(act_greedy=np.tanh(mean), act_sample=np.tanh(x), act_sample_logp=nets.tanh_gaussian_logp(x, mean, std))   # (TanhTransform(cache_size=1): log_prob of the sample uses the cached pre-image x)
+  xg = np.arctanh(np.clip(b['actions'], np.float32(-1 + 1e-6), np.float32(1 - 1e-6))).astype(np.float32)
+  res['act_logp_given'] = nets.tanh_gaussian_logp(xg, mean, std)
+  m, v = np.zeros_like(p), np.zeros_like(p)
+  for k in (1, 2):
+    bb = c['batches'][k % len(c['batches'])]
+    _, gr, _ = sac.bc_update(p, m, v, k, shapes, A, bb, lr=2.5e-4, weight_decay=0.01, return_grads=True, activation=act)
+    res[f'bc_actor_{k}'], res[f'bc_g_actor_{k}'] = p.copy(), gr.copy()
+  return res
+
+
+@pytest.mark.parametrize('name', sorted(gi.GENERAL_SAC_CASES))
+def test_general_shape_sac_matches_reference(golden_dir, name):
+  """models.py:48-69 `_create_fcnn` builds any depth with relu / tanh / sigmoid: the oracle's general form (nets.mlp_forward(activation=)) against the reference run on
+  depth 3 / tanh, depth 1 / sigmoid and a 320-wide depth-2 ReLU network - sac_update for three steps, acting, log-probabilities and behavioural cloning."""
+  c = gi.sac_case(**gi.GENERAL_SAC_CASES[name])
+  g = load(golden_dir, name)
+  check_sac_against_golden(g, run_sac_oracle(c, len(c['batches'])))
+  res = general_actor_oracle(c)
+  close(res['act_greedy'], g['act_greedy'], 'act_greedy', atol_scale=2e-6)
+  close(res['act_sample'], g['act_sample'], 'act_sample', atol_scale=2e-6)
+  close(res['act_sample_logp'], g['act_sample_logp'], 'act_sample_logp', rtol=1e-4, atol_scale=1e-5)
+  close(res['act_logp_given'], g['act_logp_given'], 'act_logp_given', rtol=1e-4, atol_scale=1e-5)
+  close(gi.strided(res['bc_g_actor_1']), g['bc_g_actor_1'], 'bc_g_actor_1')
+  for k in (1, 2): close(gi.strided(res[f'bc_actor_{k}']), g[f'bc_actor_{k}'], f'bc_actor_{k}', atol_scale=1e-5 * k)
 
 
 def test_bc_update_matches_reference(golden_dir):
