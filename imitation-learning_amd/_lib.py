@@ -186,6 +186,13 @@ _SIGNATURES = {
     'il_gail_shaped_deep_step': (C.c_int, [C.POINTER(DiscShapedDeep), C.POINTER(Batch), C.POINTER(Batch), _P, C.POINTER(GailExtra), C.c_uint32, _P]),
     'il_gail_shaped_deep_reward': (C.c_int, [C.POINTER(DiscShapedDeep), C.POINTER(Batch), _P, _P, _P, _P]),
     'il_actor_log_prob': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
+    # general shapes (csrc/general.hip)
+    'il_mlp_numel_general': (C.c_int64, [C.c_int32] * 4), 'il_mlp_stride_general': (C.c_int64, [C.c_int32] * 4),
+    'il_sac_workspace_floats_general': (C.c_int64, [C.c_int32] * 7), 'il_actor_workspace_floats_general': (C.c_int64, [C.c_int32] * 5),
+    'il_sac_update_general': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_uint32, _P]),
+    'il_actor_act_general': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_uint64, C.c_uint32, C.c_int32, _P, _P, _P, C.c_int64, _P]),
+    'il_actor_log_prob_general': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
+    'il_bc_step_general': (C.c_int, [_P, _P, C.POINTER(Adam), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Batch), _P, C.c_int64, _P, C.c_uint32, _P]),
     'il_gail_disc_step_draw': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), C.POINTER(Batch), _P, _P, _P, _P, _P, C.c_uint32, _P]),
     'il_gail_disc_step_draw_peer': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), C.POINTER(Batch), _P, _P, _P, _P, _P, C.c_uint32, C.POINTER(PeerBucket), _P]),
     'il_gail_apply_grads': (C.c_int, [C.POINTER(Disc), _P]),

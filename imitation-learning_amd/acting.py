@@ -83,6 +83,9 @@ class ActingWorker:
   def __init__(self, actor, memory, mirror: bool = False):
     assert _lib.on_device(actor.flat) and _lib.on_device(memory.ring), 'ActingWorker needs the actor and the ring on the GPU (there is no CPU path)'
     assert actor.state_size == memory.state_size and actor.action_size == memory.action_size
+    if getattr(actor, 'general', False):
+      raise NotImplementedError('ActingWorker: the one-launch acting step is built for the fused actor shape (depth 2, ReLU, hidden <= 256, action_size <= 8); a general-shape actor acts through '
+                                'actor(state).sample() (csrc/general.hip)')
     self.actor, self.memory = actor, memory
     self.S, self.A = memory.state_size, memory.action_size
     self._act_box, self._append_box = _Mailbox(self.S, self.A), _Mailbox(self.S, self.A)

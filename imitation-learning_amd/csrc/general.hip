@@ -1,0 +1,535 @@
+// General actor / critic shapes (reference models.py:48-69 `_create_fcnn`: any depth, relu / tanh / sigmoid) for gfx950: sac_update (training.py:14-54), acting and
+// log-probabilities (models.py:90-102) and behavioural cloning (training.py:57-64) for the networks the fused kernels of sac.hip do not cover (they are built for the
+// shape every shipped configuration uses: depth 2, ReLU, hidden <= 256, 2A <= 16).
+//
+// Layer-at-a-time composition instead of one fused launch per phase: activations live in HBM FEATURE-MAJOR ([feature][Bp], Bp = batch rounded up to 16, padding rows zero),
+// so that a 16-row tile of a layer's input is 64 contiguous bytes per feature, a lane's four rows of an output column are one 16-byte store, and the weight gradient
+// dW = dZ^T X reads both operands as 16-byte lanes along the batch. Every product is an exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) tile:
+//   k_g_linear   Y^T = act(W X + b)        one workgroup = 16 rows x 64 output features, the input tile staged in LDS, one wave per 16 x 16 tile
+//   k_g_bwd      dZ_prev^T = (W^T dZ) * act'(H_prev)   same shape, dZ tile staged in LDS
+//   k_g_dw       G_W = dZ^T X              one wave per 16 x 16 tile of the gradient, reduction over the batch;  k_g_dbias: one wave per feature
+// and the per-row pieces (tanh-Gaussian head, TD target, loss seeds, head backward, temperature step) are one thread per row. The optimiser steps and the target update
+// are the library's elementwise kernels (il_adam_step, il_polyak). Same parameter layout as torch (`parameters()` order, twin critics at il_mlp_stride_general).
+// Padding rows carry zeros in every dZ, so they contribute nothing to any gradient.
+#include "il_common.hpp"
+#include "mlp_tile.hpp"
+
+enum { G_ACT_NONE = -1, G_ACT_RELU = 0, G_ACT_TANH = 1, G_ACT_SIGMOID = 2 };
+
+__device__ __forceinline__ float g_act(float z, int a) {
+  if (a == G_ACT_RELU) return fmaxf(z, 0.f);
+  if (a == G_ACT_TANH) return tanhf(z);
+  if (a == G_ACT_SIGMOID) return 1.f / (1.f + expf(-z));
+  return z;
+}
+__device__ __forceinline__ float g_act_grad(float h, int a) {   // d act / d z from the POST-activation value
+  if (a == G_ACT_RELU) return h > 0.f ? 1.f : 0.f;
+  if (a == G_ACT_TANH) return 1.f - h * h;
+  if (a == G_ACT_SIGMOID) return h * (1.f - h);
+  return 1.f;
+}
+
+struct GLayer { int64_t oW, ob; int K, N; };
+__host__ __device__ static inline GLayer g_layer(int in, int H, int depth, int out, int l) {   // layer l of [0, depth]: W [N][K] at oW, b [N] at ob (torch parameters() order)
+  GLayer r; int64_t o = 0; int K = in;
+  for (int i = 0; i < l; ++i) { o += (int64_t)H * K + H; K = H; }
+  r.K = K; r.N = (l == depth) ? out : H; r.oW = o; r.ob = o + (int64_t)r.N * K;
+  return r;
+}
+__host__ __device__ static inline int64_t g_numel(int in, int H, int depth, int out) { const GLayer l = g_layer(in, H, depth, out, depth); return l.ob + out; }
+__host__ __device__ static inline int64_t g_stride(int in, int H, int depth, int out) { return (g_numel(in, H, depth, out) + 3) & ~(int64_t)3; }
+static inline int g_bp(int n) { return (n + 15) & ~15; }
+
+// ---- 16 x 16 MFMA tiles (lane (j, g) = (lane & 15, lane >> 4) holds C(4g + reg, j)) ------------------------------------------------------------------------------
+// Xs [16][ldx] (LDS, zero beyond K) . W[n0 .. n0 + 15][0 .. K)^T ; rows n >= N clamp their address (the caller drops those columns)
+__device__ __forceinline__ f32x4 g_tile_fwd(const float* Xs, int ldx, int Kpad, const float* __restrict__ W, int K, int n0, int N) {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const float* wr = W + (size_t)min(n0 + j, N - 1) * K;
+  const float* xr = Xs + j * ldx + 4 * g;
+  f32x4 acc0 = zero4(), acc1 = zero4();
+
+  for (int k0 = 0; k0 < Kpad; k0 += 16) {
+    float b[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[s] = gload(wr + min(k0 + 4 * g + s, K - 1));   // (k >= K: Xs is zero there)
+    const f32x4 a = *reinterpret_cast<const f32x4*>(xr + k0);
+    acc0 = mfma16(a[0], b[0], acc0); acc1 = mfma16(a[1], b[1], acc1); acc0 = mfma16(a[2], b[2], acc0); acc1 = mfma16(a[3], b[3], acc1);
+  }
+  return acc0 + acc1;
+}
+// dYs [16][ldy] (LDS, zero beyond N) . W[0 .. N)[k0 .. k0 + 15] ; columns k >= K clamp their address
+__device__ __forceinline__ f32x4 g_tile_bwd(const float* dYs, int ldy, int Npad, const float* __restrict__ W, int K, int N, int k0) {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const float* wp = W + min(k0 + j, K - 1);
+  const float* yr = dYs + j * ldy + 4 * g;
+  f32x4 acc0 = zero4(), acc1 = zero4();
+
+  for (int n0 = 0; n0 < Npad; n0 += 16) {
+    float b[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[s] = gload(wp + (size_t)min(n0 + 4 * g + s, N - 1) * K);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(yr + n0);
+    acc0 = mfma16(a[0], b[0], acc0); acc1 = mfma16(a[1], b[1], acc1); acc0 = mfma16(a[2], b[2], acc0); acc1 = mfma16(a[3], b[3], acc1);
+  }
+  return acc0 + acc1;
+}
+// stage a 16-row tile of a feature-major matrix [F][Bp] into LDS as [16][ld], zero beyond F (up to Fpad)
+__device__ __forceinline__ void g_stage(float* dst, int ld, int Fpad, const float* __restrict__ srcT, int F, int Bp, int row0) {
+  for (int i = threadIdx.x; i < 16 * Fpad; i += blockDim.x) {
+    const int r = i & 15, k = i >> 4;
+    dst[r * ld + k] = k < F ? gload(srcT + (size_t)k * Bp + row0 + r) : 0.f;
+  }
+}
+
+struct GLin { const float* XT; int64_t x_ns; const float* P; int64_t p_ns; int64_t oW, ob; int K, N; float* YT; int64_t y_ns; int Bp, act; };
+__global__ __launch_bounds__(256) void k_g_linear(GLin a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int net = blockIdx.z, row0 = blockIdx.x * 16, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const float* P = a.P + net * a.p_ns;
+  const int Kpad = round_up16(a.K), ldx = Kpad + 4;
+  g_stage(smem, ldx, Kpad, a.XT + net * a.x_ns, a.K, a.Bp, row0);
+  __syncthreads();
+  const int n0 = (blockIdx.y * 4 + wave) * 16;
+  if (n0 >= a.N) return;
+  const f32x4 acc = g_tile_fwd(smem, ldx, Kpad, P + a.oW, a.K, n0, a.N);
+  const int n = n0 + j;
+  if (n < a.N) {
+    const float bb = gload(P + a.ob + n);
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = g_act(acc[r] + bb, a.act);
+    *reinterpret_cast<f32x4*>(a.YT + net * a.y_ns + (size_t)n * a.Bp + row0 + 4 * g) = v;
+  }
+}
+
+// dXT[k][row] = (sum_n dZT[n][row] W[n][k]) * act'(HprevT[k][row])    (HprevT == NULL: the input layer, no activation behind it)
+struct GBwd { const float* dZT; int64_t dz_ns; const float* P; int64_t p_ns; int64_t oW; int K, N; const float* HprevT; int64_t h_ns; float* dXT; int64_t dx_ns; int Bp, act; };
+__global__ __launch_bounds__(256) void k_g_bwd(GBwd a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int net = blockIdx.z, row0 = blockIdx.x * 16, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const int Npad = round_up16(a.N), ldy = Npad + 4;
+  g_stage(smem, ldy, Npad, a.dZT + net * a.dz_ns, a.N, a.Bp, row0);
+  __syncthreads();
+  const int k0 = (blockIdx.y * 4 + wave) * 16;
+  if (k0 >= a.K) return;
+  const f32x4 acc = g_tile_bwd(smem, ldy, Npad, a.P + net * a.p_ns + a.oW, a.K, a.N, k0);
+  const int k = k0 + j;
+  if (k < a.K) {
+    f32x4 v = acc;
+    if (a.HprevT) {
+      const f32x4 h = gload4(a.HprevT + net * a.h_ns + (size_t)k * a.Bp + row0 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[r] * g_act_grad(h[r], a.act);
+    }
+    *reinterpret_cast<f32x4*>(a.dXT + net * a.dx_ns + (size_t)k * a.Bp + row0 + 4 * g) = v;
+  }
+}
+
+// G[oW + n K + k] = sum_row dZT[n][row] XT[k][row]: one wave per 16 x 16 tile; both operands as 16-byte lanes along the batch
+struct GDw { const float* dZT; int64_t dz_ns; const float* XT; int64_t x_ns; float* G; int64_t g_ns; int64_t oW, ob; int N, K, Bp; };
+__global__ __launch_bounds__(256) void k_g_dw(GDw a) {
+  const int net = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const int tk = (a.K + 15) >> 4, tn = (a.N + 15) >> 4, tile = blockIdx.x * 4 + wave;
+  if (tile >= tk * tn) return;
+  const int n0 = (tile / tk) * 16, k0 = (tile - (tile / tk) * tk) * 16;
+  const float* zr = a.dZT + net * a.dz_ns + (size_t)min(n0 + j, a.N - 1) * a.Bp + 4 * g;
+  const float* xr = a.XT + net * a.x_ns + (size_t)min(k0 + j, a.K - 1) * a.Bp + 4 * g;
+  f32x4 acc0 = zero4(), acc1 = zero4();
+
+  for (int r0 = 0; r0 < a.Bp; r0 += 16) {
+    const f32x4 z = gload4(zr + r0), x = gload4(xr + r0);
+    acc0 = mfma16(z[0], x[0], acc0); acc1 = mfma16(z[1], x[1], acc1); acc0 = mfma16(z[2], x[2], acc0); acc1 = mfma16(z[3], x[3], acc1);
+  }
+  const f32x4 acc = acc0 + acc1;
+  float* G = a.G + net * a.g_ns + a.oW;
+  const int k = k0 + j;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { const int n = n0 + 4 * g + r; if (n < a.N && k < a.K) G[(size_t)n * a.K + k] = acc[r]; }
+}
+__global__ __launch_bounds__(256) void k_g_dbias(GDw a) {   // one wave per output feature
+  const int net = blockIdx.z, lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= a.N) return;
+  const float* z = a.dZT + net * a.dz_ns + (size_t)n * a.Bp;
+  float s = 0.f;
+  for (int r = lane; r < a.Bp; r += 64) s += gload(z + r);
+  s = wave_sum(s);
+  if (lane == 0) a.G[net * a.g_ns + a.ob + n] = s;
+}
+
+// X0T[k][row] = cat(f1, f2)[row][k] for row < n, zero padding rows (f2 == NULL: K2 columns are left to the head kernel that produces them)
+__global__ __launch_bounds__(256) void k_g_pack(const float* __restrict__ f1, int ld1, int K1, const float* __restrict__ f2, int ld2, int K2, int n, int Bp, float* __restrict__ XT) {
+  const int total = (K1 + (f2 ? K2 : 0)) * Bp;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int k = i / Bp, row = i - k * Bp;
+    float v = 0.f;
+    if (row < n) v = k < K1 ? f1[(size_t)row * ld1 + k] : f2[(size_t)row * ld2 + (k - K1)];
+    XT[i] = v;
+  }
+}
+
+// ---- per-row pieces ---------------------------------------------------------------------------------------------------------------------------------------------
+// models.py:90-94 + torch.distributions: the tanh-Gaussian head of one row (op order of oracle/nets.py tanh_gaussian_logp)
+__device__ __forceinline__ void g_head(float mean, float ls_raw, float eps, float& x, float& a, float& nlp, float& ladj) {
+  const float sd = expf(fminf(fmaxf(ls_raw, -20.f), 2.f));
+  x = __fadd_rn(__fmul_rn(eps, sd), mean);
+  a = tanhf(x);
+  const float d = __fsub_rn(x, mean);
+  nlp = -(d * d) / (2.f * (sd * sd)) - logf(sd) - LOG_SQRT_2PI;
+  ladj = 2.f * (LOG_2 - x - softplus_f(-2.f * x));
+}
+struct GSample {
+  const float* outT; int Bp, n, A;                       // actor output [2A][Bp]
+  const float* eps; uint64_t seed; const uint32_t* ctr_ptr; uint32_t ctr; int stream_id;   // eps [n][A] or Philox(seed, ctr_ptr ? *ctr_ptr : ctr, stream_id)
+  const float* absorbing; int ld_abs;                    // non-NULL: the action is multiplied by (1 - absorbing) (training.py:21 on s')
+  float* aT; float* a_rows; int ld_a;                    // destinations: feature-major rows [A][Bp] and / or row-major [n][ld_a]
+  float* xT; float* epsT; float* logp; int greedy;
+};
+__global__ __launch_bounds__(256) void k_g_sample(GSample a) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= a.Bp) return;
+  if (row >= a.n) {   // padding rows: zero inputs for the next network
+    if (a.aT) for (int c = 0; c < a.A; ++c) a.aT[(size_t)c * a.Bp + row] = 0.f;
+    return;
+  }
+  const uint32_t ctr = a.ctr_ptr ? *a.ctr_ptr : a.ctr;
+  const float m = a.absorbing ? 1.f - a.absorbing[(size_t)row * a.ld_abs] : 1.f;
+  float sn = 0.f, sl = 0.f;
+  for (int c = 0; c < a.A; ++c) {
+    const float mean = a.outT[(size_t)c * a.Bp + row], lsr = a.outT[(size_t)(a.A + c) * a.Bp + row];
+    float x, act, nlp, ladj, e = 0.f;
+    if (a.greedy) { act = tanhf(mean); x = mean; nlp = 0.f; ladj = 0.f; }
+    else {
+      e = a.eps ? a.eps[(size_t)row * a.A + c] : philox_normal(a.seed, ctr, a.stream_id, (uint32_t)(row * a.A + c));
+      g_head(mean, lsr, e, x, act, nlp, ladj);
+    }
+    sn += nlp; sl += ladj;
+    if (a.aT) a.aT[(size_t)c * a.Bp + row] = m * act;
+    if (a.a_rows) a.a_rows[(size_t)row * a.ld_a + c] = m * act;
+    if (a.xT) a.xT[(size_t)c * a.Bp + row] = x;
+    if (a.epsT) a.epsT[(size_t)c * a.Bp + row] = e;
+  }
+  if (a.logp) a.logp[row] = (0.f - sl) + sn;
+}
+// models.py:97-99 log pi(a | s) of GIVEN actions (clamped, atanh); with `weights` also the behavioural-cloning seed (training.py:57-64): d(-mean(w logp)) / d(head outputs)
+__global__ __launch_bounds__(256) void k_g_logp(const float* __restrict__ outT, int Bp, int n, int A, const float* __restrict__ actions, int ld_a, float* __restrict__ logp,
+                                                const float* __restrict__ weights, int ld_w, float* __restrict__ doutT, float* __restrict__ loss_rows) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= Bp) return;
+  if (row >= n) { if (doutT) for (int c = 0; c < 2 * A; ++c) doutT[(size_t)c * Bp + row] = 0.f; return; }
+  const float up = weights ? -weights[(size_t)row * ld_w] / (float)n : 0.f;
+  float sn = 0.f, sl = 0.f;
+  for (int c = 0; c < A; ++c) {
+    const float mean = outT[(size_t)c * Bp + row], lsr = outT[(size_t)(A + c) * Bp + row];
+    const float sd = expf(fminf(fmaxf(lsr, -20.f), 2.f));
+    const float act = fminf(fmaxf(actions[(size_t)row * ld_a + c], -1.f + 1e-6f), 1.f - 1e-6f);
+    const float x = atanhf(act), df = x - mean, var = sd * sd;
+    sn += -(df * df) / (2.f * var) - logf(sd) - LOG_SQRT_2PI;
+    sl += 2.f * (LOG_2 - x - softplus_f(-2.f * x));
+    if (doutT) {
+      const float dsd = up * (df * df / (var * sd) - 1.f / sd);
+      doutT[(size_t)c * Bp + row] = up * df / var;
+      doutT[(size_t)(A + c) * Bp + row] = (lsr >= -20.f && lsr <= 2.f) ? dsd * sd : 0.f;
+    }
+  }
+  const float lp = (0.f - sl) + sn;
+  if (logp) logp[row] = lp;
+  if (loss_rows) loss_rows[row] = weights ? -weights[(size_t)row * ld_w] * lp : 0.f;
+}
+// training.py:22-31: y = r + (1 - d) gamma (min Q'(s', a') - (1 - absorbing) alpha log pi(a'|s')); dL/dQ_k = w 2 (Q_k - y) / B; Q_values = min(Q_1, Q_2) (:54)
+__global__ __launch_bounds__(256) void k_g_critic_seed(il_batch b, const float* __restrict__ qtT, const float* __restrict__ qT, const float* __restrict__ logp2, const float* __restrict__ log_alpha,
+                                                       float discount, int Bp, float* __restrict__ dqT, float* __restrict__ out_q) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= Bp) return;
+  if (row >= b.n) { dqT[row] = 0.f; dqT[Bp + row] = 0.f; return; }
+  const float alpha = expf(log_alpha[0]);
+  const float m = 1.f - b.absorbing[(size_t)row * b.ld_absorbing];
+  const float tv = fminf(qtT[row], qtT[Bp + row]) - m * alpha * logp2[row];
+  const float y = b.rewards[(size_t)row * b.ld_rewards] + (1.f - b.terminals[(size_t)row * b.ld_terminals]) * discount * tv;
+  const float w = b.weights[(size_t)row * b.ld_weights], q1 = qT[row], q2 = qT[Bp + row];
+  dqT[row] = (w * (2.f * (q1 - y))) / (float)b.n;
+  dqT[Bp + row] = (w * (2.f * (q2 - y))) / (float)b.n;
+  if (out_q) out_q[row] = fminf(q1, q2);
+}
+// training.py:37-38: d(-mean(min(Q_1, Q_2))) / dQ_k = -[k is the smaller] / B (a tie splits, like torch.min's backward)
+__global__ __launch_bounds__(256) void k_g_policy_seed(const float* __restrict__ qnT, int n, int Bp, float* __restrict__ dqT) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= Bp) return;
+  if (row >= n) { dqT[row] = 0.f; dqT[Bp + row] = 0.f; return; }
+  const float q1 = qnT[row], q2 = qnT[Bp + row];
+  const float sel = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f);
+  dqT[row] = -(sel) / (float)n;
+  dqT[Bp + row] = -(1.f - sel) / (float)n;
+}
+// training.py:35-42 back through the head: dL/d(mean, log_std_raw) from dQ/da (both critics' input gradients) and the entropy term; alpha_rows = w m (log pi + target entropy)
+struct GHeadBwd { il_batch b; const float* outT; const float* xT; const float* epsT; const float* logp; const float* dx0T; int64_t dx_ns; const float* log_alpha; float entropy_target;
+                  int S, A, Bp; float* doutT; float* alpha_rows; float* out_logp; };
+__global__ __launch_bounds__(256) void k_g_head_bwd(GHeadBwd a) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x, A = a.A, Bp = a.Bp;
+  if (row >= Bp) return;
+  if (row >= a.b.n) { for (int c = 0; c < 2 * A; ++c) a.doutT[(size_t)c * Bp + row] = 0.f; a.alpha_rows[row] = 0.f; return; }
+  const float alpha = expf(a.log_alpha[0]);
+  const float w = a.b.weights[(size_t)row * a.b.ld_weights], m = 1.f - a.b.absorbing[(size_t)row * a.b.ld_absorbing];
+  const float cc = (w * m * alpha) / (float)a.b.n;
+  for (int c = 0; c < A; ++c) {
+    const float x = a.xT[(size_t)c * Bp + row], e = a.epsT[(size_t)c * Bp + row], lsr = a.outT[(size_t)(A + c) * Bp + row];
+    const float sd = expf(fminf(fmaxf(lsr, -20.f), 2.f)), an = tanhf(x);
+    const float da = a.dx0T[(size_t)(a.S + c) * Bp + row] + a.dx0T[a.dx_ns + (size_t)(a.S + c) * Bp + row];
+    const float dx = cc * (2.f * an) + da * (1.f - an * an);
+    const float dsd = dx * e - cc / sd;
+    a.doutT[(size_t)c * Bp + row] = dx;
+    a.doutT[(size_t)(A + c) * Bp + row] = (lsr >= -20.f && lsr <= 2.f) ? dsd * sd : 0.f;
+  }
+  const float lp = a.logp[row];
+  a.alpha_rows[row] = w * m * (lp + a.entropy_target);
+  if (a.out_logp) a.out_logp[row] = lp;
+}
+// training.py:45-49: Adam (not AdamW) on log_alpha; the update's Philox counter advances here, as in the fused path's tail
+__global__ void k_g_alpha(const float* __restrict__ alpha_rows, int n, float* __restrict__ log_alpha, il_adam opt, float* __restrict__ alpha_grad, int grads_only, uint32_t* noise_counter) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += alpha_rows[i];
+  const float gr = -(expf(log_alpha[0])) * (s / (float)n);
+  if (alpha_grad) alpha_grad[0] = gr;
+  if (!grads_only) {
+    adam_tick(opt);
+    const adam_consts ac = load_adam_consts(opt);
+    float pp = log_alpha[0], mm = opt.m[0], vv = opt.v[0];
+    adam_update(pp, gr, mm, vv, ac);
+    log_alpha[0] = pp; opt.m[0] = mm; opt.v[0] = vv;
+  }
+  if (noise_counter) noise_counter[0] += 1;
+}
+__global__ void k_g_sum_rows(const float* __restrict__ rows, int n, float* __restrict__ out) {   // loss = sum / n (one thread: deterministic order)
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += rows[i];
+  out[0] = s / (float)n;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------------------------------------------------
+struct GNet { int in, H, depth, out, act; };
+static int g_check_shape(const GNet& s, const char* who) {
+  IL_CHECK_ARG(s.depth >= 1 && s.depth <= 8 && s.H >= 1 && s.H <= 2048 && s.in >= 1 && s.in <= 2048 && s.out >= 1 && s.out <= 2048 && s.act >= 0 && s.act <= 2,
+               "%s: general shapes cover depth 1-8, widths <= 2048, activation 0 relu / 1 tanh / 2 sigmoid (got in=%d hidden=%d depth=%d out=%d activation=%d)", who, s.in, s.H, s.depth, s.out, s.act);
+  return IL_OK;
+}
+static size_t g_lds(int F) { return (size_t)16 * (round_up16(F) + 4) * sizeof(float); }
+static int g_lds_ok(const void* fn, size_t bytes) {
+  if (bytes <= 64 * 1024) return IL_OK;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return il_set_error(IL_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", bytes, hipGetErrorString(e));
+  return IL_OK;
+}
+// hidden activations of `nets` networks: [net][layer 1 .. depth][H][Bp]; output [net][out][Bp]
+static inline int64_t g_hidden_floats(const GNet& s, int Bp) { return (int64_t)s.depth * s.H * Bp; }
+
+static int g_forward(hipStream_t st, const GNet& s, const float* P, int64_t p_ns, int nets, const float* X0T, int64_t x_ns, float* HT, float* OT, int Bp) {
+  const int64_t h_ns = g_hidden_floats(s, Bp);
+  for (int l = 0; l <= s.depth; ++l) {
+    const GLayer L = g_layer(s.in, s.H, s.depth, s.out, l);
+    GLin a;
+    a.XT = l == 0 ? X0T : HT + (int64_t)(l - 1) * s.H * Bp; a.x_ns = l == 0 ? x_ns : h_ns;
+    a.P = P; a.p_ns = p_ns; a.oW = L.oW; a.ob = L.ob; a.K = L.K; a.N = L.N;
+    a.YT = l == s.depth ? OT : HT + (int64_t)l * s.H * Bp; a.y_ns = l == s.depth ? (int64_t)s.out * Bp : h_ns;
+    a.Bp = Bp; a.act = l == s.depth ? G_ACT_NONE : s.act;
+    const size_t lds = g_lds(L.K);
+    if (int rc = g_lds_ok((const void*)k_g_linear, lds)) return rc;
+    { IL_TRACE("k_g_linear", st); k_g_linear<<<dim3(Bp / 16, (L.N + 63) / 64, nets), 256, lds, st>>>(a); }
+  }
+  return IL_OK;
+}
+// dOT [net][out][Bp] -> gradients G (flat, NULL: none) and dX0T [net][in][Bp] (NULL: none); dZ scratch [net][depth][H][Bp]
+static int g_backward(hipStream_t st, const GNet& s, const float* P, int64_t p_ns, int nets, const float* X0T, int64_t x_ns, const float* HT, const float* dOT, float* dZT, float* dX0T,
+                      float* G, int64_t g_ns, int Bp) {
+  const int64_t h_ns = g_hidden_floats(s, Bp);
+  for (int l = s.depth; l >= 0; --l) {
+    const GLayer L = g_layer(s.in, s.H, s.depth, s.out, l);
+    const float* dz = l == s.depth ? dOT : dZT + (int64_t)l * s.H * Bp; const int64_t dz_ns = l == s.depth ? (int64_t)s.out * Bp : h_ns;
+    const float* xin = l == 0 ? X0T : HT + (int64_t)(l - 1) * s.H * Bp; const int64_t xin_ns = l == 0 ? x_ns : h_ns;
+    if (G) {
+      GDw w; w.dZT = dz; w.dz_ns = dz_ns; w.XT = xin; w.x_ns = xin_ns; w.G = G; w.g_ns = g_ns; w.oW = L.oW; w.ob = L.ob; w.N = L.N; w.K = L.K; w.Bp = Bp;
+      const int tiles = ((L.N + 15) / 16) * ((L.K + 15) / 16);
+      { IL_TRACE("k_g_dw", st); k_g_dw<<<dim3((tiles + 3) / 4, 1, nets), 256, 0, st>>>(w); }
+      { IL_TRACE("k_g_dbias", st); k_g_dbias<<<dim3((L.N + 3) / 4, 1, nets), 256, 0, st>>>(w); }
+    }
+    if (l > 0 || dX0T) {
+      GBwd a; a.dZT = dz; a.dz_ns = dz_ns; a.P = P; a.p_ns = p_ns; a.oW = L.oW; a.K = L.K; a.N = L.N;
+      a.HprevT = l > 0 ? HT + (int64_t)(l - 1) * s.H * Bp : nullptr; a.h_ns = h_ns;
+      a.dXT = l > 0 ? dZT + (int64_t)(l - 1) * s.H * Bp : dX0T; a.dx_ns = l > 0 ? h_ns : (int64_t)s.in * Bp;
+      a.Bp = Bp; a.act = s.act;
+      const size_t lds = g_lds(L.N);
+      if (int rc = g_lds_ok((const void*)k_g_bwd, lds)) return rc;
+      { IL_TRACE("k_g_bwd", st); k_g_bwd<<<dim3(Bp / 16, (L.K + 63) / 64, nets), 256, lds, st>>>(a); }
+    }
+  }
+  return IL_OK;
+}
+static void g_pack(hipStream_t st, const float* f1, int ld1, int K1, const float* f2, int ld2, int K2, int n, int Bp, float* XT) {
+  const int total = (K1 + (f2 ? K2 : 0)) * Bp;
+  IL_TRACE("k_g_pack", st);
+  k_g_pack<<<(total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024, 256, 0, st>>>(f1, ld1, K1, f2, ld2, K2, n, Bp, XT);
+}
+
+extern "C" int64_t il_mlp_numel_general(int32_t in_dim, int32_t hidden, int32_t depth, int32_t out_dim) { return g_numel(in_dim, hidden, depth, out_dim); }
+extern "C" int64_t il_mlp_stride_general(int32_t in_dim, int32_t hidden, int32_t depth, int32_t out_dim) { return g_stride(in_dim, hidden, depth, out_dim); }
+
+// workspace of il_sac_update_general (floats)
+struct GSacWs { int64_t xa2, xa, xt, xc, xp, ha2, oa2, ha, oa, ht, qt, hc, qc, hp, qp, dz, dq, dout, dx0, logp2, logp, xpre, epsu, arows, ga, gc, total; };
+static GSacWs g_sac_ws(int S, int A, int Ha, int da, int Hc, int dc, int B) {   // actor: da hidden layers of Ha units; critics: dc of Hc
+  const int Bp = g_bp(B), IN = S + A;
+  const int64_t hid = (int64_t)da * Ha * Bp, hidc = (int64_t)dc * Hc * Bp, hidm = hid > 2 * hidc ? hid : 2 * hidc;
+  GSacWs w; int64_t o = 0;
+  auto take = [&](int64_t n) { const int64_t at = o; o += (n + 3) & ~(int64_t)3; return at; };
+  w.xa2 = take((int64_t)S * Bp); w.xa = take((int64_t)S * Bp); w.xt = take((int64_t)IN * Bp); w.xc = take((int64_t)IN * Bp); w.xp = take((int64_t)IN * Bp);
+  w.ha2 = take(hid); w.oa2 = take((int64_t)2 * A * Bp); w.ha = take(hid); w.oa = take((int64_t)2 * A * Bp);
+  w.ht = take(2 * hidc); w.qt = take(2 * Bp); w.hc = take(2 * hidc); w.qc = take(2 * Bp); w.hp = take(2 * hidc); w.qp = take(2 * Bp);
+  w.dz = take(hidm); w.dq = take(2 * Bp); w.dout = take((int64_t)2 * A * Bp); w.dx0 = take((int64_t)2 * IN * Bp);
+  w.logp2 = take(Bp); w.logp = take(Bp); w.xpre = take((int64_t)A * Bp); w.epsu = take((int64_t)A * Bp); w.arows = take(Bp);
+  w.ga = take(g_numel(S, Ha, da, 2 * A)); w.gc = take(2 * g_stride(IN, Hc, dc, 1));
+  w.total = o;
+  return w;
+}
+extern "C" int64_t il_sac_workspace_floats_general(int32_t S, int32_t A, int32_t Ha, int32_t da, int32_t Hc, int32_t dc, int32_t B) { return g_sac_ws(S, A, Ha, da, Hc, dc, B).total; }
+
+// training.py:14-54 for general shapes. The descriptor is the fused path's (`hidden` = the ACTOR's hidden width; parameter arenas in torch order, twin critics at
+// il_mlp_stride_general); the actor and the critics have their own (hidden, depth, activation), as reinforcement.actor / reinforcement.critic do in the reference's configuration.
+// workspace >= il_sac_workspace_floats_general. eps_next / eps_cur [B][A] or NULL (Philox, the fused path's streams and counter).
+extern "C" int il_sac_update_general(const il_sac* d, const il_batch* b, int32_t actor_depth, int32_t actor_activation, int32_t critic_hidden, int32_t critic_depth, int32_t critic_activation,
+                                     const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream_) {
+  IL_CHECK_ARG(d && b && d->actor && d->critic && d->target && d->log_alpha && d->workspace, "il_sac_update_general: null descriptor field");
+  IL_NO_GATHER(b, "il_sac_update_general");
+  IL_CHECK_ARG(!(flags & ~(uint32_t)IL_FLAG_GRADS_ONLY), "il_sac_update_general: only IL_FLAG_GRADS_ONLY is understood");
+  const int S = d->state_dim, A = d->action_dim, H = d->hidden, B = d->batch, IN = S + A, Bp = g_bp(B);
+  IL_CHECK_ARG(b->n == B && B >= 1, "il_sac_update_general: batch has %d rows, descriptor %d", b->n, B);
+  const GNet an = {S, H, actor_depth, 2 * A, actor_activation}, cn = {IN, critic_hidden, critic_depth, 1, critic_activation};
+  if (int rc = g_check_shape(an, "il_sac_update_general (actor)")) return rc;
+  if (int rc = g_check_shape(cn, "il_sac_update_general (critic)")) return rc;
+  const GSacWs ws = g_sac_ws(S, A, H, actor_depth, critic_hidden, critic_depth, B);
+  if (d->workspace_floats < ws.total) return il_set_error(IL_ERR_WORKSPACE, "il_sac_update_general: workspace has %lld floats, needs %lld", (long long)d->workspace_floats, (long long)ws.total);
+  const bool grads_only = (flags & IL_FLAG_GRADS_ONLY) != 0;
+  IL_CHECK_ARG(!grads_only || (d->actor_grad && d->critic_grad && d->alpha_grad), "il_sac_update_general: IL_FLAG_GRADS_ONLY needs the gradient arenas");
+  hipStream_t st = (hipStream_t)stream_;
+  float* W = d->workspace;
+  const int64_t Pa = g_numel(S, H, actor_depth, 2 * A), Pc = g_numel(IN, critic_hidden, critic_depth, 1), Ps = g_stride(IN, critic_hidden, critic_depth, 1);
+  float* ga = grads_only ? d->actor_grad : W + ws.ga; float* gc = grads_only ? d->critic_grad : W + ws.gc;
+  const int rb = (Bp + 255) / 256;
+  // inputs, feature-major
+  g_pack(st, b->next_states, b->ld_next_states, S, nullptr, 0, 0, B, Bp, W + ws.xa2);
+  g_pack(st, b->states, b->ld_states, S, nullptr, 0, 0, B, Bp, W + ws.xa);
+  g_pack(st, b->next_states, b->ld_next_states, S, nullptr, 0, A, B, Bp, W + ws.xt);   // + a' below
+  g_pack(st, b->states, b->ld_states, S, b->actions, b->ld_actions, A, B, Bp, W + ws.xc);
+  g_pack(st, b->states, b->ld_states, S, nullptr, 0, A, B, Bp, W + ws.xp);             // + a~ below
+  // target values (training.py:19-25)
+  if (int rc = g_forward(st, an, d->actor, 0, 1, W + ws.xa2, 0, W + ws.ha2, W + ws.oa2, Bp)) return rc;
+  {
+    GSample h = {}; h.outT = W + ws.oa2; h.Bp = Bp; h.n = B; h.A = A; h.eps = eps_next; h.seed = d->noise_seed; h.ctr_ptr = d->noise_counter; h.stream_id = IL_STREAM_EPS_NEXT;
+    h.absorbing = b->absorbing; h.ld_abs = b->ld_absorbing; h.aT = W + ws.xt + (int64_t)S * Bp; h.logp = W + ws.logp2;
+    IL_TRACE("k_g_sample", st); k_g_sample<<<rb, 256, 0, st>>>(h);
+  }
+  if (int rc = g_forward(st, cn, d->target, Ps, 2, W + ws.xt, 0, W + ws.ht, W + ws.qt, Bp)) return rc;
+  // critic loss, backward, AdamW (training.py:26-31)
+  if (int rc = g_forward(st, cn, d->critic, Ps, 2, W + ws.xc, 0, W + ws.hc, W + ws.qc, Bp)) return rc;
+  { IL_TRACE("k_g_critic_seed", st); k_g_critic_seed<<<rb, 256, 0, st>>>(*b, W + ws.qt, W + ws.qc, W + ws.logp2, d->log_alpha, d->discount, Bp, W + ws.dq, out_q ? out_q : d->out_q); }
+  if (int rc = g_backward(st, cn, d->critic, Ps, 2, W + ws.xc, 0, W + ws.hc, W + ws.dq, W + ws.dz, nullptr, gc, Ps, Bp)) return rc;
+  if (!grads_only) {
+    if (int rc = il_adam_step(d->critic, gc, &d->critic_opt, Pc, IL_FLAG_TICK, stream_)) return rc;
+    il_adam o2 = d->critic_opt; o2.m += Ps; o2.v += Ps;   // the second critic's slice of the arena (one tick per step: above)
+    if (int rc = il_adam_step(d->critic + Ps, gc + Ps, &o2, Pc, 0, stream_)) return rc;
+  }
+  // policy loss through the updated critic (training.py:34-42)
+  if (int rc = g_forward(st, an, d->actor, 0, 1, W + ws.xa, 0, W + ws.ha, W + ws.oa, Bp)) return rc;
+  {
+    GSample h = {}; h.outT = W + ws.oa; h.Bp = Bp; h.n = B; h.A = A; h.eps = eps_cur; h.seed = d->noise_seed; h.ctr_ptr = d->noise_counter; h.stream_id = IL_STREAM_EPS_CUR;
+    h.aT = W + ws.xp + (int64_t)S * Bp; h.xT = W + ws.xpre; h.epsT = W + ws.epsu; h.logp = W + ws.logp;
+    IL_TRACE("k_g_sample", st); k_g_sample<<<rb, 256, 0, st>>>(h);
+  }
+  if (int rc = g_forward(st, cn, d->critic, Ps, 2, W + ws.xp, 0, W + ws.hp, W + ws.qp, Bp)) return rc;
+  { IL_TRACE("k_g_policy_seed", st); k_g_policy_seed<<<rb, 256, 0, st>>>(W + ws.qp, B, Bp, W + ws.dq); }
+  if (int rc = g_backward(st, cn, d->critic, Ps, 2, W + ws.xp, 0, W + ws.hp, W + ws.dq, W + ws.dz, W + ws.dx0, nullptr, 0, Bp)) return rc;
+  {
+    GHeadBwd h = {}; h.b = *b; h.outT = W + ws.oa; h.xT = W + ws.xpre; h.epsT = W + ws.epsu; h.logp = W + ws.logp; h.dx0T = W + ws.dx0; h.dx_ns = (int64_t)IN * Bp; h.log_alpha = d->log_alpha;
+    h.entropy_target = d->entropy_target; h.S = S; h.A = A; h.Bp = Bp; h.doutT = W + ws.dout; h.alpha_rows = W + ws.arows; h.out_logp = out_logp ? out_logp : d->out_logp;
+    IL_TRACE("k_g_head_bwd", st); k_g_head_bwd<<<rb, 256, 0, st>>>(h);
+  }
+  if (int rc = g_backward(st, an, d->actor, 0, 1, W + ws.xa, 0, W + ws.ha, W + ws.dout, W + ws.dz, nullptr, ga, 0, Bp)) return rc;
+  if (!grads_only) { if (int rc = il_adam_step(d->actor, ga, &d->actor_opt, Pa, IL_FLAG_TICK, stream_)) return rc; }
+  // temperature, target network (training.py:45-52)
+  { IL_TRACE("k_g_alpha", st); k_g_alpha<<<1, 64, 0, st>>>(W + ws.arows, B, d->log_alpha, d->alpha_opt, d->alpha_grad, grads_only ? 1 : 0, d->noise_counter); }
+  if (!grads_only) {
+    if (int rc = il_polyak(d->target, d->critic, Pc, d->polyak, stream_)) return rc;
+    if (int rc = il_polyak(d->target + Ps, d->critic + Ps, Pc, d->polyak, stream_)) return rc;
+  }
+  IL_CHECK_LAUNCH("il_sac_update_general");
+  return IL_OK;
+}
+
+// workspace of the actor-only entry points below: input, hidden activations, head outputs, and (behavioural cloning) dZ, head gradient, loss rows, gradient arena
+extern "C" int64_t il_actor_workspace_floats_general(int32_t S, int32_t A, int32_t H, int32_t depth, int32_t n) {
+  const int Bp = g_bp(n);
+  return (int64_t)S * Bp + 2 * (int64_t)depth * H * Bp + 2 * (int64_t)2 * A * Bp + 2 * Bp + g_numel(S, H, depth, 2 * A) + 64;
+}
+struct GActWs { int64_t x, h, o, dz, dout, rows, g; };
+static GActWs g_act_ws(int S, int A, int H, int depth, int Bp) {
+  GActWs w; int64_t o = 0;
+  auto take = [&](int64_t n) { const int64_t at = o; o += (n + 3) & ~(int64_t)3; return at; };
+  w.x = take((int64_t)S * Bp); w.h = take((int64_t)depth * H * Bp); w.o = take((int64_t)2 * A * Bp); w.dz = take((int64_t)depth * H * Bp); w.dout = take((int64_t)2 * A * Bp); w.rows = take(Bp);
+  w.g = take(g_numel(S, H, depth, 2 * A));
+  return w;
+}
+// train.py:152 `actor(state).sample()` / models.py:101-102 get_greedy_action for general shapes (arguments of il_actor_act + depth, activation, workspace)
+extern "C" int il_actor_act_general(const float* actor, int32_t S, int32_t A, int32_t H, int32_t depth, int32_t activation, const float* states, int32_t ld_states, int32_t n, const float* eps,
+                                    uint64_t noise_seed, uint32_t noise_offset, int32_t greedy, float* out_action, float* out_logp, float* workspace, int64_t workspace_floats, il_stream_t stream_) {
+  IL_CHECK_ARG(actor && states && out_action && workspace && n > 0, "il_actor_act_general: null argument");
+  const GNet an = {S, H, depth, 2 * A, activation};
+  if (int rc = g_check_shape(an, "il_actor_act_general")) return rc;
+  IL_CHECK_ARG(workspace_floats >= il_actor_workspace_floats_general(S, A, H, depth, n), "il_actor_act_general: workspace too small");
+  hipStream_t st = (hipStream_t)stream_;
+  const int Bp = g_bp(n);
+  const GActWs ws = g_act_ws(S, A, H, depth, Bp);
+  g_pack(st, states, ld_states, S, nullptr, 0, 0, n, Bp, workspace + ws.x);
+  if (int rc = g_forward(st, an, actor, 0, 1, workspace + ws.x, 0, workspace + ws.h, workspace + ws.o, Bp)) return rc;
+  GSample h = {}; h.outT = workspace + ws.o; h.Bp = Bp; h.n = n; h.A = A; h.eps = eps; h.seed = noise_seed; h.ctr = noise_offset; h.stream_id = IL_STREAM_ACT; h.a_rows = out_action; h.ld_a = A;
+  h.logp = out_logp; h.greedy = greedy;
+  { IL_TRACE("k_g_sample", st); k_g_sample<<<(Bp + 255) / 256, 256, 0, st>>>(h); }
+  IL_CHECK_LAUNCH("il_actor_act_general");
+  return IL_OK;
+}
+// models.py:97-99 SoftActor.log_prob for general shapes
+extern "C" int il_actor_log_prob_general(const float* actor, int32_t S, int32_t A, int32_t H, int32_t depth, int32_t activation, const float* states, int32_t ld_states, const float* actions,
+                                         int32_t ld_actions, int32_t n, float* out_logp, float* workspace, int64_t workspace_floats, il_stream_t stream_) {
+  IL_CHECK_ARG(actor && states && actions && out_logp && workspace && n > 0, "il_actor_log_prob_general: null argument");
+  const GNet an = {S, H, depth, 2 * A, activation};
+  if (int rc = g_check_shape(an, "il_actor_log_prob_general")) return rc;
+  IL_CHECK_ARG(workspace_floats >= il_actor_workspace_floats_general(S, A, H, depth, n), "il_actor_log_prob_general: workspace too small");
+  hipStream_t st = (hipStream_t)stream_;
+  const int Bp = g_bp(n);
+  const GActWs ws = g_act_ws(S, A, H, depth, Bp);
+  g_pack(st, states, ld_states, S, nullptr, 0, 0, n, Bp, workspace + ws.x);
+  if (int rc = g_forward(st, an, actor, 0, 1, workspace + ws.x, 0, workspace + ws.h, workspace + ws.o, Bp)) return rc;
+  { IL_TRACE("k_g_logp", st); k_g_logp<<<(Bp + 255) / 256, 256, 0, st>>>(workspace + ws.o, Bp, n, A, actions, ld_actions, out_logp, nullptr, 0, nullptr, nullptr); }
+  IL_CHECK_LAUNCH("il_actor_log_prob_general");
+  return IL_OK;
+}
+// training.py:57-64 behavioural_cloning_update for general shapes (arguments of il_bc_step + depth, activation); out_loss [1] = mean(w * -log pi) or NULL
+extern "C" int il_bc_step_general(float* actor, float* actor_grad, const il_adam* opt, int32_t S, int32_t A, int32_t H, int32_t depth, int32_t activation, const il_batch* b, float* workspace,
+                                  int64_t workspace_floats, float* out_loss, uint32_t flags, il_stream_t stream_) {
+  IL_CHECK_ARG(actor && b && workspace && b->n > 0 && (opt || (flags & IL_FLAG_GRADS_ONLY)), "il_bc_step_general: null argument");
+  IL_NO_GATHER(b, "il_bc_step_general");
+  const GNet an = {S, H, depth, 2 * A, activation};
+  if (int rc = g_check_shape(an, "il_bc_step_general")) return rc;
+  const int n = b->n, Bp = g_bp(n);
+  IL_CHECK_ARG(workspace_floats >= il_actor_workspace_floats_general(S, A, H, depth, n), "il_bc_step_general: workspace too small");
+  const bool grads_only = (flags & IL_FLAG_GRADS_ONLY) != 0;
+  IL_CHECK_ARG(!grads_only || actor_grad, "il_bc_step_general: IL_FLAG_GRADS_ONLY needs actor_grad");
+  hipStream_t st = (hipStream_t)stream_;
+  const GActWs ws = g_act_ws(S, A, H, depth, Bp);
+  float* G = actor_grad ? actor_grad : workspace + ws.g;
+  g_pack(st, b->states, b->ld_states, S, nullptr, 0, 0, n, Bp, workspace + ws.x);
+  if (int rc = g_forward(st, an, actor, 0, 1, workspace + ws.x, 0, workspace + ws.h, workspace + ws.o, Bp)) return rc;
+  { IL_TRACE("k_g_logp", st); k_g_logp<<<(Bp + 255) / 256, 256, 0, st>>>(workspace + ws.o, Bp, n, A, b->actions, b->ld_actions, nullptr, b->weights, b->ld_weights, workspace + ws.dout, workspace + ws.rows); }
+  if (out_loss) { IL_TRACE("k_g_sum_rows", st); k_g_sum_rows<<<1, 64, 0, st>>>(workspace + ws.rows, n, out_loss); }
+  if (int rc = g_backward(st, an, actor, 0, 1, workspace + ws.x, 0, workspace + ws.h, workspace + ws.dout, workspace + ws.dz, nullptr, G, 0, Bp)) return rc;
+  if (!grads_only) { if (int rc = il_adam_step(actor, G, opt, g_numel(S, H, depth, 2 * A), IL_FLAG_TICK, stream_)) return rc; }
+  IL_CHECK_LAUNCH("il_bc_step_general");
+  return IL_OK;
+}

@@ -31,6 +31,10 @@ def _cfg_get(cfg, key, default=None):
   return cfg.get(key, default) if hasattr(cfg, 'get') else getattr(cfg, key, default)
 
 
+ACTIVATION_IDS = {'relu': 0, 'tanh': 1, 'sigmoid': 2}   # models.py:16 ACTIVATION_FUNCTIONS; the ids of csrc/general.hip
+_ACTIVATION_MODULES = {'relu': nn.ReLU, 'tanh': nn.Tanh, 'sigmoid': nn.Sigmoid}
+
+
 def _require_fused_mlp(model_cfg, what):
   depth, act = _cfg_get(model_cfg, 'depth'), _cfg_get(model_cfg, 'activation')
   hidden = _cfg_get(model_cfg, 'hidden_size')
@@ -42,16 +46,31 @@ def _require_fused_mlp(model_cfg, what):
   return hidden
 
 
-def _mlp(in_dim: int, hidden: int, out_dim: int, final_gain: float = 1.0) -> nn.Sequential:
-  """Linear-ReLU-Linear-ReLU-Linear with the reference's init (orthogonal, gain sqrt(2) hidden / final_gain last, zero bias; models.py:55-66)."""
-  dims, layers = [in_dim, hidden, hidden, out_dim], []
-  for i in range(3):
+def _mlp_shape(model_cfg, what):
+  """(hidden, depth, activation, general) of an actor / critic network (models.py:48-69 `_create_fcnn` builds any depth with relu / tanh / sigmoid). general = False: the
+  shape of every shipped configuration (depth 2, ReLU, hidden 64 .. 256), which the fused kernels of csrc/sac.hip run; True: any other shape, composed a layer at a time
+  by csrc/general.hip (per-function path: sac_update, acting, log_prob, behavioural cloning - no captured plan, population or data-parallel form)."""
+  depth, act, hidden = int(_cfg_get(model_cfg, 'depth')), str(_cfg_get(model_cfg, 'activation')), int(_cfg_get(model_cfg, 'hidden_size'))
+  if _cfg_get(model_cfg, 'input_dropout', 0) or _cfg_get(model_cfg, 'dropout', 0):
+    raise NotImplementedError(f'{what}: dropout networks (DRIL) are outside the HIP hot path')
+  if act not in ACTIVATION_IDS:
+    raise ValueError(f'{what}: activation must be one of {sorted(ACTIVATION_IDS)} (got {act})')
+  fused = depth == 2 and act == 'relu' and hidden % 64 == 0 and 64 <= hidden <= 256
+  if not fused and not (1 <= depth <= 8 and 1 <= hidden <= 2048):
+    raise NotImplementedError(f'{what}: the general HIP path covers depth 1-8 and hidden_size <= 2048 (got depth={depth}, hidden_size={hidden}); there is no CPU/torch fallback')
+  return hidden, depth, act, not fused
+
+
+def _mlp(in_dim: int, hidden: int, out_dim: int, final_gain: float = 1.0, depth: int = 2, activation: str = 'relu') -> nn.Sequential:
+  """`depth` x (Linear - activation) - Linear with the reference's init (orthogonal, gain calculate_gain(activation) hidden / final_gain last, zero bias; models.py:48-66)."""
+  dims, layers = [in_dim] + [hidden] * depth + [out_dim], []
+  for i in range(depth + 1):
     lin = nn.Linear(dims[i], dims[i + 1])
-    nn.init.orthogonal_(lin.weight, gain=sqrt(2.0) if i < 2 else final_gain)
+    nn.init.orthogonal_(lin.weight, gain=nn.init.calculate_gain(activation) if i < depth else final_gain)
     nn.init.constant_(lin.bias, 0)
     layers.append(lin)
-    if i < 2:
-      layers.append(nn.ReLU())
+    if i < depth:
+      layers.append(_ACTIVATION_MODULES[activation]())
   return nn.Sequential(*layers)
 
 
@@ -97,11 +116,11 @@ class SoftActor(_FlatModule):
   def __init__(self, state_size: int, action_size: int, model_cfg, device=None):
     super().__init__()
     self.state_size, self.action_size = state_size, action_size
-    self.hidden = _require_fused_mlp(model_cfg, 'SoftActor')
+    self.hidden, self.depth, self.activation, self.general = _mlp_shape(model_cfg, 'SoftActor')
     if 2 * action_size > 16:
-      raise NotImplementedError('SoftActor: action_size > 8 is not supported by the fused head (2A <= 16)')
+      self.general = True   # the fused head holds 2A <= 16 outputs: wider action spaces take the general kernels
     self.log_std_dev_min, self.log_std_dev_max = -20, 2
-    self.actor = _mlp(state_size, self.hidden, 2 * action_size)
+    self.actor = _mlp(state_size, self.hidden, 2 * action_size, depth=self.depth, activation=self.activation)
     offs, o = [], 0
     for p in self.parameters():
       offs.append(o); o += p.numel()
@@ -134,12 +153,26 @@ class SoftActor(_FlatModule):
     if eps is not None:
       eps = eps.to(self.flat.device, torch.float32).contiguous()
     self._act_calls += 1
+    if self.general:
+      ws = self._general_workspace(n)
+      _lib.check(_lib.lib().il_actor_act_general(_lib.ptr(self.flat), self.state_size, self.action_size, self.hidden, self.depth, ACTIVATION_IDS[self.activation], _lib.ptr(state), state.stride(0), n,
+                                                 _lib.ptr(eps), C.c_uint64(torch.initial_seed() & (2**64 - 1)), self._act_calls & 0xFFFFFFFF, int(greedy), _lib.ptr(out), _lib.ptr(logp),
+                                                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+      return out, logp
     _lib.check(_lib.lib().il_actor_act(_lib.ptr(self.flat), self.state_size, self.action_size, self.hidden, _lib.ptr(state), state.stride(0), n, _lib.ptr(eps),
                                        C.c_uint64(torch.initial_seed() & (2**64 - 1)), self._act_calls & 0xFFFFFFFF, int(greedy), _lib.ptr(out), _lib.ptr(logp), _lib.stream_ptr()))
     return out, logp
 
   def get_greedy_action(self, state: Tensor) -> Tensor:
     return self._act(state, greedy=True)[0]
+
+  def _general_workspace(self, n: int) -> Tensor:
+    """Scratch of the general-shape entry points (csrc/general.hip), grown on demand and kept with the module."""
+    need = int(_lib.lib().il_actor_workspace_floats_general(self.state_size, self.action_size, self.hidden, self.depth, n))
+    ws = getattr(self, '_gws', None)
+    if ws is None or ws.numel() < need:
+      ws = self._gws = torch.zeros(need, dtype=torch.float32, device=self.flat.device)
+    return ws
 
   def log_prob(self, state: Tensor, action: Tensor) -> Tensor:
     """models.py:97-99: log pi(a|s) with the action clamped to +-(1 - 1e-6) (k_actor_logp)."""
@@ -150,6 +183,12 @@ class SoftActor(_FlatModule):
     if action.stride(1) != 1: action = action.contiguous()
     n = state.size(0)
     out = torch.empty(n, device=dev)
+    if self.general:
+      ws = self._general_workspace(n)
+      _lib.check(_lib.lib().il_actor_log_prob_general(_lib.ptr(self.flat), self.state_size, self.action_size, self.hidden, self.depth, ACTIVATION_IDS[self.activation], _lib.ptr(state),
+                                                      state.stride(0) if n > 1 else state.size(1), _lib.ptr(action), action.stride(0) if n > 1 else action.size(1), n, _lib.ptr(out),
+                                                      _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+      return out
     _lib.check(_lib.lib().il_actor_log_prob(_lib.ptr(self.flat), self.state_size, self.action_size, self.hidden, _lib.ptr(state), state.stride(0) if n > 1 else state.size(1),
                                             _lib.ptr(action), action.stride(0) if n > 1 else action.size(1), n, _lib.ptr(out), _lib.stream_ptr()))
     return out
@@ -266,9 +305,9 @@ class DropoutSoftActor(SoftActor):
 
 
 class Critic(nn.Module):
-  def __init__(self, state_size: int, action_size: int, hidden: int):
+  def __init__(self, state_size: int, action_size: int, hidden: int, depth: int = 2, activation: str = 'relu'):
     super().__init__()
-    self.critic = _mlp(state_size + action_size, hidden, 1)
+    self.critic = _mlp(state_size + action_size, hidden, 1, depth=depth, activation=activation)
 
   def forward(self, state: Tensor, action: Tensor) -> Tensor:
     return self.critic(torch.cat([state, action], dim=1)).squeeze(dim=1)
@@ -280,8 +319,8 @@ class TwinCritic(_FlatModule):
   def __init__(self, state_size: int, action_size: int, model_cfg, device=None):
     super().__init__()
     self.state_size, self.action_size = state_size, action_size
-    self.hidden = _require_fused_mlp(model_cfg, 'TwinCritic')
-    self.critic_1, self.critic_2 = Critic(state_size, action_size, self.hidden), Critic(state_size, action_size, self.hidden)
+    self.hidden, self.depth, self.activation, self.general = _mlp_shape(model_cfg, 'TwinCritic')
+    self.critic_1, self.critic_2 = (Critic(state_size, action_size, self.hidden, self.depth, self.activation) for _ in range(2))
     numel = sum(p.numel() for p in self.critic_1.parameters())
     self.net_stride = (numel + 3) // 4 * 4
     offs = []

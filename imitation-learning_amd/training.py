@@ -54,8 +54,12 @@ def _f32(t: Optional[Tensor], device) -> Optional[Tensor]:
 def sac_descriptor(actor: SoftActor, critic: TwinCritic, log_alpha: Tensor, target_critic: TwinCritic, batch_size: int, actor_optimiser: AdamW, critic_optimiser: AdamW,
                    temperature_optimiser: Adam, discount: float, entropy_target: float, polyak_factor: float, tag=None, seed_offset: int = 0) -> _lib.Sac:
   S, A, H, dev = actor.state_size, actor.action_size, actor.hidden, actor.flat.device
-  assert critic.hidden == H and _lib.on_device(log_alpha) and log_alpha.dtype == torch.float32
-  floats = int(_lib.lib().il_sac_workspace_floats(S, A, H, batch_size))
+  assert _lib.on_device(log_alpha) and log_alpha.dtype == torch.float32
+  if _general_shape(actor, critic):   # csrc/general.hip: its own (larger) scratch layout; reinforcement.actor and reinforcement.critic may differ in every dimension
+    floats = int(_lib.lib().il_sac_workspace_floats_general(S, A, H, actor.depth, critic.hidden, critic.depth, batch_size))
+  else:
+    assert critic.hidden == H
+    floats = int(_lib.lib().il_sac_workspace_floats(S, A, H, batch_size))
   ws = _workspace('sac', floats, dev, tag)
   d = _lib.Sac()
   d.state_dim, d.action_dim, d.hidden, d.batch = S, A, H, batch_size
@@ -68,6 +72,11 @@ def sac_descriptor(actor: SoftActor, critic: TwinCritic, log_alpha: Tensor, targ
   return d
 
 
+def _general_shape(actor, critic=None) -> bool:
+  """True when the networks are outside the fused kernels' shape (models._mlp_shape) and run through csrc/general.hip."""
+  return bool(getattr(actor, 'general', False) or (critic is not None and getattr(critic, 'general', False)))
+
+
 def sac_update(actor: SoftActor, critic: TwinCritic, log_alpha: Tensor, target_critic: TwinCritic, transitions: Dict[str, Tensor], actor_optimiser: AdamW,
                critic_optimiser: AdamW, temperature_optimiser: Adam, discount: float, entropy_target: float, polyak_factor: float, *,
                eps_next: Optional[Tensor] = None, eps_cur: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
@@ -78,6 +87,11 @@ def sac_update(actor: SoftActor, critic: TwinCritic, log_alpha: Tensor, target_c
   b = batch_desc(transitions)
   logp, q = torch.empty(B, device=dev), torch.empty(B, device=dev)
   e1, e2 = _f32(eps_next, dev), _f32(eps_cur, dev)
+  if _general_shape(actor, critic):
+    from .models import ACTIVATION_IDS
+    _lib.check(_lib.lib().il_sac_update_general(C.byref(d), C.byref(b), actor.depth, ACTIVATION_IDS[actor.activation], critic.hidden, critic.depth, ACTIVATION_IDS[critic.activation],
+                                                _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(logp), _lib.ptr(q), 0, _lib.stream_ptr()))
+    return logp, q
   _lib.check(_lib.lib().il_sac_update(C.byref(d), C.byref(b), _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(logp), _lib.ptr(q), 0, _lib.stream_ptr()))
   return logp, q
 
@@ -93,6 +107,12 @@ def behavioural_cloning_update(actor: SoftActor, expert_transition: Dict[str, Te
     t.setdefault(k, t['weights'] if k != 'next_states' else t['states'])
   b = batch_desc(t)
   S, A, H, B = actor.state_size, actor.action_size, actor.hidden, b.n
+  if _general_shape(actor):
+    from .models import ACTIVATION_IDS
+    ws, loss, od = actor._general_workspace(B), torch.empty(1, device=dev), actor_optimiser.desc()
+    _lib.check(_lib.lib().il_bc_step_general(_lib.ptr(actor.flat), _lib.ptr(actor_optimiser.grad), C.byref(od), S, A, H, actor.depth, ACTIVATION_IDS[actor.activation], C.byref(b), _lib.ptr(ws),
+                                             ws.numel(), _lib.ptr(loss), 0, _lib.stream_ptr()))
+    return loss[0]
   floats = int(_lib.lib().il_sac_workspace_floats(S, A, H, B))
   ws = _workspace('sac', floats, dev)
   parts = torch.empty(B // 16, device=dev)
@@ -376,6 +396,9 @@ class UpdatePlan:
     """`learner_id`: give this plan private scratch / noise / index-stream state so that several plans can run concurrently (`PopulationPlan`).
     `mix_expert`: imitation.mix_expert_data == 'mixed_batch' (DRIL / GMMIL / RED); `bc_aux`: imitation.bc_aux_loss (train.py:201)."""
     assert algorithm in self.ALGORITHMS, f'UpdatePlan: unknown algorithm {algorithm}'
+    if _general_shape(actor, critic):
+      raise NotImplementedError('UpdatePlan: actor / critic shapes outside depth 2 / ReLU / hidden <= 256 / action_size <= 8 run through sac_update (csrc/general.hip, per-function path): '
+                                'there is no captured plan, population or data-parallel form for them')
     assert expert_memory is not None or (algorithm in ('SAC', 'PWIL') and not mix_expert and not bc_aux), f'UpdatePlan({algorithm}): needs the expert memory'
     assert not (mix_expert and algorithm in ('GAIL', 'SAC', 'PWIL', 'AdRIL')), 'mixed batches: DRIL / GMMIL / RED plans (train.py:175,183); GAIL with mixing runs the per-function path'
     # GAIL: discriminator branch || SAC branch. SAC / PWIL (no reward step, nothing host-side inside): the second stream only hosts the resident index draw.

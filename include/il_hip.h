@@ -285,6 +285,30 @@ int il_actor_act(const float* actor, int32_t state_dim, int32_t action_dim, int3
 int il_actor_log_prob(const float* actor, int32_t state_dim, int32_t action_dim, int32_t hidden, const float* states, int32_t ld_states,
                       const float* actions, int32_t ld_actions, int32_t n, float* out_logp, il_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * General actor / critic shapes (models.py:48-69 `_create_fcnn`: any depth, activation relu / tanh / sigmoid): the networks outside the fused kernels above (depth 2, ReLU,
+ * hidden <= 256, 2A <= 16), composed a layer at a time from exact-fp32 MFMA tiles (csrc/general.hip). Parameters in torch `parameters()` order for `depth` hidden layers of
+ * `hidden` units; twin critics at il_mlp_stride_general floats. activation: 0 relu, 1 tanh, 2 sigmoid. depth 1-8, widths <= 2048. Per-function path only (no captured plan).
+ * ------------------------------------------------------------------------------------------ */
+int64_t il_mlp_numel_general(int32_t in_dim, int32_t hidden, int32_t depth, int32_t out_dim);
+int64_t il_mlp_stride_general(int32_t in_dim, int32_t hidden, int32_t depth, int32_t out_dim);
+int64_t il_sac_workspace_floats_general(int32_t state_dim, int32_t action_dim, int32_t actor_hidden, int32_t actor_depth, int32_t critic_hidden, int32_t critic_depth, int32_t batch);
+int64_t il_actor_workspace_floats_general(int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t depth, int32_t n);
+/* training.py:14-54 (il_sac_update) on an il_sac whose arenas hold networks of these shapes (d->hidden = the actor's width; the actor and the critics are configured
+ * separately, like reinforcement.actor / reinforcement.critic) and whose workspace has il_sac_workspace_floats_general floats.
+ * flags: 0 or IL_FLAG_GRADS_ONLY (gradients into actor_grad / critic_grad / alpha_grad, no optimiser step, no target update). */
+int il_sac_update_general(const il_sac* d, const il_batch* batch, int32_t actor_depth, int32_t actor_activation, int32_t critic_hidden, int32_t critic_depth, int32_t critic_activation,
+                          const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream);
+/* il_actor_act / il_actor_log_prob / il_bc_step (models.py:90-102, training.py:57-64) for those shapes; workspace >= il_actor_workspace_floats_general(S, A, H, depth, n).
+ * il_bc_step_general: out_loss [1] = mean(w * -log pi) or NULL. */
+int il_actor_act_general(const float* actor, int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t depth, int32_t activation, const float* states, int32_t ld_states, int32_t n,
+                         const float* eps, uint64_t noise_seed, uint32_t noise_offset, int32_t greedy, float* out_action, float* out_logp, float* workspace, int64_t workspace_floats,
+                         il_stream_t stream);
+int il_actor_log_prob_general(const float* actor, int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t depth, int32_t activation, const float* states, int32_t ld_states,
+                              const float* actions, int32_t ld_actions, int32_t n, float* out_logp, float* workspace, int64_t workspace_floats, il_stream_t stream);
+int il_bc_step_general(float* actor, float* actor_grad, const il_adam* opt, int32_t state_dim, int32_t action_dim, int32_t hidden, int32_t depth, int32_t activation, const il_batch* batch,
+                       float* workspace, int64_t workspace_floats, float* out_loss, uint32_t flags, il_stream_t stream);
+
 /* One environment step of the acting worker (train.py:151-168) as ONE launch:
  *   [memory.append of the pending transition, memory.py:40-44] + [wrap_for_absorbing_states, memory.py:65-68] +
  *   [actor(state).sample(), models.py:90-94], with the action returned through host-pinned, device-mapped memory.

@@ -15,12 +15,14 @@ from .nets import f32
 class SacState:
   """Flat parameter / optimiser arenas for one learner (reference objects at train.py:64-67)."""
 
-  def __init__(self, state_size, action_size, hidden=256, depth=2, activation='relu'):
+  def __init__(self, state_size, action_size, hidden=256, depth=2, activation='relu', critic_hidden=None, critic_depth=None, critic_activation=None):
+    """The critics take their own (hidden, depth, activation) when given (reinforcement.critic of the reference's configuration); default: the actor's."""
     self.S, self.A, self.H, self.depth, self.activation = state_size, action_size, hidden, depth, activation
+    self.Hc, self.depth_c, self.activation_c = critic_hidden or hidden, critic_depth or depth, critic_activation or activation
     self.actor_shapes = nets.mlp_shapes(state_size, hidden, depth, 2 * action_size)
-    self.critic_shapes = nets.mlp_shapes(state_size + action_size, hidden, depth, 1)
+    self.critic_shapes = nets.mlp_shapes(state_size + action_size, self.Hc, self.depth_c, 1)
     self.Pa = nets.mlp_numel(state_size, hidden, depth, 2 * action_size)
-    self.Pc = nets.mlp_numel(state_size + action_size, hidden, depth, 1)
+    self.Pc = nets.mlp_numel(state_size + action_size, self.Hc, self.depth_c, 1)
     z = lambda n: np.zeros(n, f32)
     self.actor, self.critic, self.target = z(self.Pa), z(2 * self.Pc), z(2 * self.Pc)
     self.log_alpha = z(1)
@@ -39,7 +41,7 @@ def critic_forward(st, flat, s, a, masks=None):
   x = np.concatenate([s, a], axis=1).astype(f32)
   outs = []
   for k in range(2):
-    q, acts = nets.mlp_forward(st.critic_layers(flat, k), x, None if masks is None else masks[k], activation=st.activation)
+    q, acts = nets.mlp_forward(st.critic_layers(flat, k), x, None if masks is None else masks[k], activation=st.activation_c)
     outs.append((q[:, 0], acts))
   return outs
 
@@ -71,7 +73,7 @@ def sac_update(st: SacState, batch, eps_next, eps_cur, *, discount, entropy_targ
   g_c = []
   for k, (q, acts) in enumerate(((q1, acts1), (q2, acts2))):
     dq = (w * (f32(2) * (q - y))) / f32(B)
-    g, _ = nets.mlp_backward(st.critic_layers(st.critic, k), acts, dq[:, None], need_dx=False, masks=mk['critic'][k] if masks else None, activation=st.activation)
+    g, _ = nets.mlp_backward(st.critic_layers(st.critic, k), acts, dq[:, None], need_dx=False, masks=mk['critic'][k] if masks else None, activation=st.activation_c)
     g_c.append(g)
   g_c = np.concatenate(g_c)
   st.t_critic += 1
@@ -88,7 +90,7 @@ def sac_update(st: SacState, batch, eps_next, eps_cur, *, discount, entropy_targ
   sel1 = np.where(qn1 < qn2, f32(1), np.where(qn1 == qn2, f32(0.5), f32(0)))
   da = np.zeros((B, A), f32)
   for k, (acts, sel) in enumerate(((actsn1, sel1), (actsn2, f32(1) - sel1))):
-    _, dx = nets.mlp_backward(st.critic_layers(st.critic, k), acts, (-(sel) / f32(B))[:, None], need_dx=True, masks=mk['pcritic'][k] if masks else None, activation=st.activation)
+    _, dx = nets.mlp_backward(st.critic_layers(st.critic, k), acts, (-(sel) / f32(B))[:, None], need_dx=True, masks=mk['pcritic'][k] if masks else None, activation=st.activation_c)
     da += dx[:, st.S:]
   c = (w * m * alpha) / f32(B)                       # dL/dlogp
   dx_pre = c[:, None] * (f32(2) * np.tanh(x)) + da * (f32(1) - an * an)

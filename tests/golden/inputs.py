@@ -45,18 +45,20 @@ def transitions(rs, n, S, A, *, state_shift=0.0, absorbing_frac=0.02, terminal_f
   return out
 
 
-def sac_case(seed, env='halfcheetah', hidden=256, batch=256, steps=3, depth=2, activation='relu'):
+def sac_case(seed, env='halfcheetah', hidden=256, batch=256, steps=3, depth=2, activation='relu', critic=None):
+  """critic: (hidden, depth, activation) of the twin critics when they differ from the actor's (reinforcement.critic of the reference's configuration)."""
   S, A = DIMS[env]
+  ch, cd, ca = critic or (hidden, depth, activation)
   rs = np.random.RandomState(seed)
   actor = mlp_params(rs, S, hidden, depth, 2 * A, out_scale=0.3)
-  critic = np.concatenate([mlp_params(rs, S + A, hidden, depth, 1) for _ in range(2)])
-  target = (critic + rs.standard_normal(critic.size).astype(f32) * f32(0.01)).astype(f32)
+  crit = np.concatenate([mlp_params(rs, S + A, ch, cd, 1) for _ in range(2)])
+  target = (crit + rs.standard_normal(crit.size).astype(f32) * f32(0.01)).astype(f32)
   log_alpha = np.array([-0.3], f32)
   batches = [transitions(rs, batch, S, A, weighted=True) for _ in range(steps)]
   eps_next = [rs.standard_normal((batch, A)).astype(f32) for _ in range(steps)]
   eps_cur = [rs.standard_normal((batch, A)).astype(f32) for _ in range(steps)]
-  return dict(S=S, A=A, H=hidden, B=batch, depth=depth, activation=activation, actor=actor, critic=critic, target=target, log_alpha=log_alpha, batches=batches,
-              eps_next=eps_next, eps_cur=eps_cur, discount=0.97, entropy_target=-0.5 * A, polyak=0.99, lr=3e-4, weight_decay=0.0)
+  return dict(S=S, A=A, H=hidden, B=batch, depth=depth, activation=activation, critic_hidden=ch, critic_depth=cd, critic_activation=ca, actor=actor, critic=crit, target=target,
+              log_alpha=log_alpha, batches=batches, eps_next=eps_next, eps_cur=eps_cur, discount=0.97, entropy_target=-0.5 * A, polyak=0.99, lr=3e-4, weight_decay=0.0)
 
 
 # General actor / critic shapes (models.py:48-69 `_create_fcnn`: any depth, relu / tanh / sigmoid) - the shapes outside the fused kernels. name -> sac_case arguments
@@ -64,6 +66,7 @@ GENERAL_SAC_CASES = {
     'sac_general_d3_tanh': dict(seed=41, env='hopper', hidden=48, batch=96, steps=3, depth=3, activation='tanh'),
     'sac_general_d1_sigmoid': dict(seed=42, env='halfcheetah', hidden=80, batch=64, steps=3, depth=1, activation='sigmoid'),
     'sac_general_d2_relu_h320': dict(seed=43, env='walker2d', hidden=320, batch=40, steps=2, depth=2, activation='relu'),
+    'sac_general_mixed': dict(seed=44, env='hopper', hidden=32, batch=50, steps=3, depth=1, activation='relu', critic=(72, 3, 'sigmoid')),   # reinforcement.actor != reinforcement.critic
 }
 
 

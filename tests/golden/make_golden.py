@@ -123,7 +123,8 @@ def gen_replay():
 # ---------------------------------------------------------------- SAC
 def build_sac(c):
   cfg = DictConfig(hidden_size=c['H'], depth=c.get('depth', 2), activation=c.get('activation', 'relu'))
-  actor, critic = ref_models.SoftActor(c['S'], c['A'], cfg), ref_models.TwinCritic(c['S'], c['A'], cfg)
+  ccfg = DictConfig(hidden_size=c.get('critic_hidden', c['H']), depth=c.get('critic_depth', c.get('depth', 2)), activation=c.get('critic_activation', c.get('activation', 'relu')))
+  actor, critic = ref_models.SoftActor(c['S'], c['A'], cfg), ref_models.TwinCritic(c['S'], c['A'], ccfg)
   torch.nn.utils.vector_to_parameters(T(c['actor']), actor.parameters())
   torch.nn.utils.vector_to_parameters(T(c['critic']), critic.parameters())
   target = ref_models.create_target_network(critic)

@@ -119,8 +119,9 @@ def crit_from_flat(critic_mod, flat_t):
 
 def make_sac(c):
   """HIP-side SAC objects initialised from a golden/inputs.py case dict."""
-  cfg = Cfg(hidden_size=c['H'], depth=2, activation='relu')
-  actor, critic = il.SoftActor(c['S'], c['A'], cfg, device=DEV), il.TwinCritic(c['S'], c['A'], cfg, device=DEV)
+  cfg = Cfg(hidden_size=c['H'], depth=c.get('depth', 2), activation=c.get('activation', 'relu'))
+  ccfg = Cfg(hidden_size=c.get('critic_hidden', c['H']), depth=c.get('critic_depth', c.get('depth', 2)), activation=c.get('critic_activation', c.get('activation', 'relu')))
+  actor, critic = il.SoftActor(c['S'], c['A'], cfg, device=DEV), il.TwinCritic(c['S'], c['A'], ccfg, device=DEV)
   actor.flat.copy_(T(c['actor'])); critic.flat.copy_(crit_to_flat(critic, c['critic']))
   target = il.create_target_network(critic)
   target.flat.copy_(crit_to_flat(critic, c['target']))
@@ -130,7 +131,7 @@ def make_sac(c):
 
 
 def make_sac_oracle(c):
-  st = osac.SacState(c['S'], c['A'], c['H'])
+  st = osac.SacState(c['S'], c['A'], c['H'], c.get('depth', 2), c.get('activation', 'relu'), c.get('critic_hidden'), c.get('critic_depth'), c.get('critic_activation'))
   st.actor[:], st.critic[:], st.target[:], st.log_alpha[:] = c['actor'], c['critic'], c['target'], c['log_alpha']
   return st
 

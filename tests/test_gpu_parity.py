@@ -171,6 +171,53 @@ def test_sac_gradients_match_oracle(golden_dir, name, args):
   close_params(crit_from_flat(critic, target.flat), st.target, 'target after split step', c['lr']); close(N(log_alpha), st.log_alpha, 'log_alpha after split step')
 
 
+@pytest.mark.parametrize('name', sorted(gi.GENERAL_SAC_CASES))
+def test_general_shape_sac_matches_oracle_and_reference(golden_dir, name):
+  """Actor / critic shapes outside the fused kernels (models.py:48-69 `_create_fcnn`: any depth, relu / tanh / sigmoid) run layer by layer through csrc/general.hip:
+  depth 3 / tanh, depth 1 / sigmoid and a 320-wide depth-2 ReLU network - sac_update for the case's steps against the oracle and against the vectors the reference
+  produced, then acting (greedy, a sample with fed noise and its log-probability), log pi of given actions and two behavioural_cloning_update steps."""
+  g, c = load(golden_dir, name), gi.sac_case(**gi.GENERAL_SAC_CASES[name])
+  actor, critic, target, log_alpha, ao, co, to = make_sac(c)
+  assert (actor.general or critic.general) and (actor.depth, actor.activation) == (c['depth'], c['activation']) and (critic.hidden, critic.depth, critic.activation) == (c['critic_hidden'], c['critic_depth'], c['critic_activation'])
+  st = make_sac_oracle(c)
+  b0 = tbatch(c['batches'][0])
+  # acting and log-probabilities on the initial actor
+  close(N(actor.get_greedy_action(b0['states'])), g['act_greedy'], 'golden greedy action', atol_scale=2e-6)
+  a, lp = actor(b0['states']).sample_with_log_prob(eps=T(c['eps_cur'][0]))
+  close(N(a), g['act_sample'], 'golden sample', atol_scale=2e-6); close(N(lp), g['act_sample_logp'], 'golden log-prob of the sample', rtol=1e-4, atol_scale=1e-5)
+  close(N(actor.log_prob(b0['states'], b0['actions'])), g['act_logp_given'], 'golden log-prob of given actions', rtol=1e-4, atol_scale=1e-5)
+  steps = len(c['batches'])
+  for k in range(1, steps + 1):
+    b = c['batches'][k - 1]
+    logp, q = il.sac_update(actor, critic, log_alpha, target, tbatch(b), ao, co, to, c['discount'], c['entropy_target'], c['polyak'], eps_next=T(c['eps_next'][k - 1]),
+                            eps_cur=T(c['eps_cur'][k - 1]))
+    ologp, oq = osac.sac_update(st, b, c['eps_next'][k - 1], c['eps_cur'][k - 1], discount=c['discount'], entropy_target=c['entropy_target'], polyak_factor=c['polyak'],
+                                lr=c['lr'], weight_decay=c['weight_decay'])
+    torch.cuda.synchronize()
+    s = 1e-5 * k
+    close(N(logp), ologp, f'logp step {k}', atol_scale=2e-6 * k); close(N(q), oq, f'q step {k}', atol_scale=2e-6 * k)
+    close_params(N(actor.flat), st.actor, f'general actor step {k}', c['lr'], k); close_params(crit_from_flat(critic, critic.flat), st.critic, f'general critic step {k}', c['lr'], k)
+    close_params(crit_from_flat(critic, target.flat), st.target, f'general target step {k}', c['lr'], k); close(N(log_alpha), st.log_alpha, f'log_alpha step {k}')
+    close(N(ao.exp_avg), st.actor_m, f'actor m step {k}', atol_scale=s); close(crit_from_flat(critic, co.exp_avg), st.critic_m, f'critic m step {k}', atol_scale=s)
+    close(N(logp), g[f'logp_{k}'], f'golden logp {k}', atol_scale=2e-6 * k); close(N(q), g[f'q_{k}'], f'golden q {k}', atol_scale=2e-6 * k)
+    close_params(gi.strided(N(actor.flat)), g[f'actor_{k}'], f'golden general actor {k}', c['lr'], k)
+    close_params(gi.strided(crit_from_flat(critic, critic.flat)), g[f'critic_{k}'], f'golden general critic {k}', c['lr'], k)
+    close_params(gi.strided(crit_from_flat(critic, target.flat)), g[f'target_{k}'], f'golden general target {k}', c['lr'], k)
+    close(N(log_alpha), g[f'log_alpha_{k}'], f'golden log_alpha {k}')
+  assert int(ao.step_count[0]) == steps and int(co.step_count[0]) == steps and int(to.step_count[0]) == steps
+  # behavioural cloning from the initial parameters (training.py:57-64)
+  actor2 = make_sac(gi.sac_case(**gi.GENERAL_SAC_CASES[name]))[0]
+  opt = il.AdamW(actor2, lr=2.5e-4, weight_decay=0.01)
+  for k in (1, 2):
+    il.behavioural_cloning_update(actor2, tbatch(c['batches'][k % steps]), opt)
+    torch.cuda.synchronize()
+    if k == 1: close(gi.strided(N(opt.grad)), g['bc_g_actor_1'], 'golden behavioural-cloning gradient')
+    close_params(gi.strided(N(actor2.flat)), g[f'bc_actor_{k}'], f'golden general actor after BC step {k}', 2.5e-4, k)
+  # plans and the acting worker refuse these shapes loudly
+  with pytest.raises(NotImplementedError):
+    il.UpdatePlan('SAC', actor, critic, log_alpha, target, il.ReplayMemory(64, c['S'], c['A'], True, device=DEV), ao, co, to, 16, 0.97, -1.0, 0.99)
+
+
 def test_bc_update_matches_oracle_and_reference(golden_dir):
   g = load(golden_dir, 'bc_hopper')
   S, A = gi.DIMS['hopper']

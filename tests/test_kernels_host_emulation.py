@@ -402,7 +402,7 @@ def _emulated_product(monkeypatch, streams=False):
 # mailbox and the multi-process paths need streams, graphs or a second process, i.e. a GPU)
 GPU_BODIES = (
     'test_replay_matches_reference_bit_exact', 'test_transfer_transitions_matches_sequential_appends', 'test_replay_full_size_gather_property',
-    'test_sac_update_matches_oracle_and_reference', 'test_sac_gradients_match_oracle', 'test_sac_update_other_shapes',
+    'test_sac_update_matches_oracle_and_reference', 'test_sac_gradients_match_oracle', 'test_sac_update_other_shapes', 'test_general_shape_sac_matches_oracle_and_reference',
     'test_bc_update_matches_oracle_and_reference', 'test_actor_act_matches_oracle', 'test_adam_and_polyak_kernels',
     'test_gail_update_matches_oracle_and_reference', 'test_gail_loss_variants_match_reference', 'test_gail_ragged_batch_and_state_only',
     'test_gmmil_matches_oracle_and_reference', 'test_gmmil_full_size_properties', 'test_pwil_matches_oracle_and_reference', 'test_pwil_every_launch_path_matches_oracle',

@@ -53,7 +53,7 @@ def test_replay_bit_exact(golden_dir, name, seed, size, fill):
 
 # ------------------------------------------------------------------ SAC
 def run_sac_oracle(c, steps):
-  st = sac.SacState(c['S'], c['A'], c['H'], c.get('depth', 2), c.get('activation', 'relu'))
+  st = sac.SacState(c['S'], c['A'], c['H'], c.get('depth', 2), c.get('activation', 'relu'), c.get('critic_hidden'), c.get('critic_depth'), c.get('critic_activation'))
   st.actor[:], st.critic[:], st.target[:], st.log_alpha[:] = c['actor'], c['critic'], c['target'], c['log_alpha']
   outs = []
   for i in range(steps):

@@ -43,6 +43,10 @@ COMMON = ['steps=260', 'training.start=120', 'evaluation.interval=130', 'evaluat
     ['algorithm=SAC', 'env=walker2d', '+acting.schedule=fused'],
     ['algorithm=GAIL', 'env=walker2d', '+acting.schedule=per_function'],
     ['algorithm=BC', 'env=hopper', 'bc_pretraining.iterations=60'],
+    # actor / critic shapes outside the fused kernels (models.py:48-69: any depth, relu / tanh / sigmoid; reinforcement.actor and reinforcement.critic configured separately): csrc/general.hip
+    ['algorithm=SAC', 'env=hopper', 'reinforcement.actor.depth=3', 'reinforcement.actor.activation=tanh', 'reinforcement.actor.hidden_size=48', 'reinforcement.critic.depth=1',
+     'reinforcement.critic.activation=sigmoid', 'reinforcement.critic.hidden_size=80'],
+    ['algorithm=GAIL', 'env=halfcheetah', 'reinforcement.actor.hidden_size=320', 'reinforcement.critic.hidden_size=320', 'bc_pretraining.iterations=20'],
 ])
 def test_train_runs(tmp_path, args):
   sys.path.insert(0, ROOT)
@@ -54,7 +58,7 @@ def test_train_runs(tmp_path, args):
   assert np.isfinite(score)
   agent = torch.load(tmp_path / 'agent.pth', weights_only=False)
   assert 'actor' in agent and all(torch.isfinite(v).all() for v in agent['actor'].values())
-  assert set(agent['actor']) == {'actor.0.weight', 'actor.0.bias', 'actor.2.weight', 'actor.2.bias', 'actor.4.weight', 'actor.4.bias'}
+  assert set(agent['actor']) == {f'actor.{2 * l}.{p}' for l in range(cfg.reinforcement.actor.depth + 1) for p in ('weight', 'bias')}   # Sequential slots: Linear, activation, Linear, ...
   metrics = torch.load(tmp_path / 'metrics.pth', weights_only=False)
   if cfg.algorithm != 'BC':
     assert 'critic_1.critic.0.weight' in agent['critic'] and len(metrics['update_steps']) >= 2

@@ -173,6 +173,8 @@ def train(cfg, file_prefix: str = '') -> float:
                                   or cfg.imitation.discriminator.subtract_log_policy or cfg.imitation.discriminator.reward_shaping
                                   or (cfg.imitation.discriminator.depth, cfg.imitation.discriminator.activation) != (1, 'relu')):
     fusable = False   # per-update host inputs (Beta(alpha != 1) draws) / an extra actor pass / a mix between the discriminator step and the relabel: per-function path
+  general = bool(getattr(actor, 'general', False) or getattr(critic, 'general', False))   # reinforcement.actor / critic outside depth 2 / relu / hidden <= 256 (csrc/general.hip)
+  if general: fusable = False
   if fusable:
     plan = il.UpdatePlan(cfg.algorithm, actor, critic, log_alpha, target_critic, memory, actor_optimiser, critic_optimiser, temperature_optimiser, B, cfg.reinforcement.discount,
                          entropy_target, cfg.reinforcement.polyak_factor, expert_memory=expert_memory, discriminator=discriminator, discriminator_optimiser=discriminator_optimiser,
@@ -188,7 +190,7 @@ def train(cfg, file_prefix: str = '') -> float:
   # acting (train.py:151-168): il_act_step through a pinned mailbox; PWIL computes its reward per step on the device and keeps the per-function path
   schedule = (cfg.get('acting', {}) or {}).get('schedule', 'exact')  # `+acting.schedule=fused|overlap`: see imitation_learning_amd/acting.py (behaviour policy lags 1-2 updates)
   assert schedule in ('exact', 'fused', 'overlap', 'per_function')
-  worker = il.ActingWorker(actor, memory, mirror=schedule == 'overlap') if cfg.algorithm != 'PWIL' and schedule != 'per_function' else None
+  worker = il.ActingWorker(actor, memory, mirror=schedule == 'overlap') if cfg.algorithm != 'PWIL' and schedule != 'per_function' and not general else None
   if worker is None: schedule = 'per_function'
   if schedule == 'overlap' and world > 1:
     raise NotImplementedError('+acting.schedule=overlap with distributed.world_size > 1: the overlap schedule captures the append in the update plan\'s hooks, which the '
