@@ -204,6 +204,7 @@ class DropoutSoftActor(SoftActor):
   the Monte-Carlo-dropout uncertainty runs k_dril_unc.  Pass `masks=(mask_in, mask_hidden[, mask_hidden2])` to reproduce given dropout draws; otherwise
   the masks come from the on-chip Philox stream.  state_dict keys: actor.N.* with the Dropout / activation modules occupying Sequential slots too."""
   ENSEMBLE = 5
+  general = False   # (its kernels are k_dril_*: never the general-shape engine of csrc/general.hip)
 
   def __init__(self, state_size: int, action_size: int, model_cfg, device=None):
     nn.Module.__init__(self)
