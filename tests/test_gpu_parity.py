@@ -577,12 +577,18 @@ def test_sac_update_other_shapes(env, hidden, batch):
 
 
 def test_unsupported_shapes_and_options_fail_loudly():
+  # shapes outside the fused kernels run through csrc/general.hip (test_general_shape_sac_matches_oracle_and_reference); what that engine does not cover still raises
+  assert il.SoftActor(18, 6, Cfg(hidden_size=256, depth=3, activation='relu')).general and il.SoftActor(18, 6, Cfg(hidden_size=100, depth=2, activation='relu')).general
+  assert il.TwinCritic(18, 6, Cfg(hidden_size=256, depth=2, activation='tanh')).general and not il.TwinCritic(18, 6, Cfg(hidden_size=256, depth=2, activation='relu')).general
+  assert il.SoftActor(18, 12, Cfg(hidden_size=256, depth=2, activation='relu')).general   # 2A > 16: the fused head is too narrow
   with pytest.raises(NotImplementedError):
-    il.SoftActor(18, 6, Cfg(hidden_size=256, depth=3, activation='relu'))
+    il.SoftActor(18, 6, Cfg(hidden_size=256, depth=9, activation='relu'))
   with pytest.raises(NotImplementedError):
-    il.SoftActor(18, 6, Cfg(hidden_size=100, depth=2, activation='relu'))
+    il.TwinCritic(18, 6, Cfg(hidden_size=4096, depth=2, activation='relu'))
+  with pytest.raises(ValueError):
+    il.SoftActor(18, 6, Cfg(hidden_size=256, depth=2, activation='gelu'))
   with pytest.raises(NotImplementedError):
-    il.TwinCritic(18, 6, Cfg(hidden_size=256, depth=2, activation='tanh'))
+    il.TwinCritic(18, 6, Cfg(hidden_size=256, depth=2, activation='relu', dropout=0.1))
   c = gi.sac_case(3, 'halfcheetah', 256, 24, 1)   # batch not a multiple of the 16-row tile
   actor, critic, target, log_alpha, ao, co, to = make_sac(c)
   with pytest.raises(RuntimeError, match='multiple of 16'):
