@@ -75,15 +75,15 @@ __device__ __forceinline__ void sn_wave(const float* W1s, const float* W2s, int 
 // LDS store (the rows are D floats long - 23 at HalfCheetah dims - so a row-wise copy is a dword per load, and a load -> store loop makes one fabric round trip per
 // element a thread owns: 24 of them in a 256-thread workgroup, 7.8 us of a 21 us k_gail_grad workgroup on the population path, profiles/r04_population_disc_timeline.txt).
 // NV = 16-byte lanes per thread per round. The caller zeroes the padding columns [D, Dp). Same values in the same places: bit-identical to the element loop.
-template <int NV> struct W1Stage { f32x4 v[NV]; };
-__device__ __forceinline__ bool w1_flat_ok(const float* W1, int D, int H) { return ((reinterpret_cast<uintptr_t>(W1) & 15) == 0) && ((H * D) & 3) == 0; }
+template <int NV> struct DiscW1 { f32x4 v[NV]; };
+__device__ __forceinline__ bool disc_w1_flat_ok(const float* W1, int D, int H) { return ((reinterpret_cast<uintptr_t>(W1) & 15) == 0) && ((H * D) & 3) == 0; }
 template <int NV>
-__device__ __forceinline__ void w1_issue(W1Stage<NV>& s, const float* __restrict__ W1, int nvec, int base) {
+__device__ __forceinline__ void disc_w1_issue(DiscW1<NV>& s, const float* __restrict__ W1, int nvec, int base) {
 #pragma unroll
   for (int q = 0; q < NV; ++q) s.v[q] = gload4(W1 + 4 * (size_t)min(base + q * (int)blockDim.x + (int)threadIdx.x, nvec - 1));
 }
 template <int NV>
-__device__ __forceinline__ void w1_commit(const W1Stage<NV>& s, float* W1s, int D, int ldw, int nvec, int base, unsigned magic_d) {   // (H * D < 2^16: the rows fit the LDS)
+__device__ __forceinline__ void disc_w1_commit(const DiscW1<NV>& s, float* W1s, int D, int ldw, int nvec, int base, unsigned magic_d) {   // (H * D < 2^16: the rows fit the LDS)
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     const int i = base + q * (int)blockDim.x + (int)threadIdx.x;
@@ -94,7 +94,7 @@ __device__ __forceinline__ void w1_commit(const W1Stage<NV>& s, float* W1s, int 
     }
   }
 }
-__device__ __forceinline__ void w1_zero_padding(float* W1s, int D, int Dp, int H, int ldw) {
+__device__ __forceinline__ void disc_w1_zero_padding(float* W1s, int D, int Dp, int H, int ldw) {
   const int pad = Dp - D;
   for (int i = threadIdx.x; i < H * pad; i += blockDim.x) { const int n = i / pad, k = D + (i - n * pad); W1s[n * ldw + k] = 0.f; }
 }
@@ -121,11 +121,11 @@ __device__ __forceinline__ void disc_reward_tile(const il_disc& d, const RewardL
     // u / v: 4.5 us of the relabel's 6 (profiles/r04_update_timeline.md).
     const float* W1 = d.params + lay.oW1; const float* b1 = d.params + lay.ob1; const float* W2 = d.params + lay.oW2;
     const int bd = blockDim.x, sn = d.spectral_norm, th = min(tid, H - 1), tk = min(tid, D - 1);
-    const bool flat = w1_flat_ok(W1, D, H);
+    const bool flat = disc_w1_flat_ok(W1, D, H);
     const int nvec = (H * D) >> 2;
     const unsigned md = fastdiv_magic(Dp), mdd = fastdiv_magic(D);   // (H * Dp < 2^16 for every shape whose tile fits the LDS)
-    W1Stage<NV> ws; float v[4];
-    if (flat) w1_issue(ws, W1, nvec, 0);
+    DiscW1<NV> ws; float v[4];
+    if (flat) disc_w1_issue(ws, W1, nvec, 0);
     else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) { const int i = min(q * bd + tid, H * Dp - 1), n = fastdiv(i, md), k = min(i - n * Dp, D - 1); v[q] = gload(W1 + (size_t)n * D + k); }
@@ -134,9 +134,9 @@ __device__ __forceinline__ void disc_reward_tile(const il_disc& d, const RewardL
     float vu1 = 0.f, vv2 = 0.f, vv1 = 0.f, vu2 = 0.f;
     if (sn) { vu1 = gload(d.u1 + th); vv2 = gload(d.v2 + th); vv1 = gload(d.v1 + tk); vu2 = gload(d.u2); }
     if (flat) {
-      w1_commit(ws, L.W1s, D, ldw, nvec, 0, mdd);
-      for (int base = NV * bd; base < nvec; base += NV * bd) { w1_issue(ws, W1, nvec, base); w1_commit(ws, L.W1s, D, ldw, nvec, base, mdd); }   // (shapes beyond NV lanes per thread)
-      w1_zero_padding(L.W1s, D, Dp, H, ldw);
+      disc_w1_commit(ws, L.W1s, D, ldw, nvec, 0, mdd);
+      for (int base = NV * bd; base < nvec; base += NV * bd) { disc_w1_issue(ws, W1, nvec, base); disc_w1_commit(ws, L.W1s, D, ldw, nvec, base, mdd); }   // (shapes beyond NV lanes per thread)
+      disc_w1_zero_padding(L.W1s, D, Dp, H, ldw);
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) { const int i = q * bd + tid; if (i < H * Dp) { const int n = fastdiv(i, md), k = i - n * Dp; L.W1s[n * ldw + k] = k < D ? v[q] : 0.f; } }

@@ -139,15 +139,15 @@ __device__ __forceinline__ DiscLds carve(float* s, int D, int H) {
 // stage W1 (padded rows), b1, W2 into LDS
 __device__ __forceinline__ void stage_weights(const DiscLds& L, const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2, int D, int H) {
   const int Dp = L.Dp, ldw = Dp + 4, tid = threadIdx.x, bd = blockDim.x;
-  if (w1_flat_ok(W1, D, H)) {   // (round 4) 16-byte lanes of the flat array, six per thread in flight (disc_reward.hpp)
+  if (disc_w1_flat_ok(W1, D, H)) {   // (round 4) 16-byte lanes of the flat array, six per thread in flight (disc_reward.hpp)
     const int nvec = (H * D) >> 2;
     const unsigned mdd = fastdiv_magic(D);
-    W1Stage<6> ws;
-    w1_issue(ws, W1, nvec, 0);
+    DiscW1<6> ws;
+    disc_w1_issue(ws, W1, nvec, 0);
     const float vb1 = gload(b1 + min(tid, H - 1)), vw2 = gload(W2 + min(tid, H - 1));
-    w1_commit(ws, L.W1s, D, ldw, nvec, 0, mdd);
-    for (int base = 6 * bd; base < nvec; base += 6 * bd) { w1_issue(ws, W1, nvec, base); w1_commit(ws, L.W1s, D, ldw, nvec, base, mdd); }
-    w1_zero_padding(L.W1s, D, Dp, H, ldw);
+    disc_w1_commit(ws, L.W1s, D, ldw, nvec, 0, mdd);
+    for (int base = 6 * bd; base < nvec; base += 6 * bd) { disc_w1_issue(ws, W1, nvec, base); disc_w1_commit(ws, L.W1s, D, ldw, nvec, base, mdd); }
+    disc_w1_zero_padding(L.W1s, D, Dp, H, ldw);
     if (tid < H) { L.b1s[tid] = vb1; L.W2s[tid] = vw2; }
     for (int i = bd + tid; i < H; i += bd) { L.b1s[i] = b1[i]; L.W2s[i] = W2[i]; }
     return;
@@ -675,7 +675,8 @@ extern "C" int il_gail_step_population(const il_disc* descs_dev, const il_batch*
   hipStream_t st = (hipStream_t)stream_;
   const int D = d->state_dim + (d->state_only ? 0 : d->action_dim), nt = ceil_div(d->batch, IL_TILE_R), L = n_learners;
   static const int compact = [] { const char* e = getenv("IL_POP_DISC_LDS"); return e && e[0] == '0' ? 0 : 1; }();   // IL_POP_DISC_LDS=0: one workgroup per CU, as in round 3 (A/B)
-  const size_t lds = compact ? disc_lds_floats(D, d->hidden) * sizeof(float) : (size_t)96 * 1024, lds_r = compact ? disc_reward_lds_floats(D, d->hidden) * sizeof(float) : lds;
+  const size_t need = disc_lds_floats(D, d->hidden) * sizeof(float);
+  const size_t lds = compact || need > (size_t)96 * 1024 ? need : (size_t)96 * 1024, lds_r = compact ? disc_reward_lds_floats(D, d->hidden) * sizeof(float) : lds;
   if (int rc = ensure_lds((const void*)k_gail_grad_pop, lds)) return rc;
   if (int rc = ensure_lds((const void*)k_gail_reward, lds_r)) return rc;
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
