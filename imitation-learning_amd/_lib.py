@@ -136,6 +136,7 @@ _SIGNATURES = {
     'il_mt19937_sample_indices_device': (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     'il_struct_size': (C.c_int32, [C.c_int32]),
     'il_noise_fill': (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, _P, _P]),
+    'il_noise_fill_beta': (C.c_int, [C.c_uint64, _P, C.c_float, C.c_int64, _P, _P]),
     'il_sync_probe': (C.c_int, [_P, C.c_int32, _P]),
     'il_replay_gather_workgroups': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     'il_replay_sample_device': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),

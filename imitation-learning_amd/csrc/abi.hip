@@ -109,6 +109,20 @@ extern "C" int il_noise_fill(uint64_t noise_seed, uint32_t ctr, uint32_t stream_
   return IL_OK;
 }
 
+// il_noise_fill_beta: n Beta(alpha, alpha) draws of the Mixup stream at the update counter *ctr_dev (read on the DEVICE, so the launch can sit in a captured update: the
+// counter is the discriminator's noise_counter, advanced once per update by the actor step). `out` is then passed as il_gail_extra.eps_mix (training.py:105-107).
+__global__ void k_noise_fill_beta(uint64_t seed, const uint32_t* __restrict__ ctr_dev, float alpha, long long n, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = philox_beta(seed, ctr_dev ? *ctr_dev : 0u, IL_STREAM_MIX, (uint32_t)i, alpha);
+}
+extern "C" int il_noise_fill_beta(uint64_t noise_seed, const uint32_t* ctr_dev, float alpha, int64_t n, float* out, il_stream_t stream) {
+  IL_CHECK_ARG(out && n >= 0 && n < (1LL << 32) && alpha > 0.f, "il_noise_fill_beta: bad arguments (alpha must be > 0: train.py:46)");
+  if (n == 0) return IL_OK;
+  k_noise_fill_beta<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(noise_seed, ctr_dev, alpha, (long long)n, out);
+  IL_CHECK_LAUNCH("il_noise_fill_beta");
+  return IL_OK;
+}
+
 // sizeof() of the descriptor structs as this library was compiled: a binding checks its own struct definitions against these
 // (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red, 7 il_dril, 8 il_disc_shaped, 9 il_disc_deep, 10 il_peer_bucket).
 extern "C" int32_t il_struct_size(int32_t which) {

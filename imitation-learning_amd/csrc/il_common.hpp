@@ -174,6 +174,31 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t ctr, uin
   const philox_out o = philox4x32_10(idx, ctr, stream_id, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
   return (float)(o.v[0] >> 8) * (1.0f / 16777216.0f);  // [0,1) like torch.rand
 }
+// Beta(alpha, alpha) #idx of stream `stream_id` at update `ctr` (Mixup's coefficients, training.py:105-107, for alpha != 1; Beta(1, 1) is philox_uniform): X / (X + Y) with
+// X, Y ~ Gamma(alpha) by Marsaglia & Tsang's squeeze-free form (alpha < 1: Gamma(alpha + 1) U^(1/alpha)). Attempt t of variate `which` keys the Philox counter's fourth word
+// (1 + 2 t + which; word 0 is philox_uniform's), so a draw is a pure function of (seed, ctr, stream, idx, alpha): every workgroup that needs row idx's coefficient computes
+// the same bits. The reference draws with torch's CPU Beta sampler: equal in distribution, not in bits.
+__device__ __forceinline__ float philox_gamma(uint64_t seed, uint32_t ctr, uint32_t stream_id, uint32_t idx, float alpha, uint32_t which) {
+  const float a = alpha < 1.f ? alpha + 1.f : alpha, d = a - 1.f / 3.f, c = 1.f / sqrtf(9.f * d);
+  float out = d;   // (never left as is: 64 attempts at a > 95 % acceptance rate)
+  for (uint32_t t = 0; t < 64u; ++t) {
+    const philox_out o = philox4x32_10(idx, ctr, stream_id, 1u + 2u * t + which, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float x = sqrtf(-2.0f * logf(u32_to_unit_open(o.v[0]))) * cosf(6.28318530717958647692f * u32_to_unit_open(o.v[1]));
+    const float v0 = 1.f + c * x;
+    if (v0 <= 0.f) continue;
+    const float v = v0 * v0 * v0, u = u32_to_unit_open(o.v[2]);
+    if (logf(u) < 0.5f * x * x + d - d * v + d * logf(v)) {
+      out = d * v;
+      if (alpha < 1.f) out *= powf(u32_to_unit_open(o.v[3]), 1.f / alpha);
+      break;
+    }
+  }
+  return out;
+}
+__device__ __forceinline__ float philox_beta(uint64_t seed, uint32_t ctr, uint32_t stream_id, uint32_t idx, float alpha) {
+  const float x = philox_gamma(seed, ctr, stream_id, idx, alpha, 0u), y = philox_gamma(seed, ctr, stream_id, idx, alpha, 1u);
+  return x / (x + y);
+}
 enum { IL_STREAM_EPS_NEXT = 1, IL_STREAM_EPS_CUR = 2, IL_STREAM_GP = 3, IL_STREAM_ACT = 4, IL_STREAM_MIX = 7 };   // 5, 6: dropout masks (dril.hip)
 
 // ---------------------------------------------------------------------------------------------

@@ -438,11 +438,18 @@ class UpdatePlan:
       host_mixup = imitation_cfg is not None and imitation_cfg.loss_function == 'Mixup' and float(_cfg_value(imitation_cfg, 'mixup_alpha', 1.0)) != 1.0
       deep = type(discriminator).__name__ == 'DeepGAILDiscriminator'   # depth 2 / tanh: the general kernels, per-function path
       pu_margin = imitation_cfg is not None and imitation_cfg.loss_function == 'PUGAIL' and float(_cfg_value(imitation_cfg, 'nonnegative_margin', float('inf'))) != float('inf')
-      if imitation_cfg is not None and (host_mixup or deep or pu_margin or discriminator.subtract_log_policy or getattr(discriminator, 'reward_shaping', False)):
-        # Mixup with alpha = 1 draws its Beta(1, 1) = U(0, 1) coefficients from the on-chip Philox stream like the gradient penalty does: capturable
-        raise NotImplementedError('UpdatePlan: GAIL with Mixup (alpha != 1: Beta draws on the host) / PUGAIL with a finite margin / subtract_log_policy / reward shaping / a depth-2 or tanh discriminator runs through '
+      if imitation_cfg is not None and (deep or pu_margin or discriminator.subtract_log_policy or getattr(discriminator, 'reward_shaping', False)):
+        raise NotImplementedError('UpdatePlan: GAIL with PUGAIL with a finite margin / subtract_log_policy / reward shaping / a depth-2 or tanh discriminator runs through '
                                   'adversarial_imitation_update + sac_update')
       self.disc = disc_descriptor(discriminator, batch_size, discriminator_optimiser, imitation_cfg, tag=tag, seed_offset=off)
+      # Mixup (training.py:105-107): Beta(1, 1) = U(0, 1) coefficients come from the on-chip Philox stream inside the discriminator kernel, like the gradient penalty's. For
+      # alpha != 1 (the reference draws them with torch's CPU Beta sampler: a host input per update) a launch captured ahead of the discriminator step draws them on the
+      # device (il_noise_fill_beta: same distribution, Philox bits) into `eps_mix`, which that step takes as il_gail_extra.eps_mix. The launch reads the update counter on the
+      # device, so it has to be stream-ordered behind the previous update's actor step: such a plan keeps plain stream dependencies (no device-side hand-off).
+      self._beta_alpha = float(_cfg_value(imitation_cfg, 'mixup_alpha', 1.0)) if host_mixup else None
+      if self._beta_alpha is not None:
+        self.eps_mix = torch.empty(batch_size, device=dev)
+        self._mix_extra = _lib.GailExtra(); self._mix_extra.eps_mix = self.eps_mix.data_ptr()
       self.rewards = torch.empty(batch_size, device=dev)
       self.transitions['rewards'] = self.rewards  # train.py:194: rewards replaced by the discriminator's prediction
     self.pb = batch_desc(self.transitions)
@@ -454,7 +461,7 @@ class UpdatePlan:
     self._chain_fits = None
     self.pre_hooks, self.post_hooks = [], []   # callables enqueuing extra work on the update's stream before / after it (captured with it), e.g. ActingWorker
     self.stream_ordered_draw = False   # True: the index draw stays the first kernel of the SAC branch (bit-identical; what per-kernel timing wants: see bench.py roofline())
-    if self._two_stream and device_index_draw and os.environ.get('IL_DEVICE_SYNC', '1') != '0':
+    if self._two_stream and device_index_draw and os.environ.get('IL_DEVICE_SYNC', '1') != '0' and getattr(self, '_beta_alpha', None) is None:
       # HIP multiplexes streams onto a few hardware queues (round-robin at creation): a side stream that landed on the caller's queue runs serialised with it and
       # fails the probe. Another stream usually lands elsewhere: try a few (the rejected ones stay alive meanwhile, so that the next one gets a different queue).
       ok, rejected = self._probe_device_sync(graph=False), []
@@ -707,7 +714,15 @@ class UpdatePlan:
       self._disc_step(0)
       _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(rp), _lib.ptr(self.rewards), None, None, st))
       return
-    _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))
+    self._disc_step_and_relabel_on_gathered_rows(st)
+
+  def _disc_step_and_relabel_on_gathered_rows(self, st):
+    """train.py:178-194 on the gathered batches (the stream-dependency schedules): discriminator step, then the relabel kernel."""
+    L, extra = _lib.lib(), None
+    if getattr(self, '_beta_alpha', None) is not None:   # this update's Beta(alpha, alpha) coefficients, drawn on the device (see __init__)
+      _lib.check(L.il_noise_fill_beta(C.c_uint64(self.disc.noise_seed), self.disc.noise_counter, self._beta_alpha, self.B, _lib.ptr(self.eps_mix), st))
+      extra = C.byref(self._mix_extra)
+    _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, extra, 0, st))
     _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
 
   def _fused_exchange_needs_the_resident_sampler(self):
@@ -764,9 +779,7 @@ class UpdatePlan:
       self.sample_all()
       self.side.wait_stream(main)                                   # the discriminator needs the sampled batches
       with torch.cuda.stream(self.side):
-        st = _lib.stream_ptr()
-        _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))
-        _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
+        self._disc_step_and_relabel_on_gathered_rows(_lib.stream_ptr())
       st = _lib.stream_ptr()
       _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), fwd, st))
       main.wait_stream(self.side)                                   # join: the critic loss reads the rewards
@@ -798,8 +811,7 @@ class UpdatePlan:
     if self.algorithm != 'GAIL':
       self.sac.sync = None   # one stream from here on: no kernel of this schedule hands anything over on the device (the critic loss would wait for [IL_SYNC_REWARDS])
     if self.algorithm == 'GAIL':
-      _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, None, 0, st))
-      _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
+      self._disc_step_and_relabel_on_gathered_rows(st)
     else:
       self._enqueue_reward_model(st)
     flag = self.prepared_flag()

@@ -69,6 +69,10 @@ int il_trace_report(char* buf_host, int len);
  *   repeat_interleave order for the 5-member ensemble; ctr = the call's noise_offset (+ *il_dril.noise_counter). */
 enum { IL_NOISE_EPS_NEXT = 1, IL_NOISE_EPS_CUR = 2, IL_NOISE_GP = 3, IL_NOISE_ACT = 4, IL_NOISE_DROP_IN = 5, IL_NOISE_DROP_HID = 6, IL_NOISE_MIX = 7, IL_NOISE_DROP_HID2 = 11 };
 int il_noise_fill(uint64_t noise_seed, uint32_t ctr, uint32_t stream_id, int64_t n, float* out, il_stream_t stream);
+/* n Beta(alpha, alpha) draws (Mixup with mixup_alpha != 1, training.py:105-107) of the Mixup stream at the update counter *ctr_dev, read on the DEVICE: the launch can sit
+ * in a captured update ahead of il_gail_disc_step, which takes `out` as il_gail_extra.eps_mix. Philox + Marsaglia-Tsang: equal in distribution to torch's CPU Beta sampler,
+ * not in bits; a pure function of (noise_seed, *ctr_dev, index, alpha). */
+int il_noise_fill_beta(uint64_t noise_seed, const uint32_t* ctr_dev, float alpha, int64_t n, float* out, il_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * A batch of transitions as strided fp32 fields: row b of field f is f + b*ld_f.

@@ -413,7 +413,7 @@ def test_pwil_every_launch_path_matches_oracle(name, Nn, Th):
   assert int((d.expert_weights >= 0).sum()) == len(o.weights)
 
 
-def _make_plan(algorithm, seed, device_draw=True, loss='BCE', entropy_bonus=0.0, B=256, margin=float('inf'), reward_function='AIRL'):
+def _make_plan(algorithm, seed, device_draw=True, loss='BCE', entropy_bonus=0.0, B=256, margin=float('inf'), reward_function='AIRL', mixup_alpha=1):
   S, A = gi.DIMS['halfcheetah']
   torch.manual_seed(seed)
   cfg = Cfg(hidden_size=256, depth=2, activation='relu')
@@ -423,7 +423,7 @@ def _make_plan(algorithm, seed, device_draw=True, loss='BCE', entropy_bonus=0.0,
   rs = np.random.RandomState(seed)
   mem = il.ReplayMemory(20000, S, A, True, device=DEV); fill_memory(mem, gi.transitions(rs, 5000, S, A), 5000)
   emem = il.ReplayMemory(2000, S, A, True, device=DEV); fill_memory(emem, gi.transitions(rs, 2000, S, A, state_shift=0.5), 2000)
-  icfg = Cfg(state_only=False, spectral_norm=True, loss_function=loss, grad_penalty=1.0, entropy_bonus=entropy_bonus, mixup_alpha=1, pos_class_prior=0.7, nonnegative_margin=margin,
+  icfg = Cfg(state_only=False, spectral_norm=True, loss_function=loss, grad_penalty=1.0, entropy_bonus=entropy_bonus, mixup_alpha=mixup_alpha, pos_class_prior=0.7, nonnegative_margin=margin,
              discriminator=Cfg(hidden_size=64, depth=1, activation='relu', reward_shaping=False, subtract_log_policy=False, reward_function=reward_function))
   disc = il.GAILDiscriminator(S, A, icfg, 0.97, device=DEV)
   do = il.AdamW(disc, lr=3e-5, weight_decay=10)
@@ -447,6 +447,70 @@ def test_inline_relabel_heads_equal_the_reward_kernel(reward_function):
   torch.cuda.synchronize()
   assert np.isfinite(N(plan.rewards)).all() and (N(plan.rewards) > 0).any() == (reward_function != 'FAIRL' or (N(want) > 0).any())
   np.testing.assert_array_equal(N(plan.rewards), N(want))
+
+
+def _beta_draws(seed, counter, alpha, n):
+  """il_noise_fill_beta for the update counter `counter` (include/il_hip.h): what a captured Mixup update with mixup_alpha != 1 consumes."""
+  ctr, out = torch.tensor([counter], dtype=torch.int32, device=DEV), torch.empty(n, device=DEV)
+  _lib.check(_lib.lib().il_noise_fill_beta(C.c_uint64(seed), _lib.ptr(ctr), alpha, n, _lib.ptr(out), _lib.stream_ptr()))
+  return N(out)
+
+
+@pytest.mark.parametrize('alpha', [0.3, 0.5, 2.0, 7.5])
+def test_device_beta_draws_are_beta_distributed(alpha):
+  """training.py:105-107 draws the Mixup coefficients from Beta(alpha, alpha) with torch's CPU sampler; a captured update draws them on the device (Philox + Marsaglia-Tsang,
+  il_noise_fill_beta): the same distribution - Kolmogorov-Smirnov against scipy's Beta, mean 1/2, variance 1 / (4 (2 alpha + 1)) - inside (0, 1), a pure function of
+  (key, counter, index), different and uncorrelated for another counter or key."""
+  from scipy import stats
+  n = 200_000
+  u = _beta_draws(12345, 7, alpha, n).astype(np.float64)
+  assert np.isfinite(u).all() and 0.0 <= u.min() and u.max() <= 1.0
+  assert stats.kstest(u, stats.beta(alpha, alpha).cdf).pvalue > 1e-3
+  var = 1.0 / (4.0 * (2.0 * alpha + 1.0))
+  assert abs(u.mean() - 0.5) < 5 * np.sqrt(var / n) and abs(u.var() - var) < 0.02 * var
+  np.testing.assert_array_equal(u, _beta_draws(12345, 7, alpha, n).astype(np.float64))
+  for other in (_beta_draws(12345, 8, alpha, n), _beta_draws(12346, 7, alpha, n)):
+    assert abs(np.corrcoef(u, other)[0, 1]) < 5 / np.sqrt(n)
+
+
+@pytest.mark.parametrize('alpha', [0.4, 2.5])
+def test_update_plan_mixup_with_beta_coefficients_drawn_on_the_device(alpha):
+  """loss_function = Mixup with mixup_alpha != 1 in the captured plan: the Beta(alpha, alpha) coefficients of update k are drawn by a launch captured ahead of the discriminator
+  step (they are exactly il_noise_fill_beta's draws for counter k, new every update), the graph replays evolve the learner bit for bit like eager launches, and the
+  discriminator step each update took is the oracle's Mixup step (oracle/gail.py, pinned to the reference) on the rows the plan gathered with those coefficients and the
+  gradient-penalty uniforms of the same counter."""
+  B, K = 64, 4
+
+  def gp_uniforms(key, k):   # the gradient-penalty U(0, 1) of update k (include/il_hip.h il_noise_fill, IL_NOISE_GP = 3)
+    out = torch.empty(B, device=DEV)
+    _lib.check(_lib.lib().il_noise_fill(C.c_uint64(key), k, 3, B, _lib.ptr(out), _lib.stream_ptr()))
+    return N(out)
+  results = []
+  for mode in ('eager', 'graph'):
+    il.seed(43); il_training._NOISE.clear()
+    plan, nets = _make_plan('GAIL', 27, loss='Mixup', mixup_alpha=alpha, B=B, entropy_bonus=0.05)
+    assert not plan.device_sync and plan._beta_alpha == alpha, 'the draw reads the update counter on the device: stream-ordered schedule'
+    disc = nets[4]
+    ods = ogail.DiscState(disc.in_dim, 64, True)
+    ods.unpack_into(N(disc.flat)); v = disc.views()
+    for kk in ('u1', 'v1', 'u2', 'v2'): getattr(ods, kk)[...] = N(v[kk])
+    key = int(plan.disc.noise_seed)
+    for k in range(K):
+      if mode == 'graph' and k == 1: plan.capture(warmup=0)
+      (plan.replay if (mode == 'graph' and k >= 1) else plan.run)()
+      torch.cuda.synchronize()
+      eps = N(plan.eps_mix).copy()
+      np.testing.assert_array_equal(eps, _beta_draws(key, k, alpha, B), err_msg=f'update {k}: the coefficients are the Mixup stream\'s Beta draws of counter {k}')
+      if mode == 'eager':
+        cat = lambda t: np.concatenate([N(t['states']), N(t['actions'])], axis=1)
+        t, e = plan.transitions, plan.expert_transitions
+        ogail.gail_update(ods, cat(t), N(t['weights']), cat(e), N(e['weights']), gp_uniforms(key, k), lr=3e-5, weight_decay=10, grad_penalty=1.0, entropy_bonus=0.05,
+                          loss_function='Mixup', eps_mix=eps)
+        close_params(N(disc.flat)[:ods.pack().size], ods.pack(), f'mixup alpha {alpha}: discriminator after update {k + 1}', 3e-5, k + 1)
+    results.append([N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [N(plan.logp), N(plan.rewards)])
+  for a, b in zip(*results):
+    assert np.isfinite(a).all()
+    np.testing.assert_array_equal(a, b)
 
 
 @pytest.mark.parametrize('algorithm', ['SAC', 'GAIL'])

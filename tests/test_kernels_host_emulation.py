@@ -403,6 +403,7 @@ def _emulated_product(monkeypatch, streams=False):
 GPU_BODIES = (
     'test_replay_matches_reference_bit_exact', 'test_transfer_transitions_matches_sequential_appends', 'test_replay_full_size_gather_property',
     'test_sac_update_matches_oracle_and_reference', 'test_sac_gradients_match_oracle', 'test_sac_update_other_shapes', 'test_general_shape_sac_matches_oracle_and_reference',
+    'test_device_beta_draws_are_beta_distributed',
     'test_bc_update_matches_oracle_and_reference', 'test_actor_act_matches_oracle', 'test_adam_and_polyak_kernels',
     'test_gail_update_matches_oracle_and_reference', 'test_gail_loss_variants_match_reference', 'test_gail_ragged_batch_and_state_only',
     'test_gmmil_matches_oracle_and_reference', 'test_gmmil_full_size_properties', 'test_pwil_matches_oracle_and_reference', 'test_pwil_every_launch_path_matches_oracle',
@@ -451,8 +452,9 @@ def test_gpu_parity_bodies_on_the_emulated_kernels(golden_dir, monkeypatch, body
 
 @pytest.mark.parametrize('body,kw', [('test_inline_relabel_heads_equal_the_reward_kernel', dict(reward_function='GAIL')), ('test_inline_relabel_heads_equal_the_reward_kernel', dict(reward_function='FAIRL')),
                                      ('test_batch_gather_is_rejected_where_it_is_not_honoured', {}),
-                                     ('test_gail_pugail_finite_margin_matches_reference', dict(name='clamped')), ('test_gail_pugail_finite_margin_matches_reference', dict(name='open'))],
-                         ids=['inline_relabel-GAIL', 'inline_relabel-FAIRL', 'gather_rejected', 'pugail_margin-clamped', 'pugail_margin-open'])
+                                     ('test_gail_pugail_finite_margin_matches_reference', dict(name='clamped')), ('test_gail_pugail_finite_margin_matches_reference', dict(name='open')),
+                                     ('test_update_plan_mixup_with_beta_coefficients_drawn_on_the_device', dict(alpha=0.4)), ('test_update_plan_mixup_with_beta_coefficients_drawn_on_the_device', dict(alpha=2.5))],
+                         ids=['inline_relabel-GAIL', 'inline_relabel-FAIRL', 'gather_rejected', 'pugail_margin-clamped', 'pugail_margin-open', 'mixup_beta-0.4', 'mixup_beta-2.5'])
 def test_gpu_parity_bodies_that_build_a_plan_on_the_emulated_kernels(golden_dir, monkeypatch, body, kw):
   """More bodies of tests/test_gpu_parity.py: the ones that construct an UpdatePlan (its second stream, the device-sync probe) around what they check."""
   tgp = _emulated_product(monkeypatch, streams=True)

@@ -26,7 +26,7 @@ COMMON = ['steps=260', 'training.start=120', 'evaluation.interval=130', 'evaluat
     ['algorithm=GAIL', 'env=walker2d', 'imitation.discriminator.depth=2', 'imitation.loss_function=Mixup', 'imitation.spectral_norm=false'],
     ['algorithm=GAIL', 'env=walker2d', 'imitation.loss_function=Mixup', 'imitation.discriminator.reward_function=FAIRL'],
     ['algorithm=GAIL', 'env=hopper', 'imitation.loss_function=Mixup', 'imitation.entropy_bonus=0.24', 'imitation.grad_penalty=0.28', 'imitation.weight_decay=8.5'],   # GAIL_5_trajectories.yaml's shape: fused plan
-    ['algorithm=GAIL', 'env=hopper', 'imitation.loss_function=Mixup', 'imitation.mixup_alpha=0.5'],   # Beta(0.5, 0.5) drawn on the host: per-function path
+    ['algorithm=GAIL', 'env=hopper', 'imitation.loss_function=Mixup', 'imitation.mixup_alpha=0.5'],   # Beta(0.5, 0.5) coefficients drawn on the device inside the captured plan (il_noise_fill_beta)
     ['algorithm=GAIL', 'env=halfcheetah', 'imitation.discriminator.subtract_log_policy=true'],
     ['algorithm=GAIL', 'env=hopper', 'imitation.discriminator.reward_shaping=true', 'imitation.discriminator.subtract_log_policy=true'],
     ['algorithm=GAIL', 'env=hopper', 'imitation.discriminator.reward_shaping=true', 'imitation.discriminator.depth=2', 'imitation.discriminator.activation=tanh',

@@ -168,11 +168,11 @@ def train(cfg, file_prefix: str = '') -> float:
   plan = None
   mixed = cfg.imitation.mix_expert_data == 'mixed_batch'
   fusable = B % 16 == 0
-  if cfg.algorithm == 'GAIL' and (mixed or cfg.imitation.bc_aux_loss or (cfg.imitation.loss_function == 'Mixup' and float(cfg.imitation.mixup_alpha) != 1.0)
+  if cfg.algorithm == 'GAIL' and (mixed or cfg.imitation.bc_aux_loss
                                   or (cfg.imitation.loss_function == 'PUGAIL' and float(cfg.imitation.nonnegative_margin) != float('inf'))
                                   or cfg.imitation.discriminator.subtract_log_policy or cfg.imitation.discriminator.reward_shaping
                                   or (cfg.imitation.discriminator.depth, cfg.imitation.discriminator.activation) != (1, 'relu')):
-    fusable = False   # per-update host inputs (Beta(alpha != 1) draws) / an extra actor pass / a mix between the discriminator step and the relabel: per-function path
+    fusable = False   # an extra actor pass / a value pass / a mix between the discriminator step and the relabel: per-function path (Mixup with alpha != 1 draws its Beta coefficients on the device: UpdatePlan)
   general = bool(getattr(actor, 'general', False) or getattr(critic, 'general', False))   # reinforcement.actor / critic outside depth 2 / relu / hidden <= 256 (csrc/general.hip)
   if general: fusable = False
   if fusable:
