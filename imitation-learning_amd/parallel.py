@@ -397,6 +397,10 @@ class DataParallelUpdate:
 
   def __init__(self, plan, group=None):
     self.plan, self.group = plan, group
+    if getattr(plan, '_variant', False) or getattr(plan, '_beta_alpha', None) is not None:
+      raise NotImplementedError('DataParallelUpdate: GAIL with a finite PUGAIL margin / subtract_log_policy / reward shaping / a depth-2 or tanh discriminator / Mixup with mixup_alpha != 1 '
+                                'runs its discriminator step through the per-function entry points inside the plan: there are no gradient-only kernels to all-reduce for them; '
+                                'run these configurations with distributed.world_size=1')
     if plan.bc_aux:
       raise NotImplementedError('DataParallelUpdate: imitation.bc_aux_loss (the behavioural-cloning auxiliary step, train.py:201) has no data-parallel form; run it with distributed.world_size=1')
     # Device-side hand-off between the discriminator branch and the SAC branch, as on one GPU (UpdatePlan): no stream dependency between the two streams, the index

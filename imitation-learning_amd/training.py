@@ -438,10 +438,19 @@ class UpdatePlan:
       host_mixup = imitation_cfg is not None and imitation_cfg.loss_function == 'Mixup' and float(_cfg_value(imitation_cfg, 'mixup_alpha', 1.0)) != 1.0
       deep = type(discriminator).__name__ == 'DeepGAILDiscriminator'   # depth 2 / tanh: the general kernels, per-function path
       pu_margin = imitation_cfg is not None and imitation_cfg.loss_function == 'PUGAIL' and float(_cfg_value(imitation_cfg, 'nonnegative_margin', float('inf'))) != float('inf')
-      if imitation_cfg is not None and (deep or pu_margin or discriminator.subtract_log_policy or getattr(discriminator, 'reward_shaping', False)):
-        raise NotImplementedError('UpdatePlan: GAIL with PUGAIL with a finite margin / subtract_log_policy / reward shaping / a depth-2 or tanh discriminator runs through '
-                                  'adversarial_imitation_update + sac_update')
-      self.disc = disc_descriptor(discriminator, batch_size, discriminator_optimiser, imitation_cfg, tag=tag, seed_offset=off)
+      # The discriminator variants outside the fused depth-1 kernels' two-stream schedule - a finite PUGAIL margin (a value pass ahead of the gradients), subtract_log_policy
+      # (two actor passes), reward shaping, depth-2 / tanh discriminators - run their per-function entry points (adversarial_imitation_update + predict_reward, the calls of
+      # train.py:178-194) INSIDE the plan, on the gathered rows: every input is device-resident, so the same launches are captured with the rest of the update. They keep
+      # plain stream dependencies (no device-side hand-off, no data-parallel or population form).
+      sub = bool(imitation_cfg is not None and discriminator.subtract_log_policy)
+      self._variant = bool(imitation_cfg is not None and (deep or pu_margin or sub or getattr(discriminator, 'reward_shaping', False)))
+      if self._variant:
+        if learner_id is not None:
+          raise NotImplementedError('UpdatePlan: a population of GAIL learners with a finite PUGAIL margin / subtract_log_policy / reward shaping / a depth-2 or tanh discriminator')
+        self._gail_parts, self.disc = (actor, discriminator, discriminator_optimiser, imitation_cfg), None
+        host_mixup = host_mixup or (imitation_cfg.loss_function == 'Mixup' and sub)   # (that combination needs the coefficients on the host side of the call as well)
+      else:
+        self.disc = disc_descriptor(discriminator, batch_size, discriminator_optimiser, imitation_cfg, tag=tag, seed_offset=off)
       # Mixup (training.py:105-107): Beta(1, 1) = U(0, 1) coefficients come from the on-chip Philox stream inside the discriminator kernel, like the gradient penalty's. For
       # alpha != 1 (the reference draws them with torch's CPU Beta sampler: a host input per update) a launch captured ahead of the discriminator step draws them on the
       # device (il_noise_fill_beta: same distribution, Philox bits) into `eps_mix`, which that step takes as il_gail_extra.eps_mix. The launch reads the update counter on the
@@ -461,7 +470,7 @@ class UpdatePlan:
     self._chain_fits = None
     self.pre_hooks, self.post_hooks = [], []   # callables enqueuing extra work on the update's stream before / after it (captured with it), e.g. ActingWorker
     self.stream_ordered_draw = False   # True: the index draw stays the first kernel of the SAC branch (bit-identical; what per-kernel timing wants: see bench.py roofline())
-    if self._two_stream and device_index_draw and os.environ.get('IL_DEVICE_SYNC', '1') != '0' and getattr(self, '_beta_alpha', None) is None:
+    if self._two_stream and device_index_draw and os.environ.get('IL_DEVICE_SYNC', '1') != '0' and getattr(self, '_beta_alpha', None) is None and not getattr(self, '_variant', False):
       # HIP multiplexes streams onto a few hardware queues (round-robin at creation): a side stream that landed on the caller's queue runs serialised with it and
       # fails the probe. Another stream usually lands elsewhere: try a few (the rejected ones stay alive meanwhile, so that the next one gets a different queue).
       ok, rejected = self._probe_device_sync(graph=False), []
@@ -501,7 +510,7 @@ class UpdatePlan:
                          else L.il_replay_gather_workgroups(self.B, self.memory.row, self.expert_memory.row if self.has_expert else 0))
     ptr = self.sync.data_ptr() if on else None
     self.sac.sync = ptr
-    if self.algorithm == 'GAIL':
+    if self.algorithm == 'GAIL' and self.disc is not None:
       self.disc.sync = ptr
 
   def _probe_device_sync(self, graph: bool) -> bool:
@@ -719,9 +728,17 @@ class UpdatePlan:
   def _disc_step_and_relabel_on_gathered_rows(self, st):
     """train.py:178-194 on the gathered batches (the stream-dependency schedules): discriminator step, then the relabel kernel."""
     L, extra = _lib.lib(), None
-    if getattr(self, '_beta_alpha', None) is not None:   # this update's Beta(alpha, alpha) coefficients, drawn on the device (see __init__)
-      _lib.check(L.il_noise_fill_beta(C.c_uint64(self.disc.noise_seed), self.disc.noise_counter, self._beta_alpha, self.B, _lib.ptr(self.eps_mix), st))
+    if getattr(self, '_beta_alpha', None) is not None:   # this update's Beta(alpha, alpha) coefficients, drawn on the device (see __init__); the learner's one Philox key / counter
+      _lib.check(L.il_noise_fill_beta(C.c_uint64(self.sac.noise_seed), self.sac.noise_counter, self._beta_alpha, self.B, _lib.ptr(self.eps_mix), st))
       extra = C.byref(self._mix_extra)
+    if getattr(self, '_variant', False):
+      from .models import make_gail_input
+      actor, disc, opt, icfg = self._gail_parts
+      t, e = self.transitions, self.expert_transitions
+      adversarial_imitation_update(actor, disc, t, e, opt, icfg, eps_mix=self.eps_mix if self._beta_alpha is not None else None)
+      self.rewards.copy_(disc.predict_reward(**make_gail_input(t['states'], t['actions'], t['next_states'], t['terminals'], actor, bool(getattr(disc, 'reward_shaping', False)),
+                                                               bool(disc.subtract_log_policy))))
+      return
     _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, extra, 0, st))
     _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
 

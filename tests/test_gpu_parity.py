@@ -1149,8 +1149,8 @@ def test_gail_pugail_finite_margin_matches_reference(golden_dir, name):
     close(N(opt.grad), g[f'{name}.g_{i + 1}'], f'{name} gradient {i + 1} (reference)', atol_scale=4e-6 * (i + 1)); close(N(opt.grad), ogr, f'{name} gradient {i + 1} (oracle)', atol_scale=4e-6 * (i + 1))
     close(N(d.flat), g[f'{name}.p_{i + 1}'], f'{name} parameters {i + 1}', atol_scale=4e-6 * (i + 1))
   assert int(opt.step_count[0]) == 2, 'the value pass must not tick the optimiser'
-  with pytest.raises(NotImplementedError, match='PUGAIL with a finite margin'):   # the captured plan keeps the per-function path for it (train.py does)
-    _make_plan('GAIL', 3, loss='PUGAIL', margin=0.1)
+  plan, _ = _make_plan('GAIL', 3, loss='PUGAIL', margin=0.1)   # the captured plan runs the same per-function entry point inside (tests/test_update_plans_gpu.py)
+  assert plan._variant and not plan.device_sync
 
 
 @pytest.mark.gpu

@@ -526,8 +526,10 @@ def test_timed_path_replays_through_the_oracle_on_the_emulated_kernels(monkeypat
 
 
 def _update_plan_cases():
+  """(The GAIL discriminator variants run torch operations - log-probability buffers, the reward copy - between their launches inside the plan; the emulator defers kernels on its
+  streams but cannot defer torch's CPU operations with them, so those cases need a GPU.)"""
   import test_update_plans_gpu as tp
-  return tp.CASES
+  return [c for c in tp.CASES if c[0] != 'GAIL']
 
 
 @pytest.mark.parametrize('algorithm,mixed,bc_aux,kw', _update_plan_cases(), ids=[f'{c[0]}{"-mixed" if c[1] else ""}{"-bc_aux" if c[2] else ""}{"-" + "-".join(f"{k}={v}" for k, v in c[3].items()) if c[3] else ""}' for c in _update_plan_cases()])
@@ -779,7 +781,9 @@ def _train_cases():
   slow = pytest.mark.skipif(os.environ.get('IL_EMU_SLOW', '0') != '1', reason='IL_EMU_SLOW=1 sweeps every train.py configuration of the GPU suite (~7 min)')
   fast = [['algorithm=GAIL', 'env=hopper'], ['algorithm=SAC', 'env=hopper', '+acting.schedule=overlap']]
   out = [pytest.param(a, id='-'.join(x.split('=')[-1] for x in a)) for a in fast]
+  in_plan_variant = ('subtract_log_policy=true', 'reward_shaping=true', 'imitation.discriminator.depth=2', 'nonnegative_margin=')   # torch operations inside the plan: GPU only (_update_plan_cases)
   for args in [m for m in ttg.test_train_runs.pytestmark if m.name == 'parametrize'][0].args[1]:
+    if args[0] == 'algorithm=GAIL' and any(v in x for x in args for v in in_plan_variant) and not any('mix_expert_data' in x or 'bc_aux' in x for x in args): continue
     if args not in fast:
       out.append(pytest.param([re.sub(r'iterations=\d+', 'iterations=8', x) for x in args], id='-'.join(x.split('=')[-1] for x in args)[:60], marks=slow))
   return out

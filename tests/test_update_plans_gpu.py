@@ -21,7 +21,16 @@ if torch.cuda.is_available():
 S, A, B = gi.DIMS['halfcheetah'][0], gi.DIMS['halfcheetah'][1], 64
 
 
-def build(algorithm, seed, mixed=False, bc_aux=False, balanced=True, update_freq=1250):
+GAIL_VARIANTS = {   # the discriminator variants whose per-function entry points run INSIDE the plan (UpdatePlan._variant): name -> (imitation overrides, discriminator overrides)
+    'pu_margin': (dict(loss_function='PUGAIL', nonnegative_margin=0.05), {}),
+    'sublogp': (dict(loss_function='BCE'), dict(subtract_log_policy=True)),
+    'shaping': (dict(loss_function='PUGAIL'), dict(reward_shaping=True)),
+    'deep': (dict(loss_function='BCE', entropy_bonus=0.02), dict(depth=2, activation='tanh')),
+    'shaping_deep_sublogp': (dict(loss_function='BCE'), dict(reward_shaping=True, subtract_log_policy=True, depth=2, activation='tanh', hidden_size=64)),
+}
+
+
+def build(algorithm, seed, mixed=False, bc_aux=False, balanced=True, update_freq=1250, variant=None):
   torch.manual_seed(seed); il.seed(seed)
   il_training._NOISE.clear(); il_training._WS.clear()
   cfg = Cfg(hidden_size=128, depth=2, activation='relu')
@@ -45,6 +54,12 @@ def build(algorithm, seed, mixed=False, bc_aux=False, balanced=True, update_freq
     disc.set_uncertainty_threshold(emem['states'][:200], emem['actions'][:200], 0.6)
   elif algorithm == 'AdRIL':
     disc = il.RewardRelabeller(update_freq, balanced)
+  elif algorithm == 'GAIL':
+    io, do_ = GAIL_VARIANTS[variant]
+    icfg = Cfg(dict(state_only=False, spectral_norm=True, loss_function='BCE', grad_penalty=0.7, entropy_bonus=0.0, mixup_alpha=1, pos_class_prior=0.7, nonnegative_margin=float('inf')), **io)
+    icfg['discriminator'] = Cfg(dict(hidden_size=32, depth=1, activation='relu', reward_shaping=False, subtract_log_policy=False, reward_function='AIRL'), **do_)
+    disc = il.GAILDiscriminator(S, A, icfg, 0.97, device=DEV)
+    disc.test_extra = dict(discriminator_optimiser=il.AdamW(disc, lr=3e-5, weight_decay=10), imitation_cfg=icfg)
   il.seed(seed)   # the set-up above consumed index draws: restart the stream so that both runs see the same one
   nets = (actor, critic, log_alpha, target)   # the argument order of sac_update / UpdatePlan
   return nets, (ao, co, to), mem, emem, disc
@@ -58,6 +73,11 @@ def per_function_update(algorithm, nets, opts, mem, emem, disc, step, mixed, bc_
   masks = None
   if algorithm == 'AdRIL':
     disc.resample_and_relabel(t, e, step, mem.num_trajectories, emem.num_trajectories)
+  elif algorithm == 'GAIL':   # train.py:178-194
+    x = disc.test_extra
+    il.adversarial_imitation_update(actor, disc, t, e, x['discriminator_optimiser'], x['imitation_cfg'])
+    dc = x['imitation_cfg'].discriminator
+    t['rewards'] = disc.predict_reward(**il.make_gail_input(t['states'], t['actions'], t['next_states'], t['terminals'], actor, dc.reward_shaping, dc.subtract_log_policy))
   elif algorithm == 'GMMIL':
     t['rewards'] = disc.predict_reward(t['states'], t['actions'], e['states'], e['actions'], t['weights'].contiguous(), e['weights'].contiguous())
   elif algorithm == 'RED':
@@ -78,7 +98,7 @@ def per_function_update(algorithm, nets, opts, mem, emem, disc, step, mixed, bc_
 
 CASES = [('GMMIL', False, False, {}), ('GMMIL', True, False, {}), ('RED', False, False, {}), ('RED', True, True, {}), ('DRIL', False, False, {}), ('DRIL', True, False, {}),
          ('AdRIL', False, False, dict(balanced=True)), ('AdRIL', False, False, dict(balanced=False)), ('AdRIL', False, True, dict(balanced=True, update_freq=0)),
-         ('PWIL', False, False, {}), ('SAC', False, True, {})]
+         ('PWIL', False, False, {}), ('SAC', False, True, {})] + [('GAIL', False, False, dict(variant=v)) for v in GAIL_VARIANTS]
 
 
 @pytest.mark.parametrize('algorithm,mixed,bc_aux,kw', CASES)
@@ -87,9 +107,11 @@ def test_plan_of_every_algorithm_equals_the_per_function_sequence(algorithm, mix
   nets, opts, mem, emem, disc = build(algorithm, 11, **kw)
   want = [per_function_update(algorithm, nets, opts, mem, emem, disc, step0 + 37 * k, mixed, bc_aux) for k in range(K)]
   ref_state = [N(n.flat if hasattr(n, 'flat') else n) for n in nets]
+  ref_disc = N(disc.flat) if algorithm == 'GAIL' else None
 
   nets, opts, mem, emem, disc = build(algorithm, 11, **kw)
-  plan = il.UpdatePlan(algorithm, *nets, mem, *opts, B, 0.97, -0.5 * A, 0.99, expert_memory=emem, discriminator=disc, mix_expert=mixed, bc_aux=bc_aux)
+  plan = il.UpdatePlan(algorithm, *nets, mem, *opts, B, 0.97, -0.5 * A, 0.99, expert_memory=emem, discriminator=disc, mix_expert=mixed, bc_aux=bc_aux, **getattr(disc, 'test_extra', {}))
+  if algorithm == 'GAIL': assert plan._variant and not plan.device_sync, 'these discriminator variants run their per-function entry points inside the plan, on stream dependencies'
   got = []
   for k in range(K):
     if algorithm == 'AdRIL': plan.relabel_args(step0 + 37 * k, mem.num_trajectories)
@@ -102,6 +124,7 @@ def test_plan_of_every_algorithm_equals_the_per_function_sequence(algorithm, mix
   for k, (w, g) in enumerate(zip(want, got)):
     for name, a, b in zip(('rewards', 'log pi', 'min Q'), w, g):
       np.testing.assert_array_equal(N(a), N(b), err_msg=f'{algorithm} update {k}: {name}')
+  if algorithm == 'GAIL': ref_state.append(ref_disc); nets = tuple(nets) + (disc,)
   for i, (a, n) in enumerate(zip(ref_state, nets)):
     assert np.isfinite(a).all()
     np.testing.assert_array_equal(a, N(n.flat if hasattr(n, 'flat') else n), err_msg=f'{algorithm}: tensor {i} after {K} updates')

@@ -168,11 +168,9 @@ def train(cfg, file_prefix: str = '') -> float:
   plan = None
   mixed = cfg.imitation.mix_expert_data == 'mixed_batch'
   fusable = B % 16 == 0
-  if cfg.algorithm == 'GAIL' and (mixed or cfg.imitation.bc_aux_loss
-                                  or (cfg.imitation.loss_function == 'PUGAIL' and float(cfg.imitation.nonnegative_margin) != float('inf'))
-                                  or cfg.imitation.discriminator.subtract_log_policy or cfg.imitation.discriminator.reward_shaping
-                                  or (cfg.imitation.discriminator.depth, cfg.imitation.discriminator.activation) != (1, 'relu')):
-    fusable = False   # an extra actor pass / a value pass / a mix between the discriminator step and the relabel: per-function path (Mixup with alpha != 1 draws its Beta coefficients on the device: UpdatePlan)
+  if cfg.algorithm == 'GAIL' and (mixed or cfg.imitation.bc_aux_loss):
+    fusable = False   # a mix between the discriminator step and the relabel / an auxiliary actor step on the expert batch: per-function path. (Every discriminator variant -
+    # loss functions, finite PUGAIL margin, subtract_log_policy, reward shaping, depth 2 / tanh, Mixup with any alpha - is captured by UpdatePlan.)
   general = bool(getattr(actor, 'general', False) or getattr(critic, 'general', False))   # reinforcement.actor / critic outside depth 2 / relu / hidden <= 256 (csrc/general.hip)
   if general: fusable = False
   if fusable:
