@@ -13,6 +13,7 @@ f32 = np.float32
 
 DIMS = {  # state size incl. absorbing bit, action size (environments.py:27, gym MuJoCo dims)
     'halfcheetah': (18, 6), 'walker2d': (18, 6), 'hopper': (12, 3), 'ant': (112, 8),
+    'wide': (21, 12),   # not a gym task: an action space wider than the fused head (2A > 16) for the general-shape kernels
 }
 
 
@@ -66,6 +67,7 @@ GENERAL_SAC_CASES = {
     'sac_general_d3_tanh': dict(seed=41, env='hopper', hidden=48, batch=96, steps=3, depth=3, activation='tanh'),
     'sac_general_d1_sigmoid': dict(seed=42, env='halfcheetah', hidden=80, batch=64, steps=3, depth=1, activation='sigmoid'),
     'sac_general_d2_relu_h320': dict(seed=43, env='walker2d', hidden=320, batch=40, steps=2, depth=2, activation='relu'),
+    'sac_general_wide_action': dict(seed=45, env='wide', hidden=128, batch=48, steps=2, depth=2, activation='relu'),   # the fused SHAPE, but 2A = 24 outputs: general kernels
     'sac_general_mixed': dict(seed=44, env='hopper', hidden=32, batch=50, steps=3, depth=1, activation='relu', critic=(72, 3, 'sigmoid')),   # reinforcement.actor != reinforcement.critic
 }
 
