@@ -105,6 +105,31 @@ def test_host_index_draw_rejects_empty_ranges():
   assert b'range' in _lib.lib().il_last_error()
 
 
+def test_general_shape_entry_points_size_and_reject_on_the_host():
+  """csrc/general.hip without a GPU: the parameter counts of general shapes equal torch's (`parameters()` order: W [out][in], b [out] per layer), strides are 16-byte
+  multiples, the workspace sizes grow with depth, and shapes / arguments outside the engine's range come back as error codes before any launch."""
+  from imitation_learning_amd import _lib
+  L = _lib.lib()
+  for (i, h, d, o) in ((12, 48, 3, 6), (18, 80, 1, 12), (33, 320, 2, 1), (24, 72, 3, 1), (5, 7, 8, 3)):
+    dims = [i] + [h] * d + [o]
+    want = sum(dims[k + 1] * dims[k] + dims[k + 1] for k in range(len(dims) - 1))
+    assert L.il_mlp_numel_general(i, h, d, o) == want
+    s = L.il_mlp_stride_general(i, h, d, o)
+    assert s % 4 == 0 and want <= s < want + 4
+  assert L.il_mlp_numel_general(18, 256, 2, 12) == L.il_mlp_numel(18, 256, 12)   # the fused shape: the two layouts agree
+  assert L.il_sac_workspace_floats_general(18, 6, 256, 3, 256, 3, 256) > L.il_sac_workspace_floats_general(18, 6, 256, 2, 256, 2, 256) > 0
+  assert L.il_actor_workspace_floats_general(18, 6, 64, 2, 1) > 0
+  ws = (C.c_float * 16)()
+  out = (C.c_float * 16)()
+  # depth 9 / an unknown activation / a workspace that is too small: refused before anything is launched
+  assert L.il_actor_act_general(ws, 4, 2, 8, 9, 0, ws, 4, 1, None, 0, 0, 1, out, None, ws, 1 << 30, None) != 0 and b'depth' in L.il_last_error()
+  assert L.il_actor_act_general(ws, 4, 2, 8, 2, 3, ws, 4, 1, None, 0, 0, 1, out, None, ws, 1 << 30, None) != 0
+  assert L.il_actor_act_general(ws, 4, 2, 8, 2, 0, ws, 4, 1, None, 0, 0, 1, out, None, ws, 16, None) != 0 and b'workspace' in L.il_last_error()
+  assert L.il_actor_log_prob_general(None, 4, 2, 8, 2, 0, ws, 4, ws, 2, 1, out, ws, 1 << 30, None) != 0
+  assert L.il_sac_update_general(None, None, 2, 0, 8, 2, 0, None, None, None, None, 0, None) != 0 and b'il_sac_update_general' in L.il_last_error()
+  assert L.il_noise_fill_beta(1, None, 0.0, 16, out, None) != 0 and b'alpha' in L.il_last_error()
+
+
 def test_ctypes_structs_match_the_compiled_library():
   """sizeof() of every descriptor struct as compiled into libil_hip.so equals the ctypes mirror's (a stale binding would pass garbage)."""
   from imitation_learning_amd import _lib
