@@ -7,7 +7,7 @@
 // dW = dZ^T X reads both operands as 16-byte lanes along the batch. Every product is an exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) tile:
 //   k_g_linear   Y^T = act(W X + b)        one workgroup = 16 rows x 64 output features, the input tile staged in LDS, one wave per 16 x 16 tile
 //   k_g_bwd      dZ_prev^T = (W^T dZ) * act'(H_prev)   same shape, dZ tile staged in LDS
-//   k_g_dw       G_W = dZ^T X              one wave per 16 x 16 tile of the gradient, reduction over the batch;  k_g_dbias: one wave per feature
+//   k_g_dw       G_W = dZ^T X              one wave per 16 x 16 tile of the gradient, reduction over the batch; the bias sums (one wave per feature) ride in the same launch
 // and the per-row pieces (tanh-Gaussian head, TD target, loss seeds, head backward, temperature step) are one thread per row. The optimiser steps and the target update
 // are the library's elementwise kernels (il_adam_step, il_polyak). Same parameter layout as torch (`parameters()` order, twin critics at il_mlp_stride_general).
 // Padding rows carry zeros in every dZ, so they contribute nothing to any gradient.
@@ -127,9 +127,20 @@ __global__ __launch_bounds__(256) void k_g_bwd(GBwd a) {
 
 // G[oW + n K + k] = sum_row dZT[n][row] XT[k][row]: one wave per 16 x 16 tile; both operands as 16-byte lanes along the batch
 struct GDw { const float* dZT; int64_t dz_ns; const float* XT; int64_t x_ns; float* G; int64_t g_ns; int64_t oW, ob; int N, K, Bp; };
+__device__ __forceinline__ void g_dbias(const GDw& a, int net, int n) {   // one wave per output feature
+  const int lane = threadIdx.x & 63;
+  if (n >= a.N) return;
+  const float* z = a.dZT + net * a.dz_ns + (size_t)n * a.Bp;
+  float s = 0.f;
+  for (int r = lane; r < a.Bp; r += 64) s += gload(z + r);
+  s = wave_sum(s);
+  if (lane == 0) a.G[net * a.g_ns + a.ob + n] = s;
+}
+// grid.x = ceil(tiles / 4) workgroups of weight-gradient tiles, then ceil(N / 4) workgroups of bias sums (one launch per layer instead of two)
 __global__ __launch_bounds__(256) void k_g_dw(GDw a) {
   const int net = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
-  const int tk = (a.K + 15) >> 4, tn = (a.N + 15) >> 4, tile = blockIdx.x * 4 + wave;
+  const int tk = (a.K + 15) >> 4, tn = (a.N + 15) >> 4, tile = blockIdx.x * 4 + wave, tile_wgs = (tk * tn + 3) >> 2;
+  if ((int)blockIdx.x >= tile_wgs) { g_dbias(a, net, ((int)blockIdx.x - tile_wgs) * 4 + wave); return; }
   if (tile >= tk * tn) return;
   const int n0 = (tile / tk) * 16, k0 = (tile - (tile / tk) * tk) * 16;
   const float* zr = a.dZT + net * a.dz_ns + (size_t)min(n0 + j, a.N - 1) * a.Bp + 4 * g;
@@ -146,16 +157,6 @@ __global__ __launch_bounds__(256) void k_g_dw(GDw a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) { const int n = n0 + 4 * g + r; if (n < a.N && k < a.K) G[(size_t)n * a.K + k] = acc[r]; }
 }
-__global__ __launch_bounds__(256) void k_g_dbias(GDw a) {   // one wave per output feature
-  const int net = blockIdx.z, lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= a.N) return;
-  const float* z = a.dZT + net * a.dz_ns + (size_t)n * a.Bp;
-  float s = 0.f;
-  for (int r = lane; r < a.Bp; r += 64) s += gload(z + r);
-  s = wave_sum(s);
-  if (lane == 0) a.G[net * a.g_ns + a.ob + n] = s;
-}
-
 // X0T[k][row] = cat(f1, f2)[row][k] for row < n, zero padding rows (f2 == NULL: K2 columns are left to the head kernel that produces them)
 __global__ __launch_bounds__(256) void k_g_pack(const float* __restrict__ f1, int ld1, int K1, const float* __restrict__ f2, int ld2, int K2, int n, int Bp, float* __restrict__ XT) {
   const int total = (K1 + (f2 ? K2 : 0)) * Bp;
@@ -163,6 +164,22 @@ __global__ __launch_bounds__(256) void k_g_pack(const float* __restrict__ f1, in
     const int k = i / Bp, row = i - k * Bp;
     float v = 0.f;
     if (row < n) v = k < K1 ? f1[(size_t)row * ld1 + k] : f2[(size_t)row * ld2 + (k - K1)];
+    XT[i] = v;
+  }
+}
+
+// the five inputs of one SAC update in one launch: blockIdx.y selects (s'), (s), (s', .), (s, a), (s, .)
+struct GPackSac { il_batch b; int S, A, Bp; float* xa2; float* xa; float* xt; float* xc; float* xp; };
+__global__ __launch_bounds__(256) void k_g_pack_sac(GPackSac a) {
+  const int which = blockIdx.y, S = a.S, A = a.A, Bp = a.Bp;
+  const bool next = which == 0 || which == 2, with_a = which == 3;
+  float* XT = which == 0 ? a.xa2 : (which == 1 ? a.xa : (which == 2 ? a.xt : (which == 3 ? a.xc : a.xp)));
+  const float* f1 = next ? a.b.next_states : a.b.states; const int ld1 = next ? a.b.ld_next_states : a.b.ld_states;
+  const int total = (S + (with_a ? A : 0)) * Bp;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int k = i / Bp, row = i - k * Bp;
+    float v = 0.f;
+    if (row < a.b.n) v = k < S ? f1[(size_t)row * ld1 + k] : a.b.actions[(size_t)row * a.b.ld_actions + (k - S)];
     XT[i] = v;
   }
 }
@@ -349,8 +366,7 @@ static int g_backward(hipStream_t st, const GNet& s, const float* P, int64_t p_n
     if (G) {
       GDw w; w.dZT = dz; w.dz_ns = dz_ns; w.XT = xin; w.x_ns = xin_ns; w.G = G; w.g_ns = g_ns; w.oW = L.oW; w.ob = L.ob; w.N = L.N; w.K = L.K; w.Bp = Bp;
       const int tiles = ((L.N + 15) / 16) * ((L.K + 15) / 16);
-      { IL_TRACE("k_g_dw", st); k_g_dw<<<dim3((tiles + 3) / 4, 1, nets), 256, 0, st>>>(w); }
-      { IL_TRACE("k_g_dbias", st); k_g_dbias<<<dim3((L.N + 3) / 4, 1, nets), 256, 0, st>>>(w); }
+      { IL_TRACE("k_g_dw", st); k_g_dw<<<dim3((tiles + 3) / 4 + (L.N + 3) / 4, 1, nets), 256, 0, st>>>(w); }
     }
     if (l > 0 || dX0T) {
       GBwd a; a.dZT = dz; a.dz_ns = dz_ns; a.P = P; a.p_ns = p_ns; a.oW = L.oW; a.K = L.K; a.N = L.N;
@@ -414,11 +430,11 @@ extern "C" int il_sac_update_general(const il_sac* d, const il_batch* b, int32_t
   float* ga = grads_only ? d->actor_grad : W + ws.ga; float* gc = grads_only ? d->critic_grad : W + ws.gc;
   const int rb = (Bp + 255) / 256;
   // inputs, feature-major
-  g_pack(st, b->next_states, b->ld_next_states, S, nullptr, 0, 0, B, Bp, W + ws.xa2);
-  g_pack(st, b->states, b->ld_states, S, nullptr, 0, 0, B, Bp, W + ws.xa);
-  g_pack(st, b->next_states, b->ld_next_states, S, nullptr, 0, A, B, Bp, W + ws.xt);   // + a' below
-  g_pack(st, b->states, b->ld_states, S, b->actions, b->ld_actions, A, B, Bp, W + ws.xc);
-  g_pack(st, b->states, b->ld_states, S, nullptr, 0, A, B, Bp, W + ws.xp);             // + a~ below
+  {   // (the action rows of xt / xp are written by the head kernels below: a', a~)
+    GPackSac pk = {*b, S, A, Bp, W + ws.xa2, W + ws.xa, W + ws.xt, W + ws.xc, W + ws.xp};
+    const int total = IN * Bp;
+    IL_TRACE("k_g_pack", st); k_g_pack_sac<<<dim3((total + 255) / 256 < 256 ? (total + 255) / 256 : 256, 5), 256, 0, st>>>(pk);
+  }
   // target values (training.py:19-25)
   if (int rc = g_forward(st, an, d->actor, 0, 1, W + ws.xa2, 0, W + ws.ha2, W + ws.oa2, Bp)) return rc;
   {
@@ -456,8 +472,7 @@ extern "C" int il_sac_update_general(const il_sac* d, const il_batch* b, int32_t
   // temperature, target network (training.py:45-52)
   { IL_TRACE("k_g_alpha", st); k_g_alpha<<<1, 64, 0, st>>>(W + ws.arows, B, d->log_alpha, d->alpha_opt, d->alpha_grad, grads_only ? 1 : 0, d->noise_counter); }
   if (!grads_only) {
-    if (int rc = il_polyak(d->target, d->critic, Pc, d->polyak, stream_)) return rc;
-    if (int rc = il_polyak(d->target + Ps, d->critic + Ps, Pc, d->polyak, stream_)) return rc;
+    if (int rc = il_polyak(d->target, d->critic, Ps + Pc, d->polyak, stream_)) return rc;   // both networks in one launch (the <= 3 pad floats between them are never parameters)
   }
   IL_CHECK_LAUNCH("il_sac_update_general");
   return IL_OK;
