@@ -7,7 +7,7 @@ the importable alias at the repo root points its package path here).
 from . import _lib  # noqa: F401
 from .acting import ActingWorker  # noqa: F401
 from .memory import IndexStream, ReplayMemory, seed  # noqa: F401
-from .models import (GAILDiscriminator, GMMILDiscriminator, PWILDiscriminator, REDDiscriminator, RewardRelabeller, SoftActor, TwinCritic, create_target_network,  # noqa: F401
+from .models import (DropoutSoftActor, GAILDiscriminator, GMMILDiscriminator, PWILDiscriminator, REDDiscriminator, RewardRelabeller, SoftActor, TwinCritic, create_target_network,  # noqa: F401
                      make_gail_input, mix_expert_agent_transitions, update_target_network)
 from .optim import Adam, AdamW  # noqa: F401
 from .training import (BatchedPopulationPlan, PopulationPlan, UpdatePlan, adversarial_imitation_update, behavioural_cloning_update, sac_update,  # noqa: F401

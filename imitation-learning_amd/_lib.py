@@ -126,6 +126,7 @@ _SIGNATURES = {
     'il_sync_layout': (None, [C.POINTER(C.c_int32)]),
     'il_trace_enable': (C.c_int, [C.c_int]),
     'il_trace_report': (C.c_int, [C.c_char_p, C.c_int]),
+    'il_kernel_stamp_ids': (C.c_int32, []), 'il_kernel_stamps': (C.c_int, [C.POINTER(C.c_uint64)]), 'il_kernel_stamps_clear': (C.c_int, []),
     'il_ring_row_floats': (C.c_int32, [C.c_int32, C.c_int32]),
     'il_replay_write_rows': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int64, _P, C.c_int32, _P]),
     'il_replay_wrap_absorbing': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P]),
@@ -248,6 +249,24 @@ def sync_layout():
     lib().il_sync_layout(out)
     _SYNC_LAYOUT = tuple(int(v) for v in out)
   return _SYNC_LAYOUT
+
+
+STAMP_KERNELS = ('k_gail_grad', 'k_gail_reduce', 'k_sac_chain_pair', 'k_dw_adam_critic', 'k_policy_critic_pair', 'k_dw_adam_actor', 'k_gmmil_direct', 'k_pwil')   # IL_STAMP_* (include/il_hip.h)
+
+
+def kernel_stamps(handle=None) -> dict:
+  """il_kernel_stamps as {kernel: dict(begin_us, last_begin_us, first_end_us, end_us, duration_us, workgroups)} for the kernels that ran since the last clear; times are
+  microseconds on the device-wide 100 MHz counter (comparable between kernels: begin/end of different kernels give the launch boundaries of one update)."""
+  L = handle or lib()
+  n = int(L.il_kernel_stamp_ids())
+  buf = (C.c_uint64 * (5 * n))()
+  check(L.il_kernel_stamps(buf))
+  out = {}
+  for k in range(n):
+    b0, b1, e0, e1, wgs = (int(buf[5 * k + i]) for i in range(5))
+    if wgs:
+      out[STAMP_KERNELS[k]] = dict(begin_us=b0 / 100.0, last_begin_us=b1 / 100.0, first_end_us=e0 / 100.0, end_us=e1 / 100.0, duration_us=(e1 - b0) / 100.0, workgroups=wgs)
+  return out
 
 
 def check(rc: int):

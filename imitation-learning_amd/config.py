@@ -169,7 +169,7 @@ def write_conf_tree(path: str):
     return out
 
   def dump(d):
-    return yaml.safe_dump(d, sort_keys=False, default_flow_style=False).replace('.inf', '.inf')
+    return yaml.safe_dump(d, sort_keys=False, default_flow_style=False)
   os.makedirs(os.path.join(path, 'algorithm'), exist_ok=True)
   os.makedirs(os.path.join(path, 'optimised_hyperparameters'), exist_ok=True)
   base = {k: copy.deepcopy(v) for k, v in BASE.items() if k not in ('algorithm', 'distributed')}

@@ -123,6 +123,46 @@ extern "C" int il_noise_fill_beta(uint64_t noise_seed, const uint32_t* ctr_dev, 
   return IL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Launch stamps of the headline schedule (il_common.hpp "Always-on launch stamps"): per kernel id of the LAST launch that ran, in ticks of the 100 MHz device-wide
+// counter: out_host[kid][0..4] = {min begin, max begin, min end, max end, workgroups stamped}; all 0 when the kernel has not run since il_kernel_stamps_clear().
+// Synchronises the device. bench.py derives `roofline.kernels` from these after its timed graph replays.
+// ---------------------------------------------------------------------------------------------
+extern "C" int il_stamps_sac(unsigned long long*); extern "C" int il_stamps_gail(unsigned long long*); extern "C" int il_stamps_sac_clear(); extern "C" int il_stamps_gail_clear();
+extern "C" int32_t il_kernel_stamp_ids(void) { return IL_ST_K; }
+extern "C" int il_kernel_stamps(uint64_t* out_host) {
+  IL_CHECK_ARG(out_host, "il_kernel_stamps: null argument");
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return il_set_error(IL_ERR_HIP, "il_kernel_stamps: %s", hipGetErrorString(e));
+  typedef unsigned long long table_t[IL_ST_K][IL_ST_WGS][2];
+  static table_t tb;
+  memset(out_host, 0, sizeof(uint64_t) * IL_ST_K * 5);
+  struct Src { int (*read)(unsigned long long*); int first, last; };
+  const Src srcs[2] = {{il_stamps_gail, IL_ST_GAIL_GRAD, IL_ST_GAIL_REDUCE}, {il_stamps_sac, IL_ST_CHAIN, IL_ST_DW_ACTOR}};
+  for (const Src& sc : srcs) {
+    if (sc.read(&tb[0][0][0]) != 0) return il_set_error(IL_ERR_HIP, "il_kernel_stamps: reading a stamp table failed");
+    for (int k = sc.first; k <= sc.last; ++k) {
+      uint64_t* o = out_host + 5 * k;
+      for (int w = 0; w < IL_ST_WGS; ++w) {
+        const uint64_t b = tb[k][w][0], en = tb[k][w][1];
+        if (!b || !en) continue;
+        if (!o[4]) { o[0] = o[1] = b; o[2] = o[3] = en; }
+        if (b < o[0]) o[0] = b;
+        if (b > o[1]) o[1] = b;
+        if (en < o[2]) o[2] = en;
+        if (en > o[3]) o[3] = en;
+        o[4] += 1;
+      }
+    }
+  }
+  return IL_OK;
+}
+extern "C" int il_kernel_stamps_clear(void) {
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return il_set_error(IL_ERR_HIP, "il_kernel_stamps_clear: %s", hipGetErrorString(e));
+  return (il_stamps_gail_clear() == 0 && il_stamps_sac_clear() == 0) ? IL_OK : il_set_error(IL_ERR_HIP, "il_kernel_stamps_clear: clearing a stamp table failed");
+}
+
 // sizeof() of the descriptor structs as this library was compiled: a binding checks its own struct definitions against these
 // (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red, 7 il_dril, 8 il_disc_shaped, 9 il_disc_deep, 10 il_peer_bucket).
 extern "C" int32_t il_struct_size(int32_t which) {

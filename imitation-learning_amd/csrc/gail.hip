@@ -15,6 +15,7 @@
 #include "mlp_tile.hpp"
 #include "disc_reward.hpp"
 #include "peer_device.hpp"
+IL_ST_TABLE
 
 struct DiscWs { int64_t slabs, sn_new, pu, total; };   // pu: [2][nt] per-tile sums of w softplus(z) of the policy / expert call (PUGAIL with a finite nonnegative_margin)
 __host__ __device__ inline DiscWs disc_ws(int D, int H, int B) {
@@ -458,7 +459,9 @@ __device__ __forceinline__ void gail_grad_body(il_disc d, il_batch pol, il_batch
 __global__ __launch_bounds__(256) void k_gail_grad(il_disc d, il_batch pol, il_batch exp, const float* __restrict__ eps_gp, il_gail_extra x, const il_disc* __restrict__ dL,
                                                    const il_batch* __restrict__ polL, const il_batch* __restrict__ expL, GailSampler sa, int pu_value_pass) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  IL_ST_BEGIN(IL_ST_GAIL_GRAD);
   gail_grad_body<false>(d, pol, exp, eps_gp, x, dL, polL, expL, sa, pu_value_pass, 1, smem);
+  IL_ST_END(IL_ST_GAIL_GRAD);
 }
 __global__ __launch_bounds__(256) void k_gail_grad_pop(il_disc d, const il_disc* __restrict__ dL, const il_batch* __restrict__ polL, const il_batch* __restrict__ expL, int tpw) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -472,6 +475,7 @@ __host__ __device__ inline int gail_calls(const il_disc& d) { return (d.loss_fun
 // critic-loss workgroups of k_sac_chain - so each workgroup reports [IL_SYNC_PARAMS] and the last one closes the side branch's epoch.
 __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const il_disc* __restrict__ dL, int close_epoch, il_peer_bucket peer) {
   IL_TL(1, 0);
+  if (!dL) IL_ST_BEGIN(IL_ST_GAIL_REDUCE);
   if (dL) d = dL[blockIdx.y];
   globalize(d);
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, B = d.batch;
@@ -530,6 +534,7 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const
     }
   }
   IL_TL(1, 7);
+  if (!dL) IL_ST_END(IL_ST_GAIL_REDUCE);
 }
 
 __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, float* __restrict__ out_r, float* __restrict__ out_logit, const float* __restrict__ logit_offset, const il_disc* __restrict__ dL,
@@ -729,3 +734,4 @@ extern "C" int il_gail_reward(const il_disc* d, const il_batch* b, float* out_re
 
 IL_STAMP_READER(il_debug_stamps_gail)
 IL_TL_READER(il_debug_timeline_gail)
+IL_ST_READER(il_stamps_gail)

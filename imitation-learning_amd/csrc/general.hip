@@ -479,17 +479,17 @@ extern "C" int il_sac_update_general(const il_sac* d, const il_batch* b, int32_t
 }
 
 // workspace of the actor-only entry points below: input, hidden activations, head outputs, and (behavioural cloning) dZ, head gradient, loss rows, gradient arena
-extern "C" int64_t il_actor_workspace_floats_general(int32_t S, int32_t A, int32_t H, int32_t depth, int32_t n) {
-  const int Bp = g_bp(n);
-  return (int64_t)S * Bp + 2 * (int64_t)depth * H * Bp + 2 * (int64_t)2 * A * Bp + 2 * Bp + g_numel(S, H, depth, 2 * A) + 64;
-}
-struct GActWs { int64_t x, h, o, dz, dout, rows, g; };
+struct GActWs { int64_t x, h, o, dz, dout, rows, g, total; };
 static GActWs g_act_ws(int S, int A, int H, int depth, int Bp) {
   GActWs w; int64_t o = 0;
   auto take = [&](int64_t n) { const int64_t at = o; o += (n + 3) & ~(int64_t)3; return at; };
   w.x = take((int64_t)S * Bp); w.h = take((int64_t)depth * H * Bp); w.o = take((int64_t)2 * A * Bp); w.dz = take((int64_t)depth * H * Bp); w.dout = take((int64_t)2 * A * Bp); w.rows = take(Bp);
   w.g = take(g_numel(S, H, depth, 2 * A));
+  w.total = o;
   return w;
+}
+extern "C" int64_t il_actor_workspace_floats_general(int32_t S, int32_t A, int32_t H, int32_t depth, int32_t n) {   // the layout's own total: a layout change cannot outgrow the size check
+  return g_act_ws(S, A, H, depth, g_bp(n)).total;
 }
 // train.py:152 `actor(state).sample()` / models.py:101-102 get_greedy_action for general shapes (arguments of il_actor_act + depth, activation, workspace)
 extern "C" int il_actor_act_general(const float* actor, int32_t S, int32_t A, int32_t H, int32_t depth, int32_t activation, const float* states, int32_t ld_states, int32_t n, const float* eps,

@@ -178,9 +178,10 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t ctr, uin
 // X, Y ~ Gamma(alpha) by Marsaglia & Tsang's squeeze-free form (alpha < 1: Gamma(alpha + 1) U^(1/alpha)). Attempt t of variate `which` keys the Philox counter's fourth word
 // (1 + 2 t + which; word 0 is philox_uniform's), so a draw is a pure function of (seed, ctr, stream, idx, alpha): every workgroup that needs row idx's coefficient computes
 // the same bits. The reference draws with torch's CPU Beta sampler: equal in distribution, not in bits.
-__device__ __forceinline__ float philox_gamma(uint64_t seed, uint32_t ctr, uint32_t stream_id, uint32_t idx, float alpha, uint32_t which) {
+__device__ __forceinline__ float philox_gamma(uint64_t seed, uint32_t ctr, uint32_t stream_id, uint32_t idx, float alpha, uint32_t which, float* log_out = nullptr) {
   const float a = alpha < 1.f ? alpha + 1.f : alpha, d = a - 1.f / 3.f, c = 1.f / sqrtf(9.f * d);
   float out = d;   // (never left as is: 64 attempts at a > 95 % acceptance rate)
+  if (log_out) *log_out = logf(d);
   for (uint32_t t = 0; t < 64u; ++t) {
     const philox_out o = philox4x32_10(idx, ctr, stream_id, 1u + 2u * t + which, (uint32_t)seed, (uint32_t)(seed >> 32));
     const float x = sqrtf(-2.0f * logf(u32_to_unit_open(o.v[0]))) * cosf(6.28318530717958647692f * u32_to_unit_open(o.v[1]));
@@ -189,6 +190,7 @@ __device__ __forceinline__ float philox_gamma(uint64_t seed, uint32_t ctr, uint3
     const float v = v0 * v0 * v0, u = u32_to_unit_open(o.v[2]);
     if (logf(u) < 0.5f * x * x + d - d * v + d * logf(v)) {
       out = d * v;
+      if (log_out) *log_out = logf(out) + (alpha < 1.f ? logf(u32_to_unit_open(o.v[3])) / alpha : 0.f);   // the variate's logarithm: finite where U^(1/alpha) underflows
       if (alpha < 1.f) out *= powf(u32_to_unit_open(o.v[3]), 1.f / alpha);
       break;
     }
@@ -196,7 +198,11 @@ __device__ __forceinline__ float philox_gamma(uint64_t seed, uint32_t ctr, uint3
   return out;
 }
 __device__ __forceinline__ float philox_beta(uint64_t seed, uint32_t ctr, uint32_t stream_id, uint32_t idx, float alpha) {
-  const float x = philox_gamma(seed, ctr, stream_id, idx, alpha, 0u), y = philox_gamma(seed, ctr, stream_id, idx, alpha, 1u);
+  float lx, ly;
+  const float x = philox_gamma(seed, ctr, stream_id, idx, alpha, 0u, &lx), y = philox_gamma(seed, ctr, stream_id, idx, alpha, 1u, &ly);
+  // small alpha: both Gamma(alpha + 1) U^(1/alpha) variates can underflow to 0 in fp32 (alpha = 0.05: U^20) and 0 / 0 would put a NaN into the discriminator step; the ratio
+  // of their logarithms is still exact there (the reference's sampler is guarded the same way). Any other draw keeps the plain quotient's bits.
+  if (!(x + y > 0.f)) return 1.f / (1.f + expf(ly - lx));
   return x / (x + y);
 }
 enum { IL_STREAM_EPS_NEXT = 1, IL_STREAM_EPS_CUR = 2, IL_STREAM_GP = 3, IL_STREAM_ACT = 4, IL_STREAM_MIX = 7 };   // 5, 6: dropout masks (dril.hip)
@@ -323,6 +329,22 @@ static __device__ unsigned long long il_tl[IL_TL_K][IL_TL_WGS][IL_TL_SLOTS];
 #define IL_TL_END(kid) do { } while (0)
 #define IL_TL_READER(name)
 #endif
+
+// ---------------------------------------------------------------------------------------------
+// Always-on launch stamps of the headline schedule's kernels (il_kernel_stamps, include/il_hip.h): thread 0 of every workgroup stores s_memrealtime (the 100 MHz
+// device-wide counter) when it starts and after its last wave has finished - two 8-byte fire-and-forget stores per workgroup into a table of this translation unit,
+// overwritten by every launch. After a run of graph replays the host reads, per kernel, min(begin) and max(end) over the workgroups of the LAST launch: the kernel's
+// duration inside the timed schedule itself (bench.py builds `roofline` from these; no HIP events, no eager re-run). One kernel id per launch of an update.
+// ---------------------------------------------------------------------------------------------
+enum { IL_ST_GAIL_GRAD = 0, IL_ST_GAIL_REDUCE = 1, IL_ST_CHAIN = 2, IL_ST_DW_CRITIC = 3, IL_ST_POLICY_CRITIC = 4, IL_ST_DW_ACTOR = 5, IL_ST_GMMIL = 6, IL_ST_PWIL = 7, IL_ST_K = 8 };
+#define IL_ST_WGS 512
+#define IL_ST_TABLE static __device__ unsigned long long il_st[IL_ST_K][IL_ST_WGS][2];
+#define IL_ST_MARK(kid, slot) do { const unsigned st_w = blockIdx.x + gridDim.x * blockIdx.y; if (threadIdx.x == 0 && st_w < IL_ST_WGS && blockIdx.z == 0) il_st[kid][st_w][slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define IL_ST_BEGIN(kid) IL_ST_MARK(kid, 0)
+#define IL_ST_END(kid) do { __syncthreads(); IL_ST_MARK(kid, 1); } while (0)   // every thread of the workgroup passes here (bodies return, never s_endpgm): a workgroup's end = its last wave's
+// out_host [IL_ST_K][IL_ST_WGS][2]: only the rows of the kernel ids this translation unit owns are meaningful
+#define IL_ST_READER(name) extern "C" int name(unsigned long long* out_host) { return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(il_st), sizeof(il_st)) == hipSuccess ? 0 : 3; } \
+                           extern "C" int name##_clear() { static unsigned long long z[IL_ST_K][IL_ST_WGS][2]; return hipMemcpyToSymbol(HIP_SYMBOL(il_st), z, sizeof(z)) == hipSuccess ? 0 : 3; }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

@@ -16,6 +16,7 @@
 #include "mlp_tile.hpp"
 #include "peer_device.hpp"
 #include "disc_reward.hpp"
+IL_ST_TABLE
 
 // Measured (round 3, same box, three interleaved rounds): write-through stores in the dW / AdamW epilogue ONLY: 14.71k -> 14.90k updates/s; ALSO for the activations and dZ
 // the tile kernels leave in the workspace: 14.59k - the next launch reads those, and a written-through line is not left behind in the L2 for the readers of its own XCD.
@@ -897,7 +898,9 @@ __global__ __launch_bounds__(512) void k_sac_chain_pair(il_sac d, il_batch b, co
   extern __shared__ __attribute__((aligned(16))) float smem[];
   globalize(d); globalize(b);
   if (rl.on) { globalize(rl.dd); rl.out = as_global(rl.out); }
+  IL_ST_BEGIN(IL_ST_CHAIN);
   sac_chain_pair_body(d, b, eps_next, eps_cur, rewards, rows_out, rl, smem);
+  IL_ST_END(IL_ST_CHAIN);
 }
 
 // policy-loss backward of one 16-row tile: min-Q selection, tanh-Gaussian backward, actor back-prop (dz3, dz2, dz1 for the dW kernel), alpha partial.
@@ -1337,6 +1340,7 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
 __global__ __launch_bounds__(512) void k_policy_critic_pair(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, int helpers) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   globalize(d); globalize(b);
+  IL_ST_BEGIN(IL_ST_POLICY_CRITIC);
   const int nt = d.batch / IL_TILE_R, bx = blockIdx.x;
   if (bx >= 4 * nt) {   // helper: behind both critics' pairs of its tile in block order
     const int h = bx - 4 * nt, tile = h % nt, part = h / nt;
@@ -1362,12 +1366,14 @@ __global__ __launch_bounds__(512) void k_policy_critic_pair(il_sac d, il_batch b
     if ((d.hidden >> 4) <= helpers * (int)(blockDim.x >> 6)) actor_bwd_tile<16, true, true>(d, b, tile, out_logp, out_q, smem, part, helpers, wait);   // one output tile of the last GEMM per wave at most
     else actor_bwd_tile<16, false, true>(d, b, tile, out_logp, out_q, smem, part, helpers, wait);
     IL_TL_END(3);
+    IL_ST_END(IL_ST_POLICY_CRITIC);
     return;
   }
   const int half = bx < 2 * nt ? 1 : 0;
   int k, tile;
   seg_decode(bx % (2 * nt), nt, 2, k, tile);
   policy_critic_pair(d, b, k, tile, half, smem);
+  IL_ST_END(IL_ST_POLICY_CRITIC);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2016,23 +2022,28 @@ static inline bool dw_block32_fits(int H, int B) { return H % DWS == 0 && B % DW
 
 template <bool PEER>
 __device__ __forceinline__ void dw_adam_kernel(const DwArgs& a, const DwPeer* pp, float* smem) {
-  IL_TL(a.log_alpha ? 2 : 1, 0);   // [1] critic launch, [2] actor launch (the one with the alpha / polyak tail)
+  IL_TL(a.log_alpha ? 2 : 1, 0);
+  const int st_kid = a.log_alpha ? IL_ST_DW_ACTOR : IL_ST_DW_CRITIC;
+  IL_ST_BEGIN(st_kid);   // [1] critic launch, [2] actor launch (the one with the alpha / polyak tail)
   if (a.n_big_blocks > 0) {   // [0, n_big_blocks): every layer's dW + bias as 32 x 32 block jobs through LDS (x0 must be feature-major); then the tail blocks
     const int bx = (int)blockIdx.x;
     if (bx < a.n_big_blocks) {
       const int per_net = dw_block_jobs(a.in_dim, a.hidden, a.out_dim);
       dw_block_job<PEER>(a, bx / per_net, bx % per_net, smem, pp, bx);
       IL_TL_END(a.log_alpha ? 2 : 1);
+      IL_ST_END(st_kid);
       return;
     }
     DwArgs r = a;
     r.n_dw_blocks = 0;   // nothing but the tail is left
     dw_adam_body<IL_DW_U, true, PEER>(r, bx - a.n_big_blocks, (int)gridDim.x - a.n_big_blocks, pp);
     IL_TL_END(a.log_alpha ? 2 : 1);
+    IL_ST_END(st_kid);
     return;
   }
   dw_adam_body<IL_DW_U>(a, (int)blockIdx.x, (int)gridDim.x);
   IL_TL_END(a.log_alpha ? 2 : 1);
+  IL_ST_END(st_kid);
 }
 __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[2 * DWS * DWS_LD];
@@ -3059,3 +3070,4 @@ extern "C" int il_act_step(const float* actor, int32_t S, int32_t A, int32_t H, 
 
 IL_STAMP_READER(il_debug_stamps_sac)
 IL_TL_READER(il_debug_timeline_sac)
+IL_ST_READER(il_stamps_sac)

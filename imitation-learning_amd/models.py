@@ -107,9 +107,9 @@ class SoftActor(_FlatModule):
 
   def __new__(cls, state_size=None, action_size=None, model_cfg=None, device=None):
     # train.py:73 builds the DRIL "discriminator" with this same class from the imitation.discriminator config (conf/algorithm/DRIL.yaml: depth 1, tanh,
-    # dropout; conf/optimised_hyperparameters/DRIL_*.yaml: also depth 2 / relu): a config with dropout, or the depth-1 tanh shape, is the policy ensemble
-    if cls is SoftActor and model_cfg is not None and ((_cfg_get(model_cfg, 'depth') == 1 and _cfg_get(model_cfg, 'activation') == 'tanh')
-                                                      or float(_cfg_get(model_cfg, 'dropout', 0) or 0) > 0 or float(_cfg_get(model_cfg, 'input_dropout', 0) or 0) > 0):
+    # dropout 0.1; conf/optimised_hyperparameters/DRIL_*.yaml: also depth 2 / relu): a config WITH dropout is the policy ensemble. A dropout-free depth-1 tanh
+    # network is an ordinary actor of the general-shape engine (reinforcement.actor may ask for it); a dropout-free ensemble is built as DropoutSoftActor(...) directly.
+    if cls is SoftActor and model_cfg is not None and (float(_cfg_get(model_cfg, 'dropout', 0) or 0) > 0 or float(_cfg_get(model_cfg, 'input_dropout', 0) or 0) > 0):
       return super().__new__(DropoutSoftActor)
     return super().__new__(cls)
 

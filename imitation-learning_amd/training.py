@@ -15,7 +15,7 @@ from torch import Tensor
 
 from . import _lib
 from .memory import ReplayMemory, batch_desc, batch_views
-from .models import LOSS_FUNCTIONS, REWARD_FUNCTIONS, GAILDiscriminator, GMMILDiscriminator, SoftActor, TwinCritic
+from .models import LOSS_FUNCTIONS, REWARD_FUNCTIONS, DropoutSoftActor, GAILDiscriminator, GMMILDiscriminator, SoftActor, TwinCritic
 from .optim import Adam, AdamW
 
 _WS: Dict[tuple, Tensor] = {}
@@ -55,11 +55,20 @@ def sac_descriptor(actor: SoftActor, critic: TwinCritic, log_alpha: Tensor, targ
                    temperature_optimiser: Adam, discount: float, entropy_target: float, polyak_factor: float, tag=None, seed_offset: int = 0) -> _lib.Sac:
   S, A, H, dev = actor.state_size, actor.action_size, actor.hidden, actor.flat.device
   assert _lib.on_device(log_alpha) and log_alpha.dtype == torch.float32
+  if isinstance(actor, DropoutSoftActor):
+    raise NotImplementedError('sac_update: a dropout policy ensemble (DRIL discriminator) is not a reinforcement-learning actor of the HIP path')
   if _general_shape(actor, critic):   # csrc/general.hip: its own (larger) scratch layout; reinforcement.actor and reinforcement.critic may differ in every dimension
     floats = int(_lib.lib().il_sac_workspace_floats_general(S, A, H, actor.depth, critic.hidden, critic.depth, batch_size))
   else:
     assert critic.hidden == H
+    # the fused kernels index the arenas by the depth-2 layout: refuse anything whose arena is not exactly that long (an out-of-bounds optimiser step otherwise)
+    want_a, want_c = H * S + H + H * H + H + 2 * A * H + 2 * A, 2 * int(_lib.lib().il_mlp_stride(S + A, H, 1))
+    if actor.flat.numel() != want_a or critic.flat.numel() != want_c or target_critic.flat.numel() != want_c:
+      raise ValueError(f'sac_update: actor / critic arenas of {actor.flat.numel()} / {critic.flat.numel()} floats do not have the fused depth-2 layout ({want_a} / {want_c})')
     floats = int(_lib.lib().il_sac_workspace_floats(S, A, H, batch_size))
+  for opt, net in ((actor_optimiser, actor), (critic_optimiser, critic)):
+    if opt.grad.numel() < net.flat.numel():
+      raise ValueError('sac_update: optimiser state arena shorter than its network')
   ws = _workspace('sac', floats, dev, tag)
   d = _lib.Sac()
   d.state_dim, d.action_dim, d.hidden, d.batch = S, A, H, batch_size
@@ -197,7 +206,7 @@ def shaped_descriptor(disc, batch_size: int, opt, imitation_cfg=None):
     d.grad, d.opt = opt.grad.data_ptr(), opt.desc()
   d.grad_penalty, d.entropy_bonus, d.pos_class_prior, d.discount = grad_penalty, entropy_bonus, prior, float(disc.discount)
   d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
-  d.noise_seed, d.noise_counter = _noise_seed() & (2**64 - 1), _noise_counter(dev, 'disc_shaped').data_ptr()
+  d.noise_seed, d.noise_counter = _noise_seed() & (2**64 - 1), _noise_counter(dev, None).data_ptr()   # the learner's ONE update counter (advanced by the actor step of sac_update): fresh GP / Mixup draws per update
   if loss_function == 'PUGAIL' and margin != float('inf'):   # training.py:102, as in disc_descriptor
     d.pu_clamped, d.nonnegative_margin = 1, margin
   return d
@@ -224,7 +233,7 @@ def deep_descriptor(disc, batch_size: int, opt, imitation_cfg=None) -> _lib.Disc
     d.grad, d.opt = opt.grad.data_ptr(), opt.desc()
   d.grad_penalty, d.entropy_bonus, d.pos_class_prior = grad_penalty, entropy_bonus, prior
   d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
-  d.noise_seed, d.noise_counter = _noise_seed() & (2**64 - 1), _noise_counter(dev, 'disc_deep').data_ptr()
+  d.noise_seed, d.noise_counter = _noise_seed() & (2**64 - 1), _noise_counter(dev, None).data_ptr()   # the learner's ONE update counter (advanced by the actor step of sac_update): fresh GP / Mixup draws per update
   if loss_function == 'PUGAIL' and margin != float('inf'):   # training.py:102, as in disc_descriptor
     d.pu_clamped, d.nonnegative_margin = 1, margin
   return d

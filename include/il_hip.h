@@ -56,6 +56,14 @@ int il_device_info(char* name_host, int name_len, int* cu_count_host);
  * il_trace_report synchronises the device and writes "kernel_name launches total_ms" lines into buf_host. */
 int il_trace_enable(int on);
 int il_trace_report(char* buf_host, int len);
+/* Launch stamps (always on; SURVEY.md 8d measurement, no reference line: the reference has no kernels): thread 0 of every workgroup of the headline schedule's kernels
+ * stores the 100 MHz device-wide counter at its start and after its last wave (two fire-and-forget stores per workgroup; each launch overwrites the previous one's).
+ * il_kernel_stamps synchronises the device and writes, per kernel id (IL_STAMP_*), {min begin, max begin, min end, max end, workgroups} of the LAST launch into
+ * out_host [il_kernel_stamp_ids()][5] (ticks of 10 ns; zeros: not launched since il_kernel_stamps_clear). bench.py reads them after its timed graph replays. */
+enum { IL_STAMP_GAIL_GRAD = 0, IL_STAMP_GAIL_REDUCE = 1, IL_STAMP_CHAIN = 2, IL_STAMP_DW_CRITIC = 3, IL_STAMP_POLICY_CRITIC = 4, IL_STAMP_DW_ACTOR = 5, IL_STAMP_GMMIL = 6, IL_STAMP_PWIL = 7 };
+int32_t il_kernel_stamp_ids(void);
+int il_kernel_stamps(uint64_t* out_host);
+int il_kernel_stamps_clear(void);
 
 /* The on-chip noise of the update kernels as a function: out[i] = draw #i of noise stream `stream_id` at update counter `ctr` under key `noise_seed`,
  * evaluated by the same device functions the kernels call when their eps pointer is NULL (Philox4x32-10 keyed by noise_seed, counter words

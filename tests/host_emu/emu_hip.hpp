@@ -484,7 +484,8 @@ inline void __threadfence_block() {}
 inline void emu_wave_barrier() { const int z = 0; (void)emu::wave_exchange(&z, 4); }   // lanes of a wave run one after the other here: a wave barrier has to be a real rendezvous
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 #define __builtin_amdgcn_s_memtime() 0ull
-#define __builtin_amdgcn_s_memrealtime() 0ull
+inline unsigned long long emu_realtime() { static unsigned long long t = 1000; return ++t; }   // a monotonic stand-in for the 100 MHz device counter (launch stamps: begin < end)
+#define __builtin_amdgcn_s_memrealtime() emu_realtime()
 #define __builtin_amdgcn_s_barrier() __syncthreads()
 namespace emu { inline unsigned xcc_id() { static const char* e = getenv("IL_EMU_XCC"); const unsigned l = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); return e ? (l * 2654435761u >> 7) & 7u : l & 7u; } }   // IL_EMU_XCC=scatter: a placement under which partners do not share an XCD
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
@@ -513,6 +514,9 @@ inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 256; return hip
 inline hipError_t hipDeviceSynchronize() { emu::drain(); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { emu::drain(); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { emu::drain(); memcpy(d, s, n); return hipSuccess; }
+#define HIP_SYMBOL(x) x
+template <class T> inline hipError_t hipMemcpyFromSymbol(void* d, const T& sym, size_t n) { emu::drain(); memcpy(d, &sym, n); return hipSuccess; }
+template <class T> inline hipError_t hipMemcpyToSymbol(T& sym, const void* s, size_t n) { emu::drain(); memcpy(&sym, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t*) { return hipSuccess; }

@@ -521,6 +521,12 @@ def test_timed_path_replays_through_the_oracle_on_the_emulated_kernels(monkeypat
     om.update(k, masks=tt.relu_masks(plan))
     tt.reward_bracket(o, nets[4], got[2], k)
   assert plan.sync_timeouts() == 0
+  # the launch stamps bench.py builds its roofline from (il_kernel_stamps): the six launches of the last replay, every workgroup stamped, begin before end
+  st = _lib.kernel_stamps()
+  assert set(st) >= {'k_gail_grad', 'k_gail_reduce', 'k_sac_chain_pair', 'k_dw_adam_critic', 'k_policy_critic_pair', 'k_dw_adam_actor'}, sorted(st)
+  assert all(v['workgroups'] > 0 and v['begin_us'] < v['end_us'] and v['begin_us'] <= v['last_begin_us'] and v['first_end_us'] <= v['end_us'] for v in st.values()), st
+  assert st['k_sac_chain_pair']['workgroups'] >= 10 * 16 and st['k_dw_adam_critic']['begin_us'] > st['k_sac_chain_pair']['begin_us']
+  _lib.check(_lib.lib().il_kernel_stamps_clear()); assert _lib.kernel_stamps() == {}
   tt.compare_learner_masked(om, nets, plan, WARM + K)
   tt.compare_learner(o, nets, plan, WARM + K)
 

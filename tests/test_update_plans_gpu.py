@@ -146,3 +146,28 @@ def test_plan_rejects_what_it_cannot_capture():
   plan = il.UpdatePlan('AdRIL', *nets, mem, *opts, B, 0.97, -0.5 * A, 0.99, expert_memory=emem, discriminator=disc)
   with pytest.raises(AssertionError, match='relabel_args'):
     plan.run()
+
+
+@pytest.mark.parametrize('variant', ['deep', 'shaping', 'shaping_deep_sublogp'])
+def test_discriminator_variants_draw_fresh_noise_every_update(variant):
+  """training.py:117-119: the gradient-penalty epsilon is a fresh torch.rand per update. The deep / shaped kernels key their on-chip draw by the learner's update counter (the
+  one sac_update's actor step advances): the same discriminator step from the same parameters differs between update counters and repeats for equal counters."""
+  outs = []
+  for bump in (0, 0, 1):
+    nets, opts, mem, emem, disc = build('GAIL', 5, variant=variant)
+    actor = nets[0]
+    ctr = il_training._noise_counter(actor.flat.device)
+    ctr.fill_(bump)
+    t, e = mem.sample(B), emem.sample(B)
+    x = disc.test_extra
+    il.adversarial_imitation_update(actor, disc, t, e, x['discriminator_optimiser'], x['imitation_cfg'])
+    outs.append(N(disc.flat).copy())
+  assert np.isfinite(outs[0]).all()
+  np.testing.assert_array_equal(outs[0], outs[1])
+  assert not np.array_equal(outs[0], outs[2]), 'the gradient-penalty draw must follow the update counter'
+  # and the counter it reads is the one a SAC update advances
+  nets, opts, mem, emem, disc = build('GAIL', 5, variant=variant)
+  ctr = il_training._noise_counter(nets[0].flat.device)
+  before = int(N(ctr)[0])
+  il.sac_update(*nets, mem.sample(B), *opts, 0.97, -0.5 * A, 0.99)
+  assert int(N(ctr)[0]) == before + 1

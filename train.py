@@ -114,7 +114,7 @@ def train(cfg, file_prefix: str = '') -> float:
   elif cfg.algorithm == 'PWIL':
     discriminator = il.PWILDiscriminator(state_size, action_size, cfg.imitation, expert_memory, env.max_episode_steps)
   elif cfg.algorithm == 'DRIL':
-    discriminator = il.SoftActor(state_size, action_size, cfg.imitation.discriminator)   # dropout policy ensemble (train.py:73)
+    discriminator = il.DropoutSoftActor(state_size, action_size, cfg.imitation.discriminator)   # dropout policy ensemble (train.py:73 builds it as SoftActor(...))
     discriminator_optimiser = il.AdamW(discriminator, lr=cfg.imitation.learning_rate, weight_decay=cfg.imitation.weight_decay)
   elif cfg.algorithm == 'RED':
     discriminator = il.REDDiscriminator(state_size, action_size, cfg.imitation)
