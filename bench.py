@@ -298,7 +298,85 @@ def cpu_reference(budget_s=20.0):
               sample=f"{ref['updates_timed']} updates after {ref['warmup']} warm-up: {ref['what']}; source profiles/cpu_reference.json (committed; not re-timed in this run)")
 
 
-def roofline(run_fn, trace_steps, units_per_launch, ms_per_step, side_stream_disc, kernel_units=None):
+STAMP_MODEL = {   # launch-stamp kernel name (imitation_learning_amd._lib.STAMP_KERNELS) -> key of algorithmic_model()'s tables / of profiles/pmc_latest.json
+    'k_gail_grad': 'k_gail_grad', 'k_gail_reduce': 'k_gail_reduce', 'k_sac_chain_pair': 'k_sac_chain', 'k_dw_adam_critic': 'k_dw_adam_critic', 'k_policy_critic_pair': 'k_policy_critic',
+    'k_dw_adam_actor': 'k_dw_adam_actor'}
+PMC_NAMES = {'k_gail_grad': 'k_gail_grad', 'k_gail_reduce': 'k_gail_reduce', 'k_sac_chain_pair': 'k_sac_chain_pair', 'k_dw_adam_critic': 'k_dw_adam', 'k_policy_critic_pair': 'k_policy_critic_pair',
+             'k_dw_adam_actor': 'k_dw_adam'}
+
+
+def load_pmc(schedule_kernels):
+  """profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed with their collection date and commit). Raises when the file does not list the
+  kernels of the schedule that was just timed: a stale counter file must not decorate a new schedule's line."""
+  pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')))
+  missing = sorted({PMC_NAMES[k] for k in schedule_kernels if k in PMC_NAMES} - set(pmc['kernels']))
+  if missing:
+    raise RuntimeError(f'profiles/pmc_latest.json (collected {pmc.get("collected", "?")}) has no entry for {missing}: the counter passes predate the timed schedule - '
+                       're-collect them (profiles/tools/r5_profile.sh pmc) or run with --no-pmc')
+  return pmc
+
+
+def stamp_sample(L_mod):
+  """One reading of the launch stamps (the LAST launch of each headline kernel): {kernel: duration_us} + the main stream's boundaries and span."""
+  st = L_mod.kernel_stamps()
+  out = {k: v['duration_us'] for k, v in st.items()}
+  main = [k for k in ('k_sac_chain_pair', 'k_dw_adam_critic', 'k_policy_critic_pair', 'k_dw_adam_actor') if k in st]
+  if len(main) == 4:
+    for a, b in zip(main[:-1], main[1:]):
+      out[f'boundary:{a}->{b}'] = st[b]['begin_us'] - st[a]['end_us']
+    out['span:main_stream'] = st[main[-1]]['end_us'] - st[main[0]]['begin_us']
+  return out
+
+
+def roofline_from_stamps(samples, ms_per_step, use_pmc=True):
+  """`roofline` of the headline line from device stamps taken INSIDE the timed graph replays (include/il_hip.h il_kernel_stamps): per kernel, first workgroup's start to
+  last workgroup's end of the last launch of a burst of replays; `samples` = one reading per timed repeat / burst; medians reported."""
+  bytes_k, flops_k, update_bytes, update_flops = algorithmic_model()
+  med = lambda xs: float(np.median(np.asarray(xs, dtype=np.float64)))
+  names = [k for k in samples[0] if ':' not in k]
+  kern, per_kernel = {}, {}
+  for k in names:
+    xs = [sm[k] for sm in samples if k in sm]
+    kern[k] = med(xs)
+    e = dict(avg_us=round(kern[k], 3), min_us=round(min(xs), 3), max_us=round(max(xs), 3), samples=len(xs), launches_per_update=1.0)
+    mk = STAMP_MODEL.get(k)
+    if mk in bytes_k: e['hbm_GBps'] = round(bytes_k[mk] / (kern[k] * 1e-6) / 1e9, 2)
+    if mk in flops_k: e['fp32_TFLOPs'] = round(flops_k[mk] / (kern[k] * 1e-6) / 1e12, 3)
+    per_kernel[k] = e
+  side = ('k_gail_grad', 'k_gail_reduce')   # the discriminator branch runs beside the SAC branch on its own stream
+  dom = max((k for k in kern if k not in side), key=lambda k: kern[k])
+  mk = STAMP_MODEL[dom]
+  if mk in flops_k:
+    ach = flops_k[mk] / (kern[dom] * 1e-6) / 1e12
+    roof = dict(bound='mfma', kernel=dom, note='fp32: MFMA f32 rate == VALU f32 rate == 157.3 TFLOP/s on gfx950', achieved=round(ach, 3), peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
+                frac=round(ach / FP32_PEAK_TFLOPS, 5), traffic=None)
+  else:
+    ach = bytes_k.get(mk, 0) / (kern[dom] * 1e-6) / 1e9
+    roof = dict(bound='hbm', kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 5), traffic=None)
+  roof['duration_source'] = (f'device stamps inside the timed hipGraph replays (il_kernel_stamps: thread 0 of every workgroup stores the 100 MHz device counter at start / end; '
+                             f'duration = last end - first start of the last launch of a burst), median of {len(samples)} readings; compare profiles/r05_headline_kernel_stats.md (rocprofv3 '
+                             '--kernel-trace of the same command: dispatch-to-completion, i.e. + the command processor\'s launch and end-of-kernel work)')
+  if use_pmc:
+    pmc = load_pmc(names)
+    roof['traffic'] = pmc['kernels'][PMC_NAMES[dom]]['traffic_bytes']
+    roof['traffic_source'] = dict(file='profiles/pmc_latest.json', collected=pmc.get('collected'), commit=pmc.get('commit'), command=pmc.get('command'),
+                                  how='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, 2*FETCH + WRITE (gfx950 correction of MI355X_MICROARCH.md), per launch; a counter-collecting '
+                                      'profiler serialises kernels, so the passes run `bench.py --no-graph --no-overlap` (same kernels, stream-dependency schedule); not collected in this run')
+    for k, e in per_kernel.items():
+      if PMC_NAMES.get(k) in pmc['kernels']: e['hbm_traffic_bytes'] = pmc['kernels'][PMC_NAMES[k]]['traffic_bytes']
+  upd_gbs = update_bytes / (ms_per_step * 1e-3) / 1e9
+  roof['hbm_frac'] = round(upd_gbs / HBM_PEAK_GBS, 5)
+  roof['fp32_frac'] = round(update_flops / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5)
+  roof['binding_roof'] = 'fp32 (exact-fp32 MFMA = VALU rate): the update needs 3.7 us of fp32 issue but only 0.8 us of HBM time; `frac` above is the dominant kernel against that roof'
+  bnd = {k.split(':', 1)[1]: round(med([sm[k] for sm in samples if k in sm]), 3) for k in samples[0] if k.startswith('boundary:')}
+  roof['update'] = dict(algorithmic_bytes=update_bytes, achieved_GBps=round(upd_gbs, 2), hbm_frac=round(upd_gbs / HBM_PEAK_GBS, 5), algorithmic_flops=update_flops,
+                        fp32_frac=roof['fp32_frac'], sum_main_stream_kernel_us=round(sum(kern[k] for k in kern if k not in side), 2), launch_boundaries_us=bnd,
+                        main_stream_span_us=(round(med([sm['span:main_stream'] for sm in samples if 'span:main_stream' in sm]), 3) if 'span:main_stream' in samples[0] else None))
+  roof['kernels'] = per_kernel
+  return roof
+
+
+def roofline_eager(run_fn, trace_steps, units_per_launch, ms_per_step, side_stream_disc, kernel_units=None):
   """Per-kernel average durations from HIP events recorded on the launch stream(s) (il_trace_*), eager launches of the same kernels;
   `units_per_launch` = updates one step / replay advances (1, or the number of learners on the population path); `kernel_units` = updates ONE kernel launch advances when that
   differs (a population replayed as g parallel sub-populations: learners / g per launch; the per-kernel rates are then lower bounds - a launch shares the chip with the other
@@ -335,18 +413,7 @@ def roofline(run_fn, trace_steps, units_per_launch, ms_per_step, side_stream_dis
   else:
     ach = ku * bytes_k.get(dom, 0) / (kern[dom]['avg_us'] * 1e-6) / 1e9
     roof = dict(bound='hbm', kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 5), traffic=None)
-  try:  # HBM-side bytes per launch from the committed PMC passes (profiles/pmc_latest.json; collected with rocprofv3 --pmc, not in this run)
-    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')))['kernels']
-    if units_per_launch == 1:
-      key = 'k_dw_adam' if dom.startswith('k_dw_adam') else dom
-      roof['traffic'] = pmc.get(key, {}).get('traffic_bytes')
-      roof['traffic_source'] = ('profiles/pmc_latest.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --no-overlap` (a counter-collecting profiler serialises '
-                                'kernels, so the device hand-off schedule cannot run under it: same kernels, stream-dependency schedule, gathered rows); not collected in this run')
-      for k, e in per_kernel.items():
-        kk = 'k_dw_adam' if k.startswith('k_dw_adam') else k
-        if kk in pmc: e['hbm_traffic_bytes'] = pmc[kk]['traffic_bytes']
-  except Exception:
-    pass
+  roof['duration_source'] = 'HIP events around EAGER launches of the same kernels (il_trace_*): an upper bound on each duration (the window includes device-side waits the timed schedule overlaps)'
   upd_gbs = units_per_launch * update_bytes / (ms_per_step * 1e-3) / 1e9
   # Whole-update fractions at the top level. The contract figure is the HBM fraction; the BINDING roof of this path is fp32 compute:
   # 0.587 GFLOP at 157.3 TFLOP/s is 3.7 us per update = 268k updates/s = 22 % of the HBM roof, so hbm_frac cannot exceed 0.22 before fp32_frac reaches 1.
@@ -373,6 +440,7 @@ def self_launch(args) -> int:
           '(IL_BENCH_SHARE_GPU=1 lets test ranks share a device over gloo)', file=sys.stderr)
     return 2
   attempts = [({}, None)]
+  os.environ.setdefault('IL_PEER_EXCHANGE', '1')   # the benchmark A/Bs both exchanges in one job (main()); the product's default is RCCL (parallel.DataParallelUpdate)
   if os.environ.get('IL_PEER_EXCHANGE', '1') != '0':
     attempts.append((dict(IL_PEER_EXCHANGE='0'), 'the run with the peer-window gradient exchange failed (launcher exit code {rc}); this is the retry with IL_PEER_EXCHANGE=0 (RCCL all-reduces)'))
   rc, note = 1, None
@@ -406,6 +474,10 @@ def main():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=2000)
   ap.add_argument('--warmup', type=int, default=200)
+  ap.add_argument('--repeats', type=int, default=5, help='timed repeats; `value` is their median (SURVEY.md 8d)')
+  ap.add_argument('--min-seconds', type=float, default=0.2, help='a timed repeat runs max(--steps, enough replays for this many seconds)')
+  ap.add_argument('--stamp-bursts', type=int, default=20, help='extra untimed bursts of 50 replays after the timed repeats, each read for its launch stamps')
+  ap.add_argument('--no-pmc', action='store_true', help='do not attach roofline.traffic from profiles/pmc_latest.json (what the counter-collecting passes themselves run with)')
   ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--trace-steps', type=int, default=100)
@@ -421,6 +493,7 @@ def main():
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
     sys.exit(self_launch(args))   # `python bench.py --gpus N` on its own: start the N ranks (torch.distributed.run), pass their JSON line through
   world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+  if world > 1: os.environ.setdefault('IL_PEER_EXCHANGE', '1')   # N > 1: time the peer-window exchange AND the RCCL all-reduces in this one job (exchange_ab), report the better valid one; RCCL is the product's default
   if world != args.gpus:
     sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...` '
              f'(or plain `python bench.py --gpus {args.gpus}`, which starts the ranks itself)')
@@ -468,7 +541,7 @@ def main():
       torch.cuda.synchronize()
 
   def measure():
-    """warm-up (eager, then captured), the timed region, max over ranks. Returns (elapsed seconds, launch mode)."""
+    """warm-up (eager, then captured), the timed repeats, max over ranks. Returns (median seconds of a repeat, launch mode, timing record)."""
     beat('eager warm-up')
     for _ in range(5):
       runner.run()   # loads code objects before capture; the first one sets up communicators / peer windows (self-test + soak)
@@ -492,16 +565,33 @@ def main():
     for _ in range(args.warmup):
       step()
     barrier()
+
+    def timed(n):
+      """n steps between two barrier + synchronize brackets; seconds, max over ranks."""
+      t0 = time.perf_counter()
+      for _ in range(n):
+        step()
+      barrier()
+      t = torch.tensor([time.perf_counter() - t0], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
+      if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      return float(t.item())
+
     beat('timed region')
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-      step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
-    if world > 1:
-      dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item()), launch
+    # `--steps` replays alone can be a ~1 ms window (the driver's --steps 20): every repeat times max(--steps, enough replays for --min-seconds), sized from one pass
+    # of --steps (max over ranks, so every rank computes the same count); `value` = the median of --repeats such repeats.
+    probe = timed(args.steps)
+    n = max(args.steps, int(np.ceil(args.min_seconds / max(probe / args.steps, 1e-9))))
+    reps, stamps = [], []
+    stamped = args.learners == 1
+    if stamped: _lib.check(_lib.lib().il_kernel_stamps_clear())
+    for _ in range(max(1, args.repeats)):
+      reps.append(timed(n))
+      if stamped and rank == 0: stamps.append(stamp_sample(_lib))   # the last replay's launches, read outside the timed bracket
+    for _ in range(args.stamp_bursts if stamped else 0):   # more readings of the same schedule: short bursts of back-to-back replays (untimed), the last replay of each is read
+      timed(min(n, 50))
+      if rank == 0: stamps.append(stamp_sample(_lib))
+    return float(np.median(reps)), launch, dict(timed_replays=n, repeats=len(reps), repeat_seconds=[round(r, 6) for r in reps], probe_seconds=round(probe, 6), stamps=stamps)
 
   def health():
     """Collective verdict on the run just timed: (ok on every rank, replicas bit-identical, digests, note)."""
@@ -512,7 +602,8 @@ def main():
     note = f'rank {rank}: {ex} expired exchange waits, {hs} expired hand-off waits' if (ex or hs) else None
     return ok, same, digests, note
 
-  elapsed, launch = measure()
+  elapsed, launch, timing = measure()
+  steps_timed = timing['timed_replays']
   exchange_fallback = None
   ok, same, digests, note = health()
   # N > 1: BOTH gradient exchanges timed in this one invocation (an 8-GPU node may be available for a single run per round): first the default - the peer-window exchange,
@@ -520,20 +611,21 @@ def main():
   # that passed the post-run check (no expired wait, replicas bit-identical); config.exchange names it, config.exchange_ab carries both.
   exchange_ab = None
   if world > 1 and getattr(runner, 'peer', None) is not None and ok and same and os.environ.get('IL_BENCH_EXCHANGE_AB', '1') != '0':
-    first = dict(exchange=runner.exchange_name(), updates_per_s=round(world * args.steps / elapsed, 1), ms_per_step=round(elapsed / args.steps * 1e3, 5), launch=launch,
+    first = dict(exchange=runner.exchange_name(), updates_per_s=round(world * steps_timed / elapsed, 1), ms_per_step=round(elapsed / steps_timed * 1e3, 5), launch=launch,
                  replicas_bit_identical=same, replica_digests=[d[:16] for d in digests], exchange_soak=getattr(runner.peer, 'soak_report', None), valid=True)
     peer_form = getattr(runner.peer, 'form', 0)
     beat('A/B: the collectives')
     runner.use_collectives('A/B run of bench.py: the same job re-timed with torch.distributed all-reduces')
     plan.sync[plan._sync_timeouts] = 0
     runner.resync_replicas()
-    elapsed2, launch2 = measure()
+    elapsed2, launch2, timing2 = measure()
     ok2, same2, digests2, note2 = health()
-    second = dict(exchange=runner.exchange_name(), updates_per_s=round(world * args.steps / elapsed2, 1), ms_per_step=round(elapsed2 / args.steps * 1e3, 5), launch=launch2,
+    second = dict(exchange=runner.exchange_name(), updates_per_s=round(world * timing2['timed_replays'] / elapsed2, 1), ms_per_step=round(elapsed2 / timing2['timed_replays'] * 1e3, 5), launch=launch2,
                   replicas_bit_identical=same2, replica_digests=[d[:16] for d in digests2], valid=bool(ok2 and same2), note=note2)
-    exchange_ab = dict(peer=first, collectives=second, chosen='peer' if (not second['valid'] or elapsed <= elapsed2) else 'collectives')
+    exchange_ab = dict(peer=first, collectives=second, chosen='peer' if (not second['valid'] or first['ms_per_step'] <= second['ms_per_step']) else 'collectives')
     if exchange_ab['chosen'] == 'collectives':
-      elapsed, launch, ok, same, digests, note = elapsed2, launch2, ok2, same2, digests2, note2
+      elapsed, launch, ok, same, digests, note, timing = elapsed2, launch2, ok2, same2, digests2, note2, timing2
+      steps_timed = timing['timed_replays']
     else:
       exchange_ab['reported_exchange'] = first['exchange']   # (the runner itself now sits on the collectives; the line below reports the run that was chosen)
   if world > 1 and getattr(runner, 'peer', None) is not None and not (ok and same):
@@ -544,7 +636,8 @@ def main():
     runner.use_collectives(exchange_fallback)
     plan.sync[plan._sync_timeouts] = 0
     runner.resync_replicas()
-    elapsed, launch = measure()
+    elapsed, launch, timing = measure()
+    steps_timed = timing['timed_replays']
     ok, same, digests, note = health()
   finite = all(bool(torch.isfinite(n.flat if hasattr(n, 'flat') else n).all()) for n in nets)
   if not ok:
@@ -573,21 +666,26 @@ def main():
     barrier()
     del plan1, nets1
   if rank == 0:
-    ms_per_step = elapsed / args.steps * 1e3
-    ups = world * args.learners * args.steps / elapsed
-    # ---- per-kernel durations, HIP events on the launch stream, eager launches of the very same kernels
-    # (traced with the index draw stream-ordered ahead of the forward / critic-loss launch: with the resident draw that launch is dispatched while the draw is still
-    #  waiting for the previous update, so its HIP-event window would include that wait instead of its own work; both schedules are bit-identical)
-    fused_desc, plan.peer_desc = getattr(plan, 'peer_desc', None), None   # (data-parallel runs: the per-kernel windows are taken on this rank's plain single-GPU launches - the fused exchange lives on the resident-sampler schedule only, and rank 0 alone runs this section)
-    plan.stream_ordered_draw = True
-    roof = roofline(plan.run, args.trace_steps, 1, ms_per_step, getattr(plan, 'overlap', False))
-    plan.stream_ordered_draw = False
-    plan.peer_desc = fused_desc
-    roof['frac_note'] = ('`frac` / `achieved` are an eager-window LOWER bound: the HIP-event window around an eager launch includes the device-side waits the timed schedule overlaps '
-                         '(k_sac_chain 30 us here against 24.0 us in the rocprofv3 trace of the graph replays, profiles/r04_headline_kernel_stats.md: 289 MFLOP / 24.0 us = 12.0 TFLOP/s = 0.077 of fp32)')
-    roof['timing_note'] = 'kernel durations: HIP events around eager launches with the index draw stream-ordered (il_replay_sample_device); the timed `value` above runs the resident-draw schedule as two hipGraphs'
+    ms_per_step = elapsed / steps_timed * 1e3
+    ups = world * args.learners * steps_timed / elapsed
+    # ---- per-kernel durations: device stamps taken inside the timed graph replays (il_kernel_stamps). Schedules whose kernels carry no stamps (IL_PAIR=0, shapes outside
+    # pair mode, --no-graph --no-overlap runs under a counter-collecting profiler) fall back to HIP events around eager launches of the same kernels.
+    samples = [sm for sm in timing['stamps'] if 'k_sac_chain_pair' in sm and 'k_policy_critic_pair' in sm and 'k_dw_adam_actor' in sm]
+    if samples and world == 1:
+      roof = roofline_from_stamps(samples, ms_per_step, use_pmc=not args.no_pmc)
+    else:
+      # (traced with the index draw stream-ordered ahead of the forward / critic-loss launch: with the resident draw that launch is dispatched while the draw is still
+      #  waiting for the previous update, so its HIP-event window would include that wait instead of its own work; both schedules are bit-identical)
+      fused_desc, plan.peer_desc = getattr(plan, 'peer_desc', None), None   # (data-parallel runs: the per-kernel windows are taken on this rank's plain single-GPU launches - the fused exchange lives on the resident-sampler schedule only, and rank 0 alone runs this section)
+      plan.stream_ordered_draw = True
+      roof = roofline_eager(plan.run, args.trace_steps, 1, ms_per_step, getattr(plan, 'overlap', False))
+      plan.stream_ordered_draw = False
+      plan.peer_desc = fused_desc
+      if samples:   # N > 1: rank 0's stamps of the data-parallel launches, beside the eager windows of its single-GPU launches
+        roof['stamped_kernels_data_parallel'] = roofline_from_stamps(samples, ms_per_step, use_pmc=False)['kernels']
+    roof['timing'] = {k: v for k, v in timing.items() if k != 'stamps'}
 
-    out = dict(metric='SAC+GAIL grad-updates/sec (batch 256, HalfCheetah dims)', value=round(ups, 1), unit='updates/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+    out = dict(metric='SAC+GAIL grad-updates/sec (batch 256, HalfCheetah dims)', value=round(ups, 1), unit='updates/s', n_gpus=world, steps=args.steps, warmup=args.warmup, timed_replays=steps_timed, repeats=timing['repeats'],
                ms_per_step=round(ms_per_step, 5), higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                config=dict(workload='algorithm=GAIL env=halfcheetah: 2 replay samples + discriminator step (BCE+GP+SN) + AIRL relabel + sac_update per step',
                            batch_per_gpu=B, global_batch=B * world, state_dim=S, action_dim=A, hidden=H, replay_capacity=1_000_000, replay_fill=100_000, expert_rows=25_000,
@@ -622,8 +720,8 @@ def main():
         pop.replay()
       torch.cuda.synchronize()
       dt = (time.perf_counter() - t1) / 200
-      proof = roofline(pop.run, 10, Lp, dt * 1e3, False, kernel_units=Lp // max(1, args.population_groups))
-      if args.population_groups > 1: proof['note'] += f'; {args.population_groups} sub-populations run as parallel branches: `frac` is a lower bound (a launch covers {Lp // args.population_groups} learners and shares the chip with the other branch for part of its HIP-event window), the whole-replay fp32_frac is exact'
+      proof = roofline_eager(pop.run, 10, Lp, dt * 1e3, False, kernel_units=Lp // max(1, args.population_groups))
+      if args.population_groups > 1: proof['note'] = proof.get('note', '') + f'; {args.population_groups} sub-populations run as parallel branches: `frac` is a lower bound (a launch covers {Lp // args.population_groups} learners and shares the chip with the other branch for part of its HIP-event window), the whole-replay fp32_frac is exact'
       proof.pop('kernels', None)
       out['population'] = dict(learners=Lp, groups=args.population_groups, aggregate_updates_per_s=round(Lp / dt, 1), ms_per_replay=round(dt * 1e3, 5), roofline=proof,
                                note=f'{Lp} independent batch-256 SAC+GAIL learners (il_*_population launches: learner id = grid dimension, learner l on XCD l % 8; {args.population_groups} sub-populations as parallel graph branches), own replay ring / index stream / Philox counter each')

@@ -43,9 +43,13 @@ extern "C" int il_peer_window_alloc(int64_t bytes, void** window_host, unsigned 
   IL_CHECK_ARG(bytes > 0 && window_host && handle_host && kind_host, "il_peer_window_alloc: bad arguments");
   *kind_host = 0;
   void* p = nullptr;
-  // uncached (MTYPE UC: neither this GPU's L2 nor a peer's keeps a line of it, what RCCL uses for its own flag / LL buffers on gfx94x+), else fine-grained
-  hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
-  if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained); *kind_host = 1; }
+  // uncached (MTYPE UC: neither this GPU's L2 nor a peer's keeps a line of it, what RCCL uses for its own flag / LL buffers on gfx94x+), else fine-grained.
+  // IL_PEER_WINDOW_KIND=uncached | finegrained forces one kind (tests: both kinds of window under the two-process soak; no fallback to the other kind then).
+  const char* want = getenv("IL_PEER_WINDOW_KIND");
+  const bool only_uc = want && want[0] == 'u', only_fg = want && want[0] == 'f';
+  hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, only_fg ? hipDeviceMallocFinegrained : hipDeviceMallocUncached);
+  if (only_fg) *kind_host = 1;
+  if (e != hipSuccess && !only_uc && !only_fg) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained); *kind_host = 1; }
   if (e != hipSuccess) return il_set_error(IL_ERR_HIP, "il_peer_window_alloc: hipExtMallocWithFlags(uncached / fine-grained, %lld bytes): %s", (long long)bytes, hipGetErrorString(e));
   e = hipMemset(p, 0, (size_t)bytes);
   if (e == hipSuccess) e = hipDeviceSynchronize();

@@ -459,10 +459,11 @@ class DataParallelUpdate:
       dist.barrier(self.group)
 
   def _setup_peer_exchange(self):
-    """IL_PEER_EXCHANGE: unset / '1' = the one-kernel exchange over peer-mapped windows whenever more than one rank takes part (falls back, on every rank, if set-up or
-    the self-test fails anywhere); '0' = torch.distributed all-reduces; 'force' = also with a single rank (exercises the kernel on a 1-GPU box); 'require' = raise instead
-    of falling back."""
-    mode = os.environ.get('IL_PEER_EXCHANGE', '1')
+    """IL_PEER_EXCHANGE: unset / '0' = torch.distributed all-reduces (RCCL: the exchange BASELINE.json's north_star names, and the default of every run); '1' = the
+    one-kernel exchange over peer-mapped windows whenever more than one rank takes part (falls back, on every rank, if set-up or the self-test fails anywhere) - opt-in
+    until a multi-GPU run has shown it to win (bench.py --gpus N times both in one job and reports the better VALID one); 'force' = also with a single rank (exercises the
+    kernel on a 1-GPU box); 'require' = raise instead of falling back."""
+    mode = os.environ.get('IL_PEER_EXCHANGE', '0')
     world = dist.get_world_size(self.group) if dist.is_initialized() else 1
     if mode == '0' or (world == 1 and mode not in ('force', 'require')):
       self.fused = False   # (the fused form lives on the peer windows)

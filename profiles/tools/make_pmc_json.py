@@ -1,6 +1,7 @@
 """Builds profiles/pmc_latest.json (what bench.py reports as roofline.traffic) from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd sqlite).
-Usage: python profiles/tools/make_pmc_json.py <FETCH db> <WRITE db> > profiles/pmc_latest.json"""
-import json, sqlite3, sys
+Usage: IL_COMMIT=<short sha> python profiles/tools/make_pmc_json.py <FETCH db> <WRITE db> "<profiled command>" > profiles/pmc_latest.json
+Kernel names are the launched kernels' own (k_sac_chain_pair, ...): bench.py refuses a file that does not list the kernels of the schedule it timed."""
+import datetime, json, os, sqlite3, sys
 
 def per_kernel(path, counter):
   agg = {}
@@ -15,6 +16,7 @@ fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'W
 out = {'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), eager launches of bench.py --no-graph; per-launch averages in KB; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024: '
                'gfx950 FETCH_SIZE reports half of wide coalesced reads (MI355X_MICROARCH.md HBM section). k_dw_adam averages the critic and the actor launch; '
                'k_policy_critic includes the policy backward that runs as its tail.',
+       'collected': datetime.datetime.utcnow().strftime('%Y-%m-%d %H:%M UTC'), 'commit': os.environ.get('IL_COMMIT', 'unknown'), 'command': sys.argv[3] if len(sys.argv) > 3 else None,
        'kernels': {}}
 for k in sorted(set(fetch) | set(write)):
   f, w = fetch.get(k, 0.0), write.get(k, 0.0)

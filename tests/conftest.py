@@ -34,3 +34,8 @@ def pytest_terminal_summary(terminalreporter):
     return
   worst = sorted(gu.FRACTIONS, key=lambda t: -t[1])[:5]
   terminalreporter.write_line('largest outlier fractions (measured / allowed): ' + '; '.join(f'{n}: {f:.1e} / {a:.0e}' for n, f, a in worst))
+  out = os.environ.get('IL_FRACTIONS_OUT')   # every measured fraction as JSON (the tolerance ledger of DESIGN.md 4 is built from a GPU run's file)
+  if out:
+    import json
+    with open(out, 'w') as f:
+      json.dump([dict(site=n, measured=fr, allowed=a) for n, fr, a in gu.FRACTIONS], f, indent=1)

@@ -179,3 +179,18 @@ def test_reference_cpu_baseline_runner_reports_every_configuration():
     assert res['one_thread_without_memory_sample'] >= res['one_thread_with_memory_sample'] * 0.8
   assert j['nproc'] >= 1 and j['cpu_model'] and set(j['manifest']['modules']) == {'memory', 'models', 'training'}
   assert time.time() - t0 < 120, 'the runner must stay inside its time box'
+
+
+def test_committed_pmc_file_lists_the_kernels_of_the_timed_schedule():
+  """bench.py attaches roofline.traffic from profiles/pmc_latest.json and refuses (raises) when the file does not list the kernels of the schedule it has just timed: checked
+  here, on the CPU, so that a stale counter file is caught before the round-end bench is."""
+  import bench
+  pmc = bench.load_pmc(list(bench.STAMP_MODEL))
+  assert pmc.get('collected') and pmc.get('commit'), 'the PMC passes carry their collection date and commit (roofline.traffic_source)'
+  for k in bench.STAMP_MODEL:
+    assert pmc['kernels'][bench.PMC_NAMES[k]]['traffic_bytes'] > 0
+  import pytest
+  with pytest.raises(RuntimeError, match='predate the timed schedule'):
+    bench.PMC_NAMES['k_new_kernel'] = 'k_new_kernel'
+    try: bench.load_pmc(['k_new_kernel'])
+    finally: bench.PMC_NAMES.pop('k_new_kernel')

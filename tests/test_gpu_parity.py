@@ -465,7 +465,16 @@ def test_device_beta_draws_are_beta_distributed(alpha):
   n = 200_000
   u = _beta_draws(12345, 7, alpha, n).astype(np.float64)
   assert np.isfinite(u).all() and 0.0 <= u.min() and u.max() <= 1.0
-  assert stats.kstest(u, stats.beta(alpha, alpha).cdf).pvalue > 1e-3
+  if alpha >= 0.2:
+    assert stats.kstest(u, stats.beta(alpha, alpha).cdf).pvalue > 1e-3
+  else:
+    # Beta(0.05, 0.05) puts ~20 % of its mass within 6e-8 of 1, where float32 has no numbers left (they round to 1.0; float32 resolves the same mass near 0 down to 1e-38):
+    # the lower half against the truncated law, the halves' weights against 1/2
+    # and ~1 % below 1e-38, which float32 flushes to 0): the law truncated to (1e-30, 0.5) on the draws in it, and the weights of the three pieces
+    F, cut = stats.beta(alpha, alpha).cdf, 1e-30
+    lo = u[(u > cut) & (u < 0.5)]
+    assert abs((u < 0.5).mean() - 0.5) < 5 * np.sqrt(0.25 / n) and abs((u <= cut).mean() - F(cut)) < 5 * np.sqrt(F(cut) / n)
+    assert stats.kstest(lo, lambda x: (F(x) - F(cut)) / (0.5 - F(cut))).pvalue > 1e-3
   var = 1.0 / (4.0 * (2.0 * alpha + 1.0))
   assert abs(u.mean() - 0.5) < 5 * np.sqrt(var / n) and abs(u.var() - var) < 0.02 * var
   np.testing.assert_array_equal(u, _beta_draws(12345, 7, alpha, n).astype(np.float64))

@@ -513,6 +513,7 @@ def test_timed_path_replays_through_the_oracle_on_the_emulated_kernels(monkeypat
   plan.capture(warmup=0)
   assert plan.device_sync and plan.ring_mode and plan.inline_relabel and plan.resident_sampler and plan.graph_side is not None, 'this must be the schedule bench.py times'
   tt.compare_learner(o, nets, plan, WARM, 'eager warm-up: ')
+  _lib.check(_lib.lib().il_kernel_stamps_clear())   # (launches of earlier tests in this process: other grids)
   for k in range(WARM, WARM + K):
     plan.replay()
     torch.cuda.synchronize()

@@ -177,6 +177,48 @@ def test_peer_exchange_kernel_two_ranks(tmp_path):
     assert (rounds, mism, expired, nb, has_load) == (300, 0, 0, 11, 1), 'create() adopts a form only after the soak: every bucket + the 4 MB load bucket, interleaved on three streams, bitwise every round'
 
 
+SOAK_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from imitation_learning_amd import parallel
+rank, _, dev = parallel.init_from_env(2, 'gloo')
+sizes = dict(disc=1665, critic=144904, actor=73744)                       # the three gradient buckets of the headline shape
+x = parallel.PeerExchange.create(sizes, dev, jobs=dict(disc=7, critic=160, actor=149) if sys.argv[3] == 'jobs' else None)   # jobs: the form that rides in the optimiser launches
+assert x is not None, 'peer-window set-up, self-test or soak failed'
+rep = dict(x.soak_report, uncached=bool(x.uncached), form_flag=int(x.form), timeouts=x.timeouts())
+json.dump(rep, open(os.path.join(sys.argv[2], f'soak{rank}.json'), 'w'))
+x.close()
+dist.barrier(); dist.destroy_process_group()
+'''
+HAMMER = "import torch, time\na = torch.empty(64 << 20, dtype=torch.uint8, device='cuda'); b = torch.empty_like(a)\nm = torch.randn(2048, 2048, device='cuda')\nt = time.time(); k = 0\nwhile time.time() - t < 120:\n  b.copy_(a); k += 1\n  if k % 7 == 0: (m @ m).sum().item()\n  torch.cuda.synchronize(); time.sleep(0.0003 * (k % 5))\n"
+
+
+@pytest.mark.parametrize('kind,layout', [('uncached', 'chunks'), ('uncached', 'jobs'), ('finegrained', 'chunks'), ('finegrained', 'jobs')])
+def test_peer_protocol_between_two_processes_soaks_under_uneven_load(tmp_path, kind, layout):
+  """The peer-window protocol between two PROCESSES (own address spaces; each maps the other's window through hipIpc, as two GPUs would) under the set-up soak - every bucket
+  of the headline shape, interleaved on three streams with the 4 MB load bucket, compared bitwise on the device every round - while a THIRD process hammers the same GPU with
+  copy bursts and GEMMs at irregular intervals (uneven load: the MI355X guide's warning that idle chips and uniform load hide hand-off failures). Both window kinds forced
+  (IL_PEER_WINDOW_KIND): uncached windows must adopt the write-through form (payload through sc0 sc1 stores, drained flag, no fences), fine-grained windows the
+  system-scope release / acquire form. One GPU: what this cannot show is the xGMI path to a PEER's HBM (DESIGN.md 5)."""
+  import json
+  script = tmp_path / 'soak_worker.py'
+  script.write_text(SOAK_WORKER)
+  bg = subprocess.Popen([sys.executable, '-c', HAMMER], cwd=ROOT)
+  try:
+    import time
+    time.sleep(4)   # the hammer's first copies are under way
+    _launch([str(script), ROOT, str(tmp_path), layout], str(tmp_path), IL_PEER_SOAK_ROUNDS='1500', IL_PEER_WINDOW_KIND=kind, IL_PEER_EXCHANGE='require')
+  finally:
+    bg.kill(); bg.wait()
+  for r in (0, 1):
+    rep = json.load(open(tmp_path / f'soak{r}.json'))
+    assert rep['rounds'] == 1500 and rep['expired_waits'] == 0 and rep['timeouts'] == 0 and not any(rep['mismatching_elements'].values()), rep
+    assert set(rep['buckets']) == {'disc', 'critic', 'actor', '_load'}
+    assert rep['uncached'] == (kind == 'uncached') and rep['form'] == ('write-through' if kind == 'uncached' else 'fences'), rep
+
+
 def test_peer_exchange_single_rank_is_identity():
   """World size 1 (IL_PEER_EXCHANGE=force, no process group): push to the own window, sum of one slab, mean = the input bits; the data-parallel split path through it equals
   the split path without an exchange."""
@@ -270,7 +312,7 @@ def test_bench_runs_the_multi_gpu_default_schedule_with_one_rank(fused):
   c = j['config']
   assert j['n_gpus'] == 1 and j['value'] > 0 and c['replicas_bit_identical'] is True and c['exchange'].startswith('peer')
   assert ('inside the optimiser launches' in c['exchange']) == (fused == '1')
-  assert 'k_sac_chain' in j['roofline']['kernels'] and c['finite'] is True
+  assert any(k.startswith('k_sac_chain') for k in j['roofline']['kernels']) and c['finite'] is True
 
 
 @pytest.mark.parametrize('peer', ['1', '0'])

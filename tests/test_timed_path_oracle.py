@@ -130,6 +130,11 @@ def compare_learner_masked(o, nets, plan, k, tag='masked oracle: '):
   close_sparse(crit_from_flat(critic, co.exp_avg), o.st.critic_m, f'{tag}critic exp_avg', atol_scale=s, outlier_frac=f); close_sparse(crit_from_flat(critic, co.exp_avg_sq), o.st.critic_v, f'{tag}critic exp_avg_sq', atol_scale=s, outlier_frac=f)
 
 
+# the unmasked twin-critic comparison's allowance: what the three seeds of test_captured_update_plan_replays_through_the_oracle and the three learners of the population
+# test measure (tolerance ledger) + 25 %
+CRITIC_UNMASKED_FRAC = 1.5e-3
+
+
 def compare_learner(o, nets, plan, k, tag=''):
   """Every persistent tensor of the learner after k updates, at the tests/gpu_util.py bounds."""
   actor, critic, target, log_alpha, disc = nets
@@ -139,8 +144,8 @@ def compare_learner(o, nets, plan, k, tag=''):
   # measured worst case over the learners of these tests is 1.0e-3 of the elements, round 3; everything else uses the 5e-4 default of tests/gpu_util.py). The run prints the
   # largest measured fractions at its end (conftest.pytest_terminal_summary).
   # (gate=False: the fraction is recorded, not warned about - compare_learner_masked is the gate of these tests; this comparison documents how far two correct evaluations drift)
-  close_params(N(actor.flat), o.st.actor, f'{tag}actor after {k}', LR, k); close_params(crit_from_flat(critic, critic.flat), o.st.critic, f'{tag}critic after {k}', LR, k, outlier_frac=1.5e-3, gate=False)
-  close_params(crit_from_flat(critic, target.flat), o.st.target, f'{tag}target after {k}', LR, k, outlier_frac=1.5e-3, gate=False)
+  close_params(N(actor.flat), o.st.actor, f'{tag}actor after {k}', LR, k); close_params(crit_from_flat(critic, critic.flat), o.st.critic, f'{tag}critic after {k}', LR, k, outlier_frac=CRITIC_UNMASKED_FRAC, gate=False)
+  close_params(crit_from_flat(critic, target.flat), o.st.target, f'{tag}target after {k}', LR, k, outlier_frac=CRITIC_UNMASKED_FRAC, gate=False)
   close(N(log_alpha), o.st.log_alpha, f'{tag}log_alpha after {k}', atol_scale=s)
   close_sparse(N(ao.exp_avg), o.st.actor_m, f'{tag}actor exp_avg', atol_scale=s); close_sparse(N(ao.exp_avg_sq), o.st.actor_v, f'{tag}actor exp_avg_sq', atol_scale=s)
   close_sparse(crit_from_flat(critic, co.exp_avg), o.st.critic_m, f'{tag}critic exp_avg', atol_scale=s); close_sparse(crit_from_flat(critic, co.exp_avg_sq), o.st.critic_v, f'{tag}critic exp_avg_sq', atol_scale=s)
@@ -176,8 +181,9 @@ def compare_outputs(got, want, k, tag=''):
 
 
 # ------------------------------------------------------------------------------------------------ a23: the single-learner plan bench.py times
-def test_captured_update_plan_replays_through_the_oracle():
-  WARM, K, SEED = 2, 10, 3
+@pytest.mark.parametrize('SEED', [3, 4, 5])
+def test_captured_update_plan_replays_through_the_oracle(SEED):
+  WARM, K = 2, 10
   il_training._NOISE.clear(); il_training._WS.clear()
   plan, nets, (tr, et) = bench.build(torch.device(DEV), 0, seed=SEED)
   o = OracleLearner(nets, plan, tr, et, index_seed=SEED)
