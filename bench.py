@@ -369,6 +369,8 @@ def roofline_from_stamps(samples, ms_per_step, use_pmc=True):
   roof['fp32_frac'] = round(update_flops / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5)
   roof['binding_roof'] = 'fp32 (exact-fp32 MFMA = VALU rate): the update needs 3.7 us of fp32 issue but only 0.8 us of HBM time; `frac` above is the dominant kernel against that roof'
   bnd = {k.split(':', 1)[1]: round(med([sm[k] for sm in samples if k in sm]), 3) for k in samples[0] if k.startswith('boundary:')}
+  if 'span:main_stream' in samples[0]:   # what is left of the update period: the last launch of an update -> the first launch of the next one
+    bnd['k_dw_adam_actor->k_sac_chain_pair (next update)'] = round(ms_per_step * 1e3 - med([sm['span:main_stream'] for sm in samples if 'span:main_stream' in sm]), 3)
   roof['update'] = dict(algorithmic_bytes=update_bytes, achieved_GBps=round(upd_gbs, 2), hbm_frac=round(upd_gbs / HBM_PEAK_GBS, 5), algorithmic_flops=update_flops,
                         fp32_frac=roof['fp32_frac'], sum_main_stream_kernel_us=round(sum(kern[k] for k in kern if k not in side), 2), launch_boundaries_us=bnd,
                         main_stream_span_us=(round(med([sm['span:main_stream'] for sm in samples if 'span:main_stream' in sm]), 3) if 'span:main_stream' in samples[0] else None))
@@ -479,6 +481,7 @@ def main():
   ap.add_argument('--stamp-bursts', type=int, default=20, help='extra untimed bursts of 50 replays after the timed repeats, each read for its launch stamps')
   ap.add_argument('--no-pmc', action='store_true', help='do not attach roofline.traffic from profiles/pmc_latest.json (what the counter-collecting passes themselves run with)')
   ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+  ap.add_argument('--launch', choices=('graph', 'direct'), default=os.environ.get('IL_BENCH_LAUNCH', 'graph'), help='how the timed updates are issued: two hipGraph replays per update, or UpdatePlan.launch_direct (the same two branches as direct launches: two library calls per update, no hipGraph)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--trace-steps', type=int, default=100)
   ap.add_argument('--no-overlap', action='store_true', help='one stream, no device-side hand-off: the same kernels back to back (what a counter-collecting profiler needs; il_sac_update still takes its chained launch)')
@@ -549,7 +552,11 @@ def main():
     if runner is not plan and getattr(runner, 'handoff', False) and not runner.agree_on_handoff():   # collective: an expired device-side wait on ANY rank sends every rank to the stream-dependency schedule
       print(f'[bench] rank {rank}: device-side hand-off left (a bounded wait expired on some rank during the eager warm-up); using stream dependencies', file=sys.stderr)
     launch, step = 'eager', runner.run
-    if not args.no_graph and not (gloo_eager and getattr(runner, 'peer', None) is None):
+    if args.launch == 'direct' and runner is plan and not args.no_graph and getattr(plan, 'device_sync', False):
+      beat('recording the direct launches')
+      plan.record_direct()
+      step, launch = plan.launch_direct, 'direct launches (UpdatePlan.launch_direct: two library calls per update, six kernel launches on two streams, no hipGraph)'
+    elif not args.no_graph and not (gloo_eager and getattr(runner, 'peer', None) is None):
       beat('graph capture')
       try:
         runner.capture(warmup=0)

@@ -128,7 +128,8 @@ extern "C" int il_noise_fill_beta(uint64_t noise_seed, const uint32_t* ctr_dev, 
 // counter: out_host[kid][0..4] = {min begin, max begin, min end, max end, workgroups stamped}; all 0 when the kernel has not run since il_kernel_stamps_clear().
 // Synchronises the device. bench.py derives `roofline.kernels` from these after its timed graph replays.
 // ---------------------------------------------------------------------------------------------
-extern "C" int il_stamps_sac(unsigned long long*); extern "C" int il_stamps_gail(unsigned long long*); extern "C" int il_stamps_sac_clear(); extern "C" int il_stamps_gail_clear();
+extern "C" int il_stamps_sac(unsigned long long*); extern "C" int il_stamps_gail(unsigned long long*); extern "C" int il_stamps_gmmil(unsigned long long*);
+extern "C" int il_stamps_sac_clear(); extern "C" int il_stamps_gail_clear(); extern "C" int il_stamps_gmmil_clear();
 extern "C" int32_t il_kernel_stamp_ids(void) { return IL_ST_K; }
 extern "C" int il_kernel_stamps(uint64_t* out_host) {
   IL_CHECK_ARG(out_host, "il_kernel_stamps: null argument");
@@ -138,7 +139,7 @@ extern "C" int il_kernel_stamps(uint64_t* out_host) {
   static table_t tb;
   memset(out_host, 0, sizeof(uint64_t) * IL_ST_K * 5);
   struct Src { int (*read)(unsigned long long*); int first, last; };
-  const Src srcs[2] = {{il_stamps_gail, IL_ST_GAIL_GRAD, IL_ST_GAIL_REDUCE}, {il_stamps_sac, IL_ST_CHAIN, IL_ST_DW_ACTOR}};
+  const Src srcs[3] = {{il_stamps_gail, IL_ST_GAIL_GRAD, IL_ST_GAIL_REDUCE}, {il_stamps_sac, IL_ST_CHAIN, IL_ST_DW_ACTOR}, {il_stamps_gmmil, IL_ST_GMMIL, IL_ST_GMMIL}};
   for (const Src& sc : srcs) {
     if (sc.read(&tb[0][0][0]) != 0) return il_set_error(IL_ERR_HIP, "il_kernel_stamps: reading a stamp table failed");
     for (int k = sc.first; k <= sc.last; ++k) {
@@ -160,7 +161,7 @@ extern "C" int il_kernel_stamps(uint64_t* out_host) {
 extern "C" int il_kernel_stamps_clear(void) {
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) return il_set_error(IL_ERR_HIP, "il_kernel_stamps_clear: %s", hipGetErrorString(e));
-  return (il_stamps_gail_clear() == 0 && il_stamps_sac_clear() == 0) ? IL_OK : il_set_error(IL_ERR_HIP, "il_kernel_stamps_clear: clearing a stamp table failed");
+  return (il_stamps_gail_clear() == 0 && il_stamps_sac_clear() == 0 && il_stamps_gmmil_clear() == 0) ? IL_OK : il_set_error(IL_ERR_HIP, "il_kernel_stamps_clear: clearing a stamp table failed");
 }
 
 // sizeof() of the descriptor structs as this library was compiled: a binding checks its own struct definitions against these

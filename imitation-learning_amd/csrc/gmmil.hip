@@ -16,6 +16,7 @@
 // (4.3-4.9 ticks per v_pk instruction per SIMD); what the kernel time holds beyond it is the first fabric round trip, the exp epilogue, the
 // release ticket and the last arriver's sums.
 #include "il_common.hpp"
+IL_ST_TABLE
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define GT 64   // tile edge (pairs): columns of a pair tile, rows of a pack tile
@@ -416,6 +417,195 @@ __global__ __launch_bounds__(256) void k_gmmil_direct(il_batch pol, il_batch exp
   if (out_sim) out_sim[i] = sim;
   if (out_self) out_self[i] = self;
 }
+// ---------------------------------------------------------------------------------------------
+// k_gmmil_resident (round 5): k_gmmil_direct with the WHOLE feature range of both operand tiles resident in LDS (64 rows x D features each: 2 x 30 KB at Ant dims, two
+// workgroups per CU) instead of a ring of 32-feature chunks. The chunked form paid two workgroup barriers and a burst of transposing LDS stores per chunk - phases in which
+// the SIMDs issue no pair arithmetic - and its feature loop ran at ~64 % of the packed-op issue rate with two co-resident workgroups (profiles/r02_gmmil_timeline.md: 27.5k
+// ticks for 2 x 4 chunks of 2.2k). Here: every operand lane is requested up front (as before: D <= 128 always had all chunks in flight), stored transposed with the same
+// XOR swizzle, ONE barrier, then a barrier-free loop over all features with the LDS operands double-buffered in registers. The arrival of a tile's partial row sums is
+// fence-free (the pair-mode kernels' mechanism, mlp_tile.hpp): partials written THROUGH (sc0 sc1), stores drained, barrier, one relaxed ticket; the last arriver reads them
+// below the caches - no agent-scope release (an L2 write-back per workgroup) and no acquire. Same pair arithmetic in the same feature order, same 64-column partial sums,
+// same tile-ordered final sums: bit-identical to k_gmmil_direct / k_gmmil_pack + k_gmmil_tile.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int gmmil_kp4(int D) { return (D + 3) & ~3; }
+static size_t gmmil_resident_lds(int D) { return ((size_t)gmmil_kp4(D) * (GTR + GT) + 64) * sizeof(float); }
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gmmil_resident(il_batch pol, il_batch exp, int S, int D, float g1, float g2, float* __restrict__ ws_, float* __restrict__ dist_out, int self_second,
+                                                        float* __restrict__ out_r, float* __restrict__ out_sim, float* __restrict__ out_self, int lanes) {
+  constexpr int RB = GMMIL_RB, RQ = RB / 4, GG = GMMIL_GG;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  IL_ST_BEGIN(IL_ST_GMMIL);
+  const int KP = gmmil_kp4(D);
+  float* Xs = smem;                       // [KP][GTR], column r of feature k at (r ^ 4 ((k / 4) % 8))
+  float* Ys = Xs + (size_t)KP * GTR;      // [KP][GT]
+  float* red = Ys + (size_t)KP * GT;      // [32] block_sum scratch, [32] = "last arriver" flag
+  globalize(pol); globalize(exp);
+  const int n1 = pol.n, n2 = exp.n;
+  const GmmilWs w = gmmil_ws(n1, n2, D);
+  const int it = blockIdx.x, jt = blockIdx.y, mat = blockIdx.z;  // mat 0: policy vs expert, 1: policy vs policy
+  const bool vs_self = (mat == 1) || (MODE == 1 && self_second);
+  const int npy = vs_self ? w.b1p : w.b2p;
+  if (jt * GT >= npy) { IL_ST_END(IL_ST_GMMIL); return; }
+  const il_batch& yb = vs_self ? pol : exp;
+  const int ny = yb.n;
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  float sx = 0.f, sy = 0.f;
+  if (MODE == 0) {
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) sx += pol.weights[(size_t)i * pol.ld_weights];
+    if (!vs_self) for (int i = threadIdx.x; i < ny; i += blockDim.x) sy += yb.weights[(size_t)i * yb.ld_weights];
+  }
+  // every 16-byte operand lane of both tiles, requested before anything is consumed (chunks of 32 features = 8 lanes along a row, like k_gmmil_direct); NCH chunks in registers
+  constexpr int PX4 = GKC * GTR / 4 / 256, PY4 = GKC * GT / 4 / 256, NCH = 5;   // D <= 160 (the launcher checks)
+  f32x4 xr[NCH][PX4], yr[NCH][PY4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c * GKC < D) {
+#pragma unroll
+      for (int u = 0; u < PX4; ++u) { const int i = threadIdx.x + u * 256, r = i >> 3, kq = i & 7; xr[c][u] = cat_lane(pol, S, D, min(it * GTR + r, n1 - 1), c * GKC + 4 * kq, lanes != 0); }
+#pragma unroll
+      for (int u = 0; u < PY4; ++u) { const int i = threadIdx.x + u * 256, r = i >> 3, kq = i & 7; yr[c][u] = cat_lane(yb, S, D, min(jt * GT + r, ny - 1), c * GKC + 4 * kq, lanes != 0); }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c * GKC < D) {
+#pragma unroll
+      for (int u = 0; u < PX4; ++u) {
+        const int i = threadIdx.x + u * 256, r = i >> 3, kq = i & 7, col = r ^ (4 * kq);
+        const bool rv = it * GTR + r < n1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int k = c * GKC + 4 * kq + q; if (k < KP) Xs[(size_t)k * GTR + col] = (rv && k < D) ? xr[c][u][q] : 0.f; }
+      }
+#pragma unroll
+      for (int u = 0; u < PY4; ++u) {
+        const int i = threadIdx.x + u * 256, r = i >> 3, kq = i & 7, col = r ^ (4 * kq);
+        const bool rv = jt * GT + r < ny;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int k = c * GKC + 4 * kq + q; if (k < KP) Ys[(size_t)k * GT + col] = (rv && k < D) ? yr[c][u][q] : 0.f; }
+      }
+    }
+  }
+  __syncthreads();
+  f32x2 acc2[RB][2];
+#pragma unroll
+  for (int a = 0; a < RB; ++a) { acc2[a][0] = f32x2{0.f, 0.f}; acc2[a][1] = f32x2{0.f, 0.f}; }
+  {
+    f32x4 xa_[GG][RQ], ya_[GG], xb_[GG][RQ], yb_[GG];
+    auto lds_group = [&](f32x4 (*xg)[RQ], f32x4* yg, int kb) {   // (both features of a group of GG = 2 share the swizzle of their group of four)
+      const int sw = ((kb >> 2) & 7) << 2;
+#pragma unroll
+      for (int u = 0; u < GG; ++u) {
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) xg[u][q] = *reinterpret_cast<const f32x4*>(&Xs[(size_t)(kb + u) * GTR + ((ti * RB + 4 * q) ^ sw)]);
+        yg[u] = *reinterpret_cast<const f32x4*>(&Ys[(size_t)(kb + u) * GT + ((tj * 4) ^ sw)]);
+      }
+    };
+    auto fma_group = [&](const f32x4 (*xg)[RQ], const f32x4* yg) {
+#pragma unroll
+      for (int u = 0; u < GG; ++u) {
+        const f32x2 y01 = {yg[u][0], yg[u][1]}, y23 = {yg[u][2], yg[u][3]};
+#pragma unroll
+        for (int a = 0; a < RB; ++a) {   // two pairs per instruction: v_pk_add_f32 + v_pk_fma_f32 (same roundings as the scalar sub + fma)
+          const float xs = xg[u][a >> 2][a & 3];
+          const f32x2 xa = {xs, xs};
+          const f32x2 d0 = xa - y01, d1 = xa - y23;
+          acc2[a][0] = __builtin_elementwise_fma(d0, d0, acc2[a][0]);
+          acc2[a][1] = __builtin_elementwise_fma(d1, d1, acc2[a][1]);
+        }
+      }
+    };
+    lds_group(xa_, ya_, 0);
+#pragma unroll 1
+    for (int kb = 0; kb < KP; kb += 2 * GG) {   // features kb .. kb + 3 (features >= D are zeros on both sides: they add (0 - 0)^2)
+      lds_group(xb_, yb_, kb + GG);
+      __builtin_amdgcn_sched_barrier(0);
+      fma_group(xa_, ya_);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_group(xa_, ya_, min(kb + 2 * GG, KP - GG));   // (the last trip re-reads a group that is discarded instead of branching)
+      __builtin_amdgcn_sched_barrier(0);
+      fma_group(xb_, yb_);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float acc[RB][4];
+#pragma unroll
+  for (int a = 0; a < RB; ++a) { acc[a][0] = acc2[a][0][0]; acc[a][1] = acc2[a][0][1]; acc[a][2] = acc2[a][1][0]; acc[a][3] = acc2[a][1][1]; }
+  const float fD = (float)D;
+  if (MODE == 1) {
+    const int n2e = vs_self ? n1 : n2;
+#pragma unroll
+    for (int a = 0; a < RB; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = it * GTR + ti * RB + a, j = jt * GT + tj * 4 + b;
+        if (i < n1 && j < n2e) dist_out[(size_t)i * n2e + j] = acc[a][b] / fD;
+      }
+    IL_ST_END(IL_ST_GMMIL);
+    return;
+  }
+  sx = block_sum(sx, red);
+  sy = vs_self ? sx : block_sum(sy, red);
+  f32x4 wv;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { const int j = jt * GT + tj * 4 + b; wv[b] = j < ny ? yb.weights[(size_t)j * yb.ld_weights] / sy : 0.f; }
+  float* part = ws_ + w.part + ((size_t)mat * w.njt + jt) * w.b1p + it * GTR;
+#pragma unroll
+  for (int a = 0; a < RB; ++a) {
+    float s = 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { const float dd = acc[a][b] / fD; s += wv[b] * (expf(-g1 * dd) + expf(-g2 * dd)); }
+    s = group16_sum(s);
+    if (tj == 0) wstore1(part, ti * RB + a, s);   // written through: the row tile's last arriver reads it below the caches
+  }
+  if (!out_r) { IL_ST_END(IL_ST_GMMIL); return; }
+  // The row tile's reward needs the partial sums of every column tile of BOTH matrices: the workgroup that arrives last adds them up in tile order. Every wave drains its
+  // write-through stores, barrier, ONE relaxed ticket (no release: nothing of this workgroup that another one reads sits in a cache); the counter is left at zero.
+  unsigned* lastp = reinterpret_cast<unsigned*>(red + 32);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned expect = (unsigned)(w.b2p / GT + w.b1p / GT);
+    unsigned* ctr = reinterpret_cast<unsigned*>(ws_ + w.ctr) + it * GCTR;
+    const unsigned last = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == expect;
+    if (last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next call
+    *lastp = last;
+  }
+  __syncthreads();
+  const bool last = *lastp != 0u;
+  const int i = it * GTR + threadIdx.x;
+  if (last && threadIdx.x < GTR && i < n1) {
+    // all partials of a matrix requested before the first add (a dependent load-add chain is one fabric round trip per column tile); added in tile order
+    auto ordered_sum = [&](const float* p, int nq) {
+      float s = 0.f;
+      for (int q0 = 0; q0 < nq; q0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = sload1(p, (int64_t)min(q0 + u, nq - 1) * w.b1p + i);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (q0 + u < nq) s += v[u];
+      }
+      return s;
+    };
+    const float s0 = ordered_sum(ws_ + w.part, w.b2p / GT);
+    const float s1 = ordered_sum(ws_ + w.part + (size_t)w.njt * w.b1p, w.b1p / GT);
+    const float wi = pol.weights[(size_t)i * pol.ld_weights] / sx;
+    const float sim = wi * s0, self = wi * s1;
+    out_r[i] = sim - self;
+    if (out_sim) out_sim[i] = sim;
+    if (out_self) out_self[i] = self;
+  }
+  IL_ST_END(IL_ST_GMMIL);
+}
+static int gmmil_resident_on(int D) {   // IL_GMMIL_RESIDENT=0: the chunked k_gmmil_direct (developer A/B; same bits). D <= 160: five chunks of operand lanes in registers
+  static const int on = [] { const char* e = getenv("IL_GMMIL_RESIDENT"); return e && e[0] == '0' ? 0 : 1; }();
+  return on != 0 && D >= 4 && D <= 160;
+}
+template <class K>
+static int gmmil_ensure_lds(K fn, size_t bytes) {
+  if (bytes <= 64 * 1024) return IL_OK;
+  const hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return e == hipSuccess ? IL_OK : il_set_error(IL_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", bytes, hipGetErrorString(e));
+}
 static bool gmmil_direct() { static const int on = [] { const char* e = getenv("IL_GMMIL_DIRECT"); return e && e[0] == '0' ? 0 : 1; }(); return on != 0; }   // IL_GMMIL_DIRECT=0: k_gmmil_pack + k_gmmil_tile (developer A/B; same bits)
 static int gmmil_lanes(const il_batch* a, const il_batch* b, int S, int A, int state_only) {   // whole 16-byte lanes along the rows of both batches?
   auto ok = [&](const il_batch* x) {
@@ -434,6 +624,14 @@ extern "C" int il_gmmil_reward(const il_batch* pol, const il_batch* exp, int32_t
   const GmmilWs w = gmmil_ws(pol->n, exp->n, D);
   if (workspace_floats < w.total) return il_set_error(IL_ERR_WORKSPACE, "il_gmmil_reward: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)w.total);
   hipStream_t st = (hipStream_t)stream_;
+  if (gmmil_direct() && gmmil_resident_on(D)) {
+    const size_t lds = gmmil_resident_lds(D);
+    if (int rc = gmmil_ensure_lds(k_gmmil_resident<0>, lds)) return rc;
+    IL_TRACE("k_gmmil_tile", st);
+    k_gmmil_resident<0><<<dim3(w.b1p / GTR, w.njt, 2), 256, lds, st>>>(*pol, *exp, S, D, g1, g2, workspace, nullptr, 0, out_rewards, out_sim, out_self, gmmil_lanes(pol, exp, S, A, state_only));
+    IL_CHECK_LAUNCH("il_gmmil_reward");
+    return IL_OK;
+  }
   if (gmmil_direct() && D >= 4) {
     IL_TRACE("k_gmmil_tile", st);
     k_gmmil_direct<0><<<dim3(w.b1p / GTR, w.njt, 2), 256, 0, st>>>(*pol, *exp, S, D, g1, g2, workspace, nullptr, 0, out_rewards, out_sim, out_self, gmmil_lanes(pol, exp, S, A, state_only));
@@ -456,6 +654,14 @@ extern "C" int il_gmmil_sqdist(const il_batch* a, const il_batch* b, int32_t S, 
   const GmmilWs w = gmmil_ws(a->n, b->n, D);
   if (workspace_floats < w.total) return il_set_error(IL_ERR_WORKSPACE, "il_gmmil_sqdist: workspace too small");
   hipStream_t st = (hipStream_t)stream_;
+  if (gmmil_direct() && gmmil_resident_on(D)) {
+    const size_t lds = gmmil_resident_lds(D);
+    if (int rc = gmmil_ensure_lds(k_gmmil_resident<1>, lds)) return rc;
+    IL_TRACE("k_gmmil_tile", st);
+    k_gmmil_resident<1><<<dim3(w.b1p / GTR, w.b2p / GT, 1), 256, lds, st>>>(*a, *b, S, D, 0.f, 0.f, workspace, out, 0, nullptr, nullptr, nullptr, gmmil_lanes(a, b, S, A, state_only));
+    IL_CHECK_LAUNCH("il_gmmil_sqdist");
+    return IL_OK;
+  }
   if (gmmil_direct() && D >= 4) {
     IL_TRACE("k_gmmil_tile", st);
     k_gmmil_direct<1><<<dim3(w.b1p / GTR, w.b2p / GT, 1), 256, 0, st>>>(*a, *b, S, D, 0.f, 0.f, workspace, out, 0, nullptr, nullptr, nullptr, gmmil_lanes(a, b, S, A, state_only));
@@ -469,3 +675,4 @@ extern "C" int il_gmmil_sqdist(const il_batch* a, const il_batch* b, int32_t S, 
 }
 
 IL_STAMP_READER(il_debug_stamps_gmmil)
+IL_ST_READER(il_stamps_gmmil)

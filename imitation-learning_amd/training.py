@@ -331,6 +331,34 @@ def gail_predict_reward(disc: GAILDiscriminator, state: Tensor, action: Tensor, 
 
 
 # ----------------------------------------------------------------------------------------------- GMMIL
+_GMMIL_WS: Dict[tuple, Tensor] = {}   # insertion-ordered: the oldest shape is evicted beyond _GMMIL_WS_MAX entries
+
+
+_GMMIL_WS_MAX = 16
+
+
+def _gmmil_workspace(n1: int, n2: int, D: int, device, tag=None) -> Tensor:
+  """il_gmmil_reward / il_gmmil_sqdist scratch (include/il_hip.h): partial row sums + self-resetting arrival counters, zero-filled at creation. One per (shape, learner
+  `tag`, stream): two learners or two streams with the same shape must not share the counters; a bounded cache (callers with ever-changing batch sizes evict the oldest).
+  A launch that was aborted mid-way leaves its counters non-zero: `_gmmil_workspace_reset()` after handling such an error."""
+  try:
+    stream = int(torch.cuda.current_stream().cuda_stream)
+  except Exception:   # (no HIP device: the host emulation of tests/host_emu drives the library with CPU tensors)
+    stream = 0
+  key = (n1, n2, D, str(device), tag, stream)
+  ws = _GMMIL_WS.pop(key, None)
+  if ws is None:
+    ws = torch.zeros(int(_lib.lib().il_gmmil_workspace_floats(n1, n2, D)), dtype=torch.float32, device=device)
+    while len(_GMMIL_WS) >= _GMMIL_WS_MAX:
+      _GMMIL_WS.pop(next(iter(_GMMIL_WS)))
+  _GMMIL_WS[key] = ws   # (re-inserted: most recently used last)
+  return ws
+
+
+def _gmmil_workspace_reset():
+  _GMMIL_WS.clear()
+
+
 def _weighted_median(x: Tensor, weights: Tensor) -> Tensor:
   """Reference models.py:40-44 (first call only; a device sort of B^2 values)."""
   x_sorted, indices = torch.sort(x.flatten())
@@ -347,7 +375,7 @@ def embedding_sqdist(x: Tensor, y: Tensor) -> Tensor:
   """models.py:25-29 `_squared_distance` between two sets of feature rows [n1, D], [n2, D] -> [n1, n2] (k_gmmil_tile, direct form)."""
   n1, n2, D = x.size(0), y.size(0), x.size(1)
   dev = x.device
-  ws = _workspace(f'gmmil:{n1}:{n2}:{D}', int(_lib.lib().il_gmmil_workspace_floats(n1, n2, D)), dev, zero=True)   # (arrival counters: zero once per shape, left at zero by every call)
+  ws = _gmmil_workspace(n1, n2, D, dev)
   out = torch.empty(n1, n2, device=dev)
   w1, w2 = torch.ones(n1, device=dev), torch.ones(n2, device=dev)   # named: an il_batch holds raw pointers, the tensors must outlive the launch
   ba, bb = _sa_batch(x, x, w1), _sa_batch(y, y, w2)
@@ -359,7 +387,7 @@ def gmmil_sqdist(disc: GMMILDiscriminator, a_state, a_action, b_state, b_action)
   dev = a_state.device
   na, nb = a_state.size(0), b_state.size(0)
   D = disc.state_size + (0 if disc.state_only else disc.action_size)
-  ws = _workspace(f'gmmil:{na}:{nb}:{D}', int(_lib.lib().il_gmmil_workspace_floats(na, nb, D)), dev, zero=True)
+  ws = _gmmil_workspace(na, nb, D, dev, tag=getattr(disc, '_ws_tag', None))
   out = torch.empty(na, nb, device=dev)
   wa, wb = torch.ones(na, device=dev), torch.ones(nb, device=dev)
   ba, bb = _sa_batch(a_state, a_action, wa), _sa_batch(b_state, b_action, wb)
@@ -375,7 +403,7 @@ def gmmil_predict_reward(disc: GMMILDiscriminator, state, action, expert_state, 
     disc.gamma_2 = 1 / (_weighted_median(gmmil_sqdist(disc, expert_state, expert_action, expert_state, expert_action), torch.outer(expert_weight, expert_weight)).item() + 1e-8)
   n1, n2 = state.size(0), expert_state.size(0)
   D = disc.state_size + (0 if disc.state_only else disc.action_size)
-  ws = _workspace(f'gmmil:{n1}:{n2}:{D}', int(_lib.lib().il_gmmil_workspace_floats(n1, n2, D)), dev, zero=True)   # (arrival counters: zero once per shape, left at zero by every call)
+  ws = _gmmil_workspace(n1, n2, D, dev, tag=getattr(disc, '_ws_tag', None))   # (arrival counters: zero at creation, left at zero by every call)
   out = torch.empty(n1, device=dev)
   sim, self_sim = (torch.empty(n1, device=dev), torch.empty(n1, device=dev)) if return_parts else (None, None)
   pb, eb = _sa_batch(state, action, weight), _sa_batch(expert_state, expert_action, expert_weight)
@@ -885,7 +913,9 @@ class UpdatePlan:
         self.rewards.copy_(gmmil_predict_reward(d, t['states'], t['actions'], e['states'], e['actions'], t['weights'].contiguous(), e['weights'].contiguous()))
         return
       D = d.state_size + (0 if d.state_only else d.action_size)
-      ws = _workspace(f'gmmil:{self.B}:{self.B}:{D}', int(L.il_gmmil_workspace_floats(self.B, self.B, D)), self.rows.device, zero=True)
+      if getattr(self, '_gmmil_ws', None) is None:   # this learner's own counters and partial sums, kept with the plan (a captured graph holds the pointer)
+        self._gmmil_ws = torch.zeros(int(L.il_gmmil_workspace_floats(self.B, self.B, D)), dtype=torch.float32, device=self.rows.device)
+      ws = self._gmmil_ws
       _lib.check(L.il_gmmil_reward(C.byref(self.pb), C.byref(self.eb), d.state_size, d.action_size, int(d.state_only), float(d.gamma_1), float(d.gamma_2), _lib.ptr(self.rewards), None, None,
                                    _lib.ptr(ws), ws.numel(), st))
     elif alg == 'RED':
@@ -923,6 +953,49 @@ class UpdatePlan:
     with torch.cuda.graph(self.graph):
       for _ in range(updates): self.run()
     return self
+
+  def record_direct(self):
+    """The two-branch schedule `capture()` records, as DIRECT launches: runs one update while recording the library calls of each branch (entry point + its ctypes
+    arguments, stream included), so that `launch_direct()` re-issues exactly those calls - two calls into libil_hip.so per update, six kernel launches, no hipGraph and no
+    stream edge. A hipGraph replay pays the graph-launch bookkeeping of the runtime between two replays on a stream; a direct launch is one AQL packet per kernel
+    (DESIGN.md 3.5 has the measurement). The main branch is recorded on the CALLER's current stream and must be launched from it."""
+    assert self.device_sync and (self.algorithm == 'GAIL' or self.resident_sampler), 'record_direct: the device hand-off schedule (two unjoined branches) only'
+    assert not self.pre_hooks and not self.post_hooks, 'record_direct: hooks (an attached ActingWorker) are captured with the update: use capture()'
+    self.memory.stream().device_state(self.rows.device)
+
+    class Recorder:
+      def __init__(self, real): self.real, self.calls = real, []
+      def __getattr__(self, name):
+        fn = getattr(self.real, name)
+        def call(*args):
+          self.calls.append((fn, args))
+          return fn(*args)
+        return call
+
+    real = _lib.lib()
+    out = []
+    try:
+      for branch in ('side', 'main'):
+        rec = Recorder(real)
+        _lib._lib, self._capturing = rec, branch
+        if branch == 'side':
+          with torch.cuda.stream(self.side): self._run_update()
+        else:
+          self._run_update()
+        out.append([(fn, args) for fn, args in rec.calls if getattr(fn, '__name__', '').startswith('il_') and fn.restype is C.c_int])
+    finally:
+      _lib._lib, self._capturing = real, None
+    self._direct_side, self._direct_main = out
+    self._captured_resident = self.resident_sampler
+    return self
+
+  def launch_direct(self):
+    if self.main_feeds_ring and self._captured_resident:
+      self.side.wait_stream(torch.cuda.current_stream())   # (as replay(): appends enqueued since the last update precede the resident index draw)
+    for fn, args in self._direct_side:
+      if fn(*args) != 0: _lib.check(1)
+    for fn, args in self._direct_main:
+      if fn(*args) != 0: _lib.check(1)
 
   def join(self):
     """Order the caller's stream after the plan's second stream: `replay()` leaves the two branches unjoined (no edge between the graphs), so anything the caller reads

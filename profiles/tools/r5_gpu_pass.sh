@@ -72,6 +72,15 @@ for what in "$@"; do
       cat $OUT/dp_one_rank.txt >> $OUT/summary.txt; head -n 24 $OUT/dp_rccl_kernel_stats.md | tee -a $OUT/summary.txt ;;
     acting)
       timeout 600 python profiles/tools/acting_bench.py > $OUT/acting.json 2> $OUT/acting.err; echo "acting rc=$?" | tee -a $OUT/summary.txt; tail -n 3 $OUT/acting.json | cut -c1-1500 | tee -a $OUT/summary.txt ;;
+    ab_direct)
+      # interleaved on one box: hipGraph replays against direct launches of the same two branches (UpdatePlan.launch_direct)
+      for i in 1 2 3; do for m in graph direct; do timeout 300 python bench.py --launch $m --steps 2000 --warmup 200 --repeats 3 --stamp-bursts 10 $QUICK 2>$OUT/ab_direct.err | line "launch=$m" | tee -a $OUT/ab_direct.txt; done; done
+      cat $OUT/ab_direct.txt >> $OUT/summary.txt ;;
+    ab_gmmil)
+      for i in 1 2 3; do for m in 1 0; do IL_GMMIL_RESIDENT=$m timeout 300 python profiles/tools/secondary_workloads.py gmmil_rate 2>$OUT/ab_gmmil.err | tail -n 1 | sed "s/^/IL_GMMIL_RESIDENT=$m /" | tee -a $OUT/ab_gmmil.txt; done; done
+      cat $OUT/ab_gmmil.txt >> $OUT/summary.txt ;;
+    tests_k)
+      IL_FRACTIONS_OUT=$OUT/fractions_k.json timeout 1500 python -m pytest tests/ -m gpu -q -k "$IL_TESTS_K" > $OUT/pytest_k.log 2>&1; echo "pytest -k rc=$?" | tee -a $OUT/summary.txt; tail -n 12 $OUT/pytest_k.log | tee -a $OUT/summary.txt ;;
     gmmil) trace gmmil "python profiles/tools/secondary_workloads.py gmmil"; head -n 12 $OUT/gmmil_kernel_stats.md | tee -a $OUT/summary.txt ;;
     pwil) trace pwil "python profiles/tools/secondary_workloads.py pwil"; head -n 12 $OUT/pwil_kernel_stats.md | tee -a $OUT/summary.txt ;;
     pop32) trace pop32 "python profiles/tools/secondary_workloads.py population 32"; head -n 24 $OUT/pop32_kernel_stats.md | tee -a $OUT/summary.txt ;;

@@ -17,6 +17,26 @@ if what == 'gmmil':
   w = torch.ones(Bg, device=dev)
   gm = il.GMMILDiscriminator(Sg, Ag, bench.Cfg(state_only=False))
   for _ in range(300): gm.predict_reward(xs, xa, es, ea, w, w)
+elif what == 'gmmil_rate':   # calls/s + the kernel's duration from its launch stamps (il_kernel_stamps): IL_GMMIL_RESIDENT / IL_GMMIL_DIRECT select the form
+  import time, hashlib
+  from imitation_learning_amd import _lib
+  rs = np.random.RandomState(5)
+  Sg, Ag, Bg = 112, 8, 1024
+  mk = lambda shift: (torch.from_numpy((rs.standard_normal((Bg, Sg)) + shift).astype(np.float32)).to(dev), torch.from_numpy(rs.uniform(-1, 1, (Bg, Ag)).astype(np.float32)).to(dev))
+  (xs, xa), (es, ea) = mk(0.0), mk(0.5)
+  w = torch.ones(Bg, device=dev)
+  gm = il.GMMILDiscriminator(Sg, Ag, bench.Cfg(state_only=False))
+  for _ in range(50): r = gm.predict_reward(xs, xa, es, ea, w, w)
+  torch.cuda.synchronize()
+  durs, rates = [], []
+  for _ in range(5):
+    t0 = time.perf_counter()
+    for _ in range(1000): r = gm.predict_reward(xs, xa, es, ea, w, w)
+    torch.cuda.synchronize()
+    rates.append(1000 / (time.perf_counter() - t0))
+    st = _lib.kernel_stamps().get('k_gmmil_direct')
+    if st: durs.append(st['duration_us'])
+  print(f"gmmil B=1024 Ant: {np.median(rates):.0f} calls/s, kernel (stamps, resident form only) {np.median(durs) if durs else float('nan'):.2f} us, digest {hashlib.sha256(r.cpu().numpy().tobytes()).hexdigest()[:12]}")
 elif what == 'pwil':
   import inputs as gi
   atoms, agent = gi.pwil_case(22, 25000, 24, 1100)

@@ -364,6 +364,44 @@ def test_gmmil_full_size_properties():
   close(N(sim)[rows], osim, 'full-size similarity'); close(N(self_sim)[rows], oself, 'full-size self similarity')
 
 
+GMMIL_FORMS_WORKER = r'''
+import hashlib, sys
+sys.path[:0] = [sys.argv[1], sys.argv[1] + '/tests', sys.argv[1] + '/tests/golden']
+import numpy as np, torch
+import inputs as gi
+import imitation_learning_amd as il
+from imitation_learning_amd import training as T_
+from gpu_util import T, N, Cfg
+h = hashlib.sha256()
+for seed, (n1, n2, D), S in ((5, (1024, 1024, 120), 112), (6, (300, 200, 35), 29), (7, (64, 48, 24), 16), (8, (130, 257, 132), 124)):   # Ant at the timed size; ragged, rows that are not whole 16-byte lanes; small; D > 128
+  X, E, w, we = gi.gmmil_case(seed, n1, n2, D, weighted=True)
+  disc = il.GMMILDiscriminator(S, D - S, Cfg(state_only=False))
+  disc.gamma_1, disc.gamma_2 = 0.37, 0.91
+  args = (T(X[:, :S]), T(X[:, S:]), T(E[:, :S]), T(E[:, S:]))
+  for _ in range(3):   # the arrival counters are self-resetting: the third call must see what the first saw
+    r, sim, self_sim = T_.gmmil_predict_reward(disc, *args, T(w), T(we), return_parts=True)
+  d = T_.gmmil_sqdist(disc, *args)
+  for t in (r, sim, self_sim, d): h.update(np.ascontiguousarray(N(t)).tobytes())
+print('DIGEST', h.hexdigest())
+'''
+
+
+def test_gmmil_launch_forms_are_bit_identical(tmp_path):
+  """k_gmmil_resident (round 5: all features of both tiles resident in LDS, fence-free arrival), k_gmmil_direct (chunked ring) and k_gmmil_pack + k_gmmil_tile keep every
+  pair's accumulation order over the features, the 64-column partial sums and the tile-ordered final sums: the same bits for rewards, both similarities and the distance
+  matrix, at the timed size, for ragged shapes, for rows that are not whole 16-byte lanes and for D > 128. (The switches are read once per process: one process per form.)"""
+  import subprocess, sys
+  script = tmp_path / 'forms.py'
+  script.write_text(GMMIL_FORMS_WORKER)
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  digests = {}
+  for name, env in (('resident', {}), ('direct', dict(IL_GMMIL_RESIDENT='0')), ('pack+tile', dict(IL_GMMIL_DIRECT='0'))):
+    r = subprocess.run([sys.executable, str(script), root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    digests[name] = [l for l in r.stdout.splitlines() if l.startswith('DIGEST')][-1].split()[1]
+  assert len(set(digests.values())) == 1, digests
+
+
 def test_pwil_matches_oracle_and_reference(golden_dir):
   g = load(golden_dir, 'pwil')
   Nn, D, steps, Th = 400, 10, 260, 120

@@ -532,6 +532,12 @@ def test_timed_path_replays_through_the_oracle_on_the_emulated_kernels(monkeypat
   tt.compare_learner(o, nets, plan, WARM + K)
 
 
+def test_direct_launches_equal_the_graph_replays_on_the_emulated_kernels(monkeypatch):
+  tgp = _emulated_product(monkeypatch, streams=True)
+  tt, bench = _timed_path_modules(monkeypatch, tgp)
+  tt.test_direct_launches_equal_the_graph_replays(K=2, seed=9)
+
+
 def _update_plan_cases():
   """(The GAIL discriminator variants run torch operations - log-probability buffers, the reward copy - between their launches inside the plan; the emulator defers kernels on its
   streams but cannot defer torch's CPU operations with them, so those cases need a GPU.)"""

@@ -123,7 +123,10 @@ def compare_learner_masked(o, nets, plan, k, tag='masked oracle: '):
   actor, critic, target, log_alpha, disc = nets
   ao, co, to = plan._keep[4], plan._keep[5], plan._keep[6]
   s, f = 1e-5 * k, 1e-5
-  close_params(N(actor.flat), o.st.actor, f'{tag}actor after {k}', LR, k, outlier_frac=f); close_params(crit_from_flat(critic, critic.flat), o.st.critic, f'{tag}critic after {k}', LR, k, outlier_frac=f)
+  # (the actor: 73,740 elements - 1e-5 of them is less than ONE element. Adam turns ulp-level gradient noise on an element whose gradient is ~eps into a fraction of a step
+  #  (close_params); seeds 4 and 5 leave 2 and 1 such elements 7e-6 outside the bound after 12 updates. Up to four elements; a moved ROW is 256.)
+  fa = max(f, 4.0 / actor.flat.numel())
+  close_params(N(actor.flat), o.st.actor, f'{tag}actor after {k}', LR, k, outlier_frac=fa); close_params(crit_from_flat(critic, critic.flat), o.st.critic, f'{tag}critic after {k}', LR, k, outlier_frac=f)
   close_params(crit_from_flat(critic, target.flat), o.st.target, f'{tag}target after {k}', LR, k, outlier_frac=f)
   close(N(log_alpha), o.st.log_alpha, f'{tag}log_alpha after {k}', atol_scale=s)
   close_sparse(N(ao.exp_avg), o.st.actor_m, f'{tag}actor exp_avg', atol_scale=s, outlier_frac=f); close_sparse(N(ao.exp_avg_sq), o.st.actor_v, f'{tag}actor exp_avg_sq', atol_scale=s, outlier_frac=f)
@@ -132,7 +135,7 @@ def compare_learner_masked(o, nets, plan, k, tag='masked oracle: '):
 
 # the unmasked twin-critic comparison's allowance: what the three seeds of test_captured_update_plan_replays_through_the_oracle and the three learners of the population
 # test measure (tolerance ledger) + 25 %
-CRITIC_UNMASKED_FRAC = 1.5e-3
+CRITIC_UNMASKED_FRAC = 1.25e-3   # measured (round 5, gpurun_out/r05a/fractions.json): 0 on the single learner's seeds, 1.0007e-3 = ONE flipped ReLU row on learner 1 of the population
 
 
 def compare_learner(o, nets, plan, k, tag=''):
@@ -232,6 +235,30 @@ def test_captured_update_plan_replays_through_the_oracle(SEED):
   assert plan2.sync_timeouts() == 0
   for a, n in zip(final, nets2):
     np.testing.assert_array_equal(a, N(n.flat if hasattr(n, 'flat') else n))
+
+
+def test_direct_launches_equal_the_graph_replays(K=6, seed=9):
+  """UpdatePlan.record_direct / launch_direct: the same two branches as direct launches (two library calls per update, no hipGraph) leave every persistent tensor and every
+  per-update output with the bits of the graph replays."""
+  finals = []
+  for mode in ('graph', 'direct'):
+    il_training._NOISE.clear(); il_training._WS.clear()
+    plan, nets, _ = bench.build(torch.device(DEV), 0, seed=seed)
+    for _ in range(2): plan.run()
+    torch.cuda.synchronize()
+    if mode == 'graph':
+      plan.capture(warmup=0); step = plan.replay
+      step()   # (record_direct runs one update while it records)
+    else:
+      plan.record_direct(); step = plan.launch_direct
+      assert len(plan._direct_side) == 1 and len(plan._direct_main) == 1, 'one library call per branch'
+    for _ in range(K): step()
+    torch.cuda.synchronize()
+    assert plan.sync_timeouts() == 0
+    finals.append([N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [N(plan.logp), N(plan.q), N(plan.rewards), N(plan.idx), N(plan.eidx)])
+  for a, b in zip(*finals):
+    assert np.isfinite(a).all()
+    np.testing.assert_array_equal(a, b)
 
 
 # ------------------------------------------------------------------------------------------------ f1: the population launches
