@@ -248,6 +248,9 @@ __device__ __forceinline__ void gail_grad_body(il_disc d, il_batch pol, il_batch
     long long* sy = reinterpret_cast<long long*>(d.sync);
     IL_TL(0, 1);
     if (pol.gather && exp.gather) sync_wait(sy, IL_SYNC_INDICES, sy[IL_SYNC_SIDE_EPOCH] + 1);   // rows come straight from the rings: only the draw has to be done
+    // (round 5) the draw may now be AHEAD of the previous update's end: this step reads the Philox counter that update's actor step advances (below), so it still starts
+    // behind [IL_SYNC_MAIN_EPOCH] (= the number of discriminator steps closed so far) - 4 us earlier than when the draw itself waited for it
+    if (pol.gather && exp.gather && has_sampler) sync_wait(sy, IL_SYNC_MAIN_EPOCH, sy[IL_SYNC_SIDE_EPOCH]);
     else sync_wait(sy, IL_SYNC_ROWS, (sy[IL_SYNC_SIDE_EPOCH] + 1) * sy[IL_SYNC_GATHER_WGS]);
     IL_TL(0, 2);
     ctr = d.noise_counter ? *d.noise_counter : 0u;   // after the wait: the previous update's actor step (which bumps it) precedes this update's gather

@@ -231,6 +231,16 @@ __device__ __forceinline__ void tile_arrive(unsigned* ctr) {
 // A wait that gives up is counted twice: in the workspace slot il_sac_handoff_timeouts() reads, and in [IL_SYNC_TIMEOUTS] when the learner has il_sync counters
 // (what UpdatePlan.sync_timeouts() checks). Neither can happen while the launch is co-resident or dispatched in block order; both must read 0.
 struct TileTimeouts { unsigned* slot; long long* sync; };
+// [IL_SYNC_CHAIN_WGS] / [IL_SYNC_CHAIN_DONE] (include/il_hip.h): the forward / critic-loss launch tells the resident sampler how many workgroups it has and when each has
+// retired - every read of the update's index arrays on the main stream happens in this launch, so the next update's draw may start once all of them are gone.
+// chain_done: after a workgroup barrier (every wave's loads have returned: their values were used); relaxed - the sampler only OVERWRITES what these workgroups read.
+__device__ __forceinline__ void chain_publish_grid(const il_sac& d, int on) {
+  if (on && d.sync && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(reinterpret_cast<long long*>(d.sync) + IL_SYNC_CHAIN_WGS, (long long)gridDim.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_done(const il_sac& d, int on) {
+  if (on && d.sync && threadIdx.x == 0) __hip_atomic_fetch_add(reinterpret_cast<long long*>(d.sync) + IL_SYNC_CHAIN_DONE, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ TileTimeouts tile_timeouts(const il_sac& d) {
   const SacWs ws = sac_ws(d.state_dim, d.action_dim, d.hidden, d.batch);
   return {reinterpret_cast<unsigned*>(d.workspace + ws.chain_ctr) + (d.batch / IL_TILE_R) * IL_CTR_STRIDE + 1, reinterpret_cast<long long*>(d.sync)};
@@ -444,7 +454,7 @@ __device__ __forceinline__ void critic_bwd_resident_gemm(const il_sac& d, int k,
 }
 // relabel: the rewards of this tile are the discriminator `dd`'s prediction on (s, a) - the rows still sit in Xs - computed here once its AdamW step of
 // this update is complete ([IL_SYNC_PARAMS], n_reduce workgroups per step); otherwise dense `rewards` or the batch's own reward field.
-struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; int fwd_only; int wait_indices; int local_rewards; int xcd_nets, gather_wgs; };   // xcd_nets: grid = 8 * nt, one network per XCD (chain_decode_xcd); gather_wgs: row-copy workgroups among the blocks of XCDs 6, 7   // wait_indices: IL_FLAG_SAC_WAIT_INDICES; local_rewards: il_sac_update_gather without `rewards` / `relabel` (the ring's reward field: nothing to wait for)   // fwd_only: the forward kernels only (IL_FLAG_SAC_FORWARD_ONLY / data-parallel phase 0): no critic backward
+struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; int fwd_only; int wait_indices; int local_rewards; int xcd_nets, gather_wgs; int early_draw; };   // early_draw: publish [IL_SYNC_CHAIN_WGS] (IL_EARLY_DRAW=0: the resident sampler waits for the previous update's end, as in round 4)   // xcd_nets: grid = 8 * nt, one network per XCD (chain_decode_xcd); gather_wgs: row-copy workgroups among the blocks of XCDs 6, 7   // wait_indices: IL_FLAG_SAC_WAIT_INDICES; local_rewards: il_sac_update_gather without `rewards` / `relabel` (the ring's reward field: nothing to wait for)   // fwd_only: the forward kernels only (IL_FLAG_SAC_FORWARD_ONLY / data-parallel phase 0): no critic backward
 // Runs between the critic's own work and its wait for the targets: the discriminator's step usually lands while the targets are still being computed,
 // so the relabel stays off the critical path. Leaves the tile's rewards in LDS (rew16) for critic_bwd_resident_scale.
 __device__ __forceinline__ void critic_relabel_tile(const il_sac& d, const ChainRelabel& rl, int k, int tile, float* smem) {
@@ -615,7 +625,10 @@ __global__ __launch_bounds__(1024) void k_sac_chain(il_sac d, il_batch b, const 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   globalize(d); globalize(b);
   if (rl.on) { globalize(rl.dd); rl.out = as_global(rl.out); }
+  chain_publish_grid(d, rl.early_draw);
   sac_chain_body(d, b, eps_next, eps_cur, rewards, rows_out, rl, smem);
+  __syncthreads();
+  chain_done(d, rl.early_draw);
 }
 
 // Population launch of the chain: grid (6 * nt, learners). Workgroups are dispatched in linear order (x fastest), a role only waits for lower-numbered workgroups of ITS
@@ -899,8 +912,10 @@ __global__ __launch_bounds__(512) void k_sac_chain_pair(il_sac d, il_batch b, co
   globalize(d); globalize(b);
   if (rl.on) { globalize(rl.dd); rl.out = as_global(rl.out); }
   IL_ST_BEGIN(IL_ST_CHAIN);
+  chain_publish_grid(d, rl.early_draw);
   sac_chain_pair_body(d, b, eps_next, eps_cur, rewards, rows_out, rl, smem);
   IL_ST_END(IL_ST_CHAIN);
+  chain_done(d, rl.early_draw);
 }
 
 // policy-loss backward of one 16-row tile: min-Q selection, tanh-Gaussian backward, actor back-prop (dz3, dz2, dz1 for the dW kernel), alpha partial.
@@ -2315,6 +2330,7 @@ static int sac_update_gather_impl(const il_sac* d, const il_batch* rows, const i
   }
   if (flags & IL_FLAG_SAC_WAIT_INDICES) { IL_CHECK_ARG(d->sync, "il_sac_update_gather: IL_FLAG_SAC_WAIT_INDICES needs the il_sync counters"); rl.wait_indices = 1; }
   rl.local_rewards = (!rewards && !relabel) ? 1 : 0;
+  { static const int early = [] { const char* e = getenv("IL_EARLY_DRAW"); return e && e[0] == '0' ? 0 : 1; }(); rl.early_draw = early; }
   IL_CHECK_ARG(ring && ring->gather && ring->gather_capacity > 0 && ring->n == d->batch, "il_sac_update_gather: `ring` must carry the %d drawn indices (il_batch.gather)", d->batch);
   IL_CHECK_ARG(rows->states && ring->states && rows->ld_states == ring->ld_states && ring->ld_states % 4 == 0, "il_sac_update_gather: rows / ring must be packed rows of the same width");
   IL_CHECK_ARG(!(flags & (IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY)), "il_sac_update_gather: whole updates (or, with IL_FLAG_GRADS_ONLY, everything up to the critic gradients)");

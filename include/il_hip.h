@@ -189,6 +189,10 @@ int il_polyak(float* target, const float* param, int64_t n, double tau, il_strea
  *   [IL_SYNC_HOST_FLAG]  = address of a host-mapped (pinned) int64, or 0: a wait that gives up ALSO stores the new [IL_SYNC_TIMEOUTS] value there (system scope), so the host
  *                          loop can notice an expired wait by reading its own memory every step - no synchronisation, no copy node in the captured update. Same read-only line.
  *   [IL_SYNC_INDICES]    += 1 per finished index draw              -> k_gail_grad on il_batch.gather batches waits for side_epoch + 1 (not for the rows)
+ *   [IL_SYNC_CHAIN_DONE] += 1 per finished workgroup of the forward / critic-loss launch (k_sac_chain[_pair]: the last reader of an update's index arrays on the main
+ *                          stream); [IL_SYNC_CHAIN_WGS] = that launch's grid size, published by the launch itself. The resident sampler draws the NEXT update's indices as
+ *                          soon as [IL_SYNC_CHAIN_DONE] >= draws so far x [IL_SYNC_CHAIN_WGS] (round 5: ~30 us before that update's first kernel needs them) instead of
+ *                          waiting for [IL_SYNC_MAIN_EPOCH]; the discriminator workgroups, which read the Philox counter the actor step advances, still wait for the epoch.
  *   [IL_SYNC_PARAMS]     += 1 per finished AdamW(discriminator) workgroup (IL_FLAG_GAIL_CLOSE_EPOCH) -> the inline relabel of il_sac_update_gather waits
  *                          for (main_epoch + 1) * il_gail_step_workgroups()
  * With it the two branches need no stream dependency between the gather and the critic loss (fork at the start of the update, join at
@@ -203,7 +207,8 @@ int il_sync_probe(int64_t* sync, int32_t setter, il_stream_t stream);
 #endif
 enum { IL_SYNC_ROWS = 0, IL_SYNC_REWARDS = 1 * IL_SYNC_STRIDE, IL_SYNC_SIDE_EPOCH = 2 * IL_SYNC_STRIDE, IL_SYNC_MAIN_EPOCH = 3 * IL_SYNC_STRIDE, IL_SYNC_TIMEOUTS = 4 * IL_SYNC_STRIDE,
        IL_SYNC_GATHER_WGS = 5 * IL_SYNC_STRIDE, IL_SYNC_PROBE_FLAG = 6 * IL_SYNC_STRIDE, IL_SYNC_PROBE_EPOCH = 7 * IL_SYNC_STRIDE, IL_SYNC_INDICES = 8 * IL_SYNC_STRIDE,
-       IL_SYNC_PARAMS = 9 * IL_SYNC_STRIDE, IL_SYNC_SPIN = 5 * IL_SYNC_STRIDE + 1, IL_SYNC_HOST_FLAG = 5 * IL_SYNC_STRIDE + 2, IL_SYNC_SLOTS = 16 * IL_SYNC_STRIDE };
+       IL_SYNC_PARAMS = 9 * IL_SYNC_STRIDE, IL_SYNC_CHAIN_DONE = 10 * IL_SYNC_STRIDE, IL_SYNC_CHAIN_WGS = 11 * IL_SYNC_STRIDE, IL_SYNC_SPIN = 5 * IL_SYNC_STRIDE + 1,
+       IL_SYNC_HOST_FLAG = 5 * IL_SYNC_STRIDE + 2, IL_SYNC_SLOTS = 16 * IL_SYNC_STRIDE };
 /* out[0] = IL_SYNC_SLOTS (int64 elements to allocate and zero), out[1] = IL_SYNC_TIMEOUTS, out[2] = IL_SYNC_GATHER_WGS, out[3] = IL_SYNC_STRIDE, out[4] = IL_SYNC_SPIN, out[5] = IL_SYNC_HOST_FLAG */
 void il_sync_layout(int32_t* out);
 

@@ -74,7 +74,7 @@ for what in "$@"; do
       timeout 600 python profiles/tools/acting_bench.py > $OUT/acting.json 2> $OUT/acting.err; echo "acting rc=$?" | tee -a $OUT/summary.txt; tail -n 3 $OUT/acting.json | cut -c1-1500 | tee -a $OUT/summary.txt ;;
     ab_direct)
       # interleaved on one box: hipGraph replays against direct launches of the same two branches (UpdatePlan.launch_direct)
-      for i in 1 2 3; do for m in graph direct; do timeout 300 python bench.py --launch $m --steps 2000 --warmup 200 --repeats 3 --stamp-bursts 10 $QUICK 2>$OUT/ab_direct.err | line "launch=$m" | tee -a $OUT/ab_direct.txt; done; done
+      for i in 1 2 3; do for e in ${IL_AB_EARLY:-1}; do for m in graph direct; do IL_EARLY_DRAW=$e timeout 300 python bench.py --launch $m --steps 2000 --warmup 200 --repeats 3 --stamp-bursts 10 $QUICK 2>$OUT/ab_direct.err | line "early_draw=$e launch=$m" | tee -a $OUT/ab_direct.txt; done; done; done
       cat $OUT/ab_direct.txt >> $OUT/summary.txt ;;
     ab_gmmil)
       for i in 1 2 3; do for m in 1 0; do IL_GMMIL_RESIDENT=$m timeout 300 python profiles/tools/secondary_workloads.py gmmil_rate 2>$OUT/ab_gmmil.err | tail -n 1 | sed "s/^/IL_GMMIL_RESIDENT=$m /" | tee -a $OUT/ab_gmmil.txt; done; done
