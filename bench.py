@@ -481,7 +481,7 @@ def main():
   ap.add_argument('--stamp-bursts', type=int, default=20, help='extra untimed bursts of 50 replays after the timed repeats, each read for its launch stamps')
   ap.add_argument('--no-pmc', action='store_true', help='do not attach roofline.traffic from profiles/pmc_latest.json (what the counter-collecting passes themselves run with)')
   ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
-  ap.add_argument('--launch', choices=('graph', 'direct'), default=os.environ.get('IL_BENCH_LAUNCH', 'graph'), help='how the timed updates are issued: two hipGraph replays per update, or UpdatePlan.launch_direct (the same two branches as direct launches: two library calls per update, no hipGraph)')
+  ap.add_argument('--launch', choices=('graph', 'direct'), default=os.environ.get('IL_BENCH_LAUNCH', 'direct'), help='how the timed single-GPU updates are issued: UpdatePlan.launch_direct (the two branches as direct launches: two library calls per update, no hipGraph; the default since round 5: 17.5k against 16.6k updates/s on one box, profiles/r05_launch_ab.txt) or two hipGraph replays per update')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--trace-steps', type=int, default=100)
   ap.add_argument('--no-overlap', action='store_true', help='one stream, no device-side hand-off: the same kernels back to back (what a counter-collecting profiler needs; il_sac_update still takes its chained launch)')

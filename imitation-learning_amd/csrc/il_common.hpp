@@ -339,7 +339,7 @@ static __device__ unsigned long long il_tl[IL_TL_K][IL_TL_WGS][IL_TL_SLOTS];
 enum { IL_ST_GAIL_GRAD = 0, IL_ST_GAIL_REDUCE = 1, IL_ST_CHAIN = 2, IL_ST_DW_CRITIC = 3, IL_ST_POLICY_CRITIC = 4, IL_ST_DW_ACTOR = 5, IL_ST_GMMIL = 6, IL_ST_PWIL = 7, IL_ST_K = 8 };
 #define IL_ST_WGS 512
 #define IL_ST_TABLE static __device__ unsigned long long il_st[IL_ST_K][IL_ST_WGS][2];
-#define IL_ST_MARK(kid, slot) do { const unsigned st_w = blockIdx.x + gridDim.x * blockIdx.y; if (threadIdx.x == 0 && st_w < IL_ST_WGS && blockIdx.z == 0) il_st[kid][st_w][slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define IL_ST_MARK(kid, slot) do { const unsigned st_w = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); if (threadIdx.x == 0 && st_w < IL_ST_WGS) il_st[kid][st_w][slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define IL_ST_BEGIN(kid) IL_ST_MARK(kid, 0)
 #define IL_ST_END(kid) do { __syncthreads(); IL_ST_MARK(kid, 1); } while (0)   // every thread of the workgroup passes here (bodies return, never s_endpgm): a workgroup's end = its last wave's
 // out_host [IL_ST_K][IL_ST_WGS][2]: only the rows of the kernel ids this translation unit owns are meaningful

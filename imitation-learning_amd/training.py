@@ -954,22 +954,31 @@ class UpdatePlan:
       for _ in range(updates): self.run()
     return self
 
+  def direct_launch_ok(self) -> bool:
+    """record_direct / launch_direct apply: the device hand-off schedule with two unjoined branches and nothing hooked into the update (an ActingWorker attached for
+    +acting.schedule=overlap rides in the captured graph instead)."""
+    return bool(self.device_sync and (self.algorithm == 'GAIL' or self.resident_sampler) and not self.pre_hooks and not self.post_hooks)
+
   def record_direct(self):
-    """The two-branch schedule `capture()` records, as DIRECT launches: runs one update while recording the library calls of each branch (entry point + its ctypes
-    arguments, stream included), so that `launch_direct()` re-issues exactly those calls - two calls into libil_hip.so per update, six kernel launches, no hipGraph and no
-    stream edge. A hipGraph replay pays the graph-launch bookkeeping of the runtime between two replays on a stream; a direct launch is one AQL packet per kernel
-    (DESIGN.md 3.5 has the measurement). The main branch is recorded on the CALLER's current stream and must be launched from it."""
-    assert self.device_sync and (self.algorithm == 'GAIL' or self.resident_sampler), 'record_direct: the device hand-off schedule (two unjoined branches) only'
-    assert not self.pre_hooks and not self.post_hooks, 'record_direct: hooks (an attached ActingWorker) are captured with the update: use capture()'
+    """The two-branch schedule `capture()` records, as DIRECT launches: walks the update's host code once with a recording stand-in for the library (nothing is launched),
+    keeping each branch's entry point + ctypes arguments (stream included), so that `launch_direct()` re-issues exactly those calls - two calls into libil_hip.so per
+    update, six kernel launches, no hipGraph and no stream edge. A hipGraph replay pays the runtime's graph-launch bookkeeping between two replays on a stream (~4.5 us per
+    update here); a direct launch is one AQL packet per kernel (profiles/r05_launch_ab.txt). Run at least one update first (run(): code objects loaded, LDS
+    attributes set, lane-ordered weight copies built). The main branch is recorded on the CALLER's current stream and must be launched from it; descriptors are passed by
+    reference, so later changes of their fields (watch_timeouts, widen_handoff_bound) apply, unlike in a captured graph."""
+    assert self.direct_launch_ok(), 'record_direct: the device hand-off schedule (two unjoined branches, no hooks) only'
+    assert self._prepared, 'record_direct: run() at least one update first'
     self.memory.stream().device_state(self.rows.device)
 
     class Recorder:
       def __init__(self, real): self.real, self.calls = real, []
       def __getattr__(self, name):
         fn = getattr(self.real, name)
+        if not name.startswith('il_') or fn.restype is not C.c_int:
+          return fn   # size / layout queries: answered by the library itself
         def call(*args):
           self.calls.append((fn, args))
-          return fn(*args)
+          return 0
         return call
 
     real = _lib.lib()
@@ -982,7 +991,7 @@ class UpdatePlan:
           with torch.cuda.stream(self.side): self._run_update()
         else:
           self._run_update()
-        out.append([(fn, args) for fn, args in rec.calls if getattr(fn, '__name__', '').startswith('il_') and fn.restype is C.c_int])
+        out.append(list(rec.calls))
     finally:
       _lib._lib, self._capturing = real, None
     self._direct_side, self._direct_main = out

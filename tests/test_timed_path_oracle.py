@@ -248,7 +248,6 @@ def test_direct_launches_equal_the_graph_replays(K=6, seed=9):
     torch.cuda.synchronize()
     if mode == 'graph':
       plan.capture(warmup=0); step = plan.replay
-      step()   # (record_direct runs one update while it records)
     else:
       plan.record_direct(); step = plan.launch_direct
       assert len(plan._direct_side) == 1 and len(plan._direct_main) == 1, 'one library call per branch'

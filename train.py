@@ -244,6 +244,11 @@ def train(cfg, file_prefix: str = '') -> float:
             discriminator.gamma_1, discriminator.gamma_2 = parallel.broadcast_scalars([discriminator.gamma_1, discriminator.gamma_2])
           if world > 1 and cfg.distributed.backend != 'nccl' and getattr(runner, 'peer', None) is None:
             step_update = runner.run   # gloo collectives synchronise the host: not capturable (and a failed capture poisons the stream) - eager launches
+          elif runner is plan and plan.direct_launch_ok() and os.environ.get('IL_TRAIN_LAUNCH', 'direct') != 'graph':
+            # one GPU, the two-branch schedule: the update's six launches issued directly (two library calls per update). A hipGraph replay costs ~4.5 us more between
+            # two updates than the launch boundary of the same kernels (profiles/r05_launch_ab.txt); IL_TRAIN_LAUNCH=graph keeps the graphs
+            plan.record_direct()
+            step_update = plan.launch_direct
           else:
             runner.capture(warmup=0)   # the gradient exchange (peer-window kernels, or RCCL collectives) is captured with the kernels: one graph replay per data-parallel update
             step_update = runner.replay
