@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get('IL_HIP_LIBRARY') or os.path.join(_HERE, 'libil_hip.so
 IL_FLAG_GRADS_ONLY, IL_FLAG_TICK, IL_FLAG_SAC_FORWARD_ONLY, IL_FLAG_SAC_SKIP_FORWARD, IL_FLAG_SAC_PREPARED = 1, 2, 4, 8, 16
 IL_FLAG_GAIL_CLOSE_EPOCH = 32
 IL_FLAG_SAC_WAIT_INDICES = 64
+IL_FLAG_SAC_STAGED_ROWS = 0x400
 c_f32p, c_i32p, c_u32p, c_i64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)
 
 
@@ -196,6 +197,7 @@ _SIGNATURES = {
     'il_actor_log_prob_general': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
     'il_bc_step_general': (C.c_int, [_P, _P, C.POINTER(Adam), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Batch), _P, C.c_int64, _P, C.c_uint32, _P]),
     'il_gail_disc_step_draw': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), C.POINTER(Batch), _P, _P, _P, _P, _P, C.c_uint32, _P]),
+    'il_gail_disc_step_draw_staged': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), C.POINTER(Batch), _P, _P, _P, _P, _P, _P, C.c_uint32, _P]),
     'il_gail_disc_step_draw_peer': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), C.POINTER(Batch), _P, _P, _P, _P, _P, C.c_uint32, C.POINTER(PeerBucket), _P]),
     'il_gail_apply_grads': (C.c_int, [C.POINTER(Disc), _P]),
     'il_gail_reward': (C.c_int, [C.POINTER(Disc), C.POINTER(Batch), _P, _P, _P, _P]),

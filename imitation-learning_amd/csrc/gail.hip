@@ -165,7 +165,7 @@ __device__ __forceinline__ void stage_weights(const DiscLds& L, const float* __r
 // The index draw of the update riding in this launch (il_gail_disc_step_draw): gridDim.x carries ONE extra column of workgroups, of which (nt, 0) is the sampler.
 // The discriminator workgroups are resident early - weights staged, Gram matrix and power iterations done - and wait for [IL_SYNC_INDICES]; a sampler launched BEHIND
 // this kernel in the same stream could never satisfy that wait, and one launched AHEAD of it would put this kernel's preparation back on the update's critical path.
-struct GailSampler { uint32_t* state; const int64_t* rs_a; int32_t* idx_a; const int64_t* rs_b; int32_t* idx_b; int n; };
+struct GailSampler { uint32_t* state; const int64_t* rs_a; int32_t* idx_a; const int64_t* rs_b; int32_t* idx_b; int n; MtStage stage; };
 
 // MULTI: several tiles per workgroup (k_gail_grad_pop); the one-tile instantiation is the single learner's kernel, whose registers and schedule the loop must not touch
 // (as a run-time trip count it cost the headline 2 %: profiles/r04_pop_ab.txt).
@@ -176,8 +176,11 @@ __device__ __forceinline__ void gail_grad_body(il_disc d, il_batch pol, il_batch
   IL_TL(0, 0);
   const int has_sampler = sa.state != nullptr;
   if (has_sampler && (int)blockIdx.x == (int)gridDim.x - 1) {
-    if (blockIdx.y == 0) mt_sample_update(*reinterpret_cast<MtShared*>(smem), as_global(sa.state), sa.n, as_global(sa.rs_a), as_global(sa.idx_a), as_global(sa.rs_b), as_global(sa.idx_b),
-                                          reinterpret_cast<long long*>(as_global(d.sync)), 1);
+    if (blockIdx.y == 0) {
+      MtStage stg = sa.stage; stg.ring = as_global(stg.ring); stg.rows = as_global(stg.rows);
+      mt_sample_update(*reinterpret_cast<MtShared*>(smem), as_global(sa.state), sa.n, as_global(sa.rs_a), as_global(sa.idx_a), as_global(sa.rs_b), as_global(sa.idx_b),
+                       reinterpret_cast<long long*>(as_global(d.sync)), 1, stg);
+    }
     return;
   }
   if (dL) { d = dL[blockIdx.z]; pol = polL[blockIdx.z]; exp = expL[blockIdx.z]; }  // population axis
@@ -637,7 +640,7 @@ extern "C" int il_gail_disc_step(const il_disc* d, const il_batch* pol, const il
 }
 
 static int gail_disc_step_draw_impl(const il_disc* d, const il_batch* pol, const il_batch* exp, uint32_t* mt_state_dev, const int64_t* ring_state_a, int32_t* idx_a,
-                                    const int64_t* ring_state_b, int32_t* idx_b, uint32_t flags, const il_peer_bucket* peer, il_stream_t stream_) {
+                                    const int64_t* ring_state_b, int32_t* idx_b, uint32_t flags, const il_peer_bucket* peer, il_stream_t stream_, float* stage_rows = nullptr) {
   if (int rc = check_disc(d)) return rc;
   IL_CHECK_ARG(pol && exp && pol->n == d->batch && exp->n == d->batch && pol->gather && exp->gather, "il_gail_disc_step_draw: both batches must be rings read through il_batch.gather");
   IL_CHECK_ARG(d->sync && mt_state_dev && ring_state_a && idx_a && ring_state_b && idx_b, "il_gail_disc_step_draw: the il_sync counters, the generator state and both rings' states / index arrays are required");
@@ -648,7 +651,11 @@ static int gail_disc_step_draw_impl(const il_disc* d, const il_batch* pol, const
   const size_t lds = disc_lds_single(D, d->hidden);
   IL_CHECK_ARG(lds >= sizeof(MtShared), "il_gail_disc_step_draw: discriminator too small to host the sampler's state in its workgroup LDS");
   if (int rc = ensure_lds((const void*)k_gail_grad, lds)) return rc;
-  const GailSampler sa = {mt_state_dev, ring_state_a, idx_a, ring_state_b, idx_b, d->batch};
+  GailSampler sa = {mt_state_dev, ring_state_a, idx_a, ring_state_b, idx_b, d->batch, MtStage{}};
+  if (stage_rows) {   // the policy batch IS the agent ring read through idx_a: its packed rows start at `states`
+    IL_CHECK_ARG(pol->ld_states % 4 == 0 && (reinterpret_cast<uintptr_t>(pol->states) & 15) == 0 && (reinterpret_cast<uintptr_t>(stage_rows) & 15) == 0, "il_gail_disc_step_draw_staged: packed rows of whole 16-byte lanes");
+    sa.stage = MtStage{pol->states, stage_rows, (long long)pol->gather_capacity, pol->ld_states / 4};
+  }
   { IL_TRACE("k_gail_grad", st); k_gail_grad<<<dim3(nt + 1, gail_calls(*d)), 256, lds, st>>>(*d, *pol, *exp, nullptr, il_gail_extra{}, nullptr, nullptr, nullptr, sa, 0); }
   const int64_t P = disc_layout(D, d->hidden, d->spectral_norm).P;
   il_peer_bucket px = {};
@@ -666,6 +673,11 @@ static int gail_disc_step_draw_impl(const il_disc* d, const il_batch* pol, const
 extern "C" int il_gail_disc_step_draw(const il_disc* d, const il_batch* pol, const il_batch* exp, uint32_t* mt_state_dev, const int64_t* ring_state_a, int32_t* idx_a,
                                       const int64_t* ring_state_b, int32_t* idx_b, uint32_t flags, il_stream_t stream_) {
   return gail_disc_step_draw_impl(d, pol, exp, mt_state_dev, ring_state_a, idx_a, ring_state_b, idx_b, flags, nullptr, stream_);
+}
+extern "C" int il_gail_disc_step_draw_staged(const il_disc* d, const il_batch* pol, const il_batch* exp, uint32_t* mt_state_dev, const int64_t* ring_state_a, int32_t* idx_a,
+                                             const int64_t* ring_state_b, int32_t* idx_b, float* stage_rows, uint32_t flags, il_stream_t stream_) {
+  IL_CHECK_ARG(stage_rows, "il_gail_disc_step_draw_staged: null staging slab");
+  return gail_disc_step_draw_impl(d, pol, exp, mt_state_dev, ring_state_a, idx_a, ring_state_b, idx_b, flags, nullptr, stream_, stage_rows);
 }
 extern "C" int il_gail_disc_step_draw_peer(const il_disc* d, const il_batch* pol, const il_batch* exp, uint32_t* mt_state_dev, const int64_t* ring_state_a, int32_t* idx_a,
                                            const int64_t* ring_state_b, int32_t* idx_b, uint32_t flags, const il_peer_bucket* peer, il_stream_t stream_) {

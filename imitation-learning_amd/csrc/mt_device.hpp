@@ -98,8 +98,12 @@ __device__ __forceinline__ void mt_draw(MtShared& sh, const int64_t* __restrict_
 
 // The whole draw of an update by one workgroup of 256 threads (`sh` in LDS): generator state in, the next block prepared, [wait for the previous update: resident],
 // agent batch then expert batch (train.py:173), [IL_SYNC_INDICES] signalled, state out.
+// `stage` (round 5, il_gail_disc_step_draw_staged): after the draw the workgroup also copies the n drawn AGENT rows (row4 16-byte lanes each, ring rows at `stage_ring`,
+// indices clamped like il_replay_gather) into the dense slab `stage` BEFORE it signals: with the early draw (IL_SYNC_CHAIN_DONE) this happens tens of microseconds ahead
+// of the next update, whose forward / critic-loss launch then reads dense rows - one global trip in its prologues instead of index -> row.
+struct MtStage { const float* ring; float* rows; long long capacity; int row4; };
 __device__ __forceinline__ void mt_sample_update(MtShared& sh, uint32_t* __restrict__ state, int n, const int64_t* __restrict__ rs_a, int32_t* __restrict__ idx_a,
-                                                 const int64_t* __restrict__ rs_b, int32_t* __restrict__ idx_b, long long* __restrict__ sync, int resident) {
+                                                 const int64_t* __restrict__ rs_b, int32_t* __restrict__ idx_b, long long* __restrict__ sync, int resident, MtStage stage = MtStage{}) {
   const int tid = threadIdx.x;
   for (int i = tid; i < MT_N; i += 256) sh.mt[i] = state[i];
   if (tid == 0) { sh.pos = (int)state[MT_N]; sh.have_next = 0; }
@@ -122,7 +126,23 @@ __device__ __forceinline__ void mt_sample_update(MtShared& sh, uint32_t* __restr
   mt_draw(sh, rs_a, n, idx_a);
   if (rs_b) { __syncthreads(); mt_draw(sh, rs_b, n, idx_b); }
   IL_TL(0, 3);
-  if (sync) sync_signal(sync + IL_SYNC_INDICES);   // both index arrays are in place (a consumer that gathers its own rows need not wait for k_gather2)
+  if (stage.rows) {
+    __syncthreads();   // idx_a as written by this workgroup's threads above
+    typedef float st_f32x4 __attribute__((ext_vector_type(4)));
+    const st_f32x4* src = reinterpret_cast<const st_f32x4*>(stage.ring);
+    st_f32x4* dst = reinterpret_cast<st_f32x4*>(stage.rows);
+    const int lanes = n * stage.row4;
+    for (int i0 = tid; i0 < lanes; i0 += 4 * 256) {   // four lanes per thread and trip: indices, then rows, requested together
+      long long sr[4]; st_f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * 256, lanes - 1); const long long s_ = idx_a[i / stage.row4]; sr[u] = s_ < 0 ? 0 : (s_ >= stage.capacity ? stage.capacity - 1 : s_); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * 256, lanes - 1); v[u] = src[sr[u] * stage.row4 + i % stage.row4]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * 256; if (i < lanes) dst[i] = v[u]; }
+    }
+  }
+  if (sync) sync_signal(sync + IL_SYNC_INDICES);   // both index arrays (and the staged rows) are in place (a consumer that gathers its own rows need not wait for k_gather2)
   __syncthreads();
   for (int i = tid; i < MT_N; i += 256) state[i] = sh.mt[i];
   if (tid == 0) state[MT_N] = (uint32_t)sh.pos;

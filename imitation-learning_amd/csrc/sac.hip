@@ -2331,6 +2331,9 @@ static int sac_update_gather_impl(const il_sac* d, const il_batch* rows, const i
   if (flags & IL_FLAG_SAC_WAIT_INDICES) { IL_CHECK_ARG(d->sync, "il_sac_update_gather: IL_FLAG_SAC_WAIT_INDICES needs the il_sync counters"); rl.wait_indices = 1; }
   rl.local_rewards = (!rewards && !relabel) ? 1 : 0;
   { static const int early = [] { const char* e = getenv("IL_EARLY_DRAW"); return e && e[0] == '0' ? 0 : 1; }(); rl.early_draw = early; }
+  if (flags & IL_FLAG_SAC_STAGED_ROWS) {   // `ring` = the dense slab the resident sampler staged this update's rows into (il_gail_disc_step_draw_staged): no index trip
+    IL_CHECK_ARG(ring && !ring->gather && ring->n == d->batch && (flags & IL_FLAG_SAC_WAIT_INDICES), "il_sac_update_gather: IL_FLAG_SAC_STAGED_ROWS takes a dense batch of %d rows and waits for [IL_SYNC_INDICES]", d->batch);
+  } else
   IL_CHECK_ARG(ring && ring->gather && ring->gather_capacity > 0 && ring->n == d->batch, "il_sac_update_gather: `ring` must carry the %d drawn indices (il_batch.gather)", d->batch);
   IL_CHECK_ARG(rows->states && ring->states && rows->ld_states == ring->ld_states && ring->ld_states % 4 == 0, "il_sac_update_gather: rows / ring must be packed rows of the same width");
   IL_CHECK_ARG(!(flags & (IL_FLAG_SAC_SKIP_FORWARD | IL_FLAG_SAC_FORWARD_ONLY)), "il_sac_update_gather: whole updates (or, with IL_FLAG_GRADS_ONLY, everything up to the critic gradients)");

@@ -397,6 +397,7 @@ class DataParallelUpdate:
 
   def __init__(self, plan, group=None):
     self.plan, self.group = plan, group
+    plan.data_parallel = True   # (the single-GPU extras that assume one branch pair per update - staged rows - stay off)
     if getattr(plan, '_variant', False) or getattr(plan, '_beta_alpha', None) is not None:
       raise NotImplementedError('DataParallelUpdate: GAIL with a finite PUGAIL margin / subtract_log_policy / reward shaping / a depth-2 or tanh discriminator / Mixup with mixup_alpha != 1 '
                                 'runs its discriminator step through the per-function entry points inside the plan: there are no gradient-only kernels to all-reduce for them; '

@@ -707,6 +707,25 @@ class UpdatePlan:
       self._ring_desc = (ring_desc(self.memory, self.idx), ring_desc(self.expert_memory, self.eidx) if self.has_expert else None)
     return self._ring_desc
 
+  @property
+  def staged_rows(self) -> bool:
+    """GAIL with the resident sampler on one GPU: the sampler workgroup also copies the drawn agent rows into a dense slab (`stage`) before it signals
+    (il_gail_disc_step_draw_staged) - with the early draw that is ~30 us before the update starts - and the forward / critic-loss launch reads them from there
+    (IL_FLAG_SAC_STAGED_ROWS): one global trip in its prologues instead of index -> row. The discriminator step keeps reading through the indices. IL_STAGE_ROWS=0: off."""
+    return bool(self.algorithm == 'GAIL' and self.resident_sampler and self.peer_desc is None and not getattr(self, 'data_parallel', False) and os.environ.get('IL_STAGE_ROWS', '1') != '0')
+
+  def _staged_batch(self):
+    if getattr(self, '_stage_desc', None) is None:
+      m = self.memory
+      self.stage = torch.empty(self.B, m.row, device=self.rows.device)
+      t = batch_views(self.stage, m.state_size, m.action_size, True)
+      if not m.absorbing:
+        self._keep_zero_stage = torch.zeros(1, dtype=torch.float32, device=self.rows.device)
+        t['absorbing'] = self._keep_zero_stage.expand(self.B)
+      self._stage_desc = batch_desc(t)
+      self._stage_desc.n = self.B
+    return self._stage_desc
+
   def _zero_column(self, mem):
     """A ring-strided view of zeros for the `absorbing` field of a ring without absorbing states (one float per ring row would be wasteful: every
     row reads the same zero through stride 0)."""
@@ -744,6 +763,11 @@ class UpdatePlan:
       if self.peer_desc is not None:   # data-parallel: the gradient exchange rides in the reduce + AdamW launch (parallel.DataParallelUpdate, fused form)
         _lib.check(L.il_gail_disc_step_draw_peer(C.byref(self.disc), C.byref(rp), C.byref(re_), _lib.ptr(mt), _lib.ptr(m._ring_state), _lib.ptr(self.idx), _lib.ptr(e._ring_state),
                                                  _lib.ptr(self.eidx), flags, C.byref(self.peer_desc['disc']), st))
+        return
+      if self.staged_rows:
+        self._staged_batch()
+        _lib.check(L.il_gail_disc_step_draw_staged(C.byref(self.disc), C.byref(rp), C.byref(re_), _lib.ptr(mt), _lib.ptr(m._ring_state), _lib.ptr(self.idx), _lib.ptr(e._ring_state),
+                                                   _lib.ptr(self.eidx), _lib.ptr(self.stage), flags, st))
         return
       _lib.check(L.il_gail_disc_step_draw(C.byref(self.disc), C.byref(rp), C.byref(re_), _lib.ptr(mt), _lib.ptr(m._ring_state), _lib.ptr(self.idx), _lib.ptr(e._ring_state), _lib.ptr(self.eidx),
                                           flags, st))
@@ -802,9 +826,10 @@ class UpdatePlan:
                                                         C.byref(self.disc) if inline else None, _lib.ptr(self.rewards) if inline else None, None, None,
                                                         _lib.ptr(self.logp), _lib.ptr(self.q), flags, C.byref(self.peer_desc['critic']), C.byref(self.peer_desc['actor']), _lib.stream_ptr()))
         return
-      _lib.check(_lib.lib().il_sac_update_gather(C.byref(self.sac), C.byref(self.pb), C.byref(self._ring_batches()[0]), None if inline else _lib.ptr(self.rewards),
+      staged = resident and self.staged_rows
+      _lib.check(_lib.lib().il_sac_update_gather(C.byref(self.sac), C.byref(self.pb), C.byref(self._staged_batch() if staged else self._ring_batches()[0]), None if inline else _lib.ptr(self.rewards),
                                                  C.byref(self.disc) if inline else None, _lib.ptr(self.rewards) if inline else None, None, None,
-                                                 _lib.ptr(self.logp), _lib.ptr(self.q), flags, _lib.stream_ptr()))
+                                                 _lib.ptr(self.logp), _lib.ptr(self.q), flags | (_lib.IL_FLAG_SAC_STAGED_ROWS if staged else 0), _lib.stream_ptr()))
       return
     _lib.check(_lib.lib().il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), self.prepared_flag(), _lib.stream_ptr()))
 

@@ -42,6 +42,7 @@ enum { IL_OK = 0, IL_ERR_ARG = 1, IL_ERR_UNSUPPORTED = 2, IL_ERR_HIP = 3, IL_ERR
 #define IL_FLAG_GAIL_CLOSE_EPOCH 32u /* il_gail_disc_step with il_sync counters: no il_gail_reward follows (il_sac_update_gather relabels inline): the AdamW
                                       workgroups report [IL_SYNC_PARAMS] and the last one closes the discriminator branch's epoch */
 #define IL_FLAG_SAC_SKIP_FORWARD 8u /* il_sac_update: everything after them (the caller already ran FORWARD_ONLY on this batch) */
+#define IL_FLAG_SAC_STAGED_ROWS 0x400u /* il_sac_update_gather: `ring` is the dense slab of this update's rows staged by il_gail_disc_step_draw_staged (no il_batch.gather) */
 #define IL_FLAG_SAC_WAIT_INDICES 64u /* il_sac_update_gather: no sampling kernel precedes this call in its stream - wait on the device for [IL_SYNC_INDICES] (il_replay_draw_resident) */
 
 typedef void* il_stream_t; /* hipStream_t */
@@ -404,6 +405,11 @@ int il_gail_apply_grads(const il_disc* d, il_stream_t stream);
  * on-chip Philox noise; flags as il_gail_disc_step. The SAC branch on the other stream uses il_sac_update_gather(IL_FLAG_SAC_WAIT_INDICES). */
 int il_gail_disc_step_draw(const il_disc* d, const il_batch* policy, const il_batch* expert, uint32_t* mt_state_dev, const int64_t* ring_state_a, int32_t* idx_a,
                            const int64_t* ring_state_b, int32_t* idx_b, uint32_t flags, il_stream_t stream);
+/* The same, and the sampler workgroup also copies the drawn AGENT rows (memory.py:58-63: the packed ring rows behind policy->states, through idx_a) into the dense slab
+ * stage_rows [batch][policy->ld_states] before it signals [IL_SYNC_INDICES]. With the early draw (il_sync: [IL_SYNC_CHAIN_DONE]) that is tens of microseconds before the
+ * next update starts; il_sac_update_gather(IL_FLAG_SAC_STAGED_ROWS, ring = a dense il_batch over stage_rows) then reads its rows with one global trip instead of two. */
+int il_gail_disc_step_draw_staged(const il_disc* d, const il_batch* policy, const il_batch* expert, uint32_t* mt_state_dev, const int64_t* ring_state_a, int32_t* idx_a,
+                                  const int64_t* ring_state_b, int32_t* idx_b, float* stage_rows, uint32_t flags, il_stream_t stream);
 /* Population axis: discriminator step + AIRL/GAIL/FAIRL reward relabel for n_learners discriminators; rewards_out_dev[l] -> float[batch]. */
 int il_gail_step_population(const il_disc* descs_dev, const il_batch* policy_dev, const il_batch* expert_dev, float* const* rewards_out_dev,
                             int32_t n_learners, const il_disc* shape_host, il_stream_t stream);

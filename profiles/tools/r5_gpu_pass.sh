@@ -76,6 +76,19 @@ for what in "$@"; do
       # interleaved on one box: hipGraph replays against direct launches of the same two branches (UpdatePlan.launch_direct)
       for i in 1 2 3; do for e in ${IL_AB_EARLY:-1}; do for m in graph direct; do IL_EARLY_DRAW=$e timeout 300 python bench.py --launch $m --steps 2000 --warmup 200 --repeats 3 --stamp-bursts 10 $QUICK 2>$OUT/ab_direct.err | line "early_draw=$e launch=$m" | tee -a $OUT/ab_direct.txt; done; done; done
       cat $OUT/ab_direct.txt >> $OUT/summary.txt ;;
+    ab_env)
+      # interleaved A/B of one environment switch on the headline line: IL_AB_SWITCH=NAME (values 1 / 0), direct launches
+      for i in 1 2 3; do for v in 1 0; do env $IL_AB_SWITCH=$v timeout 300 python bench.py --steps 2000 --warmup 200 --repeats 3 --stamp-bursts 10 $QUICK 2>$OUT/ab_env.err | line "$IL_AB_SWITCH=$v" | tee -a $OUT/ab_$IL_AB_SWITCH.txt; done; done
+      cat $OUT/ab_$IL_AB_SWITCH.txt >> $OUT/summary.txt ;;
+    ab_gmmil_rb8)
+      for i in 1 2 3; do for lib in "" "$ROOT/variants/rb8/libil_hip.so"; do IL_HIP_LIBRARY=$lib timeout 300 python profiles/tools/secondary_workloads.py gmmil_rate 2>$OUT/ab_gmmil.err | tail -n 1 | sed "s|^|lib=${lib:-in-tree} |" | tee -a $OUT/ab_gmmil_rb8.txt; done; done
+      cat $OUT/ab_gmmil_rb8.txt >> $OUT/summary.txt
+      IL_HIP_LIBRARY=$ROOT/variants/rb8/libil_hip.so trace gmmil_rb8 "python profiles/tools/secondary_workloads.py gmmil"; head -n 4 $OUT/gmmil_rb8_kernel_stats.md | tee -a $OUT/summary.txt ;;
+    popline)
+      timeout 600 python bench.py --steps 300 --warmup 50 --repeats 1 --stamp-bursts 0 --no-cpu-baseline --no-secondary --trace-steps 10 2>$OUT/popline.err | python -c "
+import sys, json
+j = json.loads(sys.stdin.read().strip().splitlines()[-1]); p = j['population']
+print('population', p['learners'], p['groups'], p['aggregate_updates_per_s'], p['ms_per_replay'], p['roofline'].get('fp32_frac'))" | tee -a $OUT/summary.txt ;;
     ab_gmmil)
       for i in 1 2 3; do for m in 1 0; do IL_GMMIL_RESIDENT=$m timeout 300 python profiles/tools/secondary_workloads.py gmmil_rate 2>$OUT/ab_gmmil.err | tail -n 1 | sed "s/^/IL_GMMIL_RESIDENT=$m /" | tee -a $OUT/ab_gmmil.txt; done; done
       cat $OUT/ab_gmmil.txt >> $OUT/summary.txt ;;

@@ -1262,7 +1262,7 @@ def test_update_plan_batch_sizes_of_the_tuned_configs(monkeypatch, B, ring):
 @pytest.mark.gpu
 @pytest.mark.parametrize('switch,B', [('IL_RING_GATHER', 256), ('IL_INLINE_RELABEL', 256), ('IL_SAC_CHAIN', 256), ('IL_PC_SPLIT', 256), ('IL_RESIDENT_SAMPLER', 256), ('IL_RESIDENT_SAMPLER', 80),
                                       ('IL_SAC_CHAIN', 80), ('IL_RING_GATHER', 80), ('IL_PC_SPLIT', 48), ('IL_CHAIN_XCD_NETS', 256), ('IL_CHAIN_XCD_NETS', 80),
-                                      ('IL_PAIR', 256), ('IL_PAIR', 128), ('IL_PAIR', 80)])   # IL_PAIR: the column-split pairs of k_sac_chain_pair / k_policy_critic_pair against the 16-wave workgroups   # 80 / 48 rows: 5 / 3 tiles, the non-XCD-aware role decode; IL_CHAIN_XCD_NETS: one network per XCD (off by default)
+                                      ('IL_PAIR', 256), ('IL_PAIR', 128), ('IL_PAIR', 80), ('IL_STAGE_ROWS', 256), ('IL_STAGE_ROWS', 80), ('IL_EARLY_DRAW', 256), ('IL_EARLY_DRAW', 48)])   # IL_PAIR: the column-split pairs of k_sac_chain_pair / k_policy_critic_pair against the 16-wave workgroups   # 80 / 48 rows: 5 / 3 tiles, the non-XCD-aware role decode; IL_CHAIN_XCD_NETS: one network per XCD (off by default)
 def test_schedule_switches_are_bit_identical(monkeypatch, switch, B):
   """Every schedule of the update (rows through il_batch.gather vs a gather kernel, inline relabel vs k_gail_reward, chained vs separate forward / critic-loss
   launches, helper-split vs second-arriver policy tail) runs the same arithmetic per element: switching one off must not change a bit.
