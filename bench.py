@@ -114,8 +114,15 @@ def secondary(device, plan, nets):
   actor, critic, target, log_alpha, disc = nets
   keep = plan._keep
   sac_plan = il.UpdatePlan('SAC', actor, critic, log_alpha, target, plan.memory, keep[4], keep[5], keep[6], B, 0.97, -0.5 * A, 0.99, learner_id=9001)
-  sac_plan.run(); sac_plan.capture(warmup=0)
-  out['sac_only_updates_per_s'] = round(timed(sac_plan.replay, 1000, 100), 1)
+  sac_plan.run()
+  if sac_plan.direct_launch_ok():   # as the headline: the update's launches issued directly (two library calls per update), no hipGraph
+    sac_plan.record_direct()
+    out['sac_only_updates_per_s'] = round(timed(sac_plan.launch_direct, 2000, 200), 1)
+    out['sac_only_launch'] = 'direct launches'
+  else:
+    sac_plan.capture(warmup=0)
+    out['sac_only_updates_per_s'] = round(timed(sac_plan.replay, 1000, 100), 1)
+    out['sac_only_launch'] = 'hipGraph replay'
 
   # the headline update with FOUR consecutive updates captured per replay (UpdatePlan.capture(updates=4): offline training / several updates per environment step):
   # the ~3.5 us of queue work between two graph launches is then paid once per four updates. The headline `value` replays one update per launch, like train.py does.

@@ -711,8 +711,10 @@ class UpdatePlan:
   def staged_rows(self) -> bool:
     """GAIL with the resident sampler on one GPU: the sampler workgroup also copies the drawn agent rows into a dense slab (`stage`) before it signals
     (il_gail_disc_step_draw_staged) - with the early draw that is ~30 us before the update starts - and the forward / critic-loss launch reads them from there
-    (IL_FLAG_SAC_STAGED_ROWS): one global trip in its prologues instead of index -> row. The discriminator step keeps reading through the indices. IL_STAGE_ROWS=0: off."""
-    return bool(self.algorithm == 'GAIL' and self.resident_sampler and self.peer_desc is None and not getattr(self, 'data_parallel', False) and os.environ.get('IL_STAGE_ROWS', '1') != '0')
+    (IL_FLAG_SAC_STAGED_ROWS): one global trip in its prologues instead of index -> row. The discriminator step keeps reading through the indices. Measured NEUTRAL on an
+    interleaved A/B (17.55-17.63k against 17.47-17.64k updates/s, k_sac_chain_pair 22.1-22.3 us either way, profiles/r05_stage_rows_ab.txt): with the indices drawn ~30 us
+    ahead the index -> row trip of the prologues is not what the forward / critic-loss launch waits for. Kept bit-identical and switchable, OFF by default (IL_STAGE_ROWS=1)."""
+    return bool(self.algorithm == 'GAIL' and self.resident_sampler and self.peer_desc is None and not getattr(self, 'data_parallel', False) and os.environ.get('IL_STAGE_ROWS', '0') == '1')
 
   def _staged_batch(self):
     if getattr(self, '_stage_desc', None) is None:

@@ -38,4 +38,5 @@ def pytest_terminal_summary(terminalreporter):
   if out:
     import json
     with open(out, 'w') as f:
-      json.dump([dict(site=n, measured=fr, allowed=a) for n, fr, a in gu.FRACTIONS], f, indent=1)
+      json.dump(dict(outlier_fractions=[dict(site=n, measured=fr, allowed=a) for n, fr, a in gu.FRACTIONS],
+                     f64_brackets=[dict(site=n, hip_err_over_scale=h, reference_f32_err_over_scale=r) for n, h, r in getattr(gu, 'BRACKETS', [])]), f, indent=1)

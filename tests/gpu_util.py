@@ -38,6 +38,7 @@ def close(a, b, name, rtol=1e-5, atol_scale=2e-6):
   assert float(err.max()) <= atol, f'{name}: max excess err {err.max():.3e} > atol {atol:.3e} at flat index {i} (hip {a.ravel()[i]:.8e} vs oracle {b.ravel()[i]:.8e})'
 
 
+BRACKETS = []    # (name, max |hip - f64| / scale, max |reference f32 - f64| / scale) of every bracket() call: the tolerance ledger of DESIGN.md 4
 FRACTIONS = []   # (name, measured outlier fraction, allowed) of every close_params / close_sparse call: conftest prints the largest at the end of a run, so a drift
                  # towards the allowance is visible long before it fails
 
@@ -77,6 +78,7 @@ def bracket(hip, ref32, ref64, name, factor=2.0, floor=1e-6):
   assert eh.max() <= factor * er.max() + floor * scale, f'{name}: max |hip - f64| = {eh.max():.3e} vs reference f32 {er.max():.3e} (scale {scale:.3e}): more than {factor}x the reference\'s own float32 error'
   rh, rr = float(np.sqrt((eh ** 2).mean())), float(np.sqrt((er ** 2).mean()))
   assert rh <= factor * rr + floor * scale, f'{name}: rms |hip - f64| = {rh:.3e} vs reference f32 {rr:.3e} (scale {scale:.3e})'
+  BRACKETS.append((name, float(eh.max() / scale), float(er.max() / scale)))
   return eh.max() / scale, er.max() / scale
 
 

@@ -1280,13 +1280,14 @@ def test_schedule_switches_are_bit_identical(monkeypatch, switch, B):
       "assert plan.sync_timeouts() == 0\n"
       "h = hashlib.sha256()\n"
       "for n in list(nets) + [plan.logp, plan.q, plan.rewards, plan.idx]: h.update(np.ascontiguousarray(N(n.flat if hasattr(n, 'flat') else n)).tobytes())\n"
-      "print(json.dumps(dict(digest=h.hexdigest(), ring=plan.ring_mode, inline=plan.inline_relabel)))\n")
+      "print(json.dumps(dict(digest=h.hexdigest(), ring=plan.ring_mode, inline=plan.inline_relabel, staged=plan.staged_rows)))\n")
   outs = []
   for value in ('1', '0'):
     env = dict(os.environ, **{switch: value})
     r = subprocess.run([sys.executable, '-c', code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+  if switch == 'IL_STAGE_ROWS': assert outs[0]['staged'] and not outs[1]['staged']
   assert outs[0]['ring'] and outs[0]['inline'], 'the default schedule reads rows through il_batch.gather and relabels inline'
   if switch == 'IL_RING_GATHER': assert not outs[1]['ring']
   if switch == 'IL_INLINE_RELABEL': assert outs[1]['ring'] and not outs[1]['inline']
