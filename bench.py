@@ -197,7 +197,8 @@ def secondary(device, plan, nets):
     if k[0] % 1000 == 0: pw.reset()
   out['pwil_reward_25k_atoms_steps_per_s'] = round(timed(pwil_step, 2000, 100), 1)
 
-  # an actor / critic shape outside the fused kernels (models.py:48-69: depth 3, tanh): sac_update through csrc/general.hip, per-function call, batch 256.
+  # an actor / critic shape outside the fused kernels (models.py:48-69: depth 3, tanh): WHOLE updates (2 device draws + gather + sac_update through csrc/general.hip's
+  # layer-at-a-time launches) as one captured graph per update (round 5: UpdatePlan accepts these shapes on one stream), next to the per-function call on a fixed batch.
   # Reported, never part of `value`; a failure here must not cost the line.
   try:
     cfg3 = Cfg(hidden_size=H, depth=3, activation='tanh')
@@ -207,6 +208,9 @@ def secondary(device, plan, nets):
     from imitation_learning_amd.memory import batch_views
     gb = batch_views(plan.memory.ring[:B].clone(), S, A, True)   # the first B rows of the ring: no index draw (the generator's state is the timed schedule's)
     out['sac_general_shape_depth3_tanh_updates_per_s'] = round(timed(lambda: il.sac_update(ga, gc, gla, gt, gb, gao, gco, gto, 0.97, -0.5 * A, 0.99), 300, 30), 1)
+    gplan3 = il.UpdatePlan('SAC', ga, gc, gla, gt, plan.memory, gao, gco, gto, B, 0.97, -0.5 * A, 0.99, learner_id=None)
+    gplan3.run(); gplan3.capture(warmup=0)
+    out['sac_general_shape_depth3_tanh_captured_plan_updates_per_s'] = round(timed(gplan3.replay, 300, 30), 1)
   except Exception as e:   # noqa: BLE001
     out['sac_general_shape_depth3_tanh_updates_per_s'] = f'failed: {type(e).__name__}: {e}'[:200]
   return out

@@ -402,6 +402,9 @@ class DataParallelUpdate:
       raise NotImplementedError('DataParallelUpdate: GAIL with a finite PUGAIL margin / subtract_log_policy / reward shaping / a depth-2 or tanh discriminator / Mixup with mixup_alpha != 1 '
                                 'runs its discriminator step through the per-function entry points inside the plan: there are no gradient-only kernels to all-reduce for them; '
                                 'run these configurations with distributed.world_size=1')
+    if getattr(plan, 'general', False):
+      raise NotImplementedError('DataParallelUpdate: actor / critic shapes outside depth 2 / ReLU / hidden <= 256 / action_size <= 8 (csrc/general.hip) have no gradient-only kernels '
+                                'to all-reduce; run these configurations with distributed.world_size=1')
     if plan.bc_aux:
       raise NotImplementedError('DataParallelUpdate: imitation.bc_aux_loss (the behavioural-cloning auxiliary step, train.py:201) has no data-parallel form; run it with distributed.world_size=1')
     # Device-side hand-off between the discriminator branch and the SAC branch, as on one GPU (UpdatePlan): no stream dependency between the two streams, the index

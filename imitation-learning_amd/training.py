@@ -433,9 +433,14 @@ class UpdatePlan:
     """`learner_id`: give this plan private scratch / noise / index-stream state so that several plans can run concurrently (`PopulationPlan`).
     `mix_expert`: imitation.mix_expert_data == 'mixed_batch' (DRIL / GMMIL / RED); `bc_aux`: imitation.bc_aux_loss (train.py:201)."""
     assert algorithm in self.ALGORITHMS, f'UpdatePlan: unknown algorithm {algorithm}'
-    if _general_shape(actor, critic):
-      raise NotImplementedError('UpdatePlan: actor / critic shapes outside depth 2 / ReLU / hidden <= 256 / action_size <= 8 run through sac_update (csrc/general.hip, per-function path): '
-                                'there is no captured plan, population or data-parallel form for them')
+    # reinforcement.actor / critic outside the fused kernels' shape (models._mlp_shape: any depth 1-8, relu / tanh / sigmoid, hidden <= 2048, wide action spaces): the same plan
+    # on ONE stream - device draws + gather, the algorithm's reward step, il_sac_update_general's layer-at-a-time launches (csrc/general.hip) - capturable as one hipGraph.
+    # No device hand-off, population or data-parallel form for these shapes.
+    self.general = _general_shape(actor, critic)
+    if self.general:
+      overlap = False
+      if learner_id is not None:
+        raise NotImplementedError('UpdatePlan: a population of learners with actor / critic shapes outside depth 2 / ReLU / hidden <= 256 / action_size <= 8')
     assert expert_memory is not None or (algorithm in ('SAC', 'PWIL') and not mix_expert and not bc_aux), f'UpdatePlan({algorithm}): needs the expert memory'
     assert not (mix_expert and algorithm in ('GAIL', 'SAC', 'PWIL', 'AdRIL')), 'mixed batches: DRIL / GMMIL / RED plans (train.py:175,183); GAIL with mixing runs the per-function path'
     # GAIL: discriminator branch || SAC branch. SAC / PWIL (no reward step, nothing host-side inside): the second stream only hosts the resident index draw.
@@ -528,6 +533,7 @@ class UpdatePlan:
     it found > 0 - [10, B, H] floats: actor(s) layers 1, 2; critic_k(s, a) at 2 + 2k, 3 + 2k; the updated critic_k(s, a~) at 6 + 2k, 7 + 2k. Call before capture()
     (a captured launch carries the descriptor by value). The oracle replays an update with these decisions (oracle.nets.mlp_forward(masks=...))."""
     assert self.graph is None, 'record_relu_masks(): before capture()'
+    assert not self.general, 'record_relu_masks(): the fused kernels only'
     self.relu_masks = torch.zeros(10, self.B, self.sac.hidden, device=self.rows.device)
     self.sac.debug_masks = self.relu_masks.data_ptr()
     return self.relu_masks
@@ -899,10 +905,22 @@ class UpdatePlan:
     if self.bc_aux:   # train.py:201: a behavioural-cloning step on the expert batch with the ACTOR's optimiser; it moves the actor, so the lane-ordered copies are re-derived
       a, ao = self._keep[0], self._keep[4]
       od = ao.desc()
-      _lib.check(L.il_bc_step(_lib.ptr(a.flat), _lib.ptr(ao.grad), C.byref(od), a.state_size, a.action_size, a.hidden, C.byref(self.eb), C.c_void_p(self.sac.workspace), self.sac.workspace_floats,
-                              None, 0, st))
+      if self.general:
+        from .models import ACTIVATION_IDS
+        ws = a._general_workspace(self.B)
+        _lib.check(L.il_bc_step_general(_lib.ptr(a.flat), _lib.ptr(ao.grad), C.byref(od), a.state_size, a.action_size, a.hidden, a.depth, ACTIVATION_IDS[a.activation], C.byref(self.eb), _lib.ptr(ws),
+                                        ws.numel(), None, 0, st))
+      else:
+        _lib.check(L.il_bc_step(_lib.ptr(a.flat), _lib.ptr(ao.grad), C.byref(od), a.state_size, a.action_size, a.hidden, C.byref(self.eb), C.c_void_p(self.sac.workspace), self.sac.workspace_floats,
+                                None, 0, st))
       flag = 0
-    _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), flag, st))
+    if self.general:
+      from .models import ACTIVATION_IDS
+      a, c = self._keep[0], self._keep[1]
+      _lib.check(L.il_sac_update_general(C.byref(self.sac), C.byref(self.pb), a.depth, ACTIVATION_IDS[a.activation], c.hidden, c.depth, ACTIVATION_IDS[c.activation], None, None,
+                                         _lib.ptr(self.logp), _lib.ptr(self.q), 0, st))
+    else:
+      _lib.check(L.il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), flag, st))
     self.sac.sync = sync_kept
     self._prepared = True
 

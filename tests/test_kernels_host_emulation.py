@@ -560,6 +560,20 @@ def test_update_plan_of_every_algorithm_on_the_emulated_kernels(monkeypatch, alg
   tp.test_plan_of_every_algorithm_equals_the_per_function_sequence(algorithm, mixed, bc_aux, kw)
 
 
+@pytest.mark.parametrize('algorithm,mixed,bc_aux,nets_name', [('SAC', False, True, 'd3_tanh'), ('GMMIL', True, False, 'mixed'), ('AdRIL', False, False, 'mixed')])
+def test_general_shape_update_plan_on_the_emulated_kernels(monkeypatch, algorithm, mixed, bc_aux, nets_name):
+  """UpdatePlan for actor / critic shapes outside the fused kernels (csrc/general.hip on one stream, captured as one graph): bit-identical to the per-function sequence."""
+  tgp = _emulated_product(monkeypatch, streams=True)
+  import gpu_util
+  import test_update_plans_gpu as tp
+  from imitation_learning_amd import training as il_training
+  for k in ('DEV', 'N', 'Cfg', 'fill_memory'):
+    monkeypatch.setattr(tp, k, getattr(gpu_util, k), raising=False)
+  for k, v in (('il', tgp.il), ('_lib', _lib), ('il_training', il_training)):
+    monkeypatch.setattr(tp, k, v, raising=False)
+  tp.test_general_shape_plan_equals_the_per_function_sequence(algorithm, mixed, bc_aux, nets_name)
+
+
 @pytest.mark.parametrize('absorbing', [True, False])
 @pytest.mark.parametrize('schedule', ['exact', 'fused', 'overlap'])
 def test_acting_worker_on_the_emulated_kernels(monkeypatch, absorbing, schedule):

@@ -30,11 +30,11 @@ GAIL_VARIANTS = {   # the discriminator variants whose per-function entry points
 }
 
 
-def build(algorithm, seed, mixed=False, bc_aux=False, balanced=True, update_freq=1250, variant=None):
+def build(algorithm, seed, mixed=False, bc_aux=False, balanced=True, update_freq=1250, variant=None, net=None, critic_net=None):
   torch.manual_seed(seed); il.seed(seed)
   il_training._NOISE.clear(); il_training._WS.clear()
-  cfg = Cfg(hidden_size=128, depth=2, activation='relu')
-  actor, critic = il.SoftActor(S, A, cfg, device=DEV), il.TwinCritic(S, A, cfg, device=DEV)
+  cfg = Cfg(net or dict(hidden_size=128, depth=2, activation='relu'))
+  actor, critic = il.SoftActor(S, A, cfg, device=DEV), il.TwinCritic(S, A, Cfg(critic_net) if critic_net else cfg, device=DEV)
   target, log_alpha = il.create_target_network(critic), torch.zeros(1, device=DEV)
   ao, co, to = il.AdamW(actor, lr=3e-4, weight_decay=0), il.AdamW(critic, lr=3e-4, weight_decay=0), il.Adam(log_alpha, lr=3e-4)
   rs = np.random.RandomState(seed)
@@ -55,7 +55,7 @@ def build(algorithm, seed, mixed=False, bc_aux=False, balanced=True, update_freq
   elif algorithm == 'AdRIL':
     disc = il.RewardRelabeller(update_freq, balanced)
   elif algorithm == 'GAIL':
-    io, do_ = GAIL_VARIANTS[variant]
+    io, do_ = GAIL_VARIANTS[variant] if variant else ({}, {})
     icfg = Cfg(dict(state_only=False, spectral_norm=True, loss_function='BCE', grad_penalty=0.7, entropy_bonus=0.0, mixup_alpha=1, pos_class_prior=0.7, nonnegative_margin=float('inf')), **io)
     icfg['discriminator'] = Cfg(dict(hidden_size=32, depth=1, activation='relu', reward_shaping=False, subtract_log_policy=False, reward_function='AIRL'), **do_)
     disc = il.GAILDiscriminator(S, A, icfg, 0.97, device=DEV)
@@ -171,3 +171,37 @@ def test_discriminator_variants_draw_fresh_noise_every_update(variant):
   before = int(N(ctr)[0])
   il.sac_update(*nets, mem.sample(B), *opts, 0.97, -0.5 * A, 0.99)
   assert int(N(ctr)[0]) == before + 1
+
+
+GENERAL_NETS = dict(d3_tanh=(dict(hidden_size=96, depth=3, activation='tanh'), None), mixed=(dict(hidden_size=32, depth=1, activation='relu'), dict(hidden_size=72, depth=3, activation='sigmoid')))
+
+
+@pytest.mark.parametrize('algorithm,mixed,bc_aux,nets_name', [('SAC', False, True, 'd3_tanh'), ('GAIL', False, False, 'd3_tanh'), ('GMMIL', True, False, 'mixed'), ('AdRIL', False, False, 'mixed')])
+def test_general_shape_plan_equals_the_per_function_sequence(algorithm, mixed, bc_aux, nets_name):
+  """models.py:48-69 builds actor / critic networks of any depth and activation: UpdatePlan runs such shapes on one stream (device draws + gather, the reward step,
+  il_sac_update_general) and captures them as ONE hipGraph - bit-identical to the per-function entry points called in the order of train.py:173-203."""
+  K, step0 = 4, 2400
+  net, cnet = GENERAL_NETS[nets_name]
+  kw = dict(net=net, critic_net=cnet)
+  nets, opts, mem, emem, disc = build(algorithm, 13, **kw)
+  assert nets[0].general or nets[1].general
+  want = [per_function_update(algorithm, nets, opts, mem, emem, disc, step0 + 37 * k, mixed, bc_aux) for k in range(K)]
+  ref_state = [N(n.flat if hasattr(n, 'flat') else n) for n in nets] + ([N(disc.flat)] if algorithm == 'GAIL' else [])
+  nets, opts, mem, emem, disc = build(algorithm, 13, **kw)
+  plan = il.UpdatePlan(algorithm, *nets, mem, *opts, B, 0.97, -0.5 * A, 0.99, expert_memory=emem, discriminator=disc, mix_expert=mixed, bc_aux=bc_aux, **getattr(disc, 'test_extra', {}))
+  assert plan.general and not plan.device_sync and plan.side is None
+  got = []
+  for k in range(K):
+    if algorithm == 'AdRIL': plan.relabel_args(step0 + 37 * k, mem.num_trajectories)
+    if k == 0:
+      plan.run(); plan.capture(warmup=0)
+    else:
+      plan.replay()
+    torch.cuda.synchronize()
+    got.append((plan.transitions['rewards'].clone(), plan.logp.clone(), plan.q.clone()))
+  for k, (w, g) in enumerate(zip(want, got)):
+    for name, a, b in zip(('rewards', 'log pi', 'min Q'), w, g):
+      np.testing.assert_array_equal(N(a), N(b), err_msg=f'{algorithm} update {k}: {name}')
+  for i, (a, n) in enumerate(zip(ref_state, tuple(nets) + ((disc,) if algorithm == 'GAIL' else ()))):
+    assert np.isfinite(a).all()
+    np.testing.assert_array_equal(a, N(n.flat if hasattr(n, 'flat') else n), err_msg=f'{algorithm}: tensor {i} after {K} updates')

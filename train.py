@@ -171,8 +171,7 @@ def train(cfg, file_prefix: str = '') -> float:
   if cfg.algorithm == 'GAIL' and (mixed or cfg.imitation.bc_aux_loss):
     fusable = False   # a mix between the discriminator step and the relabel / an auxiliary actor step on the expert batch: per-function path. (Every discriminator variant -
     # loss functions, finite PUGAIL margin, subtract_log_policy, reward shaping, depth 2 / tanh, Mixup with any alpha - is captured by UpdatePlan.)
-  general = bool(getattr(actor, 'general', False) or getattr(critic, 'general', False))   # reinforcement.actor / critic outside depth 2 / relu / hidden <= 256 (csrc/general.hip)
-  if general: fusable = False
+  general = bool(getattr(actor, 'general', False) or getattr(critic, 'general', False))   # reinforcement.actor / critic outside depth 2 / relu / hidden <= 256 (csrc/general.hip): the plan runs them on one stream, captured as one graph
   if fusable:
     plan = il.UpdatePlan(cfg.algorithm, actor, critic, log_alpha, target_critic, memory, actor_optimiser, critic_optimiser, temperature_optimiser, B, cfg.reinforcement.discount,
                          entropy_target, cfg.reinforcement.polyak_factor, expert_memory=expert_memory, discriminator=discriminator, discriminator_optimiser=discriminator_optimiser,
