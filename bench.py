@@ -208,7 +208,7 @@ def secondary(device, plan, nets):
     from imitation_learning_amd.memory import batch_views
     gb = batch_views(plan.memory.ring[:B].clone(), S, A, True)   # the first B rows of the ring: no index draw (the generator's state is the timed schedule's)
     out['sac_general_shape_depth3_tanh_updates_per_s'] = round(timed(lambda: il.sac_update(ga, gc, gla, gt, gb, gao, gco, gto, 0.97, -0.5 * A, 0.99), 300, 30), 1)
-    gplan3 = il.UpdatePlan('SAC', ga, gc, gla, gt, plan.memory, gao, gco, gto, B, 0.97, -0.5 * A, 0.99, learner_id=None)
+    gplan3 = il.UpdatePlan('SAC', ga, gc, gla, gt, plan.memory, gao, gco, gto, B, 0.97, -0.5 * A, 0.99, learner_id=9003)
     gplan3.run(); gplan3.capture(warmup=0)
     out['sac_general_shape_depth3_tanh_captured_plan_updates_per_s'] = round(timed(gplan3.replay, 300, 30), 1)
   except Exception as e:   # noqa: BLE001

@@ -77,6 +77,7 @@ def sac_descriptor(actor: SoftActor, critic: TwinCritic, log_alpha: Tensor, targ
   d.actor_opt, d.critic_opt, d.alpha_opt = actor_optimiser.desc(), critic_optimiser.desc(), temperature_optimiser.desc()
   d.discount, d.entropy_target, d.polyak = float(discount), float(entropy_target), float(polyak_factor)
   d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
+  d._ws = ws   # the descriptor holds a raw pointer: keep the arena alive with it (a later, larger request under the same key replaces the cached tensor)
   d.noise_seed, d.noise_counter = (_noise_seed() + seed_offset) & (2**64 - 1), _noise_counter(dev, tag).data_ptr()
   return d
 
@@ -169,6 +170,7 @@ def disc_descriptor(disc: GAILDiscriminator, batch_size: int, opt: AdamW, imitat
     d.grad = ws.data_ptr()  # reward only: never written
   d.grad_penalty, d.entropy_bonus = grad_penalty, entropy_bonus
   d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
+  d._ws = ws   # the descriptor holds a raw pointer: keep the arena alive with it (a later, larger request under the same key replaces the cached tensor)
   d.noise_seed, d.noise_counter = (_noise_seed() + seed_offset) & (2**64 - 1), _noise_counter(dev, tag).data_ptr()
   d.loss_function, d.pos_class_prior = LOSS_FUNCTIONS[loss_function], prior
   if loss_function == 'PUGAIL' and margin != float('inf'):   # training.py:102: torch.clamp(..., min=-nonnegative_margin) on the batch-wide value (a value pass precedes the gradients)
@@ -206,6 +208,7 @@ def shaped_descriptor(disc, batch_size: int, opt, imitation_cfg=None):
     d.grad, d.opt = opt.grad.data_ptr(), opt.desc()
   d.grad_penalty, d.entropy_bonus, d.pos_class_prior, d.discount = grad_penalty, entropy_bonus, prior, float(disc.discount)
   d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
+  d._ws = ws   # the descriptor holds a raw pointer: keep the arena alive with it (a later, larger request under the same key replaces the cached tensor)
   d.noise_seed, d.noise_counter = _noise_seed() & (2**64 - 1), _noise_counter(dev, None).data_ptr()   # the learner's ONE update counter (advanced by the actor step of sac_update): fresh GP / Mixup draws per update
   if loss_function == 'PUGAIL' and margin != float('inf'):   # training.py:102, as in disc_descriptor
     d.pu_clamped, d.nonnegative_margin = 1, margin
@@ -233,6 +236,7 @@ def deep_descriptor(disc, batch_size: int, opt, imitation_cfg=None) -> _lib.Disc
     d.grad, d.opt = opt.grad.data_ptr(), opt.desc()
   d.grad_penalty, d.entropy_bonus, d.pos_class_prior = grad_penalty, entropy_bonus, prior
   d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
+  d._ws = ws   # the descriptor holds a raw pointer: keep the arena alive with it (a later, larger request under the same key replaces the cached tensor)
   d.noise_seed, d.noise_counter = _noise_seed() & (2**64 - 1), _noise_counter(dev, None).data_ptr()   # the learner's ONE update counter (advanced by the actor step of sac_update): fresh GP / Mixup draws per update
   if loss_function == 'PUGAIL' and margin != float('inf'):   # training.py:102, as in disc_descriptor
     d.pu_clamped, d.nonnegative_margin = 1, margin
@@ -439,8 +443,6 @@ class UpdatePlan:
     self.general = _general_shape(actor, critic)
     if self.general:
       overlap = False
-      if learner_id is not None:
-        raise NotImplementedError('UpdatePlan: a population of learners with actor / critic shapes outside depth 2 / ReLU / hidden <= 256 / action_size <= 8')
     assert expert_memory is not None or (algorithm in ('SAC', 'PWIL') and not mix_expert and not bc_aux), f'UpdatePlan({algorithm}): needs the expert memory'
     assert not (mix_expert and algorithm in ('GAIL', 'SAC', 'PWIL', 'AdRIL')), 'mixed batches: DRIL / GMMIL / RED plans (train.py:175,183); GAIL with mixing runs the per-function path'
     # GAIL: discriminator branch || SAC branch. SAC / PWIL (no reward step, nothing host-side inside): the second stream only hosts the resident index draw.
@@ -1133,6 +1135,8 @@ class BatchedPopulationPlan:
       p._set_device_sync(False)   # one stream, one set of launches for all learners: plain stream order
     p0 = self.plans[0]
     assert all(p.algorithm == p0.algorithm and p.B == p0.B for p in self.plans) and p0.algorithm in ('SAC', 'GAIL'), 'the population launches exist for SAC and GAIL learners'
+    if any(getattr(p, 'general', False) for p in self.plans):
+      raise NotImplementedError('BatchedPopulationPlan: actor / critic shapes outside depth 2 / ReLU / hidden <= 256 / action_size <= 8 have no population launches (PopulationPlan runs them as independent graph branches)')
     self.algorithm, self.B, self.L, dev = p0.algorithm, p0.B, len(self.plans), p0.rows.device
     self.sac_descs = _device_array([p.sac for p in self.plans], dev)
     self.batches = _device_array([p.pb for p in self.plans], dev)

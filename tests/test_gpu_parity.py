@@ -213,9 +213,15 @@ def test_general_shape_sac_matches_oracle_and_reference(golden_dir, name):
     torch.cuda.synchronize()
     if k == 1: close(gi.strided(N(opt.grad)), g['bc_g_actor_1'], 'golden behavioural-cloning gradient')
     close_params(gi.strided(N(actor2.flat)), g[f'bc_actor_{k}'], f'golden general actor after BC step {k}', 2.5e-4, k)
-  # plans and the acting worker refuse these shapes loudly
+  # round 5: UpdatePlan takes these shapes on one stream (tests/test_update_plans_gpu.py::test_general_shape_plan_equals_the_per_function_sequence); the population launches
+  # and the data-parallel runner still refuse them loudly
+  gplan = il.UpdatePlan('SAC', actor, critic, log_alpha, target, il.ReplayMemory(64, c['S'], c['A'], True, device=DEV), ao, co, to, 16, 0.97, -1.0, 0.99, learner_id=77)
+  assert gplan.general and gplan.side is None and not gplan.device_sync
   with pytest.raises(NotImplementedError):
-    il.UpdatePlan('SAC', actor, critic, log_alpha, target, il.ReplayMemory(64, c['S'], c['A'], True, device=DEV), ao, co, to, 16, 0.97, -1.0, 0.99)
+    il.BatchedPopulationPlan([gplan, gplan])
+  from imitation_learning_amd import parallel
+  with pytest.raises(NotImplementedError):
+    parallel.DataParallelUpdate(gplan)
 
 
 def test_bc_update_matches_oracle_and_reference(golden_dir):
