@@ -162,8 +162,11 @@ def secondary(device, plan, nets):
   gm.predict_reward(xs, xa, es, ea, w, w)   # first call fixes the bandwidths (median heuristic)
   rate = timed(lambda: gm.predict_reward(xs, xa, es, ea, w, w))
   pair_flops = 2 * (2 * Bg * Bg) * (3 * (Sg + Ag))   # two gammas share the distances: 2 matrices x B^2 pairs x 3 flop per pair-feature (direct form)
-  out['gmmil_reward_B1024_ant'] = dict(calls_per_s=round(rate, 1), pair_feature_TFLOPs=round(pair_flops * rate / 1e12 / 2, 2),
-                                        note='k_gmmil_direct (one launch reading the batches; IL_GMMIL_DIRECT=0: k_gmmil_pack + k_gmmil_tile); the reference materialises [B,B,D] temporaries (0.33 s per call on its CPU path, SURVEY.md a20)')
+  gst = _lib_mod().kernel_stamps().get('k_gmmil_direct')
+  kus = gst['duration_us'] if gst else None
+  out['gmmil_reward_B1024_ant'] = dict(calls_per_s=round(rate, 1), pair_feature_TFLOPs=round(pair_flops * rate / 1e12 / 2, 2), kernel_us=kus,
+                                        kernel_fp32_frac=(round(pair_flops / 2 / (kus * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, 4) if kus else None),
+                                        note='k_gmmil_sx (one launch: row operand in scalar registers, 256 columns x all features resident in LDS; IL_GMMIL_SX=0 / IL_GMMIL_RESIDENT=0 / IL_GMMIL_DIRECT=0: the earlier forms, same bits); calls_per_s is bound by the host call (~26 us of Python per predict_reward), kernel_us is the launch itself (device stamps); the reference materialises [B,B,D] temporaries (0.33 s per call on its CPU path, SURVEY.md a20)')
 
   # BASELINE.json configs[3] as WHOLE updates: algorithm=GMMIL env=ant, batch 1024 - 2 replay samples + the pairwise-RBF reward + sac_update as one captured graph per step
   rs2 = np.random.RandomState(6)
@@ -367,6 +370,18 @@ def roofline_from_stamps(samples, ms_per_step, use_pmc=True):
   roof['duration_source'] = (f'device stamps inside the timed hipGraph replays (il_kernel_stamps: thread 0 of every workgroup stores the 100 MHz device counter at start / end; '
                              f'duration = last end - first start of the last launch of a burst), median of {len(samples)} readings; compare profiles/r05_headline_kernel_stats.md (rocprofv3 '
                              '--kernel-trace of the same command: dispatch-to-completion, i.e. + the command processor\'s launch and end-of-kernel work)')
+  try:   # the committed rocprofv3 --kernel-trace of the same command (dispatch-to-completion: + the command processor's launch and end-of-kernel work, i.e. part of what the
+    # stamps show as launch boundaries): the dominant kernel's duration and fraction by that clock, beside the stamps'
+    prof = os.path.join(ROOT, 'profiles', 'r05_headline_kernel_stats.md')
+    for line in open(prof):
+      cells = [c.strip() for c in line.strip().strip('|').split('|')]
+      if len(cells) >= 3 and cells[0] == dom:
+        avg = float(cells[2])
+        roof['rocprofv3_reference'] = dict(file='profiles/r05_headline_kernel_stats.md', kernel=dom, avg_us=avg, frac=round(flops_k[mk] / (avg * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, 5) if mk in flops_k else None,
+                                           note='rocprofv3 times a dispatch from the packet to the completion signal; the stamps from the first workgroup\'s first instruction to the last workgroup\'s last: the difference (~2.3 us for a 163 x 512-thread launch with 160 KB of LDS per workgroup) is what `update.launch_boundaries_us` holds')
+        break
+  except Exception:
+    pass
   if use_pmc:
     pmc = load_pmc(names)
     roof['traffic'] = pmc['kernels'][PMC_NAMES[dom]]['traffic_bytes']

@@ -39,7 +39,7 @@ __host__ __device__ inline GmmilWs gmmil_ws(int n1, int n2, int D) {
   const int nj1 = w.b2p / GT, nj2 = w.b1p / GT; w.njt = nj1 > nj2 ? nj1 : nj2;
   int64_t o = 0;
   w.xt = o; o += (int64_t)D * w.b1p; w.et = o; o += (int64_t)D * w.b2p; w.wn = o; o += w.b1p; w.wen = o; o += w.b2p;
-  w.part = o; o += (int64_t)2 * w.njt * w.b1p; w.ctr = o; o += (int64_t)(w.b1p / GTR) * GCTR;   // arrival counter per row tile, one 128-byte line each (zeroed by k_gmmil_pack)
+  w.part = o; o += (int64_t)2 * w.njt * w.b1p; w.ctr = o; o += (int64_t)(w.b1p / 32) * GCTR;   // arrival counter per row tile (64 rows; k_gmmil_sx: 32 rows), one 128-byte line each (zeroed by k_gmmil_pack)
   w.total = o;
   return w;
 }
@@ -606,6 +606,205 @@ static int gmmil_ensure_lds(K fn, size_t bytes) {
   const hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   return e == hipSuccess ? IL_OK : il_set_error(IL_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", bytes, hipGetErrorString(e));
 }
+// ---------------------------------------------------------------------------------------------
+// k_gmmil_sx (round 5): the pair arithmetic with the ROW operand in scalar registers. In k_gmmil_direct / _resident a thread's 4 x 4 pairs need two ds_read_b128 per
+// feature (its 4 rows, its 4 columns) for 16 packed instructions: with two workgroups per CU the LDS pipe (8 waves x 16 clocks per feature) is as busy as the SIMDs
+// (2 waves x 64 clocks): neither reaches its rate (round-2 timeline: 64 % of the packed-op issue rate; 8 x 4 blocks halve the reads but leave one wave per SIMD and
+// lose, profiles/r05_gmmil_rb8_ab.txt). Here a WAVE owns 4 rows x 256 columns: its rows' features are wave-uniform, so they come through the scalar cache
+// (s_load_dwordx8 from the row-major batch, constant address space) into SGPRs and feed v_pk_add_f32 as broadcast scalar operands (op_sel) - no LDS read, no VALU
+// instruction; the lane's 4 columns stay ONE ds_read_b128 per feature. Workgroup = 8 waves = 32 rows x 256 columns with all D features of the 256 columns resident in
+// LDS (120 KB at Ant dims: one workgroup per CU, two waves per SIMD, 256 workgroups at B = 1024). Same pair arithmetic in the same feature order, the same 64-column
+// partial sums (a 16-lane group = one 64-column tile), the same tile-ordered final sums, the weight sums by the first 256 threads in the old order: bit-identical.
+// Needs whole 16-byte lanes, S and D multiples of 8 (a group of 8 features never straddles states | actions) and D <= 156 (LDS); other shapes keep k_gmmil_resident.
+// ---------------------------------------------------------------------------------------------
+#define GSX_ROWS 32
+#define GSX_COLS 256
+#define AS4 __attribute__((address_space(4)))
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+static size_t gmmil_sx_lds(int D) { return ((size_t)D * GSX_COLS + 64) * sizeof(float); }
+template <int MODE>
+__global__ __launch_bounds__(512) void k_gmmil_sx(il_batch pol, il_batch exp, int S, int D, float g1, float g2, float* __restrict__ ws_, float* __restrict__ dist_out, int self_second,
+                                                  float* __restrict__ out_r, float* __restrict__ out_sim, float* __restrict__ out_self) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  IL_ST_BEGIN(IL_ST_GMMIL);
+  float* Ys = smem;                          // [D][256], column c of feature k at (c ^ 4 ((k / 4) % 8))
+  float* red = Ys + (size_t)D * GSX_COLS;    // [32] block_sum scratch, [32] = "last arriver" flag
+  // (the row operand's base pointers as the kernel arguments carry them - scalar registers; globalize() launders the descriptors through vector registers)
+  const AS4 float* x_states = (const AS4 float*)pol.states; const AS4 float* x_actions = (const AS4 float*)pol.actions;
+  const int x_ld_s = pol.ld_states, x_ld_a = pol.ld_actions;
+  globalize(pol); globalize(exp);
+  const int n1 = pol.n, n2 = exp.n;
+  const GmmilWs w = gmmil_ws(n1, n2, D);
+  const int it = blockIdx.x, jt4 = blockIdx.y, mat = blockIdx.z;  // mat 0: policy vs expert, 1: policy vs policy
+  const bool vs_self = (mat == 1) || (MODE == 1 && self_second);
+  const int npy = vs_self ? w.b1p : w.b2p;
+  if (jt4 * GSX_COLS >= npy) { IL_ST_END(IL_ST_GMMIL); return; }
+  const il_batch& yb = vs_self ? pol : exp;
+  const int ny = yb.n, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // weight-column sums (MODE 0): the first 256 threads in the order of the 256-thread kernels (the other waves add exact zeros in block_sum)
+  float sx = 0.f, sy = 0.f;
+  if (MODE == 0 && tid < 256) {
+    for (int i = tid; i < n1; i += 256) sx += pol.weights[(size_t)i * pol.ld_weights];
+    if (!vs_self) for (int i = tid; i < ny; i += 256) sy += yb.weights[(size_t)i * yb.ld_weights];
+  }
+  // the 256 columns' features: every 16-byte lane requested before anything is consumed (chunks of 32 features = 8 lanes along a row, 4 lanes per thread and chunk)
+  constexpr int NCH = 5, PY4 = GKC * GSX_COLS / 4 / 512;
+  f32x4 yr[NCH][PY4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c * GKC < D) {
+#pragma unroll
+      for (int u = 0; u < PY4; ++u) { const int i = tid + u * 512, r = i >> 3, kq = i & 7; yr[c][u] = cat_lane(yb, S, D, min(jt4 * GSX_COLS + r, ny - 1), c * GKC + 4 * kq, true); }
+    }
+  }
+  // this wave's 4 rows through the scalar cache: 8 features of a row = one s_load_dwordx8 (uniform addresses in the constant address space)
+  const AS4 float* xrow[4]; const AS4 float* xact[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int r = min(it * GSX_ROWS + wave * 4 + a, n1 - 1);
+    xrow[a] = x_states + (size_t)r * x_ld_s;
+    xact[a] = x_actions + (size_t)r * x_ld_a;
+  }
+  auto xload = [&](f32x8* x8, int k0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) x8[a] = k0 < S ? *(const AS4 f32x8*)(xrow[a] + k0) : *(const AS4 f32x8*)(xact[a] + (k0 - S));
+  };
+  f32x8 xr[4], xn[4];
+  xload(xr, 0);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c * GKC < D) {
+#pragma unroll
+      for (int u = 0; u < PY4; ++u) {
+        const int i = tid + u * 512, r = i >> 3, kq = i & 7, col = r ^ (4 * kq);
+        const bool rv = jt4 * GSX_COLS + r < ny;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int k = c * GKC + 4 * kq + q; if (k < D) Ys[(size_t)k * GSX_COLS + col] = rv ? yr[c][u][q] : 0.f; }
+      }
+    }
+  }
+  __syncthreads();
+  f32x2 acc2[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { acc2[a][0] = f32x2{0.f, 0.f}; acc2[a][1] = f32x2{0.f, 0.f}; }
+  {
+    // Two phases of four features per group of eight. The column operands of a phase are in registers before its 64 packed instructions start, the reads of the NEXT
+    // phase (and, in phase 1, the next group's row loads) are issued in front of them: 256 clocks of arithmetic cover both latencies. Why in this order: scalar loads
+    // return out of order, so while one is outstanding every LDS wait the compiler emits is lgkmcnt(0) - it would also drain the reads issued for the next phase. Here
+    // the only wait behind the s_loads is the one at the start of phase 2, 256 clocks later, when they and the phase's reads have long returned.
+    f32x4 y0[4], y1[4];
+    auto lds4 = [&](f32x4* yg, int kb) {   // features kb .. kb + 3 (kb % 4 == 0: one swizzle)
+      const int sw = ((kb >> 2) & 7) << 2;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) yg[u] = *reinterpret_cast<const f32x4*>(&Ys[(size_t)(kb + u) * GSX_COLS + ((4 * lane) ^ sw)]);
+    };
+#define GSX_FMA4(X8, U0, YG)                                                                                           \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                     \
+      const f32x2 y01 = {YG[u][0], YG[u][1]}, y23 = {YG[u][2], YG[u][3]};                                               \
+      _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                                   \
+        const float xs = X8[a][(U0) + u];                                                                               \
+        const f32x2 xa = {xs, xs};                                                                                      \
+        const f32x2 d0 = xa - y01, d1 = xa - y23;                                                                       \
+        acc2[a][0] = __builtin_elementwise_fma(d0, d0, acc2[a][0]);                                                     \
+        acc2[a][1] = __builtin_elementwise_fma(d1, d1, acc2[a][1]);                                                     \
+      }                                                                                                                 \
+    }
+    lds4(y0, 0);
+#pragma unroll 1
+    for (int k0 = 0; k0 < D; k0 += 8) {
+      // (register pin: phase 1's operands have landed - the reads were issued a phase ago - BEFORE the scalar loads go out; behind them the wait would be lgkmcnt(0))
+      asm volatile("" :: "v"(y0[0]), "v"(y0[1]), "v"(y0[2]), "v"(y0[3]));
+      __builtin_amdgcn_sched_barrier(0);
+      xload(xn, min(k0 + 8, D - 8));   // the next group's rows (the last trip re-reads its own, discarded)
+      lds4(y1, k0 + 4);
+      __builtin_amdgcn_sched_barrier(0);
+      GSX_FMA4(xr, 0, y0)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" :: "v"(y1[0]), "v"(y1[1]), "v"(y1[2]), "v"(y1[3]));   // (phase 2's operands and the scalar loads, both issued 256 clocks ago, before the next reads go out)
+      __builtin_amdgcn_sched_barrier(0);
+      lds4(y0, min(k0 + 8, D - 4));
+      __builtin_amdgcn_sched_barrier(0);
+      GSX_FMA4(xr, 4, y1)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xr[a] = xn[a];
+    }
+#undef GSX_FMA4
+  }
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { acc[a][0] = acc2[a][0][0]; acc[a][1] = acc2[a][0][1]; acc[a][2] = acc2[a][1][0]; acc[a][3] = acc2[a][1][1]; }
+  const float fD = (float)D;
+  const int row0 = it * GSX_ROWS + wave * 4;
+  if (MODE == 1) {
+    const int n2e = vs_self ? n1 : n2;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = row0 + a, j = jt4 * GSX_COLS + lane * 4 + b;
+        if (i < n1 && j < n2e) dist_out[(size_t)i * n2e + j] = acc[a][b] / fD;
+      }
+    IL_ST_END(IL_ST_GMMIL);
+    return;
+  }
+  sx = block_sum(sx, red);
+  sy = vs_self ? sx : block_sum(sy, red);
+  f32x4 wv;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { const int j = jt4 * GSX_COLS + lane * 4 + b; wv[b] = j < ny ? yb.weights[(size_t)j * yb.ld_weights] / sy : 0.f; }
+  const int q = jt4 * 4 + (lane >> 4);   // this 16-lane group's 64-column tile
+  float* part = ws_ + w.part + ((size_t)mat * w.njt + q) * w.b1p + row0;
+  const bool tile_exists = q * GT < npy;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float s = 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { const float dd = acc[a][b] / fD; s += wv[b] * (expf(-g1 * dd) + expf(-g2 * dd)); }
+    s = group16_sum(s);
+    if ((lane & 15) == 0 && tile_exists) wstore1(part, a, s);   // written through: the row tile's last arriver reads it below the caches
+  }
+  if (!out_r) { IL_ST_END(IL_ST_GMMIL); return; }
+  unsigned* lastp = reinterpret_cast<unsigned*>(red + 32);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned expect = (unsigned)((w.b2p + GSX_COLS - 1) / GSX_COLS + (w.b1p + GSX_COLS - 1) / GSX_COLS);
+    unsigned* ctr = reinterpret_cast<unsigned*>(ws_ + w.ctr) + it * GCTR;
+    const unsigned last = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == expect;
+    if (last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next call
+    *lastp = last;
+  }
+  __syncthreads();
+  const bool last = *lastp != 0u;
+  const int i = it * GSX_ROWS + tid;
+  if (last && tid < GSX_ROWS && i < n1) {
+    auto ordered_sum = [&](const float* p, int nq) {
+      float s = 0.f;
+      for (int q0 = 0; q0 < nq; q0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = sload1(p, (int64_t)min(q0 + u, nq - 1) * w.b1p + i);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (q0 + u < nq) s += v[u];
+      }
+      return s;
+    };
+    const float s0 = ordered_sum(ws_ + w.part, w.b2p / GT);
+    const float s1 = ordered_sum(ws_ + w.part + (size_t)w.njt * w.b1p, w.b1p / GT);
+    const float wi = pol.weights[(size_t)i * pol.ld_weights] / sx;
+    const float sim = wi * s0, self = wi * s1;
+    out_r[i] = sim - self;
+    if (out_sim) out_sim[i] = sim;
+    if (out_self) out_self[i] = self;
+  }
+  IL_ST_END(IL_ST_GMMIL);
+}
+static int gmmil_sx_on(int S, int A, int D, int state_only, int lanes) {   // IL_GMMIL_SX=0: k_gmmil_resident (developer A/B; same bits)
+  static const int on = [] { const char* e = getenv("IL_GMMIL_SX"); return e && e[0] == '0' ? 0 : 1; }();
+  return on != 0 && lanes && D >= 8 && D % 8 == 0 && S % 8 == 0 && gmmil_sx_lds(D) <= (size_t)160 * 1024 && D <= 5 * GKC;
+}
 static bool gmmil_direct() { static const int on = [] { const char* e = getenv("IL_GMMIL_DIRECT"); return e && e[0] == '0' ? 0 : 1; }(); return on != 0; }   // IL_GMMIL_DIRECT=0: k_gmmil_pack + k_gmmil_tile (developer A/B; same bits)
 static int gmmil_lanes(const il_batch* a, const il_batch* b, int S, int A, int state_only) {   // whole 16-byte lanes along the rows of both batches?
   auto ok = [&](const il_batch* x) {
@@ -624,6 +823,14 @@ extern "C" int il_gmmil_reward(const il_batch* pol, const il_batch* exp, int32_t
   const GmmilWs w = gmmil_ws(pol->n, exp->n, D);
   if (workspace_floats < w.total) return il_set_error(IL_ERR_WORKSPACE, "il_gmmil_reward: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)w.total);
   hipStream_t st = (hipStream_t)stream_;
+  if (gmmil_direct() && gmmil_sx_on(S, A, D, state_only, gmmil_lanes(pol, exp, S, A, state_only))) {
+    const size_t lds = gmmil_sx_lds(D);
+    if (int rc = gmmil_ensure_lds(k_gmmil_sx<0>, lds)) return rc;
+    IL_TRACE("k_gmmil_tile", st);
+    k_gmmil_sx<0><<<dim3(w.b1p / GSX_ROWS, (w.njt * GT + GSX_COLS - 1) / GSX_COLS, 2), 512, lds, st>>>(*pol, *exp, S, D, g1, g2, workspace, nullptr, 0, out_rewards, out_sim, out_self);
+    IL_CHECK_LAUNCH("il_gmmil_reward");
+    return IL_OK;
+  }
   if (gmmil_direct() && gmmil_resident_on(D)) {
     const size_t lds = gmmil_resident_lds(D);
     if (int rc = gmmil_ensure_lds(k_gmmil_resident<0>, lds)) return rc;
@@ -654,6 +861,14 @@ extern "C" int il_gmmil_sqdist(const il_batch* a, const il_batch* b, int32_t S, 
   const GmmilWs w = gmmil_ws(a->n, b->n, D);
   if (workspace_floats < w.total) return il_set_error(IL_ERR_WORKSPACE, "il_gmmil_sqdist: workspace too small");
   hipStream_t st = (hipStream_t)stream_;
+  if (gmmil_direct() && gmmil_sx_on(S, A, D, state_only, gmmil_lanes(a, b, S, A, state_only))) {
+    const size_t lds = gmmil_sx_lds(D);
+    if (int rc = gmmil_ensure_lds(k_gmmil_sx<1>, lds)) return rc;
+    IL_TRACE("k_gmmil_tile", st);
+    k_gmmil_sx<1><<<dim3(w.b1p / GSX_ROWS, (w.b2p + GSX_COLS - 1) / GSX_COLS, 1), 512, lds, st>>>(*a, *b, S, D, 0.f, 0.f, workspace, out, 0, nullptr, nullptr, nullptr);
+    IL_CHECK_LAUNCH("il_gmmil_sqdist");
+    return IL_OK;
+  }
   if (gmmil_direct() && gmmil_resident_on(D)) {
     const size_t lds = gmmil_resident_lds(D);
     if (int rc = gmmil_ensure_lds(k_gmmil_resident<1>, lds)) return rc;

@@ -36,7 +36,7 @@ elif what == 'gmmil_rate':   # calls/s + the kernel's duration from its launch s
     rates.append(1000 / (time.perf_counter() - t0))
     st = _lib.kernel_stamps().get('k_gmmil_direct')
     if st: durs.append(st['duration_us'])
-  print(f"gmmil B=1024 Ant: {np.median(rates):.0f} calls/s, kernel (stamps, resident form only) {np.median(durs) if durs else float('nan'):.2f} us, digest {hashlib.sha256(r.cpu().numpy().tobytes()).hexdigest()[:12]}")
+  print(f"gmmil B=1024 Ant: {np.median(rates):.0f} calls/s, kernel (device stamps) {np.median(durs) if durs else float('nan'):.2f} us, digest {hashlib.sha256(r.cpu().numpy().tobytes()).hexdigest()[:12]}")
 elif what == 'pwil':
   import inputs as gi
   atoms, agent = gi.pwil_case(22, 25000, 24, 1100)

@@ -379,7 +379,7 @@ import imitation_learning_amd as il
 from imitation_learning_amd import training as T_
 from gpu_util import T, N, Cfg
 h = hashlib.sha256()
-for seed, (n1, n2, D), S in ((5, (1024, 1024, 120), 112), (6, (300, 200, 35), 29), (7, (64, 48, 24), 16), (8, (130, 257, 132), 124)):   # Ant at the timed size; ragged, rows that are not whole 16-byte lanes; small; D > 128
+for seed, (n1, n2, D), S in ((5, (1024, 1024, 120), 112), (6, (300, 200, 35), 29), (7, (64, 48, 24), 16), (8, (130, 257, 132), 124), (9, (130, 257, 128), 120), (10, (40, 700, 152), 144)):   # Ant at the timed size; ragged, rows that are not whole 16-byte lanes; small; D > 128; ragged with D % 8 == 0 (the scalar-row kernel: 2 column tiles of 256, the second nearly empty); its largest D
   X, E, w, we = gi.gmmil_case(seed, n1, n2, D, weighted=True)
   disc = il.GMMILDiscriminator(S, D - S, Cfg(state_only=False))
   disc.gamma_1, disc.gamma_2 = 0.37, 0.91
@@ -393,7 +393,8 @@ print('DIGEST', h.hexdigest())
 
 
 def test_gmmil_launch_forms_are_bit_identical(tmp_path):
-  """k_gmmil_resident (round 5: all features of both tiles resident in LDS, fence-free arrival), k_gmmil_direct (chunked ring) and k_gmmil_pack + k_gmmil_tile keep every
+  """k_gmmil_sx (round 5: the row operand in scalar registers, 32 x 256 pairs per workgroup), k_gmmil_resident (all features of both tiles resident in LDS, fence-free arrival),
+  k_gmmil_direct (chunked ring) and k_gmmil_pack + k_gmmil_tile keep every
   pair's accumulation order over the features, the 64-column partial sums and the tile-ordered final sums: the same bits for rewards, both similarities and the distance
   matrix, at the timed size, for ragged shapes, for rows that are not whole 16-byte lanes and for D > 128. (The switches are read once per process: one process per form.)"""
   import subprocess, sys
@@ -401,7 +402,7 @@ def test_gmmil_launch_forms_are_bit_identical(tmp_path):
   script.write_text(GMMIL_FORMS_WORKER)
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   digests = {}
-  for name, env in (('resident', {}), ('direct', dict(IL_GMMIL_RESIDENT='0')), ('pack+tile', dict(IL_GMMIL_DIRECT='0'))):
+  for name, env in (('scalar rows', {}), ('resident', dict(IL_GMMIL_SX='0')), ('direct', dict(IL_GMMIL_SX='0', IL_GMMIL_RESIDENT='0')), ('pack+tile', dict(IL_GMMIL_DIRECT='0'))):
     r = subprocess.run([sys.executable, str(script), root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     digests[name] = [l for l in r.stdout.splitlines() if l.startswith('DIGEST')][-1].split()[1]
