@@ -33,6 +33,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define GTR (16 * GMMIL_RB)
 #define GCTR 32   // floats between two arrival counters: same-line atomics from 8 XCDs serialise at the memory side
 
+// exp(-g1 d) + exp(-g2 d), d = ssq / D (models.py:25-33), for one pair from its sum of squared differences: 2^(ssq * c), c = -g * log2(e) / D folded into one scalar per
+// bandwidth (round 5). The straight form - an IEEE division, two expf() of the device library with their range reductions: ~50 instructions per pair - made the epilogue of a
+// tile as long as its feature loop (7.5 of 21 us, profiles/r05_gmmil_sx_timeline.txt); this is two multiplies and two v_exp_f32. Error: the exponent's argument carries two
+// roundings (|arg| 2^-23) and v_exp_f32 one ulp, so a term e^-x is off by <= (1.2e-7 x + 6e-8) e^-x <= 1e-7 absolute for every x >= 0: four decades inside the 1e-5 bound
+// the rewards are tested at (tests/test_timed_sizes.py, test_gpu_parity.py). Every launch form shares it: they stay bit-identical to each other.
+struct GmmilExp { float c1, c2; };
+__host__ __device__ inline GmmilExp gmmil_exp_consts(float g1, float g2, int D) { return GmmilExp{-g1 * 1.44269504088896340736f / (float)D, -g2 * 1.44269504088896340736f / (float)D}; }
+__device__ __forceinline__ float gmmil_pair_kernel(float ssq, const GmmilExp& e) { return __builtin_amdgcn_exp2f(ssq * e.c1) + __builtin_amdgcn_exp2f(ssq * e.c2); }
+
 struct GmmilWs { int64_t xt, et, wn, wen, part, ctr, total; int b1p, b2p, njt; };
 __host__ __device__ inline GmmilWs gmmil_ws(int n1, int n2, int D) {
   GmmilWs w; w.b1p = (n1 + GTR - 1) / GTR * GTR; w.b2p = (n2 + GT - 1) / GT * GT;   // policy rows: whole row tiles (GTR is a multiple of GT); padded rows / columns carry weight 0
@@ -180,6 +189,7 @@ __global__ __launch_bounds__(256) void k_gmmil_tile(int n1, int n2, int D, float
 #pragma unroll
   for (int a = 0; a < RB; ++a) { acc[a][0] = acc2[a][0][0]; acc[a][1] = acc2[a][0][1]; acc[a][2] = acc2[a][1][0]; acc[a][3] = acc2[a][1][1]; }
   const float fD = (float)D;
+  const GmmilExp gex = gmmil_exp_consts(g1, g2, D);
   if (MODE == 1) {
     const int n2e = vs_self ? n1 : n2;
 #pragma unroll
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(256) void k_gmmil_tile(int n1, int n2, int D, float
   for (int a = 0; a < RB; ++a) {
     float s = 0.f;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { const float dd = acc[a][b] / fD; s += wv[b] * (expf(-g1 * dd) + expf(-g2 * dd)); }
+    for (int b = 0; b < 4; ++b) s += wv[b] * gmmil_pair_kernel(acc[a][b], gex);
     s = group16_sum(s);
     if (tj == 0) part[ti * RB + a] = s;
   }
@@ -360,6 +370,7 @@ __global__ __launch_bounds__(256) void k_gmmil_direct(il_batch pol, il_batch exp
 #pragma unroll
   for (int a = 0; a < RB; ++a) { acc[a][0] = acc2[a][0][0]; acc[a][1] = acc2[a][0][1]; acc[a][2] = acc2[a][1][0]; acc[a][3] = acc2[a][1][1]; }
   const float fD = (float)D;
+  const GmmilExp gex = gmmil_exp_consts(g1, g2, D);
   if (MODE == 1) {
     const int n2e = vs_self ? n1 : n2;
 #pragma unroll
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(256) void k_gmmil_direct(il_batch pol, il_batch exp
   for (int a = 0; a < RB; ++a) {
     float s = 0.f;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { const float dd = acc[a][b] / fD; s += wv[b] * (expf(-g1 * dd) + expf(-g2 * dd)); }
+    for (int b = 0; b < 4; ++b) s += wv[b] * gmmil_pair_kernel(acc[a][b], gex);
     s = group16_sum(s);
     if (tj == 0) part[ti * RB + a] = s;
   }
@@ -531,6 +542,7 @@ __global__ __launch_bounds__(256) void k_gmmil_resident(il_batch pol, il_batch e
 #pragma unroll
   for (int a = 0; a < RB; ++a) { acc[a][0] = acc2[a][0][0]; acc[a][1] = acc2[a][0][1]; acc[a][2] = acc2[a][1][0]; acc[a][3] = acc2[a][1][1]; }
   const float fD = (float)D;
+  const GmmilExp gex = gmmil_exp_consts(g1, g2, D);
   if (MODE == 1) {
     const int n2e = vs_self ? n1 : n2;
 #pragma unroll
@@ -553,7 +565,7 @@ __global__ __launch_bounds__(256) void k_gmmil_resident(il_batch pol, il_batch e
   for (int a = 0; a < RB; ++a) {
     float s = 0.f;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { const float dd = acc[a][b] / fD; s += wv[b] * (expf(-g1 * dd) + expf(-g2 * dd)); }
+    for (int b = 0; b < 4; ++b) s += wv[b] * gmmil_pair_kernel(acc[a][b], gex);
     s = group16_sum(s);
     if (tj == 0) wstore1(part, ti * RB + a, s);   // written through: the row tile's last arriver reads it below the caches
   }
@@ -621,12 +633,13 @@ static int gmmil_ensure_lds(K fn, size_t bytes) {
 #define GSX_COLS 256
 #define AS4 __attribute__((address_space(4)))
 typedef float f32x8 __attribute__((ext_vector_type(8)));
-static size_t gmmil_sx_lds(int D) { return ((size_t)D * GSX_COLS + 64) * sizeof(float); }
+static size_t gmmil_sx_lds(int D) { return ((size_t)D * GSX_COLS + 64 + 4 * GSX_ROWS) * sizeof(float); }
 template <int MODE>
 __global__ __launch_bounds__(512) void k_gmmil_sx(il_batch pol, il_batch exp, int S, int D, float g1, float g2, float* __restrict__ ws_, float* __restrict__ dist_out, int self_second,
                                                   float* __restrict__ out_r, float* __restrict__ out_sim, float* __restrict__ out_self) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   IL_ST_BEGIN(IL_ST_GMMIL);
+  IL_TL(0, 0);
   float* Ys = smem;                          // [D][256], column c of feature k at (c ^ 4 ((k / 4) % 8))
   float* red = Ys + (size_t)D * GSX_COLS;    // [32] block_sum scratch, [32] = "last arriver" flag
   // (the row operand's base pointers as the kernel arguments carry them - scalar registers; globalize() launders the descriptors through vector registers)
@@ -647,6 +660,11 @@ __global__ __launch_bounds__(512) void k_gmmil_sx(il_batch pol, il_batch exp, in
   if (MODE == 0 && tid < 256) {
     for (int i = tid; i < n1; i += 256) sx += pol.weights[(size_t)i * pol.ld_weights];
     if (!vs_self) for (int i = tid; i < ny; i += 256) sy += yb.weights[(size_t)i * yb.ld_weights];
+  }
+  f32x4 wv = {0.f, 0.f, 0.f, 0.f};   // this lane's four column weights, requested with everything else (normalised once the sums are known)
+  if (MODE == 0) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { const int j = jt4 * GSX_COLS + lane * 4 + b; wv[b] = j < ny ? yb.weights[(size_t)j * yb.ld_weights] : 0.f; }
   }
   // the 256 columns' features: every 16-byte lane requested before anything is consumed (chunks of 32 features = 8 lanes along a row, 4 lanes per thread and chunk)
   constexpr int NCH = 5, PY4 = GKC * GSX_COLS / 4 / 512;
@@ -684,58 +702,75 @@ __global__ __launch_bounds__(512) void k_gmmil_sx(il_batch pol, il_batch exp, in
       }
     }
   }
+  IL_TL(0, 1);
+  if (MODE == 0) {   // block_sum's arithmetic (wave sums, then the waves' partials in wave order) with its barrier folded into the one the operands need
+    sx = wave_sum(sx);
+    if (!vs_self) sy = wave_sum(sy);
+    if (lane == 0) { red[wave] = sx; red[8 + wave] = sy; }
+  }
   __syncthreads();
+  if (MODE == 0) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s0 += red[i]; s1 += red[8 + i]; }
+    sx = s0; sy = vs_self ? s0 : s1;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { const int j = jt4 * GSX_COLS + lane * 4 + b; wv[b] = j < ny ? wv[b] / sy : 0.f; }
+  }
+  IL_TL(0, 2); IL_TLC(1, 2);
   f32x2 acc2[4][2];
 #pragma unroll
   for (int a = 0; a < 4; ++a) { acc2[a][0] = f32x2{0.f, 0.f}; acc2[a][1] = f32x2{0.f, 0.f}; }
   {
-    // Two phases of four features per group of eight. The column operands of a phase are in registers before its 64 packed instructions start, the reads of the NEXT
-    // phase (and, in phase 1, the next group's row loads) are issued in front of them: 256 clocks of arithmetic cover both latencies. Why in this order: scalar loads
-    // return out of order, so while one is outstanding every LDS wait the compiler emits is lgkmcnt(0) - it would also drain the reads issued for the next phase. Here
-    // the only wait behind the s_loads is the one at the start of phase 2, 256 clocks later, when they and the phase's reads have long returned.
-    f32x4 y0[4], y1[4];
-    auto lds4 = [&](f32x4* yg, int kb) {   // features kb .. kb + 3 (kb % 4 == 0: one swizzle)
-      const int sw = ((kb >> 2) & 7) << 2;
+    // One phase per group of eight features: its column operands (8 ds_read_b128) and row operands (4 s_load_dwordx8) are requested a whole phase - 128 packed
+    // instructions, 512 clocks of this wave's issue - ahead and pinned in registers before the phase starts. Why so far ahead: the rows are streamed once, so every scalar
+    // load misses the scalar cache and comes from L2 (~600 clocks); and scalar loads return out of order, so while one is outstanding every LDS wait the compiler emits
+    // is lgkmcnt(0) - the only wait of a phase therefore sits at its start, behind requests that are a phase old. (Round-5 timeline with phases of four features: the
+    // second wave of each SIMD finished 4.5 us after the first: alone on the SIMD it issued a packed instruction every 15 clocks, stalled on these loads.)
+    f32x4 y0[8], y1[8];
+    auto lds8 = [&](f32x4* yg, int kb) {   // features kb .. kb + 7 (kb % 8 == 0: two swizzle groups)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) yg[u] = *reinterpret_cast<const f32x4*>(&Ys[(size_t)(kb + u) * GSX_COLS + ((4 * lane) ^ sw)]);
+      for (int u = 0; u < 8; ++u) { const int sw = (((kb + u) >> 2) & 7) << 2; yg[u] = *reinterpret_cast<const f32x4*>(&Ys[(size_t)(kb + u) * GSX_COLS + ((4 * lane) ^ sw)]); }
     };
-#define GSX_FMA4(X8, U0, YG)                                                                                           \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                     \
+#define GSX_FMA8(X8, YG)                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                                     \
       const f32x2 y01 = {YG[u][0], YG[u][1]}, y23 = {YG[u][2], YG[u][3]};                                               \
       _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                                   \
-        const float xs = X8[a][(U0) + u];                                                                               \
+        const float xs = X8[a][u];   /* (a v_mov into a vector register first: measured slower, 13.7 vs 12.1 us for the loop) */               \
         const f32x2 xa = {xs, xs};                                                                                      \
         const f32x2 d0 = xa - y01, d1 = xa - y23;                                                                       \
         acc2[a][0] = __builtin_elementwise_fma(d0, d0, acc2[a][0]);                                                     \
         acc2[a][1] = __builtin_elementwise_fma(d1, d1, acc2[a][1]);                                                     \
       }                                                                                                                 \
     }
-    lds4(y0, 0);
+    lds8(y0, 0);
 #pragma unroll 1
-    for (int k0 = 0; k0 < D; k0 += 8) {
-      // (register pin: phase 1's operands have landed - the reads were issued a phase ago - BEFORE the scalar loads go out; behind them the wait would be lgkmcnt(0))
-      asm volatile("" :: "v"(y0[0]), "v"(y0[1]), "v"(y0[2]), "v"(y0[3]));
+    for (int k0 = 0; k0 < D; k0 += 16) {
+      // (register pins: a phase's operands have landed BEFORE the next requests go out - behind them the wait would also drain those)
+      asm volatile("" :: "v"(y0[0]), "v"(y0[1]), "v"(y0[2]), "v"(y0[3]), "v"(y0[4]), "v"(y0[5]), "v"(y0[6]), "v"(y0[7]));
       __builtin_amdgcn_sched_barrier(0);
-      xload(xn, min(k0 + 8, D - 8));   // the next group's rows (the last trip re-reads its own, discarded)
-      lds4(y1, k0 + 4);
+      xload(xn, min(k0 + 8, D - 8));
+      lds8(y1, min(k0 + 8, D - 8));
       __builtin_amdgcn_sched_barrier(0);
-      GSX_FMA4(xr, 0, y0)
+      GSX_FMA8(xr, y0)
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("" :: "v"(y1[0]), "v"(y1[1]), "v"(y1[2]), "v"(y1[3]));   // (phase 2's operands and the scalar loads, both issued 256 clocks ago, before the next reads go out)
+      if (k0 + 8 >= D) break;   // (D / 8 odd: the second phase of the last trip does not exist)
+      asm volatile("" :: "v"(y1[0]), "v"(y1[1]), "v"(y1[2]), "v"(y1[3]), "v"(y1[4]), "v"(y1[5]), "v"(y1[6]), "v"(y1[7]));
       __builtin_amdgcn_sched_barrier(0);
-      lds4(y0, min(k0 + 8, D - 4));
+      xload(xr, min(k0 + 16, D - 8));
+      lds8(y0, min(k0 + 16, D - 8));
       __builtin_amdgcn_sched_barrier(0);
-      GSX_FMA4(xr, 4, y1)
+      GSX_FMA8(xn, y1)
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) xr[a] = xn[a];
     }
-#undef GSX_FMA4
+#undef GSX_FMA8
   }
+  IL_TL(0, 3); IL_TLC(1, 3);
   float acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a) { acc[a][0] = acc2[a][0][0]; acc[a][1] = acc2[a][0][1]; acc[a][2] = acc2[a][1][0]; acc[a][3] = acc2[a][1][1]; }
   const float fD = (float)D;
+  const GmmilExp gex = gmmil_exp_consts(g1, g2, D);
   const int row0 = it * GSX_ROWS + wave * 4;
   if (MODE == 1) {
     const int n2e = vs_self ? n1 : n2;
@@ -749,26 +784,34 @@ __global__ __launch_bounds__(512) void k_gmmil_sx(il_batch pol, il_batch exp, in
     IL_ST_END(IL_ST_GMMIL);
     return;
   }
-  sx = block_sum(sx, red);
-  sy = vs_self ? sx : block_sum(sy, red);
-  f32x4 wv;
-#pragma unroll
-  for (int b = 0; b < 4; ++b) { const int j = jt4 * GSX_COLS + lane * 4 + b; wv[b] = j < ny ? yb.weights[(size_t)j * yb.ld_weights] / sy : 0.f; }
-  const int q = jt4 * 4 + (lane >> 4);   // this 16-lane group's 64-column tile
-  float* part = ws_ + w.part + ((size_t)mat * w.njt + q) * w.b1p + row0;
-  const bool tile_exists = q * GT < npy;
+  // The workgroup's 32 rows x 4 column tiles of partial row sums are collected in LDS and handed over by one wave (below).
+  float* ps = red + 64;   // [4 tiles][32 rows]
+  const int g16 = lane >> 4;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     float s = 0.f;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { const float dd = acc[a][b] / fD; s += wv[b] * (expf(-g1 * dd) + expf(-g2 * dd)); }
+    for (int b = 0; b < 4; ++b) s += wv[b] * gmmil_pair_kernel(acc[a][b], gex);
     s = group16_sum(s);
-    if ((lane & 15) == 0 && tile_exists) wstore1(part, a, s);   // written through: the row tile's last arriver reads it below the caches
+    if ((lane & 15) == 0) ps[g16 * GSX_ROWS + wave * 4 + a] = s;
+  }
+  IL_TL(0, 4);
+  __syncthreads();
+  IL_TL(0, 5);
+  if (tid < 64) {   // 4 tiles x 16 pairs of floats, handed over as agent-scope atomic exchanges: they execute at the memory side like the arrival ticket (0.5 us there and
+    // back on the timeline), where write-through stores of the same 512 bytes took 4.8 us to drain - per workgroup, with 256 workgroups arriving together
+    const int tl = tid >> 4, l16 = tid & 15, q = jt4 * 4 + tl;
+    if (q * GT < npy) {
+      const unsigned long long v = *reinterpret_cast<const unsigned long long*>(ps + tl * GSX_ROWS + 2 * l16);
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(ws_ + w.part + (((int64_t)mat * w.njt + q) * w.b1p + it * GSX_ROWS + 2 * l16));
+      (void)__hip_atomic_exchange(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if (!out_r) { IL_ST_END(IL_ST_GMMIL); return; }
   unsigned* lastp = reinterpret_cast<unsigned*>(red + 32);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  IL_TL(0, 6);
   if (tid == 0) {
     const unsigned expect = (unsigned)((w.b2p + GSX_COLS - 1) / GSX_COLS + (w.b1p + GSX_COLS - 1) / GSX_COLS);
     unsigned* ctr = reinterpret_cast<unsigned*>(ws_ + w.ctr) + it * GCTR;
@@ -777,6 +820,7 @@ __global__ __launch_bounds__(512) void k_gmmil_sx(il_batch pol, il_batch exp, in
     *lastp = last;
   }
   __syncthreads();
+  IL_TL(0, 7);
   const bool last = *lastp != 0u;
   const int i = it * GSX_ROWS + tid;
   if (last && tid < GSX_ROWS && i < n1) {
@@ -891,3 +935,4 @@ extern "C" int il_gmmil_sqdist(const il_batch* a, const il_batch* b, int32_t S, 
 
 IL_STAMP_READER(il_debug_stamps_gmmil)
 IL_ST_READER(il_stamps_gmmil)
+IL_TL_READER(il_debug_timeline_gmmil)

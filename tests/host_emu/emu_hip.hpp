@@ -68,6 +68,7 @@ inline float __fsqrt_rn(float a) { return sqrtf(a); }
 template <class T> inline T __hip_atomic_fetch_add(T* p, T v, int, int) { const T old = *p; *p = old + v; return old; }
 template <class T> inline T __hip_atomic_load(const T* p, int, int) { return *p; }
 template <class T> inline void __hip_atomic_store(T* p, T v, int, int) { *p = v; }
+template <class T> inline T __hip_atomic_exchange(T* p, T v, int, int) { const T old = *p; *p = v; return old; }
 template <class V> inline V emu_elementwise_fma(V a, V b, V c) { V r = c; for (unsigned i = 0; i < sizeof(V) / sizeof(float); ++i) r[i] = fmaf(a[i], b[i], c[i]); return r; }
 #define __builtin_elementwise_fma emu_elementwise_fma
 
@@ -477,6 +478,7 @@ inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x);
 inline int __ffs(unsigned x) { return __builtin_ffs((int)x); }
 inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }   // v_exp_f32 (the device's is within 1 ulp and flushes denormal results)
 inline void __threadfence() {}
 inline void __threadfence_system() {}
 inline void __threadfence_block() {}
