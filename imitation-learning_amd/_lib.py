@@ -128,6 +128,7 @@ _SIGNATURES = {
     'il_trace_enable': (C.c_int, [C.c_int]),
     'il_trace_report': (C.c_int, [C.c_char_p, C.c_int]),
     'il_kernel_stamp_ids': (C.c_int32, []), 'il_kernel_stamps': (C.c_int, [C.POINTER(C.c_uint64)]), 'il_kernel_stamps_clear': (C.c_int, []),
+    'il_kernel_stamp_workgroups': (C.c_int32, []), 'il_kernel_stamp_rows': (C.c_int, [C.c_int32, C.POINTER(C.c_uint64)]),
     'il_ring_row_floats': (C.c_int32, [C.c_int32, C.c_int32]),
     'il_replay_write_rows': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int64, _P, C.c_int32, _P]),
     'il_replay_wrap_absorbing': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P]),
@@ -269,6 +270,16 @@ def kernel_stamps(handle=None) -> dict:
     if wgs:
       out[STAMP_KERNELS[k]] = dict(begin_us=b0 / 100.0, last_begin_us=b1 / 100.0, first_end_us=e0 / 100.0, end_us=e1 / 100.0, duration_us=(e1 - b0) / 100.0, workgroups=wgs)
   return out
+
+
+def kernel_stamp_rows(kernel: str, handle=None):
+  """Per-workgroup stamps of the last launch of `kernel` (a STAMP_KERNELS name): list of (begin_us, end_us, placement) for the stamped workgroups; placement =
+  XCC_ID << 16 | SE / SH / CU byte (one value per physical CU)."""
+  L = handle or lib()
+  n = int(L.il_kernel_stamp_workgroups())
+  buf = (C.c_uint64 * (4 * n))()
+  check(L.il_kernel_stamp_rows(STAMP_KERNELS.index(kernel), buf))
+  return [(int(buf[4 * w]) / 100.0, int(buf[4 * w + 1]) / 100.0, int(buf[4 * w + 2])) for w in range(n) if buf[4 * w] and buf[4 * w + 1]]
 
 
 def check(rc: int):

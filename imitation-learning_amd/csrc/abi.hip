@@ -135,7 +135,7 @@ extern "C" int il_kernel_stamps(uint64_t* out_host) {
   IL_CHECK_ARG(out_host, "il_kernel_stamps: null argument");
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) return il_set_error(IL_ERR_HIP, "il_kernel_stamps: %s", hipGetErrorString(e));
-  typedef unsigned long long table_t[IL_ST_K][IL_ST_WGS][2];
+  typedef unsigned long long table_t[IL_ST_K][IL_ST_WGS][4];
   static table_t tb;
   memset(out_host, 0, sizeof(uint64_t) * IL_ST_K * 5);
   struct Src { int (*read)(unsigned long long*); int first, last; };
@@ -156,6 +156,19 @@ extern "C" int il_kernel_stamps(uint64_t* out_host) {
       }
     }
   }
+  return IL_OK;
+}
+// the raw rows of one kernel id: out_host [IL_ST_WGS][4] = {begin, end, placement (XCC_ID << 16 | SE / SH / CU byte of HW_ID), 0} per workgroup of the last launch (zeros: not stamped)
+extern "C" int32_t il_kernel_stamp_workgroups(void) { return IL_ST_WGS; }
+extern "C" int il_kernel_stamp_rows(int32_t kid, uint64_t* out_host) {
+  IL_CHECK_ARG(out_host && kid >= 0 && kid < IL_ST_K, "il_kernel_stamp_rows: bad arguments");
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return il_set_error(IL_ERR_HIP, "il_kernel_stamp_rows: %s", hipGetErrorString(e));
+  typedef unsigned long long table_t[IL_ST_K][IL_ST_WGS][4];
+  static table_t tb;
+  int (*read)(unsigned long long*) = kid <= IL_ST_GAIL_REDUCE ? il_stamps_gail : (kid <= IL_ST_DW_ACTOR ? il_stamps_sac : il_stamps_gmmil);
+  if (read(&tb[0][0][0]) != 0) return il_set_error(IL_ERR_HIP, "il_kernel_stamp_rows: reading a stamp table failed");
+  memcpy(out_host, &tb[kid][0][0], sizeof(unsigned long long) * IL_ST_WGS * 4);
   return IL_OK;
 }
 extern "C" int il_kernel_stamps_clear(void) {

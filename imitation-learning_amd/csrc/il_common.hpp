@@ -336,17 +336,20 @@ static __device__ unsigned long long il_tl[IL_TL_K][IL_TL_WGS][IL_TL_SLOTS];
 // Always-on launch stamps of the headline schedule's kernels (il_kernel_stamps, include/il_hip.h): thread 0 of every workgroup stores s_memrealtime (the 100 MHz
 // device-wide counter) when it starts and after its last wave has finished - two 8-byte fire-and-forget stores per workgroup into a table of this translation unit,
 // overwritten by every launch. After a run of graph replays the host reads, per kernel, min(begin) and max(end) over the workgroups of the LAST launch: the kernel's
-// duration inside the timed schedule itself (bench.py builds `roofline` from these; no HIP events, no eager re-run). One kernel id per launch of an update.
+// duration inside the timed schedule itself (bench.py builds `roofline` from these; no HIP events, no eager re-run). One kernel id per launch of an update. The begin stamp also
+// records WHERE the workgroup runs (XCD, shader engine / array, CU): tests assert from it that no workgroup of the side stream shares a CU with a pair-mode workgroup.
 // ---------------------------------------------------------------------------------------------
 enum { IL_ST_GAIL_GRAD = 0, IL_ST_GAIL_REDUCE = 1, IL_ST_CHAIN = 2, IL_ST_DW_CRITIC = 3, IL_ST_POLICY_CRITIC = 4, IL_ST_DW_ACTOR = 5, IL_ST_GMMIL = 6, IL_ST_PWIL = 7, IL_ST_K = 8 };
 #define IL_ST_WGS 512
-#define IL_ST_TABLE static __device__ unsigned long long il_st[IL_ST_K][IL_ST_WGS][2];
-#define IL_ST_MARK(kid, slot) do { const unsigned st_w = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); if (threadIdx.x == 0 && st_w < IL_ST_WGS) il_st[kid][st_w][slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define IL_ST_BEGIN(kid) IL_ST_MARK(kid, 0)
-#define IL_ST_END(kid) do { __syncthreads(); IL_ST_MARK(kid, 1); } while (0)   // every thread of the workgroup passes here (bodies return, never s_endpgm): a workgroup's end = its last wave's
-// out_host [IL_ST_K][IL_ST_WGS][2]: only the rows of the kernel ids this translation unit owns are meaningful
+#define IL_ST_TABLE static __device__ unsigned long long il_st[IL_ST_K][IL_ST_WGS][4];   // {begin, end, placement, 0}: placement = XCC_ID << 16 | HW_ID[15:8] (SE / SH / CU of the workgroup's first wave)
+__device__ __forceinline__ unsigned il_st_xcc() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 0xfu; }
+__device__ __forceinline__ unsigned il_st_hwid() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v)); return v; }
+#define IL_ST_INDEX (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z))
+#define IL_ST_BEGIN(kid) do { const unsigned st_w = IL_ST_INDEX; if (threadIdx.x == 0 && st_w < IL_ST_WGS) { il_st[kid][st_w][0] = __builtin_amdgcn_s_memrealtime(); il_st[kid][st_w][2] = ((unsigned long long)il_st_xcc() << 16) | ((il_st_hwid() >> 8) & 0xffu); } } while (0)
+#define IL_ST_END(kid) do { __syncthreads(); const unsigned st_w = IL_ST_INDEX; if (threadIdx.x == 0 && st_w < IL_ST_WGS) il_st[kid][st_w][1] = __builtin_amdgcn_s_memrealtime(); } while (0)   // every thread of the workgroup passes here (bodies return, never s_endpgm): a workgroup's end = its last wave's
+// out_host [IL_ST_K][IL_ST_WGS][4]: only the rows of the kernel ids this translation unit owns are meaningful
 #define IL_ST_READER(name) extern "C" int name(unsigned long long* out_host) { return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(il_st), sizeof(il_st)) == hipSuccess ? 0 : 3; } \
-                           extern "C" int name##_clear() { static unsigned long long z[IL_ST_K][IL_ST_WGS][2]; return hipMemcpyToSymbol(HIP_SYMBOL(il_st), z, sizeof(z)) == hipSuccess ? 0 : 3; }
+                           extern "C" int name##_clear() { static unsigned long long z[IL_ST_K][IL_ST_WGS][4]; return hipMemcpyToSymbol(HIP_SYMBOL(il_st), z, sizeof(z)) == hipSuccess ? 0 : 3; }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

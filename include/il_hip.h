@@ -65,6 +65,10 @@ enum { IL_STAMP_GAIL_GRAD = 0, IL_STAMP_GAIL_REDUCE = 1, IL_STAMP_CHAIN = 2, IL_
 int32_t il_kernel_stamp_ids(void);
 int il_kernel_stamps(uint64_t* out_host);
 int il_kernel_stamps_clear(void);
+/* the raw rows of one kernel id: out_host [il_kernel_stamp_workgroups()][4] = {begin, end, placement, 0} per workgroup of the last launch; placement = XCC_ID << 16 | the
+ * shader-engine / shader-array / CU byte of HW_ID: tests assert from it that side-stream workgroups never share a CU with a pair-mode workgroup */
+int32_t il_kernel_stamp_workgroups(void);
+int il_kernel_stamp_rows(int32_t kernel_id, uint64_t* out_host);
 
 /* The on-chip noise of the update kernels as a function: out[i] = draw #i of noise stream `stream_id` at update counter `ctr` under key `noise_seed`,
  * evaluated by the same device functions the kernels call when their eps pointer is NULL (Philox4x32-10 keyed by noise_seed, counter words

@@ -72,6 +72,7 @@ def translate(src: str) -> str:
   src = re.sub(r'asm volatile\(""[^;]*\);', '', src)
   src = re.sub(r'asm volatile\("s_waitcnt [^"]*"[^;]*\);', '', src)
   src = re.sub(r'asm volatile\("s_getreg_b32 %0, hwreg\(HW_REG_XCC_ID\)" : "=s"\((\w+)\)\);', r'\1 = emu::xcc_id();', src)   # which XCD: the block's linear id mod 8, as observed on the device
+  src = re.sub(r'asm volatile\("s_getreg_b32 %0, hwreg\(HW_REG_HW_ID\)" : "=s"\((\w+)\)\);', r'\1 = ((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >> 3 & 31u) << 8;', src)   # CU within the XCD: workgroups are dealt round-robin to the XCDs, then to their CUs
   assert 'asm volatile' not in src, 'an inline-assembly statement the emulator does not know'
   src = _SHARED.sub(_shared_decl, src)
   assert '__shared__' not in re.sub(r'//[^\n]*', '', src), 'a static __shared__ declaration the translation did not recognise'

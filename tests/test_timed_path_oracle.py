@@ -260,6 +260,36 @@ def test_direct_launches_equal_the_graph_replays(K=6, seed=9):
     np.testing.assert_array_equal(a, b)
 
 
+def test_side_stream_workgroups_never_share_a_cu_with_a_pair_workgroup():
+  """DESIGN.md 3.2 "whole-CU LDS": the pair-mode kernels ask for 160 KB of LDS and k_gail_reduce for 1 KB it never touches so that the dispatcher cannot co-locate a
+  workgroup of the discriminator branch with a pair workgroup (whose weight stream its loads would queue behind: the first pair build LOST 4 % to exactly that). The
+  launch stamps record where every workgroup ran (XCD, shader engine / array, CU) and when: in the timed schedule no k_gail_grad / k_gail_reduce workgroup overlaps in
+  time with a k_sac_chain_pair workgroup on the same CU, and the pair kernels' workgroups have a CU each."""
+  il_training._NOISE.clear(); il_training._WS.clear()
+  plan, nets, _ = bench.build(torch.device(DEV), 0, seed=21)
+  for _ in range(5): plan.run()
+  torch.cuda.synchronize()
+  plan.record_direct()
+  _lib.check(_lib.lib().il_kernel_stamps_clear())
+  for burst in range(5):   # five readings of the last update of a burst of back-to-back updates
+    for _ in range(100): plan.launch_direct()
+    torch.cuda.synchronize()
+    rows = {k: _lib.kernel_stamp_rows(k) for k in ('k_sac_chain_pair', 'k_policy_critic_pair', 'k_gail_grad', 'k_gail_reduce')}
+    chain, pc = rows['k_sac_chain_pair'], rows['k_policy_critic_pair']
+    assert len(chain) >= 10 * (256 // 16) and len(pc) >= 4 * (256 // 16)
+    assert len({p for _, _, p in chain}) == len(chain), 'two workgroups of k_sac_chain_pair on one CU: the 160 KB LDS request no longer reserves whole CUs'
+    assert len({p for _, _, p in pc}) == len(pc)
+    overlapped = 0
+    for side in ('k_gail_grad', 'k_gail_reduce'):
+      for b2, e2, p2 in rows[side]:
+        for b, e, p in chain:
+          if p == p2 and b < e2 and b2 < e:
+            raise AssertionError(f'{side} workgroup on CU {p:#x} during [{b2:.2f}, {e2:.2f}] us overlaps a k_sac_chain_pair workgroup there during [{b:.2f}, {e:.2f}] us')
+          overlapped += int(b < e2 and b2 < e)
+    assert overlapped > 0, 'the discriminator branch must overlap the forward / critic-loss launch in time (otherwise this test asserts nothing)'
+  assert plan.sync_timeouts() == 0
+
+
 # ------------------------------------------------------------------------------------------------ f1: the population launches
 def test_batched_population_replays_through_the_oracle():
   Lp, K = 3, 6
