@@ -128,6 +128,7 @@ _SIGNATURES = {
     'il_trace_enable': (C.c_int, [C.c_int]),
     'il_trace_report': (C.c_int, [C.c_char_p, C.c_int]),
     'il_kernel_stamp_ids': (C.c_int32, []), 'il_kernel_stamps': (C.c_int, [C.POINTER(C.c_uint64)]), 'il_kernel_stamps_clear': (C.c_int, []),
+    'il_stream_create_cu_mask': (C.c_int, [C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_void_p)]), 'il_stream_destroy': (C.c_int, [_P]),
     'il_kernel_stamp_workgroups': (C.c_int32, []), 'il_kernel_stamp_rows': (C.c_int, [C.c_int32, C.POINTER(C.c_uint64)]),
     'il_ring_row_floats': (C.c_int32, [C.c_int32, C.c_int32]),
     'il_replay_write_rows': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int64, _P, C.c_int32, _P]),

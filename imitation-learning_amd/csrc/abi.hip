@@ -177,6 +177,23 @@ extern "C" int il_kernel_stamps_clear(void) {
   return (il_stamps_gail_clear() == 0 && il_stamps_sac_clear() == 0 && il_stamps_gmmil_clear() == 0) ? IL_OK : il_set_error(IL_ERR_HIP, "il_kernel_stamps_clear: clearing a stamp table failed");
 }
 
+// A stream whose kernels may only run on the CUs of `mask` (hipExtStreamCreateWithCUMask; bit i = CU i in the runtime's enumeration: on a multi-XCD part the bits are
+// dealt round-robin to the XCDs). Experiment of round 5: the discriminator branch on CUs of its own instead of the whole-CU LDS requests that keep its
+// workgroups off the pair-mode workgroups' CUs. Not used by default.
+extern "C" int il_stream_create_cu_mask(const uint32_t* mask_host, int32_t words, void** stream_out) {
+  IL_CHECK_ARG(mask_host && words > 0 && stream_out, "il_stream_create_cu_mask: bad arguments");
+  hipStream_t s = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask_host);
+  if (e != hipSuccess) return il_set_error(IL_ERR_HIP, "hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+  *stream_out = (void*)s;
+  return IL_OK;
+}
+extern "C" int il_stream_destroy(void* stream) {
+  if (!stream) return IL_OK;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  return e == hipSuccess ? IL_OK : il_set_error(IL_ERR_HIP, "hipStreamDestroy: %s", hipGetErrorString(e));
+}
+
 // sizeof() of the descriptor structs as this library was compiled: a binding checks its own struct definitions against these
 // (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red, 7 il_dril, 8 il_disc_shaped, 9 il_disc_deep, 10 il_peer_bucket).
 extern "C" int32_t il_struct_size(int32_t which) {

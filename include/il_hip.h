@@ -67,6 +67,9 @@ int il_kernel_stamps(uint64_t* out_host);
 int il_kernel_stamps_clear(void);
 /* the raw rows of one kernel id: out_host [il_kernel_stamp_workgroups()][4] = {begin, end, placement, 0} per workgroup of the last launch; placement = XCC_ID << 16 | the
  * shader-engine / shader-array / CU byte of HW_ID: tests assert from it that side-stream workgroups never share a CU with a pair-mode workgroup */
+/* a stream restricted to the CUs of mask_host [words x 32 bits] (hipExtStreamCreateWithCUMask); experiment only */
+int il_stream_create_cu_mask(const uint32_t* mask_host, int32_t words, void** stream_out);
+int il_stream_destroy(void* stream);
 int32_t il_kernel_stamp_workgroups(void);
 int il_kernel_stamp_rows(int32_t kernel_id, uint64_t* out_host);
 

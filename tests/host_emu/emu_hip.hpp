@@ -535,4 +535,6 @@ inline hipError_t hipFree(void* p) { emu::drain(); free(p); return hipSuccess; }
 inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) { memset(h, 0, sizeof(*h)); memcpy(h->reserved, &p, sizeof(p)); return hipSuccess; }
 inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) { memcpy(p, h.reserved, sizeof(*p)); return hipSuccess; }
 inline hipError_t hipIpcCloseMemHandle(void*) { return hipSuccess; }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, unsigned, const unsigned*) { static uintptr_t next = 0x9000; next += 0x10; *s = (hipStream_t)next; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t* s) { static uintptr_t next = 0x7000; next += 0x10; *s = (hipStream_t)next; return hipSuccess; }
