@@ -321,12 +321,17 @@ static __device__ unsigned long long il_phase_stamps[64];  // one copy per trans
 #define IL_TL_WGS 512
 #define IL_TL_SLOTS 8
 static __device__ unsigned long long il_tl[IL_TL_K][IL_TL_WGS][IL_TL_SLOTS];
-#define IL_TL(kid, slot) do { const unsigned tl_w = blockIdx.x + gridDim.x * blockIdx.y; if (threadIdx.x == 0 && tl_w < IL_TL_WGS && blockIdx.z == 0) il_tl[kid][tl_w][slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define IL_TLC(kid, slot) do { const unsigned tl_w = blockIdx.x + gridDim.x * blockIdx.y; if (threadIdx.x == 0 && tl_w < IL_TL_WGS && blockIdx.z == 0) il_tl[kid][tl_w][slot] = __builtin_amdgcn_s_memtime(); } while (0)   // the shader-clock counter (clock rate = its delta / the 100 MHz counter's)
+#ifndef IL_TL_STRIDE
+#define IL_TL_STRIDE 1   // sample every IL_TL_STRIDE-th workgroup (linear id) instead of the first IL_TL_WGS: a whole population launch (thousands of workgroups) in one table
+#endif
+#define IL_TLV(kid, slot, value) do { const unsigned tl_l = blockIdx.x + gridDim.x * blockIdx.y, tl_w = tl_l / IL_TL_STRIDE; if (threadIdx.x == 0 && tl_l % IL_TL_STRIDE == 0 && tl_w < IL_TL_WGS && blockIdx.z == 0) il_tl[kid][tl_w][slot] = (value); } while (0)
+#define IL_TL(kid, slot) IL_TLV(kid, slot, __builtin_amdgcn_s_memrealtime())
+#define IL_TLC(kid, slot) IL_TLV(kid, slot, __builtin_amdgcn_s_memtime())   // the shader-clock counter (clock rate = its delta / the 100 MHz counter's)
 #define IL_TL_READER(name) extern "C" int name(unsigned long long* out_host) { return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(il_tl), sizeof(il_tl)) == hipSuccess ? 0 : 3; }
 #define IL_TL_END(kid) do { __syncthreads(); IL_TL(kid, 7); } while (0)   // a workgroup's end = its last wave's
 #else
 #define IL_TL(kid, slot) do { } while (0)
+#define IL_TLV(kid, slot, value) do { } while (0)
 #define IL_TLC(kid, slot) do { } while (0)
 #define IL_TL_END(kid) do { } while (0)
 #define IL_TL_READER(name)

@@ -1724,6 +1724,9 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
 #define IL_POP_XCD_DW 1
 #endif
 #define DWB 64            // block edge (features) and batch rows per chunk
+#ifndef IL_POP_DW_EARLY_PMV
+#define IL_POP_DW_EARLY_PMV 1   // 0: p / m / v requested at the start of the AdamW epilogue (round 4; A/B builds)
+#endif
 #define DWB_LD (DWB + 4)
 __device__ __forceinline__ void dw_block64(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dzT, const float* __restrict__ xT, int H, int n0, int k0, int64_t poff,
                                            float* __restrict__ pkf, float* __restrict__ pkb, float* smem) {
@@ -1743,13 +1746,13 @@ __device__ __forceinline__ void dw_block64(const DwArgs& a, const adam_consts& a
 #pragma unroll
     for (int u = 0; u < 4; ++u) { zr[u] = gload4(dzT + (size_t)(n0 + sf + 16 * u) * B + r0 + sr); xr[u] = gload4(xT + (size_t)(k0 + sf + 16 * u) * B + r0 + sr); }
   };
-  fetch(0);
-  for (int r0 = 0; r0 < B; r0 += DWB) {
+  const auto stage = [&] {
     __syncthreads();   // the previous chunk's readers are done
 #pragma unroll
     for (int u = 0; u < 4; ++u) { *reinterpret_cast<f32x4*>(Zs + (sf + 16 * u) * DWB_LD + sr) = zr[u]; *reinterpret_cast<f32x4*>(Xs + (sf + 16 * u) * DWB_LD + sr) = xr[u]; }
     __syncthreads();
-    if (r0 + DWB < B) fetch(r0 + DWB);
+  };
+  const auto products = [&] {
 #pragma unroll
     for (int u = 0; u < DWB / 16; ++u) {   // 16-row groups in ascending order, like dw_tile
       f32x4 av[2], bv[2];
@@ -1765,7 +1768,23 @@ __device__ __forceinline__ void dw_block64(const DwArgs& a, const adam_consts& a
           acc[i][q][1] = mfma16(av[i][3], bv[q][3], acc[i][q][1]);
         }
     }
+  };
+  fetch(0);
+  for (int r0 = 0; r0 + DWB < B; r0 += DWB) { stage(); fetch(r0 + DWB); products(); }
+  // (round 5) The last chunk, written out: once it is parked in LDS the staging registers are free, and the block's p / m / v lanes - HBM, last touched an update ago -
+  // are requested HERE, in front of the chunk's 64 MFMAs per wave, instead of behind the gradient block's trip through LDS: their round trip (5.9 of a block
+  // workgroup's 16.1 us, profiles/r04_population_timeline.txt) runs under the products. Same loads, same arithmetic: same bits.
+  stage();
+  f32x4 pv[4], mv[4], vv[4];
+  if (!a.grads_only && IL_POP_DW_EARLY_PMV) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t o = poff + (int64_t)(n0 + sf + 16 * u) * H + k0 + sr;
+      pv[u] = gload4(a.params + o); mv[u] = gload4(a.opt.m + o); vv[u] = gload4(a.opt.v + o);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
+  products();
   // Epilogue through LDS: the accumulator layout (a lane owns 4 rows of ONE column) would stream p / m / v as 64-byte pieces of 16 different rows per instruction;
   // parked in LDS the block is re-read row-wise, so that every wave instruction moves whole 256-byte row segments (the AdamW traffic is the floor of this kernel:
   // 24 B per parameter). The updated parameters go back to LDS once more for the column-wise lane order of the PB copy.
@@ -1791,11 +1810,12 @@ __device__ __forceinline__ void dw_block64(const DwArgs& a, const adam_consts& a
     }
     return;
   }
-  f32x4 pv[4], mv[4], vv[4];
+  if (!IL_POP_DW_EARLY_PMV) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int64_t o = poff + (int64_t)(n0 + sf + 16 * u) * H + k0 + sr;
-    pv[u] = gload4(a.params + o); mv[u] = gload4(a.opt.m + o); vv[u] = gload4(a.opt.v + o);
+    for (int u = 0; u < 4; ++u) {
+      const int64_t o = poff + (int64_t)(n0 + sf + 16 * u) * H + k0 + sr;
+      pv[u] = gload4(a.params + o); mv[u] = gload4(a.opt.m + o); vv[u] = gload4(a.opt.v + o);
+    }
   }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -2390,16 +2410,53 @@ static inline int pop_dw_small_grid(int IN, int H, int OUT, int nets, int B, boo
   if (b64 && pop_small_blocks(H, B)) return (dw_block_jobs(IN, H, OUT) - (H / DWS) * (H / DWS)) * nets + (H / 16 * nets + 3) / 4;
   return dw_blocks(IN, H, OUT, nets, b64);
 }
-__global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ dL, const il_batch* __restrict__ bL, int kind, uint32_t flags, int nb64) {
+// (round 5, experiment) The dW launches' own decode of the linear workgroup id. pop_ids hands out, per group of 8 learners, the group's 64 x 64 blocks (16 us each), then its 32 x 32
+// block jobs (7 - 10 us), bias jobs and tail, and only then the next group's blocks: the launch is slot-bound (3 - 4 workgroups per CU, profiles/r05_pop_dw_timeline.txt),
+// so the LAST group's block workgroups start at 37 of a 52 us launch and its end is 15 us of a chip that drains. Here: the blocks of ALL full groups first, then
+// everything else - the launch ends on jobs half as long. Learner l stays on XCD l % 8 (both phases start at a multiple of 8); learners behind the last full group of 8
+// keep the natural decode. No job of these launches waits for another one: pure re-labelling, same bits. MEASURED NEUTRAL (three interleaved same-box A/Bs,
+// profiles/r05_pop_dw_ab.txt: +0.8 %, +0.1 %; with 4 waves per SIMD -1 %): with every slot holding a block workgroup the MFMA pipes saturate (products 12 -> 15 - 20 us)
+// and the small jobs' memory latency no longer hides under them. Kept as an A/B switch, OFF: IL_POP_DW_BIG_FIRST=1 selects it.
+#ifndef IL_POP_DW_BIG_FIRST
+#define IL_POP_DW_BIG_FIRST 0
+#endif
+__device__ __forceinline__ void pop_dw_ids(int& bx, int& by, int nb64) {
+#if IL_POP_DW_BIG_FIRST && IL_POP_XCD
+  const int nx = gridDim.x, lf = ((int)gridDim.y >> 3) * 8, g = by * nx + bx;
+  if (nb64 > 0 && nb64 < nx && g < lf * nx) {
+    const int nbig = lf * nb64;
+    if (g < nbig) { const int q = g >> 3; by = (q / nb64) * 8 + (g & 7); bx = q % nb64; }
+    else { const int r = g - nbig, q = r >> 3, nr = nx - nb64; by = (q / nr) * 8 + (r & 7); bx = nb64 + q % nr; }
+    return;
+  }
+  if (g >= lf * nx) return;
+#endif
+  pop_ids(bx, by);
+}
+// (round 5) Register budget of 4 waves per SIMD: the default allocation (121 VGPRs + 32 AGPRs for the accumulators) leaves 3 workgroups per CU; capped at 128 the kernel
+// keeps everything in VGPRs without a spill and a CU holds 4 (LDS: 4 x 34 KB). The launch is slot-bound outside its 64 x 64 blocks' products
+// (profiles/r05_pop_dw_timeline.txt): +1.0 - 1.4 % on the population line in two interleaved same-box A/Bs (profiles/r05_pop_dw_ab.txt). IL_POP_DW_WAVES=0: no cap.
+#ifndef IL_POP_DW_WAVES
+#define IL_POP_DW_WAVES 4
+#endif
+#if IL_POP_DW_WAVES > 0
+#define IL_POP_DW_ATTR __attribute__((amdgpu_waves_per_eu(IL_POP_DW_WAVES, IL_POP_DW_WAVES)))
+#else
+#define IL_POP_DW_ATTR
+#endif
+__global__ __launch_bounds__(256) IL_POP_DW_ATTR void k_dw_adam_pop(const il_sac* __restrict__ dL, const il_batch* __restrict__ bL, int kind, uint32_t flags, int nb64) {
   __shared__ __attribute__((aligned(16))) float smem[2 * DWB * DWB_LD];
   int bx = blockIdx.x, by = blockIdx.y;
 #if IL_POP_XCD_DW
-  pop_ids(bx, by);   // a learner's blocks on one XCD: the four blocks that share a [64 features][B] operand panel find it in that L2
+  pop_dw_ids(bx, by, nb64);   // a learner's blocks on one XCD: the four blocks that share a [64 features][B] operand panel find it in that L2
 #endif
   il_sac d = dL[by]; il_batch b = bL[by];
   globalize(d); globalize(b);
   DwArgs a = kind ? actor_dw_args(&d, &b, flags) : critic_dw_args(&d, flags);
   IL_TL(kind ? 11 : 10, 0);
+  IL_TLV(kind ? 11 : 10, 2, (unsigned long long)(unsigned)bx | ((unsigned long long)(unsigned)by << 32));   // which job of which learner (profiles/tools/pop_dw_timeline.py)
+  IL_TLV(kind ? 11 : 10, 3, ((unsigned long long)il_st_xcc() << 16) | ((il_st_hwid() >> 8) & 0xffu));   // and where it runs
+  IL_TLC(kind ? 11 : 10, 4);   // shader-clock counter at the start (slot 5: at the end) - the clock this workgroup ran at = delta / the 100 MHz counter's delta
   // Measured at 32 learners (round 2, one box; critic launch with dw_tile for every layer: 103 us = 23 TFLOP/s, MfmaUtil 12.7 %, 1.8 waves per SIMD resident on average):
   // the products alone took 79 us, the Adam epilogue alone 46 us. What did NOT move it: 32 x 32 blocks of dW per wave straight from global memory (half the operand
   // bytes per MFMA): 100 us; every learner confined to XCD l % 8 (`s_getreg XCC_ID` confirms workgroup g runs on XCD g % 8): 103 us; 16 instead of 8 operand loads in
@@ -2413,14 +2470,14 @@ __global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ 
       const int64_t oW2 = (int64_t)net * a.net_stride + (int64_t)H * a.in_dim + H;
       dw_block64(a, ac, a.dz2 + net * a.h_net_stride, a.h1 + net * a.h_net_stride, H, (blk / nbh) * DWB, (blk % nbh) * DWB, oW2,
                  a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem);
-      IL_TL_END(kind ? 11 : 10);
+      IL_TLC(kind ? 11 : 10, 5); IL_TL_END(kind ? 11 : 10);
       return;
     }
     if (pop_small_blocks(a.hidden, a.batch)) {
       // (round 3) layers 1 and 3 with their biases as 32 x 32 LDS block jobs (dw_block32: whole-line staging instead of the wave-per-tile jobs' half-line gathers, which were
       // 72 % of this launch's line requests), bias 2 as wave jobs (dw_block64 does not fold it), then the tail. Grid: pop_dw_grid().
       const int nb32 = H / DWS, small = dw_block_jobs(a.in_dim, H, a.out_dim) - nb32 * nb32, sb = bx - nb64;
-      if (sb < small * a.n_nets) { dw_block_job(a, sb / small, nb32 * nb32 + sb % small, smem); IL_TL_END(kind ? 11 : 10); return; }
+      if (sb < small * a.n_nets) { dw_block_job(a, sb / small, nb32 * nb32 + sb % small, smem); IL_TLC(kind ? 11 : 10, 5); IL_TL_END(kind ? 11 : 10); return; }
       const int bias_blocks = (H / 16 * a.n_nets + 3) / 4, bb = sb - small * a.n_nets;
       if (bb < bias_blocks) {
         const int job = bb * 4 + (int)(threadIdx.x >> 6);
@@ -2430,17 +2487,17 @@ __global__ __launch_bounds__(256) void k_dw_adam_pop(const il_sac* __restrict__ 
           if (!a.grads_only) ac = load_adam_consts(a.opt);
           dw_bias(a, ac, a.dz2 + net * a.h_net_stride, H, jn * 16, (int64_t)net * a.net_stride + (int64_t)H * a.in_dim + H + (int64_t)H * H);
         }
-        IL_TL_END(kind ? 11 : 10);
+        IL_TLC(kind ? 11 : 10, 5); IL_TL_END(kind ? 11 : 10);
         return;
       }
       a.n_dw_blocks = 0; a.n_big_blocks = 0; a.jobs_per_block = 4;   // the tail blocks (actor launch)
       dw_adam_body<4, true>(a, bb - bias_blocks, (int)gridDim.x - nb64 - small * a.n_nets - bias_blocks);
-      IL_TL_END(kind ? 11 : 10);
+      IL_TLC(kind ? 11 : 10, 5); IL_TL_END(kind ? 11 : 10);
       return;
     }
     a.n_dw_blocks = dw_blocks(a.in_dim, a.hidden, a.out_dim, a.n_nets, 1); a.n_big_blocks = 0; a.jobs_per_block = 4;
     dw_adam_body<4, true>(a, bx - nb64, (int)gridDim.x - nb64);
-    IL_TL_END(kind ? 11 : 10);
+    IL_TLC(kind ? 11 : 10, 5); IL_TL_END(kind ? 11 : 10);
     return;
   }
   a.n_dw_blocks = dw_blocks(a.in_dim, a.hidden, a.out_dim, a.n_nets, 0); a.n_big_blocks = 0; a.jobs_per_block = 4;

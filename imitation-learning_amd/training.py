@@ -341,15 +341,16 @@ _GMMIL_WS: Dict[tuple, Tensor] = {}   # insertion-ordered: the oldest shape is e
 _GMMIL_WS_MAX = 16
 
 
-def _gmmil_workspace(n1: int, n2: int, D: int, device, tag=None) -> Tensor:
+def _gmmil_workspace(n1: int, n2: int, D: int, device, tag=None, stream: Optional[int] = None) -> Tensor:
   """il_gmmil_reward / il_gmmil_sqdist scratch (include/il_hip.h): partial row sums + self-resetting arrival counters, zero-filled at creation. One per (shape, learner
   `tag`, stream): two learners or two streams with the same shape must not share the counters; a bounded cache (callers with ever-changing batch sizes evict the oldest).
   A launch that was aborted mid-way leaves its counters non-zero: `_gmmil_workspace_reset()` after handling such an error."""
-  try:
-    stream = int(torch.cuda.current_stream().cuda_stream)
-  except Exception:   # (no HIP device: the host emulation of tests/host_emu drives the library with CPU tensors)
-    stream = 0
-  key = (n1, n2, D, str(device), tag, stream)
+  if stream is None:
+    try:
+      stream = int(torch.cuda.current_stream().cuda_stream)
+    except Exception:   # (no HIP device: the host emulation of tests/host_emu drives the library with CPU tensors)
+      stream = 0
+  key = (n1, n2, D, device, tag, stream)
   ws = _GMMIL_WS.pop(key, None)
   if ws is None:
     ws = torch.zeros(int(_lib.lib().il_gmmil_workspace_floats(n1, n2, D)), dtype=torch.float32, device=device)
@@ -371,8 +372,24 @@ def _weighted_median(x: Tensor, weights: Tensor) -> Tensor:
 
 
 def _sa_batch(state, action, weight):
-  dummy = weight
-  return batch_desc(dict(states=state, actions=action, rewards=dummy, next_states=state, terminals=dummy, weights=weight, absorbing=dummy))
+  """il_batch of (state, action, weight) rows for the kernels that read nothing else (GMMIL / embedding distances): the per-row scalar fields alias
+  `weight`. Same checks as memory.batch_desc, once per distinct tensor - this sits on the per-call path of `predict_reward`."""
+  n = state.size(0)
+  for k, v in (('states', state), ('actions', action), ('weights', weight)):
+    if v.dtype != torch.float32 or not _lib.on_device(v):
+      raise TypeError(f'transitions[{k!r}] must be a float32 CUDA tensor (got {v.dtype} on {v.device})')
+    if v.dim() == 2 and v.stride(1) != 1:
+      raise ValueError(f'transitions[{k!r}] must have unit inner stride')
+    assert v.size(0) == n, 'ragged transitions dict'
+  b = _lib.Batch()
+  ps, pa, pw = state.data_ptr(), action.data_ptr(), weight.data_ptr()
+  ls, la, lw = (state.stride(0), action.stride(0), weight.stride(0)) if n > 1 else (state.size(1), action.size(1), 1)
+  b.states = b.next_states = ps; b.ld_states = b.ld_next_states = ls
+  b.actions = pa; b.ld_actions = la
+  b.rewards = b.terminals = b.weights = b.absorbing = pw
+  b.ld_rewards = b.ld_terminals = b.ld_weights = b.ld_absorbing = lw
+  b.n = n
+  return b
 
 
 def embedding_sqdist(x: Tensor, y: Tensor) -> Tensor:
@@ -407,12 +424,13 @@ def gmmil_predict_reward(disc: GMMILDiscriminator, state, action, expert_state, 
     disc.gamma_2 = 1 / (_weighted_median(gmmil_sqdist(disc, expert_state, expert_action, expert_state, expert_action), torch.outer(expert_weight, expert_weight)).item() + 1e-8)
   n1, n2 = state.size(0), expert_state.size(0)
   D = disc.state_size + (0 if disc.state_only else disc.action_size)
-  ws = _gmmil_workspace(n1, n2, D, dev, tag=getattr(disc, '_ws_tag', None))   # (arrival counters: zero at creation, left at zero by every call)
+  stream = _lib.stream_ptr()
+  ws = _gmmil_workspace(n1, n2, D, dev, tag=getattr(disc, '_ws_tag', None), stream=getattr(stream, 'value', None) or 0)   # (arrival counters: zero at creation, left at zero by every call)
   out = torch.empty(n1, device=dev)
   sim, self_sim = (torch.empty(n1, device=dev), torch.empty(n1, device=dev)) if return_parts else (None, None)
   pb, eb = _sa_batch(state, action, weight), _sa_batch(expert_state, expert_action, expert_weight)
   _lib.check(_lib.lib().il_gmmil_reward(C.byref(pb), C.byref(eb), disc.state_size, disc.action_size, int(disc.state_only), float(disc.gamma_1), float(disc.gamma_2),
-                                        _lib.ptr(out), _lib.ptr(sim), _lib.ptr(self_sim), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+                                        _lib.ptr(out), _lib.ptr(sim), _lib.ptr(self_sim), _lib.ptr(ws), ws.numel(), stream))
   return (out, sim, self_sim) if return_parts else out
 
 
