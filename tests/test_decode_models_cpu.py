@@ -37,6 +37,38 @@ def chain_decode_xcd(bid):
   return None                        # XCDs 6, 7: row-copy workgroups / idle
 
 
+def pop_dw_ids(bx, by, nx, L, nb64):
+  """csrc/sac.hip pop_dw_ids (IL_POP_DW_BIG_FIRST=1 builds; an A/B switch, off by default): the 64 x 64 block workgroups of ALL full groups of 8 learners first, then every
+  other job; learners behind the last full group keep the natural decode."""
+  lf, g = (L >> 3) * 8, by * nx + bx
+  if 0 < nb64 < nx and g < lf * nx:
+    nbig = lf * nb64
+    if g < nbig:
+      q = g >> 3
+      return q % nb64, (q // nb64) * 8 + (g & 7)
+    r = g - nbig
+    q, nr = r >> 3, nx - nb64
+    return nb64 + q % nr, (q // nr) * 8 + (r & 7)
+  if g >= lf * nx:
+    return bx, by
+  return pop_ids(bx, by, nx, L)
+
+
+@pytest.mark.parametrize('nx,L,nb64', [(72, 32, 32), (69, 18, 16), (69, 9, 16), (72, 3, 32), (69, 64, 16), (40, 16, 0)])
+def test_pop_dw_ids_is_a_bijection_that_keeps_a_learner_on_its_xcd_and_puts_the_blocks_first(nx, L, nb64):
+  seen, lf, first_small = set(), (L >> 3) * 8, None
+  for g in range(nx * L):
+    by, bx = divmod(g, nx)
+    nbx, nby = pop_dw_ids(bx, by, nx, L, nb64)
+    assert 0 <= nbx < nx and 0 <= nby < L and (nbx, nby) not in seen
+    seen.add((nbx, nby))
+    if nby < lf:
+      assert g % 8 == nby % 8
+      if nb64 and nbx >= nb64 and first_small is None: first_small = g
+      if nb64 and nbx < nb64: assert first_small is None, 'every block workgroup of the full groups is dispatched before the first small job'
+  assert len(seen) == nx * L
+
+
 @pytest.mark.parametrize('nt', [1, 5, 16, 32])
 def test_chain_decode_xcd_one_network_per_xcd_and_waits_only_on_lower_blocks(nt):
   where = {}
