@@ -1437,6 +1437,10 @@ struct DwArgs {
   float* log_alpha; float* alpha_grad; il_adam alpha_opt; const float* alpha_part; int n_alpha_part;
   float* target; const float* polyak_src; int64_t polyak_n; double tau; uint32_t* noise_counter; int64_t* sync;
   float* pk_target; const float* pk_critic; int64_t pk_n;   // lane-ordered copies of the target / critic hidden layers (polyak is elementwise, so it commutes with the re-ordering)
+  // (round 5, population; +2.2 % on the population line, profiles/r05_pop_dw_ab.txt) the target step of the critics' H x H layers folded into their optimiser pass: `fuse_polyak` (critic launch: dw_block64 also
+  // writes target / pk_target from the new parameters in its registers); `polyak_fused` (actor launch's tail: skips the two networks' H x H ranges
+  // and the lane-ordered copies, and steps the rest of the arena element by element at the ranges' edges)
+  int fuse_polyak, polyak_fused;
 };
 // data-parallel: the gradient exchange of an optimiser step rides in its block jobs (peer_device.hpp "the exchange INSIDE the kernel that produces the gradients"): job = the
 // block job's index (the log-alpha step: n_big_blocks). A kernel argument of its own, and a kernel of its own (k_dw_adam_peer: the functions below are templated on PEER):
@@ -1623,7 +1627,7 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
       // (round 3) target <- tau target + (1 - tau) critic over the parameter arena AND its lane-ordered copies as ONE index space of 16-byte lanes, four lanes per thread
       // and trip with all eight loads requested first: the grid-stride loops below were a dependent HBM round trip per trip (the target was last touched an update ago),
       // 8 trips per thread with 33 tail blocks. Elementwise: the bits do not depend on who computes which lane.
-      if ((a.polyak_n & 3) == 0 && (!a.pk_target || (a.pk_n & 3) == 0)) {
+      if ((a.polyak_n & 3) == 0 && (!a.pk_target || (a.pk_n & 3) == 0) && !a.polyak_fused) {
         const int64_t n1 = a.polyak_n >> 2, n2 = a.pk_target ? (a.pk_n >> 2) : 0, stride = (int64_t)ntb * blockDim.x;
         for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < n1 + n2; i += 4 * stride) {
           f32x4 t[4], p[4]; f32x4* dst[4];
@@ -1653,6 +1657,23 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
       }
 #endif
       for (int64_t i = ((int64_t)tb * blockDim.x + threadIdx.x) * 4; i < a.polyak_n; i += (int64_t)ntb * blockDim.x * 4) {
+        if (a.polyak_fused) {   // the H x H layers were stepped by the critic launch's blocks: whole lanes inside them are skipped, lanes at their edges go element by element
+          // (the twin critic's layout from what the tail knows: polyak_n = 2 strides, stride = H IN + H | H H | H | H | 1 rounded up to a multiple of 4 floats)
+          const int64_t fz_stride = a.polyak_n >> 1, fz_hh = (int64_t)a.hidden * a.hidden;
+          const int64_t fz_w2_off = ((fz_stride - fz_hh - 3 * a.hidden - 1) / a.hidden) * a.hidden + a.hidden;
+          int inr = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int64_t r0 = i + q - fz_w2_off, r1 = r0 - fz_stride;
+            inr |= ((r0 >= 0 && r0 < fz_hh) || (r1 >= 0 && r1 < fz_hh)) ? (1 << q) : 0;
+          }
+          if (inr == 15) continue;
+          if (inr != 0) {
+            for (int q = 0; q < 4; ++q)
+              if (i + q < a.polyak_n && !((inr >> q) & 1)) a.target[i + q] = __fadd_rn(__fmul_rn(a.target[i + q], tau), __fmul_rn(omt, a.polyak_src[i + q]));
+            continue;
+          }
+        }
         if (i + 3 < a.polyak_n) {
           f32x4 t = *reinterpret_cast<f32x4*>(a.target + i); const f32x4 p = *reinterpret_cast<const f32x4*>(a.polyak_src + i);
 #pragma unroll
@@ -1723,13 +1744,14 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
 #ifndef IL_POP_XCD_DW
 #define IL_POP_XCD_DW 1
 #endif
+#define IL_FLAG_POP_FUSE_POLYAK 0x8000u   // internal (set by il_sac_update_population unless IL_POP_FUSE_POLYAK=0): see DwArgs.fuse_polyak
 #define DWB 64            // block edge (features) and batch rows per chunk
 #ifndef IL_POP_DW_EARLY_PMV
 #define IL_POP_DW_EARLY_PMV 1   // 0: p / m / v requested at the start of the AdamW epilogue (round 4; A/B builds)
 #endif
 #define DWB_LD (DWB + 4)
 __device__ __forceinline__ void dw_block64(const DwArgs& a, const adam_consts& ac, const float* __restrict__ dzT, const float* __restrict__ xT, int H, int n0, int k0, int64_t poff,
-                                           float* __restrict__ pkf, float* __restrict__ pkb, float* smem) {
+                                           float* __restrict__ pkf, float* __restrict__ pkb, float* smem, const il_sac* dsrc = nullptr) {
   float* Zs = smem; float* Xs = smem + DWB * DWB_LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int ti = wave >> 1, tq = wave & 1;   // this wave's 32 x 32 quadrant: tiles (2 ti + i, 2 tq + q)
@@ -1817,6 +1839,21 @@ __device__ __forceinline__ void dw_block64(const DwArgs& a, const adam_consts& a
       pv[u] = gload4(a.params + o); mv[u] = gload4(a.opt.m + o); vv[u] = gload4(a.opt.v + o);
     }
   }
+  // (round 5, IL_POP_FUSE_POLYAK) target <- tau target + (1 - tau) critic for this block, from the NEW parameters in registers: the tail of the actor launch read the
+  // target, the critic and both lane-ordered copies again (36 B per H x H parameter); here 4 B are read and 8 written. Same two multiplies and one add per element.
+  f32x4 tv[4];
+  float* tgt = nullptr; float* pkt = nullptr; float tau = 0.f, omt = 0.f;
+  if (a.fuse_polyak && dsrc) {
+    // the target's pointers and tau are read from the descriptor HERE (an opaque pointer: the compiler cannot merge these loads with the kernel's first read of the
+    // descriptor), not carried in scalar registers through the products: the kernel sits at its 128-VGPR budget and three more live pointers spilled to scratch
+    const il_sac* dp = dsrc;
+    asm volatile("" : "+s"(dp));
+    const SacWs ws = sac_ws(dp->state_dim, dp->action_dim, dp->hidden, dp->batch);
+    tgt = dp->target; tau = (float)dp->polyak; omt = (float)(1.0 - dp->polyak);
+    pkt = pkf ? dp->workspace + ws.pk_tf + (pkf - a.pk_f) : nullptr;   // the same network's slab of the target's forward-order copy
+#pragma unroll
+    for (int u = 0; u < 4; ++u) tv[u] = gload4(tgt + poff + (int64_t)(n0 + sf + 16 * u) * H + k0 + sr);
+  }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int rr = sf + 16 * u, n = n0 + rr, k = k0 + sr;
@@ -1828,6 +1865,16 @@ __device__ __forceinline__ void dw_block64(const DwArgs& a, const adam_consts& a
     if (pkf) {
       *reinterpret_cast<f32x4*>(pkf + packed_fwd_index(n, k, H)) = pv[u];   // k .. k+3 of row n: one 16-byte lane of PF
       *reinterpret_cast<f32x4*>(Gs + rr * DWB_LD + sr) = pv[u];
+    }
+  }
+  if (a.fuse_polyak && dsrc) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = n0 + sf + 16 * u, k = k0 + sr;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tv[u][q] = __fadd_rn(__fmul_rn(tv[u][q], tau), __fmul_rn(omt, pv[u][q]));
+      *reinterpret_cast<f32x4*>(tgt + poff + (int64_t)n * H + k) = tv[u];
+      if (pkt) *reinterpret_cast<f32x4*>(pkt + packed_fwd_index(n, k, H)) = tv[u];
     }
   }
   if (!pkf) return;
@@ -2155,6 +2202,7 @@ __host__ __device__ static DwArgs critic_dw_args(const il_sac* d, uint32_t flags
   a.n_big_blocks = (dw_block32_on() && H % 32 == 0 && B % 128 == 0) ? 2 * dw_block_jobs_n(IN, H, 1) : 0;   // every layer + the biases as 32 x 32 block jobs (dw_block32)
   a.jobs_per_block = 4;
   a.n_dw_blocks = a.n_big_blocks > 0 ? a.n_big_blocks : dw_blocks(IN, H, 1, 2);
+  if ((flags & IL_FLAG_POP_FUSE_POLYAK) && !a.grads_only && d->target) a.fuse_polyak = 1;   // (the target's pointers are fetched from `desc` where they are used: dw_block64)
   return a;
 }
 
@@ -2229,6 +2277,10 @@ __host__ __device__ static DwArgs actor_dw_args(const il_sac* d, const il_batch*
   a.n_dw_blocks = a.n_big_blocks > 0 ? a.n_big_blocks : dw_blocks(S, H, 2 * A, 1);
   a.log_alpha = d->log_alpha; a.alpha_grad = d->alpha_grad; a.alpha_opt = d->alpha_opt; a.alpha_part = d->workspace + ws.alpha_part; a.n_alpha_part = B / IL_TILE_R;
   a.target = d->target; a.polyak_src = d->critic; a.polyak_n = 2 * net_stride(S + A, H, 1); a.tau = d->polyak; a.noise_counter = d->noise_counter; a.sync = d->sync;
+  if ((flags & IL_FLAG_POP_FUSE_POLYAK) && !a.grads_only && d->target) {   // the H x H layers and their copies were stepped by the critic launch's blocks (critic_dw_args)
+    a.polyak_fused = 1;
+    return a;
+  }
   a.pk_target = d->workspace + ws.pk_tf; a.pk_critic = d->workspace + ws.pk_cf; a.pk_n = 2 * (int64_t)H * H;   // the FORWARD-order copies of both target critics only: targets are never back-propagated, so their PB copies (pk_tb) have no reader (round 2: 1.5 MB of polyak traffic per update removed)
   return a;
 }
@@ -2469,7 +2521,7 @@ __global__ __launch_bounds__(256) IL_POP_DW_ATTR void k_dw_adam_pop(const il_sac
       if (!a.grads_only) ac = load_adam_consts(a.opt);
       const int64_t oW2 = (int64_t)net * a.net_stride + (int64_t)H * a.in_dim + H;
       dw_block64(a, ac, a.dz2 + net * a.h_net_stride, a.h1 + net * a.h_net_stride, H, (blk / nbh) * DWB, (blk % nbh) * DWB, oW2,
-                 a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem);
+                 a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem, dL + by);
       IL_TLC(kind ? 11 : 10, 5); IL_TL_END(kind ? 11 : 10);
       return;
     }
@@ -2507,6 +2559,7 @@ __global__ __launch_bounds__(256) IL_POP_DW_ATTR void k_dw_adam_pop(const il_sac
 extern "C" int il_sac_update_population(const il_sac* descs_dev, const il_batch* batches_dev, int32_t n_learners, const il_sac* shape_host, uint32_t flags, il_stream_t stream_) {
   IL_CHECK_ARG(descs_dev && batches_dev && shape_host && n_learners >= 1 && n_learners <= 65535, "il_sac_update_population: bad arguments");
   IL_CHECK_ARG(!(flags & IL_FLAG_GRADS_ONLY), "il_sac_update_population: IL_FLAG_GRADS_ONLY is not supported on the population path");
+  { static const uint32_t fuse = [] { const char* e = getenv("IL_POP_FUSE_POLYAK"); return e && e[0] == '0' ? 0u : IL_FLAG_POP_FUSE_POLYAK; }(); flags |= fuse; }   // (round 5: on; IL_POP_FUSE_POLYAK=0 keeps the whole target step in the actor launch's tail - same bits)
   const il_sac* d = shape_host;
   IL_CHECK_ARG(d->hidden % 64 == 0 && d->hidden >= 64 && d->hidden <= 256 && d->batch % IL_TILE_R == 0 && d->batch > 0 && 2 * d->action_dim <= 16, "il_sac_update_population: unsupported shape");
   hipStream_t st = (hipStream_t)stream_;

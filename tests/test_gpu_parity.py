@@ -1302,12 +1302,13 @@ def test_schedule_switches_are_bit_identical(monkeypatch, switch, B):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('switch,values', [('IL_POP_SPLIT_TAIL', ('1', '0')), ('IL_POP_DISC_TPW', ('4', '1')), ('IL_POP_DISC_TPW', ('3', '16'))])
+@pytest.mark.parametrize('switch,values', [('IL_POP_SPLIT_TAIL', ('1', '0')), ('IL_POP_DISC_TPW', ('4', '1')), ('IL_POP_DISC_TPW', ('3', '16')), ('IL_POP_FUSE_POLYAK', ('1', '0'))])
 def test_population_switches_are_bit_identical(switch, values):
   """The round-4 forms of the population launches - the policy backward as a launch of its own (k_actor_bwd_pop) instead of the tail of each tile's second critic
   workgroup, several tiles per workgroup of k_gail_grad_pop (3: a ragged last workgroup; 16: a whole call in one workgroup) - only move work between workgroups:
   three learners after two population updates must not differ in a bit from the other setting (and, by test_batched_population_equals_independent_learners, from
-  independent learners). The switches are read once per process: compared through subprocesses."""
+  independent learners). IL_POP_FUSE_POLYAK (round 5): the target step of the critics' H x H layers inside their optimiser blocks instead of the actor launch's tail. The
+  switches are read once per process: compared through subprocesses."""
   import subprocess, sys, json
   code = (
       "import sys, json, hashlib, numpy as np, torch; sys.path[:0] = ['.', 'tests', 'tests/golden']\n"
