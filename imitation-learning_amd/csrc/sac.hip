@@ -2559,7 +2559,6 @@ __global__ __launch_bounds__(256) IL_POP_DW_ATTR void k_dw_adam_pop(const il_sac
 extern "C" int il_sac_update_population(const il_sac* descs_dev, const il_batch* batches_dev, int32_t n_learners, const il_sac* shape_host, uint32_t flags, il_stream_t stream_) {
   IL_CHECK_ARG(descs_dev && batches_dev && shape_host && n_learners >= 1 && n_learners <= 65535, "il_sac_update_population: bad arguments");
   IL_CHECK_ARG(!(flags & IL_FLAG_GRADS_ONLY), "il_sac_update_population: IL_FLAG_GRADS_ONLY is not supported on the population path");
-  { static const uint32_t fuse = [] { const char* e = getenv("IL_POP_FUSE_POLYAK"); return e && e[0] == '0' ? 0u : IL_FLAG_POP_FUSE_POLYAK; }(); flags |= fuse; }   // (round 5: on; IL_POP_FUSE_POLYAK=0 keeps the whole target step in the actor launch's tail - same bits)
   const il_sac* d = shape_host;
   IL_CHECK_ARG(d->hidden % 64 == 0 && d->hidden >= 64 && d->hidden <= 256 && d->batch % IL_TILE_R == 0 && d->batch > 0 && 2 * d->action_dim <= 16, "il_sac_update_population: unsupported shape");
   hipStream_t st = (hipStream_t)stream_;
@@ -2604,6 +2603,10 @@ extern "C" int il_sac_update_population(const il_sac* descs_dev, const il_batch*
     static const int lds_dw = [] { const char* e = getenv("IL_POP_DW_LDS"); return e && e[0] == '0' ? 0 : 1; }();
     const bool b64 = lds_dw && H % DWB == 0 && B % DWB == 0;   // H x H layers as 64 x 64 blocks staged through LDS (dw_block64); IL_POP_DW_LDS=0: dw_tile for every layer
     const int nbc = b64 ? dw_block64_count(H, 2) : 0, nba = b64 ? dw_block64_count(H, 1) : 0;
+    // (round 5) the target step of the critics' H x H layers inside their 64 x 64 optimiser blocks (DwArgs.fuse_polyak) - only where those blocks exist; both dW launches
+    // must see the same setting (the actor launch's tail skips exactly what the critic launch's blocks stepped). IL_POP_FUSE_POLYAK=0: the whole step in the tail - same bits.
+    static const uint32_t fuse = [] { const char* e = getenv("IL_POP_FUSE_POLYAK"); return e && e[0] == '0' ? 0u : IL_FLAG_POP_FUSE_POLYAK; }();
+    if (b64) flags |= fuse;
     { IL_TRACE("k_dw_adam_critic", st); k_dw_adam_pop<<<dim3(nbc + pop_dw_small_grid(S + A, H, 1, 2, B, b64), L), 256, 0, st>>>(descs_dev, batches_dev, 0, flags, nbc); }
     {
       IL_TRACE("k_policy_critic", st);
