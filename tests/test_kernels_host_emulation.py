@@ -618,6 +618,18 @@ def test_population_launches_equal_independent_learners_on_the_emulated_kernels(
   assert not np.array_equal(results[0][0][0], results[0][1][0])
 
 
+@pytest.mark.parametrize('env', [dict(IL_POP_DW_LDS='0'), dict(IL_POP_FUSE_POLYAK='0')], ids=['no 64 x 64 blocks', 'target step in the tail'])
+def test_population_dw_switches_on_the_emulated_kernels(env):
+  """The population's optimiser launches under their two process-wide switches (read once per process: a child pytest each): without the 64 x 64 blocks (IL_POP_DW_LDS=0)
+  the target step must stay whole in the actor launch's tail - round 5 folded the H x H layers' share into those blocks, and a tail that skipped them while no block had
+  stepped them left the target's hidden layers frozen (caught on the GPU by test_population_launch_switches_are_bit_identical; this is the no-GPU guard) - and with the
+  folding switched off the launches must still equal independent learners."""
+  import subprocess, sys
+  r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k', 'test_population_launches_equal_independent_learners_on_the_emulated_kernels'],
+                     env=dict(os.environ, **env), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
+
+
 _PLAIN_PLAN_RESULT = []
 
 
