@@ -618,6 +618,47 @@ def test_population_launches_equal_independent_learners_on_the_emulated_kernels(
   assert not np.array_equal(results[0][0][0], results[0][1][0])
 
 
+@pytest.mark.parametrize('hidden,env_name', [(128, 'hopper'), (64, 'ant'), (192, 'walker2d')])
+def test_population_launches_at_other_shapes_on_the_emulated_kernels(monkeypatch, hidden, env_name):
+  """The population launches away from the headline shape (hidden 64 / 128 / 192, Hopper / Ant / Walker2d dims): two SAC learners, two updates, batched against one by one,
+  every network incl. the target bit-identical. The optimiser launches derive the twin critic's layout (network stride, the H x H layers' ranges the folded target step
+  owns) from these dims: a wrong range shows up as a target that differs."""
+  tgp = _emulated_product(monkeypatch, streams=True)
+  gi, il, torch = tgp.gi, tgp.il, tgp.torch
+
+  def learners(n):
+    tgp.il_training._NOISE.clear(); tgp.il_training._WS.clear()
+    plans, nets_all = [], []
+    for l in range(n):
+      S, A = gi.DIMS[env_name]
+      torch.manual_seed(30 + l)
+      cfg = tgp.Cfg(hidden_size=hidden, depth=2, activation='relu')
+      actor, critic = il.SoftActor(S, A, cfg, device=tgp.DEV), il.TwinCritic(S, A, cfg, device=tgp.DEV)
+      target, log_alpha = il.create_target_network(critic), torch.zeros(1, device=tgp.DEV)
+      ao, co, to = il.AdamW(actor, lr=3e-4, weight_decay=0), il.AdamW(critic, lr=3e-4, weight_decay=0), il.Adam(log_alpha, lr=3e-4)
+      mem = il.ReplayMemory(20000, S, A, True, device=tgp.DEV); tgp.fill_memory(mem, gi.transitions(np.random.RandomState(30 + l), 5000, S, A), 5000)
+      mem.index_rng = il.IndexStream(100 + l)
+      plans.append(il.UpdatePlan('SAC', actor, critic, log_alpha, target, mem, ao, co, to, 256, 0.97, -0.5 * A, 0.99, overlap=False, learner_id=l))
+      nets_all.append((actor, critic, target, log_alpha))
+    return plans, nets_all
+
+  results = []
+  for batched in (False, True):
+    plans, nets_all = learners(2)
+    if batched:
+      pop = il.BatchedPopulationPlan(plans)
+      for _ in range(2): pop.run()
+    else:
+      for _ in range(2):
+        for p in plans: p.run()
+    results.append([[tgp.N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [tgp.N(p.idx), tgp.N(p.logp)] for nets, p in zip(nets_all, plans)])
+  for l, (a_l, b_l) in enumerate(zip(*results)):
+    for i, (a, b) in enumerate(zip(a_l, b_l)):
+      assert np.isfinite(a).all()
+      np.testing.assert_array_equal(a, b, err_msg=f'learner {l}, tensor {i}')
+  assert not np.array_equal(results[0][0][0], results[0][1][0])
+
+
 @pytest.mark.parametrize('env', [dict(IL_POP_DW_LDS='0'), dict(IL_POP_FUSE_POLYAK='0')], ids=['no 64 x 64 blocks', 'target step in the tail'])
 def test_population_dw_switches_on_the_emulated_kernels(env):
   """The population's optimiser launches under their two process-wide switches (read once per process: a child pytest each): without the 64 x 64 blocks (IL_POP_DW_LDS=0)
