@@ -166,7 +166,7 @@ def secondary(device, plan, nets):
   kus = gst['duration_us'] if gst else None
   out['gmmil_reward_B1024_ant'] = dict(calls_per_s=round(rate, 1), pair_feature_TFLOPs=round(pair_flops * rate / 1e12 / 2, 2), kernel_us=kus,
                                         kernel_fp32_frac=(round(pair_flops / 2 / (kus * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, 4) if kus else None),
-                                        note='k_gmmil_sx (one launch: row operand in scalar registers, 256 columns x all features resident in LDS; IL_GMMIL_SX=0 / IL_GMMIL_RESIDENT=0 / IL_GMMIL_DIRECT=0: the earlier forms, same bits); calls_per_s is back-to-back predict_reward calls (host ~10 us each since round 5: at the kernel's own period), kernel_us is the launch itself (device stamps); the reference materialises [B,B,D] temporaries (0.33 s per call on its CPU path)')
+                                        note='k_gmmil_sx (one launch: row operand in scalar registers, 256 columns x all features resident in LDS; IL_GMMIL_SX=0 / IL_GMMIL_RESIDENT=0 / IL_GMMIL_DIRECT=0: the earlier forms, same bits); calls_per_s is back-to-back predict_reward calls (host ~10 us each since round 5: at the period of the kernel itself), kernel_us is the launch itself (device stamps); the reference materialises [B,B,D] temporaries (0.33 s per call on its CPU path, SURVEY.md a20)')
 
   # BASELINE.json configs[3] as WHOLE updates: algorithm=GMMIL env=ant, batch 1024 - 2 replay samples + the pairwise-RBF reward + sac_update as one captured graph per step
   rs2 = np.random.RandomState(6)
