@@ -161,6 +161,10 @@ _SIGNATURES = {
     'il_sac_dp_phase': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.c_int32, _P, _P, C.c_uint32, _P]),
     'il_sac_update': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), _P, _P, _P, _P, C.c_uint32, _P]),
     'il_sac_update_gather': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.POINTER(Batch), _P, C.POINTER(Disc), _P, _P, _P, _P, _P, C.c_uint32, _P]),
+    'il_sac_update_gather_overlap': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.POINTER(Batch), _P, C.POINTER(Disc), _P, _P, _P, _P, _P, C.c_uint32, _P, _P]),
+    'il_sac_overlap_enter': (C.c_int, [C.POINTER(Sac), _P]),
+    'il_sync_clear_poison': (C.c_int, [_P, _P]),
+    'il_sync_layout_ex': (None, [C.POINTER(C.c_int32), C.c_int32]),
     'il_sac_update_gather_peer': (C.c_int, [C.POINTER(Sac), C.POINTER(Batch), C.POINTER(Batch), _P, C.POINTER(Disc), _P, _P, _P, _P, _P, C.c_uint32, C.POINTER(PeerBucket), C.POINTER(PeerBucket), _P]),
     'il_gail_step_workgroups': (C.c_int32, [C.POINTER(Disc)]),
     'il_sac_chain_gather_workgroups': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
@@ -255,6 +259,13 @@ def sync_layout():
   return _SYNC_LAYOUT
 
 
+def sync_layout_ex():
+  """sync_layout() followed by (poison index, first stage-epoch index, first stage-ticket index, main-epoch index): include/il_hip.h IL_SYNC_POISON / IL_SYNC_OV_EPOCH / IL_SYNC_OV_TICKET."""
+  out = (C.c_int32 * 10)()
+  lib().il_sync_layout_ex(out, 10)
+  return tuple(int(v) for v in out)
+
+
 STAMP_KERNELS = ('k_gail_grad', 'k_gail_reduce', 'k_sac_chain_pair', 'k_dw_adam_critic', 'k_policy_critic_pair', 'k_dw_adam_actor', 'k_gmmil_direct', 'k_pwil')   # IL_STAMP_* (include/il_hip.h)
 
 
@@ -281,6 +292,17 @@ def kernel_stamp_rows(kernel: str, handle=None):
   buf = (C.c_uint64 * (4 * n))()
   check(L.il_kernel_stamp_rows(STAMP_KERNELS.index(kernel), buf))
   return [(int(buf[4 * w]) / 100.0, int(buf[4 * w + 1]) / 100.0, int(buf[4 * w + 2])) for w in range(n) if buf[4 * w] and buf[4 * w + 1]]
+
+
+def kernel_stamp_gates(kernel: str, handle=None):
+  """Overlapped launches (il_sac_update_gather_overlap): (first, last) time in us at which a workgroup of the last launch of `kernel` got past its wait for the other
+  stream's launch, or None when no workgroup of that launch had such a wait (in-order launches)."""
+  L = handle or lib()
+  n = int(L.il_kernel_stamp_workgroups())
+  buf = (C.c_uint64 * (4 * n))()
+  check(L.il_kernel_stamp_rows(STAMP_KERNELS.index(kernel), buf))
+  g = [int(buf[4 * w + 3]) / 100.0 for w in range(n) if buf[4 * w] and buf[4 * w + 1] and buf[4 * w + 3]]
+  return (min(g), max(g)) if g else None
 
 
 def check(rc: int):

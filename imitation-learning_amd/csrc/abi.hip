@@ -83,6 +83,18 @@ __global__ void k_sync_probe(long long* sync, int setter) {
   if (threadIdx.x == 0) sync[IL_SYNC_PROBE_EPOCH] = e + 1;
 }
 extern "C" void il_sync_layout(int32_t* out) { out[0] = IL_SYNC_SLOTS; out[1] = IL_SYNC_TIMEOUTS; out[2] = IL_SYNC_GATHER_WGS; out[3] = IL_SYNC_STRIDE; out[4] = IL_SYNC_SPIN; out[5] = IL_SYNC_HOST_FLAG; }
+// out[0 .. n): il_sync_layout's six, then [6] IL_SYNC_POISON, [7] IL_SYNC_OV_EPOCH, [8] IL_SYNC_OV_TICKET, [9] IL_SYNC_MAIN_EPOCH
+extern "C" void il_sync_layout_ex(int32_t* out, int32_t n) {
+  const int32_t v[10] = {IL_SYNC_SLOTS, IL_SYNC_TIMEOUTS, IL_SYNC_GATHER_WGS, IL_SYNC_STRIDE, IL_SYNC_SPIN, IL_SYNC_HOST_FLAG, IL_SYNC_POISON, IL_SYNC_OV_EPOCH, IL_SYNC_OV_TICKET, IL_SYNC_MAIN_EPOCH};
+  for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
+}
+__global__ void k_sync_clear_poison(long long* sync) { if (threadIdx.x == 0 && blockIdx.x == 0) { sync[IL_SYNC_POISON] = 0; sync[IL_SYNC_TIMEOUTS] = 0; } }
+extern "C" int il_sync_clear_poison(int64_t* sync, il_stream_t stream) {
+  IL_CHECK_ARG(sync, "il_sync_clear_poison: null counters");
+  k_sync_clear_poison<<<1, 64, 0, (hipStream_t)stream>>>((long long*)sync);
+  IL_CHECK_LAUNCH("il_sync_clear_poison");
+  return IL_OK;
+}
 extern "C" int il_sync_probe(int64_t* sync, int32_t setter, il_stream_t stream) {
   IL_CHECK_ARG(sync, "il_sync_probe: null counters");
   k_sync_probe<<<1, 64, 0, (hipStream_t)stream>>>((long long*)sync, setter);

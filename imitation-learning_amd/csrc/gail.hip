@@ -250,11 +250,14 @@ __device__ __forceinline__ void gail_grad_body(il_disc d, il_batch pol, il_batch
     if (tid < 64 && d.spectral_norm) sn_chain(L.W1s, L.W2s, L.Ms, D, H, L.u1(0), L.v1(0), L.v2(0), L.tmp, pass + 1, L.sc(0));
     long long* sy = reinterpret_cast<long long*>(d.sync);
     IL_TL(0, 1);
-    if (pol.gather && exp.gather) sync_wait(sy, IL_SYNC_INDICES, sy[IL_SYNC_SIDE_EPOCH] + 1);   // rows come straight from the rings: only the draw has to be done
-    // (round 5) the draw may now be AHEAD of the previous update's end: this step reads the Philox counter that update's actor step advances (below), so it still starts
-    // behind [IL_SYNC_MAIN_EPOCH] (= the number of discriminator steps closed so far) - 4 us earlier than when the draw itself waited for it
-    if (pol.gather && exp.gather && has_sampler) sync_wait(sy, IL_SYNC_MAIN_EPOCH, sy[IL_SYNC_SIDE_EPOCH]);
-    else sync_wait(sy, IL_SYNC_ROWS, (sy[IL_SYNC_SIDE_EPOCH] + 1) * sy[IL_SYNC_GATHER_WGS]);
+    if (pol.gather && exp.gather) {
+      sync_wait(sy, IL_SYNC_INDICES, sy[IL_SYNC_SIDE_EPOCH] + 1);   // rows come straight from the rings: only the draw has to be done
+      // (round 5) the draw may now be AHEAD of the previous update's end: this step reads the Philox counter that update's actor step advances (below), so it still starts
+      // behind [IL_SYNC_MAIN_EPOCH] (= the number of discriminator steps closed so far) - 4 us earlier than when the draw itself waited for it
+      if (has_sampler) sync_wait(sy, IL_SYNC_MAIN_EPOCH, sy[IL_SYNC_SIDE_EPOCH]);
+    } else {
+      sync_wait(sy, IL_SYNC_ROWS, (sy[IL_SYNC_SIDE_EPOCH] + 1) * sy[IL_SYNC_GATHER_WGS]);   // gathered batches: every gather workgroup of this update has signalled
+    }
     IL_TL(0, 2);
     ctr = d.noise_counter ? *d.noise_counter : 0u;   // after the wait: the previous update's actor step (which bumps it) precedes this update's gather
     // (round 4) The rows of this call with every load of a round in flight: stage_rows' element loop makes, per element, an index load and then a dependent row load -

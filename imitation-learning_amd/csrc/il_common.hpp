@@ -281,8 +281,15 @@ __device__ __forceinline__ void sync_signal(long long* ctr) {   // all threads o
 }
 __device__ __forceinline__ void sync_timed_out(long long* sync) {   // one thread: count the expired wait, and raise the host's flag if it gave us one ([IL_SYNC_HOST_FLAG])
   const long long n = __hip_atomic_fetch_add(sync + IL_SYNC_TIMEOUTS, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  // poison the learner (round 6): the optimiser epilogues of this and every later launch skip their stores until the host has seen it (il_sync_clear_poison) - an update
+  // whose hand-off expired must not reach the weights
+  __hip_atomic_store(sync + IL_SYNC_POISON, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const long long host = sync[IL_SYNC_HOST_FLAG];
   if (host) __hip_atomic_store((__attribute__((address_space(1))) long long*)host, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // typed global: a FLAT store would make every later wait of the kernel conservative
+}
+// wave-uniform: has a bounded wait of this learner expired (now or in an earlier launch)? Read by the optimiser epilogues right before their stores.
+__device__ __forceinline__ bool sync_poisoned(const long long* sync) {
+  return sync && __hip_atomic_load(sync + IL_SYNC_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 __device__ __forceinline__ void sync_wait(long long* sync, int which, long long target, int limit = 0) {   // all threads of the workgroup, before their loads
   if (threadIdx.x == 0) {   // limit 0: the learner's own bound [IL_SYNC_SPIN] (0 there = IL_SYNC_SPIN_LIMIT), read only once a poll has failed: nothing on the fast path
@@ -297,6 +304,31 @@ __device__ __forceinline__ void sync_wait(long long* sync, int which, long long 
 #endif
   }
   __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage epochs of the overlapped SAC branch (il_sac_update_gather_overlap; include/il_hip.h [IL_SYNC_OV_EPOCH] / [IL_SYNC_OV_TICKET]). The four launches of an update alternate
+// over two streams; a launch is dispatched while its predecessor (the other stream's head) still runs and waits for that stage's epoch behind its independent prologue.
+//   ov_own:  this stage's epoch = the number of updates it has completed. Stable while any workgroup of the launch is alive (the last one to retire bumps it).
+//   ov_wait: all threads; one polling lane, agent-scope acquire, barrier (sync_wait).
+//   ov_done: all threads, at the workgroup's end. Every wave drains its stores, barrier, one release (L2 write-back) + ticket; the last ticket resets the line and
+//            bumps the epoch. The consumer's acquire then sees every workgroup's stores.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long ov_own(long long* sync, int stage) {
+  return __hip_atomic_load(sync + IL_SYNC_OV_EPOCH + stage * IL_SYNC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ov_wait(long long* sync, int stage, long long target) { sync_wait(sync, IL_SYNC_OV_EPOCH + stage * IL_SYNC_STRIDE, target); }
+__device__ __forceinline__ void ov_done(long long* sync, int stage) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const long long total = (long long)gridDim.x * gridDim.y * gridDim.z;
+    long long* tk = sync + IL_SYNC_OV_TICKET + stage * IL_SYNC_STRIDE;
+    if (__hip_atomic_fetch_add(tk, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+      __hip_atomic_store(tk, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(sync + IL_SYNC_OV_EPOCH + stage * IL_SYNC_STRIDE, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 #define LOG_SQRT_2PI 0.91893853320467274178f
@@ -346,11 +378,13 @@ static __device__ unsigned long long il_tl[IL_TL_K][IL_TL_WGS][IL_TL_SLOTS];
 // ---------------------------------------------------------------------------------------------
 enum { IL_ST_GAIL_GRAD = 0, IL_ST_GAIL_REDUCE = 1, IL_ST_CHAIN = 2, IL_ST_DW_CRITIC = 3, IL_ST_POLICY_CRITIC = 4, IL_ST_DW_ACTOR = 5, IL_ST_GMMIL = 6, IL_ST_PWIL = 7, IL_ST_K = 8 };
 #define IL_ST_WGS 512
-#define IL_ST_TABLE static __device__ unsigned long long il_st[IL_ST_K][IL_ST_WGS][4];   // {begin, end, placement, 0}: placement = XCC_ID << 16 | HW_ID[15:8] (SE / SH / CU of the workgroup's first wave)
+#define IL_ST_TABLE static __device__ unsigned long long il_st[IL_ST_K][IL_ST_WGS][4];   // {begin, end, placement, gate}: placement = XCC_ID << 16 | HW_ID[15:8] (SE / SH / CU of the workgroup's first wave)
 __device__ __forceinline__ unsigned il_st_xcc() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 0xfu; }
 __device__ __forceinline__ unsigned il_st_hwid() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v)); return v; }
 #define IL_ST_INDEX (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z))
-#define IL_ST_BEGIN(kid) do { const unsigned st_w = IL_ST_INDEX; if (threadIdx.x == 0 && st_w < IL_ST_WGS) { il_st[kid][st_w][0] = __builtin_amdgcn_s_memrealtime(); il_st[kid][st_w][2] = ((unsigned long long)il_st_xcc() << 16) | ((il_st_hwid() >> 8) & 0xffu); } } while (0)
+#define IL_ST_BEGIN(kid) do { const unsigned st_w = IL_ST_INDEX; if (threadIdx.x == 0 && st_w < IL_ST_WGS) { il_st[kid][st_w][0] = __builtin_amdgcn_s_memrealtime(); il_st[kid][st_w][2] = ((unsigned long long)il_st_xcc() << 16) | ((il_st_hwid() >> 8) & 0xffu); il_st[kid][st_w][3] = 0ull; } } while (0)
+// (round 6) overlapped launches: when this workgroup's wait for the other stream's launch was satisfied (slot 3; 0 = the workgroup has no such wait)
+#define IL_ST_GATE(kid) do { const unsigned st_w = IL_ST_INDEX; if (threadIdx.x == 0 && st_w < IL_ST_WGS) il_st[kid][st_w][3] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define IL_ST_END(kid) do { __syncthreads(); const unsigned st_w = IL_ST_INDEX; if (threadIdx.x == 0 && st_w < IL_ST_WGS) il_st[kid][st_w][1] = __builtin_amdgcn_s_memrealtime(); } while (0)   // every thread of the workgroup passes here (bodies return, never s_endpgm): a workgroup's end = its last wave's
 // out_host [IL_ST_K][IL_ST_WGS][4]: only the rows of the kernel ids this translation unit owns are meaningful
 #define IL_ST_READER(name) extern "C" int name(unsigned long long* out_host) { return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(il_st), sizeof(il_st)) == hipSuccess ? 0 : 3; } \

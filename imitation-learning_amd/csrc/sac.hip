@@ -454,7 +454,7 @@ __device__ __forceinline__ void critic_bwd_resident_gemm(const il_sac& d, int k,
 }
 // relabel: the rewards of this tile are the discriminator `dd`'s prediction on (s, a) - the rows still sit in Xs - computed here once its AdamW step of
 // this update is complete ([IL_SYNC_PARAMS], n_reduce workgroups per step); otherwise dense `rewards` or the batch's own reward field.
-struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; int fwd_only; int wait_indices; int local_rewards; int xcd_nets, gather_wgs; int early_draw; };   // early_draw: publish [IL_SYNC_CHAIN_WGS] (IL_EARLY_DRAW=0: the resident sampler waits for the previous update's end, as in round 4)   // xcd_nets: grid = 8 * nt, one network per XCD (chain_decode_xcd); gather_wgs: row-copy workgroups among the blocks of XCDs 6, 7   // wait_indices: IL_FLAG_SAC_WAIT_INDICES; local_rewards: il_sac_update_gather without `rewards` / `relabel` (the ring's reward field: nothing to wait for)   // fwd_only: the forward kernels only (IL_FLAG_SAC_FORWARD_ONLY / data-parallel phase 0): no critic backward
+struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; int fwd_only; int wait_indices; int local_rewards; int xcd_nets, gather_wgs; int early_draw; int overlap; long long ov_n; };   // overlap (k_sac_chain_pair, il_sac_update_gather_overlap): the previous update's actor optimiser launch may still be running on the other stream - ov_n = this stage's own epoch (ov_own, set by the kernel) stands in for [IL_SYNC_MAIN_EPOCH] and the roles wait for [IL_SYNC_OV_EPOCH + IL_OV_DWA] >= ov_n where they first need what that launch writes   // early_draw: publish [IL_SYNC_CHAIN_WGS] (IL_EARLY_DRAW=0: the resident sampler waits for the previous update's end, as in round 4)   // xcd_nets: grid = 8 * nt, one network per XCD (chain_decode_xcd); gather_wgs: row-copy workgroups among the blocks of XCDs 6, 7   // wait_indices: IL_FLAG_SAC_WAIT_INDICES; local_rewards: il_sac_update_gather without `rewards` / `relabel` (the ring's reward field: nothing to wait for)   // fwd_only: the forward kernels only (IL_FLAG_SAC_FORWARD_ONLY / data-parallel phase 0): no critic backward
 // Runs between the critic's own work and its wait for the targets: the discriminator's step usually lands while the targets are still being computed,
 // so the relabel stays off the critical path. Leaves the tile's rewards in LDS (rew16) for critic_bwd_resident_scale.
 __device__ __forceinline__ void critic_relabel_tile(const il_sac& d, const ChainRelabel& rl, int k, int tile, float* smem) {
@@ -680,7 +680,9 @@ __host__ __device__ static inline int chain_pair_workgroups(int nt, int relabel,
 // LDS of a pair-mode tile: the tile kernels' carve (tile_lds_bytes) followed by W1s[H][Kpad + 4]
 __device__ __forceinline__ float* pair_w1s(float* smem, int in_pad, int H) { return smem + IL_TILE_R * (in_pad + 4) + 2 * IL_TILE_R * (H + 4) + (H >> 4) * 256 + 256 + 64; }
 // actor(s') of one tile as a pair (reference models.py:90-94 on next_states; training.py:21): the arithmetic of actor_fwd_tile(is_cur = false)
-__device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch& b, const float* __restrict__ eps_next, int tile, int half, float* smem, float* slab, unsigned* flag) {
+// ov >= 0 (overlapped launches): the previous update's actor optimiser launch may still be running. The row indices and the rows are requested first; everything that launch
+// writes (the actor's parameters and lane-ordered copy, the Philox counter) is requested behind the wait for its epoch.
+__device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch& b, const float* __restrict__ eps_next, int tile, int half, float* smem, float* slab, unsigned* flag, long long ov = -1) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
   const int row0 = tile * IL_TILE_R;
   const int Sp = round_up16(S), ldx = Sp + 4, ldh = H + 4, ldw1 = Sp + 4;
@@ -698,6 +700,13 @@ __device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch&
   const int hr = tid / A, hc = tid - hr * A;
   int64_t hidx = row0 + min(hr, IL_TILE_R - 1);
   if (head_thread && b.gather) hidx = gload(b.gather + row0 + hr);
+  float absorb_pre = 0.f;
+  if (ov >= 0) {   // rows first, then the wait; the weights behind it
+    rows_issue(rp, Sp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, b.gather != nullptr, b.gather_capacity, false);
+    if (head_thread) { if (b.gather) hidx = hidx < 0 ? 0 : (hidx >= b.gather_capacity ? b.gather_capacity - 1 : hidx); absorb_pre = gload(b.absorbing + (size_t)hidx * b.ld_absorbing); }
+    ov_wait(reinterpret_cast<long long*>(d.sync), IL_OV_DWA, ov);
+    IL_ST_GATE(IL_ST_CHAIN);
+  }
   const int w1_lanes = H * S / 4;
   const bool w1_regs = l1_rows_aligned(net.W1, S);
   W1Pre w1; L1Pre w1r;
@@ -705,9 +714,10 @@ __device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch&
   const float pb1a = gload(net.b1 + wave * 16 + j), pb1b = gload(net.b1 + min((wave + nw) * 16 + j, H - 1)), pb2 = gload(net.b2 + t2 * 16 + j);
   const uint32_t nctr = (half == 0 && d.noise_counter) ? gload(d.noise_counter) : 0u;
   __builtin_amdgcn_sched_barrier(0);
-  rows_issue(rp, Sp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, b.gather != nullptr, b.gather_capacity, false);
-  float absorb_pre = 0.f;
-  if (head_thread) { if (b.gather) hidx = hidx < 0 ? 0 : (hidx >= b.gather_capacity ? b.gather_capacity - 1 : hidx); absorb_pre = gload(b.absorbing + (size_t)hidx * b.ld_absorbing); }
+  if (ov < 0) {
+    rows_issue(rp, Sp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, b.gather != nullptr, b.gather_capacity, false);
+    if (head_thread) { if (b.gather) hidx = hidx < 0 ? 0 : (hidx >= b.gather_capacity ? b.gather_capacity - 1 : hidx); absorb_pre = gload(b.absorbing + (size_t)hidx * b.ld_absorbing); }
+  }
   SmallPre w3pre = {};
   if (half == 0) w3pre = tile_fwd_small_prefetch(net.W3, H, 2 * A, H);
   // Only the FIRST HALF of the hidden layer's panel is requested here (panel_prefetch_lo), behind every wave's small loads (issue_fence): a wave that issues 16 KB of
@@ -771,7 +781,7 @@ __device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch&
 }
 
 // target_k(s', a') of one tile as a pair (training.py:22): the arithmetic of critic_fwd_tile(net = 2 + k, await)
-__device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, int k, int tile, int half, float* smem, float* slab, unsigned* flag, unsigned* ctr) {
+__device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, int k, int tile, int half, float* smem, float* slab, unsigned* flag, unsigned* ctr, long long ov = -1) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int row0 = tile * IL_TILE_R;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
@@ -784,6 +794,11 @@ __device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, 
   const int t2 = 8 * half + wave;
   if (half == 0) pair_announce(flag);
   RowsPre rp; rows_idx(rp, INp, row0, b.gather);
+  if (ov >= 0) {   // overlapped launches: the target network is being stepped by the previous update's tail - rows first, its parameters behind the wait
+    rows_issue(rp, INp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, b.gather != nullptr, b.gather_capacity, false);
+    ov_wait(reinterpret_cast<long long*>(d.sync), IL_OV_DWA, ov);
+    IL_ST_GATE(IL_ST_CHAIN);
+  }
   const bool w1_regs = l1_rows_aligned(p.W1, IN);   // (wave-uniform) aligned rows: operand lanes straight into registers; otherwise through LDS
   W1Pre w1; L1Pre w1r;
   if (w1_regs) l1_prefetch(w1r, p.W1, IN, INp, H); else w1_issue(w1, p.W1, w1_lanes);
@@ -792,7 +807,7 @@ __device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, 
 #pragma unroll
   for (int u = 0; u < 4; ++u) w3v[u] = gload(p.W3 + min(lane + 64 * u, H - 1));
   __builtin_amdgcn_sched_barrier(0);
-  rows_issue(rp, INp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, b.gather != nullptr, b.gather_capacity, false);   // s' columns, zero elsewhere
+  if (ov < 0) rows_issue(rp, INp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, b.gather != nullptr, b.gather_capacity, false);   // s' columns, zero elsewhere
   issue_fence();
   Panel16 pn; panel_prefetch(pn, W + ws.pk_tf + (size_t)k * H * H, t2);   // (this workgroup is about to wait for its tile's actor(s'): being held at the issue stage costs nothing here)
   if (!w1_regs) w1_commit(w1, W1s, ldw1, IN, INp, H, w1_lanes);
@@ -848,7 +863,7 @@ __device__ __forceinline__ void relabel_role(const il_sac& d, const il_batch& b,
   load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R, b.gather, b.gather_capacity);
   long long* sy = reinterpret_cast<long long*>(d.sync);
   IL_TL(10, 1);
-  sync_wait(sy, IL_SYNC_PARAMS, (sy[IL_SYNC_MAIN_EPOCH] + 1) * (long long)rl.n_reduce);   // (its barrier also covers the rows above)
+  sync_wait(sy, IL_SYNC_PARAMS, ((rl.overlap ? rl.ov_n : sy[IL_SYNC_MAIN_EPOCH]) + 1) * (long long)rl.n_reduce);   // (its barrier also covers the rows above)
   IL_TL(10, 2);
   const RewardLds R = reward_carve(q16 + 64, rl.dd.state_dim + rl.dd.action_dim, rl.dd.hidden);
   disc_reward_tile<3>(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
@@ -863,7 +878,9 @@ __device__ __forceinline__ void sac_chain_pair_body(il_sac& d, il_batch& b, cons
   const int nt = d.batch / IL_TILE_R, H = d.hidden;
   const PairIds id = chain_pair_decode(blockIdx.x, nt, rl.on);
   IL_TL(10, 0);
-  if (rl.wait_indices) { long long* sy = reinterpret_cast<long long*>(d.sync); sync_wait(sy, IL_SYNC_INDICES, sy[IL_SYNC_MAIN_EPOCH] + 1); }
+  long long* sy = reinterpret_cast<long long*>(d.sync);
+  const long long ov = rl.overlap ? rl.ov_n : -1;   // >= 0: [IL_SYNC_MAIN_EPOCH] may not count the previous update yet (its last launch is still running on the other stream)
+  if (rl.wait_indices) sync_wait(sy, IL_SYNC_INDICES, (ov >= 0 ? ov : sy[IL_SYNC_MAIN_EPOCH]) + 1);
   if (id.role == 5) {
     const int G = (int)gridDim.x - chain_pair_workgroups(nt, rl.on, 0), gw = id.tile;
     const int row4 = b.ld_states / 4, lanes = d.batch * row4;
@@ -883,10 +900,10 @@ __device__ __forceinline__ void sac_chain_pair_body(il_sac& d, il_batch& b, cons
   float* slab = d.workspace + ws.x_slab + (size_t)slot * IL_TILE_R * (H / 2);
   unsigned* flag = reinterpret_cast<unsigned*>(d.workspace + ws.x_flag) + slot * IL_CTR_STRIDE;
   if (id.role == 0) {
-    actor_next_pair(d, b, eps_next, id.tile, id.half, smem, slab, flag);
+    actor_next_pair(d, b, eps_next, id.tile, id.half, smem, slab, flag, ov);
     if (id.half == 0) { tile_arrive_through(ctr, 1u); IL_TL(10, 7); }
   } else if (id.role == 1) {
-    target_pair(d, b, id.net, id.tile, id.half, smem, slab, flag, ctr);
+    target_pair(d, b, id.net, id.tile, id.half, smem, slab, flag, ctr, ov);
     if (id.half == 0) { tile_arrive_through(ctr, 1u); IL_TL(10, 7); }
   } else if (id.role == 4) {
     relabel_role(d, b, rl, id.tile, smem);
@@ -897,13 +914,18 @@ __device__ __forceinline__ void sac_chain_pair_body(il_sac& d, il_batch& b, cons
     IL_TL(10, 2);
     critic_bwd_resident_gemm(d, id.net, smem);
     IL_TL(10, 3);
+    // overlapped launches: the critics' own parameters were stepped two launches ago (visible since this launch began); log alpha, read below, is the previous tail's
+    if (ov >= 0) { ov_wait(sy, IL_OV_DWA, ov); IL_ST_GATE(IL_ST_CHAIN); }
     const RowScalars rs = critic_row_scalars(b, !rl.on && !rewards && !d.sync, id.tile);
     tile_await_bits<false>(ctr, 3u, rl.on ? 16u : 0u, tile_timeouts(d));   // (no acquire: what this workgroup reads of the tile's producers was written through, critic_bwd_resident_scale reads it below the L1)
     IL_TL(10, 5);
     if (threadIdx.x == 0 && (__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 15u) == 4u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     critic_bwd_resident_scale(d, b, rewards, rl, rs, id.net, id.tile, smem, rl.on ? d.workspace + ws.c_rew : nullptr, true);
     IL_TL(10, 7);
-  } else { actor_fwd_tile(d, b, eps_next, eps_cur, true, id.tile, smem); IL_TL(10, 7); }
+  } else {
+    if (ov >= 0) { ov_wait(sy, IL_OV_DWA, ov); IL_ST_GATE(IL_ST_CHAIN); }   // actor(s): the previous actor optimiser launch reads the buffers this role writes, and writes the weights it reads
+    actor_fwd_tile(d, b, eps_next, eps_cur, true, id.tile, smem); IL_TL(10, 7);
+  }
 }
 
 __global__ __launch_bounds__(512) void k_sac_chain_pair(il_sac d, il_batch b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, const float* __restrict__ rewards,
@@ -913,9 +935,11 @@ __global__ __launch_bounds__(512) void k_sac_chain_pair(il_sac d, il_batch b, co
   if (rl.on) { globalize(rl.dd); rl.out = as_global(rl.out); }
   IL_ST_BEGIN(IL_ST_CHAIN);
   chain_publish_grid(d, rl.early_draw);
+  if (rl.overlap) rl.ov_n = ov_own(reinterpret_cast<long long*>(d.sync), IL_OV_CHAIN);
   sac_chain_pair_body(d, b, eps_next, eps_cur, rewards, rows_out, rl, smem);
   IL_ST_END(IL_ST_CHAIN);
   chain_done(d, rl.early_draw);
+  if (rl.overlap) ov_done(reinterpret_cast<long long*>(d.sync), IL_OV_CHAIN);
 }
 
 // policy-loss backward of one 16-row tile: min-Q selection, tanh-Gaussian backward, actor back-prop (dz3, dz2, dz1 for the dW kernel), alpha partial.
@@ -1232,7 +1256,9 @@ IL_TILE_KERNELS(_pop, IL_POP_PANEL, __launch_bounds__(512, IL_POP_WAVES_PER_EU))
 // sends its half of dz1 and exits, half 0 runs the dQ/da columns and arrives on the tile's counter. Helpers as in k_policy_critic. Block order: critics p = 1, p = 0,
 // helpers. A pair waits for each other: both halves must be resident - (4 + helpers) * nt <= CUs is checked by the caller. Bit-identical to k_policy_critic.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_batch& b, int k, int tile, int half, float* smem) {
+// ov >= 0 (overlapped launches): the critic optimiser launch of this update may still be running on the other stream - the rows ((s, a~): written by the forward launch that
+// precedes this one in its stream) are requested first, the critic's parameters behind the wait for that launch's epoch.
+__device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_batch& b, int k, int tile, int half, float* smem, long long ov = -1) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R, row0 = tile * IL_TILE_R;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
@@ -1252,10 +1278,15 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
   IL_TL(11, 0);
   pair_announce(flags + (size_t)(sa + 1 - half) * IL_CTR_STRIDE);   // consumer of the partner's h2 half ...
   RowsPre rp; rows_idx(rp, INp, row0, nullptr);
+  if (ov >= 0) {
+    rows_issue(rp, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, false, 0, true);
+    ov_wait(reinterpret_cast<long long*>(d.sync), IL_OV_DWC, ov + 1);
+    IL_ST_GATE(IL_ST_POLICY_CRITIC);
+  }
   const bool w1_regs = l1_rows_aligned(p.W1, IN);
   W1Pre w1; L1Pre w1r;
   if (w1_regs) l1_prefetch(w1r, p.W1, IN, INp, H); else w1_issue(w1, p.W1, w1_lanes);
-  rows_issue(rp, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, false, 0, true);
+  if (ov < 0) rows_issue(rp, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, false, 0, true);
   const float pb1a = gload(p.b1 + wave * 16 + j), pb1b = gload(p.b1 + min((wave + nw) * 16 + j, H - 1)), pb2 = gload(p.b2 + t2 * 16 + j), pb3 = gload(p.b3);
   float w3v[4];
 #pragma unroll
@@ -1352,11 +1383,13 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
   IL_TL(11, 7);
 }
 
-__global__ __launch_bounds__(512) void k_policy_critic_pair(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, int helpers) {
+__global__ __launch_bounds__(512) void k_policy_critic_pair(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, int helpers, int overlap) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   globalize(d); globalize(b);
   IL_ST_BEGIN(IL_ST_POLICY_CRITIC);
   const int nt = d.batch / IL_TILE_R, bx = blockIdx.x;
+  long long* osy = reinterpret_cast<long long*>(d.sync);
+  const long long ov = overlap ? ov_own(osy, IL_OV_PC) : -1;   // (helpers need nothing of the critic optimiser launch: they wait for this launch's critic workgroups)
   if (bx >= 4 * nt) {   // helper: behind both critics' pairs of its tile in block order
     const int h = bx - 4 * nt, tile = h % nt, part = h / nt;
     const SacWs ws = sac_ws(d.state_dim, d.action_dim, d.hidden, d.batch);
@@ -1382,13 +1415,15 @@ __global__ __launch_bounds__(512) void k_policy_critic_pair(il_sac d, il_batch b
     else actor_bwd_tile<16, false, true>(d, b, tile, out_logp, out_q, smem, part, helpers, wait);
     IL_TL_END(3);
     IL_ST_END(IL_ST_POLICY_CRITIC);
+    if (overlap) ov_done(osy, IL_OV_PC);
     return;
   }
   const int half = bx < 2 * nt ? 1 : 0;
   int k, tile;
   seg_decode(bx % (2 * nt), nt, 2, k, tile);
-  policy_critic_pair(d, b, k, tile, half, smem);
+  policy_critic_pair(d, b, k, tile, half, smem, ov);
   IL_ST_END(IL_ST_POLICY_CRITIC);
+  if (overlap) ov_done(osy, IL_OV_PC);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1441,7 +1476,20 @@ struct DwArgs {
   // writes target / pk_target from the new parameters in its registers); `polyak_fused` (actor launch's tail: skips the two networks' H x H ranges
   // and the lane-ordered copies, and steps the rest of the arena element by element at the ranges' edges)
   int fuse_polyak, polyak_fused;
+  // (round 6) overlapped launches (il_sac_update_gather_overlap): 0 = off; otherwise 1 + this launch's stage (IL_OV_DWC / IL_OV_DWA). The launch is resident while the
+  // launch that produces its dZ / activations (stage - 1, on the other stream) still runs: block jobs request their p / m / v lanes, the tail's target step runs, and only
+  // then they wait for [IL_SYNC_OV_EPOCH + stage - 1] > own epoch. `sync` is set for both launches in this mode.
+  int ov_stage;
 };
+template <bool STAMP = false>   // STAMP: the single-learner kernel records when the wait was satisfied (IL_ST_GATE)
+__device__ __forceinline__ void dw_ov_wait(const DwArgs& a) {   // all threads of the workgroup
+  const int stage = __builtin_amdgcn_readfirstlane(a.ov_stage);   // (wave-uniform by construction; a population launch builds its DwArgs from a descriptor it loaded)
+  if (stage) {
+    long long* sy = reinterpret_cast<long long*>(a.sync); const int st = stage - 1;
+    ov_wait(sy, st - 1, ov_own(sy, st) + 1);
+    if (STAMP) IL_ST_GATE(st == IL_OV_DWA ? IL_ST_DW_ACTOR : IL_ST_DW_CRITIC);
+  }
+}
 // data-parallel: the gradient exchange of an optimiser step rides in its block jobs (peer_device.hpp "the exchange INSIDE the kernel that produces the gradients"): job = the
 // block job's index (the log-alpha step: n_big_blocks). A kernel argument of its own, and a kernel of its own (k_dw_adam_peer: the functions below are templated on PEER):
 // the descriptor's window array is indexed at run time, which sends whatever struct holds it to scratch memory - inside DwArgs that cost the single-GPU k_dw_adam
@@ -1587,110 +1635,123 @@ __device__ __forceinline__ void dw_bias(const DwArgs& a, const adam_consts& ac, 
   if (g == 0 && n0 + j < Nvalid) adam_store(a, ac, poff + n0 + j, s);
 }
 
+template <bool PEER>
+__device__ __forceinline__ void dw_tail_alpha(const DwArgs& a, const DwPeer* pp) {   // tail block 0: Adam(log alpha), the Philox counter, the end-of-update signal (one thread)
+  if (a.log_alpha && threadIdx.x == 0) {
+    float s = 0.f;
+    int i0 = 0;
+#if IL_DW_SCHED_BARRIER
+    for (; i0 + 16 <= a.n_alpha_part; i0 += 16) {   // one thread, B / 16 partials: requested together, added in index order (as a plain loop: one dependent round trip per partial)
+      float t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = gload(a.alpha_part + i0 + u);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += t[u];
+    }
+#endif
+    for (int i = i0; i < a.n_alpha_part; ++i) s += a.alpha_part[i];
+    const float alpha = expf(a.log_alpha[0]);
+    float gr = -(alpha) * (s / (float)a.batch);
+    if (PEER) gr = peer_thread_allreduce1(pp->x, a.n_big_blocks, pp->alpha_at, gr);   // data-parallel: the mean over the ranks (its own arrival line behind the block jobs')
+    if (a.grads_only) a.alpha_grad[0] = gr;
+    else {
+      const adam_consts ac = load_adam_consts(a.alpha_opt);
+      float pp = a.log_alpha[0], mm = a.alpha_opt.m[0], vv = a.alpha_opt.v[0];
+      adam_update(pp, gr, mm, vv, ac);
+      a.log_alpha[0] = pp; a.alpha_opt.m[0] = mm; a.alpha_opt.v[0] = vv;
+    }
+    if (a.noise_counter) a.noise_counter[0] += 1;
+    // this update's SAC half is done. Release: the resident sampler and, behind it, the discriminator kernels of the NEXT update start from this signal and read the noise counter bumped above
+    if (a.sync) __hip_atomic_fetch_add(reinterpret_cast<long long*>(a.sync) + IL_SYNC_MAIN_EPOCH, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ void dw_tail_polyak(const DwArgs& a, const int tb, const int ntb) {   // every tail block: target <- tau target + (1 - tau) critic
+  if (a.target && !a.grads_only) {
+    const float omt = (float)(1.0 - a.tau), tau = (float)a.tau;
+#if IL_DW_SCHED_BARRIER
+    // (round 3) target <- tau target + (1 - tau) critic over the parameter arena AND its lane-ordered copies as ONE index space of 16-byte lanes, four lanes per thread
+    // and trip with all eight loads requested first: the grid-stride loops below were a dependent HBM round trip per trip (the target was last touched an update ago),
+    // 8 trips per thread with 33 tail blocks. Elementwise: the bits do not depend on who computes which lane.
+    if ((a.polyak_n & 3) == 0 && (!a.pk_target || (a.pk_n & 3) == 0) && !a.polyak_fused) {
+      const int64_t n1 = a.polyak_n >> 2, n2 = a.pk_target ? (a.pk_n >> 2) : 0, stride = (int64_t)ntb * blockDim.x;
+      for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < n1 + n2; i += 4 * stride) {
+        f32x4 t[4], p[4]; f32x4* dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t q = i + u * stride, qc = q < n1 + n2 ? q : i;   // out of range: re-read lane i, never stored
+          const bool second = qc >= n1;
+          dst[u] = reinterpret_cast<f32x4*>(second ? a.pk_target : a.target) + (second ? qc - n1 : qc);
+          t[u] = *dst[u]; p[u] = *(reinterpret_cast<const f32x4*>(second ? a.pk_critic : a.polyak_src) + (second ? qc - n1 : qc));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t[u][q] = __fadd_rn(__fmul_rn(t[u][q], tau), __fmul_rn(omt, p[u][q]));
+          if (i + u * stride < n1 + n2) {
+#if IL_DW_STORE_MODE == 2 && IL_POLYAK_WT
+            const int64_t q2 = i + u * stride;   // written through like p / m / v: the target network is not read again before the next update's forward
+            if (q2 >= n1) wstore4(a.pk_target, (q2 - n1) * 4, t[u]); else wstore4(a.target, q2 * 4, t[u]);
+#else
+            *dst[u] = t[u];
+#endif
+          }
+        }
+      }
+      return;
+    }
+#endif
+    for (int64_t i = ((int64_t)tb * blockDim.x + threadIdx.x) * 4; i < a.polyak_n; i += (int64_t)ntb * blockDim.x * 4) {
+      if (a.polyak_fused) {   // the H x H layers were stepped by the critic launch's blocks: whole lanes inside them are skipped, lanes at their edges go element by element
+        // (the twin critic's layout from what the tail knows: polyak_n = 2 strides, stride = H IN + H | H H | H | H | 1 rounded up to a multiple of 4 floats)
+        const int64_t fz_stride = a.polyak_n >> 1, fz_hh = (int64_t)a.hidden * a.hidden;
+        const int64_t fz_w2_off = ((fz_stride - fz_hh - 3 * a.hidden - 1) / a.hidden) * a.hidden + a.hidden;
+        int inr = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t r0 = i + q - fz_w2_off, r1 = r0 - fz_stride;
+          inr |= ((r0 >= 0 && r0 < fz_hh) || (r1 >= 0 && r1 < fz_hh)) ? (1 << q) : 0;
+        }
+        if (inr == 15) continue;
+        if (inr != 0) {
+          for (int q = 0; q < 4; ++q)
+            if (i + q < a.polyak_n && !((inr >> q) & 1)) a.target[i + q] = __fadd_rn(__fmul_rn(a.target[i + q], tau), __fmul_rn(omt, a.polyak_src[i + q]));
+          continue;
+        }
+      }
+      if (i + 3 < a.polyak_n) {
+        f32x4 t = *reinterpret_cast<f32x4*>(a.target + i); const f32x4 p = *reinterpret_cast<const f32x4*>(a.polyak_src + i);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = __fadd_rn(__fmul_rn(t[q], tau), __fmul_rn(omt, p[q]));
+        *reinterpret_cast<f32x4*>(a.target + i) = t;
+      } else {
+        for (int64_t q = i; q < a.polyak_n; ++q) a.target[q] = __fadd_rn(__fmul_rn(a.target[q], tau), __fmul_rn(omt, a.polyak_src[q]));
+      }
+    }
+    if (a.pk_target)
+      for (int64_t i = ((int64_t)tb * blockDim.x + threadIdx.x) * 4; i < a.pk_n; i += (int64_t)ntb * blockDim.x * 4) {
+        f32x4 t = *reinterpret_cast<f32x4*>(a.pk_target + i); const f32x4 p = *reinterpret_cast<const f32x4*>(a.pk_critic + i);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = __fadd_rn(__fmul_rn(t[q], tau), __fmul_rn(omt, p[q]));
+        *reinterpret_cast<f32x4*>(a.pk_target + i) = t;
+      }
+  }
+}
 template <int U, bool SKIPBIG = false, bool PEER = false>   // SKIPBIG: the H x H layers are done by dw_block64 workgroups of the same launch (population path)
 __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, const int nblocks, const DwPeer* pp = nullptr) {   // bid / nblocks: this learner's block index / count
   const int wave_in_block = threadIdx.x >> 6;
   if (bid >= a.n_dw_blocks) {  // ---- tail blocks
     const int tb = bid - a.n_dw_blocks;
-    if (a.log_alpha && tb == 0 && threadIdx.x == 0) {
-      float s = 0.f;
-      int i0 = 0;
-#if IL_DW_SCHED_BARRIER
-      for (; i0 + 16 <= a.n_alpha_part; i0 += 16) {   // one thread, B / 16 partials: requested together, added in index order (as a plain loop: one dependent round trip per partial)
-        float t[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) t[u] = gload(a.alpha_part + i0 + u);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 16; ++u) s += t[u];
-      }
-#endif
-      for (int i = i0; i < a.n_alpha_part; ++i) s += a.alpha_part[i];
-      const float alpha = expf(a.log_alpha[0]);
-      float gr = -(alpha) * (s / (float)a.batch);
-      if (PEER) gr = peer_thread_allreduce1(pp->x, a.n_big_blocks, pp->alpha_at, gr);   // data-parallel: the mean over the ranks (its own arrival line behind the block jobs')
-      if (a.grads_only) a.alpha_grad[0] = gr;
-      else {
-        const adam_consts ac = load_adam_consts(a.alpha_opt);
-        float pp = a.log_alpha[0], mm = a.alpha_opt.m[0], vv = a.alpha_opt.v[0];
-        adam_update(pp, gr, mm, vv, ac);
-        a.log_alpha[0] = pp; a.alpha_opt.m[0] = mm; a.alpha_opt.v[0] = vv;
-      }
-      if (a.noise_counter) a.noise_counter[0] += 1;
-      // this update's SAC half is done. Release: the resident sampler and, behind it, the discriminator kernels of the NEXT update start from this signal and read the noise counter bumped above
-      if (a.sync) __hip_atomic_fetch_add(reinterpret_cast<long long*>(a.sync) + IL_SYNC_MAIN_EPOCH, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // overlapped launches: the target step needs nothing of the launch this one waits for (the critics were stepped by this stream's previous launch, the targets' last
+    // readers are gone) - it runs while that launch is still busy; block 0 then waits and closes the update (Adam(log alpha), Philox counter, [IL_SYNC_MAIN_EPOCH])
+    if (a.ov_stage) {
+      dw_tail_polyak(a, tb, nblocks - a.n_dw_blocks);
+      if (tb == 0) { dw_ov_wait(a); dw_tail_alpha<PEER>(a, pp); }
+      return;
     }
-    if (a.target && !a.grads_only) {
-      const float omt = (float)(1.0 - a.tau), tau = (float)a.tau;
-      const int ntb = nblocks - a.n_dw_blocks;
-#if IL_DW_SCHED_BARRIER
-      // (round 3) target <- tau target + (1 - tau) critic over the parameter arena AND its lane-ordered copies as ONE index space of 16-byte lanes, four lanes per thread
-      // and trip with all eight loads requested first: the grid-stride loops below were a dependent HBM round trip per trip (the target was last touched an update ago),
-      // 8 trips per thread with 33 tail blocks. Elementwise: the bits do not depend on who computes which lane.
-      if ((a.polyak_n & 3) == 0 && (!a.pk_target || (a.pk_n & 3) == 0) && !a.polyak_fused) {
-        const int64_t n1 = a.polyak_n >> 2, n2 = a.pk_target ? (a.pk_n >> 2) : 0, stride = (int64_t)ntb * blockDim.x;
-        for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < n1 + n2; i += 4 * stride) {
-          f32x4 t[4], p[4]; f32x4* dst[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int64_t q = i + u * stride, qc = q < n1 + n2 ? q : i;   // out of range: re-read lane i, never stored
-            const bool second = qc >= n1;
-            dst[u] = reinterpret_cast<f32x4*>(second ? a.pk_target : a.target) + (second ? qc - n1 : qc);
-            t[u] = *dst[u]; p[u] = *(reinterpret_cast<const f32x4*>(second ? a.pk_critic : a.polyak_src) + (second ? qc - n1 : qc));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) t[u][q] = __fadd_rn(__fmul_rn(t[u][q], tau), __fmul_rn(omt, p[u][q]));
-            if (i + u * stride < n1 + n2) {
-#if IL_DW_STORE_MODE == 2 && IL_POLYAK_WT
-              const int64_t q2 = i + u * stride;   // written through like p / m / v: the target network is not read again before the next update's forward
-              if (q2 >= n1) wstore4(a.pk_target, (q2 - n1) * 4, t[u]); else wstore4(a.target, q2 * 4, t[u]);
-#else
-              *dst[u] = t[u];
-#endif
-            }
-          }
-        }
-        return;
-      }
-#endif
-      for (int64_t i = ((int64_t)tb * blockDim.x + threadIdx.x) * 4; i < a.polyak_n; i += (int64_t)ntb * blockDim.x * 4) {
-        if (a.polyak_fused) {   // the H x H layers were stepped by the critic launch's blocks: whole lanes inside them are skipped, lanes at their edges go element by element
-          // (the twin critic's layout from what the tail knows: polyak_n = 2 strides, stride = H IN + H | H H | H | H | 1 rounded up to a multiple of 4 floats)
-          const int64_t fz_stride = a.polyak_n >> 1, fz_hh = (int64_t)a.hidden * a.hidden;
-          const int64_t fz_w2_off = ((fz_stride - fz_hh - 3 * a.hidden - 1) / a.hidden) * a.hidden + a.hidden;
-          int inr = 0;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int64_t r0 = i + q - fz_w2_off, r1 = r0 - fz_stride;
-            inr |= ((r0 >= 0 && r0 < fz_hh) || (r1 >= 0 && r1 < fz_hh)) ? (1 << q) : 0;
-          }
-          if (inr == 15) continue;
-          if (inr != 0) {
-            for (int q = 0; q < 4; ++q)
-              if (i + q < a.polyak_n && !((inr >> q) & 1)) a.target[i + q] = __fadd_rn(__fmul_rn(a.target[i + q], tau), __fmul_rn(omt, a.polyak_src[i + q]));
-            continue;
-          }
-        }
-        if (i + 3 < a.polyak_n) {
-          f32x4 t = *reinterpret_cast<f32x4*>(a.target + i); const f32x4 p = *reinterpret_cast<const f32x4*>(a.polyak_src + i);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) t[q] = __fadd_rn(__fmul_rn(t[q], tau), __fmul_rn(omt, p[q]));
-          *reinterpret_cast<f32x4*>(a.target + i) = t;
-        } else {
-          for (int64_t q = i; q < a.polyak_n; ++q) a.target[q] = __fadd_rn(__fmul_rn(a.target[q], tau), __fmul_rn(omt, a.polyak_src[q]));
-        }
-      }
-      if (a.pk_target)
-        for (int64_t i = ((int64_t)tb * blockDim.x + threadIdx.x) * 4; i < a.pk_n; i += (int64_t)ntb * blockDim.x * 4) {
-          f32x4 t = *reinterpret_cast<f32x4*>(a.pk_target + i); const f32x4 p = *reinterpret_cast<const f32x4*>(a.pk_critic + i);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) t[q] = __fadd_rn(__fmul_rn(t[q], tau), __fmul_rn(omt, p[q]));
-          *reinterpret_cast<f32x4*>(a.pk_target + i) = t;
-        }
-    }
+    if (tb == 0) dw_tail_alpha<PEER>(a, pp);
+    dw_tail_polyak(a, tb, nblocks - a.n_dw_blocks);
     return;
   }
   // ---- job decode (wave-uniform)
@@ -1914,7 +1975,7 @@ static inline int dw_block64_count(int H, int nets) { return (H / DWB) * (H / DW
 // then the four g as (g0 + g1) + (g2 + g3)), so the bias keeps its bits too. With it a network's whole optimiser step is nbh^2 + 2 nbh uniform workgroups (H = 256: 80)
 // and no wave-per-tile job is left: those were 72 % of the launch's line requests (32 KB of half-line gathers each).
 // `boff` >= 0: parameter offset of the bias of this dZ (only looked at by blocks with k0 == 0).
-template <bool PEER = false>
+template <bool PEER = false, bool GATE = false>
 __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restrict__ dzT, int Nvalid, const float* __restrict__ xT, int Kvalid, int n0, int k0, int64_t poff,
                                            int64_t boff, float* __restrict__ pkf, float* __restrict__ pkb, float* smem, const DwPeer* pp = nullptr, int pjob = -1) {
   float* Zs = smem; float* Xs = smem + DWS * DWS_LD;
@@ -1951,6 +2012,7 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
   const bool bias_owner = do_bias && tid < 128 && bg == 0 && n0 + bf < Nvalid;
   float bpp = 0.f, bmm = 0.f, bvv = 0.f;
   if (bias_owner && !a.grads_only) { const int64_t o = boff + n0 + bf; bpp = gload(a.params + o); bmm = gload(a.opt.m + o); bvv = gload(a.opt.v + o); }   // the bias's Adam operands: with the block's, up front
+  dw_ov_wait<GATE>(a);   // overlapped launches: dZ / the activations are still being written by the other stream's launch; p / m / v are on their way meanwhile
   f32x4 acc0 = zero4(), acc1 = zero4();
   for (int r0 = 0; r0 < B; r0 += 2 * DWS_ROWS) {   // two chunks per trip, all their loads in flight together (B = 256: one trip)
     f32x4 zr[2][4], xr[2][4];
@@ -2075,7 +2137,7 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
 // One network's optimiser step as uniform block jobs: [0, nbh^2) the H x H layer (bias 2 with the k0 = 0 blocks), then nbh x kin blocks of layer 1 (bias 1), then
 // nout x nbh blocks of layer 3 (bias 3). Returns false when `job` is past the network's list.
 __host__ __device__ static inline int dw_block_jobs(int IN, int H, int OUT) { const int nbh = H / DWS; return nbh * nbh + nbh * ((IN + DWS - 1) / DWS) + ((OUT + DWS - 1) / DWS) * nbh; }
-template <bool PEER = false>
+template <bool PEER = false, bool GATE = false>
 __device__ __forceinline__ void dw_block_job(const DwArgs& a, int net, int job, float* smem, const DwPeer* pp = nullptr, int pjob = -1) {
   const int IN = a.in_dim, H = a.hidden, OUT = a.out_dim, nbh = H / DWS, kin = (IN + DWS - 1) / DWS;
   const int64_t pbase = (int64_t)net * a.net_stride;
@@ -2091,13 +2153,13 @@ __device__ __forceinline__ void dw_block_job(const DwArgs& a, int net, int job, 
       const int x = job & 7, slot = job >> 3;
       nb = 2 * (x >> 1) + (slot >> 2); kb = 4 * (x & 1) + (slot & 3);
     }
-    dw_block32<PEER>(a, dz2, H, h1, H, nb * DWS, kb * DWS, oW2, ob2, a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem, pp, pjob);
+    dw_block32<PEER, GATE>(a, dz2, H, h1, H, nb * DWS, kb * DWS, oW2, ob2, a.pk_f ? a.pk_f + (size_t)net * H * H : nullptr, a.pk_b ? a.pk_b + (size_t)net * H * H : nullptr, smem, pp, pjob);
     return;
   }
   job -= nbh * nbh;
-  if (job < nbh * kin) { dw_block32<PEER>(a, dz1, H, a.x0 + net * a.x0_net_stride, IN, (job / kin) * DWS, (job % kin) * DWS, oW1, ob1, nullptr, nullptr, smem, pp, pjob); return; }
+  if (job < nbh * kin) { dw_block32<PEER, GATE>(a, dz1, H, a.x0 + net * a.x0_net_stride, IN, (job / kin) * DWS, (job % kin) * DWS, oW1, ob1, nullptr, nullptr, smem, pp, pjob); return; }
   job -= nbh * kin;
-  dw_block32<PEER>(a, a.dz3 + net * a.dz3_net_stride, OUT, h2, H, (job / nbh) * DWS, (job % nbh) * DWS, oW3, ob3, nullptr, nullptr, smem, pp, pjob);
+  dw_block32<PEER, GATE>(a, a.dz3 + net * a.dz3_net_stride, OUT, h2, H, (job / nbh) * DWS, (job % nbh) * DWS, oW3, ob3, nullptr, nullptr, smem, pp, pjob);
 }
 static inline int dw_block32_count(int H, int nets) { return (H / DWS) * (H / DWS) * nets; }
 static inline bool dw_block32_fits(int H, int B) { return H % DWS == 0 && B % DWS_ROWS == 0; }
@@ -2114,6 +2176,7 @@ __device__ __forceinline__ void dw_adam_kernel(const DwArgs& a, const DwPeer* pp
       dw_block_job<PEER>(a, bx / per_net, bx % per_net, smem, pp, bx);
       IL_TL_END(a.log_alpha ? 2 : 1);
       IL_ST_END(st_kid);
+      if (a.ov_stage) ov_done(reinterpret_cast<long long*>(a.sync), a.ov_stage - 1);
       return;
     }
     DwArgs r = a;
@@ -2121,15 +2184,46 @@ __device__ __forceinline__ void dw_adam_kernel(const DwArgs& a, const DwPeer* pp
     dw_adam_body<IL_DW_U, true, PEER>(r, bx - a.n_big_blocks, (int)gridDim.x - a.n_big_blocks, pp);
     IL_TL_END(a.log_alpha ? 2 : 1);
     IL_ST_END(st_kid);
+    if (a.ov_stage) ov_done(reinterpret_cast<long long*>(a.sync), a.ov_stage - 1);
     return;
   }
   dw_adam_body<IL_DW_U>(a, (int)blockIdx.x, (int)gridDim.x);
   IL_TL_END(a.log_alpha ? 2 : 1);
   IL_ST_END(st_kid);
 }
-__global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {
+// (round 6) Two kernels instead of one: the wave-per-tile jobs (dw_tile with 16 operand lanes in flight) cost 256 VGPRs + AGPRs, i.e. ONE workgroup per CU and none beside a
+// pair-mode workgroup - which did not matter while an optimiser launch had the chip to itself, but an overlapped launch (il_sac_update_gather_overlap) is resident next to
+// the forward / policy launch of the other stream. k_dw_adam is the block form alone (32 x 32 block jobs + the tail: what every single-GPU update of a block-shaped
+// network launches); k_dw_adam_tiles is the general body (shapes without the block form, behavioural cloning). Same device functions, same bits.
+__global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {   // a.n_big_blocks > 0
+  __shared__ __attribute__((aligned(16))) float smem[2 * DWS * DWS_LD];
+  IL_TL(a.log_alpha ? 2 : 1, 0);
+  const int st_kid = a.log_alpha ? IL_ST_DW_ACTOR : IL_ST_DW_CRITIC;
+  IL_ST_BEGIN(st_kid);
+  const int bx = (int)blockIdx.x;
+  if (bx < a.n_big_blocks) {
+    const int per_net = dw_block_jobs(a.in_dim, a.hidden, a.out_dim);
+    dw_block_job<false, true>(a, bx / per_net, bx % per_net, smem, nullptr, bx);
+  } else {
+    const int tb = bx - a.n_big_blocks, ntb = (int)gridDim.x - a.n_big_blocks;
+    if (a.ov_stage) {   // overlapped launches: see dw_adam_body's tail
+      dw_tail_polyak(a, tb, ntb);
+      if (tb == 0) { dw_ov_wait<true>(a); dw_tail_alpha<false>(a, nullptr); }
+    } else {
+      if (tb == 0) dw_tail_alpha<false>(a, nullptr);
+      dw_tail_polyak(a, tb, ntb);
+    }
+  }
+  IL_TL_END(a.log_alpha ? 2 : 1);
+  IL_ST_END(st_kid);
+  if (a.ov_stage) ov_done(reinterpret_cast<long long*>(a.sync), a.ov_stage - 1);
+}
+__global__ __launch_bounds__(256) void k_dw_adam_tiles(DwArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[2 * DWS * DWS_LD];
   dw_adam_kernel<false>(a, nullptr, smem);
+}
+static inline void launch_dw_adam(const DwArgs& a, int grid, hipStream_t st) {
+  if (a.n_big_blocks > 0) k_dw_adam<<<grid, 256, 0, st>>>(a); else k_dw_adam_tiles<<<grid, 256, 0, st>>>(a);
 }
 // the same launch with the gradient exchange of a data-parallel run inside its block jobs (il_sac_update_gather_peer; n_big_blocks > 0 is checked by the caller)
 __global__ __launch_bounds__(256) void k_dw_adam_peer(DwArgs a, DwPeer p) {
@@ -2239,11 +2333,15 @@ static int pair_lds_ready() {
   return rc == 0;
 }
 static bool chain_pair_ok(const il_sac* d, int relabel, int G) { return pair_env() && pair_shape_ok(d) && chain_pair_workgroups(d->batch / IL_TILE_R, relabel, G) <= device_cu_count() && pair_lds_ready(); }
-static void launch_policy_critic(const il_sac* d, const il_batch* b, float* out_logp, float* out_q, size_t lds, hipStream_t st) {
+static bool policy_critic_pair_ok(const il_sac* d) {
+  const int nt = d->batch / IL_TILE_R, hp = pc_helpers(nt);
+  return pair_env() && pair_shape_ok(d) && hp > 0 && (4 + hp) * nt <= device_cu_count() && pair_lds_ready();
+}
+static void launch_policy_critic(const il_sac* d, const il_batch* b, float* out_logp, float* out_q, size_t lds, hipStream_t st, int overlap = 0) {
   const int H = d->hidden, nt = d->batch / IL_TILE_R;
   IL_TRACE("k_policy_critic", st);
   const int hp = pc_helpers(nt);
-  if (pair_env() && pair_shape_ok(d) && hp > 0 && (4 + hp) * nt <= device_cu_count() && pair_lds_ready()) { k_policy_critic_pair<<<(4 + hp) * nt, 512, IL_PAIR_LDS_BYTES, st>>>(*d, *b, out_logp, out_q, hp); return; }
+  if (policy_critic_pair_ok(d)) { k_policy_critic_pair<<<(4 + hp) * nt, 512, IL_PAIR_LDS_BYTES, st>>>(*d, *b, out_logp, out_q, hp, overlap); return; }
   const bool px = hp > 0 && hp <= 6 && chain_xcd_nets(nt);
   k_policy_critic<<<px ? 8 * nt : (2 + hp) * nt, tile_threads(H), lds, st>>>(*d, *b, out_logp, out_q, nullptr, nullptr, px ? (hp | IL_PC_XCD_NETS) : hp);
 }
@@ -2257,7 +2355,7 @@ extern "C" int il_sac_critic_step(const il_sac* d, const il_batch* b, const floa
   { IL_TRACE("k_critic_fwd", st); k_critic_fwd<<<4 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
   { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
   DwArgs a = critic_dw_args(d, flags);
-  { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<a.n_dw_blocks, 256, 0, st>>>(a); }
+  { IL_TRACE("k_dw_adam_critic", st); launch_dw_adam(a, a.n_dw_blocks, st); }
   IL_CHECK_LAUNCH("il_sac_critic_step");
   return IL_OK;
 }
@@ -2295,7 +2393,7 @@ extern "C" int il_sac_actor_step(const il_sac* d, const il_batch* b, const float
   launch_policy_critic(d, b, out_logp, out_q, lds, st);
   DwArgs a = actor_dw_args(d, b, flags);
   const int tail = (flags & IL_FLAG_GRADS_ONLY) ? 1 : IL_TAIL_BLOCKS;
-  { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<a.n_dw_blocks + tail, 256, 0, st>>>(a); }
+  { IL_TRACE("k_dw_adam_actor", st); launch_dw_adam(a, a.n_dw_blocks + tail, st); }
   IL_CHECK_LAUNCH("il_sac_actor_step");
   return IL_OK;
 }
@@ -2336,10 +2434,10 @@ extern "C" int il_sac_update(const il_sac* d, const il_batch* b, const float* ep
   if (!(flags & IL_FLAG_SAC_FORWARD_ONLY)) {
     if (!(flags & 0x80000000u)) { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
     DwArgs ca = critic_dw_args(d, flags);
-    { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
+    { IL_TRACE("k_dw_adam_critic", st); launch_dw_adam(ca, ca.n_dw_blocks, st); }
     launch_policy_critic(d, b, out_logp, out_q, lds, st);
     DwArgs aa = actor_dw_args(d, b, flags);
-    { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + IL_TAIL_BLOCKS, 256, 0, st>>>(aa); }
+    { IL_TRACE("k_dw_adam_actor", st); launch_dw_adam(aa, aa.n_dw_blocks + IL_TAIL_BLOCKS, st); }
   }
   IL_CHECK_LAUNCH("il_sac_update");
   return IL_OK;
@@ -2382,7 +2480,7 @@ static int check_peer_jobs(const il_peer_bucket* x, int64_t n, int32_t jobs, con
 }
 static int sac_update_gather_impl(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const il_disc* relabel, float* rewards_out,
                                   const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, const il_peer_bucket* peer_critic,
-                                  const il_peer_bucket* peer_actor, il_stream_t stream_) {
+                                  const il_peer_bucket* peer_actor, il_stream_t stream_, il_stream_t stream_b_ = nullptr) {   // stream_b_: il_sac_update_gather_overlap
   if (int rc = check_sac(d, rows)) return rc;
   if (peer_critic || peer_actor) {
     IL_CHECK_ARG(peer_critic && peer_actor && !(flags & IL_FLAG_GRADS_ONLY), "il_sac_update_gather_peer: both buckets, and no IL_FLAG_GRADS_ONLY (the optimiser steps run inside)");
@@ -2415,6 +2513,23 @@ static int sac_update_gather_impl(const il_sac* d, const il_batch* rows, const i
   const int G = il_sac_chain_gather_workgroups(B, ring->ld_states, H);
   if (6 * nt + G > device_cu_count()) return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update_gather: %d workgroups cannot be co-resident on %d CUs (gather first, then il_sac_update)", 6 * nt + G, device_cu_count());
   const size_t lds = tile_lds_bytes(round_up16(S + A), H);
+  if (stream_b_) {   // the four launches alternate over two streams and hand over through [IL_SYNC_OV_EPOCH] (include/il_hip.h il_sac_update_gather_overlap)
+    hipStream_t sb = (hipStream_t)stream_b_;
+    IL_CHECK_ARG(d->sync && sb != st, "il_sac_update_gather_overlap: needs the il_sync counters and two different streams");
+    IL_CHECK_ARG(!(flags & IL_FLAG_GRADS_ONLY) && !peer_critic && !peer_actor, "il_sac_update_gather_overlap: whole single-GPU updates only");
+    IL_CHECK_ARG(flags & IL_FLAG_SAC_PREPARED, "il_sac_update_gather_overlap: the lane-ordered weight copies must be in step (IL_FLAG_SAC_PREPARED): run one il_sac_update_gather first");
+    DwArgs ca = critic_dw_args(d, flags), aa = actor_dw_args(d, rows, flags);
+    if (!chain_pair_ok(d, rl.on, G) || !policy_critic_pair_ok(d) || ca.n_big_blocks <= 0 || aa.n_big_blocks <= 0)
+      return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update_gather_overlap: the pair-mode shape (hidden 256, round_up16(S + A) <= 64, batch %% 128 == 0, every launch co-resident) only");
+    rl.overlap = 1;
+    ca.sync = d->sync; ca.ov_stage = 1 + IL_OV_DWC; aa.ov_stage = 1 + IL_OV_DWA;
+    { IL_TRACE("k_sac_chain", st); k_sac_chain_pair<<<chain_pair_workgroups(nt, rl.on, G), 512, IL_PAIR_LDS_BYTES, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl); }
+    { IL_TRACE("k_dw_adam_critic", sb); launch_dw_adam(ca, ca.n_dw_blocks, sb); }
+    launch_policy_critic(d, rows, out_logp, out_q, lds, st, 1);
+    { IL_TRACE("k_dw_adam_actor", sb); launch_dw_adam(aa, aa.n_dw_blocks + IL_TAIL_BLOCKS, sb); }
+    IL_CHECK_LAUNCH("il_sac_update_gather_overlap");
+    return IL_OK;
+  }
   if (!(flags & IL_FLAG_SAC_PREPARED)) { IL_TRACE("k_repack", st); k_repack<<<dim3(repack_blocks(H), 5), 256, 0, st>>>(*d, 0x1Fu, nullptr); }
   if (chain_pair_ok(d, rl.on, G)) { IL_TRACE("k_sac_chain", st); k_sac_chain_pair<<<chain_pair_workgroups(nt, rl.on, G), 512, IL_PAIR_LDS_BYTES, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl); }
   else {
@@ -2423,7 +2538,7 @@ static int sac_update_gather_impl(const il_sac* d, const il_batch* rows, const i
   }
   DwArgs ca = critic_dw_args(d, flags);
   if (peer_critic) { DwPeer cp = {*peer_critic, 0}; IL_TRACE("k_dw_adam_critic", st); k_dw_adam_peer<<<ca.n_dw_blocks, 256, 0, st>>>(ca, cp); }
-  else { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
+  else { IL_TRACE("k_dw_adam_critic", st); launch_dw_adam(ca, ca.n_dw_blocks, st); }
   if (flags & IL_FLAG_GRADS_ONLY) {   // data-parallel: stop at the critic gradients (critic_grad); the caller all-reduces them and continues with il_sac_dp_phase(rows, 2) and (rows, 3)
     IL_CHECK_LAUNCH("il_sac_update_gather");
     return IL_OK;
@@ -2433,13 +2548,30 @@ static int sac_update_gather_impl(const il_sac* d, const il_batch* rows, const i
   if (peer_actor) {
     DwPeer ap = {*peer_actor, mlp_numel(d->state_dim, d->hidden, 2 * d->action_dim)};
     IL_TRACE("k_dw_adam_actor", st); k_dw_adam_peer<<<aa.n_dw_blocks + IL_TAIL_BLOCKS, 256, 0, st>>>(aa, ap);
-  } else { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + IL_TAIL_BLOCKS, 256, 0, st>>>(aa); }
+  } else { IL_TRACE("k_dw_adam_actor", st); launch_dw_adam(aa, aa.n_dw_blocks + IL_TAIL_BLOCKS, st); }
   IL_CHECK_LAUNCH("il_sac_update_gather");
   return IL_OK;
 }
 extern "C" int il_sac_update_gather(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const il_disc* relabel, float* rewards_out,
                                     const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream_) {
   return sac_update_gather_impl(d, rows, ring, rewards, relabel, rewards_out, eps_next, eps_cur, out_logp, out_q, flags, nullptr, nullptr, stream_);
+}
+extern "C" int il_sac_update_gather_overlap(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const il_disc* relabel, float* rewards_out,
+                                            const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream_a, il_stream_t stream_b) {
+  IL_CHECK_ARG(stream_b, "il_sac_update_gather_overlap: stream_b must be a stream of its own");
+  return sac_update_gather_impl(d, rows, ring, rewards, relabel, rewards_out, eps_next, eps_cur, out_logp, out_q, flags, nullptr, nullptr, stream_a, stream_b);
+}
+__global__ void k_overlap_enter(long long* sy) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const long long n = sy[IL_SYNC_MAIN_EPOCH];
+    for (int st = 0; st < 4; ++st) { sy[IL_SYNC_OV_EPOCH + st * IL_SYNC_STRIDE] = n; sy[IL_SYNC_OV_TICKET + st * IL_SYNC_STRIDE] = 0; }
+  }
+}
+extern "C" int il_sac_overlap_enter(const il_sac* d, il_stream_t stream_) {
+  IL_CHECK_ARG(d && d->sync, "il_sac_overlap_enter: needs the il_sync counters");
+  k_overlap_enter<<<1, 64, 0, (hipStream_t)stream_>>>(reinterpret_cast<long long*>(d->sync));
+  IL_CHECK_LAUNCH("il_sac_overlap_enter");
+  return IL_OK;
 }
 extern "C" int il_sac_update_gather_peer(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const il_disc* relabel, float* rewards_out,
                                          const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, const il_peer_bucket* peer_critic,
@@ -2818,13 +2950,13 @@ extern "C" int il_sac_dp_phase(const il_sac* d, const il_batch* b, int32_t phase
   } else if (phase == 1) {
     { IL_TRACE("k_critic_bwd", st); k_critic_bwd<<<2 * nt, tile_threads(H), lds, st>>>(*d, *b, nullptr, nullptr); }
     DwArgs ca = critic_dw_args(d, IL_FLAG_GRADS_ONLY);
-    { IL_TRACE("k_dw_adam_critic", st); k_dw_adam<<<ca.n_dw_blocks, 256, 0, st>>>(ca); }
+    { IL_TRACE("k_dw_adam_critic", st); launch_dw_adam(ca, ca.n_dw_blocks, st); }
   } else if (phase == 2) {
     const int64_t n = 2 * net_stride(S + A, H, 1);
     { IL_TRACE("k_apply_critic", st); k_apply_critic<<<(int)((n + 255) / 256), 256, 0, st>>>(*d); }
     launch_policy_critic(d, b, out_logp, out_q, lds, st);
     DwArgs aa = actor_dw_args(d, b, IL_FLAG_GRADS_ONLY);
-    { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 1, 256, 0, st>>>(aa); }
+    { IL_TRACE("k_dw_adam_actor", st); launch_dw_adam(aa, aa.n_dw_blocks + 1, st); }
   } else {
     const int na = (int)((mlp_numel(S, H, 2 * A) + 255) / 256);
     { IL_TRACE("k_apply_actor_tail", st); k_apply_actor_tail<<<na + 64, 256, 0, st>>>(*d, na); }
@@ -2848,7 +2980,7 @@ extern "C" int il_sac_dp_phase_peer(const il_sac* d, const il_batch* b, int32_t 
     { IL_TRACE("k_peer_apply_critic", st); k_peer_apply_critic<<<(unsigned)peer_chunks(x->n), 256, 0, st>>>(*d, *x); }
     launch_policy_critic(d, b, out_logp, out_q, lds, st);
     DwArgs aa = actor_dw_args(d, b, IL_FLAG_GRADS_ONLY);
-    { IL_TRACE("k_dw_adam_actor", st); k_dw_adam<<<aa.n_dw_blocks + 1, 256, 0, st>>>(aa); }
+    { IL_TRACE("k_dw_adam_actor", st); launch_dw_adam(aa, aa.n_dw_blocks + 1, st); }
   } else {
     const int64_t Pa = mlp_numel(S, H, 2 * A), alpha_at = d->alpha_grad - d->actor_grad;
     IL_CHECK_ARG(alpha_at >= Pa && alpha_at < x->n, "il_sac_dp_phase_peer: phase 3 takes the actor bucket: actor_grad | alpha_grad must be one allocation of %lld floats (GradBuckets)", (long long)x->n);
@@ -2985,7 +3117,7 @@ extern "C" int il_bc_step(float* actor, float* actor_grad, const il_adam* opt, i
   a.h1 = workspace + ws.a_h1; a.h2 = workspace + ws.a_h2; a.dz1 = workspace + ws.a_dz1; a.dz2 = workspace + ws.a_dz2;
   a.dz3 = workspace + ws.a_dz3;
   a.n_dw_blocks = dw_blocks(S, H, 2 * A, 1);
-  { IL_TRACE("k_dw_adam_bc", st); k_dw_adam<<<a.n_dw_blocks, 256, 0, st>>>(a); }
+  { IL_TRACE("k_dw_adam_bc", st); launch_dw_adam(a, a.n_dw_blocks, st); }
   IL_CHECK_LAUNCH("il_bc_step");
   return IL_OK;
 }

@@ -547,6 +547,11 @@ class UpdatePlan:
     self._ring_desc = None
     self._capturing = None   # 'main' / 'side' while one branch of the device-synchronised update is being captured
     self._prepared = False   # True once an update of THIS plan has left the lane-ordered weight copies in step with the parameters
+    # (round 6) the SAC branch's four launches alternating over two streams (il_sac_update_gather_overlap): `ov_stream` hosts the two optimiser launches; `_ov_active`:
+    # the last SAC-branch enqueue of this plan was an overlapped one (the stage epochs are in step with [IL_SYNC_MAIN_EPOCH]; the caller's stream is NOT ordered behind
+    # `ov_stream` until `join()`); `_ov_probe`: None = not probed yet
+    self.ov_stream, self._ov_active, self._ov_probe, self._recording, self._direct_overlap = None, False, None, False, False
+    self._sync_poison = _lib.sync_layout_ex()[6]
 
   def record_relu_masks(self) -> Tensor:
     """Tests only (il_sac.debug_masks, include/il_hip.h): from now on every update ALSO writes, for its three back-propagated passes, which hidden pre-activations
@@ -615,9 +620,94 @@ class UpdatePlan:
     torch.cuda.synchronize()
     ok = self.sync_timeouts() == before
     self.sync[self._sync_timeouts] = 0
+    self.sync[self._sync_poison] = 0   # (an expired PROBE wait is not an expired wait of an update: the optimiser launches must not skip their stores for it)
     w = getattr(self, '_watch_host', None)
     if w is not None: w[0] = 0   # an expired PROBE wait also reached the pinned host word (watch_timeouts): it is not an expired wait of an update
     return ok
+
+  def _probe_streams(self, waiter, setter) -> bool:
+    """True if a kernel on `waiter` that polls a counter is overtaken by a kernel enqueued AFTER it on `setter` - i.e. the two streams sit on different hardware queues."""
+    L = _lib.lib()
+
+    def on(stream, which):
+      with torch.cuda.stream(stream):
+        _lib.check(L.il_sync_probe(_lib.ptr(self.sync), which, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    before = self.sync_timeouts()
+    on(setter, 1)   # code object loaded, counters one ahead: the first timed waiter cannot be late because of a cold launch
+    torch.cuda.synchronize()
+    on(waiter, 0)
+    torch.cuda.synchronize()
+    for _ in range(3):
+      on(waiter, 0)
+      on(setter, 1)
+      torch.cuda.synchronize()
+    ok = self.sync_timeouts() == before
+    self.sync[self._sync_timeouts] = 0
+    self.sync[self._sync_poison] = 0
+    w = getattr(self, '_watch_host', None)
+    if w is not None: w[0] = 0
+    return ok
+
+  @property
+  def main_overlap(self) -> bool:
+    """(round 6) Ring mode on one GPU, pair-mode shape: the SAC branch's four launches ALTERNATE over two streams - forward / critic loss and policy / critic on the caller's,
+    the two optimiser launches on `ov_stream` - and hand over through stage epochs on the device (il_sac_update_gather_overlap, include/il_hip.h): every launch is dispatched
+    while its predecessor still runs, does what does not depend on it (row gathers, the optimiser's p / m / v streams, the target step, the critics' forward) and waits behind
+    that. Bit-identical to the in-order schedule (`test_schedule_switches_are_bit_identical[IL_MAIN_OVERLAP-*]`). Needs three streams on three hardware queues (probed once:
+    `ov_stream` against the caller's stream both ways, and against the discriminator branch's). IL_MAIN_OVERLAP=0: in-order launches on one stream."""
+    if os.environ.get('IL_MAIN_OVERLAP', '1') == '0' or not self.device_sync or not self._prepared or self.general:
+      return False
+    if self.peer_desc is not None or getattr(self, 'data_parallel', False) or self.pre_hooks or self.post_hooks or not self.ring_mode:
+      return False
+    if self.sac.hidden != 256 or self.B % 128 != 0 or (self.sac.state_dim + self.sac.action_dim + 15) // 16 * 16 > 64:
+      return False
+    if self._ov_probe is None:
+      main, rejected = torch.cuda.current_stream(), []
+      self._ov_probe = False
+      for _ in range(8):   # (streams are dealt to the hardware queues round-robin at creation: a rejected one stays alive so that the next lands elsewhere)
+        cand = torch.cuda.Stream()
+        if self._probe_streams(cand, main) and self._probe_streams(main, cand) and (self.side is None or self._probe_streams(self.side, cand)):
+          self.ov_stream, self._ov_probe = cand, True
+          break
+        rejected.append(cand)
+    return self._ov_probe
+
+  def _ov_enter(self):
+    """Before the first overlapped update that follows anything else on this learner: the stage epochs := [IL_SYNC_MAIN_EPOCH] (one tiny launch on the caller's stream), and
+    `ov_stream` ordered behind it."""
+    _lib.check(_lib.lib().il_sac_overlap_enter(C.byref(self.sac), _lib.stream_ptr()))
+    self.ov_stream.wait_stream(torch.cuda.current_stream())
+    self._ov_active = True
+
+  def _ov_leave(self):
+    """Before anything else is enqueued on the caller's stream for this learner: order it behind the optimiser launches on `ov_stream`."""
+    if self._ov_active:
+      torch.cuda.current_stream().wait_stream(self.ov_stream)
+      self._ov_active = False
+
+  def _sac_gather(self, ring, rewards, relabel, rewards_out, flags):
+    """il_sac_update_gather, or its overlapped form when `main_overlap` applies and no hipGraph is being captured."""
+    L = _lib.lib()
+    if self.main_overlap and (self._capturing is None or self._recording):
+      if not self._ov_active:
+        assert not self._recording, 'record_direct() enters the overlapped schedule before it starts recording'
+        self._ov_enter()
+      _lib.check(L.il_sac_update_gather_overlap(C.byref(self.sac), C.byref(self.pb), C.byref(ring), rewards, relabel, rewards_out, None, None, _lib.ptr(self.logp), _lib.ptr(self.q),
+                                                flags, _lib.stream_ptr(), C.c_void_p(self.ov_stream.cuda_stream)))
+      return
+    self._ov_leave()
+    _lib.check(L.il_sac_update_gather(C.byref(self.sac), C.byref(self.pb), C.byref(ring), rewards, relabel, rewards_out, None, None, _lib.ptr(self.logp), _lib.ptr(self.q), flags, _lib.stream_ptr()))
+
+  def poisoned(self) -> bool:
+    """[IL_SYNC_POISON]: a bounded device-side wait of this learner has expired; from that launch on the optimiser launches skip their stores (the weights are those of the
+    last complete update). Synchronous read."""
+    return bool(int(self.sync[self._sync_poison].item()))
+
+  def clear_poison(self):
+    _lib.check(_lib.lib().il_sync_clear_poison(_lib.ptr(self.sync), _lib.stream_ptr()))
+    w = getattr(self, '_watch_host', None)
+    if w is not None: w[0] = 0
 
   def widen_handoff_bound(self, polls: Optional[int] = None):
     """[IL_SYNC_SPIN]: the bound of this learner's device-side waits, in polls. A data-parallel rank waits for the all-reduced discriminator step inside its SAC branch and
@@ -850,15 +940,16 @@ class UpdatePlan:
       inline = self.inline_relabel
       flags = self.prepared_flag() | (_lib.IL_FLAG_SAC_WAIT_INDICES if resident else 0)
       if self.peer_desc is not None:   # data-parallel: the critic's and the actor's exchange ride in the two optimiser launches
+        self._ov_leave()
         _lib.check(_lib.lib().il_sac_update_gather_peer(C.byref(self.sac), C.byref(self.pb), C.byref(self._ring_batches()[0]), None if inline else _lib.ptr(self.rewards),
                                                         C.byref(self.disc) if inline else None, _lib.ptr(self.rewards) if inline else None, None, None,
                                                         _lib.ptr(self.logp), _lib.ptr(self.q), flags, C.byref(self.peer_desc['critic']), C.byref(self.peer_desc['actor']), _lib.stream_ptr()))
         return
       staged = resident and self.staged_rows
-      _lib.check(_lib.lib().il_sac_update_gather(C.byref(self.sac), C.byref(self.pb), C.byref(self._staged_batch() if staged else self._ring_batches()[0]), None if inline else _lib.ptr(self.rewards),
-                                                 C.byref(self.disc) if inline else None, _lib.ptr(self.rewards) if inline else None, None, None,
-                                                 _lib.ptr(self.logp), _lib.ptr(self.q), flags | (_lib.IL_FLAG_SAC_STAGED_ROWS if staged else 0), _lib.stream_ptr()))
+      self._sac_gather(self._staged_batch() if staged else self._ring_batches()[0], None if inline else _lib.ptr(self.rewards), C.byref(self.disc) if inline else None,
+                       _lib.ptr(self.rewards) if inline else None, flags | (_lib.IL_FLAG_SAC_STAGED_ROWS if staged else 0))
       return
+    self._ov_leave()
     _lib.check(_lib.lib().il_sac_update(C.byref(self.sac), C.byref(self.pb), None, None, _lib.ptr(self.logp), _lib.ptr(self.q), self.prepared_flag(), _lib.stream_ptr()))
 
   def _run_update(self):
@@ -879,10 +970,12 @@ class UpdatePlan:
           self._enqueue_sac_branch()
         if self._capturing is None:
           main.wait_stream(self.side)   # eager: leave the caller's stream ordered after both branches
+          if self._ov_active: main.wait_stream(self.ov_stream)   # (... and after the optimiser launches of an overlapped update; the stage epochs stay in step)
         if self._capturing != 'side':
           self._prepared = True         # the SAC branch has (or, once replayed, will have) left the lane-ordered weight copies in step
         return
       # fallback (the runtime does not run the two streams concurrently, or IL_DEVICE_SYNC=0): one graph, fork after the gather, join before the critic loss
+      self._ov_leave()
       self.sample_all()
       self.side.wait_stream(main)                                   # the discriminator needs the sampled batches
       with torch.cuda.stream(self.side):
@@ -906,12 +999,13 @@ class UpdatePlan:
           _lib.check(L.il_replay_draw_resident(_lib.ptr(mt), self.B, _lib.ptr(m._ring_state), _lib.ptr(self.idx), _lib.ptr(e._ring_state) if e else None, _lib.ptr(self.eidx) if e else None,
                                                _lib.ptr(self.sync), _lib.stream_ptr()))
       if self._capturing != 'side':
-        _lib.check(L.il_sac_update_gather(C.byref(self.sac), C.byref(self.pb), C.byref(self._ring_batches()[0]), None, None, None, None, None, _lib.ptr(self.logp), _lib.ptr(self.q),
-                                          self.prepared_flag() | _lib.IL_FLAG_SAC_WAIT_INDICES, _lib.stream_ptr()))
+        self._sac_gather(self._ring_batches()[0], None, None, None, self.prepared_flag() | _lib.IL_FLAG_SAC_WAIT_INDICES)
         self._prepared = True
       if self._capturing is None:
         main.wait_stream(self.side)
+        if self._ov_active: main.wait_stream(self.ov_stream)
       return
+    self._ov_leave()
     self.sample_all()
     st = _lib.stream_ptr()
     sync_kept = self.sac.sync
@@ -1004,6 +1098,7 @@ class UpdatePlan:
     if warmup and self.sync_timeouts():
       raise RuntimeError(f'UpdatePlan.capture: {self.sync_timeouts()} device-side waits expired during the warm-up updates (the two branches did not run concurrently); '
                          'their results are invalid. Set IL_DEVICE_SYNC=0 to keep plain stream dependencies.')
+    self._ov_leave()   # (the warm-up updates may have alternated over `ov_stream`: a captured update is the in-order schedule)
     if self.device_sync and (self.algorithm == 'GAIL' or self.resident_sampler):   # two graphs, one per branch, replayed on two streams; no edge between them (see _run_update)
       self._captured_resident = self.resident_sampler
       self.graph_side, self._capturing = torch.cuda.CUDAGraph(), 'side'
@@ -1048,7 +1143,10 @@ class UpdatePlan:
 
     real = _lib.lib()
     out = []
+    if self.main_overlap and not self._ov_active:
+      self._ov_enter()   # (a real launch, ahead of the recording: the recorded update is the steady state)
     try:
+      self._recording = True
       for branch in ('side', 'main'):
         rec = Recorder(real)
         _lib._lib, self._capturing = rec, branch
@@ -1058,26 +1156,38 @@ class UpdatePlan:
           self._run_update()
         out.append(list(rec.calls))
     finally:
-      _lib._lib, self._capturing = real, None
+      _lib._lib, self._capturing, self._recording = real, None, False
     self._direct_side, self._direct_main = out
     self._captured_resident = self.resident_sampler
+    self._direct_overlap = bool(self._ov_active)
     return self
 
-  def launch_direct(self):
+  def launch_direct(self, join: bool = True):
+    """`join` (overlapped schedule only): order the caller's stream behind the update's last launch, which sits on `ov_stream` - whatever the caller enqueues next on its own
+    stream (an acting forward, an evaluation, a checkpoint) then sees the stepped networks, as it does behind an in-order update. join=False: back-to-back updates with
+    nothing in between (offline training, several updates per environment step, bench.py): the next update's first launch is dispatched while this one's last still runs;
+    call `join()` before reading anything."""
     if self.main_feeds_ring and self._captured_resident:
       self.side.wait_stream(torch.cuda.current_stream())   # (as replay(): appends enqueued since the last update precede the resident index draw)
+    if self._direct_overlap and not self._ov_active:
+      self._ov_enter()   # (something else ran on this learner since the last overlapped update: run(), replay())
     for fn, args in self._direct_side:
       if fn(*args) != 0: _lib.check(1)
     for fn, args in self._direct_main:
       if fn(*args) != 0: _lib.check(1)
+    if join and self._direct_overlap:
+      torch.cuda.current_stream().wait_stream(self.ov_stream)
 
   def join(self):
     """Order the caller's stream after the plan's second stream: `replay()` leaves the two branches unjoined (no edge between the graphs), so anything the caller reads
     on its own stream that the other branch wrote - the discriminator's parameters / buffers for a checkpoint, the rewards on the fallback schedules - needs this first."""
     if self.side is not None:
       torch.cuda.current_stream().wait_stream(self.side)
+    if self._ov_active:
+      torch.cuda.current_stream().wait_stream(self.ov_stream)
 
   def replay(self):
+    self._ov_leave()
     if self.graph_side is not None:
       if self.main_feeds_ring and self._captured_resident:
         self.side.wait_stream(torch.cuda.current_stream())   # appends enqueued on the caller's stream since the last update must precede the resident index draw

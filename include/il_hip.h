@@ -203,6 +203,13 @@ int il_polyak(float* target, const float* param, int64_t n, double tau, il_strea
  *                          waiting for [IL_SYNC_MAIN_EPOCH]; the discriminator workgroups, which read the Philox counter the actor step advances, still wait for the epoch.
  *   [IL_SYNC_PARAMS]     += 1 per finished AdamW(discriminator) workgroup (IL_FLAG_GAIL_CLOSE_EPOCH) -> the inline relabel of il_sac_update_gather waits
  *                          for (main_epoch + 1) * il_gail_step_workgroups()
+ *   [IL_SYNC_OV_EPOCH + stage]  += 1 when EVERY workgroup of that stage's launch has retired (il_sac_update_gather_overlap only; the last workgroup to take a ticket on
+ *                          [IL_SYNC_OV_TICKET + stage] resets the ticket line and bumps the epoch with an agent-scope release). The next stage's launch sits on the OTHER
+ *                          stream, is resident before this one ends, and waits for the epoch behind its independent prologue. il_sac_overlap_enter() sets all four to
+ *                          [IL_SYNC_MAIN_EPOCH] so that a stage's own epoch is also the number of finished updates.
+ *   [IL_SYNC_POISON]     != 0 once a bounded wait of this learner has given up: the optimiser epilogues (k_dw_adam, k_gail_reduce) of every later launch skip their
+ *                          stores - an update whose hand-off expired never reaches the weights - until the host clears the word (il_sync_clear_poison). Same read-only line
+ *                          as [IL_SYNC_SPIN].
  * With it the two branches need no stream dependency between the gather and the critic loss (fork at the start of the update, join at
  * its end). NULL everywhere = plain stream ordering (the caller serialises or uses events). */
 /* il_sync_probe: [IL_SYNC_PROBE_FLAG], [IL_SYNC_PROBE_EPOCH] of the same buffer; enqueue setter = 0 on the side stream first, then setter = 1 on the main stream. */
@@ -216,9 +223,17 @@ int il_sync_probe(int64_t* sync, int32_t setter, il_stream_t stream);
 enum { IL_SYNC_ROWS = 0, IL_SYNC_REWARDS = 1 * IL_SYNC_STRIDE, IL_SYNC_SIDE_EPOCH = 2 * IL_SYNC_STRIDE, IL_SYNC_MAIN_EPOCH = 3 * IL_SYNC_STRIDE, IL_SYNC_TIMEOUTS = 4 * IL_SYNC_STRIDE,
        IL_SYNC_GATHER_WGS = 5 * IL_SYNC_STRIDE, IL_SYNC_PROBE_FLAG = 6 * IL_SYNC_STRIDE, IL_SYNC_PROBE_EPOCH = 7 * IL_SYNC_STRIDE, IL_SYNC_INDICES = 8 * IL_SYNC_STRIDE,
        IL_SYNC_PARAMS = 9 * IL_SYNC_STRIDE, IL_SYNC_CHAIN_DONE = 10 * IL_SYNC_STRIDE, IL_SYNC_CHAIN_WGS = 11 * IL_SYNC_STRIDE, IL_SYNC_SPIN = 5 * IL_SYNC_STRIDE + 1,
-       IL_SYNC_HOST_FLAG = 5 * IL_SYNC_STRIDE + 2, IL_SYNC_SLOTS = 16 * IL_SYNC_STRIDE };
+       IL_SYNC_HOST_FLAG = 5 * IL_SYNC_STRIDE + 2, IL_SYNC_POISON = 5 * IL_SYNC_STRIDE + 3,
+       IL_SYNC_OV_EPOCH = 12 * IL_SYNC_STRIDE,  /* + stage * IL_SYNC_STRIDE, stage = IL_OV_CHAIN .. IL_OV_DWA (lines 12 .. 15) */
+       IL_SYNC_OV_TICKET = 16 * IL_SYNC_STRIDE, /* + stage * IL_SYNC_STRIDE (lines 16 .. 19) */
+       IL_SYNC_SLOTS = 20 * IL_SYNC_STRIDE };
+/* Stages of the SAC branch when its four launches alternate over two streams (il_sac_update_gather_overlap): forward / critic loss, critic optimiser,
+ * policy / critic, actor optimiser + tail. */
+enum { IL_OV_CHAIN = 0, IL_OV_DWC = 1, IL_OV_PC = 2, IL_OV_DWA = 3 };
 /* out[0] = IL_SYNC_SLOTS (int64 elements to allocate and zero), out[1] = IL_SYNC_TIMEOUTS, out[2] = IL_SYNC_GATHER_WGS, out[3] = IL_SYNC_STRIDE, out[4] = IL_SYNC_SPIN, out[5] = IL_SYNC_HOST_FLAG */
 void il_sync_layout(int32_t* out);
+/* the same, open-ended: out[0 .. n) = il_sync_layout's six, then [6] IL_SYNC_POISON, [7] IL_SYNC_OV_EPOCH, [8] IL_SYNC_OV_TICKET, [9] IL_SYNC_MAIN_EPOCH */
+void il_sync_layout_ex(int32_t* out, int32_t n);
 
 /* ------------------------------------------------------------------------------------------
  * SAC (reference training.py:14-54 `sac_update`; models.py:84-141 SoftActor / TwinCritic).
@@ -291,6 +306,21 @@ int il_sac_update_gather(const il_sac* d, const il_batch* rows, const il_batch* 
  * soon as [IL_SYNC_PARAMS] says its AdamW step is done - no relabel kernel, no reward hand-off; written to rewards_out [B] if given. Same code and
  * thread mapping as il_gail_reward, so the values are bit-identical. IL_ERR_UNSUPPORTED for state_only discriminators or ones too large for the
  * workgroup's spare LDS (then relabel with il_gail_reward and pass `rewards`). */
+/* il_sac_update_gather with the SAC branch's four launches ALTERNATING over two streams (round 6; reference train.py:173-203, training.py:26-31,34-42,52 - the same update):
+ *   stream_a: forward / critic loss (k_sac_chain_pair) -> policy / critic (k_policy_critic_pair);   stream_b: critic optimiser (k_dw_adam) -> actor optimiser + tail (k_dw_adam).
+ * Same-stream order gives the two-hop dependencies; the one-hop dependency is a device counter: every launch is dispatched while its predecessor still runs, does what does
+ * not depend on it (row gathers through the indices, the optimiser's p / m / v streams, the target step, the critics' forward) and then waits for
+ * [IL_SYNC_OV_EPOCH + predecessor] (bounded like every device-side wait; an expired wait poisons the learner: [IL_SYNC_POISON]). No stream edge is created by this call.
+ * Needs d->sync, the pair-mode shape (hidden 256, round_up16(S + A) <= 64) and the block form of the optimiser launches (batch % 128 == 0): IL_ERR_UNSUPPORTED otherwise -
+ * fall back to il_sac_update_gather. Not with IL_FLAG_GRADS_ONLY. The caller (1) calls il_sac_overlap_enter() on stream_a and orders stream_b behind it (an event) before the
+ * FIRST overlapped update that follows anything else on this descriptor, (2) orders stream_a behind stream_b (an event) before it reads results or issues any other il_sac_*
+ * call. Consecutive overlapped updates need neither. Bit-identical to il_sac_update_gather. */
+int il_sac_update_gather_overlap(const il_sac* d, const il_batch* rows, const il_batch* ring, const float* rewards, const struct il_disc* relabel, float* rewards_out,
+                                 const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, uint32_t flags, il_stream_t stream_a, il_stream_t stream_b);
+/* one tiny launch on `stream`: [IL_SYNC_OV_EPOCH + 0..3] = [IL_SYNC_MAIN_EPOCH], [IL_SYNC_OV_TICKET + 0..3] = 0 */
+int il_sac_overlap_enter(const il_sac* d, il_stream_t stream);
+/* [IL_SYNC_POISON] = 0 and [IL_SYNC_TIMEOUTS] = 0 (stream-ordered): the host has seen the expired wait and restored a consistent state (e.g. reloaded a checkpoint) */
+int il_sync_clear_poison(int64_t* sync, il_stream_t stream);
 int32_t il_gail_step_workgroups(const struct il_disc* d); /* AdamW workgroups of il_gail_disc_step = what [IL_SYNC_PARAMS] advances by per step */
 int32_t il_sac_chain_gather_workgroups(int32_t batch, int32_t row_floats, int32_t hidden);
 /* Bounded in-launch waits (tile counters of the chained forward / critic-loss launch and of the policy helpers) that gave up since the last k_repack of this workspace (= the

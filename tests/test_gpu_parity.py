@@ -1269,7 +1269,8 @@ def test_update_plan_batch_sizes_of_the_tuned_configs(monkeypatch, B, ring):
 @pytest.mark.gpu
 @pytest.mark.parametrize('switch,B', [('IL_RING_GATHER', 256), ('IL_INLINE_RELABEL', 256), ('IL_SAC_CHAIN', 256), ('IL_PC_SPLIT', 256), ('IL_RESIDENT_SAMPLER', 256), ('IL_RESIDENT_SAMPLER', 80),
                                       ('IL_SAC_CHAIN', 80), ('IL_RING_GATHER', 80), ('IL_PC_SPLIT', 48), ('IL_CHAIN_XCD_NETS', 256), ('IL_CHAIN_XCD_NETS', 80),
-                                      ('IL_PAIR', 256), ('IL_PAIR', 128), ('IL_PAIR', 80), ('IL_STAGE_ROWS', 256), ('IL_STAGE_ROWS', 80), ('IL_EARLY_DRAW', 256), ('IL_EARLY_DRAW', 48)])   # IL_PAIR: the column-split pairs of k_sac_chain_pair / k_policy_critic_pair against the 16-wave workgroups   # 80 / 48 rows: 5 / 3 tiles, the non-XCD-aware role decode; IL_CHAIN_XCD_NETS: one network per XCD (off by default)
+                                      ('IL_PAIR', 256), ('IL_PAIR', 128), ('IL_PAIR', 80), ('IL_STAGE_ROWS', 256), ('IL_STAGE_ROWS', 80), ('IL_EARLY_DRAW', 256), ('IL_EARLY_DRAW', 48),
+                                      ('IL_MAIN_OVERLAP', 256), ('IL_MAIN_OVERLAP', 128)])   # IL_MAIN_OVERLAP (round 6): the SAC branch's four launches alternating over two streams (il_sac_update_gather_overlap) against in-order launches   # IL_PAIR: the column-split pairs of k_sac_chain_pair / k_policy_critic_pair against the 16-wave workgroups   # 80 / 48 rows: 5 / 3 tiles, the non-XCD-aware role decode; IL_CHAIN_XCD_NETS: one network per XCD (off by default)
 def test_schedule_switches_are_bit_identical(monkeypatch, switch, B):
   """Every schedule of the update (rows through il_batch.gather vs a gather kernel, inline relabel vs k_gail_reward, chained vs separate forward / critic-loss
   launches, helper-split vs second-arriver policy tail) runs the same arithmetic per element: switching one off must not change a bit.
@@ -1287,7 +1288,7 @@ def test_schedule_switches_are_bit_identical(monkeypatch, switch, B):
       "assert plan.sync_timeouts() == 0\n"
       "h = hashlib.sha256()\n"
       "for n in list(nets) + [plan.logp, plan.q, plan.rewards, plan.idx]: h.update(np.ascontiguousarray(N(n.flat if hasattr(n, 'flat') else n)).tobytes())\n"
-      "print(json.dumps(dict(digest=h.hexdigest(), ring=plan.ring_mode, inline=plan.inline_relabel, staged=plan.staged_rows)))\n")
+      "print(json.dumps(dict(digest=h.hexdigest(), ring=plan.ring_mode, inline=plan.inline_relabel, staged=plan.staged_rows, overlap=bool(plan._ov_active), poisoned=plan.poisoned())))\n")
   outs = []
   for value in ('1', '0'):
     env = dict(os.environ, **{switch: value})
@@ -1295,6 +1296,8 @@ def test_schedule_switches_are_bit_identical(monkeypatch, switch, B):
     assert r.returncode == 0, r.stderr[-2000:]
     outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
   if switch == 'IL_STAGE_ROWS': assert outs[0]['staged'] and not outs[1]['staged']
+  if switch == 'IL_MAIN_OVERLAP': assert outs[0]['overlap'] and not outs[1]['overlap'], 'the overlapped launches did not run (no third hardware queue?)'
+  assert not outs[0]['poisoned'] and not outs[1]['poisoned']
   assert outs[0]['ring'] and outs[0]['inline'], 'the default schedule reads rows through il_batch.gather and relabels inline'
   if switch == 'IL_RING_GATHER': assert not outs[1]['ring']
   if switch == 'IL_INLINE_RELABEL': assert outs[1]['ring'] and not outs[1]['inline']

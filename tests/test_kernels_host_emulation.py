@@ -392,6 +392,7 @@ def _emulated_product(monkeypatch, streams=False):
     monkeypatch.setattr(torch.cuda, 'device', lambda d: contextlib.nullcontext())
     monkeypatch.setattr(torch.cuda, 'get_device_properties', lambda *a, **k: Props())
     monkeypatch.setattr(il_training.UpdatePlan, '_probe_device_sync', lambda self, graph: True)   # "the two streams run concurrently": true of the emulated ones
+    monkeypatch.setattr(il_training.UpdatePlan, '_probe_streams', lambda self, waiter, setter: True)
     host_copy = gpu_util.N
     monkeypatch.setattr(gpu_util, 'N', lambda t: (h.emu_drain(), host_copy(t))[1])
     monkeypatch.setattr(tgp, 'N', gpu_util.N, raising=False)
