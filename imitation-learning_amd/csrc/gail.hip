@@ -520,15 +520,17 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const
     if (e < lay.P) g = peer_job_mean1(peer, pj, e);
     peer_job_end(peer, pj, (int)blockIdx.x);
   }
+  // an update whose hand-off expired (this launch's producers waited for rows / indices that never came) never reaches the weights: [IL_SYNC_POISON]. The step still signals.
+  const bool poisoned = sync_poisoned(reinterpret_cast<const long long*>(d.sync));
   if (e < lay.P) {
     d.grad[e] = g;
-    if (apply) {
+    if (apply && !poisoned) {
       const adam_consts ac = load_adam_consts(d.opt);
       adam_update(pp, g, mm, vv, ac);
       d.params[e] = pp; d.opt.m[e] = mm; d.opt.v[e] = vv;
     }
   }
-  if (blockIdx.x == 0 && d.spectral_norm) {
+  if (blockIdx.x == 0 && d.spectral_norm && !poisoned) {
     const float* o = d.workspace + wsl.sn_new;
     for (int i = threadIdx.x; i < H; i += blockDim.x) { d.u1[i] = o[i]; d.v2[i] = o[H + D + 1 + i]; }
     for (int i = threadIdx.x; i < D; i += blockDim.x) d.v1[i] = o[H + i];

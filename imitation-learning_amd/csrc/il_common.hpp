@@ -307,28 +307,58 @@ __device__ __forceinline__ void sync_wait(long long* sync, int which, long long 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Stage epochs of the overlapped SAC branch (il_sac_update_gather_overlap; include/il_hip.h [IL_SYNC_OV_EPOCH] / [IL_SYNC_OV_TICKET]). The four launches of an update alternate
-// over two streams; a launch is dispatched while its predecessor (the other stream's head) still runs and waits for that stage's epoch behind its independent prologue.
-//   ov_own:  this stage's epoch = the number of updates it has completed. Stable while any workgroup of the launch is alive (the last one to retire bumps it).
-//   ov_wait: all threads; one polling lane, agent-scope acquire, barrier (sync_wait).
-//   ov_done: all threads, at the workgroup's end. Every wave drains its stores, barrier, one release (L2 write-back) + ticket; the last ticket resets the line and
-//            bumps the epoch. The consumer's acquire then sees every workgroup's stores.
+// Stage hand-offs of the overlapped SAC branch (il_sac_update_gather_overlap; include/il_hip.h [IL_SYNC_OV_EPOCH] / [IL_SYNC_OV_TICKET]). The four launches of an update alternate
+// over two streams; a launch is dispatched while its predecessor (the other stream's head) still runs and waits for it behind its independent prologue.
+//   producer (ov_done, all threads, at the workgroup's end): every wave drains its stores, barrier, one agent-scope release (L2 write-back) and a fire-and-forget add on the
+//            stage's ticket line - no returned value, the workgroup retires without a round trip to memory.
+//   consumer (ov_wait, all threads): workgroup 0 of the waiting launch is its LEADER, the only poller of the ticket line (160 workgroups polling one line were measured to
+//            slow every kernel on the chip down and to delay the tickets themselves: 11.4k against 17.4k updates/s): ticket >= the producer's grid (passed by the host with
+//            the launch) or epoch >= target; it acquires, CLOSES the producer's stage (epoch = target first, ticket = 0 second) and stores `target` into the flag line of
+//            every workgroup of its own launch; the others poll their own line. By the time the stage is closed every producer workgroup has arrived, and the producer
+//            stage's next launch cannot have started (it follows, in its own stream, a launch that waits for this one).
+//   ov_own:  a stage's epoch = the number of updates it has completed, as seen by its OWN launch: closed by its consumer before its next launch starts, so every workgroup of
+//            a launch reads the same value. il_sac_overlap_enter() sets all four to [IL_SYNC_MAIN_EPOCH].
 // ---------------------------------------------------------------------------------------------
+#ifndef IL_OV_POLL_SLEEP
+#define IL_OV_POLL_SLEEP 2
+#endif
 __device__ __forceinline__ long long ov_own(long long* sync, int stage) {
   return __hip_atomic_load(sync + IL_SYNC_OV_EPOCH + stage * IL_SYNC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void ov_wait(long long* sync, int stage, long long target) { sync_wait(sync, IL_SYNC_OV_EPOCH + stage * IL_SYNC_STRIDE, target); }
+// waits for launch number `target` (1-based) of `stage`, whose grid has `grid` workgroups. Workgroup 0 of the waiting launch is the LEADER: the only poller of the ticket
+// line; it closes the stage and tells every other workgroup of its launch through that workgroup's own flag line.
+__device__ __forceinline__ void ov_wait(long long* sync, int stage, long long target, int grid) {
+  const bool leader = blockIdx.x == 0;
+  long long* flags = sync + IL_SYNC_OV_FLAGS + (long long)stage * IL_OV_MAX_GRID * IL_SYNC_STRIDE;
+  if (threadIdx.x == 0) {
+    long long* tk = sync + IL_SYNC_OV_TICKET + stage * IL_SYNC_STRIDE;
+    long long* ep = sync + IL_SYNC_OV_EPOCH + stage * IL_SYNC_STRIDE;
+    long long* mine = flags + (long long)blockIdx.x * IL_SYNC_STRIDE;
+    int spins = 0, limit = 0;
+    bool expired = false;
+    for (;;) {
+      if (leader) {
+        if (__hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (long long)grid) break;
+        if (__hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+      } else if (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+      __builtin_amdgcn_s_sleep(IL_OV_POLL_SLEEP);
+      if (limit == 0) { const long long own = sync[IL_SYNC_SPIN]; limit = own > 0 ? (int)(own > 0x7fffffffLL ? 0x7fffffffLL : own) : IL_SYNC_SPIN_LIMIT; }
+      if (++spins > limit) { sync_timed_out(sync); expired = true; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (leader && !expired && __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // close the stage: epoch first, ticket second
+      __hip_atomic_store(ep, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(tk, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (leader)   // (also after an expired wait: the followers then proceed, poisoned like the leader, instead of each running into its own bound)
+    for (int w = threadIdx.x; w < (int)gridDim.x && w < IL_OV_MAX_GRID; w += blockDim.x) __hip_atomic_store(flags + (long long)w * IL_SYNC_STRIDE, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void ov_done(long long* sync, int stage) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const long long total = (long long)gridDim.x * gridDim.y * gridDim.z;
-    long long* tk = sync + IL_SYNC_OV_TICKET + stage * IL_SYNC_STRIDE;
-    if (__hip_atomic_fetch_add(tk, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
-      __hip_atomic_store(tk, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(sync + IL_SYNC_OV_EPOCH + stage * IL_SYNC_STRIDE, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(sync + IL_SYNC_OV_TICKET + stage * IL_SYNC_STRIDE, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 #define LOG_SQRT_2PI 0.91893853320467274178f

@@ -454,7 +454,7 @@ __device__ __forceinline__ void critic_bwd_resident_gemm(const il_sac& d, int k,
 }
 // relabel: the rewards of this tile are the discriminator `dd`'s prediction on (s, a) - the rows still sit in Xs - computed here once its AdamW step of
 // this update is complete ([IL_SYNC_PARAMS], n_reduce workgroups per step); otherwise dense `rewards` or the batch's own reward field.
-struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; int fwd_only; int wait_indices; int local_rewards; int xcd_nets, gather_wgs; int early_draw; int overlap; long long ov_n; };   // overlap (k_sac_chain_pair, il_sac_update_gather_overlap): the previous update's actor optimiser launch may still be running on the other stream - ov_n = this stage's own epoch (ov_own, set by the kernel) stands in for [IL_SYNC_MAIN_EPOCH] and the roles wait for [IL_SYNC_OV_EPOCH + IL_OV_DWA] >= ov_n where they first need what that launch writes   // early_draw: publish [IL_SYNC_CHAIN_WGS] (IL_EARLY_DRAW=0: the resident sampler waits for the previous update's end, as in round 4)   // xcd_nets: grid = 8 * nt, one network per XCD (chain_decode_xcd); gather_wgs: row-copy workgroups among the blocks of XCDs 6, 7   // wait_indices: IL_FLAG_SAC_WAIT_INDICES; local_rewards: il_sac_update_gather without `rewards` / `relabel` (the ring's reward field: nothing to wait for)   // fwd_only: the forward kernels only (IL_FLAG_SAC_FORWARD_ONLY / data-parallel phase 0): no critic backward
+struct ChainRelabel { il_disc dd; int on, n_reduce; float* out; int fwd_only; int wait_indices; int local_rewards; int xcd_nets, gather_wgs; int early_draw; int overlap; long long ov_n; };   // overlap: 0 = off, else the grid size of the actor optimiser launch this launch waits for   // overlap (k_sac_chain_pair, il_sac_update_gather_overlap): the previous update's actor optimiser launch may still be running on the other stream - ov_n = this stage's own epoch (ov_own, set by the kernel) stands in for [IL_SYNC_MAIN_EPOCH] and the roles wait for [IL_SYNC_OV_EPOCH + IL_OV_DWA] >= ov_n where they first need what that launch writes   // early_draw: publish [IL_SYNC_CHAIN_WGS] (IL_EARLY_DRAW=0: the resident sampler waits for the previous update's end, as in round 4)   // xcd_nets: grid = 8 * nt, one network per XCD (chain_decode_xcd); gather_wgs: row-copy workgroups among the blocks of XCDs 6, 7   // wait_indices: IL_FLAG_SAC_WAIT_INDICES; local_rewards: il_sac_update_gather without `rewards` / `relabel` (the ring's reward field: nothing to wait for)   // fwd_only: the forward kernels only (IL_FLAG_SAC_FORWARD_ONLY / data-parallel phase 0): no critic backward
 // Runs between the critic's own work and its wait for the targets: the discriminator's step usually lands while the targets are still being computed,
 // so the relabel stays off the critical path. Leaves the tile's rewards in LDS (rew16) for critic_bwd_resident_scale.
 __device__ __forceinline__ void critic_relabel_tile(const il_sac& d, const ChainRelabel& rl, int k, int tile, float* smem) {
@@ -682,7 +682,7 @@ __device__ __forceinline__ float* pair_w1s(float* smem, int in_pad, int H) { ret
 // actor(s') of one tile as a pair (reference models.py:90-94 on next_states; training.py:21): the arithmetic of actor_fwd_tile(is_cur = false)
 // ov >= 0 (overlapped launches): the previous update's actor optimiser launch may still be running. The row indices and the rows are requested first; everything that launch
 // writes (the actor's parameters and lane-ordered copy, the Philox counter) is requested behind the wait for its epoch.
-__device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch& b, const float* __restrict__ eps_next, int tile, int half, float* smem, float* slab, unsigned* flag, long long ov = -1) {
+__device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch& b, const float* __restrict__ eps_next, int tile, int half, float* smem, float* slab, unsigned* flag, long long ov = -1, int ov_grid = 0) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch;
   const int row0 = tile * IL_TILE_R;
   const int Sp = round_up16(S), ldx = Sp + 4, ldh = H + 4, ldw1 = Sp + 4;
@@ -704,7 +704,7 @@ __device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch&
   if (ov >= 0) {   // rows first, then the wait; the weights behind it
     rows_issue(rp, Sp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, b.gather != nullptr, b.gather_capacity, false);
     if (head_thread) { if (b.gather) hidx = hidx < 0 ? 0 : (hidx >= b.gather_capacity ? b.gather_capacity - 1 : hidx); absorb_pre = gload(b.absorbing + (size_t)hidx * b.ld_absorbing); }
-    ov_wait(reinterpret_cast<long long*>(d.sync), IL_OV_DWA, ov);
+    ov_wait(reinterpret_cast<long long*>(d.sync), IL_OV_DWA, ov, ov_grid);
     IL_ST_GATE(IL_ST_CHAIN);
   }
   const int w1_lanes = H * S / 4;
@@ -781,7 +781,7 @@ __device__ __forceinline__ void actor_next_pair(const il_sac& d, const il_batch&
 }
 
 // target_k(s', a') of one tile as a pair (training.py:22): the arithmetic of critic_fwd_tile(net = 2 + k, await)
-__device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, int k, int tile, int half, float* smem, float* slab, unsigned* flag, unsigned* ctr, long long ov = -1) {
+__device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, int k, int tile, int half, float* smem, float* slab, unsigned* flag, unsigned* ctr, long long ov = -1, int ov_grid = 0) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int row0 = tile * IL_TILE_R;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
@@ -796,7 +796,7 @@ __device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, 
   RowsPre rp; rows_idx(rp, INp, row0, b.gather);
   if (ov >= 0) {   // overlapped launches: the target network is being stepped by the previous update's tail - rows first, its parameters behind the wait
     rows_issue(rp, INp, b.next_states, b.ld_next_states, S, nullptr, 0, 0, row0, b.gather != nullptr, b.gather_capacity, false);
-    ov_wait(reinterpret_cast<long long*>(d.sync), IL_OV_DWA, ov);
+    ov_wait(reinterpret_cast<long long*>(d.sync), IL_OV_DWA, ov, ov_grid);
     IL_ST_GATE(IL_ST_CHAIN);
   }
   const bool w1_regs = l1_rows_aligned(p.W1, IN);   // (wave-uniform) aligned rows: operand lanes straight into registers; otherwise through LDS
@@ -900,22 +900,24 @@ __device__ __forceinline__ void sac_chain_pair_body(il_sac& d, il_batch& b, cons
   float* slab = d.workspace + ws.x_slab + (size_t)slot * IL_TILE_R * (H / 2);
   unsigned* flag = reinterpret_cast<unsigned*>(d.workspace + ws.x_flag) + slot * IL_CTR_STRIDE;
   if (id.role == 0) {
-    actor_next_pair(d, b, eps_next, id.tile, id.half, smem, slab, flag, ov);
+    actor_next_pair(d, b, eps_next, id.tile, id.half, smem, slab, flag, ov, rl.overlap);
     if (id.half == 0) { tile_arrive_through(ctr, 1u); IL_TL(10, 7); }
   } else if (id.role == 1) {
-    target_pair(d, b, id.net, id.tile, id.half, smem, slab, flag, ctr, ov);
+    target_pair(d, b, id.net, id.tile, id.half, smem, slab, flag, ctr, ov, rl.overlap);
     if (id.half == 0) { tile_arrive_through(ctr, 1u); IL_TL(10, 7); }
   } else if (id.role == 4) {
     relabel_role(d, b, rl, id.tile, smem);
     tile_arrive_through(ctr, 16u);
     IL_TL(10, 7);
   } else if (id.role == 2) {
+    // overlapped launches: the critics could run their forward and the backward GEMM ahead of the wait (their parameters were stepped two launches ago), but measured
+    // (profiles/r06_overlap_timeline.txt) that work slowed down under the other workgroups' acquires and left dirty lines in the L2s that the previous launch's releases
+    // then had to write back: they wait first - they are not on the launch's critical path (actor(s') -> targets)
+    if (ov >= 0) { ov_wait(sy, IL_OV_DWA, ov, rl.overlap); IL_ST_GATE(IL_ST_CHAIN); }
     critic_fwd_tile(d, b, id.net, id.tile, smem, nullptr);
     IL_TL(10, 2);
     critic_bwd_resident_gemm(d, id.net, smem);
     IL_TL(10, 3);
-    // overlapped launches: the critics' own parameters were stepped two launches ago (visible since this launch began); log alpha, read below, is the previous tail's
-    if (ov >= 0) { ov_wait(sy, IL_OV_DWA, ov); IL_ST_GATE(IL_ST_CHAIN); }
     const RowScalars rs = critic_row_scalars(b, !rl.on && !rewards && !d.sync, id.tile);
     tile_await_bits<false>(ctr, 3u, rl.on ? 16u : 0u, tile_timeouts(d));   // (no acquire: what this workgroup reads of the tile's producers was written through, critic_bwd_resident_scale reads it below the L1)
     IL_TL(10, 5);
@@ -923,7 +925,7 @@ __device__ __forceinline__ void sac_chain_pair_body(il_sac& d, il_batch& b, cons
     critic_bwd_resident_scale(d, b, rewards, rl, rs, id.net, id.tile, smem, rl.on ? d.workspace + ws.c_rew : nullptr, true);
     IL_TL(10, 7);
   } else {
-    if (ov >= 0) { ov_wait(sy, IL_OV_DWA, ov); IL_ST_GATE(IL_ST_CHAIN); }   // actor(s): the previous actor optimiser launch reads the buffers this role writes, and writes the weights it reads
+    if (ov >= 0) { ov_wait(sy, IL_OV_DWA, ov, rl.overlap); IL_ST_GATE(IL_ST_CHAIN); }   // actor(s): the previous actor optimiser launch reads the buffers this role writes, and writes the weights it reads
     actor_fwd_tile(d, b, eps_next, eps_cur, true, id.tile, smem); IL_TL(10, 7);
   }
 }
@@ -1258,7 +1260,7 @@ IL_TILE_KERNELS(_pop, IL_POP_PANEL, __launch_bounds__(512, IL_POP_WAVES_PER_EU))
 // ---------------------------------------------------------------------------------------------
 // ov >= 0 (overlapped launches): the critic optimiser launch of this update may still be running on the other stream - the rows ((s, a~): written by the forward launch that
 // precedes this one in its stream) are requested first, the critic's parameters behind the wait for that launch's epoch.
-__device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_batch& b, int k, int tile, int half, float* smem, long long ov = -1) {
+__device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_batch& b, int k, int tile, int half, float* smem, long long ov = -1, int ov_grid = 0) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, B = d.batch, IN = S + A;
   const int nt = B / IL_TILE_R, row0 = tile * IL_TILE_R;
   const int INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
@@ -1280,7 +1282,7 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
   RowsPre rp; rows_idx(rp, INp, row0, nullptr);
   if (ov >= 0) {
     rows_issue(rp, INp, b.states, b.ld_states, S, W + ws.a_anew, A, A, row0, false, 0, true);
-    ov_wait(reinterpret_cast<long long*>(d.sync), IL_OV_DWC, ov + 1);
+    ov_wait(reinterpret_cast<long long*>(d.sync), IL_OV_DWC, ov + 1, ov_grid);
     IL_ST_GATE(IL_ST_POLICY_CRITIC);
   }
   const bool w1_regs = l1_rows_aligned(p.W1, IN);
@@ -1383,7 +1385,7 @@ __device__ __forceinline__ void policy_critic_pair(const il_sac& d, const il_bat
   IL_TL(11, 7);
 }
 
-__global__ __launch_bounds__(512) void k_policy_critic_pair(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, int helpers, int overlap) {
+__global__ __launch_bounds__(512) void k_policy_critic_pair(il_sac d, il_batch b, float* __restrict__ out_logp, float* __restrict__ out_q, int helpers, int overlap) {   // overlap: 0 = off, else the grid size of the critic optimiser launch this launch waits for
   extern __shared__ __attribute__((aligned(16))) float smem[];
   globalize(d); globalize(b);
   IL_ST_BEGIN(IL_ST_POLICY_CRITIC);
@@ -1421,7 +1423,7 @@ __global__ __launch_bounds__(512) void k_policy_critic_pair(il_sac d, il_batch b
   const int half = bx < 2 * nt ? 1 : 0;
   int k, tile;
   seg_decode(bx % (2 * nt), nt, 2, k, tile);
-  policy_critic_pair(d, b, k, tile, half, smem, ov);
+  policy_critic_pair(d, b, k, tile, half, smem, ov, overlap);
   IL_ST_END(IL_ST_POLICY_CRITIC);
   if (overlap) ov_done(osy, IL_OV_PC);
 }
@@ -1479,14 +1481,14 @@ struct DwArgs {
   // (round 6) overlapped launches (il_sac_update_gather_overlap): 0 = off; otherwise 1 + this launch's stage (IL_OV_DWC / IL_OV_DWA). The launch is resident while the
   // launch that produces its dZ / activations (stage - 1, on the other stream) still runs: block jobs request their p / m / v lanes, the tail's target step runs, and only
   // then they wait for [IL_SYNC_OV_EPOCH + stage - 1] > own epoch. `sync` is set for both launches in this mode.
-  int ov_stage;
+  int ov_stage, ov_grid;   // ov_grid: the grid size of the launch this one waits for
 };
 template <bool STAMP = false>   // STAMP: the single-learner kernel records when the wait was satisfied (IL_ST_GATE)
 __device__ __forceinline__ void dw_ov_wait(const DwArgs& a) {   // all threads of the workgroup
   const int stage = __builtin_amdgcn_readfirstlane(a.ov_stage);   // (wave-uniform by construction; a population launch builds its DwArgs from a descriptor it loaded)
   if (stage) {
     long long* sy = reinterpret_cast<long long*>(a.sync); const int st = stage - 1;
-    ov_wait(sy, st - 1, ov_own(sy, st) + 1);
+    ov_wait(sy, st - 1, ov_own(sy, st) + 1, a.ov_grid);
     if (STAMP) IL_ST_GATE(st == IL_OV_DWA ? IL_ST_DW_ACTOR : IL_ST_DW_CRITIC);
   }
 }
@@ -1636,7 +1638,7 @@ __device__ __forceinline__ void dw_bias(const DwArgs& a, const adam_consts& ac, 
 }
 
 template <bool PEER>
-__device__ __forceinline__ void dw_tail_alpha(const DwArgs& a, const DwPeer* pp) {   // tail block 0: Adam(log alpha), the Philox counter, the end-of-update signal (one thread)
+__device__ __forceinline__ void dw_tail_alpha(const DwArgs& a, const DwPeer* pp, bool poisoned = false) {   // tail block 0: Adam(log alpha), the Philox counter, the end-of-update signal (one thread); poisoned: no store to log alpha or its moments
   if (a.log_alpha && threadIdx.x == 0) {
     float s = 0.f;
     int i0 = 0;
@@ -1655,7 +1657,7 @@ __device__ __forceinline__ void dw_tail_alpha(const DwArgs& a, const DwPeer* pp)
     float gr = -(alpha) * (s / (float)a.batch);
     if (PEER) gr = peer_thread_allreduce1(pp->x, a.n_big_blocks, pp->alpha_at, gr);   // data-parallel: the mean over the ranks (its own arrival line behind the block jobs')
     if (a.grads_only) a.alpha_grad[0] = gr;
-    else {
+    else if (!poisoned) {
       const adam_consts ac = load_adam_consts(a.alpha_opt);
       float pp = a.log_alpha[0], mm = a.alpha_opt.m[0], vv = a.alpha_opt.v[0];
       adam_update(pp, gr, mm, vv, ac);
@@ -1743,13 +1745,6 @@ __device__ __forceinline__ void dw_adam_body(const DwArgs& a, const int bid, con
   const int wave_in_block = threadIdx.x >> 6;
   if (bid >= a.n_dw_blocks) {  // ---- tail blocks
     const int tb = bid - a.n_dw_blocks;
-    // overlapped launches: the target step needs nothing of the launch this one waits for (the critics were stepped by this stream's previous launch, the targets' last
-    // readers are gone) - it runs while that launch is still busy; block 0 then waits and closes the update (Adam(log alpha), Philox counter, [IL_SYNC_MAIN_EPOCH])
-    if (a.ov_stage) {
-      dw_tail_polyak(a, tb, nblocks - a.n_dw_blocks);
-      if (tb == 0) { dw_ov_wait(a); dw_tail_alpha<PEER>(a, pp); }
-      return;
-    }
     if (tb == 0) dw_tail_alpha<PEER>(a, pp);
     dw_tail_polyak(a, tb, nblocks - a.n_dw_blocks);
     return;
@@ -2012,7 +2007,8 @@ __device__ __forceinline__ void dw_block32(const DwArgs& a, const float* __restr
   const bool bias_owner = do_bias && tid < 128 && bg == 0 && n0 + bf < Nvalid;
   float bpp = 0.f, bmm = 0.f, bvv = 0.f;
   if (bias_owner && !a.grads_only) { const int64_t o = boff + n0 + bf; bpp = gload(a.params + o); bmm = gload(a.opt.m + o); bvv = gload(a.opt.v + o); }   // the bias's Adam operands: with the block's, up front
-  dw_ov_wait<GATE>(a);   // overlapped launches: dZ / the activations are still being written by the other stream's launch; p / m / v are on their way meanwhile
+  // (k_dw_adam only) an update whose hand-off expired - in an earlier launch of this update, or in the wait above - never reaches the weights: [IL_SYNC_POISON]
+  if (GATE) { dw_ov_wait<true>(a); if (a.sync && __syncthreads_or(sync_poisoned(reinterpret_cast<const long long*>(a.sync)) ? 1 : 0)) return; }   // overlapped launches: dZ / the activations are still being written by the other stream's launch; p / m / v are on their way meanwhile
   f32x4 acc0 = zero4(), acc1 = zero4();
   for (int r0 = 0; r0 < B; r0 += 2 * DWS_ROWS) {   // two chunks per trip, all their loads in flight together (B = 256: one trip)
     f32x4 zr[2][4], xr[2][4];
@@ -2176,7 +2172,6 @@ __device__ __forceinline__ void dw_adam_kernel(const DwArgs& a, const DwPeer* pp
       dw_block_job<PEER>(a, bx / per_net, bx % per_net, smem, pp, bx);
       IL_TL_END(a.log_alpha ? 2 : 1);
       IL_ST_END(st_kid);
-      if (a.ov_stage) ov_done(reinterpret_cast<long long*>(a.sync), a.ov_stage - 1);
       return;
     }
     DwArgs r = a;
@@ -2184,7 +2179,6 @@ __device__ __forceinline__ void dw_adam_kernel(const DwArgs& a, const DwPeer* pp
     dw_adam_body<IL_DW_U, true, PEER>(r, bx - a.n_big_blocks, (int)gridDim.x - a.n_big_blocks, pp);
     IL_TL_END(a.log_alpha ? 2 : 1);
     IL_ST_END(st_kid);
-    if (a.ov_stage) ov_done(reinterpret_cast<long long*>(a.sync), a.ov_stage - 1);
     return;
   }
   dw_adam_body<IL_DW_U>(a, (int)blockIdx.x, (int)gridDim.x);
@@ -2206,12 +2200,15 @@ __global__ __launch_bounds__(256) void k_dw_adam(DwArgs a) {   // a.n_big_blocks
     dw_block_job<false, true>(a, bx / per_net, bx % per_net, smem, nullptr, bx);
   } else {
     const int tb = bx - a.n_big_blocks, ntb = (int)gridDim.x - a.n_big_blocks;
-    if (a.ov_stage) {   // overlapped launches: see dw_adam_body's tail
-      dw_tail_polyak(a, tb, ntb);
-      if (tb == 0) { dw_ov_wait<true>(a); dw_tail_alpha<false>(a, nullptr); }
+    // overlapped launches: the target step needs nothing of the launch this one waits for (the critics were stepped by this stream's previous launch, the targets' last
+    // readers are gone) - it runs while that launch is still busy; block 0 then waits and closes the update (Adam(log alpha), Philox counter, [IL_SYNC_MAIN_EPOCH])
+    const bool poisoned = a.sync && __syncthreads_or(sync_poisoned(reinterpret_cast<const long long*>(a.sync)) ? 1 : 0);   // (the tail still closes the update: counters and signals keep the pipeline moving until the host has seen the flag)
+    if (a.ov_stage) {
+      if (!poisoned) dw_tail_polyak(a, tb, ntb);
+      if (tb == 0) { dw_ov_wait<true>(a); dw_tail_alpha<false>(a, nullptr, poisoned || sync_poisoned(reinterpret_cast<const long long*>(a.sync))); }
     } else {
-      if (tb == 0) dw_tail_alpha<false>(a, nullptr);
-      dw_tail_polyak(a, tb, ntb);
+      if (tb == 0) dw_tail_alpha<false>(a, nullptr, poisoned);
+      if (!poisoned) dw_tail_polyak(a, tb, ntb);
     }
   }
   IL_TL_END(a.log_alpha ? 2 : 1);
@@ -2288,7 +2285,7 @@ __host__ __device__ static DwArgs critic_dw_args(const il_sac* d, uint32_t flags
   const SacWs ws = sac_ws(S, A, H, B);
   DwArgs a = {};
   a.params = d->critic; a.grads = d->critic_grad; a.opt = d->critic_opt; a.grads_only = (flags & IL_FLAG_GRADS_ONLY) ? 1 : 0;
-  a.n_nets = 2; a.net_stride = net_stride(IN, H, 1); a.in_dim = IN; a.hidden = H; a.out_dim = 1; a.batch = B;
+  a.n_nets = 2; a.net_stride = net_stride(IN, H, 1); a.in_dim = IN; a.hidden = H; a.out_dim = 1; a.batch = B; a.sync = d->sync;   // (sync: the poison check of k_dw_adam; the tail that signals through it belongs to the actor's launch)
   a.x0 = d->workspace + ws.c_x0; a.ld_x0 = 0; a.x0_transposed = 1; a.x0_net_stride = 0;
   a.h1 = d->workspace + ws.c_h1; a.h2 = d->workspace + ws.c_h2; a.dz1 = d->workspace + ws.c_dz1; a.dz2 = d->workspace + ws.c_dz2; a.h_net_stride = (int64_t)B * H;
   a.dz3 = d->workspace + ws.c_dz3; a.dz3_net_stride = B;
@@ -2521,11 +2518,13 @@ static int sac_update_gather_impl(const il_sac* d, const il_batch* rows, const i
     DwArgs ca = critic_dw_args(d, flags), aa = actor_dw_args(d, rows, flags);
     if (!chain_pair_ok(d, rl.on, G) || !policy_critic_pair_ok(d) || ca.n_big_blocks <= 0 || aa.n_big_blocks <= 0)
       return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update_gather_overlap: the pair-mode shape (hidden 256, round_up16(S + A) <= 64, batch %% 128 == 0, every launch co-resident) only");
-    rl.overlap = 1;
-    ca.sync = d->sync; ca.ov_stage = 1 + IL_OV_DWC; aa.ov_stage = 1 + IL_OV_DWA;
+    const int hp = pc_helpers(nt), g_chain = chain_pair_workgroups(nt, rl.on, G), g_dwc = ca.n_dw_blocks, g_pc = (4 + hp) * nt, g_dwa = aa.n_dw_blocks + IL_TAIL_BLOCKS;
+    if (g_chain > IL_OV_MAX_GRID || g_dwc > IL_OV_MAX_GRID || g_pc > IL_OV_MAX_GRID || g_dwa > IL_OV_MAX_GRID) return il_set_error(IL_ERR_UNSUPPORTED, "il_sac_update_gather_overlap: a launch of more than %d workgroups", IL_OV_MAX_GRID);
+    rl.overlap = g_dwa;
+    ca.sync = d->sync; ca.ov_stage = 1 + IL_OV_DWC; ca.ov_grid = g_chain; aa.ov_stage = 1 + IL_OV_DWA; aa.ov_grid = g_pc;
     { IL_TRACE("k_sac_chain", st); k_sac_chain_pair<<<chain_pair_workgroups(nt, rl.on, G), 512, IL_PAIR_LDS_BYTES, st>>>(*d, *ring, eps_next, eps_cur, rewards, const_cast<float*>(rows->states), rl); }
     { IL_TRACE("k_dw_adam_critic", sb); launch_dw_adam(ca, ca.n_dw_blocks, sb); }
-    launch_policy_critic(d, rows, out_logp, out_q, lds, st, 1);
+    launch_policy_critic(d, rows, out_logp, out_q, lds, st, g_dwc);
     { IL_TRACE("k_dw_adam_actor", sb); launch_dw_adam(aa, aa.n_dw_blocks + IL_TAIL_BLOCKS, sb); }
     IL_CHECK_LAUNCH("il_sac_update_gather_overlap");
     return IL_OK;
@@ -2561,15 +2560,15 @@ extern "C" int il_sac_update_gather_overlap(const il_sac* d, const il_batch* row
   IL_CHECK_ARG(stream_b, "il_sac_update_gather_overlap: stream_b must be a stream of its own");
   return sac_update_gather_impl(d, rows, ring, rewards, relabel, rewards_out, eps_next, eps_cur, out_logp, out_q, flags, nullptr, nullptr, stream_a, stream_b);
 }
-__global__ void k_overlap_enter(long long* sy) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const long long n = sy[IL_SYNC_MAIN_EPOCH];
-    for (int st = 0; st < 4; ++st) { sy[IL_SYNC_OV_EPOCH + st * IL_SYNC_STRIDE] = n; sy[IL_SYNC_OV_TICKET + st * IL_SYNC_STRIDE] = 0; }
-  }
+__global__ void k_overlap_enter(long long* sy) {   // <<<4, IL_OV_MAX_GRID>>>: block = stage, thread = workgroup flag
+  const long long n = sy[IL_SYNC_MAIN_EPOCH];
+  const int st = blockIdx.x;
+  if (threadIdx.x == 0) { sy[IL_SYNC_OV_EPOCH + st * IL_SYNC_STRIDE] = n; sy[IL_SYNC_OV_TICKET + st * IL_SYNC_STRIDE] = 0; }
+  sy[IL_SYNC_OV_FLAGS + ((long long)st * IL_OV_MAX_GRID + threadIdx.x) * IL_SYNC_STRIDE] = n;
 }
 extern "C" int il_sac_overlap_enter(const il_sac* d, il_stream_t stream_) {
   IL_CHECK_ARG(d && d->sync, "il_sac_overlap_enter: needs the il_sync counters");
-  k_overlap_enter<<<1, 64, 0, (hipStream_t)stream_>>>(reinterpret_cast<long long*>(d->sync));
+  k_overlap_enter<<<4, IL_OV_MAX_GRID, 0, (hipStream_t)stream_>>>(reinterpret_cast<long long*>(d->sync));
   IL_CHECK_LAUNCH("il_sac_overlap_enter");
   return IL_OK;
 }

@@ -527,6 +527,7 @@ class UpdatePlan:
     # Device-side hand-off between the two branches (include/il_hip.h `il_sync`): the discriminator branch and the SAC forward then share no stream
     # dependency between the gather and the critic loss. Validated by `capture()`; IL_DEVICE_SYNC=0 keeps plain stream dependencies.
     self._sync_slots, self._sync_timeouts, self._sync_gather_wgs, _, self._sync_spin, self._sync_host_flag = _lib.sync_layout()
+    self._sync_poison = _lib.sync_layout_ex()[6]
     self.sync = torch.zeros(self._sync_slots, dtype=torch.int64, device=dev)   # IL_SYNC_SLOTS: every counter on its own 128-byte line
     self.device_sync = False
     self._chain_fits = None
@@ -551,7 +552,7 @@ class UpdatePlan:
     # the last SAC-branch enqueue of this plan was an overlapped one (the stage epochs are in step with [IL_SYNC_MAIN_EPOCH]; the caller's stream is NOT ordered behind
     # `ov_stream` until `join()`); `_ov_probe`: None = not probed yet
     self.ov_stream, self._ov_active, self._ov_probe, self._recording, self._direct_overlap = None, False, None, False, False
-    self._sync_poison = _lib.sync_layout_ex()[6]
+    self._watch_np = None
 
   def record_relu_masks(self) -> Tensor:
     """Tests only (il_sac.debug_masks, include/il_hip.h): from now on every update ALSO writes, for its three back-propagated passes, which hidden pre-activations
@@ -655,8 +656,11 @@ class UpdatePlan:
     the two optimiser launches on `ov_stream` - and hand over through stage epochs on the device (il_sac_update_gather_overlap, include/il_hip.h): every launch is dispatched
     while its predecessor still runs, does what does not depend on it (row gathers, the optimiser's p / m / v streams, the target step, the critics' forward) and waits behind
     that. Bit-identical to the in-order schedule (`test_schedule_switches_are_bit_identical[IL_MAIN_OVERLAP-*]`). Needs three streams on three hardware queues (probed once:
-    `ov_stream` against the caller's stream both ways, and against the discriminator branch's). IL_MAIN_OVERLAP=0: in-order launches on one stream."""
-    if os.environ.get('IL_MAIN_OVERLAP', '1') == '0' or not self.device_sync or not self._prepared or self.general:
+    `ov_stream` against the caller's stream both ways, and against the discriminator branch's).
+    OFF by default (IL_MAIN_OVERLAP=1 switches it on): measured SLOWER than in-order launches on one stream, 15.5k against 17.8k updates/s (profiles/r06_overlap_ab.txt,
+    r06_overlap_timeline.txt): a device-side hand-off (drain, L2 write-back, ticket; poll, flag, poll; L2 invalidate) takes 3 - 4.5 us where the queue's own
+    launch boundary takes 1.5 - 2.5, and that eats the 2 - 3 us of prologue each launch moves ahead of its wait."""
+    if os.environ.get('IL_MAIN_OVERLAP', '0') != '1' or not self.device_sync or not self._prepared or self.general:
       return False
     if self.peer_desc is not None or getattr(self, 'data_parallel', False) or self.pre_hooks or self.post_hooks or not self.ring_mode:
       return False
@@ -722,6 +726,7 @@ class UpdatePlan:
     device when a wait expires, not baked into a launch)."""
     if getattr(self, '_watch_host', None) is None:
       self._watch_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+      self._watch_np = self._watch_host.numpy()   # (the same pinned words as a numpy view: a ~100 ns host read per launch_direct / replay)
     self.sync[self._sync_host_flag] = self._watch_host.data_ptr()
     if peer_status is not None:
       peer_status[1] = self._watch_host[1:].data_ptr()
@@ -1167,6 +1172,7 @@ class UpdatePlan:
     stream (an acting forward, an evaluation, a checkpoint) then sees the stepped networks, as it does behind an in-order update. join=False: back-to-back updates with
     nothing in between (offline training, several updates per environment step, bench.py): the next update's first launch is dispatched while this one's last still runs;
     call `join()` before reading anything."""
+    self._raise_if_poisoned()
     if self.main_feeds_ring and self._captured_resident:
       self.side.wait_stream(torch.cuda.current_stream())   # (as replay(): appends enqueued since the last update precede the resident index draw)
     if self._direct_overlap and not self._ov_active:
@@ -1186,7 +1192,17 @@ class UpdatePlan:
     if self._ov_active:
       torch.cuda.current_stream().wait_stream(self.ov_stream)
 
+  def _raise_if_poisoned(self):
+    """watch_timeouts(): a bounded device-side wait of this learner has given up (pinned host word, no synchronisation). From that launch on the optimiser launches have
+    skipped their stores ([IL_SYNC_POISON]): the weights are those of the last complete update. Raised at the NEXT launch, not at the next logging interval."""
+    w = self._watch_np
+    if w is not None and w[0]:
+      raise RuntimeError(f'UpdatePlan: {int(w[0])} device-side hand-off wait(s) expired (the branches of the update did not run concurrently: a profiler that serialises kernels, a CU '
+                         'mask, a co-tenant process). The optimiser launches of that update and of every later one skipped their stores - the networks hold the last complete '
+                         'update - and will keep doing so until clear_poison(). IL_DEVICE_SYNC=0 selects plain stream dependencies.')
+
   def replay(self):
+    self._raise_if_poisoned()
     self._ov_leave()
     if self.graph_side is not None:
       if self.main_feeds_ring and self._captured_resident:

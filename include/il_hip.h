@@ -203,10 +203,12 @@ int il_polyak(float* target, const float* param, int64_t n, double tau, il_strea
  *                          waiting for [IL_SYNC_MAIN_EPOCH]; the discriminator workgroups, which read the Philox counter the actor step advances, still wait for the epoch.
  *   [IL_SYNC_PARAMS]     += 1 per finished AdamW(discriminator) workgroup (IL_FLAG_GAIL_CLOSE_EPOCH) -> the inline relabel of il_sac_update_gather waits
  *                          for (main_epoch + 1) * il_gail_step_workgroups()
- *   [IL_SYNC_OV_EPOCH + stage]  += 1 when EVERY workgroup of that stage's launch has retired (il_sac_update_gather_overlap only; the last workgroup to take a ticket on
- *                          [IL_SYNC_OV_TICKET + stage] resets the ticket line and bumps the epoch with an agent-scope release). The next stage's launch sits on the OTHER
- *                          stream, is resident before this one ends, and waits for the epoch behind its independent prologue. il_sac_overlap_enter() sets all four to
- *                          [IL_SYNC_MAIN_EPOCH] so that a stage's own epoch is also the number of finished updates.
+ *   [IL_SYNC_OV_TICKET + stage] += 1 (release, no returned value) by every retiring workgroup of that stage's launch (il_sac_update_gather_overlap only). The next stage's
+ *                          launch sits on the OTHER stream and is resident before this one ends. Its workgroup 0 - the only poller of the ticket line - waits for
+ *                          ticket >= the producer's grid behind its independent prologue, CLOSES the stage ([IL_SYNC_OV_EPOCH + stage] = launch number, ticket = 0) and
+ *                          stores the launch number into [IL_SYNC_OV_FLAGS + stage, w] for every workgroup w of its own launch; workgroup w polls that line of its own
+ *                          (160 workgroups polling ONE line were measured to slow every kernel on the chip down: the line's memory channel queues).
+ *                          il_sac_overlap_enter() sets the four epochs and every flag to [IL_SYNC_MAIN_EPOCH]: a stage's own epoch is also the number of finished updates.
  *   [IL_SYNC_POISON]     != 0 once a bounded wait of this learner has given up: the optimiser epilogues (k_dw_adam, k_gail_reduce) of every later launch skip their
  *                          stores - an update whose hand-off expired never reaches the weights - until the host clears the word (il_sync_clear_poison). Same read-only line
  *                          as [IL_SYNC_SPIN].
@@ -226,7 +228,9 @@ enum { IL_SYNC_ROWS = 0, IL_SYNC_REWARDS = 1 * IL_SYNC_STRIDE, IL_SYNC_SIDE_EPOC
        IL_SYNC_HOST_FLAG = 5 * IL_SYNC_STRIDE + 2, IL_SYNC_POISON = 5 * IL_SYNC_STRIDE + 3,
        IL_SYNC_OV_EPOCH = 12 * IL_SYNC_STRIDE,  /* + stage * IL_SYNC_STRIDE, stage = IL_OV_CHAIN .. IL_OV_DWA (lines 12 .. 15) */
        IL_SYNC_OV_TICKET = 16 * IL_SYNC_STRIDE, /* + stage * IL_SYNC_STRIDE (lines 16 .. 19) */
-       IL_SYNC_SLOTS = 20 * IL_SYNC_STRIDE };
+       IL_SYNC_OV_FLAGS = 20 * IL_SYNC_STRIDE,  /* + (stage * IL_OV_MAX_GRID + workgroup) * IL_SYNC_STRIDE: one line per WAITING workgroup of the stage's consumer launch */
+       IL_OV_MAX_GRID = 256,
+       IL_SYNC_SLOTS = (20 + 4 * 256) * IL_SYNC_STRIDE };
 /* Stages of the SAC branch when its four launches alternate over two streams (il_sac_update_gather_overlap): forward / critic loss, critic optimiser,
  * policy / critic, actor optimiser + tail. */
 enum { IL_OV_CHAIN = 0, IL_OV_DWC = 1, IL_OV_PC = 2, IL_OV_DWA = 3 };

@@ -122,6 +122,7 @@ struct Block {
   uint64_t* shfl_val = nullptr; unsigned* shfl_tag = nullptr; unsigned* shfl_seq = nullptr;
   unsigned char* coll_val = nullptr; unsigned* coll_tag = nullptr; unsigned* coll_seq = nullptr;   // wave-level exchange: payload slots [ring][lane], per (ring slot, wave) {arrivals, exchange number}, per-lane exchange counter
   unsigned* wave_done = nullptr;   // per wave: lanes that have returned from the kernel
+  unsigned* or_seq = nullptr; int or_val[2] = {0, 0};   // __syncthreads_or: per-thread call counter, two alternating accumulators
   std::vector<std::pair<const void*, void*>> statics;   // static __shared__ variables of the kernel: per workgroup (build.py turns the declarations into lookups)
   const std::function<void()>* body = nullptr;
   bool yield_requested = false;
@@ -184,7 +185,7 @@ inline Block* acquire_block(int n) {
     if (b->stacks == (char*)MAP_FAILED) { perror("emu: mmap of fiber stacks"); abort(); }
     b->fibers = new Fiber[n];
     b->shfl_val = new uint64_t[(size_t)SHFL_RING * n]; b->shfl_tag = new unsigned[(size_t)SHFL_RING * n]; b->shfl_seq = new unsigned[n];
-    b->coll_val = new unsigned char[(size_t)COLL_RING * n * COLL_BYTES]; b->coll_tag = new unsigned[(size_t)COLL_RING * n]; b->coll_seq = new unsigned[n]; b->wave_done = new unsigned[(n + 63) / 64];
+    b->coll_val = new unsigned char[(size_t)COLL_RING * n * COLL_BYTES]; b->coll_tag = new unsigned[(size_t)COLL_RING * n]; b->coll_seq = new unsigned[n]; b->wave_done = new unsigned[(n + 63) / 64]; b->or_seq = new unsigned[n];
   }
   return b;
 }
@@ -192,7 +193,8 @@ inline void start_block(Block* b, dim3 idx, dim3 gdim, dim3 bdim, size_t lds_byt
   b->idx = idx; b->gdim = gdim; b->bdim = bdim; b->n = (int)(bdim.x * bdim.y * bdim.z); b->body = body; b->yield_requested = false;
   b->lds = malloc(lds_bytes ? lds_bytes : 16);   // exactly the launch's LDS (16-byte aligned like every malloc): an AddressSanitizer build sees the first byte past it
   memset(b->lds, 0xcd, lds_bytes);               // LDS is not zero on the GPU either: poison it so that a read of an unwritten word shows
-  for (int i = 0; i < b->n; ++i) { make_fiber(b, i); b->fibers[i].state = RUNNABLE; b->shfl_seq[i] = 0; b->coll_seq[i] = 0; }
+  for (int i = 0; i < b->n; ++i) { make_fiber(b, i); b->fibers[i].state = RUNNABLE; b->shfl_seq[i] = 0; b->coll_seq[i] = 0; b->or_seq[i] = 0; }
+  b->or_val[0] = b->or_val[1] = 0;
   memset(b->shfl_tag, 0xff, sizeof(unsigned) * SHFL_RING * b->cap);
   memset(b->coll_tag, 0xff, sizeof(unsigned) * COLL_RING * b->cap);
   memset(b->wave_done, 0, sizeof(unsigned) * ((b->cap + 63) / 64));
@@ -400,6 +402,18 @@ inline void emu_log_launch(const char* name) { static const char* f = getenv("IL
 inline void __syncthreads() {
   emu::blk->fibers[emu::cur].state = emu::AT_BARRIER;
   emu::to_scheduler();
+}
+// every thread of the workgroup calls; non-zero if any thread's predicate is. Two alternating accumulators: a slot is cleared (by thread 0, behind the second barrier) before
+// any thread can reach the call after next, which is the next user of that slot.
+inline int __syncthreads_or(int pred) {
+  emu::Block* b = emu::blk;
+  const int t = emu::linear_tid(), slot = (int)(b->or_seq[t]++ & 1u);
+  if (pred) b->or_val[slot] = 1;
+  __syncthreads();
+  const int r = b->or_val[slot];
+  __syncthreads();
+  if (t == 0) b->or_val[slot] = 0;
+  return r;
 }
 template <class T>
 inline T __shfl(T v, int src, int width = 64) {

@@ -539,6 +539,23 @@ def test_direct_launches_equal_the_graph_replays_on_the_emulated_kernels(monkeyp
   tt.test_direct_launches_equal_the_graph_replays(K=2, seed=9)
 
 
+def test_overlapped_launches_equal_the_graph_replays_on_the_emulated_kernels(monkeypatch):
+  """IL_MAIN_OVERLAP=1: il_sac_update_gather_overlap's four launches on two emulated streams (forward / critic loss and policy / critic on the caller's, the optimiser
+  launches on another), co-resident with their predecessors and handing over through tickets, stage epochs and per-workgroup flag lines: the bits of the in-order replays."""
+  tgp = _emulated_product(monkeypatch, streams=True)
+  tt, bench = _timed_path_modules(monkeypatch, tgp)
+  monkeypatch.setenv('IL_MAIN_OVERLAP', '1')
+  tt.test_direct_launches_equal_the_graph_replays(K=3, seed=9, expect_overlap=True)
+
+
+def test_expired_wait_poisons_the_learner_on_the_emulated_kernels(monkeypatch):
+  """[IL_SYNC_POISON]: tests/test_timed_path_oracle.py's body - a branch launched without its partner under a four-poll bound - on the kernel sources: the optimiser
+  epilogues of k_dw_adam / k_gail_reduce skip every store, the flags are raised, the next launch raises on the host."""
+  tgp = _emulated_product(monkeypatch, streams=True)
+  tt, bench = _timed_path_modules(monkeypatch, tgp)
+  tt.test_expired_wait_poisons_the_learner_and_the_weights_stay()
+
+
 def _update_plan_cases():
   """(The GAIL discriminator variants run torch operations - log-probability buffers, the reward copy - between their launches inside the plan; the emulator defers kernels on its
   streams but cannot defer torch's CPU operations with them, so those cases need a GPU.)"""

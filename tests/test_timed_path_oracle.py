@@ -237,7 +237,51 @@ def test_captured_update_plan_replays_through_the_oracle(SEED):
     np.testing.assert_array_equal(a, N(n.flat if hasattr(n, 'flat') else n))
 
 
-def test_direct_launches_equal_the_graph_replays(K=6, seed=9):
+@pytest.mark.gpu
+def test_expired_wait_poisons_the_learner_and_the_weights_stay():
+  """[IL_SYNC_POISON] (round 6): a bounded device-side wait that gives up must not let its update reach the weights. The SAC branch is launched ALONE with a bound of four
+  polls - its wait for the index draw and the relabel's wait for the discriminator step expire - and, separately, the discriminator branch alone: afterwards every
+  parameter, Adam moment, the target network, log alpha and the spectral-norm vectors hold the bits they had before; the device flag, the time-out counter and the pinned
+  host word are raised, and the next launch_direct() / replay() raises on the host instead of at the next logging interval."""
+  il_training._NOISE.clear(); il_training._WS.clear()
+  plan, nets, _ = bench.build(torch.device(DEV), 0, seed=13)
+  for _ in range(3): plan.run()
+  torch.cuda.synchronize()
+  plan.watch_timeouts()
+  plan.record_direct()
+  for _ in range(3): plan.launch_direct()
+  plan.join(); torch.cuda.synchronize()
+  assert plan.sync_timeouts() == 0 and not plan.poisoned() and plan.timeouts_seen() == (0, 0)
+  actor, critic, target, log_alpha, disc = nets
+  ao, co, to, do = plan._keep[4], plan._keep[5], plan._keep[6], plan._keep[8]
+  state = lambda: [N(t).copy() for t in (actor.flat, critic.flat, target.flat, log_alpha, disc.flat, disc.sn, ao.exp_avg, ao.exp_avg_sq, co.exp_avg, co.exp_avg_sq, to.exp_avg, to.exp_avg_sq,
+                                         do.exp_avg, do.exp_avg_sq)]
+  before = state()
+  plan.sync[plan._sync_spin] = 4   # every [IL_SYNC_SPIN]-bounded wait gives up after four polls
+  for fn, args in plan._direct_main:   # the SAC branch without its discriminator branch: no index draw, no discriminator step to wait for
+    assert fn(*args) == 0
+  torch.cuda.synchronize()
+  assert plan.sync_timeouts() > 0 and plan.poisoned() and plan.timeouts_seen()[0] > 0
+  for a, b in zip(before, state()): np.testing.assert_array_equal(a, b)
+  with pytest.raises(RuntimeError, match='hand-off wait'): plan.launch_direct()
+  for fn, args in plan._direct_side:   # ... and a discriminator step of the poisoned learner stores nothing either
+    assert fn(*args) == 0
+  torch.cuda.synchronize()
+  for a, b in zip(before, state()): np.testing.assert_array_equal(a, b)
+  plan.sync[plan._sync_spin] = 0
+  plan.clear_poison(); torch.cuda.synchronize()
+  assert not plan.poisoned() and plan.sync_timeouts() == 0 and plan.timeouts_seen()[0] == 0
+
+
+@pytest.mark.gpu
+def test_overlapped_launches_equal_the_graph_replays(monkeypatch):
+  """IL_MAIN_OVERLAP=1 (round 6, off by default: measured slower): the SAC branch's four launches alternating over two streams with stage hand-offs on the device
+  (il_sac_update_gather_overlap), issued back to back without a join, leave the bits of the in-order graph replays; no wait expired, the learner is not poisoned."""
+  monkeypatch.setenv('IL_MAIN_OVERLAP', '1')
+  test_direct_launches_equal_the_graph_replays(K=40, seed=11, expect_overlap=True)
+
+
+def test_direct_launches_equal_the_graph_replays(K=6, seed=9, expect_overlap=False):
   """UpdatePlan.record_direct / launch_direct: the same two branches as direct launches (two library calls per update, no hipGraph) leave every persistent tensor and every
   per-update output with the bits of the graph replays."""
   finals = []
@@ -251,9 +295,14 @@ def test_direct_launches_equal_the_graph_replays(K=6, seed=9):
     else:
       plan.record_direct(); step = plan.launch_direct
       assert len(plan._direct_side) == 1 and len(plan._direct_main) == 1, 'one library call per branch'
+      assert bool(plan._direct_overlap) == bool(expect_overlap), 'the overlapped launches were expected and did not run (no third hardware queue?)' if expect_overlap else 'overlapped launches are opt-in'
+      if expect_overlap:
+        import functools
+        step = functools.partial(plan.launch_direct, join=False)   # back to back: the next update's first launch is dispatched while this one's last still runs
     for _ in range(K): step()
+    plan.join()
     torch.cuda.synchronize()
-    assert plan.sync_timeouts() == 0
+    assert plan.sync_timeouts() == 0 and not plan.poisoned()
     finals.append([N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [N(plan.logp), N(plan.q), N(plan.rewards), N(plan.idx), N(plan.eidx)])
   for a, b in zip(*finals):
     assert np.isfinite(a).all()
