@@ -386,11 +386,389 @@ static void g_pack(hipStream_t st, const float* f1, int ld1, int K1, const float
   k_g_pack<<<(total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024, 256, 0, st>>>(f1, ld1, K1, f2, ld2, K2, n, Bp, XT);
 }
 
+
+// =================================================================================================================================================================
+// Tile engine (round 6): the same networks as 16-row tiles that stay in LDS across ALL layers of a pass, built from the fused path's primitives (mlp_tile.hpp: tile_fwd,
+// tile_fwd_packed / tile_bwd_packed on lane-ordered copies of the H x H layers, tile_bwd_dx, tile_fwd_small). A depth-3 update is 9 launches instead of 49:
+//   k_gt_repack   lane-ordered PF / PB copies of every H x H layer (actor, critics, targets)
+//   k_gt_fwd      up to four PASSES per launch (blockIdx.y): actor(s') and actor(s) with the tanh-Gaussian head in the epilogue, critic_1,2(s, a); then target_1,2(s', a');
+//                 later critic_1,2(s, a~). A workgroup = (tile, pass): input rows -> every hidden layer -> output, hidden activations written feature-major for the backward
+//   k_gt_bwd      (tile, net): the loss seed of the tile's rows in the prologue (critic loss / policy / actor head / behavioural cloning - the per-row kernels' arithmetic),
+//                 then dZ of every layer back to front, written feature-major for k_gt_dw; the policy pass ends with the action columns of dL/d(input)
+//   k_gt_dw       every layer's weight and bias gradient of up to two networks in one launch (k_g_dw's tiles), AdamW in the epilogue (and the lane-ordered copies kept in step);
+//                 the actor's launch carries the temperature step, the target update and the Philox counter as tail workgroups
+// Applies when both networks have hidden widths that are multiples of 16 (<= 512), inputs <= 512 wide and 2A <= 16; anything else keeps the layer-at-a-time launches above
+// (IL_GENERAL_TILES=0 forces them: the A/B and the bit-for-bit reference of the hidden layers). Per element the hidden layers run k_g_linear / k_g_bwd's MFMA order; the output
+// layer's dot product is split over the waves (tile_fwd_small: partial tiles summed in k-block order), so results equal the layer-at-a-time path to rounding, not bit for bit.
+// =================================================================================================================================================================
+struct GtNet { const float* P; int in, H, depth, out, act; const float* PF; const float* PB; };   // PF / PB: [depth - 1][H * H] lane-ordered copies (NULL: read W directly)
+__host__ __device__ static inline int gt_threads(int H) { return H * 4 < 256 ? 256 : (H * 4 > 1024 ? 1024 : H * 4); }
+
+struct GtFwdPass {
+  GtNet net;
+  const float* f1; int ld1, K1; const float* f2; int ld2, K2;   // input rows cat(f1, f2), row-major; rows >= n are zero
+  float* X0T; float* HT; float* OT;                              // feature-major outputs (NULL: not kept): input copy [in][Bp], hidden activations [depth][H][Bp], raw output [out][Bp]
+  int head;                                                      // 1: tanh-Gaussian sample of an actor pass (GSample's fields below)
+  const float* eps; uint64_t seed; const uint32_t* ctr_ptr; uint32_t ctr; int stream_id; const float* absorbing; int ld_abs; int greedy;
+  float* a_rows; int ld_a; float* xT; float* epsT; float* logp;
+};
+struct GtFwd { GtFwdPass p[4]; int n, Bp; };
+
+__global__ __launch_bounds__(1024) void k_gt_fwd(GtFwd a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const GtFwdPass& q = a.p[blockIdx.y];
+  const GtNet& nn = q.net;
+  const int H = nn.H, in = nn.in, depth = nn.depth, out = nn.out, act = nn.act, Bp = a.Bp;
+  const int row0 = blockIdx.x * 16, nrows = min(16, a.n - row0);
+  const int inp = round_up16(in), ldx = inp + 4, ldh = H + 4;
+  float* Xs = smem; float* A0 = Xs + 16 * ldx; float* A1 = A0 + 16 * ldh; float* part = A1 + 16 * ldh; float* Os = part + (H >> 4) * 256;
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, tid = threadIdx.x;
+  load_rows_cat(Xs, ldx, inp, q.f1, q.ld1, q.K1, q.f2, q.ld2, q.K2, row0, nrows);
+  __syncthreads();
+  if (q.X0T)
+    for (int i = tid; i < 16 * in; i += blockDim.x) { const int c = i >> 4, r = i & 15; q.X0T[(size_t)c * Bp + row0 + r] = Xs[r * ldx + c]; }
+  const float* P = nn.P;
+  float* cur = A0; float* nxt = A1;
+  {
+    const GLayer L = g_layer(in, H, depth, out, 0);
+    const float* bias = P + L.ob;
+    tile_fwd(Xs, ldx, inp, P + L.oW, in, in, H, [&](int c0, f32x4 acc) {
+      const int col = c0 + j; const float bb = gload(bias + col);
+      f32x4 hv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { hv[r] = g_act(acc[r] + bb, act); cur[(4 * g + r) * ldh + col] = hv[r]; }
+      if (q.HT) *reinterpret_cast<f32x4*>(q.HT + (size_t)col * Bp + row0 + 4 * g) = hv;
+    });
+  }
+  __syncthreads();
+  for (int l = 1; l < depth; ++l) {
+    const GLayer L = g_layer(in, H, depth, out, l);
+    const float* bias = P + L.ob;
+    float* ht = q.HT ? q.HT + (size_t)l * H * Bp : nullptr;
+    auto epi = [&](int c0, f32x4 acc) {
+      const int col = c0 + j; const float bb = gload(bias + col);
+      f32x4 hv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { hv[r] = g_act(acc[r] + bb, act); nxt[(4 * g + r) * ldh + col] = hv[r]; }
+      if (ht) *reinterpret_cast<f32x4*>(ht + (size_t)col * Bp + row0 + 4 * g) = hv;
+    };
+    if (nn.PF) tile_fwd_packed(cur, ldh, H, nn.PF + (size_t)(l - 1) * H * H, epi);
+    else tile_fwd(cur, ldh, H, P + L.oW, H, H, H, epi);
+    __syncthreads();
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  {
+    const GLayer L = g_layer(in, H, depth, out, depth);
+    tile_fwd_small(cur, ldh, H, P + L.oW, H, out, P + L.ob, Os, part);   // (barriers inside)
+  }
+  if (q.OT)
+    for (int i = tid; i < 16 * out; i += blockDim.x) { const int c = i >> 4, r = i & 15; q.OT[(size_t)c * Bp + row0 + r] = Os[r * 16 + c]; }
+  if (q.head && tid < 16) {   // k_g_sample's arithmetic, one thread per row of the tile
+    const int row = row0 + tid, A = out >> 1;
+    if (row < a.n) {
+      const uint32_t ctr = q.ctr_ptr ? *q.ctr_ptr : q.ctr;
+      const float m = q.absorbing ? 1.f - q.absorbing[(size_t)row * q.ld_abs] : 1.f;
+      float sn = 0.f, sl = 0.f;
+      for (int c = 0; c < A; ++c) {
+        const float mean = Os[tid * 16 + c], lsr = Os[tid * 16 + A + c];
+        float x, av, nlp, ladj, e = 0.f;
+        if (q.greedy) { av = tanhf(mean); x = mean; nlp = 0.f; ladj = 0.f; }
+        else {
+          e = q.eps ? q.eps[(size_t)row * A + c] : philox_normal(q.seed, ctr, q.stream_id, (uint32_t)(row * A + c));
+          g_head(mean, lsr, e, x, av, nlp, ladj);
+        }
+        sn += nlp; sl += ladj;
+        if (q.a_rows) q.a_rows[(size_t)row * q.ld_a + c] = m * av;
+        if (q.xT) q.xT[(size_t)c * Bp + row] = x;
+        if (q.epsT) q.epsT[(size_t)c * Bp + row] = e;
+      }
+      if (q.logp) q.logp[row] = (0.f - sl) + sn;
+    }
+  }
+}
+
+// seeds of k_gt_bwd (the per-row kernels' arithmetic: k_g_critic_seed, k_g_policy_seed, k_g_head_bwd, k_g_logp)
+enum { GT_SEED_CRITIC = 1, GT_SEED_POLICY = 2, GT_SEED_HEAD = 3, GT_SEED_BC = 4 };
+struct GtBwd {
+  GtNet net; int64_t p_ns, pk_ns;            // twin critics: parameters / lane-ordered copies of net k at + k * stride
+  const float* HT; int64_t h_ns; float* dZT; int64_t dz_ns; float* dOT; int64_t do_ns;   // [net][depth][H][Bp] activations in, dZ out; [net][out][Bp] output-layer dZ out
+  float* dX0T; int64_t dx_ns; int dx_c0, dx_c1;   // columns [c0, c1) of dL/d(input) -> dX0T[net][in][Bp] (NULL: none)
+  int seed, n, Bp;
+  il_batch b;
+  const float* qtT; const float* qT; const float* logp2; const float* log_alpha; float discount; float* out_q;   // critic loss (qT also: the policy pass's Q(s, a~))
+  const float* outT; const float* xT; const float* epsT; const float* logp; const float* dx0T; int64_t dx0_ns; float entropy_target; int S; float* alpha_rows; float* out_logp;   // actor head
+  float* loss_rows;                                                                                           // behavioural cloning
+  il_adam tick;                                                                                              // ticked by (tile 0, net 0): consumed by the k_gt_dw that follows (step == NULL: none)
+};
+__global__ __launch_bounds__(1024) void k_gt_bwd(GtBwd a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const GtNet& nn = a.net;
+  const int H = nn.H, in = nn.in, depth = nn.depth, out = nn.out, act = nn.act, Bp = a.Bp, net = blockIdx.y;
+  const int row0 = blockIdx.x * 16, ldh = H + 4, ldy = 20;
+  float* dYs = smem; float* Z0 = dYs + 16 * ldy; float* Z1 = Z0 + 16 * ldh;
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, tid = threadIdx.x;
+  const float* P = nn.P + net * a.p_ns;
+  const float* HT = a.HT + net * a.h_ns;
+  float* dZT = a.dZT + net * a.dz_ns;
+  for (int i = tid; i < 16 * ldy; i += blockDim.x) dYs[i] = 0.f;
+  __syncthreads();
+  if (tid < 16) {
+    const int row = row0 + tid, n = a.n;
+    const bool live = row < n;
+    if (a.seed == GT_SEED_CRITIC) {
+      float dq = 0.f;
+      if (live) {
+        const float alpha = expf(a.log_alpha[0]);
+        const float m = 1.f - a.b.absorbing[(size_t)row * a.b.ld_absorbing];
+        const float tv = fminf(a.qtT[row], a.qtT[Bp + row]) - m * alpha * a.logp2[row];
+        const float y = a.b.rewards[(size_t)row * a.b.ld_rewards] + (1.f - a.b.terminals[(size_t)row * a.b.ld_terminals]) * a.discount * tv;
+        const float w = a.b.weights[(size_t)row * a.b.ld_weights], q1 = a.qT[row], q2 = a.qT[Bp + row];
+        dq = (w * (2.f * ((net == 0 ? q1 : q2) - y))) / (float)n;
+        if (net == 0 && a.out_q) a.out_q[row] = fminf(q1, q2);
+      }
+      dYs[tid * ldy] = dq;
+    } else if (a.seed == GT_SEED_POLICY) {
+      float dq = 0.f;
+      if (live) {
+        const float q1 = a.qT[row], q2 = a.qT[Bp + row];
+        const float sel = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f);
+        dq = net == 0 ? -(sel) / (float)n : -(1.f - sel) / (float)n;
+      }
+      dYs[tid * ldy] = dq;
+    } else if (a.seed == GT_SEED_HEAD) {
+      const int A = out >> 1;
+      if (live) {
+        const float alpha = expf(a.log_alpha[0]);
+        const float w = a.b.weights[(size_t)row * a.b.ld_weights], m = 1.f - a.b.absorbing[(size_t)row * a.b.ld_absorbing];
+        const float cc = (w * m * alpha) / (float)n;
+        for (int c = 0; c < A; ++c) {
+          const float x = a.xT[(size_t)c * Bp + row], e = a.epsT[(size_t)c * Bp + row], lsr = a.outT[(size_t)(A + c) * Bp + row];
+          const float sd = expf(fminf(fmaxf(lsr, -20.f), 2.f)), an = tanhf(x);
+          const float da = a.dx0T[(size_t)(a.S + c) * Bp + row] + a.dx0T[a.dx0_ns + (size_t)(a.S + c) * Bp + row];
+          const float dx = cc * (2.f * an) + da * (1.f - an * an);
+          const float dsd = dx * e - cc / sd;
+          dYs[tid * ldy + c] = dx;
+          dYs[tid * ldy + A + c] = (lsr >= -20.f && lsr <= 2.f) ? dsd * sd : 0.f;
+        }
+        const float lp = a.logp[row];
+        a.alpha_rows[row] = w * m * (lp + a.entropy_target);
+        if (a.out_logp) a.out_logp[row] = lp;
+      } else if (row < Bp) a.alpha_rows[row] = 0.f;
+    } else {   // GT_SEED_BC: d(-mean(w log pi(a | s))) / d(head outputs)
+      const int A = out >> 1;
+      if (live) {
+        const float wt = a.b.weights[(size_t)row * a.b.ld_weights], up = -wt / (float)n;
+        float sn = 0.f, sl = 0.f;
+        for (int c = 0; c < A; ++c) {
+          const float mean = a.outT[(size_t)c * Bp + row], lsr = a.outT[(size_t)(A + c) * Bp + row];
+          const float sd = expf(fminf(fmaxf(lsr, -20.f), 2.f));
+          const float av = fminf(fmaxf(a.b.actions[(size_t)row * a.b.ld_actions + c], -1.f + 1e-6f), 1.f - 1e-6f);
+          const float x = atanhf(av), df = x - mean, var = sd * sd;
+          sn += -(df * df) / (2.f * var) - logf(sd) - LOG_SQRT_2PI;
+          sl += 2.f * (LOG_2 - x - softplus_f(-2.f * x));
+          const float dsd = up * (df * df / (var * sd) - 1.f / sd);
+          dYs[tid * ldy + c] = up * df / var;
+          dYs[tid * ldy + A + c] = (lsr >= -20.f && lsr <= 2.f) ? dsd * sd : 0.f;
+        }
+        if (a.loss_rows) a.loss_rows[row] = -wt * ((0.f - sl) + sn);
+      } else if (row < Bp && a.loss_rows) a.loss_rows[row] = 0.f;
+    }
+  }
+  if (blockIdx.x == 0 && net == 0 && tid == 64 && a.tick.step) adam_tick(a.tick);
+  __syncthreads();
+  if (a.dOT)
+    for (int i = tid; i < 16 * out; i += blockDim.x) { const int c = i >> 4, r = i & 15; a.dOT[net * a.do_ns + (size_t)c * Bp + row0 + r] = dYs[r * ldy + c]; }
+  float* cur = Z0; float* nxt = Z1;
+  {   // through the output layer: dZ of the last hidden layer
+    const GLayer L = g_layer(in, H, depth, out, depth);
+    const float* hp = HT + (size_t)(depth - 1) * H * Bp;
+    float* dz = dZT + (size_t)(depth - 1) * H * Bp;
+    tile_bwd_dx(dYs, ldy, 16, out, P + L.oW, H, H, [&](int kb, f32x4 acc) {
+      const size_t off = (size_t)(kb + j) * Bp + row0 + 4 * g;
+      const f32x4 h = gload4(hp + off);
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = acc[r] * g_act_grad(h[r], act); cur[(4 * g + r) * ldh + kb + j] = v[r]; }
+      *reinterpret_cast<f32x4*>(dz + off) = v;
+    });
+  }
+  __syncthreads();
+  for (int l = depth - 1; l >= 1; --l) {   // dZ of hidden layer l (in `cur`) -> dZ of hidden layer l - 1
+    const GLayer L = g_layer(in, H, depth, out, l);
+    const float* hp = HT + (size_t)(l - 1) * H * Bp;
+    float* dz = dZT + (size_t)(l - 1) * H * Bp;
+    auto epi = [&](int kb, f32x4 acc) {
+      const size_t off = (size_t)(kb + j) * Bp + row0 + 4 * g;
+      const f32x4 h = gload4(hp + off);
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = acc[r] * g_act_grad(h[r], act); nxt[(4 * g + r) * ldh + kb + j] = v[r]; }
+      *reinterpret_cast<f32x4*>(dz + off) = v;
+    };
+    if (nn.PB) tile_bwd_packed(cur, ldh, H, nn.PB + net * a.pk_ns + (size_t)(l - 1) * H * H, epi);
+    else tile_bwd_dx(cur, ldh, H, H, P + L.oW, H, H, epi);
+    __syncthreads();
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  if (a.dX0T) {   // dL/d(input), columns [dx_c0, dx_c1): no activation behind the input
+    const GLayer L = g_layer(in, H, depth, out, 0);
+    float* dx = a.dX0T + net * a.dx_ns;
+    tile_bwd_dx(cur, ldh, H, H, P + L.oW, in, in, [&](int kb, f32x4 acc) {
+      const int k = kb + j;
+      if (k >= a.dx_c0 && k < a.dx_c1) *reinterpret_cast<f32x4*>(dx + (size_t)k * Bp + row0 + 4 * g) = acc;
+    });
+  }
+}
+
+// every layer's dW and db of `nets` networks with the optimiser in the epilogue
+struct GtDwLayer { const float* dZT; int64_t dz_ns; const float* XT; int64_t x_ns; int64_t oW, ob; int N, K; int tile0, bias0; float* PF; float* PB; };   // tile0 / bias0: first wave-job of the layer's tiles / bias features; PF / PB: this layer's lane-ordered copies (NULL: none)
+struct GtDw {
+  GtDwLayer L[9]; int n_layers, jobs_per_net, nets; int64_t p_ns, pk_ns;
+  float* P; float* G; int64_t g_ns; il_adam opt; int grads_only, Bp;
+  int n_job_wgs;   // workgroups of tile / bias jobs; behind them the tail workgroups
+  // tail (the actor's launch): temperature step (k_g_alpha), target update (k_polyak), Philox counter
+  const float* alpha_rows; int n_rows; float* log_alpha; il_adam alpha_opt; float* alpha_grad; uint32_t* noise_counter;
+  float* target; const float* polyak_src; int64_t polyak_n; double tau;
+};
+__global__ __launch_bounds__(256) void k_gt_dw(GtDw a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  if ((int)blockIdx.x >= a.n_job_wgs) {   // ---- tail
+    const int tb = (int)blockIdx.x - a.n_job_wgs, ntb = (int)gridDim.x - a.n_job_wgs;
+    if (tb == 0 && threadIdx.x == 0 && a.log_alpha) {
+      float s = 0.f;
+      for (int i = 0; i < a.n_rows; ++i) s += a.alpha_rows[i];
+      const float gr = -(expf(a.log_alpha[0])) * (s / (float)a.n_rows);
+      if (a.alpha_grad) a.alpha_grad[0] = gr;
+      if (!a.grads_only) {
+        adam_tick(a.alpha_opt);
+        const adam_consts ac = load_adam_consts(a.alpha_opt);
+        float pp = a.log_alpha[0], mm = a.alpha_opt.m[0], vv = a.alpha_opt.v[0];
+        adam_update(pp, gr, mm, vv, ac);
+        a.log_alpha[0] = pp; a.alpha_opt.m[0] = mm; a.alpha_opt.v[0] = vv;
+      }
+      if (a.noise_counter) a.noise_counter[0] += 1;
+    }
+    if (a.target && !a.grads_only) {
+      const float omt = (float)(1.0 - a.tau), tau = (float)a.tau;
+      for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < a.polyak_n; i += (int64_t)ntb * blockDim.x)
+        a.target[i] = __fadd_rn(__fmul_rn(a.target[i], tau), __fmul_rn(omt, a.polyak_src[i]));
+    }
+    return;
+  }
+  int job = blockIdx.x * 4 + wave;
+  if (job >= a.jobs_per_net * a.nets) return;
+  const int net = job / a.jobs_per_net; job -= net * a.jobs_per_net;
+  int li = 0;
+  for (int i = 1; i < a.n_layers; ++i) if (job >= a.L[i].tile0) li = i;
+  const GtDwLayer& L = a.L[li];
+  float* P = a.P + net * a.p_ns;
+  il_adam opt = a.opt; opt.m += net * a.p_ns; opt.v += net * a.p_ns;
+  adam_consts ac = {};
+  if (!a.grads_only) ac = load_adam_consts(a.opt);
+  if (job >= L.bias0) {   // bias: one wave per output feature (g_dbias)
+    const int n = job - L.bias0;
+    if (n >= L.N) return;
+    const float* z = L.dZT + net * L.dz_ns + (size_t)n * a.Bp;
+    float s = 0.f;
+    for (int r = lane; r < a.Bp; r += 64) s += gload(z + r);
+    s = wave_sum(s);
+    if (lane == 0) {
+      const int64_t o = L.ob + n;
+      if (a.G) a.G[net * a.g_ns + o] = s;   // (the gradient arena is part of the entry points' contract: behavioural cloning's callers read it back)
+      if (!a.grads_only) { float pp = P[o], mm = opt.m[o], vv = opt.v[o]; adam_update(pp, s, mm, vv, ac); P[o] = pp; opt.m[o] = mm; opt.v[o] = vv; }
+    }
+    return;
+  }
+  const int tile = job - L.tile0, tk = (L.K + 15) >> 4;
+  const int n0 = (tile / tk) * 16, k0 = (tile - (tile / tk) * tk) * 16;
+  const float* zr = L.dZT + net * L.dz_ns + (size_t)min(n0 + j, L.N - 1) * a.Bp + 4 * g;
+  const float* xr = L.XT + net * L.x_ns + (size_t)min(k0 + j, L.K - 1) * a.Bp + 4 * g;
+  f32x4 acc0 = zero4(), acc1 = zero4();
+  int r0 = 0;
+  for (; r0 + 64 <= a.Bp; r0 += 64) {   // four row groups per trip, their eight lanes requested together (k_g_dw's MFMA order)
+    f32x4 z[4], x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { z[u] = gload4(zr + r0 + 16 * u); x[u] = gload4(xr + r0 + 16 * u); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { acc0 = mfma16(z[u][0], x[u][0], acc0); acc1 = mfma16(z[u][1], x[u][1], acc1); acc0 = mfma16(z[u][2], x[u][2], acc0); acc1 = mfma16(z[u][3], x[u][3], acc1); }
+  }
+  for (; r0 < a.Bp; r0 += 16) {
+    const f32x4 z = gload4(zr + r0), x = gload4(xr + r0);
+    acc0 = mfma16(z[0], x[0], acc0); acc1 = mfma16(z[1], x[1], acc1); acc0 = mfma16(z[2], x[2], acc0); acc1 = mfma16(z[3], x[3], acc1);
+  }
+  const f32x4 acc = acc0 + acc1;
+  const int k = k0 + j;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + 4 * g + r;
+    if (n >= L.N || k >= L.K) continue;
+    const int64_t o = L.oW + (int64_t)n * L.K + k;
+    if (a.G) a.G[net * a.g_ns + o] = acc[r];
+    if (a.grads_only) continue;
+    float pp = P[o], mm = opt.m[o], vv = opt.v[o];
+    adam_update(pp, acc[r], mm, vv, ac);
+    P[o] = pp; opt.m[o] = mm; opt.v[o] = vv;
+    if (L.PF) { L.PF[net * a.pk_ns + packed_fwd_index(n, k, L.K)] = pp; L.PB[net * a.pk_ns + packed_bwd_index(n, k, L.K)] = pp; }
+  }
+}
+
+// lane-ordered copies of the H x H layers: blockIdx.y = slot; slot s copies W (src[s]) into PF[s] / PB[s] (PB NULL: forward copy only)
+struct GtRepack { const float* W[16]; float* PF[16]; float* PB[16]; int H[16]; };
+__global__ __launch_bounds__(256) void k_gt_repack(GtRepack a) {
+  const int s = blockIdx.y, H = a.H[s], kq = H / 4;
+  const float* W2 = a.W[s]; float* pf = a.PF[s]; float* pb = a.PB[s];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kq * kq; i += gridDim.x * blockDim.x) {   // one thread = a 4 x 4 block (k_repack)
+    const int n = (i / kq) * 4, k = (i - (i / kq) * kq) * 4;
+    f32x4 w[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4*>(W2 + (size_t)(n + r) * H + k);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(pf + packed_fwd_index(n + r, k, H)) = w[r];
+    if (pb) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { f32x4 c; c[0] = w[0][q]; c[1] = w[1][q]; c[2] = w[2][q]; c[3] = w[3][q]; *reinterpret_cast<f32x4*>(pb + packed_bwd_index(n, k + q, H)) = c; }
+    }
+  }
+}
+
+static bool gt_env() { static const int on = [] { const char* e = getenv("IL_GENERAL_TILES"); return e && e[0] == '0' ? 0 : 1; }(); return on != 0; }
+static bool gt_shape_ok(const GNet& s) {
+  const auto al = [](int64_t v) { return (v & 3) == 0; };
+  (void)al;
+  return s.H % 16 == 0 && s.H >= 16 && s.H <= 512 && s.in <= 512 && s.out <= 16 && s.depth >= 1 && s.depth <= 8;
+}
+static size_t gt_fwd_lds(const GNet& s) { return sizeof(float) * ((size_t)16 * (round_up16(s.in) + 4) + 2 * (size_t)16 * (s.H + 4) + (size_t)(s.H >> 4) * 256 + 256); }
+static size_t gt_bwd_lds(const GNet& s) { return sizeof(float) * ((size_t)16 * 20 + 2 * (size_t)16 * (s.H + 4)); }
+// packed copies need 16-byte aligned H x H layers (their offset in the flat vector is a multiple of 4 floats) - otherwise the passes read W directly
+static bool gt_packable(const GNet& s, const float* P) {
+  if (s.depth < 2 || s.H % 64 != 0) return false;   // (tile_packed walks a panel four 16-wide k-blocks at a time)
+  for (int l = 1; l < s.depth; ++l) { const GLayer L = g_layer(s.in, s.H, s.depth, s.out, l); if ((L.oW & 3) != 0 || (reinterpret_cast<uintptr_t>(P) & 15) != 0) return false; }
+  return true;
+}
+// fills the layer table of a k_gt_dw launch; returns the wave-jobs per network
+static int gt_dw_layers(GtDw& w, const GNet& s, const float* X0T, int64_t x_ns, const float* HT, int64_t h_ns, const float* dZT, int64_t dz_ns, const float* dOT, int64_t do_ns, float* PF, float* PB, int Bp) {
+  int job = 0;
+  w.n_layers = s.depth + 1;
+  for (int l = 0; l <= s.depth; ++l) {
+    const GLayer L = g_layer(s.in, s.H, s.depth, s.out, l);
+    GtDwLayer& d = w.L[l];
+    d.dZT = l == s.depth ? dOT : dZT + (int64_t)l * s.H * Bp; d.dz_ns = l == s.depth ? do_ns : dz_ns;
+    d.XT = l == 0 ? X0T : HT + (int64_t)(l - 1) * s.H * Bp; d.x_ns = l == 0 ? x_ns : h_ns;
+    d.oW = L.oW; d.ob = L.ob; d.N = L.N; d.K = L.K;
+    d.tile0 = job; job += ((L.N + 15) / 16) * ((L.K + 15) / 16);
+    d.bias0 = job; job += L.N;
+    const bool hh = l >= 1 && l < s.depth && PF;
+    d.PF = hh ? PF + (int64_t)(l - 1) * s.H * s.H : nullptr; d.PB = hh ? PB + (int64_t)(l - 1) * s.H * s.H : nullptr;
+  }
+  return job;
+}
+
 extern "C" int64_t il_mlp_numel_general(int32_t in_dim, int32_t hidden, int32_t depth, int32_t out_dim) { return g_numel(in_dim, hidden, depth, out_dim); }
 extern "C" int64_t il_mlp_stride_general(int32_t in_dim, int32_t hidden, int32_t depth, int32_t out_dim) { return g_stride(in_dim, hidden, depth, out_dim); }
 
 // workspace of il_sac_update_general (floats)
-struct GSacWs { int64_t xa2, xa, xt, xc, xp, ha2, oa2, ha, oa, ht, qt, hc, qc, hp, qp, dz, dq, dout, dx0, logp2, logp, xpre, epsu, arows, ga, gc, total; };
+struct GSacWs { int64_t xa2, xa, xt, xc, xp, ha2, oa2, ha, oa, ht, qt, hc, qc, hp, qp, dz, dq, dout, dx0, logp2, logp, xpre, epsu, arows, ga, gc, a2r, anr, pk_af, pk_ab, pk_cf, pk_cb, pk_tf, total; };   // a2r / anr: a' and a~ row-major [B][A]; pk_*: lane-ordered copies of the H x H layers (tile engine)
 static GSacWs g_sac_ws(int S, int A, int Ha, int da, int Hc, int dc, int B) {   // actor: da hidden layers of Ha units; critics: dc of Hc
   const int Bp = g_bp(B), IN = S + A;
   const int64_t hid = (int64_t)da * Ha * Bp, hidc = (int64_t)dc * Hc * Bp, hidm = hid > 2 * hidc ? hid : 2 * hidc;
@@ -402,10 +780,110 @@ static GSacWs g_sac_ws(int S, int A, int Ha, int da, int Hc, int dc, int B) {   
   w.dz = take(hidm); w.dq = take(2 * Bp); w.dout = take((int64_t)2 * A * Bp); w.dx0 = take((int64_t)2 * IN * Bp);
   w.logp2 = take(Bp); w.logp = take(Bp); w.xpre = take((int64_t)A * Bp); w.epsu = take((int64_t)A * Bp); w.arows = take(Bp);
   w.ga = take(g_numel(S, Ha, da, 2 * A)); w.gc = take(2 * g_stride(IN, Hc, dc, 1));
+  w.a2r = take((int64_t)B * A); w.anr = take((int64_t)B * A);
+  const int64_t pa = (int64_t)(da > 1 ? da - 1 : 0) * Ha * Ha, pc = (int64_t)(dc > 1 ? dc - 1 : 0) * Hc * Hc;
+  w.pk_af = take(pa); w.pk_ab = take(pa); w.pk_cf = take(2 * pc); w.pk_cb = take(2 * pc); w.pk_tf = take(2 * pc);
   w.total = o;
   return w;
 }
 extern "C" int64_t il_sac_workspace_floats_general(int32_t S, int32_t A, int32_t Ha, int32_t da, int32_t Hc, int32_t dc, int32_t B) { return g_sac_ws(S, A, Ha, da, Hc, dc, B).total; }
+
+// training.py:14-54 through the tile engine (9 launches; see the engine's header). Same arguments, workspace and results as the layer-at-a-time sequence below.
+static int g_sac_update_tiles(const il_sac* d, const il_batch* b, const GNet& an, const GNet& cn, const float* eps_next, const float* eps_cur, float* out_logp, float* out_q, bool grads_only,
+                              hipStream_t st) {
+  const int S = d->state_dim, A = d->action_dim, B = d->batch, IN = S + A, Bp = g_bp(B), nt = Bp / 16;
+  const GSacWs ws = g_sac_ws(S, A, an.H, an.depth, cn.H, cn.depth, B);
+  float* W = d->workspace;
+  const int64_t Pa = g_numel(S, an.H, an.depth, 2 * A), Pc = g_numel(IN, cn.H, cn.depth, 1), Ps = g_stride(IN, cn.H, cn.depth, 1);
+  const int64_t hid_a = g_hidden_floats(an, Bp), hid_c = g_hidden_floats(cn, Bp), pkc = (int64_t)(cn.depth > 1 ? cn.depth - 1 : 0) * cn.H * cn.H;
+  const bool pack_a = gt_packable(an, d->actor), pack_c = gt_packable(cn, d->critic) && gt_packable(cn, d->target) && (Ps & 3) == 0;
+  float* ga = grads_only ? d->actor_grad : W + ws.ga; float* gc = grads_only ? d->critic_grad : W + ws.gc;
+  const size_t lds_f = gt_fwd_lds(an) > gt_fwd_lds(cn) ? gt_fwd_lds(an) : gt_fwd_lds(cn), lds_b = gt_bwd_lds(an) > gt_bwd_lds(cn) ? gt_bwd_lds(an) : gt_bwd_lds(cn);
+  if (int rc = g_lds_ok((const void*)k_gt_fwd, lds_f)) return rc;
+  if (int rc = g_lds_ok((const void*)k_gt_bwd, lds_b)) return rc;
+  const int th_a = gt_threads(an.H), th_c = gt_threads(cn.H), th_m = th_a > th_c ? th_a : th_c;
+  // 0. lane-ordered copies of every H x H layer (the critics' are kept in step by their optimiser launch below: the policy pass reads the stepped critics)
+  {
+    GtRepack r = {}; int n = 0;
+    auto add = [&](const float* P, const GNet& s, float* pf, float* pb) {
+      for (int l = 1; l < s.depth; ++l) { const GLayer L = g_layer(s.in, s.H, s.depth, s.out, l); r.W[n] = P + L.oW; r.PF[n] = pf + (int64_t)(l - 1) * s.H * s.H; r.PB[n] = pb ? pb + (int64_t)(l - 1) * s.H * s.H : nullptr; r.H[n] = s.H; ++n; }
+    };
+    if (pack_a && an.depth - 1 <= 3) add(d->actor, an, W + ws.pk_af, W + ws.pk_ab);
+    if (pack_c && 4 * (cn.depth - 1) + n <= 16) for (int k = 0; k < 2; ++k) { add(d->critic + k * Ps, cn, W + ws.pk_cf + k * pkc, W + ws.pk_cb + k * pkc); add(d->target + k * Ps, cn, W + ws.pk_tf + k * pkc, nullptr); }
+    if (n > 0) { int hm = 0; for (int i = 0; i < n; ++i) hm = r.H[i] > hm ? r.H[i] : hm; IL_TRACE("k_gt_repack", st); k_gt_repack<<<dim3((hm * hm / 16 + 255) / 256, n), 256, 0, st>>>(r); }
+  }
+  const bool pa = pack_a && an.depth - 1 <= 3, pc = pack_c && 4 * (cn.depth - 1) + (pa ? an.depth - 1 : 0) <= 16;
+  const GtNet actor = {d->actor, S, an.H, an.depth, 2 * A, an.act, pa ? W + ws.pk_af : nullptr, pa ? W + ws.pk_ab : nullptr};
+  auto critic = [&](int k) { GtNet c = {d->critic + k * Ps, IN, cn.H, cn.depth, 1, cn.act, pc ? W + ws.pk_cf + k * pkc : nullptr, pc ? W + ws.pk_cb + k * pkc : nullptr}; return c; };
+  auto target = [&](int k) { GtNet c = {d->target + k * Ps, IN, cn.H, cn.depth, 1, cn.act, pc ? W + ws.pk_tf + k * pkc : nullptr, nullptr}; return c; };
+  // A. actor(s') -> a', log pi(a'|s'); actor(s) -> a~, log pi, pre-tanh sample, noise; critic_1,2(s, a)
+  {
+    GtFwd f = {}; f.n = B; f.Bp = Bp;
+    GtFwdPass& p0 = f.p[0]; p0.net = actor; p0.f1 = b->next_states; p0.ld1 = b->ld_next_states; p0.K1 = S; p0.head = 1; p0.eps = eps_next; p0.seed = d->noise_seed; p0.ctr_ptr = d->noise_counter;
+    p0.stream_id = IL_STREAM_EPS_NEXT; p0.absorbing = b->absorbing; p0.ld_abs = b->ld_absorbing; p0.a_rows = W + ws.a2r; p0.ld_a = A; p0.logp = W + ws.logp2;
+    GtFwdPass& p1 = f.p[1]; p1.net = actor; p1.f1 = b->states; p1.ld1 = b->ld_states; p1.K1 = S; p1.X0T = W + ws.xa; p1.HT = W + ws.ha; p1.OT = W + ws.oa; p1.head = 1; p1.eps = eps_cur; p1.seed = d->noise_seed;
+    p1.ctr_ptr = d->noise_counter; p1.stream_id = IL_STREAM_EPS_CUR; p1.a_rows = W + ws.anr; p1.ld_a = A; p1.xT = W + ws.xpre; p1.epsT = W + ws.epsu; p1.logp = W + ws.logp;
+    for (int k = 0; k < 2; ++k) {
+      GtFwdPass& pk = f.p[2 + k]; pk.net = critic(k); pk.f1 = b->states; pk.ld1 = b->ld_states; pk.K1 = S; pk.f2 = b->actions; pk.ld2 = b->ld_actions; pk.K2 = A;
+      pk.X0T = k == 0 ? W + ws.xc : nullptr; pk.HT = W + ws.hc + k * hid_c; pk.OT = W + ws.qc + (int64_t)k * Bp;
+    }
+    IL_TRACE("k_gt_fwd", st); k_gt_fwd<<<dim3(nt, 4), th_m, lds_f, st>>>(f);
+  }
+  // B. target_1,2(s', a')
+  {
+    GtFwd f = {}; f.n = B; f.Bp = Bp;
+    for (int k = 0; k < 2; ++k) {
+      GtFwdPass& pk = f.p[k]; pk.net = target(k); pk.f1 = b->next_states; pk.ld1 = b->ld_next_states; pk.K1 = S; pk.f2 = W + ws.a2r; pk.ld2 = A; pk.K2 = A; pk.OT = W + ws.qt + (int64_t)k * Bp;
+    }
+    IL_TRACE("k_gt_fwd", st); k_gt_fwd<<<dim3(nt, 2), th_c, lds_f, st>>>(f);
+  }
+  // C. critic loss seed + backward (training.py:22-31), D. every layer's dW + AdamW
+  {
+    GtBwd g = {}; g.net = critic(0); g.p_ns = Ps; g.pk_ns = pkc; g.HT = W + ws.hc; g.h_ns = hid_c; g.dZT = W + ws.dz; g.dz_ns = hid_c; g.dOT = W + ws.dq; g.do_ns = Bp; g.seed = GT_SEED_CRITIC; g.n = B; g.Bp = Bp;
+    g.b = *b; g.qtT = W + ws.qt; g.qT = W + ws.qc; g.logp2 = W + ws.logp2; g.log_alpha = d->log_alpha; g.discount = d->discount; g.out_q = out_q ? out_q : d->out_q;
+    if (!grads_only) g.tick = d->critic_opt;
+    IL_TRACE("k_gt_bwd", st); k_gt_bwd<<<dim3(nt, 2), th_c, lds_b, st>>>(g);
+  }
+  {
+    GtDw w = {}; w.nets = 2; w.p_ns = Ps; w.pk_ns = pkc; w.P = d->critic; w.G = gc; w.g_ns = Ps; w.opt = d->critic_opt; w.grads_only = grads_only ? 1 : 0; w.Bp = Bp;
+    w.jobs_per_net = gt_dw_layers(w, cn, W + ws.xc, 0, W + ws.hc, hid_c, W + ws.dz, hid_c, W + ws.dq, Bp, pc ? W + ws.pk_cf : nullptr, pc ? W + ws.pk_cb : nullptr, Bp);
+    w.n_job_wgs = (w.jobs_per_net * 2 + 3) / 4;
+    IL_TRACE("k_gt_dw", st); k_gt_dw<<<w.n_job_wgs, 256, 0, st>>>(w);
+  }
+  // E. the stepped critics on (s, a~), F. policy seed + backward down to dQ/da~ (training.py:34-38)
+  {
+    GtFwd f = {}; f.n = B; f.Bp = Bp;
+    for (int k = 0; k < 2; ++k) {
+      GtFwdPass& pk = f.p[k]; pk.net = critic(k); pk.f1 = b->states; pk.ld1 = b->ld_states; pk.K1 = S; pk.f2 = W + ws.anr; pk.ld2 = A; pk.K2 = A; pk.HT = W + ws.hp + k * hid_c; pk.OT = W + ws.qp + (int64_t)k * Bp;
+    }
+    IL_TRACE("k_gt_fwd", st); k_gt_fwd<<<dim3(nt, 2), th_c, lds_f, st>>>(f);
+  }
+  {
+    GtBwd g = {}; g.net = critic(0); g.p_ns = Ps; g.pk_ns = pkc; g.HT = W + ws.hp; g.h_ns = hid_c; g.dZT = W + ws.dz; g.dz_ns = hid_c; g.seed = GT_SEED_POLICY; g.n = B; g.Bp = Bp; g.qT = W + ws.qp;
+    g.dX0T = W + ws.dx0; g.dx_ns = (int64_t)IN * Bp; g.dx_c0 = S; g.dx_c1 = IN;
+    IL_TRACE("k_gt_bwd", st); k_gt_bwd<<<dim3(nt, 2), th_c, lds_b, st>>>(g);
+  }
+  // G. back through the tanh-Gaussian head and the actor (training.py:35-42), H. the actor's dW + AdamW, temperature step, target update (training.py:45-52)
+  {
+    GtBwd g = {}; g.net = actor; g.HT = W + ws.ha; g.dZT = W + ws.dz; g.dOT = W + ws.dout; g.seed = GT_SEED_HEAD; g.n = B; g.Bp = Bp; g.b = *b;
+    g.outT = W + ws.oa; g.xT = W + ws.xpre; g.epsT = W + ws.epsu; g.logp = W + ws.logp; g.dx0T = W + ws.dx0; g.dx0_ns = (int64_t)IN * Bp; g.log_alpha = d->log_alpha; g.entropy_target = d->entropy_target; g.S = S;
+    g.alpha_rows = W + ws.arows; g.out_logp = out_logp ? out_logp : d->out_logp;
+    if (!grads_only) g.tick = d->actor_opt;
+    IL_TRACE("k_gt_bwd", st); k_gt_bwd<<<dim3(nt, 1), th_a, lds_b, st>>>(g);
+  }
+  {
+    GtDw w = {}; w.nets = 1; w.P = d->actor; w.G = ga; w.opt = d->actor_opt; w.grads_only = grads_only ? 1 : 0; w.Bp = Bp;
+    w.jobs_per_net = gt_dw_layers(w, an, W + ws.xa, 0, W + ws.ha, hid_a, W + ws.dz, hid_a, W + ws.dout, 0, nullptr, nullptr, Bp);   // (the actor's copies are re-derived at the next update's start)
+    w.n_job_wgs = (w.jobs_per_net + 3) / 4;
+    w.alpha_rows = W + ws.arows; w.n_rows = B; w.log_alpha = d->log_alpha; w.alpha_opt = d->alpha_opt; w.alpha_grad = d->alpha_grad; w.noise_counter = d->noise_counter;
+    w.target = d->target; w.polyak_src = d->critic; w.polyak_n = Ps + Pc; w.tau = d->polyak;
+    const int tail = grads_only ? 1 : 1 + (int)(((Ps + Pc) / 256 + 7) / 8 < 64 ? ((Ps + Pc) / 256 + 7) / 8 : 64);
+    IL_TRACE("k_gt_dw", st); k_gt_dw<<<w.n_job_wgs + tail, 256, 0, st>>>(w);
+  }
+  (void)Pa;
+  IL_CHECK_LAUNCH("il_sac_update_general (tile engine)");
+  return IL_OK;
+}
 
 // training.py:14-54 for general shapes. The descriptor is the fused path's (`hidden` = the ACTOR's hidden width; parameter arenas in torch order, twin critics at
 // il_mlp_stride_general); the actor and the critics have their own (hidden, depth, activation), as reinforcement.actor / reinforcement.critic do in the reference's configuration.
@@ -425,6 +903,7 @@ extern "C" int il_sac_update_general(const il_sac* d, const il_batch* b, int32_t
   const bool grads_only = (flags & IL_FLAG_GRADS_ONLY) != 0;
   IL_CHECK_ARG(!grads_only || (d->actor_grad && d->critic_grad && d->alpha_grad), "il_sac_update_general: IL_FLAG_GRADS_ONLY needs the gradient arenas");
   hipStream_t st = (hipStream_t)stream_;
+  if (gt_env() && gt_shape_ok(an) && gt_shape_ok(cn)) return g_sac_update_tiles(d, b, an, cn, eps_next, eps_cur, out_logp, out_q, grads_only, st);
   float* W = d->workspace;
   const int64_t Pa = g_numel(S, H, actor_depth, 2 * A), Pc = g_numel(IN, critic_hidden, critic_depth, 1), Ps = g_stride(IN, critic_hidden, critic_depth, 1);
   float* ga = grads_only ? d->actor_grad : W + ws.ga; float* gc = grads_only ? d->critic_grad : W + ws.gc;
@@ -501,6 +980,16 @@ extern "C" int il_actor_act_general(const float* actor, int32_t S, int32_t A, in
   hipStream_t st = (hipStream_t)stream_;
   const int Bp = g_bp(n);
   const GActWs ws = g_act_ws(S, A, H, depth, Bp);
+  if (gt_env() && gt_shape_ok(an)) {   // tile engine: one launch (rows -> every layer -> head)
+    const size_t lds = gt_fwd_lds(an);
+    if (int rc = g_lds_ok((const void*)k_gt_fwd, lds)) return rc;
+    GtFwd f = {}; f.n = n; f.Bp = Bp;
+    GtFwdPass& p0 = f.p[0]; p0.net = GtNet{actor, S, H, depth, 2 * A, activation, nullptr, nullptr}; p0.f1 = states; p0.ld1 = ld_states; p0.K1 = S; p0.head = 1; p0.eps = eps; p0.seed = noise_seed; p0.ctr = noise_offset;
+    p0.stream_id = IL_STREAM_ACT; p0.greedy = greedy; p0.a_rows = out_action; p0.ld_a = A; p0.logp = out_logp;
+    { IL_TRACE("k_gt_fwd", st); k_gt_fwd<<<dim3(Bp / 16, 1), gt_threads(H), lds, st>>>(f); }
+    IL_CHECK_LAUNCH("il_actor_act_general (tile engine)");
+    return IL_OK;
+  }
   g_pack(st, states, ld_states, S, nullptr, 0, 0, n, Bp, workspace + ws.x);
   if (int rc = g_forward(st, an, actor, 0, 1, workspace + ws.x, 0, workspace + ws.h, workspace + ws.o, Bp)) return rc;
   GSample h = {}; h.outT = workspace + ws.o; h.Bp = Bp; h.n = n; h.A = A; h.eps = eps; h.seed = noise_seed; h.ctr = noise_offset; h.stream_id = IL_STREAM_ACT; h.a_rows = out_action; h.ld_a = A;
@@ -539,6 +1028,25 @@ extern "C" int il_bc_step_general(float* actor, float* actor_grad, const il_adam
   hipStream_t st = (hipStream_t)stream_;
   const GActWs ws = g_act_ws(S, A, H, depth, Bp);
   float* G = actor_grad ? actor_grad : workspace + ws.g;
+  if (gt_env() && gt_shape_ok(an)) {   // tile engine: forward, BC seed + backward, every layer's dW + AdamW: three launches
+    const size_t lds_f = gt_fwd_lds(an), lds_b = gt_bwd_lds(an);
+    if (int rc = g_lds_ok((const void*)k_gt_fwd, lds_f)) return rc;
+    if (int rc = g_lds_ok((const void*)k_gt_bwd, lds_b)) return rc;
+    const GtNet net = {actor, S, H, depth, 2 * A, activation, nullptr, nullptr};
+    GtFwd f = {}; f.n = n; f.Bp = Bp;
+    GtFwdPass& p0 = f.p[0]; p0.net = net; p0.f1 = b->states; p0.ld1 = b->ld_states; p0.K1 = S; p0.X0T = workspace + ws.x; p0.HT = workspace + ws.h; p0.OT = workspace + ws.o;
+    { IL_TRACE("k_gt_fwd", st); k_gt_fwd<<<dim3(Bp / 16, 1), gt_threads(H), lds_f, st>>>(f); }
+    GtBwd g = {}; g.net = net; g.HT = workspace + ws.h; g.dZT = workspace + ws.dz; g.dOT = workspace + ws.dout; g.seed = GT_SEED_BC; g.n = n; g.Bp = Bp; g.b = *b; g.outT = workspace + ws.o; g.loss_rows = workspace + ws.rows;
+    if (!grads_only) g.tick = *opt;
+    { IL_TRACE("k_gt_bwd", st); k_gt_bwd<<<dim3(Bp / 16, 1), gt_threads(H), lds_b, st>>>(g); }
+    if (out_loss) { IL_TRACE("k_g_sum_rows", st); k_g_sum_rows<<<1, 64, 0, st>>>(workspace + ws.rows, n, out_loss); }
+    GtDw w = {}; w.nets = 1; w.P = actor; w.G = G; if (opt) w.opt = *opt; w.grads_only = grads_only ? 1 : 0; w.Bp = Bp;
+    w.jobs_per_net = gt_dw_layers(w, an, workspace + ws.x, 0, workspace + ws.h, 0, workspace + ws.dz, 0, workspace + ws.dout, 0, nullptr, nullptr, Bp);
+    w.n_job_wgs = (w.jobs_per_net + 3) / 4;
+    { IL_TRACE("k_gt_dw", st); k_gt_dw<<<w.n_job_wgs, 256, 0, st>>>(w); }
+    IL_CHECK_LAUNCH("il_bc_step_general (tile engine)");
+    return IL_OK;
+  }
   g_pack(st, b->states, b->ld_states, S, nullptr, 0, 0, n, Bp, workspace + ws.x);
   if (int rc = g_forward(st, an, actor, 0, 1, workspace + ws.x, 0, workspace + ws.h, workspace + ws.o, Bp)) return rc;
   { IL_TRACE("k_g_logp", st); k_g_logp<<<(Bp + 255) / 256, 256, 0, st>>>(workspace + ws.o, Bp, n, A, b->actions, b->ld_actions, nullptr, b->weights, b->ld_weights, workspace + ws.dout, workspace + ws.rows); }
