@@ -13,6 +13,7 @@
 // Padding rows carry zeros in every dZ, so they contribute nothing to any gradient.
 #include "il_common.hpp"
 #include "mlp_tile.hpp"
+#include "dw_block.hpp"
 
 enum { G_ACT_NONE = -1, G_ACT_RELU = 0, G_ACT_TANH = 1, G_ACT_SIGMOID = 2 };
 
@@ -402,7 +403,7 @@ static void g_pack(hipStream_t st, const float* f1, int ld1, int K1, const float
 // layer's dot product is split over the waves (tile_fwd_small: partial tiles summed in k-block order), so results equal the layer-at-a-time path to rounding, not bit for bit.
 // =================================================================================================================================================================
 struct GtNet { const float* P; int in, H, depth, out, act; const float* PF; const float* PB; };   // PF / PB: [depth - 1][H * H] lane-ordered copies (NULL: read W directly)
-__host__ __device__ static inline int gt_threads(int H) { return H * 4 < 256 ? 256 : (H * 4 > 1024 ? 1024 : H * 4); }
+__host__ __device__ static inline int gt_threads(int H) { return H * 4 < 256 ? 256 : (H * 4 > 512 ? 512 : H * 4); }   // (8 waves: the 256-VGPR budget keeps a whole 16 KB weight panel in registers without a spill; 16 waves spilled 18 - 30 VGPRs)
 
 struct GtFwdPass {
   GtNet net;
@@ -414,7 +415,7 @@ struct GtFwdPass {
 };
 struct GtFwd { GtFwdPass p[4]; int n, Bp; };
 
-__global__ __launch_bounds__(1024) void k_gt_fwd(GtFwd a) {
+__global__ __launch_bounds__(512) void k_gt_fwd(GtFwd a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const GtFwdPass& q = a.p[blockIdx.y];
   const GtNet& nn = q.net;
@@ -423,17 +424,22 @@ __global__ __launch_bounds__(1024) void k_gt_fwd(GtFwd a) {
   const int inp = round_up16(in), ldx = inp + 4, ldh = H + 4;
   float* Xs = smem; float* A0 = Xs + 16 * ldx; float* A1 = A0 + 16 * ldh; float* part = A1 + 16 * ldh; float* Os = part + (H >> 4) * 256;
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, tid = threadIdx.x;
+  const bool stamp = blockIdx.x == 0 && blockIdx.y == 1;
+  IL_STAMP(stamp, 0);
   load_rows_cat(Xs, ldx, inp, q.f1, q.ld1, q.K1, q.f2, q.ld2, q.K2, row0, nrows);
   __syncthreads();
+  IL_STAMP(stamp, 1);
   if (q.X0T)
     for (int i = tid; i < 16 * in; i += blockDim.x) { const int c = i >> 4, r = i & 15; q.X0T[(size_t)c * Bp + row0 + r] = Xs[r * ldx + c]; }
   const float* P = nn.P;
   float* cur = A0; float* nxt = A1;
+  const int wcol = min((int)(threadIdx.x >> 6) * 16 + j, H - 1);   // this lane's column of the wave's FIRST output tile: its bias is requested ahead of each layer's MFMAs
   {
     const GLayer L = g_layer(in, H, depth, out, 0);
     const float* bias = P + L.ob;
+    const float pb = gload(bias + wcol);
     tile_fwd(Xs, ldx, inp, P + L.oW, in, in, H, [&](int c0, f32x4 acc) {
-      const int col = c0 + j; const float bb = gload(bias + col);
+      const int col = c0 + j; const float bb = col == wcol ? pb : gload(bias + col);
       f32x4 hv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { hv[r] = g_act(acc[r] + bb, act); cur[(4 * g + r) * ldh + col] = hv[r]; }
@@ -441,26 +447,30 @@ __global__ __launch_bounds__(1024) void k_gt_fwd(GtFwd a) {
     });
   }
   __syncthreads();
+  IL_STAMP(stamp, 2);
   for (int l = 1; l < depth; ++l) {
     const GLayer L = g_layer(in, H, depth, out, l);
     const float* bias = P + L.ob;
     float* ht = q.HT ? q.HT + (size_t)l * H * Bp : nullptr;
+    const float pb = gload(bias + wcol);
     auto epi = [&](int c0, f32x4 acc) {
-      const int col = c0 + j; const float bb = gload(bias + col);
+      const int col = c0 + j; const float bb = col == wcol ? pb : gload(bias + col);
       f32x4 hv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { hv[r] = g_act(acc[r] + bb, act); nxt[(4 * g + r) * ldh + col] = hv[r]; }
       if (ht) *reinterpret_cast<f32x4*>(ht + (size_t)col * Bp + row0 + 4 * g) = hv;
     };
-    if (nn.PF) tile_fwd_packed(cur, ldh, H, nn.PF + (size_t)(l - 1) * H * H, epi);
+    if (nn.PF) tile_packed_x2(cur, ldh, H, nn.PF + (size_t)(l - 1) * H * H, epi);
     else tile_fwd(cur, ldh, H, P + L.oW, H, H, H, epi);
     __syncthreads();
+    IL_STAMP(stamp, 2 + l);
     float* t = cur; cur = nxt; nxt = t;
   }
   {
     const GLayer L = g_layer(in, H, depth, out, depth);
     tile_fwd_small(cur, ldh, H, P + L.oW, H, out, P + L.ob, Os, part);   // (barriers inside)
   }
+  IL_STAMP(stamp, 10);
   if (q.OT)
     for (int i = tid; i < 16 * out; i += blockDim.x) { const int c = i >> 4, r = i & 15; q.OT[(size_t)c * Bp + row0 + r] = Os[r * 16 + c]; }
   if (q.head && tid < 16) {   // k_g_sample's arithmetic, one thread per row of the tile
@@ -485,6 +495,7 @@ __global__ __launch_bounds__(1024) void k_gt_fwd(GtFwd a) {
       if (q.logp) q.logp[row] = (0.f - sl) + sn;
     }
   }
+  IL_STAMP(stamp, 11);
 }
 
 // seeds of k_gt_bwd (the per-row kernels' arithmetic: k_g_critic_seed, k_g_policy_seed, k_g_head_bwd, k_g_logp)
@@ -500,7 +511,7 @@ struct GtBwd {
   float* loss_rows;                                                                                           // behavioural cloning
   il_adam tick;                                                                                              // ticked by (tile 0, net 0): consumed by the k_gt_dw that follows (step == NULL: none)
 };
-__global__ __launch_bounds__(1024) void k_gt_bwd(GtBwd a) {
+__global__ __launch_bounds__(512) void k_gt_bwd(GtBwd a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const GtNet& nn = a.net;
   const int H = nn.H, in = nn.in, depth = nn.depth, out = nn.out, act = nn.act, Bp = a.Bp, net = blockIdx.y;
@@ -510,6 +521,8 @@ __global__ __launch_bounds__(1024) void k_gt_bwd(GtBwd a) {
   const float* P = nn.P + net * a.p_ns;
   const float* HT = a.HT + net * a.h_ns;
   float* dZT = a.dZT + net * a.dz_ns;
+  const bool stamp = blockIdx.x == 0 && blockIdx.y == 0;
+  IL_STAMP(stamp, 16);
   for (int i = tid; i < 16 * ldy; i += blockDim.x) dYs[i] = 0.f;
   __syncthreads();
   if (tid < 16) {
@@ -535,21 +548,9 @@ __global__ __launch_bounds__(1024) void k_gt_bwd(GtBwd a) {
         dq = net == 0 ? -(sel) / (float)n : -(1.f - sel) / (float)n;
       }
       dYs[tid * ldy] = dq;
-    } else if (a.seed == GT_SEED_HEAD) {
-      const int A = out >> 1;
+    } else if (a.seed == GT_SEED_HEAD) {   // (the per-row outputs; the head gradient itself: one thread per (row, component) below)
       if (live) {
-        const float alpha = expf(a.log_alpha[0]);
         const float w = a.b.weights[(size_t)row * a.b.ld_weights], m = 1.f - a.b.absorbing[(size_t)row * a.b.ld_absorbing];
-        const float cc = (w * m * alpha) / (float)n;
-        for (int c = 0; c < A; ++c) {
-          const float x = a.xT[(size_t)c * Bp + row], e = a.epsT[(size_t)c * Bp + row], lsr = a.outT[(size_t)(A + c) * Bp + row];
-          const float sd = expf(fminf(fmaxf(lsr, -20.f), 2.f)), an = tanhf(x);
-          const float da = a.dx0T[(size_t)(a.S + c) * Bp + row] + a.dx0T[a.dx0_ns + (size_t)(a.S + c) * Bp + row];
-          const float dx = cc * (2.f * an) + da * (1.f - an * an);
-          const float dsd = dx * e - cc / sd;
-          dYs[tid * ldy + c] = dx;
-          dYs[tid * ldy + A + c] = (lsr >= -20.f && lsr <= 2.f) ? dsd * sd : 0.f;
-        }
         const float lp = a.logp[row];
         a.alpha_rows[row] = w * m * (lp + a.entropy_target);
         if (a.out_logp) a.out_logp[row] = lp;
@@ -574,18 +575,39 @@ __global__ __launch_bounds__(1024) void k_gt_bwd(GtBwd a) {
       } else if (row < Bp && a.loss_rows) a.loss_rows[row] = 0.f;
     }
   }
-  if (blockIdx.x == 0 && net == 0 && tid == 64 && a.tick.step) adam_tick(a.tick);
+  if (a.seed == GT_SEED_HEAD) {   // k_g_head_bwd's arithmetic with every operand of the tile requested at once (a thread per row walked A dependent round trips: 5.5 us)
+    const int A = out >> 1, t2 = tid - 64;   // (waves 1, 2: wave 0 holds the per-row threads above)
+    if (t2 >= 0 && t2 < 16 * A) {
+      const int r = t2 / A, c = t2 - r * A, row = row0 + r;
+      if (row < a.n) {
+        const float alpha = expf(a.log_alpha[0]);
+        const float w = a.b.weights[(size_t)row * a.b.ld_weights], m = 1.f - a.b.absorbing[(size_t)row * a.b.ld_absorbing];
+        const float cc = (w * m * alpha) / (float)a.n;
+        const float x = a.xT[(size_t)c * Bp + row], e = a.epsT[(size_t)c * Bp + row], lsr = a.outT[(size_t)(A + c) * Bp + row];
+        const float da = a.dx0T[(size_t)(a.S + c) * Bp + row] + a.dx0T[a.dx0_ns + (size_t)(a.S + c) * Bp + row];
+        const float sd = expf(fminf(fmaxf(lsr, -20.f), 2.f)), an = tanhf(x);
+        const float dx = cc * (2.f * an) + da * (1.f - an * an);
+        const float dsd = dx * e - cc / sd;
+        dYs[r * ldy + c] = dx;
+        dYs[r * ldy + A + c] = (lsr >= -20.f && lsr <= 2.f) ? dsd * sd : 0.f;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && net == 0 && tid == 192 && a.tick.step) adam_tick(a.tick);
   __syncthreads();
+  IL_STAMP(stamp, 17);
   if (a.dOT)
     for (int i = tid; i < 16 * out; i += blockDim.x) { const int c = i >> 4, r = i & 15; a.dOT[net * a.do_ns + (size_t)c * Bp + row0 + r] = dYs[r * ldy + c]; }
   float* cur = Z0; float* nxt = Z1;
+  const int wk = min((int)(threadIdx.x >> 6) * 16 + j, H - 1);   // this lane's feature of the wave's FIRST tile: its activation lane is requested ahead of each layer's MFMAs
   {   // through the output layer: dZ of the last hidden layer
     const GLayer L = g_layer(in, H, depth, out, depth);
     const float* hp = HT + (size_t)(depth - 1) * H * Bp;
     float* dz = dZT + (size_t)(depth - 1) * H * Bp;
+    const f32x4 hpre = gload4(hp + (size_t)wk * Bp + row0 + 4 * g);
     tile_bwd_dx(dYs, ldy, 16, out, P + L.oW, H, H, [&](int kb, f32x4 acc) {
       const size_t off = (size_t)(kb + j) * Bp + row0 + 4 * g;
-      const f32x4 h = gload4(hp + off);
+      const f32x4 h = kb + j == wk ? hpre : gload4(hp + off);
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v[r] = acc[r] * g_act_grad(h[r], act); cur[(4 * g + r) * ldh + kb + j] = v[r]; }
@@ -593,46 +615,48 @@ __global__ __launch_bounds__(1024) void k_gt_bwd(GtBwd a) {
     });
   }
   __syncthreads();
+  IL_STAMP(stamp, 18);
   for (int l = depth - 1; l >= 1; --l) {   // dZ of hidden layer l (in `cur`) -> dZ of hidden layer l - 1
     const GLayer L = g_layer(in, H, depth, out, l);
     const float* hp = HT + (size_t)(l - 1) * H * Bp;
     float* dz = dZT + (size_t)(l - 1) * H * Bp;
+    const f32x4 hpre = gload4(hp + (size_t)wk * Bp + row0 + 4 * g);
     auto epi = [&](int kb, f32x4 acc) {
       const size_t off = (size_t)(kb + j) * Bp + row0 + 4 * g;
-      const f32x4 h = gload4(hp + off);
+      const f32x4 h = kb + j == wk ? hpre : gload4(hp + off);
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v[r] = acc[r] * g_act_grad(h[r], act); nxt[(4 * g + r) * ldh + kb + j] = v[r]; }
       *reinterpret_cast<f32x4*>(dz + off) = v;
     };
-    if (nn.PB) tile_bwd_packed(cur, ldh, H, nn.PB + net * a.pk_ns + (size_t)(l - 1) * H * H, epi);
+    if (nn.PB) tile_packed_x2(cur, ldh, H, nn.PB + net * a.pk_ns + (size_t)(l - 1) * H * H, epi);
     else tile_bwd_dx(cur, ldh, H, H, P + L.oW, H, H, epi);
     __syncthreads();
+    IL_STAMP(stamp, 18 + (depth - l));
     float* t = cur; cur = nxt; nxt = t;
   }
   if (a.dX0T) {   // dL/d(input), columns [dx_c0, dx_c1): no activation behind the input
     const GLayer L = g_layer(in, H, depth, out, 0);
     float* dx = a.dX0T + net * a.dx_ns;
-    tile_bwd_dx(cur, ldh, H, H, P + L.oW, in, in, [&](int kb, f32x4 acc) {
-      const int k = kb + j;
-      if (k >= a.dx_c0 && k < a.dx_c1) *reinterpret_cast<f32x4*>(dx + (size_t)k * Bp + row0 + 4 * g) = acc;
+    // a few columns of a K = in wide product: the N-reduction split over the waves (tile_bwd_dx would keep one or two waves busy with H / 4 dependent MFMAs each)
+    tile_bwd_dx_cols(cur, ldh, H, P + L.oW, in, in, a.dx_c0, a.dx_c1, nxt, [&](int col, int row, float v) {
+      if (col >= a.dx_c0 && col < a.dx_c1) dx[(size_t)col * Bp + row0 + row] = v;
     });
   }
+  IL_STAMP(stamp, 27);
 }
 
 // every layer's dW and db of `nets` networks with the optimiser in the epilogue
-struct GtDwLayer { const float* dZT; int64_t dz_ns; const float* XT; int64_t x_ns; int64_t oW, ob; int N, K; int tile0, bias0; float* PF; float* PB; };   // tile0 / bias0: first wave-job of the layer's tiles / bias features; PF / PB: this layer's lane-ordered copies (NULL: none)
+struct GtDwLayer { const float* dZT; int64_t dz_ns; const float* XT; int64_t x_ns; int64_t oW, ob; int N, K; int tile0, bias0, blk0; float* PF; float* PB; };   // blk0: first 32 x 32 block job of the layer (k_gt_dw32)   // tile0 / bias0: first wave-job of the layer's tiles / bias features; PF / PB: this layer's lane-ordered copies (NULL: none)
 struct GtDw {
-  GtDwLayer L[9]; int n_layers, jobs_per_net, nets; int64_t p_ns, pk_ns;
+  GtDwLayer L[9]; int n_layers, jobs_per_net, blocks_per_net, nets; int64_t p_ns, pk_ns;
   float* P; float* G; int64_t g_ns; il_adam opt; int grads_only, Bp;
   int n_job_wgs;   // workgroups of tile / bias jobs; behind them the tail workgroups
   // tail (the actor's launch): temperature step (k_g_alpha), target update (k_polyak), Philox counter
   const float* alpha_rows; int n_rows; float* log_alpha; il_adam alpha_opt; float* alpha_grad; uint32_t* noise_counter;
   float* target; const float* polyak_src; int64_t polyak_n; double tau;
 };
-__global__ __launch_bounds__(256) void k_gt_dw(GtDw a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
-  if ((int)blockIdx.x >= a.n_job_wgs) {   // ---- tail
+__device__ __forceinline__ void gt_dw_tail(const GtDw& a) {   // the workgroups behind the jobs: temperature step + Philox counter (workgroup 0), target update (all)
     const int tb = (int)blockIdx.x - a.n_job_wgs, ntb = (int)gridDim.x - a.n_job_wgs;
     if (tb == 0 && threadIdx.x == 0 && a.log_alpha) {
       float s = 0.f;
@@ -653,8 +677,10 @@ __global__ __launch_bounds__(256) void k_gt_dw(GtDw a) {
       for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < a.polyak_n; i += (int64_t)ntb * blockDim.x)
         a.target[i] = __fadd_rn(__fmul_rn(a.target[i], tau), __fmul_rn(omt, a.polyak_src[i]));
     }
-    return;
-  }
+}
+__global__ __launch_bounds__(256) void k_gt_dw(GtDw a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  if ((int)blockIdx.x >= a.n_job_wgs) { gt_dw_tail(a); return; }
   int job = blockIdx.x * 4 + wave;
   if (job >= a.jobs_per_net * a.nets) return;
   const int net = job / a.jobs_per_net; job -= net * a.jobs_per_net;
@@ -665,25 +691,12 @@ __global__ __launch_bounds__(256) void k_gt_dw(GtDw a) {
   il_adam opt = a.opt; opt.m += net * a.p_ns; opt.v += net * a.p_ns;
   adam_consts ac = {};
   if (!a.grads_only) ac = load_adam_consts(a.opt);
-  if (job >= L.bias0) {   // bias: one wave per output feature (g_dbias)
-    const int n = job - L.bias0;
-    if (n >= L.N) return;
-    const float* z = L.dZT + net * L.dz_ns + (size_t)n * a.Bp;
-    float s = 0.f;
-    for (int r = lane; r < a.Bp; r += 64) s += gload(z + r);
-    s = wave_sum(s);
-    if (lane == 0) {
-      const int64_t o = L.ob + n;
-      if (a.G) a.G[net * a.g_ns + o] = s;   // (the gradient arena is part of the entry points' contract: behavioural cloning's callers read it back)
-      if (!a.grads_only) { float pp = P[o], mm = opt.m[o], vv = opt.v[o]; adam_update(pp, s, mm, vv, ac); P[o] = pp; opt.m[o] = mm; opt.v[o] = vv; }
-    }
-    return;
-  }
   const int tile = job - L.tile0, tk = (L.K + 15) >> 4;
   const int n0 = (tile / tk) * 16, k0 = (tile - (tile / tk) * tk) * 16;
   const float* zr = L.dZT + net * L.dz_ns + (size_t)min(n0 + j, L.N - 1) * a.Bp + 4 * g;
   const float* xr = L.XT + net * L.x_ns + (size_t)min(k0 + j, L.K - 1) * a.Bp + 4 * g;
   f32x4 acc0 = zero4(), acc1 = zero4();
+  float bs = 0.f;   // the layer's bias gradient rides in the tiles of its first k-column: this lane's rows of dZ[n0 + j], summed in row order
   int r0 = 0;
   for (; r0 + 64 <= a.Bp; r0 += 64) {   // four row groups per trip, their eight lanes requested together (k_g_dw's MFMA order)
     f32x4 z[4], x[4];
@@ -691,11 +704,24 @@ __global__ __launch_bounds__(256) void k_gt_dw(GtDw a) {
     for (int u = 0; u < 4; ++u) { z[u] = gload4(zr + r0 + 16 * u); x[u] = gload4(xr + r0 + 16 * u); }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { acc0 = mfma16(z[u][0], x[u][0], acc0); acc1 = mfma16(z[u][1], x[u][1], acc1); acc0 = mfma16(z[u][2], x[u][2], acc0); acc1 = mfma16(z[u][3], x[u][3], acc1); }
+    for (int u = 0; u < 4; ++u) {
+      acc0 = mfma16(z[u][0], x[u][0], acc0); acc1 = mfma16(z[u][1], x[u][1], acc1); acc0 = mfma16(z[u][2], x[u][2], acc0); acc1 = mfma16(z[u][3], x[u][3], acc1);
+      bs += (z[u][0] + z[u][1]) + (z[u][2] + z[u][3]);
+    }
   }
   for (; r0 < a.Bp; r0 += 16) {
     const f32x4 z = gload4(zr + r0), x = gload4(xr + r0);
     acc0 = mfma16(z[0], x[0], acc0); acc1 = mfma16(z[1], x[1], acc1); acc0 = mfma16(z[2], x[2], acc0); acc1 = mfma16(z[3], x[3], acc1);
+    bs += (z[0] + z[1]) + (z[2] + z[3]);
+  }
+  if (k0 == 0) {   // (wave-uniform) the four row groups g of feature n0 + j meet in lane j
+    bs += __shfl_xor(bs, 16, 64);
+    bs += __shfl_xor(bs, 32, 64);
+    if (g == 0 && n0 + j < L.N) {
+      const int64_t o = L.ob + n0 + j;
+      if (a.G) a.G[net * a.g_ns + o] = bs;   // (the gradient arena is part of the entry points' contract: behavioural cloning's callers read it back)
+      if (!a.grads_only) { float pp = P[o], mm = opt.m[o], vv = opt.v[o]; adam_update(pp, bs, mm, vv, ac); P[o] = pp; opt.m[o] = mm; opt.v[o] = vv; }
+    }
   }
   const f32x4 acc = acc0 + acc1;
   const int k = k0 + j;
@@ -713,6 +739,24 @@ __global__ __launch_bounds__(256) void k_gt_dw(GtDw a) {
   }
 }
 
+// the same launch as 32 x 32 BLOCK jobs (dw_block.hpp dw_block32: operands staged through LDS with whole-line loads, the layer's bias in the blocks of its first k-column, AdamW and
+// the lane-ordered copies in the epilogue) - the form the single learner's k_dw_adam runs; needs Bp % 128 == 0. k_gt_dw's wave-per-tile gathers are texture-address bound (17.6 us
+// per launch at depth 3 / 256 against ~6 here).
+__global__ __launch_bounds__(256) void k_gt_dw32(GtDw a) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * DWS * DWS_LD];
+  if ((int)blockIdx.x >= a.n_job_wgs) { gt_dw_tail(a); return; }
+  int job = blockIdx.x;
+  const int net = job / a.blocks_per_net; job -= net * a.blocks_per_net;
+  int li = 0;
+  for (int i = 1; i < a.n_layers; ++i) if (job >= a.L[i].blk0) li = i;
+  const GtDwLayer& L = a.L[li];
+  const int b = job - L.blk0, nbk = (L.K + DWS - 1) / DWS;
+  DwArgs d = {};
+  d.params = a.P; d.grads = a.G; d.opt = a.opt; d.grads_only = a.grads_only; d.batch = a.Bp;
+  const int64_t base = net * a.p_ns;
+  dw_block32<false>(d, L.dZT + net * L.dz_ns, L.N, L.XT + net * L.x_ns, L.K, (b / nbk) * DWS, (b % nbk) * DWS, base + L.oW, base + L.ob, L.PF ? L.PF + net * a.pk_ns : nullptr,
+                    L.PB ? L.PB + net * a.pk_ns : nullptr, smem);
+}
 // lane-ordered copies of the H x H layers: blockIdx.y = slot; slot s copies W (src[s]) into PF[s] / PB[s] (PB NULL: forward copy only)
 struct GtRepack { const float* W[16]; float* PF[16]; float* PB[16]; int H[16]; };
 __global__ __launch_bounds__(256) void k_gt_repack(GtRepack a) {
@@ -748,7 +792,7 @@ static bool gt_packable(const GNet& s, const float* P) {
 }
 // fills the layer table of a k_gt_dw launch; returns the wave-jobs per network
 static int gt_dw_layers(GtDw& w, const GNet& s, const float* X0T, int64_t x_ns, const float* HT, int64_t h_ns, const float* dZT, int64_t dz_ns, const float* dOT, int64_t do_ns, float* PF, float* PB, int Bp) {
-  int job = 0;
+  int job = 0, blk = 0;
   w.n_layers = s.depth + 1;
   for (int l = 0; l <= s.depth; ++l) {
     const GLayer L = g_layer(s.in, s.H, s.depth, s.out, l);
@@ -757,10 +801,12 @@ static int gt_dw_layers(GtDw& w, const GNet& s, const float* X0T, int64_t x_ns, 
     d.XT = l == 0 ? X0T : HT + (int64_t)(l - 1) * s.H * Bp; d.x_ns = l == 0 ? x_ns : h_ns;
     d.oW = L.oW; d.ob = L.ob; d.N = L.N; d.K = L.K;
     d.tile0 = job; job += ((L.N + 15) / 16) * ((L.K + 15) / 16);
-    d.bias0 = job; job += L.N;
+    d.bias0 = job;   // (no bias jobs: the tiles of a layer's first k-column carry its bias gradient)
+    d.blk0 = blk; blk += ((L.N + DWS - 1) / DWS) * ((L.K + DWS - 1) / DWS);
     const bool hh = l >= 1 && l < s.depth && PF;
     d.PF = hh ? PF + (int64_t)(l - 1) * s.H * s.H : nullptr; d.PB = hh ? PB + (int64_t)(l - 1) * s.H * s.H : nullptr;
   }
+  w.blocks_per_net = blk;
   return job;
 }
 
@@ -847,8 +893,8 @@ static int g_sac_update_tiles(const il_sac* d, const il_batch* b, const GNet& an
   {
     GtDw w = {}; w.nets = 2; w.p_ns = Ps; w.pk_ns = pkc; w.P = d->critic; w.G = gc; w.g_ns = Ps; w.opt = d->critic_opt; w.grads_only = grads_only ? 1 : 0; w.Bp = Bp;
     w.jobs_per_net = gt_dw_layers(w, cn, W + ws.xc, 0, W + ws.hc, hid_c, W + ws.dz, hid_c, W + ws.dq, Bp, pc ? W + ws.pk_cf : nullptr, pc ? W + ws.pk_cb : nullptr, Bp);
-    w.n_job_wgs = (w.jobs_per_net * 2 + 3) / 4;
-    IL_TRACE("k_gt_dw", st); k_gt_dw<<<w.n_job_wgs, 256, 0, st>>>(w);
+    if (Bp % DWS_ROWS == 0) { w.n_job_wgs = w.blocks_per_net * 2; IL_TRACE("k_gt_dw32", st); k_gt_dw32<<<w.n_job_wgs, 256, 0, st>>>(w); }
+    else { w.n_job_wgs = (w.jobs_per_net * 2 + 3) / 4; IL_TRACE("k_gt_dw", st); k_gt_dw<<<w.n_job_wgs, 256, 0, st>>>(w); }
   }
   // E. the stepped critics on (s, a~), F. policy seed + backward down to dQ/da~ (training.py:34-38)
   {
@@ -874,11 +920,13 @@ static int g_sac_update_tiles(const il_sac* d, const il_batch* b, const GNet& an
   {
     GtDw w = {}; w.nets = 1; w.P = d->actor; w.G = ga; w.opt = d->actor_opt; w.grads_only = grads_only ? 1 : 0; w.Bp = Bp;
     w.jobs_per_net = gt_dw_layers(w, an, W + ws.xa, 0, W + ws.ha, hid_a, W + ws.dz, hid_a, W + ws.dout, 0, nullptr, nullptr, Bp);   // (the actor's copies are re-derived at the next update's start)
-    w.n_job_wgs = (w.jobs_per_net + 3) / 4;
+    const bool blocks = Bp % DWS_ROWS == 0;
+    w.n_job_wgs = blocks ? w.blocks_per_net : (w.jobs_per_net + 3) / 4;
     w.alpha_rows = W + ws.arows; w.n_rows = B; w.log_alpha = d->log_alpha; w.alpha_opt = d->alpha_opt; w.alpha_grad = d->alpha_grad; w.noise_counter = d->noise_counter;
     w.target = d->target; w.polyak_src = d->critic; w.polyak_n = Ps + Pc; w.tau = d->polyak;
     const int tail = grads_only ? 1 : 1 + (int)(((Ps + Pc) / 256 + 7) / 8 < 64 ? ((Ps + Pc) / 256 + 7) / 8 : 64);
-    IL_TRACE("k_gt_dw", st); k_gt_dw<<<w.n_job_wgs + tail, 256, 0, st>>>(w);
+    if (blocks) { IL_TRACE("k_gt_dw32", st); k_gt_dw32<<<w.n_job_wgs + tail, 256, 0, st>>>(w); }
+    else { IL_TRACE("k_gt_dw", st); k_gt_dw<<<w.n_job_wgs + tail, 256, 0, st>>>(w); }
   }
   (void)Pa;
   IL_CHECK_LAUNCH("il_sac_update_general (tile engine)");
@@ -1056,3 +1104,4 @@ extern "C" int il_bc_step_general(float* actor, float* actor_grad, const il_adam
   IL_CHECK_LAUNCH("il_bc_step_general");
   return IL_OK;
 }
+IL_STAMP_READER(il_debug_stamps_general)

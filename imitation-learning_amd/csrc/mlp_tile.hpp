@@ -325,6 +325,42 @@ __device__ __forceinline__ void tile_packed(const float* As, int lda, int H, con
     epi(t * 16, acc);
   }
 }
+// (round 6, the general-shape tile engine) Two output tiles per wave (an 8-wave workgroup at H = 256, 256 VGPRs per wave): BOTH 16 KB panels are requested before the
+// first MFMA - the whole layer's 256 KB is in flight at once - instead of tile_packed's load, 64 MFMAs, load, 64 MFMAs (measured: 6.1 - 6.9 us per 16 x 256 x 256 layer
+// against 3.4 us of MFMA issue). Same MFMA order per tile: same bits. Falls back to tile_packed for any other shape.
+template <class Epi>
+__device__ __forceinline__ void tile_packed_x2(const float* As, int lda, int H, const float* __restrict__ P, Epi epi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int j = lane & 15, g = lane >> 4, nb = H >> 4;
+  if (nb != 16 || nw != 8) { tile_packed<16>(As, lda, H, P, epi); return; }
+  const float* p0 = P + (size_t)wave * nb * 256 + lane * 4;
+  const float* p1 = P + (size_t)(wave + 8) * nb * 256 + lane * 4;
+  const float* ar = As + j * lda + 4 * g;
+  f32x4 b0[16], b1[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) b0[u] = gload4(p0 + (size_t)u * 256);
+#pragma unroll
+  for (int u = 0; u < 16; ++u) b1[u] = gload4(p1 + (size_t)u * 256);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ar + 16 * u);
+      acc0 = mfma16(a[0], b0[u][0], acc0); acc1 = mfma16(a[1], b0[u][1], acc1); acc0 = mfma16(a[2], b0[u][2], acc0); acc1 = mfma16(a[3], b0[u][3], acc1);
+    }
+    epi(wave * 16, acc0 + acc1);
+  }
+  {
+    f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ar + 16 * u);
+      acc0 = mfma16(a[0], b1[u][0], acc0); acc1 = mfma16(a[1], b1[u][1], acc1); acc0 = mfma16(a[2], b1[u][2], acc0); acc1 = mfma16(a[3], b1[u][3], acc1);
+    }
+    epi((wave + 8) * 16, acc0 + acc1);
+  }
+}
 // (Measured and dropped in round 2: an early "touch" of a workgroup's packed panels - one dword per 128-byte line requested at the top of the kernel so that the
 // lines rewritten by the previous Adam kernel are already in this XCD's L2 when the layer starts. Same-box A/B 14.24k -> 13.39k updates/s: loads return in order,
 // so the rows and first-layer operands issued behind the cold touches wait for them; profiles/r02_update_timeline.md.)

@@ -741,7 +741,7 @@ class UpdatePlan:
     """Bounded waits that gave up (device counter). Non-zero means the two branches did not run concurrently (e.g. a counter-collecting
     profiler serialises kernels): results of those updates are invalid; `capture()` checks this once and falls back to stream dependencies."""
     handoff = C.c_uint32(0)
-    if getattr(self, '_prepared', False):   # the in-launch waits of the chained kernels (counted since the first update's k_repack); with il_sync counters they are in sync[IL_SYNC_TIMEOUTS] too
+    if getattr(self, '_prepared', False) and not self.general:   # (general shapes: another workspace layout, no in-launch waits)   # the in-launch waits of the chained kernels (counted since the first update's k_repack); with il_sync counters they are in sync[IL_SYNC_TIMEOUTS] too
       _lib.check(_lib.lib().il_sac_handoff_timeouts(C.byref(self.sac), C.byref(handoff)))
     return max(int(self.sync[self._sync_timeouts].item()), int(handoff.value))
 

@@ -224,6 +224,28 @@ def test_general_shape_sac_matches_oracle_and_reference(golden_dir, name):
     parallel.DataParallelUpdate(gplan)
 
 
+@pytest.mark.parametrize('hidden,depth,activation,batch,critic', [(128, 3, 'tanh', 128, None), (64, 2, 'sigmoid', 256, (128, 1, 'tanh')), (256, 3, 'tanh', 256, None)])
+def test_general_shape_tile_engine_matches_oracle_at_block_batches(hidden, depth, activation, batch, critic):
+  """(round 6) general.hip's tile engine at batches that are multiples of 128, where its optimiser launches run dw_block.hpp's 32 x 32 block jobs (the single learner's
+  form) and - at hidden widths that are multiples of 64 - every H x H layer runs from its lane-ordered copies, two panels per wave: two sac_update steps against the oracle
+  (models.py:48-69 shapes: depth 3 / tanh, a sigmoid actor beside a depth-1 tanh critic, and depth 3 / tanh / 256 - the shape bench.py's `secondary` line times)."""
+  kw = dict(seed=51, env='halfcheetah', hidden=hidden, batch=batch, steps=2, depth=depth, activation=activation)
+  if critic is not None: kw['critic'] = critic
+  c = gi.sac_case(**kw)
+  actor, critic_net, target, log_alpha, ao, co, to = make_sac(c)
+  assert actor.general or critic_net.general
+  st = make_sac_oracle(c)
+  for k in (1, 2):
+    b = c['batches'][k - 1]
+    logp, q = il.sac_update(actor, critic_net, log_alpha, target, tbatch(b), ao, co, to, c['discount'], c['entropy_target'], c['polyak'], eps_next=T(c['eps_next'][k - 1]), eps_cur=T(c['eps_cur'][k - 1]))
+    ologp, oq = osac.sac_update(st, b, c['eps_next'][k - 1], c['eps_cur'][k - 1], discount=c['discount'], entropy_target=c['entropy_target'], polyak_factor=c['polyak'], lr=c['lr'], weight_decay=c['weight_decay'])
+    torch.cuda.synchronize()
+    close(N(logp), ologp, f'logp step {k}', atol_scale=2e-6 * k); close(N(q), oq, f'q step {k}', atol_scale=2e-6 * k)
+    close_params(N(actor.flat), st.actor, f'block-batch actor step {k}', c['lr'], k); close_params(crit_from_flat(critic_net, critic_net.flat), st.critic, f'block-batch critic step {k}', c['lr'], k)
+    close_params(crit_from_flat(critic_net, target.flat), st.target, f'block-batch target step {k}', c['lr'], k); close(N(log_alpha), st.log_alpha, f'log_alpha step {k}')
+    close(N(ao.exp_avg), st.actor_m, f'actor m step {k}', atol_scale=1e-5 * k); close(crit_from_flat(critic_net, co.exp_avg), st.critic_m, f'critic m step {k}', atol_scale=1e-5 * k)
+
+
 def test_bc_update_matches_oracle_and_reference(golden_dir):
   g = load(golden_dir, 'bc_hopper')
   S, A = gi.DIMS['hopper']

@@ -410,6 +410,7 @@ GPU_BODIES = (
     'test_gmmil_matches_oracle_and_reference', 'test_gmmil_full_size_properties', 'test_pwil_matches_oracle_and_reference', 'test_pwil_every_launch_path_matches_oracle',
     'test_reward_relabeller_bit_exact', 'test_mix_expert_agent_transitions_bit_exact',
     'test_red_matches_reference', 'test_dril_matches_reference', 'test_every_shipped_red_dril_shape_runs_at_ant_dims', 'test_dril_onchip_masks_are_bernoulli_and_change_per_call',
+    'test_general_shape_tile_engine_matches_oracle_at_block_batches',
     'test_gail_deep_discriminator_matches_reference', 'test_gail_deep_pugail_finite_margin_matches_reference',
     'test_gail_reward_shaping_matches_reference', 'test_gail_reward_shaping_mixup_matches_reference', 'test_gail_shaped_pugail_finite_margin_matches_reference',
     'test_gail_reward_shaping_general_potential_matches_reference', 'test_red_dril_shaped_at_ant_dims_match_oracle',
