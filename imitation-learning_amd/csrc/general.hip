@@ -413,18 +413,22 @@ struct GtFwdPass {
   const float* eps; uint64_t seed; const uint32_t* ctr_ptr; uint32_t ctr; int stream_id; const float* absorbing; int ld_abs; int greedy;
   float* a_rows; int ld_a; float* xT; float* epsT; float* logp;
 };
-struct GtFwd { GtFwdPass p[4]; int n, Bp; };
+struct GtFwd { GtFwdPass p[4]; int n, Bp, npass; };
 
 __global__ __launch_bounds__(512) void k_gt_fwd(GtFwd a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const GtFwdPass& q = a.p[blockIdx.y];
+  // 1-D grid of (tile, pass) pairs, decoded so that the tiles of ONE pass share 8 / passes XCDs (xcd_tile_net): an XCD's private L2 then pulls one or two networks through
+  // the fabric per layer instead of all of them (the first launch of an update, 4 passes x 16 tiles: 31 -> us with every XCD pulling all four networks)
+  int tile_, pass_;
+  xcd_tile_net((int)blockIdx.x, a.Bp / 16, a.npass, tile_, pass_);
+  const GtFwdPass& q = a.p[pass_];
   const GtNet& nn = q.net;
   const int H = nn.H, in = nn.in, depth = nn.depth, out = nn.out, act = nn.act, Bp = a.Bp;
-  const int row0 = blockIdx.x * 16, nrows = min(16, a.n - row0);
+  const int row0 = tile_ * 16, nrows = min(16, a.n - row0);
   const int inp = round_up16(in), ldx = inp + 4, ldh = H + 4;
   float* Xs = smem; float* A0 = Xs + 16 * ldx; float* A1 = A0 + 16 * ldh; float* part = A1 + 16 * ldh; float* Os = part + (H >> 4) * 256;
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, tid = threadIdx.x;
-  const bool stamp = blockIdx.x == 0 && blockIdx.y == 1;
+  const bool stamp = tile_ == 0 && pass_ == 1;
   IL_STAMP(stamp, 0);
   load_rows_cat(Xs, ldx, inp, q.f1, q.ld1, q.K1, q.f2, q.ld2, q.K2, row0, nrows);
   __syncthreads();
@@ -473,26 +477,32 @@ __global__ __launch_bounds__(512) void k_gt_fwd(GtFwd a) {
   IL_STAMP(stamp, 10);
   if (q.OT)
     for (int i = tid; i < 16 * out; i += blockDim.x) { const int c = i >> 4, r = i & 15; q.OT[(size_t)c * Bp + row0 + r] = Os[r * 16 + c]; }
-  if (q.head && tid < 16) {   // k_g_sample's arithmetic, one thread per row of the tile
-    const int row = row0 + tid, A = out >> 1;
-    if (row < a.n) {
-      const uint32_t ctr = q.ctr_ptr ? *q.ctr_ptr : q.ctr;
-      const float m = q.absorbing ? 1.f - q.absorbing[(size_t)row * q.ld_abs] : 1.f;
-      float sn = 0.f, sl = 0.f;
-      for (int c = 0; c < A; ++c) {
-        const float mean = Os[tid * 16 + c], lsr = Os[tid * 16 + A + c];
+  if (q.head) {   // k_g_sample's arithmetic: one thread per (row, component) (a thread per row walked A Philox draws and heads one after the other: ~5 us of the launch), then
+    const int A = out >> 1;                                                       // the per-row sums in component order, as k_g_sample adds them
+    float* nl = part; float* la = part + 256;
+    if (tid < 16 * A) {
+      const int r = tid / A, c = tid - r * A, row = row0 + r;
+      if (row < a.n) {
+        const uint32_t ctr = q.ctr_ptr ? *q.ctr_ptr : q.ctr;
+        const float m = q.absorbing ? 1.f - q.absorbing[(size_t)row * q.ld_abs] : 1.f;
+        const float mean = Os[r * 16 + c], lsr = Os[r * 16 + A + c];
         float x, av, nlp, ladj, e = 0.f;
         if (q.greedy) { av = tanhf(mean); x = mean; nlp = 0.f; ladj = 0.f; }
         else {
           e = q.eps ? q.eps[(size_t)row * A + c] : philox_normal(q.seed, ctr, q.stream_id, (uint32_t)(row * A + c));
           g_head(mean, lsr, e, x, av, nlp, ladj);
         }
-        sn += nlp; sl += ladj;
+        nl[r * 16 + c] = nlp; la[r * 16 + c] = ladj;
         if (q.a_rows) q.a_rows[(size_t)row * q.ld_a + c] = m * av;
         if (q.xT) q.xT[(size_t)c * Bp + row] = x;
         if (q.epsT) q.epsT[(size_t)c * Bp + row] = e;
       }
-      if (q.logp) q.logp[row] = (0.f - sl) + sn;
+    }
+    __syncthreads();
+    if (tid < 16 && row0 + tid < a.n && q.logp) {
+      float sn = 0.f, sl = 0.f;
+      for (int c = 0; c < A; ++c) { sn += nl[tid * 16 + c]; sl += la[tid * 16 + c]; }
+      q.logp[row0 + tid] = (0.f - sl) + sn;
     }
   }
   IL_STAMP(stamp, 11);
@@ -504,7 +514,7 @@ struct GtBwd {
   GtNet net; int64_t p_ns, pk_ns;            // twin critics: parameters / lane-ordered copies of net k at + k * stride
   const float* HT; int64_t h_ns; float* dZT; int64_t dz_ns; float* dOT; int64_t do_ns;   // [net][depth][H][Bp] activations in, dZ out; [net][out][Bp] output-layer dZ out
   float* dX0T; int64_t dx_ns; int dx_c0, dx_c1;   // columns [c0, c1) of dL/d(input) -> dX0T[net][in][Bp] (NULL: none)
-  int seed, n, Bp;
+  int seed, n, Bp, nets;
   il_batch b;
   const float* qtT; const float* qT; const float* logp2; const float* log_alpha; float discount; float* out_q;   // critic loss (qT also: the policy pass's Q(s, a~))
   const float* outT; const float* xT; const float* epsT; const float* logp; const float* dx0T; int64_t dx0_ns; float entropy_target; int S; float* alpha_rows; float* out_logp;   // actor head
@@ -514,14 +524,16 @@ struct GtBwd {
 __global__ __launch_bounds__(512) void k_gt_bwd(GtBwd a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const GtNet& nn = a.net;
-  const int H = nn.H, in = nn.in, depth = nn.depth, out = nn.out, act = nn.act, Bp = a.Bp, net = blockIdx.y;
-  const int row0 = blockIdx.x * 16, ldh = H + 4, ldy = 20;
+  int tile_, net;
+  xcd_tile_net((int)blockIdx.x, a.Bp / 16, a.nets, tile_, net);   // (a network's tiles on 8 / nets XCDs: see k_gt_fwd)
+  const int H = nn.H, in = nn.in, depth = nn.depth, out = nn.out, act = nn.act, Bp = a.Bp;
+  const int row0 = tile_ * 16, ldh = H + 4, ldy = 20;
   float* dYs = smem; float* Z0 = dYs + 16 * ldy; float* Z1 = Z0 + 16 * ldh;
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, tid = threadIdx.x;
   const float* P = nn.P + net * a.p_ns;
   const float* HT = a.HT + net * a.h_ns;
   float* dZT = a.dZT + net * a.dz_ns;
-  const bool stamp = blockIdx.x == 0 && blockIdx.y == 0;
+  const bool stamp = tile_ == 0 && net == 0;
   IL_STAMP(stamp, 16);
   for (int i = tid; i < 16 * ldy; i += blockDim.x) dYs[i] = 0.f;
   __syncthreads();
@@ -593,7 +605,7 @@ __global__ __launch_bounds__(512) void k_gt_bwd(GtBwd a) {
       }
     }
   }
-  if (blockIdx.x == 0 && net == 0 && tid == 192 && a.tick.step) adam_tick(a.tick);
+  if (tile_ == 0 && net == 0 && tid == 192 && a.tick.step) adam_tick(a.tick);
   __syncthreads();
   IL_STAMP(stamp, 17);
   if (a.dOT)
@@ -658,9 +670,14 @@ struct GtDw {
 };
 __device__ __forceinline__ void gt_dw_tail(const GtDw& a) {   // the workgroups behind the jobs: temperature step + Philox counter (workgroup 0), target update (all)
     const int tb = (int)blockIdx.x - a.n_job_wgs, ntb = (int)gridDim.x - a.n_job_wgs;
+    __shared__ float red[32];
+    float srow = 0.f;
+    if (tb == 0 && a.log_alpha) {   // the rows' terms: thread-strided partial sums, then the block reduction (fixed order; a single thread adding n_rows dependent loads took ~9 us)
+      for (int i = threadIdx.x; i < a.n_rows; i += blockDim.x) srow += gload(a.alpha_rows + i);
+      srow = block_sum(srow, red);
+    }
     if (tb == 0 && threadIdx.x == 0 && a.log_alpha) {
-      float s = 0.f;
-      for (int i = 0; i < a.n_rows; ++i) s += a.alpha_rows[i];
+      const float s = srow;
       const float gr = -(expf(a.log_alpha[0])) * (s / (float)a.n_rows);
       if (a.alpha_grad) a.alpha_grad[0] = gr;
       if (!a.grads_only) {
@@ -674,7 +691,21 @@ __device__ __forceinline__ void gt_dw_tail(const GtDw& a) {   // the workgroups 
     }
     if (a.target && !a.grads_only) {
       const float omt = (float)(1.0 - a.tau), tau = (float)a.tau;
-      for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < a.polyak_n; i += (int64_t)ntb * blockDim.x)
+      // 16-byte lanes, four per thread and trip with all eight loads requested first (the elementwise loop was a dependent HBM round trip per element: 8 us of this launch)
+      const int64_t n4 = ((a.polyak_n & 3) == 0 && (reinterpret_cast<uintptr_t>(a.target) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.polyak_src) & 15) == 0) ? a.polyak_n >> 2 : 0, stride = (int64_t)ntb * blockDim.x;
+      for (int64_t i = (int64_t)tb * blockDim.x + threadIdx.x; i < n4; i += 4 * stride) {
+        f32x4 t[4], p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int64_t q = i + u * stride < n4 ? i + u * stride : i; t[u] = gload4(a.target + 4 * q); p[u] = gload4(a.polyak_src + 4 * q); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) t[u][c] = __fadd_rn(__fmul_rn(t[u][c], tau), __fmul_rn(omt, p[u][c]));
+          if (i + u * stride < n4) *reinterpret_cast<f32x4*>(a.target + 4 * (i + u * stride)) = t[u];
+        }
+      }
+      for (int64_t i = 4 * n4 + (int64_t)tb * blockDim.x + threadIdx.x; i < a.polyak_n; i += stride)
         a.target[i] = __fadd_rn(__fmul_rn(a.target[i], tau), __fmul_rn(omt, a.polyak_src[i]));
     }
 }
@@ -873,7 +904,7 @@ static int g_sac_update_tiles(const il_sac* d, const il_batch* b, const GNet& an
       GtFwdPass& pk = f.p[2 + k]; pk.net = critic(k); pk.f1 = b->states; pk.ld1 = b->ld_states; pk.K1 = S; pk.f2 = b->actions; pk.ld2 = b->ld_actions; pk.K2 = A;
       pk.X0T = k == 0 ? W + ws.xc : nullptr; pk.HT = W + ws.hc + k * hid_c; pk.OT = W + ws.qc + (int64_t)k * Bp;
     }
-    IL_TRACE("k_gt_fwd", st); k_gt_fwd<<<dim3(nt, 4), th_m, lds_f, st>>>(f);
+    f.npass = 4; IL_TRACE("k_gt_fwd", st); k_gt_fwd<<<nt * 4, th_m, lds_f, st>>>(f);
   }
   // B. target_1,2(s', a')
   {
@@ -881,14 +912,14 @@ static int g_sac_update_tiles(const il_sac* d, const il_batch* b, const GNet& an
     for (int k = 0; k < 2; ++k) {
       GtFwdPass& pk = f.p[k]; pk.net = target(k); pk.f1 = b->next_states; pk.ld1 = b->ld_next_states; pk.K1 = S; pk.f2 = W + ws.a2r; pk.ld2 = A; pk.K2 = A; pk.OT = W + ws.qt + (int64_t)k * Bp;
     }
-    IL_TRACE("k_gt_fwd", st); k_gt_fwd<<<dim3(nt, 2), th_c, lds_f, st>>>(f);
+    f.npass = 2; IL_TRACE("k_gt_fwd", st); k_gt_fwd<<<nt * 2, th_c, lds_f, st>>>(f);
   }
   // C. critic loss seed + backward (training.py:22-31), D. every layer's dW + AdamW
   {
     GtBwd g = {}; g.net = critic(0); g.p_ns = Ps; g.pk_ns = pkc; g.HT = W + ws.hc; g.h_ns = hid_c; g.dZT = W + ws.dz; g.dz_ns = hid_c; g.dOT = W + ws.dq; g.do_ns = Bp; g.seed = GT_SEED_CRITIC; g.n = B; g.Bp = Bp;
     g.b = *b; g.qtT = W + ws.qt; g.qT = W + ws.qc; g.logp2 = W + ws.logp2; g.log_alpha = d->log_alpha; g.discount = d->discount; g.out_q = out_q ? out_q : d->out_q;
     if (!grads_only) g.tick = d->critic_opt;
-    IL_TRACE("k_gt_bwd", st); k_gt_bwd<<<dim3(nt, 2), th_c, lds_b, st>>>(g);
+    g.nets = 2; IL_TRACE("k_gt_bwd", st); k_gt_bwd<<<nt * 2, th_c, lds_b, st>>>(g);
   }
   {
     GtDw w = {}; w.nets = 2; w.p_ns = Ps; w.pk_ns = pkc; w.P = d->critic; w.G = gc; w.g_ns = Ps; w.opt = d->critic_opt; w.grads_only = grads_only ? 1 : 0; w.Bp = Bp;
@@ -902,12 +933,12 @@ static int g_sac_update_tiles(const il_sac* d, const il_batch* b, const GNet& an
     for (int k = 0; k < 2; ++k) {
       GtFwdPass& pk = f.p[k]; pk.net = critic(k); pk.f1 = b->states; pk.ld1 = b->ld_states; pk.K1 = S; pk.f2 = W + ws.anr; pk.ld2 = A; pk.K2 = A; pk.HT = W + ws.hp + k * hid_c; pk.OT = W + ws.qp + (int64_t)k * Bp;
     }
-    IL_TRACE("k_gt_fwd", st); k_gt_fwd<<<dim3(nt, 2), th_c, lds_f, st>>>(f);
+    f.npass = 2; IL_TRACE("k_gt_fwd", st); k_gt_fwd<<<nt * 2, th_c, lds_f, st>>>(f);
   }
   {
     GtBwd g = {}; g.net = critic(0); g.p_ns = Ps; g.pk_ns = pkc; g.HT = W + ws.hp; g.h_ns = hid_c; g.dZT = W + ws.dz; g.dz_ns = hid_c; g.seed = GT_SEED_POLICY; g.n = B; g.Bp = Bp; g.qT = W + ws.qp;
     g.dX0T = W + ws.dx0; g.dx_ns = (int64_t)IN * Bp; g.dx_c0 = S; g.dx_c1 = IN;
-    IL_TRACE("k_gt_bwd", st); k_gt_bwd<<<dim3(nt, 2), th_c, lds_b, st>>>(g);
+    g.nets = 2; IL_TRACE("k_gt_bwd", st); k_gt_bwd<<<nt * 2, th_c, lds_b, st>>>(g);
   }
   // G. back through the tanh-Gaussian head and the actor (training.py:35-42), H. the actor's dW + AdamW, temperature step, target update (training.py:45-52)
   {
@@ -915,7 +946,7 @@ static int g_sac_update_tiles(const il_sac* d, const il_batch* b, const GNet& an
     g.outT = W + ws.oa; g.xT = W + ws.xpre; g.epsT = W + ws.epsu; g.logp = W + ws.logp; g.dx0T = W + ws.dx0; g.dx0_ns = (int64_t)IN * Bp; g.log_alpha = d->log_alpha; g.entropy_target = d->entropy_target; g.S = S;
     g.alpha_rows = W + ws.arows; g.out_logp = out_logp ? out_logp : d->out_logp;
     if (!grads_only) g.tick = d->actor_opt;
-    IL_TRACE("k_gt_bwd", st); k_gt_bwd<<<dim3(nt, 1), th_a, lds_b, st>>>(g);
+    g.nets = 1; IL_TRACE("k_gt_bwd", st); k_gt_bwd<<<nt, th_a, lds_b, st>>>(g);
   }
   {
     GtDw w = {}; w.nets = 1; w.P = d->actor; w.G = ga; w.opt = d->actor_opt; w.grads_only = grads_only ? 1 : 0; w.Bp = Bp;
@@ -1034,7 +1065,7 @@ extern "C" int il_actor_act_general(const float* actor, int32_t S, int32_t A, in
     GtFwd f = {}; f.n = n; f.Bp = Bp;
     GtFwdPass& p0 = f.p[0]; p0.net = GtNet{actor, S, H, depth, 2 * A, activation, nullptr, nullptr}; p0.f1 = states; p0.ld1 = ld_states; p0.K1 = S; p0.head = 1; p0.eps = eps; p0.seed = noise_seed; p0.ctr = noise_offset;
     p0.stream_id = IL_STREAM_ACT; p0.greedy = greedy; p0.a_rows = out_action; p0.ld_a = A; p0.logp = out_logp;
-    { IL_TRACE("k_gt_fwd", st); k_gt_fwd<<<dim3(Bp / 16, 1), gt_threads(H), lds, st>>>(f); }
+    f.npass = 1; { IL_TRACE("k_gt_fwd", st); k_gt_fwd<<<Bp / 16, gt_threads(H), lds, st>>>(f); }
     IL_CHECK_LAUNCH("il_actor_act_general (tile engine)");
     return IL_OK;
   }
@@ -1083,10 +1114,10 @@ extern "C" int il_bc_step_general(float* actor, float* actor_grad, const il_adam
     const GtNet net = {actor, S, H, depth, 2 * A, activation, nullptr, nullptr};
     GtFwd f = {}; f.n = n; f.Bp = Bp;
     GtFwdPass& p0 = f.p[0]; p0.net = net; p0.f1 = b->states; p0.ld1 = b->ld_states; p0.K1 = S; p0.X0T = workspace + ws.x; p0.HT = workspace + ws.h; p0.OT = workspace + ws.o;
-    { IL_TRACE("k_gt_fwd", st); k_gt_fwd<<<dim3(Bp / 16, 1), gt_threads(H), lds_f, st>>>(f); }
+    f.npass = 1; { IL_TRACE("k_gt_fwd", st); k_gt_fwd<<<Bp / 16, gt_threads(H), lds_f, st>>>(f); }
     GtBwd g = {}; g.net = net; g.HT = workspace + ws.h; g.dZT = workspace + ws.dz; g.dOT = workspace + ws.dout; g.seed = GT_SEED_BC; g.n = n; g.Bp = Bp; g.b = *b; g.outT = workspace + ws.o; g.loss_rows = workspace + ws.rows;
     if (!grads_only) g.tick = *opt;
-    { IL_TRACE("k_gt_bwd", st); k_gt_bwd<<<dim3(Bp / 16, 1), gt_threads(H), lds_b, st>>>(g); }
+    g.nets = 1; { IL_TRACE("k_gt_bwd", st); k_gt_bwd<<<Bp / 16, gt_threads(H), lds_b, st>>>(g); }
     if (out_loss) { IL_TRACE("k_g_sum_rows", st); k_g_sum_rows<<<1, 64, 0, st>>>(workspace + ws.rows, n, out_loss); }
     GtDw w = {}; w.nets = 1; w.P = actor; w.G = G; if (opt) w.opt = *opt; w.grads_only = grads_only ? 1 : 0; w.Bp = Bp;
     w.jobs_per_net = gt_dw_layers(w, an, workspace + ws.x, 0, workspace + ws.h, 0, workspace + ws.dz, 0, workspace + ws.dout, 0, nullptr, nullptr, Bp);
