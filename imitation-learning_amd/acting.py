@@ -94,6 +94,7 @@ class ActingWorker:
     self._seq = 0   # one sequence for both mailboxes: the device de-duplicates appends by commit word
     self._seed = C.c_uint64(torch.initial_seed() & (2**64 - 1))
     self._fixed = {}
+    self._pending_seq = None
     self.mirror = None
     if mirror:
       self._stride = (actor.flat.numel() + 63) // 64 * 64
@@ -110,10 +111,11 @@ class ActingWorker:
     fixed = self._fixed.get(key)
     if fixed is None or fixed[0] != a.flat.data_ptr():  # pointers are stable for the life of the worker; re-derive if the arena was re-homed
       params = self.mirror if snapshot else a.flat
-      fixed = self._fixed[key] = (a.flat.data_ptr(), _lib.lib().il_act_step, _lib.ptr(params), C.c_void_p(box.tensor.data_ptr()), _lib.ptr(self.carry),
+      fixed = self._fixed[key] = (a.flat.data_ptr(), None, _lib.ptr(params), C.c_void_p(box.tensor.data_ptr()), _lib.ptr(self.carry),
                                   _lib.ptr(self.memory.ring), _lib.ptr(self.memory._ring_state), _lib.ptr(self._version) if snapshot else None,
                                   self._stride if snapshot else 0)
-    _, fn, p_actor, p_box, p_carry, p_ring, p_state, p_version, stride = fixed
+    _, _, p_actor, p_box, p_carry, p_ring, p_state, p_version, stride = fixed
+    fn = _lib.lib().il_act_step   # (looked up per call: UpdatePlan.record_direct walks the hooks with a recording stand-in for the library)
     st = (stream or torch.cuda.current_stream()).cuda_stream
     rc = fn(p_actor, self.S, self.A, a.hidden, p_box, p_carry, p_ring, p_state, self._seed, a._act_calls & 0xFFFFFFFF, p_version, stride, st)
     if rc: _lib.check(rc)
@@ -143,6 +145,23 @@ class ActingWorker:
     else:
       self._launch(box, stream=self.act_stream, snapshot=True)
     return self._collect(box, seq)
+
+  def act_begin(self, obs, greedy: bool = False):
+    """The launch half of `act` (round 6): post the observation and enqueue the act launch, return at once; `act_end()` collects the action. With a mirror the launch runs
+    on the worker's own stream from the latest snapshot, so a caller can put its update's host work (a graph replay or the direct launches: ~30 us) between the two calls -
+    the act launch's ~29 us turn-around (dispatch, one workgroup through the actor, the echo into pinned memory) then hides behind it instead of following it
+    (profiles/r06_acting_host_profile.json: 96 -> us per environment step with one update per step)."""
+    box = self._act_box
+    self._pending_seq = box.post(self._next_seq(), GREEDY if greedy else 0, obs=_row(obs))
+    if self.mirror is None:
+      self._launch(box)
+    else:
+      self._launch(box, stream=self.act_stream, snapshot=True)
+
+  def act_end(self) -> torch.Tensor:
+    seq, self._pending_seq = self._pending_seq, None
+    assert seq is not None, 'act_end() without act_begin()'
+    return self._collect(self._act_box, seq)
 
   def append(self, step, next_obs, reward, terminal: bool, timeout: bool):
     """`memory.append(step, state, action, reward, next_state, terminal, timeout)` for the (state, action) of the last `act`, plus the
@@ -189,6 +208,9 @@ class ActingWorker:
     """Snapshot the actor arena for the act stream; enqueue after anything that changes the actor (capturable)."""
     a = self.actor
     _lib.check(_lib.lib().il_act_publish(_lib.ptr(a.flat), a.flat.numel(), _lib.ptr(self.mirror), self._stride, _lib.ptr(self._version), _lib.stream_ptr()))
+
+  enqueue_append._il_recordable = True    # UpdatePlan.record_direct: library calls only, every argument a fixed pointer (what to append / publish is read on the device)
+  enqueue_publish._il_recordable = True
 
   def attach(self, plan):
     """Make `plan` (UpdatePlan) carry this worker's append before, and its parameter snapshot after, every update. Attach before capture."""

@@ -1122,7 +1122,8 @@ class UpdatePlan:
   def direct_launch_ok(self) -> bool:
     """record_direct / launch_direct apply: the device hand-off schedule with two unjoined branches and nothing hooked into the update (an ActingWorker attached for
     +acting.schedule=overlap rides in the captured graph instead)."""
-    return bool(self.device_sync and (self.algorithm == 'GAIL' or self.resident_sampler) and not self.pre_hooks and not self.post_hooks)
+    recordable = all(getattr(h, '_il_recordable', False) for h in self.pre_hooks + self.post_hooks)   # (round 6) an ActingWorker's append / publish launches are library calls too
+    return bool(self.device_sync and (self.algorithm == 'GAIL' or self.resident_sampler) and recordable)
 
   def record_direct(self):
     """The two-branch schedule `capture()` records, as DIRECT launches: walks the update's host code once with a recording stand-in for the library (nothing is launched),
@@ -1131,7 +1132,7 @@ class UpdatePlan:
     update here); a direct launch is one AQL packet per kernel (profiles/r05_launch_ab.txt). Run at least one update first (run(): code objects loaded, LDS
     attributes set, lane-ordered weight copies built). The main branch is recorded on the CALLER's current stream and must be launched from it; descriptors are passed by
     reference, so later changes of their fields (watch_timeouts, widen_handoff_bound) apply, unlike in a captured graph."""
-    assert self.direct_launch_ok(), 'record_direct: the device hand-off schedule (two unjoined branches, no hooks) only'
+    assert self.direct_launch_ok(), 'record_direct: the device hand-off schedule (two unjoined branches; hooks that are library calls) only'
     assert self._prepared, 'record_direct: run() at least one update first'
     self.memory.stream().device_state(self.rows.device)
 
@@ -1158,7 +1159,7 @@ class UpdatePlan:
         if branch == 'side':
           with torch.cuda.stream(self.side): self._run_update()
         else:
-          self._run_update()
+          self.run()   # (with the hooks: an attached ActingWorker's append before, its parameter snapshot after)
         out.append(list(rec.calls))
     finally:
       _lib._lib, self._capturing, self._recording = real, None, False

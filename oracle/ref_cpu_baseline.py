@@ -104,7 +104,9 @@ def main():
 
   nproc = os.cpu_count()
   usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else nproc
-  many = min(usable, int(os.environ.get('IL_CPU_BASELINE_THREADS', usable)))
+  # The largest pool is capped at 64 threads (round 6): at 256 OpenMP threads ONE update of the reference's ~2,800 tiny aten calls took ~20 s - a single sample, 55 s of the bench's
+  # wall clock - and no pool beyond a socket's physical cores has ever been the best (`value` is the best of 1 / 8 / this many). IL_CPU_BASELINE_THREADS overrides.
+  many = min(usable, int(os.environ.get('IL_CPU_BASELINE_THREADS', min(usable, 64))))
   configs = [(1, 'one_thread')] + ([(8, 'eight_threads')] if many > 8 else []) + [(many, 'all_cores')]
   res, counts = {}, {}
   t_all = time.perf_counter()

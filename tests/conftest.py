@@ -26,6 +26,28 @@ def golden_dir():
   return os.path.join(ROOT, 'tests', 'golden')
 
 
+LEDGER = os.path.join(ROOT, 'tests', 'tolerance_ledger.json')   # the sites DESIGN.md 4 documents as running close to their allowance: {site prefix: why}
+
+
+def pytest_sessionfinish(session, exitstatus):
+  """Round 6: a measured outlier fraction above 60 % of its allowance fails the run unless its site has an entry in tests/tolerance_ledger.json (and with it in DESIGN.md 4):
+  a drift towards an allowance is a finding, not noise to be absorbed by the next widening."""
+  import json
+  gu = sys.modules.get('gpu_util')
+  if gu is None or not getattr(gu, 'FRACTIONS', None) or os.environ.get('IL_TOLERANCE_GATE', '1') == '0':
+    return
+  try:
+    ledger = json.load(open(LEDGER))
+  except Exception:
+    ledger = {}
+  over = sorted({(n, f, a) for n, f, a in gu.FRACTIONS if a > 0 and f > 0.6 * a and not any(n.startswith(k) for k in ledger)})
+  if over:
+    tr = session.config.pluginmanager.get_plugin('terminalreporter')
+    msg = 'outlier fractions above 60 % of their allowance without an entry in tests/tolerance_ledger.json / DESIGN.md 4: ' + '; '.join(f'{n}: {f:.2e} / {a:.0e}' for n, f, a in over)
+    if tr is not None: tr.write_line('TOLERANCE GATE: ' + msg, red=True)
+    session.exitstatus = 1
+
+
 def pytest_terminal_summary(terminalreporter):
   """The largest measured outlier fractions of the Adam-state comparisons (tests/gpu_util.py close_params / close_sparse) against their allowance."""
   import sys

@@ -231,6 +231,8 @@ def train(cfg, file_prefix: str = '') -> float:
     else:
       state = next_state
 
+    act_early = schedule == 'overlap' and update_due and plan is not None and captured   # (round 6) the act launch ahead of the update's host work (ActingWorker.act_begin)
+    if act_early: worker.act_begin(state)
     if update_due:
       if plan is not None:
         if cfg.algorithm == 'AdRIL': plan.relabel_args(step, memory.num_trajectories)   # the relabeller's per-update scalars -> device buffer (models.py:300-318)
@@ -290,7 +292,7 @@ def train(cfg, file_prefix: str = '') -> float:
         metrics['update_steps'].append(step); metrics['predicted_rewards'].append(rewards.cpu().numpy())
         metrics['alphas'].append(log_alpha.exp().cpu().numpy()); metrics['entropies'].append((-log_probs).cpu().numpy()); metrics['Q_values'].append(Q_values.cpu().numpy())
 
-    if schedule == 'overlap': action = worker.act(state)   # own stream, published snapshot: returns while the update is still running
+    if schedule == 'overlap': action = worker.act_end() if act_early else worker.act(state)   # own stream, published snapshot: returns while the update is still running
 
     if dog is not None and step % cfg.evaluation.interval == 0 and not cfg.check_time_usage:   # every rank: rank 0 evaluates, its peers wait for it inside their next collective
       dog.grace(0.005 * cfg.evaluation.episodes * env.max_episode_steps, 'evaluation')
