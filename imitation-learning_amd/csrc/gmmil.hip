@@ -849,6 +849,274 @@ static int gmmil_sx_on(int S, int A, int D, int state_only, int lanes) {   // IL
   static const int on = [] { const char* e = getenv("IL_GMMIL_SX"); return e && e[0] == '0' ? 0 : 1; }();
   return on != 0 && lanes && D >= 8 && D % 8 == 0 && S % 8 == 0 && gmmil_sx_lds(D) <= (size_t)160 * 1024 && D <= 5 * GKC;
 }
+// ---------------------------------------------------------------------------------------------
+// k_gmmil_mfma (round 6): the pair distances as a CENTRED Gram product on the matrix pipes - the default reward launch for D <= 128.
+//   ssq(x, y) = |x - c|^2 + |y - c|^2 - 2 (x - c).(y - c),   c = the mean of 8 rows spread over the expert batch, the same for every operand of a workgroup.
+// Why this is allowed now: the plain |x|^2 + |y|^2 - 2 x.y form loses the digits the data's OFFSET takes (observations around 50: rewards off by 7e-8 against a bound of
+// 1e-8; around 1000: 2e-5), which is why rounds 1-5 stayed on the direct difference form - three VALU flops per pair-feature at the packed instructions' issue rate,
+// 31 % of fp32 at best. Centred, every term is of the size of the data's SPREAD, of which the median pair distance - the kernel's own length scale,
+// gamma = 1 / median - is a fixed multiple: the exponent's absolute error is ~1e-7 whatever the offset, and the rewards are as close to float64 as the direct form's
+// (measured on the B = 1024 Ant case at offsets 0 / 50 / 1000: 2.0e-10 / 2.3e-10 / 2.6e-10 against 2.6e-10 / 2.3e-10 / 2.1e-10 for the direct form; bound 1.0e-8;
+// tests/test_gmmil_centred_form.py keeps that experiment). The distance matrix the bandwidths' medians are taken from (il_gmmil_sqdist, first call only) stays on the
+// direct form. A workgroup = 4 waves = 64 rows x 128 columns; wave w keeps its 16 rows' centred features in registers as MFMA A fragments (one 16-byte lane per 16
+// features: lane l holds features 16 q + 4 (l >> 4) .. + 3 of row l & 15, so one register quad feeds four v_mfma_f32_16x16x4_f32 and A and B agree on the k order), the
+// 128 columns' centred features sit in LDS row-major with a 4-float skew (16 lanes' 16-byte reads hit 64 distinct banks), two column tiles are accumulated side by
+// side (independent MFMA chains) while the previous two tiles' exponentials run on the VALU. 2 flop per pair-feature on the pipe that delivers them: 0.54 GFLOP at
+// B = 1024, D = 120 (padded to 128) against 0.755 on the VALU. Partial row sums, arrival ticket and the last arriver's block-ordered sums as in k_gmmil_sx.
+// ---------------------------------------------------------------------------------------------
+#define GMF_ROWS 64
+#define GMF_COLS 128
+template <int NKQ> struct GmfLds {   // floats
+  static constexpr int DP = 16 * NKQ, LD = DP + 4;
+  static constexpr int ys = 0, cs = ys + GMF_COLS * LD, cpart = cs + DP, nyh = cpart + 8 * DP, wys = nyh + 2 * GMF_COLS, nxs = wys + GMF_COLS, red = nxs + GMF_ROWS, ps = red + 64, total = ps + GMF_ROWS;
+};
+// features k .. k + 3 (k % 4 == 0) of row r of the concatenated [states | actions] batch as ONE branch-free request per 16-byte lane (LANES: whole lanes along the rows, S and A
+// multiples of 4) or four dword requests: the side of the concatenation is a select on the ADDRESS (a select on the loaded value makes hipcc branch around each load and wait
+// for it - the first build of this kernel spent 4.7 us requesting its operands one after the other); beyond D the address is clamped and the caller zeroes the value.
+template <bool LANES>
+__device__ __forceinline__ f32x4 gmf_load(const il_batch& b, int S, int D, int r, int k) {
+  if (LANES) {
+    const int kc = min(k, D - 4);
+    const float* p = kc < S ? b.states + ((size_t)r * b.ld_states + kc) : b.actions + ((size_t)r * b.ld_actions + (kc - S));
+    return gload4(p);
+  }
+  f32x4 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int kc = min(k + q, D - 1);
+    const float* p = kc < S ? b.states + ((size_t)r * b.ld_states + kc) : b.actions + ((size_t)r * b.ld_actions + (kc - S));
+    v[q] = gload(p);
+  }
+  return v;
+}
+// a thread's share of a weight column's sum: the first 1,024 rows as four independent requests issued with the operands (gmf_weight_req; a plain strided loop waits for
+// each load before it issues the next - and for everything requested before it), longer columns in a loop behind them
+struct GmfW4 { float a[4]; };
+__device__ __forceinline__ GmfW4 gmf_weight_req(const il_batch& b, int tid) {
+  GmfW4 r;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) r.a[u] = gload(b.weights + (size_t)min(tid + 256 * u, b.n - 1) * b.ld_weights);
+  return r;
+}
+__device__ __forceinline__ float gmf_weight_share(const il_batch& b, int tid, const GmfW4& first) {
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) s += (tid + 256 * u < b.n) ? first.a[u] : 0.f;
+  for (int i = 1024 + tid; i < b.n; i += 256) s += gload(b.weights + (size_t)i * b.ld_weights);
+  return s;
+}
+template <int NKQ, bool LANES>
+__global__ __launch_bounds__(256) void k_gmmil_mfma(il_batch pol, il_batch exp, int S, int D, float g1, float g2, float* __restrict__ ws_,
+                                                    float* __restrict__ out_r, float* __restrict__ out_sim, float* __restrict__ out_self) {
+  using L = GmfLds<NKQ>;
+  constexpr int DP = L::DP, LD = L::LD, NQ = DP / 4, HQ = NQ / 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  IL_ST_BEGIN(IL_ST_GMMIL);
+  IL_TL(2, 0);
+  float* Ys = smem + L::ys; float* cs = smem + L::cs; float* cpart = smem + L::cpart; float* nyh = smem + L::nyh; float* wys = smem + L::wys;
+  float* nxs = smem + L::nxs; float* red = smem + L::red; float* ps = smem + L::ps;
+  globalize(pol); globalize(exp);
+  const int n1 = pol.n, n2 = exp.n;
+  const GmmilWs w = gmmil_ws(n1, n2, D);
+  const int nE = (w.b2p + GMF_COLS - 1) / GMF_COLS, nX = (w.b1p + GMF_COLS - 1) / GMF_COLS;
+  // workgroup -> (row block, column block): consecutive workgroup ids go to the eight XCDs in turn, so the 32 workgroups an XCD hosts of every 256 are given an 8 x 4 patch
+  // of the block grid - its L2 then fetches 8 row blocks + 4 column blocks instead of 2 row blocks + every column block (1 MB -> 0.5 MB per XCD at B = 1024)
+  const int nI = w.b1p / GMF_ROWS, nJ = nE + nX;
+  int it = (int)blockIdx.x % nI, jy = (int)blockIdx.x / nI;
+  if (nI % 8 == 0 && nJ % 4 == 0 && ((nI / 8) * (nJ / 4)) % 8 == 0) {
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, patch = (slot >> 5) * 8 + xcd, in = slot & 31;
+    it = (patch % (nI / 8)) * 8 + (in & 7); jy = (patch / (nI / 8)) * 4 + (in >> 3);
+  }
+  const int mat = jy >= nE ? 1 : 0, jb = jy - (mat ? nE : 0);   // mat 0: policy vs expert, 1: policy vs policy
+  const bool vs_self = mat == 1;
+  const il_batch& yb = vs_self ? pol : exp;
+  const int ny = yb.n, tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto zero_tail = [&](f32x4 v, int k, bool row_ok) {   // features >= D (and rows beyond the batch) are exact zeros in both operands; whole lanes: a quad is inside D or outside
+    if (LANES) { const bool ok = row_ok && k < D; return f32x4{ok ? v[0] : 0.f, ok ? v[1] : 0.f, ok ? v[2] : 0.f, ok ? v[3] : 0.f}; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (row_ok && k + e < D) ? v[e] : 0.f;
+    return v;
+  };
+  auto sumsq = [](float acc, const f32x4& v) { return __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], acc)))); };
+  // ---- everything this workgroup reads from memory is requested here
+  f32x4 cv[1];   // centre: 8 expert rows spread over the batch, one 16-byte feature lane per thread
+  const int cq = tid & 31, cg = tid >> 5;
+  if (cq < NQ) {
+#pragma unroll
+    for (int u = 0; u < 1; ++u) cv[u] = gmf_load<LANES>(exp, S, D, (int)(((long long)cg * n2) >> 3), 4 * cq);
+  }
+  const GmfW4 wx4 = gmf_weight_req(pol, tid), wy4 = gmf_weight_req(yb, tid);
+  float wv = gload(yb.weights + (size_t)min(jb * GMF_COLS + (tid & (GMF_COLS - 1)), ny - 1) * yb.ld_weights);
+  wv = jb * GMF_COLS + (tid & (GMF_COLS - 1)) < ny ? wv : 0.f;
+  const int ycol = tid & (GMF_COLS - 1), yhalf = tid >> 7, yrow = jb * GMF_COLS + ycol;
+  f32x4 yq[HQ];
+#pragma unroll
+  for (int u = 0; u < HQ; ++u) yq[u] = gmf_load<LANES>(yb, S, D, min(yrow, ny - 1), 4 * (yhalf * HQ + u));
+  const int xrow = it * GMF_ROWS + wave * 16 + l16;
+  f32x4 xq[NKQ];
+#pragma unroll
+  for (int q = 0; q < NKQ; ++q) xq[q] = gmf_load<LANES>(pol, S, D, min(xrow, n1 - 1), 16 * q + 4 * g);
+  // ---- centre and weight sums
+  float sx = gmf_weight_share(pol, tid, wx4), sy = 0.f;
+  if (!vs_self) sy = gmf_weight_share(yb, tid, wy4);
+  if (cq < NQ) {
+    f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 1; ++u) c4 += zero_tail(cv[u], 4 * cq, true);
+    *reinterpret_cast<f32x4*>(&cpart[cg * DP + 4 * cq]) = c4;
+  }
+  sx = wave_sum(sx);
+  if (!vs_self) sy = wave_sum(sy);
+  if (lane == 0) { red[wave] = sx; red[4 + wave] = sy; }
+  IL_TL(2, 1);
+  __syncthreads();
+  if (tid < NQ) {
+    f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c4 += *reinterpret_cast<const f32x4*>(&cpart[u * DP + 4 * tid]);
+    *reinterpret_cast<f32x4*>(&cs[4 * tid]) = c4 * (1.f / 8.f);
+  }
+  {
+    const float s0 = (red[0] + red[1]) + (red[2] + red[3]), s1 = (red[4] + red[5]) + (red[6] + red[7]);
+    sx = s0; sy = vs_self ? s0 : s1;
+  }
+  __syncthreads();
+  IL_TL(2, 2);
+  // ---- centred operands: the columns into LDS with their squared norms, the rows in registers (the centre's lanes are read in one batch: a read per quad, each waited
+  // for, was an LDS round trip per quad)
+  {
+    f32x4 cy[HQ], cx[NKQ];
+#pragma unroll
+    for (int u = 0; u < HQ; ++u) cy[u] = *reinterpret_cast<const f32x4*>(&cs[4 * (yhalf * HQ + u)]);
+#pragma unroll
+    for (int q = 0; q < NKQ; ++q) cx[q] = *reinterpret_cast<const f32x4*>(&cs[16 * q + 4 * g]);
+    __builtin_amdgcn_sched_barrier(0);
+    float nyp = 0.f;
+    const bool ok = yrow < ny;
+#pragma unroll
+    for (int u = 0; u < HQ; ++u) {
+      const int k = 4 * (yhalf * HQ + u);
+      const f32x4 v = zero_tail(yq[u] - cy[u], k, ok);
+      nyp = sumsq(nyp, v);
+      *reinterpret_cast<f32x4*>(&Ys[ycol * LD + k]) = v;
+    }
+    nyh[yhalf * GMF_COLS + ycol] = nyp;
+    if (tid < GMF_COLS) wys[tid] = wv / sy;
+    float nxp = 0.f;
+#pragma unroll
+    for (int q = 0; q < NKQ; ++q) {
+      xq[q] = zero_tail(xq[q] - cx[q], 16 * q + 4 * g, true);
+      nxp = sumsq(nxp, xq[q]);
+    }
+    nxp += __shfl_xor(nxp, 16);
+    nxp += __shfl_xor(nxp, 32);
+    if (g == 0) nxs[wave * 16 + l16] = nxp;
+  }
+  IL_TL(2, 3);
+  __syncthreads();
+  IL_TL(2, 4);
+  // ---- the Gram tiles: two column tiles per trip on independent accumulators; a trip's exponentials are written after the next trip's MFMAs
+  const f32x4 nx4 = *reinterpret_cast<const f32x4*>(&nxs[wave * 16 + 4 * g]);
+  const GmmilExp gex = gmmil_exp_consts(g1, g2, D);
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};
+  auto gram2 = [&](int ct, f32x4& acc0, f32x4& acc1) {
+    const float* y0 = Ys + (ct * 16 + l16) * LD + 4 * g;
+    const float* y1 = y0 + 16 * LD;
+    acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NKQ; ++q) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(y0 + 16 * q), b1 = *reinterpret_cast<const f32x4*>(y1 + 16 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc0 = mfma16(xq[q][e], b0[e], acc0); acc1 = mfma16(xq[q][e], b1[e], acc1); }
+    }
+  };
+  auto finish = [&](int ct, const f32x4& acc) {   // lane: rows 4 g + r of the wave's 16, column 16 ct + l16 of the workgroup's 128
+    const int c = ct * 16 + l16;
+    const float nyv = nyh[c] + nyh[GMF_COLS + c], wyv = wys[c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ssq = fmaxf(__builtin_fmaf(-2.f, acc[r], nx4[r] + nyv), 0.f);
+      rs[r] = __builtin_fmaf(wyv, gmmil_pair_kernel(ssq, gex), rs[r]);
+    }
+  };
+  f32x4 a0, a1, p0, p1;
+  gram2(0, p0, p1);
+#pragma unroll
+  for (int ct = 2; ct < GMF_COLS / 16; ct += 2) {
+    gram2(ct, a0, a1);
+    finish(ct - 2, p0); finish(ct - 1, p1);
+    p0 = a0; p1 = a1;
+  }
+  finish(GMF_COLS / 16 - 2, p0); finish(GMF_COLS / 16 - 1, p1);
+  IL_TL(2, 5);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float s = group16_sum(rs[r]);
+    if (l16 == 0) ps[wave * 16 + 4 * g + r] = s;
+  }
+  __syncthreads();
+  if (tid < GMF_ROWS / 2) {   // the workgroup's 64 partial row sums leave as agent-scope atomic exchanges (executed at the memory side, like the arrival ticket)
+    const unsigned long long v = *reinterpret_cast<const unsigned long long*>(ps + 2 * tid);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(ws_ + w.part + (((int64_t)mat * w.njt + jb) * w.b1p + it * GMF_ROWS + 2 * tid));
+    (void)__hip_atomic_exchange(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  unsigned* lastp = reinterpret_cast<unsigned*>(red + 32);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  IL_TL(2, 6);
+  if (tid == 0) {
+    unsigned* ctr = reinterpret_cast<unsigned*>(ws_ + w.ctr) + (2 * it) * GCTR;
+    const unsigned last = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)(nE + nX);
+    if (last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next call
+    *lastp = last;
+  }
+  __syncthreads();
+  IL_TL(2, 7);
+  const int i = it * GMF_ROWS + tid;
+  if (*lastp != 0u && tid < GMF_ROWS && i < n1) {
+    auto ordered_sum = [&](const float* p, int nq) {
+      float s = 0.f;
+      for (int q0 = 0; q0 < nq; q0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = sload1(p, (int64_t)min(q0 + u, nq - 1) * w.b1p + i);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (q0 + u < nq) s += v[u];
+      }
+      return s;
+    };
+    const float s0 = ordered_sum(ws_ + w.part, nE);
+    const float s1 = ordered_sum(ws_ + w.part + (size_t)w.njt * w.b1p, nX);
+    const float wi = pol.weights[(size_t)i * pol.ld_weights] / sx;
+    const float sim = wi * s0, self = wi * s1;
+    out_r[i] = sim - self;
+    if (out_sim) out_sim[i] = sim;
+    if (out_self) out_self[i] = self;
+  }
+  IL_ST_END(IL_ST_GMMIL);
+}
+static int gmmil_mfma_on(int D) {   // IL_GMMIL_MFMA=0: the direct-difference launches (k_gmmil_sx and the forms behind it)
+  static const int on = [] { const char* e = getenv("IL_GMMIL_MFMA"); return e && e[0] == '0' ? 0 : 1; }();
+  return on != 0 && D >= 1 && D <= 128;
+}
+template <int NKQ, bool LANES>
+static int gmmil_mfma_launch_(const il_batch* pol, const il_batch* exp, int S, int D, float g1, float g2, float* workspace, float* out_r, float* out_sim, float* out_self, hipStream_t st) {
+  const GmmilWs w = gmmil_ws(pol->n, exp->n, D);
+  const size_t lds = (size_t)GmfLds<NKQ>::total * sizeof(float);
+  if (int rc = gmmil_ensure_lds((k_gmmil_mfma<NKQ, LANES>), lds)) return rc;
+  const int nE = (w.b2p + GMF_COLS - 1) / GMF_COLS, nX = (w.b1p + GMF_COLS - 1) / GMF_COLS;
+  IL_TRACE("k_gmmil_tile", st);
+  auto kern = k_gmmil_mfma<NKQ, LANES>;   // (one identifier: the host emulator's launch macro splits its arguments at commas)
+  kern<<<dim3((w.b1p / GMF_ROWS) * (nE + nX), 1, 1), 256, lds, st>>>(*pol, *exp, S, D, g1, g2, workspace, out_r, out_sim, out_self);
+  IL_CHECK_LAUNCH("il_gmmil_reward");
+  return IL_OK;
+}
+template <int NKQ>
+static int gmmil_mfma_launch(const il_batch* pol, const il_batch* exp, int S, int D, float g1, float g2, float* workspace, float* out_r, float* out_sim, float* out_self, int lanes, hipStream_t st) {
+  return lanes && D >= 4 ? gmmil_mfma_launch_<NKQ, true>(pol, exp, S, D, g1, g2, workspace, out_r, out_sim, out_self, st)
+                         : gmmil_mfma_launch_<NKQ, false>(pol, exp, S, D, g1, g2, workspace, out_r, out_sim, out_self, st);
+}
 static bool gmmil_direct() { static const int on = [] { const char* e = getenv("IL_GMMIL_DIRECT"); return e && e[0] == '0' ? 0 : 1; }(); return on != 0; }   // IL_GMMIL_DIRECT=0: k_gmmil_pack + k_gmmil_tile (developer A/B; same bits)
 static int gmmil_lanes(const il_batch* a, const il_batch* b, int S, int A, int state_only) {   // whole 16-byte lanes along the rows of both batches?
   auto ok = [&](const il_batch* x) {
@@ -867,6 +1135,12 @@ extern "C" int il_gmmil_reward(const il_batch* pol, const il_batch* exp, int32_t
   const GmmilWs w = gmmil_ws(pol->n, exp->n, D);
   if (workspace_floats < w.total) return il_set_error(IL_ERR_WORKSPACE, "il_gmmil_reward: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)w.total);
   hipStream_t st = (hipStream_t)stream_;
+  if (gmmil_mfma_on(D)) {
+    const int lanes = gmmil_lanes(pol, exp, S, A, state_only);
+    if (D <= 32) return gmmil_mfma_launch<2>(pol, exp, S, D, g1, g2, workspace, out_rewards, out_sim, out_self, lanes, st);
+    if (D <= 64) return gmmil_mfma_launch<4>(pol, exp, S, D, g1, g2, workspace, out_rewards, out_sim, out_self, lanes, st);
+    return gmmil_mfma_launch<8>(pol, exp, S, D, g1, g2, workspace, out_rewards, out_sim, out_self, lanes, st);
+  }
   if (gmmil_direct() && gmmil_sx_on(S, A, D, state_only, gmmil_lanes(pol, exp, S, A, state_only))) {
     const size_t lds = gmmil_sx_lds(D);
     if (int rc = gmmil_ensure_lds(k_gmmil_sx<0>, lds)) return rc;

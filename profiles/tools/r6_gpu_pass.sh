@@ -93,6 +93,11 @@ for what in "$@"; do
 import sys, json
 j = json.loads(sys.stdin.read().strip().splitlines()[-1]); p = j['population']
 print('population', p['learners'], p['groups'], p['aggregate_updates_per_s'], p['ms_per_replay'], p['roofline'].get('fp32_frac'))" | tee -a $OUT/summary.txt ;;
+    ab_gmmil_mfma)
+      # round 6: the centred Gram form on the matrix pipes (k_gmmil_mfma, default) against the direct-difference launch (k_gmmil_sx), interleaved on one box
+      for i in 1 2 3; do for m in 1 0; do IL_GMMIL_MFMA=$m timeout 300 python profiles/tools/secondary_workloads.py gmmil_rate 2>$OUT/ab_gmmil.err | tail -n 1 | sed "s/^/IL_GMMIL_MFMA=$m /" | tee -a $OUT/ab_gmmil_mfma.txt; done; done
+      for m in 1 0; do IL_GMMIL_MFMA=$m timeout 300 python profiles/tools/gmmil_ab.py 2>>$OUT/ab_gmmil.err | tail -n 1 | sed "s/^/IL_GMMIL_MFMA=$m /" | tee -a $OUT/ab_gmmil_mfma.txt; done
+      cat $OUT/ab_gmmil_mfma.txt >> $OUT/summary.txt ;;
     ab_gmmil_sx)
       for i in 1 2 3; do for m in 1 0; do IL_GMMIL_SX=$m timeout 300 python profiles/tools/secondary_workloads.py gmmil_rate 2>$OUT/ab_gmmil.err | tail -n 1 | sed "s/^/IL_GMMIL_SX=$m /" | tee -a $OUT/ab_gmmil_sx.txt; done; done
       cat $OUT/ab_gmmil_sx.txt >> $OUT/summary.txt ;;
