@@ -161,12 +161,15 @@ def secondary(device, plan, nets):
   gm = il.GMMILDiscriminator(Sg, Ag, Cfg(state_only=False))
   gm.predict_reward(xs, xa, es, ea, w, w)   # first call fixes the bandwidths (median heuristic)
   rate = timed(lambda: gm.predict_reward(xs, xa, es, ea, w, w))
-  pair_flops = 2 * (2 * Bg * Bg) * (3 * (Sg + Ag))   # two gammas share the distances: 2 matrices x B^2 pairs x 3 flop per pair-feature (direct form)
+  pair_flops = 2 * (2 * Bg * Bg) * (3 * (Sg + Ag))   # SURVEY.md 8(d)'s unit: two gammas share the distances: 2 matrices x B^2 pairs x 3 flop per pair-feature (direct form)
+  mfma_flops = (2 * Bg * Bg) * (2 * 128)              # what k_gmmil_mfma executes: 2 flop per pair-feature of the centred Gram product, D padded to 128
   gst = _lib_mod().kernel_stamps().get('k_gmmil_direct')
   kus = gst['duration_us'] if gst else None
-  out['gmmil_reward_B1024_ant'] = dict(calls_per_s=round(rate, 1), pair_feature_TFLOPs=round(pair_flops * rate / 1e12 / 2, 2), kernel_us=kus,
+  gform = 'k_gmmil_mfma' if os.environ.get('IL_GMMIL_MFMA', '1') != '0' else 'k_gmmil_sx'
+  out['gmmil_reward_B1024_ant'] = dict(calls_per_s=round(rate, 1), pair_feature_TFLOPs=round(pair_flops * rate / 1e12 / 2, 2), kernel=gform, kernel_us=kus,
                                         kernel_fp32_frac=(round(pair_flops / 2 / (kus * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, 4) if kus else None),
-                                        note='k_gmmil_sx (one launch: row operand in scalar registers, 256 columns x all features resident in LDS; IL_GMMIL_SX=0 / IL_GMMIL_RESIDENT=0 / IL_GMMIL_DIRECT=0: the earlier forms, same bits); calls_per_s is back-to-back predict_reward calls (host ~10 us each since round 5: at the period of the kernel itself), kernel_us is the launch itself (device stamps); the reference materialises [B,B,D] temporaries (0.33 s per call on its CPU path, SURVEY.md a20)')
+                                        kernel_mfma_frac=(round(mfma_flops / (kus * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, 4) if kus and gform == 'k_gmmil_mfma' else None),
+                                        note='round 6: k_gmmil_mfma (default, D <= 128): pair distances as a CENTRED Gram product |x-c|^2 + |y-c|^2 - 2 (x-c).(y-c) on v_mfma_f32_16x16x4_f32, one launch, 64 x 128 pairs per workgroup, as close to float64 as the direct-difference form whatever the data\'s offset (tests/test_gmmil_centred_form.py, test_gmmil_centred_gram_form_is_as_close_to_float64_as_the_direct_form); kernel_fp32_frac prices SURVEY 8(d)\'s 3 flop per pair-feature (the unit of earlier rounds), kernel_mfma_frac the 2 flop per pair-feature the launch executes; IL_GMMIL_MFMA=0: k_gmmil_sx (direct differences on the VALU, 18.5 us) and the forms behind it; calls_per_s is back-to-back predict_reward calls, kernel_us the launch itself (device stamps); the reference materialises [B,B,D] temporaries (0.33 s per call on its CPU path, SURVEY.md a20)')
 
   # BASELINE.json configs[3] as WHOLE updates: algorithm=GMMIL env=ant, batch 1024 - 2 replay samples + the pairwise-RBF reward + sac_update as one captured graph per step
   rs2 = np.random.RandomState(6)

@@ -152,8 +152,6 @@ def validate(cfg: Config):
     if cfg.imitation.loss_function == 'PUGAIL': assert 0 <= cfg.imitation.pos_class_prior <= 1 and cfg.imitation.nonnegative_margin >= 0
   assert cfg.logging.interval >= 0
   assert int(cfg.distributed.world_size) >= 1 and cfg.distributed.backend in ('nccl', 'gloo')
-  if int(cfg.distributed.world_size) > 1 and cfg.imitation.bc_aux_loss:
-    raise NotImplementedError('distributed.world_size > 1 with imitation.bc_aux_loss=true: the behavioural-cloning auxiliary step (train.py:201) has no data-parallel form; run it on one GPU')
   return cfg
 
 

@@ -398,22 +398,20 @@ class DataParallelUpdate:
   def __init__(self, plan, group=None):
     self.plan, self.group = plan, group
     plan.data_parallel = True   # (the single-GPU extras that assume one branch pair per update - staged rows - stay off)
-    if getattr(plan, '_variant', False) or getattr(plan, '_beta_alpha', None) is not None:
-      raise NotImplementedError('DataParallelUpdate: GAIL with a finite PUGAIL margin / subtract_log_policy / reward shaping / a depth-2 or tanh discriminator / Mixup with mixup_alpha != 1 '
-                                'runs its discriminator step through the per-function entry points inside the plan: there are no gradient-only kernels to all-reduce for them; '
-                                'run these configurations with distributed.world_size=1')
+    # GAIL with a finite PUGAIL margin / subtract_log_policy / reward shaping / a depth-2 or tanh discriminator / Mixup with mixup_alpha != 1 (round 6): these plans run the
+    # per-function entry points of their discriminator on the gathered rows, on stream dependencies; every one of those entry points takes IL_FLAG_GRADS_ONLY, so their
+    # data-parallel form is one more bucket - the discriminator optimiser's gradient arena - averaged between the gradient launch and the AdamW step (run()).
+    self.variant = bool(getattr(plan, '_variant', False) or getattr(plan, '_beta_alpha', None) is not None)
     if getattr(plan, 'general', False):
       raise NotImplementedError('DataParallelUpdate: actor / critic shapes outside depth 2 / ReLU / hidden <= 256 / action_size <= 8 (csrc/general.hip) have no gradient-only kernels '
                                 'to all-reduce; run these configurations with distributed.world_size=1')
-    if plan.bc_aux:
-      raise NotImplementedError('DataParallelUpdate: imitation.bc_aux_loss (the behavioural-cloning auxiliary step, train.py:201) has no data-parallel form; run it with distributed.world_size=1')
     # Device-side hand-off between the discriminator branch and the SAC branch, as on one GPU (UpdatePlan): no stream dependency between the two streams, the index
     # draw resident at the head of the discriminator branch, the reward relabel inline in the forward / critic-loss launch. The discriminator's all-reduce then sits
     # on a stream of its own and must not share a communicator with the critic / actor all-reduces of the main stream (two unordered streams could issue the
     # collectives of ONE communicator in different orders on different ranks): it gets its own process group. IL_DP_HANDOFF=0: stream dependencies, one communicator.
     # EVERY per-rank input of this decision (the stream / hardware-queue probe of UpdatePlan.__init__ is one) goes through a collective AND first: a rank that chose the
     # other schedule would create no side group and issue the discriminator's all-reduce on another communicator than its peers - a hang, not an error.
-    mine = bool(plan.algorithm == 'GAIL' and plan.device_sync and plan.ring_mode and plan.inline_relabel and os.environ.get('IL_DP_HANDOFF', '1') != '0')
+    mine = bool(plan.algorithm == 'GAIL' and plan.device_sync and plan.ring_mode and plan.inline_relabel and not plan.bc_aux and os.environ.get('IL_DP_HANDOFF', '1') != '0')
     self.handoff = _agree(mine, group)
     if not self.handoff:
       plan._set_device_sync(False)   # this schedule orders its two streams with events around the all-reduces
@@ -428,7 +426,7 @@ class DataParallelUpdate:
     # the optimiser launches for this shape, and the peer windows (decided collectively in _setup_peer_exchange). IL_DP_FUSED=0: the exchange launches.
     L = _lib.lib()
     self._fused_jobs = dict(disc=int(L.il_gail_step_workgroups(C.byref(plan.disc))), critic=int(L.il_sac_peer_jobs(C.byref(plan.sac), 0)), actor=int(L.il_sac_peer_jobs(C.byref(plan.sac), 1))) \
-        if plan.algorithm == 'GAIL' else {}
+        if plan.algorithm == 'GAIL' and plan.disc is not None else {}
     mine = bool(self.handoff and plan.resident_sampler and self._fused_jobs and all(self._fused_jobs.values()) and os.environ.get('IL_DP_FUSED', '1') != '0')
     self.fused = _agree(mine, group) if self.handoff else False
     self.peer = None   # PeerExchange once the first run() has set it up (collective); None = torch.distributed all-reduces
@@ -507,6 +505,22 @@ class DataParallelUpdate:
     self._exchange(name, group)
     _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), phase, logp, q, 0, _lib.stream_ptr()))
 
+  def _bc_aux_step(self):
+    """imitation.bc_aux_loss (train.py:201: `behavioural_cloning_update(actor, expert_transitions, actor_optimiser)` between the reward step and `sac_update`), data-parallel
+    (round 6): the loss is a weighted mean over the expert batch (training.py:57-64), so the gradient of the ranks' concatenated expert batches is the mean of their
+    gradients. il_bc_step(IL_FLAG_GRADS_ONLY) writes this rank's gradient into the actor bucket and ticks the actor's optimiser, the bucket is averaged (its last lane, log
+    alpha's gradient, travels along and is not applied here), il_adam_step applies it with the step the gradient launch ticked - the arithmetic of the fused epilogue, bit
+    for bit with one rank (test_data_parallel_bc_aux_equals_the_plain_plan_on_one_rank). It moves the actor: the lane-ordered copies are re-derived by phase 0."""
+    p, L = self.plan, _lib.lib()
+    a, ao = p._keep[0], p._keep[4]
+    od = ao.desc()
+    st = _lib.stream_ptr()
+    _lib.check(L.il_bc_step(_lib.ptr(a.flat), _lib.ptr(ao.grad), C.byref(od), a.state_size, a.action_size, a.hidden, C.byref(p.eb), C.c_void_p(p.sac.workspace), p.sac.workspace_floats,
+                            None, _lib.IL_FLAG_GRADS_ONLY, st))
+    self._exchange('actor', self.group)
+    _lib.check(L.il_adam_step(_lib.ptr(a.flat), _lib.ptr(ao.grad), C.byref(od), a.flat.numel(), 0, st))
+    p._prepared = False
+
   def replica_state(self):
     """Every tensor the ranks must agree on bit for bit after any number of data-parallel updates: parameter arenas, log alpha, spectral-norm buffers, and each optimiser's
     moments and step counter (`replicas_bit_identical` hashes them)."""
@@ -576,7 +590,13 @@ class DataParallelUpdate:
     if self.handoff:
       self._run_handoff(main)
       return
-    if p.algorithm == 'GAIL' and p.device_index_draw:
+    if p.algorithm == 'GAIL' and self.variant:
+      # a discriminator variant: its per-function entry points on the gathered rows (both batches packed), beside the reward-independent SAC forward
+      p.sample_all()
+      self.side.wait_stream(main)
+      with torch.cuda.stream(self.side):
+        p._disc_step_and_relabel_on_gathered_rows(_lib.stream_ptr(), exchange=lambda: self._exchange('disc', self.group))
+    elif p.algorithm == 'GAIL' and p.device_index_draw:
       # The discriminator branch (gradients, all-reduce, AdamW, relabel: the longer one) reads its rows straight from the rings through the drawn indices
       # (il_batch.gather), so it forks right after the index draw; the gathers the SAC kernels need run on the main stream beside it.
       p.draw_all()
@@ -587,7 +607,7 @@ class DataParallelUpdate:
         self._exchange('disc', self.group)
         _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
         _lib.check(L.il_gail_reward(C.byref(p.disc), C.byref(rp), _lib.ptr(p.rewards), None, None, _lib.stream_ptr()))
-      p.gather_all(expert=False)   # the SAC kernels read the packed agent rows; the expert rows were only needed by the discriminator step
+      p.gather_all(expert=p.bc_aux)   # the SAC kernels read the packed agent rows; the expert rows are only needed by the discriminator step (through the indices) and the BC auxiliary step
     else:
       p.sample_all()
       if p.algorithm not in ('SAC', 'PWIL', 'GAIL'):
@@ -599,6 +619,8 @@ class DataParallelUpdate:
           self._exchange('disc', self.group)
           _lib.check(L.il_gail_apply_grads(C.byref(p.disc), _lib.stream_ptr()))
           _lib.check(L.il_gail_reward(C.byref(p.disc), C.byref(p.pb), _lib.ptr(p.rewards), None, None, _lib.stream_ptr()))
+    if p.bc_aux:
+      self._bc_aux_step()
     _lib.check(L.il_sac_dp_phase(C.byref(p.sac), C.byref(p.pb), 0, None, None, p.prepared_flag(), _lib.stream_ptr()))
     if p.algorithm == 'GAIL':
       main.wait_stream(self.side)

@@ -275,9 +275,10 @@ def shaped_predict_reward(disc, state: Tensor, action: Tensor, next_state: Tenso
 
 
 def adversarial_imitation_update(actor, discriminator: GAILDiscriminator, transitions: Dict[str, Tensor], expert_transitions: Dict[str, Tensor], discriminator_optimiser: AdamW,
-                                 imitation_cfg, *, eps_gp: Optional[Tensor] = None, eps_mix: Optional[Tensor] = None):
+                                 imitation_cfg, *, eps_gp: Optional[Tensor] = None, eps_mix: Optional[Tensor] = None, flags: int = 0):
   """Reference training.py:85-134: loss_function BCE / PUGAIL (any nonnegative_margin) / Mixup, + gradient penalty, spectral norm, entropy bonus,
-  subtract_log_policy.  `eps_gp` / `eps_mix`: the U(0,1) and Beta(alpha, alpha) draws (None: drawn here)."""
+  subtract_log_policy.  `eps_gp` / `eps_mix`: the U(0,1) and Beta(alpha, alpha) draws (None: drawn here). `flags` = IL_FLAG_GRADS_ONLY: the gradient is left in
+  `discriminator_optimiser.grad` (the optimiser is ticked, the spectral-norm buffers advance) and the caller applies it after averaging it over ranks (parallel.DataParallelUpdate)."""
   dev = discriminator.flat.device
   B = transitions['states'].size(0)
   pb, eb = batch_desc(transitions), batch_desc(expert_transitions)
@@ -300,7 +301,7 @@ def adversarial_imitation_update(actor, discriminator: GAILDiscriminator, transi
       keep += [actor.log_prob(transitions['states'], transitions['actions']), actor.log_prob(expert_transitions['states'], expert_transitions['actions'])]
       x.logit_offset_policy, x.logit_offset_expert = keep[-2].data_ptr(), keep[-1].data_ptr()
     step = _lib.lib().il_gail_shaped_deep_step if _shaped_general(discriminator) else _lib.lib().il_gail_shaped_step
-    _lib.check(step(C.byref(d), C.byref(pb), C.byref(eb), _lib.ptr(e), C.byref(x), 0, _lib.stream_ptr()))
+    _lib.check(step(C.byref(d), C.byref(pb), C.byref(eb), _lib.ptr(e), C.byref(x), int(flags), _lib.stream_ptr()))
     return
   deep = type(discriminator).__name__ == 'DeepGAILDiscriminator'   # depth 2 and / or tanh: the general kernels, same arguments
   d = (deep_descriptor if deep else disc_descriptor)(discriminator, B, discriminator_optimiser, imitation_cfg)
@@ -319,7 +320,7 @@ def adversarial_imitation_update(actor, discriminator: GAILDiscriminator, transi
     keep += [actor.log_prob(transitions['states'], transitions['actions']), actor.log_prob(expert_transitions['states'], expert_transitions['actions'])]
     x.logit_offset_policy, x.logit_offset_expert = keep[-2].data_ptr(), keep[-1].data_ptr()
   step = _lib.lib().il_gail_deep_step if deep else _lib.lib().il_gail_disc_step
-  _lib.check(step(C.byref(d), C.byref(pb), C.byref(eb), _lib.ptr(e), C.byref(x), 0, _lib.stream_ptr()))
+  _lib.check(step(C.byref(d), C.byref(pb), C.byref(eb), _lib.ptr(e), C.byref(x), int(flags), _lib.stream_ptr()))
 
 
 def gail_predict_reward(disc: GAILDiscriminator, state: Tensor, action: Tensor, want_logits: bool = False, log_policy: Optional[Tensor] = None):
@@ -909,9 +910,13 @@ class UpdatePlan:
       return
     self._disc_step_and_relabel_on_gathered_rows(st)
 
-  def _disc_step_and_relabel_on_gathered_rows(self, st):
-    """train.py:178-194 on the gathered batches (the stream-dependency schedules): discriminator step, then the relabel kernel."""
+  def _disc_step_and_relabel_on_gathered_rows(self, st, exchange=None):
+    """train.py:178-194 on the gathered batches (the stream-dependency schedules): discriminator step, then the relabel kernel. `exchange` (parallel.DataParallelUpdate,
+    round 6: every discriminator variant has a data-parallel form): the step leaves its gradient in the optimiser's arena (IL_FLAG_GRADS_ONLY; the optimiser is ticked and the
+    spectral-norm buffers, which depend on the replicated weights only, advance), `exchange()` averages that arena over the ranks on this stream, and the AdamW step is applied
+    from it - il_gail_apply_grads for the fused depth-1 kernels, il_adam_step for the variants' (the same adam_update on the same constants as their reduce launch's epilogue)."""
     L, extra = _lib.lib(), None
+    G = _lib.IL_FLAG_GRADS_ONLY if exchange is not None else 0
     if getattr(self, '_beta_alpha', None) is not None:   # this update's Beta(alpha, alpha) coefficients, drawn on the device (see __init__); the learner's one Philox key / counter
       _lib.check(L.il_noise_fill_beta(C.c_uint64(self.sac.noise_seed), self.sac.noise_counter, self._beta_alpha, self.B, _lib.ptr(self.eps_mix), st))
       extra = C.byref(self._mix_extra)
@@ -919,11 +924,18 @@ class UpdatePlan:
       from .models import make_gail_input
       actor, disc, opt, icfg = self._gail_parts
       t, e = self.transitions, self.expert_transitions
-      adversarial_imitation_update(actor, disc, t, e, opt, icfg, eps_mix=self.eps_mix if self._beta_alpha is not None else None)
+      adversarial_imitation_update(actor, disc, t, e, opt, icfg, eps_mix=self.eps_mix if self._beta_alpha is not None else None, flags=G)
+      if exchange is not None:
+        exchange()
+        od = opt.desc()
+        _lib.check(L.il_adam_step(_lib.ptr(disc.flat), _lib.ptr(opt.grad), C.byref(od), min(disc.flat.numel(), opt.grad.numel()), 0, st))
       self.rewards.copy_(disc.predict_reward(**make_gail_input(t['states'], t['actions'], t['next_states'], t['terminals'], actor, bool(getattr(disc, 'reward_shaping', False)),
                                                                bool(disc.subtract_log_policy))))
       return
-    _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, extra, 0, st))
+    _lib.check(L.il_gail_disc_step(C.byref(self.disc), C.byref(self.pb), C.byref(self.eb), None, extra, G, st))
+    if exchange is not None:
+      exchange()
+      _lib.check(L.il_gail_apply_grads(C.byref(self.disc), st))
     _lib.check(L.il_gail_reward(C.byref(self.disc), C.byref(self.pb), _lib.ptr(self.rewards), None, None, st))
 
   def _fused_exchange_needs_the_resident_sampler(self):

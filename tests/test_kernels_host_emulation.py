@@ -579,6 +579,21 @@ def test_update_plan_of_every_algorithm_on_the_emulated_kernels(monkeypatch, alg
   tp.test_plan_of_every_algorithm_equals_the_per_function_sequence(algorithm, mixed, bc_aux, kw)
 
 
+@pytest.mark.parametrize('algorithm,mixed', [('SAC', False), ('DRIL', False)])
+def test_data_parallel_bc_aux_on_the_emulated_kernels(monkeypatch, algorithm, mixed):
+  """tests/test_update_plans_gpu.py::test_data_parallel_bc_aux_equals_the_plain_plan_on_one_rank on the emulated kernels: the BC auxiliary step of a data-parallel update
+  (gradient launch -> bucket mean -> il_adam_step) against the plain plan's fused step, bit for bit, eager and captured."""
+  tgp = _emulated_product(monkeypatch, streams=True)
+  import gpu_util
+  import test_update_plans_gpu as tp
+  from imitation_learning_amd import training as il_training
+  for k in ('DEV', 'N', 'Cfg', 'fill_memory'):
+    monkeypatch.setattr(tp, k, getattr(gpu_util, k), raising=False)
+  for k, v in (('il', tgp.il), ('_lib', _lib), ('il_training', il_training)):
+    monkeypatch.setattr(tp, k, v, raising=False)
+  tp.test_data_parallel_bc_aux_equals_the_plain_plan_on_one_rank(algorithm, mixed)
+
+
 @pytest.mark.parametrize('algorithm,mixed,bc_aux,nets_name', [('SAC', False, True, 'd3_tanh'), ('GMMIL', True, False, 'mixed'), ('AdRIL', False, False, 'mixed')])
 def test_general_shape_update_plan_on_the_emulated_kernels(monkeypatch, algorithm, mixed, bc_aux, nets_name):
   """UpdatePlan for actor / critic shapes outside the fused kernels (csrc/general.hip on one stream, captured as one graph): bit-identical to the per-function sequence."""

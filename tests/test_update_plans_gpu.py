@@ -134,6 +134,59 @@ def test_plan_of_every_algorithm_equals_the_per_function_sequence(algorithm, mix
     r = N(got[-1][0]); assert set(np.unique(r)) <= {-1.0, 1.0} and 0 < (r > 0).mean() < 1, 'the threshold should split the batch'
 
 
+@pytest.mark.parametrize('algorithm,mixed', [('SAC', False), ('RED', True), ('DRIL', False)])
+def test_data_parallel_bc_aux_equals_the_plain_plan_on_one_rank(algorithm, mixed):
+  """imitation.bc_aux_loss under DataParallelUpdate (round 6; train.py:201 between the reward step and sac_update): il_bc_step(IL_FLAG_GRADS_ONLY) -> [mean over ranks of the
+  actor bucket] -> il_adam_step. With one rank the exchange is the identity, so the learner must evolve bit for bit like the plain plan (whose BC step applies AdamW in the
+  gradient launch's epilogue) - eagerly and as a captured graph. DRIL ships with bc_aux_loss=true: before this it had no data-parallel form."""
+  from imitation_learning_amd.parallel import DataParallelUpdate
+  outs = []
+  for mode in ('plan', 'dp', 'dp_graph'):
+    nets, opts, mem, emem, disc = build(algorithm, 17)
+    plan = il.UpdatePlan(algorithm, *nets, mem, *opts, B, 0.97, -0.5 * A, 0.99, expert_memory=emem, discriminator=disc, mix_expert=mixed, bc_aux=True)
+    runner = plan if mode == 'plan' else DataParallelUpdate(plan)
+    for k in range(4):
+      if mode == 'dp_graph' and k == 1: runner.capture(warmup=0)
+      (runner.replay if mode == 'dp_graph' and k >= 1 else runner.run)()
+    torch.cuda.synchronize()
+    outs.append([N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [N(opts[0].exp_avg), N(opts[0].exp_avg_sq), N(opts[0].step_count[:1]), N(plan.logp), N(plan.q), N(plan.transitions['rewards'])])
+  for mode, got in zip(('dp', 'dp_graph'), outs[1:]):
+    for i, (a, b) in enumerate(zip(outs[0], got)):
+      assert np.isfinite(a).all()
+      np.testing.assert_array_equal(a, b, err_msg=f'{algorithm} {mode}: tensor {i}')
+  assert int(outs[0][6][0]) == 8   # the actor's optimiser stepped twice per update: the BC auxiliary step and the policy step
+
+
+@pytest.mark.parametrize('variant', list(GAIL_VARIANTS) + ['mixup_alpha'])
+def test_data_parallel_gail_variants_equal_the_plain_plan_on_one_rank(variant):
+  """The discriminator variants under DataParallelUpdate (round 6; training.py:100-114,130-132): a finite PUGAIL margin, subtract_log_policy, reward shaping, depth-2 / tanh
+  discriminators and Mixup with mixup_alpha != 1 leave their gradient in the optimiser's arena (IL_FLAG_GRADS_ONLY), the arena is averaged over ranks, the AdamW step is applied
+  from it. One rank: the exchange is the identity, the learner and its discriminator must evolve bit for bit like the plain plan - eagerly and as a captured graph."""
+  from imitation_learning_amd.parallel import DataParallelUpdate
+  kw = dict(variant=variant) if variant != 'mixup_alpha' else {}
+  outs = []
+  for mode in ('plan', 'dp', 'dp_graph'):
+    nets, opts, mem, emem, disc = build('GAIL', 23, **kw)
+    if variant == 'mixup_alpha':
+      disc.test_extra['imitation_cfg']['loss_function'], disc.test_extra['imitation_cfg']['mixup_alpha'] = 'Mixup', 0.4
+    plan = il.UpdatePlan('GAIL', *nets, mem, *opts, B, 0.97, -0.5 * A, 0.99, expert_memory=emem, discriminator=disc, **disc.test_extra)
+    assert (plan._variant or plan._beta_alpha is not None) and not plan.device_sync
+    runner = plan if mode == 'plan' else DataParallelUpdate(plan)
+    if mode != 'plan': assert runner.variant and not runner.handoff
+    for k in range(4):
+      if mode == 'dp_graph' and k == 1: runner.capture(warmup=0)
+      (runner.replay if mode == 'dp_graph' and k >= 1 else runner.run)()
+    torch.cuda.synchronize()
+    do = disc.test_extra['discriminator_optimiser']
+    outs.append([N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [N(disc.flat), N(disc.sn) if getattr(disc, 'sn', None) is not None else np.zeros(1), N(do.exp_avg), N(do.exp_avg_sq), N(do.step_count[:1]),
+                                                                            N(plan.logp), N(plan.q), N(plan.transitions['rewards'])])
+  for mode, got in zip(('dp', 'dp_graph'), outs[1:]):
+    for i, (a, b) in enumerate(zip(outs[0], got)):
+      assert np.isfinite(a).all()
+      np.testing.assert_array_equal(a, b, err_msg=f'GAIL {variant} {mode}: tensor {i}')
+  assert int(outs[0][8][0]) == 4
+
+
 def test_plan_rejects_what_it_cannot_capture():
   nets, opts, mem, emem, disc = build('GMMIL', 3)
   with pytest.raises(AssertionError):
