@@ -147,7 +147,9 @@ def secondary(device, plan, nets):
     disc_step(); torch.cuda.synchronize()
     with torch.cuda.graph(g, stream=side):
       disc_step()
-    out['gail_disc_step_and_relabel_per_s'] = round(max(timed(g.replay, 1000, 100), timed(disc_step, 1000, 100)), 1)   # hipGraph replays / the two library calls issued directly: the better
+    r_graph, r_direct = timed(g.replay, 1000, 100), timed(disc_step, 1000, 100)
+    out['gail_disc_step_and_relabel_per_s'] = round(r_direct, 1)   # the two library calls issued directly: the product's default launch path on one GPU (train.py, bench.py)
+    out['gail_disc_step_and_relabel_forms'] = dict(direct_calls=round(r_direct, 1), graph_replays=round(r_graph, 1))   # (rounds 1-5 reported the better of the two under the first key)
   torch.cuda.current_stream().wait_stream(side)
   plan._set_device_sync(was)
   del dd

@@ -1086,8 +1086,19 @@ __global__ __launch_bounds__(256) void k_gmmil_mfma(il_batch pol, il_batch exp, 
       }
       return s;
     };
-    const float s0 = ordered_sum(ws_ + w.part, nE);
-    const float s1 = ordered_sum(ws_ + w.part + (size_t)w.njt * w.b1p, nX);
+    float s0, s1;
+    if (nE <= 8 && nX <= 8) {   // both matrices' partials requested together: one trip to memory instead of two behind each other
+      float v0[8], v1[8];
+      const float* p1 = ws_ + w.part + (size_t)w.njt * w.b1p;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { v0[u] = sload1(ws_ + w.part, (int64_t)min(u, nE - 1) * w.b1p + i); v1[u] = sload1(p1, (int64_t)min(u, nX - 1) * w.b1p + i); }
+      s0 = 0.f; s1 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { if (u < nE) s0 += v0[u]; if (u < nX) s1 += v1[u]; }
+    } else {
+      s0 = ordered_sum(ws_ + w.part, nE);
+      s1 = ordered_sum(ws_ + w.part + (size_t)w.njt * w.b1p, nX);
+    }
     const float wi = pol.weights[(size_t)i * pol.ld_weights] / sx;
     const float sim = wi * s0, self = wi * s1;
     out_r[i] = sim - self;
