@@ -383,16 +383,16 @@ def roofline_from_stamps(samples, ms_per_step, use_pmc=True):
     ach = bytes_k.get(mk, 0) / (kern[dom] * 1e-6) / 1e9
     roof = dict(bound='hbm', kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 5), traffic=None)
   roof['duration_source'] = (f'device stamps inside the timed hipGraph replays (il_kernel_stamps: thread 0 of every workgroup stores the 100 MHz device counter at start / end; '
-                             f'duration = last end - first start of the last launch of a burst), median of {len(samples)} readings; compare profiles/r05_headline_kernel_stats.md (rocprofv3 '
+                             f'duration = last end - first start of the last launch of a burst), median of {len(samples)} readings; compare profiles/r06_headline_kernel_stats.md (rocprofv3 '
                              '--kernel-trace of the same command: dispatch-to-completion, i.e. + the command processor\'s launch and end-of-kernel work)')
   try:   # the committed rocprofv3 --kernel-trace of the same command (dispatch-to-completion: + the command processor's launch and end-of-kernel work, i.e. part of what the
     # stamps show as launch boundaries): the dominant kernel's duration and fraction by that clock, beside the stamps'
-    prof = os.path.join(ROOT, 'profiles', 'r05_headline_kernel_stats.md')
+    prof = os.path.join(ROOT, 'profiles', 'r06_headline_kernel_stats.md')
     for line in open(prof):
       cells = [c.strip() for c in line.strip().strip('|').split('|')]
       if len(cells) >= 3 and cells[0] == dom:
         avg = float(cells[2])
-        roof['rocprofv3_reference'] = dict(file='profiles/r05_headline_kernel_stats.md', kernel=dom, avg_us=avg, frac=round(flops_k[mk] / (avg * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, 5) if mk in flops_k else None,
+        roof['rocprofv3_reference'] = dict(file='profiles/r06_headline_kernel_stats.md', kernel=dom, avg_us=avg, frac=round(flops_k[mk] / (avg * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, 5) if mk in flops_k else None,
                                            note='rocprofv3 times a dispatch from the packet to the completion signal; the stamps from the first workgroup\'s first instruction to the last workgroup\'s last: the difference (~2.3 us for a 163 x 512-thread launch with 160 KB of LDS per workgroup) is what `update.launch_boundaries_us` holds')
         break
   except Exception:
@@ -608,6 +608,10 @@ def main():
         step = functools.partial(plan.launch_direct, join=False)
         launch = ('direct launches, SAC branch alternating over two streams (il_sac_update_gather_overlap: forward / critic loss and policy / critic on one, the two optimiser '
                   'launches on another, stage epochs on the device instead of stream order; discriminator branch on a third): two library calls per update, six kernel launches, no hipGraph')
+    elif args.launch == 'direct' and runner is not plan and not args.no_graph and getattr(runner, 'direct_launch_ok', None) is not None and runner.direct_launch_ok():
+      beat('recording the direct launches (data parallel, exchanges inside the optimiser launches)')
+      runner.record_direct()
+      step, launch = runner.launch_direct, 'direct launches (DataParallelUpdate.launch_direct: the plan\'s two branches with the gradient exchanges inside the optimiser launches, two library calls per update, no hipGraph)'
     elif not args.no_graph and not (gloo_eager and getattr(runner, 'peer', None) is None):
       beat('graph capture')
       try:

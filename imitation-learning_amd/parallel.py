@@ -699,6 +699,22 @@ class DataParallelUpdate:
       self.run()
     return self
 
+  # --- direct launches (round 6): with the exchanges INSIDE the optimiser launches (`fused`) a data-parallel update is the launch sequence of one GPU - the plan's own two
+  # branches with the peer descriptors attached - so it can be issued the way the single-GPU plan is: two library calls per update, no hipGraph (a graph replay costs ~4.5 us
+  # more between two updates than the launch boundary of the same kernels). The RCCL schedule keeps its graphs: its all-reduces are torch.distributed calls.
+  def direct_launch_ok(self) -> bool:
+    return bool(self.handoff and self.fused and self.peer is not None and self.plan.peer_desc is not None and self.plan.direct_launch_ok())
+
+  def record_direct(self):
+    if self._warm_collectives_pending:
+      self._warm_collectives()
+    assert self.direct_launch_ok(), 'DataParallelUpdate.record_direct: the fused peer-window schedule only (IL_PEER_EXCHANGE=1 with the device hand-off); capture() otherwise'
+    self.plan.record_direct()
+    return self
+
+  def launch_direct(self):
+    self.plan.launch_direct()
+
   def replay(self):
     if self.graph_side is not None:
       if self.plan.main_feeds_ring and self.plan.resident_sampler:

@@ -30,8 +30,13 @@ plan, nets = tg._make_plan(algorithm, 40 + rank)    # different replay shards pe
 parallel.broadcast_parameters(parallel.replica_tensors(nets[0], nets[1], nets[2], nets[3], nets[4] if algorithm == 'GAIL' else None))
 dp = parallel.DataParallelUpdate(plan)
 idx0 = None
+direct = os.environ.get('IL_TEST_DIRECT') == '1'
 for k in range(4):
-  dp.run()
+  if direct and k == 2:
+    assert dp.direct_launch_ok()
+    dp.record_direct()
+    dist.barrier()
+  (dp.launch_direct if direct and k >= 2 else dp.run)()
   torch.cuda.synchronize()
   if k == 0: idx0 = plan.idx.cpu().numpy().copy()
 out = {f't{i}': (n.flat if hasattr(n, 'flat') else n).detach().cpu().numpy() for i, n in enumerate(nets)}
@@ -100,6 +105,30 @@ def test_exchange_inside_the_optimiser_launches_equals_the_exchange_launches(tmp
   for rank in (0, 1):
     for k in ('t0', 't1', 't2', 't3', 't4', 'sn', 'logp'):
       np.testing.assert_array_equal(res['1'][rank][k], res['0'][rank][k], err_msg=f'rank {rank}, {k}')
+
+
+def test_data_parallel_direct_launches_equal_the_eager_updates(tmp_path):
+  """Round 6: with the exchanges inside the optimiser launches a data-parallel update is the plan's own two branches, so `DataParallelUpdate.record_direct()` /
+  `launch_direct()` issue it as direct launches (what bench.py --gpus N and train.py do on the fused schedule). Two ranks, two eager updates then two direct ones: every
+  replica tensor keeps the bits of four eager updates, on both ranks."""
+  script = tmp_path / 'worker.py'
+  script.write_text(WORKER)
+  res = {}
+  for direct in ('0', '1'):
+    d = tmp_path / f'direct_{direct}'
+    d.mkdir()
+    _launch([str(script), ROOT, str(d), 'GAIL'], str(tmp_path), IL_DP_HANDOFF='1', IL_PEER_EXCHANGE='require', IL_DP_FUSED='1', IL_TEST_DIRECT=direct)
+    res[direct] = [np.load(d / 'rank0.npz'), np.load(d / 'rank1.npz')]
+    for r in res[direct]:
+      assert int(r['peer'][1]) == 0, 'a device-side wait of the peer-window exchange expired'
+      assert int(r['peer'][2]) == 1
+      if r['handoff'][1]:
+        pytest.skip('bounded device-side waits expired: the two ranks of this test SHARE one GPU and were time-sliced against each other')
+  for rank in (0, 1):
+    for k in ('t0', 't1', 't2', 't3', 't4', 'sn', 'logp'):
+      np.testing.assert_array_equal(res['1'][rank][k], res['0'][rank][k], err_msg=f'rank {rank}, {k}')
+  for k in ('t0', 't1', 't2', 't3', 't4', 'sn'):
+    np.testing.assert_array_equal(res['1'][0][k], res['1'][1][k], err_msg=f'replica tensor {k} differs between the ranks')
 
 
 def test_peer_exchange_equals_the_collective(tmp_path):

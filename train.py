@@ -250,6 +250,9 @@ def train(cfg, file_prefix: str = '') -> float:
             # two updates than the launch boundary of the same kernels (profiles/r05_launch_ab.txt); IL_TRAIN_LAUNCH=graph keeps the graphs
             plan.record_direct()
             step_update = plan.launch_direct
+          elif runner is not plan and runner.direct_launch_ok() and os.environ.get('IL_TRAIN_LAUNCH', 'direct') != 'graph':
+            runner.record_direct()   # (round 6) data parallel with the exchanges inside the optimiser launches: the launch sequence of one GPU, issued the same way
+            step_update = runner.launch_direct
           else:
             runner.capture(warmup=0)   # the gradient exchange (peer-window kernels, or RCCL collectives) is captured with the kernels: one graph replay per data-parallel update
             step_update = runner.replay
