@@ -397,11 +397,12 @@ def embedding_sqdist(x: Tensor, y: Tensor) -> Tensor:
   """models.py:25-29 `_squared_distance` between two sets of feature rows [n1, D], [n2, D] -> [n1, n2] (k_gmmil_tile, direct form)."""
   n1, n2, D = x.size(0), y.size(0), x.size(1)
   dev = x.device
-  ws = _gmmil_workspace(n1, n2, D, dev)
+  st = _lib.stream_ptr()   # (the workspace is keyed by the stream the launch goes to, not by torch's current stream: they differ when the caller passes a stream of its own)
+  ws = _gmmil_workspace(n1, n2, D, dev, stream=getattr(st, 'value', None) or 0)
   out = torch.empty(n1, n2, device=dev)
   w1, w2 = torch.ones(n1, device=dev), torch.ones(n2, device=dev)   # named: an il_batch holds raw pointers, the tensors must outlive the launch
   ba, bb = _sa_batch(x, x, w1), _sa_batch(y, y, w2)
-  _lib.check(_lib.lib().il_gmmil_sqdist(C.byref(ba), C.byref(bb), D, 0, 1, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+  _lib.check(_lib.lib().il_gmmil_sqdist(C.byref(ba), C.byref(bb), D, 0, 1, _lib.ptr(out), _lib.ptr(ws), ws.numel(), st))
   return out
 
 
@@ -409,11 +410,12 @@ def gmmil_sqdist(disc: GMMILDiscriminator, a_state, a_action, b_state, b_action)
   dev = a_state.device
   na, nb = a_state.size(0), b_state.size(0)
   D = disc.state_size + (0 if disc.state_only else disc.action_size)
-  ws = _gmmil_workspace(na, nb, D, dev, tag=getattr(disc, '_ws_tag', None))
+  st = _lib.stream_ptr()
+  ws = _gmmil_workspace(na, nb, D, dev, tag=getattr(disc, '_ws_tag', None), stream=getattr(st, 'value', None) or 0)
   out = torch.empty(na, nb, device=dev)
   wa, wb = torch.ones(na, device=dev), torch.ones(nb, device=dev)
   ba, bb = _sa_batch(a_state, a_action, wa), _sa_batch(b_state, b_action, wb)
-  _lib.check(_lib.lib().il_gmmil_sqdist(C.byref(ba), C.byref(bb), disc.state_size, disc.action_size, int(disc.state_only), _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+  _lib.check(_lib.lib().il_gmmil_sqdist(C.byref(ba), C.byref(bb), disc.state_size, disc.action_size, int(disc.state_only), _lib.ptr(out), _lib.ptr(ws), ws.numel(), st))
   return out
 
 
@@ -1152,8 +1154,11 @@ class UpdatePlan:
       def __init__(self, real): self.real, self.calls = real, []
       def __getattr__(self, name):
         fn = getattr(self.real, name)
-        if not name.startswith('il_') or fn.restype is not C.c_int:
-          return fn   # size / layout queries: answered by the library itself
+        # a LAUNCH is an il_* entry point that returns a status and takes the stream as its last argument; everything else (size / layout / grid queries - which are
+        # c_int32 = c_int on this platform and were swallowed by the first form of this recorder -, host-side reads) is answered by the library itself
+        args_t = getattr(fn, 'argtypes', None) or ()
+        if not (name.startswith('il_') and fn.restype is C.c_int and len(args_t) > 0 and args_t[-1] is _lib._P):
+          return fn
         def call(*args):
           self.calls.append((fn, args))
           return 0

@@ -579,6 +579,38 @@ def test_update_plan_of_every_algorithm_on_the_emulated_kernels(monkeypatch, alg
   tp.test_plan_of_every_algorithm_equals_the_per_function_sequence(algorithm, mixed, bc_aux, kw)
 
 
+def test_gmmil_centred_gram_kernel_on_random_shapes_on_the_emulated_kernels(monkeypatch):
+  """k_gmmil_mfma over a sweep of shapes the fixed cases do not hit: row counts around the 64-row / 128-column block edges, every feature-group count (D <= 32, <= 64, <= 128),
+  whole-lane and element-wise operand loads, state_only, zero weights, a constant offset - against float64 at the GMMIL bound, twice per shape (self-resetting tickets)."""
+  tgp = _emulated_product(monkeypatch)
+  import torch
+  from imitation_learning_amd import training as il_training
+  rs = np.random.RandomState(77)
+  cases = [(1, 1, 4, 0), (63, 129, 8, 4), (65, 127, 33, 7), (128, 64, 60, 4), (70, 200, 100, 28), (64, 64, 124, 4), (33, 257, 17, 0), (130, 1, 3, 1)]
+  for n1, n2, S, A in cases:
+    D = S + A
+    off = float(rs.choice([0.0, 30.0]))
+    X = (rs.standard_normal((n1, D)) + off).astype(np.float32); E = (rs.standard_normal((n2, D)) * 0.7 + 0.3 + off).astype(np.float32)
+    w = rs.uniform(0.2, 1.5, n1).astype(np.float32); we = rs.uniform(0.2, 1.5, n2).astype(np.float32)
+    if n2 > 4: we[rs.randint(0, n2, 2)] = 0.0
+    state_only = A == 0
+    disc = tgp.il.GMMILDiscriminator(S, max(A, 1), tgp.Cfg(state_only=state_only))
+    d64 = lambda a, b: ((a.astype(np.float64)[:, None, :] - b.astype(np.float64)[None, :, :]) ** 2).mean(2)
+    dxe, dxx = d64(X, E), d64(X, X)
+    g1, g2 = float(np.float32(1.0 / (np.median(dxe) + 1e-8))), float(np.float32(0.5 / (np.median(dxx) + 1e-3)))
+    disc.gamma_1, disc.gamma_2 = g1, g2
+    wn, wen = w.astype(np.float64) / w.astype(np.float64).sum(), we.astype(np.float64) / we.astype(np.float64).sum()
+    sim64 = sum(wn * (np.exp(-gm * dxe) @ wen) for gm in (g1, g2)); self64 = sum(wn * (np.exp(-gm * dxx) @ wn) for gm in (g1, g2))
+    Tn = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    act = lambda M: Tn(M[:, S:]) if A else Tn(np.zeros((M.shape[0], 1), np.float32))
+    for _ in range(2):
+      r, sim, self_sim = il_training.gmmil_predict_reward(disc, Tn(X[:, :S]), act(X), Tn(E[:, :S]), act(E), Tn(w), Tn(we), return_parts=True)
+    bound = 1e-5 * max(np.abs(sim64).max(), np.abs(self64).max())
+    got = [tgp.N(t) for t in (sim, self_sim, r)]
+    for name, a, b in zip(('similarity', 'self similarity', 'reward'), got, (sim64, self64, sim64 - self64)):
+      assert np.abs(a - b).max() <= bound, (n1, n2, S, A, off, name, np.abs(a - b).max() / bound)
+
+
 @pytest.mark.parametrize('algorithm,mixed', [('SAC', False), ('DRIL', False)])
 def test_data_parallel_bc_aux_on_the_emulated_kernels(monkeypatch, algorithm, mixed):
   """tests/test_update_plans_gpu.py::test_data_parallel_bc_aux_equals_the_plain_plan_on_one_rank on the emulated kernels: the BC auxiliary step of a data-parallel update
