@@ -139,6 +139,13 @@ _SIGNATURES = {
     'il_mt19937_randint': (C.c_int, [c_u32p, C.c_int64, C.c_int32, c_i32p]),
     'il_mt19937_sample_indices_device': (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     'il_struct_size': (C.c_int32, [C.c_int32]),
+    'il_launcher_create': (C.c_int, [C.POINTER(C.c_void_p)]),
+    'il_launcher_destroy': (C.c_int, [C.c_void_p]),
+    'il_launcher_clear': (C.c_int, [C.c_void_p]),
+    'il_launcher_add': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_int32]),
+    'il_launcher_submit': (C.c_int, [C.c_void_p]),
+    'il_launcher_wait': (C.c_int, [C.c_void_p]),
+    'il_launcher_pending': (C.c_int64, [C.c_void_p]),
     'il_noise_fill': (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, _P, _P]),
     'il_noise_fill_beta': (C.c_int, [C.c_uint64, _P, C.c_float, C.c_int64, _P, _P]),
     'il_sync_probe': (C.c_int, [_P, C.c_int32, _P]),

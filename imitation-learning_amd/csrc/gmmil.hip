@@ -940,12 +940,9 @@ __global__ __launch_bounds__(256) void k_gmmil_mfma(il_batch pol, il_batch exp, 
   };
   auto sumsq = [](float acc, const f32x4& v) { return __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], acc)))); };
   // ---- everything this workgroup reads from memory is requested here
-  f32x4 cv[1];   // centre: 8 expert rows spread over the batch, one 16-byte feature lane per thread
+  f32x4 cv = {0.f, 0.f, 0.f, 0.f};   // centre: 8 expert rows spread over the batch (thread group cg reads row cg n2 / 8), one 16-byte feature lane per thread
   const int cq = tid & 31, cg = tid >> 5;
-  if (cq < NQ) {
-#pragma unroll
-    for (int u = 0; u < 1; ++u) cv[u] = gmf_load<LANES>(exp, S, D, (int)(((long long)cg * n2) >> 3), 4 * cq);
-  }
+  if (cq < NQ) cv = gmf_load<LANES>(exp, S, D, (int)(((long long)cg * n2) >> 3), 4 * cq);
   const GmfW4 wx4 = gmf_weight_req(pol, tid), wy4 = gmf_weight_req(yb, tid);
   float wv = gload(yb.weights + (size_t)min(jb * GMF_COLS + (tid & (GMF_COLS - 1)), ny - 1) * yb.ld_weights);
   wv = jb * GMF_COLS + (tid & (GMF_COLS - 1)) < ny ? wv : 0.f;
@@ -960,12 +957,7 @@ __global__ __launch_bounds__(256) void k_gmmil_mfma(il_batch pol, il_batch exp, 
   // ---- centre and weight sums
   float sx = gmf_weight_share(pol, tid, wx4), sy = 0.f;
   if (!vs_self) sy = gmf_weight_share(yb, tid, wy4);
-  if (cq < NQ) {
-    f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < 1; ++u) c4 += zero_tail(cv[u], 4 * cq, true);
-    *reinterpret_cast<f32x4*>(&cpart[cg * DP + 4 * cq]) = c4;
-  }
+  if (cq < NQ) *reinterpret_cast<f32x4*>(&cpart[cg * DP + 4 * cq]) = zero_tail(cv, 4 * cq, true);
   sx = wave_sum(sx);
   if (!vs_self) sy = wave_sum(sy);
   if (lane == 0) { red[wave] = sx; red[4 + wave] = sy; }

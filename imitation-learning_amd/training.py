@@ -793,6 +793,7 @@ class UpdatePlan:
         _lib.ptr(self.erows) if e and not self.ring_mode else None, _lib.ptr(self.sync) if self.device_sync and self.algorithm == 'GAIL' else None, _lib.stream_ptr()))   # ring mode: the draw only (SAC / PWIL reach this call on their one-stream schedule only: no counters move)
 
   def run(self):
+    self.launcher_wait()   # (round 6: updates handed to the launcher thread are issued first)
     for hook in self.pre_hooks:
       hook()
     self._run_update()
@@ -1191,6 +1192,7 @@ class UpdatePlan:
     nothing in between (offline training, several updates per environment step, bench.py): the next update's first launch is dispatched while this one's last still runs;
     call `join()` before reading anything."""
     self._raise_if_poisoned()
+    self.launcher_wait()   # (passes handed to the launcher thread go out first)
     if self.main_feeds_ring and self._captured_resident:
       self.side.wait_stream(torch.cuda.current_stream())   # (as replay(): appends enqueued since the last update precede the resident index draw)
     if self._direct_overlap and not self._ov_active:
@@ -1202,9 +1204,57 @@ class UpdatePlan:
     if join and self._direct_overlap:
       torch.cuda.current_stream().wait_stream(self.ov_stream)
 
+  # --- (round 6) the recorded launches issued by a thread of the library (csrc/launcher.hip): the host returns at once and goes on with its environment step
+  @staticmethod
+  def _word(a) -> int:
+    """One recorded ctypes argument as the 64-bit word the launcher passes on (pointers / integers only)."""
+    if a is None: return 0
+    if isinstance(a, int): return a & 0xFFFFFFFFFFFFFFFF
+    if isinstance(a, (C.c_void_p, C.c_char_p)): return int(a.value or 0)
+    if isinstance(a, (C.c_int, C.c_uint, C.c_int32, C.c_uint32, C.c_int64, C.c_uint64, C.c_long, C.c_ulong, C.c_longlong, C.c_ulonglong, C.c_size_t)): return int(a.value) & 0xFFFFFFFFFFFFFFFF
+    if hasattr(a, '_obj'): return C.addressof(a._obj)          # C.byref(descriptor): the descriptor stays this plan's, later changes of its fields apply
+    if isinstance(a, (C.Structure, C.Array)): raise TypeError('a structure passed by value cannot be re-issued by the launcher')
+    if hasattr(a, 'contents'): return C.cast(a, C.c_void_p).value or 0   # a ctypes pointer
+    raise TypeError(f'launch_async: argument of type {type(a).__name__} is not a pointer or an integer')
+
+  def launch_async(self):
+    """`launch_direct()` issued by the library's launcher thread (il_launcher_*): the two recorded branches - and an attached ActingWorker's append before / parameter
+    snapshot after them - go out in the recorded order while the caller returns at once (~1 us on this thread instead of the ~20 us of launch work), e.g. to post the next
+    observation and step the environment (profiles/r06_acting.json). Call `launcher_wait()` (or `join()`) before synchronising a stream, reading a result, or issuing
+    anything else of this learner: a device synchronisation only waits for what has been ISSUED. Same launches in the same order as `launch_direct()`: bit-identical
+    (test_launcher_thread_issues_the_recorded_update)."""
+    self._raise_if_poisoned()
+    L = _lib.lib()
+    recorded = getattr(self, '_launcher_of', (None, None))
+    if getattr(self, '_launcher', None) is None or recorded[0] is not self._direct_side or recorded[1] is not self._direct_main:
+      assert getattr(self, '_direct_main', None) is not None, 'launch_async: record_direct() first'
+      assert not self._direct_overlap, 'launch_async: the overlapped schedule joins streams on the host after every update; use launch_direct()'
+      if getattr(self, '_launcher', None) is None:
+        h = C.c_void_p()
+        _lib.check(L.il_launcher_create(C.byref(h)))
+        self._launcher = h
+        import weakref
+        weakref.finalize(self, lambda hv=h.value: L.il_launcher_destroy(C.c_void_p(hv)))
+      _lib.check(L.il_launcher_clear(self._launcher))
+      for fn, args in self._direct_side + self._direct_main:
+        if any(t is C.c_float or t is C.c_double for t in (fn.argtypes or ())):
+          raise NotImplementedError(f'launch_async: {fn.__name__} takes floating-point arguments; the launcher re-issues integer / pointer arguments only (use launch_direct)')
+        words = (C.c_uint64 * 16)(*[self._word(a) for a in args])
+        _lib.check(L.il_launcher_add(self._launcher, C.cast(fn, C.c_void_p), words, len(args)))
+      self._launcher_of = (self._direct_side, self._direct_main)
+    if self.main_feeds_ring and self._captured_resident:
+      self.side.wait_stream(torch.cuda.current_stream())   # (as launch_direct(): appends enqueued since the last update precede the resident index draw)
+    _lib.check(L.il_launcher_submit(self._launcher))
+
+  def launcher_wait(self):
+    """Every update submitted with `launch_async()` has been issued to its streams (raises if a recorded call failed)."""
+    if getattr(self, '_launcher', None) is not None:
+      _lib.check(_lib.lib().il_launcher_wait(self._launcher))
+
   def join(self):
     """Order the caller's stream after the plan's second stream: `replay()` leaves the two branches unjoined (no edge between the graphs), so anything the caller reads
     on its own stream that the other branch wrote - the discriminator's parameters / buffers for a checkpoint, the rewards on the fallback schedules - needs this first."""
+    self.launcher_wait()
     if self.side is not None:
       torch.cuda.current_stream().wait_stream(self.side)
     if self._ov_active:
@@ -1221,6 +1271,7 @@ class UpdatePlan:
 
   def replay(self):
     self._raise_if_poisoned()
+    self.launcher_wait()
     self._ov_leave()
     if self.graph_side is not None:
       if self.main_feeds_ring and self._captured_resident:

@@ -717,6 +717,21 @@ int il_sac_update_gather_peer(const il_sac* d, const il_batch* rows, const il_ba
 int il_gail_disc_step_draw_peer(const il_disc* d, const il_batch* policy, const il_batch* expert, uint32_t* mt_state_dev, const int64_t* ring_state_a, int32_t* idx_a,
                                 const int64_t* ring_state_b, int32_t* idx_b, uint32_t flags, const il_peer_bucket* peer, il_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Launcher thread (round 6). The reference's loop (train.py:151-203) acts, steps the environment, appends and updates one after the other on one host thread; with the
+ * update fused into two library calls its ~20 us of launch work were what stood between two environment steps. An il_launcher re-issues RECORDED calls - entry points of
+ * this ABI with their arguments (pointers / integers only, <= 16; descriptors by reference) - from a thread of the library: il_launcher_submit returns at once, the calls go
+ * out in recorded order, one pass per submit, passes in submission order. il_launcher_wait: every submitted pass has been ISSUED (synchronise the streams afterwards to wait
+ * for the kernels); both return the sticky status of the recorded calls (il_last_error carries the failing call's text). The thread uses the device that was current at
+ * il_launcher_create. Python: UpdatePlan.launch_async() / launcher_wait(). */
+int il_launcher_create(void** out);
+int il_launcher_destroy(void* launcher);
+int il_launcher_clear(void* launcher);
+int il_launcher_add(void* launcher, void* entry_point, const uint64_t* args_host, int32_t nargs);
+int il_launcher_submit(void* launcher);
+int il_launcher_wait(void* launcher);
+int64_t il_launcher_pending(void* launcher);
+
 /* sizeof() of the descriptor structs in this build (0 il_batch, 1 il_adam, 2 il_sac, 3 il_disc, 4 il_pwil, 5 il_sample_args, 6 il_red,
  * 7 il_dril, 8 il_disc_shaped, 9 il_disc_deep, 10 il_peer_bucket, 11 il_disc_shaped_deep; -1 otherwise): lets a binding verify its own struct definitions. */
 int32_t il_struct_size(int32_t which);

@@ -13,14 +13,14 @@ import imitation_learning_amd as il  # noqa: E402
 from imitation_learning_amd.environments import make_env  # noqa: E402
 
 
-def loop(schedule, plan, actor, memory, env, steps, update, early_act=True, direct=True):
+def loop(schedule, plan, actor, memory, env, steps, update, early_act=True, direct=True, thread=False):
   worker = il.ActingWorker(actor, memory, mirror=schedule == 'overlap') if schedule != 'per_function' else None
   step_update = plan.replay
   if schedule == 'overlap' and update:   # the update with this worker's append before and its snapshot after: recorded as direct launches (round 6), or re-captured as graphs
     plan.graph = plan.graph_side = None; plan.pre_hooks.clear(); plan.post_hooks.clear()
     worker.attach(plan)
     if direct and plan.direct_launch_ok():
-      plan.record_direct(); step_update = plan.launch_direct
+      plan.record_direct(); step_update = plan.launch_async if thread else plan.launch_direct
     else:
       plan.capture(warmup=0)
   state, t = env.reset(), 0
@@ -51,6 +51,7 @@ def loop(schedule, plan, actor, memory, env, steps, update, early_act=True, dire
     if schedule == 'overlap' and early_act: worker.act_begin(state)   # (round 6) the act launch ahead of the update's host work: its turn-around hides behind the replay
     if update: step_update()
     if schedule == 'overlap': action = worker.act_end() if early_act else worker.act(state)
+  plan.launcher_wait()
   torch.cuda.synchronize()
   return steps / (time.perf_counter() - t0)
 
@@ -73,6 +74,8 @@ def main():
     for schedule in ('per_function', 'exact', 'fused', 'overlap'):
       loop(schedule, plan, actor, memory, env, 200, update)
       out[f'{schedule}{"+update" if update else ""}'] = round(loop(schedule, plan, actor, memory, env, 3000, update), 1)
+  loop('overlap', plan, actor, memory, env, 200, True, thread=True)
+  out['overlap+update (launcher thread: UpdatePlan.launch_async)'] = round(loop('overlap', plan, actor, memory, env, 3000, True, thread=True), 1)
   loop('overlap', plan, actor, memory, env, 200, True, direct=False)
   out['overlap+update (graph replays instead of direct launches)'] = round(loop('overlap', plan, actor, memory, env, 3000, True, direct=False), 1)
   loop('overlap', plan, actor, memory, env, 200, True, early_act=False, direct=False)

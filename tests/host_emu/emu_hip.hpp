@@ -525,6 +525,7 @@ typedef void* hipEvent_t;
 struct hipDeviceProp_t { char gcnArchName[64]; int multiProcessorCount; };
 enum { hipMemcpyDeviceToHost = 2, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToDevice = 3, hipDeviceAttributeMultiprocessorCount = 63 };
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }   // (csrc/launcher.hip's thread makes the caller's device current; the launcher itself is not driven on the emulator: its fibers are not thread-safe)
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { strcpy(p->gcnArchName, "host-emulation"); p->multiProcessorCount = 256; return hipSuccess; }
 inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 256; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { emu::drain(); return hipSuccess; }

@@ -309,6 +309,33 @@ def test_direct_launches_equal_the_graph_replays(K=6, seed=9, expect_overlap=Fal
     np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.gpu
+def test_launcher_thread_issues_the_recorded_update(K=40, seed=13):
+  """UpdatePlan.launch_async (round 6, csrc/launcher.hip): the recorded branches re-issued by a thread of the library - the caller returns at once - are the launches of
+  launch_direct in the same order: every persistent tensor and per-update output keeps its bits; a host synchronisation needs launcher_wait() / join() first; run(),
+  replay() and launch_direct() drain the launcher before they issue anything themselves."""
+  finals = []
+  for mode in ('direct', 'async', 'mixed'):
+    il_training._NOISE.clear(); il_training._WS.clear()
+    plan, nets, _ = bench.build(torch.device(DEV), 0, seed=seed)
+    for _ in range(2): plan.run()
+    torch.cuda.synchronize()
+    plan.record_direct()
+    for k in range(K):
+      if mode == 'direct' or (mode == 'mixed' and k % 7 == 3): plan.launch_direct()
+      elif mode == 'mixed' and k % 7 == 5: plan.run()
+      else: plan.launch_async()
+    plan.join()
+    assert int(_lib.lib().il_launcher_pending(plan._launcher)) == 0 if mode != 'direct' else True
+    torch.cuda.synchronize()
+    assert plan.sync_timeouts() == 0 and not plan.poisoned()
+    finals.append([N(n.flat if hasattr(n, 'flat') else n) for n in nets] + [N(plan.logp), N(plan.q), N(plan.rewards), N(plan.idx), N(plan.eidx)])
+  for other in finals[1:]:
+    for a, b in zip(finals[0], other):
+      assert np.isfinite(a).all()
+      np.testing.assert_array_equal(a, b)
+
+
 def test_side_stream_workgroups_never_share_a_cu_with_a_pair_workgroup():
   """DESIGN.md 3.2 "whole-CU LDS": the pair-mode kernels ask for 160 KB of LDS and k_gail_reduce for 1 KB it never touches so that the dispatcher cannot co-locate a
   workgroup of the discriminator branch with a pair workgroup (whose weight stream its loads would queue behind: the first pair build LOST 4 % to exactly that). The

@@ -221,7 +221,9 @@ def train(cfg, file_prefix: str = '') -> float:
         action = worker.step(step, next_state, reward, terminal and not timed_out, timed_out, obs=following)
       else:
         worker.post(step, state, action, next_state, reward, terminal and not timed_out, timed_out)
-        if not (update_due and plan is not None): worker.enqueue_append()   # otherwise the update graph carries it
+        if not (update_due and plan is not None):
+          if plan is not None: plan.launcher_wait()   # (an update handed to the launcher thread is issued before this append)
+          worker.enqueue_append()   # otherwise the update graph carries it
     train_return += reward
     if terminal:
       if cfg.algorithm == 'PWIL': discriminator.reset()
@@ -249,7 +251,10 @@ def train(cfg, file_prefix: str = '') -> float:
             # one GPU, the two-branch schedule: the update's six launches issued directly (two library calls per update). A hipGraph replay costs ~4.5 us more between
             # two updates than the launch boundary of the same kernels (profiles/r05_launch_ab.txt); IL_TRAIN_LAUNCH=graph keeps the graphs
             plan.record_direct()
-            step_update = plan.launch_direct
+            # (round 6) +acting.schedule=overlap: the recorded launches go out from the library's launcher thread (UpdatePlan.launch_async) while this thread posts the next
+            # observation and steps the environment; every host-side read / launch of this learner below drains the launcher first. IL_TRAIN_LAUNCH_THREAD=0: this thread.
+            use_thread = schedule == 'overlap' and not plan._direct_overlap and os.environ.get('IL_TRAIN_LAUNCH_THREAD', '1') != '0'
+            step_update = plan.launch_async if use_thread else plan.launch_direct
           elif runner is not plan and runner.direct_launch_ok() and os.environ.get('IL_TRAIN_LAUNCH', 'direct') != 'graph':
             runner.record_direct()   # (round 6) data parallel with the exchanges inside the optimiser launches: the launch sequence of one GPU, issued the same way
             step_update = runner.launch_direct
@@ -300,6 +305,7 @@ def train(cfg, file_prefix: str = '') -> float:
     if dog is not None and step % cfg.evaluation.interval == 0 and not cfg.check_time_usage:   # every rank: rank 0 evaluates, its peers wait for it inside their next collective
       dog.grace(0.005 * cfg.evaluation.episodes * env.max_episode_steps, 'evaluation')
     if step % cfg.evaluation.interval == 0 and not cfg.check_time_usage and lead:
+      if plan is not None: plan.launcher_wait()
       episode_returns = evaluate_agent(actor, eval_env, cfg.evaluation.episodes)
       normalised = normalise(episode_returns)
       score.append(float(normalised.mean()))
