@@ -1149,6 +1149,7 @@ class UpdatePlan:
     reference, so later changes of their fields (watch_timeouts, widen_handoff_bound) apply, unlike in a captured graph."""
     assert self.direct_launch_ok(), 'record_direct: the device hand-off schedule (two unjoined branches; hooks that are library calls) only'
     assert self._prepared, 'record_direct: run() at least one update first'
+    self.launcher_wait()   # (passes of an earlier recording handed to the launcher thread go out before the descriptors are walked again)
     self.memory.stream().device_state(self.rows.device)
 
     class Recorder:
@@ -1158,7 +1159,7 @@ class UpdatePlan:
         # a LAUNCH is an il_* entry point that returns a status and takes the stream as its last argument; everything else (size / layout / grid queries - which are
         # c_int32 = c_int on this platform and were swallowed by the first form of this recorder -, host-side reads) is answered by the library itself
         args_t = getattr(fn, 'argtypes', None) or ()
-        if not (name.startswith('il_') and fn.restype is C.c_int and len(args_t) > 0 and args_t[-1] is _lib._P):
+        if not (name.startswith('il_') and not name.startswith('il_launcher_') and fn.restype is C.c_int and len(args_t) > 0 and args_t[-1] is _lib._P):
           return fn
         def call(*args):
           self.calls.append((fn, args))
@@ -1248,7 +1249,7 @@ class UpdatePlan:
 
   def launcher_wait(self):
     """Every update submitted with `launch_async()` has been issued to its streams (raises if a recorded call failed)."""
-    if getattr(self, '_launcher', None) is not None:
+    if getattr(self, '_launcher', None) is not None and not getattr(self, '_recording', False):   # (record_direct walks run() with a recording stand-in for the library: nothing of the launcher's own belongs in a recorded pass)
       _lib.check(_lib.lib().il_launcher_wait(self._launcher))
 
   def join(self):

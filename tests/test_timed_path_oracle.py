@@ -321,6 +321,10 @@ def test_launcher_thread_issues_the_recorded_update(K=40, seed=13):
     for _ in range(2): plan.run()
     torch.cuda.synchronize()
     plan.record_direct()
+    if mode != 'direct':   # a second recording while a launcher exists: nothing of the launcher's own may end up in the recorded pass
+      plan.launch_async(); plan.record_direct(); plan.launch_direct()
+    else:
+      plan.launch_direct(); plan.launch_direct()
     for k in range(K):
       if mode == 'direct' or (mode == 'mixed' and k % 7 == 3): plan.launch_direct()
       elif mode == 'mixed' and k % 7 == 5: plan.run()
