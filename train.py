@@ -251,9 +251,11 @@ def train(cfg, file_prefix: str = '') -> float:
             # one GPU, the two-branch schedule: the update's six launches issued directly (two library calls per update). A hipGraph replay costs ~4.5 us more between
             # two updates than the launch boundary of the same kernels (profiles/r05_launch_ab.txt); IL_TRAIN_LAUNCH=graph keeps the graphs
             plan.record_direct()
-            # (round 6) +acting.schedule=overlap: the recorded launches go out from the library's launcher thread (UpdatePlan.launch_async) while this thread posts the next
-            # observation and steps the environment; every host-side read / launch of this learner below drains the launcher first. IL_TRAIN_LAUNCH_THREAD=0: this thread.
-            use_thread = schedule == 'overlap' and not plan._direct_overlap and os.environ.get('IL_TRAIN_LAUNCH_THREAD', '1') != '0'
+            # (round 6) IL_TRAIN_LAUNCH_THREAD=1 with +acting.schedule=overlap: the recorded launches go out from the library's launcher thread (UpdatePlan.launch_async) while
+            # this thread posts the next observation and steps the environment; every host-side read / launch of this learner below drains the launcher first. Opt-in: it pays
+            # when an environment step costs more than the act launch's turn-around (a real simulator); on the synthetic environment it measured 10.3k against 11.5k
+            # env-steps/s (profiles/r06_acting.json: the loop is bound by that turn-around, which then has nothing to hide behind).
+            use_thread = schedule == 'overlap' and not plan._direct_overlap and os.environ.get('IL_TRAIN_LAUNCH_THREAD', '0') == '1'
             step_update = plan.launch_async if use_thread else plan.launch_direct
           elif runner is not plan and runner.direct_launch_ok() and os.environ.get('IL_TRAIN_LAUNCH', 'direct') != 'graph':
             runner.record_direct()   # (round 6) data parallel with the exchanges inside the optimiser launches: the launch sequence of one GPU, issued the same way
