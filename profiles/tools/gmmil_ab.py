@@ -41,4 +41,10 @@ def case(Bp, Be, Sg, Ag, calls):
   return dict(us_per_call=round(t0.elapsed_time(t1) * 1e3 / calls, 2), kernels_us=kern, digest=digest)
 
 
-print(os.environ.get('IL_HIP_LIBRARY', 'default'), dict(b1024_ant=case(1024, 1024, 112, 8, 300), ragged_200x333=case(200, 333, 18, 6, 100), b256_hc=case(256, 256, 18, 6, 100)), flush=True)
+if os.environ.get('IL_GMMIL_AB_SWEEP') == '1':   # round 6: where the centred Gram launch (IL_GMMIL_MFMA=1) wins over the direct-difference launch: batch x feature sweep
+  for B in (128, 256, 512, 1024, 2048):
+    for Sg, Ag in ((18, 6), (112, 8)):
+      r = case(B, B, Sg, Ag, 200)
+      print(f"IL_GMMIL_MFMA={os.environ.get('IL_GMMIL_MFMA', '1')} B={B} D={Sg + Ag}: kernel {r['kernels_us'].get('k_gmmil_tile')} us, {r['us_per_call']} us per call", flush=True)
+else:
+  print(os.environ.get('IL_HIP_LIBRARY', 'default'), dict(b1024_ant=case(1024, 1024, 112, 8, 300), ragged_200x333=case(200, 333, 18, 6, 100), b256_hc=case(256, 256, 18, 6, 100)), flush=True)
