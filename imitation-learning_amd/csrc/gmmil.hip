@@ -42,13 +42,14 @@ struct GmmilExp { float c1, c2; };
 __host__ __device__ inline GmmilExp gmmil_exp_consts(float g1, float g2, int D) { return GmmilExp{-g1 * 1.44269504088896340736f / (float)D, -g2 * 1.44269504088896340736f / (float)D}; }
 __device__ __forceinline__ float gmmil_pair_kernel(float ssq, const GmmilExp& e) { return __builtin_amdgcn_exp2f(ssq * e.c1) + __builtin_amdgcn_exp2f(ssq * e.c2); }
 
-struct GmmilWs { int64_t xt, et, wn, wen, part, ctr, total; int b1p, b2p, njt; };
+struct GmmilWs { int64_t xt, et, wn, wen, part, ctr, part2, total; int b1p, b2p, njt; };
 __host__ __device__ inline GmmilWs gmmil_ws(int n1, int n2, int D) {
   GmmilWs w; w.b1p = (n1 + GTR - 1) / GTR * GTR; w.b2p = (n2 + GT - 1) / GT * GT;   // policy rows: whole row tiles (GTR is a multiple of GT); padded rows / columns carry weight 0
   const int nj1 = w.b2p / GT, nj2 = w.b1p / GT; w.njt = nj1 > nj2 ? nj1 : nj2;
   int64_t o = 0;
   w.xt = o; o += (int64_t)D * w.b1p; w.et = o; o += (int64_t)D * w.b2p; w.wn = o; o += w.b1p; w.wen = o; o += w.b2p;
   w.part = o; o += (int64_t)2 * w.njt * w.b1p; w.ctr = o; o += (int64_t)(w.b1p / 32) * GCTR;   // arrival counter per row tile (64 rows; k_gmmil_sx: 32 rows), one 128-byte line each (zeroed by k_gmmil_pack)
+  w.part2 = o; o += (int64_t)((w.b2p + 31) / 32 + (w.b1p + 31) / 32) * w.b1p;   // k_gmmil_mfma: one partial row sum per (column block of >= 32, row)
   w.total = o;
   return w;
 }
@@ -865,10 +866,9 @@ static int gmmil_sx_on(int S, int A, int D, int state_only, int lanes) {   // IL
 // B = 1024, D = 120 (padded to 128) against 0.755 on the VALU. Partial row sums, arrival ticket and the last arriver's block-ordered sums as in k_gmmil_sx.
 // ---------------------------------------------------------------------------------------------
 #define GMF_ROWS 64
-#define GMF_COLS 128
-template <int NKQ> struct GmfLds {   // floats
+template <int NKQ, int COLS> struct GmfLds {   // floats
   static constexpr int DP = 16 * NKQ, LD = DP + 4;
-  static constexpr int ys = 0, cs = ys + GMF_COLS * LD, cpart = cs + DP, nyh = cpart + 8 * DP, wys = nyh + 2 * GMF_COLS, nxs = wys + GMF_COLS, red = nxs + GMF_ROWS, ps = red + 64, total = ps + GMF_ROWS;
+  static constexpr int ys = 0, cs = ys + COLS * LD, cpart = cs + DP, nyh = cpart + 8 * DP, wys = nyh + 256, nxs = wys + COLS, red = nxs + GMF_ROWS, ps = red + 64, total = ps + GMF_ROWS;
 };
 // features k .. k + 3 (k % 4 == 0) of row r of the concatenated [states | actions] batch as ONE branch-free request per 16-byte lane (LANES: whole lanes along the rows, S and A
 // multiples of 4) or four dword requests: the side of the concatenation is a select on the ADDRESS (a select on the loaded value makes hipcc branch around each load and wait
@@ -905,11 +905,11 @@ __device__ __forceinline__ float gmf_weight_share(const il_batch& b, int tid, co
   for (int i = 1024 + tid; i < b.n; i += 256) s += gload(b.weights + (size_t)i * b.ld_weights);
   return s;
 }
-template <int NKQ, bool LANES>
+template <int NKQ, bool LANES, int COLS>
 __global__ __launch_bounds__(256) void k_gmmil_mfma(il_batch pol, il_batch exp, int S, int D, float g1, float g2, float* __restrict__ ws_,
                                                     float* __restrict__ out_r, float* __restrict__ out_sim, float* __restrict__ out_self) {
-  using L = GmfLds<NKQ>;
-  constexpr int DP = L::DP, LD = L::LD, NQ = DP / 4, HQ = NQ / 2;
+  using L = GmfLds<NKQ, COLS>;
+  constexpr int DP = L::DP, LD = L::LD, NQ = DP / 4, YP = 256 / COLS, HQ = NQ / YP;   // a column's features are split over YP threads, HQ 16-byte lanes each
   extern __shared__ __attribute__((aligned(16))) float smem[];
   IL_ST_BEGIN(IL_ST_GMMIL);
   IL_TL(2, 0);
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(256) void k_gmmil_mfma(il_batch pol, il_batch exp, 
   globalize(pol); globalize(exp);
   const int n1 = pol.n, n2 = exp.n;
   const GmmilWs w = gmmil_ws(n1, n2, D);
-  const int nE = (w.b2p + GMF_COLS - 1) / GMF_COLS, nX = (w.b1p + GMF_COLS - 1) / GMF_COLS;
+  const int nE = (w.b2p + COLS - 1) / COLS, nX = (w.b1p + COLS - 1) / COLS;
   // workgroup -> (row block, column block): consecutive workgroup ids go to the eight XCDs in turn, so the 32 workgroups an XCD hosts of every 256 are given an 8 x 4 patch
   // of the block grid - its L2 then fetches 8 row blocks + 4 column blocks instead of 2 row blocks + every column block (1 MB -> 0.5 MB per XCD at B = 1024)
   const int nI = w.b1p / GMF_ROWS, nJ = nE + nX;
@@ -944,9 +944,9 @@ __global__ __launch_bounds__(256) void k_gmmil_mfma(il_batch pol, il_batch exp, 
   const int cq = tid & 31, cg = tid >> 5;
   if (cq < NQ) cv = gmf_load<LANES>(exp, S, D, (int)(((long long)cg * n2) >> 3), 4 * cq);
   const GmfW4 wx4 = gmf_weight_req(pol, tid), wy4 = gmf_weight_req(yb, tid);
-  float wv = gload(yb.weights + (size_t)min(jb * GMF_COLS + (tid & (GMF_COLS - 1)), ny - 1) * yb.ld_weights);
-  wv = jb * GMF_COLS + (tid & (GMF_COLS - 1)) < ny ? wv : 0.f;
-  const int ycol = tid & (GMF_COLS - 1), yhalf = tid >> 7, yrow = jb * GMF_COLS + ycol;
+  float wv = gload(yb.weights + (size_t)min(jb * COLS + (tid & (COLS - 1)), ny - 1) * yb.ld_weights);
+  wv = jb * COLS + (tid & (COLS - 1)) < ny ? wv : 0.f;
+  const int ycol = tid & (COLS - 1), yhalf = tid / COLS, yrow = jb * COLS + ycol;
   f32x4 yq[HQ];
 #pragma unroll
   for (int u = 0; u < HQ; ++u) yq[u] = gmf_load<LANES>(yb, S, D, min(yrow, ny - 1), 4 * (yhalf * HQ + u));
@@ -993,8 +993,8 @@ __global__ __launch_bounds__(256) void k_gmmil_mfma(il_batch pol, il_batch exp, 
       nyp = sumsq(nyp, v);
       *reinterpret_cast<f32x4*>(&Ys[ycol * LD + k]) = v;
     }
-    nyh[yhalf * GMF_COLS + ycol] = nyp;
-    if (tid < GMF_COLS) wys[tid] = wv / sy;
+    nyh[yhalf * COLS + ycol] = nyp;
+    if (tid < COLS) wys[tid] = wv / sy;
     float nxp = 0.f;
 #pragma unroll
     for (int q = 0; q < NKQ; ++q) {
@@ -1025,7 +1025,10 @@ __global__ __launch_bounds__(256) void k_gmmil_mfma(il_batch pol, il_batch exp, 
   };
   auto finish = [&](int ct, const f32x4& acc) {   // lane: rows 4 g + r of the wave's 16, column 16 ct + l16 of the workgroup's 128
     const int c = ct * 16 + l16;
-    const float nyv = nyh[c] + nyh[GMF_COLS + c], wyv = wys[c];
+    float nyv = nyh[c];
+#pragma unroll
+    for (int q = 1; q < YP; ++q) nyv += nyh[q * COLS + c];
+    const float wyv = wys[c];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float ssq = fmaxf(__builtin_fmaf(-2.f, acc[r], nx4[r] + nyv), 0.f);
@@ -1035,12 +1038,12 @@ __global__ __launch_bounds__(256) void k_gmmil_mfma(il_batch pol, il_batch exp, 
   f32x4 a0, a1, p0, p1;
   gram2(0, p0, p1);
 #pragma unroll
-  for (int ct = 2; ct < GMF_COLS / 16; ct += 2) {
+  for (int ct = 2; ct < COLS / 16; ct += 2) {
     gram2(ct, a0, a1);
     finish(ct - 2, p0); finish(ct - 1, p1);
     p0 = a0; p1 = a1;
   }
-  finish(GMF_COLS / 16 - 2, p0); finish(GMF_COLS / 16 - 1, p1);
+  finish(COLS / 16 - 2, p0); finish(COLS / 16 - 1, p1);
   IL_TL(2, 5);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -1050,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_gmmil_mfma(il_batch pol, il_batch exp, 
   __syncthreads();
   if (tid < GMF_ROWS / 2) {   // the workgroup's 64 partial row sums leave as agent-scope atomic exchanges (executed at the memory side, like the arrival ticket)
     const unsigned long long v = *reinterpret_cast<const unsigned long long*>(ps + 2 * tid);
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(ws_ + w.part + (((int64_t)mat * w.njt + jb) * w.b1p + it * GMF_ROWS + 2 * tid));
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(ws_ + w.part2 + ((int64_t)jy * w.b1p + it * GMF_ROWS + 2 * tid));
     (void)__hip_atomic_exchange(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   unsigned* lastp = reinterpret_cast<unsigned*>(red + 32);
@@ -1069,27 +1072,27 @@ __global__ __launch_bounds__(256) void k_gmmil_mfma(il_batch pol, il_batch exp, 
   if (*lastp != 0u && tid < GMF_ROWS && i < n1) {
     auto ordered_sum = [&](const float* p, int nq) {
       float s = 0.f;
-      for (int q0 = 0; q0 < nq; q0 += 8) {
-        float v[8];
+      for (int q0 = 0; q0 < nq; q0 += 16) {
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = sload1(p, (int64_t)min(q0 + u, nq - 1) * w.b1p + i);
+        for (int u = 0; u < 16; ++u) v[u] = sload1(p, (int64_t)min(q0 + u, nq - 1) * w.b1p + i);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (q0 + u < nq) s += v[u];
+        for (int u = 0; u < 16; ++u) if (q0 + u < nq) s += v[u];
       }
       return s;
     };
+    const float* p0 = ws_ + w.part2; const float* p1 = p0 + (size_t)nE * w.b1p;
     float s0, s1;
     if (nE <= 8 && nX <= 8) {   // both matrices' partials requested together: one trip to memory instead of two behind each other
       float v0[8], v1[8];
-      const float* p1 = ws_ + w.part + (size_t)w.njt * w.b1p;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { v0[u] = sload1(ws_ + w.part, (int64_t)min(u, nE - 1) * w.b1p + i); v1[u] = sload1(p1, (int64_t)min(u, nX - 1) * w.b1p + i); }
+      for (int u = 0; u < 8; ++u) { v0[u] = sload1(p0, (int64_t)min(u, nE - 1) * w.b1p + i); v1[u] = sload1(p1, (int64_t)min(u, nX - 1) * w.b1p + i); }
       s0 = 0.f; s1 = 0.f;
 #pragma unroll
       for (int u = 0; u < 8; ++u) { if (u < nE) s0 += v0[u]; if (u < nX) s1 += v1[u]; }
     } else {
-      s0 = ordered_sum(ws_ + w.part, nE);
-      s1 = ordered_sum(ws_ + w.part + (size_t)w.njt * w.b1p, nX);
+      s0 = ordered_sum(p0, nE);
+      s1 = ordered_sum(p1, nX);
     }
     const float wi = pol.weights[(size_t)i * pol.ld_weights] / sx;
     const float sim = wi * s0, self = wi * s1;
@@ -1103,22 +1106,40 @@ static int gmmil_mfma_on(int D) {   // IL_GMMIL_MFMA=0: the direct-difference la
   static const int on = [] { const char* e = getenv("IL_GMMIL_MFMA"); return e && e[0] == '0' ? 0 : 1; }();
   return on != 0 && D >= 1 && D <= 128;
 }
-template <int NKQ, bool LANES>
+template <int NKQ, bool LANES, int COLS>
 static int gmmil_mfma_launch_(const il_batch* pol, const il_batch* exp, int S, int D, float g1, float g2, float* workspace, float* out_r, float* out_sim, float* out_self, hipStream_t st) {
   const GmmilWs w = gmmil_ws(pol->n, exp->n, D);
-  const size_t lds = (size_t)GmfLds<NKQ>::total * sizeof(float);
-  if (int rc = gmmil_ensure_lds((k_gmmil_mfma<NKQ, LANES>), lds)) return rc;
-  const int nE = (w.b2p + GMF_COLS - 1) / GMF_COLS, nX = (w.b1p + GMF_COLS - 1) / GMF_COLS;
+  const size_t lds = (size_t)GmfLds<NKQ, COLS>::total * sizeof(float);
+  auto kern = k_gmmil_mfma<NKQ, LANES, COLS>;   // (one identifier: the host emulator's launch macro splits its arguments at commas)
+  if (int rc = gmmil_ensure_lds(kern, lds)) return rc;
+  const int nE = (w.b2p + COLS - 1) / COLS, nX = (w.b1p + COLS - 1) / COLS;
   IL_TRACE("k_gmmil_tile", st);
-  auto kern = k_gmmil_mfma<NKQ, LANES>;   // (one identifier: the host emulator's launch macro splits its arguments at commas)
   kern<<<dim3((w.b1p / GMF_ROWS) * (nE + nX), 1, 1), 256, lds, st>>>(*pol, *exp, S, D, g1, g2, workspace, out_r, out_sim, out_self);
   IL_CHECK_LAUNCH("il_gmmil_reward");
   return IL_OK;
 }
+// column block: 128, halved while the grid stays at <= 128 workgroups (B = 1024: 128 -> 256 workgroups; B = 512: 32 -> 256; B = 256: 32 -> 64). IL_GMMIL_COLS=32|64|128 forces one.
+static int gmmil_mfma_cols(const il_batch* pol, const il_batch* exp, int D) {
+  static const int forced = [] { const char* e = getenv("IL_GMMIL_COLS"); const int v = e ? atoi(e) : 0; return (v == 32 || v == 64 || v == 128) ? v : 0; }();
+  if (forced) return forced;
+  const GmmilWs w = gmmil_ws(pol->n, exp->n, D);
+  int cols = 128;
+  while (cols > 32 && (w.b1p / GMF_ROWS) * ((w.b2p + cols / 2 - 1) / (cols / 2) + (w.b1p + cols / 2 - 1) / (cols / 2)) <= 256 &&
+         (w.b1p / GMF_ROWS) * ((w.b2p + cols - 1) / cols + (w.b1p + cols - 1) / cols) <= 128) cols >>= 1;
+  return cols;
+}
+template <int NKQ, bool LANES>
+static int gmmil_mfma_launch_l(const il_batch* pol, const il_batch* exp, int S, int D, float g1, float g2, float* workspace, float* out_r, float* out_sim, float* out_self, hipStream_t st) {
+  switch (gmmil_mfma_cols(pol, exp, D)) {
+    case 32: return gmmil_mfma_launch_<NKQ, LANES, 32>(pol, exp, S, D, g1, g2, workspace, out_r, out_sim, out_self, st);
+    case 64: return gmmil_mfma_launch_<NKQ, LANES, 64>(pol, exp, S, D, g1, g2, workspace, out_r, out_sim, out_self, st);
+    default: return gmmil_mfma_launch_<NKQ, LANES, 128>(pol, exp, S, D, g1, g2, workspace, out_r, out_sim, out_self, st);
+  }
+}
 template <int NKQ>
 static int gmmil_mfma_launch(const il_batch* pol, const il_batch* exp, int S, int D, float g1, float g2, float* workspace, float* out_r, float* out_sim, float* out_self, int lanes, hipStream_t st) {
-  return lanes && D >= 4 ? gmmil_mfma_launch_<NKQ, true>(pol, exp, S, D, g1, g2, workspace, out_r, out_sim, out_self, st)
-                         : gmmil_mfma_launch_<NKQ, false>(pol, exp, S, D, g1, g2, workspace, out_r, out_sim, out_self, st);
+  return lanes && D >= 4 ? gmmil_mfma_launch_l<NKQ, true>(pol, exp, S, D, g1, g2, workspace, out_r, out_sim, out_self, st)
+                         : gmmil_mfma_launch_l<NKQ, false>(pol, exp, S, D, g1, g2, workspace, out_r, out_sim, out_self, st);
 }
 static bool gmmil_direct() { static const int on = [] { const char* e = getenv("IL_GMMIL_DIRECT"); return e && e[0] == '0' ? 0 : 1; }(); return on != 0; }   // IL_GMMIL_DIRECT=0: k_gmmil_pack + k_gmmil_tile (developer A/B; same bits)
 static int gmmil_lanes(const il_batch* a, const il_batch* b, int S, int A, int state_only) {   // whole 16-byte lanes along the rows of both batches?
