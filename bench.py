@@ -191,8 +191,17 @@ def secondary(device, plan, nets):
     return m
   gplan = il.UpdatePlan('GMMIL', a2, c2, la2, t2, ring(100_000, 1_000_000, 0.0), *o2, Bg, 0.99, -1.0 * Ag, 0.995, expert_memory=ring(25_000, 25_000, 0.5),
                         discriminator=il.GMMILDiscriminator(Sg, Ag, Cfg(state_only=False)), learner_id=9002)
-  gplan.run(); gplan.capture(warmup=0)
-  out['gmmil_ant_b1024_updates_per_s'] = round(timed(gplan.replay, 300, 30), 1)
+  gplan.run()
+  if gplan.direct_launch_ok() and os.environ.get('IL_BENCH_LAUNCH', 'direct') != 'graph':   # (round 6) a one-stream plan is library calls only: recorded once, re-issued per update (no hipGraph: a replay costs
+    gplan.record_direct()                                                                    # the replay-to-replay gap and torch.cuda.CUDAGraph's per-replay generator fill, ~11 us of 148)
+    out['gmmil_ant_b1024_updates_per_s'] = round(timed(gplan.launch_direct, 300, 30), 1)
+    out['gmmil_ant_b1024_launch'] = 'direct launches (UpdatePlan.launch_direct)'
+    gplan.capture(warmup=0)
+    out['gmmil_ant_b1024_graph_replays_per_s'] = round(timed(gplan.replay, 300, 30), 1)
+  else:
+    gplan.capture(warmup=0)
+    out['gmmil_ant_b1024_updates_per_s'] = round(timed(gplan.replay, 300, 30), 1)
+    out['gmmil_ant_b1024_launch'] = 'hipGraph replays'
 
   # PWIL: one (state, action) against N = 25,000 standardised expert atoms, D = 24, consumed greedily (models.py:232-249)
   emem = plan.expert_memory
@@ -217,7 +226,11 @@ def secondary(device, plan, nets):
     gb = batch_views(plan.memory.ring[:B].clone(), S, A, True)   # the first B rows of the ring: no index draw (the generator's state is the timed schedule's)
     out['sac_general_shape_depth3_tanh_updates_per_s'] = round(timed(lambda: il.sac_update(ga, gc, gla, gt, gb, gao, gco, gto, 0.97, -0.5 * A, 0.99), 300, 30), 1)
     gplan3 = il.UpdatePlan('SAC', ga, gc, gla, gt, plan.memory, gao, gco, gto, B, 0.97, -0.5 * A, 0.99, learner_id=9003)
-    gplan3.run(); gplan3.capture(warmup=0)
+    gplan3.run()
+    if gplan3.direct_launch_ok():
+      gplan3.record_direct()
+      out['sac_general_shape_depth3_tanh_plan_direct_launches_updates_per_s'] = round(timed(gplan3.launch_direct, 300, 30), 1)
+    gplan3.capture(warmup=0)
     out['sac_general_shape_depth3_tanh_captured_plan_updates_per_s'] = round(timed(gplan3.replay, 300, 30), 1)
   except Exception as e:   # noqa: BLE001
     out['sac_general_shape_depth3_tanh_updates_per_s'] = f'failed: {type(e).__name__}: {e}'[:200]

@@ -1077,7 +1077,7 @@ class UpdatePlan:
     if self.mix_expert:   # models.py:287-290: the first half of every field <- expert rows
       _lib.check(L.il_batch_mix_relabel(_lib.ptr(self.rows), _lib.ptr(self.erows), self.B, m.state_size, m.action_size, self.B // 2, 0, 0, 0, 0.0, 0, st))
     if alg == 'AdRIL':
-      capturing = torch.cuda.is_current_stream_capturing()   # a captured launch reads whatever relabel_args() stored before the replay
+      capturing = torch.cuda.is_current_stream_capturing() or self._recording   # a captured / recorded launch reads whatever relabel_args() stored before it is replayed / re-issued
       assert capturing or self._dyn_set, 'UpdatePlan(AdRIL): call relabel_args(step, memory.num_trajectories) before every update'
       r = self.discriminator
       import numpy as np
@@ -1138,7 +1138,20 @@ class UpdatePlan:
     """record_direct / launch_direct apply: the device hand-off schedule with two unjoined branches and nothing hooked into the update (an ActingWorker attached for
     +acting.schedule=overlap rides in the captured graph instead)."""
     recordable = all(getattr(h, '_il_recordable', False) for h in self.pre_hooks + self.post_hooks)   # (round 6) an ActingWorker's append / publish launches are library calls too
-    return bool(self.device_sync and (self.algorithm == 'GAIL' or self.resident_sampler) and recordable)
+    return bool(recordable and (self._two_branch_schedule() or self._one_stream_recordable()))
+
+  def _two_branch_schedule(self) -> bool:
+    return bool(self.device_sync and (self.algorithm == 'GAIL' or self.resident_sampler))
+
+  def _one_stream_recordable(self) -> bool:
+    """(round 6) The one-stream plans - GMMIL / RED / DRIL / AdRIL, SAC / PWIL with mixed batches or the BC auxiliary step, general actor / critic shapes - are library calls
+    on the caller's stream and nothing else (no torch operation, no stream edge: checked on the GPU by wrapping every tensor factory / fill / copy around run()), so they can be
+    recorded and re-issued like the two-branch schedule. A hipGraph replay of such a plan costs the runtime's replay-to-replay gap (~6 us) AND one fill kernel of
+    torch.cuda.CUDAGraph.replay(), which re-seeds the default generator's graph-safe Philox offset on every replay (5 us on the stream; profiles/r06_gmmil_plan_kernel_stats.md).
+    Not recordable: GAIL on stream dependencies (host-side stream waits between its branches) and the discriminator variants that run torch operations inside the plan."""
+    if self.device_sync or not self.device_index_draw or self.algorithm == 'GAIL': return False
+    if self.algorithm == 'GMMIL' and self.discriminator.gamma_1 is None: return False   # (the first update fixes the bandwidths on the host)
+    return True
 
   def record_direct(self):
     """The two-branch schedule `capture()` records, as DIRECT launches: walks the update's host code once with a recording stand-in for the library (nothing is launched),
@@ -1147,7 +1160,7 @@ class UpdatePlan:
     update here); a direct launch is one AQL packet per kernel (profiles/r05_launch_ab.txt). Run at least one update first (run(): code objects loaded, LDS
     attributes set, lane-ordered weight copies built). The main branch is recorded on the CALLER's current stream and must be launched from it; descriptors are passed by
     reference, so later changes of their fields (watch_timeouts, widen_handoff_bound) apply, unlike in a captured graph."""
-    assert self.direct_launch_ok(), 'record_direct: the device hand-off schedule (two unjoined branches; hooks that are library calls) only'
+    assert self.direct_launch_ok(), 'record_direct: the device hand-off schedule (two unjoined branches) or a one-stream plan of library calls; hooks that are library calls only'
     assert self._prepared, 'record_direct: run() at least one update first'
     self.launcher_wait()   # (passes of an earlier recording handed to the launcher thread go out before the descriptors are walked again)
     self.memory.stream().device_state(self.rows.device)
@@ -1172,7 +1185,13 @@ class UpdatePlan:
       self._ov_enter()   # (a real launch, ahead of the recording: the recorded update is the steady state)
     try:
       self._recording = True
-      for branch in ('side', 'main'):
+      for branch in (('side', 'main') if self._two_branch_schedule() else ('one stream',)):
+        if branch == 'one stream':   # everything on the caller's stream: one recorded list
+          rec = Recorder(real)
+          _lib._lib = rec
+          self.run()
+          out += [[], list(rec.calls)]
+          break
         rec = Recorder(real)
         _lib._lib, self._capturing = rec, branch
         if branch == 'side':
@@ -1183,7 +1202,7 @@ class UpdatePlan:
     finally:
       _lib._lib, self._capturing, self._recording = real, None, False
     self._direct_side, self._direct_main = out
-    self._captured_resident = self.resident_sampler
+    self._captured_resident = self.resident_sampler if self._two_branch_schedule() else False
     self._direct_overlap = bool(self._ov_active)
     return self
 

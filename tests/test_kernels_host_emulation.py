@@ -626,6 +626,21 @@ def test_data_parallel_bc_aux_on_the_emulated_kernels(monkeypatch, algorithm, mi
   tp.test_data_parallel_bc_aux_equals_the_plain_plan_on_one_rank(algorithm, mixed)
 
 
+@pytest.mark.parametrize('algorithm,mixed,bc_aux,kw', [('GMMIL', True, False, {}), ('RED', True, True, {}), ('DRIL', False, False, {}), ('AdRIL', False, False, dict(balanced=True)), ('SAC', False, True, {})])
+def test_one_stream_plans_as_direct_launches_on_the_emulated_kernels(monkeypatch, algorithm, mixed, bc_aux, kw):
+  """tests/test_update_plans_gpu.py::test_one_stream_plans_as_direct_launches_equal_the_per_function_sequence: the one-stream plans recorded once and re-issued as library calls
+  (no hipGraph), bit-identical to the per-function sequence of train.py."""
+  tgp = _emulated_product(monkeypatch, streams=True)
+  import gpu_util
+  import test_update_plans_gpu as tp
+  from imitation_learning_amd import training as il_training
+  for k in ('DEV', 'N', 'Cfg', 'fill_memory'):
+    monkeypatch.setattr(tp, k, getattr(gpu_util, k), raising=False)
+  for k, v in (('il', tgp.il), ('_lib', _lib), ('il_training', il_training)):
+    monkeypatch.setattr(tp, k, v, raising=False)
+  tp.test_plan_of_every_algorithm_equals_the_per_function_sequence(algorithm, mixed, bc_aux, kw, launch='direct')
+
+
 @pytest.mark.parametrize('algorithm,mixed,bc_aux,nets_name', [('SAC', False, True, 'd3_tanh'), ('GMMIL', True, False, 'mixed'), ('AdRIL', False, False, 'mixed')])
 def test_general_shape_update_plan_on_the_emulated_kernels(monkeypatch, algorithm, mixed, bc_aux, nets_name):
   """UpdatePlan for actor / critic shapes outside the fused kernels (csrc/general.hip on one stream, captured as one graph): bit-identical to the per-function sequence."""

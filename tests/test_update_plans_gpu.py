@@ -102,7 +102,7 @@ CASES = [('GMMIL', False, False, {}), ('GMMIL', True, False, {}), ('RED', False,
 
 
 @pytest.mark.parametrize('algorithm,mixed,bc_aux,kw', CASES)
-def test_plan_of_every_algorithm_equals_the_per_function_sequence(algorithm, mixed, bc_aux, kw):
+def test_plan_of_every_algorithm_equals_the_per_function_sequence(algorithm, mixed, bc_aux, kw, launch='graph'):
   K, step0 = 5, 2400   # AdRIL: steps 2400.. straddle a round boundary of update_freq = 1250 (rows are stamped 1..3000)
   nets, opts, mem, emem, disc = build(algorithm, 11, **kw)
   want = [per_function_update(algorithm, nets, opts, mem, emem, disc, step0 + 37 * k, mixed, bc_aux) for k in range(K)]
@@ -116,9 +116,15 @@ def test_plan_of_every_algorithm_equals_the_per_function_sequence(algorithm, mix
   for k in range(K):
     if algorithm == 'AdRIL': plan.relabel_args(step0 + 37 * k, mem.num_trajectories)
     if k == 0:
-      plan.run(); plan.capture(warmup=0)    # first update eagerly (GMMIL: fixes the bandwidths), the rest as graph replays
+      plan.run()    # first update eagerly (GMMIL: fixes the bandwidths), the rest as graph replays - or, launch='direct' (round 6), as recorded library calls re-issued on this stream
+      if launch == 'direct':
+        assert plan.direct_launch_ok()
+        plan.record_direct()
+        assert (plan._direct_side == [] and len(plan._direct_main) >= 2) if not plan.device_sync else len(plan._direct_side) == 1   # one stream: one list; SAC / PWIL: the resident draw on the second stream
+      else:
+        plan.capture(warmup=0)
     else:
-      plan.replay()
+      (plan.launch_direct if launch == 'direct' else plan.replay)()
     torch.cuda.synchronize()
     got.append((plan.transitions['rewards'].clone(), plan.logp.clone(), plan.q.clone()))
   for k, (w, g) in enumerate(zip(want, got)):
@@ -132,6 +138,13 @@ def test_plan_of_every_algorithm_equals_the_per_function_sequence(algorithm, mix
     assert disc.gamma_1 is not None and disc.gamma_2 is not None
   if algorithm == 'DRIL':
     r = N(got[-1][0]); assert set(np.unique(r)) <= {-1.0, 1.0} and 0 < (r > 0).mean() < 1, 'the threshold should split the batch'
+
+
+@pytest.mark.parametrize('algorithm,mixed,bc_aux,kw', [c for c in CASES if c[0] != 'GAIL'])
+def test_one_stream_plans_as_direct_launches_equal_the_per_function_sequence(algorithm, mixed, bc_aux, kw):
+  """UpdatePlan.record_direct / launch_direct for the one-stream plans (round 6): GMMIL, RED, DRIL, AdRIL / SQIL, PWIL, SAC with the BC auxiliary step - library calls on the
+  caller's stream and nothing else - re-issued without a hipGraph: bit-identical to the per-function sequence, like the graph replays."""
+  test_plan_of_every_algorithm_equals_the_per_function_sequence(algorithm, mixed, bc_aux, kw, launch='direct')
 
 
 @pytest.mark.parametrize('algorithm,mixed', [('SAC', False), ('RED', True), ('DRIL', False)])
