@@ -106,6 +106,9 @@ print('population', p['learners'], p['groups'], p['aggregate_updates_per_s'], p[
       cat $OUT/ab_gmmil.txt >> $OUT/summary.txt ;;
     tests_k)
       IL_FRACTIONS_OUT=$OUT/fractions_k.json timeout 1500 python -m pytest tests/ -m gpu -q -k "$IL_TESTS_K" > $OUT/pytest_k.log 2>&1; echo "pytest -k rc=$?" | tee -a $OUT/summary.txt; tail -n 12 $OUT/pytest_k.log | tee -a $OUT/summary.txt ;;
+    gmmil_plan)
+      rm -rf /tmp/prof_gp; (cd $ROOT && timeout 600 rocprofv3 --kernel-trace -d /tmp/prof_gp -o gp -- python profiles/tools/gmmil_plan_trace.py > $OUT/gmmil_plan.log 2>&1)
+      db=$(find /tmp/prof_gp -name "*.db" | head -1); [ -n "$db" ] && python profiles/summarize_rocpd.py $db > $OUT/gmmil_plan_kernel_stats.md; tail -n 1 $OUT/gmmil_plan.log | tee -a $OUT/summary.txt; head -n 14 $OUT/gmmil_plan_kernel_stats.md | tee -a $OUT/summary.txt ;;
     gmmil) trace gmmil "python profiles/tools/secondary_workloads.py gmmil"; head -n 12 $OUT/gmmil_kernel_stats.md | tee -a $OUT/summary.txt ;;
     pwil) trace pwil "python profiles/tools/secondary_workloads.py pwil"; head -n 12 $OUT/pwil_kernel_stats.md | tee -a $OUT/summary.txt ;;
     pop32) trace pop32 "python profiles/tools/secondary_workloads.py population 32"; head -n 24 $OUT/pop32_kernel_stats.md | tee -a $OUT/summary.txt ;;
