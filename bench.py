@@ -694,6 +694,7 @@ def main():
     beat('A/B: the collectives')
     runner.use_collectives('A/B run of bench.py: the same job re-timed with torch.distributed all-reduces')
     plan.sync[plan._sync_timeouts] = 0
+    if getattr(plan, 'device_sync', False) or plan.poisoned(): plan.clear_poison()   # (an expired wait of the run just discarded must not keep this rank's optimiser launches from storing)
     runner.resync_replicas()
     elapsed2, launch2, timing2 = measure()
     ok2, same2, digests2, note2 = health()
@@ -712,6 +713,7 @@ def main():
     beat('fall-back to the collectives')
     runner.use_collectives(exchange_fallback)
     plan.sync[plan._sync_timeouts] = 0
+    if getattr(plan, 'device_sync', False) or plan.poisoned(): plan.clear_poison()   # (an expired wait of the run just discarded must not keep this rank's optimiser launches from storing)
     runner.resync_replicas()
     elapsed, launch, timing = measure()
     steps_timed = timing['timed_replays']

@@ -576,6 +576,9 @@ class DataParallelUpdate:
       self.plan.sync.zero_()
       self.plan.sync[self.plan._sync_spin], self.plan.sync[self.plan._sync_host_flag] = keep
       self.plan._set_device_sync(False)
+      # (round 6) an expired wait POISONS its learner: the optimiser launches of that update (and of every later one) skipped their stores on the affected rank only, so the
+      # replicas are no longer identical - the zeroed sync buffer above cleared the poison; rank 0's state everywhere puts the ranks back on one learner (collective)
+      self.resync_replicas()
     return self.handoff
 
   def run(self):

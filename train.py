@@ -242,7 +242,7 @@ def train(cfg, file_prefix: str = '') -> float:
           runner.run()   # first update eagerly (loads code objects; GMMIL: fixes the kernel bandwidths), then capture
           if world > 1 and getattr(runner, 'handoff', False) and not runner.agree_on_handoff():   # collective decision (see DataParallelUpdate.agree_on_handoff)
             print(f'[train] rank {rank}: a bounded device-side wait expired during the first data-parallel update on some rank: every rank continues with stream dependencies '
-                  '(that one update used stale rewards on the affected rank; replicas remain identical)', file=sys.stderr)
+                  '(the affected rank skipped that update - an expired wait poisons its learner -; every rank has been reset to rank 0\'s replica)', file=sys.stderr)
           if world > 1 and cfg.algorithm == 'GMMIL':   # one reward function on every rank: rank 0's bandwidths (models.py:193-195 freezes the first batch's)
             discriminator.gamma_1, discriminator.gamma_2 = parallel.broadcast_scalars([discriminator.gamma_1, discriminator.gamma_2])
           if world > 1 and cfg.distributed.backend != 'nccl' and getattr(runner, 'peer', None) is None:
