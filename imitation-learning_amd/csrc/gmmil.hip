@@ -1,10 +1,11 @@
 // GMMIL pairwise-RBF reward (reference models.py:25-44, 183-201) for gfx950.
 //
-// reward_i = sum_gamma w~_i sum_j exp(-gamma d(x_i, e_j)) w~e_j  -  w~_i sum_j exp(-gamma d(x_i, x_j)) w~_j,
-// d(x, y) = (1/D) sum_k (x_k - y_k)^2 evaluated in the DIRECT difference form (the ||x||^2+||y||^2-2xy GEMM form loses
-// ~3 digits to cancellation, and the reward is itself a difference of near-equal sums), so this is an fp32-VALU-bound
-// kernel (3 flop per pair-feature), not an MFMA one. The reference materialises [B,B,D] temporaries (0.5 GB at
-// B=1024, D=120); here nothing larger than a 64x64 tile of pair distances ever exists, and it lives in registers:
+// reward_i = sum_gamma w~_i sum_j exp(-gamma d(x_i, e_j)) w~e_j  -  w~_i sum_j exp(-gamma d(x_i, x_j)) w~_j,   d(x, y) = (1/D) sum_k (x_k - y_k)^2.
+// Round 6: the reward launch for D <= 128 is k_gmmil_mfma (below): the distances as a CENTRED Gram product on the matrix pipes - as close to float64 as the direct
+// difference form whatever the data's offset. The kernels that follow first are the DIRECT difference forms of rounds 1-5 (3 VALU flop per pair-feature): they still
+// compute the distance matrix the bandwidths' medians come from (il_gmmil_sqdist), rewards for D > 128, and everything under IL_GMMIL_MFMA=0. (The UNcentred
+// ||x||^2+||y||^2-2xy form loses ~3 digits to cancellation once the data has an offset, and the reward is itself a difference of near-equal sums: never used.)
+// The reference materialises [B,B,D] temporaries (0.5 GB at B=1024, D=120); here nothing larger than a tile of pair distances ever exists, and it lives in registers:
 //   k_gmmil_pack   feature-major copies XT[D][B1], ET[D][B2] (so LDS tiles load coalesced and read conflict-free) and
 //                  the normalised weights;
 //   k_gmmil_tile   grid (i-tile, j-tile, matrix): 64x64 pairs per workgroup, 4x4 per thread, features streamed through
