@@ -77,10 +77,20 @@ __device__ __forceinline__ void sn_wave(const float* W1s, const float* W2s, int 
 // NV = 16-byte lanes per thread per round. The caller zeroes the padding columns [D, Dp). Same values in the same places: bit-identical to the element loop.
 template <int NV> struct DiscW1 { f32x4 v[NV]; };
 __device__ __forceinline__ bool disc_w1_flat_ok(const float* W1, int D, int H) { return ((reinterpret_cast<uintptr_t>(W1) & 15) == 0) && ((H * D) & 3) == 0; }
-template <int NV>
+// COH (the reward relabel inside the critic-loss launch, sac.hip): the parameters were stepped by a kernel of ANOTHER stream while this launch was resident, and the pre-step
+// lines may sit in this XCD's L2 (that kernel's own gradient launch read them there): every parameter load goes below the caches (sc0 sc1, like the polls) instead of relying
+// on an invalidate (il_common.hpp sync_acquire_all; profiles/r06_soak_under_load.md).
+// (base: wave-uniform - it becomes the buffer resource; off: this lane's element)
+template <bool COH> __device__ __forceinline__ float disc_pload(const float* base, int64_t off) { return COH ? sload1(base, off) : gload(base + off); }
+template <bool COH> __device__ __forceinline__ f32x4 disc_pload4(const float* base, int64_t off) {
+  if (!COH) return gload4(base + off);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7ffffff0, 0x00020000);
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off * 4), 0, 17));   // sc0 | sc1
+}
+template <int NV, bool COH = false>
 __device__ __forceinline__ void disc_w1_issue(DiscW1<NV>& s, const float* __restrict__ W1, int nvec, int base) {
 #pragma unroll
-  for (int q = 0; q < NV; ++q) s.v[q] = gload4(W1 + 4 * (size_t)min(base + q * (int)blockDim.x + (int)threadIdx.x, nvec - 1));
+  for (int q = 0; q < NV; ++q) s.v[q] = disc_pload4<COH>(W1, 4 * (int64_t)min(base + q * (int)blockDim.x + (int)threadIdx.x, nvec - 1));
 }
 template <int NV>
 __device__ __forceinline__ void disc_w1_commit(const DiscW1<NV>& s, float* W1s, int D, int ldw, int nvec, int base, unsigned magic_d) {   // (H * D < 2^16: the rows fit the LDS)
@@ -110,11 +120,11 @@ __device__ __forceinline__ RewardLds reward_carve(float* p, int D, int H) {
 // Every thread of the workgroup calls (barriers inside). X: the tile's rows in LDS, row stride ldX (16-byte aligned, zero-padded to Dp columns).
 // Thread tid < 256 with (tid & 15) == 0 and row r = tid >> 4 < nrows gets reward / logit of row r through `emit(r, reward, logit)`.
 // NV: 16-byte lanes of W1 a thread requests per round (ceil(H D / 4 / blockDim.x) at the shape the caller is tuned for; any shape works, in more rounds).
-template <int NV = 6, class Emit>
+template <int NV = 6, bool COH = false, class Emit>
 __device__ __forceinline__ void disc_reward_tile(const il_disc& d, const RewardLds& L, const float* X, int ldX, int nrows, const float* __restrict__ logit_offset, int row0, Emit emit) {
   const int S = d.state_dim, A = d.state_only ? 0 : d.action_dim, D = S + A, H = d.hidden, Dp = (D + 3) & ~3, ldw = Dp + 4, tid = threadIdx.x;
   const DiscLayout lay = disc_layout(D, H, d.spectral_norm);
-  const float b2 = gload(d.params + lay.ob2);
+  const float b2 = disc_pload<COH>(d.params, lay.ob2);
   {
     // (round 4) EVERY parameter this thread stages is requested before its first LDS store: the parameters were rewritten by the AdamW launch an instant ago (each line a
     // fabric / HBM round trip), and the load -> store loops this replaces made one such trip after the other - three for W1 in a 512-thread workgroup, then b1 / W2, then
@@ -125,30 +135,30 @@ __device__ __forceinline__ void disc_reward_tile(const il_disc& d, const RewardL
     const int nvec = (H * D) >> 2;
     const unsigned md = fastdiv_magic(Dp), mdd = fastdiv_magic(D);   // (H * Dp < 2^16 for every shape whose tile fits the LDS)
     DiscW1<NV> ws; float v[4];
-    if (flat) disc_w1_issue(ws, W1, nvec, 0);
+    if (flat) disc_w1_issue<NV, COH>(ws, W1, nvec, 0);
     else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const int i = min(q * bd + tid, H * Dp - 1), n = fastdiv(i, md), k = min(i - n * Dp, D - 1); v[q] = gload(W1 + (size_t)n * D + k); }
+      for (int q = 0; q < 4; ++q) { const int i = min(q * bd + tid, H * Dp - 1), n = fastdiv(i, md), k = min(i - n * Dp, D - 1); v[q] = disc_pload<COH>(W1, (size_t)n * D + k); }
     }
-    const float vb1 = gload(b1 + th), vw2 = gload(W2 + th);
+    const float vb1 = disc_pload<COH>(b1, th), vw2 = disc_pload<COH>(W2, th);
     float vu1 = 0.f, vv2 = 0.f, vv1 = 0.f, vu2 = 0.f;
-    if (sn) { vu1 = gload(d.u1 + th); vv2 = gload(d.v2 + th); vv1 = gload(d.v1 + tk); vu2 = gload(d.u2); }
+    if (sn) { vu1 = disc_pload<COH>(d.u1, th); vv2 = disc_pload<COH>(d.v2, th); vv1 = disc_pload<COH>(d.v1, tk); vu2 = disc_pload<COH>(d.u2, 0); }
     if (flat) {
       disc_w1_commit(ws, L.W1s, D, ldw, nvec, 0, mdd);
-      for (int base = NV * bd; base < nvec; base += NV * bd) { disc_w1_issue(ws, W1, nvec, base); disc_w1_commit(ws, L.W1s, D, ldw, nvec, base, mdd); }   // (shapes beyond NV lanes per thread)
+      for (int base = NV * bd; base < nvec; base += NV * bd) { disc_w1_issue<NV, COH>(ws, W1, nvec, base); disc_w1_commit(ws, L.W1s, D, ldw, nvec, base, mdd); }   // (shapes beyond NV lanes per thread)
       disc_w1_zero_padding(L.W1s, D, Dp, H, ldw);
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) { const int i = q * bd + tid; if (i < H * Dp) { const int n = fastdiv(i, md), k = i - n * Dp; L.W1s[n * ldw + k] = k < D ? v[q] : 0.f; } }
-      for (int i = 4 * bd + tid; i < H * Dp; i += bd) { const int n = i / Dp, k = i - n * Dp; L.W1s[n * ldw + k] = k < D ? W1[(size_t)n * D + k] : 0.f; }   // (shapes beyond four elements per thread)
+      for (int i = 4 * bd + tid; i < H * Dp; i += bd) { const int n = i / Dp, k = i - n * Dp; L.W1s[n * ldw + k] = k < D ? disc_pload<COH>(W1, (size_t)n * D + k) : 0.f; }   // (shapes beyond four elements per thread)
     }
     if (tid < H) { L.b1s[tid] = vb1; L.W2s[tid] = vw2; }
-    for (int i = bd + tid; i < H; i += bd) { L.b1s[i] = b1[i]; L.W2s[i] = W2[i]; }
+    for (int i = bd + tid; i < H; i += bd) { L.b1s[i] = disc_pload<COH>(b1, i); L.W2s[i] = disc_pload<COH>(W2, i); }
     if (sn) {
       if (tid < H) { L.u1[tid] = vu1; L.v2[tid] = vv2; }
-      for (int i = bd + tid; i < H; i += bd) { L.u1[i] = d.u1[i]; L.v2[i] = d.v2[i]; }
+      for (int i = bd + tid; i < H; i += bd) { L.u1[i] = disc_pload<COH>(d.u1, i); L.v2[i] = disc_pload<COH>(d.v2, i); }
       if (tid < Dp) L.v1[tid] = tid < D ? vv1 : 0.f;
-      for (int i = bd + tid; i < Dp; i += bd) L.v1[i] = i < D ? d.v1[i] : 0.f;
+      for (int i = bd + tid; i < Dp; i += bd) L.v1[i] = i < D ? disc_pload<COH>(d.v1, i) : 0.f;
       if (tid == 0) L.sc[2] = vu2;
     } else if (tid == 0) { L.sc[0] = 1.f; L.sc[1] = 1.f; }
   }

@@ -251,12 +251,12 @@ __device__ __forceinline__ void gail_grad_body(il_disc d, il_batch pol, il_batch
     long long* sy = reinterpret_cast<long long*>(d.sync);
     IL_TL(0, 1);
     if (pol.gather && exp.gather) {
-      sync_wait(sy, IL_SYNC_INDICES, sy[IL_SYNC_SIDE_EPOCH] + 1);   // rows come straight from the rings: only the draw has to be done
+      sync_wait(sy, IL_SYNC_INDICES, sync_read(sy, IL_SYNC_SIDE_EPOCH) + 1);   // rows come straight from the rings: only the draw has to be done
       // (round 5) the draw may now be AHEAD of the previous update's end: this step reads the Philox counter that update's actor step advances (below), so it still starts
       // behind [IL_SYNC_MAIN_EPOCH] (= the number of discriminator steps closed so far) - 4 us earlier than when the draw itself waited for it
-      if (has_sampler) sync_wait(sy, IL_SYNC_MAIN_EPOCH, sy[IL_SYNC_SIDE_EPOCH]);
+      if (has_sampler) sync_wait(sy, IL_SYNC_MAIN_EPOCH, sync_read(sy, IL_SYNC_SIDE_EPOCH));
     } else {
-      sync_wait(sy, IL_SYNC_ROWS, (sy[IL_SYNC_SIDE_EPOCH] + 1) * sy[IL_SYNC_GATHER_WGS]);   // gathered batches: every gather workgroup of this update has signalled
+      sync_wait(sy, IL_SYNC_ROWS, (sync_read(sy, IL_SYNC_SIDE_EPOCH) + 1) * sy[IL_SYNC_GATHER_WGS]);   // gathered batches: every gather workgroup of this update has signalled
     }
     IL_TL(0, 2);
     ctr = d.noise_counter ? *d.noise_counter : 0u;   // after the wait: the previous update's actor step (which bumps it) precedes this update's gather
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, floa
   IL_TL(2, 0);
   if (d.sync && !b.gather) {   // gathered rows: the discriminator step before this kernel may have run off the index draw alone, so their arrival is checked here
     long long* sy = reinterpret_cast<long long*>(d.sync);
-    sync_wait(sy, IL_SYNC_ROWS, (sy[IL_SYNC_SIDE_EPOCH] + 1) * sy[IL_SYNC_GATHER_WGS]);
+    sync_wait(sy, IL_SYNC_ROWS, (sync_read(sy, IL_SYNC_SIDE_EPOCH) + 1) * sy[IL_SYNC_GATHER_WGS]);
   }
   {   // the tile's rows, four elements per thread and round: their indices requested together, then their rows (an index -> row chain per element made 2 x 2 serial round trips)
     const unsigned mdp = fastdiv_magic(Dp);

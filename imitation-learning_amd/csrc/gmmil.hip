@@ -223,9 +223,9 @@ __global__ __launch_bounds__(256) void k_gmmil_tile(int n1, int n2, int D, float
   if (threadIdx.x == 0) {
     const unsigned expect = (unsigned)(w.b2p / GT + w.b1p / GT);
     last = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(ws_ + w.ctr) + it * GCTR, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1u == expect;
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
+  if (last) sync_acquire_all();   // (every wave of the last arriver: il_common.hpp)
   IL_STAMP(stamp, 3);
   if (!last || threadIdx.x >= GTR) return;
   const int i = it * GTR + threadIdx.x;
@@ -405,9 +405,10 @@ __global__ __launch_bounds__(256) void k_gmmil_direct(il_batch pol, il_batch exp
     const unsigned expect = (unsigned)(w.b2p / GT + w.b1p / GT);
     unsigned* ctr = reinterpret_cast<unsigned*>(ws_ + w.ctr) + it * GCTR;
     last = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1u == expect;
-    if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // zero again for the next call
+    if (last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next call
   }
   __syncthreads();
+  if (last) sync_acquire_all();
   if (!last || threadIdx.x >= GTR) return;
   const int i = it * GTR + threadIdx.x;
   if (i >= n1) return;

@@ -291,6 +291,35 @@ __device__ __forceinline__ void sync_timed_out(long long* sync) {   // one threa
 __device__ __forceinline__ bool sync_poisoned(const long long* sync) {
   return sync && __hip_atomic_load(sync + IL_SYNC_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
+// The acquire behind a workgroup's poll: EVERY wave executes it, after the barrier that follows the poll (round 6). The agent-scope acquire is a cache invalidate
+// (buffer_inv sc1) that is ordered only against the later loads of the wave that issued it - it is not counted by vmcnt, so the polling wave cannot wait for its completion
+// before it releases the barrier. With the invalidate issued by thread 0 alone, the OTHER waves' first loads could overtake it and hit a line this XCD's L2 still held from
+// before the producer's write - e.g. the discriminator's parameters, which the concurrently running k_gail_grad of the same update read (pre-step) into the same L2 while the
+// critic-loss launch was already resident. Measured: profiles/r06_soak_under_load.md (a 16-row tile of rewards computed from the previous step's parameters about once per
+// 10^5 updates under a copy-hammering neighbour process; never on a quiet GPU). IL_SYNC_LEADER_ACQUIRE: the round-5 form, for that A/B.
+__device__ __forceinline__ void sync_acquire_all() {
+#ifndef IL_SYNC_UNSAFE
+#ifdef IL_SYNC_LEADER_ACQUIRE
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+#endif
+}
+// a counter read as a wait TARGET (the epoch of this launch): an agent-scope load like the polls, never a cached one - a poll of another resident kernel that was in flight
+// when this launch's start invalidated the L2 can install the line's previous value behind the invalidation, and a plain load would then hit it (IL_SYNC_PLAIN_EPOCH: the
+// round-5 plain loads, for the soak A/B under profiles/)
+__device__ __forceinline__ long long sync_read(const long long* sync, int which) {
+#ifdef IL_SYNC_PLAIN_EPOCH
+  return sync[which];
+#else
+  return __hip_atomic_load(sync + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// LEADER_ACQUIRE (sync_wait_leader): one invalidate, by the polling thread, in front of the barrier - ONLY where no cache of this XCD can hold a line of the guarded data that
+// was fetched after this launch started and before its producer wrote it (each use says why); everywhere else every wave acquires (sync_acquire_all).
+template <bool LEADER_ACQUIRE = false>
 __device__ __forceinline__ void sync_wait(long long* sync, int which, long long target, int limit = 0) {   // all threads of the workgroup, before their loads
   if (threadIdx.x == 0) {   // limit 0: the learner's own bound [IL_SYNC_SPIN] (0 there = IL_SYNC_SPIN_LIMIT), read only once a poll has failed: nothing on the fast path
     int spins = 0;
@@ -300,11 +329,13 @@ __device__ __forceinline__ void sync_wait(long long* sync, int which, long long 
       if (++spins > limit) { sync_timed_out(sync); break; }
     }
 #ifndef IL_SYNC_UNSAFE
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the producer's stores are visible to this CU from here on (every producer is a kernel on this GPU)
+    if (LEADER_ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
   }
   __syncthreads();
+  if (!LEADER_ACQUIRE) sync_acquire_all();
 }
+__device__ __forceinline__ void sync_wait_leader(long long* sync, int which, long long target) { sync_wait<true>(sync, which, target); }
 
 // ---------------------------------------------------------------------------------------------
 // Stage hand-offs of the overlapped SAC branch (il_sac_update_gather_overlap; include/il_hip.h [IL_SYNC_OV_EPOCH] / [IL_SYNC_OV_TICKET]). The four launches of an update alternate
@@ -345,13 +376,13 @@ __device__ __forceinline__ void ov_wait(long long* sync, int stage, long long ta
       if (limit == 0) { const long long own = sync[IL_SYNC_SPIN]; limit = own > 0 ? (int)(own > 0x7fffffffLL ? 0x7fffffffLL : own) : IL_SYNC_SPIN_LIMIT; }
       if (++spins > limit) { sync_timed_out(sync); expired = true; break; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (leader && !expired && __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // close the stage: epoch first, ticket second
       __hip_atomic_store(ep, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(tk, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();
+  sync_acquire_all();
   if (leader)   // (also after an expired wait: the followers then proceed, poisoned like the leader, instead of each running into its own bound)
     for (int w = threadIdx.x; w < (int)gridDim.x && w < IL_OV_MAX_GRID; w += blockDim.x) __hip_atomic_store(flags + (long long)w * IL_SYNC_STRIDE, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

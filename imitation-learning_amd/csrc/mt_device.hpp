@@ -118,8 +118,8 @@ __device__ __forceinline__ void mt_sample_update(MtShared& sh, uint32_t* __restr
     // workgroups ([IL_SYNC_CHAIN_DONE], [IL_SYNC_CHAIN_WGS] published by that launch): the draw then runs ~30 us ahead of the next update instead of between two updates.
     // No such launch seen yet (first update, schedules without it): the previous update's end, as before.
     const long long cw = __hip_atomic_load(sync + IL_SYNC_CHAIN_WGS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cw > 0) sync_wait(sync, IL_SYNC_CHAIN_DONE, sync[IL_SYNC_INDICES] * cw);
-    else sync_wait(sync, IL_SYNC_MAIN_EPOCH, sync[IL_SYNC_INDICES]);
+    if (cw > 0) sync_wait(sync, IL_SYNC_CHAIN_DONE, sync_read(sync, IL_SYNC_INDICES) * cw);
+    else sync_wait(sync, IL_SYNC_MAIN_EPOCH, sync_read(sync, IL_SYNC_INDICES));
   }
   IL_TL(0, 2);
   __syncthreads();

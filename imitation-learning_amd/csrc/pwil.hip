@@ -406,11 +406,11 @@ __global__ __launch_bounds__(PW_CHUNK) void k_pwil_step(il_pwil d, const float* 
     last = t == gridDim.x - 1 ? 1u : 0u;
     if (last) {
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next step's launch (stream-ordered behind this one)
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
   }
   IL_TL(0, 4);   // ticket taken
   __syncthreads();
+  if (last) sync_acquire_all();
   if (!last) return;
   pwil_merge_block(d, (int)gridDim.x, K, cand, out);
   IL_TL(1, 7);

@@ -17,6 +17,11 @@
 #include "peer_device.hpp"
 #include "disc_reward.hpp"
 IL_ST_TABLE
+#ifdef IL_EXP_CHECK   // developer build (profiles/tools/direct_soak_matrix.py): what the consumers of the fence-free hand-offs READ against what their producers finally WROTE
+static __device__ unsigned il_chk[16];
+static __device__ float il_chk_rew[2][4096], il_chk_tq[2][3][4096], il_chk_a2[4][4096 * 8], il_chk_rel[4096];
+extern "C" int il_debug_check(unsigned* out_host) { return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(il_chk), sizeof(il_chk)) == hipSuccess ? 0 : 3; }
+#endif
 
 // Measured (round 3, same box, three interleaved rounds): write-through stores in the dW / AdamW epilogue ONLY: 14.71k -> 14.90k updates/s; ALSO for the activations and dZ
 // the tile kernels leave in the workspace: 14.59k - the next launch reads those, and a written-through line is not left behind in the L2 for the readers of its own XCD.
@@ -256,9 +261,9 @@ __device__ __forceinline__ void tile_await(unsigned* ctr, unsigned target, const
         break;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
+  sync_acquire_all();
 }
 
 // Pair-mode chain: arrivals in the low four bits of the tile counter, flag bits above them (the relabel role arrives with += 16, so that it cannot be mistaken for
@@ -277,9 +282,9 @@ __device__ __forceinline__ void tile_await_bits(unsigned* ctr, unsigned low, uns
         break;
       }
     }
-    if (ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
+  if (ACQUIRE) sync_acquire_all();
 }
 // the producer side of the same: every wave drains its write-through stores, barrier, ONE relaxed arrival
 __device__ __forceinline__ void tile_arrive_through(unsigned* ctr, unsigned inc) {
@@ -389,7 +394,7 @@ __device__ __forceinline__ void k_critic_bwd_body(il_sac d, il_batch b, const il
   const f32x4 hv1 = gload4(h1 + (size_t)min(wave * 16 + j, H - 1) * B + row0 + 4 * g);
   if (d.sync) {   // the rewards come from the discriminator branch on another stream: ready once every reward workgroup of THIS update has signalled
     long long* sy = reinterpret_cast<long long*>(d.sync);
-    sync_wait(sy, IL_SYNC_REWARDS, (sy[IL_SYNC_MAIN_EPOCH] + 1) * (long long)nt);
+    sync_wait_leader(sy, IL_SYNC_REWARDS, (sync_read(sy, IL_SYNC_MAIN_EPOCH) + 1) * (long long)nt);   // (leader: nothing on the device reads the rewards array between this launch's start and the relabel kernel's stores)
   }
   if (threadIdx.x < IL_TILE_R) {
     const int row = row0 + threadIdx.x;
@@ -462,10 +467,10 @@ __device__ __forceinline__ void critic_relabel_tile(const il_sac& d, const Chain
   const int row0 = tile * IL_TILE_R, INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
   float* Xs = smem; float* q16 = Xs + IL_TILE_R * ldx + 2 * IL_TILE_R * ldh; float* rew16 = q16 + 2 * IL_TILE_R;
   long long* sy = reinterpret_cast<long long*>(d.sync);
-  sync_wait(sy, IL_SYNC_PARAMS, (sy[IL_SYNC_MAIN_EPOCH] + 1) * (long long)rl.n_reduce);
+  sync_wait_leader(sy, IL_SYNC_PARAMS, (sync_read(sy, IL_SYNC_MAIN_EPOCH) + 1) * (long long)rl.n_reduce);   // (leader: the stepped parameters are read below the caches, disc_reward_tile<.., true>)
   IL_TL(4, 0);   // [4]: the moment the discriminator's step became visible to this critic workgroup
   const RewardLds R = reward_carve(q16 + 64, rl.dd.state_dim + rl.dd.action_dim, rl.dd.hidden);
-  disc_reward_tile<3>(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
+  disc_reward_tile<3, true>(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
     rew16[r] = reward;
     if (k == 0 && rl.out) rl.out[row0 + r] = reward;
   });
@@ -496,7 +501,7 @@ __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const
   float* rew16 = dz3s + IL_TILE_R;   // filled by critic_relabel_tile when rl.on
   if (!rl.on && d.sync && !rl.local_rewards) {   // rewards come from the discriminator branch on another stream (see k_critic_bwd); the ring's own rewards (SAC / PWIL plans) need no hand-off
     long long* sy = reinterpret_cast<long long*>(d.sync);
-    sync_wait(sy, IL_SYNC_REWARDS, (sy[IL_SYNC_MAIN_EPOCH] + 1) * (long long)nt);
+    sync_wait_leader(sy, IL_SYNC_REWARDS, (sync_read(sy, IL_SYNC_MAIN_EPOCH) + 1) * (long long)nt);   // (leader: nothing on the device reads the rewards array between this launch's start and the relabel kernel's stores)
   }
   if (threadIdx.x < IL_TILE_R) {
     const int row = row0 + threadIdx.x;
@@ -511,6 +516,9 @@ __device__ __forceinline__ void critic_bwd_resident_scale(const il_sac& d, const
     const float dq = (rs.weight * (2.f * (q - y))) / (float)B;
     dz3s[threadIdx.x] = dq;
     W[ws.c_dz3 + (size_t)k * B + row] = dq;
+#ifdef IL_EXP_CHECK
+    if (through && row < 4096) { il_chk_rew[k][row] = rew; il_chk_tq[k][0][row] = tq1; il_chk_tq[k][1][row] = tq2; il_chk_tq[k][2][row] = lp2; }
+#endif
   }
   if (k == 0 && tile == 0 && threadIdx.x == 64) adam_tick(d.critic_opt);
   __syncthreads();
@@ -575,7 +583,7 @@ __device__ __forceinline__ void sac_chain_body(il_sac& d, il_batch& b, const flo
   if (rl.xcd_nets) { if ((bid & 7) >= 6) { gw = 2 * (bid >> 3) + (bid & 7) - 6; G = rl.gather_wgs; if (gw >= G) return; } }
   else if (bid >= 6 * nt) { gw = bid - 6 * nt; G = (int)gridDim.x - 6 * nt; }
   IL_TL(0, 0);
-  if (rl.wait_indices) { long long* sy = reinterpret_cast<long long*>(d.sync); sync_wait(sy, IL_SYNC_INDICES, sy[IL_SYNC_MAIN_EPOCH] + 1); }
+  if (rl.wait_indices) { long long* sy = reinterpret_cast<long long*>(d.sync); sync_wait_leader(sy, IL_SYNC_INDICES, sync_read(sy, IL_SYNC_MAIN_EPOCH) + 1); }   // (leader: see k_sac_chain_pair)
   IL_TL(0, 1);
   if (gw >= 0) {
     const int row4 = b.ld_states / 4, lanes = d.batch * row4;
@@ -816,6 +824,9 @@ __device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, 
   tile_await_bits<false>(ctr, 1u, 0u, tile_timeouts(d));   // a' of this tile, written through by its actor(s') workgroup (the barrier also covers the LDS writes above)
   IL_TL(10, 2);
   for (int i = threadIdx.x; i < IL_TILE_R * A; i += blockDim.x) { const int r = i / A, c = i - r * A; Xs[r * ldx + S + c] = sload1(W, ws.n_a2 + (int64_t)(row0 + r) * A + c); }
+#ifdef IL_EXP_CHECK
+  if (A <= 8) for (int i = threadIdx.x; i < IL_TILE_R * A; i += blockDim.x) { const int r = i / A, c = i - r * A; if (row0 + r < 4096) il_chk_a2[2 * k + half][(row0 + r) * 8 + c] = Xs[r * ldx + S + c]; }
+#endif
   __syncthreads();
   {
     auto epi1 = [&](int c0, f32x4 acc) {
@@ -863,14 +874,39 @@ __device__ __forceinline__ void relabel_role(const il_sac& d, const il_batch& b,
   load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R, b.gather, b.gather_capacity);
   long long* sy = reinterpret_cast<long long*>(d.sync);
   IL_TL(10, 1);
-  sync_wait(sy, IL_SYNC_PARAMS, ((rl.overlap ? rl.ov_n : sy[IL_SYNC_MAIN_EPOCH]) + 1) * (long long)rl.n_reduce);   // (its barrier also covers the rows above)
+  // (leader acquire: the stepped parameters - the one thing this role reads that another stream wrote during this launch - are read below the caches, disc_reward_tile<.., true>;
+  // the barrier also covers the rows above)
+  sync_wait_leader(sy, IL_SYNC_PARAMS, ((rl.overlap ? rl.ov_n : sync_read(sy, IL_SYNC_MAIN_EPOCH)) + 1) * (long long)rl.n_reduce);
   IL_TL(10, 2);
   const RewardLds R = reward_carve(q16 + 64, rl.dd.state_dim + rl.dd.action_dim, rl.dd.hidden);
-  disc_reward_tile<3>(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
+#ifdef IL_EXP_CHECK
+  {
+    const long long want = ((rl.overlap ? rl.ov_n : sync_read(sy, IL_SYNC_MAIN_EPOCH)) + 1) * (long long)rl.n_reduce;
+    if (threadIdx.x == 0) {
+      const long long pv = __hip_atomic_load(sy + IL_SYNC_PARAMS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), sv = __hip_atomic_load(sy + IL_SYNC_SIDE_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (pv < want) atomicAdd(&il_chk[1], 1u);
+      if (pv > want) atomicAdd(&il_chk[2], 1u);
+      if (sv * rl.n_reduce > want) atomicAdd(&il_chk[3], 1u);
+    }
+  }
+#endif
+  disc_reward_tile<3, true>(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
     wstore1(W, ws.c_rew + row0 + r, reward);
     if (rl.out) rl.out[row0 + r] = reward;
+#ifdef IL_EXP_CHECK
+    if (row0 + r < 4096) il_chk_rel[row0 + r] = reward;
+#endif
   });
   IL_TL(10, 6);
+#ifdef IL_EXP_CHECK   // the same tile once more, rows and parameters re-read behind a full acquire: must give the same bits
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R, b.gather, b.gather_capacity);
+  __syncthreads();
+  disc_reward_tile<3, true>(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
+    if (row0 + r < 4096 && __float_as_uint(il_chk_rel[row0 + r]) != __float_as_uint(reward)) atomicAdd(&il_chk[4], 1u);
+  });
+#endif
 }
 
 __device__ __forceinline__ void sac_chain_pair_body(il_sac& d, il_batch& b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, const float* __restrict__ rewards,
@@ -880,7 +916,9 @@ __device__ __forceinline__ void sac_chain_pair_body(il_sac& d, il_batch& b, cons
   IL_TL(10, 0);
   long long* sy = reinterpret_cast<long long*>(d.sync);
   const long long ov = rl.overlap ? rl.ov_n : -1;   // >= 0: [IL_SYNC_MAIN_EPOCH] may not count the previous update yet (its last launch is still running on the other stream)
-  if (rl.wait_indices) sync_wait(sy, IL_SYNC_INDICES, (ov >= 0 ? ov : sy[IL_SYNC_MAIN_EPOCH]) + 1);
+  // (leader acquire: the index arrays are read by no kernel between this launch's start and the draw - the discriminator step that shares them waits for the same counter -
+  // so no L2 can hold a pre-draw copy fetched during this launch; 163 workgroups x 8 waves of invalidates here cost the launch 7 us: profiles/r06_soak_under_load.md)
+  if (rl.wait_indices) sync_wait_leader(sy, IL_SYNC_INDICES, (ov >= 0 ? ov : sync_read(sy, IL_SYNC_MAIN_EPOCH)) + 1);
   if (id.role == 5) {
     const int G = (int)gridDim.x - chain_pair_workgroups(nt, rl.on, 0), gw = id.tile;
     const int row4 = b.ld_states / 4, lanes = d.batch * row4;
@@ -1391,6 +1429,22 @@ __global__ __launch_bounds__(512) void k_policy_critic_pair(il_sac d, il_batch b
   IL_ST_BEGIN(IL_ST_POLICY_CRITIC);
   const int nt = d.batch / IL_TILE_R, bx = blockIdx.x;
   long long* osy = reinterpret_cast<long long*>(d.sync);
+#ifdef IL_EXP_CHECK
+  if (bx == 0) {
+    const SacWs cws = sac_ws(d.state_dim, d.action_dim, d.hidden, d.batch);
+    const float* CW = d.workspace; const int CB = min(d.batch, 4096), CA = d.action_dim;
+    for (int row = threadIdx.x; row < CB; row += blockDim.x) {
+      const unsigned fr = __float_as_uint(sload1(CW, cws.c_rew + row)), t1 = __float_as_uint(sload1(CW, cws.t_q + row)), t2 = __float_as_uint(sload1(CW, cws.t_q + d.batch + row)), lp = __float_as_uint(sload1(CW, cws.n_logp2 + row));
+      for (int k = 0; k < 2; ++k) {
+        if (__float_as_uint(il_chk_rew[k][row]) != fr) atomicAdd(&il_chk[5], 1u);
+        if (__float_as_uint(il_chk_tq[k][0][row]) != t1 || __float_as_uint(il_chk_tq[k][1][row]) != t2) atomicAdd(&il_chk[6], 1u);
+        if (__float_as_uint(il_chk_tq[k][2][row]) != lp) atomicAdd(&il_chk[7], 1u);
+      }
+      if (CA <= 8) for (int c = 0; c < CA; ++c) { const unsigned a2 = __float_as_uint(sload1(CW, cws.n_a2 + (int64_t)row * CA + c)); for (int q = 0; q < 4; ++q) if (__float_as_uint(il_chk_a2[q][row * 8 + c]) != a2) atomicAdd(&il_chk[8], 1u); }
+    }
+    if (threadIdx.x == 0) atomicAdd(&il_chk[0], 1u);   // checks made
+  }
+#endif
   const long long ov = overlap ? ov_own(osy, IL_OV_PC) : -1;   // (helpers need nothing of the critic optimiser launch: they wait for this launch's critic workgroups)
   if (bx >= 4 * nt) {   // helper: behind both critics' pairs of its tile in block order
     const int h = bx - 4 * nt, tile = h % nt, part = h / nt;
@@ -2338,7 +2392,7 @@ extern "C" int il_sac_update_gather_overlap(const il_sac* d, const il_batch* row
   return sac_update_gather_impl(d, rows, ring, rewards, relabel, rewards_out, eps_next, eps_cur, out_logp, out_q, flags, nullptr, nullptr, stream_a, stream_b);
 }
 __global__ void k_overlap_enter(long long* sy) {   // <<<4, IL_OV_MAX_GRID>>>: block = stage, thread = workgroup flag
-  const long long n = sy[IL_SYNC_MAIN_EPOCH];
+  const long long n = sync_read(sy, IL_SYNC_MAIN_EPOCH);
   const int st = blockIdx.x;
   if (threadIdx.x == 0) { sy[IL_SYNC_OV_EPOCH + st * IL_SYNC_STRIDE] = n; sy[IL_SYNC_OV_TICKET + st * IL_SYNC_STRIDE] = 0; }
   sy[IL_SYNC_OV_FLAGS + ((long long)st * IL_OV_MAX_GRID + threadIdx.x) * IL_SYNC_STRIDE] = n;

@@ -12,13 +12,27 @@ import sys, hashlib, numpy as np, torch; sys.path[:0] = ['.', 'tests', 'tests/go
 import bench
 from imitation_learning_amd import training as T
 plan, nets, _ = bench.build(torch.device('cuda', 0), 0, seed=11)
-plan.capture(warmup=2)
-for _ in range({N}): plan.replay()
+import os
+if os.environ.get('IL_SOAK_LAUNCH') == 'direct':   # (round 6) the product's default launch path on one GPU: UpdatePlan.launch_direct
+  for _ in range(3): plan.run()
+  torch.cuda.synchronize(); plan.record_direct(); step = plan.launch_direct
+elif os.environ.get('IL_SOAK_LAUNCH') == 'thread':   # the launcher thread (UpdatePlan.launch_async)
+  for _ in range(3): plan.run()
+  torch.cuda.synchronize(); plan.record_direct(); step = plan.launch_async
+else:
+  plan.capture(warmup=2); plan.replay(); step = plan.replay   # (3 updates ahead of the loop in every mode)
+for _ in range({N}): step()
+plan.join()
 torch.cuda.synchronize()
 assert plan.sync_timeouts() == 0
 h = hashlib.sha256()
 for n in list(nets) + [plan.logp, plan.q, plan.rewards, plan.idx]: h.update(np.ascontiguousarray((n.flat if hasattr(n, 'flat') else n).detach().cpu().numpy()).tobytes())
-print('DIGEST', h.hexdigest())
+import ctypes
+from imitation_learning_amd import _lib as _L
+chk = ''
+if hasattr(_L.lib(), 'il_debug_check'):   # developer build -DIL_EXP_CHECK: consumed-vs-produced counters of the fence-free hand-offs
+  buf = (ctypes.c_uint32 * 16)(); _L.lib().il_debug_check(buf); chk = ' CHECK ' + ','.join(str(int(v)) for v in buf[:9])
+print('DIGEST', h.hexdigest()[:16] + chk.replace(' ', '_'))
 """
 LOADS = {
     'copies': "import torch, time\na = torch.empty(256 << 20, dtype=torch.uint8, device='cuda'); b = torch.empty_like(a)\nt = time.time()\nwhile time.time() - t < 60: b.copy_(a); torch.cuda.synchronize()\n",
