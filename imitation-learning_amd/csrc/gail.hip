@@ -251,7 +251,9 @@ __device__ __forceinline__ void gail_grad_body(il_disc d, il_batch pol, il_batch
     long long* sy = reinterpret_cast<long long*>(d.sync);
     IL_TL(0, 1);
     if (pol.gather && exp.gather) {
-      sync_wait(sy, IL_SYNC_INDICES, sync_read(sy, IL_SYNC_SIDE_EPOCH) + 1);   // rows come straight from the rings: only the draw has to be done
+      // rows come straight from the rings: only the draw has to be done (with the in-launch sampler a second wait follows, and the acquire - by every wave - sits behind that one)
+      if (has_sampler) sync_wait_only(sy, IL_SYNC_INDICES, sync_read(sy, IL_SYNC_SIDE_EPOCH) + 1);
+      else sync_wait(sy, IL_SYNC_INDICES, sync_read(sy, IL_SYNC_SIDE_EPOCH) + 1);
       // (round 5) the draw may now be AHEAD of the previous update's end: this step reads the Philox counter that update's actor step advances (below), so it still starts
       // behind [IL_SYNC_MAIN_EPOCH] (= the number of discriminator steps closed so far) - 4 us earlier than when the draw itself waited for it
       if (has_sampler) sync_wait(sy, IL_SYNC_MAIN_EPOCH, sync_read(sy, IL_SYNC_SIDE_EPOCH));
@@ -538,6 +540,7 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const
   }
   if (close_epoch && d.sync) {
     long long* sy = reinterpret_cast<long long*>(d.sync);
+    sync_drain_stores();
     __syncthreads();
     if (threadIdx.x == 0) {
       const long long done = __hip_atomic_fetch_add(sy + IL_SYNC_PARAMS, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1;
@@ -586,6 +589,7 @@ __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, floa
   IL_TL_END(2);
   if (d.sync) {   // rewards of this tile are in place; the workgroup that completes the relabel closes the side branch's epoch
     long long* sy = reinterpret_cast<long long*>(d.sync);
+    sync_drain_stores();
     __syncthreads();
     if (tid == 0) {
       const long long done = __hip_atomic_fetch_add(sy + IL_SYNC_REWARDS, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1;
@@ -725,6 +729,7 @@ __global__ __launch_bounds__(256) void k_disc_adam(il_disc d, int64_t P) {
   }
   if (d.sync) {   // data-parallel schedule with the device-side hand-off: this is the discriminator branch's last kernel (cf. k_gail_reduce with close_epoch): the inline relabel of
     long long* sy = reinterpret_cast<long long*>(d.sync);   // il_sac_update_gather waits for [IL_SYNC_PARAMS]; the last workgroup closes the branch's epoch
+    sync_drain_stores();
     __syncthreads();
     if (threadIdx.x == 0) {
       const long long done = __hip_atomic_fetch_add(sy + IL_SYNC_PARAMS, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1;

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void k_gmmil_tile(int n1, int n2, int D, float
   // ticket per workgroup, after a barrier; only the last arriver pays for the acquire) adds them up in tile order - the separate, launch-bound
   // "final" kernel this replaces cost 11 us.
   __shared__ unsigned last;
+  sync_drain_stores();
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned expect = (unsigned)(w.b2p / GT + w.b1p / GT);
@@ -400,6 +401,7 @@ __global__ __launch_bounds__(256) void k_gmmil_direct(il_batch pol, il_batch exp
   }
   if (!out_r) return;
   __shared__ unsigned last;
+  sync_drain_stores();
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned expect = (unsigned)(w.b2p / GT + w.b1p / GT);

@@ -271,7 +271,12 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
 // serialises the two queues (a counter-collecting profiler) can never hang the GPU.
 // ---------------------------------------------------------------------------------------------
 #define IL_SYNC_SPIN_LIMIT (1 << 20)   // ~1 s of polling: the first replay of a freshly instantiated graph can reach the device >10 ms after the other branch's
+// Every wave, in front of the barrier that precedes a workgroup's release (round 6): its own stores have been acknowledged by the L2. The release that follows is ONE thread's
+// (an L2 write-back + its own vmcnt); the workgroup barrier in between does not wait for the other waves' stores in flight (workgroup scope needs no vmcnt on this target), so a
+// store that reached the L2 behind the write-back stayed there, dirty, until the kernel's end - and a consumer on another XCD read the previous contents from memory.
+__device__ __forceinline__ void sync_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void sync_signal(long long* ctr) {   // all threads of the workgroup, after their stores
+  sync_drain_stores();
   __syncthreads();
 #ifdef IL_SYNC_UNSAFE
   if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -292,11 +297,11 @@ __device__ __forceinline__ bool sync_poisoned(const long long* sync) {
   return sync && __hip_atomic_load(sync + IL_SYNC_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 // The acquire behind a workgroup's poll: EVERY wave executes it, after the barrier that follows the poll (round 6). The agent-scope acquire is a cache invalidate
-// (buffer_inv sc1) that is ordered only against the later loads of the wave that issued it - it is not counted by vmcnt, so the polling wave cannot wait for its completion
-// before it releases the barrier. With the invalidate issued by thread 0 alone, the OTHER waves' first loads could overtake it and hit a line this XCD's L2 still held from
-// before the producer's write - e.g. the discriminator's parameters, which the concurrently running k_gail_grad of the same update read (pre-step) into the same L2 while the
-// critic-loss launch was already resident. Measured: profiles/r06_soak_under_load.md (a 16-row tile of rewards computed from the previous step's parameters about once per
-// 10^5 updates under a copy-hammering neighbour process; never on a quiet GPU). IL_SYNC_LEADER_ACQUIRE: the round-5 form, for that A/B.
+// (buffer_inv sc1) that is ordered only against the later loads of the wave that issued it and is not counted by vmcnt, so the polling wave cannot wait for its completion
+// before it releases the barrier; two XCDs' L2s are not coherent inside a launch (profiles/tools/l2_stale_probe.hip: a plain re-load of a line another XCD rewrote was stale
+// 20 000 times of 20 000), e.g. the discriminator's parameters, which the concurrently running k_gail_grad of the same update reads (pre-step) into the L2 the critic-loss
+// launch uses. Hardening found while chasing profiles/r06_soak_under_load.md (whose main cause was on the release side: sync_drain_stores). IL_SYNC_LEADER_ACQUIRE: the
+// round-5 form, for A/B builds.
 __device__ __forceinline__ void sync_acquire_all() {
 #ifndef IL_SYNC_UNSAFE
 #ifdef IL_SYNC_LEADER_ACQUIRE
@@ -319,7 +324,8 @@ __device__ __forceinline__ long long sync_read(const long long* sync, int which)
 }
 // LEADER_ACQUIRE (sync_wait_leader): one invalidate, by the polling thread, in front of the barrier - ONLY where no cache of this XCD can hold a line of the guarded data that
 // was fetched after this launch started and before its producer wrote it (each use says why); everywhere else every wave acquires (sync_acquire_all).
-template <bool LEADER_ACQUIRE = false>
+// NO_ACQUIRE (sync_wait_only): the poll and the barrier alone - for the first of two waits in a row, whose guarded data is only read behind the second one's acquire.
+template <bool LEADER_ACQUIRE = false, bool NO_ACQUIRE = false>
 __device__ __forceinline__ void sync_wait(long long* sync, int which, long long target, int limit = 0) {   // all threads of the workgroup, before their loads
   if (threadIdx.x == 0) {   // limit 0: the learner's own bound [IL_SYNC_SPIN] (0 there = IL_SYNC_SPIN_LIMIT), read only once a poll has failed: nothing on the fast path
     int spins = 0;
@@ -329,12 +335,13 @@ __device__ __forceinline__ void sync_wait(long long* sync, int which, long long 
       if (++spins > limit) { sync_timed_out(sync); break; }
     }
 #ifndef IL_SYNC_UNSAFE
-    if (LEADER_ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (LEADER_ACQUIRE && !NO_ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
   }
   __syncthreads();
-  if (!LEADER_ACQUIRE) sync_acquire_all();
+  if (!LEADER_ACQUIRE && !NO_ACQUIRE) sync_acquire_all();
 }
+__device__ __forceinline__ void sync_wait_only(long long* sync, int which, long long target) { sync_wait<false, true>(sync, which, target); }
 __device__ __forceinline__ void sync_wait_leader(long long* sync, int which, long long target) { sync_wait<true>(sync, which, target); }
 
 // ---------------------------------------------------------------------------------------------

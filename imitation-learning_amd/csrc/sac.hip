@@ -230,6 +230,7 @@ __device__ __forceinline__ void k_actor_fwd_body(il_sac d, il_batch b, const flo
 // -> 5 (both critics have read the targets; the one that sees 4 resets it to 0 for the next launch). Producer side: every thread's stores,
 // barrier, ONE agent-scope release; consumer side: ONE polling lane, an agent-scope acquire, barrier (cf. sync_signal / sync_wait).
 __device__ __forceinline__ void tile_arrive(unsigned* ctr) {
+  sync_drain_stores();
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -607,6 +608,7 @@ __device__ __forceinline__ void sac_chain_body(il_sac& d, il_batch& b, const flo
     IL_TL(0, 6);
     if (!rl.fwd_only) { tile_arrive(ctr); IL_TL(0, 7); }
     else {   // nobody waits for the targets in this launch: the second target workgroup of the tile leaves the counter at 0 for the next one
+      sync_drain_stores();
       __syncthreads();
       if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == 2u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -865,6 +867,21 @@ __device__ __forceinline__ void target_pair(const il_sac& d, const il_batch& b, 
 }
 
 // the reward relabel of one tile as a role of its own (models.py:177-180 through disc_reward_tile: the code, thread mapping and bits of k_gail_reward)
+#ifdef IL_EXP_CHECK   // the same tile once more, AFTER the role has arrived (its timing up to the arrival is the product's): rows and parameters re-read behind an acquire of every wave
+__device__ __forceinline__ void relabel_verify(const il_sac& d, const il_batch& b, const ChainRelabel& rl, int tile, float* smem) {
+  const int S = d.state_dim, A = d.action_dim, H = d.hidden, IN = S + A;
+  const int row0 = tile * IL_TILE_R, INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
+  float* Xs = smem; float* q16 = Xs + IL_TILE_R * ldx + 2 * IL_TILE_R * ldh;
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R, b.gather, b.gather_capacity);
+  __syncthreads();
+  const RewardLds R = reward_carve(q16 + 64, rl.dd.state_dim + rl.dd.action_dim, rl.dd.hidden);
+  disc_reward_tile<3, true>(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
+    if (row0 + r < 4096 && __float_as_uint(il_chk_rel[row0 + r]) != __float_as_uint(reward)) atomicAdd(&il_chk[4], 1u);
+  });
+}
+#endif
 __device__ __forceinline__ void relabel_role(const il_sac& d, const il_batch& b, const ChainRelabel& rl, int tile, float* smem) {
   const int S = d.state_dim, A = d.action_dim, H = d.hidden, IN = S + A;
   const int row0 = tile * IL_TILE_R, INp = round_up16(IN), ldx = INp + 4, ldh = H + 4;
@@ -898,15 +915,6 @@ __device__ __forceinline__ void relabel_role(const il_sac& d, const il_batch& b,
 #endif
   });
   IL_TL(10, 6);
-#ifdef IL_EXP_CHECK   // the same tile once more, rows and parameters re-read behind a full acquire: must give the same bits
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  load_rows_cat(Xs, ldx, INp, b.states, b.ld_states, S, b.actions, b.ld_actions, A, row0, IL_TILE_R, b.gather, b.gather_capacity);
-  __syncthreads();
-  disc_reward_tile<3, true>(rl.dd, R, Xs, ldx, IL_TILE_R, nullptr, row0, [&](int r, float reward, float) {
-    if (row0 + r < 4096 && __float_as_uint(il_chk_rel[row0 + r]) != __float_as_uint(reward)) atomicAdd(&il_chk[4], 1u);
-  });
-#endif
 }
 
 __device__ __forceinline__ void sac_chain_pair_body(il_sac& d, il_batch& b, const float* __restrict__ eps_next, const float* __restrict__ eps_cur, const float* __restrict__ rewards,
@@ -946,6 +954,9 @@ __device__ __forceinline__ void sac_chain_pair_body(il_sac& d, il_batch& b, cons
   } else if (id.role == 4) {
     relabel_role(d, b, rl, id.tile, smem);
     tile_arrive_through(ctr, 16u);
+#ifdef IL_EXP_CHECK
+    relabel_verify(d, b, rl, id.tile, smem);
+#endif
     IL_TL(10, 7);
   } else if (id.role == 2) {
     // overlapped launches: the critics could run their forward and the backward GEMM ahead of the wait (their parameters were stepped two launches ago), but measured

@@ -16,6 +16,12 @@ import os
 if os.environ.get('IL_SOAK_LAUNCH') == 'direct':   # (round 6) the product's default launch path on one GPU: UpdatePlan.launch_direct
   for _ in range(3): plan.run()
   torch.cuda.synchronize(); plan.record_direct(); step = plan.launch_direct
+elif os.environ.get('IL_SOAK_LAUNCH') == 'dp':   # one rank of the data-parallel fused schedule: the gradient exchanges inside the optimiser launches (peer windows), direct launches
+  os.environ.setdefault('IL_PEER_EXCHANGE', '1')
+  from imitation_learning_amd.parallel import DataParallelUpdate
+  runner = DataParallelUpdate(plan)
+  for _ in range(3): runner.run()
+  torch.cuda.synchronize(); assert runner.direct_launch_ok(); runner.record_direct(); step = runner.launch_direct
 elif os.environ.get('IL_SOAK_LAUNCH') == 'thread':   # the launcher thread (UpdatePlan.launch_async)
   for _ in range(3): plan.run()
   torch.cuda.synchronize(); plan.record_direct(); step = plan.launch_async
