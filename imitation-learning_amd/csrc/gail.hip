@@ -529,14 +529,23 @@ __global__ __launch_bounds__(256) void k_gail_reduce(il_disc d, int apply, const
     if (apply && !poisoned) {
       const adam_consts ac = load_adam_consts(d.opt);
       adam_update(pp, g, mm, vv, ac);
-      d.params[e] = pp; d.opt.m[e] = mm; d.opt.v[e] = vv;
+      // close_epoch: the stepped parameters are consumed by a launch of ANOTHER stream that is already resident (the inline relabel of k_sac_chain*): written THROUGH
+      // (sc0 sc1: acknowledged once they are in memory) like every other in-launch hand-off of the schedule, and read below the caches there (disc_reward_tile<.., COH>)
+      if (close_epoch) wstore1(d.params, e, pp); else d.params[e] = pp;
+      d.opt.m[e] = mm; d.opt.v[e] = vv;
     }
   }
   if (blockIdx.x == 0 && d.spectral_norm && !poisoned) {
     const float* o = d.workspace + wsl.sn_new;
-    for (int i = threadIdx.x; i < H; i += blockDim.x) { d.u1[i] = o[i]; d.v2[i] = o[H + D + 1 + i]; }
-    for (int i = threadIdx.x; i < D; i += blockDim.x) d.v1[i] = o[H + i];
-    if (threadIdx.x == 0) d.u2[0] = o[H + D];
+    if (close_epoch) {
+      for (int i = threadIdx.x; i < H; i += blockDim.x) { wstore1(d.u1, i, o[i]); wstore1(d.v2, i, o[H + D + 1 + i]); }
+      for (int i = threadIdx.x; i < D; i += blockDim.x) wstore1(d.v1, i, o[H + i]);
+      if (threadIdx.x == 0) wstore1(d.u2, 0, o[H + D]);
+    } else {
+      for (int i = threadIdx.x; i < H; i += blockDim.x) { d.u1[i] = o[i]; d.v2[i] = o[H + D + 1 + i]; }
+      for (int i = threadIdx.x; i < D; i += blockDim.x) d.v1[i] = o[H + i];
+      if (threadIdx.x == 0) d.u2[0] = o[H + D];
+    }
   }
   if (close_epoch && d.sync) {
     long long* sy = reinterpret_cast<long long*>(d.sync);
@@ -725,7 +734,8 @@ __global__ __launch_bounds__(256) void k_disc_adam(il_disc d, int64_t P) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < P; e += (int64_t)gridDim.x * blockDim.x) {
     float pp = d.params[e], mm = d.opt.m[e], vv = d.opt.v[e];
     adam_update(pp, d.grad[e], mm, vv, ac);
-    d.params[e] = pp; d.opt.m[e] = mm; d.opt.v[e] = vv;
+    if (d.sync) wstore1(d.params, e, pp); else d.params[e] = pp;   // (written through where the inline relabel of a resident launch consumes them: k_gail_reduce)
+    d.opt.m[e] = mm; d.opt.v[e] = vv;
   }
   if (d.sync) {   // data-parallel schedule with the device-side hand-off: this is the discriminator branch's last kernel (cf. k_gail_reduce with close_epoch): the inline relabel of
     long long* sy = reinterpret_cast<long long*>(d.sync);   // il_sac_update_gather waits for [IL_SYNC_PARAMS]; the last workgroup closes the branch's epoch

@@ -17,7 +17,7 @@ if os.environ.get('IL_SOAK_LAUNCH') == 'direct':   # (round 6) the product's def
   for _ in range(3): plan.run()
   torch.cuda.synchronize(); plan.record_direct(); step = plan.launch_direct
 elif os.environ.get('IL_SOAK_LAUNCH') == 'dp':   # one rank of the data-parallel fused schedule: the gradient exchanges inside the optimiser launches (peer windows), direct launches
-  os.environ.setdefault('IL_PEER_EXCHANGE', '1')
+  os.environ.setdefault('IL_PEER_EXCHANGE', 'force')   # (one rank: the windows are this GPU's own)
   from imitation_learning_amd.parallel import DataParallelUpdate
   runner = DataParallelUpdate(plan)
   for _ in range(3): runner.run()
