@@ -1,10 +1,10 @@
 """`-m gpu`: the headline schedule (device hand-offs between two unjoined streams, direct launches) next to a busy NEIGHBOUR process.
 
-Round 6 found silent races this way (profiles/r06_soak_under_load.md): with a second process saturating the memory system, about one update in 10^5 relabelled a 16-row
-tile with data that was not this update's. The producers released with ONE thread behind a workgroup barrier that does not wait for the other waves' stores in flight (those
-then missed the L2 write-back and stayed invisible to other XCDs until the kernel's end), and the consumers' acquire was executed by the polling thread alone.  No wait
-expired, nothing raised; only the digest of the learner differed from the quiet run's.  The schedule must be a pure function of its inputs whatever else the GPU is doing:
-50 000 updates, four times, beside a process that copies 256 MiB buffers back to back (the round-5 hand-offs failed one such run in four)."""
+Round 6 found a silent race this way (profiles/r06_soak_under_load.md): with a second process saturating the memory system, about one update in 10^5 relabelled a 16-row
+tile with discriminator parameters that were only partly this update's - k_gail_reduce's "every thread stores, barrier, thread 0 release-add" had become visible to the other
+XCDs before all of its lines were in memory.  No wait expired, nothing raised; only the digest of the learner differed from the quiet run's.  The schedule must be a pure
+function of its inputs whatever else the GPU is doing: 50 000 updates, four times, beside a process that copies 256 MiB buffers back to back, inside this pytest process's own
+(idle) GPU context - the worst situation found (the round-5 hand-offs failed one such run in four)."""
 import os
 import subprocess
 import sys
@@ -49,8 +49,8 @@ def _runs_beside_the_neighbour(source, runs):
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
 def test_updates_beside_a_copy_hammering_process_equal_the_quiet_run():
-  """Round-5 hand-offs: one such run in four differed. After round 6's fixes 1 run in 90 still did (profiles/r06_soak_under_load.md "What is left"), so a single mismatch
-  gets a second batch and the test fails only if that one mismatches too (old behaviour: fails ~50 % of the time; now: ~0.2 %)."""
+  """Round-5 hand-offs: one such run in four differed; the committed ones: 0 of 108. A single mismatch gets a second batch and the test fails only if that one mismatches too
+  (the round-5 behaviour fails ~50 % of the time, a one-in-a-hundred residual ~0.2 %)."""
   source = _learner_source()
   quiet = _digest(source)
   got = _runs_beside_the_neighbour(source, RUNS)
