@@ -592,7 +592,8 @@ __global__ __launch_bounds__(256) void k_gail_reward(il_disc d, il_batch b, floa
   IL_TL(2, 1);
   const RewardLds R = {L.W1s, L.b1s, L.W2s, L.u1(0), L.v1(0), L.v2(0), L.sc(0)};
   disc_reward_tile<6>(d, R, L.X(0), Dp, nrows, logit_offset, row0, [&](int r, float reward, float logit) {
-    out_r[row0 + r] = reward;
+    if (d.sync) wstore1(out_r, row0 + r, reward);   // consumed by the critic-loss workgroups of a resident launch of the other stream ([IL_SYNC_REWARDS]): written through, like the parameters in k_gail_reduce
+    else out_r[row0 + r] = reward;
     if (out_logit) out_logit[row0 + r] = logit;
   });
   IL_TL_END(2);

@@ -42,7 +42,7 @@ __device__ __forceinline__ void mt_draw(MtShared& sh, const int64_t* __restrict_
   if (tid == 0) sh.count = 0;
   __syncthreads();
   if (rng == 0) {  // degenerate range: numpy returns 0 without consuming the stream
-    for (int i = tid; i < n; i += 256) out[i] = 0;
+    for (int i = tid; i < n; i += 256) wstore1(reinterpret_cast<float*>(out), i, 0.f);
     return;
   }
   for (int guard = 0; guard < 100000; ++guard) {
@@ -84,7 +84,9 @@ __device__ __forceinline__ void mt_draw(MtShared& sh, const int64_t* __restrict_
     const int tot = sh.wave_cnt[0] + sh.wave_cnt[1] + sh.wave_cnt[2] + sh.wave_cnt[3];
     const int need = n - count;
     // candidates are consumed up to and including the one that completes the batch
-    if (ok && before < need) out[count + before] = (int32_t)v;
+    // written THROUGH (round 6, profiles/r06_soak_under_load.md): the resident draw hands the indices to launches of another stream that are already running; like every other
+    // in-launch hand-off of the schedule they are in memory once the store is acknowledged (sync_signal drains every wave before the arrival), not after a later L2 write-back
+    if (ok && before < need) wstore1(reinterpret_cast<float*>(out), count + before, __uint_as_float(v));
     if (tot >= need) { if (ok && before == need - 1) sh.last = tid; }
     __syncthreads();
     if (tid == 0) {

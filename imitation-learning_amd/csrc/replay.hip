@@ -217,7 +217,10 @@ __global__ __launch_bounds__(256) void k_gather2(const float* __restrict__ ring_
     int64_t s = (isb ? idx_b : idx_a)[r];
     const int64_t cap = isb ? cap_b : cap_a;
     s = s < 0 ? 0 : (s >= cap ? cap - 1 : s);
-    reinterpret_cast<f32x4*>(isb ? rows_b : rows_a)[ii] = reinterpret_cast<const f32x4*>(isb ? ring_b : ring_a)[s * row4 + c];
+    const f32x4 v = reinterpret_cast<const f32x4*>(isb ? ring_b : ring_a)[s * row4 + c];
+    if (!sync) reinterpret_cast<f32x4*>(isb ? rows_b : rows_a)[ii] = v;
+    else if (isb) wstore4<true>(rows_b, 4 * (int64_t)ii, v);   // device hand-off ([IL_SYNC_ROWS]): the consumer is a resident launch of another stream - written through (round 6,
+    else wstore4<true>(rows_a, 4 * (int64_t)ii, v);            // profiles/r06_soak_under_load.md), in memory once sync_signal's drain has passed
   }
   if (sync) sync_signal(sync + IL_SYNC_ROWS);   // rows of this workgroup are in place
 }
