@@ -1681,7 +1681,9 @@ __device__ __forceinline__ void dw_tail_alpha(const DwArgs& a, const DwPeer* pp,
       adam_update(pp, gr, mm, vv, ac);
       a.log_alpha[0] = pp; a.alpha_opt.m[0] = mm; a.alpha_opt.v[0] = vv;
     }
-    if (a.noise_counter) a.noise_counter[0] += 1;
+    // (with il_sync counters the bumped counter is read by the NEXT update's discriminator launch, resident on the other stream: written through and drained like every
+    // other in-launch hand-off, profiles/r06_soak_under_load.md)
+    if (a.noise_counter) { if (a.sync) { wstore1(reinterpret_cast<float*>(a.noise_counter), 0, __uint_as_float(a.noise_counter[0] + 1u)); sync_drain_stores(); } else a.noise_counter[0] += 1; }
     // this update's SAC half is done. Release: the resident sampler and, behind it, the discriminator kernels of the NEXT update start from this signal and read the noise counter bumped above
     if (a.sync) __hip_atomic_fetch_add(reinterpret_cast<long long*>(a.sync) + IL_SYNC_MAIN_EPOCH, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
