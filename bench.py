@@ -781,6 +781,8 @@ def main():
                            rows=('read from the rings through the drawn indices (il_batch.gather); reward relabel as a role of k_sac_chain_pair (16-wave schedule: inline in the critic-loss workgroups)' if getattr(plan, 'inline_relabel', False) and runner is plan
                                  else ('read from the rings through the drawn indices (il_batch.gather)' if getattr(plan, 'ring_mode', False) and runner is plan else 'gathered by k_gather2'))),
                roofline=roof)
+    out['config']['handoffs'] = ('in-launch hand-offs between the two streams: producers write through (sc0 sc1) and drain, consumers read below the caches or acquire with every wave; soaked beside a '
+                                 'busy neighbour process: 0 mismatching 50k-update runs in 108 (profiles/r06_soak_under_load.md; the round-5 forms: 27 %, at 2 % more updates/s)')
     if world == 1 and args.learners == 1 and not args.no_population:
       # population axis (the reference's own usage: 10-seed sweeps / Ax trials): independent batch-256 learners advanced by the
       # SAME launches (learner id = grid dimension). Reported next to, never instead of, the single-learner `value`.
